@@ -1,0 +1,305 @@
+"""ctypes binding of the CPU oracle (oracle/mik_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by ``__graft_entry__.smoke()`` and by the
+``cpu_baseline`` leg of ``bench.py`` -- never by the product package.  Each wrapper names the
+reference function it restates (paths relative to the IterativeSolvers.jl v0.9.4 checkout).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libmik_oracle.so")
+
+SEQ, PAIR, TREE = 0, 1, 2
+MODES = {"seq": SEQ, "pair": PAIR, "tree": TREE}
+MGS, CGS, DGKS = 0, 1, 2
+METHODS = {"mgs": MGS, "cgs": CGS, "dgks": DGKS}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+        for f in ("mik_oracle.c", "orc_impl.inc", "Makefile")
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct)) if a is not None else None
+
+
+_i64p, _f64p, _f32p, _i32p = (C.POINTER(t) for t in (C.c_int64, C.c_double, C.c_float, C.c_int))
+
+
+def _declare(L):
+    for suf, fp, ft in (("f64", _f64p, C.c_double), ("f32", _f32p, C.c_float)):
+        f = getattr(L, f"orc_csc_spmv_{suf}")
+        f.argtypes = [C.c_int64, C.c_int64, _i64p, _i64p, fp, C.c_int, fp, fp]
+        f.restype = None
+        f = getattr(L, f"orc_dot_{suf}")
+        f.argtypes = [fp, fp, C.c_int64, C.c_int, C.c_int, C.c_int]
+        f.restype = ft
+        f = getattr(L, f"orc_nrm2_{suf}")
+        f.argtypes = [fp, C.c_int64, C.c_int, C.c_int, C.c_int]
+        f.restype = ft
+        f = getattr(L, f"orc_cg_{suf}")
+        f.argtypes = [C.c_int64, _i64p, _i64p, fp, C.c_int, fp, fp, C.c_double, C.c_double,
+                      C.c_int64, C.c_int, fp, C.c_int, _i32p, _f64p, _i64p, _i64p, _i32p, _f64p,
+                      _f64p]
+        f.restype = None
+        f = getattr(L, f"orc_gmres_{suf}")
+        f.argtypes = [C.c_int64, _i64p, _i64p, fp, C.c_int, fp, fp, C.c_double, C.c_double,
+                      C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _f64p, _i64p, _i64p,
+                      _i32p, _f64p, _f64p]
+        f.restype = None
+        f = getattr(L, f"orc_orthogonalize_{suf}")
+        f.argtypes = [fp, C.c_int64, C.c_int64, C.c_int, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int]
+        f.restype = ft
+        f = getattr(L, f"orc_gemv_n_{suf}")
+        f.argtypes = [fp, C.c_int64, C.c_int64, C.c_int, fp, ft, fp]
+        f.restype = None
+        f = getattr(L, f"orc_givens_{suf}")
+        f.argtypes = [ft, ft, fp, fp, fp]
+        f.restype = None
+        f = getattr(L, f"orc_hessenberg_ldiv_{suf}")
+        f.argtypes = [fp, C.c_int64, C.c_int, fp]
+        f.restype = None
+    L.orc_laplace_nnz.argtypes = [C.c_int64, C.c_int]
+    L.orc_laplace_nnz.restype = C.c_int64
+    L.orc_laplace_csc.argtypes = [C.c_int64, C.c_int, C.c_int, _i64p, _i64p, _f64p]
+    L.orc_laplace_csc.restype = None
+    L.orc_advdiff_csc.argtypes = [C.c_int64, C.c_double, C.c_int, _i64p, _i64p, _f64p, _f64p]
+    L.orc_advdiff_csc.restype = None
+    L.orc_hashed_rhs.argtypes = [C.c_int64, _f64p]
+    L.orc_hashed_rhs.restype = None
+
+
+def _suf(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return "f64", C.c_double
+    if dtype == np.float32:
+        return "f32", C.c_float
+    raise TypeError(f"oracle supports float64/float32, got {dtype}")
+
+
+@dataclass
+class CSC:
+    """A Julia ``SparseMatrixCSC{T,Int64}``: colptr / rowval (``index_base``-based) / nzval."""
+    n: int
+    colptr: np.ndarray
+    rowval: np.ndarray
+    nzval: np.ndarray
+    index_base: int = 1
+
+    @property
+    def nnz(self) -> int:
+        return int(self.nzval.shape[0])
+
+    def astype(self, dtype) -> "CSC":
+        return CSC(self.n, self.colptr, self.rowval, self.nzval.astype(dtype), self.index_base)
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csc_matrix((self.nzval, self.rowval - self.index_base,
+                              self.colptr - self.index_base), shape=(self.n, self.n))
+
+    @staticmethod
+    def from_dense(a, index_base: int = 1) -> "CSC":
+        """All entries stored (a dense Matrix pushed through the sparse interface)."""
+        a = np.asarray(a)
+        n = a.shape[0]
+        colptr = np.arange(0, n * n + 1, n, dtype=np.int64) + index_base
+        rowval = np.tile(np.arange(n, dtype=np.int64), n) + index_base
+        return CSC(n, colptr, rowval, np.ascontiguousarray(a.T).reshape(-1).copy(), index_base)
+
+    @staticmethod
+    def from_scipy(m, index_base: int = 1) -> "CSC":
+        m = m.tocsc()
+        m.sort_indices()
+        return CSC(m.shape[0], m.indptr.astype(np.int64) + index_base,
+                   m.indices.astype(np.int64) + index_base, m.data.copy(), index_base)
+
+
+def laplace(N: int, dims: int = 3, index_base: int = 1) -> CSC:
+    """``laplace_matrix(Float64, N, dims)`` -- test/laplace_matrix.jl:1-12."""
+    L = lib()
+    n = N ** dims
+    nnz = L.orc_laplace_nnz(N, dims)
+    colptr = np.empty(n + 1, np.int64)
+    rowval = np.empty(nnz, np.int64)
+    nzval = np.empty(nnz, np.float64)
+    L.orc_laplace_csc(N, dims, index_base, _p(colptr, C.c_int64), _p(rowval, C.c_int64),
+                      _p(nzval, C.c_double))
+    return CSC(n, colptr, rowval, nzval, index_base)
+
+
+def advdiff(N: int = 50, beta: float = 1000.0, index_base: int = 1):
+    """``advection_dominated(;N, β)`` -- benchmark/advection_diffusion.jl:3-30 -> (A, b)."""
+    L = lib()
+    n = N ** 3
+    nnz = L.orc_laplace_nnz(N, 3)
+    colptr = np.empty(n + 1, np.int64)
+    rowval = np.empty(nnz, np.int64)
+    nzval = np.empty(nnz, np.float64)
+    b = np.empty(n, np.float64)
+    L.orc_advdiff_csc(N, beta, index_base, _p(colptr, C.c_int64), _p(rowval, C.c_int64),
+                      _p(nzval, C.c_double), _p(b, C.c_double))
+    return CSC(n, colptr, rowval, nzval, index_base), b
+
+
+def hashed_rhs(n: int) -> np.ndarray:
+    """b[i] = ((i*2654435761) mod 2^32)/2^32 - 0.5."""
+    b = np.empty(n, np.float64)
+    lib().orc_hashed_rhs(n, _p(b, C.c_double))
+    return b
+
+
+def spmv(A: CSC, x: np.ndarray) -> np.ndarray:
+    """``mul!(y, A::SparseMatrixCSC, x)`` (column scatter) -- call sites src/cg.jl:54."""
+    suf, ct = _suf(A.nzval.dtype)
+    x = np.ascontiguousarray(x, A.nzval.dtype)
+    y = np.empty(A.n, A.nzval.dtype)
+    getattr(lib(), f"orc_csc_spmv_{suf}")(A.n, A.n, _p(A.colptr, C.c_int64),
+                                          _p(A.rowval, C.c_int64), _p(A.nzval, ct),
+                                          A.index_base, _p(x, ct), _p(y, ct))
+    return y
+
+
+def dot(x, y, mode="seq", W=1, L=1):
+    suf, ct = _suf(x.dtype)
+    x = np.ascontiguousarray(x)
+    y = np.ascontiguousarray(y, x.dtype)
+    return getattr(lib(), f"orc_dot_{suf}")(_p(x, ct), _p(y, ct), x.size, MODES[mode], W, L)
+
+
+def nrm2(x, mode="seq", W=1, L=1):
+    suf, ct = _suf(x.dtype)
+    x = np.ascontiguousarray(x)
+    return getattr(lib(), f"orc_nrm2_{suf}")(_p(x, ct), x.size, MODES[mode], W, L)
+
+
+def _eps_sqrt(dtype):
+    return float(np.sqrt(np.finfo(dtype).eps))
+
+
+def cg(A: CSC, b, x0=None, *, abstol=0.0, reltol=None, maxiter=None, jacobi_diag=None,
+       mode="seq", shape=(1, 1, 1, 1)):
+    """``cg!(x, A, b; log=true)`` / ``cg(A, b)`` when ``x0 is None`` -- src/cg.jl:209-242,162.
+
+    Returns ``(x, history)`` with history keys iters, mvps, isconverged, resnorm, res0, tol.
+    """
+    dtype = A.nzval.dtype
+    suf, ct = _suf(dtype)
+    b = np.ascontiguousarray(b, dtype)
+    n = A.n
+    initially_zero = x0 is None
+    x = np.zeros(n, dtype) if x0 is None else np.array(x0, dtype, copy=True)
+    reltol = _eps_sqrt(dtype) if reltol is None else reltol
+    maxiter = n if maxiter is None else int(maxiter)
+    res = np.zeros(max(maxiter, 1), np.float64)
+    iters, mvps = C.c_int64(0), C.c_int64(0)
+    conv = C.c_int(0)
+    res0, tol = C.c_double(0), C.c_double(0)
+    shp = np.asarray(shape, np.int32)
+    jd = None if jacobi_diag is None else np.ascontiguousarray(jacobi_diag, dtype)
+    getattr(lib(), f"orc_cg_{suf}")(n, _p(A.colptr, C.c_int64), _p(A.rowval, C.c_int64),
+                                    _p(A.nzval, ct), A.index_base, _p(b, ct), _p(x, ct),
+                                    float(abstol), float(reltol), maxiter, int(initially_zero),
+                                    _p(jd, ct), MODES[mode], _p(shp, C.c_int),
+                                    _p(res, C.c_double), C.byref(iters), C.byref(mvps),
+                                    C.byref(conv), C.byref(res0), C.byref(tol))
+    hist = dict(iters=iters.value, mvps=mvps.value, isconverged=bool(conv.value),
+                resnorm=res[:iters.value].copy(), res0=res0.value, tol=tol.value,
+                abstol=abstol, reltol=reltol)
+    return x, hist
+
+
+def gmres(A: CSC, b, x0=None, *, abstol=0.0, reltol=None, restart=None, maxiter=None,
+          orth_meth="mgs", mode="seq", shape=(1, 1)):
+    """``gmres!(x, A, b; log=true)`` / ``gmres(A, b)`` when ``x0 is None`` -- src/gmres.jl:184-222,143."""
+    dtype = A.nzval.dtype
+    suf, ct = _suf(dtype)
+    b = np.ascontiguousarray(b, dtype)
+    n = A.n
+    initially_zero = x0 is None
+    x = np.zeros(n, dtype) if x0 is None else np.array(x0, dtype, copy=True)
+    reltol = _eps_sqrt(dtype) if reltol is None else reltol
+    restart = min(20, n) if restart is None else int(restart)
+    maxiter = n if maxiter is None else int(maxiter)
+    res = np.zeros(max(maxiter, 1), np.float64)
+    iters, mvps = C.c_int64(0), C.c_int64(0)
+    conv = C.c_int(0)
+    beta0, tol = C.c_double(0), C.c_double(0)
+    shp = np.asarray(shape, np.int32)
+    getattr(lib(), f"orc_gmres_{suf}")(n, _p(A.colptr, C.c_int64), _p(A.rowval, C.c_int64),
+                                       _p(A.nzval, ct), A.index_base, _p(b, ct), _p(x, ct),
+                                       float(abstol), float(reltol), restart, maxiter,
+                                       int(initially_zero), METHODS[orth_meth], MODES[mode],
+                                       _p(shp, C.c_int), _p(res, C.c_double), C.byref(iters),
+                                       C.byref(mvps), C.byref(conv), C.byref(beta0), C.byref(tol))
+    hist = dict(iters=iters.value, mvps=mvps.value, isconverged=bool(conv.value),
+                resnorm=res[:iters.value].copy(), res0=beta0.value, tol=tol.value,
+                abstol=abstol, reltol=reltol, restart=restart)
+    return x, hist
+
+
+def orthogonalize(V, w, method="mgs", mode="seq", W=1, L=1):
+    """``orthogonalize_and_normalize!(V, w, h, method)`` -- src/orthogonalize.jl:13-79.
+
+    ``V`` is (n, k) Fortran-ordered; returns (w_new, h, nrm)."""
+    V = np.asfortranarray(V)
+    suf, ct = _suf(V.dtype)
+    n, k = V.shape
+    w = np.array(w, V.dtype, copy=True)
+    h = np.zeros(k, V.dtype)
+    nrm = getattr(lib(), f"orc_orthogonalize_{suf}")(_p(V, ct), n, n, k, _p(w, ct), _p(h, ct),
+                                                     METHODS[method], MODES[mode], W, L)
+    return w, h, nrm
+
+
+def gemv_n(V, c, y, alpha=1.0):
+    """``mul!(y, V, c, alpha, 1)`` -- src/gmres.jl:275, src/orthogonalize.jl:16."""
+    V = np.asfortranarray(V)
+    suf, ct = _suf(V.dtype)
+    n, k = V.shape
+    c = np.ascontiguousarray(c, V.dtype)
+    y = np.array(y, V.dtype, copy=True)
+    getattr(lib(), f"orc_gemv_n_{suf}")(_p(V, ct), n, n, k, _p(c, ct), alpha, _p(y, ct))
+    return y
+
+
+def givens(f, g, dtype=np.float64):
+    """``LinearAlgebra.givensAlgorithm(f, g)`` -> (c, s, r) -- used at src/hessenberg.jl:24."""
+    suf, ct = _suf(dtype)
+    out = np.zeros(3, dtype)
+    getattr(lib(), f"orc_givens_{suf}")(f, g, _p(out[0:1], ct), _p(out[1:2], ct), _p(out[2:3], ct))
+    return tuple(out.tolist())
+
+
+def hessenberg_ldiv(H, rhs):
+    """``ldiv!(FastHessenberg(H), rhs)`` -- src/hessenberg.jl:15-46.  Returns (R, [y; residual])."""
+    H = np.array(H, order="F", copy=True)
+    suf, ct = _suf(H.dtype)
+    rhs = np.array(rhs, H.dtype, copy=True)
+    getattr(lib(), f"orc_hessenberg_ldiv_{suf}")(_p(H, ct), H.shape[0], H.shape[1], _p(rhs, ct))
+    return H, rhs
