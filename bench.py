@@ -1,0 +1,135 @@
+#!/usr/bin/env python
+"""bench.py -- CG iterations/s + achieved SpMV HBM GB/s on the 3D 7-point Laplacian (fp64).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one cg! iteration (iterate(::CGIterable), src/cg.jl:43-66) on synthetic input already
+resident in HBM.  N = 1: BASELINE.json configs[1], cg! on the 256^3 Laplacian.  N > 1 (launched by
+torch.distributed.run, one rank per GPU): configs[3]'s row-partitioned layout, 256^3 rows per GPU
+(z-slabs of an N_z = 256*N grid), halo exchange + scalar all-gathers over RCCL -- weak scaling.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); copy ceiling 6290 GB/s
+
+
+def cpu_baseline(N: int, iters: int):
+    """The oracle's reference-shaped CG (serial CSC column-scatter SpMV with Int64 indices, serial
+    fused loops, 1 thread) timed on this box's host cores on a bounded sample of the same workload."""
+    orc = graft.load_oracle()
+    A = orc.laplace(N, 3)
+    b = orc.hashed_rhs(A.n)
+    orc.cg(A, b, maxiter=2, mode="seq")                      # page-in / warm caches
+    t0 = time.perf_counter()
+    _, h = orc.cg(A, b, maxiter=iters, mode="seq")
+    dt = time.perf_counter() - t0
+    return {"value": h["iters"] / dt, "unit": "iters/s", "cores": 1, "kind": "port",
+            "sample": f"{h['iters']} cg! iterations on the same {N}^3 operator and rhs, oracle/mik_oracle.c mode SEQ "
+                      f"(host has {os.cpu_count()} cores; the reference's SpMV and broadcasts are single-threaded)",
+            "seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=256, help="grid points per dimension per GPU (default 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=30)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 or args.gpus > 1:
+        from importlib import import_module
+        pkg = graft.load_package()
+        dist_bench = import_module(pkg.__name__ + ".dist").bench_main
+        return dist_bench(args)
+
+    import torch
+    pkg = graft.load_package()
+    N, K, Wm = args.n, args.steps, args.warmup
+    ctx = pkg.default_context()
+    n, colptr, rowval, nzval = pkg.fixtures.laplace_matrix(N, 3)
+    A = pkg.HipCSR(n, n, colptr, rowval, nzval, index_base=1)
+    nnz = A.nnz
+    del colptr, rowval, nzval
+    b = pkg.HipVector.from_numpy(pkg.fixtures.hashed_rhs(n))
+    x = pkg.zerox(A, b)
+    # default tolerances converge in 613 iterations at 256^3; if more steps are requested the stopping
+    # test is disabled (reltol = 0) so that exactly K steps of identical work run
+    reltol = None if (K + Wm) <= 600 and N >= 256 else 0.0
+    it = pkg.cg_iterator_(x, A, b, reltol=reltol, initially_zero=True, maxiter=10 ** 9)
+
+    iteration = 0
+    for _ in range(Wm):
+        assert it.iterate(iteration) is not None
+        iteration += 1
+    it.profile(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        nxt = it.iterate(iteration)          # one host-visible residual per step, like the reference loop
+        assert nxt is not None, "CG converged inside the timed region; lower --steps or use reltol=0"
+        iteration += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    spmv_ms_total, spmv_launches = it.profile(0)
+    residual = it.residual
+
+    ms_per_step = dt / K * 1e3
+    spmv_ms = spmv_ms_total / max(spmv_launches, 1)
+    alg_bytes = A.spmv_algorithmic_bytes()
+    achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9
+    # steady-state back-to-back launches of the same kernel, for comparison with rocprofv3
+    u = pkg.HipVector.wrap(it.u.ptr, n, np.float64, ctx, owner=it.u)
+    scratch = pkg.HipVector(n)
+    b2b_ms = A.time_spmv(u, scratch, reps=20, fused_dot=True)
+    # same loop with one host synchronisation per 50 steps (device-side stopping test)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    done = 0
+    while done < K:
+        r = it.iterate_many(iteration, min(50, K - done))
+        assert r.size > 0
+        done += r.size
+        iteration += r.size
+    torch.cuda.synchronize()
+    dt_batched = time.perf_counter() - t1
+
+    out = {
+        "metric": "cg_iters_per_sec", "value": K / dt, "unit": "iters/s", "n_gpus": 1, "steps": K, "warmup": Wm,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"cg! on {N}^3 3D 7-point Laplacian (test/laplace_matrix.jl), fp64, hashed rhs, x0 = 0 "
+                               f"(BASELINE.json configs[1])", "n": n, "nnz": nnz,
+                   "reltol": "sqrt(eps)" if reltol is None else reltol, "host_sync_per_step": 1,
+                   "final_residual": residual},
+        "roofline": {"bound": "hbm", "kernel": "k_spmv_rowblock<double, fused dot>", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms, "launches_timed": spmv_launches,
+                     "back_to_back_ms": b2b_ms, "frac_of_copy_ceiling_6290": achieved / 6290.0},
+        "cg_iteration_algorithmic_bytes": alg_bytes + 9 * n * 8,
+        "cg_iteration_gbs": (alg_bytes + 9 * n * 8) / (dt / K) / 1e9,
+        "batched_50_steps_per_sync_iters_per_sec": K / dt_batched,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(N, args.cpu_iters)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,190 @@
+/*
+ * mik.h -- C ABI of libmik.so: the MI355X (gfx950) Krylov inner loop behind IterativeSolvers.jl's
+ *          cg! / gmres! iteration path.
+ *
+ * This is the drop-in boundary.  IterativeSolvers.jl (v0.9.4, pure Julia) has no FFI of its own;
+ * its "plugin mechanism" is multiple dispatch on the operator/vector types
+ * (docs/src/getting_started.md:25-30).  A Julia host binds these entry points with `ccall` behind
+ * `mul!`, `dot`, `norm`, broadcast and `iterate` methods for a device vector / CSR operator type
+ * (INTEGRATION.md shows the binding); the Python harness in this repo binds the same symbols with
+ * ctypes.  Each entry point cites the reference call it replaces (file:line relative to the
+ * reference checkout).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only.  Every function returns an int status
+ *    (MIK_OK = 0); no C++ exception crosses the boundary; mik_last_error() gives the text.
+ *  - `dtype` is MIK_F64 or MIK_F32 (the arithmetic type of the whole path; indices are Int32 on
+ *    the device).  Scalars cross the boundary as `const void*` / `void*` to a host value of that
+ *    dtype, or as double where stated.
+ *  - Vector arguments are raw DEVICE pointers (from mik_malloc, or from any HIP allocator of the
+ *    same device -- e.g. a torch tensor's data_ptr or an AMDGPU.jl ROCArray).  16-byte aligned
+ *    pointers take the vectorised kernels, others a scalar-load variant with identical results.
+ *  - Host pointers are borrowed for the duration of the call.  Calls that return a scalar to the
+ *    host synchronise the context's stream; everything else is asynchronous on that stream.
+ *  - One mik_ctx = one device + one HIP stream; calls on a ctx are not re-entrant (the reference
+ *    is single-threaded).  Multi-GPU = one process (and one ctx) per GPU.
+ *
+ * Reduction semantics (what makes results reproducible and checkable bit-for-bit)
+ *  Every dot / norm on the device is a fixed-shape two-level tree that depends only on (n, dtype):
+ *   level 1: the vector is cut into segments of 256*W*L elements (mik_reduce_shape()); virtual
+ *            thread t of a segment sums its elements e -> (e/W)*(256*W) + W*t + e%W in ascending
+ *            e, then a wave-64 shuffle-down tree (offsets 32..1), then the 4 wave sums left to
+ *            right;  the dot fused into the SpMV (CG's dot(u, c)) uses W = L = 1 (one row per
+ *            thread, segment = 256 rows);
+ *   level 2: 1024 virtual threads; thread t sums segment sums t, t+1024, ... ascending, wave tree
+ *            per 64, then the 16 wave sums left to right.
+ *  Multiply and add are never contracted into an FMA (the library is built -ffp-contract=off) and
+ *  the SpMV sums each row serially in ascending column order, exactly like the reference's CSC
+ *  column scatter.  oracle/mik_oracle.c (mode ORC_TREE) restates the same tree on the CPU.
+ */
+#ifndef MIK_H
+#define MIK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIK_ABI_VERSION 1
+
+/* status codes */
+enum {
+    MIK_OK = 0,
+    MIK_ERR_INVALID = 1,     /* invalid argument */
+    MIK_ERR_HIP = 2,         /* HIP runtime error (text in mik_last_error) */
+    MIK_ERR_MISMATCH = 3,    /* dimension / dtype mismatch */
+    MIK_ERR_NOMEM = 4,       /* out of (device or host) memory */
+    MIK_ERR_NOTIMPL = 5      /* not implemented (e.g. nnz >= 2^31) */
+};
+
+enum { MIK_F64 = 0, MIK_F32 = 1 };
+
+/* orthogonalisation methods -- src/orthogonalize.jl:4-7 */
+enum { MIK_MGS = 0, MIK_CGS = 1, MIK_DGKS = 2 };
+
+typedef struct mik_ctx mik_ctx;       /* device + stream + reduction workspace */
+typedef struct mik_csr mik_csr;       /* device CSR operator (the `A` of mul!(y, A, x)) */
+typedef struct mik_cg mik_cg;         /* CGIterable            -- src/cg.jl:5-16 */
+typedef struct mik_gmres mik_gmres;   /* GMRESIterable + ArnoldiDecomp + Residual -- src/gmres.jl:5-49 */
+
+/* ---- library / context ------------------------------------------------------------------ */
+int mik_abi_version(void);
+int mik_device_count(int *count);
+int mik_ctx_create(int device, mik_ctx **out);
+int mik_ctx_destroy(mik_ctx *ctx);
+/* Adopt an external hipStream_t (e.g. torch's current stream); NULL restores the ctx's own. */
+int mik_ctx_set_stream(mik_ctx *ctx, void *hip_stream);
+int mik_ctx_synchronize(mik_ctx *ctx);
+const char *mik_last_error(mik_ctx *ctx);   /* ctx may be NULL: last error of a failed create */
+/* (W, L) of the level-1 reduction tree for `dtype` (see "Reduction semantics"). */
+int mik_reduce_shape(int dtype, int *W, int *L);
+
+/* ---- device memory (similar / zero / copyto! / fill! of the vector interface) ----------- */
+int mik_malloc(mik_ctx *ctx, size_t bytes, void **dptr);            /* similar(x)             */
+int mik_free(mik_ctx *ctx, void *dptr);
+int mik_memcpy_h2d(mik_ctx *ctx, void *dst, const void *src, size_t bytes);   /* synchronous  */
+int mik_memcpy_d2h(mik_ctx *ctx, void *dst, const void *src, size_t bytes);   /* synchronous  */
+int mik_copy(mik_ctx *ctx, int dtype, int64_t n, const void *x, void *y);     /* copyto!(y, x) src/cg.jl:130 */
+int mik_fill(mik_ctx *ctx, int dtype, int64_t n, const void *value, void *x); /* x .= value    src/cg.jl:129 */
+
+/* ---- operator ---------------------------------------------------------------------------- */
+/* Upload a SparseMatrixCSC (is_csc = 1: ptr = colptr, idx = rowval -- the layout of
+ * test/laplace_matrix.jl:12) or a CSR matrix (is_csc = 0).  Host arrays, Int64 indices with
+ * `index_base` (1 for Julia).  Converts to 0-based Int32 CSR (CSC -> CSR transpose on the host,
+ * columns ascending within a row) and copies to the device. */
+int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                   const int64_t *ptr, const int64_t *idx, const void *val, int index_base,
+                   int is_csc, mik_csr **out);
+int mik_csr_destroy(mik_csr *A);
+/* size(A, d), nnz, eltype(A) */
+int mik_csr_info(const mik_csr *A, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, int *dtype);
+
+/* ---- L1 operator / vector interface ------------------------------------------------------ */
+/* mul!(y, A, x) -- SparseArrays mul!, called at src/cg.jl:54,137; src/gmres.jl:245,287 */
+int mik_spmv(mik_ctx *ctx, const mik_csr *A, const void *x, void *y);
+/* dot(x, y) -- src/cg.jl:55, src/orthogonalize.jl:71.  *out is a host scalar of `dtype`. */
+int mik_dot(mik_ctx *ctx, int dtype, int64_t n, const void *x, const void *y, void *out);
+/* norm(x) -- src/cg.jl:62,140; src/orthogonalize.jl:75; src/gmres.jl:252 */
+int mik_nrm2(mik_ctx *ctx, int dtype, int64_t n, const void *x, void *out);
+/* y .+= alpha .* x  -- src/cg.jl:58 (alpha) / :59 (-alpha) */
+int mik_axpy(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, const void *x, void *y);
+/* y .= x .+ beta .* y -- src/cg.jl:51 (u .= r .+ beta .* u) */
+int mik_xpby(mik_ctx *ctx, int dtype, int64_t n, const void *x, const void *beta, void *y);
+/* y .-= x -- src/cg.jl:138, src/gmres.jl:246 */
+int mik_sub(mik_ctx *ctx, int dtype, int64_t n, const void *x, void *y);
+/* x .*= alpha -- src/orthogonalize.jl:76, src/gmres.jl:253 */
+int mik_scal(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, void *x);
+/* y .= x ./ d -- ldiv!(y, P::JacobiPrec, x) of test/cg.jl:18 (diagonal left preconditioner) */
+int mik_divide(mik_ctx *ctx, int dtype, int64_t n, const void *x, const void *d, void *y);
+
+/* ---- L2 Krylov helpers ------------------------------------------------------------------- */
+/* orthogonalize_and_normalize!(V[:, 1:k], w, h, method) -> nrm -- src/orthogonalize.jl:13-79.
+ * V: device, column-major, leading dimension ldv (elements); w: device n-vector (updated in
+ * place, normalised); h: HOST array of k scalars (written); nrm: HOST scalar (written). */
+int mik_orthogonalize(mik_ctx *ctx, int dtype, int64_t n, int k, const void *V, int64_t ldv,
+                      void *w, void *h, void *nrm, int method);
+/* mul!(y, V[:, 1:k], c, alpha, 1) -- src/gmres.jl:275 (alpha = 1), src/orthogonalize.jl:16 (-1).
+ * c: HOST array of k scalars. */
+int mik_gemv_n(mik_ctx *ctx, int dtype, int64_t n, int k, const void *V, int64_t ldv,
+               const void *c, const void *alpha, void *y);
+
+/* ---- L3 iterables ------------------------------------------------------------------------ */
+/* cg_iterator!(x, A, b, Pl; abstol, reltol, maxiter, statevars, initially_zero)
+ *   -- src/cg.jl:120-155.  x, b and the CGStateVariables u, r, c (src/cg.jl:114-118) are device
+ * n-vectors owned by the caller.  `jacobi_diag` (device n-vector or NULL) selects the
+ * PCGIterable with a diagonal left preconditioner (src/cg.jl:18-30,72-100); NULL = Identity(). */
+int mik_cg_create(mik_ctx *ctx, const mik_csr *A, void *x, const void *b, void *u, void *r,
+                  void *c, const void *jacobi_diag, double abstol, double reltol,
+                  int64_t maxiter, int initially_zero, mik_cg **out);
+int mik_cg_destroy(mik_cg *it);
+/* iterate(it, iteration) -- src/cg.jl:43-66 / :72-100.  *done = 1 and nothing is computed when
+ * done(it, iteration) (src/cg.jl:36); otherwise one step runs and *residual = it.residual. */
+int mik_cg_iterate(mik_cg *it, int64_t iteration, double *residual, int *done);
+/* Up to max_steps consecutive iterate() calls with ONE host synchronisation: the stopping test
+ * of src/cg.jl:36 is evaluated on the device after every step and later steps become no-ops.
+ * residuals[0..*steps_done-1] receive it.residual after each executed step. */
+int mik_cg_iterate_many(mik_cg *it, int64_t iteration, int64_t max_steps, double *residuals,
+                        int64_t *steps_done);
+/* fields of CGIterable read by cg! (src/cg.jl:227,232,238): mv_products, residual, tol,
+ * converged(it) */
+int mik_cg_state(const mik_cg *it, double *residual, double *prev_residual, double *tol,
+                 int64_t *maxiter, int64_t *mv_products, int *converged);
+
+/* gmres_iterable!(x, A, b; Pl = Identity, Pr = Identity, abstol, reltol, restart, maxiter,
+ *                 initially_zero, orth_meth) -- src/gmres.jl:108-136.  x, b: device n-vectors owned
+ * by the caller.  The Krylov basis V (n x (restart+1), src/gmres.jl:13) lives on the device and
+ * the Hessenberg matrix, Givens least squares and null-vector residual recurrence
+ * (src/gmres.jl:224-233,262-271; src/hessenberg.jl:15-46) on the host, inside the handle. */
+int mik_gmres_create(mik_ctx *ctx, const mik_csr *A, void *x, const void *b, double abstol,
+                     double reltol, int restart, int64_t maxiter, int initially_zero,
+                     int orth_method, mik_gmres **out);
+int mik_gmres_destroy(mik_gmres *it);
+/* iterate(g, iteration) -- src/gmres.jl:57-106 */
+int mik_gmres_iterate(mik_gmres *it, int64_t iteration, double *residual, int *done);
+/* fields read by gmres! (src/gmres.jl:210,218): mv_products, residual.current, tol, k, beta */
+int mik_gmres_state(const mik_gmres *it, double *residual, double *tol, double *beta, int *k,
+                    int64_t *mv_products, int *converged);
+
+/* ---- Hessenberg least squares (host) ------------------------------------------------------ */
+/* ldiv!(FastHessenberg(H), rhs) -- src/hessenberg.jl:15-46.  Host arrays of `dtype`; H is
+ * (width+1) x width column-major with leading dimension ldh, overwritten by R; rhs has width+1
+ * entries, overwritten by [y; residual]. */
+int mik_hessenberg_ldiv(int dtype, void *H, int64_t ldh, int width, void *rhs);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+/* Time `reps` back-to-back launches of the SpMV (optionally with the fused dot epilogue used by
+ * the CG step) with HIP events on the ctx stream; returns average milliseconds per launch. */
+int mik_time_spmv(mik_ctx *ctx, const mik_csr *A, const void *x, void *y, int fused_dot, int reps,
+                  double *avg_ms);
+/* In-loop timing of the SpMV launch inside mik_cg_iterate / mik_cg_iterate_many: a HIP event pair
+ * on the ctx stream brackets every SpMV launch of the CG step.  First reports the totals gathered
+ * so far (either pointer may be NULL), then: enable = 1 resets the totals and switches timing on,
+ * 0 switches it off, -1 leaves the mode unchanged. */
+int mik_cg_profile(mik_cg *it, int enable, double *spmv_ms_total, int64_t *spmv_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIK_H */

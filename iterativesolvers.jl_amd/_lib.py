@@ -1,0 +1,114 @@
+"""ctypes binding of libmik.so -- the C ABI declared in include/mik.h.
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails, this module
+raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmik.so")
+
+MIK_OK = 0
+MIK_F64, MIK_F32 = 0, 1
+MIK_MGS, MIK_CGS, MIK_DGKS = 0, 1, 2
+STATUS = {1: "invalid argument", 2: "HIP runtime error", 3: "dimension/dtype mismatch",
+          4: "out of memory", 5: "not implemented"}
+
+
+class MikError(RuntimeError):
+    def __init__(self, code: int, where: str, detail: str = ""):
+        self.code = code
+        super().__init__(f"{where}: status {code} ({STATUS.get(code, '?')}) {detail}".rstrip())
+
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+_i64p = C.POINTER(C.c_int64)
+_f64p = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); mirrors include/mik.h one to one
+SIGNATURES = {
+    "mik_abi_version": (C.c_int, []),
+    "mik_device_count": (C.c_int, [_ip]),
+    "mik_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "mik_ctx_destroy": (C.c_int, [_vp]),
+    "mik_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "mik_ctx_synchronize": (C.c_int, [_vp]),
+    "mik_last_error": (C.c_char_p, [_vp]),
+    "mik_reduce_shape": (C.c_int, [C.c_int, _ip, _ip]),
+    "mik_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "mik_free": (C.c_int, [_vp, _vp]),
+    "mik_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "mik_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "mik_copy": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp]),
+    "mik_fill": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp]),
+    "mik_csr_create": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _i64p, _i64p, _vp, C.c_int, C.c_int,
+                                 C.POINTER(_vp)]),
+    "mik_csr_destroy": (C.c_int, [_vp]),
+    "mik_csr_info": (C.c_int, [_vp, _i64p, _i64p, _i64p, _ip]),
+    "mik_spmv": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "mik_dot": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp]),
+    "mik_nrm2": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp]),
+    "mik_axpy": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp]),
+    "mik_xpby": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp]),
+    "mik_sub": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp]),
+    "mik_scal": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp]),
+    "mik_divide": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp]),
+    "mik_orthogonalize": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _vp, _i64, _vp, _vp, _vp, C.c_int]),
+    "mik_gemv_n": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _vp, _i64, _vp, _vp, _vp]),
+    "mik_cg_create": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, _i64,
+                                C.c_int, C.POINTER(_vp)]),
+    "mik_cg_destroy": (C.c_int, [_vp]),
+    "mik_cg_iterate": (C.c_int, [_vp, _i64, _f64p, _ip]),
+    "mik_cg_iterate_many": (C.c_int, [_vp, _i64, _i64, _f64p, _i64p]),
+    "mik_cg_state": (C.c_int, [_vp, _f64p, _f64p, _f64p, _i64p, _i64p, _ip]),
+    "mik_gmres_create": (C.c_int, [_vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int, _i64, C.c_int,
+                                   C.c_int, C.POINTER(_vp)]),
+    "mik_gmres_destroy": (C.c_int, [_vp]),
+    "mik_gmres_iterate": (C.c_int, [_vp, _i64, _f64p, _ip]),
+    "mik_gmres_state": (C.c_int, [_vp, _f64p, _f64p, _f64p, _ip, _i64p, _ip]),
+    "mik_hessenberg_ldiv": (C.c_int, [C.c_int, _vp, _i64, C.c_int, _vp]),
+    "mik_time_spmv": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _f64p]),
+    "mik_cg_profile": (C.c_int, [_vp, C.c_int, _f64p, _i64p]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libmik.so (built in-tree by ``__graft_entry__.build()``).  Fails loudly if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "There is no CPU fallback for the product path.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)      # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def dtype_code(dtype) -> int:
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return MIK_F64
+    if dtype == np.float32:
+        return MIK_F32
+    raise TypeError(f"libmik supports float64 and float32 (complex is out of scope), got {dtype}")
+
+
+def check(code: int, where: str, ctx_handle=None):
+    if code != MIK_OK:
+        detail = lib().mik_last_error(ctx_handle)
+        raise MikError(code, where, detail.decode() if detail else "")

@@ -1,0 +1,766 @@
+"""Host-side mirror of IterativeSolvers.jl's interface for the cg! / gmres! path, over libmik.so.
+
+Julia is not available in this environment, so this module plays the role the Julia shim
+(``julia/MIK.jl``) plays for a Julia host: it keeps the package's names, argument meaning,
+defaults and error behaviour, and forwards every vector operation to the C ABI.  Julia's ``f!``
+is spelled ``f_`` here.  Citations are file:line in the reference checkout (v0.9.4).
+
+    reference                                   here
+    ---------------------------------------     -----------------------------------------
+    SparseMatrixCSC{T,Int} operator A            HipCSR            (mul_(y, A, x), size, eltype)
+    Vector{T}                                    HipVector         (dot, norm, similar, zero ...)
+    cg(A, b; ...) / cg!(x, A, b; ...)            cg / cg_                     src/cg.jl:162,209
+    cg_iterator!(x, A, b, Pl; ...)               cg_iterator_                 src/cg.jl:120
+    CGIterable / PCGIterable + iterate           CGIterable / PCGIterable     src/cg.jl:5-100
+    CGStateVariables                             CGStateVariables             src/cg.jl:114
+    gmres / gmres! / gmres_iterable!             gmres / gmres_ / gmres_iterable_   src/gmres.jl
+    GMRESIterable + iterate                      GMRESIterable                src/gmres.jl:31-106
+    orthogonalize_and_normalize!                 orthogonalize_and_normalize_ src/orthogonalize.jl
+    DGKS / ClassicalGramSchmidt / ModifiedGS     same names                   src/orthogonalize.jl:4-7
+    Identity                                     Identity                     src/common.jl:28-32
+    ConvergenceHistory, niters, nprods, nrests   same names                   src/history.jl
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import MikError, check, dtype_code, lib
+
+_vp = C.c_void_p
+
+
+def _scalar(dtype, value):
+    """A host scalar of `dtype` and a pointer to it."""
+    a = np.asarray([value], dtype=dtype)
+    return a, a.ctypes.data_as(_vp)
+
+
+# ==============================================================================================
+# context, vectors, operator  (the L1 interface: docs/src/getting_started.md:25-30)
+# ==============================================================================================
+class HipContext:
+    """One device + one HIP stream (``mik_ctx``)."""
+
+    def __init__(self, device: int = 0):
+        h = _vp()
+        check(lib().mik_ctx_create(device, C.byref(h)), "mik_ctx_create", None)
+        self.handle = h
+        self.device = device
+
+    def set_stream(self, hip_stream: Optional[int]):
+        check(lib().mik_ctx_set_stream(self.handle, _vp(hip_stream)), "mik_ctx_set_stream", self.handle)
+
+    def synchronize(self):
+        check(lib().mik_ctx_synchronize(self.handle), "mik_ctx_synchronize", self.handle)
+
+    def reduce_shape(self, dtype):
+        w, l = C.c_int(), C.c_int()
+        check(lib().mik_reduce_shape(dtype_code(dtype), C.byref(w), C.byref(l)), "mik_reduce_shape", self.handle)
+        return w.value, l.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().mik_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx: Optional[HipContext] = None
+
+
+def default_context() -> HipContext:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = HipContext(0)
+    return _default_ctx
+
+
+class HipVector:
+    """Device n-vector of float64/float32: what ``similar``/``zero``/``copyto!``/``dot``/``norm``
+    and in-place broadcast need (src/cg.jl:51,58-59,62,124,129-130,138)."""
+
+    def __init__(self, n: int, dtype=np.float64, ctx: Optional[HipContext] = None, *, _ptr=None, _owner=None):
+        self.ctx = ctx or default_context()
+        self.n = int(n)
+        self.dtype = np.dtype(dtype)
+        self.code = dtype_code(dtype)
+        if _ptr is None:
+            p = _vp()
+            check(lib().mik_malloc(self.ctx.handle, self.n * self.dtype.itemsize, C.byref(p)), "mik_malloc", self.ctx.handle)
+            self.ptr = p.value
+            self._owner = None
+            self._owns = True
+        else:
+            self.ptr = int(_ptr)
+            self._owner = _owner          # keeps the parent allocation alive
+            self._owns = False
+
+    # -- construction ---------------------------------------------------------------------------
+    @staticmethod
+    def from_numpy(a, ctx: Optional[HipContext] = None) -> "HipVector":
+        a = np.ascontiguousarray(a)
+        v = HipVector(a.size, a.dtype, ctx)
+        v.copy_from_host(a)
+        return v
+
+    @staticmethod
+    def wrap(ptr: int, n: int, dtype, ctx: Optional[HipContext] = None, owner=None) -> "HipVector":
+        """Adopt an existing device allocation (e.g. ``torch_tensor.data_ptr()``)."""
+        return HipVector(n, dtype, ctx, _ptr=ptr, _owner=owner)
+
+    def view(self, offset: int, n: int) -> "HipVector":
+        return HipVector(n, self.dtype, self.ctx, _ptr=self.ptr + offset * self.dtype.itemsize, _owner=self)
+
+    def similar(self) -> "HipVector":
+        return HipVector(self.n, self.dtype, self.ctx)
+
+    def zero(self) -> "HipVector":
+        return self.similar().fill_(0)
+
+    def copy(self) -> "HipVector":
+        return self.similar().copyto_(self)
+
+    # -- host <-> device ------------------------------------------------------------------------
+    def copy_from_host(self, a) -> "HipVector":
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if a.size != self.n:
+            raise ValueError(f"DimensionMismatch: vector has length {self.n}, host array {a.size}")
+        check(lib().mik_memcpy_h2d(self.ctx.handle, _vp(self.ptr), a.ctypes.data_as(_vp), a.nbytes), "mik_memcpy_h2d", self.ctx.handle)
+        return self
+
+    def to_numpy(self) -> np.ndarray:
+        out = np.empty(self.n, self.dtype)
+        check(lib().mik_memcpy_d2h(self.ctx.handle, out.ctypes.data_as(_vp), _vp(self.ptr), out.nbytes), "mik_memcpy_d2h", self.ctx.handle)
+        return out
+
+    # -- vector interface -----------------------------------------------------------------------
+    def _same(self, other: "HipVector"):
+        if other.n != self.n or other.dtype != self.dtype:
+            raise ValueError(f"DimensionMismatch: {self.n}/{self.dtype} vs {other.n}/{other.dtype}")
+
+    def fill_(self, value) -> "HipVector":                               # x .= value
+        _, p = _scalar(self.dtype, value)
+        check(lib().mik_fill(self.ctx.handle, self.code, self.n, p, _vp(self.ptr)), "mik_fill", self.ctx.handle)
+        return self
+
+    def copyto_(self, src: "HipVector") -> "HipVector":                  # copyto!(self, src)
+        self._same(src)
+        check(lib().mik_copy(self.ctx.handle, self.code, self.n, _vp(src.ptr), _vp(self.ptr)), "mik_copy", self.ctx.handle)
+        return self
+
+    def axpy_(self, alpha, x: "HipVector") -> "HipVector":               # self .+= alpha .* x
+        self._same(x)
+        _, p = _scalar(self.dtype, alpha)
+        check(lib().mik_axpy(self.ctx.handle, self.code, self.n, p, _vp(x.ptr), _vp(self.ptr)), "mik_axpy", self.ctx.handle)
+        return self
+
+    def xpby_(self, x: "HipVector", beta) -> "HipVector":                # self .= x .+ beta .* self
+        self._same(x)
+        _, p = _scalar(self.dtype, beta)
+        check(lib().mik_xpby(self.ctx.handle, self.code, self.n, _vp(x.ptr), p, _vp(self.ptr)), "mik_xpby", self.ctx.handle)
+        return self
+
+    def sub_(self, x: "HipVector") -> "HipVector":                       # self .-= x
+        self._same(x)
+        check(lib().mik_sub(self.ctx.handle, self.code, self.n, _vp(x.ptr), _vp(self.ptr)), "mik_sub", self.ctx.handle)
+        return self
+
+    def scal_(self, alpha) -> "HipVector":                               # self .*= alpha
+        _, p = _scalar(self.dtype, alpha)
+        check(lib().mik_scal(self.ctx.handle, self.code, self.n, p, _vp(self.ptr)), "mik_scal", self.ctx.handle)
+        return self
+
+    def __len__(self):
+        return self.n
+
+    def __del__(self):
+        try:
+            if self._owns and self.ptr and self.ctx.handle:
+                lib().mik_free(self.ctx.handle, _vp(self.ptr))
+                self.ptr = 0
+        except Exception:
+            pass
+
+
+def dot(x: HipVector, y: HipVector):
+    """``dot(x, y)`` -- src/cg.jl:55."""
+    x._same(y)
+    out = np.zeros(1, x.dtype)
+    check(lib().mik_dot(x.ctx.handle, x.code, x.n, _vp(x.ptr), _vp(y.ptr), out.ctypes.data_as(_vp)), "mik_dot", x.ctx.handle)
+    return out[0]
+
+
+def norm(x: HipVector):
+    """``norm(x)`` -- src/cg.jl:62."""
+    out = np.zeros(1, x.dtype)
+    check(lib().mik_nrm2(x.ctx.handle, x.code, x.n, _vp(x.ptr), out.ctypes.data_as(_vp)), "mik_nrm2", x.ctx.handle)
+    return out[0]
+
+
+class HipMatrix:
+    """Device n x cols column-major block (the Krylov basis ``V`` of src/gmres.jl:7,13)."""
+
+    def __init__(self, n: int, cols: int, dtype=np.float64, ctx: Optional[HipContext] = None):
+        self.ctx = ctx or default_context()
+        self.n, self.cols = int(n), int(cols)
+        self.dtype = np.dtype(dtype)
+        self.ld = (self.n + 63) // 64 * 64 or 64
+        self.buf = HipVector(self.ld * self.cols, dtype, self.ctx)
+        self.buf.fill_(0)
+
+    @staticmethod
+    def from_numpy(a, ctx=None) -> "HipMatrix":
+        a = np.asarray(a)
+        m = HipMatrix(a.shape[0], a.shape[1], a.dtype, ctx)
+        for j in range(a.shape[1]):
+            m.col(j).copy_from_host(a[:, j])
+        return m
+
+    def col(self, j: int) -> HipVector:
+        return self.buf.view(j * self.ld, self.n)
+
+    def to_numpy(self) -> np.ndarray:
+        return np.stack([self.col(j).to_numpy() for j in range(self.cols)], axis=1)
+
+
+class HipCSR:
+    """The operator ``A``: a SparseMatrixCSC uploaded as device CSR (``mik_csr``).
+
+    ``HipCSR(n_rows, n_cols, colptr, rowval, nzval, index_base=1)`` takes exactly the fields of a
+    Julia ``SparseMatrixCSC{T,Int}`` (test/laplace_matrix.jl:12)."""
+
+    def __init__(self, n_rows, n_cols, ptr, idx, val, *, index_base=1, is_csc=True, ctx: Optional[HipContext] = None):
+        self.ctx = ctx or default_context()
+        val = np.ascontiguousarray(val)
+        self.dtype = val.dtype
+        self.code = dtype_code(val.dtype)
+        ptr = np.ascontiguousarray(ptr, np.int64)
+        idx = np.ascontiguousarray(idx, np.int64)
+        self.n_rows, self.n_cols, self.nnz = int(n_rows), int(n_cols), int(val.size)
+        h = _vp()
+        check(lib().mik_csr_create(self.ctx.handle, self.code, self.n_rows, self.n_cols, self.nnz,
+                                   ptr.ctypes.data_as(C.POINTER(C.c_int64)), idx.ctypes.data_as(C.POINTER(C.c_int64)),
+                                   val.ctypes.data_as(_vp), int(index_base), int(bool(is_csc)), C.byref(h)),
+              "mik_csr_create", self.ctx.handle)
+        self.handle = h
+
+    @staticmethod
+    def from_scipy(m, ctx=None) -> "HipCSR":
+        m = m.tocsc()
+        m.sort_indices()
+        return HipCSR(m.shape[0], m.shape[1], m.indptr, m.indices, m.data, index_base=0, is_csc=True, ctx=ctx)
+
+    def size(self, d: Optional[int] = None):
+        return (self.n_rows, self.n_cols) if d is None else (self.n_rows, self.n_cols)[d - 1]
+
+    def eltype(self):
+        return self.dtype
+
+    def __matmul__(self, x: HipVector) -> HipVector:                     # A * v
+        y = HipVector(self.n_rows, self.dtype, self.ctx)
+        return mul_(y, self, x)
+
+    def spmv_algorithmic_bytes(self) -> int:
+        """nnz*(s+4) + (n+1)*4 + 2*n*s."""
+        s = self.dtype.itemsize
+        return self.nnz * (s + 4) + (self.n_rows + 1) * 4 + self.n_cols * s + self.n_rows * s
+
+    def time_spmv(self, x: HipVector, y: HipVector, reps: int = 20, fused_dot: bool = False) -> float:
+        ms = C.c_double()
+        check(lib().mik_time_spmv(self.ctx.handle, self.handle, _vp(x.ptr), _vp(y.ptr), int(fused_dot), reps, C.byref(ms)),
+              "mik_time_spmv", self.ctx.handle)
+        return ms.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and self.ctx.handle:
+                lib().mik_csr_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def mul_(y: HipVector, A: HipCSR, x: HipVector) -> HipVector:
+    """``mul!(y, A, x)`` -- src/cg.jl:54."""
+    if x.n != A.n_cols or y.n != A.n_rows or x.dtype != A.dtype or y.dtype != A.dtype:
+        raise ValueError("DimensionMismatch in mul_(y, A, x)")
+    check(lib().mik_spmv(A.ctx.handle, A.handle, _vp(x.ptr), _vp(y.ptr)), "mik_spmv", A.ctx.handle)
+    return y
+
+
+# ==============================================================================================
+# common.jl / preconditioners
+# ==============================================================================================
+class Identity:
+    """No-op preconditioner -- src/common.jl:28-32."""
+
+    def ldiv_(self, y: HipVector, x: Optional[HipVector] = None):
+        if x is None:
+            return y                                                     # ldiv!(::Identity, x) = x
+        return y.copyto_(x)                                              # ldiv!(y, ::Identity, x)
+
+
+class JacobiPrec:
+    """``ldiv!(y, P::JacobiPrec, x) = y .= x ./ P.diagonal`` -- the fixture of test/cg.jl:14-18."""
+
+    def __init__(self, diagonal: HipVector):
+        self.diagonal = diagonal
+
+    def ldiv_(self, y: HipVector, x: Optional[HipVector] = None):
+        x = y if x is None else x
+        check(lib().mik_divide(y.ctx.handle, y.code, y.n, _vp(x.ptr), _vp(self.diagonal.ptr), _vp(y.ptr)), "mik_divide", y.ctx.handle)
+        return y
+
+
+def zerox(A: HipCSR, b: HipVector) -> HipVector:
+    """``zerox(A, b)`` -- src/common.jl:18-23."""
+    return HipVector(A.size(2), np.result_type(A.dtype, b.dtype), b.ctx).fill_(0)
+
+
+# ==============================================================================================
+# history.jl
+# ==============================================================================================
+class ConvergenceHistory:
+    """``ConvergenceHistory`` -- src/history.jl:54-66; ``partial=True`` stores nothing per iteration."""
+
+    def __init__(self, partial: bool = False, restart=None):
+        self.mvps = 0
+        self.mtvps = 0
+        self.iters = 0
+        self.restart = restart
+        self.isconverged = False
+        self.partial = partial
+        self.data = {}
+
+    def __getitem__(self, key):
+        return self.data[key]
+
+    def __setitem__(self, key, val):
+        self.data[key] = val
+
+    def reserve_(self, key, n):                                          # src/history.jl:181-201
+        if not self.partial:
+            self.data[key] = np.empty(int(n), np.float64)
+
+    def nextiter_(self, mvps=0, mtvps=0):                                # src/history.jl:211-215
+        self.iters += 1
+        self.mvps += mvps
+        self.mtvps += mtvps
+
+    def push_(self, key, val):                                           # src/history.jl:139-142
+        if self.partial:
+            self.data[key] = val
+        else:
+            self.data[key][self.iters - 1] = val
+
+    def setconv(self, val: bool):
+        self.isconverged = bool(val)
+
+    def shrink_(self):                                                   # src/history.jl:196-208
+        if not self.partial:
+            for k, v in list(self.data.items()):
+                if isinstance(v, np.ndarray):
+                    self.data[k] = v[: self.iters].copy()
+
+
+def niters(ch: ConvergenceHistory) -> int:
+    return ch.iters
+
+
+def nprods(ch: ConvergenceHistory) -> int:
+    return ch.mvps + ch.mtvps
+
+
+def nrests(ch: ConvergenceHistory) -> int:
+    return int(math.ceil(ch.iters / ch.restart))
+
+
+# ==============================================================================================
+# cg.jl
+# ==============================================================================================
+class CGStateVariables:
+    """``CGStateVariables(u, r, c)`` -- src/cg.jl:114-118."""
+
+    def __init__(self, u: HipVector, r: HipVector, c: HipVector):
+        self.u, self.r, self.c = u, r, c
+
+
+class CGIterable:
+    """``CGIterable`` (src/cg.jl:5-16) / ``PCGIterable`` with a diagonal ``Pl`` (src/cg.jl:18-30),
+    driven by the fused device step (``mik_cg``)."""
+
+    def __init__(self, A: HipCSR, x: HipVector, b: HipVector, statevars: CGStateVariables, Pl, *, abstol, reltol,
+                 maxiter, initially_zero):
+        self.A, self.x, self.b = A, x, b
+        self.u, self.r, self.c = statevars.u, statevars.r, statevars.c
+        self.Pl = Pl
+        for v in (x, b, self.u, self.r, self.c):
+            if v.n != A.n_rows or v.dtype != A.dtype:
+                raise ValueError("DimensionMismatch in cg_iterator_")
+        diag = Pl.diagonal.ptr if isinstance(Pl, JacobiPrec) else None
+        h = _vp()
+        check(lib().mik_cg_create(A.ctx.handle, A.handle, _vp(x.ptr), _vp(b.ptr), _vp(self.u.ptr), _vp(self.r.ptr),
+                                  _vp(self.c.ptr), _vp(diag), float(abstol), float(reltol), int(maxiter),
+                                  int(bool(initially_zero)), C.byref(h)), "mik_cg_create", A.ctx.handle)
+        self.handle = h
+        self.maxiter = int(maxiter)
+        self._refresh()
+
+    def _refresh(self):
+        res, prev, tol = C.c_double(), C.c_double(), C.c_double()
+        mx, mv = C.c_int64(), C.c_int64()
+        conv = C.c_int()
+        check(lib().mik_cg_state(self.handle, C.byref(res), C.byref(prev), C.byref(tol), C.byref(mx), C.byref(mv), C.byref(conv)),
+              "mik_cg_state", self.A.ctx.handle)
+        self.residual, self.prev_residual, self.tol = res.value, prev.value, tol.value
+        self.mv_products = mv.value
+
+    def converged(self) -> bool:                                         # src/cg.jl:32
+        return self.residual <= self.tol
+
+    def start(self) -> int:                                              # src/cg.jl:34
+        return 0
+
+    def done(self, iteration: int) -> bool:                              # src/cg.jl:36
+        return iteration >= self.maxiter or self.converged()
+
+    def iterate(self, iteration: Optional[int] = None):
+        """``iterate(it, iteration)`` -> ``None`` or ``(residual, iteration + 1)`` -- src/cg.jl:43-66."""
+        iteration = self.start() if iteration is None else iteration
+        res = C.c_double()
+        done = C.c_int()
+        check(lib().mik_cg_iterate(self.handle, int(iteration), C.byref(res), C.byref(done)), "mik_cg_iterate", self.A.ctx.handle)
+        if done.value:
+            return None
+        self.prev_residual, self.residual = self.residual, res.value
+        self.mv_products += 1
+        return self.residual, iteration + 1
+
+    def iterate_many(self, iteration: int, max_steps: int) -> np.ndarray:
+        """Up to ``max_steps`` ``iterate`` calls with one host synchronisation; returns the residuals."""
+        out = np.empty(max(int(max_steps), 1), np.float64)
+        nd = C.c_int64()
+        check(lib().mik_cg_iterate_many(self.handle, int(iteration), int(max_steps), out.ctypes.data_as(C.POINTER(C.c_double)),
+                                        C.byref(nd)), "mik_cg_iterate_many", self.A.ctx.handle)
+        self._refresh()
+        return out[: nd.value].copy()
+
+    def profile(self, enable: int = -1):
+        """In-loop HIP-event timing of the SpMV launch: returns (total_ms, launches) gathered so far,
+        then switches timing on (1, resets totals) / off (0) / leaves it (-1)."""
+        ms, cnt = C.c_double(), C.c_int64()
+        check(lib().mik_cg_profile(self.handle, int(enable), C.byref(ms), C.byref(cnt)), "mik_cg_profile", self.A.ctx.handle)
+        return ms.value, cnt.value
+
+    def __iter__(self):
+        iteration = self.start()
+        while True:
+            nxt = self.iterate(iteration)
+            if nxt is None:
+                return
+            residual, iteration = nxt
+            yield residual
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and self.A.ctx.handle:
+                lib().mik_cg_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+PCGIterable = CGIterable   # same handle; the diagonal Pl selects the src/cg.jl:72-100 branch
+
+
+class GenericCGIterable:
+    """The reference's ``iterate(::CGIterable)`` / ``iterate(::PCGIterable)`` spelled with the L1
+    entry points only (mul_, dot, norm, broadcast forms) -- i.e. what the unmodified package does
+    with a device vector type (SURVEY.md section 8b plug point 1).  Works with any ``Pl`` that has
+    ``ldiv_(y, x)``."""
+
+    def __init__(self, A, x, b, statevars, Pl, *, abstol, reltol, maxiter, initially_zero):
+        self.A, self.x, self.Pl = A, x, Pl
+        self.u, self.r, self.c = statevars.u, statevars.r, statevars.c
+        T = x.dtype.type
+        self.u.fill_(0)                                                  # src/cg.jl:129
+        self.r.copyto_(b)                                                # :130
+        if initially_zero:
+            self.mv_products = 0
+        else:
+            self.mv_products = 1
+            mul_(self.c, A, x)                                           # :137
+            self.r.sub_(self.c)                                          # :138
+        self.residual = norm(self.r)                                     # :140
+        self.tol = max(T(reltol) * self.residual, T(abstol))             # :141
+        self.prev_residual = T(1)
+        self.rho = T(1)
+        self.maxiter = int(maxiter)
+        self.pcg = not isinstance(Pl, Identity)
+
+    def converged(self):
+        return self.residual <= self.tol
+
+    def start(self):
+        return 0
+
+    def done(self, iteration):
+        return iteration >= self.maxiter or self.converged()
+
+    def iterate(self, iteration=None):
+        iteration = 0 if iteration is None else iteration
+        if self.done(iteration):
+            return None
+        if not self.pcg:
+            beta = self.residual * self.residual / (self.prev_residual * self.prev_residual)   # :50
+            self.u.xpby_(self.r, beta)                                   # :51
+            mul_(self.c, self.A, self.u)                                 # :54
+            alpha = self.residual * self.residual / dot(self.u, self.c)  # :55
+        else:
+            self.Pl.ldiv_(self.c, self.r)                                # :79
+            rho_prev = self.rho
+            self.rho = dot(self.c, self.r)                               # :82
+            beta = self.rho / rho_prev                                   # :85
+            self.u.xpby_(self.c, beta)                                   # :86
+            mul_(self.c, self.A, self.u)                                 # :89
+            alpha = self.rho / dot(self.u, self.c)                       # :90
+        self.x.axpy_(alpha, self.u)                                      # :58
+        self.r.axpy_(-alpha, self.c)                                     # :59
+        self.prev_residual = self.residual
+        self.residual = norm(self.r)                                     # :62
+        self.mv_products += 1
+        return self.residual, iteration + 1
+
+    def __iter__(self):
+        iteration = 0
+        while True:
+            nxt = self.iterate(iteration)
+            if nxt is None:
+                return
+            residual, iteration = nxt
+            yield residual
+
+
+def _default_reltol(b: HipVector) -> float:
+    return float(np.sqrt(np.finfo(b.dtype).eps))
+
+
+def cg_iterator_(x: HipVector, A: HipCSR, b: HipVector, Pl=None, *, abstol=0.0, reltol=None, maxiter=None,
+                 statevars: Optional[CGStateVariables] = None, initially_zero: bool = False, fused: bool = True):
+    """``cg_iterator!(x, A, b, Pl; ...)`` -- src/cg.jl:120-155."""
+    Pl = Identity() if Pl is None else Pl
+    reltol = _default_reltol(b) if reltol is None else reltol
+    maxiter = A.size(2) if maxiter is None else maxiter
+    if statevars is None:
+        statevars = CGStateVariables(x.zero(), x.similar(), x.similar())  # :124
+    kw = dict(abstol=abstol, reltol=reltol, maxiter=maxiter, initially_zero=initially_zero)
+    if fused and isinstance(Pl, (Identity, JacobiPrec)):
+        return CGIterable(A, x, b, statevars, Pl, **kw)
+    return GenericCGIterable(A, x, b, statevars, Pl, **kw)
+
+
+def cg_(x: HipVector, A: HipCSR, b: HipVector, *, abstol=0.0, reltol=None, maxiter=None, log: bool = False,
+        statevars: Optional[CGStateVariables] = None, verbose: bool = False, Pl=None, **kwargs):
+    """``cg!(x, A, b; ...)`` -> ``x`` or ``(x, history)`` -- src/cg.jl:209-242."""
+    reltol = _default_reltol(b) if reltol is None else reltol
+    maxiter = A.size(2) if maxiter is None else maxiter
+    history = ConvergenceHistory(partial=not log)                         # :218
+    history["abstol"] = abstol
+    history["reltol"] = reltol
+    if log:
+        history.reserve_("resnorm", maxiter + 1)                          # :221
+    iterable = cg_iterator_(x, A, b, Pl, abstol=abstol, reltol=reltol, maxiter=maxiter, statevars=statevars, **kwargs)
+    if log:
+        history.mvps = iterable.mv_products                               # :227
+    for iteration, _item in enumerate(iterable, start=1):                 # :229
+        if log:
+            history.nextiter_(mvps=1)                                     # :231
+            history.push_("resnorm", iterable.residual)                   # :232
+        if verbose:
+            print("%3d\t%1.2e" % (iteration, iterable.residual))
+    if verbose:
+        print()
+    if log:
+        history.setconv(iterable.converged())                             # :238
+        history.shrink_()                                                 # :239
+    return (iterable.x, history) if log else iterable.x
+
+
+def cg(A: HipCSR, b: HipVector, **kwargs):
+    """``cg(A, b; ...)`` -- src/cg.jl:162."""
+    return cg_(zerox(A, b), A, b, initially_zero=True, **kwargs)
+
+
+# ==============================================================================================
+# orthogonalize.jl
+# ==============================================================================================
+class OrthogonalizationMethod:
+    code = None
+
+
+class DGKS(OrthogonalizationMethod):
+    code = _lib.MIK_DGKS
+
+
+class ClassicalGramSchmidt(OrthogonalizationMethod):
+    code = _lib.MIK_CGS
+
+
+class ModifiedGramSchmidt(OrthogonalizationMethod):
+    code = _lib.MIK_MGS
+
+
+def orthogonalize_and_normalize_(V: HipMatrix, k: int, w: HipVector, h: np.ndarray, method=None):
+    """``orthogonalize_and_normalize!(view(V, :, 1:k), w, h, method)`` -> nrm -- src/orthogonalize.jl:13-79.
+    ``h`` is a host array of at least k entries, written in place."""
+    method = ModifiedGramSchmidt() if method is None else method           # :10-11
+    if w.n != V.n or w.dtype != V.dtype or k > V.cols:
+        raise ValueError("DimensionMismatch in orthogonalize_and_normalize_")
+    hh = np.zeros(max(k, 1), V.dtype)
+    nrm = np.zeros(1, V.dtype)
+    check(lib().mik_orthogonalize(V.ctx.handle, dtype_code(V.dtype), V.n, int(k), _vp(V.buf.ptr), V.ld, _vp(w.ptr),
+                                  hh.ctypes.data_as(_vp), nrm.ctypes.data_as(_vp), method.code), "mik_orthogonalize", V.ctx.handle)
+    h[:k] = hh[:k]
+    return nrm[0]
+
+
+def gemv_n_(y: HipVector, V: HipMatrix, k: int, c: np.ndarray, alpha=1.0) -> HipVector:
+    """``mul!(y, view(V, :, 1:k), c, alpha, 1)`` -- src/gmres.jl:275."""
+    c = np.ascontiguousarray(c[:k], V.dtype)
+    _, pa = _scalar(V.dtype, alpha)
+    check(lib().mik_gemv_n(V.ctx.handle, dtype_code(V.dtype), V.n, int(k), _vp(V.buf.ptr), V.ld, c.ctypes.data_as(_vp), pa, _vp(y.ptr)),
+          "mik_gemv_n", V.ctx.handle)
+    return y
+
+
+def hessenberg_ldiv_(H: np.ndarray, rhs: np.ndarray):
+    """``ldiv!(FastHessenberg(H), rhs)`` (host) -- src/hessenberg.jl:15-46.  ``H`` must be Fortran-ordered."""
+    if not H.flags.f_contiguous or H.dtype != rhs.dtype or H.shape[0] != H.shape[1] + 1 or rhs.size != H.shape[0]:
+        raise ValueError("hessenberg_ldiv_: H must be an F-ordered (m+1) x m array, rhs of length m+1, same dtype")
+    check(lib().mik_hessenberg_ldiv(dtype_code(H.dtype), H.ctypes.data_as(_vp), H.shape[0], H.shape[1], rhs.ctypes.data_as(_vp)),
+          "mik_hessenberg_ldiv", None)
+    return rhs
+
+
+# ==============================================================================================
+# gmres.jl
+# ==============================================================================================
+class GMRESIterable:
+    """``GMRESIterable`` -- src/gmres.jl:31-49, driven by ``mik_gmres`` (device Krylov basis, host Hessenberg)."""
+
+    def __init__(self, x: HipVector, A: HipCSR, b: HipVector, *, abstol, reltol, restart, maxiter, initially_zero, orth_meth):
+        if x.n != A.n_rows or b.n != A.n_rows or x.dtype != A.dtype or b.dtype != A.dtype:
+            raise ValueError("DimensionMismatch in gmres_iterable_")
+        self.A, self.x, self.b = A, x, b
+        self.restart, self.maxiter = int(restart), int(maxiter)
+        self.orth_meth = orth_meth
+        h = _vp()
+        check(lib().mik_gmres_create(A.ctx.handle, A.handle, _vp(x.ptr), _vp(b.ptr), float(abstol), float(reltol), int(restart),
+                                     int(maxiter), int(bool(initially_zero)), orth_meth.code, C.byref(h)), "mik_gmres_create", A.ctx.handle)
+        self.handle = h
+        self._refresh()
+
+    def _refresh(self):
+        res, tol, beta = C.c_double(), C.c_double(), C.c_double()
+        k = C.c_int()
+        mv = C.c_int64()
+        conv = C.c_int()
+        check(lib().mik_gmres_state(self.handle, C.byref(res), C.byref(tol), C.byref(beta), C.byref(k), C.byref(mv), C.byref(conv)),
+              "mik_gmres_state", self.A.ctx.handle)
+        self.residual_current, self.tol, self.beta, self.k, self.mv_products = res.value, tol.value, beta.value, k.value, mv.value
+
+    def converged(self) -> bool:                                         # src/gmres.jl:51
+        return self.residual_current <= self.tol
+
+    def start(self) -> int:
+        return 0
+
+    def done(self, iteration: int) -> bool:                              # src/gmres.jl:55
+        return iteration >= self.maxiter or self.converged()
+
+    def iterate(self, iteration: Optional[int] = None):
+        """``iterate(g, iteration)`` -- src/gmres.jl:57-106."""
+        iteration = 0 if iteration is None else iteration
+        res = C.c_double()
+        done = C.c_int()
+        check(lib().mik_gmres_iterate(self.handle, int(iteration), C.byref(res), C.byref(done)), "mik_gmres_iterate", self.A.ctx.handle)
+        if done.value:
+            return None
+        self._refresh()
+        return self.residual_current, iteration + 1
+
+    def __iter__(self):
+        iteration = 0
+        while True:
+            nxt = self.iterate(iteration)
+            if nxt is None:
+                return
+            residual, iteration = nxt
+            yield residual
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and self.A.ctx.handle:
+                lib().mik_gmres_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def gmres_iterable_(x: HipVector, A: HipCSR, b: HipVector, *, Pl=None, Pr=None, abstol=0.0, reltol=None, restart=None,
+                    maxiter=None, initially_zero: bool = False, orth_meth: Optional[OrthogonalizationMethod] = None):
+    """``gmres_iterable!(x, A, b; ...)`` -- src/gmres.jl:108-136."""
+    for P, name in ((Pl, "Pl"), (Pr, "Pr")):
+        if P is not None and not isinstance(P, Identity):
+            raise MikError(5, "gmres_iterable_", f"{name} other than Identity() is not implemented on the device path")
+    reltol = _default_reltol(b) if reltol is None else reltol
+    restart = min(20, A.size(2)) if restart is None else restart           # :113
+    maxiter = A.size(2) if maxiter is None else maxiter                    # :114
+    orth_meth = ModifiedGramSchmidt() if orth_meth is None else orth_meth  # :116
+    return GMRESIterable(x, A, b, abstol=abstol, reltol=reltol, restart=restart, maxiter=maxiter, initially_zero=initially_zero,
+                         orth_meth=orth_meth)
+
+
+def gmres_(x: HipVector, A: HipCSR, b: HipVector, *, Pl=None, Pr=None, abstol=0.0, reltol=None, restart=None, maxiter=None,
+           log: bool = False, initially_zero: bool = False, verbose: bool = False, orth_meth=None):
+    """``gmres!(x, A, b; ...)`` -> ``x`` or ``(x, history)`` -- src/gmres.jl:184-222."""
+    reltol = _default_reltol(b) if reltol is None else reltol
+    restart = min(20, A.size(2)) if restart is None else restart
+    maxiter = A.size(2) if maxiter is None else maxiter
+    history = ConvergenceHistory(partial=not log, restart=restart)          # :195
+    history["abstol"] = abstol
+    history["reltol"] = reltol
+    if log:
+        history.reserve_("resnorm", maxiter)                               # :198
+    iterable = gmres_iterable_(x, A, b, Pl=Pl, Pr=Pr, abstol=abstol, reltol=reltol, maxiter=maxiter, restart=restart,
+                               initially_zero=initially_zero, orth_meth=orth_meth)
+    if verbose:
+        print("=== gmres ===\n%4s\t%4s\t%7s" % ("rest", "iter", "resnorm"))
+    for iteration, residual in enumerate(iterable, start=1):               # :207
+        if log:
+            history.nextiter_()                                            # :209
+            history.mvps = iterable.mv_products                            # :210
+            history.push_("resnorm", residual)                             # :211
+        if verbose:
+            print("%3d\t%3d\t%1.2e" % (1 + (iteration - 1) // restart, 1 + (iteration - 1) % restart, residual))
+    if verbose:
+        print()
+    history.setconv(iterable.converged())                                  # :218
+    if log:
+        history.shrink_()                                                  # :219
+    return (x, history) if log else x
+
+
+def gmres(A: HipCSR, b: HipVector, **kwargs):
+    """``gmres(A, b; ...)`` -- src/gmres.jl:143."""
+    return gmres_(zerox(A, b), A, b, initially_zero=True, **kwargs)

@@ -1,0 +1,436 @@
+// mik_core.hip -- context, device memory, CSR upload, and the L1 operator/vector entry points
+// (mul!, dot, norm, broadcast forms) of include/mik.h.
+#include <algorithm>
+#include <cstdarg>
+#include <new>
+
+#include "mik_kernels.h"
+
+thread_local std::string g_mik_create_error;
+
+int mik_fail(mik_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_mik_create_error = buf;
+    return code;
+}
+
+int mik_ensure_partials(mik_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->partials_bytes) return MIK_OK;
+    size_t want = std::max(bytes, (size_t)1 << 20);
+    if (ctx->partials) {
+        MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MIK_HIP(ctx, hipFree(ctx->partials));
+        ctx->partials = nullptr;
+        ctx->partials_bytes = 0;
+    }
+    MIK_HIP(ctx, hipMalloc(&ctx->partials, want));
+    ctx->partials_bytes = want;
+    return MIK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------
+
+template <typename T> static int read_scalars(mik_ctx *ctx, const T *dev, int count, T *host_out)
+{
+    MIK_HIP(ctx, hipMemcpyAsync(ctx->coef_host, dev, sizeof(T) * count, hipMemcpyDeviceToHost, ctx->stream));
+    MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(host_out, ctx->coef_host, sizeof(T) * count);
+    return MIK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// library / context
+// ---------------------------------------------------------------------------------------------
+extern "C" int mik_abi_version(void) { return MIK_ABI_VERSION; }
+
+extern "C" int mik_device_count(int *count)
+{
+    if (!count) return MIK_ERR_INVALID;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *count = 0; return mik_fail(nullptr, MIK_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = c;
+    return MIK_OK;
+}
+
+extern "C" int mik_ctx_create(int device, mik_ctx **out)
+{
+    if (!out) return mik_fail(nullptr, MIK_ERR_INVALID, "mik_ctx_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return mik_fail(nullptr, MIK_ERR_HIP, "mik_ctx_create: no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= count)
+        return mik_fail(nullptr, MIK_ERR_INVALID, "mik_ctx_create: device %d out of range [0, %d)", device, count);
+    mik_ctx *ctx = new (std::nothrow) mik_ctx();
+    if (!ctx) return mik_fail(nullptr, MIK_ERR_NOMEM, "mik_ctx_create: host allocation failed");
+    ctx->device = device;
+    auto bail = [&](hipError_t err, const char *what) {
+        int rc = mik_fail(nullptr, MIK_ERR_HIP, "mik_ctx_create: %s: %s", what, hipGetErrorString(err));
+        delete ctx;
+        return rc;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    ctx->stream = ctx->own_stream;
+    if ((e = hipMalloc(&ctx->coef, mik_ctx::COEF_BYTES)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipHostMalloc(&ctx->coef_host, mik_ctx::COEF_BYTES, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+    *out = ctx;
+    return MIK_OK;
+}
+
+extern "C" int mik_ctx_destroy(mik_ctx *ctx)
+{
+    if (!ctx) return MIK_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->partials) (void)hipFree(ctx->partials);
+    if (ctx->coef) (void)hipFree(ctx->coef);
+    if (ctx->coef_host) (void)hipHostFree(ctx->coef_host);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return MIK_OK;
+}
+
+extern "C" int mik_ctx_set_stream(mik_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return MIK_ERR_INVALID;
+    MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return MIK_OK;
+}
+
+extern "C" int mik_ctx_synchronize(mik_ctx *ctx)
+{
+    if (!ctx) return MIK_ERR_INVALID;
+    MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MIK_OK;
+}
+
+extern "C" const char *mik_last_error(mik_ctx *ctx) { return ctx ? ctx->err.c_str() : g_mik_create_error.c_str(); }
+
+extern "C" int mik_reduce_shape(int dtype, int *W, int *L)
+{
+    if (dtype != MIK_F64 && dtype != MIK_F32) return MIK_ERR_INVALID;
+    if (W) *W = dtype == MIK_F64 ? VT<double>::W : VT<float>::W;
+    if (L) *L = MIK_RED_L;
+    return MIK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device memory
+// ---------------------------------------------------------------------------------------------
+extern "C" int mik_malloc(mik_ctx *ctx, size_t bytes, void **dptr)
+{
+    if (!ctx || !dptr) return MIK_ERR_INVALID;
+    *dptr = nullptr;
+    MIK_HIP(ctx, hipSetDevice(ctx->device));
+    MIK_HIP(ctx, hipMalloc(dptr, bytes ? bytes : 16));
+    return MIK_OK;
+}
+
+extern "C" int mik_free(mik_ctx *ctx, void *dptr)
+{
+    if (!ctx) return MIK_ERR_INVALID;
+    if (!dptr) return MIK_OK;
+    MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MIK_HIP(ctx, hipFree(dptr));
+    return MIK_OK;
+}
+
+extern "C" int mik_memcpy_h2d(mik_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !src))) return MIK_ERR_INVALID;
+    if (!bytes) return MIK_OK;
+    MIK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MIK_OK;
+}
+
+extern "C" int mik_memcpy_d2h(mik_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !src))) return MIK_ERR_INVALID;
+    if (!bytes) return MIK_OK;
+    MIK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MIK_OK;
+}
+
+extern "C" int mik_copy(mik_ctx *ctx, int dtype, int64_t n, const void *x, void *y)
+{
+    if (!ctx || n < 0 || (n && (!x || !y))) return MIK_ERR_INVALID;
+    if (n == 0 || x == y) return MIK_OK;
+    MIK_HIP(ctx, hipMemcpyAsync(y, x, (size_t)n * mik_dtype_size(dtype), hipMemcpyDeviceToDevice, ctx->stream));
+    return MIK_OK;
+}
+
+template <typename T> static int fill_impl(mik_ctx *ctx, int64_t n, const void *value, void *x)
+{
+    OpFill<T> op{(T *)x, *(const T *)value};
+    return launch_map<T>(ctx, n, op, mik_aligned16(x), (T *)nullptr, nullptr);
+}
+
+extern "C" int mik_fill(mik_ctx *ctx, int dtype, int64_t n, const void *value, void *x)
+{
+    if (!ctx || n < 0 || !value || (n && !x)) return MIK_ERR_INVALID;
+    return dtype == MIK_F64 ? fill_impl<double>(ctx, n, value, x) : fill_impl<float>(ctx, n, value, x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// operator upload
+// ---------------------------------------------------------------------------------------------
+extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                              const int64_t *ptr, const int64_t *idx, const void *val, int index_base,
+                              int is_csc, mik_csr **out)
+{
+    if (!ctx || !out) return MIK_ERR_INVALID;
+    *out = nullptr;
+    if (dtype != MIK_F64 && dtype != MIK_F32) return mik_fail(ctx, MIK_ERR_INVALID, "mik_csr_create: bad dtype %d", dtype);
+    if (n_rows < 0 || n_cols < 0 || nnz < 0 || !ptr || (nnz && (!idx || !val)))
+        return mik_fail(ctx, MIK_ERR_INVALID, "mik_csr_create: bad sizes or NULL arrays");
+    if (n_rows >= (int64_t)INT32_MAX - MIK_BLOCK || n_cols >= INT32_MAX || nnz >= (int64_t)INT32_MAX - MIK_SPMV_TILE)
+        return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_csr_create: sizes exceed the Int32 device index range");
+    const int64_t n_major = is_csc ? n_cols : n_rows;   // length of ptr - 1
+    const int64_t n_minor = is_csc ? n_rows : n_cols;   // range of idx
+    if (ptr[0] != index_base || ptr[n_major] - index_base != nnz)
+        return mik_fail(ctx, MIK_ERR_MISMATCH, "mik_csr_create: ptr[0]=%lld, ptr[end]=%lld inconsistent with nnz=%lld, base=%d",
+                        (long long)ptr[0], (long long)ptr[n_major], (long long)nnz, index_base);
+    const size_t es = mik_dtype_size(dtype);
+    std::vector<int> rowptr, col;
+    std::vector<unsigned char> v;
+    try {
+        rowptr.assign((size_t)n_rows + 1, 0);
+        col.resize((size_t)nnz);
+        v.resize((size_t)nnz * es);
+    } catch (const std::bad_alloc &) {
+        return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host staging allocation failed");
+    }
+    for (int64_t j = 0; j < n_major; ++j)
+        if (ptr[j + 1] < ptr[j]) return mik_fail(ctx, MIK_ERR_INVALID, "mik_csr_create: ptr not monotone at %lld", (long long)j);
+    for (int64_t k = 0; k < nnz; ++k) {
+        const int64_t i = idx[k] - index_base;
+        if (i < 0 || i >= n_minor) return mik_fail(ctx, MIK_ERR_INVALID, "mik_csr_create: index %lld out of range at %lld", (long long)idx[k], (long long)k);
+    }
+    int max_row = 0;
+    if (is_csc) {
+        // CSC -> CSR: counting-sort transpose; walking columns in ascending order keeps every row's
+        // entries in ascending column order = the order Julia's column scatter reaches that row.
+        for (int64_t k = 0; k < nnz; ++k) rowptr[(size_t)(idx[k] - index_base) + 1]++;
+        for (int64_t r = 0; r < n_rows; ++r) {
+            max_row = std::max(max_row, rowptr[r + 1]);
+            rowptr[r + 1] += rowptr[r];
+        }
+        std::vector<int> cursor(rowptr.begin(), rowptr.end() - 1);
+        for (int64_t j = 0; j < n_cols; ++j)
+            for (int64_t k = ptr[j] - index_base; k < ptr[j + 1] - index_base; ++k) {
+                const int64_t r = idx[k] - index_base;
+                const int dst = cursor[r]++;
+                col[dst] = (int)j;
+                memcpy(&v[(size_t)dst * es], (const unsigned char *)val + (size_t)k * es, es);
+            }
+    } else {
+        for (int64_t r = 0; r <= n_rows; ++r) rowptr[r] = (int)(ptr[r] - index_base);
+        for (int64_t r = 0; r < n_rows; ++r) max_row = std::max(max_row, rowptr[r + 1] - rowptr[r]);
+        for (int64_t k = 0; k < nnz; ++k) col[k] = (int)(idx[k] - index_base);
+        if (nnz) memcpy(v.data(), val, (size_t)nnz * es);
+    }
+
+    mik_csr *A = new (std::nothrow) mik_csr();
+    if (!A) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host allocation failed");
+    A->ctx = ctx; A->dtype = dtype; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz; A->max_row_nnz = max_row;
+    const size_t pad = MIK_SPMV_TILE;   // slack so tile-granular reads never leave the allocation
+    auto cleanup = [&]() { mik_csr_destroy(A); };
+    hipError_t e;
+    (void)hipSetDevice(ctx->device);
+    if ((e = hipMalloc((void **)&A->rowptr, sizeof(int) * ((size_t)n_rows + 1 + 256))) != hipSuccess ||
+        (e = hipMalloc((void **)&A->col, sizeof(int) * ((size_t)nnz + pad))) != hipSuccess ||
+        (e = hipMalloc(&A->val, es * ((size_t)nnz + pad))) != hipSuccess) {
+        cleanup();
+        return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: hipMalloc: %s", hipGetErrorString(e));
+    }
+    if ((e = hipMemsetAsync(A->col + nnz, 0, sizeof(int) * pad, ctx->stream)) != hipSuccess ||
+        (e = hipMemsetAsync((unsigned char *)A->val + es * (size_t)nnz, 0, es * pad, ctx->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(A->rowptr, rowptr.data(), sizeof(int) * ((size_t)n_rows + 1), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+        (nnz && (e = hipMemcpyAsync(A->col, col.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) ||
+        (nnz && (e = hipMemcpyAsync(A->val, v.data(), es * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) ||
+        (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) {
+        cleanup();
+        return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create: upload: %s", hipGetErrorString(e));
+    }
+    *out = A;
+    return MIK_OK;
+}
+
+extern "C" int mik_csr_destroy(mik_csr *A)
+{
+    if (!A) return MIK_OK;
+    if (A->ctx) (void)hipStreamSynchronize(A->ctx->stream);
+    if (A->rowptr) (void)hipFree(A->rowptr);
+    if (A->col) (void)hipFree(A->col);
+    if (A->val) (void)hipFree(A->val);
+    delete A;
+    return MIK_OK;
+}
+
+extern "C" int mik_csr_info(const mik_csr *A, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, int *dtype)
+{
+    if (!A) return MIK_ERR_INVALID;
+    if (n_rows) *n_rows = A->n_rows;
+    if (n_cols) *n_cols = A->n_cols;
+    if (nnz) *nnz = A->nnz;
+    if (dtype) *dtype = A->dtype;
+    return MIK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpMV
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done)
+{
+    const int n = (int)A->n_rows;
+    if (n == 0) return MIK_OK;
+    const int nb = (n + MIK_BLOCK - 1) / MIK_BLOCK;
+    if (fuse_dot)
+        hipLaunchKernelGGL((k_spmv_rowblock<T, true>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, A->rowptr, A->col,
+                           (const T *)A->val, x, y, seg_out, done);
+    else
+        hipLaunchKernelGGL((k_spmv_rowblock<T, false>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, A->rowptr, A->col,
+                           (const T *)A->val, x, y, seg_out, done);
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+template int mik_spmv_launch<double>(mik_ctx *, const mik_csr *, const double *, double *, bool, double *, const int *);
+template int mik_spmv_launch<float>(mik_ctx *, const mik_csr *, const float *, float *, bool, float *, const int *);
+
+extern "C" int mik_spmv(mik_ctx *ctx, const mik_csr *A, const void *x, void *y)
+{
+    if (!ctx || !A || !x || !y) return MIK_ERR_INVALID;
+    if (x == y) return mik_fail(ctx, MIK_ERR_INVALID, "mik_spmv: x and y must not alias");
+    return A->dtype == MIK_F64 ? mik_spmv_launch<double>(ctx, A, (const double *)x, (double *)y, false, nullptr, nullptr)
+                               : mik_spmv_launch<float>(ctx, A, (const float *)x, (float *)y, false, nullptr, nullptr);
+}
+
+template <typename T>
+static int time_spmv_impl(mik_ctx *ctx, const mik_csr *A, const void *x, void *y, int fused, int reps, double *avg_ms)
+{
+    const int64_t nb = (A->n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
+    int rc = mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(nb, 1));
+    if (rc) return rc;
+    hipEvent_t e0, e1;
+    MIK_HIP(ctx, hipEventCreate(&e0));
+    MIK_HIP(ctx, hipEventCreate(&e1));
+    MIK_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < reps; ++i) {
+        rc = mik_spmv_launch<T>(ctx, A, (const T *)x, (T *)y, fused != 0, (T *)ctx->partials, nullptr);
+        if (rc) return rc;
+    }
+    MIK_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    MIK_HIP(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    MIK_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = (double)ms / reps;
+    return MIK_OK;
+}
+
+extern "C" int mik_time_spmv(mik_ctx *ctx, const mik_csr *A, const void *x, void *y, int fused_dot, int reps, double *avg_ms)
+{
+    if (!ctx || !A || !x || !y || reps <= 0 || !avg_ms) return MIK_ERR_INVALID;
+    return A->dtype == MIK_F64 ? time_spmv_impl<double>(ctx, A, x, y, fused_dot, reps, avg_ms)
+                               : time_spmv_impl<float>(ctx, A, x, y, fused_dot, reps, avg_ms);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BLAS-1 forms
+// ---------------------------------------------------------------------------------------------
+template <typename T> static int reduce_to_host(mik_ctx *ctx, int64_t n, bool take_sqrt, T *out)
+{
+    // level 2 of the segment sums sitting in ctx->partials -> ctx->coef[0] -> host
+    const int64_t nseg = mik_nseg<T>(n);
+    hipLaunchKernelGGL((k_finalize_store<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg,
+                       (int64_t)0, (T *)ctx->coef, (const int *)nullptr);
+    MIK_LAUNCH_CHECK(ctx);
+    T v;
+    int rc = read_scalars<T>(ctx, (const T *)ctx->coef, 1, &v);
+    if (rc) return rc;
+    *out = take_sqrt ? (T)std::sqrt(v) : v;   // host sqrt is IEEE correctly rounded
+    return MIK_OK;
+}
+
+template <typename T> static int dot_impl(mik_ctx *ctx, int64_t n, const void *x, const void *y, void *out, bool nrm)
+{
+    int rc = mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(mik_nseg<T>(n), 1));
+    if (rc) return rc;
+    OpDot<T> op{(const T *)x, (const T *)y};
+    rc = launch_map<T>(ctx, n, op, mik_aligned16(x) && mik_aligned16(y), (T *)ctx->partials, nullptr);
+    if (rc) return rc;
+    return reduce_to_host<T>(ctx, n, nrm, (T *)out);
+}
+
+extern "C" int mik_dot(mik_ctx *ctx, int dtype, int64_t n, const void *x, const void *y, void *out)
+{
+    if (!ctx || n < 0 || !out || (n && (!x || !y))) return MIK_ERR_INVALID;
+    return dtype == MIK_F64 ? dot_impl<double>(ctx, n, x, y, out, false) : dot_impl<float>(ctx, n, x, y, out, false);
+}
+
+extern "C" int mik_nrm2(mik_ctx *ctx, int dtype, int64_t n, const void *x, void *out)
+{
+    if (!ctx || n < 0 || !out || (n && !x)) return MIK_ERR_INVALID;
+    return dtype == MIK_F64 ? dot_impl<double>(ctx, n, x, x, out, true) : dot_impl<float>(ctx, n, x, x, out, true);
+}
+
+extern "C" int mik_axpy(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, const void *x, void *y)
+{
+    if (!ctx || n < 0 || !alpha || (n && (!x || !y))) return MIK_ERR_INVALID;
+    const bool vec = mik_aligned16(x) && mik_aligned16(y);
+    if (dtype == MIK_F64) { OpAxpy<double> op{(const double *)x, (double *)y, coef_val(*(const double *)alpha)}; return launch_map<double>(ctx, n, op, vec, (double *)nullptr, nullptr); }
+    if (dtype == MIK_F32) { OpAxpy<float> op{(const float *)x, (float *)y, coef_val(*(const float *)alpha)}; return launch_map<float>(ctx, n, op, vec, (float *)nullptr, nullptr); }
+    return MIK_ERR_INVALID;
+}
+
+extern "C" int mik_xpby(mik_ctx *ctx, int dtype, int64_t n, const void *x, const void *beta, void *y)
+{
+    if (!ctx || n < 0 || !beta || (n && (!x || !y))) return MIK_ERR_INVALID;
+    const bool vec = mik_aligned16(x) && mik_aligned16(y);
+    if (dtype == MIK_F64) { OpXpby<double> op{(const double *)x, (double *)y, coef_val(*(const double *)beta)}; return launch_map<double>(ctx, n, op, vec, (double *)nullptr, nullptr); }
+    if (dtype == MIK_F32) { OpXpby<float> op{(const float *)x, (float *)y, coef_val(*(const float *)beta)}; return launch_map<float>(ctx, n, op, vec, (float *)nullptr, nullptr); }
+    return MIK_ERR_INVALID;
+}
+
+extern "C" int mik_sub(mik_ctx *ctx, int dtype, int64_t n, const void *x, void *y)
+{
+    if (!ctx || n < 0 || (n && (!x || !y))) return MIK_ERR_INVALID;
+    const bool vec = mik_aligned16(x) && mik_aligned16(y);
+    if (dtype == MIK_F64) { OpSub<double> op{(const double *)x, (double *)y}; return launch_map<double>(ctx, n, op, vec, (double *)nullptr, nullptr); }
+    if (dtype == MIK_F32) { OpSub<float> op{(const float *)x, (float *)y}; return launch_map<float>(ctx, n, op, vec, (float *)nullptr, nullptr); }
+    return MIK_ERR_INVALID;
+}
+
+extern "C" int mik_scal(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, void *x)
+{
+    if (!ctx || n < 0 || !alpha || (n && !x)) return MIK_ERR_INVALID;
+    const bool vec = mik_aligned16(x);
+    if (dtype == MIK_F64) { OpScal<double> op{(double *)x, coef_val(*(const double *)alpha)}; return launch_map<double>(ctx, n, op, vec, (double *)nullptr, nullptr); }
+    if (dtype == MIK_F32) { OpScal<float> op{(float *)x, coef_val(*(const float *)alpha)}; return launch_map<float>(ctx, n, op, vec, (float *)nullptr, nullptr); }
+    return MIK_ERR_INVALID;
+}
+
+extern "C" int mik_divide(mik_ctx *ctx, int dtype, int64_t n, const void *x, const void *d, void *y)
+{
+    if (!ctx || n < 0 || (n && (!x || !d || !y))) return MIK_ERR_INVALID;
+    const bool vec = mik_aligned16(x) && mik_aligned16(d) && mik_aligned16(y);
+    if (dtype == MIK_F64) { OpDivide<double> op{(const double *)x, (const double *)d, (double *)y}; return launch_map<double>(ctx, n, op, vec, (double *)nullptr, nullptr); }
+    if (dtype == MIK_F32) { OpDivide<float> op{(const float *)x, (const float *)d, (float *)y}; return launch_map<float>(ctx, n, op, vec, (float *)nullptr, nullptr); }
+    return MIK_ERR_INVALID;
+}

@@ -1,0 +1,160 @@
+// mik_internal.h -- shared host structures and device helpers of libmik (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mik.h"
+
+// ---------------------------------------------------------------------------------------------
+// compile-time shape of the level-1 reduction tree (exported through mik_reduce_shape)
+// ---------------------------------------------------------------------------------------------
+constexpr int MIK_BLOCK = 256;       // threads per workgroup = 4 wave-64
+constexpr int MIK_RED_L = 2;         // 16-byte loads per thread per segment
+constexpr int MIK_FIN_THREADS = 1024;
+constexpr int MIK_SPMV_TILE = 2048;  // nnz staged in LDS per row-block pass
+constexpr int MIK_MAX_GRID = 256 * 8 * 4;
+
+template <typename T> struct VT;
+template <> struct VT<double> { static constexpr int W = 2; using vec = double2; };
+template <> struct VT<float>  { static constexpr int W = 4; using vec = float4;  };
+
+// ---------------------------------------------------------------------------------------------
+// host structures
+// ---------------------------------------------------------------------------------------------
+struct mik_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    void *partials = nullptr;        // level-1 segment sums (device)
+    size_t partials_bytes = 0;
+    void *coef = nullptr;            // small device array of coefficients / scalar results
+    void *coef_host = nullptr;       // pinned host mirror
+    static constexpr size_t COEF_BYTES = 4096;
+};
+
+struct mik_csr {
+    mik_ctx *ctx = nullptr;
+    int dtype = MIK_F64;
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    int *rowptr = nullptr;           // device, n_rows + 1
+    int *col = nullptr;              // device, nnz (+ padding)
+    void *val = nullptr;             // device, nnz (+ padding)
+    int max_row_nnz = 0;
+};
+
+extern thread_local std::string g_mik_create_error;
+
+int mik_fail(mik_ctx *ctx, int code, const char *fmt, ...);
+int mik_ensure_partials(mik_ctx *ctx, size_t bytes);
+
+#define MIK_HIP(ctx, call)                                                                    \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return mik_fail((ctx), e_ == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP,    \
+                            "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,   \
+                            __LINE__);                                                        \
+    } while (0)
+
+#define MIK_LAUNCH_CHECK(ctx)                                                                 \
+    do {                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess)                                                                 \
+            return mik_fail((ctx), MIK_ERR_HIP, "kernel launch failed: %s (%s:%d)",           \
+                            hipGetErrorString(e_), __FILE__, __LINE__);                       \
+    } while (0)
+
+static inline bool mik_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline size_t mik_dtype_size(int dtype) { return dtype == MIK_F64 ? 8 : 4; }
+
+// number of level-1 segments of an n-vector for dtype T
+template <typename T> static inline int64_t mik_nseg(int64_t n)
+{
+    const int64_t seg = (int64_t)MIK_BLOCK * VT<T>::W * MIK_RED_L;
+    return (n + seg - 1) / seg;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+// A coefficient that is either an immediate or read from device memory (written by a finalise
+// kernel earlier on the stream), optionally negated/never contracted.
+template <typename T> struct Coef {
+    const T *ptr;
+    T val;
+    __device__ __forceinline__ T get() const { return ptr ? *ptr : val; }
+};
+template <typename T> static inline Coef<T> coef_val(T v) { return Coef<T>{nullptr, v}; }
+template <typename T> static inline Coef<T> coef_ptr(const T *p) { return Coef<T>{p, T(0)}; }
+
+// wave-64 shuffle-down tree, offsets 32..1; the value in lane 0 is the tree sum
+template <typename T> __device__ __forceinline__ T wave_tree(T v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_down(v, off, 64);
+    return v;
+}
+
+// 256-thread block: wave tree, then the 4 wave sums left to right.  Result valid in thread 0.
+template <typename T> __device__ __forceinline__ T block_tree_256(T v, T *lds4)
+{
+    v = wave_tree(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) lds4[w] = v;
+    __syncthreads();
+    T tot = T(0);
+    if (threadIdx.x == 0) {
+        tot = lds4[0];
+        tot = tot + lds4[1];
+        tot = tot + lds4[2];
+        tot = tot + lds4[3];
+    }
+    __syncthreads();
+    return tot;
+}
+
+// 1024-thread block: wave tree, then the 16 wave sums left to right.  Result valid in thread 0.
+template <typename T> __device__ __forceinline__ T block_tree_1024(T v, T *lds16)
+{
+    v = wave_tree(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) lds16[w] = v;
+    __syncthreads();
+    T tot = T(0);
+    if (threadIdx.x == 0) {
+        tot = lds16[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) tot = tot + lds16[i];
+    }
+    return tot;
+}
+
+// level 2: sum of m segment sums with the fixed 1024-thread shape; result valid in thread 0
+template <typename T> __device__ __forceinline__ T level2_sum(const T *__restrict__ S, int64_t m, T *lds16)
+{
+    T acc = T(0);
+    for (int64_t j = threadIdx.x; j < m; j += MIK_FIN_THREADS) acc = acc + S[j];
+    return block_tree_1024(acc, lds16);
+}
+
+// correctly rounded square root (IEEE): the product path needs sqrt(rr) to match the host's
+__device__ __forceinline__ double mik_sqrt(double x) { return __dsqrt_rn(x); }
+__device__ __forceinline__ float mik_sqrt(float x) { return __fsqrt_rn(x); }
+
+// block -> row-block map that hands every XCD (block b runs on XCD b % 8) one contiguous range
+__device__ __forceinline__ int xcd_remap(int b, int nb)
+{
+    const int xcd = b & 7, idx = b >> 3;
+    const int q = nb >> 3, rem = nb & 7;
+    return xcd * q + (xcd < rem ? xcd : rem) + idx;
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,509 @@
+// mik_kernels.h -- hand-written gfx950 kernels of the Krylov inner loop (HBM-bound; no MFMA).
+//
+// Every kernel is a 256-thread (4 wave-64) workgroup.  Element-wise kernels stream 16 bytes per
+// lane per load; reductions follow the fixed-shape tree documented in include/mik.h so that the
+// CPU oracle can reproduce them bit for bit.  The library is compiled with -ffp-contract=off:
+// `a + b * c` below is always a rounded multiply followed by a rounded add, like the reference's
+// Julia broadcast (src/cg.jl:51,58-59) and SparseArrays' `y[i] += a * x` scatter.
+#pragma once
+#include <algorithm>
+
+#include "mik_internal.h"
+
+#ifdef __HIPCC__
+
+// =============================================================================================
+// element-wise map (+ optional level-1 reduction)
+// =============================================================================================
+//
+// Op interface:
+//   static constexpr bool REDUCE;
+//   __device__ void apply(int64_t i, T &acc) const;            // one element
+//   __device__ void apply_vec(int64_t i, T &acc) const;        // W elements starting at i (16 B)
+//
+// Segment s = 256*W*L elements; thread t owns, for l = 0..L-1, the W elements starting at
+// s*SEG + l*256*W + W*t (coalesced 16-byte loads), accumulated in that order.
+
+template <typename T, bool VEC, typename Op>
+__global__ __launch_bounds__(MIK_BLOCK) void k_map(int64_t n, int64_t nseg, Op op, T *__restrict__ seg_out,
+                                                    const int *__restrict__ done)
+{
+    if (done && *done) return;
+    constexpr int W = VT<T>::W;
+    constexpr int L = MIK_RED_L;
+    constexpr int64_t SEG = (int64_t)MIK_BLOCK * W * L;
+    __shared__ T lds4[4];
+    for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+        const int64_t base = s * SEG + (int64_t)W * threadIdx.x;
+        T acc = T(0);
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int64_t i = base + (int64_t)l * MIK_BLOCK * W;
+            if (VEC && i + W <= n) {
+                op.apply_vec(i, acc);
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; ++e)
+                    if (i + e < n) op.apply(i + e, acc);
+            }
+        }
+        if (Op::REDUCE) {
+            T tot = block_tree_256(acc, lds4);
+            if (threadIdx.x == 0) seg_out[s] = tot;
+        }
+    }
+}
+
+// host-side launcher of k_map: one workgroup per segment, capped grid with a grid-stride loop
+template <typename T, typename Op>
+static inline int launch_map(mik_ctx *ctx, int64_t n, Op op, bool vec, T *seg_out, const int *done)
+{
+    const int64_t nseg = mik_nseg<T>(n);
+    if (nseg == 0) return MIK_OK;
+    const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
+    if (vec)
+        hipLaunchKernelGGL((k_map<T, true, Op>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, seg_out, done);
+    else
+        hipLaunchKernelGGL((k_map<T, false, Op>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, seg_out, done);
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+
+template <typename T> __device__ __forceinline__ typename VT<T>::vec vload(const T *p)
+{
+    return *reinterpret_cast<const typename VT<T>::vec *>(p);
+}
+template <typename T> __device__ __forceinline__ void vstore(T *p, typename VT<T>::vec v)
+{
+    *reinterpret_cast<typename VT<T>::vec *>(p) = v;
+}
+template <typename T> __device__ __forceinline__ T &el(typename VT<T>::vec &v, int e)
+{
+    return reinterpret_cast<T *>(&v)[e];
+}
+
+// Helper macro: define apply_vec in terms of a per-element lambda over loaded vectors is not
+// possible generically, so each op spells out its loads (all issued before the arithmetic).
+
+// y .= x .+ beta .* y            -- src/cg.jl:51  (u .= r .+ beta .* u), :86
+template <typename T> struct OpXpby {
+    static constexpr bool REDUCE = false;
+    const T *__restrict__ x; T *__restrict__ y; Coef<T> beta;
+    __device__ __forceinline__ void apply(int64_t i, T &) const { T t = beta.get() * y[i]; y[i] = x[i] + t; }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &) const
+    {
+        const T b = beta.get();
+        auto xv = vload(x + i); auto yv = vload<T>(y + i);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) { T t = b * el<T>(yv, e); el<T>(yv, e) = el<T>(xv, e) + t; }
+        vstore(y + i, yv);
+    }
+};
+
+// y .+= alpha .* x               -- src/cg.jl:58
+template <typename T> struct OpAxpy {
+    static constexpr bool REDUCE = false;
+    const T *__restrict__ x; T *__restrict__ y; Coef<T> alpha;
+    __device__ __forceinline__ void apply(int64_t i, T &) const { T t = alpha.get() * x[i]; y[i] = y[i] + t; }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &) const
+    {
+        const T a = alpha.get();
+        auto xv = vload(x + i); auto yv = vload<T>(y + i);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) { T t = a * el<T>(xv, e); el<T>(yv, e) = el<T>(yv, e) + t; }
+        vstore(y + i, yv);
+    }
+};
+
+// y .-= x                        -- src/cg.jl:138, src/gmres.jl:246
+template <typename T> struct OpSub {
+    static constexpr bool REDUCE = false;
+    const T *__restrict__ x; T *__restrict__ y;
+    __device__ __forceinline__ void apply(int64_t i, T &) const { y[i] = y[i] - x[i]; }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &) const
+    {
+        auto xv = vload(x + i); auto yv = vload<T>(y + i);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) el<T>(yv, e) = el<T>(yv, e) - el<T>(xv, e);
+        vstore(y + i, yv);
+    }
+};
+
+// x .*= alpha                    -- src/orthogonalize.jl:76, src/gmres.jl:253
+template <typename T> struct OpScal {
+    static constexpr bool REDUCE = false;
+    T *__restrict__ x; Coef<T> alpha;
+    __device__ __forceinline__ void apply(int64_t i, T &) const { x[i] = x[i] * alpha.get(); }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &) const
+    {
+        const T a = alpha.get();
+        auto xv = vload<T>(x + i);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) el<T>(xv, e) = el<T>(xv, e) * a;
+        vstore(x + i, xv);
+    }
+};
+
+// y .= x ./ d                    -- ldiv!(y, P::JacobiPrec, x), test/cg.jl:18
+template <typename T> struct OpDivide {
+    static constexpr bool REDUCE = false;
+    const T *x; const T *d; T *y;   // y may alias x
+    __device__ __forceinline__ void apply(int64_t i, T &) const { y[i] = x[i] / d[i]; }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &) const
+    {
+        auto xv = vload(x + i); auto dv = vload(d + i); typename VT<T>::vec yv;
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) el<T>(yv, e) = el<T>(xv, e) / el<T>(dv, e);
+        vstore(y + i, yv);
+    }
+};
+
+// x .= value                     -- src/cg.jl:129 (u .= 0)
+template <typename T> struct OpFill {
+    static constexpr bool REDUCE = false;
+    T *__restrict__ x; T value;
+    __device__ __forceinline__ void apply(int64_t i, T &) const { x[i] = value; }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &) const
+    {
+        typename VT<T>::vec v;
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) el<T>(v, e) = value;
+        vstore(x + i, v);
+    }
+};
+
+// partial sums of x .* y         -- dot(x, y): src/cg.jl:55, src/orthogonalize.jl:71
+template <typename T> struct OpDot {
+    static constexpr bool REDUCE = true;
+    const T *__restrict__ x; const T *__restrict__ y;
+    __device__ __forceinline__ void apply(int64_t i, T &acc) const { T p = x[i] * y[i]; acc = acc + p; }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &acc) const
+    {
+        auto xv = vload(x + i); auto yv = vload(y + i);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) { T p = el<T>(xv, e) * el<T>(yv, e); acc = acc + p; }
+    }
+};
+
+// out .= a .- b (b may be null: out .= a); partial sums of out.^2
+//   -- r = b - A*x and norm(r): src/cg.jl:130,138,140; src/gmres.jl:241,246,252
+template <typename T> struct OpSubNrm {
+    static constexpr bool REDUCE = true;
+    const T *__restrict__ a; const T *__restrict__ b; T *__restrict__ out;
+    __device__ __forceinline__ void apply(int64_t i, T &acc) const
+    {
+        T v = b ? a[i] - b[i] : a[i];
+        out[i] = v;
+        T p = v * v; acc = acc + p;
+    }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &acc) const
+    {
+        auto av = vload(a + i);
+        if (b) {
+            auto bv = vload(b + i);
+#pragma unroll
+            for (int e = 0; e < VT<T>::W; ++e) el<T>(av, e) = el<T>(av, e) - el<T>(bv, e);
+        }
+        vstore(out + i, av);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) { T p = el<T>(av, e) * el<T>(av, e); acc = acc + p; }
+    }
+};
+
+// fused CG update: x .+= alpha .* u; r .-= alpha .* c; partial sums of r.^2
+//   -- src/cg.jl:58-59,62 (and :93-96)
+template <typename T> struct OpCgUpdate {
+    static constexpr bool REDUCE = true;
+    T *__restrict__ x; T *__restrict__ r; const T *__restrict__ u; const T *__restrict__ c; Coef<T> alpha;
+    __device__ __forceinline__ void apply(int64_t i, T &acc) const
+    {
+        const T a = alpha.get();
+        T t = a * u[i]; x[i] = x[i] + t;
+        T s = a * c[i]; T rn = r[i] - s; r[i] = rn;
+        T p = rn * rn; acc = acc + p;
+    }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &acc) const
+    {
+        const T a = alpha.get();
+        auto xv = vload<T>(x + i); auto uv = vload(u + i); auto rv = vload<T>(r + i); auto cv = vload(c + i);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) {
+            T t = a * el<T>(uv, e); el<T>(xv, e) = el<T>(xv, e) + t;
+            T s = a * el<T>(cv, e); el<T>(rv, e) = el<T>(rv, e) - s;
+        }
+        vstore(x + i, xv); vstore(r + i, rv);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) { T p = el<T>(rv, e) * el<T>(rv, e); acc = acc + p; }
+    }
+};
+
+// PCG preconditioner application: c .= r ./ d; partial sums of c .* r   -- src/cg.jl:79,82
+template <typename T> struct OpJacobiDot {
+    static constexpr bool REDUCE = true;
+    const T *__restrict__ r; const T *__restrict__ d; T *__restrict__ c;
+    __device__ __forceinline__ void apply(int64_t i, T &acc) const
+    {
+        T v = r[i] / d[i]; c[i] = v;
+        T p = v * r[i]; acc = acc + p;
+    }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &acc) const
+    {
+        auto rv = vload(r + i); auto dv = vload(d + i); typename VT<T>::vec cv;
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) el<T>(cv, e) = el<T>(rv, e) / el<T>(dv, e);
+        vstore(c + i, cv);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) { T p = el<T>(cv, e) * el<T>(rv, e); acc = acc + p; }
+    }
+};
+
+// Modified Gram-Schmidt pass: w .-= h .* v; partial sums of z .* w (z = next column, or w itself
+// for the closing norm)           -- src/orthogonalize.jl:71-72,75
+template <typename T, bool SELF> struct OpMgsPass {
+    static constexpr bool REDUCE = true;
+    T *__restrict__ w; const T *__restrict__ v; const T *__restrict__ z; Coef<T> h;
+    __device__ __forceinline__ void apply(int64_t i, T &acc) const
+    {
+        T t = h.get() * v[i]; T wn = w[i] - t; w[i] = wn;
+        T p = (SELF ? wn : z[i]) * wn; acc = acc + p;
+    }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &acc) const
+    {
+        const T hh = h.get();
+        auto wv = vload<T>(w + i); auto vv = vload(v + i);
+        typename VT<T>::vec zv;
+        if (!SELF) zv = vload(z + i);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) { T t = hh * el<T>(vv, e); el<T>(wv, e) = el<T>(wv, e) - t; }
+        vstore(w + i, wv);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) {
+            T p = (SELF ? el<T>(wv, e) : el<T>(zv, e)) * el<T>(wv, e);
+            acc = acc + p;
+        }
+    }
+};
+
+// =============================================================================================
+// level-2 finalise kernels (one 1024-thread workgroup per reduced column)
+// =============================================================================================
+
+// out[col] = sum of column col's segment sums
+template <typename T>
+__global__ __launch_bounds__(MIK_FIN_THREADS) void k_finalize_store(const T *__restrict__ S, int64_t m,
+                                                                     int64_t col_stride, T *__restrict__ out,
+                                                                     const int *__restrict__ done)
+{
+    if (done && *done) return;
+    __shared__ T lds16[16];
+    T tot = level2_sum(S + (int64_t)blockIdx.x * col_stride, m, lds16);
+    if (threadIdx.x == 0) out[blockIdx.x] = tot;
+}
+
+// nrm = sqrt(sum); out[0] = nrm; out[1] = 1 / nrm   -- norm(w); inv(nrm): src/orthogonalize.jl:75-76
+template <typename T>
+__global__ __launch_bounds__(MIK_FIN_THREADS) void k_finalize_nrm_inv(const T *__restrict__ S, int64_t m,
+                                                                       T *__restrict__ out)
+{
+    __shared__ T lds16[16];
+    T tot = level2_sum(S, m, lds16);
+    if (threadIdx.x == 0) {
+        T nrm = mik_sqrt(tot);
+        out[0] = nrm;
+        out[1] = T(1) / nrm;
+    }
+}
+
+// =============================================================================================
+// CSR SpMV: row-block workgroups, LDS-staged products, serial per-row sums
+// =============================================================================================
+//
+// A workgroup owns 256 consecutive rows (one per thread).  The rows' nonzeros form one contiguous
+// range of the CSR arrays; the workgroup streams it in tiles of MIK_SPMV_TILE entries with
+// fully coalesced loads of val[] (8 B/lane) and col[] (4 B/lane), gathers x[col] (L2 / Infinity
+// Cache hits for stencil matrices), and parks the products in LDS.  Each thread then adds up its
+// own row's products from LDS in ascending column order -- the same order in which the reference's
+// CSC column scatter reaches that row -- so y is bit-identical to the oracle.  For the 7-point
+// stencil the per-thread LDS stride is 7 doubles = 14 banks, conflict-free for ds_read_b64.
+//
+// FUSE_DOT adds CG's dot(u, c) (src/cg.jl:55) as an epilogue: p = x[row] * y[row] per thread,
+// block tree, one segment sum per row-block (W = L = 1 shape).
+//
+// Block -> row-block mapping is XCD-aware: the 8 XCDs (private 4 MiB L2 each) walk 8 disjoint
+// contiguous row ranges, so the x-window a stencil touches is shared inside one L2.
+
+template <typename T, bool FUSE_DOT>
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, const int *__restrict__ rowptr,
+                                                             const int *__restrict__ col, const T *__restrict__ val,
+                                                             const T *__restrict__ x, T *__restrict__ y,
+                                                             T *__restrict__ seg_out, const int *__restrict__ done)
+{
+    if (done && *done) return;
+    constexpr int TILE = MIK_SPMV_TILE;
+    constexpr int PER = TILE / MIK_BLOCK;
+    __shared__ T prod[TILE];
+    __shared__ T lds4[4];
+
+    const int t = threadIdx.x;
+    const int rb = xcd_remap(blockIdx.x, nb);
+    const int r0 = rb * MIK_BLOCK;
+    const int r = r0 + t;
+    const int rlast = min(r0 + MIK_BLOCK, n);
+    int ks = 0, ke = 0;
+    if (r < n) { ks = rowptr[r]; ke = rowptr[r + 1]; }
+    const int kb = rowptr[r0];
+    const int kend = rowptr[rlast];
+
+    T acc = T(0);
+    for (int kc = kb; kc < kend; kc += TILE) {
+        const int cnt = min(TILE, kend - kc);
+        // ---- stage: coalesced stream of val/col, gather of x, products into LDS ----
+        T v[PER];
+        int c[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int j = t + MIK_BLOCK * i;
+            if (j < cnt) { v[i] = val[kc + j]; c[i] = col[kc + j]; }
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int j = t + MIK_BLOCK * i;
+            if (j < cnt) prod[j] = v[i] * x[c[i]];
+        }
+        __syncthreads();
+        // ---- per-row serial sum, ascending column order ----
+        int a = max(ks, kc) - kc;
+        int len = min(ke, kc + cnt) - kc - a;
+        while (len > 0) {
+            T q[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[i] = prod[min(a + i, TILE - 1)];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < len) acc = acc + q[i];
+            a += 8;
+            len -= 8;
+        }
+        __syncthreads();
+    }
+    if (r < n) y[r] = acc;
+    if (FUSE_DOT) {
+        T p = T(0);
+        if (r < n) p = x[r] * acc;
+        T tot = block_tree_256(p, lds4);
+        if (t == 0) seg_out[rb] = tot;
+    }
+}
+
+// =============================================================================================
+// batched dot (gemv-T) and axpy sweep (gemv-N) over the Krylov basis
+// =============================================================================================
+
+// partial sums of V[:, j] .* w for j = 0..k-1, one segment per workgroup; w is read once.
+//   -- mul!(h, adjoint(V), w): src/orthogonalize.jl:15,27,43
+template <typename T, bool VEC>
+__global__ __launch_bounds__(MIK_BLOCK) void k_multidot(int64_t n, int64_t nseg, int k, const T *__restrict__ V,
+                                                        int64_t ldv, const T *__restrict__ w,
+                                                        T *__restrict__ seg_out /* [k][nseg] */)
+{
+    constexpr int W = VT<T>::W;
+    constexpr int L = MIK_RED_L;
+    constexpr int64_t SEG = (int64_t)MIK_BLOCK * W * L;
+    __shared__ T lds4[4];
+    for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+        const int64_t base = s * SEG + (int64_t)W * threadIdx.x;
+        T wr[L * W];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int64_t i = base + (int64_t)l * MIK_BLOCK * W;
+            if (VEC && i + W <= n) {
+                auto wv = vload(w + i);
+#pragma unroll
+                for (int e = 0; e < W; ++e) wr[l * W + e] = el<T>(wv, e);
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; ++e) wr[l * W + e] = (i + e < n) ? w[i + e] : T(0);
+            }
+        }
+        for (int j = 0; j < k; ++j) {
+            const T *__restrict__ col = V + (int64_t)j * ldv;
+            T acc = T(0);
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int64_t i = base + (int64_t)l * MIK_BLOCK * W;
+                if (VEC && i + W <= n) {
+                    auto cv = vload(col + i);
+#pragma unroll
+                    for (int e = 0; e < W; ++e) { T p = el<T>(cv, e) * wr[l * W + e]; acc = acc + p; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < W; ++e)
+                        if (i + e < n) { T p = col[i + e] * wr[l * W + e]; acc = acc + p; }
+                }
+            }
+            T tot = block_tree_256(acc, lds4);
+            if (threadIdx.x == 0) seg_out[(int64_t)j * nseg + s] = tot;
+        }
+    }
+}
+
+// y += sum_j (alpha * c[j]) * V[:, j], columns ascending (reference-BLAS dgemv 'N' order)
+//   -- mul!(y, V, c, alpha, 1): src/orthogonalize.jl:16,30,44; src/gmres.jl:275
+template <typename T, bool VEC>
+__global__ __launch_bounds__(MIK_BLOCK) void k_gemv_n(int64_t n, int64_t nseg, int k, const T *__restrict__ V,
+                                                      int64_t ldv, const T *__restrict__ cf, T alpha,
+                                                      T *__restrict__ y)
+{
+    constexpr int W = VT<T>::W;
+    constexpr int L = MIK_RED_L;
+    constexpr int64_t SEG = (int64_t)MIK_BLOCK * W * L;
+    for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+        const int64_t base = s * SEG + (int64_t)W * threadIdx.x;
+        T yr[L * W];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int64_t i = base + (int64_t)l * MIK_BLOCK * W;
+            if (VEC && i + W <= n) {
+                auto yv = vload<T>(y + i);
+#pragma unroll
+                for (int e = 0; e < W; ++e) yr[l * W + e] = el<T>(yv, e);
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; ++e) yr[l * W + e] = (i + e < n) ? y[i + e] : T(0);
+            }
+        }
+        for (int j = 0; j < k; ++j) {
+            const T *__restrict__ col = V + (int64_t)j * ldv;
+            const T temp = alpha * cf[j];
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int64_t i = base + (int64_t)l * MIK_BLOCK * W;
+                if (VEC && i + W <= n) {
+                    auto cv = vload(col + i);
+#pragma unroll
+                    for (int e = 0; e < W; ++e) { T p = temp * el<T>(cv, e); yr[l * W + e] = yr[l * W + e] + p; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < W; ++e)
+                        if (i + e < n) { T p = temp * col[i + e]; yr[l * W + e] = yr[l * W + e] + p; }
+                }
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int64_t i = base + (int64_t)l * MIK_BLOCK * W;
+            if (VEC && i + W <= n) {
+                typename VT<T>::vec yv;
+#pragma unroll
+                for (int e = 0; e < W; ++e) el<T>(yv, e) = yr[l * W + e];
+                vstore(y + i, yv);
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; ++e)
+                    if (i + e < n) y[i + e] = yr[l * W + e];
+            }
+        }
+    }
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,783 @@
+// mik_krylov.hip -- L2 Krylov helpers (orthogonalize_and_normalize!, gemv) and the L3 iterables
+// (CGIterable / PCGIterable, GMRESIterable) of include/mik.h.
+//
+// Host-side control flow restates the reference's iterate() methods (src/cg.jl:43-100,
+// src/gmres.jl:57-106); all vector arithmetic runs in the kernels of mik_kernels.h.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <new>
+
+#include "mik_kernels.h"
+
+template <typename T>
+int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done);
+
+
+#define MIK_TRY(expr)                 \
+    do {                              \
+        int rc_ = (expr);             \
+        if (rc_ != MIK_OK) return rc_; \
+    } while (0)
+
+// =============================================================================================
+// Hessenberg least squares (host) -- src/hessenberg.jl:15-46
+// =============================================================================================
+
+// LinearAlgebra.givensAlgorithm(f, g): LAPACK xLARTG-style plane rotation with power-of-two
+// rescaling; [c s; -s c] * [f; g] = [r; 0].
+template <typename T> static void givens_algorithm(T f, T g, T &cs, T &sn, T &r)
+{
+    const T eps = std::numeric_limits<T>::epsilon() / 2;
+    const T safmin = std::numeric_limits<T>::min();
+    const T safmn2 = std::pow(T(2), T((int)(std::log(safmin / eps) / std::log(T(2)) / T(2))));
+    const T safmx2 = T(1) / safmn2;
+    if (g == T(0)) { cs = T(1); sn = T(0); r = f; return; }
+    if (f == T(0)) { cs = T(0); sn = T(1); r = g; return; }
+    T f1 = f, g1 = g;
+    T scale = std::max(std::fabs(f1), std::fabs(g1));
+    int count = 0;
+    if (scale >= safmx2) {
+        do { ++count; f1 *= safmn2; g1 *= safmn2; scale = std::max(std::fabs(f1), std::fabs(g1)); } while (scale >= safmx2);
+        r = std::sqrt(f1 * f1 + g1 * g1); cs = f1 / r; sn = g1 / r;
+        for (int i = 0; i < count; ++i) r *= safmx2;
+    } else if (scale <= safmn2) {
+        do { ++count; f1 *= safmx2; g1 *= safmx2; scale = std::max(std::fabs(f1), std::fabs(g1)); } while (scale <= safmn2);
+        r = std::sqrt(f1 * f1 + g1 * g1); cs = f1 / r; sn = g1 / r;
+        for (int i = 0; i < count; ++i) r *= safmn2;
+    } else {
+        r = std::sqrt(f1 * f1 + g1 * g1); cs = f1 / r; sn = g1 / r;
+    }
+    if (std::fabs(f) > std::fabs(g) && cs < T(0)) { cs = -cs; sn = -sn; r = -r; }
+}
+
+template <typename T> static void hessenberg_ldiv(T *H, int64_t ldh, int width, T *rhs)
+{
+    auto at = [&](int i, int j) -> T & { return H[(size_t)j * ldh + i]; };
+    for (int i = 0; i < width; ++i) {
+        T c, s, rr;
+        givens_algorithm(at(i, i), at(i + 1, i), c, s, rr);
+        at(i, i) = c * at(i, i) + s * at(i + 1, i);
+        for (int j = i + 1; j < width; ++j) {
+            const T tmp = -s * at(i, j) + c * at(i + 1, j);
+            at(i, j) = c * at(i, j) + s * at(i + 1, j);
+            at(i + 1, j) = tmp;
+        }
+        const T tmp = -s * rhs[i] + c * rhs[i + 1];
+        rhs[i] = c * rhs[i] + s * rhs[i + 1];
+        rhs[i + 1] = tmp;
+    }
+    // UpperTriangular back substitution, column sweep from the last column
+    for (int j = width - 1; j >= 0; --j) {
+        rhs[j] = rhs[j] / at(j, j);
+        const T t = rhs[j];
+        for (int i = 0; i < j; ++i) rhs[i] = rhs[i] - t * at(i, j);
+    }
+}
+
+extern "C" int mik_hessenberg_ldiv(int dtype, void *H, int64_t ldh, int width, void *rhs)
+{
+    if (!H || !rhs || width < 0 || ldh < width + 1) return MIK_ERR_INVALID;
+    if (dtype == MIK_F64) hessenberg_ldiv<double>((double *)H, ldh, width, (double *)rhs);
+    else if (dtype == MIK_F32) hessenberg_ldiv<float>((float *)H, ldh, width, (float *)rhs);
+    else return MIK_ERR_INVALID;
+    return MIK_OK;
+}
+
+// =============================================================================================
+// gemv-N and orthogonalisation
+// =============================================================================================
+template <typename T>
+static int gemv_n_dev(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, const T *cf_dev, T alpha, T *y)
+{
+    const int64_t nseg = mik_nseg<T>(n);
+    if (nseg == 0 || k == 0) return MIK_OK;
+    const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
+    const bool vec = mik_aligned16(V) && mik_aligned16(y) && (ldv % VT<T>::W == 0);
+    if (vec) hipLaunchKernelGGL((k_gemv_n<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, cf_dev, alpha, y);
+    else hipLaunchKernelGGL((k_gemv_n<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, cf_dev, alpha, y);
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+
+// Copy k host scalars into the coefficient area of the context (device), at element `slot`.
+template <typename T> static int coef_upload(mik_ctx *ctx, int slot, const T *host, int k)
+{
+    if ((size_t)(slot + k) * sizeof(T) > mik_ctx::COEF_BYTES) return mik_fail(ctx, MIK_ERR_NOTIMPL, "coefficient block too large (k = %d)", k);
+    MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // staging buffer must be idle
+    memcpy((T *)ctx->coef_host + slot, host, sizeof(T) * k);
+    MIK_HIP(ctx, hipMemcpyAsync((T *)ctx->coef + slot, (T *)ctx->coef_host + slot, sizeof(T) * k, hipMemcpyHostToDevice, ctx->stream));
+    return MIK_OK;
+}
+
+template <typename T> static int coef_download(mik_ctx *ctx, int slot, T *host, int k)
+{
+    MIK_HIP(ctx, hipMemcpyAsync((T *)ctx->coef_host + slot, (T *)ctx->coef + slot, sizeof(T) * k, hipMemcpyDeviceToHost, ctx->stream));
+    MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(host, (T *)ctx->coef_host + slot, sizeof(T) * k);
+    return MIK_OK;
+}
+
+template <typename T>
+static int gemv_n_impl(mik_ctx *ctx, int64_t n, int k, const void *V, int64_t ldv, const void *c, const void *alpha, void *y)
+{
+    if (k == 0 || n == 0) return MIK_OK;
+    MIK_TRY(coef_upload<T>(ctx, 0, (const T *)c, k));
+    return gemv_n_dev<T>(ctx, n, k, (const T *)V, ldv, (const T *)ctx->coef, *(const T *)alpha, (T *)y);
+}
+
+extern "C" int mik_gemv_n(mik_ctx *ctx, int dtype, int64_t n, int k, const void *V, int64_t ldv, const void *c,
+                          const void *alpha, void *y)
+{
+    if (!ctx || n < 0 || k < 0 || !alpha || (k && !c) || (n && k && (!V || !y)) || ldv < n) return MIK_ERR_INVALID;
+    if (dtype == MIK_F64) return gemv_n_impl<double>(ctx, n, k, V, ldv, c, alpha, y);
+    if (dtype == MIK_F32) return gemv_n_impl<float>(ctx, n, k, V, ldv, c, alpha, y);
+    return MIK_ERR_INVALID;
+}
+
+template <typename T> static int finalize_store(mik_ctx *ctx, int64_t nseg, int cols, T *out_dev)
+{
+    hipLaunchKernelGGL((k_finalize_store<T>), dim3(cols), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg,
+                       nseg, out_dev, (const int *)nullptr);
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+
+template <typename T> static int finalize_nrm_inv(mik_ctx *ctx, int64_t nseg, T *out_dev)
+{
+    hipLaunchKernelGGL((k_finalize_nrm_inv<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, out_dev);
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+
+template <typename T>
+static int multidot(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, const T *w, T *out_dev)
+{
+    const int64_t nseg = mik_nseg<T>(n);
+    if (nseg == 0) {   // empty vectors: every dot is +0
+        MIK_HIP(ctx, hipMemsetAsync(out_dev, 0, sizeof(T) * k, ctx->stream));
+        return MIK_OK;
+    }
+    const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
+    const bool vec = mik_aligned16(V) && mik_aligned16(w) && (ldv % VT<T>::W == 0);
+    if (vec) hipLaunchKernelGGL((k_multidot<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, w, (T *)ctx->partials);
+    else hipLaunchKernelGGL((k_multidot<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, w, (T *)ctx->partials);
+    MIK_LAUNCH_CHECK(ctx);
+    return finalize_store<T>(ctx, nseg, k, out_dev);
+}
+
+// orthogonalize_and_normalize!(V[:, 1:k], w, h, method) -> nrm   -- src/orthogonalize.jl:13-79
+// Coefficient area layout (elements of T): [0, k) = h, [k] = nrm, [k+1] = 1/nrm, [k+2, 2k+2) = DGKS correction.
+template <typename T>
+static int orthogonalize_impl(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, T *w, T *h_host, T *nrm_host, int method)
+{
+    if ((size_t)(2 * k + 4) * sizeof(T) > mik_ctx::COEF_BYTES) return mik_fail(ctx, MIK_ERR_NOTIMPL, "orthogonalize: k = %d too large", k);
+    const int64_t nseg = mik_nseg<T>(n);
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(nseg, 1) * (size_t)std::max(k, 1)));
+    T *hd = (T *)ctx->coef;
+    T *part = (T *)ctx->partials;
+    const bool vecw = mik_aligned16(w);
+    const bool vec = vecw && mik_aligned16(V) && (ldv % VT<T>::W == 0);
+
+    if (method == MIK_MGS) {
+        // src/orthogonalize.jl:69-76.  Pass i subtracts h[i] * V[:, i] from w and, in the same sweep,
+        // accumulates the next projection dot(V[:, i+1], w) -- or norm(w)^2 on the last pass.
+        if (k > 0) {
+            OpDot<T> d0{V, w};
+            MIK_TRY((launch_map<T>(ctx, n, d0, vec, part, nullptr)));
+            MIK_TRY(finalize_store<T>(ctx, nseg, 1, hd));
+            for (int i = 0; i + 1 < k; ++i) {
+                OpMgsPass<T, false> op{w, V + (int64_t)i * ldv, V + (int64_t)(i + 1) * ldv, coef_ptr<T>(hd + i)};
+                MIK_TRY((launch_map<T>(ctx, n, op, vec, part, nullptr)));
+                MIK_TRY(finalize_store<T>(ctx, nseg, 1, hd + i + 1));
+            }
+            OpMgsPass<T, true> last{w, V + (int64_t)(k - 1) * ldv, nullptr, coef_ptr<T>(hd + k - 1)};
+            MIK_TRY((launch_map<T>(ctx, n, last, vec, part, nullptr)));
+        } else {
+            OpDot<T> dn{w, w};
+            MIK_TRY((launch_map<T>(ctx, n, dn, vecw, part, nullptr)));
+        }
+        MIK_TRY(finalize_nrm_inv<T>(ctx, nseg, hd + k));
+    } else {
+        // src/orthogonalize.jl:15-17 / :43-45: h = V' w (batched dot), w -= V h (axpy sweep), norm
+        MIK_TRY(multidot<T>(ctx, n, k, V, ldv, w, hd));
+        MIK_TRY(gemv_n_dev<T>(ctx, n, k, V, ldv, hd, T(-1), w));
+        OpDot<T> dn{w, w};
+        MIK_TRY((launch_map<T>(ctx, n, dn, vecw, part, nullptr)));
+        MIK_TRY(finalize_nrm_inv<T>(ctx, nseg, hd + k));
+        if (method == MIK_DGKS) {
+            std::vector<T> hh(k + 2), corr(std::max(k, 1));
+            MIK_TRY(coef_download<T>(ctx, 0, hh.data(), k + 2));
+            T nrm = hh[k];
+            const T eta = T(1) / std::sqrt(T(2));                       // :20
+            auto small_norm = [](const T *v, int len) { T s = T(0); for (int j = 0; j < len; ++j) { T p = v[j] * v[j]; s = s + p; } return (T)std::sqrt(s); };
+            T projection_size = small_norm(hh.data(), k);              // :22
+            while (nrm < eta * projection_size) {                        // :26
+                T *cd = hd + k + 2;
+                MIK_TRY(multidot<T>(ctx, n, k, V, ldv, w, cd));          // :27
+                MIK_TRY(gemv_n_dev<T>(ctx, n, k, V, ldv, cd, T(-1), w)); // :30
+                MIK_TRY((launch_map<T>(ctx, n, dn, vecw, part, nullptr)));
+                MIK_TRY(finalize_nrm_inv<T>(ctx, nseg, hd + k));        // :32
+                MIK_TRY(coef_download<T>(ctx, k + 2, corr.data(), k));
+                T nn[2];
+                MIK_TRY(coef_download<T>(ctx, k, nn, 2));
+                projection_size = small_norm(corr.data(), k);           // :28
+                for (int j = 0; j < k; ++j) hh[j] = hh[j] + corr[j];    // :31
+                nrm = nn[0];
+            }
+            OpScal<T> sc{w, coef_ptr<T>(hd + k + 1)};                   // :36
+            MIK_TRY((launch_map<T>(ctx, n, sc, vecw, (T *)nullptr, nullptr)));
+            for (int j = 0; j < k; ++j) h_host[j] = hh[j];
+            *nrm_host = nrm;
+            return MIK_OK;
+        }
+    }
+    OpScal<T> sc{w, coef_ptr<T>(hd + k + 1)};                           // w .*= inv(nrm)  :76 / :48
+    MIK_TRY((launch_map<T>(ctx, n, sc, vecw, (T *)nullptr, nullptr)));
+    std::vector<T> out(k + 1);
+    MIK_TRY(coef_download<T>(ctx, 0, out.data(), k + 1));
+    for (int j = 0; j < k; ++j) h_host[j] = out[j];
+    *nrm_host = out[k];
+    return MIK_OK;
+}
+
+extern "C" int mik_orthogonalize(mik_ctx *ctx, int dtype, int64_t n, int k, const void *V, int64_t ldv, void *w, void *h,
+                                 void *nrm, int method)
+{
+    if (!ctx || n < 0 || k < 0 || !nrm || (k && (!h || !V)) || (n && !w) || (k && ldv < n)) return MIK_ERR_INVALID;
+    if (method != MIK_MGS && method != MIK_CGS && method != MIK_DGKS) return MIK_ERR_INVALID;
+    if (dtype == MIK_F64) return orthogonalize_impl<double>(ctx, n, k, (const double *)V, ldv, (double *)w, (double *)h, (double *)nrm, method);
+    if (dtype == MIK_F32) return orthogonalize_impl<float>(ctx, n, k, (const float *)V, ldv, (float *)w, (float *)h, (float *)nrm, method);
+    return MIK_ERR_INVALID;
+}
+
+// =============================================================================================
+// CGIterable / PCGIterable
+// =============================================================================================
+template <typename T> struct CgDev {
+    T res, prev_res, alpha, beta, dot_uc, rr, tol, rho;
+    int done, nhist;
+};
+
+// after norm(r) of cg_iterator! (src/cg.jl:140-152)
+template <typename T>
+__global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_init(const T *__restrict__ S, int64_t m, CgDev<T> *d, T reltol, T abstol,
+                                                                 long long maxiter)
+{
+    __shared__ T lds16[16];
+    T tot = level2_sum(S, m, lds16);
+    if (threadIdx.x == 0) {
+        const T res = mik_sqrt(tot);
+        const T a = reltol * res;
+        d->rr = tot;
+        d->res = res;
+        d->prev_res = T(1);                       // one(residual)      :146
+        d->rho = T(1);                            // one(eltype(x))     :151
+        d->tol = a > abstol ? a : abstol;         // :141
+        d->beta = (res * res) / (T(1) * T(1));    // what the first iterate() will use (:50)
+        d->alpha = T(0);
+        d->dot_uc = T(0);
+        d->done = (0 >= maxiter || res <= d->tol) ? 1 : 0;
+        d->nhist = 0;
+    }
+}
+
+// alpha = residual^2 / dot(u, c) (src/cg.jl:55) or rho / dot(u, c) (:90)
+template <typename T>
+__global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_alpha(const T *__restrict__ S, int64_t m, CgDev<T> *d, int pcg)
+{
+    if (d->done) return;
+    __shared__ T lds16[16];
+    T tot = level2_sum(S, m, lds16);
+    if (threadIdx.x == 0) {
+        d->dot_uc = tot;
+        const T num = pcg ? d->rho : d->res * d->res;
+        d->alpha = num / tot;
+    }
+}
+
+// rho = dot(c, r); beta = rho / rho_prev (src/cg.jl:81-85)
+template <typename T>
+__global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_rho(const T *__restrict__ S, int64_t m, CgDev<T> *d)
+{
+    if (d->done) return;
+    __shared__ T lds16[16];
+    T tot = level2_sum(S, m, lds16);
+    if (threadIdx.x == 0) {
+        const T rho_prev = d->rho;
+        d->rho = tot;
+        d->beta = tot / rho_prev;
+    }
+}
+
+// residual = norm(r) (src/cg.jl:61-62 / :96), history, and the stopping test of :36 for the NEXT
+// iterate() call (iteration index `it_next`)
+template <typename T>
+__global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_res(const T *__restrict__ S, int64_t m, CgDev<T> *d, T *__restrict__ hist,
+                                                                long long it_next, long long maxiter)
+{
+    if (d->done) return;
+    __shared__ T lds16[16];
+    T tot = level2_sum(S, m, lds16);
+    if (threadIdx.x == 0) {
+        const T prev = d->res;
+        const T res = mik_sqrt(tot);
+        d->rr = tot;
+        d->prev_res = prev;
+        d->res = res;
+        d->beta = (res * res) / (prev * prev);    // :50 of the next step
+        hist[d->nhist] = res;
+        d->nhist = d->nhist + 1;
+        if (it_next >= maxiter || res <= d->tol) d->done = 1;
+    }
+}
+
+struct mik_cg {
+    mik_ctx *ctx = nullptr;
+    const mik_csr *A = nullptr;
+    int dtype = MIK_F64;
+    int64_t n = 0;
+    void *x = nullptr, *u = nullptr, *r = nullptr, *c = nullptr;
+    const void *b = nullptr, *diag = nullptr;
+    void *dev = nullptr;       // CgDev<T>
+    void *hist = nullptr;      // device history of one iterate_many call
+    int64_t hist_cap = 0;
+    void *seg_spmv = nullptr;  // one partial per row-block
+    void *seg_vec = nullptr;   // one partial per vector segment
+    double residual = 0, prev_residual = 1, tol = 0;
+    int64_t maxiter = 0, mv_products = 0;
+    // optional in-loop timing of the SpMV launch (HIP events on the ctx stream)
+    bool profile = false;
+    std::vector<hipEvent_t> ev;    // pairs (start, stop), recycled
+    size_t ev_used = 0;
+    double spmv_ms = 0;
+    int64_t spmv_launches = 0;
+};
+
+static int cg_profile_collect(mik_cg *it)
+{
+    // stream must be idle (called after a synchronising read-back)
+    for (size_t i = 0; i + 1 < it->ev_used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, it->ev[i], it->ev[i + 1]) == hipSuccess) { it->spmv_ms += ms; it->spmv_launches += 1; }
+    }
+    it->ev_used = 0;
+    return MIK_OK;
+}
+
+static hipEvent_t cg_profile_event(mik_cg *it)
+{
+    if (it->ev_used == it->ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; it->ev.push_back(e); }
+    return it->ev[it->ev_used++];
+}
+
+template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next)
+{
+    mik_ctx *ctx = it->ctx;
+    CgDev<T> *d = (CgDev<T> *)it->dev;
+    const int *done = &d->done;
+    const int64_t n = it->n;
+    const int64_t nseg = mik_nseg<T>(n);
+    const int64_t nb = (n + MIK_BLOCK - 1) / MIK_BLOCK;
+    T *x = (T *)it->x, *u = (T *)it->u, *r = (T *)it->r, *c = (T *)it->c;
+    const bool vec = mik_aligned16(x) && mik_aligned16(u) && mik_aligned16(r) && mik_aligned16(c) && (!it->diag || mik_aligned16(it->diag));
+    const int pcg = it->diag ? 1 : 0;
+    if (pcg) {
+        // c = Pl \ r; rho = dot(c, r)                                   src/cg.jl:79-82
+        OpJacobiDot<T> pj{r, (const T *)it->diag, c};
+        MIK_TRY((launch_map<T>(ctx, n, pj, vec, (T *)it->seg_vec, done)));
+        hipLaunchKernelGGL((k_cg_fin_rho<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)it->seg_vec, nseg, d);
+        MIK_LAUNCH_CHECK(ctx);
+        // u .= c .+ beta .* u                                           src/cg.jl:86
+        OpXpby<T> op{c, u, coef_ptr<T>(&d->beta)};
+        MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
+    } else {
+        // u .= r .+ beta .* u                                           src/cg.jl:50-51
+        OpXpby<T> op{r, u, coef_ptr<T>(&d->beta)};
+        MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
+    }
+    // c = A * u with the dot(u, c) epilogue                             src/cg.jl:54-55
+    if (it->profile) { hipEvent_t e = cg_profile_event(it); if (e) (void)hipEventRecord(e, ctx->stream); }
+    MIK_TRY(mik_spmv_launch<T>(ctx, it->A, u, c, true, (T *)it->seg_spmv, done));
+    if (it->profile) { hipEvent_t e = cg_profile_event(it); if (e) (void)hipEventRecord(e, ctx->stream); }
+    hipLaunchKernelGGL((k_cg_fin_alpha<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)it->seg_spmv, nb, d, pcg);
+    MIK_LAUNCH_CHECK(ctx);
+    // x .+= alpha .* u; r .-= alpha .* c; norm(r)                       src/cg.jl:58-62
+    OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha)};
+    MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done)));
+    hipLaunchKernelGGL((k_cg_fin_res<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)it->seg_vec, nseg, d, (T *)it->hist,
+                       it_next, (long long)it->maxiter);
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+
+template <typename T> static int cg_fetch_state(mik_cg *it, CgDev<T> *host)
+{
+    mik_ctx *ctx = it->ctx;
+    MIK_HIP(ctx, hipMemcpyAsync(ctx->coef_host, it->dev, sizeof(CgDev<T>), hipMemcpyDeviceToHost, ctx->stream));
+    MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(host, ctx->coef_host, sizeof(CgDev<T>));
+    return MIK_OK;
+}
+
+template <typename T>
+static int cg_init_impl(mik_cg *it, double abstol, double reltol, int initially_zero)
+{
+    mik_ctx *ctx = it->ctx;
+    const int64_t n = it->n;
+    const int64_t nseg = mik_nseg<T>(n);
+    T *x = (T *)it->x, *u = (T *)it->u, *r = (T *)it->r, *c = (T *)it->c;
+    const T *b = (const T *)it->b;
+    OpFill<T> z{u, T(0)};                                                 // u .= 0          :129
+    MIK_TRY((launch_map<T>(ctx, n, z, mik_aligned16(u), (T *)nullptr, nullptr)));
+    const bool vec = mik_aligned16(r) && mik_aligned16(b) && mik_aligned16(c);
+    if (initially_zero) {
+        it->mv_products = 0;                                              // :134
+        OpSubNrm<T> op{b, nullptr, r};                                    // copyto!(r, b)   :130
+        MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)it->seg_vec, nullptr)));
+    } else {
+        it->mv_products = 1;                                              // :136
+        MIK_TRY(mik_spmv_launch<T>(ctx, it->A, x, c, false, nullptr, nullptr));   // :137
+        OpSubNrm<T> op{b, c, r};                                          // r = b - c       :130,138
+        MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)it->seg_vec, nullptr)));
+    }
+    hipLaunchKernelGGL((k_cg_fin_init<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)it->seg_vec, nseg,
+                       (CgDev<T> *)it->dev, (T)reltol, (T)abstol, (long long)it->maxiter);
+    MIK_LAUNCH_CHECK(ctx);
+    CgDev<T> h;
+    MIK_TRY(cg_fetch_state<T>(it, &h));
+    it->residual = (double)h.res;
+    it->prev_residual = (double)h.prev_res;
+    it->tol = (double)h.tol;
+    return MIK_OK;
+}
+
+extern "C" int mik_cg_create(mik_ctx *ctx, const mik_csr *A, void *x, const void *b, void *u, void *r, void *c,
+                             const void *jacobi_diag, double abstol, double reltol, int64_t maxiter, int initially_zero,
+                             mik_cg **out)
+{
+    if (!ctx || !out) return MIK_ERR_INVALID;
+    *out = nullptr;
+    if (!A || A->n_rows != A->n_cols) return mik_fail(ctx, MIK_ERR_MISMATCH, "mik_cg_create: A must be square");
+    const int64_t n = A->n_rows;
+    if (n && (!x || !b || !u || !r || !c)) return mik_fail(ctx, MIK_ERR_INVALID, "mik_cg_create: NULL vector");
+    mik_cg *it = new (std::nothrow) mik_cg();
+    if (!it) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_cg_create: host allocation failed");
+    it->ctx = ctx; it->A = A; it->dtype = A->dtype; it->n = n;
+    it->x = x; it->b = b; it->u = u; it->r = r; it->c = c; it->diag = jacobi_diag;
+    it->maxiter = maxiter;
+    const size_t es = mik_dtype_size(A->dtype);
+    const int64_t nseg = A->dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
+    const int64_t nb = (n + MIK_BLOCK - 1) / MIK_BLOCK;
+    hipError_t e;
+    (void)hipSetDevice(ctx->device);
+    if ((e = hipMalloc(&it->dev, 256)) != hipSuccess || (e = hipMalloc(&it->seg_spmv, es * (size_t)std::max<int64_t>(nb, 1))) != hipSuccess ||
+        (e = hipMalloc(&it->seg_vec, es * (size_t)std::max<int64_t>(nseg, 1))) != hipSuccess ||
+        (e = hipMalloc(&it->hist, es * 64)) != hipSuccess) {
+        mik_cg_destroy(it);
+        return mik_fail(ctx, MIK_ERR_NOMEM, "mik_cg_create: hipMalloc: %s", hipGetErrorString(e));
+    }
+    it->hist_cap = 64;
+    int rc = A->dtype == MIK_F64 ? cg_init_impl<double>(it, abstol, reltol, initially_zero)
+                                 : cg_init_impl<float>(it, abstol, reltol, initially_zero);
+    if (rc) { mik_cg_destroy(it); return rc; }
+    *out = it;
+    return MIK_OK;
+}
+
+extern "C" int mik_cg_destroy(mik_cg *it)
+{
+    if (!it) return MIK_OK;
+    if (it->ctx) (void)hipStreamSynchronize(it->ctx->stream);
+    if (it->dev) (void)hipFree(it->dev);
+    if (it->hist) (void)hipFree(it->hist);
+    if (it->seg_spmv) (void)hipFree(it->seg_spmv);
+    if (it->seg_vec) (void)hipFree(it->seg_vec);
+    for (hipEvent_t e : it->ev) (void)hipEventDestroy(e);
+    delete it;
+    return MIK_OK;
+}
+
+template <typename T>
+static int cg_iterate_many_impl(mik_cg *it, int64_t iteration, int64_t max_steps, double *residuals, int64_t *steps_done)
+{
+    mik_ctx *ctx = it->ctx;
+    *steps_done = 0;
+    // done(it, iteration)                                               src/cg.jl:36
+    if (max_steps <= 0 || iteration >= it->maxiter || it->residual <= it->tol) return MIK_OK;
+    max_steps = std::min(max_steps, it->maxiter - iteration);
+    if (max_steps > it->hist_cap) {
+        MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MIK_HIP(ctx, hipFree(it->hist));
+        it->hist = nullptr;
+        MIK_HIP(ctx, hipMalloc(&it->hist, sizeof(T) * (size_t)max_steps));
+        it->hist_cap = max_steps;
+    }
+    CgDev<T> *d = (CgDev<T> *)it->dev;
+    MIK_HIP(ctx, hipMemsetAsync(&d->done, 0, 2 * sizeof(int), ctx->stream));   // done = 0, nhist = 0
+    for (int64_t j = 0; j < max_steps; ++j) MIK_TRY(cg_enqueue_step<T>(it, (long long)(iteration + j + 1)));
+    CgDev<T> h;
+    MIK_TRY(cg_fetch_state<T>(it, &h));
+    const int64_t nd = h.nhist;
+    if (nd > 0) {
+        std::vector<T> tmp((size_t)nd);
+        MIK_HIP(ctx, hipMemcpy(tmp.data(), it->hist, sizeof(T) * (size_t)nd, hipMemcpyDeviceToHost));
+        if (residuals) for (int64_t j = 0; j < nd; ++j) residuals[j] = (double)tmp[j];
+    }
+    it->residual = (double)h.res;
+    it->prev_residual = (double)h.prev_res;
+    it->mv_products += nd;
+    *steps_done = nd;
+    if (it->profile) cg_profile_collect(it);
+    return MIK_OK;
+}
+
+extern "C" int mik_cg_iterate_many(mik_cg *it, int64_t iteration, int64_t max_steps, double *residuals, int64_t *steps_done)
+{
+    if (!it || !steps_done || iteration < 0) return MIK_ERR_INVALID;
+    return it->dtype == MIK_F64 ? cg_iterate_many_impl<double>(it, iteration, max_steps, residuals, steps_done)
+                                : cg_iterate_many_impl<float>(it, iteration, max_steps, residuals, steps_done);
+}
+
+extern "C" int mik_cg_iterate(mik_cg *it, int64_t iteration, double *residual, int *done)
+{
+    if (!it || !done) return MIK_ERR_INVALID;
+    int64_t nd = 0;
+    double res = 0;
+    int rc = mik_cg_iterate_many(it, iteration, 1, &res, &nd);
+    if (rc) return rc;
+    *done = nd == 0 ? 1 : 0;
+    if (residual) *residual = it->residual;
+    return MIK_OK;
+}
+
+extern "C" int mik_cg_profile(mik_cg *it, int enable, double *spmv_ms_total, int64_t *spmv_launches)
+{
+    if (!it) return MIK_ERR_INVALID;
+    if (spmv_ms_total) *spmv_ms_total = it->spmv_ms;
+    if (spmv_launches) *spmv_launches = it->spmv_launches;
+    if (enable >= 0) {
+        it->profile = enable != 0;
+        if (enable) { it->spmv_ms = 0; it->spmv_launches = 0; it->ev_used = 0; }
+    }
+    return MIK_OK;
+}
+
+extern "C" int mik_cg_state(const mik_cg *it, double *residual, double *prev_residual, double *tol, int64_t *maxiter,
+                            int64_t *mv_products, int *converged)
+{
+    if (!it) return MIK_ERR_INVALID;
+    if (residual) *residual = it->residual;
+    if (prev_residual) *prev_residual = it->prev_residual;
+    if (tol) *tol = it->tol;
+    if (maxiter) *maxiter = it->maxiter;
+    if (mv_products) *mv_products = it->mv_products;
+    if (converged) *converged = it->residual <= it->tol ? 1 : 0;   // src/cg.jl:32
+    return MIK_OK;
+}
+
+// =============================================================================================
+// GMRESIterable
+// =============================================================================================
+struct mik_gmres {
+    mik_ctx *ctx = nullptr;
+    const mik_csr *A = nullptr;
+    int dtype = MIK_F64;
+    int64_t n = 0, ldv = 0;
+    void *x = nullptr;
+    const void *b = nullptr;
+    void *V = nullptr;        // device n x (restart + 1), column-major   src/gmres.jl:13
+    void *Ax = nullptr;       // device work vector                        src/gmres.jl:125
+    std::vector<double> H64; std::vector<float> H32;             // (restart+1) x restart   :14
+    std::vector<double> nv64; std::vector<float> nv32;           // Residual.nullvec        :27
+    double current = 1, accumulator = 1, res_beta = 1;           // Residual                :24-29
+    double g_beta = 1, tol = 0;
+    int k = 1, restart = 0, method = MIK_MGS;
+    int64_t maxiter = 0, mv_products = 0;
+};
+
+template <typename T> static std::vector<T> &gm_H(mik_gmres *g);
+template <> std::vector<double> &gm_H<double>(mik_gmres *g) { return g->H64; }
+template <> std::vector<float> &gm_H<float>(mik_gmres *g) { return g->H32; }
+template <typename T> static std::vector<T> &gm_nv(mik_gmres *g);
+template <> std::vector<double> &gm_nv<double>(mik_gmres *g) { return g->nv64; }
+template <> std::vector<float> &gm_nv<float>(mik_gmres *g) { return g->nv32; }
+
+// init!(arnoldi, x, b, Pl = Identity, Ax; initially_zero) -> beta      src/gmres.jl:235-255
+template <typename T> static int gmres_init_residual(mik_gmres *g, int initially_zero, T *beta_out)
+{
+    mik_ctx *ctx = g->ctx;
+    const int64_t n = g->n;
+    const int64_t nseg = mik_nseg<T>(n);
+    T *V0 = (T *)g->V;
+    const T *b = (const T *)g->b;
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(nseg, 1) * (size_t)(g->restart + 1)));
+    const bool vec = mik_aligned16(b) && mik_aligned16(V0) && mik_aligned16(g->Ax);
+    if (initially_zero) {
+        OpSubNrm<T> op{b, nullptr, V0};                                   // :241
+        MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)ctx->partials, nullptr)));
+    } else {
+        MIK_TRY(mik_spmv_launch<T>(ctx, g->A, (const T *)g->x, (T *)g->Ax, false, nullptr, nullptr));   // :245
+        OpSubNrm<T> op{b, (const T *)g->Ax, V0};                          // :241,246
+        MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)ctx->partials, nullptr)));
+    }
+    T *hd = (T *)ctx->coef;
+    MIK_TRY(finalize_nrm_inv<T>(ctx, nseg, hd));                          // :252
+    OpScal<T> sc{V0, coef_ptr<T>(hd + 1)};                                // :253
+    MIK_TRY((launch_map<T>(ctx, n, sc, mik_aligned16(V0), (T *)nullptr, nullptr)));
+    T out[2];
+    MIK_TRY(coef_download<T>(ctx, 0, out, 2));
+    *beta_out = out[0];
+    return MIK_OK;
+}
+
+template <typename T> static int gmres_create_impl(mik_gmres *g, double abstol, double reltol, int initially_zero)
+{
+    const int m = g->restart;
+    gm_H<T>(g).assign((size_t)(m + 1) * (size_t)std::max(m, 1), T(0));   // :14
+    gm_nv<T>(g).assign((size_t)m + 1, T(1));                             // :27
+    g->mv_products = initially_zero ? 1 : 0;                             // :122 (sic)
+    T beta;
+    MIK_TRY(gmres_init_residual<T>(g, initially_zero, &beta));           // :126
+    g->current = (double)beta;
+    g->accumulator = 1.0;                                                // :258
+    g->res_beta = (double)beta;                                          // :259
+    const T a = (T)reltol * beta;
+    const T tol = a > (T)abstol ? a : (T)abstol;                         // :129
+    g->tol = (double)tol;
+    g->g_beta = (double)beta;                                            // :133
+    g->k = 1;
+    return MIK_OK;
+}
+
+extern "C" int mik_gmres_create(mik_ctx *ctx, const mik_csr *A, void *x, const void *b, double abstol, double reltol,
+                                int restart, int64_t maxiter, int initially_zero, int orth_method, mik_gmres **out)
+{
+    if (!ctx || !out) return MIK_ERR_INVALID;
+    *out = nullptr;
+    if (!A || A->n_rows != A->n_cols) return mik_fail(ctx, MIK_ERR_MISMATCH, "mik_gmres_create: A must be square");
+    if (restart < 1) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create: restart must be >= 1");
+    if (orth_method != MIK_MGS && orth_method != MIK_CGS && orth_method != MIK_DGKS) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create: bad orth_method");
+    const int64_t n = A->n_rows;
+    if (n && (!x || !b)) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create: NULL vector");
+    if ((size_t)(2 * restart + 6) * 8 > mik_ctx::COEF_BYTES) return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_gmres_create: restart %d too large", restart);
+    mik_gmres *g = new (std::nothrow) mik_gmres();
+    if (!g) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_gmres_create: host allocation failed");
+    g->ctx = ctx; g->A = A; g->dtype = A->dtype; g->n = n; g->x = x; g->b = b;
+    g->restart = restart; g->maxiter = maxiter; g->method = orth_method;
+    g->ldv = (n + 63) / 64 * 64;
+    if (g->ldv == 0) g->ldv = 64;
+    const size_t es = mik_dtype_size(A->dtype);
+    hipError_t e;
+    (void)hipSetDevice(ctx->device);
+    if ((e = hipMalloc(&g->V, es * (size_t)g->ldv * (size_t)(restart + 1))) != hipSuccess ||
+        (e = hipMalloc(&g->Ax, es * (size_t)g->ldv)) != hipSuccess) {
+        mik_gmres_destroy(g);
+        return mik_fail(ctx, MIK_ERR_NOMEM, "mik_gmres_create: hipMalloc of the Krylov basis (%lld x %d): %s", (long long)n, restart + 1, hipGetErrorString(e));
+    }
+    if ((e = hipMemsetAsync(g->V, 0, es * (size_t)g->ldv * (size_t)(restart + 1), ctx->stream)) != hipSuccess) {   // zeros(T, n, m+1) :13
+        mik_gmres_destroy(g);
+        return mik_fail(ctx, MIK_ERR_HIP, "mik_gmres_create: memset: %s", hipGetErrorString(e));
+    }
+    int rc = A->dtype == MIK_F64 ? gmres_create_impl<double>(g, abstol, reltol, initially_zero)
+                                 : gmres_create_impl<float>(g, abstol, reltol, initially_zero);
+    if (rc) { mik_gmres_destroy(g); return rc; }
+    *out = g;
+    return MIK_OK;
+}
+
+extern "C" int mik_gmres_destroy(mik_gmres *g)
+{
+    if (!g) return MIK_OK;
+    if (g->ctx) (void)hipStreamSynchronize(g->ctx->stream);
+    if (g->V) (void)hipFree(g->V);
+    if (g->Ax) (void)hipFree(g->Ax);
+    delete g;
+    return MIK_OK;
+}
+
+// iterate(g::GMRESIterable, iteration)                                   src/gmres.jl:57-106
+template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iteration, double *residual, int *done)
+{
+    mik_ctx *ctx = g->ctx;
+    const int m = g->restart;
+    const int64_t ldh = m + 1;
+    std::vector<T> &H = gm_H<T>(g);
+    std::vector<T> &nullvec = gm_nv<T>(g);
+    auto Hat = [&](int i, int j) -> T & { return H[(size_t)j * ldh + i]; };
+    auto is_done = [&](int64_t it) { return it >= g->maxiter || (T)g->current <= (T)g->tol; };   // :55, :51
+
+    if (is_done(iteration)) { *done = 1; if (residual) *residual = g->current; return MIK_OK; }   // :59
+    *done = 0;
+    int k = g->k;                                                         // 1-based, as in the reference
+    T *V = (T *)g->V;
+    T *vk = V + (int64_t)(k - 1) * g->ldv, *vk1 = V + (int64_t)k * g->ldv;
+
+    // expand!: V[:, k+1] = A * V[:, k]                                   :64, :285-288
+    MIK_TRY(mik_spmv_launch<T>(ctx, g->A, vk, vk1, false, nullptr, nullptr));
+    g->mv_products += 1;                                                  // :65
+
+    // H[k+1, k] = orthogonalize_and_normalize!(V[:, 1:k], V[:, k+1], H[1:k, k], orth_meth)   :68-73
+    T nrm;
+    MIK_TRY(orthogonalize_impl<T>(ctx, g->n, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));
+    Hat(k, k - 1) = nrm;
+
+    // update_residual!                                                   :76, :224-233
+    T current = (T)g->current, accumulator = (T)g->accumulator;
+    if (Hat(k, k - 1) == T(0)) {
+        current = T(0);
+    } else {
+        T dsum = T(0);
+        for (int i = 0; i < k; ++i) { T p = nullvec[i] * Hat(i, k - 1); dsum = dsum + p; }
+        nullvec[k] = -(dsum / Hat(k, k - 1));
+        T sq = nullvec[k] * nullvec[k];
+        accumulator = accumulator + sq;
+        current = (T)g->res_beta / std::sqrt(accumulator);
+    }
+    g->current = (double)current;
+    g->accumulator = (double)accumulator;
+
+    k += 1;                                                               // :78
+
+    if (k == m + 1 || is_done(iteration + 1)) {                           // :82
+        // solve_least_squares!: rhs = [beta, 0, ...] of length k; H view = H[1:k, 1:k-1]   :85, :262-271
+        std::vector<T> rhs((size_t)k, T(0));
+        rhs[0] = (T)g->g_beta;
+        hessenberg_ldiv<T>(H.data(), ldh, k - 1, rhs.data());
+        // update_solution!: x += V[:, 1:k-1] * y                         :88, :273-276
+        MIK_TRY(coef_upload<T>(ctx, 0, rhs.data(), k - 1));
+        MIK_TRY(gemv_n_dev<T>(ctx, g->n, k - 1, V, g->ldv, (const T *)ctx->coef, T(1), (T *)g->x));
+        k = 1;                                                            // :90
+        if (!is_done(iteration)) {                                        // :93
+            T beta;
+            MIK_TRY(gmres_init_residual<T>(g, 0, &beta));                 // :96
+            g->g_beta = (double)beta;
+            g->accumulator = 1.0;                                         // :99, :258
+            g->res_beta = (double)beta;                                   // :259
+            g->mv_products += 1;                                          // :101
+        }
+    }
+    g->k = k;
+    if (residual) *residual = g->current;                                 // :105
+    return MIK_OK;
+}
+
+extern "C" int mik_gmres_iterate(mik_gmres *g, int64_t iteration, double *residual, int *done)
+{
+    if (!g || !done || iteration < 0) return MIK_ERR_INVALID;
+    return g->dtype == MIK_F64 ? gmres_iterate_impl<double>(g, iteration, residual, done)
+                               : gmres_iterate_impl<float>(g, iteration, residual, done);
+}
+
+extern "C" int mik_gmres_state(const mik_gmres *g, double *residual, double *tol, double *beta, int *k, int64_t *mv_products,
+                               int *converged)
+{
+    if (!g) return MIK_ERR_INVALID;
+    if (residual) *residual = g->current;
+    if (tol) *tol = g->tol;
+    if (beta) *beta = g->g_beta;
+    if (k) *k = g->k;
+    if (mv_products) *mv_products = g->mv_products;
+    if (converged) *converged = g->current <= g->tol ? 1 : 0;            // src/gmres.jl:51
+    return MIK_OK;
+}

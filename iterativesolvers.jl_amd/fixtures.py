@@ -1,0 +1,70 @@
+"""Synthetic inputs of the hot path (numpy, host side): the reference's own fixtures, vectorised.
+
+These build the *inputs* handed to the C ABI (SparseMatrixCSC arrays + right-hand sides) for
+bench.py and the tests; they contain no solver arithmetic.  The oracle has its own independent
+generators in oracle/mik_oracle.c; tests cross-check the two.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def laplace_matrix(N: int, dims: int = 3, dtype=np.float64, index_base: int = 1, rows=None):
+    """``laplace_matrix(T, N, dims)`` -- test/laplace_matrix.jl:1-12, as SparseMatrixCSC fields
+    ``(n, colptr, rowval, nzval)`` with ``index_base``-based Int64 indices.
+
+    The matrix is symmetric, so columns ``rows = (r0, r1)`` of the CSC are also rows r0..r1-1 of
+    the CSR; passing ``rows`` returns only that slab's ``(ptr, idx, val)`` (idx global), which is
+    how the row-partitioned multi-GPU case builds its local block without forming 512^3 on one host.
+    """
+    n = N ** dims
+    r0, r1 = (0, n) if rows is None else rows
+    j = np.arange(r0, r1, dtype=np.int64)
+    strides = [N ** d for d in range(dims)]
+    cand = []
+    for d in reversed(range(dims)):                       # rows above the diagonal: j - N^2, j - N, j - 1
+        c = (j // strides[d]) % N
+        cand.append((j - strides[d], c > 0, -1.0))
+    cand.append((j, np.ones(j.shape, bool), 2.0 * dims))
+    for d in range(dims):                                 # j + 1, j + N, j + N^2
+        c = (j // strides[d]) % N
+        cand.append((j + strides[d], c < N - 1, -1.0))
+    idx = np.stack([c[0] for c in cand], axis=1)
+    mask = np.stack([c[1] for c in cand], axis=1)
+    val = np.broadcast_to(np.asarray([c[2] for c in cand], dtype=dtype), idx.shape)
+    counts = mask.sum(axis=1)
+    ptr = np.empty(j.size + 1, np.int64)
+    ptr[0] = 0
+    np.cumsum(counts, out=ptr[1:])
+    return n, ptr + index_base, idx[mask] + index_base, np.ascontiguousarray(val[mask])
+
+
+def advection_dominated(N: int = 50, beta: float = 1000.0, index_base: int = 1):
+    """``advection_dominated(; N, β)`` -- benchmark/advection_diffusion.jl:3-30 -> CSC fields and b.
+
+    A = laplace_matrix(Float64, N, 3) ./ -h^2 + kron(I, spdiagm(-1 => -β/2h, 1 => β/2h)), h = 1/(N+1).
+    """
+    n, colptr, rowval, _ = laplace_matrix(N, 3, np.float64, 0)
+    h = 1.0 / (N + 1)
+    mh2 = -(h * h)
+    lap_diag, lap_off = 6.0 / mh2, -1.0 / mh2
+    dx_sub, dx_sup = (-beta) / (2.0 * h), beta / (2.0 * h)
+    cols = np.repeat(np.arange(n, dtype=np.int64), np.diff(colptr))
+    diff = rowval - cols                                   # row - col
+    nzval = np.full(rowval.shape, lap_off)
+    nzval[diff == 0] = lap_diag
+    nzval[diff == -1] = lap_off + dx_sup                    # A[i, i+1]
+    nzval[diff == 1] = lap_off + dx_sub                     # A[i, i-1]
+    xs = np.arange(1, N + 1, dtype=np.float64) / np.float64(N + 1)
+    X, Y, Z = xs[None, None, :], xs[None, :, None], xs[:, None, None]    # x fastest
+    b = np.exp(X * Y * Z) * np.sin(np.pi * X) * np.sin(np.pi * Y) * np.sin(np.pi * Z)
+    return n, colptr + index_base, rowval + index_base, nzval, np.ascontiguousarray(b.reshape(-1))
+
+
+def hashed_rhs(n: int, start: int = 0, stop=None, dtype=np.float64) -> np.ndarray:
+    """b[i] = ((i * 2654435761) mod 2^32) / 2^32 - 0.5 for the 1-based i in (start, stop]
+    (exact in any language)."""
+    stop = n if stop is None else stop
+    i = np.arange(start + 1, stop + 1, dtype=np.uint64)
+    h = (i * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+    return (h.astype(np.float64) / 4294967296.0 - 0.5).astype(dtype)

@@ -1,0 +1,43 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import __graft_entry__ as graft  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (oracle/mik_oracle.c via ctypes) -- the checker, never the thing under test."""
+    o = graft.load_oracle()
+    o.lib()
+    return o
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    """The product package (iterativesolvers.jl_amd); loading it needs libmik.so built."""
+    if not os.path.exists(os.path.join(graft.PKG_DIR, "libmik.so")):
+        graft.build()
+    return graft.load_package()
+
+
+@pytest.fixture(scope="session")
+def ctx(pkg):
+    """A device context; GPU tests only.  Fails loudly (no CPU fallback) if there is no device."""
+    return pkg.default_context()
+
+
+def fromhex(lst):
+    return np.array([float.fromhex(s) for s in lst], dtype=np.float64)

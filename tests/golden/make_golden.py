@@ -1,0 +1,65 @@
+"""Regenerates the golden residual histories under tests/golden/ from the CPU oracle.
+
+Julia (hence the reference itself) cannot run in this environment, so these vectors are produced
+by oracle/mik_oracle.c -- the restatement pinned against the reference's own known-answer
+material in tests/test_oracle_pinning.py.  They pin (a) the oracle against regressions and
+(b) the HIP path at sizes where running the oracle inside the GPU test would be too slow.
+
+    python tests/golden/make_golden.py          # rewrites the .json files (takes a few minutes)
+
+`tree` histories depend on the device reduction shape (W, L) = mik_reduce_shape(); it is stored
+in each file and the tests skip the bit-exact comparison if the library's shape has changed.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from oracle import orc  # noqa: E402
+
+W, L = 2, 2          # mik_reduce_shape(MIK_F64) at the time of generation
+
+
+def hexlist(a):
+    return [float(v).hex() for v in a]
+
+
+def dump(name, obj):
+    with open(os.path.join(HERE, name), "w") as f:
+        json.dump(obj, f, indent=0)
+    print("wrote", name)
+
+
+def cg_case(N, maxiter=None):
+    A = orc.laplace(N, 3)
+    b = orc.hashed_rhs(A.n)
+    out = dict(case=f"cg(laplace_matrix(Float64,{N},3), hashed_rhs) reltol=sqrt(eps) abstol=0", N=N, W=W, L=L,
+               maxiter=maxiter)
+    for mode, shape in (("seq", (1, 1, 1, 1)), ("tree", (1, 1, W, L))):
+        x, h = orc.cg(A, b, maxiter=maxiter, mode=mode, shape=shape)
+        out[mode] = dict(iters=h["iters"], mvps=h["mvps"], isconverged=h["isconverged"], res0=float(h["res0"]).hex(),
+                         tol=float(h["tol"]).hex(), resnorm=hexlist(h["resnorm"]),
+                         x_checksum=float(np.sum(x)).hex(), x_norm=float(np.linalg.norm(x)).hex())
+    return out
+
+
+def gmres_case(N, restart):
+    A, b = orc.advdiff(N, 1000.0)
+    out = dict(case=f"gmres(advection_dominated(N={N}, beta=1000), restart={restart})", N=N, restart=restart, W=W, L=L,
+               b_from="oracle/orc_advdiff_csc (glibc exp/sin)")
+    for mode, shape in (("seq", (1, 1)), ("tree", (W, L))):
+        x, h = orc.gmres(A, b, restart=restart, mode=mode, shape=shape)
+        out[mode] = dict(iters=h["iters"], mvps=h["mvps"], isconverged=h["isconverged"], res0=float(h["res0"]).hex(),
+                         tol=float(h["tol"]).hex(), resnorm=hexlist(h["resnorm"]),
+                         x_checksum=float(np.sum(x)).hex(), x_norm=float(np.linalg.norm(x)).hex())
+    return out
+
+
+if __name__ == "__main__":
+    dump("cg_lap32.json", cg_case(32))
+    dump("cg_lap64.json", cg_case(64))
+    dump("gmres_advdiff50_r30.json", gmres_case(50, 30))
+    dump("cg_lap256_first40.json", cg_case(256, maxiter=40))

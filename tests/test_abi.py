@@ -1,0 +1,99 @@
+"""The C-ABI shared library: loads, exports every symbol include/mik.h declares, fails cleanly
+without a device.  No compute calls (this file runs on the CPU-only build box)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "mik.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mik_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_something():
+    syms = declared_symbols()
+    assert "mik_spmv" in syms and "mik_cg_iterate" in syms and "mik_gmres_iterate" in syms and len(syms) >= 35
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    path = pkg._lib.LIB_PATH
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [s for s in declared_symbols() if s not in exported]
+    assert not missing, f"libmik.so does not export: {missing}"
+
+
+def test_ctypes_binding_covers_header(pkg):
+    assert sorted(pkg._lib.SIGNATURES) == declared_symbols()
+    L = pkg.lib()
+    assert L.mik_abi_version() == 1
+
+
+def test_reduce_shape_is_exported_constant(pkg):
+    L = pkg.lib()
+    w, l = C.c_int(), C.c_int()
+    assert L.mik_reduce_shape(0, C.byref(w), C.byref(l)) == 0 and (w.value, l.value) == (2, 2)
+    assert L.mik_reduce_shape(1, C.byref(w), C.byref(l)) == 0 and (w.value, l.value) == (4, 2)
+    assert L.mik_reduce_shape(7, C.byref(w), C.byref(l)) == 1
+
+
+def test_no_device_fails_loudly_not_silently(pkg):
+    """On a box without a GPU the product path must raise -- there is no CPU fallback."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(pkg.MikError) as ei:
+        pkg.HipContext(0)
+    assert ei.value.code == 2 and "no HIP device" in str(ei.value)
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg_dir = os.path.join(ROOT, "iterativesolvers.jl_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".jl", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+                assert "libmik_oracle" not in text and not re.search(r"\borc_[a-z]+\s*\(", text), f
+
+
+# ---- host-only entry point: Hessenberg least squares (no device needed) -----------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_hessenberg_ldiv_host_matches_oracle_and_lstsq(pkg, orc, dtype):
+    from test_oracle_pinning import H1
+    H = np.asfortranarray(H1.astype(dtype))
+    rhs = np.zeros(7, dtype)
+    rhs[0] = 1
+    Hc, rc = H.copy(order="F"), rhs.copy()
+    pkg.hessenberg_ldiv_(Hc, rc)
+    Ro, so = orc.hessenberg_ldiv(H, rhs)
+    assert np.array_equal(rc, so) and np.array_equal(Hc, Ro)          # same algorithm, same bits
+    ref, *_ = np.linalg.lstsq(H1, rhs.astype(np.float64), rcond=None)
+    np.testing.assert_allclose(rc[:6], ref, rtol=1e-12 if dtype == np.float64 else 2e-5)   # test/hessenberg.jl:40
+
+
+def test_hessenberg_ldiv_random_widths(pkg, orc):
+    rng = np.random.default_rng(0)
+    for m in (1, 2, 5, 30, 50):
+        H = np.triu(rng.standard_normal((m + 1, m)), -1) + np.vstack([3 * np.eye(m), np.zeros((1, m))])
+        H = np.asfortranarray(H)
+        rhs = np.zeros(m + 1)
+        rhs[0] = rng.standard_normal()
+        Hc, rc = H.copy(order="F"), rhs.copy()
+        pkg.hessenberg_ldiv_(Hc, rc)
+        _, so = orc.hessenberg_ldiv(H, rhs)
+        assert np.array_equal(rc, so)
+        ref, *_ = np.linalg.lstsq(H, rhs, rcond=None)
+        np.testing.assert_allclose(rc[:m], ref, rtol=1e-9, atol=1e-12)
+    with pytest.raises(ValueError):
+        pkg.hessenberg_ldiv_(np.zeros((3, 3)), np.zeros(3))

@@ -1,0 +1,418 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  GPU box only (-m gpu).
+
+Bar: BIT-EXACT against the oracle's TREE mode (the oracle restating the device's fixed reduction
+tree), and within the oracle's own SEQ-vs-PAIR reordering floor against the reference-shaped SEQ
+mode (north-star tolerance 1e-12 relative where the floor allows it -- see DESIGN.md).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import GOLDEN, fromhex
+
+pytestmark = pytest.mark.gpu
+
+
+def upload(pkg, A):
+    """oracle CSC -> device operator, exactly as a Julia SparseMatrixCSC would be handed over"""
+    return pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval, index_base=A.index_base)
+
+
+def shape_of(ctx, dtype):
+    return ctx.reduce_shape(dtype)
+
+
+# ==============================================================================================
+# SpMV  (mul!(y, A, x))
+# ==============================================================================================
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("case", ["lap3d_20", "lap2d_33", "lap1d_1000", "advdiff_12", "lap3d_64"])
+def test_spmv_bit_exact(pkg, orc, ctx, case, dtype):
+    if case.startswith("lap"):
+        dims = int(case[3])
+        A = orc.laplace(int(case.split("_")[1]), dims)
+    else:
+        A, _ = orc.advdiff(12, 1000.0)           # nonsymmetric: a missing CSC->CSR transpose shows here
+    A = A.astype(dtype)
+    x = np.random.default_rng(1).standard_normal(A.n).astype(dtype)
+    y = (upload(pkg, A) @ pkg.HipVector.from_numpy(x)).to_numpy()
+    assert np.array_equal(y, orc.spmv(A, x))
+
+
+def test_spmv_irregular_rows_empty_rows_long_rows(pkg, orc, ctx):
+    """ragged input: empty rows, a row longer than the LDS tile (2048), duplicates-free random fill"""
+    rng = np.random.RandomState(11)
+    n = 3000
+    M = sp.random(n, n, 0.002, random_state=rng, format="lil")
+    M[17, :] = rng.standard_normal(n)            # dense row: 3000 nnz > tile
+    M[1500, ::2] = 1.5                           # 1500 nnz
+    M[5, :] = 0                                  # empty row
+    M[2999, :] = 0
+    M = M.tocsc()
+    M.eliminate_zeros()
+    A = orc.CSC.from_scipy(M)
+    x = rng.standard_normal(n)
+    y = (upload(pkg, A) @ pkg.HipVector.from_numpy(x)).to_numpy()
+    assert np.array_equal(y, orc.spmv(A, x))
+    assert y[5] == 0 and y[2999] == 0
+
+
+def test_spmv_rectangular_csr_input_and_index_bases(pkg, orc, ctx):
+    rng = np.random.RandomState(3)
+    M = sp.random(700, 300, 0.02, random_state=rng, format="csr")
+    M.sort_indices()
+    x = rng.standard_normal(300)
+    ref = None
+    for base in (0, 1):
+        A = pkg.HipCSR(700, 300, M.indptr.astype(np.int64) + base, M.indices.astype(np.int64) + base, M.data,
+                       index_base=base, is_csc=False)
+        y = pkg.HipVector(700)
+        pkg.mul_(y, A, pkg.HipVector.from_numpy(x))
+        ref = y.to_numpy() if ref is None else ref
+        assert np.array_equal(y.to_numpy(), ref)
+    np.testing.assert_allclose(ref, M @ x, rtol=1e-13, atol=1e-14)
+    Mc = M.tocsc()
+    Mc.sort_indices()
+    Ac = pkg.HipCSR(700, 300, Mc.indptr, Mc.indices, Mc.data, index_base=0, is_csc=True)
+    assert np.array_equal((Ac @ pkg.HipVector.from_numpy(x)).to_numpy(), ref)
+
+
+def test_csr_create_rejects_bad_input(pkg, ctx):
+    ptr = np.array([0, 1, 2], np.int64)
+    with pytest.raises(pkg.MikError) as e:
+        pkg.HipCSR(2, 2, ptr, np.array([0, 5], np.int64), np.ones(2), index_base=0)      # index out of range
+    assert e.value.code == 1
+    with pytest.raises(pkg.MikError) as e:
+        pkg.HipCSR(2, 2, ptr + 1, np.array([0, 1], np.int64), np.ones(2), index_base=0)  # ptr[0] != base
+    assert e.value.code == 3
+    A = pkg.HipCSR(2, 2, ptr, np.array([0, 1], np.int64), np.ones(2), index_base=0)
+    with pytest.raises(ValueError):
+        pkg.mul_(pkg.HipVector(3), A, pkg.HipVector(2))                                   # DimensionMismatch
+
+
+# ==============================================================================================
+# BLAS-1 forms
+# ==============================================================================================
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n", [0, 1, 63, 255, 1024, 1025, 4099, 100003, 1 << 20])
+def test_dot_nrm2_bit_exact_vs_tree_oracle(pkg, orc, ctx, n, dtype):
+    rng = np.random.default_rng(n + 1)
+    x = rng.standard_normal(n).astype(dtype)
+    y = rng.standard_normal(n).astype(dtype)
+    W, L = shape_of(ctx, dtype)
+    dx, dy = pkg.HipVector.from_numpy(x), pkg.HipVector.from_numpy(y)
+    d = pkg.dot(dx, dy)
+    assert d == dtype(orc.dot(x, y, "tree", W, L)) if n else d == 0
+    nr = pkg.norm(dx)
+    assert nr == dtype(orc.nrm2(x, "tree", W, L)) if n else nr == 0
+    if n:
+        tol = 1e-13 if dtype == np.float64 else 1e-5
+        assert abs(d - np.dot(x.astype(np.float64), y.astype(np.float64))) <= tol * np.linalg.norm(x) * np.linalg.norm(y)
+        assert abs(nr - np.linalg.norm(x.astype(np.float64))) <= tol * nr
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,off", [(1, 0), (1000, 0), (1000, 1), (5001, 3), (300000, 0)])
+def test_elementwise_forms_exact(pkg, ctx, n, off, dtype):
+    """broadcast forms of src/cg.jl:51,58-59,138; views at odd offsets take the scalar-load kernels"""
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal(n + off).astype(dtype)
+    Y = rng.standard_normal(n + off).astype(dtype)
+    D = (rng.random(n + off) + 1).astype(dtype)
+    a = dtype(0.37)
+    dX, dD = pkg.HipVector.from_numpy(X).view(off, n), pkg.HipVector.from_numpy(D).view(off, n)
+    x, y, d = X[off:], Y[off:], D[off:]
+
+    def fresh():
+        return pkg.HipVector.from_numpy(Y).view(off, n)
+
+    assert np.array_equal(fresh().axpy_(a, dX).to_numpy(), y + a * x)
+    assert np.array_equal(fresh().xpby_(dX, a).to_numpy(), x + a * y)
+    assert np.array_equal(fresh().sub_(dX).to_numpy(), y - x)
+    assert np.array_equal(fresh().scal_(a).to_numpy(), y * a)
+    assert np.array_equal(fresh().fill_(2.5).to_numpy(), np.full(n, 2.5, dtype))
+    assert np.array_equal(fresh().copyto_(dX).to_numpy(), x)
+    out = fresh()
+    pkg.JacobiPrec(dD).ldiv_(out, dX)
+    assert np.array_equal(out.to_numpy(), x / d)
+    # misaligned views must reduce exactly like aligned ones
+    assert pkg.dot(dX, fresh()) == pkg.dot(pkg.HipVector.from_numpy(x), pkg.HipVector.from_numpy(y))
+
+
+# ==============================================================================================
+# CG
+# ==============================================================================================
+@pytest.mark.parametrize("N", [5, 16, 20, 32])
+def test_cg_history_bit_exact_vs_tree_oracle(pkg, orc, ctx, N):
+    A = orc.laplace(N, 3)
+    b = orc.hashed_rhs(A.n)
+    W, L = shape_of(ctx, np.float64)
+    x, ch = pkg.cg(upload(pkg, A), pkg.HipVector.from_numpy(b), log=True)
+    xo, ho = orc.cg(A, b, mode="tree", shape=(1, 1, W, L))
+    assert ch.iters == ho["iters"] and ch.mvps == ho["mvps"] and ch.isconverged == ho["isconverged"]
+    assert np.array_equal(ch["resnorm"], ho["resnorm"])
+    assert np.array_equal(x.to_numpy(), xo)
+    # reference-shaped order: same iteration count, history within the SEQ-vs-PAIR floor (>= 1e-12)
+    _, hs = orc.cg(A, b, mode="seq")
+    _, hp = orc.cg(A, b, mode="pair")
+    assert ch.iters == hs["iters"]
+    floor = np.max(np.abs(hs["resnorm"] - hp["resnorm"]) / hs["resnorm"]) if hp["iters"] == hs["iters"] else 1e-10
+    dev = np.max(np.abs(ch["resnorm"] - hs["resnorm"]) / hs["resnorm"])
+    assert dev <= max(1e-12, 3 * floor), (dev, floor)
+
+
+def test_cg_golden_64(pkg, ctx):
+    """config 1 of BASELINE.json: cg on the 64^3 Laplacian, against the committed golden history"""
+    g = json.load(open(os.path.join(GOLDEN, "cg_lap64.json")))
+    n, colptr, rowval, nzval = pkg.fixtures.laplace_matrix(64, 3)
+    b = pkg.fixtures.hashed_rhs(n)
+    x, ch = pkg.cg(pkg.HipCSR(n, n, colptr, rowval, nzval), pkg.HipVector.from_numpy(b), log=True)
+    assert ch.iters == g["seq"]["iters"] == 195 and ch.isconverged
+    seq = fromhex(g["seq"]["resnorm"])
+    assert np.max(np.abs(ch["resnorm"] - seq) / seq) <= 3e-12          # floor at 64^3 is 5.7e-13 (seq vs pair)
+    if (g["W"], g["L"]) == ctx.reduce_shape(np.float64):
+        assert np.array_equal(ch["resnorm"], fromhex(g["tree"]["resnorm"]))
+        assert float(np.sum(x.to_numpy())).hex() == g["tree"]["x_checksum"]
+
+
+def test_cg_reference_properties(pkg, orc, ctx):
+    """test/cg.jl:55-87 on the device path (Sparse Laplacian, Jacobi PCG, starting guess)"""
+    A = orc.laplace(10, 2)
+    S = A.to_scipy()
+    rng = np.random.default_rng(7)
+    rhs = rng.standard_normal(A.n)
+    rhs *= 1.0 / np.linalg.norm(rhs)
+    dA, drhs = upload(pkg, A), pkg.HipVector.from_numpy(rhs)
+    P = pkg.JacobiPrec(pkg.HipVector.from_numpy(S.diagonal()))
+    xCG = pkg.cg(dA, drhs, reltol=1e-5, maxiter=100).to_numpy()
+    xJAC = pkg.cg(dA, drhs, Pl=P, reltol=1e-5, maxiter=100).to_numpy()
+    assert np.linalg.norm(S @ xCG - rhs) <= 1e-5 and np.linalg.norm(S @ xJAC - rhs) <= 1e-5      # :67-68
+    x0 = rng.standard_normal(A.n)
+    xCG, hCG = pkg.cg_(pkg.HipVector.from_numpy(x0), dA, drhs, abstol=1e-5, reltol=0.0, maxiter=100, log=True)
+    xJAC, hJAC = pkg.cg_(pkg.HipVector.from_numpy(x0), dA, drhs, Pl=P, abstol=1e-5, reltol=0.0, maxiter=100, log=True)
+    assert np.linalg.norm(S @ xCG.to_numpy() - rhs) <= 1e-5 and np.linalg.norm(S @ xJAC.to_numpy() - rhs) <= 1e-5
+    assert pkg.niters(hJAC) == pkg.niters(hCG)                                                    # :85
+    # bit-exact against the oracle for both, including the starting-guess SpMV (mvps = 1 + iters)
+    W, L = shape_of(ctx, np.float64)
+    _, ho = orc.cg(A, rhs, x0, abstol=1e-5, reltol=0.0, maxiter=100, mode="tree", shape=(1, 1, W, L))
+    assert np.array_equal(hCG["resnorm"], ho["resnorm"]) and hCG.mvps == ho["mvps"]
+    _, hj = orc.cg(A, rhs, x0, abstol=1e-5, reltol=0.0, maxiter=100, jacobi_diag=S.diagonal(), mode="tree", shape=(1, 1, W, L))
+    assert np.array_equal(hJAC["resnorm"], hj["resnorm"]) and hJAC.mvps == hj["mvps"]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_cg_small_dense_and_edge_cases(pkg, orc, ctx, dtype):
+    """test/cg.jl:24-53 (dense SPD pushed through the sparse interface) and :98-122"""
+    rng = np.random.default_rng(1234321)
+    n = 10
+    M = rng.random((n, n)).astype(dtype)
+    A_d = (M.T @ M + np.eye(n, dtype=dtype)).astype(dtype)
+    b = rng.random(n).astype(dtype)
+    A = orc.CSC.from_dense(A_d)
+    dA = upload(pkg, A)
+    reltol = float(np.sqrt(np.finfo(dtype).eps))
+    x, ch = pkg.cg(dA, pkg.HipVector.from_numpy(b), reltol=reltol, maxiter=2 * n, log=True)
+    assert isinstance(ch, pkg.ConvergenceHistory) and ch.isconverged
+    assert np.linalg.norm(A_d @ x.to_numpy() - b) / np.linalg.norm(b) <= reltol                   # :35
+    xe = np.linalg.solve(A_d.astype(np.float64), b.astype(np.float64)).astype(dtype)
+    x, ch = pkg.cg_(pkg.HipVector.from_numpy(xe), dA, pkg.HipVector.from_numpy(b), abstol=2 * n * float(np.finfo(dtype).eps),
+                    reltol=0.0, log=True)
+    assert pkg.niters(ch) <= 1 and pkg.nprods(ch) <= 2                                            # :40-41
+    x0 = pkg.cg(dA, pkg.HipVector.from_numpy(np.zeros(n, dtype)))
+    assert np.all(x0.to_numpy() == 0)                                                             # :50-51
+    # termination criterion :98-122
+    T3 = np.array([[2, -1, 0], [-1, 2, -1], [0, -1, 2]], dtype)
+    d3 = upload(pkg, orc.CSC.from_dense(T3))
+    b3 = np.ones(3, dtype)
+    xs = np.linalg.solve(T3.astype(np.float64), b3.astype(np.float64)).astype(dtype)
+    pert = (10 * np.sqrt(np.finfo(dtype).eps) * np.array([-1.0, 1.0, -1.0])).astype(dtype)
+    x, ch = pkg.cg_(pkg.HipVector.from_numpy(xs + pert), d3, pkg.HipVector.from_numpy(b3), log=True)
+    assert 2 <= pkg.niters(ch) <= 3
+    r0 = float(np.linalg.norm(T3 @ (xs + pert) - b3))
+    x, ch = pkg.cg_(pkg.HipVector.from_numpy(xs + pert), d3, pkg.HipVector.from_numpy(b3), abstol=2 * r0, reltol=0.0, log=True)
+    assert pkg.niters(ch) == 0
+
+
+def test_cg_fp32_history_bit_exact(pkg, orc, ctx):
+    A = orc.laplace(12, 3).astype(np.float32)
+    b = orc.hashed_rhs(A.n).astype(np.float32)
+    W, L = shape_of(ctx, np.float32)
+    x, ch = pkg.cg(upload(pkg, A), pkg.HipVector.from_numpy(b), log=True)
+    xo, ho = orc.cg(A, b, mode="tree", shape=(1, 1, W, L))
+    assert ch.iters == ho["iters"] and np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
+
+
+def test_cg_iterable_protocol_and_batched_steps(pkg, orc, ctx):
+    """iterate(it, iteration) one step at a time == iterate_many (one sync) == cg_ driver; maxiter honoured"""
+    A = orc.laplace(14, 3)
+    b = orc.hashed_rhs(A.n)
+    dA, db = upload(pkg, A), pkg.HipVector.from_numpy(b)
+    _, ch = pkg.cg(dA, db, log=True)
+    it = pkg.cg_iterator_(pkg.zerox(dA, db), dA, db, initially_zero=True)
+    assert it.mv_products == 0 and it.prev_residual == 1.0
+    res, iteration = [], it.start()
+    while (nxt := it.iterate(iteration)) is not None:
+        r, iteration = nxt
+        res.append(r)
+    assert np.array_equal(res, ch["resnorm"]) and it.mv_products == ch.iters and it.converged()
+    assert it.iterate(iteration) is None                                         # stays done
+    it2 = pkg.cg_iterator_(pkg.zerox(dA, db), dA, db, initially_zero=True)
+    r1 = it2.iterate_many(0, 7)
+    r2 = it2.iterate_many(7, 10 ** 6)                                            # device-side stop test ends the batch
+    assert np.array_equal(np.concatenate([r1, r2]), ch["resnorm"]) and it2.converged()
+    x3, ch3 = pkg.cg(dA, db, log=True, maxiter=5)
+    assert ch3.iters == 5 and not ch3.isconverged and np.array_equal(ch3["resnorm"], ch["resnorm"][:5])
+
+
+def test_cg_generic_l1_path_matches_oracle(pkg, orc, ctx):
+    """The unmodified reference iterate() over the L1 entry points (mul_, dot, norm, broadcast)."""
+    A = orc.laplace(12, 3)
+    b = orc.hashed_rhs(A.n)
+    W, L = shape_of(ctx, np.float64)
+    dA, db = upload(pkg, A), pkg.HipVector.from_numpy(b)
+    x, ch = pkg.cg(dA, db, log=True, fused=False)
+    xo, ho = orc.cg(A, b, mode="tree", shape=(W, L, W, L))       # unfused dot(u, c) uses the BLAS-1 tree shape
+    assert ch.iters == ho["iters"] and np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
+
+
+# ==============================================================================================
+# orthogonalisation + GMRES
+# ==============================================================================================
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("method", ["mgs", "cgs", "dgks"])
+@pytest.mark.parametrize("n,k", [(10, 3), (1000, 1), (5000, 7), (70001, 30)])
+def test_orthogonalize_bit_exact_and_invariants(pkg, orc, ctx, method, n, k, dtype):
+    rng = np.random.default_rng(n + k)
+    V, _ = np.linalg.qr(rng.standard_normal((n, k)))
+    V = np.asfortranarray(V.astype(dtype))
+    w0 = rng.standard_normal(n).astype(dtype)
+    if method == "dgks":
+        w0 = (V @ rng.standard_normal(k).astype(dtype) + dtype(1e-3) * w0).astype(dtype)   # forces re-orthogonalisation
+    W, L = shape_of(ctx, dtype)
+    M = {"mgs": pkg.ModifiedGramSchmidt(), "cgs": pkg.ClassicalGramSchmidt(), "dgks": pkg.DGKS()}[method]
+    dV, dw = pkg.HipMatrix.from_numpy(V), pkg.HipVector.from_numpy(w0)
+    h = np.zeros(k, dtype)
+    nrm = pkg.orthogonalize_and_normalize_(dV, k, dw, h, M)
+    wo, ho, no = orc.orthogonalize(V, w0, method=method, mode="tree", W=W, L=L)
+    assert nrm == no and np.array_equal(h, ho) and np.array_equal(dw.to_numpy(), wo)
+    if dtype == np.float64 and method != "dgks":
+        w = dw.to_numpy()                                                         # test/orthogonalize.jl:27-33
+        assert abs(np.linalg.norm(w) - 1) < 1e-13
+        np.testing.assert_allclose(nrm * w + V @ h, w0, rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("orth", ["mgs", "cgs", "dgks"])
+def test_gmres_history_bit_exact_vs_tree_oracle(pkg, orc, ctx, orth):
+    A, b = orc.advdiff(12, 1000.0)
+    W, L = shape_of(ctx, np.float64)
+    M = {"mgs": pkg.ModifiedGramSchmidt(), "cgs": pkg.ClassicalGramSchmidt(), "dgks": pkg.DGKS()}[orth]
+    x, ch = pkg.gmres(upload(pkg, A), pkg.HipVector.from_numpy(b), restart=10, log=True, orth_meth=M)
+    xo, ho = orc.gmres(A, b, restart=10, orth_meth=orth, mode="tree", shape=(W, L))
+    assert ch.iters == ho["iters"] and ch.mvps == ho["mvps"] and ch.isconverged == ho["isconverged"]
+    assert np.array_equal(ch["resnorm"], ho["resnorm"])
+    assert np.array_equal(x.to_numpy(), xo)
+    assert np.all(np.diff(ch["resnorm"]) <= 0.0)                                  # test/gmres.jl:25
+    S = A.to_scipy()
+    assert np.linalg.norm(S @ x.to_numpy() - b) / np.linalg.norm(b) <= 2e-8
+    # reference-shaped order: first restart cycle within 1e-12, same iteration count +- 2 overall
+    _, hs = orc.gmres(A, b, restart=10, orth_meth=orth, mode="seq")
+    assert np.max(np.abs(ch["resnorm"][:10] - hs["resnorm"][:10]) / hs["resnorm"][:10]) <= 1e-12
+    assert abs(ch.iters - hs["iters"]) <= 2
+
+
+def test_gmres_golden_config3(pkg, ctx):
+    """config 3 of BASELINE.json: gmres(restart=30) on advection_dominated(N=50, beta=1000)"""
+    g = json.load(open(os.path.join(GOLDEN, "gmres_advdiff50_r30.json")))
+    from __graft_entry__ import load_oracle
+    A, b = load_oracle().advdiff(50, 1000.0)              # same b as the golden run (glibc exp/sin)
+    x, ch = pkg.gmres(upload(pkg, A), pkg.HipVector.from_numpy(b), restart=30, log=True)
+    seq = fromhex(g["seq"]["resnorm"])
+    assert abs(ch.iters - g["seq"]["iters"]) <= 2 and ch.isconverged
+    assert np.max(np.abs(ch["resnorm"][:30] - seq[:30]) / seq[:30]) <= 1e-12     # first cycle
+    m = min(ch.iters, seq.size)
+    assert np.max(np.abs(ch["resnorm"][:m] - seq[:m]) / seq[:m]) <= 1e-6         # restart-sensitivity band
+    if (g["W"], g["L"]) == ctx.reduce_shape(np.float64):
+        assert ch.iters == g["tree"]["iters"] and ch.mvps == g["tree"]["mvps"]
+        assert np.array_equal(ch["resnorm"], fromhex(g["tree"]["resnorm"]))
+        assert float(np.sum(x.to_numpy())).hex() == g["tree"]["x_checksum"]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gmres_reference_edge_cases(pkg, orc, ctx, dtype):
+    # test/gmres.jl:68-73: identity, zero sub-diagonal branch => x == b exactly
+    dI = upload(pkg, orc.CSC.from_dense(np.eye(2, dtype=dtype)))
+    b = np.array([1.0, 2.2], dtype)
+    x = pkg.gmres(dI, pkg.HipVector.from_numpy(b))
+    assert np.all(x.to_numpy() == b)
+    # test/gmres.jl:75-99 termination criterion
+    T3 = np.array([[2, -1, 0], [-1, 2, -1], [0, -1, 2]], dtype)
+    d3 = upload(pkg, orc.CSC.from_dense(T3))
+    b3 = np.ones(3, dtype)
+    xs = np.linalg.solve(T3.astype(np.float64), b3.astype(np.float64)).astype(dtype)
+    pert = (10 * np.sqrt(np.finfo(dtype).eps) * np.array([-1.0, 1.0, -1.0])).astype(dtype)
+    x, ch = pkg.gmres_(pkg.HipVector.from_numpy(xs + pert), d3, pkg.HipVector.from_numpy(b3), log=True)
+    assert 2 <= pkg.niters(ch) <= 3
+    r0 = float(np.linalg.norm(T3 @ (xs + pert) - b3))
+    x, ch = pkg.gmres_(pkg.HipVector.from_numpy(xs + pert), d3, pkg.HipVector.from_numpy(b3), abstol=2 * r0, reltol=0.0, log=True)
+    assert pkg.niters(ch) == 0
+
+
+def test_gmres_counters_and_maxiter_quirk(pkg, orc, ctx):
+    """mv_products bookkeeping of src/gmres.jl:65,101,122 incl. the extra init! on maxiter exhaustion"""
+    A, b = orc.advdiff(6, 50.0)
+    dA, db = upload(pkg, A), pkg.HipVector.from_numpy(b)
+    x, ch = pkg.gmres(dA, db, restart=5, maxiter=12, reltol=1e-30, log=True)
+    xo, ho = orc.gmres(A, b, restart=5, maxiter=12, reltol=1e-30, mode="tree", shape=shape_of(ctx, np.float64))
+    assert ch.iters == 12 and not ch.isconverged and ch.mvps == ho["mvps"] == 16 and pkg.nrests(ch) == 3
+    assert np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
+    with pytest.raises(pkg.MikError) as e:
+        pkg.gmres(dA, db, Pl=pkg.JacobiPrec(db))
+    assert e.value.code == 5
+
+
+def test_gmres_fp32(pkg, orc, ctx):
+    A, b = orc.advdiff(10, 100.0)
+    A, b = A.astype(np.float32), b.astype(np.float32)
+    x, ch = pkg.gmres(upload(pkg, A), pkg.HipVector.from_numpy(b), restart=15, log=True)
+    xo, ho = orc.gmres(A, b, restart=15, mode="tree", shape=shape_of(ctx, np.float32))
+    assert ch.iters == ho["iters"] and np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
+
+
+# ==============================================================================================
+# full-size checks (BASELINE.json config 2: 256^3) through size-independent properties
+# ==============================================================================================
+def test_full_size_256_properties_and_golden_prefix(pkg, ctx):
+    N = 256
+    n, colptr, rowval, nzval = pkg.fixtures.laplace_matrix(N, 3)
+    A = pkg.HipCSR(n, n, colptr, rowval, nzval)
+    del colptr, rowval, nzval
+    b = pkg.fixtures.hashed_rhs(n)
+    db = pkg.HipVector.from_numpy(b)
+    # (1) SpMV against the stencil evaluated with numpy slices (exact: same per-row order is not needed
+    #     for a tolerance check; linearity + symmetry are exact-arithmetic properties)
+    g = b.reshape(N, N, N)
+    ref = 6.0 * g.copy()
+    ref[1:, :, :] -= g[:-1, :, :]; ref[:-1, :, :] -= g[1:, :, :]
+    ref[:, 1:, :] -= g[:, :-1, :]; ref[:, :-1, :] -= g[:, 1:, :]
+    ref[:, :, 1:] -= g[:, :, :-1]; ref[:, :, :-1] -= g[:, :, 1:]
+    y = A @ db
+    np.testing.assert_allclose(y.to_numpy(), ref.reshape(-1), rtol=0, atol=1e-14)
+    # (2) symmetry: dot(u, A v) == dot(A u, v) to rounding
+    v = pkg.HipVector.from_numpy(pkg.fixtures.hashed_rhs(2 * n)[n:])
+    Av = A @ v
+    lhs, rhs = pkg.dot(db, Av), pkg.dot(y, v)
+    assert abs(lhs - rhs) <= 1e-12 * abs(lhs)
+    # (3) first 40 CG residuals against the committed golden prefix generated by the oracle
+    gold = json.load(open(os.path.join(GOLDEN, "cg_lap256_first40.json")))
+    x, ch = pkg.cg(A, db, log=True, maxiter=40)
+    seq = fromhex(gold["seq"]["resnorm"])
+    assert ch.iters == 40 and np.max(np.abs(ch["resnorm"] - seq) / seq) <= 1e-12
+    if (gold["W"], gold["L"]) == ctx.reduce_shape(np.float64):
+        assert np.array_equal(ch["resnorm"], fromhex(gold["tree"]["resnorm"]))
+    # (4) the recurrence residual equals the true residual after 40 steps (round trip through A)
+    r = pkg.HipVector.from_numpy(b)
+    r.sub_(A @ x)
+    assert abs(pkg.norm(r) - ch["resnorm"][-1]) <= 1e-10 * ch["resnorm"][-1]

@@ -1,0 +1,95 @@
+"""Host-side logic that needs no device: fixtures vs the oracle's independent generators,
+ConvergenceHistory semantics (src/history.jl), golden-vector regression of the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import GOLDEN, fromhex
+
+
+@pytest.mark.parametrize("N,dims", [(5, 1), (7, 2), (6, 3), (16, 3)])
+def test_laplace_fixture_matches_oracle_and_kron(pkg, orc, N, dims):
+    n, colptr, rowval, nzval = pkg.fixtures.laplace_matrix(N, dims)
+    A = orc.laplace(N, dims)
+    assert n == A.n and np.array_equal(colptr, A.colptr) and np.array_equal(rowval, A.rowval) and np.array_equal(nzval, A.nzval)
+    # test/laplace_matrix.jl:1-12 spelled with scipy kron
+    D = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(N, N))
+    K = D.copy()
+    for _ in range(2, dims + 1):
+        K = sp.kron(K, sp.eye(N)) + sp.kron(sp.eye(K.shape[0]), D)
+    assert abs(A.to_scipy() - K).max() == 0
+    assert A.nnz == {1: 3 * N - 2, 2: 5 * N * N - 4 * N, 3: 7 * N ** 3 - 6 * N * N}[dims]
+
+
+def test_laplace_slab_rows(pkg):
+    N = 6
+    n, ptr, idx, val = pkg.fixtures.laplace_matrix(N, 3, index_base=0)
+    r0, r1 = 2 * N * N, 5 * N * N
+    _, p2, i2, v2 = pkg.fixtures.laplace_matrix(N, 3, index_base=0, rows=(r0, r1))
+    assert np.array_equal(p2, ptr[r0:r1 + 1] - ptr[r0])
+    assert np.array_equal(i2, idx[ptr[r0]:ptr[r1]]) and np.array_equal(v2, val[ptr[r0]:ptr[r1]])
+
+
+def test_advdiff_fixture_matches_oracle(pkg, orc):
+    n, colptr, rowval, nzval, b = pkg.fixtures.advection_dominated(9, 1000.0)
+    A, bo = orc.advdiff(9, 1000.0)
+    assert np.array_equal(colptr, A.colptr) and np.array_equal(rowval, A.rowval)
+    assert np.array_equal(nzval, A.nzval)
+    np.testing.assert_allclose(b, bo, rtol=2e-15)            # numpy vs glibc exp/sin: last-ulp differences allowed
+    S = A.to_scipy()
+    assert abs(S - S.T).max() > 1e3                          # nonsymmetric (max|A - A'| = beta/h)
+    h = 1.0 / 10
+    assert S[0, 0] == 6.0 / -(h * h) and S[1, 0] == 1.0 / (h * h) - 1000.0 / (2 * h) and S[0, 1] == 1.0 / (h * h) + 1000.0 / (2 * h)
+
+
+def test_hashed_rhs(pkg, orc):
+    b = pkg.fixtures.hashed_rhs(1000)
+    assert np.array_equal(b, orc.hashed_rhs(1000))
+    assert b[0] == (2654435761 % 2 ** 32) / 2 ** 32 - 0.5
+    assert np.array_equal(pkg.fixtures.hashed_rhs(1000, 100, 300), b[100:300])
+
+
+def test_convergence_history_semantics(pkg):
+    # src/history.jl:62-66,139-142,181-216,238-252
+    ch = pkg.ConvergenceHistory(partial=False, restart=3)
+    ch.reserve_("resnorm", 10)
+    for r in (3.0, 2.0, 1.0, 0.5):
+        ch.nextiter_(mvps=1)
+        ch.push_("resnorm", r)
+    ch.setconv(True)
+    ch.shrink_()
+    assert pkg.niters(ch) == 4 and pkg.nprods(ch) == 4 and pkg.nrests(ch) == 2 and ch.isconverged
+    assert np.array_equal(ch["resnorm"], [3.0, 2.0, 1.0, 0.5])
+    ph = pkg.ConvergenceHistory(partial=True)
+    ph.reserve_("resnorm", 10)
+    assert "resnorm" not in ph.data                          # PartialHistory stores nothing (:177)
+
+
+@pytest.mark.parametrize("name", ["cg_lap32.json", "gmres_advdiff50_r30.json"])
+def test_oracle_reproduces_golden(orc, name):
+    """Regression pin of the oracle itself (the larger golden files are checked on the GPU only)."""
+    g = json.load(open(os.path.join(GOLDEN, name)))
+    if name.startswith("cg"):
+        A = orc.laplace(g["N"], 3)
+        b = orc.hashed_rhs(A.n)
+        runs = {"seq": lambda: orc.cg(A, b, mode="seq"), "tree": lambda: orc.cg(A, b, mode="tree", shape=(1, 1, g["W"], g["L"]))}
+    else:
+        A, b = orc.advdiff(g["N"], 1000.0)
+        runs = {"seq": lambda: orc.gmres(A, b, restart=g["restart"], mode="seq"),
+                "tree": lambda: orc.gmres(A, b, restart=g["restart"], mode="tree", shape=(g["W"], g["L"]))}
+    for mode, run in runs.items():
+        x, h = run()
+        assert h["iters"] == g[mode]["iters"] and h["mvps"] == g[mode]["mvps"] and h["isconverged"] == g[mode]["isconverged"]
+        assert np.array_equal(h["resnorm"], fromhex(g[mode]["resnorm"]))
+        assert float(np.sum(x)).hex() == g[mode]["x_checksum"]
+
+
+def test_golden_noise_floor_is_what_design_md_says():
+    """|seq - tree| / seq of the golden histories = the intrinsic reordering floor quoted in DESIGN.md."""
+    g = json.load(open(os.path.join(GOLDEN, "cg_lap64.json")))
+    s, t = fromhex(g["seq"]["resnorm"]), fromhex(g["tree"]["resnorm"])
+    assert s.size == t.size == 195
+    assert np.max(np.abs(s - t) / s) < 5e-12
