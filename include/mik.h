@@ -29,8 +29,8 @@
  *   level 1: the vector is cut into segments of 256*W*L elements (mik_reduce_shape()); virtual
  *            thread t of a segment sums its elements e -> (e/W)*(256*W) + W*t + e%W in ascending
  *            e, then a wave-64 shuffle-down tree (offsets 32..1), then the 4 wave sums left to
- *            right;  the dot fused into the SpMV (CG's dot(u, c)) uses W = L = 1 (one row per
- *            thread, segment = 256 rows);
+ *            right;  the dot fused into the SpMV (CG's dot(u, c)) uses W = 1 (one row per
+ *            thread) and L = mik_spmv_dot_shape() consecutive 256-row blocks per segment;
  *   level 2: 1024 virtual threads; thread t sums segment sums t, t+1024, ... ascending, wave tree
  *            per 64, then the 16 wave sums left to right.
  *  Multiply and add are never contracted into an FMA (the library is built -ffp-contract=off) and
@@ -80,6 +80,12 @@ int mik_ctx_synchronize(mik_ctx *ctx);
 const char *mik_last_error(mik_ctx *ctx);   /* ctx may be NULL: last error of a failed create */
 /* (W, L) of the level-1 reduction tree for `dtype` (see "Reduction semantics"). */
 int mik_reduce_shape(int dtype, int *W, int *L);
+/* (W, L) of the dot(u, c) fused into the SpMV of the CG step: one row per thread (W = 1), L
+ * consecutive 256-row blocks per workgroup. */
+int mik_spmv_dot_shape(int *W, int *L);
+/* Development knobs (not part of the reference interface): SpMV kernel variants for A/B timing --
+ * key 0: 1 = cached (temporal) val/col/y streams; key 1: 1 = narrow loads; key 2: block map mode. */
+int mik_set_tuning(int key, int value);
 
 /* ---- device memory (similar / zero / copyto! / fill! of the vector interface) ----------- */
 int mik_malloc(mik_ctx *ctx, size_t bytes, void **dptr);            /* similar(x)             */

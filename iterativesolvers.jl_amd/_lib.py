@@ -42,6 +42,8 @@ SIGNATURES = {
     "mik_ctx_synchronize": (C.c_int, [_vp]),
     "mik_last_error": (C.c_char_p, [_vp]),
     "mik_reduce_shape": (C.c_int, [C.c_int, _ip, _ip]),
+    "mik_spmv_dot_shape": (C.c_int, [_ip, _ip]),
+    "mik_set_tuning": (C.c_int, [C.c_int, C.c_int]),
     "mik_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "mik_free": (C.c_int, [_vp, _vp]),
     "mik_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
@@ -95,6 +97,9 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)      # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
+        for kv in filter(None, os.environ.get("MIK_TUNING", "").split(",")):   # development knobs, e.g. "0=1"
+            k, v = kv.split("=")
+            L.mik_set_tuning(int(k), int(v))
         _lib = L
     return _lib
 

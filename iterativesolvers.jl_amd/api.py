@@ -63,6 +63,15 @@ class HipContext:
         check(lib().mik_reduce_shape(dtype_code(dtype), C.byref(w), C.byref(l)), "mik_reduce_shape", self.handle)
         return w.value, l.value
 
+    def spmv_dot_shape(self):
+        w, l = C.c_int(), C.c_int()
+        check(lib().mik_spmv_dot_shape(C.byref(w), C.byref(l)), "mik_spmv_dot_shape", self.handle)
+        return w.value, l.value
+
+    def cg_shape(self, dtype):
+        """(Wd, Ld, W, L): reduction shapes of the fused CG step, as the oracle's `shape` argument."""
+        return self.spmv_dot_shape() + self.reduce_shape(dtype)
+
     def close(self):
         if getattr(self, "handle", None):
             lib().mik_ctx_destroy(self.handle)

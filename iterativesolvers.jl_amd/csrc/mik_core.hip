@@ -5,8 +5,10 @@
 #include <new>
 
 #include "mik_kernels.h"
+#include "mik_spmv.h"
 
 thread_local std::string g_mik_create_error;
+int g_mik_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 int mik_fail(mik_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -117,6 +119,20 @@ extern "C" int mik_ctx_synchronize(mik_ctx *ctx)
 }
 
 extern "C" const char *mik_last_error(mik_ctx *ctx) { return ctx ? ctx->err.c_str() : g_mik_create_error.c_str(); }
+
+extern "C" int mik_spmv_dot_shape(int *W, int *L)
+{
+    if (W) *W = 1;
+    if (L) *L = MIK_SPMV_G;
+    return MIK_OK;
+}
+
+extern "C" int mik_set_tuning(int key, int value)
+{
+    if (key < 0 || key >= 8) return MIK_ERR_INVALID;
+    g_mik_tuning[key] = value;
+    return MIK_OK;
+}
 
 extern "C" int mik_reduce_shape(int dtype, int *W, int *L)
 {
@@ -244,8 +260,13 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
         if (nnz) memcpy(v.data(), val, (size_t)nnz * es);
     }
 
+    int max_rb = 0;
+    for (int64_t r0 = 0; r0 < n_rows; r0 += MIK_BLOCK)
+        max_rb = std::max(max_rb, rowptr[std::min<int64_t>(r0 + MIK_BLOCK, n_rows)] - rowptr[r0]);
+
     mik_csr *A = new (std::nothrow) mik_csr();
     if (!A) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host allocation failed");
+    A->max_rowblock_nnz = max_rb;
     A->ctx = ctx; A->dtype = dtype; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz; A->max_row_nnz = max_row;
     const size_t pad = MIK_SPMV_TILE;   // slack so tile-granular reads never leave the allocation
     auto cleanup = [&]() { mik_csr_destroy(A); };
@@ -299,13 +320,24 @@ int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_
 {
     const int n = (int)A->n_rows;
     if (n == 0) return MIK_OK;
-    const int nb = (n + MIK_BLOCK - 1) / MIK_BLOCK;
-    if (fuse_dot)
-        hipLaunchKernelGGL((k_spmv_rowblock<T, true>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, A->rowptr, A->col,
-                           (const T *)A->val, x, y, seg_out, done);
-    else
-        hipLaunchKernelGGL((k_spmv_rowblock<T, false>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, A->rowptr, A->col,
-                           (const T *)A->val, x, y, seg_out, done);
+    // development knobs (mik_set_tuning): [0] 1 = temporal (cached) streams, [1] 1 = narrow loads,
+    // [2] block map (0 identity, 1 contiguous range per XCD)
+    const int nb = (int)mik_spmv_nwg(n);
+    const bool nt = g_mik_tuning[0] == 0;
+    const bool wide = g_mik_tuning[1] == 0;
+    const int map_mode = g_mik_tuning[2];
+    const dim3 grid(nb), block(MIK_BLOCK);
+#define MIK_SPMV_GO(FD, NT, WD)                                                                              \
+    hipLaunchKernelGGL((k_spmv_rowblock<T, FD, NT, WD>), grid, block, 0, ctx->stream, n, nb, map_mode, A->rowptr, \
+                       A->col, (const T *)A->val, x, y, seg_out, done)
+#define MIK_SPMV_GO2(FD)                                                          \
+    do {                                                                          \
+        if (nt) { if (wide) MIK_SPMV_GO(FD, true, true); else MIK_SPMV_GO(FD, true, false); }   \
+        else    { if (wide) MIK_SPMV_GO(FD, false, true); else MIK_SPMV_GO(FD, false, false); } \
+    } while (0)
+    if (fuse_dot) MIK_SPMV_GO2(true); else MIK_SPMV_GO2(false);
+#undef MIK_SPMV_GO2
+#undef MIK_SPMV_GO
     MIK_LAUNCH_CHECK(ctx);
     return MIK_OK;
 }
@@ -323,8 +355,7 @@ extern "C" int mik_spmv(mik_ctx *ctx, const mik_csr *A, const void *x, void *y)
 template <typename T>
 static int time_spmv_impl(mik_ctx *ctx, const mik_csr *A, const void *x, void *y, int fused, int reps, double *avg_ms)
 {
-    const int64_t nb = (A->n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
-    int rc = mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(nb, 1));
+    int rc = mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>((A->n_rows + MIK_BLOCK - 1) / MIK_BLOCK, 1));
     if (rc) return rc;
     hipEvent_t e0, e1;
     MIK_HIP(ctx, hipEventCreate(&e0));

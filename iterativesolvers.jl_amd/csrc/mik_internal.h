@@ -17,6 +17,7 @@ constexpr int MIK_BLOCK = 256;       // threads per workgroup = 4 wave-64
 constexpr int MIK_RED_L = 2;         // 16-byte loads per thread per segment
 constexpr int MIK_FIN_THREADS = 1024;
 constexpr int MIK_SPMV_TILE = 2048;  // nnz staged in LDS per row-block pass
+constexpr int MIK_SPMV_G = 1;        // row-blocks per SpMV workgroup (= L of the fused-dot tree); >1 measured slower
 constexpr int MIK_MAX_GRID = 256 * 8 * 4;
 
 template <typename T> struct VT;
@@ -46,9 +47,11 @@ struct mik_csr {
     int *col = nullptr;              // device, nnz (+ padding)
     void *val = nullptr;             // device, nnz (+ padding)
     int max_row_nnz = 0;
+    int max_rowblock_nnz = 0;        // largest nnz of any 256-row block; <= MIK_SPMV_TILE selects the pipelined kernel
 };
 
 extern thread_local std::string g_mik_create_error;
+extern int g_mik_tuning[8];   // development knobs (mik_set_tuning), see mik_spmv_launch
 
 int mik_fail(mik_ctx *ctx, int code, const char *fmt, ...);
 int mik_ensure_partials(mik_ctx *ctx, size_t bytes);
@@ -74,6 +77,13 @@ static inline bool mik_aligned16(const void *p) { return (reinterpret_cast<uintp
 static inline size_t mik_dtype_size(int dtype) { return dtype == MIK_F64 ? 8 : 4; }
 
 // number of level-1 segments of an n-vector for dtype T
+// number of SpMV workgroups (= fused-dot segment sums) for n rows
+static inline int64_t mik_spmv_nwg(int64_t n)
+{
+    const int64_t rows = (int64_t)MIK_BLOCK * MIK_SPMV_G;
+    return (n + rows - 1) / rows;
+}
+
 template <typename T> static inline int64_t mik_nseg(int64_t n)
 {
     const int64_t seg = (int64_t)MIK_BLOCK * VT<T>::W * MIK_RED_L;
@@ -140,14 +150,34 @@ template <typename T> __device__ __forceinline__ T block_tree_1024(T v, T *lds16
 // level 2: sum of m segment sums with the fixed 1024-thread shape; result valid in thread 0
 template <typename T> __device__ __forceinline__ T level2_sum(const T *__restrict__ S, int64_t m, T *lds16)
 {
+    // Same ascending-j order as `for j: acc += S[j]`, but 32 (then 8) independent loads are issued before the
+    // dependent add chain consumes them (a single workgroup is latency-bound, not bandwidth-bound).
     T acc = T(0);
-    for (int64_t j = threadIdx.x; j < m; j += MIK_FIN_THREADS) acc = acc + S[j];
+    int64_t j = threadIdx.x;
+    for (; j + 31 * (int64_t)MIK_FIN_THREADS < m; j += 32 * (int64_t)MIK_FIN_THREADS) {
+        T v[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v[q] = S[j + q * (int64_t)MIK_FIN_THREADS];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) acc = acc + v[q];
+    }
+    for (; j + 7 * (int64_t)MIK_FIN_THREADS < m; j += 8 * (int64_t)MIK_FIN_THREADS) {
+        T v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = S[j + q * (int64_t)MIK_FIN_THREADS];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = acc + v[q];
+    }
+    for (; j < m; j += MIK_FIN_THREADS) acc = acc + S[j];
     return block_tree_1024(acc, lds16);
 }
 
-// correctly rounded square root (IEEE): the product path needs sqrt(rr) to match the host's
-__device__ __forceinline__ double mik_sqrt(double x) { return __dsqrt_rn(x); }
-__device__ __forceinline__ float mik_sqrt(float x) { return __fsqrt_rn(x); }
+// correctly rounded square root (IEEE): the product path needs sqrt(rr) to match the host's.
+// NB: HIP's __fsqrt_rn is __ocml_native_sqrt_f32 (NOT correctly rounded) unless
+// OCML_BASIC_ROUNDED_OPERATIONS is defined; sqrtf()/sqrt() lower to the correctly rounded OCML
+// routines (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt).
+__device__ __forceinline__ double mik_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float mik_sqrt(float x) { return sqrtf(x); }
 
 // block -> row-block map that hands every XCD (block b runs on XCD b % 8) one contiguous range
 __device__ __forceinline__ int xcd_remap(int b, int nb)

@@ -315,87 +315,6 @@ __global__ __launch_bounds__(MIK_FIN_THREADS) void k_finalize_nrm_inv(const T *_
 }
 
 // =============================================================================================
-// CSR SpMV: row-block workgroups, LDS-staged products, serial per-row sums
-// =============================================================================================
-//
-// A workgroup owns 256 consecutive rows (one per thread).  The rows' nonzeros form one contiguous
-// range of the CSR arrays; the workgroup streams it in tiles of MIK_SPMV_TILE entries with
-// fully coalesced loads of val[] (8 B/lane) and col[] (4 B/lane), gathers x[col] (L2 / Infinity
-// Cache hits for stencil matrices), and parks the products in LDS.  Each thread then adds up its
-// own row's products from LDS in ascending column order -- the same order in which the reference's
-// CSC column scatter reaches that row -- so y is bit-identical to the oracle.  For the 7-point
-// stencil the per-thread LDS stride is 7 doubles = 14 banks, conflict-free for ds_read_b64.
-//
-// FUSE_DOT adds CG's dot(u, c) (src/cg.jl:55) as an epilogue: p = x[row] * y[row] per thread,
-// block tree, one segment sum per row-block (W = L = 1 shape).
-//
-// Block -> row-block mapping is XCD-aware: the 8 XCDs (private 4 MiB L2 each) walk 8 disjoint
-// contiguous row ranges, so the x-window a stencil touches is shared inside one L2.
-
-template <typename T, bool FUSE_DOT>
-__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, const int *__restrict__ rowptr,
-                                                             const int *__restrict__ col, const T *__restrict__ val,
-                                                             const T *__restrict__ x, T *__restrict__ y,
-                                                             T *__restrict__ seg_out, const int *__restrict__ done)
-{
-    if (done && *done) return;
-    constexpr int TILE = MIK_SPMV_TILE;
-    constexpr int PER = TILE / MIK_BLOCK;
-    __shared__ T prod[TILE];
-    __shared__ T lds4[4];
-
-    const int t = threadIdx.x;
-    const int rb = xcd_remap(blockIdx.x, nb);
-    const int r0 = rb * MIK_BLOCK;
-    const int r = r0 + t;
-    const int rlast = min(r0 + MIK_BLOCK, n);
-    int ks = 0, ke = 0;
-    if (r < n) { ks = rowptr[r]; ke = rowptr[r + 1]; }
-    const int kb = rowptr[r0];
-    const int kend = rowptr[rlast];
-
-    T acc = T(0);
-    for (int kc = kb; kc < kend; kc += TILE) {
-        const int cnt = min(TILE, kend - kc);
-        // ---- stage: coalesced stream of val/col, gather of x, products into LDS ----
-        T v[PER];
-        int c[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int j = t + MIK_BLOCK * i;
-            if (j < cnt) { v[i] = val[kc + j]; c[i] = col[kc + j]; }
-        }
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int j = t + MIK_BLOCK * i;
-            if (j < cnt) prod[j] = v[i] * x[c[i]];
-        }
-        __syncthreads();
-        // ---- per-row serial sum, ascending column order ----
-        int a = max(ks, kc) - kc;
-        int len = min(ke, kc + cnt) - kc - a;
-        while (len > 0) {
-            T q[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) q[i] = prod[min(a + i, TILE - 1)];
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (i < len) acc = acc + q[i];
-            a += 8;
-            len -= 8;
-        }
-        __syncthreads();
-    }
-    if (r < n) y[r] = acc;
-    if (FUSE_DOT) {
-        T p = T(0);
-        if (r < n) p = x[r] * acc;
-        T tot = block_tree_256(p, lds4);
-        if (t == 0) seg_out[rb] = tot;
-    }
-}
-
-// =============================================================================================
 // batched dot (gemv-T) and axpy sweep (gemv-N) over the Krylov basis
 // =============================================================================================
 

@@ -259,6 +259,15 @@ template <typename T> struct CgDev {
     int done, nhist;
 };
 
+// Host-mapped (pinned, device-visible) mirror of the scalars the host needs after a step.  The
+// closing finalise kernel of every step stores it with system scope and then publishes `seq`;
+// the host polls `seq` instead of paying a D2H copy kernel + hipStreamSynchronize per iteration.
+struct CgMirror {
+    double res, prev_res;
+    int done, nhist;
+    unsigned long long seq;
+};
+
 // after norm(r) of cg_iterator! (src/cg.jl:140-152)
 template <typename T>
 __global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_init(const T *__restrict__ S, int64_t m, CgDev<T> *d, T reltol, T abstol,
@@ -314,9 +323,14 @@ __global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_rho(const T *__restr
 // iterate() call (iteration index `it_next`)
 template <typename T>
 __global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_res(const T *__restrict__ S, int64_t m, CgDev<T> *d, T *__restrict__ hist,
-                                                                long long it_next, long long maxiter)
+                                                                long long it_next, long long maxiter, CgMirror *mirror,
+                                                                unsigned long long seq)
 {
-    if (d->done) return;
+    if (d->done) {
+        // a no-op step (the stopping test fired earlier in this batch): still publish, state unchanged
+        if (threadIdx.x == 0) __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     __shared__ T lds16[16];
     T tot = level2_sum(S, m, lds16);
     if (threadIdx.x == 0) {
@@ -327,8 +341,15 @@ __global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_res(const T *__restr
         d->res = res;
         d->beta = (res * res) / (prev * prev);    // :50 of the next step
         hist[d->nhist] = res;
-        d->nhist = d->nhist + 1;
-        if (it_next >= maxiter || res <= d->tol) d->done = 1;
+        const int nh = d->nhist + 1;
+        d->nhist = nh;
+        const int dn = (it_next >= maxiter || res <= d->tol) ? 1 : 0;
+        if (dn) d->done = 1;
+        mirror->res = (double)res;
+        mirror->prev_res = (double)prev;
+        mirror->done = dn;
+        mirror->nhist = nh;
+        __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -346,6 +367,9 @@ struct mik_cg {
     void *seg_vec = nullptr;   // one partial per vector segment
     double residual = 0, prev_residual = 1, tol = 0;
     int64_t maxiter = 0, mv_products = 0;
+    CgMirror *mirror = nullptr;      // host-mapped; same pointer is valid on the device
+    unsigned long long seq = 0;      // steps enqueued so far (published by k_cg_fin_res)
+    bool dev_done = false;           // device stopping flag known to be set
     // optional in-loop timing of the SpMV launch (HIP events on the ctx stream)
     bool profile = false;
     std::vector<hipEvent_t> ev;    // pairs (start, stop), recycled
@@ -378,7 +402,7 @@ template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next)
     const int *done = &d->done;
     const int64_t n = it->n;
     const int64_t nseg = mik_nseg<T>(n);
-    const int64_t nb = (n + MIK_BLOCK - 1) / MIK_BLOCK;
+    const int64_t nb = mik_spmv_nwg(n);
     T *x = (T *)it->x, *u = (T *)it->u, *r = (T *)it->r, *c = (T *)it->c;
     const bool vec = mik_aligned16(x) && mik_aligned16(u) && mik_aligned16(r) && mik_aligned16(c) && (!it->diag || mik_aligned16(it->diag));
     const int pcg = it->diag ? 1 : 0;
@@ -405,10 +429,32 @@ template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next)
     // x .+= alpha .* u; r .-= alpha .* c; norm(r)                       src/cg.jl:58-62
     OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha)};
     MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done)));
+    it->seq += 1;
     hipLaunchKernelGGL((k_cg_fin_res<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)it->seg_vec, nseg, d, (T *)it->hist,
-                       it_next, (long long)it->maxiter);
+                       it_next, (long long)it->maxiter, it->mirror, it->seq);
     MIK_LAUNCH_CHECK(ctx);
     return MIK_OK;
+}
+
+// Wait until the device has published step `seq` in the host-mapped mirror (bounded spin).
+static int cg_wait_mirror(mik_cg *it)
+{
+    volatile unsigned long long *p = &it->mirror->seq;
+    const unsigned long long want = it->seq;
+    for (unsigned long long spins = 0;; ++spins) {
+        if (__atomic_load_n((const unsigned long long *)p, __ATOMIC_ACQUIRE) == want) return MIK_OK;
+        if ((spins & 0xFFFFF) == 0xFFFFF) {   // every ~1M polls: has the stream died or finished without publishing?
+            hipError_t e = hipStreamQuery(it->ctx->stream);
+            if (e == hipSuccess) {
+                if (__atomic_load_n((const unsigned long long *)p, __ATOMIC_ACQUIRE) == want) return MIK_OK;
+                return mik_fail(it->ctx, MIK_ERR_HIP, "cg: stream idle but step %llu was never published", want);
+            }
+            if (e != hipErrorNotReady) return mik_fail(it->ctx, MIK_ERR_HIP, "cg: %s while waiting for a step", hipGetErrorString(e));
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
 }
 
 template <typename T> static int cg_fetch_state(mik_cg *it, CgDev<T> *host)
@@ -449,6 +495,7 @@ static int cg_init_impl(mik_cg *it, double abstol, double reltol, int initially_
     it->residual = (double)h.res;
     it->prev_residual = (double)h.prev_res;
     it->tol = (double)h.tol;
+    it->dev_done = h.done != 0;
     return MIK_OK;
 }
 
@@ -468,7 +515,7 @@ extern "C" int mik_cg_create(mik_ctx *ctx, const mik_csr *A, void *x, const void
     it->maxiter = maxiter;
     const size_t es = mik_dtype_size(A->dtype);
     const int64_t nseg = A->dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
-    const int64_t nb = (n + MIK_BLOCK - 1) / MIK_BLOCK;
+    const int64_t nb = mik_spmv_nwg(n);
     hipError_t e;
     (void)hipSetDevice(ctx->device);
     if ((e = hipMalloc(&it->dev, 256)) != hipSuccess || (e = hipMalloc(&it->seg_spmv, es * (size_t)std::max<int64_t>(nb, 1))) != hipSuccess ||
@@ -478,6 +525,11 @@ extern "C" int mik_cg_create(mik_ctx *ctx, const mik_csr *A, void *x, const void
         return mik_fail(ctx, MIK_ERR_NOMEM, "mik_cg_create: hipMalloc: %s", hipGetErrorString(e));
     }
     it->hist_cap = 64;
+    if ((e = hipHostMalloc((void **)&it->mirror, sizeof(CgMirror), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) {
+        mik_cg_destroy(it);
+        return mik_fail(ctx, MIK_ERR_NOMEM, "mik_cg_create: hipHostMalloc: %s", hipGetErrorString(e));
+    }
+    memset(it->mirror, 0, sizeof(CgMirror));
     int rc = A->dtype == MIK_F64 ? cg_init_impl<double>(it, abstol, reltol, initially_zero)
                                  : cg_init_impl<float>(it, abstol, reltol, initially_zero);
     if (rc) { mik_cg_destroy(it); return rc; }
@@ -494,6 +546,7 @@ extern "C" int mik_cg_destroy(mik_cg *it)
     if (it->seg_spmv) (void)hipFree(it->seg_spmv);
     if (it->seg_vec) (void)hipFree(it->seg_vec);
     for (hipEvent_t e : it->ev) (void)hipEventDestroy(e);
+    if (it->mirror) (void)hipHostFree(it->mirror);
     delete it;
     return MIK_OK;
 }
@@ -514,18 +567,27 @@ static int cg_iterate_many_impl(mik_cg *it, int64_t iteration, int64_t max_steps
         it->hist_cap = max_steps;
     }
     CgDev<T> *d = (CgDev<T> *)it->dev;
-    MIK_HIP(ctx, hipMemsetAsync(&d->done, 0, 2 * sizeof(int), ctx->stream));   // done = 0, nhist = 0
+    // nhist = 0 for this call; the stopping flag only needs clearing if a previous call left it set
+    // (the host test above said "not done", e.g. the caller restarted the iteration count)
+    if (it->dev_done) MIK_HIP(ctx, hipMemsetAsync(&d->done, 0, 2 * sizeof(int), ctx->stream));
+    else MIK_HIP(ctx, hipMemsetAsync(&d->nhist, 0, sizeof(int), ctx->stream));
     for (int64_t j = 0; j < max_steps; ++j) MIK_TRY(cg_enqueue_step<T>(it, (long long)(iteration + j + 1)));
-    CgDev<T> h;
-    MIK_TRY(cg_fetch_state<T>(it, &h));
-    const int64_t nd = h.nhist;
-    if (nd > 0) {
+    MIK_TRY(cg_wait_mirror(it));
+    const CgMirror m = *it->mirror;
+    const int64_t nd = m.nhist;
+    if (nd == 1) {
+        if (residuals) residuals[0] = m.res;
+    } else if (nd > 1) {
         std::vector<T> tmp((size_t)nd);
-        MIK_HIP(ctx, hipMemcpy(tmp.data(), it->hist, sizeof(T) * (size_t)nd, hipMemcpyDeviceToHost));
+        MIK_HIP(ctx, hipMemcpyAsync(tmp.data(), it->hist, sizeof(T) * (size_t)nd, hipMemcpyDeviceToHost, ctx->stream));
+        MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (residuals) for (int64_t j = 0; j < nd; ++j) residuals[j] = (double)tmp[j];
     }
-    it->residual = (double)h.res;
-    it->prev_residual = (double)h.prev_res;
+    if (nd > 0) {
+        it->residual = m.res;
+        it->prev_residual = m.prev_res;
+    }
+    it->dev_done = m.done != 0;
     it->mv_products += nd;
     *steps_done = nd;
     if (it->profile) cg_profile_collect(it);

@@ -1,0 +1,145 @@
+// mik_spmv.h -- CSR SpMV for gfx950: row-block workgroups, LDS-staged products, serial row sums.
+//
+// y = A*x replaces SparseArrays' mul!(y, A::SparseMatrixCSC, x) at src/cg.jl:54,137 and
+// src/gmres.jl:245,287 (the reference's bottleneck: a serial column scatter over Int64 indices).
+//
+// Layout.  A workgroup of 256 threads owns one row-block of 256 consecutive rows (one row per
+// thread).  The nonzeros of a row-block are one contiguous range of the CSR arrays; the workgroup
+// streams it in tiles of MIK_SPMV_TILE entries with fully coalesced loads of val[] and col[],
+// gathers x[col] (L1/L2/Infinity-Cache hits for stencil matrices) and parks the products in LDS.
+// Each thread then adds up its own row's products from LDS in ascending column order -- the order
+// in which the reference's CSC column scatter reaches that row -- so y is bit-identical to the
+// oracle.  For the 7-point stencil the per-thread LDS stride is 7 doubles = 14 banks:
+// conflict-free for ds_read_b64.
+//
+// What was measured on MI355X (256^3 Laplacian, profiles/ and DESIGN.md):
+//  * one row-block per workgroup and ~65k workgroups beats persistent / software-pipelined
+//    variants (the hardware's 8 resident workgroups per CU already overlap the load, gather and
+//    row-sum phases of different row-blocks; a register-prefetching loop cut occupancy to 6 and
+//    lost 15-25 %);
+//  * the val/col/y streams are touched exactly once: non-temporal loads/stores (NT) keep them
+//    from evicting x out of the 4 MiB L2s and cut fabric reads (-8 % time);
+//  * WIDE: 16-byte loads of val and 8/16-byte loads of col (aligned tile start) halve the number
+//    of vector-memory instructions per tile.
+//
+// FUSE_DOT adds CG's dot(u, c) (src/cg.jl:55) as an epilogue: p = x[row] * y[row] per thread,
+// block tree, one segment sum per row-block: the (W, L) = (1, 1) reduction shape of include/mik.h.
+#pragma once
+#include "mik_internal.h"
+
+#ifdef __HIPCC__
+
+// streamed-once data (val, col, y) can bypass cache retention so that x keeps its place in L2
+template <bool NT, typename U> __device__ __forceinline__ U ld_stream(const U *p)
+{
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT, typename U> __device__ __forceinline__ void st_stream(U *p, U v)
+{
+    if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
+// native clang vectors (the non-temporal builtins reject HIP's struct-based double2 / int4)
+typedef double mik_f64x2 __attribute__((ext_vector_type(2)));
+typedef float mik_f32x4 __attribute__((ext_vector_type(4)));
+typedef int mik_i32x2 __attribute__((ext_vector_type(2)));
+typedef int mik_i32x4 __attribute__((ext_vector_type(4)));
+template <typename T> struct WideVec;
+template <> struct WideVec<double> { using val = mik_f64x2; using idx = mik_i32x2; };
+template <> struct WideVec<float>  { using val = mik_f32x4; using idx = mik_i32x4; };
+
+// block -> row-block map.  mode 0: identity (block b runs on XCD b % 8, so the 8 XCDs interleave
+// row-blocks; rows +-N^2 of a stencil then live in the SAME XCD whenever the plane size is a
+// multiple of 8 row-blocks).  mode 1: contiguous range per XCD.
+__device__ __forceinline__ int spmv_block_map(int b, int nb, int mode) { return mode == 1 ? xcd_remap(b, nb) : b; }
+
+template <typename T, bool FUSE_DOT, bool NT, bool WIDE>
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int map_mode, const int *__restrict__ rowptr,
+                                                             const int *__restrict__ col, const T *__restrict__ val,
+                                                             const T *__restrict__ x, T *__restrict__ y,
+                                                             T *__restrict__ seg_out, const int *__restrict__ done)
+{
+    if (done && *done) return;
+    constexpr int TILE = MIK_SPMV_TILE;
+    constexpr int VW = WIDE ? VT<T>::W : 1;            // elements per lane per load
+    constexpr int PER = TILE / (MIK_BLOCK * VW);       // loads per lane per tile
+    __shared__ T prod[TILE];
+    __shared__ T lds4[4];
+
+    const int t = threadIdx.x;
+    const int rb = spmv_block_map(blockIdx.x, nb, map_mode);
+    const int r0 = rb * MIK_BLOCK;
+    const int r = r0 + t;
+    int ks = 0, ke = 0;
+    if (r < n) { ks = rowptr[r]; ke = rowptr[r + 1]; }
+    const int kb = rowptr[r0] & ~(VW - 1);             // tile start aligned for the wide loads
+    const int kend = rowptr[min(r0 + MIK_BLOCK, n)];
+
+    T acc = T(0);
+    for (int kc = kb; kc < kend; kc += TILE) {
+        const int cnt = min(TILE, kend - kc);
+        // ---- stage: coalesced stream of val/col, gather of x, products into LDS ----
+        if (WIDE) {
+            using VV = typename WideVec<T>::val;
+            using IV = typename WideVec<T>::idx;
+            VV v[PER];
+            IV c[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int j = VW * (t + MIK_BLOCK * i);
+                if (j < cnt) {      // reads past kend stay inside the padded allocation
+                    v[i] = ld_stream<NT>(reinterpret_cast<const VV *>(val + kc + j));
+                    c[i] = ld_stream<NT>(reinterpret_cast<const IV *>(col + kc + j));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int j = VW * (t + MIK_BLOCK * i);
+                if (j < cnt) {
+                    T xv[VW];
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) xv[e] = x[c[i][e]];   // padding cols are 0
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) prod[j + e] = v[i][e] * xv[e];
+                }
+            }
+        } else {
+            T v[PER];
+            int c[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int j = t + MIK_BLOCK * i;
+                if (j < cnt) { v[i] = ld_stream<NT>(val + kc + j); c[i] = ld_stream<NT>(col + kc + j); }
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int j = t + MIK_BLOCK * i;
+                if (j < cnt) prod[j] = v[i] * x[c[i]];
+            }
+        }
+        __syncthreads();
+        // ---- per-row serial sum, ascending column order ----
+        int a = max(ks, kc) - kc;
+        int len = min(ke, kc + cnt) - kc - a;
+        while (len > 0) {
+            T q[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[i] = prod[min(a + i, TILE - 1)];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < len) acc = acc + q[i];
+            a += 8;
+            len -= 8;
+        }
+        __syncthreads();
+    }
+    if (r < n) st_stream<NT>(y + r, acc);
+    if (FUSE_DOT) {
+        T p = T(0);
+        if (r < n) p = x[r] * acc;
+        T tot = block_tree_256(p, lds4);
+        if (t == 0) seg_out[rb] = tot;
+    }
+}
+
+#endif  // __HIPCC__

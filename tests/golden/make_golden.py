@@ -21,6 +21,7 @@ sys.path.insert(0, os.path.join(HERE, "..", ".."))
 from oracle import orc  # noqa: E402
 
 W, L = 2, 2          # mik_reduce_shape(MIK_F64) at the time of generation
+LD = 1               # mik_spmv_dot_shape() -> (1, LD): the dot(u, c) fused into the CG SpMV
 
 
 def hexlist(a):
@@ -36,9 +37,9 @@ def dump(name, obj):
 def cg_case(N, maxiter=None):
     A = orc.laplace(N, 3)
     b = orc.hashed_rhs(A.n)
-    out = dict(case=f"cg(laplace_matrix(Float64,{N},3), hashed_rhs) reltol=sqrt(eps) abstol=0", N=N, W=W, L=L,
+    out = dict(case=f"cg(laplace_matrix(Float64,{N},3), hashed_rhs) reltol=sqrt(eps) abstol=0", N=N, W=W, L=L, Ld=LD,
                maxiter=maxiter)
-    for mode, shape in (("seq", (1, 1, 1, 1)), ("tree", (1, 1, W, L))):
+    for mode, shape in (("seq", (1, 1, 1, 1)), ("pair", (1, 1, 1, 1)), ("tree", (1, LD, W, L))):
         x, h = orc.cg(A, b, maxiter=maxiter, mode=mode, shape=shape)
         out[mode] = dict(iters=h["iters"], mvps=h["mvps"], isconverged=h["isconverged"], res0=float(h["res0"]).hex(),
                          tol=float(h["tol"]).hex(), resnorm=hexlist(h["resnorm"]),
@@ -50,7 +51,7 @@ def gmres_case(N, restart):
     A, b = orc.advdiff(N, 1000.0)
     out = dict(case=f"gmres(advection_dominated(N={N}, beta=1000), restart={restart})", N=N, restart=restart, W=W, L=L,
                b_from="oracle/orc_advdiff_csc (glibc exp/sin)")
-    for mode, shape in (("seq", (1, 1)), ("tree", (W, L))):
+    for mode, shape in (("seq", (1, 1)), ("pair", (1, 1)), ("tree", (W, L))):
         x, h = orc.gmres(A, b, restart=restart, mode=mode, shape=shape)
         out[mode] = dict(iters=h["iters"], mvps=h["mvps"], isconverged=h["isconverged"], res0=float(h["res0"]).hex(),
                          tol=float(h["tol"]).hex(), resnorm=hexlist(h["resnorm"]),

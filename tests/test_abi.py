@@ -44,6 +44,7 @@ def test_reduce_shape_is_exported_constant(pkg):
     assert L.mik_reduce_shape(0, C.byref(w), C.byref(l)) == 0 and (w.value, l.value) == (2, 2)
     assert L.mik_reduce_shape(1, C.byref(w), C.byref(l)) == 0 and (w.value, l.value) == (4, 2)
     assert L.mik_reduce_shape(7, C.byref(w), C.byref(l)) == 1
+    assert L.mik_spmv_dot_shape(C.byref(w), C.byref(l)) == 0 and (w.value, l.value) == (1, 1)
 
 
 def test_no_device_fails_loudly_not_silently(pkg):

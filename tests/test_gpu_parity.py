@@ -151,7 +151,7 @@ def test_cg_history_bit_exact_vs_tree_oracle(pkg, orc, ctx, N):
     b = orc.hashed_rhs(A.n)
     W, L = shape_of(ctx, np.float64)
     x, ch = pkg.cg(upload(pkg, A), pkg.HipVector.from_numpy(b), log=True)
-    xo, ho = orc.cg(A, b, mode="tree", shape=(1, 1, W, L))
+    xo, ho = orc.cg(A, b, mode="tree", shape=ctx.cg_shape(np.float64))
     assert ch.iters == ho["iters"] and ch.mvps == ho["mvps"] and ch.isconverged == ho["isconverged"]
     assert np.array_equal(ch["resnorm"], ho["resnorm"])
     assert np.array_equal(x.to_numpy(), xo)
@@ -173,7 +173,7 @@ def test_cg_golden_64(pkg, ctx):
     assert ch.iters == g["seq"]["iters"] == 195 and ch.isconverged
     seq = fromhex(g["seq"]["resnorm"])
     assert np.max(np.abs(ch["resnorm"] - seq) / seq) <= 3e-12          # floor at 64^3 is 5.7e-13 (seq vs pair)
-    if (g["W"], g["L"]) == ctx.reduce_shape(np.float64):
+    if (1, g["Ld"], g["W"], g["L"]) == ctx.cg_shape(np.float64):
         assert np.array_equal(ch["resnorm"], fromhex(g["tree"]["resnorm"]))
         assert float(np.sum(x.to_numpy())).hex() == g["tree"]["x_checksum"]
 
@@ -197,9 +197,9 @@ def test_cg_reference_properties(pkg, orc, ctx):
     assert pkg.niters(hJAC) == pkg.niters(hCG)                                                    # :85
     # bit-exact against the oracle for both, including the starting-guess SpMV (mvps = 1 + iters)
     W, L = shape_of(ctx, np.float64)
-    _, ho = orc.cg(A, rhs, x0, abstol=1e-5, reltol=0.0, maxiter=100, mode="tree", shape=(1, 1, W, L))
+    _, ho = orc.cg(A, rhs, x0, abstol=1e-5, reltol=0.0, maxiter=100, mode="tree", shape=ctx.cg_shape(np.float64))
     assert np.array_equal(hCG["resnorm"], ho["resnorm"]) and hCG.mvps == ho["mvps"]
-    _, hj = orc.cg(A, rhs, x0, abstol=1e-5, reltol=0.0, maxiter=100, jacobi_diag=S.diagonal(), mode="tree", shape=(1, 1, W, L))
+    _, hj = orc.cg(A, rhs, x0, abstol=1e-5, reltol=0.0, maxiter=100, jacobi_diag=S.diagonal(), mode="tree", shape=ctx.cg_shape(np.float64))
     assert np.array_equal(hJAC["resnorm"], hj["resnorm"]) and hJAC.mvps == hj["mvps"]
 
 
@@ -239,9 +239,8 @@ def test_cg_small_dense_and_edge_cases(pkg, orc, ctx, dtype):
 def test_cg_fp32_history_bit_exact(pkg, orc, ctx):
     A = orc.laplace(12, 3).astype(np.float32)
     b = orc.hashed_rhs(A.n).astype(np.float32)
-    W, L = shape_of(ctx, np.float32)
     x, ch = pkg.cg(upload(pkg, A), pkg.HipVector.from_numpy(b), log=True)
-    xo, ho = orc.cg(A, b, mode="tree", shape=(1, 1, W, L))
+    xo, ho = orc.cg(A, b, mode="tree", shape=ctx.cg_shape(np.float32))
     assert ch.iters == ho["iters"] and np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
 
 
@@ -329,11 +328,18 @@ def test_gmres_golden_config3(pkg, ctx):
     from __graft_entry__ import load_oracle
     A, b = load_oracle().advdiff(50, 1000.0)              # same b as the golden run (glibc exp/sin)
     x, ch = pkg.gmres(upload(pkg, A), pkg.HipVector.from_numpy(b), restart=30, log=True)
-    seq = fromhex(g["seq"]["resnorm"])
+    seq, pair = fromhex(g["seq"]["resnorm"]), fromhex(g["pair"]["resnorm"])
     assert abs(ch.iters - g["seq"]["iters"]) <= 2 and ch.isconverged
-    assert np.max(np.abs(ch["resnorm"][:30] - seq[:30]) / seq[:30]) <= 1e-12     # first cycle
-    m = min(ch.iters, seq.size)
-    assert np.max(np.abs(ch["resnorm"][:m] - seq[:m]) / seq[:m]) <= 1e-6         # restart-sensitivity band
+    # first restart cycle: <= 1e-12 against both CPU summation orders
+    assert np.max(np.abs(ch["resnorm"][:30] - seq[:30]) / seq[:30]) <= 1e-12
+    assert np.max(np.abs(ch["resnorm"][:30] - pair[:30]) / pair[:30]) <= 1e-12
+    # after restarts GMRES amplifies rounding differences (DESIGN.md "restart sensitivity"): the two CPU
+    # orders themselves differ by `floor`; the device history must sit inside that band
+    m = min(ch.iters, seq.size, pair.size)
+    floor = np.max(np.abs(seq[:m] - pair[:m]) / seq[:m])
+    assert 1e-8 < floor < 1e-4
+    assert np.max(np.abs(ch["resnorm"][:m] - seq[:m]) / seq[:m]) <= 3 * floor
+    assert np.max(np.abs(ch["resnorm"][:m] - pair[:m]) / pair[:m]) <= 3 * floor
     if (g["W"], g["L"]) == ctx.reduce_shape(np.float64):
         assert ch.iters == g["tree"]["iters"] and ch.mvps == g["tree"]["mvps"]
         assert np.array_equal(ch["resnorm"], fromhex(g["tree"]["resnorm"]))
@@ -408,9 +414,13 @@ def test_full_size_256_properties_and_golden_prefix(pkg, ctx):
     # (3) first 40 CG residuals against the committed golden prefix generated by the oracle
     gold = json.load(open(os.path.join(GOLDEN, "cg_lap256_first40.json")))
     x, ch = pkg.cg(A, db, log=True, maxiter=40)
-    seq = fromhex(gold["seq"]["resnorm"])
-    assert ch.iters == 40 and np.max(np.abs(ch["resnorm"] - seq) / seq) <= 1e-12
-    if (gold["W"], gold["L"]) == ctx.reduce_shape(np.float64):
+    seq, pair = fromhex(gold["seq"]["resnorm"]), fromhex(gold["pair"]["resnorm"])
+    # n = 16.7M: a naive left-to-right sum carries ~1e-11 of its own rounding error, so the 1e-12 bar is
+    # held against the pairwise CPU order and the sequential one is checked against the CPU-vs-CPU floor
+    assert ch.iters == 40 and np.max(np.abs(ch["resnorm"] - pair) / pair) <= 1e-12
+    floor = np.max(np.abs(seq - pair) / seq)
+    assert np.max(np.abs(ch["resnorm"] - seq) / seq) <= 3 * floor
+    if (1, gold["Ld"], gold["W"], gold["L"]) == ctx.cg_shape(np.float64):
         assert np.array_equal(ch["resnorm"], fromhex(gold["tree"]["resnorm"]))
     # (4) the recurrence residual equals the true residual after 40 steps (round trip through A)
     r = pkg.HipVector.from_numpy(b)

@@ -75,7 +75,7 @@ def test_oracle_reproduces_golden(orc, name):
     if name.startswith("cg"):
         A = orc.laplace(g["N"], 3)
         b = orc.hashed_rhs(A.n)
-        runs = {"seq": lambda: orc.cg(A, b, mode="seq"), "tree": lambda: orc.cg(A, b, mode="tree", shape=(1, 1, g["W"], g["L"]))}
+        runs = {"seq": lambda: orc.cg(A, b, mode="seq"), "tree": lambda: orc.cg(A, b, mode="tree", shape=(1, g["Ld"], g["W"], g["L"]))}
     else:
         A, b = orc.advdiff(g["N"], 1000.0)
         runs = {"seq": lambda: orc.gmres(A, b, restart=g["restart"], mode="seq"),
