@@ -50,10 +50,11 @@ def main():
     ap.add_argument("--n", type=int, default=256, help="grid points per dimension per GPU (default 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=30)
+    ap.add_argument("--force-dist", action="store_true", help="run the row-partitioned code path even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 or args.gpus > 1:
+    if world > 1 or args.gpus > 1 or args.force_dist:
         from importlib import import_module
         pkg = graft.load_package()
         dist_bench = import_module(pkg.__name__ + ".dist").bench_main

@@ -173,6 +173,34 @@ int mik_gmres_iterate(mik_gmres *it, int64_t iteration, double *residual, int *d
 int mik_gmres_state(const mik_gmres *it, double *residual, double *tol, double *beta, int *k,
                     int64_t *mv_products, int *converged);
 
+/* ---- row-partitioned CGIterable: one process per GPU (new design; the reference is serial) --- */
+/* out[i] = x[idx[i]], i < m (idx: device Int32) -- packs halo entries for the neighbour ranks. */
+int mik_gather(mik_ctx *ctx, int dtype, int64_t m, const int32_t *idx, const void *x, void *out);
+/* Rank `rank` of `nranks` owns a contiguous block of n_loc rows.  A_loc is that block as an
+ * n_loc x (n_loc + n_ghost) operator: columns [0, n_loc) are the owned entries of a vector, columns
+ * [n_loc, n_loc + n_ghost) the halo entries the host receives from the neighbours into the tail of
+ * u_ext before phase 1 / 11.  x, b, r, c: device n_loc-vectors; u_ext: device (n_loc + n_ghost)-
+ * vector; send_idx / send_buf: local indices to pack and the packed buffer (n_send entries);
+ * dot_all / rr_all: device arrays of nranks scalars -- every rank writes slot [rank], the host
+ * all-gathers them between phases (RCCL over xGMI via torch.distributed, gloo in CPU tests).
+ * Sums over ranks run in rank order on every rank, so all ranks hold identical scalars. */
+typedef struct mik_cgd mik_cgd;
+int mik_cgd_create(mik_ctx *ctx, const mik_csr *A_loc, void *x, const void *b, void *u_ext, void *r,
+                   void *c, const int32_t *send_idx, int64_t n_send, void *send_buf, void *dot_all,
+                   void *rr_all, int rank, int nranks, double abstol, double reltol, int64_t maxiter,
+                   int initially_zero, mik_cgd **out);
+int mik_cgd_destroy(mik_cgd *it);
+/* Enqueue one phase (no host synchronisation).  cg_iterator! (src/cg.jl:120-155): 10 = pack x's
+ * halo, [exchange], 11 = r = b - A x and local |r|^2, [all-gather rr], 12 = residual, tolerance.
+ * iterate (src/cg.jl:43-66): 0 = u = r + beta u and pack, [exchange], 1 = c = A u with local
+ * dot(u, c), [all-gather dot], 2 = alpha, x += alpha u, r -= alpha c, local |r|^2, [all-gather rr],
+ * 3 = residual, beta, stopping test of src/cg.jl:36 for iteration + 1 (later steps become no-ops). */
+int mik_cgd_phase(mik_cgd *it, int phase, int64_t iteration);
+/* Wait for everything enqueued; residual / tol / done of the last step and the residuals of the
+ * steps executed since the previous wait (at most 1024 steps may be enqueued between waits). */
+int mik_cgd_wait(mik_cgd *it, double *residual, double *tol, int *done, double *history, int64_t cap,
+                 int64_t *steps);
+
 /* ---- Hessenberg least squares (host) ------------------------------------------------------ */
 /* ldiv!(FastHessenberg(H), rhs) -- src/hessenberg.jl:15-46.  Host arrays of `dtype`; H is
  * (width+1) x width column-major with leading dimension ldh, overwritten by R; rhs has width+1

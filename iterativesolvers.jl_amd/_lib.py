@@ -75,12 +75,41 @@ SIGNATURES = {
     "mik_gmres_destroy": (C.c_int, [_vp]),
     "mik_gmres_iterate": (C.c_int, [_vp, _i64, _f64p, _ip]),
     "mik_gmres_state": (C.c_int, [_vp, _f64p, _f64p, _f64p, _ip, _i64p, _ip]),
+    "mik_gather": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp]),
+    "mik_cgd_create": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, C.c_int, C.c_int,
+                                 C.c_double, C.c_double, _i64, C.c_int, C.POINTER(_vp)]),
+    "mik_cgd_destroy": (C.c_int, [_vp]),
+    "mik_cgd_phase": (C.c_int, [_vp, C.c_int, _i64]),
+    "mik_cgd_wait": (C.c_int, [_vp, _f64p, _f64p, _ip, _f64p, _i64, _i64p]),
     "mik_hessenberg_ldiv": (C.c_int, [C.c_int, _vp, _i64, C.c_int, _vp]),
     "mik_time_spmv": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _f64p]),
     "mik_cg_profile": (C.c_int, [_vp, C.c_int, _f64p, _i64p]),
 }
 
 _lib = None
+
+
+def _share_hip_runtime():
+    """One HIP runtime per process.  libmik.so needs the unversioned "libamdhip64.so" (csrc/Makefile).
+    PyTorch-ROCm bundles its own copy under that name; if torch is installed, map that copy first
+    (without importing torch) so that libmik.so and a later `import torch` both bind to it.  Two
+    different runtimes in one process break whichever initialises second (observed: torch reports
+    "no ROCm-capable device" after the system runtime has opened the GPU).  Without torch the name
+    resolves through libmik.so's RUNPATH to /opt/rocm/lib."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("MIK_NO_TORCH_RUNTIME") == "1":
+        return                                  # torch's runtime is already mapped (or sharing is declined)
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None:
+        return
+    # Importing torch maps its bundled runtime under the bare name "libamdhip64.so", which is what
+    # libmik.so's DT_NEEDED then matches.  (dlopen() of the same file by absolute path does not
+    # register that name, and the system runtime would be loaded beside it.)
+    import torch  # noqa: F401
 
 
 def lib() -> C.CDLL:
@@ -92,6 +121,7 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} not found: the HIP extension has not been built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
                 "There is no CPU fallback for the product path.")
+        _share_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)      # AttributeError if the .so does not export a declared symbol

@@ -5,6 +5,7 @@
 // src/gmres.jl:57-106); all vector arithmetic runs in the kernels of mik_kernels.h.
 #include <algorithm>
 #include <cfloat>
+#include <cstddef>
 #include <cmath>
 #include <new>
 
@@ -263,8 +264,9 @@ template <typename T> struct CgDev {
 // closing finalise kernel of every step stores it with system scope and then publishes `seq`;
 // the host polls `seq` instead of paying a D2H copy kernel + hipStreamSynchronize per iteration.
 struct CgMirror {
-    double res, prev_res;
+    double res, prev_res, tol;
     int done, nhist;
+    int tol_valid, pad;
     unsigned long long seq;
 };
 
@@ -841,5 +843,289 @@ extern "C" int mik_gmres_state(const mik_gmres *g, double *residual, double *tol
     if (k) *k = g->k;
     if (mv_products) *mv_products = g->mv_products;
     if (converged) *converged = g->current <= g->tol ? 1 : 0;            // src/gmres.jl:51
+    return MIK_OK;
+}
+
+// =============================================================================================
+// Row-partitioned CGIterable (one process per GPU)
+// =============================================================================================
+//
+// New design (the reference is single-process): rank p owns a contiguous block of rows; the
+// operator's local block is a CSR matrix whose columns are renumbered to [0, n_loc) for owned
+// entries of x and [n_loc, n_loc + n_ghost) for halo entries received from the neighbours.  The
+// host side (dist.py) runs the exchanges with torch.distributed (RCCL over xGMI on the GPU box,
+// gloo in the CPU tests) between the phases below; every phase only enqueues kernels.
+//
+//   phase 10  init A: (x given) copy x into u_ext, pack the halo send buffer
+//   phase 11  init B: r = b - A*u_ext (or r = b), local sum of r.^2 -> rr_all[rank]; u_ext = 0
+//   phase 12  init C: residual = sqrt(sum_p rr_all[p]), tol, beta; publish
+//   phase  0  step A: u = r + beta*u (src/cg.jl:51); pack the halo send buffer
+//   phase  1  step B: c = A_loc * u_ext with the local dot(u, c) -> dot_all[rank]   (:54-55)
+//   phase  2  step C: alpha = residual^2 / sum_p dot_all[p]; x += alpha*u; r -= alpha*c;
+//                     local sum of r.^2 -> rr_all[rank]                               (:55-59)
+//   phase  3  step D: residual = sqrt(sum_p rr_all[p]) (:62); beta; stopping test; publish
+//
+// Cross-rank sums run in rank order 0..P-1 on every rank, so all ranks hold bit-identical
+// scalars and the history is reproducible (and equals the single-GPU path for P = 1).
+
+template <typename T>
+__global__ void k_gather(int64_t m, const int *__restrict__ idx, const T *__restrict__ x, T *__restrict__ out, const int *__restrict__ done)
+{
+    if (done && *done) return;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) out[i] = x[idx[i]];
+}
+
+template <typename T> static int gather_launch(mik_ctx *ctx, int64_t m, const int *idx, const T *x, T *out, const int *done)
+{
+    if (m <= 0) return MIK_OK;
+    const int grid = (int)std::min<int64_t>((m + MIK_BLOCK - 1) / MIK_BLOCK, MIK_MAX_GRID);
+    hipLaunchKernelGGL((k_gather<T>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, m, idx, x, out, done);
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+
+extern "C" int mik_gather(mik_ctx *ctx, int dtype, int64_t m, const int32_t *idx, const void *x, void *out)
+{
+    if (!ctx || m < 0 || (m && (!idx || !x || !out))) return MIK_ERR_INVALID;
+    if (dtype == MIK_F64) return gather_launch<double>(ctx, m, idx, (const double *)x, (double *)out, nullptr);
+    if (dtype == MIK_F32) return gather_launch<float>(ctx, m, idx, (const float *)x, (float *)out, nullptr);
+    return MIK_ERR_INVALID;
+}
+
+// sum of the P per-rank partial sums, rank order
+template <typename T> __device__ __forceinline__ T rank_sum(const T *__restrict__ all, int nranks)
+{
+    T s = all[0];
+    for (int p = 1; p < nranks; ++p) s = s + all[p];
+    return s;
+}
+
+template <typename T> __global__ void k_cgd_alpha(const T *__restrict__ dot_all, int nranks, CgDev<T> *d)
+{
+    if (d->done) return;
+    const T tot = rank_sum(dot_all, nranks);
+    d->dot_uc = tot;
+    d->alpha = (d->res * d->res) / tot;
+}
+
+template <typename T>
+__global__ void k_cgd_fin_init(const T *__restrict__ rr_all, int nranks, CgDev<T> *d, T reltol, T abstol, long long maxiter, CgMirror *mirror,
+                               unsigned long long seq)
+{
+    const T tot = rank_sum(rr_all, nranks);
+    const T res = mik_sqrt(tot);
+    const T a = reltol * res;
+    d->rr = tot; d->res = res; d->prev_res = T(1); d->rho = T(1);
+    d->tol = a > abstol ? a : abstol;
+    d->beta = (res * res) / (T(1) * T(1));
+    d->alpha = T(0); d->dot_uc = T(0);
+    d->done = (0 >= maxiter || res <= d->tol) ? 1 : 0;
+    d->nhist = 0;
+    mirror->res = (double)res; mirror->prev_res = 1.0; mirror->done = d->done; mirror->nhist = 0;
+    mirror->tol = (double)d->tol; mirror->tol_valid = 1;
+    __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <typename T>
+__global__ void k_cgd_fin_res(const T *__restrict__ rr_all, int nranks, CgDev<T> *d, T *__restrict__ hist, long long it_next, long long maxiter,
+                              CgMirror *mirror, unsigned long long seq)
+{
+    if (d->done) { __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+    const T tot = rank_sum(rr_all, nranks);
+    const T prev = d->res;
+    const T res = mik_sqrt(tot);
+    d->rr = tot; d->prev_res = prev; d->res = res;
+    d->beta = (res * res) / (prev * prev);
+    hist[d->nhist] = res;
+    const int nh = d->nhist + 1;
+    d->nhist = nh;
+    const int dn = (it_next >= maxiter || res <= d->tol) ? 1 : 0;
+    if (dn) d->done = 1;
+    mirror->res = (double)res; mirror->prev_res = (double)prev; mirror->done = dn; mirror->nhist = nh;
+    __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+struct mik_cgd {
+    mik_cg base;                 // reuses the single-GPU handle's buffers / mirror / scalars
+    int rank = 0, nranks = 1;
+    int64_t n_send = 0;
+    const int *send_idx = nullptr;   // device: local indices to pack for the neighbours
+    void *send_buf = nullptr;        // device: packed halo values (caller-owned, n_send entries)
+    void *u_ext = nullptr;           // device: n_loc + n_ghost entries (u and its halo)
+    int64_t n_ext = 0;
+    void *dot_all = nullptr, *rr_all = nullptr;   // device: nranks scalars each (caller-owned comm buffers)
+    double abstol = 0, reltol = 0;
+    int initially_zero = 1;
+    int64_t hist_total = 0;
+};
+
+extern "C" int mik_cgd_create(mik_ctx *ctx, const mik_csr *A_loc, void *x, const void *b, void *u_ext, void *r, void *c,
+                              const int32_t *send_idx, int64_t n_send, void *send_buf, void *dot_all, void *rr_all, int rank,
+                              int nranks, double abstol, double reltol, int64_t maxiter, int initially_zero, mik_cgd **out)
+{
+    if (!ctx || !out) return MIK_ERR_INVALID;
+    *out = nullptr;
+    if (!A_loc || A_loc->n_cols < A_loc->n_rows) return mik_fail(ctx, MIK_ERR_MISMATCH, "mik_cgd_create: local block must be n_loc x (n_loc + n_ghost)");
+    if (nranks < 1 || rank < 0 || rank >= nranks || !dot_all || !rr_all || (n_send && (!send_idx || !send_buf)))
+        return mik_fail(ctx, MIK_ERR_INVALID, "mik_cgd_create: bad rank / comm buffers");
+    const int64_t n = A_loc->n_rows;
+    if (n && (!x || !b || !u_ext || !r || !c)) return mik_fail(ctx, MIK_ERR_INVALID, "mik_cgd_create: NULL vector");
+    mik_cgd *it = new (std::nothrow) mik_cgd();
+    if (!it) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_cgd_create: host allocation failed");
+    mik_cg &bs = it->base;
+    bs.ctx = ctx; bs.A = A_loc; bs.dtype = A_loc->dtype; bs.n = n;
+    bs.x = x; bs.b = b; bs.u = u_ext; bs.r = r; bs.c = c; bs.maxiter = maxiter;
+    it->rank = rank; it->nranks = nranks; it->n_send = n_send; it->send_idx = send_idx; it->send_buf = send_buf;
+    it->u_ext = u_ext; it->n_ext = A_loc->n_cols; it->dot_all = dot_all; it->rr_all = rr_all;
+    it->abstol = abstol; it->reltol = reltol; it->initially_zero = initially_zero;
+    const size_t es = mik_dtype_size(A_loc->dtype);
+    const int64_t nseg = A_loc->dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
+    const int64_t nb = mik_spmv_nwg(n);
+    hipError_t e;
+    (void)hipSetDevice(ctx->device);
+    auto fail = [&](const char *what, hipError_t err) {
+        int rc = mik_fail(ctx, MIK_ERR_NOMEM, "mik_cgd_create: %s: %s", what, hipGetErrorString(err));
+        mik_cgd_destroy(it);
+        return rc;
+    };
+    if ((e = hipMalloc(&bs.dev, 256)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMalloc(&bs.seg_spmv, es * (size_t)std::max<int64_t>(nb, 1))) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMalloc(&bs.seg_vec, es * (size_t)std::max<int64_t>(nseg, 1))) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMalloc(&bs.hist, es * 1024)) != hipSuccess) return fail("hipMalloc", e);
+    bs.hist_cap = 1024;
+    if ((e = hipHostMalloc((void **)&bs.mirror, sizeof(CgMirror), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return fail("hipHostMalloc", e);
+    memset(bs.mirror, 0, sizeof(CgMirror));
+    if ((e = hipMemsetAsync(bs.dev, 0, 256, ctx->stream)) != hipSuccess) return fail("hipMemsetAsync", e);
+    *out = it;
+    return MIK_OK;
+}
+
+extern "C" int mik_cgd_destroy(mik_cgd *it)
+{
+    if (!it) return MIK_OK;
+    mik_cg &bs = it->base;
+    if (bs.ctx) (void)hipStreamSynchronize(bs.ctx->stream);
+    if (bs.dev) (void)hipFree(bs.dev);
+    if (bs.hist) (void)hipFree(bs.hist);
+    if (bs.seg_spmv) (void)hipFree(bs.seg_spmv);
+    if (bs.seg_vec) (void)hipFree(bs.seg_vec);
+    if (bs.mirror) (void)hipHostFree(bs.mirror);
+    delete it;
+    return MIK_OK;
+}
+
+template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t iteration)
+{
+    mik_cg &bs = it->base;
+    mik_ctx *ctx = bs.ctx;
+    CgDev<T> *d = (CgDev<T> *)bs.dev;
+    const int *done = &d->done;
+    const int64_t n = bs.n, nseg = mik_nseg<T>(n), nb = mik_spmv_nwg(n);
+    T *x = (T *)bs.x, *u = (T *)it->u_ext, *r = (T *)bs.r, *c = (T *)bs.c;
+    const T *b = (const T *)bs.b;
+    T *dot_slot = (T *)it->dot_all + it->rank, *rr_slot = (T *)it->rr_all + it->rank;
+    const bool vec = mik_aligned16(x) && mik_aligned16(u) && mik_aligned16(r) && mik_aligned16(c) && mik_aligned16(b);
+    switch (phase) {
+    case 10:   // init A
+        if (!it->initially_zero) {
+            MIK_HIP(ctx, hipMemcpyAsync(u, x, sizeof(T) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+            MIK_TRY(gather_launch<T>(ctx, it->n_send, it->send_idx, u, (T *)it->send_buf, nullptr));
+        }
+        return MIK_OK;
+    case 11: { // init B
+        if (it->initially_zero) {
+            bs.mv_products = 0;
+            OpSubNrm<T> op{b, nullptr, r};
+            MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)bs.seg_vec, nullptr)));
+        } else {
+            bs.mv_products = 1;
+            MIK_TRY(mik_spmv_launch<T>(ctx, bs.A, u, c, false, nullptr, nullptr));
+            OpSubNrm<T> op{b, c, r};
+            MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)bs.seg_vec, nullptr)));
+        }
+        hipLaunchKernelGGL((k_finalize_store<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)bs.seg_vec, nseg, (int64_t)0, rr_slot,
+                           (const int *)nullptr);
+        MIK_LAUNCH_CHECK(ctx);
+        OpFill<T> z{u, T(0)};   // u .= 0 (src/cg.jl:129), halo included
+        return launch_map<T>(ctx, it->n_ext, z, mik_aligned16(u), (T *)nullptr, nullptr);
+    }
+    case 12:   // init C
+        bs.seq += 1;
+        hipLaunchKernelGGL((k_cgd_fin_init<T>), dim3(1), dim3(1), 0, ctx->stream, (const T *)it->rr_all, it->nranks, d, (T)it->reltol, (T)it->abstol,
+                           (long long)bs.maxiter, bs.mirror, bs.seq);
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    case 0: {  // step A
+        OpXpby<T> op{r, u, coef_ptr<T>(&d->beta)};
+        MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
+        return gather_launch<T>(ctx, it->n_send, it->send_idx, u, (T *)it->send_buf, done);
+    }
+    case 1:    // step B
+        MIK_TRY(mik_spmv_launch<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done));
+        hipLaunchKernelGGL((k_finalize_store<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)bs.seg_spmv, nb, (int64_t)0, dot_slot, done);
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    case 2: {  // step C
+        hipLaunchKernelGGL((k_cgd_alpha<T>), dim3(1), dim3(1), 0, ctx->stream, (const T *)it->dot_all, it->nranks, d);
+        MIK_LAUNCH_CHECK(ctx);
+        OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha)};
+        MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)bs.seg_vec, done)));
+        hipLaunchKernelGGL((k_finalize_store<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)bs.seg_vec, nseg, (int64_t)0, rr_slot, done);
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    }
+    case 3:    // step D
+        if (it->hist_total >= bs.hist_cap) return mik_fail(ctx, MIK_ERR_INVALID, "mik_cgd_phase: more than %lld steps enqueued without mik_cgd_wait", (long long)bs.hist_cap);
+        it->hist_total += 1;
+        bs.seq += 1;
+        hipLaunchKernelGGL((k_cgd_fin_res<T>), dim3(1), dim3(1), 0, ctx->stream, (const T *)it->rr_all, it->nranks, d, (T *)bs.hist,
+                           (long long)(iteration + 1), (long long)bs.maxiter, bs.mirror, bs.seq);
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    default:
+        return mik_fail(ctx, MIK_ERR_INVALID, "mik_cgd_phase: unknown phase %d", phase);
+    }
+}
+
+extern "C" int mik_cgd_phase(mik_cgd *it, int phase, int64_t iteration)
+{
+    if (!it || iteration < 0) return MIK_ERR_INVALID;
+    return it->base.dtype == MIK_F64 ? cgd_phase_impl<double>(it, phase, iteration) : cgd_phase_impl<float>(it, phase, iteration);
+}
+
+// Block until every phase enqueued so far has run; returns the scalars of the last step and the
+// residuals recorded since the previous wait (history[0..*steps-1], at most `cap`).
+extern "C" int mik_cgd_wait(mik_cgd *it, double *residual, double *tol, int *done, double *history, int64_t cap, int64_t *steps)
+{
+    if (!it) return MIK_ERR_INVALID;
+    mik_cg &bs = it->base;
+    mik_ctx *ctx = bs.ctx;
+    MIK_TRY(cg_wait_mirror(&bs));
+    const CgMirror m = *bs.mirror;
+    const int64_t nd = m.nhist;
+    if (history && nd > 0) {
+        const int64_t take = std::min<int64_t>(nd, cap);
+        const size_t es = mik_dtype_size(bs.dtype);
+        std::vector<unsigned char> tmp((size_t)take * es);
+        MIK_HIP(ctx, hipMemcpyAsync(tmp.data(), bs.hist, es * (size_t)take, hipMemcpyDeviceToHost, ctx->stream));
+        MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int64_t j = 0; j < take; ++j)
+            history[j] = bs.dtype == MIK_F64 ? ((const double *)tmp.data())[j] : (double)((const float *)tmp.data())[j];
+    }
+    // start a fresh history window for the next batch of steps
+    if (nd > 0) {
+        const size_t off = bs.dtype == MIK_F64 ? offsetof(CgDev<double>, nhist) : offsetof(CgDev<float>, nhist);
+        MIK_HIP(ctx, hipMemsetAsync((unsigned char *)bs.dev + off, 0, sizeof(int), ctx->stream));
+        bs.mirror->nhist = 0;
+    }
+    it->hist_total = 0;
+    bs.residual = m.res;
+    bs.prev_residual = m.prev_res;
+    if (m.tol_valid) bs.tol = m.tol;
+    bs.mv_products += nd;
+    if (residual) *residual = m.res;
+    if (tol) *tol = bs.tol;
+    if (done) *done = m.done;
+    if (steps) *steps = nd;
     return MIK_OK;
 }

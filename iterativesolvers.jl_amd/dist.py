@@ -1,0 +1,492 @@
+"""Row-partitioned CG across the GPUs of one node: one process per GPU, torch.distributed over
+RCCL/xGMI (backend "nccl" on ROCm), gloo on CPU for the tests.
+
+The reference is a serial library (no parallelism of any kind), so this layer
+is new design: rank p owns a contiguous block of rows of A and the matching
+slices of x, b, r, c, u; per iteration the only exchanges are
+  * one halo exchange of u before the SpMV (for the 3D Laplacian cut into z-slabs: N^2 doubles to
+    each neighbour), and
+  * two all-gathers of ONE scalar per rank -- the local dot(u, c) and the local |r|^2 -- which
+    every rank then sums in rank order 0..P-1, so all ranks hold bit-identical alpha / residual.
+All arithmetic runs in libmik.so (``mik_cgd_*`` phases); this module only orchestrates phases and
+collectives, and never synchronises the host except to read the residual.
+
+The compute "engine" is pluggable so that the orchestration, the partitioning and the exchange
+plans can be exercised without a GPU: ``HipEngine`` is the product; the CPU tests inject a numpy
+test double with the same phase interface (tests/dist_double.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import time
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_vp = C.c_void_p
+
+# phases of mik_cgd_phase (include/mik.h)
+INIT_A, INIT_B, INIT_C = 10, 11, 12
+STEP_A, STEP_B, STEP_C, STEP_D = 0, 1, 2, 3
+
+
+# ==============================================================================================
+# partitioning (host, numpy)
+# ==============================================================================================
+def partition_rows(n: int, nranks: int, align: int = 1) -> np.ndarray:
+    """Contiguous row blocks of (almost) equal size, cut on multiples of ``align`` (e.g. N^2 so that
+    a 3D Laplacian is cut into z-slabs).  Returns nranks + 1 offsets."""
+    units = -(-n // align)
+    cuts = [min(n, align * ((units * p) // nranks)) for p in range(nranks + 1)]
+    cuts[-1] = n
+    return np.asarray(cuts, np.int64)
+
+
+@dataclass
+class HaloPlan:
+    """What rank `rank` receives into / sends from its extended vector."""
+    rank: int
+    nranks: int
+    n_loc: int
+    ghost_gids: np.ndarray                                   # sorted global ids of the halo entries
+    recv: List[tuple] = field(default_factory=list)          # (peer, offset into ghost region, count)
+    send: List[tuple] = field(default_factory=list)          # (peer, offset into send buffer, count)
+    send_idx: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))   # local indices, concatenated per peer
+
+    @property
+    def n_ghost(self) -> int:
+        return int(self.ghost_gids.size)
+
+    @property
+    def n_send(self) -> int:
+        return int(self.send_idx.size)
+
+
+def localize_block(ptr, idx, offsets, rank):
+    """Rows offsets[rank]:offsets[rank+1] of a CSR matrix with GLOBAL 0-based column ids -> local
+    column ids ([0, n_loc) owned, [n_loc, n_loc + n_ghost) halo, halo sorted by global id) and the
+    receive side of the halo plan."""
+    r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
+    n_loc = r1 - r0
+    idx = np.asarray(idx, np.int64)
+    owned = (idx >= r0) & (idx < r1)
+    ghost_gids = np.unique(idx[~owned])
+    local = np.empty(idx.shape, np.int64)
+    local[owned] = idx[owned] - r0
+    local[~owned] = n_loc + np.searchsorted(ghost_gids, idx[~owned])
+    plan = HaloPlan(rank, len(offsets) - 1, n_loc, ghost_gids)
+    owner = np.searchsorted(offsets, ghost_gids, side="right") - 1
+    for peer in np.unique(owner):
+        sel = np.nonzero(owner == peer)[0]
+        plan.recv.append((int(peer), int(sel[0]), int(sel.size)))      # contiguous: ghost ids are sorted
+    return local, plan
+
+
+def complete_plan(plan: HaloPlan, offsets, needs_of_peers):
+    """``needs_of_peers[q]`` = sorted global ids rank q wants (its ghost_gids).  Fills the send side."""
+    r0, r1 = int(offsets[plan.rank]), int(offsets[plan.rank + 1])
+    chunks, off = [], 0
+    plan.send = []
+    for q, gids in enumerate(needs_of_peers):
+        if q == plan.rank or gids is None:
+            continue
+        mine = gids[(gids >= r0) & (gids < r1)]
+        if mine.size:
+            plan.send.append((q, off, int(mine.size)))
+            chunks.append((mine - r0).astype(np.int32))
+            off += int(mine.size)
+    plan.send_idx = np.concatenate(chunks) if chunks else np.zeros(0, np.int32)
+    return plan
+
+
+# ==============================================================================================
+# communicator
+# ==============================================================================================
+class TorchComm:
+    """torch.distributed: "nccl" (= RCCL over xGMI) for device tensors, "gloo" for the CPU tests."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank, self.size = dist.get_rank(), dist.get_world_size()
+        # MIK_DIST_FORCE_COLLECTIVES=1: issue the collectives even in a world of one (exercises the
+        # backend's call paths on a single-GPU box)
+        self.force = os.environ.get("MIK_DIST_FORCE_COLLECTIVES", "0") == "1"
+
+    def all_gather_objects(self, obj):
+        out = [None] * self.size
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def exchange(self, plan: HaloPlan, send_buf, ghost_view):
+        """send_buf / ghost_view: 1-D tensors (packed halo values; tail of the extended vector)."""
+        if (self.size == 1 and not self.force) or (not plan.send and not plan.recv):
+            return
+        dist = self.dist
+        ops = []
+        for peer, off, cnt in plan.recv:
+            ops.append(dist.P2POp(dist.irecv, ghost_view[off:off + cnt], peer))
+        for peer, off, cnt in plan.send:
+            ops.append(dist.P2POp(dist.isend, send_buf[off:off + cnt], peer))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()             # nccl: makes the current stream wait; gloo: blocks the host
+
+    def all_gather_scalar(self, all_t, rank_slot):
+        """all_t[p] <- rank p's all_t[p] (in-place all-gather of one scalar per rank)."""
+        if self.size == 1 and not self.force:
+            return
+        if all_t.is_cuda:
+            self.dist.all_gather_into_tensor(all_t, rank_slot)       # in-place form: slot [rank] is the input
+        else:
+            self.dist.all_gather(list(all_t.chunk(self.size)), rank_slot.clone())
+
+    def barrier(self):
+        if self.size > 1:
+            self.dist.barrier()
+
+
+class SelfComm:
+    """World of one process (no torch.distributed needed)."""
+    rank, size = 0, 1
+
+    def all_gather_objects(self, obj):
+        return [obj]
+
+    def exchange(self, plan, send_buf, ghost_view):
+        pass
+
+    def all_gather_scalar(self, all_t, rank_slot):
+        pass
+
+    def barrier(self):
+        pass
+
+
+# ==============================================================================================
+# product engine: libmik.so
+# ==============================================================================================
+class HipEngine:
+    """Owns the device state of one rank and enqueues ``mik_cgd`` phases on the current torch stream."""
+
+    def __init__(self, pkg, ptr, local_idx, val, plan: HaloPlan, b_loc, x_loc=None, *, abstol, reltol, maxiter, device=0,
+                 stream=None):
+        import torch
+        self.pkg, self.torch, self.plan = pkg, torch, plan
+        L = pkg.lib()
+        self.L = L
+        dtype = np.dtype(val.dtype)
+        tdt = {np.dtype(np.float64): torch.float64, np.dtype(np.float32): torch.float32}[dtype]
+        dev = torch.device("cuda", device)
+        self.ctx = pkg.HipContext(device)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)   # loopback ranks share one stream
+        self.ctx.set_stream(self.stream.cuda_stream)
+        n_loc, n_ext = plan.n_loc, plan.n_loc + plan.n_ghost
+        self.A = pkg.HipCSR(n_loc, n_ext, ptr, local_idx, val, index_base=0, is_csc=False, ctx=self.ctx)
+        with torch.cuda.stream(self.stream):
+            self.u_ext = torch.zeros(max(n_ext, 1), dtype=tdt, device=dev)           # receives the halo in place
+            self.send_buf = torch.zeros(max(plan.n_send, 1), dtype=tdt, device=dev)
+            self.dot_all = torch.zeros(plan.nranks, dtype=tdt, device=dev)
+            self.rr_all = torch.zeros(plan.nranks, dtype=tdt, device=dev)
+            self.send_idx = torch.from_numpy(plan.send_idx.astype(np.int32)).to(dev) if plan.n_send else torch.zeros(1, dtype=torch.int32, device=dev)
+        self.b = pkg.HipVector.from_numpy(np.ascontiguousarray(b_loc, dtype), self.ctx)
+        self.x = pkg.HipVector.from_numpy(np.ascontiguousarray(x_loc, dtype), self.ctx) if x_loc is not None else pkg.HipVector(n_loc, dtype, self.ctx).fill_(0)
+        self.r = pkg.HipVector(n_loc, dtype, self.ctx)
+        self.c = pkg.HipVector(n_loc, dtype, self.ctx)
+        h = _vp()
+        pkg._lib.check(L.mik_cgd_create(self.ctx.handle, self.A.handle, _vp(self.x.ptr), _vp(self.b.ptr), _vp(self.u_ext.data_ptr()),
+                                        _vp(self.r.ptr), _vp(self.c.ptr), _vp(self.send_idx.data_ptr()), plan.n_send,
+                                        _vp(self.send_buf.data_ptr()), _vp(self.dot_all.data_ptr()), _vp(self.rr_all.data_ptr()),
+                                        plan.rank, plan.nranks, float(abstol), float(reltol), int(maxiter), int(x_loc is None),
+                                        C.byref(h)), "mik_cgd_create", self.ctx.handle)
+        self.handle = h
+        self.ctx.synchronize()
+
+    # tensors the communicator works on
+    def ghost_view(self):
+        return self.u_ext[self.plan.n_loc:self.plan.n_loc + self.plan.n_ghost]
+
+    def dot_slot(self):
+        return self.dot_all[self.plan.rank:self.plan.rank + 1]
+
+    def rr_slot(self):
+        return self.rr_all[self.plan.rank:self.plan.rank + 1]
+
+    def phase(self, ph: int, iteration: int = 0):
+        self.pkg._lib.check(self.L.mik_cgd_phase(self.handle, ph, int(iteration)), "mik_cgd_phase", self.ctx.handle)
+
+    def wait(self, cap: int = 1024):
+        res, tol = C.c_double(), C.c_double()
+        done = C.c_int()
+        steps = C.c_int64()
+        hist = np.empty(cap, np.float64)
+        self.pkg._lib.check(self.L.mik_cgd_wait(self.handle, C.byref(res), C.byref(tol), C.byref(done),
+                                                hist.ctypes.data_as(C.POINTER(C.c_double)), cap, C.byref(steps)), "mik_cgd_wait", self.ctx.handle)
+        return res.value, tol.value, bool(done.value), hist[:steps.value].copy()
+
+    def stream_ctx(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def solution(self) -> np.ndarray:
+        return self.x.to_numpy()
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.mik_cgd_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ==============================================================================================
+# the distributed iterable
+# ==============================================================================================
+class DistCGIterable:
+    """``CGIterable`` (src/cg.jl:5-16) over a row partition.  ``iterate`` follows src/cg.jl:43-66;
+    construction follows ``cg_iterator!`` (src/cg.jl:120-155)."""
+
+    def __init__(self, engine, comm, *, maxiter):
+        self.e, self.comm, self.maxiter = engine, comm, int(maxiter)
+        self.mv_products = 0
+        e = engine
+        with e.stream_ctx():
+            e.phase(INIT_A)
+            comm.exchange(e.plan, e.send_buf, e.ghost_view())
+            e.phase(INIT_B)
+            comm.all_gather_scalar(e.rr_all, e.rr_slot())
+            e.phase(INIT_C)
+        self.residual, self.tol, _, _ = e.wait()
+        self.prev_residual = 1.0
+
+    def converged(self) -> bool:
+        return self.residual <= self.tol
+
+    def done(self, iteration: int) -> bool:
+        return iteration >= self.maxiter or self.converged()
+
+    def _enqueue_step(self, iteration: int):
+        e, comm = self.e, self.comm
+        e.phase(STEP_A)
+        comm.exchange(e.plan, e.send_buf, e.ghost_view())
+        e.phase(STEP_B)
+        comm.all_gather_scalar(e.dot_all, e.dot_slot())
+        e.phase(STEP_C)
+        comm.all_gather_scalar(e.rr_all, e.rr_slot())
+        e.phase(STEP_D, iteration)
+
+    def iterate_many(self, iteration: int, max_steps: int) -> np.ndarray:
+        """Up to max_steps iterate() calls with one host wait; the stopping test of src/cg.jl:36 runs on
+        the device after every step (identically on every rank) and turns later steps into no-ops."""
+        if max_steps <= 0 or self.done(iteration):
+            return np.zeros(0)
+        max_steps = min(int(max_steps), self.maxiter - iteration, 1024)
+        with self.e.stream_ctx():
+            for j in range(max_steps):
+                self._enqueue_step(iteration + j)
+        res, _, _, hist = self.e.wait()
+        if hist.size:
+            self.prev_residual = hist[-2] if hist.size > 1 else self.residual
+            self.residual = res
+            self.mv_products += hist.size
+        return hist
+
+    def iterate(self, iteration: int = 0):
+        h = self.iterate_many(iteration, 1)
+        return None if h.size == 0 else (self.residual, iteration + 1)
+
+    def __iter__(self):
+        iteration = 0
+        while (nxt := self.iterate(iteration)) is not None:
+            _, iteration = nxt
+            yield self.residual
+
+
+class LoopbackCG:
+    """P virtual ranks in ONE process (all engines on one device / one stream), stepped in lockstep:
+    the same phases and exchange plans as the multi-process path, with the collectives replaced by
+    tensor copies.  This is how the partitioned path is verified on a single GPU."""
+
+    def __init__(self, engines: Sequence, *, maxiter):
+        self.engines, self.maxiter = list(engines), int(maxiter)
+        self._all(INIT_A)
+        self._exchange()
+        self._all(INIT_B)
+        self._gather("rr_all")
+        self._all(INIT_C)
+        waits = [e.wait() for e in self.engines]
+        self.residual, self.tol = waits[0][0], waits[0][1]
+        assert all(w[0] == self.residual and w[1] == self.tol for w in waits), "ranks disagree on the initial residual"
+
+    def _all(self, ph, iteration=0):
+        for e in self.engines:
+            with e.stream_ctx():
+                e.phase(ph, iteration)
+
+    def _exchange(self):
+        for p, e in enumerate(self.engines):
+            with e.stream_ctx():
+                for peer, off, cnt in e.plan.recv:
+                    src = self.engines[peer]
+                    soff = next(o for (q, o, c) in src.plan.send if q == p)
+                    e.ghost_view()[off:off + cnt].copy_(src.send_buf[soff:soff + cnt])
+
+    def _gather(self, name):
+        for e in self.engines:
+            with e.stream_ctx():
+                for q, src in enumerate(self.engines):
+                    if src is not e:
+                        getattr(e, name)[q:q + 1].copy_(getattr(src, name)[q:q + 1])
+
+    def done(self, iteration):
+        return iteration >= self.maxiter or self.residual <= self.tol
+
+    def iterate_many(self, iteration: int, max_steps: int) -> np.ndarray:
+        if max_steps <= 0 or self.done(iteration):
+            return np.zeros(0)
+        max_steps = min(int(max_steps), self.maxiter - iteration, 1024)
+        for j in range(max_steps):
+            self._all(STEP_A)
+            self._exchange()
+            self._all(STEP_B)
+            self._gather("dot_all")
+            self._all(STEP_C)
+            self._gather("rr_all")
+            self._all(STEP_D, iteration + j)
+        waits = [e.wait() for e in self.engines]
+        hist = waits[0][3]
+        assert all(np.array_equal(w[3], hist) for w in waits), "ranks disagree on the residual history"
+        if hist.size:
+            self.residual = waits[0][0]
+        return hist
+
+    def solve(self) -> np.ndarray:
+        out, iteration = [], 0
+        while True:
+            h = self.iterate_many(iteration, 64)
+            if h.size == 0:
+                break
+            out.append(h)
+            iteration += h.size
+        return np.concatenate(out) if out else np.zeros(0)
+
+    def solution(self) -> np.ndarray:
+        return np.concatenate([e.solution() for e in self.engines])
+
+
+def build_rank_problem(pkg, comm, N: int, nz_per_rank: Optional[int] = None, dtype=np.float64):
+    """z-slab of the 3D Laplacian on an N x N x (nz_per_rank * P) grid -- or of the cubic N^3 grid when
+    nz_per_rank is None -- plus the hashed rhs; returns (ptr, local_idx, val, plan, b_loc, n_global)."""
+    P, rank = comm.size, comm.rank
+    if nz_per_rank is None:
+        n = N ** 3
+        offsets = partition_rows(n, P, align=N * N)
+        n_glob, ptr, idx, val = _laplace_rows(pkg, N, N, offsets[rank], offsets[rank + 1], dtype)
+    else:
+        NZ = nz_per_rank * P
+        n = N * N * NZ
+        offsets = np.arange(P + 1, dtype=np.int64) * (N * N * nz_per_rank)
+        n_glob, ptr, idx, val = _laplace_rows(pkg, N, NZ, offsets[rank], offsets[rank + 1], dtype)
+    local_idx, plan = localize_block(ptr, idx, offsets, rank)
+    needs = comm.all_gather_objects(plan.ghost_gids)
+    complete_plan(plan, offsets, needs)
+    b_loc = pkg.fixtures.hashed_rhs(n, int(offsets[rank]), int(offsets[rank + 1]), dtype)
+    return ptr, local_idx, val, plan, b_loc, n, offsets
+
+
+def _laplace_rows(pkg, N, NZ, r0, r1, dtype):
+    """Rows r0:r1 of the 7-point Laplacian on an N x N x NZ grid (x fastest), CSR with global columns."""
+    j = np.arange(r0, r1, dtype=np.int64)
+    dims = [(1, N), (N, N), (N * N, NZ)]
+    cand = []
+    for stride, ext in reversed(dims):
+        c = (j // stride) % ext
+        cand.append((j - stride, c > 0, -1.0))
+    cand.append((j, np.ones(j.shape, bool), 6.0))
+    for stride, ext in dims:
+        c = (j // stride) % ext
+        cand.append((j + stride, c < ext - 1, -1.0))
+    idx = np.stack([c[0] for c in cand], axis=1)
+    mask = np.stack([c[1] for c in cand], axis=1)
+    val = np.broadcast_to(np.asarray([c[2] for c in cand], dtype=dtype), idx.shape)
+    ptr = np.zeros(j.size + 1, np.int64)
+    np.cumsum(mask.sum(axis=1), out=ptr[1:])
+    return N * N * NZ, ptr, idx[mask], np.ascontiguousarray(val[mask])
+
+
+# ==============================================================================================
+# bench entry (bench.py --gpus N under torch.distributed.run)
+# ==============================================================================================
+def bench_main(args):
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    torch.cuda.set_device(local_rank)
+    if world > 1 or "RANK" in os.environ:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        comm = TorchComm()
+    else:
+        comm = SelfComm()
+    N, K, Wm = args.n, args.steps, args.warmup
+    ptr, local_idx, val, plan, b_loc, n, offsets = build_rank_problem(pkg, comm, N, nz_per_rank=N)
+    nnz_loc = int(val.size)
+    eng = HipEngine(pkg, ptr, local_idx, val, plan, b_loc, abstol=0.0, reltol=0.0, maxiter=10 ** 9, device=local_rank)
+    del ptr, local_idx, val
+    it = DistCGIterable(eng, comm, maxiter=10 ** 9)
+    batch = 25
+    iteration = 0
+    while iteration < Wm:
+        iteration += it.iterate_many(iteration, min(batch, Wm - iteration)).size
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = 0
+    while done < K:
+        h = it.iterate_many(iteration, min(batch, K - done))
+        assert h.size > 0
+        done += h.size
+        iteration += h.size
+    torch.cuda.synchronize()
+    comm.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # SpMV roofline on rank 0: back-to-back launches of the local block on the live u (HIP events, own stream)
+    alg_bytes = eng.A.spmv_algorithmic_bytes()
+    u = pkg.HipVector.wrap(eng.u_ext.data_ptr(), plan.n_loc + plan.n_ghost, np.float64, eng.ctx, owner=eng.u_ext)
+    spmv_ms = eng.A.time_spmv(u, eng.c, reps=20, fused_dot=True)
+    achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9
+    if rank == 0:
+        # weak scaling: every rank iterates its own 256^3-row slab of one global system, so the units all
+        # ranks processed are world * K slab-iterations (at N = 1 this is exactly bench.py's single-GPU metric)
+        out = {
+            "metric": "cg_iters_per_sec", "value": world * K / dt, "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "global_system_iters_per_sec": K / dt,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"cg! on the {N}x{N}x{N * world} 3D 7-point Laplacian row-partitioned into {world} z-slabs of {N}^3 rows "
+                                   f"(BASELINE.json configs[3] layout; weak scaling of configs[1])", "n": int(n), "n_per_gpu": plan.n_loc,
+                       "nnz_per_gpu": nnz_loc, "halo_doubles_per_neighbour": N * N, "host_sync_every_steps": batch,
+                       "collectives_per_step": "1 halo exchange (P2P) + 2 all-gathers of 1 double per rank",
+                       "final_residual": it.residual},
+            "roofline": {"bound": "hbm", "kernel": "k_spmv_rowblock<double, fused dot> (rank 0, back-to-back)", "achieved": achieved,
+                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms},
+            "aggregate_row_updates_per_sec": K / dt * n,
+        }
+        print(json.dumps(out))
+    if dist.is_initialized():
+        dist.destroy_process_group()

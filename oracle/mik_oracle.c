@@ -30,6 +30,18 @@
 #define ORC_CGS 1
 #define ORC_DGKS 2
 
+/* optional row partition for ORC_TREE reductions over full-length vectors (multi-GPU layout) */
+#define ORC_MAX_PARTS 64
+static int g_orc_nparts = 0;
+static int64_t g_orc_part[ORC_MAX_PARTS + 1];
+int orc_set_partition(int nparts, const int64_t *offsets)
+{
+    if (nparts < 0 || nparts > ORC_MAX_PARTS) return 1;
+    g_orc_nparts = nparts;
+    for (int i = 0; i <= nparts && nparts > 0; ++i) g_orc_part[i] = offsets[i];
+    return 0;
+}
+
 /* ---- fp64 instantiation ---- */
 #define T double
 #define F(x) x##_f64

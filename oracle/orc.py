@@ -89,8 +89,19 @@ def _declare(L):
     L.orc_laplace_csc.restype = None
     L.orc_advdiff_csc.argtypes = [C.c_int64, C.c_double, C.c_int, _i64p, _i64p, _f64p, _f64p]
     L.orc_advdiff_csc.restype = None
+    L.orc_set_partition.argtypes = [C.c_int, _i64p]
+    L.orc_set_partition.restype = C.c_int
     L.orc_hashed_rhs.argtypes = [C.c_int64, _f64p]
     L.orc_hashed_rhs.restype = None
+
+
+def set_partition(offsets=None):
+    """TREE-mode reductions over full-length vectors follow a row partition (rank order); None resets."""
+    if offsets is None:
+        lib().orc_set_partition(0, None)
+        return
+    off = np.ascontiguousarray(offsets, np.int64)
+    assert lib().orc_set_partition(off.size - 1, _p(off, C.c_int64)) == 0
 
 
 def _suf(dtype):

@@ -1,0 +1,203 @@
+"""Row-partitioned CG (dist.py): partition / halo-plan logic, the in-process loopback ranks, and the
+torch.distributed orchestration on gloo with world_size 2 (CPU, via a numpy test double of the engine),
+plus the same loopback on the real HIP engine (-m gpu)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def dist_mod(pkg):
+    return importlib.import_module(pkg.__name__ + ".dist")
+
+
+def global_csr(orc, N, NZ):
+    """The N x N x NZ Laplacian as global CSR via dist._laplace_rows (all rows)"""
+    return None
+
+
+# ------------------------------------------------------------------------------------------------
+# partitioning and plans
+# ------------------------------------------------------------------------------------------------
+def test_partition_rows(pkg):
+    d = dist_mod(pkg)
+    assert d.partition_rows(100, 4).tolist() == [0, 25, 50, 75, 100]
+    assert d.partition_rows(10, 3).tolist() == [0, 3, 6, 10]
+    off = d.partition_rows(6 ** 3, 4, align=36)
+    assert off[0] == 0 and off[-1] == 216 and all(o % 36 == 0 for o in off) and np.all(np.diff(off) > 0)
+    assert d.partition_rows(5, 8).tolist()[-1] == 5            # more ranks than rows: empty blocks allowed
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 5])
+def test_halo_plans_are_consistent(pkg, P):
+    """localize + complete_plan: renumbered local blocks reproduce the global SpMV; send/recv lists mirror"""
+    d = dist_mod(pkg)
+    N, NZ = 5, 7
+    n, ptr, idx, val = d._laplace_rows(pkg, N, NZ, 0, N * N * NZ, np.float64)
+    import scipy.sparse as sp
+    Aglob = sp.csr_matrix((val, idx, ptr), shape=(n, n))
+    offsets = d.partition_rows(n, P, align=N * N)
+    x = np.random.default_rng(0).standard_normal(n)
+    plans, blocks = [], []
+    for p in range(P):
+        _, pp, ii, vv = d._laplace_rows(pkg, N, NZ, offsets[p], offsets[p + 1], np.float64)
+        li, plan = d.localize_block(pp, ii, offsets, p)
+        plans.append(plan)
+        blocks.append((pp, li, vv))
+    needs = [pl.ghost_gids for pl in plans]
+    for pl in plans:
+        d.complete_plan(pl, offsets, needs)
+    y = np.empty(n)
+    for p, (pl, (pp, li, vv)) in enumerate(zip(plans, blocks)):
+        r0, r1 = offsets[p], offsets[p + 1]
+        x_ext = np.concatenate([x[r0:r1], np.zeros(pl.n_ghost)])
+        for (peer, off, cnt) in pl.recv:                      # what the exchange would deliver
+            src = plans[peer]
+            soff = next(o for (q, o, c) in src.send if q == p)
+            assert next(c for (q, o, c) in src.send if q == p) == cnt
+            packed = x[offsets[peer]:offsets[peer + 1]][src.send_idx[soff:soff + cnt]]
+            x_ext[pl.n_loc + off: pl.n_loc + off + cnt] = packed
+        assert np.array_equal(x_ext[pl.n_loc:], x[pl.ghost_gids])
+        Aloc = sp.csr_matrix((vv, li, pp), shape=(pl.n_loc, pl.n_loc + pl.n_ghost))
+        y[r0:r1] = Aloc @ x_ext
+    assert np.array_equal(y, Aglob @ x)
+    if P > 1:
+        assert plans[0].n_ghost == N * N and plans[1].n_ghost in (N * N, 2 * N * N)     # z-slab halos are planes
+
+
+# ------------------------------------------------------------------------------------------------
+# loopback ranks with the numpy engine (CPU)
+# ------------------------------------------------------------------------------------------------
+def make_engines(pkg, orc, N, NZ, P, make_engine, x0=None):
+    d = dist_mod(pkg)
+    n = N * N * NZ
+    offsets = d.partition_rows(n, P, align=N * N)
+    plans, parts = [], []
+    for p in range(P):
+        _, pp, ii, vv = d._laplace_rows(pkg, N, NZ, offsets[p], offsets[p + 1], np.float64)
+        li, plan = d.localize_block(pp, ii, offsets, p)
+        plans.append(plan)
+        parts.append((pp, li, vv))
+    for pl in plans:
+        d.complete_plan(pl, offsets, [q.ghost_gids for q in plans])
+    b = pkg.fixtures.hashed_rhs(n)
+    engines = [make_engine(pp, li, vv, pl, b[offsets[p]:offsets[p + 1]], None if x0 is None else x0[offsets[p]:offsets[p + 1]])
+               for p, (pl, (pp, li, vv)) in enumerate(zip(plans, parts))]
+    return engines, offsets, b
+
+
+def oracle_history(orc, pkg, N, NZ, offsets, b, shape, x0=None, maxiter=None):
+    d = dist_mod(pkg)
+    n, ptr, idx, val = d._laplace_rows(pkg, N, NZ, 0, N * N * NZ, np.float64)
+    A = orc.CSC(n, ptr, idx, val, 0)            # symmetric: CSR arrays are a valid CSC
+    orc.set_partition(offsets)
+    try:
+        return orc.cg(A, b, x0, mode="tree", shape=shape, maxiter=maxiter)
+    finally:
+        orc.set_partition(None)
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 4])
+@pytest.mark.parametrize("with_x0", [False, True])
+def test_loopback_numpy_engine_matches_partitioned_oracle(pkg, orc, P, with_x0):
+    from dist_double import NumpyEngine
+    d = dist_mod(pkg)
+    N, NZ, shape = 6, 8, (1, 1, 2, 2)
+    x0 = np.random.default_rng(3).standard_normal(N * N * NZ) if with_x0 else None
+    mk = lambda pp, li, vv, pl, bl, xl: NumpyEngine(orc, pp, li, vv, pl, bl, xl, abstol=0.0, reltol=1.5e-8, maxiter=10 ** 6, shape=shape)
+    engines, offsets, b = make_engines(pkg, orc, N, NZ, P, mk, x0)
+    lb = d.LoopbackCG(engines, maxiter=10 ** 6)
+    hist = lb.solve()
+    xo, ho = oracle_history(orc, pkg, N, NZ, offsets, b, shape, x0)
+    assert hist.size == ho["iters"] and np.array_equal(hist, ho["resnorm"])
+    assert np.array_equal(lb.solution(), xo)
+    assert lb.residual <= lb.tol
+
+
+# ------------------------------------------------------------------------------------------------
+# torch.distributed on gloo, world_size 2 (CPU)
+# ------------------------------------------------------------------------------------------------
+def _gloo_worker(rank, world, port, N, nz, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    from dist_double import NumpyEngine
+    pkg = graft.load_package()
+    orc = graft.load_oracle()
+    d = importlib.import_module(pkg.__name__ + ".dist")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = d.TorchComm()
+    ptr, li, val, plan, b_loc, n, offsets = d.build_rank_problem(pkg, comm, N, nz_per_rank=nz)
+    eng = NumpyEngine(orc, ptr, li, val, plan, b_loc, abstol=0.0, reltol=1.5e-8, maxiter=10 ** 6)
+    it = d.DistCGIterable(eng, comm, maxiter=10 ** 6)
+    hist, iteration = [], 0
+    while True:                                   # mix single steps and batches
+        h = it.iterate_many(iteration, 1 if iteration < 3 else 7)
+        if h.size == 0:
+            break
+        hist.append(h)
+        iteration += h.size
+    np.save(os.path.join(out_dir, f"hist{rank}.npy"), np.concatenate(hist))
+    np.save(os.path.join(out_dir, f"x{rank}.npy"), eng.solution())
+    np.save(os.path.join(out_dir, f"off{rank}.npy"), offsets)
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_matches_partitioned_oracle(pkg, orc, tmp_path):
+    import torch.multiprocessing as mp
+    N, nz, world = 6, 4, 2
+    port = 29600 + os.getpid() % 300
+    mp.spawn(_gloo_worker, args=(world, port, N, nz, str(tmp_path)), nprocs=world, join=True)
+    h0, h1 = np.load(tmp_path / "hist0.npy"), np.load(tmp_path / "hist1.npy")
+    assert np.array_equal(h0, h1)                 # rank-ordered sums: every rank holds identical scalars
+    offsets = np.load(tmp_path / "off0.npy")
+    b = pkg.fixtures.hashed_rhs(N * N * nz * world)
+    xo, ho = oracle_history(orc, pkg, N, nz * world, offsets, b, (1, 1, 2, 2))
+    assert h0.size == ho["iters"] and np.array_equal(h0, ho["resnorm"])
+    x = np.concatenate([np.load(tmp_path / "x0.npy"), np.load(tmp_path / "x1.npy")])
+    assert np.array_equal(x, xo)
+
+
+# ------------------------------------------------------------------------------------------------
+# the HIP engine: loopback ranks on one GPU
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [1, 2, 4])
+@pytest.mark.parametrize("with_x0", [False, True])
+def test_loopback_hip_engine_matches_partitioned_oracle(pkg, orc, ctx, P, with_x0):
+    import torch
+    d = dist_mod(pkg)
+    N, NZ = 12, 16
+    shape = ctx.cg_shape(np.float64)
+    x0 = np.random.default_rng(3).standard_normal(N * N * NZ) if with_x0 else None
+    stream = torch.cuda.Stream()
+    mk = lambda pp, li, vv, pl, bl, xl: d.HipEngine(pkg, pp, li, vv, pl, bl, xl, abstol=0.0, reltol=1.5e-8, maxiter=10 ** 6, stream=stream)
+    engines, offsets, b = make_engines(pkg, orc, N, NZ, P, mk, x0)
+    lb = d.LoopbackCG(engines, maxiter=10 ** 6)
+    hist = lb.solve()
+    xo, ho = oracle_history(orc, pkg, N, NZ, offsets, b, shape, x0)
+    assert hist.size == ho["iters"] and np.array_equal(hist, ho["resnorm"])
+    assert np.array_equal(lb.solution(), xo)
+
+
+@pytest.mark.gpu
+def test_dist_world1_equals_single_gpu_path(pkg, orc, ctx):
+    """P = 1 through DistCGIterable + SelfComm is bit-identical to the fused single-GPU iterable"""
+    d = dist_mod(pkg)
+    N = 16
+    comm = d.SelfComm()
+    ptr, li, val, plan, b_loc, n, offsets = d.build_rank_problem(pkg, comm, N, nz_per_rank=N)
+    eng = d.HipEngine(pkg, ptr, li, val, plan, b_loc, abstol=0.0, reltol=1.5e-8, maxiter=10 ** 6)
+    it = d.DistCGIterable(eng, comm, maxiter=10 ** 6)
+    hist = np.array(list(it))
+    nA, colptr, rowval, nzval = pkg.fixtures.laplace_matrix(N, 3)
+    x, ch = pkg.cg(pkg.HipCSR(nA, nA, colptr, rowval, nzval), pkg.HipVector.from_numpy(b_loc), reltol=1.5e-8, log=True)
+    assert np.array_equal(hist, ch["resnorm"]) and np.array_equal(eng.solution(), x.to_numpy())
