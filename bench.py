@@ -42,6 +42,21 @@ def cpu_baseline(N: int, iters: int):
             "seconds": dt}
 
 
+def pmc_traffic(kernel_key: str = "k_spmv_rowblock"):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_traffic.json, written by scripts/pmc_summary.py from separate --pmc runs of this same
+    command: FETCH_SIZE x 2 per the gfx950 note in MI355X_MICROARCH.md + WRITE_SIZE).  None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return d.get(kernel_key, {}).get("traffic_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,7 +135,7 @@ def main():
                    "reltol": "sqrt(eps)" if reltol is None else reltol, "host_sync_per_step": 1,
                    "final_residual": residual},
         "roofline": {"bound": "hbm", "kernel": "k_spmv_rowblock<double, fused dot>", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms, "launches_timed": spmv_launches,
                      "back_to_back_ms": b2b_ms, "frac_of_copy_ceiling_6290": achieved / 6290.0},
         "cg_iteration_algorithmic_bytes": alg_bytes + 9 * n * 8,

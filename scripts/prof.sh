@@ -16,4 +16,4 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$i -o bench -- python $R/bench.py $PMCARGS > $OUT/pmc_$i.log 2>&1 || echo "pmc pass $i ($C) failed"
 done
-python $R/scripts/pmc_summary.py $OUT | tee $OUT/pmc_summary.txt
+python $R/scripts/pmc_summary.py $OUT $OUT/traffic.json | tee $OUT/pmc_summary.txt
