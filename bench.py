@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=256, help="grid points per dimension per GPU (default 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=30)
+    ap.add_argument("--cpu-iters", type=int, default=120)
     ap.add_argument("--force-dist", action="store_true", help="run the row-partitioned code path even with one rank")
     args = ap.parse_args()
 

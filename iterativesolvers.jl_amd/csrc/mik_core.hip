@@ -260,6 +260,50 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
         if (nnz) memcpy(v.data(), val, (size_t)nnz * es);
     }
 
+    // Long rows (> MIK_LONG_ROW entries) leave the row-block layout: their entries move behind all
+    // short-row entries and a wave-per-row kernel sums them (still serially, in column order).  In the
+    // short part a long row becomes an empty row, so the row-block kernel keeps its contiguous ranges.
+    std::vector<int> long_rows, long_start, long_len;
+    std::vector<unsigned char> is_long;
+    // development knob [4]: > 0 overrides the threshold, < 0 disables the split
+    const int long_row = g_mik_tuning[4] > 0 ? g_mik_tuning[4] : MIK_LONG_ROW;
+    if (max_row > long_row && g_mik_tuning[4] >= 0) {
+        is_long.assign((size_t)n_rows, 0);
+        std::vector<int> rp2((size_t)n_rows + 1, 0), col2((size_t)nnz);
+        std::vector<unsigned char> v2((size_t)nnz * es);
+        int64_t short_nnz = 0;
+        for (int64_t r = 0; r < n_rows; ++r)
+            if (rowptr[r + 1] - rowptr[r] <= long_row) short_nnz += rowptr[r + 1] - rowptr[r];
+        int64_t ps = 0, pl = (short_nnz + 3) & ~(int64_t)3;           // long part starts 16-byte aligned
+        if (pl + (nnz - short_nnz) > (int64_t)col2.size()) { col2.resize((size_t)(pl + nnz - short_nnz)); v2.resize(col2.size() * es); }
+        for (int64_t r = 0; r < n_rows; ++r) {
+            const int len = rowptr[r + 1] - rowptr[r];
+            rp2[r] = (int)ps;
+            if (len <= long_row) {
+                if (len) { memcpy(&col2[ps], &col[rowptr[r]], sizeof(int) * len); memcpy(&v2[(size_t)ps * es], &v[(size_t)rowptr[r] * es], es * len); }
+                ps += len;
+            } else {
+                is_long[r] = 1;
+                long_rows.push_back((int)r); long_start.push_back((int)pl); long_len.push_back(len);
+                memcpy(&col2[pl], &col[rowptr[r]], sizeof(int) * len);
+                memcpy(&v2[(size_t)pl * es], &v[(size_t)rowptr[r] * es], es * len);
+                pl += len;
+            }
+        }
+        rp2[n_rows] = (int)ps;
+        {   // longest rows first: their serial chains are the critical path of the SpMV
+            std::vector<int> ord(long_rows.size());
+            for (size_t q = 0; q < ord.size(); ++q) ord[q] = (int)q;
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return long_len[a] > long_len[b]; });
+            std::vector<int> lr(ord.size()), ls(ord.size()), ll(ord.size());
+            for (size_t q = 0; q < ord.size(); ++q) { lr[q] = long_rows[ord[q]]; ls[q] = long_start[ord[q]]; ll[q] = long_len[ord[q]]; }
+            long_rows.swap(lr); long_start.swap(ls); long_len.swap(ll);
+        }
+        for (int64_t q = ps; q < ((short_nnz + 3) & ~(int64_t)3); ++q) { col2[q] = 0; memset(&v2[(size_t)q * es], 0, es); }
+        rowptr.swap(rp2); col.swap(col2); v.swap(v2);
+    }
+    const int64_t nnz_store = (int64_t)col.size();                     // entries physically stored (>= nnz when re-laid out)
+
     int max_rb = 0;
     for (int64_t r0 = 0; r0 < n_rows; r0 += MIK_BLOCK)
         max_rb = std::max(max_rb, rowptr[std::min<int64_t>(r0 + MIK_BLOCK, n_rows)] - rowptr[r0]);
@@ -267,25 +311,39 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
     mik_csr *A = new (std::nothrow) mik_csr();
     if (!A) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host allocation failed");
     A->max_rowblock_nnz = max_rb;
+    A->n_long = (int)long_rows.size();
     A->ctx = ctx; A->dtype = dtype; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz; A->max_row_nnz = max_row;
     const size_t pad = MIK_SPMV_TILE;   // slack so tile-granular reads never leave the allocation
     auto cleanup = [&]() { mik_csr_destroy(A); };
     hipError_t e;
     (void)hipSetDevice(ctx->device);
+    const size_t ns = (size_t)nnz_store;
     if ((e = hipMalloc((void **)&A->rowptr, sizeof(int) * ((size_t)n_rows + 1 + 256))) != hipSuccess ||
-        (e = hipMalloc((void **)&A->col, sizeof(int) * ((size_t)nnz + pad))) != hipSuccess ||
-        (e = hipMalloc(&A->val, es * ((size_t)nnz + pad))) != hipSuccess) {
+        (e = hipMalloc((void **)&A->col, sizeof(int) * (ns + pad))) != hipSuccess ||
+        (e = hipMalloc(&A->val, es * (ns + pad))) != hipSuccess) {
         cleanup();
         return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: hipMalloc: %s", hipGetErrorString(e));
     }
-    if ((e = hipMemsetAsync(A->col + nnz, 0, sizeof(int) * pad, ctx->stream)) != hipSuccess ||
-        (e = hipMemsetAsync((unsigned char *)A->val + es * (size_t)nnz, 0, es * pad, ctx->stream)) != hipSuccess ||
+    if ((e = hipMemsetAsync(A->col + ns, 0, sizeof(int) * pad, ctx->stream)) != hipSuccess ||
+        (e = hipMemsetAsync((unsigned char *)A->val + es * ns, 0, es * pad, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(A->rowptr, rowptr.data(), sizeof(int) * ((size_t)n_rows + 1), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
-        (nnz && (e = hipMemcpyAsync(A->col, col.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) ||
-        (nnz && (e = hipMemcpyAsync(A->val, v.data(), es * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) ||
+        (ns && (e = hipMemcpyAsync(A->col, col.data(), sizeof(int) * ns, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) ||
+        (ns && (e = hipMemcpyAsync(A->val, v.data(), es * ns, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) ||
         (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) {
         cleanup();
         return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create: upload: %s", hipGetErrorString(e));
+    }
+    if (A->n_long) {
+        const size_t nl = (size_t)A->n_long;
+        if ((e = hipMalloc((void **)&A->long_rows, sizeof(int) * nl * 3)) != hipSuccess ||
+            (e = hipMalloc((void **)&A->is_long, (size_t)n_rows)) != hipSuccess ||
+            (e = hipMemcpy(A->long_rows, long_rows.data(), sizeof(int) * nl, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(A->long_rows + nl, long_start.data(), sizeof(int) * nl, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(A->long_rows + 2 * nl, long_len.data(), sizeof(int) * nl, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(A->is_long, is_long.data(), (size_t)n_rows, hipMemcpyHostToDevice)) != hipSuccess) {
+            cleanup();
+            return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create: long-row tables: %s", hipGetErrorString(e));
+        }
     }
     *out = A;
     return MIK_OK;
@@ -298,6 +356,8 @@ extern "C" int mik_csr_destroy(mik_csr *A)
     if (A->rowptr) (void)hipFree(A->rowptr);
     if (A->col) (void)hipFree(A->col);
     if (A->val) (void)hipFree(A->val);
+    if (A->long_rows) (void)hipFree(A->long_rows);
+    if (A->is_long) (void)hipFree(A->is_long);
     delete A;
     return MIK_OK;
 }
@@ -326,16 +386,27 @@ int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_
     const bool nt = g_mik_tuning[0] == 0;
     const bool wide = g_mik_tuning[1] == 0;
     const int map_mode = g_mik_tuning[2];
-    const dim3 grid(nb), block(MIK_BLOCK);
-#define MIK_SPMV_GO(FD, NT, WD)                                                                              \
-    hipLaunchKernelGGL((k_spmv_rowblock<T, FD, NT, WD>), grid, block, 0, ctx->stream, n, nb, map_mode, A->rowptr, \
-                       A->col, (const T *)A->val, x, y, seg_out, done)
-#define MIK_SPMV_GO2(FD)                                                          \
-    do {                                                                          \
-        if (nt) { if (wide) MIK_SPMV_GO(FD, true, true); else MIK_SPMV_GO(FD, true, false); }   \
-        else    { if (wide) MIK_SPMV_GO(FD, false, true); else MIK_SPMV_GO(FD, false, false); } \
+    const int nlong = A->n_long;
+    const int nlb = (nlong + 3) / 4;
+    const bool merge = nlong > 0 && !fuse_dot;           // one launch: long-row workgroups first, then row-blocks
+    if (nlong && !merge) {
+        // fused dot: long rows first in their own launch, the row-block kernel then picks y[r] up
+        hipLaunchKernelGGL((k_spmv_longrows<T>), dim3(nlb), dim3(MIK_BLOCK), 0, ctx->stream, nlong, A->long_rows, A->long_rows + nlong,
+                           A->long_rows + 2 * nlong, A->col, (const T *)A->val, x, y, done);
+        MIK_LAUNCH_CHECK(ctx);
+    }
+    const dim3 grid(nb + (merge ? nlb : 0)), block(MIK_BLOCK);
+#define MIK_SPMV_GO(FD, NT, WD, MG)                                                                              \
+    hipLaunchKernelGGL((k_spmv_rowblock<T, FD, NT, WD, MG>), grid, block, 0, ctx->stream, n, nb, map_mode, A->rowptr, \
+                       A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, nlong, A->long_rows)
+#define MIK_SPMV_GO2(FD, MG)                                                              \
+    do {                                                                                  \
+        if (nt) { if (wide) MIK_SPMV_GO(FD, true, true, MG); else MIK_SPMV_GO(FD, true, false, MG); }   \
+        else    { if (wide) MIK_SPMV_GO(FD, false, true, MG); else MIK_SPMV_GO(FD, false, false, MG); } \
     } while (0)
-    if (fuse_dot) MIK_SPMV_GO2(true); else MIK_SPMV_GO2(false);
+    if (fuse_dot) MIK_SPMV_GO2(true, false);
+    else if (merge) MIK_SPMV_GO2(false, true);
+    else MIK_SPMV_GO2(false, false);
 #undef MIK_SPMV_GO2
 #undef MIK_SPMV_GO
     MIK_LAUNCH_CHECK(ctx);

@@ -53,21 +53,148 @@ template <> struct WideVec<float>  { using val = mik_f32x4; using idx = mik_i32x
 // multiple of 8 row-blocks).  mode 1: contiguous range per XCD.
 __device__ __forceinline__ int spmv_block_map(int b, int nb, int mode) { return mode == 1 ? xcd_remap(b, nb) : b; }
 
-template <typename T, bool FUSE_DOT, bool NT, bool WIDE>
+// ---------------------------------------------------------------------------------------------
+// long rows: one wave per row
+// ---------------------------------------------------------------------------------------------
+// Rows with more than `long_row` entries (mik_csr_create; default MIK_LONG_ROW) are stored behind
+// the short part and summed here -- a thread-per-row tile only pays while a 2048-entry tile covers
+// many rows.  The sum stays SERIAL in ascending column order (bit-identical to the reference's
+// scatter order): the wave streams the row in chunks of 64*U entries with coalesced loads, gathers
+// x, parks the products in a wave-private LDS buffer, and lane 0 folds them into one accumulator with
+// 16-byte LDS reads, software-pipelined one 32-value batch ahead of the dependent add chain.  The
+// next chunk's val/col stream is issued before the chain starts; rows are ordered longest first
+// (mik_csr_create) and different rows run concurrently on different waves, so the critical path is
+// the longest single row at ~6 cycles per entry.
+constexpr int MIK_LONG_U = 8;                          // entries per lane per chunk
+constexpr int MIK_LONG_CH = 64 * MIK_LONG_U;           // 512-entry chunks
+
+template <typename T>
+__device__ __forceinline__ void spmv_longrow_wave(int w, T *__restrict__ wbuf, const int *__restrict__ rows,
+                                                  const int *__restrict__ starts, const int *__restrict__ lens,
+                                                  const int *__restrict__ col, const T *__restrict__ val,
+                                                  const T *__restrict__ x, T *__restrict__ y)
+{
+    constexpr int U = MIK_LONG_U, CH = MIK_LONG_CH;
+    constexpr int VW = VT<T>::W;                       // elements per 16-byte LDS read
+    constexpr int B = 32 / VW;                         // 16-byte reads per 32-value batch
+    using VV = typename WideVec<T>::val;
+    const int lane = threadIdx.x & 63;
+    const int k0 = starts[w], len = lens[w];
+    T acc = T(0);
+    // Three-stage software pipeline over chunks: while chunk c is multiplied and chained, the x-gather
+    // of chunk c+1 and the val/col stream of chunk c+2 are in flight.
+    T vA[U], xA[U], vB[U], vC[U];
+    int cB[U], cC[U];
+    auto stream = [&](int base, T(&vv)[U], int(&cc)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = base + u * 64 + lane;
+            vv[u] = j < len ? val[k0 + j] : T(0);
+            cc[u] = j < len ? col[k0 + j] : 0;       // padding gathers x[0]; its product is replaced by +0 below
+        }
+    };
+    stream(0, vA, cB);                                  // chunk 0 (cB doubles as its column registers)
+#pragma unroll
+    for (int u = 0; u < U; ++u) xA[u] = x[cB[u]];
+    stream(CH, vB, cB);                                 // chunk 1
+    for (int base = 0; base < len; base += CH) {
+        stream(base + 2 * CH, vC, cC);                  // chunk c+2: stream
+        T xB[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xB[u] = x[cB[u]];   // chunk c+1: gather
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                   // chunk c: products (entries past the row end contribute +0)
+            const T prod = vA[u] * xA[u];
+            wbuf[u * 64 + lane] = (base + u * 64 + lane < len) ? prod : T(0);
+        }
+        // LDS operations of one wave execute in issue order, so lane 0's reads below see every lane's
+        // writes above without a fence (a wavefront-scope fence would also drain vmcnt and with it the
+        // loads in flight); the wave barrier only pins the compiler's instruction order.
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            const VV *q = reinterpret_cast<const VV *>(wbuf);
+            const int cnt = min(CH, len - base);                 // zero padding inside the last batch adds nothing
+            // One v_add per entry plus one 16-byte LDS read per VW entries, fully unrolled: a single wave
+            // issues roughly one instruction every 4-5 cycles, so instruction count and LDS latency are
+            // the chain's cost.  Full chunks take the branch-free form, which lets the scheduler hoist
+            // the next batches' LDS reads above the current adds.
+            if (cnt == CH) {
+#pragma unroll
+                for (int g = 0; g < CH / 32; ++g) {
+                    VV t[B];
+#pragma unroll
+                    for (int i = 0; i < B; ++i) t[i] = q[g * B + i];
+#pragma unroll
+                    for (int i = 0; i < B; ++i)
+#pragma unroll
+                        for (int e = 0; e < VW; ++e) acc = acc + t[i][e];
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < CH / 32; ++g) {
+                    if (g * 32 < cnt) {
+                        VV t[B];
+#pragma unroll
+                        for (int i = 0; i < B; ++i) t[i] = q[g * B + i];
+#pragma unroll
+                        for (int i = 0; i < B; ++i)
+#pragma unroll
+                            for (int e = 0; e < VW; ++e) acc = acc + t[i][e];
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < U; ++u) { vA[u] = vB[u]; xA[u] = xB[u]; vB[u] = vC[u]; cB[u] = cC[u]; }
+    }
+    if (lane == 0) y[rows[w]] = acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_longrows(int nlong, const int *__restrict__ rows, const int *__restrict__ starts,
+                                                             const int *__restrict__ lens, const int *__restrict__ col,
+                                                             const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y,
+                                                             const int *__restrict__ done)
+{
+    if (done && *done) return;
+    __shared__ __attribute__((aligned(16))) T buf[MIK_BLOCK / 64][MIK_LONG_CH];
+    const int wv = threadIdx.x >> 6;
+    const int w = blockIdx.x * (MIK_BLOCK / 64) + wv;
+    if (w >= nlong) return;                            // whole waves leave: no block-level barrier is used
+    spmv_longrow_wave<T>(w, buf[wv], rows, starts, lens, col, val, x, y);
+}
+
+// MERGE_LONG: the first `nlong_blocks` workgroups of the launch are long-row workgroups (4 rows each,
+// scheduled first so the longest chains start earliest); the rest are row-block workgroups.
+template <typename T, bool FUSE_DOT, bool NT, bool WIDE, bool MERGE_LONG>
 __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int map_mode, const int *__restrict__ rowptr,
                                                              const int *__restrict__ col, const T *__restrict__ val,
                                                              const T *__restrict__ x, T *__restrict__ y,
-                                                             T *__restrict__ seg_out, const int *__restrict__ done)
+                                                             T *__restrict__ seg_out, const int *__restrict__ done,
+                                                             const unsigned char *__restrict__ is_long, int nlong,
+                                                             const int *__restrict__ long_tab)
 {
     if (done && *done) return;
     constexpr int TILE = MIK_SPMV_TILE;
     constexpr int VW = WIDE ? VT<T>::W : 1;            // elements per lane per load
     constexpr int PER = TILE / (MIK_BLOCK * VW);       // loads per lane per tile
-    __shared__ T prod[TILE];
+    static_assert(TILE >= (MIK_BLOCK / 64) * MIK_LONG_CH, "LDS tile doubles as the long-row wave buffers");
+    __shared__ __attribute__((aligned(16))) T prod[TILE];
     __shared__ T lds4[4];
 
     const int t = threadIdx.x;
-    const int rb = spmv_block_map(blockIdx.x, nb, map_mode);
+    int bid = blockIdx.x;
+    if (MERGE_LONG) {
+        const int nlb = (nlong + MIK_BLOCK / 64 - 1) / (MIK_BLOCK / 64);
+        if (bid < nlb) {
+            const int wv = t >> 6, w = bid * (MIK_BLOCK / 64) + wv;
+            if (w < nlong) spmv_longrow_wave<T>(w, prod + wv * MIK_LONG_CH, long_tab, long_tab + nlong, long_tab + 2 * nlong, col, val, x, y);
+            return;
+        }
+        bid -= nlb;
+    }
+    const int rb = spmv_block_map(bid, nb, map_mode);
     const int r0 = rb * MIK_BLOCK;
     const int r = r0 + t;
     int ks = 0, ke = 0;
@@ -133,7 +260,8 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
         }
         __syncthreads();
     }
-    if (r < n) st_stream<NT>(y + r, acc);
+    if (is_long && r < n && is_long[r]) acc = y[r];    // summed by k_spmv_longrows earlier on the stream
+    else if (r < n) st_stream<NT>(y + r, acc);
     if (FUSE_DOT) {
         T p = T(0);
         if (r < n) p = x[r] * acc;

@@ -61,6 +61,54 @@ def advection_dominated(N: int = 50, beta: float = 1000.0, index_base: int = 1):
     return n, colptr + index_base, rowval + index_base, nzval, np.ascontiguousarray(b.reshape(-1))
 
 
+def _hash32(x: np.ndarray, mult: int) -> np.ndarray:
+    """(x * mult) mod 2^32 followed by an xorshift -- integer arithmetic only, exact in any language."""
+    h = (x.astype(np.uint64) * np.uint64(mult)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(2246822519)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13)
+    return h
+
+
+def irregular_matrix(n: int = 1_000_000, dtype=np.float32, long_rows: bool = True):
+    """Synthetic irregular CSR operator standing in for BASELINE.json configs[4] (the SuiteSparse files
+    of benchmark/matrixmarket.jl:5 / matrixcollection.jl:6 cannot be downloaded here) -- SURVEY.md
+    section 8d: row-length classes {90 %: 5-15, 9.9 %: 50-200, 0.1 %: 5,000-20,000 (capped at n/2)}
+    chosen by an integer hash of the row index, column indices by a second hash, off-diagonal values in
+    [-1, 1) by a third, diagonal = 1 + sum |off-diagonal| (strictly diagonally dominant => GMRES
+    converges).  Returns 0-based CSR fields (n, rowptr, colidx, val) with columns ascending in a row;
+    duplicate off-diagonal columns are merged by keeping the first."""
+    rows = np.arange(n, dtype=np.int64)
+    cls = _hash32(rows, 2654435761) % np.uint64(1000)
+    sel = _hash32(rows, 40503)
+    length = np.where(cls < 900, 5 + sel % np.uint64(11),
+                      np.where((cls < 999) | (not long_rows), 50 + sel % np.uint64(151),
+                               5000 + sel % np.uint64(15001))).astype(np.int64)
+    length = np.minimum(length, max(1, n // 2))
+    start = np.zeros(n + 1, np.int64)
+    np.cumsum(length, out=start[1:])
+    total = int(start[-1])
+    r = np.repeat(rows, length)
+    k = np.arange(total, dtype=np.int64) - start[r]                   # position inside the row
+    c = (_hash32(r * 131071 + k, 2246822519) % np.uint64(n)).astype(np.int64)
+    c = np.where(c == r, (c + 1) % n, c)                               # keep the diagonal separate
+    v = (_hash32(r * 8191 + k + 7, 3266489917).astype(np.float64) / 2147483648.0 - 1.0)
+    order = np.lexsort((k, c, r))                                      # sort by (row, col), first occurrence first
+    r, c, v = r[order], c[order], v[order]
+    keep = np.ones(total, bool)
+    keep[1:] = (r[1:] != r[:-1]) | (c[1:] != c[:-1])
+    r, c, v = r[keep], c[keep], v[keep]
+    diag = 1.0 + np.bincount(r, weights=np.abs(v), minlength=n)
+    r_all = np.concatenate([r, rows])
+    c_all = np.concatenate([c, rows])
+    v_all = np.concatenate([v, diag])
+    order = np.lexsort((c_all, r_all))
+    r_all, c_all, v_all = r_all[order], c_all[order], v_all[order]
+    rowptr = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(r_all, minlength=n), out=rowptr[1:])
+    return n, rowptr, c_all, np.ascontiguousarray(v_all.astype(dtype))
+
+
 def hashed_rhs(n: int, start: int = 0, stop=None, dtype=np.float64) -> np.ndarray:
     """b[i] = ((i * 2654435761) mod 2^32) / 2^32 - 0.5 for the 1-based i in (start, stop]
     (exact in any language)."""

@@ -1,0 +1,38 @@
+"""BASELINE.json configs[4] stand-in: fp32 gmres(restart=50) on an irregular CSR operator (row lengths from 5 to
+thousands) -- the load-imbalance / long-row case of the SpMV.  GPU box only."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def as_oracle_csc(orc, n, rowptr, colidx, val):
+    M = sp.csr_matrix((val, colidx, rowptr), shape=(n, n)).tocsc()
+    M.sort_indices()
+    return orc.CSC(n, M.indptr.astype(np.int64), M.indices.astype(np.int64), M.data.copy(), 0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_irregular_spmv_bit_exact(pkg, orc, ctx, dtype):
+    n, rowptr, colidx, val = pkg.fixtures.irregular_matrix(20000, dtype)
+    lens = np.diff(rowptr)
+    assert lens.min() >= 6 and lens.max() > 2048          # rows longer than one LDS tile are present
+    A = pkg.HipCSR(n, n, rowptr, colidx, val, index_base=0, is_csc=False)
+    x = np.random.default_rng(2).standard_normal(n).astype(dtype)
+    y = (A @ pkg.HipVector.from_numpy(x)).to_numpy()
+    assert np.array_equal(y, orc.spmv(as_oracle_csc(orc, n, rowptr, colidx, val), x))
+
+
+def test_irregular_gmres_fp32_restart50(pkg, orc, ctx):
+    n, rowptr, colidx, val = pkg.fixtures.irregular_matrix(20000, np.float32)
+    A = pkg.HipCSR(n, n, rowptr, colidx, val, index_base=0, is_csc=False)
+    b = pkg.fixtures.hashed_rhs(n, dtype=np.float32)
+    x, ch = pkg.gmres(A, pkg.HipVector.from_numpy(b), restart=50, log=True)
+    Ao = as_oracle_csc(orc, n, rowptr, colidx, val)
+    xo, ho = orc.gmres(Ao, b, restart=50, mode="tree", shape=ctx.reduce_shape(np.float32))
+    assert ch.iters == ho["iters"] and ch.mvps == ho["mvps"] and ch.isconverged and ho["isconverged"]
+    assert np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
+    S = sp.csr_matrix((val.astype(np.float64), colidx, rowptr), shape=(n, n))
+    assert np.linalg.norm(S @ x.to_numpy().astype(np.float64) - b) / np.linalg.norm(b) <= 5e-4      # sqrt(eps_f32) = 3.5e-4
+    assert np.all(np.diff(ch["resnorm"]) <= 0)
