@@ -176,6 +176,29 @@ template <typename T> __device__ __forceinline__ T level2_sum(const T *__restric
     return block_tree_1024(acc, lds16);
 }
 
+// level 2 evaluated by a 256-thread workgroup for m <= 1024 segment sums: bit-identical to level2_sum
+// (virtual thread vt holds 0 + S[vt]; wave tree per 64 virtual threads; 16 wave sums left to right).
+// Every thread returns the total.  Lets a consumer kernel finalise its producer's reduction itself
+// instead of waiting for a separate single-workgroup launch.
+template <typename T> __device__ __forceinline__ T block_level2_256(const T *__restrict__ S, int m, T *lds16)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int vt = (w + 4 * j) * 64 + lane;
+        T v = T(0);
+        if (vt < m) v = v + S[vt];
+        v = wave_tree(v);
+        if (lane == 0) lds16[w + 4 * j] = v;
+    }
+    __syncthreads();
+    T tot = lds16[0];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) tot = tot + lds16[q];
+    __syncthreads();
+    return tot;
+}
+
 // correctly rounded square root (IEEE): the product path needs sqrt(rr) to match the host's.
 // NB: HIP's __fsqrt_rn is __ocml_native_sqrt_f32 (NOT correctly rounded) unless
 // OCML_BASIC_ROUNDED_OPERATIONS is defined; sqrtf()/sqrt() lower to the correctly rounded OCML

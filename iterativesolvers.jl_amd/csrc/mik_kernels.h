@@ -54,6 +54,63 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_map(int64_t n, int64_t nseg, Op o
     }
 }
 
+// k_map whose coefficient is the level-2 sum of a PRODUCER kernel's segment sums, finalised by every
+// workgroup itself (m <= 1024 partials: 4 loads + 4 wave trees per thread) instead of by a separate
+// single-workgroup launch.  PRO = 1: coef = sum (a projection h_i of Gram-Schmidt); PRO = 2:
+// coef = 1 / sqrt(sum) (the closing normalisation), with sqrt(sum) stored next to it.  Workgroup 0
+// publishes the value(s) at `coef_out` for the host.  Halves the launch count of the MGS chain.
+template <typename T, bool VEC, typename Op, int PRO>
+__global__ __launch_bounds__(MIK_BLOCK) void k_map_pro(int64_t n, int64_t nseg, Op op, T *__restrict__ seg_out,
+                                                        const T *__restrict__ prev_part, int prev_m, T *__restrict__ coef_out)
+{
+    constexpr int W = VT<T>::W;
+    constexpr int L = MIK_RED_L;
+    constexpr int64_t SEG = (int64_t)MIK_BLOCK * W * L;
+    __shared__ T lds16[16];
+    __shared__ T lds4[4];
+    T cf = block_level2_256(prev_part, prev_m, lds16);
+    if (PRO == 2) {
+        const T nrm = mik_sqrt(cf);
+        cf = T(1) / nrm;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { coef_out[0] = nrm; coef_out[1] = cf; }
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+        coef_out[0] = cf;
+    }
+    op.set_coef(cf);
+    for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+        const int64_t base = s * SEG + (int64_t)W * threadIdx.x;
+        T acc = T(0);
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int64_t i = base + (int64_t)l * MIK_BLOCK * W;
+            if (VEC && i + W <= n) {
+                op.apply_vec(i, acc);
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; ++e)
+                    if (i + e < n) op.apply(i + e, acc);
+            }
+        }
+        if (Op::REDUCE) {
+            T tot = block_tree_256(acc, lds4);
+            if (threadIdx.x == 0) seg_out[s] = tot;
+        }
+    }
+}
+
+template <typename T, int PRO, typename Op>
+static inline int launch_map_pro(mik_ctx *ctx, int64_t n, Op op, bool vec, T *seg_out, const T *prev_part, int prev_m, T *coef_out)
+{
+    const int64_t nseg = mik_nseg<T>(n);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(nseg, MIK_MAX_GRID));   // >= 1: workgroup 0 publishes the coefficient
+    if (vec)
+        hipLaunchKernelGGL((k_map_pro<T, true, Op, PRO>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, seg_out, prev_part, prev_m, coef_out);
+    else
+        hipLaunchKernelGGL((k_map_pro<T, false, Op, PRO>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, seg_out, prev_part, prev_m, coef_out);
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+
 // host-side launcher of k_map: one workgroup per segment, capped grid with a grid-stride loop
 template <typename T, typename Op>
 static inline int launch_map(mik_ctx *ctx, int64_t n, Op op, bool vec, T *seg_out, const int *done)
@@ -133,6 +190,7 @@ template <typename T> struct OpSub {
 template <typename T> struct OpScal {
     static constexpr bool REDUCE = false;
     T *__restrict__ x; Coef<T> alpha;
+    __device__ __forceinline__ void set_coef(T c) { alpha.ptr = nullptr; alpha.val = c; }
     __device__ __forceinline__ void apply(int64_t i, T &) const { x[i] = x[i] * alpha.get(); }
     __device__ __forceinline__ void apply_vec(int64_t i, T &) const
     {
@@ -262,6 +320,7 @@ template <typename T> struct OpJacobiDot {
 template <typename T, bool SELF> struct OpMgsPass {
     static constexpr bool REDUCE = true;
     T *__restrict__ w; const T *__restrict__ v; const T *__restrict__ z; Coef<T> h;
+    __device__ __forceinline__ void set_coef(T c) { h.ptr = nullptr; h.val = c; }
     __device__ __forceinline__ void apply(int64_t i, T &acc) const
     {
         T t = h.get() * v[i]; T wn = w[i] - t; w[i] = wn;

@@ -180,6 +180,34 @@ static int orthogonalize_impl(mik_ctx *ctx, int64_t n, int k, const T *V, int64_
     const bool vecw = mik_aligned16(w);
     const bool vec = vecw && mik_aligned16(V) && (ldv % VT<T>::W == 0);
 
+    if (method == MIK_MGS && nseg <= 1024 && g_mik_tuning[5] == 0) {
+        // src/orthogonalize.jl:69-76, launch-lean form for n up to ~1M: every pass finalises the
+        // previous pass's reduction itself (k_map_pro), so the chain is k + 2 launches instead of
+        // 2k + 3.  Segment sums ping-pong between two buffers (a pass reads one while writing the other).
+        MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * 2 * 1024));
+        T *P[2] = {(T *)ctx->partials, (T *)ctx->partials + 1024};
+        const int m = (int)nseg;
+        if (k > 0) {
+            OpDot<T> d0{V, w};
+            MIK_TRY((launch_map<T>(ctx, n, d0, vec, P[0], nullptr)));
+            for (int i = 0; i + 1 < k; ++i) {
+                OpMgsPass<T, false> op{w, V + (int64_t)i * ldv, V + (int64_t)(i + 1) * ldv, coef_val<T>(T(0))};
+                MIK_TRY((launch_map_pro<T, 1>(ctx, n, op, vec, P[(i + 1) & 1], P[i & 1], m, hd + i)));
+            }
+            OpMgsPass<T, true> last{w, V + (int64_t)(k - 1) * ldv, nullptr, coef_val<T>(T(0))};
+            MIK_TRY((launch_map_pro<T, 1>(ctx, n, last, vec, P[k & 1], P[(k - 1) & 1], m, hd + k - 1)));
+        } else {
+            OpDot<T> dn{w, w};
+            MIK_TRY((launch_map<T>(ctx, n, dn, vecw, P[0], nullptr)));
+        }
+        OpScal<T> sc{w, coef_val<T>(T(0))};                                // w .*= inv(norm(w))  :75-76
+        MIK_TRY((launch_map_pro<T, 2>(ctx, n, sc, vecw, (T *)nullptr, P[k & 1], m, hd + k)));
+        std::vector<T> out(k + 1);
+        MIK_TRY(coef_download<T>(ctx, 0, out.data(), k + 1));
+        for (int j = 0; j < k; ++j) h_host[j] = out[j];
+        *nrm_host = out[k];
+        return MIK_OK;
+    }
     if (method == MIK_MGS) {
         // src/orthogonalize.jl:69-76.  Pass i subtracts h[i] * V[:, i] from w and, in the same sweep,
         // accumulates the next projection dot(V[:, i+1], w) -- or norm(w)^2 on the last pass.

@@ -297,6 +297,15 @@ def test_orthogonalize_bit_exact_and_invariants(pkg, orc, ctx, method, n, k, dty
     nrm = pkg.orthogonalize_and_normalize_(dV, k, dw, h, M)
     wo, ho, no = orc.orthogonalize(V, w0, method=method, mode="tree", W=W, L=L)
     assert nrm == no and np.array_equal(h, ho) and np.array_equal(dw.to_numpy(), wo)
+    if method == "mgs":
+        # the launch-lean chain (consumer-side finalise, n <= ~1M) and the general chain must agree bit for bit
+        pkg.lib().mik_set_tuning(5, 1)
+        try:
+            dw2, h2 = pkg.HipVector.from_numpy(w0), np.zeros(k, dtype)
+            nrm2 = pkg.orthogonalize_and_normalize_(dV, k, dw2, h2, M)
+        finally:
+            pkg.lib().mik_set_tuning(5, 0)
+        assert nrm2 == nrm and np.array_equal(h2, h) and np.array_equal(dw2.to_numpy(), dw.to_numpy())
     if dtype == np.float64 and method != "dgks":
         w = dw.to_numpy()                                                         # test/orthogonalize.jl:27-33
         assert abs(np.linalg.norm(w) - 1) < 1e-13
