@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=256, help="grid points per dimension per GPU (default 256)")
+    ap.add_argument("--grid", dest="n", type=int, default=256, help="grid points per dimension per GPU (default 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=120)
     ap.add_argument("--force-dist", action="store_true", help="run the row-partitioned code path even with one rank")

@@ -115,6 +115,9 @@ class TorchComm:
         # MIK_DIST_FORCE_COLLECTIVES=1: issue the collectives even in a world of one (exercises the
         # backend's call paths on a single-GPU box)
         self.force = os.environ.get("MIK_DIST_FORCE_COLLECTIVES", "0") == "1"
+        # gloo cannot move device tensors: stage them through host copies (slow; used to run several
+        # ranks on ONE GPU for verification, where RCCL refuses duplicate devices)
+        self.staged = dist.get_backend() == "gloo"
 
     def all_gather_objects(self, obj):
         out = [None] * self.size
@@ -126,6 +129,11 @@ class TorchComm:
         if (self.size == 1 and not self.force) or (not plan.send and not plan.recv):
             return
         dist = self.dist
+        staged = self.staged and send_buf.is_cuda
+        if staged:
+            import torch
+            torch.cuda.current_stream().synchronize()
+            dev_ghost, send_buf, ghost_view = ghost_view, send_buf.cpu(), ghost_view.cpu()
         ops = []
         for peer, off, cnt in plan.recv:
             ops.append(dist.P2POp(dist.irecv, ghost_view[off:off + cnt], peer))
@@ -133,12 +141,20 @@ class TorchComm:
             ops.append(dist.P2POp(dist.isend, send_buf[off:off + cnt], peer))
         for req in dist.batch_isend_irecv(ops):
             req.wait()             # nccl: makes the current stream wait; gloo: blocks the host
+        if staged:
+            dev_ghost.copy_(ghost_view)
 
     def all_gather_scalar(self, all_t, rank_slot):
         """all_t[p] <- rank p's all_t[p] (in-place all-gather of one scalar per rank)."""
         if self.size == 1 and not self.force:
             return
-        if all_t.is_cuda:
+        if all_t.is_cuda and self.staged:
+            import torch
+            torch.cuda.current_stream().synchronize()
+            host = all_t.cpu()
+            self.dist.all_gather(list(host.chunk(self.size)), host[self.rank:self.rank + 1].clone())
+            all_t.copy_(host)
+        elif all_t.is_cuda:
             self.dist.all_gather_into_tensor(all_t, rank_slot)       # in-place form: slot [rank] is the input
         else:
             self.dist.all_gather(list(all_t.chunk(self.size)), rank_slot.clone())
@@ -432,9 +448,15 @@ def bench_main(args):
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    if "MIK_FORCE_DEVICE" in os.environ:          # development: several ranks on one GPU (if the backend allows it)
+        local_rank = int(os.environ["MIK_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1 or "RANK" in os.environ:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("MIK_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         comm = TorchComm()
     else:
         comm = SelfComm()
@@ -461,7 +483,7 @@ def bench_main(args):
     comm.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # SpMV roofline on rank 0: back-to-back launches of the local block on the live u (HIP events, own stream)

@@ -201,3 +201,53 @@ def test_dist_world1_equals_single_gpu_path(pkg, orc, ctx):
     nA, colptr, rowval, nzval = pkg.fixtures.laplace_matrix(N, 3)
     x, ch = pkg.cg(pkg.HipCSR(nA, nA, colptr, rowval, nzval), pkg.HipVector.from_numpy(b_loc), reltol=1.5e-8, log=True)
     assert np.array_equal(hist, ch["resnorm"]) and np.array_equal(eng.solution(), x.to_numpy())
+
+
+# ------------------------------------------------------------------------------------------------
+# two PROCESSES sharing one GPU: the real multi-process orchestration (DistCGIterable + TorchComm +
+# HipEngine), with gloo staging the device buffers through the host because RCCL refuses two ranks
+# on one device ("Duplicate GPU detected")
+# ------------------------------------------------------------------------------------------------
+def _gpu_worker(rank, world, port, N, nz, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    d = importlib.import_module(pkg.__name__ + ".dist")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = d.TorchComm()
+    ptr, li, val, plan, b_loc, n, offsets = d.build_rank_problem(pkg, comm, N, nz_per_rank=nz)
+    eng = d.HipEngine(pkg, ptr, li, val, plan, b_loc, abstol=0.0, reltol=1.5e-8, maxiter=10 ** 6, device=0)
+    it = d.DistCGIterable(eng, comm, maxiter=10 ** 6)
+    hist, iteration = [], 0
+    while True:
+        h = it.iterate_many(iteration, 1 if iteration < 2 else 9)
+        if h.size == 0:
+            break
+        hist.append(h)
+        iteration += h.size
+    np.save(os.path.join(out_dir, f"hist{rank}.npy"), np.concatenate(hist))
+    np.save(os.path.join(out_dir, f"x{rank}.npy"), eng.solution())
+    np.save(os.path.join(out_dir, f"off{rank}.npy"), offsets)
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_multiprocess_ranks_on_one_gpu_match_partitioned_oracle(pkg, orc, ctx, tmp_path, world):
+    import torch.multiprocessing as mp
+    N, nz = 12, 6
+    port = 29700 + os.getpid() % 200 + world
+    mp.spawn(_gpu_worker, args=(world, port, N, nz, str(tmp_path)), nprocs=world, join=True)
+    hs = [np.load(tmp_path / f"hist{r}.npy") for r in range(world)]
+    assert all(np.array_equal(hs[0], h) for h in hs)
+    offsets = np.load(tmp_path / "off0.npy")
+    b = pkg.fixtures.hashed_rhs(N * N * nz * world)
+    xo, ho = oracle_history(orc, pkg, N, nz * world, offsets, b, ctx.cg_shape(np.float64))
+    assert hs[0].size == ho["iters"] and np.array_equal(hs[0], ho["resnorm"])
+    x = np.concatenate([np.load(tmp_path / f"x{r}.npy") for r in range(world)])
+    assert np.array_equal(x, xo)
