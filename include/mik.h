@@ -158,14 +158,15 @@ int mik_cg_iterate_many(mik_cg *it, int64_t iteration, int64_t max_steps, double
 int mik_cg_state(const mik_cg *it, double *residual, double *prev_residual, double *tol,
                  int64_t *maxiter, int64_t *mv_products, int *converged);
 
-/* gmres_iterable!(x, A, b; Pl = Identity, Pr = Identity, abstol, reltol, restart, maxiter,
- *                 initially_zero, orth_meth) -- src/gmres.jl:108-136.  x, b: device n-vectors owned
- * by the caller.  The Krylov basis V (n x (restart+1), src/gmres.jl:13) lives on the device and
+/* gmres_iterable!(x, A, b; Pl, Pr, abstol, reltol, restart, maxiter, initially_zero, orth_meth)
+ * -- src/gmres.jl:108-136.  x, b: device n-vectors owned by the caller.  pl_diag / pr_diag: NULL =
+ * Identity(), or a device n-vector d making the preconditioner ldiv!(y, P, x) = y .= x ./ d (the three
+ * expand! methods src/gmres.jl:285-304, init! :249 and update_solution! :278-283 are followed).  The Krylov basis V (n x (restart+1), src/gmres.jl:13) lives on the device and
  * the Hessenberg matrix, Givens least squares and null-vector residual recurrence
  * (src/gmres.jl:224-233,262-271; src/hessenberg.jl:15-46) on the host, inside the handle. */
-int mik_gmres_create(mik_ctx *ctx, const mik_csr *A, void *x, const void *b, double abstol,
-                     double reltol, int restart, int64_t maxiter, int initially_zero,
-                     int orth_method, mik_gmres **out);
+int mik_gmres_create(mik_ctx *ctx, const mik_csr *A, void *x, const void *b, const void *pl_diag,
+                     const void *pr_diag, double abstol, double reltol, int restart, int64_t maxiter,
+                     int initially_zero, int orth_method, mik_gmres **out);
 int mik_gmres_destroy(mik_gmres *it);
 /* iterate(g, iteration) -- src/gmres.jl:57-106 */
 int mik_gmres_iterate(mik_gmres *it, int64_t iteration, double *residual, int *done);

@@ -70,7 +70,7 @@ SIGNATURES = {
     "mik_cg_iterate": (C.c_int, [_vp, _i64, _f64p, _ip]),
     "mik_cg_iterate_many": (C.c_int, [_vp, _i64, _i64, _f64p, _i64p]),
     "mik_cg_state": (C.c_int, [_vp, _f64p, _f64p, _f64p, _i64p, _i64p, _ip]),
-    "mik_gmres_create": (C.c_int, [_vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int, _i64, C.c_int,
+    "mik_gmres_create": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int, _i64, C.c_int,
                                    C.c_int, C.POINTER(_vp)]),
     "mik_gmres_destroy": (C.c_int, [_vp]),
     "mik_gmres_iterate": (C.c_int, [_vp, _i64, _f64p, _ip]),

@@ -667,14 +667,18 @@ def hessenberg_ldiv_(H: np.ndarray, rhs: np.ndarray):
 class GMRESIterable:
     """``GMRESIterable`` -- src/gmres.jl:31-49, driven by ``mik_gmres`` (device Krylov basis, host Hessenberg)."""
 
-    def __init__(self, x: HipVector, A: HipCSR, b: HipVector, *, abstol, reltol, restart, maxiter, initially_zero, orth_meth):
+    def __init__(self, x: HipVector, A: HipCSR, b: HipVector, *, abstol, reltol, restart, maxiter, initially_zero, orth_meth,
+                 Pl=None, Pr=None):
         if x.n != A.n_rows or b.n != A.n_rows or x.dtype != A.dtype or b.dtype != A.dtype:
             raise ValueError("DimensionMismatch in gmres_iterable_")
         self.A, self.x, self.b = A, x, b
+        self.Pl, self.Pr = Pl, Pr
+        pl = Pl.diagonal.ptr if isinstance(Pl, JacobiPrec) else None
+        pr = Pr.diagonal.ptr if isinstance(Pr, JacobiPrec) else None
         self.restart, self.maxiter = int(restart), int(maxiter)
         self.orth_meth = orth_meth
         h = _vp()
-        check(lib().mik_gmres_create(A.ctx.handle, A.handle, _vp(x.ptr), _vp(b.ptr), float(abstol), float(reltol), int(restart),
+        check(lib().mik_gmres_create(A.ctx.handle, A.handle, _vp(x.ptr), _vp(b.ptr), _vp(pl), _vp(pr), float(abstol), float(reltol), int(restart),
                                      int(maxiter), int(bool(initially_zero)), orth_meth.code, C.byref(h)), "mik_gmres_create", A.ctx.handle)
         self.handle = h
         self._refresh()
@@ -730,14 +734,14 @@ def gmres_iterable_(x: HipVector, A: HipCSR, b: HipVector, *, Pl=None, Pr=None, 
                     maxiter=None, initially_zero: bool = False, orth_meth: Optional[OrthogonalizationMethod] = None):
     """``gmres_iterable!(x, A, b; ...)`` -- src/gmres.jl:108-136."""
     for P, name in ((Pl, "Pl"), (Pr, "Pr")):
-        if P is not None and not isinstance(P, Identity):
-            raise MikError(5, "gmres_iterable_", f"{name} other than Identity() is not implemented on the device path")
+        if P is not None and not isinstance(P, (Identity, JacobiPrec)):
+            raise MikError(5, "gmres_iterable_", f"{name} must be Identity() or a diagonal JacobiPrec on the device path")
     reltol = _default_reltol(b) if reltol is None else reltol
     restart = min(20, A.size(2)) if restart is None else restart           # :113
     maxiter = A.size(2) if maxiter is None else maxiter                    # :114
     orth_meth = ModifiedGramSchmidt() if orth_meth is None else orth_meth  # :116
     return GMRESIterable(x, A, b, abstol=abstol, reltol=reltol, restart=restart, maxiter=maxiter, initially_zero=initially_zero,
-                         orth_meth=orth_meth)
+                         orth_meth=orth_meth, Pl=Pl, Pr=Pr)
 
 
 def gmres_(x: HipVector, A: HipCSR, b: HipVector, *, Pl=None, Pr=None, abstol=0.0, reltol=None, restart=None, maxiter=None,

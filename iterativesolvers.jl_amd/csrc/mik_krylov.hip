@@ -678,6 +678,7 @@ struct mik_gmres {
     int64_t n = 0, ldv = 0;
     void *x = nullptr;
     const void *b = nullptr;
+    const void *pl = nullptr, *pr = nullptr;   // diagonal left / right preconditioners (device n-vectors) or NULL = Identity()
     void *V = nullptr;        // device n x (restart + 1), column-major   src/gmres.jl:13
     void *Ax = nullptr;       // device work vector                        src/gmres.jl:125
     std::vector<double> H64; std::vector<float> H32;             // (restart+1) x restart   :14
@@ -713,6 +714,12 @@ template <typename T> static int gmres_init_residual(mik_gmres *g, int initially
         OpSubNrm<T> op{b, (const T *)g->Ax, V0};                          // :241,246
         MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)ctx->partials, nullptr)));
     }
+    if (g->pl) {                                                          // ldiv!(Pl, first_col)  :249
+        OpDivide<T> dv{V0, (const T *)g->pl, V0};
+        MIK_TRY((launch_map<T>(ctx, n, dv, mik_aligned16(V0) && mik_aligned16(g->pl), (T *)nullptr, nullptr)));
+        OpDot<T> dn{V0, V0};
+        MIK_TRY((launch_map<T>(ctx, n, dn, mik_aligned16(V0), (T *)ctx->partials, nullptr)));
+    }
     T *hd = (T *)ctx->coef;
     MIK_TRY(finalize_nrm_inv<T>(ctx, nseg, hd));                          // :252
     OpScal<T> sc{V0, coef_ptr<T>(hd + 1)};                                // :253
@@ -742,8 +749,9 @@ template <typename T> static int gmres_create_impl(mik_gmres *g, double abstol, 
     return MIK_OK;
 }
 
-extern "C" int mik_gmres_create(mik_ctx *ctx, const mik_csr *A, void *x, const void *b, double abstol, double reltol,
-                                int restart, int64_t maxiter, int initially_zero, int orth_method, mik_gmres **out)
+extern "C" int mik_gmres_create(mik_ctx *ctx, const mik_csr *A, void *x, const void *b, const void *pl_diag, const void *pr_diag,
+                                double abstol, double reltol, int restart, int64_t maxiter, int initially_zero, int orth_method,
+                                mik_gmres **out)
 {
     if (!ctx || !out) return MIK_ERR_INVALID;
     *out = nullptr;
@@ -755,7 +763,7 @@ extern "C" int mik_gmres_create(mik_ctx *ctx, const mik_csr *A, void *x, const v
     if ((size_t)(2 * restart + 6) * 8 > mik_ctx::COEF_BYTES) return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_gmres_create: restart %d too large", restart);
     mik_gmres *g = new (std::nothrow) mik_gmres();
     if (!g) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_gmres_create: host allocation failed");
-    g->ctx = ctx; g->A = A; g->dtype = A->dtype; g->n = n; g->x = x; g->b = b;
+    g->ctx = ctx; g->A = A; g->dtype = A->dtype; g->n = n; g->x = x; g->b = b; g->pl = pl_diag; g->pr = pr_diag;
     g->restart = restart; g->maxiter = maxiter; g->method = orth_method;
     g->ldv = (n + 63) / 64 * 64;
     if (g->ldv == 0) g->ldv = 64;
@@ -805,8 +813,20 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
     T *V = (T *)g->V;
     T *vk = V + (int64_t)(k - 1) * g->ldv, *vk1 = V + (int64_t)k * g->ldv;
 
-    // expand!: V[:, k+1] = A * V[:, k]                                   :64, :285-288
-    MIK_TRY(mik_spmv_launch<T>(ctx, g->A, vk, vk1, false, nullptr, nullptr));
+    // expand!                                                            :64, :285-304
+    if (g->pr) {
+        // Pl \ (A * (Pr \ v)) through the work vector Ax                  :297-304
+        OpDivide<T> dr{vk, (const T *)g->pr, vk1};
+        MIK_TRY((launch_map<T>(ctx, g->n, dr, mik_aligned16(vk) && mik_aligned16(vk1) && mik_aligned16(g->pr), (T *)nullptr, nullptr)));
+        MIK_TRY(mik_spmv_launch<T>(ctx, g->A, vk1, (T *)g->Ax, false, nullptr, nullptr));
+        MIK_HIP(ctx, hipMemcpyAsync(vk1, g->Ax, sizeof(T) * (size_t)g->n, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        MIK_TRY(mik_spmv_launch<T>(ctx, g->A, vk, vk1, false, nullptr, nullptr));   // V[:, k+1] = A * V[:, k]   :287
+    }
+    if (g->pl) {                                                          // ldiv!(Pl, nextV)  :294 / :303
+        OpDivide<T> dl{vk1, (const T *)g->pl, vk1};
+        MIK_TRY((launch_map<T>(ctx, g->n, dl, mik_aligned16(vk1) && mik_aligned16(g->pl), (T *)nullptr, nullptr)));
+    }
     g->mv_products += 1;                                                  // :65
 
     // H[k+1, k] = orthogonalize_and_normalize!(V[:, 1:k], V[:, k+1], H[1:k, k], orth_meth)   :68-73
@@ -838,7 +858,19 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
         hessenberg_ldiv<T>(H.data(), ldh, k - 1, rhs.data());
         // update_solution!: x += V[:, 1:k-1] * y                         :88, :273-276
         MIK_TRY(coef_upload<T>(ctx, 0, rhs.data(), k - 1));
-        MIK_TRY(gemv_n_dev<T>(ctx, g->n, k - 1, V, g->ldv, (const T *)ctx->coef, T(1), (T *)g->x));
+        if (g->pr) {
+            // x += Pr \ (V * y) with Ax as work space                     :278-283
+            T *Ax = (T *)g->Ax;
+            OpFill<T> z{Ax, T(0)};
+            MIK_TRY((launch_map<T>(ctx, g->n, z, mik_aligned16(Ax), (T *)nullptr, nullptr)));
+            MIK_TRY(gemv_n_dev<T>(ctx, g->n, k - 1, V, g->ldv, (const T *)ctx->coef, T(1), Ax));
+            OpDivide<T> dr{Ax, (const T *)g->pr, Ax};
+            MIK_TRY((launch_map<T>(ctx, g->n, dr, mik_aligned16(Ax) && mik_aligned16(g->pr), (T *)nullptr, nullptr)));
+            OpAxpy<T> ax{Ax, (T *)g->x, coef_val<T>(T(1))};
+            MIK_TRY((launch_map<T>(ctx, g->n, ax, mik_aligned16(Ax) && mik_aligned16(g->x), (T *)nullptr, nullptr)));
+        } else {
+            MIK_TRY(gemv_n_dev<T>(ctx, g->n, k - 1, V, g->ldv, (const T *)ctx->coef, T(1), (T *)g->x));
+        }
         k = 1;                                                            // :90
         if (!is_done(iteration)) {                                        // :93
             T beta;

@@ -51,7 +51,23 @@ template <> struct WideVec<float>  { using val = mik_f32x4; using idx = mik_i32x
 // block -> row-block map.  mode 0: identity (block b runs on XCD b % 8, so the 8 XCDs interleave
 // row-blocks; rows +-N^2 of a stencil then live in the SAME XCD whenever the plane size is a
 // multiple of 8 row-blocks).  mode 1: contiguous range per XCD.
-__device__ __forceinline__ int spmv_block_map(int b, int nb, int mode) { return mode == 1 ? xcd_remap(b, nb) : b; }
+// mode P >= 8 (a multiple of 8): "strips" -- the row-blocks are taken in planes of P (P = row-blocks
+// between a stencil row and its farthest neighbour row); inside every plane XCD k owns the contiguous
+// strip [k*P/8, (k+1)*P/8), and walks strip k of plane 0, then of plane 1, ...  Both the +-1 line
+// neighbours (same strip) and the +-plane neighbours (same XCD, P/8 workgroups earlier) then hit in
+// that XCD's L2, so x is fetched from the fabric about once instead of three times.
+__device__ __forceinline__ int spmv_block_map(int b, int nb, int mode)
+{
+    if (mode == 1) return xcd_remap(b, nb);
+    if (mode >= 8) {
+        const int P = mode, S = P >> 3;
+        if (b < (nb / P) * P) {
+            const int xcd = b & 7, q = b >> 3;
+            return (q / S) * P + xcd * S + (q % S);
+        }
+    }
+    return b;
+}
 
 // ---------------------------------------------------------------------------------------------
 // long rows: one wave per row

@@ -239,11 +239,13 @@ function IterativeSolvers.gmres_iterable!(x::HipVector{T}, A::HipCSR{T}, b::HipV
         Pl = Identity(), Pr = Identity(), abstol::Real = zero(T), reltol::Real = sqrt(eps(T)),
         restart::Int = min(20, size(A, 2)), maxiter::Int = size(A, 2), initially_zero::Bool = false,
         orth_meth::OrthogonalizationMethod = ModifiedGramSchmidt()) where {T}
-    (Pl isa Identity && Pr isa Identity) || throw(MikError(Cint(5), "gmres_iterable!", "preconditioners are not implemented on the device path"))
+    all(P -> P isa Identity || P isa HipJacobi, (Pl, Pr)) || throw(MikError(Cint(5), "gmres_iterable!", "Pl / Pr must be Identity() or HipJacobi on the device path"))
+    pl = Pl isa HipJacobi ? Pl.diagonal.ptr : C_NULL
+    pr = Pr isa HipJacobi ? Pr.diagonal.ptr : C_NULL
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:mik_gmres_create, libmik), Cint,
-        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Cint, Int64, Cint, Cint, Ref{Ptr{Cvoid}}),
-        A.ctx.handle, A.handle, x.ptr, b.ptr, Float64(abstol), Float64(reltol), restart, maxiter, initially_zero ? 1 : 0, orth_code(orth_meth), h),
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Cint, Int64, Cint, Cint, Ref{Ptr{Cvoid}}),
+        A.ctx.handle, A.handle, x.ptr, b.ptr, pl, pr, Float64(abstol), Float64(reltol), restart, maxiter, initially_zero ? 1 : 0, orth_code(orth_meth), h),
         "mik_gmres_create", A.ctx.handle)
     g = HipGMRESIterable{T, typeof(x)}(h[], A, x, b, HipResidual{T}(one(T)), 0, restart, 1, maxiter, zero(T), one(T))
     finalizer(i -> ccall((:mik_gmres_destroy, libmik), Cint, (Ptr{Cvoid},), i.handle), g)

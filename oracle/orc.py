@@ -69,7 +69,7 @@ def _declare(L):
         f = getattr(L, f"orc_gmres_{suf}")
         f.argtypes = [C.c_int64, _i64p, _i64p, fp, C.c_int, fp, fp, C.c_double, C.c_double,
                       C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _f64p, _i64p, _i64p,
-                      _i32p, _f64p, _f64p]
+                      _i32p, _f64p, _f64p, fp, fp]
         f.restype = None
         f = getattr(L, f"orc_orthogonalize_{suf}")
         f.argtypes = [fp, C.c_int64, C.c_int64, C.c_int, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -246,7 +246,7 @@ def cg(A: CSC, b, x0=None, *, abstol=0.0, reltol=None, maxiter=None, jacobi_diag
 
 
 def gmres(A: CSC, b, x0=None, *, abstol=0.0, reltol=None, restart=None, maxiter=None,
-          orth_meth="mgs", mode="seq", shape=(1, 1)):
+          orth_meth="mgs", mode="seq", shape=(1, 1), pl_diag=None, pr_diag=None):
     """``gmres!(x, A, b; log=true)`` / ``gmres(A, b)`` when ``x0 is None`` -- src/gmres.jl:184-222,143."""
     dtype = A.nzval.dtype
     suf, ct = _suf(dtype)
@@ -267,7 +267,9 @@ def gmres(A: CSC, b, x0=None, *, abstol=0.0, reltol=None, restart=None, maxiter=
                                        float(abstol), float(reltol), restart, maxiter,
                                        int(initially_zero), METHODS[orth_meth], MODES[mode],
                                        _p(shp, C.c_int), _p(res, C.c_double), C.byref(iters),
-                                       C.byref(mvps), C.byref(conv), C.byref(beta0), C.byref(tol))
+                                       C.byref(mvps), C.byref(conv), C.byref(beta0), C.byref(tol),
+                                       _p(None if pl_diag is None else np.ascontiguousarray(pl_diag, dtype), ct),
+                                       _p(None if pr_diag is None else np.ascontiguousarray(pr_diag, dtype), ct))
     hist = dict(iters=iters.value, mvps=mvps.value, isconverged=bool(conv.value),
                 resnorm=res[:iters.value].copy(), res0=beta0.value, tol=tol.value,
                 abstol=abstol, reltol=reltol, restart=restart)
