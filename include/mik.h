@@ -104,6 +104,11 @@ int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_cols, int6
                    const int64_t *ptr, const int64_t *idx, const void *val, int index_base,
                    int is_csc, mik_csr **out);
 int mik_csr_destroy(mik_csr *A);
+/* Opt-in, lossless: additionally store the operator dictionary-coded (one 16-bit code per entry: value
+ * index << 8 | (column - row) index; both dictionaries <= 256 entries, e.g. stencil operators).  Later
+ * mik_spmv / iterable calls then read 2 B instead of 12 B per entry and return bit-identical
+ * results.  MIK_ERR_NOTIMPL (operator unchanged) when the matrix does not qualify. */
+int mik_csr_pack(mik_csr *A);
 /* size(A, d), nnz, eltype(A) */
 int mik_csr_info(const mik_csr *A, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, int *dtype);
 

@@ -269,6 +269,16 @@ class HipCSR:
         m.sort_indices()
         return HipCSR(m.shape[0], m.shape[1], m.indptr, m.indices, m.data, index_base=0, is_csc=True, ctx=ctx)
 
+    def pack(self) -> bool:
+        """Opt in to the dictionary-coded operator (``mik_csr_pack``): 2 B instead of 12 B per entry for
+        matrices with <= 256 distinct values and column offsets; results are bit-identical.  Returns
+        False (operator unchanged) when the matrix does not qualify."""
+        code = lib().mik_csr_pack(self.handle)
+        if code == 5:
+            return False
+        check(code, "mik_csr_pack", self.ctx.handle)
+        return True
+
     def size(self, d: Optional[int] = None):
         return (self.n_rows, self.n_cols) if d is None else (self.n_rows, self.n_cols)[d - 1]
 

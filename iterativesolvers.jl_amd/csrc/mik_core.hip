@@ -6,6 +6,8 @@
 
 #include "mik_kernels.h"
 #include "mik_spmv.h"
+#include "mik_packed.h"
+#include <unordered_map>
 
 thread_local std::string g_mik_create_error;
 int g_mik_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -358,8 +360,81 @@ extern "C" int mik_csr_destroy(mik_csr *A)
     if (A->val) (void)hipFree(A->val);
     if (A->long_rows) (void)hipFree(A->long_rows);
     if (A->is_long) (void)hipFree(A->is_long);
+    if (A->codes) (void)hipFree(A->codes);
+    if (A->vtab) (void)hipFree(A->vtab);
+    if (A->dtab) (void)hipFree(A->dtab);
     delete A;
     return MIK_OK;
+}
+
+// Build the dictionary-coded form (csrc/mik_packed.h) from the device CSR.  MIK_ERR_NOTIMPL (and no
+// change) when the matrix does not qualify: more than 256 distinct values or (column - row) offsets,
+// or rows long enough to have been split off (n_long > 0).
+template <typename T> static int csr_pack_impl(mik_csr *A)
+{
+    mik_ctx *ctx = A->ctx;
+    const size_t n = (size_t)A->n_rows, nnz = (size_t)A->nnz;
+    std::vector<int> rowptr(n + 1), col(nnz);
+    std::vector<T> val(nnz);
+    MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MIK_HIP(ctx, hipMemcpy(rowptr.data(), A->rowptr, sizeof(int) * (n + 1), hipMemcpyDeviceToHost));
+    if (nnz) {
+        MIK_HIP(ctx, hipMemcpy(col.data(), A->col, sizeof(int) * nnz, hipMemcpyDeviceToHost));
+        MIK_HIP(ctx, hipMemcpy(val.data(), A->val, sizeof(T) * nnz, hipMemcpyDeviceToHost));
+    }
+    using Bits = typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type;
+    std::unordered_map<Bits, int> vmap;
+    std::unordered_map<int, int> dmap;
+    std::vector<T> vtab;
+    std::vector<int> dtab;
+    std::vector<unsigned short> codes(nnz + MIK_PACK_TILE, 0);
+    Bits last_bits = 0; int last_vc = -1, last_delta = 0, last_dc = -1;
+    for (size_t r = 0; r < n; ++r)
+        for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+            Bits bits;
+            memcpy(&bits, &val[k], sizeof(T));
+            int vc;
+            if (last_vc >= 0 && bits == last_bits) vc = last_vc;
+            else {
+                auto it = vmap.find(bits);
+                if (it == vmap.end()) {
+                    if (vtab.size() == 256) return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_csr_pack: more than 256 distinct values");
+                    vc = (int)vtab.size(); vmap.emplace(bits, vc); vtab.push_back(val[k]);
+                } else vc = it->second;
+                last_bits = bits; last_vc = vc;
+            }
+            const int delta = col[k] - (int)r;
+            int dc;
+            if (last_dc >= 0 && delta == last_delta) dc = last_dc;
+            else {
+                auto it = dmap.find(delta);
+                if (it == dmap.end()) {
+                    if (dtab.size() == 256) return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_csr_pack: more than 256 distinct column offsets");
+                    dc = (int)dtab.size(); dmap.emplace(delta, dc); dtab.push_back(delta);
+                } else dc = it->second;
+                last_delta = delta; last_dc = dc;
+            }
+            codes[k] = (unsigned short)((vc << 8) | dc);
+        }
+    A->nv = (int)vtab.size(); A->nd = (int)dtab.size();
+    vtab.resize(256, T(0)); dtab.resize(256, 0);
+    (void)hipSetDevice(ctx->device);
+    MIK_HIP(ctx, hipMalloc((void **)&A->codes, sizeof(unsigned short) * codes.size()));
+    MIK_HIP(ctx, hipMalloc(&A->vtab, sizeof(T) * 256));
+    MIK_HIP(ctx, hipMalloc((void **)&A->dtab, sizeof(int) * 256));
+    MIK_HIP(ctx, hipMemcpy(A->codes, codes.data(), sizeof(unsigned short) * codes.size(), hipMemcpyHostToDevice));
+    MIK_HIP(ctx, hipMemcpy(A->vtab, vtab.data(), sizeof(T) * 256, hipMemcpyHostToDevice));
+    MIK_HIP(ctx, hipMemcpy(A->dtab, dtab.data(), sizeof(int) * 256, hipMemcpyHostToDevice));
+    A->packed = true;
+    return MIK_OK;
+}
+
+extern "C" int mik_csr_pack(mik_csr *A)
+{
+    if (!A) return MIK_ERR_INVALID;
+    if (A->packed) return MIK_OK;
+    if (A->n_long) return mik_fail(A->ctx, MIK_ERR_NOTIMPL, "mik_csr_pack: matrix has long rows");
+    return A->dtype == MIK_F64 ? csr_pack_impl<double>(A) : csr_pack_impl<float>(A);
 }
 
 extern "C" int mik_csr_info(const mik_csr *A, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, int *dtype)
@@ -386,6 +461,17 @@ int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_
     const bool nt = g_mik_tuning[0] == 0;
     const bool wide = g_mik_tuning[1] == 0;
     const int map_mode = g_mik_tuning[2];
+    if (A->packed && g_mik_tuning[6] == 0) {
+        // dictionary-coded operator (mik_csr_pack): 2 B per entry instead of 12, same arithmetic
+        if (fuse_dot)
+            hipLaunchKernelGGL((k_spmv_packed<T, true>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, A->rowptr, A->codes,
+                               (const T *)A->vtab, A->dtab, A->nv, A->nd, x, y, seg_out, done);
+        else
+            hipLaunchKernelGGL((k_spmv_packed<T, false>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, A->rowptr, A->codes,
+                               (const T *)A->vtab, A->dtab, A->nv, A->nd, x, y, seg_out, done);
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    }
     const int nlong = A->n_long;
     const int nlb = (nlong + 3) / 4;
     const bool merge = nlong > 0 && !fuse_dot;           // one launch: long-row workgroups first, then row-blocks

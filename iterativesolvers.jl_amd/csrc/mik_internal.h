@@ -52,6 +52,12 @@ struct mik_csr {
     int n_long = 0;                  // rows longer than MIK_LONG_ROW, stored behind the short part
     int *long_rows = nullptr;        // device: [n_long] row ids, [n_long] start offsets, [n_long] lengths
     unsigned char *is_long = nullptr;   // device: n_rows flags (only when n_long > 0)
+    // optional dictionary-coded form (mik_csr_pack): one 16-bit code per entry + two <= 256-entry tables
+    unsigned short *codes = nullptr; // device, nnz (+ padding)
+    void *vtab = nullptr;            // device, 256 values of dtype
+    int *dtab = nullptr;             // device, 256 (column - row) offsets
+    int nv = 0, nd = 0;
+    bool packed = false;
 };
 
 extern thread_local std::string g_mik_create_error;
