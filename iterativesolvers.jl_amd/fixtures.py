@@ -61,6 +61,48 @@ def advection_dominated(N: int = 50, beta: float = 1000.0, index_base: int = 1):
     return n, colptr + index_base, rowval + index_base, nzval, np.ascontiguousarray(b.reshape(-1))
 
 
+def read_matrix_market(path: str, dtype=np.float64, index_base: int = 1):
+    """MatrixMarket ``coordinate`` reader -- the on-disk format of BASELINE.json configs[4]
+    (benchmark/matrixmarket.jl:5-10 downloads ``s3dkq4m2.mtx`` and calls ``MatrixMarket.mmread``).
+    Supports real / integer / pattern fields and general / symmetric / skew-symmetric symmetry; returns
+    SparseMatrixCSC fields ``(n_rows, n_cols, colptr, rowval, nzval)`` (duplicates summed, rows ascending
+    within a column) ready for ``HipCSR``."""
+    with open(path, "rb") as f:
+        header = f.readline().decode().strip().lower().split()
+        if len(header) < 5 or header[0] != "%%matrixmarket" or header[1] != "matrix" or header[2] != "coordinate":
+            raise ValueError(f"{path}: only '%%MatrixMarket matrix coordinate ...' files are supported")
+        field, symmetry = header[3], header[4]
+        if field not in ("real", "integer", "pattern", "double"):
+            raise ValueError(f"{path}: field '{field}' is out of scope (complex element types are not on this path)")
+        line = f.readline()
+        while line.startswith(b"%") or not line.strip():
+            line = f.readline()
+        n_rows, n_cols, nnz = (int(t) for t in line.split())
+        data = np.loadtxt(f, dtype=np.float64, ndmin=2) if nnz else np.zeros((0, 3))
+    if data.shape[0] != nnz:
+        raise ValueError(f"{path}: expected {nnz} entries, found {data.shape[0]}")
+    i = data[:, 0].astype(np.int64) - 1
+    j = data[:, 1].astype(np.int64) - 1
+    v = np.ones(nnz) if field == "pattern" else data[:, 2]
+    if symmetry in ("symmetric", "skew-symmetric"):
+        off = i != j
+        sign = -1.0 if symmetry == "skew-symmetric" else 1.0
+        i, j, v = np.concatenate([i, j[off]]), np.concatenate([j, i[off]]), np.concatenate([v, sign * v[off]])
+    elif symmetry != "general":
+        raise ValueError(f"{path}: symmetry '{symmetry}' is not supported")
+    order = np.lexsort((i, j))                                   # column-major, rows ascending
+    i, j, v = i[order], j[order], v[order]
+    if i.size:
+        first = np.ones(i.size, bool)
+        first[1:] = (i[1:] != i[:-1]) | (j[1:] != j[:-1])
+        group = np.cumsum(first) - 1
+        v = np.bincount(group, weights=v)                        # duplicates are summed
+        i, j = i[first], j[first]
+    colptr = np.zeros(n_cols + 1, np.int64)
+    np.cumsum(np.bincount(j, minlength=n_cols), out=colptr[1:])
+    return n_rows, n_cols, colptr + index_base, i + index_base, np.ascontiguousarray(v.astype(dtype))
+
+
 def _hash32(x: np.ndarray, mult: int) -> np.ndarray:
     """(x * mult) mod 2^32 followed by an xorshift -- integer arithmetic only, exact in any language."""
     h = (x.astype(np.uint64) * np.uint64(mult)) & np.uint64(0xFFFFFFFF)
