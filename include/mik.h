@@ -141,6 +141,15 @@ int mik_orthogonalize(mik_ctx *ctx, int dtype, int64_t n, int k, const void *V, 
 int mik_gemv_n(mik_ctx *ctx, int dtype, int64_t n, int k, const void *V, int64_t ldv,
                const void *c, const void *alpha, void *y);
 
+/* h = V[:, 1:k]' * w -- mul!(h, adjoint(V), w): src/orthogonalize.jl:15,43 and (column by column) the
+ * Gram matrix of src/bicgstabl.jl:121.  One sweep reads w once and every column once.  h: HOST. */
+int mik_gemv_t(mik_ctx *ctx, int dtype, int64_t n, int k, const void *V, int64_t ldv, const void *w,
+               void *h);
+/* Host: solve the small dense system A x = b (column-major n x n) by LU with partial pivoting --
+ * lu! + ldiv! at src/bicgstabl.jl:124-125.  A is overwritten by its factors, b by x; status 1 if A is
+ * exactly singular. */
+int mik_lu_solve(int dtype, void *A, int64_t lda, int n, void *b);
+
 /* ---- L3 iterables ------------------------------------------------------------------------ */
 /* cg_iterator!(x, A, b, Pl; abstol, reltol, maxiter, statevars, initially_zero)
  *   -- src/cg.jl:120-155.  x, b and the CGStateVariables u, r, c (src/cg.jl:114-118) are device

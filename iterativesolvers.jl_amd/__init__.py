@@ -16,4 +16,5 @@ from .api import (CGIterable, CGStateVariables, ClassicalGramSchmidt, Convergenc
                   GenericCGIterable, GMRESIterable, HipContext, HipCSR, HipMatrix, HipVector, Identity,
                   JacobiPrec, ModifiedGramSchmidt, PCGIterable, cg, cg_, cg_iterator_, default_context,
                   dot, gemv_n_, gmres, gmres_, gmres_iterable_, hessenberg_ldiv_, mul_, niters, norm, nprods,
-                  nrests, orthogonalize_and_normalize_, zerox)
+                  nrests, orthogonalize_and_normalize_, zerox, BiCGStabIterable, bicgstabl, bicgstabl_, bicgstabl_iterator_,
+                  gemv_t_, lu_solve_)

@@ -65,6 +65,8 @@ SIGNATURES = {
     "mik_divide": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp]),
     "mik_orthogonalize": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _vp, _i64, _vp, _vp, _vp, C.c_int]),
     "mik_gemv_n": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _vp, _i64, _vp, _vp, _vp]),
+    "mik_gemv_t": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _vp, _i64, _vp, _vp]),
+    "mik_lu_solve": (C.c_int, [C.c_int, _vp, _i64, C.c_int, _vp]),
     "mik_cg_create": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, _i64,
                                 C.c_int, C.POINTER(_vp)]),
     "mik_cg_destroy": (C.c_int, [_vp]),

@@ -653,13 +653,32 @@ def orthogonalize_and_normalize_(V: HipMatrix, k: int, w: HipVector, h: np.ndarr
     return nrm[0]
 
 
-def gemv_n_(y: HipVector, V: HipMatrix, k: int, c: np.ndarray, alpha=1.0) -> HipVector:
-    """``mul!(y, view(V, :, 1:k), c, alpha, 1)`` -- src/gmres.jl:275."""
+def gemv_n_(y: HipVector, V: HipMatrix, k: int, c: np.ndarray, alpha=1.0, col0: int = 0) -> HipVector:
+    """``mul!(y, view(V, :, col0+1 : col0+k), c, alpha, 1)`` -- src/gmres.jl:275, src/bicgstabl.jl:127-129."""
     c = np.ascontiguousarray(c[:k], V.dtype)
     _, pa = _scalar(V.dtype, alpha)
-    check(lib().mik_gemv_n(V.ctx.handle, dtype_code(V.dtype), V.n, int(k), _vp(V.buf.ptr), V.ld, c.ctypes.data_as(_vp), pa, _vp(y.ptr)),
+    check(lib().mik_gemv_n(V.ctx.handle, dtype_code(V.dtype), V.n, int(k), _vp(V.col(col0).ptr), V.ld, c.ctypes.data_as(_vp), pa, _vp(y.ptr)),
           "mik_gemv_n", V.ctx.handle)
     return y
+
+
+def gemv_t_(V: HipMatrix, k: int, w: HipVector, col0: int = 0) -> np.ndarray:
+    """``adjoint(view(V, :, col0+1 : col0+k)) * w`` -- src/orthogonalize.jl:15, one column of src/bicgstabl.jl:121."""
+    h = np.zeros(max(k, 1), V.dtype)
+    check(lib().mik_gemv_t(V.ctx.handle, dtype_code(V.dtype), V.n, int(k), _vp(V.col(col0).ptr), V.ld, _vp(w.ptr), h.ctypes.data_as(_vp)),
+          "mik_gemv_t", V.ctx.handle)
+    return h[:k]
+
+
+def lu_solve_(A: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """``ldiv!(x, lu!(A), b)`` for a small dense host matrix -- src/bicgstabl.jl:124-125.  Overwrites both."""
+    if not A.flags.f_contiguous or A.dtype != b.dtype or A.shape[0] != A.shape[1] or b.size != A.shape[0]:
+        raise ValueError("lu_solve_: A must be a square F-ordered array, b a vector of the same dtype")
+    code = lib().mik_lu_solve(dtype_code(A.dtype), A.ctypes.data_as(_vp), A.shape[0], A.shape[0], b.ctypes.data_as(_vp))
+    if code == 1:
+        raise np.linalg.LinAlgError("SingularException")
+    check(code, "mik_lu_solve", None)
+    return b
 
 
 def hessenberg_ldiv_(H: np.ndarray, rhs: np.ndarray):
@@ -787,3 +806,134 @@ def gmres_(x: HipVector, A: HipCSR, b: HipVector, *, Pl=None, Pr=None, abstol=0.
 def gmres(A: HipCSR, b: HipVector, **kwargs):
     """``gmres(A, b; ...)`` -- src/gmres.jl:143."""
     return gmres_(zerox(A, b), A, b, initially_zero=True, **kwargs)
+
+
+# ==============================================================================================
+# bicgstabl.jl  (SURVEY.md section 8f rank 3: composed from the L1 / L2 entry points)
+# ==============================================================================================
+class BiCGStabIterable:
+    """``BiCGStabIterable`` -- src/bicgstabl.jl:5-23; construction follows ``bicgstabl_iterator!`` (:25-73).
+    ``r_shadow`` replaces the reference's ``rand(T, n)`` (:38) so that runs are reproducible; by default it
+    is the hashed vector of ``fixtures.hashed_rhs`` shifted into (0, 1)."""
+
+    def __init__(self, x: HipVector, A: HipCSR, b: HipVector, l: int = 2, *, Pl=None, max_mv_products, abstol, reltol,
+                 initial_zero, r_shadow: Optional[HipVector] = None):
+        from . import fixtures
+        T = x.dtype.type
+        n = A.size(1)
+        self.A, self.l, self.x = A, int(l), x
+        self.Pl = Identity() if Pl is None else Pl
+        if not isinstance(self.Pl, (Identity, JacobiPrec)):
+            raise MikError(5, "bicgstabl_iterator_", "Pl must be Identity() or a diagonal JacobiPrec on the device path")
+        self.mv_products = 0
+        self.r_shadow = r_shadow if r_shadow is not None else HipVector.from_numpy((fixtures.hashed_rhs(n) + 0.5).astype(x.dtype), x.ctx)
+        self.rs = HipMatrix(n, self.l + 1, x.dtype, x.ctx)                  # :39
+        self.us = HipMatrix(n, self.l + 1, x.dtype, x.ctx)                  # :40 zeros
+        residual = self.rs.col(0)
+        if initial_zero:
+            residual.copyto_(b)                                              # :46
+        else:
+            mul_(residual, A, x)                                             # :48
+            residual.xpby_(b, T(-1))                                         # residual .= b .- residual  :49
+            self.mv_products += 1
+        self._ldiv(residual)                                                 # :55
+        self.gamma = np.zeros(self.l, x.dtype)                               # :58
+        self.omega = self.sigma = T(1)                                       # :59
+        self.residual = norm(residual)                                       # :61
+        self.M = np.zeros((self.l + 1, self.l + 1), x.dtype, order="F")      # :66
+        self.tol = max(T(reltol) * self.residual, T(abstol))                 # :69
+        self.max_mv_products = int(max_mv_products)
+
+    def _ldiv(self, v: HipVector):
+        if isinstance(self.Pl, JacobiPrec):
+            self.Pl.ldiv_(v)
+
+    def converged(self) -> bool:                                             # :75
+        return self.residual <= self.tol
+
+    def start(self) -> int:
+        return 0
+
+    def done(self, iteration: int) -> bool:                                  # :77
+        return self.mv_products >= self.max_mv_products or self.converged()
+
+    def iterate(self, iteration: Optional[int] = None):
+        """``iterate(it, iteration)`` -- src/bicgstabl.jl:79-134."""
+        iteration = 0 if iteration is None else iteration
+        if self.done(iteration):
+            return None
+        l, rs, us = self.l, self.rs, self.us
+        self.sigma = -self.omega * self.sigma                                # :85
+        for j in range(l):                                                   # BiCG part  :88
+            rho = dot(self.r_shadow, rs.col(j))                              # :89
+            beta = rho / self.sigma                                          # :90
+            for q in range(j + 1):
+                us.col(q).xpby_(rs.col(q), -beta)                            # us = rs - beta*us  :93
+            mul_(us.col(j + 1), self.A, us.col(j))                           # :97
+            self._ldiv(us.col(j + 1))                                        # :98
+            self.sigma = dot(self.r_shadow, us.col(j + 1))                   # :100
+            alpha = rho / self.sigma                                         # :101
+            for q in range(j + 1):
+                rs.col(q).axpy_(-alpha, us.col(q + 1))                       # rs -= alpha*us  :103
+            mul_(rs.col(j + 1), self.A, rs.col(j))                           # :107
+            self._ldiv(rs.col(j + 1))                                        # :108
+            self.x.axpy_(alpha, us.col(0))                                   # :111
+        self.mv_products += 2 * l                                            # :115
+        for c in range(l + 1):                                               # M = rs' * rs  :120
+            self.M[:, c] = gemv_t_(rs, l + 1, rs.col(c))
+        Msub = np.asfortranarray(self.M[1:, 1:].copy())
+        self.gamma = lu_solve_(Msub, self.M[1:, 0].copy())                   # :123-125
+        gemv_n_(us.col(0), us, l, self.gamma, -1.0, col0=1)                  # :127
+        gemv_n_(self.x, rs, l, self.gamma, 1.0, col0=0)                      # :128
+        gemv_n_(rs.col(0), rs, l, self.gamma, -1.0, col0=1)                  # :129
+        self.omega = self.gamma[l - 1]                                       # :131
+        self.residual = norm(rs.col(0))                                      # :132
+        return self.residual, iteration + 1
+
+    def __iter__(self):
+        iteration = 0
+        while (nxt := self.iterate(iteration)) is not None:
+            residual, iteration = nxt
+            yield residual
+
+
+def bicgstabl_iterator_(x: HipVector, A: HipCSR, b: HipVector, l: int = 2, *, Pl=None, max_mv_products=None, abstol=0.0,
+                        reltol=None, initial_zero: bool = False, r_shadow: Optional[HipVector] = None):
+    """``bicgstabl_iterator!(x, A, b, l; ...)`` -- src/bicgstabl.jl:25-73."""
+    reltol = _default_reltol(b) if reltol is None else reltol
+    max_mv_products = A.size(2) if max_mv_products is None else max_mv_products
+    return BiCGStabIterable(x, A, b, l, Pl=Pl, max_mv_products=max_mv_products, abstol=abstol, reltol=reltol,
+                            initial_zero=initial_zero, r_shadow=r_shadow)
+
+
+def bicgstabl_(x: HipVector, A: HipCSR, b: HipVector, l: int = 2, *, abstol=0.0, reltol=None, max_mv_products=None,
+               log: bool = False, verbose: bool = False, Pl=None, **kwargs):
+    """``bicgstabl!(x, A, b, l; ...)`` -> ``x`` or ``(x, history)`` -- src/bicgstabl.jl:181-219."""
+    reltol = _default_reltol(b) if reltol is None else reltol
+    max_mv_products = A.size(2) if max_mv_products is None else max_mv_products
+    history = ConvergenceHistory(partial=not log)
+    history["abstol"] = abstol
+    history["reltol"] = reltol
+    if log:
+        history.reserve_("resnorm", max_mv_products)                        # :194
+    iterable = bicgstabl_iterator_(x, A, b, l, Pl=Pl, abstol=abstol, reltol=reltol, max_mv_products=max_mv_products, **kwargs)
+    if log:
+        history.mvps = iterable.mv_products                                  # :202
+    for iteration, _item in enumerate(iterable, start=1):                    # :205
+        if log:
+            history.nextiter_()
+            history.mvps = iterable.mv_products                              # :208
+            history.push_("resnorm", iterable.residual)
+        if verbose:
+            print("%3d\t%1.2e" % (iteration, iterable.residual))
+    if verbose:
+        print()
+    if log:
+        history.setconv(iterable.converged())
+        history.shrink_()
+    return (iterable.x, history) if log else iterable.x
+
+
+def bicgstabl(A: HipCSR, b: HipVector, l: int = 2, **kwargs):
+    """``bicgstabl(A, b, l; ...)`` -- src/bicgstabl.jl:142."""
+    return bicgstabl_(zerox(A, b), A, b, l, initial_zero=True, **kwargs)

@@ -1189,3 +1189,67 @@ extern "C" int mik_cgd_wait(mik_cgd *it, double *residual, double *tol, int *don
     if (steps) *steps = nd;
     return MIK_OK;
 }
+
+// =============================================================================================
+// helpers for BiCGStab(l) (src/bicgstabl.jl): batched dot to the host, small dense LU solve
+// =============================================================================================
+
+// h = V[:, 1:k]' * w -- mul!(h, adjoint(V), w) (src/orthogonalize.jl:15) and, column by column, the
+// Gram matrix mul!(M, adjoint(rs), rs) of src/bicgstabl.jl:121.  h: HOST array of k scalars.
+template <typename T> static int gemv_t_impl(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, const T *w, T *h_host)
+{
+    if (k == 0) return MIK_OK;
+    if ((size_t)k * sizeof(T) > mik_ctx::COEF_BYTES) return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_gemv_t: k = %d too large", k);
+    const int64_t nseg = mik_nseg<T>(n);
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(nseg, 1) * (size_t)k));
+    MIK_TRY(multidot<T>(ctx, n, k, V, ldv, w, (T *)ctx->coef));
+    return coef_download<T>(ctx, 0, h_host, k);
+}
+
+extern "C" int mik_gemv_t(mik_ctx *ctx, int dtype, int64_t n, int k, const void *V, int64_t ldv, const void *w, void *h)
+{
+    if (!ctx || n < 0 || k < 0 || (k && (!h || !V || ldv < n)) || (n && k && !w)) return MIK_ERR_INVALID;
+    if (dtype == MIK_F64) return gemv_t_impl<double>(ctx, n, k, (const double *)V, ldv, (const double *)w, (double *)h);
+    if (dtype == MIK_F32) return gemv_t_impl<float>(ctx, n, k, (const float *)V, ldv, (const float *)w, (float *)h);
+    return MIK_ERR_INVALID;
+}
+
+// Solve A x = b for a small dense column-major A (n x n, leading dimension lda) by LU with partial
+// pivoting -- F = lu!(view(M, L, L)); ldiv!(gamma, F, view(M, L, 1)) at src/bicgstabl.jl:124-125.
+// A is overwritten by its factors, b by the solution.  Returns 1 (MIK_ERR_INVALID) on an exactly
+// singular pivot (the reference throws SingularException).
+template <typename T> static int lu_solve(T *A, int64_t lda, int n, T *b)
+{
+    auto at = [&](int i, int j) -> T & { return A[(size_t)j * lda + i]; };
+    for (int j = 0; j < n; ++j) {
+        int p = j;
+        T best = std::fabs(at(j, j));
+        for (int i = j + 1; i < n; ++i) { const T a = std::fabs(at(i, j)); if (a > best) { best = a; p = i; } }
+        if (best == T(0)) return MIK_ERR_INVALID;
+        if (p != j) {
+            for (int c = 0; c < n; ++c) std::swap(at(j, c), at(p, c));
+            std::swap(b[j], b[p]);
+        }
+        const T piv = at(j, j);
+        for (int i = j + 1; i < n; ++i) {
+            const T m = at(i, j) / piv;
+            at(i, j) = m;
+            for (int c = j + 1; c < n; ++c) at(i, c) = at(i, c) - m * at(j, c);
+            b[i] = b[i] - m * b[j];
+        }
+    }
+    for (int j = n - 1; j >= 0; --j) {
+        b[j] = b[j] / at(j, j);
+        const T t = b[j];
+        for (int i = 0; i < j; ++i) b[i] = b[i] - t * at(i, j);
+    }
+    return MIK_OK;
+}
+
+extern "C" int mik_lu_solve(int dtype, void *A, int64_t lda, int n, void *b)
+{
+    if (!A || !b || n < 0 || lda < n) return MIK_ERR_INVALID;
+    if (dtype == MIK_F64) return lu_solve<double>((double *)A, lda, n, (double *)b);
+    if (dtype == MIK_F32) return lu_solve<float>((float *)A, lda, n, (float *)b);
+    return MIK_ERR_INVALID;
+}

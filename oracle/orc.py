@@ -80,6 +80,13 @@ def _declare(L):
         f = getattr(L, f"orc_givens_{suf}")
         f.argtypes = [ft, ft, fp, fp, fp]
         f.restype = None
+        f = getattr(L, f"orc_bicgstabl_{suf}")
+        f.argtypes = [C.c_int64, _i64p, _i64p, fp, C.c_int, fp, fp, fp, C.c_int, C.c_double, C.c_double, C.c_int64,
+                      C.c_int, C.c_int, _i32p, _f64p, _i64p, _i64p, _i32p, _f64p, _f64p]
+        f.restype = C.c_int
+        f = getattr(L, f"orc_lu_solve_{suf}")
+        f.argtypes = [fp, C.c_int64, C.c_int, fp]
+        f.restype = C.c_int
         f = getattr(L, f"orc_hessenberg_ldiv_{suf}")
         f.argtypes = [fp, C.c_int64, C.c_int, fp]
         f.restype = None
@@ -316,3 +323,44 @@ def hessenberg_ldiv(H, rhs):
     rhs = np.array(rhs, H.dtype, copy=True)
     getattr(lib(), f"orc_hessenberg_ldiv_{suf}")(_p(H, ct), H.shape[0], H.shape[1], _p(rhs, ct))
     return H, rhs
+
+
+def lu_solve(A, b):
+    """``ldiv!(x, lu!(A), b)`` on a small dense matrix -- src/bicgstabl.jl:124-125.  Returns x."""
+    A = np.array(A, order="F", copy=True)
+    suf, ct = _suf(A.dtype)
+    b = np.array(b, A.dtype, copy=True)
+    rc = getattr(lib(), f"orc_lu_solve_{suf}")(_p(A, ct), A.shape[0], A.shape[0], _p(b, ct))
+    if rc:
+        raise np.linalg.LinAlgError("singular matrix")
+    return b
+
+
+def bicgstabl(A: CSC, b, l=2, x0=None, *, r_shadow, abstol=0.0, reltol=None, max_mv_products=None, mode="seq",
+              shape=(1, 1)):
+    """``bicgstabl!(x, A, b, l; log=true)`` / ``bicgstabl(A, b, l)`` when ``x0 is None`` -- src/bicgstabl.jl:181-219,142.
+    ``r_shadow`` replaces the reference's ``rand(T, n)`` (src/bicgstabl.jl:38)."""
+    dtype = A.nzval.dtype
+    suf, ct = _suf(dtype)
+    b = np.ascontiguousarray(b, dtype)
+    rsh = np.ascontiguousarray(r_shadow, dtype)
+    n = A.n
+    initial_zero = x0 is None
+    x = np.zeros(n, dtype) if x0 is None else np.array(x0, dtype, copy=True)
+    reltol = _eps_sqrt(dtype) if reltol is None else reltol
+    max_mv = n if max_mv_products is None else int(max_mv_products)
+    res = np.zeros(max(max_mv, 1), np.float64)
+    iters, mvps = C.c_int64(0), C.c_int64(0)
+    conv = C.c_int(0)
+    res0, tol = C.c_double(0), C.c_double(0)
+    shp = np.asarray(shape, np.int32)
+    rc = getattr(lib(), f"orc_bicgstabl_{suf}")(n, _p(A.colptr, C.c_int64), _p(A.rowval, C.c_int64), _p(A.nzval, ct),
+                                                A.index_base, _p(b, ct), _p(x, ct), _p(rsh, ct), int(l), float(abstol),
+                                                float(reltol), max_mv, int(initial_zero), MODES[mode], _p(shp, C.c_int),
+                                                _p(res, C.c_double), C.byref(iters), C.byref(mvps), C.byref(conv),
+                                                C.byref(res0), C.byref(tol))
+    if rc:
+        raise np.linalg.LinAlgError("singular matrix in the MR part")
+    hist = dict(iters=iters.value, mvps=mvps.value, isconverged=bool(conv.value), resnorm=res[:iters.value].copy(),
+                res0=res0.value, tol=tol.value, abstol=abstol, reltol=reltol)
+    return x, hist

@@ -1,0 +1,91 @@
+"""BiCGStab(l) (src/bicgstabl.jl): the reference's property tests against
+the oracle (CPU) and bit-level parity of the device composition against the oracle (GPU)."""
+import numpy as np
+import pytest
+
+
+# ---- oracle: test/bicgstabl.jl ---------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("l", [2, 4])
+def test_oracle_dense(orc, dtype, l):
+    rng = np.random.default_rng(123)
+    n = 20
+    Ad = (rng.random((n, n)) + 15 * np.eye(n)).astype(dtype)                 # test/bicgstabl.jl:17
+    b = (Ad @ np.ones(n, dtype)).astype(dtype)
+    reltol = float(np.sqrt(np.finfo(dtype).eps))
+    A = orc.CSC.from_dense(Ad)
+    sh = rng.random(n).astype(dtype)
+    x1, h1 = orc.bicgstabl(A, b, l, r_shadow=sh, max_mv_products=100, reltol=reltol)
+    assert np.linalg.norm(Ad @ x1 - b) / np.linalg.norm(b) <= reltol          # :27
+    x2, h2 = orc.bicgstabl(A, b, l, rng.random(n).astype(dtype), r_shadow=sh, max_mv_products=100, reltol=reltol)
+    assert np.linalg.norm(Ad @ x2 - b) / np.linalg.norm(b) <= reltol          # :34
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_oracle_termination(orc, dtype):
+    T3 = np.array([[2, -1, 0], [-1, 2, -1], [0, -1, 2]], dtype)               # test/bicgstabl.jl:50-72
+    A = orc.CSC.from_dense(T3)
+    b = np.ones(3, dtype)
+    x0 = np.linalg.solve(T3.astype(np.float64), b.astype(np.float64)).astype(dtype)
+    pert = (10 * np.sqrt(np.finfo(dtype).eps) * np.array([-1.0, 1.0, -1.0])).astype(dtype)
+    sh = np.array([0.3, 0.7, 0.5], dtype)
+    x, ch = orc.bicgstabl(A, b, 2, x0 + pert, r_shadow=sh)
+    assert 1 <= ch["iters"] <= 3 // 2                                          # :63
+    r0 = float(np.linalg.norm(T3 @ (x0 + pert) - b))
+    x, ch = orc.bicgstabl(A, b, 2, x0 + pert, r_shadow=sh, abstol=2 * r0, reltol=0.0)
+    assert ch["iters"] == 0                                                    # :70
+
+
+def test_lu_solve_matches_numpy(pkg, orc):
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 4, 7):
+        A = rng.standard_normal((n, n)) + n * np.eye(n)
+        b = rng.standard_normal(n)
+        x = orc.lu_solve(A, b)
+        np.testing.assert_allclose(x, np.linalg.solve(A, b), rtol=1e-12)
+        Af, bf = np.asfortranarray(A.copy()), b.copy()
+        assert np.array_equal(pkg.lu_solve_(Af, bf), x)                        # product (C++) == oracle (C), bit for bit
+    with pytest.raises(np.linalg.LinAlgError):
+        pkg.lu_solve_(np.zeros((2, 2), order="F"), np.ones(2))
+
+
+# ---- device ----------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("l", [2, 4])
+def test_device_matches_oracle_bit_exact(pkg, orc, ctx, l, dtype):
+    """the reference authors' own BiCGStab benchmark operator (benchmark/benchmark-linear-systems.jl:68-77), small"""
+    A, b = orc.advdiff(12, 300.0)
+    A, b = A.astype(dtype), b.astype(dtype)
+    sh = (orc.hashed_rhs(A.n) + 0.5).astype(dtype)
+    dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
+    x0 = np.random.default_rng(2).standard_normal(A.n).astype(dtype)
+    for start in (None, x0):
+        if start is None:
+            x, ch = pkg.bicgstabl(dA, pkg.HipVector.from_numpy(b), l, log=True, max_mv_products=2000, r_shadow=pkg.HipVector.from_numpy(sh))
+        else:
+            x, ch = pkg.bicgstabl_(pkg.HipVector.from_numpy(start), dA, pkg.HipVector.from_numpy(b), l, log=True, max_mv_products=2000,
+                                   r_shadow=pkg.HipVector.from_numpy(sh))
+        xo, ho = orc.bicgstabl(A, b, l, start, r_shadow=sh, max_mv_products=2000, mode="tree", shape=ctx.reduce_shape(dtype))
+        assert ch.iters == ho["iters"] and ch.mvps == ho["mvps"] and ch.isconverged == ho["isconverged"]
+        assert np.array_equal(ch["resnorm"], ho["resnorm"], equal_nan=True) and np.array_equal(x.to_numpy(), xo, equal_nan=True)   # fp32, l = 4 breaks down (NaN) identically on both sides
+    if dtype == np.float64:
+        S = A.to_scipy()
+        assert ch.isconverged and np.linalg.norm(S @ x.to_numpy() - b) / np.linalg.norm(b) <= 1e-3   # recurrence residual, not the true one (src/bicgstabl.jl:161-163)
+
+
+@pytest.mark.gpu
+def test_device_reference_properties(pkg, orc, ctx):
+    rng = np.random.default_rng(123)
+    n = 20
+    Ad = rng.random((n, n)) + 15 * np.eye(n)
+    b = Ad @ np.ones(n)
+    dA = pkg.HipCSR(n, n, *[getattr(orc.CSC.from_dense(Ad), f) for f in ("colptr", "rowval", "nzval")])
+    for l in (2, 4):
+        x1, his1 = pkg.bicgstabl(dA, pkg.HipVector.from_numpy(b), l, max_mv_products=100, log=True)
+        assert isinstance(his1, pkg.ConvergenceHistory)
+        assert np.linalg.norm(Ad @ x1.to_numpy() - b) / np.linalg.norm(b) <= np.sqrt(np.finfo(float).eps)
+        xg = pkg.HipVector.from_numpy(rng.random(n))
+        x2, his2 = pkg.bicgstabl_(xg, dA, pkg.HipVector.from_numpy(b), l, max_mv_products=100, log=True)
+        assert x2 is xg                                                          # test/bicgstabl.jl:33
+        assert np.linalg.norm(Ad @ x2.to_numpy() - b) / np.linalg.norm(b) <= np.sqrt(np.finfo(float).eps)
