@@ -222,6 +222,10 @@ int mik_cgd_wait(mik_cgd *it, double *residual, double *tol, int *done, double *
  * entries, overwritten by [y; residual]. */
 int mik_hessenberg_ldiv(int dtype, void *H, int64_t ldh, int width, void *rhs);
 
+/* Host: LinearAlgebra.givensAlgorithm(f, g) -> out = {c, s, r} with [c s; -s c] [f; g] = [r; 0]
+ * (src/hessenberg.jl:24, src/minres.jl:129).  f, g, out: host scalars / 3-array of dtype. */
+int mik_givens(int dtype, const void *f, const void *g, void *out);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 /* Time `reps` back-to-back launches of the SpMV (optionally with the fused dot epilogue used by
  * the CG step) with HIP events on the ctx stream; returns average milliseconds per launch. */

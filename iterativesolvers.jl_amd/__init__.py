@@ -17,4 +17,5 @@ from .api import (CGIterable, CGStateVariables, ClassicalGramSchmidt, Convergenc
                   JacobiPrec, ModifiedGramSchmidt, PCGIterable, cg, cg_, cg_iterator_, default_context,
                   dot, gemv_n_, gmres, gmres_, gmres_iterable_, hessenberg_ldiv_, mul_, niters, norm, nprods,
                   nrests, orthogonalize_and_normalize_, zerox, BiCGStabIterable, bicgstabl, bicgstabl_, bicgstabl_iterator_,
-                  gemv_t_, lu_solve_)
+                  gemv_t_, lu_solve_, ChebyshevIterable, chebyshev, chebyshev_, chebyshev_iterable_, MINRESIterable, minres, minres_,
+                  minres_iterable_, givens_algorithm)

@@ -937,3 +937,229 @@ def bicgstabl_(x: HipVector, A: HipCSR, b: HipVector, l: int = 2, *, abstol=0.0,
 def bicgstabl(A: HipCSR, b: HipVector, l: int = 2, **kwargs):
     """``bicgstabl(A, b, l; ...)`` -- src/bicgstabl.jl:142."""
     return bicgstabl_(zerox(A, b), A, b, l, initial_zero=True, **kwargs)
+
+
+# ==============================================================================================
+# chebyshev.jl, minres.jl  (SURVEY.md section 8f rank 4: composed from the L1 entry points)
+# ==============================================================================================
+def givens_algorithm(f, g, dtype=np.float64):
+    """``LinearAlgebra.givensAlgorithm(f, g)`` -> (c, s, r) on the host -- src/minres.jl:129."""
+    fa, ga, out = np.asarray([f], dtype), np.asarray([g], dtype), np.zeros(3, dtype)
+    check(lib().mik_givens(dtype_code(dtype), fa.ctypes.data_as(_vp), ga.ctypes.data_as(_vp), out.ctypes.data_as(_vp)), "mik_givens", None)
+    return out[0], out[1], out[2]
+
+
+class ChebyshevIterable:
+    """``ChebyshevIterable`` -- src/chebyshev.jl:5-22, construction per ``chebyshev_iterable!`` (:59-91).  Follows the
+    v0.9.4 source as written: ``start = 0`` with the ``iteration == 1`` branch (:26, :37) and
+    ``u .= c .+ beta .* c`` (:45)."""
+
+    def __init__(self, x, A, b, lmin, lmax, *, abstol, reltol, maxiter, Pl=None, initially_zero=False):
+        T = x.dtype.type
+        self.Pl = Identity() if Pl is None else Pl
+        if not isinstance(self.Pl, (Identity, JacobiPrec)):
+            raise MikError(5, "chebyshev_iterable_", "Pl must be Identity() or a diagonal JacobiPrec on the device path")
+        self.A, self.x = A, x
+        self.l_avg = (T(lmax) + T(lmin)) / T(2)                              # :66
+        self.l_diff = (T(lmax) - T(lmin)) / T(2)                             # :67
+        self.r = x.similar().copyto_(b)                                      # :70-71
+        self.u = x.zero()
+        self.c = x.similar()
+        if initially_zero:
+            self.mv_products = 0
+        else:
+            self.mv_products = 1
+            mul_(self.c, A, x)                                               # :80
+            self.r.sub_(self.c)                                              # :81
+        self.resnorm = norm(self.r)                                          # :83
+        self.tol = max(T(reltol) * self.resnorm, T(abstol))                  # :84
+        self.alpha = T(0)
+        self.maxiter = int(maxiter)
+
+    def converged(self):
+        return self.resnorm <= self.tol
+
+    def start(self):
+        return 0
+
+    def done(self, iteration):
+        return iteration >= self.maxiter or self.converged()
+
+    def iterate(self, iteration=None):
+        iteration = 0 if iteration is None else iteration
+        if self.done(iteration):
+            return None
+        T = self.x.dtype.type
+        self.Pl.ldiv_(self.c, self.r)                                        # :35
+        if iteration == 1:                                                   # :37
+            self.alpha = T(2) / self.l_avg
+            self.u.copyto_(self.c)
+        else:
+            h = (self.l_diff * self.alpha) / T(2)
+            beta = h * h                                                     # :41
+            self.alpha = T(1) / (self.l_avg - beta)                          # :42
+            self.u.copyto_(self.c).axpy_(beta, self.c)                       # u .= c .+ beta .* c  :45
+        mul_(self.c, self.A, self.u)                                         # :48
+        self.mv_products += 1
+        self.x.axpy_(self.alpha, self.u)                                     # :51
+        self.r.axpy_(-self.alpha, self.c)                                    # :52
+        self.resnorm = norm(self.r)                                          # :54
+        return self.resnorm, iteration + 1
+
+    def __iter__(self):
+        iteration = 0
+        while (nxt := self.iterate(iteration)) is not None:
+            resnorm, iteration = nxt
+            yield resnorm
+
+
+def chebyshev_iterable_(x, A, b, lmin, lmax, *, abstol=0.0, reltol=None, maxiter=None, Pl=None, initially_zero=False):
+    """``chebyshev_iterable!`` -- src/chebyshev.jl:59-91."""
+    return ChebyshevIterable(x, A, b, lmin, lmax, abstol=abstol, reltol=_default_reltol(b) if reltol is None else reltol,
+                             maxiter=A.size(2) if maxiter is None else maxiter, Pl=Pl, initially_zero=initially_zero)
+
+
+def _drive(iterable, history, log, verbose, per_iter_mvps=None):
+    for iteration, resnorm in enumerate(iterable, start=1):
+        history.nextiter_(**({} if per_iter_mvps is None else {"mvps": per_iter_mvps}))
+        if per_iter_mvps is None:
+            history.mvps = iterable.mv_products
+        history.push_("resnorm", resnorm)
+        if verbose:
+            print("%3d\t%1.2e" % (iteration, resnorm))
+    history.setconv(iterable.converged())
+    if log:
+        history.shrink_()
+
+
+def chebyshev_(x, A, b, lmin, lmax, *, abstol=0.0, reltol=None, Pl=None, maxiter=None, log=False, verbose=False,
+               initially_zero=False):
+    """``chebyshev!(x, A, b, lmin, lmax; ...)`` -- src/chebyshev.jl:142-169."""
+    reltol = _default_reltol(b) if reltol is None else reltol
+    maxiter = A.size(2) if maxiter is None else maxiter
+    history = ConvergenceHistory(partial=not log)
+    history["abstol"], history["reltol"] = abstol, reltol
+    history.reserve_("resnorm", maxiter)                                     # :154
+    it = chebyshev_iterable_(x, A, b, lmin, lmax, abstol=abstol, reltol=reltol, maxiter=maxiter, Pl=Pl, initially_zero=initially_zero)
+    history.mvps = it.mv_products                                            # :160
+    _drive(it, history, log, verbose)
+    return (x, history) if log else x
+
+
+def chebyshev(A, b, lmin, lmax, **kwargs):
+    """``chebyshev(A, b, lmin, lmax; ...)`` -- src/chebyshev.jl:100-101."""
+    return chebyshev_(zerox(A, b), A, b, lmin, lmax, initially_zero=True, **kwargs)
+
+
+class MINRESIterable:
+    """``MINRESIterable`` -- src/minres.jl:6-36, construction per ``minres_iterable!`` (:38-87); real element types."""
+
+    def __init__(self, x, A, b, *, initially_zero=False, skew_hermitian=False, abstol, reltol, maxiter):
+        T = x.dtype.type
+        self.A, self.x, self.skew = A, x, bool(skew_hermitian)
+        self.v_prev, self.v_curr, self.v_next = x.similar(), x.similar().copyto_(b), x.similar()       # :47-50
+        self.w_prev, self.w_curr, self.w_next = x.zero(), x.zero(), x.zero()                            # :51-53
+        self.mv_products = 0
+        if not initially_zero:
+            mul_(self.v_next, A, x)                                          # :60
+            self.v_curr.axpy_(T(-1), self.v_next)                            # :61
+            self.mv_products = 1
+        self.resnorm = norm(self.v_curr)                                     # :65
+        self.tol = max(T(reltol) * self.resnorm, T(abstol))                  # :66
+        self.H = np.zeros(4, x.dtype)                                        # :70
+        self.rhs = np.array([self.resnorm, 0], x.dtype)                      # :71
+        self.v_curr.scal_(T(1) / self.resnorm)                               # :74
+        self.c_prev, self.s_prev, self.c_curr, self.s_curr = T(1), T(0), T(1), T(0)
+        self.maxiter = int(maxiter)
+
+    def converged(self):
+        return self.resnorm <= self.tol                                      # :89
+
+    def start(self):
+        return 1                                                             # :91
+
+    def done(self, iteration):
+        return iteration > self.maxiter or self.converged()                  # :93
+
+    def iterate(self, iteration=None):
+        """``iterate(m, iteration)`` -- src/minres.jl:95-159."""
+        iteration = 1 if iteration is None else iteration
+        if self.done(iteration):
+            return None
+        T, H, rhs = self.x.dtype.type, self.H, self.rhs
+        mul_(self.v_next, self.A, self.v_curr)                               # :102
+        if iteration > 1:
+            self.v_next.axpy_(-H[1], self.v_prev)                            # :104
+        proj = dot(self.v_curr, self.v_next)                                 # :107
+        H[2] = proj
+        self.v_next.axpy_(-proj, self.v_curr)                                # :109
+        H[3] = norm(self.v_next)                                             # :112
+        self.v_next.scal_(T(1) / H[3])                                       # :113
+        if iteration > 2:                                                    # :116-119
+            H[0] = self.s_prev * H[1]
+            H[1] = self.c_prev * H[1]
+        if iteration > 1:                                                    # :122-126
+            tmp = -self.s_curr * H[1] + self.c_curr * H[2]
+            H[1] = self.c_curr * H[1] + self.s_curr * H[2]
+            H[2] = tmp
+        c, s, H[2] = givens_algorithm(H[2], H[3], self.x.dtype)              # :129
+        rhs[1] = -s * rhs[0]                                                 # :132
+        rhs[0] = c * rhs[0]                                                  # :133
+        self.w_next.copyto_(self.v_curr)                                     # :136
+        if iteration > 1:
+            self.w_next.axpy_(-H[1], self.w_curr)                            # :137
+        if iteration > 2:
+            self.w_next.axpy_(-H[0], self.w_prev)                            # :138
+        self.w_next.scal_(T(1) / H[2])                                       # :139
+        self.x.axpy_(rhs[0], self.w_next)                                    # :142
+        self.v_prev, self.v_curr, self.v_next = self.v_curr, self.v_next, self.v_prev       # :145
+        self.w_prev, self.w_curr, self.w_next = self.w_curr, self.w_next, self.w_prev       # :146
+        self.c_prev, self.s_prev, self.c_curr, self.s_curr = self.c_curr, self.s_curr, c, s  # :147
+        rhs[0] = rhs[1]                                                      # :148
+        H[1] = -H[3] if self.skew else H[3]                                  # :151
+        self.resnorm = abs(rhs[1])                                           # :154
+        self.mv_products += 1
+        return self.resnorm, iteration + 1
+
+    def __iter__(self):
+        iteration = 1
+        while (nxt := self.iterate(iteration)) is not None:
+            resnorm, iteration = nxt
+            yield resnorm
+
+
+def minres_iterable_(x, A, b, *, initially_zero=False, skew_hermitian=False, abstol=0.0, reltol=None, maxiter=None):
+    """``minres_iterable!`` -- src/minres.jl:38-87."""
+    return MINRESIterable(x, A, b, initially_zero=initially_zero, skew_hermitian=skew_hermitian, abstol=abstol,
+                          reltol=_default_reltol(b) if reltol is None else reltol, maxiter=A.size(2) if maxiter is None else maxiter)
+
+
+def minres_(x, A, b, *, skew_hermitian=False, verbose=False, log=False, abstol=0.0, reltol=None, maxiter=None, initially_zero=False):
+    """``minres!(x, A, b; ...)`` -- src/minres.jl:197-230."""
+    reltol = _default_reltol(b) if reltol is None else reltol
+    maxiter = A.size(2) if maxiter is None else maxiter
+    history = ConvergenceHistory(partial=not log)
+    history["abstol"], history["reltol"] = abstol, reltol
+    if log:
+        history.reserve_("resnorm", maxiter)
+    it = minres_iterable_(x, A, b, skew_hermitian=skew_hermitian, abstol=abstol, reltol=reltol, maxiter=maxiter, initially_zero=initially_zero)
+    mv0 = it.mv_products
+    if log:
+        history.mvps = mv0                                                   # :211
+    n_it = 0
+    for iteration, resnorm in enumerate(it, start=1):                        # :214
+        n_it += 1
+        if log:
+            history.nextiter_(mvps=1)                                        # :216
+            history.push_("resnorm", resnorm)
+        if verbose:
+            print("%3d\t%1.2e" % (iteration, resnorm))
+    if log:
+        history.setconv(it.converged())
+        history.shrink_()
+    return (it.x, history) if log else it.x
+
+
+def minres(A, b, **kwargs):
+    """``minres(A, b; ...)`` -- src/minres.jl:236."""
+    return minres_(zerox(A, b), A, b, initially_zero=True, **kwargs)

@@ -1253,3 +1253,13 @@ extern "C" int mik_lu_solve(int dtype, void *A, int64_t lda, int n, void *b)
     if (dtype == MIK_F32) return lu_solve<float>((float *)A, lda, n, (float *)b);
     return MIK_ERR_INVALID;
 }
+
+// LinearAlgebra.givensAlgorithm(f, g) -> (c, s, r) on the host -- used at src/hessenberg.jl:24 and
+// src/minres.jl:129.  out = {c, s, r} of dtype.
+extern "C" int mik_givens(int dtype, const void *f, const void *g, void *out)
+{
+    if (!f || !g || !out) return MIK_ERR_INVALID;
+    if (dtype == MIK_F64) { double *o = (double *)out; givens_algorithm<double>(*(const double *)f, *(const double *)g, o[0], o[1], o[2]); return MIK_OK; }
+    if (dtype == MIK_F32) { float *o = (float *)out; givens_algorithm<float>(*(const float *)f, *(const float *)g, o[0], o[1], o[2]); return MIK_OK; }
+    return MIK_ERR_INVALID;
+}

@@ -87,6 +87,14 @@ def _declare(L):
         f = getattr(L, f"orc_lu_solve_{suf}")
         f.argtypes = [fp, C.c_int64, C.c_int, fp]
         f.restype = C.c_int
+        f = getattr(L, f"orc_chebyshev_{suf}")
+        f.argtypes = [C.c_int64, _i64p, _i64p, fp, C.c_int, fp, fp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
+                      C.c_int, fp, C.c_int, _i32p, _f64p, _i64p, _i64p, _i32p, _f64p, _f64p]
+        f.restype = None
+        f = getattr(L, f"orc_minres_{suf}")
+        f.argtypes = [C.c_int64, _i64p, _i64p, fp, C.c_int, fp, fp, C.c_int, C.c_double, C.c_double, C.c_int64, C.c_int,
+                      C.c_int, _i32p, _f64p, _i64p, _i64p, _i32p, _f64p, _f64p]
+        f.restype = None
         f = getattr(L, f"orc_hessenberg_ldiv_{suf}")
         f.argtypes = [fp, C.c_int64, C.c_int, fp]
         f.restype = None
@@ -364,3 +372,46 @@ def bicgstabl(A: CSC, b, l=2, x0=None, *, r_shadow, abstol=0.0, reltol=None, max
     hist = dict(iters=iters.value, mvps=mvps.value, isconverged=bool(conv.value), resnorm=res[:iters.value].copy(),
                 res0=res0.value, tol=tol.value, abstol=abstol, reltol=reltol)
     return x, hist
+
+
+def _run_simple(fn_name, A, b, x0, maxiter, call):
+    dtype = A.nzval.dtype
+    suf, ct = _suf(dtype)
+    b = np.ascontiguousarray(b, dtype)
+    n = A.n
+    x = np.zeros(n, dtype) if x0 is None else np.array(x0, dtype, copy=True)
+    maxiter = n if maxiter is None else int(maxiter)
+    res = np.zeros(max(maxiter, 1), np.float64)
+    iters, mvps = C.c_int64(0), C.c_int64(0)
+    conv = C.c_int(0)
+    res0, tol = C.c_double(0), C.c_double(0)
+    call(getattr(lib(), f"{fn_name}_{suf}"), ct, b, x, maxiter, res, iters, mvps, conv, res0, tol)
+    return x, dict(iters=iters.value, mvps=mvps.value, isconverged=bool(conv.value), resnorm=res[:iters.value].copy(),
+                   res0=res0.value, tol=tol.value)
+
+
+def chebyshev(A: CSC, b, lmin, lmax, x0=None, *, abstol=0.0, reltol=None, maxiter=None, pl_diag=None, mode="seq", shape=(1, 1)):
+    """``chebyshev!(x, A, b, lmin, lmax; log=true)`` / ``chebyshev(A, b, ...)`` when ``x0 is None`` -- src/chebyshev.jl:142-169,100."""
+    dtype = A.nzval.dtype
+    reltol = _eps_sqrt(dtype) if reltol is None else reltol
+    shp = np.asarray(shape, np.int32)
+    pd = None if pl_diag is None else np.ascontiguousarray(pl_diag, dtype)
+
+    def call(f, ct, b, x, maxiter, res, iters, mvps, conv, res0, tol):
+        f(A.n, _p(A.colptr, C.c_int64), _p(A.rowval, C.c_int64), _p(A.nzval, ct), A.index_base, _p(b, ct), _p(x, ct), float(lmin),
+          float(lmax), float(abstol), float(reltol), maxiter, int(x0 is None), _p(pd, ct), MODES[mode], _p(shp, C.c_int),
+          _p(res, C.c_double), C.byref(iters), C.byref(mvps), C.byref(conv), C.byref(res0), C.byref(tol))
+    return _run_simple("orc_chebyshev", A, b, x0, maxiter, call)
+
+
+def minres(A: CSC, b, x0=None, *, skew_hermitian=False, abstol=0.0, reltol=None, maxiter=None, mode="seq", shape=(1, 1)):
+    """``minres!(x, A, b; log=true)`` / ``minres(A, b)`` when ``x0 is None`` -- src/minres.jl:197-230,236."""
+    dtype = A.nzval.dtype
+    reltol = _eps_sqrt(dtype) if reltol is None else reltol
+    shp = np.asarray(shape, np.int32)
+
+    def call(f, ct, b, x, maxiter, res, iters, mvps, conv, res0, tol):
+        f(A.n, _p(A.colptr, C.c_int64), _p(A.rowval, C.c_int64), _p(A.nzval, ct), A.index_base, _p(b, ct), _p(x, ct),
+          int(skew_hermitian), float(abstol), float(reltol), maxiter, int(x0 is None), MODES[mode], _p(shp, C.c_int),
+          _p(res, C.c_double), C.byref(iters), C.byref(mvps), C.byref(conv), C.byref(res0), C.byref(tol))
+    return _run_simple("orc_minres", A, b, x0, maxiter, call)

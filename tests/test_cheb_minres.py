@@ -1,0 +1,129 @@
+"""Chebyshev iteration and MINRES (src/chebyshev.jl, src/minres.jl): the
+reference's property tests against the oracle (CPU) and bit-level parity of the device compositions (GPU)."""
+import numpy as np
+import pytest
+
+
+def rand_spd(rng, n, dtype):
+    B = rng.random((n, n)) + n * np.eye(n)                       # test/chebyshev.jl:8-11
+    return (B.T @ B).astype(dtype)
+
+
+def eig_bounds(Ad):
+    lam = np.linalg.eigvalsh(Ad.astype(np.float64))              # test/chebyshev.jl:13-18
+    d = (lam[-1] - lam[0]) / 100
+    return lam[0] - d, lam[-1] + d
+
+
+# ---- oracle ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_oracle_chebyshev(orc, dtype):
+    rng = np.random.default_rng(1234321)
+    n = 10
+    Ad, b = rand_spd(rng, n, dtype), rng.random(n).astype(dtype)
+    lo, hi = eig_bounds(Ad)
+    reltol = float(np.sqrt(np.finfo(dtype).eps))
+    A = orc.CSC.from_dense(Ad)
+    x, h = orc.chebyshev(A, b, lo, hi, reltol=reltol, maxiter=10 * n)
+    assert h["isconverged"] and np.linalg.norm(Ad @ x - b) / np.linalg.norm(b) <= reltol                 # test/chebyshev.jl:37-38
+    x0 = rng.random(n).astype(dtype)
+    r0 = np.linalg.norm(Ad @ x0 - b)
+    x, h = orc.chebyshev(A, b, lo, hi, x0, reltol=reltol, maxiter=10 * n)
+    assert h["isconverged"] and np.linalg.norm(Ad @ x - b) <= reltol * r0 * 1.01                         # :49
+    x, h = orc.chebyshev(A, b, lo, hi, x0, abstol=reltol, reltol=0.0, maxiter=10 * n)
+    assert h["isconverged"] and np.linalg.norm(Ad @ x - b) <= 2 * reltol                                  # :55
+    x, h = orc.chebyshev(A, b, lo, hi, reltol=reltol, maxiter=10 * n, pl_diag=np.ones(n, dtype))
+    assert h["isconverged"]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_oracle_minres(orc, dtype):
+    rng = np.random.default_rng(123)
+    n = 15
+    B = rng.random((n, n)) + n * np.eye(n)
+    reltol = float(np.sqrt(np.finfo(dtype).eps))
+    As, bs = (B + B.T).astype(dtype), (B @ np.ones(n)).astype(dtype)                                       # test/minres.jl:12-18
+    x1, h1 = orc.minres(orc.CSC.from_dense(As), bs, maxiter=10 * n, reltol=reltol)
+    assert h1["isconverged"] and np.linalg.norm(bs - As @ x1) / np.linalg.norm(bs) <= reltol               # :43-45
+    x2, h2 = orc.minres(orc.CSC.from_dense(As), bs, rng.random(n).astype(dtype), maxiter=10 * n, reltol=reltol)
+    assert np.linalg.norm(bs - As @ x2) / np.linalg.norm(bs) <= reltol                                     # :46
+    Ak = (B - B.T).astype(dtype)
+    bk = (Ak @ np.ones(n, dtype)).astype(dtype)
+    xk, hk = orc.minres(orc.CSC.from_dense(Ak), bk, skew_hermitian=True, maxiter=10 * n, reltol=reltol)
+    assert hk["isconverged"] and np.linalg.norm(bk - Ak @ xk) / np.linalg.norm(bk) <= reltol * 4           # :55-56
+    T3 = np.array([[2, -1, 0], [-1, 2, -1], [0, -1, 2]], dtype)                                            # :76-99
+    b3 = np.ones(3, dtype)
+    x0 = np.linalg.solve(T3.astype(np.float64), b3.astype(np.float64)).astype(dtype)
+    pert = (10 * np.sqrt(np.finfo(dtype).eps) * np.array([-1.0, 1.0, -1.0])).astype(dtype)
+    x, ch = orc.minres(orc.CSC.from_dense(T3), b3, x0 + pert)
+    assert 2 <= ch["iters"] <= 3
+    r0 = float(np.linalg.norm(T3 @ (x0 + pert) - b3))
+    x, ch = orc.minres(orc.CSC.from_dense(T3), b3, x0 + pert, abstol=2 * r0, reltol=0.0)
+    assert ch["iters"] == 0
+
+
+def test_givens_host_entry_matches_oracle(pkg, orc):
+    for f, g in [(1.0, 0.0), (0.0, 2.0), (3.0, 4.0), (-3.0, 4.0), (1e-200, 1e-200), (-5.0, 1.0)]:
+        assert pkg.givens_algorithm(f, g) == orc.givens(f, g)
+    assert pkg.givens_algorithm(3.0, -4.0, np.float32) == orc.givens(3.0, -4.0, np.float32)
+
+
+# ---- device ------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("precond", [False, True])
+def test_chebyshev_device_bit_exact(pkg, orc, ctx, dtype, precond):
+    import scipy.sparse as sp
+    # shifted Laplacian: spectrum in (20.2, 31.8).  The v0.9.4 iteration as written (u = c + beta*c) is only
+    # stable for well-conditioned operators like the reference's own randSPD test matrices.
+    L0 = orc.laplace(10, 3)
+    A = orc.CSC.from_scipy((L0.to_scipy() + 20 * sp.eye(L0.n)).tocsc()).astype(dtype)
+    b = orc.hashed_rhs(A.n).astype(dtype)
+    lo, hi = 20.0, 32.0
+    d = (6 + 0.1 * np.arange(A.n) / A.n).astype(dtype)
+    dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
+    okw = {"pl_diag": d / 6} if precond else {}
+    dkw = {"Pl": pkg.JacobiPrec(pkg.HipVector.from_numpy(d / 6))} if precond else {}
+    x0 = np.random.default_rng(0).standard_normal(A.n).astype(dtype)
+    for start in (None, x0):
+        if start is None:
+            x, ch = pkg.chebyshev(dA, pkg.HipVector.from_numpy(b), lo, hi, log=True, maxiter=400, **dkw)
+        else:
+            x, ch = pkg.chebyshev_(pkg.HipVector.from_numpy(start), dA, pkg.HipVector.from_numpy(b), lo, hi, log=True, maxiter=400, **dkw)
+        xo, ho = orc.chebyshev(A, b, lo, hi, start, maxiter=400, mode="tree", shape=ctx.reduce_shape(dtype), **okw)
+        assert ch.iters == ho["iters"] and ch.mvps == ho["mvps"] and ch.isconverged == ho["isconverged"]
+        assert np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
+    assert ch.isconverged
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_minres_device_bit_exact(pkg, orc, ctx, dtype):
+    A = orc.laplace(10, 3).astype(dtype)
+    b = orc.hashed_rhs(A.n).astype(dtype)
+    dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
+    x0 = np.random.default_rng(0).standard_normal(A.n).astype(dtype)
+    for start in (None, x0):
+        if start is None:
+            x, ch = pkg.minres(dA, pkg.HipVector.from_numpy(b), log=True)
+        else:
+            x, ch = pkg.minres_(pkg.HipVector.from_numpy(start), dA, pkg.HipVector.from_numpy(b), log=True)
+        xo, ho = orc.minres(A, b, start, mode="tree", shape=ctx.reduce_shape(dtype))
+        assert ch.iters == ho["iters"] and ch.mvps == ho["mvps"] and ch.isconverged == ho["isconverged"]
+        assert np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
+    S = A.to_scipy()
+    assert np.linalg.norm(S @ x.to_numpy() - b) / np.linalg.norm(b) <= (1e-6 if dtype == np.float64 else 2e-2)   # recurrence residual drifts
+
+
+@pytest.mark.gpu
+def test_minres_skew_symmetric_device(pkg, orc, ctx):
+    rng = np.random.default_rng(123)
+    n = 15
+    B = rng.random((n, n)) + n * np.eye(n)
+    Ak = B - B.T
+    bk = Ak @ np.ones(n)
+    A = orc.CSC.from_dense(Ak)
+    x, ch = pkg.minres(pkg.HipCSR(n, n, A.colptr, A.rowval, A.nzval), pkg.HipVector.from_numpy(bk), skew_hermitian=True, maxiter=10 * n, log=True)
+    xo, ho = orc.minres(A, bk, skew_hermitian=True, maxiter=10 * n, mode="tree", shape=ctx.reduce_shape(np.float64))
+    assert ch.isconverged and np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
+    assert np.linalg.norm(bk - Ak @ x.to_numpy()) / np.linalg.norm(bk) <= 1e-7
