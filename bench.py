@@ -38,8 +38,24 @@ def cpu_baseline(N: int, iters: int):
     dt = time.perf_counter() - t0
     return {"value": h["iters"] / dt, "unit": "iters/s", "cores": 1, "kind": "port",
             "sample": f"{h['iters']} cg! iterations on the same {N}^3 operator and rhs, oracle/mik_oracle.c mode SEQ "
-                      f"(host has {os.cpu_count()} cores; the reference's SpMV and broadcasts are single-threaded)",
+                      f"(host shows {os.cpu_count()} cores, {orc.effective_cpus()} usable under the cgroup quota; the reference's "
+                      f"SpMV and broadcasts are single-threaded)",
             "seconds": dt}
+
+
+def cpu_baseline_omp(N: int, iters: int):
+    """Best-effort multi-threaded host baseline (`cpu_ref_omp`): same algorithm and
+    stopping rule, row-parallel CSR SpMV + OpenMP reductions on all host cores (oracle/mik_oracle_omp.c)."""
+    orc = graft.load_oracle()
+    A = orc.laplace(N, 3)
+    b = orc.hashed_rhs(A.n)
+    orc.omp_cg(A, b, maxiter=3)
+    t0 = time.perf_counter()
+    _, it, _, threads = orc.omp_cg(A, b, maxiter=iters)
+    dt = time.perf_counter() - t0
+    return {"value": it / dt, "unit": "iters/s", "cores": threads, "kind": "port",
+            "sample": f"{it} cg! iterations on the same {N}^3 operator, OpenMP row-parallel CSR restatement "
+                      f"(not the reference's serial loop; summation order differs)", "seconds": dt}
 
 
 def pmc_traffic(kernel_key: str = "k_spmv_rowblock"):
@@ -171,6 +187,10 @@ def main():
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, args.cpu_iters)
+        try:
+            out["cpu_baseline_omp"] = cpu_baseline_omp(N, args.cpu_iters)
+        except Exception as e:                      # OpenMP runtime missing on the box: the serial baseline above stands
+            out["cpu_baseline_omp"] = {"error": str(e)[:200]}
     print(json.dumps(out))
 
 

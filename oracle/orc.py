@@ -26,9 +26,9 @@ _lib = None
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile)."""
-    if force or not os.path.exists(_LIB_PATH) or any(
+    if force or not os.path.exists(_LIB_PATH) or not os.path.exists(os.path.join(_HERE, "_build", "libmik_oracle_omp.so")) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-        for f in ("mik_oracle.c", "orc_impl.inc", "Makefile")
+        for f in ("mik_oracle.c", "orc_impl.inc", "Makefile", "mik_oracle_omp.c")
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
@@ -415,3 +415,50 @@ def minres(A: CSC, b, x0=None, *, skew_hermitian=False, abstol=0.0, reltol=None,
           int(skew_hermitian), float(abstol), float(reltol), maxiter, int(x0 is None), MODES[mode], _p(shp, C.c_int),
           _p(res, C.c_double), C.byref(iters), C.byref(mvps), C.byref(conv), C.byref(res0), C.byref(tol))
     return _run_simple("orc_minres", A, b, x0, maxiter, call)
+
+
+_omp = None
+
+
+def effective_cpus() -> int:
+    """Host cores this process may actually use: min(affinity mask, cgroup v2 CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def omp_lib():
+    """The OpenMP CPU baseline (oracle/mik_oracle_omp.c) -- bench.py's ``cpu_baseline_omp`` leg only."""
+    global _omp
+    if _omp is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "_build", "libmik_oracle_omp.so"))
+        L.orc_omp_threads.restype = C.c_int
+        L.orc_omp_set_threads.argtypes = [C.c_int]
+        L.orc_omp_set_threads(effective_cpus())
+        L.orc_omp_cg_f64.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, C.c_double, C.c_double, C.c_int64, _f64p]
+        L.orc_omp_cg_f64.restype = C.c_int64
+        _omp = L
+    return _omp
+
+
+def omp_cg(A: CSC, b, *, abstol=0.0, reltol=None, maxiter=None):
+    """cg(A, b) with all host cores (symmetric A: its CSC arrays are read as CSR).  Returns (x, iters, resnorm, threads)."""
+    L = omp_lib()
+    n = A.n
+    rowptr = (A.colptr - A.index_base).astype(np.int32)
+    col = (A.rowval - A.index_base).astype(np.int32)
+    val = np.ascontiguousarray(A.nzval, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    x = np.empty(n)
+    reltol = _eps_sqrt(np.float64) if reltol is None else reltol
+    maxiter = n if maxiter is None else int(maxiter)
+    res = np.zeros(max(maxiter, 1))
+    it = L.orc_omp_cg_f64(n, _p(rowptr, C.c_int), _p(col, C.c_int), _p(val, C.c_double), _p(b, C.c_double), _p(x, C.c_double),
+                          float(abstol), float(reltol), maxiter, _p(res, C.c_double))
+    return x, int(it), res[:it].copy(), int(L.orc_omp_threads())
