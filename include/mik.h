@@ -35,7 +35,8 @@
  *            per 64, then the 16 wave sums left to right.
  *  Multiply and add are never contracted into an FMA (the library is built -ffp-contract=off) and
  *  the SpMV sums each row serially in ascending column order, exactly like the reference's CSC
- *  column scatter.  oracle/mik_oracle.c (mode ORC_TREE) restates the same tree on the CPU.
+ *  column scatter (rows longer than mik_spmv_long_row() entries: one wave per row, lane l sums the
+ *  products of entries l, l+64, ... in order, then the wave tree).  oracle/mik_oracle.c (mode ORC_TREE) restates the same tree on the CPU.
  */
 #ifndef MIK_H
 #define MIK_H
@@ -83,6 +84,10 @@ int mik_reduce_shape(int dtype, int *W, int *L);
 /* (W, L) of the dot(u, c) fused into the SpMV of the CG step: one row per thread (W = 1), L
  * consecutive 256-row blocks per workgroup. */
 int mik_spmv_dot_shape(int *W, int *L);
+/* Rows with more than *threshold stored entries are summed with the wave shape (lane l adds the
+ * products of entries l, l+64, ... in order, then the wave-64 tree); shorter rows strictly in column
+ * order like the reference.  None of the reference's fixtures has such rows. */
+int mik_spmv_long_row(int *threshold);
 /* Development knobs (not part of the reference interface): SpMV kernel variants for A/B timing --
  * key 0: 1 = cached (temporal) val/col/y streams; key 1: 1 = narrow loads; key 2: block map mode. */
 int mik_set_tuning(int key, int value);

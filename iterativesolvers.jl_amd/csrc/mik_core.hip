@@ -129,6 +129,12 @@ extern "C" int mik_spmv_dot_shape(int *W, int *L)
     return MIK_OK;
 }
 
+extern "C" int mik_spmv_long_row(int *threshold)
+{
+    if (threshold) *threshold = g_mik_tuning[4] > 0 ? g_mik_tuning[4] : (g_mik_tuning[4] < 0 ? INT32_MAX : MIK_LONG_ROW);
+    return MIK_OK;
+}
+
 extern "C" int mik_set_tuning(int key, int value)
 {
     if (key < 0 || key >= 8) return MIK_ERR_INVALID;
@@ -215,7 +221,7 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
     if (dtype != MIK_F64 && dtype != MIK_F32) return mik_fail(ctx, MIK_ERR_INVALID, "mik_csr_create: bad dtype %d", dtype);
     if (n_rows < 0 || n_cols < 0 || nnz < 0 || !ptr || (nnz && (!idx || !val)))
         return mik_fail(ctx, MIK_ERR_INVALID, "mik_csr_create: bad sizes or NULL arrays");
-    if (n_rows >= (int64_t)INT32_MAX - MIK_BLOCK || n_cols >= INT32_MAX || nnz >= (int64_t)INT32_MAX - MIK_SPMV_TILE)
+    if (n_rows >= (int64_t)INT32_MAX - MIK_BLOCK || n_cols >= INT32_MAX || nnz >= (int64_t)INT32_MAX - 2 * MIK_SPMV_TILE)
         return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_csr_create: sizes exceed the Int32 device index range");
     const int64_t n_major = is_csc ? n_cols : n_rows;   // length of ptr - 1
     const int64_t n_minor = is_csc ? n_rows : n_cols;   // range of idx
@@ -314,8 +320,10 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
     if (!A) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host allocation failed");
     A->max_rowblock_nnz = max_rb;
     A->n_long = (int)long_rows.size();
+    A->n_long_big = 0;
+    for (int len : long_len) if (len > 256) A->n_long_big++;            // sorted longest first: a prefix of the list
     A->ctx = ctx; A->dtype = dtype; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz; A->max_row_nnz = max_row;
-    const size_t pad = MIK_SPMV_TILE;   // slack so tile-granular reads never leave the allocation
+    const size_t pad = 2 * MIK_SPMV_TILE;   // slack so tile-granular reads never leave the allocation
     auto cleanup = [&]() { mik_csr_destroy(A); };
     hipError_t e;
     (void)hipSetDevice(ctx->device);
@@ -473,18 +481,20 @@ int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_
         return MIK_OK;
     }
     const int nlong = A->n_long;
-    const int nlb = (nlong + 3) / 4;
+    const int nbig = A->n_long_big;
+    const int nwaves_long = nbig + (nlong - nbig + MIK_LONG_R - 1) / MIK_LONG_R;   // one wave per big row, MIK_LONG_R medium rows per wave
+    const int nlb = (nwaves_long + 3) / 4;
     const bool merge = nlong > 0 && !fuse_dot;           // one launch: long-row workgroups first, then row-blocks
     if (nlong && !merge) {
         // fused dot: long rows first in their own launch, the row-block kernel then picks y[r] up
-        hipLaunchKernelGGL((k_spmv_longrows<T>), dim3(nlb), dim3(MIK_BLOCK), 0, ctx->stream, nlong, A->long_rows, A->long_rows + nlong,
+        hipLaunchKernelGGL((k_spmv_longrows<T>), dim3(nlb), dim3(MIK_BLOCK), 0, ctx->stream, nlong, nbig, A->long_rows, A->long_rows + nlong,
                            A->long_rows + 2 * nlong, A->col, (const T *)A->val, x, y, done);
         MIK_LAUNCH_CHECK(ctx);
     }
     const dim3 grid(nb + (merge ? nlb : 0)), block(MIK_BLOCK);
 #define MIK_SPMV_GO(FD, NT, WD, MG)                                                                              \
     hipLaunchKernelGGL((k_spmv_rowblock<T, FD, NT, WD, MG>), grid, block, 0, ctx->stream, n, nb, map_mode, A->rowptr, \
-                       A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, nlong, A->long_rows)
+                       A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, nlong, nbig, nlb, A->long_rows)
 #define MIK_SPMV_GO2(FD, MG)                                                              \
     do {                                                                                  \
         if (nt) { if (wide) MIK_SPMV_GO(FD, true, true, MG); else MIK_SPMV_GO(FD, true, false, MG); }   \

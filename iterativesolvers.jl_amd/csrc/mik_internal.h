@@ -18,7 +18,7 @@ constexpr int MIK_RED_L = 2;         // 16-byte loads per thread per segment
 constexpr int MIK_FIN_THREADS = 1024;
 constexpr int MIK_SPMV_TILE = 2048;  // nnz staged in LDS per row-block pass
 constexpr int MIK_SPMV_G = 1;        // row-blocks per SpMV workgroup (= L of the fused-dot tree); >1 measured slower
-constexpr int MIK_LONG_ROW = 128;      // rows with more entries go to the wave-per-row kernel
+constexpr int MIK_LONG_ROW = 64;       // rows with more entries go to the wave-per-row kernel (wave-shaped row sum)
 constexpr int MIK_MAX_GRID = 256 * 8 * 4;
 
 template <typename T> struct VT;
@@ -50,6 +50,7 @@ struct mik_csr {
     int max_row_nnz = 0;
     int max_rowblock_nnz = 0;        // largest nnz of any 256-row block (short part)
     int n_long = 0;                  // rows longer than MIK_LONG_ROW, stored behind the short part
+    int n_long_big = 0;              // how many of them exceed 256 entries (one wave each; the rest go 4 per wave)
     int *long_rows = nullptr;        // device: [n_long] row ids, [n_long] start offsets, [n_long] lengths
     unsigned char *is_long = nullptr;   // device: n_rows flags (only when n_long > 0)
     // optional dictionary-coded form (mik_csr_pack): one 16-bit code per entry + two <= 256-entry tables

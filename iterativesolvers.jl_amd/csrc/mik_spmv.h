@@ -72,33 +72,50 @@ __device__ __forceinline__ int spmv_block_map(int b, int nb, int mode)
 // ---------------------------------------------------------------------------------------------
 // long rows: one wave per row
 // ---------------------------------------------------------------------------------------------
-// Rows with more than `long_row` entries (mik_csr_create; default MIK_LONG_ROW) are stored behind
-// the short part and summed here -- a thread-per-row tile only pays while a 2048-entry tile covers
-// many rows.  The sum stays SERIAL in ascending column order (bit-identical to the reference's
-// scatter order): the wave streams the row in chunks of 64*U entries with coalesced loads, gathers
-// x, parks the products in a wave-private LDS buffer, and lane 0 folds them into one accumulator with
-// 16-byte LDS reads, software-pipelined one 32-value batch ahead of the dependent add chain.  The
-// next chunk's val/col stream is issued before the chain starts; rows are ordered longest first
-// (mik_csr_create) and different rows run concurrently on different waves, so the critical path is
-// the longest single row at ~6 cycles per entry.
+// Rows with more than MIK_LONG_ROW entries are stored behind the short part (mik_csr_create) and summed
+// here -- a thread-per-row tile only pays while a 2048-entry tile covers many rows, and a single serial
+// chain over a 20,000-entry row costs > 100 us however it is fed (measured: ~13 cycles per entry).
+//
+// Row-sum shape for these rows (part of the documented reduction semantics, include/mik.h; the oracle's
+// TREE mode mirrors it): lane l of the wave sums the products of entries l, l+64, l+128, ... of the row
+// in ascending order starting from +0, then the wave-64 shuffle-down tree (offsets 32..1) -- the same
+// shape as one 64-thread segment of a dot product.  Rows up to MIK_LONG_ROW entries keep the reference's
+// strictly sequential order.
+//
+// The wave streams the row in chunks of 64*U entries (coalesced val/col loads, gathered x) through a
+// three-stage software pipeline: while chunk c is accumulated, the x-gather of chunk c+1 and the
+// val/col stream of chunk c+2 are in flight.
 constexpr int MIK_LONG_U = 8;                          // entries per lane per chunk
 constexpr int MIK_LONG_CH = 64 * MIK_LONG_U;           // 512-entry chunks
 
 template <typename T>
-__device__ __forceinline__ void spmv_longrow_wave(int w, T *__restrict__ wbuf, const int *__restrict__ rows,
-                                                  const int *__restrict__ starts, const int *__restrict__ lens,
-                                                  const int *__restrict__ col, const T *__restrict__ val,
-                                                  const T *__restrict__ x, T *__restrict__ y)
+__device__ __forceinline__ void spmv_longrow_wave(int w, const int *__restrict__ rows, const int *__restrict__ starts,
+                                                  const int *__restrict__ lens, const int *__restrict__ col,
+                                                  const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y)
 {
     constexpr int U = MIK_LONG_U, CH = MIK_LONG_CH;
-    constexpr int VW = VT<T>::W;                       // elements per 16-byte LDS read
-    constexpr int B = 32 / VW;                         // 16-byte reads per 32-value batch
-    using VV = typename WideVec<T>::val;
     const int lane = threadIdx.x & 63;
     const int k0 = starts[w], len = lens[w];
     T acc = T(0);
-    // Three-stage software pipeline over chunks: while chunk c is multiplied and chained, the x-gather
-    // of chunk c+1 and the val/col stream of chunk c+2 are in flight.
+    if (len <= CH) {
+        // medium rows: one chunk, every load issued at once (no pipeline prologue / epilogue)
+        T v[U], xv[U];
+        int c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = u * 64 + lane;
+            if (j < len) { v[u] = val[k0 + j]; c[u] = col[k0 + j]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (u * 64 + lane < len) xv[u] = x[c[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (u * 64 + lane < len) { const T prod = v[u] * xv[u]; acc = acc + prod; }
+        acc = wave_tree(acc);
+        if (lane == 0) y[rows[w]] = acc;
+        return;
+    }
     T vA[U], xA[U], vB[U], vC[U];
     int cB[U], cC[U];
     auto stream = [&](int base, T(&vv)[U], int(&cc)[U]) {
@@ -106,7 +123,7 @@ __device__ __forceinline__ void spmv_longrow_wave(int w, T *__restrict__ wbuf, c
         for (int u = 0; u < U; ++u) {
             const int j = base + u * 64 + lane;
             vv[u] = j < len ? val[k0 + j] : T(0);
-            cc[u] = j < len ? col[k0 + j] : 0;       // padding gathers x[0]; its product is replaced by +0 below
+            cc[u] = j < len ? col[k0 + j] : 0;       // padding gathers x[0]; its product is never added
         }
     };
     stream(0, vA, cB);                                  // chunk 0 (cB doubles as its column registers)
@@ -119,66 +136,77 @@ __device__ __forceinline__ void spmv_longrow_wave(int w, T *__restrict__ wbuf, c
 #pragma unroll
         for (int u = 0; u < U; ++u) xB[u] = x[cB[u]];   // chunk c+1: gather
 #pragma unroll
-        for (int u = 0; u < U; ++u) {                   // chunk c: products (entries past the row end contribute +0)
+        for (int u = 0; u < U; ++u) {                   // chunk c: this lane's entries, ascending
             const T prod = vA[u] * xA[u];
-            wbuf[u * 64 + lane] = (base + u * 64 + lane < len) ? prod : T(0);
+            if (base + u * 64 + lane < len) acc = acc + prod;
         }
-        // LDS operations of one wave execute in issue order, so lane 0's reads below see every lane's
-        // writes above without a fence (a wavefront-scope fence would also drain vmcnt and with it the
-        // loads in flight); the wave barrier only pins the compiler's instruction order.
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
-            const VV *q = reinterpret_cast<const VV *>(wbuf);
-            const int cnt = min(CH, len - base);                 // zero padding inside the last batch adds nothing
-            // One v_add per entry plus one 16-byte LDS read per VW entries, fully unrolled: a single wave
-            // issues roughly one instruction every 4-5 cycles, so instruction count and LDS latency are
-            // the chain's cost.  Full chunks take the branch-free form, which lets the scheduler hoist
-            // the next batches' LDS reads above the current adds.
-            if (cnt == CH) {
-#pragma unroll
-                for (int g = 0; g < CH / 32; ++g) {
-                    VV t[B];
-#pragma unroll
-                    for (int i = 0; i < B; ++i) t[i] = q[g * B + i];
-#pragma unroll
-                    for (int i = 0; i < B; ++i)
-#pragma unroll
-                        for (int e = 0; e < VW; ++e) acc = acc + t[i][e];
-                }
-            } else {
-#pragma unroll
-                for (int g = 0; g < CH / 32; ++g) {
-                    if (g * 32 < cnt) {
-                        VV t[B];
-#pragma unroll
-                        for (int i = 0; i < B; ++i) t[i] = q[g * B + i];
-#pragma unroll
-                        for (int i = 0; i < B; ++i)
-#pragma unroll
-                            for (int e = 0; e < VW; ++e) acc = acc + t[i][e];
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int u = 0; u < U; ++u) { vA[u] = vB[u]; xA[u] = xB[u]; vB[u] = vC[u]; cB[u] = cC[u]; }
     }
+    acc = wave_tree(acc);
     if (lane == 0) y[rows[w]] = acc;
 }
 
+// A wave takes MIK_LONG_R consecutive rows of the (longest-first) long-row list.  Medium rows (<= 256
+// entries) are latency-bound one at a time -- ~1 KB in flight per wave -- so their loads are issued for
+// all R rows before anything is waited for; longer rows go through the pipelined path one by one.  The
+// per-row arithmetic (lane l: entries l, l+64, ... in order; wave tree) is identical either way.
+constexpr int MIK_LONG_R = 4;
+
 template <typename T>
-__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_longrows(int nlong, const int *__restrict__ rows, const int *__restrict__ starts,
+__device__ __forceinline__ void spmv_longrow_group(int wv, int nlong, int nbig, const int *__restrict__ rows,
+                                                   const int *__restrict__ starts, const int *__restrict__ lens,
+                                                   const int *__restrict__ col, const T *__restrict__ val,
+                                                   const T *__restrict__ x, T *__restrict__ y)
+{
+    constexpr int R = MIK_LONG_R, U = 4;
+    // waves [0, nbig): one row each (rows longer than 64*U entries, longest first: their pipelined sums are
+    // the critical path); waves from nbig on: R medium rows each
+    if (wv < nbig) { spmv_longrow_wave<T>(wv, rows, starts, lens, col, val, x, y); return; }
+    const int w0 = nbig + (wv - nbig) * R;
+    if (w0 >= nlong) return;
+    const int lane = threadIdx.x & 63;
+    int k0[R], len[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const bool ok = w0 + q < nlong;
+        k0[q] = ok ? starts[w0 + q] : 0;
+        len[q] = ok ? lens[w0 + q] : 0;
+    }
+    T v[R][U], xv[R][U];
+    int c[R][U];
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = u * 64 + lane;
+            if (j < len[q]) { v[q][u] = val[k0[q] + j]; c[q][u] = col[k0[q] + j]; }
+        }
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (u * 64 + lane < len[q]) xv[q][u] = x[c[q][u]];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        T acc = T(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (u * 64 + lane < len[q]) { const T prod = v[q][u] * xv[q][u]; acc = acc + prod; }
+        acc = wave_tree(acc);
+        if (lane == 0 && w0 + q < nlong) y[rows[w0 + q]] = acc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_longrows(int nlong, int nbig, const int *__restrict__ rows, const int *__restrict__ starts,
                                                              const int *__restrict__ lens, const int *__restrict__ col,
                                                              const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y,
                                                              const int *__restrict__ done)
 {
     if (done && *done) return;
-    __shared__ __attribute__((aligned(16))) T buf[MIK_BLOCK / 64][MIK_LONG_CH];
-    const int wv = threadIdx.x >> 6;
-    const int w = blockIdx.x * (MIK_BLOCK / 64) + wv;
-    if (w >= nlong) return;                            // whole waves leave: no block-level barrier is used
-    spmv_longrow_wave<T>(w, buf[wv], rows, starts, lens, col, val, x, y);
+    const int wv = blockIdx.x * (MIK_BLOCK / 64) + (threadIdx.x >> 6);     // whole waves work alone: no block-level barrier
+    spmv_longrow_group<T>(wv, nlong, nbig, rows, starts, lens, col, val, x, y);
 }
 
 // MERGE_LONG: the first `nlong_blocks` workgroups of the launch are long-row workgroups (4 rows each,
@@ -188,24 +216,21 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
                                                              const int *__restrict__ col, const T *__restrict__ val,
                                                              const T *__restrict__ x, T *__restrict__ y,
                                                              T *__restrict__ seg_out, const int *__restrict__ done,
-                                                             const unsigned char *__restrict__ is_long, int nlong,
-                                                             const int *__restrict__ long_tab)
+                                                             const unsigned char *__restrict__ is_long, int nlong, int nbig,
+                                                             int nlb, const int *__restrict__ long_tab)
 {
     if (done && *done) return;
-    constexpr int TILE = MIK_SPMV_TILE;
+    constexpr int TILE = MIK_SPMV_TILE * (int)(8 / sizeof(T));   // 16 KB of LDS: 2048 fp64 / 4096 fp32 products
     constexpr int VW = WIDE ? VT<T>::W : 1;            // elements per lane per load
     constexpr int PER = TILE / (MIK_BLOCK * VW);       // loads per lane per tile
-    static_assert(TILE >= (MIK_BLOCK / 64) * MIK_LONG_CH, "LDS tile doubles as the long-row wave buffers");
     __shared__ __attribute__((aligned(16))) T prod[TILE];
     __shared__ T lds4[4];
 
     const int t = threadIdx.x;
     int bid = blockIdx.x;
     if (MERGE_LONG) {
-        const int nlb = (nlong + MIK_BLOCK / 64 - 1) / (MIK_BLOCK / 64);
         if (bid < nlb) {
-            const int wv = t >> 6, w = bid * (MIK_BLOCK / 64) + wv;
-            if (w < nlong) spmv_longrow_wave<T>(w, prod + wv * MIK_LONG_CH, long_tab, long_tab + nlong, long_tab + 2 * nlong, col, val, x, y);
+            spmv_longrow_group<T>(bid * (MIK_BLOCK / 64) + (t >> 6), nlong, nbig, long_tab, long_tab + nlong, long_tab + 2 * nlong, col, val, x, y);
             return;
         }
         bid -= nlb;

@@ -42,6 +42,10 @@ int orc_set_partition(int nparts, const int64_t *offsets)
     return 0;
 }
 
+/* optional device row-sum shape for long rows (0 = off: every row strictly sequential) */
+static int64_t g_orc_long_row = 0;
+void orc_set_long_row(int64_t threshold) { g_orc_long_row = threshold > 0 ? threshold : 0; }
+
 /* ---- fp64 instantiation ---- */
 #define T double
 #define F(x) x##_f64

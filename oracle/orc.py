@@ -104,6 +104,8 @@ def _declare(L):
     L.orc_laplace_csc.restype = None
     L.orc_advdiff_csc.argtypes = [C.c_int64, C.c_double, C.c_int, _i64p, _i64p, _f64p, _f64p]
     L.orc_advdiff_csc.restype = None
+    L.orc_set_long_row.argtypes = [C.c_int64]
+    L.orc_set_long_row.restype = None
     L.orc_set_partition.argtypes = [C.c_int, _i64p]
     L.orc_set_partition.restype = C.c_int
     L.orc_hashed_rhs.argtypes = [C.c_int64, _f64p]
@@ -117,6 +119,11 @@ def set_partition(offsets=None):
         return
     off = np.ascontiguousarray(offsets, np.int64)
     assert lib().orc_set_partition(off.size - 1, _p(off, C.c_int64)) == 0
+
+
+def set_long_row(threshold=0):
+    """Rows with more than `threshold` entries use the device's wave-shaped row sum in spmv (0 = off)."""
+    lib().orc_set_long_row(int(threshold or 0))
 
 
 def _suf(dtype):

@@ -7,6 +7,14 @@ import scipy.sparse as sp
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def long_row_shape(orc, ctx):
+    """rows longer than mik_spmv_long_row() use the wave-shaped row sum; the oracle's spmv mirrors it"""
+    orc.set_long_row(ctx.spmv_long_row())
+    yield
+    orc.set_long_row(0)
+
+
 def as_oracle_csc(orc, n, rowptr, colidx, val):
     M = sp.csr_matrix((val, colidx, rowptr), shape=(n, n)).tocsc()
     M.sort_indices()
@@ -21,7 +29,15 @@ def test_irregular_spmv_bit_exact(pkg, orc, ctx, dtype):
     A = pkg.HipCSR(n, n, rowptr, colidx, val, index_base=0, is_csc=False)
     x = np.random.default_rng(2).standard_normal(n).astype(dtype)
     y = (A @ pkg.HipVector.from_numpy(x)).to_numpy()
-    assert np.array_equal(y, orc.spmv(as_oracle_csc(orc, n, rowptr, colidx, val), x))
+    Ao = as_oracle_csc(orc, n, rowptr, colidx, val)
+    yo = orc.spmv(Ao, x)
+    assert np.array_equal(y, yo)
+    # rows up to the threshold keep the reference's strictly sequential order; longer rows differ from it by rounding only
+    orc.set_long_row(0)
+    yseq = orc.spmv(Ao, x)
+    short = lens <= ctx.spmv_long_row()
+    assert np.array_equal(y[short], yseq[short]) and not np.array_equal(y[~short], yseq[~short])
+    np.testing.assert_allclose(y, yseq, rtol=1e-4 if dtype == np.float32 else 1e-12, atol=1e-4 if dtype == np.float32 else 1e-12)
 
 
 def test_irregular_gmres_fp32_restart50(pkg, orc, ctx):
