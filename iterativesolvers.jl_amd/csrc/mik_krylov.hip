@@ -354,7 +354,7 @@ __global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_rho(const T *__restr
 template <typename T>
 __global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_res(const T *__restrict__ S, int64_t m, CgDev<T> *d, T *__restrict__ hist,
                                                                 long long it_next, long long maxiter, CgMirror *mirror,
-                                                                unsigned long long seq)
+                                                                unsigned long long seq, int hist_index)
 {
     if (d->done) {
         // a no-op step (the stopping test fired earlier in this batch): still publish, state unchanged
@@ -370,15 +370,13 @@ __global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_res(const T *__restr
         d->prev_res = prev;
         d->res = res;
         d->beta = (res * res) / (prev * prev);    // :50 of the next step
-        hist[d->nhist] = res;
-        const int nh = d->nhist + 1;
-        d->nhist = nh;
+        hist[hist_index] = res;                   // step `hist_index` of this host call (the host zeroes mirror->nhist)
         const int dn = (it_next >= maxiter || res <= d->tol) ? 1 : 0;
         if (dn) d->done = 1;
         mirror->res = (double)res;
         mirror->prev_res = (double)prev;
         mirror->done = dn;
-        mirror->nhist = nh;
+        mirror->nhist = hist_index + 1;
         __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -425,7 +423,7 @@ static hipEvent_t cg_profile_event(mik_cg *it)
     return it->ev[it->ev_used++];
 }
 
-template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next)
+template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next, int hist_index)
 {
     mik_ctx *ctx = it->ctx;
     CgDev<T> *d = (CgDev<T> *)it->dev;
@@ -461,7 +459,7 @@ template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next)
     MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done)));
     it->seq += 1;
     hipLaunchKernelGGL((k_cg_fin_res<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)it->seg_vec, nseg, d, (T *)it->hist,
-                       it_next, (long long)it->maxiter, it->mirror, it->seq);
+                       it_next, (long long)it->maxiter, it->mirror, it->seq, hist_index);
     MIK_LAUNCH_CHECK(ctx);
     return MIK_OK;
 }
@@ -597,11 +595,12 @@ static int cg_iterate_many_impl(mik_cg *it, int64_t iteration, int64_t max_steps
         it->hist_cap = max_steps;
     }
     CgDev<T> *d = (CgDev<T> *)it->dev;
-    // nhist = 0 for this call; the stopping flag only needs clearing if a previous call left it set
-    // (the host test above said "not done", e.g. the caller restarted the iteration count)
-    if (it->dev_done) MIK_HIP(ctx, hipMemsetAsync(&d->done, 0, 2 * sizeof(int), ctx->stream));
-    else MIK_HIP(ctx, hipMemsetAsync(&d->nhist, 0, sizeof(int), ctx->stream));
-    for (int64_t j = 0; j < max_steps; ++j) MIK_TRY(cg_enqueue_step<T>(it, (long long)(iteration + j + 1)));
+    // The device is idle here (the previous call waited for its last step), so the host may reset the
+    // step counter in the host-mapped mirror directly.  The stopping flag only needs clearing if a previous
+    // call left it set while the host test above said "not done" (e.g. the caller restarted the count).
+    it->mirror->nhist = 0;
+    if (it->dev_done) MIK_HIP(ctx, hipMemsetAsync(&d->done, 0, sizeof(int), ctx->stream));
+    for (int64_t j = 0; j < max_steps; ++j) MIK_TRY(cg_enqueue_step<T>(it, (long long)(iteration + j + 1), (int)j));
     MIK_TRY(cg_wait_mirror(it));
     const CgMirror m = *it->mirror;
     const int64_t nd = m.nhist;
