@@ -138,6 +138,28 @@ template <typename T> __device__ __forceinline__ T &el(typename VT<T>::vec &v, i
 {
     return reinterpret_cast<T *>(&v)[e];
 }
+// non-temporal 16-byte accesses for operands that are not needed again before they would be evicted anyway
+// (keeps the vectors that ARE re-read by the next kernel in L2 / Infinity Cache)
+template <typename T> struct NativeVec;
+template <> struct NativeVec<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct NativeVec<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <typename T> __device__ __forceinline__ typename VT<T>::vec vload_nt(const T *p)
+{
+    using NV = typename NativeVec<T>::type;
+    NV v = __builtin_nontemporal_load(reinterpret_cast<const NV *>(p));
+    typename VT<T>::vec out;
+#pragma unroll
+    for (int e = 0; e < VT<T>::W; ++e) reinterpret_cast<T *>(&out)[e] = v[e];
+    return out;
+}
+template <typename T> __device__ __forceinline__ void vstore_nt(T *p, typename VT<T>::vec v)
+{
+    using NV = typename NativeVec<T>::type;
+    NV o;
+#pragma unroll
+    for (int e = 0; e < VT<T>::W; ++e) o[e] = reinterpret_cast<const T *>(&v)[e];
+    __builtin_nontemporal_store(o, reinterpret_cast<NV *>(p));
+}
 
 // Helper macro: define apply_vec in terms of a per-element lambda over loaded vectors is not
 // possible generically, so each op spells out its loads (all issued before the arithmetic).
@@ -145,15 +167,16 @@ template <typename T> __device__ __forceinline__ T &el(typename VT<T>::vec &v, i
 // y .= x .+ beta .* y            -- src/cg.jl:51  (u .= r .+ beta .* u), :86
 template <typename T> struct OpXpby {
     static constexpr bool REDUCE = false;
-    const T *__restrict__ x; T *__restrict__ y; Coef<T> beta;
+    const T *__restrict__ x; T *__restrict__ y; Coef<T> beta; int nt = 0;   // nt & 1: x is streamed (non-temporal load)
     __device__ __forceinline__ void apply(int64_t i, T &) const { T t = beta.get() * y[i]; y[i] = x[i] + t; }
     __device__ __forceinline__ void apply_vec(int64_t i, T &) const
     {
         const T b = beta.get();
-        auto xv = vload(x + i); auto yv = vload<T>(y + i);
+        auto xv = (nt & 1) ? vload_nt(x + i) : vload(x + i);
+        auto yv = (nt & 2) ? vload_nt<T>(y + i) : vload<T>(y + i);
 #pragma unroll
         for (int e = 0; e < VT<T>::W; ++e) { T t = b * el<T>(yv, e); el<T>(yv, e) = el<T>(xv, e) + t; }
-        vstore(y + i, yv);
+        if (nt & 4) vstore_nt(y + i, yv); else vstore(y + i, yv);
     }
 };
 
@@ -273,6 +296,7 @@ template <typename T> struct OpSubNrm {
 template <typename T> struct OpCgUpdate {
     static constexpr bool REDUCE = true;
     T *__restrict__ x; T *__restrict__ r; const T *__restrict__ u; const T *__restrict__ c; Coef<T> alpha;
+    int nt = 0;   // bit 0: x streamed (load + store), bit 1: c streamed, bit 2: u streamed
     __device__ __forceinline__ void apply(int64_t i, T &acc) const
     {
         const T a = alpha.get();
@@ -283,13 +307,17 @@ template <typename T> struct OpCgUpdate {
     __device__ __forceinline__ void apply_vec(int64_t i, T &acc) const
     {
         const T a = alpha.get();
-        auto xv = vload<T>(x + i); auto uv = vload(u + i); auto rv = vload<T>(r + i); auto cv = vload(c + i);
+        auto xv = (nt & 1) ? vload_nt<T>(x + i) : vload<T>(x + i);
+        auto uv = (nt & 4) ? vload_nt(u + i) : vload(u + i);
+        auto rv = (nt & 8) ? vload_nt<T>(r + i) : vload<T>(r + i);
+        auto cv = (nt & 2) ? vload_nt(c + i) : vload(c + i);
 #pragma unroll
         for (int e = 0; e < VT<T>::W; ++e) {
             T t = a * el<T>(uv, e); el<T>(xv, e) = el<T>(xv, e) + t;
             T s = a * el<T>(cv, e); el<T>(rv, e) = el<T>(rv, e) - s;
         }
-        vstore(x + i, xv); vstore(r + i, rv);
+        if (nt & 1) vstore_nt(x + i, xv); else vstore(x + i, xv);
+        if (nt & 16) vstore_nt(r + i, rv); else vstore(r + i, rv);
 #pragma unroll
         for (int e = 0; e < VT<T>::W; ++e) { T p = el<T>(rv, e) * el<T>(rv, e); acc = acc + p; }
     }

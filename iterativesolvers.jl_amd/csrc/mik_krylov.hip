@@ -423,6 +423,18 @@ static hipEvent_t cg_profile_event(mik_cg *it)
     return it->ev[it->ev_used++];
 }
 
+// Cache hints of the two vector kernels of a CG step (results unchanged).  x is touched once per iteration, c
+// and u are dead / about to be overwritten after the update, and r has just been read for the last time in
+// u .= r .+ beta .* u: streaming them past L2 (non-temporal) leaves the cache to the operator's gather and
+// took the in-loop SpMV from 322 to 307 us and the step from 546 to 507 us at 256^3.
+// bits 0-2: xpby {r load, u load, u store}; bits 3-7: update {x, c load, u load, r load, r store}.
+// tuning[7]: 0 = default (57), < 0 = all temporal, > 0 = explicit mask.
+static inline int cg_stream_hints()
+{
+    const int k = g_mik_tuning[7];
+    return k == 0 ? 57 : (k < 0 ? 0 : k);
+}
+
 template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next, int hist_index)
 {
     mik_ctx *ctx = it->ctx;
@@ -445,7 +457,7 @@ template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next, 
         MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
     } else {
         // u .= r .+ beta .* u                                           src/cg.jl:50-51
-        OpXpby<T> op{r, u, coef_ptr<T>(&d->beta)};
+        OpXpby<T> op{r, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 7};
         MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
     }
     // c = A * u with the dot(u, c) epilogue                             src/cg.jl:54-55
@@ -455,7 +467,7 @@ template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next, 
     hipLaunchKernelGGL((k_cg_fin_alpha<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)it->seg_spmv, nb, d, pcg);
     MIK_LAUNCH_CHECK(ctx);
     // x .+= alpha .* u; r .-= alpha .* c; norm(r)                       src/cg.jl:58-62
-    OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha)};
+    OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints() >> 3};
     MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done)));
     it->seq += 1;
     hipLaunchKernelGGL((k_cg_fin_res<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)it->seg_vec, nseg, d, (T *)it->hist,
@@ -1115,7 +1127,7 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     case 0: {  // step A
-        OpXpby<T> op{r, u, coef_ptr<T>(&d->beta)};
+        OpXpby<T> op{r, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 7};
         MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
         return gather_launch<T>(ctx, it->n_send, it->send_idx, u, (T *)it->send_buf, done);
     }
@@ -1127,7 +1139,7 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
     case 2: {  // step C
         hipLaunchKernelGGL((k_cgd_alpha<T>), dim3(1), dim3(1), 0, ctx->stream, (const T *)it->dot_all, it->nranks, d);
         MIK_LAUNCH_CHECK(ctx);
-        OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha)};
+        OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints() >> 3};
         MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)bs.seg_vec, done)));
         hipLaunchKernelGGL((k_finalize_store<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)bs.seg_vec, nseg, (int64_t)0, rr_slot, done);
         MIK_LAUNCH_CHECK(ctx);
