@@ -57,7 +57,8 @@ enum {
     MIK_ERR_HIP = 2,         /* HIP runtime error (text in mik_last_error) */
     MIK_ERR_MISMATCH = 3,    /* dimension / dtype mismatch */
     MIK_ERR_NOMEM = 4,       /* out of (device or host) memory */
-    MIK_ERR_NOTIMPL = 5      /* not implemented (e.g. nnz >= 2^31) */
+    MIK_ERR_NOTIMPL = 5,     /* not implemented (e.g. nnz >= 2^31) */
+    MIK_ERR_CALLBACK = 6     /* a mik_partition callback returned non-zero */
 };
 
 enum { MIK_F64 = 0, MIK_F32 = 1 };
@@ -192,6 +193,38 @@ int mik_gmres_iterate(mik_gmres *it, int64_t iteration, double *residual, int *d
 /* fields read by gmres! (src/gmres.jl:210,218): mv_products, residual.current, tol, k, beta */
 int mik_gmres_state(const mik_gmres *it, double *residual, double *tol, double *beta, int *k,
                     int64_t *mv_products, int *converged);
+
+/* ---- row-partitioned GMRESIterable: one process per GPU ---------------------------------------- */
+/* The same iterable (src/gmres.jl:57-106) over a contiguous row block.  The Arnoldi basis, x, b and
+ * the diagonal preconditioners are this rank's n_loc rows; A_loc is the block as an n_loc x n_ext
+ * operator whose columns [n_loc, n_ext) are halo entries (same layout as mik_cgd_create).  The two
+ * places where ranks couple are handed to the caller:
+ *   halo(user):   called with send_buf[i] = v[send_idx[i]] packed (enqueued on the ctx stream) for the
+ *                 vector v about to be multiplied; must leave x_ext[n_loc .. n_ext) filled with the
+ *                 neighbours' entries, ordered after that packing on the ctx stream (RCCL send/recv on
+ *                 the same stream, or a host-staged copy after a stream synchronisation);
+ *   reduce(user, dtype, count, values):  values[0..count) are this rank's partial sums (host scalars of
+ *                 `dtype`); on return they must hold  ((p_0 + p_1) + p_2) + ...  over ranks 0..P-1 in rank
+ *                 order, identically on every rank (dot / norm^2 of src/orthogonalize.jl:71,75,
+ *                 src/gmres.jl:252; CGS / DGKS pass all k projections in one call).
+ * Either callback returns 0 on success.  Every rank must make the same sequence of calls.  Hessenberg
+ * matrix, Givens solve and stopping test are replicated on every rank from identical scalars. */
+typedef int (*mik_halo_fn)(void *user);
+typedef int (*mik_reduce_fn)(void *user, int dtype, int count, void *values);
+typedef struct mik_partition {
+    int rank, nranks;
+    int64_t n_ext;              /* n_loc + number of halo columns of A_loc */
+    void *x_ext;                /* device n_ext-vector: SpMV input; the library writes [0, n_loc) */
+    const int32_t *send_idx;    /* device: local indices packed for the neighbours */
+    int64_t n_send;
+    void *send_buf;             /* device: n_send packed entries */
+    mik_halo_fn halo;
+    mik_reduce_fn reduce;
+    void *user;
+} mik_partition;
+int mik_gmres_create_partitioned(mik_ctx *ctx, const mik_csr *A_loc, void *x, const void *b, const void *pl_diag,
+                                 const void *pr_diag, double abstol, double reltol, int restart, int64_t maxiter,
+                                 int initially_zero, int orth_method, const mik_partition *part, mik_gmres **out);
 
 /* ---- row-partitioned CGIterable: one process per GPU (new design; the reference is serial) --- */
 /* out[i] = x[idx[i]], i < m (idx: device Int32) -- packs halo entries for the neighbour ranks. */

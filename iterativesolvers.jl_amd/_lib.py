@@ -17,7 +17,7 @@ MIK_OK = 0
 MIK_F64, MIK_F32 = 0, 1
 MIK_MGS, MIK_CGS, MIK_DGKS = 0, 1, 2
 STATUS = {1: "invalid argument", 2: "HIP runtime error", 3: "dimension/dtype mismatch",
-          4: "out of memory", 5: "not implemented"}
+          4: "out of memory", 5: "not implemented", 6: "partition callback failed"}
 
 
 class MikError(RuntimeError):
@@ -31,6 +31,17 @@ _i64 = C.c_int64
 _i64p = C.POINTER(C.c_int64)
 _f64p = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
+
+# callbacks of a row-partitioned iterable (include/mik.h: mik_halo_fn, mik_reduce_fn, mik_partition)
+HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
+
+
+class MikPartition(C.Structure):
+    _fields_ = [("rank", C.c_int), ("nranks", C.c_int), ("n_ext", C.c_int64), ("x_ext", C.c_void_p),
+                ("send_idx", C.c_void_p), ("n_send", C.c_int64), ("send_buf", C.c_void_p),
+                ("halo", HALO_FN), ("reduce", REDUCE_FN), ("user", C.c_void_p)]
+
 
 # name -> (restype, argtypes); mirrors include/mik.h one to one
 SIGNATURES = {
@@ -76,6 +87,8 @@ SIGNATURES = {
     "mik_cg_state": (C.c_int, [_vp, _f64p, _f64p, _f64p, _i64p, _i64p, _ip]),
     "mik_gmres_create": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int, _i64, C.c_int,
                                    C.c_int, C.POINTER(_vp)]),
+    "mik_gmres_create_partitioned": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int, _i64, C.c_int,
+                                               C.c_int, C.POINTER(MikPartition), C.POINTER(_vp)]),
     "mik_gmres_destroy": (C.c_int, [_vp]),
     "mik_gmres_iterate": (C.c_int, [_vp, _i64, _f64p, _ip]),
     "mik_gmres_state": (C.c_int, [_vp, _f64p, _f64p, _f64p, _ip, _i64p, _ip]),

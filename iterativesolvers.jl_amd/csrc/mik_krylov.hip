@@ -698,7 +698,107 @@ struct mik_gmres {
     double g_beta = 1, tol = 0;
     int k = 1, restart = 0, method = MIK_MGS;
     int64_t maxiter = 0, mv_products = 0;
+    bool dist = false;        // row-partitioned: SpMV input goes through part.x_ext + halo(), sums through reduce()
+    mik_partition part{};
 };
+
+template <typename T> static int gather_launch(mik_ctx *ctx, int64_t m, const int *idx, const T *x, T *out, const int *done);
+
+// mul!(dst, A, src) on this rank's rows; with a partition, src is staged in x_ext and the halo callback
+// fills its ghost tail before the local block is applied.                src/gmres.jl:245,287,293,301
+template <typename T> static int gm_spmv(mik_gmres *g, const T *src, T *dst)
+{
+    mik_ctx *ctx = g->ctx;
+    if (!g->dist) return mik_spmv_launch<T>(ctx, g->A, src, dst, false, nullptr, nullptr);
+    T *ext = (T *)g->part.x_ext;
+    if (src != ext && g->n > 0) MIK_HIP(ctx, hipMemcpyAsync(ext, src, sizeof(T) * (size_t)g->n, hipMemcpyDeviceToDevice, ctx->stream));
+    if (g->part.n_send > 0) MIK_TRY(gather_launch<T>(ctx, g->part.n_send, g->part.send_idx, ext, (T *)g->part.send_buf, nullptr));
+    if (g->part.halo && g->part.halo(g->part.user) != 0) return mik_fail(ctx, MIK_ERR_CALLBACK, "gmres: halo callback failed");
+    return mik_spmv_launch<T>(ctx, g->A, ext, dst, false, nullptr, nullptr);
+}
+
+// values[0..count): this rank's partial sums -> sums over ranks in rank order (identity without a partition)
+template <typename T> static int gm_reduce(mik_gmres *g, T *values, int count)
+{
+    if (!g->dist || !g->part.reduce || count <= 0) return MIK_OK;
+    if (g->part.reduce(g->part.user, g->dtype, count, values) != 0) return mik_fail(g->ctx, MIK_ERR_CALLBACK, "gmres: reduce callback failed");
+    return MIK_OK;
+}
+
+// orthogonalize_and_normalize! over a row partition (src/orthogonalize.jl:13-79): the same sweeps as
+// orthogonalize_impl on the local rows; every projection / norm^2 is finalised to a host scalar, summed
+// over the ranks by the caller's reduce() and fed back as a kernel argument.
+template <typename T>
+static int orthogonalize_part(mik_gmres *g, int k, const T *V, int64_t ldv, T *w, T *h, T *nrm_out, int method)
+{
+    mik_ctx *ctx = g->ctx;
+    const int64_t n = g->n;
+    if ((size_t)(2 * k + 4) * sizeof(T) > mik_ctx::COEF_BYTES) return mik_fail(ctx, MIK_ERR_NOTIMPL, "orthogonalize: k = %d too large", k);
+    const int64_t nseg = mik_nseg<T>(n);
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(nseg, 1) * (size_t)std::max(k, 1)));
+    T *hd = (T *)ctx->coef;
+    T *part = (T *)ctx->partials;
+    const bool vecw = mik_aligned16(w);
+    const bool vec = vecw && mik_aligned16(V) && (ldv % VT<T>::W == 0);
+    auto fetch = [&](int slot, T *dst) -> int {     // level 2 of the local tree -> host -> sum over ranks
+        MIK_TRY(finalize_store<T>(ctx, nseg, 1, hd + slot));
+        MIK_TRY(coef_download<T>(ctx, slot, dst, 1));
+        return gm_reduce<T>(g, dst, 1);
+    };
+    OpDot<T> dn{w, w};
+    T ss = T(0);
+    if (method == MIK_MGS) {                                             // :69-76
+        if (k > 0) {
+            OpDot<T> d0{V, w};
+            MIK_TRY((launch_map<T>(ctx, n, d0, vec, part, nullptr)));
+            MIK_TRY(fetch(0, &h[0]));
+            for (int i = 0; i + 1 < k; ++i) {
+                OpMgsPass<T, false> op{w, V + (int64_t)i * ldv, V + (int64_t)(i + 1) * ldv, coef_val<T>(h[i])};
+                MIK_TRY((launch_map<T>(ctx, n, op, vec, part, nullptr)));
+                MIK_TRY(fetch(0, &h[i + 1]));
+            }
+            OpMgsPass<T, true> last{w, V + (int64_t)(k - 1) * ldv, nullptr, coef_val<T>(h[k - 1])};
+            MIK_TRY((launch_map<T>(ctx, n, last, vec, part, nullptr)));
+        } else {
+            MIK_TRY((launch_map<T>(ctx, n, dn, vecw, part, nullptr)));
+        }
+        MIK_TRY(fetch(0, &ss));
+    } else {                                                             // :15-17 / :43-45
+        auto project = [&](int slot, T *coef) -> int {   // coef = V' w over all ranks; w -= V coef
+            if (k == 0) return MIK_OK;
+            MIK_TRY(multidot<T>(ctx, n, k, V, ldv, w, hd + slot));
+            MIK_TRY(coef_download<T>(ctx, slot, coef, k));
+            MIK_TRY(gm_reduce<T>(g, coef, k));
+            MIK_TRY(coef_upload<T>(ctx, slot, coef, k));
+            return gemv_n_dev<T>(ctx, n, k, V, ldv, hd + slot, T(-1), w);
+        };
+        MIK_TRY(project(0, h));
+        MIK_TRY((launch_map<T>(ctx, n, dn, vecw, part, nullptr)));
+        MIK_TRY(fetch(k, &ss));
+        if (method == MIK_DGKS) {
+            std::vector<T> corr((size_t)std::max(k, 1));
+            auto small_norm = [](const T *v, int len) { T s = T(0); for (int j = 0; j < len; ++j) { T p = v[j] * v[j]; s = s + p; } return (T)std::sqrt(s); };
+            const T eta = T(1) / std::sqrt(T(2));                        // :20
+            T nrm = std::sqrt(ss);
+            T projection_size = small_norm(h, k);                        // :22
+            while (nrm < eta * projection_size) {                        // :26
+                MIK_TRY(project(k + 2, corr.data()));                    // :27, :30
+                MIK_TRY((launch_map<T>(ctx, n, dn, vecw, part, nullptr)));
+                MIK_TRY(fetch(k, &ss));                                  // :32
+                nrm = std::sqrt(ss);
+                projection_size = small_norm(corr.data(), k);            // :28
+                for (int j = 0; j < k; ++j) h[j] = h[j] + corr[j];       // :31
+            }
+        }
+    }
+    const T nrm = std::sqrt(ss);
+    const T inv = T(1) / nrm;
+    OpScal<T> sc{w, coef_val<T>(inv)};                                   // w .*= inv(nrm)  :76 / :48 / :36
+    MIK_TRY((launch_map<T>(ctx, n, sc, vecw, (T *)nullptr, nullptr)));
+    *nrm_out = nrm;
+    return MIK_OK;
+}
+
 
 template <typename T> static std::vector<T> &gm_H(mik_gmres *g);
 template <> std::vector<double> &gm_H<double>(mik_gmres *g) { return g->H64; }
@@ -721,7 +821,7 @@ template <typename T> static int gmres_init_residual(mik_gmres *g, int initially
         OpSubNrm<T> op{b, nullptr, V0};                                   // :241
         MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)ctx->partials, nullptr)));
     } else {
-        MIK_TRY(mik_spmv_launch<T>(ctx, g->A, (const T *)g->x, (T *)g->Ax, false, nullptr, nullptr));   // :245
+        MIK_TRY(gm_spmv<T>(g, (const T *)g->x, (T *)g->Ax));              // :245
         OpSubNrm<T> op{b, (const T *)g->Ax, V0};                          // :241,246
         MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)ctx->partials, nullptr)));
     }
@@ -732,6 +832,18 @@ template <typename T> static int gmres_init_residual(mik_gmres *g, int initially
         MIK_TRY((launch_map<T>(ctx, n, dn, mik_aligned16(V0), (T *)ctx->partials, nullptr)));
     }
     T *hd = (T *)ctx->coef;
+    if (g->dist) {
+        T ss;
+        MIK_TRY(finalize_store<T>(ctx, nseg, 1, hd));
+        MIK_TRY(coef_download<T>(ctx, 0, &ss, 1));
+        MIK_TRY(gm_reduce<T>(g, &ss, 1));
+        const T beta = std::sqrt(ss);                                     // :252
+        const T inv = T(1) / beta;
+        OpScal<T> scd{V0, coef_val<T>(inv)};                              // :253
+        MIK_TRY((launch_map<T>(ctx, n, scd, mik_aligned16(V0), (T *)nullptr, nullptr)));
+        *beta_out = beta;
+        return MIK_OK;
+    }
     MIK_TRY(finalize_nrm_inv<T>(ctx, nseg, hd));                          // :252
     OpScal<T> sc{V0, coef_ptr<T>(hd + 1)};                                // :253
     MIK_TRY((launch_map<T>(ctx, n, sc, mik_aligned16(V0), (T *)nullptr, nullptr)));
@@ -760,13 +872,21 @@ template <typename T> static int gmres_create_impl(mik_gmres *g, double abstol, 
     return MIK_OK;
 }
 
-extern "C" int mik_gmres_create(mik_ctx *ctx, const mik_csr *A, void *x, const void *b, const void *pl_diag, const void *pr_diag,
-                                double abstol, double reltol, int restart, int64_t maxiter, int initially_zero, int orth_method,
-                                mik_gmres **out)
+static int gmres_create_common(mik_ctx *ctx, const mik_csr *A, void *x, const void *b, const void *pl_diag, const void *pr_diag,
+                               double abstol, double reltol, int restart, int64_t maxiter, int initially_zero, int orth_method,
+                               const mik_partition *part, mik_gmres **out)
 {
     if (!ctx || !out) return MIK_ERR_INVALID;
     *out = nullptr;
-    if (!A || A->n_rows != A->n_cols) return mik_fail(ctx, MIK_ERR_MISMATCH, "mik_gmres_create: A must be square");
+    if (!A) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create: NULL operator");
+    if (!part && A->n_rows != A->n_cols) return mik_fail(ctx, MIK_ERR_MISMATCH, "mik_gmres_create: A must be square");
+    if (part) {
+        if (part->nranks < 1 || part->rank < 0 || part->rank >= part->nranks) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create_partitioned: bad rank %d of %d", part->rank, part->nranks);
+        if (part->n_ext != A->n_cols || part->n_ext < A->n_rows) return mik_fail(ctx, MIK_ERR_MISMATCH, "mik_gmres_create_partitioned: A_loc must be n_loc x n_ext");
+        if ((part->n_ext && !part->x_ext) || part->n_send < 0 || (part->n_send && (!part->send_idx || !part->send_buf)))
+            return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create_partitioned: NULL halo buffers");
+        if (part->nranks > 1 && (!part->reduce || !part->halo)) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create_partitioned: callbacks required for nranks > 1");
+    }
     if (restart < 1) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create: restart must be >= 1");
     if (orth_method != MIK_MGS && orth_method != MIK_CGS && orth_method != MIK_DGKS) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create: bad orth_method");
     const int64_t n = A->n_rows;
@@ -776,6 +896,7 @@ extern "C" int mik_gmres_create(mik_ctx *ctx, const mik_csr *A, void *x, const v
     if (!g) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_gmres_create: host allocation failed");
     g->ctx = ctx; g->A = A; g->dtype = A->dtype; g->n = n; g->x = x; g->b = b; g->pl = pl_diag; g->pr = pr_diag;
     g->restart = restart; g->maxiter = maxiter; g->method = orth_method;
+    if (part) { g->dist = true; g->part = *part; }
     g->ldv = (n + 63) / 64 * 64;
     if (g->ldv == 0) g->ldv = 64;
     const size_t es = mik_dtype_size(A->dtype);
@@ -795,6 +916,21 @@ extern "C" int mik_gmres_create(mik_ctx *ctx, const mik_csr *A, void *x, const v
     if (rc) { mik_gmres_destroy(g); return rc; }
     *out = g;
     return MIK_OK;
+}
+
+extern "C" int mik_gmres_create(mik_ctx *ctx, const mik_csr *A, void *x, const void *b, const void *pl_diag, const void *pr_diag,
+                                double abstol, double reltol, int restart, int64_t maxiter, int initially_zero, int orth_method,
+                                mik_gmres **out)
+{
+    return gmres_create_common(ctx, A, x, b, pl_diag, pr_diag, abstol, reltol, restart, maxiter, initially_zero, orth_method, nullptr, out);
+}
+
+extern "C" int mik_gmres_create_partitioned(mik_ctx *ctx, const mik_csr *A_loc, void *x, const void *b, const void *pl_diag,
+                                            const void *pr_diag, double abstol, double reltol, int restart, int64_t maxiter,
+                                            int initially_zero, int orth_method, const mik_partition *part, mik_gmres **out)
+{
+    if (!part) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create_partitioned: NULL partition");
+    return gmres_create_common(ctx, A_loc, x, b, pl_diag, pr_diag, abstol, reltol, restart, maxiter, initially_zero, orth_method, part, out);
 }
 
 extern "C" int mik_gmres_destroy(mik_gmres *g)
@@ -829,10 +965,10 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
         // Pl \ (A * (Pr \ v)) through the work vector Ax                  :297-304
         OpDivide<T> dr{vk, (const T *)g->pr, vk1};
         MIK_TRY((launch_map<T>(ctx, g->n, dr, mik_aligned16(vk) && mik_aligned16(vk1) && mik_aligned16(g->pr), (T *)nullptr, nullptr)));
-        MIK_TRY(mik_spmv_launch<T>(ctx, g->A, vk1, (T *)g->Ax, false, nullptr, nullptr));
+        MIK_TRY(gm_spmv<T>(g, vk1, (T *)g->Ax));
         MIK_HIP(ctx, hipMemcpyAsync(vk1, g->Ax, sizeof(T) * (size_t)g->n, hipMemcpyDeviceToDevice, ctx->stream));
     } else {
-        MIK_TRY(mik_spmv_launch<T>(ctx, g->A, vk, vk1, false, nullptr, nullptr));   // V[:, k+1] = A * V[:, k]   :287
+        MIK_TRY(gm_spmv<T>(g, vk, vk1));                                  // V[:, k+1] = A * V[:, k]   :287
     }
     if (g->pl) {                                                          // ldiv!(Pl, nextV)  :294 / :303
         OpDivide<T> dl{vk1, (const T *)g->pl, vk1};
@@ -842,7 +978,8 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
 
     // H[k+1, k] = orthogonalize_and_normalize!(V[:, 1:k], V[:, k+1], H[1:k, k], orth_meth)   :68-73
     T nrm;
-    MIK_TRY(orthogonalize_impl<T>(ctx, g->n, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));
+    if (g->dist) MIK_TRY(orthogonalize_part<T>(g, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));
+    else MIK_TRY(orthogonalize_impl<T>(ctx, g->n, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));
     Hat(k, k - 1) = nrm;
 
     // update_residual!                                                   :76, :224-233

@@ -159,6 +159,22 @@ class TorchComm:
         else:
             self.dist.all_gather(list(all_t.chunk(self.size)), rank_slot.clone())
 
+    def all_gather_host(self, values: np.ndarray) -> np.ndarray:
+        """(P, count) array of every rank's host scalars, rank order (blocking)."""
+        values = np.ascontiguousarray(values)
+        if self.size == 1 and not self.force:
+            return values[None, :].copy()
+        import torch
+        if self.staged:
+            out = [torch.empty(values.size, dtype=torch.from_numpy(values).dtype) for _ in range(self.size)]
+            self.dist.all_gather(out, torch.from_numpy(values.copy()))
+            return np.stack([o.numpy() for o in out])
+        dev = torch.device("cuda", torch.cuda.current_device())
+        mine = torch.from_numpy(values.copy()).to(dev)
+        out = torch.empty(self.size * values.size, dtype=mine.dtype, device=dev)
+        self.dist.all_gather_into_tensor(out, mine)
+        return out.cpu().numpy().reshape(self.size, values.size)
+
     def barrier(self):
         if self.size > 1:
             self.dist.barrier()
@@ -177,8 +193,65 @@ class SelfComm:
     def all_gather_scalar(self, all_t, rank_slot):
         pass
 
+    def all_gather_host(self, values):
+        return np.ascontiguousarray(values)[None, :].copy()
+
     def barrier(self):
         pass
+
+
+class ThreadComm:
+    """P virtual ranks = P host threads of ONE process sharing one GPU (each with its own ctx and
+    stream).  The blocking callbacks of the partitioned GMRES handle meet at a barrier -- this is how
+    that path is verified on a single-GPU box, where RCCL refuses two ranks on one device.
+    ``ThreadComm.world(P)`` returns the P per-rank communicators."""
+
+    def __init__(self, shared, rank):
+        self.shared, self.rank, self.size = shared, rank, shared["P"]
+
+    @staticmethod
+    def world(P: int):
+        import threading
+        shared = {"P": P, "barrier": threading.Barrier(P, timeout=120), "slots": [None] * P, "send": [None] * P, "plans": [None] * P}
+        return [ThreadComm(shared, r) for r in range(P)]
+
+    def all_gather_objects(self, obj):
+        return self._gather(obj)
+
+    def _gather(self, obj):
+        sh = self.shared
+        sh["slots"][self.rank] = obj
+        sh["barrier"].wait()
+        out = list(sh["slots"])
+        sh["barrier"].wait()
+        return out
+
+    def all_gather_host(self, values):
+        return np.stack(self._gather(np.ascontiguousarray(values).copy()))
+
+    def exchange(self, plan, send_buf, ghost_view):
+        import torch
+        sh = self.shared
+        torch.cuda.current_stream().synchronize()          # my packed halo is complete
+        sh["send"][self.rank], sh["plans"][self.rank] = send_buf, plan
+        sh["barrier"].wait()
+        for peer, off, cnt in plan.recv:
+            soff = next(o for (q, o, c) in sh["plans"][peer].send if q == self.rank)
+            ghost_view[off:off + cnt].copy_(sh["send"][peer][soff:soff + cnt])
+        torch.cuda.current_stream().synchronize()          # my reads of the peers' buffers are complete
+        sh["barrier"].wait()
+
+    def barrier(self):
+        self.shared["barrier"].wait()
+
+
+def rank_ordered_sum(parts: np.ndarray) -> np.ndarray:
+    """((p_0 + p_1) + p_2) + ... along axis 0 in the array's own dtype: the order every rank uses, so all
+    ranks obtain identical bits (include/mik.h: mik_reduce_fn)."""
+    tot = parts[0].copy()
+    for q in range(1, parts.shape[0]):
+        tot = tot + parts[q]
+    return tot
 
 
 # ==============================================================================================
@@ -321,6 +394,145 @@ class DistCGIterable:
         while (nxt := self.iterate(iteration)) is not None:
             _, iteration = nxt
             yield self.residual
+
+
+class PartitionLinks:
+    """The two points where the ranks of a row-partitioned iterable couple (include/mik.h: mik_halo_fn,
+    mik_reduce_fn), on top of a communicator.  ``send_buf`` / ``x_ext`` are 1-D tensors (device tensors for
+    the product, CPU tensors for the gloo test double)."""
+
+    def __init__(self, comm, plan: HaloPlan, send_buf, x_ext):
+        self.comm, self.plan, self.send_buf, self.x_ext = comm, plan, send_buf, x_ext
+
+    def halo(self):
+        p = self.plan
+        self.comm.exchange(p, self.send_buf, self.x_ext[p.n_loc:p.n_loc + p.n_ghost])
+
+    def reduce(self, values: np.ndarray):
+        """values: this rank's partial sums -> in place, the sums over ranks 0..P-1 in rank order."""
+        values[:] = rank_ordered_sum(self.comm.all_gather_host(values))
+
+
+class DistGMRESIterable:
+    """``GMRESIterable`` (src/gmres.jl:31-49) over a row partition: this rank's block of the Arnoldi basis
+    lives in ``mik_gmres_create_partitioned``; the halo exchange before every SpMV and the rank-ordered
+    sums of the projections / norms (src/orthogonalize.jl:71,75; src/gmres.jl:252) come back here as
+    callbacks and go through ``comm``.  ``iterate`` follows src/gmres.jl:57-106 on every rank identically."""
+
+    def __init__(self, pkg, comm, ptr, local_idx, val, plan: HaloPlan, b_loc, x_loc=None, *, abstol=0.0, reltol=None, restart=20,
+                 maxiter=None, orth_meth=None, pl_diag=None, pr_diag=None, device=0, n_global=None):
+        import torch
+        self.pkg, self.comm, self.plan, self.torch = pkg, comm, plan, torch
+        L = pkg.lib()
+        self.L = L
+        dtype = np.dtype(val.dtype)
+        self.dtype = dtype
+        tdt = {np.dtype(np.float64): torch.float64, np.dtype(np.float32): torch.float32}[dtype]
+        dev = torch.device("cuda", device)
+        self.ctx = pkg.HipContext(device)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.ctx.set_stream(self.stream.cuda_stream)
+        n_loc, n_ext = plan.n_loc, plan.n_loc + plan.n_ghost
+        self.A = pkg.HipCSR(n_loc, n_ext, ptr, local_idx, val, index_base=0, is_csc=False, ctx=self.ctx)
+        with torch.cuda.stream(self.stream):
+            self.x_ext = torch.zeros(max(n_ext, 1), dtype=tdt, device=dev)
+            self.send_buf = torch.zeros(max(plan.n_send, 1), dtype=tdt, device=dev)
+            self.send_idx = (torch.from_numpy(plan.send_idx.astype(np.int32)).to(dev) if plan.n_send
+                             else torch.zeros(1, dtype=torch.int32, device=dev))
+        self.b = pkg.HipVector.from_numpy(np.ascontiguousarray(b_loc, dtype), self.ctx)
+        initially_zero = x_loc is None
+        self.x = pkg.HipVector(n_loc, dtype, self.ctx).fill_(0) if initially_zero else pkg.HipVector.from_numpy(np.ascontiguousarray(x_loc, dtype), self.ctx)
+        self.pl = pkg.HipVector.from_numpy(np.ascontiguousarray(pl_diag, dtype), self.ctx) if pl_diag is not None else None
+        self.pr = pkg.HipVector.from_numpy(np.ascontiguousarray(pr_diag, dtype), self.ctx) if pr_diag is not None else None
+        n_glob = int(n_global) if n_global is not None else int(sum(comm.all_gather_objects(n_loc)))
+        self.restart = int(min(20, n_glob) if restart is None else restart)                 # src/gmres.jl:113
+        self.maxiter = int(n_glob if maxiter is None else maxiter)                           # :114
+        reltol = float(np.sqrt(np.finfo(dtype).eps)) if reltol is None else float(reltol)    # :112
+        self.orth_meth = orth_meth if orth_meth is not None else pkg.ModifiedGramSchmidt()   # :116
+        self.callback_error = None
+        ctype = C.c_double if dtype == np.float64 else C.c_float
+
+        self.links = PartitionLinks(comm, plan, self.send_buf, self.x_ext)
+
+        def _halo(_user):
+            try:
+                self.links.halo()
+                return 0
+            except BaseException as e:                      # never let an exception cross the C frame
+                self.callback_error = e
+                return 1
+
+        def _reduce(_user, _dtype, count, values):
+            try:
+                self.links.reduce(np.ctypeslib.as_array(C.cast(values, C.POINTER(ctype)), shape=(count,)))
+                return 0
+            except BaseException as e:
+                self.callback_error = e
+                return 1
+
+        self._halo_cb, self._reduce_cb = pkg._lib.HALO_FN(_halo), pkg._lib.REDUCE_FN(_reduce)   # keep alive
+        self.part = pkg._lib.MikPartition(plan.rank, plan.nranks, n_ext, self.x_ext.data_ptr(), self.send_idx.data_ptr(), plan.n_send,
+                                          self.send_buf.data_ptr(), self._halo_cb, self._reduce_cb, None)
+        h = _vp()
+        with torch.cuda.stream(self.stream):
+            self._check(L.mik_gmres_create_partitioned(
+                self.ctx.handle, self.A.handle, _vp(self.x.ptr), _vp(self.b.ptr), _vp(self.pl.ptr if self.pl else None),
+                _vp(self.pr.ptr if self.pr else None), float(abstol), reltol, self.restart, self.maxiter, int(initially_zero),
+                self.orth_meth.code, C.byref(self.part), C.byref(h)), "mik_gmres_create_partitioned")
+        self.handle = h
+        self._refresh()
+
+    def _check(self, status, where):
+        if status and self.callback_error is not None:
+            err, self.callback_error = self.callback_error, None
+            raise err
+        self.pkg._lib.check(status, where, self.ctx.handle)
+
+    def _refresh(self):
+        res, tol, beta = C.c_double(), C.c_double(), C.c_double()
+        k, mv, conv = C.c_int(), C.c_int64(), C.c_int()
+        self._check(self.L.mik_gmres_state(self.handle, C.byref(res), C.byref(tol), C.byref(beta), C.byref(k), C.byref(mv), C.byref(conv)),
+                    "mik_gmres_state")
+        self.residual_current, self.tol, self.beta, self.k, self.mv_products = res.value, tol.value, beta.value, k.value, mv.value
+
+    def converged(self) -> bool:                                         # src/gmres.jl:51
+        return self.residual_current <= self.tol
+
+    def done(self, iteration: int) -> bool:                              # src/gmres.jl:55
+        return iteration >= self.maxiter or self.converged()
+
+    def iterate(self, iteration: int = 0):
+        res, done = C.c_double(), C.c_int()
+        with self.torch.cuda.stream(self.stream):
+            self._check(self.L.mik_gmres_iterate(self.handle, int(iteration), C.byref(res), C.byref(done)), "mik_gmres_iterate")
+        if done.value:
+            return None
+        self._refresh()
+        return self.residual_current, iteration + 1
+
+    def __iter__(self):
+        iteration = 0
+        while (nxt := self.iterate(iteration)) is not None:
+            _, iteration = nxt
+            yield self.residual_current
+
+    def solve(self) -> np.ndarray:
+        """The loop of gmres! (src/gmres.jl:207-214): residual history of this solve."""
+        return np.asarray(list(self))
+
+    def solution(self) -> np.ndarray:
+        return self.x.to_numpy()
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.mik_gmres_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class LoopbackCG:

@@ -39,5 +39,12 @@ def ctx(pkg):
     return pkg.default_context()
 
 
+@pytest.fixture(scope="session")
+def dist(pkg):
+    """The row-partition layer of the product package."""
+    from importlib import import_module
+    return import_module(pkg.__name__ + ".dist")
+
+
 def fromhex(lst):
     return np.array([float.fromhex(s) for s in lst], dtype=np.float64)

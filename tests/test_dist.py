@@ -166,6 +166,80 @@ def test_gloo_world2_matches_partitioned_oracle(pkg, orc, tmp_path):
     assert np.array_equal(x, xo)
 
 
+def _gloo_gmres_worker(rank, world, port, method, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scipy.sparse as sp
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    from dist_double import NumpyGmresRank
+    pkg = graft.load_package()
+    orc = graft.load_oracle()
+    d = importlib.import_module(pkg.__name__ + ".dist")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = d.TorchComm()
+    n, colptr, rowval, nzval, b = pkg.fixtures.advection_dominated(7, 300.0)        # nonsymmetric: CSC(A) != CSR(A)
+    S = sp.csc_matrix((nzval, rowval - 1, colptr - 1), shape=(n, n)).tocsr()
+    offsets = np.array([0, 150, n]) if world == 2 else d.partition_rows(n, world)    # cut inside a grid plane
+    blk = S[offsets[rank]:offsets[rank + 1]]
+    ptr, idx, val = blk.indptr.astype(np.int64), blk.indices.astype(np.int64), blk.data
+    local_idx, plan = d.localize_block(ptr, idx, offsets, rank)
+    d.complete_plan(plan, offsets, comm.all_gather_objects(plan.ghost_gids))
+    x_ext = torch.zeros(max(plan.n_loc + plan.n_ghost, 1), dtype=torch.float64)
+    send_buf = torch.zeros(max(plan.n_send, 1), dtype=torch.float64)
+    links = d.PartitionLinks(comm, plan, send_buf, x_ext)
+    g = NumpyGmresRank(orc, links, ptr, local_idx, val, plan, b[offsets[rank]:offsets[rank + 1]], restart=6,
+                       reltol=1.5e-8, maxiter=60, method=method)
+    hist, iteration = [], 0
+    while (nxt := g.iterate(iteration)) is not None:
+        hist.append(nxt[0])
+        iteration = nxt[1]
+    np.save(os.path.join(out_dir, f"hist{rank}.npy"), np.array(hist))
+    np.save(os.path.join(out_dir, f"x{rank}.npy"), g.x)
+    np.save(os.path.join(out_dir, f"mv{rank}.npy"), np.array([g.mv_products]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("method", ["mgs", "cgs"])
+def test_gloo_world2_partitioned_gmres_links_match_oracle(pkg, orc, tmp_path, method):
+    """The halo / rank-ordered-sum callbacks of the partitioned GMRES (dist.PartitionLinks over gloo) with a
+    numpy stand-in for the device arithmetic: bit-identical to the oracle's gmres with the same partition."""
+    import torch.multiprocessing as mp
+    world = 2
+    port = 29300 + os.getpid() % 250 + (7 if method == "cgs" else 0)
+    mp.spawn(_gloo_gmres_worker, args=(world, port, method, str(tmp_path)), nprocs=world, join=True)
+    A, _ = orc.advdiff(7, 300.0)
+    b = pkg.fixtures.advection_dominated(7, 300.0)[4]     # the workers' rhs (numpy's exp/sin, not libm's)
+    orc.set_partition(np.array([0, 150, A.n]))
+    try:
+        xo, ho = orc.gmres(A, b, restart=6, maxiter=60, reltol=1.5e-8, orth_meth=method, mode="tree", shape=(2, 2))
+    finally:
+        orc.set_partition(None)
+    h0, h1 = np.load(tmp_path / "hist0.npy"), np.load(tmp_path / "hist1.npy")
+    assert np.array_equal(h0, h1) and np.array_equal(h0, ho["resnorm"])
+    assert int(np.load(tmp_path / "mv0.npy")[0]) == ho["mvps"]
+    assert np.array_equal(np.concatenate([np.load(tmp_path / "x0.npy"), np.load(tmp_path / "x1.npy")]), xo)
+
+
+def test_rank_ordered_sum_and_thread_comm(pkg):
+    import threading
+    d = dist_mod(pkg)
+    parts = np.array([[1e16, 1.0], [1.0, 1e16], [-1e16, -1e16]])
+    assert np.array_equal(d.rank_ordered_sum(parts), np.array([(1e16 + 1.0) - 1e16, (1.0 + 1e16) - 1e16]))
+    assert d.rank_ordered_sum(parts.astype(np.float32)).dtype == np.float32
+    comms, got = d.ThreadComm.world(3), [None] * 3
+
+    def work(r):
+        got[r] = comms[r].all_gather_host(np.array([float(r), 10.0 * r]))
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(3)]
+    [t.start() for t in ts]
+    [t.join(30) for t in ts]
+    assert all(np.array_equal(g, np.array([[0.0, 0.0], [1.0, 10.0], [2.0, 20.0]])) for g in got)
+
+
 # ------------------------------------------------------------------------------------------------
 # the HIP engine: loopback ranks on one GPU
 # ------------------------------------------------------------------------------------------------

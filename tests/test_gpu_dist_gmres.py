@@ -1,0 +1,186 @@
+"""Row-partitioned GMRES (mik_gmres_create_partitioned + dist.DistGMRESIterable) against the oracle's
+gmres with the same partition-ordered sums: bit-exact residual history, solution and counters.
+
+On one GPU the P ranks are P host threads (dist.ThreadComm) or P processes with gloo-staged exchanges;
+the RCCL path uses the same callbacks with device tensors (dist.TorchComm)."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def csr_block(S, r0, r1):
+    blk = S[r0:r1]
+    return blk.indptr.astype(np.int64), blk.indices.astype(np.int64), np.ascontiguousarray(blk.data)
+
+
+def run_threads(pkg, dist, S, b, P, *, x0=None, pl=None, pr=None, offsets=None, **kw):
+    n = S.shape[0]
+    offsets = dist.partition_rows(n, P) if offsets is None else np.asarray(offsets, np.int64)
+    comms = dist.ThreadComm.world(P)
+    out, errs = [None] * P, [None] * P
+
+    def worker(r):
+        try:
+            r0, r1 = int(offsets[r]), int(offsets[r + 1])
+            ptr, idx, val = csr_block(S, r0, r1)
+            local_idx, plan = dist.localize_block(ptr, idx, offsets, r)
+            dist.complete_plan(plan, offsets, comms[r].all_gather_objects(plan.ghost_gids))
+            it = dist.DistGMRESIterable(pkg, comms[r], ptr, local_idx, val, plan, b[r0:r1], None if x0 is None else x0[r0:r1],
+                                        pl_diag=None if pl is None else pl[r0:r1], pr_diag=None if pr is None else pr[r0:r1],
+                                        n_global=n, **kw)
+            hist = it.solve()
+            out[r] = dict(hist=hist, x=it.solution(), mvps=it.mv_products, conv=it.converged())
+            it.close()
+        except BaseException as e:          # release the other ranks from their barrier
+            errs[r] = e
+            comms[r].shared["barrier"].abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(P)]
+    [t.start() for t in ts]
+    [t.join(timeout=120) for t in ts]
+    first = next((e for e in errs if e is not None and not isinstance(e, threading.BrokenBarrierError)), None) or next((e for e in errs if e), None)
+    if first is not None:
+        raise first
+    assert all(o is not None for o in out), "a rank thread did not finish"
+    return offsets, out
+
+
+@pytest.mark.parametrize("P", [1, 2, 3])
+@pytest.mark.parametrize("orth", ["mgs", "cgs", "dgks"])
+def test_partitioned_gmres_bit_exact_vs_partitioned_oracle(pkg, orc, ctx, dist, P, orth):
+    A, b = orc.advdiff(12, 1000.0)
+    S = A.to_scipy().tocsr()
+    M = {"mgs": pkg.ModifiedGramSchmidt(), "cgs": pkg.ClassicalGramSchmidt(), "dgks": pkg.DGKS()}[orth]
+    offsets, out = run_threads(pkg, dist, S, b, P, restart=10, orth_meth=M)
+    orc.set_partition(offsets)
+    try:
+        xo, ho = orc.gmres(A, b, restart=10, orth_meth=orth, mode="tree", shape=ctx.reduce_shape(np.float64))
+    finally:
+        orc.set_partition(None)
+    for o in out:
+        assert np.array_equal(o["hist"], ho["resnorm"]) and o["mvps"] == ho["mvps"] and o["conv"] == ho["isconverged"]
+    assert np.array_equal(np.concatenate([o["x"] for o in out]), xo)
+    assert np.linalg.norm(S @ xo - b) / np.linalg.norm(b) <= 2e-8
+
+
+def test_partitioned_gmres_preconditioned_nonzero_start_uneven_blocks(pkg, orc, ctx, dist):
+    A, b = orc.advdiff(10, 500.0)
+    S = A.to_scipy().tocsr()
+    n = S.shape[0]
+    d = S.diagonal()
+    pl, pr = np.sqrt(np.abs(d)), np.sign(d) * np.sqrt(np.abs(d))          # Pl * Pr = diag(A)
+    x0 = np.cos(np.arange(n) * 0.37)
+    offsets = np.array([0, 137, 138, 700, n])          # ragged blocks, one of a single row
+    offsets, out = run_threads(pkg, dist, S, b, 4, x0=x0, pl=pl, pr=pr, offsets=offsets, restart=7, maxiter=40)
+    orc.set_partition(offsets)
+    try:
+        xo, ho = orc.gmres(A, b, x0, restart=7, maxiter=40, mode="tree", shape=ctx.reduce_shape(np.float64), pl_diag=pl, pr_diag=pr)
+    finally:
+        orc.set_partition(None)
+    for o in out:
+        assert np.array_equal(o["hist"], ho["resnorm"]) and o["mvps"] == ho["mvps"]
+    assert np.array_equal(np.concatenate([o["x"] for o in out]), xo)
+
+
+def test_partitioned_gmres_fp32(pkg, orc, ctx, dist):
+    A64, b64 = orc.advdiff(10, 100.0)
+    A, b = orc.CSC(A64.n, A64.colptr, A64.rowval, A64.nzval.astype(np.float32), A64.index_base), b64.astype(np.float32)
+    S = A.to_scipy().tocsr()
+    offsets, out = run_threads(pkg, dist, S, b, 2, restart=15, orth_meth=pkg.ClassicalGramSchmidt())
+    orc.set_partition(offsets)
+    try:
+        xo, ho = orc.gmres(A, b, restart=15, orth_meth="cgs", mode="tree", shape=ctx.reduce_shape(np.float32))
+    finally:
+        orc.set_partition(None)
+    assert np.array_equal(out[0]["hist"], ho["resnorm"]) and np.array_equal(out[1]["hist"], ho["resnorm"])
+    assert np.array_equal(np.concatenate([o["x"] for o in out]), xo)
+
+
+def test_one_rank_partition_equals_the_plain_iterable(pkg, orc, ctx, dist):
+    A, b = orc.advdiff(12, 1000.0)
+    S = A.to_scipy().tocsr()
+    _, out = run_threads(pkg, dist, S, b, 1, restart=10)
+    dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval, index_base=A.index_base)
+    x, ch = pkg.gmres(dA, pkg.HipVector.from_numpy(b), restart=10, log=True)
+    assert np.array_equal(out[0]["hist"], ch["resnorm"]) and np.array_equal(out[0]["x"], x.to_numpy())
+
+
+def test_callback_failure_surfaces_as_an_error(pkg, orc, ctx, dist):
+    A, b = orc.advdiff(6, 10.0)
+    S = A.to_scipy().tocsr()
+
+    class Boom(dist.SelfComm):
+        calls = 0
+
+        def all_gather_host(self, values):
+            Boom.calls += 1
+            if Boom.calls > 3:
+                raise RuntimeError("link down")
+            return super().all_gather_host(values)
+
+    n = S.shape[0]
+    offsets = np.array([0, n])
+    ptr, idx, val = csr_block(S, 0, n)
+    local_idx, plan = dist.localize_block(ptr, idx, offsets, 0)
+    dist.complete_plan(plan, offsets, [plan.ghost_gids])
+    it = dist.DistGMRESIterable(pkg, Boom(), ptr, local_idx, val, plan, b, n_global=n, restart=5)
+    with pytest.raises(RuntimeError, match="link down"):
+        list(it)
+    it.close()
+
+
+def _proc_worker(rank, world, port, out_dir, backend="gloo"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if backend == "nccl":
+        os.environ["MIK_DIST_FORCE_COLLECTIVES"] = "1"      # a world of one still issues the RCCL calls
+    import torch
+    import torch.distributed as td
+    import __graft_entry__ as graft
+    from importlib import import_module
+    pkg = graft.load_package()
+    dist = import_module(pkg.__name__ + ".dist")
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        td.init_process_group("gloo", rank=rank, world_size=world)
+    comm = dist.TorchComm()
+    n, colptr, rowval, nzval, b = pkg.fixtures.advection_dominated(10, 1000.0)
+    import scipy.sparse as sp
+    S = sp.csc_matrix((nzval, rowval - 1, colptr - 1), shape=(n, n)).tocsr()
+    offsets = dist.partition_rows(n, world)
+    r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
+    ptr, idx, val = csr_block(S, r0, r1)
+    local_idx, plan = dist.localize_block(ptr, idx, offsets, rank)
+    dist.complete_plan(plan, offsets, comm.all_gather_objects(plan.ghost_gids))
+    it = dist.DistGMRESIterable(pkg, comm, ptr, local_idx, val, plan, b[r0:r1], n_global=n, restart=8, orth_meth=pkg.DGKS())
+    hist = it.solve()
+    np.save(os.path.join(out_dir, f"hist{rank}.npy"), hist)
+    np.save(os.path.join(out_dir, f"x{rank}.npy"), it.solution())
+    np.save(os.path.join(out_dir, f"off{rank}.npy"), offsets)
+    it.close()
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (1, "nccl")])
+def test_process_ranks_match_partitioned_oracle(pkg, orc, ctx, tmp_path, world, backend):
+    """2 processes on one GPU with gloo-staged exchanges; and the RCCL call path (device all-gather of the
+    partial sums, stream-ordered send/recv plumbing) in a world of one -- RCCL refuses two ranks per device."""
+    import torch.multiprocessing as mp
+    port = 29900 + os.getpid() % 90 + world
+    mp.spawn(_proc_worker, args=(world, port, str(tmp_path), backend), nprocs=world, join=True)
+    A, _ = orc.advdiff(10, 1000.0)
+    b = pkg.fixtures.advection_dominated(10, 1000.0)[4]   # the workers' rhs (numpy's exp/sin, not libm's)
+    offsets = np.load(tmp_path / "off0.npy")
+    orc.set_partition(offsets)
+    try:
+        xo, ho = orc.gmres(A, b, restart=8, orth_meth="dgks", mode="tree", shape=ctx.reduce_shape(np.float64))
+    finally:
+        orc.set_partition(None)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"hist{r}.npy"), ho["resnorm"])
+    assert np.array_equal(np.concatenate([np.load(tmp_path / f"x{r}.npy") for r in range(world)]), xo)
