@@ -1,0 +1,60 @@
+"""Per-iteration time of the widened solvers on the 256^3 Laplacian, fp64, one MI355X:
+PCG with a Jacobi Pl, BiCGStab(2), MINRES, Chebyshev -- next to plain CG.  `gbs` = bytes of the reference's
+own operation sequence (SpMV algorithmic bytes + its vector sweeps, unfused) / time.
+    python scripts/solver_bench.py [--grid 256] [--iters 60]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as graft  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--grid", type=int, default=256)
+ap.add_argument("--iters", type=int, default=60)
+args = ap.parse_args()
+pkg = graft.load_package()
+import torch  # noqa: E402
+
+N = args.grid
+n, colptr, rowval, nzval = pkg.fixtures.laplace_matrix(N, 3)
+A = pkg.HipCSR(n, n, colptr, rowval, nzval, index_base=1)
+del colptr, rowval, nzval
+b = pkg.HipVector.from_numpy(pkg.fixtures.hashed_rhs(n))
+spmv_b = A.spmv_algorithmic_bytes()
+vec = 8 * n
+
+
+def timed(name, it, start, words, mv_per_iter, iters=args.iters, warm=5):
+    i = start
+    for _ in range(warm):
+        _, i = it.iterate(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        _, i = it.iterate(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    bytes_ = mv_per_iter * spmv_b + words * vec
+    print(json.dumps({"solver": name, "grid": N, "us_per_iter": dt * 1e6, "iters_per_sec": 1 / dt, "spmv_per_iter": mv_per_iter,
+                      "vector_words_per_row_unfused": words, "gbs_of_reference_sequence": bytes_ / dt / 1e9}))
+
+
+x = pkg.zerox(A, b)
+timed("cg", pkg.cg_iterator_(x, A, b, reltol=0.0, initially_zero=True, maxiter=10 ** 9), 0, 12, 1)
+d = pkg.HipVector.from_numpy(np.full(n, 6.0))
+x = pkg.zerox(A, b)
+timed("pcg_jacobi", pkg.cg_iterator_(x, A, b, pkg.JacobiPrec(d), reltol=0.0, initially_zero=True, maxiter=10 ** 9), 0, 15, 1)
+x = pkg.zerox(A, b)
+# BiCGStab(2): per outer iteration 4 SpMV; sweeps: 2 dots x2 (2 words each) ... counted from src/bicgstabl.jl:88-132
+l = 2
+words = sum(2 + 3 * (j + 1) + 2 + 3 * (j + 1) + 3 for j in range(l)) + (l + 1) * (l + 1) * 2 + (l + 2) + (l + 2) + (l + 2) + 1
+timed("bicgstabl2", pkg.bicgstabl_iterator_(x, A, b, 2, reltol=0.0, max_mv_products=10 ** 9, initial_zero=True), 0, words, 2 * l, iters=max(args.iters // 3, 10))
+x = pkg.zerox(A, b)
+timed("minres", pkg.minres_iterable_(x, A, b, reltol=0.0, initially_zero=True, maxiter=10 ** 9), 1, 27, 1)
+x = pkg.zerox(A, b)
+timed("chebyshev", pkg.chebyshev_iterable_(x, A, b, 4.5e-4, 12.0, reltol=0.0, initially_zero=True, maxiter=10 ** 9), 0, 2 + 3 + 3 + 3 + 1, 1)
