@@ -194,6 +194,22 @@ int mik_gmres_iterate(mik_gmres *it, int64_t iteration, double *residual, int *d
 int mik_gmres_state(const mik_gmres *it, double *residual, double *tol, double *beta, int *k,
                     int64_t *mv_products, int *converged);
 
+/* ---- fused sweeps for the other solvers of the package ------------------------------------------- */
+/* Each call is several consecutive reference statements executed as ONE pass over the vectors, with the
+ * same per-element operations in the same order (bit-identical to issuing the L1 calls one by one). */
+/* y .+= alpha .* x (x NULL: no update); then *out = dot(z, y), or norm(y) when z is NULL
+ *   -- src/minres.jl:104+107 and :109+112 */
+int mik_axpy_dot(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, const void *x, void *y, const void *z, void *out);
+/* x .+= alpha .* u; r .-= alpha .* c; *out = norm(r)   -- src/chebyshev.jl:51-54 (same shape as src/cg.jl:58-62) */
+int mik_axpy2_nrm2(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, const void *u, void *x, const void *c, void *r, void *out);
+/* c = Pl \ r (pl_diag NULL = Identity); u .= c when `first`, else u .= c .+ beta .* c   -- src/chebyshev.jl:35-45 */
+int mik_cheb_direction(mik_ctx *ctx, int dtype, int64_t n, const void *r, const void *pl_diag, const void *beta, int first, void *u);
+/* v_next .*= inv_h3; w_next .= v_curr .+ neg_h1 .* w_curr .+ neg_h0 .* w_prev (each term skipped when its vector
+ * is NULL); w_next .*= inv_h2; x .+= rhs0 .* w_next   -- src/minres.jl:113, :136-142 */
+int mik_minres_update(mik_ctx *ctx, int dtype, int64_t n, const void *inv_h3, void *v_next, const void *v_curr, const void *neg_h1,
+                      const void *w_curr, const void *neg_h0, const void *w_prev, const void *inv_h2, void *w_next,
+                      const void *rhs0, void *x);
+
 /* ---- row-partitioned GMRESIterable: one process per GPU ---------------------------------------- */
 /* The same iterable (src/gmres.jl:57-106) over a contiguous row block.  The Arnoldi basis, x, b and
  * the diagonal preconditioners are this rank's n_loc rows; A_loc is the block as an n_loc x n_ext

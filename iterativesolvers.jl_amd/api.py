@@ -222,6 +222,25 @@ def norm(x: HipVector):
     return out[0]
 
 
+def axpy_dot_(alpha, x: Optional[HipVector], y: HipVector, z: Optional[HipVector]):
+    """``y .+= alpha .* x`` (skipped when x is None) and, in the same sweep, ``dot(z, y)`` -- or ``norm(y)`` when z is
+    None (src/minres.jl:104+107, :109+112)."""
+    out = np.zeros(1, y.dtype)
+    _, pa = _scalar(y.dtype, 0 if x is None else alpha)
+    check(lib().mik_axpy_dot(y.ctx.handle, y.code, y.n, pa, _vp(x.ptr if x is not None else None), _vp(y.ptr),
+                             _vp(z.ptr if z is not None else None), out.ctypes.data_as(_vp)), "mik_axpy_dot", y.ctx.handle)
+    return out[0]
+
+
+def axpy2_nrm2_(alpha, u: HipVector, x: HipVector, c: HipVector, r: HipVector):
+    """``x .+= alpha .* u; r .-= alpha .* c; norm(r)`` in one sweep (src/chebyshev.jl:51-54)."""
+    out = np.zeros(1, x.dtype)
+    _, pa = _scalar(x.dtype, alpha)
+    check(lib().mik_axpy2_nrm2(x.ctx.handle, x.code, x.n, pa, _vp(u.ptr), _vp(x.ptr), _vp(c.ptr), _vp(r.ptr), out.ctypes.data_as(_vp)),
+          "mik_axpy2_nrm2", x.ctx.handle)
+    return out[0]
+
+
 class HipMatrix:
     """Device n x cols column-major block (the Krylov basis ``V`` of src/gmres.jl:7,13)."""
 
@@ -960,8 +979,9 @@ class ChebyshevIterable:
     v0.9.4 source as written: ``start = 0`` with the ``iteration == 1`` branch (:26, :37) and
     ``u .= c .+ beta .* c`` (:45)."""
 
-    def __init__(self, x, A, b, lmin, lmax, *, abstol, reltol, maxiter, Pl=None, initially_zero=False):
+    def __init__(self, x, A, b, lmin, lmax, *, abstol, reltol, maxiter, Pl=None, initially_zero=False, fused=True):
         T = x.dtype.type
+        self.fused = bool(fused)          # one sweep per statement group (same bits) instead of one L1 call per statement
         self.Pl = Identity() if Pl is None else Pl
         if not isinstance(self.Pl, (Identity, JacobiPrec)):
             raise MikError(5, "chebyshev_iterable_", "Pl must be Identity() or a diagonal JacobiPrec on the device path")
@@ -996,6 +1016,23 @@ class ChebyshevIterable:
         if self.done(iteration):
             return None
         T = self.x.dtype.type
+        if self.fused:
+            first = iteration == 1                                           # :37
+            if first:
+                self.alpha = T(2) / self.l_avg
+                beta = T(0)
+            else:
+                h = (self.l_diff * self.alpha) / T(2)
+                beta = h * h                                                 # :41
+                self.alpha = T(1) / (self.l_avg - beta)                      # :42
+            _, pb = _scalar(self.x.dtype, beta)
+            d = self.Pl.diagonal.ptr if isinstance(self.Pl, JacobiPrec) else None
+            check(lib().mik_cheb_direction(self.x.ctx.handle, self.x.code, self.x.n, _vp(self.r.ptr), _vp(d), pb, int(first), _vp(self.u.ptr)),
+                  "mik_cheb_direction", self.x.ctx.handle)                   # :35-45
+            mul_(self.c, self.A, self.u)                                     # :48
+            self.mv_products += 1
+            self.resnorm = axpy2_nrm2_(self.alpha, self.u, self.x, self.c, self.r)   # :51-54
+            return self.resnorm, iteration + 1
         self.Pl.ldiv_(self.c, self.r)                                        # :35
         if iteration == 1:                                                   # :37
             self.alpha = T(2) / self.l_avg
@@ -1019,10 +1056,10 @@ class ChebyshevIterable:
             yield resnorm
 
 
-def chebyshev_iterable_(x, A, b, lmin, lmax, *, abstol=0.0, reltol=None, maxiter=None, Pl=None, initially_zero=False):
+def chebyshev_iterable_(x, A, b, lmin, lmax, *, abstol=0.0, reltol=None, maxiter=None, Pl=None, initially_zero=False, fused=True):
     """``chebyshev_iterable!`` -- src/chebyshev.jl:59-91."""
     return ChebyshevIterable(x, A, b, lmin, lmax, abstol=abstol, reltol=_default_reltol(b) if reltol is None else reltol,
-                             maxiter=A.size(2) if maxiter is None else maxiter, Pl=Pl, initially_zero=initially_zero)
+                             maxiter=A.size(2) if maxiter is None else maxiter, Pl=Pl, initially_zero=initially_zero, fused=fused)
 
 
 def _drive(iterable, history, log, verbose, per_iter_mvps=None):
@@ -1060,8 +1097,9 @@ def chebyshev(A, b, lmin, lmax, **kwargs):
 class MINRESIterable:
     """``MINRESIterable`` -- src/minres.jl:6-36, construction per ``minres_iterable!`` (:38-87); real element types."""
 
-    def __init__(self, x, A, b, *, initially_zero=False, skew_hermitian=False, abstol, reltol, maxiter):
+    def __init__(self, x, A, b, *, initially_zero=False, skew_hermitian=False, abstol, reltol, maxiter, fused=True):
         T = x.dtype.type
+        self.fused = bool(fused)          # one sweep per statement group (same bits) instead of one L1 call per statement
         self.A, self.x, self.skew = A, x, bool(skew_hermitian)
         self.v_prev, self.v_curr, self.v_next = x.similar(), x.similar().copyto_(b), x.similar()       # :47-50
         self.w_prev, self.w_curr, self.w_next = x.zero(), x.zero(), x.zero()                            # :51-53
@@ -1094,13 +1132,19 @@ class MINRESIterable:
             return None
         T, H, rhs = self.x.dtype.type, self.H, self.rhs
         mul_(self.v_next, self.A, self.v_curr)                               # :102
-        if iteration > 1:
-            self.v_next.axpy_(-H[1], self.v_prev)                            # :104
-        proj = dot(self.v_curr, self.v_next)                                 # :107
-        H[2] = proj
-        self.v_next.axpy_(-proj, self.v_curr)                                # :109
-        H[3] = norm(self.v_next)                                             # :112
-        self.v_next.scal_(T(1) / H[3])                                       # :113
+        if self.fused:
+            proj = axpy_dot_(-H[1], self.v_prev if iteration > 1 else None, self.v_next, self.v_curr)   # :104, :107
+            H[2] = proj
+            H[3] = axpy_dot_(-proj, self.v_curr, self.v_next, None)          # :109, :112
+        else:
+            if iteration > 1:
+                self.v_next.axpy_(-H[1], self.v_prev)                        # :104
+            proj = dot(self.v_curr, self.v_next)                             # :107
+            H[2] = proj
+            self.v_next.axpy_(-proj, self.v_curr)                            # :109
+            H[3] = norm(self.v_next)                                         # :112
+            self.v_next.scal_(T(1) / H[3])                                   # :113
+        inv_h3 = T(1) / H[3]
         if iteration > 2:                                                    # :116-119
             H[0] = self.s_prev * H[1]
             H[1] = self.c_prev * H[1]
@@ -1111,13 +1155,21 @@ class MINRESIterable:
         c, s, H[2] = givens_algorithm(H[2], H[3], self.x.dtype)              # :129
         rhs[1] = -s * rhs[0]                                                 # :132
         rhs[0] = c * rhs[0]                                                  # :133
-        self.w_next.copyto_(self.v_curr)                                     # :136
-        if iteration > 1:
-            self.w_next.axpy_(-H[1], self.w_curr)                            # :137
-        if iteration > 2:
-            self.w_next.axpy_(-H[0], self.w_prev)                            # :138
-        self.w_next.scal_(T(1) / H[2])                                       # :139
-        self.x.axpy_(rhs[0], self.w_next)                                    # :142
+        if self.fused:                                                       # :113, :136-142 in one sweep
+            dt = self.x.dtype
+            sc = [_scalar(dt, v) for v in (inv_h3, -H[1], -H[0], T(1) / H[2], rhs[0])]
+            check(lib().mik_minres_update(self.x.ctx.handle, self.x.code, self.x.n, sc[0][1], _vp(self.v_next.ptr), _vp(self.v_curr.ptr),
+                                          sc[1][1], _vp(self.w_curr.ptr if iteration > 1 else None),
+                                          sc[2][1], _vp(self.w_prev.ptr if iteration > 2 else None),
+                                          sc[3][1], _vp(self.w_next.ptr), sc[4][1], _vp(self.x.ptr)), "mik_minres_update", self.x.ctx.handle)
+        else:
+            self.w_next.copyto_(self.v_curr)                                 # :136
+            if iteration > 1:
+                self.w_next.axpy_(-H[1], self.w_curr)                        # :137
+            if iteration > 2:
+                self.w_next.axpy_(-H[0], self.w_prev)                        # :138
+            self.w_next.scal_(T(1) / H[2])                                   # :139
+            self.x.axpy_(rhs[0], self.w_next)                                # :142
         self.v_prev, self.v_curr, self.v_next = self.v_curr, self.v_next, self.v_prev       # :145
         self.w_prev, self.w_curr, self.w_next = self.w_curr, self.w_next, self.w_prev       # :146
         self.c_prev, self.s_prev, self.c_curr, self.s_curr = self.c_curr, self.s_curr, c, s  # :147
@@ -1134,10 +1186,11 @@ class MINRESIterable:
             yield resnorm
 
 
-def minres_iterable_(x, A, b, *, initially_zero=False, skew_hermitian=False, abstol=0.0, reltol=None, maxiter=None):
+def minres_iterable_(x, A, b, *, initially_zero=False, skew_hermitian=False, abstol=0.0, reltol=None, maxiter=None, fused=True):
     """``minres_iterable!`` -- src/minres.jl:38-87."""
     return MINRESIterable(x, A, b, initially_zero=initially_zero, skew_hermitian=skew_hermitian, abstol=abstol,
-                          reltol=_default_reltol(b) if reltol is None else reltol, maxiter=A.size(2) if maxiter is None else maxiter)
+                          reltol=_default_reltol(b) if reltol is None else reltol, maxiter=A.size(2) if maxiter is None else maxiter,
+                          fused=fused)
 
 
 def minres_(x, A, b, *, skew_hermitian=False, verbose=False, log=False, abstol=0.0, reltol=None, maxiter=None, initially_zero=False):

@@ -45,7 +45,7 @@ int mik_ensure_partials(mik_ctx *ctx, size_t bytes)
 template <typename T> static int read_scalars(mik_ctx *ctx, const T *dev, int count, T *host_out)
 {
     MIK_HIP(ctx, hipMemcpyAsync(ctx->coef_host, dev, sizeof(T) * count, hipMemcpyDeviceToHost, ctx->stream));
-    MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MIK_HIP(ctx, mik_wait(ctx));
     memcpy(host_out, ctx->coef_host, sizeof(T) * count);
     return MIK_OK;
 }
@@ -88,6 +88,7 @@ extern "C" int mik_ctx_create(int device, mik_ctx **out)
     ctx->stream = ctx->own_stream;
     if ((e = hipMalloc(&ctx->coef, mik_ctx::COEF_BYTES)) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipHostMalloc(&ctx->coef_host, mik_ctx::COEF_BYTES, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+    if ((e = hipEventCreateWithFlags(&ctx->wait_event, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     *out = ctx;
     return MIK_OK;
 }
@@ -100,6 +101,7 @@ extern "C" int mik_ctx_destroy(mik_ctx *ctx)
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->coef) (void)hipFree(ctx->coef);
     if (ctx->coef_host) (void)hipHostFree(ctx->coef_host);
+    if (ctx->wait_event) (void)hipEventDestroy(ctx->wait_event);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MIK_OK;
@@ -116,7 +118,7 @@ extern "C" int mik_ctx_set_stream(mik_ctx *ctx, void *hip_stream)
 extern "C" int mik_ctx_synchronize(mik_ctx *ctx)
 {
     if (!ctx) return MIK_ERR_INVALID;
-    MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MIK_HIP(ctx, mik_wait(ctx));
     return MIK_OK;
 }
 
@@ -621,6 +623,87 @@ extern "C" int mik_scal(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, v
     const bool vec = mik_aligned16(x);
     if (dtype == MIK_F64) { OpScal<double> op{(double *)x, coef_val(*(const double *)alpha)}; return launch_map<double>(ctx, n, op, vec, (double *)nullptr, nullptr); }
     if (dtype == MIK_F32) { OpScal<float> op{(float *)x, coef_val(*(const float *)alpha)}; return launch_map<float>(ctx, n, op, vec, (float *)nullptr, nullptr); }
+    return MIK_ERR_INVALID;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused sweeps of the widened solvers (one pass over HBM instead of the reference's 2-6)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int axpy_dot_impl(mik_ctx *ctx, int64_t n, const void *alpha, const void *x, void *y, const void *z, void *out)
+{
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(mik_nseg<T>(n), 1)));
+    OpAxpyDot<T> op{(const T *)x, (T *)y, (const T *)z, x ? *(const T *)alpha : T(0)};
+    const bool vec = mik_aligned16(y) && (!x || mik_aligned16(x)) && (!z || mik_aligned16(z));
+    MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)ctx->partials, nullptr)));
+    return reduce_to_host<T>(ctx, n, z == nullptr, (T *)out);
+}
+
+extern "C" int mik_axpy_dot(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, const void *x, void *y, const void *z, void *out)
+{
+    if (!ctx || n < 0 || !out || (x && !alpha) || (n && !y)) return MIK_ERR_INVALID;
+    if (dtype == MIK_F64) return axpy_dot_impl<double>(ctx, n, alpha, x, y, z, out);
+    if (dtype == MIK_F32) return axpy_dot_impl<float>(ctx, n, alpha, x, y, z, out);
+    return MIK_ERR_INVALID;
+}
+
+template <typename T>
+static int axpy2_nrm2_impl(mik_ctx *ctx, int64_t n, const void *alpha, const void *u, void *x, const void *c, void *r, void *out)
+{
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(mik_nseg<T>(n), 1)));
+    OpCgUpdate<T> op{(T *)x, (T *)r, (const T *)u, (const T *)c, coef_val(*(const T *)alpha), 0};
+    const bool vec = mik_aligned16(u) && mik_aligned16(x) && mik_aligned16(c) && mik_aligned16(r);
+    MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)ctx->partials, nullptr)));
+    return reduce_to_host<T>(ctx, n, true, (T *)out);
+}
+
+extern "C" int mik_axpy2_nrm2(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, const void *u, void *x, const void *c, void *r,
+                              void *out)
+{
+    if (!ctx || n < 0 || !out || !alpha || (n && (!u || !x || !c || !r))) return MIK_ERR_INVALID;
+    if (dtype == MIK_F64) return axpy2_nrm2_impl<double>(ctx, n, alpha, u, x, c, r, out);
+    if (dtype == MIK_F32) return axpy2_nrm2_impl<float>(ctx, n, alpha, u, x, c, r, out);
+    return MIK_ERR_INVALID;
+}
+
+extern "C" int mik_cheb_direction(mik_ctx *ctx, int dtype, int64_t n, const void *r, const void *pl_diag, const void *beta, int first,
+                                  void *u)
+{
+    if (!ctx || n < 0 || (!first && !beta) || (n && (!r || !u))) return MIK_ERR_INVALID;
+    const bool vec = mik_aligned16(r) && mik_aligned16(u) && (!pl_diag || mik_aligned16(pl_diag));
+    if (dtype == MIK_F64) {
+        OpChebDirection<double> op{(const double *)r, (const double *)pl_diag, (double *)u, first ? 0.0 : *(const double *)beta, first};
+        return launch_map<double>(ctx, n, op, vec, (double *)nullptr, nullptr);
+    }
+    if (dtype == MIK_F32) {
+        OpChebDirection<float> op{(const float *)r, (const float *)pl_diag, (float *)u, first ? 0.0f : *(const float *)beta, first};
+        return launch_map<float>(ctx, n, op, vec, (float *)nullptr, nullptr);
+    }
+    return MIK_ERR_INVALID;
+}
+
+template <typename T>
+static int minres_update_impl(mik_ctx *ctx, int64_t n, const void *inv_h3, void *v_next, const void *v_curr, const void *neg_h1,
+                              const void *w_curr, const void *neg_h0, const void *w_prev, const void *inv_h2, void *w_next,
+                              const void *rhs0, void *x)
+{
+    OpMinresUpdate<T> op{(T *)v_next, (const T *)v_curr, (const T *)w_curr, (const T *)w_prev, (T *)w_next, (T *)x,
+                         *(const T *)inv_h3, w_curr ? *(const T *)neg_h1 : T(0), w_prev ? *(const T *)neg_h0 : T(0), *(const T *)inv_h2,
+                         *(const T *)rhs0};
+    const bool vec = mik_aligned16(v_next) && mik_aligned16(v_curr) && mik_aligned16(w_next) && mik_aligned16(x) &&
+                     (!w_curr || mik_aligned16(w_curr)) && (!w_prev || mik_aligned16(w_prev));
+    return launch_map<T>(ctx, n, op, vec, (T *)nullptr, nullptr);
+}
+
+extern "C" int mik_minres_update(mik_ctx *ctx, int dtype, int64_t n, const void *inv_h3, void *v_next, const void *v_curr,
+                                 const void *neg_h1, const void *w_curr, const void *neg_h0, const void *w_prev, const void *inv_h2,
+                                 void *w_next, const void *rhs0, void *x)
+{
+    if (!ctx || n < 0 || !inv_h3 || !inv_h2 || !rhs0 || (w_curr && !neg_h1) || (w_prev && !neg_h0) ||
+        (n && (!v_next || !v_curr || !w_next || !x)))
+        return MIK_ERR_INVALID;
+    if (dtype == MIK_F64) return minres_update_impl<double>(ctx, n, inv_h3, v_next, v_curr, neg_h1, w_curr, neg_h0, w_prev, inv_h2, w_next, rhs0, x);
+    if (dtype == MIK_F32) return minres_update_impl<float>(ctx, n, inv_h3, v_next, v_curr, neg_h1, w_curr, neg_h0, w_prev, inv_h2, w_next, rhs0, x);
     return MIK_ERR_INVALID;
 }
 

@@ -37,6 +37,7 @@ struct mik_ctx {
     size_t partials_bytes = 0;
     void *coef = nullptr;            // small device array of coefficients / scalar results
     void *coef_host = nullptr;       // pinned host mirror
+    hipEvent_t wait_event = nullptr; // for mik_wait
     static constexpr size_t COEF_BYTES = 4096;
 };
 
@@ -220,5 +221,24 @@ __device__ __forceinline__ int xcd_remap(int b, int nb)
     const int q = nb >> 3, rem = nb & 7;
     return xcd * q + (xcd < rem ? xcd : rem) + idx;
 }
+
+// Wait for everything enqueued on the ctx stream.  hipStreamSynchronize parks the host thread when the queue
+// is not about to drain and takes hundreds of microseconds to come back -- more than the kernels of one solver
+// iteration -- so the per-iteration scalar reads spin on an event instead (tuning[3] = 1: plain synchronize).
+extern int g_mik_tuning[8];
+static inline hipError_t mik_wait(mik_ctx *ctx)
+{
+    if (g_mik_tuning[3] == 1 || !ctx->wait_event) return hipStreamSynchronize(ctx->stream);
+    hipError_t e = hipEventRecord(ctx->wait_event, ctx->stream);
+    if (e != hipSuccess) return e;
+    while ((e = hipEventQuery(ctx->wait_event)) == hipErrorNotReady) __builtin_ia32_pause();
+    return e;
+}
+
+#define MIK_TRY(expr)                 \
+    do {                              \
+        int rc_ = (expr);             \
+        if (rc_ != MIK_OK) return rc_; \
+    } while (0)
 
 #endif  // __HIPCC__

@@ -323,6 +323,98 @@ template <typename T> struct OpCgUpdate {
     }
 };
 
+// y .+= alpha .* x (skipped when x is null); partial sums of z .* y, or of y.^2 when z is null
+//   -- src/minres.jl:104+107 (Lanczos three-term step + projection) and :109+112 (orthogonalise + norm)
+template <typename T> struct OpAxpyDot {
+    static constexpr bool REDUCE = true;
+    const T *x; T *y; const T *z; T alpha;          // z may alias y's storage only as "null = y itself"
+    __device__ __forceinline__ void apply(int64_t i, T &acc) const
+    {
+        T yv = y[i];
+        if (x) { T t = alpha * x[i]; yv = yv + t; y[i] = yv; }
+        T p = (z ? z[i] : yv) * yv; acc = acc + p;
+    }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &acc) const
+    {
+        auto yv = vload<T>(y + i);
+        typename VT<T>::vec zv;
+        if (z) zv = vload(z + i);
+        if (x) {
+            auto xv = vload(x + i);
+#pragma unroll
+            for (int e = 0; e < VT<T>::W; ++e) { T t = alpha * el<T>(xv, e); el<T>(yv, e) = el<T>(yv, e) + t; }
+            vstore(y + i, yv);
+        }
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) { T p = (z ? el<T>(zv, e) : el<T>(yv, e)) * el<T>(yv, e); acc = acc + p; }
+    }
+};
+
+// MINRES tail of one iteration in one sweep                             -- src/minres.jl:113, :136-142
+//   v_next .*= inv_h3;  w_next .= v_curr;  w_next .+= neg_h1 .* w_curr (if w_curr);  w_next .+= neg_h0 .* w_prev
+//   (if w_prev);  w_next .*= inv_h2;  x .+= rhs0 .* w_next
+template <typename T> struct OpMinresUpdate {
+    static constexpr bool REDUCE = false;
+    T *__restrict__ v_next; const T *__restrict__ v_curr; const T *__restrict__ w_curr; const T *__restrict__ w_prev;
+    T *__restrict__ w_next; T *__restrict__ x;
+    T inv_h3, neg_h1, neg_h0, inv_h2, rhs0;
+    __device__ __forceinline__ void apply(int64_t i, T &) const
+    {
+        v_next[i] = v_next[i] * inv_h3;
+        T w = v_curr[i];
+        if (w_curr) { T t = neg_h1 * w_curr[i]; w = w + t; }
+        if (w_prev) { T t = neg_h0 * w_prev[i]; w = w + t; }
+        w = w * inv_h2;
+        w_next[i] = w;
+        T t = rhs0 * w; x[i] = x[i] + t;
+    }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &) const
+    {
+        auto vn = vload<T>(v_next + i); auto w = vload(v_curr + i); auto xv = vload<T>(x + i);
+        typename VT<T>::vec wc, wp;
+        if (w_curr) wc = vload(w_curr + i);
+        if (w_prev) wp = vload(w_prev + i);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) {
+            el<T>(vn, e) = el<T>(vn, e) * inv_h3;
+            T we = el<T>(w, e);
+            if (w_curr) { T t = neg_h1 * el<T>(wc, e); we = we + t; }
+            if (w_prev) { T t = neg_h0 * el<T>(wp, e); we = we + t; }
+            we = we * inv_h2;
+            el<T>(w, e) = we;
+            T t = rhs0 * we; el<T>(xv, e) = el<T>(xv, e) + t;
+        }
+        vstore(v_next + i, vn); vstore(w_next + i, w); vstore(x + i, xv);
+    }
+};
+
+// Chebyshev search direction: c = Pl \ r (Identity or diagonal); u .= c (first) or u .= c .+ beta .* c
+//   -- src/chebyshev.jl:35-45 as written (c itself is overwritten by the SpMV that follows, so it is not stored)
+template <typename T> struct OpChebDirection {
+    static constexpr bool REDUCE = false;
+    const T *__restrict__ r; const T *__restrict__ d; T *__restrict__ u; T beta; int first;
+    __device__ __forceinline__ void apply(int64_t i, T &) const
+    {
+        T c = d ? r[i] / d[i] : r[i];
+        if (!first) { T t = beta * c; c = c + t; }
+        u[i] = c;
+    }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &) const
+    {
+        auto cv = vload(r + i);
+        if (d) {
+            auto dv = vload(d + i);
+#pragma unroll
+            for (int e = 0; e < VT<T>::W; ++e) el<T>(cv, e) = el<T>(cv, e) / el<T>(dv, e);
+        }
+        if (!first) {
+#pragma unroll
+            for (int e = 0; e < VT<T>::W; ++e) { T t = beta * el<T>(cv, e); el<T>(cv, e) = el<T>(cv, e) + t; }
+        }
+        vstore(u + i, cv);
+    }
+};
+
 // PCG preconditioner application: c .= r ./ d; partial sums of c .* r   -- src/cg.jl:79,82
 template <typename T> struct OpJacobiDot {
     static constexpr bool REDUCE = true;

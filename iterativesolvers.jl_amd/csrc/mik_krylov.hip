@@ -15,11 +15,6 @@ template <typename T>
 int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done);
 
 
-#define MIK_TRY(expr)                 \
-    do {                              \
-        int rc_ = (expr);             \
-        if (rc_ != MIK_OK) return rc_; \
-    } while (0)
 
 // =============================================================================================
 // Hessenberg least squares (host) -- src/hessenberg.jl:15-46
@@ -105,7 +100,7 @@ static int gemv_n_dev(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, c
 template <typename T> static int coef_upload(mik_ctx *ctx, int slot, const T *host, int k)
 {
     if ((size_t)(slot + k) * sizeof(T) > mik_ctx::COEF_BYTES) return mik_fail(ctx, MIK_ERR_NOTIMPL, "coefficient block too large (k = %d)", k);
-    MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // staging buffer must be idle
+    MIK_HIP(ctx, mik_wait(ctx));                        // staging buffer must be idle
     memcpy((T *)ctx->coef_host + slot, host, sizeof(T) * k);
     MIK_HIP(ctx, hipMemcpyAsync((T *)ctx->coef + slot, (T *)ctx->coef_host + slot, sizeof(T) * k, hipMemcpyHostToDevice, ctx->stream));
     return MIK_OK;
@@ -114,7 +109,7 @@ template <typename T> static int coef_upload(mik_ctx *ctx, int slot, const T *ho
 template <typename T> static int coef_download(mik_ctx *ctx, int slot, T *host, int k)
 {
     MIK_HIP(ctx, hipMemcpyAsync((T *)ctx->coef_host + slot, (T *)ctx->coef + slot, sizeof(T) * k, hipMemcpyDeviceToHost, ctx->stream));
-    MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MIK_HIP(ctx, mik_wait(ctx));
     memcpy(host, (T *)ctx->coef_host + slot, sizeof(T) * k);
     return MIK_OK;
 }
@@ -1316,7 +1311,7 @@ extern "C" int mik_cgd_wait(mik_cgd *it, double *residual, double *tol, int *don
         const size_t es = mik_dtype_size(bs.dtype);
         std::vector<unsigned char> tmp((size_t)take * es);
         MIK_HIP(ctx, hipMemcpyAsync(tmp.data(), bs.hist, es * (size_t)take, hipMemcpyDeviceToHost, ctx->stream));
-        MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MIK_HIP(ctx, mik_wait(ctx));
         for (int64_t j = 0; j < take; ++j)
             history[j] = bs.dtype == MIK_F64 ? ((const double *)tmp.data())[j] : (double)((const float *)tmp.data())[j];
     }

@@ -3,6 +3,7 @@ PCG with a Jacobi Pl, BiCGStab(2), MINRES, Chebyshev -- next to plain CG.  `gbs`
 own operation sequence (SpMV algorithmic bytes + its vector sweeps, unfused) / time.
     python scripts/solver_bench.py [--grid 256] [--iters 60]"""
 import argparse
+import gc
 import json
 import os
 import sys
@@ -16,6 +17,7 @@ import __graft_entry__ as graft  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--grid", type=int, default=256)
 ap.add_argument("--iters", type=int, default=60)
+ap.add_argument("--only", default="")
 args = ap.parse_args()
 pkg = graft.load_package()
 import torch  # noqa: E402
@@ -30,15 +32,23 @@ vec = 8 * n
 
 
 def timed(name, it, start, words, mv_per_iter, iters=args.iters, warm=5):
+    if args.only and name not in args.only.split(","):
+        return
     i = start
     for _ in range(warm):
         _, i = it.iterate(i)
+    gc.collect()                      # device buffers of the previous solver are freed here, not inside the timed loop
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    per = []
     for _ in range(iters):
+        t1 = time.perf_counter()
         _, i = it.iterate(i)
+        per.append(time.perf_counter() - t1)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
+    if os.environ.get("SOLVER_BENCH_DEBUG"):
+        print(name, "per-iteration us:", " ".join("%.0f" % (p * 1e6) for p in per), file=sys.stderr)
     bytes_ = mv_per_iter * spmv_b + words * vec
     print(json.dumps({"solver": name, "grid": N, "us_per_iter": dt * 1e6, "iters_per_sec": 1 / dt, "spmv_per_iter": mv_per_iter,
                       "vector_words_per_row_unfused": words, "gbs_of_reference_sequence": bytes_ / dt / 1e9}))

@@ -127,3 +127,90 @@ def test_minres_skew_symmetric_device(pkg, orc, ctx):
     xo, ho = orc.minres(A, bk, skew_hermitian=True, maxiter=10 * n, mode="tree", shape=ctx.reduce_shape(np.float64))
     assert ch.isconverged and np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
     assert np.linalg.norm(bk - Ak @ x.to_numpy()) / np.linalg.norm(bk) <= 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fused_sweeps_equal_the_statement_by_statement_path(pkg, orc, ctx, dtype):
+    """mik_axpy_dot / mik_minres_update / mik_cheb_direction / mik_axpy2_nrm2 vs one L1 call per reference statement"""
+    import scipy.sparse as sp
+    A = orc.laplace(9, 3).astype(dtype)
+    b = orc.hashed_rhs(A.n).astype(dtype)
+    dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
+    runs = []
+    for fused in (True, False):
+        x = pkg.HipVector.from_numpy(np.zeros(A.n, dtype))
+        it = pkg.minres_iterable_(x, dA, pkg.HipVector.from_numpy(b), initially_zero=True, maxiter=40, reltol=0.0, fused=fused)
+        runs.append((np.array(list(it)), x.to_numpy()))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and runs[0][0].size == 40
+    As = orc.CSC.from_scipy((A.to_scipy() + 20 * sp.eye(A.n)).tocsc()).astype(dtype)
+    dAs = pkg.HipCSR(As.n, As.n, As.colptr, As.rowval, As.nzval)
+    d = pkg.HipVector.from_numpy((1 + 0.1 * np.arange(A.n) / A.n).astype(dtype))
+    for Pl in (None, pkg.JacobiPrec(d)):
+        runs = []
+        for fused in (True, False):
+            x = pkg.HipVector.from_numpy(np.zeros(A.n, dtype))
+            it = pkg.chebyshev_iterable_(x, dAs, pkg.HipVector.from_numpy(b), 20.0, 32.0, initially_zero=True, maxiter=25, reltol=0.0, Pl=Pl, fused=fused)
+            runs.append((np.array(list(it)), x.to_numpy()))
+        assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and runs[0][0].size == 25
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,shift", [(1, 0), (1000, 0), (5000, 1), (300001, 0)])
+def test_fused_entry_points_against_numpy(pkg, orc, ctx, dtype, n, shift):
+    """element-wise results exact (one rounded op per step, as numpy does); reductions equal the tree oracle;
+    `shift` = 1 offsets every pointer by one element (unaligned scalar path)"""
+    rng = np.random.default_rng(n + shift)
+    W, L = ctx.reduce_shape(dtype)
+    T = np.dtype(dtype).type
+
+    def dev(a):
+        full = pkg.HipVector.from_numpy(np.concatenate([np.zeros(shift, dtype), a]))
+        return full, pkg.HipVector.wrap(full.ptr + shift * np.dtype(dtype).itemsize, a.size, dtype, ctx, owner=full)
+
+    x, y, z = (rng.standard_normal(n).astype(dtype) for _ in range(3))
+    alpha = T(-0.7321)
+    (_, dx), (fy, dy), (_, dz) = dev(x), dev(y), dev(z)
+    got = pkg.axpy_dot_(alpha, dx, dy, dz)
+    y1 = y + alpha * x
+    assert np.array_equal(dy.to_numpy(), y1) and got == orc.dot(z, y1, "tree", W, L)
+    got = pkg.axpy_dot_(alpha, None, dy, dz)                                    # no update, just the projection
+    assert np.array_equal(dy.to_numpy(), y1) and got == orc.dot(z, y1, "tree", W, L)
+    got = pkg.axpy_dot_(alpha, dz, dy, None)                                    # update + norm
+    y2 = y1 + alpha * z
+    assert np.array_equal(dy.to_numpy(), y2) and got == orc.nrm2(y2, "tree", W, L)
+    # x += a u; r -= a c; norm(r)
+    u, xs, c, r = (rng.standard_normal(n).astype(dtype) for _ in range(4))
+    (_, du), (_, dxs), (_, dc), (_, dr) = dev(u), dev(xs), dev(c), dev(r)
+    got = pkg.axpy2_nrm2_(alpha, du, dxs, dc, dr)
+    r1 = r - alpha * c
+    assert np.array_equal(dxs.to_numpy(), xs + alpha * u) and np.array_equal(dr.to_numpy(), r1) and got == orc.nrm2(r1, "tree", W, L)
+    # Chebyshev direction
+    dd = (1 + rng.random(n)).astype(dtype)
+    (_, ddd), (_, dout) = dev(dd), dev(np.zeros(n, dtype))
+    L_ = pkg.lib()
+    import ctypes as C
+    beta = np.array([0.37], dtype)
+    for first in (1, 0):
+        for diag in (None, ddd):
+            assert L_.mik_cheb_direction(ctx.handle, dr.code, n, C.c_void_p(dr.ptr), C.c_void_p(diag.ptr if diag else None),
+                                         beta.ctypes.data_as(C.c_void_p), first, C.c_void_p(dout.ptr)) == 0
+            cc = r1 / dd if diag else r1
+            assert np.array_equal(dout.to_numpy(), cc if first else cc + beta[0] * cc)
+    # MINRES tail
+    vn, vc, wc, wp, xx = (rng.standard_normal(n).astype(dtype) for _ in range(5))
+    sc = np.array([1.37, -0.41, 0.93, 0.77, -1.9], dtype)
+    for use_c, use_p in ((False, False), (True, False), (True, True)):
+        (_, dvn), (_, dvc), (_, dwc), (_, dwp), (_, dwn), (_, dxx) = dev(vn), dev(vc), dev(wc), dev(wp), dev(np.zeros(n, dtype)), dev(xx)
+        p = [sc[i:i + 1].ctypes.data_as(C.c_void_p) for i in range(5)]
+        assert L_.mik_minres_update(ctx.handle, dvn.code, n, p[0], C.c_void_p(dvn.ptr), C.c_void_p(dvc.ptr), p[1],
+                                    C.c_void_p(dwc.ptr if use_c else None), p[2], C.c_void_p(dwp.ptr if use_p else None), p[3],
+                                    C.c_void_p(dwn.ptr), p[4], C.c_void_p(dxx.ptr)) == 0
+        w = vc.copy()
+        if use_c:
+            w = w + sc[1] * wc
+        if use_p:
+            w = w + sc[2] * wp
+        w = w * sc[3]
+        assert np.array_equal(dvn.to_numpy(), vn * sc[0]) and np.array_equal(dwn.to_numpy(), w) and np.array_equal(dxx.to_numpy(), xx + sc[4] * w)
