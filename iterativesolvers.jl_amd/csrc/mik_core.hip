@@ -270,6 +270,21 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
         if (nnz) memcpy(v.data(), val, (size_t)nnz * es);
     }
 
+    // Banded operators (stencils): distance, in 256-row blocks, between a row and its farthest in-block
+    // neighbour row, rounded up to a multiple of 8 -> the "strips" workgroup map of spmv_block_map, which
+    // keeps a row-block, its line neighbours and its plane neighbours in ONE XCD's L2 (x is then fetched from
+    // the fabric about once instead of three times).  Columns >= n_rows are halo entries of a row partition.
+    int strip = 0;
+    {
+        int64_t bw = 0;
+        for (int64_t r = 0; r < n_rows; ++r)
+            for (int k = rowptr[r]; k < rowptr[r + 1]; ++k)
+                if (col[k] < n_rows) bw = std::max<int64_t>(bw, std::llabs((long long)col[k] - (long long)r));
+        const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
+        const int64_t P = ((bw + MIK_BLOCK - 1) / MIK_BLOCK + 7) / 8 * 8;
+        if (P >= 8 && P <= nb / 4) strip = (int)P;
+    }
+
     // Long rows (> MIK_LONG_ROW entries) leave the row-block layout: their entries move behind all
     // short-row entries and a wave-per-row kernel sums them (still serially, in column order).  In the
     // short part a long row becomes an empty row, so the row-block kernel keeps its contiguous ranges.
@@ -324,7 +339,7 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
     A->n_long = (int)long_rows.size();
     A->n_long_big = 0;
     for (int len : long_len) if (len > 256) A->n_long_big++;            // sorted longest first: a prefix of the list
-    A->ctx = ctx; A->dtype = dtype; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz; A->max_row_nnz = max_row;
+    A->ctx = ctx; A->dtype = dtype; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz; A->max_row_nnz = max_row; A->strip = strip;
     const size_t pad = 2 * MIK_SPMV_TILE;   // slack so tile-granular reads never leave the allocation
     auto cleanup = [&]() { mik_csr_destroy(A); };
     hipError_t e;
@@ -466,18 +481,19 @@ int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_
     const int n = (int)A->n_rows;
     if (n == 0) return MIK_OK;
     // development knobs (mik_set_tuning): [0] 1 = temporal (cached) streams, [1] 1 = narrow loads,
-    // [2] block map (0 identity, 1 contiguous range per XCD)
+    // [2] block map (0 = the operator's own choice: strips for banded operators, else identity; < 0 identity;
+    //     1 contiguous range per XCD; P >= 8 strips of P row-blocks)
     const int nb = (int)mik_spmv_nwg(n);
     const bool nt = g_mik_tuning[0] == 0;
     const bool wide = g_mik_tuning[1] == 0;
-    const int map_mode = g_mik_tuning[2];
+    const int map_mode = g_mik_tuning[2] == 0 ? A->strip : std::max(g_mik_tuning[2], 0);
     if (A->packed && g_mik_tuning[6] == 0) {
         // dictionary-coded operator (mik_csr_pack): 2 B per entry instead of 12, same arithmetic
         if (fuse_dot)
-            hipLaunchKernelGGL((k_spmv_packed<T, true>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, A->rowptr, A->codes,
+            hipLaunchKernelGGL((k_spmv_packed<T, true>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, map_mode, A->rowptr, A->codes,
                                (const T *)A->vtab, A->dtab, A->nv, A->nd, x, y, seg_out, done);
         else
-            hipLaunchKernelGGL((k_spmv_packed<T, false>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, A->rowptr, A->codes,
+            hipLaunchKernelGGL((k_spmv_packed<T, false>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, map_mode, A->rowptr, A->codes,
                                (const T *)A->vtab, A->dtab, A->nv, A->nd, x, y, seg_out, done);
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;

@@ -25,7 +25,7 @@ constexpr int MIK_PACK_TILE = 8192;     // codes staged per pass (16 KB of LDS)
 typedef unsigned int mik_u32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T, bool FUSE_DOT>
-__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_packed(int n, int nb, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_packed(int n, int nb, int map_mode, const int *__restrict__ rowptr,
                                                            const unsigned short *__restrict__ codes, const T *__restrict__ vtab_g,
                                                            const int *__restrict__ dtab_g, int nv, int nd, const T *__restrict__ x,
                                                            T *__restrict__ y, T *__restrict__ seg_out, const int *__restrict__ done)
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_packed(int n, int nb, const 
     __shared__ T lds4[4];
 
     const int t = threadIdx.x;
-    const int rb = blockIdx.x;
+    const int rb = spmv_block_map((int)blockIdx.x, nb, map_mode);
     const int r0 = rb * MIK_BLOCK;
     const int r = r0 + t;
     int ks = 0, ke = 0;
