@@ -68,6 +68,20 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_map_pro(int64_t n, int64_t nseg, 
     constexpr int64_t SEG = (int64_t)MIK_BLOCK * W * L;
     __shared__ T lds16[16];
     __shared__ T lds4[4];
+    // One segment per workgroup (n up to ~1M, the launch-bound regime): issue the vector loads BEFORE the
+    // prologue, so their latency overlaps the prologue's load -> wave trees -> LDS chain instead of following it.
+    const bool ahead = nseg <= (int64_t)gridDim.x && (int64_t)blockIdx.x < nseg;
+    typename Op::Regs rg[L];
+    bool full[L];
+    if (ahead) {
+        const int64_t base = (int64_t)blockIdx.x * SEG + (int64_t)W * threadIdx.x;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int64_t i = base + (int64_t)l * MIK_BLOCK * W;
+            full[l] = VEC && i + W <= n;
+            if (full[l]) op.load_vec(i, rg[l]);
+        }
+    }
     T cf = block_level2_256(prev_part, prev_m, lds16);
     if (PRO == 2) {
         const T nrm = mik_sqrt(cf);
@@ -77,6 +91,27 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_map_pro(int64_t n, int64_t nseg, 
         coef_out[0] = cf;
     }
     op.set_coef(cf);
+    if (ahead) {
+        const int64_t s = blockIdx.x;
+        const int64_t base = s * SEG + (int64_t)W * threadIdx.x;
+        T acc = T(0);
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int64_t i = base + (int64_t)l * MIK_BLOCK * W;
+            if (full[l]) {
+                op.compute_vec(i, rg[l], acc);
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; ++e)
+                    if (i + e < n) op.apply(i + e, acc);
+            }
+        }
+        if (Op::REDUCE) {
+            T tot = block_tree_256(acc, lds4);
+            if (threadIdx.x == 0) seg_out[s] = tot;
+        }
+        return;
+    }
     for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
         const int64_t base = s * SEG + (int64_t)W * threadIdx.x;
         T acc = T(0);
@@ -214,6 +249,15 @@ template <typename T> struct OpScal {
     static constexpr bool REDUCE = false;
     T *__restrict__ x; Coef<T> alpha;
     __device__ __forceinline__ void set_coef(T c) { alpha.ptr = nullptr; alpha.val = c; }
+    struct Regs { typename VT<T>::vec xv; };                  // load / compute halves of apply_vec (k_map_pro)
+    __device__ __forceinline__ void load_vec(int64_t i, Regs &r) const { r.xv = vload<T>(x + i); }
+    __device__ __forceinline__ void compute_vec(int64_t i, Regs &r, T &) const
+    {
+        const T a = alpha.get();
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) el<T>(r.xv, e) = el<T>(r.xv, e) * a;
+        vstore(x + i, r.xv);
+    }
     __device__ __forceinline__ void apply(int64_t i, T &) const { x[i] = x[i] * alpha.get(); }
     __device__ __forceinline__ void apply_vec(int64_t i, T &) const
     {
@@ -441,6 +485,24 @@ template <typename T, bool SELF> struct OpMgsPass {
     static constexpr bool REDUCE = true;
     T *__restrict__ w; const T *__restrict__ v; const T *__restrict__ z; Coef<T> h;
     __device__ __forceinline__ void set_coef(T c) { h.ptr = nullptr; h.val = c; }
+    struct Regs { typename VT<T>::vec wv, vv, zv; };          // load / compute halves of apply_vec (k_map_pro)
+    __device__ __forceinline__ void load_vec(int64_t i, Regs &r) const
+    {
+        r.wv = vload<T>(w + i); r.vv = vload(v + i);
+        if (!SELF) r.zv = vload(z + i);
+    }
+    __device__ __forceinline__ void compute_vec(int64_t i, Regs &r, T &acc) const
+    {
+        const T hh = h.get();
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) { T t = hh * el<T>(r.vv, e); el<T>(r.wv, e) = el<T>(r.wv, e) - t; }
+        vstore(w + i, r.wv);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) {
+            T p = (SELF ? el<T>(r.wv, e) : el<T>(r.zv, e)) * el<T>(r.wv, e);
+            acc = acc + p;
+        }
+    }
     __device__ __forceinline__ void apply(int64_t i, T &acc) const
     {
         T t = h.get() * v[i]; T wn = w[i] - t; w[i] = wn;

@@ -7,7 +7,9 @@
 #include <cfloat>
 #include <cstddef>
 #include <cmath>
+#include <map>
 #include <new>
+#include <tuple>
 
 #include "mik_kernels.h"
 
@@ -150,6 +152,7 @@ template <typename T>
 static int multidot(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, const T *w, T *out_dev)
 {
     const int64_t nseg = mik_nseg<T>(n);
+    if (k <= 0) return MIK_OK;
     if (nseg == 0) {   // empty vectors: every dot is +0
         MIK_HIP(ctx, hipMemsetAsync(out_dev, 0, sizeof(T) * k, ctx->stream));
         return MIK_OK;
@@ -164,23 +167,32 @@ static int multidot(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, con
 
 // orthogonalize_and_normalize!(V[:, 1:k], w, h, method) -> nrm   -- src/orthogonalize.jl:13-79
 // Coefficient area layout (elements of T): [0, k) = h, [k] = nrm, [k+1] = 1/nrm, [k+2, 2k+2) = DGKS correction.
-template <typename T>
-static int orthogonalize_impl(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, T *w, T *h_host, T *nrm_host, int method)
+
+// Workspace the chains below need in ctx->partials (allocate BEFORE a graph capture).
+template <typename T> static size_t orthogonalize_workspace(int64_t n, int k)
 {
-    if ((size_t)(2 * k + 4) * sizeof(T) > mik_ctx::COEF_BYTES) return mik_fail(ctx, MIK_ERR_NOTIMPL, "orthogonalize: k = %d too large", k);
     const int64_t nseg = mik_nseg<T>(n);
-    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(nseg, 1) * (size_t)std::max(k, 1)));
+    return sizeof(T) * std::max<size_t>((size_t)std::max<int64_t>(nseg, 1) * (size_t)std::max(k, 1), 2 * 1024);
+}
+
+// Kernels only (no host synchronisation; capturable into a hipGraph): ModifiedGramSchmidt / ClassicalGramSchmidt
+// up to and including w .*= inv(nrm); leaves h in coef[0, k), nrm in coef[k].  For DGKS: the first CGS sweep and
+// the norm (the re-orthogonalisation loop needs the host, see orthogonalize_impl).
+template <typename T>
+static int orthogonalize_enqueue(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, T *w, int method)
+{
+    const int64_t nseg = mik_nseg<T>(n);
     T *hd = (T *)ctx->coef;
     T *part = (T *)ctx->partials;
     const bool vecw = mik_aligned16(w);
     const bool vec = vecw && mik_aligned16(V) && (ldv % VT<T>::W == 0);
+    OpDot<T> dn{w, w};
 
-    if (method == MIK_MGS && nseg <= 1024 && g_mik_tuning[5] == 0) {
+    if (method == MIK_MGS && nseg <= 1024 && g_mik_tuning[5] != 1) {
         // src/orthogonalize.jl:69-76, launch-lean form for n up to ~1M: every pass finalises the
         // previous pass's reduction itself (k_map_pro), so the chain is k + 2 launches instead of
         // 2k + 3.  Segment sums ping-pong between two buffers (a pass reads one while writing the other).
-        MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * 2 * 1024));
-        T *P[2] = {(T *)ctx->partials, (T *)ctx->partials + 1024};
+        T *P[2] = {part, part + 1024};
         const int m = (int)nseg;
         if (k > 0) {
             OpDot<T> d0{V, w};
@@ -192,16 +204,10 @@ static int orthogonalize_impl(mik_ctx *ctx, int64_t n, int k, const T *V, int64_
             OpMgsPass<T, true> last{w, V + (int64_t)(k - 1) * ldv, nullptr, coef_val<T>(T(0))};
             MIK_TRY((launch_map_pro<T, 1>(ctx, n, last, vec, P[k & 1], P[(k - 1) & 1], m, hd + k - 1)));
         } else {
-            OpDot<T> dn{w, w};
             MIK_TRY((launch_map<T>(ctx, n, dn, vecw, P[0], nullptr)));
         }
         OpScal<T> sc{w, coef_val<T>(T(0))};                                // w .*= inv(norm(w))  :75-76
-        MIK_TRY((launch_map_pro<T, 2>(ctx, n, sc, vecw, (T *)nullptr, P[k & 1], m, hd + k)));
-        std::vector<T> out(k + 1);
-        MIK_TRY(coef_download<T>(ctx, 0, out.data(), k + 1));
-        for (int j = 0; j < k; ++j) h_host[j] = out[j];
-        *nrm_host = out[k];
-        return MIK_OK;
+        return launch_map_pro<T, 2>(ctx, n, sc, vecw, (T *)nullptr, P[k & 1], m, hd + k);
     }
     if (method == MIK_MGS) {
         // src/orthogonalize.jl:69-76.  Pass i subtracts h[i] * V[:, i] from w and, in the same sweep,
@@ -218,7 +224,6 @@ static int orthogonalize_impl(mik_ctx *ctx, int64_t n, int k, const T *V, int64_
             OpMgsPass<T, true> last{w, V + (int64_t)(k - 1) * ldv, nullptr, coef_ptr<T>(hd + k - 1)};
             MIK_TRY((launch_map<T>(ctx, n, last, vec, part, nullptr)));
         } else {
-            OpDot<T> dn{w, w};
             MIK_TRY((launch_map<T>(ctx, n, dn, vecw, part, nullptr)));
         }
         MIK_TRY(finalize_nrm_inv<T>(ctx, nseg, hd + k));
@@ -226,38 +231,50 @@ static int orthogonalize_impl(mik_ctx *ctx, int64_t n, int k, const T *V, int64_
         // src/orthogonalize.jl:15-17 / :43-45: h = V' w (batched dot), w -= V h (axpy sweep), norm
         MIK_TRY(multidot<T>(ctx, n, k, V, ldv, w, hd));
         MIK_TRY(gemv_n_dev<T>(ctx, n, k, V, ldv, hd, T(-1), w));
-        OpDot<T> dn{w, w};
         MIK_TRY((launch_map<T>(ctx, n, dn, vecw, part, nullptr)));
         MIK_TRY(finalize_nrm_inv<T>(ctx, nseg, hd + k));
-        if (method == MIK_DGKS) {
-            std::vector<T> hh(k + 2), corr(std::max(k, 1));
-            MIK_TRY(coef_download<T>(ctx, 0, hh.data(), k + 2));
-            T nrm = hh[k];
-            const T eta = T(1) / std::sqrt(T(2));                       // :20
-            auto small_norm = [](const T *v, int len) { T s = T(0); for (int j = 0; j < len; ++j) { T p = v[j] * v[j]; s = s + p; } return (T)std::sqrt(s); };
-            T projection_size = small_norm(hh.data(), k);              // :22
-            while (nrm < eta * projection_size) {                        // :26
-                T *cd = hd + k + 2;
-                MIK_TRY(multidot<T>(ctx, n, k, V, ldv, w, cd));          // :27
-                MIK_TRY(gemv_n_dev<T>(ctx, n, k, V, ldv, cd, T(-1), w)); // :30
-                MIK_TRY((launch_map<T>(ctx, n, dn, vecw, part, nullptr)));
-                MIK_TRY(finalize_nrm_inv<T>(ctx, nseg, hd + k));        // :32
-                MIK_TRY(coef_download<T>(ctx, k + 2, corr.data(), k));
-                T nn[2];
-                MIK_TRY(coef_download<T>(ctx, k, nn, 2));
-                projection_size = small_norm(corr.data(), k);           // :28
-                for (int j = 0; j < k; ++j) hh[j] = hh[j] + corr[j];    // :31
-                nrm = nn[0];
-            }
-            OpScal<T> sc{w, coef_ptr<T>(hd + k + 1)};                   // :36
-            MIK_TRY((launch_map<T>(ctx, n, sc, vecw, (T *)nullptr, nullptr)));
-            for (int j = 0; j < k; ++j) h_host[j] = hh[j];
-            *nrm_host = nrm;
-            return MIK_OK;
-        }
+        if (method == MIK_DGKS) return MIK_OK;                           // normalisation after the host loop
     }
     OpScal<T> sc{w, coef_ptr<T>(hd + k + 1)};                           // w .*= inv(nrm)  :76 / :48
-    MIK_TRY((launch_map<T>(ctx, n, sc, vecw, (T *)nullptr, nullptr)));
+    return launch_map<T>(ctx, n, sc, vecw, (T *)nullptr, nullptr);
+}
+
+template <typename T>
+static int orthogonalize_impl(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, T *w, T *h_host, T *nrm_host, int method)
+{
+    if ((size_t)(2 * k + 4) * sizeof(T) > mik_ctx::COEF_BYTES) return mik_fail(ctx, MIK_ERR_NOTIMPL, "orthogonalize: k = %d too large", k);
+    const int64_t nseg = mik_nseg<T>(n);
+    MIK_TRY(mik_ensure_partials(ctx, orthogonalize_workspace<T>(n, k)));
+    MIK_TRY(orthogonalize_enqueue<T>(ctx, n, k, V, ldv, w, method));
+    T *hd = (T *)ctx->coef;
+    if (method == MIK_DGKS) {                                            // src/orthogonalize.jl:20-36
+        const bool vecw = mik_aligned16(w);
+        OpDot<T> dn{w, w};
+        std::vector<T> hh(k + 2), corr(std::max(k, 1));
+        MIK_TRY(coef_download<T>(ctx, 0, hh.data(), k + 2));
+        T nrm = hh[k];
+        const T eta = T(1) / std::sqrt(T(2));                           // :20
+        auto small_norm = [](const T *v, int len) { T s = T(0); for (int j = 0; j < len; ++j) { T p = v[j] * v[j]; s = s + p; } return (T)std::sqrt(s); };
+        T projection_size = small_norm(hh.data(), k);                  // :22
+        while (nrm < eta * projection_size) {                            // :26
+            T *cd = hd + k + 2;
+            MIK_TRY(multidot<T>(ctx, n, k, V, ldv, w, cd));              // :27
+            MIK_TRY(gemv_n_dev<T>(ctx, n, k, V, ldv, cd, T(-1), w));     // :30
+            MIK_TRY((launch_map<T>(ctx, n, dn, vecw, (T *)ctx->partials, nullptr)));
+            MIK_TRY(finalize_nrm_inv<T>(ctx, nseg, hd + k));            // :32
+            MIK_TRY(coef_download<T>(ctx, k + 2, corr.data(), k));
+            T nn[2];
+            MIK_TRY(coef_download<T>(ctx, k, nn, 2));
+            projection_size = small_norm(corr.data(), k);               // :28
+            for (int j = 0; j < k; ++j) hh[j] = hh[j] + corr[j];        // :31
+            nrm = nn[0];
+        }
+        OpScal<T> sc{w, coef_ptr<T>(hd + k + 1)};                       // :36
+        MIK_TRY((launch_map<T>(ctx, n, sc, vecw, (T *)nullptr, nullptr)));
+        for (int j = 0; j < k; ++j) h_host[j] = hh[j];
+        *nrm_host = nrm;
+        return MIK_OK;
+    }
     std::vector<T> out(k + 1);
     MIK_TRY(coef_download<T>(ctx, 0, out.data(), k + 1));
     for (int j = 0; j < k; ++j) h_host[j] = out[j];
@@ -695,9 +712,14 @@ struct mik_gmres {
     int64_t maxiter = 0, mv_products = 0;
     bool dist = false;        // row-partitioned: SpMV input goes through part.x_ext + halo(), sums through reduce()
     mik_partition part{};
+    // launch-bound sizes: expand! + the Gram-Schmidt chain + the D2H of (h, nrm) of column k as ONE hipGraph
+    std::vector<hipGraphExec_t> graphs;       // index k = 1..restart
+    const void *graph_partials = nullptr;     // ctx->partials the graphs were captured against
+    bool graph_off = false;                   // capture / instantiation failed once: plain stream launches from then on
 };
 
 template <typename T> static int gather_launch(mik_ctx *ctx, int64_t m, const int *idx, const T *x, T *out, const int *done);
+static void gm_drop_graphs(mik_gmres *g);
 
 // mul!(dst, A, src) on this rank's rows; with a partition, src is staged in x_ext and the halo callback
 // fills its ghost tail before the local block is applied.                src/gmres.jl:245,287,293,301
@@ -932,9 +954,82 @@ extern "C" int mik_gmres_destroy(mik_gmres *g)
 {
     if (!g) return MIK_OK;
     if (g->ctx) (void)hipStreamSynchronize(g->ctx->stream);
+    gm_drop_graphs(g);
     if (g->V) (void)hipFree(g->V);
     if (g->Ax) (void)hipFree(g->Ax);
     delete g;
+    return MIK_OK;
+}
+
+// expand!(arnoldi, Pl, Pr, k, Ax): V[:, k+1] = Pl \ (A * (Pr \ V[:, k]))   src/gmres.jl:285-304 (kernels only)
+template <typename T> static int gm_expand(mik_gmres *g, T *vk, T *vk1)
+{
+    mik_ctx *ctx = g->ctx;
+    if (g->pr) {
+        // Pl \ (A * (Pr \ v)) through the work vector Ax                  :297-304
+        OpDivide<T> dr{vk, (const T *)g->pr, vk1};
+        MIK_TRY((launch_map<T>(ctx, g->n, dr, mik_aligned16(vk) && mik_aligned16(vk1) && mik_aligned16(g->pr), (T *)nullptr, nullptr)));
+        MIK_TRY(gm_spmv<T>(g, vk1, (T *)g->Ax));
+        MIK_HIP(ctx, hipMemcpyAsync(vk1, g->Ax, sizeof(T) * (size_t)g->n, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        MIK_TRY(gm_spmv<T>(g, vk, vk1));                                  // V[:, k+1] = A * V[:, k]   :287
+    }
+    if (g->pl) {                                                          // ldiv!(Pl, nextV)  :294 / :303
+        OpDivide<T> dl{vk1, (const T *)g->pl, vk1};
+        MIK_TRY((launch_map<T>(ctx, g->n, dl, mik_aligned16(vk1) && mik_aligned16(g->pl), (T *)nullptr, nullptr)));
+    }
+    return MIK_OK;
+}
+
+static void gm_drop_graphs(mik_gmres *g)
+{
+    for (hipGraphExec_t e : g->graphs)
+        if (e) (void)hipGraphExecDestroy(e);
+    g->graphs.clear();
+}
+
+// Column k of the Arnoldi process as one graph launch (n up to ~1M: the k + 3 small kernels are bound by their
+// launch / dependency latency, not by bandwidth).  Captured once per k and handle; results are those of the same
+// kernels launched one by one.  MEASURED (configs[2], n = 125 k, ROCm 7.2): no gain -- MGS 101 vs 100-112 us per
+// inner iteration, CGS 67 vs 60 us: the dependent-kernel boundary on the GPU (~3.7 us per pass inside a graph,
+// 4.3 us from the stream) is the cost, not host launch overhead, and a graph launch itself costs more than the
+// 6 launches of the CGS chain.  Therefore OFF by default; mik_set_tuning(5, 3) enables it.  *ran = false if the graph path is unavailable (the caller falls back).
+template <typename T> static int gm_step_graph(mik_gmres *g, int k, T *vk, T *vk1, T *h_out, T *nrm_out, bool *ran)
+{
+    *ran = false;
+    mik_ctx *ctx = g->ctx;
+    T *V = (T *)g->V;
+    MIK_TRY(mik_ensure_partials(ctx, orthogonalize_workspace<T>(g->n, g->restart)));
+    if (g->graph_partials != ctx->partials) {        // the reduction workspace moved: captured pointers are stale
+        gm_drop_graphs(g);
+        g->graph_partials = ctx->partials;
+    }
+    if (g->graphs.empty()) g->graphs.assign((size_t)g->restart + 1, nullptr);
+    hipGraphExec_t &exec = g->graphs[(size_t)k];
+    if (!exec) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); g->graph_off = true; return MIK_OK; }
+        int rc = gm_expand<T>(g, vk, vk1);
+        if (!rc) rc = orthogonalize_enqueue<T>(ctx, g->n, k, V, g->ldv, vk1, g->method);
+        hipError_t e = hipSuccess;
+        if (!rc) e = hipMemcpyAsync(ctx->coef_host, ctx->coef, sizeof(T) * (size_t)(k + 1), hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e2 = hipStreamEndCapture(ctx->stream, &graph);
+        if (rc || e != hipSuccess || e2 != hipSuccess || !graph ||
+            hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (graph) (void)hipGraphDestroy(graph);
+            exec = nullptr;
+            g->graph_off = true;
+            return MIK_OK;
+        }
+        (void)hipGraphDestroy(graph);
+    }
+    MIK_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
+    MIK_HIP(ctx, mik_wait(ctx));
+    const T *out = (const T *)ctx->coef_host;
+    for (int j = 0; j < k; ++j) h_out[j] = out[j];
+    *nrm_out = out[k];
+    *ran = true;
     return MIK_OK;
 }
 
@@ -955,26 +1050,17 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
     T *V = (T *)g->V;
     T *vk = V + (int64_t)(k - 1) * g->ldv, *vk1 = V + (int64_t)k * g->ldv;
 
-    // expand!                                                            :64, :285-304
-    if (g->pr) {
-        // Pl \ (A * (Pr \ v)) through the work vector Ax                  :297-304
-        OpDivide<T> dr{vk, (const T *)g->pr, vk1};
-        MIK_TRY((launch_map<T>(ctx, g->n, dr, mik_aligned16(vk) && mik_aligned16(vk1) && mik_aligned16(g->pr), (T *)nullptr, nullptr)));
-        MIK_TRY(gm_spmv<T>(g, vk1, (T *)g->Ax));
-        MIK_HIP(ctx, hipMemcpyAsync(vk1, g->Ax, sizeof(T) * (size_t)g->n, hipMemcpyDeviceToDevice, ctx->stream));
-    } else {
-        MIK_TRY(gm_spmv<T>(g, vk, vk1));                                  // V[:, k+1] = A * V[:, k]   :287
-    }
-    if (g->pl) {                                                          // ldiv!(Pl, nextV)  :294 / :303
-        OpDivide<T> dl{vk1, (const T *)g->pl, vk1};
-        MIK_TRY((launch_map<T>(ctx, g->n, dl, mik_aligned16(vk1) && mik_aligned16(g->pl), (T *)nullptr, nullptr)));
+    // expand! (:64, :285-304), then H[k+1, k] = orthogonalize_and_normalize!(V[:, 1:k], V[:, k+1], H[1:k, k], orth_meth)  :68-73
+    T nrm;
+    bool ran = false;
+    if (g_mik_tuning[5] == 3 && !g->dist && !g->graph_off && g->method != MIK_DGKS && mik_nseg<T>(g->n) <= 1024)
+        MIK_TRY(gm_step_graph<T>(g, k, vk, vk1, &Hat(0, k - 1), &nrm, &ran));
+    if (!ran) {
+        MIK_TRY(gm_expand<T>(g, vk, vk1));
+        if (g->dist) MIK_TRY(orthogonalize_part<T>(g, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));
+        else MIK_TRY(orthogonalize_impl<T>(ctx, g->n, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));
     }
     g->mv_products += 1;                                                  // :65
-
-    // H[k+1, k] = orthogonalize_and_normalize!(V[:, 1:k], V[:, k+1], H[1:k, k], orth_meth)   :68-73
-    T nrm;
-    if (g->dist) MIK_TRY(orthogonalize_part<T>(g, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));
-    else MIK_TRY(orthogonalize_impl<T>(ctx, g->n, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));
     Hat(k, k - 1) = nrm;
 
     // update_residual!                                                   :76, :224-233

@@ -82,3 +82,20 @@ def test_two_contexts_and_handles_are_independent(pkg, orc, ctx):
     _, h = orc.cg(A, b, mode="tree", shape=ctx.cg_shape(np.float64))
     _, h2 = orc.cg(A, 2 * b, mode="tree", shape=ctx.cg_shape(np.float64))
     assert np.array_equal(r1, h["resnorm"]) and np.array_equal(r2, h2["resnorm"])
+
+
+@pytest.mark.parametrize("method", ["mgs", "cgs", "dgks"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_orthogonalize_against_an_empty_basis(pkg, orc, ctx, method, dtype):
+    """k = 0: nothing to project against, w is only normalised (src/orthogonalize.jl with an n x 0 view)"""
+    n = 5000
+    M = {"mgs": pkg.ModifiedGramSchmidt(), "cgs": pkg.ClassicalGramSchmidt(), "dgks": pkg.DGKS()}[method]
+    w0 = np.random.default_rng(5).standard_normal(n).astype(dtype)
+    V = pkg.HipMatrix.from_numpy(np.zeros((n, 1), dtype, order="F"))
+    w = pkg.HipVector.from_numpy(w0)
+    h = np.zeros(1, dtype)
+    nrm = pkg.orthogonalize_and_normalize_(V, 0, w, h, M)
+    W, L = ctx.reduce_shape(dtype)
+    want = orc.nrm2(w0, "tree", W, L)
+    assert nrm == want and np.array_equal(w.to_numpy(), w0 * (dtype(1) / want))
+    assert pkg.gemv_t_(V, 0, w).size == 0
