@@ -440,3 +440,23 @@ def test_full_size_256_properties_and_golden_prefix(pkg, ctx):
     r = pkg.HipVector.from_numpy(b)
     r.sub_(A @ x)
     assert abs(pkg.norm(r) - ch["resnorm"][-1]) <= 1e-10 * ch["resnorm"][-1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("orth", ["mgs", "cgs"])
+def test_gmres_graph_replay_equals_stream_launches(pkg, orc, ctx, orth):
+    """mik_set_tuning(5, 3): every Arnoldi column as one captured hipGraph (off by default) -- same bits"""
+    A, b = orc.advdiff(12, 1000.0)
+    M = {"mgs": pkg.ModifiedGramSchmidt(), "cgs": pkg.ClassicalGramSchmidt()}[orth]
+    x0, ch0 = pkg.gmres(upload(pkg, A), pkg.HipVector.from_numpy(b), restart=10, log=True, orth_meth=M)
+    pkg.lib().mik_set_tuning(5, 3)
+    try:
+        x1, ch1 = pkg.gmres(upload(pkg, A), pkg.HipVector.from_numpy(b), restart=10, log=True, orth_meth=M)
+        d = (np.abs(A.to_scipy().diagonal()) ** 0.5)
+        P = pkg.JacobiPrec(pkg.HipVector.from_numpy(d))
+        x2, ch2 = pkg.gmres(upload(pkg, A), pkg.HipVector.from_numpy(b), restart=10, log=True, orth_meth=M, Pl=P, Pr=P)
+    finally:
+        pkg.lib().mik_set_tuning(5, 0)
+    x3, ch3 = pkg.gmres(upload(pkg, A), pkg.HipVector.from_numpy(b), restart=10, log=True, orth_meth=M, Pl=P, Pr=P)
+    assert np.array_equal(ch0["resnorm"], ch1["resnorm"]) and np.array_equal(x0.to_numpy(), x1.to_numpy()) and ch0.mvps == ch1.mvps
+    assert np.array_equal(ch2["resnorm"], ch3["resnorm"]) and np.array_equal(x2.to_numpy(), x3.to_numpy())
