@@ -7,10 +7,11 @@
 #include "mik_kernels.h"
 #include "mik_spmv.h"
 #include "mik_packed.h"
+#include "mik_sell.h"
 #include <unordered_map>
 
 thread_local std::string g_mik_create_error;
-int g_mik_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+int g_mik_tuning[16] = {0};
 
 int mik_fail(mik_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -139,7 +140,7 @@ extern "C" int mik_spmv_long_row(int *threshold)
 
 extern "C" int mik_set_tuning(int key, int value)
 {
-    if (key < 0 || key >= 8) return MIK_ERR_INVALID;
+    if (key < 0 || key >= 16) return MIK_ERR_INVALID;
     g_mik_tuning[key] = value;
     return MIK_OK;
 }
@@ -372,6 +373,54 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
             return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create: long-row tables: %s", hipGetErrorString(e));
         }
     }
+    // Sliced-ELL form (csrc/mik_sell.h): per 256-row block, entry j of all rows contiguous, padded to the block's
+    // longest row.  Built when no row was split off as long and padding costs < 1/8 extra entries.
+    if (A->n_long == 0 && n_rows > 0 && nnz > 0 && max_row <= 255 && g_mik_tuning[8] == 0) {
+        const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
+        std::vector<int> sptr((size_t)nb + 1, 0);
+        int64_t padded = 0;
+        for (int64_t b = 0; b < nb; ++b) {
+            int w = 0;
+            for (int64_t r = b * MIK_BLOCK; r < std::min<int64_t>((b + 1) * MIK_BLOCK, n_rows); ++r) w = std::max(w, rowptr[r + 1] - rowptr[r]);
+            padded += (int64_t)w * MIK_BLOCK;
+            if (padded >= INT32_MAX) break;
+            sptr[(size_t)b + 1] = (int)padded;
+        }
+        if (padded < INT32_MAX && padded <= nnz + nnz / 8 + 8 * MIK_BLOCK) {
+            std::vector<int> scol;
+            std::vector<unsigned char> sval, slen;
+            try {
+                scol.assign((size_t)padded, 0);
+                sval.assign((size_t)padded * es, 0);
+                slen.assign((size_t)n_rows, 0);
+            } catch (const std::bad_alloc &) {
+                cleanup();
+                return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host staging allocation failed (sliced-ELL form)");
+            }
+            for (int64_t r = 0; r < n_rows; ++r) {
+                const int64_t b = r / MIK_BLOCK, t = r % MIK_BLOCK;
+                const int len = rowptr[r + 1] - rowptr[r];
+                slen[(size_t)r] = (unsigned char)len;
+                for (int j = 0; j < len; ++j) {
+                    const size_t dst = (size_t)sptr[(size_t)b] + (size_t)j * MIK_BLOCK + (size_t)t;
+                    scol[dst] = col[(size_t)rowptr[r] + j];
+                    memcpy(&sval[dst * es], &v[((size_t)rowptr[r] + j) * es], es);
+                }
+            }
+            if ((e = hipMalloc((void **)&A->sell_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
+                (e = hipMalloc((void **)&A->sell_len, (size_t)n_rows)) != hipSuccess ||
+                (e = hipMalloc((void **)&A->sell_col, sizeof(int) * (size_t)padded)) != hipSuccess ||
+                (e = hipMalloc(&A->sell_val, es * (size_t)padded)) != hipSuccess ||
+                (e = hipMemcpy(A->sell_ptr, sptr.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(A->sell_len, slen.data(), (size_t)n_rows, hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(A->sell_col, scol.data(), sizeof(int) * (size_t)padded, hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(A->sell_val, sval.data(), es * (size_t)padded, hipMemcpyHostToDevice)) != hipSuccess) {
+                cleanup();
+                return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: sliced-ELL form: %s", hipGetErrorString(e));
+            }
+            A->sell_entries = padded;
+        }
+    }
     *out = A;
     return MIK_OK;
 }
@@ -385,6 +434,10 @@ extern "C" int mik_csr_destroy(mik_csr *A)
     if (A->val) (void)hipFree(A->val);
     if (A->long_rows) (void)hipFree(A->long_rows);
     if (A->is_long) (void)hipFree(A->is_long);
+    if (A->sell_ptr) (void)hipFree(A->sell_ptr);
+    if (A->sell_len) (void)hipFree(A->sell_len);
+    if (A->sell_col) (void)hipFree(A->sell_col);
+    if (A->sell_val) (void)hipFree(A->sell_val);
     if (A->codes) (void)hipFree(A->codes);
     if (A->vtab) (void)hipFree(A->vtab);
     if (A->dtab) (void)hipFree(A->dtab);
@@ -495,6 +548,17 @@ int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_
         else
             hipLaunchKernelGGL((k_spmv_packed<T, false>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, map_mode, A->rowptr, A->codes,
                                (const T *)A->vtab, A->dtab, A->nv, A->nd, x, y, seg_out, done);
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    }
+    if (A->sell_val && g_mik_tuning[8] == 0) {
+        // sliced-ELL form (mik_sell.h): coalesced streams, per-thread row sums, no LDS
+#define MIK_SELL_GO(FD, NTV)                                                                                                   \
+    hipLaunchKernelGGL((k_spmv_sell<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, map_mode, A->sell_ptr, A->sell_len, \
+                       A->sell_col, (const T *)A->sell_val, x, y, seg_out, done)
+        if (fuse_dot) { if (nt) MIK_SELL_GO(true, true); else MIK_SELL_GO(true, false); }
+        else          { if (nt) MIK_SELL_GO(false, true); else MIK_SELL_GO(false, false); }
+#undef MIK_SELL_GO
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     }

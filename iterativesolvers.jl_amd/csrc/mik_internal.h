@@ -55,6 +55,12 @@ struct mik_csr {
     int n_long_big = 0;              // how many of them exceed 256 entries (one wave each; the rest go 4 per wave)
     int *long_rows = nullptr;        // device: [n_long] row ids, [n_long] start offsets, [n_long] lengths
     unsigned char *is_long = nullptr;   // device: n_rows flags (only when n_long > 0)
+    // sliced-ELL form (csrc/mik_sell.h), built at upload for operators with near-uniform row lengths per block
+    int *sell_ptr = nullptr;         // device, nb + 1: entry offset of every 256-row slice
+    unsigned char *sell_len = nullptr;   // device, n_rows: entries of every row
+    int *sell_col = nullptr;         // device, padded entries, column-major inside a slice
+    void *sell_val = nullptr;
+    int64_t sell_entries = 0;
     // optional dictionary-coded form (mik_csr_pack): one 16-bit code per entry + two <= 256-entry tables
     unsigned short *codes = nullptr; // device, nnz (+ padding)
     void *vtab = nullptr;            // device, 256 values of dtype
@@ -64,7 +70,7 @@ struct mik_csr {
 };
 
 extern thread_local std::string g_mik_create_error;
-extern int g_mik_tuning[8];   // development knobs (mik_set_tuning), see mik_spmv_launch
+extern int g_mik_tuning[16];  // development knobs (mik_set_tuning), see mik_spmv_launch
 
 int mik_fail(mik_ctx *ctx, int code, const char *fmt, ...);
 int mik_ensure_partials(mik_ctx *ctx, size_t bytes);
@@ -226,7 +232,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nb)
 // Wait for everything enqueued on the ctx stream.  hipStreamSynchronize parks the host thread when the queue
 // is not about to drain and takes hundreds of microseconds to come back -- more than the kernels of one solver
 // iteration -- so the per-iteration scalar reads spin on an event instead (tuning[3] = 1: plain synchronize).
-extern int g_mik_tuning[8];
+extern int g_mik_tuning[16];
 static inline hipError_t mik_wait(mik_ctx *ctx)
 {
     if (g_mik_tuning[3] == 1 || !ctx->wait_event) return hipStreamSynchronize(ctx->stream);
