@@ -419,6 +419,49 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
                 return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: sliced-ELL form: %s", hipGetErrorString(e));
             }
             A->sell_entries = padded;
+
+            // 8-bit column codes (k_spmv_sell8): at most 255 distinct (column - row) offsets over the whole operator
+            std::vector<int> tab;
+            std::unordered_map<int, int> code_of;
+            bool ok = g_mik_tuning[10] == 0;
+            for (int64_t r = 0; r < n_rows && ok; ++r)
+                for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
+                    const int d = col[(size_t)k2] - (int)r;
+                    if (code_of.find(d) == code_of.end()) {
+                        if (tab.size() == 255) { ok = false; break; }
+                        code_of.emplace(d, (int)tab.size());
+                        tab.push_back(d);
+                    }
+                }
+            if (ok) {
+                std::vector<int> cptr((size_t)nb + 1, 0);
+                int64_t cbytes = 0;
+                for (int64_t b = 0; b < nb; ++b) {
+                    const int w = (sptr[(size_t)b + 1] - sptr[(size_t)b]) / MIK_BLOCK;
+                    cbytes += (int64_t)((w + 7) / 8 * 8) * MIK_BLOCK;
+                    cptr[(size_t)b + 1] = (int)cbytes;
+                }
+                if (cbytes < INT32_MAX) {
+                    std::vector<unsigned char> codes((size_t)cbytes, 255);
+                    for (int64_t r = 0; r < n_rows; ++r) {
+                        const int64_t b = r / MIK_BLOCK, t = r % MIK_BLOCK;
+                        const int w8 = (cptr[(size_t)b + 1] - cptr[(size_t)b]) / MIK_BLOCK;
+                        unsigned char *dst = &codes[(size_t)cptr[(size_t)b] + (size_t)t * w8];
+                        for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) dst[k2 - rowptr[r]] = (unsigned char)code_of[col[(size_t)k2] - (int)r];
+                    }
+                    tab.resize(256, 0);
+                    if ((e = hipMalloc((void **)&A->sell8_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
+                        (e = hipMalloc((void **)&A->sell8_codes, (size_t)cbytes + 8)) != hipSuccess ||
+                        (e = hipMalloc((void **)&A->sell8_tab, sizeof(int) * 256)) != hipSuccess ||
+                        (e = hipMemcpy(A->sell8_ptr, cptr.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice)) != hipSuccess ||
+                        (e = hipMemcpy(A->sell8_codes, codes.data(), (size_t)cbytes, hipMemcpyHostToDevice)) != hipSuccess ||
+                        (e = hipMemcpy(A->sell8_tab, tab.data(), sizeof(int) * 256, hipMemcpyHostToDevice)) != hipSuccess) {
+                        cleanup();
+                        return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: column codes: %s", hipGetErrorString(e));
+                    }
+                    A->sell8_nd = (int)code_of.size();
+                }
+            }
         }
     }
     *out = A;
@@ -434,6 +477,9 @@ extern "C" int mik_csr_destroy(mik_csr *A)
     if (A->val) (void)hipFree(A->val);
     if (A->long_rows) (void)hipFree(A->long_rows);
     if (A->is_long) (void)hipFree(A->is_long);
+    if (A->sell8_ptr) (void)hipFree(A->sell8_ptr);
+    if (A->sell8_codes) (void)hipFree(A->sell8_codes);
+    if (A->sell8_tab) (void)hipFree(A->sell8_tab);
     if (A->sell_ptr) (void)hipFree(A->sell_ptr);
     if (A->sell_len) (void)hipFree(A->sell_len);
     if (A->sell_col) (void)hipFree(A->sell_col);
@@ -551,13 +597,33 @@ int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     }
+    if (A->sell8_codes && g_mik_tuning[8] == 0 && g_mik_tuning[10] == 0) {
+        // sliced-ELL values + 8-bit column codes (mik_sell.h)
+#define MIK_SELL8_GO(FD, NTV)                                                                                                 \
+    hipLaunchKernelGGL((k_spmv_sell8<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, map_mode, A->sell_ptr, A->sell8_ptr, \
+                       A->sell8_codes, A->sell8_tab, A->sell8_nd, (const T *)A->sell_val, x, y, seg_out, done)
+        if (fuse_dot) { if (nt) MIK_SELL8_GO(true, true); else MIK_SELL8_GO(true, false); }
+        else          { if (nt) MIK_SELL8_GO(false, true); else MIK_SELL8_GO(false, false); }
+#undef MIK_SELL8_GO
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    }
     if (A->sell_val && g_mik_tuning[8] == 0) {
         // sliced-ELL form (mik_sell.h): coalesced streams, per-thread row sums, no LDS
 #define MIK_SELL_GO(FD, NTV)                                                                                                   \
     hipLaunchKernelGGL((k_spmv_sell<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, map_mode, A->sell_ptr, A->sell_len, \
                        A->sell_col, (const T *)A->sell_val, x, y, seg_out, done)
-        if (fuse_dot) { if (nt) MIK_SELL_GO(true, true); else MIK_SELL_GO(true, false); }
-        else          { if (nt) MIK_SELL_GO(false, true); else MIK_SELL_GO(false, false); }
+#define MIK_SELL2_GO(FD, NTV)                                                                                                  \
+    hipLaunchKernelGGL((k_spmv_sell2<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK / 2), 0, ctx->stream, n, nb, map_mode, A->sell_ptr,  \
+                       A->sell_len, A->sell_col, (const T *)A->sell_val, x, y, seg_out, done, (int)(((uintptr_t)y % (2 * sizeof(T))) == 0))
+        if (g_mik_tuning[9] == 1) {       // two rows per thread (wide loads)
+            if (fuse_dot) { if (nt) MIK_SELL2_GO(true, true); else MIK_SELL2_GO(true, false); }
+            else          { if (nt) MIK_SELL2_GO(false, true); else MIK_SELL2_GO(false, false); }
+        } else {
+            if (fuse_dot) { if (nt) MIK_SELL_GO(true, true); else MIK_SELL_GO(true, false); }
+            else          { if (nt) MIK_SELL_GO(false, true); else MIK_SELL_GO(false, false); }
+        }
+#undef MIK_SELL2_GO
 #undef MIK_SELL_GO
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;

@@ -61,6 +61,11 @@ struct mik_csr {
     int *sell_col = nullptr;         // device, padded entries, column-major inside a slice
     void *sell_val = nullptr;
     int64_t sell_entries = 0;
+    // 8-bit column codes for the sliced-ELL form (<= 255 distinct column - row offsets)
+    int *sell8_ptr = nullptr;        // device, nb + 1: byte offset of every slice's codes
+    unsigned char *sell8_codes = nullptr;
+    int *sell8_tab = nullptr;        // device, 256 offsets
+    int sell8_nd = 0;
     // optional dictionary-coded form (mik_csr_pack): one 16-bit code per entry + two <= 256-entry tables
     unsigned short *codes = nullptr; // device, nnz (+ padding)
     void *vtab = nullptr;            // device, 256 values of dtype
