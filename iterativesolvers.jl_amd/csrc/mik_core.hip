@@ -419,6 +419,7 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
                 return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: sliced-ELL form: %s", hipGetErrorString(e));
             }
             A->sell_entries = padded;
+            for (int64_t b = 0; b < nb; ++b) A->sell_maxw = std::max(A->sell_maxw, (sptr[(size_t)b + 1] - sptr[(size_t)b]) / MIK_BLOCK);
 
             // 8-bit column codes (k_spmv_sell8): at most 255 distinct (column - row) offsets over the whole operator
             std::vector<int> tab;
@@ -613,17 +614,8 @@ int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_
 #define MIK_SELL_GO(FD, NTV)                                                                                                   \
     hipLaunchKernelGGL((k_spmv_sell<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, map_mode, A->sell_ptr, A->sell_len, \
                        A->sell_col, (const T *)A->sell_val, x, y, seg_out, done)
-#define MIK_SELL2_GO(FD, NTV)                                                                                                  \
-    hipLaunchKernelGGL((k_spmv_sell2<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK / 2), 0, ctx->stream, n, nb, map_mode, A->sell_ptr,  \
-                       A->sell_len, A->sell_col, (const T *)A->sell_val, x, y, seg_out, done, (int)(((uintptr_t)y % (2 * sizeof(T))) == 0))
-        if (g_mik_tuning[9] == 1) {       // two rows per thread (wide loads)
-            if (fuse_dot) { if (nt) MIK_SELL2_GO(true, true); else MIK_SELL2_GO(true, false); }
-            else          { if (nt) MIK_SELL2_GO(false, true); else MIK_SELL2_GO(false, false); }
-        } else {
-            if (fuse_dot) { if (nt) MIK_SELL_GO(true, true); else MIK_SELL_GO(true, false); }
-            else          { if (nt) MIK_SELL_GO(false, true); else MIK_SELL_GO(false, false); }
-        }
-#undef MIK_SELL2_GO
+        if (fuse_dot) { if (nt) MIK_SELL_GO(true, true); else MIK_SELL_GO(true, false); }
+        else          { if (nt) MIK_SELL_GO(false, true); else MIK_SELL_GO(false, false); }
 #undef MIK_SELL_GO
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;

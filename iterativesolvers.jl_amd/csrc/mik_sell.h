@@ -10,6 +10,11 @@
 // barrier.  Slices are padded to the block's longest row (padding entries are never added: j < len[row]); the
 // layout is only built when padding stays below ~12 % and no row was split off as "long" (mik_csr_create).
 //
+// Measured and dropped (256^3 fp64, same results): two rows per thread with 16-byte value loads (284.7 vs 284.6 us:
+// the kernel is not instruction-bound), and workgroups that walk G = 2 / 4 / 8 slices with the next slice's codes
+// prefetched (251 / 262 / 265 vs 248 us: as for the CSR kernel, many short workgroups at full occupancy beat
+// fewer software-pipelined ones).
+//
 // Bytes per launch vs CSR: no row pointer (4 B/row) but one length byte per row and the padding
 // (256^3 Laplacian: +0.6 % entries) -- ~1.70 GB instead of 1.74 GB.
 #ifndef MIK_SELL_H
@@ -63,78 +68,6 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sell(int n, int nb, int map_
         if (r < n) p = x[r] * acc;
         T tot = block_tree_256(p, lds4);
         if (t == 0) seg_out[rb] = tot;
-    }
-}
-
-// Two rows per thread (128-thread workgroups): rows 2t and 2t+1 of the slice sit next to each other in every
-// column-major line, so val / col stream as 16-byte / 8-byte loads -- half the vector-memory instructions.
-// The fused dot keeps the (1, 1) shape of one value per ROW: a 64-row "virtual wave" is 32 lanes x 2 rows, the
-// shuffle-down tree over rows (offsets 32..2) becomes offsets 16..1 over lanes on both values, the last step
-// (row i += row i+1) adds the thread's own pair; then the 4 virtual-wave sums left to right, as block_tree_256.
-template <typename T, bool FUSE_DOT, bool NT>
-__global__ __launch_bounds__(MIK_BLOCK / 2) void k_spmv_sell2(int n, int nb, int map_mode, const int *__restrict__ blkptr,
-                                                              const unsigned char *__restrict__ rlen, const int *__restrict__ col,
-                                                              const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y,
-                                                              T *__restrict__ seg_out, const int *__restrict__ done, int yvec)
-{
-    if (done && *done) return;
-    constexpr int U = MIK_SELL_U;
-    typedef T TV2 __attribute__((ext_vector_type(2)));
-    typedef int IV2 __attribute__((ext_vector_type(2)));
-    __shared__ T lds4[4];
-    const int t = threadIdx.x;
-    const int rb = spmv_block_map((int)blockIdx.x, nb, map_mode);
-    const int r0 = rb * MIK_BLOCK + 2 * t;
-    const int base = blkptr[rb];
-    const int width = (blkptr[rb + 1] - base) / MIK_BLOCK;
-    const int len0 = r0 < n ? (int)rlen[r0] : 0;
-    const int len1 = r0 + 1 < n ? (int)rlen[r0 + 1] : 0;
-    const T *__restrict__ vp = val + base + 2 * t;
-    const int *__restrict__ cp = col + base + 2 * t;
-
-    T acc0 = T(0), acc1 = T(0);
-    for (int j0 = 0; j0 < width; j0 += U) {
-        TV2 v[U];
-        IV2 c[U];
-#pragma unroll
-        for (int q = 0; q < U; ++q) {
-            const int jj = min(j0 + q, width - 1);
-            v[q] = ld_stream<NT>(reinterpret_cast<const TV2 *>(vp + (size_t)jj * MIK_BLOCK));
-            c[q] = ld_stream<NT>(reinterpret_cast<const IV2 *>(cp + (size_t)jj * MIK_BLOCK));
-        }
-        T xa[U], xb[U];
-#pragma unroll
-        for (int q = 0; q < U; ++q) { xa[q] = x[c[q][0]]; xb[q] = x[c[q][1]]; }
-#pragma unroll
-        for (int q = 0; q < U; ++q) {
-            if (j0 + q < len0) { T p = v[q][0] * xa[q]; acc0 = acc0 + p; }
-            if (j0 + q < len1) { T p = v[q][1] * xb[q]; acc1 = acc1 + p; }
-        }
-    }
-    if (r0 + 1 < n && yvec) {
-        TV2 o; o[0] = acc0; o[1] = acc1;
-        st_stream<NT>(reinterpret_cast<TV2 *>(y + r0), o);
-    } else {
-        if (r0 < n) st_stream<NT>(y + r0, acc0);
-        if (r0 + 1 < n) st_stream<NT>(y + r0 + 1, acc1);
-    }
-    if (FUSE_DOT) {
-        T p0 = T(0), p1 = T(0);
-        if (r0 < n) p0 = x[r0] * acc0;
-        if (r0 + 1 < n) p1 = x[r0 + 1] * acc1;
-#pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) {
-            p0 = p0 + __shfl_down(p0, off, 32);
-            p1 = p1 + __shfl_down(p1, off, 32);
-        }
-        const T ws = p0 + p1;                      // valid in lane 0 of every 32-lane group = one 64-row virtual wave
-        if ((t & 31) == 0) lds4[t >> 5] = ws;
-        __syncthreads();
-        if (t == 0) {
-            T tot = lds4[0];
-            tot = tot + lds4[1]; tot = tot + lds4[2]; tot = tot + lds4[3];
-            seg_out[rb] = tot;
-        }
     }
 }
 
