@@ -142,6 +142,40 @@ def main():
     torch.cuda.synchronize()
     dt_batched = time.perf_counter() - t1
 
+    layout = A.layout()
+    stored_bytes = A.spmv_stored_bytes()
+
+    # the same operator forced into the plain CSR row-block layout (12 B per entry + row pointers, LDS-staged
+    # products): what the default layout is measured against, and what irregular matrices run on
+    csr_ref = None
+    if layout != "csr-rowblock":
+        L = pkg.lib()
+        L.mik_set_tuning(8, 1)
+        try:
+            n2, colptr, rowval, nzval = pkg.fixtures.laplace_matrix(N, 3)
+            A_csr = pkg.HipCSR(n2, n2, colptr, rowval, nzval, index_base=1)
+            del colptr, rowval, nzval
+            A_csr.time_spmv(u, scratch, reps=3, fused_dot=True)
+            c_b2b = A_csr.time_spmv(u, scratch, reps=20, fused_dot=True)
+            it3 = pkg.cg_iterator_(pkg.zerox(A_csr, b), A_csr, b, reltol=reltol, initially_zero=True, maxiter=10 ** 9)
+            i3 = 0
+            for _ in range(Wm):
+                it3.iterate(i3)
+                i3 += 1
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(K):
+                assert it3.iterate(i3) is not None
+                i3 += 1
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t3
+            csr_ref = {"layout": A_csr.layout(), "iters_per_sec": K / dt3, "ms_per_step": dt3 / K * 1e3, "spmv_back_to_back_ms": c_b2b,
+                       "spmv_back_to_back_gbs": alg_bytes / (c_b2b * 1e-3) / 1e9,
+                       "residual_after_same_steps_equals_default_layout": bool(it3.residual == residual)}
+            del it3, A_csr
+        finally:
+            L.mik_set_tuning(8, 0)
+
     # opt-in dictionary-coded operator (mik_csr_pack: 2 B instead of 12 B per entry, bit-identical results):
     # reported separately -- the headline `value` and `roofline` above are the plain CSR path
     packed = None
@@ -176,13 +210,21 @@ def main():
                                f"(BASELINE.json configs[1])", "n": n, "nnz": nnz,
                    "reltol": "sqrt(eps)" if reltol is None else reltol, "host_sync_per_step": 1,
                    "final_residual": residual},
-        "roofline": {"bound": "hbm", "kernel": "k_spmv_rowblock<double, fused dot>", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
+        "roofline": {"bound": "hbm", "kernel": {"csr-rowblock": "k_spmv_rowblock", "sliced-ell": "k_spmv_sell",
+                                                 "sliced-ell+8-bit-column-codes": "k_spmv_sell8"}.get(layout, layout) + "<double, fused dot>",
+                     "operator_layout": layout, "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic({"csr-rowblock": "k_spmv_rowblock", "sliced-ell": "k_spmv_sell",
+                                             "sliced-ell+8-bit-column-codes": "k_spmv_sell8"}.get(layout, "k_spmv_rowblock")),
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms, "launches_timed": spmv_launches,
-                     "back_to_back_ms": b2b_ms, "frac_of_copy_ceiling_6290": achieved / 6290.0},
+                     "back_to_back_ms": b2b_ms, "frac_of_copy_ceiling_6290": achieved / 6290.0,
+                     "stored_bytes_per_launch": stored_bytes, "physical_gbs": stored_bytes / (spmv_ms * 1e-3) / 1e9,
+                     "note": "achieved = CSR algorithmic bytes (SURVEY.md 8d) / in-loop launch time; physical_gbs = bytes the "
+                             "active device layout actually streams / the same time"},
         "cg_iteration_algorithmic_bytes": alg_bytes + 9 * n * 8,
         "cg_iteration_gbs": (alg_bytes + 9 * n * 8) / (dt / K) / 1e9,
         "batched_50_steps_per_sync_iters_per_sec": K / dt_batched,
+        "csr_rowblock_layout": csr_ref,
         "packed_operator": packed,
     }
     if not args.no_cpu_baseline:

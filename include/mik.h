@@ -115,6 +115,14 @@ int mik_csr_destroy(mik_csr *A);
  * mik_spmv / iterable calls then read 2 B instead of 12 B per entry and return bit-identical
  * results.  MIK_ERR_NOTIMPL (operator unchanged) when the matrix does not qualify. */
 int mik_csr_pack(mik_csr *A);
+/* Device layout mik_spmv uses for this operator (chosen at upload from the sparsity pattern; results are
+ * bit-identical across layouts): 0 = CSR row-blocks (LDS-staged products; any matrix), 1 = sliced-ELL (256-row
+ * slices stored column-major; near-uniform row lengths per slice), 2 = sliced-ELL values + 8-bit codes for the
+ * (column - row) offsets (banded / stencil operators with <= 255 distinct offsets), 3 = dictionary-coded
+ * (after mik_csr_pack). */
+int mik_csr_layout(const mik_csr *A, int *layout);
+/* Bytes of operator data (values, indices / codes, pointers) one mik_spmv launch streams in that layout. */
+int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes);
 /* size(A, d), nnz, eltype(A) */
 int mik_csr_info(const mik_csr *A, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, int *dtype);
 

@@ -314,6 +314,21 @@ class HipCSR:
         y = HipVector(self.n_rows, self.dtype, self.ctx)
         return mul_(y, self, x)
 
+    LAYOUTS = ("csr-rowblock", "sliced-ell", "sliced-ell+8-bit-column-codes", "dictionary-coded")
+
+    def layout(self) -> str:
+        """Device layout ``mul_`` uses for this operator (``mik_csr_layout``); results do not depend on it."""
+        out = C.c_int()
+        check(lib().mik_csr_layout(self.handle, C.byref(out)), "mik_csr_layout", self.ctx.handle)
+        return self.LAYOUTS[out.value]
+
+    def spmv_stored_bytes(self) -> int:
+        """Bytes one ``mul_`` launch actually streams in the active layout: operator data + x once + y once."""
+        out = C.c_int64()
+        check(lib().mik_csr_stored_bytes(self.handle, C.byref(out)), "mik_csr_stored_bytes", self.ctx.handle)
+        s = np.dtype(self.dtype).itemsize
+        return int(out.value) + (self.n_cols + self.n_rows) * s
+
     def spmv_algorithmic_bytes(self) -> int:
         """nnz*(s+4) + (n+1)*4 + 2*n*s."""
         s = self.dtype.itemsize

@@ -461,6 +461,7 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
                         return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: column codes: %s", hipGetErrorString(e));
                     }
                     A->sell8_nd = (int)code_of.size();
+                    A->sell8_bytes = cbytes;
                 }
             }
         }
@@ -560,6 +561,32 @@ extern "C" int mik_csr_pack(mik_csr *A)
     if (A->packed) return MIK_OK;
     if (A->n_long) return mik_fail(A->ctx, MIK_ERR_NOTIMPL, "mik_csr_pack: matrix has long rows");
     return A->dtype == MIK_F64 ? csr_pack_impl<double>(A) : csr_pack_impl<float>(A);
+}
+
+extern "C" int mik_csr_layout(const mik_csr *A, int *layout)
+{
+    if (!A || !layout) return MIK_ERR_INVALID;
+    if (A->packed && g_mik_tuning[6] == 0) *layout = 3;
+    else if (A->sell8_codes && g_mik_tuning[8] == 0 && g_mik_tuning[10] == 0) *layout = 2;
+    else if (A->sell_val && g_mik_tuning[8] == 0) *layout = 1;
+    else *layout = 0;
+    return MIK_OK;
+}
+
+extern "C" int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes)
+{
+    if (!A || !bytes) return MIK_ERR_INVALID;
+    int layout = 0;
+    (void)mik_csr_layout(A, &layout);
+    const int64_t es = (int64_t)mik_dtype_size(A->dtype);
+    const int64_t nb = (A->n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
+    switch (layout) {
+    case 3: *bytes = A->nnz * 2 + (A->n_rows + 1) * 4 + 256 * (es + 4); break;
+    case 2: *bytes = A->sell_entries * es + A->sell8_bytes + (nb + 1) * 8 + 256 * 4; break;
+    case 1: *bytes = A->sell_entries * (es + 4) + A->n_rows + (nb + 1) * 4; break;
+    default: *bytes = A->nnz * (es + 4) + (A->n_rows + 1) * 4 + (A->n_long ? A->n_rows + 12LL * A->n_long : 0); break;
+    }
+    return MIK_OK;
 }
 
 extern "C" int mik_csr_info(const mik_csr *A, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, int *dtype)

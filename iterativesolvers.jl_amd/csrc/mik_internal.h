@@ -66,6 +66,7 @@ struct mik_csr {
     unsigned char *sell8_codes = nullptr;
     int *sell8_tab = nullptr;        // device, 256 offsets
     int sell8_nd = 0;
+    int64_t sell8_bytes = 0;
     int sell_maxw = 0;               // widest slice
     // optional dictionary-coded form (mik_csr_pack): one 16-bit code per entry + two <= 256-entry tables
     unsigned short *codes = nullptr; // device, nnz (+ padding)

@@ -716,7 +716,7 @@ def bench_main(args):
                        "nnz_per_gpu": nnz_loc, "halo_doubles_per_neighbour": N * N, "host_sync_every_steps": batch,
                        "collectives_per_step": "1 halo exchange (P2P) + 2 all-gathers of 1 double per rank",
                        "final_residual": it.residual},
-            "roofline": {"bound": "hbm", "kernel": "k_spmv_rowblock<double, fused dot> (rank 0, back-to-back)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": f"SpMV, operator layout {eng.A.layout()}, fused dot (rank 0, back-to-back)", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms},
             "aggregate_row_updates_per_sec": K / dt * n,

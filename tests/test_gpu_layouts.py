@@ -1,0 +1,102 @@
+"""The operator's device layouts (mik_csr_layout): CSR row-blocks, sliced-ELL, sliced-ELL + 8-bit column codes.
+The layout is picked at upload from the sparsity pattern; mul! and every solver must return the same bits in all."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+FORMS = {"csr-rowblock": {8: 1}, "sliced-ell": {10: 1}, "sliced-ell+8-bit-column-codes": {}}
+
+
+def with_knobs(pkg, knobs, fn):
+    L = pkg.lib()
+    for k, v in knobs.items():
+        L.mik_set_tuning(k, v)
+    try:
+        return fn()
+    finally:
+        for k in knobs:
+            L.mik_set_tuning(k, 0)
+
+
+def upload(pkg, A):
+    return pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval, index_base=A.index_base)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("case", ["laplace3d", "laplace2d", "advdiff", "banded_wide"])
+def test_spmv_and_cg_identical_in_every_layout(pkg, orc, ctx, case, dtype):
+    if case == "laplace3d":
+        A = orc.laplace(11, 3)
+    elif case == "laplace2d":
+        A = orc.laplace(37, 2)
+    elif case == "advdiff":
+        A = orc.advdiff(9, 300.0)[0]
+    else:   # 19 diagonals, SPD: slices wider than one 8-entry pass
+        n = 3000
+        offs = [0] + [o for d in (1, 2, 3, 7, 50, 51, 200, 333, 900) for o in (d, -d)]
+        S = sp.diags([np.full(n - abs(o), 40.0 if o == 0 else -1.0 / (1 + abs(o) % 5)) for o in offs], offs, format="csc")
+        A = orc.CSC.from_scipy(S)
+    A = A.astype(dtype)
+    x = np.random.default_rng(1).standard_normal(A.n).astype(dtype)
+    want = orc.spmv(A, x)
+    b = orc.hashed_rhs(A.n).astype(dtype)
+    hist = {}
+    for form, knobs in FORMS.items():
+        def run():
+            dA = upload(pkg, A)
+            assert dA.layout() == form
+            y = pkg.mul_(pkg.HipVector(A.n, dtype), dA, pkg.HipVector.from_numpy(x)).to_numpy()
+            xs, ch = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True, maxiter=60) if case != "advdiff" else pkg.gmres(
+                dA, pkg.HipVector.from_numpy(b), log=True, maxiter=40, restart=8)
+            return y, ch["resnorm"], xs.to_numpy()
+        y, res, xs = with_knobs(pkg, knobs, run)
+        assert np.array_equal(y, want), form
+        hist[form] = (res, xs)
+    ref = hist["csr-rowblock"]
+    for form, (res, xs) in hist.items():
+        assert np.array_equal(res, ref[0]) and np.array_equal(xs, ref[1]), form
+
+
+def test_layout_choice_follows_the_pattern(pkg, orc, ctx):
+    # irregular row lengths (padding > 1/8): stays CSR;  > 255 distinct offsets: sliced-ELL without codes
+    n, rowptr, colidx, val = pkg.fixtures.irregular_matrix(20000, np.float32, long_rows=False)
+    assert pkg.HipCSR(n, n, rowptr, colidx, val, index_base=0, is_csc=False).layout() == "csr-rowblock"
+    rng = np.random.default_rng(0)
+    n = 4096
+    cols = (np.arange(n)[:, None] + rng.integers(-1500, 1500, size=(n, 6))) % n     # 6 entries per row, ~3000 distinct offsets
+    S = sp.csr_matrix((rng.standard_normal(6 * n), cols.ravel(), np.arange(0, 6 * n + 1, 6)), shape=(n, n))
+    S.sum_duplicates()
+    A = orc.CSC.from_scipy(S.tocsc())
+    dA = upload(pkg, A)
+    assert dA.layout() == "sliced-ell"
+    x = rng.standard_normal(n)
+    assert np.array_equal(pkg.mul_(pkg.HipVector(n), dA, pkg.HipVector.from_numpy(x)).to_numpy(), orc.spmv(A, x))
+    # empty rows, a slice of empty rows, an empty last slice
+    D = sp.lil_matrix((1000, 1000))
+    D[5, 7] = 2.0; D[5, 5] = 1.0; D[700, 3] = -4.0; D[999, 999] = 3.0
+    A = orc.CSC.from_scipy(D.tocsc())
+    dA = upload(pkg, A)
+    x = rng.standard_normal(1000)
+    assert np.array_equal(pkg.mul_(pkg.HipVector(1000), dA, pkg.HipVector.from_numpy(x)).to_numpy(), orc.spmv(A, x))
+
+
+def test_rectangular_block_with_halo_columns(pkg, orc, ctx, dist):
+    """a rank's n_loc x n_ext block (ghost columns behind the owned ones) takes the coded layout too"""
+    N, NZ, P = 12, 12, 3
+    n = N * N * NZ
+    A = orc.laplace(N, 3)
+    S = A.to_scipy().tocsr()
+    offsets = dist.partition_rows(n, P, align=N * N)
+    x = np.random.default_rng(2).standard_normal(n)
+    want = orc.spmv(A, x)
+    for r in range(P):
+        r0, r1 = int(offsets[r]), int(offsets[r + 1])
+        blk = S[r0:r1]
+        li, plan = dist.localize_block(blk.indptr.astype(np.int64), blk.indices.astype(np.int64), offsets, r)
+        dA = pkg.HipCSR(plan.n_loc, plan.n_loc + plan.n_ghost, blk.indptr.astype(np.int64), li, blk.data, index_base=0, is_csc=False)
+        assert dA.layout() == "sliced-ell+8-bit-column-codes"
+        xe = np.concatenate([x[r0:r1], x[plan.ghost_gids]])
+        y = pkg.mul_(pkg.HipVector(plan.n_loc), dA, pkg.HipVector.from_numpy(xe)).to_numpy()
+        assert np.array_equal(y, want[r0:r1])
