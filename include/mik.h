@@ -218,6 +218,14 @@ int mik_minres_update(mik_ctx *ctx, int dtype, int64_t n, const void *inv_h3, vo
                       const void *w_curr, const void *neg_h0, const void *w_prev, const void *inv_h2, void *w_next,
                       const void *rhs0, void *x);
 
+/* M = V' * V for k <= 5 columns in ONE pass over V (all pairwise dots; M is k x k, column-major, host) -- the
+ * Gram matrix of src/bicgstabl.jl:120; entry (r, c) equals mik_dot(V[:, r], V[:, c]) bit for bit. */
+int mik_gram(mik_ctx *ctx, int dtype, int64_t n, int k, const void *V, int64_t ldv, void *M);
+/* BiCGStab(l) minimal-residual update, src/bicgstabl.jl:127-132, as one sweep: us[:, 1] -= us[:, 2:l+1] * gamma;
+ * x += rs[:, 1:l] * gamma; rs[:, 1] -= rs[:, 2:l+1] * gamma; *out = norm(rs[:, 1]).  l <= 8; gamma: l host scalars. */
+int mik_bicgstab_mr_update(mik_ctx *ctx, int dtype, int64_t n, int l, void *us, int64_t ldu, void *rs, int64_t ldr, void *x,
+                           const void *gamma, void *out);
+
 /* ---- row-partitioned GMRESIterable: one process per GPU ---------------------------------------- */
 /* The same iterable (src/gmres.jl:57-106) over a contiguous row block.  The Arnoldi basis, x, b and
  * the diagonal preconditioners are this rank's n_loc rows; A_loc is the block as an n_loc x n_ext

@@ -710,6 +710,14 @@ def gemv_t_(V: HipMatrix, k: int, w: HipVector, col0: int = 0) -> np.ndarray:
     return h[:k]
 
 
+def gram_(V: HipMatrix, k: int, col0: int = 0) -> np.ndarray:
+    """``adjoint(V[:, col0+1 : col0+k]) * V[:, col0+1 : col0+k]`` in one pass (k <= 5) -- src/bicgstabl.jl:120."""
+    M = np.zeros((k, k), V.dtype, order="F")
+    check(lib().mik_gram(V.ctx.handle, dtype_code(V.dtype), V.n, int(k), _vp(V.col(col0).ptr), V.ld, M.ctypes.data_as(_vp)),
+          "mik_gram", V.ctx.handle)
+    return M
+
+
 def lu_solve_(A: np.ndarray, b: np.ndarray) -> np.ndarray:
     """``ldiv!(x, lu!(A), b)`` for a small dense host matrix -- src/bicgstabl.jl:124-125.  Overwrites both."""
     if not A.flags.f_contiguous or A.dtype != b.dtype or A.shape[0] != A.shape[1] or b.size != A.shape[0]:
@@ -857,9 +865,10 @@ class BiCGStabIterable:
     is the hashed vector of ``fixtures.hashed_rhs`` shifted into (0, 1)."""
 
     def __init__(self, x: HipVector, A: HipCSR, b: HipVector, l: int = 2, *, Pl=None, max_mv_products, abstol, reltol,
-                 initial_zero, r_shadow: Optional[HipVector] = None):
+                 initial_zero, r_shadow: Optional[HipVector] = None, fused: bool = True):
         from . import fixtures
         T = x.dtype.type
+        self.fused = bool(fused)          # one-pass Gram matrix and one-sweep MR update (same bits) for l <= 4
         n = A.size(1)
         self.A, self.l, self.x = A, int(l), x
         self.Pl = Identity() if Pl is None else Pl
@@ -919,14 +928,26 @@ class BiCGStabIterable:
             self._ldiv(rs.col(j + 1))                                        # :108
             self.x.axpy_(alpha, us.col(0))                                   # :111
         self.mv_products += 2 * l                                            # :115
-        for c in range(l + 1):                                               # M = rs' * rs  :120
-            self.M[:, c] = gemv_t_(rs, l + 1, rs.col(c))
+        fused = self.fused and l + 1 <= 5
+        if fused:
+            self.M[:, :] = gram_(rs, l + 1)                                  # M = rs' * rs  :120, one pass
+        else:
+            for c in range(l + 1):                                           # M = rs' * rs  :120
+                self.M[:, c] = gemv_t_(rs, l + 1, rs.col(c))
         Msub = np.asfortranarray(self.M[1:, 1:].copy())
         self.gamma = lu_solve_(Msub, self.M[1:, 0].copy())                   # :123-125
+        self.omega = self.gamma[l - 1]                                       # :131
+        if fused:                                                            # :127-129, :132 in one sweep
+            out = np.zeros(1, self.x.dtype)
+            g = np.ascontiguousarray(self.gamma, self.x.dtype)
+            check(lib().mik_bicgstab_mr_update(self.x.ctx.handle, self.x.code, self.x.n, l, _vp(us.col(0).ptr), us.ld, _vp(rs.col(0).ptr),
+                                               rs.ld, _vp(self.x.ptr), g.ctypes.data_as(_vp), out.ctypes.data_as(_vp)),
+                  "mik_bicgstab_mr_update", self.x.ctx.handle)
+            self.residual = out[0]
+            return self.residual, iteration + 1
         gemv_n_(us.col(0), us, l, self.gamma, -1.0, col0=1)                  # :127
         gemv_n_(self.x, rs, l, self.gamma, 1.0, col0=0)                      # :128
         gemv_n_(rs.col(0), rs, l, self.gamma, -1.0, col0=1)                  # :129
-        self.omega = self.gamma[l - 1]                                       # :131
         self.residual = norm(rs.col(0))                                      # :132
         return self.residual, iteration + 1
 
@@ -938,12 +959,12 @@ class BiCGStabIterable:
 
 
 def bicgstabl_iterator_(x: HipVector, A: HipCSR, b: HipVector, l: int = 2, *, Pl=None, max_mv_products=None, abstol=0.0,
-                        reltol=None, initial_zero: bool = False, r_shadow: Optional[HipVector] = None):
+                        reltol=None, initial_zero: bool = False, r_shadow: Optional[HipVector] = None, fused: bool = True):
     """``bicgstabl_iterator!(x, A, b, l; ...)`` -- src/bicgstabl.jl:25-73."""
     reltol = _default_reltol(b) if reltol is None else reltol
     max_mv_products = A.size(2) if max_mv_products is None else max_mv_products
     return BiCGStabIterable(x, A, b, l, Pl=Pl, max_mv_products=max_mv_products, abstol=abstol, reltol=reltol,
-                            initial_zero=initial_zero, r_shadow=r_shadow)
+                            initial_zero=initial_zero, r_shadow=r_shadow, fused=fused)
 
 
 def bicgstabl_(x: HipVector, A: HipCSR, b: HipVector, l: int = 2, *, abstol=0.0, reltol=None, max_mv_products=None,

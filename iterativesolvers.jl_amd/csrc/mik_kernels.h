@@ -607,6 +607,148 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_multidot(int64_t n, int64_t nseg,
     }
 }
 
+// All pairwise dots of K columns in ONE pass: seg_out[p][s], p = index of the pair (r <= c) in row-major order of
+// the upper triangle.  Each pair uses the same per-thread order, wave trees and 4-wave-sum order as k_multidot /
+// OpDot, so M[r][c] equals dot(V[:, r], V[:, c]) of the column-by-column path bit for bit.
+//   -- M = rs' * rs: src/bicgstabl.jl:120 (the column-by-column form reads every column K + 1 times)
+template <typename T, bool VEC, int K>
+__global__ __launch_bounds__(MIK_BLOCK) void k_gram(int64_t n, int64_t nseg, const T *__restrict__ V, int64_t ldv,
+                                                    T *__restrict__ seg_out)
+{
+    constexpr int W = VT<T>::W;
+    constexpr int L = MIK_RED_L;
+    constexpr int NP = K * (K + 1) / 2;
+    constexpr int64_t SEG = (int64_t)MIK_BLOCK * W * L;
+    __shared__ T lds[NP][4];
+    for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+        const int64_t base = s * SEG + (int64_t)W * threadIdx.x;
+        T cr[K][L * W];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const T *__restrict__ col = V + (int64_t)j * ldv;
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int64_t i = base + (int64_t)l * MIK_BLOCK * W;
+                if (VEC && i + W <= n) {
+                    auto cv = vload(col + i);
+#pragma unroll
+                    for (int e = 0; e < W; ++e) cr[j][l * W + e] = el<T>(cv, e);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < W; ++e) cr[j][l * W + e] = (i + e < n) ? col[i + e] : T(0);
+                }
+            }
+        }
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        int p = 0;
+#pragma unroll
+        for (int r = 0; r < K; ++r)
+#pragma unroll
+            for (int c = r; c < K; ++c) {
+                T acc = T(0);
+#pragma unroll
+                for (int q = 0; q < L * W; ++q) {
+                    const int64_t i = base + (int64_t)(q / W) * MIK_BLOCK * W + (q % W);
+                    if (i < n) { T pr = cr[r][q] * cr[c][q]; acc = acc + pr; }
+                }
+                acc = wave_tree(acc);
+                if (lane == 0) lds[p][w] = acc;
+                ++p;
+            }
+        __syncthreads();
+        if (threadIdx.x < NP) {
+            T tot = lds[threadIdx.x][0];
+            tot = tot + lds[threadIdx.x][1]; tot = tot + lds[threadIdx.x][2]; tot = tot + lds[threadIdx.x][3];
+            seg_out[(int64_t)threadIdx.x * nseg + s] = tot;
+        }
+        __syncthreads();
+    }
+}
+
+// BiCGStab(l) minimal-residual update in one sweep                      -- src/bicgstabl.jl:127-132
+//   us_0 -= sum_{j=1..l} gamma_j us_j;  x += sum_{j=0..l-1} gamma_{j+1} rs_j;  rs_0 -= sum_{j=1..l} gamma_j rs_j;
+//   partial sums of rs_0.^2.  Same per-element operations and order as the three mul!(y, V, c, alpha, 1) calls
+//   (k_gemv_n: temp = alpha * c[j]; y = y + temp * V[:, j], j ascending); x uses rs_0 before its update.
+template <typename T> struct BicgGamma { T g[8]; };
+template <typename T, bool VEC>
+__global__ __launch_bounds__(MIK_BLOCK) void k_bicg_mr(int64_t n, int64_t nseg, int l, T *__restrict__ us, int64_t ldu,
+                                                       T *__restrict__ rs, int64_t ldr, T *__restrict__ x, BicgGamma<T> gm,
+                                                       T *__restrict__ seg_out)
+{
+    constexpr int W = VT<T>::W;
+    constexpr int L = MIK_RED_L;
+    constexpr int64_t SEG = (int64_t)MIK_BLOCK * W * L;
+    __shared__ T lds4[4];
+    for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+        const int64_t base = s * SEG + (int64_t)W * threadIdx.x;
+        T acc = T(0);
+#pragma unroll
+        for (int lq = 0; lq < L; ++lq) {
+            const int64_t i0 = base + (int64_t)lq * MIK_BLOCK * W;
+            const bool full = VEC && i0 + W <= n;
+            T u0[W], xx[W], r0[W], rold[W];
+            if (full) {
+                auto a = vload<T>(us + i0); auto b = vload<T>(x + i0); auto c = vload<T>(rs + i0);
+#pragma unroll
+                for (int e = 0; e < W; ++e) { u0[e] = el<T>(a, e); xx[e] = el<T>(b, e); r0[e] = el<T>(c, e); }
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    const bool in = i0 + e < n;
+                    u0[e] = in ? us[i0 + e] : T(0); xx[e] = in ? x[i0 + e] : T(0); r0[e] = in ? rs[i0 + e] : T(0);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < W; ++e) rold[e] = r0[e];
+            {   // x += gamma_1 * rs_0 (the not yet updated residual)
+                const T temp = T(1) * gm.g[0];
+#pragma unroll
+                for (int e = 0; e < W; ++e) { T p = temp * rold[e]; xx[e] = xx[e] + p; }
+            }
+            for (int j = 1; j <= l; ++j) {
+                T uj[W], rj[W];
+                if (full) {
+                    auto a = vload(us + (int64_t)j * ldu + i0); auto c = vload(rs + (int64_t)j * ldr + i0);
+#pragma unroll
+                    for (int e = 0; e < W; ++e) { uj[e] = el<T>(a, e); rj[e] = el<T>(c, e); }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < W; ++e) {
+                        const bool in = i0 + e < n;
+                        uj[e] = in ? us[(int64_t)j * ldu + i0 + e] : T(0); rj[e] = in ? rs[(int64_t)j * ldr + i0 + e] : T(0);
+                    }
+                }
+                const T tneg = T(-1) * gm.g[j - 1];
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    T p = tneg * uj[e]; u0[e] = u0[e] + p;
+                    T q = tneg * rj[e]; r0[e] = r0[e] + q;
+                }
+                if (j < l) {
+                    const T tpos = T(1) * gm.g[j];
+#pragma unroll
+                    for (int e = 0; e < W; ++e) { T p = tpos * rj[e]; xx[e] = xx[e] + p; }
+                }
+            }
+            if (full) {
+                typename VT<T>::vec a, b, c;
+#pragma unroll
+                for (int e = 0; e < W; ++e) { el<T>(a, e) = u0[e]; el<T>(b, e) = xx[e]; el<T>(c, e) = r0[e]; }
+                vstore(us + i0, a); vstore(x + i0, b); vstore(rs + i0, c);
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; ++e)
+                    if (i0 + e < n) { us[i0 + e] = u0[e]; x[i0 + e] = xx[e]; rs[i0 + e] = r0[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < W; ++e)
+                if (i0 + e < n) { T p = r0[e] * r0[e]; acc = acc + p; }
+        }
+        T tot = block_tree_256(acc, lds4);
+        if (threadIdx.x == 0) seg_out[s] = tot;
+    }
+}
+
 // y += sum_j (alpha * c[j]) * V[:, j], columns ascending (reference-BLAS dgemv 'N' order)
 //   -- mul!(y, V, c, alpha, 1): src/orthogonalize.jl:16,30,44; src/gmres.jl:275
 template <typename T, bool VEC>

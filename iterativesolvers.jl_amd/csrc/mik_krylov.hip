@@ -1443,6 +1443,83 @@ extern "C" int mik_gemv_t(mik_ctx *ctx, int dtype, int64_t n, int k, const void 
     return MIK_ERR_INVALID;
 }
 
+// M = V' * V for k <= 5 columns in one pass over V -- src/bicgstabl.jl:120 (M = rs' * rs)
+template <typename T, int K> static int gram_launch(mik_ctx *ctx, int64_t n, const T *V, int64_t ldv)
+{
+    const int64_t nseg = mik_nseg<T>(n);
+    const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
+    const bool vec = mik_aligned16(V) && (ldv % VT<T>::W == 0);
+    if (vec) hipLaunchKernelGGL((k_gram<T, true, K>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, V, ldv, (T *)ctx->partials);
+    else hipLaunchKernelGGL((k_gram<T, false, K>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, V, ldv, (T *)ctx->partials);
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+
+template <typename T> static int gram_impl(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, T *M)
+{
+    const int np = k * (k + 1) / 2;
+    const int64_t nseg = mik_nseg<T>(n);
+    T *hd = (T *)ctx->coef;
+    if (nseg == 0) {
+        for (int i = 0; i < k * k; ++i) M[i] = T(0);
+        return MIK_OK;
+    }
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)nseg * (size_t)np));
+    switch (k) {
+    case 1: MIK_TRY((gram_launch<T, 1>(ctx, n, V, ldv))); break;
+    case 2: MIK_TRY((gram_launch<T, 2>(ctx, n, V, ldv))); break;
+    case 3: MIK_TRY((gram_launch<T, 3>(ctx, n, V, ldv))); break;
+    case 4: MIK_TRY((gram_launch<T, 4>(ctx, n, V, ldv))); break;
+    default: MIK_TRY((gram_launch<T, 5>(ctx, n, V, ldv))); break;
+    }
+    MIK_TRY(finalize_store<T>(ctx, nseg, np, hd));
+    std::vector<T> out((size_t)np);
+    MIK_TRY(coef_download<T>(ctx, 0, out.data(), np));
+    int p = 0;
+    for (int r = 0; r < k; ++r)
+        for (int c = r; c < k; ++c) { M[(size_t)c * k + r] = out[p]; M[(size_t)r * k + c] = out[p]; ++p; }
+    return MIK_OK;
+}
+
+extern "C" int mik_gram(mik_ctx *ctx, int dtype, int64_t n, int k, const void *V, int64_t ldv, void *M)
+{
+    if (!ctx || n < 0 || k < 1 || !M || (n && (!V || ldv < n))) return MIK_ERR_INVALID;
+    if (k > 5) return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_gram: k = %d (at most 5 columns; use mik_gemv_t per column)", k);
+    if (dtype == MIK_F64) return gram_impl<double>(ctx, n, k, (const double *)V, ldv, (double *)M);
+    if (dtype == MIK_F32) return gram_impl<float>(ctx, n, k, (const float *)V, ldv, (float *)M);
+    return MIK_ERR_INVALID;
+}
+
+// src/bicgstabl.jl:127-132 in one sweep (k_bicg_mr); *out = norm(rs[:, 1])
+template <typename T>
+static int bicg_mr_impl(mik_ctx *ctx, int64_t n, int l, T *us, int64_t ldu, T *rs, int64_t ldr, T *x, const T *gamma, T *out)
+{
+    const int64_t nseg = mik_nseg<T>(n);
+    if (nseg == 0) { *out = T(0); return MIK_OK; }
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)nseg));
+    BicgGamma<T> gm{};
+    for (int j = 0; j < l; ++j) gm.g[j] = gamma[j];
+    const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
+    const bool vec = mik_aligned16(us) && mik_aligned16(rs) && mik_aligned16(x) && (ldu % VT<T>::W == 0) && (ldr % VT<T>::W == 0);
+    if (vec) hipLaunchKernelGGL((k_bicg_mr<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, l, us, ldu, rs, ldr, x, gm, (T *)ctx->partials);
+    else hipLaunchKernelGGL((k_bicg_mr<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, l, us, ldu, rs, ldr, x, gm, (T *)ctx->partials);
+    MIK_LAUNCH_CHECK(ctx);
+    MIK_TRY(finalize_store<T>(ctx, nseg, 1, (T *)ctx->coef));
+    T ss;
+    MIK_TRY(coef_download<T>(ctx, 0, &ss, 1));
+    *out = (T)std::sqrt(ss);
+    return MIK_OK;
+}
+
+extern "C" int mik_bicgstab_mr_update(mik_ctx *ctx, int dtype, int64_t n, int l, void *us, int64_t ldu, void *rs, int64_t ldr, void *x,
+                                      const void *gamma, void *out)
+{
+    if (!ctx || n < 0 || l < 1 || l > 8 || !gamma || !out || (n && (!us || !rs || !x || ldu < n || ldr < n))) return MIK_ERR_INVALID;
+    if (dtype == MIK_F64) return bicg_mr_impl<double>(ctx, n, l, (double *)us, ldu, (double *)rs, ldr, (double *)x, (const double *)gamma, (double *)out);
+    if (dtype == MIK_F32) return bicg_mr_impl<float>(ctx, n, l, (float *)us, ldu, (float *)rs, ldr, (float *)x, (const float *)gamma, (float *)out);
+    return MIK_ERR_INVALID;
+}
+
 // Solve A x = b for a small dense column-major A (n x n, leading dimension lda) by LU with partial
 // pivoting -- F = lu!(view(M, L, L)); ldiv!(gamma, F, view(M, L, 1)) at src/bicgstabl.jl:124-125.
 // A is overwritten by its factors, b by the solution.  Returns 1 (MIK_ERR_INVALID) on an exactly

@@ -89,3 +89,34 @@ def test_device_reference_properties(pkg, orc, ctx):
         x2, his2 = pkg.bicgstabl_(xg, dA, pkg.HipVector.from_numpy(b), l, max_mv_products=100, log=True)
         assert x2 is xg                                                          # test/bicgstabl.jl:33
         assert np.linalg.norm(Ad @ x2.to_numpy() - b) / np.linalg.norm(b) <= np.sqrt(np.finfo(float).eps)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,k", [(1, 1), (1000, 3), (4099, 5), (300001, 2)])
+def test_gram_equals_pairwise_dots(pkg, orc, ctx, dtype, n, k):
+    """mik_gram: every entry bit-identical to dot(V[:, r], V[:, c]) (tree oracle); symmetric; one pass"""
+    rng = np.random.default_rng(n + k)
+    V = np.asfortranarray(rng.standard_normal((n, k)).astype(dtype))
+    M = pkg.gram_(pkg.HipMatrix.from_numpy(V), k)
+    W, L = ctx.reduce_shape(dtype)
+    want = np.array([[orc.dot(np.ascontiguousarray(V[:, r]), np.ascontiguousarray(V[:, c]), "tree", W, L) for c in range(k)] for r in range(k)], dtype)
+    assert np.array_equal(M, want) and np.array_equal(M, M.T)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("l", [1, 2, 4])
+def test_fused_bicgstab_equals_statement_by_statement(pkg, orc, ctx, l, dtype):
+    A, b = orc.advdiff(11, 300.0)
+    A, b = A.astype(dtype), b.astype(dtype)
+    sh = (orc.hashed_rhs(A.n) + 0.5).astype(dtype)
+    dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
+    runs = []
+    for fused in (True, False):
+        x = pkg.HipVector.from_numpy(np.zeros(A.n, dtype))
+        it = pkg.bicgstabl_iterator_(x, dA, pkg.HipVector.from_numpy(b), l, max_mv_products=60 * l, reltol=0.0, initial_zero=True,
+                                     r_shadow=pkg.HipVector.from_numpy(sh), fused=fused)
+        runs.append((np.array(list(it)), x.to_numpy()))
+    assert runs[0][0].size == 30
+    assert np.array_equal(runs[0][0], runs[1][0], equal_nan=True) and np.array_equal(runs[0][1], runs[1][1], equal_nan=True)
