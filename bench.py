@@ -211,11 +211,12 @@ def main():
                    "reltol": "sqrt(eps)" if reltol is None else reltol, "host_sync_per_step": 1,
                    "final_residual": residual},
         "roofline": {"bound": "hbm", "kernel": {"csr-rowblock": "k_spmv_rowblock", "sliced-ell": "k_spmv_sell",
-                                                 "sliced-ell+8-bit-column-codes": "k_spmv_sell8"}.get(layout, layout) + "<double, fused dot>",
+                                                 "sliced-ell+8-bit-column-codes": "k_spmv_sell8", "sliced-ell+slice-offsets+row-masks": "k_spmv_sdia"}.get(layout, layout) + "<double, fused dot>",
                      "operator_layout": layout, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic({"csr-rowblock": "k_spmv_rowblock", "sliced-ell": "k_spmv_sell",
-                                             "sliced-ell+8-bit-column-codes": "k_spmv_sell8"}.get(layout, "k_spmv_rowblock")),
+                                             "sliced-ell+8-bit-column-codes": "k_spmv_sell8",
+                                             "sliced-ell+slice-offsets+row-masks": "k_spmv_sdia"}.get(layout, "k_spmv_rowblock")),
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms, "launches_timed": spmv_launches,
                      "back_to_back_ms": b2b_ms, "frac_of_copy_ceiling_6290": achieved / 6290.0,
                      "stored_bytes_per_launch": stored_bytes, "physical_gbs": stored_bytes / (spmv_ms * 1e-3) / 1e9,

@@ -119,7 +119,8 @@ int mik_csr_pack(mik_csr *A);
  * bit-identical across layouts): 0 = CSR row-blocks (LDS-staged products; any matrix), 1 = sliced-ELL (256-row
  * slices stored column-major; near-uniform row lengths per slice), 2 = sliced-ELL values + 8-bit codes for the
  * (column - row) offsets (banded / stencil operators with <= 255 distinct offsets), 3 = dictionary-coded
- * (after mik_csr_pack). */
+ * (after mik_csr_pack), 4 = sliced-ELL values with per-slice offsets and one presence-mask byte per row (every
+ * 256-row slice uses <= 8 distinct offsets: stencils on structured grids). */
 int mik_csr_layout(const mik_csr *A, int *layout);
 /* Bytes of operator data (values, indices / codes, pointers) one mik_spmv launch streams in that layout. */
 int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes);

@@ -466,6 +466,83 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
             }
         }
     }
+    // Sliced-ELL with per-slice offsets and per-row masks (k_spmv_sdia): every 256-row slice uses at most 8
+    // distinct (column - row) offsets and the slot padding stays below 1/8 extra entries.
+    if (A->n_long == 0 && n_rows > 0 && nnz > 0 && n_cols > 0 && g_mik_tuning[8] == 0 && g_mik_tuning[12] == 0) {
+        const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
+        std::vector<int> dptr((size_t)nb + 1, 0), doff((size_t)nb * 8, 0);
+        bool ok = true;
+        int64_t slots = 0;
+        for (int64_t b = 0; b < nb && ok; ++b) {
+            // The slice's slot pattern: a common super-sequence of its rows' offset sequences (each row lists its
+            // entries in the order they are summed -- ascending GLOBAL column, which for a rank's block with halo
+            // columns is not ascending local offset), built by merging row after row.
+            int offs8[8];
+            int ns = 0;
+            const int64_t rend = std::min<int64_t>((b + 1) * MIK_BLOCK, n_rows);
+            for (int64_t r = b * MIK_BLOCK; r < rend && ok; ++r) {
+                int p = 0;                                         // next admissible pattern position for this row
+                for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
+                    const int d = col[(size_t)k2] - (int)r;
+                    int q = 0;
+                    while (q < ns && offs8[q] != d) ++q;
+                    if (q < ns) {
+                        if (q < p) { ok = false; break; }          // two rows order the same offsets differently
+                        p = q + 1;
+                    } else {
+                        if (ns == 8) { ok = false; break; }
+                        for (int z = ns; z > p; --z) offs8[z] = offs8[z - 1];
+                        offs8[p] = d;
+                        ++ns;
+                        ++p;
+                    }
+                }
+            }
+            for (int q = 0; q < ns; ++q) doff[(size_t)b * 8 + q] = offs8[q];
+            slots += (int64_t)ns * MIK_BLOCK;
+            if (slots >= INT32_MAX) ok = false;
+            dptr[(size_t)b + 1] = (int)slots;
+        }
+        if (ok && slots <= nnz + nnz / 8 + 8 * MIK_BLOCK) {
+            std::vector<unsigned char> dval, dmask;
+            try {
+                dval.assign((size_t)slots * es, 0);
+                dmask.assign((size_t)n_rows, 0);
+            } catch (const std::bad_alloc &) {
+                cleanup();
+                return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host staging allocation failed (sliced-diagonal form)");
+            }
+            for (int64_t r = 0; r < n_rows && ok; ++r) {
+                const int64_t b = r / MIK_BLOCK, t = r % MIK_BLOCK;
+                const int ns = (dptr[(size_t)b + 1] - dptr[(size_t)b]) / MIK_BLOCK;
+                const int *so = &doff[(size_t)b * 8];
+                int q = 0, prevq = -1;
+                for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
+                    const int d = col[(size_t)k2] - (int)r;
+                    while (q < ns && so[q] != d) ++q;             // columns ascend within a row, so do the slots
+                    if (q >= ns || q <= prevq) { ok = false; break; }   // unsorted or duplicate column: keep the other layouts
+                    const size_t dst = (size_t)dptr[(size_t)b] + (size_t)q * MIK_BLOCK + (size_t)t;
+                    memcpy(&dval[dst * es], &v[(size_t)k2 * es], es);
+                    dmask[(size_t)r] |= (unsigned char)(1u << q);
+                    prevq = q;
+                }
+            }
+            if (ok) {
+                if ((e = hipMalloc((void **)&A->sdia_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
+                    (e = hipMalloc((void **)&A->sdia_off, sizeof(int) * (size_t)nb * 8)) != hipSuccess ||
+                    (e = hipMalloc((void **)&A->sdia_mask, (size_t)n_rows)) != hipSuccess ||
+                    (e = hipMalloc(&A->sdia_val, es * (size_t)std::max<int64_t>(slots, 1))) != hipSuccess ||
+                    (e = hipMemcpy(A->sdia_ptr, dptr.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice)) != hipSuccess ||
+                    (e = hipMemcpy(A->sdia_off, doff.data(), sizeof(int) * (size_t)nb * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+                    (e = hipMemcpy(A->sdia_mask, dmask.data(), (size_t)n_rows, hipMemcpyHostToDevice)) != hipSuccess ||
+                    (slots && (e = hipMemcpy(A->sdia_val, dval.data(), es * (size_t)slots, hipMemcpyHostToDevice)) != hipSuccess)) {
+                    cleanup();
+                    return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: sliced-diagonal form: %s", hipGetErrorString(e));
+                }
+                A->sdia_entries = slots;
+            }
+        }
+    }
     *out = A;
     return MIK_OK;
 }
@@ -479,6 +556,10 @@ extern "C" int mik_csr_destroy(mik_csr *A)
     if (A->val) (void)hipFree(A->val);
     if (A->long_rows) (void)hipFree(A->long_rows);
     if (A->is_long) (void)hipFree(A->is_long);
+    if (A->sdia_ptr) (void)hipFree(A->sdia_ptr);
+    if (A->sdia_off) (void)hipFree(A->sdia_off);
+    if (A->sdia_mask) (void)hipFree(A->sdia_mask);
+    if (A->sdia_val) (void)hipFree(A->sdia_val);
     if (A->sell8_ptr) (void)hipFree(A->sell8_ptr);
     if (A->sell8_codes) (void)hipFree(A->sell8_codes);
     if (A->sell8_tab) (void)hipFree(A->sell8_tab);
@@ -567,6 +648,7 @@ extern "C" int mik_csr_layout(const mik_csr *A, int *layout)
 {
     if (!A || !layout) return MIK_ERR_INVALID;
     if (A->packed && g_mik_tuning[6] == 0) *layout = 3;
+    else if (A->sdia_val && g_mik_tuning[8] == 0 && g_mik_tuning[12] == 0) *layout = 4;
     else if (A->sell8_codes && g_mik_tuning[8] == 0 && g_mik_tuning[10] == 0) *layout = 2;
     else if (A->sell_val && g_mik_tuning[8] == 0) *layout = 1;
     else *layout = 0;
@@ -581,6 +663,7 @@ extern "C" int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes)
     const int64_t es = (int64_t)mik_dtype_size(A->dtype);
     const int64_t nb = (A->n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
     switch (layout) {
+    case 4: *bytes = A->sdia_entries * es + A->n_rows + nb * 36; break;
     case 3: *bytes = A->nnz * 2 + (A->n_rows + 1) * 4 + 256 * (es + 4); break;
     case 2: *bytes = A->sell_entries * es + A->sell8_bytes + (nb + 1) * 8 + 256 * 4; break;
     case 1: *bytes = A->sell_entries * (es + 4) + A->n_rows + (nb + 1) * 4; break;
@@ -622,6 +705,17 @@ int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_
         else
             hipLaunchKernelGGL((k_spmv_packed<T, false>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, map_mode, A->rowptr, A->codes,
                                (const T *)A->vtab, A->dtab, A->nv, A->nd, x, y, seg_out, done);
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    }
+    if (A->sdia_val && g_mik_tuning[8] == 0 && g_mik_tuning[12] == 0) {
+        // sliced-ELL values + per-slice offsets + row masks (mik_sell.h)
+#define MIK_SDIA_GO(FD, NTV)                                                                                                  \
+    hipLaunchKernelGGL((k_spmv_sdia<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, (int)A->n_cols, nb, map_mode, A->sdia_ptr, \
+                       A->sdia_off, A->sdia_mask, (const T *)A->sdia_val, x, y, seg_out, done)
+        if (fuse_dot) { if (nt) MIK_SDIA_GO(true, true); else MIK_SDIA_GO(true, false); }
+        else          { if (nt) MIK_SDIA_GO(false, true); else MIK_SDIA_GO(false, false); }
+#undef MIK_SDIA_GO
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     }

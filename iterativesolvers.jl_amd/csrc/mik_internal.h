@@ -68,6 +68,12 @@ struct mik_csr {
     int sell8_nd = 0;
     int64_t sell8_bytes = 0;
     int sell_maxw = 0;               // widest slice
+    // sliced-ELL with per-slice offsets + per-row masks (k_spmv_sdia): every slice uses <= 8 distinct offsets
+    int *sdia_ptr = nullptr;         // device, nb + 1
+    int *sdia_off = nullptr;         // device, nb * 8
+    unsigned char *sdia_mask = nullptr;   // device, n_rows
+    void *sdia_val = nullptr;        // device, slot-major inside a slice
+    int64_t sdia_entries = 0;
     // optional dictionary-coded form (mik_csr_pack): one 16-bit code per entry + two <= 256-entry tables
     unsigned short *codes = nullptr; // device, nnz (+ padding)
     void *vtab = nullptr;            // device, 256 values of dtype

@@ -137,5 +137,54 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sell8(int n, int nb, int map
     }
 }
 
+// Sliced-ELL with PER-SLICE offsets and per-row presence masks ("sliced diagonal" form).  When the rows of a
+// 256-row slice together use at most 8 distinct (column - row) offsets -- any stencil on a structured grid -- the
+// slice stores those offsets once (in the order the rows sum them: a common super-sequence of the rows' entry
+// orders, built at upload), every row keeps one value slot per offset (zero where the row has
+// no such entry, e.g. at grid boundaries) and one mask byte saying which slots are real.  The column of slot q
+// is then row + offs[q] with offs[q] wave-uniform: the gather of x no longer waits for a per-row index load (it is
+// issued together with the value stream), needs no table lookup, and the index data shrinks from 8 bytes to 1
+// byte per row.  A row's real slots are visited in its own entry order from +0 and absent slots are skipped,
+// so the sum is bit-identical to the other layouts.
+template <typename T, bool FUSE_DOT, bool NT>
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdia(int n, int ncols, int nb, int map_mode, const int *__restrict__ blkptr,
+                                                         const int *__restrict__ offs, const unsigned char *__restrict__ mask,
+                                                         const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y,
+                                                         T *__restrict__ seg_out, const int *__restrict__ done)
+{
+    if (done && *done) return;
+    constexpr int U = 8;
+    __shared__ T lds4[4];
+    const int t = threadIdx.x;
+    const int rb = spmv_block_map((int)blockIdx.x, nb, map_mode);
+    const int r = rb * MIK_BLOCK + t;
+    const int base = blkptr[rb];
+    const int ns = (blkptr[rb + 1] - base) / MIK_BLOCK;            // offsets used by this slice, <= 8
+    const int *__restrict__ so = offs + (size_t)rb * U;
+    const T *__restrict__ vp = val + base + t;
+
+    T acc = T(0);
+    if (ns > 0) {
+        T v[U], xv[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int qq = min(q, ns - 1);                           // clamp: all loads unconditional (batched)
+            v[q] = ld_stream<NT>(vp + (size_t)qq * MIK_BLOCK);
+            xv[q] = x[min(max(r + so[qq], 0), ncols - 1)];           // absent slots gather from a valid address
+        }
+        const int m = r < n ? (int)mask[r] : 0;
+#pragma unroll
+        for (int q = 0; q < U; ++q)
+            if ((m >> q) & 1) { T p = v[q] * xv[q]; acc = acc + p; }
+    }
+    if (r < n) st_stream<NT>(y + r, acc);
+    if (FUSE_DOT) {
+        T p = T(0);
+        if (r < n) p = x[r] * acc;
+        T tot = block_tree_256(p, lds4);
+        if (t == 0) seg_out[rb] = tot;
+    }
+}
+
 #endif  // __HIPCC__
 #endif  // MIK_SELL_H

@@ -35,7 +35,7 @@ for k, m in means.items():
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
         rd, wr = 2.0 * m["FETCH_SIZE"] * 1024.0, m["WRITE_SIZE"] * 1024.0
         short = ("k_spmv_packed" if "spmv_packed" in k else "k_spmv_rowblock" if "spmv_rowblock" in k else
-                 "k_spmv_sell8" if "spmv_sell8" in k else "k_spmv_sell" if "spmv_sell" in k else k.replace("void ", "").strip())
+                 "k_spmv_sdia" if "spmv_sdia" in k else "k_spmv_sell8" if "spmv_sell8" in k else "k_spmv_sell" if "spmv_sell" in k else k.replace("void ", "").strip())
         traffic[short] = {"kernel": k, "fetch_bytes_x2": rd, "write_bytes": wr, "traffic_bytes_per_launch": rd + wr,
                           "l2_hit_rate": (m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])) if "TCC_HIT_sum" in m else None}
         print("traffic", short, "read %.3f GB  write %.3f GB  total %.3f GB" % (rd / 1e9, wr / 1e9, (rd + wr) / 1e9))
