@@ -373,9 +373,87 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
             return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create: long-row tables: %s", hipGetErrorString(e));
         }
     }
+    // Sliced-ELL with per-slice offsets and per-row masks (k_spmv_sdia): every 256-row slice uses at most 8
+    // distinct (column - row) offsets and the slot padding stays below 1/8 extra entries.
+    if (A->n_long == 0 && n_rows > 0 && nnz > 0 && n_cols > 0 && g_mik_tuning[8] == 0 && g_mik_tuning[12] == 0) {
+        const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
+        std::vector<int> dptr((size_t)nb + 1, 0), doff((size_t)nb * 8, 0);
+        bool ok = true;
+        int64_t slots = 0;
+        for (int64_t b = 0; b < nb && ok; ++b) {
+            // The slice's slot pattern: a common super-sequence of its rows' offset sequences (each row lists its
+            // entries in the order they are summed -- ascending GLOBAL column, which for a rank's block with halo
+            // columns is not ascending local offset), built by merging row after row.
+            int offs8[8];
+            int ns = 0;
+            const int64_t rend = std::min<int64_t>((b + 1) * MIK_BLOCK, n_rows);
+            for (int64_t r = b * MIK_BLOCK; r < rend && ok; ++r) {
+                int p = 0;                                         // next admissible pattern position for this row
+                for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
+                    const int d = col[(size_t)k2] - (int)r;
+                    int q = 0;
+                    while (q < ns && offs8[q] != d) ++q;
+                    if (q < ns) {
+                        if (q < p) { ok = false; break; }          // two rows order the same offsets differently
+                        p = q + 1;
+                    } else {
+                        if (ns == 8) { ok = false; break; }
+                        for (int z = ns; z > p; --z) offs8[z] = offs8[z - 1];
+                        offs8[p] = d;
+                        ++ns;
+                        ++p;
+                    }
+                }
+            }
+            for (int q = 0; q < ns; ++q) doff[(size_t)b * 8 + q] = offs8[q];
+            slots += (int64_t)ns * MIK_BLOCK;
+            if (slots >= INT32_MAX) ok = false;
+            dptr[(size_t)b + 1] = (int)slots;
+        }
+        if (ok && slots <= nnz + nnz / 8 + 8 * MIK_BLOCK) {
+            std::vector<unsigned char> dval, dmask;
+            try {
+                dval.assign((size_t)slots * es, 0);
+                dmask.assign((size_t)n_rows, 0);
+            } catch (const std::bad_alloc &) {
+                cleanup();
+                return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host staging allocation failed (sliced-diagonal form)");
+            }
+            for (int64_t r = 0; r < n_rows && ok; ++r) {
+                const int64_t b = r / MIK_BLOCK, t = r % MIK_BLOCK;
+                const int ns = (dptr[(size_t)b + 1] - dptr[(size_t)b]) / MIK_BLOCK;
+                const int *so = &doff[(size_t)b * 8];
+                int q = 0, prevq = -1;
+                for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
+                    const int d = col[(size_t)k2] - (int)r;
+                    while (q < ns && so[q] != d) ++q;             // columns ascend within a row, so do the slots
+                    if (q >= ns || q <= prevq) { ok = false; break; }   // unsorted or duplicate column: keep the other layouts
+                    const size_t dst = (size_t)dptr[(size_t)b] + (size_t)q * MIK_BLOCK + (size_t)t;
+                    memcpy(&dval[dst * es], &v[(size_t)k2 * es], es);
+                    dmask[(size_t)r] |= (unsigned char)(1u << q);
+                    prevq = q;
+                }
+            }
+            if (ok) {
+                if ((e = hipMalloc((void **)&A->sdia_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
+                    (e = hipMalloc((void **)&A->sdia_off, sizeof(int) * (size_t)nb * 8)) != hipSuccess ||
+                    (e = hipMalloc((void **)&A->sdia_mask, (size_t)n_rows)) != hipSuccess ||
+                    (e = hipMalloc(&A->sdia_val, es * (size_t)std::max<int64_t>(slots, 1))) != hipSuccess ||
+                    (e = hipMemcpy(A->sdia_ptr, dptr.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice)) != hipSuccess ||
+                    (e = hipMemcpy(A->sdia_off, doff.data(), sizeof(int) * (size_t)nb * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+                    (e = hipMemcpy(A->sdia_mask, dmask.data(), (size_t)n_rows, hipMemcpyHostToDevice)) != hipSuccess ||
+                    (slots && (e = hipMemcpy(A->sdia_val, dval.data(), es * (size_t)slots, hipMemcpyHostToDevice)) != hipSuccess)) {
+                    cleanup();
+                    return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: sliced-diagonal form: %s", hipGetErrorString(e));
+                }
+                A->sdia_entries = slots;
+            }
+        }
+    }
     // Sliced-ELL form (csrc/mik_sell.h): per 256-row block, entry j of all rows contiguous, padded to the block's
     // longest row.  Built when no row was split off as long and padding costs < 1/8 extra entries.
-    if (A->n_long == 0 && n_rows > 0 && nnz > 0 && max_row <= 255 && g_mik_tuning[8] == 0) {
+    // (skipped when the per-slice-offset form above exists: mik_spmv would never use it)
+    if (!A->sdia_val && A->n_long == 0 && n_rows > 0 && nnz > 0 && max_row <= 255 && g_mik_tuning[8] == 0) {
         const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
         std::vector<int> sptr((size_t)nb + 1, 0);
         int64_t padded = 0;
@@ -463,83 +541,6 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
                     A->sell8_nd = (int)code_of.size();
                     A->sell8_bytes = cbytes;
                 }
-            }
-        }
-    }
-    // Sliced-ELL with per-slice offsets and per-row masks (k_spmv_sdia): every 256-row slice uses at most 8
-    // distinct (column - row) offsets and the slot padding stays below 1/8 extra entries.
-    if (A->n_long == 0 && n_rows > 0 && nnz > 0 && n_cols > 0 && g_mik_tuning[8] == 0 && g_mik_tuning[12] == 0) {
-        const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
-        std::vector<int> dptr((size_t)nb + 1, 0), doff((size_t)nb * 8, 0);
-        bool ok = true;
-        int64_t slots = 0;
-        for (int64_t b = 0; b < nb && ok; ++b) {
-            // The slice's slot pattern: a common super-sequence of its rows' offset sequences (each row lists its
-            // entries in the order they are summed -- ascending GLOBAL column, which for a rank's block with halo
-            // columns is not ascending local offset), built by merging row after row.
-            int offs8[8];
-            int ns = 0;
-            const int64_t rend = std::min<int64_t>((b + 1) * MIK_BLOCK, n_rows);
-            for (int64_t r = b * MIK_BLOCK; r < rend && ok; ++r) {
-                int p = 0;                                         // next admissible pattern position for this row
-                for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
-                    const int d = col[(size_t)k2] - (int)r;
-                    int q = 0;
-                    while (q < ns && offs8[q] != d) ++q;
-                    if (q < ns) {
-                        if (q < p) { ok = false; break; }          // two rows order the same offsets differently
-                        p = q + 1;
-                    } else {
-                        if (ns == 8) { ok = false; break; }
-                        for (int z = ns; z > p; --z) offs8[z] = offs8[z - 1];
-                        offs8[p] = d;
-                        ++ns;
-                        ++p;
-                    }
-                }
-            }
-            for (int q = 0; q < ns; ++q) doff[(size_t)b * 8 + q] = offs8[q];
-            slots += (int64_t)ns * MIK_BLOCK;
-            if (slots >= INT32_MAX) ok = false;
-            dptr[(size_t)b + 1] = (int)slots;
-        }
-        if (ok && slots <= nnz + nnz / 8 + 8 * MIK_BLOCK) {
-            std::vector<unsigned char> dval, dmask;
-            try {
-                dval.assign((size_t)slots * es, 0);
-                dmask.assign((size_t)n_rows, 0);
-            } catch (const std::bad_alloc &) {
-                cleanup();
-                return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host staging allocation failed (sliced-diagonal form)");
-            }
-            for (int64_t r = 0; r < n_rows && ok; ++r) {
-                const int64_t b = r / MIK_BLOCK, t = r % MIK_BLOCK;
-                const int ns = (dptr[(size_t)b + 1] - dptr[(size_t)b]) / MIK_BLOCK;
-                const int *so = &doff[(size_t)b * 8];
-                int q = 0, prevq = -1;
-                for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
-                    const int d = col[(size_t)k2] - (int)r;
-                    while (q < ns && so[q] != d) ++q;             // columns ascend within a row, so do the slots
-                    if (q >= ns || q <= prevq) { ok = false; break; }   // unsorted or duplicate column: keep the other layouts
-                    const size_t dst = (size_t)dptr[(size_t)b] + (size_t)q * MIK_BLOCK + (size_t)t;
-                    memcpy(&dval[dst * es], &v[(size_t)k2 * es], es);
-                    dmask[(size_t)r] |= (unsigned char)(1u << q);
-                    prevq = q;
-                }
-            }
-            if (ok) {
-                if ((e = hipMalloc((void **)&A->sdia_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
-                    (e = hipMalloc((void **)&A->sdia_off, sizeof(int) * (size_t)nb * 8)) != hipSuccess ||
-                    (e = hipMalloc((void **)&A->sdia_mask, (size_t)n_rows)) != hipSuccess ||
-                    (e = hipMalloc(&A->sdia_val, es * (size_t)std::max<int64_t>(slots, 1))) != hipSuccess ||
-                    (e = hipMemcpy(A->sdia_ptr, dptr.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice)) != hipSuccess ||
-                    (e = hipMemcpy(A->sdia_off, doff.data(), sizeof(int) * (size_t)nb * 8, hipMemcpyHostToDevice)) != hipSuccess ||
-                    (e = hipMemcpy(A->sdia_mask, dmask.data(), (size_t)n_rows, hipMemcpyHostToDevice)) != hipSuccess ||
-                    (slots && (e = hipMemcpy(A->sdia_val, dval.data(), es * (size_t)slots, hipMemcpyHostToDevice)) != hipSuccess)) {
-                    cleanup();
-                    return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: sliced-diagonal form: %s", hipGetErrorString(e));
-                }
-                A->sdia_entries = slots;
             }
         }
     }
