@@ -377,7 +377,7 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
     // distinct (column - row) offsets and the slot padding stays below 1/8 extra entries.
     if (A->n_long == 0 && n_rows > 0 && nnz > 0 && n_cols > 0 && g_mik_tuning[8] == 0 && g_mik_tuning[12] == 0) {
         const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
-        std::vector<int> dptr((size_t)nb + 1, 0), doff((size_t)nb * 8, 0);
+        std::vector<int> dptr((size_t)nb + 1, 0), doff((size_t)nb * 8, 0), dtri((size_t)nb, -1);
         bool ok = true;
         int64_t slots = 0;
         for (int64_t b = 0; b < nb && ok; ++b) {
@@ -406,6 +406,8 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
                 }
             }
             for (int q = 0; q < ns; ++q) doff[(size_t)b * 8 + q] = offs8[q];
+            for (int q = 0; q + 2 < ns; ++q)
+                if (offs8[q + 1] == offs8[q] + 1 && offs8[q + 2] == offs8[q] + 2) { dtri[(size_t)b] = q; break; }
             slots += (int64_t)ns * MIK_BLOCK;
             if (slots >= INT32_MAX) ok = false;
             dptr[(size_t)b + 1] = (int)slots;
@@ -437,6 +439,8 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
             if (ok) {
                 if ((e = hipMalloc((void **)&A->sdia_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
                     (e = hipMalloc((void **)&A->sdia_off, sizeof(int) * (size_t)nb * 8)) != hipSuccess ||
+                    (e = hipMalloc((void **)&A->sdia_tri, sizeof(int) * (size_t)nb)) != hipSuccess ||
+                    (e = hipMemcpy(A->sdia_tri, dtri.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice)) != hipSuccess ||
                     (e = hipMalloc((void **)&A->sdia_mask, (size_t)n_rows)) != hipSuccess ||
                     (e = hipMalloc(&A->sdia_val, es * (size_t)std::max<int64_t>(slots, 1))) != hipSuccess ||
                     (e = hipMemcpy(A->sdia_ptr, dptr.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice)) != hipSuccess ||
@@ -559,6 +563,7 @@ extern "C" int mik_csr_destroy(mik_csr *A)
     if (A->is_long) (void)hipFree(A->is_long);
     if (A->sdia_ptr) (void)hipFree(A->sdia_ptr);
     if (A->sdia_off) (void)hipFree(A->sdia_off);
+    if (A->sdia_tri) (void)hipFree(A->sdia_tri);
     if (A->sdia_mask) (void)hipFree(A->sdia_mask);
     if (A->sdia_val) (void)hipFree(A->sdia_val);
     if (A->sell8_ptr) (void)hipFree(A->sell8_ptr);
@@ -713,7 +718,7 @@ int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_
         // sliced-ELL values + per-slice offsets + row masks (mik_sell.h)
 #define MIK_SDIA_GO(FD, NTV)                                                                                                  \
     hipLaunchKernelGGL((k_spmv_sdia<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, (int)A->n_cols, nb, map_mode, A->sdia_ptr, \
-                       A->sdia_off, A->sdia_mask, (const T *)A->sdia_val, x, y, seg_out, done)
+                       A->sdia_off, A->sdia_tri, A->sdia_mask, (const T *)A->sdia_val, x, y, seg_out, done)
         if (fuse_dot) { if (nt) MIK_SDIA_GO(true, true); else MIK_SDIA_GO(true, false); }
         else          { if (nt) MIK_SDIA_GO(false, true); else MIK_SDIA_GO(false, false); }
 #undef MIK_SDIA_GO

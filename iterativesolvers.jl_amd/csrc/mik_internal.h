@@ -71,6 +71,7 @@ struct mik_csr {
     // sliced-ELL with per-slice offsets + per-row masks (k_spmv_sdia): every slice uses <= 8 distinct offsets
     int *sdia_ptr = nullptr;         // device, nb + 1
     int *sdia_off = nullptr;         // device, nb * 8
+    int *sdia_tri = nullptr;         // device, nb: first slot of an (o-1, o, o+1) run, or -1
     unsigned char *sdia_mask = nullptr;   // device, n_rows
     void *sdia_val = nullptr;        // device, slot-major inside a slice
     int64_t sdia_entries = 0;

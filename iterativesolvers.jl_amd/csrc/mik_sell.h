@@ -146,11 +146,53 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sell8(int n, int nb, int map
 // issued together with the value stream), needs no table lookup, and the index data shrinks from 8 bytes to 1
 // byte per row.  A row's real slots are visited in its own entry order from +0 and absent slots are skipped,
 // so the sum is bit-identical to the other layouts.
+//
+// Runs of offsets (o - 1, o, o + 1) in consecutive slots -- the line neighbours of a stencil -- are served by ONE
+// gather: the centre value moves one lane up / down the wave (shuffles), and only the wave's first and last lane
+// fetch their outer neighbour themselves.  The load path of the CU (64 B/clk), not HBM, is what the 7 gathers of a
+// 7-point row cost (measured: gathers from one and the same address are as slow as the real ones), so every
+// gather avoided counts.  `trio[slice]` = first slot of such a run, or -1.
+// One row of a slice; TRI (compile time) = first slot of the (o-1, o, o+1) run served by shuffles, -1 = none.
+template <typename T, bool NT, int TRI>
+__device__ __forceinline__ T sdia_row(int r, int n, int ncols, int ns, const int *__restrict__ so, const T *__restrict__ vp,
+                                      const unsigned char *__restrict__ mask, const T *__restrict__ x, T &xr, bool &have_xr)
+{
+    constexpr int U = 8;
+    T v[U], xv[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+        const int qq = min(q, ns - 1);                               // clamp: all loads unconditional (batched)
+        v[q] = ld_stream<NT>(vp + (size_t)qq * MIK_BLOCK);
+        if (TRI < 0 || (q != TRI && q != TRI + 2))
+            xv[q] = x[min(max(r + so[qq], 0), ncols - 1)];           // absent slots gather from a valid address
+    }
+    if (TRI >= 0) {
+        const int oc = so[TRI + 1];
+        const T c = xv[TRI + 1];
+        T lo = __shfl_up(c, 1), hi = __shfl_down(c, 1);
+        const int lane = threadIdx.x & 63;
+        if (lane == 0 || lane == 63) {
+            const T e = x[min(max(r + oc + (lane == 0 ? -1 : 1), 0), ncols - 1)];
+            if (lane == 0) lo = e; else hi = e;
+        }
+        xv[TRI >= 0 ? TRI : 0] = lo;
+        xv[TRI >= 0 ? TRI + 2 : 0] = hi;
+        if (oc == 0) { xr = c; have_xr = true; }
+    }
+    const int m = r < n ? (int)mask[r] : 0;
+    T acc = T(0);
+#pragma unroll
+    for (int q = 0; q < U; ++q)
+        if ((m >> q) & 1) { T p = v[q] * xv[q]; acc = acc + p; }
+    return acc;
+}
+
 template <typename T, bool FUSE_DOT, bool NT>
 __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdia(int n, int ncols, int nb, int map_mode, const int *__restrict__ blkptr,
-                                                         const int *__restrict__ offs, const unsigned char *__restrict__ mask,
-                                                         const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y,
-                                                         T *__restrict__ seg_out, const int *__restrict__ done)
+                                                         const int *__restrict__ offs, const int *__restrict__ trio,
+                                                         const unsigned char *__restrict__ mask, const T *__restrict__ val,
+                                                         const T *__restrict__ x, T *__restrict__ y, T *__restrict__ seg_out,
+                                                         const int *__restrict__ done)
 {
     if (done && *done) return;
     constexpr int U = 8;
@@ -160,27 +202,28 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdia(int n, int ncols, int n
     const int r = rb * MIK_BLOCK + t;
     const int base = blkptr[rb];
     const int ns = (blkptr[rb + 1] - base) / MIK_BLOCK;            // offsets used by this slice, <= 8
+    const int tri = trio[rb];
     const int *__restrict__ so = offs + (size_t)rb * U;
     const T *__restrict__ vp = val + base + t;
 
     T acc = T(0);
+    T xr = T(0);
+    bool have_xr = false;
     if (ns > 0) {
-        T v[U], xv[U];
-#pragma unroll
-        for (int q = 0; q < U; ++q) {
-            const int qq = min(q, ns - 1);                           // clamp: all loads unconditional (batched)
-            v[q] = ld_stream<NT>(vp + (size_t)qq * MIK_BLOCK);
-            xv[q] = x[min(max(r + so[qq], 0), ncols - 1)];           // absent slots gather from a valid address
+        switch (tri) {                                              // slice-uniform: one specialised path per run position
+        case 0: acc = sdia_row<T, NT, 0>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
+        case 1: acc = sdia_row<T, NT, 1>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
+        case 2: acc = sdia_row<T, NT, 2>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
+        case 3: acc = sdia_row<T, NT, 3>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
+        case 4: acc = sdia_row<T, NT, 4>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
+        case 5: acc = sdia_row<T, NT, 5>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
+        default: acc = sdia_row<T, NT, -1>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
         }
-        const int m = r < n ? (int)mask[r] : 0;
-#pragma unroll
-        for (int q = 0; q < U; ++q)
-            if ((m >> q) & 1) { T p = v[q] * xv[q]; acc = acc + p; }
     }
     if (r < n) st_stream<NT>(y + r, acc);
     if (FUSE_DOT) {
         T p = T(0);
-        if (r < n) p = x[r] * acc;
+        if (r < n) p = (have_xr ? xr : x[r]) * acc;
         T tot = block_tree_256(p, lds4);
         if (t == 0) seg_out[rb] = tot;
     }
