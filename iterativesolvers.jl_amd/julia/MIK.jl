@@ -267,4 +267,44 @@ end
 
 # zerox(A, b) (src/common.jl:18-23) already works: similar(b, T, size(A, 2)) + fill! are defined above.
 
+# ------------------------------------------------------------------------------------------------
+# gmres! over a row partition (one process per GPU): include/mik.h `mik_partition`
+# ------------------------------------------------------------------------------------------------
+# The handle calls back for the two couplings between ranks; everything else is the iterable above.
+#   halo(user)::Cint                      -- send_buf is packed (stream-ordered); fill x_ext[n_loc+1:n_ext]
+#   reduce(user, dtype, count, values)    -- partial sums in, ((p0 + p1) + p2) + ... in rank order out
+struct Partition                     # same field order and types as the C struct
+    rank::Cint
+    nranks::Cint
+    n_ext::Int64
+    x_ext::Ptr{Cvoid}
+    send_idx::Ptr{Int32}
+    n_send::Int64
+    send_buf::Ptr{Cvoid}
+    halo::Ptr{Cvoid}                 # @cfunction(halo_cb, Cint, (Ptr{Cvoid},))
+    reduce::Ptr{Cvoid}               # @cfunction(reduce_cb, Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}))
+    user::Ptr{Cvoid}
+end
+
+"""
+    gmres_iterable_partitioned!(x, A_loc, b, part; kwargs...)
+
+`A_loc` is this rank's `n_loc x n_ext` block (halo columns behind the owned ones), `x`, `b` its rows.  Returns the
+same `HipGMRESIterable`; drive it with `iterate` / `gmres!`-style loops on every rank in lockstep.
+"""
+function gmres_iterable_partitioned!(x::HipVector{T}, A::HipCSR{T}, b::HipVector{T}, part::Partition; Pl = Identity(), Pr = Identity(),
+        abstol::Real = zero(real(T)), reltol::Real = sqrt(eps(real(T))), restart::Int = 20, maxiter::Int,
+        initially_zero::Bool = false, orth_meth::OrthogonalizationMethod = ClassicalGramSchmidt()) where {T}
+    pl = Pl isa HipJacobi ? Pl.diagonal.ptr : C_NULL
+    pr = Pr isa HipJacobi ? Pr.diagonal.ptr : C_NULL
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:mik_gmres_create_partitioned, libmik), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Cint, Int64, Cint, Cint, Ref{Partition}, Ref{Ptr{Cvoid}}),
+        A.ctx.handle, A.handle, x.ptr, b.ptr, pl, pr, Float64(abstol), Float64(reltol), restart, maxiter, initially_zero ? 1 : 0,
+        orth_code(orth_meth), Ref(part), h), "mik_gmres_create_partitioned", A.ctx.handle)
+    g = HipGMRESIterable{T, typeof(x)}(h[], A, x, b, HipResidual{T}(one(T)), 0, restart, 1, maxiter, zero(T), one(T))
+    finalizer(i -> ccall((:mik_gmres_destroy, libmik), Cint, (Ptr{Cvoid},), i.handle), g)
+    refresh!(g)
+end
+
 end # module
