@@ -89,8 +89,15 @@ int mik_spmv_dot_shape(int *W, int *L);
  * products of entries l, l+64, ... in order, then the wave-64 tree); shorter rows strictly in column
  * order like the reference.  None of the reference's fixtures has such rows. */
 int mik_spmv_long_row(int *threshold);
-/* Development knobs (not part of the reference interface): SpMV kernel variants for A/B timing --
- * key 0: 1 = cached (temporal) val/col/y streams; key 1: 1 = narrow loads; key 2: block map mode. */
+/* Development knobs (not part of the reference interface; results never depend on them) for A/B timing and for
+ * the tests that pin every kernel variant against the oracle.  All default to 0.
+ *   0: 1 = cached (temporal) val/col/y streams in SpMV            1: 1 = narrow loads in the CSR kernel
+ *   2: workgroup map: 0 = operator's choice, < 0 identity, 1 = contiguous range per XCD, P >= 8 = strips of P
+ *   3: 1 = hipStreamSynchronize instead of the event spin wait    4: long-row threshold (> 0), < 0 = no split
+ *   5: 1 = unfused MGS chain, 2 = launch-lean MGS without graphs, 3 = one hipGraph per GMRES column
+ *   6: 1 = ignore the dictionary-coded form                       7: cache hints of the CG vector kernels
+ *   8: 1 = CSR row-block layout only (read at mik_csr_create and at launch)
+ *  10: 1 = no 8-bit column codes                                  12: 1 = no per-slice-offset layout */
 int mik_set_tuning(int key, int value);
 
 /* ---- device memory (similar / zero / copyto! / fill! of the vector interface) ----------- */
