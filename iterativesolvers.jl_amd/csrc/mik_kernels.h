@@ -484,6 +484,7 @@ template <typename T> struct OpJacobiDot {
 template <typename T, bool SELF> struct OpMgsPass {
     static constexpr bool REDUCE = true;
     T *__restrict__ w; const T *__restrict__ v; const T *__restrict__ z; Coef<T> h;
+    int nt = 0;    // 1: v (subtracted here, not needed again in this orthogonalisation) is streamed non-temporally
     __device__ __forceinline__ void set_coef(T c) { h.ptr = nullptr; h.val = c; }
     struct Regs { typename VT<T>::vec wv, vv, zv; };          // load / compute halves of apply_vec (k_map_pro)
     __device__ __forceinline__ void load_vec(int64_t i, Regs &r) const
@@ -511,7 +512,7 @@ template <typename T, bool SELF> struct OpMgsPass {
     __device__ __forceinline__ void apply_vec(int64_t i, T &acc) const
     {
         const T hh = h.get();
-        auto wv = vload<T>(w + i); auto vv = vload(v + i);
+        auto wv = vload<T>(w + i); auto vv = nt ? vload_nt(v + i) : vload(v + i);
         typename VT<T>::vec zv;
         if (!SELF) zv = vload(z + i);
 #pragma unroll
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(MIK_FIN_THREADS) void k_finalize_nrm_inv(const T *_
 template <typename T, bool VEC>
 __global__ __launch_bounds__(MIK_BLOCK) void k_multidot(int64_t n, int64_t nseg, int k, const T *__restrict__ V,
                                                         int64_t ldv, const T *__restrict__ w,
-                                                        T *__restrict__ seg_out /* [k][nseg] */)
+                                                        T *__restrict__ seg_out /* [k][nseg] */, int nt)
 {
     constexpr int W = VT<T>::W;
     constexpr int L = MIK_RED_L;
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_multidot(int64_t n, int64_t nseg,
             for (int l = 0; l < L; ++l) {
                 const int64_t i = base + (int64_t)l * MIK_BLOCK * W;
                 if (VEC && i + W <= n) {
-                    auto cv = vload(col + i);
+                    auto cv = nt ? vload_nt(col + i) : vload(col + i);
 #pragma unroll
                     for (int e = 0; e < W; ++e) { T p = el<T>(cv, e) * wr[l * W + e]; acc = acc + p; }
                 } else {
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_bicg_mr(int64_t n, int64_t nseg, 
 template <typename T, bool VEC>
 __global__ __launch_bounds__(MIK_BLOCK) void k_gemv_n(int64_t n, int64_t nseg, int k, const T *__restrict__ V,
                                                       int64_t ldv, const T *__restrict__ cf, T alpha,
-                                                      T *__restrict__ y)
+                                                      T *__restrict__ y, int nt)
 {
     constexpr int W = VT<T>::W;
     constexpr int L = MIK_RED_L;
@@ -781,7 +782,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_gemv_n(int64_t n, int64_t nseg, i
             for (int l = 0; l < L; ++l) {
                 const int64_t i = base + (int64_t)l * MIK_BLOCK * W;
                 if (VEC && i + W <= n) {
-                    auto cv = vload(col + i);
+                    auto cv = nt ? vload_nt(col + i) : vload(col + i);
 #pragma unroll
                     for (int e = 0; e < W; ++e) { T p = temp * el<T>(cv, e); yr[l * W + e] = yr[l * W + e] + p; }
                 } else {

@@ -85,6 +85,14 @@ extern "C" int mik_hessenberg_ldiv(int dtype, void *H, int64_t ldh, int width, v
 // =============================================================================================
 // gemv-N and orthogonalisation
 // =============================================================================================
+// Stream the Krylov basis past the caches when it cannot stay resident anyway (k columns exceed the 256 MB
+// Infinity Cache), so that the vector being orthogonalised does.  tuning[13] bits switch the hints off for A/B runs.
+template <typename T> static inline int mik_basis_nt(int64_t n, int k, int bit)
+{
+    if (g_mik_tuning[13] & bit) return 0;
+    return (double)n * (double)k * sizeof(T) > 192.0e6 ? 1 : 0;
+}
+
 template <typename T>
 static int gemv_n_dev(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, const T *cf_dev, T alpha, T *y)
 {
@@ -92,8 +100,8 @@ static int gemv_n_dev(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, c
     if (nseg == 0 || k == 0) return MIK_OK;
     const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
     const bool vec = mik_aligned16(V) && mik_aligned16(y) && (ldv % VT<T>::W == 0);
-    if (vec) hipLaunchKernelGGL((k_gemv_n<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, cf_dev, alpha, y);
-    else hipLaunchKernelGGL((k_gemv_n<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, cf_dev, alpha, y);
+    if (vec) hipLaunchKernelGGL((k_gemv_n<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, cf_dev, alpha, y, mik_basis_nt<T>(n, k, 2));
+    else hipLaunchKernelGGL((k_gemv_n<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, cf_dev, alpha, y, 0);
     MIK_LAUNCH_CHECK(ctx);
     return MIK_OK;
 }
@@ -159,8 +167,8 @@ static int multidot(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, con
     }
     const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
     const bool vec = mik_aligned16(V) && mik_aligned16(w) && (ldv % VT<T>::W == 0);
-    if (vec) hipLaunchKernelGGL((k_multidot<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, w, (T *)ctx->partials);
-    else hipLaunchKernelGGL((k_multidot<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, w, (T *)ctx->partials);
+    if (vec) hipLaunchKernelGGL((k_multidot<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, w, (T *)ctx->partials, mik_basis_nt<T>(n, k, 4));
+    else hipLaunchKernelGGL((k_multidot<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, w, (T *)ctx->partials, 0);
     MIK_LAUNCH_CHECK(ctx);
     return finalize_store<T>(ctx, nseg, k, out_dev);
 }
@@ -217,11 +225,11 @@ static int orthogonalize_enqueue(mik_ctx *ctx, int64_t n, int k, const T *V, int
             MIK_TRY((launch_map<T>(ctx, n, d0, vec, part, nullptr)));
             MIK_TRY(finalize_store<T>(ctx, nseg, 1, hd));
             for (int i = 0; i + 1 < k; ++i) {
-                OpMgsPass<T, false> op{w, V + (int64_t)i * ldv, V + (int64_t)(i + 1) * ldv, coef_ptr<T>(hd + i)};
+                OpMgsPass<T, false> op{w, V + (int64_t)i * ldv, V + (int64_t)(i + 1) * ldv, coef_ptr<T>(hd + i), (g_mik_tuning[13] & 1) == 0};
                 MIK_TRY((launch_map<T>(ctx, n, op, vec, part, nullptr)));
                 MIK_TRY(finalize_store<T>(ctx, nseg, 1, hd + i + 1));
             }
-            OpMgsPass<T, true> last{w, V + (int64_t)(k - 1) * ldv, nullptr, coef_ptr<T>(hd + k - 1)};
+            OpMgsPass<T, true> last{w, V + (int64_t)(k - 1) * ldv, nullptr, coef_ptr<T>(hd + k - 1), (g_mik_tuning[13] & 1) == 0};
             MIK_TRY((launch_map<T>(ctx, n, last, vec, part, nullptr)));
         } else {
             MIK_TRY((launch_map<T>(ctx, n, dn, vecw, part, nullptr)));

@@ -99,3 +99,18 @@ def test_orthogonalize_against_an_empty_basis(pkg, orc, ctx, method, dtype):
     want = orc.nrm2(w0, "tree", W, L)
     assert nrm == want and np.array_equal(w.to_numpy(), w0 * (dtype(1) / want))
     assert pkg.gemv_t_(V, 0, w).size == 0
+
+
+@pytest.mark.parametrize("method", ["mgs", "cgs"])
+def test_orthogonalize_large_basis_with_streaming_hints(pkg, orc, ctx, method):
+    """basis larger than the cache budget (n k 8 B > 192 MB): the non-temporal paths of the Gram-Schmidt kernels"""
+    n, k = 3_300_000, 8
+    rng = np.random.default_rng(11)
+    V = np.asfortranarray(rng.standard_normal((n, k)))
+    w0 = rng.standard_normal(n)
+    M = {"mgs": pkg.ModifiedGramSchmidt(), "cgs": pkg.ClassicalGramSchmidt()}[method]
+    dw, h = pkg.HipVector.from_numpy(w0), np.zeros(k)
+    nrm = pkg.orthogonalize_and_normalize_(pkg.HipMatrix.from_numpy(V), k, dw, h, M)
+    W, L = ctx.reduce_shape(np.float64)
+    wo, ho, no = orc.orthogonalize(V, w0, method=method, mode="tree", W=W, L=L)
+    assert nrm == no and np.array_equal(h, ho) and np.array_equal(dw.to_numpy(), wo)
