@@ -212,19 +212,23 @@ int mik_gmres_state(const mik_gmres *it, double *residual, double *tol, double *
 
 /* ---- fused sweeps for the other solvers of the package ------------------------------------------- */
 /* Each call is several consecutive reference statements executed as ONE pass over the vectors, with the
- * same per-element operations in the same order (bit-identical to issuing the L1 calls one by one). */
+ * same per-element operations in the same order (bit-identical to issuing the L1 calls one by one).  `hints` is a
+ * bit mask of operands the caller will not touch again soon: they are streamed past the caches (non-temporal
+ * loads / stores) so that the operands that ARE re-read stay resident; results never depend on it (0 = none). */
 /* y .+= alpha .* x (x NULL: no update); then *out = dot(z, y), or norm(y) when z is NULL
  *   -- src/minres.jl:104+107 and :109+112 */
-int mik_axpy_dot(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, const void *x, void *y, const void *z, void *out);
+int mik_axpy_dot(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, const void *x, void *y, const void *z, void *out,
+                 int hints /* 1: x */);
 /* x .+= alpha .* u; r .-= alpha .* c; *out = norm(r)   -- src/chebyshev.jl:51-54 (same shape as src/cg.jl:58-62) */
-int mik_axpy2_nrm2(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, const void *u, void *x, const void *c, void *r, void *out);
+int mik_axpy2_nrm2(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, const void *u, void *x, const void *c, void *r, void *out,
+                   int hints /* 1: x, 2: c, 4: u */);
 /* c = Pl \ r (pl_diag NULL = Identity); u .= c when `first`, else u .= c .+ beta .* c   -- src/chebyshev.jl:35-45 */
 int mik_cheb_direction(mik_ctx *ctx, int dtype, int64_t n, const void *r, const void *pl_diag, const void *beta, int first, void *u);
 /* v_next .*= inv_h3; w_next .= v_curr .+ neg_h1 .* w_curr .+ neg_h0 .* w_prev (each term skipped when its vector
  * is NULL); w_next .*= inv_h2; x .+= rhs0 .* w_next   -- src/minres.jl:113, :136-142 */
 int mik_minres_update(mik_ctx *ctx, int dtype, int64_t n, const void *inv_h3, void *v_next, const void *v_curr, const void *neg_h1,
                       const void *w_curr, const void *neg_h0, const void *w_prev, const void *inv_h2, void *w_next,
-                      const void *rhs0, void *x);
+                      const void *rhs0, void *x, int hints /* 1: x, 2: w_prev */);
 
 /* M = V' * V for k <= 5 columns in ONE pass over V (all pairwise dots; M is k x k, column-major, host) -- the
  * Gram matrix of src/bicgstabl.jl:120; entry (r, c) equals mik_dot(V[:, r], V[:, c]) bit for bit. */

@@ -94,10 +94,10 @@ SIGNATURES = {
     "mik_gmres_destroy": (C.c_int, [_vp]),
     "mik_gmres_iterate": (C.c_int, [_vp, _i64, _f64p, _ip]),
     "mik_gmres_state": (C.c_int, [_vp, _f64p, _f64p, _f64p, _ip, _i64p, _ip]),
-    "mik_axpy_dot": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "mik_axpy2_nrm2": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mik_axpy_dot": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int]),
+    "mik_axpy2_nrm2": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "mik_cheb_direction": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp, C.c_int, _vp]),
-    "mik_minres_update": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mik_minres_update": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "mik_gram": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _vp, _i64, _vp]),
     "mik_bicgstab_mr_update": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "mik_gather": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp]),

@@ -222,21 +222,21 @@ def norm(x: HipVector):
     return out[0]
 
 
-def axpy_dot_(alpha, x: Optional[HipVector], y: HipVector, z: Optional[HipVector]):
+def axpy_dot_(alpha, x: Optional[HipVector], y: HipVector, z: Optional[HipVector], hints: int = 0):
     """``y .+= alpha .* x`` (skipped when x is None) and, in the same sweep, ``dot(z, y)`` -- or ``norm(y)`` when z is
     None (src/minres.jl:104+107, :109+112)."""
     out = np.zeros(1, y.dtype)
     _, pa = _scalar(y.dtype, 0 if x is None else alpha)
     check(lib().mik_axpy_dot(y.ctx.handle, y.code, y.n, pa, _vp(x.ptr if x is not None else None), _vp(y.ptr),
-                             _vp(z.ptr if z is not None else None), out.ctypes.data_as(_vp)), "mik_axpy_dot", y.ctx.handle)
+                             _vp(z.ptr if z is not None else None), out.ctypes.data_as(_vp), int(hints)), "mik_axpy_dot", y.ctx.handle)
     return out[0]
 
 
-def axpy2_nrm2_(alpha, u: HipVector, x: HipVector, c: HipVector, r: HipVector):
+def axpy2_nrm2_(alpha, u: HipVector, x: HipVector, c: HipVector, r: HipVector, hints: int = 0):
     """``x .+= alpha .* u; r .-= alpha .* c; norm(r)`` in one sweep (src/chebyshev.jl:51-54)."""
     out = np.zeros(1, x.dtype)
     _, pa = _scalar(x.dtype, alpha)
-    check(lib().mik_axpy2_nrm2(x.ctx.handle, x.code, x.n, pa, _vp(u.ptr), _vp(x.ptr), _vp(c.ptr), _vp(r.ptr), out.ctypes.data_as(_vp)),
+    check(lib().mik_axpy2_nrm2(x.ctx.handle, x.code, x.n, pa, _vp(u.ptr), _vp(x.ptr), _vp(c.ptr), _vp(r.ptr), out.ctypes.data_as(_vp), int(hints)),
           "mik_axpy2_nrm2", x.ctx.handle)
     return out[0]
 
@@ -1067,7 +1067,7 @@ class ChebyshevIterable:
                   "mik_cheb_direction", self.x.ctx.handle)                   # :35-45
             mul_(self.c, self.A, self.u)                                     # :48
             self.mv_products += 1
-            self.resnorm = axpy2_nrm2_(self.alpha, self.u, self.x, self.c, self.r)   # :51-54
+            self.resnorm = axpy2_nrm2_(self.alpha, self.u, self.x, self.c, self.r, hints=7)   # :51-54; x, c, u are not re-read
             return self.resnorm, iteration + 1
         self.Pl.ldiv_(self.c, self.r)                                        # :35
         if iteration == 1:                                                   # :37
@@ -1169,7 +1169,7 @@ class MINRESIterable:
         T, H, rhs = self.x.dtype.type, self.H, self.rhs
         mul_(self.v_next, self.A, self.v_curr)                               # :102
         if self.fused:
-            proj = axpy_dot_(-H[1], self.v_prev if iteration > 1 else None, self.v_next, self.v_curr)   # :104, :107
+            proj = axpy_dot_(-H[1], self.v_prev if iteration > 1 else None, self.v_next, self.v_curr, hints=1)   # :104, :107; v_prev is dead
             H[2] = proj
             H[3] = axpy_dot_(-proj, self.v_curr, self.v_next, None)          # :109, :112
         else:
@@ -1197,7 +1197,7 @@ class MINRESIterable:
             check(lib().mik_minres_update(self.x.ctx.handle, self.x.code, self.x.n, sc[0][1], _vp(self.v_next.ptr), _vp(self.v_curr.ptr),
                                           sc[1][1], _vp(self.w_curr.ptr if iteration > 1 else None),
                                           sc[2][1], _vp(self.w_prev.ptr if iteration > 2 else None),
-                                          sc[3][1], _vp(self.w_next.ptr), sc[4][1], _vp(self.x.ptr)), "mik_minres_update", self.x.ctx.handle)
+                                          sc[3][1], _vp(self.w_next.ptr), sc[4][1], _vp(self.x.ptr), 3), "mik_minres_update", self.x.ctx.handle)
         else:
             self.w_next.copyto_(self.v_curr)                                 # :136
             if iteration > 1:

@@ -895,39 +895,40 @@ extern "C" int mik_scal(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, v
 // fused sweeps of the widened solvers (one pass over HBM instead of the reference's 2-6)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-static int axpy_dot_impl(mik_ctx *ctx, int64_t n, const void *alpha, const void *x, void *y, const void *z, void *out)
+static int axpy_dot_impl(mik_ctx *ctx, int64_t n, const void *alpha, const void *x, void *y, const void *z, void *out, int hints)
 {
     MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(mik_nseg<T>(n), 1)));
-    OpAxpyDot<T> op{(const T *)x, (T *)y, (const T *)z, x ? *(const T *)alpha : T(0)};
+    OpAxpyDot<T> op{(const T *)x, (T *)y, (const T *)z, x ? *(const T *)alpha : T(0), hints};
     const bool vec = mik_aligned16(y) && (!x || mik_aligned16(x)) && (!z || mik_aligned16(z));
     MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)ctx->partials, nullptr)));
     return reduce_to_host<T>(ctx, n, z == nullptr, (T *)out);
 }
 
-extern "C" int mik_axpy_dot(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, const void *x, void *y, const void *z, void *out)
+extern "C" int mik_axpy_dot(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, const void *x, void *y, const void *z, void *out,
+                            int hints)
 {
     if (!ctx || n < 0 || !out || (x && !alpha) || (n && !y)) return MIK_ERR_INVALID;
-    if (dtype == MIK_F64) return axpy_dot_impl<double>(ctx, n, alpha, x, y, z, out);
-    if (dtype == MIK_F32) return axpy_dot_impl<float>(ctx, n, alpha, x, y, z, out);
+    if (dtype == MIK_F64) return axpy_dot_impl<double>(ctx, n, alpha, x, y, z, out, hints);
+    if (dtype == MIK_F32) return axpy_dot_impl<float>(ctx, n, alpha, x, y, z, out, hints);
     return MIK_ERR_INVALID;
 }
 
 template <typename T>
-static int axpy2_nrm2_impl(mik_ctx *ctx, int64_t n, const void *alpha, const void *u, void *x, const void *c, void *r, void *out)
+static int axpy2_nrm2_impl(mik_ctx *ctx, int64_t n, const void *alpha, const void *u, void *x, const void *c, void *r, void *out, int hints)
 {
     MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(mik_nseg<T>(n), 1)));
-    OpCgUpdate<T> op{(T *)x, (T *)r, (const T *)u, (const T *)c, coef_val(*(const T *)alpha), 0};
+    OpCgUpdate<T> op{(T *)x, (T *)r, (const T *)u, (const T *)c, coef_val(*(const T *)alpha), hints & 7};
     const bool vec = mik_aligned16(u) && mik_aligned16(x) && mik_aligned16(c) && mik_aligned16(r);
     MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)ctx->partials, nullptr)));
     return reduce_to_host<T>(ctx, n, true, (T *)out);
 }
 
 extern "C" int mik_axpy2_nrm2(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, const void *u, void *x, const void *c, void *r,
-                              void *out)
+                              void *out, int hints)
 {
     if (!ctx || n < 0 || !out || !alpha || (n && (!u || !x || !c || !r))) return MIK_ERR_INVALID;
-    if (dtype == MIK_F64) return axpy2_nrm2_impl<double>(ctx, n, alpha, u, x, c, r, out);
-    if (dtype == MIK_F32) return axpy2_nrm2_impl<float>(ctx, n, alpha, u, x, c, r, out);
+    if (dtype == MIK_F64) return axpy2_nrm2_impl<double>(ctx, n, alpha, u, x, c, r, out, hints);
+    if (dtype == MIK_F32) return axpy2_nrm2_impl<float>(ctx, n, alpha, u, x, c, r, out, hints);
     return MIK_ERR_INVALID;
 }
 
@@ -950,11 +951,11 @@ extern "C" int mik_cheb_direction(mik_ctx *ctx, int dtype, int64_t n, const void
 template <typename T>
 static int minres_update_impl(mik_ctx *ctx, int64_t n, const void *inv_h3, void *v_next, const void *v_curr, const void *neg_h1,
                               const void *w_curr, const void *neg_h0, const void *w_prev, const void *inv_h2, void *w_next,
-                              const void *rhs0, void *x)
+                              const void *rhs0, void *x, int hints)
 {
     OpMinresUpdate<T> op{(T *)v_next, (const T *)v_curr, (const T *)w_curr, (const T *)w_prev, (T *)w_next, (T *)x,
                          *(const T *)inv_h3, w_curr ? *(const T *)neg_h1 : T(0), w_prev ? *(const T *)neg_h0 : T(0), *(const T *)inv_h2,
-                         *(const T *)rhs0};
+                         *(const T *)rhs0, hints};
     const bool vec = mik_aligned16(v_next) && mik_aligned16(v_curr) && mik_aligned16(w_next) && mik_aligned16(x) &&
                      (!w_curr || mik_aligned16(w_curr)) && (!w_prev || mik_aligned16(w_prev));
     return launch_map<T>(ctx, n, op, vec, (T *)nullptr, nullptr);
@@ -962,13 +963,13 @@ static int minres_update_impl(mik_ctx *ctx, int64_t n, const void *inv_h3, void 
 
 extern "C" int mik_minres_update(mik_ctx *ctx, int dtype, int64_t n, const void *inv_h3, void *v_next, const void *v_curr,
                                  const void *neg_h1, const void *w_curr, const void *neg_h0, const void *w_prev, const void *inv_h2,
-                                 void *w_next, const void *rhs0, void *x)
+                                 void *w_next, const void *rhs0, void *x, int hints)
 {
     if (!ctx || n < 0 || !inv_h3 || !inv_h2 || !rhs0 || (w_curr && !neg_h1) || (w_prev && !neg_h0) ||
         (n && (!v_next || !v_curr || !w_next || !x)))
         return MIK_ERR_INVALID;
-    if (dtype == MIK_F64) return minres_update_impl<double>(ctx, n, inv_h3, v_next, v_curr, neg_h1, w_curr, neg_h0, w_prev, inv_h2, w_next, rhs0, x);
-    if (dtype == MIK_F32) return minres_update_impl<float>(ctx, n, inv_h3, v_next, v_curr, neg_h1, w_curr, neg_h0, w_prev, inv_h2, w_next, rhs0, x);
+    if (dtype == MIK_F64) return minres_update_impl<double>(ctx, n, inv_h3, v_next, v_curr, neg_h1, w_curr, neg_h0, w_prev, inv_h2, w_next, rhs0, x, hints);
+    if (dtype == MIK_F32) return minres_update_impl<float>(ctx, n, inv_h3, v_next, v_curr, neg_h1, w_curr, neg_h0, w_prev, inv_h2, w_next, rhs0, x, hints);
     return MIK_ERR_INVALID;
 }
 

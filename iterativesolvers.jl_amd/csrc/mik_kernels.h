@@ -372,6 +372,7 @@ template <typename T> struct OpCgUpdate {
 template <typename T> struct OpAxpyDot {
     static constexpr bool REDUCE = true;
     const T *x; T *y; const T *z; T alpha;          // z may alias y's storage only as "null = y itself"
+    int nt = 0;                                       // bit 0: x is streamed (not needed again soon)
     __device__ __forceinline__ void apply(int64_t i, T &acc) const
     {
         T yv = y[i];
@@ -384,7 +385,7 @@ template <typename T> struct OpAxpyDot {
         typename VT<T>::vec zv;
         if (z) zv = vload(z + i);
         if (x) {
-            auto xv = vload(x + i);
+            auto xv = (nt & 1) ? vload_nt(x + i) : vload(x + i);
 #pragma unroll
             for (int e = 0; e < VT<T>::W; ++e) { T t = alpha * el<T>(xv, e); el<T>(yv, e) = el<T>(yv, e) + t; }
             vstore(y + i, yv);
@@ -402,6 +403,7 @@ template <typename T> struct OpMinresUpdate {
     T *__restrict__ v_next; const T *__restrict__ v_curr; const T *__restrict__ w_curr; const T *__restrict__ w_prev;
     T *__restrict__ w_next; T *__restrict__ x;
     T inv_h3, neg_h1, neg_h0, inv_h2, rhs0;
+    int nt = 0;                                       // bit 0: x streamed, bit 1: w_prev streamed (dead afterwards)
     __device__ __forceinline__ void apply(int64_t i, T &) const
     {
         v_next[i] = v_next[i] * inv_h3;
@@ -414,10 +416,11 @@ template <typename T> struct OpMinresUpdate {
     }
     __device__ __forceinline__ void apply_vec(int64_t i, T &) const
     {
-        auto vn = vload<T>(v_next + i); auto w = vload(v_curr + i); auto xv = vload<T>(x + i);
+        auto vn = vload<T>(v_next + i); auto w = vload(v_curr + i);
+        auto xv = (nt & 1) ? vload_nt<T>(x + i) : vload<T>(x + i);
         typename VT<T>::vec wc, wp;
         if (w_curr) wc = vload(w_curr + i);
-        if (w_prev) wp = vload(w_prev + i);
+        if (w_prev) wp = (nt & 2) ? vload_nt(w_prev + i) : vload(w_prev + i);
 #pragma unroll
         for (int e = 0; e < VT<T>::W; ++e) {
             el<T>(vn, e) = el<T>(vn, e) * inv_h3;
@@ -428,7 +431,8 @@ template <typename T> struct OpMinresUpdate {
             el<T>(w, e) = we;
             T t = rhs0 * we; el<T>(xv, e) = el<T>(xv, e) + t;
         }
-        vstore(v_next + i, vn); vstore(w_next + i, w); vstore(x + i, xv);
+        vstore(v_next + i, vn); vstore(w_next + i, w);
+        if (nt & 1) vstore_nt(x + i, xv); else vstore(x + i, xv);
     }
 };
 

@@ -177,13 +177,13 @@ def test_fused_entry_points_against_numpy(pkg, orc, ctx, dtype, n, shift):
     assert np.array_equal(dy.to_numpy(), y1) and got == orc.dot(z, y1, "tree", W, L)
     got = pkg.axpy_dot_(alpha, None, dy, dz)                                    # no update, just the projection
     assert np.array_equal(dy.to_numpy(), y1) and got == orc.dot(z, y1, "tree", W, L)
-    got = pkg.axpy_dot_(alpha, dz, dy, None)                                    # update + norm
+    got = pkg.axpy_dot_(alpha, dz, dy, None, hints=1)                           # update + norm, x streamed
     y2 = y1 + alpha * z
     assert np.array_equal(dy.to_numpy(), y2) and got == orc.nrm2(y2, "tree", W, L)
     # x += a u; r -= a c; norm(r)
     u, xs, c, r = (rng.standard_normal(n).astype(dtype) for _ in range(4))
     (_, du), (_, dxs), (_, dc), (_, dr) = dev(u), dev(xs), dev(c), dev(r)
-    got = pkg.axpy2_nrm2_(alpha, du, dxs, dc, dr)
+    got = pkg.axpy2_nrm2_(alpha, du, dxs, dc, dr, hints=7 if n > 1000 else 0)
     r1 = r - alpha * c
     assert np.array_equal(dxs.to_numpy(), xs + alpha * u) and np.array_equal(dr.to_numpy(), r1) and got == orc.nrm2(r1, "tree", W, L)
     # Chebyshev direction
@@ -206,7 +206,7 @@ def test_fused_entry_points_against_numpy(pkg, orc, ctx, dtype, n, shift):
         p = [sc[i:i + 1].ctypes.data_as(C.c_void_p) for i in range(5)]
         assert L_.mik_minres_update(ctx.handle, dvn.code, n, p[0], C.c_void_p(dvn.ptr), C.c_void_p(dvc.ptr), p[1],
                                     C.c_void_p(dwc.ptr if use_c else None), p[2], C.c_void_p(dwp.ptr if use_p else None), p[3],
-                                    C.c_void_p(dwn.ptr), p[4], C.c_void_p(dxx.ptr)) == 0
+                                    C.c_void_p(dwn.ptr), p[4], C.c_void_p(dxx.ptr), 3 if use_p else 0) == 0
         w = vc.copy()
         if use_c:
             w = w + sc[1] * wc
