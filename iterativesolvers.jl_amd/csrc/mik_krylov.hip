@@ -318,6 +318,51 @@ struct CgMirror {
     unsigned long long seq;
 };
 
+// Level 2 of a reduction spread over MIK_FIN_WGS single-wave workgroups (the single 1024-thread workgroup of
+// level2_sum pulls its 64 k partials through ONE CU: ~10 us at 256^3).  Workgroup w plays virtual threads
+// 64 w .. 64 w + 63 of the same 1024-thread shape (serial stride-1024 sums, then the wave tree); the workgroup that
+// arrives last at the ticket adds the 16 wave sums left to right -- the order block_tree_1024 uses -- so the
+// total is bit-identical.  Returns true in lane 0 of that last workgroup only.
+constexpr int MIK_FIN_WGS = MIK_FIN_THREADS / 64;
+template <typename T> struct FinScratch { T ws[MIK_FIN_WGS]; unsigned ticket; };
+
+template <typename T> __device__ __forceinline__ bool level2_sum_spread(const T *__restrict__ S, int64_t m, FinScratch<T> *fs, T &tot)
+{
+    const int w = blockIdx.x, lane = threadIdx.x;              // blockDim.x == 64, gridDim.x == MIK_FIN_WGS
+    T acc = T(0);
+    int64_t j = 64 * (int64_t)w + lane;
+    for (; j + 31 * (int64_t)MIK_FIN_THREADS < m; j += 32 * (int64_t)MIK_FIN_THREADS) {
+        T v[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v[q] = S[j + q * (int64_t)MIK_FIN_THREADS];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) acc = acc + v[q];
+    }
+    for (; j + 7 * (int64_t)MIK_FIN_THREADS < m; j += 8 * (int64_t)MIK_FIN_THREADS) {
+        T v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = S[j + q * (int64_t)MIK_FIN_THREADS];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = acc + v[q];
+    }
+    for (; j < m; j += MIK_FIN_THREADS) acc = acc + S[j];
+    acc = wave_tree(acc);
+    bool last = false;
+    if (lane == 0) {
+        __hip_atomic_store(&fs->ws[w], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned tk = __hip_atomic_fetch_add(&fs->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (tk == (unsigned)gridDim.x - 1u) {
+            T t = __hip_atomic_load(&fs->ws[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int q = 1; q < MIK_FIN_WGS; ++q) t = t + __hip_atomic_load(&fs->ws[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&fs->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tot = t;
+            last = true;
+        }
+    }
+    return last;
+}
+
 // after norm(r) of cg_iterator! (src/cg.jl:140-152)
 template <typename T>
 __global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_init(const T *__restrict__ S, int64_t m, CgDev<T> *d, T reltol, T abstol,
@@ -343,12 +388,11 @@ __global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_init(const T *__rest
 
 // alpha = residual^2 / dot(u, c) (src/cg.jl:55) or rho / dot(u, c) (:90)
 template <typename T>
-__global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_alpha(const T *__restrict__ S, int64_t m, CgDev<T> *d, int pcg)
+__global__ __launch_bounds__(64) void k_cg_fin_alpha(const T *__restrict__ S, int64_t m, CgDev<T> *d, int pcg, FinScratch<T> *fs)
 {
     if (d->done) return;
-    __shared__ T lds16[16];
-    T tot = level2_sum(S, m, lds16);
-    if (threadIdx.x == 0) {
+    T tot;
+    if (level2_sum_spread(S, m, fs, tot)) {
         d->dot_uc = tot;
         const T num = pcg ? d->rho : d->res * d->res;
         d->alpha = num / tot;
@@ -357,12 +401,11 @@ __global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_alpha(const T *__res
 
 // rho = dot(c, r); beta = rho / rho_prev (src/cg.jl:81-85)
 template <typename T>
-__global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_rho(const T *__restrict__ S, int64_t m, CgDev<T> *d)
+__global__ __launch_bounds__(64) void k_cg_fin_rho(const T *__restrict__ S, int64_t m, CgDev<T> *d, FinScratch<T> *fs)
 {
     if (d->done) return;
-    __shared__ T lds16[16];
-    T tot = level2_sum(S, m, lds16);
-    if (threadIdx.x == 0) {
+    T tot;
+    if (level2_sum_spread(S, m, fs, tot)) {
         const T rho_prev = d->rho;
         d->rho = tot;
         d->beta = tot / rho_prev;
@@ -372,18 +415,17 @@ __global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_rho(const T *__restr
 // residual = norm(r) (src/cg.jl:61-62 / :96), history, and the stopping test of :36 for the NEXT
 // iterate() call (iteration index `it_next`)
 template <typename T>
-__global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_res(const T *__restrict__ S, int64_t m, CgDev<T> *d, T *__restrict__ hist,
-                                                                long long it_next, long long maxiter, CgMirror *mirror,
-                                                                unsigned long long seq, int hist_index)
+__global__ __launch_bounds__(64) void k_cg_fin_res(const T *__restrict__ S, int64_t m, CgDev<T> *d, T *__restrict__ hist,
+                                                    long long it_next, long long maxiter, CgMirror *mirror,
+                                                    unsigned long long seq, int hist_index, FinScratch<T> *fs)
 {
     if (d->done) {
         // a no-op step (the stopping test fired earlier in this batch): still publish, state unchanged
-        if (threadIdx.x == 0) __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
-    __shared__ T lds16[16];
-    T tot = level2_sum(S, m, lds16);
-    if (threadIdx.x == 0) {
+    T tot;
+    if (level2_sum_spread(S, m, fs, tot)) {
         const T prev = d->res;
         const T res = mik_sqrt(tot);
         d->rr = tot;
@@ -409,6 +451,7 @@ struct mik_cg {
     void *x = nullptr, *u = nullptr, *r = nullptr, *c = nullptr;
     const void *b = nullptr, *diag = nullptr;
     void *dev = nullptr;       // CgDev<T>
+    void *fin = nullptr;       // FinScratch<T>: wave sums + ticket of the spread level-2 reductions
     void *hist = nullptr;      // device history of one iterate_many call
     int64_t hist_cap = 0;
     void *seg_spmv = nullptr;  // one partial per row-block
@@ -470,7 +513,7 @@ template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next, 
         // c = Pl \ r; rho = dot(c, r)                                   src/cg.jl:79-82
         OpJacobiDot<T> pj{r, (const T *)it->diag, c};
         MIK_TRY((launch_map<T>(ctx, n, pj, vec, (T *)it->seg_vec, done)));
-        hipLaunchKernelGGL((k_cg_fin_rho<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)it->seg_vec, nseg, d);
+        hipLaunchKernelGGL((k_cg_fin_rho<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_vec, nseg, d, (FinScratch<T> *)it->fin);
         MIK_LAUNCH_CHECK(ctx);
         // u .= c .+ beta .* u                                           src/cg.jl:86
         OpXpby<T> op{c, u, coef_ptr<T>(&d->beta)};
@@ -484,14 +527,14 @@ template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next, 
     if (it->profile) { hipEvent_t e = cg_profile_event(it); if (e) (void)hipEventRecord(e, ctx->stream); }
     MIK_TRY(mik_spmv_launch<T>(ctx, it->A, u, c, true, (T *)it->seg_spmv, done));
     if (it->profile) { hipEvent_t e = cg_profile_event(it); if (e) (void)hipEventRecord(e, ctx->stream); }
-    hipLaunchKernelGGL((k_cg_fin_alpha<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)it->seg_spmv, nb, d, pcg);
+    hipLaunchKernelGGL((k_cg_fin_alpha<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_spmv, nb, d, pcg, (FinScratch<T> *)it->fin);
     MIK_LAUNCH_CHECK(ctx);
     // x .+= alpha .* u; r .-= alpha .* c; norm(r)                       src/cg.jl:58-62
     OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints() >> 3};
     MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done)));
     it->seq += 1;
-    hipLaunchKernelGGL((k_cg_fin_res<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)it->seg_vec, nseg, d, (T *)it->hist,
-                       it_next, (long long)it->maxiter, it->mirror, it->seq, hist_index);
+    hipLaunchKernelGGL((k_cg_fin_res<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_vec, nseg, d, (T *)it->hist,
+                       it_next, (long long)it->maxiter, it->mirror, it->seq, hist_index, (FinScratch<T> *)it->fin);
     MIK_LAUNCH_CHECK(ctx);
     return MIK_OK;
 }
@@ -578,7 +621,8 @@ extern "C" int mik_cg_create(mik_ctx *ctx, const mik_csr *A, void *x, const void
     const int64_t nb = mik_spmv_nwg(n);
     hipError_t e;
     (void)hipSetDevice(ctx->device);
-    if ((e = hipMalloc(&it->dev, 256)) != hipSuccess || (e = hipMalloc(&it->seg_spmv, es * (size_t)std::max<int64_t>(nb, 1))) != hipSuccess ||
+    if ((e = hipMalloc(&it->dev, 256)) != hipSuccess || (e = hipMalloc(&it->fin, 256)) != hipSuccess ||
+        (e = hipMemset(it->fin, 0, 256)) != hipSuccess || (e = hipMalloc(&it->seg_spmv, es * (size_t)std::max<int64_t>(nb, 1))) != hipSuccess ||
         (e = hipMalloc(&it->seg_vec, es * (size_t)std::max<int64_t>(nseg, 1))) != hipSuccess ||
         (e = hipMalloc(&it->hist, es * 64)) != hipSuccess) {
         mik_cg_destroy(it);
@@ -602,6 +646,7 @@ extern "C" int mik_cg_destroy(mik_cg *it)
     if (!it) return MIK_OK;
     if (it->ctx) (void)hipStreamSynchronize(it->ctx->stream);
     if (it->dev) (void)hipFree(it->dev);
+    if (it->fin) (void)hipFree(it->fin);
     if (it->hist) (void)hipFree(it->hist);
     if (it->seg_spmv) (void)hipFree(it->seg_spmv);
     if (it->seg_vec) (void)hipFree(it->seg_vec);
