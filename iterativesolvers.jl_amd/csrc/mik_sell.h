@@ -152,6 +152,9 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sell8(int n, int nb, int map
 // fetch their outer neighbour themselves.  The load path of the CU (64 B/clk), not HBM, is what the 7 gathers of a
 // 7-point row cost (measured: gathers from one and the same address are as slow as the real ones), so every
 // gather avoided counts.  `trio[slice]` = first slot of such a run, or -1.
+// (Measured and dropped: 2 or 4 neighbouring slices per 512- / 1024-thread workgroup passing their centre values
+// through LDS, which also removes the +-N_x gathers of the inner slices -- 225 / 255 us vs 219 us: the barrier and
+// the larger workgroups cost more than the gathers they save.)
 // One row of a slice; TRI (compile time) = first slot of the (o-1, o, o+1) run served by shuffles, -1 = none.
 template <typename T, bool NT, int TRI>
 __device__ __forceinline__ T sdia_row(int r, int n, int ncols, int ns, const int *__restrict__ so, const T *__restrict__ vp,
