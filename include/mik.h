@@ -293,6 +293,11 @@ int mik_cgd_destroy(mik_cgd *it);
  * dot(u, c), [all-gather dot], 2 = alpha, x += alpha u, r -= alpha c, local |r|^2, [all-gather rr],
  * 3 = residual, beta, stopping test of src/cg.jl:36 for iteration + 1 (later steps become no-ops). */
 int mik_cgd_phase(mik_cgd *it, int phase, int64_t iteration);
+/* Overlap of the halo exchange with the SpMV: row-blocks (256 rows each) [rb_begin, rb_end) of this rank contain no
+ * row that references a halo column.  Step B may then be issued as phase 4 (those row-blocks; needs no halo, so
+ * it runs while the exchange is in flight) followed by phase 5 (the remaining row-blocks + the local dot) -- same
+ * results as phase 1.  MIK_ERR_NOTIMPL if the operator's layout cannot be launched over a range. */
+int mik_cgd_set_interior(mik_cgd *it, int64_t rb_begin, int64_t rb_end);
 /* Wait for everything enqueued; residual / tol / done of the last step and the residuals of the
  * steps executed since the previous wait (at most 1024 steps may be enqueued between waits). */
 int mik_cgd_wait(mik_cgd *it, double *residual, double *tol, int *done, double *history, int64_t cap,

@@ -105,6 +105,7 @@ SIGNATURES = {
                                  C.c_double, C.c_double, _i64, C.c_int, C.POINTER(_vp)]),
     "mik_cgd_destroy": (C.c_int, [_vp]),
     "mik_cgd_phase": (C.c_int, [_vp, C.c_int, _i64]),
+    "mik_cgd_set_interior": (C.c_int, [_vp, _i64, _i64]),
     "mik_cgd_wait": (C.c_int, [_vp, _f64p, _f64p, _ip, _f64p, _i64, _i64p]),
     "mik_hessenberg_ldiv": (C.c_int, [C.c_int, _vp, _i64, C.c_int, _vp]),
     "mik_givens": (C.c_int, [C.c_int, _vp, _vp, _vp]),

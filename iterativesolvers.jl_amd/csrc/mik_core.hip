@@ -692,17 +692,43 @@ extern "C" int mik_csr_info(const mik_csr *A, int64_t *n_rows, int64_t *n_cols, 
 // SpMV
 // ---------------------------------------------------------------------------------------------
 template <typename T>
+int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done, int rb_begin,
+                          int rb_count);
+
+// Can mik_spmv_launch_range serve a sub-range of row-blocks for this operator (sliced-ELL layouts only)?
+bool mik_spmv_can_split(const mik_csr *A)
+{
+    if (A->packed && g_mik_tuning[6] == 0) return false;
+    return (A->sdia_val || A->sell_val) && g_mik_tuning[8] == 0;
+}
+
+template <typename T>
 int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done)
+{
+    return mik_spmv_launch_range<T>(ctx, A, x, y, fuse_dot, seg_out, done, 0, -1);
+}
+
+// Row-blocks [rb_begin, rb_begin + rb_count) only (rb_count < 0: all).  Partial ranges need mik_spmv_can_split.
+template <typename T>
+int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done, int rb_begin,
+                          int rb_count)
 {
     const int n = (int)A->n_rows;
     if (n == 0) return MIK_OK;
+    const int nb_all = (int)mik_spmv_nwg(n);
+    const bool whole = rb_count < 0 || (rb_begin == 0 && rb_count == nb_all);
+    if (!whole && !mik_spmv_can_split(A)) return mik_fail(ctx, MIK_ERR_NOTIMPL, "SpMV over a row-block range needs a sliced-ELL layout");
+    if (!whole && (rb_begin < 0 || rb_begin + rb_count > nb_all)) return mik_fail(ctx, MIK_ERR_INVALID, "SpMV row-block range out of bounds");
+    if (!whole && rb_count == 0) return MIK_OK;
+    const int rb0 = whole ? 0 : rb_begin;
     // development knobs (mik_set_tuning): [0] 1 = temporal (cached) streams, [1] 1 = narrow loads,
     // [2] block map (0 = the operator's own choice: strips for banded operators, else identity; < 0 identity;
     //     1 contiguous range per XCD; P >= 8 strips of P row-blocks)
-    const int nb = (int)mik_spmv_nwg(n);
+    const int nb = whole ? nb_all : rb_count;
     const bool nt = g_mik_tuning[0] == 0;
     const bool wide = g_mik_tuning[1] == 0;
-    const int map_mode = g_mik_tuning[2] == 0 ? A->strip : std::max(g_mik_tuning[2], 0);
+    int map_mode = g_mik_tuning[2] == 0 ? A->strip : std::max(g_mik_tuning[2], 0);
+    if (!whole && map_mode >= 8 && (rb0 % map_mode != 0 || nb % map_mode != 0)) map_mode = 0;   // strips need whole planes
     if (A->packed && g_mik_tuning[6] == 0) {
         // dictionary-coded operator (mik_csr_pack): 2 B per entry instead of 12, same arithmetic
         if (fuse_dot)
@@ -717,7 +743,7 @@ int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_
     if (A->sdia_val && g_mik_tuning[8] == 0 && g_mik_tuning[12] == 0) {
         // sliced-ELL values + per-slice offsets + row masks (mik_sell.h)
 #define MIK_SDIA_GO(FD, NTV)                                                                                                  \
-    hipLaunchKernelGGL((k_spmv_sdia<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, (int)A->n_cols, nb, map_mode, A->sdia_ptr, \
+    hipLaunchKernelGGL((k_spmv_sdia<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, (int)A->n_cols, rb0, nb, map_mode, A->sdia_ptr, \
                        A->sdia_off, A->sdia_tri, A->sdia_mask, (const T *)A->sdia_val, x, y, seg_out, done)
         if (fuse_dot) { if (nt) MIK_SDIA_GO(true, true); else MIK_SDIA_GO(true, false); }
         else          { if (nt) MIK_SDIA_GO(false, true); else MIK_SDIA_GO(false, false); }
@@ -728,7 +754,7 @@ int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_
     if (A->sell8_codes && g_mik_tuning[8] == 0 && g_mik_tuning[10] == 0) {
         // sliced-ELL values + 8-bit column codes (mik_sell.h)
 #define MIK_SELL8_GO(FD, NTV)                                                                                                 \
-    hipLaunchKernelGGL((k_spmv_sell8<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, map_mode, A->sell_ptr, A->sell8_ptr, \
+    hipLaunchKernelGGL((k_spmv_sell8<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, rb0, nb, map_mode, A->sell_ptr, A->sell8_ptr, \
                        A->sell8_codes, A->sell8_tab, A->sell8_nd, (const T *)A->sell_val, x, y, seg_out, done)
         if (fuse_dot) { if (nt) MIK_SELL8_GO(true, true); else MIK_SELL8_GO(true, false); }
         else          { if (nt) MIK_SELL8_GO(false, true); else MIK_SELL8_GO(false, false); }
@@ -739,7 +765,7 @@ int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_
     if (A->sell_val && g_mik_tuning[8] == 0) {
         // sliced-ELL form (mik_sell.h): coalesced streams, per-thread row sums, no LDS
 #define MIK_SELL_GO(FD, NTV)                                                                                                   \
-    hipLaunchKernelGGL((k_spmv_sell<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, map_mode, A->sell_ptr, A->sell_len, \
+    hipLaunchKernelGGL((k_spmv_sell<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, rb0, nb, map_mode, A->sell_ptr, A->sell_len, \
                        A->sell_col, (const T *)A->sell_val, x, y, seg_out, done)
         if (fuse_dot) { if (nt) MIK_SELL_GO(true, true); else MIK_SELL_GO(true, false); }
         else          { if (nt) MIK_SELL_GO(false, true); else MIK_SELL_GO(false, false); }
@@ -777,6 +803,8 @@ int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_
 }
 template int mik_spmv_launch<double>(mik_ctx *, const mik_csr *, const double *, double *, bool, double *, const int *);
 template int mik_spmv_launch<float>(mik_ctx *, const mik_csr *, const float *, float *, bool, float *, const int *);
+template int mik_spmv_launch_range<double>(mik_ctx *, const mik_csr *, const double *, double *, bool, double *, const int *, int, int);
+template int mik_spmv_launch_range<float>(mik_ctx *, const mik_csr *, const float *, float *, bool, float *, const int *, int, int);
 
 extern "C" int mik_spmv(mik_ctx *ctx, const mik_csr *A, const void *x, void *y)
 {

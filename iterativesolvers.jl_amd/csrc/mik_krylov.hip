@@ -15,6 +15,10 @@
 
 template <typename T>
 int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done);
+template <typename T>
+int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done, int rb_begin,
+                          int rb_count);
+bool mik_spmv_can_split(const mik_csr *A);
 
 
 
@@ -1299,6 +1303,7 @@ struct mik_cgd {
     double abstol = 0, reltol = 0;
     int initially_zero = 1;
     int64_t hist_total = 0;
+    int64_t int_begin = 0, int_end = 0;   // row-blocks [int_begin, int_end) reference no halo column (mik_cgd_set_interior)
 };
 
 extern "C" int mik_cgd_create(mik_ctx *ctx, const mik_csr *A_loc, void *x, const void *b, void *u_ext, void *r, void *c,
@@ -1339,6 +1344,17 @@ extern "C" int mik_cgd_create(mik_ctx *ctx, const mik_csr *A_loc, void *x, const
     memset(bs.mirror, 0, sizeof(CgMirror));
     if ((e = hipMemsetAsync(bs.dev, 0, 256, ctx->stream)) != hipSuccess) return fail("hipMemsetAsync", e);
     *out = it;
+    return MIK_OK;
+}
+
+extern "C" int mik_cgd_set_interior(mik_cgd *it, int64_t rb_begin, int64_t rb_end)
+{
+    if (!it) return MIK_ERR_INVALID;
+    const int64_t nb = mik_spmv_nwg(it->base.n);
+    if (rb_begin < 0 || rb_end < rb_begin || rb_end > nb) return mik_fail(it->base.ctx, MIK_ERR_INVALID, "mik_cgd_set_interior: bad range");
+    if (!mik_spmv_can_split(it->base.A)) return mik_fail(it->base.ctx, MIK_ERR_NOTIMPL, "mik_cgd_set_interior: the operator's layout cannot be launched over a row-block range");
+    it->int_begin = rb_begin;
+    it->int_end = rb_end;
     return MIK_OK;
 }
 
@@ -1404,6 +1420,15 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
     }
     case 1:    // step B
         MIK_TRY(mik_spmv_launch<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done));
+        hipLaunchKernelGGL((k_finalize_store<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)bs.seg_spmv, nb, (int64_t)0, dot_slot, done);
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    case 4:    // step B1: the row-blocks that reference no halo column -- runs while the halo is in flight
+        if (it->int_end <= it->int_begin) return mik_fail(ctx, MIK_ERR_INVALID, "mik_cgd_phase: no interior range set (mik_cgd_set_interior)");
+        return mik_spmv_launch_range<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done, (int)it->int_begin, (int)(it->int_end - it->int_begin));
+    case 5:    // step B2: the row-blocks before and after the interior range, then the local dot(u, c) as in step B
+        MIK_TRY(mik_spmv_launch_range<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done, 0, (int)it->int_begin));
+        MIK_TRY(mik_spmv_launch_range<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done, (int)it->int_end, (int)(nb - it->int_end)));
         hipLaunchKernelGGL((k_finalize_store<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)bs.seg_spmv, nb, (int64_t)0, dot_slot, done);
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;

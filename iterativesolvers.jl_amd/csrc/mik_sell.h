@@ -28,7 +28,7 @@
 constexpr int MIK_SELL_U = 8;     // entries per thread in flight per pass (7-point stencil: one pass)
 
 template <typename T, bool FUSE_DOT, bool NT>
-__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sell(int n, int nb, int map_mode, const int *__restrict__ blkptr,
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sell(int n, int rb0, int nb, int map_mode, const int *__restrict__ blkptr,
                                                          const unsigned char *__restrict__ rlen, const int *__restrict__ col,
                                                          const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y,
                                                          T *__restrict__ seg_out, const int *__restrict__ done)
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sell(int n, int nb, int map_
     constexpr int U = MIK_SELL_U;
     __shared__ T lds4[4];
     const int t = threadIdx.x;
-    const int rb = spmv_block_map((int)blockIdx.x, nb, map_mode);
+    const int rb = rb0 + spmv_block_map((int)blockIdx.x, nb, map_mode);   // this launch covers row-blocks [rb0, rb0 + nb)
     const int r = rb * MIK_BLOCK + t;
     const int base = blkptr[rb];
     const int width = (blkptr[rb + 1] - base) / MIK_BLOCK;     // longest row of this block
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sell(int n, int nb, int map_
 // brings the columns of 8 entries; the value lines are the ones of the plain sliced-ELL form.  Same products, same
 // order, same bits -- 9 instead of 12 bytes per fp64 entry and no row-length array.
 template <typename T, bool FUSE_DOT, bool NT>
-__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sell8(int n, int nb, int map_mode, const int *__restrict__ blkptr,
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sell8(int n, int rb0, int nb, int map_mode, const int *__restrict__ blkptr,
                                                           const int *__restrict__ cptr, const unsigned char *__restrict__ codes,
                                                           const int *__restrict__ dtab_g, int nd, const T *__restrict__ val,
                                                           const T *__restrict__ x, T *__restrict__ y, T *__restrict__ seg_out,
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sell8(int n, int nb, int map
     __shared__ T lds4[4];
     const int t = threadIdx.x;
     dtab[t] = t < nd ? dtab_g[t] : 0;
-    const int rb = spmv_block_map((int)blockIdx.x, nb, map_mode);
+    const int rb = rb0 + spmv_block_map((int)blockIdx.x, nb, map_mode);   // this launch covers row-blocks [rb0, rb0 + nb)
     const int r = rb * MIK_BLOCK + t;
     const int base = blkptr[rb];
     const int width = (blkptr[rb + 1] - base) / MIK_BLOCK;
@@ -191,7 +191,7 @@ __device__ __forceinline__ T sdia_row(int r, int n, int ncols, int ns, const int
 }
 
 template <typename T, bool FUSE_DOT, bool NT>
-__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdia(int n, int ncols, int nb, int map_mode, const int *__restrict__ blkptr,
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdia(int n, int ncols, int rb0, int nb, int map_mode, const int *__restrict__ blkptr,
                                                          const int *__restrict__ offs, const int *__restrict__ trio,
                                                          const unsigned char *__restrict__ mask, const T *__restrict__ val,
                                                          const T *__restrict__ x, T *__restrict__ y, T *__restrict__ seg_out,
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdia(int n, int ncols, int n
     constexpr int U = 8;
     __shared__ T lds4[4];
     const int t = threadIdx.x;
-    const int rb = spmv_block_map((int)blockIdx.x, nb, map_mode);
+    const int rb = rb0 + spmv_block_map((int)blockIdx.x, nb, map_mode);   // this launch covers row-blocks [rb0, rb0 + nb)
     const int r = rb * MIK_BLOCK + t;
     const int base = blkptr[rb];
     const int ns = (blkptr[rb + 1] - base) / MIK_BLOCK;            // offsets used by this slice, <= 8

@@ -31,6 +31,7 @@ _vp = C.c_void_p
 # phases of mik_cgd_phase (include/mik.h)
 INIT_A, INIT_B, INIT_C = 10, 11, 12
 STEP_A, STEP_B, STEP_C, STEP_D = 0, 1, 2, 3
+STEP_B_INTERIOR, STEP_B_REST = 4, 5      # step B split so that the halo exchange overlaps the interior rows
 
 
 # ==============================================================================================
@@ -102,6 +103,26 @@ def complete_plan(plan: HaloPlan, offsets, needs_of_peers):
     return plan
 
 
+def interior_row_blocks(ptr, local_idx, n_loc: int, block: int = 256):
+    """Row-blocks [a, b) (of `block` rows) that contain no row referencing a halo column (local index >= n_loc),
+    when the blocks that do form a prefix and a suffix of the rank's rows (slab partitions); else None."""
+    nb = (n_loc + block - 1) // block
+    ptr = np.asarray(ptr)
+    ghost_entries = np.nonzero(np.asarray(local_idx) >= n_loc)[0]
+    if ghost_entries.size == 0:
+        return (0, nb) if nb else None
+    rows = np.searchsorted(ptr, ghost_entries, side="right") - 1
+    blocks = np.unique(rows // block)
+    a = 0
+    while a < blocks.size and blocks[a] == a:
+        a += 1
+    rest = blocks[a:]
+    b = nb - rest.size
+    if rest.size and not np.array_equal(rest, np.arange(b, nb)):
+        return None
+    return (a, b) if b > a else None
+
+
 # ==============================================================================================
 # communicator
 # ==============================================================================================
@@ -143,6 +164,25 @@ class TorchComm:
             req.wait()             # nccl: makes the current stream wait; gloo: blocks the host
         if staged:
             dev_ghost.copy_(ghost_view)
+
+    def exchange_begin(self, plan: HaloPlan, send_buf, ghost_view):
+        """Start the halo exchange and return a handle for ``exchange_end``.  With RCCL the transfers run on the
+        backend's own stream (ordered after what is already enqueued on the current stream) and the current stream
+        is NOT made to wait yet -- kernels enqueued before ``exchange_end`` overlap the transfer.  Host-staged
+        modes complete the exchange right here."""
+        if (self.size == 1 and not self.force) or (not plan.send and not plan.recv):
+            return None
+        if self.staged and send_buf.is_cuda or not send_buf.is_cuda:
+            self.exchange(plan, send_buf, ghost_view)
+            return None
+        dist = self.dist
+        ops = [dist.P2POp(dist.irecv, ghost_view[off:off + cnt], peer) for peer, off, cnt in plan.recv]
+        ops += [dist.P2POp(dist.isend, send_buf[off:off + cnt], peer) for peer, off, cnt in plan.send]
+        return dist.batch_isend_irecv(ops)
+
+    def exchange_end(self, handle):
+        for req in handle or ():
+            req.wait()             # the current stream waits for the transfers
 
     def all_gather_scalar(self, all_t, rank_slot):
         """all_t[p] <- rank p's all_t[p] (in-place all-gather of one scalar per rank)."""
@@ -188,6 +228,12 @@ class SelfComm:
         return [obj]
 
     def exchange(self, plan, send_buf, ghost_view):
+        pass
+
+    def exchange_begin(self, plan, send_buf, ghost_view):
+        return None
+
+    def exchange_end(self, handle):
         pass
 
     def all_gather_scalar(self, all_t, rank_slot):
@@ -291,6 +337,12 @@ class HipEngine:
                                         plan.rank, plan.nranks, float(abstol), float(reltol), int(maxiter), int(x_loc is None),
                                         C.byref(h)), "mik_cgd_create", self.ctx.handle)
         self.handle = h
+        # overlap of the halo exchange with the rows that need no halo (MIK_DIST_OVERLAP=0 switches it off)
+        self.overlap = False
+        rng = interior_row_blocks(ptr, local_idx, n_loc) if os.environ.get("MIK_DIST_OVERLAP", "1") != "0" else None
+        if rng is not None and L.mik_cgd_set_interior(self.handle, int(rng[0]), int(rng[1])) == 0:
+            self.overlap = True
+            self.interior = rng
         self.ctx.synchronize()
 
     # tensors the communicator works on
@@ -362,8 +414,14 @@ class DistCGIterable:
     def _enqueue_step(self, iteration: int):
         e, comm = self.e, self.comm
         e.phase(STEP_A)
-        comm.exchange(e.plan, e.send_buf, e.ghost_view())
-        e.phase(STEP_B)
+        if getattr(e, "overlap", False):
+            pending = comm.exchange_begin(e.plan, e.send_buf, e.ghost_view())
+            e.phase(STEP_B_INTERIOR)                    # runs while the halo is in flight
+            comm.exchange_end(pending)
+            e.phase(STEP_B_REST)
+        else:
+            comm.exchange(e.plan, e.send_buf, e.ghost_view())
+            e.phase(STEP_B)
         comm.all_gather_scalar(e.dot_all, e.dot_slot())
         e.phase(STEP_C)
         comm.all_gather_scalar(e.rr_all, e.rr_slot())
@@ -578,10 +636,16 @@ class LoopbackCG:
         if max_steps <= 0 or self.done(iteration):
             return np.zeros(0)
         max_steps = min(int(max_steps), self.maxiter - iteration, 1024)
+        split = all(getattr(e, "overlap", False) for e in self.engines)
         for j in range(max_steps):
             self._all(STEP_A)
-            self._exchange()
-            self._all(STEP_B)
+            if split:                                   # same phase order as DistCGIterable with an overlapping halo
+                self._all(STEP_B_INTERIOR)
+                self._exchange()
+                self._all(STEP_B_REST)
+            else:
+                self._exchange()
+                self._all(STEP_B)
             self._gather("dot_all")
             self._all(STEP_C)
             self._gather("rr_all")

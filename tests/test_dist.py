@@ -262,6 +262,42 @@ def test_loopback_hip_engine_matches_partitioned_oracle(pkg, orc, ctx, P, with_x
     assert np.array_equal(lb.solution(), xo)
 
 
+def test_interior_row_blocks_of_a_slab(pkg):
+    d = dist_mod(pkg)
+    N, NZ, P = 16, 12, 3                          # one plane = 256 rows = one row-block
+    offsets = d.partition_rows(N * N * NZ, P, align=N * N)
+    for p, want in ((0, (0, 3)), (1, (1, 3)), (2, (1, 4))):
+        _, pp, ii, vv = d._laplace_rows(pkg, N, NZ, offsets[p], offsets[p + 1], np.float64)
+        li, plan = d.localize_block(pp, ii, offsets, p)
+        assert d.interior_row_blocks(pp, li, plan.n_loc) == want
+    # a partition whose halo rows are scattered over all blocks has no interior range
+    ptr = np.arange(0, 2 * 1024 + 1, 2)
+    li = np.stack([np.arange(1024), np.where(np.arange(1024) % 100 == 0, 1024, np.arange(1024))], axis=1).ravel()
+    assert d.interior_row_blocks(ptr, li, 1024) is None
+    assert d.interior_row_blocks(ptr, np.zeros(2048, np.int64), 1024) == (0, 4)      # no halo at all
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [1, 2, 3])
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_loopback_with_halo_overlap_matches_partitioned_oracle(pkg, orc, ctx, P, overlap, monkeypatch):
+    """slabs with an interior range: step B split into interior rows (before the halo arrives) + boundary rows"""
+    import torch
+    monkeypatch.setenv("MIK_DIST_OVERLAP", overlap)
+    d = dist_mod(pkg)
+    N, NZ = 16, 12
+    shape = ctx.cg_shape(np.float64)
+    stream = torch.cuda.Stream()
+    mk = lambda pp, li, vv, pl, bl, xl: d.HipEngine(pkg, pp, li, vv, pl, bl, xl, abstol=0.0, reltol=1.5e-8, maxiter=10 ** 6, stream=stream)
+    engines, offsets, b = make_engines(pkg, orc, N, NZ, P, mk)
+    assert all(e.overlap == (overlap == "1") for e in engines)
+    lb = d.LoopbackCG(engines, maxiter=10 ** 6)
+    hist = lb.solve()
+    xo, ho = oracle_history(orc, pkg, N, NZ, offsets, b, shape)
+    assert hist.size == ho["iters"] and np.array_equal(hist, ho["resnorm"])
+    assert np.array_equal(lb.solution(), xo)
+
+
 @pytest.mark.gpu
 def test_dist_world1_equals_single_gpu_path(pkg, orc, ctx):
     """P = 1 through DistCGIterable + SelfComm is bit-identical to the fused single-GPU iterable"""
@@ -314,7 +350,7 @@ def _gpu_worker(rank, world, port, N, nz, out_dir):
 @pytest.mark.parametrize("world", [2, 3])
 def test_multiprocess_ranks_on_one_gpu_match_partitioned_oracle(pkg, orc, ctx, tmp_path, world):
     import torch.multiprocessing as mp
-    N, nz = 12, 6
+    N, nz = 16, 4                                 # 4 planes of 256 rows per rank: interior row-blocks exist (halo overlap path)
     port = 29700 + os.getpid() % 200 + world
     mp.spawn(_gpu_worker, args=(world, port, N, nz, str(tmp_path)), nprocs=world, join=True)
     hs = [np.load(tmp_path / f"hist{r}.npy") for r in range(world)]
