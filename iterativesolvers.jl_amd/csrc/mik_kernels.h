@@ -467,6 +467,7 @@ template <typename T> struct OpChebDirection {
 template <typename T> struct OpJacobiDot {
     static constexpr bool REDUCE = true;
     const T *__restrict__ r; const T *__restrict__ d; T *__restrict__ c;
+    int nt = 0;    // 1: the diagonal (read once per iteration) is streamed non-temporally
     __device__ __forceinline__ void apply(int64_t i, T &acc) const
     {
         T v = r[i] / d[i]; c[i] = v;
@@ -474,7 +475,7 @@ template <typename T> struct OpJacobiDot {
     }
     __device__ __forceinline__ void apply_vec(int64_t i, T &acc) const
     {
-        auto rv = vload(r + i); auto dv = vload(d + i); typename VT<T>::vec cv;
+        auto rv = vload(r + i); auto dv = nt ? vload_nt(d + i) : vload(d + i); typename VT<T>::vec cv;
 #pragma unroll
         for (int e = 0; e < VT<T>::W; ++e) el<T>(cv, e) = el<T>(rv, e) / el<T>(dv, e);
         vstore(c + i, cv);

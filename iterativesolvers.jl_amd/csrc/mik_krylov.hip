@@ -515,12 +515,12 @@ template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next, 
     const int pcg = it->diag ? 1 : 0;
     if (pcg) {
         // c = Pl \ r; rho = dot(c, r)                                   src/cg.jl:79-82
-        OpJacobiDot<T> pj{r, (const T *)it->diag, c};
+        OpJacobiDot<T> pj{r, (const T *)it->diag, c, cg_stream_hints() != 0};
         MIK_TRY((launch_map<T>(ctx, n, pj, vec, (T *)it->seg_vec, done)));
         hipLaunchKernelGGL((k_cg_fin_rho<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_vec, nseg, d, (FinScratch<T> *)it->fin);
         MIK_LAUNCH_CHECK(ctx);
         // u .= c .+ beta .* u                                           src/cg.jl:86
-        OpXpby<T> op{c, u, coef_ptr<T>(&d->beta)};
+        OpXpby<T> op{c, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 1};   // c = Pl \\ r is dead after this sweep
         MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
     } else {
         // u .= r .+ beta .* u                                           src/cg.jl:50-51
