@@ -26,7 +26,17 @@ import __graft_entry__ as graft  # noqa: E402
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); copy ceiling 6290 GB/s
 
 
-def cpu_baseline(N: int, iters: int):
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(N: int, iters: int, gpu_history=None):
     """The oracle's reference-shaped CG (serial CSC column-scatter SpMV with Int64 indices, serial
     fused loops, 1 thread) timed on this box's host cores on a bounded sample of the same workload."""
     orc = graft.load_oracle()
@@ -36,11 +46,19 @@ def cpu_baseline(N: int, iters: int):
     t0 = time.perf_counter()
     _, h = orc.cg(A, b, maxiter=iters, mode="seq")
     dt = time.perf_counter() - t0
-    return {"value": h["iters"] / dt, "unit": "iters/s", "cores": 1, "kind": "port",
-            "sample": f"{h['iters']} cg! iterations on the same {N}^3 operator and rhs, oracle/mik_oracle.c mode SEQ "
-                      f"(host shows {os.cpu_count()} cores, {orc.effective_cpus()} usable under the cgroup quota; the reference's "
-                      f"SpMV and broadcasts are single-threaded)",
-            "seconds": dt}
+    out = {"value": h["iters"] / dt, "unit": "iters/s", "cores": 1, "kind": "port",
+           "sample": f"{h['iters']} cg! iterations on the same {N}^3 operator and rhs, oracle/mik_oracle.c mode SEQ "
+                     f"(host shows {os.cpu_count()} cores, {orc.effective_cpus()} usable under the cgroup quota; the reference's "
+                     f"SpMV and broadcasts are single-threaded)",
+           "seconds": dt, "cpu_model": cpu_model(), "final_residual": float(h["resnorm"][-1]) if h["iters"] else None}
+    if gpu_history is not None and h["iters"]:
+        m = min(len(gpu_history), h["iters"])
+        g, c = np.asarray(gpu_history[:m]), np.asarray(h["resnorm"][:m])
+        # deviation of the GPU residual history from this CPU run (a left-to-right CPU sum
+        # carries ~1e-11 of its own rounding error at n = 16.7 M; DESIGN.md section 2 has the pairwise-order floor)
+        out["gpu_vs_cpu_history_max_rel_dev"] = float(np.max(np.abs(g - c) / c))
+        out["history_steps_compared"] = int(m)
+    return out
 
 
 def cpu_baseline_omp(N: int, iters: int):
@@ -107,8 +125,11 @@ def main():
     it = pkg.cg_iterator_(x, A, b, reltol=reltol, initially_zero=True, maxiter=10 ** 9)
 
     iteration = 0
+    gpu_history = []
     for _ in range(Wm):
-        assert it.iterate(iteration) is not None
+        nxt = it.iterate(iteration)
+        assert nxt is not None
+        gpu_history.append(nxt[0])
         iteration += 1
     it.profile(1)
     torch.cuda.synchronize()
@@ -116,6 +137,7 @@ def main():
     for _ in range(K):
         nxt = it.iterate(iteration)          # one host-visible residual per step, like the reference loop
         assert nxt is not None, "CG converged inside the timed region; lower --steps or use reltol=0"
+        gpu_history.append(nxt[0])
         iteration += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -229,7 +251,7 @@ def main():
         "packed_operator": packed,
     }
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(N, args.cpu_iters)
+        out["cpu_baseline"] = cpu_baseline(N, args.cpu_iters, gpu_history)
         try:
             out["cpu_baseline_omp"] = cpu_baseline_omp(N, args.cpu_iters)
         except Exception as e:                      # OpenMP runtime missing on the box: the serial baseline above stands
