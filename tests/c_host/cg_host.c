@@ -7,10 +7,12 @@
  *
  *      gcc -std=c99 -Wall -pedantic -I include tests/c_host/cg_host.c -o cg_host -L iterativesolvers.jl_amd -l:libmik.so
  *      ./cg_host 16            (grid points per dimension)
+ *      ./cg_host 12 gmres      x, history = gmres(A, b; restart = 10, log = true) on the same operator (src/gmres.jl:143,184-222)
  */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "mik.h"
 
@@ -62,6 +64,34 @@ int main(int argc, char **argv)
     CHECK(mik_memcpy_h2d(ctx, db, b, bytes));
     const double zero = 0.0;
     CHECK(mik_fill(ctx, MIK_F64, n, &zero, dx));                       /* zerox(A, b): src/common.jl:18-23 */
+
+    if (argc > 2 && strcmp(argv[2], "gmres") == 0) {
+        mik_gmres *g = NULL;                                            /* gmres_iterable!(x, A, b; restart = 10, initially_zero = true) */
+        CHECK(mik_gmres_create(ctx, A, dx, db, NULL, NULL, 0.0, 1.4901161193847656e-8, 10, n, 1, MIK_MGS, &g));
+        int64_t iteration = 0;
+        for (;;) {
+            double residual;
+            int done;
+            CHECK(mik_gmres_iterate(g, iteration, &residual, &done));
+            if (done) break;
+            printf("%a\n", residual);
+            ++iteration;
+        }
+        double res, tol, beta;
+        int kk, conv;
+        int64_t mv;
+        CHECK(mik_gmres_state(g, &res, &tol, &beta, &kk, &mv, &conv));
+        printf("iters %lld converged %d layout %d mvps %lld\n", (long long)iteration, conv, layout, (long long)mv);
+        double *xg = malloc(bytes);
+        CHECK(mik_memcpy_d2h(ctx, xg, dx, bytes));
+        double sg = 0.0;
+        for (int64_t i = 0; i < n; ++i) sg += xg[i];
+        printf("sum_x %a\n", sg);
+        CHECK(mik_gmres_destroy(g));
+        CHECK(mik_csr_destroy(A));
+        CHECK(mik_ctx_destroy(ctx));
+        return 0;
+    }
 
     mik_cg *it = NULL;                                                  /* cg_iterator!(x, A, b; initially_zero = true) */
     CHECK(mik_cg_create(ctx, A, dx, db, du, dr, dc, NULL, 0.0 /* abstol */, 1.4901161193847656e-8 /* sqrt(eps) */, n /* maxiter */,

@@ -29,17 +29,21 @@ def test_header_is_c99_and_host_fails_cleanly_without_a_device(pkg, tmp_path):
 
 
 @pytest.mark.gpu
-def test_c_host_reproduces_the_oracle_history(pkg, orc, ctx, tmp_path):
+@pytest.mark.parametrize("solver", ["cg", "gmres"])
+def test_c_host_reproduces_the_oracle_history(pkg, orc, ctx, tmp_path, solver):
     exe = build(tmp_path, pkg)
     N = 12
-    p = subprocess.run([exe, str(N)], capture_output=True, text=True, timeout=120)
+    p = subprocess.run([exe, str(N)] + (["gmres"] if solver == "gmres" else []), capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stderr
     lines = p.stdout.split("\n")
     hist = np.array([float.fromhex(s) for s in lines if s.startswith("0x")])
     tail = next(s for s in lines if s.startswith("iters")).split()
     A = orc.laplace(N, 3)
     b = orc.hashed_rhs(A.n)
-    xo, ho = orc.cg(A, b, mode="tree", shape=ctx.cg_shape(np.float64))
+    if solver == "cg":
+        xo, ho = orc.cg(A, b, mode="tree", shape=ctx.cg_shape(np.float64))
+    else:
+        xo, ho = orc.gmres(A, b, restart=10, mode="tree", shape=ctx.reduce_shape(np.float64))
     assert int(tail[1]) == ho["iters"] and int(tail[3]) == int(ho["isconverged"]) and int(tail[7]) == ho["mvps"]
     assert np.array_equal(hist, ho["resnorm"])
     s = 0.0
