@@ -164,10 +164,13 @@ __device__ __forceinline__ T sdia_row(int r, int n, int ncols, int ns, const int
     T v[U], xv[U];
 #pragma unroll
     for (int q = 0; q < U; ++q) {
-        const int qq = min(q, ns - 1);                               // clamp: all loads unconditional (batched)
-        v[q] = ld_stream<NT>(vp + (size_t)qq * MIK_BLOCK);
-        if (TRI < 0 || (q != TRI && q != TRI + 2))
-            xv[q] = x[min(max(r + so[qq], 0), ncols - 1)];           // absent slots gather from a valid address
+        v[q] = T(0);
+        xv[q] = T(0);
+        if (q < ns) {                                                // slice-uniform: slots the slice does not have cost nothing
+            v[q] = ld_stream<NT>(vp + (size_t)q * MIK_BLOCK);
+            if (TRI < 0 || (q != TRI && q != TRI + 2))
+                xv[q] = x[min(max(r + so[q], 0), ncols - 1)];        // absent slots gather from a valid address
+        }
     }
     if (TRI >= 0) {
         const int oc = so[TRI + 1];
