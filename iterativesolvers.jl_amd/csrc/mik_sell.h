@@ -51,13 +51,19 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sell(int n, int rb0, int nb,
         int c[U];
 #pragma unroll
         for (int q = 0; q < U; ++q) {
-            const int jj = min(j0 + q, width - 1);               // clamp: all U loads are unconditional (batched)
-            v[q] = ld_stream<NT>(vp + (size_t)jj * MIK_BLOCK);
-            c[q] = ld_stream<NT>(cp + (size_t)jj * MIK_BLOCK);
+            v[q] = T(0);
+            c[q] = 0;
+            if (j0 + q < width) {                                // slice-uniform: no loads for slots past the slice's width
+                v[q] = ld_stream<NT>(vp + (size_t)(j0 + q) * MIK_BLOCK);
+                c[q] = ld_stream<NT>(cp + (size_t)(j0 + q) * MIK_BLOCK);
+            }
         }
         T xv[U];
 #pragma unroll
-        for (int q = 0; q < U; ++q) xv[q] = x[c[q]];
+        for (int q = 0; q < U; ++q) {
+            xv[q] = T(0);
+            if (j0 + q < width) xv[q] = x[c[q]];
+        }
 #pragma unroll
         for (int q = 0; q < U; ++q)
             if (j0 + q < len) { T p = v[q] * xv[q]; acc = acc + p; }
