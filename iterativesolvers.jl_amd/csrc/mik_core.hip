@@ -213,6 +213,198 @@ extern "C" int mik_fill(mik_ctx *ctx, int dtype, int64_t n, const void *value, v
 }
 
 // ---------------------------------------------------------------------------------------------
+// sliced-ELL layout builders (host side of csrc/mik_sell.h)
+// ---------------------------------------------------------------------------------------------
+// Sliced-ELL with per-slice offsets and per-row masks (k_spmv_sdia): every 256-row slice uses at most 8
+// distinct (column - row) offsets and the slot padding stays below 1/8 extra entries.
+// Leaves A->sdia_* unset (and returns MIK_OK) when the operator does not qualify.
+static int csr_build_sdia(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowptr, const std::vector<int> &col, const std::vector<unsigned char> &v,
+        size_t es, int64_t n_rows, int64_t n_cols, int64_t nnz, int max_row)
+{
+    (void)max_row;
+    hipError_t e;
+    if (A->n_long == 0 && n_rows > 0 && nnz > 0 && n_cols > 0 && g_mik_tuning[8] == 0 && g_mik_tuning[12] == 0)
+    {
+        const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
+        std::vector<int> dptr((size_t)nb + 1, 0), doff((size_t)nb * 8, 0), dtri((size_t)nb, -1);
+        bool ok = true;
+        int64_t slots = 0;
+        for (int64_t b = 0; b < nb && ok; ++b) {
+            // The slice's slot pattern: a common super-sequence of its rows' offset sequences (each row lists its
+            // entries in the order they are summed -- ascending GLOBAL column, which for a rank's block with halo
+            // columns is not ascending local offset), built by merging row after row.
+            int offs8[8];
+            int ns = 0;
+            const int64_t rend = std::min<int64_t>((b + 1) * MIK_BLOCK, n_rows);
+            for (int64_t r = b * MIK_BLOCK; r < rend && ok; ++r) {
+                int p = 0;                                         // next admissible pattern position for this row
+                for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
+                    const int d = col[(size_t)k2] - (int)r;
+                    int q = 0;
+                    while (q < ns && offs8[q] != d) ++q;
+                    if (q < ns) {
+                        if (q < p) { ok = false; break; }          // two rows order the same offsets differently
+                        p = q + 1;
+                    } else {
+                        if (ns == 8) { ok = false; break; }
+                        for (int z = ns; z > p; --z) offs8[z] = offs8[z - 1];
+                        offs8[p] = d;
+                        ++ns;
+                        ++p;
+                    }
+                }
+            }
+            for (int q = 0; q < ns; ++q) doff[(size_t)b * 8 + q] = offs8[q];
+            for (int q = 0; q + 2 < ns; ++q)
+                if (offs8[q + 1] == offs8[q] + 1 && offs8[q + 2] == offs8[q] + 2) { dtri[(size_t)b] = q; break; }
+            slots += (int64_t)ns * MIK_BLOCK;
+            if (slots >= INT32_MAX) ok = false;
+            dptr[(size_t)b + 1] = (int)slots;
+        }
+        if (ok && slots <= nnz + nnz / 8 + 8 * MIK_BLOCK) {
+            std::vector<unsigned char> dval, dmask;
+            try {
+                dval.assign((size_t)slots * es, 0);
+                dmask.assign((size_t)n_rows, 0);
+            } catch (const std::bad_alloc &) {
+                return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host staging allocation failed (sliced-diagonal form)");
+            }
+            for (int64_t r = 0; r < n_rows && ok; ++r) {
+                const int64_t b = r / MIK_BLOCK, t = r % MIK_BLOCK;
+                const int ns = (dptr[(size_t)b + 1] - dptr[(size_t)b]) / MIK_BLOCK;
+                const int *so = &doff[(size_t)b * 8];
+                int q = 0, prevq = -1;
+                for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
+                    const int d = col[(size_t)k2] - (int)r;
+                    while (q < ns && so[q] != d) ++q;             // columns ascend within a row, so do the slots
+                    if (q >= ns || q <= prevq) { ok = false; break; }   // unsorted or duplicate column: keep the other layouts
+                    const size_t dst = (size_t)dptr[(size_t)b] + (size_t)q * MIK_BLOCK + (size_t)t;
+                    memcpy(&dval[dst * es], &v[(size_t)k2 * es], es);
+                    dmask[(size_t)r] |= (unsigned char)(1u << q);
+                    prevq = q;
+                }
+            }
+            if (ok) {
+                if ((e = hipMalloc((void **)&A->sdia_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
+                    (e = hipMalloc((void **)&A->sdia_off, sizeof(int) * (size_t)nb * 8)) != hipSuccess ||
+                    (e = hipMalloc((void **)&A->sdia_tri, sizeof(int) * (size_t)nb)) != hipSuccess ||
+                    (e = hipMemcpy(A->sdia_tri, dtri.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice)) != hipSuccess ||
+                    (e = hipMalloc((void **)&A->sdia_mask, (size_t)n_rows)) != hipSuccess ||
+                    (e = hipMalloc(&A->sdia_val, es * (size_t)std::max<int64_t>(slots, 1))) != hipSuccess ||
+                    (e = hipMemcpy(A->sdia_ptr, dptr.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice)) != hipSuccess ||
+                    (e = hipMemcpy(A->sdia_off, doff.data(), sizeof(int) * (size_t)nb * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+                    (e = hipMemcpy(A->sdia_mask, dmask.data(), (size_t)n_rows, hipMemcpyHostToDevice)) != hipSuccess ||
+                    (slots && (e = hipMemcpy(A->sdia_val, dval.data(), es * (size_t)slots, hipMemcpyHostToDevice)) != hipSuccess)) {
+                    return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: sliced-diagonal form: %s", hipGetErrorString(e));
+                }
+                A->sdia_entries = slots;
+            }
+        }
+    }
+    return MIK_OK;
+}
+
+// Sliced-ELL form (csrc/mik_sell.h): per 256-row block, entry j of all rows contiguous, padded to the block's
+// longest row.  Built when no row was split off as long and padding costs < 1/8 extra entries.
+// (skipped when the per-slice-offset form above exists: mik_spmv would never use it)
+static int csr_build_sell(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowptr, const std::vector<int> &col, const std::vector<unsigned char> &v,
+        size_t es, int64_t n_rows, int64_t n_cols, int64_t nnz, int max_row)
+{
+    (void)n_cols;
+    hipError_t e;
+    if (!A->sdia_val && A->n_long == 0 && n_rows > 0 && nnz > 0 && max_row <= 255 && g_mik_tuning[8] == 0)
+    {
+        const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
+        std::vector<int> sptr((size_t)nb + 1, 0);
+        int64_t padded = 0;
+        for (int64_t b = 0; b < nb; ++b) {
+            int w = 0;
+            for (int64_t r = b * MIK_BLOCK; r < std::min<int64_t>((b + 1) * MIK_BLOCK, n_rows); ++r) w = std::max(w, rowptr[r + 1] - rowptr[r]);
+            padded += (int64_t)w * MIK_BLOCK;
+            if (padded >= INT32_MAX) break;
+            sptr[(size_t)b + 1] = (int)padded;
+        }
+        if (padded < INT32_MAX && padded <= nnz + nnz / 8 + 8 * MIK_BLOCK) {
+            std::vector<int> scol;
+            std::vector<unsigned char> sval, slen;
+            try {
+                scol.assign((size_t)padded, 0);
+                sval.assign((size_t)padded * es, 0);
+                slen.assign((size_t)n_rows, 0);
+            } catch (const std::bad_alloc &) {
+                return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host staging allocation failed (sliced-ELL form)");
+            }
+            for (int64_t r = 0; r < n_rows; ++r) {
+                const int64_t b = r / MIK_BLOCK, t = r % MIK_BLOCK;
+                const int len = rowptr[r + 1] - rowptr[r];
+                slen[(size_t)r] = (unsigned char)len;
+                for (int j = 0; j < len; ++j) {
+                    const size_t dst = (size_t)sptr[(size_t)b] + (size_t)j * MIK_BLOCK + (size_t)t;
+                    scol[dst] = col[(size_t)rowptr[r] + j];
+                    memcpy(&sval[dst * es], &v[((size_t)rowptr[r] + j) * es], es);
+                }
+            }
+            if ((e = hipMalloc((void **)&A->sell_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
+                (e = hipMalloc((void **)&A->sell_len, (size_t)n_rows)) != hipSuccess ||
+                (e = hipMalloc((void **)&A->sell_col, sizeof(int) * (size_t)padded)) != hipSuccess ||
+                (e = hipMalloc(&A->sell_val, es * (size_t)padded)) != hipSuccess ||
+                (e = hipMemcpy(A->sell_ptr, sptr.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(A->sell_len, slen.data(), (size_t)n_rows, hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(A->sell_col, scol.data(), sizeof(int) * (size_t)padded, hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(A->sell_val, sval.data(), es * (size_t)padded, hipMemcpyHostToDevice)) != hipSuccess) {
+                return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: sliced-ELL form: %s", hipGetErrorString(e));
+            }
+            A->sell_entries = padded;
+            for (int64_t b = 0; b < nb; ++b) A->sell_maxw = std::max(A->sell_maxw, (sptr[(size_t)b + 1] - sptr[(size_t)b]) / MIK_BLOCK);
+
+            // 8-bit column codes (k_spmv_sell8): at most 255 distinct (column - row) offsets over the whole operator
+            std::vector<int> tab;
+            std::unordered_map<int, int> code_of;
+            bool ok = g_mik_tuning[10] == 0;
+            for (int64_t r = 0; r < n_rows && ok; ++r)
+                for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
+                    const int d = col[(size_t)k2] - (int)r;
+                    if (code_of.find(d) == code_of.end()) {
+                        if (tab.size() == 255) { ok = false; break; }
+                        code_of.emplace(d, (int)tab.size());
+                        tab.push_back(d);
+                    }
+                }
+            if (ok) {
+                std::vector<int> cptr((size_t)nb + 1, 0);
+                int64_t cbytes = 0;
+                for (int64_t b = 0; b < nb; ++b) {
+                    const int w = (sptr[(size_t)b + 1] - sptr[(size_t)b]) / MIK_BLOCK;
+                    cbytes += (int64_t)((w + 7) / 8 * 8) * MIK_BLOCK;
+                    cptr[(size_t)b + 1] = (int)cbytes;
+                }
+                if (cbytes < INT32_MAX) {
+                    std::vector<unsigned char> codes((size_t)cbytes, 255);
+                    for (int64_t r = 0; r < n_rows; ++r) {
+                        const int64_t b = r / MIK_BLOCK, t = r % MIK_BLOCK;
+                        const int w8 = (cptr[(size_t)b + 1] - cptr[(size_t)b]) / MIK_BLOCK;
+                        unsigned char *dst = &codes[(size_t)cptr[(size_t)b] + (size_t)t * w8];
+                        for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) dst[k2 - rowptr[r]] = (unsigned char)code_of[col[(size_t)k2] - (int)r];
+                    }
+                    tab.resize(256, 0);
+                    if ((e = hipMalloc((void **)&A->sell8_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
+                        (e = hipMalloc((void **)&A->sell8_codes, (size_t)cbytes + 8)) != hipSuccess ||
+                        (e = hipMalloc((void **)&A->sell8_tab, sizeof(int) * 256)) != hipSuccess ||
+                        (e = hipMemcpy(A->sell8_ptr, cptr.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice)) != hipSuccess ||
+                        (e = hipMemcpy(A->sell8_codes, codes.data(), (size_t)cbytes, hipMemcpyHostToDevice)) != hipSuccess ||
+                        (e = hipMemcpy(A->sell8_tab, tab.data(), sizeof(int) * 256, hipMemcpyHostToDevice)) != hipSuccess) {
+                        return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: column codes: %s", hipGetErrorString(e));
+                    }
+                    A->sell8_nd = (int)code_of.size();
+                    A->sell8_bytes = cbytes;
+                }
+            }
+        }
+    }
+    return MIK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // operator upload
 // ---------------------------------------------------------------------------------------------
 extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_cols, int64_t nnz,
@@ -373,181 +565,10 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
             return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create: long-row tables: %s", hipGetErrorString(e));
         }
     }
-    // Sliced-ELL with per-slice offsets and per-row masks (k_spmv_sdia): every 256-row slice uses at most 8
-    // distinct (column - row) offsets and the slot padding stays below 1/8 extra entries.
-    if (A->n_long == 0 && n_rows > 0 && nnz > 0 && n_cols > 0 && g_mik_tuning[8] == 0 && g_mik_tuning[12] == 0) {
-        const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
-        std::vector<int> dptr((size_t)nb + 1, 0), doff((size_t)nb * 8, 0), dtri((size_t)nb, -1);
-        bool ok = true;
-        int64_t slots = 0;
-        for (int64_t b = 0; b < nb && ok; ++b) {
-            // The slice's slot pattern: a common super-sequence of its rows' offset sequences (each row lists its
-            // entries in the order they are summed -- ascending GLOBAL column, which for a rank's block with halo
-            // columns is not ascending local offset), built by merging row after row.
-            int offs8[8];
-            int ns = 0;
-            const int64_t rend = std::min<int64_t>((b + 1) * MIK_BLOCK, n_rows);
-            for (int64_t r = b * MIK_BLOCK; r < rend && ok; ++r) {
-                int p = 0;                                         // next admissible pattern position for this row
-                for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
-                    const int d = col[(size_t)k2] - (int)r;
-                    int q = 0;
-                    while (q < ns && offs8[q] != d) ++q;
-                    if (q < ns) {
-                        if (q < p) { ok = false; break; }          // two rows order the same offsets differently
-                        p = q + 1;
-                    } else {
-                        if (ns == 8) { ok = false; break; }
-                        for (int z = ns; z > p; --z) offs8[z] = offs8[z - 1];
-                        offs8[p] = d;
-                        ++ns;
-                        ++p;
-                    }
-                }
-            }
-            for (int q = 0; q < ns; ++q) doff[(size_t)b * 8 + q] = offs8[q];
-            for (int q = 0; q + 2 < ns; ++q)
-                if (offs8[q + 1] == offs8[q] + 1 && offs8[q + 2] == offs8[q] + 2) { dtri[(size_t)b] = q; break; }
-            slots += (int64_t)ns * MIK_BLOCK;
-            if (slots >= INT32_MAX) ok = false;
-            dptr[(size_t)b + 1] = (int)slots;
-        }
-        if (ok && slots <= nnz + nnz / 8 + 8 * MIK_BLOCK) {
-            std::vector<unsigned char> dval, dmask;
-            try {
-                dval.assign((size_t)slots * es, 0);
-                dmask.assign((size_t)n_rows, 0);
-            } catch (const std::bad_alloc &) {
-                cleanup();
-                return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host staging allocation failed (sliced-diagonal form)");
-            }
-            for (int64_t r = 0; r < n_rows && ok; ++r) {
-                const int64_t b = r / MIK_BLOCK, t = r % MIK_BLOCK;
-                const int ns = (dptr[(size_t)b + 1] - dptr[(size_t)b]) / MIK_BLOCK;
-                const int *so = &doff[(size_t)b * 8];
-                int q = 0, prevq = -1;
-                for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
-                    const int d = col[(size_t)k2] - (int)r;
-                    while (q < ns && so[q] != d) ++q;             // columns ascend within a row, so do the slots
-                    if (q >= ns || q <= prevq) { ok = false; break; }   // unsorted or duplicate column: keep the other layouts
-                    const size_t dst = (size_t)dptr[(size_t)b] + (size_t)q * MIK_BLOCK + (size_t)t;
-                    memcpy(&dval[dst * es], &v[(size_t)k2 * es], es);
-                    dmask[(size_t)r] |= (unsigned char)(1u << q);
-                    prevq = q;
-                }
-            }
-            if (ok) {
-                if ((e = hipMalloc((void **)&A->sdia_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
-                    (e = hipMalloc((void **)&A->sdia_off, sizeof(int) * (size_t)nb * 8)) != hipSuccess ||
-                    (e = hipMalloc((void **)&A->sdia_tri, sizeof(int) * (size_t)nb)) != hipSuccess ||
-                    (e = hipMemcpy(A->sdia_tri, dtri.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice)) != hipSuccess ||
-                    (e = hipMalloc((void **)&A->sdia_mask, (size_t)n_rows)) != hipSuccess ||
-                    (e = hipMalloc(&A->sdia_val, es * (size_t)std::max<int64_t>(slots, 1))) != hipSuccess ||
-                    (e = hipMemcpy(A->sdia_ptr, dptr.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice)) != hipSuccess ||
-                    (e = hipMemcpy(A->sdia_off, doff.data(), sizeof(int) * (size_t)nb * 8, hipMemcpyHostToDevice)) != hipSuccess ||
-                    (e = hipMemcpy(A->sdia_mask, dmask.data(), (size_t)n_rows, hipMemcpyHostToDevice)) != hipSuccess ||
-                    (slots && (e = hipMemcpy(A->sdia_val, dval.data(), es * (size_t)slots, hipMemcpyHostToDevice)) != hipSuccess)) {
-                    cleanup();
-                    return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: sliced-diagonal form: %s", hipGetErrorString(e));
-                }
-                A->sdia_entries = slots;
-            }
-        }
-    }
-    // Sliced-ELL form (csrc/mik_sell.h): per 256-row block, entry j of all rows contiguous, padded to the block's
-    // longest row.  Built when no row was split off as long and padding costs < 1/8 extra entries.
-    // (skipped when the per-slice-offset form above exists: mik_spmv would never use it)
-    if (!A->sdia_val && A->n_long == 0 && n_rows > 0 && nnz > 0 && max_row <= 255 && g_mik_tuning[8] == 0) {
-        const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
-        std::vector<int> sptr((size_t)nb + 1, 0);
-        int64_t padded = 0;
-        for (int64_t b = 0; b < nb; ++b) {
-            int w = 0;
-            for (int64_t r = b * MIK_BLOCK; r < std::min<int64_t>((b + 1) * MIK_BLOCK, n_rows); ++r) w = std::max(w, rowptr[r + 1] - rowptr[r]);
-            padded += (int64_t)w * MIK_BLOCK;
-            if (padded >= INT32_MAX) break;
-            sptr[(size_t)b + 1] = (int)padded;
-        }
-        if (padded < INT32_MAX && padded <= nnz + nnz / 8 + 8 * MIK_BLOCK) {
-            std::vector<int> scol;
-            std::vector<unsigned char> sval, slen;
-            try {
-                scol.assign((size_t)padded, 0);
-                sval.assign((size_t)padded * es, 0);
-                slen.assign((size_t)n_rows, 0);
-            } catch (const std::bad_alloc &) {
-                cleanup();
-                return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host staging allocation failed (sliced-ELL form)");
-            }
-            for (int64_t r = 0; r < n_rows; ++r) {
-                const int64_t b = r / MIK_BLOCK, t = r % MIK_BLOCK;
-                const int len = rowptr[r + 1] - rowptr[r];
-                slen[(size_t)r] = (unsigned char)len;
-                for (int j = 0; j < len; ++j) {
-                    const size_t dst = (size_t)sptr[(size_t)b] + (size_t)j * MIK_BLOCK + (size_t)t;
-                    scol[dst] = col[(size_t)rowptr[r] + j];
-                    memcpy(&sval[dst * es], &v[((size_t)rowptr[r] + j) * es], es);
-                }
-            }
-            if ((e = hipMalloc((void **)&A->sell_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
-                (e = hipMalloc((void **)&A->sell_len, (size_t)n_rows)) != hipSuccess ||
-                (e = hipMalloc((void **)&A->sell_col, sizeof(int) * (size_t)padded)) != hipSuccess ||
-                (e = hipMalloc(&A->sell_val, es * (size_t)padded)) != hipSuccess ||
-                (e = hipMemcpy(A->sell_ptr, sptr.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice)) != hipSuccess ||
-                (e = hipMemcpy(A->sell_len, slen.data(), (size_t)n_rows, hipMemcpyHostToDevice)) != hipSuccess ||
-                (e = hipMemcpy(A->sell_col, scol.data(), sizeof(int) * (size_t)padded, hipMemcpyHostToDevice)) != hipSuccess ||
-                (e = hipMemcpy(A->sell_val, sval.data(), es * (size_t)padded, hipMemcpyHostToDevice)) != hipSuccess) {
-                cleanup();
-                return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: sliced-ELL form: %s", hipGetErrorString(e));
-            }
-            A->sell_entries = padded;
-            for (int64_t b = 0; b < nb; ++b) A->sell_maxw = std::max(A->sell_maxw, (sptr[(size_t)b + 1] - sptr[(size_t)b]) / MIK_BLOCK);
-
-            // 8-bit column codes (k_spmv_sell8): at most 255 distinct (column - row) offsets over the whole operator
-            std::vector<int> tab;
-            std::unordered_map<int, int> code_of;
-            bool ok = g_mik_tuning[10] == 0;
-            for (int64_t r = 0; r < n_rows && ok; ++r)
-                for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
-                    const int d = col[(size_t)k2] - (int)r;
-                    if (code_of.find(d) == code_of.end()) {
-                        if (tab.size() == 255) { ok = false; break; }
-                        code_of.emplace(d, (int)tab.size());
-                        tab.push_back(d);
-                    }
-                }
-            if (ok) {
-                std::vector<int> cptr((size_t)nb + 1, 0);
-                int64_t cbytes = 0;
-                for (int64_t b = 0; b < nb; ++b) {
-                    const int w = (sptr[(size_t)b + 1] - sptr[(size_t)b]) / MIK_BLOCK;
-                    cbytes += (int64_t)((w + 7) / 8 * 8) * MIK_BLOCK;
-                    cptr[(size_t)b + 1] = (int)cbytes;
-                }
-                if (cbytes < INT32_MAX) {
-                    std::vector<unsigned char> codes((size_t)cbytes, 255);
-                    for (int64_t r = 0; r < n_rows; ++r) {
-                        const int64_t b = r / MIK_BLOCK, t = r % MIK_BLOCK;
-                        const int w8 = (cptr[(size_t)b + 1] - cptr[(size_t)b]) / MIK_BLOCK;
-                        unsigned char *dst = &codes[(size_t)cptr[(size_t)b] + (size_t)t * w8];
-                        for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) dst[k2 - rowptr[r]] = (unsigned char)code_of[col[(size_t)k2] - (int)r];
-                    }
-                    tab.resize(256, 0);
-                    if ((e = hipMalloc((void **)&A->sell8_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
-                        (e = hipMalloc((void **)&A->sell8_codes, (size_t)cbytes + 8)) != hipSuccess ||
-                        (e = hipMalloc((void **)&A->sell8_tab, sizeof(int) * 256)) != hipSuccess ||
-                        (e = hipMemcpy(A->sell8_ptr, cptr.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice)) != hipSuccess ||
-                        (e = hipMemcpy(A->sell8_codes, codes.data(), (size_t)cbytes, hipMemcpyHostToDevice)) != hipSuccess ||
-                        (e = hipMemcpy(A->sell8_tab, tab.data(), sizeof(int) * 256, hipMemcpyHostToDevice)) != hipSuccess) {
-                        cleanup();
-                        return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: column codes: %s", hipGetErrorString(e));
-                    }
-                    A->sell8_nd = (int)code_of.size();
-                    A->sell8_bytes = cbytes;
-                }
-            }
-        }
-    }
+    // device layouts for banded / stencil operators (see the two builders above)
+    int rc_layout = csr_build_sdia(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz, max_row);
+    if (rc_layout == MIK_OK) rc_layout = csr_build_sell(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz, max_row);
+    if (rc_layout != MIK_OK) { cleanup(); return rc_layout; }
     *out = A;
     return MIK_OK;
 }
