@@ -1,0 +1,125 @@
+"""A second, independent restatement of the reference in pure Python scalar loops (IEEE double arithmetic, one rounded
+operation per statement, strictly left-to-right sums) for tiny systems, compared BIT FOR BIT with the C oracle's SEQ
+mode.  Two restatements written separately from the same reference lines agreeing exactly is the strongest pin of
+the oracle available without a Julia runtime (the reference stores no residual histories)."""
+import math
+
+import numpy as np
+import pytest
+
+
+def csc_mul(A, x):
+    """mul!(y, A::SparseMatrixCSC, x): column scatter, y[rowval[k]] += nzval[k] * x[col]  (SparseArrays)"""
+    y = [0.0] * A.n
+    for j in range(A.n):
+        for k in range(int(A.colptr[j]) - A.index_base, int(A.colptr[j + 1]) - A.index_base):
+            i = int(A.rowval[k]) - A.index_base
+            y[i] = y[i] + float(A.nzval[k]) * x[j]
+    return y
+
+
+def dot(x, y):
+    s = 0.0
+    for a, b in zip(x, y):
+        s = s + a * b
+    return s
+
+
+def py_cg(A, b, reltol, maxiter):
+    """src/cg.jl:120-155 (cg_iterator!, initially_zero) + :43-66 (iterate) + :209-242 (cg!)"""
+    n = A.n
+    x, u, r = [0.0] * n, [0.0] * n, list(map(float, b))
+    residual = math.sqrt(dot(r, r))                          # :140
+    prev_residual = 1.0                                      # :146
+    tol = max(reltol * residual, 0.0)                        # :141
+    hist = []
+    iteration = 0
+    while not (iteration >= maxiter or residual <= tol):     # :36
+        beta = residual * residual / (prev_residual * prev_residual)   # :50
+        u = [ri + beta * ui for ri, ui in zip(r, u)]         # :51
+        c = csc_mul(A, u)                                    # :54
+        alpha = residual * residual / dot(u, c)              # :55
+        x = [xi + alpha * ui for xi, ui in zip(x, u)]        # :58
+        r = [ri - alpha * ci for ri, ci in zip(r, c)]        # :59
+        prev_residual = residual                             # :61
+        residual = math.sqrt(dot(r, r))                      # :62
+        hist.append(residual)
+        iteration += 1
+    return x, hist
+
+
+def py_gmres_mgs(A, b, restart, reltol, maxiter):
+    """src/gmres.jl:108-136, :57-106, :224-304 with ModifiedGramSchmidt (src/orthogonalize.jl:67-79); x0 = 0.
+    The least-squares solve goes through numpy.linalg.lstsq, so only the residual history (which never touches the
+    Givens rotations, src/gmres.jl:224-233) is compared exactly, and x approximately."""
+    n = A.n
+    x = [0.0] * n
+    V = [[0.0] * n for _ in range(restart + 1)]
+    H = np.zeros((restart + 1, restart))
+    nullvec = [1.0] * (restart + 1)
+
+    def init():
+        r = [bi - yi for bi, yi in zip(map(float, b), csc_mul(A, x))] if any(x) else list(map(float, b))
+        beta = math.sqrt(dot(r, r))
+        inv = 1.0 / beta
+        V[0][:] = [ri * inv for ri in r]
+        return beta
+
+    beta = init()
+    current, accumulator, res_beta = beta, 1.0, beta
+    tol = max(reltol * beta, 0.0)
+    k, iteration, hist = 1, 0, []
+    done = lambda it: it >= maxiter or current <= tol
+    while not done(iteration):
+        w = csc_mul(A, V[k - 1])
+        for i in range(k):
+            h = dot(V[i], w)
+            H[i, k - 1] = h
+            w = [wi - h * vi for wi, vi in zip(w, V[i])]
+        nrm = math.sqrt(dot(w, w))
+        inv = 1.0 / nrm
+        V[k][:] = [wi * inv for wi in w]
+        H[k, k - 1] = nrm
+        if H[k, k - 1] == 0.0:
+            current = 0.0
+        else:
+            d = 0.0
+            for i in range(k):
+                d = d + nullvec[i] * H[i, k - 1]
+            nullvec[k] = -(d / H[k, k - 1])
+            accumulator = accumulator + nullvec[k] * nullvec[k]
+            current = res_beta / math.sqrt(accumulator)
+        k += 1
+        if k == restart + 1 or done(iteration + 1):
+            rhs = np.zeros(k)
+            rhs[0] = beta
+            y = np.linalg.lstsq(H[:k, :k - 1], rhs, rcond=None)[0]
+            for j in range(k - 1):
+                x = [xi + float(y[j]) * vi for xi, vi in zip(x, V[j])]
+            k = 1
+            if not done(iteration):
+                beta = init()
+                accumulator, res_beta = 1.0, beta
+        hist.append(current)
+        iteration += 1
+    return x, hist
+
+
+@pytest.mark.parametrize("N,dims", [(3, 3), (7, 2), (30, 1)])
+def test_python_cg_equals_the_c_oracle_bit_for_bit(orc, N, dims):
+    A = orc.laplace(N, dims)
+    b = orc.hashed_rhs(A.n)
+    x, hist = py_cg(A, b, 1.4901161193847656e-8, A.n)
+    xo, ho = orc.cg(A, b, mode="seq")
+    assert len(hist) == ho["iters"] and hist == list(ho["resnorm"]) and x == list(xo)
+
+
+def test_python_gmres_history_equals_the_c_oracle_bit_for_bit(orc):
+    A, b = orc.advdiff(4, 30.0)
+    x, hist = py_gmres_mgs(A, b, 6, 1.4901161193847656e-8, 40)
+    xo, ho = orc.gmres(A, b, restart=6, maxiter=40, orth_meth="mgs", mode="seq")
+    assert len(hist) == ho["iters"]
+    first_cycle = 6
+    assert hist[:first_cycle] == list(ho["resnorm"][:first_cycle])          # before the first least-squares solve: exact
+    np.testing.assert_allclose(hist, ho["resnorm"], rtol=1e-6)              # afterwards x comes from lstsq vs Givens
+    np.testing.assert_allclose(x, xo, rtol=1e-7, atol=1e-12)
