@@ -123,3 +123,58 @@ def test_python_gmres_history_equals_the_c_oracle_bit_for_bit(orc):
     assert hist[:first_cycle] == list(ho["resnorm"][:first_cycle])          # before the first least-squares solve: exact
     np.testing.assert_allclose(hist, ho["resnorm"], rtol=1e-6)              # afterwards x comes from lstsq vs Givens
     np.testing.assert_allclose(x, xo, rtol=1e-7, atol=1e-12)
+
+
+def wave_tree(v):
+    """64 values -> shuffle-down tree with offsets 32, 16, ..., 1 (lane i adds lane i + offset); lane 0's result"""
+    v = list(v)
+    off = 32
+    while off >= 1:
+        v = [v[i] + (v[i + off] if i + off < 64 else v[i]) for i in range(64)]
+        off //= 2
+    return v[0]
+
+
+def py_tree_dot(x, y, W, L):
+    """The device's fixed-shape reduction written from its documentation (include/mik.h "Reduction semantics",
+    DESIGN.md section 3), independently of oracle/orc_impl.inc."""
+    n = len(x)
+    seg = 256 * W * L
+    nseg = (n + seg - 1) // seg
+    S = []
+    for s in range(nseg):
+        lanes = []
+        for t in range(256):
+            acc = 0.0
+            for e in range(W * L):
+                i = s * seg + (e // W) * (256 * W) + W * t + e % W
+                if i < n:
+                    acc = acc + x[i] * y[i]
+            lanes.append(acc)
+        ws = [wave_tree(lanes[64 * w:64 * w + 64]) for w in range(4)]
+        tot = ws[0]
+        for w in range(1, 4):
+            tot = tot + ws[w]
+        S.append(tot)
+    # level 2: 1024 virtual threads, stride-1024 serial sums, wave trees, 16 wave sums left to right
+    vt = []
+    for t in range(1024):
+        acc = 0.0
+        j = t
+        while j < nseg:
+            acc = acc + S[j]
+            j += 1024
+        vt.append(acc)
+    ws = [wave_tree(vt[64 * w:64 * w + 64]) for w in range(16)]
+    tot = ws[0]
+    for w in range(1, 16):
+        tot = tot + ws[w]
+    return tot
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 1024, 1025, 4097, 70001])
+@pytest.mark.parametrize("W,L", [(2, 2), (1, 1)])
+def test_tree_reduction_shape_written_from_the_documentation(orc, n, W, L):
+    rng = np.random.default_rng(n)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    assert py_tree_dot(list(map(float, x)), list(map(float, y)), W, L) == orc.dot(x, y, "tree", W, L)
