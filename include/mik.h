@@ -37,6 +37,16 @@
  *  the SpMV sums each row serially in ascending column order, exactly like the reference's CSC
  *  column scatter (rows longer than mik_spmv_long_row() entries: one wave per row, lane l sums the
  *  products of entries l, l+64, ... in order, then the wave tree).  oracle/mik_oracle.c (mode ORC_TREE) restates the same tree on the CPU.
+ *
+ * Norms (the reference's norm() is BLAS nrm2 / generic_norm2: over- and underflow-safe)
+ *  norm(x) = sqrt(t), t = tree sum of x_i^2, whenever t lies in [2^-900, 2^900] (fp32: [2^-70, 2^100]) -- then no
+ *  square that matters has underflowed and nothing has overflowed.  Outside that range (t = 0, denormal, Inf or NaN
+ *  although x may be finite and non-zero: a badly scaled system) the norm is recomputed with scaling: amax = max |x_i|
+ *  (0, Inf, NaN are returned as they are); s = 2^-e with amax = f * 2^e, f in [0.5, 1), e clamped to +-1022 (+-126);
+ *  t' = the same tree over (x_i * s)^2; norm = sqrt(t') / s.  mik_nrm2, the fused sweeps and the single-GPU iterables
+ *  (CG residual, GMRES beta and the Gram-Schmidt norms) all do this, so a solve on a system scaled by 1e-200 takes
+ *  the iterations of the unscaled one instead of "converging" on a residual that underflowed to 0.  The row-partitioned
+ *  iterables return MIK_ERR_RANGE instead (the scaled pass would need a max over ranks).  The oracle mirrors it.
  */
 #ifndef MIK_H
 #define MIK_H
@@ -48,7 +58,7 @@
 extern "C" {
 #endif
 
-#define MIK_ABI_VERSION 1
+#define MIK_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -58,7 +68,8 @@ enum {
     MIK_ERR_MISMATCH = 3,    /* dimension / dtype mismatch */
     MIK_ERR_NOMEM = 4,       /* out of (device or host) memory */
     MIK_ERR_NOTIMPL = 5,     /* not implemented (e.g. nnz >= 2^31) */
-    MIK_ERR_CALLBACK = 6     /* a mik_partition callback returned non-zero */
+    MIK_ERR_CALLBACK = 6,    /* a mik_partition / operator / preconditioner callback returned non-zero */
+    MIK_ERR_RANGE = 7        /* a norm left the range in which the row-partitioned path can evaluate it (see "Norms") */
 };
 
 enum { MIK_F64 = 0, MIK_F32 = 1 };
@@ -97,7 +108,8 @@ int mik_spmv_long_row(int *threshold);
  *   5: 1 = unfused MGS chain, 2 = launch-lean MGS without graphs, 3 = one hipGraph per GMRES column
  *   6: 1 = ignore the dictionary-coded form                       7: cache hints of the CG vector kernels
  *   8: 1 = CSR row-block layout only (read at mik_csr_create and at launch)
- *  10: 1 = no 8-bit column codes                                  12: 1 = no per-slice-offset layout */
+ *  10: 1 = no 8-bit column codes                                  12: 1 = no per-slice-offset layout
+ *  13: bit mask switching the Krylov-basis streaming hints off    14: CSR kernel: 0 = LDS-DMA tile + per-row gather, 1 = register-staged products */
 int mik_set_tuning(int key, int value);
 
 /* ---- device memory (similar / zero / copyto! / fill! of the vector interface) ----------- */
@@ -302,6 +314,50 @@ int mik_cgd_set_interior(mik_cgd *it, int64_t rb_begin, int64_t rb_end);
  * steps executed since the previous wait (at most 1024 steps may be enqueued between waits). */
 int mik_cgd_wait(mik_cgd *it, double *residual, double *tol, int *done, double *history, int64_t cap,
                  int64_t *steps);
+
+/* ---- the exchanges of the row-partitioned CGIterable inside the library ----------------------------------- */
+/* With the calls below the host no longer drives phases and collectives itself: after mik_cgd_create it registers the
+ * halo plan and a transport once, and every batch of iterate() calls is ONE entry (a Julia host: one ccall).
+ * Halo plan: rank `rank` receives recv_cnt[i] entries from rank recv_peer[i] into the ghost tail of u_ext at element
+ * offset recv_off[i] (relative to n_loc), and sends send_cnt[i] entries of send_buf starting at send_off[i] to rank
+ * send_peer[i] (the packing order of send_idx).  Arrays are copied. */
+int mik_cgd_set_halo_plan(mik_cgd *it, int n_recv, const int *recv_peer, const int64_t *recv_off, const int64_t *recv_cnt,
+                          int n_send, const int *send_peer, const int64_t *send_off, const int64_t *send_cnt);
+
+/* Transport 1 -- RCCL over xGMI, one process per GPU.  librccl is bound at run time (dlopen; a process that already
+ * carries RCCL, e.g. PyTorch-ROCm, shares that copy); MIK_ERR_NOTIMPL if it cannot be loaded.  Rank 0 obtains the
+ * 128-byte ncclUniqueId with mik_comm_unique_id and hands it to the other ranks by whatever channel the host has (MPI.jl
+ * bcast, a file, torch.distributed); every rank then calls mik_comm_create (collective).  id128 = NULL with nranks = 1
+ * gives a world of one that needs no library. */
+typedef struct mik_comm mik_comm;
+int mik_comm_unique_id(void *id128);
+int mik_comm_create(mik_ctx *ctx, const void *id128, int rank, int nranks, mik_comm **out);
+int mik_comm_destroy(mik_comm *comm);
+int mik_comm_info(const mik_comm *comm, int *rank, int *nranks, int *uses_rccl);
+/* values[0..count) (host scalars of dtype, count <= 256): this rank's partial sums in, ((p_0 + p_1) + p_2) + ... over the
+ * ranks out, identical on every rank -- exactly the mik_reduce_fn contract, so a row-partitioned GMRES host passes a
+ * two-line callback around it.  Blocks (ncclAllGather on the ctx stream + one read-back). */
+int mik_comm_allgather_sum(mik_comm *comm, int dtype, int count, void *values);
+/* The mik_halo_fn of a row-partitioned GMRES over RCCL: ncclSend / ncclRecv of the packed buffer into the ghost region
+ * on the ctx stream; segments as in mik_cgd_set_halo_plan. */
+int mik_comm_halo(mik_comm *comm, int dtype, const void *send_buf, void *ghost, int n_recv, const int *recv_peer,
+                  const int64_t *recv_off, const int64_t *recv_cnt, int n_send, const int *send_peer, const int64_t *send_off,
+                  const int64_t *send_cnt);
+int mik_cgd_set_comm(mik_cgd *it, mik_comm *comm);
+/* cg_iterator! (src/cg.jl:120-155) over the partition: init phases + exchanges + one wait. */
+int mik_cgd_init(mik_cgd *it, double *residual, double *tol);
+/* Up to max_steps iterate() calls (src/cg.jl:43-66) with ONE host wait; collective: every rank makes the same call.
+ * Per step: pack, halo (ncclSend / ncclRecv on a side stream -- the interior row-blocks of the SpMV run meanwhile when
+ * mik_cgd_set_interior was called), c = A u with the local dot, ncclAllGather of one scalar per rank, update,
+ * ncclAllGather, stopping test; the P partial sums are added in rank order on every device.  At most 1024 steps. */
+int mik_cgd_iterate_many(mik_cgd *it, int64_t iteration, int64_t max_steps, double *residuals, int64_t *steps_done);
+
+/* Transport 2 -- in-process group: ONE host thread drives all P ranks (its[p] = rank p, each created on its own ctx;
+ * the contexts may sit on different GPUs -- halos and scalars then move by peer copies over xGMI -- or share one, which
+ * is how the step routine is verified on a single-GPU box).  Same steps, same bits as transport 1. */
+int mik_cgd_group_init(mik_cgd **its, int P, double *residual, double *tol);
+int mik_cgd_group_iterate_many(mik_cgd **its, int P, int64_t iteration, int64_t max_steps, double *residuals, int64_t *steps_done);
+int mik_cgd_group_release(mik_cgd **its, int P);    /* frees the group's events / side streams (also done by mik_cgd_destroy) */
 
 /* ---- Hessenberg least squares (host) ------------------------------------------------------ */
 /* ldiv!(FastHessenberg(H), rhs) -- src/hessenberg.jl:15-46.  Host arrays of `dtype`; H is

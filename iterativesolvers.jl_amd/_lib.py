@@ -17,7 +17,7 @@ MIK_OK = 0
 MIK_F64, MIK_F32 = 0, 1
 MIK_MGS, MIK_CGS, MIK_DGKS = 0, 1, 2
 STATUS = {1: "invalid argument", 2: "HIP runtime error", 3: "dimension/dtype mismatch",
-          4: "out of memory", 5: "not implemented", 6: "partition callback failed"}
+          4: "out of memory", 5: "not implemented", 6: "callback failed", 7: "norm outside the safely representable range"}
 
 
 class MikError(RuntimeError):
@@ -107,6 +107,19 @@ SIGNATURES = {
     "mik_cgd_phase": (C.c_int, [_vp, C.c_int, _i64]),
     "mik_cgd_set_interior": (C.c_int, [_vp, _i64, _i64]),
     "mik_cgd_wait": (C.c_int, [_vp, _f64p, _f64p, _ip, _f64p, _i64, _i64p]),
+    "mik_cgd_set_halo_plan": (C.c_int, [_vp, C.c_int, _ip, _i64p, _i64p, C.c_int, _ip, _i64p, _i64p]),
+    "mik_comm_unique_id": (C.c_int, [_vp]),
+    "mik_comm_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "mik_comm_destroy": (C.c_int, [_vp]),
+    "mik_comm_info": (C.c_int, [_vp, _ip, _ip, _ip]),
+    "mik_comm_allgather_sum": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "mik_comm_halo": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _ip, _i64p, _i64p, C.c_int, _ip, _i64p, _i64p]),
+    "mik_cgd_set_comm": (C.c_int, [_vp, _vp]),
+    "mik_cgd_init": (C.c_int, [_vp, _f64p, _f64p]),
+    "mik_cgd_iterate_many": (C.c_int, [_vp, _i64, _i64, _f64p, _i64p]),
+    "mik_cgd_group_init": (C.c_int, [C.POINTER(_vp), C.c_int, _f64p, _f64p]),
+    "mik_cgd_group_iterate_many": (C.c_int, [C.POINTER(_vp), C.c_int, _i64, _i64, _f64p, _i64p]),
+    "mik_cgd_group_release": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "mik_hessenberg_ldiv": (C.c_int, [C.c_int, _vp, _i64, C.c_int, _vp]),
     "mik_givens": (C.c_int, [C.c_int, _vp, _vp, _vp]),
     "mik_time_spmv": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _f64p]),

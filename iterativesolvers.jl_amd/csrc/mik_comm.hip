@@ -1,0 +1,596 @@
+// mik_comm.hip -- the exchanges of the row-partitioned iterables INSIDE libmik.so.
+//
+// The reference is a serial library; the partition is new design: contiguous row blocks, one
+// halo exchange of u per SpMV and two sums of one scalar per rank per CG step.  Two transports behind one step
+// routine, so that a host (Julia through ccall, C, Python) runs multi-GPU cg! with ONE call per batch of steps:
+//
+//  * RCCL over xGMI, one process per GPU (mik_comm_create from an ncclUniqueId): the halo is ncclSend / ncclRecv on
+//    a side stream (ordered by events, so the interior row-blocks of the SpMV run while it is in flight), the scalars
+//    are ncclAllGather of one element per rank on the compute stream; every rank then adds the P partial sums in
+//    rank order on the device (k_cgd_alpha / k_cgd_fin_res), so all ranks hold identical bits.  librccl is bound at
+//    run time (dlopen): hosts that never go multi-GPU do not need it, and a process that already carries RCCL
+//    (PyTorch-ROCm bundles one) shares that copy.
+//  * an in-process group (mik_cgd_group_*): one host thread drives P ranks, each with its own ctx / device; halos and
+//    scalars move by peer copies ordered with events (xGMI P2P when the ranks sit on different GPUs).  This is also
+//    how the step routine is verified on a single-GPU box: P virtual ranks on one device, bit-exact against the
+//    partition-aware oracle.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <new>
+
+#include "mik_iter.h"
+
+// ---------------------------------------------------------------------------------------------
+// RCCL, bound at run time
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct NcclId { char internal[128]; };
+using nccl_comm_t = void *;
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(NcclId *) = nullptr;
+    int (*CommInitRank)(nccl_comm_t *, int, NcclId, int) = nullptr;
+    int (*CommDestroy)(nccl_comm_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+
+Rccl *rccl()
+{
+    static Rccl R;
+    static bool tried = false;
+    if (tried) return R.h ? &R : nullptr;
+    tried = true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        R.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (R.h) break;
+    }
+    if (!R.h) { const char *de = dlerror(); R.err = de ? de : "librccl.so not found"; return nullptr; }
+    auto sym = [&](const char *s) { void *p = dlsym(R.h, s); if (!p) R.err = std::string("missing symbol ") + s; return p; };
+    R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
+    R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
+    R.CommDestroy = (decltype(R.CommDestroy))sym("ncclCommDestroy");
+    R.Send = (decltype(R.Send))sym("ncclSend");
+    R.Recv = (decltype(R.Recv))sym("ncclRecv");
+    R.AllGather = (decltype(R.AllGather))sym("ncclAllGather");
+    R.GroupStart = (decltype(R.GroupStart))sym("ncclGroupStart");
+    R.GroupEnd = (decltype(R.GroupEnd))sym("ncclGroupEnd");
+    R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
+    if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.Send || !R.Recv || !R.AllGather || !R.GroupStart || !R.GroupEnd) {
+        dlclose(R.h);
+        R.h = nullptr;
+        return nullptr;
+    }
+    return &R;
+}
+constexpr int NCCL_F32 = 7, NCCL_F64 = 8;   // ncclFloat32 / ncclFloat64 (rccl.h)
+}  // namespace
+
+struct mik_comm {
+    mik_ctx *ctx = nullptr;
+    int rank = 0, nranks = 1;
+    nccl_comm_t nccl = nullptr;          // NULL: a world of one without the library
+    hipStream_t side = nullptr;          // halo transfers (so that the interior SpMV overlaps them)
+    hipEvent_t ev_packed = nullptr, ev_halo = nullptr;
+    void *scratch = nullptr;             // device: nranks * MAX_COUNT scalars for mik_comm_allgather_sum
+    void *scratch_host = nullptr;        // pinned mirror
+    static constexpr int MAX_COUNT = 256;
+};
+
+#define MIK_NCCL(ctx, call)                                                                                        \
+    do {                                                                                                           \
+        int r_ = (call);                                                                                           \
+        if (r_ != 0) {                                                                                             \
+            Rccl *R_ = rccl();                                                                                     \
+            return mik_fail((ctx), MIK_ERR_HIP, "%s failed: %s (%s:%d)", #call,                                    \
+                            (R_ && R_->GetErrorString) ? R_->GetErrorString(r_) : "rccl error", __FILE__, __LINE__); \
+        }                                                                                                          \
+    } while (0)
+
+extern "C" int mik_comm_unique_id(void *id128)
+{
+    if (!id128) return MIK_ERR_INVALID;
+    Rccl *R = rccl();
+    if (!R) return mik_fail(nullptr, MIK_ERR_NOTIMPL, "mik_comm_unique_id: RCCL is not available in this process");
+    NcclId id;
+    if (R->GetUniqueId(&id) != 0) return mik_fail(nullptr, MIK_ERR_HIP, "ncclGetUniqueId failed");
+    memcpy(id128, id.internal, 128);
+    return MIK_OK;
+}
+
+extern "C" int mik_comm_create(mik_ctx *ctx, const void *id128, int rank, int nranks, mik_comm **out)
+{
+    if (!ctx || !out) return MIK_ERR_INVALID;
+    *out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return mik_fail(ctx, MIK_ERR_INVALID, "mik_comm_create: bad rank %d of %d", rank, nranks);
+    if (nranks > 1 && !id128) return mik_fail(ctx, MIK_ERR_INVALID, "mik_comm_create: %d ranks need the ncclUniqueId of rank 0", nranks);
+    mik_comm *cm = new (std::nothrow) mik_comm();
+    if (!cm) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_comm_create: host allocation failed");
+    cm->ctx = ctx; cm->rank = rank; cm->nranks = nranks;
+    auto bail = [&](int rc) { mik_comm_destroy(cm); return rc; };
+    hipError_t e;
+    (void)hipSetDevice(ctx->device);
+    if ((e = hipStreamCreateWithFlags(&cm->side, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&cm->ev_packed, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&cm->ev_halo, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipMalloc(&cm->scratch, 8 * (size_t)nranks * mik_comm::MAX_COUNT)) != hipSuccess ||
+        (e = hipHostMalloc(&cm->scratch_host, 8 * (size_t)nranks * mik_comm::MAX_COUNT, hipHostMallocDefault)) != hipSuccess)
+        return bail(mik_fail(ctx, MIK_ERR_HIP, "mik_comm_create: %s", hipGetErrorString(e)));
+    if (id128) {
+        Rccl *R = rccl();
+        if (!R) return bail(mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_comm_create: RCCL is not available in this process (dlopen librccl.so failed)"));
+        NcclId id;
+        memcpy(id.internal, id128, 128);
+        int r = R->CommInitRank(&cm->nccl, nranks, id, rank);
+        if (r != 0) return bail(mik_fail(ctx, MIK_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, nranks, R->GetErrorString ? R->GetErrorString(r) : "?"));
+    }
+    *out = cm;
+    return MIK_OK;
+}
+
+extern "C" int mik_comm_destroy(mik_comm *cm)
+{
+    if (!cm) return MIK_OK;
+    if (cm->ctx) { (void)hipSetDevice(cm->ctx->device); (void)hipStreamSynchronize(cm->ctx->stream); }
+    if (cm->side) (void)hipStreamSynchronize(cm->side);
+    if (cm->nccl) { Rccl *R = rccl(); if (R) (void)R->CommDestroy(cm->nccl); }
+    if (cm->side) (void)hipStreamDestroy(cm->side);
+    if (cm->ev_packed) (void)hipEventDestroy(cm->ev_packed);
+    if (cm->ev_halo) (void)hipEventDestroy(cm->ev_halo);
+    if (cm->scratch) (void)hipFree(cm->scratch);
+    if (cm->scratch_host) (void)hipHostFree(cm->scratch_host);
+    delete cm;
+    return MIK_OK;
+}
+
+extern "C" int mik_comm_info(const mik_comm *cm, int *rank, int *nranks, int *uses_rccl)
+{
+    if (!cm) return MIK_ERR_INVALID;
+    if (rank) *rank = cm->rank;
+    if (nranks) *nranks = cm->nranks;
+    if (uses_rccl) *uses_rccl = cm->nccl ? 1 : 0;
+    return MIK_OK;
+}
+
+// values[0..count): this rank's partial sums (host scalars) -> ((p_0 + p_1) + p_2) + ... over the ranks, identically
+// on every rank: the mik_reduce_fn contract (dot / norm^2 of a row-partitioned GMRES).  Blocks.
+template <typename T> static int allgather_sum_impl(mik_comm *cm, int count, T *values)
+{
+    mik_ctx *ctx = cm->ctx;
+    if (cm->nranks == 1 && !cm->nccl) return MIK_OK;
+    Rccl *R = rccl();
+    T *dev = (T *)cm->scratch, *host = (T *)cm->scratch_host;
+    MIK_HIP(ctx, mik_wait(ctx));                                       // the pinned staging buffer must be idle
+    memcpy(host, values, sizeof(T) * count);
+    MIK_HIP(ctx, hipMemcpyAsync(dev + (size_t)cm->rank * count, host, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream));
+    MIK_NCCL(ctx, R->AllGather(dev + (size_t)cm->rank * count, dev, (size_t)count, sizeof(T) == 8 ? NCCL_F64 : NCCL_F32, cm->nccl, ctx->stream));
+    MIK_HIP(ctx, hipMemcpyAsync(host, dev, sizeof(T) * count * cm->nranks, hipMemcpyDeviceToHost, ctx->stream));
+    MIK_HIP(ctx, mik_wait(ctx));
+    for (int j = 0; j < count; ++j) {
+        T s = host[j];
+        for (int p = 1; p < cm->nranks; ++p) s = s + host[(size_t)p * count + j];
+        values[j] = s;
+    }
+    return MIK_OK;
+}
+
+extern "C" int mik_comm_allgather_sum(mik_comm *cm, int dtype, int count, void *values)
+{
+    if (!cm || count < 0 || (count && !values)) return MIK_ERR_INVALID;
+    if (count > mik_comm::MAX_COUNT) return mik_fail(cm->ctx, MIK_ERR_NOTIMPL, "mik_comm_allgather_sum: at most %d values per call", mik_comm::MAX_COUNT);
+    if (count == 0) return MIK_OK;
+    if (dtype == MIK_F64) return allgather_sum_impl<double>(cm, count, (double *)values);
+    if (dtype == MIK_F32) return allgather_sum_impl<float>(cm, count, (float *)values);
+    return MIK_ERR_INVALID;
+}
+
+// Halo exchange of a packed send buffer into a ghost region on the ctx stream (the mik_halo_fn of a row-partitioned
+// GMRES handle): segments as in mik_cgd_set_halo_plan.
+extern "C" int mik_comm_halo(mik_comm *cm, int dtype, const void *send_buf, void *ghost, int n_recv, const int *recv_peer,
+                             const int64_t *recv_off, const int64_t *recv_cnt, int n_send, const int *send_peer, const int64_t *send_off,
+                             const int64_t *send_cnt)
+{
+    if (!cm || n_recv < 0 || n_send < 0) return MIK_ERR_INVALID;
+    if (n_recv + n_send == 0) return MIK_OK;
+    if (!cm->nccl) return mik_fail(cm->ctx, MIK_ERR_INVALID, "mik_comm_halo: a world of one has no neighbours");
+    Rccl *R = rccl();
+    const size_t es = mik_dtype_size(dtype);
+    const int nt = dtype == MIK_F64 ? NCCL_F64 : NCCL_F32;
+    MIK_NCCL(cm->ctx, R->GroupStart());
+    for (int i = 0; i < n_recv; ++i)
+        MIK_NCCL(cm->ctx, R->Recv((unsigned char *)ghost + es * (size_t)recv_off[i], (size_t)recv_cnt[i], nt, recv_peer[i], cm->nccl, cm->ctx->stream));
+    for (int i = 0; i < n_send; ++i)
+        MIK_NCCL(cm->ctx, R->Send((const unsigned char *)send_buf + es * (size_t)send_off[i], (size_t)send_cnt[i], nt, send_peer[i], cm->nccl, cm->ctx->stream));
+    MIK_NCCL(cm->ctx, R->GroupEnd());
+    return MIK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row-partitioned CG driven by the library
+// ---------------------------------------------------------------------------------------------
+extern "C" int mik_cgd_set_halo_plan(mik_cgd *it, int n_recv, const int *recv_peer, const int64_t *recv_off, const int64_t *recv_cnt,
+                                     int n_send, const int *send_peer, const int64_t *send_off, const int64_t *send_cnt)
+{
+    if (!it || n_recv < 0 || n_send < 0 || (n_recv && (!recv_peer || !recv_off || !recv_cnt)) || (n_send && (!send_peer || !send_off || !send_cnt)))
+        return MIK_ERR_INVALID;
+    mik_ctx *ctx = it->base.ctx;
+    const int64_t n_ghost = it->n_ext - it->base.n;
+    it->recv.clear();
+    it->send.clear();
+    for (int i = 0; i < n_recv; ++i) {
+        if (recv_peer[i] < 0 || recv_peer[i] >= it->nranks || recv_peer[i] == it->rank || recv_off[i] < 0 || recv_cnt[i] < 0 || recv_off[i] + recv_cnt[i] > n_ghost)
+            return mik_fail(ctx, MIK_ERR_INVALID, "mik_cgd_set_halo_plan: receive segment %d out of range", i);
+        it->recv.push_back({recv_peer[i], recv_off[i], recv_cnt[i]});
+    }
+    for (int i = 0; i < n_send; ++i) {
+        if (send_peer[i] < 0 || send_peer[i] >= it->nranks || send_peer[i] == it->rank || send_off[i] < 0 || send_cnt[i] < 0 || send_off[i] + send_cnt[i] > it->n_send)
+            return mik_fail(ctx, MIK_ERR_INVALID, "mik_cgd_set_halo_plan: send segment %d out of range", i);
+        it->send.push_back({send_peer[i], send_off[i], send_cnt[i]});
+    }
+    return MIK_OK;
+}
+
+extern "C" int mik_cgd_set_comm(mik_cgd *it, mik_comm *cm)
+{
+    if (!it) return MIK_ERR_INVALID;
+    if (cm && (cm->rank != it->rank || cm->nranks != it->nranks || cm->ctx != it->base.ctx))
+        return mik_fail(it->base.ctx, MIK_ERR_MISMATCH, "mik_cgd_set_comm: communicator is rank %d of %d, the iterable rank %d of %d (or another ctx)",
+                        cm->rank, cm->nranks, it->rank, it->nranks);
+    it->comm = cm;
+    return MIK_OK;
+}
+
+// The halo of u (or of x during init) over RCCL: issued on the side stream after the pack kernel; *pending = true if
+// the compute stream still has to wait for ev_halo.
+static int rccl_halo_begin(mik_cgd *it, bool *pending)
+{
+    *pending = false;
+    mik_comm *cm = it->comm;
+    mik_ctx *ctx = it->base.ctx;
+    if (!cm || !cm->nccl || (it->recv.empty() && it->send.empty())) return MIK_OK;
+    Rccl *R = rccl();
+    const size_t es = mik_dtype_size(it->base.dtype);
+    const int nt = it->base.dtype == MIK_F64 ? NCCL_F64 : NCCL_F32;
+    unsigned char *ghost = (unsigned char *)it->u_ext + es * (size_t)it->base.n;
+    MIK_HIP(ctx, hipEventRecord(cm->ev_packed, ctx->stream));
+    MIK_HIP(ctx, hipStreamWaitEvent(cm->side, cm->ev_packed, 0));
+    MIK_NCCL(ctx, R->GroupStart());
+    for (const auto &sg : it->recv) MIK_NCCL(ctx, R->Recv(ghost + es * (size_t)sg.off, (size_t)sg.cnt, nt, sg.peer, cm->nccl, cm->side));
+    for (const auto &sg : it->send) MIK_NCCL(ctx, R->Send((const unsigned char *)it->send_buf + es * (size_t)sg.off, (size_t)sg.cnt, nt, sg.peer, cm->nccl, cm->side));
+    MIK_NCCL(ctx, R->GroupEnd());
+    MIK_HIP(ctx, hipEventRecord(cm->ev_halo, cm->side));
+    *pending = true;
+    return MIK_OK;
+}
+
+static int rccl_halo_end(mik_cgd *it, bool pending)
+{
+    if (pending) MIK_HIP(it->base.ctx, hipStreamWaitEvent(it->base.ctx->stream, it->comm->ev_halo, 0));
+    return MIK_OK;
+}
+
+// slot [rank] of `all` -> every rank's `all` (one scalar per rank), on the compute stream
+static int rccl_gather_scalar(mik_cgd *it, void *all)
+{
+    mik_comm *cm = it->comm;
+    if (!cm || !cm->nccl) return MIK_OK;
+    Rccl *R = rccl();
+    const size_t es = mik_dtype_size(it->base.dtype);
+    MIK_NCCL(it->base.ctx, R->AllGather((const unsigned char *)all + es * (size_t)it->rank, all, 1, it->base.dtype == MIK_F64 ? NCCL_F64 : NCCL_F32,
+                                        cm->nccl, it->base.ctx->stream));
+    return MIK_OK;
+}
+
+static int cgd_require_transport(mik_cgd *it, const char *who)
+{
+    if (it->nranks > 1 && (!it->comm || !it->comm->nccl))
+        return mik_fail(it->base.ctx, MIK_ERR_INVALID, "%s: %d ranks need a communicator (mik_cgd_set_comm) or the in-process group calls", who, it->nranks);
+    return MIK_OK;
+}
+
+// cg_iterator! (src/cg.jl:120-155) over the partition: phases 10, [halo of x], 11, [gather |r|^2], 12, then one wait.
+extern "C" int mik_cgd_init(mik_cgd *it, double *residual, double *tol)
+{
+    if (!it) return MIK_ERR_INVALID;
+    MIK_TRY(cgd_require_transport(it, "mik_cgd_init"));
+    MIK_TRY(mik_cgd_phase(it, 10, 0));
+    bool pending = false;
+    if (!it->initially_zero) MIK_TRY(rccl_halo_begin(it, &pending));
+    MIK_TRY(rccl_halo_end(it, pending));
+    MIK_TRY(mik_cgd_phase(it, 11, 0));
+    MIK_TRY(rccl_gather_scalar(it, it->rr_all));
+    MIK_TRY(mik_cgd_phase(it, 12, 0));
+    int done = 0;
+    int64_t steps = 0;
+    MIK_TRY(mik_cgd_wait(it, residual, tol, &done, nullptr, 0, &steps));
+    it->initialised = true;
+    return MIK_OK;
+}
+
+// one iterate() (src/cg.jl:43-66) of this rank, enqueued without any host synchronisation
+static int cgd_enqueue_step(mik_cgd *it, int64_t iteration)
+{
+    MIK_TRY(mik_cgd_phase(it, 0, iteration));                       // u = r + beta u; pack the halo
+    bool pending = false;
+    MIK_TRY(rccl_halo_begin(it, &pending));
+    if (pending && it->int_end > it->int_begin) {
+        MIK_TRY(mik_cgd_phase(it, 4, iteration));                   // interior row-blocks while the halo is in flight
+        MIK_TRY(rccl_halo_end(it, pending));
+        MIK_TRY(mik_cgd_phase(it, 5, iteration));                   // boundary row-blocks + local dot(u, c)
+    } else {
+        MIK_TRY(rccl_halo_end(it, pending));
+        MIK_TRY(mik_cgd_phase(it, 1, iteration));
+    }
+    MIK_TRY(rccl_gather_scalar(it, it->dot_all));
+    MIK_TRY(mik_cgd_phase(it, 2, iteration));                       // alpha; x, r update; local |r|^2
+    MIK_TRY(rccl_gather_scalar(it, it->rr_all));
+    return mik_cgd_phase(it, 3, iteration);                         // residual, beta, stopping test
+}
+
+// Up to max_steps iterate() calls of this rank with ONE host wait (every rank makes the same call; the stopping test
+// runs on the device from identical scalars, so all ranks execute the same number of steps).
+extern "C" int mik_cgd_iterate_many(mik_cgd *it, int64_t iteration, int64_t max_steps, double *residuals, int64_t *steps_done)
+{
+    if (!it || !steps_done || iteration < 0) return MIK_ERR_INVALID;
+    *steps_done = 0;
+    MIK_TRY(cgd_require_transport(it, "mik_cgd_iterate_many"));
+    if (!it->initialised) return mik_fail(it->base.ctx, MIK_ERR_INVALID, "mik_cgd_iterate_many: call mik_cgd_init first");
+    mik_cg &bs = it->base;
+    if (max_steps <= 0 || iteration >= bs.maxiter || bs.residual <= bs.tol) return MIK_OK;      // done(it, iteration), src/cg.jl:36
+    max_steps = std::min<int64_t>(std::min<int64_t>(max_steps, bs.maxiter - iteration), bs.hist_cap);
+    for (int64_t j = 0; j < max_steps; ++j) MIK_TRY(cgd_enqueue_step(it, iteration + j));
+    int done = 0;
+    return mik_cgd_wait(it, nullptr, nullptr, &done, residuals, max_steps, steps_done);
+}
+
+// ---------------------------------------------------------------------------------------------
+// in-process group: one host thread, P ranks (one ctx each; same or different devices)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct GroupEvents {
+    std::vector<hipEvent_t> packed, halo, dot, rr;
+    std::vector<hipStream_t> side;
+};
+
+struct GroupState {
+    int P = 0;
+    std::vector<mik_cgd *> its;
+    GroupEvents ev;
+    ~GroupState()
+    {
+        for (auto *v : {&ev.packed, &ev.halo, &ev.dot, &ev.rr})
+            for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
+        for (hipStream_t s : ev.side) if (s) (void)hipStreamDestroy(s);
+    }
+};
+
+// groups are keyed by their rank-0 handle and live until mik_cgd_group_release (or process exit)
+std::vector<GroupState *> g_groups;
+
+GroupState *find_group(mik_cgd **its, int P)
+{
+    for (GroupState *g : g_groups)
+        if (g->P == P && std::equal(g->its.begin(), g->its.end(), its)) return g;
+    return nullptr;
+}
+}  // namespace
+
+static int group_check(mik_cgd **its, int P, const char *who)
+{
+    if (!its || P < 1) return MIK_ERR_INVALID;
+    for (int p = 0; p < P; ++p) {
+        if (!its[p]) return MIK_ERR_INVALID;
+        if (its[p]->nranks != P || its[p]->rank != p) return mik_fail(its[p]->base.ctx, MIK_ERR_MISMATCH, "%s: handle %d is rank %d of %d", who, p, its[p]->rank, its[p]->nranks);
+        if (its[p]->base.dtype != its[0]->base.dtype) return mik_fail(its[p]->base.ctx, MIK_ERR_MISMATCH, "%s: mixed dtypes", who);
+    }
+    return MIK_OK;
+}
+
+static int group_get(mik_cgd **its, int P, GroupState **out)
+{
+    GroupState *g = find_group(its, P);
+    if (!g) {
+        g = new (std::nothrow) GroupState();
+        if (!g) return MIK_ERR_NOMEM;
+        g->P = P;
+        g->its.assign(its, its + P);
+        for (auto *v : {&g->ev.packed, &g->ev.halo, &g->ev.dot, &g->ev.rr}) v->assign((size_t)P, nullptr);
+        g->ev.side.assign((size_t)P, nullptr);
+        for (int p = 0; p < P; ++p) {
+            mik_ctx *ctx = its[p]->base.ctx;
+            MIK_HIP(ctx, hipSetDevice(ctx->device));
+            for (int q = 0; q < P; ++q)          // peer access for copies between different devices (xGMI P2P)
+                if (its[q]->base.ctx->device != ctx->device) {
+                    hipError_t e = hipDeviceEnablePeerAccess(its[q]->base.ctx->device, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { delete g; return mik_fail(ctx, MIK_ERR_HIP, "hipDeviceEnablePeerAccess(%d): %s", its[q]->base.ctx->device, hipGetErrorString(e)); }
+                    (void)hipGetLastError();
+                }
+            for (auto *v : {&g->ev.packed, &g->ev.halo, &g->ev.dot, &g->ev.rr}) MIK_HIP(ctx, hipEventCreateWithFlags(&(*v)[p], hipEventDisableTiming));
+            MIK_HIP(ctx, hipStreamCreateWithFlags(&g->ev.side[p], hipStreamNonBlocking));
+        }
+        g_groups.push_back(g);
+    }
+    *out = g;
+    return MIK_OK;
+}
+
+// called by mik_cgd_destroy: a group must not outlive one of its handles
+void mik_cgd_group_forget(mik_cgd *it)
+{
+    for (size_t i = 0; i < g_groups.size();) {
+        GroupState *g = g_groups[i];
+        if (std::find(g->its.begin(), g->its.end(), it) != g->its.end()) {
+            for (int p = 0; p < g->P; ++p) (void)hipStreamSynchronize(g->ev.side[p]);
+            g_groups.erase(g_groups.begin() + (long)i);
+            delete g;
+        } else ++i;
+    }
+}
+
+extern "C" int mik_cgd_group_release(mik_cgd **its, int P)
+{
+    GroupState *g = its ? find_group(its, P) : nullptr;
+    if (!g) return MIK_OK;
+    for (int p = 0; p < P; ++p) { (void)hipSetDevice(its[p]->base.ctx->device); (void)hipStreamSynchronize(its[p]->base.ctx->stream); (void)hipStreamSynchronize(g->ev.side[p]); }
+    g_groups.erase(std::find(g_groups.begin(), g_groups.end(), g));
+    delete g;
+    return MIK_OK;
+}
+
+// halo of every rank: rank p's ghost segments are copied from the owners' packed send buffers on p's side stream,
+// after the owner's pack kernel (ev.packed[peer]) and after p's own previous SpMV (ev.packed[p])
+static int group_halo_begin(GroupState *g, std::vector<char> &pending)
+{
+    const int P = g->P;
+    pending.assign((size_t)P, 0);
+    for (int p = 0; p < P; ++p) {
+        mik_ctx *ctx = g->its[p]->base.ctx;
+        MIK_HIP(ctx, hipSetDevice(ctx->device));
+        MIK_HIP(ctx, hipEventRecord(g->ev.packed[p], ctx->stream));
+    }
+    for (int p = 0; p < P; ++p) {
+        mik_cgd *it = g->its[p];
+        if (it->recv.empty()) continue;
+        mik_ctx *ctx = it->base.ctx;
+        const size_t es = mik_dtype_size(it->base.dtype);
+        MIK_HIP(ctx, hipSetDevice(ctx->device));
+        MIK_HIP(ctx, hipStreamWaitEvent(g->ev.side[p], g->ev.packed[p], 0));
+        unsigned char *ghost = (unsigned char *)it->u_ext + es * (size_t)it->base.n;
+        for (const auto &sg : it->recv) {
+            mik_cgd *src = g->its[sg.peer];
+            const mik_cgd::HaloSeg *match = nullptr;
+            for (const auto &ss : src->send) if (ss.peer == p) { match = &ss; break; }
+            if (!match || match->cnt != sg.cnt)
+                return mik_fail(ctx, MIK_ERR_MISMATCH, "halo plans disagree: rank %d expects %lld entries from rank %d", p, (long long)sg.cnt, sg.peer);
+            MIK_HIP(ctx, hipStreamWaitEvent(g->ev.side[p], g->ev.packed[sg.peer], 0));
+            MIK_HIP(ctx, hipMemcpyAsync(ghost + es * (size_t)sg.off, (const unsigned char *)src->send_buf + es * (size_t)match->off, es * (size_t)sg.cnt,
+                                        hipMemcpyDeviceToDevice, g->ev.side[p]));
+        }
+        MIK_HIP(ctx, hipEventRecord(g->ev.halo[p], g->ev.side[p]));
+        pending[(size_t)p] = 1;
+    }
+    return MIK_OK;
+}
+
+// slot [q] of rank q's array -> slot [q] of every other rank's array (`which`: 0 = dot_all, 1 = rr_all)
+static int group_gather_scalar(GroupState *g, int which)
+{
+    const int P = g->P;
+    if (P == 1) return MIK_OK;
+    std::vector<hipEvent_t> &ev = which == 0 ? g->ev.dot : g->ev.rr;
+    for (int p = 0; p < P; ++p) {
+        mik_ctx *ctx = g->its[p]->base.ctx;
+        MIK_HIP(ctx, hipSetDevice(ctx->device));
+        MIK_HIP(ctx, hipEventRecord(ev[p], ctx->stream));
+    }
+    for (int p = 0; p < P; ++p) {
+        mik_cgd *it = g->its[p];
+        mik_ctx *ctx = it->base.ctx;
+        const size_t es = mik_dtype_size(it->base.dtype);
+        MIK_HIP(ctx, hipSetDevice(ctx->device));
+        unsigned char *mine = (unsigned char *)(which == 0 ? it->dot_all : it->rr_all);
+        for (int q = 0; q < P; ++q) {
+            if (q == p) continue;
+            const unsigned char *theirs = (const unsigned char *)(which == 0 ? g->its[q]->dot_all : g->its[q]->rr_all);
+            MIK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ev[q], 0));
+            MIK_HIP(ctx, hipMemcpyAsync(mine + es * (size_t)q, theirs + es * (size_t)q, es, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+    }
+    return MIK_OK;
+}
+
+static int group_all(GroupState *g, int phase, int64_t iteration)
+{
+    for (int p = 0; p < g->P; ++p) {
+        MIK_HIP(g->its[p]->base.ctx, hipSetDevice(g->its[p]->base.ctx->device));
+        MIK_TRY(mik_cgd_phase(g->its[p], phase, iteration));
+    }
+    return MIK_OK;
+}
+
+static int group_halo_end(GroupState *g, const std::vector<char> &pending, int p)
+{
+    if (pending[(size_t)p]) MIK_HIP(g->its[p]->base.ctx, hipStreamWaitEvent(g->its[p]->base.ctx->stream, g->ev.halo[p], 0));
+    return MIK_OK;
+}
+
+extern "C" int mik_cgd_group_init(mik_cgd **its, int P, double *residual, double *tol)
+{
+    MIK_TRY(group_check(its, P, "mik_cgd_group_init"));
+    GroupState *g = nullptr;
+    MIK_TRY(group_get(its, P, &g));
+    std::vector<char> pending;
+    MIK_TRY(group_all(g, 10, 0));
+    if (!its[0]->initially_zero) {
+        MIK_TRY(group_halo_begin(g, pending));
+        for (int p = 0; p < P; ++p) MIK_TRY(group_halo_end(g, pending, p));
+    }
+    MIK_TRY(group_all(g, 11, 0));
+    MIK_TRY(group_gather_scalar(g, 1));
+    MIK_TRY(group_all(g, 12, 0));
+    for (int p = 0; p < P; ++p) {
+        double res = 0, tl = 0;
+        int done = 0;
+        int64_t steps = 0;
+        MIK_HIP(its[p]->base.ctx, hipSetDevice(its[p]->base.ctx->device));
+        MIK_TRY(mik_cgd_wait(its[p], &res, &tl, &done, nullptr, 0, &steps));
+        its[p]->initialised = true;
+        if (p == 0) { if (residual) *residual = res; if (tol) *tol = tl; }
+        else if (res != its[0]->base.residual || tl != its[0]->base.tol)
+            return mik_fail(its[p]->base.ctx, MIK_ERR_MISMATCH, "mik_cgd_group_init: rank %d disagrees with rank 0 on the initial residual", p);
+    }
+    return MIK_OK;
+}
+
+extern "C" int mik_cgd_group_iterate_many(mik_cgd **its, int P, int64_t iteration, int64_t max_steps, double *residuals, int64_t *steps_done)
+{
+    MIK_TRY(group_check(its, P, "mik_cgd_group_iterate_many"));
+    if (!steps_done || iteration < 0) return MIK_ERR_INVALID;
+    *steps_done = 0;
+    GroupState *g = nullptr;
+    MIK_TRY(group_get(its, P, &g));
+    mik_cg &b0 = its[0]->base;
+    for (int p = 0; p < P; ++p) if (!its[p]->initialised) return mik_fail(b0.ctx, MIK_ERR_INVALID, "mik_cgd_group_iterate_many: call mik_cgd_group_init first");
+    if (max_steps <= 0 || iteration >= b0.maxiter || b0.residual <= b0.tol) return MIK_OK;
+    max_steps = std::min<int64_t>(std::min<int64_t>(max_steps, b0.maxiter - iteration), b0.hist_cap);
+    bool split = true;
+    for (int p = 0; p < P; ++p) split = split && its[p]->int_end > its[p]->int_begin;
+    std::vector<char> pending;
+    for (int64_t j = 0; j < max_steps; ++j) {
+        const int64_t itn = iteration + j;
+        MIK_TRY(group_all(g, 0, itn));
+        MIK_TRY(group_halo_begin(g, pending));
+        if (split) {
+            MIK_TRY(group_all(g, 4, itn));
+            for (int p = 0; p < P; ++p) MIK_TRY(group_halo_end(g, pending, p));
+            MIK_TRY(group_all(g, 5, itn));
+        } else {
+            for (int p = 0; p < P; ++p) MIK_TRY(group_halo_end(g, pending, p));
+            MIK_TRY(group_all(g, 1, itn));
+        }
+        MIK_TRY(group_gather_scalar(g, 0));
+        MIK_TRY(group_all(g, 2, itn));
+        MIK_TRY(group_gather_scalar(g, 1));
+        MIK_TRY(group_all(g, 3, itn));
+    }
+    std::vector<double> h0((size_t)max_steps), hp((size_t)max_steps);
+    int64_t n0 = 0;
+    for (int p = 0; p < P; ++p) {
+        int done = 0;
+        int64_t steps = 0;
+        MIK_HIP(its[p]->base.ctx, hipSetDevice(its[p]->base.ctx->device));
+        MIK_TRY(mik_cgd_wait(its[p], nullptr, nullptr, &done, p == 0 ? h0.data() : hp.data(), max_steps, &steps));
+        if (p == 0) n0 = steps;
+        else if (steps != n0 || !std::equal(h0.begin(), h0.begin() + n0, hp.begin()))
+            return mik_fail(its[p]->base.ctx, MIK_ERR_MISMATCH, "mik_cgd_group_iterate_many: rank %d disagrees with rank 0 on the residual history", p);
+    }
+    if (residuals) std::copy(h0.begin(), h0.begin() + n0, residuals);
+    *steps_done = n0;
+    return MIK_OK;
+}

@@ -1,7 +1,9 @@
 // mik_core.hip -- context, device memory, CSR upload, and the L1 operator/vector entry points
 // (mul!, dot, norm, broadcast forms) of include/mik.h.
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
+#include <limits>
 #include <new>
 
 #include "mik_kernels.h"
@@ -671,14 +673,11 @@ extern "C" int mik_csr_pack(mik_csr *A)
     return A->dtype == MIK_F64 ? csr_pack_impl<double>(A) : csr_pack_impl<float>(A);
 }
 
+static int spmv_kernel_choice(const mik_csr *A);
 extern "C" int mik_csr_layout(const mik_csr *A, int *layout)
 {
     if (!A || !layout) return MIK_ERR_INVALID;
-    if (A->packed && g_mik_tuning[6] == 0) *layout = 3;
-    else if (A->sdia_val && g_mik_tuning[8] == 0 && g_mik_tuning[12] == 0) *layout = 4;
-    else if (A->sell8_codes && g_mik_tuning[8] == 0 && g_mik_tuning[10] == 0) *layout = 2;
-    else if (A->sell_val && g_mik_tuning[8] == 0) *layout = 1;
-    else *layout = 0;
+    *layout = spmv_kernel_choice(A);
     return MIK_OK;
 }
 
@@ -716,11 +715,29 @@ template <typename T>
 int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done, int rb_begin,
                           int rb_count);
 
-// Can mik_spmv_launch_range serve a sub-range of row-blocks for this operator (sliced-ELL layouts only)?
+// Which kernel mik_spmv_launch_range picks for this operator under the current development knobs -- ONE function, used
+// by the launcher, by mik_csr_layout and by mik_spmv_can_split, so the three can never disagree.
+//   3 packed, 4 sliced-ELL + per-slice offsets, 2 sliced-ELL + 8-bit codes, 1 sliced-ELL, 0 CSR
+static int spmv_kernel_choice(const mik_csr *A)
+{
+    if (A->packed && g_mik_tuning[6] == 0) return 3;
+    if (g_mik_tuning[8] == 0) {
+        if (A->sdia_val && g_mik_tuning[12] == 0) return 4;
+        if (A->sell8_codes && g_mik_tuning[10] == 0) return 2;
+        if (A->sell_val) return 1;
+    }
+    return 0;
+}
+
+// Can mik_spmv_launch_range serve a sub-range of row-blocks for this operator?  The sliced-ELL kernels and the default
+// CSR kernel take a first row-block; the dictionary-coded kernel, k_spmv_rowblock (tuning[14] = 1) and operators with
+// split-off long rows (their wave-per-row launch covers the whole matrix) do not.
 bool mik_spmv_can_split(const mik_csr *A)
 {
-    if (A->packed && g_mik_tuning[6] == 0) return false;
-    return (A->sdia_val || A->sell_val) && g_mik_tuning[8] == 0;
+    const int kc = spmv_kernel_choice(A);
+    if (kc == 3) return false;
+    if (kc == 0) return g_mik_tuning[14] != 1 && A->n_long == 0;
+    return true;
 }
 
 template <typename T>
@@ -738,7 +755,7 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
     if (n == 0) return MIK_OK;
     const int nb_all = (int)mik_spmv_nwg(n);
     const bool whole = rb_count < 0 || (rb_begin == 0 && rb_count == nb_all);
-    if (!whole && !mik_spmv_can_split(A)) return mik_fail(ctx, MIK_ERR_NOTIMPL, "SpMV over a row-block range needs a sliced-ELL layout");
+    if (!whole && !mik_spmv_can_split(A)) return mik_fail(ctx, MIK_ERR_NOTIMPL, "SpMV over a row-block range is not available for this operator layout");
     if (!whole && (rb_begin < 0 || rb_begin + rb_count > nb_all)) return mik_fail(ctx, MIK_ERR_INVALID, "SpMV row-block range out of bounds");
     if (!whole && rb_count == 0) return MIK_OK;
     const int rb0 = whole ? 0 : rb_begin;
@@ -750,7 +767,8 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
     const bool wide = g_mik_tuning[1] == 0;
     int map_mode = g_mik_tuning[2] == 0 ? A->strip : std::max(g_mik_tuning[2], 0);
     if (!whole && map_mode >= 8 && (rb0 % map_mode != 0 || nb % map_mode != 0)) map_mode = 0;   // strips need whole planes
-    if (A->packed && g_mik_tuning[6] == 0) {
+    const int choice = spmv_kernel_choice(A);
+    if (choice == 3) {
         // dictionary-coded operator (mik_csr_pack): 2 B per entry instead of 12, same arithmetic
         if (fuse_dot)
             hipLaunchKernelGGL((k_spmv_packed<T, true>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, map_mode, A->rowptr, A->codes,
@@ -761,7 +779,7 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     }
-    if (A->sdia_val && g_mik_tuning[8] == 0 && g_mik_tuning[12] == 0) {
+    if (choice == 4) {
         // sliced-ELL values + per-slice offsets + row masks (mik_sell.h)
 #define MIK_SDIA_GO(FD, NTV)                                                                                                  \
     hipLaunchKernelGGL((k_spmv_sdia<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, (int)A->n_cols, rb0, nb, map_mode, A->sdia_ptr, \
@@ -772,7 +790,7 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     }
-    if (A->sell8_codes && g_mik_tuning[8] == 0 && g_mik_tuning[10] == 0) {
+    if (choice == 2) {
         // sliced-ELL values + 8-bit column codes (mik_sell.h)
 #define MIK_SELL8_GO(FD, NTV)                                                                                                 \
     hipLaunchKernelGGL((k_spmv_sell8<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, rb0, nb, map_mode, A->sell_ptr, A->sell8_ptr, \
@@ -783,7 +801,7 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     }
-    if (A->sell_val && g_mik_tuning[8] == 0) {
+    if (choice == 1) {
         // sliced-ELL form (mik_sell.h): coalesced streams, per-thread row sums, no LDS
 #define MIK_SELL_GO(FD, NTV)                                                                                                   \
     hipLaunchKernelGGL((k_spmv_sell<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, rb0, nb, map_mode, A->sell_ptr, A->sell_len, \
@@ -798,6 +816,23 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
     const int nbig = A->n_long_big;
     const int nwaves_long = nbig + (nlong - nbig + MIK_LONG_R - 1) / MIK_LONG_R;   // one wave per big row, MIK_LONG_R medium rows per wave
     const int nlb = (nwaves_long + 3) / 4;
+    // CSR kernels.  tuning[14]: 0 = row-block tile filled by LDS-DMA with the per-row gather (k_spmv_rowgather, default),
+    // 1 = products staged through registers (k_spmv_rowblock).  Same results bit for bit (tests/test_gpu_layouts.py).
+    if (g_mik_tuning[14] != 1) {
+        if (nlong) {   // long rows first (whole launches only, see mik_spmv_can_split); the row kernel then picks y[r] up
+            hipLaunchKernelGGL((k_spmv_longrows<T>), dim3(nlb), dim3(MIK_BLOCK), 0, ctx->stream, nlong, nbig, A->long_rows, A->long_rows + nlong,
+                               A->long_rows + 2 * nlong, A->col, (const T *)A->val, x, y, done);
+            MIK_LAUNCH_CHECK(ctx);
+        }
+#define MIK_RG_GO(FD, NTV)                                                                                                      \
+    hipLaunchKernelGGL((k_spmv_rowgather<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, rb0, nb, map_mode, A->rowptr, \
+                       A->col, (const T *)A->val, x, y, seg_out, done, A->is_long)
+        if (fuse_dot) { if (nt) MIK_RG_GO(true, true); else MIK_RG_GO(true, false); }
+        else          { if (nt) MIK_RG_GO(false, true); else MIK_RG_GO(false, false); }
+#undef MIK_RG_GO
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    }
     const bool merge = nlong > 0 && !fuse_dot;           // one launch: long-row workgroups first, then row-blocks
     if (nlong && !merge) {
         // fused dot: long rows first in their own launch, the row-block kernel then picks y[r] up
@@ -868,19 +903,53 @@ extern "C" int mik_time_spmv(mik_ctx *ctx, const mik_csr *A, const void *x, void
 // ---------------------------------------------------------------------------------------------
 // BLAS-1 forms
 // ---------------------------------------------------------------------------------------------
-template <typename T> static int reduce_to_host(mik_ctx *ctx, int64_t n, bool take_sqrt, T *out)
+template <typename T> static int reduce_to_host(mik_ctx *ctx, int64_t n, T *out)
 {
     // level 2 of the segment sums sitting in ctx->partials -> ctx->coef[0] -> host
     const int64_t nseg = mik_nseg<T>(n);
     hipLaunchKernelGGL((k_finalize_store<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg,
                        (int64_t)0, (T *)ctx->coef, (const int *)nullptr);
     MIK_LAUNCH_CHECK(ctx);
-    T v;
-    int rc = read_scalars<T>(ctx, (const T *)ctx->coef, 1, &v);
-    if (rc) return rc;
-    *out = take_sqrt ? (T)std::sqrt(v) : v;   // host sqrt is IEEE correctly rounded
+    return read_scalars<T>(ctx, (const T *)ctx->coef, 1, out);
+}
+
+// norm(x) from the sum of squares t the caller has just reduced: sqrt(t) (host sqrt: IEEE correctly rounded) when t
+// is inside the safe range, the scaled recomputation otherwise (include/mik.h "Norms").
+template <typename T> static int norm_from_sumsq(mik_ctx *ctx, int64_t n, const T *x, T t, T *out)
+{
+    if (mik_nrm_in_range(t)) { *out = (T)std::sqrt(t); return MIK_OK; }
+    return mik_safe_norm_slow<T>(ctx, n, x, out);
+}
+
+template <typename T> int mik_safe_norm_slow(mik_ctx *ctx, int64_t n, const T *x, T *out)
+{
+    if (n <= 0) { *out = T(0); return MIK_OK; }
+    T *scr = (T *)((unsigned char *)ctx->coef + mik_ctx::COEF_SAFE_SLOT);
+    const int grid = (int)std::min<int64_t>((n + MIK_BLOCK - 1) / MIK_BLOCK, 1024);
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(std::max<int64_t>(mik_nseg<T>(n), grid), 1)));
+    hipLaunchKernelGGL((k_amax<T>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, x, (T *)ctx->partials);
+    MIK_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL((k_amax<T>), dim3(1), dim3(MIK_BLOCK), 0, ctx->stream, (int64_t)grid, (const T *)ctx->partials, scr);
+    MIK_LAUNCH_CHECK(ctx);
+    T amax;
+    MIK_TRY(read_scalars<T>(ctx, scr, 1, &amax));
+    if (amax == T(0) || amax != amax || amax > std::numeric_limits<T>::max()) { *out = amax; return MIK_OK; }   // 0, NaN, Inf as they are
+    int e;
+    (void)std::frexp((double)amax, &e);                 // amax = f * 2^e, f in [0.5, 1)
+    e = std::max(-NrmRange<T>::EC, std::min(NrmRange<T>::EC, e));   // keep s and 1 / s normal numbers of T
+    const T sc = (T)std::ldexp(1.0, -e), sinv = (T)std::ldexp(1.0, e);
+    OpScaledSq<T> op{x, sc};
+    MIK_TRY((launch_map<T>(ctx, n, op, mik_aligned16(x), (T *)ctx->partials, nullptr)));
+    hipLaunchKernelGGL((k_finalize_store<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, mik_nseg<T>(n),
+                       (int64_t)0, scr, (const int *)nullptr);
+    MIK_LAUNCH_CHECK(ctx);
+    T t2;
+    MIK_TRY(read_scalars<T>(ctx, scr, 1, &t2));
+    *out = (T)std::sqrt(t2) * sinv;
     return MIK_OK;
 }
+template int mik_safe_norm_slow<double>(mik_ctx *, int64_t, const double *, double *);
+template int mik_safe_norm_slow<float>(mik_ctx *, int64_t, const float *, float *);
 
 template <typename T> static int dot_impl(mik_ctx *ctx, int64_t n, const void *x, const void *y, void *out, bool nrm)
 {
@@ -889,7 +958,10 @@ template <typename T> static int dot_impl(mik_ctx *ctx, int64_t n, const void *x
     OpDot<T> op{(const T *)x, (const T *)y};
     rc = launch_map<T>(ctx, n, op, mik_aligned16(x) && mik_aligned16(y), (T *)ctx->partials, nullptr);
     if (rc) return rc;
-    return reduce_to_host<T>(ctx, n, nrm, (T *)out);
+    T v;
+    MIK_TRY(reduce_to_host<T>(ctx, n, &v));
+    if (!nrm) { *(T *)out = v; return MIK_OK; }
+    return norm_from_sumsq<T>(ctx, n, (const T *)x, v, (T *)out);
 }
 
 extern "C" int mik_dot(mik_ctx *ctx, int dtype, int64_t n, const void *x, const void *y, void *out)
@@ -950,7 +1022,10 @@ static int axpy_dot_impl(mik_ctx *ctx, int64_t n, const void *alpha, const void 
     OpAxpyDot<T> op{(const T *)x, (T *)y, (const T *)z, x ? *(const T *)alpha : T(0), hints};
     const bool vec = mik_aligned16(y) && (!x || mik_aligned16(x)) && (!z || mik_aligned16(z));
     MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)ctx->partials, nullptr)));
-    return reduce_to_host<T>(ctx, n, z == nullptr, (T *)out);
+    T v;
+    MIK_TRY(reduce_to_host<T>(ctx, n, &v));
+    if (z) { *(T *)out = v; return MIK_OK; }
+    return norm_from_sumsq<T>(ctx, n, (const T *)y, v, (T *)out);           // norm(y)
 }
 
 extern "C" int mik_axpy_dot(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, const void *x, void *y, const void *z, void *out,
@@ -969,7 +1044,9 @@ static int axpy2_nrm2_impl(mik_ctx *ctx, int64_t n, const void *alpha, const voi
     OpCgUpdate<T> op{(T *)x, (T *)r, (const T *)u, (const T *)c, coef_val(*(const T *)alpha), hints & 7};
     const bool vec = mik_aligned16(u) && mik_aligned16(x) && mik_aligned16(c) && mik_aligned16(r);
     MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)ctx->partials, nullptr)));
-    return reduce_to_host<T>(ctx, n, true, (T *)out);
+    T v;
+    MIK_TRY(reduce_to_host<T>(ctx, n, &v));
+    return norm_from_sumsq<T>(ctx, n, (const T *)r, v, (T *)out);           // norm(r)
 }
 
 extern "C" int mik_axpy2_nrm2(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, const void *u, void *x, const void *c, void *r,

@@ -38,7 +38,8 @@ struct mik_ctx {
     void *coef = nullptr;            // small device array of coefficients / scalar results
     void *coef_host = nullptr;       // pinned host mirror
     hipEvent_t wait_event = nullptr; // for mik_wait
-    static constexpr size_t COEF_BYTES = 4096;
+    static constexpr size_t COEF_BYTES = 8192;      // [0, 4096): coefficient blocks of the callers; the tail: scratch of mik_safe_norm_slow
+    static constexpr size_t COEF_SAFE_SLOT = 4096;  // byte offset of that scratch
 };
 
 struct mik_csr {
@@ -82,6 +83,18 @@ struct mik_csr {
     int nv = 0, nd = 0;
     bool packed = false;
 };
+
+// norm(x) from t = sum of x_i^2: sqrt(t) whenever t lies inside [LO, HI] -- then no square that matters has
+// underflowed and nothing has overflowed.  Outside (0, denormal range, Inf, NaN) the norm is recomputed with
+// scaling (mik_safe_norm_slow); include/mik.h "Norms".  oracle/mik_oracle.c carries the same constants.
+template <typename T> struct NrmRange;
+template <> struct NrmRange<double> { static constexpr double LO = 0x1p-900, HI = 0x1p+900; static constexpr int EC = 1022; };
+template <> struct NrmRange<float>  { static constexpr float LO = 0x1p-70f, HI = 0x1p+100f; static constexpr int EC = 126; };
+template <typename T> __host__ __device__ static inline bool mik_nrm_in_range(T t) { return t >= NrmRange<T>::LO && t <= NrmRange<T>::HI; }
+
+// Over-/underflow-safe norm of a device n-vector (amax pass, exact power-of-two scaling, the same fixed-shape
+// tree over the scaled squares); *out is a host scalar.  Uses ctx->partials and the tail of ctx->coef; synchronises.
+template <typename T> int mik_safe_norm_slow(mik_ctx *ctx, int64_t n, const T *x, T *out);
 
 extern thread_local std::string g_mik_create_error;
 extern int g_mik_tuning[16];  // development knobs (mik_set_tuning), see mik_spmv_launch
@@ -252,7 +265,11 @@ static inline hipError_t mik_wait(mik_ctx *ctx)
     if (g_mik_tuning[3] == 1 || !ctx->wait_event) return hipStreamSynchronize(ctx->stream);
     hipError_t e = hipEventRecord(ctx->wait_event, ctx->stream);
     if (e != hipSuccess) return e;
-    while ((e = hipEventQuery(ctx->wait_event)) == hipErrorNotReady) __builtin_ia32_pause();
+    while ((e = hipEventQuery(ctx->wait_event)) == hipErrorNotReady) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
     return e;
 }
 

@@ -1,0 +1,71 @@
+// mik_iter.h -- host structures of the L3 iterables (CGIterable and its row-partitioned form), shared by
+// mik_krylov.hip (kernels, single-GPU protocol) and mik_comm.hip (RCCL / in-process transports).
+#pragma once
+#include "mik_internal.h"
+
+template <typename T> struct CgDev {
+    T res, prev_res, alpha, beta, dot_uc, rr, tol, rho;
+    int done, nhist;
+};
+
+// Host-mapped (pinned, device-visible) mirror of the scalars the host needs after a step.  The
+// closing finalise kernel of every step stores it with system scope and then publishes `seq`;
+// the host polls `seq` instead of paying a D2H copy kernel + hipStreamSynchronize per iteration.
+struct CgMirror {
+    double res, prev_res, tol;
+    int done, nhist;
+    int tol_valid;
+    int range;            // 1: the sum of squares of the step after `nhist` left the safe range; the host finishes that step
+    unsigned long long seq;
+};
+
+struct mik_cg {
+    mik_ctx *ctx = nullptr;
+    const mik_csr *A = nullptr;
+    int dtype = MIK_F64;
+    int64_t n = 0;
+    void *x = nullptr, *u = nullptr, *r = nullptr, *c = nullptr;
+    const void *b = nullptr, *diag = nullptr;
+    void *dev = nullptr;       // CgDev<T>
+    void *fin = nullptr;       // FinScratch<T>: wave sums + ticket of the spread level-2 reductions
+    void *hist = nullptr;      // device history of one iterate_many call
+    int64_t hist_cap = 0;
+    void *seg_spmv = nullptr;  // one partial per row-block
+    void *seg_vec = nullptr;   // one partial per vector segment
+    double residual = 0, prev_residual = 1, tol = 0;
+    int64_t maxiter = 0, mv_products = 0;
+    CgMirror *mirror = nullptr;      // host-mapped; same pointer is valid on the device
+    unsigned long long seq = 0;      // steps enqueued so far (published by k_cg_fin_res)
+    bool dev_done = false;           // device stopping flag known to be set
+    // optional in-loop timing of the SpMV launch (HIP events on the ctx stream)
+    bool profile = false;
+    std::vector<hipEvent_t> ev;    // pairs (start, stop), recycled
+    size_t ev_used = 0;
+    double spmv_ms = 0;
+    int64_t spmv_launches = 0;
+};
+
+// Wait until the device has published step `it->seq` in the host-mapped mirror (bounded spin).
+int cg_wait_mirror(mik_cg *it);
+
+struct mik_comm;
+struct mik_cgd {
+    mik_cg base;                 // reuses the single-GPU handle's buffers / mirror / scalars
+    int rank = 0, nranks = 1;
+    int64_t n_send = 0;
+    const int *send_idx = nullptr;   // device: local indices to pack for the neighbours
+    void *send_buf = nullptr;        // device: packed halo values (caller-owned, n_send entries)
+    void *u_ext = nullptr;           // device: n_loc + n_ghost entries (u and its halo)
+    int64_t n_ext = 0;
+    void *dot_all = nullptr, *rr_all = nullptr;   // device: nranks scalars each (caller-owned comm buffers)
+    double abstol = 0, reltol = 0;
+    int initially_zero = 1;
+    int64_t hist_total = 0;
+    int64_t int_begin = 0, int_end = 0;   // row-blocks [int_begin, int_end) reference no halo column (mik_cgd_set_interior)
+    // transport owned by the library (mik_cgd_set_halo_plan / mik_cgd_set_comm, csrc/mik_comm.hip)
+    struct HaloSeg { int peer; int64_t off, cnt; };
+    std::vector<HaloSeg> recv, send;      // offsets into the ghost tail of u_ext / into send_buf, in elements
+    mik_comm *comm = nullptr;
+    bool initialised = false;             // mik_cgd_init ran
+};
+

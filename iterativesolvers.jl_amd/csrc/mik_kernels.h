@@ -84,8 +84,10 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_map_pro(int64_t n, int64_t nseg, 
     }
     T cf = block_level2_256(prev_part, prev_m, lds16);
     if (PRO == 2) {
-        const T nrm = mik_sqrt(cf);
-        cf = T(1) / nrm;
+        T nrm = mik_sqrt(cf);
+        const bool ok = mik_nrm_in_range(cf);       // outside the safe range: leave w alone (* 1), the host rescales
+        cf = ok ? T(1) / nrm : T(1);
+        if (!ok) nrm = __builtin_nan("");
         if (blockIdx.x == 0 && threadIdx.x == 0) { coef_out[0] = nrm; coef_out[1] = cf; }
     } else if (blockIdx.x == 0 && threadIdx.x == 0) {
         coef_out[0] = cf;
@@ -335,6 +337,40 @@ template <typename T> struct OpSubNrm {
     }
 };
 
+// partial sums of (x .* s).^2 -- the scaled pass of the over-/underflow-safe norm (s = exact power of two)
+template <typename T> struct OpScaledSq {
+    static constexpr bool REDUCE = true;
+    const T *__restrict__ x; T s;
+    __device__ __forceinline__ void apply(int64_t i, T &acc) const { T q = x[i] * s; T p = q * q; acc = acc + p; }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &acc) const
+    {
+        auto xv = vload(x + i);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) { T q = el<T>(xv, e) * s; T p = q * q; acc = acc + p; }
+    }
+};
+
+// max |x_i| with NaN propagation (order-independent, so any launch geometry gives the same value):
+// per-workgroup maxima to part[], then one workgroup folds them (launched as <<<1, 256>>> with m partials).
+template <typename T> __device__ __forceinline__ T amax_fold(T m, T a) { return (a > m || a != a) ? a : m; }
+template <typename T>
+__global__ __launch_bounds__(MIK_BLOCK) void k_amax(int64_t n, const T *__restrict__ x, T *__restrict__ part)
+{
+    __shared__ T sm[MIK_BLOCK];
+    T m = T(0);
+    for (int64_t i = (int64_t)blockIdx.x * MIK_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * MIK_BLOCK) {
+        const T v = x[i];
+        m = amax_fold(m, v < T(0) ? -v : v);
+    }
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = MIK_BLOCK / 2; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) sm[threadIdx.x] = amax_fold(sm[threadIdx.x], sm[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+}
+
 // fused CG update: x .+= alpha .* u; r .-= alpha .* c; partial sums of r.^2
 //   -- src/cg.jl:58-59,62 (and :93-96)
 template <typename T> struct OpCgUpdate {
@@ -556,8 +592,10 @@ __global__ __launch_bounds__(MIK_FIN_THREADS) void k_finalize_nrm_inv(const T *_
     T tot = level2_sum(S, m, lds16);
     if (threadIdx.x == 0) {
         T nrm = mik_sqrt(tot);
+        T inv = T(1) / nrm;
+        if (!mik_nrm_in_range(tot)) { nrm = __builtin_nan(""); inv = T(1); }   // host: scaled recomputation (mik_safe_norm_slow)
         out[0] = nrm;
-        out[1] = T(1) / nrm;
+        out[1] = inv;
     }
 }
 

@@ -12,6 +12,7 @@
 #include <tuple>
 
 #include "mik_kernels.h"
+#include "mik_iter.h"
 
 template <typename T>
 int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done);
@@ -30,7 +31,9 @@ bool mik_spmv_can_split(const mik_csr *A);
 // rescaling; [c s; -s c] * [f; g] = [r; 0].
 template <typename T> static void givens_algorithm(T f, T g, T &cs, T &sn, T &r)
 {
-    const T eps = std::numeric_limits<T>::epsilon() / 2;
+    // safmn2 = LinearAlgebra.floatmin2(T) = 2^trunc(log2(floatmin(T) / eps(T)) / 2) with eps(T) = the spacing at 1
+    // (2^-52 / 2^-23, NOT LAPACK's unit roundoff): 2^-485 for Float64 (0x21a0000000000000), 2^-51 for Float32.
+    const T eps = std::numeric_limits<T>::epsilon();
     const T safmin = std::numeric_limits<T>::min();
     const T safmn2 = std::pow(T(2), T((int)(std::log(safmin / eps) / std::log(T(2)) / T(2))));
     const T safmx2 = T(1) / safmn2;
@@ -251,6 +254,18 @@ static int orthogonalize_enqueue(mik_ctx *ctx, int64_t n, int k, const T *V, int
     return launch_map<T>(ctx, n, sc, vecw, (T *)nullptr, nullptr);
 }
 
+// The closing norm of a Gram-Schmidt chain came back as NaN: its sum of squares was outside the safe range and the
+// kernels left w unscaled (k_finalize_nrm_inv / k_map_pro<2> multiply by 1).  Scaled norm, then w .*= inv(nrm).
+template <typename T> static int orth_rescale(mik_ctx *ctx, int64_t n, T *w, T *nrm_host)
+{
+    T nrm;
+    MIK_TRY(mik_safe_norm_slow<T>(ctx, n, w, &nrm));
+    OpScal<T> sc{w, coef_val<T>(T(1) / nrm)};
+    MIK_TRY((launch_map<T>(ctx, n, sc, mik_aligned16(w), (T *)nullptr, nullptr)));
+    *nrm_host = nrm;
+    return MIK_OK;
+}
+
 template <typename T>
 static int orthogonalize_impl(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, T *w, T *h_host, T *nrm_host, int method)
 {
@@ -265,6 +280,7 @@ static int orthogonalize_impl(mik_ctx *ctx, int64_t n, int k, const T *V, int64_
         std::vector<T> hh(k + 2), corr(std::max(k, 1));
         MIK_TRY(coef_download<T>(ctx, 0, hh.data(), k + 2));
         T nrm = hh[k];
+        if (nrm != nrm) MIK_TRY(mik_safe_norm_slow<T>(ctx, n, w, &nrm));   // sum of squares outside the safe range (k_finalize_nrm_inv)
         const T eta = T(1) / std::sqrt(T(2));                           // :20
         auto small_norm = [](const T *v, int len) { T s = T(0); for (int j = 0; j < len; ++j) { T p = v[j] * v[j]; s = s + p; } return (T)std::sqrt(s); };
         T projection_size = small_norm(hh.data(), k);                  // :22
@@ -280,8 +296,9 @@ static int orthogonalize_impl(mik_ctx *ctx, int64_t n, int k, const T *V, int64_
             projection_size = small_norm(corr.data(), k);               // :28
             for (int j = 0; j < k; ++j) hh[j] = hh[j] + corr[j];        // :31
             nrm = nn[0];
+            if (nrm != nrm) MIK_TRY(mik_safe_norm_slow<T>(ctx, n, w, &nrm));
         }
-        OpScal<T> sc{w, coef_ptr<T>(hd + k + 1)};                       // :36
+        OpScal<T> sc{w, coef_val<T>(T(1) / nrm)};                       // :36 (same IEEE quotient the device forms)
         MIK_TRY((launch_map<T>(ctx, n, sc, vecw, (T *)nullptr, nullptr)));
         for (int j = 0; j < k; ++j) h_host[j] = hh[j];
         *nrm_host = nrm;
@@ -291,6 +308,7 @@ static int orthogonalize_impl(mik_ctx *ctx, int64_t n, int k, const T *V, int64_
     MIK_TRY(coef_download<T>(ctx, 0, out.data(), k + 1));
     for (int j = 0; j < k; ++j) h_host[j] = out[j];
     *nrm_host = out[k];
+    if (out[k] != out[k]) MIK_TRY(orth_rescale<T>(ctx, n, w, nrm_host));
     return MIK_OK;
 }
 
@@ -307,21 +325,6 @@ extern "C" int mik_orthogonalize(mik_ctx *ctx, int dtype, int64_t n, int k, cons
 // =============================================================================================
 // CGIterable / PCGIterable
 // =============================================================================================
-template <typename T> struct CgDev {
-    T res, prev_res, alpha, beta, dot_uc, rr, tol, rho;
-    int done, nhist;
-};
-
-// Host-mapped (pinned, device-visible) mirror of the scalars the host needs after a step.  The
-// closing finalise kernel of every step stores it with system scope and then publishes `seq`;
-// the host polls `seq` instead of paying a D2H copy kernel + hipStreamSynchronize per iteration.
-struct CgMirror {
-    double res, prev_res, tol;
-    int done, nhist;
-    int tol_valid, pad;
-    unsigned long long seq;
-};
-
 // Level 2 of a reduction spread over MIK_FIN_WGS single-wave workgroups (the single 1024-thread workgroup of
 // level2_sum pulls its 64 k partials through ONE CU: ~10 us at 256^3).  Workgroup w plays virtual threads
 // 64 w .. 64 w + 63 of the same 1024-thread shape (serial stride-1024 sums, then the wave tree); the workgroup that
@@ -368,26 +371,34 @@ template <typename T> __device__ __forceinline__ bool level2_sum_spread(const T 
 }
 
 // after norm(r) of cg_iterator! (src/cg.jl:140-152)
+template <typename T> __device__ __forceinline__ void cg_init_scalars(CgDev<T> *d, T tot, T res, T reltol, T abstol, long long maxiter)
+{
+    const T a = reltol * res;
+    d->rr = tot;
+    d->res = res;
+    d->prev_res = T(1);                       // one(residual)      :146
+    d->rho = T(1);                            // one(eltype(x))     :151
+    d->tol = a > abstol ? a : abstol;         // :141
+    d->beta = (res * res) / (T(1) * T(1));    // what the first iterate() will use (:50)
+    d->alpha = T(0);
+    d->dot_uc = T(0);
+    d->done = (0 >= maxiter || res <= d->tol) ? 1 : 0;
+    d->nhist = 0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(MIK_FIN_THREADS) void k_cg_fin_init(const T *__restrict__ S, int64_t m, CgDev<T> *d, T reltol, T abstol,
                                                                  long long maxiter)
 {
     __shared__ T lds16[16];
     T tot = level2_sum(S, m, lds16);
-    if (threadIdx.x == 0) {
-        const T res = mik_sqrt(tot);
-        const T a = reltol * res;
-        d->rr = tot;
-        d->res = res;
-        d->prev_res = T(1);                       // one(residual)      :146
-        d->rho = T(1);                            // one(eltype(x))     :151
-        d->tol = a > abstol ? a : abstol;         // :141
-        d->beta = (res * res) / (T(1) * T(1));    // what the first iterate() will use (:50)
-        d->alpha = T(0);
-        d->dot_uc = T(0);
-        d->done = (0 >= maxiter || res <= d->tol) ? 1 : 0;
-        d->nhist = 0;
-    }
+    if (threadIdx.x == 0) cg_init_scalars(d, tot, mik_sqrt(tot), reltol, abstol, maxiter);   // the host re-does this if tot is out of range
+}
+
+// the same with a residual norm the host obtained through the scaled pass (mik_safe_norm_slow)
+template <typename T> __global__ void k_cg_set_init(CgDev<T> *d, T res, T reltol, T abstol, long long maxiter)
+{
+    cg_init_scalars(d, res * res, res, reltol, abstol, maxiter);
 }
 
 // alpha = residual^2 / dot(u, c) (src/cg.jl:55) or rho / dot(u, c) (:90)
@@ -419,6 +430,25 @@ __global__ __launch_bounds__(64) void k_cg_fin_rho(const T *__restrict__ S, int6
 // residual = norm(r) (src/cg.jl:61-62 / :96), history, and the stopping test of :36 for the NEXT
 // iterate() call (iteration index `it_next`)
 template <typename T>
+__device__ __forceinline__ void cg_res_scalars(CgDev<T> *d, T tot, T res, T *__restrict__ hist, long long it_next, long long maxiter,
+                                               CgMirror *mirror, unsigned long long seq, int hist_index)
+{
+    const T prev = d->res;
+    d->rr = tot;
+    d->prev_res = prev;
+    d->res = res;
+    d->beta = (res * res) / (prev * prev);    // :50 of the next step
+    hist[hist_index] = res;                   // step `hist_index` of this host call (the host zeroes mirror->nhist)
+    const int dn = (it_next >= maxiter || res <= d->tol) ? 1 : 0;
+    if (dn) d->done = 1;
+    mirror->res = (double)res;
+    mirror->prev_res = (double)prev;
+    mirror->done = dn;
+    mirror->nhist = hist_index + 1;
+    __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <typename T>
 __global__ __launch_bounds__(64) void k_cg_fin_res(const T *__restrict__ S, int64_t m, CgDev<T> *d, T *__restrict__ hist,
                                                     long long it_next, long long maxiter, CgMirror *mirror,
                                                     unsigned long long seq, int hist_index, FinScratch<T> *fs)
@@ -430,48 +460,29 @@ __global__ __launch_bounds__(64) void k_cg_fin_res(const T *__restrict__ S, int6
     }
     T tot;
     if (level2_sum_spread(S, m, fs, tot)) {
-        const T prev = d->res;
-        const T res = mik_sqrt(tot);
-        d->rr = tot;
-        d->prev_res = prev;
-        d->res = res;
-        d->beta = (res * res) / (prev * prev);    // :50 of the next step
-        hist[hist_index] = res;                   // step `hist_index` of this host call (the host zeroes mirror->nhist)
-        const int dn = (it_next >= maxiter || res <= d->tol) ? 1 : 0;
-        if (dn) d->done = 1;
-        mirror->res = (double)res;
-        mirror->prev_res = (double)prev;
-        mirror->done = dn;
-        mirror->nhist = hist_index + 1;
-        __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!mik_nrm_in_range(tot)) {
+            // |r|^2 underflowed / overflowed (or r is exactly zero): x and r of this step are final, its norm is not.
+            // Freeze the batch (later steps become no-ops) and let the host finish the step with the scaled norm.
+            d->done = 1;
+            mirror->done = 0;
+            mirror->nhist = hist_index;
+            mirror->range = 1;
+            __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        cg_res_scalars(d, tot, mik_sqrt(tot), hist, it_next, maxiter, mirror, seq, hist_index);
     }
 }
 
-struct mik_cg {
-    mik_ctx *ctx = nullptr;
-    const mik_csr *A = nullptr;
-    int dtype = MIK_F64;
-    int64_t n = 0;
-    void *x = nullptr, *u = nullptr, *r = nullptr, *c = nullptr;
-    const void *b = nullptr, *diag = nullptr;
-    void *dev = nullptr;       // CgDev<T>
-    void *fin = nullptr;       // FinScratch<T>: wave sums + ticket of the spread level-2 reductions
-    void *hist = nullptr;      // device history of one iterate_many call
-    int64_t hist_cap = 0;
-    void *seg_spmv = nullptr;  // one partial per row-block
-    void *seg_vec = nullptr;   // one partial per vector segment
-    double residual = 0, prev_residual = 1, tol = 0;
-    int64_t maxiter = 0, mv_products = 0;
-    CgMirror *mirror = nullptr;      // host-mapped; same pointer is valid on the device
-    unsigned long long seq = 0;      // steps enqueued so far (published by k_cg_fin_res)
-    bool dev_done = false;           // device stopping flag known to be set
-    // optional in-loop timing of the SpMV launch (HIP events on the ctx stream)
-    bool profile = false;
-    std::vector<hipEvent_t> ev;    // pairs (start, stop), recycled
-    size_t ev_used = 0;
-    double spmv_ms = 0;
-    int64_t spmv_launches = 0;
-};
+// closes a step whose residual norm the host computed through the scaled pass
+template <typename T>
+__global__ void k_cg_fix_res(CgDev<T> *d, T res, T *__restrict__ hist, long long it_next, long long maxiter, CgMirror *mirror,
+                             unsigned long long seq, int hist_index)
+{
+    d->done = 0;
+    mirror->range = 0;
+    cg_res_scalars(d, res * res, res, hist, it_next, maxiter, mirror, seq, hist_index);
+}
 
 static int cg_profile_collect(mik_cg *it)
 {
@@ -544,7 +555,7 @@ template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next, 
 }
 
 // Wait until the device has published step `seq` in the host-mapped mirror (bounded spin).
-static int cg_wait_mirror(mik_cg *it)
+int cg_wait_mirror(mik_cg *it)
 {
     volatile unsigned long long *p = &it->mirror->seq;
     const unsigned long long want = it->seq;
@@ -599,6 +610,14 @@ static int cg_init_impl(mik_cg *it, double abstol, double reltol, int initially_
     MIK_LAUNCH_CHECK(ctx);
     CgDev<T> h;
     MIK_TRY(cg_fetch_state<T>(it, &h));
+    if (!mik_nrm_in_range(h.rr)) {
+        // badly scaled system (or r = 0): the over-/underflow-safe norm, then the same scalar set-up
+        T res;
+        MIK_TRY(mik_safe_norm_slow<T>(ctx, n, r, &res));
+        hipLaunchKernelGGL((k_cg_set_init<T>), dim3(1), dim3(1), 0, ctx->stream, (CgDev<T> *)it->dev, res, (T)reltol, (T)abstol, (long long)it->maxiter);
+        MIK_LAUNCH_CHECK(ctx);
+        MIK_TRY(cg_fetch_state<T>(it, &h));
+    }
     it->residual = (double)h.res;
     it->prev_residual = (double)h.prev_res;
     it->tol = (double)h.tol;
@@ -626,7 +645,7 @@ extern "C" int mik_cg_create(mik_ctx *ctx, const mik_csr *A, void *x, const void
     hipError_t e;
     (void)hipSetDevice(ctx->device);
     if ((e = hipMalloc(&it->dev, 256)) != hipSuccess || (e = hipMalloc(&it->fin, 256)) != hipSuccess ||
-        (e = hipMemset(it->fin, 0, 256)) != hipSuccess || (e = hipMalloc(&it->seg_spmv, es * (size_t)std::max<int64_t>(nb, 1))) != hipSuccess ||
+        (e = hipMemsetAsync(it->fin, 0, 256, ctx->stream)) != hipSuccess || (e = hipMalloc(&it->seg_spmv, es * (size_t)std::max<int64_t>(nb, 1))) != hipSuccess ||
         (e = hipMalloc(&it->seg_vec, es * (size_t)std::max<int64_t>(nseg, 1))) != hipSuccess ||
         (e = hipMalloc(&it->hist, es * 64)) != hipSuccess) {
         mik_cg_destroy(it);
@@ -680,10 +699,27 @@ static int cg_iterate_many_impl(mik_cg *it, int64_t iteration, int64_t max_steps
     // step counter in the host-mapped mirror directly.  The stopping flag only needs clearing if a previous
     // call left it set while the host test above said "not done" (e.g. the caller restarted the count).
     it->mirror->nhist = 0;
+    it->mirror->range = 0;
     if (it->dev_done) MIK_HIP(ctx, hipMemsetAsync(&d->done, 0, sizeof(int), ctx->stream));
-    for (int64_t j = 0; j < max_steps; ++j) MIK_TRY(cg_enqueue_step<T>(it, (long long)(iteration + j + 1), (int)j));
-    MIK_TRY(cg_wait_mirror(it));
-    const CgMirror m = *it->mirror;
+    CgMirror m;
+    for (int64_t j0 = 0;;) {
+        for (int64_t j = j0; j < max_steps; ++j) MIK_TRY(cg_enqueue_step<T>(it, (long long)(iteration + j + 1), (int)j));
+        MIK_TRY(cg_wait_mirror(it));
+        m = *it->mirror;
+        if (!m.range) break;
+        // Step m.nhist of this call updated x and r, but |r|^2 left the range in which sqrt(sum of squares) is safe
+        // (include/mik.h "Norms"): the device froze the batch; finish that step with the scaled norm and go on.
+        T res;
+        MIK_TRY(mik_safe_norm_slow<T>(ctx, it->n, (const T *)it->r, &res));
+        it->seq += 1;
+        hipLaunchKernelGGL((k_cg_fix_res<T>), dim3(1), dim3(1), 0, ctx->stream, d, res, (T *)it->hist, (long long)(iteration + m.nhist + 1),
+                           (long long)it->maxiter, it->mirror, it->seq, (int)m.nhist);
+        MIK_LAUNCH_CHECK(ctx);
+        MIK_TRY(cg_wait_mirror(it));
+        m = *it->mirror;
+        j0 = m.nhist;
+        if (m.done || j0 >= max_steps) break;
+    }
     const int64_t nd = m.nhist;
     if (nd == 1) {
         if (residuals) residuals[0] = m.res;
@@ -799,6 +835,16 @@ template <typename T> static int gm_reduce(mik_gmres *g, T *values, int count)
     return MIK_OK;
 }
 
+// Row-partitioned norms: sqrt(sum over ranks of the local sums of squares).  The scaled recomputation of the single-GPU
+// path would need a max over ranks, which the reduce() callback does not offer: outside the safe range the call fails
+// loudly on every rank alike (ss is identical everywhere) instead of declaring convergence on an underflowed residual.
+// An exact 0 is taken as a zero vector.
+template <typename T> static int gm_range_check(mik_gmres *g, T ss)
+{
+    if (ss == T(0) || mik_nrm_in_range(ss)) return MIK_OK;
+    return mik_fail(g->ctx, MIK_ERR_RANGE, "gmres (row-partitioned): sum of squares %g outside the range of a safe norm; rescale the system", (double)ss);
+}
+
 // orthogonalize_and_normalize! over a row partition (src/orthogonalize.jl:13-79): the same sweeps as
 // orthogonalize_impl on the local rows; every projection / norm^2 is finalised to a host scalar, summed
 // over the ranks by the caller's reduce() and fed back as a kernel argument.
@@ -865,6 +911,7 @@ static int orthogonalize_part(mik_gmres *g, int k, const T *V, int64_t ldv, T *w
             }
         }
     }
+    MIK_TRY(gm_range_check<T>(g, ss));
     const T nrm = std::sqrt(ss);
     const T inv = T(1) / nrm;
     OpScal<T> sc{w, coef_val<T>(inv)};                                   // w .*= inv(nrm)  :76 / :48 / :36
@@ -911,6 +958,7 @@ template <typename T> static int gmres_init_residual(mik_gmres *g, int initially
         MIK_TRY(finalize_store<T>(ctx, nseg, 1, hd));
         MIK_TRY(coef_download<T>(ctx, 0, &ss, 1));
         MIK_TRY(gm_reduce<T>(g, &ss, 1));
+        MIK_TRY(gm_range_check<T>(g, ss));
         const T beta = std::sqrt(ss);                                     // :252
         const T inv = T(1) / beta;
         OpScal<T> scd{V0, coef_val<T>(inv)};                              // :253
@@ -924,6 +972,7 @@ template <typename T> static int gmres_init_residual(mik_gmres *g, int initially
     T out[2];
     MIK_TRY(coef_download<T>(ctx, 0, out, 2));
     *beta_out = out[0];
+    if (out[0] != out[0]) MIK_TRY(orth_rescale<T>(ctx, n, V0, beta_out));   // badly scaled residual: scaled norm, then :253
     return MIK_OK;
 }
 
@@ -1087,6 +1136,7 @@ template <typename T> static int gm_step_graph(mik_gmres *g, int k, T *vk, T *vk
     for (int j = 0; j < k; ++j) h_out[j] = out[j];
     *nrm_out = out[k];
     *ran = true;
+    if (out[k] != out[k]) MIK_TRY(orth_rescale<T>(ctx, g->n, vk1, nrm_out));
     return MIK_OK;
 }
 
@@ -1259,6 +1309,11 @@ __global__ void k_cgd_fin_init(const T *__restrict__ rr_all, int nranks, CgDev<T
                                unsigned long long seq)
 {
     const T tot = rank_sum(rr_all, nranks);
+    if (tot != T(0) && !mik_nrm_in_range(tot)) {   // see gm_range_check: fail loudly (mik_cgd_wait returns MIK_ERR_RANGE)
+        d->done = 1; mirror->done = 1; mirror->range = 1;
+        __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     const T res = mik_sqrt(tot);
     const T a = reltol * res;
     d->rr = tot; d->res = res; d->prev_res = T(1); d->rho = T(1);
@@ -1278,6 +1333,11 @@ __global__ void k_cgd_fin_res(const T *__restrict__ rr_all, int nranks, CgDev<T>
 {
     if (d->done) { __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); return; }
     const T tot = rank_sum(rr_all, nranks);
+    if (tot != T(0) && !mik_nrm_in_range(tot)) {
+        d->done = 1; mirror->done = 1; mirror->range = 1;
+        __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     const T prev = d->res;
     const T res = mik_sqrt(tot);
     d->rr = tot; d->prev_res = prev; d->res = res;
@@ -1290,21 +1350,6 @@ __global__ void k_cgd_fin_res(const T *__restrict__ rr_all, int nranks, CgDev<T>
     mirror->res = (double)res; mirror->prev_res = (double)prev; mirror->done = dn; mirror->nhist = nh;
     __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-
-struct mik_cgd {
-    mik_cg base;                 // reuses the single-GPU handle's buffers / mirror / scalars
-    int rank = 0, nranks = 1;
-    int64_t n_send = 0;
-    const int *send_idx = nullptr;   // device: local indices to pack for the neighbours
-    void *send_buf = nullptr;        // device: packed halo values (caller-owned, n_send entries)
-    void *u_ext = nullptr;           // device: n_loc + n_ghost entries (u and its halo)
-    int64_t n_ext = 0;
-    void *dot_all = nullptr, *rr_all = nullptr;   // device: nranks scalars each (caller-owned comm buffers)
-    double abstol = 0, reltol = 0;
-    int initially_zero = 1;
-    int64_t hist_total = 0;
-    int64_t int_begin = 0, int_end = 0;   // row-blocks [int_begin, int_end) reference no halo column (mik_cgd_set_interior)
-};
 
 extern "C" int mik_cgd_create(mik_ctx *ctx, const mik_csr *A_loc, void *x, const void *b, void *u_ext, void *r, void *c,
                               const int32_t *send_idx, int64_t n_send, void *send_buf, void *dot_all, void *rr_all, int rank,
@@ -1358,9 +1403,12 @@ extern "C" int mik_cgd_set_interior(mik_cgd *it, int64_t rb_begin, int64_t rb_en
     return MIK_OK;
 }
 
+void mik_cgd_group_forget(mik_cgd *it);   // mik_comm.hip
+
 extern "C" int mik_cgd_destroy(mik_cgd *it)
 {
     if (!it) return MIK_OK;
+    mik_cgd_group_forget(it);
     mik_cg &bs = it->base;
     if (bs.ctx) (void)hipStreamSynchronize(bs.ctx->stream);
     if (bs.dev) (void)hipFree(bs.dev);
@@ -1469,6 +1517,8 @@ extern "C" int mik_cgd_wait(mik_cgd *it, double *residual, double *tol, int *don
     mik_ctx *ctx = bs.ctx;
     MIK_TRY(cg_wait_mirror(&bs));
     const CgMirror m = *bs.mirror;
+    if (m.range)
+        return mik_fail(ctx, MIK_ERR_RANGE, "cg (row-partitioned): |r|^2 left the range of a safe norm (badly scaled system); rescale b and A");
     const int64_t nd = m.nhist;
     if (history && nd > 0) {
         const int64_t take = std::min<int64_t>(nd, cap);
@@ -1585,8 +1635,8 @@ static int bicg_mr_impl(mik_ctx *ctx, int64_t n, int l, T *us, int64_t ldu, T *r
     MIK_TRY(finalize_store<T>(ctx, nseg, 1, (T *)ctx->coef));
     T ss;
     MIK_TRY(coef_download<T>(ctx, 0, &ss, 1));
-    *out = (T)std::sqrt(ss);
-    return MIK_OK;
+    if (mik_nrm_in_range(ss)) { *out = (T)std::sqrt(ss); return MIK_OK; }
+    return mik_safe_norm_slow<T>(ctx, n, rs, out);                       // norm(rs[:, 1]) of a badly scaled residual
 }
 
 extern "C" int mik_bicgstab_mr_update(mik_ctx *ctx, int dtype, int64_t n, int l, void *us, int64_t ldu, void *rs, int64_t ldr, void *x,

@@ -311,4 +311,102 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// the default CSR kernel: row-block tile filled by LDS-DMA, per-row gather
+// ---------------------------------------------------------------------------------------------
+// k_spmv_rowblock parks PRODUCTS in LDS: the lanes that stream consecutive ENTRIES also gather x for them, so one
+// gather instruction of a wave touches ~10 cache lines for a 7-point row-block (entries of ~9 rows, 7 regions of x).
+// Here the tile holds the operator's val[] / col[] AS THEY ARE; after the barrier every lane walks ITS row: column and
+// value from LDS, x[column] from memory -- lanes l, l + 1 then read neighbouring x entries for banded operators
+// (1-2 lines per wave-instruction) -- multiply, add, in ascending column order from +0: same products, same order,
+// same bits.
+// The tile is filled by global_load_lds_dwordx4 (gfx950 LDS-DMA: HBM -> LDS without passing through VGPRs; 1 KiB per
+// wave-instruction, the LDS image is the memory image), so staging costs no vector registers, no ds_write and no
+// VALU work; the stream is waited for with one vmcnt(0) before the barrier.
+//
+// Measured at 256^3 fp64 inside the CG loop (scripts/spmv_inloop.py, interleaved rounds): k_spmv_rowblock 302 us,
+// this layout staged through registers 299 us, filled by LDS-DMA 291 us (278 us back to back = 6.25 TB/s).  Also
+// built and measured: wave-private tiles (every wave stages its own 64 rows, no workgroup barrier at all) -- 354-380 us
+// in all four variants (row / entry gather, padded or not): the barriers were not what the workgroup tile was
+// waiting for, and per-element LDS writes cost more than they saved.
+template <typename T, bool FUSE_DOT, bool NT>
+__global__ __launch_bounds__(MIK_BLOCK, 6) void k_spmv_rowgather(int n, int rb0, int nb, int map_mode, const int *__restrict__ rowptr,
+                                                              const int *__restrict__ col, const T *__restrict__ val,
+                                                              const T *__restrict__ x, T *__restrict__ y, T *__restrict__ seg_out,
+                                                              const int *__restrict__ done, const unsigned char *__restrict__ is_long)
+{
+    if (done && *done) return;
+    constexpr int TILE = MIK_SPMV_TILE;                // entries per pass: 2048 (fp64: 16 KB values + 8 KB columns)
+    constexpr int VW = VT<T>::W;
+    constexpr int VP = 1024 / (int)sizeof(T);          // entries per 1-KiB DMA piece of val
+    constexpr int CP = 256;                            // entries per 1-KiB DMA piece of col
+    __shared__ __attribute__((aligned(16))) T sval[TILE];
+    __shared__ __attribute__((aligned(16))) int scol[TILE];
+    __shared__ T lds4[4];
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int rb = rb0 + spmv_block_map((int)blockIdx.x, nb, map_mode);   // this launch covers row-blocks [rb0, rb0 + nb)
+    const int r0 = rb * MIK_BLOCK;
+    const int r = r0 + t;
+    int ks = 0, ke = 0;
+    if (r < n) { ks = rowptr[r]; ke = rowptr[r + 1]; }
+    const int kb = rowptr[r0] & ~3;                    // 16-byte aligned start of both streams
+    const int kend = rowptr[min(r0 + MIK_BLOCK, n)];
+
+    T acc = T(0);
+    for (int kc = kb; kc < kend; kc += TILE) {
+        const int cnt = min(TILE, kend - kc);
+        // wave wv issues pieces wv, wv + 4, ...; a piece is issued iff it holds an entry < cnt (wave-uniform);
+        // reads past kend stay inside the padded allocation
+#pragma unroll
+        for (int p = 0; p < TILE / VP / 4; ++p) {
+            const int piece = wv + 4 * p;
+            if (piece * VP < cnt)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(val + kc + piece * VP + lane * VW),
+                                                 (__attribute__((address_space(3))) void *)(sval + piece * VP), 16, 0, NT ? 2 : 0);
+        }
+#pragma unroll
+        for (int p = 0; p < TILE / CP / 4; ++p) {
+            const int piece = wv + 4 * p;
+            if (piece * CP < cnt)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(col + kc + piece * CP + lane * 4),
+                                                 (__attribute__((address_space(3))) void *)(scol + piece * CP), 16, 0, NT ? 2 : 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- this lane's row, ascending column order ----
+        int a = max(ks, kc) - kc;
+        int len = min(ke, kc + cnt) - kc - a;
+        while (len > 0) {
+            T q[8];
+            int cc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int s = min(a + i, TILE - 1);
+                cc[i] = scol[s];
+                q[i] = sval[s];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const T xv = x[i < len ? cc[i] : 0];              // slots past the row gather a valid address
+                q[i] = q[i] * xv;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < len) acc = acc + q[i];
+            a += 8;
+            len -= 8;
+        }
+        if (kc + TILE < kend) __syncthreads();         // workgroup-uniform: another pass will overwrite the tile
+    }
+    if (is_long && r < n && is_long[r]) acc = y[r];    // summed by k_spmv_longrows earlier on the stream
+    else if (r < n) st_stream<NT>(y + r, acc);
+    if (FUSE_DOT) {
+        T p = T(0);
+        if (r < n) p = x[r] * acc;
+        T tot = block_tree_256(p, lds4);
+        if (t == 0) seg_out[rb] = tot;
+    }
+}
+
 #endif  // __HIPCC__

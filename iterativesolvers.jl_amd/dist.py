@@ -454,6 +454,157 @@ class DistCGIterable:
             yield self.residual
 
 
+def _plan_arrays(plan: HaloPlan):
+    """(n, peer int32[], off int64[], cnt int64[]) x 2 for mik_cgd_set_halo_plan / mik_comm_halo (kept alive by the caller)."""
+    def pack(segs):
+        peer = np.asarray([s[0] for s in segs], np.int32)
+        off = np.asarray([s[1] for s in segs], np.int64)
+        cnt = np.asarray([s[2] for s in segs], np.int64)
+        return peer, off, cnt
+    return pack(plan.recv), pack(plan.send)
+
+
+def register_halo_plan(pkg, engine):
+    """Hand the rank's halo plan to the library (``mik_cgd_set_halo_plan``): from then on libmik.so runs the exchanges."""
+    (rp, ro, rc), (sp, so, sc) = _plan_arrays(engine.plan)
+    ip, lp = C.POINTER(C.c_int), C.POINTER(C.c_int64)
+    pkg._lib.check(engine.L.mik_cgd_set_halo_plan(engine.handle, rp.size, rp.ctypes.data_as(ip), ro.ctypes.data_as(lp), rc.ctypes.data_as(lp),
+                                                  sp.size, sp.ctypes.data_as(ip), so.ctypes.data_as(lp), sc.ctypes.data_as(lp)),
+                   "mik_cgd_set_halo_plan", engine.ctx.handle)
+
+
+class NativeComm:
+    """``mik_comm``: RCCL bound INSIDE libmik.so (include/mik.h "Transport 1").  ``bootstrap`` is any communicator of this
+    module (TorchComm over gloo or nccl, SelfComm): it only carries rank 0's 128-byte ncclUniqueId to the other ranks --
+    what MPI.jl's ``bcast`` would do for a Julia host.  ``force_rccl`` creates a real RCCL communicator even in a world
+    of one (exercises the library's RCCL call path on a single-GPU box)."""
+
+    def __init__(self, pkg, ctx, bootstrap, *, force_rccl=False):
+        self.pkg, self.ctx, self.L = pkg, ctx, pkg.lib()
+        self.rank, self.size = bootstrap.rank, bootstrap.size
+        ident = None
+        if self.size > 1 or force_rccl:
+            buf = C.create_string_buffer(128)
+            if self.rank == 0:
+                pkg._lib.check(self.L.mik_comm_unique_id(buf), "mik_comm_unique_id")
+            ident = bootstrap.all_gather_objects(bytes(buf.raw))[0]
+        h = _vp()
+        pkg._lib.check(self.L.mik_comm_create(ctx.handle, ident, self.rank, self.size, C.byref(h)), "mik_comm_create", ctx.handle)
+        self.handle = h
+
+    def uses_rccl(self) -> bool:
+        out = C.c_int()
+        self.L.mik_comm_info(self.handle, None, None, C.byref(out))
+        return bool(out.value)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.mik_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NativeDistCGIterable:
+    """``CGIterable`` over a row partition with the exchanges run by libmik.so itself: ``iterate_many`` is ONE C call
+    (``mik_cgd_iterate_many``: pack, ncclSend/ncclRecv halo on a side stream overlapped with the interior rows, SpMV,
+    ncclAllGather of one scalar per rank, update, ncclAllGather, stopping test -- per step, no host code in between)."""
+
+    def __init__(self, pkg, engine, native_comm: NativeComm, *, maxiter):
+        self.pkg, self.e, self.comm, self.maxiter = pkg, engine, native_comm, int(maxiter)
+        self.mv_products = 0
+        register_halo_plan(pkg, engine)
+        pkg._lib.check(engine.L.mik_cgd_set_comm(engine.handle, native_comm.handle), "mik_cgd_set_comm", engine.ctx.handle)
+        res, tol = C.c_double(), C.c_double()
+        with engine.stream_ctx():
+            pkg._lib.check(engine.L.mik_cgd_init(engine.handle, C.byref(res), C.byref(tol)), "mik_cgd_init", engine.ctx.handle)
+        self.residual, self.tol, self.prev_residual = res.value, tol.value, 1.0
+
+    def converged(self) -> bool:
+        return self.residual <= self.tol
+
+    def done(self, iteration: int) -> bool:
+        return iteration >= self.maxiter or self.converged()
+
+    def iterate_many(self, iteration: int, max_steps: int) -> np.ndarray:
+        if max_steps <= 0 or self.done(iteration):
+            return np.zeros(0)
+        max_steps = min(int(max_steps), self.maxiter - iteration, 1024)
+        hist = np.empty(max_steps, np.float64)
+        steps = C.c_int64()
+        e = self.e
+        with e.stream_ctx():
+            self.pkg._lib.check(e.L.mik_cgd_iterate_many(e.handle, int(iteration), max_steps, hist.ctypes.data_as(C.POINTER(C.c_double)),
+                                                         C.byref(steps)), "mik_cgd_iterate_many", e.ctx.handle)
+        hist = hist[:steps.value].copy()
+        if hist.size:
+            self.prev_residual = hist[-2] if hist.size > 1 else self.residual
+            self.residual = float(hist[-1])
+            self.mv_products += hist.size
+        return hist
+
+    def iterate(self, iteration: int = 0):
+        h = self.iterate_many(iteration, 1)
+        return None if h.size == 0 else (self.residual, iteration + 1)
+
+
+class GroupCG:
+    """P ranks driven by ONE host thread through ``mik_cgd_group_*`` (include/mik.h "Transport 2"): every engine has its own
+    ctx (and may sit on its own GPU: peer copies over xGMI), the library orders halos and scalar gathers with events.
+    On a single-GPU box this runs P virtual ranks on one device -- the check that the library's step routine equals the
+    partition-aware oracle bit for bit."""
+
+    def __init__(self, pkg, engines: Sequence, *, maxiter):
+        self.pkg, self.engines, self.maxiter = pkg, list(engines), int(maxiter)
+        for e in self.engines:
+            register_halo_plan(pkg, e)
+        self.P = len(self.engines)
+        self.handles = (_vp * self.P)(*[e.handle for e in self.engines])
+        self.L = self.engines[0].L
+        res, tol = C.c_double(), C.c_double()
+        pkg._lib.check(self.L.mik_cgd_group_init(self.handles, self.P, C.byref(res), C.byref(tol)), "mik_cgd_group_init", self.engines[0].ctx.handle)
+        self.residual, self.tol = res.value, tol.value
+
+    def done(self, iteration):
+        return iteration >= self.maxiter or self.residual <= self.tol
+
+    def iterate_many(self, iteration: int, max_steps: int) -> np.ndarray:
+        if max_steps <= 0 or self.done(iteration):
+            return np.zeros(0)
+        max_steps = min(int(max_steps), self.maxiter - iteration, 1024)
+        hist = np.empty(max_steps, np.float64)
+        steps = C.c_int64()
+        self.pkg._lib.check(self.L.mik_cgd_group_iterate_many(self.handles, self.P, int(iteration), max_steps,
+                                                              hist.ctypes.data_as(C.POINTER(C.c_double)), C.byref(steps)),
+                            "mik_cgd_group_iterate_many", self.engines[0].ctx.handle)
+        hist = hist[:steps.value].copy()
+        if hist.size:
+            self.residual = float(hist[-1])
+        return hist
+
+    def solve(self) -> np.ndarray:
+        out, iteration = [], 0
+        while True:
+            h = self.iterate_many(iteration, 64)
+            if h.size == 0:
+                break
+            out.append(h)
+            iteration += h.size
+        return np.concatenate(out) if out else np.zeros(0)
+
+    def solution(self) -> np.ndarray:
+        return np.concatenate([e.solution() for e in self.engines])
+
+    def close(self):
+        if getattr(self, "handles", None) is not None:
+            self.L.mik_cgd_group_release(self.handles, self.P)
+            self.handles = None
+
+
 class PartitionLinks:
     """The two points where the ranks of a row-partitioned iterable couple (include/mik.h: mik_halo_fn,
     mik_reduce_fn), on top of a communicator.  ``send_buf`` / ``x_ext`` are 1-D tensors (device tensors for

@@ -25,6 +25,7 @@
 #define ORC_SEQ 0
 #define ORC_PAIR 1
 #define ORC_TREE 2
+#define ORC_BLAS 3
 
 #define ORC_MGS 0
 #define ORC_CGS 1
@@ -46,6 +47,29 @@ int orc_set_partition(int nparts, const int64_t *offsets)
 static int64_t g_orc_long_row = 0;
 void orc_set_long_row(int64_t threshold) { g_orc_long_row = threshold > 0 ? threshold : 0; }
 
+/* ORC_BLAS: entry points of the host's OpenBLAS (CBLAS interface, 32-bit ints), bound by oracle/orc.py from the
+ * library NumPy / SciPy ship -- the same library family LinearAlgebra.dot / norm / mul! reach in the reference. */
+typedef double (*orc_ddot_fn)(int, const double *, int, const double *, int);
+typedef double (*orc_dnrm2_fn)(int, const double *, int);
+typedef void (*orc_dgemv_fn)(int, int, int, int, double, const double *, int, const double *, int, double, double *, int);
+typedef float (*orc_sdot_fn)(int, const float *, int, const float *, int);
+typedef float (*orc_snrm2_fn)(int, const float *, int);
+typedef void (*orc_sgemv_fn)(int, int, int, int, float, const float *, int, const float *, int, float, float *, int);
+static orc_ddot_fn g_blas_dot_f64;
+static orc_dnrm2_fn g_blas_nrm2_f64;
+static orc_dgemv_fn g_blas_gemv_f64;
+static orc_sdot_fn g_blas_dot_f32;
+static orc_snrm2_fn g_blas_nrm2_f32;
+static orc_sgemv_fn g_blas_gemv_f32;
+int orc_set_blas(void *ddot, void *dnrm2, void *dgemv, void *sdot, void *snrm2, void *sgemv)
+{
+    if (!ddot || !dnrm2 || !dgemv || !sdot || !snrm2 || !sgemv) return 1;
+    g_blas_dot_f64 = (orc_ddot_fn)ddot; g_blas_nrm2_f64 = (orc_dnrm2_fn)dnrm2; g_blas_gemv_f64 = (orc_dgemv_fn)dgemv;
+    g_blas_dot_f32 = (orc_sdot_fn)sdot; g_blas_nrm2_f32 = (orc_snrm2_fn)snrm2; g_blas_gemv_f32 = (orc_sgemv_fn)sgemv;
+    return 0;
+}
+int orc_have_blas(void) { return g_blas_dot_f64 != 0; }
+
 /* ---- fp64 instantiation ---- */
 #define T double
 #define F(x) x##_f64
@@ -53,8 +77,12 @@ void orc_set_long_row(int64_t threshold) { g_orc_long_row = threshold > 0 ? thre
 #define FABS_f64 fabs
 #define POW_f64 pow
 #define LOG_f64 log
-#define EPS_f64 (DBL_EPSILON / 2) /* LAPACK eps = relative machine precision (unit roundoff) */
+#define EPS_f64 DBL_EPSILON /* Julia's eps(Float64) = 2^-52: LinearAlgebra.floatmin2 uses it, not LAPACK's unit roundoff */
 #define TMIN_f64 DBL_MIN
+#define TMAX_f64 DBL_MAX
+#define NRM_LO_f64 0x1p-900     /* safe range of a sum of squares, see safe_nrm_ */
+#define NRM_HI_f64 0x1p+900
+#define NRM_EC_f64 1022
 #include "orc_impl.inc"
 #undef T
 #undef F
@@ -66,8 +94,12 @@ void orc_set_long_row(int64_t threshold) { g_orc_long_row = threshold > 0 ? thre
 #define FABS_f32 fabsf
 #define POW_f32 powf
 #define LOG_f32 logf
-#define EPS_f32 (FLT_EPSILON / 2)
+#define EPS_f32 FLT_EPSILON
 #define TMIN_f32 FLT_MIN
+#define TMAX_f32 FLT_MAX
+#define NRM_LO_f32 0x1p-70f
+#define NRM_HI_f32 0x1p+100f
+#define NRM_EC_f32 126
 #include "orc_impl.inc"
 #undef T
 #undef F

@@ -16,8 +16,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libmik_oracle.so")
 
-SEQ, PAIR, TREE = 0, 1, 2
-MODES = {"seq": SEQ, "pair": PAIR, "tree": TREE}
+SEQ, PAIR, TREE, BLAS = 0, 1, 2, 3
+MODES = {"seq": SEQ, "pair": PAIR, "tree": TREE, "blas": BLAS}
 MGS, CGS, DGKS = 0, 1, 2
 METHODS = {"mgs": MGS, "cgs": CGS, "dgks": DGKS}
 
@@ -41,6 +41,46 @@ def lib() -> C.CDLL:
         _lib = C.CDLL(_LIB_PATH)
         _declare(_lib)
     return _lib
+
+
+_blas = None
+
+
+def blas_info():
+    """The host OpenBLAS bound for mode="blas" (None until bind_blas ran)."""
+    return _blas
+
+
+def bind_blas(threads: int = 1):
+    """Bind mode="blas" to the OpenBLAS that SciPy ships (LP64 CBLAS symbols ``scipy_cblas_*``): LinearAlgebra.dot /
+    norm / mul! of the reference reach the same library family through libblastrampoline.  ``threads`` pins the
+    BLAS thread count (1 = deterministic across machines with the same kernel; OpenBLAS splits ?dot / ?nrm2 across
+    threads for long vectors, which changes the summation order).  Returns a description of what was bound."""
+    global _blas
+    import glob
+    import scipy
+    cands = sorted(glob.glob(os.path.join(os.path.dirname(scipy.__file__) + ".libs", "libscipy_openblas*.so")))
+    if not cands:
+        raise RuntimeError("no bundled OpenBLAS found next to SciPy")
+    B = C.CDLL(cands[0])
+    B.scipy_openblas_set_num_threads(int(threads))
+    B.scipy_openblas_get_config.restype = C.c_char_p
+    B.scipy_openblas_get_corename.restype = C.c_char_p
+    L = lib()
+    L.orc_set_blas.argtypes = [C.c_void_p] * 6
+    L.orc_set_blas.restype = C.c_int
+    fns = [C.cast(getattr(B, "scipy_cblas_" + nm), C.c_void_p) for nm in ("ddot", "dnrm2", "dgemv", "sdot", "snrm2", "sgemv")]
+    assert L.orc_set_blas(*fns) == 0
+    _blas = dict(library=os.path.basename(cands[0]), config=B.scipy_openblas_get_config().decode(),
+                 core=B.scipy_openblas_get_corename().decode(), threads=int(threads), _handle=B)
+    return {k: v for k, v in _blas.items() if not k.startswith("_")}
+
+
+def _mode(mode):
+    m = MODES[mode]
+    if m == BLAS and _blas is None:
+        bind_blas(1)
+    return m
 
 
 def _p(a, ct):
@@ -222,13 +262,13 @@ def dot(x, y, mode="seq", W=1, L=1):
     suf, ct = _suf(x.dtype)
     x = np.ascontiguousarray(x)
     y = np.ascontiguousarray(y, x.dtype)
-    return getattr(lib(), f"orc_dot_{suf}")(_p(x, ct), _p(y, ct), x.size, MODES[mode], W, L)
+    return getattr(lib(), f"orc_dot_{suf}")(_p(x, ct), _p(y, ct), x.size, _mode(mode), W, L)
 
 
 def nrm2(x, mode="seq", W=1, L=1):
     suf, ct = _suf(x.dtype)
     x = np.ascontiguousarray(x)
-    return getattr(lib(), f"orc_nrm2_{suf}")(_p(x, ct), x.size, MODES[mode], W, L)
+    return getattr(lib(), f"orc_nrm2_{suf}")(_p(x, ct), x.size, _mode(mode), W, L)
 
 
 def _eps_sqrt(dtype):
@@ -258,7 +298,7 @@ def cg(A: CSC, b, x0=None, *, abstol=0.0, reltol=None, maxiter=None, jacobi_diag
     getattr(lib(), f"orc_cg_{suf}")(n, _p(A.colptr, C.c_int64), _p(A.rowval, C.c_int64),
                                     _p(A.nzval, ct), A.index_base, _p(b, ct), _p(x, ct),
                                     float(abstol), float(reltol), maxiter, int(initially_zero),
-                                    _p(jd, ct), MODES[mode], _p(shp, C.c_int),
+                                    _p(jd, ct), _mode(mode), _p(shp, C.c_int),
                                     _p(res, C.c_double), C.byref(iters), C.byref(mvps),
                                     C.byref(conv), C.byref(res0), C.byref(tol))
     hist = dict(iters=iters.value, mvps=mvps.value, isconverged=bool(conv.value),
@@ -287,7 +327,7 @@ def gmres(A: CSC, b, x0=None, *, abstol=0.0, reltol=None, restart=None, maxiter=
     getattr(lib(), f"orc_gmres_{suf}")(n, _p(A.colptr, C.c_int64), _p(A.rowval, C.c_int64),
                                        _p(A.nzval, ct), A.index_base, _p(b, ct), _p(x, ct),
                                        float(abstol), float(reltol), restart, maxiter,
-                                       int(initially_zero), METHODS[orth_meth], MODES[mode],
+                                       int(initially_zero), METHODS[orth_meth], _mode(mode),
                                        _p(shp, C.c_int), _p(res, C.c_double), C.byref(iters),
                                        C.byref(mvps), C.byref(conv), C.byref(beta0), C.byref(tol),
                                        _p(None if pl_diag is None else np.ascontiguousarray(pl_diag, dtype), ct),
@@ -308,7 +348,7 @@ def orthogonalize(V, w, method="mgs", mode="seq", W=1, L=1):
     w = np.array(w, V.dtype, copy=True)
     h = np.zeros(k, V.dtype)
     nrm = getattr(lib(), f"orc_orthogonalize_{suf}")(_p(V, ct), n, n, k, _p(w, ct), _p(h, ct),
-                                                     METHODS[method], MODES[mode], W, L)
+                                                     METHODS[method], _mode(mode), W, L)
     return w, h, nrm
 
 
@@ -371,7 +411,7 @@ def bicgstabl(A: CSC, b, l=2, x0=None, *, r_shadow, abstol=0.0, reltol=None, max
     shp = np.asarray(shape, np.int32)
     rc = getattr(lib(), f"orc_bicgstabl_{suf}")(n, _p(A.colptr, C.c_int64), _p(A.rowval, C.c_int64), _p(A.nzval, ct),
                                                 A.index_base, _p(b, ct), _p(x, ct), _p(rsh, ct), int(l), float(abstol),
-                                                float(reltol), max_mv, int(initial_zero), MODES[mode], _p(shp, C.c_int),
+                                                float(reltol), max_mv, int(initial_zero), _mode(mode), _p(shp, C.c_int),
                                                 _p(res, C.c_double), C.byref(iters), C.byref(mvps), C.byref(conv),
                                                 C.byref(res0), C.byref(tol))
     if rc:
@@ -406,7 +446,7 @@ def chebyshev(A: CSC, b, lmin, lmax, x0=None, *, abstol=0.0, reltol=None, maxite
 
     def call(f, ct, b, x, maxiter, res, iters, mvps, conv, res0, tol):
         f(A.n, _p(A.colptr, C.c_int64), _p(A.rowval, C.c_int64), _p(A.nzval, ct), A.index_base, _p(b, ct), _p(x, ct), float(lmin),
-          float(lmax), float(abstol), float(reltol), maxiter, int(x0 is None), _p(pd, ct), MODES[mode], _p(shp, C.c_int),
+          float(lmax), float(abstol), float(reltol), maxiter, int(x0 is None), _p(pd, ct), _mode(mode), _p(shp, C.c_int),
           _p(res, C.c_double), C.byref(iters), C.byref(mvps), C.byref(conv), C.byref(res0), C.byref(tol))
     return _run_simple("orc_chebyshev", A, b, x0, maxiter, call)
 
@@ -419,7 +459,7 @@ def minres(A: CSC, b, x0=None, *, skew_hermitian=False, abstol=0.0, reltol=None,
 
     def call(f, ct, b, x, maxiter, res, iters, mvps, conv, res0, tol):
         f(A.n, _p(A.colptr, C.c_int64), _p(A.rowval, C.c_int64), _p(A.nzval, ct), A.index_base, _p(b, ct), _p(x, ct),
-          int(skew_hermitian), float(abstol), float(reltol), maxiter, int(x0 is None), MODES[mode], _p(shp, C.c_int),
+          int(skew_hermitian), float(abstol), float(reltol), maxiter, int(x0 is None), _mode(mode), _p(shp, C.c_int),
           _p(res, C.c_double), C.byref(iters), C.byref(mvps), C.byref(conv), C.byref(res0), C.byref(tol))
     return _run_simple("orc_minres", A, b, x0, maxiter, call)
 

@@ -9,6 +9,12 @@ material in tests/test_oracle_pinning.py.  They pin (a) the oracle against regre
 
 `tree` histories depend on the device reduction shape (W, L) = mik_reduce_shape(); it is stored
 in each file and the tests skip the bit-exact comparison if the library's shape has changed.
+
+Summation orders per file: `seq` (one accumulator), `pair` (pairwise), `tree` (the device's fixed tree) and
+`blas` / `blas8`: dot, norm and gemv evaluated by the host's OpenBLAS (the library SciPy bundles; recorded under
+"blas_library") with 1 resp. 8 BLAS threads -- the library family the reference executes for LinearAlgebra.dot /
+norm / mul!.  OpenBLAS picks its kernel by CPU (DYNAMIC_ARCH) and splits long vectors across threads, so the
+`blas*` histories are those of THIS machine ("core" in the file); they are not regenerated on the GPU box.
 """
 import json
 import os
@@ -34,14 +40,24 @@ def dump(name, obj):
     print("wrote", name)
 
 
+def blas_modes():
+    """(key, oracle mode, BLAS threads): binding happens right before the run that uses it."""
+    return (("blas", "blas", 1), ("blas8", "blas", 8))
+
+
 def cg_case(N, maxiter=None):
     A = orc.laplace(N, 3)
     b = orc.hashed_rhs(A.n)
     out = dict(case=f"cg(laplace_matrix(Float64,{N},3), hashed_rhs) reltol=sqrt(eps) abstol=0", N=N, W=W, L=L, Ld=LD,
                maxiter=maxiter)
-    for mode, shape in (("seq", (1, 1, 1, 1)), ("pair", (1, 1, 1, 1)), ("tree", (1, LD, W, L))):
+    runs = [("seq", "seq", (1, 1, 1, 1), 0), ("pair", "pair", (1, 1, 1, 1), 0), ("tree", "tree", (1, LD, W, L), 0)]
+    runs += [(key, mode, (1, 1, 1, 1), thr) for key, mode, thr in blas_modes()]
+    for key, mode, shape, thr in runs:
+        if thr:
+            out["blas_library"] = orc.bind_blas(thr)
         x, h = orc.cg(A, b, maxiter=maxiter, mode=mode, shape=shape)
-        out[mode] = dict(iters=h["iters"], mvps=h["mvps"], isconverged=h["isconverged"], res0=float(h["res0"]).hex(),
+        print(f"  cg {N}^3 {key}: {h['iters']} iterations", flush=True)
+        out[key] = dict(iters=h["iters"], mvps=h["mvps"], isconverged=h["isconverged"], res0=float(h["res0"]).hex(),
                          tol=float(h["tol"]).hex(), resnorm=hexlist(h["resnorm"]),
                          x_checksum=float(np.sum(x)).hex(), x_norm=float(np.linalg.norm(x)).hex())
     return out
@@ -51,9 +67,14 @@ def gmres_case(N, restart):
     A, b = orc.advdiff(N, 1000.0)
     out = dict(case=f"gmres(advection_dominated(N={N}, beta=1000), restart={restart})", N=N, restart=restart, W=W, L=L,
                b_from="oracle/orc_advdiff_csc (glibc exp/sin)")
-    for mode, shape in (("seq", (1, 1)), ("pair", (1, 1)), ("tree", (W, L))):
+    runs = [("seq", "seq", (1, 1), 0), ("pair", "pair", (1, 1), 0), ("tree", "tree", (W, L), 0)]
+    runs += [(key, mode, (1, 1), thr) for key, mode, thr in blas_modes()]
+    for key, mode, shape, thr in runs:
+        if thr:
+            out["blas_library"] = orc.bind_blas(thr)
         x, h = orc.gmres(A, b, restart=restart, mode=mode, shape=shape)
-        out[mode] = dict(iters=h["iters"], mvps=h["mvps"], isconverged=h["isconverged"], res0=float(h["res0"]).hex(),
+        print(f"  gmres N={N} {key}: {h['iters']} iterations", flush=True)
+        out[key] = dict(iters=h["iters"], mvps=h["mvps"], isconverged=h["isconverged"], res0=float(h["res0"]).hex(),
                          tol=float(h["tol"]).hex(), resnorm=hexlist(h["resnorm"]),
                          x_checksum=float(np.sum(x)).hex(), x_norm=float(np.linalg.norm(x)).hex())
     return out
@@ -63,4 +84,4 @@ if __name__ == "__main__":
     dump("cg_lap32.json", cg_case(32))
     dump("cg_lap64.json", cg_case(64))
     dump("gmres_advdiff50_r30.json", gmres_case(50, 30))
-    dump("cg_lap256_first40.json", cg_case(256, maxiter=40))
+    dump("cg_lap256.json", cg_case(256))       # the full 613-iteration history of configs[1] (about ten minutes)

@@ -361,3 +361,84 @@ def test_multiprocess_ranks_on_one_gpu_match_partitioned_oracle(pkg, orc, ctx, t
     assert hs[0].size == ho["iters"] and np.array_equal(hs[0], ho["resnorm"])
     x = np.concatenate([np.load(tmp_path / f"x{r}.npy") for r in range(world)])
     assert np.array_equal(x, xo)
+
+
+# ------------------------------------------------------------------------------------------------
+# the exchanges INSIDE libmik.so (include/mik.h "Transport 1 / 2"): no host code between the phases
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [1, 2, 3, 4])
+@pytest.mark.parametrize("with_x0", [False, True])
+def test_inprocess_group_matches_partitioned_oracle(pkg, orc, ctx, P, with_x0):
+    """mik_cgd_group_*: one host thread, P ranks with their own ctx / stream on one GPU, halos and scalar gathers as
+    event-ordered peer copies enqueued by the library: bit-exact against the partition-aware oracle, batches of mixed
+    length, with and without an interior range (N = 16: a plane is one row-block)"""
+    d = dist_mod(pkg)
+    for N, NZ in ((12, 16), (16, 12)):
+        shape = ctx.cg_shape(np.float64)
+        x0 = np.random.default_rng(3).standard_normal(N * N * NZ) if with_x0 else None
+        mk = lambda pp, li, vv, pl, bl, xl: d.HipEngine(pkg, pp, li, vv, pl, bl, xl, abstol=0.0, reltol=1.5e-8, maxiter=10 ** 6)
+        engines, offsets, b = make_engines(pkg, orc, N, NZ, P, mk, x0)
+        assert len({e.stream.cuda_stream for e in engines}) == P        # every rank on its own stream
+        grp = d.GroupCG(pkg, engines, maxiter=10 ** 6)
+        hist, iteration = [], 0
+        while True:
+            h = grp.iterate_many(iteration, 1 if iteration < 2 else 13)
+            if h.size == 0:
+                break
+            hist.append(h)
+            iteration += h.size
+        hist = np.concatenate(hist)
+        xo, ho = oracle_history(orc, pkg, N, NZ, offsets, b, shape, x0)
+        assert hist.size == ho["iters"] and np.array_equal(hist, ho["resnorm"])
+        assert np.array_equal(grp.solution(), xo)
+        grp.close()
+        for e in engines:
+            e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_rccl", [False, True])
+def test_native_comm_world1_equals_single_gpu_path(pkg, orc, ctx, force_rccl):
+    """mik_cgd_iterate_many through a mik_comm: a world of one without the library, and a REAL RCCL communicator of one
+    rank (ncclCommInitRank + ncclAllGather issued from inside libmik.so on the ctx stream) -- both bit-identical to the
+    fused single-GPU iterable"""
+    d = dist_mod(pkg)
+    N = 16
+    boot = d.SelfComm()
+    ptr, li, val, plan, b_loc, n, offsets = d.build_rank_problem(pkg, boot, N, nz_per_rank=N)
+    eng = d.HipEngine(pkg, ptr, li, val, plan, b_loc, abstol=0.0, reltol=1.5e-8, maxiter=10 ** 6)
+    nc = d.NativeComm(pkg, eng.ctx, boot, force_rccl=force_rccl)
+    assert nc.uses_rccl() == force_rccl
+    it = d.NativeDistCGIterable(pkg, eng, nc, maxiter=10 ** 6)
+    hist, iteration = [], 0
+    while True:
+        h = it.iterate_many(iteration, 1 if iteration < 3 else 20)
+        if h.size == 0:
+            break
+        hist.append(h)
+        iteration += h.size
+    hist = np.concatenate(hist)
+    nA, colptr, rowval, nzval = pkg.fixtures.laplace_matrix(N, 3)
+    x, ch = pkg.cg(pkg.HipCSR(nA, nA, colptr, rowval, nzval), pkg.HipVector.from_numpy(b_loc), reltol=1.5e-8, log=True)
+    assert np.array_equal(hist, ch["resnorm"]) and np.array_equal(eng.solution(), x.to_numpy())
+    # the reduce entry a row-partitioned GMRES host wraps: rank-ordered sums (identity in a world of one)
+    v = np.array([1.5, -2.0, 3.25])
+    pkg._lib.check(pkg.lib().mik_comm_allgather_sum(nc.handle, 0, 3, v.ctypes.data_as(__import__("ctypes").c_void_p)), "mik_comm_allgather_sum")
+    assert v.tolist() == [1.5, -2.0, 3.25]
+    eng.close()
+    nc.close()
+
+
+def test_native_transport_argument_checks(pkg):
+    """no GPU needed: the new entry points reject NULL handles instead of crashing"""
+    import ctypes as C
+    L = pkg.lib()
+    assert L.mik_cgd_set_halo_plan(None, 0, None, None, None, 0, None, None, None) == 1
+    assert L.mik_cgd_set_comm(None, None) == 1
+    assert L.mik_cgd_init(None, None, None) == 1
+    n = C.c_int64()
+    assert L.mik_cgd_iterate_many(None, 0, 1, None, C.byref(n)) == 1
+    assert L.mik_cgd_group_init(None, 2, None, None) == 1
+    assert L.mik_comm_create(None, None, 0, 1, None) == 1
+    assert L.mik_comm_destroy(None) == 0 and L.mik_comm_allgather_sum(None, 0, 1, None) == 1

@@ -6,7 +6,10 @@ import scipy.sparse as sp
 
 pytestmark = pytest.mark.gpu
 
-FORMS = {"csr-rowblock": {8: 1}, "sliced-ell": {10: 1, 12: 1}, "sliced-ell+8-bit-column-codes": {12: 1}, "best": {}}
+# knob 14 selects the CSR kernel: 0 = tile filled by LDS-DMA + per-row gather (k_spmv_rowgather, default), 1 = products
+# staged through registers (k_spmv_rowblock)
+FORMS = {"csr-rowblock": {8: 1}, "csr-rowblock/products": {8: 1, 14: 1},
+         "sliced-ell": {10: 1, 12: 1}, "sliced-ell+8-bit-column-codes": {12: 1}, "best": {}}
 
 
 def with_knobs(pkg, knobs, fn):
@@ -47,7 +50,7 @@ def test_spmv_and_cg_identical_in_every_layout(pkg, orc, ctx, case, dtype):
         def run():
             dA = upload(pkg, A)
             if form != "best":
-                assert dA.layout() == form
+                assert dA.layout() == form.split("/")[0]
             elif case != "banded_wide":       # every slice of the stencils uses <= 8 offsets
                 assert dA.layout() == "sliced-ell+slice-offsets+row-masks"
             y = pkg.mul_(pkg.HipVector(A.n, dtype), dA, pkg.HipVector.from_numpy(x)).to_numpy()
@@ -103,3 +106,36 @@ def test_rectangular_block_with_halo_columns(pkg, orc, ctx, dist):
         xe = np.concatenate([x[r0:r1], x[plan.ghost_gids]])
         y = pkg.mul_(pkg.HipVector(plan.n_loc), dA, pkg.HipVector.from_numpy(xe)).to_numpy()
         assert np.array_equal(y, want[r0:r1])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_csr_kernel_variants_on_ragged_rows(pkg, orc, ctx, dtype):
+    """rows of 0..64 entries (several LDS passes per wave, even and odd lengths, empty rows, a ragged last block):
+    every CSR kernel variant returns the oracle's bits, with and without the fused dot"""
+    rng = np.random.default_rng(5)
+    n = 5 * 256 + 77
+    lens = rng.integers(0, 65, size=n)
+    lens[rng.integers(0, n, 40)] = 0
+    lens[300:364] = 64                                    # one wave whose 64 rows are all full
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    cols = np.concatenate([np.sort(rng.choice(n, size=l, replace=False)) for l in lens]).astype(np.int64)
+    val = rng.standard_normal(cols.size).astype(dtype)
+    S = sp.csr_matrix((val, cols, rowptr), shape=(n, n))
+    A = orc.CSC.from_scipy(S.tocsc())
+    x = rng.standard_normal(n).astype(dtype)
+    want = orc.spmv(A, x)
+    b = orc.hashed_rhs(n).astype(dtype)
+    ref = None
+    for variant in (0, 1):
+        def run():
+            dA = pkg.HipCSR(n, n, rowptr, cols, val, index_base=0, is_csc=False)
+            assert dA.layout() == "csr-rowblock"
+            y = pkg.mul_(pkg.HipVector(n, dtype), dA, pkg.HipVector.from_numpy(x)).to_numpy()
+            # 3 CG steps exercise the fused-dot epilogue (the matrix is not SPD; only the bits matter)
+            xs, ch = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True, maxiter=3)
+            return y, ch["resnorm"], xs.to_numpy()
+        y, res, xs = with_knobs(pkg, {8: 1, 14: variant}, run)
+        assert np.array_equal(y, want), variant
+        if ref is None:
+            ref = (res, xs)
+        assert np.array_equal(res, ref[0]) and np.array_equal(xs, ref[1]), variant
