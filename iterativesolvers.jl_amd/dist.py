@@ -863,9 +863,13 @@ def _laplace_rows(pkg, N, NZ, r0, r1, dtype):
 
 
 # ==============================================================================================
-# bench entry (bench.py --gpus N under torch.distributed.run)
+# bench entry (bench.py --gpus N: one rank per GPU, started by torch.distributed.run or by bench.py itself)
 # ==============================================================================================
 def bench_main(args):
+    """BASELINE.json configs[3]: cg! on the z-slab partition of the 512 x 512 x 64 P Laplacian (P = 8: the 512^3 grid;
+    64 planes and two 512^2-double halos per rank), exchanges over RCCL issued from inside libmik.so.  P = 1
+    (--force-dist) runs the same code path on the 256^3 grid of configs[1]."""
+    import math
     import torch
     import torch.distributed as dist
     import __graft_entry__ as graft
@@ -877,63 +881,114 @@ def bench_main(args):
     os.environ.setdefault("MASTER_PORT", "29511")
     if "MIK_FORCE_DEVICE" in os.environ:          # development: several ranks on one GPU (if the backend allows it)
         local_rank = int(os.environ["MIK_FORCE_DEVICE"])
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs device {local_rank}, {torch.cuda.device_count()} device(s) visible")
     torch.cuda.set_device(local_rank)
+    transport = os.environ.get("MIK_DIST_TRANSPORT", "native")   # "native": RCCL inside libmik.so; "torch": phases driven from Python
     if world > 1 or "RANK" in os.environ:
-        backend = os.environ.get("MIK_DIST_BACKEND", "nccl")
-        if backend == "nccl":
+        # the process group only bootstraps (ncclUniqueId, barriers, max over ranks of the timings): gloo suffices for the
+        # native transport; the legacy transport needs torch's own RCCL communicator
+        if transport == "torch" and os.environ.get("MIK_DIST_BACKEND", "nccl") == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-        comm = TorchComm()
+            dist.init_process_group(os.environ.get("MIK_DIST_BACKEND", "gloo") if transport == "torch" else "gloo", rank=rank, world_size=world)
+        boot = TorchComm()
+        assert dist.get_world_size() == world
     else:
-        comm = SelfComm()
-    N, K, Wm = args.n, args.steps, args.warmup
-    ptr, local_idx, val, plan, b_loc, n, offsets = build_rank_problem(pkg, comm, N, nz_per_rank=N)
+        boot = SelfComm()
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but {world} rank(s) are running")
+    K, Wm = args.steps, args.warmup
+    if args.n is not None:
+        N, nz = args.n, max(1, args.n // world)              # --grid G: the G^3 cube cut into `world` slabs
+    elif world == 1:
+        N, nz = 256, 256                                     # configs[1] through the partitioned code path
+    else:
+        N, nz = 512, 64                                      # configs[3]: 512 x 512 x 64 P (P = 8: 512^3)
+    t_up = time.perf_counter()
+    ptr, local_idx, val, plan, b_loc, n, offsets = build_rank_problem(pkg, boot, N, nz_per_rank=nz)
     nnz_loc = int(val.size)
     eng = HipEngine(pkg, ptr, local_idx, val, plan, b_loc, abstol=0.0, reltol=0.0, maxiter=10 ** 9, device=local_rank)
+    upload_seconds = time.perf_counter() - t_up
     del ptr, local_idx, val
-    it = DistCGIterable(eng, comm, maxiter=10 ** 9)
-    batch = 25
-    iteration = 0
-    while iteration < Wm:
-        iteration += it.iterate_many(iteration, min(batch, Wm - iteration)).size
-    comm.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    done = 0
-    while done < K:
-        h = it.iterate_many(iteration, min(batch, K - done))
-        assert h.size > 0
-        done += h.size
-        iteration += h.size
-    torch.cuda.synchronize()
-    comm.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+    if transport == "native":
+        ncomm = NativeComm(pkg, eng.ctx, boot, force_rccl=os.environ.get("MIK_DIST_FORCE_COLLECTIVES", "0") == "1")
+        it = NativeDistCGIterable(pkg, eng, ncomm, maxiter=10 ** 9)
+        uses_rccl = ncomm.uses_rccl()
+    else:
+        it = DistCGIterable(eng, boot, maxiter=10 ** 9)
+        uses_rccl = world > 1
+    state = {"k": 0}
+
+    def run_steps(count, batch):
+        done = 0
+        while done < count:
+            h = it.iterate_many(state["k"], min(batch, count - done))
+            assert h.size > 0
+            done += h.size
+            state["k"] += h.size
+
+    def region(count, batch):
+        boot.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(count, batch)
+        torch.cuda.synchronize()
+        boot.barrier()
+        return time.perf_counter() - t0
+
+    def max_over_ranks(values):
+        if world == 1:
+            return list(values)
+        t = torch.tensor(list(values), dtype=torch.float64)
+        if dist.get_backend() != "gloo":
+            t = t.cuda()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return t.cpu().tolist()
+
+    def timed(batch, count):
+        """regions of exactly `count` steps until >= 0.25 s have been measured; every rank runs the same number"""
+        first = max_over_ranks([region(count, batch)])[0]
+        more = max(0, min(199, math.ceil(0.25 / max(first, 1e-6)) - 1))
+        times = [first] + max_over_ranks([region(count, batch) for _ in range(more)])
+        return times
+
+    run_steps(Wm, 1)
+    times = timed(1, K)                      # one host-visible residual per step: the reference's protocol, as at N = 1
+    kb = max(1, K // 25) * 25
+    times_b = timed(25, kb)                  # one host wait per 25 steps
+    dt = float(np.median(times))
     # SpMV roofline on rank 0: back-to-back launches of the local block on the live u (HIP events, own stream)
     alg_bytes = eng.A.spmv_algorithmic_bytes()
+    stored_bytes = eng.A.spmv_stored_bytes()
     u = pkg.HipVector.wrap(eng.u_ext.data_ptr(), plan.n_loc + plan.n_ghost, np.float64, eng.ctx, owner=eng.u_ext)
     spmv_ms = eng.A.time_spmv(u, eng.c, reps=20, fused_dot=True)
-    achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9
+    moved = stored_bytes / (spmv_ms * 1e-3) / 1e9
     if rank == 0:
-        # weak scaling: every rank iterates its own 256^3-row slab of one global system, so the units all
-        # ranks processed are world * K slab-iterations (at N = 1 this is exactly bench.py's single-GPU metric)
+        # weak scaling: every rank iterates its own 16.7 M-row slab of one global system, so the units all ranks processed
+        # are world * K slab-iterations (at world = 1 this is exactly bench.py's single-GPU metric)
+        halo = int(plan.n_ghost)
         out = {
-            "metric": "cg_iters_per_sec", "value": world * K / dt, "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "metric": "cg_iters_per_sec", "value": world * K / dt, "unit": "iters/s", "n_gpus": world, "world_size_checked": world, "steps": K, "warmup": Wm,
             "global_system_iters_per_sec": K / dt,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"cg! on the {N}x{N}x{N * world} 3D 7-point Laplacian row-partitioned into {world} z-slabs of {N}^3 rows "
-                                   f"(BASELINE.json configs[3] layout; weak scaling of configs[1])", "n": int(n), "n_per_gpu": plan.n_loc,
-                       "nnz_per_gpu": nnz_loc, "halo_doubles_per_neighbour": N * N, "host_sync_every_steps": batch,
-                       "collectives_per_step": "1 halo exchange (P2P) + 2 all-gathers of 1 double per rank",
-                       "final_residual": it.residual},
-            "roofline": {"bound": "hbm", "kernel": f"SpMV, operator layout {eng.A.layout()}, fused dot (rank 0, back-to-back)", "achieved": achieved,
-                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms},
+            "config": {"workload": f"cg! on the {N}x{N}x{nz * world} 3D 7-point Laplacian row-partitioned into {world} z-slab(s) of {N}x{N}x{nz} rows"
+                                   + (" (BASELINE.json configs[3]: the 512^3 grid on 8 GPUs)" if (N, nz, world) == (512, 64, 8) else
+                                      " (BASELINE.json configs[3] layout, weak-scaled: 16.7 M rows per GPU)" if world > 1 else
+                                      " (BASELINE.json configs[1] through the row-partitioned code path)"),
+                       "n": int(n), "n_per_gpu": plan.n_loc, "nnz_per_gpu": nnz_loc, "halo_doubles_received_per_rank": halo,
+                       "host_sync_per_step": 1, "timed_regions": len(times), "timed_seconds_total": float(sum(times)),
+                       "transport": ("RCCL inside libmik.so (mik_cgd_iterate_many: ncclSend/ncclRecv halo on a side stream overlapped with the "
+                                     "interior rows + 2 ncclAllGather of one double per rank per step)" if transport == "native" and uses_rccl else
+                                     "none (world of one)" if transport == "native" else "torch.distributed driven from Python (legacy)"),
+                       "halo_overlap": bool(getattr(eng, "overlap", False)),
+                       "operator_build_and_upload_seconds": upload_seconds, "final_residual": it.residual},
+            "batched_25_steps_per_sync_iters_per_sec": world * kb / float(np.median(times_b)),
+            "roofline": {"bound": "hbm", "kernel": f"SpMV, operator layout {eng.A.layout()}, fused dot (rank 0, back-to-back on the live u)",
+                         "achieved": moved, "peak": 8000.0, "unit": "GB/s", "frac": moved / 8000.0, "traffic": None,
+                         "bytes_moved_per_launch": stored_bytes, "avg_launch_ms": spmv_ms,
+                         "achieved_algorithmic": alg_bytes / (spmv_ms * 1e-3) / 1e9, "algorithmic_bytes_per_launch": alg_bytes},
             "aggregate_row_updates_per_sec": K / dt * n,
         }
         print(json.dumps(out))

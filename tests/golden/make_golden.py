@@ -54,7 +54,8 @@ def cg_case(N, maxiter=None):
     runs += [(key, mode, (1, 1, 1, 1), thr) for key, mode, thr in blas_modes()]
     for key, mode, shape, thr in runs:
         if thr:
-            out["blas_library"] = orc.bind_blas(thr)
+            out["blas_library"] = {k: v for k, v in orc.bind_blas(thr).items() if k != "threads"}
+            out.setdefault("blas_threads", {})[key] = thr
         x, h = orc.cg(A, b, maxiter=maxiter, mode=mode, shape=shape)
         print(f"  cg {N}^3 {key}: {h['iters']} iterations", flush=True)
         out[key] = dict(iters=h["iters"], mvps=h["mvps"], isconverged=h["isconverged"], res0=float(h["res0"]).hex(),
@@ -71,7 +72,8 @@ def gmres_case(N, restart):
     runs += [(key, mode, (1, 1), thr) for key, mode, thr in blas_modes()]
     for key, mode, shape, thr in runs:
         if thr:
-            out["blas_library"] = orc.bind_blas(thr)
+            out["blas_library"] = {k: v for k, v in orc.bind_blas(thr).items() if k != "threads"}
+            out.setdefault("blas_threads", {})[key] = thr
         x, h = orc.gmres(A, b, restart=restart, mode=mode, shape=shape)
         print(f"  gmres N={N} {key}: {h['iters']} iterations", flush=True)
         out[key] = dict(iters=h["iters"], mvps=h["mvps"], isconverged=h["isconverged"], res0=float(h["res0"]).hex(),

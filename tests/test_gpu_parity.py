@@ -343,7 +343,7 @@ def test_gmres_golden_config3(pkg, ctx):
     A, b = load_oracle().advdiff(50, 1000.0)              # same b as the golden run (glibc exp/sin)
     x, ch = pkg.gmres(upload(pkg, A), pkg.HipVector.from_numpy(b), restart=30, log=True)
     seq, pair = fromhex(g["seq"]["resnorm"]), fromhex(g["pair"]["resnorm"])
-    assert abs(ch.iters - g["seq"]["iters"]) <= 2 and ch.isconverged
+    assert ch.iters == g["seq"]["iters"] and ch.isconverged
     # first restart cycle: <= 1e-12 against both CPU summation orders
     assert np.max(np.abs(ch["resnorm"][:30] - seq[:30]) / seq[:30]) <= 1e-12
     assert np.max(np.abs(ch["resnorm"][:30] - pair[:30]) / pair[:30]) <= 1e-12
@@ -354,6 +354,18 @@ def test_gmres_golden_config3(pkg, ctx):
     assert 1e-8 < floor < 1e-4
     assert np.max(np.abs(ch["resnorm"][:m] - seq[:m]) / seq[:m]) <= 3 * floor
     assert np.max(np.abs(ch["resnorm"][:m] - pair[:m]) / pair[:m]) <= 3 * floor
+    # the host OpenBLAS order (dot, nrm2 and gemv of the reference), all 358 iterations: same counters, first restart
+    # cycle to 1e-12, afterwards inside the band by which the reference's own result moves with the BLAS thread count
+    blas, blas8 = fromhex(g["blas"]["resnorm"]), fromhex(g["blas8"]["resnorm"])
+    for k in ("blas", "blas8", "seq", "pair"):
+        assert (ch.iters, ch.mvps, ch.isconverged) == (g[k]["iters"], g[k]["mvps"], g[k]["isconverged"]) == (358, 370, True), k
+    res = np.asarray(ch["resnorm"])
+    assert np.max(np.abs(res[:30] - blas[:30]) / blas[:30]) <= 1e-12
+    floor_threads = np.max(np.abs(blas8 - blas) / blas)
+    floor_blas = np.max(np.abs(blas - pair) / pair)
+    assert 1e-9 < floor_threads < 1e-5
+    assert np.max(np.abs(res - blas) / blas) <= 3 * max(floor_threads, floor_blas)
+    assert np.max(np.abs(res - blas8) / blas8) <= 3 * max(floor_threads, floor_blas)
     if (g["W"], g["L"]) == ctx.reduce_shape(np.float64):
         assert ch.iters == g["tree"]["iters"] and ch.mvps == g["tree"]["mvps"]
         assert np.array_equal(ch["resnorm"], fromhex(g["tree"]["resnorm"]))
@@ -404,7 +416,7 @@ def test_gmres_fp32(pkg, orc, ctx):
 # ==============================================================================================
 # full-size checks (BASELINE.json config 2: 256^3) through size-independent properties
 # ==============================================================================================
-def test_full_size_256_properties_and_golden_prefix(pkg, ctx):
+def test_full_size_256_properties_and_full_history(pkg, ctx):
     N = 256
     n, colptr, rowval, nzval = pkg.fixtures.laplace_matrix(N, 3)
     A = pkg.HipCSR(n, n, colptr, rowval, nzval)
@@ -425,21 +437,45 @@ def test_full_size_256_properties_and_golden_prefix(pkg, ctx):
     Av = A @ v
     lhs, rhs = pkg.dot(db, Av), pkg.dot(y, v)
     assert abs(lhs - rhs) <= 1e-12 * abs(lhs)
-    # (3) first 40 CG residuals against the committed golden prefix generated by the oracle
-    gold = json.load(open(os.path.join(GOLDEN, "cg_lap256_first40.json")))
-    x, ch = pkg.cg(A, db, log=True, maxiter=40)
-    seq, pair = fromhex(gold["seq"]["resnorm"]), fromhex(gold["pair"]["resnorm"])
-    # n = 16.7M: a naive left-to-right sum carries ~1e-11 of its own rounding error, so the 1e-12 bar is
-    # held against the pairwise CPU order and the sequential one is checked against the CPU-vs-CPU floor
-    assert ch.iters == 40 and np.max(np.abs(ch["resnorm"] - pair) / pair) <= 1e-12
-    floor = np.max(np.abs(seq - pair) / seq)
-    assert np.max(np.abs(ch["resnorm"] - seq) / seq) <= 3 * floor
+    # (3) the FULL solve (613 iterations to the default tolerance) against the committed CPU histories of the same solve
+    #     (tests/golden/make_golden.py): the host OpenBLAS order (what LinearAlgebra.dot / norm execute in the reference),
+    #     pairwise, one accumulator -- and the device's documented tree, bit for bit.
+    gold = json.load(open(os.path.join(GOLDEN, "cg_lap256.json")))
+    x, ch = pkg.cg(A, db, log=True)
+    H = {k: fromhex(gold[k]["resnorm"]) for k in ("seq", "pair", "blas", "blas8", "tree")}
+
+    def dev(a, ref):
+        return float(np.max(np.abs(a - ref) / ref))
+    for k in H:                                   # same iteration count, mvps, isconverged as every CPU order
+        assert (ch.iters, ch.mvps, ch.isconverged) == (gold[k]["iters"], gold[k]["mvps"], gold[k]["isconverged"]) == (613, 613, True), k
+    res = np.asarray(ch["resnorm"])
+    floor_blas = dev(H["blas"], H["pair"])        # CPU vs CPU: how far two valid orders of the reference's own arithmetic differ
+    floor_threads = dev(H["blas8"], H["blas"])    # the reference's own dependence on the BLAS thread count
+    # north-star bar: 1e-12 relative against the BLAS order over the WHOLE history (measured 2.9e-13 at iteration 375)
+    assert dev(res, H["blas"]) <= max(1e-12, 3 * floor_blas)
+    assert dev(res, H["blas8"]) <= max(1e-12, 3 * floor_threads)
+    assert dev(res, H["pair"]) <= 1e-12
+    # a naive 16.7 M-term left-to-right sum carries ~1e-11 of its own rounding error (it is 1.3e-11 away from OpenBLAS
+    # as well): the device must sit inside that CPU-vs-CPU band
+    floor_seq = dev(H["seq"], H["blas"])
+    assert 1e-12 < floor_seq < 1e-10 and dev(res, H["seq"]) <= 3 * floor_seq
     if (1, gold["Ld"], gold["W"], gold["L"]) == ctx.cg_shape(np.float64):
-        assert np.array_equal(ch["resnorm"], fromhex(gold["tree"]["resnorm"]))
-    # (4) the recurrence residual equals the true residual after 40 steps (round trip through A)
+        assert np.array_equal(res, H["tree"])
+        assert float(np.sum(x.to_numpy())).hex() == gold["tree"]["x_checksum"]
+    # (3b) batched stepping (device-side stopping test) reproduces the same 613 residuals and stops by itself
+    it = pkg.cg_iterator_(pkg.zerox(A, db), A, db, initially_zero=True)
+    got, k = [], 0
+    while True:
+        r = it.iterate_many(k, 100)
+        if r.size == 0:
+            break
+        got.append(r)
+        k += r.size
+    assert np.array_equal(np.concatenate(got), res)
+    # (4) the recurrence residual equals the true residual at convergence (round trip through A)
     r = pkg.HipVector.from_numpy(b)
     r.sub_(A @ x)
-    assert abs(pkg.norm(r) - ch["resnorm"][-1]) <= 1e-10 * ch["resnorm"][-1]
+    assert abs(pkg.norm(r) - ch["resnorm"][-1]) <= 1e-3 * ch["resnorm"][-1]
 
 
 @pytest.mark.gpu
