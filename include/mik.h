@@ -222,6 +222,37 @@ int mik_gmres_iterate(mik_gmres *it, int64_t iteration, double *residual, int *d
 int mik_gmres_state(const mik_gmres *it, double *residual, double *tol, double *beta, int *k,
                     int64_t *mv_products, int *converged);
 
+/* ---- any operator, any preconditioner on the fused iterables -------------------------------------------- */
+/* The reference asks of A only mul!(y, A, v) and of Pl / Pr only ldiv!(y, P, x) (docs/src/getting_started.md:25-30,
+ * docs/src/preconditioning.md:5-14; exercised with a LinearMap at test/gmres.jl:59-66 and with lu(A) as Pl at
+ * test/gmres.jl:28-35, test/cg.jl:71-77).  The callbacks below carry that contract across the C ABI: x and y are DEVICE
+ * n-vectors of the handle's dtype; the callback must leave its work ordered on the context's stream (enqueue kernels on
+ * it -- mik_ctx_set_stream adopts a host framework's stream -- or finish before returning) and return 0.  A non-zero
+ * return surfaces as MIK_ERR_CALLBACK.  With a callback operator the CG step keeps its fused vector sweeps and reduces
+ * dot(u, c) with the (W, L) shape of mik_reduce_shape instead of inside the SpMV epilogue. */
+typedef int (*mik_mul_fn)(void *user, const void *x, void *y);      /* y = A * x      -- mul!(y, A, x)   */
+typedef int (*mik_ldiv_fn)(void *user, void *y, const void *x);     /* y = P \ x      -- ldiv!(y, P, x); y may alias x */
+typedef struct mik_operator {
+    int dtype;                  /* MIK_F64 / MIK_F32 (ignored when csr is given) */
+    int64_t n;                  /* size(A, 1) = size(A, 2) (ignored when csr is given) */
+    const mik_csr *csr;         /* a device CSR operator: the fully fused path ...                            */
+    mik_mul_fn mul;             /* ... or any operator as a callback (csr == NULL)                           */
+    void *user;
+} mik_operator;
+typedef struct mik_precond {    /* all NULL = Identity() (src/common.jl:28-32) */
+    const void *diag;           /* device n-vector d: ldiv!(y, P, x) = y .= x ./ d, fused into the sweeps       */
+    mik_ldiv_fn ldiv;           /* or any preconditioner as a callback                                        */
+    void *user;
+} mik_precond;
+/* cg_iterator!(x, A, b, Pl; ...) -- src/cg.jl:120-155 with any A / Pl; mik_cg_iterate* and mik_cg_state work as usual. */
+int mik_cg_create_op(mik_ctx *ctx, const mik_operator *A, const mik_precond *Pl, void *x, const void *b, void *u, void *r,
+                     void *c, double abstol, double reltol, int64_t maxiter, int initially_zero, mik_cg **out);
+/* gmres_iterable!(x, A, b; Pl, Pr, ...) -- src/gmres.jl:108-136 with any A / Pl / Pr (all three expand! methods,
+ * src/gmres.jl:285-304). */
+int mik_gmres_create_op(mik_ctx *ctx, const mik_operator *A, const mik_precond *Pl, const mik_precond *Pr, void *x, const void *b,
+                        double abstol, double reltol, int restart, int64_t maxiter, int initially_zero, int orth_method,
+                        mik_gmres **out);
+
 /* ---- fused sweeps for the other solvers of the package ------------------------------------------- */
 /* Each call is several consecutive reference statements executed as ONE pass over the vectors, with the
  * same per-element operations in the same order (bit-identical to issuing the L1 calls one by one).  `hints` is a

@@ -37,6 +37,19 @@ HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
 
 
+# any operator / any preconditioner on the fused iterables (include/mik.h: mik_mul_fn, mik_ldiv_fn, mik_operator, mik_precond)
+MUL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+LDIV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+
+
+class MikOperator(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("n", C.c_int64), ("csr", C.c_void_p), ("mul", MUL_FN), ("user", C.c_void_p)]
+
+
+class MikPrecond(C.Structure):
+    _fields_ = [("diag", C.c_void_p), ("ldiv", LDIV_FN), ("user", C.c_void_p)]
+
+
 class MikPartition(C.Structure):
     _fields_ = [("rank", C.c_int), ("nranks", C.c_int), ("n_ext", C.c_int64), ("x_ext", C.c_void_p),
                 ("send_idx", C.c_void_p), ("n_send", C.c_int64), ("send_buf", C.c_void_p),
@@ -83,6 +96,10 @@ SIGNATURES = {
     "mik_lu_solve": (C.c_int, [C.c_int, _vp, _i64, C.c_int, _vp]),
     "mik_cg_create": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, _i64,
                                 C.c_int, C.POINTER(_vp)]),
+    "mik_cg_create_op": (C.c_int, [_vp, C.POINTER(MikOperator), C.POINTER(MikPrecond), _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, _i64,
+                                   C.c_int, C.POINTER(_vp)]),
+    "mik_gmres_create_op": (C.c_int, [_vp, C.POINTER(MikOperator), C.POINTER(MikPrecond), C.POINTER(MikPrecond), _vp, _vp, C.c_double, C.c_double,
+                                      C.c_int, _i64, C.c_int, C.c_int, C.POINTER(_vp)]),
     "mik_cg_destroy": (C.c_int, [_vp]),
     "mik_cg_iterate": (C.c_int, [_vp, _i64, _f64p, _ip]),
     "mik_cg_iterate_many": (C.c_int, [_vp, _i64, _i64, _f64p, _i64p]),

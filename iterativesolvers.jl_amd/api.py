@@ -349,12 +349,90 @@ class HipCSR:
             pass
 
 
-def mul_(y: HipVector, A: HipCSR, x: HipVector) -> HipVector:
+def mul_(y: HipVector, A, x: HipVector) -> HipVector:
     """``mul!(y, A, x)`` -- src/cg.jl:54."""
     if x.n != A.n_cols or y.n != A.n_rows or x.dtype != A.dtype or y.dtype != A.dtype:
         raise ValueError("DimensionMismatch in mul_(y, A, x)")
+    if isinstance(A, LinearOperator):
+        A.mul(y, x)
+        return y
     check(lib().mik_spmv(A.ctx.handle, A.handle, _vp(x.ptr), _vp(y.ptr)), "mik_spmv", A.ctx.handle)
     return y
+
+
+class LinearOperator:
+    """Any operator the reference accepts: something with ``mul!(y, A, x)``, ``eltype`` and ``size``
+    (docs/src/getting_started.md:25-30) -- e.g. the LinearMap of test/gmres.jl:59-66.  ``mul(y, x)`` receives two device
+    vectors and must leave ``y = A * x`` ordered on the context's stream (any composition of this module's calls does)."""
+
+    def __init__(self, n: int, dtype, mul, ctx: Optional[HipContext] = None):
+        self.n_rows = self.n_cols = int(n)
+        self.dtype = np.dtype(dtype)
+        self.mul = mul
+        self.ctx = ctx or default_context()
+
+    def size(self, d: Optional[int] = None):
+        return (self.n_rows, self.n_cols) if d is None else self.n_rows
+
+    def eltype(self):
+        return self.dtype
+
+    def __matmul__(self, x: HipVector) -> HipVector:
+        return mul_(HipVector(self.n_rows, self.dtype, self.ctx), self, x)
+
+
+class _Bound:
+    """ctypes structures + callbacks that carry a Python operator / preconditioner across the C ABI (kept alive by the
+    iterable that owns them).  An exception inside a callback is parked and re-raised by the caller of the C entry."""
+
+    def __init__(self, ctx: HipContext, n: int, dtype):
+        self.ctx, self.n, self.dtype = ctx, int(n), np.dtype(dtype)
+        self.error = None
+        self.keep = []
+
+    def _vec(self, ptr):
+        return HipVector.wrap(ptr, self.n, self.dtype, self.ctx)
+
+    def operator(self, A) -> "_lib.MikOperator":
+        if isinstance(A, HipCSR):
+            return _lib.MikOperator(A.code, A.n_rows, A.handle, _lib.MUL_FN(), None)
+
+        def cb(_user, x, y):
+            try:
+                A.mul(self._vec(y), self._vec(x)) if isinstance(A, LinearOperator) else mul_(self._vec(y), A, self._vec(x))
+                return 0
+            except BaseException as e:               # never let an exception cross the C frame
+                self.error = e
+                return 1
+        fn = _lib.MUL_FN(cb)
+        self.keep.append(fn)
+        return _lib.MikOperator(dtype_code(self.dtype), self.n, None, fn, None)
+
+    def precond(self, P):
+        """None for Identity(); else a MikPrecond (diagonal fused into the sweeps, or ``ldiv_`` as a callback)."""
+        if P is None or isinstance(P, Identity):
+            return None
+        if isinstance(P, JacobiPrec):
+            return _lib.MikPrecond(P.diagonal.ptr, _lib.LDIV_FN(), None)
+        if not callable(getattr(P, "ldiv_", None)):
+            raise MikError(5, "preconditioner", "needs ldiv_(y, x) (docs/src/preconditioning.md:5-14)")
+
+        def cb(_user, y, x):
+            try:
+                P.ldiv_(self._vec(y), self._vec(x))
+                return 0
+            except BaseException as e:
+                self.error = e
+                return 1
+        fn = _lib.LDIV_FN(cb)
+        self.keep.append(fn)
+        return _lib.MikPrecond(None, fn, None)
+
+    def check(self, code, where):
+        if code and self.error is not None:
+            err, self.error = self.error, None
+            raise err
+        check(code, where, self.ctx.handle)
 
 
 # ==============================================================================================
@@ -466,11 +544,19 @@ class CGIterable:
         for v in (x, b, self.u, self.r, self.c):
             if v.n != A.n_rows or v.dtype != A.dtype:
                 raise ValueError("DimensionMismatch in cg_iterator_")
-        diag = Pl.diagonal.ptr if isinstance(Pl, JacobiPrec) else None
         h = _vp()
-        check(lib().mik_cg_create(A.ctx.handle, A.handle, _vp(x.ptr), _vp(b.ptr), _vp(self.u.ptr), _vp(self.r.ptr),
-                                  _vp(self.c.ptr), _vp(diag), float(abstol), float(reltol), int(maxiter),
-                                  int(bool(initially_zero)), C.byref(h)), "mik_cg_create", A.ctx.handle)
+        if isinstance(A, HipCSR) and isinstance(Pl, (Identity, JacobiPrec)):
+            diag = Pl.diagonal.ptr if isinstance(Pl, JacobiPrec) else None
+            check(lib().mik_cg_create(A.ctx.handle, A.handle, _vp(x.ptr), _vp(b.ptr), _vp(self.u.ptr), _vp(self.r.ptr),
+                                      _vp(self.c.ptr), _vp(diag), float(abstol), float(reltol), int(maxiter),
+                                      int(bool(initially_zero)), C.byref(h)), "mik_cg_create", A.ctx.handle)
+        else:
+            # any operator with mul!, any Pl with ldiv! (mik_cg_create_op): the fused sweeps stay, A / Pl come back as callbacks
+            self._bound = _Bound(A.ctx, A.n_rows, A.dtype)
+            op, pl = self._bound.operator(A), self._bound.precond(Pl)
+            self._bound.check(lib().mik_cg_create_op(A.ctx.handle, C.byref(op), C.byref(pl) if pl is not None else None, _vp(x.ptr), _vp(b.ptr),
+                                                     _vp(self.u.ptr), _vp(self.r.ptr), _vp(self.c.ptr), float(abstol), float(reltol), int(maxiter),
+                                                     int(bool(initially_zero)), C.byref(h)), "mik_cg_create_op")
         self.handle = h
         self.maxiter = int(maxiter)
         self._refresh()
@@ -483,6 +569,10 @@ class CGIterable:
               "mik_cg_state", self.A.ctx.handle)
         self.residual, self.prev_residual, self.tol = res.value, prev.value, tol.value
         self.mv_products = mv.value
+
+    def _check(self, code, where):
+        b = getattr(self, "_bound", None)
+        b.check(code, where) if b is not None else check(code, where, self.A.ctx.handle)
 
     def converged(self) -> bool:                                         # src/cg.jl:32
         return self.residual <= self.tol
@@ -498,7 +588,7 @@ class CGIterable:
         iteration = self.start() if iteration is None else iteration
         res = C.c_double()
         done = C.c_int()
-        check(lib().mik_cg_iterate(self.handle, int(iteration), C.byref(res), C.byref(done)), "mik_cg_iterate", self.A.ctx.handle)
+        self._check(lib().mik_cg_iterate(self.handle, int(iteration), C.byref(res), C.byref(done)), "mik_cg_iterate")
         if done.value:
             return None
         self.prev_residual, self.residual = self.residual, res.value
@@ -509,8 +599,8 @@ class CGIterable:
         """Up to ``max_steps`` ``iterate`` calls with one host synchronisation; returns the residuals."""
         out = np.empty(max(int(max_steps), 1), np.float64)
         nd = C.c_int64()
-        check(lib().mik_cg_iterate_many(self.handle, int(iteration), int(max_steps), out.ctypes.data_as(C.POINTER(C.c_double)),
-                                        C.byref(nd)), "mik_cg_iterate_many", self.A.ctx.handle)
+        self._check(lib().mik_cg_iterate_many(self.handle, int(iteration), int(max_steps), out.ctypes.data_as(C.POINTER(C.c_double)),
+                                              C.byref(nd)), "mik_cg_iterate_many")
         self._refresh()
         return out[: nd.value].copy()
 
@@ -623,7 +713,7 @@ def cg_iterator_(x: HipVector, A: HipCSR, b: HipVector, Pl=None, *, abstol=0.0, 
     if statevars is None:
         statevars = CGStateVariables(x.zero(), x.similar(), x.similar())  # :124
     kw = dict(abstol=abstol, reltol=reltol, maxiter=maxiter, initially_zero=initially_zero)
-    if fused and isinstance(Pl, (Identity, JacobiPrec)):
+    if fused:
         return CGIterable(A, x, b, statevars, Pl, **kw)
     return GenericCGIterable(A, x, b, statevars, Pl, **kw)
 
@@ -750,13 +840,23 @@ class GMRESIterable:
             raise ValueError("DimensionMismatch in gmres_iterable_")
         self.A, self.x, self.b = A, x, b
         self.Pl, self.Pr = Pl, Pr
-        pl = Pl.diagonal.ptr if isinstance(Pl, JacobiPrec) else None
-        pr = Pr.diagonal.ptr if isinstance(Pr, JacobiPrec) else None
         self.restart, self.maxiter = int(restart), int(maxiter)
         self.orth_meth = orth_meth
         h = _vp()
-        check(lib().mik_gmres_create(A.ctx.handle, A.handle, _vp(x.ptr), _vp(b.ptr), _vp(pl), _vp(pr), float(abstol), float(reltol), int(restart),
-                                     int(maxiter), int(bool(initially_zero)), orth_meth.code, C.byref(h)), "mik_gmres_create", A.ctx.handle)
+        simple = lambda P: P is None or isinstance(P, (Identity, JacobiPrec))
+        if isinstance(A, HipCSR) and simple(Pl) and simple(Pr):
+            pl = Pl.diagonal.ptr if isinstance(Pl, JacobiPrec) else None
+            pr = Pr.diagonal.ptr if isinstance(Pr, JacobiPrec) else None
+            check(lib().mik_gmres_create(A.ctx.handle, A.handle, _vp(x.ptr), _vp(b.ptr), _vp(pl), _vp(pr), float(abstol), float(reltol), int(restart),
+                                         int(maxiter), int(bool(initially_zero)), orth_meth.code, C.byref(h)), "mik_gmres_create", A.ctx.handle)
+        else:
+            # any operator with mul!, any Pl / Pr with ldiv! (mik_gmres_create_op), e.g. test/gmres.jl:28-35 and :59-66
+            self._bound = _Bound(A.ctx, A.n_rows, A.dtype)
+            op, pl, pr = self._bound.operator(A), self._bound.precond(Pl), self._bound.precond(Pr)
+            self._bound.check(lib().mik_gmres_create_op(A.ctx.handle, C.byref(op), C.byref(pl) if pl is not None else None,
+                                                        C.byref(pr) if pr is not None else None, _vp(x.ptr), _vp(b.ptr), float(abstol), float(reltol),
+                                                        int(restart), int(maxiter), int(bool(initially_zero)), orth_meth.code, C.byref(h)),
+                              "mik_gmres_create_op")
         self.handle = h
         self._refresh()
 
@@ -783,7 +883,9 @@ class GMRESIterable:
         iteration = 0 if iteration is None else iteration
         res = C.c_double()
         done = C.c_int()
-        check(lib().mik_gmres_iterate(self.handle, int(iteration), C.byref(res), C.byref(done)), "mik_gmres_iterate", self.A.ctx.handle)
+        code = lib().mik_gmres_iterate(self.handle, int(iteration), C.byref(res), C.byref(done))
+        b = getattr(self, "_bound", None)
+        b.check(code, "mik_gmres_iterate") if b is not None else check(code, "mik_gmres_iterate", self.A.ctx.handle)
         if done.value:
             return None
         self._refresh()
@@ -811,8 +913,8 @@ def gmres_iterable_(x: HipVector, A: HipCSR, b: HipVector, *, Pl=None, Pr=None, 
                     maxiter=None, initially_zero: bool = False, orth_meth: Optional[OrthogonalizationMethod] = None):
     """``gmres_iterable!(x, A, b; ...)`` -- src/gmres.jl:108-136."""
     for P, name in ((Pl, "Pl"), (Pr, "Pr")):
-        if P is not None and not isinstance(P, (Identity, JacobiPrec)):
-            raise MikError(5, "gmres_iterable_", f"{name} must be Identity() or a diagonal JacobiPrec on the device path")
+        if P is not None and not isinstance(P, (Identity, JacobiPrec)) and not callable(getattr(P, "ldiv_", None)):
+            raise MikError(5, "gmres_iterable_", f"{name} needs ldiv_(y, x) (docs/src/preconditioning.md:5-14)")
     reltol = _default_reltol(b) if reltol is None else reltol
     restart = min(20, A.size(2)) if restart is None else restart           # :113
     maxiter = A.size(2) if maxiter is None else maxiter                    # :114

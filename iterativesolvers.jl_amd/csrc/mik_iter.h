@@ -26,6 +26,10 @@ struct mik_cg {
     int64_t n = 0;
     void *x = nullptr, *u = nullptr, *r = nullptr, *c = nullptr;
     const void *b = nullptr, *diag = nullptr;
+    mik_mul_fn op_mul = nullptr;     // A as a callback (A == nullptr): mik_cg_create_op
+    void *op_user = nullptr;
+    mik_ldiv_fn pl_fn = nullptr;     // Pl as a callback
+    void *pl_user = nullptr;
     void *dev = nullptr;       // CgDev<T>
     void *fin = nullptr;       // FinScratch<T>: wave sums + ticket of the spread level-2 reductions
     void *hist = nullptr;      // device history of one iterate_many call

@@ -116,7 +116,7 @@ static int gemv_n_dev(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, c
 // Copy k host scalars into the coefficient area of the context (device), at element `slot`.
 template <typename T> static int coef_upload(mik_ctx *ctx, int slot, const T *host, int k)
 {
-    if ((size_t)(slot + k) * sizeof(T) > mik_ctx::COEF_BYTES) return mik_fail(ctx, MIK_ERR_NOTIMPL, "coefficient block too large (k = %d)", k);
+    if ((size_t)(slot + k) * sizeof(T) > mik_ctx::COEF_SAFE_SLOT) return mik_fail(ctx, MIK_ERR_NOTIMPL, "coefficient block too large (k = %d)", k);
     MIK_HIP(ctx, mik_wait(ctx));                        // staging buffer must be idle
     memcpy((T *)ctx->coef_host + slot, host, sizeof(T) * k);
     MIK_HIP(ctx, hipMemcpyAsync((T *)ctx->coef + slot, (T *)ctx->coef_host + slot, sizeof(T) * k, hipMemcpyHostToDevice, ctx->stream));
@@ -269,7 +269,7 @@ template <typename T> static int orth_rescale(mik_ctx *ctx, int64_t n, T *w, T *
 template <typename T>
 static int orthogonalize_impl(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, T *w, T *h_host, T *nrm_host, int method)
 {
-    if ((size_t)(2 * k + 4) * sizeof(T) > mik_ctx::COEF_BYTES) return mik_fail(ctx, MIK_ERR_NOTIMPL, "orthogonalize: k = %d too large", k);
+    if ((size_t)(2 * k + 4) * sizeof(T) > mik_ctx::COEF_SAFE_SLOT) return mik_fail(ctx, MIK_ERR_NOTIMPL, "orthogonalize: k = %d too large", k);
     const int64_t nseg = mik_nseg<T>(n);
     MIK_TRY(mik_ensure_partials(ctx, orthogonalize_workspace<T>(n, k)));
     MIK_TRY(orthogonalize_enqueue<T>(ctx, n, k, V, ldv, w, method));
@@ -523,11 +523,18 @@ template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next, 
     const int64_t nb = mik_spmv_nwg(n);
     T *x = (T *)it->x, *u = (T *)it->u, *r = (T *)it->r, *c = (T *)it->c;
     const bool vec = mik_aligned16(x) && mik_aligned16(u) && mik_aligned16(r) && mik_aligned16(c) && (!it->diag || mik_aligned16(it->diag));
-    const int pcg = it->diag ? 1 : 0;
-    if (pcg) {
+    const int pcg = (it->diag || it->pl_fn) ? 1 : 0;
+    if (it->diag) {
         // c = Pl \ r; rho = dot(c, r)                                   src/cg.jl:79-82
         OpJacobiDot<T> pj{r, (const T *)it->diag, c, cg_stream_hints() != 0};
         MIK_TRY((launch_map<T>(ctx, n, pj, vec, (T *)it->seg_vec, done)));
+    } else if (it->pl_fn) {
+        // any Pl: ldiv!(c, Pl, r) through the callback, then the dot as its own sweep
+        if (it->pl_fn(it->pl_user, c, r) != 0) return mik_fail(ctx, MIK_ERR_CALLBACK, "cg: the preconditioner callback failed");
+        OpDot<T> dcr{c, r};
+        MIK_TRY((launch_map<T>(ctx, n, dcr, vec, (T *)it->seg_vec, done)));
+    }
+    if (pcg) {
         hipLaunchKernelGGL((k_cg_fin_rho<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_vec, nseg, d, (FinScratch<T> *)it->fin);
         MIK_LAUNCH_CHECK(ctx);
         // u .= c .+ beta .* u                                           src/cg.jl:86
@@ -539,10 +546,18 @@ template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next, 
         MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
     }
     // c = A * u with the dot(u, c) epilogue                             src/cg.jl:54-55
-    if (it->profile) { hipEvent_t e = cg_profile_event(it); if (e) (void)hipEventRecord(e, ctx->stream); }
-    MIK_TRY(mik_spmv_launch<T>(ctx, it->A, u, c, true, (T *)it->seg_spmv, done));
-    if (it->profile) { hipEvent_t e = cg_profile_event(it); if (e) (void)hipEventRecord(e, ctx->stream); }
-    hipLaunchKernelGGL((k_cg_fin_alpha<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_spmv, nb, d, pcg, (FinScratch<T> *)it->fin);
+    if (it->A) {
+        if (it->profile) { hipEvent_t e = cg_profile_event(it); if (e) (void)hipEventRecord(e, ctx->stream); }
+        MIK_TRY(mik_spmv_launch<T>(ctx, it->A, u, c, true, (T *)it->seg_spmv, done));
+        if (it->profile) { hipEvent_t e = cg_profile_event(it); if (e) (void)hipEventRecord(e, ctx->stream); }
+        hipLaunchKernelGGL((k_cg_fin_alpha<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_spmv, nb, d, pcg, (FinScratch<T> *)it->fin);
+    } else {
+        // any operator: mul!(c, A, u) through the callback; dot(u, c) as its own sweep with the vector tree shape
+        if (it->op_mul(it->op_user, u, c) != 0) return mik_fail(ctx, MIK_ERR_CALLBACK, "cg: the operator callback failed");
+        OpDot<T> duc{u, c};
+        MIK_TRY((launch_map<T>(ctx, n, duc, vec, (T *)it->seg_vec, done)));
+        hipLaunchKernelGGL((k_cg_fin_alpha<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_vec, nseg, d, pcg, (FinScratch<T> *)it->fin);
+    }
     MIK_LAUNCH_CHECK(ctx);
     // x .+= alpha .* u; r .-= alpha .* c; norm(r)                       src/cg.jl:58-62
     OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints() >> 3};
@@ -601,7 +616,8 @@ static int cg_init_impl(mik_cg *it, double abstol, double reltol, int initially_
         MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)it->seg_vec, nullptr)));
     } else {
         it->mv_products = 1;                                              // :136
-        MIK_TRY(mik_spmv_launch<T>(ctx, it->A, x, c, false, nullptr, nullptr));   // :137
+        if (it->A) MIK_TRY(mik_spmv_launch<T>(ctx, it->A, x, c, false, nullptr, nullptr));   // :137
+        else if (it->op_mul(it->op_user, x, c) != 0) return mik_fail(ctx, MIK_ERR_CALLBACK, "cg: the operator callback failed");
         OpSubNrm<T> op{b, c, r};                                          // r = b - c       :130,138
         MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)it->seg_vec, nullptr)));
     }
@@ -625,22 +641,19 @@ static int cg_init_impl(mik_cg *it, double abstol, double reltol, int initially_
     return MIK_OK;
 }
 
-extern "C" int mik_cg_create(mik_ctx *ctx, const mik_csr *A, void *x, const void *b, void *u, void *r, void *c,
-                             const void *jacobi_diag, double abstol, double reltol, int64_t maxiter, int initially_zero,
-                             mik_cg **out)
+static int cg_create_common(mik_ctx *ctx, const mik_csr *A, int dtype, int64_t n, mik_mul_fn op_mul, void *op_user, const void *jacobi_diag,
+                            mik_ldiv_fn pl_fn, void *pl_user, void *x, const void *b, void *u, void *r, void *c, double abstol, double reltol,
+                            int64_t maxiter, int initially_zero, mik_cg **out)
 {
-    if (!ctx || !out) return MIK_ERR_INVALID;
-    *out = nullptr;
-    if (!A || A->n_rows != A->n_cols) return mik_fail(ctx, MIK_ERR_MISMATCH, "mik_cg_create: A must be square");
-    const int64_t n = A->n_rows;
     if (n && (!x || !b || !u || !r || !c)) return mik_fail(ctx, MIK_ERR_INVALID, "mik_cg_create: NULL vector");
     mik_cg *it = new (std::nothrow) mik_cg();
     if (!it) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_cg_create: host allocation failed");
-    it->ctx = ctx; it->A = A; it->dtype = A->dtype; it->n = n;
+    it->ctx = ctx; it->A = A; it->dtype = dtype; it->n = n;
+    it->op_mul = op_mul; it->op_user = op_user; it->pl_fn = pl_fn; it->pl_user = pl_user;
     it->x = x; it->b = b; it->u = u; it->r = r; it->c = c; it->diag = jacobi_diag;
     it->maxiter = maxiter;
-    const size_t es = mik_dtype_size(A->dtype);
-    const int64_t nseg = A->dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
+    const size_t es = mik_dtype_size(dtype);
+    const int64_t nseg = dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
     const int64_t nb = mik_spmv_nwg(n);
     hipError_t e;
     (void)hipSetDevice(ctx->device);
@@ -657,11 +670,50 @@ extern "C" int mik_cg_create(mik_ctx *ctx, const mik_csr *A, void *x, const void
         return mik_fail(ctx, MIK_ERR_NOMEM, "mik_cg_create: hipHostMalloc: %s", hipGetErrorString(e));
     }
     memset(it->mirror, 0, sizeof(CgMirror));
-    int rc = A->dtype == MIK_F64 ? cg_init_impl<double>(it, abstol, reltol, initially_zero)
-                                 : cg_init_impl<float>(it, abstol, reltol, initially_zero);
+    int rc = dtype == MIK_F64 ? cg_init_impl<double>(it, abstol, reltol, initially_zero)
+                              : cg_init_impl<float>(it, abstol, reltol, initially_zero);
     if (rc) { mik_cg_destroy(it); return rc; }
     *out = it;
     return MIK_OK;
+}
+
+extern "C" int mik_cg_create(mik_ctx *ctx, const mik_csr *A, void *x, const void *b, void *u, void *r, void *c,
+                             const void *jacobi_diag, double abstol, double reltol, int64_t maxiter, int initially_zero,
+                             mik_cg **out)
+{
+    if (!ctx || !out) return MIK_ERR_INVALID;
+    *out = nullptr;
+    if (!A || A->n_rows != A->n_cols) return mik_fail(ctx, MIK_ERR_MISMATCH, "mik_cg_create: A must be square");
+    return cg_create_common(ctx, A, A->dtype, A->n_rows, nullptr, nullptr, jacobi_diag, nullptr, nullptr, x, b, u, r, c, abstol, reltol, maxiter,
+                            initially_zero, out);
+}
+
+// the operator of a *_create_op call: a CSR handle or a callback
+static int resolve_operator(mik_ctx *ctx, const mik_operator *A, const char *who, const mik_csr **csr, int *dtype, int64_t *n)
+{
+    if (!A || (!A->csr && !A->mul)) return mik_fail(ctx, MIK_ERR_INVALID, "%s: the operator needs a csr handle or a mul callback", who);
+    if (A->csr) {
+        if (A->csr->n_rows != A->csr->n_cols) return mik_fail(ctx, MIK_ERR_MISMATCH, "%s: A must be square", who);
+        *csr = A->csr; *dtype = A->csr->dtype; *n = A->csr->n_rows;
+        return MIK_OK;
+    }
+    if ((A->dtype != MIK_F64 && A->dtype != MIK_F32) || A->n < 0) return mik_fail(ctx, MIK_ERR_INVALID, "%s: bad dtype / size of the callback operator", who);
+    *csr = nullptr; *dtype = A->dtype; *n = A->n;
+    return MIK_OK;
+}
+
+extern "C" int mik_cg_create_op(mik_ctx *ctx, const mik_operator *A, const mik_precond *Pl, void *x, const void *b, void *u, void *r, void *c,
+                                double abstol, double reltol, int64_t maxiter, int initially_zero, mik_cg **out)
+{
+    if (!ctx || !out) return MIK_ERR_INVALID;
+    *out = nullptr;
+    const mik_csr *csr = nullptr;
+    int dtype = MIK_F64;
+    int64_t n = 0;
+    MIK_TRY(resolve_operator(ctx, A, "mik_cg_create_op", &csr, &dtype, &n));
+    if (Pl && Pl->diag && Pl->ldiv) return mik_fail(ctx, MIK_ERR_INVALID, "mik_cg_create_op: Pl has both a diagonal and a callback");
+    return cg_create_common(ctx, csr, dtype, n, csr ? nullptr : A->mul, A->user, Pl ? Pl->diag : nullptr, Pl ? Pl->ldiv : nullptr,
+                            Pl ? Pl->user : nullptr, x, b, u, r, c, abstol, reltol, maxiter, initially_zero, out);
 }
 
 extern "C" int mik_cg_destroy(mik_cg *it)
@@ -795,6 +847,10 @@ struct mik_gmres {
     void *x = nullptr;
     const void *b = nullptr;
     const void *pl = nullptr, *pr = nullptr;   // diagonal left / right preconditioners (device n-vectors) or NULL = Identity()
+    mik_mul_fn op_mul = nullptr;                // A as a callback (A == nullptr): mik_gmres_create_op
+    void *op_user = nullptr;
+    mik_ldiv_fn pl_fn = nullptr, pr_fn = nullptr;   // Pl / Pr as callbacks
+    void *pl_user = nullptr, *pr_user = nullptr;
     void *V = nullptr;        // device n x (restart + 1), column-major   src/gmres.jl:13
     void *Ax = nullptr;       // device work vector                        src/gmres.jl:125
     std::vector<double> H64; std::vector<float> H32;             // (restart+1) x restart   :14
@@ -819,6 +875,10 @@ static void gm_drop_graphs(mik_gmres *g);
 template <typename T> static int gm_spmv(mik_gmres *g, const T *src, T *dst)
 {
     mik_ctx *ctx = g->ctx;
+    if (g->op_mul) {                                    // any operator: mul!(dst, A, src) through the callback
+        if (g->op_mul(g->op_user, src, dst) != 0) return mik_fail(ctx, MIK_ERR_CALLBACK, "gmres: the operator callback failed");
+        return MIK_OK;
+    }
     if (!g->dist) return mik_spmv_launch<T>(ctx, g->A, src, dst, false, nullptr, nullptr);
     T *ext = (T *)g->part.x_ext;
     if (src != ext && g->n > 0) MIK_HIP(ctx, hipMemcpyAsync(ext, src, sizeof(T) * (size_t)g->n, hipMemcpyDeviceToDevice, ctx->stream));
@@ -853,7 +913,7 @@ static int orthogonalize_part(mik_gmres *g, int k, const T *V, int64_t ldv, T *w
 {
     mik_ctx *ctx = g->ctx;
     const int64_t n = g->n;
-    if ((size_t)(2 * k + 4) * sizeof(T) > mik_ctx::COEF_BYTES) return mik_fail(ctx, MIK_ERR_NOTIMPL, "orthogonalize: k = %d too large", k);
+    if ((size_t)(2 * k + 4) * sizeof(T) > mik_ctx::COEF_SAFE_SLOT) return mik_fail(ctx, MIK_ERR_NOTIMPL, "orthogonalize: k = %d too large", k);
     const int64_t nseg = mik_nseg<T>(n);
     MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(nseg, 1) * (size_t)std::max(k, 1)));
     T *hd = (T *)ctx->coef;
@@ -928,6 +988,21 @@ template <typename T> static std::vector<T> &gm_nv(mik_gmres *g);
 template <> std::vector<double> &gm_nv<double>(mik_gmres *g) { return g->nv64; }
 template <> std::vector<float> &gm_nv<float>(mik_gmres *g) { return g->nv32; }
 
+// ldiv!(y, P, x) for the left (side 0) or right (side 1) preconditioner: fused diagonal sweep or the callback
+template <typename T> static int gm_ldiv(mik_gmres *g, int side, T *y, const T *x)
+{
+    const void *diag = side ? g->pr : g->pl;
+    mik_ldiv_fn fn = side ? g->pr_fn : g->pl_fn;
+    if (diag) {
+        OpDivide<T> dv{x, (const T *)diag, y};
+        return launch_map<T>(g->ctx, g->n, dv, mik_aligned16(x) && mik_aligned16(y) && mik_aligned16(diag), (T *)nullptr, nullptr);
+    }
+    if (fn && fn(side ? g->pr_user : g->pl_user, y, x) != 0) return mik_fail(g->ctx, MIK_ERR_CALLBACK, "gmres: the %s preconditioner callback failed", side ? "right" : "left");
+    return MIK_OK;
+}
+static inline bool gm_has_pl(const mik_gmres *g) { return g->pl || g->pl_fn; }
+static inline bool gm_has_pr(const mik_gmres *g) { return g->pr || g->pr_fn; }
+
 // init!(arnoldi, x, b, Pl = Identity, Ax; initially_zero) -> beta      src/gmres.jl:235-255
 template <typename T> static int gmres_init_residual(mik_gmres *g, int initially_zero, T *beta_out)
 {
@@ -946,9 +1021,8 @@ template <typename T> static int gmres_init_residual(mik_gmres *g, int initially
         OpSubNrm<T> op{b, (const T *)g->Ax, V0};                          // :241,246
         MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)ctx->partials, nullptr)));
     }
-    if (g->pl) {                                                          // ldiv!(Pl, first_col)  :249
-        OpDivide<T> dv{V0, (const T *)g->pl, V0};
-        MIK_TRY((launch_map<T>(ctx, n, dv, mik_aligned16(V0) && mik_aligned16(g->pl), (T *)nullptr, nullptr)));
+    if (gm_has_pl(g)) {                                                   // ldiv!(Pl, first_col)  :249
+        MIK_TRY(gm_ldiv<T>(g, 0, V0, V0));
         OpDot<T> dn{V0, V0};
         MIK_TRY((launch_map<T>(ctx, n, dn, mik_aligned16(V0), (T *)ctx->partials, nullptr)));
     }
@@ -995,14 +1069,22 @@ template <typename T> static int gmres_create_impl(mik_gmres *g, double abstol, 
     return MIK_OK;
 }
 
+struct GmresOpArgs {          // the callback forms of A / Pl / Pr (mik_gmres_create_op); all NULL for the CSR / diagonal entry points
+    int dtype = MIK_F64;
+    int64_t n = 0;
+    mik_mul_fn mul = nullptr; void *mul_user = nullptr;
+    mik_ldiv_fn pl = nullptr; void *pl_user = nullptr;
+    mik_ldiv_fn pr = nullptr; void *pr_user = nullptr;
+};
+
 static int gmres_create_common(mik_ctx *ctx, const mik_csr *A, void *x, const void *b, const void *pl_diag, const void *pr_diag,
                                double abstol, double reltol, int restart, int64_t maxiter, int initially_zero, int orth_method,
-                               const mik_partition *part, mik_gmres **out)
+                               const mik_partition *part, mik_gmres **out, const GmresOpArgs *op = nullptr)
 {
     if (!ctx || !out) return MIK_ERR_INVALID;
     *out = nullptr;
-    if (!A) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create: NULL operator");
-    if (!part && A->n_rows != A->n_cols) return mik_fail(ctx, MIK_ERR_MISMATCH, "mik_gmres_create: A must be square");
+    if (!A && !(op && op->mul)) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create: NULL operator");
+    if (A && !part && A->n_rows != A->n_cols) return mik_fail(ctx, MIK_ERR_MISMATCH, "mik_gmres_create: A must be square");
     if (part) {
         if (part->nranks < 1 || part->rank < 0 || part->rank >= part->nranks) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create_partitioned: bad rank %d of %d", part->rank, part->nranks);
         if (part->n_ext != A->n_cols || part->n_ext < A->n_rows) return mik_fail(ctx, MIK_ERR_MISMATCH, "mik_gmres_create_partitioned: A_loc must be n_loc x n_ext");
@@ -1012,17 +1094,19 @@ static int gmres_create_common(mik_ctx *ctx, const mik_csr *A, void *x, const vo
     }
     if (restart < 1) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create: restart must be >= 1");
     if (orth_method != MIK_MGS && orth_method != MIK_CGS && orth_method != MIK_DGKS) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create: bad orth_method");
-    const int64_t n = A->n_rows;
+    const int64_t n = A ? A->n_rows : op->n;
+    const int dtype = A ? A->dtype : op->dtype;
     if (n && (!x || !b)) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create: NULL vector");
-    if ((size_t)(2 * restart + 6) * 8 > mik_ctx::COEF_BYTES) return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_gmres_create: restart %d too large", restart);
+    if ((size_t)(2 * restart + 6) * 8 > mik_ctx::COEF_SAFE_SLOT) return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_gmres_create: restart %d too large", restart);
     mik_gmres *g = new (std::nothrow) mik_gmres();
     if (!g) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_gmres_create: host allocation failed");
-    g->ctx = ctx; g->A = A; g->dtype = A->dtype; g->n = n; g->x = x; g->b = b; g->pl = pl_diag; g->pr = pr_diag;
+    g->ctx = ctx; g->A = A; g->dtype = dtype; g->n = n; g->x = x; g->b = b; g->pl = pl_diag; g->pr = pr_diag;
+    if (op) { g->op_mul = A ? nullptr : op->mul; g->op_user = op->mul_user; g->pl_fn = op->pl; g->pl_user = op->pl_user; g->pr_fn = op->pr; g->pr_user = op->pr_user; }
     g->restart = restart; g->maxiter = maxiter; g->method = orth_method;
     if (part) { g->dist = true; g->part = *part; }
     g->ldv = (n + 63) / 64 * 64;
     if (g->ldv == 0) g->ldv = 64;
-    const size_t es = mik_dtype_size(A->dtype);
+    const size_t es = mik_dtype_size(dtype);
     hipError_t e;
     (void)hipSetDevice(ctx->device);
     if ((e = hipMalloc(&g->V, es * (size_t)g->ldv * (size_t)(restart + 1))) != hipSuccess ||
@@ -1034,8 +1118,8 @@ static int gmres_create_common(mik_ctx *ctx, const mik_csr *A, void *x, const vo
         mik_gmres_destroy(g);
         return mik_fail(ctx, MIK_ERR_HIP, "mik_gmres_create: memset: %s", hipGetErrorString(e));
     }
-    int rc = A->dtype == MIK_F64 ? gmres_create_impl<double>(g, abstol, reltol, initially_zero)
-                                 : gmres_create_impl<float>(g, abstol, reltol, initially_zero);
+    int rc = dtype == MIK_F64 ? gmres_create_impl<double>(g, abstol, reltol, initially_zero)
+                              : gmres_create_impl<float>(g, abstol, reltol, initially_zero);
     if (rc) { mik_gmres_destroy(g); return rc; }
     *out = g;
     return MIK_OK;
@@ -1046,6 +1130,23 @@ extern "C" int mik_gmres_create(mik_ctx *ctx, const mik_csr *A, void *x, const v
                                 mik_gmres **out)
 {
     return gmres_create_common(ctx, A, x, b, pl_diag, pr_diag, abstol, reltol, restart, maxiter, initially_zero, orth_method, nullptr, out);
+}
+
+extern "C" int mik_gmres_create_op(mik_ctx *ctx, const mik_operator *A, const mik_precond *Pl, const mik_precond *Pr, void *x, const void *b,
+                                   double abstol, double reltol, int restart, int64_t maxiter, int initially_zero, int orth_method,
+                                   mik_gmres **out)
+{
+    if (!ctx || !out) return MIK_ERR_INVALID;
+    *out = nullptr;
+    const mik_csr *csr = nullptr;
+    GmresOpArgs op;
+    MIK_TRY(resolve_operator(ctx, A, "mik_gmres_create_op", &csr, &op.dtype, &op.n));
+    if ((Pl && Pl->diag && Pl->ldiv) || (Pr && Pr->diag && Pr->ldiv)) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create_op: a preconditioner has both a diagonal and a callback");
+    if (!csr) { op.mul = A->mul; op.mul_user = A->user; }
+    if (Pl) { op.pl = Pl->ldiv; op.pl_user = Pl->user; }
+    if (Pr) { op.pr = Pr->ldiv; op.pr_user = Pr->user; }
+    return gmres_create_common(ctx, csr, x, b, Pl ? Pl->diag : nullptr, Pr ? Pr->diag : nullptr, abstol, reltol, restart, maxiter, initially_zero,
+                               orth_method, nullptr, out, &op);
 }
 
 extern "C" int mik_gmres_create_partitioned(mik_ctx *ctx, const mik_csr *A_loc, void *x, const void *b, const void *pl_diag,
@@ -1071,19 +1172,15 @@ extern "C" int mik_gmres_destroy(mik_gmres *g)
 template <typename T> static int gm_expand(mik_gmres *g, T *vk, T *vk1)
 {
     mik_ctx *ctx = g->ctx;
-    if (g->pr) {
+    if (gm_has_pr(g)) {
         // Pl \ (A * (Pr \ v)) through the work vector Ax                  :297-304
-        OpDivide<T> dr{vk, (const T *)g->pr, vk1};
-        MIK_TRY((launch_map<T>(ctx, g->n, dr, mik_aligned16(vk) && mik_aligned16(vk1) && mik_aligned16(g->pr), (T *)nullptr, nullptr)));
+        MIK_TRY(gm_ldiv<T>(g, 1, vk1, vk));                                // ldiv!(nextV, Pr, V[:, k])  :300
         MIK_TRY(gm_spmv<T>(g, vk1, (T *)g->Ax));
         MIK_HIP(ctx, hipMemcpyAsync(vk1, g->Ax, sizeof(T) * (size_t)g->n, hipMemcpyDeviceToDevice, ctx->stream));
     } else {
         MIK_TRY(gm_spmv<T>(g, vk, vk1));                                  // V[:, k+1] = A * V[:, k]   :287
     }
-    if (g->pl) {                                                          // ldiv!(Pl, nextV)  :294 / :303
-        OpDivide<T> dl{vk1, (const T *)g->pl, vk1};
-        MIK_TRY((launch_map<T>(ctx, g->n, dl, mik_aligned16(vk1) && mik_aligned16(g->pl), (T *)nullptr, nullptr)));
-    }
+    if (gm_has_pl(g)) MIK_TRY(gm_ldiv<T>(g, 0, vk1, vk1));              // ldiv!(Pl, nextV)  :294 / :303
     return MIK_OK;
 }
 
@@ -1160,7 +1257,7 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
     // expand! (:64, :285-304), then H[k+1, k] = orthogonalize_and_normalize!(V[:, 1:k], V[:, k+1], H[1:k, k], orth_meth)  :68-73
     T nrm;
     bool ran = false;
-    if (g_mik_tuning[5] == 3 && !g->dist && !g->graph_off && g->method != MIK_DGKS && mik_nseg<T>(g->n) <= 1024)
+    if (g_mik_tuning[5] == 3 && !g->dist && !g->graph_off && g->method != MIK_DGKS && mik_nseg<T>(g->n) <= 1024 && !g->op_mul && !g->pl_fn && !g->pr_fn)
         MIK_TRY(gm_step_graph<T>(g, k, vk, vk1, &Hat(0, k - 1), &nrm, &ran));
     if (!ran) {
         MIK_TRY(gm_expand<T>(g, vk, vk1));
@@ -1194,14 +1291,13 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
         hessenberg_ldiv<T>(H.data(), ldh, k - 1, rhs.data());
         // update_solution!: x += V[:, 1:k-1] * y                         :88, :273-276
         MIK_TRY(coef_upload<T>(ctx, 0, rhs.data(), k - 1));
-        if (g->pr) {
+        if (gm_has_pr(g)) {
             // x += Pr \ (V * y) with Ax as work space                     :278-283
             T *Ax = (T *)g->Ax;
             OpFill<T> z{Ax, T(0)};
             MIK_TRY((launch_map<T>(ctx, g->n, z, mik_aligned16(Ax), (T *)nullptr, nullptr)));
             MIK_TRY(gemv_n_dev<T>(ctx, g->n, k - 1, V, g->ldv, (const T *)ctx->coef, T(1), Ax));
-            OpDivide<T> dr{Ax, (const T *)g->pr, Ax};
-            MIK_TRY((launch_map<T>(ctx, g->n, dr, mik_aligned16(Ax) && mik_aligned16(g->pr), (T *)nullptr, nullptr)));
+            MIK_TRY(gm_ldiv<T>(g, 1, Ax, Ax));                               // ldiv!(Pr, Ax)  :281
             OpAxpy<T> ax{Ax, (T *)g->x, coef_val<T>(T(1))};
             MIK_TRY((launch_map<T>(ctx, g->n, ax, mik_aligned16(Ax) && mik_aligned16(g->x), (T *)nullptr, nullptr)));
         } else {
@@ -1556,7 +1652,7 @@ extern "C" int mik_cgd_wait(mik_cgd *it, double *residual, double *tol, int *don
 template <typename T> static int gemv_t_impl(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, const T *w, T *h_host)
 {
     if (k == 0) return MIK_OK;
-    if ((size_t)k * sizeof(T) > mik_ctx::COEF_BYTES) return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_gemv_t: k = %d too large", k);
+    if ((size_t)k * sizeof(T) > mik_ctx::COEF_SAFE_SLOT) return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_gemv_t: k = %d too large", k);
     const int64_t nseg = mik_nseg<T>(n);
     MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(nseg, 1) * (size_t)k));
     MIK_TRY(multidot<T>(ctx, n, k, V, ldv, w, (T *)ctx->coef));

@@ -112,14 +112,19 @@ def _hash32(x: np.ndarray, mult: int) -> np.ndarray:
     return h
 
 
-def irregular_matrix(n: int = 1_000_000, dtype=np.float32, long_rows: bool = True):
+def irregular_matrix(n: int = 1_000_000, dtype=np.float32, long_rows: bool = True, bandwidth: int = 0):
     """Synthetic irregular CSR operator standing in for BASELINE.json configs[4] (the SuiteSparse files
     of benchmark/matrixmarket.jl:5 / matrixcollection.jl:6 cannot be downloaded here) -- SURVEY.md
     section 8d: row-length classes {90 %: 5-15, 9.9 %: 50-200, 0.1 %: 5,000-20,000 (capped at n/2)}
     chosen by an integer hash of the row index, column indices by a second hash, off-diagonal values in
     [-1, 1) by a third, diagonal = 1 + sum |off-diagonal| (strictly diagonally dominant => GMRES
     converges).  Returns 0-based CSR fields (n, rowptr, colidx, val) with columns ascending in a row;
-    duplicate off-diagonal columns are merged by keeping the first."""
+    duplicate off-diagonal columns are merged by keeping the first.
+
+    ``bandwidth`` = 0: columns uniformly random over the whole matrix (no locality at all: every gather of x misses
+    L1 -- the worst case).  ``bandwidth`` = w > 0: "banded-irregular" -- the same row lengths and values, but a row's
+    columns are drawn from [row - w_r, row + w_r] with w_r = max(w, 4 x row length): the locality a bandwidth-reducing
+    ordering (RCM) gives finite-element / shell matrices such as the s3dkq4m2 of benchmark/matrixmarket.jl:5."""
     rows = np.arange(n, dtype=np.int64)
     cls = _hash32(rows, 2654435761) % np.uint64(1000)
     sel = _hash32(rows, 40503)
@@ -132,7 +137,12 @@ def irregular_matrix(n: int = 1_000_000, dtype=np.float32, long_rows: bool = Tru
     total = int(start[-1])
     r = np.repeat(rows, length)
     k = np.arange(total, dtype=np.int64) - start[r]                   # position inside the row
-    c = (_hash32(r * 131071 + k, 2246822519) % np.uint64(n)).astype(np.int64)
+    hcol = _hash32(r * 131071 + k, 2246822519)
+    if bandwidth > 0:
+        w = np.maximum(np.int64(bandwidth), 4 * length)[r]             # half-width of this row's band
+        c = (r + (hcol % (2 * w + 1).astype(np.uint64)).astype(np.int64) - w) % n
+    else:
+        c = (hcol % np.uint64(n)).astype(np.int64)
     c = np.where(c == r, (c + 1) % n, c)                               # keep the diagonal separate
     v = (_hash32(r * 8191 + k + 7, 3266489917).astype(np.float64) / 2147483648.0 - 1.0)
     order = np.lexsort((k, c, r))                                      # sort by (row, col), first occurrence first
