@@ -100,6 +100,10 @@ int mik_spmv_dot_shape(int *W, int *L);
  * products of entries l, l+64, ... in order, then the wave-64 tree); shorter rows strictly in column
  * order like the reference.  None of the reference's fixtures has such rows. */
 int mik_spmv_long_row(int *threshold);
+/* Rows with more than *segment entries are cut into segments of that many consecutive entries; every segment is summed
+ * with the wave shape above and the segment sums are added left to right (one wave per row left a 20,000-entry row to a
+ * single wave). */
+int mik_spmv_long_segment(int *segment);
 /* Development knobs (not part of the reference interface; results never depend on them) for A/B timing and for
  * the tests that pin every kernel variant against the oracle.  All default to 0.
  *   0: 1 = cached (temporal) val/col/y streams in SpMV            1: 1 = narrow loads in the CSR kernel
@@ -109,7 +113,8 @@ int mik_spmv_long_row(int *threshold);
  *   6: 1 = ignore the dictionary-coded form                       7: cache hints of the CG vector kernels
  *   8: 1 = CSR row-block layout only (read at mik_csr_create and at launch)
  *  10: 1 = no 8-bit column codes                                  12: 1 = no per-slice-offset layout
- *  13: bit mask switching the Krylov-basis streaming hints off    14: CSR kernel: 0 = LDS-DMA tile + per-row gather, 1 = register-staged products */
+ *  13: bit mask switching the Krylov-basis streaming hints off    14: CSR kernel: 0 = LDS-DMA tile + per-row gather, 1 = register-staged products
+ *  15: long-row segment length (> 0; read at mik_csr_create) */
 int mik_set_tuning(int key, int value);
 
 /* ---- device memory (similar / zero / copyto! / fill! of the vector interface) ----------- */

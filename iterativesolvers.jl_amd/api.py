@@ -74,6 +74,12 @@ class HipContext:
         check(lib().mik_spmv_long_row(C.byref(t)), "mik_spmv_long_row", self.handle)
         return t.value
 
+    def spmv_long_segment(self) -> int:
+        """Rows with more stored entries than this are summed segment by segment (include/mik.h)."""
+        t = C.c_int()
+        check(lib().mik_spmv_long_segment(C.byref(t)), "mik_spmv_long_segment", self.handle)
+        return t.value
+
     def cg_shape(self, dtype):
         """(Wd, Ld, W, L): reduction shapes of the fused CG step, as the oracle's `shape` argument."""
         return self.spmv_dot_shape() + self.reduce_shape(dtype)

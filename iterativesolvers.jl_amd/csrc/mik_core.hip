@@ -140,6 +140,12 @@ extern "C" int mik_spmv_long_row(int *threshold)
     return MIK_OK;
 }
 
+extern "C" int mik_spmv_long_segment(int *segment)
+{
+    if (segment) *segment = g_mik_tuning[15] > 0 ? g_mik_tuning[15] : MIK_LONG_SEG;
+    return MIK_OK;
+}
+
 extern "C" int mik_set_tuning(int key, int value)
 {
     if (key < 0 || key >= 16) return MIK_ERR_INVALID;
@@ -483,7 +489,8 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
     // Long rows (> MIK_LONG_ROW entries) leave the row-block layout: their entries move behind all
     // short-row entries and a wave-per-row kernel sums them (still serially, in column order).  In the
     // short part a long row becomes an empty row, so the row-block kernel keeps its contiguous ranges.
-    std::vector<int> long_rows, long_start, long_len;
+    std::vector<int> long_rows, long_start, long_len;          // virtual rows of the long part: whole rows and segments of cut rows
+    std::vector<int> seg_row, cut_row, cut_first, cut_nseg;    // segment -> cut row; cut row -> matrix row, first segment, segments
     std::vector<unsigned char> is_long;
     // development knob [4]: > 0 overrides the threshold, < 0 disables the split
     const int long_row = g_mik_tuning[4] > 0 ? g_mik_tuning[4] : MIK_LONG_ROW;
@@ -521,6 +528,26 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
         }
         for (int64_t q = ps; q < ((short_nnz + 3) & ~(int64_t)3); ++q) { col2[q] = 0; memset(&v2[(size_t)q * es], 0, es); }
         rowptr.swap(rp2); col.swap(col2); v.swap(v2);
+        {   // rows longer than one segment are cut: every segment becomes a virtual row of its own (csrc/mik_spmv.h, LongTab)
+            const int seg = g_mik_tuning[15] > 0 ? g_mik_tuning[15] : MIK_LONG_SEG;      // development knob: segment length
+            std::vector<int> vr, vs, vl;
+            for (size_t q = 0; q < long_rows.size(); ++q) {
+                if (long_len[q] <= seg) { vr.push_back(long_rows[q]); vs.push_back(long_start[q]); vl.push_back(long_len[q]); continue; }
+                const int ns = (long_len[q] + seg - 1) / seg;
+                cut_row.push_back(long_rows[q]); cut_first.push_back((int)seg_row.size()); cut_nseg.push_back(ns);
+                for (int z = 0; z < ns; ++z) {
+                    vr.push_back(-((int)seg_row.size() + 1));
+                    vs.push_back(long_start[q] + z * seg);
+                    vl.push_back(std::min(seg, long_len[q] - z * seg));
+                    seg_row.push_back((int)cut_row.size() - 1);
+                }
+            }
+            std::vector<int> ord(vr.size());
+            for (size_t q = 0; q < ord.size(); ++q) ord[q] = (int)q;
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return vl[a] > vl[b]; });
+            long_rows.resize(vr.size()); long_start.resize(vr.size()); long_len.resize(vr.size());
+            for (size_t q = 0; q < ord.size(); ++q) { long_rows[q] = vr[ord[q]]; long_start[q] = vs[ord[q]]; long_len[q] = vl[ord[q]]; }
+        }
     }
     const int64_t nnz_store = (int64_t)col.size();                     // entries physically stored (>= nnz when re-laid out)
 
@@ -533,7 +560,7 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
     A->max_rowblock_nnz = max_rb;
     A->n_long = (int)long_rows.size();
     A->n_long_big = 0;
-    for (int len : long_len) if (len > 256) A->n_long_big++;            // sorted longest first: a prefix of the list
+    for (int len : long_len) if (len > 256) A->n_long_big++;            // sorted longest first: a prefix of the list (segments included)
     A->ctx = ctx; A->dtype = dtype; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz; A->max_row_nnz = max_row; A->strip = strip;
     const size_t pad = 2 * MIK_SPMV_TILE;   // slack so tile-granular reads never leave the allocation
     auto cleanup = [&]() { mik_csr_destroy(A); };
@@ -556,16 +583,26 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
         return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create: upload: %s", hipGetErrorString(e));
     }
     if (A->n_long) {
-        const size_t nl = (size_t)A->n_long;
-        if ((e = hipMalloc((void **)&A->long_rows, sizeof(int) * nl * 3)) != hipSuccess ||
+        const size_t nl = (size_t)A->n_long, nsg = seg_row.size(), nc = cut_row.size();
+        A->n_seg = (int)nsg; A->n_cut = (int)nc;
+        std::vector<int> tab;
+        tab.insert(tab.end(), long_rows.begin(), long_rows.end());
+        tab.insert(tab.end(), long_start.begin(), long_start.end());
+        tab.insert(tab.end(), long_len.begin(), long_len.end());
+        tab.insert(tab.end(), seg_row.begin(), seg_row.end());
+        tab.insert(tab.end(), cut_row.begin(), cut_row.end());
+        tab.insert(tab.end(), cut_first.begin(), cut_first.end());
+        tab.insert(tab.end(), cut_nseg.begin(), cut_nseg.end());
+        tab.insert(tab.end(), nc, 0);                                          // tickets
+        if ((e = hipMalloc((void **)&A->long_rows, sizeof(int) * std::max<size_t>(tab.size(), 1))) != hipSuccess ||
             (e = hipMalloc((void **)&A->is_long, (size_t)n_rows)) != hipSuccess ||
-            (e = hipMemcpy(A->long_rows, long_rows.data(), sizeof(int) * nl, hipMemcpyHostToDevice)) != hipSuccess ||
-            (e = hipMemcpy(A->long_rows + nl, long_start.data(), sizeof(int) * nl, hipMemcpyHostToDevice)) != hipSuccess ||
-            (e = hipMemcpy(A->long_rows + 2 * nl, long_len.data(), sizeof(int) * nl, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMalloc(&A->seg_sum, es * std::max<size_t>(nsg, 1))) != hipSuccess ||
+            (e = hipMemcpy(A->long_rows, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(A->is_long, is_long.data(), (size_t)n_rows, hipMemcpyHostToDevice)) != hipSuccess) {
             cleanup();
             return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create: long-row tables: %s", hipGetErrorString(e));
         }
+        (void)nl;
     }
     // device layouts for banded / stencil operators (see the two builders above)
     int rc_layout = csr_build_sdia(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz, max_row);
@@ -584,6 +621,7 @@ extern "C" int mik_csr_destroy(mik_csr *A)
     if (A->val) (void)hipFree(A->val);
     if (A->long_rows) (void)hipFree(A->long_rows);
     if (A->is_long) (void)hipFree(A->is_long);
+    if (A->seg_sum) (void)hipFree(A->seg_sum);
     if (A->sdia_ptr) (void)hipFree(A->sdia_ptr);
     if (A->sdia_off) (void)hipFree(A->sdia_off);
     if (A->sdia_tri) (void)hipFree(A->sdia_tri);
@@ -693,7 +731,7 @@ extern "C" int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes)
     case 3: *bytes = A->nnz * 2 + (A->n_rows + 1) * 4 + 256 * (es + 4); break;
     case 2: *bytes = A->sell_entries * es + A->sell8_bytes + (nb + 1) * 8 + 256 * 4; break;
     case 1: *bytes = A->sell_entries * (es + 4) + A->n_rows + (nb + 1) * 4; break;
-    default: *bytes = A->nnz * (es + 4) + (A->n_rows + 1) * 4 + (A->n_long ? A->n_rows + 12LL * A->n_long : 0); break;
+    default: *bytes = A->nnz * (es + 4) + (A->n_rows + 1) * 4 + (A->n_long ? A->n_rows + 12LL * A->n_long + 4LL * A->n_seg + 16LL * A->n_cut : 0); break;
     }
     return MIK_OK;
 }
@@ -814,14 +852,22 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
     }
     const int nlong = A->n_long;
     const int nbig = A->n_long_big;
+    LongTab lt{};
+    if (nlong) {
+        int *tb = A->long_rows;
+        lt.rows = tb; lt.starts = tb + nlong; lt.lens = tb + 2 * nlong;
+        lt.seg_row = tb + 3 * nlong;
+        lt.cut_row = lt.seg_row + A->n_seg; lt.cut_first = lt.cut_row + A->n_cut; lt.cut_nseg = lt.cut_first + A->n_cut;
+        lt.tickets = (unsigned *)(tb + 3 * nlong + A->n_seg + 3 * A->n_cut);
+        lt.seg_sum = A->seg_sum; lt.nlong = nlong; lt.nbig = nbig;
+    }
     const int nwaves_long = nbig + (nlong - nbig + MIK_LONG_R - 1) / MIK_LONG_R;   // one wave per big row, MIK_LONG_R medium rows per wave
     const int nlb = (nwaves_long + 3) / 4;
     // CSR kernels.  tuning[14]: 0 = row-block tile filled by LDS-DMA with the per-row gather (k_spmv_rowgather, default),
     // 1 = products staged through registers (k_spmv_rowblock).  Same results bit for bit (tests/test_gpu_layouts.py).
     if (g_mik_tuning[14] != 1) {
         if (nlong) {   // long rows first (whole launches only, see mik_spmv_can_split); the row kernel then picks y[r] up
-            hipLaunchKernelGGL((k_spmv_longrows<T>), dim3(nlb), dim3(MIK_BLOCK), 0, ctx->stream, nlong, nbig, A->long_rows, A->long_rows + nlong,
-                               A->long_rows + 2 * nlong, A->col, (const T *)A->val, x, y, done);
+            hipLaunchKernelGGL((k_spmv_longrows<T>), dim3(nlb), dim3(MIK_BLOCK), 0, ctx->stream, lt, A->col, (const T *)A->val, x, y, done);
             MIK_LAUNCH_CHECK(ctx);
         }
 #define MIK_RG_GO(FD, NTV)                                                                                                      \
@@ -836,14 +882,13 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
     const bool merge = nlong > 0 && !fuse_dot;           // one launch: long-row workgroups first, then row-blocks
     if (nlong && !merge) {
         // fused dot: long rows first in their own launch, the row-block kernel then picks y[r] up
-        hipLaunchKernelGGL((k_spmv_longrows<T>), dim3(nlb), dim3(MIK_BLOCK), 0, ctx->stream, nlong, nbig, A->long_rows, A->long_rows + nlong,
-                           A->long_rows + 2 * nlong, A->col, (const T *)A->val, x, y, done);
+        hipLaunchKernelGGL((k_spmv_longrows<T>), dim3(nlb), dim3(MIK_BLOCK), 0, ctx->stream, lt, A->col, (const T *)A->val, x, y, done);
         MIK_LAUNCH_CHECK(ctx);
     }
     const dim3 grid(nb + (merge ? nlb : 0)), block(MIK_BLOCK);
 #define MIK_SPMV_GO(FD, NT, WD, MG)                                                                              \
     hipLaunchKernelGGL((k_spmv_rowblock<T, FD, NT, WD, MG>), grid, block, 0, ctx->stream, n, nb, map_mode, A->rowptr, \
-                       A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, nlong, nbig, nlb, A->long_rows)
+                       A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, nlb, lt)
 #define MIK_SPMV_GO2(FD, MG)                                                              \
     do {                                                                                  \
         if (nt) { if (wide) MIK_SPMV_GO(FD, true, true, MG); else MIK_SPMV_GO(FD, true, false, MG); }   \

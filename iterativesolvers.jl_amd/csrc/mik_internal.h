@@ -54,7 +54,10 @@ struct mik_csr {
     int max_rowblock_nnz = 0;        // largest nnz of any 256-row block (short part)
     int n_long = 0;                  // rows longer than MIK_LONG_ROW, stored behind the short part
     int n_long_big = 0;              // how many of them exceed 256 entries (one wave each; the rest go 4 per wave)
-    int *long_rows = nullptr;        // device: [n_long] row ids, [n_long] start offsets, [n_long] lengths
+    int *long_rows = nullptr;        // device: [n_long] targets, [n_long] start offsets, [n_long] lengths of the virtual rows, then the
+                                     // segment tables: [n_seg] cut-row index, [n_cut] row, [n_cut] first segment, [n_cut] segments, [n_cut] tickets
+    int n_seg = 0, n_cut = 0;        // rows longer than MIK_LONG_SEG are cut into n_seg segments (csrc/mik_spmv.h)
+    void *seg_sum = nullptr;         // device: one partial per segment
     unsigned char *is_long = nullptr;   // device: n_rows flags (only when n_long > 0)
     // sliced-ELL form (csrc/mik_sell.h), built at upload for operators with near-uniform row lengths per block
     int *sell_ptr = nullptr;         // device, nb + 1: entry offset of every 256-row slice

@@ -88,14 +88,56 @@ __device__ __forceinline__ int spmv_block_map(int b, int nb, int mode)
 constexpr int MIK_LONG_U = 8;                          // entries per lane per chunk
 constexpr int MIK_LONG_CH = 64 * MIK_LONG_U;           // 512-entry chunks
 
+// Rows with more than MIK_LONG_SEG entries are cut into SEGMENTS of MIK_LONG_SEG consecutive entries: every segment is
+// summed by its own wave with the shape above (lane l: the segment's entries l, l + 64, ... in order; wave tree), and
+// the segment sums are added left to right -- by whichever wave finishes the row's last outstanding segment (an integer
+// ticket elects it; the sums themselves are stored individually and always added in segment order, so the result does
+// not depend on the order in which the waves finish).  One wave per row left a 20,000-entry row to a single wave: the
+// irregular configs[4] stand-in holds 37 % of its entries in 0.1 % of its rows and spent 118 of 180 us there.
+// The oracle's long-row mode mirrors the segments (orc.set_long_row(threshold, segment)).
+constexpr int MIK_LONG_SEG = 2048;
+
+// Tables of the long-row part (device, built at upload).  `rows[w]` >= 0: virtual row w is a whole row, its sum goes to
+// y[rows[w]]; < 0: it is segment -(rows[w] + 1) of a cut row.
+struct LongTab {
+    const int *rows, *starts, *lens;   // per virtual row (whole rows and segments, longest first)
+    const int *seg_row;                // per segment: index h of its cut row
+    const int *cut_row, *cut_first, *cut_nseg;   // per cut row: matrix row, first segment, number of segments
+    unsigned *tickets;                 // per cut row, zero between launches
+    void *seg_sum;                     // per segment, dtype of the operator
+    int nlong, nbig;
+};
+
+template <typename T> __device__ __forceinline__ void longrow_store(const LongTab &lt, int w, T acc, T *__restrict__ y)
+{
+    const int tgt = lt.rows[w];
+    if (tgt >= 0) { y[tgt] = acc; return; }
+    const int sg = -tgt - 1;
+    T *ss = (T *)lt.seg_sum;
+    // Hand-off without cache-wide fences (an acq_rel ticket costs a buffer_wbl2 + buffer_inv per segment: measured 402 us
+    // instead of 196 us for the whole SpMV): the segment sum is ONE write-through (sc1) store, drained before the ticket
+    // is taken; the wave that takes the last ticket reads the sums back with sc1 loads, which are served past its L1.
+    __hip_atomic_store(&ss[sg], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int h = lt.seg_row[sg];
+    const unsigned tk = __hip_atomic_fetch_add(&lt.tickets[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int ns = lt.cut_nseg[h];
+    if (tk == (unsigned)ns - 1u) {
+        const int f = lt.cut_first[h];
+        T t = __hip_atomic_load(&ss[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 1; q < ns; ++q) t = t + __hip_atomic_load(&ss[f + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&lt.tickets[h], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        y[lt.cut_row[h]] = t;
+    }
+}
+
 template <typename T>
-__device__ __forceinline__ void spmv_longrow_wave(int w, const int *__restrict__ rows, const int *__restrict__ starts,
-                                                  const int *__restrict__ lens, const int *__restrict__ col,
+__device__ __forceinline__ void spmv_longrow_wave(int w, const LongTab &lt, const int *__restrict__ col,
                                                   const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y)
 {
     constexpr int U = MIK_LONG_U, CH = MIK_LONG_CH;
     const int lane = threadIdx.x & 63;
-    const int k0 = starts[w], len = lens[w];
+    const int k0 = lt.starts[w], len = lt.lens[w];
     T acc = T(0);
     if (len <= CH) {
         // medium rows: one chunk, every load issued at once (no pipeline prologue / epilogue)
@@ -113,7 +155,7 @@ __device__ __forceinline__ void spmv_longrow_wave(int w, const int *__restrict__
         for (int u = 0; u < U; ++u)
             if (u * 64 + lane < len) { const T prod = v[u] * xv[u]; acc = acc + prod; }
         acc = wave_tree(acc);
-        if (lane == 0) y[rows[w]] = acc;
+        if (lane == 0) longrow_store<T>(lt, w, acc, y);
         return;
     }
     T vA[U], xA[U], vB[U], vC[U];
@@ -144,7 +186,7 @@ __device__ __forceinline__ void spmv_longrow_wave(int w, const int *__restrict__
         for (int u = 0; u < U; ++u) { vA[u] = vB[u]; xA[u] = xB[u]; vB[u] = vC[u]; cB[u] = cC[u]; }
     }
     acc = wave_tree(acc);
-    if (lane == 0) y[rows[w]] = acc;
+    if (lane == 0) longrow_store<T>(lt, w, acc, y);
 }
 
 // A wave takes MIK_LONG_R consecutive rows of the (longest-first) long-row list.  Medium rows (<= 256
@@ -154,15 +196,15 @@ __device__ __forceinline__ void spmv_longrow_wave(int w, const int *__restrict__
 constexpr int MIK_LONG_R = 4;
 
 template <typename T>
-__device__ __forceinline__ void spmv_longrow_group(int wv, int nlong, int nbig, const int *__restrict__ rows,
-                                                   const int *__restrict__ starts, const int *__restrict__ lens,
-                                                   const int *__restrict__ col, const T *__restrict__ val,
+__device__ __forceinline__ void spmv_longrow_group(int wv, const LongTab &lt, const int *__restrict__ col, const T *__restrict__ val,
                                                    const T *__restrict__ x, T *__restrict__ y)
 {
     constexpr int R = MIK_LONG_R, U = 4;
-    // waves [0, nbig): one row each (rows longer than 64*U entries, longest first: their pipelined sums are
-    // the critical path); waves from nbig on: R medium rows each
-    if (wv < nbig) { spmv_longrow_wave<T>(wv, rows, starts, lens, col, val, x, y); return; }
+    const int nlong = lt.nlong, nbig = lt.nbig;
+    const int *__restrict__ starts = lt.starts, *__restrict__ lens = lt.lens;
+    // waves [0, nbig): one virtual row each (more than 64*U entries, longest first: their pipelined sums are
+    // the critical path); waves from nbig on: R medium rows each (never segments: those are longer)
+    if (wv < nbig) { spmv_longrow_wave<T>(wv, lt, col, val, x, y); return; }
     const int w0 = nbig + (wv - nbig) * R;
     if (w0 >= nlong) return;
     const int lane = threadIdx.x & 63;
@@ -194,19 +236,17 @@ __device__ __forceinline__ void spmv_longrow_group(int wv, int nlong, int nbig, 
         for (int u = 0; u < U; ++u)
             if (u * 64 + lane < len[q]) { const T prod = v[q][u] * xv[q][u]; acc = acc + prod; }
         acc = wave_tree(acc);
-        if (lane == 0 && w0 + q < nlong) y[rows[w0 + q]] = acc;
+        if (lane == 0 && w0 + q < nlong) longrow_store<T>(lt, w0 + q, acc, y);     // a cut row's short last segment lands here too
     }
 }
 
 template <typename T>
-__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_longrows(int nlong, int nbig, const int *__restrict__ rows, const int *__restrict__ starts,
-                                                             const int *__restrict__ lens, const int *__restrict__ col,
-                                                             const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y,
-                                                             const int *__restrict__ done)
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_longrows(LongTab lt, const int *__restrict__ col, const T *__restrict__ val,
+                                                             const T *__restrict__ x, T *__restrict__ y, const int *__restrict__ done)
 {
     if (done && *done) return;
     const int wv = blockIdx.x * (MIK_BLOCK / 64) + (threadIdx.x >> 6);     // whole waves work alone: no block-level barrier
-    spmv_longrow_group<T>(wv, nlong, nbig, rows, starts, lens, col, val, x, y);
+    spmv_longrow_group<T>(wv, lt, col, val, x, y);
 }
 
 // MERGE_LONG: the first `nlong_blocks` workgroups of the launch are long-row workgroups (4 rows each,
@@ -216,8 +256,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
                                                              const int *__restrict__ col, const T *__restrict__ val,
                                                              const T *__restrict__ x, T *__restrict__ y,
                                                              T *__restrict__ seg_out, const int *__restrict__ done,
-                                                             const unsigned char *__restrict__ is_long, int nlong, int nbig,
-                                                             int nlb, const int *__restrict__ long_tab)
+                                                             const unsigned char *__restrict__ is_long, int nlb, LongTab lt)
 {
     if (done && *done) return;
     constexpr int TILE = MIK_SPMV_TILE * (int)(8 / sizeof(T));   // 16 KB of LDS: 2048 fp64 / 4096 fp32 products
@@ -230,7 +269,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
     int bid = blockIdx.x;
     if (MERGE_LONG) {
         if (bid < nlb) {
-            spmv_longrow_group<T>(bid * (MIK_BLOCK / 64) + (t >> 6), nlong, nbig, long_tab, long_tab + nlong, long_tab + 2 * nlong, col, val, x, y);
+            spmv_longrow_group<T>(bid * (MIK_BLOCK / 64) + (t >> 6), lt, col, val, x, y);
             return;
         }
         bid -= nlb;

@@ -45,7 +45,9 @@ int orc_set_partition(int nparts, const int64_t *offsets)
 
 /* optional device row-sum shape for long rows (0 = off: every row strictly sequential) */
 static int64_t g_orc_long_row = 0;
+static int64_t g_orc_long_seg = 0;     /* rows longer than this are summed segment by segment (0 = never cut) */
 void orc_set_long_row(int64_t threshold) { g_orc_long_row = threshold > 0 ? threshold : 0; }
+void orc_set_long_segment(int64_t segment) { g_orc_long_seg = segment > 0 ? segment : 0; }
 
 /* ORC_BLAS: entry points of the host's OpenBLAS (CBLAS interface, 32-bit ints), bound by oracle/orc.py from the
  * library NumPy / SciPy ship -- the same library family LinearAlgebra.dot / norm / mul! reach in the reference. */

@@ -1,23 +1,68 @@
-"""BASELINE.json configs[4] stand-in: gmres!(restart=50), fp32, synthetic irregular CSR (n = 1e6, 34 M nnz).
-Development tool (GPU box): SpMV time / GB/s and GMRES time per inner iteration."""
-import os, sys, time
+"""BASELINE.json configs[4] stand-in: gmres!(restart=50), fp32, irregular CSR (n = 1e6, ~34 M nnz, rows from 6 to ~20 k entries).
+
+Development / profiling tool (GPU box).  Two synthetic generators (fixtures.irregular_matrix) -- `random`: columns uniform
+over the matrix (no locality: the worst case for the gather of x) and `banded`: the same rows with columns inside a band
+(the locality an RCM-ordered finite-element matrix such as s3dkq4m2 has) -- plus every *.mtx under $MIK_MTX_DIR
+(benchmark/matrixmarket.jl:5 reads such a file).  Prints row-length statistics, SpMV time / GB/s of the CSR algorithmic
+bytes for both CSR kernels, and GMRES time per inner iteration.
+
+    KINDS=random,banded GMRES=1 python scripts/config5_bench.py
+"""
+import glob
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as g
+
 pkg = g.load_package()
-n = int(os.environ.get("N", 1_000_000))
-t0 = time.time(); n, rowptr, colidx, val = pkg.fixtures.irregular_matrix(n, np.float32, long_rows=os.environ.get("LONG", "1") == "1"); print(f"generated in {time.time()-t0:.1f} s: n {n} nnz {val.size} max row {np.diff(rowptr).max()}")
-A = pkg.HipCSR(n, n, rowptr, colidx, val, index_base=0, is_csc=False)
-b = pkg.HipVector.from_numpy(pkg.fixtures.hashed_rhs(n, dtype=np.float32))
-y = pkg.HipVector(n, np.float32)
-A.time_spmv(b, y, reps=3)          # first launch of a kernel instantiation pays lazy code-object loading
-ms = A.time_spmv(b, y, reps=20)
-msf = A.time_spmv(b, y, reps=3, fused_dot=True); msf = A.time_spmv(b, y, reps=20, fused_dot=True)
-print(f"SpMV fused-dot variant (long rows in their own launch) {msf*1e3:.1f} us")
-print(f"SpMV {ms*1e3:.1f} us  {A.spmv_algorithmic_bytes()/ms/1e6:.0f} GB/s algorithmic ({A.spmv_algorithmic_bytes()/1e6:.0f} MB)")
-for name, M in ((("mgs", pkg.ModifiedGramSchmidt()), ("cgs", pkg.ClassicalGramSchmidt())) if os.environ.get("GMRES", "1") == "1" else ()):
-    pkg.gmres(A, b, restart=50, orth_meth=M, maxiter=60)
-    pkg.default_context().synchronize(); t0 = time.perf_counter()
-    x, ch = pkg.gmres(A, b, restart=50, orth_meth=M, log=True, maxiter=2000)
-    pkg.default_context().synchronize(); dt = time.perf_counter() - t0
-    print(f"gmres fp32 restart=50 {name}: iters {ch.iters} converged {ch.isconverged} {dt*1e3:.1f} ms  {dt/max(ch.iters,1)*1e6:.1f} us/inner-iteration  final rel {ch['resnorm'][-1]/ch['resnorm'][0]:.2e}")
+L = pkg.lib()
+n_req = int(os.environ.get("N", 1_000_000))
+kinds = [k for k in os.environ.get("KINDS", "random,banded").split(",") if k]
+cases = []
+for kind in kinds:
+    t0 = time.time()
+    n, rowptr, colidx, val = pkg.fixtures.irregular_matrix(n_req, np.float32, long_rows=os.environ.get("LONG", "1") == "1",
+                                                           bandwidth=0 if kind == "random" else int(os.environ.get("BAND", 2000)))
+    cases.append((kind, n, rowptr, colidx, val, time.time() - t0))
+for path in sorted(glob.glob(os.path.join(os.environ.get("MIK_MTX_DIR", "/nonexistent"), "*.mtx"))):
+    t0 = time.time()
+    n, colptr, rowval, nzval = pkg.fixtures.read_matrix_market(path)
+    import scipy.sparse as sp
+    S = sp.csc_matrix((nzval, rowval - 1, colptr - 1), shape=(n, n)).tocsr()
+    S.sort_indices()
+    cases.append((os.path.basename(path), n, S.indptr.astype(np.int64), S.indices.astype(np.int64), S.data.astype(np.float32), time.time() - t0))
+
+for kind, n, rowptr, colidx, val, tgen in cases:
+    lens = np.diff(rowptr)
+    rb = np.add.reduceat(lens, np.arange(0, n, 256))
+    print(f"== {kind}: n {n} nnz {val.size} generated/read in {tgen:.1f} s; row length min {lens.min()} median {int(np.median(lens))} "
+          f"mean {lens.mean():.1f} max {lens.max()}; rows > 64: {(lens > 64).sum()}; nnz per 256-row block max/mean {rb.max() / rb.mean():.2f}")
+    b = pkg.HipVector.from_numpy(pkg.fixtures.hashed_rhs(n, dtype=np.float32))
+    y = pkg.HipVector(n, np.float32)
+    for variant, name in ((0, "k_spmv_rowgather (LDS-DMA tile, row gather)"), (1, "k_spmv_rowblock (products)")):
+        L.mik_set_tuning(14, variant)
+        t0 = time.time()
+        A = pkg.HipCSR(n, n, rowptr, colidx, val, index_base=0, is_csc=False)
+        tup = time.time() - t0
+        A.time_spmv(b, y, reps=3)          # first launch of a kernel instantiation pays lazy code-object loading
+        ms = A.time_spmv(b, y, reps=20)
+        A.time_spmv(b, y, reps=3, fused_dot=True)
+        msf = A.time_spmv(b, y, reps=20, fused_dot=True)
+        ab = A.spmv_algorithmic_bytes()
+        print(f"   {name}: layout {A.layout()}  SpMV {ms * 1e3:7.1f} us = {ab / ms / 1e6:6.0f} GB/s of {ab / 1e6:.0f} MB algorithmic "
+              f"({ab / ms / 1e6 / 8000:.3f} of 8 TB/s); with the fused dot {msf * 1e3:7.1f} us; upload {tup:.1f} s")
+        if variant == 0 and os.environ.get("GMRES", "1") == "1":
+            for oname, M in (("mgs", pkg.ModifiedGramSchmidt()), ("cgs", pkg.ClassicalGramSchmidt())):
+                pkg.gmres(A, b, restart=50, orth_meth=M, maxiter=60)
+                pkg.default_context().synchronize()
+                t0 = time.perf_counter()
+                x, ch = pkg.gmres(A, b, restart=50, orth_meth=M, log=True, maxiter=2000)
+                pkg.default_context().synchronize()
+                dt = time.perf_counter() - t0
+                print(f"   gmres fp32 restart=50 {oname}: iters {ch.iters} converged {ch.isconverged} {dt * 1e3:.1f} ms  "
+                      f"{dt / max(ch.iters, 1) * 1e6:.1f} us/inner-iteration  final rel {ch['resnorm'][-1] / ch['resnorm'][0]:.2e}")
+        del A
+    L.mik_set_tuning(14, 0)

@@ -1,0 +1,88 @@
+"""Condense the rocprofv3 output of scripts/prof_r02.sh into small files fit for profiles/:
+   <what>_kernel_stats.csv   (name, calls, total / average / min / max duration in us, percentage)
+   <what>_pmc_summary.txt    (mean counter value per dispatch, per kernel) + derived figures
+   <what>_traffic.json       (HBM-side bytes per launch: 2 * FETCH_SIZE + WRITE_SIZE, KiB counters; gfx950 note in
+                              MI355X_MICROARCH.md: FETCH_SIZE tallies 128-B requests at 64 B)
+
+    python scripts/prof_collect.py gpurun_out/r02
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+root = sys.argv[1]
+summ = os.path.join(root, "summary")
+os.makedirs(summ, exist_ok=True)
+
+
+def short(name):
+    n = name.replace("void ", "").strip()
+    return n.split("(")[0][:110]
+
+
+for d in sorted(glob.glob(os.path.join(root, "*"))):
+    what = os.path.basename(d)
+    if not os.path.isdir(d) or what == "summary":
+        continue
+    # ---- kernel stats ---------------------------------------------------------------------------
+    for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        with open(os.path.join(summ, f"{what}_kernel_stats.csv"), "w") as o:
+            o.write("kernel,calls,total_us,avg_us,min_us,max_us,percent\n")
+            for r in rows:
+                o.write(f"\"{short(r['Name'])}\",{r['Calls']},{float(r['TotalDurationNs']) / 1e3:.1f},{float(r['AverageNs']) / 1e3:.2f},"
+                        f"{float(r['MinNs']) / 1e3:.2f},{float(r['MaxNs']) / 1e3:.2f},{r['Percentage']}\n")
+    for f in glob.glob(os.path.join(d, "*_under_rocprof.*")):
+        open(os.path.join(summ, f"{what}_{os.path.basename(f)}"), "w").write(open(f).read())
+    # ---- counters ---------------------------------------------------------------------------------
+    means = collections.defaultdict(dict)
+    counts = {}
+    for f in sorted(glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for row in csv.DictReader(open(f)):
+            acc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        for k, cs in acc.items():
+            for c, v in cs.items():
+                means[k][c] = sum(v) / len(v)
+                counts[k] = len(v)
+    if not means:
+        continue
+    traffic = {}
+    with open(os.path.join(summ, f"{what}_pmc_summary.txt"), "w") as o:
+        o.write("mean counter value per dispatch (separate rocprofv3 --pmc passes; scripts/prof_r02.sh)\n")
+        for k in sorted(means, key=lambda k: -means[k].get("SQ_WAVE_CYCLES", means[k].get("FETCH_SIZE", 0))):
+            m = means[k]
+            if not any(s in k for s in ("spmv", "k_map", "k_cg", "multidot", "gemv", "k_mgs", "finalize")):
+                continue
+            o.write(f"\n{k}   (dispatches sampled: {counts[k]})\n")
+            for c in sorted(m):
+                o.write(f"    {c:38s} {m[c]:18.1f}\n")
+            der = []
+            if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+                rd, wr = 2.0 * m["FETCH_SIZE"] * 1024.0, m["WRITE_SIZE"] * 1024.0
+                der.append(f"HBM-side traffic per launch: read {rd / 1e9:.4f} GB (2 x FETCH_SIZE) + write {wr / 1e9:.4f} GB = {(rd + wr) / 1e9:.4f} GB")
+                kk = k.split("<")[0]
+                traffic[kk] = {"kernel": k, "fetch_bytes_x2": rd, "write_bytes": wr, "traffic_bytes_per_launch": rd + wr}
+            if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m:
+                der.append(f"L2 hit rate {m['TCC_HIT_sum'] / (m['TCC_HIT_sum'] + m['TCC_MISS_sum']):.3f}")
+                if k.split("<")[0] in traffic:
+                    traffic[k.split("<")[0]]["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
+            if "SQ_WAVE_CYCLES" in m and "SQ_WAIT_ANY" in m:
+                der.append(f"SQ_WAIT_ANY / SQ_WAVE_CYCLES = {m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES']:.3f}; "
+                           f"SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES = {m.get('SQ_ACTIVE_INST_ANY', 0) / m['SQ_WAVE_CYCLES']:.3f}")
+            if "SQ_LDS_BANK_CONFLICT" in m and m.get("SQ_LDS_IDX_ACTIVE"):
+                der.append(f"LDS bank-conflict cycles / LDS active cycles = {m['SQ_LDS_BANK_CONFLICT'] / m['SQ_LDS_IDX_ACTIVE']:.3f}")
+            if "TA_TA_BUSY_sum" in m and "GRBM_GUI_ACTIVE" in m:
+                der.append(f"TA busy (sum over TAs) / (GRBM_GUI_ACTIVE x 256 CUs) = {m['TA_TA_BUSY_sum'] / (m['GRBM_GUI_ACTIVE'] * 256):.3f}")
+            if "TCP_GATE_EN1_sum" in m and "TCP_PENDING_STALL_CYCLES_sum" in m and m["TCP_GATE_EN1_sum"]:
+                der.append(f"TCP pending-stall cycles / TCP active cycles = {m['TCP_PENDING_STALL_CYCLES_sum'] / m['TCP_GATE_EN1_sum']:.3f}")
+            if "TCP_TCC_READ_REQ_sum" in m and m.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+                der.append(f"L1 (TCP) -> L2 read requests / TCP cache accesses = {m['TCP_TCC_READ_REQ_sum'] / m['TCP_TOTAL_CACHE_ACCESSES_sum']:.3f}")
+            for line in der:
+                o.write(f"    => {line}\n")
+    if traffic:
+        json.dump(traffic, open(os.path.join(summ, f"{what}_traffic.json"), "w"), indent=1)
+print("summaries:", sorted(os.listdir(summ)))

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def long_row_shape(orc, ctx):
     """rows longer than mik_spmv_long_row() use the wave-shaped row sum; the oracle's spmv mirrors it"""
-    orc.set_long_row(ctx.spmv_long_row())
+    orc.set_long_row(ctx.spmv_long_row(), ctx.spmv_long_segment())
     yield
     orc.set_long_row(0)
 
@@ -52,3 +52,41 @@ def test_irregular_gmres_fp32_restart50(pkg, orc, ctx):
     S = sp.csr_matrix((val.astype(np.float64), colidx, rowptr), shape=(n, n))
     assert np.linalg.norm(S @ x.to_numpy().astype(np.float64) - b) / np.linalg.norm(b) <= 5e-4      # sqrt(eps_f32) = 3.5e-4
     assert np.all(np.diff(ch["resnorm"]) <= 0)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("segment", [0, 300])
+def test_cut_rows_segment_sums(pkg, orc, ctx, dtype, segment):
+    """rows longer than mik_spmv_long_segment() are cut into segments summed by separate waves; segment sums are added in
+    segment order whatever the order the waves finish in: lengths around the segment boundaries (a last segment of 1 or 4
+    entries, exactly one / two segments), both CSR kernels, repeated launches (the tickets reset themselves)"""
+    L = pkg.lib()
+    L.mik_set_tuning(15, segment)
+    try:
+        seg = ctx.spmv_long_segment()
+        assert seg == (segment or 2048)
+        orc.set_long_row(ctx.spmv_long_row(), seg)
+        rng = np.random.default_rng(9)
+        n = 12000
+        lens = rng.integers(3, 40, size=n)
+        for i, l in enumerate((seg - 1, seg, seg + 1, 2 * seg, 2 * seg + 4, 5 * seg + seg // 2, 65, 64, 256, 257, 10 * seg)):
+            lens[37 + 501 * i] = min(l, n)
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        cols = np.concatenate([np.sort(rng.choice(n, size=l, replace=False)) for l in lens]).astype(np.int64)
+        val = rng.standard_normal(cols.size).astype(dtype)
+        Ao = as_oracle_csc(orc, n, rowptr, cols, val)
+        x = rng.standard_normal(n).astype(dtype)
+        want = orc.spmv(Ao, x)
+        for variant in (0, 1):
+            L.mik_set_tuning(14, variant)
+            A = pkg.HipCSR(n, n, rowptr, cols, val, index_base=0, is_csc=False)
+            dx = pkg.HipVector.from_numpy(x)
+            for _ in range(3):
+                assert np.array_equal((A @ dx).to_numpy(), want), (variant, segment)
+            b = pkg.HipVector.from_numpy(orc.hashed_rhs(n).astype(dtype))
+            xs, ch = pkg.cg(A, b, log=True, maxiter=3)                   # fused-dot launches (matrix not SPD: bits only)
+            xo, ho = orc.cg(Ao, orc.hashed_rhs(n).astype(dtype), maxiter=3, mode="tree", shape=ctx.cg_shape(dtype))
+            assert np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(xs.to_numpy(), xo)
+    finally:
+        L.mik_set_tuning(15, 0)
+        L.mik_set_tuning(14, 0)
