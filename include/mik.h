@@ -111,9 +111,9 @@ int mik_spmv_long_segment(int *segment);
  *   3: 1 = hipStreamSynchronize instead of the event spin wait    4: long-row threshold (> 0), < 0 = no split
  *   5: 1 = unfused MGS chain, 2 = launch-lean MGS without graphs, 3 = one hipGraph per GMRES column
  *   6: 1 = ignore the dictionary-coded form                       7: cache hints of the CG vector kernels
- *   8: 1 = CSR row-block layout only (read at mik_csr_create and at launch)
+ *   8: 1 = CSR row-block layout only (read at mik_csr_create and at launch)    9: 1 = GMRES: no Arnoldi column enqueued ahead of the host
  *  10: 1 = no 8-bit column codes                                  12: 1 = no per-slice-offset layout
- *  13: bit mask switching the Krylov-basis streaming hints off    14: CSR kernel: 0 = LDS-DMA tile + per-row gather, 1 = register-staged products
+ *  13: bit mask switching the Krylov-basis streaming hints off    14: CSR kernel: 0 = by operator, 1 = register-staged products, 2 = LDS-DMA tile + per-row gather
  *  15: long-row segment length (> 0; read at mik_csr_create) */
 int mik_set_tuning(int key, int value);
 
@@ -223,6 +223,9 @@ int mik_gmres_create(mik_ctx *ctx, const mik_csr *A, void *x, const void *b, con
 int mik_gmres_destroy(mik_gmres *it);
 /* iterate(g, iteration) -- src/gmres.jl:57-106 */
 int mik_gmres_iterate(mik_gmres *it, int64_t iteration, double *residual, int *done);
+/* Up to max_steps consecutive iterate() calls in one entry (the loop of gmres!, src/gmres.jl:207-214): residuals[j] =
+ * residual.current after step j; *steps_done < max_steps iff done(g, iteration + *steps_done). */
+int mik_gmres_iterate_many(mik_gmres *it, int64_t iteration, int64_t max_steps, double *residuals, int64_t *steps_done);
 /* fields read by gmres! (src/gmres.jl:210,218): mv_products, residual.current, tol, k, beta */
 int mik_gmres_state(const mik_gmres *it, double *residual, double *tol, double *beta, int *k,
                     int64_t *mv_products, int *converged);

@@ -111,6 +111,7 @@ SIGNATURES = {
                                                C.c_int, C.POINTER(MikPartition), C.POINTER(_vp)]),
     "mik_gmres_destroy": (C.c_int, [_vp]),
     "mik_gmres_iterate": (C.c_int, [_vp, _i64, _f64p, _ip]),
+    "mik_gmres_iterate_many": (C.c_int, [_vp, _i64, _i64, _f64p, _i64p]),
     "mik_gmres_state": (C.c_int, [_vp, _f64p, _f64p, _f64p, _ip, _i64p, _ip]),
     "mik_axpy_dot": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "mik_axpy2_nrm2": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),

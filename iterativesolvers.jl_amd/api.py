@@ -897,6 +897,16 @@ class GMRESIterable:
         self._refresh()
         return self.residual_current, iteration + 1
 
+    def iterate_many(self, iteration: int, max_steps: int) -> np.ndarray:
+        """Up to ``max_steps`` ``iterate`` calls inside the library (``mik_gmres_iterate_many``); returns the residuals."""
+        out = np.empty(max(int(max_steps), 1), np.float64)
+        nd = C.c_int64()
+        code = lib().mik_gmres_iterate_many(self.handle, int(iteration), int(max_steps), out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(nd))
+        b = getattr(self, "_bound", None)
+        b.check(code, "mik_gmres_iterate_many") if b is not None else check(code, "mik_gmres_iterate_many", self.A.ctx.handle)
+        self._refresh()
+        return out[: nd.value].copy()
+
     def __iter__(self):
         iteration = 0
         while True:

@@ -767,6 +767,11 @@ static int spmv_kernel_choice(const mik_csr *A)
     return 0;
 }
 
+static inline bool spmv_csr_rowgather(const mik_csr *A)
+{
+    return g_mik_tuning[14] == 2 || (g_mik_tuning[14] == 0 && A->n_long == 0);
+}
+
 // Can mik_spmv_launch_range serve a sub-range of row-blocks for this operator?  The sliced-ELL kernels and the default
 // CSR kernel take a first row-block; the dictionary-coded kernel, k_spmv_rowblock (tuning[14] = 1) and operators with
 // split-off long rows (their wave-per-row launch covers the whole matrix) do not.
@@ -774,7 +779,7 @@ bool mik_spmv_can_split(const mik_csr *A)
 {
     const int kc = spmv_kernel_choice(A);
     if (kc == 3) return false;
-    if (kc == 0) return g_mik_tuning[14] != 1 && A->n_long == 0;
+    if (kc == 0) return spmv_csr_rowgather(A) && A->n_long == 0;
     return true;
 }
 
@@ -863,9 +868,11 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
     }
     const int nwaves_long = nbig + (nlong - nbig + MIK_LONG_R - 1) / MIK_LONG_R;   // one wave per big row, MIK_LONG_R medium rows per wave
     const int nlb = (nwaves_long + 3) / 4;
-    // CSR kernels.  tuning[14]: 0 = row-block tile filled by LDS-DMA with the per-row gather (k_spmv_rowgather, default),
-    // 1 = products staged through registers (k_spmv_rowblock).  Same results bit for bit (tests/test_gpu_layouts.py).
-    if (g_mik_tuning[14] != 1) {
+    // CSR kernels.  k_spmv_rowgather (row-block tile filled by LDS-DMA, per-row gather) unless the operator has split-off
+    // long rows: then k_spmv_rowblock, whose launch carries the long-row workgroups along (one launch instead of two:
+    // 180 vs 196 us on the random configs[4] stand-in, 107 vs 121 us on the banded one).  tuning[14]: 0 = that rule,
+    // 1 = always k_spmv_rowblock, 2 = always k_spmv_rowgather.  Same results bit for bit (tests/test_gpu_layouts.py).
+    if (spmv_csr_rowgather(A)) {
         if (nlong) {   // long rows first (whole launches only, see mik_spmv_can_split); the row kernel then picks y[r] up
             hipLaunchKernelGGL((k_spmv_longrows<T>), dim3(nlb), dim3(MIK_BLOCK), 0, ctx->stream, lt, A->col, (const T *)A->val, x, y, done);
             MIK_LAUNCH_CHECK(ctx);

@@ -568,6 +568,174 @@ template <typename T, bool SELF> struct OpMgsPass {
 };
 
 // =============================================================================================
+// Modified Gram-Schmidt as ONE launch (n up to 256 reduction segments: the launch-latency-bound sizes)
+// =============================================================================================
+// orthogonalize_and_normalize!(V[:, 1:k], w, h, ModifiedGramSchmidt()) -- src/orthogonalize.jl:67-79 -- is a chain of
+// k + 1 grid-wide reductions (h_i = dot(v_i, w) needs the w of pass i - 1; then norm(w)).  As k + 2 launches each link
+// costs a dependent kernel boundary plus a sweep (3.7-4.3 us at n = 125 k).  Here one workgroup per reduction segment
+// keeps its 256*W*L elements of w in REGISTERS across all passes and the links are hand-offs through memory:
+//   * a workgroup publishes its segment sum of pass i with one write-through (sc1) store into slot P[i][wg];
+//   * every workgroup then reads ALL slots of pass i (one per thread, sc1 loads that are served past L1) until none
+//     of them holds the "not yet written" pattern any more, and folds them with the same level-2 tree as everywhere else
+//     (virtual thread vt = 0 + S[vt]; wave tree per 64; the 16 wave sums left to right) -- so every workgroup obtains
+//     bit-identical h_i, and the values equal those of the multi-launch chain.
+// No counter, no fence: the slot itself is the flag.  "Not yet written" = all bits set (a NaN no arithmetic produces);
+// the slots of the other buffer are re-armed by their owners for the next launch (two buffers alternate, the kernel
+// boundary in between orders re-arming against use).  Polling is bounded: a workgroup that never sees a slot filled
+// (it cannot happen while all <= 256 workgroups are resident, which one workgroup per CU guarantees) raises `err` in
+// the mirror instead of hanging the GPU.  v_{i+1} is loaded before the poll, so its latency hides behind the hand-off.
+#ifndef MIK_MGS_SLEEP
+#define MIK_MGS_SLEEP 0
+#endif
+template <typename T> struct MgsBits;
+template <> struct MgsBits<double> { using U = unsigned long long; static constexpr U EMPTY = ~0ull; };
+template <> struct MgsBits<float>  { using U = unsigned int;       static constexpr U EMPTY = ~0u; };
+
+struct MgsMirror {             // host-mapped; h[] follows (restart + 2 scalars of the handle's dtype)
+    unsigned long long seq;
+    int err, pad;
+};
+
+template <typename T>
+__device__ __forceinline__ T mgs_grid_sum(const T *__restrict__ slots, int m, T *lds16, int *err)
+{
+    using U = typename MgsBits<T>::U;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    T v = T(0);
+    if (t < m) {
+        U bits = MgsBits<T>::EMPTY;
+        for (int spin = 0; spin < (1 << 18); ++spin) {
+            bits = __hip_atomic_load(reinterpret_cast<const U *>(slots) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (bits != MgsBits<T>::EMPTY) break;
+            if (MIK_MGS_SLEEP) __builtin_amdgcn_s_sleep(1);
+        }
+        if (bits == MgsBits<T>::EMPTY) *err = 1;          // timed out: never hang the device
+        T val;
+        __builtin_memcpy(&val, &bits, sizeof(T));
+        v = v + val;                                       // 0 + S[vt], as block_level2_256
+    }
+    v = wave_tree(v);
+    if (lane == 0) lds16[w] = v;
+    if (t >= 4 && t < 16) lds16[t] = T(0);                 // virtual threads 256..1023 hold +0
+    __syncthreads();
+    T tot = lds16[0];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) tot = tot + lds16[q];
+    __syncthreads();
+    return tot;
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(MIK_BLOCK) void k_mgs_fused(int64_t n, int k, const T *__restrict__ V, int64_t ldv, T *__restrict__ w,
+                                                         T *__restrict__ P /* [2][kmax + 1][256] */, int kmax, int parity,
+                                                         MgsMirror *mirror, unsigned long long seq)
+{
+    using U = typename MgsBits<T>::U;
+    constexpr int W = VT<T>::W, L = MIK_RED_L;
+    constexpr int64_t SEG = (int64_t)MIK_BLOCK * W * L;
+    __shared__ T lds16[16];
+    __shared__ T lds4[4];
+    __shared__ int s_err;
+    const int t = threadIdx.x, s = blockIdx.x, m = gridDim.x;
+    if (t == 0) s_err = 0;
+    T *cur = P + (size_t)parity * (size_t)(kmax + 1) * 256;
+    T *oth = P + (size_t)(parity ^ 1) * (size_t)(kmax + 1) * 256;
+    if (t <= kmax) __hip_atomic_store(reinterpret_cast<U *>(oth + (size_t)t * 256) + s, MgsBits<T>::EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int64_t base = (int64_t)s * SEG + (int64_t)W * t;
+    // this thread's elements of w and of the column in flight: i0[l] .. i0[l] + W - 1, valid where < n
+    T wr[L][W], zr[L][W], vr[L][W];
+    auto load = [&](const T *__restrict__ p, T(&dst)[L][W]) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int64_t i = base + (int64_t)l * MIK_BLOCK * W;
+            if (VEC && i + W <= n) {
+                auto v = vload(p + i);
+#pragma unroll
+                for (int e = 0; e < W; ++e) dst[l][e] = el<T>(v, e);
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; ++e) dst[l][e] = (i + e < n) ? p[i + e] : T(0);
+            }
+        }
+    };
+    auto publish = [&](int pass, T acc) {
+        T tot = block_tree_256(acc, lds4);
+        if (t == 0) {
+            U bits;
+            __builtin_memcpy(&bits, &tot, sizeof(T));
+            __hip_atomic_store(reinterpret_cast<U *>(cur + (size_t)pass * 256) + s, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    load(w, wr);
+    T *hout = reinterpret_cast<T *>(mirror + 1);
+    T acc = T(0);
+    if (k > 0) {
+        load(V, zr);
+        // dot(v_1, w)                                                    src/orthogonalize.jl:71 (i = 1)
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int e = 0; e < W; ++e)
+                if (base + (int64_t)l * MIK_BLOCK * W + e < n) { T p = zr[l][e] * wr[l][e]; acc = acc + p; }
+    } else {
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int e = 0; e < W; ++e)
+                if (base + (int64_t)l * MIK_BLOCK * W + e < n) { T p = wr[l][e] * wr[l][e]; acc = acc + p; }
+    }
+    publish(0, acc);
+    for (int i = 0; i < k; ++i) {
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int e = 0; e < W; ++e) vr[l][e] = zr[l][e];              // v_i: subtracted in this pass
+        const bool last = i + 1 == k;
+        if (!last) load(V + (int64_t)(i + 1) * ldv, zr);                   // v_{i+1}: in flight during the hand-off
+        const T h = mgs_grid_sum<T>(cur + (size_t)i * 256, m, lds16, &s_err);
+        if (s == 0 && t == 0) hout[i] = h;
+        acc = T(0);
+        // w .-= h[i] .* v_i; then dot(v_{i+1}, w) or norm(w)^2            :72, :71 / :75 -- per 16-byte group: all W
+        // elements updated, then their products added in element order (the order of OpMgsPass::compute_vec)
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int64_t i0 = base + (int64_t)l * MIK_BLOCK * W;
+#pragma unroll
+            for (int e = 0; e < W; ++e)
+                if (i0 + e < n) { T tt = h * vr[l][e]; wr[l][e] = wr[l][e] - tt; }
+#pragma unroll
+            for (int e = 0; e < W; ++e)
+                if (i0 + e < n) { T p = (last ? wr[l][e] : zr[l][e]) * wr[l][e]; acc = acc + p; }
+        }
+        publish(i + 1, acc);
+    }
+    const T ss = mgs_grid_sum<T>(cur + (size_t)k * 256, m, lds16, &s_err);
+    T nrm = mik_sqrt(ss);
+    const bool ok = mik_nrm_in_range(ss);          // outside the safe range: leave w unscaled, the host rescales
+    const T inv = ok ? T(1) / nrm : T(1);
+    if (!ok) nrm = __builtin_nan("");
+#pragma unroll
+    for (int l = 0; l < L; ++l) {                  // w .*= inv(nrm)                                :76
+        const int64_t i0 = base + (int64_t)l * MIK_BLOCK * W;
+        if (VEC && i0 + W <= n) {
+            typename VT<T>::vec o;
+#pragma unroll
+            for (int e = 0; e < W; ++e) el<T>(o, e) = wr[l][e] * inv;
+            vstore(w + i0, o);
+        } else {
+#pragma unroll
+            for (int e = 0; e < W; ++e)
+                if (i0 + e < n) w[i0 + e] = wr[l][e] * inv;
+        }
+    }
+    if (t == 0 && s_err) __hip_atomic_store(&mirror->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (s == 0 && t == 0) {
+        hout[k] = nrm;
+        __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// =============================================================================================
 // level-2 finalise kernels (one 1024-thread workgroup per reduced column)
 // =============================================================================================
 

@@ -865,6 +865,13 @@ struct mik_gmres {
     std::vector<hipGraphExec_t> graphs;       // index k = 1..restart
     const void *graph_partials = nullptr;     // ctx->partials the graphs were captured against
     bool graph_off = false;                   // capture / instantiation failed once: plain stream launches from then on
+    // single-launch Modified Gram-Schmidt (k_mgs_fused): slot buffers [2][restart + 1][256] and the host-mapped mirror of (h, nrm)
+    void *mgs_P = nullptr;
+    MgsMirror *mgs_mirror = nullptr;          // two mirrors (bytes apart: mgs_mirror_stride), used alternately
+    size_t mgs_mirror_stride = 0;
+    unsigned long long mgs_seq = 0, mgs_slot_seq[2] = {0, 0};
+    int mgs_parity = 0;
+    int pre_k = 0, pre_slot = 0;              // Arnoldi column already enqueued ahead of the host (0 = none) and its mirror
 };
 
 template <typename T> static int gather_launch(mik_ctx *ctx, int64_t m, const int *idx, const T *x, T *out, const int *done);
@@ -1114,6 +1121,19 @@ static int gmres_create_common(mik_ctx *ctx, const mik_csr *A, void *x, const vo
         mik_gmres_destroy(g);
         return mik_fail(ctx, MIK_ERR_NOMEM, "mik_gmres_create: hipMalloc of the Krylov basis (%lld x %d): %s", (long long)n, restart + 1, hipGetErrorString(e));
     }
+    {
+        const int64_t nseg = dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
+        if (!part && orth_method == MIK_MGS && nseg >= 1 && nseg <= 256) {
+            const size_t pbytes = es * 2 * (size_t)(restart + 1) * 256;
+            if ((e = hipMalloc(&g->mgs_P, pbytes)) != hipSuccess || (e = hipMemsetAsync(g->mgs_P, 0xFF, pbytes, ctx->stream)) != hipSuccess ||
+                (g->mgs_mirror_stride = (sizeof(MgsMirror) + es * (size_t)(restart + 2) + 255) / 256 * 256, false) ||
+                (e = hipHostMalloc((void **)&g->mgs_mirror, 2 * g->mgs_mirror_stride, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) {
+                mik_gmres_destroy(g);
+                return mik_fail(ctx, MIK_ERR_NOMEM, "mik_gmres_create: single-launch Gram-Schmidt buffers: %s", hipGetErrorString(e));
+            }
+            memset(g->mgs_mirror, 0, 2 * g->mgs_mirror_stride);
+        }
+    }
     if ((e = hipMemsetAsync(g->V, 0, es * (size_t)g->ldv * (size_t)(restart + 1), ctx->stream)) != hipSuccess) {   // zeros(T, n, m+1) :13
         mik_gmres_destroy(g);
         return mik_fail(ctx, MIK_ERR_HIP, "mik_gmres_create: memset: %s", hipGetErrorString(e));
@@ -1162,6 +1182,8 @@ extern "C" int mik_gmres_destroy(mik_gmres *g)
     if (!g) return MIK_OK;
     if (g->ctx) (void)hipStreamSynchronize(g->ctx->stream);
     gm_drop_graphs(g);
+    if (g->mgs_P) (void)hipFree(g->mgs_P);
+    if (g->mgs_mirror) (void)hipHostFree(g->mgs_mirror);
     if (g->V) (void)hipFree(g->V);
     if (g->Ax) (void)hipFree(g->Ax);
     delete g;
@@ -1237,6 +1259,68 @@ template <typename T> static int gm_step_graph(mik_gmres *g, int k, T *vk, T *vk
     return MIK_OK;
 }
 
+// orthogonalize_and_normalize! with ModifiedGramSchmidt as ONE launch (k_mgs_fused) + one poll of a host-mapped mirror:
+// n up to 256 reduction segments, where the k + 2 launches of the chain are pure dependent-launch latency.
+// Split into "enqueue" (expand! + the kernel for Arnoldi column k) and "wait" (poll + read h, nrm), so that the column
+// AFTER the current one can be put on the stream before the host has seen the current result: its inputs are all on the
+// device, only "did the solve just converge?" is not known yet -- then the extra column is simply never read.
+static inline MgsMirror *gm_mirror(mik_gmres *g, int slot) { return (MgsMirror *)((unsigned char *)g->mgs_mirror + (size_t)slot * g->mgs_mirror_stride); }
+
+template <typename T> static int gm_expand(mik_gmres *g, T *vk, T *vk1);
+
+template <typename T> static int gm_fused_enqueue(mik_gmres *g, int k, int slot)
+{
+    mik_ctx *ctx = g->ctx;
+    const int64_t n = g->n;
+    const int m = (int)mik_nseg<T>(n);
+    T *V = (T *)g->V;
+    T *vk = V + (int64_t)(k - 1) * g->ldv, *w = V + (int64_t)k * g->ldv;
+    MIK_TRY(gm_expand<T>(g, vk, w));
+    const bool vec = mik_aligned16(V) && mik_aligned16(w) && (g->ldv % VT<T>::W == 0);
+    g->mgs_seq += 1;
+    g->mgs_slot_seq[slot] = g->mgs_seq;
+    if (vec) hipLaunchKernelGGL((k_mgs_fused<T, true>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart,
+                                g->mgs_parity, gm_mirror(g, slot), g->mgs_seq);
+    else hipLaunchKernelGGL((k_mgs_fused<T, false>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart,
+                            g->mgs_parity, gm_mirror(g, slot), g->mgs_seq);
+    MIK_LAUNCH_CHECK(ctx);
+    g->mgs_parity ^= 1;
+    return MIK_OK;
+}
+
+template <typename T> static int gm_fused_wait(mik_gmres *g, int k, int slot, T *h_out, T *nrm_out, bool *rescaled)
+{
+    mik_ctx *ctx = g->ctx;
+    MgsMirror *mir = gm_mirror(g, slot);
+    const unsigned long long want = g->mgs_slot_seq[slot];
+    volatile unsigned long long *p = &mir->seq;
+    for (unsigned long long spins = 0;; ++spins) {
+        if (__atomic_load_n((const unsigned long long *)p, __ATOMIC_ACQUIRE) == want) break;
+        if ((spins & 0xFFFFF) == 0xFFFFF) {
+            hipError_t e = hipStreamQuery(ctx->stream);
+            if (e == hipSuccess) {
+                if (__atomic_load_n((const unsigned long long *)p, __ATOMIC_ACQUIRE) == want) break;
+                return mik_fail(ctx, MIK_ERR_HIP, "gmres: stream idle but the Gram-Schmidt step %llu was never published", want);
+            }
+            if (e != hipErrorNotReady) return mik_fail(ctx, MIK_ERR_HIP, "gmres: %s while waiting for the Gram-Schmidt step", hipGetErrorString(e));
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    if (mir->err) return mik_fail(ctx, MIK_ERR_HIP, "gmres: the single-launch Gram-Schmidt timed out waiting for a workgroup (not all resident?)");
+    const T *out = reinterpret_cast<const T *>(mir + 1);
+    for (int j = 0; j < k; ++j) h_out[j] = out[j];
+    *nrm_out = out[k];
+    *rescaled = false;
+    if (out[k] != out[k]) {                     // sum of squares outside the safe range: the kernel left w unscaled
+        T *w = (T *)g->V + (int64_t)k * g->ldv;
+        MIK_TRY(orth_rescale<T>(ctx, g->n, w, nrm_out));
+        *rescaled = true;
+    }
+    return MIK_OK;
+}
+
 // iterate(g::GMRESIterable, iteration)                                   src/gmres.jl:57-106
 template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iteration, double *residual, int *done)
 {
@@ -1260,9 +1344,23 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
     if (g_mik_tuning[5] == 3 && !g->dist && !g->graph_off && g->method != MIK_DGKS && mik_nseg<T>(g->n) <= 1024 && !g->op_mul && !g->pl_fn && !g->pr_fn)
         MIK_TRY(gm_step_graph<T>(g, k, vk, vk1, &Hat(0, k - 1), &nrm, &ran));
     if (!ran) {
-        MIK_TRY(gm_expand<T>(g, vk, vk1));
-        if (g->dist) MIK_TRY(orthogonalize_part<T>(g, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));
-        else MIK_TRY(orthogonalize_impl<T>(ctx, g->n, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));
+        if (g->mgs_P && !g->dist && g_mik_tuning[5] == 0) {                // tuning[5]: 1 / 2 = the multi-launch chains
+            // single-launch Gram-Schmidt, one column ahead of the host: column k is on the stream already if the previous
+            // call put it there; column k + 1 goes on the stream BEFORE this call waits for column k (never across a restart,
+            // never with host callbacks in expand!, whose call count the caller may observe)
+            const int slot = g->pre_k == k ? g->pre_slot : 0;
+            if (g->pre_k != k) MIK_TRY(gm_fused_enqueue<T>(g, k, slot));
+            g->pre_k = 0;
+            const bool ahead = k < m && iteration + 1 < g->maxiter && !g->op_mul && !g->pl_fn && !g->pr_fn && g_mik_tuning[9] == 0;
+            if (ahead) MIK_TRY(gm_fused_enqueue<T>(g, k + 1, slot ^ 1));
+            bool rescaled = false;
+            MIK_TRY(gm_fused_wait<T>(g, k, slot, &Hat(0, k - 1), &nrm, &rescaled));
+            if (ahead && !rescaled) { g->pre_k = k + 1; g->pre_slot = slot ^ 1; }    // rescaled: column k + 1 was built on an unscaled w
+        } else {
+            MIK_TRY(gm_expand<T>(g, vk, vk1));
+            if (g->dist) MIK_TRY(orthogonalize_part<T>(g, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));
+            else MIK_TRY(orthogonalize_impl<T>(ctx, g->n, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));
+        }
     }
     g->mv_products += 1;                                                  // :65
     Hat(k, k - 1) = nrm;
@@ -1304,6 +1402,7 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
             MIK_TRY(gemv_n_dev<T>(ctx, g->n, k - 1, V, g->ldv, (const T *)ctx->coef, T(1), (T *)g->x));
         }
         k = 1;                                                            // :90
+        g->pre_k = 0;                                                     // a column enqueued ahead belongs to the cycle that just ended
         if (!is_done(iteration)) {                                        // :93
             T beta;
             MIK_TRY(gmres_init_residual<T>(g, 0, &beta));                 // :96
@@ -1323,6 +1422,25 @@ extern "C" int mik_gmres_iterate(mik_gmres *g, int64_t iteration, double *residu
     if (!g || !done || iteration < 0) return MIK_ERR_INVALID;
     return g->dtype == MIK_F64 ? gmres_iterate_impl<double>(g, iteration, residual, done)
                                : gmres_iterate_impl<float>(g, iteration, residual, done);
+}
+
+// Up to max_steps consecutive iterate() calls inside the library: the loop of gmres! (src/gmres.jl:207-214) without a
+// trip through the host language per inner iteration (each step still waits once for its Hessenberg column).
+extern "C" int mik_gmres_iterate_many(mik_gmres *g, int64_t iteration, int64_t max_steps, double *residuals, int64_t *steps_done)
+{
+    if (!g || !steps_done || iteration < 0) return MIK_ERR_INVALID;
+    *steps_done = 0;
+    for (int64_t j = 0; j < max_steps; ++j) {
+        double res = 0;
+        int done = 0;
+        int rc = g->dtype == MIK_F64 ? gmres_iterate_impl<double>(g, iteration + j, &res, &done)
+                                     : gmres_iterate_impl<float>(g, iteration + j, &res, &done);
+        if (rc) return rc;
+        if (done) break;
+        if (residuals) residuals[j] = res;
+        *steps_done = j + 1;
+    }
+    return MIK_OK;
 }
 
 extern "C" int mik_gmres_state(const mik_gmres *g, double *residual, double *tol, double *beta, int *k, int64_t *mv_products,

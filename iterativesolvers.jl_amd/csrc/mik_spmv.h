@@ -92,8 +92,10 @@ constexpr int MIK_LONG_CH = 64 * MIK_LONG_U;           // 512-entry chunks
 // summed by its own wave with the shape above (lane l: the segment's entries l, l + 64, ... in order; wave tree), and
 // the segment sums are added left to right -- by whichever wave finishes the row's last outstanding segment (an integer
 // ticket elects it; the sums themselves are stored individually and always added in segment order, so the result does
-// not depend on the order in which the waves finish).  One wave per row left a 20,000-entry row to a single wave: the
-// irregular configs[4] stand-in holds 37 % of its entries in 0.1 % of its rows and spent 118 of 180 us there.
+// not depend on the order in which the waves finish).  A guard against pathological rows: one wave per row makes a dense
+// row of 10^6 entries a single serial chain of ~2000 chunks (milliseconds).  On the irregular configs[4] stand-in (rows up
+// to 20 k entries) cutting changes nothing -- 196 us uncut, 198 us cut: that SpMV is bound by its 34 M random gathers of x
+// (profiles/r02_c5_*), not by the length of any chain.
 // The oracle's long-row mode mirrors the segments (orc.set_long_row(threshold, segment)).
 constexpr int MIK_LONG_SEG = 2048;
 

@@ -42,7 +42,7 @@ for kind, n, rowptr, colidx, val, tgen in cases:
           f"mean {lens.mean():.1f} max {lens.max()}; rows > 64: {(lens > 64).sum()}; nnz per 256-row block max/mean {rb.max() / rb.mean():.2f}")
     b = pkg.HipVector.from_numpy(pkg.fixtures.hashed_rhs(n, dtype=np.float32))
     y = pkg.HipVector(n, np.float32)
-    for variant, name in ((0, "k_spmv_rowgather (LDS-DMA tile, row gather)"), (1, "k_spmv_rowblock (products)")):
+    for variant, name in ((2, "k_spmv_rowgather (LDS-DMA tile, row gather) + k_spmv_longrows"), (1, "k_spmv_rowblock (products, long rows merged)")):
         L.mik_set_tuning(14, variant)
         t0 = time.time()
         A = pkg.HipCSR(n, n, rowptr, colidx, val, index_base=0, is_csc=False)
@@ -54,7 +54,7 @@ for kind, n, rowptr, colidx, val, tgen in cases:
         ab = A.spmv_algorithmic_bytes()
         print(f"   {name}: layout {A.layout()}  SpMV {ms * 1e3:7.1f} us = {ab / ms / 1e6:6.0f} GB/s of {ab / 1e6:.0f} MB algorithmic "
               f"({ab / ms / 1e6 / 8000:.3f} of 8 TB/s); with the fused dot {msf * 1e3:7.1f} us; upload {tup:.1f} s")
-        if variant == 0 and os.environ.get("GMRES", "1") == "1":
+        if variant == 1 and os.environ.get("GMRES", "1") == "1":
             for oname, M in (("mgs", pkg.ModifiedGramSchmidt()), ("cgs", pkg.ClassicalGramSchmidt())):
                 pkg.gmres(A, b, restart=50, orth_meth=M, maxiter=60)
                 pkg.default_context().synchronize()

@@ -16,8 +16,16 @@ for name, M in (("mgs", pkg.ModifiedGramSchmidt()), ("cgs", pkg.ClassicalGramSch
     x, ch = pkg.gmres(A, db, restart=restart, orth_meth=M, log=True)
     pkg.default_context().synchronize()
     dt = time.perf_counter() - t0
-    r = b - (A @ x).to_numpy() if False else None
-    print(f"{name}: iters {ch.iters} mvps {ch.mvps} converged {ch.isconverged}  {dt*1e3:8.1f} ms total  {dt/ch.iters*1e6:8.1f} us/inner-iteration  final {ch['resnorm'][-1]:.3e}")
+    # the same solve with the inner loop inside the library (mik_gmres_iterate_many): what a compiled host pays
+    it = pkg.gmres_iterable_(pkg.zerox(A, db), A, db, restart=restart, orth_meth=M, initially_zero=True)
+    pkg.default_context().synchronize()
+    t1 = time.perf_counter()
+    hist = it.iterate_many(0, 10 ** 6)
+    pkg.default_context().synchronize()
+    dt2 = time.perf_counter() - t1
+    same = np.array_equal(hist, ch["resnorm"])
+    print(f"{name}: iters {ch.iters} mvps {ch.mvps} converged {ch.isconverged}  {dt*1e3:8.1f} ms total  {dt/ch.iters*1e6:8.1f} us/inner-iteration "
+          f"(Python loop)  {dt2/max(hist.size,1)*1e6:8.1f} us/inner-iteration (loop inside libmik, same history: {same})  final {ch['resnorm'][-1]:.3e}")
 if os.environ.get("CPU", "1") == "1":
     orc = g.load_oracle()
     Ao = orc.CSC(n, colptr, rowval, nzval, 1)
