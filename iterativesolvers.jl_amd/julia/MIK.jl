@@ -15,7 +15,8 @@
 #       -> method gmres_iterable!(x::HipVector, A::HipCSR, b::HipVector; ...) returns a
 #          HipGMRESIterable (needed because ArnoldiDecomp pins V to a host Matrix, src/gmres.jl:7,13).
 #   Generic code paths (any other solver of the package) see HipVector/HipCSR through
-#   mul!, dot, norm, axpy!, axpby!, rmul!, copyto!, fill!, similar, zero.
+#   mul!, dot, norm, axpy!, rmul!, ldiv!, copyto!, fill!, similar, zero and the broadcast style below (the four
+#   vector-update shapes of src/cg.jl), so the unmodified iterate(::CGIterable) runs on device vectors as well.
 module MIK
 
 using LinearAlgebra
@@ -49,10 +50,17 @@ mutable struct Context
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:mik_ctx_create, libmik), Cint, (Cint, Ref{Ptr{Cvoid}}), device, h), "mik_ctx_create")
         ctx = new(h[])
-        finalizer(c -> ccall((:mik_ctx_destroy, libmik), Cint, (Ptr{Cvoid},), c.handle), ctx)
+        # Julia gives no finalizer order at exit: the context marks itself dead (handle = C_NULL) and every child's
+        # finalizer checks `alive(ctx)` first -- a child outliving its context leaks device memory of a dying process
+        # instead of handing mik_free a context that no longer exists.
+        finalizer(ctx) do c
+            c.handle == C_NULL || ccall((:mik_ctx_destroy, libmik), Cint, (Ptr{Cvoid},), c.handle)
+            c.handle = C_NULL
+        end
         ctx
     end
 end
+alive(c::Context) = c.handle != C_NULL
 const default_ctx = Ref{Union{Nothing, Context}}(nothing)
 context() = (default_ctx[] === nothing && (default_ctx[] = Context(0)); default_ctx[]::Context)
 
@@ -65,9 +73,11 @@ mutable struct HipVector{T<:MikFloat} <: AbstractVector{T}
         p = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:mik_malloc, libmik), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), ctx.handle, n * sizeof(T), p), "mik_malloc", ctx.handle)
         v = new{T}(p[], n, ctx)
-        finalizer(x -> ccall((:mik_free, libmik), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), x.ctx.handle, x.ptr), v)
+        finalizer(x -> alive(x.ctx) && ccall((:mik_free, libmik), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), x.ctx.handle, x.ptr), v)
         v
     end
+    # a view of device memory owned by somebody else (no finalizer): what the operator / preconditioner callbacks receive
+    HipVector{T}(ptr::Ptr{Cvoid}, n::Integer, ctx::Context, ::Val{:unowned}) where {T<:MikFloat} = new{T}(ptr, n, ctx)
 end
 function HipVector(a::Vector{T}, ctx::Context = context()) where {T<:MikFloat}
     v = HipVector{T}(undef, length(a), ctx)
@@ -86,7 +96,19 @@ function Base.Array(v::HipVector{T}) where {T}
                                v.ctx.handle, pointer(a), v.ptr, sizeof(a)), "mik_memcpy_d2h", v.ctx.handle)
     a
 end
-Base.getindex(v::HipVector, i::Int) = Array(v)[i]        # debugging / show only: one D2H copy per call
+# Scalar indexing would copy the WHOLE vector device-to-host per element (134 MB at 256^3): any generic AbstractVector
+# fallback that reaches it -- show, a missed broadcast, a generic dot -- must fail loudly instead of crawling.
+const scalar_indexing_allowed = Ref(false)
+"allowscalar(true) permits v[i] (one full device-to-host copy per call) for debugging at the REPL."
+allowscalar(flag::Bool) = (scalar_indexing_allowed[] = flag)
+function Base.getindex(v::HipVector, i::Int)
+    scalar_indexing_allowed[] || error("scalar indexing of a HipVector is disabled (it copies the whole vector per element); ",
+                                       "use Array(v), or MIK.allowscalar(true) at the REPL")
+    Array(v)[i]
+end
+Base.setindex!(v::HipVector, x, i::Int) = error("setindex! on a HipVector is not supported; build a Vector and upload it with HipVector(a)")
+Base.show(io::IO, v::HipVector{T}) where {T} = print(io, "HipVector{", T, "}(n = ", v.n, ") on device memory")
+Base.show(io::IO, ::MIME"text/plain", v::HipVector) = show(io, v)
 function Base.fill!(v::HipVector{T}, val) where {T}
     check(ccall((:mik_fill, libmik), Cint, (Ptr{Cvoid}, Cint, Int64, Ref{T}, Ptr{Cvoid}), v.ctx.handle, dtype_code(T), v.n, T(val), v.ptr), "mik_fill", v.ctx.handle)
     v
@@ -118,6 +140,43 @@ function LinearAlgebra.rmul!(x::HipVector{T}, a::Number) where {T}              
     x
 end
 
+function sub!(x::HipVector{T}, y::HipVector{T}) where {T}                               # y .-= x
+    check(ccall((:mik_sub, libmik), Cint, (Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Ptr{Cvoid}), y.ctx.handle, dtype_code(T), y.n, x.ptr, y.ptr), "mik_sub", y.ctx.handle)
+    y
+end
+
+# ---- broadcast: SURVEY.md section 8b plug point (1) -----------------------------------------------------------------------
+# The UNMODIFIED iterate(::CGIterable) writes its vector updates as fused broadcasts.  With this style they lower to
+# the L1 entry points instead of falling into scalar indexing; the four shapes of src/cg.jl are
+#     u .= r .+ beta .* u      (:51, :86)   -> mik_xpby
+#     x .+= alpha .* u         (:58, :93)   -> mik_axpy(alpha)
+#     r .-= alpha .* c         (:59, :94)   -> mik_axpy(-alpha)        [same rounded product, then a rounded subtract]
+#     r .-= c                  (:138)       -> mik_sub
+# plus  x .= value (fill!) and  y .= x (copyto!).  Anything else throws -- by design: a shape that is not listed here
+# would otherwise run as n scalar device-to-host copies.
+struct HipStyle <: Base.Broadcast.AbstractArrayStyle{1} end
+HipStyle(::Val{1}) = HipStyle()
+HipStyle(::Val{N}) where {N} = Base.Broadcast.DefaultArrayStyle{N}()
+Base.BroadcastStyle(::Type{<:HipVector}) = HipStyle()
+const Bc = Base.Broadcast.Broadcasted
+
+is_scaled(b) = b isa Bc && b.f === (*) && length(b.args) == 2 && b.args[1] isa Number && b.args[2] isa HipVector
+function Base.copyto!(dest::HipVector{T}, bc::Bc{HipStyle}) where {T}
+    f, a = bc.f, bc.args
+    if f === identity && length(a) == 1
+        return a[1] isa Number ? fill!(dest, a[1]) : copyto!(dest, a[1]::HipVector{T})
+    elseif f === (+) && length(a) == 2 && is_scaled(a[2])
+        s, v = a[2].args
+        a[1] === dest && return LinearAlgebra.axpy!(s, v, dest)                    # x .+= alpha .* u
+        v === dest && a[1] isa HipVector && return xpby!(a[1], s, dest)              # u .= r .+ beta .* u
+    elseif f === (-) && length(a) == 2 && a[1] === dest
+        is_scaled(a[2]) && return LinearAlgebra.axpy!(-a[2].args[1], a[2].args[2], dest)   # r .-= alpha .* c
+        a[2] isa HipVector && return sub!(a[2], dest)                                # r .-= c
+    end
+    error("broadcast shape not lowered for HipVector (MIK.jl lists the supported ones); expression: ", f, " over ", map(typeof, a))
+end
+Base.similar(bc::Bc{HipStyle}, ::Type{T}) where {T<:MikFloat} = HipVector{T}(undef, length(bc), first(x for x in Base.Broadcast.flatten(bc).args if x isa HipVector).ctx)
+
 # ---- operator -----------------------------------------------------------------------------------
 mutable struct HipCSR{T<:MikFloat}
     handle::Ptr{Cvoid}
@@ -133,7 +192,7 @@ function HipCSR(A::SparseMatrixCSC{T, Int64}, ctx::Context = context()) where {T
         ctx.handle, dtype_code(T), size(A, 1), size(A, 2), nnz(A), pointer(A.colptr), pointer(A.rowval), pointer(A.nzval), 1, 1, h),
         "mik_csr_create", ctx.handle)
     op = HipCSR{T}(h[], size(A, 1), size(A, 2), ctx)
-    finalizer(o -> ccall((:mik_csr_destroy, libmik), Cint, (Ptr{Cvoid},), o.handle), op)
+    finalizer(o -> alive(o.ctx) && ccall((:mik_csr_destroy, libmik), Cint, (Ptr{Cvoid},), o.handle), op)
     op
 end
 Base.eltype(::HipCSR{T}) where {T} = T
@@ -149,11 +208,22 @@ Base.:*(A::HipCSR{T}, x::HipVector{T}) where {T} = mul!(HipVector{T}(undef, A.m,
 struct HipJacobi{T}
     diagonal::HipVector{T}
 end
+# ldiv!(y, P, x) / ldiv!(P, x): the contract of docs/src/preconditioning.md:5-14, so the GENERIC iterables (PCGIterable of
+# src/cg.jl:72-100 through the broadcast style above, or any other solver of the package) accept it too
+function LinearAlgebra.ldiv!(y::HipVector{T}, P::HipJacobi{T}, x::HipVector{T}) where {T}
+    check(ccall((:mik_divide, libmik), Cint, (Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), y.ctx.handle, dtype_code(T), y.n, x.ptr, P.diagonal.ptr, y.ptr),
+          "mik_divide", y.ctx.handle)
+    y
+end
+LinearAlgebra.ldiv!(P::HipJacobi{T}, x::HipVector{T}) where {T} = LinearAlgebra.ldiv!(x, P, x)
+Base.:\(P::HipJacobi{T}, x::HipVector{T}) where {T} = LinearAlgebra.ldiv!(similar(x), P, x)
 
 # ---- CGIterable ---------------------------------------------------------------------------------
 mutable struct HipCGIterable{T, Tx<:HipVector{T}}
     handle::Ptr{Cvoid}
-    A::HipCSR{T}
+    A                                # HipCSR or any operator with mul!
+    ctx::Context
+    keep::Vector{Any}                # callback boxes: must outlive the handle
     x::Tx
     r::Tx; c::Tx; u::Tx; b::Tx       # keep the vectors alive while the handle uses their pointers
     Pl
@@ -167,25 +237,93 @@ end
 function refresh!(it::HipCGIterable{T}) where {T}
     res = Ref{Cdouble}(); prev = Ref{Cdouble}(); tol = Ref{Cdouble}(); mx = Ref{Int64}(); mv = Ref{Int64}(); cv = Ref{Cint}()
     check(ccall((:mik_cg_state, libmik), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ref{Cdouble}, Ref{Cdouble}, Ref{Int64}, Ref{Int64}, Ref{Cint}),
-                it.handle, res, prev, tol, mx, mv, cv), "mik_cg_state", it.A.ctx.handle)
+                it.handle, res, prev, tol, mx, mv, cv), "mik_cg_state", it.ctx.handle)
     it.residual = T(res[]); it.prev_residual = T(prev[]); it.tol = T(tol[]); it.mv_products = mv[]
     it
 end
 
-# cg_iterator!(x, A, b, Pl; ...)  -- src/cg.jl:120-155, specialised on the device types
-function IterativeSolvers.cg_iterator!(x::HipVector{T}, A::HipCSR{T}, b::HipVector{T}, Pl = Identity();
+# ---- any operator / any preconditioner: C callbacks (include/mik.h mik_mul_fn, mik_ldiv_fn) ------------------------------
+# `user` carries a pointer to a Julia object that holds the operator and a template vector; the trampolines wrap the raw
+# device pointers in non-owning HipVectors and call the ordinary mul! / ldiv! methods, so LinearMaps.jl maps over
+# HipVectors, or any struct with mul! / ldiv! methods for HipVector, work unchanged (test/gmres.jl:59-66, :28-35).
+struct MikOperator          # same field order and types as the C struct mik_operator
+    dtype::Cint
+    n::Int64
+    csr::Ptr{Cvoid}
+    mul::Ptr{Cvoid}
+    user::Ptr{Cvoid}
+end
+struct MikPrecond           # mik_precond
+    diag::Ptr{Cvoid}
+    ldiv::Ptr{Cvoid}
+    user::Ptr{Cvoid}
+end
+mutable struct CallbackBox{T}
+    obj::Any
+    n::Int
+    ctx::Context
+end
+unowned(::Type{T}, p::Ptr{Cvoid}, n::Int, ctx::Context) where {T} = HipVector{T}(p, n, ctx, Val(:unowned))
+function mul_trampoline(user::Ptr{Cvoid}, x::Ptr{Cvoid}, y::Ptr{Cvoid})::Cint
+    box = unsafe_pointer_to_objref(user)::CallbackBox
+    T = typeof(box).parameters[1]
+    try
+        LinearAlgebra.mul!(unowned(T, y, box.n, box.ctx), box.obj, unowned(T, x, box.n, box.ctx))
+        return Cint(0)
+    catch
+        return Cint(1)          # surfaces as MIK_ERR_CALLBACK; never unwind through the C frame
+    end
+end
+function ldiv_trampoline(user::Ptr{Cvoid}, y::Ptr{Cvoid}, x::Ptr{Cvoid})::Cint
+    box = unsafe_pointer_to_objref(user)::CallbackBox
+    T = typeof(box).parameters[1]
+    try
+        LinearAlgebra.ldiv!(unowned(T, y, box.n, box.ctx), box.obj, unowned(T, x, box.n, box.ctx))
+        return Cint(0)
+    catch
+        return Cint(1)
+    end
+end
+function operator_struct(A, ::Type{T}, n::Int, ctx::Context, keep::Vector{Any}) where {T}
+    A isa HipCSR && return MikOperator(dtype_code(T), n, A.handle, C_NULL, C_NULL)
+    box = CallbackBox{T}(A, n, ctx); push!(keep, box)
+    MikOperator(dtype_code(T), n, C_NULL, @cfunction(mul_trampoline, Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid})), pointer_from_objref(box))
+end
+function precond_struct(P, ::Type{T}, n::Int, ctx::Context, keep::Vector{Any}) where {T}
+    P isa Identity && return nothing
+    P isa HipJacobi && return MikPrecond(P.diagonal.ptr, C_NULL, C_NULL)
+    box = CallbackBox{T}(P, n, ctx); push!(keep, box)
+    MikPrecond(C_NULL, @cfunction(ldiv_trampoline, Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid})), pointer_from_objref(box))
+end
+refptr(::Nothing) = C_NULL
+refptr(r::Ref) = Base.unsafe_convert(Ptr{Cvoid}, r)
+
+# cg_iterator!(x, A, b, Pl; ...)  -- src/cg.jl:120-155, specialised on the device vector type: A may be a HipCSR (fully fused
+# step) or ANY operator with mul!(::HipVector, A, ::HipVector); Pl Identity(), HipJacobi (fused) or anything with ldiv!.
+function IterativeSolvers.cg_iterator!(x::HipVector{T}, A, b::HipVector{T}, Pl = Identity();
         abstol::Real = zero(T), reltol::Real = sqrt(eps(T)), maxiter::Int = size(A, 2),
         statevars::IterativeSolvers.CGStateVariables = IterativeSolvers.CGStateVariables(zero(x), similar(x), similar(x)),
         initially_zero::Bool = false) where {T}
-    Pl isa Identity || Pl isa HipJacobi || throw(MikError(Cint(5), "cg_iterator!", "Pl must be Identity() or HipJacobi on the device path"))
-    diag = Pl isa HipJacobi ? Pl.diagonal.ptr : C_NULL
+    ctx = x.ctx
+    keep = Any[]
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:mik_cg_create, libmik), Cint,
-        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Int64, Cint, Ref{Ptr{Cvoid}}),
-        A.ctx.handle, A.handle, x.ptr, b.ptr, statevars.u.ptr, statevars.r.ptr, statevars.c.ptr, diag,
-        Float64(abstol), Float64(reltol), maxiter, initially_zero ? 1 : 0, h), "mik_cg_create", A.ctx.handle)
-    it = HipCGIterable{T, typeof(x)}(h[], A, x, statevars.r, statevars.c, statevars.u, b, Pl, zero(T), zero(T), one(T), maxiter, 0)
-    finalizer(i -> ccall((:mik_cg_destroy, libmik), Cint, (Ptr{Cvoid},), i.handle), it)
+    if A isa HipCSR && (Pl isa Identity || Pl isa HipJacobi)
+        diag = Pl isa HipJacobi ? Pl.diagonal.ptr : C_NULL
+        check(ccall((:mik_cg_create, libmik), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Int64, Cint, Ref{Ptr{Cvoid}}),
+            ctx.handle, A.handle, x.ptr, b.ptr, statevars.u.ptr, statevars.r.ptr, statevars.c.ptr, diag,
+            Float64(abstol), Float64(reltol), maxiter, initially_zero ? 1 : 0, h), "mik_cg_create", ctx.handle)
+    else
+        op = Ref(operator_struct(A, T, x.n, ctx, keep))
+        pl = precond_struct(Pl, T, x.n, ctx, keep)
+        plref = pl === nothing ? nothing : Ref(pl)
+        GC.@preserve op plref keep check(ccall((:mik_cg_create_op, libmik), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Int64, Cint, Ref{Ptr{Cvoid}}),
+            ctx.handle, refptr(op), refptr(plref), x.ptr, b.ptr, statevars.u.ptr, statevars.r.ptr, statevars.c.ptr,
+            Float64(abstol), Float64(reltol), maxiter, initially_zero ? 1 : 0, h), "mik_cg_create_op", ctx.handle)
+    end
+    it = HipCGIterable{T, typeof(x)}(h[], A, ctx, keep, x, statevars.r, statevars.c, statevars.u, b, Pl, zero(T), zero(T), one(T), maxiter, 0)
+    finalizer(i -> alive(i.ctx) && ccall((:mik_cg_destroy, libmik), Cint, (Ptr{Cvoid},), i.handle), it)
     refresh!(it)
 end
 
@@ -196,12 +334,26 @@ IterativeSolvers.done(it::HipCGIterable, iteration::Int) = iteration ≥ it.maxi
 # iterate(it, iteration) -- src/cg.jl:43-66 (fused device step; one host-visible residual per call)
 function Base.iterate(it::HipCGIterable{T}, iteration::Int = IterativeSolvers.start(it)) where {T}
     res = Ref{Cdouble}(); done = Ref{Cint}()
-    check(ccall((:mik_cg_iterate, libmik), Cint, (Ptr{Cvoid}, Int64, Ref{Cdouble}, Ref{Cint}), it.handle, iteration, res, done), "mik_cg_iterate", it.A.ctx.handle)
+    check(ccall((:mik_cg_iterate, libmik), Cint, (Ptr{Cvoid}, Int64, Ref{Cdouble}, Ref{Cint}), it.handle, iteration, res, done), "mik_cg_iterate", it.ctx.handle)
     done[] != 0 && return nothing
     it.prev_residual = it.residual
     it.residual = T(res[])
     it.mv_products += 1
     it.residual, iteration + 1
+end
+
+"""
+    iterate_many!(it, iteration, max_steps) -> Vector{Float64}
+
+Up to `max_steps` `iterate` calls with ONE host synchronisation (`mik_cg_iterate_many`): the stopping test of src/cg.jl:36
+runs on the device after every step.  Returns the residuals of the executed steps.
+"""
+function iterate_many!(it::HipCGIterable{T}, iteration::Int, max_steps::Int) where {T}
+    res = Vector{Cdouble}(undef, max(max_steps, 1)); nd = Ref{Int64}(0)
+    check(ccall((:mik_cg_iterate_many, libmik), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ref{Int64}), it.handle, iteration, max_steps, res, nd),
+          "mik_cg_iterate_many", it.ctx.handle)
+    refresh!(it)
+    resize!(res, nd[])
 end
 
 # ---- GMRESIterable ------------------------------------------------------------------------------
@@ -214,7 +366,9 @@ mutable struct HipResidual{T}      # stands in for g.residual.current read by th
 end
 mutable struct HipGMRESIterable{T, Tx<:HipVector{T}}
     handle::Ptr{Cvoid}
-    A::HipCSR{T}
+    A
+    ctx::Context
+    keep::Vector{Any}
     x::Tx
     b::Tx
     residual::HipResidual{T}
@@ -229,26 +383,39 @@ end
 function refresh!(g::HipGMRESIterable{T}) where {T}
     res = Ref{Cdouble}(); tol = Ref{Cdouble}(); beta = Ref{Cdouble}(); k = Ref{Cint}(); mv = Ref{Int64}(); cv = Ref{Cint}()
     check(ccall((:mik_gmres_state, libmik), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ref{Cdouble}, Ref{Cdouble}, Ref{Cint}, Ref{Int64}, Ref{Cint}),
-                g.handle, res, tol, beta, k, mv, cv), "mik_gmres_state", g.A.ctx.handle)
+                g.handle, res, tol, beta, k, mv, cv), "mik_gmres_state", g.ctx.handle)
     g.residual.current = T(res[]); g.tol = T(tol[]); g.β = T(beta[]); g.k = k[]; g.mv_products = mv[]
     g
 end
 
-# gmres_iterable!(x, A, b; ...) -- src/gmres.jl:108-136
-function IterativeSolvers.gmres_iterable!(x::HipVector{T}, A::HipCSR{T}, b::HipVector{T};
+# gmres_iterable!(x, A, b; ...) -- src/gmres.jl:108-136; A: HipCSR or any operator with mul!, Pl / Pr: Identity(), HipJacobi or
+# anything with ldiv! (all three expand! methods of src/gmres.jl:285-304 run on the device side of the handle)
+function IterativeSolvers.gmres_iterable!(x::HipVector{T}, A, b::HipVector{T};
         Pl = Identity(), Pr = Identity(), abstol::Real = zero(T), reltol::Real = sqrt(eps(T)),
         restart::Int = min(20, size(A, 2)), maxiter::Int = size(A, 2), initially_zero::Bool = false,
         orth_meth::OrthogonalizationMethod = ModifiedGramSchmidt()) where {T}
-    all(P -> P isa Identity || P isa HipJacobi, (Pl, Pr)) || throw(MikError(Cint(5), "gmres_iterable!", "Pl / Pr must be Identity() or HipJacobi on the device path"))
-    pl = Pl isa HipJacobi ? Pl.diagonal.ptr : C_NULL
-    pr = Pr isa HipJacobi ? Pr.diagonal.ptr : C_NULL
+    ctx = x.ctx
+    keep = Any[]
+    simple(P) = P isa Identity || P isa HipJacobi
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:mik_gmres_create, libmik), Cint,
-        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Cint, Int64, Cint, Cint, Ref{Ptr{Cvoid}}),
-        A.ctx.handle, A.handle, x.ptr, b.ptr, pl, pr, Float64(abstol), Float64(reltol), restart, maxiter, initially_zero ? 1 : 0, orth_code(orth_meth), h),
-        "mik_gmres_create", A.ctx.handle)
-    g = HipGMRESIterable{T, typeof(x)}(h[], A, x, b, HipResidual{T}(one(T)), 0, restart, 1, maxiter, zero(T), one(T))
-    finalizer(i -> ccall((:mik_gmres_destroy, libmik), Cint, (Ptr{Cvoid},), i.handle), g)
+    if A isa HipCSR && simple(Pl) && simple(Pr)
+        pl = Pl isa HipJacobi ? Pl.diagonal.ptr : C_NULL
+        pr = Pr isa HipJacobi ? Pr.diagonal.ptr : C_NULL
+        check(ccall((:mik_gmres_create, libmik), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Cint, Int64, Cint, Cint, Ref{Ptr{Cvoid}}),
+            ctx.handle, A.handle, x.ptr, b.ptr, pl, pr, Float64(abstol), Float64(reltol), restart, maxiter, initially_zero ? 1 : 0, orth_code(orth_meth), h),
+            "mik_gmres_create", ctx.handle)
+    else
+        op = Ref(operator_struct(A, T, x.n, ctx, keep))
+        pl = precond_struct(Pl, T, x.n, ctx, keep); plref = pl === nothing ? nothing : Ref(pl)
+        pr = precond_struct(Pr, T, x.n, ctx, keep); prref = pr === nothing ? nothing : Ref(pr)
+        GC.@preserve op plref prref keep check(ccall((:mik_gmres_create_op, libmik), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Cint, Int64, Cint, Cint, Ref{Ptr{Cvoid}}),
+            ctx.handle, refptr(op), refptr(plref), refptr(prref), x.ptr, b.ptr, Float64(abstol), Float64(reltol), restart, maxiter,
+            initially_zero ? 1 : 0, orth_code(orth_meth), h), "mik_gmres_create_op", ctx.handle)
+    end
+    g = HipGMRESIterable{T, typeof(x)}(h[], A, ctx, keep, x, b, HipResidual{T}(one(T)), 0, restart, 1, maxiter, zero(T), one(T))
+    finalizer(i -> alive(i.ctx) && ccall((:mik_gmres_destroy, libmik), Cint, (Ptr{Cvoid},), i.handle), g)
     refresh!(g)
 end
 
@@ -259,7 +426,7 @@ IterativeSolvers.done(g::HipGMRESIterable, iteration::Int) = iteration ≥ g.max
 # iterate(g, iteration) -- src/gmres.jl:57-106
 function Base.iterate(g::HipGMRESIterable{T}, iteration::Int = IterativeSolvers.start(g)) where {T}
     res = Ref{Cdouble}(); done = Ref{Cint}()
-    check(ccall((:mik_gmres_iterate, libmik), Cint, (Ptr{Cvoid}, Int64, Ref{Cdouble}, Ref{Cint}), g.handle, iteration, res, done), "mik_gmres_iterate", g.A.ctx.handle)
+    check(ccall((:mik_gmres_iterate, libmik), Cint, (Ptr{Cvoid}, Int64, Ref{Cdouble}, Ref{Cint}), g.handle, iteration, res, done), "mik_gmres_iterate", g.ctx.handle)
     done[] != 0 && return nothing
     refresh!(g)
     g.residual.current, iteration + 1
@@ -287,14 +454,18 @@ struct Partition                     # same field order and types as the C struc
 end
 
 """
-    gmres_iterable_partitioned!(x, A_loc, b, part; kwargs...)
+    gmres_iterable_partitioned!(x, A_loc, b, part; n_global, kwargs...)
 
-`A_loc` is this rank's `n_loc x n_ext` block (halo columns behind the owned ones), `x`, `b` its rows.  Returns the
-same `HipGMRESIterable`; drive it with `iterate` / `gmres!`-style loops on every rank in lockstep.
+`A_loc` is this rank's `n_loc x n_ext` block (halo columns behind the owned ones), `x`, `b` its rows.  Returns the same
+`HipGMRESIterable`; drive it with `iterate` / `gmres!`-style loops on every rank in lockstep.  Defaults are those of
+`gmres_iterable!` (src/gmres.jl:108-117) evaluated on the GLOBAL size: `restart = min(20, n_global)`,
+`maxiter = n_global`, `orth_meth = ModifiedGramSchmidt()` -- switching a solve to the partitioned call does not change
+its result.  (ClassicalGramSchmidt() needs one reduction per step instead of k: pass it explicitly at scale.)
 """
-function gmres_iterable_partitioned!(x::HipVector{T}, A::HipCSR{T}, b::HipVector{T}, part::Partition; Pl = Identity(), Pr = Identity(),
-        abstol::Real = zero(real(T)), reltol::Real = sqrt(eps(real(T))), restart::Int = 20, maxiter::Int,
-        initially_zero::Bool = false, orth_meth::OrthogonalizationMethod = ClassicalGramSchmidt()) where {T}
+function gmres_iterable_partitioned!(x::HipVector{T}, A::HipCSR{T}, b::HipVector{T}, part::Partition; n_global::Int, Pl = Identity(), Pr = Identity(),
+        abstol::Real = zero(real(T)), reltol::Real = sqrt(eps(real(T))), restart::Int = min(20, n_global), maxiter::Int = n_global,
+        initially_zero::Bool = false, orth_meth::OrthogonalizationMethod = ModifiedGramSchmidt()) where {T}
+    all(P -> P isa Identity || P isa HipJacobi, (Pl, Pr)) || throw(MikError(Cint(5), "gmres_iterable_partitioned!", "Pl / Pr must be Identity() or HipJacobi"))
     pl = Pl isa HipJacobi ? Pl.diagonal.ptr : C_NULL
     pr = Pr isa HipJacobi ? Pr.diagonal.ptr : C_NULL
     h = Ref{Ptr{Cvoid}}(C_NULL)
@@ -302,9 +473,77 @@ function gmres_iterable_partitioned!(x::HipVector{T}, A::HipCSR{T}, b::HipVector
         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Cint, Int64, Cint, Cint, Ref{Partition}, Ref{Ptr{Cvoid}}),
         A.ctx.handle, A.handle, x.ptr, b.ptr, pl, pr, Float64(abstol), Float64(reltol), restart, maxiter, initially_zero ? 1 : 0,
         orth_code(orth_meth), Ref(part), h), "mik_gmres_create_partitioned", A.ctx.handle)
-    g = HipGMRESIterable{T, typeof(x)}(h[], A, x, b, HipResidual{T}(one(T)), 0, restart, 1, maxiter, zero(T), one(T))
-    finalizer(i -> ccall((:mik_gmres_destroy, libmik), Cint, (Ptr{Cvoid},), i.handle), g)
+    g = HipGMRESIterable{T, typeof(x)}(h[], A, A.ctx, Any[], x, b, HipResidual{T}(one(T)), 0, restart, 1, maxiter, zero(T), one(T))
+    finalizer(i -> alive(i.ctx) && ccall((:mik_gmres_destroy, libmik), Cint, (Ptr{Cvoid},), i.handle), g)
     refresh!(g)
+end
+
+# ------------------------------------------------------------------------------------------------
+# cg! over a row partition, exchanges inside libmik.so (include/mik.h "Transport 1": RCCL over xGMI, one process per GPU)
+# ------------------------------------------------------------------------------------------------
+"RCCL communicator owned by libmik.so.  `id` = the 128 bytes of `unique_id()` made on rank 0 and broadcast by the host (MPI.jl)."
+mutable struct Comm
+    handle::Ptr{Cvoid}
+    ctx::Context
+end
+function unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:mik_comm_unique_id, libmik), Cint, (Ptr{UInt8},), id), "mik_comm_unique_id")
+    id
+end
+function Comm(ctx::Context, id::Union{Nothing, Vector{UInt8}}, rank::Integer, nranks::Integer)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve id check(ccall((:mik_comm_create, libmik), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint, Ref{Ptr{Cvoid}}),
+                                ctx.handle, id === nothing ? C_NULL : pointer(id), rank, nranks, h), "mik_comm_create", ctx.handle)
+    c = Comm(h[], ctx)
+    finalizer(x -> alive(x.ctx) && ccall((:mik_comm_destroy, libmik), Cint, (Ptr{Cvoid},), x.handle), c)
+    c
+end
+
+"Row-partitioned CGIterable: this rank's block, the halo plan and the communicator; `iterate_many!` is ONE ccall per batch."
+mutable struct HipDistCG{T}
+    handle::Ptr{Cvoid}
+    ctx::Context
+    keep::Vector{Any}
+    residual::Float64
+    tol::Float64
+    maxiter::Int
+end
+function dist_cg_iterator!(x::HipVector{T}, A_loc::HipCSR{T}, b::HipVector{T}, comm::Comm, rank::Integer, nranks::Integer;
+        send_idx::Vector{Int32}, recv::Vector{NTuple{3, Int}}, send::Vector{NTuple{3, Int}},        # (peer, offset, count)
+        abstol::Real = 0.0, reltol::Real = sqrt(eps(T)), maxiter::Int, initially_zero::Bool = true) where {T}
+    ctx = x.ctx
+    n_loc, n_ext = size(A_loc)
+    u_ext = fill!(HipVector{T}(undef, n_ext, ctx), 0); r = similar(x); c = similar(x)
+    sbuf = HipVector{T}(undef, max(length(send_idx), 1), ctx)
+    dot_all = fill!(HipVector{T}(undef, nranks, ctx), 0); rr_all = fill!(HipVector{T}(undef, nranks, ctx), 0)
+    sidx = HipVector{Float32}(undef, max(length(send_idx), 1), ctx)      # 4-byte slots: holds the Int32 indices
+    isempty(send_idx) || GC.@preserve send_idx check(ccall((:mik_memcpy_h2d, libmik), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
+                                                           ctx.handle, sidx.ptr, pointer(send_idx), sizeof(send_idx)), "mik_memcpy_h2d", ctx.handle)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:mik_cgd_create, libmik), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint,
+         Cdouble, Cdouble, Int64, Cint, Ref{Ptr{Cvoid}}),
+        ctx.handle, A_loc.handle, x.ptr, b.ptr, u_ext.ptr, r.ptr, c.ptr, sidx.ptr, length(send_idx), sbuf.ptr, dot_all.ptr, rr_all.ptr, rank, nranks,
+        Float64(abstol), Float64(reltol), maxiter, initially_zero ? 1 : 0, h), "mik_cgd_create", ctx.handle)
+    rp = Cint[p for (p, _, _) in recv]; ro = Int64[o for (_, o, _) in recv]; rc = Int64[k for (_, _, k) in recv]
+    sp = Cint[p for (p, _, _) in send]; so = Int64[o for (_, o, _) in send]; sc = Int64[k for (_, _, k) in send]
+    check(ccall((:mik_cgd_set_halo_plan, libmik), Cint, (Ptr{Cvoid}, Cint, Ptr{Cint}, Ptr{Int64}, Ptr{Int64}, Cint, Ptr{Cint}, Ptr{Int64}, Ptr{Int64}),
+                h[], length(rp), rp, ro, rc, length(sp), sp, so, sc), "mik_cgd_set_halo_plan", ctx.handle)
+    check(ccall((:mik_cgd_set_comm, libmik), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h[], comm.handle), "mik_cgd_set_comm", ctx.handle)
+    res = Ref{Cdouble}(); tol = Ref{Cdouble}()
+    check(ccall((:mik_cgd_init, libmik), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ref{Cdouble}), h[], res, tol), "mik_cgd_init", ctx.handle)
+    it = HipDistCG{T}(h[], ctx, Any[x, b, u_ext, r, c, sbuf, dot_all, rr_all, sidx, A_loc, comm], res[], tol[], maxiter)
+    finalizer(i -> alive(i.ctx) && ccall((:mik_cgd_destroy, libmik), Cint, (Ptr{Cvoid},), i.handle), it)
+    it
+end
+function iterate_many!(it::HipDistCG, iteration::Int, max_steps::Int)
+    res = Vector{Cdouble}(undef, max(max_steps, 1)); nd = Ref{Int64}(0)
+    check(ccall((:mik_cgd_iterate_many, libmik), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ref{Int64}), it.handle, iteration, max_steps, res, nd),
+          "mik_cgd_iterate_many", it.ctx.handle)
+    resize!(res, nd[])
+    isempty(res) || (it.residual = res[end])
+    res
 end
 
 end # module
