@@ -8,6 +8,8 @@
  *      gcc -std=c99 -Wall -pedantic -I include tests/c_host/cg_host.c -o cg_host -L iterativesolvers.jl_amd -l:libmik.so
  *      ./cg_host 16            (grid points per dimension)
  *      ./cg_host 12 gmres      x, history = gmres(A, b; restart = 10, log = true) on the same operator (src/gmres.jl:143,184-222)
+ *      ./cg_host 12 cgop       cg with the operator handed over as a C CALLBACK (mik_cg_create_op: "any A with mul!",
+ *                              docs/src/getting_started.md:25-30) and all iterations in ONE call (mik_cg_iterate_many)
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -24,6 +26,16 @@
             return rc_ == MIK_ERR_HIP && !ctx ? 3 : 1;                                       \
         }                                                                                    \
     } while (0)
+
+/* mul!(y, A, x) of a user-defined operator: here it forwards to the library's own SpMV, a Julia host would pass an
+ * @cfunction around its LinearMap */
+struct my_operator { mik_ctx *ctx; const mik_csr *A; long calls; };
+static int my_mul(void *user, const void *x, void *y)
+{
+    struct my_operator *op = (struct my_operator *)user;
+    op->calls += 1;
+    return mik_spmv(op->ctx, op->A, x, y);
+}
 
 int main(int argc, char **argv)
 {
@@ -88,6 +100,32 @@ int main(int argc, char **argv)
         for (int64_t i = 0; i < n; ++i) sg += xg[i];
         printf("sum_x %a\n", sg);
         CHECK(mik_gmres_destroy(g));
+        CHECK(mik_csr_destroy(A));
+        CHECK(mik_ctx_destroy(ctx));
+        return 0;
+    }
+
+    if (argc > 2 && strcmp(argv[2], "cgop") == 0) {
+        struct my_operator mine = {ctx, A, 0};
+        mik_operator op = {MIK_F64, n, NULL, my_mul, &mine};
+        mik_cg *itop = NULL;
+        CHECK(mik_cg_create_op(ctx, &op, NULL /* Pl = Identity() */, dx, db, du, dr, dc, 0.0, 1.4901161193847656e-8, n, 1, &itop));
+        double *hist = malloc(sizeof(double) * (size_t)n);
+        int64_t steps = 0;
+        CHECK(mik_cg_iterate_many(itop, 0, n, hist, &steps));           /* the device-side stopping test ends the batch */
+        for (int64_t i = 0; i < steps; ++i) printf("%a\n", hist[i]);
+        double res, prev, tol;
+        int64_t maxiter, mv;
+        int conv;
+        CHECK(mik_cg_state(itop, &res, &prev, &tol, &maxiter, &mv, &conv));
+        printf("iters %lld converged %d layout %d mvps %lld\n", (long long)steps, conv, layout, (long long)mv);
+        printf("callback_calls %ld\n", mine.calls);
+        double *xo = malloc(bytes);
+        CHECK(mik_memcpy_d2h(ctx, xo, dx, bytes));
+        double so = 0.0;
+        for (int64_t i = 0; i < n; ++i) so += xo[i];
+        printf("sum_x %a\n", so);
+        CHECK(mik_cg_destroy(itop));
         CHECK(mik_csr_destroy(A));
         CHECK(mik_ctx_destroy(ctx));
         return 0;

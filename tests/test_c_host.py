@@ -29,11 +29,11 @@ def test_header_is_c99_and_host_fails_cleanly_without_a_device(pkg, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("solver", ["cg", "gmres"])
+@pytest.mark.parametrize("solver", ["cg", "gmres", "cgop"])
 def test_c_host_reproduces_the_oracle_history(pkg, orc, ctx, tmp_path, solver):
     exe = build(tmp_path, pkg)
     N = 12
-    p = subprocess.run([exe, str(N)] + (["gmres"] if solver == "gmres" else []), capture_output=True, text=True, timeout=120)
+    p = subprocess.run([exe, str(N)] + ([solver] if solver != "cg" else []), capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stderr
     lines = p.stdout.split("\n")
     hist = np.array([float.fromhex(s) for s in lines if s.startswith("0x")])
@@ -42,6 +42,11 @@ def test_c_host_reproduces_the_oracle_history(pkg, orc, ctx, tmp_path, solver):
     b = orc.hashed_rhs(A.n)
     if solver == "cg":
         xo, ho = orc.cg(A, b, mode="tree", shape=ctx.cg_shape(np.float64))
+    elif solver == "cgop":                      # callback operator: dot(u, c) is reduced with the vector tree shape
+        W, L = ctx.reduce_shape(np.float64)
+        xo, ho = orc.cg(A, b, mode="tree", shape=(W, L, W, L))
+        # every step of the batch enqueues one callback, also the no-op steps after the device-side stopping test fired
+        assert int(next(l for l in lines if l.startswith("callback_calls")).split()[1]) >= ho["iters"]
     else:
         xo, ho = orc.gmres(A, b, restart=10, mode="tree", shape=ctx.reduce_shape(np.float64))
     assert int(tail[1]) == ho["iters"] and int(tail[3]) == int(ho["isconverged"]) and int(tail[7]) == ho["mvps"]
