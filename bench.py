@@ -33,7 +33,8 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md);
 COPY_CEILING_GBS = 6290.0
 MIN_TIMED_SECONDS = float(os.environ.get("MIK_BENCH_MIN_SECONDS", "0.25"))   # the K-step timed region is repeated until this much has been measured
 KERNEL_OF_LAYOUT = {"csr-rowblock": "k_spmv_rowgather", "sliced-ell": "k_spmv_sell", "sliced-ell+8-bit-column-codes": "k_spmv_sell8",
-                    "sliced-ell+slice-offsets+row-masks": "k_spmv_sdia", "dictionary-coded": "k_spmv_packed"}
+                    "sliced-ell+slice-offsets+row-masks": "k_spmv_sdia", "slice-offsets+slice-values+row-masks": "k_spmv_sdiac",
+                    "dictionary-coded": "k_spmv_packed"}
 
 
 def cpu_model() -> str:

@@ -112,7 +112,7 @@ int mik_spmv_long_segment(int *segment);
  *   5: 1 = unfused MGS chain, 2 = launch-lean MGS without graphs, 3 = one hipGraph per GMRES column
  *   6: 1 = ignore the dictionary-coded form                       7: cache hints of the CG vector kernels
  *   8: 1 = CSR row-block layout only (read at mik_csr_create and at launch)    9: 1 = GMRES: no Arnoldi column enqueued ahead of the host
- *  10: 1 = no 8-bit column codes                                  12: 1 = no per-slice-offset layout
+ *  10: 1 = no 8-bit column codes        11: 1 = no slice-constant values        12: 1 = no per-slice-offset layout
  *  13: bit mask switching the Krylov-basis streaming hints off    14: CSR kernel: 0 = by operator, 1 = register-staged products, 2 = LDS-DMA tile + per-row gather
  *  15: long-row segment length (> 0; read at mik_csr_create) */
 int mik_set_tuning(int key, int value);
@@ -144,7 +144,9 @@ int mik_csr_pack(mik_csr *A);
  * slices stored column-major; near-uniform row lengths per slice), 2 = sliced-ELL values + 8-bit codes for the
  * (column - row) offsets (banded / stencil operators with <= 255 distinct offsets), 3 = dictionary-coded
  * (after mik_csr_pack), 4 = sliced-ELL values with per-slice offsets and one presence-mask byte per row (every
- * 256-row slice uses <= 8 distinct offsets: stencils on structured grids). */
+ * 256-row slice uses <= 8 distinct offsets: stencils on structured grids), 5 = the same with slice-CONSTANT slot values
+ * (within a slice every row that has a slot carries the same value there -- constant-coefficient stencils): the slice
+ * stores its <= 8 values once and a row is one mask byte. */
 int mik_csr_layout(const mik_csr *A, int *layout);
 /* Bytes of operator data (values, indices / codes, pointers) one mik_spmv launch streams in that layout. */
 int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes);

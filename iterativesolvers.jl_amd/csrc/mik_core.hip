@@ -10,10 +10,12 @@
 #include "mik_spmv.h"
 #include "mik_packed.h"
 #include "mik_sell.h"
+#include <map>
+#include <string>
 #include <unordered_map>
 
 thread_local std::string g_mik_create_error;
-int g_mik_tuning[16] = {0};
+int g_mik_tuning[32] = {0};
 
 int mik_fail(mik_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -148,7 +150,7 @@ extern "C" int mik_spmv_long_segment(int *segment)
 
 extern "C" int mik_set_tuning(int key, int value)
 {
-    if (key < 0 || key >= 16) return MIK_ERR_INVALID;
+    if (key < 0 || key >= 32) return MIK_ERR_INVALID;
     g_mik_tuning[key] = value;
     return MIK_OK;
 }
@@ -292,7 +294,55 @@ static int csr_build_sdia(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
                     prevq = q;
                 }
             }
-            if (ok) {
+            // slice-constant slots (k_spmv_sdiac): every row of a slice that has slot q carries the same value BITS there
+            std::vector<unsigned char> cval;
+            bool constant = ok && g_mik_tuning[11] == 0;
+            if (constant) {
+                cval.assign((size_t)nb * 8 * es, 0);
+                std::vector<unsigned char> seen((size_t)nb * 8, 0);
+                for (int64_t r = 0; r < n_rows && constant; ++r) {
+                    const int64_t b = r / MIK_BLOCK, t = r % MIK_BLOCK;
+                    const int ns = (dptr[(size_t)b + 1] - dptr[(size_t)b]) / MIK_BLOCK;
+                    for (int q = 0; q < ns; ++q) {
+                        if (!((dmask[(size_t)r] >> q) & 1)) continue;
+                        const unsigned char *src = &dval[((size_t)dptr[(size_t)b] + (size_t)q * MIK_BLOCK + (size_t)t) * es];
+                        unsigned char *dst = &cval[((size_t)b * 8 + q) * es];
+                        if (!seen[(size_t)b * 8 + q]) { memcpy(dst, src, es); seen[(size_t)b * 8 + q] = 1; }
+                        else if (memcmp(dst, src, es) != 0) { constant = false; break; }
+                    }
+                }
+            }
+            if (ok && constant) {
+                // equal slice descriptions {ns, tri, offsets, value bits} are stored once; a slice keeps a pattern index
+                const size_t psz = 8 + 32 + 8 * es;                        // sizeof(SdiaPattern<T>): 2 ints, 8 ints, 8 values
+                std::map<std::string, int> index;
+                std::vector<unsigned char> pats;
+                std::vector<int> pid((size_t)nb, 0);
+                for (int64_t b = 0; b < nb; ++b) {
+                    std::string key(psz, '\0');
+                    const int ns = (dptr[(size_t)b + 1] - dptr[(size_t)b]) / MIK_BLOCK;
+                    int hdr[2] = {ns, dtri[(size_t)b]};
+                    memcpy(&key[0], hdr, 8);
+                    memcpy(&key[8], &doff[(size_t)b * 8], 32);
+                    memcpy(&key[40], &cval[(size_t)b * 8 * es], 8 * es);
+                    auto it = index.find(key);
+                    if (it == index.end()) {
+                        it = index.emplace(key, (int)index.size()).first;
+                        pats.insert(pats.end(), key.begin(), key.end());
+                    }
+                    pid[(size_t)b] = it->second;
+                }
+                if ((e = hipMalloc((void **)&A->sdia_pat_id, sizeof(int) * (size_t)nb)) != hipSuccess ||
+                    (e = hipMalloc((void **)&A->sdia_mask, (size_t)n_rows)) != hipSuccess ||
+                    (e = hipMalloc(&A->sdia_pats, pats.size())) != hipSuccess ||
+                    (e = hipMemcpy(A->sdia_pat_id, pid.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice)) != hipSuccess ||
+                    (e = hipMemcpy(A->sdia_mask, dmask.data(), (size_t)n_rows, hipMemcpyHostToDevice)) != hipSuccess ||
+                    (e = hipMemcpy(A->sdia_pats, pats.data(), pats.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+                    return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: slice-constant form: %s", hipGetErrorString(e));
+                }
+                A->sdia_npat = (int)index.size();
+                A->sdia_entries = slots;
+            } else if (ok) {
                 if ((e = hipMalloc((void **)&A->sdia_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
                     (e = hipMalloc((void **)&A->sdia_off, sizeof(int) * (size_t)nb * 8)) != hipSuccess ||
                     (e = hipMalloc((void **)&A->sdia_tri, sizeof(int) * (size_t)nb)) != hipSuccess ||
@@ -320,7 +370,7 @@ static int csr_build_sell(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
 {
     (void)n_cols;
     hipError_t e;
-    if (!A->sdia_val && A->n_long == 0 && n_rows > 0 && nnz > 0 && max_row <= 255 && g_mik_tuning[8] == 0)
+    if (!A->sdia_val && !A->sdia_pats && A->n_long == 0 && n_rows > 0 && nnz > 0 && max_row <= 255 && g_mik_tuning[8] == 0)
     {
         const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
         std::vector<int> sptr((size_t)nb + 1, 0);
@@ -627,6 +677,8 @@ extern "C" int mik_csr_destroy(mik_csr *A)
     if (A->sdia_tri) (void)hipFree(A->sdia_tri);
     if (A->sdia_mask) (void)hipFree(A->sdia_mask);
     if (A->sdia_val) (void)hipFree(A->sdia_val);
+    if (A->sdia_pats) (void)hipFree(A->sdia_pats);
+    if (A->sdia_pat_id) (void)hipFree(A->sdia_pat_id);
     if (A->sell8_ptr) (void)hipFree(A->sell8_ptr);
     if (A->sell8_codes) (void)hipFree(A->sell8_codes);
     if (A->sell8_tab) (void)hipFree(A->sell8_tab);
@@ -727,6 +779,7 @@ extern "C" int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes)
     const int64_t es = (int64_t)mik_dtype_size(A->dtype);
     const int64_t nb = (A->n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
     switch (layout) {
+    case 5: *bytes = A->n_rows + nb * 4 + (int64_t)A->sdia_npat * (40 + 8 * es); break;
     case 4: *bytes = A->sdia_entries * es + A->n_rows + nb * 36; break;
     case 3: *bytes = A->nnz * 2 + (A->n_rows + 1) * 4 + 256 * (es + 4); break;
     case 2: *bytes = A->sell_entries * es + A->sell8_bytes + (nb + 1) * 8 + 256 * 4; break;
@@ -755,11 +808,12 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
 
 // Which kernel mik_spmv_launch_range picks for this operator under the current development knobs -- ONE function, used
 // by the launcher, by mik_csr_layout and by mik_spmv_can_split, so the three can never disagree.
-//   3 packed, 4 sliced-ELL + per-slice offsets, 2 sliced-ELL + 8-bit codes, 1 sliced-ELL, 0 CSR
+//   3 packed, 5 per-slice offsets + slice-constant values, 4 sliced-ELL + per-slice offsets, 2 sliced-ELL + 8-bit codes, 1 sliced-ELL, 0 CSR
 static int spmv_kernel_choice(const mik_csr *A)
 {
     if (A->packed && g_mik_tuning[6] == 0) return 3;
     if (g_mik_tuning[8] == 0) {
+        if (A->sdia_pats && g_mik_tuning[12] == 0) return 5;
         if (A->sdia_val && g_mik_tuning[12] == 0) return 4;
         if (A->sell8_codes && g_mik_tuning[10] == 0) return 2;
         if (A->sell_val) return 1;
@@ -819,6 +873,22 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
         else
             hipLaunchKernelGGL((k_spmv_packed<T, false>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, map_mode, A->rowptr, A->codes,
                                (const T *)A->vtab, A->dtab, A->nv, A->nd, x, y, seg_out, done);
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    }
+    if (choice == 5) {
+        // slice patterns {offsets, values} + one mask byte per row (mik_sell.h); G slices per workgroup
+        const int G = g_mik_tuning[16] > 0 ? g_mik_tuning[16] : MIK_SDIAC_G;   // development knob 16: 1 / 2 / 4 slices per workgroup
+        const int wgs = ((nb + G - 1) / G + 7) / 8 * 8;                         // a multiple of 8: see k_spmv_sdiac
+#define MIK_SDIAC_GO3(FD, NTV, GG)                                                                                             \
+    hipLaunchKernelGGL((k_spmv_sdiac<T, FD, NTV, GG>), dim3(wgs), dim3(MIK_BLOCK), 0, ctx->stream, n, (int)A->n_cols, rb0, nb, map_mode, A->sdia_pat_id, \
+                       (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done)
+#define MIK_SDIAC_GO(FD, NTV)                                                                      \
+    do { if (G == 1) MIK_SDIAC_GO3(FD, NTV, 1); else if (G == 4) MIK_SDIAC_GO3(FD, NTV, 4); else MIK_SDIAC_GO3(FD, NTV, 2); } while (0)
+        if (fuse_dot) { if (nt) MIK_SDIAC_GO(true, true); else MIK_SDIAC_GO(true, false); }
+        else          { if (nt) MIK_SDIAC_GO(false, true); else MIK_SDIAC_GO(false, false); }
+#undef MIK_SDIAC_GO3
+#undef MIK_SDIAC_GO
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     }

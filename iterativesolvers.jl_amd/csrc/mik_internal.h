@@ -77,8 +77,12 @@ struct mik_csr {
     int *sdia_off = nullptr;         // device, nb * 8
     int *sdia_tri = nullptr;         // device, nb: first slot of an (o-1, o, o+1) run, or -1
     unsigned char *sdia_mask = nullptr;   // device, n_rows
-    void *sdia_val = nullptr;        // device, slot-major inside a slice
+    void *sdia_val = nullptr;        // device, slot-major inside a slice (absent when the slice-constant form below exists)
     int64_t sdia_entries = 0;
+    // slice-constant slot values (k_spmv_sdiac): distinct slice patterns {ns, tri, off[8], val[8]} + one pattern index per slice
+    void *sdia_pats = nullptr;       // device, sdia_npat patterns (SdiaPattern<T>), or NULL
+    int *sdia_pat_id = nullptr;      // device, nb
+    int sdia_npat = 0;
     // optional dictionary-coded form (mik_csr_pack): one 16-bit code per entry + two <= 256-entry tables
     unsigned short *codes = nullptr; // device, nnz (+ padding)
     void *vtab = nullptr;            // device, 256 values of dtype
@@ -100,7 +104,7 @@ template <typename T> __host__ __device__ static inline bool mik_nrm_in_range(T 
 template <typename T> int mik_safe_norm_slow(mik_ctx *ctx, int64_t n, const T *x, T *out);
 
 extern thread_local std::string g_mik_create_error;
-extern int g_mik_tuning[16];  // development knobs (mik_set_tuning), see mik_spmv_launch
+extern int g_mik_tuning[32];  // development knobs (mik_set_tuning), see mik_spmv_launch
 
 int mik_fail(mik_ctx *ctx, int code, const char *fmt, ...);
 int mik_ensure_partials(mik_ctx *ctx, size_t bytes);
@@ -262,7 +266,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nb)
 // Wait for everything enqueued on the ctx stream.  hipStreamSynchronize parks the host thread when the queue
 // is not about to drain and takes hundreds of microseconds to come back -- more than the kernels of one solver
 // iteration -- so the per-iteration scalar reads spin on an event instead (tuning[3] = 1: plain synchronize).
-extern int g_mik_tuning[16];
+extern int g_mik_tuning[32];
 static inline hipError_t mik_wait(mik_ctx *ctx)
 {
     if (g_mik_tuning[3] == 1 || !ctx->wait_event) return hipStreamSynchronize(ctx->stream);

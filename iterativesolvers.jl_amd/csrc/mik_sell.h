@@ -162,7 +162,9 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sell8(int n, int rb0, int nb
 // through LDS, which also removes the +-N_x gathers of the inner slices -- 225 / 255 us vs 219 us: the barrier and
 // the larger workgroups cost more than the gathers they save.)
 // One row of a slice; TRI (compile time) = first slot of the (o-1, o, o+1) run served by shuffles, -1 = none.
-template <typename T, bool NT, int TRI>
+// CV = true: the slot's value is the same for every row of the slice that has it ("slice-constant slots", k_spmv_sdiac):
+// vp then points at the slice's 8 values and v[q] is a wave-uniform scalar load instead of a per-row stream.
+template <typename T, bool NT, int TRI, bool CV>
 __device__ __forceinline__ T sdia_row(int r, int n, int ncols, int ns, const int *__restrict__ so, const T *__restrict__ vp,
                                       const unsigned char *__restrict__ mask, const T *__restrict__ x, T &xr, bool &have_xr)
 {
@@ -173,7 +175,7 @@ __device__ __forceinline__ T sdia_row(int r, int n, int ncols, int ns, const int
         v[q] = T(0);
         xv[q] = T(0);
         if (q < ns) {                                                // slice-uniform: slots the slice does not have cost nothing
-            v[q] = ld_stream<NT>(vp + (size_t)q * MIK_BLOCK);
+            v[q] = CV ? vp[q] : ld_stream<NT>(vp + (size_t)q * MIK_BLOCK);
             if (TRI < 0 || (q != TRI && q != TRI + 2))
                 xv[q] = x[min(max(r + so[q], 0), ncols - 1)];        // absent slots gather from a valid address
         }
@@ -199,14 +201,12 @@ __device__ __forceinline__ T sdia_row(int r, int n, int ncols, int ns, const int
     return acc;
 }
 
-template <typename T, bool FUSE_DOT, bool NT>
-__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdia(int n, int ncols, int rb0, int nb, int map_mode, const int *__restrict__ blkptr,
-                                                         const int *__restrict__ offs, const int *__restrict__ trio,
-                                                         const unsigned char *__restrict__ mask, const T *__restrict__ val,
-                                                         const T *__restrict__ x, T *__restrict__ y, T *__restrict__ seg_out,
-                                                         const int *__restrict__ done)
+template <typename T, bool FUSE_DOT, bool NT, bool CV>
+__device__ __forceinline__ void spmv_sdia_body(int n, int ncols, int rb0, int nb, int map_mode, const int *__restrict__ blkptr,
+                                               const int *__restrict__ offs, const int *__restrict__ trio,
+                                               const unsigned char *__restrict__ mask, const T *__restrict__ val,
+                                               const T *__restrict__ x, T *__restrict__ y, T *__restrict__ seg_out)
 {
-    if (done && *done) return;
     constexpr int U = 8;
     __shared__ T lds4[4];
     const int t = threadIdx.x;
@@ -216,20 +216,20 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdia(int n, int ncols, int r
     const int ns = (blkptr[rb + 1] - base) / MIK_BLOCK;            // offsets used by this slice, <= 8
     const int tri = trio[rb];
     const int *__restrict__ so = offs + (size_t)rb * U;
-    const T *__restrict__ vp = val + base + t;
+    const T *__restrict__ vp = CV ? val + (size_t)rb * U : val + base + t;
 
     T acc = T(0);
     T xr = T(0);
     bool have_xr = false;
     if (ns > 0) {
         switch (tri) {                                              // slice-uniform: one specialised path per run position
-        case 0: acc = sdia_row<T, NT, 0>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
-        case 1: acc = sdia_row<T, NT, 1>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
-        case 2: acc = sdia_row<T, NT, 2>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
-        case 3: acc = sdia_row<T, NT, 3>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
-        case 4: acc = sdia_row<T, NT, 4>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
-        case 5: acc = sdia_row<T, NT, 5>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
-        default: acc = sdia_row<T, NT, -1>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
+        case 0: acc = sdia_row<T, NT, 0, CV>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
+        case 1: acc = sdia_row<T, NT, 1, CV>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
+        case 2: acc = sdia_row<T, NT, 2, CV>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
+        case 3: acc = sdia_row<T, NT, 3, CV>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
+        case 4: acc = sdia_row<T, NT, 4, CV>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
+        case 5: acc = sdia_row<T, NT, 5, CV>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
+        default: acc = sdia_row<T, NT, -1, CV>(r, n, ncols, ns, so, vp, mask, x, xr, have_xr); break;
         }
     }
     if (r < n) st_stream<NT>(y + r, acc);
@@ -238,6 +238,100 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdia(int n, int ncols, int r
         if (r < n) p = (have_xr ? xr : x[r]) * acc;
         T tot = block_tree_256(p, lds4);
         if (t == 0) seg_out[rb] = tot;
+    }
+}
+
+template <typename T, bool FUSE_DOT, bool NT>
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdia(int n, int ncols, int rb0, int nb, int map_mode, const int *__restrict__ blkptr,
+                                                         const int *__restrict__ offs, const int *__restrict__ trio,
+                                                         const unsigned char *__restrict__ mask, const T *__restrict__ val,
+                                                         const T *__restrict__ x, T *__restrict__ y, T *__restrict__ seg_out,
+                                                         const int *__restrict__ done)
+{
+    if (done && *done) return;
+    spmv_sdia_body<T, FUSE_DOT, NT, false>(n, ncols, rb0, nb, map_mode, blkptr, offs, trio, mask, val, x, y, seg_out);
+}
+
+// Slice-CONSTANT slots: in every 256-row slice, all rows that have slot q carry the same value bits there -- any
+// constant-coefficient stencil (the Laplacian and advection-diffusion fixtures of the reference; a rank's block of them).
+// A slice is then described by a PATTERN {number of slots, run position, <= 8 offsets, <= 8 values}; equal patterns are
+// stored once (a 256^3 Laplacian has 9: interior lines and the faces / edges of the grid) and a slice carries a 4-byte
+// pattern index, a row one mask byte: the operator shrinks from 57 bytes to ~1 byte per row and the SpMV moves 17 B per
+// row (mask + x + y) instead of 73.  The pattern table stays hot in the scalar cache, so the only per-slice metadata
+// that comes from memory is its index (the per-slice offset / value arrays of a first version were two dependent HBM
+// misses per workgroup: 117 us).  Same products (value x gathered x, rounded), same order, same bits as
+// every other layout; constancy is decided at upload on value BIT patterns (not numbers), so -0.0 / NaN payloads cannot
+// alias.  Anything with varying coefficients keeps the per-row value slots of k_spmv_sdia.
+#ifndef MIK_SDIAC_G
+#define MIK_SDIAC_G 2       // slices per workgroup of k_spmv_sdiac
+#endif
+template <typename T> struct SdiaPattern {
+    int ns, tri;
+    int off[8];
+    T val[8];
+};
+
+template <typename T, bool FUSE_DOT, bool NT, int G>
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiac(int n, int ncols, int rb0, int nb, int map_mode, const int *__restrict__ pat_id,
+                                                          const SdiaPattern<T> *__restrict__ pats, const unsigned char *__restrict__ mask,
+                                                          const T *__restrict__ x, T *__restrict__ y, T *__restrict__ seg_out,
+                                                          const int *__restrict__ done)
+{
+    if (done && *done) return;
+    constexpr int U = 8;
+    __shared__ T lds[G][4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    // this workgroup takes G slices: virtual blocks blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is a multiple of 8,
+    // so all of them carry this workgroup's XCD in the strip map); this launch covers row-blocks [rb0, rb0 + nb)
+    int rb[G], r[G], m[G];
+    const SdiaPattern<T> *__restrict__ pt[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int vb = (int)blockIdx.x + g * (int)gridDim.x;
+        rb[g] = vb < nb ? rb0 + spmv_block_map(vb, nb, map_mode) : -1;
+        r[g] = rb[g] >= 0 ? rb[g] * MIK_BLOCK + t : n;
+        pt[g] = pats + (rb[g] >= 0 ? pat_id[rb[g]] : 0);
+        m[g] = r[g] < n ? (int)ld_stream<NT>(mask + r[g]) : 0;
+    }
+    T xv[G][U];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            xv[g][q] = T(0);
+            if (rb[g] >= 0 && q < pt[g]->ns) xv[g][q] = x[min(max(r[g] + pt[g]->off[q], 0), ncols - 1)];   // absent slots gather a valid address
+        }
+    // (serving the +-1 neighbours by wave shuffles, as k_spmv_sdia does with a compile-time run position, was measured here
+    //  with the run position read from the pattern: 145 us instead of 112 us -- the selects cost more than two gathers)
+    T p[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        T acc = T(0), xr = T(0);
+        bool have = false;
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            if (rb[g] >= 0 && q < pt[g]->ns && pt[g]->off[q] == 0) { xr = xv[g][q]; have = true; }
+            if ((m[g] >> q) & 1) { T pr = pt[g]->val[q] * xv[g][q]; acc = acc + pr; }
+        }
+        if (r[g] < n) st_stream<NT>(y + r[g], acc);
+        p[g] = T(0);
+        if (FUSE_DOT && r[g] < n) p[g] = (have ? xr : x[r[g]]) * acc;
+    }
+    if (FUSE_DOT) {                                   // one partial per slice: wave tree, then the 4 wave sums left to right
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const T ws = wave_tree(p[g]);
+            if (lane == 0) lds[g][w] = ws;
+        }
+        __syncthreads();
+        if (t < G) {
+            const int vb = (int)blockIdx.x + t * (int)gridDim.x;
+            if (vb < nb) {
+                T tot = lds[t][0];
+                tot = tot + lds[t][1]; tot = tot + lds[t][2]; tot = tot + lds[t][3];
+                seg_out[rb0 + spmv_block_map(vb, nb, map_mode)] = tot;
+            }
+        }
     }
 }
 

@@ -75,8 +75,14 @@ for d in sorted(glob.glob(os.path.join(root, "*"))):
                            f"SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES = {m.get('SQ_ACTIVE_INST_ANY', 0) / m['SQ_WAVE_CYCLES']:.3f}")
             if "SQ_LDS_BANK_CONFLICT" in m and m.get("SQ_LDS_IDX_ACTIVE"):
                 der.append(f"LDS bank-conflict cycles / LDS active cycles = {m['SQ_LDS_BANK_CONFLICT'] / m['SQ_LDS_IDX_ACTIVE']:.3f}")
-            if "TA_TA_BUSY_sum" in m and "GRBM_GUI_ACTIVE" in m:
-                der.append(f"TA busy (sum over TAs) / (GRBM_GUI_ACTIVE x 256 CUs) = {m['TA_TA_BUSY_sum'] / (m['GRBM_GUI_ACTIVE'] * 256):.3f}")
+            if "TA_BUSY_avr" in m and "GRBM_GUI_ACTIVE" in m:
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs (value / duration = 8 x the shader clock), TA_BUSY_avr is the mean over the TAs
+                cyc = m["GRBM_GUI_ACTIVE"] / 8.0
+                der.append(f"TA_BUSY_avr / (GRBM_GUI_ACTIVE / 8 XCDs) = {m['TA_BUSY_avr'] / cyc:.3f}  (a TA counts as busy while requests are outstanding: "
+                           f"~0.7 for EVERY HBM-bound kernel here, streaming or gathering)")
+                if "TA_ADDR_STALLED_BY_TC_CYCLES_sum" in m:
+                    der.append(f"per TA: address path stalled by the cache {m['TA_ADDR_STALLED_BY_TC_CYCLES_sum'] / 256 / cyc:.3f}, "
+                               f"data return stalled {m.get('TA_DATA_STALLED_BY_TC_CYCLES_sum', 0) / 256 / cyc:.3f} of the kernel's cycles")
             if "TCP_GATE_EN1_sum" in m and "TCP_PENDING_STALL_CYCLES_sum" in m and m["TCP_GATE_EN1_sum"]:
                 der.append(f"TCP pending-stall cycles / TCP active cycles = {m['TCP_PENDING_STALL_CYCLES_sum'] / m['TCP_GATE_EN1_sum']:.3f}")
             if "TCP_TCC_READ_REQ_sum" in m and m.get("TCP_TOTAL_CACHE_ACCESSES_sum"):

@@ -23,7 +23,7 @@ variants = [{int(k): int(v) for k, v in (kv.split("=") for kv in spec.split(",")
 
 
 def set_knobs(v):
-    for k in range(16):
+    for k in range(32):
         L.mik_set_tuning(k, v.get(k, 0))
 
 

@@ -17,7 +17,7 @@ for spec in sys.argv[1:]:
 res = {i: [] for i in range(len(variants))}
 for rnd in range(4):
     for i, v in enumerate(variants):
-        for k in range(16):
+        for k in range(32):
             L.mik_set_tuning(k, v.get(k, 0))
         res[i].append(A.time_spmv(x, y, reps=20, fused_dot=True))
 gb = A.spmv_algorithmic_bytes() / 1e9

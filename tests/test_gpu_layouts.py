@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 # knob 14 selects the CSR kernel: 0 = tile filled by LDS-DMA + per-row gather (k_spmv_rowgather, default), 1 = products
 # staged through registers (k_spmv_rowblock)
 FORMS = {"csr-rowblock": {8: 1}, "csr-rowblock/products": {8: 1, 14: 1},
-         "sliced-ell": {10: 1, 12: 1}, "sliced-ell+8-bit-column-codes": {12: 1}, "best": {}}
+         "sliced-ell": {10: 1, 12: 1}, "sliced-ell+8-bit-column-codes": {12: 1}, "sliced-ell+slice-offsets+row-masks": {11: 1}, "best": {}}
 
 
 def with_knobs(pkg, knobs, fn):
@@ -49,10 +49,12 @@ def test_spmv_and_cg_identical_in_every_layout(pkg, orc, ctx, case, dtype):
     for form, knobs in FORMS.items():
         def run():
             dA = upload(pkg, A)
-            if form != "best":
+            if form == "sliced-ell+slice-offsets+row-masks" and case == "banded_wide":
+                assert dA.layout() == "sliced-ell+8-bit-column-codes"       # > 8 offsets per slice: no per-slice-offset form at all
+            elif form != "best":
                 assert dA.layout() == form.split("/")[0]
-            elif case != "banded_wide":       # every slice of the stencils uses <= 8 offsets
-                assert dA.layout() == "sliced-ell+slice-offsets+row-masks"
+            elif case != "banded_wide":       # every slice of these constant-coefficient stencils uses <= 8 offsets, one value per slot
+                assert dA.layout() == "slice-offsets+slice-values+row-masks"
             y = pkg.mul_(pkg.HipVector(A.n, dtype), dA, pkg.HipVector.from_numpy(x)).to_numpy()
             xs, ch = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True, maxiter=60) if case != "advdiff" else pkg.gmres(
                 dA, pkg.HipVector.from_numpy(b), log=True, maxiter=40, restart=8)
@@ -102,7 +104,7 @@ def test_rectangular_block_with_halo_columns(pkg, orc, ctx, dist):
         blk = S[r0:r1]
         li, plan = dist.localize_block(blk.indptr.astype(np.int64), blk.indices.astype(np.int64), offsets, r)
         dA = pkg.HipCSR(plan.n_loc, plan.n_loc + plan.n_ghost, blk.indptr.astype(np.int64), li, blk.data, index_base=0, is_csc=False)
-        assert dA.layout() == "sliced-ell+slice-offsets+row-masks"
+        assert dA.layout() == "slice-offsets+slice-values+row-masks"
         xe = np.concatenate([x[r0:r1], x[plan.ghost_gids]])
         y = pkg.mul_(pkg.HipVector(plan.n_loc), dA, pkg.HipVector.from_numpy(xe)).to_numpy()
         assert np.array_equal(y, want[r0:r1])
@@ -139,3 +141,25 @@ def test_csr_kernel_variants_on_ragged_rows(pkg, orc, ctx, dtype):
         if ref is None:
             ref = (res, xs)
         assert np.array_equal(res, ref[0]) and np.array_equal(xs, ref[1]), variant
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_slice_constant_values_only_when_the_bits_agree(pkg, orc, ctx, dtype):
+    """constant-coefficient stencil -> one value per slot and slice; perturb ONE entry (or flip the sign of a zero) and the
+    operator keeps per-row value slots; either way mul! returns the oracle's bits"""
+    A = orc.laplace(13, 3).astype(dtype)
+    x = np.random.default_rng(3).standard_normal(A.n).astype(dtype)
+    assert upload(pkg, A).layout() == "slice-offsets+slice-values+row-masks"
+    B = orc.CSC(A.n, A.colptr, A.rowval, A.nzval.copy(), A.index_base)
+    B.nzval[1234] = np.nextafter(B.nzval[1234], dtype(10))          # one ulp in one entry
+    dB = upload(pkg, B)
+    assert dB.layout() == "sliced-ell+slice-offsets+row-masks"
+    assert np.array_equal(pkg.mul_(pkg.HipVector(A.n, dtype), dB, pkg.HipVector.from_numpy(x)).to_numpy(), orc.spmv(B, x))
+    # variable coefficients that are constant per SLICE still qualify: scale rows slice by slice
+    S = A.to_scipy().tocsr()
+    scale = np.repeat(np.arange(1, (A.n + 255) // 256 + 1, dtype=np.float64), 256)[:A.n]
+    D = orc.CSC.from_scipy(sp.diags(scale) @ S)
+    D = D.astype(dtype)
+    dD = upload(pkg, D)
+    assert dD.layout() == "slice-offsets+slice-values+row-masks"
+    assert np.array_equal(pkg.mul_(pkg.HipVector(A.n, dtype), dD, pkg.HipVector.from_numpy(x)).to_numpy(), orc.spmv(D, x))
