@@ -301,8 +301,9 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiac(int n, int ncols, int 
             xv[g][q] = T(0);
             if (rb[g] >= 0 && q < pt[g]->ns) xv[g][q] = x[min(max(r[g] + pt[g]->off[q], 0), ncols - 1)];   // absent slots gather a valid address
         }
-    // (serving the +-1 neighbours by wave shuffles, as k_spmv_sdia does with a compile-time run position, was measured here
-    //  with the run position read from the pattern: 145 us instead of 112 us -- the selects cost more than two gathers)
+    // Measured and dropped: serving the +-1 neighbours by wave shuffles with the run position read from the pattern (145 us
+    // instead of 112 us: the selects cost more than two gathers); two rows per thread with 16-byte gathers of x, 2-byte mask
+    // loads and 16-byte stores (332 us: the 8-byte-aligned 16-byte gathers are far slower than two 8-byte ones).
     T p[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
