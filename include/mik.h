@@ -417,9 +417,12 @@ int mik_time_spmv(mik_ctx *ctx, const mik_csr *A, const void *x, void *y, int fu
                   double *avg_ms);
 /* In-loop timing of the SpMV launch inside mik_cg_iterate / mik_cg_iterate_many: a HIP event pair
  * on the ctx stream brackets every SpMV launch of the CG step.  First reports the totals gathered
- * so far (either pointer may be NULL), then: enable = 1 resets the totals and switches timing on,
+ * so far (either pointer may be NULL), then: enable = 1 (or 2, see below) resets the totals and switches timing on,
  * 0 switches it off, -1 leaves the mode unchanged. */
 int mik_cg_profile(mik_cg *it, int enable, double *spmv_ms_total, int64_t *spmv_launches);
+/* enable = 2 in mik_cg_profile brackets all three streaming launches of the step; totals per kernel:
+ * [0] the SpMV (src/cg.jl:54), [1] u .= r .+ beta .* u (:51), [2] x / r update + |r|^2 (:58-62).  ms_total / launches: 3 entries each. */
+int mik_cg_profile_kernels(const mik_cg *it, double *ms_total, int64_t *launches);
 
 #ifdef __cplusplus
 }

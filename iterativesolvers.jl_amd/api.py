@@ -618,6 +618,13 @@ class CGIterable:
         check(lib().mik_cg_profile(self.handle, int(enable), C.byref(ms), C.byref(cnt)), "mik_cg_profile", self.A.ctx.handle)
         return ms.value, cnt.value
 
+    def profile_kernels(self):
+        """After ``profile(2)``: {kernel: (total_ms, launches)} for the SpMV, ``u = r + beta u`` and the x / r update."""
+        ms = (C.c_double * 3)()
+        cnt = (C.c_int64 * 3)()
+        check(lib().mik_cg_profile_kernels(self.handle, ms, cnt), "mik_cg_profile_kernels", self.A.ctx.handle)
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(("spmv", "xpby", "update"))}
+
     def __iter__(self):
         iteration = self.start()
         while True:

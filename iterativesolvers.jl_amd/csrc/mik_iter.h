@@ -42,11 +42,12 @@ struct mik_cg {
     unsigned long long seq = 0;      // steps enqueued so far (published by k_cg_fin_res)
     bool dev_done = false;           // device stopping flag known to be set
     // optional in-loop timing of the SpMV launch (HIP events on the ctx stream)
-    bool profile = false;
+    int profile = 0;               // 0 off, 1 = the SpMV launch, 2 = SpMV + the two vector sweeps of the step
     std::vector<hipEvent_t> ev;    // pairs (start, stop), recycled
+    std::vector<int> ev_kind;      // per pair: 0 = SpMV, 1 = u = r + beta u, 2 = x / r update
     size_t ev_used = 0;
-    double spmv_ms = 0;
-    int64_t spmv_launches = 0;
+    double kern_ms[3] = {0, 0, 0};
+    int64_t kern_launches[3] = {0, 0, 0};
 };
 
 // Wait until the device has published step `it->seq` in the host-mapped mirror (bounded spin).

@@ -489,17 +489,35 @@ static int cg_profile_collect(mik_cg *it)
     // stream must be idle (called after a synchronising read-back)
     for (size_t i = 0; i + 1 < it->ev_used; i += 2) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, it->ev[i], it->ev[i + 1]) == hipSuccess) { it->spmv_ms += ms; it->spmv_launches += 1; }
+        const int kind = it->ev_kind[i / 2];
+        if (hipEventElapsedTime(&ms, it->ev[i], it->ev[i + 1]) == hipSuccess) { it->kern_ms[kind] += ms; it->kern_launches[kind] += 1; }
     }
     it->ev_used = 0;
     return MIK_OK;
 }
 
-static hipEvent_t cg_profile_event(mik_cg *it)
-{
-    if (it->ev_used == it->ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; it->ev.push_back(e); }
-    return it->ev[it->ev_used++];
-}
+// HIP events on the ctx stream around one launch of the step (kind: 0 = SpMV, 1 = xpby, 2 = update)
+struct CgProfileScope {
+    mik_cg *it; bool on;
+    CgProfileScope(mik_cg *it_, int kind) : it(it_), on(it_->profile == 2 || (it_->profile == 1 && kind == 0))
+    {
+        if (!on) return;
+        if (it->ev_used + 2 > it->ev.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            it->ev.push_back(a); it->ev.push_back(b);
+            it->ev_kind.push_back(0);
+        }
+        it->ev_kind[it->ev_used / 2] = kind;
+        (void)hipEventRecord(it->ev[it->ev_used], it->ctx->stream);
+    }
+    ~CgProfileScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(it->ev[it->ev_used + 1], it->ctx->stream);
+        it->ev_used += 2;
+    }
+};
 
 // Cache hints of the two vector kernels of a CG step (results unchanged).  x is touched once per iteration, c
 // and u are dead / about to be overwritten after the update, and r has just been read for the last time in
@@ -539,17 +557,20 @@ template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next, 
         MIK_LAUNCH_CHECK(ctx);
         // u .= c .+ beta .* u                                           src/cg.jl:86
         OpXpby<T> op{c, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 1};   // c = Pl \\ r is dead after this sweep
+        CgProfileScope ps(it, 1);
         MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
     } else {
         // u .= r .+ beta .* u                                           src/cg.jl:50-51
         OpXpby<T> op{r, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 7};
+        CgProfileScope ps(it, 1);
         MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
     }
     // c = A * u with the dot(u, c) epilogue                             src/cg.jl:54-55
     if (it->A) {
-        if (it->profile) { hipEvent_t e = cg_profile_event(it); if (e) (void)hipEventRecord(e, ctx->stream); }
-        MIK_TRY(mik_spmv_launch<T>(ctx, it->A, u, c, true, (T *)it->seg_spmv, done));
-        if (it->profile) { hipEvent_t e = cg_profile_event(it); if (e) (void)hipEventRecord(e, ctx->stream); }
+        {
+            CgProfileScope ps(it, 0);
+            MIK_TRY(mik_spmv_launch<T>(ctx, it->A, u, c, true, (T *)it->seg_spmv, done));
+        }
         hipLaunchKernelGGL((k_cg_fin_alpha<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_spmv, nb, d, pcg, (FinScratch<T> *)it->fin);
     } else {
         // any operator: mul!(c, A, u) through the callback; dot(u, c) as its own sweep with the vector tree shape
@@ -561,7 +582,10 @@ template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next, 
     MIK_LAUNCH_CHECK(ctx);
     // x .+= alpha .* u; r .-= alpha .* c; norm(r)                       src/cg.jl:58-62
     OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints() >> 3};
-    MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done)));
+    {
+        CgProfileScope ps(it, 2);
+        MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done)));
+    }
     it->seq += 1;
     hipLaunchKernelGGL((k_cg_fin_res<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_vec, nseg, d, (T *)it->hist,
                        it_next, (long long)it->maxiter, it->mirror, it->seq, hist_index, (FinScratch<T> *)it->fin);
@@ -814,11 +838,21 @@ extern "C" int mik_cg_iterate(mik_cg *it, int64_t iteration, double *residual, i
 extern "C" int mik_cg_profile(mik_cg *it, int enable, double *spmv_ms_total, int64_t *spmv_launches)
 {
     if (!it) return MIK_ERR_INVALID;
-    if (spmv_ms_total) *spmv_ms_total = it->spmv_ms;
-    if (spmv_launches) *spmv_launches = it->spmv_launches;
+    if (spmv_ms_total) *spmv_ms_total = it->kern_ms[0];
+    if (spmv_launches) *spmv_launches = it->kern_launches[0];
     if (enable >= 0) {
-        it->profile = enable != 0;
-        if (enable) { it->spmv_ms = 0; it->spmv_launches = 0; it->ev_used = 0; }
+        it->profile = enable;
+        if (enable) { for (int q = 0; q < 3; ++q) { it->kern_ms[q] = 0; it->kern_launches[q] = 0; } it->ev_used = 0; }
+    }
+    return MIK_OK;
+}
+
+extern "C" int mik_cg_profile_kernels(const mik_cg *it, double *ms_total, int64_t *launches)
+{
+    if (!it) return MIK_ERR_INVALID;
+    for (int q = 0; q < 3; ++q) {
+        if (ms_total) ms_total[q] = it->kern_ms[q];
+        if (launches) launches[q] = it->kern_launches[q];
     }
     return MIK_OK;
 }

@@ -18,6 +18,13 @@ summ = os.path.join(root, "summary")
 os.makedirs(summ, exist_ok=True)
 
 
+def tkey(k):
+    """key of a kernel in <what>_traffic.json: the name up to its template list; k_map / k_map_pro kernels by their Op"""
+    import re
+    m = re.match(r"(k_map(?:_pro)?)<[^,]+, [^,]+, (Op\w+)", k)
+    return f"{m.group(1)}<{m.group(2)}>" if m else k.split("<")[0]
+
+
 def short(name):
     n = name.replace("void ", "").strip()
     return n.split("(")[0][:110]
@@ -64,12 +71,12 @@ for d in sorted(glob.glob(os.path.join(root, "*"))):
             if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
                 rd, wr = 2.0 * m["FETCH_SIZE"] * 1024.0, m["WRITE_SIZE"] * 1024.0
                 der.append(f"HBM-side traffic per launch: read {rd / 1e9:.4f} GB (2 x FETCH_SIZE) + write {wr / 1e9:.4f} GB = {(rd + wr) / 1e9:.4f} GB")
-                kk = k.split("<")[0]
+                kk = tkey(k)
                 traffic[kk] = {"kernel": k, "fetch_bytes_x2": rd, "write_bytes": wr, "traffic_bytes_per_launch": rd + wr}
             if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m:
                 der.append(f"L2 hit rate {m['TCC_HIT_sum'] / (m['TCC_HIT_sum'] + m['TCC_MISS_sum']):.3f}")
-                if k.split("<")[0] in traffic:
-                    traffic[k.split("<")[0]]["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
+                if tkey(k) in traffic:
+                    traffic[tkey(k)]["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
             if "SQ_WAVE_CYCLES" in m and "SQ_WAIT_ANY" in m:
                 der.append(f"SQ_WAIT_ANY / SQ_WAVE_CYCLES = {m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES']:.3f}; "
                            f"SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES = {m.get('SQ_ACTIVE_INST_ANY', 0) / m['SQ_WAVE_CYCLES']:.3f}")
