@@ -329,6 +329,13 @@ class HipCSR:
         check(lib().mik_csr_layout(self.handle, C.byref(out)), "mik_csr_layout", self.ctx.handle)
         return self.LAYOUTS[out.value]
 
+    def spmv_kernel(self) -> str:
+        """Name of the SpMV kernel ``mul_`` launches for this operator in its layout (for profiles / the bench line)."""
+        name = {"csr-rowblock": "k_spmv_rowgather", "sliced-ell": "k_spmv_sell", "sliced-ell+8-bit-column-codes": "k_spmv_sell8",
+                "sliced-ell+slice-offsets+row-masks": "k_spmv_sdia", "slice-offsets+slice-values+row-masks": "k_spmv_sdiac",
+                "dictionary-coded": "k_spmv_packed"}[self.layout()]
+        return name
+
     def spmv_stored_bytes(self) -> int:
         """Bytes one ``mul_`` launch actually streams in the active layout: operator data + x once + y once."""
         out = C.c_int64()
