@@ -342,6 +342,26 @@ static int csr_build_sdia(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
                 }
                 A->sdia_npat = (int)index.size();
                 A->sdia_entries = slots;
+                // k_spmv_sdiab (buffer loads; absent slots read 0.0 and add value * 0): needs finite values and 32-bit byte offsets
+                {
+                    int64_t omin = 0, omax = 0;
+                    bool finite = true;
+                    for (size_t ip = 0; ip < index.size(); ++ip) {
+                        int hdr[2], off[8];
+                        memcpy(hdr, &pats[ip * psz], 8);
+                        memcpy(off, &pats[ip * psz + 8], 32);
+                        for (int q = 0; q < hdr[0]; ++q) {
+                            omin = std::min<int64_t>(omin, off[q]);
+                            omax = std::max<int64_t>(omax, off[q]);
+                            double vq;
+                            if (es == 8) memcpy(&vq, &pats[ip * psz + 40 + 8 * (size_t)q], 8);
+                            else { float f; memcpy(&f, &pats[ip * psz + 40 + 4 * (size_t)q], 4); vq = f; }
+                            finite = finite && std::isfinite(vq);
+                        }
+                    }
+                    A->sdia_koff = (int)(-omin);
+                    A->sdia_buf_ok = finite && (uint64_t)n_rows * es <= 0xFFFFFFF0ull && (uint64_t)(omax - omin) * es < 0x7FFFFFF0ull;
+                }
             } else if (ok) {
                 if ((e = hipMalloc((void **)&A->sdia_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
                     (e = hipMalloc((void **)&A->sdia_off, sizeof(int) * (size_t)nb * 8)) != hipSuccess ||
@@ -880,6 +900,25 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
         // slice patterns {offsets, values} + one mask byte per row (mik_sell.h); G slices per workgroup
         const int G = g_mik_tuning[16] > 0 ? g_mik_tuning[16] : MIK_SDIAC_G;   // development knob 16: 1 / 2 / 4 slices per workgroup
         const int wgs = ((nb + G - 1) / G + 7) / 8 * 8;                         // a multiple of 8: see k_spmv_sdiac
+        if (A->sdia_buf_ok && g_mik_tuning[17] == 0) {                          // development knob 17: 1 = the flat-load kernel
+            // strips of a power-of-two number of row-blocks are mapped by shifts; any other map runs as identity here
+            int sshift = -1, nfull = 0;
+            if (map_mode >= 8) {
+                const int S = map_mode >> 3;
+                if ((S & (S - 1)) == 0) { sshift = 0; while ((1 << sshift) < S) ++sshift; nfull = nb / map_mode * map_mode; }
+            }
+#define MIK_SDIAB_GO3(FD, NTV, GG)                                                                                             \
+    hipLaunchKernelGGL((k_spmv_sdiab<T, FD, NTV, GG>), dim3(wgs), dim3(MIK_BLOCK), 0, ctx->stream, n, A->sdia_koff, rb0, nb, nfull, sshift, \
+                       A->sdia_pat_id, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done)
+#define MIK_SDIAB_GO(FD, NTV)                                                                      \
+    do { if (G == 1) MIK_SDIAB_GO3(FD, NTV, 1); else if (G == 4) MIK_SDIAB_GO3(FD, NTV, 4); else MIK_SDIAB_GO3(FD, NTV, 2); } while (0)
+            if (fuse_dot) { if (nt) MIK_SDIAB_GO(true, true); else MIK_SDIAB_GO(true, false); }
+            else          { if (nt) MIK_SDIAB_GO(false, true); else MIK_SDIAB_GO(false, false); }
+#undef MIK_SDIAB_GO3
+#undef MIK_SDIAB_GO
+            MIK_LAUNCH_CHECK(ctx);
+            return MIK_OK;
+        }
 #define MIK_SDIAC_GO3(FD, NTV, GG)                                                                                             \
     hipLaunchKernelGGL((k_spmv_sdiac<T, FD, NTV, GG>), dim3(wgs), dim3(MIK_BLOCK), 0, ctx->stream, n, (int)A->n_cols, rb0, nb, map_mode, A->sdia_pat_id, \
                        (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done)

@@ -83,6 +83,8 @@ struct mik_csr {
     void *sdia_pats = nullptr;       // device, sdia_npat patterns (SdiaPattern<T>), or NULL
     int *sdia_pat_id = nullptr;      // device, nb
     int sdia_npat = 0;
+    bool sdia_buf_ok = false;        // k_spmv_sdiab applies: finite pattern values, 32-bit row / slot byte offsets
+    int sdia_koff = 0;               // - (most negative slot offset) of the operator, >= 0
     // optional dictionary-coded form (mik_csr_pack): one 16-bit code per entry + two <= 256-entry tables
     unsigned short *codes = nullptr; // device, nnz (+ padding)
     void *vtab = nullptr;            // device, 256 values of dtype
@@ -158,11 +160,36 @@ template <typename T> struct Coef {
 template <typename T> static inline Coef<T> coef_val(T v) { return Coef<T>{nullptr, v}; }
 template <typename T> static inline Coef<T> coef_ptr(const T *p) { return Coef<T>{p, T(0)}; }
 
+// The value `OFF` lanes further down the wave (OFF = 32, 16: gfx950 lane-swap instructions; 8, 4, 2, 1: DPP shifts inside a
+// 16-lane row) for the lanes a shuffle-down tree reads at that level (lane l < OFF; other lanes: unspecified).  All of it
+// runs on the vector ALU; __shfl_down goes through the LDS crossbar (ds_bpermute) and costs a wave ~12 dependent LDS
+// round trips per tree.
+template <int OFF> __device__ __forceinline__ unsigned lane_down_u32(unsigned v)
+{
+    if (OFF == 32) return __builtin_amdgcn_permlane32_swap(v, v, false, false)[1];   // lanes 0..31 <- lanes 32..63
+    if (OFF == 16) return __builtin_amdgcn_permlane16_swap(v, v, false, false)[1];   // rows 0, 2 <- rows 1, 3
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + OFF, 0xf, 0xf, true);   // row_shl:OFF
+}
+template <int OFF> __device__ __forceinline__ double lane_down(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = lane_down_u32<OFF>((unsigned)b), hi = lane_down_u32<OFF>((unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <int OFF> __device__ __forceinline__ float lane_down(float v)
+{
+    return __builtin_bit_cast(float, lane_down_u32<OFF>(__builtin_bit_cast(unsigned, v)));
+}
+
 // wave-64 shuffle-down tree, offsets 32..1; the value in lane 0 is the tree sum
 template <typename T> __device__ __forceinline__ T wave_tree(T v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_down(v, off, 64);
+    v = v + lane_down<32>(v);
+    v = v + lane_down<16>(v);
+    v = v + lane_down<8>(v);
+    v = v + lane_down<4>(v);
+    v = v + lane_down<2>(v);
+    v = v + lane_down<1>(v);
     return v;
 }
 

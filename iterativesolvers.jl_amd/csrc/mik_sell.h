@@ -336,5 +336,120 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiac(int n, int ncols, int 
     }
 }
 
+// The slice-constant layout through BUFFER loads.  k_spmv_sdiac spends its time issuing instructions, not waiting for
+// memory: ~180 vector-ALU instructions per row for 7 multiply-adds (address clamps so that absent slots gather a valid
+// element, mask tests and selects around every add, 64-bit address arithmetic), 77 us of VALU issue alone at 256^3.
+// Here x is read through a buffer descriptor: the hardware adds a per-slot SCALAR offset (the slot's column offset) to
+// a per-row vector offset and returns ZERO for a vector offset outside the descriptor's range -- so an absent slot just
+// ORs all-ones into its row offset (one v_bfe of the inverted mask, one v_or), reads 0.0, and contributes value * 0 =
+// +-0, which leaves the sum bit for bit as it was (the sum starts from +0 and +0 + -0 = +0, any other acc + +-0 = acc).
+// No clamp, no select, no 64-bit add: 4 VALU per slot (bfe, or, mul, add).  Used when every pattern value is finite
+// (Inf * 0 would be NaN), and row and slot offsets fit the 32-bit fields (mik_csr_create decides: sdia_buf_ok).
+// The descriptor's base is x - koff elements (koff = the most negative slot offset of the operator), so every scalar
+// offset (off[q] + koff) * sizeof(T) is non-negative; addresses below x are formed but never read.
+template <typename T> __device__ __forceinline__ T buffer_gather(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff);
+template <> __device__ __forceinline__ double buffer_gather<double>(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff)
+{
+    typedef unsigned mik_u32x2 __attribute__((ext_vector_type(2)));
+    const mik_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, soff, 0);
+    return __builtin_bit_cast(double, v);
+}
+template <> __device__ __forceinline__ float buffer_gather<float>(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff)
+{
+    const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, soff, 0);
+    return __builtin_bit_cast(float, v);
+}
+
+// spmv_block_map for strips of a power-of-two number of row-blocks: P = 8 << sshift row-blocks per plane, `nfull` =
+// the row-blocks in whole planes ((nb / P) * P, computed by the host); sshift < 0: identity
+__device__ __forceinline__ int spmv_block_map_shift(int b, int nfull, int sshift)
+{
+    if (sshift >= 0 && b < nfull) {
+        const int xcd = b & 7, q = b >> 3;
+        return ((q >> sshift) << (sshift + 3)) + (xcd << sshift) + (q & ((1 << sshift) - 1));
+    }
+    return b;
+}
+
+template <typename T, bool FUSE_DOT, bool NT, int G>
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab(int n, int koff, int rb0, int nb, int nfull, int sshift, const int *__restrict__ pat_id,
+                                                          const SdiaPattern<T> *__restrict__ pats, const unsigned char *__restrict__ mask,
+                                                          const T *__restrict__ x, T *__restrict__ y, T *__restrict__ seg_out,
+                                                          const int *__restrict__ done)
+{
+    if (done && *done) return;
+    constexpr int U = 8;
+    constexpr unsigned ES = (unsigned)sizeof(T);
+    __shared__ T lds[G][4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    // rows are addressed by a 32-bit byte offset; only offsets below n * sizeof(T) are in range
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((uintptr_t)x - (uintptr_t)koff * ES), (short)0,
+                                                                        (int)0xFFFFFFF0u, (int)0x00020000);
+    int rb[G], minv[G];
+    unsigned rowoff[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {                       // virtual blocks blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8)
+        const int vb = min((int)blockIdx.x + g * (int)gridDim.x, nb - 1);   // past the end: the last block once more (same bits)
+        rb[g] = rb0 + spmv_block_map_shift(vb, nfull, sshift);
+        const int r = rb[g] * MIK_BLOCK + t;
+        rowoff[g] = (unsigned)r * ES;
+        minv[g] = ~(int)ld_stream<NT>(mask + min(r, n - 1)) | (r < n ? 0 : -1);     // bit q set: this row has no slot q
+    }
+    SdiaPattern<T> P[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) P[g] = pats[pat_id[rb[g]]];
+#pragma unroll
+    for (int g = 0; g < G; ++g) asm volatile("" : "+v"(minv[g]));       // all masks have arrived before the first gather is issued
+    unsigned voff[G][U];                                // every mask is consumed here, before the first gather is issued
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int q = 0; q < U; ++q) voff[g][q] = rowoff[g] | (unsigned)__builtin_amdgcn_sbfe(minv[g], q, 1);   // absent: all ones
+    T xv[G][U];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            xv[g][q] = T(0);
+            if (q < P[g].ns) xv[g][q] = buffer_gather<T>(rs, voff[g][q], (P[g].off[q] + koff) * (int)ES);
+        }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        T acc = T(0), xr = T(0);
+        int cq = -1;
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            if (q < P[g].ns) {
+                if (P[g].off[q] == 0) { xr = xv[g][q]; cq = q; }
+                T pr = P[g].val[q] * xv[g][q];
+                acc = acc + pr;
+            }
+        }
+        const int r = (int)(rowoff[g] / ES);
+        if (r < n) st_stream<NT>(y + r, acc);
+        if (FUSE_DOT) {
+            T pd = T(0);
+            if (r < n) {
+                if (cq < 0 || ((minv[g] >> cq) & 1)) xr = x[r];          // no diagonal slot in this row
+                pd = xr * acc;
+            }
+            const T ws = wave_tree(pd);
+            if (lane == 0) lds[g][w] = ws;
+        }
+    }
+    if (FUSE_DOT) {                                   // one partial per slice: the 4 wave sums left to right
+        __syncthreads();
+        if (t < G) {
+            T tot = lds[t][0];
+            tot = tot + lds[t][1]; tot = tot + lds[t][2]; tot = tot + lds[t][3];
+            int rbt = rb[0];
+#pragma unroll
+            for (int g = 1; g < G; ++g)
+                if (t == g) rbt = rb[g];
+            seg_out[rbt] = tot;
+        }
+    }
+}
+
 #endif  // __HIPCC__
 #endif  // MIK_SELL_H
