@@ -313,24 +313,74 @@ static int csr_build_sdia(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
                 }
             }
             if (ok && constant) {
-                // equal slice descriptions {ns, tri, offsets, value bits} are stored once; a slice keeps a pattern index
-                const size_t psz = 8 + 32 + 8 * es;                        // sizeof(SdiaPattern<T>): 2 ints, 8 ints, 8 values
+                // equal slice descriptions {ns, tri, centre slot, diagonal-in-every-row, offsets, value bits} are stored once
+                // (SdiaPattern<T>: 4 ints, 8 offsets, 8 scalar byte offsets filled below, 8 values); a slice keeps a pattern index
+                const size_t psz = 16 + 32 + 32 + 8 * es, voff0 = 80;
                 std::map<std::string, int> index;
                 std::vector<unsigned char> pats;
                 std::vector<int> pid((size_t)nb, 0);
+                std::vector<int64_t> slices_of;                            // slices per pattern
                 for (int64_t b = 0; b < nb; ++b) {
                     std::string key(psz, '\0');
                     const int ns = (dptr[(size_t)b + 1] - dptr[(size_t)b]) / MIK_BLOCK;
-                    int hdr[2] = {ns, dtri[(size_t)b]};
-                    memcpy(&key[0], hdr, 8);
-                    memcpy(&key[8], &doff[(size_t)b * 8], 32);
-                    memcpy(&key[40], &cval[(size_t)b * 8 * es], 8 * es);
+                    int cq = -1;
+                    for (int q = 0; q < ns; ++q)
+                        if (doff[(size_t)b * 8 + q] == 0) cq = q;
+                    int dfull = cq >= 0;
+                    for (int64_t r = b * MIK_BLOCK; dfull && r < std::min<int64_t>(n_rows, (b + 1) * MIK_BLOCK); ++r)
+                        dfull = (dmask[(size_t)r] >> cq) & 1;
+                    int hdr[4] = {ns, dtri[(size_t)b], cq, dfull};
+                    memcpy(&key[0], hdr, 16);
+                    memcpy(&key[16], &doff[(size_t)b * 8], 32);
+                    memcpy(&key[voff0], &cval[(size_t)b * 8 * es], 8 * es);
                     auto it = index.find(key);
                     if (it == index.end()) {
                         it = index.emplace(key, (int)index.size()).first;
                         pats.insert(pats.end(), key.begin(), key.end());
+                        slices_of.push_back(0);
                     }
                     pid[(size_t)b] = it->second;
+                    ++slices_of[(size_t)it->second];
+                }
+                // k_spmv_sdiab (buffer loads; absent slots read 0.0 and add value * 0): needs finite values and 32-bit byte
+                // offsets; the scalar offset of slot q is (off[q] + koff) * sizeof(T), koff = - the operator's smallest offset
+                {
+                    int64_t omin = 0, omax = 0;
+                    bool finite = true;
+                    for (size_t ip = 0; ip < index.size(); ++ip) {
+                        int hdr[4], off[8];
+                        memcpy(hdr, &pats[ip * psz], 16);
+                        memcpy(off, &pats[ip * psz + 16], 32);
+                        for (int q = 0; q < hdr[0]; ++q) {
+                            omin = std::min<int64_t>(omin, off[q]);
+                            omax = std::max<int64_t>(omax, off[q]);
+                            double vq;
+                            if (es == 8) memcpy(&vq, &pats[ip * psz + voff0 + 8 * (size_t)q], 8);
+                            else { float f; memcpy(&f, &pats[ip * psz + voff0 + 4 * (size_t)q], 4); vq = f; }
+                            finite = finite && std::isfinite(vq);
+                        }
+                    }
+                    A->sdia_koff = (int)(-omin);
+                    A->sdia_buf_ok = finite && (uint64_t)n_rows * es <= 0xFFFFFFF0ull && (uint64_t)(omax - omin) * es < 0x7FFFFFF0ull;
+                    // the (slots, centre slot) class most slices have, among the ones k_spmv_sdiab is specialised for
+                    int64_t best = 0;
+                    A->sdia_cls = 0;
+                    for (int c = 1; c < MIK_SDIAB_NCLS; ++c) {
+                        int64_t cnt = 0;
+                        for (size_t ip = 0; ip < index.size(); ++ip) {
+                            int hdr[4];
+                            memcpy(hdr, &pats[ip * psz], 16);
+                            if (hdr[0] == mik_sdiab_cls_ns(c) && hdr[2] == mik_sdiab_cls_cq(c)) cnt += slices_of[ip];
+                        }
+                        if (cnt > best) { best = cnt; A->sdia_cls = c; }
+                    }
+                    if (A->sdia_buf_ok)
+                        for (size_t ip = 0; ip < index.size(); ++ip) {
+                            int off[8], soff[8];
+                            memcpy(off, &pats[ip * psz + 16], 32);
+                            for (int q = 0; q < 8; ++q) soff[q] = (int)(((int64_t)off[q] + A->sdia_koff) * (int64_t)es);
+                            memcpy(&pats[ip * psz + 48], soff, 32);
+                        }
                 }
                 if ((e = hipMalloc((void **)&A->sdia_pat_id, sizeof(int) * (size_t)nb)) != hipSuccess ||
                     (e = hipMalloc((void **)&A->sdia_mask, (size_t)n_rows)) != hipSuccess ||
@@ -342,26 +392,6 @@ static int csr_build_sdia(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
                 }
                 A->sdia_npat = (int)index.size();
                 A->sdia_entries = slots;
-                // k_spmv_sdiab (buffer loads; absent slots read 0.0 and add value * 0): needs finite values and 32-bit byte offsets
-                {
-                    int64_t omin = 0, omax = 0;
-                    bool finite = true;
-                    for (size_t ip = 0; ip < index.size(); ++ip) {
-                        int hdr[2], off[8];
-                        memcpy(hdr, &pats[ip * psz], 8);
-                        memcpy(off, &pats[ip * psz + 8], 32);
-                        for (int q = 0; q < hdr[0]; ++q) {
-                            omin = std::min<int64_t>(omin, off[q]);
-                            omax = std::max<int64_t>(omax, off[q]);
-                            double vq;
-                            if (es == 8) memcpy(&vq, &pats[ip * psz + 40 + 8 * (size_t)q], 8);
-                            else { float f; memcpy(&f, &pats[ip * psz + 40 + 4 * (size_t)q], 4); vq = f; }
-                            finite = finite && std::isfinite(vq);
-                        }
-                    }
-                    A->sdia_koff = (int)(-omin);
-                    A->sdia_buf_ok = finite && (uint64_t)n_rows * es <= 0xFFFFFFF0ull && (uint64_t)(omax - omin) * es < 0x7FFFFFF0ull;
-                }
             } else if (ok) {
                 if ((e = hipMalloc((void **)&A->sdia_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
                     (e = hipMalloc((void **)&A->sdia_off, sizeof(int) * (size_t)nb * 8)) != hipSuccess ||
@@ -799,7 +829,7 @@ extern "C" int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes)
     const int64_t es = (int64_t)mik_dtype_size(A->dtype);
     const int64_t nb = (A->n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
     switch (layout) {
-    case 5: *bytes = A->n_rows + nb * 4 + (int64_t)A->sdia_npat * (40 + 8 * es); break;
+    case 5: *bytes = A->n_rows + nb * 4 + (int64_t)A->sdia_npat * (80 + 8 * es); break;
     case 4: *bytes = A->sdia_entries * es + A->n_rows + nb * 36; break;
     case 3: *bytes = A->nnz * 2 + (A->n_rows + 1) * 4 + 256 * (es + 4); break;
     case 2: *bytes = A->sell_entries * es + A->sell8_bytes + (nb + 1) * 8 + 256 * 4; break;
@@ -907,13 +937,18 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
                 const int S = map_mode >> 3;
                 if ((S & (S - 1)) == 0) { sshift = 0; while ((1 << sshift) < S) ++sshift; nfull = nb / map_mode * map_mode; }
             }
-#define MIK_SDIAB_GO3(FD, NTV, GG)                                                                                             \
-    hipLaunchKernelGGL((k_spmv_sdiab<T, FD, NTV, GG>), dim3(wgs), dim3(MIK_BLOCK), 0, ctx->stream, n, A->sdia_koff, rb0, nb, nfull, sshift, \
-                       A->sdia_pat_id, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done)
+#define MIK_SDIAB_GO4(FD, NTV, GG, C)                                                                                                      \
+    hipLaunchKernelGGL((k_spmv_sdiab<T, FD, NTV, GG, mik_sdiab_cls_ns(C), mik_sdiab_cls_cq(C)>), dim3(wgs), dim3(MIK_BLOCK), 0, ctx->stream, n, A->sdia_koff, \
+                       rb0, nb, nfull, sshift, A->sdia_pat_id, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done)
+#define MIK_SDIAB_GO3(FD, NTV, GG)                                                                                                          \
+    do { if (cls == 1) MIK_SDIAB_GO4(FD, NTV, GG, 1); else if (cls == 2) MIK_SDIAB_GO4(FD, NTV, GG, 2); else if (cls == 3) MIK_SDIAB_GO4(FD, NTV, GG, 3); \
+         else MIK_SDIAB_GO4(FD, NTV, GG, 0); } while (0)
 #define MIK_SDIAB_GO(FD, NTV)                                                                      \
-    do { if (G == 1) MIK_SDIAB_GO3(FD, NTV, 1); else if (G == 4) MIK_SDIAB_GO3(FD, NTV, 4); else MIK_SDIAB_GO3(FD, NTV, 2); } while (0)
+    do { if (G == 1) MIK_SDIAB_GO4(FD, NTV, 1, 0); else if (G == 4) MIK_SDIAB_GO4(FD, NTV, 4, 0); else MIK_SDIAB_GO3(FD, NTV, 2); } while (0)
+            const int cls = g_mik_tuning[18] == 1 ? 0 : A->sdia_cls;            // development knob 18: 1 = slot-by-slot path only
             if (fuse_dot) { if (nt) MIK_SDIAB_GO(true, true); else MIK_SDIAB_GO(true, false); }
             else          { if (nt) MIK_SDIAB_GO(false, true); else MIK_SDIAB_GO(false, false); }
+#undef MIK_SDIAB_GO4
 #undef MIK_SDIAB_GO3
 #undef MIK_SDIAB_GO
             MIK_LAUNCH_CHECK(ctx);

@@ -266,8 +266,10 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdia(int n, int ncols, int r
 #define MIK_SDIAC_G 2       // slices per workgroup of k_spmv_sdiac
 #endif
 template <typename T> struct SdiaPattern {
-    int ns, tri;
+    int ns, tri;        // slots used; first slot of an (o - 1, o, o + 1) run or -1
+    int cq, dfull;      // the slot with offset 0 (-1: none); 1 = every row of the slice has it
     int off[8];
+    int soff[8];        // (off[q] + koff) * sizeof(T): the scalar byte offsets of k_spmv_sdiab
     T val[8];
 };
 
@@ -371,7 +373,16 @@ __device__ __forceinline__ int spmv_block_map_shift(int b, int nfull, int sshift
     return b;
 }
 
-template <typename T, bool FUSE_DOT, bool NT, int G>
+// The kernel issues instructions, it does not wait for memory (a CU retires one scalar instruction per clock for all of
+// its waves: the ~400 scalar instructions per wave of the slot-by-slot form -- "does the slice have slot q", "is it the
+// diagonal", offset arithmetic -- were 85 us of its 91).  So the common (slots, centre slot) CLASS of the operator is
+// compiled in: template NS / CQ; a workgroup whose slices all have NS slots with the diagonal in slot CQ runs
+// straight-line code (per slot: v_bfe, v_or, buffer_load, v_mul, v_add), any other workgroup the slot-by-slot path.
+constexpr int MIK_SDIAB_NCLS = 4;   // 0: none; 1: 7 slots, centre 3 (3-D 7-point); 2: 5 slots, centre 2 (2-D 5-point); 3: 3 slots, centre 1
+__host__ __device__ constexpr int mik_sdiab_cls_ns(int c) { return c == 1 ? 7 : c == 2 ? 5 : c == 3 ? 3 : 0; }
+__host__ __device__ constexpr int mik_sdiab_cls_cq(int c) { return c == 1 ? 3 : c == 2 ? 2 : c == 3 ? 1 : -1; }
+
+template <typename T, bool FUSE_DOT, bool NT, int G, int NS, int CQ>
 __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab(int n, int koff, int rb0, int nb, int nfull, int sshift, const int *__restrict__ pat_id,
                                                           const SdiaPattern<T> *__restrict__ pats, const unsigned char *__restrict__ mask,
                                                           const T *__restrict__ x, T *__restrict__ y, T *__restrict__ seg_out,
@@ -382,57 +393,75 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab(int n, int koff, int r
     constexpr unsigned ES = (unsigned)sizeof(T);
     __shared__ T lds[G][4];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    // rows are addressed by a 32-bit byte offset; only offsets below n * sizeof(T) are in range
+    // rows are addressed by a 32-bit byte offset; an offset of all ones is out of the descriptor's range (reads 0)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((uintptr_t)x - (uintptr_t)koff * ES), (short)0,
                                                                         (int)0xFFFFFFF0u, (int)0x00020000);
-    int rb[G], minv[G];
-    unsigned rowoff[G];
+    int rb[G], minv[G], rr[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {                       // virtual blocks blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8)
         const int vb = min((int)blockIdx.x + g * (int)gridDim.x, nb - 1);   // past the end: the last block once more (same bits)
         rb[g] = rb0 + spmv_block_map_shift(vb, nfull, sshift);
-        const int r = rb[g] * MIK_BLOCK + t;
-        rowoff[g] = (unsigned)r * ES;
-        minv[g] = ~(int)ld_stream<NT>(mask + min(r, n - 1)) | (r < n ? 0 : -1);     // bit q set: this row has no slot q
+        rr[g] = rb[g] * MIK_BLOCK + t;
+        minv[g] = ~(int)ld_stream<NT>(mask + min(rr[g], n - 1)) | (rr[g] < n ? 0 : -1);     // bit q set: this row has no slot q
     }
-    SdiaPattern<T> P[G];
+    const SdiaPattern<T> *__restrict__ pt[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) P[g] = pats[pat_id[rb[g]]];
+    for (int g = 0; g < G; ++g) pt[g] = pats + pat_id[rb[g]];
+    bool fast = NS > 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) fast = fast & (pt[g]->ns == NS) & (pt[g]->cq == CQ);
 #pragma unroll
     for (int g = 0; g < G; ++g) asm volatile("" : "+v"(minv[g]));       // all masks have arrived before the first gather is issued
-    unsigned voff[G][U];                                // every mask is consumed here, before the first gather is issued
+    T acc[G], xr[G];
+    if (fast) {
+        constexpr int NQ = NS > 0 ? NS : 1, CC = CQ >= 0 ? CQ : 0;
+        T xv[G][NQ];
 #pragma unroll
-    for (int g = 0; g < G; ++g)
+        for (int g = 0; g < G; ++g) {
+            const unsigned rowoff = (unsigned)rr[g] * ES;
 #pragma unroll
-        for (int q = 0; q < U; ++q) voff[g][q] = rowoff[g] | (unsigned)__builtin_amdgcn_sbfe(minv[g], q, 1);   // absent: all ones
-    T xv[G][U];
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int q = 0; q < U; ++q) {
-            xv[g][q] = T(0);
-            if (q < P[g].ns) xv[g][q] = buffer_gather<T>(rs, voff[g][q], (P[g].off[q] + koff) * (int)ES);
+            for (int q = 0; q < NQ; ++q)
+                xv[g][q] = buffer_gather<T>(rs, rowoff | (unsigned)__builtin_amdgcn_sbfe(minv[g], q, 1), pt[g]->soff[q]);
         }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            T a = T(0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { T pr = pt[g]->val[q] * xv[g][q]; a = a + pr; }
+            acc[g] = a;
+            xr[g] = xv[g][CC];
+            if (FUSE_DOT && !pt[g]->dfull && ((minv[g] >> CC) & 1) && rr[g] < n) xr[g] = x[rr[g]];   // a row without a diagonal entry
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const unsigned rowoff = (unsigned)rr[g] * ES;
+            const int ns = pt[g]->ns, cq = pt[g]->cq;
+            T xv[U];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                xv[q] = T(0);
+                if (q < ns) xv[q] = buffer_gather<T>(rs, rowoff | (unsigned)__builtin_amdgcn_sbfe(minv[g], q, 1), pt[g]->soff[q]);
+            }
+            T a = T(0), c = T(0);
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                if (q < ns) {
+                    if (q == cq) c = xv[q];
+                    T pr = pt[g]->val[q] * xv[q];
+                    a = a + pr;
+                }
+            }
+            acc[g] = a;
+            xr[g] = c;
+            if (FUSE_DOT && rr[g] < n && (cq < 0 || ((minv[g] >> cq) & 1))) xr[g] = x[rr[g]];
+        }
+    }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        T acc = T(0), xr = T(0);
-        int cq = -1;
-#pragma unroll
-        for (int q = 0; q < U; ++q) {
-            if (q < P[g].ns) {
-                if (P[g].off[q] == 0) { xr = xv[g][q]; cq = q; }
-                T pr = P[g].val[q] * xv[g][q];
-                acc = acc + pr;
-            }
-        }
-        const int r = (int)(rowoff[g] / ES);
-        if (r < n) st_stream<NT>(y + r, acc);
+        if (rr[g] < n) st_stream<NT>(y + rr[g], acc[g]);
         if (FUSE_DOT) {
-            T pd = T(0);
-            if (r < n) {
-                if (cq < 0 || ((minv[g] >> cq) & 1)) xr = x[r];          // no diagonal slot in this row
-                pd = xr * acc;
-            }
+            const T pd = rr[g] < n ? xr[g] * acc[g] : T(0);
             const T ws = wave_tree(pd);
             if (lane == 0) lds[g][w] = ws;
         }
