@@ -94,6 +94,20 @@ for d in sorted(glob.glob(os.path.join(root, "*"))):
                 der.append(f"TCP pending-stall cycles / TCP active cycles = {m['TCP_PENDING_STALL_CYCLES_sum'] / m['TCP_GATE_EN1_sum']:.3f}")
             if "TCP_TCC_READ_REQ_sum" in m and m.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
                 der.append(f"L1 (TCP) -> L2 read requests / TCP cache accesses = {m['TCP_TCC_READ_REQ_sum'] / m['TCP_TOTAL_CACHE_ACCESSES_sum']:.3f}")
+            if "SQ_ACTIVE_INST_VALU" in m and "SQ_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m:
+                # SQ_ACTIVE_INST_* count cycles (x4: the counters tick once per 4 clocks on this part? no -- they are summed over
+                # the SIMDs of all CUs); normalised here per SIMD: / (1024 SIMDs x kernel cycles)
+                cyc = m["GRBM_GUI_ACTIVE"] / 8.0
+                per = lambda c: m.get(c, 0.0) / (1024.0 * cyc)
+                der.append("issue activity per SIMD (counter / (1024 SIMDs x kernel cycles)): "
+                           f"VALU {per('SQ_ACTIVE_INST_VALU'):.3f}, scalar {per('SQ_ACTIVE_INST_SCA'):.3f}, VMEM {per('SQ_ACTIVE_INST_VMEM'):.3f}, "
+                           f"LDS {per('SQ_ACTIVE_INST_LDS'):.3f}, misc {per('SQ_ACTIVE_INST_MISC'):.3f}; SALU inst cycles {per('SQ_INST_CYCLES_SALU'):.3f}")
+            if "SQ_INST_LEVEL_VMEM" in m and "SQ_LEVEL_WAVES" in m and "GRBM_GUI_ACTIVE" in m:
+                cyc = m["GRBM_GUI_ACTIVE"] / 8.0
+                der.append(f"mean resident waves per CU {m['SQ_LEVEL_WAVES'] / (256.0 * cyc):.2f}; mean vector-memory instructions in flight per CU "
+                           f"{m['SQ_INST_LEVEL_VMEM'] / (256.0 * cyc):.2f} (scalar-memory {m.get('SQ_INST_LEVEL_SMEM', 0) / (256.0 * cyc):.2f}); "
+                           f"TA address FIFO full {m.get('SQ_VMEM_TA_ADDR_FIFO_FULL', 0) / (256.0 * cyc):.3f}, TA command FIFO full "
+                           f"{m.get('SQ_VMEM_TA_CMD_FIFO_FULL', 0) / (256.0 * cyc):.3f} of the cycles")
             for line in der:
                 o.write(f"    => {line}\n")
     if traffic:

@@ -32,6 +32,8 @@ for w in $WHAT; do
   pmc $D/pmc_tcp TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum -- $B
   pmc $D/pmc_tcp2 TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum -- $B
   pmc $D/pmc_grbm GRBM_GUI_ACTIVE -- $B
+  pmc $D/pmc_issue SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH SQ_BUSY_CYCLES -- $B
+  pmc $D/pmc_level SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_SMEM SQ_LEVEL_WAVES SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_SMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL -- $B
   ;;
  c5)
   D=$OUT/c5; mkdir -p $D
