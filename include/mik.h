@@ -114,7 +114,8 @@ int mik_spmv_long_segment(int *segment);
  *   8: 1 = CSR row-block layout only (read at mik_csr_create and at launch)    9: 1 = GMRES: no Arnoldi column enqueued ahead of the host
  *  10: 1 = no 8-bit column codes        11: 1 = no slice-constant values        12: 1 = no per-slice-offset layout
  *  13: bit mask switching the Krylov-basis streaming hints off    14: CSR kernel: 0 = by operator, 1 = register-staged products, 2 = LDS-DMA tile + per-row gather
- *  15: long-row segment length (> 0; read at mik_csr_create) */
+ *  15: long-row segment length (> 0; read at mik_csr_create)   16: slices per workgroup of the layout-5 kernels (1 / 2 / 4)
+ *  17: 1 = layout 5 through flat loads (k_spmv_sdiac)              18: 1 = k_spmv_sdiab without the compiled-in slot class */
 int mik_set_tuning(int key, int value);
 
 /* ---- device memory (similar / zero / copyto! / fill! of the vector interface) ----------- */
@@ -148,6 +149,10 @@ int mik_csr_pack(mik_csr *A);
  * (within a slice every row that has a slot carries the same value there -- constant-coefficient stencils): the slice
  * stores its <= 8 values once and a row is one mask byte. */
 int mik_csr_layout(const mik_csr *A, int *layout);
+/* Name of the kernel mik_spmv launches for this operator now (layout, operator properties, development knobs): for
+ * profiles and the bench line.  Layout 5 runs k_spmv_sdiab (x through buffer loads: a slot a row does not have reads 0.0 by
+ * the descriptor's range check) when every slice value is finite and the offsets fit 32 bits, else k_spmv_sdiac. */
+int mik_spmv_kernel(const mik_csr *A, char *name, int len);
 /* Bytes of operator data (values, indices / codes, pointers) one mik_spmv launch streams in that layout. */
 int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes);
 /* size(A, d), nnz, eltype(A) */

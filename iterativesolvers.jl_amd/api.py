@@ -330,11 +330,10 @@ class HipCSR:
         return self.LAYOUTS[out.value]
 
     def spmv_kernel(self) -> str:
-        """Name of the SpMV kernel ``mul_`` launches for this operator in its layout (for profiles / the bench line)."""
-        name = {"csr-rowblock": "k_spmv_rowgather", "sliced-ell": "k_spmv_sell", "sliced-ell+8-bit-column-codes": "k_spmv_sell8",
-                "sliced-ell+slice-offsets+row-masks": "k_spmv_sdia", "slice-offsets+slice-values+row-masks": "k_spmv_sdiac",
-                "dictionary-coded": "k_spmv_packed"}[self.layout()]
-        return name
+        """Name of the SpMV kernel ``mul_`` launches for this operator now (``mik_spmv_kernel``; for profiles / the bench line)."""
+        buf = C.create_string_buffer(64)
+        check(lib().mik_spmv_kernel(self.handle, buf, 64), "mik_spmv_kernel", self.ctx.handle)
+        return buf.value.decode()
 
     def spmv_stored_bytes(self) -> int:
         """Bytes one ``mul_`` launch actually streams in the active layout: operator data + x once + y once."""

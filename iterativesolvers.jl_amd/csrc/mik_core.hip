@@ -222,6 +222,36 @@ extern "C" int mik_fill(mik_ctx *ctx, int dtype, int64_t n, const void *value, v
     return dtype == MIK_F64 ? fill_impl<double>(ctx, n, value, x) : fill_impl<float>(ctx, n, value, x);
 }
 
+// k_spmv_sdiab relies on two properties of raw buffer loads on this GPU: the scalar offset is added to the address, and a
+// vector offset of all ones is out of range and reads 0.0 whatever the scalar offset.  Checked once per process on the
+// device itself; if the probe disagrees the slice-constant layout keeps its flat-load kernel (k_spmv_sdiac).
+__global__ void k_probe_buffer_range(const double *x, double *out)
+{
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)x, (short)0, (int)0xFFFFFFF0u, (int)0x00020000);
+    const int t = threadIdx.x;
+    out[t] = buffer_gather<double>(rs, (t & 1) ? ~0u : (unsigned)t * 4u, 8);     // even lanes: x[t / 2 + 1]; odd lanes: out of range
+}
+
+static bool buffer_range_semantics_ok(mik_ctx *ctx)
+{
+    static int state = -1;                                                         // -1 unknown, 0 no, 1 yes
+    if (state >= 0) return state == 1;
+    double h[16], r[8], *d = nullptr;
+    for (int i = 0; i < 16; ++i) h[i] = 1.0 + i;
+    state = 0;
+    if (hipMalloc((void **)&d, sizeof(h) + sizeof(r)) != hipSuccess) return false;
+    if (hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) == hipSuccess) {
+        hipLaunchKernelGGL(k_probe_buffer_range, dim3(1), dim3(8), 0, ctx->stream, d, d + 16);
+        if (hipStreamSynchronize(ctx->stream) == hipSuccess && hipMemcpy(r, d + 16, sizeof(r), hipMemcpyDeviceToHost) == hipSuccess) {
+            bool ok = true;
+            for (int t = 0; t < 8; ++t) ok = ok && r[t] == ((t & 1) ? 0.0 : h[t / 2 + 1]);
+            state = ok ? 1 : 0;
+        }
+    }
+    (void)hipFree(d);
+    return state == 1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // sliced-ELL layout builders (host side of csrc/mik_sell.h)
 // ---------------------------------------------------------------------------------------------
@@ -361,7 +391,8 @@ static int csr_build_sdia(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
                         }
                     }
                     A->sdia_koff = (int)(-omin);
-                    A->sdia_buf_ok = finite && (uint64_t)n_rows * es <= 0xFFFFFFF0ull && (uint64_t)(omax - omin) * es < 0x7FFFFFF0ull;
+                    A->sdia_buf_ok = finite && (uint64_t)n_rows * es <= 0xFFFFFFF0ull && (uint64_t)(omax - omin) * es < 0x7FFFFFF0ull &&
+                                     buffer_range_semantics_ok(ctx);
                     // the (slots, centre slot) class most slices have, among the ones k_spmv_sdiab is specialised for
                     int64_t best = 0;
                     A->sdia_cls = 0;
@@ -874,6 +905,22 @@ static int spmv_kernel_choice(const mik_csr *A)
 static inline bool spmv_csr_rowgather(const mik_csr *A)
 {
     return g_mik_tuning[14] == 2 || (g_mik_tuning[14] == 0 && A->n_long == 0);
+}
+
+extern "C" int mik_spmv_kernel(const mik_csr *A, char *name, int len)
+{
+    if (!A || !name || len <= 0) return MIK_ERR_INVALID;
+    const char *k = "k_spmv_rowblock";
+    switch (spmv_kernel_choice(A)) {
+    case 5: k = A->sdia_buf_ok && g_mik_tuning[17] == 0 ? "k_spmv_sdiab" : "k_spmv_sdiac"; break;
+    case 4: k = "k_spmv_sdia"; break;
+    case 3: k = "k_spmv_packed"; break;
+    case 2: k = "k_spmv_sell8"; break;
+    case 1: k = "k_spmv_sell"; break;
+    default: k = spmv_csr_rowgather(A) ? "k_spmv_rowgather" : "k_spmv_rowblock"; break;
+    }
+    snprintf(name, (size_t)len, "%s", k);
+    return MIK_OK;
 }
 
 // Can mik_spmv_launch_range serve a sub-range of row-blocks for this operator?  The sliced-ELL kernels and the default

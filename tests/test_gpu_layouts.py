@@ -9,7 +9,9 @@ pytestmark = pytest.mark.gpu
 # knob 14 selects the CSR kernel: 0 = tile filled by LDS-DMA + per-row gather (k_spmv_rowgather, default), 1 = products
 # staged through registers (k_spmv_rowblock)
 FORMS = {"csr-rowblock": {8: 1}, "csr-rowblock/products": {8: 1, 14: 1},
-         "sliced-ell": {10: 1, 12: 1}, "sliced-ell+8-bit-column-codes": {12: 1}, "sliced-ell+slice-offsets+row-masks": {11: 1}, "best": {}}
+         "sliced-ell": {10: 1, 12: 1}, "sliced-ell+8-bit-column-codes": {12: 1}, "sliced-ell+slice-offsets+row-masks": {11: 1}, "best": {},
+         # the kernels of the slice-constant layout: flat loads, buffer loads slot by slot, 1 / 4 slices per workgroup
+         "best/flat-loads": {17: 1}, "best/slot-by-slot": {18: 1}, "best/1-slice": {16: 1}, "best/4-slices": {16: 4}, "best/flat-4": {17: 1, 16: 4}}
 
 
 def with_knobs(pkg, knobs, fn):
@@ -51,7 +53,7 @@ def test_spmv_and_cg_identical_in_every_layout(pkg, orc, ctx, case, dtype):
             dA = upload(pkg, A)
             if form == "sliced-ell+slice-offsets+row-masks" and case == "banded_wide":
                 assert dA.layout() == "sliced-ell+8-bit-column-codes"       # > 8 offsets per slice: no per-slice-offset form at all
-            elif form != "best":
+            elif not form.startswith("best"):
                 assert dA.layout() == form.split("/")[0]
             elif case != "banded_wide":       # every slice of these constant-coefficient stencils uses <= 8 offsets, one value per slot
                 assert dA.layout() == "slice-offsets+slice-values+row-masks"
@@ -163,3 +165,50 @@ def test_slice_constant_values_only_when_the_bits_agree(pkg, orc, ctx, dtype):
     dD = upload(pkg, D)
     assert dD.layout() == "slice-offsets+slice-values+row-masks"
     assert np.array_equal(pkg.mul_(pkg.HipVector(A.n, dtype), dD, pkg.HipVector.from_numpy(x)).to_numpy(), orc.spmv(D, x))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_slice_constant_kernels_absent_slots_and_missing_diagonals(pkg, orc, ctx, dtype):
+    """k_spmv_sdiab reads 0.0 for a slot a row does not have (buffer range check) and adds value * 0: x entries that are
+    Inf / NaN must only reach the rows that really reference them; rows without a diagonal entry (the fused dot takes x[r]
+    from the centre slot otherwise); an Inf coefficient keeps the flat-load kernel"""
+    rng = np.random.default_rng(11)
+    n = 1500
+    S = sp.diags([np.full(n - 40, -1.0), np.full(n - 1, -2.0), np.full(n, 5.0), np.full(n - 1, -3.0), np.full(n - 40, -0.5)],
+                 [-40, -1, 0, 1, 40], format="lil")
+    for r in (0, 3, 255, 256, 700, 1499):               # rows without a diagonal entry, also at slice edges
+        S[r, r] = 0.0
+    for r in (39, 40, 41, 900):                         # rows without one of the other slots
+        S[r, r - 1] = 0.0
+    S = S.tocsc()
+    S.eliminate_zeros()
+    A = orc.CSC.from_scipy(S).astype(dtype)
+    x = rng.standard_normal(n).astype(dtype)
+    x[[0, 38, 255, 256, 899, 1499]] = [np.inf, np.nan, -np.inf, np.nan, np.inf, np.nan]
+    want = orc.spmv(A, x)
+    xf = rng.standard_normal(n).astype(dtype)
+    b = orc.hashed_rhs(n).astype(dtype)
+    ref = None
+    for form, knobs in (("csr-rowblock", {8: 1}), ("best", {}), ("best/flat-loads", {17: 1}), ("best/slot-by-slot", {18: 1}), ("best/4-slices", {16: 4})):
+        def run():
+            dA = upload(pkg, A)
+            if form.startswith("best"):
+                assert dA.layout() == "slice-offsets+slice-values+row-masks"
+                assert dA.spmv_kernel() == ("k_spmv_sdiac" if 17 in knobs else "k_spmv_sdiab")
+            y = pkg.mul_(pkg.HipVector(n, dtype), dA, pkg.HipVector.from_numpy(x)).to_numpy()
+            xs, ch = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True, maxiter=4)     # fused dot; only the bits matter
+            return y, ch["resnorm"], xs.to_numpy(), pkg.mul_(pkg.HipVector(n, dtype), dA, pkg.HipVector.from_numpy(xf)).to_numpy()
+        y, res, xs, yf = with_knobs(pkg, knobs, run)
+        assert np.array_equal(y, want, equal_nan=True), form
+        assert np.array_equal(yf, orc.spmv(A, xf)), form
+        if ref is None:
+            ref = (res, xs)
+        assert np.array_equal(res, ref[0]) and np.array_equal(xs, ref[1]), form
+    # a non-finite coefficient: value * 0.0 would be NaN, so the buffer kernel is not used
+    S2 = S.copy().tolil()
+    S2[10, 11] = np.inf
+    A2 = orc.CSC.from_scipy(S2.tocsc()).astype(dtype)
+    dA2 = upload(pkg, A2)
+    if dA2.layout() == "slice-offsets+slice-values+row-masks":
+        assert dA2.spmv_kernel() == "k_spmv_sdiac"
+    assert np.array_equal(pkg.mul_(pkg.HipVector(n, dtype), dA2, pkg.HipVector.from_numpy(xf)).to_numpy(), orc.spmv(A2, xf), equal_nan=True)
