@@ -13,7 +13,8 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "iterativesolvers.jl_amd", "csrc", "mik_core.hip")
-WANT = {"k_spmv_sdia<double, true, true>": "_Z11k_spmv_sdiaIdLb1ELb1EE", "k_spmv_rowgather<double, true, true>": "_Z16k_spmv_rowgatherIdLb1ELb1EE",
+WANT = {"k_spmv_sdiab<double, true, true, 2, 7, 3>  (both paths: compiled-in class and slot by slot)": "_Z12k_spmv_sdiabIdLb1ELb1ELi2ELi7ELi3EE",
+        "k_spmv_sdiac<double, true, true, 2>": "_Z12k_spmv_sdiacIdLb1ELb1ELi2EE", "k_spmv_sdia<double, true, true>": "_Z11k_spmv_sdiaIdLb1ELb1EE", "k_spmv_rowgather<double, true, true>": "_Z16k_spmv_rowgatherIdLb1ELb1EE",
         "k_spmv_rowblock<double, true, true, true, false>": "_Z15k_spmv_rowblockIdLb1ELb1ELb1ELb0EE", "k_spmv_sell8<double, true, true>": "_Z12k_spmv_sell8IdLb1ELb1EE"}
 with tempfile.TemporaryDirectory() as tmp:
     asm = os.path.join(tmp, "core.s")
