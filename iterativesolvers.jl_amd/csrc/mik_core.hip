@@ -252,6 +252,84 @@ static bool buffer_range_semantics_ok(mik_ctx *ctx)
     return state == 1;
 }
 
+// Slice descriptions (one SdiaPattern-shaped record per slice, soff still empty) -> the pattern table of the slice-constant
+// layout: equal descriptions are stored once, a slice keeps a pattern index.  Shared by the host builder below and the
+// device-side upload (mik_upload.hip).  Also decides whether k_spmv_sdiab applies (finite values, 32-bit byte offsets,
+// range-check semantics of the device) and which (slots, centre slot) class it runs specialised.
+size_t mik_sdia_pattern_bytes(size_t es) { return 16 + 32 + 32 + 8 * es; }
+
+int mik_sdiac_finish(mik_ctx *ctx, mik_csr *A, const std::vector<unsigned char> &desc, int64_t nb, size_t es, int64_t slots)
+{
+    hipError_t e;
+    const int64_t n_rows = A->n_rows;
+    const size_t psz = mik_sdia_pattern_bytes(es), voff0 = 80;
+    std::map<std::string, int> index;
+    std::vector<unsigned char> pats;
+    std::vector<int> pid((size_t)nb, 0);
+    std::vector<int64_t> slices_of;                            // slices per pattern
+    for (int64_t b = 0; b < nb; ++b) {
+        std::string key((const char *)&desc[(size_t)b * psz], psz);
+        auto it = index.find(key);
+        if (it == index.end()) {
+            it = index.emplace(key, (int)index.size()).first;
+            pats.insert(pats.end(), key.begin(), key.end());
+            slices_of.push_back(0);
+        }
+        pid[(size_t)b] = it->second;
+        ++slices_of[(size_t)it->second];
+    }
+    // k_spmv_sdiab (buffer loads; absent slots read 0.0 and add value * 0): needs finite values and 32-bit byte
+    // offsets; the scalar offset of slot q is (off[q] + koff) * sizeof(T), koff = - the operator's smallest offset
+    {
+        int64_t omin = 0, omax = 0;
+        bool finite = true;
+        for (size_t ip = 0; ip < index.size(); ++ip) {
+            int hdr[4], off[8];
+            memcpy(hdr, &pats[ip * psz], 16);
+            memcpy(off, &pats[ip * psz + 16], 32);
+            for (int q = 0; q < hdr[0]; ++q) {
+                omin = std::min<int64_t>(omin, off[q]);
+                omax = std::max<int64_t>(omax, off[q]);
+                double vq;
+                if (es == 8) memcpy(&vq, &pats[ip * psz + voff0 + 8 * (size_t)q], 8);
+                else { float f; memcpy(&f, &pats[ip * psz + voff0 + 4 * (size_t)q], 4); vq = f; }
+                finite = finite && std::isfinite(vq);
+            }
+        }
+        A->sdia_koff = (int)(-omin);
+        A->sdia_buf_ok = finite && (uint64_t)n_rows * es <= 0xFFFFFFF0ull && (uint64_t)(omax - omin) * es < 0x7FFFFFF0ull &&
+                         buffer_range_semantics_ok(ctx);
+        // the (slots, centre slot) class most slices have, among the ones k_spmv_sdiab is specialised for
+        int64_t best = 0;
+        A->sdia_cls = 0;
+        for (int c = 1; c < MIK_SDIAB_NCLS; ++c) {
+            int64_t cnt = 0;
+            for (size_t ip = 0; ip < index.size(); ++ip) {
+                int hdr[4];
+                memcpy(hdr, &pats[ip * psz], 16);
+                if (hdr[0] == mik_sdiab_cls_ns(c) && hdr[2] == mik_sdiab_cls_cq(c)) cnt += slices_of[ip];
+            }
+            if (cnt > best) { best = cnt; A->sdia_cls = c; }
+        }
+        if (A->sdia_buf_ok)
+            for (size_t ip = 0; ip < index.size(); ++ip) {
+                int off[8], soff[8];
+                memcpy(off, &pats[ip * psz + 16], 32);
+                for (int q = 0; q < 8; ++q) soff[q] = (int)(((int64_t)off[q] + A->sdia_koff) * (int64_t)es);
+                memcpy(&pats[ip * psz + 48], soff, 32);
+            }
+    }
+    if ((e = hipMalloc((void **)&A->sdia_pat_id, sizeof(int) * (size_t)nb)) != hipSuccess ||
+        (e = hipMalloc(&A->sdia_pats, pats.size())) != hipSuccess ||
+        (e = hipMemcpy(A->sdia_pat_id, pid.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(A->sdia_pats, pats.data(), pats.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+        return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: slice-constant form: %s", hipGetErrorString(e));
+    }
+    A->sdia_npat = (int)index.size();
+    A->sdia_entries = slots;
+    return MIK_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // sliced-ELL layout builders (host side of csrc/mik_sell.h)
 // ---------------------------------------------------------------------------------------------
@@ -343,15 +421,10 @@ static int csr_build_sdia(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
                 }
             }
             if (ok && constant) {
-                // equal slice descriptions {ns, tri, centre slot, diagonal-in-every-row, offsets, value bits} are stored once
-                // (SdiaPattern<T>: 4 ints, 8 offsets, 8 scalar byte offsets filled below, 8 values); a slice keeps a pattern index
-                const size_t psz = 16 + 32 + 32 + 8 * es, voff0 = 80;
-                std::map<std::string, int> index;
-                std::vector<unsigned char> pats;
-                std::vector<int> pid((size_t)nb, 0);
-                std::vector<int64_t> slices_of;                            // slices per pattern
+                // per-slice descriptions {ns, tri, centre slot, diagonal-in-every-row, offsets, value bits} -> pattern table
+                const size_t psz = mik_sdia_pattern_bytes(es);
+                std::vector<unsigned char> desc((size_t)nb * psz, 0);
                 for (int64_t b = 0; b < nb; ++b) {
-                    std::string key(psz, '\0');
                     const int ns = (dptr[(size_t)b + 1] - dptr[(size_t)b]) / MIK_BLOCK;
                     int cq = -1;
                     for (int q = 0; q < ns; ++q)
@@ -360,69 +433,15 @@ static int csr_build_sdia(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
                     for (int64_t r = b * MIK_BLOCK; dfull && r < std::min<int64_t>(n_rows, (b + 1) * MIK_BLOCK); ++r)
                         dfull = (dmask[(size_t)r] >> cq) & 1;
                     int hdr[4] = {ns, dtri[(size_t)b], cq, dfull};
-                    memcpy(&key[0], hdr, 16);
-                    memcpy(&key[16], &doff[(size_t)b * 8], 32);
-                    memcpy(&key[voff0], &cval[(size_t)b * 8 * es], 8 * es);
-                    auto it = index.find(key);
-                    if (it == index.end()) {
-                        it = index.emplace(key, (int)index.size()).first;
-                        pats.insert(pats.end(), key.begin(), key.end());
-                        slices_of.push_back(0);
-                    }
-                    pid[(size_t)b] = it->second;
-                    ++slices_of[(size_t)it->second];
+                    memcpy(&desc[(size_t)b * psz], hdr, 16);
+                    memcpy(&desc[(size_t)b * psz + 16], &doff[(size_t)b * 8], 32);
+                    memcpy(&desc[(size_t)b * psz + 80], &cval[(size_t)b * 8 * es], 8 * es);
                 }
-                // k_spmv_sdiab (buffer loads; absent slots read 0.0 and add value * 0): needs finite values and 32-bit byte
-                // offsets; the scalar offset of slot q is (off[q] + koff) * sizeof(T), koff = - the operator's smallest offset
-                {
-                    int64_t omin = 0, omax = 0;
-                    bool finite = true;
-                    for (size_t ip = 0; ip < index.size(); ++ip) {
-                        int hdr[4], off[8];
-                        memcpy(hdr, &pats[ip * psz], 16);
-                        memcpy(off, &pats[ip * psz + 16], 32);
-                        for (int q = 0; q < hdr[0]; ++q) {
-                            omin = std::min<int64_t>(omin, off[q]);
-                            omax = std::max<int64_t>(omax, off[q]);
-                            double vq;
-                            if (es == 8) memcpy(&vq, &pats[ip * psz + voff0 + 8 * (size_t)q], 8);
-                            else { float f; memcpy(&f, &pats[ip * psz + voff0 + 4 * (size_t)q], 4); vq = f; }
-                            finite = finite && std::isfinite(vq);
-                        }
-                    }
-                    A->sdia_koff = (int)(-omin);
-                    A->sdia_buf_ok = finite && (uint64_t)n_rows * es <= 0xFFFFFFF0ull && (uint64_t)(omax - omin) * es < 0x7FFFFFF0ull &&
-                                     buffer_range_semantics_ok(ctx);
-                    // the (slots, centre slot) class most slices have, among the ones k_spmv_sdiab is specialised for
-                    int64_t best = 0;
-                    A->sdia_cls = 0;
-                    for (int c = 1; c < MIK_SDIAB_NCLS; ++c) {
-                        int64_t cnt = 0;
-                        for (size_t ip = 0; ip < index.size(); ++ip) {
-                            int hdr[4];
-                            memcpy(hdr, &pats[ip * psz], 16);
-                            if (hdr[0] == mik_sdiab_cls_ns(c) && hdr[2] == mik_sdiab_cls_cq(c)) cnt += slices_of[ip];
-                        }
-                        if (cnt > best) { best = cnt; A->sdia_cls = c; }
-                    }
-                    if (A->sdia_buf_ok)
-                        for (size_t ip = 0; ip < index.size(); ++ip) {
-                            int off[8], soff[8];
-                            memcpy(off, &pats[ip * psz + 16], 32);
-                            for (int q = 0; q < 8; ++q) soff[q] = (int)(((int64_t)off[q] + A->sdia_koff) * (int64_t)es);
-                            memcpy(&pats[ip * psz + 48], soff, 32);
-                        }
-                }
-                if ((e = hipMalloc((void **)&A->sdia_pat_id, sizeof(int) * (size_t)nb)) != hipSuccess ||
-                    (e = hipMalloc((void **)&A->sdia_mask, (size_t)n_rows)) != hipSuccess ||
-                    (e = hipMalloc(&A->sdia_pats, pats.size())) != hipSuccess ||
-                    (e = hipMemcpy(A->sdia_pat_id, pid.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice)) != hipSuccess ||
-                    (e = hipMemcpy(A->sdia_mask, dmask.data(), (size_t)n_rows, hipMemcpyHostToDevice)) != hipSuccess ||
-                    (e = hipMemcpy(A->sdia_pats, pats.data(), pats.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+                if ((e = hipMalloc((void **)&A->sdia_mask, (size_t)n_rows)) != hipSuccess ||
+                    (e = hipMemcpy(A->sdia_mask, dmask.data(), (size_t)n_rows, hipMemcpyHostToDevice)) != hipSuccess)
                     return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: slice-constant form: %s", hipGetErrorString(e));
-                }
-                A->sdia_npat = (int)index.size();
-                A->sdia_entries = slots;
+                const int rc = mik_sdiac_finish(ctx, A, desc, nb, es, slots);
+                if (rc != MIK_OK) return rc;
             } else if (ok) {
                 if ((e = hipMalloc((void **)&A->sdia_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
                     (e = hipMalloc((void **)&A->sdia_off, sizeof(int) * (size_t)nb * 8)) != hipSuccess ||
@@ -565,6 +584,37 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
     const size_t es = mik_dtype_size(dtype);
     std::vector<int> rowptr, col;
     std::vector<unsigned char> v;
+    // Default: everything past the raw host-to-device copy happens on the device (mik_upload.hip).  MIK_ERR_NOTIMPL from it
+    // = a matrix the host path below handles (long rows, duplicate entries, no room for the raw copy); development knob 20:
+    // 1 = host path only.
+    if (g_mik_tuning[20] == 0 && nnz > 0 && n_rows > 0 && n_cols > 0) {
+        mik_csr *A = new (std::nothrow) mik_csr();
+        if (!A) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host allocation failed");
+        A->ctx = ctx; A->dtype = dtype; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz;
+        (void)hipSetDevice(ctx->device);
+        int rc = mik_upload_device(ctx, A, dtype, n_rows, n_cols, nnz, ptr, idx, val, index_base, is_csc);
+        if (rc == MIK_OK && !A->sdia_val && !A->sdia_pats && g_mik_tuning[8] == 0) {
+            // no per-slice-offset layout: the other sliced-ELL forms are built by the host builder from a copy of the device CSR
+            try {
+                rowptr.resize((size_t)n_rows + 1);
+                col.resize((size_t)nnz);
+                v.resize((size_t)nnz * es);
+            } catch (const std::bad_alloc &) {
+                mik_csr_destroy(A);
+                return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host staging allocation failed");
+            }
+            if (hipMemcpy(rowptr.data(), A->rowptr, sizeof(int) * ((size_t)n_rows + 1), hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(col.data(), A->col, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(v.data(), A->val, es * (size_t)nnz, hipMemcpyDeviceToHost) != hipSuccess) {
+                mik_csr_destroy(A);
+                return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create: reading the device CSR back failed");
+            }
+            rc = csr_build_sell(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz, A->max_row_nnz);
+        }
+        if (rc == MIK_OK) { *out = A; return MIK_OK; }
+        mik_csr_destroy(A);
+        if (rc != MIK_ERR_NOTIMPL) return rc;
+    }
     try {
         rowptr.assign((size_t)n_rows + 1, 0);
         col.resize((size_t)nnz);

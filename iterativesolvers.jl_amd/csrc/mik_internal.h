@@ -110,6 +110,12 @@ extern thread_local std::string g_mik_create_error;
 extern int g_mik_tuning[32];  // development knobs (mik_set_tuning), see mik_spmv_launch
 
 int mik_fail(mik_ctx *ctx, int code, const char *fmt, ...);
+// operator upload (mik_core.hip / mik_upload.hip)
+size_t mik_sdia_pattern_bytes(size_t es);
+int mik_sdiac_finish(mik_ctx *ctx, mik_csr *A, const std::vector<unsigned char> &desc, int64_t nb, size_t es, int64_t slots);
+int mik_upload_device(mik_ctx *ctx, mik_csr *A, int dtype, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *ptr, const int64_t *idx,
+                      const void *val, int index_base, int is_csc);
+
 int mik_ensure_partials(mik_ctx *ctx, size_t bytes);
 
 #define MIK_HIP(ctx, call)                                                                    \

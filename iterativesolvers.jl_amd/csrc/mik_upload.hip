@@ -1,0 +1,490 @@
+// mik_upload.hip -- device-side operator upload (mik_csr_create's default path).
+//
+// The host hands over the SparseMatrixCSC fields as they are (1-based Int64 colptr / rowval + nzval, the layout of
+// test/laplace_matrix.jl:12; or a CSR triple).  They are copied to the device once, raw, and everything else happens
+// there: validation, Int64 -> Int32 / 0-based conversion, the CSC -> CSR transpose (row histogram, exclusive scan, scatter
+// by atomic cursor, per-row sort by column -- the order Julia's column scatter reaches a row), the operator statistics
+// (longest row, bandwidth for the XCD strip map, densest row-block) and the analysis for the per-slice-offset layouts of
+// csrc/mik_sell.h (slot pattern per 256-row slice, row masks, slice-constancy of the slot values, value slots).  Only the
+// per-slice descriptions (144 B per 256 rows) travel back for the pattern table (mik_sdiac_finish).  No host pass over
+// the nnz entries, no host staging copies.
+//
+// Falls back to the host path of mik_core.hip (return MIK_ERR_NOTIMPL, nothing allocated in A) for what is rare and
+// order-sensitive there: rows longer than the long-row threshold, duplicate (row, column) entries in CSC input, matrices
+// that need the other sliced-ELL layouts.
+#include "mik_internal.h"
+#include "mik_sell.h"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int NO_ROW = 0x7f7f7f7f;             // first_row[] after its memset: no row has this slot
+
+struct UploadStats {
+    int bad_ptr, bad_idx, dup, max_row, max_rb, sdia_bad, not_constant, pad_;
+    long long bw, slots;
+};
+
+// ---------------------------------------------------------------------------------------------
+// exclusive scan of an int array (in place), total returned in *total (device)
+// ---------------------------------------------------------------------------------------------
+constexpr int SCAN_PER = 8;                       // elements per thread
+constexpr int SCAN_TILE = MIK_BLOCK * SCAN_PER;   // 2048 per workgroup
+
+__global__ __launch_bounds__(MIK_BLOCK) void k_scan_tiles(int *__restrict__ data, long long n, int *__restrict__ sums)
+{
+    __shared__ int part[MIK_BLOCK];
+    const int t = threadIdx.x;
+    const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)t * SCAN_PER;
+    int v[SCAN_PER], s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_PER; ++i) {
+        v[i] = base + i < n ? data[base + i] : 0;
+        s += v[i];
+    }
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < MIK_BLOCK; d <<= 1) {     // Hillis-Steele over the 256 thread sums
+        const int add = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    int run = part[t] - s;                        // exclusive prefix of this thread inside the tile
+#pragma unroll
+    for (int i = 0; i < SCAN_PER; ++i) {
+        if (base + i < n) data[base + i] = run;
+        run += v[i];
+    }
+    if (t == MIK_BLOCK - 1) sums[blockIdx.x] = part[t];
+}
+
+__global__ __launch_bounds__(MIK_BLOCK) void k_scan_add(int *__restrict__ data, long long n, const int *__restrict__ offs)
+{
+    const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_PER;
+    const int o = offs[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_PER; ++i)
+        if (base + i < n) data[base + i] += o;
+}
+
+// data[0..n) -> exclusive prefix sums; data[n] (must be allocated) = total.  scratch: >= n / 2048 + n / 2048^2 + 8 ints
+static hipError_t device_exclusive_scan(hipStream_t st, int *data, long long n, int *scratch)
+{
+    if (n <= 0) return hipMemsetAsync(data, 0, sizeof(int), st);
+    const long long tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    int *sums = scratch;
+    hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)tiles), dim3(MIK_BLOCK), 0, st, data, n, sums);
+    if (tiles > 1) {
+        hipError_t e = device_exclusive_scan(st, sums, tiles, scratch + tiles + 1);      // sums[tiles] = grand total
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)tiles), dim3(MIK_BLOCK), 0, st, data, n, sums);
+        return hipMemcpyAsync(data + n, sums + tiles, sizeof(int), hipMemcpyDeviceToDevice, st);
+    }
+    return hipMemcpyAsync(data + n, sums, sizeof(int), hipMemcpyDeviceToDevice, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// validation, conversion, transpose
+// ---------------------------------------------------------------------------------------------
+__global__ void k_up_check_ptr(const long long *__restrict__ ptr, long long n_major, UploadStats *st)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_major && ptr[j + 1] < ptr[j]) st->bad_ptr = 1;
+}
+
+// CSC: count entries per row (rowlen[r + 1]), check the row indices
+__global__ void k_up_count_rows(const long long *__restrict__ idx, long long nnz, long long n_minor, int base, int *__restrict__ rowlen, UploadStats *st)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    const long long i = idx[k] - base;
+    if (i < 0 || i >= n_minor) { st->bad_idx = 1; return; }
+    atomicAdd(&rowlen[i], 1);
+}
+
+// CSC: column j hands its entries to their rows (position by atomic cursor; the rows are sorted afterwards)
+template <typename T>
+__global__ void k_up_scatter(const long long *__restrict__ ptr, const long long *__restrict__ idx, const T *__restrict__ val, long long n_cols, int base,
+                             const int *__restrict__ rowptr, int *__restrict__ cursor, int *__restrict__ col, T *__restrict__ out)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_cols) return;
+    for (long long k = ptr[j] - base; k < ptr[j + 1] - base; ++k) {
+        const long long r = idx[k] - base;
+        const int dst = rowptr[r] + atomicAdd(&cursor[r], 1);
+        col[dst] = (int)j;
+        out[dst] = val[k];
+    }
+}
+
+// every row: insertion sort by column (rows are short here; longer ones leave for the host path); duplicates are reported
+template <typename T>
+__global__ void k_up_sort_rows(const int *__restrict__ rowptr, long long n_rows, int *__restrict__ col, T *__restrict__ val, UploadStats *st)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int a = rowptr[r], b = rowptr[r + 1];
+    if (b - a > 256) return;                                     // long row: the host path takes this matrix
+    for (int i = a + 1; i < b; ++i) {
+        const int c = col[i];
+        const T v = val[i];
+        int j = i - 1;
+        while (j >= a && col[j] > c) { col[j + 1] = col[j]; val[j + 1] = val[j]; --j; }
+        col[j + 1] = c;
+        val[j + 1] = v;
+    }
+    for (int i = a + 1; i < b; ++i)
+        if (col[i] == col[i - 1]) st->dup = 1;
+}
+
+// CSR input: convert in place of a transpose
+template <typename T>
+__global__ void k_up_convert(const long long *__restrict__ idx, const T *__restrict__ val, long long nnz, long long n_minor, int base,
+                             int *__restrict__ col, T *__restrict__ out, UploadStats *st)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    const long long i = idx[k] - base;
+    if (i < 0 || i >= n_minor) { st->bad_idx = 1; return; }
+    col[k] = (int)i;
+    out[k] = val[k];
+}
+__global__ void k_up_rowptr(const long long *__restrict__ ptr, long long n_rows, int base, int *__restrict__ rowptr)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r <= n_rows) rowptr[r] = (int)(ptr[r] - base);
+}
+
+// longest row, |column - row| of in-block columns (strip map), densest 256-row block
+__global__ __launch_bounds__(MIK_BLOCK) void k_up_stats(const int *__restrict__ rowptr, const int *__restrict__ col, long long n_rows, UploadStats *st)
+{
+    const long long r = (long long)blockIdx.x * MIK_BLOCK + threadIdx.x;
+    int len = 0;
+    long long bw = 0;
+    if (r < n_rows) {
+        const int a = rowptr[r], b = rowptr[r + 1];
+        len = b - a;
+        for (int k = a; k < b; ++k)
+            if (col[k] < n_rows) bw = max(bw, (long long)llabs((long long)col[k] - r));
+    }
+    __shared__ int slen[MIK_BLOCK];
+    __shared__ long long sbw[MIK_BLOCK];
+    slen[threadIdx.x] = len;
+    sbw[threadIdx.x] = bw;
+    __syncthreads();
+    for (int d = MIK_BLOCK / 2; d > 0; d >>= 1) {
+        if (threadIdx.x < d) {
+            slen[threadIdx.x] = max(slen[threadIdx.x], slen[threadIdx.x + d]);
+            sbw[threadIdx.x] = max(sbw[threadIdx.x], sbw[threadIdx.x + d]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicMax(&st->max_row, slen[0]);
+        atomicMax((unsigned long long *)&st->bw, (unsigned long long)sbw[0]);
+        const long long r0 = (long long)blockIdx.x * MIK_BLOCK;
+        atomicMax(&st->max_rb, rowptr[min(r0 + MIK_BLOCK, n_rows)] - rowptr[r0]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-slice-offset layouts (the host builder csr_build_sdia of mik_core.hip, statement for statement)
+// ---------------------------------------------------------------------------------------------
+// one thread per 256-row slice: the slice's slot pattern = a common super-sequence of its rows' offset sequences, built by
+// merging row after row; nslot[b] = slots * 256 (scanned into the value-slot pointer afterwards)
+__global__ void k_up_slice_pattern(const int *__restrict__ rowptr, const int *__restrict__ col, long long n_rows, long long nb, int *__restrict__ doff,
+                                   int *__restrict__ dtri, int *__restrict__ nslot, UploadStats *st)
+{
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    int offs8[8];
+    int ns = 0;
+    bool ok = true;
+    const long long rend = min((b + 1) * MIK_BLOCK, n_rows);
+    for (long long r = b * MIK_BLOCK; r < rend && ok; ++r) {
+        int p = 0;                                               // next admissible pattern position for this row
+        for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
+            const int d = col[k2] - (int)r;
+            int q = 0;
+            while (q < ns && offs8[q] != d) ++q;
+            if (q < ns) {
+                if (q < p) { ok = false; break; }                // two rows order the same offsets differently
+                p = q + 1;
+            } else {
+                if (ns == 8) { ok = false; break; }
+                for (int z = ns; z > p; --z) offs8[z] = offs8[z - 1];
+                offs8[p] = d;
+                ++ns;
+                ++p;
+            }
+        }
+    }
+    if (!ok) { st->sdia_bad = 1; ns = 0; }
+    int tri = -1;
+    for (int q = 0; q < 8; ++q) doff[b * 8 + q] = q < ns ? offs8[q] : 0;
+    for (int q = 0; q + 2 < ns; ++q)
+        if (offs8[q + 1] == offs8[q] + 1 && offs8[q + 2] == offs8[q] + 2) { tri = q; break; }
+    dtri[b] = tri;
+    nslot[b] = ns * MIK_BLOCK;
+}
+
+// one thread per row: which slots the row has (mask byte) and, per (slice, slot), the first row that has it
+__global__ void k_up_row_masks(const int *__restrict__ rowptr, const int *__restrict__ col, long long n_rows, const int *__restrict__ doff,
+                               const int *__restrict__ dptr, unsigned char *__restrict__ mask, int *__restrict__ first_row, UploadStats *st)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const long long b = r / MIK_BLOCK;
+    const int ns = (dptr[b + 1] - dptr[b]) / MIK_BLOCK;
+    const int *so = doff + b * 8;
+    int q = 0, prevq = -1, m = 0;
+    for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
+        const int d = col[k2] - (int)r;
+        while (q < ns && so[q] != d) ++q;                        // columns ascend within a row, so do the slots
+        if (q >= ns || q <= prevq) { st->sdia_bad = 1; break; }  // unsorted or duplicate column: keep the other layouts
+        m |= 1 << q;
+        atomicMin(&first_row[b * 8 + q], (int)r);
+        prevq = q;
+    }
+    mask[r] = (unsigned char)m;
+}
+
+template <typename T> struct BitsOf;
+template <> struct BitsOf<double> { using type = unsigned long long; };
+template <> struct BitsOf<float> { using type = unsigned; };
+
+// one thread per row: does every slot value equal (bit for bit) the value the slot's first row carries?
+template <typename T>
+__global__ void k_up_row_constancy(const int *__restrict__ rowptr, const int *__restrict__ col, const T *__restrict__ val, long long n_rows,
+                                   const int *__restrict__ doff, const int *__restrict__ dptr, const int *__restrict__ first_row, UploadStats *st)
+{
+    using B = typename BitsOf<T>::type;
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const long long b = r / MIK_BLOCK;
+    const int ns = (dptr[b + 1] - dptr[b]) / MIK_BLOCK;
+    const int *so = doff + b * 8;
+    int q = 0;
+    for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
+        const int d = col[k2] - (int)r;
+        while (q < ns && so[q] != d) ++q;
+        if (q >= ns) break;
+        const int fr = first_row[b * 8 + q];
+        if (fr == NO_ROW || fr == (int)r) continue;
+        for (int k3 = rowptr[fr]; k3 < rowptr[fr + 1]; ++k3)
+            if (col[k3] - fr == d) {
+                if (__builtin_bit_cast(B, val[k3]) != __builtin_bit_cast(B, val[k2])) st->not_constant = 1;
+                break;
+            }
+    }
+}
+
+// one thread per slice: the SdiaPattern-shaped description {ns, tri, cq, dfull, off[8], soff[8] = 0, val[8]}
+template <typename T>
+__global__ void k_up_slice_desc(const int *__restrict__ rowptr, const int *__restrict__ col, const T *__restrict__ val, long long n_rows, long long nb,
+                                const int *__restrict__ doff, const int *__restrict__ dtri, const int *__restrict__ dptr,
+                                const unsigned char *__restrict__ mask, const int *__restrict__ first_row, SdiaPattern<T> *__restrict__ desc)
+{
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    SdiaPattern<T> P;
+    memset(&P, 0, sizeof(P));
+    P.ns = (dptr[b + 1] - dptr[b]) / MIK_BLOCK;
+    P.tri = dtri[b];
+    P.cq = -1;
+    for (int q = 0; q < 8; ++q) {
+        P.off[q] = doff[b * 8 + q];
+        if (q < P.ns && P.off[q] == 0) P.cq = q;
+        const int fr = q < P.ns ? first_row[b * 8 + q] : NO_ROW;
+        if (fr != NO_ROW)
+            for (int k3 = rowptr[fr]; k3 < rowptr[fr + 1]; ++k3)
+                if (col[k3] - fr == P.off[q]) P.val[q] = val[k3];
+    }
+    int dfull = P.cq >= 0;
+    const long long rend = min((b + 1) * MIK_BLOCK, n_rows);
+    for (long long r = b * MIK_BLOCK; dfull && r < rend; ++r) dfull = (mask[r] >> P.cq) & 1;
+    P.dfull = dfull;
+    desc[b] = P;
+}
+
+// one thread per row: the per-row value slots of k_spmv_sdia (operators whose coefficients vary inside a slice)
+template <typename T>
+__global__ void k_up_row_values(const int *__restrict__ rowptr, const int *__restrict__ col, const T *__restrict__ val, long long n_rows,
+                                const int *__restrict__ doff, const int *__restrict__ dptr, T *__restrict__ dval)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const long long b = r / MIK_BLOCK;
+    const int t = (int)(r % MIK_BLOCK);
+    const int ns = (dptr[b + 1] - dptr[b]) / MIK_BLOCK;
+    const int *so = doff + b * 8;
+    int q = 0;
+    for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
+        const int d = col[k2] - (int)r;
+        while (q < ns && so[q] != d) ++q;
+        if (q >= ns) break;
+        dval[(size_t)dptr[b] + (size_t)q * MIK_BLOCK + t] = val[k2];
+    }
+}
+
+struct Scratch {                                   // device temporaries of one upload, freed on every exit
+    std::vector<void *> ptrs;
+    ~Scratch() { for (void *p : ptrs) if (p) (void)hipFree(p); }
+    template <typename P> hipError_t alloc(P **p, size_t bytes)
+    {
+        hipError_t e = hipMalloc((void **)p, bytes ? bytes : 8);
+        if (e == hipSuccess) ptrs.push_back((void *)*p);
+        return e;
+    }
+    void keep(void *p) { for (auto &q : ptrs) if (q == p) q = nullptr; }    // ownership moves to the operator
+};
+
+inline unsigned blocks_for(long long n) { return (unsigned)((n + MIK_BLOCK - 1) / MIK_BLOCK); }
+
+template <typename T>
+int upload_device_t(mik_ctx *ctx, mik_csr *A, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *ptr, const int64_t *idx, const void *val,
+                    int index_base, int is_csc)
+{
+    const size_t es = sizeof(T);
+    const int64_t n_major = is_csc ? n_cols : n_rows, n_minor = is_csc ? n_rows : n_cols;
+    const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
+    hipStream_t st = ctx->stream;
+    Scratch S;
+    hipError_t e;
+    long long *d_ptr = nullptr, *d_idx = nullptr;
+    T *d_val = nullptr;
+    UploadStats *d_st = nullptr;
+    int *cursor = nullptr, *scan_tmp = nullptr;
+    const size_t pad = 2 * MIK_SPMV_TILE;          // slack so tile-granular reads never leave the allocation
+    const size_t scan_ints = (size_t)(std::max<int64_t>(n_rows, nb) / SCAN_TILE + 1) * 2 + 64;
+#define UP_TRY(call) do { if ((e = (call)) != hipSuccess) goto hip_fail; } while (0)
+    UploadStats hs;
+    int long_row;
+    int rc = MIK_OK;
+    UP_TRY(S.alloc(&d_ptr, sizeof(long long) * ((size_t)n_major + 1)));
+    UP_TRY(S.alloc(&d_idx, sizeof(long long) * (size_t)nnz));
+    UP_TRY(S.alloc(&d_val, es * (size_t)nnz));
+    UP_TRY(S.alloc(&d_st, sizeof(UploadStats)));
+    UP_TRY(S.alloc(&scan_tmp, sizeof(int) * scan_ints));
+    UP_TRY(hipMalloc((void **)&A->rowptr, sizeof(int) * ((size_t)n_rows + 1 + 256)));
+    UP_TRY(hipMalloc((void **)&A->col, sizeof(int) * ((size_t)nnz + pad)));
+    UP_TRY(hipMalloc(&A->val, es * ((size_t)nnz + pad)));
+    UP_TRY(hipMemsetAsync(d_st, 0, sizeof(UploadStats), st));
+    UP_TRY(hipMemsetAsync(A->rowptr, 0, sizeof(int) * ((size_t)n_rows + 1 + 256), st));
+    UP_TRY(hipMemsetAsync(A->col + nnz, 0, sizeof(int) * pad, st));
+    UP_TRY(hipMemsetAsync((unsigned char *)A->val + es * (size_t)nnz, 0, es * pad, st));
+    UP_TRY(hipMemcpyAsync(d_ptr, ptr, sizeof(long long) * ((size_t)n_major + 1), hipMemcpyHostToDevice, st));
+    UP_TRY(hipMemcpyAsync(d_idx, idx, sizeof(long long) * (size_t)nnz, hipMemcpyHostToDevice, st));
+    UP_TRY(hipMemcpyAsync(d_val, val, es * (size_t)nnz, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_up_check_ptr, dim3(blocks_for(n_major)), dim3(MIK_BLOCK), 0, st, d_ptr, (long long)n_major, d_st);
+    if (is_csc) {
+        UP_TRY(S.alloc(&cursor, sizeof(int) * ((size_t)n_rows + 1)));
+        UP_TRY(hipMemsetAsync(cursor, 0, sizeof(int) * ((size_t)n_rows + 1), st));
+        hipLaunchKernelGGL(k_up_count_rows, dim3(blocks_for(nnz)), dim3(MIK_BLOCK), 0, st, d_idx, (long long)nnz, (long long)n_minor, index_base, A->rowptr, d_st);
+    } else {
+        hipLaunchKernelGGL(k_up_rowptr, dim3(blocks_for(n_rows + 1)), dim3(MIK_BLOCK), 0, st, d_ptr, (long long)n_rows, index_base, A->rowptr);
+        hipLaunchKernelGGL((k_up_convert<T>), dim3(blocks_for(nnz)), dim3(MIK_BLOCK), 0, st, d_idx, d_val, (long long)nnz, (long long)n_minor, index_base, A->col,
+                           (T *)A->val, d_st);
+    }
+    // nothing below may run on a pointer array that is not monotone or on indices out of range
+    UP_TRY(hipMemcpyAsync(&hs, d_st, sizeof(hs), hipMemcpyDeviceToHost, st));
+    UP_TRY(hipStreamSynchronize(st));
+    if (hs.bad_ptr) { rc = mik_fail(ctx, MIK_ERR_INVALID, "mik_csr_create: ptr not monotone"); goto give_up; }
+    if (hs.bad_idx) { rc = mik_fail(ctx, MIK_ERR_INVALID, "mik_csr_create: index out of range"); goto give_up; }
+    if (is_csc) {
+        UP_TRY(device_exclusive_scan(st, A->rowptr, n_rows, scan_tmp));
+        hipLaunchKernelGGL((k_up_scatter<T>), dim3(blocks_for(n_cols)), dim3(MIK_BLOCK), 0, st, d_ptr, d_idx, d_val, (long long)n_cols, index_base, A->rowptr,
+                           cursor, A->col, (T *)A->val);
+    }
+    if (is_csc)
+        hipLaunchKernelGGL((k_up_sort_rows<T>), dim3(blocks_for(n_rows)), dim3(MIK_BLOCK), 0, st, A->rowptr, (long long)n_rows, A->col, (T *)A->val, d_st);
+    hipLaunchKernelGGL(k_up_stats, dim3((unsigned)nb), dim3(MIK_BLOCK), 0, st, A->rowptr, A->col, (long long)n_rows, d_st);
+    UP_TRY(hipMemcpyAsync(&hs, d_st, sizeof(hs), hipMemcpyDeviceToHost, st));
+    UP_TRY(hipStreamSynchronize(st));
+    long_row = g_mik_tuning[4] > 0 ? g_mik_tuning[4] : MIK_LONG_ROW;
+    if (hs.dup || (hs.max_row > long_row && g_mik_tuning[4] >= 0)) { rc = MIK_ERR_NOTIMPL; goto give_up; }     // the host path's business
+    A->max_row_nnz = hs.max_row;
+    A->max_rowblock_nnz = hs.max_rb;
+    {
+        const int64_t P = ((hs.bw + MIK_BLOCK - 1) / MIK_BLOCK + 7) / 8 * 8;
+        A->strip = (P >= 8 && P <= nb / 4) ? (int)P : 0;
+    }
+    // ---- the per-slice-offset layouts -------------------------------------------------------------------------
+    if (g_mik_tuning[8] == 0 && g_mik_tuning[12] == 0 && n_cols > 0) {
+        int *doff = nullptr, *dtri = nullptr, *dptr = nullptr, *first_row = nullptr;
+        unsigned char *mask = nullptr;
+        SdiaPattern<T> *desc = nullptr;
+        int slots_total = 0;
+        UP_TRY(S.alloc(&doff, sizeof(int) * (size_t)nb * 8));
+        UP_TRY(S.alloc(&dtri, sizeof(int) * (size_t)nb));
+        UP_TRY(S.alloc(&dptr, sizeof(int) * ((size_t)nb + 1)));
+        UP_TRY(S.alloc(&first_row, sizeof(int) * (size_t)nb * 8));
+        UP_TRY(S.alloc(&mask, (size_t)n_rows));
+        UP_TRY(hipMemsetAsync(first_row, 0x7f, sizeof(int) * (size_t)nb * 8, st));       // 0x7f7f7f7f: "no row yet"
+        hipLaunchKernelGGL(k_up_slice_pattern, dim3(blocks_for(nb)), dim3(MIK_BLOCK), 0, st, A->rowptr, A->col, (long long)n_rows, (long long)nb, doff, dtri, dptr,
+                           d_st);
+        UP_TRY(device_exclusive_scan(st, dptr, nb, scan_tmp));
+        UP_TRY(hipMemcpyAsync(&slots_total, dptr + nb, sizeof(int), hipMemcpyDeviceToHost, st));
+        UP_TRY(hipMemcpyAsync(&hs, d_st, sizeof(hs), hipMemcpyDeviceToHost, st));
+        UP_TRY(hipStreamSynchronize(st));
+        // (the scan is in 32 bits: more than 2^31 slots cannot qualify anyway, and nnz < 2^31 bounds slots by the test below only if it did not wrap)
+        if (!hs.sdia_bad && slots_total >= 0 && (int64_t)slots_total <= nnz + nnz / 8 + 8 * MIK_BLOCK && (int64_t)nb * 8 * MIK_BLOCK < INT32_MAX) {
+            hipLaunchKernelGGL(k_up_row_masks, dim3(blocks_for(n_rows)), dim3(MIK_BLOCK), 0, st, A->rowptr, A->col, (long long)n_rows, doff, dptr, mask, first_row, d_st);
+            if (g_mik_tuning[11] == 0)
+                hipLaunchKernelGGL((k_up_row_constancy<T>), dim3(blocks_for(n_rows)), dim3(MIK_BLOCK), 0, st, A->rowptr, A->col, (const T *)A->val, (long long)n_rows,
+                                   doff, dptr, first_row, d_st);
+            UP_TRY(hipMemcpyAsync(&hs, d_st, sizeof(hs), hipMemcpyDeviceToHost, st));
+            UP_TRY(hipStreamSynchronize(st));
+            if (!hs.sdia_bad) {
+                const bool constant = g_mik_tuning[11] == 0 && !hs.not_constant;
+                if (constant) {
+                    std::vector<unsigned char> hdesc((size_t)nb * sizeof(SdiaPattern<T>));
+                    UP_TRY(S.alloc(&desc, sizeof(SdiaPattern<T>) * (size_t)nb));
+                    hipLaunchKernelGGL((k_up_slice_desc<T>), dim3(blocks_for(nb)), dim3(MIK_BLOCK), 0, st, A->rowptr, A->col, (const T *)A->val, (long long)n_rows,
+                                       (long long)nb, doff, dtri, dptr, mask, first_row, desc);
+                    UP_TRY(hipMemcpyAsync(hdesc.data(), desc, hdesc.size(), hipMemcpyDeviceToHost, st));
+                    UP_TRY(hipStreamSynchronize(st));
+                    A->sdia_mask = mask;
+                    S.keep(mask);
+                    rc = mik_sdiac_finish(ctx, A, hdesc, nb, es, (int64_t)slots_total);
+                    if (rc != MIK_OK) goto give_up;
+                } else {
+                    UP_TRY(hipMalloc(&A->sdia_val, es * (size_t)std::max(slots_total, 1)));
+                    UP_TRY(hipMemsetAsync(A->sdia_val, 0, es * (size_t)std::max(slots_total, 1), st));
+                    hipLaunchKernelGGL((k_up_row_values<T>), dim3(blocks_for(n_rows)), dim3(MIK_BLOCK), 0, st, A->rowptr, A->col, (const T *)A->val, (long long)n_rows,
+                                       doff, dptr, (T *)A->sdia_val);
+                    UP_TRY(hipStreamSynchronize(st));
+                    A->sdia_ptr = dptr; A->sdia_off = doff; A->sdia_tri = dtri; A->sdia_mask = mask;
+                    S.keep(dptr); S.keep(doff); S.keep(dtri); S.keep(mask);
+                    A->sdia_entries = slots_total;
+                }
+            }
+        }
+    }
+    UP_TRY(hipGetLastError());
+    return MIK_OK;
+hip_fail:
+    rc = (e == hipErrorOutOfMemory) ? MIK_ERR_NOTIMPL      // not enough room for the raw copy next to the operator: the host path needs less
+                                    : mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create (device upload): %s", hipGetErrorString(e));
+give_up:
+    (void)hipStreamSynchronize(st);
+    (void)hipGetLastError();
+    return rc;
+#undef UP_TRY
+}
+
+}  // namespace
+
+// MIK_OK: A holds the CSR arrays, the statistics and (if the pattern qualifies) a per-slice-offset layout, all built on the
+// device.  MIK_ERR_NOTIMPL: take the host path (A's device arrays, if any, are released by the caller through
+// mik_csr_destroy-style cleanup of the fields this function sets).  Anything else: the error to return.
+int mik_upload_device(mik_ctx *ctx, mik_csr *A, int dtype, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *ptr, const int64_t *idx,
+                      const void *val, int index_base, int is_csc)
+{
+    if (dtype == MIK_F64) return upload_device_t<double>(ctx, A, n_rows, n_cols, nnz, ptr, idx, val, index_base, is_csc);
+    return upload_device_t<float>(ctx, A, n_rows, n_cols, nnz, ptr, idx, val, index_base, is_csc);
+}

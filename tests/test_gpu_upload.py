@@ -1,0 +1,125 @@
+"""mik_csr_create: the device-side upload pipeline (csrc/mik_upload.hip: raw CSC -> validated Int32 CSR + layout analysis on
+the device) against the host path (development knob 20 = 1) and the oracle: same layout choice, same stored bytes, same bits
+out of mul_ -- for symmetric and nonsymmetric CSC input, CSR input, a rank's rectangular block, empty rows, both dtypes --
+and the matrices that are handed back to the host path (long rows, duplicate entries).  GPU box only."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def both_paths(pkg, make):
+    L = pkg.lib()
+    dev = make()
+    L.mik_set_tuning(20, 1)
+    try:
+        host = make()
+    finally:
+        L.mik_set_tuning(20, 0)
+    return dev, host
+
+
+def same_operator(pkg, orc, dev, host, A, x):
+    assert dev.layout() == host.layout()
+    assert dev.spmv_kernel() == host.spmv_kernel()
+    assert dev.spmv_stored_bytes() == host.spmv_stored_bytes()
+    yd = pkg.mul_(pkg.HipVector(dev.n_rows, x.dtype), dev, pkg.HipVector.from_numpy(x)).to_numpy()
+    yh = pkg.mul_(pkg.HipVector(host.n_rows, x.dtype), host, pkg.HipVector.from_numpy(x)).to_numpy()
+    assert np.array_equal(yd, yh)
+    if A is not None:
+        assert np.array_equal(yd, orc.spmv(A, x))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("case", ["laplace3d", "laplace2d", "advdiff", "varying", "banded_wide", "random", "empty_rows"])
+def test_device_upload_equals_host_upload(pkg, orc, ctx, case, dtype):
+    rng = np.random.default_rng(3)
+    if case == "laplace3d":
+        A = orc.laplace(13, 3)
+    elif case == "laplace2d":
+        A = orc.laplace(41, 2)
+    elif case == "advdiff":                                  # nonsymmetric: the transpose matters
+        A = orc.advdiff(9, 300.0)[0]
+    elif case == "varying":                                  # stencil with varying coefficients: per-row value slots
+        n = 2000
+        S = sp.diags([rng.standard_normal(n - abs(o)) for o in (-45, -1, 0, 1, 45)], (-45, -1, 0, 1, 45), format="csc")
+        A = orc.CSC.from_scipy(S)
+    elif case == "banded_wide":                              # > 8 offsets per slice: 8-bit column codes (host builder on the device CSR)
+        n = 3000
+        offs = [0] + [o for d in (1, 2, 3, 7, 50, 51, 200, 333, 900) for o in (d, -d)]
+        S = sp.diags([np.full(n - abs(o), 40.0 if o == 0 else -1.0 / (1 + abs(o) % 5)) for o in offs], offs, format="csc")
+        A = orc.CSC.from_scipy(S)
+    elif case == "random":                                   # rows of 0..40 entries, random columns: CSR layout
+        n = 3000
+        S = sp.random(n, n, density=0.004, random_state=5, format="csc")
+        S.sort_indices()
+        A = orc.CSC.from_scipy(S)
+    else:
+        D = sp.lil_matrix((1000, 1000))
+        D[5, 7] = 2.0; D[5, 5] = 1.0; D[700, 3] = -4.0; D[999, 999] = 3.0
+        A = orc.CSC.from_scipy(D.tocsc())
+    A = A.astype(dtype)
+    x = rng.standard_normal(A.n).astype(dtype)
+    dev, host = both_paths(pkg, lambda: pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval, index_base=A.index_base))
+    same_operator(pkg, orc, dev, host, A, x)
+    # the same matrix handed over as CSR (0-based)
+    S = A.to_scipy().tocsr()
+    S.sort_indices()
+    dev, host = both_paths(pkg, lambda: pkg.HipCSR(A.n, A.n, S.indptr.astype(np.int64), S.indices.astype(np.int64), S.data.astype(dtype), index_base=0,
+                                                   is_csc=False))
+    same_operator(pkg, orc, dev, host, A, x)
+
+
+def test_device_upload_of_a_rank_block_with_halo_columns(pkg, orc, ctx, dist):
+    N, NZ, P = 12, 12, 3
+    n = N * N * NZ
+    A = orc.laplace(N, 3)
+    S = A.to_scipy().tocsr()
+    offsets = dist.partition_rows(n, P, align=N * N)
+    x = np.random.default_rng(2).standard_normal(n)
+    want = orc.spmv(A, x)
+    for r in range(P):
+        r0, r1 = int(offsets[r]), int(offsets[r + 1])
+        blk = S[r0:r1]
+        li, plan = dist.localize_block(blk.indptr.astype(np.int64), blk.indices.astype(np.int64), offsets, r)
+        dev, host = both_paths(pkg, lambda: pkg.HipCSR(plan.n_loc, plan.n_loc + plan.n_ghost, blk.indptr.astype(np.int64), li, blk.data, index_base=0,
+                                                       is_csc=False))
+        xe = np.concatenate([x[r0:r1], x[plan.ghost_gids]])
+        same_operator(pkg, orc, dev, host, None, xe)
+        assert np.array_equal(pkg.mul_(pkg.HipVector(plan.n_loc), dev, pkg.HipVector.from_numpy(xe)).to_numpy(), want[r0:r1])
+
+
+def test_matrices_handed_back_to_the_host_path(pkg, orc, ctx):
+    """long rows (the wave-shaped row sum) and duplicate (row, column) entries in CSC input keep the host path's semantics"""
+    orc.set_long_row(ctx.spmv_long_row(), ctx.spmv_long_segment())
+    try:
+        n, rowptr, colidx, val = pkg.fixtures.irregular_matrix(6000, np.float64)
+        dev, host = both_paths(pkg, lambda: pkg.HipCSR(n, n, rowptr, colidx, val, index_base=0, is_csc=False))
+        x = np.random.default_rng(4).standard_normal(n)
+        M = sp.csr_matrix((val, colidx, rowptr), shape=(n, n)).tocsc()
+        M.sort_indices()
+        same_operator(pkg, orc, dev, host, orc.CSC(n, M.indptr.astype(np.int64), M.indices.astype(np.int64), M.data.copy(), 0), x)
+    finally:
+        orc.set_long_row(0)
+    # duplicates: column 1 lists row 2 twice; the host path adds both in the order given (Julia's column scatter would too)
+    colptr = np.array([0, 1, 4, 5], np.int64)
+    rowval = np.array([0, 2, 1, 2, 2], np.int64)
+    nz = np.array([1.0, 0.1, 5.0, 0.7, 3.0])
+    dev, host = both_paths(pkg, lambda: pkg.HipCSR(3, 3, colptr, rowval, nz, index_base=0))
+    x = np.array([1.0, 3.0, -2.0])
+    yd = pkg.mul_(pkg.HipVector(3), dev, pkg.HipVector.from_numpy(x)).to_numpy()
+    yh = pkg.mul_(pkg.HipVector(3), host, pkg.HipVector.from_numpy(x)).to_numpy()
+    assert np.array_equal(yd, yh)
+    assert yd[2] == (0.1 * 3.0 + 0.7 * 3.0) + 3.0 * -2.0
+
+
+def test_invalid_input_is_rejected_by_the_device_path(pkg, ctx):
+    ptr = np.array([0, 1, 2], np.int64)
+    with pytest.raises(pkg.MikError):
+        pkg.HipCSR(2, 2, ptr, np.array([0, 5], np.int64), np.ones(2), index_base=0)       # index out of range
+    with pytest.raises(pkg.MikError):
+        pkg.HipCSR(3, 3, np.array([0, 2, 1, 3], np.int64), np.array([0, 1, 2], np.int64), np.ones(3), index_base=0)   # ptr not monotone
+    A = pkg.HipCSR(2, 2, ptr, np.array([0, 1], np.int64), np.array([2.0, 3.0]), index_base=0)   # the context is still usable
+    y = pkg.mul_(pkg.HipVector(2), A, pkg.HipVector.from_numpy(np.array([1.0, 1.0]))).to_numpy()
+    assert np.array_equal(y, [2.0, 3.0])
