@@ -115,7 +115,8 @@ int mik_spmv_long_segment(int *segment);
  *  10: 1 = no 8-bit column codes        11: 1 = no slice-constant values        12: 1 = no per-slice-offset layout
  *  13: bit mask switching the Krylov-basis streaming hints off    14: CSR kernel: 0 = by operator, 1 = register-staged products, 2 = LDS-DMA tile + per-row gather
  *  15: long-row segment length (> 0; read at mik_csr_create)   16: slices per workgroup of the layout-5 kernels (1 / 2 / 4)
- *  17: 1 = layout 5 through flat loads (k_spmv_sdiac)              18: 1 = k_spmv_sdiab without the compiled-in slot class */
+ *  17: 1 = layout 5 through flat loads (k_spmv_sdiac)              18: 1 = k_spmv_sdiab without the compiled-in slot class
+ *  20: 1 = mik_csr_create on the host path only */
 int mik_set_tuning(int key, int value);
 
 /* ---- device memory (similar / zero / copyto! / fill! of the vector interface) ----------- */
@@ -129,8 +130,11 @@ int mik_fill(mik_ctx *ctx, int dtype, int64_t n, const void *value, void *x); /*
 /* ---- operator ---------------------------------------------------------------------------- */
 /* Upload a SparseMatrixCSC (is_csc = 1: ptr = colptr, idx = rowval -- the layout of
  * test/laplace_matrix.jl:12) or a CSR matrix (is_csc = 0).  Host arrays, Int64 indices with
- * `index_base` (1 for Julia).  Converts to 0-based Int32 CSR (CSC -> CSR transpose on the host,
- * columns ascending within a row) and copies to the device. */
+ * `index_base` (1 for Julia).  The arrays are copied to the device as they are; validation, the conversion to 0-based
+ * Int32 CSR (CSC -> CSR transpose, columns ascending within a row = the order Julia's column scatter reaches a row), the
+ * operator statistics and the layout analysis run there as kernels (csrc/mik_upload.hip; 0.06 s for the 256^3 Laplacian).
+ * Matrices with rows longer than mik_spmv_long_row() or with duplicate (row, column) entries take the host path
+ * (single-threaded counting-sort transpose + builders), as does everything when development knob 20 is set. */
 int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_cols, int64_t nnz,
                    const int64_t *ptr, const int64_t *idx, const void *val, int index_base,
                    int is_csc, mik_csr **out);

@@ -19,24 +19,30 @@ def laplace_matrix(N: int, dims: int = 3, dtype=np.float64, index_base: int = 1,
     """
     n = N ** dims
     r0, r1 = (0, n) if rows is None else rows
-    j = np.arange(r0, r1, dtype=np.int64)
     strides = [N ** d for d in range(dims)]
-    cand = []
-    for d in reversed(range(dims)):                       # rows above the diagonal: j - N^2, j - N, j - 1
-        c = (j // strides[d]) % N
-        cand.append((j - strides[d], c > 0, -1.0))
-    cand.append((j, np.ones(j.shape, bool), 2.0 * dims))
-    for d in range(dims):                                 # j + 1, j + N, j + N^2
-        c = (j // strides[d]) % N
-        cand.append((j + strides[d], c < N - 1, -1.0))
-    idx = np.stack([c[0] for c in cand], axis=1)
-    mask = np.stack([c[1] for c in cand], axis=1)
-    val = np.broadcast_to(np.asarray([c[2] for c in cand], dtype=dtype), idx.shape)
-    counts = mask.sum(axis=1)
-    ptr = np.empty(j.size + 1, np.int64)
+    CH = 1 << 21                                          # rows per chunk: bounds the temporaries to ~0.4 GB whatever the slab size
+    ptr = np.empty(r1 - r0 + 1, np.int64)
     ptr[0] = 0
-    np.cumsum(counts, out=ptr[1:])
-    return n, ptr + index_base, idx[mask] + index_base, np.ascontiguousarray(val[mask])
+    idx_parts, val_parts = [], []
+    for c0 in range(r0, r1, CH):
+        j = np.arange(c0, min(c0 + CH, r1), dtype=np.int64)
+        cand = []
+        for d in reversed(range(dims)):                   # rows above the diagonal: j - N^2, j - N, j - 1
+            c = (j // strides[d]) % N
+            cand.append((j - strides[d], c > 0, -1.0))
+        cand.append((j, np.ones(j.shape, bool), 2.0 * dims))
+        for d in range(dims):                             # j + 1, j + N, j + N^2
+            c = (j // strides[d]) % N
+            cand.append((j + strides[d], c < N - 1, -1.0))
+        idx = np.stack([c[0] for c in cand], axis=1)
+        mask = np.stack([c[1] for c in cand], axis=1)
+        val = np.broadcast_to(np.asarray([c[2] for c in cand], dtype=dtype), idx.shape)
+        np.cumsum(mask.sum(axis=1), out=ptr[c0 - r0 + 1:c0 - r0 + 1 + j.size])
+        ptr[c0 - r0 + 1:c0 - r0 + 1 + j.size] += ptr[c0 - r0]
+        idx_parts.append(idx[mask] + index_base)
+        val_parts.append(np.ascontiguousarray(val[mask]))
+    return n, ptr + index_base, np.concatenate(idx_parts) if idx_parts else np.empty(0, np.int64), \
+        np.concatenate(val_parts) if val_parts else np.empty(0, dtype)
 
 
 def advection_dominated(N: int = 50, beta: float = 1000.0, index_base: int = 1):
