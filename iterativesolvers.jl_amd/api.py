@@ -294,6 +294,25 @@ class HipCSR:
               "mik_csr_create", self.ctx.handle)
         self.handle = h
 
+    @classmethod
+    def from_device(cls, n_rows, n_cols, nnz, ptr_dev: int, idx_dev: int, val_dev: int, dtype, *, index_base=1, is_csc=True,
+                    ctx: Optional[HipContext] = None) -> "HipCSR":
+        """The same operator from arrays that already live in device memory (raw device pointers of an Int64 ``ptr`` /
+        ``idx`` and a ``val`` array of ``dtype`` -- a ROCSparseMatrixCSC, torch tensors): ``mik_csr_create`` detects the
+        placement and starts its device-side pipeline from them; no host copy.  The arrays are only read during the call."""
+        self = cls.__new__(cls)
+        self.ctx = ctx or default_context()
+        self.dtype = np.dtype(dtype)
+        self.code = dtype_code(self.dtype)
+        self.n_rows, self.n_cols, self.nnz = int(n_rows), int(n_cols), int(nnz)
+        h = _vp()
+        check(lib().mik_csr_create(self.ctx.handle, self.code, self.n_rows, self.n_cols, self.nnz,
+                                   C.cast(_vp(int(ptr_dev)), C.POINTER(C.c_int64)), C.cast(_vp(int(idx_dev)), C.POINTER(C.c_int64)),
+                                   _vp(int(val_dev)), int(index_base), int(bool(is_csc)), C.byref(h)),
+              "mik_csr_create", self.ctx.handle)
+        self.handle = h
+        return self
+
     @staticmethod
     def from_scipy(m, ctx=None) -> "HipCSR":
         m = m.tocsc()

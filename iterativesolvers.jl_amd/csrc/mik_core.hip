@@ -565,6 +565,16 @@ static int csr_build_sell(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
 // ---------------------------------------------------------------------------------------------
 // operator upload
 // ---------------------------------------------------------------------------------------------
+static bool is_device_pointer(const void *p)
+{
+    hipPointerAttribute_t attr;
+    if (!p || hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain host memory: "invalid value"
+    return attr.type == hipMemoryTypeDevice;
+}
+
+static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *ptr, const int64_t *idx,
+                           const void *val, int index_base, int is_csc, bool on_device, mik_csr **out);
+
 extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_cols, int64_t nnz,
                               const int64_t *ptr, const int64_t *idx, const void *val, int index_base,
                               int is_csc, mik_csr **out)
@@ -576,11 +586,52 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
         return mik_fail(ctx, MIK_ERR_INVALID, "mik_csr_create: bad sizes or NULL arrays");
     if (n_rows >= (int64_t)INT32_MAX - MIK_BLOCK || n_cols >= INT32_MAX || nnz >= (int64_t)INT32_MAX - 2 * MIK_SPMV_TILE)
         return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_csr_create: sizes exceed the Int32 device index range");
+    // The three arrays may also live in device memory (a ROCSparseMatrixCSC, a torch tensor): the upload pipeline then starts
+    // from them without a host copy.  Mixed placement is refused.
+    (void)hipSetDevice(ctx->device);
+    const bool dev_in = is_device_pointer(ptr);
+    if (nnz && (is_device_pointer(idx) != dev_in || is_device_pointer(val) != dev_in))
+        return mik_fail(ctx, MIK_ERR_INVALID, "mik_csr_create: ptr / idx / val must all be host arrays or all device arrays");
+    if (!dev_in) return csr_create_impl(ctx, dtype, n_rows, n_cols, nnz, ptr, idx, val, index_base, is_csc, false, out);
+    int rc = csr_create_impl(ctx, dtype, n_rows, n_cols, nnz, ptr, idx, val, index_base, is_csc, true, out);
+    if (rc != MIK_ERR_NOTIMPL) return rc;
+    // the host path's matrices (long rows, duplicates, knob 20): stage the arrays on the host once
+    const int64_t n_major = is_csc ? n_cols : n_rows;
+    const size_t es = mik_dtype_size(dtype);
+    std::vector<int64_t> hp, hi;
+    std::vector<unsigned char> hv;
+    try {
+        hp.resize((size_t)n_major + 1);
+        hi.resize((size_t)nnz);
+        hv.resize((size_t)nnz * es);
+    } catch (const std::bad_alloc &) {
+        return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host staging allocation failed");
+    }
+    if (hipMemcpy(hp.data(), ptr, sizeof(int64_t) * hp.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+        (nnz && (hipMemcpy(hi.data(), idx, sizeof(int64_t) * hi.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+                 hipMemcpy(hv.data(), val, hv.size(), hipMemcpyDeviceToHost) != hipSuccess)))
+        return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create: reading the device arrays failed");
+    return csr_create_impl(ctx, dtype, n_rows, n_cols, nnz, hp.data(), hi.data(), hv.data(), index_base, is_csc, false, out);
+}
+
+// on_device: ptr / idx / val are device arrays; only the device pipeline can consume them (MIK_ERR_NOTIMPL otherwise)
+static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *ptr, const int64_t *idx,
+                           const void *val, int index_base, int is_csc, bool on_device, mik_csr **out)
+{
     const int64_t n_major = is_csc ? n_cols : n_rows;   // length of ptr - 1
     const int64_t n_minor = is_csc ? n_rows : n_cols;   // range of idx
-    if (ptr[0] != index_base || ptr[n_major] - index_base != nnz)
+    int64_t ends[2] = {0, 0};
+    if (on_device) {
+        if (hipMemcpy(&ends[0], ptr, sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(&ends[1], ptr + n_major, sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess)
+            return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create: reading ptr from the device failed");
+    } else {
+        ends[0] = ptr[0];
+        ends[1] = ptr[n_major];
+    }
+    if (ends[0] != index_base || ends[1] - index_base != nnz)
         return mik_fail(ctx, MIK_ERR_MISMATCH, "mik_csr_create: ptr[0]=%lld, ptr[end]=%lld inconsistent with nnz=%lld, base=%d",
-                        (long long)ptr[0], (long long)ptr[n_major], (long long)nnz, index_base);
+                        (long long)ends[0], (long long)ends[1], (long long)nnz, index_base);
     const size_t es = mik_dtype_size(dtype);
     std::vector<int> rowptr, col;
     std::vector<unsigned char> v;
@@ -615,6 +666,7 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
         mik_csr_destroy(A);
         if (rc != MIK_ERR_NOTIMPL) return rc;
     }
+    if (on_device) return MIK_ERR_NOTIMPL;             // the caller stages the arrays on the host and comes back
     try {
         rowptr.assign((size_t)n_rows + 1, 0);
         col.resize((size_t)nnz);

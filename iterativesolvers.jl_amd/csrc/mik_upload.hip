@@ -377,9 +377,9 @@ int upload_device_t(mik_ctx *ctx, mik_csr *A, int64_t n_rows, int64_t n_cols, in
     UP_TRY(hipMemsetAsync(A->rowptr, 0, sizeof(int) * ((size_t)n_rows + 1 + 256), st));
     UP_TRY(hipMemsetAsync(A->col + nnz, 0, sizeof(int) * pad, st));
     UP_TRY(hipMemsetAsync((unsigned char *)A->val + es * (size_t)nnz, 0, es * pad, st));
-    UP_TRY(hipMemcpyAsync(d_ptr, ptr, sizeof(long long) * ((size_t)n_major + 1), hipMemcpyHostToDevice, st));
-    UP_TRY(hipMemcpyAsync(d_idx, idx, sizeof(long long) * (size_t)nnz, hipMemcpyHostToDevice, st));
-    UP_TRY(hipMemcpyAsync(d_val, val, es * (size_t)nnz, hipMemcpyHostToDevice, st));
+    UP_TRY(hipMemcpyAsync(d_ptr, ptr, sizeof(long long) * ((size_t)n_major + 1), hipMemcpyDefault, st));
+    UP_TRY(hipMemcpyAsync(d_idx, idx, sizeof(long long) * (size_t)nnz, hipMemcpyDefault, st));
+    UP_TRY(hipMemcpyAsync(d_val, val, es * (size_t)nnz, hipMemcpyDefault, st));
     hipLaunchKernelGGL(k_up_check_ptr, dim3(blocks_for(n_major)), dim3(MIK_BLOCK), 0, st, d_ptr, (long long)n_major, d_st);
     if (is_csc) {
         UP_TRY(S.alloc(&cursor, sizeof(int) * ((size_t)n_rows + 1)));

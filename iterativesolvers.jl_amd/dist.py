@@ -107,12 +107,20 @@ def interior_row_blocks(ptr, local_idx, n_loc: int, block: int = 256):
     """Row-blocks [a, b) (of `block` rows) that contain no row referencing a halo column (local index >= n_loc),
     when the blocks that do form a prefix and a suffix of the rank's rows (slab partitions); else None."""
     nb = (n_loc + block - 1) // block
-    ptr = np.asarray(ptr)
-    ghost_entries = np.nonzero(np.asarray(local_idx) >= n_loc)[0]
-    if ghost_entries.size == 0:
-        return (0, nb) if nb else None
-    rows = np.searchsorted(ptr, ghost_entries, side="right") - 1
-    blocks = np.unique(rows // block)
+    if not isinstance(ptr, np.ndarray) and hasattr(ptr, "data_ptr"):           # torch tensors on the device: same steps there
+        import torch
+        ghost_entries = torch.nonzero(local_idx >= n_loc).flatten()
+        if ghost_entries.numel() == 0:
+            return (0, nb) if nb else None
+        rows = torch.searchsorted(ptr, ghost_entries, right=True) - 1
+        blocks = torch.unique(torch.div(rows, block, rounding_mode="floor")).cpu().numpy()
+    else:
+        ptr = np.asarray(ptr)
+        ghost_entries = np.nonzero(np.asarray(local_idx) >= n_loc)[0]
+        if ghost_entries.size == 0:
+            return (0, nb) if nb else None
+        rows = np.searchsorted(ptr, ghost_entries, side="right") - 1
+        blocks = np.unique(rows // block)
     a = 0
     while a < blocks.size and blocks[a] == a:
         a += 1
@@ -312,14 +320,19 @@ class HipEngine:
         self.pkg, self.torch, self.plan = pkg, torch, plan
         L = pkg.lib()
         self.L = L
-        dtype = np.dtype(val.dtype)
+        dtype = np.dtype({torch.float64: np.float64, torch.float32: np.float32}[val.dtype]) if isinstance(val, torch.Tensor) else np.dtype(val.dtype)
         tdt = {np.dtype(np.float64): torch.float64, np.dtype(np.float32): torch.float32}[dtype]
         dev = torch.device("cuda", device)
         self.ctx = pkg.HipContext(device)
         self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)   # loopback ranks share one stream
         self.ctx.set_stream(self.stream.cuda_stream)
         n_loc, n_ext = plan.n_loc, plan.n_loc + plan.n_ghost
-        self.A = pkg.HipCSR(n_loc, n_ext, ptr, local_idx, val, index_base=0, is_csc=False, ctx=self.ctx)
+        if isinstance(val, torch.Tensor):               # the rank's block was generated on the device (build_rank_problem)
+            torch.cuda.synchronize(dev)                 # the generator ran on torch's stream, the upload runs on the ctx stream
+            self.A = pkg.HipCSR.from_device(n_loc, n_ext, int(val.numel()), ptr.data_ptr(), local_idx.data_ptr(), val.data_ptr(), dtype,
+                                            index_base=0, is_csc=False, ctx=self.ctx)
+        else:
+            self.A = pkg.HipCSR(n_loc, n_ext, ptr, local_idx, val, index_base=0, is_csc=False, ctx=self.ctx)
         with torch.cuda.stream(self.stream):
             self.u_ext = torch.zeros(max(n_ext, 1), dtype=tdt, device=dev)           # receives the halo in place
             self.send_buf = torch.zeros(max(plan.n_send, 1), dtype=tdt, device=dev)
@@ -822,20 +835,25 @@ class LoopbackCG:
         return np.concatenate([e.solution() for e in self.engines])
 
 
-def build_rank_problem(pkg, comm, N: int, nz_per_rank: Optional[int] = None, dtype=np.float64):
+def build_rank_problem(pkg, comm, N: int, nz_per_rank: Optional[int] = None, dtype=np.float64, device=None):
     """z-slab of the 3D Laplacian on an N x N x (nz_per_rank * P) grid -- or of the cubic N^3 grid when
     nz_per_rank is None -- plus the hashed rhs; returns (ptr, local_idx, val, plan, b_loc, n_global)."""
     P, rank = comm.size, comm.rank
+    rows = _laplace_rows
+    localize = localize_block
+    if device is not None:                          # generate and localise the slab on the GPU: no host pass over its entries
+        rows = lambda pkg_, N_, NZ_, a, b, dt: _laplace_rows_torch(N_, NZ_, a, b, dt, device)
+        localize = localize_block_torch
     if nz_per_rank is None:
         n = N ** 3
         offsets = partition_rows(n, P, align=N * N)
-        n_glob, ptr, idx, val = _laplace_rows(pkg, N, N, offsets[rank], offsets[rank + 1], dtype)
+        n_glob, ptr, idx, val = rows(pkg, N, N, offsets[rank], offsets[rank + 1], dtype)
     else:
         NZ = nz_per_rank * P
         n = N * N * NZ
         offsets = np.arange(P + 1, dtype=np.int64) * (N * N * nz_per_rank)
-        n_glob, ptr, idx, val = _laplace_rows(pkg, N, NZ, offsets[rank], offsets[rank + 1], dtype)
-    local_idx, plan = localize_block(ptr, idx, offsets, rank)
+        n_glob, ptr, idx, val = rows(pkg, N, NZ, offsets[rank], offsets[rank + 1], dtype)
+    local_idx, plan = localize(ptr, idx, offsets, rank)
     needs = comm.all_gather_objects(plan.ghost_gids)
     complete_plan(plan, offsets, needs)
     b_loc = pkg.fixtures.hashed_rhs(n, int(offsets[rank]), int(offsets[rank + 1]), dtype)
@@ -860,6 +878,46 @@ def _laplace_rows(pkg, N, NZ, r0, r1, dtype):
     ptr = np.zeros(j.size + 1, np.int64)
     np.cumsum(mask.sum(axis=1), out=ptr[1:])
     return N * N * NZ, ptr, idx[mask], np.ascontiguousarray(val[mask])
+
+
+def _laplace_rows_torch(N, NZ, r0, r1, dtype, device):
+    """_laplace_rows on the GPU (torch tensors): the rank's slab never exists on the host."""
+    import torch
+    dev = torch.device("cuda", device) if isinstance(device, int) else device
+    tdt = {np.dtype(np.float64): torch.float64, np.dtype(np.float32): torch.float32}[np.dtype(dtype)]
+    j = torch.arange(int(r0), int(r1), dtype=torch.int64, device=dev)
+    dims = [(1, N), (N, N), (N * N, NZ)]
+    cand = []
+    for stride, ext in reversed(dims):
+        c = torch.div(j, stride, rounding_mode="floor") % ext
+        cand.append((j - stride, c > 0, -1.0))
+    cand.append((j, torch.ones_like(j, dtype=torch.bool), 6.0))
+    for stride, ext in dims:
+        c = torch.div(j, stride, rounding_mode="floor") % ext
+        cand.append((j + stride, c < ext - 1, -1.0))
+    idx = torch.stack([c[0] for c in cand], dim=1)
+    mask = torch.stack([c[1] for c in cand], dim=1)
+    val = torch.tensor([c[2] for c in cand], dtype=tdt, device=dev).expand(idx.shape)
+    ptr = torch.zeros(j.numel() + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(mask.sum(dim=1), dim=0, out=ptr[1:])
+    return N * N * NZ, ptr, idx[mask].contiguous(), val[mask].contiguous()
+
+
+def localize_block_torch(ptr, idx, offsets, rank):
+    """localize_block for device tensors: local column ids stay on the device, the (small) halo plan comes to the host."""
+    import torch
+    r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
+    n_loc = r1 - r0
+    owned = (idx >= r0) & (idx < r1)
+    ghost = torch.unique(idx[~owned])                                   # sorted
+    local = torch.where(owned, idx - r0, n_loc + torch.searchsorted(ghost, idx))
+    ghost_gids = ghost.cpu().numpy()
+    plan = HaloPlan(rank, len(offsets) - 1, n_loc, ghost_gids)
+    owner = np.searchsorted(offsets, ghost_gids, side="right") - 1
+    for peer in np.unique(owner):
+        sel = np.nonzero(owner == peer)[0]
+        plan.recv.append((int(peer), int(sel[0]), int(sel.size)))
+    return local.contiguous(), plan
 
 
 # ==============================================================================================
@@ -906,8 +964,9 @@ def bench_main(args):
     else:
         N, nz = 512, 64                                      # configs[3]: 512 x 512 x 64 P (P = 8: 512^3)
     t_up = time.perf_counter()
-    ptr, local_idx, val, plan, b_loc, n, offsets = build_rank_problem(pkg, boot, N, nz_per_rank=nz)
-    nnz_loc = int(val.size)
+    on_host = os.environ.get("MIK_DIST_HOST_BUILD", "0") == "1"           # development: the numpy generator + host arrays
+    ptr, local_idx, val, plan, b_loc, n, offsets = build_rank_problem(pkg, boot, N, nz_per_rank=nz, device=None if on_host else local_rank)
+    nnz_loc = int(val.numel() if hasattr(val, "numel") else val.size)
     eng = HipEngine(pkg, ptr, local_idx, val, plan, b_loc, abstol=0.0, reltol=0.0, maxiter=10 ** 9, device=local_rank)
     upload_seconds = time.perf_counter() - t_up
     del ptr, local_idx, val

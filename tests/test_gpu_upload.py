@@ -123,3 +123,42 @@ def test_invalid_input_is_rejected_by_the_device_path(pkg, ctx):
     A = pkg.HipCSR(2, 2, ptr, np.array([0, 1], np.int64), np.array([2.0, 3.0]), index_base=0)   # the context is still usable
     y = pkg.mul_(pkg.HipVector(2), A, pkg.HipVector.from_numpy(np.array([1.0, 1.0]))).to_numpy()
     assert np.array_equal(y, [2.0, 3.0])
+
+
+def test_device_resident_input_arrays(pkg, orc, ctx, dist):
+    """mik_csr_create on arrays that already live in device memory (torch tensors), incl. a matrix the host path must take;
+    the row-partitioned bench builds its slab this way (dist._laplace_rows_torch / localize_block_torch)"""
+    import torch
+    A = orc.advdiff(9, 300.0)[0]
+    dev = torch.device("cuda", 0)
+    tp, ti, tv = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (A.colptr.astype(np.int64), A.rowval.astype(np.int64), A.nzval))
+    torch.cuda.synchronize()
+    dA = pkg.HipCSR.from_device(A.n, A.n, A.nzval.size, tp.data_ptr(), ti.data_ptr(), tv.data_ptr(), np.float64, index_base=A.index_base)
+    hA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval, index_base=A.index_base)
+    x = np.random.default_rng(8).standard_normal(A.n)
+    same_operator(pkg, orc, dA, hA, A, x)
+    # long rows: handed back to the host path, which stages the device arrays once
+    orc.set_long_row(ctx.spmv_long_row(), ctx.spmv_long_segment())
+    try:
+        n, rowptr, colidx, val = pkg.fixtures.irregular_matrix(6000, np.float64)
+        tp, ti, tv = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (rowptr.astype(np.int64), colidx.astype(np.int64), val))
+        torch.cuda.synchronize()
+        dA = pkg.HipCSR.from_device(n, n, val.size, tp.data_ptr(), ti.data_ptr(), tv.data_ptr(), np.float64, index_base=0, is_csc=False)
+        hA = pkg.HipCSR(n, n, rowptr, colidx, val, index_base=0, is_csc=False)
+        same_operator(pkg, orc, dA, hA, None, np.random.default_rng(9).standard_normal(n))
+    finally:
+        orc.set_long_row(0)
+    # mixed placement is refused
+    with pytest.raises(pkg.MikError):
+        pkg.HipCSR.from_device(A.n, A.n, A.nzval.size, tp.data_ptr(), A.rowval.ctypes.data, tv.data_ptr(), np.float64)
+    # the slab generator and the localisation on the device equal the numpy ones
+    N, NZ, P = 12, 9, 3
+    offsets = np.arange(P + 1, dtype=np.int64) * (N * N * (NZ // P))
+    for r in range(P):
+        _, ptr, idx, val = dist._laplace_rows(pkg, N, NZ, offsets[r], offsets[r + 1], np.float64)
+        _, tptr, tidx, tval = dist._laplace_rows_torch(N, NZ, offsets[r], offsets[r + 1], np.float64, 0)
+        assert np.array_equal(ptr, tptr.cpu().numpy()) and np.array_equal(idx, tidx.cpu().numpy()) and np.array_equal(val, tval.cpu().numpy())
+        li, plan = dist.localize_block(ptr, idx, offsets, r)
+        tli, tplan = dist.localize_block_torch(tptr, tidx, offsets, r)
+        assert np.array_equal(li, tli.cpu().numpy()) and np.array_equal(plan.ghost_gids, tplan.ghost_gids) and plan.recv == tplan.recv
+        assert dist.interior_row_blocks(ptr, li, plan.n_loc) == dist.interior_row_blocks(tptr, tli, plan.n_loc)
