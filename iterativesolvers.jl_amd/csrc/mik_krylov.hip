@@ -1157,8 +1157,8 @@ static int gmres_create_common(mik_ctx *ctx, const mik_csr *A, void *x, const vo
     }
     {
         const int64_t nseg = dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
-        if (!part && orth_method == MIK_MGS && nseg >= 1 && nseg <= 256) {
-            const size_t pbytes = es * 2 * (size_t)(restart + 1) * 256;
+        if (!part && (orth_method == MIK_MGS || orth_method == MIK_CGS) && nseg >= 1 && nseg <= 256 && restart <= 254) {
+            const size_t pbytes = es * 2 * (size_t)(restart + 2) * 256;     // k_cgs_fused: one more row (the final h values)
             if ((e = hipMalloc(&g->mgs_P, pbytes)) != hipSuccess || (e = hipMemsetAsync(g->mgs_P, 0xFF, pbytes, ctx->stream)) != hipSuccess ||
                 (g->mgs_mirror_stride = (sizeof(MgsMirror) + es * (size_t)(restart + 2) + 255) / 256 * 256, false) ||
                 (e = hipHostMalloc((void **)&g->mgs_mirror, 2 * g->mgs_mirror_stride, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) {
@@ -1313,7 +1313,12 @@ template <typename T> static int gm_fused_enqueue(mik_gmres *g, int k, int slot)
     const bool vec = mik_aligned16(V) && mik_aligned16(w) && (g->ldv % VT<T>::W == 0);
     g->mgs_seq += 1;
     g->mgs_slot_seq[slot] = g->mgs_seq;
-    if (vec) hipLaunchKernelGGL((k_mgs_fused<T, true>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart,
+    if (g->method == MIK_CGS) {
+        if (vec) hipLaunchKernelGGL((k_cgs_fused<T, true>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart,
+                                    g->mgs_parity, gm_mirror(g, slot), g->mgs_seq);
+        else hipLaunchKernelGGL((k_cgs_fused<T, false>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart,
+                                g->mgs_parity, gm_mirror(g, slot), g->mgs_seq);
+    } else if (vec) hipLaunchKernelGGL((k_mgs_fused<T, true>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart,
                                 g->mgs_parity, gm_mirror(g, slot), g->mgs_seq);
     else hipLaunchKernelGGL((k_mgs_fused<T, false>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart,
                             g->mgs_parity, gm_mirror(g, slot), g->mgs_seq);
