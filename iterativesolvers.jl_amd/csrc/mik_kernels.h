@@ -735,16 +735,20 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_mgs_fused(int64_t n, int k, const
     }
 }
 
-// Classical Gram-Schmidt as ONE launch (same sizes, same hand-off mechanism as k_mgs_fused):
+// Classical Gram-Schmidt (and DGKS) as ONE launch (same sizes, same hand-off mechanism as k_mgs_fused):
 //   h = V' w  (all k dots on the SAME w: one batch);  w -= V h;  nrm = norm(w);  w *= inv(nrm)      src/orthogonalize.jl:15-17,75-76
 // Three dependent grid-wide steps instead of k + 1:  (1) every workgroup publishes its k segment sums (rows 0..k-1 of the
 // slot buffer);  (2) column j is reduced by ONE workgroup (j mod m) with the usual level-2 tree and published as a final
 // value (row kmax + 1), which every workgroup then picks up -- k x m slot reads per workgroup would cost more than the second
 // hand-off;  (3) the norm goes through row k like the last pass of k_mgs_fused.  Products, per-thread order, block and
 // level-2 trees are those of k_multidot / k_gemv_n / OpDot + k_finalize_*: bit-identical to the multi-launch chain.
-template <typename T, bool VEC>
+// DGKS (src/orthogonalize.jl:20-36): the same round is repeated while nrm < eta * norm(correction), every round in its own
+// block of slot rows; all workgroups evaluate the condition on identical values.  After `rounds` rounds (or when the sum of
+// squares leaves the safe range) the kernel stops WITHOUT scaling w and reports {h, nrm, projection size, more = 1}: the host
+// continues the loop with the multi-launch chain (it "typically runs once", ibid.).
+template <typename T, bool VEC, bool DGKS>
 __global__ __launch_bounds__(MIK_BLOCK) void k_cgs_fused(int64_t n, int k, const T *__restrict__ V, int64_t ldv, T *__restrict__ w,
-                                                         T *__restrict__ P /* [2][kmax + 2][256] */, int kmax, int parity,
+                                                         T *__restrict__ P /* [2][rounds][kmax + 2][256] */, int kmax, int rounds, int parity,
                                                          MgsMirror *mirror, unsigned long long seq)
 {
     using U = typename MgsBits<T>::U;
@@ -752,16 +756,20 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_cgs_fused(int64_t n, int k, const
     constexpr int64_t SEG = (int64_t)MIK_BLOCK * W * L;
     __shared__ T lds16[16];
     __shared__ T lds4[4];
-    __shared__ T wsum[256][4];                         // wave sums of the k column dots; later hs[j] = wsum[j][0]
+    __shared__ T wsum[256][4];                         // wave sums of the k column dots; then this round's h / correction in wsum[j][0]
+    __shared__ T hacc[256];                            // h, summed over the rounds
+    __shared__ T s_proj;
     __shared__ int s_err;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, s = blockIdx.x, m = gridDim.x;
     if (t == 0) s_err = 0;
-    const size_t rows = (size_t)(kmax + 2);
-    T *cur = P + (size_t)parity * rows * 256;
-    T *oth = P + (size_t)(parity ^ 1) * rows * 256;
-    T *fin = cur + (size_t)(kmax + 1) * 256;           // final h[j]
-    if (t <= kmax) __hip_atomic_store(reinterpret_cast<U *>(oth + (size_t)t * 256) + s, MgsBits<T>::EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (s == 0) __hip_atomic_store(reinterpret_cast<U *>(oth + (size_t)(kmax + 1) * 256) + t, MgsBits<T>::EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int rows = kmax + 2;                          // per round: k column rows, the norm row (index k <= kmax), the finals row
+    T *cur = P + (size_t)parity * (size_t)rounds * rows * 256;
+    T *oth = P + (size_t)(parity ^ 1) * (size_t)rounds * rows * 256;
+    for (int q = t; q < rounds * rows; q += MIK_BLOCK)  // re-arm the other buffer: this workgroup's slot of every row ...
+        __hip_atomic_store(reinterpret_cast<U *>(oth + (size_t)q * 256) + s, MgsBits<T>::EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (s == 0)                                         // ... and all 256 entries of the finals rows
+        for (int r = 0; r < rounds; ++r)
+            __hip_atomic_store(reinterpret_cast<U *>(oth + ((size_t)r * rows + kmax + 1) * 256) + t, MgsBits<T>::EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int64_t base = (int64_t)s * SEG + (int64_t)W * t;
     T wr[L][W];
     auto load = [&](const T *__restrict__ p, T(&dst)[L][W]) {
@@ -780,79 +788,102 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_cgs_fused(int64_t n, int k, const
     };
     load(w, wr);
     T *hout = reinterpret_cast<T *>(mirror + 1);
-    // (1) segment sums of V[:, j] .* w, j = 0..k-1                                     k_multidot
-    for (int j = 0; j < k; ++j) {
-        T vr[L][W];
-        load(V + (int64_t)j * ldv, vr);
+    const T eta = T(1) / mik_sqrt(T(2));                // the constant of src/orthogonalize.jl:20
+    T nrm = T(0);
+    bool ok = true, more = false;
+    for (int round = 0;; ++round) {
+        T *rb = cur + (size_t)round * rows * 256;
+        T *fin = rb + (size_t)(kmax + 1) * 256;
+        // (1) segment sums of V[:, j] .* w, j = 0..k-1                                     k_multidot
+        for (int j = 0; j < k; ++j) {
+            T vr[L][W];
+            load(V + (int64_t)j * ldv, vr);
+            T acc = T(0);
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+#pragma unroll
+                for (int e = 0; e < W; ++e)
+                    if (base + (int64_t)l * MIK_BLOCK * W + e < n) { T p = vr[l][e] * wr[l][e]; acc = acc + p; }
+            const T ws = wave_tree(acc);
+            if (lane == 0) wsum[j][wv] = ws;
+        }
+        __syncthreads();
+        T tot_t = T(0);
+        if (t < k) {
+            tot_t = wsum[t][0];
+            tot_t = tot_t + wsum[t][1]; tot_t = tot_t + wsum[t][2]; tot_t = tot_t + wsum[t][3];
+        }
+        if (t < k) {
+            U bits;
+            __builtin_memcpy(&bits, &tot_t, sizeof(T));
+            __hip_atomic_store(reinterpret_cast<U *>(rb + (size_t)t * 256) + s, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // (2) level 2 of column j by workgroup j mod m; everybody picks the finals up          k_finalize_store
+        for (int j = s; j < k; j += m) {
+            const T h = mgs_grid_sum<T>(rb + (size_t)j * 256, m, lds16, &s_err);
+            if (t == 0) {
+                U bits;
+                __builtin_memcpy(&bits, &h, sizeof(T));
+                __hip_atomic_store(reinterpret_cast<U *>(fin) + j, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        if (t < k) {
+            U bits = MgsBits<T>::EMPTY;
+            for (int spin = 0; spin < (1 << 18); ++spin) {
+                bits = __hip_atomic_load(reinterpret_cast<const U *>(fin) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (bits != MgsBits<T>::EMPTY) break;
+            }
+            if (bits == MgsBits<T>::EMPTY) s_err = 1;
+            T hv;
+            __builtin_memcpy(&hv, &bits, sizeof(T));
+            wsum[t][0] = hv;                                                       // this round's h / correction
+            hacc[t] = round == 0 ? hv : hacc[t] + hv;                              // h .+= correction               :31
+        }
+        __syncthreads();
+        // w += (-1 * c[j]) * V[:, j], j ascending                                              k_gemv_n
+        for (int j = 0; j < k; ++j) {
+            T vr[L][W];
+            load(V + (int64_t)j * ldv, vr);
+            const T temp = T(-1) * wsum[j][0];
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+#pragma unroll
+                for (int e = 0; e < W; ++e)
+                    if (base + (int64_t)l * MIK_BLOCK * W + e < n) { T p = temp * vr[l][e]; wr[l][e] = wr[l][e] + p; }
+        }
+        // (3) norm(w)                                                                          OpDot{w, w} + k_finalize_nrm_inv
         T acc = T(0);
 #pragma unroll
         for (int l = 0; l < L; ++l)
 #pragma unroll
             for (int e = 0; e < W; ++e)
-                if (base + (int64_t)l * MIK_BLOCK * W + e < n) { T p = vr[l][e] * wr[l][e]; acc = acc + p; }
-        const T ws = wave_tree(acc);
-        if (lane == 0) wsum[j][wv] = ws;
-    }
-    __syncthreads();
-    if (t < k) {
-        T tot = wsum[t][0];
-        tot = tot + wsum[t][1]; tot = tot + wsum[t][2]; tot = tot + wsum[t][3];
-        U bits;
-        __builtin_memcpy(&bits, &tot, sizeof(T));
-        __hip_atomic_store(reinterpret_cast<U *>(cur + (size_t)t * 256) + s, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // (2) level 2 of column j by workgroup j mod m; everybody picks the finals up          k_finalize_store
-    for (int j = s; j < k; j += m) {
-        const T h = mgs_grid_sum<T>(cur + (size_t)j * 256, m, lds16, &s_err);
-        if (t == 0) {
-            U bits;
-            __builtin_memcpy(&bits, &h, sizeof(T));
-            __hip_atomic_store(reinterpret_cast<U *>(fin) + j, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (base + (int64_t)l * MIK_BLOCK * W + e < n) { T p = wr[l][e] * wr[l][e]; acc = acc + p; }
+        {
+            T tot = block_tree_256(acc, lds4);
+            if (t == 0) {
+                U bits;
+                __builtin_memcpy(&bits, &tot, sizeof(T));
+                __hip_atomic_store(reinterpret_cast<U *>(rb + (size_t)k * 256) + s, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-    }
-    __syncthreads();
-    if (t < k) {
-        U bits = MgsBits<T>::EMPTY;
-        for (int spin = 0; spin < (1 << 18); ++spin) {
-            bits = __hip_atomic_load(reinterpret_cast<const U *>(fin) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (bits != MgsBits<T>::EMPTY) break;
+        const T ss = mgs_grid_sum<T>(rb + (size_t)k * 256, m, lds16, &s_err);
+        nrm = mik_sqrt(ss);
+        ok = mik_nrm_in_range(ss);
+        if (!DGKS) break;
+        if (t == 0) {                                   // norm(h) / norm(correction): serial, like the host's small_norm    :22, :28
+            T q = T(0);
+            for (int j = 0; j < k; ++j) { T p = wsum[j][0] * wsum[j][0]; q = q + p; }
+            s_proj = mik_sqrt(q);
         }
-        if (bits == MgsBits<T>::EMPTY) s_err = 1;
-        T hv;
-        __builtin_memcpy(&hv, &bits, sizeof(T));
-        wsum[t][0] = hv;
+        __syncthreads();
+        if (!ok) { more = true; break; }                // the host recomputes the norm with scaling and goes on
+        if (!(nrm < eta * s_proj)) break;               // :26
+        if (round + 1 >= rounds) { more = true; break; }
+        __syncthreads();
     }
-    __syncthreads();
-    // w += (-1 * h[j]) * V[:, j], j ascending                                              k_gemv_n
-    for (int j = 0; j < k; ++j) {
-        T vr[L][W];
-        load(V + (int64_t)j * ldv, vr);
-        const T temp = T(-1) * wsum[j][0];
-#pragma unroll
-        for (int l = 0; l < L; ++l)
-#pragma unroll
-            for (int e = 0; e < W; ++e)
-                if (base + (int64_t)l * MIK_BLOCK * W + e < n) { T p = temp * vr[l][e]; wr[l][e] = wr[l][e] + p; }
-    }
-    // (3) norm(w)                                                                          OpDot{w, w} + k_finalize_nrm_inv
-    T acc = T(0);
-#pragma unroll
-    for (int l = 0; l < L; ++l)
-#pragma unroll
-        for (int e = 0; e < W; ++e)
-            if (base + (int64_t)l * MIK_BLOCK * W + e < n) { T p = wr[l][e] * wr[l][e]; acc = acc + p; }
-    {
-        T tot = block_tree_256(acc, lds4);
-        if (t == 0) {
-            U bits;
-            __builtin_memcpy(&bits, &tot, sizeof(T));
-            __hip_atomic_store(reinterpret_cast<U *>(cur + (size_t)k * 256) + s, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    const T ss = mgs_grid_sum<T>(cur + (size_t)k * 256, m, lds16, &s_err);
-    T nrm = mik_sqrt(ss);
-    const bool ok = mik_nrm_in_range(ss);          // outside the safe range: leave w unscaled, the host rescales
-    const T inv = ok ? T(1) / nrm : T(1);
+    // outside the safe range (or DGKS handed back): leave w unscaled, the host goes on
+    const T inv = (ok && !more) ? T(1) / nrm : T(1);
     if (!ok) nrm = __builtin_nan("");
 #pragma unroll
     for (int l = 0; l < L; ++l) {                  // w .*= inv(nrm)
@@ -870,9 +901,11 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_cgs_fused(int64_t n, int k, const
     }
     __syncthreads();
     if (t == 0 && s_err) __hip_atomic_store(&mirror->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (s == 0 && t == 0) {                        // one writer for the whole mirror: h (picked up from the finals), nrm, then seq
-        for (int j = 0; j < k; ++j) hout[j] = wsum[j][0];
+    if (s == 0 && t == 0) {                        // one writer for the whole mirror: h, nrm, (projection size), then seq
+        for (int j = 0; j < k; ++j) hout[j] = hacc[j];
         hout[k] = nrm;
+        if (DGKS) hout[k + 1] = s_proj;
+        mirror->pad = more ? 1 : 0;
         __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

@@ -266,40 +266,59 @@ template <typename T> static int orth_rescale(mik_ctx *ctx, int64_t n, T *w, T *
     return MIK_OK;
 }
 
+// The DGKS loop of src/orthogonalize.jl:26-36 from a given state {w (unscaled), hh, nrm, projection size}, then the
+// normalisation; multi-launch chain + host control.  Shared by orthogonalize_impl and the single-launch kernel's hand-back.
+template <typename T> static T dgks_small_norm(const T *v, int len)
+{
+    T s = T(0);
+    for (int j = 0; j < len; ++j) { T p = v[j] * v[j]; s = s + p; }
+    return (T)std::sqrt(s);
+}
+
+template <typename T>
+static int dgks_host_loop(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, T *w, T *hh, T *nrm_io, T projection_size)
+{
+    const int64_t nseg = mik_nseg<T>(n);
+    MIK_TRY(mik_ensure_partials(ctx, orthogonalize_workspace<T>(n, k)));
+    T *hd = (T *)ctx->coef;
+    const bool vecw = mik_aligned16(w);
+    OpDot<T> dn{w, w};
+    std::vector<T> corr(std::max(k, 1));
+    T nrm = *nrm_io;
+    const T eta = T(1) / std::sqrt(T(2));                               // :20
+    while (nrm < eta * projection_size) {                                // :26
+        T *cd = hd + k + 2;
+        MIK_TRY(multidot<T>(ctx, n, k, V, ldv, w, cd));                  // :27
+        MIK_TRY(gemv_n_dev<T>(ctx, n, k, V, ldv, cd, T(-1), w));         // :30
+        MIK_TRY((launch_map<T>(ctx, n, dn, vecw, (T *)ctx->partials, nullptr)));
+        MIK_TRY(finalize_nrm_inv<T>(ctx, nseg, hd + k));                // :32
+        MIK_TRY(coef_download<T>(ctx, k + 2, corr.data(), k));
+        T nn[2];
+        MIK_TRY(coef_download<T>(ctx, k, nn, 2));
+        projection_size = dgks_small_norm<T>(corr.data(), k);           // :28
+        for (int j = 0; j < k; ++j) hh[j] = hh[j] + corr[j];            // :31
+        nrm = nn[0];
+        if (nrm != nrm) MIK_TRY(mik_safe_norm_slow<T>(ctx, n, w, &nrm));
+    }
+    OpScal<T> sc{w, coef_val<T>(T(1) / nrm)};                           // :36 (same IEEE quotient the device forms)
+    MIK_TRY((launch_map<T>(ctx, n, sc, vecw, (T *)nullptr, nullptr)));
+    *nrm_io = nrm;
+    return MIK_OK;
+}
+
 template <typename T>
 static int orthogonalize_impl(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, T *w, T *h_host, T *nrm_host, int method)
 {
     if ((size_t)(2 * k + 4) * sizeof(T) > mik_ctx::COEF_SAFE_SLOT) return mik_fail(ctx, MIK_ERR_NOTIMPL, "orthogonalize: k = %d too large", k);
-    const int64_t nseg = mik_nseg<T>(n);
     MIK_TRY(mik_ensure_partials(ctx, orthogonalize_workspace<T>(n, k)));
     MIK_TRY(orthogonalize_enqueue<T>(ctx, n, k, V, ldv, w, method));
-    T *hd = (T *)ctx->coef;
     if (method == MIK_DGKS) {                                            // src/orthogonalize.jl:20-36
-        const bool vecw = mik_aligned16(w);
-        OpDot<T> dn{w, w};
-        std::vector<T> hh(k + 2), corr(std::max(k, 1));
+        std::vector<T> hh(k + 2);
         MIK_TRY(coef_download<T>(ctx, 0, hh.data(), k + 2));
         T nrm = hh[k];
         if (nrm != nrm) MIK_TRY(mik_safe_norm_slow<T>(ctx, n, w, &nrm));   // sum of squares outside the safe range (k_finalize_nrm_inv)
-        const T eta = T(1) / std::sqrt(T(2));                           // :20
-        auto small_norm = [](const T *v, int len) { T s = T(0); for (int j = 0; j < len; ++j) { T p = v[j] * v[j]; s = s + p; } return (T)std::sqrt(s); };
-        T projection_size = small_norm(hh.data(), k);                  // :22
-        while (nrm < eta * projection_size) {                            // :26
-            T *cd = hd + k + 2;
-            MIK_TRY(multidot<T>(ctx, n, k, V, ldv, w, cd));              // :27
-            MIK_TRY(gemv_n_dev<T>(ctx, n, k, V, ldv, cd, T(-1), w));     // :30
-            MIK_TRY((launch_map<T>(ctx, n, dn, vecw, (T *)ctx->partials, nullptr)));
-            MIK_TRY(finalize_nrm_inv<T>(ctx, nseg, hd + k));            // :32
-            MIK_TRY(coef_download<T>(ctx, k + 2, corr.data(), k));
-            T nn[2];
-            MIK_TRY(coef_download<T>(ctx, k, nn, 2));
-            projection_size = small_norm(corr.data(), k);               // :28
-            for (int j = 0; j < k; ++j) hh[j] = hh[j] + corr[j];        // :31
-            nrm = nn[0];
-            if (nrm != nrm) MIK_TRY(mik_safe_norm_slow<T>(ctx, n, w, &nrm));
-        }
-        OpScal<T> sc{w, coef_val<T>(T(1) / nrm)};                       // :36 (same IEEE quotient the device forms)
-        MIK_TRY((launch_map<T>(ctx, n, sc, vecw, (T *)nullptr, nullptr)));
+        T projection_size = dgks_small_norm<T>(hh.data(), k);          // :22
+        MIK_TRY(dgks_host_loop<T>(ctx, n, k, V, ldv, w, hh.data(), &nrm, projection_size));
         for (int j = 0; j < k; ++j) h_host[j] = hh[j];
         *nrm_host = nrm;
         return MIK_OK;
@@ -901,6 +920,7 @@ struct mik_gmres {
     bool graph_off = false;                   // capture / instantiation failed once: plain stream launches from then on
     // single-launch Modified Gram-Schmidt (k_mgs_fused): slot buffers [2][restart + 1][256] and the host-mapped mirror of (h, nrm)
     void *mgs_P = nullptr;
+    int mgs_rounds = 1;              // DGKS rounds the single-launch kernel runs before it hands back to the host loop
     MgsMirror *mgs_mirror = nullptr;          // two mirrors (bytes apart: mgs_mirror_stride), used alternately
     size_t mgs_mirror_stride = 0;
     unsigned long long mgs_seq = 0, mgs_slot_seq[2] = {0, 0};
@@ -1157,8 +1177,10 @@ static int gmres_create_common(mik_ctx *ctx, const mik_csr *A, void *x, const vo
     }
     {
         const int64_t nseg = dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
-        if (!part && (orth_method == MIK_MGS || orth_method == MIK_CGS) && nseg >= 1 && nseg <= 256 && restart <= 254) {
-            const size_t pbytes = es * 2 * (size_t)(restart + 2) * 256;     // k_cgs_fused: one more row (the final h values)
+        if (!part && nseg >= 1 && nseg <= 256 && restart <= 254) {
+            // k_cgs_fused: one more row per round (the final h values); DGKS: up to 3 rounds in the kernel
+            g->mgs_rounds = orth_method == MIK_DGKS ? (g_mik_tuning[21] > 0 ? std::min(g_mik_tuning[21], 3) : 3) : 1;   // development knob 21: DGKS rounds in the kernel
+            const size_t pbytes = es * 2 * (size_t)g->mgs_rounds * (size_t)(restart + 2) * 256;
             if ((e = hipMalloc(&g->mgs_P, pbytes)) != hipSuccess || (e = hipMemsetAsync(g->mgs_P, 0xFF, pbytes, ctx->stream)) != hipSuccess ||
                 (g->mgs_mirror_stride = (sizeof(MgsMirror) + es * (size_t)(restart + 2) + 255) / 256 * 256, false) ||
                 (e = hipHostMalloc((void **)&g->mgs_mirror, 2 * g->mgs_mirror_stride, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) {
@@ -1313,11 +1335,13 @@ template <typename T> static int gm_fused_enqueue(mik_gmres *g, int k, int slot)
     const bool vec = mik_aligned16(V) && mik_aligned16(w) && (g->ldv % VT<T>::W == 0);
     g->mgs_seq += 1;
     g->mgs_slot_seq[slot] = g->mgs_seq;
-    if (g->method == MIK_CGS) {
-        if (vec) hipLaunchKernelGGL((k_cgs_fused<T, true>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart,
-                                    g->mgs_parity, gm_mirror(g, slot), g->mgs_seq);
-        else hipLaunchKernelGGL((k_cgs_fused<T, false>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart,
-                                g->mgs_parity, gm_mirror(g, slot), g->mgs_seq);
+    if (g->method != MIK_MGS) {
+#define MIK_CGS_GO(VECV, DG)                                                                                                                   \
+    hipLaunchKernelGGL((k_cgs_fused<T, VECV, DG>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart, \
+                       g->mgs_rounds, g->mgs_parity, gm_mirror(g, slot), g->mgs_seq)
+        if (g->method == MIK_DGKS) { if (vec) MIK_CGS_GO(true, true); else MIK_CGS_GO(false, true); }
+        else                       { if (vec) MIK_CGS_GO(true, false); else MIK_CGS_GO(false, false); }
+#undef MIK_CGS_GO
     } else if (vec) hipLaunchKernelGGL((k_mgs_fused<T, true>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart,
                                 g->mgs_parity, gm_mirror(g, slot), g->mgs_seq);
     else hipLaunchKernelGGL((k_mgs_fused<T, false>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart,
@@ -1352,6 +1376,15 @@ template <typename T> static int gm_fused_wait(mik_gmres *g, int k, int slot, T 
     for (int j = 0; j < k; ++j) h_out[j] = out[j];
     *nrm_out = out[k];
     *rescaled = false;
+    if (g->method == MIK_DGKS && mir->pad) {    // the kernel stopped before the DGKS loop ended (round limit / unsafe norm): w is unscaled
+        T *w = (T *)g->V + (int64_t)k * g->ldv;
+        T nrm = out[k];
+        if (nrm != nrm) MIK_TRY(mik_safe_norm_slow<T>(ctx, g->n, w, &nrm));
+        MIK_TRY(dgks_host_loop<T>(ctx, g->n, k, (const T *)g->V, g->ldv, w, h_out, &nrm, out[k + 1]));
+        *nrm_out = nrm;
+        *rescaled = true;
+        return MIK_OK;
+    }
     if (out[k] != out[k]) {                     // sum of squares outside the safe range: the kernel left w unscaled
         T *w = (T *)g->V + (int64_t)k * g->ldv;
         MIK_TRY(orth_rescale<T>(ctx, g->n, w, nrm_out));

@@ -496,3 +496,33 @@ def test_gmres_graph_replay_equals_stream_launches(pkg, orc, ctx, orth):
     x3, ch3 = pkg.gmres(upload(pkg, A), pkg.HipVector.from_numpy(b), restart=10, log=True, orth_meth=M, Pl=P, Pr=P)
     assert np.array_equal(ch0["resnorm"], ch1["resnorm"]) and np.array_equal(x0.to_numpy(), x1.to_numpy()) and ch0.mvps == ch1.mvps
     assert np.array_equal(ch2["resnorm"], ch3["resnorm"]) and np.array_equal(x2.to_numpy(), x3.to_numpy())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gmres_dgks_reorthogonalisation_inside_the_single_launch_kernel(pkg, orc, ctx, dtype):
+    """A = I + tiny perturbation: every new Krylov vector lies almost in the span of the basis, so the DGKS condition
+    (src/orthogonalize.jl:26) holds and the loop runs -- inside k_cgs_fused (3 rounds), handed back to the host after one
+    round (knob 21 = 1), and as the multi-launch chain (knob 5 = 2): all three equal the oracle bit for bit, and differ from
+    plain CGS (i.e. the loop really ran)."""
+    import scipy.sparse as sp
+    n = 3000
+    rng = np.random.default_rng(21)
+    S = (sp.identity(n) + 1e-4 * sp.random(n, n, density=0.002, random_state=3)).tocsc()
+    S.sort_indices()
+    A = orc.CSC.from_scipy(S).astype(dtype)
+    b = rng.standard_normal(n).astype(dtype)
+    W, L = shape_of(ctx, dtype)
+    xo, ho = orc.gmres(A, b, restart=12, orth_meth="dgks", mode="tree", shape=(W, L), maxiter=20, reltol=0.0)
+    xc, hc = orc.gmres(A, b, restart=12, orth_meth="cgs", mode="tree", shape=(W, L), maxiter=20, reltol=0.0)
+    assert not np.array_equal(ho["resnorm"], hc["resnorm"]) or not np.array_equal(xo, xc)
+    lib = pkg.lib()
+    for knobs in ({}, {21: 1}, {5: 2}):
+        for kk, v in knobs.items():
+            lib.mik_set_tuning(kk, v)
+        try:
+            x, ch = pkg.gmres(upload(pkg, A), pkg.HipVector.from_numpy(b), restart=12, log=True, orth_meth=pkg.DGKS(), maxiter=20, reltol=0.0)
+        finally:
+            for kk in knobs:
+                lib.mik_set_tuning(kk, 0)
+        assert np.array_equal(ch["resnorm"], ho["resnorm"]), knobs
+        assert np.array_equal(x.to_numpy(), xo), knobs
