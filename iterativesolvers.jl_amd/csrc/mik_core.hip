@@ -230,21 +230,24 @@ __global__ void k_probe_buffer_range(const double *x, double *out)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)x, (short)0, (int)0xFFFFFFF0u, (int)0x00020000);
     const int t = threadIdx.x;
     out[t] = buffer_gather<double>(rs, (t & 1) ? ~0u : (unsigned)t * 4u, 8);     // even lanes: x[t / 2 + 1]; odd lanes: out of range
+    // stores beyond the descriptor's range must be dropped: out[8..15] are covered by a 4-element descriptor whose lanes 4..7 miss
+    const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc((void *)(out + 8), (short)0, 4 * 8, (int)0x00020000);
+    buffer_put<double>(ws, (unsigned)t * 8u, -1.0, 0);
 }
 
 static bool buffer_range_semantics_ok(mik_ctx *ctx)
 {
     static int state = -1;                                                         // -1 unknown, 0 no, 1 yes
     if (state >= 0) return state == 1;
-    double h[16], r[8], *d = nullptr;
+    double h[16], r[16], *d = nullptr;
     for (int i = 0; i < 16; ++i) h[i] = 1.0 + i;
     state = 0;
     if (hipMalloc((void **)&d, sizeof(h) + sizeof(r)) != hipSuccess) return false;
-    if (hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) == hipSuccess) {
+    if (hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) == hipSuccess && hipMemset(d + 16, 0, sizeof(r)) == hipSuccess) {
         hipLaunchKernelGGL(k_probe_buffer_range, dim3(1), dim3(8), 0, ctx->stream, d, d + 16);
         if (hipStreamSynchronize(ctx->stream) == hipSuccess && hipMemcpy(r, d + 16, sizeof(r), hipMemcpyDeviceToHost) == hipSuccess) {
             bool ok = true;
-            for (int t = 0; t < 8; ++t) ok = ok && r[t] == ((t & 1) ? 0.0 : h[t / 2 + 1]);
+            for (int t = 0; t < 8; ++t) ok = ok && r[t] == ((t & 1) ? 0.0 : h[t / 2 + 1]) && r[8 + t] == (t < 4 ? -1.0 : 0.0);
             state = ok ? 1 : 0;
         }
     }

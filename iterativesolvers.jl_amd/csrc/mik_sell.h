@@ -362,6 +362,19 @@ template <> __device__ __forceinline__ float buffer_gather<float>(__amdgpu_buffe
     return __builtin_bit_cast(float, v);
 }
 
+template <typename T> __device__ __forceinline__ void buffer_put(__amdgpu_buffer_rsrc_t rs, unsigned voff, T v, int aux);
+template <> __device__ __forceinline__ void buffer_put<double>(__amdgpu_buffer_rsrc_t rs, unsigned voff, double v, int aux)
+{
+    typedef unsigned mik_u32x2 __attribute__((ext_vector_type(2)));
+    if (aux) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mik_u32x2, v), rs, (int)voff, 0, 2);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mik_u32x2, v), rs, (int)voff, 0, 0);
+}
+template <> __device__ __forceinline__ void buffer_put<float>(__amdgpu_buffer_rsrc_t rs, unsigned voff, float v, int aux)
+{
+    if (aux) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (int)voff, 0, 2);
+    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (int)voff, 0, 0);
+}
+
 // spmv_block_map for strips of a power-of-two number of row-blocks: P = 8 << sshift row-blocks per plane, `nfull` =
 // the row-blocks in whole planes ((nb / P) * P, computed by the host); sshift < 0: identity
 __device__ __forceinline__ int spmv_block_map_shift(int b, int nfull, int sshift)
@@ -396,13 +409,17 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab(int n, int koff, int r
     // rows are addressed by a 32-bit byte offset; an offset of all ones is out of the descriptor's range (reads 0)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((uintptr_t)x - (uintptr_t)koff * ES), (short)0,
                                                                         (int)0xFFFFFFF0u, (int)0x00020000);
+    // the row masks and y go through descriptors as well: a row past the end reads mask 0 (= no slot at all: every gather out
+    // of range, sum +0) and its store is dropped by the range check -- no "row < n" branch anywhere on the main path
+    const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc((void *)mask, (short)0, n, (int)0x00020000);
+    const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc((void *)y, (short)0, (int)((unsigned)n * ES), (int)0x00020000);
     int rb[G], minv[G], rr[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {                       // virtual blocks blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8)
         const int vb = min((int)blockIdx.x + g * (int)gridDim.x, nb - 1);   // past the end: the last block once more (same bits)
         rb[g] = rb0 + spmv_block_map_shift(vb, nfull, sshift);
         rr[g] = rb[g] * MIK_BLOCK + t;
-        minv[g] = ~(int)ld_stream<NT>(mask + min(rr[g], n - 1)) | (rr[g] < n ? 0 : -1);     // bit q set: this row has no slot q
+        minv[g] = ~(int)__builtin_amdgcn_raw_buffer_load_b8(ms, rr[g], 0, NT ? 2 : 0);      // bit q set: this row has no slot q
     }
     const SdiaPattern<T> *__restrict__ pt[G];
 #pragma unroll
@@ -459,9 +476,9 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab(int n, int koff, int r
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        if (rr[g] < n) st_stream<NT>(y + rr[g], acc[g]);
+        buffer_put<T>(ys, (unsigned)rr[g] * ES, acc[g], NT ? 2 : 0);
         if (FUSE_DOT) {
-            const T pd = rr[g] < n ? xr[g] * acc[g] : T(0);
+            const T pd = xr[g] * acc[g];                // a row past the end: 0 * +0
             const T ws = wave_tree(pd);
             if (lane == 0) lds[g][w] = ws;
         }
