@@ -330,6 +330,21 @@ int mik_sdiac_finish(mik_ctx *ctx, mik_csr *A, const std::vector<unsigned char> 
     }
     A->sdia_npat = (int)index.size();
     A->sdia_entries = slots;
+    if (A->sdia_buf_ok) {                                              // per-slice records of k_spmv_sdiab
+        std::vector<SdiaSliceRec> recs((size_t)nb);
+        for (int64_t b = 0; b < nb; ++b) {
+            const unsigned char *pp = &pats[(size_t)pid[(size_t)b] * psz];
+            SdiaSliceRec &r = recs[(size_t)b];
+            memset(&r, 0, sizeof(r));
+            int hdr[4];
+            memcpy(hdr, pp, 16);
+            memcpy(r.soff, pp + 48, 32);
+            r.ns = hdr[0]; r.cq = hdr[2]; r.dfull = hdr[3]; r.pid = pid[(size_t)b];
+        }
+        if ((e = hipMalloc(&A->sdia_recs, sizeof(SdiaSliceRec) * (size_t)nb)) != hipSuccess ||
+            (e = hipMemcpy(A->sdia_recs, recs.data(), sizeof(SdiaSliceRec) * (size_t)nb, hipMemcpyHostToDevice)) != hipSuccess)
+            return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: slice records: %s", hipGetErrorString(e));
+    }
     return MIK_OK;
 }
 
@@ -865,6 +880,7 @@ extern "C" int mik_csr_destroy(mik_csr *A)
     if (A->sdia_val) (void)hipFree(A->sdia_val);
     if (A->sdia_pats) (void)hipFree(A->sdia_pats);
     if (A->sdia_pat_id) (void)hipFree(A->sdia_pat_id);
+    if (A->sdia_recs) (void)hipFree(A->sdia_recs);
     if (A->sell8_ptr) (void)hipFree(A->sell8_ptr);
     if (A->sell8_codes) (void)hipFree(A->sell8_codes);
     if (A->sell8_tab) (void)hipFree(A->sell8_tab);
@@ -965,7 +981,7 @@ extern "C" int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes)
     const int64_t es = (int64_t)mik_dtype_size(A->dtype);
     const int64_t nb = (A->n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
     switch (layout) {
-    case 5: *bytes = A->n_rows + nb * 4 + (int64_t)A->sdia_npat * (80 + 8 * es); break;
+    case 5: *bytes = A->n_rows + nb * ((A->sdia_recs && g_mik_tuning[17] == 0) ? 64 : 4) + (int64_t)A->sdia_npat * (80 + 8 * es); break;
     case 4: *bytes = A->sdia_entries * es + A->n_rows + nb * 36; break;
     case 3: *bytes = A->nnz * 2 + (A->n_rows + 1) * 4 + 256 * (es + 4); break;
     case 2: *bytes = A->sell_entries * es + A->sell8_bytes + (nb + 1) * 8 + 256 * 4; break;
@@ -1091,7 +1107,7 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
             }
 #define MIK_SDIAB_GO4(FD, NTV, GG, C)                                                                                                      \
     hipLaunchKernelGGL((k_spmv_sdiab<T, FD, NTV, GG, mik_sdiab_cls_ns(C), mik_sdiab_cls_cq(C)>), dim3(wgs), dim3(MIK_BLOCK), 0, ctx->stream, n, A->sdia_koff, \
-                       rb0, nb, nfull, sshift, A->sdia_pat_id, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done)
+                       rb0, nb, nfull, sshift, (const SdiaSliceRec *)A->sdia_recs, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done)
 #define MIK_SDIAB_GO3(FD, NTV, GG)                                                                                                          \
     do { if (cls == 1) MIK_SDIAB_GO4(FD, NTV, GG, 1); else if (cls == 2) MIK_SDIAB_GO4(FD, NTV, GG, 2); else if (cls == 3) MIK_SDIAB_GO4(FD, NTV, GG, 3); \
          else MIK_SDIAB_GO4(FD, NTV, GG, 0); } while (0)

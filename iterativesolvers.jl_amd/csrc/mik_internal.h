@@ -85,6 +85,7 @@ struct mik_csr {
     int sdia_npat = 0;
     bool sdia_buf_ok = false;        // k_spmv_sdiab applies: finite pattern values, 32-bit row / slot byte offsets
     int sdia_koff = 0;               // - (most negative slot offset) of the operator, >= 0
+    void *sdia_recs = nullptr;       // device, nb SdiaSliceRec (k_spmv_sdiab): scalar offsets + pattern shape per slice
     int sdia_cls = 0;                // (slots, centre slot) class k_spmv_sdiab runs specialised (mik_sdiab_cls_*), 0 = none
     // optional dictionary-coded form (mik_csr_pack): one 16-bit code per entry + two <= 256-entry tables
     unsigned short *codes = nullptr; // device, nnz (+ padding)

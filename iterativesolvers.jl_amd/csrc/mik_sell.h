@@ -273,6 +273,16 @@ template <typename T> struct SdiaPattern {
     T val[8];
 };
 
+// What k_spmv_sdiab needs to ISSUE a slice's gathers, per slice and in one 64-byte scalar load: the scalar byte offsets and the
+// shape of the slice's pattern.  With only a pattern index per slice the gathers waited for two dependent scalar loads
+// (index, then pattern); the kernel is latency-bound (a wave lives ~4 us, three memory round trips), so the level counts.
+// The values are still read from the pattern table -- they are not needed before the gathers return.
+struct SdiaSliceRec {
+    int soff[8];
+    int ns, cq, dfull, pid;
+    int pad[4];
+};
+
 template <typename T, bool FUSE_DOT, bool NT, int G>
 __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiac(int n, int ncols, int rb0, int nb, int map_mode, const int *__restrict__ pat_id,
                                                           const SdiaPattern<T> *__restrict__ pats, const unsigned char *__restrict__ mask,
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiac(int n, int ncols, int 
         rb[g] = vb < nb ? rb0 + spmv_block_map(vb, nb, map_mode) : -1;
         r[g] = rb[g] >= 0 ? rb[g] * MIK_BLOCK + t : n;
         pt[g] = pats + (rb[g] >= 0 ? pat_id[rb[g]] : 0);
-        m[g] = r[g] < n ? (int)ld_stream<NT>(mask + r[g]) : 0;
+        m[g] = r[g] < n ? (int)mask[r[g]] : 0;
     }
     T xv[G][U];
 #pragma unroll
@@ -396,7 +406,7 @@ __host__ __device__ constexpr int mik_sdiab_cls_ns(int c) { return c == 1 ? 7 : 
 __host__ __device__ constexpr int mik_sdiab_cls_cq(int c) { return c == 1 ? 3 : c == 2 ? 2 : c == 3 ? 1 : -1; }
 
 template <typename T, bool FUSE_DOT, bool NT, int G, int NS, int CQ>
-__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab(int n, int koff, int rb0, int nb, int nfull, int sshift, const int *__restrict__ pat_id,
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab(int n, int koff, int rb0, int nb, int nfull, int sshift, const SdiaSliceRec *__restrict__ recs,
                                                           const SdiaPattern<T> *__restrict__ pats, const unsigned char *__restrict__ mask,
                                                           const T *__restrict__ x, T *__restrict__ y, T *__restrict__ seg_out,
                                                           const int *__restrict__ done)
@@ -419,14 +429,19 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab(int n, int koff, int r
         const int vb = min((int)blockIdx.x + g * (int)gridDim.x, nb - 1);   // past the end: the last block once more (same bits)
         rb[g] = rb0 + spmv_block_map_shift(vb, nfull, sshift);
         rr[g] = rb[g] * MIK_BLOCK + t;
-        minv[g] = ~(int)__builtin_amdgcn_raw_buffer_load_b8(ms, rr[g], 0, NT ? 2 : 0);      // bit q set: this row has no slot q
+        // (the masks are read with the default cache policy: 1 B per row stays in the Infinity Cache from one SpMV to the next;
+        //  streamed past the caches they cost the launch 14 us)
+        minv[g] = ~(int)__builtin_amdgcn_raw_buffer_load_b8(ms, rr[g], 0, 0);               // bit q set: this row has no slot q
     }
+    SdiaSliceRec rc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) rc[g] = recs[rb[g]];
     const SdiaPattern<T> *__restrict__ pt[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) pt[g] = pats + pat_id[rb[g]];
+    for (int g = 0; g < G; ++g) pt[g] = pats + rc[g].pid;
     bool fast = NS > 0;
 #pragma unroll
-    for (int g = 0; g < G; ++g) fast = fast & (pt[g]->ns == NS) & (pt[g]->cq == CQ);
+    for (int g = 0; g < G; ++g) fast = fast & (rc[g].ns == NS) & (rc[g].cq == CQ);
 #pragma unroll
     for (int g = 0; g < G; ++g) asm volatile("" : "+v"(minv[g]));       // all masks have arrived before the first gather is issued
     T acc[G], xr[G];
@@ -438,7 +453,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab(int n, int koff, int r
             const unsigned rowoff = (unsigned)rr[g] * ES;
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
-                xv[g][q] = buffer_gather<T>(rs, rowoff | (unsigned)__builtin_amdgcn_sbfe(minv[g], q, 1), pt[g]->soff[q]);
+                xv[g][q] = buffer_gather<T>(rs, rowoff | (unsigned)__builtin_amdgcn_sbfe(minv[g], q, 1), rc[g].soff[q]);
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -447,18 +462,18 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab(int n, int koff, int r
             for (int q = 0; q < NQ; ++q) { T pr = pt[g]->val[q] * xv[g][q]; a = a + pr; }
             acc[g] = a;
             xr[g] = xv[g][CC];
-            if (FUSE_DOT && !pt[g]->dfull && ((minv[g] >> CC) & 1) && rr[g] < n) xr[g] = x[rr[g]];   // a row without a diagonal entry
+            if (FUSE_DOT && !rc[g].dfull && ((minv[g] >> CC) & 1) && rr[g] < n) xr[g] = x[rr[g]];   // a row without a diagonal entry
         }
     } else {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const unsigned rowoff = (unsigned)rr[g] * ES;
-            const int ns = pt[g]->ns, cq = pt[g]->cq;
+            const int ns = rc[g].ns, cq = rc[g].cq;
             T xv[U];
 #pragma unroll
             for (int q = 0; q < U; ++q) {
                 xv[q] = T(0);
-                if (q < ns) xv[q] = buffer_gather<T>(rs, rowoff | (unsigned)__builtin_amdgcn_sbfe(minv[g], q, 1), pt[g]->soff[q]);
+                if (q < ns) xv[q] = buffer_gather<T>(rs, rowoff | (unsigned)__builtin_amdgcn_sbfe(minv[g], q, 1), rc[g].soff[q]);
             }
             T a = T(0), c = T(0);
 #pragma unroll
