@@ -41,6 +41,7 @@ struct mik_cg {
     CgMirror *mirror = nullptr;      // host-mapped; same pointer is valid on the device
     unsigned long long seq = 0;      // steps enqueued so far (published by k_cg_fin_res)
     bool dev_done = false;           // device stopping flag known to be set
+    bool head_ahead = false;         // the head of the next step (u, c, alpha) is on the stream already
     // optional in-loop timing of the SpMV launch (HIP events on the ctx stream)
     int profile = 0;               // 0 off, 1 = the SpMV launch, 2 = SpMV + the two vector sweeps of the step
     std::vector<hipEvent_t> ev;    // pairs (start, stop), recycled

@@ -505,14 +505,30 @@ __global__ void k_cg_fix_res(CgDev<T> *d, T res, T *__restrict__ hist, long long
 
 static int cg_profile_collect(mik_cg *it)
 {
-    // stream must be idle (called after a synchronising read-back)
-    for (size_t i = 0; i + 1 < it->ev_used; i += 2) {
+    // called after the host has seen the last tail of a call: every bracketed launch has finished except those of a head
+    // enqueued ahead, whose events stay in the list until the next call (or a flush) finds them complete
+    size_t i = 0;
+    for (; i + 1 < it->ev_used; i += 2) {
+        if (hipEventQuery(it->ev[i + 1]) != hipSuccess) { (void)hipGetLastError(); break; }
         float ms = 0.f;
         const int kind = it->ev_kind[i / 2];
         if (hipEventElapsedTime(&ms, it->ev[i], it->ev[i + 1]) == hipSuccess) { it->kern_ms[kind] += ms; it->kern_launches[kind] += 1; }
     }
-    it->ev_used = 0;
+    size_t keep = 0;
+    for (size_t j = i; j + 1 < it->ev_used; j += 2, keep += 2) {
+        std::swap(it->ev[keep], it->ev[j]);
+        std::swap(it->ev[keep + 1], it->ev[j + 1]);
+        it->ev_kind[keep / 2] = it->ev_kind[j / 2];
+    }
+    it->ev_used = keep;
     return MIK_OK;
+}
+
+static void cg_profile_flush(mik_cg *it)
+{
+    if (!it->ev_used) return;
+    (void)hipStreamSynchronize(it->ctx->stream);
+    (void)cg_profile_collect(it);
 }
 
 // HIP events on the ctx stream around one launch of the step (kind: 0 = SpMV, 1 = xpby, 2 = update)
@@ -550,7 +566,12 @@ static inline int cg_stream_hints()
     return k == 0 ? 57 : (k < 0 ? 0 : k);
 }
 
-template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next, int hist_index)
+// One iterate() = HEAD (u = r + beta u [after c = Pl \ r, rho]; c = A u; alpha) + TAIL (x, r update; residual, stopping test).
+// The head only writes the iterable's internal vectors u and c and scalars, and all of its inputs are final once the previous
+// tail has run -- so the head of step k + 1 may be put on the stream BEFORE the host waits for the residual of step k
+// (cg_iterate_many_impl): the device never idles while the host reacts.  If step k met the stopping test the head kernels
+// early-exit on the device's `done` flag like every later step of a batch.
+template <typename T> static int cg_enqueue_head(mik_cg *it)
 {
     mik_ctx *ctx = it->ctx;
     CgDev<T> *d = (CgDev<T> *)it->dev;
@@ -599,6 +620,18 @@ template <typename T> static int cg_enqueue_step(mik_cg *it, long long it_next, 
         hipLaunchKernelGGL((k_cg_fin_alpha<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_vec, nseg, d, pcg, (FinScratch<T> *)it->fin);
     }
     MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+
+template <typename T> static int cg_enqueue_tail(mik_cg *it, long long it_next, int hist_index)
+{
+    mik_ctx *ctx = it->ctx;
+    CgDev<T> *d = (CgDev<T> *)it->dev;
+    const int *done = &d->done;
+    const int64_t n = it->n;
+    const int64_t nseg = mik_nseg<T>(n);
+    T *x = (T *)it->x, *u = (T *)it->u, *r = (T *)it->r, *c = (T *)it->c;
+    const bool vec = mik_aligned16(x) && mik_aligned16(u) && mik_aligned16(r) && mik_aligned16(c) && (!it->diag || mik_aligned16(it->diag));
     // x .+= alpha .* u; r .-= alpha .* c; norm(r)                       src/cg.jl:58-62
     OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints() >> 3};
     {
@@ -797,11 +830,20 @@ static int cg_iterate_many_impl(mik_cg *it, int64_t iteration, int64_t max_steps
     it->mirror->range = 0;
     if (it->dev_done) MIK_HIP(ctx, hipMemsetAsync(&d->done, 0, sizeof(int), ctx->stream));
     CgMirror m;
+    // the head of the step AFTER this call goes on the stream before the host waits (never with host callbacks, whose call
+    // count the caller may observe; development knob 9: 1 = off)
+    const bool ahead_ok = g_mik_tuning[9] == 0 && !it->op_mul && !it->pl_fn && iteration + max_steps < it->maxiter;
     for (int64_t j0 = 0;;) {
-        for (int64_t j = j0; j < max_steps; ++j) MIK_TRY(cg_enqueue_step<T>(it, (long long)(iteration + j + 1), (int)j));
+        for (int64_t j = j0; j < max_steps; ++j) {
+            if (!it->head_ahead) MIK_TRY(cg_enqueue_head<T>(it));
+            it->head_ahead = false;
+            MIK_TRY(cg_enqueue_tail<T>(it, (long long)(iteration + j + 1), (int)j));
+        }
+        if (ahead_ok) MIK_TRY(cg_enqueue_head<T>(it));
         MIK_TRY(cg_wait_mirror(it));
         m = *it->mirror;
-        if (!m.range) break;
+        if (!m.range) { it->head_ahead = ahead_ok && !m.done; break; }       // stopped: the head ahead was a no-op
+        it->head_ahead = false;                                              // frozen batch: so was everything behind the frozen step
         // Step m.nhist of this call updated x and r, but |r|^2 left the range in which sqrt(sum of squares) is safe
         // (include/mik.h "Norms"): the device froze the batch; finish that step with the scaled norm and go on.
         T res;
@@ -857,6 +899,7 @@ extern "C" int mik_cg_iterate(mik_cg *it, int64_t iteration, double *residual, i
 extern "C" int mik_cg_profile(mik_cg *it, int enable, double *spmv_ms_total, int64_t *spmv_launches)
 {
     if (!it) return MIK_ERR_INVALID;
+    cg_profile_flush(it);
     if (spmv_ms_total) *spmv_ms_total = it->kern_ms[0];
     if (spmv_launches) *spmv_launches = it->kern_launches[0];
     if (enable >= 0) {
@@ -869,6 +912,7 @@ extern "C" int mik_cg_profile(mik_cg *it, int enable, double *spmv_ms_total, int
 extern "C" int mik_cg_profile_kernels(const mik_cg *it, double *ms_total, int64_t *launches)
 {
     if (!it) return MIK_ERR_INVALID;
+    cg_profile_flush(const_cast<mik_cg *>(it));
     for (int q = 0; q < 3; ++q) {
         if (ms_total) ms_total[q] = it->kern_ms[q];
         if (launches) launches[q] = it->kern_launches[q];
