@@ -313,8 +313,11 @@ extern "C" int mik_cgd_init(mik_cgd *it, double *residual, double *tol)
     return MIK_OK;
 }
 
-// one iterate() (src/cg.jl:43-66) of this rank, enqueued without any host synchronisation
-static int cgd_enqueue_step(mik_cgd *it, int64_t iteration)
+// one iterate() (src/cg.jl:43-66) of this rank, enqueued without any host synchronisation, in two halves: the HEAD writes
+// only u (with its halo), c and this rank's dot slot -- all of its inputs are final once the previous tail has run -- so the
+// head of the step after a call is enqueued before the host waits (as in the single-GPU path, cg_enqueue_head); every rank
+// takes the same decision (same iteration counts, identical stopping scalars), so the RCCL call sequences stay aligned.
+static int cgd_enqueue_head(mik_cgd *it, int64_t iteration)
 {
     MIK_TRY(mik_cgd_phase(it, 0, iteration));                       // u = r + beta u; pack the halo
     bool pending = false;
@@ -327,7 +330,11 @@ static int cgd_enqueue_step(mik_cgd *it, int64_t iteration)
         MIK_TRY(rccl_halo_end(it, pending));
         MIK_TRY(mik_cgd_phase(it, 1, iteration));
     }
-    MIK_TRY(rccl_gather_scalar(it, it->dot_all));
+    return rccl_gather_scalar(it, it->dot_all);
+}
+
+static int cgd_enqueue_tail(mik_cgd *it, int64_t iteration)
+{
     MIK_TRY(mik_cgd_phase(it, 2, iteration));                       // alpha; x, r update; local |r|^2
     MIK_TRY(rccl_gather_scalar(it, it->rr_all));
     return mik_cgd_phase(it, 3, iteration);                         // residual, beta, stopping test
@@ -344,9 +351,17 @@ extern "C" int mik_cgd_iterate_many(mik_cgd *it, int64_t iteration, int64_t max_
     mik_cg &bs = it->base;
     if (max_steps <= 0 || iteration >= bs.maxiter || bs.residual <= bs.tol) return MIK_OK;      // done(it, iteration), src/cg.jl:36
     max_steps = std::min<int64_t>(std::min<int64_t>(max_steps, bs.maxiter - iteration), bs.hist_cap);
-    for (int64_t j = 0; j < max_steps; ++j) MIK_TRY(cgd_enqueue_step(it, iteration + j));
+    const bool ahead_ok = g_mik_tuning[9] == 0 && iteration + max_steps < bs.maxiter;      // development knob 9: 1 = nothing ahead of the host
+    for (int64_t j = 0; j < max_steps; ++j) {
+        if (!bs.head_ahead) MIK_TRY(cgd_enqueue_head(it, iteration + j));
+        bs.head_ahead = false;
+        MIK_TRY(cgd_enqueue_tail(it, iteration + j));
+    }
+    if (ahead_ok) MIK_TRY(cgd_enqueue_head(it, iteration + max_steps));
     int done = 0;
-    return mik_cgd_wait(it, nullptr, nullptr, &done, residuals, max_steps, steps_done);
+    MIK_TRY(mik_cgd_wait(it, nullptr, nullptr, &done, residuals, max_steps, steps_done));
+    bs.head_ahead = ahead_ok && !done;                              // stopped: the head ahead was a no-op on every rank
+    return MIK_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

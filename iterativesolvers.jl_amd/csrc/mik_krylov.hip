@@ -1626,6 +1626,15 @@ template <typename T> __device__ __forceinline__ T rank_sum(const T *__restrict_
     return s;
 }
 
+// this rank's partial (level-2 sum of its segment sums, spread over MIK_FIN_WGS single-wave workgroups like k_cg_fin_*) into its slot
+template <typename T>
+__global__ __launch_bounds__(64) void k_cgd_fin_slot(const T *__restrict__ S, int64_t m, T *__restrict__ slot, const int *__restrict__ done, FinScratch<T> *fs)
+{
+    if (done && *done) return;
+    T tot;
+    if (level2_sum_spread(S, m, fs, tot)) *slot = tot;
+}
+
 template <typename T> __global__ void k_cgd_alpha(const T *__restrict__ dot_all, int nranks, CgDev<T> *d)
 {
     if (d->done) return;
@@ -1659,7 +1668,7 @@ __global__ void k_cgd_fin_init(const T *__restrict__ rr_all, int nranks, CgDev<T
 
 template <typename T>
 __global__ void k_cgd_fin_res(const T *__restrict__ rr_all, int nranks, CgDev<T> *d, T *__restrict__ hist, long long it_next, long long maxiter,
-                              CgMirror *mirror, unsigned long long seq)
+                              CgMirror *mirror, unsigned long long seq, int hist_index)
 {
     if (d->done) { __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); return; }
     const T tot = rank_sum(rr_all, nranks);
@@ -1672,9 +1681,8 @@ __global__ void k_cgd_fin_res(const T *__restrict__ rr_all, int nranks, CgDev<T>
     const T res = mik_sqrt(tot);
     d->rr = tot; d->prev_res = prev; d->res = res;
     d->beta = (res * res) / (prev * prev);
-    hist[d->nhist] = res;
-    const int nh = d->nhist + 1;
-    d->nhist = nh;
+    hist[hist_index] = res;                   // step `hist_index` since the last wait (steps behind a stop are no-ops)
+    const int nh = hist_index + 1;
     const int dn = (it_next >= maxiter || res <= d->tol) ? 1 : 0;
     if (dn) d->done = 1;
     mirror->res = (double)res; mirror->prev_res = (double)prev; mirror->done = dn; mirror->nhist = nh;
@@ -1715,6 +1723,7 @@ extern "C" int mik_cgd_create(mik_ctx *ctx, const mik_csr *A_loc, void *x, const
     if ((e = hipMalloc(&bs.seg_vec, es * (size_t)std::max<int64_t>(nseg, 1))) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMalloc(&bs.hist, es * 1024)) != hipSuccess) return fail("hipMalloc", e);
     bs.hist_cap = 1024;
+    if ((e = hipMalloc(&bs.fin, 256)) != hipSuccess || (e = hipMemsetAsync(bs.fin, 0, 256, ctx->stream)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipHostMalloc((void **)&bs.mirror, sizeof(CgMirror), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return fail("hipHostMalloc", e);
     memset(bs.mirror, 0, sizeof(CgMirror));
     if ((e = hipMemsetAsync(bs.dev, 0, 256, ctx->stream)) != hipSuccess) return fail("hipMemsetAsync", e);
@@ -1743,6 +1752,7 @@ extern "C" int mik_cgd_destroy(mik_cgd *it)
     if (bs.ctx) (void)hipStreamSynchronize(bs.ctx->stream);
     if (bs.dev) (void)hipFree(bs.dev);
     if (bs.hist) (void)hipFree(bs.hist);
+    if (bs.fin) (void)hipFree(bs.fin);
     if (bs.seg_spmv) (void)hipFree(bs.seg_spmv);
     if (bs.seg_vec) (void)hipFree(bs.seg_vec);
     if (bs.mirror) (void)hipHostFree(bs.mirror);
@@ -1798,7 +1808,7 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
     }
     case 1:    // step B
         MIK_TRY(mik_spmv_launch<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done));
-        hipLaunchKernelGGL((k_finalize_store<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)bs.seg_spmv, nb, (int64_t)0, dot_slot, done);
+        hipLaunchKernelGGL((k_cgd_fin_slot<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)bs.seg_spmv, nb, dot_slot, done, (FinScratch<T> *)bs.fin);
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     case 4:    // step B1: the row-blocks that reference no halo column -- runs while the halo is in flight
@@ -1807,7 +1817,7 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
     case 5:    // step B2: the row-blocks before and after the interior range, then the local dot(u, c) as in step B
         MIK_TRY(mik_spmv_launch_range<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done, 0, (int)it->int_begin));
         MIK_TRY(mik_spmv_launch_range<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done, (int)it->int_end, (int)(nb - it->int_end)));
-        hipLaunchKernelGGL((k_finalize_store<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)bs.seg_spmv, nb, (int64_t)0, dot_slot, done);
+        hipLaunchKernelGGL((k_cgd_fin_slot<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)bs.seg_spmv, nb, dot_slot, done, (FinScratch<T> *)bs.fin);
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     case 2: {  // step C
@@ -1815,7 +1825,7 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
         MIK_LAUNCH_CHECK(ctx);
         OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints() >> 3};
         MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)bs.seg_vec, done)));
-        hipLaunchKernelGGL((k_finalize_store<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)bs.seg_vec, nseg, (int64_t)0, rr_slot, done);
+        hipLaunchKernelGGL((k_cgd_fin_slot<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)bs.seg_vec, nseg, rr_slot, done, (FinScratch<T> *)bs.fin);
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     }
@@ -1824,7 +1834,7 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
         it->hist_total += 1;
         bs.seq += 1;
         hipLaunchKernelGGL((k_cgd_fin_res<T>), dim3(1), dim3(1), 0, ctx->stream, (const T *)it->rr_all, it->nranks, d, (T *)bs.hist,
-                           (long long)(iteration + 1), (long long)bs.maxiter, bs.mirror, bs.seq);
+                           (long long)(iteration + 1), (long long)bs.maxiter, bs.mirror, bs.seq, (int)(it->hist_total - 1));
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     default:
@@ -1850,7 +1860,9 @@ extern "C" int mik_cgd_wait(mik_cgd *it, double *residual, double *tol, int *don
     if (m.range)
         return mik_fail(ctx, MIK_ERR_RANGE, "cg (row-partitioned): |r|^2 left the range of a safe norm (badly scaled system); rescale b and A");
     const int64_t nd = m.nhist;
-    if (history && nd > 0) {
+    if (history && nd == 1 && cap >= 1) {
+        history[0] = m.res;                                   // the mirror carries the only residual: no copy
+    } else if (history && nd > 0) {
         const int64_t take = std::min<int64_t>(nd, cap);
         const size_t es = mik_dtype_size(bs.dtype);
         std::vector<unsigned char> tmp((size_t)take * es);
@@ -1859,12 +1871,8 @@ extern "C" int mik_cgd_wait(mik_cgd *it, double *residual, double *tol, int *don
         for (int64_t j = 0; j < take; ++j)
             history[j] = bs.dtype == MIK_F64 ? ((const double *)tmp.data())[j] : (double)((const float *)tmp.data())[j];
     }
-    // start a fresh history window for the next batch of steps
-    if (nd > 0) {
-        const size_t off = bs.dtype == MIK_F64 ? offsetof(CgDev<double>, nhist) : offsetof(CgDev<float>, nhist);
-        MIK_HIP(ctx, hipMemsetAsync((unsigned char *)bs.dev + off, 0, sizeof(int), ctx->stream));
-        bs.mirror->nhist = 0;
-    }
+    // start a fresh history window for the next batch of steps (the device is idle: the host owns the mirror)
+    bs.mirror->nhist = 0;
     it->hist_total = 0;
     bs.residual = m.res;
     bs.prev_residual = m.prev_res;
