@@ -26,7 +26,7 @@ def tkey(k):
 
 
 def short(name):
-    n = name.replace("void ", "").strip()
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "").strip()
     return n.split("(")[0][:110]
 
 
