@@ -44,5 +44,5 @@ for name, mangled in WANT.items():
     print(f"{name}   ({sum(ops.values())} instructions" + (f"; VGPRs {res.group(1)}, scratch {res.group(2)}, occupancy {res.group(3)} waves/SIMD, LDS {res.group(4)} B" if res else "") + ")")
     for k, c in sorted(cls.items(), key=lambda kv: (not kv[0].startswith(("global", "buffer", "ds_")), kv[0])):
         print(f"    {k:34s} {c:5d}")
-    nt = len(re.findall(r"global_load\w* .* nt", body)) + len(re.findall(r"global_load_lds\w* .* nt", body))
-    print(f"    (loads carrying the nt hint: {nt}; stores carrying nt: {len(re.findall(r'global_store.* nt', body))})\n")
+    nt = len(re.findall(r"(?:global|buffer)_load\w* .* nt\b", body))
+    print(f"    (loads carrying the nt hint: {nt}; stores carrying nt: {len(re.findall(r'(?:global|buffer)_store.* nt', body))})\n")
