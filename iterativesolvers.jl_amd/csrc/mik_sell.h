@@ -348,9 +348,9 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiac(int n, int ncols, int 
     }
 }
 
-// The slice-constant layout through BUFFER loads.  k_spmv_sdiac spends its time issuing instructions, not waiting for
-// memory: ~180 vector-ALU instructions per row for 7 multiply-adds (address clamps so that absent slots gather a valid
-// element, mask tests and selects around every add, 64-bit address arithmetic), 77 us of VALU issue alone at 256^3.
+// The slice-constant layout through BUFFER loads.  k_spmv_sdiac executes ~180 vector-ALU instructions per row for 7
+// multiply-adds (address clamps so that absent slots gather a valid element, mask tests and selects around every add,
+// 64-bit address arithmetic).
 // Here x is read through a buffer descriptor: the hardware adds a per-slot SCALAR offset (the slot's column offset) to
 // a per-row vector offset and returns ZERO for a vector offset outside the descriptor's range -- so an absent slot just
 // ORs all-ones into its row offset (one v_bfe of the inverted mask, one v_or), reads 0.0, and contributes value * 0 =
@@ -396,11 +396,11 @@ __device__ __forceinline__ int spmv_block_map_shift(int b, int nfull, int sshift
     return b;
 }
 
-// The kernel issues instructions, it does not wait for memory (a CU retires one scalar instruction per clock for all of
-// its waves: the ~400 scalar instructions per wave of the slot-by-slot form -- "does the slice have slot q", "is it the
-// diagonal", offset arithmetic -- were 85 us of its 91).  So the common (slots, centre slot) CLASS of the operator is
-// compiled in: template NS / CQ; a workgroup whose slices all have NS slots with the diagonal in slot CQ runs
-// straight-line code (per slot: v_bfe, v_or, buffer_load, v_mul, v_add), any other workgroup the slot-by-slot path.
+// The slot-by-slot form executes ~400 scalar instructions per wave ("does the slice have slot q", "is it the diagonal",
+// offset arithmetic).  The common (slots, centre slot) CLASS of the operator is therefore compiled in: template NS / CQ; a
+// workgroup whose slices all have NS slots with the diagonal in slot CQ runs straight-line code (per slot: v_bfe, v_or,
+// buffer_load, v_mul, v_add), any other workgroup the slot-by-slot path.  Worth 5 us of 91 at 256^3 -- the launch turned out
+// to wait for its streamed mask bytes, not for its instruction stream.
 constexpr int MIK_SDIAB_NCLS = 4;   // 0: none; 1: 7 slots, centre 3 (3-D 7-point); 2: 5 slots, centre 2 (2-D 5-point); 3: 3 slots, centre 1
 __host__ __device__ constexpr int mik_sdiab_cls_ns(int c) { return c == 1 ? 7 : c == 2 ? 5 : c == 3 ? 3 : 0; }
 __host__ __device__ constexpr int mik_sdiab_cls_cq(int c) { return c == 1 ? 3 : c == 2 ? 2 : c == 3 ? 1 : -1; }
