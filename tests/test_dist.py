@@ -442,3 +442,20 @@ def test_native_transport_argument_checks(pkg):
     assert L.mik_cgd_group_init(None, 2, None, None) == 1
     assert L.mik_comm_create(None, None, 0, 1, None) == 1
     assert L.mik_comm_destroy(None) == 0 and L.mik_comm_allgather_sum(None, 0, 1, None) == 1
+
+
+def test_torch_slab_generator_and_localisation_equal_the_numpy_ones(pkg):
+    """dist._laplace_rows_torch / localize_block_torch / interior_row_blocks on tensors (here on the CPU device; the bench runs
+    them on the GPU) against the numpy reference functions: same CSR slab, same local column ids, same halo plan"""
+    import torch
+    dist = pkg.dist
+    N, NZ, P = 10, 12, 4
+    offsets = np.arange(P + 1, dtype=np.int64) * (N * N * (NZ // P))
+    for r in range(P):
+        _, ptr, idx, val = dist._laplace_rows(pkg, N, NZ, offsets[r], offsets[r + 1], np.float64)
+        _, tptr, tidx, tval = dist._laplace_rows_torch(N, NZ, offsets[r], offsets[r + 1], np.float64, torch.device("cpu"))
+        assert np.array_equal(ptr, tptr.numpy()) and np.array_equal(idx, tidx.numpy()) and np.array_equal(val, tval.numpy())
+        li, plan = dist.localize_block(ptr, idx, offsets, r)
+        tli, tplan = dist.localize_block_torch(tptr, tidx, offsets, r)
+        assert np.array_equal(li, tli.numpy()) and np.array_equal(plan.ghost_gids, tplan.ghost_gids) and plan.recv == tplan.recv
+        assert dist.interior_row_blocks(ptr, li, plan.n_loc) == dist.interior_row_blocks(tptr, tli, plan.n_loc)
