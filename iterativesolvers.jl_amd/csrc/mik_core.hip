@@ -656,7 +656,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
     // Default: everything past the raw host-to-device copy happens on the device (mik_upload.hip).  MIK_ERR_NOTIMPL from it
     // = a matrix the host path below handles (long rows, duplicate entries, no room for the raw copy); development knob 20:
     // 1 = host path only.
-    if (g_mik_tuning[20] == 0 && nnz > 0 && n_rows > 0 && n_cols > 0) {
+    if (g_mik_tuning[20] == 0 && nnz > 0 && n_rows > 0 && n_cols > 0 && n_rows < 0x7f000000) {       // (row ids below the "no row yet" pattern of the analysis)
         mik_csr *A = new (std::nothrow) mik_csr();
         if (!A) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host allocation failed");
         A->ctx = ctx; A->dtype = dtype; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz;
