@@ -341,6 +341,7 @@ struct Scratch {                                   // device temporaries of one 
         return e;
     }
     void keep(void *p) { for (auto &q : ptrs) if (q == p) q = nullptr; }    // ownership moves to the operator
+    void release(void *p) { for (auto &q : ptrs) if (q == p && p) { (void)hipFree(p); q = nullptr; } }   // done with it early
 };
 
 inline unsigned blocks_for(long long n) { return (unsigned)((n + MIK_BLOCK - 1) / MIK_BLOCK); }
@@ -405,6 +406,7 @@ int upload_device_t(mik_ctx *ctx, mik_csr *A, int64_t n_rows, int64_t n_cols, in
     hipLaunchKernelGGL(k_up_stats, dim3((unsigned)nb), dim3(MIK_BLOCK), 0, st, A->rowptr, A->col, (long long)n_rows, d_st);
     UP_TRY(hipMemcpyAsync(&hs, d_st, sizeof(hs), hipMemcpyDeviceToHost, st));
     UP_TRY(hipStreamSynchronize(st));
+    S.release(d_ptr); S.release(d_idx); S.release(d_val); S.release(cursor);       // the raw copy (2 GB at 256^3) is consumed
     long_row = g_mik_tuning[4] > 0 ? g_mik_tuning[4] : MIK_LONG_ROW;
     if (hs.dup || (hs.max_row > long_row && g_mik_tuning[4] >= 0)) { rc = MIK_ERR_NOTIMPL; goto give_up; }     // the host path's business
     A->max_row_nnz = hs.max_row;
