@@ -144,6 +144,11 @@ int mik_csr_destroy(mik_csr *A);
  * mik_spmv / iterable calls then read 2 B instead of 12 B per entry and return bit-identical
  * results.  MIK_ERR_NOTIMPL (operator unchanged) when the matrix does not qualify. */
 int mik_csr_pack(mik_csr *A);
+/* Release the CSR arrays (rowptr / col / val: 12 B per entry at fp64) of an operator whose active layout is one of the sliced
+ * forms (1, 2, 4, 5) -- mik_spmv never reads them then; they are only what the development knobs fall back to.  Afterwards
+ * those knobs have no effect on this operator and mik_csr_pack returns MIK_ERR_NOTIMPL.  MIK_ERR_NOTIMPL (nothing released)
+ * for an operator that runs on its CSR arrays. */
+int mik_csr_compact(mik_csr *A);
 /* Device layout mik_spmv uses for this operator (chosen at upload from the sparsity pattern; results are
  * bit-identical across layouts): 0 = CSR row-blocks (LDS-staged products; any matrix), 1 = sliced-ELL (256-row
  * slices stored column-major; near-uniform row lengths per slice), 2 = sliced-ELL values + 8-bit codes for the

@@ -329,6 +329,15 @@ class HipCSR:
         check(code, "mik_csr_pack", self.ctx.handle)
         return True
 
+    def compact(self) -> bool:
+        """Release the CSR arrays of an operator that runs on one of the sliced layouts (``mik_csr_compact``); False (nothing
+        released) if the operator needs them."""
+        code = lib().mik_csr_compact(self.handle)
+        if code == 5:
+            return False
+        check(code, "mik_csr_compact", self.ctx.handle)
+        return True
+
     def size(self, d: Optional[int] = None):
         return (self.n_rows, self.n_cols) if d is None else (self.n_rows, self.n_cols)[d - 1]
 

@@ -961,6 +961,7 @@ extern "C" int mik_csr_pack(mik_csr *A)
 {
     if (!A) return MIK_ERR_INVALID;
     if (A->packed) return MIK_OK;
+    if (!A->col) return mik_fail(A->ctx, MIK_ERR_NOTIMPL, "mik_csr_pack: the CSR arrays were released (mik_csr_compact)");
     if (A->n_long) return mik_fail(A->ctx, MIK_ERR_NOTIMPL, "mik_csr_pack: matrix has long rows");
     return A->dtype == MIK_F64 ? csr_pack_impl<double>(A) : csr_pack_impl<float>(A);
 }
@@ -1013,14 +1014,35 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
 //   3 packed, 5 per-slice offsets + slice-constant values, 4 sliced-ELL + per-slice offsets, 2 sliced-ELL + 8-bit codes, 1 sliced-ELL, 0 CSR
 static int spmv_kernel_choice(const mik_csr *A)
 {
-    if (A->packed && g_mik_tuning[6] == 0) return 3;
-    if (g_mik_tuning[8] == 0) {
-        if (A->sdia_pats && g_mik_tuning[12] == 0) return 5;
-        if (A->sdia_val && g_mik_tuning[12] == 0) return 4;
-        if (A->sell8_codes && g_mik_tuning[10] == 0) return 2;
+    const bool csr = A->col != nullptr;                     // false after mik_csr_compact: the development knobs cannot fall back to CSR
+    if (A->packed && csr && g_mik_tuning[6] == 0) return 3;
+    if (g_mik_tuning[8] == 0 || !csr) {
+        if (A->sdia_pats && (g_mik_tuning[12] == 0 || !csr)) return 5;
+        if (A->sdia_val && (g_mik_tuning[12] == 0 || !csr)) return 4;
+        if (A->sell8_codes && (g_mik_tuning[10] == 0 || !csr)) return 2;
         if (A->sell_val) return 1;
     }
     return 0;
+}
+
+// The CSR arrays (12 B per entry at fp64) are what every matrix can run on, and what the development knobs fall back to;
+// an operator whose active layout is one of the sliced forms never reads them.  mik_csr_compact releases them.
+extern "C" int mik_csr_compact(mik_csr *A)
+{
+    if (!A) return MIK_ERR_INVALID;
+    if (!A->col) return MIK_OK;
+    if (!(A->sdia_pats || A->sdia_val || A->sell8_codes || A->sell_val) || A->n_long)
+        return mik_fail(A->ctx, MIK_ERR_NOTIMPL, "mik_csr_compact: this operator runs on its CSR arrays");
+    if (A->ctx) { (void)hipSetDevice(A->ctx->device); (void)hipStreamSynchronize(A->ctx->stream); }
+    if (A->packed) {                                        // the dictionary-coded form reads rowptr: drop it instead
+        if (A->codes) (void)hipFree(A->codes);
+        if (A->vtab) (void)hipFree(A->vtab);
+        if (A->dtab) (void)hipFree(A->dtab);
+        A->codes = nullptr; A->vtab = nullptr; A->dtab = nullptr; A->packed = false;
+    }
+    (void)hipFree(A->rowptr); (void)hipFree(A->col); (void)hipFree(A->val);
+    A->rowptr = nullptr; A->col = nullptr; A->val = nullptr;
+    return MIK_OK;
 }
 
 static inline bool spmv_csr_rowgather(const mik_csr *A)

@@ -162,3 +162,27 @@ def test_device_resident_input_arrays(pkg, orc, ctx, dist):
         tli, tplan = dist.localize_block_torch(tptr, tidx, offsets, r)
         assert np.array_equal(li, tli.cpu().numpy()) and np.array_equal(plan.ghost_gids, tplan.ghost_gids) and plan.recv == tplan.recv
         assert dist.interior_row_blocks(ptr, li, plan.n_loc) == dist.interior_row_blocks(tptr, tli, plan.n_loc)
+
+
+def test_compact_releases_the_csr_arrays(pkg, orc, ctx):
+    A = orc.laplace(12, 3)
+    x = np.random.default_rng(1).standard_normal(A.n)
+    dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval, index_base=A.index_base)
+    want = orc.spmv(A, x)
+    assert dA.compact() and dA.compact()                              # idempotent
+    assert dA.layout() == "slice-offsets+slice-values+row-masks"
+    assert np.array_equal(pkg.mul_(pkg.HipVector(A.n), dA, pkg.HipVector.from_numpy(x)).to_numpy(), want)
+    L = pkg.lib()
+    L.mik_set_tuning(8, 1)                                            # "CSR only" has nothing to fall back to any more
+    try:
+        assert dA.layout() == "slice-offsets+slice-values+row-masks"
+        assert np.array_equal(pkg.mul_(pkg.HipVector(A.n), dA, pkg.HipVector.from_numpy(x)).to_numpy(), want)
+    finally:
+        L.mik_set_tuning(8, 0)
+    assert dA.pack() is False
+    xs, ch = pkg.cg(dA, pkg.HipVector.from_numpy(orc.hashed_rhs(A.n)), log=True)
+    assert ch.isconverged
+    # an operator that runs on its CSR arrays keeps them
+    n, rowptr, colidx, val = pkg.fixtures.irregular_matrix(3000, np.float64, long_rows=False)
+    dB = pkg.HipCSR(n, n, rowptr, colidx, val, index_base=0, is_csc=False)
+    assert dB.layout() == "csr-rowblock" and dB.compact() is False
