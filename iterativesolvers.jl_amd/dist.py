@@ -1044,8 +1044,11 @@ def bench_main(args):
                        "halo_overlap": bool(getattr(eng, "overlap", False)),
                        "operator_build_and_upload_seconds": upload_seconds, "final_residual": it.residual},
             "batched_25_steps_per_sync_iters_per_sec": world * kb / float(np.median(times_b)),
-            "roofline": {"bound": "hbm", "kernel": f"SpMV, operator layout {eng.A.layout()}, fused dot (rank 0, back-to-back on the live u)",
-                         "achieved": moved, "peak": 8000.0, "unit": "GB/s", "frac": moved / 8000.0, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": f"{eng.A.spmv_kernel()}<double, fused dot> (operator layout {eng.A.layout()}; rank 0, back-to-back on the live u)",
+                         "achieved": moved, "peak": 8000.0, "unit": "GB/s", "frac": moved / 8000.0,
+                         "traffic": (getattr(args, "pmc_traffic", None) or (lambda k: None))(eng.A.spmv_kernel()),
+                         "note": "bytes this layout moves per launch over the HIP-event time; the slice-constant layout of this operator is not HBM-bound "
+                                 "(DESIGN.md section 5) -- the single-GPU line carries the three-layout comparison and the CSR fraction",
                          "bytes_moved_per_launch": stored_bytes, "avg_launch_ms": spmv_ms,
                          "achieved_algorithmic": alg_bytes / (spmv_ms * 1e-3) / 1e9, "algorithmic_bytes_per_launch": alg_bytes},
             "aggregate_row_updates_per_sec": K / dt * n,
