@@ -375,8 +375,11 @@ template <typename T> __device__ __forceinline__ bool level2_sum_spread(const T 
     acc = wave_tree(acc);
     bool last = false;
     if (lane == 0) {
+        // hand-off without cache-wide fences (as longrow_store, mik_spmv.h): one write-through store, drained, then a relaxed ticket;
+        // the last arrival reads the sums with loads that are served past its L1
         __hip_atomic_store(&fs->ws[w], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned tk = __hip_atomic_fetch_add(&fs->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tk = __hip_atomic_fetch_add(&fs->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tk == (unsigned)gridDim.x - 1u) {
             T t = __hip_atomic_load(&fs->ws[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
