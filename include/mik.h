@@ -215,7 +215,13 @@ int mik_cg_create(mik_ctx *ctx, const mik_csr *A, void *x, const void *b, void *
                   int64_t maxiter, int initially_zero, mik_cg **out);
 int mik_cg_destroy(mik_cg *it);
 /* iterate(it, iteration) -- src/cg.jl:43-66 / :72-100.  *done = 1 and nothing is computed when
- * done(it, iteration) (src/cg.jl:36); otherwise one step runs and *residual = it.residual. */
+ * done(it, iteration) (src/cg.jl:36); otherwise one step runs and *residual = it.residual.
+ * x, r and the residual are those of the step just returned.  The search direction u and c = A u are
+ * the iterable's scratch: with a CSR operator and no host callbacks the library enqueues the first half of
+ * the NEXT step (u = r + beta u, c = A u, alpha) before it waits for this step's residual, so on return
+ * u and c may already belong to step iteration + 1 (results of any call sequence are unchanged; the
+ * device-side stopping flag turns that half into a no-op once the iteration has stopped;
+ * mik_set_tuning(9, 1) switches it off). */
 int mik_cg_iterate(mik_cg *it, int64_t iteration, double *residual, int *done);
 /* Up to max_steps consecutive iterate() calls with ONE host synchronisation: the stopping test
  * of src/cg.jl:36 is evaluated on the device after every step and later steps become no-ops.
