@@ -116,7 +116,8 @@ int mik_spmv_long_segment(int *segment);
  *  13: bit mask switching the Krylov-basis streaming hints off    14: CSR kernel: 0 = by operator, 1 = register-staged products, 2 = LDS-DMA tile + per-row gather
  *  15: long-row segment length (> 0; read at mik_csr_create)   16: slices per workgroup of the layout-5 kernels (1 / 2 / 4)
  *  17: 1 = layout 5 through flat loads (k_spmv_sdiac)              18: 1 = k_spmv_sdiab without the compiled-in slot class
- *  20: 1 = mik_csr_create on the host path only                   21: DGKS rounds inside the single-launch kernel (1..3; read at mik_gmres_create) */
+ *  20: 1 = mik_csr_create on the host path only                   21: DGKS rounds inside the single-launch kernel (1..3; read at mik_gmres_create)
+ *  23: 1 = CG updates x in the step's own sweep (read at mik_cg_create) */
 int mik_set_tuning(int key, int value);
 
 /* ---- device memory (similar / zero / copyto! / fill! of the vector interface) ----------- */
@@ -216,13 +217,19 @@ int mik_cg_create(mik_ctx *ctx, const mik_csr *A, void *x, const void *b, void *
 int mik_cg_destroy(mik_cg *it);
 /* iterate(it, iteration) -- src/cg.jl:43-66 / :72-100.  *done = 1 and nothing is computed when
  * done(it, iteration) (src/cg.jl:36); otherwise one step runs and *residual = it.residual.
- * x, r and the residual are those of the step just returned.  The search direction u and c = A u are
+ * r and the residual are those of the step just returned, and so is x for every reader ordered after the
+ * ctx stream (mik_memcpy_d2h, kernels on that stream, or after mik_synchronize): with a CSR operator the
+ * update x .+= alpha .* u of a step is carried out by the sweep over u that opens the next step (same
+ * operands, same rounding), which is on the stream before this call returns.  The search direction u and c = A u are
  * the iterable's scratch: with a CSR operator and no host callbacks the library enqueues the first half of
  * the NEXT step (u = r + beta u, c = A u, alpha) before it waits for this step's residual, so on return
  * u and c may already belong to step iteration + 1 (results of any call sequence are unchanged; the
  * device-side stopping flag turns that half into a no-op once the iteration has stopped;
  * mik_set_tuning(9, 1) switches it off). */
 int mik_cg_iterate(mik_cg *it, int64_t iteration, double *residual, int *done);
+/* 1 if this iterable applies x .+= alpha .* u in the sweep over u that opens the next step (CSR operator, no
+ * preconditioner callback; see mik_cg_iterate), 0 if in the step's own update sweep. */
+int mik_cg_fused_x(const mik_cg *it, int *fused);
 /* Up to max_steps consecutive iterate() calls with ONE host synchronisation: the stopping test
  * of src/cg.jl:36 is evaluated on the device after every step and later steps become no-ops.
  * residuals[0..*steps_done-1] receive it.residual after each executed step. */

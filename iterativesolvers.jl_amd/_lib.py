@@ -104,6 +104,7 @@ SIGNATURES = {
     "mik_gmres_create_op": (C.c_int, [_vp, C.POINTER(MikOperator), C.POINTER(MikPrecond), C.POINTER(MikPrecond), _vp, _vp, C.c_double, C.c_double,
                                       C.c_int, _i64, C.c_int, C.c_int, C.POINTER(_vp)]),
     "mik_cg_destroy": (C.c_int, [_vp]),
+    "mik_cg_fused_x": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "mik_cg_iterate": (C.c_int, [_vp, _i64, _f64p, _ip]),
     "mik_cg_iterate_many": (C.c_int, [_vp, _i64, _i64, _f64p, _i64p]),
     "mik_cg_state": (C.c_int, [_vp, _f64p, _f64p, _f64p, _i64p, _i64p, _ip]),

@@ -636,6 +636,12 @@ class CGIterable:
         self.mv_products += 1
         return self.residual, iteration + 1
 
+    def fused_x(self) -> bool:
+        """True if ``x .+= alpha .* u`` rides on the sweep over u that opens the next step (``mik_cg_fused_x``)."""
+        out = C.c_int()
+        self._check(lib().mik_cg_fused_x(self.handle, C.byref(out)), "mik_cg_fused_x")
+        return bool(out.value)
+
     def iterate_many(self, iteration: int, max_steps: int) -> np.ndarray:
         """Up to ``max_steps`` ``iterate`` calls with one host synchronisation; returns the residuals."""
         out = np.empty(max(int(max_steps), 1), np.float64)

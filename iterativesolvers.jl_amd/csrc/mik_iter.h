@@ -6,6 +6,7 @@
 template <typename T> struct CgDev {
     T res, prev_res, alpha, beta, dot_uc, rr, tol, rho;
     int done, nhist;
+    int x_pending, pad_;   // x .+= alpha .* u of the last step has not been applied yet (it rides on the next sweep over u)
 };
 
 // Host-mapped (pinned, device-visible) mirror of the scalars the host needs after a step.  The
@@ -42,6 +43,7 @@ struct mik_cg {
     unsigned long long seq = 0;      // steps enqueued so far (published by k_cg_fin_res)
     bool dev_done = false;           // device stopping flag known to be set
     bool head_ahead = false;         // the head of the next step (u, c, alpha) is on the stream already
+    bool fuse_x = false;             // x .+= alpha .* u rides on the next u = r + beta u sweep (plain / Jacobi CG on a CSR operator)
     // optional in-loop timing of the SpMV launch (HIP events on the ctx stream)
     int profile = 0;               // 0 off, 1 = the SpMV launch, 2 = SpMV + the two vector sweeps of the step
     std::vector<hipEvent_t> ev;    // pairs (start, stop), recycled

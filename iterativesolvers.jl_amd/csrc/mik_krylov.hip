@@ -406,6 +406,7 @@ template <typename T> __device__ __forceinline__ void cg_init_scalars(CgDev<T> *
     d->dot_uc = T(0);
     d->done = (0 >= maxiter || res <= d->tol) ? 1 : 0;
     d->nhist = 0;
+    d->x_pending = 0;
 }
 
 template <typename T>
@@ -427,6 +428,7 @@ template <typename T> __global__ void k_cg_set_init(CgDev<T> *d, T res, T reltol
 template <typename T>
 __global__ __launch_bounds__(64) void k_cg_fin_alpha(const T *__restrict__ S, int64_t m, CgDev<T> *d, int pcg, FinScratch<T> *fs)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) d->x_pending = 0;      // the sweep over u before this launch applied it (OpXpbyX)
     if (d->done) return;
     T tot;
     if (level2_sum_spread(S, m, fs, tot)) {
@@ -473,7 +475,7 @@ __device__ __forceinline__ void cg_res_scalars(CgDev<T> *d, T tot, T res, T *__r
 template <typename T>
 __global__ __launch_bounds__(64) void k_cg_fin_res(const T *__restrict__ S, int64_t m, CgDev<T> *d, T *__restrict__ hist,
                                                     long long it_next, long long maxiter, CgMirror *mirror,
-                                                    unsigned long long seq, int hist_index, FinScratch<T> *fs)
+                                                    unsigned long long seq, int hist_index, FinScratch<T> *fs, int fuse_x)
 {
     if (d->done) {
         // a no-op step (the stopping test fired earlier in this batch): still publish, state unchanged
@@ -482,6 +484,7 @@ __global__ __launch_bounds__(64) void k_cg_fin_res(const T *__restrict__ S, int6
     }
     T tot;
     if (level2_sum_spread(S, m, fs, tot)) {
+        if (fuse_x) d->x_pending = 1;          // r of this step is final; its x .+= alpha .* u rides on the next sweep over u
         if (!mik_nrm_in_range(tot)) {
             // |r|^2 underflowed / overflowed (or r is exactly zero): x and r of this step are final, its norm is not.
             // Freeze the batch (later steps become no-ops) and let the host finish the step with the scaled norm.
@@ -562,11 +565,14 @@ struct CgProfileScope {
 // u .= r .+ beta .* u: streaming them past L2 (non-temporal) leaves the cache to the operator's gather and
 // took the in-loop SpMV from 322 to 307 us and the step from 546 to 507 us at 256^3.
 // bits 0-2: xpby {r load, u load, u store}; bits 3-7: update {x, c load, u load, r load, r store}.
-// tuning[7]: 0 = default (57), < 0 = all temporal, > 0 = explicit mask.
-static inline int cg_stream_hints()
+// tuning[7]: 0 = default, < 0 = all temporal, > 0 = explicit mask.  Defaults (sweeps of single-bit flips and pairs inside the
+// CG loop at 256^3): 57 for the classic step; 121 (r of the update streamed as well) when x .+= alpha .* u rides on the next
+// sweep over u (OpXpbyX / OpCgUpdateR: bit 3 = x of that sweep) -- 3,887 -> 3,971 it/s, mostly through what the SpMV in
+// between finds in the Infinity Cache.
+static inline int cg_stream_hints(bool fused_x = false)
 {
     const int k = g_mik_tuning[7];
-    return k == 0 ? 57 : (k < 0 ? 0 : k);
+    return k == 0 ? (fused_x ? 121 : 57) : (k < 0 ? 0 : k);
 }
 
 // One iterate() = HEAD (u = r + beta u [after c = Pl \ r, rho]; c = A u; alpha) + TAIL (x, r update; residual, stopping test).
@@ -599,14 +605,24 @@ template <typename T> static int cg_enqueue_head(mik_cg *it)
         hipLaunchKernelGGL((k_cg_fin_rho<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_vec, nseg, d, (FinScratch<T> *)it->fin);
         MIK_LAUNCH_CHECK(ctx);
         // u .= c .+ beta .* u                                           src/cg.jl:86
-        OpXpby<T> op{c, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 1};   // c = Pl \\ r is dead after this sweep
         CgProfileScope ps(it, 1);
-        MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
+        if (it->fuse_x) {
+            OpXpbyX<T> op{c, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(true) & 9};
+            MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, (const int *)nullptr)));
+        } else {
+            OpXpby<T> op{c, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 1};   // c = Pl \\ r is dead after this sweep
+            MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
+        }
     } else {
         // u .= r .+ beta .* u                                           src/cg.jl:50-51
-        OpXpby<T> op{r, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 7};
         CgProfileScope ps(it, 1);
-        MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
+        if (it->fuse_x) {   // ... and x .+= alpha .* u of the previous step, on the u this sweep reads anyway (OpXpbyX)
+            OpXpbyX<T> op{r, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(true) & 15};
+            MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, (const int *)nullptr)));
+        } else {
+            OpXpby<T> op{r, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 7};
+            MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
+        }
     }
     // c = A * u with the dot(u, c) epilogue                             src/cg.jl:54-55
     if (it->A) {
@@ -626,6 +642,20 @@ template <typename T> static int cg_enqueue_head(mik_cg *it)
     return MIK_OK;
 }
 
+template <typename T> __global__ void k_cg_clear_pending(CgDev<T> *d) { d->x_pending = 0; }
+
+template <typename T> static int cg_enqueue_xflush(mik_cg *it)
+{
+    mik_ctx *ctx = it->ctx;
+    CgDev<T> *d = (CgDev<T> *)it->dev;
+    T *x = (T *)it->x, *u = (T *)it->u;
+    OpXFlush<T> op{u, x, coef_ptr<T>(&d->alpha), &d->x_pending};
+    MIK_TRY((launch_map<T>(ctx, it->n, op, mik_aligned16(x) && mik_aligned16(u), (T *)nullptr, (const int *)nullptr)));
+    hipLaunchKernelGGL((k_cg_clear_pending<T>), dim3(1), dim3(1), 0, ctx->stream, d);
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+
 template <typename T> static int cg_enqueue_tail(mik_cg *it, long long it_next, int hist_index)
 {
     mik_ctx *ctx = it->ctx;
@@ -636,14 +666,19 @@ template <typename T> static int cg_enqueue_tail(mik_cg *it, long long it_next, 
     T *x = (T *)it->x, *u = (T *)it->u, *r = (T *)it->r, *c = (T *)it->c;
     const bool vec = mik_aligned16(x) && mik_aligned16(u) && mik_aligned16(r) && mik_aligned16(c) && (!it->diag || mik_aligned16(it->diag));
     // x .+= alpha .* u; r .-= alpha .* c; norm(r)                       src/cg.jl:58-62
-    OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints() >> 3};
     {
         CgProfileScope ps(it, 2);
-        MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done)));
+        if (it->fuse_x) {
+            OpCgUpdateR<T> up{r, c, coef_ptr<T>(&d->alpha), cg_stream_hints(true) >> 3};
+            MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done)));
+        } else {
+            OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints() >> 3};
+            MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done)));
+        }
     }
     it->seq += 1;
     hipLaunchKernelGGL((k_cg_fin_res<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_vec, nseg, d, (T *)it->hist,
-                       it_next, (long long)it->maxiter, it->mirror, it->seq, hist_index, (FinScratch<T> *)it->fin);
+                       it_next, (long long)it->maxiter, it->mirror, it->seq, hist_index, (FinScratch<T> *)it->fin, it->fuse_x ? 1 : 0);
     MIK_LAUNCH_CHECK(ctx);
     return MIK_OK;
 }
@@ -731,6 +766,7 @@ static int cg_create_common(mik_ctx *ctx, const mik_csr *A, int dtype, int64_t n
     it->op_mul = op_mul; it->op_user = op_user; it->pl_fn = pl_fn; it->pl_user = pl_user;
     it->x = x; it->b = b; it->u = u; it->r = r; it->c = c; it->diag = jacobi_diag;
     it->maxiter = maxiter;
+    it->fuse_x = A != nullptr && !pl_fn && g_mik_tuning[23] == 0;       // development knob 23: 1 = x updated by the step's own sweep
     const size_t es = mik_dtype_size(dtype);
     const int64_t nseg = dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
     const int64_t nb = mik_spmv_nwg(n);
@@ -843,6 +879,7 @@ static int cg_iterate_many_impl(mik_cg *it, int64_t iteration, int64_t max_steps
             MIK_TRY(cg_enqueue_tail<T>(it, (long long)(iteration + j + 1), (int)j));
         }
         if (ahead_ok) MIK_TRY(cg_enqueue_head<T>(it));
+        else if (it->fuse_x) MIK_TRY(cg_enqueue_xflush<T>(it));         // no sweep over u follows: apply the last x .+= alpha .* u now
         MIK_TRY(cg_wait_mirror(it));
         m = *it->mirror;
         if (!m.range) { it->head_ahead = ahead_ok && !m.done; break; }       // stopped: the head ahead was a no-op
@@ -896,6 +933,13 @@ extern "C" int mik_cg_iterate(mik_cg *it, int64_t iteration, double *residual, i
     if (rc) return rc;
     *done = nd == 0 ? 1 : 0;
     if (residual) *residual = it->residual;
+    return MIK_OK;
+}
+
+extern "C" int mik_cg_fused_x(const mik_cg *it, int *fused)
+{
+    if (!it || !fused) return MIK_ERR_INVALID;
+    *fused = it->fuse_x ? 1 : 0;
     return MIK_OK;
 }
 

@@ -1,4 +1,5 @@
-"""CG with the head of the next step enqueued ahead of the host wait (csrc/mik_krylov.hip, cg_enqueue_head): x, r and the
+"""CG with the head of the next step enqueued ahead of the host wait, and with x .+= alpha .* u carried by the next sweep over u
+(csrc/mik_krylov.hip, cg_enqueue_head; OpXpbyX): x, r and the
 residual history after any mix of iterate / iterate_many calls equal those of the plain protocol (development knob 9 = 1)
 and the oracle, bit for bit -- including stops by tolerance, by maxiter, and a solve that is continued after a pause.
 GPU box only."""
@@ -44,10 +45,11 @@ def test_lookahead_changes_nothing_the_caller_can_see(pkg, orc, ctx, dtype, pcg)
     schedule = [1, 1, 3, 1, 7, 1, 1, 25, 1, 1]
     kw = dict(reltol=0.0, maxiter=10 ** 6)
     h1, s1, _ = run(pkg, A, b, schedule, {}, Pl, **kw)
-    h0, s0, _ = run(pkg, A, b, schedule, {9: 1}, Pl, **kw)
-    assert np.array_equal(h1, h0) and len(s1) == len(s0)
-    for (x1, r1), (x0, r0) in zip(s1, s0):
-        assert np.array_equal(x1, x0) and np.array_equal(r1, r0)
+    for knobs in ({9: 1}, {23: 1}, {9: 1, 23: 1}):       # no look-ahead; x updated by the step's own sweep; neither
+        h0, s0, _ = run(pkg, A, b, schedule, knobs, Pl, **kw)
+        assert np.array_equal(h1, h0) and len(s1) == len(s0), knobs
+        for (x1, r1), (x0, r0) in zip(s1, s0):
+            assert np.array_equal(x1, x0) and np.array_equal(r1, r0), knobs
     if not pcg:
         _, ho = orc.cg(A, b, maxiter=len(h1), mode="tree", shape=ctx.cg_shape(dtype), reltol=0.0)
         assert np.array_equal(h1, np.asarray(ho["resnorm"], dtype=np.float64)[:len(h1)])
@@ -59,8 +61,9 @@ def test_lookahead_at_the_stopping_tests(pkg, orc, ctx):
     for kw in (dict(reltol=1e-6, maxiter=10 ** 6), dict(reltol=0.0, maxiter=13), dict(reltol=1e-3, maxiter=10 ** 6)):
         for schedule in ([1] * 200, [4] * 60, [1, 5, 1, 9] * 20):
             h1, s1, _ = run(pkg, A, b, schedule, {}, **kw)
-            h0, s0, _ = run(pkg, A, b, schedule, {9: 1}, **kw)
-            assert np.array_equal(h1, h0) and len(s1) == len(s0) and len(h1) > 0
-            assert np.array_equal(s1[-1][0], s0[-1][0]) and np.array_equal(s1[-1][1], s0[-1][1])
+            for knobs in ({9: 1}, {23: 1}, {9: 1, 23: 1}):
+                h0, s0, _ = run(pkg, A, b, schedule, knobs, **kw)
+                assert np.array_equal(h1, h0) and len(s1) == len(s0) and len(h1) > 0, knobs
+                assert np.array_equal(s1[-1][0], s0[-1][0]) and np.array_equal(s1[-1][1], s0[-1][1]), knobs
             if kw["maxiter"] == 13:
                 assert len(h1) == 13
