@@ -352,12 +352,14 @@ extern "C" int mik_cgd_iterate_many(mik_cgd *it, int64_t iteration, int64_t max_
     if (max_steps <= 0 || iteration >= bs.maxiter || bs.residual <= bs.tol) return MIK_OK;      // done(it, iteration), src/cg.jl:36
     max_steps = std::min<int64_t>(std::min<int64_t>(max_steps, bs.maxiter - iteration), bs.hist_cap);
     const bool ahead_ok = g_mik_tuning[9] == 0 && iteration + max_steps < bs.maxiter;      // development knob 9: 1 = nothing ahead of the host
+    bs.fuse_x = g_mik_tuning[23] == 0;                              // x .+= alpha .* u rides on the next sweep over u (as in mik_cg_*)
     for (int64_t j = 0; j < max_steps; ++j) {
         if (!bs.head_ahead) MIK_TRY(cgd_enqueue_head(it, iteration + j));
         bs.head_ahead = false;
         MIK_TRY(cgd_enqueue_tail(it, iteration + j));
     }
     if (ahead_ok) MIK_TRY(cgd_enqueue_head(it, iteration + max_steps));
+    else if (bs.fuse_x) MIK_TRY(mik_cgd_phase(it, 6, iteration + max_steps - 1));       // no sweep over u follows: apply the last x update now
     int done = 0;
     MIK_TRY(mik_cgd_wait(it, nullptr, nullptr, &done, residuals, max_steps, steps_done));
     bs.head_ahead = ahead_ok && !done;                              // stopped: the head ahead was a no-op on every rank

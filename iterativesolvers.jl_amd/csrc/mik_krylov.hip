@@ -1684,6 +1684,7 @@ __global__ __launch_bounds__(64) void k_cgd_fin_slot(const T *__restrict__ S, in
 
 template <typename T> __global__ void k_cgd_alpha(const T *__restrict__ dot_all, int nranks, CgDev<T> *d)
 {
+    d->x_pending = 0;                          // the sweep over u of this step's head applied it (OpXpbyX)
     if (d->done) return;
     const T tot = rank_sum(dot_all, nranks);
     d->dot_uc = tot;
@@ -1715,9 +1716,10 @@ __global__ void k_cgd_fin_init(const T *__restrict__ rr_all, int nranks, CgDev<T
 
 template <typename T>
 __global__ void k_cgd_fin_res(const T *__restrict__ rr_all, int nranks, CgDev<T> *d, T *__restrict__ hist, long long it_next, long long maxiter,
-                              CgMirror *mirror, unsigned long long seq, int hist_index)
+                              CgMirror *mirror, unsigned long long seq, int hist_index, int fuse_x)
 {
     if (d->done) { __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+    if (fuse_x) d->x_pending = 1;              // r of this step is final; its x update rides on the next sweep over u
     const T tot = rank_sum(rr_all, nranks);
     if (tot != T(0) && !mik_nrm_in_range(tot)) {
         d->done = 1; mirror->done = 1; mirror->range = 1;
@@ -1849,9 +1851,21 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     case 0: {  // step A
-        OpXpby<T> op{r, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 7};
-        MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
+        if (bs.fuse_x) {   // ... with x .+= alpha .* u of the previous step on the u this sweep reads anyway (OpXpbyX)
+            OpXpbyX<T> op{r, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(true) & 15};
+            MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, (const int *)nullptr)));
+        } else {
+            OpXpby<T> op{r, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 7};
+            MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
+        }
         return gather_launch<T>(ctx, it->n_send, it->send_idx, u, (T *)it->send_buf, done);
+    }
+    case 6: {  // the x update that is still due when no head follows (end of a call without look-ahead)
+        OpXFlush<T> op{u, x, coef_ptr<T>(&d->alpha), &d->x_pending};
+        MIK_TRY((launch_map<T>(ctx, n, op, mik_aligned16(x) && mik_aligned16(u), (T *)nullptr, (const int *)nullptr)));
+        hipLaunchKernelGGL((k_cg_clear_pending<T>), dim3(1), dim3(1), 0, ctx->stream, d);
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
     }
     case 1:    // step B
         MIK_TRY(mik_spmv_launch<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done));
@@ -1870,8 +1884,13 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
     case 2: {  // step C
         hipLaunchKernelGGL((k_cgd_alpha<T>), dim3(1), dim3(1), 0, ctx->stream, (const T *)it->dot_all, it->nranks, d);
         MIK_LAUNCH_CHECK(ctx);
-        OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints() >> 3};
-        MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)bs.seg_vec, done)));
+        if (bs.fuse_x) {
+            OpCgUpdateR<T> up{r, c, coef_ptr<T>(&d->alpha), cg_stream_hints(true) >> 3};
+            MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)bs.seg_vec, done)));
+        } else {
+            OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints() >> 3};
+            MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)bs.seg_vec, done)));
+        }
         hipLaunchKernelGGL((k_cgd_fin_slot<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)bs.seg_vec, nseg, rr_slot, done, (FinScratch<T> *)bs.fin);
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
@@ -1881,7 +1900,7 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
         it->hist_total += 1;
         bs.seq += 1;
         hipLaunchKernelGGL((k_cgd_fin_res<T>), dim3(1), dim3(1), 0, ctx->stream, (const T *)it->rr_all, it->nranks, d, (T *)bs.hist,
-                           (long long)(iteration + 1), (long long)bs.maxiter, bs.mirror, bs.seq, (int)(it->hist_total - 1));
+                           (long long)(iteration + 1), (long long)bs.maxiter, bs.mirror, bs.seq, (int)(it->hist_total - 1), bs.fuse_x ? 1 : 0);
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     default:
