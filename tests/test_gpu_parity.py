@@ -526,3 +526,18 @@ def test_gmres_dgks_reorthogonalisation_inside_the_single_launch_kernel(pkg, orc
                 lib.mik_set_tuning(kk, 0)
         assert np.array_equal(ch["resnorm"], ho["resnorm"]), knobs
         assert np.array_equal(x.to_numpy(), xo), knobs
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_cg_bit_exact_at_128_cubed(pkg, orc, ctx, dtype):
+    """2 M rows: the XCD strip map (64 slices per plane), the compiled-in slot class, look-ahead and the fused x update at a
+    size where every workgroup map and tail case of the production run occurs; 40 steps bit for bit against the oracle, and the
+    same through the row-partitioned code path's single-rank case"""
+    A = orc.laplace(128, 3).astype(dtype)
+    b = orc.hashed_rhs(A.n).astype(dtype)
+    dA = upload(pkg, A)
+    assert dA.layout() == "slice-offsets+slice-values+row-masks" and dA.spmv_kernel() == "k_spmv_sdiab"
+    x, ch = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True, maxiter=40, reltol=0.0)
+    xo, ho = orc.cg(A, b, maxiter=40, reltol=0.0, mode="tree", shape=ctx.cg_shape(dtype))
+    assert np.array_equal(ch["resnorm"], np.asarray(ho["resnorm"], dtype=np.float64))
+    assert np.array_equal(x.to_numpy(), xo)
