@@ -459,3 +459,33 @@ def test_torch_slab_generator_and_localisation_equal_the_numpy_ones(pkg):
         tli, tplan = dist.localize_block_torch(tptr, tidx, offsets, r)
         assert np.array_equal(li, tli.numpy()) and np.array_equal(plan.ghost_gids, tplan.ghost_gids) and plan.recv == tplan.recv
         assert dist.interior_row_blocks(ptr, li, plan.n_loc) == dist.interior_row_blocks(tptr, tli, plan.n_loc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_rccl_send_recv_call_path_on_one_device(pkg, ctx, dtype):
+    """ncclSend / ncclRecv as libmik.so issues them (mik_comm_halo: group start, receives, sends, group end on the ctx stream),
+    exercised on hardware with the only peer a single-GPU box offers -- the rank itself: two segments of a packed send buffer
+    land at their offsets in the ghost region, element type and counts as in the halo plan of the row-partitioned solvers"""
+    import ctypes as C
+    d = dist_mod(pkg)
+    boot = d.SelfComm()
+    hctx = pkg.HipContext(0)
+    nc = d.NativeComm(pkg, hctx, boot, force_rccl=True)
+    assert nc.uses_rccl()
+    rng = np.random.default_rng(17)
+    send = rng.standard_normal(5000).astype(dtype)
+    dsend = pkg.HipVector.from_numpy(send, hctx)
+    ghost = pkg.HipVector(7000, dtype, hctx).fill_(0)
+    peers = (C.c_int * 2)(0, 0)
+    roff, rcnt = (C.c_int64 * 2)(100, 4000), (C.c_int64 * 2)(1500, 2500)
+    soff, scnt = (C.c_int64 * 2)(0, 2000), (C.c_int64 * 2)(1500, 2500)
+    code = pkg.lib().mik_comm_halo(nc.handle, 0 if dtype == np.float64 else 1, C.c_void_p(dsend.ptr), C.c_void_p(ghost.ptr), 2, peers, roff, rcnt, 2, peers,
+                                   soff, scnt)
+    pkg._lib.check(code, "mik_comm_halo", hctx.handle)
+    got = ghost.to_numpy()
+    want = np.zeros(7000, dtype)
+    want[100:1600] = send[0:1500]
+    want[4000:6500] = send[2000:4500]
+    assert np.array_equal(got, want)
+    nc.close()
