@@ -214,6 +214,7 @@ extern "C" int mik_comm_halo(mik_comm *cm, int dtype, const void *send_buf, void
 // ---------------------------------------------------------------------------------------------
 // row-partitioned CG driven by the library
 // ---------------------------------------------------------------------------------------------
+// (a rank may be its own neighbour -- a periodic direction cut into one slab: RCCL sends to self inside a group)
 extern "C" int mik_cgd_set_halo_plan(mik_cgd *it, int n_recv, const int *recv_peer, const int64_t *recv_off, const int64_t *recv_cnt,
                                      int n_send, const int *send_peer, const int64_t *send_off, const int64_t *send_cnt)
 {
@@ -224,12 +225,12 @@ extern "C" int mik_cgd_set_halo_plan(mik_cgd *it, int n_recv, const int *recv_pe
     it->recv.clear();
     it->send.clear();
     for (int i = 0; i < n_recv; ++i) {
-        if (recv_peer[i] < 0 || recv_peer[i] >= it->nranks || recv_peer[i] == it->rank || recv_off[i] < 0 || recv_cnt[i] < 0 || recv_off[i] + recv_cnt[i] > n_ghost)
+        if (recv_peer[i] < 0 || recv_peer[i] >= it->nranks || recv_off[i] < 0 || recv_cnt[i] < 0 || recv_off[i] + recv_cnt[i] > n_ghost)
             return mik_fail(ctx, MIK_ERR_INVALID, "mik_cgd_set_halo_plan: receive segment %d out of range", i);
         it->recv.push_back({recv_peer[i], recv_off[i], recv_cnt[i]});
     }
     for (int i = 0; i < n_send; ++i) {
-        if (send_peer[i] < 0 || send_peer[i] >= it->nranks || send_peer[i] == it->rank || send_off[i] < 0 || send_cnt[i] < 0 || send_off[i] + send_cnt[i] > it->n_send)
+        if (send_peer[i] < 0 || send_peer[i] >= it->nranks || send_off[i] < 0 || send_cnt[i] < 0 || send_off[i] + send_cnt[i] > it->n_send)
             return mik_fail(ctx, MIK_ERR_INVALID, "mik_cgd_set_halo_plan: send segment %d out of range", i);
         it->send.push_back({send_peer[i], send_off[i], send_cnt[i]});
     }

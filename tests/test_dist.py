@@ -489,3 +489,55 @@ def test_rccl_send_recv_call_path_on_one_device(pkg, ctx, dtype):
     want[4000:6500] = send[2000:4500]
     assert np.array_equal(got, want)
     nc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [True, False])
+def test_full_rccl_step_on_one_device_through_a_periodic_self_halo(pkg, orc, ctx, overlap, monkeypatch):
+    """The complete library-driven step of the row-partitioned CG over REAL RCCL on one GPU: a grid that is periodic in z, cut
+    into ONE slab, is its own neighbour -- the halo of the bottom / top planes is ncclSend / ncclRecv to the rank itself on the
+    side stream, overlapped with the interior row-blocks, followed by the two ncclAllGather; every call mik_cgd_iterate_many makes
+    at P = 8 is made here.  Bit-identical to the single-GPU iterable on the same periodic operator."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("MIK_DIST_OVERLAP", "1" if overlap else "0")
+    d = dist_mod(pkg)
+    N, NZ = 16, 12
+    n, plane = N * N * NZ, N * N
+    _, ptr, idx, val = d._laplace_rows(pkg, N, NZ, 0, n, np.float64)
+    S = sp.csr_matrix((val, idx, ptr), shape=(n, n)).tolil()
+    for j in range(plane):                                   # periodic wrap in z
+        S[j, j + plane * (NZ - 1)] = -1.0
+        S[j + plane * (NZ - 1), j] = -1.0
+    S = S.tocsr()
+    S.sort_indices()
+    # local block of the only rank: the wrap entries become halo columns (global order of a row's entries is kept)
+    gi = S.indices.astype(np.int64)
+    rows = np.repeat(np.arange(n), np.diff(S.indptr))
+    wrap = np.abs(gi - rows) == plane * (NZ - 1)
+    ghost_gids = np.unique(gi[wrap])
+    li = gi.copy()
+    li[wrap] = n + np.searchsorted(ghost_gids, gi[wrap])
+    plan = d.HaloPlan(0, 1, n, ghost_gids)
+    plan.recv = [(0, 0, int(ghost_gids.size))]
+    plan.send = [(0, 0, int(ghost_gids.size))]
+    plan.send_idx = ghost_gids.astype(np.int32)
+    b = orc.hashed_rhs(n)
+    eng = d.HipEngine(pkg, S.indptr.astype(np.int64), li, S.data.copy(), plan, b, abstol=0.0, reltol=1e-9, maxiter=10 ** 6)
+    assert eng.overlap == overlap
+    nc = d.NativeComm(pkg, eng.ctx, d.SelfComm(), force_rccl=True)
+    it = d.NativeDistCGIterable(pkg, eng, nc, maxiter=10 ** 6)
+    hist, iteration = [], 0
+    while True:
+        h = it.iterate_many(iteration, 1 if iteration < 4 else 17)
+        if h.size == 0:
+            break
+        hist.append(h)
+        iteration += h.size
+    hist = np.concatenate(hist)
+    C = S.tocsc()
+    C.sort_indices()
+    x, ch = pkg.cg(pkg.HipCSR(n, n, C.indptr.astype(np.int64), C.indices.astype(np.int64), C.data, index_base=0), pkg.HipVector.from_numpy(b),
+                   reltol=1e-9, log=True)
+    assert ch.isconverged and np.array_equal(hist, ch["resnorm"]) and np.array_equal(eng.solution(), x.to_numpy())
+    eng.close()
+    nc.close()
