@@ -234,6 +234,35 @@ extern "C" int mik_cgd_set_halo_plan(mik_cgd *it, int n_recv, const int *recv_pe
             return mik_fail(ctx, MIK_ERR_INVALID, "mik_cgd_set_halo_plan: send segment %d out of range", i);
         it->send.push_back({send_peer[i], send_off[i], send_cnt[i]});
     }
+    // Do the rows the neighbours need form at most two contiguous runs (the bottom and top planes of a slab)?  Then the step
+    // updates and packs them first and puts the halo on the wire before the bulk of the sweep over u (cgd_enqueue_head).
+    it->n_early = 0;
+    it->early_merged = false;
+    if (it->n_send > 0 && it->n_send <= (1 << 26) && g_mik_tuning[24] == 0) {       // development knob 24: 1 = halo after the whole sweep
+        std::vector<int> idx((size_t)it->n_send);
+        if (hipMemcpy(idx.data(), it->send_idx, sizeof(int) * idx.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+            std::vector<int> srt(idx);
+            std::sort(srt.begin(), srt.end());
+            srt.erase(std::unique(srt.begin(), srt.end()), srt.end());
+            int runs = 0;
+            int64_t a[2] = {0, 0}, b[2] = {0, 0};
+            bool ok = !srt.empty() && srt.front() >= 0 && (int64_t)srt.back() < it->base.n;
+            for (size_t q = 0; ok && q < srt.size();) {
+                size_t e = q + 1;
+                while (e < srt.size() && srt[e] == srt[e - 1] + 1) ++e;
+                if (runs == 2) { ok = false; break; }
+                a[runs] = srt[q]; b[runs] = (int64_t)srt[e - 1] + 1; ++runs;
+                q = e;
+            }
+            if (ok && runs > 0 && (b[0] - a[0]) + (b[1] - a[1]) <= it->base.n / 4) {
+                it->n_early = runs;
+                it->early_merged = (int64_t)srt.size() == it->n_send;      // no index sent twice
+                for (int q = 0; q < 2; ++q) { it->early_a[q] = a[q]; it->early_b[q] = b[q]; }
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     return MIK_OK;
 }
 
@@ -320,9 +349,16 @@ extern "C" int mik_cgd_init(mik_cgd *it, double *residual, double *tol)
 // takes the same decision (same iteration counts, identical stopping scalars), so the RCCL call sequences stay aligned.
 static int cgd_enqueue_head(mik_cgd *it, int64_t iteration)
 {
-    MIK_TRY(mik_cgd_phase(it, 0, iteration));                       // u = r + beta u; pack the halo
+    const bool early = it->n_early > 0 && it->comm && it->comm->nccl && !(it->recv.empty() && it->send.empty());
     bool pending = false;
-    MIK_TRY(rccl_halo_begin(it, &pending));
+    if (early) {
+        MIK_TRY(mik_cgd_phase(it, it->early_merged ? 9 : 7, iteration));   // u on the rows the neighbours need; pack
+        MIK_TRY(rccl_halo_begin(it, &pending));                     // the halo leaves now ...
+        MIK_TRY(mik_cgd_phase(it, 8, iteration));                   // ... and travels during the bulk of the sweep over u
+    } else {
+        MIK_TRY(mik_cgd_phase(it, 0, iteration));                   // u = r + beta u; pack the halo
+        MIK_TRY(rccl_halo_begin(it, &pending));
+    }
     if (pending && it->int_end > it->int_begin) {
         MIK_TRY(mik_cgd_phase(it, 4, iteration));                   // interior row-blocks while the halo is in flight
         MIK_TRY(rccl_halo_end(it, pending));

@@ -1084,9 +1084,34 @@ int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_
 }
 
 // Row-blocks [rb_begin, rb_begin + rb_count) only (rb_count < 0: all).  Partial ranges need mik_spmv_can_split.
+// rows OUTSIDE the row-blocks [skip_begin, skip_end): one launch for the slice-constant layout's buffer kernel, else two ranges
+template <typename T>
+static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done, int rb_begin, int rb_count,
+                            int skip_at, int skip_len);
+
 template <typename T>
 int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done, int rb_begin,
                           int rb_count)
+{
+    return spmv_launch_impl<T>(ctx, A, x, y, fuse_dot, seg_out, done, rb_begin, rb_count, 0x7fffffff, 0);
+}
+
+template <typename T>
+int mik_spmv_launch_outside(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done, int skip_begin, int skip_end)
+{
+    const int nb_all = (int)mik_spmv_nwg(A->n_rows);
+    if (skip_begin < 0 || skip_end < skip_begin || skip_end > nb_all) return mik_fail(ctx, MIK_ERR_INVALID, "SpMV: bad interior range");
+    if (spmv_kernel_choice(A) == 5 && A->sdia_buf_ok && g_mik_tuning[17] == 0 && skip_begin + (nb_all - skip_end) > 0)
+        return spmv_launch_impl<T>(ctx, A, x, y, fuse_dot, seg_out, done, 0, skip_begin + (nb_all - skip_end), skip_begin, skip_end - skip_begin);
+    MIK_TRY(mik_spmv_launch_range<T>(ctx, A, x, y, fuse_dot, seg_out, done, 0, skip_begin));
+    return mik_spmv_launch_range<T>(ctx, A, x, y, fuse_dot, seg_out, done, skip_end, nb_all - skip_end);
+}
+template int mik_spmv_launch_outside<double>(mik_ctx *, const mik_csr *, const double *, double *, bool, double *, const int *, int, int);
+template int mik_spmv_launch_outside<float>(mik_ctx *, const mik_csr *, const float *, float *, bool, float *, const int *, int, int);
+
+template <typename T>
+static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done, int rb_begin, int rb_count,
+                            int skip_at, int skip_len)
 {
     const int n = (int)A->n_rows;
     if (n == 0) return MIK_OK;
@@ -1104,6 +1129,7 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
     const bool wide = g_mik_tuning[1] == 0;
     int map_mode = g_mik_tuning[2] == 0 ? A->strip : std::max(g_mik_tuning[2], 0);
     if (!whole && map_mode >= 8 && (rb0 % map_mode != 0 || nb % map_mode != 0)) map_mode = 0;   // strips need whole planes
+    if (skip_len > 0) map_mode = 0;
     const int choice = spmv_kernel_choice(A);
     if (choice == 3) {
         // dictionary-coded operator (mik_csr_pack): 2 B per entry instead of 12, same arithmetic
@@ -1129,7 +1155,7 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
             }
 #define MIK_SDIAB_GO4(FD, NTV, GG, C)                                                                                                      \
     hipLaunchKernelGGL((k_spmv_sdiab<T, FD, NTV, GG, mik_sdiab_cls_ns(C), mik_sdiab_cls_cq(C)>), dim3(wgs), dim3(MIK_BLOCK), 0, ctx->stream, n, A->sdia_koff, \
-                       rb0, nb, nfull, sshift, (const SdiaSliceRec *)A->sdia_recs, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done)
+                       rb0, nb, nfull, sshift, skip_at, skip_len, (const SdiaSliceRec *)A->sdia_recs, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done)
 #define MIK_SDIAB_GO3(FD, NTV, GG)                                                                                                          \
     do { if (cls == 1) MIK_SDIAB_GO4(FD, NTV, GG, 1); else if (cls == 2) MIK_SDIAB_GO4(FD, NTV, GG, 2); else if (cls == 3) MIK_SDIAB_GO4(FD, NTV, GG, 3); \
          else MIK_SDIAB_GO4(FD, NTV, GG, 0); } while (0)

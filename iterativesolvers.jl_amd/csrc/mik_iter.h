@@ -75,5 +75,10 @@ struct mik_cgd {
     std::vector<HaloSeg> recv, send;      // offsets into the ghost tail of u_ext / into send_buf, in elements
     mik_comm *comm = nullptr;
     bool initialised = false;             // mik_cgd_init ran
+    // rows the neighbours need (send_idx) as at most two contiguous runs [a, b): when they are, u is updated there FIRST, packed and
+    // put on the wire before the bulk of the u = r + beta u sweep runs (mik_cgd_set_halo_plan decides; n_early = 0: not applicable)
+    int n_early = 0;
+    bool early_merged = false;            // every send index occurs once: update + pack are one launch (k_cgd_early)
+    int64_t early_a[2] = {0, 0}, early_b[2] = {0, 0};
 };
 

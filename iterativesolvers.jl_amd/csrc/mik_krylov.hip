@@ -19,6 +19,8 @@ int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_
 template <typename T>
 int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done, int rb_begin,
                           int rb_count);
+template <typename T>
+int mik_spmv_launch_outside(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done, int skip_begin, int skip_end);
 bool mik_spmv_can_split(const mik_csr *A);
 
 
@@ -1648,6 +1650,23 @@ __global__ void k_gather(int64_t m, const int *__restrict__ idx, const T *__rest
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) out[i] = x[idx[i]];
 }
 
+// The rows the neighbours need, updated and packed in ONE launch (every send index occurs once): u = r + beta u (and the
+// pending x update) exactly as OpXpbyX::apply does it, then the new u straight into the send buffer.
+template <typename T>
+__global__ __launch_bounds__(MIK_BLOCK) void k_cgd_early(int64_t m, const int *__restrict__ idx, const T *__restrict__ r, T *__restrict__ u, T *__restrict__ x,
+                                                         const T *__restrict__ beta, const T *__restrict__ alpha, const int *__restrict__ done,
+                                                         const int *__restrict__ pending, int fuse_x, T *__restrict__ out)
+{
+    const int dn = *done, pd = fuse_x ? *pending : 0;
+    for (int64_t j = (int64_t)blockIdx.x * MIK_BLOCK + threadIdx.x; j < m; j += (int64_t)gridDim.x * MIK_BLOCK) {
+        const int i = idx[j];
+        T uo = u[i];
+        if (pd) { T t = *alpha * uo; x[i] = x[i] + t; }
+        if (!dn) { T t = *beta * uo; uo = r[i] + t; u[i] = uo; }
+        out[j] = uo;
+    }
+}
+
 template <typename T> static int gather_launch(mik_ctx *ctx, int64_t m, const int *idx, const T *x, T *out, const int *done)
 {
     if (m <= 0) return MIK_OK;
@@ -1860,6 +1879,43 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
         }
         return gather_launch<T>(ctx, it->n_send, it->send_idx, u, (T *)it->send_buf, done);
     }
+    case 7:    // step A, early part: u (and the pending x update) on the rows the neighbours need, then pack -- the halo leaves first
+    case 8: {  // step A, bulk: the same sweep on all other rows, while the halo is on the wire
+        if (it->n_early <= 0) return mik_fail(ctx, MIK_ERR_INVALID, "mik_cgd_phase: no early rows (mik_cgd_set_halo_plan)");
+        int64_t lo[3], hi[3];
+        int nr = 0;
+        if (phase == 7) {
+            for (int q = 0; q < it->n_early; ++q) { lo[nr] = it->early_a[q]; hi[nr] = it->early_b[q]; ++nr; }
+        } else {
+            int64_t at = 0;
+            for (int q = 0; q < it->n_early; ++q) {
+                if (it->early_a[q] > at) { lo[nr] = at; hi[nr] = it->early_a[q]; ++nr; }
+                at = it->early_b[q];
+            }
+            if (at < n) { lo[nr] = at; hi[nr] = n; ++nr; }
+        }
+        for (int q = 0; q < nr; ++q) {
+            const int64_t o = lo[q], len = hi[q] - lo[q];
+            const bool v2 = vec && (o % VT<T>::W == 0);
+            if (bs.fuse_x) {
+                OpXpbyX<T> op{r + o, u + o, x + o, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(true) & 15};
+                MIK_TRY((launch_map<T>(ctx, len, op, v2, (T *)nullptr, (const int *)nullptr)));
+            } else {
+                OpXpby<T> op{r + o, u + o, coef_ptr<T>(&d->beta), cg_stream_hints() & 7};
+                MIK_TRY((launch_map<T>(ctx, len, op, v2, (T *)nullptr, done)));
+            }
+        }
+        if (phase == 7) return gather_launch<T>(ctx, it->n_send, it->send_idx, u, (T *)it->send_buf, done);
+        return MIK_OK;
+    }
+    case 9: {  // step A, early part as one launch (every send index occurs once: mik_cgd_set_halo_plan)
+        if (it->n_early <= 0 || !it->early_merged) return mik_fail(ctx, MIK_ERR_INVALID, "mik_cgd_phase: no merged early part");
+        const int grid = (int)std::min<int64_t>((it->n_send + MIK_BLOCK - 1) / MIK_BLOCK, MIK_MAX_GRID);
+        hipLaunchKernelGGL((k_cgd_early<T>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, it->n_send, it->send_idx, (const T *)r, u, x, (const T *)&d->beta,
+                           (const T *)&d->alpha, done, (const int *)&d->x_pending, bs.fuse_x ? 1 : 0, (T *)it->send_buf);
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    }
     case 6: {  // the x update that is still due when no head follows (end of a call without look-ahead)
         OpXFlush<T> op{u, x, coef_ptr<T>(&d->alpha), &d->x_pending};
         MIK_TRY((launch_map<T>(ctx, n, op, mik_aligned16(x) && mik_aligned16(u), (T *)nullptr, (const int *)nullptr)));
@@ -1876,8 +1932,7 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
         if (it->int_end <= it->int_begin) return mik_fail(ctx, MIK_ERR_INVALID, "mik_cgd_phase: no interior range set (mik_cgd_set_interior)");
         return mik_spmv_launch_range<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done, (int)it->int_begin, (int)(it->int_end - it->int_begin));
     case 5:    // step B2: the row-blocks before and after the interior range, then the local dot(u, c) as in step B
-        MIK_TRY(mik_spmv_launch_range<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done, 0, (int)it->int_begin));
-        MIK_TRY(mik_spmv_launch_range<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done, (int)it->int_end, (int)(nb - it->int_end)));
+        MIK_TRY(mik_spmv_launch_outside<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done, (int)it->int_begin, (int)it->int_end));
         hipLaunchKernelGGL((k_cgd_fin_slot<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)bs.seg_spmv, nb, dot_slot, done, (FinScratch<T> *)bs.fin);
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;

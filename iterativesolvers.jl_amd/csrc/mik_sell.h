@@ -406,7 +406,7 @@ __host__ __device__ constexpr int mik_sdiab_cls_ns(int c) { return c == 1 ? 7 : 
 __host__ __device__ constexpr int mik_sdiab_cls_cq(int c) { return c == 1 ? 3 : c == 2 ? 2 : c == 3 ? 1 : -1; }
 
 template <typename T, bool FUSE_DOT, bool NT, int G, int NS, int CQ>
-__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab(int n, int koff, int rb0, int nb, int nfull, int sshift, const SdiaSliceRec *__restrict__ recs,
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab(int n, int koff, int rb0, int nb, int nfull, int sshift, int skip_at, int skip_len, const SdiaSliceRec *__restrict__ recs,
                                                           const SdiaPattern<T> *__restrict__ pats, const unsigned char *__restrict__ mask,
                                                           const T *__restrict__ x, T *__restrict__ y, T *__restrict__ seg_out,
                                                           const int *__restrict__ done)
@@ -428,6 +428,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab(int n, int koff, int r
     for (int g = 0; g < G; ++g) {                       // virtual blocks blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8)
         const int vb = min((int)blockIdx.x + g * (int)gridDim.x, nb - 1);   // past the end: the last block once more (same bits)
         rb[g] = rb0 + spmv_block_map_shift(vb, nfull, sshift);
+        if (rb[g] >= skip_at) rb[g] += skip_len;        // a launch over the row-blocks OUTSIDE [skip_at, skip_at + skip_len): the boundary rows of a rank
         rr[g] = rb[g] * MIK_BLOCK + t;
         // (the masks are read with the default cache policy: 1 B per row stays in the Infinity Cache from one SpMV to the next;
         //  streamed past the caches they cost the launch 14 us)

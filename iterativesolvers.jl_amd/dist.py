@@ -880,6 +880,47 @@ def _laplace_rows(pkg, N, NZ, r0, r1, dtype):
     return N * N * NZ, ptr, idx[mask], np.ascontiguousarray(val[mask])
 
 
+def build_self_halo_problem(pkg, N: int, NZ: int, device, dtype=np.float64):
+    """ONE slab of an N x N x NZ grid that is periodic in z: the rank is its own lower and upper neighbour, so its halo
+    (bottom and top planes, 2 N^2 entries) is exchanged with itself -- over RCCL when the native transport is used.  A
+    single-GPU box then runs and times every call of the P-rank step (development / measurement aid: ``MIK_DIST_SELF_HALO=1``).
+    Returns what build_rank_problem returns."""
+    import torch
+    dev = torch.device("cuda", device) if isinstance(device, int) else device
+    tdt = {np.dtype(np.float64): torch.float64, np.dtype(np.float32): torch.float32}[np.dtype(dtype)]
+    n, plane = N * N * NZ, N * N
+    j = torch.arange(n, dtype=torch.int64, device=dev)
+    big = torch.iinfo(torch.int64).max
+    cols, vals = [], []
+    for stride, ext, periodic in ((1, N, False), (N, N, False), (plane, NZ, True)):
+        c = torch.div(j, stride, rounding_mode="floor") % ext
+        lo = torch.where(c > 0, j - stride, j + stride * (ext - 1) if periodic else torch.full_like(j, big))
+        hi = torch.where(c < ext - 1, j + stride, j - stride * (ext - 1) if periodic else torch.full_like(j, big))
+        cols += [lo, hi]
+        vals += [-1.0, -1.0]
+    cols.append(j)
+    vals.append(6.0)
+    idx = torch.stack(cols, dim=1)
+    val = torch.tensor(vals, dtype=tdt, device=dev).expand(idx.shape)
+    idx, order = torch.sort(idx, dim=1)                       # a row's entries in ascending global column, absent ones last
+    val = torch.gather(val, 1, order)
+    mask = idx != big
+    ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(mask.sum(dim=1), dim=0, out=ptr[1:])
+    rows = j.unsqueeze(1).expand(idx.shape)[mask]
+    gi, gv = idx[mask].contiguous(), val[mask].contiguous()
+    wrap = (gi - rows).abs() == plane * (NZ - 1)              # the periodic neighbours: served through the halo
+    ghost = torch.unique(gi[wrap])
+    li = torch.where(wrap, n + torch.searchsorted(ghost, gi), gi).contiguous()
+    ghost_gids = ghost.cpu().numpy()
+    plan = HaloPlan(0, 1, n, ghost_gids)
+    plan.recv = [(0, 0, int(ghost_gids.size))]
+    plan.send = [(0, 0, int(ghost_gids.size))]
+    plan.send_idx = ghost_gids.astype(np.int32)
+    b_loc = pkg.fixtures.hashed_rhs(n, 0, n, dtype)
+    return ptr, li, gv, plan, b_loc, n, np.array([0, n], np.int64)
+
+
 def _laplace_rows_torch(N, NZ, r0, r1, dtype, device):
     """_laplace_rows on the GPU (torch tensors): the rank's slab never exists on the host."""
     import torch
@@ -965,13 +1006,17 @@ def bench_main(args):
         N, nz = 512, 64                                      # configs[3]: 512 x 512 x 64 P (P = 8: 512^3)
     t_up = time.perf_counter()
     on_host = os.environ.get("MIK_DIST_HOST_BUILD", "0") == "1"           # development: the numpy generator + host arrays
-    ptr, local_idx, val, plan, b_loc, n, offsets = build_rank_problem(pkg, boot, N, nz_per_rank=nz, device=None if on_host else local_rank)
+    self_halo = world == 1 and os.environ.get("MIK_DIST_SELF_HALO", "0") == "1"      # z-periodic slab: the rank exchanges its halo with itself
+    if self_halo:
+        ptr, local_idx, val, plan, b_loc, n, offsets = build_self_halo_problem(pkg, N, nz, local_rank)
+    else:
+        ptr, local_idx, val, plan, b_loc, n, offsets = build_rank_problem(pkg, boot, N, nz_per_rank=nz, device=None if on_host else local_rank)
     nnz_loc = int(val.numel() if hasattr(val, "numel") else val.size)
     eng = HipEngine(pkg, ptr, local_idx, val, plan, b_loc, abstol=0.0, reltol=0.0, maxiter=10 ** 9, device=local_rank)
     upload_seconds = time.perf_counter() - t_up
     del ptr, local_idx, val
     if transport == "native":
-        ncomm = NativeComm(pkg, eng.ctx, boot, force_rccl=os.environ.get("MIK_DIST_FORCE_COLLECTIVES", "0") == "1")
+        ncomm = NativeComm(pkg, eng.ctx, boot, force_rccl=self_halo or os.environ.get("MIK_DIST_FORCE_COLLECTIVES", "0") == "1")
         it = NativeDistCGIterable(pkg, eng, ncomm, maxiter=10 ** 9)
         uses_rccl = ncomm.uses_rccl()
     else:
@@ -1035,7 +1080,8 @@ def bench_main(args):
             "config": {"workload": f"cg! on the {N}x{N}x{nz * world} 3D 7-point Laplacian row-partitioned into {world} z-slab(s) of {N}x{N}x{nz} rows"
                                    + (" (BASELINE.json configs[3]: the 512^3 grid on 8 GPUs)" if (N, nz, world) == (512, 64, 8) else
                                       " (BASELINE.json configs[3] layout, weak-scaled: 16.7 M rows per GPU)" if world > 1 else
-                                      " (BASELINE.json configs[1] through the row-partitioned code path)"),
+                                      " (BASELINE.json configs[1] through the row-partitioned code path)")
+                                   + (" -- z-PERIODIC variant: the slab exchanges its 2 N^2 halo entries with itself over RCCL (MIK_DIST_SELF_HALO)" if self_halo else ""),
                        "n": int(n), "n_per_gpu": plan.n_loc, "nnz_per_gpu": nnz_loc, "halo_doubles_received_per_rank": halo,
                        "host_sync_per_step": 1, "timed_regions": len(times), "timed_seconds_total": float(sum(times)),
                        "transport": ("RCCL inside libmik.so (mik_cgd_iterate_many: ncclSend/ncclRecv halo on a side stream overlapped with the "
