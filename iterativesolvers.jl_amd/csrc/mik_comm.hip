@@ -278,7 +278,26 @@ extern "C" int mik_cgd_set_comm(mik_cgd *it, mik_comm *cm)
 
 // The halo of u (or of x during init) over RCCL: issued on the side stream after the pack kernel; *pending = true if
 // the compute stream still has to wait for ev_halo.
+// rccl_halo_begin = rccl_halo_mark ("the send buffer is packed": an event on the compute stream) + rccl_halo_issue (the side
+// stream waits for that event, then the RCCL group).  Split so that the compute-stream work that overlaps the exchange can be
+// enqueued BEFORE the host spends its tens of microseconds inside the RCCL calls.
+static int rccl_halo_mark(mik_cgd *it)
+{
+    mik_comm *cm = it->comm;
+    if (!cm || !cm->nccl || (it->recv.empty() && it->send.empty())) return MIK_OK;
+    MIK_HIP(it->base.ctx, hipEventRecord(cm->ev_packed, it->base.ctx->stream));
+    return MIK_OK;
+}
+
+static int rccl_halo_issue(mik_cgd *it, bool *pending);
+
 static int rccl_halo_begin(mik_cgd *it, bool *pending)
+{
+    MIK_TRY(rccl_halo_mark(it));
+    return rccl_halo_issue(it, pending);
+}
+
+static int rccl_halo_issue(mik_cgd *it, bool *pending)
 {
     *pending = false;
     mik_comm *cm = it->comm;
@@ -288,7 +307,6 @@ static int rccl_halo_begin(mik_cgd *it, bool *pending)
     const size_t es = mik_dtype_size(it->base.dtype);
     const int nt = it->base.dtype == MIK_F64 ? NCCL_F64 : NCCL_F32;
     unsigned char *ghost = (unsigned char *)it->u_ext + es * (size_t)it->base.n;
-    MIK_HIP(ctx, hipEventRecord(cm->ev_packed, ctx->stream));
     MIK_HIP(ctx, hipStreamWaitEvent(cm->side, cm->ev_packed, 0));
     MIK_NCCL(ctx, R->GroupStart());
     for (const auto &sg : it->recv) MIK_NCCL(ctx, R->Recv(ghost + es * (size_t)sg.off, (size_t)sg.cnt, nt, sg.peer, cm->nccl, cm->side));
@@ -353,8 +371,16 @@ static int cgd_enqueue_head(mik_cgd *it, int64_t iteration)
     bool pending = false;
     if (early) {
         MIK_TRY(mik_cgd_phase(it, it->early_merged ? 9 : 7, iteration));   // u on the rows the neighbours need; pack
-        MIK_TRY(rccl_halo_begin(it, &pending));                     // the halo leaves now ...
-        MIK_TRY(mik_cgd_phase(it, 8, iteration));                   // ... and travels during the bulk of the sweep over u
+        MIK_TRY(rccl_halo_mark(it));
+        MIK_TRY(mik_cgd_phase(it, 8, iteration));                   // the bulk of the sweep over u ...
+        if (it->int_end > it->int_begin) {
+            MIK_TRY(mik_cgd_phase(it, 4, iteration));               // ... and the interior row-blocks are on the compute stream
+            MIK_TRY(rccl_halo_issue(it, &pending));                 // before the host enters RCCL: the halo travels underneath them
+            MIK_TRY(rccl_halo_end(it, pending));
+            MIK_TRY(mik_cgd_phase(it, 5, iteration));               // boundary row-blocks + local dot(u, c)
+            return rccl_gather_scalar(it, it->dot_all);
+        }
+        MIK_TRY(rccl_halo_issue(it, &pending));
     } else {
         MIK_TRY(mik_cgd_phase(it, 0, iteration));                   // u = r + beta u; pack the halo
         MIK_TRY(rccl_halo_begin(it, &pending));
