@@ -20,6 +20,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
+import sys
 import time
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
@@ -498,9 +499,16 @@ class NativeComm:
         ident = None
         if self.size > 1 or force_rccl:
             buf = C.create_string_buffer(128)
-            if self.rank == 0:
-                pkg._lib.check(self.L.mik_comm_unique_id(buf), "mik_comm_unique_id")
-            ident = bootstrap.all_gather_objects(bytes(buf.raw))[0]
+            payload = bytes(buf.raw)
+            if self.rank == 0:                        # a failure on rank 0 is told to everybody instead of leaving them in the gather
+                try:
+                    pkg._lib.check(self.L.mik_comm_unique_id(buf), "mik_comm_unique_id")
+                    payload = bytes(buf.raw)
+                except Exception as exc:              # noqa: BLE001
+                    payload = f"mik_comm_unique_id failed: {exc}"
+            ident = bootstrap.all_gather_objects(payload)[0]
+            if isinstance(ident, str):
+                raise RuntimeError(ident)
         h = _vp()
         pkg._lib.check(self.L.mik_comm_create(ctx.handle, ident, self.rank, self.size, C.byref(h)), "mik_comm_create", ctx.handle)
         self.handle = h
@@ -1016,7 +1024,21 @@ def bench_main(args):
     upload_seconds = time.perf_counter() - t_up
     del ptr, local_idx, val
     if transport == "native":
-        ncomm = NativeComm(pkg, eng.ctx, boot, force_rccl=self_halo or os.environ.get("MIK_DIST_FORCE_COLLECTIVES", "0") == "1")
+        # if the library cannot bring its RCCL communicator up on ANY rank (every rank learns of it), all ranks fall back to the
+        # Python-driven phases over the bootstrap group -- slower (host-staged over gloo), but the run still measures the solver
+        ncomm, failure = None, None
+        try:
+            ncomm = NativeComm(pkg, eng.ctx, boot, force_rccl=self_halo or os.environ.get("MIK_DIST_FORCE_COLLECTIVES", "0") == "1")
+        except Exception as exc:       # noqa: BLE001
+            failure = f"{type(exc).__name__}: {exc}"
+        failures = [f for f in boot.all_gather_objects(failure) if f]
+        if failures:
+            if rank == 0:
+                print(f"bench.py: native RCCL transport unavailable ({failures[0]}); falling back to the Python-driven transport", file=sys.stderr)
+            if ncomm is not None:
+                ncomm.close()
+            transport = "torch (fallback)"
+    if transport == "native":
         it = NativeDistCGIterable(pkg, eng, ncomm, maxiter=10 ** 9)
         uses_rccl = ncomm.uses_rccl()
     else:
