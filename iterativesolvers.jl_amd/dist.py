@@ -1012,6 +1012,8 @@ def bench_main(args):
         N, nz = 256, 256                                     # configs[1] through the partitioned code path
     else:
         N, nz = 512, 64                                      # configs[3]: 512 x 512 x 64 P (P = 8: 512^3)
+    if "MIK_DIST_NZ" in os.environ:                      # development: planes per rank (e.g. --grid 512 with 64 planes = one rank's slab of configs[3])
+        nz = int(os.environ["MIK_DIST_NZ"])
     t_up = time.perf_counter()
     on_host = os.environ.get("MIK_DIST_HOST_BUILD", "0") == "1"           # development: the numpy generator + host arrays
     self_halo = world == 1 and os.environ.get("MIK_DIST_SELF_HALO", "0") == "1"      # z-periodic slab: the rank exchanges its halo with itself
