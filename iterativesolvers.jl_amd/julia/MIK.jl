@@ -195,6 +195,34 @@ function HipCSR(A::SparseMatrixCSC{T, Int64}, ctx::Context = context()) where {T
     finalizer(o -> alive(o.ctx) && ccall((:mik_csr_destroy, libmik), Cint, (Ptr{Cvoid},), o.handle), op)
     op
 end
+"""
+The same upload from arrays that already live in DEVICE memory -- the colPtr / rowVal / nzVal buffers of an AMDGPU.jl
+ROCSparseMatrixCSC, passed as raw device pointers: mik_csr_create detects the placement and starts its device-side pipeline
+from them (no host copy).  The arrays are only read during the call.
+"""
+function HipCSR(::Type{T}, m::Integer, n::Integer, nz::Integer, colptr::Ptr{Int64}, rowval::Ptr{Int64}, nzval::Ptr{Cvoid},
+                ctx::Context = context()) where {T<:MikFloat}
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:mik_csr_create, libmik), Cint,
+        (Ptr{Cvoid}, Cint, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}, Cint, Cint, Ref{Ptr{Cvoid}}),
+        ctx.handle, dtype_code(T), m, n, nz, colptr, rowval, nzval, 1, 1, h), "mik_csr_create", ctx.handle)
+    op = HipCSR{T}(h[], m, n, ctx)
+    finalizer(o -> alive(o.ctx) && ccall((:mik_csr_destroy, libmik), Cint, (Ptr{Cvoid},), o.handle), op)
+    op
+end
+"Release the CSR arrays of an operator that runs on one of the sliced layouts (mik_csr_compact); false if it needs them."
+function compact!(A::HipCSR)
+    rc = ccall((:mik_csr_compact, libmik), Cint, (Ptr{Cvoid},), A.handle)
+    rc == 5 && return false
+    check(rc, "mik_csr_compact", A.ctx.handle)
+    true
+end
+"Name of the kernel mul!(y, A, x) launches for this operator (mik_spmv_kernel; for profiles)."
+function spmv_kernel(A::HipCSR)
+    buf = zeros(UInt8, 64)
+    check(ccall((:mik_spmv_kernel, libmik), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint), A.handle, buf, 64), "mik_spmv_kernel", A.ctx.handle)
+    unsafe_string(pointer(buf))
+end
 Base.eltype(::HipCSR{T}) where {T} = T
 Base.size(A::HipCSR) = (A.m, A.n)
 Base.size(A::HipCSR, d::Integer) = d == 1 ? A.m : d == 2 ? A.n : 1
