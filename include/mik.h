@@ -391,6 +391,10 @@ int mik_cgd_wait(mik_cgd *it, double *residual, double *tol, int *done, double *
  * send_peer[i] (the packing order of send_idx).  Arrays are copied. */
 int mik_cgd_set_halo_plan(mik_cgd *it, int n_recv, const int *recv_peer, const int64_t *recv_off, const int64_t *recv_cnt,
                           int n_send, const int *send_peer, const int64_t *send_off, const int64_t *send_cnt);
+/* What the plan made of the step: *runs = number of contiguous row runs (0, 1 or 2) that are updated, packed and put on the
+ * wire before the bulk of the u = r + beta u sweep (0: the halo follows the whole sweep), *rows = their total length,
+ * *merged = 1 if update and pack of those rows are one kernel.  Any pointer may be NULL. */
+int mik_cgd_halo_early(const mik_cgd *it, int *runs, int64_t *rows, int *merged);
 
 /* Transport 1 -- RCCL over xGMI, one process per GPU.  librccl is bound at run time (dlopen; a process that already
  * carries RCCL, e.g. PyTorch-ROCm, shares that copy); MIK_ERR_NOTIMPL if it cannot be loaded.  Rank 0 obtains the

@@ -130,6 +130,7 @@ SIGNATURES = {
     "mik_cgd_set_interior": (C.c_int, [_vp, _i64, _i64]),
     "mik_cgd_wait": (C.c_int, [_vp, _f64p, _f64p, _ip, _f64p, _i64, _i64p]),
     "mik_cgd_set_halo_plan": (C.c_int, [_vp, C.c_int, _ip, _i64p, _i64p, C.c_int, _ip, _i64p, _i64p]),
+    "mik_cgd_halo_early": (C.c_int, [_vp, _ip, _i64p, _ip]),
     "mik_comm_unique_id": (C.c_int, [_vp]),
     "mik_comm_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "mik_comm_destroy": (C.c_int, [_vp]),

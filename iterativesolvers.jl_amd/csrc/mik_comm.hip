@@ -266,6 +266,17 @@ extern "C" int mik_cgd_set_halo_plan(mik_cgd *it, int n_recv, const int *recv_pe
     return MIK_OK;
 }
 
+extern "C" int mik_cgd_halo_early(const mik_cgd *it, int *runs, int64_t *rows, int *merged)
+{
+    if (!it) return MIK_ERR_INVALID;
+    int64_t total = 0;
+    for (int q = 0; q < it->n_early; ++q) total += it->early_b[q] - it->early_a[q];
+    if (runs) *runs = it->n_early;
+    if (rows) *rows = total;
+    if (merged) *merged = it->early_merged ? 1 : 0;
+    return MIK_OK;
+}
+
 extern "C" int mik_cgd_set_comm(mik_cgd *it, mik_comm *cm)
 {
     if (!it) return MIK_ERR_INVALID;
@@ -639,13 +650,27 @@ extern "C" int mik_cgd_group_iterate_many(mik_cgd **its, int P, int64_t iteratio
     for (int p = 0; p < P; ++p) if (!its[p]->initialised) return mik_fail(b0.ctx, MIK_ERR_INVALID, "mik_cgd_group_iterate_many: call mik_cgd_group_init first");
     if (max_steps <= 0 || iteration >= b0.maxiter || b0.residual <= b0.tol) return MIK_OK;
     max_steps = std::min<int64_t>(std::min<int64_t>(max_steps, b0.maxiter - iteration), b0.hist_cap);
-    bool split = true;
-    for (int p = 0; p < P; ++p) split = split && its[p]->int_end > its[p]->int_begin;
+    bool split = true, early = true;
+    for (int p = 0; p < P; ++p) {
+        split = split && its[p]->int_end > its[p]->int_begin;
+        early = early && its[p]->n_early > 0;
+        its[p]->base.fuse_x = g_mik_tuning[23] == 0;                // as mik_cgd_iterate_many: x .+= alpha .* u rides on the next sweep over u
+    }
+    early = early && split;
     std::vector<char> pending;
     for (int64_t j = 0; j < max_steps; ++j) {
         const int64_t itn = iteration + j;
-        MIK_TRY(group_all(g, 0, itn));
-        MIK_TRY(group_halo_begin(g, pending));
+        if (early) {                                                // the step structure of cgd_enqueue_head, with peer copies for RCCL
+            for (int p = 0; p < P; ++p) {
+                MIK_HIP(its[p]->base.ctx, hipSetDevice(its[p]->base.ctx->device));
+                MIK_TRY(mik_cgd_phase(its[p], its[p]->early_merged ? 9 : 7, itn));
+            }
+            MIK_TRY(group_halo_begin(g, pending));
+            MIK_TRY(group_all(g, 8, itn));
+        } else {
+            MIK_TRY(group_all(g, 0, itn));
+            MIK_TRY(group_halo_begin(g, pending));
+        }
         if (split) {
             MIK_TRY(group_all(g, 4, itn));
             for (int p = 0; p < P; ++p) MIK_TRY(group_halo_end(g, pending, p));
@@ -659,6 +684,7 @@ extern "C" int mik_cgd_group_iterate_many(mik_cgd **its, int P, int64_t iteratio
         MIK_TRY(group_gather_scalar(g, 1));
         MIK_TRY(group_all(g, 3, itn));
     }
+    if (its[0]->base.fuse_x) MIK_TRY(group_all(g, 6, iteration + max_steps - 1));     // nothing runs ahead here: apply the last x update now
     std::vector<double> h0((size_t)max_steps), hp((size_t)max_steps);
     int64_t n0 = 0;
     for (int p = 0; p < P; ++p) {

@@ -593,6 +593,15 @@ class GroupCG:
     def done(self, iteration):
         return iteration >= self.maxiter or self.residual <= self.tol
 
+    def halo_early(self):
+        """per rank (runs, rows, merged) of ``mik_cgd_halo_early``: the rows a rank updates and packs ahead of the sweep"""
+        out = []
+        for e in self.engines:
+            runs, rows, merged = C.c_int(), C.c_int64(), C.c_int()
+            self.pkg._lib.check(self.L.mik_cgd_halo_early(e.handle, C.byref(runs), C.byref(rows), C.byref(merged)), "mik_cgd_halo_early", e.ctx.handle)
+            out.append((runs.value, rows.value, bool(merged.value)))
+        return out
+
     def iterate_many(self, iteration: int, max_steps: int) -> np.ndarray:
         if max_steps <= 0 or self.done(iteration):
             return np.zeros(0)

@@ -398,6 +398,56 @@ def test_inprocess_group_matches_partitioned_oracle(pkg, orc, ctx, P, with_x0):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("P", [2, 3, 4])
+@pytest.mark.parametrize("knobs", [(), (23,), (24,)])
+def test_inprocess_group_early_halo_step(pkg, orc, ctx, P, knobs):
+    """Tall slabs (48 planes of 8 x 8): the boundary planes of EVERY rank, middle ranks with two runs included, are at most a
+    quarter of its rows, so the group runs the step of cgd_enqueue_head -- boundary planes updated and packed first
+    (phase 9), halo copies, bulk of the sweep (phase 8), interior row-blocks, then the boundary row-blocks in one launch
+    around the interior range (mik_spmv_launch_outside) -- with x .+= alpha .* u riding on the next sweep and the flush at
+    the end of a batch.  Bit-exact against the partition-aware oracle; knob 23 (x updated in the step) and knob 24 (halo
+    after the whole sweep) give the same bits."""
+    d = dist_mod(pkg)
+    N, NZ = 8, 48
+    L = pkg.lib()
+    for k in knobs:
+        L.mik_set_tuning(k, 1)
+    try:
+        shape = ctx.cg_shape(np.float64)
+        x0 = np.random.default_rng(11).standard_normal(N * N * NZ)
+        mk = lambda pp, li, vv, pl, bl, xl: d.HipEngine(pkg, pp, li, vv, pl, bl, xl, abstol=0.0, reltol=1.5e-8, maxiter=10 ** 6)
+        engines, offsets, b = make_engines(pkg, orc, N, NZ, P, mk, x0)
+        grp = d.GroupCG(pkg, engines, maxiter=10 ** 6)
+        early = grp.halo_early()
+        if 24 in knobs:
+            assert all(runs == 0 for runs, _, _ in early)
+        else:
+            want = [1 if p in (0, P - 1) else 2 for p in range(P)]
+            assert [runs for runs, _, _ in early] == want and all(m for _, _, m in early)
+            assert [rows for _, rows, _ in early] == [N * N * w for w in want]
+        hist, iteration = [], 0
+        while True:
+            h = grp.iterate_many(iteration, 1 if iteration < 2 else 7)
+            if h.size == 0:
+                break
+            hist.append(h)
+            iteration += h.size
+            if iteration == 9:                                       # between batches x is complete (the flush of phase 6)
+                xm = grp.solution()
+                assert np.isfinite(xm).all() and not np.array_equal(xm, x0)
+        hist = np.concatenate(hist)
+        xo, ho = oracle_history(orc, pkg, N, NZ, offsets, b, shape, x0)
+        assert hist.size == ho["iters"] and np.array_equal(hist, ho["resnorm"])
+        assert np.array_equal(grp.solution(), xo)
+        grp.close()
+        for e in engines:
+            e.close()
+    finally:
+        for k in knobs:
+            L.mik_set_tuning(k, 0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("force_rccl", [False, True])
 def test_native_comm_world1_equals_single_gpu_path(pkg, orc, ctx, force_rccl):
     """mik_cgd_iterate_many through a mik_comm: a world of one without the library, and a REAL RCCL communicator of one
