@@ -1050,12 +1050,20 @@ static inline bool spmv_csr_rowgather(const mik_csr *A)
     return g_mik_tuning[14] == 2 || (g_mik_tuning[14] == 0 && A->n_long == 0);
 }
 
+// k_spmv_sdiab2 (two rows per lane): the operator's class has the lane-neighbour shape, n is even, and no development
+// knob asks for another form (16: slices per workgroup; 18: no compiled-in class; 19: 1 = one row per lane)
+static bool sdiab2_applies(const mik_csr *A)
+{
+    return A->sdia_buf_ok && A->sdia_cls >= 1 && (A->n_rows & 1) == 0 && g_mik_tuning[16] == 0 && g_mik_tuning[17] == 0 && g_mik_tuning[18] == 0 &&
+           g_mik_tuning[19] == 0;
+}
+
 extern "C" int mik_spmv_kernel(const mik_csr *A, char *name, int len)
 {
     if (!A || !name || len <= 0) return MIK_ERR_INVALID;
     const char *k = "k_spmv_rowblock";
     switch (spmv_kernel_choice(A)) {
-    case 5: k = A->sdia_buf_ok && g_mik_tuning[17] == 0 ? "k_spmv_sdiab" : "k_spmv_sdiac"; break;
+    case 5: k = A->sdia_buf_ok && g_mik_tuning[17] == 0 ? (sdiab2_applies(A) ? "k_spmv_sdiab2" : "k_spmv_sdiab") : "k_spmv_sdiac"; break;
     case 4: k = "k_spmv_sdia"; break;
     case 3: k = "k_spmv_packed"; break;
     case 2: k = "k_spmv_sell8"; break;
@@ -1162,6 +1170,21 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
 #define MIK_SDIAB_GO(FD, NTV)                                                                      \
     do { if (G == 1) MIK_SDIAB_GO4(FD, NTV, 1, 0); else if (G == 4) MIK_SDIAB_GO4(FD, NTV, 4, 0); else MIK_SDIAB_GO3(FD, NTV, 2); } while (0)
             const int cls = g_mik_tuning[18] == 1 ? 0 : A->sdia_cls;            // development knob 18: 1 = slot-by-slot path only
+            if (sdiab2_applies(A) && skip_len == 0 && (rb0 & 1) == 0 && ((nb & 1) == 0 || rb0 + nb == nb_all)) {
+                // two rows per lane, 16-byte gathers (k_spmv_sdiab2): workgroups over PAIRS of slices; strips halve with them
+                const int np = (nb + 1) / 2, pb0 = rb0 / 2, wg2 = (np + 7) / 8 * 8;
+                const int ps = sshift >= 1 ? sshift - 1 : -1, pfull = sshift >= 1 ? nfull / 2 : 0;
+#define MIK_SDIAB2_GO4(FD, NTV, C)                                                                                                       \
+    hipLaunchKernelGGL((k_spmv_sdiab2<T, FD, NTV, mik_sdiab_cls_ns(C), mik_sdiab_cls_cq(C)>), dim3(wg2), dim3(MIK_BLOCK), 0, ctx->stream, n, A->sdia_koff, \
+                       pb0, np, pfull, ps, nb_all, (const SdiaSliceRec *)A->sdia_recs, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done)
+#define MIK_SDIAB2_GO(FD, NTV) do { if (cls == 1) MIK_SDIAB2_GO4(FD, NTV, 1); else if (cls == 2) MIK_SDIAB2_GO4(FD, NTV, 2); else MIK_SDIAB2_GO4(FD, NTV, 3); } while (0)
+                if (fuse_dot) { if (nt) MIK_SDIAB2_GO(true, true); else MIK_SDIAB2_GO(true, false); }
+                else          { if (nt) MIK_SDIAB2_GO(false, true); else MIK_SDIAB2_GO(false, false); }
+#undef MIK_SDIAB2_GO4
+#undef MIK_SDIAB2_GO
+                MIK_LAUNCH_CHECK(ctx);
+                return MIK_OK;
+            }
             if (fuse_dot) { if (nt) MIK_SDIAB_GO(true, true); else MIK_SDIAB_GO(true, false); }
             else          { if (nt) MIK_SDIAB_GO(false, true); else MIK_SDIAB_GO(false, false); }
 #undef MIK_SDIAB_GO4

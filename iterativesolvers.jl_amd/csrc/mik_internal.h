@@ -189,6 +189,23 @@ template <int OFF> __device__ __forceinline__ float lane_down(float v)
     return __builtin_bit_cast(float, lane_down_u32<OFF>(__builtin_bit_cast(unsigned, v)));
 }
 
+// The value of the neighbouring lane across the WHOLE wave (DPP wave_shr:1 / wave_shl:1, GFX9 only): lane l receives lane
+// l - 1 (from_below) or lane l + 1 (from_above); the lane without a neighbour (0 / 63) receives 0 bits.
+template <bool BELOW> __device__ __forceinline__ unsigned lane_next_u32(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, BELOW ? 0x138 : 0x130, 0xf, 0xf, true);
+}
+template <bool BELOW> __device__ __forceinline__ double lane_next(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = lane_next_u32<BELOW>((unsigned)b), hi = lane_next_u32<BELOW>((unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <bool BELOW> __device__ __forceinline__ float lane_next(float v)
+{
+    return __builtin_bit_cast(float, lane_next_u32<BELOW>(__builtin_bit_cast(unsigned, v)));
+}
+
 // wave-64 shuffle-down tree, offsets 32..1; the value in lane 0 is the tree sum
 template <typename T> __device__ __forceinline__ T wave_tree(T v)
 {

@@ -362,9 +362,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiac(int n, int ncols, int 
 template <typename T> __device__ __forceinline__ T buffer_gather(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff);
 template <> __device__ __forceinline__ double buffer_gather<double>(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff)
 {
-    typedef unsigned mik_u32x2 __attribute__((ext_vector_type(2)));
-    const mik_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, soff, 0);
-    return __builtin_bit_cast(double, v);
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, soff, 0));
 }
 template <> __device__ __forceinline__ float buffer_gather<float>(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff)
 {
@@ -440,21 +438,62 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab(int n, int koff, int r
     const SdiaPattern<T> *__restrict__ pt[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) pt[g] = pats + rc[g].pid;
+    // The classes also have the slots around the centre address the row's LANE neighbours (columns row - 1 and row + 1): the
+    // wave then loads x[row] once, range-checked and whatever the masks say, and hands it to the lanes on either side (two DPP
+    // moves per 32 bits); only lanes 0 and 63 fetch their outer neighbour -- 5 full gathers per row of the 3-D stencil, not 7.
+    constexpr bool LN = NS >= 3 && CQ >= 1 && CQ + 1 < NS;
     bool fast = NS > 0;
 #pragma unroll
-    for (int g = 0; g < G; ++g) fast = fast & (rc[g].ns == NS) & (rc[g].cq == CQ);
+    for (int g = 0; g < G; ++g) {
+        fast = fast & (rc[g].ns == NS) & (rc[g].cq == CQ);
+        if (LN) fast = fast & (rc[g].soff[CQ > 0 ? CQ - 1 : 0] + (int)ES == rc[g].soff[CQ >= 0 ? CQ : 0]) & (rc[g].soff[CQ >= 0 ? CQ : 0] + (int)ES == rc[g].soff[CQ + 1 < U ? CQ + 1 : 0]);
+    }
 #pragma unroll
     for (int g = 0; g < G; ++g) asm volatile("" : "+v"(minv[g]));       // all masks have arrived before the first gather is issued
     T acc[G], xr[G];
     if (fast) {
         constexpr int NQ = NS > 0 ? NS : 1, CC = CQ >= 0 ? CQ : 0;
         T xv[G][NQ];
+        if (LN) {
+            const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc((void *)x, (short)0, (int)((unsigned)n * ES), (int)0x00020000);
+            T xc[G], xe[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const unsigned rowoff = (unsigned)rr[g] * ES;
+            for (int g = 0; g < G; ++g) {
+                const unsigned rowoff = (unsigned)rr[g] * ES;
+                xc[g] = buffer_gather<T>(xs, rowoff, 0);                     // a row past the end reads +0
+                xe[g] = T(0);
+                if (lane == 0 || lane == 63) {                               // the neighbour in another wave (or none: out of range, +0)
+                    const unsigned ab = (unsigned)(lane == 0 ? __builtin_amdgcn_sbfe(minv[g], CC - 1, 1) : __builtin_amdgcn_sbfe(minv[g], CC + 1, 1));
+                    xe[g] = buffer_gather<T>(xs, (lane == 0 ? rowoff - ES : rowoff + ES) | ab, 0);
+                }
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                xv[g][q] = buffer_gather<T>(rs, rowoff | (unsigned)__builtin_amdgcn_sbfe(minv[g], q, 1), rc[g].soff[q]);
+                for (int q = 0; q < NQ; ++q)
+                    if (q < CC - 1 || q > CC + 1)
+                        xv[g][q] = buffer_gather<T>(rs, rowoff | (unsigned)__builtin_amdgcn_sbfe(minv[g], q, 1), rc[g].soff[q]);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                T lo = lane_next<true>(xc[g]), hi = lane_next<false>(xc[g]);
+                if (lane == 0) lo = xe[g];
+                if (lane == 63) hi = xe[g];
+                xv[g][CC - 1] = ((minv[g] >> (CC - 1)) & 1) ? T(0) : lo;      // absent slots contribute value * +0, as through the gather
+                xv[g][CC] = ((minv[g] >> CC) & 1) ? T(0) : xc[g];
+                xv[g][CC + 1] = ((minv[g] >> (CC + 1)) & 1) ? T(0) : hi;
+                xr[g] = xc[g];
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const unsigned rowoff = (unsigned)rr[g] * ES;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    xv[g][q] = buffer_gather<T>(rs, rowoff | (unsigned)__builtin_amdgcn_sbfe(minv[g], q, 1), rc[g].soff[q]);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                xr[g] = xv[g][CC];
+                if (FUSE_DOT && !rc[g].dfull && ((minv[g] >> CC) & 1) && rr[g] < n) xr[g] = x[rr[g]];   // a row without a diagonal entry
+            }
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -462,8 +501,6 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab(int n, int koff, int r
 #pragma unroll
             for (int q = 0; q < NQ; ++q) { T pr = pt[g]->val[q] * xv[g][q]; a = a + pr; }
             acc[g] = a;
-            xr[g] = xv[g][CC];
-            if (FUSE_DOT && !rc[g].dfull && ((minv[g] >> CC) & 1) && rr[g] < n) xr[g] = x[rr[g]];   // a row without a diagonal entry
         }
     } else {
 #pragma unroll
@@ -509,6 +546,148 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab(int n, int koff, int r
             for (int g = 1; g < G; ++g)
                 if (t == g) rbt = rb[g];
             seg_out[rbt] = tot;
+        }
+    }
+}
+
+// ---- two consecutive rows per lane ---------------------------------------------------------------------------------------
+// A 64-lane gather is priced per INSTRUCTION on this GPU, not per byte (scripts/micro/gather_width.hip: y = sum of 5 stencil
+// neighbours over 256^3 doubles, 50.8 us with one row per lane and 8-byte loads, 33.9 us -- the copy floor -- with two rows
+// per lane and 16-byte loads).  Here lane l of a wave owns rows 2l and 2l + 1 of a 128-row piece: one 16-byte load per
+// slot serves both rows (their columns are consecutive), the slots around the centre come from the centre load of the lane
+// itself and of its neighbours (DPP), and a 16-byte store writes both sums.  A workgroup covers two consecutive slices (512
+// rows); every wave lies in one slice.  Needs an even n; a wave whose slice is not of the compiled-in class, or in which a
+// row pair differs in the presence of a gathered slot, runs the slot-by-slot path on its two rows.
+// dot(x, y) partials keep the shape of k_spmv_sdiab bit for bit: per 64 rows the shuffle-down tree (row r + 32, + 16, ...
+// + 1) -- rows r and r + 2k sit k lanes apart, rows r and r + 1 in one lane -- so lanes 0..31 and 32..63 each run the five
+// upper levels on both of their values and add the two at the end; then the 4 sums of a slice left to right.
+template <typename T> struct Pair2 { T a, b; };
+template <typename T> __device__ __forceinline__ Pair2<T> buffer_gather2(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff);
+template <> __device__ __forceinline__ Pair2<double> buffer_gather2<double>(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff)
+{
+    return __builtin_bit_cast(Pair2<double>, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0));
+}
+template <> __device__ __forceinline__ Pair2<float> buffer_gather2<float>(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff)
+{
+    // (bit_cast of the builtin's own vector type: converting it to an ext_vector_type first and reading .x / .y gave the
+    //  first dword twice with this compiler)
+    return __builtin_bit_cast(Pair2<float>, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, soff, 0));
+}
+template <typename T> __device__ __forceinline__ void buffer_put2(__amdgpu_buffer_rsrc_t rs, unsigned voff, T a, T b, bool nt);
+template <> __device__ __forceinline__ void buffer_put2<double>(__amdgpu_buffer_rsrc_t rs, unsigned voff, double a, double b, bool nt)
+{
+    typedef unsigned mik_gv4 __attribute__((__vector_size__(16)));         // the builtin's own vector type
+    const Pair2<double> v = {a, b};
+    if (nt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mik_gv4, v), rs, (int)voff, 0, 2);
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mik_gv4, v), rs, (int)voff, 0, 0);
+}
+template <> __device__ __forceinline__ void buffer_put2<float>(__amdgpu_buffer_rsrc_t rs, unsigned voff, float a, float b, bool nt)
+{
+    typedef unsigned mik_gv2 __attribute__((__vector_size__(8)));
+    const Pair2<float> v = {a, b};
+    if (nt) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mik_gv2, v), rs, (int)voff, 0, 2);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mik_gv2, v), rs, (int)voff, 0, 0);
+}
+
+template <typename T, bool FUSE_DOT, bool NT, int NS, int CQ>
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab2(int n, int koff, int pb0, int np, int nfull, int sshift, int nslices,
+                                                           const SdiaSliceRec *__restrict__ recs, const SdiaPattern<T> *__restrict__ pats,
+                                                           const unsigned char *__restrict__ mask, const T *__restrict__ x, T *__restrict__ y,
+                                                           T *__restrict__ seg_out, const int *__restrict__ done)
+{
+    static_assert(NS >= 3 && CQ >= 1 && CQ + 1 < NS, "the class must have slots around the centre");
+    if (done && *done) return;
+    constexpr int U = 8;
+    constexpr unsigned ES = (unsigned)sizeof(T);
+    __shared__ T lds[8];
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((uintptr_t)x - (uintptr_t)koff * ES), (short)0, (int)0xFFFFFFF0u, (int)0x00020000);
+    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc((void *)x, (short)0, (int)((unsigned)n * ES), (int)0x00020000);
+    const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc((void *)mask, (short)0, n, (int)0x00020000);
+    const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc((void *)y, (short)0, (int)((unsigned)n * ES), (int)0x00020000);
+    const int vb = min((int)blockIdx.x, np - 1);                          // past the end: the last pair once more (same bits)
+    const int pb = pb0 + spmv_block_map_shift(vb, nfull, sshift);         // slices 2 pb and 2 pb + 1
+    const int sl = min(2 * pb + (w >> 1), nslices - 1);                   // this wave's slice (a pair may lack its second one)
+    const int r0 = pb * (2 * MIK_BLOCK) + w * 128 + 2 * lane;             // rows r0, r0 + 1 (n is even: both in range or neither)
+    const unsigned rowoff = (unsigned)r0 * ES;
+    // the two mask bytes (temporal: they stay in the Infinity Cache from one SpMV to the next); past the end: 0 = no slot
+    const unsigned m16 = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(ms, r0, 0, 0);
+    int minv0 = ~(int)(m16 & 0xffu), minv1 = ~(int)((m16 >> 8) & 0xffu);
+    const SdiaSliceRec rc = recs[sl];
+    const SdiaPattern<T> *__restrict__ pt = pats + rc.pid;
+    asm volatile("" : "+v"(minv0), "+v"(minv1));
+    // slots other than CQ - 1, CQ, CQ + 1: both rows of every pair must agree on their presence
+    constexpr int NLMASK = ((1 << NS) - 1) & ~(7 << (CQ - 1));
+    const bool mixed = __builtin_amdgcn_ballot_w64(((minv0 ^ minv1) & NLMASK) != 0) != 0;
+    const bool fast = (rc.ns == NS) & (rc.cq == CQ) & (rc.soff[CQ - 1] + (int)ES == rc.soff[CQ]) & (rc.soff[CQ] + (int)ES == rc.soff[CQ + 1]) & !mixed;
+    T acc0, acc1, xr0, xr1;
+    if (fast) {
+        const Pair2<T> xc = buffer_gather2<T>(xs, rowoff, 0);                // x[r0], x[r0 + 1]; a pair past the end reads +0
+        T xe = T(0);
+        if (lane == 0 || lane == 63) {                                     // the outer neighbour of the wave's first / last row
+            const unsigned ab = (unsigned)(lane == 0 ? __builtin_amdgcn_sbfe(minv0, CQ - 1, 1) : __builtin_amdgcn_sbfe(minv1, CQ + 1, 1));
+            xe = buffer_gather<T>(xs, (lane == 0 ? rowoff - ES : rowoff + 2 * ES) | ab, 0);
+        }
+        Pair2<T> xg[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+            if (q < CQ - 1 || q > CQ + 1)
+                xg[q] = buffer_gather2<T>(rs, rowoff | (unsigned)__builtin_amdgcn_sbfe(minv0, q, 1), rc.soff[q]);
+        T below = lane_next<true>(xc.b), above = lane_next<false>(xc.a);   // x[r0 - 1] from the lane below, x[r0 + 2] from the lane above
+        if (lane == 0) below = xe;
+        if (lane == 63) above = xe;
+        // absent slots contribute value * +0, as through the gather
+        xg[CQ - 1] = {((minv0 >> (CQ - 1)) & 1) ? T(0) : below, ((minv1 >> (CQ - 1)) & 1) ? T(0) : xc.a};
+        xg[CQ] = {((minv0 >> CQ) & 1) ? T(0) : xc.a, ((minv1 >> CQ) & 1) ? T(0) : xc.b};
+        xg[CQ + 1] = {((minv0 >> (CQ + 1)) & 1) ? T(0) : xc.b, ((minv1 >> (CQ + 1)) & 1) ? T(0) : above};
+        T a0 = T(0), a1 = T(0);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const T v = pt->val[q];
+            T p0 = v * xg[q].a; a0 = a0 + p0;
+            T p1 = v * xg[q].b; a1 = a1 + p1;
+        }
+        acc0 = a0; acc1 = a1; xr0 = xc.a; xr1 = xc.b;
+    } else {
+        const int ns = rc.ns, cq = rc.cq;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const unsigned ro = rowoff + (unsigned)e * ES;
+            const int mi = e ? minv1 : minv0;
+            T xv[U];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                xv[q] = T(0);
+                if (q < ns) xv[q] = buffer_gather<T>(rs, ro | (unsigned)__builtin_amdgcn_sbfe(mi, q, 1), rc.soff[q]);
+            }
+            T a = T(0), c = T(0);
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                if (q < ns) {
+                    if (q == cq) c = xv[q];
+                    T pr = pt->val[q] * xv[q];
+                    a = a + pr;
+                }
+            }
+            if (FUSE_DOT && r0 + e < n && (cq < 0 || ((mi >> cq) & 1))) c = x[r0 + e];
+            if (e) { acc1 = a; xr1 = c; } else { acc0 = a; xr0 = c; }
+        }
+    }
+    buffer_put2<T>(ys, rowoff, acc0, acc1, NT);
+    if (FUSE_DOT) {
+        T s0 = xr0 * acc0, s1 = xr1 * acc1;                                // a pair past the end: 0 * +0
+        s0 = s0 + lane_down<16>(s0); s1 = s1 + lane_down<16>(s1);
+        s0 = s0 + lane_down<8>(s0);  s1 = s1 + lane_down<8>(s1);
+        s0 = s0 + lane_down<4>(s0);  s1 = s1 + lane_down<4>(s1);
+        s0 = s0 + lane_down<2>(s0);  s1 = s1 + lane_down<2>(s1);
+        s0 = s0 + lane_down<1>(s0);  s1 = s1 + lane_down<1>(s1);
+        const T ws = s0 + s1;                                             // lanes 0 and 32: the sums of rows 0..63 and 64..127 of the wave
+        if ((lane & 31) == 0) lds[2 * w + (lane >> 5)] = ws;
+        __syncthreads();
+        if (t < 2 && 2 * pb + t < nslices) {                              // one partial per slice: its 4 sums left to right
+            T tot = lds[4 * t];
+            tot = tot + lds[4 * t + 1]; tot = tot + lds[4 * t + 2]; tot = tot + lds[4 * t + 3];
+            seg_out[2 * pb + t] = tot;
         }
     }
 }

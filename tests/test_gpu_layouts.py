@@ -168,33 +168,39 @@ def test_slice_constant_values_only_when_the_bits_agree(pkg, orc, ctx, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_slice_constant_kernels_absent_slots_and_missing_diagonals(pkg, orc, ctx, dtype):
-    """k_spmv_sdiab reads 0.0 for a slot a row does not have (buffer range check) and adds value * 0: x entries that are
-    Inf / NaN must only reach the rows that really reference them; rows without a diagonal entry (the fused dot takes x[r]
-    from the centre slot otherwise); an Inf coefficient keeps the flat-load kernel"""
+@pytest.mark.parametrize("n,far", [(1500, 40), (1500, 41), (1501, 40), (1282, 255)])
+def test_slice_constant_kernels_absent_slots_and_missing_diagonals(pkg, orc, ctx, dtype, n, far):
+    """k_spmv_sdiab / k_spmv_sdiab2 read 0.0 for a slot a row does not have (buffer range check) and add value * 0: x entries
+    that are Inf / NaN must only reach the rows that really reference them; rows without a diagonal entry (the fused dot takes
+    x[r] from the centre slot otherwise); an Inf coefficient keeps the flat-load kernel.  The two-rows-per-lane kernel needs an
+    even n (1501: one row per lane) and row pairs that agree on the presence of a gathered slot (far = 41, 255: the pairs at the
+    ends of the far diagonals do not -- those waves run slot by slot); its lane-neighbour slots may be absent in any row."""
     rng = np.random.default_rng(11)
-    n = 1500
-    S = sp.diags([np.full(n - 40, -1.0), np.full(n - 1, -2.0), np.full(n, 5.0), np.full(n - 1, -3.0), np.full(n - 40, -0.5)],
-                 [-40, -1, 0, 1, 40], format="lil")
-    for r in (0, 3, 255, 256, 700, 1499):               # rows without a diagonal entry, also at slice edges
+    S = sp.diags([np.full(n - far, -1.0), np.full(n - 1, -2.0), np.full(n, 5.0), np.full(n - 1, -3.0), np.full(n - far, -0.5)],
+                 [-far, -1, 0, 1, far], format="lil")
+    for r in (0, 3, 255, 256, 700, n - 1):              # rows without a diagonal entry, also at slice edges
         S[r, r] = 0.0
-    for r in (39, 40, 41, 900):                         # rows without one of the other slots
+    for r in (39, 40, 41, 64, 128, 900):                # rows without the slot below the centre, also first in their wave
         S[r, r - 1] = 0.0
+    for r in (63, 127, 500, 501):                       # ... without the slot above it, also last in their wave
+        S[r, r + 1] = 0.0
+    S[700, 700 - far] = 0.0                             # one row of a pair without a far slot
     S = S.tocsc()
     S.eliminate_zeros()
     A = orc.CSC.from_scipy(S).astype(dtype)
     x = rng.standard_normal(n).astype(dtype)
-    x[[0, 38, 255, 256, 899, 1499]] = [np.inf, np.nan, -np.inf, np.nan, np.inf, np.nan]
+    x[[0, 38, 62, 128, 255, 256, 499, 502, 899, n - 1]] = [np.inf, np.nan, np.inf, np.nan, -np.inf, np.nan, np.inf, np.nan, np.inf, np.nan]
     want = orc.spmv(A, x)
     xf = rng.standard_normal(n).astype(dtype)
     b = orc.hashed_rhs(n).astype(dtype)
     ref = None
-    for form, knobs in (("csr-rowblock", {8: 1}), ("best", {}), ("best/flat-loads", {17: 1}), ("best/slot-by-slot", {18: 1}), ("best/4-slices", {16: 4})):
+    for form, knobs in (("csr-rowblock", {8: 1}), ("best", {}), ("best/flat-loads", {17: 1}), ("best/slot-by-slot", {18: 1}), ("best/4-slices", {16: 4}),
+                        ("best/one-row-per-lane", {19: 1})):
         def run():
             dA = upload(pkg, A)
             if form.startswith("best"):
                 assert dA.layout() == "slice-offsets+slice-values+row-masks"
-                assert dA.spmv_kernel() == ("k_spmv_sdiac" if 17 in knobs else "k_spmv_sdiab")
+                assert dA.spmv_kernel() == ("k_spmv_sdiac" if 17 in knobs else "k_spmv_sdiab2" if not knobs and n % 2 == 0 else "k_spmv_sdiab")
             y = pkg.mul_(pkg.HipVector(n, dtype), dA, pkg.HipVector.from_numpy(x)).to_numpy()
             xs, ch = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True, maxiter=4)     # fused dot; only the bits matter
             return y, ch["resnorm"], xs.to_numpy(), pkg.mul_(pkg.HipVector(n, dtype), dA, pkg.HipVector.from_numpy(xf)).to_numpy()

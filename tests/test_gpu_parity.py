@@ -536,7 +536,7 @@ def test_cg_bit_exact_at_128_cubed(pkg, orc, ctx, dtype):
     A = orc.laplace(128, 3).astype(dtype)
     b = orc.hashed_rhs(A.n).astype(dtype)
     dA = upload(pkg, A)
-    assert dA.layout() == "slice-offsets+slice-values+row-masks" and dA.spmv_kernel() == "k_spmv_sdiab"
+    assert dA.layout() == "slice-offsets+slice-values+row-masks" and dA.spmv_kernel() == "k_spmv_sdiab2"
     x, ch = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True, maxiter=40, reltol=0.0)
     xo, ho = orc.cg(A, b, maxiter=40, reltol=0.0, mode="tree", shape=ctx.cg_shape(dtype))
     assert np.array_equal(ch["resnorm"], np.asarray(ho["resnorm"], dtype=np.float64))
