@@ -642,6 +642,14 @@ class CGIterable:
         self._check(lib().mik_cg_fused_x(self.handle, C.byref(out)), "mik_cg_fused_x")
         return bool(out.value)
 
+    def fused_head(self) -> bool:
+        """True if the whole head of a step -- that x update, ``u = r + beta u``, ``c = A u`` and ``dot(u, c)`` -- is ONE
+        sweep (``k_cg_head_sdiab2``; ``mik_cg_fused_x`` reports 2).  The direction then alternates between ``u`` and a
+        library-owned buffer and is back in ``u`` once the iteration has finished."""
+        out = C.c_int()
+        self._check(lib().mik_cg_fused_x(self.handle, C.byref(out)), "mik_cg_fused_x")
+        return out.value == 2
+
     def iterate_many(self, iteration: int, max_steps: int) -> np.ndarray:
         """Up to ``max_steps`` ``iterate`` calls with one host synchronisation; returns the residuals."""
         out = np.empty(max(int(max_steps), 1), np.float64)

@@ -1117,6 +1117,55 @@ int mik_spmv_launch_outside(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
 template int mik_spmv_launch_outside<double>(mik_ctx *, const mik_csr *, const double *, double *, bool, double *, const int *, int, int);
 template int mik_spmv_launch_outside<float>(mik_ctx *, const mik_csr *, const float *, float *, bool, float *, const int *, int, int);
 
+// ---- the head of a plain CG step as one sweep (k_cg_head_sdiab2, mik_sell.h) ------------------------------------------
+// Available where k_spmv_sdiab2 is, and OFF by default: at 256^3 the sweep takes 176-182 us against 101 + 59 us for
+// k_map<OpXpbyX> followed by k_spmv_sdiab2 (it gathers r AND the old u for every neighbour -- 14 loads per 128 rows
+// against 10 -- and reaches 4.5 TB/s on its 49 B per row where the two launches reach 6.7 and 4.9 on theirs; DESIGN.md
+// section 5).  Development knob 25: 1 = use it (read at mik_cg_create); knob 26: cache-hint bits of the sweep.
+bool mik_cg_head_available(const mik_csr *A)
+{
+    return A && A->n_rows > 0 && A->n_rows == A->n_cols && spmv_kernel_choice(A) == 5 && sdiab2_applies(A) && g_mik_tuning[25] == 1;
+}
+
+template <typename T>
+int mik_cg_head_launch(mik_ctx *ctx, const mik_csr *A, const T *r, const T *uo, T *un, T *x, T *c, T *seg_out, const T *alpha, const T *beta,
+                       const int *done, const int *pending)
+{
+    if (!mik_cg_head_available(A) || uo == un) return mik_fail(ctx, MIK_ERR_INVALID, "CG head sweep: not available for this operator");
+    const int n = (int)A->n_rows;
+    const int nb = (int)mik_spmv_nwg(n);
+    const int np = (nb + 1) / 2, wgs = (np + 7) / 8 * 8;
+    const int map_mode = g_mik_tuning[2] == 0 ? A->strip : std::max(g_mik_tuning[2], 0);
+    int ps = -1, pfull = 0;
+    if (map_mode >= 16) {
+        const int S = map_mode >> 3;
+        if ((S & (S - 1)) == 0) { ps = 0; while ((2 << ps) < S) ++ps; pfull = (nb / map_mode * map_mode) / 2; }
+    }
+    const int cls = A->sdia_cls;
+    const int hint = g_mik_tuning[26] > 0 ? (g_mik_tuning[26] & 31) : 8;
+#define MIK_HEAD_GO2(C, H)                                                                                                              \
+    hipLaunchKernelGGL((k_cg_head_sdiab2<T, mik_sdiab_cls_ns(C), mik_sdiab_cls_cq(C), H>), dim3(wgs), dim3(MIK_BLOCK), 0, ctx->stream, n, A->sdia_koff, \
+                       np, pfull, ps, nb, (const SdiaSliceRec *)A->sdia_recs, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, r, uo, un, x, c, seg_out, \
+                       alpha, beta, done, pending)
+#define MIK_HEAD_GO(H) do { if (cls == 1) MIK_HEAD_GO2(1, H); else if (cls == 2) MIK_HEAD_GO2(2, H); else MIK_HEAD_GO2(3, H); } while (0)
+    switch (hint) {
+    case 12: MIK_HEAD_GO(12); break;
+    case 24: MIK_HEAD_GO(24); break;
+    case 28: MIK_HEAD_GO(28); break;
+    case 4: MIK_HEAD_GO(4); break;
+    case 16: MIK_HEAD_GO(16); break;
+    default: MIK_HEAD_GO(8); break;
+    }
+#undef MIK_HEAD_GO
+#undef MIK_HEAD_GO2
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+template int mik_cg_head_launch<double>(mik_ctx *, const mik_csr *, const double *, const double *, double *, double *, double *, double *, const double *,
+                                        const double *, const int *, const int *);
+template int mik_cg_head_launch<float>(mik_ctx *, const mik_csr *, const float *, const float *, float *, float *, float *, float *, const float *,
+                                       const float *, const int *, const int *);
+
 template <typename T>
 static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done, int rb_begin, int rb_count,
                             int skip_at, int skip_len)
@@ -1162,7 +1211,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
                 if ((S & (S - 1)) == 0) { sshift = 0; while ((1 << sshift) < S) ++sshift; nfull = nb / map_mode * map_mode; }
             }
 #define MIK_SDIAB_GO4(FD, NTV, GG, C)                                                                                                      \
-    hipLaunchKernelGGL((k_spmv_sdiab<T, FD, NTV, GG, mik_sdiab_cls_ns(C), mik_sdiab_cls_cq(C)>), dim3(wgs), dim3(MIK_BLOCK), 0, ctx->stream, n, A->sdia_koff, \
+    hipLaunchKernelGGL((k_spmv_sdiab<T, FD, NTV, GG, mik_sdiab_cls_ns(C), mik_sdiab_cls_cq(C)>), dim3(wgs), dim3(MIK_BLOCK), 0, ctx->stream, n, (int)A->n_cols, A->sdia_koff, \
                        rb0, nb, nfull, sshift, skip_at, skip_len, (const SdiaSliceRec *)A->sdia_recs, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done)
 #define MIK_SDIAB_GO3(FD, NTV, GG)                                                                                                          \
     do { if (cls == 1) MIK_SDIAB_GO4(FD, NTV, GG, 1); else if (cls == 2) MIK_SDIAB_GO4(FD, NTV, GG, 2); else if (cls == 3) MIK_SDIAB_GO4(FD, NTV, GG, 3); \
@@ -1175,7 +1224,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
                 const int np = (nb + 1) / 2, pb0 = rb0 / 2, wg2 = (np + 7) / 8 * 8;
                 const int ps = sshift >= 1 ? sshift - 1 : -1, pfull = sshift >= 1 ? nfull / 2 : 0;
 #define MIK_SDIAB2_GO4(FD, NTV, C)                                                                                                       \
-    hipLaunchKernelGGL((k_spmv_sdiab2<T, FD, NTV, mik_sdiab_cls_ns(C), mik_sdiab_cls_cq(C)>), dim3(wg2), dim3(MIK_BLOCK), 0, ctx->stream, n, A->sdia_koff, \
+    hipLaunchKernelGGL((k_spmv_sdiab2<T, FD, NTV, mik_sdiab_cls_ns(C), mik_sdiab_cls_cq(C)>), dim3(wg2), dim3(MIK_BLOCK), 0, ctx->stream, n, (int)A->n_cols, A->sdia_koff, \
                        pb0, np, pfull, ps, nb_all, (const SdiaSliceRec *)A->sdia_recs, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done)
 #define MIK_SDIAB2_GO(FD, NTV) do { if (cls == 1) MIK_SDIAB2_GO4(FD, NTV, 1); else if (cls == 2) MIK_SDIAB2_GO4(FD, NTV, 2); else MIK_SDIAB2_GO4(FD, NTV, 3); } while (0)
                 if (fuse_dot) { if (nt) MIK_SDIAB2_GO(true, true); else MIK_SDIAB2_GO(true, false); }

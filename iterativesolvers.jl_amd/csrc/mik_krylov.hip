@@ -22,6 +22,10 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
 template <typename T>
 int mik_spmv_launch_outside(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done, int skip_begin, int skip_end);
 bool mik_spmv_can_split(const mik_csr *A);
+bool mik_cg_head_available(const mik_csr *A);
+template <typename T>
+int mik_cg_head_launch(mik_ctx *ctx, const mik_csr *A, const T *r, const T *uo, T *un, T *x, T *c, T *seg_out, const T *alpha, const T *beta,
+                       const int *done, const int *pending);
 
 
 
@@ -615,6 +619,18 @@ template <typename T> static int cg_enqueue_head(mik_cg *it)
             OpXpby<T> op{c, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 1};   // c = Pl \\ r is dead after this sweep
             MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
         }
+    } else if (it->fuse_head) {
+        // x .+= alpha .* u (previous step), u' = r .+ beta .* u, c = A * u', dot(u', c): ONE sweep (k_cg_head_sdiab2); the
+        // direction moves to the other of its two buffers                     src/cg.jl:50-55,58
+        T *uo = it->u_par ? (T *)it->u_alt : u, *un = it->u_par ? u : (T *)it->u_alt;
+        {
+            CgProfileScope ps(it, 0);
+            MIK_TRY(mik_cg_head_launch<T>(ctx, it->A, r, uo, un, x, c, (T *)it->seg_spmv, &d->alpha, &d->beta, done, &d->x_pending));
+        }
+        it->u_par ^= 1;
+        hipLaunchKernelGGL((k_cg_fin_alpha<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_spmv, nb, d, pcg, (FinScratch<T> *)it->fin);
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
     } else {
         // u .= r .+ beta .* u                                           src/cg.jl:50-51
         CgProfileScope ps(it, 1);
@@ -650,7 +666,7 @@ template <typename T> static int cg_enqueue_xflush(mik_cg *it)
 {
     mik_ctx *ctx = it->ctx;
     CgDev<T> *d = (CgDev<T> *)it->dev;
-    T *x = (T *)it->x, *u = (T *)it->u;
+    T *x = (T *)it->x, *u = it->u_par ? (T *)it->u_alt : (T *)it->u;
     OpXFlush<T> op{u, x, coef_ptr<T>(&d->alpha), &d->x_pending};
     MIK_TRY((launch_map<T>(ctx, it->n, op, mik_aligned16(x) && mik_aligned16(u), (T *)nullptr, (const int *)nullptr)));
     hipLaunchKernelGGL((k_cg_clear_pending<T>), dim3(1), dim3(1), 0, ctx->stream, d);
@@ -769,6 +785,8 @@ static int cg_create_common(mik_ctx *ctx, const mik_csr *A, int dtype, int64_t n
     it->x = x; it->b = b; it->u = u; it->r = r; it->c = c; it->diag = jacobi_diag;
     it->maxiter = maxiter;
     it->fuse_x = A != nullptr && !pl_fn && g_mik_tuning[23] == 0;       // development knob 23: 1 = x updated by the step's own sweep
+    // the whole head of the step as one sweep: plain CG where k_spmv_sdiab2 applies -- development knob 25 = 1 only (it is slower)
+    it->fuse_head = it->fuse_x && !jacobi_diag && n > 0 && mik_cg_head_available(A);
     const size_t es = mik_dtype_size(dtype);
     const int64_t nseg = dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
     const int64_t nb = mik_spmv_nwg(n);
@@ -782,6 +800,10 @@ static int cg_create_common(mik_ctx *ctx, const mik_csr *A, int dtype, int64_t n
         return mik_fail(ctx, MIK_ERR_NOMEM, "mik_cg_create: hipMalloc: %s", hipGetErrorString(e));
     }
     it->hist_cap = 64;
+    if (it->fuse_head && (e = hipMalloc(&it->u_alt, es * (size_t)n)) != hipSuccess) {
+        (void)hipGetLastError();
+        it->fuse_head = false;                                           // no room for the second direction buffer: the two-launch head
+    }
     if ((e = hipHostMalloc((void **)&it->mirror, sizeof(CgMirror), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) {
         mik_cg_destroy(it);
         return mik_fail(ctx, MIK_ERR_NOMEM, "mik_cg_create: hipHostMalloc: %s", hipGetErrorString(e));
@@ -842,6 +864,7 @@ extern "C" int mik_cg_destroy(mik_cg *it)
     if (it->hist) (void)hipFree(it->hist);
     if (it->seg_spmv) (void)hipFree(it->seg_spmv);
     if (it->seg_vec) (void)hipFree(it->seg_vec);
+    if (it->u_alt) (void)hipFree(it->u_alt);
     for (hipEvent_t e : it->ev) (void)hipEventDestroy(e);
     if (it->mirror) (void)hipHostFree(it->mirror);
     delete it;
@@ -915,6 +938,11 @@ static int cg_iterate_many_impl(mik_cg *it, int64_t iteration, int64_t max_steps
     it->dev_done = m.done != 0;
     it->mv_products += nd;
     *steps_done = nd;
+    if (it->u_par && !it->head_ahead && (m.done || iteration + nd >= it->maxiter || it->residual <= it->tol)) {
+        // the iteration is over and the direction sits in the library's second buffer: back into the caller's u
+        MIK_HIP(ctx, hipMemcpyAsync(it->u, it->u_alt, sizeof(T) * (size_t)it->n, hipMemcpyDeviceToDevice, ctx->stream));
+        it->u_par = 0;
+    }
     if (it->profile) cg_profile_collect(it);
     return MIK_OK;
 }
@@ -941,7 +969,7 @@ extern "C" int mik_cg_iterate(mik_cg *it, int64_t iteration, double *residual, i
 extern "C" int mik_cg_fused_x(const mik_cg *it, int *fused)
 {
     if (!it || !fused) return MIK_ERR_INVALID;
-    *fused = it->fuse_x ? 1 : 0;
+    *fused = it->fuse_head ? 2 : it->fuse_x ? 1 : 0;
     return MIK_OK;
 }
 

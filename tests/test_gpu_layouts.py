@@ -218,3 +218,34 @@ def test_slice_constant_kernels_absent_slots_and_missing_diagonals(pkg, orc, ctx
     if dA2.layout() == "slice-offsets+slice-values+row-masks":
         assert dA2.spmv_kernel() == "k_spmv_sdiac"
     assert np.array_equal(pkg.mul_(pkg.HipVector(n, dtype), dA2, pkg.HipVector.from_numpy(xf)).to_numpy(), orc.spmv(A2, xf), equal_nan=True)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("rows", [1300, 1301, 1282, 65, 2])
+def test_rectangular_blocks_with_lane_neighbour_slots(pkg, ctx, dtype, rows):
+    """The local block of a row-partitioned operator has more columns than rows (halo entries behind the owned ones).  The
+    slice-constant kernels take the slots next to the centre from neighbouring lanes; the last row's upper neighbour is then
+    column `rows` -- outside the rows, inside the columns -- and a wave may consist of that one row (65) or pair (1282 = 10 x 128
+    + 2).  Every layout against the row-by-row sums in column order."""
+    cols, far = rows + 50, 40
+    S = sp.diags([np.full(cols - far, -1.0), np.full(cols - 1, -2.0), np.full(cols, 5.0), np.full(cols - 1, -3.0), np.full(cols - far, -0.5)],
+                 [-far, -1, 0, 1, far], format="csr")[:rows].astype(dtype).tocsr()
+    S.sort_indices()
+    x = np.random.default_rng(5).standard_normal(cols).astype(dtype)
+    want = np.zeros(rows, dtype)
+    lens = np.diff(S.indptr)
+    for k in range(int(lens.max())):                     # a = a + val * x, entries in column order, one rounding each
+        has = lens > k
+        at = S.indptr[:-1][has] + k
+        want[has] = (want[has] + (S.data[at] * x[S.indices[at]]).astype(dtype)).astype(dtype)
+    C = S.tocsc()
+    C.sort_indices()
+    seen = set()
+    for form, knobs in (("csr-rowblock", {8: 1}), ("best", {}), ("best/one-row-per-lane", {19: 1}), ("best/flat-loads", {17: 1}), ("best/slot-by-slot", {18: 1})):
+        def run():
+            dA = pkg.HipCSR(rows, cols, C.indptr.astype(np.int64), C.indices.astype(np.int64), C.data, index_base=0)
+            seen.add(dA.spmv_kernel())
+            return pkg.mul_(pkg.HipVector(rows, dtype), dA, pkg.HipVector.from_numpy(x)).to_numpy()
+        assert np.array_equal(with_knobs(pkg, knobs, run), want), form
+    if rows % 2 == 0 and rows >= 256:
+        assert "k_spmv_sdiab2" in seen and "k_spmv_sdiab" in seen

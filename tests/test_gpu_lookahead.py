@@ -30,6 +30,7 @@ def run(pkg, A, b, schedule, knobs, Pl=None, **kw):
                 if r.size < steps:
                     break
             snaps.append((x.to_numpy(), it.r.to_numpy()))          # what a caller sees between two calls
+        run.last_u, run.last_head = it.u.to_numpy(), it.fused_head()
         return np.array(hist), snaps, it.converged if hasattr(it, "converged") else None
     finally:
         for k2 in knobs:
@@ -38,15 +39,20 @@ def run(pkg, A, b, schedule, knobs, Pl=None, **kw):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("pcg", [False, True])
-def test_lookahead_changes_nothing_the_caller_can_see(pkg, orc, ctx, dtype, pcg):
-    A = orc.laplace(9, 3).astype(dtype)
+@pytest.mark.parametrize("N", [9, 10])
+def test_lookahead_changes_nothing_the_caller_can_see(pkg, orc, ctx, dtype, pcg, N):
+    A = orc.laplace(N, 3).astype(dtype)
     b = orc.hashed_rhs(A.n).astype(dtype)
     Pl = pkg.JacobiPrec(pkg.HipVector.from_numpy(np.full(A.n, 6.0, dtype))) if pcg else None
     schedule = [1, 1, 3, 1, 7, 1, 1, 25, 1, 1]
     kw = dict(reltol=0.0, maxiter=10 ** 6)
     h1, s1, _ = run(pkg, A, b, schedule, {}, Pl, **kw)
-    for knobs in ({9: 1}, {23: 1}, {9: 1, 23: 1}):       # no look-ahead; x updated by the step's own sweep; neither
+    assert not run.last_head
+    # no look-ahead; x updated by the step's own sweep; neither; the head of the step as ONE sweep (k_cg_head_sdiab2: plain CG,
+    # even number of rows), also without look-ahead; one row per lane
+    for knobs in ({9: 1}, {23: 1}, {9: 1, 23: 1}, {25: 1}, {25: 1, 9: 1}, {19: 1}):
         h0, s0, _ = run(pkg, A, b, schedule, knobs, Pl, **kw)
+        assert run.last_head == (25 in knobs and not pcg and A.n % 2 == 0), knobs
         assert np.array_equal(h1, h0) and len(s1) == len(s0), knobs
         for (x1, r1), (x0, r0) in zip(s1, s0):
             assert np.array_equal(x1, x0) and np.array_equal(r1, r0), knobs
@@ -55,15 +61,21 @@ def test_lookahead_changes_nothing_the_caller_can_see(pkg, orc, ctx, dtype, pcg)
         assert np.array_equal(h1, np.asarray(ho["resnorm"], dtype=np.float64)[:len(h1)])
 
 
-def test_lookahead_at_the_stopping_tests(pkg, orc, ctx):
-    A = orc.laplace(8, 3)
+@pytest.mark.parametrize("N", [8, 9])
+def test_lookahead_at_the_stopping_tests(pkg, orc, ctx, N):
+    A = orc.laplace(N, 3)
     b = orc.hashed_rhs(A.n)
     for kw in (dict(reltol=1e-6, maxiter=10 ** 6), dict(reltol=0.0, maxiter=13), dict(reltol=1e-3, maxiter=10 ** 6)):
         for schedule in ([1] * 200, [4] * 60, [1, 5, 1, 9] * 20):
             h1, s1, _ = run(pkg, A, b, schedule, {}, **kw)
-            for knobs in ({9: 1}, {23: 1}, {9: 1, 23: 1}):
+            u1 = run.last_u
+            for knobs in ({9: 1}, {23: 1}, {9: 1, 23: 1}, {25: 1}, {25: 1, 9: 1}):
                 h0, s0, _ = run(pkg, A, b, schedule, knobs, **kw)
+                assert run.last_head == (25 in knobs and A.n % 2 == 0), knobs
                 assert np.array_equal(h1, h0) and len(s1) == len(s0) and len(h1) > 0, knobs
                 assert np.array_equal(s1[-1][0], s0[-1][0]) and np.array_equal(s1[-1][1], s0[-1][1]), knobs
+                # the caller's u is the last direction: a head that ran ahead of a stopped iteration leaves it alone, and the
+                # one-sweep head, whose direction alternates between two buffers, hands it back
+                assert np.array_equal(u1, run.last_u), knobs
             if kw["maxiter"] == 13:
                 assert len(h1) == 13
