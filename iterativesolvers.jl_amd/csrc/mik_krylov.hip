@@ -571,14 +571,16 @@ struct CgProfileScope {
 // u .= r .+ beta .* u: streaming them past L2 (non-temporal) leaves the cache to the operator's gather and
 // took the in-loop SpMV from 322 to 307 us and the step from 546 to 507 us at 256^3.
 // bits 0-2: xpby {r load, u load, u store}; bits 3-7: update {x, c load, u load, r load, r store}.
-// tuning[7]: 0 = default, < 0 = all temporal, > 0 = explicit mask.  Defaults (sweeps of single-bit flips and pairs inside the
-// CG loop at 256^3): 57 for the classic step; 121 (r of the update streamed as well) when x .+= alpha .* u rides on the next
-// sweep over u (OpXpbyX / OpCgUpdateR: bit 3 = x of that sweep) -- 3,887 -> 3,971 it/s, mostly through what the SpMV in
-// between finds in the Infinity Cache.
+// tuning[7]: 0 = default, < 0 = all temporal, > 0 = explicit mask.  Defaults (sweeps of single-bit flips inside the CG loop at
+// 256^3, scripts/hint_sweep.py): 57 for the classic step; 248 when x .+= alpha .* u rides on the next sweep over u (OpXpbyX /
+// OpCgUpdateR: bit 3 = x of that sweep): x, c and both directions of r in the update streamed, r read with the default policy by
+// the sweep that follows.  With k_spmv_sdiab2 the r STORE is the bit that matters: streamed, it leaves the Infinity Cache to
+// what the SpMV reads (in-loop SpMV 62 -> 48 us = its back-to-back time; 121 -> 249: 4,330 -> 4,520 it/s), and r then read
+// cached rather than streamed takes 8 us off the update that wrote it (249 -> 248: 4,720 it/s).
 static inline int cg_stream_hints(bool fused_x = false)
 {
     const int k = g_mik_tuning[7];
-    return k == 0 ? (fused_x ? 121 : 57) : (k < 0 ? 0 : k);
+    return k == 0 ? (fused_x ? 248 : 57) : (k < 0 ? 0 : k);
 }
 
 // One iterate() = HEAD (u = r + beta u [after c = Pl \ r, rho]; c = A u; alpha) + TAIL (x, r update; residual, stopping test).
@@ -613,7 +615,7 @@ template <typename T> static int cg_enqueue_head(mik_cg *it)
         // u .= c .+ beta .* u                                           src/cg.jl:86
         CgProfileScope ps(it, 1);
         if (it->fuse_x) {
-            OpXpbyX<T> op{c, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(true) & 9};
+            OpXpbyX<T> op{c, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, (cg_stream_hints(true) & 8) | 1};   // c = Pl \\ r is dead after this sweep: streamed
             MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, (const int *)nullptr)));
         } else {
             OpXpby<T> op{c, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 1};   // c = Pl \\ r is dead after this sweep

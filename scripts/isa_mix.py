@@ -13,7 +13,9 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "iterativesolvers.jl_amd", "csrc", "mik_core.hip")
-WANT = {"k_spmv_sdiab<double, true, true, 2, 7, 3>  (both paths: compiled-in class and slot by slot)": "_Z12k_spmv_sdiabIdLb1ELb1ELi2ELi7ELi3EE",
+WANT = {"k_spmv_sdiab2<double, true, true, 7, 3>  (two rows per lane; both paths)": "_Z13k_spmv_sdiab2IdLb1ELb1ELi7ELi3EE",
+        "k_cg_head_sdiab2<double, 7, 3, 8>  (development knob 25)": "_Z16k_cg_head_sdiab2IdLi7ELi3ELi8EE",
+        "k_spmv_sdiab<double, true, true, 2, 7, 3>  (both paths: compiled-in class and slot by slot)": "_Z12k_spmv_sdiabIdLb1ELb1ELi2ELi7ELi3EE",
         "k_spmv_sdiac<double, true, true, 2>": "_Z12k_spmv_sdiacIdLb1ELb1ELi2EE", "k_spmv_sdia<double, true, true>": "_Z11k_spmv_sdiaIdLb1ELb1EE", "k_spmv_rowgather<double, true, true>": "_Z16k_spmv_rowgatherIdLb1ELb1EE",
         "k_spmv_rowblock<double, true, true, true, false>": "_Z15k_spmv_rowblockIdLb1ELb1ELb1ELb0EE", "k_spmv_sell8<double, true, true>": "_Z12k_spmv_sell8IdLb1ELb1EE"}
 with tempfile.TemporaryDirectory() as tmp:
@@ -23,7 +25,7 @@ with tempfile.TemporaryDirectory() as tmp:
     text = open(asm).read()
 print("static instruction mix per kernel (hipcc -O3 --offload-arch=gfx950 -ffp-contract=off; one row per opcode class)\n")
 for name, mangled in WANT.items():
-    m = re.search(r"^(%s\w*):[^\n]*\n(.*?)^\s*s_endpgm" % re.escape(mangled), text, re.S | re.M)
+    m = re.search(r"^(%s\w*):[^\n]*\n(.*?)^\.Lfunc_end" % re.escape(mangled), text, re.S | re.M)      # the whole body (early exits included)
     if not m:
         print(name, ": not found")
         continue
