@@ -1058,6 +1058,9 @@ static bool sdiab2_applies(const mik_csr *A)
            g_mik_tuning[19] == 0;
 }
 
+// the operator's SpMV moves little more than x and y (the slice-constant layout): the CG step then picks other cache hints
+bool mik_spmv_is_light(const mik_csr *A) { return A && spmv_kernel_choice(A) == 5; }
+
 extern "C" int mik_spmv_kernel(const mik_csr *A, char *name, int len)
 {
     if (!A || !name || len <= 0) return MIK_ERR_INVALID;

@@ -23,6 +23,7 @@ template <typename T>
 int mik_spmv_launch_outside(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done, int skip_begin, int skip_end);
 bool mik_spmv_can_split(const mik_csr *A);
 bool mik_cg_head_available(const mik_csr *A);
+bool mik_spmv_is_light(const mik_csr *A);
 template <typename T>
 int mik_cg_head_launch(mik_ctx *ctx, const mik_csr *A, const T *r, const T *uo, T *un, T *x, T *c, T *seg_out, const T *alpha, const T *beta,
                        const int *done, const int *pending);
@@ -577,10 +578,12 @@ struct CgProfileScope {
 // the sweep that follows.  With k_spmv_sdiab2 the r STORE is the bit that matters: streamed, it leaves the Infinity Cache to
 // what the SpMV reads (in-loop SpMV 62 -> 48 us = its back-to-back time; 121 -> 249: 4,330 -> 4,520 it/s), and r then read
 // cached rather than streamed takes 8 us off the update that wrote it (249 -> 248: 4,720 it/s).
-static inline int cg_stream_hints(bool fused_x = false)
+// (With an operator whose SpMV itself streams gigabytes -- CSR, per-row values -- the earlier mask 121 stays: 248 cost the CSR
+// loop 10 us per step.)
+static inline int cg_stream_hints(bool fused_x = false, const mik_csr *A = nullptr)
 {
     const int k = g_mik_tuning[7];
-    return k == 0 ? (fused_x ? 248 : 57) : (k < 0 ? 0 : k);
+    return k == 0 ? (fused_x ? (mik_spmv_is_light(A) ? 248 : 121) : 57) : (k < 0 ? 0 : k);
 }
 
 // One iterate() = HEAD (u = r + beta u [after c = Pl \ r, rho]; c = A u; alpha) + TAIL (x, r update; residual, stopping test).
@@ -615,7 +618,7 @@ template <typename T> static int cg_enqueue_head(mik_cg *it)
         // u .= c .+ beta .* u                                           src/cg.jl:86
         CgProfileScope ps(it, 1);
         if (it->fuse_x) {
-            OpXpbyX<T> op{c, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, (cg_stream_hints(true) & 8) | 1};   // c = Pl \\ r is dead after this sweep: streamed
+            OpXpbyX<T> op{c, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, (cg_stream_hints(true, it->A) & 8) | 1};   // c = Pl \\ r is dead after this sweep: streamed
             MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, (const int *)nullptr)));
         } else {
             OpXpby<T> op{c, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 1};   // c = Pl \\ r is dead after this sweep
@@ -637,7 +640,7 @@ template <typename T> static int cg_enqueue_head(mik_cg *it)
         // u .= r .+ beta .* u                                           src/cg.jl:50-51
         CgProfileScope ps(it, 1);
         if (it->fuse_x) {   // ... and x .+= alpha .* u of the previous step, on the u this sweep reads anyway (OpXpbyX)
-            OpXpbyX<T> op{r, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(true) & 15};
+            OpXpbyX<T> op{r, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(true, it->A) & 15};
             MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, (const int *)nullptr)));
         } else {
             OpXpby<T> op{r, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 7};
@@ -689,7 +692,7 @@ template <typename T> static int cg_enqueue_tail(mik_cg *it, long long it_next, 
     {
         CgProfileScope ps(it, 2);
         if (it->fuse_x) {
-            OpCgUpdateR<T> up{r, c, coef_ptr<T>(&d->alpha), cg_stream_hints(true) >> 3};
+            OpCgUpdateR<T> up{r, c, coef_ptr<T>(&d->alpha), cg_stream_hints(true, it->A) >> 3};
             MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done)));
         } else {
             OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints() >> 3};
@@ -1901,7 +1904,7 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
         return MIK_OK;
     case 0: {  // step A
         if (bs.fuse_x) {   // ... with x .+= alpha .* u of the previous step on the u this sweep reads anyway (OpXpbyX)
-            OpXpbyX<T> op{r, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(true) & 15};
+            OpXpbyX<T> op{r, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(true, bs.A) & 15};
             MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, (const int *)nullptr)));
         } else {
             OpXpby<T> op{r, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 7};
@@ -1928,7 +1931,7 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
             const int64_t o = lo[q], len = hi[q] - lo[q];
             const bool v2 = vec && (o % VT<T>::W == 0);
             if (bs.fuse_x) {
-                OpXpbyX<T> op{r + o, u + o, x + o, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(true) & 15};
+                OpXpbyX<T> op{r + o, u + o, x + o, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(true, bs.A) & 15};
                 MIK_TRY((launch_map<T>(ctx, len, op, v2, (T *)nullptr, (const int *)nullptr)));
             } else {
                 OpXpby<T> op{r + o, u + o, coef_ptr<T>(&d->beta), cg_stream_hints() & 7};
@@ -1970,7 +1973,7 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
         hipLaunchKernelGGL((k_cgd_alpha<T>), dim3(1), dim3(1), 0, ctx->stream, (const T *)it->dot_all, it->nranks, d);
         MIK_LAUNCH_CHECK(ctx);
         if (bs.fuse_x) {
-            OpCgUpdateR<T> up{r, c, coef_ptr<T>(&d->alpha), cg_stream_hints(true) >> 3};
+            OpCgUpdateR<T> up{r, c, coef_ptr<T>(&d->alpha), cg_stream_hints(true, bs.A) >> 3};
             MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)bs.seg_vec, done)));
         } else {
             OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints() >> 3};
