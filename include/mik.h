@@ -116,8 +116,11 @@ int mik_spmv_long_segment(int *segment);
  *  13: bit mask switching the Krylov-basis streaming hints off    14: CSR kernel: 0 = by operator, 1 = register-staged products, 2 = LDS-DMA tile + per-row gather
  *  15: long-row segment length (> 0; read at mik_csr_create)   16: slices per workgroup of the layout-5 kernels (1 / 2 / 4)
  *  17: 1 = layout 5 through flat loads (k_spmv_sdiac)              18: 1 = k_spmv_sdiab without the compiled-in slot class
+ *  19: 1 = layout 5 with one row per lane (k_spmv_sdiab instead of k_spmv_sdiab2)
  *  20: 1 = mik_csr_create on the host path only                   21: DGKS rounds inside the single-launch kernel (1..3; read at mik_gmres_create)
- *  23: 1 = CG updates x in the step's own sweep (read at mik_cg_create) */
+ *  23: 1 = CG updates x in the step's own sweep (read at mik_cg_create)      24: 1 = the halo of a row-partitioned CG step after the whole sweep over u
+ *  25: 1 = the head of a plain CG step as ONE launch (k_cg_head_sdiab2; slower, see mik_cg_fused_x; read at mik_cg_create)
+ *  26: cache-hint bits of that launch (8 = x streamed, 4 = u stored nt, 16 = c stored temporal; 0 = 8) */
 int mik_set_tuning(int key, int value);
 
 /* ---- device memory (similar / zero / copyto! / fill! of the vector interface) ----------- */
@@ -228,7 +231,10 @@ int mik_cg_destroy(mik_cg *it);
  * mik_set_tuning(9, 1) switches it off). */
 int mik_cg_iterate(mik_cg *it, int64_t iteration, double *residual, int *done);
 /* 1 if this iterable applies x .+= alpha .* u in the sweep over u that opens the next step (CSR operator, no
- * preconditioner callback; see mik_cg_iterate), 0 if in the step's own update sweep. */
+ * preconditioner callback; see mik_cg_iterate), 0 if in the step's own update sweep; 2 if that sweep is itself part of
+ * the SpMV launch (mik_set_tuning(25, 1) before mik_cg_create, plain CG on a slice-constant operator with an even number
+ * of rows): the search direction then alternates between the caller's u and a library buffer and is copied back into u
+ * when the iteration ends.  Results are bit-identical in all three forms. */
 int mik_cg_fused_x(const mik_cg *it, int *fused);
 /* Up to max_steps consecutive iterate() calls with ONE host synchronisation: the stopping test
  * of src/cg.jl:36 is evaluated on the device after every step and later steps become no-ops.

@@ -565,6 +565,12 @@ function dist_cg_iterator!(x::HipVector{T}, A_loc::HipCSR{T}, b::HipVector{T}, c
     finalizer(i -> alive(i.ctx) && ccall((:mik_cgd_destroy, libmik), Cint, (Ptr{Cvoid},), i.handle), it)
     it
 end
+"(runs, rows, merged) -- the contiguous row runs a rank updates, packs and puts on the wire ahead of the sweep over u (0 runs: the halo follows the sweep)"
+function halo_early(it::HipDistCG)
+    runs = Ref{Cint}(0); rows = Ref{Int64}(0); merged = Ref{Cint}(0)
+    check(ccall((:mik_cgd_halo_early, libmik), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Int64}, Ref{Cint}), it.handle, runs, rows, merged), "mik_cgd_halo_early", it.ctx.handle)
+    (Int(runs[]), Int(rows[]), merged[] != 0)
+end
 function iterate_many!(it::HipDistCG, iteration::Int, max_steps::Int)
     res = Vector{Cdouble}(undef, max(max_steps, 1)); nd = Ref{Int64}(0)
     check(ccall((:mik_cgd_iterate_many, libmik), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ref{Int64}), it.handle, iteration, max_steps, res, nd),
