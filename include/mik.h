@@ -120,7 +120,9 @@ int mik_spmv_long_segment(int *segment);
  *  20: 1 = mik_csr_create on the host path only                   21: DGKS rounds inside the single-launch kernel (1..3; read at mik_gmres_create)
  *  23: 1 = CG updates x in the step's own sweep (read at mik_cg_create)      24: 1 = the halo of a row-partitioned CG step after the whole sweep over u
  *  25: 1 = the head of a plain CG step as ONE launch (k_cg_head_sdiab2; slower, see mik_cg_fused_x; read at mik_cg_create)
- *  26: cache-hint bits of that launch (8 = x streamed, 4 = u stored nt, 16 = c stored temporal; 0 = 8) */
+ *  26: cache-hint bits of that launch (8 = x streamed, 4 = u stored nt, 16 = c stored temporal; 0 = 8)
+ *  27: direction of the streaming launches of a plain CG step (bit 0 / 1 / 2: the u sweep / the SpMV / the update walk from
+ *      the end of the vectors; 8: every launch against the one before it) -- no effect at the default cache hints */
 int mik_set_tuning(int key, int value);
 
 /* ---- device memory (similar / zero / copyto! / fill! of the vector interface) ----------- */

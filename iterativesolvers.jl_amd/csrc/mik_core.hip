@@ -1228,7 +1228,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
                 const int ps = sshift >= 1 ? sshift - 1 : -1, pfull = sshift >= 1 ? nfull / 2 : 0;
 #define MIK_SDIAB2_GO4(FD, NTV, C)                                                                                                       \
     hipLaunchKernelGGL((k_spmv_sdiab2<T, FD, NTV, mik_sdiab_cls_ns(C), mik_sdiab_cls_cq(C)>), dim3(wg2), dim3(MIK_BLOCK), 0, ctx->stream, n, (int)A->n_cols, A->sdia_koff, \
-                       pb0, np, pfull, ps, nb_all, (const SdiaSliceRec *)A->sdia_recs, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done)
+                       pb0, np, pfull, ps, nb_all, ctx->sweep_rev, (const SdiaSliceRec *)A->sdia_recs, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done)
 #define MIK_SDIAB2_GO(FD, NTV) do { if (cls == 1) MIK_SDIAB2_GO4(FD, NTV, 1); else if (cls == 2) MIK_SDIAB2_GO4(FD, NTV, 2); else MIK_SDIAB2_GO4(FD, NTV, 3); } while (0)
                 if (fuse_dot) { if (nt) MIK_SDIAB2_GO(true, true); else MIK_SDIAB2_GO(true, false); }
                 else          { if (nt) MIK_SDIAB2_GO(false, true); else MIK_SDIAB2_GO(false, false); }

@@ -38,6 +38,7 @@ struct mik_ctx {
     void *coef = nullptr;            // small device array of coefficients / scalar results
     void *coef_host = nullptr;       // pinned host mirror
     hipEvent_t wait_event = nullptr; // for mik_wait
+    int sweep_rev = 0;               // 1: the next SpMV launch walks its row-blocks from the end (set and cleared by the CG step)
     static constexpr size_t COEF_BYTES = 8192;      // [0, 4096): coefficient blocks of the callers; the tail: scratch of mik_safe_norm_slow
     static constexpr size_t COEF_SAFE_SLOT = 4096;  // byte offset of that scratch
 };

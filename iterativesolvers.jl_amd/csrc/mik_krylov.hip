@@ -586,6 +586,18 @@ static inline int cg_stream_hints(bool fused_x = false, const mik_csr *A = nullp
     return k == 0 ? (fused_x ? (mik_spmv_is_light(A) ? 248 : 121) : 57) : (k < 0 ? 0 : k);
 }
 
+// Development knob 27: direction of the three streaming launches of a plain CG step.  Workgroups are dispatched in index
+// order; a launch that starts where the previous one ended meets what that one left in the 256 MB Infinity Cache.
+// bit 0 / 1 / 2: the u sweep / the SpMV / the update walk from the END of the vectors; 8: every launch the other way
+// round than the one before it.  Results never depend on it (partials keep their slots).
+static inline bool cg_sweep_rev(mik_cg *it, int which)
+{
+    const int k = g_mik_tuning[27];
+    if (k == 0) return false;
+    if (k & 8) return (it->sweeps++ & 1u) != 0;
+    return ((k >> which) & 1) != 0;
+}
+
 // One iterate() = HEAD (u = r + beta u [after c = Pl \ r, rho]; c = A u; alpha) + TAIL (x, r update; residual, stopping test).
 // The head only writes the iterable's internal vectors u and c and scalars, and all of its inputs are final once the previous
 // tail has run -- so the head of step k + 1 may be put on the stream BEFORE the host waits for the residual of step k
@@ -641,7 +653,7 @@ template <typename T> static int cg_enqueue_head(mik_cg *it)
         CgProfileScope ps(it, 1);
         if (it->fuse_x) {   // ... and x .+= alpha .* u of the previous step, on the u this sweep reads anyway (OpXpbyX)
             OpXpbyX<T> op{r, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(true, it->A) & 15};
-            MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, (const int *)nullptr)));
+            MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, (const int *)nullptr, cg_sweep_rev(it, 0))));
         } else {
             OpXpby<T> op{r, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 7};
             MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
@@ -651,7 +663,10 @@ template <typename T> static int cg_enqueue_head(mik_cg *it)
     if (it->A) {
         {
             CgProfileScope ps(it, 0);
-            MIK_TRY(mik_spmv_launch<T>(ctx, it->A, u, c, true, (T *)it->seg_spmv, done));
+            ctx->sweep_rev = (!pcg && it->fuse_x && cg_sweep_rev(it, 1)) ? 1 : 0;
+            const int rc_spmv = mik_spmv_launch<T>(ctx, it->A, u, c, true, (T *)it->seg_spmv, done);
+            ctx->sweep_rev = 0;
+            MIK_TRY(rc_spmv);
         }
         hipLaunchKernelGGL((k_cg_fin_alpha<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_spmv, nb, d, pcg, (FinScratch<T> *)it->fin);
     } else {
@@ -693,7 +708,7 @@ template <typename T> static int cg_enqueue_tail(mik_cg *it, long long it_next, 
         CgProfileScope ps(it, 2);
         if (it->fuse_x) {
             OpCgUpdateR<T> up{r, c, coef_ptr<T>(&d->alpha), cg_stream_hints(true, it->A) >> 3};
-            MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done)));
+            MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done, !it->diag && !it->pl_fn && cg_sweep_rev(it, 2))));
         } else {
             OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints() >> 3};
             MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done)));
