@@ -364,12 +364,21 @@ template <typename T> __device__ __forceinline__ bool level2_sum_spread(const T 
     const int w = blockIdx.x, lane = threadIdx.x;              // blockDim.x == 64, gridDim.x == MIK_FIN_WGS
     T acc = T(0);
     int64_t j = 64 * (int64_t)w + lane;
-    for (; j + 31 * (int64_t)MIK_FIN_THREADS < m; j += 32 * (int64_t)MIK_FIN_THREADS) {
-        T v[32];
+    // (batches of 64 / 16 / 8 loads in flight, added in index order: 65,536 SpMV partials are ONE round trip per lane, the 16,384 of
+    //  a vector sweep too -- a single wave per workgroup has the registers for it)
+    for (; j + 63 * (int64_t)MIK_FIN_THREADS < m; j += 64 * (int64_t)MIK_FIN_THREADS) {
+        T v[64];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) v[q] = S[j + q * (int64_t)MIK_FIN_THREADS];
+        for (int q = 0; q < 64; ++q) v[q] = S[j + q * (int64_t)MIK_FIN_THREADS];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) acc = acc + v[q];
+        for (int q = 0; q < 64; ++q) acc = acc + v[q];
+    }
+    for (; j + 15 * (int64_t)MIK_FIN_THREADS < m; j += 16 * (int64_t)MIK_FIN_THREADS) {
+        T v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = S[j + q * (int64_t)MIK_FIN_THREADS];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc = acc + v[q];
     }
     for (; j + 7 * (int64_t)MIK_FIN_THREADS < m; j += 8 * (int64_t)MIK_FIN_THREADS) {
         T v[8];
