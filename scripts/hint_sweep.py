@@ -1,5 +1,6 @@
 """CG step rate at 256^3 under single-bit flips of the vector kernels' cache-hint mask (development knob 7; default 121 with the
-fused x update): which streams should bypass the caches now that the SpMV is k_spmv_sdiab2."""
+fused x update at the time; 248 since): which streams should bypass the caches now that the SpMV is k_spmv_sdiab2.
+    HINT_BASE=248 python scripts/hint_sweep.py [extra masks...]      SWEEP_DIR=<knob 27> ONLY=1 ... <masks> for a fixed list"""
 import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
