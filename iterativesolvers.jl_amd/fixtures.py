@@ -167,6 +167,70 @@ def irregular_matrix(n: int = 1_000_000, dtype=np.float32, long_rows: bool = Tru
     return n, rowptr, c_all, np.ascontiguousarray(v_all.astype(dtype))
 
 
+def fe_matrix(grid, dof: int = 3, dtype=np.float32):
+    """Finite-element-shaped SPD operator: what the SuiteSparse inputs of benchmark/matrixmarket.jl:5 (``s3dkq4m2``: a
+    cylindrical shell, 4-node quadrilaterals with 6 unknowns per node, n = 90,449, ~53 entries per row) and
+    benchmark/matrixcollection.jl:6-8 look like, which cannot be downloaded here.  ``grid`` = nodes per dimension of a
+    structured mesh (2 entries: quadrilaterals, 9-node neighbourhoods; 3 entries: hexahedra, 27-node neighbourhoods), ``dof``
+    unknowns per node, unknown = node * dof + k (node-major, the usual FE numbering); every unknown of a node couples with every
+    unknown of every node of the neighbourhood (dense dof x dof blocks) => interior rows carry 9 * dof resp. 27 * dof entries
+    in clusters of ``dof`` consecutive columns.  ``fe_matrix((123, 123), 6)``: n = 90,774, 4.8 M entries, rows of 24 / 36 / 54;
+    ``fe_matrix((64, 64, 64), 3)``: n = 786,432, 62 M entries, rows of 24 ... 81.
+
+    Off-diagonal values in [-1, 1) from an integer hash of the unordered pair (symmetric), diagonal = 1 + sum |off-diagonal|
+    (symmetric + strictly diagonally dominant + positive diagonal => SPD, so cg! applies as it does to s3dkq4m2).
+    Returns 0-based CSR fields ``(n, rowptr, colidx, val)``, columns ascending in a row; being symmetric they are the CSC
+    fields as well."""
+    grid = tuple(int(g) for g in grid)
+    d = len(grid)
+    assert d in (2, 3) and dof >= 1
+    nn = int(np.prod(grid))
+    node = np.arange(nn, dtype=np.int64)
+    coord, stride, s = [], [], 1
+    for g in grid:                                          # first dimension fastest
+        coord.append((node // s) % g)
+        stride.append(s)
+        s *= g
+    offs = np.stack(np.meshgrid(*[np.arange(-1, 2)] * d, indexing="ij"), axis=-1).reshape(-1, d)[:, ::-1]
+    lin = (offs * np.asarray(stride)).sum(axis=1)
+    offs = offs[np.argsort(lin, kind="stable")]             # neighbours in ascending node order
+    nb = np.empty((nn, offs.shape[0]), np.int64)
+    ok = np.ones((nn, offs.shape[0]), bool)
+    for j, o in enumerate(offs):
+        nb[:, j] = node + int((o * np.asarray(stride)).sum())
+        for a in range(d):
+            ok[:, j] &= (coord[a] + o[a] >= 0) & (coord[a] + o[a] < grid[a])
+    cnt = ok.sum(axis=1)                                    # neighbour nodes per node
+    pair_b = nb[ok]                                         # node-major, ascending neighbour
+    pair_start = np.zeros(nn + 1, np.int64)
+    np.cumsum(cnt, out=pair_start[1:])
+    n = nn * dof
+    row_len = np.repeat(cnt * dof, dof)
+    rowptr = np.zeros(n + 1, np.int64)
+    np.cumsum(row_len, out=rowptr[1:])
+    E = int(rowptr[-1])
+    colidx = np.empty(E, np.int64)
+    val = np.empty(E, np.float64)
+    CH = max(dof, (1 << 18) // dof * dof)                   # rows per chunk (bounds the temporaries)
+    diag_pos = np.empty(n, np.int64)
+    for r0 in range(0, n, CH):
+        r1 = min(r0 + CH, n)
+        rl = row_len[r0:r1]
+        r = np.repeat(np.arange(r0, r1, dtype=np.int64), rl)
+        q = np.arange(rowptr[r0], rowptr[r1], dtype=np.int64) - rowptr[r]
+        c = pair_b[pair_start[r // dof] + q // dof] * dof + q % dof
+        lo, hi = np.minimum(r, c), np.maximum(r, c)
+        v = _hash32(lo * 1000003 + hi * 7 + 11, 3266489917).astype(np.float64) / 2147483648.0 - 1.0
+        isd = r == c
+        v[isd] = 0.0
+        colidx[rowptr[r0]:rowptr[r1]] = c
+        val[rowptr[r0]:rowptr[r1]] = v
+        diag_pos[r0:r1] = np.flatnonzero(isd) + rowptr[r0]
+    absum = np.add.reduceat(np.abs(val), rowptr[:-1])
+    val[diag_pos] = 1.0 + absum
+    return n, rowptr, colidx, np.ascontiguousarray(val.astype(dtype))
+
+
 def hashed_rhs(n: int, start: int = 0, stop=None, dtype=np.float64) -> np.ndarray:
     """b[i] = ((i * 2654435761) mod 2^32) / 2^32 - 0.5 for the 1-based i in (start, stop]
     (exact in any language)."""

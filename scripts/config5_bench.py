@@ -24,8 +24,13 @@ kinds = [k for k in os.environ.get("KINDS", "random,banded").split(",") if k]
 cases = []
 for kind in kinds:
     t0 = time.time()
-    n, rowptr, colidx, val = pkg.fixtures.irregular_matrix(n_req, np.float32, long_rows=os.environ.get("LONG", "1") == "1",
-                                                           bandwidth=0 if kind == "random" else int(os.environ.get("BAND", 2000)))
+    if kind == "fe_shell":      # the shape of s3dkq4m2 (benchmark/matrixmarket.jl:5): 6 unknowns per node, 9-node neighbourhoods
+        n, rowptr, colidx, val = pkg.fixtures.fe_matrix((123, 123), 6, np.float32)
+    elif kind == "fe_hex":      # 3 unknowns per node, 27-node neighbourhoods, larger than the Infinity Cache
+        n, rowptr, colidx, val = pkg.fixtures.fe_matrix((64, 64, 64), 3, np.float32)
+    else:
+        n, rowptr, colidx, val = pkg.fixtures.irregular_matrix(n_req, np.float32, long_rows=os.environ.get("LONG", "1") == "1",
+                                                               bandwidth=0 if kind == "random" else int(os.environ.get("BAND", 2000)))
     cases.append((kind, n, rowptr, colidx, val, time.time() - t0))
 for path in sorted(glob.glob(os.path.join(os.environ.get("MIK_MTX_DIR", "/nonexistent"), "*.mtx"))):
     t0 = time.time()
