@@ -121,6 +121,7 @@ int mik_spmv_long_segment(int *segment);
  *  23: 1 = CG updates x in the step's own sweep (read at mik_cg_create)      24: 1 = the halo of a row-partitioned CG step after the whole sweep over u
  *  25: 1 = the head of a plain CG step as ONE launch (k_cg_head_sdiab2; slower, see mik_cg_fused_x; read at mik_cg_create)
  *  26: cache-hint bits of that launch (8 = x streamed, 4 = u stored nt, 16 = c stored temporal; 0 = 8)
+ *  28: jagged slices (layout 1): 1 = never, 2 = whenever the operator has no structured layout (read at mik_csr_create)
  *  27: direction of the streaming launches of a plain CG step (bit 0 / 1 / 2: the u sweep / the SpMV / the update walk from
  *      the end of the vectors; 8: every launch against the one before it) -- no effect at the default cache hints */
 int mik_set_tuning(int key, int value);
@@ -156,8 +157,9 @@ int mik_csr_pack(mik_csr *A);
  * for an operator that runs on its CSR arrays. */
 int mik_csr_compact(mik_csr *A);
 /* Device layout mik_spmv uses for this operator (chosen at upload from the sparsity pattern; results are
- * bit-identical across layouts): 0 = CSR row-blocks (LDS-staged products; any matrix), 1 = sliced-ELL (256-row
- * slices stored column-major; near-uniform row lengths per slice), 2 = sliced-ELL values + 8-bit codes for the
+ * bit-identical across layouts): 0 = CSR row-blocks (LDS tile filled by LDS-DMA; product tile for uneven rows; any matrix),
+ * 1 = jagged slices (one row per lane, groups of 16 B / sizeof(T) consecutive entries stored lane-interleaved per 64-row
+ * slice: long near-uniform rows -- finite-element matrices), 2 = sliced-ELL values + 8-bit codes for the
  * (column - row) offsets (banded / stencil operators with <= 255 distinct offsets), 3 = dictionary-coded
  * (after mik_csr_pack), 4 = sliced-ELL values with per-slice offsets and one presence-mask byte per row (every
  * 256-row slice uses <= 8 distinct offsets: stencils on structured grids), 5 = the same with slice-CONSTANT slot values

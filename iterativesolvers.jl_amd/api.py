@@ -348,7 +348,7 @@ class HipCSR:
         y = HipVector(self.n_rows, self.dtype, self.ctx)
         return mul_(y, self, x)
 
-    LAYOUTS = ("csr-rowblock", "sliced-ell", "sliced-ell+8-bit-column-codes", "dictionary-coded", "sliced-ell+slice-offsets+row-masks",
+    LAYOUTS = ("csr-rowblock", "jagged-slices", "sliced-ell+8-bit-column-codes", "dictionary-coded", "sliced-ell+slice-offsets+row-masks",
                "slice-offsets+slice-values+row-masks")
 
     def layout(self) -> str:

@@ -10,6 +10,7 @@
 #include "mik_spmv.h"
 #include "mik_packed.h"
 #include "mik_sell.h"
+#include "mik_jds.h"
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -486,9 +487,11 @@ static int csr_build_sdia(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
 static int csr_build_sell(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowptr, const std::vector<int> &col, const std::vector<unsigned char> &v,
         size_t es, int64_t n_rows, int64_t n_cols, int64_t nnz, int max_row)
 {
+    // Sliced-ELL values + 8-bit column codes (k_spmv_sell8): slices padded to their longest row cost < 1/8 extra entries and
+    // the whole operator has at most 255 distinct (column - row) offsets.
     (void)n_cols;
     hipError_t e;
-    if (!A->sdia_val && !A->sdia_pats && A->n_long == 0 && n_rows > 0 && nnz > 0 && max_row <= 255 && g_mik_tuning[8] == 0)
+    if (!A->sdia_val && !A->sdia_pats && A->n_long == 0 && n_rows > 0 && nnz > 0 && max_row <= 255 && g_mik_tuning[8] == 0 && g_mik_tuning[10] == 0)
     {
         const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
         std::vector<int> sptr((size_t)nb + 1, 0);
@@ -501,42 +504,9 @@ static int csr_build_sell(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
             sptr[(size_t)b + 1] = (int)padded;
         }
         if (padded < INT32_MAX && padded <= nnz + nnz / 8 + 8 * MIK_BLOCK) {
-            std::vector<int> scol;
-            std::vector<unsigned char> sval, slen;
-            try {
-                scol.assign((size_t)padded, 0);
-                sval.assign((size_t)padded * es, 0);
-                slen.assign((size_t)n_rows, 0);
-            } catch (const std::bad_alloc &) {
-                return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host staging allocation failed (sliced-ELL form)");
-            }
-            for (int64_t r = 0; r < n_rows; ++r) {
-                const int64_t b = r / MIK_BLOCK, t = r % MIK_BLOCK;
-                const int len = rowptr[r + 1] - rowptr[r];
-                slen[(size_t)r] = (unsigned char)len;
-                for (int j = 0; j < len; ++j) {
-                    const size_t dst = (size_t)sptr[(size_t)b] + (size_t)j * MIK_BLOCK + (size_t)t;
-                    scol[dst] = col[(size_t)rowptr[r] + j];
-                    memcpy(&sval[dst * es], &v[((size_t)rowptr[r] + j) * es], es);
-                }
-            }
-            if ((e = hipMalloc((void **)&A->sell_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
-                (e = hipMalloc((void **)&A->sell_len, (size_t)n_rows)) != hipSuccess ||
-                (e = hipMalloc((void **)&A->sell_col, sizeof(int) * (size_t)padded)) != hipSuccess ||
-                (e = hipMalloc(&A->sell_val, es * (size_t)padded)) != hipSuccess ||
-                (e = hipMemcpy(A->sell_ptr, sptr.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice)) != hipSuccess ||
-                (e = hipMemcpy(A->sell_len, slen.data(), (size_t)n_rows, hipMemcpyHostToDevice)) != hipSuccess ||
-                (e = hipMemcpy(A->sell_col, scol.data(), sizeof(int) * (size_t)padded, hipMemcpyHostToDevice)) != hipSuccess ||
-                (e = hipMemcpy(A->sell_val, sval.data(), es * (size_t)padded, hipMemcpyHostToDevice)) != hipSuccess) {
-                return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: sliced-ELL form: %s", hipGetErrorString(e));
-            }
-            A->sell_entries = padded;
-            for (int64_t b = 0; b < nb; ++b) A->sell_maxw = std::max(A->sell_maxw, (sptr[(size_t)b + 1] - sptr[(size_t)b]) / MIK_BLOCK);
-
-            // 8-bit column codes (k_spmv_sell8): at most 255 distinct (column - row) offsets over the whole operator
             std::vector<int> tab;
             std::unordered_map<int, int> code_of;
-            bool ok = g_mik_tuning[10] == 0;
+            bool ok = true;
             for (int64_t r = 0; r < n_rows && ok; ++r)
                 for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
                     const int d = col[(size_t)k2] - (int)r;
@@ -546,37 +516,135 @@ static int csr_build_sell(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
                         tab.push_back(d);
                     }
                 }
-            if (ok) {
-                std::vector<int> cptr((size_t)nb + 1, 0);
-                int64_t cbytes = 0;
-                for (int64_t b = 0; b < nb; ++b) {
-                    const int w = (sptr[(size_t)b + 1] - sptr[(size_t)b]) / MIK_BLOCK;
-                    cbytes += (int64_t)((w + 7) / 8 * 8) * MIK_BLOCK;
-                    cptr[(size_t)b + 1] = (int)cbytes;
+            std::vector<int> cptr((size_t)nb + 1, 0);
+            int64_t cbytes = 0;
+            for (int64_t b = 0; b < nb && ok; ++b) {
+                const int w = (sptr[(size_t)b + 1] - sptr[(size_t)b]) / MIK_BLOCK;
+                cbytes += (int64_t)((w + 7) / 8 * 8) * MIK_BLOCK;
+                cptr[(size_t)b + 1] = (int)cbytes;
+            }
+            if (ok && cbytes < INT32_MAX) {
+                std::vector<unsigned char> sval, codes;
+                try {
+                    sval.assign((size_t)padded * es, 0);
+                    codes.assign((size_t)cbytes, 255);
+                } catch (const std::bad_alloc &) {
+                    return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host staging allocation failed (sliced-ELL form)");
                 }
-                if (cbytes < INT32_MAX) {
-                    std::vector<unsigned char> codes((size_t)cbytes, 255);
-                    for (int64_t r = 0; r < n_rows; ++r) {
-                        const int64_t b = r / MIK_BLOCK, t = r % MIK_BLOCK;
-                        const int w8 = (cptr[(size_t)b + 1] - cptr[(size_t)b]) / MIK_BLOCK;
-                        unsigned char *dst = &codes[(size_t)cptr[(size_t)b] + (size_t)t * w8];
-                        for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) dst[k2 - rowptr[r]] = (unsigned char)code_of[col[(size_t)k2] - (int)r];
+                for (int64_t r = 0; r < n_rows; ++r) {
+                    const int64_t b = r / MIK_BLOCK, t = r % MIK_BLOCK;
+                    const int len = rowptr[r + 1] - rowptr[r];
+                    for (int j = 0; j < len; ++j) {
+                        const size_t dst = (size_t)sptr[(size_t)b] + (size_t)j * MIK_BLOCK + (size_t)t;
+                        memcpy(&sval[dst * es], &v[((size_t)rowptr[r] + j) * es], es);
                     }
-                    tab.resize(256, 0);
-                    if ((e = hipMalloc((void **)&A->sell8_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
-                        (e = hipMalloc((void **)&A->sell8_codes, (size_t)cbytes + 8)) != hipSuccess ||
-                        (e = hipMalloc((void **)&A->sell8_tab, sizeof(int) * 256)) != hipSuccess ||
-                        (e = hipMemcpy(A->sell8_ptr, cptr.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice)) != hipSuccess ||
-                        (e = hipMemcpy(A->sell8_codes, codes.data(), (size_t)cbytes, hipMemcpyHostToDevice)) != hipSuccess ||
-                        (e = hipMemcpy(A->sell8_tab, tab.data(), sizeof(int) * 256, hipMemcpyHostToDevice)) != hipSuccess) {
-                        return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: column codes: %s", hipGetErrorString(e));
-                    }
-                    A->sell8_nd = (int)code_of.size();
-                    A->sell8_bytes = cbytes;
+                    const int w8 = (cptr[(size_t)b + 1] - cptr[(size_t)b]) / MIK_BLOCK;
+                    unsigned char *dstc = &codes[(size_t)cptr[(size_t)b] + (size_t)t * w8];
+                    for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) dstc[k2 - rowptr[r]] = (unsigned char)code_of[col[(size_t)k2] - (int)r];
                 }
+                tab.resize(256, 0);
+                if ((e = hipMalloc((void **)&A->sell_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
+                    (e = hipMalloc(&A->sell_val, es * (size_t)padded)) != hipSuccess ||
+                    (e = hipMalloc((void **)&A->sell8_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
+                    (e = hipMalloc((void **)&A->sell8_codes, (size_t)cbytes + 8)) != hipSuccess ||
+                    (e = hipMalloc((void **)&A->sell8_tab, sizeof(int) * 256)) != hipSuccess ||
+                    (e = hipMemcpy(A->sell_ptr, sptr.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice)) != hipSuccess ||
+                    (e = hipMemcpy(A->sell_val, sval.data(), es * (size_t)padded, hipMemcpyHostToDevice)) != hipSuccess ||
+                    (e = hipMemcpy(A->sell8_ptr, cptr.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice)) != hipSuccess ||
+                    (e = hipMemcpy(A->sell8_codes, codes.data(), (size_t)cbytes, hipMemcpyHostToDevice)) != hipSuccess ||
+                    (e = hipMemcpy(A->sell8_tab, tab.data(), sizeof(int) * 256, hipMemcpyHostToDevice)) != hipSuccess) {
+                    return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: sliced-ELL form: %s", hipGetErrorString(e));
+                }
+                A->sell_entries = padded;
+                for (int64_t b = 0; b < nb; ++b) A->sell_maxw = std::max(A->sell_maxw, (sptr[(size_t)b + 1] - sptr[(size_t)b]) / MIK_BLOCK);
+                A->sell8_nd = (int)code_of.size();
+                A->sell8_bytes = cbytes;
             }
         }
     }
+    return MIK_OK;
+}
+
+// Jagged slices (csrc/mik_jds.h) from the SHORT part of the CSR arrays (split-off long rows have no entries there; `is_long`
+// marks them).  Built when no structured layout applies, every wave's lanes stay busy in the natural row order (wave
+// iterations within 25 % of the ideal: near-uniform rows) and either the rows are long (more than 32 entries somewhere) or the
+// group padding costs < 10 % of the CSR bytes.  Short rows with padding stay with the LDS-DMA tile, uneven rows with the
+// product tile (mik_spmv.h).
+static int csr_build_jds(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowptr, const std::vector<int> &col, const std::vector<unsigned char> &v,
+                         size_t es, int64_t n_rows, const unsigned char *is_long)
+{
+    if (A->sdia_val || A->sdia_pats || A->sell8_codes || n_rows <= 0 || g_mik_tuning[8] != 0 || g_mik_tuning[28] == 1) return MIK_OK;   // development knob 28: 1 = never, 2 = whenever possible
+    const int W = (int)(16 / es);
+    const int64_t short_nnz = rowptr[(size_t)n_rows];
+    if (short_nnz <= 0) return MIK_OK;
+    auto glen = [&](int64_t r) { return (rowptr[(size_t)r + 1] - rowptr[(size_t)r] + W - 1) / W; };
+    const int64_t nsl = (n_rows + 63) / 64;
+    int64_t groups = 0, iters = 0;                              // iters: every slice runs as long as its longest row
+    int maxlen = 0;
+    for (int64_t s = 0; s < nsl; ++s) {
+        int m = 0;
+        for (int64_t r = s * 64; r < std::min<int64_t>(s * 64 + 64, n_rows); ++r) {
+            groups += glen(r);
+            m = std::max(m, glen(r));
+            maxlen = std::max(maxlen, rowptr[(size_t)r + 1] - rowptr[(size_t)r]);
+        }
+        iters += m;
+    }
+    if (maxlen >= MIK_JDS_LONG || groups * W >= INT32_MAX) return MIK_OK;
+    const int64_t jds_bytes = groups * W * (int64_t)(es + 4) + 2 * n_rows, csr_bytes = short_nnz * (int64_t)(es + 4) + 4 * n_rows;
+    if (g_mik_tuning[28] != 2 && !(iters * 64 * 4 <= groups * 5 && (maxlen > 32 || jds_bytes * 10 <= csr_bytes * 11))) return MIK_OK;
+    std::vector<int> jptr, jcol;
+    std::vector<unsigned short> jlen;
+    std::vector<unsigned char> jval;
+    try {
+        jptr.assign((size_t)nsl + 8, 0);
+        jlen.assign((size_t)n_rows, 0);
+        jcol.assign((size_t)groups * W, 0);
+        jval.assign((size_t)groups * W * es, 0);
+    } catch (const std::bad_alloc &) {
+        return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host staging allocation failed (jagged slices)");
+    }
+    int64_t cur = 0;
+    for (int64_t s = 0; s < nsl; ++s) {
+        jptr[(size_t)s] = (int)cur;
+        const int64_t p0 = s * 64, p1 = std::min<int64_t>(p0 + 64, n_rows);
+        int m = 0;
+        for (int64_t r = p0; r < p1; ++r) m = std::max(m, glen(r));
+        for (int g = 0; g < m; ++g)
+            for (int64_t r = p0; r < p1; ++r) {
+                const int k0 = rowptr[(size_t)r], len = rowptr[(size_t)r + 1] - k0;
+                if (g * W >= len) continue;
+                for (int e = 0; e < W; ++e) {
+                    const int j = g * W + e;
+                    const size_t dst = (size_t)cur * W + e;
+                    if (j < len) {
+                        jcol[dst] = col[(size_t)k0 + j];
+                        memcpy(&jval[dst * es], &v[((size_t)k0 + j) * es], es);
+                    } else {
+                        jcol[dst] = col[(size_t)k0 + len - 1];           // padding: the row's last real column, value 0, never added
+                    }
+                }
+                ++cur;
+            }
+    }
+    for (size_t q = (size_t)nsl; q < jptr.size(); ++q) jptr[q] = (int)cur;     // the waves of the last workgroup beyond the last slice
+    for (int64_t r = 0; r < n_rows; ++r)
+        jlen[(size_t)r] = (is_long && is_long[r]) ? (unsigned short)MIK_JDS_LONG : (unsigned short)(rowptr[(size_t)r + 1] - rowptr[(size_t)r]);
+    hipError_t e;
+    const size_t pad = 64 * MIK_JDS_U * (size_t)W;         // lanes without a group read (and gather through) the tail: zero columns
+    if ((e = hipMalloc((void **)&A->jds_ptr, sizeof(int) * jptr.size())) != hipSuccess ||
+        (e = hipMalloc((void **)&A->jds_len, sizeof(unsigned short) * (size_t)n_rows)) != hipSuccess ||
+        (e = hipMalloc((void **)&A->jds_col, sizeof(int) * ((size_t)groups * W + pad))) != hipSuccess ||
+        (e = hipMalloc(&A->jds_val, es * ((size_t)groups * W + pad))) != hipSuccess ||
+        (e = hipMemcpy(A->jds_ptr, jptr.data(), sizeof(int) * jptr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(A->jds_len, jlen.data(), sizeof(unsigned short) * (size_t)n_rows, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemset(A->jds_col + (size_t)groups * W, 0, sizeof(int) * pad)) != hipSuccess ||
+        (e = hipMemset((unsigned char *)A->jds_val + es * (size_t)groups * W, 0, es * pad)) != hipSuccess ||
+        (e = hipMemcpy(A->jds_col, jcol.data(), sizeof(int) * (size_t)groups * W, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(A->jds_val, jval.data(), es * (size_t)groups * W, hipMemcpyHostToDevice)) != hipSuccess)
+        return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: jagged slices: %s", hipGetErrorString(e));
+    A->jds_groups = groups;
+    A->jds_short_nnz = short_nnz;
     return MIK_OK;
 }
 
@@ -679,6 +747,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
                 return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create: reading the device CSR back failed");
             }
             rc = csr_build_sell(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz, A->max_row_nnz);
+            if (rc == MIK_OK) rc = csr_build_jds(ctx, A, rowptr, col, v, es, n_rows, nullptr);
         }
         if (rc == MIK_OK) { *out = A; return MIK_OK; }
         mik_csr_destroy(A);
@@ -858,6 +927,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
     // device layouts for banded / stencil operators (see the two builders above)
     int rc_layout = csr_build_sdia(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz, max_row);
     if (rc_layout == MIK_OK) rc_layout = csr_build_sell(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz, max_row);
+    if (rc_layout == MIK_OK) rc_layout = csr_build_jds(ctx, A, rowptr, col, v, es, n_rows, is_long.empty() ? nullptr : is_long.data());
     if (rc_layout != MIK_OK) { cleanup(); return rc_layout; }
     *out = A;
     return MIK_OK;
@@ -885,8 +955,10 @@ extern "C" int mik_csr_destroy(mik_csr *A)
     if (A->sell8_codes) (void)hipFree(A->sell8_codes);
     if (A->sell8_tab) (void)hipFree(A->sell8_tab);
     if (A->sell_ptr) (void)hipFree(A->sell_ptr);
-    if (A->sell_len) (void)hipFree(A->sell_len);
-    if (A->sell_col) (void)hipFree(A->sell_col);
+    if (A->jds_ptr) (void)hipFree(A->jds_ptr);
+    if (A->jds_len) (void)hipFree(A->jds_len);
+    if (A->jds_col) (void)hipFree(A->jds_col);
+    if (A->jds_val) (void)hipFree(A->jds_val);
     if (A->sell_val) (void)hipFree(A->sell_val);
     if (A->codes) (void)hipFree(A->codes);
     if (A->vtab) (void)hipFree(A->vtab);
@@ -986,7 +1058,8 @@ extern "C" int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes)
     case 4: *bytes = A->sdia_entries * es + A->n_rows + nb * 36; break;
     case 3: *bytes = A->nnz * 2 + (A->n_rows + 1) * 4 + 256 * (es + 4); break;
     case 2: *bytes = A->sell_entries * es + A->sell8_bytes + (nb + 1) * 8 + 256 * 4; break;
-    case 1: *bytes = A->sell_entries * (es + 4) + A->n_rows + (nb + 1) * 4; break;
+    case 1: *bytes = A->jds_groups * (16 / es) * (es + 4) + A->n_rows * 2 + ((A->n_rows + 63) / 64 + 1) * 4 +
+                     (A->n_long ? (A->nnz - A->jds_short_nnz) * (es + 4) + 12LL * A->n_long + 4LL * A->n_seg + 16LL * A->n_cut : 0); break;
     default: *bytes = A->nnz * (es + 4) + (A->n_rows + 1) * 4 + (A->n_long ? A->n_rows + 12LL * A->n_long + 4LL * A->n_seg + 16LL * A->n_cut : 0); break;
     }
     return MIK_OK;
@@ -1020,7 +1093,7 @@ static int spmv_kernel_choice(const mik_csr *A)
         if (A->sdia_pats && (g_mik_tuning[12] == 0 || !csr)) return 5;
         if (A->sdia_val && (g_mik_tuning[12] == 0 || !csr)) return 4;
         if (A->sell8_codes && (g_mik_tuning[10] == 0 || !csr)) return 2;
-        if (A->sell_val) return 1;
+        if (A->jds_val && g_mik_tuning[28] != 1) return 1;
     }
     return 0;
 }
@@ -1031,7 +1104,7 @@ extern "C" int mik_csr_compact(mik_csr *A)
 {
     if (!A) return MIK_ERR_INVALID;
     if (!A->col) return MIK_OK;
-    if (!(A->sdia_pats || A->sdia_val || A->sell8_codes || A->sell_val) || A->n_long)
+    if (!(A->sdia_pats || A->sdia_val || A->sell8_codes || A->jds_val) || A->n_long)
         return mik_fail(A->ctx, MIK_ERR_NOTIMPL, "mik_csr_compact: this operator runs on its CSR arrays");
     if (A->ctx) { (void)hipSetDevice(A->ctx->device); (void)hipStreamSynchronize(A->ctx->stream); }
     if (A->packed) {                                        // the dictionary-coded form reads rowptr: drop it instead
@@ -1070,7 +1143,7 @@ extern "C" int mik_spmv_kernel(const mik_csr *A, char *name, int len)
     case 4: k = "k_spmv_sdia"; break;
     case 3: k = "k_spmv_packed"; break;
     case 2: k = "k_spmv_sell8"; break;
-    case 1: k = "k_spmv_sell"; break;
+    case 1: k = "k_spmv_jds"; break;
     default: k = spmv_csr_rowgather(A) ? "k_spmv_rowgather" : "k_spmv_rowblock"; break;
     }
     snprintf(name, (size_t)len, "%s", k);
@@ -1085,6 +1158,7 @@ bool mik_spmv_can_split(const mik_csr *A)
     const int kc = spmv_kernel_choice(A);
     if (kc == 3) return false;
     if (kc == 0) return spmv_csr_rowgather(A) && A->n_long == 0;
+    if (kc == 1) return A->n_long == 0;
     return true;
 }
 
@@ -1279,17 +1353,6 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     }
-    if (choice == 1) {
-        // sliced-ELL form (mik_sell.h): coalesced streams, per-thread row sums, no LDS
-#define MIK_SELL_GO(FD, NTV)                                                                                                   \
-    hipLaunchKernelGGL((k_spmv_sell<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, rb0, nb, map_mode, A->sell_ptr, A->sell_len, \
-                       A->sell_col, (const T *)A->sell_val, x, y, seg_out, done)
-        if (fuse_dot) { if (nt) MIK_SELL_GO(true, true); else MIK_SELL_GO(true, false); }
-        else          { if (nt) MIK_SELL_GO(false, true); else MIK_SELL_GO(false, false); }
-#undef MIK_SELL_GO
-        MIK_LAUNCH_CHECK(ctx);
-        return MIK_OK;
-    }
     const int nlong = A->n_long;
     const int nbig = A->n_long_big;
     LongTab lt{};
@@ -1303,6 +1366,31 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
     }
     const int nwaves_long = nbig + (nlong - nbig + MIK_LONG_R - 1) / MIK_LONG_R;   // one wave per big row, MIK_LONG_R medium rows per wave
     const int nlb = (nwaves_long + 3) / 4;
+    if (choice == 1) {
+        // jagged slices (mik_jds.h): one row per lane, 16-byte operator streams; the workgroups of split-off long rows lead the same
+        // launch.  dot(x, y) is formed inside unless long rows exist (their sums arrive from other workgroups): then by k_rowdot.
+        using IV = typename WideVec<T>::idx;
+        using VV = typename WideVec<T>::val;
+        const bool inside = fuse_dot && nlong == 0;
+#define MIK_JDS_GO(FD, NTV, MG)                                                                                                        \
+    hipLaunchKernelGGL((k_spmv_jds<T, FD, NTV, MG>), dim3(nb + (MG ? nlb : 0)), dim3(MIK_BLOCK), 0, ctx->stream, n, rb0, A->jds_ptr, A->jds_len, \
+                       (const IV *)A->jds_col, (const VV *)A->jds_val, x, y, seg_out, done, nlb, lt, A->col, (const T *)A->val)
+#define MIK_JDS_GO2(NTV)                                                                      \
+    do {                                                                                      \
+        if (inside) MIK_JDS_GO(true, NTV, false);                                             \
+        else if (nlong) MIK_JDS_GO(false, NTV, true);                                         \
+        else MIK_JDS_GO(false, NTV, false);                                                   \
+    } while (0)
+        if (nt) MIK_JDS_GO2(true); else MIK_JDS_GO2(false);
+#undef MIK_JDS_GO2
+#undef MIK_JDS_GO
+        MIK_LAUNCH_CHECK(ctx);
+        if (fuse_dot && !inside) {
+            hipLaunchKernelGGL((k_rowdot<T>), dim3(nb_all), dim3(MIK_BLOCK), 0, ctx->stream, n, x, (const T *)y, seg_out, done);
+            MIK_LAUNCH_CHECK(ctx);
+        }
+        return MIK_OK;
+    }
     // CSR kernels.  k_spmv_rowgather (row-block tile filled by LDS-DMA, per-row gather) unless the operator has split-off
     // long rows: then k_spmv_rowblock, whose launch carries the long-row workgroups along (one launch instead of two:
     // 180 vs 196 us on the random configs[4] stand-in, 107 vs 121 us on the banded one).  tuning[14]: 0 = that rule,

@@ -18,7 +18,7 @@ constexpr int MIK_RED_L = 2;         // 16-byte loads per thread per segment
 constexpr int MIK_FIN_THREADS = 1024;
 constexpr int MIK_SPMV_TILE = 2048;  // nnz staged in LDS per row-block pass
 constexpr int MIK_SPMV_G = 1;        // row-blocks per SpMV workgroup (= L of the fused-dot tree); >1 measured slower
-constexpr int MIK_LONG_ROW = 64;       // rows with more entries go to the wave-per-row kernel (wave-shaped row sum)
+constexpr int MIK_LONG_ROW = 256;      // rows with more entries go to the wave-per-row kernel (wave-shaped row sum)
 constexpr int MIK_MAX_GRID = 256 * 8 * 4;
 
 template <typename T> struct VT;
@@ -60,10 +60,15 @@ struct mik_csr {
     int n_seg = 0, n_cut = 0;        // rows longer than MIK_LONG_SEG are cut into n_seg segments (csrc/mik_spmv.h)
     void *seg_sum = nullptr;         // device: one partial per segment
     unsigned char *is_long = nullptr;   // device: n_rows flags (only when n_long > 0)
-    // sliced-ELL form (csrc/mik_sell.h), built at upload for operators with near-uniform row lengths per block
+    // jagged slices (csrc/mik_jds.h): operators with long near-uniform rows (finite elements)
+    int *jds_ptr = nullptr;          // device, slices + 1: first group of every 64-row slice
+    unsigned short *jds_len = nullptr;   // device, n_rows: entries of every row (MIK_JDS_LONG: a split-off long row)
+    int *jds_col = nullptr;          // device, groups * W columns
+    void *jds_val = nullptr;         // device, groups * W values
+    int64_t jds_groups = 0;          // groups of W = 16 B / sizeof(T) entries
+    int64_t jds_short_nnz = 0;       // entries held by the slices (the rest: split-off long rows)
+    // sliced-ELL values (csrc/mik_sell.h), the value side of the 8-bit column codes below
     int *sell_ptr = nullptr;         // device, nb + 1: entry offset of every 256-row slice
-    unsigned char *sell_len = nullptr;   // device, n_rows: entries of every row
-    int *sell_col = nullptr;         // device, padded entries, column-major inside a slice
     void *sell_val = nullptr;
     int64_t sell_entries = 0;
     // 8-bit column codes for the sliced-ELL form (<= 255 distinct column - row offsets)

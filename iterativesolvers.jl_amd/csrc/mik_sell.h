@@ -1,22 +1,15 @@
-// mik_sell.h -- sliced-ELL device layout of the operator (slice = one 256-row block) and its SpMV kernel.
+// mik_sell.h -- sliced device layouts of banded / stencil operators (slice = one 256-row block) and their SpMV kernels:
+//               sliced-ELL values + 8-bit column codes (k_spmv_sell8), per-slice offsets + row masks (k_spmv_sdia), and the
+//               slice-constant forms (k_spmv_sdiab, k_spmv_sdiab2).  Long near-uniform rows: mik_jds.h.
 //
-// mul!(y, A, x) for operators whose rows within a 256-row block have similar lengths (stencils, banded
-// matrices).  mik_csr_create re-lays the CSR out per row-block in COLUMN-MAJOR slices: entry j of the block's
-// 256 rows is contiguous, so thread t (= row r0 + t) streams val[base + 256 j + t], col[base + 256 j + t] with
-// fully coalesced loads, the gather x[col] is contiguous across the wave whenever neighbouring rows reference
-// neighbouring columns, and every thread adds its own row's products in ascending column order from +0 --
-// exactly the order Julia's CSC column scatter reaches that row (SparseArrays mul!, called at src/cg.jl:54,
-// src/gmres.jl:287), i.e. bit-identical to the row-block CSR kernel (mik_spmv.h), with no LDS staging and no
-// barrier.  Slices are padded to the block's longest row (padding entries are never added: j < len[row]); the
-// layout is only built when padding stays below ~12 % and no row was split off as "long" (mik_csr_create).
-//
-// Measured and dropped (256^3 fp64, same results): two rows per thread with 16-byte value loads (284.7 vs 284.6 us:
-// the kernel is not instruction-bound), and workgroups that walk G = 2 / 4 / 8 slices with the next slice's codes
-// prefetched (251 / 262 / 265 vs 248 us: as for the CSR kernel, many short workgroups at full occupancy beat
-// fewer software-pipelined ones).
-//
-// Bytes per launch vs CSR: no row pointer (4 B/row) but one length byte per row and the padding
-// (256^3 Laplacian: +0.6 % entries) -- ~1.70 GB instead of 1.74 GB.
+// mul!(y, A, x) (SparseArrays mul!, called at src/cg.jl:54, src/gmres.jl:287).  mik_csr_create re-lays the CSR out per row-block
+// in COLUMN-MAJOR slices: entry j of the block's 256 rows is contiguous, so thread t (= row r0 + t) streams
+// val[base + 256 j + t] with fully coalesced loads, the gather of x is contiguous across the wave whenever neighbouring rows
+// reference neighbouring columns, and every thread adds its own row's products in ascending column order from +0 -- exactly
+// the order Julia's CSC column scatter reaches that row, i.e. bit-identical to the row-block CSR kernels (mik_spmv.h), with
+// no LDS staging and no barrier.  Slices are padded to the block's longest row (padding entries are never added); the
+// layouts are only built when padding stays below ~12 % and no row was split off as "long" (mik_csr_create).
+// (Round 1's plain sliced-ELL kernel with 4-byte columns was superseded by the jagged slices of mik_jds.h in round 3.)
 #ifndef MIK_SELL_H
 #define MIK_SELL_H
 
@@ -24,58 +17,6 @@
 #include "mik_spmv.h"
 
 #ifdef __HIPCC__
-
-constexpr int MIK_SELL_U = 8;     // entries per thread in flight per pass (7-point stencil: one pass)
-
-template <typename T, bool FUSE_DOT, bool NT>
-__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sell(int n, int rb0, int nb, int map_mode, const int *__restrict__ blkptr,
-                                                         const unsigned char *__restrict__ rlen, const int *__restrict__ col,
-                                                         const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y,
-                                                         T *__restrict__ seg_out, const int *__restrict__ done)
-{
-    if (done && *done) return;
-    constexpr int U = MIK_SELL_U;
-    __shared__ T lds4[4];
-    const int t = threadIdx.x;
-    const int rb = rb0 + spmv_block_map((int)blockIdx.x, nb, map_mode);   // this launch covers row-blocks [rb0, rb0 + nb)
-    const int r = rb * MIK_BLOCK + t;
-    const int base = blkptr[rb];
-    const int width = (blkptr[rb + 1] - base) / MIK_BLOCK;     // longest row of this block
-    const int len = r < n ? (int)rlen[r] : 0;
-    const T *__restrict__ vp = val + base + t;
-    const int *__restrict__ cp = col + base + t;
-
-    T acc = T(0);
-    for (int j0 = 0; j0 < width; j0 += U) {
-        T v[U];
-        int c[U];
-#pragma unroll
-        for (int q = 0; q < U; ++q) {
-            v[q] = T(0);
-            c[q] = 0;
-            if (j0 + q < width) {                                // slice-uniform: no loads for slots past the slice's width
-                v[q] = ld_stream<NT>(vp + (size_t)(j0 + q) * MIK_BLOCK);
-                c[q] = ld_stream<NT>(cp + (size_t)(j0 + q) * MIK_BLOCK);
-            }
-        }
-        T xv[U];
-#pragma unroll
-        for (int q = 0; q < U; ++q) {
-            xv[q] = T(0);
-            if (j0 + q < width) xv[q] = x[c[q]];
-        }
-#pragma unroll
-        for (int q = 0; q < U; ++q)
-            if (j0 + q < len) { T p = v[q] * xv[q]; acc = acc + p; }
-    }
-    if (r < n) st_stream<NT>(y + r, acc);
-    if (FUSE_DOT) {
-        T p = T(0);
-        if (r < n) p = x[r] * acc;
-        T tot = block_tree_256(p, lds4);
-        if (t == 0) seg_out[rb] = tot;
-    }
-}
 
 // Sliced-ELL with 8-bit column codes.  For banded / stencil operators the difference (column - row) takes few
 // distinct values over the whole matrix; when there are at most 255 of them, every stored entry keeps its full

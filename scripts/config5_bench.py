@@ -26,6 +26,8 @@ for kind in kinds:
     t0 = time.time()
     if kind == "fe_shell":      # the shape of s3dkq4m2 (benchmark/matrixmarket.jl:5): 6 unknowns per node, 9-node neighbourhoods
         n, rowptr, colidx, val = pkg.fixtures.fe_matrix((123, 123), 6, np.float32)
+    elif kind == "stencil27":   # 27-point variable-coefficient stencil on 128^3, fp64, lexicographic numbering: qualifies for the 8-bit column codes
+        n, rowptr, colidx, val = pkg.fixtures.fe_matrix((128, 128, 128), 1, np.float64, renumber=False)
     elif kind == "fe_hex":      # 3 unknowns per node, 27-node neighbourhoods, larger than the Infinity Cache
         n, rowptr, colidx, val = pkg.fixtures.fe_matrix((64, 64, 64), 3, np.float32)
     else:
@@ -45,10 +47,14 @@ for kind, n, rowptr, colidx, val, tgen in cases:
     rb = np.add.reduceat(lens, np.arange(0, n, 256))
     print(f"== {kind}: n {n} nnz {val.size} generated/read in {tgen:.1f} s; row length min {lens.min()} median {int(np.median(lens))} "
           f"mean {lens.mean():.1f} max {lens.max()}; rows > 64: {(lens > 64).sum()}; nnz per 256-row block max/mean {rb.max() / rb.mean():.2f}")
-    b = pkg.HipVector.from_numpy(pkg.fixtures.hashed_rhs(n, dtype=np.float32))
-    y = pkg.HipVector(n, np.float32)
-    for variant, name in ((2, "k_spmv_rowgather (LDS-DMA tile, row gather) + k_spmv_longrows"), (1, "k_spmv_rowblock (products, long rows merged)")):
-        L.mik_set_tuning(14, variant)
+    b = pkg.HipVector.from_numpy(pkg.fixtures.hashed_rhs(n, dtype=val.dtype))
+    y = pkg.HipVector(n, val.dtype)
+    extra = {int(a.split("=")[0]): int(a.split("=")[1]) for a in os.environ.get("MIK_KNOBS", "").split(",") if a}     # development knobs for A/B runs
+    for knobs, name in ((extra, "default layout" + (f" + knobs {extra}" if extra else "")), ({28: 1, 14: 1}, "CSR only: k_spmv_rowblock (products in LDS, long rows merged)")):
+        if knobs is not extra and os.environ.get("CSR", "1") != "1":
+            continue
+        for k, vv in knobs.items():
+            L.mik_set_tuning(k, vv)
         t0 = time.time()
         A = pkg.HipCSR(n, n, rowptr, colidx, val, index_base=0, is_csc=False)
         tup = time.time() - t0
@@ -57,9 +63,9 @@ for kind, n, rowptr, colidx, val, tgen in cases:
         A.time_spmv(b, y, reps=3, fused_dot=True)
         msf = A.time_spmv(b, y, reps=20, fused_dot=True)
         ab = A.spmv_algorithmic_bytes()
-        print(f"   {name}: layout {A.layout()}  SpMV {ms * 1e3:7.1f} us = {ab / ms / 1e6:6.0f} GB/s of {ab / 1e6:.0f} MB algorithmic "
-              f"({ab / ms / 1e6 / 8000:.3f} of 8 TB/s); with the fused dot {msf * 1e3:7.1f} us; upload {tup:.1f} s")
-        if variant == 1 and os.environ.get("GMRES", "1") == "1":
+        print(f"   {name}: layout {A.layout()} kernel {A.spmv_kernel()}  SpMV {ms * 1e3:7.1f} us = {ab / ms / 1e6:6.0f} GB/s of {ab / 1e6:.0f} MB algorithmic "
+              f"({ab / ms / 1e6 / 8000:.3f} of 8 TB/s; stored {A.spmv_stored_bytes() / 1e6:.0f} MB); with dot(x, y) {msf * 1e3:7.1f} us; upload {tup:.1f} s")
+        if knobs is extra and os.environ.get("GMRES", "1") == "1":
             for oname, M in (("mgs", pkg.ModifiedGramSchmidt()), ("cgs", pkg.ClassicalGramSchmidt())):
                 pkg.gmres(A, b, restart=50, orth_meth=M, maxiter=60)
                 pkg.default_context().synchronize()
@@ -70,4 +76,5 @@ for kind, n, rowptr, colidx, val, tgen in cases:
                 print(f"   gmres fp32 restart=50 {oname}: iters {ch.iters} converged {ch.isconverged} {dt * 1e3:.1f} ms  "
                       f"{dt / max(ch.iters, 1) * 1e6:.1f} us/inner-iteration  final rel {ch['resnorm'][-1] / ch['resnorm'][0]:.2e}")
         del A
-    L.mik_set_tuning(14, 0)
+        for k in knobs:
+            L.mik_set_tuning(k, 0)

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 # knob 14 selects the CSR kernel: 0 = tile filled by LDS-DMA + per-row gather (k_spmv_rowgather, default), 1 = products
 # staged through registers (k_spmv_rowblock)
 FORMS = {"csr-rowblock": {8: 1}, "csr-rowblock/products": {8: 1, 14: 1},
-         "sliced-ell": {10: 1, 12: 1}, "sliced-ell+8-bit-column-codes": {12: 1}, "sliced-ell+slice-offsets+row-masks": {11: 1}, "best": {},
+         "jagged-slices": {10: 1, 12: 1, 28: 2}, "sliced-ell+8-bit-column-codes": {12: 1}, "sliced-ell+slice-offsets+row-masks": {11: 1}, "best": {},
          # the kernels of the slice-constant layout: flat loads, buffer loads slot by slot, 1 / 4 slices per workgroup
          "best/flat-loads": {17: 1}, "best/slot-by-slot": {18: 1}, "best/1-slice": {16: 1}, "best/4-slices": {16: 4}, "best/flat-4": {17: 1, 16: 4}}
 
@@ -70,9 +70,21 @@ def test_spmv_and_cg_identical_in_every_layout(pkg, orc, ctx, case, dtype):
 
 
 def test_layout_choice_follows_the_pattern(pkg, orc, ctx):
-    # irregular row lengths (padding > 1/8): stays CSR;  > 255 distinct offsets: sliced-ELL without codes
+    # uneven row lengths (5-200): the CSR product tile;  even rows with > 255 distinct offsets and no group padding: jagged
+    # slices;  short rows whose group padding costs > 10 %: the CSR tile;  finite-element rows (24-54 entries): jagged slices
     n, rowptr, colidx, val = pkg.fixtures.irregular_matrix(20000, np.float32, long_rows=False)
     assert pkg.HipCSR(n, n, rowptr, colidx, val, index_base=0, is_csc=False).layout() == "csr-rowblock"
+    for dt in (np.float32, np.float64):
+        nf, rp, ci, vv = pkg.fixtures.fe_matrix((21, 17), 6, dt)
+        dF = pkg.HipCSR(nf, nf, rp, ci, vv, index_base=0, is_csc=False)
+        assert dF.layout() == "jagged-slices" and dF.spmv_kernel() == "k_spmv_jds"
+        xf = np.random.default_rng(3).standard_normal(nf).astype(dt)
+        F = orc.CSC.from_scipy(sp.csr_matrix((vv, ci, rp), shape=(nf, nf)).tocsc())
+        assert np.array_equal(pkg.mul_(pkg.HipVector(nf, dt), dF, pkg.HipVector.from_numpy(xf)).to_numpy(), orc.spmv(F, xf))
+        bf = orc.hashed_rhs(nf).astype(dt)
+        xs, ch = pkg.cg(dF, pkg.HipVector.from_numpy(bf), log=True)           # SPD: cg! converges; dot(u, c) formed inside k_spmv_jds
+        xo, ho = orc.cg(F, bf, mode="tree", shape=ctx.cg_shape(dt))
+        assert ch.isconverged and np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(xs.to_numpy(), xo)
     rng = np.random.default_rng(0)
     n = 4096
     cols = (np.arange(n)[:, None] + rng.integers(-1500, 1500, size=(n, 6))) % n     # 6 entries per row, ~3000 distinct offsets
@@ -80,8 +92,15 @@ def test_layout_choice_follows_the_pattern(pkg, orc, ctx):
     S.sum_duplicates()
     A = orc.CSC.from_scipy(S.tocsc())
     dA = upload(pkg, A)
-    assert dA.layout() == "sliced-ell"
+    assert dA.layout() == "jagged-slices"
     x = rng.standard_normal(n)
+    assert np.array_equal(pkg.mul_(pkg.HipVector(n), dA, pkg.HipVector.from_numpy(x)).to_numpy(), orc.spmv(A, x))
+    cols = (np.arange(n)[:, None] + np.sort(rng.choice(3000, size=(n, 3)), axis=1) + 1) % n            # 3 entries per row: 33 % padding in fp64
+    S = sp.csr_matrix((rng.standard_normal(3 * n), cols.ravel(), np.arange(0, 3 * n + 1, 3)), shape=(n, n))
+    S.sum_duplicates()
+    A = orc.CSC.from_scipy(S.tocsc())
+    dA = upload(pkg, A)
+    assert dA.layout() == "csr-rowblock"
     assert np.array_equal(pkg.mul_(pkg.HipVector(n), dA, pkg.HipVector.from_numpy(x)).to_numpy(), orc.spmv(A, x))
     # empty rows, a slice of empty rows, an empty last slice
     D = sp.lil_matrix((1000, 1000))
@@ -115,7 +134,8 @@ def test_rectangular_block_with_halo_columns(pkg, orc, ctx, dist):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_csr_kernel_variants_on_ragged_rows(pkg, orc, ctx, dtype):
     """rows of 0..64 entries (several LDS passes per wave, even and odd lengths, empty rows, a ragged last block):
-    every CSR kernel variant returns the oracle's bits, with and without the fused dot"""
+    every CSR kernel variant and the jagged slices (forced: their lanes idle on such uneven rows) return the oracle's bits,
+    with and without the fused dot"""
     rng = np.random.default_rng(5)
     n = 5 * 256 + 77
     lens = rng.integers(0, 65, size=n)
@@ -130,15 +150,15 @@ def test_csr_kernel_variants_on_ragged_rows(pkg, orc, ctx, dtype):
     want = orc.spmv(A, x)
     b = orc.hashed_rhs(n).astype(dtype)
     ref = None
-    for variant in (0, 1):
+    for variant in (0, 1, "jagged-slices"):
         def run():
             dA = pkg.HipCSR(n, n, rowptr, cols, val, index_base=0, is_csc=False)
-            assert dA.layout() == "csr-rowblock"
+            assert dA.layout() == ("csr-rowblock" if variant != "jagged-slices" else variant)
             y = pkg.mul_(pkg.HipVector(n, dtype), dA, pkg.HipVector.from_numpy(x)).to_numpy()
             # 3 CG steps exercise the fused-dot epilogue (the matrix is not SPD; only the bits matter)
             xs, ch = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True, maxiter=3)
             return y, ch["resnorm"], xs.to_numpy()
-        y, res, xs = with_knobs(pkg, {8: 1, 14: variant}, run)
+        y, res, xs = with_knobs(pkg, {8: 1, 14: variant} if variant != "jagged-slices" else {28: 2}, run)
         assert np.array_equal(y, want), variant
         if ref is None:
             ref = (res, xs)

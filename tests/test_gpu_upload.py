@@ -183,6 +183,12 @@ def test_compact_releases_the_csr_arrays(pkg, orc, ctx):
     xs, ch = pkg.cg(dA, pkg.HipVector.from_numpy(orc.hashed_rhs(A.n)), log=True)
     assert ch.isconverged
     # an operator that runs on its CSR arrays keeps them
-    n, rowptr, colidx, val = pkg.fixtures.irregular_matrix(3000, np.float64, long_rows=False)
-    dB = pkg.HipCSR(n, n, rowptr, colidx, val, index_base=0, is_csc=False)
-    assert dB.layout() == "csr-rowblock" and dB.compact() is False
+    rng = np.random.default_rng(4)
+    n = 3000
+    colidx = ((np.arange(n)[:, None] + np.sort(rng.choice(2000, size=(n, 3)), axis=1) + 1) % n)
+    colidx.sort(axis=1)
+    keep = np.ones(colidx.shape, bool)
+    keep[:, 1:] = colidx[:, 1:] != colidx[:, :-1]
+    rowptr = np.concatenate([[0], np.cumsum(keep.sum(axis=1))]).astype(np.int64)
+    dB = pkg.HipCSR(n, n, rowptr, colidx[keep].astype(np.int64), rng.standard_normal(int(keep.sum())), index_base=0, is_csc=False)
+    assert dB.layout() == "csr-rowblock" and dB.compact() is False                 # 3 entries per row: the CSR tile
