@@ -166,6 +166,11 @@ int mik_csr_compact(mik_csr *A);
  * (within a slice every row that has a slot carries the same value there -- constant-coefficient stencils): the slice
  * stores its <= 8 values once and a row is one mask byte. */
 int mik_csr_layout(const mik_csr *A, int *layout);
+/* Choose the layout mik_spmv and the iterables created AFTERWARDS use for this operator: layout = 0 runs it on its plain CSR
+ * arrays (k_spmv_rowgather / k_spmv_rowblock -- what any matrix can run on; bench.py measures the north star's CSR figure this
+ * way on the same operator), layout = -1 returns to the automatic choice.  MIK_ERR_NOTIMPL for any other value or after
+ * mik_csr_compact released the CSR arrays.  Results are bit-identical either way. */
+int mik_csr_set_layout(mik_csr *A, int layout);
 /* Name of the kernel mik_spmv launches for this operator now (layout, operator properties, development knobs): for
  * profiles and the bench line.  Layout 5 runs k_spmv_sdiab (x through buffer loads: a slot a row does not have reads 0.0 by
  * the descriptor's range check) when every slice value is finite and the offsets fit 32 bits, else k_spmv_sdiac. */

@@ -81,6 +81,7 @@ SIGNATURES = {
     "mik_csr_destroy": (C.c_int, [_vp]),
     "mik_csr_pack": (C.c_int, [_vp]),
     "mik_csr_layout": (C.c_int, [_vp, _ip]),
+    "mik_csr_set_layout": (C.c_int, [_vp, C.c_int]),
     "mik_csr_stored_bytes": (C.c_int, [_vp, _i64p]),
     "mik_csr_compact": (C.c_int, [_vp]),
     "mik_spmv_kernel": (C.c_int, [_vp, C.c_char_p, C.c_int]),

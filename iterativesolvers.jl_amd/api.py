@@ -357,6 +357,12 @@ class HipCSR:
         check(lib().mik_csr_layout(self.handle, C.byref(out)), "mik_csr_layout", self.ctx.handle)
         return self.LAYOUTS[out.value]
 
+    def set_layout(self, layout: str = "auto") -> "HipCSR":
+        """``"csr"``: run ``mul_`` and the iterables created afterwards on the plain CSR arrays; ``"auto"``: the layout chosen at
+        upload (``mik_csr_set_layout``).  Results are bit-identical either way."""
+        check(lib().mik_csr_set_layout(self.handle, {"csr": 0, "auto": -1}[layout]), "mik_csr_set_layout", self.ctx.handle)
+        return self
+
     def spmv_kernel(self) -> str:
         """Name of the SpMV kernel ``mul_`` launches for this operator now (``mik_spmv_kernel``; for profiles / the bench line)."""
         buf = C.create_string_buffer(64)

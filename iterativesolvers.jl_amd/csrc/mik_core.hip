@@ -1046,6 +1046,15 @@ extern "C" int mik_csr_layout(const mik_csr *A, int *layout)
     return MIK_OK;
 }
 
+extern "C" int mik_csr_set_layout(mik_csr *A, int layout)
+{
+    if (!A) return MIK_ERR_INVALID;
+    if (layout != 0 && layout != -1) return mik_fail(A->ctx, MIK_ERR_NOTIMPL, "mik_csr_set_layout: only 0 (CSR arrays) and -1 (automatic) can be requested");
+    if (layout == 0 && !A->col) return mik_fail(A->ctx, MIK_ERR_NOTIMPL, "mik_csr_set_layout: the CSR arrays were released (mik_csr_compact)");
+    A->force_layout = layout;
+    return MIK_OK;
+}
+
 extern "C" int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes)
 {
     if (!A || !bytes) return MIK_ERR_INVALID;
@@ -1088,6 +1097,7 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
 static int spmv_kernel_choice(const mik_csr *A)
 {
     const bool csr = A->col != nullptr;                     // false after mik_csr_compact: the development knobs cannot fall back to CSR
+    if (A->force_layout == 0 && csr) return 0;              // mik_csr_set_layout
     if (A->packed && csr && g_mik_tuning[6] == 0) return 3;
     if (g_mik_tuning[8] == 0 || !csr) {
         if (A->sdia_pats && (g_mik_tuning[12] == 0 || !csr)) return 5;

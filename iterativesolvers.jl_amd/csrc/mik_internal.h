@@ -52,6 +52,7 @@ struct mik_csr {
     void *val = nullptr;             // device, nnz (+ padding)
     int max_row_nnz = 0;
     int strip = 0;                   // workgroup map for banded operators (spmv_block_map), 0 = identity
+    int force_layout = -1;           // mik_csr_set_layout: 0 = run on the CSR arrays, -1 = automatic
     int max_rowblock_nnz = 0;        // largest nnz of any 256-row block (short part)
     int n_long = 0;                  // rows longer than MIK_LONG_ROW, stored behind the short part
     int n_long_big = 0;              // how many of them exceed 256 entries (one wave each; the rest go 4 per wave)

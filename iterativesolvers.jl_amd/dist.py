@@ -1108,6 +1108,9 @@ def bench_main(args):
         out = {
             "metric": "cg_iters_per_sec", "value": world * K / dt, "unit": "iters/s", "n_gpus": world, "world_size_checked": world, "steps": K, "warmup": Wm,
             "global_system_iters_per_sec": K / dt,
+            "value_semantics": "weak scaling: `value` = slab-iterations of all ranks per second (world * K / dt, the whole-job aggregate the bench contract asks "
+                               "for; at world = 1 exactly the single-GPU metric); the ABSOLUTE rate of the one global system -- what the north star quotes at "
+                               "1 / 2 / 4 / 8 GPUs -- is `global_system_iters_per_sec` = K / dt = 1000 / ms_per_step",
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"cg! on the {N}x{N}x{nz * world} 3D 7-point Laplacian row-partitioned into {world} z-slab(s) of {N}x{N}x{nz} rows"
@@ -1132,6 +1135,14 @@ def bench_main(args):
                          "achieved_algorithmic": alg_bytes / (spmv_ms * 1e-3) / 1e9, "algorithmic_bytes_per_launch": alg_bytes},
             "aggregate_row_updates_per_sec": K / dt * n,
         }
+        fn = getattr(args, "cpu_baseline_fn", None)
+        if fn is not None and not getattr(args, "no_cpu_baseline", False):
+            # the reference-shaped CPU restatement on this box's host cores, in the same run (rank 0 only; the other ranks wait at the
+            # teardown): one rank's share is a 16.7 M-row system, i.e. the 256^3 workload of the single-GPU line
+            cb = fn(256, min(int(getattr(args, "cpu_iters", 40)), 40))
+            cb.pop("_history", None)
+            cb["sample"] += f"; one rank's share of the {world}-rank system has the same 16.7 M rows"
+            out["cpu_baseline"] = cb
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
