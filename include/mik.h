@@ -104,27 +104,6 @@ int mik_spmv_long_row(int *threshold);
  * with the wave shape above and the segment sums are added left to right (one wave per row left a 20,000-entry row to a
  * single wave). */
 int mik_spmv_long_segment(int *segment);
-/* Development knobs (not part of the reference interface; results never depend on them) for A/B timing and for
- * the tests that pin every kernel variant against the oracle.  All default to 0.
- *   0: 1 = cached (temporal) val/col/y streams in SpMV            1: 1 = narrow loads in the CSR kernel
- *   2: workgroup map: 0 = operator's choice, < 0 identity, 1 = contiguous range per XCD, P >= 8 = strips of P
- *   3: 1 = hipStreamSynchronize instead of the event spin wait    4: long-row threshold (> 0), < 0 = no split
- *   5: 1 = unfused MGS chain, 2 = launch-lean MGS without graphs, 3 = one hipGraph per GMRES column
- *   6: 1 = ignore the dictionary-coded form                       7: cache hints of the CG vector kernels
- *   8: 1 = CSR row-block layout only (read at mik_csr_create and at launch)    9: 1 = nothing enqueued ahead of the host (GMRES: the next Arnoldi column; CG: the head of the next step)
- *  10: 1 = no 8-bit column codes        11: 1 = no slice-constant values        12: 1 = no per-slice-offset layout
- *  13: bit mask switching the Krylov-basis streaming hints off    14: CSR kernel: 0 = by operator, 1 = register-staged products, 2 = LDS-DMA tile + per-row gather
- *  15: long-row segment length (> 0; read at mik_csr_create)   16: slices per workgroup of the layout-5 kernels (1 / 2 / 4)
- *  17: 1 = layout 5 through flat loads (k_spmv_sdiac)              18: 1 = k_spmv_sdiab without the compiled-in slot class
- *  19: 1 = layout 5 with one row per lane (k_spmv_sdiab instead of k_spmv_sdiab2)
- *  20: 1 = mik_csr_create on the host path only                   21: DGKS rounds inside the single-launch kernel (1..3; read at mik_gmres_create)
- *  23: 1 = CG updates x in the step's own sweep (read at mik_cg_create)      24: 1 = the halo of a row-partitioned CG step after the whole sweep over u
- *  25: 1 = the head of a plain CG step as ONE launch (k_cg_head_sdiab2; slower, see mik_cg_fused_x; read at mik_cg_create)
- *  26: cache-hint bits of that launch (8 = x streamed, 4 = u stored nt, 16 = c stored temporal; 0 = 8)
- *  28: jagged slices (layout 1): 1 = never, 2 = whenever the operator has no structured layout (read at mik_csr_create)
- *  27: direction of the streaming launches of a plain CG step (bit 0 / 1 / 2: the u sweep / the SpMV / the update walk from
- *      the end of the vectors; 8: every launch against the one before it) -- no effect at the default cache hints */
-int mik_set_tuning(int key, int value);
 
 /* ---- device memory (similar / zero / copyto! / fill! of the vector interface) ----------- */
 int mik_malloc(mik_ctx *ctx, size_t bytes, void **dptr);            /* similar(x)             */
@@ -145,23 +124,21 @@ int mik_fill(mik_ctx *ctx, int dtype, int64_t n, const void *value, void *x); /*
 int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_cols, int64_t nnz,
                    const int64_t *ptr, const int64_t *idx, const void *val, int index_base,
                    int is_csc, mik_csr **out);
+/* The same for SparseMatrixCSC{T, Int32} (the reference's tests run Ti in (Int64, Int32): test/gmres.jl:38, test/cg.jl:57): ptr / idx
+ * are 32-bit.  Host or device arrays. */
+int mik_csr_create_i32(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *ptr, const int32_t *idx,
+                       const void *val, int index_base, int is_csc, mik_csr **out);
 int mik_csr_destroy(mik_csr *A);
-/* Opt-in, lossless: additionally store the operator dictionary-coded (one 16-bit code per entry: value
- * index << 8 | (column - row) index; both dictionaries <= 256 entries, e.g. stencil operators).  Later
- * mik_spmv / iterable calls then read 2 B instead of 12 B per entry and return bit-identical
- * results.  MIK_ERR_NOTIMPL (operator unchanged) when the matrix does not qualify. */
-int mik_csr_pack(mik_csr *A);
 /* Release the CSR arrays (rowptr / col / val: 12 B per entry at fp64) of an operator whose active layout is one of the sliced
- * forms (1, 2, 4, 5) -- mik_spmv never reads them then; they are only what the development knobs fall back to.  Afterwards
- * those knobs have no effect on this operator and mik_csr_pack returns MIK_ERR_NOTIMPL.  MIK_ERR_NOTIMPL (nothing released)
- * for an operator that runs on its CSR arrays. */
+ * forms (1, 2, 4, 5) -- mik_spmv never reads them then; they are only what mik_csr_set_layout(A, 0) and the development knobs
+ * (csrc/mik_dev.h) fall back to, which have no effect on this operator afterwards.  MIK_ERR_NOTIMPL (nothing released) for an
+ * operator that runs on its CSR arrays or has split-off long rows. */
 int mik_csr_compact(mik_csr *A);
 /* Device layout mik_spmv uses for this operator (chosen at upload from the sparsity pattern; results are
  * bit-identical across layouts): 0 = CSR row-blocks (LDS tile filled by LDS-DMA; product tile for uneven rows; any matrix),
  * 1 = jagged slices (one row per lane, groups of 16 B / sizeof(T) consecutive entries stored lane-interleaved per 64-row
  * slice: long near-uniform rows -- finite-element matrices), 2 = sliced-ELL values + 8-bit codes for the
- * (column - row) offsets (banded / stencil operators with <= 255 distinct offsets), 3 = dictionary-coded
- * (after mik_csr_pack), 4 = sliced-ELL values with per-slice offsets and one presence-mask byte per row (every
+ * (column - row) offsets (banded / stencil operators with <= 255 distinct offsets), (3: retired), 4 = sliced-ELL values with per-slice offsets and one presence-mask byte per row (every
  * 256-row slice uses <= 8 distinct offsets: stencils on structured grids), 5 = the same with slice-CONSTANT slot values
  * (within a slice every row that has a slot carries the same value there -- constant-coefficient stencils): the slice
  * stores its <= 8 values once and a row is one mask byte. */
@@ -204,6 +181,10 @@ int mik_divide(mik_ctx *ctx, int dtype, int64_t n, const void *x, const void *d,
  * place, normalised); h: HOST array of k scalars (written); nrm: HOST scalar (written). */
 int mik_orthogonalize(mik_ctx *ctx, int dtype, int64_t n, int k, const void *V, int64_t ldv,
                       void *w, void *h, void *nrm, int method);
+/* orthogonalize_and_normalize!(V::Vector{Vector}, w, h, ModifiedGramSchmidt()) -> nrm -- src/orthogonalize.jl:53-65: the basis as
+ * k separate device n-vectors (V: HOST array of k device pointers).  Same arithmetic and bits as mik_orthogonalize with MIK_MGS
+ * on a matrix holding those columns.  (The reference defines this method for ModifiedGramSchmidt only.) */
+int mik_orthogonalize_vectors(mik_ctx *ctx, int dtype, int64_t n, int k, const void *const *V, void *w, void *h, void *nrm);
 /* mul!(y, V[:, 1:k], c, alpha, 1) -- src/gmres.jl:275 (alpha = 1), src/orthogonalize.jl:16 (-1).
  * c: HOST array of k scalars. */
 int mik_gemv_n(mik_ctx *ctx, int dtype, int64_t n, int k, const void *V, int64_t ldv,
@@ -236,14 +217,10 @@ int mik_cg_destroy(mik_cg *it);
  * the iterable's scratch: with a CSR operator and no host callbacks the library enqueues the first half of
  * the NEXT step (u = r + beta u, c = A u, alpha) before it waits for this step's residual, so on return
  * u and c may already belong to step iteration + 1 (results of any call sequence are unchanged; the
- * device-side stopping flag turns that half into a no-op once the iteration has stopped;
- * mik_set_tuning(9, 1) switches it off). */
+ * device-side stopping flag turns that half into a no-op once the iteration has stopped). */
 int mik_cg_iterate(mik_cg *it, int64_t iteration, double *residual, int *done);
 /* 1 if this iterable applies x .+= alpha .* u in the sweep over u that opens the next step (CSR operator, no
- * preconditioner callback; see mik_cg_iterate), 0 if in the step's own update sweep; 2 if that sweep is itself part of
- * the SpMV launch (mik_set_tuning(25, 1) before mik_cg_create, plain CG on a slice-constant operator with an even number
- * of rows): the search direction then alternates between the caller's u and a library buffer and is copied back into u
- * when the iteration ends.  Results are bit-identical in all three forms. */
+ * preconditioner callback; see mik_cg_iterate), 0 if in the step's own update sweep.  Results are bit-identical either way. */
 int mik_cg_fused_x(const mik_cg *it, int *fused);
 /* Up to max_steps consecutive iterate() calls with ONE host synchronisation: the stopping test
  * of src/cg.jl:36 is evaluated on the device after every step and later steps become no-ops.

@@ -1,0 +1,35 @@
+/*
+ * mik_dev.h -- DEVELOPMENT interface of libmik.so.  Not part of the drop-in boundary (include/mik.h): nothing a host of the
+ * reference needs is declared here.  The knobs select kernel variants for A/B timing (scripts/) and for the tests that pin
+ * every variant against the oracle (tests/test_gpu_layouts.py, test_gpu_lookahead.py); results never depend on them.  They are
+ * process-global and not thread-safe: set them from the thread that drives the library, before the objects they affect are
+ * created.  A host that wants an operator on its plain CSR arrays uses mik_csr_set_layout (include/mik.h), not a knob.
+ */
+#ifndef MIK_DEV_H
+#define MIK_DEV_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* key / value table (all default to 0; results never depend on them):
+ *   0: 1 = cached (temporal) val/col/y streams in SpMV            1: 1 = narrow loads in the CSR kernel
+ *   2: workgroup map: 0 = operator's choice, < 0 identity, 1 = contiguous range per XCD, P >= 8 = strips of P
+ *   3: 1 = hipStreamSynchronize instead of the event spin wait    4: long-row threshold (> 0), < 0 = no split
+ *   5: 1 = unfused MGS chain, 2 = launch-lean MGS without graphs, 3 = one hipGraph per GMRES column
+ *   7: cache hints of the CG vector kernels
+ *   8: 1 = CSR row-block layout only (read at mik_csr_create and at launch)    9: 1 = nothing enqueued ahead of the host (GMRES: the next Arnoldi column; CG: the head of the next step)
+ *  10: 1 = no 8-bit column codes        11: 1 = no slice-constant values        12: 1 = no per-slice-offset layout
+ *  13: bit mask switching the Krylov-basis streaming hints off    14: CSR kernel: 0 = by operator, 1 = register-staged products, 2 = LDS-DMA tile + per-row gather
+ *  15: long-row segment length (> 0; read at mik_csr_create)   16: slices per workgroup of the layout-5 kernels (1 / 2 / 4)
+ *  17: 1 = layout 5 through flat loads (k_spmv_sdiac)              18: 1 = k_spmv_sdiab without the compiled-in slot class
+ *  19: 1 = layout 5 with one row per lane (k_spmv_sdiab instead of k_spmv_sdiab2)
+ *  20: 1 = mik_csr_create on the host path only                   21: DGKS rounds inside the single-launch kernel (1..3; read at mik_gmres_create)
+ *  23: 1 = CG updates x in the step's own sweep (read at mik_cg_create)      24: 1 = the halo of a row-partitioned CG step after the whole sweep over u
+ *  30: 1 = treat the next single-launch Gram-Schmidt column as timed out (exercises the fall-back to the multi-launch chains)
+ *  28: jagged slices (layout 1): 1 = never, 2 = whenever the operator has no structured layout (read at mik_csr_create)
+ *  27: direction of the streaming launches of a plain CG step (bit 0 / 1 / 2: the u sweep / the SpMV / the update walk from
+ *      the end of the vectors; 8: every launch against the one before it) -- no effect at the default cache hints */
+int mik_set_tuning(int key, int value);
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIK_DEV_H */

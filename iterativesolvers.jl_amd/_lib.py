@@ -78,8 +78,9 @@ SIGNATURES = {
     "mik_fill": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp]),
     "mik_csr_create": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _i64p, _i64p, _vp, C.c_int, C.c_int,
                                  C.POINTER(_vp)]),
+    "mik_csr_create_i32": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _vp, C.c_int, C.c_int,
+                                     C.POINTER(_vp)]),
     "mik_csr_destroy": (C.c_int, [_vp]),
-    "mik_csr_pack": (C.c_int, [_vp]),
     "mik_csr_layout": (C.c_int, [_vp, _ip]),
     "mik_csr_set_layout": (C.c_int, [_vp, C.c_int]),
     "mik_csr_stored_bytes": (C.c_int, [_vp, _i64p]),
@@ -95,6 +96,7 @@ SIGNATURES = {
     "mik_scal": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp]),
     "mik_divide": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp]),
     "mik_orthogonalize": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _vp, _i64, _vp, _vp, _vp, C.c_int]),
+    "mik_orthogonalize_vectors": (C.c_int, [_vp, C.c_int, _i64, C.c_int, C.POINTER(_vp), _vp, _vp, _vp]),
     "mik_gemv_n": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _vp, _i64, _vp, _vp, _vp]),
     "mik_gemv_t": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _vp, _i64, _vp, _vp]),
     "mik_lu_solve": (C.c_int, [C.c_int, _vp, _i64, C.c_int, _vp]),

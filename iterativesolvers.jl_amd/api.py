@@ -277,21 +277,29 @@ class HipCSR:
     """The operator ``A``: a SparseMatrixCSC uploaded as device CSR (``mik_csr``).
 
     ``HipCSR(n_rows, n_cols, colptr, rowval, nzval, index_base=1)`` takes exactly the fields of a
-    Julia ``SparseMatrixCSC{T,Int}`` (test/laplace_matrix.jl:12)."""
+    Julia ``SparseMatrixCSC{T,Int}`` (test/laplace_matrix.jl:12); Int32 index arrays -- ``SparseMatrixCSC{T,Int32}``,
+    test/gmres.jl:38 -- go through ``mik_csr_create_i32``."""
 
     def __init__(self, n_rows, n_cols, ptr, idx, val, *, index_base=1, is_csc=True, ctx: Optional[HipContext] = None):
         self.ctx = ctx or default_context()
         val = np.ascontiguousarray(val)
         self.dtype = val.dtype
         self.code = dtype_code(val.dtype)
-        ptr = np.ascontiguousarray(ptr, np.int64)
-        idx = np.ascontiguousarray(idx, np.int64)
         self.n_rows, self.n_cols, self.nnz = int(n_rows), int(n_cols), int(val.size)
         h = _vp()
-        check(lib().mik_csr_create(self.ctx.handle, self.code, self.n_rows, self.n_cols, self.nnz,
-                                   ptr.ctypes.data_as(C.POINTER(C.c_int64)), idx.ctypes.data_as(C.POINTER(C.c_int64)),
-                                   val.ctypes.data_as(_vp), int(index_base), int(bool(is_csc)), C.byref(h)),
-              "mik_csr_create", self.ctx.handle)
+        if np.asarray(ptr).dtype == np.int32 and np.asarray(idx).dtype == np.int32:
+            ptr, idx = np.ascontiguousarray(ptr), np.ascontiguousarray(idx)
+            check(lib().mik_csr_create_i32(self.ctx.handle, self.code, self.n_rows, self.n_cols, self.nnz,
+                                           ptr.ctypes.data_as(C.POINTER(C.c_int32)), idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                           val.ctypes.data_as(_vp), int(index_base), int(bool(is_csc)), C.byref(h)),
+                  "mik_csr_create_i32", self.ctx.handle)
+        else:
+            ptr = np.ascontiguousarray(ptr, np.int64)
+            idx = np.ascontiguousarray(idx, np.int64)
+            check(lib().mik_csr_create(self.ctx.handle, self.code, self.n_rows, self.n_cols, self.nnz,
+                                       ptr.ctypes.data_as(C.POINTER(C.c_int64)), idx.ctypes.data_as(C.POINTER(C.c_int64)),
+                                       val.ctypes.data_as(_vp), int(index_base), int(bool(is_csc)), C.byref(h)),
+                  "mik_csr_create", self.ctx.handle)
         self.handle = h
 
     @classmethod
@@ -319,16 +327,6 @@ class HipCSR:
         m.sort_indices()
         return HipCSR(m.shape[0], m.shape[1], m.indptr, m.indices, m.data, index_base=0, is_csc=True, ctx=ctx)
 
-    def pack(self) -> bool:
-        """Opt in to the dictionary-coded operator (``mik_csr_pack``): 2 B instead of 12 B per entry for
-        matrices with <= 256 distinct values and column offsets; results are bit-identical.  Returns
-        False (operator unchanged) when the matrix does not qualify."""
-        code = lib().mik_csr_pack(self.handle)
-        if code == 5:
-            return False
-        check(code, "mik_csr_pack", self.ctx.handle)
-        return True
-
     def compact(self) -> bool:
         """Release the CSR arrays of an operator that runs on one of the sliced layouts (``mik_csr_compact``); False (nothing
         released) if the operator needs them."""
@@ -348,7 +346,7 @@ class HipCSR:
         y = HipVector(self.n_rows, self.dtype, self.ctx)
         return mul_(y, self, x)
 
-    LAYOUTS = ("csr-rowblock", "jagged-slices", "sliced-ell+8-bit-column-codes", "dictionary-coded", "sliced-ell+slice-offsets+row-masks",
+    LAYOUTS = ("csr-rowblock", "jagged-slices", "sliced-ell+8-bit-column-codes", "(retired)", "sliced-ell+slice-offsets+row-masks",
                "slice-offsets+slice-values+row-masks")
 
     def layout(self) -> str:
@@ -648,14 +646,6 @@ class CGIterable:
         self._check(lib().mik_cg_fused_x(self.handle, C.byref(out)), "mik_cg_fused_x")
         return bool(out.value)
 
-    def fused_head(self) -> bool:
-        """True if the whole head of a step -- that x update, ``u = r + beta u``, ``c = A u`` and ``dot(u, c)`` -- is ONE
-        sweep (``k_cg_head_sdiab2``; ``mik_cg_fused_x`` reports 2).  The direction then alternates between ``u`` and a
-        library-owned buffer and is back in ``u`` once the iteration has finished."""
-        out = C.c_int()
-        self._check(lib().mik_cg_fused_x(self.handle, C.byref(out)), "mik_cg_fused_x")
-        return out.value == 2
-
     def iterate_many(self, iteration: int, max_steps: int) -> np.ndarray:
         """Up to ``max_steps`` ``iterate`` calls with one host synchronisation; returns the residuals."""
         out = np.empty(max(int(max_steps), 1), np.float64)
@@ -837,10 +827,23 @@ class ModifiedGramSchmidt(OrthogonalizationMethod):
     code = _lib.MIK_MGS
 
 
-def orthogonalize_and_normalize_(V: HipMatrix, k: int, w: HipVector, h: np.ndarray, method=None):
+def orthogonalize_and_normalize_(V, k: int, w: HipVector, h: np.ndarray, method=None):
     """``orthogonalize_and_normalize!(view(V, :, 1:k), w, h, method)`` -> nrm -- src/orthogonalize.jl:13-79.
-    ``h`` is a host array of at least k entries, written in place."""
+    ``h`` is a host array of at least k entries, written in place.  ``V`` may also be a list of ``HipVector`` s -- the
+    vector-of-vectors method of src/orthogonalize.jl:53-65 (ModifiedGramSchmidt only, like the reference)."""
     method = ModifiedGramSchmidt() if method is None else method           # :10-11
+    if isinstance(V, (list, tuple)):
+        if not isinstance(method, ModifiedGramSchmidt):
+            raise TypeError("MethodError: orthogonalize_and_normalize!(::Vector{Vector}, ...) is defined for ModifiedGramSchmidt only")
+        if k > len(V) or any(v.n != w.n or v.dtype != w.dtype for v in V[:k]):
+            raise ValueError("DimensionMismatch in orthogonalize_and_normalize_")
+        ptrs = (_vp * max(k, 1))(*[_vp(v.ptr) for v in V[:k]])
+        hh = np.zeros(max(k, 1), w.dtype)
+        nrm = np.zeros(1, w.dtype)
+        check(lib().mik_orthogonalize_vectors(w.ctx.handle, dtype_code(w.dtype), w.n, int(k), ptrs, _vp(w.ptr), hh.ctypes.data_as(_vp),
+                                              nrm.ctypes.data_as(_vp)), "mik_orthogonalize_vectors", w.ctx.handle)
+        h[:k] = hh[:k]
+        return nrm[0]
     if w.n != V.n or w.dtype != V.dtype or k > V.cols:
         raise ValueError("DimensionMismatch in orthogonalize_and_normalize_")
     hh = np.zeros(max(k, 1), V.dtype)

@@ -8,7 +8,6 @@
 
 #include "mik_kernels.h"
 #include "mik_spmv.h"
-#include "mik_packed.h"
 #include "mik_sell.h"
 #include "mik_jds.h"
 #include <map>
@@ -700,6 +699,41 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
     return csr_create_impl(ctx, dtype, n_rows, n_cols, nnz, hp.data(), hi.data(), hv.data(), index_base, is_csc, false, out);
 }
 
+// SparseMatrixCSC{T, Int32}: widen the index arrays on the host, then the Int64 entry (the device pipeline starts from host arrays).
+extern "C" int mik_csr_create_i32(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *ptr, const int32_t *idx,
+                                  const void *val, int index_base, int is_csc, mik_csr **out)
+{
+    if (!ctx || !out) return MIK_ERR_INVALID;
+    *out = nullptr;
+    if (n_rows < 0 || n_cols < 0 || nnz < 0 || !ptr || (nnz && (!idx || !val))) return mik_fail(ctx, MIK_ERR_INVALID, "mik_csr_create_i32: bad sizes or NULL arrays");
+    if (dtype != MIK_F64 && dtype != MIK_F32) return mik_fail(ctx, MIK_ERR_INVALID, "mik_csr_create_i32: bad dtype %d", dtype);
+    const int64_t n_major = is_csc ? n_cols : n_rows;
+    (void)hipSetDevice(ctx->device);
+    const bool dev_in = is_device_pointer(ptr);
+    if (nnz && (is_device_pointer(idx) != dev_in || is_device_pointer(val) != dev_in))
+        return mik_fail(ctx, MIK_ERR_INVALID, "mik_csr_create_i32: ptr / idx / val must all be host arrays or all device arrays");
+    std::vector<int64_t> p64, i64;
+    std::vector<int32_t> p32, i32;
+    std::vector<unsigned char> hv;
+    try {
+        p64.resize((size_t)n_major + 1);
+        i64.resize((size_t)nnz);
+        if (dev_in) { p32.resize((size_t)n_major + 1); i32.resize((size_t)nnz); hv.resize((size_t)nnz * mik_dtype_size(dtype)); }
+    } catch (const std::bad_alloc &) {
+        return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create_i32: host staging allocation failed");
+    }
+    if (dev_in) {
+        if (hipMemcpy(p32.data(), ptr, sizeof(int32_t) * p32.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+            (nnz && (hipMemcpy(i32.data(), idx, sizeof(int32_t) * i32.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+                     hipMemcpy(hv.data(), val, hv.size(), hipMemcpyDeviceToHost) != hipSuccess)))
+            return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create_i32: reading the device arrays failed");
+        ptr = p32.data(); idx = i32.data(); val = hv.data();
+    }
+    for (int64_t j = 0; j <= n_major; ++j) p64[(size_t)j] = ptr[j];
+    for (int64_t k = 0; k < nnz; ++k) i64[(size_t)k] = idx[k];
+    return mik_csr_create(ctx, dtype, n_rows, n_cols, nnz, p64.data(), i64.data(), val, index_base, is_csc, out);
+}
+
 // on_device: ptr / idx / val are device arrays; only the device pipeline can consume them (MIK_ERR_NOTIMPL otherwise)
 static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *ptr, const int64_t *idx,
                            const void *val, int index_base, int is_csc, bool on_device, mik_csr **out)
@@ -960,82 +994,8 @@ extern "C" int mik_csr_destroy(mik_csr *A)
     if (A->jds_col) (void)hipFree(A->jds_col);
     if (A->jds_val) (void)hipFree(A->jds_val);
     if (A->sell_val) (void)hipFree(A->sell_val);
-    if (A->codes) (void)hipFree(A->codes);
-    if (A->vtab) (void)hipFree(A->vtab);
-    if (A->dtab) (void)hipFree(A->dtab);
     delete A;
     return MIK_OK;
-}
-
-// Build the dictionary-coded form (csrc/mik_packed.h) from the device CSR.  MIK_ERR_NOTIMPL (and no
-// change) when the matrix does not qualify: more than 256 distinct values or (column - row) offsets,
-// or rows long enough to have been split off (n_long > 0).
-template <typename T> static int csr_pack_impl(mik_csr *A)
-{
-    mik_ctx *ctx = A->ctx;
-    const size_t n = (size_t)A->n_rows, nnz = (size_t)A->nnz;
-    std::vector<int> rowptr(n + 1), col(nnz);
-    std::vector<T> val(nnz);
-    MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    MIK_HIP(ctx, hipMemcpy(rowptr.data(), A->rowptr, sizeof(int) * (n + 1), hipMemcpyDeviceToHost));
-    if (nnz) {
-        MIK_HIP(ctx, hipMemcpy(col.data(), A->col, sizeof(int) * nnz, hipMemcpyDeviceToHost));
-        MIK_HIP(ctx, hipMemcpy(val.data(), A->val, sizeof(T) * nnz, hipMemcpyDeviceToHost));
-    }
-    using Bits = typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type;
-    std::unordered_map<Bits, int> vmap;
-    std::unordered_map<int, int> dmap;
-    std::vector<T> vtab;
-    std::vector<int> dtab;
-    std::vector<unsigned short> codes(nnz + MIK_PACK_TILE, 0);
-    Bits last_bits = 0; int last_vc = -1, last_delta = 0, last_dc = -1;
-    for (size_t r = 0; r < n; ++r)
-        for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
-            Bits bits;
-            memcpy(&bits, &val[k], sizeof(T));
-            int vc;
-            if (last_vc >= 0 && bits == last_bits) vc = last_vc;
-            else {
-                auto it = vmap.find(bits);
-                if (it == vmap.end()) {
-                    if (vtab.size() == 256) return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_csr_pack: more than 256 distinct values");
-                    vc = (int)vtab.size(); vmap.emplace(bits, vc); vtab.push_back(val[k]);
-                } else vc = it->second;
-                last_bits = bits; last_vc = vc;
-            }
-            const int delta = col[k] - (int)r;
-            int dc;
-            if (last_dc >= 0 && delta == last_delta) dc = last_dc;
-            else {
-                auto it = dmap.find(delta);
-                if (it == dmap.end()) {
-                    if (dtab.size() == 256) return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_csr_pack: more than 256 distinct column offsets");
-                    dc = (int)dtab.size(); dmap.emplace(delta, dc); dtab.push_back(delta);
-                } else dc = it->second;
-                last_delta = delta; last_dc = dc;
-            }
-            codes[k] = (unsigned short)((vc << 8) | dc);
-        }
-    A->nv = (int)vtab.size(); A->nd = (int)dtab.size();
-    vtab.resize(256, T(0)); dtab.resize(256, 0);
-    (void)hipSetDevice(ctx->device);
-    MIK_HIP(ctx, hipMalloc((void **)&A->codes, sizeof(unsigned short) * codes.size()));
-    MIK_HIP(ctx, hipMalloc(&A->vtab, sizeof(T) * 256));
-    MIK_HIP(ctx, hipMalloc((void **)&A->dtab, sizeof(int) * 256));
-    MIK_HIP(ctx, hipMemcpy(A->codes, codes.data(), sizeof(unsigned short) * codes.size(), hipMemcpyHostToDevice));
-    MIK_HIP(ctx, hipMemcpy(A->vtab, vtab.data(), sizeof(T) * 256, hipMemcpyHostToDevice));
-    MIK_HIP(ctx, hipMemcpy(A->dtab, dtab.data(), sizeof(int) * 256, hipMemcpyHostToDevice));
-    A->packed = true;
-    return MIK_OK;
-}
-
-extern "C" int mik_csr_pack(mik_csr *A)
-{
-    if (!A) return MIK_ERR_INVALID;
-    if (A->packed) return MIK_OK;
-    if (!A->col) return mik_fail(A->ctx, MIK_ERR_NOTIMPL, "mik_csr_pack: the CSR arrays were released (mik_csr_compact)");
-    if (A->n_long) return mik_fail(A->ctx, MIK_ERR_NOTIMPL, "mik_csr_pack: matrix has long rows");
-    return A->dtype == MIK_F64 ? csr_pack_impl<double>(A) : csr_pack_impl<float>(A);
 }
 
 static int spmv_kernel_choice(const mik_csr *A);
@@ -1065,7 +1025,6 @@ extern "C" int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes)
     switch (layout) {
     case 5: *bytes = A->n_rows + nb * ((A->sdia_recs && g_mik_tuning[17] == 0) ? 64 : 4) + (int64_t)A->sdia_npat * (80 + 8 * es); break;
     case 4: *bytes = A->sdia_entries * es + A->n_rows + nb * 36; break;
-    case 3: *bytes = A->nnz * 2 + (A->n_rows + 1) * 4 + 256 * (es + 4); break;
     case 2: *bytes = A->sell_entries * es + A->sell8_bytes + (nb + 1) * 8 + 256 * 4; break;
     case 1: *bytes = A->jds_groups * (16 / es) * (es + 4) + A->n_rows * 2 + ((A->n_rows + 63) / 64 + 1) * 4 +
                      (A->n_long ? (A->nnz - A->jds_short_nnz) * (es + 4) + 12LL * A->n_long + 4LL * A->n_seg + 16LL * A->n_cut : 0); break;
@@ -1093,12 +1052,11 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
 
 // Which kernel mik_spmv_launch_range picks for this operator under the current development knobs -- ONE function, used
 // by the launcher, by mik_csr_layout and by mik_spmv_can_split, so the three can never disagree.
-//   3 packed, 5 per-slice offsets + slice-constant values, 4 sliced-ELL + per-slice offsets, 2 sliced-ELL + 8-bit codes, 1 sliced-ELL, 0 CSR
+//   5 per-slice offsets + slice-constant values, 4 sliced-ELL + per-slice offsets, 2 sliced-ELL + 8-bit codes, 1 sliced-ELL, 0 CSR
 static int spmv_kernel_choice(const mik_csr *A)
 {
     const bool csr = A->col != nullptr;                     // false after mik_csr_compact: the development knobs cannot fall back to CSR
     if (A->force_layout == 0 && csr) return 0;              // mik_csr_set_layout
-    if (A->packed && csr && g_mik_tuning[6] == 0) return 3;
     if (g_mik_tuning[8] == 0 || !csr) {
         if (A->sdia_pats && (g_mik_tuning[12] == 0 || !csr)) return 5;
         if (A->sdia_val && (g_mik_tuning[12] == 0 || !csr)) return 4;
@@ -1117,12 +1075,6 @@ extern "C" int mik_csr_compact(mik_csr *A)
     if (!(A->sdia_pats || A->sdia_val || A->sell8_codes || A->jds_val) || A->n_long)
         return mik_fail(A->ctx, MIK_ERR_NOTIMPL, "mik_csr_compact: this operator runs on its CSR arrays");
     if (A->ctx) { (void)hipSetDevice(A->ctx->device); (void)hipStreamSynchronize(A->ctx->stream); }
-    if (A->packed) {                                        // the dictionary-coded form reads rowptr: drop it instead
-        if (A->codes) (void)hipFree(A->codes);
-        if (A->vtab) (void)hipFree(A->vtab);
-        if (A->dtab) (void)hipFree(A->dtab);
-        A->codes = nullptr; A->vtab = nullptr; A->dtab = nullptr; A->packed = false;
-    }
     (void)hipFree(A->rowptr); (void)hipFree(A->col); (void)hipFree(A->val);
     A->rowptr = nullptr; A->col = nullptr; A->val = nullptr;
     return MIK_OK;
@@ -1151,7 +1103,6 @@ extern "C" int mik_spmv_kernel(const mik_csr *A, char *name, int len)
     switch (spmv_kernel_choice(A)) {
     case 5: k = A->sdia_buf_ok && g_mik_tuning[17] == 0 ? (sdiab2_applies(A) ? "k_spmv_sdiab2" : "k_spmv_sdiab") : "k_spmv_sdiac"; break;
     case 4: k = "k_spmv_sdia"; break;
-    case 3: k = "k_spmv_packed"; break;
     case 2: k = "k_spmv_sell8"; break;
     case 1: k = "k_spmv_jds"; break;
     default: k = spmv_csr_rowgather(A) ? "k_spmv_rowgather" : "k_spmv_rowblock"; break;
@@ -1166,7 +1117,6 @@ extern "C" int mik_spmv_kernel(const mik_csr *A, char *name, int len)
 bool mik_spmv_can_split(const mik_csr *A)
 {
     const int kc = spmv_kernel_choice(A);
-    if (kc == 3) return false;
     if (kc == 0) return spmv_csr_rowgather(A) && A->n_long == 0;
     if (kc == 1) return A->n_long == 0;
     return true;
@@ -1204,55 +1154,6 @@ int mik_spmv_launch_outside(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
 template int mik_spmv_launch_outside<double>(mik_ctx *, const mik_csr *, const double *, double *, bool, double *, const int *, int, int);
 template int mik_spmv_launch_outside<float>(mik_ctx *, const mik_csr *, const float *, float *, bool, float *, const int *, int, int);
 
-// ---- the head of a plain CG step as one sweep (k_cg_head_sdiab2, mik_sell.h) ------------------------------------------
-// Available where k_spmv_sdiab2 is, and OFF by default: at 256^3 the sweep takes 176-182 us against 101 + 59 us for
-// k_map<OpXpbyX> followed by k_spmv_sdiab2 (it gathers r AND the old u for every neighbour -- 14 loads per 128 rows
-// against 10 -- and reaches 4.5 TB/s on its 49 B per row where the two launches reach 6.7 and 4.9 on theirs; DESIGN.md
-// section 5).  Development knob 25: 1 = use it (read at mik_cg_create); knob 26: cache-hint bits of the sweep.
-bool mik_cg_head_available(const mik_csr *A)
-{
-    return A && A->n_rows > 0 && A->n_rows == A->n_cols && spmv_kernel_choice(A) == 5 && sdiab2_applies(A) && g_mik_tuning[25] == 1;
-}
-
-template <typename T>
-int mik_cg_head_launch(mik_ctx *ctx, const mik_csr *A, const T *r, const T *uo, T *un, T *x, T *c, T *seg_out, const T *alpha, const T *beta,
-                       const int *done, const int *pending)
-{
-    if (!mik_cg_head_available(A) || uo == un) return mik_fail(ctx, MIK_ERR_INVALID, "CG head sweep: not available for this operator");
-    const int n = (int)A->n_rows;
-    const int nb = (int)mik_spmv_nwg(n);
-    const int np = (nb + 1) / 2, wgs = (np + 7) / 8 * 8;
-    const int map_mode = g_mik_tuning[2] == 0 ? A->strip : std::max(g_mik_tuning[2], 0);
-    int ps = -1, pfull = 0;
-    if (map_mode >= 16) {
-        const int S = map_mode >> 3;
-        if ((S & (S - 1)) == 0) { ps = 0; while ((2 << ps) < S) ++ps; pfull = (nb / map_mode * map_mode) / 2; }
-    }
-    const int cls = A->sdia_cls;
-    const int hint = g_mik_tuning[26] > 0 ? (g_mik_tuning[26] & 31) : 8;
-#define MIK_HEAD_GO2(C, H)                                                                                                              \
-    hipLaunchKernelGGL((k_cg_head_sdiab2<T, mik_sdiab_cls_ns(C), mik_sdiab_cls_cq(C), H>), dim3(wgs), dim3(MIK_BLOCK), 0, ctx->stream, n, A->sdia_koff, \
-                       np, pfull, ps, nb, (const SdiaSliceRec *)A->sdia_recs, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, r, uo, un, x, c, seg_out, \
-                       alpha, beta, done, pending)
-#define MIK_HEAD_GO(H) do { if (cls == 1) MIK_HEAD_GO2(1, H); else if (cls == 2) MIK_HEAD_GO2(2, H); else MIK_HEAD_GO2(3, H); } while (0)
-    switch (hint) {
-    case 12: MIK_HEAD_GO(12); break;
-    case 24: MIK_HEAD_GO(24); break;
-    case 28: MIK_HEAD_GO(28); break;
-    case 4: MIK_HEAD_GO(4); break;
-    case 16: MIK_HEAD_GO(16); break;
-    default: MIK_HEAD_GO(8); break;
-    }
-#undef MIK_HEAD_GO
-#undef MIK_HEAD_GO2
-    MIK_LAUNCH_CHECK(ctx);
-    return MIK_OK;
-}
-template int mik_cg_head_launch<double>(mik_ctx *, const mik_csr *, const double *, const double *, double *, double *, double *, double *, const double *,
-                                        const double *, const int *, const int *);
-template int mik_cg_head_launch<float>(mik_ctx *, const mik_csr *, const float *, const float *, float *, float *, float *, float *, const float *,
-                                       const float *, const int *, const int *);
-
 template <typename T>
 static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done, int rb_begin, int rb_count,
                             int skip_at, int skip_len)
@@ -1275,17 +1176,6 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
     if (!whole && map_mode >= 8 && (rb0 % map_mode != 0 || nb % map_mode != 0)) map_mode = 0;   // strips need whole planes
     if (skip_len > 0) map_mode = 0;
     const int choice = spmv_kernel_choice(A);
-    if (choice == 3) {
-        // dictionary-coded operator (mik_csr_pack): 2 B per entry instead of 12, same arithmetic
-        if (fuse_dot)
-            hipLaunchKernelGGL((k_spmv_packed<T, true>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, map_mode, A->rowptr, A->codes,
-                               (const T *)A->vtab, A->dtab, A->nv, A->nd, x, y, seg_out, done);
-        else
-            hipLaunchKernelGGL((k_spmv_packed<T, false>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, nb, map_mode, A->rowptr, A->codes,
-                               (const T *)A->vtab, A->dtab, A->nv, A->nd, x, y, seg_out, done);
-        MIK_LAUNCH_CHECK(ctx);
-        return MIK_OK;
-    }
     if (choice == 5) {
         // slice patterns {offsets, values} + one mask byte per row (mik_sell.h); G slices per workgroup
         const int G = g_mik_tuning[16] > 0 ? g_mik_tuning[16] : MIK_SDIAC_G;   // development knob 16: 1 / 2 / 4 slices per workgroup

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/mik.h"
+#include "../../include/mik_dev.h"
 
 // ---------------------------------------------------------------------------------------------
 // compile-time shape of the level-1 reduction tree (exported through mik_reduce_shape)
@@ -94,12 +95,6 @@ struct mik_csr {
     int sdia_koff = 0;               // - (most negative slot offset) of the operator, >= 0
     void *sdia_recs = nullptr;       // device, nb SdiaSliceRec (k_spmv_sdiab): scalar offsets + pattern shape per slice
     int sdia_cls = 0;                // (slots, centre slot) class k_spmv_sdiab runs specialised (mik_sdiab_cls_*), 0 = none
-    // optional dictionary-coded form (mik_csr_pack): one 16-bit code per entry + two <= 256-entry tables
-    unsigned short *codes = nullptr; // device, nnz (+ padding)
-    void *vtab = nullptr;            // device, 256 values of dtype
-    int *dtab = nullptr;             // device, 256 (column - row) offsets
-    int nv = 0, nd = 0;
-    bool packed = false;
 };
 
 // norm(x) from t = sum of x_i^2: sqrt(t) whenever t lies inside [LO, HI] -- then no square that matters has

@@ -45,9 +45,6 @@ struct mik_cg {
     bool head_ahead = false;         // the head of the next step (u, c, alpha) is on the stream already
     bool fuse_x = false;             // x .+= alpha .* u rides on the next u = r + beta u sweep (plain / Jacobi CG on a CSR operator)
     unsigned sweeps = 0;             // streaming launches enqueued so far (development knob 27: alternating sweep direction)
-    bool fuse_head = false;          // ... and that sweep is part of the SpMV launch (k_cg_head_sdiab2): u alternates between u and u_alt
-    void *u_alt = nullptr;           // the second direction buffer (library-owned)
-    int u_par = 0;                   // 1: the current direction is in u_alt
     // optional in-loop timing of the SpMV launch (HIP events on the ctx stream)
     int profile = 0;               // 0 off, 1 = the SpMV launch, 2 = SpMV + the two vector sweeps of the step
     std::vector<hipEvent_t> ev;    // pairs (start, stop), recycled

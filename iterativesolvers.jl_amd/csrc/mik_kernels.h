@@ -673,8 +673,16 @@ template <typename T, bool SELF> struct OpMgsPass {
 #define MIK_MGS_SLEEP 0
 #endif
 template <typename T> struct MgsBits;
-template <> struct MgsBits<double> { using U = unsigned long long; static constexpr U EMPTY = ~0ull; };
-template <> struct MgsBits<float>  { using U = unsigned int;       static constexpr U EMPTY = ~0u; };
+template <> struct MgsBits<double> { using U = unsigned long long; static constexpr U EMPTY = ~0ull; static constexpr U QNAN = 0x7ff8000000000000ull; };
+template <> struct MgsBits<float>  { using U = unsigned int;       static constexpr U EMPTY = ~0u;   static constexpr U QNAN = 0x7fc00000u; };
+// The bits a slot receives for the value v: a NaN is published as the canonical quiet NaN, so that no payload user data can
+// carry (a vector filled with 0xFF bytes sums to the all-ones NaN) is ever mistaken for "not yet written".
+template <typename T> __device__ __forceinline__ typename MgsBits<T>::U mgs_slot_bits(T v)
+{
+    typename MgsBits<T>::U bits;
+    __builtin_memcpy(&bits, &v, sizeof(T));
+    return v != v ? MgsBits<T>::QNAN : bits;
+}
 
 struct MgsMirror {             // host-mapped; h[] follows (restart + 2 scalars of the handle's dtype)
     unsigned long long seq;
@@ -745,11 +753,8 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_mgs_fused(int64_t n, int k, const
     };
     auto publish = [&](int pass, T acc) {
         T tot = block_tree_256(acc, lds4);
-        if (t == 0) {
-            U bits;
-            __builtin_memcpy(&bits, &tot, sizeof(T));
-            __hip_atomic_store(reinterpret_cast<U *>(cur + (size_t)pass * 256) + s, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (t == 0)
+            __hip_atomic_store(reinterpret_cast<U *>(cur + (size_t)pass * 256) + s, mgs_slot_bits<T>(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     load(w, wr);
     T *hout = reinterpret_cast<T *>(mirror + 1);
@@ -898,19 +903,13 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_cgs_fused(int64_t n, int k, const
             tot_t = wsum[t][0];
             tot_t = tot_t + wsum[t][1]; tot_t = tot_t + wsum[t][2]; tot_t = tot_t + wsum[t][3];
         }
-        if (t < k) {
-            U bits;
-            __builtin_memcpy(&bits, &tot_t, sizeof(T));
-            __hip_atomic_store(reinterpret_cast<U *>(rb + (size_t)t * 256) + s, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (t < k)
+            __hip_atomic_store(reinterpret_cast<U *>(rb + (size_t)t * 256) + s, mgs_slot_bits<T>(tot_t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // (2) level 2 of column j by workgroup j mod m; everybody picks the finals up          k_finalize_store
         for (int j = s; j < k; j += m) {
             const T h = mgs_grid_sum<T>(rb + (size_t)j * 256, m, lds16, &s_err);
-            if (t == 0) {
-                U bits;
-                __builtin_memcpy(&bits, &h, sizeof(T));
-                __hip_atomic_store(reinterpret_cast<U *>(fin) + j, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (t == 0)
+                __hip_atomic_store(reinterpret_cast<U *>(fin) + j, mgs_slot_bits<T>(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (t < k) {
@@ -946,11 +945,8 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_cgs_fused(int64_t n, int k, const
                 if (base + (int64_t)l * MIK_BLOCK * W + e < n) { T p = wr[l][e] * wr[l][e]; acc = acc + p; }
         {
             T tot = block_tree_256(acc, lds4);
-            if (t == 0) {
-                U bits;
-                __builtin_memcpy(&bits, &tot, sizeof(T));
-                __hip_atomic_store(reinterpret_cast<U *>(rb + (size_t)k * 256) + s, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (t == 0)
+                __hip_atomic_store(reinterpret_cast<U *>(rb + (size_t)k * 256) + s, mgs_slot_bits<T>(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const T ss = mgs_grid_sum<T>(rb + (size_t)k * 256, m, lds16, &s_err);
         nrm = mik_sqrt(ss);

@@ -22,11 +22,7 @@ int mik_spmv_launch_range(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool
 template <typename T>
 int mik_spmv_launch_outside(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done, int skip_begin, int skip_end);
 bool mik_spmv_can_split(const mik_csr *A);
-bool mik_cg_head_available(const mik_csr *A);
 bool mik_spmv_is_light(const mik_csr *A);
-template <typename T>
-int mik_cg_head_launch(mik_ctx *ctx, const mik_csr *A, const T *r, const T *uo, T *un, T *x, T *c, T *seg_out, const T *alpha, const T *beta,
-                       const int *done, const int *pending);
 
 
 
@@ -201,13 +197,16 @@ template <typename T> static size_t orthogonalize_workspace(int64_t n, int k)
 // up to and including w .*= inv(nrm); leaves h in coef[0, k), nrm in coef[k].  For DGKS: the first CGS sweep and
 // the norm (the re-orthogonalisation loop needs the host, see orthogonalize_impl).
 template <typename T>
-static int orthogonalize_enqueue(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, T *w, int method)
+static int orthogonalize_enqueue(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, T *w, int method, const T *const *cols = nullptr)
 {
     const int64_t nseg = mik_nseg<T>(n);
     T *hd = (T *)ctx->coef;
     T *part = (T *)ctx->partials;
     const bool vecw = mik_aligned16(w);
-    const bool vec = vecw && mik_aligned16(V) && (ldv % VT<T>::W == 0);
+    bool vec = vecw && (cols || (mik_aligned16(V) && (ldv % VT<T>::W == 0)));
+    // `cols` (ModifiedGramSchmidt only): V is a vector of k separate device vectors -- the method of src/orthogonalize.jl:53-65
+    auto col = [&](int i) -> const T * { return cols ? cols[i] : V + (int64_t)i * ldv; };
+    if (cols) for (int i = 0; i < k; ++i) vec = vec && mik_aligned16(cols[i]);
     OpDot<T> dn{w, w};
 
     if (method == MIK_MGS && nseg <= 1024 && g_mik_tuning[5] != 1) {
@@ -217,13 +216,13 @@ static int orthogonalize_enqueue(mik_ctx *ctx, int64_t n, int k, const T *V, int
         T *P[2] = {part, part + 1024};
         const int m = (int)nseg;
         if (k > 0) {
-            OpDot<T> d0{V, w};
+            OpDot<T> d0{col(0), w};
             MIK_TRY((launch_map<T>(ctx, n, d0, vec, P[0], nullptr)));
             for (int i = 0; i + 1 < k; ++i) {
-                OpMgsPass<T, false> op{w, V + (int64_t)i * ldv, V + (int64_t)(i + 1) * ldv, coef_val<T>(T(0))};
+                OpMgsPass<T, false> op{w, col(i), col(i + 1), coef_val<T>(T(0))};
                 MIK_TRY((launch_map_pro<T, 1>(ctx, n, op, vec, P[(i + 1) & 1], P[i & 1], m, hd + i)));
             }
-            OpMgsPass<T, true> last{w, V + (int64_t)(k - 1) * ldv, nullptr, coef_val<T>(T(0))};
+            OpMgsPass<T, true> last{w, col(k - 1), nullptr, coef_val<T>(T(0))};
             MIK_TRY((launch_map_pro<T, 1>(ctx, n, last, vec, P[k & 1], P[(k - 1) & 1], m, hd + k - 1)));
         } else {
             MIK_TRY((launch_map<T>(ctx, n, dn, vecw, P[0], nullptr)));
@@ -235,15 +234,15 @@ static int orthogonalize_enqueue(mik_ctx *ctx, int64_t n, int k, const T *V, int
         // src/orthogonalize.jl:69-76.  Pass i subtracts h[i] * V[:, i] from w and, in the same sweep,
         // accumulates the next projection dot(V[:, i+1], w) -- or norm(w)^2 on the last pass.
         if (k > 0) {
-            OpDot<T> d0{V, w};
+            OpDot<T> d0{col(0), w};
             MIK_TRY((launch_map<T>(ctx, n, d0, vec, part, nullptr)));
             MIK_TRY(finalize_store<T>(ctx, nseg, 1, hd));
             for (int i = 0; i + 1 < k; ++i) {
-                OpMgsPass<T, false> op{w, V + (int64_t)i * ldv, V + (int64_t)(i + 1) * ldv, coef_ptr<T>(hd + i), (g_mik_tuning[13] & 1) == 0};
+                OpMgsPass<T, false> op{w, col(i), col(i + 1), coef_ptr<T>(hd + i), (g_mik_tuning[13] & 1) == 0};
                 MIK_TRY((launch_map<T>(ctx, n, op, vec, part, nullptr)));
                 MIK_TRY(finalize_store<T>(ctx, nseg, 1, hd + i + 1));
             }
-            OpMgsPass<T, true> last{w, V + (int64_t)(k - 1) * ldv, nullptr, coef_ptr<T>(hd + k - 1), (g_mik_tuning[13] & 1) == 0};
+            OpMgsPass<T, true> last{w, col(k - 1), nullptr, coef_ptr<T>(hd + k - 1), (g_mik_tuning[13] & 1) == 0};
             MIK_TRY((launch_map<T>(ctx, n, last, vec, part, nullptr)));
         } else {
             MIK_TRY((launch_map<T>(ctx, n, dn, vecw, part, nullptr)));
@@ -314,11 +313,12 @@ static int dgks_host_loop(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ld
 }
 
 template <typename T>
-static int orthogonalize_impl(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, T *w, T *h_host, T *nrm_host, int method)
+static int orthogonalize_impl(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, T *w, T *h_host, T *nrm_host, int method,
+                              const T *const *cols = nullptr)
 {
     if ((size_t)(2 * k + 4) * sizeof(T) > mik_ctx::COEF_SAFE_SLOT) return mik_fail(ctx, MIK_ERR_NOTIMPL, "orthogonalize: k = %d too large", k);
     MIK_TRY(mik_ensure_partials(ctx, orthogonalize_workspace<T>(n, k)));
-    MIK_TRY(orthogonalize_enqueue<T>(ctx, n, k, V, ldv, w, method));
+    MIK_TRY(orthogonalize_enqueue<T>(ctx, n, k, V, ldv, w, method, cols));
     if (method == MIK_DGKS) {                                            // src/orthogonalize.jl:20-36
         std::vector<T> hh(k + 2);
         MIK_TRY(coef_download<T>(ctx, 0, hh.data(), k + 2));
@@ -345,6 +345,15 @@ extern "C" int mik_orthogonalize(mik_ctx *ctx, int dtype, int64_t n, int k, cons
     if (method != MIK_MGS && method != MIK_CGS && method != MIK_DGKS) return MIK_ERR_INVALID;
     if (dtype == MIK_F64) return orthogonalize_impl<double>(ctx, n, k, (const double *)V, ldv, (double *)w, (double *)h, (double *)nrm, method);
     if (dtype == MIK_F32) return orthogonalize_impl<float>(ctx, n, k, (const float *)V, ldv, (float *)w, (float *)h, (float *)nrm, method);
+    return MIK_ERR_INVALID;
+}
+
+extern "C" int mik_orthogonalize_vectors(mik_ctx *ctx, int dtype, int64_t n, int k, const void *const *V, void *w, void *h, void *nrm)
+{
+    if (!ctx || n < 0 || k < 0 || !nrm || (k && (!h || !V)) || (n && !w)) return MIK_ERR_INVALID;
+    for (int i = 0; i < k; ++i) if (!V[i] && n) return MIK_ERR_INVALID;
+    if (dtype == MIK_F64) return orthogonalize_impl<double>(ctx, n, k, nullptr, 0, (double *)w, (double *)h, (double *)nrm, MIK_MGS, (const double *const *)V);
+    if (dtype == MIK_F32) return orthogonalize_impl<float>(ctx, n, k, nullptr, 0, (float *)w, (float *)h, (float *)nrm, MIK_MGS, (const float *const *)V);
     return MIK_ERR_INVALID;
 }
 
@@ -645,18 +654,6 @@ template <typename T> static int cg_enqueue_head(mik_cg *it)
             OpXpby<T> op{c, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 1};   // c = Pl \\ r is dead after this sweep
             MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
         }
-    } else if (it->fuse_head) {
-        // x .+= alpha .* u (previous step), u' = r .+ beta .* u, c = A * u', dot(u', c): ONE sweep (k_cg_head_sdiab2); the
-        // direction moves to the other of its two buffers                     src/cg.jl:50-55,58
-        T *uo = it->u_par ? (T *)it->u_alt : u, *un = it->u_par ? u : (T *)it->u_alt;
-        {
-            CgProfileScope ps(it, 0);
-            MIK_TRY(mik_cg_head_launch<T>(ctx, it->A, r, uo, un, x, c, (T *)it->seg_spmv, &d->alpha, &d->beta, done, &d->x_pending));
-        }
-        it->u_par ^= 1;
-        hipLaunchKernelGGL((k_cg_fin_alpha<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_spmv, nb, d, pcg, (FinScratch<T> *)it->fin);
-        MIK_LAUNCH_CHECK(ctx);
-        return MIK_OK;
     } else {
         // u .= r .+ beta .* u                                           src/cg.jl:50-51
         CgProfileScope ps(it, 1);
@@ -695,7 +692,7 @@ template <typename T> static int cg_enqueue_xflush(mik_cg *it)
 {
     mik_ctx *ctx = it->ctx;
     CgDev<T> *d = (CgDev<T> *)it->dev;
-    T *x = (T *)it->x, *u = it->u_par ? (T *)it->u_alt : (T *)it->u;
+    T *x = (T *)it->x, *u = (T *)it->u;
     OpXFlush<T> op{u, x, coef_ptr<T>(&d->alpha), &d->x_pending};
     MIK_TRY((launch_map<T>(ctx, it->n, op, mik_aligned16(x) && mik_aligned16(u), (T *)nullptr, (const int *)nullptr)));
     hipLaunchKernelGGL((k_cg_clear_pending<T>), dim3(1), dim3(1), 0, ctx->stream, d);
@@ -814,8 +811,6 @@ static int cg_create_common(mik_ctx *ctx, const mik_csr *A, int dtype, int64_t n
     it->x = x; it->b = b; it->u = u; it->r = r; it->c = c; it->diag = jacobi_diag;
     it->maxiter = maxiter;
     it->fuse_x = A != nullptr && !pl_fn && g_mik_tuning[23] == 0;       // development knob 23: 1 = x updated by the step's own sweep
-    // the whole head of the step as one sweep: plain CG where k_spmv_sdiab2 applies -- development knob 25 = 1 only (it is slower)
-    it->fuse_head = it->fuse_x && !jacobi_diag && n > 0 && mik_cg_head_available(A);
     const size_t es = mik_dtype_size(dtype);
     const int64_t nseg = dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
     const int64_t nb = mik_spmv_nwg(n);
@@ -829,10 +824,6 @@ static int cg_create_common(mik_ctx *ctx, const mik_csr *A, int dtype, int64_t n
         return mik_fail(ctx, MIK_ERR_NOMEM, "mik_cg_create: hipMalloc: %s", hipGetErrorString(e));
     }
     it->hist_cap = 64;
-    if (it->fuse_head && (e = hipMalloc(&it->u_alt, es * (size_t)n)) != hipSuccess) {
-        (void)hipGetLastError();
-        it->fuse_head = false;                                           // no room for the second direction buffer: the two-launch head
-    }
     if ((e = hipHostMalloc((void **)&it->mirror, sizeof(CgMirror), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) {
         mik_cg_destroy(it);
         return mik_fail(ctx, MIK_ERR_NOMEM, "mik_cg_create: hipHostMalloc: %s", hipGetErrorString(e));
@@ -893,7 +884,6 @@ extern "C" int mik_cg_destroy(mik_cg *it)
     if (it->hist) (void)hipFree(it->hist);
     if (it->seg_spmv) (void)hipFree(it->seg_spmv);
     if (it->seg_vec) (void)hipFree(it->seg_vec);
-    if (it->u_alt) (void)hipFree(it->u_alt);
     for (hipEvent_t e : it->ev) (void)hipEventDestroy(e);
     if (it->mirror) (void)hipHostFree(it->mirror);
     delete it;
@@ -908,6 +898,21 @@ static int cg_iterate_many_impl(mik_cg *it, int64_t iteration, int64_t max_steps
     // done(it, iteration)                                               src/cg.jl:36
     if (max_steps <= 0 || iteration >= it->maxiter || it->residual <= it->tol) return MIK_OK;
     max_steps = std::min(max_steps, it->maxiter - iteration);
+    if ((it->op_mul || it->pl_fn) && max_steps > 1) {
+        // Host callbacks run when a step is ENQUEUED: a batch would call mul! / ldiv! for steps that the device-side stopping
+        // test later turns into no-ops, and the caller may count those calls.  One host wait per step, like the reference's loop.
+        int64_t total = 0;
+        for (int64_t j = 0; j < max_steps; ++j) {
+            int64_t nd1 = 0;
+            double res1 = 0;
+            MIK_TRY(cg_iterate_many_impl<T>(it, iteration + j, 1, &res1, &nd1));
+            if (nd1 == 0) break;
+            if (residuals) residuals[total] = res1;
+            total += 1;
+        }
+        *steps_done = total;
+        return MIK_OK;
+    }
     if (max_steps > it->hist_cap) {
         MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         MIK_HIP(ctx, hipFree(it->hist));
@@ -967,11 +972,6 @@ static int cg_iterate_many_impl(mik_cg *it, int64_t iteration, int64_t max_steps
     it->dev_done = m.done != 0;
     it->mv_products += nd;
     *steps_done = nd;
-    if (it->u_par && !it->head_ahead && (m.done || iteration + nd >= it->maxiter || it->residual <= it->tol)) {
-        // the iteration is over and the direction sits in the library's second buffer: back into the caller's u
-        MIK_HIP(ctx, hipMemcpyAsync(it->u, it->u_alt, sizeof(T) * (size_t)it->n, hipMemcpyDeviceToDevice, ctx->stream));
-        it->u_par = 0;
-    }
     if (it->profile) cg_profile_collect(it);
     return MIK_OK;
 }
@@ -998,7 +998,7 @@ extern "C" int mik_cg_iterate(mik_cg *it, int64_t iteration, double *residual, i
 extern "C" int mik_cg_fused_x(const mik_cg *it, int *fused)
 {
     if (!it || !fused) return MIK_ERR_INVALID;
-    *fused = it->fuse_head ? 2 : it->fuse_x ? 1 : 0;
+    *fused = it->fuse_x ? 1 : 0;
     return MIK_OK;
 }
 
@@ -1070,6 +1070,7 @@ struct mik_gmres {
     bool graph_off = false;                   // capture / instantiation failed once: plain stream launches from then on
     // single-launch Modified Gram-Schmidt (k_mgs_fused): slot buffers [2][restart + 1][256] and the host-mapped mirror of (h, nrm)
     void *mgs_P = nullptr;
+    bool fused_off = false;          // latched when the single-launch kernel's bounded spin expired once: multi-launch chains from then on
     int mgs_rounds = 1;              // DGKS rounds the single-launch kernel runs before it hands back to the host loop
     MgsMirror *mgs_mirror = nullptr;          // two mirrors (bytes apart: mgs_mirror_stride), used alternately
     size_t mgs_mirror_stride = 0;
@@ -1501,6 +1502,8 @@ template <typename T> static int gm_fused_enqueue(mik_gmres *g, int k, int slot)
     return MIK_OK;
 }
 
+constexpr int MIK_GS_TIMEOUT = -100;      // internal: the bounded spin of the single-launch Gram-Schmidt expired
+
 template <typename T> static int gm_fused_wait(mik_gmres *g, int k, int slot, T *h_out, T *nrm_out, bool *rescaled)
 {
     mik_ctx *ctx = g->ctx;
@@ -1521,7 +1524,8 @@ template <typename T> static int gm_fused_wait(mik_gmres *g, int k, int slot, T 
         __builtin_ia32_pause();
 #endif
     }
-    if (mir->err) return mik_fail(ctx, MIK_ERR_HIP, "gmres: the single-launch Gram-Schmidt timed out waiting for a workgroup (not all resident?)");
+    if (mir->err || g_mik_tuning[30] == 1) return MIK_GS_TIMEOUT;        // (development knob 30: pretend it happened)
+    // a workgroup gave up waiting for a slot (GPU shared with other work?): the caller redoes the column
     const T *out = reinterpret_cast<const T *>(mir + 1);
     for (int j = 0; j < k; ++j) h_out[j] = out[j];
     *nrm_out = out[k];
@@ -1566,7 +1570,7 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
     if (g_mik_tuning[5] == 3 && !g->dist && !g->graph_off && g->method != MIK_DGKS && mik_nseg<T>(g->n) <= 1024 && !g->op_mul && !g->pl_fn && !g->pr_fn)
         MIK_TRY(gm_step_graph<T>(g, k, vk, vk1, &Hat(0, k - 1), &nrm, &ran));
     if (!ran) {
-        if (g->mgs_P && !g->dist && g_mik_tuning[5] == 0) {                // tuning[5]: 1 / 2 = the multi-launch chains
+        if (g->mgs_P && !g->dist && !g->fused_off && g_mik_tuning[5] == 0) {    // tuning[5]: 1 / 2 = the multi-launch chains
             // single-launch Gram-Schmidt, one column ahead of the host: column k is on the stream already if the previous
             // call put it there; column k + 1 goes on the stream BEFORE this call waits for column k (never across a restart,
             // never with host callbacks in expand!, whose call count the caller may observe)
@@ -1576,8 +1580,22 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
             const bool ahead = k < m && iteration + 1 < g->maxiter && !g->op_mul && !g->pl_fn && !g->pr_fn && g_mik_tuning[9] == 0;
             if (ahead) MIK_TRY(gm_fused_enqueue<T>(g, k + 1, slot ^ 1));
             bool rescaled = false;
-            MIK_TRY(gm_fused_wait<T>(g, k, slot, &Hat(0, k - 1), &nrm, &rescaled));
-            if (ahead && !rescaled) { g->pre_k = k + 1; g->pre_slot = slot ^ 1; }    // rescaled: column k + 1 was built on an unscaled w
+            const int rcw = gm_fused_wait<T>(g, k, slot, &Hat(0, k - 1), &nrm, &rescaled);
+            if (rcw == MIK_GS_TIMEOUT) {
+                // The hand-off needs every workgroup resident; a GPU shared with other streams or processes can break that.
+                // Not an error of the solve: drain the stream (a column enqueued ahead drains with it), switch this handle to the
+                // multi-launch chains for good, and redo column k from V[:, k - 1], which the kernel never writes.
+                MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                gm_mirror(g, 0)->err = 0;
+                gm_mirror(g, 1)->err = 0;
+                g->fused_off = true;
+                g->pre_k = 0;
+                MIK_TRY(gm_expand<T>(g, vk, vk1));
+                MIK_TRY(orthogonalize_impl<T>(ctx, g->n, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));
+            } else {
+                MIK_TRY(rcw);
+                if (ahead && !rescaled) { g->pre_k = k + 1; g->pre_slot = slot ^ 1; }    // rescaled: column k + 1 was built on an unscaled w
+            }
         } else {
             MIK_TRY(gm_expand<T>(g, vk, vk1));
             if (g->dist) MIK_TRY(orthogonalize_part<T>(g, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));

@@ -649,185 +649,5 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab2(int n, int ncols, int
     }
 }
 
-// ---- the HEAD of a plain CG step as ONE sweep ----------------------------------------------------------------------------
-//     x .+= alpha .* u   (of the previous step, if pending)     u' = r .+ beta .* u     c = A * u'     partial dot(u', c)
-// (src/cg.jl:50-55 and the x half of :58).  k_map<OpXpbyX> followed by the SpMV moves 5 n + 2 n scalars (u' is written and
-// read back); here a lane forms u' of its two rows, hands it to the lanes on either side for the slots around the centre,
-// and forms u' of the gathered neighbours from 16-byte gathers of r and of the OLD u (out of the L2, like x in the SpMV):
-// u' is written once and never read back -- 6 n scalars -- and the gathers hide under the streams.  With one row per lane
-// and 8-byte gathers the same sweep took 208 us against 100 + 79 us for the two launches; gathers are priced per
-// instruction (scripts/micro/gather_width.hip), so it only pays in this two-rows-per-lane form.
-// Every u' is the rounded multiply and rounded add of OpXpbyX, every product and sum those of k_spmv_sdiab2, the dot
-// partials its tree: bit-identical results.  The old u must stay intact while neighbours read it, so the direction
-// alternates between two buffers (uo -> un; mik_cg keeps the second one).  An absent slot reads r = u = +0 and forms
-// +0 + beta * 0 = +0 (beta finite).  Once the iteration has stopped (`done`) the sweep applies a pending x update and
-// copies u across, so the host's buffer parity holds whatever the device decided.
-// HINT bits: 8 = x streamed past the caches (load and store), 4 = u' stored nt, 16 = c stored temporal.
-template <typename T, int AUX> __device__ __forceinline__ Pair2<T> buffer_get2(__amdgpu_buffer_rsrc_t rs, unsigned voff);
-template <> __device__ __forceinline__ Pair2<double> buffer_get2<double, 0>(__amdgpu_buffer_rsrc_t rs, unsigned voff)
-{
-    return __builtin_bit_cast(Pair2<double>, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0));
-}
-template <> __device__ __forceinline__ Pair2<double> buffer_get2<double, 2>(__amdgpu_buffer_rsrc_t rs, unsigned voff)
-{
-    return __builtin_bit_cast(Pair2<double>, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 2));
-}
-template <> __device__ __forceinline__ Pair2<float> buffer_get2<float, 0>(__amdgpu_buffer_rsrc_t rs, unsigned voff)
-{
-    return __builtin_bit_cast(Pair2<float>, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, 0, 0));
-}
-template <> __device__ __forceinline__ Pair2<float> buffer_get2<float, 2>(__amdgpu_buffer_rsrc_t rs, unsigned voff)
-{
-    return __builtin_bit_cast(Pair2<float>, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, 0, 2));
-}
-
-template <typename T, int NS, int CQ, int HINT>
-__global__ __launch_bounds__(MIK_BLOCK) void k_cg_head_sdiab2(int n, int koff, int np, int nfull, int sshift, int nslices, const SdiaSliceRec *__restrict__ recs,
-                                                              const SdiaPattern<T> *__restrict__ pats, const unsigned char *__restrict__ mask,
-                                                              const T *__restrict__ r, const T *__restrict__ uo, T *__restrict__ un,
-                                                              T *__restrict__ x, T *__restrict__ c, T *__restrict__ seg_out,
-                                                              const T *__restrict__ alpha_p, const T *__restrict__ beta_p,
-                                                              const int *__restrict__ done, const int *__restrict__ pending)
-{
-    static_assert(NS >= 3 && CQ >= 1 && CQ + 1 < NS, "the class must have slots around the centre");
-    constexpr int U = 8;
-    constexpr unsigned ES = (unsigned)sizeof(T);
-    constexpr int XH = (HINT & 8) ? 2 : 0;
-    __shared__ T lds[8];
-    const int dn = *done, pd = *pending;
-    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const unsigned nbytes = (unsigned)n * ES;
-    const __amdgpu_buffer_rsrc_t gu = __builtin_amdgcn_make_buffer_rsrc((void *)((uintptr_t)uo - (uintptr_t)koff * ES), (short)0, (int)0xFFFFFFF0u, (int)0x00020000);
-    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void *)((uintptr_t)r - (uintptr_t)koff * ES), (short)0, (int)0xFFFFFFF0u, (int)0x00020000);
-    const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc((void *)mask, (short)0, n, (int)0x00020000);
-    // own-row streams, range-checked: a pair past the end reads 0 and its stores are dropped
-    const __amdgpu_buffer_rsrc_t ou = __builtin_amdgcn_make_buffer_rsrc((void *)uo, (short)0, (int)nbytes, (int)0x00020000);
-    const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void *)r, (short)0, (int)nbytes, (int)0x00020000);
-    const __amdgpu_buffer_rsrc_t nu = __builtin_amdgcn_make_buffer_rsrc((void *)un, (short)0, (int)nbytes, (int)0x00020000);
-    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc((void *)x, (short)0, (int)nbytes, (int)0x00020000);
-    const __amdgpu_buffer_rsrc_t cs = __builtin_amdgcn_make_buffer_rsrc((void *)c, (short)0, (int)nbytes, (int)0x00020000);
-    const bool real = (int)blockIdx.x < np;             // a workgroup past the end repeats the last pair: same bits, but x only once
-    const int vb = min((int)blockIdx.x, np - 1);
-    const int pb = spmv_block_map_shift(vb, nfull, sshift);
-    const int sl = min(2 * pb + (w >> 1), nslices - 1);
-    const int r0 = pb * (2 * MIK_BLOCK) + w * 128 + 2 * lane;
-    const unsigned rowoff = (unsigned)r0 * ES;
-    const unsigned m16 = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(ms, r0, 0, 0);
-    const Pair2<T> uown = buffer_get2<T, 0>(ou, rowoff);
-    if (dn) {                                           // stopped: a pending x update, and u as it is into the other buffer
-        if (pd && real) {
-            const T a = *alpha_p;
-            const Pair2<T> xo = buffer_get2<T, XH>(xs, rowoff);
-            const T ta = a * uown.a, tb = a * uown.b;
-            buffer_put2<T>(xs, rowoff, xo.a + ta, xo.b + tb, XH != 0);
-        }
-        if (uo != un) buffer_put2<T>(nu, rowoff, uown.a, uown.b, false);
-        return;
-    }
-    const Pair2<T> rown = buffer_get2<T, 0>(orr, rowoff);
-    Pair2<T> xo = {T(0), T(0)};
-    if (pd) xo = buffer_get2<T, XH>(xs, rowoff);
-    int minv0 = ~(int)(m16 & 0xffu), minv1 = ~(int)((m16 >> 8) & 0xffu);
-    const SdiaSliceRec rc = recs[sl];
-    const SdiaPattern<T> *__restrict__ pt = pats + rc.pid;
-    const T b = *beta_p;
-    asm volatile("" : "+v"(minv0), "+v"(minv1));
-    constexpr int NLMASK = ((1 << NS) - 1) & ~(7 << (CQ - 1));
-    const bool mixed = __builtin_amdgcn_ballot_w64(((minv0 ^ minv1) & NLMASK) != 0) != 0;
-    const bool fast = (rc.ns == NS) & (rc.cq == CQ) & (rc.soff[CQ - 1] + (int)ES == rc.soff[CQ]) & (rc.soff[CQ] + (int)ES == rc.soff[CQ + 1]) & !mixed;
-    // u' of the own rows                                                                                src/cg.jl:51
-    T upa, upb;
-    { const T ta = b * uown.a; upa = rown.a + ta; const T tb = b * uown.b; upb = rown.b + tb; }
-    T acc0, acc1;
-    if (fast) {
-        // the outer neighbour of the wave's first / last row: its u and r.  (The operator is square: past the last row there is
-        // nothing, and the lanes above it deliver u' = +0 -- so only lane 63 needs to look; lane 0 always does.)
-        T ue = T(0), re = T(0);
-        if (lane == 0 || lane == 63) {
-            const unsigned ab = (unsigned)(lane == 0 ? __builtin_amdgcn_sbfe(minv0, CQ - 1, 1) : __builtin_amdgcn_sbfe(minv1, CQ + 1, 1));
-            const unsigned vo = (lane == 0 ? rowoff - ES : rowoff + 2 * ES) | ab;
-            ue = buffer_gather<T>(ou, vo, 0);
-            re = buffer_gather<T>(orr, vo, 0);
-        }
-        Pair2<T> ug[NS], rg[NS];
-#pragma unroll
-        for (int q = 0; q < NS; ++q)
-            if (q < CQ - 1 || q > CQ + 1) {
-                const unsigned vo = rowoff | (unsigned)__builtin_amdgcn_sbfe(minv0, q, 1);
-                ug[q] = buffer_gather2<T>(gu, vo, rc.soff[q]);
-                rg[q] = buffer_gather2<T>(gr, vo, rc.soff[q]);
-            }
-        T below = lane_next<true>(upb), above = lane_next<false>(upa);     // u' of rows r0 - 1 and r0 + 2
-        { const T te = b * ue; const T upe = re + te; if (lane == 0) below = upe; if (lane == 63) above = upe; }
-        Pair2<T> xg[NS];
-#pragma unroll
-        for (int q = 0; q < NS; ++q)
-            if (q < CQ - 1 || q > CQ + 1) {
-                const T ta = b * ug[q].a, tb = b * ug[q].b;
-                xg[q] = {rg[q].a + ta, rg[q].b + tb};
-            }
-        xg[CQ - 1] = {((minv0 >> (CQ - 1)) & 1) ? T(0) : below, ((minv1 >> (CQ - 1)) & 1) ? T(0) : upa};
-        xg[CQ] = {((minv0 >> CQ) & 1) ? T(0) : upa, ((minv1 >> CQ) & 1) ? T(0) : upb};
-        xg[CQ + 1] = {((minv0 >> (CQ + 1)) & 1) ? T(0) : upb, ((minv1 >> (CQ + 1)) & 1) ? T(0) : above};
-        T a0 = T(0), a1 = T(0);
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-            const T v = pt->val[q];
-            T p0 = v * xg[q].a; a0 = a0 + p0;
-            T p1 = v * xg[q].b; a1 = a1 + p1;
-        }
-        acc0 = a0; acc1 = a1;
-    } else {
-        const int ns = rc.ns;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const unsigned ro = rowoff + (unsigned)e * ES;
-            const int mi = e ? minv1 : minv0;
-            T uv[U], rv[U];
-#pragma unroll
-            for (int q = 0; q < U; ++q) {
-                uv[q] = T(0); rv[q] = T(0);
-                if (q < ns) {
-                    const unsigned vo = ro | (unsigned)__builtin_amdgcn_sbfe(mi, q, 1);
-                    uv[q] = buffer_gather<T>(gu, vo, rc.soff[q]);
-                    rv[q] = buffer_gather<T>(gr, vo, rc.soff[q]);
-                }
-            }
-            T a = T(0);
-#pragma unroll
-            for (int q = 0; q < U; ++q) {
-                if (q < ns) {
-                    const T tb = b * uv[q];
-                    const T up = rv[q] + tb;
-                    const T pr = pt->val[q] * up;
-                    a = a + pr;
-                }
-            }
-            if (e) acc1 = a; else acc0 = a;
-        }
-    }
-    if (pd && real) {                                   // x .+= alpha .* u of the previous step               src/cg.jl:58
-        const T a = *alpha_p;
-        const T ta = a * uown.a, tb = a * uown.b;
-        buffer_put2<T>(xs, rowoff, xo.a + ta, xo.b + tb, XH != 0);
-    }
-    buffer_put2<T>(nu, rowoff, upa, upb, (HINT & 4) != 0);
-    buffer_put2<T>(cs, rowoff, acc0, acc1, (HINT & 16) == 0);
-    T s0 = upa * acc0, s1 = upb * acc1;                 // a pair past the end: 0 * +0
-    s0 = s0 + lane_down<16>(s0); s1 = s1 + lane_down<16>(s1);
-    s0 = s0 + lane_down<8>(s0);  s1 = s1 + lane_down<8>(s1);
-    s0 = s0 + lane_down<4>(s0);  s1 = s1 + lane_down<4>(s1);
-    s0 = s0 + lane_down<2>(s0);  s1 = s1 + lane_down<2>(s1);
-    s0 = s0 + lane_down<1>(s0);  s1 = s1 + lane_down<1>(s1);
-    const T ws = s0 + s1;
-    if ((lane & 31) == 0) lds[2 * w + (lane >> 5)] = ws;
-    __syncthreads();
-    if (t < 2 && 2 * pb + t < nslices) {
-        T tot = lds[4 * t];
-        tot = tot + lds[4 * t + 1]; tot = tot + lds[4 * t + 2]; tot = tot + lds[4 * t + 3];
-        seg_out[2 * pb + t] = tot;
-    }
-}
-
 #endif  // __HIPCC__
 #endif  // MIK_SELL_H

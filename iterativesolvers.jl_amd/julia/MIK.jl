@@ -195,6 +195,17 @@ function HipCSR(A::SparseMatrixCSC{T, Int64}, ctx::Context = context()) where {T
     finalizer(o -> alive(o.ctx) && ccall((:mik_csr_destroy, libmik), Cint, (Ptr{Cvoid},), o.handle), op)
     op
 end
+"SparseMatrixCSC{T,Int32} -- the reference's tests run `Ti in (Int64, Int32)` (test/gmres.jl:38): 32-bit colptr / rowval."
+function HipCSR(A::SparseMatrixCSC{T, Int32}, ctx::Context = context()) where {T<:MikFloat}
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve A check(ccall((:mik_csr_create_i32, libmik), Cint,
+        (Ptr{Cvoid}, Cint, Int64, Int64, Int64, Ptr{Int32}, Ptr{Int32}, Ptr{Cvoid}, Cint, Cint, Ref{Ptr{Cvoid}}),
+        ctx.handle, dtype_code(T), size(A, 1), size(A, 2), nnz(A), pointer(A.colptr), pointer(A.rowval), pointer(A.nzval), 1, 1, h),
+        "mik_csr_create_i32", ctx.handle)
+    op = HipCSR{T}(h[], size(A, 1), size(A, 2), ctx)
+    finalizer(o -> alive(o.ctx) && ccall((:mik_csr_destroy, libmik), Cint, (Ptr{Cvoid},), o.handle), op)
+    op
+end
 """
 The same upload from arrays that already live in DEVICE memory -- the colPtr / rowVal / nzVal buffers of an AMDGPU.jl
 ROCSparseMatrixCSC, passed as raw device pointers: mik_csr_create detects the placement and starts its device-side pipeline
@@ -578,6 +589,23 @@ function iterate_many!(it::HipDistCG, iteration::Int, max_steps::Int)
     resize!(res, nd[])
     isempty(res) || (it.residual = res[end])
     res
+end
+
+"""
+orthogonalize_and_normalize!(V::Vector{Vector}, w, h, ModifiedGramSchmidt()) -- src/orthogonalize.jl:53-65 -- for a basis kept as
+separate device vectors: one C call, same arithmetic and bits as the matrix method (mik_orthogonalize_vectors).
+"""
+function IterativeSolvers.orthogonalize_and_normalize!(V::Vector{HipVector{T}}, w::HipVector{T}, h::AbstractVector{T},
+                                                       ::IterativeSolvers.ModifiedGramSchmidt) where {T<:MikFloat}
+    k = length(V)
+    ptrs = Ptr{Cvoid}[v.ptr for v in V]
+    hh = Vector{T}(undef, max(k, 1))
+    nrm = Ref{T}(zero(T))
+    GC.@preserve V ptrs hh check(ccall((:mik_orthogonalize_vectors, libmik), Cint,
+        (Ptr{Cvoid}, Cint, Int64, Cint, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}, Ptr{T}, Ref{T}),
+        w.ctx.handle, dtype_code(T), w.n, k, ptrs, w.ptr, hh, nrm), "mik_orthogonalize_vectors", w.ctx.handle)
+    copyto!(h, 1, hh, 1, k)
+    nrm[]
 end
 
 end # module

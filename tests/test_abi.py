@@ -11,12 +11,17 @@ import pytest
 from conftest import ROOT
 
 HEADER = os.path.join(ROOT, "include", "mik.h")
+DEV_HEADER = os.path.join(ROOT, "include", "mik_dev.h")      # development knobs: exported, bound, but not part of the boundary
 
 
 def declared_symbols():
-    src = open(HEADER).read()
+    src = open(HEADER).read() + open(DEV_HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(mik_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_boundary_header_is_free_of_development_knobs():
+    assert "mik_set_tuning" not in open(HEADER).read() and "mik_set_tuning" in open(DEV_HEADER).read()
 
 
 def test_header_declares_something():

@@ -30,7 +30,7 @@ def run(pkg, A, b, schedule, knobs, Pl=None, **kw):
                 if r.size < steps:
                     break
             snaps.append((x.to_numpy(), it.r.to_numpy()))          # what a caller sees between two calls
-        run.last_u, run.last_head = it.u.to_numpy(), it.fused_head()
+        run.last_u = it.u.to_numpy()
         return np.array(hist), snaps, it.converged if hasattr(it, "converged") else None
     finally:
         for k2 in knobs:
@@ -47,12 +47,9 @@ def test_lookahead_changes_nothing_the_caller_can_see(pkg, orc, ctx, dtype, pcg,
     schedule = [1, 1, 3, 1, 7, 1, 1, 25, 1, 1]
     kw = dict(reltol=0.0, maxiter=10 ** 6)
     h1, s1, _ = run(pkg, A, b, schedule, {}, Pl, **kw)
-    assert not run.last_head
-    # no look-ahead; x updated by the step's own sweep; neither; the head of the step as ONE sweep (k_cg_head_sdiab2: plain CG,
-    # even number of rows), also without look-ahead; one row per lane
-    for knobs in ({9: 1}, {23: 1}, {9: 1, 23: 1}, {25: 1}, {25: 1, 9: 1}, {19: 1}):
+    # no look-ahead; x updated by the step's own sweep; neither; one row per lane
+    for knobs in ({9: 1}, {23: 1}, {9: 1, 23: 1}, {19: 1}):
         h0, s0, _ = run(pkg, A, b, schedule, knobs, Pl, **kw)
-        assert run.last_head == (25 in knobs and not pcg and A.n % 2 == 0), knobs
         assert np.array_equal(h1, h0) and len(s1) == len(s0), knobs
         for (x1, r1), (x0, r0) in zip(s1, s0):
             assert np.array_equal(x1, x0) and np.array_equal(r1, r0), knobs
@@ -69,13 +66,11 @@ def test_lookahead_at_the_stopping_tests(pkg, orc, ctx, N):
         for schedule in ([1] * 200, [4] * 60, [1, 5, 1, 9] * 20):
             h1, s1, _ = run(pkg, A, b, schedule, {}, **kw)
             u1 = run.last_u
-            for knobs in ({9: 1}, {23: 1}, {9: 1, 23: 1}, {25: 1}, {25: 1, 9: 1}):
+            for knobs in ({9: 1}, {23: 1}, {9: 1, 23: 1}):
                 h0, s0, _ = run(pkg, A, b, schedule, knobs, **kw)
-                assert run.last_head == (25 in knobs and A.n % 2 == 0), knobs
                 assert np.array_equal(h1, h0) and len(s1) == len(s0) and len(h1) > 0, knobs
                 assert np.array_equal(s1[-1][0], s0[-1][0]) and np.array_equal(s1[-1][1], s0[-1][1]), knobs
-                # the caller's u is the last direction: a head that ran ahead of a stopped iteration leaves it alone, and the
-                # one-sweep head, whose direction alternates between two buffers, hands it back
+                # the caller's u is the last direction: a head that ran ahead of a stopped iteration leaves it alone
                 assert np.array_equal(u1, run.last_u), knobs
             if kw["maxiter"] == 13:
                 assert len(h1) == 13

@@ -541,3 +541,65 @@ def test_cg_bit_exact_at_128_cubed(pkg, orc, ctx, dtype):
     xo, ho = orc.cg(A, b, maxiter=40, reltol=0.0, mode="tree", shape=ctx.cg_shape(dtype))
     assert np.array_equal(ch["resnorm"], np.asarray(ho["resnorm"], dtype=np.float64))
     assert np.array_equal(x.to_numpy(), xo)
+
+
+def test_gmres_single_launch_gram_schmidt_falls_back_and_survives_nan(pkg, orc, ctx):
+    """(1) if the bounded spin of the single-launch Gram-Schmidt expires (GPU shared with other work) the handle
+    redoes the column with the multi-launch chain and stays there -- same bits, no error (development knob 30 simulates the
+    expiry); (2) a right-hand side whose bytes are all 0xFF is a NaN with the payload the slots use for "not yet written":
+    the solve must report NaN residuals like the reference would, not a time-out."""
+    A, b = orc.advdiff(8, 50.0)
+    dA = upload(pkg, A)
+    for M in (pkg.ModifiedGramSchmidt(), pkg.ClassicalGramSchmidt(), pkg.DGKS()):
+        x0, h0 = pkg.gmres(dA, pkg.HipVector.from_numpy(b), restart=12, orth_meth=M, log=True, maxiter=60)
+        pkg.lib().mik_set_tuning(30, 1)
+        try:
+            x1, h1 = pkg.gmres(dA, pkg.HipVector.from_numpy(b), restart=12, orth_meth=M, log=True, maxiter=60)
+        finally:
+            pkg.lib().mik_set_tuning(30, 0)
+        assert np.array_equal(h0["resnorm"], h1["resnorm"]) and np.array_equal(x0.to_numpy(), x1.to_numpy()) and h0.mvps == h1.mvps
+    bad = np.frombuffer(b"\xff" * (8 * A.n), dtype=np.float64).copy()
+    bad[::3] = b[::3]
+    x, h = pkg.gmres(dA, pkg.HipVector.from_numpy(bad), restart=12, log=True, maxiter=5)
+    assert len(h["resnorm"]) >= 1 and np.all(np.isnan(h["resnorm"]))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_int32_indexed_csc_input(pkg, orc, ctx, dtype):
+    """test/gmres.jl:38 runs `Ti in (Int64, Int32)`: a SparseMatrixCSC{T,Int32} uploads through mik_csr_create_i32 and gives the
+    operator (layout, bits) of its Int64 twin"""
+    A, b = orc.advdiff(7, 80.0)
+    A = A.astype(dtype)
+    d64 = upload(pkg, A)
+    d32 = pkg.HipCSR(A.n, A.n, A.colptr.astype(np.int32), A.rowval.astype(np.int32), A.nzval, index_base=A.index_base)
+    assert d32.layout() == d64.layout() and d32.nnz == d64.nnz
+    x = np.random.default_rng(0).standard_normal(A.n).astype(dtype)
+    assert np.array_equal((d32 @ pkg.HipVector.from_numpy(x)).to_numpy(), orc.spmv(A, x))
+    xs32, h32 = pkg.gmres(d32, pkg.HipVector.from_numpy(b.astype(dtype)), restart=10, log=True, maxiter=40)
+    xs64, h64 = pkg.gmres(d64, pkg.HipVector.from_numpy(b.astype(dtype)), restart=10, log=True, maxiter=40)
+    assert np.array_equal(h32["resnorm"], h64["resnorm"]) and np.array_equal(xs32.to_numpy(), xs64.to_numpy())
+    with pytest.raises(pkg.MikError):                                   # index out of range is still caught
+        bad = A.rowval.astype(np.int32).copy()
+        bad[3] = A.n + 5
+        pkg.HipCSR(A.n, A.n, A.colptr.astype(np.int32), bad, A.nzval, index_base=A.index_base)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,k", [(1000, 0), (1000, 1), (70000, 7), (2500000, 3)])
+def test_orthogonalize_vector_of_vectors_equals_the_matrix_method(pkg, orc, ctx, dtype, n, k):
+    """src/orthogonalize.jl:53-65: the basis as a Vector of vectors (ModifiedGramSchmidt only) -- same h, nrm and w, bit for bit,
+    as the matrix method on the same columns (both chain forms: n below and above 1024 reduction segments)"""
+    rng = np.random.default_rng(7)
+    Vh = np.linalg.qr(rng.standard_normal((n, max(k, 1))))[0][:, :k].astype(dtype)
+    wh = rng.standard_normal(n).astype(dtype)
+    V = pkg.HipMatrix(n, max(k, 1), dtype)
+    for j in range(k):
+        V.col(j).copy_from_host(np.ascontiguousarray(Vh[:, j]))
+    w1, w2 = pkg.HipVector.from_numpy(wh), pkg.HipVector.from_numpy(wh)
+    h1, h2 = np.zeros(max(k, 1), dtype), np.zeros(max(k, 1), dtype)
+    n1 = pkg.orthogonalize_and_normalize_(V, k, w1, h1, pkg.ModifiedGramSchmidt())
+    cols = [pkg.HipVector.from_numpy(np.ascontiguousarray(Vh[:, j])) for j in range(k)]
+    n2 = pkg.orthogonalize_and_normalize_(cols, k, w2, h2)
+    assert n1 == n2 and np.array_equal(h1, h2) and np.array_equal(w1.to_numpy(), w2.to_numpy())
+    with pytest.raises(TypeError):
+        pkg.orthogonalize_and_normalize_(cols, k, w2, h2, pkg.ClassicalGramSchmidt())
