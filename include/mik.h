@@ -46,7 +46,11 @@
  *  t' = the same tree over (x_i * s)^2; norm = sqrt(t') / s.  mik_nrm2, the fused sweeps and the single-GPU iterables
  *  (CG residual, GMRES beta and the Gram-Schmidt norms) all do this, so a solve on a system scaled by 1e-200 takes
  *  the iterations of the unscaled one instead of "converging" on a residual that underflowed to 0.  The row-partitioned
- *  iterables return MIK_ERR_RANGE instead (the scaled pass would need a max over ranks).  The oracle mirrors it.
+ *  iterables do the same ACROSS the ranks: every rank sees the same out-of-range total, the ranks exchange their local max |x_i|
+ *  (mik_cgd_init / mik_cgd_iterate_many / the group calls: one more scalar gather; mik_gmres_create_partitioned: through the
+ *  reduce() callback, every rank contributing its value in its own slot of a zero vector), scale by the common power of two,
+ *  add the local tree sums in rank order and divide -- so switching to N GPUs does not change what converges.  Only the legacy
+ *  host-driven phases (mik_cgd_phase + mik_cgd_wait) still report MIK_ERR_RANGE.  The oracle mirrors it.
  */
 #ifndef MIK_H
 #define MIK_H
@@ -69,7 +73,7 @@ enum {
     MIK_ERR_NOMEM = 4,       /* out of (device or host) memory */
     MIK_ERR_NOTIMPL = 5,     /* not implemented (e.g. nnz >= 2^31) */
     MIK_ERR_CALLBACK = 6,    /* a mik_partition / operator / preconditioner callback returned non-zero */
-    MIK_ERR_RANGE = 7        /* a norm left the range in which the row-partitioned path can evaluate it (see "Norms") */
+    MIK_ERR_RANGE = 7        /* a norm left the safe range while the HOST drives the phases of a row-partitioned step itself (see "Norms") */
 };
 
 enum { MIK_F64 = 0, MIK_F32 = 1 };

@@ -346,11 +346,66 @@ static int rccl_gather_scalar(mik_cgd *it, void *all)
     return MIK_OK;
 }
 
+// ---- the over-/underflow-safe norm of r across the partition (include/mik.h "Norms") ---------------------------------------
+// Every rank saw the same out-of-range total, so every rank comes here.  Stage 0: local max |r_i| into rr_all[rank]; [gather];
+// stage 1: amax = max over the ranks (0 / Inf / NaN are the norm as they are), s = 2^-exponent(amax) -- the SAME exact power of
+// two on every rank -- then the local tree sum of (r_i s)^2 into rr_all[rank]; [gather]; stage 2: the rank sums added in rank
+// order, norm = sqrt(t') / s.  The oracle's safe_nrm_ with a partition (oracle/orc_impl.inc) is this arithmetic.
+template <typename T> static int cgd_read_slots(mik_cgd *it, std::vector<T> &v)
+{
+    mik_ctx *ctx = it->base.ctx;
+    v.resize((size_t)it->nranks);
+    MIK_HIP(ctx, hipMemcpyAsync(v.data(), it->rr_all, sizeof(T) * v.size(), hipMemcpyDeviceToHost, ctx->stream));
+    MIK_HIP(ctx, mik_wait(ctx));
+    return MIK_OK;
+}
+
+// returns *direct = true when the norm is known after stage 1 (no second pass; identical decision on every rank)
+template <typename T> static int cgd_norm_stage1(mik_cgd *it, bool *direct)
+{
+    std::vector<T> v;
+    MIK_TRY(cgd_read_slots<T>(it, v));
+    T amax = T(0);
+    for (T a : v) amax = (a > amax || a != a) ? a : amax;
+    *direct = amax == T(0) || amax != amax || amax > std::numeric_limits<T>::max();
+    if (*direct) { it->norm_res = (double)amax; return MIK_OK; }
+    int e;
+    (void)std::frexp((double)amax, &e);
+    e = std::max(-NrmRange<T>::EC, std::min(NrmRange<T>::EC, e));
+    it->norm_scale = std::ldexp(1.0, -e);
+    return mik_cgd_phase(it, 22, 0);
+}
+
+template <typename T> static int cgd_norm_stage2(mik_cgd *it)
+{
+    std::vector<T> v;
+    MIK_TRY(cgd_read_slots<T>(it, v));
+    T t2 = v[0];
+    for (size_t q = 1; q < v.size(); ++q) t2 = t2 + v[q];
+    const T sinv = (T)(1.0 / it->norm_scale);              // exact: a power of two
+    it->norm_res = (double)((T)std::sqrt(t2) * sinv);
+    return MIK_OK;
+}
+
+static int cgd_norm_stage1_any(mik_cgd *it, bool *direct) { return it->base.dtype == MIK_F64 ? cgd_norm_stage1<double>(it, direct) : cgd_norm_stage1<float>(it, direct); }
+static int cgd_norm_stage2_any(mik_cgd *it) { return it->base.dtype == MIK_F64 ? cgd_norm_stage2<double>(it) : cgd_norm_stage2<float>(it); }
+
 static int cgd_require_transport(mik_cgd *it, const char *who)
 {
     if (it->nranks > 1 && (!it->comm || !it->comm->nccl))
         return mik_fail(it->base.ctx, MIK_ERR_INVALID, "%s: %d ranks need a communicator (mik_cgd_set_comm) or the in-process group calls", who, it->nranks);
     return MIK_OK;
+}
+
+static int rccl_scaled_norm(mik_cgd *it)
+{
+    bool direct = false;
+    MIK_TRY(mik_cgd_phase(it, 20, 0));
+    MIK_TRY(rccl_gather_scalar(it, it->rr_all));
+    MIK_TRY(cgd_norm_stage1_any(it, &direct));
+    if (direct) return MIK_OK;
+    MIK_TRY(rccl_gather_scalar(it, it->rr_all));
+    return cgd_norm_stage2_any(it);
 }
 
 // cg_iterator! (src/cg.jl:120-155) over the partition: phases 10, [halo of x], 11, [gather |r|^2], 12, then one wait.
@@ -367,7 +422,14 @@ extern "C" int mik_cgd_init(mik_cgd *it, double *residual, double *tol)
     MIK_TRY(mik_cgd_phase(it, 12, 0));
     int done = 0;
     int64_t steps = 0;
-    MIK_TRY(mik_cgd_wait(it, residual, tol, &done, nullptr, 0, &steps));
+    CgMirror m;
+    MIK_TRY(cgd_wait_raw(it, &m));
+    if (m.range) {                                                  // norm(r) outside the safe range on every rank alike: common scale
+        MIK_TRY(rccl_scaled_norm(it));
+        MIK_TRY(mik_cgd_phase(it, 24, 0));
+        MIK_TRY(cgd_wait_raw(it, &m));
+    }
+    MIK_TRY(cgd_collect(it, m, residual, tol, &done, nullptr, 0, &steps));
     it->initialised = true;
     return MIK_OK;
 }
@@ -427,17 +489,31 @@ extern "C" int mik_cgd_iterate_many(mik_cgd *it, int64_t iteration, int64_t max_
     max_steps = std::min<int64_t>(std::min<int64_t>(max_steps, bs.maxiter - iteration), bs.hist_cap);
     const bool ahead_ok = g_mik_tuning[9] == 0 && iteration + max_steps < bs.maxiter;      // development knob 9: 1 = nothing ahead of the host
     bs.fuse_x = g_mik_tuning[23] == 0;                              // x .+= alpha .* u rides on the next sweep over u (as in mik_cg_*)
-    for (int64_t j = 0; j < max_steps; ++j) {
-        if (!bs.head_ahead) MIK_TRY(cgd_enqueue_head(it, iteration + j));
+    CgMirror m;
+    for (int64_t j0 = 0;;) {
+        for (int64_t j = j0; j < max_steps; ++j) {
+            if (!bs.head_ahead) MIK_TRY(cgd_enqueue_head(it, iteration + j));
+            bs.head_ahead = false;
+            MIK_TRY(cgd_enqueue_tail(it, iteration + j));
+        }
+        if (ahead_ok) MIK_TRY(cgd_enqueue_head(it, iteration + max_steps));
+        else if (bs.fuse_x) MIK_TRY(mik_cgd_phase(it, 6, iteration + max_steps - 1));   // no sweep over u follows: apply the last x update now
+        MIK_TRY(cgd_wait_raw(it, &m));
+        if (!m.range) { bs.head_ahead = ahead_ok && !m.done; break; }  // stopped: the head ahead was a no-op on every rank
+        // Step m.nhist of this call updated x and r, but |r|^2 summed over the ranks left the range in which sqrt(sum of squares)
+        // is safe: every rank froze its batch on the same total; finish that step with the norm rescaled across the ranks and
+        // go on (the single-GPU iterable does the same on its own, cg_iterate_many_impl).
         bs.head_ahead = false;
-        MIK_TRY(cgd_enqueue_tail(it, iteration + j));
+        MIK_TRY(rccl_scaled_norm(it));
+        it->norm_fix_index = (int)m.nhist;
+        it->norm_it_next = iteration + m.nhist + 1;
+        MIK_TRY(mik_cgd_phase(it, 23, 0));
+        MIK_TRY(cgd_wait_raw(it, &m));
+        j0 = m.nhist;
+        if (m.done || j0 >= max_steps) break;
     }
-    if (ahead_ok) MIK_TRY(cgd_enqueue_head(it, iteration + max_steps));
-    else if (bs.fuse_x) MIK_TRY(mik_cgd_phase(it, 6, iteration + max_steps - 1));       // no sweep over u follows: apply the last x update now
     int done = 0;
-    MIK_TRY(mik_cgd_wait(it, nullptr, nullptr, &done, residuals, max_steps, steps_done));
-    bs.head_ahead = ahead_ok && !done;                              // stopped: the head ahead was a no-op on every rank
-    return MIK_OK;
+    return cgd_collect(it, m, nullptr, nullptr, &done, residuals, max_steps, steps_done);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -611,6 +687,40 @@ static int group_halo_end(GroupState *g, const std::vector<char> &pending, int p
     return MIK_OK;
 }
 
+static int group_wait_raw(GroupState *g, std::vector<CgMirror> &ms)
+{
+    for (int p = 0; p < g->P; ++p) {
+        MIK_HIP(g->its[p]->base.ctx, hipSetDevice(g->its[p]->base.ctx->device));
+        MIK_TRY(cgd_wait_raw(g->its[p], &ms[(size_t)p]));
+        if (ms[(size_t)p].range != ms[0].range)
+            return mik_fail(g->its[p]->base.ctx, MIK_ERR_MISMATCH, "row-partitioned cg: rank %d disagrees with rank 0 on the range of |r|^2", p);
+    }
+    return MIK_OK;
+}
+
+// the scaled norm of r over the group's ranks (cgd_norm_stage*): every rank repeats the host arithmetic on identical slots
+static int group_scaled_norm(GroupState *g)
+{
+    const int P = g->P;
+    MIK_TRY(group_all(g, 20, 0));
+    MIK_TRY(group_gather_scalar(g, 1));
+    bool direct = false;
+    for (int p = 0; p < P; ++p) {
+        bool dp = false;
+        MIK_HIP(g->its[p]->base.ctx, hipSetDevice(g->its[p]->base.ctx->device));
+        MIK_TRY(cgd_norm_stage1_any(g->its[p], &dp));
+        if (p == 0) direct = dp;
+        else if (dp != direct) return mik_fail(g->its[p]->base.ctx, MIK_ERR_MISMATCH, "row-partitioned cg: rank %d disagrees with rank 0 on max |r|", p);
+    }
+    if (direct) return MIK_OK;
+    MIK_TRY(group_gather_scalar(g, 1));
+    for (int p = 0; p < P; ++p) {
+        MIK_HIP(g->its[p]->base.ctx, hipSetDevice(g->its[p]->base.ctx->device));
+        MIK_TRY(cgd_norm_stage2_any(g->its[p]));
+    }
+    return MIK_OK;
+}
+
 extern "C" int mik_cgd_group_init(mik_cgd **its, int P, double *residual, double *tol)
 {
     MIK_TRY(group_check(its, P, "mik_cgd_group_init"));
@@ -625,12 +735,19 @@ extern "C" int mik_cgd_group_init(mik_cgd **its, int P, double *residual, double
     MIK_TRY(group_all(g, 11, 0));
     MIK_TRY(group_gather_scalar(g, 1));
     MIK_TRY(group_all(g, 12, 0));
+    std::vector<CgMirror> ms((size_t)P);
+    MIK_TRY(group_wait_raw(g, ms));
+    if (ms[0].range) {
+        MIK_TRY(group_scaled_norm(g));
+        MIK_TRY(group_all(g, 24, 0));
+        MIK_TRY(group_wait_raw(g, ms));
+    }
     for (int p = 0; p < P; ++p) {
         double res = 0, tl = 0;
         int done = 0;
         int64_t steps = 0;
         MIK_HIP(its[p]->base.ctx, hipSetDevice(its[p]->base.ctx->device));
-        MIK_TRY(mik_cgd_wait(its[p], &res, &tl, &done, nullptr, 0, &steps));
+        MIK_TRY(cgd_collect(its[p], ms[(size_t)p], &res, &tl, &done, nullptr, 0, &steps));
         its[p]->initialised = true;
         if (p == 0) { if (residual) *residual = res; if (tol) *tol = tl; }
         else if (res != its[0]->base.residual || tl != its[0]->base.tol)
@@ -658,40 +775,55 @@ extern "C" int mik_cgd_group_iterate_many(mik_cgd **its, int P, int64_t iteratio
     }
     early = early && split;
     std::vector<char> pending;
-    for (int64_t j = 0; j < max_steps; ++j) {
-        const int64_t itn = iteration + j;
-        if (early) {                                                // the step structure of cgd_enqueue_head, with peer copies for RCCL
-            for (int p = 0; p < P; ++p) {
-                MIK_HIP(its[p]->base.ctx, hipSetDevice(its[p]->base.ctx->device));
-                MIK_TRY(mik_cgd_phase(its[p], its[p]->early_merged ? 9 : 7, itn));
+    std::vector<CgMirror> ms((size_t)P);
+    for (int64_t j0 = 0;;) {
+        for (int64_t j = j0; j < max_steps; ++j) {
+            const int64_t itn = iteration + j;
+            if (early) {                                                // the step structure of cgd_enqueue_head, with peer copies for RCCL
+                for (int p = 0; p < P; ++p) {
+                    MIK_HIP(its[p]->base.ctx, hipSetDevice(its[p]->base.ctx->device));
+                    MIK_TRY(mik_cgd_phase(its[p], its[p]->early_merged ? 9 : 7, itn));
+                }
+                MIK_TRY(group_halo_begin(g, pending));
+                MIK_TRY(group_all(g, 8, itn));
+            } else {
+                MIK_TRY(group_all(g, 0, itn));
+                MIK_TRY(group_halo_begin(g, pending));
             }
-            MIK_TRY(group_halo_begin(g, pending));
-            MIK_TRY(group_all(g, 8, itn));
-        } else {
-            MIK_TRY(group_all(g, 0, itn));
-            MIK_TRY(group_halo_begin(g, pending));
+            if (split) {
+                MIK_TRY(group_all(g, 4, itn));
+                for (int p = 0; p < P; ++p) MIK_TRY(group_halo_end(g, pending, p));
+                MIK_TRY(group_all(g, 5, itn));
+            } else {
+                for (int p = 0; p < P; ++p) MIK_TRY(group_halo_end(g, pending, p));
+                MIK_TRY(group_all(g, 1, itn));
+            }
+            MIK_TRY(group_gather_scalar(g, 0));
+            MIK_TRY(group_all(g, 2, itn));
+            MIK_TRY(group_gather_scalar(g, 1));
+            MIK_TRY(group_all(g, 3, itn));
         }
-        if (split) {
-            MIK_TRY(group_all(g, 4, itn));
-            for (int p = 0; p < P; ++p) MIK_TRY(group_halo_end(g, pending, p));
-            MIK_TRY(group_all(g, 5, itn));
-        } else {
-            for (int p = 0; p < P; ++p) MIK_TRY(group_halo_end(g, pending, p));
-            MIK_TRY(group_all(g, 1, itn));
+        if (its[0]->base.fuse_x) MIK_TRY(group_all(g, 6, iteration + max_steps - 1));     // nothing runs ahead here: apply the last x update now
+        MIK_TRY(group_wait_raw(g, ms));
+        if (!ms[0].range) break;
+        // a frozen step (|r|^2 outside the safe range on every rank alike): scaled norm over the ranks, close the step, go on
+        MIK_TRY(group_scaled_norm(g));
+        for (int p = 0; p < P; ++p) {
+            its[p]->norm_fix_index = (int)ms[(size_t)p].nhist;
+            its[p]->norm_it_next = iteration + ms[(size_t)p].nhist + 1;
         }
-        MIK_TRY(group_gather_scalar(g, 0));
-        MIK_TRY(group_all(g, 2, itn));
-        MIK_TRY(group_gather_scalar(g, 1));
-        MIK_TRY(group_all(g, 3, itn));
+        MIK_TRY(group_all(g, 23, 0));
+        MIK_TRY(group_wait_raw(g, ms));
+        j0 = ms[0].nhist;
+        if (ms[0].done || j0 >= max_steps) break;
     }
-    if (its[0]->base.fuse_x) MIK_TRY(group_all(g, 6, iteration + max_steps - 1));     // nothing runs ahead here: apply the last x update now
     std::vector<double> h0((size_t)max_steps), hp((size_t)max_steps);
     int64_t n0 = 0;
     for (int p = 0; p < P; ++p) {
         int done = 0;
         int64_t steps = 0;
         MIK_HIP(its[p]->base.ctx, hipSetDevice(its[p]->base.ctx->device));
-        MIK_TRY(mik_cgd_wait(its[p], nullptr, nullptr, &done, p == 0 ? h0.data() : hp.data(), max_steps, &steps));
+        MIK_TRY(cgd_collect(its[p], ms[(size_t)p], nullptr, nullptr, &done, p == 0 ? h0.data() : hp.data(), max_steps, &steps));
         if (p == 0) n0 = steps;
         else if (steps != n0 || !std::equal(h0.begin(), h0.begin() + n0, hp.begin()))
             return mik_fail(its[p]->base.ctx, MIK_ERR_MISMATCH, "mik_cgd_group_iterate_many: rank %d disagrees with rank 0 on the residual history", p);

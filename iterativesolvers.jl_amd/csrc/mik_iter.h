@@ -81,5 +81,14 @@ struct mik_cgd {
     int n_early = 0;
     bool early_merged = false;            // every send index occurs once: update + pack are one launch (k_cgd_early)
     int64_t early_a[2] = {0, 0}, early_b[2] = {0, 0};
+    // the over-/underflow-safe norm across the partition (phases 20-24; csrc/mik_comm.hip cgd_norm_stage)
+    double norm_scale = 1.0, norm_res = 0.0;
+    int norm_fix_index = 0;
+    int64_t norm_it_next = 0;
 };
+
+// waits for the last enqueued phase and copies the mirror; a frozen step (range) is reported in the copy, not as an error
+int cgd_wait_raw(mik_cgd *it, struct CgMirror *m);
+// what mik_cgd_wait does after a successful wait: history of the steps since the previous wait, handle scalars
+int cgd_collect(mik_cgd *it, const struct CgMirror &m, double *residual, double *tol, int *done, double *history, int64_t cap, int64_t *steps);
 

@@ -1107,14 +1107,47 @@ template <typename T> static int gm_reduce(mik_gmres *g, T *values, int count)
     return MIK_OK;
 }
 
-// Row-partitioned norms: sqrt(sum over ranks of the local sums of squares).  The scaled recomputation of the single-GPU
-// path would need a max over ranks, which the reduce() callback does not offer: outside the safe range the call fails
-// loudly on every rank alike (ss is identical everywhere) instead of declaring convergence on an underflowed residual.
-// An exact 0 is taken as a zero vector.
-template <typename T> static int gm_range_check(mik_gmres *g, T ss)
+// Row-partitioned norm(x) from ss = the rank-ordered sum of the local sums of squares (identical on every rank, so every rank
+// takes the same branch): sqrt(ss) inside the safe range; outside (0 included: every square may have underflowed), the over-/underflow-safe
+// recomputation of include/mik.h "Norms" across the ranks -- amax = max over the ranks of the local max |x_i|, obtained through
+// the SUM callback by letting every rank contribute its value in its own slot of a P-vector of zeros (0 + ... + a_q + 0 is
+// exact); s = 2^-exponent(amax), the same power of two everywhere; t' = the rank-ordered sum of the local tree sums of
+// (x_i s)^2; norm = sqrt(t') / s.  oracle/orc_impl.inc safe_nrm_ with a partition is this arithmetic.
+template <typename T> static int gm_part_norm(mik_gmres *g, const T *x, T ss, T *nrm)
 {
-    if (ss == T(0) || mik_nrm_in_range(ss)) return MIK_OK;
-    return mik_fail(g->ctx, MIK_ERR_RANGE, "gmres (row-partitioned): sum of squares %g outside the range of a safe norm; rescale the system", (double)ss);
+    if (mik_nrm_in_range(ss)) { *nrm = std::sqrt(ss); return MIK_OK; }       // (an exact 0 may be an underflow: it takes the scaled pass too)
+    mik_ctx *ctx = g->ctx;
+    const int64_t n = g->n, nseg = mik_nseg<T>(n);
+    const int P = g->part.nranks, rank = g->part.rank;
+    if (P < 1 || P > 256 || rank < 0 || rank >= P) return mik_fail(ctx, MIK_ERR_RANGE, "gmres (row-partitioned): scaled norm needs 1 <= nranks <= 256");
+    T *scr = (T *)((unsigned char *)ctx->coef + mik_ctx::COEF_SAFE_SLOT);
+    const int grid = (int)std::min<int64_t>((std::max<int64_t>(n, 1) + MIK_BLOCK - 1) / MIK_BLOCK, 1024);
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(std::max<int64_t>(nseg, grid), 1)));
+    hipLaunchKernelGGL((k_amax<T>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, x, (T *)ctx->partials);
+    MIK_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL((k_amax<T>), dim3(1), dim3(MIK_BLOCK), 0, ctx->stream, (int64_t)grid, (const T *)ctx->partials, scr);
+    MIK_LAUNCH_CHECK(ctx);
+    std::vector<T> v((size_t)P, T(0));
+    MIK_HIP(ctx, hipMemcpyAsync(&v[(size_t)rank], scr, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    MIK_HIP(ctx, mik_wait(ctx));
+    MIK_TRY(gm_reduce<T>(g, v.data(), P));
+    T amax = T(0);
+    for (T a : v) amax = (a > amax || a != a) ? a : amax;
+    if (amax == T(0) || amax != amax || amax > std::numeric_limits<T>::max()) { *nrm = amax; return MIK_OK; }
+    int e;
+    (void)std::frexp((double)amax, &e);
+    e = std::max(-NrmRange<T>::EC, std::min(NrmRange<T>::EC, e));
+    const T sc = (T)std::ldexp(1.0, -e), sinv = (T)std::ldexp(1.0, e);
+    OpScaledSq<T> op{x, sc};
+    MIK_TRY((launch_map<T>(ctx, n, op, mik_aligned16(x), (T *)ctx->partials, nullptr)));
+    hipLaunchKernelGGL((k_finalize_store<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, (int64_t)0, scr, (const int *)nullptr);
+    MIK_LAUNCH_CHECK(ctx);
+    T t2;
+    MIK_HIP(ctx, hipMemcpyAsync(&t2, scr, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    MIK_HIP(ctx, mik_wait(ctx));
+    MIK_TRY(gm_reduce<T>(g, &t2, 1));
+    *nrm = (T)std::sqrt(t2) * sinv;
+    return MIK_OK;
 }
 
 // orthogonalize_and_normalize! over a row partition (src/orthogonalize.jl:13-79): the same sweeps as
@@ -1171,20 +1204,21 @@ static int orthogonalize_part(mik_gmres *g, int k, const T *V, int64_t ldv, T *w
             std::vector<T> corr((size_t)std::max(k, 1));
             auto small_norm = [](const T *v, int len) { T s = T(0); for (int j = 0; j < len; ++j) { T p = v[j] * v[j]; s = s + p; } return (T)std::sqrt(s); };
             const T eta = T(1) / std::sqrt(T(2));                        // :20
-            T nrm = std::sqrt(ss);
+            T nrm;
+            MIK_TRY(gm_part_norm<T>(g, w, ss, &nrm));
             T projection_size = small_norm(h, k);                        // :22
             while (nrm < eta * projection_size) {                        // :26
                 MIK_TRY(project(k + 2, corr.data()));                    // :27, :30
                 MIK_TRY((launch_map<T>(ctx, n, dn, vecw, part, nullptr)));
                 MIK_TRY(fetch(k, &ss));                                  // :32
-                nrm = std::sqrt(ss);
+                MIK_TRY(gm_part_norm<T>(g, w, ss, &nrm));
                 projection_size = small_norm(corr.data(), k);            // :28
                 for (int j = 0; j < k; ++j) h[j] = h[j] + corr[j];       // :31
             }
         }
     }
-    MIK_TRY(gm_range_check<T>(g, ss));
-    const T nrm = std::sqrt(ss);
+    T nrm;
+    MIK_TRY(gm_part_norm<T>(g, w, ss, &nrm));
     const T inv = T(1) / nrm;
     OpScal<T> sc{w, coef_val<T>(inv)};                                   // w .*= inv(nrm)  :76 / :48 / :36
     MIK_TRY((launch_map<T>(ctx, n, sc, vecw, (T *)nullptr, nullptr)));
@@ -1244,8 +1278,8 @@ template <typename T> static int gmres_init_residual(mik_gmres *g, int initially
         MIK_TRY(finalize_store<T>(ctx, nseg, 1, hd));
         MIK_TRY(coef_download<T>(ctx, 0, &ss, 1));
         MIK_TRY(gm_reduce<T>(g, &ss, 1));
-        MIK_TRY(gm_range_check<T>(g, ss));
-        const T beta = std::sqrt(ss);                                     // :252
+        T beta;
+        MIK_TRY(gm_part_norm<T>(g, V0, ss, &beta));                       // :252
         const T inv = T(1) / beta;
         OpScal<T> scd{V0, coef_val<T>(inv)};                              // :253
         MIK_TRY((launch_map<T>(ctx, n, scd, mik_aligned16(V0), (T *)nullptr, nullptr)));
@@ -1790,8 +1824,10 @@ __global__ void k_cgd_fin_init(const T *__restrict__ rr_all, int nranks, CgDev<T
                                unsigned long long seq)
 {
     const T tot = rank_sum(rr_all, nranks);
-    if (tot != T(0) && !mik_nrm_in_range(tot)) {   // see gm_range_check: fail loudly (mik_cgd_wait returns MIK_ERR_RANGE)
-        d->done = 1; mirror->done = 1; mirror->range = 1;
+    if (!mik_nrm_in_range(tot)) {
+        // |r|^2 left the range of a safe sqrt(sum of squares) -- every rank sees the same total and takes this branch: the hosts
+        // recompute the norm with a common scale (phases 20-24) and finish the initialisation with k_cgd_fix_init
+        d->done = 1; mirror->done = 0; mirror->range = 1;
         __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
@@ -1815,8 +1851,10 @@ __global__ void k_cgd_fin_res(const T *__restrict__ rr_all, int nranks, CgDev<T>
     if (d->done) { __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); return; }
     if (fuse_x) d->x_pending = 1;              // r of this step is final; its x update rides on the next sweep over u
     const T tot = rank_sum(rr_all, nranks);
-    if (tot != T(0) && !mik_nrm_in_range(tot)) {
-        d->done = 1; mirror->done = 1; mirror->range = 1;
+    if (!mik_nrm_in_range(tot)) {
+        // as k_cg_fin_res: x and r of this step are final, its norm is not -- freeze the batch on every rank (identical totals);
+        // the hosts finish the step with the scaled norm over the partition (phases 20-23) and go on
+        d->done = 1; mirror->done = 0; mirror->nhist = hist_index; mirror->range = 1;
         __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
@@ -1829,6 +1867,23 @@ __global__ void k_cgd_fin_res(const T *__restrict__ rr_all, int nranks, CgDev<T>
     const int dn = (it_next >= maxiter || res <= d->tol) ? 1 : 0;
     if (dn) d->done = 1;
     mirror->res = (double)res; mirror->prev_res = (double)prev; mirror->done = dn; mirror->nhist = nh;
+    __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// finishes cg_iterator! with a residual norm obtained through the scaled pass over the partition
+template <typename T>
+__global__ void k_cgd_fix_init(CgDev<T> *d, T res, T reltol, T abstol, long long maxiter, CgMirror *mirror, unsigned long long seq)
+{
+    const T a = reltol * res;
+    d->rr = res * res; d->res = res; d->prev_res = T(1); d->rho = T(1);
+    d->tol = a > abstol ? a : abstol;
+    d->beta = (res * res) / (T(1) * T(1));
+    d->alpha = T(0); d->dot_uc = T(0);
+    d->done = (0 >= maxiter || res <= d->tol) ? 1 : 0;
+    d->nhist = 0;
+    mirror->range = 0;
+    mirror->res = (double)res; mirror->prev_res = 1.0; mirror->done = d->done; mirror->nhist = 0;
+    mirror->tol = (double)d->tol; mirror->tol_valid = 1;
     __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -2033,6 +2088,37 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
                            (long long)(iteration + 1), (long long)bs.maxiter, bs.mirror, bs.seq, (int)(it->hist_total - 1), bs.fuse_x ? 1 : 0);
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
+    case 20: {  // scaled norm of r over the partition, pass 1: this rank's max |r_i| -> rr_all[rank]   (mik_safe_norm_slow, per rank)
+        const int grid = (int)std::min<int64_t>((std::max<int64_t>(n, 1) + MIK_BLOCK - 1) / MIK_BLOCK, 1024);
+        MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(std::max<int64_t>(nseg, grid), 1)));
+        hipLaunchKernelGGL((k_amax<T>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, (const T *)r, (T *)ctx->partials);
+        MIK_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL((k_amax<T>), dim3(1), dim3(MIK_BLOCK), 0, ctx->stream, (int64_t)grid, (const T *)ctx->partials, rr_slot);
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    }
+    case 22: {  // pass 2: this rank's tree sum of (r_i * s)^2, s = the common power of two (it->norm_scale) -> rr_all[rank]
+        MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(nseg, 1)));
+        OpScaledSq<T> op{(const T *)r, (T)it->norm_scale};
+        MIK_TRY((launch_map<T>(ctx, n, op, mik_aligned16(r), (T *)ctx->partials, nullptr)));
+        hipLaunchKernelGGL((k_finalize_store<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, (int64_t)0, rr_slot,
+                           (const int *)nullptr);
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    }
+    case 23:    // the frozen step closes with the scaled norm (it->norm_res), as k_cg_fix_res does on one GPU
+        bs.seq += 1;
+        it->hist_total = it->norm_fix_index + 1;
+        hipLaunchKernelGGL((k_cg_fix_res<T>), dim3(1), dim3(1), 0, ctx->stream, d, (T)it->norm_res, (T *)bs.hist, (long long)it->norm_it_next,
+                           (long long)bs.maxiter, bs.mirror, bs.seq, it->norm_fix_index);
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    case 24:    // cg_iterator! closes with the scaled norm
+        bs.seq += 1;
+        hipLaunchKernelGGL((k_cgd_fix_init<T>), dim3(1), dim3(1), 0, ctx->stream, d, (T)it->norm_res, (T)it->reltol, (T)it->abstol, (long long)bs.maxiter,
+                           bs.mirror, bs.seq);
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
     default:
         return mik_fail(ctx, MIK_ERR_INVALID, "mik_cgd_phase: unknown phase %d", phase);
     }
@@ -2044,17 +2130,17 @@ extern "C" int mik_cgd_phase(mik_cgd *it, int phase, int64_t iteration)
     return it->base.dtype == MIK_F64 ? cgd_phase_impl<double>(it, phase, iteration) : cgd_phase_impl<float>(it, phase, iteration);
 }
 
-// Block until every phase enqueued so far has run; returns the scalars of the last step and the
-// residuals recorded since the previous wait (history[0..*steps-1], at most `cap`).
-extern "C" int mik_cgd_wait(mik_cgd *it, double *residual, double *tol, int *done, double *history, int64_t cap, int64_t *steps)
+int cgd_wait_raw(mik_cgd *it, CgMirror *m)
 {
-    if (!it) return MIK_ERR_INVALID;
+    MIK_TRY(cg_wait_mirror(&it->base));
+    *m = *it->base.mirror;
+    return MIK_OK;
+}
+
+int cgd_collect(mik_cgd *it, const CgMirror &m, double *residual, double *tol, int *done, double *history, int64_t cap, int64_t *steps)
+{
     mik_cg &bs = it->base;
     mik_ctx *ctx = bs.ctx;
-    MIK_TRY(cg_wait_mirror(&bs));
-    const CgMirror m = *bs.mirror;
-    if (m.range)
-        return mik_fail(ctx, MIK_ERR_RANGE, "cg (row-partitioned): |r|^2 left the range of a safe norm (badly scaled system); rescale b and A");
     const int64_t nd = m.nhist;
     if (history && nd == 1 && cap >= 1) {
         history[0] = m.res;                                   // the mirror carries the only residual: no copy
@@ -2079,6 +2165,27 @@ extern "C" int mik_cgd_wait(mik_cgd *it, double *residual, double *tol, int *don
     if (done) *done = m.done;
     if (steps) *steps = nd;
     return MIK_OK;
+}
+
+// Block until every phase enqueued so far has run; returns the scalars of the last step and the
+// residuals recorded since the previous wait (history[0..*steps-1], at most `cap`).  For hosts that drive the phases and the
+// exchanges themselves: a norm outside the safe range is reported as MIK_ERR_RANGE (the step's x and r are final and x is
+// flushed); mik_cgd_init / mik_cgd_iterate_many and the group calls recompute it with a common scale instead.
+extern "C" int mik_cgd_wait(mik_cgd *it, double *residual, double *tol, int *done, double *history, int64_t cap, int64_t *steps)
+{
+    if (!it) return MIK_ERR_INVALID;
+    CgMirror m;
+    MIK_TRY(cgd_wait_raw(it, &m));
+    if (m.range) {
+        mik_ctx *ctx = it->base.ctx;
+        if (it->base.fuse_x && it->initialised) {              // the frozen step's x .+= alpha .* u must not stay pending
+            (void)mik_cgd_phase(it, 6, 0);
+            (void)mik_wait(ctx);
+        }
+        return mik_fail(ctx, MIK_ERR_RANGE, "cg (row-partitioned, host-driven phases): |r|^2 left the range of a safe norm; use mik_cgd_init / "
+                                            "mik_cgd_iterate_many (or the group calls), which rescale across the ranks");
+    }
+    return cgd_collect(it, m, residual, tol, done, history, cap, steps);
 }
 
 // =============================================================================================

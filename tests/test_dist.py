@@ -74,7 +74,7 @@ def test_halo_plans_are_consistent(pkg, P):
 # ------------------------------------------------------------------------------------------------
 # loopback ranks with the numpy engine (CPU)
 # ------------------------------------------------------------------------------------------------
-def make_engines(pkg, orc, N, NZ, P, make_engine, x0=None):
+def make_engines(pkg, orc, N, NZ, P, make_engine, x0=None, b_scale=1.0):
     d = dist_mod(pkg)
     n = N * N * NZ
     offsets = d.partition_rows(n, P, align=N * N)
@@ -86,7 +86,7 @@ def make_engines(pkg, orc, N, NZ, P, make_engine, x0=None):
         parts.append((pp, li, vv))
     for pl in plans:
         d.complete_plan(pl, offsets, [q.ghost_gids for q in plans])
-    b = pkg.fixtures.hashed_rhs(n)
+    b = pkg.fixtures.hashed_rhs(n) * b_scale
     engines = [make_engine(pp, li, vv, pl, b[offsets[p]:offsets[p + 1]], None if x0 is None else x0[offsets[p]:offsets[p + 1]])
                for p, (pl, (pp, li, vv)) in enumerate(zip(plans, parts))]
     return engines, offsets, b
@@ -395,6 +395,38 @@ def test_inprocess_group_matches_partitioned_oracle(pkg, orc, ctx, P, with_x0):
         grp.close()
         for e in engines:
             e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [1, 2, 3])
+@pytest.mark.parametrize("scale,with_x0", [(1e-140, False), (1e140, False), (1e-140, True)])
+def test_inprocess_group_badly_scaled_rhs_takes_the_scaled_norm_across_ranks(pkg, orc, ctx, P, scale, with_x0):
+    """VERDICT r2 / ADVICE r2: |r|^2 summed over the ranks leaves the safe range in every step (and in cg_iterator!): the ranks
+    freeze the batch on the same total, exchange max |r_i|, rescale by the common power of two and go on -- the history of the
+    partition-aware oracle (whose safe norm does exactly that), bit for bit, instead of MIK_ERR_RANGE; switching from one GPU to
+    N does not change what converges"""
+    d = dist_mod(pkg)
+    N, NZ = 12, 12
+    shape = ctx.cg_shape(np.float64)
+    x0 = np.random.default_rng(5).standard_normal(N * N * NZ) * scale if with_x0 else None
+    mk = lambda pp, li, vv, pl, bl, xl: d.HipEngine(pkg, pp, li, vv, pl, bl, xl, abstol=0.0, reltol=1.5e-8, maxiter=10 ** 6)
+    engines, offsets, b = make_engines(pkg, orc, N, NZ, P, mk, x0, b_scale=scale)
+    grp = d.GroupCG(pkg, engines, maxiter=10 ** 6)
+    hist, iteration = [], 0
+    while True:
+        h = grp.iterate_many(iteration, 1 if iteration < 2 else 9)
+        if h.size == 0:
+            break
+        hist.append(h)
+        iteration += h.size
+    hist = np.concatenate(hist)
+    xo, ho = oracle_history(orc, pkg, N, NZ, offsets, b, shape, x0)
+    assert ho["iters"] > 10 and ho["isconverged"]
+    assert hist.size == ho["iters"] and np.array_equal(hist, ho["resnorm"])
+    assert np.array_equal(grp.solution(), xo)
+    grp.close()
+    for e in engines:
+        e.close()
 
 
 @pytest.mark.gpu

@@ -67,6 +67,29 @@ def test_partitioned_gmres_bit_exact_vs_partitioned_oracle(pkg, orc, ctx, dist, 
     assert np.linalg.norm(S @ xo - b) / np.linalg.norm(b) <= 2e-8
 
 
+@pytest.mark.parametrize("orth", ["mgs", "cgs", "dgks"])
+def test_partitioned_gmres_on_a_badly_scaled_system(pkg, orc, ctx, dist, orth):
+    """operator and rhs scaled by 1e-160: beta and every Gram-Schmidt norm leave the safe range; the ranks obtain max |x_i|
+    through the sum callback (own slot of a zero vector), rescale by the common power of two and agree with the partition-aware
+    oracle bit for bit -- MIK_ERR_RANGE no longer separates the partitioned solve from the single-GPU one"""
+    A, b = orc.advdiff(9, 200.0)
+    s = 1e-160
+    As = orc.CSC(A.n, A.colptr, A.rowval, A.nzval * s, A.index_base)
+    bs = b * s
+    S = As.to_scipy().tocsr()
+    M = {"mgs": pkg.ModifiedGramSchmidt(), "cgs": pkg.ClassicalGramSchmidt(), "dgks": pkg.DGKS()}[orth]
+    offsets, out = run_threads(pkg, dist, S, bs, 3, restart=12, orth_meth=M)
+    orc.set_partition(offsets)
+    try:
+        xo, ho = orc.gmres(As, bs, restart=12, orth_meth=orth, mode="tree", shape=ctx.reduce_shape(np.float64))
+    finally:
+        orc.set_partition(None)
+    assert ho["isconverged"] and ho["iters"] > 5
+    for o in out:
+        assert np.array_equal(o["hist"], ho["resnorm"]) and o["mvps"] == ho["mvps"] and o["conv"] == ho["isconverged"]
+    assert np.array_equal(np.concatenate([o["x"] for o in out]), xo)
+
+
 def test_partitioned_gmres_preconditioned_nonzero_start_uneven_blocks(pkg, orc, ctx, dist):
     A, b = orc.advdiff(10, 500.0)
     S = A.to_scipy().tocsr()
