@@ -653,12 +653,13 @@ template <typename T, bool SELF> struct OpMgsPass {
 };
 
 // =============================================================================================
-// Modified Gram-Schmidt as ONE launch (n up to 256 reduction segments: the launch-latency-bound sizes)
+// Modified Gram-Schmidt as ONE launch (n up to 2048 reduction segments = 2.1 M fp64 / 4.2 M fp32 elements)
 // =============================================================================================
 // orthogonalize_and_normalize!(V[:, 1:k], w, h, ModifiedGramSchmidt()) -- src/orthogonalize.jl:67-79 -- is a chain of
 // k + 1 grid-wide reductions (h_i = dot(v_i, w) needs the w of pass i - 1; then norm(w)).  As k + 2 launches each link
-// costs a dependent kernel boundary plus a sweep (3.7-4.3 us at n = 125 k).  Here one workgroup per reduction segment
-// keeps its 256*W*L elements of w in REGISTERS across all passes and the links are hand-offs through memory:
+// costs a dependent kernel boundary plus a sweep (3.7-4.3 us at n = 125 k).  Here a workgroup owns G = 1, 2, 4 or 8 consecutive
+// reduction segments (at most 256 workgroups: one per CU, all resident), keeps its G*256*W*L elements of w in REGISTERS across all
+// passes, and the links are hand-offs through memory:
 //   * a workgroup publishes its segment sum of pass i with one write-through (sc1) store into slot P[i][wg];
 //   * every workgroup then reads ALL slots of pass i (one per thread, sc1 loads that are served past L1) until none
 //     of them holds the "not yet written" pattern any more, and folds them with the same level-2 tree as everywhere else
@@ -689,27 +690,35 @@ struct MgsMirror {             // host-mapped; h[] follows (restart + 2 scalars 
     int err, pad;
 };
 
+// level 2 of a pass over `ns` slots (ns <= 2048 segment sums, published by the workgroups): the fixed 1024-virtual-thread shape
+// of level2_sum evaluated by a 256-thread workgroup -- real thread (wave w, lane l) plays the virtual threads (w + 4 j) * 64 + l,
+// j = 0..3; a virtual thread adds its slots vt, vt + 1024 in ascending order from +0; wave tree per 64; the 16 wave sums left to
+// right.  Every slot is polled until it no longer holds the "not yet written" pattern (bounded).
 template <typename T>
-__device__ __forceinline__ T mgs_grid_sum(const T *__restrict__ slots, int m, T *lds16, int *err)
+__device__ __forceinline__ T mgs_grid_sum(const T *__restrict__ slots, int ns, T *lds16, int *err)
 {
     using U = typename MgsBits<T>::U;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    T v = T(0);
-    if (t < m) {
-        U bits = MgsBits<T>::EMPTY;
-        for (int spin = 0; spin < (1 << 18); ++spin) {
-            bits = __hip_atomic_load(reinterpret_cast<const U *>(slots) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (bits != MgsBits<T>::EMPTY) break;
-            if (MIK_MGS_SLEEP) __builtin_amdgcn_s_sleep(1);
+    const int jmax = ns <= 256 ? 1 : 4;                    // ns <= 256: virtual threads 256..1023 hold +0 (their wave sums are +0)
+    for (int j = 0; j < jmax; ++j) {
+        const int vt = (w + 4 * j) * 64 + lane;
+        T v = T(0);
+        for (int q = vt; q < ns; q += MIK_FIN_THREADS) {
+            U bits = MgsBits<T>::EMPTY;
+            for (int spin = 0; spin < (1 << 18); ++spin) {
+                bits = __hip_atomic_load(reinterpret_cast<const U *>(slots) + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (bits != MgsBits<T>::EMPTY) break;
+                if (MIK_MGS_SLEEP) __builtin_amdgcn_s_sleep(1);
+            }
+            if (bits == MgsBits<T>::EMPTY) *err = 1;      // timed out: never hang the device
+            T val;
+            __builtin_memcpy(&val, &bits, sizeof(T));
+            v = v + val;                                   // 0 + S[vt] (+ S[vt + 1024]), as level2_sum
         }
-        if (bits == MgsBits<T>::EMPTY) *err = 1;          // timed out: never hang the device
-        T val;
-        __builtin_memcpy(&val, &bits, sizeof(T));
-        v = v + val;                                       // 0 + S[vt], as block_level2_256
+        v = wave_tree(v);
+        if (lane == 0) lds16[w + 4 * j] = v;
     }
-    v = wave_tree(v);
-    if (lane == 0) lds16[w] = v;
-    if (t >= 4 && t < 16) lds16[t] = T(0);                 // virtual threads 256..1023 hold +0
+    if (jmax == 1 && t >= 4 && t < 16) lds16[t] = T(0);
     __syncthreads();
     T tot = lds16[0];
 #pragma unroll
@@ -718,106 +727,134 @@ __device__ __forceinline__ T mgs_grid_sum(const T *__restrict__ slots, int m, T 
     return tot;
 }
 
-template <typename T, bool VEC>
-__global__ __launch_bounds__(MIK_BLOCK) void k_mgs_fused(int64_t n, int k, const T *__restrict__ V, int64_t ldv, T *__restrict__ w,
-                                                         T *__restrict__ P /* [2][kmax + 1][256] */, int kmax, int parity,
-                                                         MgsMirror *mirror, unsigned long long seq)
+// G consecutive reduction segments per workgroup (G = 1, 2, 4, 8: n up to 2048 segments = 4.2 M fp32 / 2.1 M fp64 elements with at
+// most 256 workgroups -- one per CU, all resident, which the slot hand-off needs): a thread keeps G x L x W elements of w in
+// registers; segment sums, slots and trees are those of G = 1, so the bits are those of the multi-launch chain.
+template <typename T, bool VEC, int G>
+__global__ __launch_bounds__(MIK_BLOCK, 1) void k_mgs_fused(int64_t n, int k, const T *__restrict__ V, int64_t ldv, T *__restrict__ w,
+                                                            T *__restrict__ P /* [2][kmax + 1][stride] */, int kmax, int stride, int nseg, int parity,
+                                                            MgsMirror *mirror, unsigned long long seq)
 {
     using U = typename MgsBits<T>::U;
     constexpr int W = VT<T>::W, L = MIK_RED_L;
     constexpr int64_t SEG = (int64_t)MIK_BLOCK * W * L;
     __shared__ T lds16[16];
-    __shared__ T lds4[4];
+    __shared__ T ldsg[G][4];
     __shared__ int s_err;
-    const int t = threadIdx.x, s = blockIdx.x, m = gridDim.x;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, s = blockIdx.x;
     if (t == 0) s_err = 0;
-    T *cur = P + (size_t)parity * (size_t)(kmax + 1) * 256;
-    T *oth = P + (size_t)(parity ^ 1) * (size_t)(kmax + 1) * 256;
-    if (t <= kmax) __hip_atomic_store(reinterpret_cast<U *>(oth + (size_t)t * 256) + s, MgsBits<T>::EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int64_t base = (int64_t)s * SEG + (int64_t)W * t;
-    // this thread's elements of w and of the column in flight: i0[l] .. i0[l] + W - 1, valid where < n
-    T wr[L][W], zr[L][W], vr[L][W];
-    auto load = [&](const T *__restrict__ p, T(&dst)[L][W]) {
+    T *cur = P + (size_t)parity * (size_t)(kmax + 1) * stride;
+    T *oth = P + (size_t)(parity ^ 1) * (size_t)(kmax + 1) * stride;
+    for (int q = t; q < (kmax + 1) * G; q += MIK_BLOCK)     // re-arm this workgroup's slots of the other buffer
+        __hip_atomic_store(reinterpret_cast<U *>(oth + (size_t)(q / G) * stride) + s * G + q % G, MgsBits<T>::EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int64_t base = (int64_t)s * G * SEG + (int64_t)W * t;
+    // this thread's elements of w and of the column in flight: segment g, load l: base + g SEG + l 256 W .. + W - 1, valid where < n
+    T wr[G][L][W], zr[G][L][W], vr[G][L][W];
+    auto load = [&](const T *__restrict__ p, T(&dst)[G][L][W]) {
 #pragma unroll
-        for (int l = 0; l < L; ++l) {
-            const int64_t i = base + (int64_t)l * MIK_BLOCK * W;
-            if (VEC && i + W <= n) {
-                auto v = vload(p + i);
+        for (int g = 0; g < G; ++g)
 #pragma unroll
-                for (int e = 0; e < W; ++e) dst[l][e] = el<T>(v, e);
-            } else {
+            for (int l = 0; l < L; ++l) {
+                const int64_t i = base + g * SEG + (int64_t)l * MIK_BLOCK * W;
+                if (VEC && i + W <= n) {
+                    auto v = vload(p + i);
 #pragma unroll
-                for (int e = 0; e < W; ++e) dst[l][e] = (i + e < n) ? p[i + e] : T(0);
+                    for (int e = 0; e < W; ++e) dst[g][l][e] = el<T>(v, e);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < W; ++e) dst[g][l][e] = (i + e < n) ? p[i + e] : T(0);
+                }
             }
-        }
     };
-    auto publish = [&](int pass, T acc) {
-        T tot = block_tree_256(acc, lds4);
-        if (t == 0)
-            __hip_atomic_store(reinterpret_cast<U *>(cur + (size_t)pass * 256) + s, mgs_slot_bits<T>(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto publish = [&](int pass, T(&acc)[G]) {             // block tree per segment: wave tree, then the 4 wave sums left to right
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const T ws = wave_tree(acc[g]);
+            if (lane == 0) ldsg[g][wv] = ws;
+        }
+        __syncthreads();
+        if (t < G && s * G + t < nseg) {
+            T tot = ldsg[t][0];
+            tot = tot + ldsg[t][1]; tot = tot + ldsg[t][2]; tot = tot + ldsg[t][3];
+            __hip_atomic_store(reinterpret_cast<U *>(cur + (size_t)pass * stride) + s * G + t, mgs_slot_bits<T>(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
     };
     load(w, wr);
     T *hout = reinterpret_cast<T *>(mirror + 1);
-    T acc = T(0);
+    T acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = T(0);
     if (k > 0) {
         load(V, zr);
         // dot(v_1, w)                                                    src/orthogonalize.jl:71 (i = 1)
 #pragma unroll
-        for (int l = 0; l < L; ++l)
+        for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int e = 0; e < W; ++e)
-                if (base + (int64_t)l * MIK_BLOCK * W + e < n) { T p = zr[l][e] * wr[l][e]; acc = acc + p; }
+            for (int l = 0; l < L; ++l)
+#pragma unroll
+                for (int e = 0; e < W; ++e)
+                    if (base + g * SEG + (int64_t)l * MIK_BLOCK * W + e < n) { T p = zr[g][l][e] * wr[g][l][e]; acc[g] = acc[g] + p; }
     } else {
 #pragma unroll
-        for (int l = 0; l < L; ++l)
+        for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int e = 0; e < W; ++e)
-                if (base + (int64_t)l * MIK_BLOCK * W + e < n) { T p = wr[l][e] * wr[l][e]; acc = acc + p; }
+            for (int l = 0; l < L; ++l)
+#pragma unroll
+                for (int e = 0; e < W; ++e)
+                    if (base + g * SEG + (int64_t)l * MIK_BLOCK * W + e < n) { T p = wr[g][l][e] * wr[g][l][e]; acc[g] = acc[g] + p; }
     }
     publish(0, acc);
     for (int i = 0; i < k; ++i) {
 #pragma unroll
-        for (int l = 0; l < L; ++l)
+        for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int e = 0; e < W; ++e) vr[l][e] = zr[l][e];              // v_i: subtracted in this pass
+            for (int l = 0; l < L; ++l)
+#pragma unroll
+                for (int e = 0; e < W; ++e) vr[g][l][e] = zr[g][l][e];        // v_i: subtracted in this pass
         const bool last = i + 1 == k;
         if (!last) load(V + (int64_t)(i + 1) * ldv, zr);                   // v_{i+1}: in flight during the hand-off
-        const T h = mgs_grid_sum<T>(cur + (size_t)i * 256, m, lds16, &s_err);
+        const T h = mgs_grid_sum<T>(cur + (size_t)i * stride, nseg, lds16, &s_err);
         if (s == 0 && t == 0) hout[i] = h;
-        acc = T(0);
         // w .-= h[i] .* v_i; then dot(v_{i+1}, w) or norm(w)^2            :72, :71 / :75 -- per 16-byte group: all W
         // elements updated, then their products added in element order (the order of OpMgsPass::compute_vec)
 #pragma unroll
-        for (int l = 0; l < L; ++l) {
-            const int64_t i0 = base + (int64_t)l * MIK_BLOCK * W;
+        for (int g = 0; g < G; ++g) {
+            acc[g] = T(0);
 #pragma unroll
-            for (int e = 0; e < W; ++e)
-                if (i0 + e < n) { T tt = h * vr[l][e]; wr[l][e] = wr[l][e] - tt; }
+            for (int l = 0; l < L; ++l) {
+                const int64_t i0 = base + g * SEG + (int64_t)l * MIK_BLOCK * W;
 #pragma unroll
-            for (int e = 0; e < W; ++e)
-                if (i0 + e < n) { T p = (last ? wr[l][e] : zr[l][e]) * wr[l][e]; acc = acc + p; }
+                for (int e = 0; e < W; ++e)
+                    if (i0 + e < n) { T tt = h * vr[g][l][e]; wr[g][l][e] = wr[g][l][e] - tt; }
+#pragma unroll
+                for (int e = 0; e < W; ++e)
+                    if (i0 + e < n) { T p = (last ? wr[g][l][e] : zr[g][l][e]) * wr[g][l][e]; acc[g] = acc[g] + p; }
+            }
         }
         publish(i + 1, acc);
     }
-    const T ss = mgs_grid_sum<T>(cur + (size_t)k * 256, m, lds16, &s_err);
+    const T ss = mgs_grid_sum<T>(cur + (size_t)k * stride, nseg, lds16, &s_err);
     T nrm = mik_sqrt(ss);
     const bool ok = mik_nrm_in_range(ss);          // outside the safe range: leave w unscaled, the host rescales
     const T inv = ok ? T(1) / nrm : T(1);
     if (!ok) nrm = __builtin_nan("");
 #pragma unroll
-    for (int l = 0; l < L; ++l) {                  // w .*= inv(nrm)                                :76
-        const int64_t i0 = base + (int64_t)l * MIK_BLOCK * W;
-        if (VEC && i0 + W <= n) {
-            typename VT<T>::vec o;
+    for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int e = 0; e < W; ++e) el<T>(o, e) = wr[l][e] * inv;
-            vstore(w + i0, o);
-        } else {
+        for (int l = 0; l < L; ++l) {              // w .*= inv(nrm)                                :76
+            const int64_t i0 = base + g * SEG + (int64_t)l * MIK_BLOCK * W;
+            if (VEC && i0 + W <= n) {
+                typename VT<T>::vec o;
 #pragma unroll
-            for (int e = 0; e < W; ++e)
-                if (i0 + e < n) w[i0 + e] = wr[l][e] * inv;
+                for (int e = 0; e < W; ++e) el<T>(o, e) = wr[g][l][e] * inv;
+                vstore(w + i0, o);
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; ++e)
+                    if (i0 + e < n) w[i0 + e] = wr[g][l][e] * inv;
+            }
         }
-    }
     if (t == 0 && s_err) __hip_atomic_store(&mirror->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (s == 0 && t == 0) {
         hout[k] = nrm;
@@ -827,54 +864,56 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_mgs_fused(int64_t n, int k, const
 
 // Classical Gram-Schmidt (and DGKS) as ONE launch (same sizes, same hand-off mechanism as k_mgs_fused):
 //   h = V' w  (all k dots on the SAME w: one batch);  w -= V h;  nrm = norm(w);  w *= inv(nrm)      src/orthogonalize.jl:15-17,75-76
-// Three dependent grid-wide steps instead of k + 1:  (1) every workgroup publishes its k segment sums (rows 0..k-1 of the
-// slot buffer);  (2) column j is reduced by ONE workgroup (j mod m) with the usual level-2 tree and published as a final
-// value (row kmax + 1), which every workgroup then picks up -- k x m slot reads per workgroup would cost more than the second
-// hand-off;  (3) the norm goes through row k like the last pass of k_mgs_fused.  Products, per-thread order, block and
+// Three dependent grid-wide steps instead of k + 1:  (1) every workgroup publishes the k sums of each of its segments (rows
+// 0..k-1 of the slot buffer);  (2) column j is reduced by ONE workgroup (j mod m) with the usual level-2 tree and published as a
+// final value (row kmax + 1), which every workgroup then picks up -- k x nseg slot reads per workgroup would cost more than the
+// second hand-off;  (3) the norm goes through row k like the last pass of k_mgs_fused.  Products, per-thread order, block and
 // level-2 trees are those of k_multidot / k_gemv_n / OpDot + k_finalize_*: bit-identical to the multi-launch chain.
 // DGKS (src/orthogonalize.jl:20-36): the same round is repeated while nrm < eta * norm(correction), every round in its own
 // block of slot rows; all workgroups evaluate the condition on identical values.  After `rounds` rounds (or when the sum of
 // squares leaves the safe range) the kernel stops WITHOUT scaling w and reports {h, nrm, projection size, more = 1}: the host
 // continues the loop with the multi-launch chain (it "typically runs once", ibid.).
-template <typename T, bool VEC, bool DGKS>
-__global__ __launch_bounds__(MIK_BLOCK) void k_cgs_fused(int64_t n, int k, const T *__restrict__ V, int64_t ldv, T *__restrict__ w,
-                                                         T *__restrict__ P /* [2][rounds][kmax + 2][256] */, int kmax, int rounds, int parity,
-                                                         MgsMirror *mirror, unsigned long long seq)
+template <typename T, bool VEC, bool DGKS, int G>
+__global__ __launch_bounds__(MIK_BLOCK, 1) void k_cgs_fused(int64_t n, int k, const T *__restrict__ V, int64_t ldv, T *__restrict__ w,
+                                                            T *__restrict__ P /* [2][rounds][kmax + 2][stride] */, int kmax, int stride, int nseg, int rounds,
+                                                            int parity, MgsMirror *mirror, unsigned long long seq)
 {
     using U = typename MgsBits<T>::U;
     constexpr int W = VT<T>::W, L = MIK_RED_L;
     constexpr int64_t SEG = (int64_t)MIK_BLOCK * W * L;
     __shared__ T lds16[16];
-    __shared__ T lds4[4];
-    __shared__ T wsum[256][4];                         // wave sums of the k column dots; then this round's h / correction in wsum[j][0]
+    __shared__ T ldsg[G][4];
+    __shared__ T wsum[256][G][4];                      // wave sums of the k column dots per segment; then this round's h / correction in wsum[j][0][0]
     __shared__ T hacc[256];                            // h, summed over the rounds
     __shared__ T s_proj;
     __shared__ int s_err;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, s = blockIdx.x, m = gridDim.x;
     if (t == 0) s_err = 0;
     const int rows = kmax + 2;                          // per round: k column rows, the norm row (index k <= kmax), the finals row
-    T *cur = P + (size_t)parity * (size_t)rounds * rows * 256;
-    T *oth = P + (size_t)(parity ^ 1) * (size_t)rounds * rows * 256;
-    for (int q = t; q < rounds * rows; q += MIK_BLOCK)  // re-arm the other buffer: this workgroup's slot of every row ...
-        __hip_atomic_store(reinterpret_cast<U *>(oth + (size_t)q * 256) + s, MgsBits<T>::EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    T *cur = P + (size_t)parity * (size_t)rounds * rows * stride;
+    T *oth = P + (size_t)(parity ^ 1) * (size_t)rounds * rows * stride;
+    for (int q = t; q < rounds * rows * G; q += MIK_BLOCK)  // re-arm the other buffer: this workgroup's slots of every row ...
+        __hip_atomic_store(reinterpret_cast<U *>(oth + (size_t)(q / G) * stride) + s * G + q % G, MgsBits<T>::EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (s == 0)                                         // ... and all 256 entries of the finals rows
         for (int r = 0; r < rounds; ++r)
-            __hip_atomic_store(reinterpret_cast<U *>(oth + ((size_t)r * rows + kmax + 1) * 256) + t, MgsBits<T>::EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int64_t base = (int64_t)s * SEG + (int64_t)W * t;
-    T wr[L][W];
-    auto load = [&](const T *__restrict__ p, T(&dst)[L][W]) {
+            __hip_atomic_store(reinterpret_cast<U *>(oth + ((size_t)r * rows + kmax + 1) * stride) + t, MgsBits<T>::EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int64_t base = (int64_t)s * G * SEG + (int64_t)W * t;
+    T wr[G][L][W];
+    auto load = [&](const T *__restrict__ p, T(&dst)[G][L][W]) {
 #pragma unroll
-        for (int l = 0; l < L; ++l) {
-            const int64_t i = base + (int64_t)l * MIK_BLOCK * W;
-            if (VEC && i + W <= n) {
-                auto v = vload(p + i);
+        for (int g = 0; g < G; ++g)
 #pragma unroll
-                for (int e = 0; e < W; ++e) dst[l][e] = el<T>(v, e);
-            } else {
+            for (int l = 0; l < L; ++l) {
+                const int64_t i = base + g * SEG + (int64_t)l * MIK_BLOCK * W;
+                if (VEC && i + W <= n) {
+                    auto v = vload(p + i);
 #pragma unroll
-                for (int e = 0; e < W; ++e) dst[l][e] = (i + e < n) ? p[i + e] : T(0);
+                    for (int e = 0; e < W; ++e) dst[g][l][e] = el<T>(v, e);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < W; ++e) dst[g][l][e] = (i + e < n) ? p[i + e] : T(0);
+                }
             }
-        }
     };
     load(w, wr);
     T *hout = reinterpret_cast<T *>(mirror + 1);
@@ -882,32 +921,37 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_cgs_fused(int64_t n, int k, const
     T nrm = T(0);
     bool ok = true, more = false;
     for (int round = 0;; ++round) {
-        T *rb = cur + (size_t)round * rows * 256;
-        T *fin = rb + (size_t)(kmax + 1) * 256;
+        T *rb = cur + (size_t)round * rows * stride;
+        T *fin = rb + (size_t)(kmax + 1) * stride;
         // (1) segment sums of V[:, j] .* w, j = 0..k-1                                     k_multidot
         for (int j = 0; j < k; ++j) {
-            T vr[L][W];
+            T vr[G][L][W];
             load(V + (int64_t)j * ldv, vr);
-            T acc = T(0);
 #pragma unroll
-            for (int l = 0; l < L; ++l)
+            for (int g = 0; g < G; ++g) {
+                T acc = T(0);
 #pragma unroll
-                for (int e = 0; e < W; ++e)
-                    if (base + (int64_t)l * MIK_BLOCK * W + e < n) { T p = vr[l][e] * wr[l][e]; acc = acc + p; }
-            const T ws = wave_tree(acc);
-            if (lane == 0) wsum[j][wv] = ws;
+                for (int l = 0; l < L; ++l)
+#pragma unroll
+                    for (int e = 0; e < W; ++e)
+                        if (base + g * SEG + (int64_t)l * MIK_BLOCK * W + e < n) { T p = vr[g][l][e] * wr[g][l][e]; acc = acc + p; }
+                const T ws = wave_tree(acc);
+                if (lane == 0) wsum[j][g][wv] = ws;
+            }
         }
         __syncthreads();
-        T tot_t = T(0);
-        if (t < k) {
-            tot_t = wsum[t][0];
-            tot_t = tot_t + wsum[t][1]; tot_t = tot_t + wsum[t][2]; tot_t = tot_t + wsum[t][3];
+        for (int q = t; q < k * G; q += MIK_BLOCK) {
+            const int j = q / G, g = q % G;
+            if (s * G + g < nseg) {
+                T tot_t = wsum[j][g][0];
+                tot_t = tot_t + wsum[j][g][1]; tot_t = tot_t + wsum[j][g][2]; tot_t = tot_t + wsum[j][g][3];
+                __hip_atomic_store(reinterpret_cast<U *>(rb + (size_t)j * stride) + s * G + g, mgs_slot_bits<T>(tot_t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        if (t < k)
-            __hip_atomic_store(reinterpret_cast<U *>(rb + (size_t)t * 256) + s, mgs_slot_bits<T>(tot_t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
         // (2) level 2 of column j by workgroup j mod m; everybody picks the finals up          k_finalize_store
         for (int j = s; j < k; j += m) {
-            const T h = mgs_grid_sum<T>(rb + (size_t)j * 256, m, lds16, &s_err);
+            const T h = mgs_grid_sum<T>(rb + (size_t)j * stride, nseg, lds16, &s_err);
             if (t == 0)
                 __hip_atomic_store(reinterpret_cast<U *>(fin) + j, mgs_slot_bits<T>(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -921,40 +965,49 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_cgs_fused(int64_t n, int k, const
             if (bits == MgsBits<T>::EMPTY) s_err = 1;
             T hv;
             __builtin_memcpy(&hv, &bits, sizeof(T));
-            wsum[t][0] = hv;                                                       // this round's h / correction
+            wsum[t][0][0] = hv;                                                    // this round's h / correction
             hacc[t] = round == 0 ? hv : hacc[t] + hv;                              // h .+= correction               :31
         }
         __syncthreads();
         // w += (-1 * c[j]) * V[:, j], j ascending                                              k_gemv_n
         for (int j = 0; j < k; ++j) {
-            T vr[L][W];
+            T vr[G][L][W];
             load(V + (int64_t)j * ldv, vr);
-            const T temp = T(-1) * wsum[j][0];
+            const T temp = T(-1) * wsum[j][0][0];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int l = 0; l < L; ++l)
+#pragma unroll
+                    for (int e = 0; e < W; ++e)
+                        if (base + g * SEG + (int64_t)l * MIK_BLOCK * W + e < n) { T p = temp * vr[g][l][e]; wr[g][l][e] = wr[g][l][e] + p; }
+        }
+        // (3) norm(w)                                                                          OpDot{w, w} + k_finalize_nrm_inv
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            T acc = T(0);
 #pragma unroll
             for (int l = 0; l < L; ++l)
 #pragma unroll
                 for (int e = 0; e < W; ++e)
-                    if (base + (int64_t)l * MIK_BLOCK * W + e < n) { T p = temp * vr[l][e]; wr[l][e] = wr[l][e] + p; }
+                    if (base + g * SEG + (int64_t)l * MIK_BLOCK * W + e < n) { T p = wr[g][l][e] * wr[g][l][e]; acc = acc + p; }
+            const T ws = wave_tree(acc);
+            if (lane == 0) ldsg[g][wv] = ws;
         }
-        // (3) norm(w)                                                                          OpDot{w, w} + k_finalize_nrm_inv
-        T acc = T(0);
-#pragma unroll
-        for (int l = 0; l < L; ++l)
-#pragma unroll
-            for (int e = 0; e < W; ++e)
-                if (base + (int64_t)l * MIK_BLOCK * W + e < n) { T p = wr[l][e] * wr[l][e]; acc = acc + p; }
-        {
-            T tot = block_tree_256(acc, lds4);
-            if (t == 0)
-                __hip_atomic_store(reinterpret_cast<U *>(rb + (size_t)k * 256) + s, mgs_slot_bits<T>(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (t < G && s * G + t < nseg) {
+            T tot = ldsg[t][0];
+            tot = tot + ldsg[t][1]; tot = tot + ldsg[t][2]; tot = tot + ldsg[t][3];
+            __hip_atomic_store(reinterpret_cast<U *>(rb + (size_t)k * stride) + s * G + t, mgs_slot_bits<T>(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const T ss = mgs_grid_sum<T>(rb + (size_t)k * 256, m, lds16, &s_err);
+        __syncthreads();
+        const T ss = mgs_grid_sum<T>(rb + (size_t)k * stride, nseg, lds16, &s_err);
         nrm = mik_sqrt(ss);
         ok = mik_nrm_in_range(ss);
         if (!DGKS) break;
         if (t == 0) {                                   // norm(h) / norm(correction): serial, like the host's small_norm    :22, :28
             T q = T(0);
-            for (int j = 0; j < k; ++j) { T p = wsum[j][0] * wsum[j][0]; q = q + p; }
+            for (int j = 0; j < k; ++j) { T p = wsum[j][0][0] * wsum[j][0][0]; q = q + p; }
             s_proj = mik_sqrt(q);
         }
         __syncthreads();
@@ -967,19 +1020,21 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_cgs_fused(int64_t n, int k, const
     const T inv = (ok && !more) ? T(1) / nrm : T(1);
     if (!ok) nrm = __builtin_nan("");
 #pragma unroll
-    for (int l = 0; l < L; ++l) {                  // w .*= inv(nrm)
-        const int64_t i0 = base + (int64_t)l * MIK_BLOCK * W;
-        if (VEC && i0 + W <= n) {
-            typename VT<T>::vec o;
+    for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int e = 0; e < W; ++e) el<T>(o, e) = wr[l][e] * inv;
-            vstore(w + i0, o);
-        } else {
+        for (int l = 0; l < L; ++l) {                  // w .*= inv(nrm)
+            const int64_t i0 = base + g * SEG + (int64_t)l * MIK_BLOCK * W;
+            if (VEC && i0 + W <= n) {
+                typename VT<T>::vec o;
 #pragma unroll
-            for (int e = 0; e < W; ++e)
-                if (i0 + e < n) w[i0 + e] = wr[l][e] * inv;
+                for (int e = 0; e < W; ++e) el<T>(o, e) = wr[g][l][e] * inv;
+                vstore(w + i0, o);
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; ++e)
+                    if (i0 + e < n) w[i0 + e] = wr[g][l][e] * inv;
+            }
         }
-    }
     __syncthreads();
     if (t == 0 && s_err) __hip_atomic_store(&mirror->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (s == 0 && t == 0) {                        // one writer for the whole mirror: h, nrm, (projection size), then seq

@@ -1070,6 +1070,7 @@ struct mik_gmres {
     bool graph_off = false;                   // capture / instantiation failed once: plain stream launches from then on
     // single-launch Modified Gram-Schmidt (k_mgs_fused): slot buffers [2][restart + 1][256] and the host-mapped mirror of (h, nrm)
     void *mgs_P = nullptr;
+    int mgs_G = 1, mgs_stride = 256;  // segments per workgroup of the single-launch kernels; slots per row of mgs_P
     bool fused_off = false;          // latched when the single-launch kernel's bounded spin expired once: multi-launch chains from then on
     int mgs_rounds = 1;              // DGKS rounds the single-launch kernel runs before it hands back to the host loop
     MgsMirror *mgs_mirror = nullptr;          // two mirrors (bytes apart: mgs_mirror_stride), used alternately
@@ -1362,10 +1363,14 @@ static int gmres_create_common(mik_ctx *ctx, const mik_csr *A, void *x, const vo
     }
     {
         const int64_t nseg = dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
-        if (!part && nseg >= 1 && nseg <= 256 && restart <= 254) {
+        // single-launch Gram-Schmidt: up to 2048 reduction segments, G = 1 / 2 / 4 / 8 of them per workgroup (<= 256 workgroups, one
+        // per CU); more than 256 segments need the library's own 16-byte aligned V (always the case here)
+        if (!part && nseg >= 1 && nseg <= 2048 && restart <= 254 && g_mik_tuning[31] == 0 && (nseg <= 256 || g->ldv % 4 == 0)) {   // development knob 31: 1 = chains only
+            g->mgs_G = nseg <= 256 ? 1 : nseg <= 512 ? 2 : nseg <= 1024 ? 4 : 8;
+            g->mgs_stride = std::max<int>(256, (int)((nseg + g->mgs_G - 1) / g->mgs_G) * g->mgs_G);
             // k_cgs_fused: one more row per round (the final h values); DGKS: up to 3 rounds in the kernel
             g->mgs_rounds = orth_method == MIK_DGKS ? (g_mik_tuning[21] > 0 ? std::min(g_mik_tuning[21], 3) : 3) : 1;   // development knob 21: DGKS rounds in the kernel
-            const size_t pbytes = es * 2 * (size_t)g->mgs_rounds * (size_t)(restart + 2) * 256;
+            const size_t pbytes = es * 2 * (size_t)g->mgs_rounds * (size_t)(restart + 2) * (size_t)g->mgs_stride;
             if ((e = hipMalloc(&g->mgs_P, pbytes)) != hipSuccess || (e = hipMemsetAsync(g->mgs_P, 0xFF, pbytes, ctx->stream)) != hipSuccess ||
                 (g->mgs_mirror_stride = (sizeof(MgsMirror) + es * (size_t)(restart + 2) + 255) / 256 * 256, false) ||
                 (e = hipHostMalloc((void **)&g->mgs_mirror, 2 * g->mgs_mirror_stride, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) {
@@ -1513,24 +1518,33 @@ template <typename T> static int gm_fused_enqueue(mik_gmres *g, int k, int slot)
 {
     mik_ctx *ctx = g->ctx;
     const int64_t n = g->n;
-    const int m = (int)mik_nseg<T>(n);
+    const int nseg = (int)mik_nseg<T>(n), G = g->mgs_G, m = (nseg + G - 1) / G, stride = g->mgs_stride;
     T *V = (T *)g->V;
     T *vk = V + (int64_t)(k - 1) * g->ldv, *w = V + (int64_t)k * g->ldv;
     MIK_TRY(gm_expand<T>(g, vk, w));
     const bool vec = mik_aligned16(V) && mik_aligned16(w) && (g->ldv % VT<T>::W == 0);
     g->mgs_seq += 1;
     g->mgs_slot_seq[slot] = g->mgs_seq;
-    if (g->method != MIK_MGS) {
-#define MIK_CGS_GO(VECV, DG)                                                                                                                   \
-    hipLaunchKernelGGL((k_cgs_fused<T, VECV, DG>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart, \
-                       g->mgs_rounds, g->mgs_parity, gm_mirror(g, slot), g->mgs_seq)
-        if (g->method == MIK_DGKS) { if (vec) MIK_CGS_GO(true, true); else MIK_CGS_GO(false, true); }
-        else                       { if (vec) MIK_CGS_GO(true, false); else MIK_CGS_GO(false, false); }
+#define MIK_CGS_GO(VECV, DG, GG)                                                                                                               \
+    hipLaunchKernelGGL((k_cgs_fused<T, VECV, DG, GG>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart, \
+                       stride, nseg, g->mgs_rounds, g->mgs_parity, gm_mirror(g, slot), g->mgs_seq)
+#define MIK_MGS_GO(VECV, GG)                                                                                                                   \
+    hipLaunchKernelGGL((k_mgs_fused<T, VECV, GG>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart, \
+                       stride, nseg, g->mgs_parity, gm_mirror(g, slot), g->mgs_seq)
+#define MIK_GS_GO(VECV, GG)                                                                          \
+    do {                                                                                             \
+        if (g->method == MIK_DGKS) MIK_CGS_GO(VECV, true, GG);                                       \
+        else if (g->method == MIK_CGS) MIK_CGS_GO(VECV, false, GG);                                  \
+        else MIK_MGS_GO(VECV, GG);                                                                   \
+    } while (0)
+    // G > 1 (more than 256 segments) is instantiated for 16-byte aligned bases only: gmres_create allocates V that way
+    if (G == 1) { if (vec) MIK_GS_GO(true, 1); else MIK_GS_GO(false, 1); }
+    else if (G == 2) MIK_GS_GO(true, 2);
+    else if (G == 4) MIK_GS_GO(true, 4);
+    else MIK_GS_GO(true, 8);
+#undef MIK_GS_GO
+#undef MIK_MGS_GO
 #undef MIK_CGS_GO
-    } else if (vec) hipLaunchKernelGGL((k_mgs_fused<T, true>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart,
-                                g->mgs_parity, gm_mirror(g, slot), g->mgs_seq);
-    else hipLaunchKernelGGL((k_mgs_fused<T, false>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart,
-                            g->mgs_parity, gm_mirror(g, slot), g->mgs_seq);
     MIK_LAUNCH_CHECK(ctx);
     g->mgs_parity ^= 1;
     return MIK_OK;

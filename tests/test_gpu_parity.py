@@ -603,3 +603,29 @@ def test_orthogonalize_vector_of_vectors_equals_the_matrix_method(pkg, orc, ctx,
     assert n1 == n2 and np.array_equal(h1, h2) and np.array_equal(w1.to_numpy(), w2.to_numpy())
     with pytest.raises(TypeError):
         pkg.orthogonalize_and_normalize_(cols, k, w2, h2, pkg.ClassicalGramSchmidt())
+
+
+@pytest.mark.parametrize("dtype,N", [(np.float64, 67), (np.float64, 85), (np.float64, 107), (np.float32, 85), (np.float32, 107), (np.float32, 135)])
+def test_gmres_single_launch_gram_schmidt_beyond_256_segments(pkg, orc, ctx, dtype, N):
+    """k_mgs_fused / k_cgs_fused with G = 2, 4, 8 reduction segments per workgroup (n up to 2048 segments): the
+    residual history, x and the counters of the multi-launch chains (development knob 31), bit for bit, for MGS, CGS and DGKS;
+    the smallest size also against the oracle"""
+    A, b = orc.advdiff(N, 300.0)
+    A = A.astype(dtype)
+    b = b.astype(dtype)
+    W, L = ctx.reduce_shape(dtype)
+    nseg = -(-A.n // (256 * W * L))
+    assert 256 < nseg <= 2048
+    db = pkg.HipVector.from_numpy(b)
+    dA = upload(pkg, A)
+    for name, M in (("mgs", pkg.ModifiedGramSchmidt()), ("cgs", pkg.ClassicalGramSchmidt()), ("dgks", pkg.DGKS())):
+        x1, h1 = pkg.gmres(dA, db, restart=7, orth_meth=M, log=True, maxiter=17)
+        pkg.lib().mik_set_tuning(31, 1)
+        try:
+            x0, h0 = pkg.gmres(dA, db, restart=7, orth_meth=M, log=True, maxiter=17)
+        finally:
+            pkg.lib().mik_set_tuning(31, 0)
+        assert np.array_equal(h1["resnorm"], h0["resnorm"]) and np.array_equal(x1.to_numpy(), x0.to_numpy()) and h1.mvps == h0.mvps, name
+        if N == 67 and name != "dgks":
+            xo, ho = orc.gmres(A, b, restart=7, orth_meth=name, maxiter=17, mode="tree", shape=(W, L))
+            assert np.array_equal(h1["resnorm"], ho["resnorm"]) and np.array_equal(x1.to_numpy(), xo), name
