@@ -23,6 +23,7 @@ extern "C" {
  *  17: 1 = layout 5 through flat loads (k_spmv_sdiac)              18: 1 = k_spmv_sdiab without the compiled-in slot class
  *  19: 1 = layout 5 with one row per lane (k_spmv_sdiab instead of k_spmv_sdiab2)
  *  20: 1 = mik_csr_create on the host path only                   21: DGKS rounds inside the single-launch kernel (1..3; read at mik_gmres_create)
+ *  22: 1 = PCG with a diagonal Pl as three vector sweeps (c = Pl \\ r and rho apart) instead of two (read at mik_cg_create)
  *  23: 1 = CG updates x in the step's own sweep (read at mik_cg_create)      24: 1 = the halo of a row-partitioned CG step after the whole sweep over u
  *  31: 1 = GMRES without the single-launch Gram-Schmidt kernels (read at mik_gmres_create)
  *  30: 1 = treat the next single-launch Gram-Schmidt column as timed out (exercises the fall-back to the multi-launch chains)

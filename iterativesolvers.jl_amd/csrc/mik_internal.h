@@ -160,6 +160,10 @@ template <typename T> static inline int64_t mik_nseg(int64_t n)
 // ---------------------------------------------------------------------------------------------
 #ifdef __HIPCC__
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libmik's device code is written for gfx950 (MI355X) only: v_permlane32_swap / v_permlane16_swap, wave-wide DPP shifts, LDS-DMA and sc1 hand-offs have no fallback"
+#endif
+
 // A coefficient that is either an immediate or read from device memory (written by a finalise
 // kernel earlier on the stream), optionally negated/never contracted.
 template <typename T> struct Coef {

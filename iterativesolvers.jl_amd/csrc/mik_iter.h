@@ -5,6 +5,7 @@
 
 template <typename T> struct CgDev {
     T res, prev_res, alpha, beta, dot_uc, rr, tol, rho;
+    T beta_rho;            // PCG with the fused tail: rho / rho_prev of the step being closed (becomes beta when the step's norm is known)
     int done, nhist;
     int x_pending, pad_;   // x .+= alpha .* u of the last step has not been applied yet (it rides on the next sweep over u)
 };
@@ -37,6 +38,8 @@ struct mik_cg {
     int64_t hist_cap = 0;
     void *seg_spmv = nullptr;  // one partial per row-block
     void *seg_vec = nullptr;   // one partial per vector segment
+    void *seg_vec2 = nullptr;  // second reduction of the fused PCG tail (dot(Pl \\ r, r))
+    bool pcg_fused = false;    // diagonal Pl on a CSR operator: c = Pl \\ r, rho ride on the tail; the head recomputes r ./ d (OpPcgUpdateR / OpPcgXpbyX)
     double residual = 0, prev_residual = 1, tol = 0;
     int64_t maxiter = 0, mv_products = 0;
     CgMirror *mirror = nullptr;      // host-mapped; same pointer is valid on the device

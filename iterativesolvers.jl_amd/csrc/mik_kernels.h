@@ -166,6 +166,49 @@ static inline int launch_map(mik_ctx *ctx, int64_t n, Op op, bool vec, T *seg_ou
     return MIK_OK;
 }
 
+// k_map with TWO reductions over the same sweep (Op::apply / apply_vec take two accumulators): both keep the segment / thread /
+// tree shape of the single-reduction kernel, so each sum has the bits it would have in a sweep of its own.
+template <typename T, bool VEC, typename Op>
+__global__ __launch_bounds__(MIK_BLOCK) void k_map2(int64_t n, int64_t nseg, Op op, T *__restrict__ seg1, T *__restrict__ seg2,
+                                                     const int *__restrict__ done)
+{
+    if (done && *done) return;
+    constexpr int W = VT<T>::W;
+    constexpr int L = MIK_RED_L;
+    constexpr int64_t SEG = (int64_t)MIK_BLOCK * W * L;
+    __shared__ T lds4[4];
+    for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+        const int64_t base = s * SEG + (int64_t)W * threadIdx.x;
+        T a1 = T(0), a2 = T(0);
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int64_t i = base + (int64_t)l * MIK_BLOCK * W;
+            if (VEC && i + W <= n) {
+                op.apply_vec(i, a1, a2);
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; ++e)
+                    if (i + e < n) op.apply(i + e, a1, a2);
+            }
+        }
+        const T t1 = block_tree_256(a1, lds4);
+        const T t2 = block_tree_256(a2, lds4);
+        if (threadIdx.x == 0) { seg1[s] = t1; seg2[s] = t2; }
+    }
+}
+
+template <typename T, typename Op>
+static inline int launch_map2(mik_ctx *ctx, int64_t n, Op op, bool vec, T *seg1, T *seg2, const int *done)
+{
+    const int64_t nseg = mik_nseg<T>(n);
+    if (nseg == 0) return MIK_OK;
+    const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
+    if (vec) hipLaunchKernelGGL((k_map2<T, true, Op>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, seg1, seg2, done);
+    else hipLaunchKernelGGL((k_map2<T, false, Op>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, seg1, seg2, done);
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+
 template <typename T> __device__ __forceinline__ typename VT<T>::vec vload(const T *p)
 {
     return *reinterpret_cast<const typename VT<T>::vec *>(p);
@@ -279,6 +322,41 @@ template <typename T> struct OpCgUpdateR {
         if (nt & 16) vstore_nt(r + i, rv); else vstore(r + i, rv);
 #pragma unroll
         for (int e = 0; e < VT<T>::W; ++e) { T p = el<T>(rv, e) * el<T>(rv, e); acc = acc + p; }
+    }
+};
+
+// The PCG step with a diagonal Pl (src/cg.jl:72-100) in TWO vector sweeps instead of three: the tail forms c = Pl \\ r of the NEXT
+// step on the r it has just updated -- stored over c = A u, which is dead by then -- and reduces dot(c, r) next to |r|^2
+// (OpPcgUpdateR, two reductions); the head is the plain OpXpbyX on that c.  The same quotients, products and orders as
+// OpJacobiDot / OpCgUpdateR, so the same bits; 10 n instead of 11 n scalars per iteration and two launches less.
+// (Recomputing r ./ d in the head instead of storing it -- 10 n too, one stream less -- was measured: 408 us against 315 us per
+// iteration at 256^3; two correctly rounded fp64 divisions per element make both sweeps instruction-bound.)
+template <typename T> struct OpPcgUpdateR {
+    static constexpr bool REDUCE = true;
+    T *__restrict__ r; T *__restrict__ c; const T *__restrict__ d; Coef<T> alpha; int nt = 0;   // nt & 8 / 16: r load / store streamed
+    __device__ __forceinline__ void apply(int64_t i, T &a1, T &a2) const
+    {
+        T s = alpha.get() * c[i]; T rn = r[i] - s; r[i] = rn;
+        T p = rn * rn; a1 = a1 + p;
+        T v = rn / d[i]; c[i] = v;
+        T q = v * rn; a2 = a2 + q;
+    }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &a1, T &a2) const
+    {
+        const T a = alpha.get();
+        auto rv = (nt & 8) ? vload_nt<T>(r + i) : vload<T>(r + i);
+        auto cv = vload<T>(c + i);
+        auto dv = vload_nt(d + i);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) { T s = a * el<T>(cv, e); el<T>(rv, e) = el<T>(rv, e) - s; }
+        if (nt & 16) vstore_nt(r + i, rv); else vstore(r + i, rv);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) { T p = el<T>(rv, e) * el<T>(rv, e); a1 = a1 + p; }
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) el<T>(cv, e) = el<T>(rv, e) / el<T>(dv, e);
+        vstore(c + i, cv);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) { T q = el<T>(cv, e) * el<T>(rv, e); a2 = a2 + q; }
     }
 };
 

@@ -417,6 +417,47 @@ template <typename T> __device__ __forceinline__ bool level2_sum_spread(const T 
     return last;
 }
 
+// the same for TWO reductions finalised by one launch (the fused PCG tail): one ticket, the last arrival adds both sets
+template <typename T> struct FinScratch2 { T ws[MIK_FIN_WGS]; T ws2[MIK_FIN_WGS]; unsigned ticket; };
+
+template <typename T>
+__device__ __forceinline__ bool level2_sum_spread2(const T *__restrict__ S1, const T *__restrict__ S2, int64_t m, FinScratch2<T> *fs, T &tot1, T &tot2)
+{
+    const int w = blockIdx.x, lane = threadIdx.x;              // blockDim.x == 64, gridDim.x == MIK_FIN_WGS
+    T a1 = T(0), a2 = T(0);
+    int64_t j = 64 * (int64_t)w + lane;
+    for (; j + 15 * (int64_t)MIK_FIN_THREADS < m; j += 16 * (int64_t)MIK_FIN_THREADS) {
+        T v[16], z[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { v[q] = S1[j + q * (int64_t)MIK_FIN_THREADS]; z[q] = S2[j + q * (int64_t)MIK_FIN_THREADS]; }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { a1 = a1 + v[q]; a2 = a2 + z[q]; }
+    }
+    for (; j < m; j += MIK_FIN_THREADS) { a1 = a1 + S1[j]; a2 = a2 + S2[j]; }
+    a1 = wave_tree(a1);
+    a2 = wave_tree(a2);
+    bool last = false;
+    if (lane == 0) {
+        __hip_atomic_store(&fs->ws[w], a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&fs->ws2[w], a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tk = __hip_atomic_fetch_add(&fs->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tk == (unsigned)gridDim.x - 1u) {
+            T t = __hip_atomic_load(&fs->ws[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            T z = __hip_atomic_load(&fs->ws2[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int q = 1; q < MIK_FIN_WGS; ++q) {
+                t = t + __hip_atomic_load(&fs->ws[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                z = z + __hip_atomic_load(&fs->ws2[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __hip_atomic_store(&fs->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tot1 = t; tot2 = z;
+            last = true;
+        }
+    }
+    return last;
+}
+
 // after norm(r) of cg_iterator! (src/cg.jl:140-152)
 template <typename T> __device__ __forceinline__ void cg_init_scalars(CgDev<T> *d, T tot, T res, T reltol, T abstol, long long maxiter)
 {
@@ -480,13 +521,13 @@ __global__ __launch_bounds__(64) void k_cg_fin_rho(const T *__restrict__ S, int6
 // iterate() call (iteration index `it_next`)
 template <typename T>
 __device__ __forceinline__ void cg_res_scalars(CgDev<T> *d, T tot, T res, T *__restrict__ hist, long long it_next, long long maxiter,
-                                               CgMirror *mirror, unsigned long long seq, int hist_index)
+                                               CgMirror *mirror, unsigned long long seq, int hist_index, int pcg_fused = 0)
 {
     const T prev = d->res;
     d->rr = tot;
     d->prev_res = prev;
     d->res = res;
-    d->beta = (res * res) / (prev * prev);    // :50 of the next step
+    d->beta = pcg_fused ? d->beta_rho : (res * res) / (prev * prev);    // :50 of the next step (PCG: rho / rho_prev, :85)
     hist[hist_index] = res;                   // step `hist_index` of this host call (the host zeroes mirror->nhist)
     const int dn = (it_next >= maxiter || res <= d->tol) ? 1 : 0;
     if (dn) d->done = 1;
@@ -527,11 +568,40 @@ __global__ __launch_bounds__(64) void k_cg_fin_res(const T *__restrict__ S, int6
 // closes a step whose residual norm the host computed through the scaled pass
 template <typename T>
 __global__ void k_cg_fix_res(CgDev<T> *d, T res, T *__restrict__ hist, long long it_next, long long maxiter, CgMirror *mirror,
-                             unsigned long long seq, int hist_index)
+                             unsigned long long seq, int hist_index, int pcg_fused = 0)
 {
     d->done = 0;
     mirror->range = 0;
-    cg_res_scalars(d, res * res, res, hist, it_next, maxiter, mirror, seq, hist_index);
+    cg_res_scalars(d, res * res, res, hist, it_next, maxiter, mirror, seq, hist_index, pcg_fused);
+}
+
+// the tail finaliser of the fused PCG step: residual = norm(r) as k_cg_fin_res, and rho = dot(Pl \\ r, r), beta = rho / rho_prev of
+// the NEXT step (src/cg.jl:81-85) from the second reduction of the same sweep
+template <typename T>
+__global__ __launch_bounds__(64) void k_cg_fin_res2(const T *__restrict__ S1, const T *__restrict__ S2, int64_t m, CgDev<T> *d, T *__restrict__ hist,
+                                                     long long it_next, long long maxiter, CgMirror *mirror, unsigned long long seq, int hist_index,
+                                                     FinScratch2<T> *fs)
+{
+    if (d->done) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    T tot, tot2;
+    if (level2_sum_spread2(S1, S2, m, fs, tot, tot2)) {
+        d->x_pending = 1;                      // r of this step is final; its x .+= alpha .* u rides on the next sweep over u
+        const T rho_prev = d->rho;
+        d->rho = tot2;
+        d->beta_rho = tot2 / rho_prev;
+        if (!mik_nrm_in_range(tot)) {          // as k_cg_fin_res: freeze the batch, the host finishes the step with the scaled norm
+            d->done = 1;
+            mirror->done = 0;
+            mirror->nhist = hist_index;
+            mirror->range = 1;
+            __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        cg_res_scalars(d, tot, mik_sqrt(tot), hist, it_next, maxiter, mirror, seq, hist_index, 1);
+    }
 }
 
 static int cg_profile_collect(mik_cg *it)
@@ -632,7 +702,9 @@ template <typename T> static int cg_enqueue_head(mik_cg *it)
     T *x = (T *)it->x, *u = (T *)it->u, *r = (T *)it->r, *c = (T *)it->c;
     const bool vec = mik_aligned16(x) && mik_aligned16(u) && mik_aligned16(r) && mik_aligned16(c) && (!it->diag || mik_aligned16(it->diag));
     const int pcg = (it->diag || it->pl_fn) ? 1 : 0;
-    if (it->diag) {
+    if (it->pcg_fused) {
+        // c = Pl \ r and rho = dot(c, r) (src/cg.jl:79-85) came with the previous tail (cg init for the first step): nothing to do here
+    } else if (it->diag) {
         // c = Pl \ r; rho = dot(c, r)                                   src/cg.jl:79-82
         OpJacobiDot<T> pj{r, (const T *)it->diag, c, cg_stream_hints() != 0};
         MIK_TRY((launch_map<T>(ctx, n, pj, vec, (T *)it->seg_vec, done)));
@@ -643,8 +715,10 @@ template <typename T> static int cg_enqueue_head(mik_cg *it)
         MIK_TRY((launch_map<T>(ctx, n, dcr, vec, (T *)it->seg_vec, done)));
     }
     if (pcg) {
-        hipLaunchKernelGGL((k_cg_fin_rho<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_vec, nseg, d, (FinScratch<T> *)it->fin);
-        MIK_LAUNCH_CHECK(ctx);
+        if (!it->pcg_fused) {
+            hipLaunchKernelGGL((k_cg_fin_rho<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_vec, nseg, d, (FinScratch<T> *)it->fin);
+            MIK_LAUNCH_CHECK(ctx);
+        }
         // u .= c .+ beta .* u                                           src/cg.jl:86
         CgProfileScope ps(it, 1);
         if (it->fuse_x) {
@@ -710,6 +784,19 @@ template <typename T> static int cg_enqueue_tail(mik_cg *it, long long it_next, 
     T *x = (T *)it->x, *u = (T *)it->u, *r = (T *)it->r, *c = (T *)it->c;
     const bool vec = mik_aligned16(x) && mik_aligned16(u) && mik_aligned16(r) && mik_aligned16(c) && (!it->diag || mik_aligned16(it->diag));
     // x .+= alpha .* u; r .-= alpha .* c; norm(r)                       src/cg.jl:58-62
+    if (it->pcg_fused) {
+        {
+            CgProfileScope ps(it, 2);
+            // r is not read again before the next tail (the head reads c = Pl \\ r, u, x): both directions streamed unless development knob 7 says otherwise
+            OpPcgUpdateR<T> up{r, c, (const T *)it->diag, coef_ptr<T>(&d->alpha), g_mik_tuning[7] == 0 ? 24 : (g_mik_tuning[7] < 0 ? 0 : g_mik_tuning[7] & 24)};
+            MIK_TRY((launch_map2<T>(ctx, n, up, vec, (T *)it->seg_vec, (T *)it->seg_vec2, done)));
+        }
+        it->seq += 1;
+        hipLaunchKernelGGL((k_cg_fin_res2<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_vec, (const T *)it->seg_vec2, nseg, d, (T *)it->hist,
+                           it_next, (long long)it->maxiter, it->mirror, it->seq, hist_index, (FinScratch2<T> *)((unsigned char *)it->fin + 512));
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    }
     {
         CgProfileScope ps(it, 2);
         if (it->fuse_x) {
@@ -796,6 +883,13 @@ static int cg_init_impl(mik_cg *it, double abstol, double reltol, int initially_
     it->prev_residual = (double)h.prev_res;
     it->tol = (double)h.tol;
     it->dev_done = h.done != 0;
+    if (it->pcg_fused) {
+        // rho of the FIRST step (src/cg.jl:79-85 with rho_prev = one): later steps get theirs from the tail of the step before
+        OpJacobiDot<T> pj{r, (const T *)it->diag, c, 0};
+        MIK_TRY((launch_map<T>(ctx, n, pj, vec && mik_aligned16(it->diag), (T *)it->seg_vec, (const int *)nullptr)));
+        hipLaunchKernelGGL((k_cg_fin_rho<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_vec, nseg, (CgDev<T> *)it->dev, (FinScratch<T> *)it->fin);
+        MIK_LAUNCH_CHECK(ctx);
+    }
     return MIK_OK;
 }
 
@@ -811,13 +905,15 @@ static int cg_create_common(mik_ctx *ctx, const mik_csr *A, int dtype, int64_t n
     it->x = x; it->b = b; it->u = u; it->r = r; it->c = c; it->diag = jacobi_diag;
     it->maxiter = maxiter;
     it->fuse_x = A != nullptr && !pl_fn && g_mik_tuning[23] == 0;       // development knob 23: 1 = x updated by the step's own sweep
+    it->pcg_fused = it->fuse_x && jacobi_diag != nullptr && g_mik_tuning[22] == 0;   // development knob 22: 1 = the three-sweep PCG step
     const size_t es = mik_dtype_size(dtype);
     const int64_t nseg = dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
     const int64_t nb = mik_spmv_nwg(n);
     hipError_t e;
     (void)hipSetDevice(ctx->device);
-    if ((e = hipMalloc(&it->dev, 256)) != hipSuccess || (e = hipMalloc(&it->fin, 256)) != hipSuccess ||
-        (e = hipMemsetAsync(it->fin, 0, 256, ctx->stream)) != hipSuccess || (e = hipMalloc(&it->seg_spmv, es * (size_t)std::max<int64_t>(nb, 1))) != hipSuccess ||
+    if ((e = hipMalloc(&it->dev, 256)) != hipSuccess || (e = hipMalloc(&it->fin, 1024)) != hipSuccess ||       // [0, 512): FinScratch; [512, 1024): FinScratch2
+        (e = hipMemsetAsync(it->fin, 0, 1024, ctx->stream)) != hipSuccess ||
+        (it->pcg_fused && (e = hipMalloc(&it->seg_vec2, es * (size_t)std::max<int64_t>(nseg, 1))) != hipSuccess) || (e = hipMalloc(&it->seg_spmv, es * (size_t)std::max<int64_t>(nb, 1))) != hipSuccess ||
         (e = hipMalloc(&it->seg_vec, es * (size_t)std::max<int64_t>(nseg, 1))) != hipSuccess ||
         (e = hipMalloc(&it->hist, es * 64)) != hipSuccess) {
         mik_cg_destroy(it);
@@ -884,6 +980,7 @@ extern "C" int mik_cg_destroy(mik_cg *it)
     if (it->hist) (void)hipFree(it->hist);
     if (it->seg_spmv) (void)hipFree(it->seg_spmv);
     if (it->seg_vec) (void)hipFree(it->seg_vec);
+    if (it->seg_vec2) (void)hipFree(it->seg_vec2);
     for (hipEvent_t e : it->ev) (void)hipEventDestroy(e);
     if (it->mirror) (void)hipHostFree(it->mirror);
     delete it;
@@ -949,7 +1046,7 @@ static int cg_iterate_many_impl(mik_cg *it, int64_t iteration, int64_t max_steps
         MIK_TRY(mik_safe_norm_slow<T>(ctx, it->n, (const T *)it->r, &res));
         it->seq += 1;
         hipLaunchKernelGGL((k_cg_fix_res<T>), dim3(1), dim3(1), 0, ctx->stream, d, res, (T *)it->hist, (long long)(iteration + m.nhist + 1),
-                           (long long)it->maxiter, it->mirror, it->seq, (int)m.nhist);
+                           (long long)it->maxiter, it->mirror, it->seq, (int)m.nhist, it->pcg_fused ? 1 : 0);
         MIK_LAUNCH_CHECK(ctx);
         MIK_TRY(cg_wait_mirror(it));
         m = *it->mirror;

@@ -48,7 +48,7 @@ def test_lookahead_changes_nothing_the_caller_can_see(pkg, orc, ctx, dtype, pcg,
     kw = dict(reltol=0.0, maxiter=10 ** 6)
     h1, s1, _ = run(pkg, A, b, schedule, {}, Pl, **kw)
     # no look-ahead; x updated by the step's own sweep; neither; one row per lane
-    for knobs in ({9: 1}, {23: 1}, {9: 1, 23: 1}, {19: 1}):
+    for knobs in ({9: 1}, {23: 1}, {9: 1, 23: 1}, {19: 1}, {22: 1}, {22: 1, 9: 1}):
         h0, s0, _ = run(pkg, A, b, schedule, knobs, Pl, **kw)
         assert np.array_equal(h1, h0) and len(s1) == len(s0), knobs
         for (x1, r1), (x0, r0) in zip(s1, s0):
