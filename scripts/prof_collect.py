@@ -1,4 +1,4 @@
-"""Condense the rocprofv3 output of scripts/prof_r02.sh into small files fit for profiles/:
+"""Condense the rocprofv3 output of scripts/prof_r03.sh into small files fit for profiles/:
    <what>_kernel_stats.csv   (name, calls, total / average / min / max duration in us, percentage)
    <what>_pmc_summary.txt    (mean counter value per dispatch, per kernel) + derived figures
    <what>_traffic.json       (HBM-side bytes per launch: 2 * FETCH_SIZE + WRITE_SIZE, KiB counters; gfx950 note in
@@ -59,10 +59,10 @@ for d in sorted(glob.glob(os.path.join(root, "*"))):
         continue
     traffic = {}
     with open(os.path.join(summ, f"{what}_pmc_summary.txt"), "w") as o:
-        o.write("mean counter value per dispatch (separate rocprofv3 --pmc passes; scripts/prof_r02.sh)\n")
+        o.write("mean counter value per dispatch (separate rocprofv3 --pmc passes; scripts/prof_r03.sh)\n")
         for k in sorted(means, key=lambda k: -means[k].get("SQ_WAVE_CYCLES", means[k].get("FETCH_SIZE", 0))):
             m = means[k]
-            if not any(s in k for s in ("spmv", "k_map", "k_cg", "multidot", "gemv", "k_mgs", "finalize")):
+            if not any(s in k for s in ("spmv", "k_map", "k_cg", "multidot", "gemv", "k_mgs", "k_cgs", "finalize", "k_rowdot")):
                 continue
             o.write(f"\n{k}   (dispatches sampled: {counts[k]})\n")
             for c in sorted(m):
@@ -72,10 +72,17 @@ for d in sorted(glob.glob(os.path.join(root, "*"))):
                 rd, wr = 2.0 * m["FETCH_SIZE"] * 1024.0, m["WRITE_SIZE"] * 1024.0
                 der.append(f"HBM-side traffic per launch: read {rd / 1e9:.4f} GB (2 x FETCH_SIZE) + write {wr / 1e9:.4f} GB = {(rd + wr) / 1e9:.4f} GB")
                 kk = tkey(k)
-                traffic[kk] = {"kernel": k, "fetch_bytes_x2": rd, "write_bytes": wr, "traffic_bytes_per_launch": rd + wr}
+                rec = {"kernel": k, "fetch_bytes_x2": rd, "write_bytes": wr, "traffic_bytes_per_launch": rd + wr}
+                # several instantiations share a key (fused dot or not, long rows merged or not): the key holds the one that moves the
+                # most (the whole-matrix launch), every instantiation is listed under "variants"
+                var = traffic.get(kk, {}).get("variants", {})
+                var[k] = rd + wr
+                if kk not in traffic or rd + wr > traffic[kk]["traffic_bytes_per_launch"]:
+                    traffic[kk] = rec
+                traffic[kk]["variants"] = var
             if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m:
                 der.append(f"L2 hit rate {m['TCC_HIT_sum'] / (m['TCC_HIT_sum'] + m['TCC_MISS_sum']):.3f}")
-                if tkey(k) in traffic:
+                if tkey(k) in traffic and traffic[tkey(k)]["kernel"] == k:
                     traffic[tkey(k)]["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
             if "SQ_WAVE_CYCLES" in m and "SQ_WAIT_ANY" in m:
                 der.append(f"SQ_WAIT_ANY / SQ_WAVE_CYCLES = {m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES']:.3f}; "

@@ -1,0 +1,52 @@
+#!/bin/bash
+# Round-3 profiling recipe (run on the GPU box through gpurun):  scripts/prof_r03.sh [what...]   what = bench c5 gmres
+#   rocprofv3 --kernel-trace --stats           -> gpurun_out/r03/<what>/trace
+#   separate --pmc passes (never combined with other trace domains; <= 8 SQ / 4 TCC counters per pass)
+# scripts/prof_collect.py then condenses everything into the small CSV / txt / json files that are committed under profiles/.
+# bench: the driver's command, so the CSR loop (k_spmv_rowgather, the contract's roofline) and the default loop (k_spmv_sdiab2)
+# are both in the trace with the shipped cache hints.  c5: one directory per configs[4] stand-in, so that the traffic of a kernel
+# is that of ONE matrix.
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out/r03
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+WHAT=${@:-bench c5 gmres}
+export MIK_BENCH_MIN_SECONDS=0            # profiled runs: one timed region is enough
+pmc() {   # pmc <dir> <counters...> -- <command...>
+  local d=$1; shift; local C=(); while [ "$1" != "--" ]; do C+=("$1"); shift; done; shift
+  rocprofv3 --kernel-trace --pmc "${C[@]}" --output-format csv -d $d -o run -- "$@" > $d.log 2>&1 || echo "pmc pass $d (${C[*]}) failed"
+}
+for w in $WHAT; do
+ case $w in
+ bench)
+  D=$OUT/bench; mkdir -p $D
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -o run -- python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-gmres --no-config5 > $D/trace.log 2>&1
+  grep "^{" $D/trace.log | tail -1 > $D/bench_under_rocprof.json
+  B="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-parity --no-gmres --no-config5"
+  pmc $D/pmc_fetch FETCH_SIZE -- $B
+  pmc $D/pmc_write WRITE_SIZE -- $B
+  pmc $D/pmc_l2 TCC_HIT_sum TCC_MISS_sum -- $B
+  pmc $D/pmc_sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_VALU -- $B
+  ;;
+ c5)
+  for k in ${C5_KINDS:-fe_shell fe_hex banded random}; do
+   D=$OUT/c5_$k; mkdir -p $D
+   C5="python $R/scripts/config5_bench.py"
+   export KINDS=$k CSR=0
+   GMRES=1 rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -o run -- $C5 > $D/trace.log 2>&1
+   grep "==\|SpMV\|gmres" $D/trace.log > $D/config5_under_rocprof.txt
+   export GMRES=0
+   pmc $D/pmc_fetch FETCH_SIZE -- $C5
+   pmc $D/pmc_write WRITE_SIZE -- $C5
+   pmc $D/pmc_l2 TCC_HIT_sum TCC_MISS_sum -- $C5
+   unset GMRES KINDS CSR
+  done
+  ;;
+ gmres)
+  D=$OUT/gmres; mkdir -p $D
+  CPU=0 rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -o run -- python $R/scripts/gmres_bench.py > $D/trace.log 2>&1
+  grep -v "^W2\|^E2\|rocprofv3" $D/trace.log > $D/gmres_c3_under_rocprof.txt
+  ;;
+ esac
+done
+python $R/scripts/prof_collect.py $OUT
