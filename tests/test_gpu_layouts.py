@@ -269,3 +269,37 @@ def test_rectangular_blocks_with_lane_neighbour_slots(pkg, ctx, dtype, rows):
         assert np.array_equal(with_knobs(pkg, knobs, run), want), form
     if rows % 2 == 0 and rows >= 256:
         assert "k_spmv_sdiab2" in seen and "k_spmv_sdiab" in seen
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_jagged_slices_with_split_off_long_rows(pkg, orc, ctx, dtype):
+    """a finite-element operator with a few dense constraint rows: the FE rows run in the jagged slices, the rows beyond
+    mik_spmv_long_row() in the wave-per-row workgroups that lead the same launch (MERGE_LONG), and dot(u, c) of the CG step comes
+    from k_rowdot -- mul! and the CG history equal the oracle's bit for bit (long rows in the documented wave shape)"""
+    n, rp, ci, vv = pkg.fixtures.fe_matrix((19, 23), 6, dtype)
+    S = sp.csr_matrix((vv.astype(np.float64), ci, rp), shape=(n, n)).tolil()
+    rng = np.random.default_rng(12)
+    for row, cnt in ((7, 300), (n // 2, 2600), (n - 3, 257)):
+        cols = np.sort(rng.choice(n, size=cnt, replace=False))
+        S[row, cols] = rng.standard_normal(cnt) * 0.01
+        S[row, row] = 50.0
+    S = (S + S.T).tocsr() * 0.5                                   # keep it symmetric (the dense rows become dense columns too)
+    S = S + sp.diags(np.full(n, 5.0))
+    S = S.astype(dtype).tocsr()
+    S.sort_indices()
+    lens = np.diff(S.indptr)
+    assert (lens > ctx.spmv_long_row()).sum() >= 2
+    dA = pkg.HipCSR(n, n, S.indptr.astype(np.int64), S.indices.astype(np.int64), S.data, index_base=0, is_csc=False)
+    assert dA.layout() == "jagged-slices" and dA.spmv_kernel() == "k_spmv_jds"
+    A = orc.CSC.from_scipy(S.tocsc())
+    orc.set_long_row(ctx.spmv_long_row(), ctx.spmv_long_segment())
+    try:
+        x = rng.standard_normal(n).astype(dtype)
+        for _ in range(2):                                        # the segment tickets reset themselves
+            assert np.array_equal(pkg.mul_(pkg.HipVector(n, dtype), dA, pkg.HipVector.from_numpy(x)).to_numpy(), orc.spmv(A, x))
+        b = orc.hashed_rhs(n).astype(dtype)
+        xs, ch = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True, maxiter=25)
+        xo, ho = orc.cg(A, b, maxiter=25, mode="tree", shape=ctx.cg_shape(dtype))
+        assert np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(xs.to_numpy(), xo)
+    finally:
+        orc.set_long_row(0)
