@@ -1,10 +1,13 @@
 /*
  * mik_dev.h -- DEVELOPMENT interface of libmik.so.  Not part of the drop-in boundary (include/mik.h): nothing a host of the
  * reference needs is declared here.  The knobs select kernel variants for A/B timing (scripts/) and for the tests that pin
- * every variant against the oracle (tests/test_gpu_layouts.py, test_gpu_lookahead.py); results never depend on them.  They are
- * process-global and not thread-safe: set them from the thread that drives the library, before the objects they affect are
- * created.  A host that wants an operator on its plain CSR arrays uses mik_csr_set_layout (include/mik.h), not a knob.
+ * every variant against the oracle (tests/test_gpu_layouts.py, test_gpu_lookahead.py); results never depend on them.
+ * Every mik_ctx carries its OWN table (a copy of the defaults when it is created); launches and object creation read only the
+ * table of their context.  mik_ctx_set_tuning changes one context; mik_set_tuning is the process-wide convenience of the test
+ * suite: it writes the defaults and every live context, and must not race with calls on those contexts.  A host that wants an
+ * operator on its plain CSR arrays uses mik_csr_set_layout (include/mik.h), not a knob.
  */
+#include "mik.h"
 #ifndef MIK_DEV_H
 #define MIK_DEV_H
 #ifdef __cplusplus
@@ -31,6 +34,7 @@ extern "C" {
  *  27: direction of the streaming launches of a plain CG step (bit 0 / 1 / 2: the u sweep / the SpMV / the update walk from
  *      the end of the vectors; 8: every launch against the one before it) -- no effect at the default cache hints */
 int mik_set_tuning(int key, int value);
+int mik_ctx_set_tuning(mik_ctx *ctx, int key, int value);
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,7 @@ SIGNATURES = {
     "mik_reduce_shape": (C.c_int, [C.c_int, _ip, _ip]),
     "mik_spmv_dot_shape": (C.c_int, [_ip, _ip]),
     "mik_set_tuning": (C.c_int, [C.c_int, C.c_int]),
+    "mik_ctx_set_tuning": (C.c_int, [_vp, C.c_int, C.c_int]),
     "mik_spmv_long_row": (C.c_int, [_ip]),
     "mik_spmv_long_segment": (C.c_int, [_ip]),
     "mik_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),

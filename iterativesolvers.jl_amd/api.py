@@ -68,6 +68,10 @@ class HipContext:
         check(lib().mik_spmv_dot_shape(C.byref(w), C.byref(l)), "mik_spmv_dot_shape", self.handle)
         return w.value, l.value
 
+    def set_tuning(self, key: int, value: int) -> None:
+        """Development knob of THIS context (include/mik_dev.h); results never depend on it."""
+        check(lib().mik_ctx_set_tuning(self.handle, int(key), int(value)), "mik_ctx_set_tuning", self.handle)
+
     def spmv_long_row(self) -> int:
         """Rows with more stored entries than this use the wave-shaped row sum (include/mik.h)."""
         t = C.c_int()

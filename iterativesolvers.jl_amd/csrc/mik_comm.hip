@@ -238,7 +238,7 @@ extern "C" int mik_cgd_set_halo_plan(mik_cgd *it, int n_recv, const int *recv_pe
     // updates and packs them first and puts the halo on the wire before the bulk of the sweep over u (cgd_enqueue_head).
     it->n_early = 0;
     it->early_merged = false;
-    if (it->n_send > 0 && it->n_send <= (1 << 26) && g_mik_tuning[24] == 0) {       // development knob 24: 1 = halo after the whole sweep
+    if (it->n_send > 0 && it->n_send <= (1 << 26) && it->base.ctx->tuning[24] == 0) {       // development knob 24: 1 = halo after the whole sweep
         std::vector<int> idx((size_t)it->n_send);
         if (hipMemcpy(idx.data(), it->send_idx, sizeof(int) * idx.size(), hipMemcpyDeviceToHost) == hipSuccess) {
             std::vector<int> srt(idx);
@@ -487,8 +487,8 @@ extern "C" int mik_cgd_iterate_many(mik_cgd *it, int64_t iteration, int64_t max_
     mik_cg &bs = it->base;
     if (max_steps <= 0 || iteration >= bs.maxiter || bs.residual <= bs.tol) return MIK_OK;      // done(it, iteration), src/cg.jl:36
     max_steps = std::min<int64_t>(std::min<int64_t>(max_steps, bs.maxiter - iteration), bs.hist_cap);
-    const bool ahead_ok = g_mik_tuning[9] == 0 && iteration + max_steps < bs.maxiter;      // development knob 9: 1 = nothing ahead of the host
-    bs.fuse_x = g_mik_tuning[23] == 0;                              // x .+= alpha .* u rides on the next sweep over u (as in mik_cg_*)
+    const bool ahead_ok = bs.ctx->tuning[9] == 0 && iteration + max_steps < bs.maxiter;      // development knob 9: 1 = nothing ahead of the host
+    bs.fuse_x = bs.ctx->tuning[23] == 0;                              // x .+= alpha .* u rides on the next sweep over u (as in mik_cg_*)
     CgMirror m;
     for (int64_t j0 = 0;;) {
         for (int64_t j = j0; j < max_steps; ++j) {
@@ -771,7 +771,7 @@ extern "C" int mik_cgd_group_iterate_many(mik_cgd **its, int P, int64_t iteratio
     for (int p = 0; p < P; ++p) {
         split = split && its[p]->int_end > its[p]->int_begin;
         early = early && its[p]->n_early > 0;
-        its[p]->base.fuse_x = g_mik_tuning[23] == 0;                // as mik_cgd_iterate_many: x .+= alpha .* u rides on the next sweep over u
+        its[p]->base.fuse_x = its[p]->base.ctx->tuning[23] == 0;                // as mik_cgd_iterate_many: x .+= alpha .* u rides on the next sweep over u
     }
     early = early && split;
     std::vector<char> pending;

@@ -8,6 +8,9 @@
 
 #include "mik_kernels.h"
 #include "mik_spmv.h"
+#include <algorithm>
+#include <mutex>
+
 #include "mik_sell.h"
 #include "mik_jds.h"
 #include <map>
@@ -16,6 +19,10 @@
 
 thread_local std::string g_mik_create_error;
 int g_mik_tuning[32] = {0};
+// every live context: mik_set_tuning (the process-wide development setter) writes the defaults AND all of them; launches only ever read
+// their own context's table
+static std::vector<mik_ctx *> g_mik_contexts;
+static std::mutex g_mik_contexts_mu;
 
 int mik_fail(mik_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -94,6 +101,11 @@ extern "C" int mik_ctx_create(int device, mik_ctx **out)
     if ((e = hipMalloc(&ctx->coef, mik_ctx::COEF_BYTES)) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipHostMalloc(&ctx->coef_host, mik_ctx::COEF_BYTES, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
     if ((e = hipEventCreateWithFlags(&ctx->wait_event, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    {
+        std::lock_guard<std::mutex> lk(g_mik_contexts_mu);
+        memcpy(ctx->tuning, g_mik_tuning, sizeof(ctx->tuning));
+        g_mik_contexts.push_back(ctx);
+    }
     *out = ctx;
     return MIK_OK;
 }
@@ -101,6 +113,10 @@ extern "C" int mik_ctx_create(int device, mik_ctx **out)
 extern "C" int mik_ctx_destroy(mik_ctx *ctx)
 {
     if (!ctx) return MIK_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_mik_contexts_mu);
+        g_mik_contexts.erase(std::remove(g_mik_contexts.begin(), g_mik_contexts.end(), ctx), g_mik_contexts.end());
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->partials) (void)hipFree(ctx->partials);
@@ -148,10 +164,19 @@ extern "C" int mik_spmv_long_segment(int *segment)
     return MIK_OK;
 }
 
+extern "C" int mik_ctx_set_tuning(mik_ctx *ctx, int key, int value)
+{
+    if (!ctx || key < 0 || key >= 32) return MIK_ERR_INVALID;
+    ctx->tuning[key] = value;
+    return MIK_OK;
+}
+
 extern "C" int mik_set_tuning(int key, int value)
 {
     if (key < 0 || key >= 32) return MIK_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(g_mik_contexts_mu);
     g_mik_tuning[key] = value;
+    for (mik_ctx *c : g_mik_contexts) c->tuning[key] = value;
     return MIK_OK;
 }
 
@@ -359,7 +384,7 @@ static int csr_build_sdia(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
 {
     (void)max_row;
     hipError_t e;
-    if (A->n_long == 0 && n_rows > 0 && nnz > 0 && n_cols > 0 && g_mik_tuning[8] == 0 && g_mik_tuning[12] == 0)
+    if (A->n_long == 0 && n_rows > 0 && nnz > 0 && n_cols > 0 && ctx->tuning[8] == 0 && ctx->tuning[12] == 0)
     {
         const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
         std::vector<int> dptr((size_t)nb + 1, 0), doff((size_t)nb * 8, 0), dtri((size_t)nb, -1);
@@ -422,7 +447,7 @@ static int csr_build_sdia(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
             }
             // slice-constant slots (k_spmv_sdiac): every row of a slice that has slot q carries the same value BITS there
             std::vector<unsigned char> cval;
-            bool constant = ok && g_mik_tuning[11] == 0;
+            bool constant = ok && ctx->tuning[11] == 0;
             if (constant) {
                 cval.assign((size_t)nb * 8 * es, 0);
                 std::vector<unsigned char> seen((size_t)nb * 8, 0);
@@ -490,7 +515,7 @@ static int csr_build_sell(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
     // the whole operator has at most 255 distinct (column - row) offsets.
     (void)n_cols;
     hipError_t e;
-    if (!A->sdia_val && !A->sdia_pats && A->n_long == 0 && n_rows > 0 && nnz > 0 && max_row <= 255 && g_mik_tuning[8] == 0 && g_mik_tuning[10] == 0)
+    if (!A->sdia_val && !A->sdia_pats && A->n_long == 0 && n_rows > 0 && nnz > 0 && max_row <= 255 && ctx->tuning[8] == 0 && ctx->tuning[10] == 0)
     {
         const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
         std::vector<int> sptr((size_t)nb + 1, 0);
@@ -572,7 +597,7 @@ static int csr_build_sell(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
 static int csr_build_jds(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowptr, const std::vector<int> &col, const std::vector<unsigned char> &v,
                          size_t es, int64_t n_rows, const unsigned char *is_long)
 {
-    if (A->sdia_val || A->sdia_pats || A->sell8_codes || n_rows <= 0 || g_mik_tuning[8] != 0 || g_mik_tuning[28] == 1) return MIK_OK;   // development knob 28: 1 = never, 2 = whenever possible
+    if (A->sdia_val || A->sdia_pats || A->sell8_codes || n_rows <= 0 || ctx->tuning[8] != 0 || ctx->tuning[28] == 1) return MIK_OK;   // development knob 28: 1 = never, 2 = whenever possible
     const int W = (int)(16 / es);
     const int64_t short_nnz = rowptr[(size_t)n_rows];
     if (short_nnz <= 0) return MIK_OK;
@@ -591,7 +616,7 @@ static int csr_build_jds(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowpt
     }
     if (maxlen >= MIK_JDS_LONG || groups * W >= INT32_MAX) return MIK_OK;
     const int64_t jds_bytes = groups * W * (int64_t)(es + 4) + 2 * n_rows, csr_bytes = short_nnz * (int64_t)(es + 4) + 4 * n_rows;
-    if (g_mik_tuning[28] != 2 && !(iters * 64 * 4 <= groups * 5 && (maxlen > 32 || jds_bytes * 10 <= csr_bytes * 11))) return MIK_OK;
+    if (ctx->tuning[28] != 2 && !(iters * 64 * 4 <= groups * 5 && (maxlen > 32 || jds_bytes * 10 <= csr_bytes * 11))) return MIK_OK;
     std::vector<int> jptr, jcol;
     std::vector<unsigned short> jlen;
     std::vector<unsigned char> jval;
@@ -758,13 +783,13 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
     // Default: everything past the raw host-to-device copy happens on the device (mik_upload.hip).  MIK_ERR_NOTIMPL from it
     // = a matrix the host path below handles (long rows, duplicate entries, no room for the raw copy); development knob 20:
     // 1 = host path only.
-    if (g_mik_tuning[20] == 0 && nnz > 0 && n_rows > 0 && n_cols > 0 && n_rows < 0x7f000000) {       // (row ids below the "no row yet" pattern of the analysis)
+    if (ctx->tuning[20] == 0 && nnz > 0 && n_rows > 0 && n_cols > 0 && n_rows < 0x7f000000) {       // (row ids below the "no row yet" pattern of the analysis)
         mik_csr *A = new (std::nothrow) mik_csr();
         if (!A) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host allocation failed");
         A->ctx = ctx; A->dtype = dtype; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz;
         (void)hipSetDevice(ctx->device);
         int rc = mik_upload_device(ctx, A, dtype, n_rows, n_cols, nnz, ptr, idx, val, index_base, is_csc);
-        if (rc == MIK_OK && !A->sdia_val && !A->sdia_pats && g_mik_tuning[8] == 0) {
+        if (rc == MIK_OK && !A->sdia_val && !A->sdia_pats && ctx->tuning[8] == 0) {
             // no per-slice-offset layout: the other sliced-ELL forms are built by the host builder from a copy of the device CSR
             try {
                 rowptr.resize((size_t)n_rows + 1);
@@ -847,8 +872,8 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
     std::vector<int> seg_row, cut_row, cut_first, cut_nseg;    // segment -> cut row; cut row -> matrix row, first segment, segments
     std::vector<unsigned char> is_long;
     // development knob [4]: > 0 overrides the threshold, < 0 disables the split
-    const int long_row = g_mik_tuning[4] > 0 ? g_mik_tuning[4] : MIK_LONG_ROW;
-    if (max_row > long_row && g_mik_tuning[4] >= 0) {
+    const int long_row = ctx->tuning[4] > 0 ? ctx->tuning[4] : MIK_LONG_ROW;
+    if (max_row > long_row && ctx->tuning[4] >= 0) {
         is_long.assign((size_t)n_rows, 0);
         std::vector<int> rp2((size_t)n_rows + 1, 0), col2((size_t)nnz);
         std::vector<unsigned char> v2((size_t)nnz * es);
@@ -883,7 +908,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
         for (int64_t q = ps; q < ((short_nnz + 3) & ~(int64_t)3); ++q) { col2[q] = 0; memset(&v2[(size_t)q * es], 0, es); }
         rowptr.swap(rp2); col.swap(col2); v.swap(v2);
         {   // rows longer than one segment are cut: every segment becomes a virtual row of its own (csrc/mik_spmv.h, LongTab)
-            const int seg = g_mik_tuning[15] > 0 ? g_mik_tuning[15] : MIK_LONG_SEG;      // development knob: segment length
+            const int seg = ctx->tuning[15] > 0 ? ctx->tuning[15] : MIK_LONG_SEG;      // development knob: segment length
             std::vector<int> vr, vs, vl;
             for (size_t q = 0; q < long_rows.size(); ++q) {
                 if (long_len[q] <= seg) { vr.push_back(long_rows[q]); vs.push_back(long_start[q]); vl.push_back(long_len[q]); continue; }
@@ -1023,7 +1048,7 @@ extern "C" int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes)
     const int64_t es = (int64_t)mik_dtype_size(A->dtype);
     const int64_t nb = (A->n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
     switch (layout) {
-    case 5: *bytes = A->n_rows + nb * ((A->sdia_recs && g_mik_tuning[17] == 0) ? 64 : 4) + (int64_t)A->sdia_npat * (80 + 8 * es); break;
+    case 5: *bytes = A->n_rows + nb * ((A->sdia_recs && A->ctx->tuning[17] == 0) ? 64 : 4) + (int64_t)A->sdia_npat * (80 + 8 * es); break;
     case 4: *bytes = A->sdia_entries * es + A->n_rows + nb * 36; break;
     case 2: *bytes = A->sell_entries * es + A->sell8_bytes + (nb + 1) * 8 + 256 * 4; break;
     case 1: *bytes = A->jds_groups * (16 / es) * (es + 4) + A->n_rows * 2 + ((A->n_rows + 63) / 64 + 1) * 4 +
@@ -1057,11 +1082,11 @@ static int spmv_kernel_choice(const mik_csr *A)
 {
     const bool csr = A->col != nullptr;                     // false after mik_csr_compact: the development knobs cannot fall back to CSR
     if (A->force_layout == 0 && csr) return 0;              // mik_csr_set_layout
-    if (g_mik_tuning[8] == 0 || !csr) {
-        if (A->sdia_pats && (g_mik_tuning[12] == 0 || !csr)) return 5;
-        if (A->sdia_val && (g_mik_tuning[12] == 0 || !csr)) return 4;
-        if (A->sell8_codes && (g_mik_tuning[10] == 0 || !csr)) return 2;
-        if (A->jds_val && g_mik_tuning[28] != 1) return 1;
+    if (A->ctx->tuning[8] == 0 || !csr) {
+        if (A->sdia_pats && (A->ctx->tuning[12] == 0 || !csr)) return 5;
+        if (A->sdia_val && (A->ctx->tuning[12] == 0 || !csr)) return 4;
+        if (A->sell8_codes && (A->ctx->tuning[10] == 0 || !csr)) return 2;
+        if (A->jds_val && A->ctx->tuning[28] != 1) return 1;
     }
     return 0;
 }
@@ -1082,15 +1107,15 @@ extern "C" int mik_csr_compact(mik_csr *A)
 
 static inline bool spmv_csr_rowgather(const mik_csr *A)
 {
-    return g_mik_tuning[14] == 2 || (g_mik_tuning[14] == 0 && A->n_long == 0);
+    return A->ctx->tuning[14] == 2 || (A->ctx->tuning[14] == 0 && A->n_long == 0);
 }
 
 // k_spmv_sdiab2 (two rows per lane): the operator's class has the lane-neighbour shape, n is even, and no development
 // knob asks for another form (16: slices per workgroup; 18: no compiled-in class; 19: 1 = one row per lane)
 static bool sdiab2_applies(const mik_csr *A)
 {
-    return A->sdia_buf_ok && A->sdia_cls >= 1 && (A->n_rows & 1) == 0 && g_mik_tuning[16] == 0 && g_mik_tuning[17] == 0 && g_mik_tuning[18] == 0 &&
-           g_mik_tuning[19] == 0;
+    return A->sdia_buf_ok && A->sdia_cls >= 1 && (A->n_rows & 1) == 0 && A->ctx->tuning[16] == 0 && A->ctx->tuning[17] == 0 && A->ctx->tuning[18] == 0 &&
+           A->ctx->tuning[19] == 0;
 }
 
 // the operator's SpMV moves little more than x and y (the slice-constant layout): the CG step then picks other cache hints
@@ -1101,7 +1126,7 @@ extern "C" int mik_spmv_kernel(const mik_csr *A, char *name, int len)
     if (!A || !name || len <= 0) return MIK_ERR_INVALID;
     const char *k = "k_spmv_rowblock";
     switch (spmv_kernel_choice(A)) {
-    case 5: k = A->sdia_buf_ok && g_mik_tuning[17] == 0 ? (sdiab2_applies(A) ? "k_spmv_sdiab2" : "k_spmv_sdiab") : "k_spmv_sdiac"; break;
+    case 5: k = A->sdia_buf_ok && A->ctx->tuning[17] == 0 ? (sdiab2_applies(A) ? "k_spmv_sdiab2" : "k_spmv_sdiab") : "k_spmv_sdiac"; break;
     case 4: k = "k_spmv_sdia"; break;
     case 2: k = "k_spmv_sell8"; break;
     case 1: k = "k_spmv_jds"; break;
@@ -1146,7 +1171,7 @@ int mik_spmv_launch_outside(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
 {
     const int nb_all = (int)mik_spmv_nwg(A->n_rows);
     if (skip_begin < 0 || skip_end < skip_begin || skip_end > nb_all) return mik_fail(ctx, MIK_ERR_INVALID, "SpMV: bad interior range");
-    if (spmv_kernel_choice(A) == 5 && A->sdia_buf_ok && g_mik_tuning[17] == 0 && skip_begin + (nb_all - skip_end) > 0)
+    if (spmv_kernel_choice(A) == 5 && A->sdia_buf_ok && A->ctx->tuning[17] == 0 && skip_begin + (nb_all - skip_end) > 0)
         return spmv_launch_impl<T>(ctx, A, x, y, fuse_dot, seg_out, done, 0, skip_begin + (nb_all - skip_end), skip_begin, skip_end - skip_begin);
     MIK_TRY(mik_spmv_launch_range<T>(ctx, A, x, y, fuse_dot, seg_out, done, 0, skip_begin));
     return mik_spmv_launch_range<T>(ctx, A, x, y, fuse_dot, seg_out, done, skip_end, nb_all - skip_end);
@@ -1170,17 +1195,17 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
     // [2] block map (0 = the operator's own choice: strips for banded operators, else identity; < 0 identity;
     //     1 contiguous range per XCD; P >= 8 strips of P row-blocks)
     const int nb = whole ? nb_all : rb_count;
-    const bool nt = g_mik_tuning[0] == 0;
-    const bool wide = g_mik_tuning[1] == 0;
-    int map_mode = g_mik_tuning[2] == 0 ? A->strip : std::max(g_mik_tuning[2], 0);
+    const bool nt = ctx->tuning[0] == 0;
+    const bool wide = ctx->tuning[1] == 0;
+    int map_mode = ctx->tuning[2] == 0 ? A->strip : std::max(ctx->tuning[2], 0);
     if (!whole && map_mode >= 8 && (rb0 % map_mode != 0 || nb % map_mode != 0)) map_mode = 0;   // strips need whole planes
     if (skip_len > 0) map_mode = 0;
     const int choice = spmv_kernel_choice(A);
     if (choice == 5) {
         // slice patterns {offsets, values} + one mask byte per row (mik_sell.h); G slices per workgroup
-        const int G = g_mik_tuning[16] > 0 ? g_mik_tuning[16] : MIK_SDIAC_G;   // development knob 16: 1 / 2 / 4 slices per workgroup
+        const int G = ctx->tuning[16] > 0 ? ctx->tuning[16] : MIK_SDIAC_G;   // development knob 16: 1 / 2 / 4 slices per workgroup
         const int wgs = ((nb + G - 1) / G + 7) / 8 * 8;                         // a multiple of 8: see k_spmv_sdiac
-        if (A->sdia_buf_ok && g_mik_tuning[17] == 0) {                          // development knob 17: 1 = the flat-load kernel
+        if (A->sdia_buf_ok && ctx->tuning[17] == 0) {                          // development knob 17: 1 = the flat-load kernel
             // strips of a power-of-two number of row-blocks are mapped by shifts; any other map runs as identity here
             int sshift = -1, nfull = 0;
             if (map_mode >= 8) {
@@ -1195,7 +1220,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
          else MIK_SDIAB_GO4(FD, NTV, GG, 0); } while (0)
 #define MIK_SDIAB_GO(FD, NTV)                                                                      \
     do { if (G == 1) MIK_SDIAB_GO4(FD, NTV, 1, 0); else if (G == 4) MIK_SDIAB_GO4(FD, NTV, 4, 0); else MIK_SDIAB_GO3(FD, NTV, 2); } while (0)
-            const int cls = g_mik_tuning[18] == 1 ? 0 : A->sdia_cls;            // development knob 18: 1 = slot-by-slot path only
+            const int cls = ctx->tuning[18] == 1 ? 0 : A->sdia_cls;            // development knob 18: 1 = slot-by-slot path only
             if (sdiab2_applies(A) && skip_len == 0 && (rb0 & 1) == 0 && ((nb & 1) == 0 || rb0 + nb == nb_all)) {
                 // two rows per lane, 16-byte gathers (k_spmv_sdiab2): workgroups over PAIRS of slices; strips halve with them
                 const int np = (nb + 1) / 2, pb0 = rb0 / 2, wg2 = (np + 7) / 8 * 8;

@@ -40,6 +40,7 @@ struct mik_ctx {
     void *coef_host = nullptr;       // pinned host mirror
     hipEvent_t wait_event = nullptr; // for mik_wait
     int sweep_rev = 0;               // 1: the next SpMV launch walks its row-blocks from the end (set and cleared by the CG step)
+    int tuning[32] = {0};            // development knobs of THIS context (include/mik_dev.h): a copy of the defaults at creation, mik_ctx_set_tuning
     static constexpr size_t COEF_BYTES = 8192;      // [0, 4096): coefficient blocks of the callers; the tail: scratch of mik_safe_norm_slow
     static constexpr size_t COEF_SAFE_SLOT = 4096;  // byte offset of that scratch
 };
@@ -110,7 +111,7 @@ template <typename T> __host__ __device__ static inline bool mik_nrm_in_range(T 
 template <typename T> int mik_safe_norm_slow(mik_ctx *ctx, int64_t n, const T *x, T *out);
 
 extern thread_local std::string g_mik_create_error;
-extern int g_mik_tuning[32];  // development knobs (mik_set_tuning), see mik_spmv_launch
+extern int g_mik_tuning[32];  // DEFAULTS of the development knobs (what a new context starts with; mik_set_tuning also writes every live context)
 
 int mik_fail(mik_ctx *ctx, int code, const char *fmt, ...);
 // operator upload (mik_core.hip / mik_upload.hip)
@@ -324,10 +325,9 @@ __device__ __forceinline__ int xcd_remap(int b, int nb)
 // Wait for everything enqueued on the ctx stream.  hipStreamSynchronize parks the host thread when the queue
 // is not about to drain and takes hundreds of microseconds to come back -- more than the kernels of one solver
 // iteration -- so the per-iteration scalar reads spin on an event instead (tuning[3] = 1: plain synchronize).
-extern int g_mik_tuning[32];
 static inline hipError_t mik_wait(mik_ctx *ctx)
 {
-    if (g_mik_tuning[3] == 1 || !ctx->wait_event) return hipStreamSynchronize(ctx->stream);
+    if (ctx->tuning[3] == 1 || !ctx->wait_event) return hipStreamSynchronize(ctx->stream);
     hipError_t e = hipEventRecord(ctx->wait_event, ctx->stream);
     if (e != hipSuccess) return e;
     while ((e = hipEventQuery(ctx->wait_event)) == hipErrorNotReady) {

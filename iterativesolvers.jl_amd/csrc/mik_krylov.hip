@@ -97,9 +97,9 @@ extern "C" int mik_hessenberg_ldiv(int dtype, void *H, int64_t ldh, int width, v
 // =============================================================================================
 // Stream the Krylov basis past the caches when it cannot stay resident anyway (k columns exceed the 256 MB
 // Infinity Cache), so that the vector being orthogonalised does.  tuning[13] bits switch the hints off for A/B runs.
-template <typename T> static inline int mik_basis_nt(int64_t n, int k, int bit)
+template <typename T> static inline int mik_basis_nt(const mik_ctx *ctx, int64_t n, int k, int bit)
 {
-    if (g_mik_tuning[13] & bit) return 0;
+    if (ctx->tuning[13] & bit) return 0;
     return (double)n * (double)k * sizeof(T) > 192.0e6 ? 1 : 0;
 }
 
@@ -110,7 +110,7 @@ static int gemv_n_dev(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, c
     if (nseg == 0 || k == 0) return MIK_OK;
     const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
     const bool vec = mik_aligned16(V) && mik_aligned16(y) && (ldv % VT<T>::W == 0);
-    if (vec) hipLaunchKernelGGL((k_gemv_n<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, cf_dev, alpha, y, mik_basis_nt<T>(n, k, 2));
+    if (vec) hipLaunchKernelGGL((k_gemv_n<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, cf_dev, alpha, y, mik_basis_nt<T>(ctx, n, k, 2));
     else hipLaunchKernelGGL((k_gemv_n<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, cf_dev, alpha, y, 0);
     MIK_LAUNCH_CHECK(ctx);
     return MIK_OK;
@@ -177,7 +177,7 @@ static int multidot(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, con
     }
     const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
     const bool vec = mik_aligned16(V) && mik_aligned16(w) && (ldv % VT<T>::W == 0);
-    if (vec) hipLaunchKernelGGL((k_multidot<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, w, (T *)ctx->partials, mik_basis_nt<T>(n, k, 4));
+    if (vec) hipLaunchKernelGGL((k_multidot<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, w, (T *)ctx->partials, mik_basis_nt<T>(ctx, n, k, 4));
     else hipLaunchKernelGGL((k_multidot<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, w, (T *)ctx->partials, 0);
     MIK_LAUNCH_CHECK(ctx);
     return finalize_store<T>(ctx, nseg, k, out_dev);
@@ -209,7 +209,7 @@ static int orthogonalize_enqueue(mik_ctx *ctx, int64_t n, int k, const T *V, int
     if (cols) for (int i = 0; i < k; ++i) vec = vec && mik_aligned16(cols[i]);
     OpDot<T> dn{w, w};
 
-    if (method == MIK_MGS && nseg <= 1024 && g_mik_tuning[5] != 1) {
+    if (method == MIK_MGS && nseg <= 1024 && ctx->tuning[5] != 1) {
         // src/orthogonalize.jl:69-76, launch-lean form for n up to ~1M: every pass finalises the
         // previous pass's reduction itself (k_map_pro), so the chain is k + 2 launches instead of
         // 2k + 3.  Segment sums ping-pong between two buffers (a pass reads one while writing the other).
@@ -238,11 +238,11 @@ static int orthogonalize_enqueue(mik_ctx *ctx, int64_t n, int k, const T *V, int
             MIK_TRY((launch_map<T>(ctx, n, d0, vec, part, nullptr)));
             MIK_TRY(finalize_store<T>(ctx, nseg, 1, hd));
             for (int i = 0; i + 1 < k; ++i) {
-                OpMgsPass<T, false> op{w, col(i), col(i + 1), coef_ptr<T>(hd + i), (g_mik_tuning[13] & 1) == 0};
+                OpMgsPass<T, false> op{w, col(i), col(i + 1), coef_ptr<T>(hd + i), (ctx->tuning[13] & 1) == 0};
                 MIK_TRY((launch_map<T>(ctx, n, op, vec, part, nullptr)));
                 MIK_TRY(finalize_store<T>(ctx, nseg, 1, hd + i + 1));
             }
-            OpMgsPass<T, true> last{w, col(k - 1), nullptr, coef_ptr<T>(hd + k - 1), (g_mik_tuning[13] & 1) == 0};
+            OpMgsPass<T, true> last{w, col(k - 1), nullptr, coef_ptr<T>(hd + k - 1), (ctx->tuning[13] & 1) == 0};
             MIK_TRY((launch_map<T>(ctx, n, last, vec, part, nullptr)));
         } else {
             MIK_TRY((launch_map<T>(ctx, n, dn, vecw, part, nullptr)));
@@ -668,9 +668,9 @@ struct CgProfileScope {
 // cached rather than streamed takes 8 us off the update that wrote it (249 -> 248: 4,720 it/s).
 // (With an operator whose SpMV itself streams gigabytes -- CSR, per-row values -- the earlier mask 121 stays: 248 cost the CSR
 // loop 10 us per step.)
-static inline int cg_stream_hints(bool fused_x = false, const mik_csr *A = nullptr)
+static inline int cg_stream_hints(const mik_ctx *ctx, bool fused_x = false, const mik_csr *A = nullptr)
 {
-    const int k = g_mik_tuning[7];
+    const int k = ctx->tuning[7];
     return k == 0 ? (fused_x ? (mik_spmv_is_light(A) ? 248 : 121) : 57) : (k < 0 ? 0 : k);
 }
 
@@ -680,7 +680,7 @@ static inline int cg_stream_hints(bool fused_x = false, const mik_csr *A = nullp
 // round than the one before it.  Results never depend on it (partials keep their slots).
 static inline bool cg_sweep_rev(mik_cg *it, int which)
 {
-    const int k = g_mik_tuning[27];
+    const int k = it->ctx->tuning[27];
     if (k == 0) return false;
     if (k & 8) return (it->sweeps++ & 1u) != 0;
     return ((k >> which) & 1) != 0;
@@ -706,7 +706,7 @@ template <typename T> static int cg_enqueue_head(mik_cg *it)
         // c = Pl \ r and rho = dot(c, r) (src/cg.jl:79-85) came with the previous tail (cg init for the first step): nothing to do here
     } else if (it->diag) {
         // c = Pl \ r; rho = dot(c, r)                                   src/cg.jl:79-82
-        OpJacobiDot<T> pj{r, (const T *)it->diag, c, cg_stream_hints() != 0};
+        OpJacobiDot<T> pj{r, (const T *)it->diag, c, cg_stream_hints(ctx) != 0};
         MIK_TRY((launch_map<T>(ctx, n, pj, vec, (T *)it->seg_vec, done)));
     } else if (it->pl_fn) {
         // any Pl: ldiv!(c, Pl, r) through the callback, then the dot as its own sweep
@@ -722,20 +722,20 @@ template <typename T> static int cg_enqueue_head(mik_cg *it)
         // u .= c .+ beta .* u                                           src/cg.jl:86
         CgProfileScope ps(it, 1);
         if (it->fuse_x) {
-            OpXpbyX<T> op{c, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, (cg_stream_hints(true, it->A) & 8) | 1};   // c = Pl \\ r is dead after this sweep: streamed
+            OpXpbyX<T> op{c, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, (cg_stream_hints(ctx, true, it->A) & 8) | 1};   // c = Pl \\ r is dead after this sweep: streamed
             MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, (const int *)nullptr)));
         } else {
-            OpXpby<T> op{c, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 1};   // c = Pl \\ r is dead after this sweep
+            OpXpby<T> op{c, u, coef_ptr<T>(&d->beta), cg_stream_hints(ctx) & 1};   // c = Pl \\ r is dead after this sweep
             MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
         }
     } else {
         // u .= r .+ beta .* u                                           src/cg.jl:50-51
         CgProfileScope ps(it, 1);
         if (it->fuse_x) {   // ... and x .+= alpha .* u of the previous step, on the u this sweep reads anyway (OpXpbyX)
-            OpXpbyX<T> op{r, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(true, it->A) & 15};
+            OpXpbyX<T> op{r, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(ctx, true, it->A) & 15};
             MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, (const int *)nullptr, cg_sweep_rev(it, 0))));
         } else {
-            OpXpby<T> op{r, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 7};
+            OpXpby<T> op{r, u, coef_ptr<T>(&d->beta), cg_stream_hints(ctx) & 7};
             MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
         }
     }
@@ -788,7 +788,7 @@ template <typename T> static int cg_enqueue_tail(mik_cg *it, long long it_next, 
         {
             CgProfileScope ps(it, 2);
             // r is not read again before the next tail (the head reads c = Pl \\ r, u, x): both directions streamed unless development knob 7 says otherwise
-            OpPcgUpdateR<T> up{r, c, (const T *)it->diag, coef_ptr<T>(&d->alpha), g_mik_tuning[7] == 0 ? 24 : (g_mik_tuning[7] < 0 ? 0 : g_mik_tuning[7] & 24)};
+            OpPcgUpdateR<T> up{r, c, (const T *)it->diag, coef_ptr<T>(&d->alpha), ctx->tuning[7] == 0 ? 24 : (ctx->tuning[7] < 0 ? 0 : ctx->tuning[7] & 24)};
             MIK_TRY((launch_map2<T>(ctx, n, up, vec, (T *)it->seg_vec, (T *)it->seg_vec2, done)));
         }
         it->seq += 1;
@@ -800,10 +800,10 @@ template <typename T> static int cg_enqueue_tail(mik_cg *it, long long it_next, 
     {
         CgProfileScope ps(it, 2);
         if (it->fuse_x) {
-            OpCgUpdateR<T> up{r, c, coef_ptr<T>(&d->alpha), cg_stream_hints(true, it->A) >> 3};
+            OpCgUpdateR<T> up{r, c, coef_ptr<T>(&d->alpha), cg_stream_hints(ctx, true, it->A) >> 3};
             MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done, !it->diag && !it->pl_fn && cg_sweep_rev(it, 2))));
         } else {
-            OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints() >> 3};
+            OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints(ctx) >> 3};
             MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done)));
         }
     }
@@ -904,8 +904,8 @@ static int cg_create_common(mik_ctx *ctx, const mik_csr *A, int dtype, int64_t n
     it->op_mul = op_mul; it->op_user = op_user; it->pl_fn = pl_fn; it->pl_user = pl_user;
     it->x = x; it->b = b; it->u = u; it->r = r; it->c = c; it->diag = jacobi_diag;
     it->maxiter = maxiter;
-    it->fuse_x = A != nullptr && !pl_fn && g_mik_tuning[23] == 0;       // development knob 23: 1 = x updated by the step's own sweep
-    it->pcg_fused = it->fuse_x && jacobi_diag != nullptr && g_mik_tuning[22] == 0;   // development knob 22: 1 = the three-sweep PCG step
+    it->fuse_x = A != nullptr && !pl_fn && ctx->tuning[23] == 0;       // development knob 23: 1 = x updated by the step's own sweep
+    it->pcg_fused = it->fuse_x && jacobi_diag != nullptr && ctx->tuning[22] == 0;   // development knob 22: 1 = the three-sweep PCG step
     const size_t es = mik_dtype_size(dtype);
     const int64_t nseg = dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
     const int64_t nb = mik_spmv_nwg(n);
@@ -1027,7 +1027,7 @@ static int cg_iterate_many_impl(mik_cg *it, int64_t iteration, int64_t max_steps
     CgMirror m;
     // the head of the step AFTER this call goes on the stream before the host waits (never with host callbacks, whose call
     // count the caller may observe; development knob 9: 1 = off)
-    const bool ahead_ok = g_mik_tuning[9] == 0 && !it->op_mul && !it->pl_fn && iteration + max_steps < it->maxiter;
+    const bool ahead_ok = ctx->tuning[9] == 0 && !it->op_mul && !it->pl_fn && iteration + max_steps < it->maxiter;
     for (int64_t j0 = 0;;) {
         for (int64_t j = j0; j < max_steps; ++j) {
             if (!it->head_ahead) MIK_TRY(cg_enqueue_head<T>(it));
@@ -1462,11 +1462,11 @@ static int gmres_create_common(mik_ctx *ctx, const mik_csr *A, void *x, const vo
         const int64_t nseg = dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
         // single-launch Gram-Schmidt: up to 2048 reduction segments, G = 1 / 2 / 4 / 8 of them per workgroup (<= 256 workgroups, one
         // per CU); more than 256 segments need the library's own 16-byte aligned V (always the case here)
-        if (!part && nseg >= 1 && nseg <= 2048 && restart <= 254 && g_mik_tuning[31] == 0 && (nseg <= 256 || g->ldv % 4 == 0)) {   // development knob 31: 1 = chains only
+        if (!part && nseg >= 1 && nseg <= 2048 && restart <= 254 && ctx->tuning[31] == 0 && (nseg <= 256 || g->ldv % 4 == 0)) {   // development knob 31: 1 = chains only
             g->mgs_G = nseg <= 256 ? 1 : nseg <= 512 ? 2 : nseg <= 1024 ? 4 : 8;
             g->mgs_stride = std::max<int>(256, (int)((nseg + g->mgs_G - 1) / g->mgs_G) * g->mgs_G);
             // k_cgs_fused: one more row per round (the final h values); DGKS: up to 3 rounds in the kernel
-            g->mgs_rounds = orth_method == MIK_DGKS ? (g_mik_tuning[21] > 0 ? std::min(g_mik_tuning[21], 3) : 3) : 1;   // development knob 21: DGKS rounds in the kernel
+            g->mgs_rounds = orth_method == MIK_DGKS ? (ctx->tuning[21] > 0 ? std::min(ctx->tuning[21], 3) : 3) : 1;   // development knob 21: DGKS rounds in the kernel
             const size_t pbytes = es * 2 * (size_t)g->mgs_rounds * (size_t)(restart + 2) * (size_t)g->mgs_stride;
             if ((e = hipMalloc(&g->mgs_P, pbytes)) != hipSuccess || (e = hipMemsetAsync(g->mgs_P, 0xFF, pbytes, ctx->stream)) != hipSuccess ||
                 (g->mgs_mirror_stride = (sizeof(MgsMirror) + es * (size_t)(restart + 2) + 255) / 256 * 256, false) ||
@@ -1669,7 +1669,7 @@ template <typename T> static int gm_fused_wait(mik_gmres *g, int k, int slot, T 
         __builtin_ia32_pause();
 #endif
     }
-    if (mir->err || g_mik_tuning[30] == 1) return MIK_GS_TIMEOUT;        // (development knob 30: pretend it happened)
+    if (mir->err || ctx->tuning[30] == 1) return MIK_GS_TIMEOUT;        // (development knob 30: pretend it happened)
     // a workgroup gave up waiting for a slot (GPU shared with other work?): the caller redoes the column
     const T *out = reinterpret_cast<const T *>(mir + 1);
     for (int j = 0; j < k; ++j) h_out[j] = out[j];
@@ -1712,17 +1712,17 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
     // expand! (:64, :285-304), then H[k+1, k] = orthogonalize_and_normalize!(V[:, 1:k], V[:, k+1], H[1:k, k], orth_meth)  :68-73
     T nrm;
     bool ran = false;
-    if (g_mik_tuning[5] == 3 && !g->dist && !g->graph_off && g->method != MIK_DGKS && mik_nseg<T>(g->n) <= 1024 && !g->op_mul && !g->pl_fn && !g->pr_fn)
+    if (ctx->tuning[5] == 3 && !g->dist && !g->graph_off && g->method != MIK_DGKS && mik_nseg<T>(g->n) <= 1024 && !g->op_mul && !g->pl_fn && !g->pr_fn)
         MIK_TRY(gm_step_graph<T>(g, k, vk, vk1, &Hat(0, k - 1), &nrm, &ran));
     if (!ran) {
-        if (g->mgs_P && !g->dist && !g->fused_off && g_mik_tuning[5] == 0) {    // tuning[5]: 1 / 2 = the multi-launch chains
+        if (g->mgs_P && !g->dist && !g->fused_off && ctx->tuning[5] == 0) {    // tuning[5]: 1 / 2 = the multi-launch chains
             // single-launch Gram-Schmidt, one column ahead of the host: column k is on the stream already if the previous
             // call put it there; column k + 1 goes on the stream BEFORE this call waits for column k (never across a restart,
             // never with host callbacks in expand!, whose call count the caller may observe)
             const int slot = g->pre_k == k ? g->pre_slot : 0;
             if (g->pre_k != k) MIK_TRY(gm_fused_enqueue<T>(g, k, slot));
             g->pre_k = 0;
-            const bool ahead = k < m && iteration + 1 < g->maxiter && !g->op_mul && !g->pl_fn && !g->pr_fn && g_mik_tuning[9] == 0;
+            const bool ahead = k < m && iteration + 1 < g->maxiter && !g->op_mul && !g->pl_fn && !g->pr_fn && ctx->tuning[9] == 0;
             if (ahead) MIK_TRY(gm_fused_enqueue<T>(g, k + 1, slot ^ 1));
             bool rescaled = false;
             const int rcw = gm_fused_wait<T>(g, k, slot, &Hat(0, k - 1), &nrm, &rescaled);
@@ -2112,10 +2112,10 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
         return MIK_OK;
     case 0: {  // step A
         if (bs.fuse_x) {   // ... with x .+= alpha .* u of the previous step on the u this sweep reads anyway (OpXpbyX)
-            OpXpbyX<T> op{r, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(true, bs.A) & 15};
+            OpXpbyX<T> op{r, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(ctx, true, bs.A) & 15};
             MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, (const int *)nullptr)));
         } else {
-            OpXpby<T> op{r, u, coef_ptr<T>(&d->beta), cg_stream_hints() & 7};
+            OpXpby<T> op{r, u, coef_ptr<T>(&d->beta), cg_stream_hints(ctx) & 7};
             MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
         }
         return gather_launch<T>(ctx, it->n_send, it->send_idx, u, (T *)it->send_buf, done);
@@ -2139,10 +2139,10 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
             const int64_t o = lo[q], len = hi[q] - lo[q];
             const bool v2 = vec && (o % VT<T>::W == 0);
             if (bs.fuse_x) {
-                OpXpbyX<T> op{r + o, u + o, x + o, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(true, bs.A) & 15};
+                OpXpbyX<T> op{r + o, u + o, x + o, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(ctx, true, bs.A) & 15};
                 MIK_TRY((launch_map<T>(ctx, len, op, v2, (T *)nullptr, (const int *)nullptr)));
             } else {
-                OpXpby<T> op{r + o, u + o, coef_ptr<T>(&d->beta), cg_stream_hints() & 7};
+                OpXpby<T> op{r + o, u + o, coef_ptr<T>(&d->beta), cg_stream_hints(ctx) & 7};
                 MIK_TRY((launch_map<T>(ctx, len, op, v2, (T *)nullptr, done)));
             }
         }
@@ -2181,10 +2181,10 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
         hipLaunchKernelGGL((k_cgd_alpha<T>), dim3(1), dim3(1), 0, ctx->stream, (const T *)it->dot_all, it->nranks, d);
         MIK_LAUNCH_CHECK(ctx);
         if (bs.fuse_x) {
-            OpCgUpdateR<T> up{r, c, coef_ptr<T>(&d->alpha), cg_stream_hints(true, bs.A) >> 3};
+            OpCgUpdateR<T> up{r, c, coef_ptr<T>(&d->alpha), cg_stream_hints(ctx, true, bs.A) >> 3};
             MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)bs.seg_vec, done)));
         } else {
-            OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints() >> 3};
+            OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints(ctx) >> 3};
             MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)bs.seg_vec, done)));
         }
         hipLaunchKernelGGL((k_cgd_fin_slot<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)bs.seg_vec, nseg, rr_slot, done, (FinScratch<T> *)bs.fin);

@@ -407,10 +407,10 @@ int upload_device_t(mik_ctx *ctx, mik_csr *A, int64_t n_rows, int64_t n_cols, in
     UP_TRY(hipMemcpyAsync(&hs, d_st, sizeof(hs), hipMemcpyDeviceToHost, st));
     UP_TRY(hipStreamSynchronize(st));
     S.release(d_ptr); S.release(d_idx); S.release(d_val); S.release(cursor);       // the raw copy (2 GB at 256^3) is consumed
-    long_row = g_mik_tuning[4] > 0 ? g_mik_tuning[4] : MIK_LONG_ROW;
+    long_row = ctx->tuning[4] > 0 ? ctx->tuning[4] : MIK_LONG_ROW;
     // the host path's business: duplicates, rows to split off -- and ANY row beyond 256 entries, which k_up_sort_rows does not sort
     // (whatever development knob 4 says: an unsorted row would break the ascending-column order = Julia's scatter order)
-    if (hs.dup || (hs.max_row > long_row && g_mik_tuning[4] >= 0) || hs.max_row > 256) { rc = MIK_ERR_NOTIMPL; goto give_up; }
+    if (hs.dup || (hs.max_row > long_row && ctx->tuning[4] >= 0) || hs.max_row > 256) { rc = MIK_ERR_NOTIMPL; goto give_up; }
     A->max_row_nnz = hs.max_row;
     A->max_rowblock_nnz = hs.max_rb;
     {
@@ -418,7 +418,7 @@ int upload_device_t(mik_ctx *ctx, mik_csr *A, int64_t n_rows, int64_t n_cols, in
         A->strip = (P >= 8 && P <= nb / 4) ? (int)P : 0;
     }
     // ---- the per-slice-offset layouts -------------------------------------------------------------------------
-    if (g_mik_tuning[8] == 0 && g_mik_tuning[12] == 0 && n_cols > 0) {
+    if (ctx->tuning[8] == 0 && ctx->tuning[12] == 0 && n_cols > 0) {
         int *doff = nullptr, *dtri = nullptr, *dptr = nullptr, *first_row = nullptr;
         unsigned char *mask = nullptr;
         SdiaPattern<T> *desc = nullptr;
@@ -438,13 +438,13 @@ int upload_device_t(mik_ctx *ctx, mik_csr *A, int64_t n_rows, int64_t n_cols, in
         // (the scan is in 32 bits: more than 2^31 slots cannot qualify anyway, and nnz < 2^31 bounds slots by the test below only if it did not wrap)
         if (!hs.sdia_bad && slots_total >= 0 && (int64_t)slots_total <= nnz + nnz / 8 + 8 * MIK_BLOCK && (int64_t)nb * 8 * MIK_BLOCK < INT32_MAX) {
             hipLaunchKernelGGL(k_up_row_masks, dim3(blocks_for(n_rows)), dim3(MIK_BLOCK), 0, st, A->rowptr, A->col, (long long)n_rows, doff, dptr, mask, first_row, d_st);
-            if (g_mik_tuning[11] == 0)
+            if (ctx->tuning[11] == 0)
                 hipLaunchKernelGGL((k_up_row_constancy<T>), dim3(blocks_for(n_rows)), dim3(MIK_BLOCK), 0, st, A->rowptr, A->col, (const T *)A->val, (long long)n_rows,
                                    doff, dptr, first_row, d_st);
             UP_TRY(hipMemcpyAsync(&hs, d_st, sizeof(hs), hipMemcpyDeviceToHost, st));
             UP_TRY(hipStreamSynchronize(st));
             if (!hs.sdia_bad) {
-                const bool constant = g_mik_tuning[11] == 0 && !hs.not_constant;
+                const bool constant = ctx->tuning[11] == 0 && !hs.not_constant;
                 if (constant) {
                     std::vector<unsigned char> hdesc((size_t)nb * sizeof(SdiaPattern<T>));
                     UP_TRY(S.alloc(&desc, sizeof(SdiaPattern<T>) * (size_t)nb));

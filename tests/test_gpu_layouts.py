@@ -303,3 +303,28 @@ def test_jagged_slices_with_split_off_long_rows(pkg, orc, ctx, dtype):
         assert np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(xs.to_numpy(), xo)
     finally:
         orc.set_long_row(0)
+
+
+def test_development_knobs_are_per_context(pkg, orc, ctx):
+    """a knob set on one context (mik_ctx_set_tuning) does not reach another; the process-wide mik_set_tuning
+    of the test suite writes the defaults and every live context"""
+    A = orc.laplace(9, 3)
+    other = pkg.HipContext(0)
+    try:
+        other.set_tuning(8, 1)                                       # CSR only -- on `other`
+        dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval, index_base=A.index_base, ctx=ctx)
+        dB = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval, index_base=A.index_base, ctx=other)
+        assert dA.layout() == "slice-offsets+slice-values+row-masks" and dB.layout() == "csr-rowblock"
+        x = np.random.default_rng(0).standard_normal(A.n)
+        ya = pkg.mul_(pkg.HipVector(A.n, ctx=ctx), dA, pkg.HipVector.from_numpy(x, ctx=ctx)).to_numpy()
+        yb = pkg.mul_(pkg.HipVector(A.n, ctx=other), dB, pkg.HipVector.from_numpy(x, ctx=other)).to_numpy()
+        assert np.array_equal(ya, yb) and np.array_equal(ya, orc.spmv(A, x))
+        del dB
+        pkg.lib().mik_set_tuning(8, 1)                               # process-wide: reaches both
+        try:
+            assert pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval, index_base=A.index_base, ctx=ctx).layout() == "csr-rowblock"
+        finally:
+            pkg.lib().mik_set_tuning(8, 0)
+        assert pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval, index_base=A.index_base, ctx=other).layout() == "slice-offsets+slice-values+row-masks"
+    finally:
+        other.close() if hasattr(other, "close") else None
