@@ -145,7 +145,8 @@ int mik_csr_compact(mik_csr *A);
  * (column - row) offsets (banded / stencil operators with <= 255 distinct offsets), (3: retired), 4 = sliced-ELL values with per-slice offsets and one presence-mask byte per row (every
  * 256-row slice uses <= 8 distinct offsets: stencils on structured grids), 5 = the same with slice-CONSTANT slot values
  * (within a slice every row that has a slot carries the same value there -- constant-coefficient stencils): the slice
- * stores its <= 8 values once and a row is one mask byte. */
+ * stores its <= 8 values once and a row is one mask byte, 6 = the same idea for up to 32 offsets per slice with one 32-bit mask per
+ * row (9-point 2-D, 13 / 19 / 27-point 3-D constant-coefficient stencils). */
 int mik_csr_layout(const mik_csr *A, int *layout);
 /* Choose the layout mik_spmv and the iterables created AFTERWARDS use for this operator: layout = 0 runs it on its plain CSR
  * arrays (k_spmv_rowgather / k_spmv_rowblock -- what any matrix can run on; bench.py measures the north star's CSR figure this

@@ -351,7 +351,7 @@ class HipCSR:
         return mul_(y, self, x)
 
     LAYOUTS = ("csr-rowblock", "jagged-slices", "sliced-ell+8-bit-column-codes", "(retired)", "sliced-ell+slice-offsets+row-masks",
-               "slice-offsets+slice-values+row-masks")
+               "slice-offsets+slice-values+row-masks", "wide-slice-values+row-masks")
 
     def layout(self) -> str:
         """Device layout ``mul_`` uses for this operator (``mik_csr_layout``); results do not depend on it."""

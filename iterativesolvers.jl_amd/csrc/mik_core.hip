@@ -515,7 +515,7 @@ static int csr_build_sell(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
     // the whole operator has at most 255 distinct (column - row) offsets.
     (void)n_cols;
     hipError_t e;
-    if (!A->sdia_val && !A->sdia_pats && A->n_long == 0 && n_rows > 0 && nnz > 0 && max_row <= 255 && ctx->tuning[8] == 0 && ctx->tuning[10] == 0)
+    if (!A->sdia_val && !A->sdia_pats && !A->sdiaw_pats && A->n_long == 0 && n_rows > 0 && nnz > 0 && max_row <= 255 && ctx->tuning[8] == 0 && ctx->tuning[10] == 0)
     {
         const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
         std::vector<int> sptr((size_t)nb + 1, 0);
@@ -589,6 +589,88 @@ static int csr_build_sell(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
     return MIK_OK;
 }
 
+// Slice-constant values with up to 32 offsets per slice (k_spmv_sdiaw, csrc/mik_sell.h): 9 / 13 / 19 / 27-point constant-coefficient
+// stencils.  Built on the host when the <= 8-offset forms do not apply: every 256-row slice uses <= 32 distinct (column - row)
+// offsets, every offset carries ONE value (bit pattern) within its slice, every value is finite (an absent slot adds value * 0), and
+// row / slot byte offsets fit the 32-bit fields of the buffer instruction.  The first slice that fails ends the attempt.
+static int csr_build_sdiaw(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowptr, const std::vector<int> &col, const std::vector<unsigned char> &v,
+                           size_t es, int64_t n_rows, int64_t n_cols, int64_t nnz)
+{
+    if (A->sdia_val || A->sdia_pats || A->n_long || n_rows <= 0 || nnz <= 0 || n_cols <= 0 || ctx->tuning[8] != 0 || ctx->tuning[12] != 0) return MIK_OK;
+    if ((uint64_t)n_rows * es >= 0xFFFFFFF0ull) return MIK_OK;
+    const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
+    struct Slot { int d; uint64_t bits; };
+    auto bits_of = [&](size_t k) { uint64_t b = 0; memcpy(&b, &v[k * es], es); return b; };
+    auto finite = [&](uint64_t b) { return es == 8 ? ((b >> 52) & 0x7ff) != 0x7ff : ((b >> 23) & 0xff) != 0xff; };
+    std::vector<unsigned> mask((size_t)n_rows, 0u);
+    std::vector<int> pat_id((size_t)nb, 0);
+    std::vector<std::vector<Slot>> pats;                    // distinct patterns (sorted slots)
+    std::map<std::vector<uint64_t>, int> pat_of;            // key: ns, then (d, bits) pairs
+    int64_t dmin = 0, dmax = 0;
+    std::vector<Slot> sl;
+    for (int64_t b = 0; b < nb; ++b) {
+        sl.clear();
+        const int64_t r0 = b * MIK_BLOCK, r1 = std::min<int64_t>(r0 + MIK_BLOCK, n_rows);
+        for (int64_t r = r0; r < r1; ++r)
+            for (int k = rowptr[(size_t)r]; k < rowptr[(size_t)r + 1]; ++k) {
+                const int d = col[(size_t)k] - (int)r;
+                const uint64_t bv = bits_of((size_t)k);
+                size_t q = 0;
+                while (q < sl.size() && sl[q].d != d) ++q;
+                if (q == sl.size()) {
+                    if (sl.size() == 32 || !finite(bv)) return MIK_OK;
+                    sl.push_back(Slot{d, bv});
+                } else if (sl[q].bits != bv) return MIK_OK;          // varying coefficients: not this layout
+            }
+        std::sort(sl.begin(), sl.end(), [](const Slot &a, const Slot &c) { return a.d < c.d; });
+        for (int64_t r = r0; r < r1; ++r) {
+            unsigned m = 0;
+            size_t q = 0;
+            for (int k = rowptr[(size_t)r]; k < rowptr[(size_t)r + 1]; ++k) {       // columns ascend within a row, and so do the slots
+                const int d = col[(size_t)k] - (int)r;
+                while (q < sl.size() && sl[q].d != d) ++q;
+                if (q == sl.size() || (m >> q) & 1u) return MIK_OK;               // unsorted or duplicate columns: not this layout
+                m |= 1u << q;
+            }
+            mask[(size_t)r] = m;
+        }
+        std::vector<uint64_t> key;
+        key.push_back(sl.size());
+        for (const Slot &s2 : sl) { key.push_back((uint64_t)(int64_t)s2.d); key.push_back(s2.bits); dmin = std::min<int64_t>(dmin, s2.d); dmax = std::max<int64_t>(dmax, s2.d); }
+        auto itp = pat_of.find(key);
+        if (itp == pat_of.end()) {
+            if (pats.size() >= 65536) return MIK_OK;
+            itp = pat_of.emplace(key, (int)pats.size()).first;
+            pats.push_back(sl);
+        }
+        pat_id[(size_t)b] = itp->second;
+    }
+    const int64_t koff = -dmin;
+    if ((uint64_t)(dmax + koff + 1) * es >= 0x7FFFFFF0ull || (uint64_t)(n_cols + koff) * es >= 0xFFFFFFF0ull) return MIK_OK;
+    const size_t pbytes = 16 + 128 + 32 * es;
+    std::vector<unsigned char> pb(pats.size() * pbytes, 0);
+    for (size_t i = 0; i < pats.size(); ++i) {
+        unsigned char *o = &pb[i * pbytes];
+        const int ns = (int)pats[i].size();
+        memcpy(o, &ns, 4);
+        for (int q = 0; q < ns; ++q) {
+            const int so = (int)((pats[i][(size_t)q].d + koff) * (int64_t)es);
+            memcpy(o + 16 + 4 * q, &so, 4);
+            memcpy(o + 16 + 128 + es * q, &pats[i][(size_t)q].bits, es);
+        }
+    }
+    hipError_t e;
+    if ((e = hipMalloc(&A->sdiaw_pats, pb.size())) != hipSuccess || (e = hipMalloc((void **)&A->sdiaw_pat_id, sizeof(int) * (size_t)nb)) != hipSuccess ||
+        (e = hipMalloc((void **)&A->sdiaw_mask, sizeof(unsigned) * (size_t)n_rows)) != hipSuccess ||
+        (e = hipMemcpy(A->sdiaw_pats, pb.data(), pb.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(A->sdiaw_pat_id, pat_id.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(A->sdiaw_mask, mask.data(), sizeof(unsigned) * (size_t)n_rows, hipMemcpyHostToDevice)) != hipSuccess)
+        return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: wide slice patterns: %s", hipGetErrorString(e));
+    A->sdiaw_npat = (int)pats.size();
+    A->sdiaw_koff = (int)koff;
+    return MIK_OK;
+}
+
 // Jagged slices (csrc/mik_jds.h) from the SHORT part of the CSR arrays (split-off long rows have no entries there; `is_long`
 // marks them).  Built when no structured layout applies, every wave's lanes stay busy in the natural row order (wave
 // iterations within 25 % of the ideal: near-uniform rows) and either the rows are long (more than 32 entries somewhere) or the
@@ -597,7 +679,7 @@ static int csr_build_sell(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
 static int csr_build_jds(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowptr, const std::vector<int> &col, const std::vector<unsigned char> &v,
                          size_t es, int64_t n_rows, const unsigned char *is_long)
 {
-    if (A->sdia_val || A->sdia_pats || A->sell8_codes || n_rows <= 0 || ctx->tuning[8] != 0 || ctx->tuning[28] == 1) return MIK_OK;   // development knob 28: 1 = never, 2 = whenever possible
+    if (A->sdia_val || A->sdia_pats || A->sdiaw_pats || A->sell8_codes || n_rows <= 0 || ctx->tuning[8] != 0 || ctx->tuning[28] == 1) return MIK_OK;   // development knob 28: 1 = never, 2 = whenever possible
     const int W = (int)(16 / es);
     const int64_t short_nnz = rowptr[(size_t)n_rows];
     if (short_nnz <= 0) return MIK_OK;
@@ -805,7 +887,8 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
                 mik_csr_destroy(A);
                 return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create: reading the device CSR back failed");
             }
-            rc = csr_build_sell(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz, A->max_row_nnz);
+            rc = csr_build_sdiaw(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz);
+            if (rc == MIK_OK) rc = csr_build_sell(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz, A->max_row_nnz);
             if (rc == MIK_OK) rc = csr_build_jds(ctx, A, rowptr, col, v, es, n_rows, nullptr);
         }
         if (rc == MIK_OK) { *out = A; return MIK_OK; }
@@ -985,6 +1068,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
     }
     // device layouts for banded / stencil operators (see the two builders above)
     int rc_layout = csr_build_sdia(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz, max_row);
+    if (rc_layout == MIK_OK) rc_layout = csr_build_sdiaw(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz);
     if (rc_layout == MIK_OK) rc_layout = csr_build_sell(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz, max_row);
     if (rc_layout == MIK_OK) rc_layout = csr_build_jds(ctx, A, rowptr, col, v, es, n_rows, is_long.empty() ? nullptr : is_long.data());
     if (rc_layout != MIK_OK) { cleanup(); return rc_layout; }
@@ -1014,6 +1098,9 @@ extern "C" int mik_csr_destroy(mik_csr *A)
     if (A->sell8_codes) (void)hipFree(A->sell8_codes);
     if (A->sell8_tab) (void)hipFree(A->sell8_tab);
     if (A->sell_ptr) (void)hipFree(A->sell_ptr);
+    if (A->sdiaw_pats) (void)hipFree(A->sdiaw_pats);
+    if (A->sdiaw_pat_id) (void)hipFree(A->sdiaw_pat_id);
+    if (A->sdiaw_mask) (void)hipFree(A->sdiaw_mask);
     if (A->jds_ptr) (void)hipFree(A->jds_ptr);
     if (A->jds_len) (void)hipFree(A->jds_len);
     if (A->jds_col) (void)hipFree(A->jds_col);
@@ -1049,6 +1136,7 @@ extern "C" int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes)
     const int64_t nb = (A->n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
     switch (layout) {
     case 5: *bytes = A->n_rows + nb * ((A->sdia_recs && A->ctx->tuning[17] == 0) ? 64 : 4) + (int64_t)A->sdia_npat * (80 + 8 * es); break;
+    case 6: *bytes = A->n_rows * 4 + nb * 4 + (int64_t)A->sdiaw_npat * (144 + 32 * es); break;
     case 4: *bytes = A->sdia_entries * es + A->n_rows + nb * 36; break;
     case 2: *bytes = A->sell_entries * es + A->sell8_bytes + (nb + 1) * 8 + 256 * 4; break;
     case 1: *bytes = A->jds_groups * (16 / es) * (es + 4) + A->n_rows * 2 + ((A->n_rows + 63) / 64 + 1) * 4 +
@@ -1085,6 +1173,7 @@ static int spmv_kernel_choice(const mik_csr *A)
     if (A->ctx->tuning[8] == 0 || !csr) {
         if (A->sdia_pats && (A->ctx->tuning[12] == 0 || !csr)) return 5;
         if (A->sdia_val && (A->ctx->tuning[12] == 0 || !csr)) return 4;
+        if (A->sdiaw_pats && (A->ctx->tuning[12] == 0 || !csr)) return 6;
         if (A->sell8_codes && (A->ctx->tuning[10] == 0 || !csr)) return 2;
         if (A->jds_val && A->ctx->tuning[28] != 1) return 1;
     }
@@ -1097,7 +1186,7 @@ extern "C" int mik_csr_compact(mik_csr *A)
 {
     if (!A) return MIK_ERR_INVALID;
     if (!A->col) return MIK_OK;
-    if (!(A->sdia_pats || A->sdia_val || A->sell8_codes || A->jds_val) || A->n_long)
+    if (!(A->sdia_pats || A->sdia_val || A->sdiaw_pats || A->sell8_codes || A->jds_val) || A->n_long)
         return mik_fail(A->ctx, MIK_ERR_NOTIMPL, "mik_csr_compact: this operator runs on its CSR arrays");
     if (A->ctx) { (void)hipSetDevice(A->ctx->device); (void)hipStreamSynchronize(A->ctx->stream); }
     (void)hipFree(A->rowptr); (void)hipFree(A->col); (void)hipFree(A->val);
@@ -1119,7 +1208,7 @@ static bool sdiab2_applies(const mik_csr *A)
 }
 
 // the operator's SpMV moves little more than x and y (the slice-constant layout): the CG step then picks other cache hints
-bool mik_spmv_is_light(const mik_csr *A) { return A && spmv_kernel_choice(A) == 5; }
+bool mik_spmv_is_light(const mik_csr *A) { return A && (spmv_kernel_choice(A) == 5 || spmv_kernel_choice(A) == 6); }
 
 extern "C" int mik_spmv_kernel(const mik_csr *A, char *name, int len)
 {
@@ -1127,6 +1216,7 @@ extern "C" int mik_spmv_kernel(const mik_csr *A, char *name, int len)
     const char *k = "k_spmv_rowblock";
     switch (spmv_kernel_choice(A)) {
     case 5: k = A->sdia_buf_ok && A->ctx->tuning[17] == 0 ? (sdiab2_applies(A) ? "k_spmv_sdiab2" : "k_spmv_sdiab") : "k_spmv_sdiac"; break;
+    case 6: k = "k_spmv_sdiaw"; break;
     case 4: k = "k_spmv_sdia"; break;
     case 2: k = "k_spmv_sell8"; break;
     case 1: k = "k_spmv_jds"; break;
@@ -1253,6 +1343,17 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         else          { if (nt) MIK_SDIAC_GO(false, true); else MIK_SDIAC_GO(false, false); }
 #undef MIK_SDIAC_GO3
 #undef MIK_SDIAC_GO
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    }
+    if (choice == 6) {
+        // slice patterns of up to 32 {offset, value} pairs + one mask word per row (mik_sell.h)
+#define MIK_SDIAW_GO(FD, NTV)                                                                                                 \
+    hipLaunchKernelGGL((k_spmv_sdiaw<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, A->sdiaw_koff, rb0, nb, map_mode, A->sdiaw_pat_id, \
+                       (const SdiawPattern<T> *)A->sdiaw_pats, A->sdiaw_mask, x, y, seg_out, done)
+        if (fuse_dot) { if (nt) MIK_SDIAW_GO(true, true); else MIK_SDIAW_GO(true, false); }
+        else          { if (nt) MIK_SDIAW_GO(false, true); else MIK_SDIAW_GO(false, false); }
+#undef MIK_SDIAW_GO
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     }

@@ -63,6 +63,11 @@ struct mik_csr {
     int n_seg = 0, n_cut = 0;        // rows longer than MIK_LONG_SEG are cut into n_seg segments (csrc/mik_spmv.h)
     void *seg_sum = nullptr;         // device: one partial per segment
     unsigned char *is_long = nullptr;   // device: n_rows flags (only when n_long > 0)
+    // slice-constant values with up to 32 offsets per slice + one mask word per row (k_spmv_sdiaw, csrc/mik_sell.h)
+    void *sdiaw_pats = nullptr;      // device, sdiaw_npat SdiawPattern<T>
+    int *sdiaw_pat_id = nullptr;     // device, nb
+    unsigned *sdiaw_mask = nullptr;  // device, n_rows
+    int sdiaw_npat = 0, sdiaw_koff = 0;
     // jagged slices (csrc/mik_jds.h): operators with long near-uniform rows (finite elements)
     int *jds_ptr = nullptr;          // device, slices + 1: first group of every 64-row slice
     unsigned short *jds_len = nullptr;   // device, n_rows: entries of every row (MIK_JDS_LONG: a split-off long row)

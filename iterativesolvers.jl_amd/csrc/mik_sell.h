@@ -649,5 +649,60 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab2(int n, int ncols, int
     }
 }
 
+// ---- slice-constant values with up to 32 offsets per slice (layout 6) -----------------------------------------------------------
+// The per-slice-offset forms above stop at 8 offsets per slice (one mask BYTE per row): 3 / 5 / 7-point stencils.  9-point 2-D,
+// 13 / 19 / 27-point 3-D constant-coefficient stencils get the same treatment with one mask WORD per row: a slice is a pattern
+// {ns <= 32 offsets in ascending order = the order in which a row's entries are summed, their scalar byte offsets, their values},
+// equal patterns are stored once, a row keeps a 32-bit presence mask.  x goes through the buffer descriptor of k_spmv_sdiab: the
+// slot's offset is the instruction's SCALAR offset, the row's byte offset the vector offset, and a slot the row does not have
+// ORs all-ones into the vector offset -- out of range, so the hardware returns 0.0 and the row adds value * 0 = +-0, which leaves
+// the sum bit for bit unchanged (the sum starts from +0).  4 B + x + y per row instead of 12 B per entry: a 27-point operator
+// moves 20 B per row instead of 340.  One row per lane, 8 gathers in flight; the kernel is priced by its ns gather instructions
+// per 64 rows (scripts/micro/gather_width.hip).  Built on the host (csr_build_sdiaw) when every value is finite and the offsets fit.
+template <typename T> struct SdiawPattern {
+    int ns, pad_[3];
+    int soff[32];          // (offset + koff) * sizeof(T), ascending; 0 beyond ns
+    T val[32];             // the slice's value for that offset; +0 beyond ns
+};
+
+template <typename T, bool FUSE_DOT, bool NT>
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiaw(int n, int koff, int rb0, int nb, int map_mode, const int *__restrict__ pat_id,
+                                                          const SdiawPattern<T> *__restrict__ pats, const unsigned *__restrict__ mask,
+                                                          const T *__restrict__ x, T *__restrict__ y, T *__restrict__ seg_out,
+                                                          const int *__restrict__ done)
+{
+    if (done && *done) return;
+    constexpr unsigned ES = (unsigned)sizeof(T);
+    __shared__ T lds4[4];
+    const int t = threadIdx.x;
+    const int rb = rb0 + spmv_block_map((int)blockIdx.x, nb, map_mode);
+    const int r = rb * MIK_BLOCK + t;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((uintptr_t)x - (uintptr_t)koff * ES), (short)0,
+                                                                        (int)0xFFFFFFF0u, (int)0x00020000);
+    const unsigned m = r < n ? mask[r] : 0u;                 // (cached: 4 B per row stay in the Infinity Cache from one SpMV to the next)
+    const SdiawPattern<T> *__restrict__ p = pats + pat_id[rb];
+    const int ns = p->ns;
+    const unsigned rowoff = (unsigned)r * ES;
+    T acc = T(0);
+    for (int q0 = 0; q0 < ns; q0 += 8) {
+        T xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = q0 + u;                             // q >= ns: mask bit 0, value +0 -- adds +0
+            const unsigned absent = ((m >> q) & 1u) ? 0u : 0xFFFFFFFFu;
+            xv[u] = buffer_gather<T>(rs, rowoff | absent, p->soff[q]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const T pr = p->val[q0 + u] * xv[u]; acc = acc + pr; }
+    }
+    if (r < n) st_stream<NT>(y + r, acc);
+    if (FUSE_DOT) {
+        T pp = T(0);
+        if (r < n) pp = x[r] * acc;
+        const T tot = block_tree_256(pp, lds4);
+        if (t == 0) seg_out[rb] = tot;
+    }
+}
+
 #endif  // __HIPCC__
 #endif  // MIK_SELL_H

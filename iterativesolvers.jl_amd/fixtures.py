@@ -247,6 +247,17 @@ def fe_matrix(grid, dof: int = 3, dtype=np.float32, renumber: bool = True):
     return n, rowptr, colidx, np.ascontiguousarray(val.astype(dtype))
 
 
+def box_stencil_matrix(N: int, dims: int = 3, dtype=np.float64):
+    """Constant-coefficient (3^dims)-point box stencil on an N^dims grid, lexicographic numbering: 27-point in 3-D, 9-point in
+    2-D -- every neighbour of the 3^dims box -1, the diagonal 3^dims - 1 everywhere (rows at the boundary are strictly
+    dominant: SPD).  The operators the reference's `laplace_matrix` fixture (test/laplace_matrix.jl:1-12) generalises to when a
+    discretisation couples the diagonal neighbours too.  0-based CSR fields ``(n, rowptr, colidx, val)``, symmetric."""
+    n, rowptr, colidx, val = fe_matrix((N,) * dims, 1, np.float64, renumber=False)
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr))
+    val = np.where(colidx == rows, float(3 ** dims - 1), -1.0).astype(dtype)
+    return n, rowptr, colidx, np.ascontiguousarray(val)
+
+
 def hashed_rhs(n: int, start: int = 0, stop=None, dtype=np.float64) -> np.ndarray:
     """b[i] = ((i * 2654435761) mod 2^32) / 2^32 - 0.5 for the 1-based i in (start, stop]
     (exact in any language)."""

@@ -28,6 +28,8 @@ for kind in kinds:
         n, rowptr, colidx, val = pkg.fixtures.fe_matrix((123, 123), 6, np.float32)
     elif kind == "stencil27":   # 27-point variable-coefficient stencil on 128^3, fp64, lexicographic numbering: qualifies for the 8-bit column codes
         n, rowptr, colidx, val = pkg.fixtures.fe_matrix((128, 128, 128), 1, np.float64, renumber=False)
+    elif kind == "box27":       # constant-coefficient 27-point box stencil on 128^3, fp64: the wide slice-constant layout
+        n, rowptr, colidx, val = pkg.fixtures.box_stencil_matrix(128, 3, np.float64)
     elif kind == "fe_hex":      # 3 unknowns per node, 27-node neighbourhoods, larger than the Infinity Cache
         n, rowptr, colidx, val = pkg.fixtures.fe_matrix((64, 64, 64), 3, np.float32)
     else:

@@ -52,11 +52,13 @@ def test_spmv_and_cg_identical_in_every_layout(pkg, orc, ctx, case, dtype):
         def run():
             dA = upload(pkg, A)
             if form == "sliced-ell+slice-offsets+row-masks" and case == "banded_wide":
-                assert dA.layout() == "sliced-ell+8-bit-column-codes"       # > 8 offsets per slice: no per-slice-offset form at all
+                assert dA.layout() == "wide-slice-values+row-masks"         # 19 constant diagonals: > 8 offsets per slice, <= 32
             elif not form.startswith("best"):
                 assert dA.layout() == form.split("/")[0]
             elif case != "banded_wide":       # every slice of these constant-coefficient stencils uses <= 8 offsets, one value per slot
                 assert dA.layout() == "slice-offsets+slice-values+row-masks"
+            else:
+                assert dA.layout() == "wide-slice-values+row-masks"
             y = pkg.mul_(pkg.HipVector(A.n, dtype), dA, pkg.HipVector.from_numpy(x)).to_numpy()
             xs, ch = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True, maxiter=60) if case != "advdiff" else pkg.gmres(
                 dA, pkg.HipVector.from_numpy(b), log=True, maxiter=40, restart=8)
@@ -328,3 +330,39 @@ def test_development_knobs_are_per_context(pkg, orc, ctx):
         assert pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval, index_base=A.index_base, ctx=other).layout() == "slice-offsets+slice-values+row-masks"
     finally:
         other.close() if hasattr(other, "close") else None
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("N,dims", [(13, 3), (40, 2), (21, 3)])
+def test_wide_slice_constant_layout_for_box_stencils(pkg, orc, ctx, dtype, N, dims):
+    """constant-coefficient 9-point (2-D) / 27-point (3-D) stencils exceed the 8 offsets per slice of the mask-byte
+    layouts; they get slice patterns of up to 32 {offset, value} pairs and one 32-bit mask per row, chosen automatically: mul!,
+    the fused dot and the CG history equal the oracle's and the CSR layout's bit for bit.  One perturbed coefficient (or an Inf)
+    and the operator falls back to a general layout with the same bits."""
+    n, rp, ci, vv = pkg.fixtures.box_stencil_matrix(N, dims, dtype)
+    dA = pkg.HipCSR(n, n, rp, ci, vv, index_base=0, is_csc=False)
+    assert dA.layout() == "wide-slice-values+row-masks" and dA.spmv_kernel() == "k_spmv_sdiaw"
+    assert dA.spmv_stored_bytes() < 0.2 * dA.spmv_algorithmic_bytes()
+    A = orc.CSC.from_scipy(sp.csr_matrix((vv, ci, rp), shape=(n, n)).tocsc())
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(n).astype(dtype)
+    x[::17] = np.inf                                                   # an Inf in x must only reach the rows that reference it
+    want = orc.spmv(A, x)
+    got = pkg.mul_(pkg.HipVector(n, dtype), dA, pkg.HipVector.from_numpy(x)).to_numpy()
+    assert np.array_equal(got, want, equal_nan=True)
+    b = orc.hashed_rhs(n).astype(dtype)
+    xs, ch = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True)
+    xo, ho = orc.cg(A, b, mode="tree", shape=ctx.cg_shape(dtype))
+    assert ch.isconverged and np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(xs.to_numpy(), xo)
+    dA.set_layout("csr")
+    xc, cc = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True)
+    assert np.array_equal(cc["resnorm"], ch["resnorm"]) and np.array_equal(xc.to_numpy(), xs.to_numpy())
+    assert dA.set_layout("auto").compact() and dA.layout() == "wide-slice-values+row-masks"
+    for bad in (np.nextafter(vv[5], dtype(10)), np.inf):
+        v2 = vv.copy()
+        v2[5] = bad
+        dB = pkg.HipCSR(n, n, rp, ci, v2, index_base=0, is_csc=False)
+        assert dB.layout() != "wide-slice-values+row-masks"
+        B = orc.CSC.from_scipy(sp.csr_matrix((v2, ci, rp), shape=(n, n)).tocsc())
+        xf = rng.standard_normal(n).astype(dtype)
+        assert np.array_equal(pkg.mul_(pkg.HipVector(n, dtype), dB, pkg.HipVector.from_numpy(xf)).to_numpy(), orc.spmv(B, xf), equal_nan=True)
