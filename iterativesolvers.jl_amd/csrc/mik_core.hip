@@ -647,7 +647,7 @@ static int csr_build_sdiaw(mik_ctx *ctx, mik_csr *A, const std::vector<int> &row
     }
     const int64_t koff = -dmin;
     if ((uint64_t)(dmax + koff + 1) * es >= 0x7FFFFFF0ull || (uint64_t)(n_cols + koff) * es >= 0xFFFFFFF0ull) return MIK_OK;
-    const size_t pbytes = 16 + 128 + 32 * es;
+    const size_t pbytes = 16 + 128 + 96 + 96 + 32 * es;      // SdiawPattern<T>
     std::vector<unsigned char> pb(pats.size() * pbytes, 0);
     for (size_t i = 0; i < pats.size(); ++i) {
         unsigned char *o = &pb[i * pbytes];
@@ -656,8 +656,26 @@ static int csr_build_sdiaw(mik_ctx *ctx, mik_csr *A, const std::vector<int> &row
         for (int q = 0; q < ns; ++q) {
             const int so = (int)((pats[i][(size_t)q].d + koff) * (int64_t)es);
             memcpy(o + 16 + 4 * q, &so, 4);
-            memcpy(o + 16 + 128 + es * q, &pats[i][(size_t)q].bits, es);
+            memcpy(o + 16 + 128 + 96 + 96 + es * q, &pats[i][(size_t)q].bits, es);
         }
+        // items of k_spmv_sdiaw2: runs (o - 1, o, o + 1) with o even; a lone even offset is such a run without its outer slots (slot
+        // 31 = "none", so ns <= 31); the list is padded to a multiple of 3 with items of three absent slots.  An odd lone offset, or
+        // more than 24 items: the slice is summed slot by slot (nitems = 0).
+        int nitems = 0, islots[24], ioff[24];
+        bool okp = ns <= 31;
+        for (int q = 0; q < ns && okp;) {
+            const int d = pats[i][(size_t)q].d;
+            if (nitems == 24) { okp = false; break; }
+            if (q + 2 < ns && pats[i][(size_t)q + 1].d == d + 1 && pats[i][(size_t)q + 2].d == d + 2 && ((d + 1) & 1) == 0) {
+                islots[nitems] = q | (q + 1) << 8 | (q + 2) << 16; ioff[nitems] = d + 1; ++nitems; q += 3;
+            } else if ((d & 1) == 0) {
+                islots[nitems] = 31 | q << 8 | 31 << 16; ioff[nitems] = d; ++nitems; q += 1;
+            } else okp = false;
+        }
+        while (okp && nitems % 3 != 0 && nitems < 24) { islots[nitems] = 31 | 31 << 8 | 31 << 16; ioff[nitems] = 0; ++nitems; }
+        if (!okp || nitems % 3 != 0) nitems = 0;
+        memcpy(o + 4, &nitems, 4);
+        if (nitems) { memcpy(o + 16 + 128, islots, 4 * (size_t)nitems); memcpy(o + 16 + 128 + 96, ioff, 4 * (size_t)nitems); }
     }
     hipError_t e;
     if ((e = hipMalloc(&A->sdiaw_pats, pb.size())) != hipSuccess || (e = hipMalloc((void **)&A->sdiaw_pat_id, sizeof(int) * (size_t)nb)) != hipSuccess ||
@@ -1136,7 +1154,7 @@ extern "C" int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes)
     const int64_t nb = (A->n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
     switch (layout) {
     case 5: *bytes = A->n_rows + nb * ((A->sdia_recs && A->ctx->tuning[17] == 0) ? 64 : 4) + (int64_t)A->sdia_npat * (80 + 8 * es); break;
-    case 6: *bytes = A->n_rows * 4 + nb * 4 + (int64_t)A->sdiaw_npat * (144 + 32 * es); break;
+    case 6: *bytes = A->n_rows * 4 + nb * 4 + (int64_t)A->sdiaw_npat * (336 + 32 * es); break;
     case 4: *bytes = A->sdia_entries * es + A->n_rows + nb * 36; break;
     case 2: *bytes = A->sell_entries * es + A->sell8_bytes + (nb + 1) * 8 + 256 * 4; break;
     case 1: *bytes = A->jds_groups * (16 / es) * (es + 4) + A->n_rows * 2 + ((A->n_rows + 63) / 64 + 1) * 4 +
@@ -1216,7 +1234,7 @@ extern "C" int mik_spmv_kernel(const mik_csr *A, char *name, int len)
     const char *k = "k_spmv_rowblock";
     switch (spmv_kernel_choice(A)) {
     case 5: k = A->sdia_buf_ok && A->ctx->tuning[17] == 0 ? (sdiab2_applies(A) ? "k_spmv_sdiab2" : "k_spmv_sdiab") : "k_spmv_sdiac"; break;
-    case 6: k = "k_spmv_sdiaw"; break;
+    case 6: k = ((A->n_rows & 1) == 0 && A->ctx->tuning[19] == 0) ? "k_spmv_sdiaw2" : "k_spmv_sdiaw"; break;
     case 4: k = "k_spmv_sdia"; break;
     case 2: k = "k_spmv_sell8"; break;
     case 1: k = "k_spmv_jds"; break;
@@ -1343,6 +1361,20 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         else          { if (nt) MIK_SDIAC_GO(false, true); else MIK_SDIAC_GO(false, false); }
 #undef MIK_SDIAC_GO3
 #undef MIK_SDIAC_GO
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    }
+    if (choice == 6 && (n & 1) == 0 && (uint64_t)A->n_cols * sizeof(T) < 0x7FFFFFF0ull && ctx->tuning[19] == 0 && (rb0 & 1) == 0 &&
+        ((nb & 1) == 0 || rb0 + nb == nb_all)) {
+        // ... two rows per lane (k_spmv_sdiaw2): workgroups over PAIRS of slices (development knob 19: 1 = one row per lane)
+        const int np = (nb + 1) / 2, pb0 = rb0 / 2;
+        const int pmode = map_mode >= 16 ? (map_mode / 2 + 7) / 8 * 8 : 0;       // strips of slice PAIRS
+#define MIK_SDIAW2_GO(FD, NTV)                                                                                                \
+    hipLaunchKernelGGL((k_spmv_sdiaw2<T, FD, NTV>), dim3(np), dim3(MIK_BLOCK), 0, ctx->stream, n, (int)A->n_cols, A->sdiaw_koff, pb0, np, pmode, nb_all, \
+                       A->sdiaw_pat_id, (const SdiawPattern<T> *)A->sdiaw_pats, A->sdiaw_mask, x, y, seg_out, done)
+        if (fuse_dot) { if (nt) MIK_SDIAW2_GO(true, true); else MIK_SDIAW2_GO(true, false); }
+        else          { if (nt) MIK_SDIAW2_GO(false, true); else MIK_SDIAW2_GO(false, false); }
+#undef MIK_SDIAW2_GO
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     }

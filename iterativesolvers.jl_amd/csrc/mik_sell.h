@@ -660,8 +660,10 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab2(int n, int ncols, int
 // moves 20 B per row instead of 340.  One row per lane, 8 gathers in flight; the kernel is priced by its ns gather instructions
 // per 64 rows (scripts/micro/gather_width.hip).  Built on the host (csr_build_sdiaw) when every value is finite and the offsets fit.
 template <typename T> struct SdiawPattern {
-    int ns, pad_[3];
+    int ns, nitems, pad_[2];   // nitems > 0 (a multiple of 3): the slots decompose into the items of k_spmv_sdiaw2 (0: that kernel runs the slice slot by slot)
     int soff[32];          // (offset + koff) * sizeof(T), ascending; 0 beyond ns
+    int islots[24];        // item i: its three slots qa | qb << 8 | qc << 16 for the columns o - 1, o, o + 1 (slot 31 = "none": mask bit never set, value +0)
+    int ioff[24];          // item i: its centre offset o (even), in elements
     T val[32];             // the slice's value for that offset; +0 beyond ns
 };
 
@@ -701,6 +703,116 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiaw(int n, int koff, int r
         if (r < n) pp = x[r] * acc;
         const T tot = block_tree_256(pp, lds4);
         if (t == 0) seg_out[rb] = tot;
+    }
+}
+
+// The same layout with TWO consecutive rows per lane (n even), for the reason k_spmv_sdiab2 exists: a 64-lane gather is priced per
+// instruction, so a lane should take what one 16-byte load brings.  A slice's sorted offsets are decomposed at upload into ITEMS:
+// a run (o - 1, o, o + 1) with o even -- the line neighbours of a stencil -- is served by ONE 16-byte gather of x[r + o], x[r + 1 + o]
+// for the lane's rows r, r + 1: row r's three values are {the lane below's second value, a, b}, row r + 1's {a, b, the lane above's
+// first value} (whole-wave DPP moves; lane 0 and the wave's last lane fetch their outer value with one sparse load), and a lone
+// even offset by one 16-byte gather.  A 27-point row pair costs 9 + 9 vector-memory instructions per 128 rows instead of 54.
+// x is read through a descriptor over the columns: a column outside [0, ncols) reads 0.0, and a slot a row does not have is
+// replaced by +0 with a select before the multiply -- value * 0 = +-0 leaves the sum as the absent-slot trick of k_spmv_sdiaw does.
+// A slice whose offsets do not decompose (an odd lone offset: odd grid sizes) is summed slot by slot by the same launch.
+// dot(u, c) partials: the tree of the one-row kernels, as in k_spmv_sdiab2.
+template <typename T, bool FUSE_DOT, bool NT>
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiaw2(int n, int ncols, int koff, int pb0, int np, int pmode, int nslices, const int *__restrict__ pat_id,
+                                                           const SdiawPattern<T> *__restrict__ pats, const unsigned *__restrict__ mask,
+                                                           const T *__restrict__ x, T *__restrict__ y, T *__restrict__ seg_out,
+                                                           const int *__restrict__ done)
+{
+    if (done && *done) return;
+    constexpr unsigned ES = (unsigned)sizeof(T);
+    __shared__ T lds[8];
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const __amdgpu_buffer_rsrc_t xw = __builtin_amdgcn_make_buffer_rsrc((void *)x, (short)0, (int)((unsigned)ncols * ES), (int)0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((uintptr_t)x - (uintptr_t)koff * ES), (short)0, (int)0xFFFFFFF0u, (int)0x00020000);
+    const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc((void *)y, (short)0, (int)((unsigned)n * ES), (int)0x00020000);
+    const int pb = pb0 + spmv_block_map(min((int)blockIdx.x, np - 1), np, pmode);   // slices 2 pb and 2 pb + 1; XCD strips as the other banded kernels
+    const int sl = min(2 * pb + (w >> 1), nslices - 1);
+    const int r0 = pb * (2 * MIK_BLOCK) + w * 128 + 2 * lane;             // rows r0, r0 + 1 (n is even: both in range or neither)
+    unsigned m0 = 0u, m1 = 0u;
+    if (r0 < n) { const uint2 mm = *reinterpret_cast<const uint2 *>(mask + r0); m0 = mm.x; m1 = mm.y; }
+    const SdiawPattern<T> *__restrict__ p = pats + pat_id[sl];
+    const int ns = p->ns, nitems = p->nitems;
+    const unsigned rowoff = (unsigned)r0 * ES;
+    T acc0 = T(0), acc1 = T(0);
+    if (nitems > 0) {
+        // Every item has the same shape -- a lone even offset o is the run (o - 1, o, o + 1) whose outer slots nobody has (slot 31:
+        // the products are value(+0) * +0, and acc + +0 = acc) -- so the body is branch-free; the item list is padded to a
+        // multiple of B with items of three absent slots.
+        const bool top = lane == 63 || r0 + 2 >= n;                       // the lane above is another wave's, or has no rows
+        const bool edge = lane == 0 || top;
+        const bool both = __builtin_amdgcn_ballot_w64(lane == 0 && top) != 0;    // wave-uniform: a wave whose first pair is its last
+        constexpr int B2 = 3;
+        for (int i0 = 0; i0 < nitems; i0 += B2) {
+            Pair2<T> P[B2];
+            T E[B2], F[B2];
+#pragma unroll
+            for (int i = 0; i < B2; ++i) {
+                const unsigned vo = rowoff + (unsigned)(p->ioff[i0 + i] * (int)ES);     // a negative column wraps beyond the descriptor's range: reads 0
+                P[i] = buffer_gather2<T>(xw, vo, 0);
+                // the outer value of the wave's first / last row: every lane issues the load, the others out of range (no branch:
+                // exec-masked loads make the compiler drain the memory queue)
+                E[i] = buffer_gather<T>(xw, edge ? (top ? vo + 2 * ES : vo - ES) : 0xFFFFFFFFu, 0);
+                F[i] = T(0);
+                if (both) F[i] = buffer_gather<T>(xw, lane == 0 ? vo - ES : 0xFFFFFFFFu, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < B2; ++i) {
+                const int sl3 = p->islots[i0 + i];
+                const int qa = sl3 & 31, qb = (sl3 >> 8) & 31, qc = (sl3 >> 16) & 31;
+                T below = lane_next<true>(P[i].b), above = lane_next<false>(P[i].a);
+                if (top) above = E[i];
+                if (lane == 0) below = top ? F[i] : E[i];
+                const T v0 = p->val[qa], v1 = p->val[qb], v2 = p->val[qc];
+                { const T xa = ((m0 >> qa) & 1u) ? below : T(0); const T pr = v0 * xa; acc0 = acc0 + pr; }
+                { const T xa = ((m0 >> qb) & 1u) ? P[i].a : T(0); const T pr = v1 * xa; acc0 = acc0 + pr; }
+                { const T xa = ((m0 >> qc) & 1u) ? P[i].b : T(0); const T pr = v2 * xa; acc0 = acc0 + pr; }
+                { const T xa = ((m1 >> qa) & 1u) ? P[i].a : T(0); const T pr = v0 * xa; acc1 = acc1 + pr; }
+                { const T xa = ((m1 >> qb) & 1u) ? P[i].b : T(0); const T pr = v1 * xa; acc1 = acc1 + pr; }
+                { const T xa = ((m1 >> qc) & 1u) ? above : T(0); const T pr = v2 * xa; acc1 = acc1 + pr; }
+            }
+        }
+    } else {
+        // slot by slot, each row on its own (k_spmv_sdiaw's body twice)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const unsigned ro = rowoff + (unsigned)e * ES, m = e ? m1 : m0;
+            T a = T(0);
+            for (int q0 = 0; q0 < ns; q0 += 8) {
+                T xv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int q = q0 + u;
+                    const unsigned absent = ((m >> q) & 1u) ? 0u : 0xFFFFFFFFu;
+                    xv[u] = buffer_gather<T>(rs, ro | absent, p->soff[q]);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const T pr = p->val[q0 + u] * xv[u]; a = a + pr; }
+            }
+            if (e) acc1 = a; else acc0 = a;
+        }
+    }
+    buffer_put2<T>(ys, rowoff, acc0, acc1, NT);
+    if (FUSE_DOT) {
+        T xr0 = T(0), xr1 = T(0);
+        if (r0 < n) { const Pair2<T> xc = buffer_gather2<T>(xw, rowoff, 0); xr0 = xc.a; xr1 = xc.b; }
+        T s0 = xr0 * acc0, s1 = xr1 * acc1;                                // a pair past the end: 0 * +0
+        s0 = s0 + lane_down<16>(s0); s1 = s1 + lane_down<16>(s1);
+        s0 = s0 + lane_down<8>(s0);  s1 = s1 + lane_down<8>(s1);
+        s0 = s0 + lane_down<4>(s0);  s1 = s1 + lane_down<4>(s1);
+        s0 = s0 + lane_down<2>(s0);  s1 = s1 + lane_down<2>(s1);
+        s0 = s0 + lane_down<1>(s0);  s1 = s1 + lane_down<1>(s1);
+        const T ws = s0 + s1;                                             // lanes 0 and 32: the sums of rows 0..63 and 64..127 of the wave
+        if ((lane & 31) == 0) lds[2 * w + (lane >> 5)] = ws;
+        __syncthreads();
+        if (t < 2 && 2 * pb + t < nslices) {                              // one partial per slice: its 4 sums left to right
+            T tot = lds[4 * t];
+            tot = tot + lds[4 * t + 1]; tot = tot + lds[4 * t + 2]; tot = tot + lds[4 * t + 3];
+            seg_out[2 * pb + t] = tot;
+        }
     }
 }
 

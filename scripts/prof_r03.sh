@@ -20,9 +20,9 @@ for w in $WHAT; do
  case $w in
  bench)
   D=$OUT/bench; mkdir -p $D
-  rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -o run -- python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-gmres --no-config5 > $D/trace.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -o run -- python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-gmres --no-config5 --stencil27 0 > $D/trace.log 2>&1
   grep "^{" $D/trace.log | tail -1 > $D/bench_under_rocprof.json
-  B="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-parity --no-gmres --no-config5"
+  B="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-parity --no-gmres --no-config5 --stencil27 0"
   pmc $D/pmc_fetch FETCH_SIZE -- $B
   pmc $D/pmc_write WRITE_SIZE -- $B
   pmc $D/pmc_l2 TCC_HIT_sum TCC_MISS_sum -- $B

@@ -333,7 +333,7 @@ def test_development_knobs_are_per_context(pkg, orc, ctx):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("N,dims", [(13, 3), (40, 2), (21, 3)])
+@pytest.mark.parametrize("N,dims", [(13, 3), (40, 2), (21, 3), (16, 3), (22, 3), (7, 2)])
 def test_wide_slice_constant_layout_for_box_stencils(pkg, orc, ctx, dtype, N, dims):
     """constant-coefficient 9-point (2-D) / 27-point (3-D) stencils exceed the 8 offsets per slice of the mask-byte
     layouts; they get slice patterns of up to 32 {offset, value} pairs and one 32-bit mask per row, chosen automatically: mul!,
@@ -341,8 +341,10 @@ def test_wide_slice_constant_layout_for_box_stencils(pkg, orc, ctx, dtype, N, di
     and the operator falls back to a general layout with the same bits."""
     n, rp, ci, vv = pkg.fixtures.box_stencil_matrix(N, dims, dtype)
     dA = pkg.HipCSR(n, n, rp, ci, vv, index_base=0, is_csc=False)
-    assert dA.layout() == "wide-slice-values+row-masks" and dA.spmv_kernel() == "k_spmv_sdiaw"
-    assert dA.spmv_stored_bytes() < 0.2 * dA.spmv_algorithmic_bytes()
+    # an even number of rows: two rows per lane (even grid sizes: every run of line neighbours has an even centre -> one 16-byte
+    # gather per run; k_spmv_sdiaw2); odd: one row per lane
+    assert dA.layout() == "wide-slice-values+row-masks" and dA.spmv_kernel() == ("k_spmv_sdiaw2" if n % 2 == 0 else "k_spmv_sdiaw")
+    assert n < 3000 or dA.spmv_stored_bytes() < 0.2 * dA.spmv_algorithmic_bytes()
     A = orc.CSC.from_scipy(sp.csr_matrix((vv, ci, rp), shape=(n, n)).tocsc())
     rng = np.random.default_rng(4)
     x = rng.standard_normal(n).astype(dtype)
@@ -357,6 +359,15 @@ def test_wide_slice_constant_layout_for_box_stencils(pkg, orc, ctx, dtype, N, di
     dA.set_layout("csr")
     xc, cc = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True)
     assert np.array_equal(cc["resnorm"], ch["resnorm"]) and np.array_equal(xc.to_numpy(), xs.to_numpy())
+    dA.set_layout("auto")
+    ctx.set_tuning(19, 1)                                              # one row per lane
+    try:
+        assert dA.spmv_kernel() == "k_spmv_sdiaw"
+        assert np.array_equal(pkg.mul_(pkg.HipVector(n, dtype), dA, pkg.HipVector.from_numpy(x)).to_numpy(), want, equal_nan=True)
+        x1, c1 = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True)
+        assert np.array_equal(c1["resnorm"], ch["resnorm"]) and np.array_equal(x1.to_numpy(), xs.to_numpy())
+    finally:
+        ctx.set_tuning(19, 0)
     assert dA.set_layout("auto").compact() and dA.layout() == "wide-slice-values+row-masks"
     for bad in (np.nextafter(vv[5], dtype(10)), np.inf):
         v2 = vv.copy()
