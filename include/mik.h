@@ -141,8 +141,7 @@ int mik_csr_compact(mik_csr *A);
 /* Device layout mik_spmv uses for this operator (chosen at upload from the sparsity pattern; results are
  * bit-identical across layouts): 0 = CSR row-blocks (LDS tile filled by LDS-DMA; product tile for uneven rows; any matrix),
  * 1 = jagged slices (one row per lane, groups of 16 B / sizeof(T) consecutive entries stored lane-interleaved per 64-row
- * slice: long near-uniform rows -- finite-element matrices), 2 = sliced-ELL values + 8-bit codes for the
- * (column - row) offsets (banded / stencil operators with <= 255 distinct offsets), (3: retired), 4 = sliced-ELL values with per-slice offsets and one presence-mask byte per row (every
+ * slice: long near-uniform rows -- finite-element matrices, variable-coefficient stencils), (2, 3: retired), 4 = sliced-ELL values with per-slice offsets and one presence-mask byte per row (every
  * 256-row slice uses <= 8 distinct offsets: stencils on structured grids), 5 = the same with slice-CONSTANT slot values
  * (within a slice every row that has a slot carries the same value there -- constant-coefficient stencils): the slice
  * stores its <= 8 values once and a row is one mask byte, 6 = the same idea for up to 32 offsets per slice with one 32-bit mask per

@@ -20,12 +20,12 @@ extern "C" {
  *   5: 1 = unfused MGS chain, 2 = launch-lean MGS without graphs, 3 = one hipGraph per GMRES column
  *   7: cache hints of the CG vector kernels
  *   8: 1 = CSR row-block layout only (read at mik_csr_create and at launch)    9: 1 = nothing enqueued ahead of the host (GMRES: the next Arnoldi column; CG: the head of the next step)
- *  10: 1 = no 8-bit column codes        11: 1 = no slice-constant values        12: 1 = no per-slice-offset layout
+ *  11: 1 = no slice-constant values        12: 1 = no per-slice-offset layout
  *  13: bit mask switching the Krylov-basis streaming hints off    14: CSR kernel: 0 = by operator, 1 = register-staged products, 2 = LDS-DMA tile + per-row gather
  *  15: long-row segment length (> 0; read at mik_csr_create)   16: slices per workgroup of the layout-5 kernels (1 / 2 / 4)
  *  17: 1 = layout 5 through flat loads (k_spmv_sdiac)              18: 1 = k_spmv_sdiab without the compiled-in slot class
  *  19: 1 = layout 5 with one row per lane (k_spmv_sdiab instead of k_spmv_sdiab2)
- *  20: 1 = mik_csr_create on the host path only                   21: DGKS rounds inside the single-launch kernel (1..3; read at mik_gmres_create)
+ *  20: 1 = mik_csr_create on the host path only, 2 = device transpose but the host builders of layouts 6 / 1                 21: DGKS rounds inside the single-launch kernel (1..3; read at mik_gmres_create)
  *  22: 1 = PCG with a diagonal Pl as three vector sweeps (c = Pl \\ r and rho apart) instead of two (read at mik_cg_create)
  *  23: 1 = CG updates x in the step's own sweep (read at mik_cg_create)      24: 1 = the halo of a row-partitioned CG step after the whole sweep over u
  *  31: 1 = GMRES without the single-launch Gram-Schmidt kernels (read at mik_gmres_create)

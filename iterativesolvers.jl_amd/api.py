@@ -350,7 +350,7 @@ class HipCSR:
         y = HipVector(self.n_rows, self.dtype, self.ctx)
         return mul_(y, self, x)
 
-    LAYOUTS = ("csr-rowblock", "jagged-slices", "sliced-ell+8-bit-column-codes", "(retired)", "sliced-ell+slice-offsets+row-masks",
+    LAYOUTS = ("csr-rowblock", "jagged-slices", "(retired-2)", "(retired)", "sliced-ell+slice-offsets+row-masks",
                "slice-offsets+slice-values+row-masks", "wide-slice-values+row-masks")
 
     def layout(self) -> str:

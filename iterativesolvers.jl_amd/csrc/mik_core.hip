@@ -505,87 +505,51 @@ static int csr_build_sdia(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
     return MIK_OK;
 }
 
-// Sliced-ELL form (csrc/mik_sell.h): per 256-row block, entry j of all rows contiguous, padded to the block's
-// longest row.  Built when no row was split off as long and padding costs < 1/8 extra entries.
-// (skipped when the per-slice-offset form above exists: mik_spmv would never use it)
-static int csr_build_sell(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowptr, const std::vector<int> &col, const std::vector<unsigned char> &v,
-        size_t es, int64_t n_rows, int64_t n_cols, int64_t nnz, int max_row)
+// Pattern table of the wide slice-constant layout from the distinct slice patterns (sorted {offset, value bits} lists): scalar byte
+// offsets, values and the item decomposition of k_spmv_sdiaw2.  MIK_ERR_NOTIMPL when the byte offsets do not fit.  Shared by the host
+// builder below and the device builder of mik_upload.hip.
+int mik_sdiaw_finish(mik_ctx *ctx, mik_csr *A, const std::vector<std::vector<std::pair<int, uint64_t>>> &pats, size_t es, int64_t n_cols)
 {
-    // Sliced-ELL values + 8-bit column codes (k_spmv_sell8): slices padded to their longest row cost < 1/8 extra entries and
-    // the whole operator has at most 255 distinct (column - row) offsets.
-    (void)n_cols;
-    hipError_t e;
-    if (!A->sdia_val && !A->sdia_pats && !A->sdiaw_pats && A->n_long == 0 && n_rows > 0 && nnz > 0 && max_row <= 255 && ctx->tuning[8] == 0 && ctx->tuning[10] == 0)
-    {
-        const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
-        std::vector<int> sptr((size_t)nb + 1, 0);
-        int64_t padded = 0;
-        for (int64_t b = 0; b < nb; ++b) {
-            int w = 0;
-            for (int64_t r = b * MIK_BLOCK; r < std::min<int64_t>((b + 1) * MIK_BLOCK, n_rows); ++r) w = std::max(w, rowptr[r + 1] - rowptr[r]);
-            padded += (int64_t)w * MIK_BLOCK;
-            if (padded >= INT32_MAX) break;
-            sptr[(size_t)b + 1] = (int)padded;
+    int64_t dmin = 0, dmax = 0;
+    for (const auto &pt : pats) for (const auto &s2 : pt) { dmin = std::min<int64_t>(dmin, s2.first); dmax = std::max<int64_t>(dmax, s2.first); }
+    const int64_t koff = -dmin;
+    if ((uint64_t)(dmax + koff + 1) * es >= 0x7FFFFFF0ull || (uint64_t)(n_cols + koff) * es >= 0xFFFFFFF0ull) return MIK_ERR_NOTIMPL;
+    const size_t pbytes = 16 + 128 + 96 + 96 + 32 * es;      // SdiawPattern<T>
+    std::vector<unsigned char> pb(pats.size() * pbytes, 0);
+    for (size_t i = 0; i < pats.size(); ++i) {
+        unsigned char *o = &pb[i * pbytes];
+        const int ns = (int)pats[i].size();
+        memcpy(o, &ns, 4);
+        for (int q = 0; q < ns; ++q) {
+            const int so = (int)((pats[i][(size_t)q].first + koff) * (int64_t)es);
+            memcpy(o + 16 + 4 * q, &so, 4);
+            memcpy(o + 16 + 128 + 96 + 96 + es * q, &pats[i][(size_t)q].second, es);
         }
-        if (padded < INT32_MAX && padded <= nnz + nnz / 8 + 8 * MIK_BLOCK) {
-            std::vector<int> tab;
-            std::unordered_map<int, int> code_of;
-            bool ok = true;
-            for (int64_t r = 0; r < n_rows && ok; ++r)
-                for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) {
-                    const int d = col[(size_t)k2] - (int)r;
-                    if (code_of.find(d) == code_of.end()) {
-                        if (tab.size() == 255) { ok = false; break; }
-                        code_of.emplace(d, (int)tab.size());
-                        tab.push_back(d);
-                    }
-                }
-            std::vector<int> cptr((size_t)nb + 1, 0);
-            int64_t cbytes = 0;
-            for (int64_t b = 0; b < nb && ok; ++b) {
-                const int w = (sptr[(size_t)b + 1] - sptr[(size_t)b]) / MIK_BLOCK;
-                cbytes += (int64_t)((w + 7) / 8 * 8) * MIK_BLOCK;
-                cptr[(size_t)b + 1] = (int)cbytes;
-            }
-            if (ok && cbytes < INT32_MAX) {
-                std::vector<unsigned char> sval, codes;
-                try {
-                    sval.assign((size_t)padded * es, 0);
-                    codes.assign((size_t)cbytes, 255);
-                } catch (const std::bad_alloc &) {
-                    return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host staging allocation failed (sliced-ELL form)");
-                }
-                for (int64_t r = 0; r < n_rows; ++r) {
-                    const int64_t b = r / MIK_BLOCK, t = r % MIK_BLOCK;
-                    const int len = rowptr[r + 1] - rowptr[r];
-                    for (int j = 0; j < len; ++j) {
-                        const size_t dst = (size_t)sptr[(size_t)b] + (size_t)j * MIK_BLOCK + (size_t)t;
-                        memcpy(&sval[dst * es], &v[((size_t)rowptr[r] + j) * es], es);
-                    }
-                    const int w8 = (cptr[(size_t)b + 1] - cptr[(size_t)b]) / MIK_BLOCK;
-                    unsigned char *dstc = &codes[(size_t)cptr[(size_t)b] + (size_t)t * w8];
-                    for (int k2 = rowptr[r]; k2 < rowptr[r + 1]; ++k2) dstc[k2 - rowptr[r]] = (unsigned char)code_of[col[(size_t)k2] - (int)r];
-                }
-                tab.resize(256, 0);
-                if ((e = hipMalloc((void **)&A->sell_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
-                    (e = hipMalloc(&A->sell_val, es * (size_t)padded)) != hipSuccess ||
-                    (e = hipMalloc((void **)&A->sell8_ptr, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
-                    (e = hipMalloc((void **)&A->sell8_codes, (size_t)cbytes + 8)) != hipSuccess ||
-                    (e = hipMalloc((void **)&A->sell8_tab, sizeof(int) * 256)) != hipSuccess ||
-                    (e = hipMemcpy(A->sell_ptr, sptr.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice)) != hipSuccess ||
-                    (e = hipMemcpy(A->sell_val, sval.data(), es * (size_t)padded, hipMemcpyHostToDevice)) != hipSuccess ||
-                    (e = hipMemcpy(A->sell8_ptr, cptr.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice)) != hipSuccess ||
-                    (e = hipMemcpy(A->sell8_codes, codes.data(), (size_t)cbytes, hipMemcpyHostToDevice)) != hipSuccess ||
-                    (e = hipMemcpy(A->sell8_tab, tab.data(), sizeof(int) * 256, hipMemcpyHostToDevice)) != hipSuccess) {
-                    return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: sliced-ELL form: %s", hipGetErrorString(e));
-                }
-                A->sell_entries = padded;
-                for (int64_t b = 0; b < nb; ++b) A->sell_maxw = std::max(A->sell_maxw, (sptr[(size_t)b + 1] - sptr[(size_t)b]) / MIK_BLOCK);
-                A->sell8_nd = (int)code_of.size();
-                A->sell8_bytes = cbytes;
-            }
+        // items of k_spmv_sdiaw2: runs (o - 1, o, o + 1) with o even; a lone even offset is such a run without its outer slots (slot
+        // 31 = "none", so ns <= 31); the list is padded to a multiple of 3 with items of three absent slots.  An odd lone offset, or
+        // more than 24 items: the slice is summed slot by slot (nitems = 0).
+        int nitems = 0, islots[24], ioff[24];
+        bool okp = ns <= 31;
+        for (int q = 0; q < ns && okp;) {
+            const int d = pats[i][(size_t)q].first;
+            if (nitems == 24) { okp = false; break; }
+            if (q + 2 < ns && pats[i][(size_t)q + 1].first == d + 1 && pats[i][(size_t)q + 2].first == d + 2 && ((d + 1) & 1) == 0) {
+                islots[nitems] = q | (q + 1) << 8 | (q + 2) << 16; ioff[nitems] = d + 1; ++nitems; q += 3;
+            } else if ((d & 1) == 0) {
+                islots[nitems] = 31 | q << 8 | 31 << 16; ioff[nitems] = d; ++nitems; q += 1;
+            } else okp = false;
         }
+        while (okp && nitems % 3 != 0 && nitems < 24) { islots[nitems] = 31 | 31 << 8 | 31 << 16; ioff[nitems] = 0; ++nitems; }
+        if (!okp || nitems % 3 != 0) nitems = 0;
+        memcpy(o + 4, &nitems, 4);
+        if (nitems) { memcpy(o + 16 + 128, islots, 4 * (size_t)nitems); memcpy(o + 16 + 128 + 96, ioff, 4 * (size_t)nitems); }
     }
+    hipError_t e;
+    if ((e = hipMalloc(&A->sdiaw_pats, std::max<size_t>(pb.size(), 8))) != hipSuccess ||
+        (e = hipMemcpy(A->sdiaw_pats, pb.data(), pb.size(), hipMemcpyHostToDevice)) != hipSuccess)
+        return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: wide slice patterns: %s", hipGetErrorString(e));
+    A->sdiaw_npat = (int)pats.size();
+    A->sdiaw_koff = (int)koff;
     return MIK_OK;
 }
 
@@ -645,47 +609,17 @@ static int csr_build_sdiaw(mik_ctx *ctx, mik_csr *A, const std::vector<int> &row
         }
         pat_id[(size_t)b] = itp->second;
     }
-    const int64_t koff = -dmin;
-    if ((uint64_t)(dmax + koff + 1) * es >= 0x7FFFFFF0ull || (uint64_t)(n_cols + koff) * es >= 0xFFFFFFF0ull) return MIK_OK;
-    const size_t pbytes = 16 + 128 + 96 + 96 + 32 * es;      // SdiawPattern<T>
-    std::vector<unsigned char> pb(pats.size() * pbytes, 0);
-    for (size_t i = 0; i < pats.size(); ++i) {
-        unsigned char *o = &pb[i * pbytes];
-        const int ns = (int)pats[i].size();
-        memcpy(o, &ns, 4);
-        for (int q = 0; q < ns; ++q) {
-            const int so = (int)((pats[i][(size_t)q].d + koff) * (int64_t)es);
-            memcpy(o + 16 + 4 * q, &so, 4);
-            memcpy(o + 16 + 128 + 96 + 96 + es * q, &pats[i][(size_t)q].bits, es);
-        }
-        // items of k_spmv_sdiaw2: runs (o - 1, o, o + 1) with o even; a lone even offset is such a run without its outer slots (slot
-        // 31 = "none", so ns <= 31); the list is padded to a multiple of 3 with items of three absent slots.  An odd lone offset, or
-        // more than 24 items: the slice is summed slot by slot (nitems = 0).
-        int nitems = 0, islots[24], ioff[24];
-        bool okp = ns <= 31;
-        for (int q = 0; q < ns && okp;) {
-            const int d = pats[i][(size_t)q].d;
-            if (nitems == 24) { okp = false; break; }
-            if (q + 2 < ns && pats[i][(size_t)q + 1].d == d + 1 && pats[i][(size_t)q + 2].d == d + 2 && ((d + 1) & 1) == 0) {
-                islots[nitems] = q | (q + 1) << 8 | (q + 2) << 16; ioff[nitems] = d + 1; ++nitems; q += 3;
-            } else if ((d & 1) == 0) {
-                islots[nitems] = 31 | q << 8 | 31 << 16; ioff[nitems] = d; ++nitems; q += 1;
-            } else okp = false;
-        }
-        while (okp && nitems % 3 != 0 && nitems < 24) { islots[nitems] = 31 | 31 << 8 | 31 << 16; ioff[nitems] = 0; ++nitems; }
-        if (!okp || nitems % 3 != 0) nitems = 0;
-        memcpy(o + 4, &nitems, 4);
-        if (nitems) { memcpy(o + 16 + 128, islots, 4 * (size_t)nitems); memcpy(o + 16 + 128 + 96, ioff, 4 * (size_t)nitems); }
-    }
+    std::vector<std::vector<std::pair<int, uint64_t>>> plist(pats.size());
+    for (size_t i = 0; i < pats.size(); ++i) for (const Slot &s2 : pats[i]) plist[i].emplace_back(s2.d, s2.bits);
+    const int rcf = mik_sdiaw_finish(ctx, A, plist, es, n_cols);
+    if (rcf == MIK_ERR_NOTIMPL) return MIK_OK;               // offsets do not fit: not this layout
+    if (rcf != MIK_OK) return rcf;
     hipError_t e;
-    if ((e = hipMalloc(&A->sdiaw_pats, pb.size())) != hipSuccess || (e = hipMalloc((void **)&A->sdiaw_pat_id, sizeof(int) * (size_t)nb)) != hipSuccess ||
+    if ((e = hipMalloc((void **)&A->sdiaw_pat_id, sizeof(int) * (size_t)nb)) != hipSuccess ||
         (e = hipMalloc((void **)&A->sdiaw_mask, sizeof(unsigned) * (size_t)n_rows)) != hipSuccess ||
-        (e = hipMemcpy(A->sdiaw_pats, pb.data(), pb.size(), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(A->sdiaw_pat_id, pat_id.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(A->sdiaw_mask, mask.data(), sizeof(unsigned) * (size_t)n_rows, hipMemcpyHostToDevice)) != hipSuccess)
         return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: wide slice patterns: %s", hipGetErrorString(e));
-    A->sdiaw_npat = (int)pats.size();
-    A->sdiaw_koff = (int)koff;
     return MIK_OK;
 }
 
@@ -697,7 +631,7 @@ static int csr_build_sdiaw(mik_ctx *ctx, mik_csr *A, const std::vector<int> &row
 static int csr_build_jds(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowptr, const std::vector<int> &col, const std::vector<unsigned char> &v,
                          size_t es, int64_t n_rows, const unsigned char *is_long)
 {
-    if (A->sdia_val || A->sdia_pats || A->sdiaw_pats || A->sell8_codes || n_rows <= 0 || ctx->tuning[8] != 0 || ctx->tuning[28] == 1) return MIK_OK;   // development knob 28: 1 = never, 2 = whenever possible
+    if (A->sdia_val || A->sdia_pats || A->sdiaw_pats || n_rows <= 0 || ctx->tuning[8] != 0 || ctx->tuning[28] == 1) return MIK_OK;   // development knob 28: 1 = never, 2 = whenever possible
     const int W = (int)(16 / es);
     const int64_t short_nnz = rowptr[(size_t)n_rows];
     if (short_nnz <= 0) return MIK_OK;
@@ -883,14 +817,18 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
     // Default: everything past the raw host-to-device copy happens on the device (mik_upload.hip).  MIK_ERR_NOTIMPL from it
     // = a matrix the host path below handles (long rows, duplicate entries, no room for the raw copy); development knob 20:
     // 1 = host path only.
-    if (ctx->tuning[20] == 0 && nnz > 0 && n_rows > 0 && n_cols > 0 && n_rows < 0x7f000000) {       // (row ids below the "no row yet" pattern of the analysis)
+    if (ctx->tuning[20] != 1 && nnz > 0 && n_rows > 0 && n_cols > 0 && n_rows < 0x7f000000) {       // (row ids below the "no row yet" pattern of the analysis)
         mik_csr *A = new (std::nothrow) mik_csr();
         if (!A) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host allocation failed");
         A->ctx = ctx; A->dtype = dtype; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz;
         (void)hipSetDevice(ctx->device);
         int rc = mik_upload_device(ctx, A, dtype, n_rows, n_cols, nnz, ptr, idx, val, index_base, is_csc);
-        if (rc == MIK_OK && !A->sdia_val && !A->sdia_pats && ctx->tuning[8] == 0) {
-            // no per-slice-offset layout: the other sliced-ELL forms are built by the host builder from a copy of the device CSR
+        // no <= 8-offset layout: the wide slice-constant form, then the jagged slices, both built on the device from A's CSR arrays
+        // (development knob 20 = 2: through the host builders, from a copy of the device CSR)
+        if (rc == MIK_OK && !A->sdia_val && !A->sdia_pats && ctx->tuning[8] == 0 && ctx->tuning[20] != 2) {
+            rc = mik_build_sdiaw_device(ctx, A);
+            if (rc == MIK_OK) rc = mik_build_jds_device(ctx, A);
+        } else if (rc == MIK_OK && !A->sdia_val && !A->sdia_pats && ctx->tuning[8] == 0) {
             try {
                 rowptr.resize((size_t)n_rows + 1);
                 col.resize((size_t)nnz);
@@ -906,7 +844,6 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
                 return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create: reading the device CSR back failed");
             }
             rc = csr_build_sdiaw(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz);
-            if (rc == MIK_OK) rc = csr_build_sell(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz, A->max_row_nnz);
             if (rc == MIK_OK) rc = csr_build_jds(ctx, A, rowptr, col, v, es, n_rows, nullptr);
         }
         if (rc == MIK_OK) { *out = A; return MIK_OK; }
@@ -1087,7 +1024,6 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
     // device layouts for banded / stencil operators (see the two builders above)
     int rc_layout = csr_build_sdia(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz, max_row);
     if (rc_layout == MIK_OK) rc_layout = csr_build_sdiaw(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz);
-    if (rc_layout == MIK_OK) rc_layout = csr_build_sell(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz, max_row);
     if (rc_layout == MIK_OK) rc_layout = csr_build_jds(ctx, A, rowptr, col, v, es, n_rows, is_long.empty() ? nullptr : is_long.data());
     if (rc_layout != MIK_OK) { cleanup(); return rc_layout; }
     *out = A;
@@ -1112,10 +1048,6 @@ extern "C" int mik_csr_destroy(mik_csr *A)
     if (A->sdia_pats) (void)hipFree(A->sdia_pats);
     if (A->sdia_pat_id) (void)hipFree(A->sdia_pat_id);
     if (A->sdia_recs) (void)hipFree(A->sdia_recs);
-    if (A->sell8_ptr) (void)hipFree(A->sell8_ptr);
-    if (A->sell8_codes) (void)hipFree(A->sell8_codes);
-    if (A->sell8_tab) (void)hipFree(A->sell8_tab);
-    if (A->sell_ptr) (void)hipFree(A->sell_ptr);
     if (A->sdiaw_pats) (void)hipFree(A->sdiaw_pats);
     if (A->sdiaw_pat_id) (void)hipFree(A->sdiaw_pat_id);
     if (A->sdiaw_mask) (void)hipFree(A->sdiaw_mask);
@@ -1123,7 +1055,6 @@ extern "C" int mik_csr_destroy(mik_csr *A)
     if (A->jds_len) (void)hipFree(A->jds_len);
     if (A->jds_col) (void)hipFree(A->jds_col);
     if (A->jds_val) (void)hipFree(A->jds_val);
-    if (A->sell_val) (void)hipFree(A->sell_val);
     delete A;
     return MIK_OK;
 }
@@ -1156,7 +1087,6 @@ extern "C" int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes)
     case 5: *bytes = A->n_rows + nb * ((A->sdia_recs && A->ctx->tuning[17] == 0) ? 64 : 4) + (int64_t)A->sdia_npat * (80 + 8 * es); break;
     case 6: *bytes = A->n_rows * 4 + nb * 4 + (int64_t)A->sdiaw_npat * (336 + 32 * es); break;
     case 4: *bytes = A->sdia_entries * es + A->n_rows + nb * 36; break;
-    case 2: *bytes = A->sell_entries * es + A->sell8_bytes + (nb + 1) * 8 + 256 * 4; break;
     case 1: *bytes = A->jds_groups * (16 / es) * (es + 4) + A->n_rows * 2 + ((A->n_rows + 63) / 64 + 1) * 4 +
                      (A->n_long ? (A->nnz - A->jds_short_nnz) * (es + 4) + 12LL * A->n_long + 4LL * A->n_seg + 16LL * A->n_cut : 0); break;
     default: *bytes = A->nnz * (es + 4) + (A->n_rows + 1) * 4 + (A->n_long ? A->n_rows + 12LL * A->n_long + 4LL * A->n_seg + 16LL * A->n_cut : 0); break;
@@ -1192,7 +1122,6 @@ static int spmv_kernel_choice(const mik_csr *A)
         if (A->sdia_pats && (A->ctx->tuning[12] == 0 || !csr)) return 5;
         if (A->sdia_val && (A->ctx->tuning[12] == 0 || !csr)) return 4;
         if (A->sdiaw_pats && (A->ctx->tuning[12] == 0 || !csr)) return 6;
-        if (A->sell8_codes && (A->ctx->tuning[10] == 0 || !csr)) return 2;
         if (A->jds_val && A->ctx->tuning[28] != 1) return 1;
     }
     return 0;
@@ -1204,7 +1133,7 @@ extern "C" int mik_csr_compact(mik_csr *A)
 {
     if (!A) return MIK_ERR_INVALID;
     if (!A->col) return MIK_OK;
-    if (!(A->sdia_pats || A->sdia_val || A->sdiaw_pats || A->sell8_codes || A->jds_val) || A->n_long)
+    if (!(A->sdia_pats || A->sdia_val || A->sdiaw_pats || A->jds_val) || A->n_long)
         return mik_fail(A->ctx, MIK_ERR_NOTIMPL, "mik_csr_compact: this operator runs on its CSR arrays");
     if (A->ctx) { (void)hipSetDevice(A->ctx->device); (void)hipStreamSynchronize(A->ctx->stream); }
     (void)hipFree(A->rowptr); (void)hipFree(A->col); (void)hipFree(A->val);
@@ -1236,7 +1165,6 @@ extern "C" int mik_spmv_kernel(const mik_csr *A, char *name, int len)
     case 5: k = A->sdia_buf_ok && A->ctx->tuning[17] == 0 ? (sdiab2_applies(A) ? "k_spmv_sdiab2" : "k_spmv_sdiab") : "k_spmv_sdiac"; break;
     case 6: k = ((A->n_rows & 1) == 0 && A->ctx->tuning[19] == 0) ? "k_spmv_sdiaw2" : "k_spmv_sdiaw"; break;
     case 4: k = "k_spmv_sdia"; break;
-    case 2: k = "k_spmv_sell8"; break;
     case 1: k = "k_spmv_jds"; break;
     default: k = spmv_csr_rowgather(A) ? "k_spmv_rowgather" : "k_spmv_rowblock"; break;
     }
@@ -1397,17 +1325,6 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         if (fuse_dot) { if (nt) MIK_SDIA_GO(true, true); else MIK_SDIA_GO(true, false); }
         else          { if (nt) MIK_SDIA_GO(false, true); else MIK_SDIA_GO(false, false); }
 #undef MIK_SDIA_GO
-        MIK_LAUNCH_CHECK(ctx);
-        return MIK_OK;
-    }
-    if (choice == 2) {
-        // sliced-ELL values + 8-bit column codes (mik_sell.h)
-#define MIK_SELL8_GO(FD, NTV)                                                                                                 \
-    hipLaunchKernelGGL((k_spmv_sell8<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, rb0, nb, map_mode, A->sell_ptr, A->sell8_ptr, \
-                       A->sell8_codes, A->sell8_tab, A->sell8_nd, (const T *)A->sell_val, x, y, seg_out, done)
-        if (fuse_dot) { if (nt) MIK_SELL8_GO(true, true); else MIK_SELL8_GO(true, false); }
-        else          { if (nt) MIK_SELL8_GO(false, true); else MIK_SELL8_GO(false, false); }
-#undef MIK_SELL8_GO
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     }

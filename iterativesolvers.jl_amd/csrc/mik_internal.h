@@ -75,17 +75,6 @@ struct mik_csr {
     void *jds_val = nullptr;         // device, groups * W values
     int64_t jds_groups = 0;          // groups of W = 16 B / sizeof(T) entries
     int64_t jds_short_nnz = 0;       // entries held by the slices (the rest: split-off long rows)
-    // sliced-ELL values (csrc/mik_sell.h), the value side of the 8-bit column codes below
-    int *sell_ptr = nullptr;         // device, nb + 1: entry offset of every 256-row slice
-    void *sell_val = nullptr;
-    int64_t sell_entries = 0;
-    // 8-bit column codes for the sliced-ELL form (<= 255 distinct column - row offsets)
-    int *sell8_ptr = nullptr;        // device, nb + 1: byte offset of every slice's codes
-    unsigned char *sell8_codes = nullptr;
-    int *sell8_tab = nullptr;        // device, 256 offsets
-    int sell8_nd = 0;
-    int64_t sell8_bytes = 0;
-    int sell_maxw = 0;               // widest slice
     // sliced-ELL with per-slice offsets + per-row masks (k_spmv_sdia): every slice uses <= 8 distinct offsets
     int *sdia_ptr = nullptr;         // device, nb + 1
     int *sdia_off = nullptr;         // device, nb * 8
@@ -126,6 +115,9 @@ int mik_upload_device(mik_ctx *ctx, mik_csr *A, int dtype, int64_t n_rows, int64
                       const void *val, int index_base, int is_csc);
 
 int mik_ensure_partials(mik_ctx *ctx, size_t bytes);
+// device builders of the wide slice-constant layout and of the jagged slices from A's device CSR arrays (mik_upload.hip)
+int mik_build_sdiaw_device(mik_ctx *ctx, mik_csr *A);
+int mik_build_jds_device(mik_ctx *ctx, mik_csr *A);
 
 #define MIK_HIP(ctx, call)                                                                    \
     do {                                                                                      \

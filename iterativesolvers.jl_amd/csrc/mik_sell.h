@@ -1,6 +1,6 @@
 // mik_sell.h -- sliced device layouts of banded / stencil operators (slice = one 256-row block) and their SpMV kernels:
-//               sliced-ELL values + 8-bit column codes (k_spmv_sell8), per-slice offsets + row masks (k_spmv_sdia), and the
-//               slice-constant forms (k_spmv_sdiab, k_spmv_sdiab2).  Long near-uniform rows: mik_jds.h.
+//               per-slice offsets + row masks (k_spmv_sdia) and the slice-constant forms (k_spmv_sdiab, k_spmv_sdiab2; up to 32
+//               offsets per slice: k_spmv_sdiaw, k_spmv_sdiaw2).  Long near-uniform rows: mik_jds.h.
 //
 // mul!(y, A, x) (SparseArrays mul!, called at src/cg.jl:54, src/gmres.jl:287).  mik_csr_create re-lays the CSR out per row-block
 // in COLUMN-MAJOR slices: entry j of the block's 256 rows is contiguous, so thread t (= row r0 + t) streams
@@ -9,7 +9,8 @@
 // the order Julia's CSC column scatter reaches that row, i.e. bit-identical to the row-block CSR kernels (mik_spmv.h), with
 // no LDS staging and no barrier.  Slices are padded to the block's longest row (padding entries are never added); the
 // layouts are only built when padding stays below ~12 % and no row was split off as "long" (mik_csr_create).
-// (Round 1's plain sliced-ELL kernel with 4-byte columns was superseded by the jagged slices of mik_jds.h in round 3.)
+// (Round 1's plain sliced-ELL kernel with 4-byte columns and its 8-bit-column-code variant were superseded in round 3 by the
+// jagged slices of mik_jds.h -- faster on every FE operator measured -- and by the wide slice-constant form below.)
 #ifndef MIK_SELL_H
 #define MIK_SELL_H
 
@@ -17,72 +18,6 @@
 #include "mik_spmv.h"
 
 #ifdef __HIPCC__
-
-// Sliced-ELL with 8-bit column codes.  For banded / stencil operators the difference (column - row) takes few
-// distinct values over the whole matrix; when there are at most 255 of them, every stored entry keeps its full
-// value but its column index becomes a 1-byte code into a table of offsets (code 255 = padding).  Thread t of a
-// slice owns 8-byte groups of codes ([row][j] layout, row length padded to a multiple of 8), so one 8-byte load
-// brings the columns of 8 entries; the value lines are the ones of the plain sliced-ELL form.  Same products, same
-// order, same bits -- 9 instead of 12 bytes per fp64 entry and no row-length array.
-template <typename T, bool FUSE_DOT, bool NT>
-__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sell8(int n, int rb0, int nb, int map_mode, const int *__restrict__ blkptr,
-                                                          const int *__restrict__ cptr, const unsigned char *__restrict__ codes,
-                                                          const int *__restrict__ dtab_g, int nd, const T *__restrict__ val,
-                                                          const T *__restrict__ x, T *__restrict__ y, T *__restrict__ seg_out,
-                                                          const int *__restrict__ done)
-{
-    if (done && *done) return;
-    constexpr int U = 8;
-    __shared__ int dtab[256];
-    __shared__ T lds4[4];
-    const int t = threadIdx.x;
-    dtab[t] = t < nd ? dtab_g[t] : 0;
-    const int rb = rb0 + spmv_block_map((int)blockIdx.x, nb, map_mode);   // this launch covers row-blocks [rb0, rb0 + nb)
-    const int r = rb * MIK_BLOCK + t;
-    const int base = blkptr[rb];
-    const int width = (blkptr[rb + 1] - base) / MIK_BLOCK;
-    const int cb = cptr[rb];
-    const int w8 = (cptr[rb + 1] - cb) / MIK_BLOCK;                // codes per row, a multiple of 8
-    const T *__restrict__ vp = val + base + t;
-    const unsigned long long *__restrict__ myc = reinterpret_cast<const unsigned long long *>(codes + (size_t)cb + (size_t)t * w8);
-
-    // The streams of the first pass are issued BEFORE the barrier that publishes the offset table: they do not
-    // depend on it, and for a stencil (width <= 8) they are the whole row.
-    unsigned long long cw = 0;
-    T v[U];
-    if (width > 0) {
-        cw = ld_stream<NT>(myc);
-#pragma unroll
-        for (int q = 0; q < U; ++q) v[q] = ld_stream<NT>(vp + (size_t)min(q, width - 1) * MIK_BLOCK);
-    }
-    __syncthreads();
-
-    T acc = T(0);
-    for (int j0 = 0; j0 < width;) {
-        T xv[U];
-#pragma unroll
-        for (int q = 0; q < U; ++q) {
-            const int code = (int)((cw >> (8 * q)) & 255ull);
-            xv[q] = x[code != 255 ? r + dtab[code] : 0];             // padding gathers from a valid address, never added
-        }
-#pragma unroll
-        for (int q = 0; q < U; ++q)
-            if (((cw >> (8 * q)) & 255ull) != 255ull) { T p = v[q] * xv[q]; acc = acc + p; }
-        j0 += U;
-        if (j0 < width) {
-            cw = ld_stream<NT>(myc + (j0 >> 3));
-#pragma unroll
-            for (int q = 0; q < U; ++q) v[q] = ld_stream<NT>(vp + (size_t)min(j0 + q, width - 1) * MIK_BLOCK);
-        }
-    }
-    if (r < n) st_stream<NT>(y + r, acc);
-    if (FUSE_DOT) {
-        T p = T(0);
-        if (r < n) p = x[r] * acc;
-        T tot = block_tree_256(p, lds4);
-        if (t == 0) seg_out[rb] = tot;
-    }
-}
 
 // Sliced-ELL with PER-SLICE offsets and per-row presence masks ("sliced diagonal" form).  When the rows of a
 // 256-row slice together use at most 8 distinct (column - row) offsets -- any stencil on a structured grid -- the

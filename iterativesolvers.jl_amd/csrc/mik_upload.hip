@@ -14,9 +14,11 @@
 // that need the other sliced-ELL layouts.
 #include "mik_internal.h"
 #include "mik_sell.h"
+#include "mik_jds.h"
 
 #include <algorithm>
 #include <cstring>
+#include <map>
 #include <vector>
 
 namespace {
@@ -491,4 +493,285 @@ int mik_upload_device(mik_ctx *ctx, mik_csr *A, int dtype, int64_t n_rows, int64
 {
     if (dtype == MIK_F64) return upload_device_t<double>(ctx, A, n_rows, n_cols, nnz, ptr, idx, val, index_base, is_csc);
     return upload_device_t<float>(ctx, A, n_rows, n_cols, nnz, ptr, idx, val, index_base, is_csc);
+}
+
+// =============================================================================================
+// device builders of the layouts for operators WITHOUT a <= 8-offset structure (round 3): the wide slice-constant form
+// (k_spmv_sdiaw, <= 32 offsets per slice) and the jagged slices (k_spmv_jds), from the device CSR arrays -- no host pass over
+// the entries (the host builders of mik_core.hip took 4.2 s for a 27-point 256^3 operator and 0.4 s for a 62 M-entry FE one)
+// =============================================================================================
+namespace {
+
+struct SdiawDesc { int ns, pad_; int d[32]; unsigned long long bits[32]; };     // one per slice: sorted offsets and their value bits
+struct WideStats { int fail; int pad_; };
+
+template <typename T> __device__ __forceinline__ unsigned long long value_bits(T v);
+template <> __device__ __forceinline__ unsigned long long value_bits<double>(double v) { return __builtin_bit_cast(unsigned long long, v); }
+template <> __device__ __forceinline__ unsigned long long value_bits<float>(float v) { return (unsigned long long)__builtin_bit_cast(unsigned, v); }
+template <typename T> __device__ __forceinline__ bool value_finite(T v) { return v - v == T(0); }
+
+// one thread per slice: the set of (column - row) offsets of its rows with the ONE value each carries (sorted by offset)
+template <typename T>
+__global__ void k_up_wide_desc(const int *__restrict__ rowptr, const int *__restrict__ col, const T *__restrict__ val, long long n_rows, long long nb,
+                               SdiawDesc *__restrict__ desc, WideStats *st)
+{
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb || st->fail) return;
+    int d[32];
+    unsigned long long bits[32];
+    int ns = 0;
+    const long long r0 = b * MIK_BLOCK, r1 = r0 + MIK_BLOCK < n_rows ? r0 + MIK_BLOCK : n_rows;
+    for (long long r = r0; r < r1; ++r)
+        for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+            const int dd = col[k] - (int)r;
+            const T v = val[k];
+            int q = 0;
+            while (q < ns && d[q] != dd) ++q;
+            if (q == ns) {
+                if (ns == 32 || !value_finite(v)) { st->fail = 1; return; }
+                d[ns] = dd; bits[ns] = value_bits<T>(v); ++ns;
+            } else if (bits[q] != value_bits<T>(v)) { st->fail = 1; return; }
+        }
+    for (int i = 1; i < ns; ++i) {                       // insertion sort by offset
+        const int dk = d[i];
+        const unsigned long long bk = bits[i];
+        int j = i - 1;
+        while (j >= 0 && d[j] > dk) { d[j + 1] = d[j]; bits[j + 1] = bits[j]; --j; }
+        d[j + 1] = dk; bits[j + 1] = bk;
+    }
+    SdiawDesc o;
+    o.ns = ns; o.pad_ = 0;
+    for (int q = 0; q < 32; ++q) { o.d[q] = q < ns ? d[q] : 0; o.bits[q] = q < ns ? bits[q] : 0ull; }
+    desc[b] = o;
+}
+
+// one thread per row: the presence mask over its slice's sorted offsets (columns ascend within a row, and so do the slots)
+__global__ void k_up_wide_masks(const int *__restrict__ rowptr, const int *__restrict__ col, long long n_rows, const SdiawDesc *__restrict__ desc,
+                                unsigned *__restrict__ mask, WideStats *st)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const SdiawDesc *ds = desc + r / MIK_BLOCK;
+    const int ns = ds->ns;
+    unsigned m = 0;
+    int q = 0;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        const int dd = col[k] - (int)r;
+        while (q < ns && ds->d[q] != dd) ++q;
+        if (q == ns || ((m >> q) & 1u)) { st->fail = 1; return; }     // unsorted or duplicate columns: not this layout
+        m |= 1u << q;
+    }
+    mask[r] = m;
+}
+
+// 128-bit hash of a slice description (two independent 64-bit mixes): equal descriptions hash alike; the assignment of pattern
+// numbers by hash is VERIFIED word for word by k_up_wide_verify
+__device__ __forceinline__ unsigned long long mix64(unsigned long long h, unsigned long long x, unsigned long long k)
+{
+    h ^= x * k; h = (h << 27) | (h >> 37); h *= 0x9E3779B97F4A7C15ull; return h ^ (h >> 31);
+}
+__global__ void k_up_wide_hash(const SdiawDesc *__restrict__ desc, long long nb, unsigned long long *__restrict__ hash)
+{
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const SdiawDesc *ds = desc + b;
+    unsigned long long h1 = 0x243F6A8885A308D3ull ^ (unsigned long long)ds->ns, h2 = 0x13198A2E03707344ull + (unsigned long long)ds->ns;
+    for (int q = 0; q < ds->ns; ++q) {
+        h1 = mix64(h1, (unsigned long long)(unsigned)ds->d[q], 0xBF58476D1CE4E5B9ull); h1 = mix64(h1, ds->bits[q], 0x94D049BB133111EBull);
+        h2 = mix64(h2, ds->bits[q], 0xD6E8FEB86659FD93ull); h2 = mix64(h2, (unsigned long long)(unsigned)ds->d[q], 0xA0761D6478BD642Full);
+    }
+    hash[2 * b] = h1; hash[2 * b + 1] = h2;
+}
+__global__ void k_up_wide_verify(const SdiawDesc *__restrict__ desc, long long nb, const int *__restrict__ pat_id, const int *__restrict__ rep, WideStats *st)
+{
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const SdiawDesc *a = desc + b, *c = desc + rep[pat_id[b]];
+    bool same = a->ns == c->ns;
+    for (int q = 0; q < 32 && same; ++q) same = a->d[q] == c->d[q] && a->bits[q] == c->bits[q];
+    if (!same) st->fail = 1;
+}
+
+// ---- jagged slices ----------------------------------------------------------------------------------------------------------------
+struct JdsStats { unsigned long long iters; int maxlen, pad_; };
+
+// one wave per 64-row slice: groups of the slice, its longest row (in groups), the row lengths
+template <int W>
+__global__ __launch_bounds__(MIK_BLOCK) void k_up_jds_count(const int *__restrict__ rowptr, long long n_rows, long long nsl, int *__restrict__ sgroups,
+                                                            unsigned short *__restrict__ jlen, JdsStats *st)
+{
+    const long long s = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (s >= nsl) return;
+    const long long r = s * 64 + lane;
+    const int len = r < n_rows ? rowptr[r + 1] - rowptr[r] : 0;
+    if (r < n_rows) jlen[r] = (unsigned short)(len < 0xFFFF ? len : 0xFFFE);
+    int g = (len + W - 1) / W, mg = g, ml = len;
+    for (int off = 32; off >= 1; off >>= 1) { g += __shfl_down(g, off); mg = max(mg, __shfl_down(mg, off)); ml = max(ml, __shfl_down(ml, off)); }
+    if (lane == 0) {
+        sgroups[s] = g;
+        atomicAdd(&st->iters, (unsigned long long)mg);
+        atomicMax(&st->maxlen, ml);
+    }
+}
+
+// one wave per slice: its rows' groups, pass by pass, lane order (the layout k_spmv_jds walks); padding = the row's last column, value 0
+template <typename T>
+__global__ __launch_bounds__(MIK_BLOCK) void k_up_jds_fill(const int *__restrict__ rowptr, const int *__restrict__ col, const T *__restrict__ val,
+                                                           long long n_rows, long long nsl, const int *__restrict__ jptr, int *__restrict__ jcol,
+                                                           T *__restrict__ jval)
+{
+    constexpr int W = (int)(16 / sizeof(T));
+    const long long s = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (s >= nsl) return;
+    const long long r = s * 64 + lane;
+    const int k0 = r < n_rows ? rowptr[r] : 0, len = r < n_rows ? rowptr[r + 1] - k0 : 0;
+    const int ng = (len + W - 1) / W;
+    long long base = jptr[s];
+    for (int g = 0;; ++g) {
+        const unsigned long long m = __ballot(g < ng);
+        if (m == 0ull) break;
+        if (g < ng) {
+            const long long idx = base + (long long)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                const int j = g * W + e;
+                jcol[idx * W + e] = col[k0 + (j < len ? j : len - 1)];
+                jval[idx * W + e] = j < len ? val[k0 + j] : T(0);
+            }
+        }
+        base += __popcll(m);
+    }
+}
+
+}  // namespace
+
+int mik_sdiaw_finish(mik_ctx *ctx, mik_csr *A, const std::vector<std::vector<std::pair<int, uint64_t>>> &pats, size_t es, int64_t n_cols);
+
+// Wide slice-constant layout from the device CSR arrays of A.  MIK_OK with A->sdiaw_pats set when the operator qualifies, MIK_OK
+// without when it does not; errors otherwise.
+template <typename T> static int build_sdiaw_device_t(mik_ctx *ctx, mik_csr *A)
+{
+    const int64_t n_rows = A->n_rows, nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
+    if ((uint64_t)n_rows * sizeof(T) >= 0xFFFFFFF0ull) return MIK_OK;
+    hipStream_t st = ctx->stream;
+    Scratch S;
+    hipError_t e;
+    SdiawDesc *desc = nullptr;
+    WideStats *d_st = nullptr, hs;
+    unsigned long long *hash = nullptr;
+    int *d_rep = nullptr;
+    unsigned *mask = nullptr;
+    int *pat_id = nullptr;
+#define WD_TRY(call) do { if ((e = (call)) != hipSuccess) return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: wide slice patterns: %s", hipGetErrorString(e)); } while (0)
+    WD_TRY(S.alloc(&desc, sizeof(SdiawDesc) * (size_t)nb));
+    WD_TRY(S.alloc(&d_st, sizeof(WideStats)));
+    WD_TRY(hipMemsetAsync(d_st, 0, sizeof(WideStats), st));
+    hipLaunchKernelGGL((k_up_wide_desc<T>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, st, A->rowptr, A->col, (const T *)A->val, (long long)n_rows, (long long)nb, desc, d_st);
+    WD_TRY(hipMemcpyAsync(&hs, d_st, sizeof(hs), hipMemcpyDeviceToHost, st));
+    WD_TRY(hipStreamSynchronize(st));
+    if (hs.fail) return MIK_OK;
+    WD_TRY(S.alloc(&mask, sizeof(unsigned) * (size_t)n_rows));
+    WD_TRY(S.alloc(&hash, sizeof(unsigned long long) * 2 * (size_t)nb));
+    hipLaunchKernelGGL(k_up_wide_masks, dim3(blocks_for(n_rows)), dim3(MIK_BLOCK), 0, st, A->rowptr, A->col, (long long)n_rows, desc, mask, d_st);
+    hipLaunchKernelGGL(k_up_wide_hash, dim3(blocks_for(nb)), dim3(MIK_BLOCK), 0, st, desc, (long long)nb, hash);
+    std::vector<unsigned long long> hh(2 * (size_t)nb);
+    WD_TRY(hipMemcpyAsync(hh.data(), hash, sizeof(unsigned long long) * hh.size(), hipMemcpyDeviceToHost, st));
+    WD_TRY(hipMemcpyAsync(&hs, d_st, sizeof(hs), hipMemcpyDeviceToHost, st));
+    WD_TRY(hipStreamSynchronize(st));
+    if (hs.fail) return MIK_OK;
+    // pattern numbers by hash (first slice with a hash represents it), verified word for word on the device below
+    std::map<std::pair<unsigned long long, unsigned long long>, int> idof;
+    std::vector<int> pid((size_t)nb), rep;
+    for (int64_t b = 0; b < nb; ++b) {
+        const auto key = std::make_pair(hh[2 * (size_t)b], hh[2 * (size_t)b + 1]);
+        auto it = idof.find(key);
+        if (it == idof.end()) {
+            if (rep.size() >= 65536) return MIK_OK;
+            it = idof.emplace(key, (int)rep.size()).first;
+            rep.push_back((int)b);
+        }
+        pid[(size_t)b] = it->second;
+    }
+    WD_TRY(S.alloc(&pat_id, sizeof(int) * (size_t)nb));
+    WD_TRY(S.alloc(&d_rep, sizeof(int) * rep.size()));
+    WD_TRY(hipMemcpyAsync(pat_id, pid.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice, st));
+    WD_TRY(hipMemcpyAsync(d_rep, rep.data(), sizeof(int) * rep.size(), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_up_wide_verify, dim3(blocks_for(nb)), dim3(MIK_BLOCK), 0, st, desc, (long long)nb, pat_id, d_rep, d_st);
+    std::vector<SdiawDesc> rd(rep.size());
+    for (size_t i = 0; i < rep.size(); ++i) WD_TRY(hipMemcpyAsync(&rd[i], desc + rep[i], sizeof(SdiawDesc), hipMemcpyDeviceToHost, st));
+    WD_TRY(hipMemcpyAsync(&hs, d_st, sizeof(hs), hipMemcpyDeviceToHost, st));
+    WD_TRY(hipStreamSynchronize(st));
+    if (hs.fail) return MIK_OK;                           // a hash collision (never seen): the host builders decide
+    std::vector<std::vector<std::pair<int, uint64_t>>> plist(rep.size());
+    for (size_t i = 0; i < rep.size(); ++i)
+        for (int q = 0; q < rd[i].ns; ++q) plist[i].emplace_back(rd[i].d[q], (uint64_t)rd[i].bits[q]);
+    const int rcf = mik_sdiaw_finish(ctx, A, plist, sizeof(T), A->n_cols);
+    if (rcf == MIK_ERR_NOTIMPL) return MIK_OK;
+    if (rcf != MIK_OK) return rcf;
+    A->sdiaw_mask = mask; S.keep(mask);
+    A->sdiaw_pat_id = pat_id; S.keep(pat_id);
+#undef WD_TRY
+    return MIK_OK;
+}
+
+int mik_build_sdiaw_device(mik_ctx *ctx, mik_csr *A)
+{
+    if (!A->rowptr || A->n_long || A->sdia_val || A->sdia_pats || A->nnz <= 0 || ctx->tuning[8] != 0 || ctx->tuning[12] != 0) return MIK_OK;
+    return A->dtype == MIK_F64 ? build_sdiaw_device_t<double>(ctx, A) : build_sdiaw_device_t<float>(ctx, A);
+}
+
+// Jagged slices from the device CSR arrays of A (no split-off long rows on this path); same criterion as the host builder.
+template <typename T> static int build_jds_device_t(mik_ctx *ctx, mik_csr *A)
+{
+    constexpr int W = (int)(16 / sizeof(T));
+    const int64_t n_rows = A->n_rows, nsl = (n_rows + 63) / 64;
+    hipStream_t st = ctx->stream;
+    Scratch S;
+    hipError_t e;
+    int *jptr = nullptr, *scan_tmp = nullptr, *jcol = nullptr;
+    unsigned short *jlen = nullptr;
+    T *jval = nullptr;
+    JdsStats *d_st = nullptr, hs;
+    int total = 0;
+#define JD_TRY(call) do { if ((e = (call)) != hipSuccess) return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: jagged slices: %s", hipGetErrorString(e)); } while (0)
+    JD_TRY(S.alloc(&jptr, sizeof(int) * ((size_t)nsl + 8)));
+    JD_TRY(S.alloc(&jlen, sizeof(unsigned short) * (size_t)n_rows));
+    JD_TRY(S.alloc(&d_st, sizeof(JdsStats)));
+    JD_TRY(S.alloc(&scan_tmp, sizeof(int) * ((size_t)(nsl / SCAN_TILE + 1) * 2 + 64)));
+    JD_TRY(hipMemsetAsync(d_st, 0, sizeof(JdsStats), st));
+    hipLaunchKernelGGL((k_up_jds_count<W>), dim3((unsigned)((nsl + 3) / 4)), dim3(MIK_BLOCK), 0, st, A->rowptr, (long long)n_rows, (long long)nsl, jptr, jlen, d_st);
+    JD_TRY(device_exclusive_scan(st, jptr, nsl, scan_tmp));
+    JD_TRY(hipMemcpyAsync(&total, jptr + nsl, sizeof(int), hipMemcpyDeviceToHost, st));
+    JD_TRY(hipMemcpyAsync(&hs, d_st, sizeof(hs), hipMemcpyDeviceToHost, st));
+    JD_TRY(hipStreamSynchronize(st));
+    const int64_t groups = total, short_nnz = A->nnz;
+    if (groups <= 0 || hs.maxlen >= MIK_JDS_LONG || groups * W >= INT32_MAX) return MIK_OK;
+    const int64_t jds_bytes = groups * W * (int64_t)(sizeof(T) + 4) + 2 * n_rows, csr_bytes = short_nnz * (int64_t)(sizeof(T) + 4) + 4 * n_rows;
+    if (ctx->tuning[28] != 2 && !((int64_t)hs.iters * 64 * 4 <= groups * 5 && (hs.maxlen > 32 || jds_bytes * 10 <= csr_bytes * 11))) return MIK_OK;
+    const size_t pad = 64 * 4 * (size_t)W;                  // = 64 * MIK_JDS_U * W: lanes without a group read (and gather through) the tail
+    JD_TRY(S.alloc(&jcol, sizeof(int) * ((size_t)groups * W + pad)));
+    JD_TRY(S.alloc(&jval, sizeof(T) * ((size_t)groups * W + pad)));
+    JD_TRY(hipMemsetAsync(jcol + (size_t)groups * W, 0, sizeof(int) * pad, st));
+    JD_TRY(hipMemsetAsync(jval + (size_t)groups * W, 0, sizeof(T) * pad, st));
+    for (int q = 1; q < 8; ++q) JD_TRY(hipMemcpyAsync(jptr + nsl + q, jptr + nsl, sizeof(int), hipMemcpyDeviceToDevice, st));    // waves of the last workgroup beyond the last slice
+    hipLaunchKernelGGL((k_up_jds_fill<T>), dim3((unsigned)((nsl + 3) / 4)), dim3(MIK_BLOCK), 0, st, A->rowptr, A->col, (const T *)A->val, (long long)n_rows,
+                       (long long)nsl, jptr, jcol, jval);
+    JD_TRY(hipStreamSynchronize(st));
+    A->jds_ptr = jptr; S.keep(jptr);
+    A->jds_len = jlen; S.keep(jlen);
+    A->jds_col = jcol; S.keep(jcol);
+    A->jds_val = jval; S.keep(jval);
+    A->jds_groups = groups;
+    A->jds_short_nnz = short_nnz;
+#undef JD_TRY
+    return MIK_OK;
+}
+
+int mik_build_jds_device(mik_ctx *ctx, mik_csr *A)
+{
+    if (!A->rowptr || A->n_long || A->sdia_val || A->sdia_pats || A->sdiaw_pats || A->nnz <= 0 || ctx->tuning[8] != 0 || ctx->tuning[28] == 1)
+        return MIK_OK;
+    return A->dtype == MIK_F64 ? build_jds_device_t<double>(ctx, A) : build_jds_device_t<float>(ctx, A);
 }

@@ -1,4 +1,4 @@
-"""The operator's device layouts (mik_csr_layout): CSR row-blocks, sliced-ELL, sliced-ELL + 8-bit column codes.
+"""The operator's device layouts (mik_csr_layout): CSR row-blocks, jagged slices, per-slice-offset forms, slice-constant forms.
 The layout is picked at upload from the sparsity pattern; mul! and every solver must return the same bits in all."""
 import numpy as np
 import pytest
@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 # knob 14 selects the CSR kernel: 0 = tile filled by LDS-DMA + per-row gather (k_spmv_rowgather, default), 1 = products
 # staged through registers (k_spmv_rowblock)
 FORMS = {"csr-rowblock": {8: 1}, "csr-rowblock/products": {8: 1, 14: 1},
-         "jagged-slices": {10: 1, 12: 1, 28: 2}, "sliced-ell+8-bit-column-codes": {12: 1}, "sliced-ell+slice-offsets+row-masks": {11: 1}, "best": {},
+         "jagged-slices": {12: 1, 28: 2}, "sliced-ell+slice-offsets+row-masks": {11: 1}, "best": {},
          # the kernels of the slice-constant layout: flat loads, buffer loads slot by slot, 1 / 4 slices per workgroup
          "best/flat-loads": {17: 1}, "best/slot-by-slot": {18: 1}, "best/1-slice": {16: 1}, "best/4-slices": {16: 4}, "best/flat-4": {17: 1, 16: 4}}
 

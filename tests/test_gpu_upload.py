@@ -32,7 +32,7 @@ def same_operator(pkg, orc, dev, host, A, x):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("case", ["laplace3d", "laplace2d", "advdiff", "varying", "banded_wide", "random", "empty_rows"])
+@pytest.mark.parametrize("case", ["laplace3d", "laplace2d", "advdiff", "varying", "banded_wide", "random", "empty_rows", "fe", "box27"])
 def test_device_upload_equals_host_upload(pkg, orc, ctx, case, dtype):
     rng = np.random.default_rng(3)
     if case == "laplace3d":
@@ -45,7 +45,13 @@ def test_device_upload_equals_host_upload(pkg, orc, ctx, case, dtype):
         n = 2000
         S = sp.diags([rng.standard_normal(n - abs(o)) for o in (-45, -1, 0, 1, 45)], (-45, -1, 0, 1, 45), format="csc")
         A = orc.CSC.from_scipy(S)
-    elif case == "banded_wide":                              # > 8 offsets per slice: 8-bit column codes (host builder on the device CSR)
+    elif case == "fe":                                       # finite-element rows: jagged slices, built on the device / by the host builder
+        nf, rp, ci, vv = pkg.fixtures.fe_matrix((17, 19), 6, np.float64)
+        A = orc.CSC.from_scipy(sp.csr_matrix((vv, ci, rp), shape=(nf, nf)).tocsc())
+    elif case == "box27":                                    # constant-coefficient 27-point stencil: wide slice-constant form, both builders
+        nf, rp, ci, vv = pkg.fixtures.box_stencil_matrix(14, 3, np.float64)
+        A = orc.CSC.from_scipy(sp.csr_matrix((vv, ci, rp), shape=(nf, nf)).tocsc())
+    elif case == "banded_wide":                              # 19 constant diagonals (> 8 offsets per slice): wide slice-constant form
         n = 3000
         offs = [0] + [o for d in (1, 2, 3, 7, 50, 51, 200, 333, 900) for o in (d, -d)]
         S = sp.diags([np.full(n - abs(o), 40.0 if o == 0 else -1.0 / (1 + abs(o) % 5)) for o in offs], offs, format="csc")
