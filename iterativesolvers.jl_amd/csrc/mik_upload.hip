@@ -700,7 +700,14 @@ template <typename T> static int build_sdiaw_device_t(mik_ctx *ctx, mik_csr *A)
     WD_TRY(hipMemcpyAsync(d_rep, rep.data(), sizeof(int) * rep.size(), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_up_wide_verify, dim3(blocks_for(nb)), dim3(MIK_BLOCK), 0, st, desc, (long long)nb, pat_id, d_rep, d_st);
     std::vector<SdiawDesc> rd(rep.size());
-    for (size_t i = 0; i < rep.size(); ++i) WD_TRY(hipMemcpyAsync(&rd[i], desc + rep[i], sizeof(SdiawDesc), hipMemcpyDeviceToHost, st));
+    if (rep.size() <= 256) {
+        for (size_t i = 0; i < rep.size(); ++i) WD_TRY(hipMemcpyAsync(&rd[i], desc + rep[i], sizeof(SdiawDesc), hipMemcpyDeviceToHost, st));
+    } else {                                              // many distinct patterns (values that change from slice to slice): one copy of everything
+        std::vector<SdiawDesc> all((size_t)nb);
+        WD_TRY(hipMemcpyAsync(all.data(), desc, sizeof(SdiawDesc) * (size_t)nb, hipMemcpyDeviceToHost, st));
+        WD_TRY(hipStreamSynchronize(st));
+        for (size_t i = 0; i < rep.size(); ++i) rd[i] = all[(size_t)rep[i]];
+    }
     WD_TRY(hipMemcpyAsync(&hs, d_st, sizeof(hs), hipMemcpyDeviceToHost, st));
     WD_TRY(hipStreamSynchronize(st));
     if (hs.fail) return MIK_OK;                           // a hash collision (never seen): the host builders decide
