@@ -514,7 +514,8 @@ int mik_sdiaw_finish(mik_ctx *ctx, mik_csr *A, const std::vector<std::vector<std
     for (const auto &pt : pats) for (const auto &s2 : pt) { dmin = std::min<int64_t>(dmin, s2.first); dmax = std::max<int64_t>(dmax, s2.first); }
     const int64_t koff = -dmin;
     if ((uint64_t)(dmax + koff + 1) * es >= 0x7FFFFFF0ull || (uint64_t)(n_cols + koff) * es >= 0xFFFFFFF0ull) return MIK_ERR_NOTIMPL;
-    const size_t pbytes = 16 + 128 + 96 + 96 + 32 * es;      // SdiawPattern<T>
+    const size_t ibytes = 16 + 3 * es, soff0 = 32, voff = soff0 + 128, ioff0 = voff + 32 * es;   // SdiawItem<T>; SdiawPattern<T>: val, items
+    const size_t pbytes = ioff0 + 24 * ibytes;
     std::vector<unsigned char> pb(pats.size() * pbytes, 0);
     for (size_t i = 0; i < pats.size(); ++i) {
         unsigned char *o = &pb[i * pbytes];
@@ -522,27 +523,46 @@ int mik_sdiaw_finish(mik_ctx *ctx, mik_csr *A, const std::vector<std::vector<std
         memcpy(o, &ns, 4);
         for (int q = 0; q < ns; ++q) {
             const int so = (int)((pats[i][(size_t)q].first + koff) * (int64_t)es);
-            memcpy(o + 16 + 4 * q, &so, 4);
-            memcpy(o + 16 + 128 + 96 + 96 + es * q, &pats[i][(size_t)q].second, es);
+            memcpy(o + soff0 + 4 * q, &so, 4);
+            memcpy(o + voff + es * q, &pats[i][(size_t)q].second, es);
         }
-        // items of k_spmv_sdiaw2: runs (o - 1, o, o + 1) with o even; a lone even offset is such a run without its outer slots (slot
-        // 31 = "none", so ns <= 31); the list is padded to a multiple of 3 with items of three absent slots.  An odd lone offset, or
-        // more than 24 items: the slice is summed slot by slot (nitems = 0).
-        int nitems = 0, islots[24], ioff[24];
-        bool okp = ns <= 31;
+        // items of k_spmv_sdiaw2: runs (o - 1, o, o + 1) with o even; a lone even offset is such a run without its outer slots; the
+        // list is padded to a multiple of 3 with items without slots.  An odd lone offset, or more than 24 items: the slice is
+        // summed slot by slot (nitems = 0).
+        struct Item { int off; unsigned b[3]; uint64_t v[3]; };
+        std::vector<Item> items;
+        bool okp = true;
         for (int q = 0; q < ns && okp;) {
             const int d = pats[i][(size_t)q].first;
-            if (nitems == 24) { okp = false; break; }
+            if (items.size() == 24) { okp = false; break; }
             if (q + 2 < ns && pats[i][(size_t)q + 1].first == d + 1 && pats[i][(size_t)q + 2].first == d + 2 && ((d + 1) & 1) == 0) {
-                islots[nitems] = q | (q + 1) << 8 | (q + 2) << 16; ioff[nitems] = d + 1; ++nitems; q += 3;
+                items.push_back(Item{d + 1, {1u << q, 1u << (q + 1), 1u << (q + 2)},
+                                     {pats[i][(size_t)q].second, pats[i][(size_t)q + 1].second, pats[i][(size_t)q + 2].second}});
+                q += 3;
             } else if ((d & 1) == 0) {
-                islots[nitems] = 31 | q << 8 | 31 << 16; ioff[nitems] = d; ++nitems; q += 1;
+                items.push_back(Item{d, {0u, 1u << q, 0u}, {0, pats[i][(size_t)q].second, 0}});
+                q += 1;
             } else okp = false;
         }
-        while (okp && nitems % 3 != 0 && nitems < 24) { islots[nitems] = 31 | 31 << 8 | 31 << 16; ioff[nitems] = 0; ++nitems; }
-        if (!okp || nitems % 3 != 0) nitems = 0;
+        while (okp && items.size() % 3 != 0 && items.size() < 24) items.push_back(Item{0, {0u, 0u, 0u}, {0, 0, 0}});
+        int nitems = (!okp || items.size() % 3 != 0) ? 0 : (int)items.size();
         memcpy(o + 4, &nitems, 4);
-        if (nitems) { memcpy(o + 16 + 128, islots, 4 * (size_t)nitems); memcpy(o + 16 + 128 + 96, ioff, 4 * (size_t)nitems); }
+        unsigned exa = 0, exc = 0, fullbits = 0;
+        bool all_full = nitems > 0;
+        for (int k = 0; k < nitems; ++k) {
+            unsigned char *it = o + ioff0 + (size_t)k * ibytes;
+            const int offb = items[(size_t)k].off * (int)es;
+            memcpy(it, &offb, 4);
+            all_full = all_full && items[(size_t)k].b[0] && items[(size_t)k].b[1] && items[(size_t)k].b[2];
+            fullbits |= items[(size_t)k].b[0] | items[(size_t)k].b[1] | items[(size_t)k].b[2];
+            memcpy(it + 4, items[(size_t)k].b, 12);
+            for (int c = 0; c < 3; ++c) memcpy(it + 16 + es * (size_t)c, &items[(size_t)k].v[c], es);
+            exa |= items[(size_t)k].b[0]; exc |= items[(size_t)k].b[2];
+        }
+        if (!all_full) fullbits = 0x80000000u;
+        memcpy(o + 8, &exa, 4);
+        memcpy(o + 12, &exc, 4);
+        memcpy(o + 16, &fullbits, 4);
     }
     hipError_t e;
     if ((e = hipMalloc(&A->sdiaw_pats, std::max<size_t>(pb.size(), 8))) != hipSuccess ||
@@ -550,6 +570,22 @@ int mik_sdiaw_finish(mik_ctx *ctx, mik_csr *A, const std::vector<std::vector<std
         return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: wide slice patterns: %s", hipGetErrorString(e));
     A->sdiaw_npat = (int)pats.size();
     A->sdiaw_koff = (int)koff;
+    A->sdiaw_pat_bytes = (int)pbytes;
+    return MIK_OK;
+}
+
+// {all, any} slot sets per 128-row chunk of the wide layout's row masks (k_sdiaw_chunk_bits): what lets k_spmv_sdiaw2 skip the
+// per-lane slot test wherever a wave's rows agree.
+static int sdiaw_chunk_bits(mik_ctx *ctx, mik_csr *A)
+{
+    if (!A->sdiaw_pats || A->sdiaw_uz) return MIK_OK;
+    const int64_t nsl = (A->n_rows + MIK_BLOCK - 1) / MIK_BLOCK, nch = (nsl + 1) / 2 * 4;
+    hipError_t e = hipMalloc(&A->sdiaw_uz, 16 * (size_t)nch);
+    if (e != hipSuccess) return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: chunk bits: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_sdiaw_chunk_bits, dim3((unsigned)((nch + 3) / 4)), dim3(MIK_BLOCK), 0, ctx->stream, (int)A->n_rows, (int)nch, (int)nsl,
+                       A->sdiaw_mask, A->sdiaw_pat_id, (const unsigned char *)A->sdiaw_pats, A->sdiaw_pat_bytes, (uint4 *)A->sdiaw_uz);
+    e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create: chunk bits: %s", hipGetErrorString(e));
     return MIK_OK;
 }
 
@@ -846,6 +882,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
             rc = csr_build_sdiaw(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz);
             if (rc == MIK_OK) rc = csr_build_jds(ctx, A, rowptr, col, v, es, n_rows, nullptr);
         }
+        if (rc == MIK_OK) rc = sdiaw_chunk_bits(ctx, A);
         if (rc == MIK_OK) { *out = A; return MIK_OK; }
         mik_csr_destroy(A);
         if (rc != MIK_ERR_NOTIMPL) return rc;
@@ -1025,6 +1062,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
     int rc_layout = csr_build_sdia(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz, max_row);
     if (rc_layout == MIK_OK) rc_layout = csr_build_sdiaw(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz);
     if (rc_layout == MIK_OK) rc_layout = csr_build_jds(ctx, A, rowptr, col, v, es, n_rows, is_long.empty() ? nullptr : is_long.data());
+    if (rc_layout == MIK_OK) rc_layout = sdiaw_chunk_bits(ctx, A);
     if (rc_layout != MIK_OK) { cleanup(); return rc_layout; }
     *out = A;
     return MIK_OK;
@@ -1051,6 +1089,7 @@ extern "C" int mik_csr_destroy(mik_csr *A)
     if (A->sdiaw_pats) (void)hipFree(A->sdiaw_pats);
     if (A->sdiaw_pat_id) (void)hipFree(A->sdiaw_pat_id);
     if (A->sdiaw_mask) (void)hipFree(A->sdiaw_mask);
+    if (A->sdiaw_uz) (void)hipFree(A->sdiaw_uz);
     if (A->jds_ptr) (void)hipFree(A->jds_ptr);
     if (A->jds_len) (void)hipFree(A->jds_len);
     if (A->jds_col) (void)hipFree(A->jds_col);
@@ -1085,7 +1124,7 @@ extern "C" int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes)
     const int64_t nb = (A->n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
     switch (layout) {
     case 5: *bytes = A->n_rows + nb * ((A->sdia_recs && A->ctx->tuning[17] == 0) ? 64 : 4) + (int64_t)A->sdia_npat * (80 + 8 * es); break;
-    case 6: *bytes = A->n_rows * 4 + nb * 4 + (int64_t)A->sdiaw_npat * (336 + 32 * es); break;
+    case 6: *bytes = A->n_rows * 4 + nb * 4 + (nb + 1) / 2 * 64 + (int64_t)A->sdiaw_npat * A->sdiaw_pat_bytes; break;
     case 4: *bytes = A->sdia_entries * es + A->n_rows + nb * 36; break;
     case 1: *bytes = A->jds_groups * (16 / es) * (es + 4) + A->n_rows * 2 + ((A->n_rows + 63) / 64 + 1) * 4 +
                      (A->n_long ? (A->nnz - A->jds_short_nnz) * (es + 4) + 12LL * A->n_long + 4LL * A->n_seg + 16LL * A->n_cut : 0); break;
@@ -1299,7 +1338,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         const int pmode = map_mode >= 16 ? (map_mode / 2 + 7) / 8 * 8 : 0;       // strips of slice PAIRS
 #define MIK_SDIAW2_GO(FD, NTV)                                                                                                \
     hipLaunchKernelGGL((k_spmv_sdiaw2<T, FD, NTV>), dim3(np), dim3(MIK_BLOCK), 0, ctx->stream, n, (int)A->n_cols, A->sdiaw_koff, pb0, np, pmode, nb_all, \
-                       A->sdiaw_pat_id, (const SdiawPattern<T> *)A->sdiaw_pats, A->sdiaw_mask, x, y, seg_out, done)
+                       A->sdiaw_pat_id, (const SdiawPattern<T> *)A->sdiaw_pats, A->sdiaw_mask, (const uint4 *)A->sdiaw_uz, x, y, seg_out, done)
         if (fuse_dot) { if (nt) MIK_SDIAW2_GO(true, true); else MIK_SDIAW2_GO(true, false); }
         else          { if (nt) MIK_SDIAW2_GO(false, true); else MIK_SDIAW2_GO(false, false); }
 #undef MIK_SDIAW2_GO

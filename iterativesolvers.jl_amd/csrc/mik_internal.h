@@ -67,7 +67,8 @@ struct mik_csr {
     void *sdiaw_pats = nullptr;      // device, sdiaw_npat SdiawPattern<T>
     int *sdiaw_pat_id = nullptr;     // device, nb
     unsigned *sdiaw_mask = nullptr;  // device, n_rows
-    int sdiaw_npat = 0, sdiaw_koff = 0;
+    void *sdiaw_uz = nullptr;        // device, one uint4 {all even, any even, all odd, any odd} per 128-row chunk (k_sdiaw_chunk_bits)
+    int sdiaw_npat = 0, sdiaw_koff = 0, sdiaw_pat_bytes = 0;
     // jagged slices (csrc/mik_jds.h): operators with long near-uniform rows (finite elements)
     int *jds_ptr = nullptr;          // device, slices + 1: first group of every 64-row slice
     unsigned short *jds_len = nullptr;   // device, n_rows: entries of every row (MIK_JDS_LONG: a split-off long row)

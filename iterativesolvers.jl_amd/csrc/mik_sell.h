@@ -594,13 +594,26 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab2(int n, int ncols, int
 // the sum bit for bit unchanged (the sum starts from +0).  4 B + x + y per row instead of 12 B per entry: a 27-point operator
 // moves 20 B per row instead of 340.  One row per lane, 8 gathers in flight; the kernel is priced by its ns gather instructions
 // per 64 rows (scripts/micro/gather_width.hip).  Built on the host (csr_build_sdiaw) when every value is finite and the offsets fit.
-template <typename T> struct SdiawPattern {
-    int ns, nitems, pad_[2];   // nitems > 0 (a multiple of 3): the slots decompose into the items of k_spmv_sdiaw2 (0: that kernel runs the slice slot by slot)
-    int soff[32];          // (offset + koff) * sizeof(T), ascending; 0 beyond ns
-    int islots[24];        // item i: its three slots qa | qb << 8 | qc << 16 for the columns o - 1, o, o + 1 (slot 31 = "none": mask bit never set, value +0)
-    int ioff[24];          // item i: its centre offset o (even), in elements
-    T val[32];             // the slice's value for that offset; +0 beyond ns
+// item of k_spmv_sdiaw2: the run (o - 1, o, o + 1), o even, as slot BITS (0: the slice has no such slot) and values -- everything
+// a wave needs for the item in one scalar load, no decoding
+template <typename T> struct SdiawItem {
+    int off;               // o * sizeof(T)
+    unsigned ba, bb, bc;   // 1 << slot of o - 1 / o / o + 1, or 0
+    T va, vb, vc;          // their values (+0 where the bit is 0)
 };
+template <typename T> struct SdiawPattern {
+    int ns, nitems;        // nitems > 0 (a multiple of 3): the slots decompose into items (0: k_spmv_sdiaw2 runs the slice slot by slot)
+    unsigned exa, exc;     // union of the items' ba / bc: the slots whose value reaches a wave's first / last row from outside the wave
+    unsigned fullbits;     // all slots, if every item is a full run (o - 1, o, o + 1) -- else bit 31, which no row mask has
+    int pad_[3];
+    int soff[32];          // (offset + koff) * sizeof(T), ascending; 0 beyond ns
+    T val[32];             // the slice's value for that offset; +0 beyond ns
+    SdiawItem<T> items[24];
+};
+
+// mik_sdiaw_finish (mik_core.hip) writes the table byte by byte
+static_assert(sizeof(SdiawItem<double>) == 40 && sizeof(SdiawItem<float>) == 28, "SdiawItem layout");
+static_assert(sizeof(SdiawPattern<double>) == 160 + 256 + 24 * 40 && sizeof(SdiawPattern<float>) == 160 + 128 + 24 * 28, "SdiawPattern layout");
 
 template <typename T, bool FUSE_DOT, bool NT>
 __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiaw(int n, int koff, int rb0, int nb, int map_mode, const int *__restrict__ pat_id,
@@ -641,21 +654,108 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiaw(int n, int koff, int r
     }
 }
 
+// Per 128-row chunk (= the rows of one wave of k_spmv_sdiaw2) of the row masks: {U0, Z0, U1, Z1} = the slots ALL / ANY of its even
+// rows have, and the same for its odd rows (rows >= n count as rows without slots).  The first row of the chunk is left out of U0
+// for the slots that reach it from outside the wave (pattern.exa), the last row out of U1 for pattern.exc: those values come
+// from the kernel's sparse edge load, which reads 0 when the row lacks the slot -- so the rows on the x faces of a grid do not
+// make their whole wave take the per-lane path.  Built once at upload.
+static __global__ __launch_bounds__(MIK_BLOCK) void k_sdiaw_chunk_bits(int n, int nchunks, int nslices, const unsigned *__restrict__ mask,
+                                                                       const int *__restrict__ pat_id, const unsigned char *__restrict__ pats,
+                                                                       int pat_bytes, uint4 *__restrict__ uz)
+{
+    const int c = (int)blockIdx.x * (MIK_BLOCK / 64) + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+    if (c >= nchunks) return;
+    const unsigned *ph = reinterpret_cast<const unsigned *>(pats + (size_t)pat_id[min(c / 2, nslices - 1)] * (size_t)pat_bytes);
+    const unsigned exa = ph[2], exc = ph[3];
+    const int64_t r0 = (int64_t)c * 128 + 2 * lane;
+    const unsigned m0 = r0 < n ? mask[r0] : 0u, m1 = r0 + 1 < n ? mask[r0 + 1] : 0u;
+    unsigned a0 = lane == 0 && r0 < n ? (m0 | exa) : m0, a1 = lane == 63 && r0 + 1 < n ? (m1 | exc) : m1, o0 = m0, o1 = m1;
+    for (int d = 32; d >= 1; d >>= 1) {
+        a0 &= (unsigned)__shfl_xor((int)a0, d); o0 |= (unsigned)__shfl_xor((int)o0, d);
+        a1 &= (unsigned)__shfl_xor((int)a1, d); o1 |= (unsigned)__shfl_xor((int)o1, d);
+    }
+    if (lane == 0) uz[c] = make_uint4(a0, o0, a1, o1);
+}
+
+// One product of k_spmv_sdiaw2.  U / Z: the slots all / any of the wave's rows of this parity have (wave-uniform, from
+// k_sdiaw_chunk_bits): a slot every row has costs a multiply and an add, a slot no row has nothing, and only a slot SOME rows
+// have -- the rows on a face of the grid -- takes the per-lane test (absent: value * +0 = +-0, and acc + +-0 = acc since acc
+// starts at +0 and never becomes -0).  The kernel is bound by vector-ALU issue, not by memory: the per-lane test and select
+// tripled the instructions of a product.
+template <typename T> __device__ __forceinline__ void sdiaw_term(T &acc, unsigned U, unsigned Z, unsigned m, unsigned bit, T val, T xv)
+{
+    if (U & bit) {
+        const T pr = val * xv;
+        acc = acc + pr;
+    } else if (Z & bit) {
+        const T pr = val * ((m & bit) ? xv : T(0));
+        acc = acc + pr;
+    }
+}
+// the neighbouring lane's value, the lane without a neighbour (0 / 63) keeps `old`
+template <bool BELOW> __device__ __forceinline__ unsigned lane_next_old_u32(unsigned v, unsigned old)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, BELOW ? 0x138 : 0x130, 0xf, 0xf, false);
+}
+template <bool BELOW> __device__ __forceinline__ double lane_next_old(double v, double old)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v), o = __builtin_bit_cast(unsigned long long, old);
+    const unsigned lo = lane_next_old_u32<BELOW>((unsigned)b, (unsigned)o), hi = lane_next_old_u32<BELOW>((unsigned)(b >> 32), (unsigned)(o >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <bool BELOW> __device__ __forceinline__ float lane_next_old(float v, float old)
+{
+    return __builtin_bit_cast(float, lane_next_old_u32<BELOW>(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, old)));
+}
+
+// Items of a wave whose rows all have every slot of a pattern made of full runs: B items' loads in flight, then 6 multiplies and
+// 6 adds per item (a multiple of B items).  B = 9 -- a 27-point stencil's rows in ONE round trip -- costs registers (6 instead
+// of 8 waves per SIMD) and still wins: the kernel waits for x, and what is in flight per CU is what counts.
+template <typename T, int B>
+__device__ __forceinline__ void sdiaw_full_runs(const SdiawPattern<T> *__restrict__ p, int nitems, __amdgpu_buffer_rsrc_t xw, unsigned rowoff,
+                                                unsigned voe, unsigned pe, T &acc0, T &acc1)
+{
+    constexpr unsigned ES = (unsigned)sizeof(T);
+    for (int i0 = 0; i0 < nitems; i0 += B) {
+        Pair2<T> P[B];
+        T E[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            const int4 hd = *reinterpret_cast<const int4 *>(&p->items[i0 + i]);       // {off, ba, bb, bc}: one scalar load
+            P[i] = buffer_gather2<T>(xw, rowoff + (unsigned)hd.x, 0);                 // a negative column wraps beyond the descriptor's range: reads 0
+            E[i] = buffer_gather<T>(xw, (pe & (unsigned)(hd.y | hd.w)) ? voe + (unsigned)hd.x : 0xFFFFFFFFu, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            const T va = p->items[i0 + i].va, vb = p->items[i0 + i].vb, vc = p->items[i0 + i].vc;
+            const T below = lane_next_old<true>(P[i].b, E[i]), above = lane_next_old<false>(P[i].a, E[i]);
+            { const T pr = va * below; acc0 = acc0 + pr; }
+            { const T pr = vb * P[i].a; acc0 = acc0 + pr; }
+            { const T pr = vc * P[i].b; acc0 = acc0 + pr; }
+            { const T pr = va * P[i].a; acc1 = acc1 + pr; }
+            { const T pr = vb * P[i].b; acc1 = acc1 + pr; }
+            { const T pr = vc * above; acc1 = acc1 + pr; }
+        }
+    }
+    (void)ES;
+}
+
 // The same layout with TWO consecutive rows per lane (n even), for the reason k_spmv_sdiab2 exists: a 64-lane gather is priced per
 // instruction, so a lane should take what one 16-byte load brings.  A slice's sorted offsets are decomposed at upload into ITEMS:
 // a run (o - 1, o, o + 1) with o even -- the line neighbours of a stencil -- is served by ONE 16-byte gather of x[r + o], x[r + 1 + o]
 // for the lane's rows r, r + 1: row r's three values are {the lane below's second value, a, b}, row r + 1's {a, b, the lane above's
-// first value} (whole-wave DPP moves; lane 0 and the wave's last lane fetch their outer value with one sparse load), and a lone
-// even offset by one 16-byte gather.  A 27-point row pair costs 9 + 9 vector-memory instructions per 128 rows instead of 54.
-// x is read through a descriptor over the columns: a column outside [0, ncols) reads 0.0, and a slot a row does not have is
-// replaced by +0 with a select before the multiply -- value * 0 = +-0 leaves the sum as the absent-slot trick of k_spmv_sdiaw does.
+// first value} (whole-wave DPP moves; lane 0 and lane 63 fetch their outer value with one sparse load and the DPP move leaves it
+// in place), and a lone even offset by one 16-byte gather.  A 27-point row pair costs 9 + 9 vector-memory instructions per 128
+// rows instead of 54.
+// x is read through a descriptor over the columns: a column outside [0, ncols) reads 0.0 (so the pair of lanes past the last row
+// delivers the right outer value to the last row), and a slot a row does not have is replaced by +0 before the multiply (sdiaw_term).
 // A slice whose offsets do not decompose (an odd lone offset: odd grid sizes) is summed slot by slot by the same launch.
 // dot(u, c) partials: the tree of the one-row kernels, as in k_spmv_sdiab2.
 template <typename T, bool FUSE_DOT, bool NT>
 __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiaw2(int n, int ncols, int koff, int pb0, int np, int pmode, int nslices, const int *__restrict__ pat_id,
                                                            const SdiawPattern<T> *__restrict__ pats, const unsigned *__restrict__ mask,
-                                                           const T *__restrict__ x, T *__restrict__ y, T *__restrict__ seg_out,
-                                                           const int *__restrict__ done)
+                                                           const uint4 *__restrict__ chunk_bits, const T *__restrict__ x, T *__restrict__ y,
+                                                           T *__restrict__ seg_out, const int *__restrict__ done)
 {
     if (done && *done) return;
     constexpr unsigned ES = (unsigned)sizeof(T);
@@ -672,42 +772,48 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiaw2(int n, int ncols, int
     const SdiawPattern<T> *__restrict__ p = pats + pat_id[sl];
     const int ns = p->ns, nitems = p->nitems;
     const unsigned rowoff = (unsigned)r0 * ES;
+    Pair2<T> xc{T(0), T(0)};
+    if (FUSE_DOT) xc = buffer_gather2<T>(xw, r0 < n ? rowoff : 0xFFFFFFFFu, 0);      // x[r0], x[r0 + 1] for the dot, in flight with the rest
     T acc0 = T(0), acc1 = T(0);
     if (nitems > 0) {
-        // Every item has the same shape -- a lone even offset o is the run (o - 1, o, o + 1) whose outer slots nobody has (slot 31:
-        // the products are value(+0) * +0, and acc + +0 = acc) -- so the body is branch-free; the item list is padded to a
-        // multiple of B with items of three absent slots.
-        const bool top = lane == 63 || r0 + 2 >= n;                       // the lane above is another wave's, or has no rows
-        const bool edge = lane == 0 || top;
-        const bool both = __builtin_amdgcn_ballot_w64(lane == 0 && top) != 0;    // wave-uniform: a wave whose first pair is its last
+        // Every item has the same shape -- a lone even offset o is the run (o - 1, o, o + 1) whose outer slots nobody has (slot 31)
+        // -- and the item list is padded to a multiple of B2 with items of three absent slots.
+        const uint4 uz = chunk_bits[pb * 4 + w];
+        const unsigned U0 = uz.x, Z0 = uz.y, U1 = uz.z, Z1 = uz.w;
+        // the sparse load of the outer values: lane 0 fetches column r0 - 1 + o if its first row has the slot, lane 63 column
+        // r0 + 2 + o if its second row has it -- everybody else, and a row without the slot, an out-of-range offset (reads 0; no
+        // branch: exec-masked loads make the compiler drain the memory queue).  exa and exc are disjoint, so one test serves both.
+        const unsigned pe = lane == 0 ? (m0 & p->exa) : (lane == 63 ? (m1 & p->exc) : 0u);
+        const unsigned voe = rowoff + (lane ? 2 * ES : 0u - ES);
         constexpr int B2 = 3;
-        for (int i0 = 0; i0 < nitems; i0 += B2) {
-            Pair2<T> P[B2];
-            T E[B2], F[B2];
+        const unsigned full = p->fullbits;
+        if ((U0 & U1 & full) == full) {
+            // every row of the wave has every slot and all items are full runs: 6 multiplies and 6 adds per item and row pair,
+            // nothing to test (the kernel is bound by instruction issue, vector and scalar, not by memory)
+            if (nitems % 9 == 0) sdiaw_full_runs<T, 9>(p, nitems, xw, rowoff, voe, pe, acc0, acc1);
+            else sdiaw_full_runs<T, 3>(p, nitems, xw, rowoff, voe, pe, acc0, acc1);
+        } else {
+            for (int i0 = 0; i0 < nitems; i0 += B2) {
+                Pair2<T> P[B2];
+                T E[B2];
+                SdiawItem<T> its[B2];
 #pragma unroll
-            for (int i = 0; i < B2; ++i) {
-                const unsigned vo = rowoff + (unsigned)(p->ioff[i0 + i] * (int)ES);     // a negative column wraps beyond the descriptor's range: reads 0
-                P[i] = buffer_gather2<T>(xw, vo, 0);
-                // the outer value of the wave's first / last row: every lane issues the load, the others out of range (no branch:
-                // exec-masked loads make the compiler drain the memory queue)
-                E[i] = buffer_gather<T>(xw, edge ? (top ? vo + 2 * ES : vo - ES) : 0xFFFFFFFFu, 0);
-                F[i] = T(0);
-                if (both) F[i] = buffer_gather<T>(xw, lane == 0 ? vo - ES : 0xFFFFFFFFu, 0);
-            }
+                for (int i = 0; i < B2; ++i) its[i] = p->items[i0 + i];
 #pragma unroll
-            for (int i = 0; i < B2; ++i) {
-                const int sl3 = p->islots[i0 + i];
-                const int qa = sl3 & 31, qb = (sl3 >> 8) & 31, qc = (sl3 >> 16) & 31;
-                T below = lane_next<true>(P[i].b), above = lane_next<false>(P[i].a);
-                if (top) above = E[i];
-                if (lane == 0) below = top ? F[i] : E[i];
-                const T v0 = p->val[qa], v1 = p->val[qb], v2 = p->val[qc];
-                { const T xa = ((m0 >> qa) & 1u) ? below : T(0); const T pr = v0 * xa; acc0 = acc0 + pr; }
-                { const T xa = ((m0 >> qb) & 1u) ? P[i].a : T(0); const T pr = v1 * xa; acc0 = acc0 + pr; }
-                { const T xa = ((m0 >> qc) & 1u) ? P[i].b : T(0); const T pr = v2 * xa; acc0 = acc0 + pr; }
-                { const T xa = ((m1 >> qa) & 1u) ? P[i].a : T(0); const T pr = v0 * xa; acc1 = acc1 + pr; }
-                { const T xa = ((m1 >> qb) & 1u) ? P[i].b : T(0); const T pr = v1 * xa; acc1 = acc1 + pr; }
-                { const T xa = ((m1 >> qc) & 1u) ? above : T(0); const T pr = v2 * xa; acc1 = acc1 + pr; }
+                for (int i = 0; i < B2; ++i) {
+                    P[i] = buffer_gather2<T>(xw, rowoff + (unsigned)its[i].off, 0);
+                    E[i] = buffer_gather<T>(xw, (pe & (its[i].ba | its[i].bc)) ? voe + (unsigned)its[i].off : 0xFFFFFFFFu, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < B2; ++i) {
+                    const SdiawItem<T> &it = its[i];
+                    if (Z0 & it.ba) sdiaw_term<T>(acc0, U0, Z0, m0, it.ba, it.va, lane_next_old<true>(P[i].b, E[i]));
+                    sdiaw_term<T>(acc0, U0, Z0, m0, it.bb, it.vb, P[i].a);
+                    sdiaw_term<T>(acc0, U0, Z0, m0, it.bc, it.vc, P[i].b);
+                    sdiaw_term<T>(acc1, U1, Z1, m1, it.ba, it.va, P[i].a);
+                    sdiaw_term<T>(acc1, U1, Z1, m1, it.bb, it.vb, P[i].b);
+                    if (Z1 & it.bc) sdiaw_term<T>(acc1, U1, Z1, m1, it.bc, it.vc, lane_next_old<false>(P[i].a, E[i]));
+                }
             }
         }
     } else {
@@ -732,9 +838,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiaw2(int n, int ncols, int
     }
     buffer_put2<T>(ys, rowoff, acc0, acc1, NT);
     if (FUSE_DOT) {
-        T xr0 = T(0), xr1 = T(0);
-        if (r0 < n) { const Pair2<T> xc = buffer_gather2<T>(xw, rowoff, 0); xr0 = xc.a; xr1 = xc.b; }
-        T s0 = xr0 * acc0, s1 = xr1 * acc1;                                // a pair past the end: 0 * +0
+        T s0 = xc.a * acc0, s1 = xc.b * acc1;                              // a pair past the end: 0 * +0
         s0 = s0 + lane_down<16>(s0); s1 = s1 + lane_down<16>(s1);
         s0 = s0 + lane_down<8>(s0);  s1 = s1 + lane_down<8>(s1);
         s0 = s0 + lane_down<4>(s0);  s1 = s1 + lane_down<4>(s1);

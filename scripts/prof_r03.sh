@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 profiling recipe (run on the GPU box through gpurun):  scripts/prof_r03.sh [what...]   what = bench c5 gmres
+# Round-3 profiling recipe (run on the GPU box through gpurun):  scripts/prof_r03.sh [what...]   what = bench c5 gmres s27
 #   rocprofv3 --kernel-trace --stats           -> gpurun_out/r03/<what>/trace
 #   separate --pmc passes (never combined with other trace domains; <= 8 SQ / 4 TCC counters per pass)
 # scripts/prof_collect.py then condenses everything into the small CSV / txt / json files that are committed under profiles/.
@@ -41,6 +41,22 @@ for w in $WHAT; do
    pmc $D/pmc_l2 TCC_HIT_sum TCC_MISS_sum -- $C5
    unset GMRES KINDS CSR
   done
+  ;;
+ s27)
+  # the 27-point box stencil in the wide slice-constant layout (k_spmv_sdiaw2): where its time goes.  256 x 256 x 64 nodes: the
+  # per-row time of the 256^3 fixture (the kernel is not HBM-bound) at a sixth of the generation time.
+  D=$OUT/s27; mkdir -p $D
+  B="python $R/scripts/box_stencil_bench.py --no-csr --shape 256,256,64 --steps 30"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -o run -- $B > $D/trace.log 2>&1
+  grep "^{" $D/trace.log | tail -1 > $D/bench_under_rocprof.json
+  pmc $D/pmc_fetch FETCH_SIZE -- $B
+  pmc $D/pmc_write WRITE_SIZE -- $B
+  pmc $D/pmc_l2 TCC_HIT_sum TCC_MISS_sum -- $B
+  pmc $D/pmc_sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_SALU SQ_INSTS_VALU -- $B
+  pmc $D/pmc_issue SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- $B
+  pmc $D/pmc_level SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_SMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL GRBM_GUI_ACTIVE -- $B
+  pmc $D/pmc_ta TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE -- $B
+  pmc $D/pmc_tcp TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum -- $B
   ;;
  gmres)
   D=$OUT/gmres; mkdir -p $D
