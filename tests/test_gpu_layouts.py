@@ -333,6 +333,43 @@ def test_development_knobs_are_per_context(pkg, orc, ctx):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(128, 6, 5), (256, 5, 4), (128, 9), (384, 7), (64, 8, 6), (128, 3, 3)])
+def test_wide_layout_slot_tests_per_wave(pkg, orc, ctx, dtype, shape):
+    """k_spmv_sdiaw2 tests a slot once per wave where its 128 rows agree (k_sdiaw_chunk_bits, built at upload): grid lines of 128 /
+    256 / 384 nodes put whole waves into the interior (every slot present: the multiply-add-only loop, 9 or 3 items in flight),
+    onto a y / z face (whole runs absent: skipped) and -- lines of 64 -- across line ends (some rows lack a slot: per-lane
+    select).  The first / last row of a wave takes its outer value from the edge load, which must read 0 where the row has no
+    such neighbour: the line ends of x carry Inf, which may only reach the rows that reference them.  Distinct values per offset."""
+    n, rp, ci, _ = pkg.fixtures.fe_matrix(shape, 1, np.float64, renumber=False)
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp))
+    off = ci - rows
+    vv = np.where(off == 0, 30.0, -1.0 - ((off % 97) / 128.0)).astype(dtype)
+    dA = pkg.HipCSR(n, n, rp, ci, vv, index_base=0, is_csc=False)
+    assert dA.layout() == "wide-slice-values+row-masks" and dA.spmv_kernel() == "k_spmv_sdiaw2"
+    A = orc.CSC.from_scipy(sp.csr_matrix((vv, ci, rp), shape=(n, n)).tocsc())
+    rng = np.random.default_rng(11)
+    for trial in range(3):
+        x = rng.standard_normal(n).astype(dtype)
+        if trial == 1:
+            x[shape[0] - 1::shape[0]] = np.inf                         # last node of every line
+        if trial == 2:
+            x[::shape[0]] = -np.inf                                    # first node of every line
+        want = orc.spmv(A, x)
+        dx = pkg.HipVector.from_numpy(x)
+        got = pkg.mul_(pkg.HipVector(n, dtype), dA, dx).to_numpy()
+        assert np.array_equal(got, want, equal_nan=True)
+    # the dot fused into the SpMV: six steps of the CG recurrence (the operator is not symmetric -- only the arithmetic matters)
+    b = orc.hashed_rhs(n).astype(dtype)
+    xs, ch = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True, maxiter=6)
+    xo, ho = orc.cg(A, b, maxiter=6, mode="tree", shape=ctx.cg_shape(dtype))
+    assert np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(xs.to_numpy(), xo)
+    dA.set_layout("csr")
+    xc, cc = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True, maxiter=6)
+    dA.set_layout("auto")
+    assert np.array_equal(cc["resnorm"], ch["resnorm"]) and np.array_equal(xc.to_numpy(), xs.to_numpy())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("N,dims", [(13, 3), (40, 2), (21, 3), (16, 3), (22, 3), (7, 2)])
 def test_wide_slice_constant_layout_for_box_stencils(pkg, orc, ctx, dtype, N, dims):
     """constant-coefficient 9-point (2-D) / 27-point (3-D) stencils exceed the 8 offsets per slice of the mask-byte
