@@ -531,7 +531,7 @@ int mik_sdiaw_finish(mik_ctx *ctx, mik_csr *A, const std::vector<std::vector<std
         // summed slot by slot (nitems = 0).
         struct Item { int off; unsigned b[3]; uint64_t v[3]; };
         std::vector<Item> items;
-        bool okp = true;
+        bool okp = ns <= 31;                                  // bit 31 stays free: SdiawPattern::fullbits uses it as "never"
         for (int q = 0; q < ns && okp;) {
             const int d = pats[i][(size_t)q].first;
             if (items.size() == 24) { okp = false; break; }

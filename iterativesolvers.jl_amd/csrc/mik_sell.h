@@ -601,6 +601,7 @@ template <typename T> struct SdiawItem {
     unsigned ba, bb, bc;   // 1 << slot of o - 1 / o / o + 1, or 0
     T va, vb, vc;          // their values (+0 where the bit is 0)
 };
+struct SdiawItemHead { int off; unsigned ba, bb, bc; };   // the first 16 bytes of an item (4-byte aligned in the fp32 table)
 template <typename T> struct SdiawPattern {
     int ns, nitems;        // nitems > 0 (a multiple of 3): the slots decompose into items (0: k_spmv_sdiaw2 runs the slice slot by slot)
     unsigned exa, exc;     // union of the items' ba / bc: the slots whose value reaches a wave's first / last row from outside the wave
@@ -721,9 +722,9 @@ __device__ __forceinline__ void sdiaw_full_runs(const SdiawPattern<T> *__restric
         T E[B];
 #pragma unroll
         for (int i = 0; i < B; ++i) {
-            const int4 hd = *reinterpret_cast<const int4 *>(&p->items[i0 + i]);       // {off, ba, bb, bc}: one scalar load
-            P[i] = buffer_gather2<T>(xw, rowoff + (unsigned)hd.x, 0);                 // a negative column wraps beyond the descriptor's range: reads 0
-            E[i] = buffer_gather<T>(xw, (pe & (unsigned)(hd.y | hd.w)) ? voe + (unsigned)hd.x : 0xFFFFFFFFu, 0);
+            const SdiawItemHead hd = *reinterpret_cast<const SdiawItemHead *>(&p->items[i0 + i]);   // {off, ba, bb, bc}: one scalar load
+            P[i] = buffer_gather2<T>(xw, rowoff + (unsigned)hd.off, 0);                 // a negative column wraps beyond the descriptor's range: reads 0
+            E[i] = buffer_gather<T>(xw, (pe & (hd.ba | hd.bc)) ? voe + (unsigned)hd.off : 0xFFFFFFFFu, 0);
         }
 #pragma unroll
         for (int i = 0; i < B; ++i) {

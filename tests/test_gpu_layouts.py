@@ -333,6 +333,28 @@ def test_development_knobs_are_per_context(pkg, orc, ctx):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("lo,hi", [(-16, 15), (-15, 15), (-20, 11)])
+def test_wide_layout_at_its_slot_limit(pkg, orc, dtype, lo, hi):
+    """31 and 32 constant offsets per slice (the mask word's capacity): 32 leave no spare mask bit, so the slice is summed slot by
+    slot; 31 decompose into runs and lone offsets.  Same bits as the oracle either way."""
+    n = 1536
+    offs = np.arange(lo, hi + 1)
+    rows = np.repeat(np.arange(n), offs.size)
+    cols = rows + np.tile(offs, n)
+    ok = (cols >= 0) & (cols < n)
+    rows, cols = rows[ok], cols[ok]
+    vals = np.where(cols == rows, 40.0, -1.0 - ((cols - rows) % 13) / 16.0).astype(dtype)
+    M = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+    M.sort_indices()
+    dA = pkg.HipCSR(n, n, M.indptr, M.indices, M.data, index_base=0, is_csc=False)
+    assert dA.layout() == "wide-slice-values+row-masks"
+    A = orc.CSC.from_scipy(M.tocsc())
+    x = np.random.default_rng(2).standard_normal(n).astype(dtype)
+    x[100] = np.inf
+    assert np.array_equal(pkg.mul_(pkg.HipVector(n, dtype), dA, pkg.HipVector.from_numpy(x)).to_numpy(), orc.spmv(A, x), equal_nan=True)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", [(128, 6, 5), (256, 5, 4), (128, 9), (384, 7), (64, 8, 6), (128, 3, 3)])
 def test_wide_layout_slot_tests_per_wave(pkg, orc, ctx, dtype, shape):
     """k_spmv_sdiaw2 tests a slot once per wave where its 128 rows agree (k_sdiaw_chunk_bits, built at upload): grid lines of 128 /
