@@ -1,6 +1,8 @@
 """Per-iteration time of the widened solvers on the 256^3 Laplacian, fp64, one MI355X:
 PCG with a Jacobi Pl, BiCGStab(2), MINRES, Chebyshev -- next to plain CG.  `gbs` = bytes of the reference's
-own operation sequence (SpMV algorithmic bytes + its vector sweeps, unfused) / time.
+own operation sequence (SpMV algorithmic bytes + its vector sweeps, unfused) / time; `frac_moved_of_8000` = the bytes the
+device path actually streams per iteration (the operator layout's stored bytes per SpMV + the words of its fused sweeps) / time
+/ 8 TB/s -- the figure to hold against the 0.78 copy ceiling.
     python scripts/solver_bench.py [--grid 256] [--iters 60]"""
 import argparse
 import gc
@@ -31,7 +33,7 @@ spmv_b = A.spmv_algorithmic_bytes()
 vec = 8 * n
 
 
-def timed(name, it, start, words, mv_per_iter, iters=args.iters, warm=5):
+def timed(name, it, start, words, mv_per_iter, iters=args.iters, warm=5, moved_words=None):
     if args.only and name not in args.only.split(","):
         return
     i = start
@@ -50,21 +52,27 @@ def timed(name, it, start, words, mv_per_iter, iters=args.iters, warm=5):
     if os.environ.get("SOLVER_BENCH_DEBUG"):
         print(name, "per-iteration us:", " ".join("%.0f" % (p * 1e6) for p in per), file=sys.stderr)
     bytes_ = mv_per_iter * spmv_b + words * vec
-    print(json.dumps({"solver": name, "grid": N, "us_per_iter": dt * 1e6, "iters_per_sec": 1 / dt, "spmv_per_iter": mv_per_iter,
-                      "vector_words_per_row_unfused": words, "gbs_of_reference_sequence": bytes_ / dt / 1e9}))
+    out = {"solver": name, "grid": N, "us_per_iter": dt * 1e6, "iters_per_sec": 1 / dt, "spmv_per_iter": mv_per_iter,
+           "vector_words_per_row_unfused": words, "gbs_of_reference_sequence": bytes_ / dt / 1e9}
+    if moved_words is not None:
+        moved = mv_per_iter * A.spmv_stored_bytes() + moved_words * vec
+        out.update({"vector_words_per_row_moved": moved_words, "bytes_moved_per_iter": moved, "frac_moved_of_8000": moved / dt / 8e12})
+    print(json.dumps(out))
 
 
 x = pkg.zerox(A, b)
-timed("cg", pkg.cg_iterator_(x, A, b, reltol=0.0, initially_zero=True, maxiter=10 ** 9), 0, 12, 1)
+timed("cg", pkg.cg_iterator_(x, A, b, reltol=0.0, initially_zero=True, maxiter=10 ** 9), 0, 12, 1, moved_words=3 + 5)             # r -= a c (+ |r|^2): 3; x += a u, u = r + b u: 5
 d = pkg.HipVector.from_numpy(np.full(n, 6.0))
 x = pkg.zerox(A, b)
-timed("pcg_jacobi", pkg.cg_iterator_(x, A, b, pkg.JacobiPrec(d), reltol=0.0, initially_zero=True, maxiter=10 ** 9), 0, 15, 1)
+timed("pcg_jacobi", pkg.cg_iterator_(x, A, b, pkg.JacobiPrec(d), reltol=0.0, initially_zero=True, maxiter=10 ** 9), 0, 15, 1, moved_words=5 + 5)   # r -= a c, c = r ./ d (+ 2 sums): 5; x, u sweep: 5
 x = pkg.zerox(A, b)
 # BiCGStab(2): per outer iteration 4 SpMV; sweeps: 2 dots x2 (2 words each) ... counted from src/bicgstabl.jl:88-132
 l = 2
 words = sum(2 + 3 * (j + 1) + 2 + 3 * (j + 1) + 3 for j in range(l)) + (l + 1) * (l + 1) * 2 + (l + 2) + (l + 2) + (l + 2) + 1
-timed("bicgstabl2", pkg.bicgstabl_iterator_(x, A, b, 2, reltol=0.0, max_mv_products=10 ** 9, initial_zero=True), 0, words, 2 * l, iters=max(args.iters // 3, 10))
+timed("bicgstabl2", pkg.bicgstabl_iterator_(x, A, b, 2, reltol=0.0, max_mv_products=10 ** 9, initial_zero=True), 0, words, 2 * l, iters=max(args.iters // 3, 10),
+      moved_words=sum(2 + 3 * (j + 1) + 2 + 3 * (j + 1) + 3 for j in range(l)) + (l + 1) + (3 * l + 4))   # + one-pass Gram + one-sweep MR update
 x = pkg.zerox(A, b)
-timed("minres", pkg.minres_iterable_(x, A, b, reltol=0.0, initially_zero=True, maxiter=10 ** 9), 1, 27, 1)
+timed("minres", pkg.minres_iterable_(x, A, b, reltol=0.0, initially_zero=True, maxiter=10 ** 9), 1, 27, 1, moved_words=4 + 3 + 8)             # Lanczos step + projection: 4; orthogonalise + norm: 3; tail: 8
 x = pkg.zerox(A, b)
-timed("chebyshev", pkg.chebyshev_iterable_(x, A, b, 4.5e-4, 12.0, reltol=0.0, initially_zero=True, maxiter=10 ** 9), 0, 2 + 3 + 3 + 3 + 1, 1)
+timed("chebyshev", pkg.chebyshev_iterable_(x, A, b, 4.5e-4, 12.0, reltol=0.0, initially_zero=True, maxiter=10 ** 9), 0, 2 + 3 + 3 + 3 + 1, 1,
+      moved_words=3 + 6)                                               # direction: 3; x, r update + norm: 6
