@@ -20,6 +20,7 @@ extern "C" {
  *   5: 1 = unfused MGS chain, 2 = launch-lean MGS without graphs, 3 = one hipGraph per GMRES column
  *   7: cache hints of the CG vector kernels
  *   8: 1 = CSR row-block layout only (read at mik_csr_create and at launch)    9: 1 = nothing enqueued ahead of the host (GMRES: the next Arnoldi column; CG: the head of the next step)
+ *  10: 1 = scalar results through hipMemcpyAsync + event spin instead of the publish kernel + mailbox spin
  *  11: 1 = no slice-constant values        12: 1 = no per-slice-offset layout
  *  13: bit mask switching the Krylov-basis streaming hints off    14: CSR kernel: 0 = by operator, 1 = register-staged products, 2 = LDS-DMA tile + per-row gather
  *  15: long-row segment length (> 0; read at mik_csr_create)   16: slices per workgroup of the layout-5 kernels (1 / 2 / 4)

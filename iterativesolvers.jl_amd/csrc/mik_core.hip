@@ -54,14 +54,6 @@ int mik_ensure_partials(mik_ctx *ctx, size_t bytes)
 // launch helpers
 // ---------------------------------------------------------------------------------------------
 
-template <typename T> static int read_scalars(mik_ctx *ctx, const T *dev, int count, T *host_out)
-{
-    MIK_HIP(ctx, hipMemcpyAsync(ctx->coef_host, dev, sizeof(T) * count, hipMemcpyDeviceToHost, ctx->stream));
-    MIK_HIP(ctx, mik_wait(ctx));
-    memcpy(host_out, ctx->coef_host, sizeof(T) * count);
-    return MIK_OK;
-}
-
 // ---------------------------------------------------------------------------------------------
 // library / context
 // ---------------------------------------------------------------------------------------------
@@ -101,6 +93,8 @@ extern "C" int mik_ctx_create(int device, mik_ctx **out)
     if ((e = hipMalloc(&ctx->coef, mik_ctx::COEF_BYTES)) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipHostMalloc(&ctx->coef_host, mik_ctx::COEF_BYTES, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
     if ((e = hipEventCreateWithFlags(&ctx->wait_event, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipHostMalloc(&ctx->pub, mik_ctx::PUB_BYTES + 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail(e, "hipHostMalloc");
+    memset(ctx->pub, 0, mik_ctx::PUB_BYTES + 64);
     {
         std::lock_guard<std::mutex> lk(g_mik_contexts_mu);
         memcpy(ctx->tuning, g_mik_tuning, sizeof(ctx->tuning));
@@ -122,6 +116,7 @@ extern "C" int mik_ctx_destroy(mik_ctx *ctx)
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->coef) (void)hipFree(ctx->coef);
     if (ctx->coef_host) (void)hipHostFree(ctx->coef_host);
+    if (ctx->pub) (void)hipHostFree(ctx->pub);
     if (ctx->wait_event) (void)hipEventDestroy(ctx->wait_event);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -1499,7 +1494,7 @@ template <typename T> static int reduce_to_host(mik_ctx *ctx, int64_t n, T *out)
     hipLaunchKernelGGL((k_finalize_store<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg,
                        (int64_t)0, (T *)ctx->coef, (const int *)nullptr);
     MIK_LAUNCH_CHECK(ctx);
-    return read_scalars<T>(ctx, (const T *)ctx->coef, 1, out);
+    return mik_read_scalars<T>(ctx, (const T *)ctx->coef, 1, out);
 }
 
 // norm(x) from the sum of squares t the caller has just reduced: sqrt(t) (host sqrt: IEEE correctly rounded) when t
@@ -1521,7 +1516,7 @@ template <typename T> int mik_safe_norm_slow(mik_ctx *ctx, int64_t n, const T *x
     hipLaunchKernelGGL((k_amax<T>), dim3(1), dim3(MIK_BLOCK), 0, ctx->stream, (int64_t)grid, (const T *)ctx->partials, scr);
     MIK_LAUNCH_CHECK(ctx);
     T amax;
-    MIK_TRY(read_scalars<T>(ctx, scr, 1, &amax));
+    MIK_TRY(mik_read_scalars<T>(ctx, scr, 1, &amax));
     if (amax == T(0) || amax != amax || amax > std::numeric_limits<T>::max()) { *out = amax; return MIK_OK; }   // 0, NaN, Inf as they are
     int e;
     (void)std::frexp((double)amax, &e);                 // amax = f * 2^e, f in [0.5, 1)
@@ -1533,7 +1528,7 @@ template <typename T> int mik_safe_norm_slow(mik_ctx *ctx, int64_t n, const T *x
                        (int64_t)0, scr, (const int *)nullptr);
     MIK_LAUNCH_CHECK(ctx);
     T t2;
-    MIK_TRY(read_scalars<T>(ctx, scr, 1, &t2));
+    MIK_TRY(mik_read_scalars<T>(ctx, scr, 1, &t2));
     *out = (T)std::sqrt(t2) * sinv;
     return MIK_OK;
 }

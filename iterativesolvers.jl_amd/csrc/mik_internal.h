@@ -39,6 +39,9 @@ struct mik_ctx {
     void *coef = nullptr;            // small device array of coefficients / scalar results
     void *coef_host = nullptr;       // pinned host mirror
     hipEvent_t wait_event = nullptr; // for mik_wait
+    void *pub = nullptr;             // pinned, device-mapped, coherent: PUB_BYTES of scalar results + the ticket of the last publication (read_scalars)
+    unsigned long long pub_seq = 0;
+    static constexpr size_t PUB_BYTES = 4096;
     int sweep_rev = 0;               // 1: the next SpMV launch walks its row-blocks from the end (set and cleared by the CG step)
     int tuning[32] = {0};            // development knobs of THIS context (include/mik_dev.h): a copy of the defaults at creation, mik_ctx_set_tuning
     static constexpr size_t COEF_BYTES = 8192;      // [0, 4096): coefficient blocks of the callers; the tail: scratch of mik_safe_norm_slow
@@ -341,5 +344,50 @@ static inline hipError_t mik_wait(mik_ctx *ctx)
         int rc_ = (expr);             \
         if (rc_ != MIK_OK) return rc_; \
     } while (0)
+
+
+// `count` values of the device array `dev`, as soon as everything enqueued before has run.  A one-wave kernel copies them into the
+// context's pinned mailbox and then stores a ticket (system scope); the host spins on the ticket -- no copy engine, no event in
+// the path (hipMemcpyAsync + event spin, development knob 10 = 1, takes several microseconds longer per read, and the solvers that
+// are driven from the host -- MINRES, BiCGStab(l), the generic GMRES path -- read 2 ... 5 scalars per iteration).
+template <typename T>
+__global__ __launch_bounds__(64) void k_publish(const T *__restrict__ src, int count, T *__restrict__ dst, unsigned long long *ticket, unsigned long long seq)
+{
+    for (int i = (int)threadIdx.x; i < count; i += 64) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <typename T> static inline int mik_read_scalars(mik_ctx *ctx, const T *dev, int count, T *host_out)
+{
+    if (ctx->tuning[10] == 1 || !ctx->pub || sizeof(T) * (size_t)count > mik_ctx::PUB_BYTES) {
+        MIK_HIP(ctx, hipMemcpyAsync(ctx->coef_host, dev, sizeof(T) * count, hipMemcpyDeviceToHost, ctx->stream));
+        MIK_HIP(ctx, mik_wait(ctx));
+        memcpy(host_out, ctx->coef_host, sizeof(T) * count);
+        return MIK_OK;
+    }
+    unsigned long long *ticket = reinterpret_cast<unsigned long long *>((unsigned char *)ctx->pub + mik_ctx::PUB_BYTES);
+    const unsigned long long want = ++ctx->pub_seq;
+    hipLaunchKernelGGL((k_publish<T>), dim3(1), dim3(64), 0, ctx->stream, dev, count, (T *)ctx->pub, ticket, want);
+    MIK_LAUNCH_CHECK(ctx);
+    for (unsigned long long spins = 0;; ++spins) {
+        if (__atomic_load_n(ticket, __ATOMIC_ACQUIRE) == want) break;
+        if ((spins & 0xFFFFF) == 0xFFFFF) {                  // every ~1M polls: has the stream died, or finished without publishing?
+            const hipError_t e = hipStreamQuery(ctx->stream);
+            if (e == hipSuccess) {
+                if (__atomic_load_n(ticket, __ATOMIC_ACQUIRE) == want) break;
+                return mik_fail(ctx, MIK_ERR_HIP, "scalar read: stream idle but ticket %llu was never published", want);
+            }
+            if (e != hipErrorNotReady) return mik_fail(ctx, MIK_ERR_HIP, "scalar read: %s", hipGetErrorString(e));
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    memcpy(host_out, ctx->pub, sizeof(T) * count);
+    return MIK_OK;
+}
+
 
 #endif  // __HIPCC__

@@ -128,10 +128,7 @@ template <typename T> static int coef_upload(mik_ctx *ctx, int slot, const T *ho
 
 template <typename T> static int coef_download(mik_ctx *ctx, int slot, T *host, int k)
 {
-    MIK_HIP(ctx, hipMemcpyAsync((T *)ctx->coef_host + slot, (T *)ctx->coef + slot, sizeof(T) * k, hipMemcpyDeviceToHost, ctx->stream));
-    MIK_HIP(ctx, mik_wait(ctx));
-    memcpy(host, (T *)ctx->coef_host + slot, sizeof(T) * k);
-    return MIK_OK;
+    return mik_read_scalars<T>(ctx, (const T *)ctx->coef + slot, k, host);
 }
 
 template <typename T>

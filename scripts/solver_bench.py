@@ -24,6 +24,10 @@ args = ap.parse_args()
 pkg = graft.load_package()
 import torch  # noqa: E402
 
+for kv in os.environ.get("MIK_KNOBS", "").split(","):            # development knobs for A/B runs, e.g. MIK_KNOBS=10=1
+    if kv:
+        pkg.lib().mik_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
+
 N = args.grid
 n, colptr, rowval, nzval = pkg.fixtures.laplace_matrix(N, 3)
 A = pkg.HipCSR(n, n, colptr, rowval, nzval, index_base=1)
