@@ -314,6 +314,33 @@ int mik_gram(mik_ctx *ctx, int dtype, int64_t n, int k, const void *V, int64_t l
 int mik_bicgstab_mr_update(mik_ctx *ctx, int dtype, int64_t n, int l, void *us, int64_t ldu, void *rs, int64_t ldr, void *x,
                            const void *gamma, void *out);
 
+/* One whole outer iteration of BiCGStab(l) -- iterate(::BiCGStabIterable), src/bicgstabl.jl:79-134 -- per call, with rho, beta,
+ * sigma, alpha, the Gram matrix, gamma and omega kept on the device: the host waits once, for the residual norm it returns
+ * (the statement-by-statement form through mik_dot / mik_xpby / mik_spmv / mik_axpy / mik_gram / mik_lu_solve /
+ * mik_bicgstab_mr_update waits 2 l + 3 times; both produce the same bits).  The caller owns x, the residual block rs and the
+ * search block us (n x (l + 1), column-major, leading dimensions ldr / ldu) as set up by bicgstabl_iterator!
+ * (src/bicgstabl.jl:25-73: rs[:, 1] = Pl \ (b - A x), us = 0) and the shadow residual r_shadow (:38); pl_diag: the diagonal
+ * of a Jacobi Pl (ldiv! = elementwise division, :98, :108) or NULL for Identity.  omega = sigma = 1 at creation (:59).
+ * l = 1 ... 4.  MIK_ERR_INVALID when lu! meets an exactly singular pivot (the reference throws SingularException). */
+typedef struct mik_bicgstab mik_bicgstab;
+int mik_bicgstab_create(mik_ctx *ctx, const mik_csr *A, int l, void *x, void *rs, int64_t ldr, void *us, int64_t ldu,
+                        const void *r_shadow, const void *pl_diag, mik_bicgstab **out);
+int mik_bicgstab_step(mik_bicgstab *it, void *residual);          /* residual: one scalar of A's element type */
+int mik_bicgstab_destroy(mik_bicgstab *it);
+
+/* One whole iteration of MINRES -- iterate(::MINRESIterable), src/minres.jl:95-159 -- per call: mul!, the Lanczos step with its
+ * projection (:104-107), the orthogonalisation with its norm (:109-112), both Givens rotations and the right-hand side (:116-133),
+ * and the tail sweep (:113, :136-142), the scalars on the device; the host waits once, for the residual norm |rhs[2]| (:154) it
+ * returns (the statement-by-statement form through mik_spmv / mik_axpy_dot / mik_givens / mik_minres_update waits twice inside
+ * the iteration; same bits).  The caller owns x and the six work vectors as minres_iterable! sets them up (:38-87:
+ * v_curr = (b - A x) / resnorm0, w's = 0); the handle rotates its three v and three w pointers after every step exactly as
+ * :145-146 do, and the caller rotates its own names with it.  iteration counts from 1 (:91). */
+typedef struct mik_minres mik_minres;
+int mik_minres_create(mik_ctx *ctx, const mik_csr *A, void *x, void *v_prev, void *v_curr, void *v_next, void *w_prev, void *w_curr,
+                      void *w_next, double resnorm0, int skew_hermitian, mik_minres **out);
+int mik_minres_step(mik_minres *it, int64_t iteration, void *resnorm);   /* resnorm: one scalar of A's element type */
+int mik_minres_destroy(mik_minres *it);
+
 /* ---- row-partitioned GMRESIterable: one process per GPU ---------------------------------------- */
 /* The same iterable (src/gmres.jl:57-106) over a contiguous row block.  The Arnoldi basis, x, b and
  * the diagonal preconditioners are this rank's n_loc rows; A_loc is the block as an n_loc x n_ext

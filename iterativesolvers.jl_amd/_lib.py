@@ -126,6 +126,12 @@ SIGNATURES = {
     "mik_minres_update": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "mik_gram": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _vp, _i64, _vp]),
     "mik_bicgstab_mr_update": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "mik_bicgstab_create": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _i64, _vp, _i64, _vp, _vp, C.POINTER(_vp)]),
+    "mik_bicgstab_step": (C.c_int, [_vp, _vp]),
+    "mik_bicgstab_destroy": (C.c_int, [_vp]),
+    "mik_minres_create": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_int, C.POINTER(_vp)]),
+    "mik_minres_step": (C.c_int, [_vp, _i64, _vp]),
+    "mik_minres_destroy": (C.c_int, [_vp]),
     "mik_gather": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp]),
     "mik_cgd_create": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, C.c_int, C.c_int,
                                  C.c_double, C.c_double, _i64, C.c_int, C.POINTER(_vp)]),

@@ -1079,6 +1079,15 @@ class BiCGStabIterable:
         self.M = np.zeros((self.l + 1, self.l + 1), x.dtype, order="F")      # :66
         self.tol = max(T(reltol) * self.residual, T(abstol))                 # :69
         self.max_mv_products = int(max_mv_products)
+        # fused, l <= 4, a HipCSR operator: the whole outer iteration is one C call with its scalars on the device
+        # (mik_bicgstab_step); omega, sigma, gamma and M then live there and the host copies above stay at their initial values
+        self._step = None
+        if self.fused and self.l <= 4 and isinstance(A, HipCSR):
+            h = _vp()
+            d = self.Pl.diagonal.ptr if isinstance(self.Pl, JacobiPrec) else None
+            check(lib().mik_bicgstab_create(x.ctx.handle, A.handle, self.l, _vp(x.ptr), _vp(self.rs.col(0).ptr), self.rs.ld, _vp(self.us.col(0).ptr),
+                                            self.us.ld, _vp(self.r_shadow.ptr), _vp(d), C.byref(h)), "mik_bicgstab_create", x.ctx.handle)
+            self._step = h
 
     def _ldiv(self, v: HipVector):
         if isinstance(self.Pl, JacobiPrec):
@@ -1099,6 +1108,15 @@ class BiCGStabIterable:
         if self.done(iteration):
             return None
         l, rs, us = self.l, self.rs, self.us
+        if self._step is not None:
+            out = np.zeros(1, self.x.dtype)
+            rc = lib().mik_bicgstab_step(self._step, out.ctypes.data_as(_vp))
+            if rc == 1:
+                raise np.linalg.LinAlgError("SingularException")
+            check(rc, "mik_bicgstab_step", self.x.ctx.handle)
+            self.mv_products += 2 * l                                        # :115
+            self.residual = out[0]
+            return self.residual, iteration + 1
         self.sigma = -self.omega * self.sigma                                # :85
         for j in range(l):                                                   # BiCG part  :88
             rho = dot(self.r_shadow, rs.col(j))                              # :89
@@ -1143,6 +1161,14 @@ class BiCGStabIterable:
         while (nxt := self.iterate(iteration)) is not None:
             residual, iteration = nxt
             yield residual
+
+    def __del__(self):
+        try:
+            if getattr(self, "_step", None) is not None and self.x.ctx.handle:
+                lib().mik_bicgstab_destroy(self._step)
+                self._step = None
+        except Exception:
+            pass
 
 
 def bicgstabl_iterator_(x: HipVector, A: HipCSR, b: HipVector, l: int = 2, *, Pl=None, max_mv_products=None, abstol=0.0,
@@ -1338,6 +1364,15 @@ class MINRESIterable:
         self.v_curr.scal_(T(1) / self.resnorm)                               # :74
         self.c_prev, self.s_prev, self.c_curr, self.s_curr = T(1), T(0), T(1), T(0)
         self.maxiter = int(maxiter)
+        # fused, a HipCSR operator: the whole iteration is one C call with H, rhs and the rotations on the device (mik_minres_step);
+        # the host copies above then stay at their initial values
+        self._step = None
+        if self.fused and isinstance(A, HipCSR):
+            h = _vp()
+            check(lib().mik_minres_create(x.ctx.handle, A.handle, _vp(x.ptr), _vp(self.v_prev.ptr), _vp(self.v_curr.ptr), _vp(self.v_next.ptr),
+                                          _vp(self.w_prev.ptr), _vp(self.w_curr.ptr), _vp(self.w_next.ptr), float(self.resnorm), int(self.skew), C.byref(h)),
+                  "mik_minres_create", x.ctx.handle)
+            self._step = h
 
     def converged(self):
         return self.resnorm <= self.tol                                      # :89
@@ -1354,6 +1389,14 @@ class MINRESIterable:
         if self.done(iteration):
             return None
         T, H, rhs = self.x.dtype.type, self.H, self.rhs
+        if self._step is not None:
+            out = np.zeros(1, self.x.dtype)
+            check(lib().mik_minres_step(self._step, int(iteration), out.ctypes.data_as(_vp)), "mik_minres_step", self.x.ctx.handle)
+            self.v_prev, self.v_curr, self.v_next = self.v_curr, self.v_next, self.v_prev       # :145 (the handle rotates its pointers alike)
+            self.w_prev, self.w_curr, self.w_next = self.w_curr, self.w_next, self.w_prev       # :146
+            self.resnorm = out[0]                                            # :154
+            self.mv_products += 1
+            return self.resnorm, iteration + 1
         mul_(self.v_next, self.A, self.v_curr)                               # :102
         if self.fused:
             proj = axpy_dot_(-H[1], self.v_prev if iteration > 1 else None, self.v_next, self.v_curr, hints=1)   # :104, :107; v_prev is dead
@@ -1407,6 +1450,14 @@ class MINRESIterable:
         while (nxt := self.iterate(iteration)) is not None:
             resnorm, iteration = nxt
             yield resnorm
+
+    def __del__(self):
+        try:
+            if getattr(self, "_step", None) is not None and self.x.ctx.handle:
+                lib().mik_minres_destroy(self._step)
+                self._step = None
+        except Exception:
+            pass
 
 
 def minres_iterable_(x, A, b, *, initially_zero=False, skew_hermitian=False, abstol=0.0, reltol=None, maxiter=None, fused=True):

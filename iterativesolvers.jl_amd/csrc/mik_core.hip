@@ -1603,7 +1603,7 @@ template <typename T>
 static int axpy_dot_impl(mik_ctx *ctx, int64_t n, const void *alpha, const void *x, void *y, const void *z, void *out, int hints)
 {
     MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(mik_nseg<T>(n), 1)));
-    OpAxpyDot<T> op{(const T *)x, (T *)y, (const T *)z, x ? *(const T *)alpha : T(0), hints};
+    OpAxpyDot<T> op{(const T *)x, (T *)y, (const T *)z, coef_val(x ? *(const T *)alpha : T(0)), hints};
     const bool vec = mik_aligned16(y) && (!x || mik_aligned16(x)) && (!z || mik_aligned16(z));
     MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)ctx->partials, nullptr)));
     T v;
@@ -1664,8 +1664,8 @@ static int minres_update_impl(mik_ctx *ctx, int64_t n, const void *inv_h3, void 
                               const void *rhs0, void *x, int hints)
 {
     OpMinresUpdate<T> op{(T *)v_next, (const T *)v_curr, (const T *)w_curr, (const T *)w_prev, (T *)w_next, (T *)x,
-                         *(const T *)inv_h3, w_curr ? *(const T *)neg_h1 : T(0), w_prev ? *(const T *)neg_h0 : T(0), *(const T *)inv_h2,
-                         *(const T *)rhs0, hints};
+                         coef_val(*(const T *)inv_h3), coef_val(w_curr ? *(const T *)neg_h1 : T(0)), coef_val(w_prev ? *(const T *)neg_h0 : T(0)),
+                         coef_val(*(const T *)inv_h2), coef_val(*(const T *)rhs0), hints};
     const bool vec = mik_aligned16(v_next) && mik_aligned16(v_curr) && mik_aligned16(w_next) && mik_aligned16(x) &&
                      (!w_curr || mik_aligned16(w_curr)) && (!w_prev || mik_aligned16(w_prev));
     return launch_map<T>(ctx, n, op, vec, (T *)nullptr, nullptr);

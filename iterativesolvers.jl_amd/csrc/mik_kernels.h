@@ -570,12 +570,12 @@ template <typename T> struct OpCgUpdate {
 //   -- src/minres.jl:104+107 (Lanczos three-term step + projection) and :109+112 (orthogonalise + norm)
 template <typename T> struct OpAxpyDot {
     static constexpr bool REDUCE = true;
-    const T *x; T *y; const T *z; T alpha;          // z may alias y's storage only as "null = y itself"
+    const T *x; T *y; const T *z; Coef<T> alpha;    // z may alias y's storage only as "null = y itself"
     int nt = 0;                                       // bit 0: x is streamed (not needed again soon)
     __device__ __forceinline__ void apply(int64_t i, T &acc) const
     {
         T yv = y[i];
-        if (x) { T t = alpha * x[i]; yv = yv + t; y[i] = yv; }
+        if (x) { T t = alpha.get() * x[i]; yv = yv + t; y[i] = yv; }
         T p = (z ? z[i] : yv) * yv; acc = acc + p;
     }
     __device__ __forceinline__ void apply_vec(int64_t i, T &acc) const
@@ -585,8 +585,9 @@ template <typename T> struct OpAxpyDot {
         if (z) zv = vload(z + i);
         if (x) {
             auto xv = (nt & 1) ? vload_nt(x + i) : vload(x + i);
+            const T a = alpha.get();
 #pragma unroll
-            for (int e = 0; e < VT<T>::W; ++e) { T t = alpha * el<T>(xv, e); el<T>(yv, e) = el<T>(yv, e) + t; }
+            for (int e = 0; e < VT<T>::W; ++e) { T t = a * el<T>(xv, e); el<T>(yv, e) = el<T>(yv, e) + t; }
             vstore(y + i, yv);
         }
 #pragma unroll
@@ -601,17 +602,17 @@ template <typename T> struct OpMinresUpdate {
     static constexpr bool REDUCE = false;
     T *__restrict__ v_next; const T *__restrict__ v_curr; const T *__restrict__ w_curr; const T *__restrict__ w_prev;
     T *__restrict__ w_next; T *__restrict__ x;
-    T inv_h3, neg_h1, neg_h0, inv_h2, rhs0;
+    Coef<T> inv_h3, neg_h1, neg_h0, inv_h2, rhs0;     // host values, or left on the device by the iteration's own scalar kernel (mik_minres_step)
     int nt = 0;                                       // bit 0: x streamed, bit 1: w_prev streamed (dead afterwards)
     __device__ __forceinline__ void apply(int64_t i, T &) const
     {
-        v_next[i] = v_next[i] * inv_h3;
+        v_next[i] = v_next[i] * inv_h3.get();
         T w = v_curr[i];
-        if (w_curr) { T t = neg_h1 * w_curr[i]; w = w + t; }
-        if (w_prev) { T t = neg_h0 * w_prev[i]; w = w + t; }
-        w = w * inv_h2;
+        if (w_curr) { T t = neg_h1.get() * w_curr[i]; w = w + t; }
+        if (w_prev) { T t = neg_h0.get() * w_prev[i]; w = w + t; }
+        w = w * inv_h2.get();
         w_next[i] = w;
-        T t = rhs0 * w; x[i] = x[i] + t;
+        T t = rhs0.get() * w; x[i] = x[i] + t;
     }
     __device__ __forceinline__ void apply_vec(int64_t i, T &) const
     {
@@ -620,15 +621,16 @@ template <typename T> struct OpMinresUpdate {
         typename VT<T>::vec wc, wp;
         if (w_curr) wc = vload(w_curr + i);
         if (w_prev) wp = (nt & 2) ? vload_nt(w_prev + i) : vload(w_prev + i);
+        const T c3 = inv_h3.get(), c1 = w_curr ? neg_h1.get() : T(0), c0 = w_prev ? neg_h0.get() : T(0), c2 = inv_h2.get(), cr = rhs0.get();
 #pragma unroll
         for (int e = 0; e < VT<T>::W; ++e) {
-            el<T>(vn, e) = el<T>(vn, e) * inv_h3;
+            el<T>(vn, e) = el<T>(vn, e) * c3;
             T we = el<T>(w, e);
-            if (w_curr) { T t = neg_h1 * el<T>(wc, e); we = we + t; }
-            if (w_prev) { T t = neg_h0 * el<T>(wp, e); we = we + t; }
-            we = we * inv_h2;
+            if (w_curr) { T t = c1 * el<T>(wc, e); we = we + t; }
+            if (w_prev) { T t = c0 * el<T>(wp, e); we = we + t; }
+            we = we * c2;
             el<T>(w, e) = we;
-            T t = rhs0 * we; el<T>(xv, e) = el<T>(xv, e) + t;
+            T t = cr * we; el<T>(xv, e) = el<T>(xv, e) + t;
         }
         vstore(v_next + i, vn); vstore(w_next + i, w);
         if (nt & 1) vstore_nt(x + i, xv); else vstore(x + i, xv);
@@ -1274,12 +1276,16 @@ template <typename T> struct BicgGamma { T g[8]; };
 template <typename T, bool VEC>
 __global__ __launch_bounds__(MIK_BLOCK) void k_bicg_mr(int64_t n, int64_t nseg, int l, T *__restrict__ us, int64_t ldu,
                                                        T *__restrict__ rs, int64_t ldr, T *__restrict__ x, BicgGamma<T> gm,
-                                                       T *__restrict__ seg_out)
+                                                       T *__restrict__ seg_out, const T *__restrict__ gamma_dev)
 {
     constexpr int W = VT<T>::W;
     constexpr int L = MIK_RED_L;
     constexpr int64_t SEG = (int64_t)MIK_BLOCK * W * L;
     __shared__ T lds4[4];
+    if (gamma_dev) {               // gamma left on the device by the step's own LU solve (mik_bicgstab_step)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gm.g[j] = gamma_dev[j];
+    }
     for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
         const int64_t base = s * SEG + (int64_t)W * threadIdx.x;
         T acc = T(0);

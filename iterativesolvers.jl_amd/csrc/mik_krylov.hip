@@ -2378,8 +2378,8 @@ static int bicg_mr_impl(mik_ctx *ctx, int64_t n, int l, T *us, int64_t ldu, T *r
     for (int j = 0; j < l; ++j) gm.g[j] = gamma[j];
     const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
     const bool vec = mik_aligned16(us) && mik_aligned16(rs) && mik_aligned16(x) && (ldu % VT<T>::W == 0) && (ldr % VT<T>::W == 0);
-    if (vec) hipLaunchKernelGGL((k_bicg_mr<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, l, us, ldu, rs, ldr, x, gm, (T *)ctx->partials);
-    else hipLaunchKernelGGL((k_bicg_mr<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, l, us, ldu, rs, ldr, x, gm, (T *)ctx->partials);
+    if (vec) hipLaunchKernelGGL((k_bicg_mr<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, l, us, ldu, rs, ldr, x, gm, (T *)ctx->partials, (const T *)nullptr);
+    else hipLaunchKernelGGL((k_bicg_mr<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, l, us, ldu, rs, ldr, x, gm, (T *)ctx->partials, (const T *)nullptr);
     MIK_LAUNCH_CHECK(ctx);
     MIK_TRY(finalize_store<T>(ctx, nseg, 1, (T *)ctx->coef));
     T ss;

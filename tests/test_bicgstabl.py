@@ -120,3 +120,37 @@ def test_fused_bicgstab_equals_statement_by_statement(pkg, orc, ctx, l, dtype):
         runs.append((np.array(list(it)), x.to_numpy()))
     assert runs[0][0].size == 30
     assert np.array_equal(runs[0][0], runs[1][0], equal_nan=True) and np.array_equal(runs[0][1], runs[1][1], equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
+def test_singular_mr_system_raises_like_lu(pkg, fused):
+    """A = 2 I, l = 1: the BiCG step lands on the solution (alpha = 1 / 2 exactly), rs = 0, and lu! of the 1 x 1 MR system
+    [rs_2' rs_2] meets a zero pivot -- SingularException in the reference (src/bicgstabl.jl:124), LinAlgError here, from the
+    whole-iteration call (the flag travels through its mirror) as from the statement-by-statement path."""
+    n = 96
+    dA = pkg.HipCSR(n, n, np.arange(1, n + 2), np.arange(1, n + 1), np.full(n, 2.0))
+    b = pkg.HipVector.from_numpy(np.linspace(1.0, 2.0, n))
+    it = pkg.bicgstabl_iterator_(pkg.zerox(dA, b), dA, b, 1, max_mv_products=100, initial_zero=True, fused=fused)
+    with pytest.raises(np.linalg.LinAlgError):
+        list(it)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_whole_iteration_call_with_jacobi_pl(pkg, orc, ctx, dtype):
+    """mik_bicgstab_step with a diagonal Pl (ldiv! after both mul! of the BiCG part, src/bicgstabl.jl:98, :108) against the
+    statement-by-statement path: same history, same x."""
+    A, b = orc.advdiff(10, 200.0)
+    A, b = A.astype(dtype), b.astype(dtype)
+    dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
+    diag = A.to_scipy().diagonal().astype(dtype)
+    sh = (orc.hashed_rhs(A.n) + 0.5).astype(dtype)
+    runs = []
+    for fused in (True, False):
+        x = pkg.HipVector.from_numpy(np.zeros(A.n, dtype))
+        it = pkg.bicgstabl_iterator_(x, dA, pkg.HipVector.from_numpy(b), 2, Pl=pkg.JacobiPrec(pkg.HipVector.from_numpy(diag)), max_mv_products=80,
+                                     reltol=0.0, initial_zero=True, r_shadow=pkg.HipVector.from_numpy(sh), fused=fused)
+        runs.append((np.array(list(it)), x.to_numpy()))
+    assert runs[0][0].size == 20
+    assert np.array_equal(runs[0][0], runs[1][0], equal_nan=True) and np.array_equal(runs[0][1], runs[1][1], equal_nan=True)

@@ -214,3 +214,22 @@ def test_fused_entry_points_against_numpy(pkg, orc, ctx, dtype, n, shift):
             w = w + sc[2] * wp
         w = w * sc[3]
         assert np.array_equal(dvn.to_numpy(), vn * sc[0]) and np.array_equal(dwn.to_numpy(), w) and np.array_equal(dxx.to_numpy(), xx + sc[4] * w)
+
+
+@pytest.mark.gpu
+def test_minres_whole_iteration_call_rescales_the_lanczos_norm(pkg, orc, ctx):
+    """fp32 operator with entries ~1e22: |v_next|^2 overflows a plain sum of squares, so norm(v_next) (src/minres.jl:112) takes
+    the scaled path -- inside mik_minres_step the tail sweep is held back, the host rescales, the scalar kernel and the tail
+    follow.  Same history and x as the statement-by-statement path, and finite."""
+    dtype = np.float32
+    A = orc.laplace(6, 3)
+    A = orc.CSC(A.n, A.colptr, A.rowval, (A.nzval * 1e22).astype(dtype), A.index_base)
+    b = (orc.hashed_rhs(A.n) * 1e22).astype(dtype)
+    dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
+    runs = []
+    for fused in (True, False):
+        x = pkg.HipVector.from_numpy(np.zeros(A.n, dtype))
+        it = pkg.minres_iterable_(x, dA, pkg.HipVector.from_numpy(b), reltol=0.0, initially_zero=True, maxiter=12, fused=fused)
+        runs.append((np.array(list(it)), x.to_numpy()))
+    assert runs[0][0].size == 12 and np.all(np.isfinite(runs[0][0])) and np.all(np.isfinite(runs[0][1]))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
