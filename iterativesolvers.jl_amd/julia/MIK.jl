@@ -14,6 +14,9 @@
 #   gmres!(x, A, b; ...)     src/gmres.jl:184 calls gmres_iterable!(x, A, b; ...) at :200
 #       -> method gmres_iterable!(x::HipVector, A::HipCSR, b::HipVector; ...) returns a
 #          HipGMRESIterable (needed because ArnoldiDecomp pins V to a host Matrix, src/gmres.jl:7,13).
+#   bicgstabl!(x, A, b, l)   src/bicgstabl.jl:181 calls bicgstabl_iterator!(x, A, b, l; ...) at :197 -> HipBiCGStabIterable
+#   minres!(x, A, b)         src/minres.jl:197 calls minres_iterable!(x, A, b; ...) at :208 -> HipMINRESIterable
+#       (one C call per iteration each: mik_bicgstab_step, mik_minres_step)
 #   Generic code paths (any other solver of the package) see HipVector/HipCSR through
 #   mul!, dot, norm, axpy!, rmul!, ldiv!, copyto!, fill!, similar, zero and the broadcast style below (the four
 #   vector-update shapes of src/cg.jl), so the unmodified iterate(::CGIterable) runs on device vectors as well.
@@ -469,6 +472,138 @@ function Base.iterate(g::HipGMRESIterable{T}, iteration::Int = IterativeSolvers.
     done[] != 0 && return nothing
     refresh!(g)
     g.residual.current, iteration + 1
+end
+
+# ---- BiCGStabIterable ---------------------------------------------------------------------------
+# bicgstabl!(x, A, b, l; ...) (src/bicgstabl.jl:181-219) calls bicgstabl_iterator!(x, A, b, l; ...) at :197; the reference's
+# iterable keeps rs / us as host Matrices (:39-40), so the device path returns its own iterable with the fields the driver
+# reads (`mv_products`, `residual`, `x`) and one C call per outer iteration: rho, beta, sigma, alpha, M, gamma, omega stay
+# on the device (include/mik.h, mik_bicgstab_step).  `r_shadow` replaces rand(T, n) (:38) when reproducibility is wanted.
+mutable struct HipBiCGStabIterable{T, Tx<:HipVector{T}}
+    handle::Ptr{Cvoid}
+    A::HipCSR{T}
+    l::Int
+    x::Tx
+    r_shadow::Tx
+    rs::Tx                 # n x (l + 1), column-major, leading dimension ld
+    us::Tx
+    ld::Int
+    max_mv_products::Int
+    mv_products::Int
+    tol::T
+    residual::T
+    Pl
+end
+# column j (1-based) of a device block: a view, no finalizer
+column(block::HipVector{T}, ld::Int, n::Int, j::Int) where {T} = HipVector{T}(block.ptr + (j - 1) * ld * sizeof(T), n, block.ctx, Val(:unowned))
+
+function IterativeSolvers.bicgstabl_iterator!(x::HipVector{T}, A::HipCSR{T}, b::HipVector{T}, l::Int = 2;
+        Pl = Identity(), max_mv_products = size(A, 2), abstol::Real = zero(T), reltol::Real = sqrt(eps(T)), initial_zero = false,
+        r_shadow::HipVector{T} = HipVector(rand(T, x.n), x.ctx)) where {T}
+    (Pl isa Identity || Pl isa HipJacobi) || throw(MikError(Cint(5), "bicgstabl_iterator!", "Pl must be Identity() or HipJacobi on the device path"))
+    1 <= l <= 4 || throw(MikError(Cint(5), "bicgstabl_iterator!", "l must be 1 ... 4 on the device path"))
+    n = x.n
+    ld = cld(n, 64) * 64
+    rs = HipVector{T}(undef, ld * (l + 1), x.ctx)                            # :39
+    us = fill!(HipVector{T}(undef, ld * (l + 1), x.ctx), zero(T))            # :40
+    residual = column(rs, ld, n, 1)
+    mv_products = 0
+    if initial_zero
+        copyto!(residual, b)                                                 # :46
+    else
+        mul!(residual, A, x)                                                 # :48
+        xpby!(b, -one(T), residual)                                          # residual .= b .- residual  :49
+        mv_products += 1
+    end
+    Pl isa HipJacobi && ldiv!(residual, Pl, residual)                        # :55
+    nrm = norm(residual)                                                     # :61
+    tolerance = max(T(reltol) * nrm, T(abstol))                              # :69
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    pl = Pl isa HipJacobi ? Pl.diagonal.ptr : C_NULL
+    check(ccall((:mik_bicgstab_create, libmik), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
+        x.ctx.handle, A.handle, l, x.ptr, rs.ptr, ld, us.ptr, ld, r_shadow.ptr, pl, h), "mik_bicgstab_create", x.ctx.handle)
+    it = HipBiCGStabIterable{T, typeof(x)}(h[], A, l, x, r_shadow, rs, us, ld, Int(max_mv_products), mv_products, tolerance, nrm, Pl)
+    finalizer(i -> alive(i.x.ctx) && ccall((:mik_bicgstab_destroy, libmik), Cint, (Ptr{Cvoid},), i.handle), it)
+    it
+end
+
+IterativeSolvers.converged(it::HipBiCGStabIterable) = it.residual ≤ it.tol                    # src/bicgstabl.jl:75
+IterativeSolvers.start(::HipBiCGStabIterable) = 0
+IterativeSolvers.done(it::HipBiCGStabIterable, iteration::Int) = it.mv_products ≥ it.max_mv_products || IterativeSolvers.converged(it)   # :77
+
+# iterate(it, iteration) -- src/bicgstabl.jl:79-134, one call
+function Base.iterate(it::HipBiCGStabIterable{T}, iteration::Int = IterativeSolvers.start(it)) where {T}
+    IterativeSolvers.done(it, iteration) && return nothing
+    res = Ref{T}()
+    code = ccall((:mik_bicgstab_step, libmik), Cint, (Ptr{Cvoid}, Ref{T}), it.handle, res)
+    code == 1 && throw(LinearAlgebra.SingularException(0))                   # lu! at :124
+    check(code, "mik_bicgstab_step", it.x.ctx.handle)
+    it.mv_products += 2 * it.l                                               # :115
+    it.residual = res[]                                                      # :132
+    it.residual, iteration + 1
+end
+
+# ---- MINRESIterable -----------------------------------------------------------------------------
+# minres!(x, A, b; ...) (src/minres.jl:197-230) calls minres_iterable!(x, A, b; ...) at :208; MINRESIterable wants DenseVector
+# work vectors (:6), so the device path returns its own iterable with the fields the driver reads (`mv_products`, `x`) and one
+# C call per iteration (include/mik.h, mik_minres_step): H, rhs and the rotations stay on the device.
+mutable struct HipMINRESIterable{T, Tx<:HipVector{T}}
+    handle::Ptr{Cvoid}
+    A::HipCSR{T}
+    skew_hermitian::Bool
+    x::Tx
+    v_prev::Tx
+    v_curr::Tx
+    v_next::Tx
+    w_prev::Tx
+    w_curr::Tx
+    w_next::Tx
+    mv_products::Int
+    maxiter::Int
+    tol::T
+    resnorm::T
+end
+
+function IterativeSolvers.minres_iterable!(x::HipVector{T}, A::HipCSR{T}, b::HipVector{T};
+        initially_zero::Bool = false, skew_hermitian::Bool = false, abstol::Real = zero(T), reltol::Real = sqrt(eps(T)), maxiter = size(A, 2)) where {T}
+    v_prev = similar(x)
+    v_curr = copyto!(similar(x), b)                                          # :47-48
+    v_next = similar(x)
+    w_prev = zero(x); w_curr = zero(x); w_next = zero(x)                     # :51-53 (similar there; zeros here: read only once written)
+    mv_products = 0
+    if !initially_zero
+        mul!(v_next, A, x)                                                   # :60
+        axpy!(-one(T), v_next, v_curr)                                       # :61
+        mv_products = 1
+    end
+    resnorm = norm(v_curr)                                                   # :65
+    tolerance = max(T(reltol) * resnorm, T(abstol))                          # :66
+    rmul!(v_curr, inv(resnorm))                                              # :74
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:mik_minres_create, libmik), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cint, Ref{Ptr{Cvoid}}),
+        x.ctx.handle, A.handle, x.ptr, v_prev.ptr, v_curr.ptr, v_next.ptr, w_prev.ptr, w_curr.ptr, w_next.ptr, Float64(resnorm), skew_hermitian ? 1 : 0, h),
+        "mik_minres_create", x.ctx.handle)
+    m = HipMINRESIterable{T, typeof(x)}(h[], A, skew_hermitian, x, v_prev, v_curr, v_next, w_prev, w_curr, w_next, mv_products, Int(maxiter), tolerance, resnorm)
+    finalizer(i -> alive(i.x.ctx) && ccall((:mik_minres_destroy, libmik), Cint, (Ptr{Cvoid},), i.handle), m)
+    m
+end
+
+IterativeSolvers.converged(m::HipMINRESIterable) = m.resnorm ≤ m.tol                          # src/minres.jl:89
+IterativeSolvers.start(::HipMINRESIterable) = 1                                                # :91
+IterativeSolvers.done(m::HipMINRESIterable, iteration::Int) = iteration > m.maxiter || IterativeSolvers.converged(m)   # :93
+
+# iterate(m, iteration) -- src/minres.jl:95-159, one call
+function Base.iterate(m::HipMINRESIterable{T}, iteration::Int = IterativeSolvers.start(m)) where {T}
+    IterativeSolvers.done(m, iteration) && return nothing
+    res = Ref{T}()
+    check(ccall((:mik_minres_step, libmik), Cint, (Ptr{Cvoid}, Int64, Ref{T}), m.handle, iteration, res), "mik_minres_step", m.x.ctx.handle)
+    m.v_prev, m.v_curr, m.v_next = m.v_curr, m.v_next, m.v_prev              # :145 (the handle rotates its pointers alike)
+    m.w_prev, m.w_curr, m.w_next = m.w_curr, m.w_next, m.w_prev              # :146
+    m.resnorm = res[]                                                        # :154
+    m.mv_products += 1
+    m.resnorm, iteration + 1
 end
 
 # zerox(A, b) (src/common.jl:18-23) already works: similar(b, T, size(A, 2)) + fill! are defined above.

@@ -70,6 +70,11 @@ def test_call_sequences_equal_the_python_mirror():
     assert jl("IterativeSolvers.gmres_iterable!") == ["mik_gmres_create", "mik_gmres_create_op"] == py_calls("GMRESIterable", "__init__")
     assert jl("Base.iterate(g::HipGMRESIterable") == ["mik_gmres_iterate"] == py_calls("GMRESIterable", "iterate")
     assert jl("refresh!(g::HipGMRESIterable") == ["mik_gmres_state"] == py_calls("GMRESIterable", "_refresh")
+    # the widened solvers: one C call per iteration on both sides (the Python mirror keeps the statement-by-statement path next to it)
+    assert jl("IterativeSolvers.bicgstabl_iterator!") == ["mik_bicgstab_create"] == py_calls("BiCGStabIterable", "__init__")
+    assert jl("Base.iterate(it::HipBiCGStabIterable") == ["mik_bicgstab_step"] == py_calls("BiCGStabIterable", "iterate")[:1]
+    assert jl("IterativeSolvers.minres_iterable!") == ["mik_minres_create"] == py_calls("MINRESIterable", "__init__")
+    assert jl("Base.iterate(m::HipMINRESIterable") == ["mik_minres_step"] == py_calls("MINRESIterable", "iterate")[:1]
 
 
 def test_shim_has_no_silent_scalar_fallback_and_reference_defaults():
