@@ -25,6 +25,10 @@ args = ap.parse_args()
 pkg = graft.load_package()
 import torch  # noqa: E402
 
+for kv in os.environ.get("MIK_KNOBS", "").split(","):            # development knobs for A/B runs
+    if kv:
+        pkg.lib().mik_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
+
 t0 = time.perf_counter()
 if args.shape:
     shape = tuple(int(v) for v in args.shape.split(","))
