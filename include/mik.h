@@ -62,7 +62,7 @@
 extern "C" {
 #endif
 
-#define MIK_ABI_VERSION 2
+#define MIK_ABI_VERSION 3   /* 3 (round 3): mik_csr_pack and the knob setters left this header (include/mik_dev.h); additions only otherwise */
 
 /* status codes */
 enum {
