@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 profiling recipe (run on the GPU box through gpurun):  scripts/prof_r03.sh [what...]   what = bench c5 gmres s27
 #   rocprofv3 --kernel-trace --stats           -> gpurun_out/r03/<what>/trace
-#   separate --pmc passes (never combined with other trace domains; <= 8 SQ / 4 TCC counters per pass)
+#   separate --pmc passes (never combined with other trace domains; <= 8 SQ / 4 TCC counters per pass; PMC=0 skips them for `bench`)
 # scripts/prof_collect.py then condenses everything into the small CSV / txt / json files that are committed under profiles/.
 # bench: the driver's command, so the CSR loop (k_spmv_rowgather, the contract's roofline) and the default loop (k_spmv_sdiab2)
 # are both in the trace with the shipped cache hints.  c5: one directory per configs[4] stand-in, so that the traffic of a kernel
@@ -23,6 +23,7 @@ for w in $WHAT; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -o run -- python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-gmres --no-config5 --stencil27 0 > $D/trace.log 2>&1
   grep "^{" $D/trace.log | tail -1 > $D/bench_under_rocprof.json
   B="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-parity --no-gmres --no-config5 --stencil27 0"
+  [ "${PMC:-1}" = "0" ] && continue            # PMC=0: the kernel trace only
   pmc $D/pmc_fetch FETCH_SIZE -- $B
   pmc $D/pmc_write WRITE_SIZE -- $B
   pmc $D/pmc_l2 TCC_HIT_sum TCC_MISS_sum -- $B
