@@ -1,8 +1,8 @@
 """Instruction mix of the SpMV kernels as hipcc emits them for gfx950 (no GPU needed): compiles csrc/mik_core.hip to
 device assembly and counts, per kernel body, the vector-memory / LDS / VALU / SALU / wait instructions -- the evidence behind
-"what the kernel issues" in DESIGN.md (the dynamic counts are in profiles/r02_bench_pmc_summary.txt: SQ_INSTS_*).
+"what the kernel issues" in DESIGN.md (the dynamic counts are in profiles/r03_bench_pmc_summary.txt, r03_s27_pmc_summary.txt: SQ_INSTS_*).
 
-    python scripts/isa_mix.py > profiles/r02_isa_mix.txt
+    python scripts/isa_mix.py > profiles/r03_isa_mix.txt
 """
 import collections
 import os
@@ -14,10 +14,11 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "iterativesolvers.jl_amd", "csrc", "mik_core.hip")
 WANT = {"k_spmv_sdiab2<double, true, true, 7, 3>  (two rows per lane; both paths)": "_Z13k_spmv_sdiab2IdLb1ELb1ELi7ELi3EE",
-        "k_cg_head_sdiab2<double, 7, 3, 8>  (development knob 25)": "_Z16k_cg_head_sdiab2IdLi7ELi3ELi8EE",
         "k_spmv_sdiab<double, true, true, 2, 7, 3>  (both paths: compiled-in class and slot by slot)": "_Z12k_spmv_sdiabIdLb1ELb1ELi2ELi7ELi3EE",
         "k_spmv_sdiac<double, true, true, 2>": "_Z12k_spmv_sdiacIdLb1ELb1ELi2EE", "k_spmv_sdia<double, true, true>": "_Z11k_spmv_sdiaIdLb1ELb1EE", "k_spmv_rowgather<double, true, true>": "_Z16k_spmv_rowgatherIdLb1ELb1EE",
-        "k_spmv_rowblock<double, true, true, true, false>": "_Z15k_spmv_rowblockIdLb1ELb1ELb1ELb0EE", "k_spmv_sell8<double, true, true>": "_Z12k_spmv_sell8IdLb1ELb1EE"}
+        "k_spmv_rowblock<double, true, true, true, false>": "_Z15k_spmv_rowblockIdLb1ELb1ELb1ELb0EE",
+        "k_spmv_sdiaw2<double, true, true>  (wide slice-constant layout, two rows per lane; all paths)": "_Z13k_spmv_sdiaw2IdLb1ELb1EE",
+        "k_spmv_jds<float, false, true, false>  (jagged slices)": "_Z10k_spmv_jdsIfLb0ELb1ELb0EE"}
 with tempfile.TemporaryDirectory() as tmp:
     asm = os.path.join(tmp, "core.s")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S",
