@@ -154,3 +154,32 @@ def test_whole_iteration_call_with_jacobi_pl(pkg, orc, ctx, dtype):
         runs.append((np.array(list(it)), x.to_numpy()))
     assert runs[0][0].size == 20
     assert np.array_equal(runs[0][0], runs[1][0], equal_nan=True) and np.array_equal(runs[0][1], runs[1][1], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_whole_iteration_calls_validate_their_arguments(pkg, ctx):
+    """mik_bicgstab_create / mik_minres_create: status codes instead of crashes for what a host can get wrong"""
+    import ctypes as C
+    L = pkg.lib()
+    n = 64
+    dA = pkg.HipCSR(n, n, np.arange(1, n + 2), np.arange(1, n + 1), np.full(n, 2.0))
+    v = [pkg.HipVector(n, np.float64) for _ in range(8)]
+    blk = pkg.HipMatrix(n, 6, np.float64, v[0].ctx)
+    P = lambda o: C.c_void_p(o.ptr)                                            # noqa: E731
+    h = C.c_void_p()
+    args = lambda l, A=dA.handle, x=P(v[0]): (v[0].ctx.handle, A, l, x, P(blk.col(0)), blk.ld, P(blk.col(0)), blk.ld, P(v[1]), None, C.byref(h))   # noqa: E731
+    assert L.mik_bicgstab_create(*args(5)) == 5 and not h.value               # l > 4: MIK_ERR_NOTIMPL (the L1 entry points take over)
+    assert L.mik_bicgstab_create(*args(0)) == 5
+    assert L.mik_bicgstab_create(*args(2, A=None)) != 0 and not h.value
+    assert L.mik_bicgstab_create(*args(2, x=None)) == 1 and not h.value
+    assert L.mik_bicgstab_step(None, None) == 1 and L.mik_bicgstab_destroy(None) == 0
+    rect = pkg.HipCSR(2, 3, np.array([1, 2, 3, 3]), np.array([1, 2]), np.array([1.0, 1.0]))
+    assert L.mik_bicgstab_create(*args(2, A=rect.handle)) == 3                 # MIK_ERR_MISMATCH: not square
+    m = lambda A=dA.handle, x=P(v[0]): (v[0].ctx.handle, A, x, P(v[1]), P(v[2]), P(v[3]), P(v[4]), P(v[5]), P(v[6]), 1.0, 0, C.byref(h))   # noqa: E731
+    assert L.mik_minres_create(*m(A=rect.handle)) == 3 and not h.value
+    assert L.mik_minres_create(*m(x=None)) == 1 and not h.value
+    assert L.mik_minres_create(*m()) == 0 and h.value
+    out = np.zeros(1)
+    assert L.mik_minres_step(h, 0, out.ctypes.data_as(C.c_void_p)) == 1       # iteration counts from 1 (src/minres.jl:91)
+    assert L.mik_minres_step(h, 1, None) == 1
+    assert L.mik_minres_destroy(h) == 0 and L.mik_minres_destroy(None) == 0
