@@ -304,9 +304,21 @@ template <typename T> struct OpXpbyX {
 };
 
 // r .-= alpha .* c; partial sums of r.^2        -- src/cg.jl:59-62 (the x half of :58 rides on OpXpbyX)
-template <typename T> struct OpCgUpdateR {
+// alpha of a row-partitioned step formed by every thread itself from the P per-rank partial sums of dot(u, c) (rank order) and
+// the residual norm: alpha = res^2 / dot(u, c) (src/cg.jl:55) -- the arithmetic of k_cgd_alpha without its launch
+template <typename T> struct CoefAlphaRanks {
+    const T *all; int nranks; const T *res;
+    __device__ __forceinline__ T get() const
+    {
+        T tot = all[0];
+        for (int p = 1; p < nranks; ++p) tot = tot + all[p];
+        const T r = *res;
+        return (r * r) / tot;
+    }
+};
+template <typename T, typename C = Coef<T>> struct OpCgUpdateR {
     static constexpr bool REDUCE = true;
-    T *__restrict__ r; const T *__restrict__ c; Coef<T> alpha; int nt = 0;        // nt & 2: c streamed; nt & 8 / 16: r load / store streamed
+    T *__restrict__ r; const T *__restrict__ c; C alpha; int nt = 0;              // nt & 2: c streamed; nt & 8 / 16: r load / store streamed
     __device__ __forceinline__ void apply(int64_t i, T &acc) const
     {
         T s = alpha.get() * c[i]; T rn = r[i] - s; r[i] = rn;

@@ -1918,6 +1918,23 @@ __global__ __launch_bounds__(64) void k_cgd_fin_slot(const T *__restrict__ S, in
     if (level2_sum_spread(S, m, fs, tot)) *slot = tot;
 }
 
+// k_cgd_fin_slot for |r|^2 that also does what k_cgd_alpha did for this step (whose sweep formed alpha by itself: CoefAlphaRanks):
+// the pending-x flag cleared, dot(u, c) and alpha stored for the head of the next step -- one launch less per step
+template <typename T>
+__global__ __launch_bounds__(64) void k_cgd_fin_slot_alpha(const T *__restrict__ S, int64_t m, T *__restrict__ slot, const int *__restrict__ done,
+                                                           FinScratch<T> *fs, const T *__restrict__ dot_all, int nranks, CgDev<T> *d)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) d->x_pending = 0;     // the sweep over u of this step's head applied it (OpXpbyX)
+    if (done && *done) return;
+    T tot;
+    if (level2_sum_spread(S, m, fs, tot)) {
+        *slot = tot;
+        const T dt = rank_sum(dot_all, nranks);
+        d->dot_uc = dt;
+        d->alpha = (d->res * d->res) / dt;
+    }
+}
+
 template <typename T> __global__ void k_cgd_alpha(const T *__restrict__ dot_all, int nranks, CgDev<T> *d)
 {
     d->x_pending = 0;                          // the sweep over u of this step's head applied it (OpXpbyX)
@@ -2175,6 +2192,14 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     case 2: {  // step C
+        if (bs.fuse_x && ctx->tuning[26] == 0) {   // alpha inside the sweep, its bookkeeping inside the finaliser (knob 26 = 1: the separate k_cgd_alpha)
+            OpCgUpdateR<T, CoefAlphaRanks<T>> up{r, c, CoefAlphaRanks<T>{(const T *)it->dot_all, it->nranks, &d->res}, cg_stream_hints(ctx, true, bs.A) >> 3};
+            MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)bs.seg_vec, done)));
+            hipLaunchKernelGGL((k_cgd_fin_slot_alpha<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)bs.seg_vec, nseg, rr_slot, done,
+                               (FinScratch<T> *)bs.fin, (const T *)it->dot_all, it->nranks, d);
+            MIK_LAUNCH_CHECK(ctx);
+            return MIK_OK;
+        }
         hipLaunchKernelGGL((k_cgd_alpha<T>), dim3(1), dim3(1), 0, ctx->stream, (const T *)it->dot_all, it->nranks, d);
         MIK_LAUNCH_CHECK(ctx);
         if (bs.fuse_x) {
