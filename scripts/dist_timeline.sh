@@ -1,13 +1,13 @@
 #!/bin/bash
 # Steady-state kernel timeline of ONE step of the row-partitioned CG with a real RCCL halo exchange on a single GPU (z-periodic
-# slab: the rank is its own neighbour; MIK_DIST_SELF_HALO=1) -> gpurun_out/r02/dist_selfhalo_timeline.txt
+# slab: the rank is its own neighbour; MIK_DIST_SELF_HALO=1) -> gpurun_out/r03/dist_selfhalo_timeline.txt
 #   bash scripts/dist_timeline.sh        (on the GPU box, through gpurun)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$R/gpurun_out/r02
+OUT=$R/gpurun_out/r03
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/dist_tl
-MIK_DIST_SELF_HALO=1 rocprofv3 --kernel-trace --output-format csv -d /tmp/dist_tl -o run -- python $R/bench.py --gpus 1 --force-dist --steps 200 --warmup 5 > /tmp/dist_tl.log 2>&1
+MIK_DIST_SELF_HALO=1 MIK_DIST_NZ=64 rocprofv3 --kernel-trace --output-format csv -d /tmp/dist_tl -o run -- python $R/bench.py --gpus 1 --force-dist --grid 512 --steps 200 --warmup 5 > /tmp/dist_tl.log 2>&1
 T=$(find /tmp/dist_tl -name "*kernel_trace.csv" | head -1)
 python - "$T" > $OUT/dist_selfhalo_timeline.txt <<'PY'
 import csv, sys
@@ -17,7 +17,7 @@ mid = len(rows) // 2
 while "OpCgUpdateR" not in rows[mid]["Kernel_Name"]:
     mid += 1
 t0 = int(rows[mid]["Start_Timestamp"])
-print("one steady-state step of mik_cgd_iterate_many, 256^3 rows on one MI355X, halo (2 x 256^2 doubles) exchanged with the rank itself over RCCL")
+print("one steady-state step of mik_cgd_iterate_many, one configs[3] slab (512 x 512 x 64 rows) on one MI355X, halo (2 x 512^2 doubles) exchanged with the rank itself over RCCL")
 print("(rocprofv3 --kernel-trace; start offset and duration in us; queue = HIP stream: the RCCL kernel runs on the library's side stream)\n")
 print(f"{'kernel':58s} {'queue':>5s} {'start':>8s} {'dur':>7s}")
 n = 0
