@@ -407,6 +407,55 @@ template <typename T> struct OpAxpy {
     }
 };
 
+// BiCGStab(l), the two block updates of the BiCG part in one launch each (mik_bicgstab_step) -- per element exactly OpXpby /
+// OpAxpy column by column:
+//   us[:, 1:j] .= rs[:, 1:j] .- beta .* us[:, 1:j]                                  -- src/bicgstabl.jl:93   (neg_beta = -beta)
+//   rs[:, 1:j] .-= alpha .* us[:, 2:j+1];  x .+= alpha .* us[:, 1]                   -- :103, :111 (x does not depend on :107)
+template <typename T> struct OpBicgU {
+    static constexpr bool REDUCE = false;
+    T *__restrict__ us; int64_t ldu; const T *__restrict__ rs; int64_t ldr; int ncols; Coef<T> neg_beta;
+    __device__ __forceinline__ void apply(int64_t i, T &) const
+    {
+        const T b = neg_beta.get();
+        for (int q = 0; q < ncols; ++q) { T *u = us + q * ldu; T t = b * u[i]; u[i] = rs[q * ldr + i] + t; }
+    }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &) const
+    {
+        const T b = neg_beta.get();
+        for (int q = 0; q < ncols; ++q) {
+            T *u = us + q * ldu;
+            auto xv = vload(rs + q * ldr + i); auto yv = vload<T>(u + i);
+#pragma unroll
+            for (int e = 0; e < VT<T>::W; ++e) { T t = b * el<T>(yv, e); el<T>(yv, e) = el<T>(xv, e) + t; }
+            vstore(u + i, yv);
+        }
+    }
+};
+template <typename T> struct OpBicgR {
+    static constexpr bool REDUCE = false;
+    const T *__restrict__ us; int64_t ldu; T *__restrict__ rs; int64_t ldr; int ncols; T *__restrict__ x; Coef<T> neg_alpha, alpha;
+    __device__ __forceinline__ void apply(int64_t i, T &) const
+    {
+        const T na = neg_alpha.get(), a = alpha.get();
+        for (int q = 0; q < ncols; ++q) { T t = na * us[(q + 1) * ldu + i]; rs[q * ldr + i] = rs[q * ldr + i] + t; }
+        { T t = a * us[i]; x[i] = x[i] + t; }
+    }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &) const
+    {
+        const T na = neg_alpha.get(), a = alpha.get();
+        for (int q = 0; q < ncols; ++q) {
+            auto xv = vload(us + (q + 1) * ldu + i); auto yv = vload<T>(rs + q * ldr + i);
+#pragma unroll
+            for (int e = 0; e < VT<T>::W; ++e) { T t = na * el<T>(xv, e); el<T>(yv, e) = el<T>(yv, e) + t; }
+            vstore(rs + q * ldr + i, yv);
+        }
+        auto uv = vload(us + i); auto xx = vload<T>(x + i);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) { T t = a * el<T>(uv, e); el<T>(xx, e) = el<T>(xx, e) + t; }
+        vstore(x + i, xx);
+    }
+};
+
 // y .-= x                        -- src/cg.jl:138, src/gmres.jl:246
 template <typename T> struct OpSub {
     static constexpr bool REDUCE = false;

@@ -205,31 +205,26 @@ template <typename T> static int bicg_step_impl(mik_bicgstab *it, T *residual)
         return launch_map<T>(ctx, n, op, mik_aligned16(a) && mik_aligned16(b), (T *)ctx->partials, nullptr);
     };
     auto ldiv = [&](T *v) { return it->pl_diag ? mik_divide(ctx, it->dtype, n, v, it->pl_diag, v) : MIK_OK; };
+    const bool blockvec = mik_aligned16(us) && mik_aligned16(rs) && mik_aligned16(x) && (it->ldu % VT<T>::W == 0) && (it->ldr % VT<T>::W == 0);
     for (int j = 0; j < l; ++j) {                                                            // BiCG part  :88
         MIK_TRY(dot_partials(sh, col(rs, it->ldr, j)));                                      // :89
         hipLaunchKernelGGL((k_bicg_fin_rho<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, d, j == 0 ? 1 : 0);
         MIK_LAUNCH_CHECK(ctx);
-        for (int q = 0; q <= j; ++q) {                                                       // us = rs - beta * us  :93
-            T *uq = col(us, it->ldu, q);
-            const T *rq = col(rs, it->ldr, q);
-            OpXpby<T> op{rq, uq, coef_ptr<T>(&d->neg_beta)};
-            MIK_TRY((launch_map<T>(ctx, n, op, mik_aligned16(rq) && mik_aligned16(uq), (T *)nullptr, nullptr)));
+        {                                                                                    // us = rs - beta * us  :93, all j + 1 columns in one launch
+            OpBicgU<T> op{us, it->ldu, rs, it->ldr, j + 1, coef_ptr<T>(&d->neg_beta)};
+            MIK_TRY((launch_map<T>(ctx, n, op, blockvec, (T *)nullptr, nullptr)));
         }
         MIK_TRY(mik_spmv_launch<T>(ctx, it->A, col(us, it->ldu, j), col(us, it->ldu, j + 1), false, nullptr, nullptr));   // :97
         MIK_TRY(ldiv(col(us, it->ldu, j + 1)));                                              // :98
         MIK_TRY(dot_partials(sh, col(us, it->ldu, j + 1)));                                  // :100
         hipLaunchKernelGGL((k_bicg_fin_sigma<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, d);
         MIK_LAUNCH_CHECK(ctx);
-        for (int q = 0; q <= j; ++q) {                                                       // rs -= alpha * us  :103
-            const T *uq = col(us, it->ldu, q + 1);
-            T *rq = col(rs, it->ldr, q);
-            OpAxpy<T> op{uq, rq, coef_ptr<T>(&d->neg_alpha)};
-            MIK_TRY((launch_map<T>(ctx, n, op, mik_aligned16(uq) && mik_aligned16(rq), (T *)nullptr, nullptr)));
+        {                                                                                    // rs -= alpha * us  :103 and x += alpha * us[:, 1]  :111 (independent of :107) in one launch
+            OpBicgR<T> op{us, it->ldu, rs, it->ldr, j + 1, x, coef_ptr<T>(&d->neg_alpha), coef_ptr<T>(&d->alpha)};
+            MIK_TRY((launch_map<T>(ctx, n, op, blockvec, (T *)nullptr, nullptr)));
         }
         MIK_TRY(mik_spmv_launch<T>(ctx, it->A, col(rs, it->ldr, j), col(rs, it->ldr, j + 1), false, nullptr, nullptr));   // :107
         MIK_TRY(ldiv(col(rs, it->ldr, j + 1)));                                              // :108
-        OpAxpy<T> ax{us, x, coef_ptr<T>(&d->alpha)};                                         // x += alpha * us[:, 1]  :111
-        MIK_TRY((launch_map<T>(ctx, n, ax, mik_aligned16(us) && mik_aligned16(x), (T *)nullptr, nullptr)));
     }
     // MR part: M = rs' * rs (:120) in one pass, gamma (:123-125), the three updates and the norm (:127-132) in one sweep
     switch (l + 1) {
