@@ -33,6 +33,77 @@ struct BicgMirror {                 // pinned, written by the last kernel of a s
     unsigned long long seq;
 };
 
+// k_map whose coefficient comes from the level-2 sum of the PRODUCER's segment sums, formed by every workgroup itself (m <= 1024
+// partials: block_level2_256 = the tree of k_finalize_store) and turned into the sweep's coefficient by `pro` -- the scalar
+// statement of the reference that sits between the reduction and the sweep; workgroup 0 publishes what later kernels need.
+// One launch instead of reduction finaliser + sweep: at the sizes where an iteration is launch-bound that is where its time goes.
+template <typename T, bool VEC, typename Op, typename Pro>
+__global__ __launch_bounds__(MIK_BLOCK) void k_map_with(int64_t n, int64_t nseg, Op op, Pro pro, const T *__restrict__ part, int m, T *__restrict__ seg_out)
+{
+    constexpr int W = VT<T>::W;
+    constexpr int L = MIK_RED_L;
+    constexpr int64_t SEG = (int64_t)MIK_BLOCK * W * L;
+    __shared__ T lds16[16];
+    __shared__ T lds4[4];
+    const T tot = block_level2_256(part, m, lds16);
+    pro(tot, op, blockIdx.x == 0 && threadIdx.x == 0);
+    for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+        const int64_t base = s * SEG + (int64_t)W * threadIdx.x;
+        T acc = T(0);
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int64_t i = base + (int64_t)l * MIK_BLOCK * W;
+            if (VEC && i + W <= n) {
+                op.apply_vec(i, acc);
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; ++e)
+                    if (i + e < n) op.apply(i + e, acc);
+            }
+        }
+        if (Op::REDUCE) {
+            const T t2 = block_tree_256(acc, lds4);
+            if (threadIdx.x == 0) seg_out[s] = t2;
+        }
+    }
+}
+
+template <typename T, typename Op, typename Pro>
+int launch_map_with(mik_ctx *ctx, int64_t n, Op op, Pro pro, bool vec, const T *part, int m, T *seg_out)
+{
+    const int64_t nseg = mik_nseg<T>(n);
+    if (nseg == 0) return MIK_OK;
+    const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
+    if (vec) hipLaunchKernelGGL((k_map_with<T, true, Op, Pro>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, pro, part, m, seg_out);
+    else hipLaunchKernelGGL((k_map_with<T, false, Op, Pro>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, pro, part, m, seg_out);
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+
+// :89-90 in front of :93 -- what k_bicg_fin_rho does, per workgroup (reads sigma, omega; writes rho: no other workgroup reads it here)
+template <typename T> struct ProBicgRho {
+    BicgDev<T> *d; int first;
+    __device__ __forceinline__ void operator()(T tot, OpBicgU<T> &op, bool publish) const
+    {
+        T sigma = d->sigma;
+        if (first) { const T p = d->omega * sigma; sigma = -p; }
+        const T beta = tot / sigma;
+        op.neg_beta = Coef<T>{nullptr, -beta};
+        if (publish) d->rho = tot;
+    }
+};
+// :100-101 in front of :103, :111 -- k_bicg_fin_sigma per workgroup (reads rho; writes sigma for the next column)
+template <typename T> struct ProBicgSigma {
+    BicgDev<T> *d;
+    __device__ __forceinline__ void operator()(T tot, OpBicgR<T> &op, bool publish) const
+    {
+        const T alpha = d->rho / tot;
+        op.neg_alpha = Coef<T>{nullptr, -alpha};
+        op.alpha = Coef<T>{nullptr, alpha};
+        if (publish) { d->sigma = tot; d->alpha = alpha; d->neg_alpha = -alpha; }
+    }
+};
+
 // rho = dot(r_shadow, rs[:, j]) (:89); beta = rho / sigma (:90); first: sigma = -omega * sigma before (:85)
 template <typename T>
 __global__ __launch_bounds__(MIK_FIN_THREADS) void k_bicg_fin_rho(const T *__restrict__ S, int64_t m, BicgDev<T> *d, int first)
@@ -63,7 +134,7 @@ __global__ __launch_bounds__(MIK_FIN_THREADS) void k_bicg_fin_sigma(const T *__r
 
 // F = lu!(view(M, L, L)); ldiv!(gamma, F, view(M, L, 1)); omega = gamma[l]   (:123-125, :131) -- lu_solve of mik_krylov.hip, on
 // the packed upper triangle the Gram finaliser left (row r, columns r..k-1, r ascending)
-template <typename T> __global__ void k_bicg_gamma(const T *__restrict__ packed, int l, BicgDev<T> *d, BicgMirror *mirror)
+template <typename T> __device__ void bicg_gamma(const T *__restrict__ packed, int l, BicgDev<T> *d, BicgMirror *mirror)
 {
     const int k = l + 1;
     T M[5][5], b[4];
@@ -102,6 +173,23 @@ template <typename T> __global__ void k_bicg_gamma(const T *__restrict__ packed,
     }
     for (int j = 0; j < 8; ++j) d->gamma[j] = j < l ? b[j] : T(0);
     d->omega = b[l - 1];
+}
+template <typename T> __global__ void k_bicg_gamma(const T *__restrict__ packed, int l, BicgDev<T> *d, BicgMirror *mirror)
+{
+    bicg_gamma<T>(packed, l, d, mirror);
+}
+// few segments: the np level-2 sums of the Gram matrix and the LU solve in ONE single-workgroup launch
+template <typename T>
+__global__ __launch_bounds__(MIK_FIN_THREADS) void k_bicg_gram_gamma(const T *__restrict__ S, int64_t nseg, int np, int l, BicgDev<T> *d, BicgMirror *mirror)
+{
+    __shared__ T lds16[16];
+    __shared__ T packed[15];
+    for (int c = 0; c < np; ++c) {
+        const T tot = level2_sum(S + (int64_t)c * nseg, nseg, lds16);
+        if (threadIdx.x == 0) packed[c] = tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bicg_gamma<T>(packed, l, d, mirror);
 }
 
 // residual = norm(rs[:, 1]) (:132) and the publication of the step
@@ -206,20 +294,27 @@ template <typename T> static int bicg_step_impl(mik_bicgstab *it, T *residual)
     };
     auto ldiv = [&](T *v) { return it->pl_diag ? mik_divide(ctx, it->dtype, n, v, it->pl_diag, v) : MIK_OK; };
     const bool blockvec = mik_aligned16(us) && mik_aligned16(rs) && mik_aligned16(x) && (it->ldu % VT<T>::W == 0) && (it->ldr % VT<T>::W == 0);
+    const bool lean = nseg <= 1024;            // the sweeps finalise their producers' reductions themselves (k_map_with)
     for (int j = 0; j < l; ++j) {                                                            // BiCG part  :88
         MIK_TRY(dot_partials(sh, col(rs, it->ldr, j)));                                      // :89
-        hipLaunchKernelGGL((k_bicg_fin_rho<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, d, j == 0 ? 1 : 0);
-        MIK_LAUNCH_CHECK(ctx);
-        {                                                                                    // us = rs - beta * us  :93, all j + 1 columns in one launch
+        if (lean) {                                                                          // :90, :93 -- us = rs - beta * us, all j + 1 columns
+            OpBicgU<T> op{us, it->ldu, rs, it->ldr, j + 1, Coef<T>{nullptr, T(0)}};
+            MIK_TRY((launch_map_with<T>(ctx, n, op, ProBicgRho<T>{d, j == 0 ? 1 : 0}, blockvec, (const T *)ctx->partials, (int)nseg, (T *)nullptr)));
+        } else {
+            hipLaunchKernelGGL((k_bicg_fin_rho<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, d, j == 0 ? 1 : 0);
+            MIK_LAUNCH_CHECK(ctx);
             OpBicgU<T> op{us, it->ldu, rs, it->ldr, j + 1, coef_ptr<T>(&d->neg_beta)};
             MIK_TRY((launch_map<T>(ctx, n, op, blockvec, (T *)nullptr, nullptr)));
         }
         MIK_TRY(mik_spmv_launch<T>(ctx, it->A, col(us, it->ldu, j), col(us, it->ldu, j + 1), false, nullptr, nullptr));   // :97
         MIK_TRY(ldiv(col(us, it->ldu, j + 1)));                                              // :98
         MIK_TRY(dot_partials(sh, col(us, it->ldu, j + 1)));                                  // :100
-        hipLaunchKernelGGL((k_bicg_fin_sigma<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, d);
-        MIK_LAUNCH_CHECK(ctx);
-        {                                                                                    // rs -= alpha * us  :103 and x += alpha * us[:, 1]  :111 (independent of :107) in one launch
+        if (lean) {                                                                          // :101, :103, :111 (x does not depend on :107)
+            OpBicgR<T> op{us, it->ldu, rs, it->ldr, j + 1, x, Coef<T>{nullptr, T(0)}, Coef<T>{nullptr, T(0)}};
+            MIK_TRY((launch_map_with<T>(ctx, n, op, ProBicgSigma<T>{d}, blockvec, (const T *)ctx->partials, (int)nseg, (T *)nullptr)));
+        } else {
+            hipLaunchKernelGGL((k_bicg_fin_sigma<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, d);
+            MIK_LAUNCH_CHECK(ctx);
             OpBicgR<T> op{us, it->ldu, rs, it->ldr, j + 1, x, coef_ptr<T>(&d->neg_alpha), coef_ptr<T>(&d->alpha)};
             MIK_TRY((launch_map<T>(ctx, n, op, blockvec, (T *)nullptr, nullptr)));
         }
@@ -233,11 +328,16 @@ template <typename T> static int bicg_step_impl(mik_bicgstab *it, T *residual)
     case 4: MIK_TRY((gram_partials<T, 4>(ctx, n, rs, it->ldr))); break;
     default: MIK_TRY((gram_partials<T, 5>(ctx, n, rs, it->ldr))); break;
     }
-    T *packed = (T *)ctx->coef;
-    hipLaunchKernelGGL((k_finalize_store<T>), dim3(np), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, nseg, packed, (const int *)nullptr);
-    MIK_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL((k_bicg_gamma<T>), dim3(1), dim3(1), 0, ctx->stream, (const T *)packed, l, d, it->mirror);
-    MIK_LAUNCH_CHECK(ctx);
+    if (lean) {
+        hipLaunchKernelGGL((k_bicg_gram_gamma<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, np, l, d, it->mirror);
+        MIK_LAUNCH_CHECK(ctx);
+    } else {
+        T *packed = (T *)ctx->coef;
+        hipLaunchKernelGGL((k_finalize_store<T>), dim3(np), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, nseg, packed, (const int *)nullptr);
+        MIK_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL((k_bicg_gamma<T>), dim3(1), dim3(1), 0, ctx->stream, (const T *)packed, l, d, it->mirror);
+        MIK_LAUNCH_CHECK(ctx);
+    }
     {
         const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
         const bool vec = mik_aligned16(us) && mik_aligned16(rs) && mik_aligned16(x) && (it->ldu % VT<T>::W == 0) && (it->ldr % VT<T>::W == 0);
@@ -356,6 +456,16 @@ __device__ void minres_scalars(MinresDev<T> *d, T h3, long long iteration, int s
     mirror->range = 0;
     __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+
+// :107 in front of :109 -- k_minres_fin_proj per workgroup of the orthogonalisation sweep (k_map_with)
+template <typename T> struct ProMinresProj {
+    MinresDev<T> *d;
+    __device__ __forceinline__ void operator()(T tot, OpAxpyDot<T> &op, bool publish) const
+    {
+        op.alpha = Coef<T>{nullptr, -tot};
+        if (publish) { d->H[2] = tot; d->neg_proj = -tot; }
+    }
+};
 
 // proj = dot(v_curr, v_next) (:107): H[3] = proj, the coefficient of :109
 template <typename T>
@@ -487,21 +597,27 @@ template <typename T> static int minres_step_impl(mik_minres *it, int64_t iterat
     MinresDev<T> *d = (MinresDev<T> *)it->dev;
     T *x = (T *)it->x, *v_prev = (T *)it->v[0], *v_curr = (T *)it->v[1], *v_next = (T *)it->v[2];
     T *w_prev = (T *)it->w[0], *w_curr = (T *)it->w[1], *w_next = (T *)it->w[2];
-    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(nseg, 1)));
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * 2 * (size_t)std::max<int64_t>(nseg, 1)));
+    const bool lean = nseg <= 1024;            // the orthogonalisation sweep finalises the projection itself (k_map_with)
+    T *part_a = (T *)ctx->partials, *part_b = lean ? part_a + nseg : part_a;
     MIK_TRY(mik_spmv_launch<T>(ctx, it->A, v_curr, v_next, false, nullptr, nullptr));                        // :102
     {   // v_next -= H[2] v_prev (iteration > 1) and proj = dot(v_curr, v_next)                               :104, :107; v_prev is dead afterwards
         const T *xp = iteration > 1 ? v_prev : nullptr;
         OpAxpyDot<T> op{xp, v_next, v_curr, coef_ptr<T>(&d->neg_h1_lanczos), 1};
         const bool vec = mik_aligned16(v_next) && (!xp || mik_aligned16(xp)) && mik_aligned16(v_curr);
-        MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)ctx->partials, nullptr)));
-        hipLaunchKernelGGL((k_minres_fin_proj<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, d);
-        MIK_LAUNCH_CHECK(ctx);
+        MIK_TRY((launch_map<T>(ctx, n, op, vec, part_a, nullptr)));
+        if (!lean) {
+            hipLaunchKernelGGL((k_minres_fin_proj<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)part_a, nseg, d);
+            MIK_LAUNCH_CHECK(ctx);
+        }
     }
     it->seq += 1;
     {   // v_next -= proj v_curr; H[4] = norm(v_next)                                                          :109, :112
         OpAxpyDot<T> op{v_curr, v_next, nullptr, coef_ptr<T>(&d->neg_proj), 0};
-        MIK_TRY((launch_map<T>(ctx, n, op, mik_aligned16(v_next) && mik_aligned16(v_curr), (T *)ctx->partials, nullptr)));
-        hipLaunchKernelGGL((k_minres_fin_norm<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, d, (long long)iteration,
+        const bool vec = mik_aligned16(v_next) && mik_aligned16(v_curr);
+        if (lean) MIK_TRY((launch_map_with<T>(ctx, n, op, ProMinresProj<T>{d}, vec, (const T *)part_a, (int)nseg, part_b)));
+        else MIK_TRY((launch_map<T>(ctx, n, op, vec, part_b, nullptr)));
+        hipLaunchKernelGGL((k_minres_fin_norm<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)part_b, nseg, d, (long long)iteration,
                            it->skew, it->mirror, it->seq);
         MIK_LAUNCH_CHECK(ctx);
     }
