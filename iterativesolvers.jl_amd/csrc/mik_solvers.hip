@@ -294,7 +294,7 @@ template <typename T> static int bicg_step_impl(mik_bicgstab *it, T *residual)
     };
     auto ldiv = [&](T *v) { return it->pl_diag ? mik_divide(ctx, it->dtype, n, v, it->pl_diag, v) : MIK_OK; };
     const bool blockvec = mik_aligned16(us) && mik_aligned16(rs) && mik_aligned16(x) && (it->ldu % VT<T>::W == 0) && (it->ldr % VT<T>::W == 0);
-    const bool lean = nseg <= 1024;            // the sweeps finalise their producers' reductions themselves (k_map_with)
+    const bool lean = nseg <= 1024 && ctx->tuning[25] == 0;   // the sweeps finalise their producers' reductions themselves (k_map_with; development knob 25 = 1: separate finaliser launches)
     for (int j = 0; j < l; ++j) {                                                            // BiCG part  :88
         MIK_TRY(dot_partials(sh, col(rs, it->ldr, j)));                                      // :89
         if (lean) {                                                                          // :90, :93 -- us = rs - beta * us, all j + 1 columns
@@ -598,7 +598,7 @@ template <typename T> static int minres_step_impl(mik_minres *it, int64_t iterat
     T *x = (T *)it->x, *v_prev = (T *)it->v[0], *v_curr = (T *)it->v[1], *v_next = (T *)it->v[2];
     T *w_prev = (T *)it->w[0], *w_curr = (T *)it->w[1], *w_next = (T *)it->w[2];
     MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * 2 * (size_t)std::max<int64_t>(nseg, 1)));
-    const bool lean = nseg <= 1024;            // the orthogonalisation sweep finalises the projection itself (k_map_with)
+    const bool lean = nseg <= 1024 && ctx->tuning[25] == 0;   // the orthogonalisation sweep finalises the projection itself (k_map_with)
     T *part_a = (T *)ctx->partials, *part_b = lean ? part_a + nseg : part_a;
     MIK_TRY(mik_spmv_launch<T>(ctx, it->A, v_curr, v_next, false, nullptr, nullptr));                        // :102
     {   // v_next -= H[2] v_prev (iteration > 1) and proj = dot(v_curr, v_next)                               :104, :107; v_prev is dead afterwards

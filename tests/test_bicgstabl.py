@@ -183,3 +183,34 @@ def test_whole_iteration_calls_validate_their_arguments(pkg, ctx):
     assert L.mik_minres_step(h, 0, out.ctypes.data_as(C.c_void_p)) == 1       # iteration counts from 1 (src/minres.jl:91)
     assert L.mik_minres_step(h, 1, None) == 1
     assert L.mik_minres_destroy(h) == 0 and L.mik_minres_destroy(None) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_whole_iteration_calls_with_separate_finalisers(pkg, orc, ctx, dtype):
+    """Beyond 1,024 reduction segments mik_bicgstab_step / mik_minres_step run their finalisers as separate launches; development
+    knob 25 selects that form at any size: same histories and x as the launch-lean form (and therefore as the oracle)."""
+    A, b = orc.advdiff(12, 300.0)
+    A, b = A.astype(dtype), b.astype(dtype)
+    dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
+    sh = (orc.hashed_rhs(A.n) + 0.5).astype(dtype)
+    L = orc.laplace(10, 3).astype(dtype)
+    dL = pkg.HipCSR(L.n, L.n, L.colptr, L.rowval, L.nzval)
+    bl = orc.hashed_rhs(L.n).astype(dtype)
+    runs = []
+    for knob in (0, 1):
+        ctx.set_tuning(25, knob)
+        try:
+            x = pkg.HipVector.from_numpy(np.zeros(A.n, dtype))
+            it = pkg.bicgstabl_iterator_(x, dA, pkg.HipVector.from_numpy(b), 2, max_mv_products=80, reltol=0.0, initial_zero=True,
+                                         r_shadow=pkg.HipVector.from_numpy(sh))
+            hb = np.array(list(it))
+            y = pkg.HipVector.from_numpy(np.zeros(L.n, dtype))
+            im = pkg.minres_iterable_(y, dL, pkg.HipVector.from_numpy(bl), reltol=0.0, initially_zero=True, maxiter=25)
+            hm = np.array(list(im))
+            runs.append((hb, x.to_numpy(), hm, y.to_numpy()))
+        finally:
+            ctx.set_tuning(25, 0)
+    assert runs[0][0].size == 20 and runs[0][2].size == 25
+    for a, c in zip(runs[0], runs[1]):
+        assert np.array_equal(a, c, equal_nan=True)
