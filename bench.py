@@ -77,10 +77,11 @@ def cpu_baseline_omp(N: int, iters: int):
                       f"(not the reference's serial loop; summation order differs)", "seconds": dt}
 
 
-def pmc_traffic(kernel_key: str):
+def pmc_traffic(kernel_key: str, with_source: bool = False):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_traffic.json,
-    written by scripts/prof_r03.sh + prof_collect.py from separate --pmc runs of this same command: FETCH_SIZE x 2 per the gfx950 note
-    in MI355X_MICROARCH.md + WRITE_SIZE).  None if absent."""
+    written by scripts/prof_r04.sh + prof_collect.py from separate --pmc runs of this same command: FETCH_SIZE x 2 per the gfx950 note
+    in MI355X_MICROARCH.md + WRITE_SIZE).  None if absent.  A COMMITTED CONSTANT, not a measurement of this run (counters need
+    rocprofv3 around the process): every consumer prints the file it came from next to it (`traffic_source`)."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*bench*_traffic.json")), reverse=True):     # newest round first
         try:
@@ -88,8 +89,8 @@ def pmc_traffic(kernel_key: str):
         except Exception:
             v = None
         if v:
-            return v
-    return None
+            return (v, os.path.relpath(f, ROOT)) if with_source else v
+    return (None, None) if with_source else None
 
 
 def history_parity(N: int, gpu_hist: np.ndarray, gpu_iters: int, gpu_mvps: int, gpu_converged: bool):
@@ -383,7 +384,9 @@ def run_single(args):
     for kk in step_kernels:
         kk["gbs"] = kk["bytes_moved"] / (kk["avg_launch_ms"] * 1e-3) / 1e9
         kk["frac_of_8000"] = kk["gbs"] / HBM_PEAK_GBS
-        kk["traffic"] = pmc_traffic(kk["kernel"].split("<")[0] if kk["kernel"].startswith("k_spmv") else kk["kernel"])
+        kk["traffic"], kk["traffic_source"] = pmc_traffic(kk["kernel"].split("<")[0] if kk["kernel"].startswith("k_spmv") else kk["kernel"], with_source=True)
+        if kk["gbs"] > COPY_CEILING_GBS:
+            kk["note"] = "above the 6,290 GB/s HBM copy ceiling: part of this sweep is served by the Infinity Cache (the previous launch left it there); frac_of_8000 is then not an HBM fraction"
     del it
 
     # ---- (3) the CONTRACT loop: the same operator on its plain CSR arrays (the north star's "CSR SpMV inside cg!") --------
@@ -410,29 +413,39 @@ def run_single(args):
                "final_residual": residual}
 
     moved_gbs = stored_bytes / (spmv_ms * 1e-3) / 1e9
+    iter_moved = stored_bytes + (8 if fx else 9) * n * 8          # bytes ONE step of the loop behind `value` moves (its SpMV + the two sweeps)
+    iter_alg = alg_bytes + 9 * n * 8                               # B_cg = B_spmv + 9 n s
+    d_traffic, d_src = pmc_traffic(kern, with_source=True)
     default_spmv = {"kernel": kern + "<double, fused dot>", "operator_layout": layout, "bytes_moved_per_launch": stored_bytes, "avg_launch_ms": spmv_ms,
                     "launches_timed": int(spmv_launches), "back_to_back_ms": b2b_ms, "achieved_moved": moved_gbs, "frac_moved": moved_gbs / HBM_PEAK_GBS,
-                    "frac_of_copy_ceiling_6290": moved_gbs / COPY_CEILING_GBS, "traffic": pmc_traffic(kern),
+                    "frac_of_copy_ceiling_6290": moved_gbs / COPY_CEILING_GBS, "traffic": d_traffic, "traffic_source": d_src,
                     "note": "the SpMV of the loop behind `value`: this constant-coefficient operator keeps ONE mask byte per row instead of 57 B of values "
                             "and indices, so the launch moves 17 B per row instead of 73; achieved_moved / frac_moved = the bytes it actually streams "
-                            "(confirmed by `traffic`) over its HIP-event time inside the loop.  Not the north star's CSR figure: that is `roofline`."}
+                            "(`traffic`: committed PMC constant) over its HIP-event time inside the loop.  Not the north star's CSR figure: that is `roofline`."}
     if csr is not None:
         c_ms = csr["spmv_in_loop_ms"]
+        c_traffic, c_src = pmc_traffic(csr["kernel"], with_source=True)
         roofline = {"bound": "hbm", "kernel": csr["kernel"] + "<double, fused dot>", "loop": "contract_csr_loop" if layout != "csr-rowblock" else "the timed loop",
                     "achieved": alg_bytes / (c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "traffic": pmc_traffic(csr["kernel"]), "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": c_ms, "launches_timed": csr["launches_timed"],
+                    "traffic": c_traffic, "traffic_source": c_src, "traffic_is": "committed constant from separate rocprofv3 --pmc passes of this command, not measured in this run",
+                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": c_ms, "launches_timed": csr["launches_timed"],
                     "back_to_back_ms": csr["spmv_back_to_back_ms"], "frac_of_copy_ceiling_6290": alg_bytes / (c_ms * 1e-3) / 1e9 / COPY_CEILING_GBS,
+                    # the loop this kernel was timed in -- so that bytes/step / ms_per_step <= peak and avg_launch_ms <= ms_per_step can be checked from here alone
+                    "loop_ms_per_step": csr["ms_per_step"], "loop_iters_per_sec": csr["iters_per_sec"],
+                    "loop_algorithmic_bytes_per_step": iter_alg, "loop_gbs": iter_alg / (csr["ms_per_step"] * 1e-3) / 1e9,
+                    "loop_frac": iter_alg / (csr["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "target": 0.60,
                     "note": "SURVEY.md 8d: algorithmic bytes of the Int32 CSR SpMV (nnz*(s+4) + (n+1)*4 + 2*n*s = 1,740,111,876 B at 256^3 fp64) over the "
                             "average HIP-event duration of the SpMV launch INSIDE the cg! loop, on the plain CSR arrays of the operator "
-                            "(mik_csr_set_layout(A, 0); k_spmv_rowgather moves exactly those bytes: `traffic`).  `value` is the loop in the operator's default "
-                            "layout (`default_layout_spmv`); the CSR loop's own rate is `contract_csr_loop.iters_per_sec`."}
+                            "(mik_csr_set_layout(A, 0); k_spmv_rowgather moves exactly those bytes: `traffic`).  loop_* = that CSR loop itself (the contract "
+                            "rate: cg! iterations/s moving B_spmv + 9 n s per step).  `value` is the SAME iteration, bit-identical results, in the operator's "
+                            "default layout, which moves config.value_loop_bytes_per_step instead (`default_layout_spmv`)."}
     else:
         roofline = {"bound": "hbm", "kernel": kern + "<double, fused dot>", "loop": "the timed loop (contract CSR loop skipped: --no-csr)",
-                    "achieved": moved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(kern),
+                    "achieved": moved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved_gbs / HBM_PEAK_GBS, "traffic": d_traffic, "traffic_source": d_src,
                     "bytes_moved_per_launch": stored_bytes, "avg_launch_ms": spmv_ms,
+                    "loop_ms_per_step": dt / K * 1e3, "loop_iters_per_sec": K / dt,
                     "note": "bytes this layout actually moves per launch over the in-loop HIP-event time; NOT the CSR-algorithmic figure"}
-    iter_moved = stored_bytes + (8 if fx else 9) * n * 8
     out = {
         "metric": "cg_iters_per_sec", "value": K / dt, "unit": "iters/s", "n_gpus": 1, "steps": K, "warmup": Wm,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -440,18 +453,25 @@ def run_single(args):
         "config": {"workload": f"cg! on {N}^3 3D 7-point Laplacian (test/laplace_matrix.jl), fp64, hashed rhs, x0 = 0 "
                                f"(BASELINE.json configs[1])", "n": n, "nnz": nnz, "reltol_in_timed_loop": 0.0, "host_sync_per_step": 1,
                    "operator_layout_of_the_timed_loop": layout,
+                   "value_loop_bytes_per_step": iter_moved, "value_loop_gbs": iter_moved / (dt / K) / 1e9,
+                   "value_loop_frac_of_8000": iter_moved / (dt / K) / 1e9 / HBM_PEAK_GBS,
+                   "value_loop_spmv_avg_launch_ms": spmv_ms,
+                   "value_loop_note": ("`value` = this loop.  Its SpMV streams one mask byte per row instead of the CSR arrays (constant-coefficient operator, "
+                                       "bit-identical results), so a step moves value_loop_bytes_per_step, not SURVEY.md 8d's B_cg; the CSR contract loop "
+                                       "(B_cg per step) is roofline.loop_*") if layout != "csr-rowblock" else "`value` = the CSR loop",
                    "timed_regions": len(times), "timed_seconds_total": float(sum(times)), "region_seconds_min_max": [float(min(times)), float(max(times))],
                    "operator_upload_seconds": upload_seconds, "final_residual": residual},
         "contract_csr_loop": csr,
         "roofline": roofline,
         "default_layout_spmv": default_spmv,
         "longest_kernel_of_the_step": (lambda kk: {"kernel": kk["kernel"], "avg_launch_ms": kk["avg_launch_ms"], "bytes_moved": kk["bytes_moved"],
-                                                   "frac_of_8000": kk["frac_of_8000"], "traffic": kk["traffic"]})(max(step_kernels, key=lambda q: q["avg_launch_ms"])),
+                                                   "frac_of_8000": kk["frac_of_8000"], "traffic": kk["traffic"], "traffic_source": kk["traffic_source"],
+                                                   **({"note": kk["note"]} if "note" in kk else {})})(max(step_kernels, key=lambda q: q["avg_launch_ms"])),
         "step_kernels": step_kernels,
         "cg_iteration_moved_bytes": iter_moved, "cg_iteration_moved_gbs": iter_moved / (dt / K) / 1e9,
         "cg_iteration_moved_frac_of_8000": iter_moved / (dt / K) / 1e9 / HBM_PEAK_GBS,
-        "cg_iteration_algorithmic_bytes": alg_bytes + 9 * n * 8,
-        "contract_cg_iteration_gbs": ((alg_bytes + 9 * n * 8) / (csr["ms_per_step"] * 1e-3) / 1e9) if csr else None,
+        "cg_iteration_algorithmic_bytes": iter_alg,
+        "contract_cg_iteration_gbs": (iter_alg / (csr["ms_per_step"] * 1e-3) / 1e9) if csr else None,
         "batched_25_steps_per_sync_iters_per_sec": kb / float(np.median(tb)),
         "parity_full_history": parity,
     }
@@ -473,6 +493,16 @@ def run_single(args):
                 m = min(cpu_hist.size, g_tree.size)
                 cb["gpu_vs_cpu_history_max_rel_dev"] = float(np.max(np.abs(g_tree[:m] - cpu_hist[:m]) / cpu_hist[:m]))
                 cb["history_steps_compared"] = int(m)
+                cb["gpu_vs_cpu_history_order"] = "SEQ (one accumulator left to right over 16.7 M terms: this run of the oracle); its own distance to the BLAS order is cpu_seq_vs_blas_floor"
+            # the order the reference itself executes (LinearAlgebra.dot / norm -> OpenBLAS), over the WHOLE solve: committed golden history
+            for key, name in (("blas", "gpu_vs_blas_order_history_max_rel_dev"), ("blas8", "gpu_vs_blas_8_threads_history_max_rel_dev"), ("pair", "gpu_vs_pairwise_history_max_rel_dev")):
+                if key in parity:
+                    cb[name] = parity[key]["gpu_vs_cpu_history_max_rel_dev"]
+                    cb[name.replace("max_rel_dev", "steps_compared")] = parity[key]["steps_compared"]
+            if "blas" in parity:
+                cb["same_iters_mvps_isconverged_as_blas_order"] = parity["blas"]["same_iters_mvps_isconverged"]
+                cb["parity_target"] = 1e-12
+                cb["cpu_seq_vs_blas_floor"] = parity.get("cpu_vs_cpu_floors", {}).get("seq_vs_blas")
         out["cpu_baseline"] = cb
         try:
             out["cpu_baseline_omp"] = cpu_baseline_omp(N, args.cpu_iters)
@@ -511,7 +541,7 @@ def main():
     ap.add_argument("--no-gmres", action="store_true", help="skip the configs[2] sub-benchmark (gmres_config3)")
     ap.add_argument("--no-config5", action="store_true", help="skip the configs[4] stand-ins (config5)")
     ap.add_argument("--config5-kinds", default="fe_shell,fe_hex,banded,random")
-    ap.add_argument("--stencil27", type=int, default=256, help="grid of the 27-point box-stencil sub-benchmark (0 = skip)")
+    ap.add_argument("--stencil27", type=int, default=0, help="grid of the 27-point box-stencil sub-benchmark (off by default: outside every BASELINE.json config; frozen, VERDICT r3 #8)")
     ap.add_argument("--cpu-iters", type=int, default=120)
     ap.add_argument("--force-dist", action="store_true", help="run the row-partitioned code path even with one rank")
     args = ap.parse_args()

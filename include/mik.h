@@ -62,7 +62,9 @@
 extern "C" {
 #endif
 
-#define MIK_ABI_VERSION 3   /* 3 (round 3): mik_csr_pack and the knob setters left this header (include/mik_dev.h); additions only otherwise */
+#define MIK_ABI_VERSION 4   /* 4 (round 4): MIK_ERR_SINGULAR replaces MIK_ERR_INVALID for an exactly singular pivot (mik_lu_solve, mik_bicgstab_step);
+                             *   the scalar mailbox transport (mik_mailbox_*); additions only otherwise.  3 (round 3): mik_csr_pack and the knob setters
+                             *   left this header (include/mik_dev.h) */
 
 /* status codes */
 enum {
@@ -73,7 +75,9 @@ enum {
     MIK_ERR_NOMEM = 4,       /* out of (device or host) memory */
     MIK_ERR_NOTIMPL = 5,     /* not implemented (e.g. nnz >= 2^31) */
     MIK_ERR_CALLBACK = 6,    /* a mik_partition / operator / preconditioner callback returned non-zero */
-    MIK_ERR_RANGE = 7        /* a norm left the safe range while the HOST drives the phases of a row-partitioned step itself (see "Norms") */
+    MIK_ERR_RANGE = 7,       /* a norm left the safe range while the HOST drives the phases of a row-partitioned step itself (see "Norms") */
+    MIK_ERR_SINGULAR = 8     /* lu! met an exactly singular pivot (the reference throws SingularException, src/bicgstabl.jl:124): mik_lu_solve,
+                              * mik_bicgstab_step -- a code of its own, so that an invalid handle is never reported as a singular matrix */
 };
 
 enum { MIK_F64 = 0, MIK_F32 = 1 };
@@ -199,7 +203,7 @@ int mik_gemv_n(mik_ctx *ctx, int dtype, int64_t n, int k, const void *V, int64_t
 int mik_gemv_t(mik_ctx *ctx, int dtype, int64_t n, int k, const void *V, int64_t ldv, const void *w,
                void *h);
 /* Host: solve the small dense system A x = b (column-major n x n) by LU with partial pivoting --
- * lu! + ldiv! at src/bicgstabl.jl:124-125.  A is overwritten by its factors, b by x; status 1 if A is
+ * lu! + ldiv! at src/bicgstabl.jl:124-125.  A is overwritten by its factors, b by x; MIK_ERR_SINGULAR if A is
  * exactly singular. */
 int mik_lu_solve(int dtype, void *A, int64_t lda, int n, void *b);
 
@@ -321,7 +325,9 @@ int mik_bicgstab_mr_update(mik_ctx *ctx, int dtype, int64_t n, int l, void *us, 
  * search block us (n x (l + 1), column-major, leading dimensions ldr / ldu) as set up by bicgstabl_iterator!
  * (src/bicgstabl.jl:25-73: rs[:, 1] = Pl \ (b - A x), us = 0) and the shadow residual r_shadow (:38); pl_diag: the diagonal
  * of a Jacobi Pl (ldiv! = elementwise division, :98, :108) or NULL for Identity.  omega = sigma = 1 at creation (:59).
- * l = 1 ... 4.  MIK_ERR_INVALID when lu! meets an exactly singular pivot (the reference throws SingularException). */
+ * l = 1 ... 4.  MIK_ERR_SINGULAR when lu! meets an exactly singular pivot (the reference throws SingularException); the handle is
+ * then latched: every later mik_bicgstab_step reports MIK_ERR_SINGULAR again (its device scalars are not steppable).  Handles a host
+ * never destroys are freed by mik_ctx_destroy of their context (a finalizer that finds the context closed must skip the destroy call). */
 typedef struct mik_bicgstab mik_bicgstab;
 int mik_bicgstab_create(mik_ctx *ctx, const mik_csr *A, int l, void *x, void *rs, int64_t ldr, void *us, int64_t ldu,
                         const void *r_shadow, const void *pl_diag, mik_bicgstab **out);

@@ -888,7 +888,7 @@ def lu_solve_(A: np.ndarray, b: np.ndarray) -> np.ndarray:
     if not A.flags.f_contiguous or A.dtype != b.dtype or A.shape[0] != A.shape[1] or b.size != A.shape[0]:
         raise ValueError("lu_solve_: A must be a square F-ordered array, b a vector of the same dtype")
     code = lib().mik_lu_solve(dtype_code(A.dtype), A.ctypes.data_as(_vp), A.shape[0], A.shape[0], b.ctypes.data_as(_vp))
-    if code == 1:
+    if code == 8:                                                            # MIK_ERR_SINGULAR
         raise np.linalg.LinAlgError("SingularException")
     check(code, "mik_lu_solve", None)
     return b
@@ -1111,7 +1111,7 @@ class BiCGStabIterable:
         if self._step is not None:
             out = np.zeros(1, self.x.dtype)
             rc = lib().mik_bicgstab_step(self._step, out.ctypes.data_as(_vp))
-            if rc == 1:
+            if rc == 8:                                                      # MIK_ERR_SINGULAR (never an invalid-argument code)
                 raise np.linalg.LinAlgError("SingularException")
             check(rc, "mik_bicgstab_step", self.x.ctx.handle)
             self.mv_products += 2 * l                                        # :115

@@ -504,6 +504,11 @@ extern "C" int mik_cgd_iterate_many(mik_cgd *it, int64_t iteration, int64_t max_
         // is safe: every rank froze its batch on the same total; finish that step with the norm rescaled across the ranks and
         // go on (the single-GPU iterable does the same on its own, cg_iterate_many_impl).
         bs.head_ahead = false;
+        // The frozen step's x .+= alpha .* u has been applied by now whatever came behind it: by the head of the next (no-op) step of
+        // the batch, by the head enqueued ahead (ahead_ok) or by the flush of phase 6 -- but only a TAIL clears the pending flag, and
+        // none follows the head ahead when the frozen step was the last of the batch.  Left set, the fresh head of the next call
+        // would add the same alpha u to x a second time: clear it behind everything that is enqueued.
+        if (bs.fuse_x) MIK_TRY(mik_cgd_phase(it, 25, 0));
         MIK_TRY(rccl_scaled_norm(it));
         it->norm_fix_index = (int)m.nhist;
         it->norm_it_next = iteration + m.nhist + 1;

@@ -113,6 +113,11 @@ extern "C" int mik_ctx_destroy(mik_ctx *ctx)
     }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    {   // step handles the host never destroyed (their destroy functions unregister themselves: walk a copy)
+        std::vector<std::pair<void *, int (*)(void *)>> owned;
+        owned.swap(ctx->owned);
+        for (auto &h : owned) (void)h.second(h.first);
+    }
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->coef) (void)hipFree(ctx->coef);
     if (ctx->coef_host) (void)hipHostFree(ctx->coef_host);

@@ -46,6 +46,9 @@ struct mik_ctx {
     int tuning[32] = {0};            // development knobs of THIS context (include/mik_dev.h): a copy of the defaults at creation, mik_ctx_set_tuning
     static constexpr size_t COEF_BYTES = 8192;      // [0, 4096): coefficient blocks of the callers; the tail: scratch of mik_safe_norm_slow
     static constexpr size_t COEF_SAFE_SLOT = 4096;  // byte offset of that scratch
+    // whole-iteration handles (mik_bicgstab / mik_minres) still alive: mik_ctx_destroy frees them, so that a host finalizer which
+    // finds its context already closed (and must then skip mik_*_destroy) leaks nothing
+    std::vector<std::pair<void *, int (*)(void *)>> owned;
 };
 
 struct mik_csr {

@@ -2246,6 +2246,10 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
                            (long long)bs.maxiter, bs.mirror, bs.seq, it->norm_fix_index);
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
+    case 25:    // the pending x update of a frozen step has been applied (by a no-op head, the head ahead or phase 6): drop the flag
+        hipLaunchKernelGGL((k_cg_clear_pending<T>), dim3(1), dim3(1), 0, ctx->stream, d);
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
     case 24:    // cg_iterator! closes with the scaled norm
         bs.seq += 1;
         hipLaunchKernelGGL((k_cgd_fix_init<T>), dim3(1), dim3(1), 0, ctx->stream, d, (T)it->norm_res, (T)it->reltol, (T)it->abstol, (long long)bs.maxiter,
@@ -2424,7 +2428,7 @@ extern "C" int mik_bicgstab_mr_update(mik_ctx *ctx, int dtype, int64_t n, int l,
 
 // Solve A x = b for a small dense column-major A (n x n, leading dimension lda) by LU with partial
 // pivoting -- F = lu!(view(M, L, L)); ldiv!(gamma, F, view(M, L, 1)) at src/bicgstabl.jl:124-125.
-// A is overwritten by its factors, b by the solution.  Returns 1 (MIK_ERR_INVALID) on an exactly
+// A is overwritten by its factors, b by the solution.  Returns MIK_ERR_SINGULAR on an exactly
 // singular pivot (the reference throws SingularException).
 template <typename T> static int lu_solve(T *A, int64_t lda, int n, T *b)
 {
@@ -2433,7 +2437,7 @@ template <typename T> static int lu_solve(T *A, int64_t lda, int n, T *b)
         int p = j;
         T best = std::fabs(at(j, j));
         for (int i = j + 1; i < n; ++i) { const T a = std::fabs(at(i, j)); if (a > best) { best = a; p = i; } }
-        if (best == T(0)) return MIK_ERR_INVALID;
+        if (best == T(0)) return MIK_ERR_SINGULAR;
         if (p != j) {
             for (int c = 0; c < n; ++c) std::swap(at(j, c), at(p, c));
             std::swap(b[j], b[p]);

@@ -225,14 +225,22 @@ struct mik_bicgstab {
     int64_t n = 0, ldr = 0, ldu = 0;
     void *x = nullptr, *rs = nullptr, *us = nullptr;
     const void *r_shadow = nullptr, *pl_diag = nullptr;
+    bool failed = false;                       // a singular MR system was reported: every later step reports it again
     void *dev = nullptr;            // BicgDev<T>
     BicgMirror *mirror = nullptr;
     unsigned long long seq = 0;
 };
 
+static void ctx_disown(mik_ctx *ctx, void *h)
+{
+    for (size_t i = 0; i < ctx->owned.size(); ++i)
+        if (ctx->owned[i].first == h) { ctx->owned.erase(ctx->owned.begin() + (long)i); return; }
+}
+
 extern "C" int mik_bicgstab_destroy(mik_bicgstab *it)
 {
     if (!it) return MIK_OK;
+    ctx_disown(it->ctx, it);
     (void)hipSetDevice(it->ctx->device);
     (void)hipStreamSynchronize(it->ctx->stream);
     if (it->dev) (void)hipFree(it->dev);
@@ -272,6 +280,7 @@ extern "C" int mik_bicgstab_create(mik_ctx *ctx, const mik_csr *A, int l, void *
         mik_bicgstab_destroy(it);
         return rc;
     }
+    ctx->owned.push_back({it, [](void *h) { return mik_bicgstab_destroy((mik_bicgstab *)h); }});
     *out = it;
     return MIK_OK;
 }
@@ -365,8 +374,10 @@ template <typename T> static int bicg_step_impl(mik_bicgstab *it, T *residual)
 #endif
     }
     if (it->mirror->singular) {
-        it->mirror->singular = 0;
-        return mik_fail(ctx, MIK_ERR_INVALID, "bicgstabl: lu! of the %d x %d MR system met an exactly singular pivot", l, l);
+        // the device state is not steppable any more (gamma = 0, omega stale): the handle stays failed, like the reference's iterable
+        // after the SingularException of lu! (src/bicgstabl.jl:124)
+        it->failed = true;
+        return mik_fail(ctx, MIK_ERR_SINGULAR, "bicgstabl: lu! of the %d x %d MR system met an exactly singular pivot", l, l);
     }
     if (it->mirror->range) return mik_safe_norm_slow<T>(ctx, n, rs, residual);               // norm(rs[:, 1]) of a badly scaled residual
     *residual = (T)it->mirror->residual;
@@ -376,6 +387,7 @@ template <typename T> static int bicg_step_impl(mik_bicgstab *it, T *residual)
 extern "C" int mik_bicgstab_step(mik_bicgstab *it, void *residual)
 {
     if (!it || !residual) return MIK_ERR_INVALID;
+    if (it->failed) return mik_fail(it->ctx, MIK_ERR_SINGULAR, "bicgstabl: this handle met a singular MR system in an earlier step and cannot be stepped");
     (void)hipSetDevice(it->ctx->device);
     return it->dtype == MIK_F64 ? bicg_step_impl<double>(it, (double *)residual) : bicg_step_impl<float>(it, (float *)residual);
 }
@@ -522,6 +534,7 @@ struct mik_minres {
 extern "C" int mik_minres_destroy(mik_minres *it)
 {
     if (!it) return MIK_OK;
+    ctx_disown(it->ctx, it);
     (void)hipSetDevice(it->ctx->device);
     (void)hipStreamSynchronize(it->ctx->stream);
     if (it->dev) (void)hipFree(it->dev);
@@ -568,6 +581,7 @@ extern "C" int mik_minres_create(mik_ctx *ctx, const mik_csr *A, void *x, void *
         mik_minres_destroy(it);
         return rc;
     }
+    ctx->owned.push_back({it, [](void *h) { return mik_minres_destroy((mik_minres *)h); }});
     *out = it;
     return MIK_OK;
 }

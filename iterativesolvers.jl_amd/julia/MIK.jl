@@ -537,7 +537,7 @@ function Base.iterate(it::HipBiCGStabIterable{T}, iteration::Int = IterativeSolv
     IterativeSolvers.done(it, iteration) && return nothing
     res = Ref{T}()
     code = ccall((:mik_bicgstab_step, libmik), Cint, (Ptr{Cvoid}, Ref{T}), it.handle, res)
-    code == 1 && throw(LinearAlgebra.SingularException(0))                   # lu! at :124
+    code == 8 && throw(LinearAlgebra.SingularException(0))                   # MIK_ERR_SINGULAR: lu! at :124
     check(code, "mik_bicgstab_step", it.x.ctx.handle)
     it.mv_products += 2 * it.l                                               # :115
     it.residual = res[]                                                      # :132

@@ -121,7 +121,7 @@ def _declare(L):
         f.argtypes = [ft, ft, fp, fp, fp]
         f.restype = None
         f = getattr(L, f"orc_bicgstabl_{suf}")
-        f.argtypes = [C.c_int64, _i64p, _i64p, fp, C.c_int, fp, fp, fp, C.c_int, C.c_double, C.c_double, C.c_int64,
+        f.argtypes = [C.c_int64, _i64p, _i64p, fp, C.c_int, fp, fp, fp, fp, C.c_int, C.c_double, C.c_double, C.c_int64,
                       C.c_int, C.c_int, _i32p, _f64p, _i64p, _i64p, _i32p, _f64p, _f64p]
         f.restype = C.c_int
         f = getattr(L, f"orc_lu_solve_{suf}")
@@ -396,9 +396,10 @@ def lu_solve(A, b):
 
 
 def bicgstabl(A: CSC, b, l=2, x0=None, *, r_shadow, abstol=0.0, reltol=None, max_mv_products=None, mode="seq",
-              shape=(1, 1)):
-    """``bicgstabl!(x, A, b, l; log=true)`` / ``bicgstabl(A, b, l)`` when ``x0 is None`` -- src/bicgstabl.jl:181-219,142.
-    ``r_shadow`` replaces the reference's ``rand(T, n)`` (src/bicgstabl.jl:38)."""
+              shape=(1, 1), pl_diag=None):
+    """``bicgstabl!(x, A, b, l; Pl, log=true)`` / ``bicgstabl(A, b, l)`` when ``x0 is None`` -- src/bicgstabl.jl:181-219,142.
+    ``r_shadow`` replaces the reference's ``rand(T, n)`` (src/bicgstabl.jl:38); ``pl_diag`` = the diagonal of a Jacobi ``Pl``
+    (``ldiv!`` at src/bicgstabl.jl:55,98,108), None = ``Identity()``."""
     dtype = A.nzval.dtype
     suf, ct = _suf(dtype)
     b = np.ascontiguousarray(b, dtype)
@@ -414,7 +415,8 @@ def bicgstabl(A: CSC, b, l=2, x0=None, *, r_shadow, abstol=0.0, reltol=None, max
     res0, tol = C.c_double(0), C.c_double(0)
     shp = np.asarray(shape, np.int32)
     rc = getattr(lib(), f"orc_bicgstabl_{suf}")(n, _p(A.colptr, C.c_int64), _p(A.rowval, C.c_int64), _p(A.nzval, ct),
-                                                A.index_base, _p(b, ct), _p(x, ct), _p(rsh, ct), int(l), float(abstol),
+                                                A.index_base, _p(b, ct), _p(x, ct), _p(rsh, ct),
+                                                _p(None if pl_diag is None else np.ascontiguousarray(pl_diag, dtype), ct), int(l), float(abstol),
                                                 float(reltol), max_mv, int(initial_zero), _mode(mode), _p(shp, C.c_int),
                                                 _p(res, C.c_double), C.byref(iters), C.byref(mvps), C.byref(conv),
                                                 C.byref(res0), C.byref(tol))

@@ -36,6 +36,38 @@ def test_oracle_termination(orc, dtype):
     assert ch["iters"] == 0                                                    # :70
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("l", [1, 2, 4])
+@pytest.mark.parametrize("with_x0", [False, True])
+def test_oracle_pl_equals_the_explicitly_preconditioned_system(orc, dtype, l, with_x0):
+    """Pins the oracle's `Pl` path (ldiv! at src/bicgstabl.jl:55, :98, :108) without Julia: with a diagonal of POWERS OF TWO,
+    scaling the rows of A and the entries of b by 1 / d_i is exact and commutes with every rounding of the row sums, so
+    bicgstabl(A, b; Pl = D) must give bit for bit the history and x of bicgstabl(D^-1 A, D^-1 b; Pl = Identity) -- in every
+    summation mode.  A generic (non power of two) diagonal then differs from that only by the roundings of the divisions."""
+    A, b = orc.advdiff(8, 150.0)
+    A, b = A.astype(dtype), b.astype(dtype)
+    n = A.n
+    d = (2.0 ** ((np.arange(n) * 7) % 9 - 4)).astype(dtype)
+    S = A.to_scipy().tocsc()
+    import scipy.sparse as sp
+    SA = (sp.diags(1.0 / d.astype(np.float64)) @ S.astype(np.float64)).astype(dtype).tocsc()
+    SA.sort_indices()
+    As = orc.CSC(n, SA.indptr.astype(np.int64), SA.indices.astype(np.int64), SA.data.astype(dtype), 0)
+    sh = (orc.hashed_rhs(n) + 0.5).astype(dtype)
+    x0 = np.random.default_rng(4).standard_normal(n).astype(dtype) if with_x0 else None
+    for mode, shape in (("seq", (1, 1)), ("tree", (2, 2))):
+        x1, h1 = orc.bicgstabl(A, b, l, x0, r_shadow=sh, max_mv_products=40 * l, reltol=0.0, mode=mode, shape=shape, pl_diag=d)
+        if with_x0:   # r0 = D^-1 (b - A x0) on the left, D^-1 b - (D^-1 A) x0 on the right: equal because the scaling is exact
+            x2, h2 = orc.bicgstabl(As, (b / d).astype(dtype), l, x0, r_shadow=sh, max_mv_products=40 * l, reltol=0.0, mode=mode, shape=shape)
+        else:
+            x2, h2 = orc.bicgstabl(As, (b / d).astype(dtype), l, None, r_shadow=sh, max_mv_products=40 * l, reltol=0.0, mode=mode, shape=shape)
+        assert h1["iters"] == h2["iters"] >= 10 and h1["mvps"] == h2["mvps"]
+        assert np.array_equal(h1["resnorm"], h2["resnorm"], equal_nan=True) and np.array_equal(x1, x2, equal_nan=True)
+    # and Pl really acts: not the unpreconditioned history
+    _, h0 = orc.bicgstabl(A, b, l, x0, r_shadow=sh, max_mv_products=40 * l, reltol=0.0)
+    assert not np.array_equal(h0["resnorm"], h1["resnorm"])
+
+
 def test_lu_solve_matches_numpy(pkg, orc):
     rng = np.random.default_rng(0)
     for n in (1, 2, 4, 7):
@@ -134,26 +166,61 @@ def test_singular_mr_system_raises_like_lu(pkg, fused):
     it = pkg.bicgstabl_iterator_(pkg.zerox(dA, b), dA, b, 1, max_mv_products=100, initial_zero=True, fused=fused)
     with pytest.raises(np.linalg.LinAlgError):
         list(it)
+    if fused:
+        # a code of its own (MIK_ERR_SINGULAR = 8), never the invalid-argument code; the handle is latched afterwards
+        import ctypes as C
+        out = np.zeros(1)
+        assert pkg.lib().mik_bicgstab_step(it._step, out.ctypes.data_as(C.c_void_p)) == 8
+        assert pkg.lib().mik_bicgstab_step(None, out.ctypes.data_as(C.c_void_p)) == 1
+        assert pkg.lib().mik_lu_solve(0, np.zeros((2, 2), order="F").ctypes.data_as(C.c_void_p), 2, 2, np.ones(2).ctypes.data_as(C.c_void_p)) == 8
+
+
+@pytest.mark.gpu
+def test_context_frees_step_handles_the_host_never_destroyed(pkg):
+    """a finalizer that finds its context closed skips mik_*_destroy; the context owns the step handles still alive and
+    frees them in mik_ctx_destroy (a destroyed handle unregisters itself: no double free either way)."""
+    import ctypes as C
+    L = pkg.lib()
+    hctx = pkg.HipContext(0)
+    n = 64
+    dA = pkg.HipCSR(n, n, np.arange(1, n + 2), np.arange(1, n + 1), np.full(n, 2.0), ctx=hctx)
+    blk = pkg.HipMatrix(n, 6, np.float64, hctx)
+    v = [pkg.HipVector(n, np.float64, hctx) for _ in range(8)]
+    P = lambda o: C.c_void_p(o.ptr)                                            # noqa: E731
+    hs = [C.c_void_p() for _ in range(3)]
+    for h in hs[:2]:
+        assert L.mik_bicgstab_create(hctx.handle, dA.handle, 2, P(v[0]), P(blk.col(0)), blk.ld, P(blk.col(3)), blk.ld, P(v[1]), None, C.byref(h)) == 0
+    assert L.mik_minres_create(hctx.handle, dA.handle, P(v[0]), P(v[1]), P(v[2]), P(v[3]), P(v[4]), P(v[5]), P(v[6]), 1.0, 0, C.byref(hs[2])) == 0
+    assert L.mik_bicgstab_destroy(hs[0]) == 0                                  # one destroyed by the host, two left to the context
+    del dA, blk, v
+    hctx.close()
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_whole_iteration_call_with_jacobi_pl(pkg, orc, ctx, dtype):
-    """mik_bicgstab_step with a diagonal Pl (ldiv! after both mul! of the BiCG part, src/bicgstabl.jl:98, :108) against the
-    statement-by-statement path: same history, same x."""
+@pytest.mark.parametrize("l", [1, 2, 4])
+@pytest.mark.parametrize("with_x0", [False, True])
+def test_jacobi_pl_matches_oracle_bit_exact(pkg, orc, ctx, dtype, l, with_x0):
+    """BiCGStab(l) with a diagonal Pl (ldiv! on the initial residual and after both mul! of the BiCG part,
+    src/bicgstabl.jl:55, :98, :108) -- the whole-iteration call mik_bicgstab_step AND the statement-by-statement path against the
+    ORACLE (tree mode; oracle/orc_impl.inc orc_bicgstabl with pl_diag): history, counters and x bit for bit, zero and nonzero
+    start, fp64 and fp32."""
     A, b = orc.advdiff(10, 200.0)
     A, b = A.astype(dtype), b.astype(dtype)
     dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
     diag = A.to_scipy().diagonal().astype(dtype)
     sh = (orc.hashed_rhs(A.n) + 0.5).astype(dtype)
-    runs = []
+    x0 = np.random.default_rng(7).standard_normal(A.n).astype(dtype) if with_x0 else None
+    max_mv = 40 * l
+    xo, ho = orc.bicgstabl(A, b, l, x0, r_shadow=sh, max_mv_products=max_mv, reltol=0.0, mode="tree", shape=ctx.reduce_shape(dtype), pl_diag=diag)
+    assert ho["iters"] == 20
     for fused in (True, False):
-        x = pkg.HipVector.from_numpy(np.zeros(A.n, dtype))
-        it = pkg.bicgstabl_iterator_(x, dA, pkg.HipVector.from_numpy(b), 2, Pl=pkg.JacobiPrec(pkg.HipVector.from_numpy(diag)), max_mv_products=80,
-                                     reltol=0.0, initial_zero=True, r_shadow=pkg.HipVector.from_numpy(sh), fused=fused)
-        runs.append((np.array(list(it)), x.to_numpy()))
-    assert runs[0][0].size == 20
-    assert np.array_equal(runs[0][0], runs[1][0], equal_nan=True) and np.array_equal(runs[0][1], runs[1][1], equal_nan=True)
+        x = pkg.HipVector.from_numpy(np.zeros(A.n, dtype) if x0 is None else x0.copy())
+        it = pkg.bicgstabl_iterator_(x, dA, pkg.HipVector.from_numpy(b), l, Pl=pkg.JacobiPrec(pkg.HipVector.from_numpy(diag)), max_mv_products=max_mv,
+                                     reltol=0.0, initial_zero=not with_x0, r_shadow=pkg.HipVector.from_numpy(sh), fused=fused)
+        hist = np.array(list(it))
+        assert hist.size == ho["iters"] and it.mv_products == ho["mvps"]
+        assert np.array_equal(hist, ho["resnorm"], equal_nan=True) and np.array_equal(x.to_numpy(), xo, equal_nan=True)
 
 
 @pytest.mark.gpu

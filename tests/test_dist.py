@@ -512,6 +512,48 @@ def test_native_comm_world1_equals_single_gpu_path(pkg, orc, ctx, force_rccl):
     nc.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("knobs", [(), (9,), (26,), (9, 26)])
+@pytest.mark.parametrize("scale,with_x0", [(1e-140, False), (1e140, False), (1e-140, True)])
+@pytest.mark.parametrize("batch", [1, 9])
+def test_rccl_path_badly_scaled_rhs_freezes_on_the_last_step_of_a_batch(pkg, orc, ctx, knobs, scale, with_x0, batch):
+    """mik_cgd_iterate_many -- the RCCL call path, a world of one needs no transport -- on a system whose |r|^2
+    leaves the safe range in EVERY step.  With batch = 1 (DistCG.iterate()) every frozen step is the last of its batch: the head
+    enqueued ahead applies the step's x .+= alpha .* u but no tail follows to clear the pending flag, and the next call's fresh head
+    used to add the same alpha u again -- a silently wrong x under a correct-looking history.  x and the history bit for bit
+    against the oracle, with and without look-ahead (knob 9), both alpha forms (knob 26), freezes mid-batch and on the last step
+    (batch = 9 with a 1-step prologue)."""
+    d = dist_mod(pkg)
+    N, NZ = 12, 12
+    L = pkg.lib()
+    for k in knobs:
+        L.mik_set_tuning(k, 1)
+    try:
+        shape = ctx.cg_shape(np.float64)
+        x0 = np.random.default_rng(5).standard_normal(N * N * NZ) * scale if with_x0 else None
+        mk = lambda pp, li, vv, pl, bl, xl: d.HipEngine(pkg, pp, li, vv, pl, bl, xl, abstol=0.0, reltol=1.5e-8, maxiter=10 ** 6)
+        (eng,), offsets, b = make_engines(pkg, orc, N, NZ, 1, mk, x0, b_scale=scale)
+        nc = d.NativeComm(pkg, eng.ctx, d.SelfComm())
+        it = d.NativeDistCGIterable(pkg, eng, nc, maxiter=10 ** 6)
+        hist, iteration = [], 0
+        while True:
+            h = it.iterate_many(iteration, 1 if iteration < 2 else batch)
+            if h.size == 0:
+                break
+            hist.append(h)
+            iteration += h.size
+        hist = np.concatenate(hist)
+        xo, ho = oracle_history(orc, pkg, N, NZ, offsets, b, shape, x0)
+        assert ho["iters"] > 10 and ho["isconverged"]
+        assert hist.size == ho["iters"] and np.array_equal(hist, ho["resnorm"])
+        assert np.array_equal(eng.solution(), xo)
+        eng.close()
+        nc.close()
+    finally:
+        for k in knobs:
+            L.mik_set_tuning(k, 0)
+
+
 def test_native_transport_argument_checks(pkg):
     """no GPU needed: the new entry points reject NULL handles instead of crashing"""
     import ctypes as C
