@@ -35,8 +35,8 @@
  *            per 64, then the 16 wave sums left to right.
  *  Multiply and add are never contracted into an FMA (the library is built -ffp-contract=off) and
  *  the SpMV sums each row serially in ascending column order, exactly like the reference's CSC
- *  column scatter (rows longer than mik_spmv_long_row() entries: one wave per row, lane l sums the
- *  products of entries l, l+64, ... in order, then the wave tree).  oracle/mik_oracle.c (mode ORC_TREE) restates the same tree on the CPU.
+ *  column scatter (rows longer than mik_spmv_long_row() entries: one wave per row segment, lane l sums the
+ *  products of the groups l, l+64, ... of 4 consecutive entries in order, then the wave tree: mik_spmv_long_row below).  oracle/mik_oracle.c (mode ORC_TREE) restates the same tree on the CPU.
  *
  * Norms (the reference's norm() is BLAS nrm2 / generic_norm2: over- and underflow-safe)
  *  norm(x) = sqrt(t), t = tree sum of x_i^2, whenever t lies in [2^-900, 2^900] (fp32: [2^-70, 2^100]) -- then no
@@ -104,13 +104,15 @@ int mik_reduce_shape(int dtype, int *W, int *L);
 /* (W, L) of the dot(u, c) fused into the SpMV of the CG step: one row per thread (W = 1), L
  * consecutive 256-row blocks per workgroup. */
 int mik_spmv_dot_shape(int *W, int *L);
-/* Rows with more than *threshold stored entries are summed with the wave shape (lane l adds the
- * products of entries l, l+64, ... in order, then the wave-64 tree); shorter rows strictly in column
- * order like the reference.  None of the reference's fixtures has such rows. */
+/* Rows with more than *threshold stored entries are summed with the wave shape: the row's entries are taken in GROUPS of *group
+ * (= 4) consecutive entries; lane l of a wave adds, from +0 and in ascending order, the products of the groups l, l + 64, ...
+ * (entry e belongs to lane (e / 4) % 64 -- the shape of one 64-thread segment of a dot product read with 16-byte loads), then the
+ * wave-64 tree; shorter rows strictly in column order like the reference.  None of the reference's fixtures has such rows. */
 int mik_spmv_long_row(int *threshold);
-/* Rows with more than *segment entries are cut into segments of that many consecutive entries; every segment is summed
- * with the wave shape above and the segment sums are added left to right (one wave per row left a 20,000-entry row to a
- * single wave). */
+int mik_spmv_long_group(int *group);
+/* Rows with more than *segment entries (a multiple of the group) are cut into segments of that many consecutive entries; every
+ * segment is summed with the wave shape above and the segment sums are added left to right (one wave per row left a
+ * 20,000-entry row to a single wave). */
 int mik_spmv_long_segment(int *segment);
 
 /* ---- device memory (similar / zero / copyto! / fill! of the vector interface) ----------- */

@@ -71,6 +71,7 @@ SIGNATURES = {
     "mik_ctx_set_tuning": (C.c_int, [_vp, C.c_int, C.c_int]),
     "mik_spmv_long_row": (C.c_int, [_ip]),
     "mik_spmv_long_segment": (C.c_int, [_ip]),
+    "mik_spmv_long_group": (C.c_int, [_ip]),
     "mik_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "mik_free": (C.c_int, [_vp, _vp]),
     "mik_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),

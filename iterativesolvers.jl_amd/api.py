@@ -78,6 +78,12 @@ class HipContext:
         check(lib().mik_spmv_long_row(C.byref(t)), "mik_spmv_long_row", self.handle)
         return t.value
 
+    def spmv_long_group(self) -> int:
+        """Long rows are summed in groups of this many consecutive entries per lane (include/mik.h)."""
+        t = C.c_int()
+        check(lib().mik_spmv_long_group(C.byref(t)), "mik_spmv_long_group", self.handle)
+        return t.value
+
     def spmv_long_segment(self) -> int:
         """Rows with more stored entries than this are summed segment by segment (include/mik.h)."""
         t = C.c_int()

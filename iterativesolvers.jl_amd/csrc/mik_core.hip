@@ -160,9 +160,17 @@ extern "C" int mik_spmv_long_row(int *threshold)
 
 extern "C" int mik_spmv_long_segment(int *segment)
 {
-    if (segment) *segment = g_mik_tuning[15] > 0 ? g_mik_tuning[15] : MIK_LONG_SEG;
+    if (segment) *segment = ((g_mik_tuning[15] > 0 ? g_mik_tuning[15] : MIK_LONG_SEG) + 3) & ~3;   // whole groups of MIK_LONG_G entries
     return MIK_OK;
 }
+
+extern "C" int mik_spmv_long_group(int *group)
+{
+    if (group) *group = MIK_LONG_G;
+    return MIK_OK;
+}
+
+static inline bool spmv_csr_rowgather(const mik_csr *A);
 
 extern "C" int mik_ctx_set_tuning(mik_ctx *ctx, int key, int value)
 {
@@ -659,6 +667,46 @@ static int csr_build_sdiaw(mik_ctx *ctx, mik_csr *A, const std::vector<int> &row
     return MIK_OK;
 }
 
+// Windows of x for the product-tile kernel (k_spmv_rowblock XWIN, csrc/mik_spmv.h): for every 256-row block the first column its
+// SHORT rows reference, aligned down to 16 bytes; one common span = the widest block's, rounded up to whole 1-KiB LDS-DMA pieces.
+// Built for irregular operators (split-off long rows or rows beyond 32 entries: the uniform short-row operators stay with the
+// LDS-DMA tile of k_spmv_rowgather) when the blocks that span at most 32 KB of x hold three quarters of the entries and x is at least
+// one span long; a wider block (rows that wrap around the matrix) is marked -1 and gathers from memory; a window that would leave x at
+// the end of the vector slides down.  Development knob 29: 1 = never (read here), 2 = not used at launch.
+static int csr_build_xwin(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowptr, const std::vector<int> &col, size_t es, int64_t n_rows, int64_t n_cols,
+                          int max_row)
+{
+    if (A->sdia_val || A->sdia_pats || A->sdiaw_pats || A->jds_val || n_rows <= 0 || ctx->tuning[29] == 1) return MIK_OK;
+    if (A->n_long == 0 && max_row <= 32) return MIK_OK;
+    const int W = (int)(16 / es), XP = (int)(1024 / es);
+    const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK, cap = 32768 / (int64_t)es - W;
+    std::vector<int> lo((size_t)nb, 0);
+    int64_t need = 0, inside = 0;                               // widest qualifying block; entries of the qualifying blocks
+    for (int64_t b = 0; b < nb; ++b) {
+        const int ka = rowptr[(size_t)(b * MIK_BLOCK)], kb = rowptr[(size_t)std::min<int64_t>((b + 1) * MIK_BLOCK, n_rows)];
+        if (kb <= ka) continue;
+        int mn = INT32_MAX, mx = -1;
+        for (int k = ka; k < kb; ++k) { mn = std::min(mn, col[(size_t)k]); mx = std::max(mx, col[(size_t)k]); }
+        lo[(size_t)b] = mn & ~(W - 1);
+        const int64_t nd = (int64_t)mx + 1 - lo[(size_t)b];
+        if (nd > cap) { lo[(size_t)b] = -1; continue; }         // this block gathers from memory
+        need = std::max(need, nd);
+        inside += kb - ka;
+    }
+    if (need <= 0 || 4 * inside < 3 * (int64_t)rowptr[(size_t)n_rows]) return MIK_OK;
+    const int64_t span = (need + W + XP - 1) / XP * XP;
+    if (span + W > n_cols) return MIK_OK;
+    for (int64_t b = 0; b < nb; ++b)
+        if (lo[(size_t)b] >= 0 && (int64_t)lo[(size_t)b] + span > n_cols) lo[(size_t)b] = (int)((n_cols - span) & ~(int64_t)(W - 1));
+    hipError_t e;
+    (void)hipSetDevice(ctx->device);
+    if ((e = hipMalloc((void **)&A->xwin_lo, sizeof(int) * (size_t)nb)) != hipSuccess ||
+        (e = hipMemcpy(A->xwin_lo, lo.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice)) != hipSuccess)
+        return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: window table: %s", hipGetErrorString(e));
+    A->xwin_span = (int)span;
+    return MIK_OK;
+}
+
 // Jagged slices (csrc/mik_jds.h) from the SHORT part of the CSR arrays (split-off long rows have no entries there; `is_long`
 // marks them).  Built when no structured layout applies, every wave's lanes stay busy in the natural row order (wave
 // iterations within 25 % of the ideal: near-uniform rows) and either the rows are long (more than 32 entries somewhere) or the
@@ -950,13 +998,19 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
     const int long_row = ctx->tuning[4] > 0 ? ctx->tuning[4] : MIK_LONG_ROW;
     if (max_row > long_row && ctx->tuning[4] >= 0) {
         is_long.assign((size_t)n_rows, 0);
-        std::vector<int> rp2((size_t)n_rows + 1, 0), col2((size_t)nnz);
-        std::vector<unsigned char> v2((size_t)nnz * es);
-        int64_t short_nnz = 0;
-        for (int64_t r = 0; r < n_rows; ++r)
-            if (rowptr[r + 1] - rowptr[r] <= long_row) short_nnz += rowptr[r + 1] - rowptr[r];
-        int64_t ps = 0, pl = (short_nnz + 3) & ~(int64_t)3;           // long part starts 16-byte aligned
-        if (pl + (nnz - short_nnz) > (int64_t)col2.size()) { col2.resize((size_t)(pl + nnz - short_nnz)); v2.resize(col2.size() * es); }
+        std::vector<int> rp2((size_t)n_rows + 1, 0), col2;
+        std::vector<unsigned char> v2;
+        int64_t short_nnz = 0, long_store = 0;
+        for (int64_t r = 0; r < n_rows; ++r) {
+            const int64_t len = rowptr[r + 1] - rowptr[r];
+            if (len <= long_row) short_nnz += len; else long_store += (len + 3) & ~(int64_t)3;
+        }
+        // the long part starts 16-byte aligned and EVERY long row does (padded to a multiple of 4 entries with {column 0, value 0}:
+        // a lane reads its group of 4 with one 16-byte load, spmv_longrow_wave; the padding is gathered, multiplied and never added)
+        int64_t ps = 0, pl = (short_nnz + 3) & ~(int64_t)3;
+        if (pl + long_store > INT32_MAX) return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_csr_create: more than 2^31 stored entries");
+        col2.assign((size_t)(pl + long_store), 0);
+        v2.assign(col2.size() * es, 0);
         for (int64_t r = 0; r < n_rows; ++r) {
             const int len = rowptr[r + 1] - rowptr[r];
             rp2[r] = (int)ps;
@@ -968,22 +1022,14 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
                 long_rows.push_back((int)r); long_start.push_back((int)pl); long_len.push_back(len);
                 memcpy(&col2[pl], &col[rowptr[r]], sizeof(int) * len);
                 memcpy(&v2[(size_t)pl * es], &v[(size_t)rowptr[r] * es], es * len);
-                pl += len;
+                pl += (len + 3) & ~3;
             }
         }
         rp2[n_rows] = (int)ps;
-        {   // longest rows first: their serial chains are the critical path of the SpMV
-            std::vector<int> ord(long_rows.size());
-            for (size_t q = 0; q < ord.size(); ++q) ord[q] = (int)q;
-            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return long_len[a] > long_len[b]; });
-            std::vector<int> lr(ord.size()), ls(ord.size()), ll(ord.size());
-            for (size_t q = 0; q < ord.size(); ++q) { lr[q] = long_rows[ord[q]]; ls[q] = long_start[ord[q]]; ll[q] = long_len[ord[q]]; }
-            long_rows.swap(lr); long_start.swap(ls); long_len.swap(ll);
-        }
-        for (int64_t q = ps; q < ((short_nnz + 3) & ~(int64_t)3); ++q) { col2[q] = 0; memset(&v2[(size_t)q * es], 0, es); }
         rowptr.swap(rp2); col.swap(col2); v.swap(v2);
-        {   // rows longer than one segment are cut: every segment becomes a virtual row of its own (csrc/mik_spmv.h, LongTab)
-            const int seg = ctx->tuning[15] > 0 ? ctx->tuning[15] : MIK_LONG_SEG;      // development knob: segment length
+        {   // rows longer than one segment are cut: every segment becomes a virtual row of its own (csrc/mik_spmv.h, LongTab); the
+            // list stays in (row, segment) order -- the four waves of a workgroup then walk neighbouring pieces of one row
+            const int seg = ((ctx->tuning[15] > 0 ? ctx->tuning[15] : MIK_LONG_SEG) + 3) & ~3;    // development knob: segment length (whole groups of 4)
             std::vector<int> vr, vs, vl;
             for (size_t q = 0; q < long_rows.size(); ++q) {
                 if (long_len[q] <= seg) { vr.push_back(long_rows[q]); vs.push_back(long_start[q]); vl.push_back(long_len[q]); continue; }
@@ -996,11 +1042,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
                     seg_row.push_back((int)cut_row.size() - 1);
                 }
             }
-            std::vector<int> ord(vr.size());
-            for (size_t q = 0; q < ord.size(); ++q) ord[q] = (int)q;
-            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return vl[a] > vl[b]; });
-            long_rows.resize(vr.size()); long_start.resize(vr.size()); long_len.resize(vr.size());
-            for (size_t q = 0; q < ord.size(); ++q) { long_rows[q] = vr[ord[q]]; long_start[q] = vs[ord[q]]; long_len[q] = vl[ord[q]]; }
+            long_rows.swap(vr); long_start.swap(vs); long_len.swap(vl);
         }
     }
     const int64_t nnz_store = (int64_t)col.size();                     // entries physically stored (>= nnz when re-laid out)
@@ -1013,8 +1055,6 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
     if (!A) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host allocation failed");
     A->max_rowblock_nnz = max_rb;
     A->n_long = (int)long_rows.size();
-    A->n_long_big = 0;
-    for (int len : long_len) if (len > 256) A->n_long_big++;            // sorted longest first: a prefix of the list (segments included)
     A->ctx = ctx; A->dtype = dtype; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz; A->max_row_nnz = max_row; A->strip = strip;
     const size_t pad = 2 * MIK_SPMV_TILE;   // slack so tile-granular reads never leave the allocation
     auto cleanup = [&]() { mik_csr_destroy(A); };
@@ -1062,6 +1102,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
     int rc_layout = csr_build_sdia(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz, max_row);
     if (rc_layout == MIK_OK) rc_layout = csr_build_sdiaw(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz);
     if (rc_layout == MIK_OK) rc_layout = csr_build_jds(ctx, A, rowptr, col, v, es, n_rows, is_long.empty() ? nullptr : is_long.data());
+    if (rc_layout == MIK_OK) rc_layout = csr_build_xwin(ctx, A, rowptr, col, es, n_rows, n_cols, max_row);
     if (rc_layout == MIK_OK) rc_layout = sdiaw_chunk_bits(ctx, A);
     if (rc_layout != MIK_OK) { cleanup(); return rc_layout; }
     *out = A;
@@ -1090,6 +1131,7 @@ extern "C" int mik_csr_destroy(mik_csr *A)
     if (A->sdiaw_pat_id) (void)hipFree(A->sdiaw_pat_id);
     if (A->sdiaw_mask) (void)hipFree(A->sdiaw_mask);
     if (A->sdiaw_uz) (void)hipFree(A->sdiaw_uz);
+    if (A->xwin_lo) (void)hipFree(A->xwin_lo);
     if (A->jds_ptr) (void)hipFree(A->jds_ptr);
     if (A->jds_len) (void)hipFree(A->jds_len);
     if (A->jds_col) (void)hipFree(A->jds_col);
@@ -1128,7 +1170,8 @@ extern "C" int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes)
     case 4: *bytes = A->sdia_entries * es + A->n_rows + nb * 36; break;
     case 1: *bytes = A->jds_groups * (16 / es) * (es + 4) + A->n_rows * 2 + ((A->n_rows + 63) / 64 + 1) * 4 +
                      (A->n_long ? (A->nnz - A->jds_short_nnz) * (es + 4) + 12LL * A->n_long + 4LL * A->n_seg + 16LL * A->n_cut : 0); break;
-    default: *bytes = A->nnz * (es + 4) + (A->n_rows + 1) * 4 + (A->n_long ? A->n_rows + 12LL * A->n_long + 4LL * A->n_seg + 16LL * A->n_cut : 0); break;
+    default: *bytes = A->nnz * (es + 4) + (A->n_rows + 1) * 4 + (A->n_long ? A->n_rows + 12LL * A->n_long + 4LL * A->n_seg + 16LL * A->n_cut : 0) +
+                      ((A->xwin_lo && !spmv_csr_rowgather(A)) ? nb * 4 : 0); break;
     }
     return MIK_OK;
 }
@@ -1182,7 +1225,8 @@ extern "C" int mik_csr_compact(mik_csr *A)
 
 static inline bool spmv_csr_rowgather(const mik_csr *A)
 {
-    return A->ctx->tuning[14] == 2 || (A->ctx->tuning[14] == 0 && A->n_long == 0);
+    // operators with x windows (irregular rows inside a band, csr_build_xwin) run on the product tile, which gathers from them
+    return A->ctx->tuning[14] == 2 || (A->ctx->tuning[14] == 0 && A->n_long == 0 && !A->xwin_lo);
 }
 
 // k_spmv_sdiab2 (two rows per lane): the operator's class has the lane-neighbour shape, n is even, and no development
@@ -1205,7 +1249,7 @@ extern "C" int mik_spmv_kernel(const mik_csr *A, char *name, int len)
     case 6: k = ((A->n_rows & 1) == 0 && A->ctx->tuning[19] == 0) ? "k_spmv_sdiaw2" : "k_spmv_sdiaw"; break;
     case 4: k = "k_spmv_sdia"; break;
     case 1: k = "k_spmv_jds"; break;
-    default: k = spmv_csr_rowgather(A) ? "k_spmv_rowgather" : "k_spmv_rowblock"; break;
+    default: k = spmv_csr_rowgather(A) ? "k_spmv_rowgather" : ((A->xwin_lo && A->ctx->tuning[29] == 0 && A->ctx->tuning[1] == 0) ? "k_spmv_rowblock+xwin" : "k_spmv_rowblock"); break;
     }
     snprintf(name, (size_t)len, "%s", k);
     return MIK_OK;
@@ -1368,7 +1412,6 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         return MIK_OK;
     }
     const int nlong = A->n_long;
-    const int nbig = A->n_long_big;
     LongTab lt{};
     if (nlong) {
         int *tb = A->long_rows;
@@ -1376,10 +1419,9 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         lt.seg_row = tb + 3 * nlong;
         lt.cut_row = lt.seg_row + A->n_seg; lt.cut_first = lt.cut_row + A->n_cut; lt.cut_nseg = lt.cut_first + A->n_cut;
         lt.tickets = (unsigned *)(tb + 3 * nlong + A->n_seg + 3 * A->n_cut);
-        lt.seg_sum = A->seg_sum; lt.nlong = nlong; lt.nbig = nbig;
+        lt.seg_sum = A->seg_sum; lt.nlong = nlong;
     }
-    const int nwaves_long = nbig + (nlong - nbig + MIK_LONG_R - 1) / MIK_LONG_R;   // one wave per big row, MIK_LONG_R medium rows per wave
-    const int nlb = (nwaves_long + 3) / 4;
+    const int nlb = (nlong + 3) / 4;                    // one wave per virtual row (a whole row or a segment of a cut row)
     if (choice == 1) {
         // jagged slices (mik_jds.h): one row per lane, 16-byte operator streams; the workgroups of split-off long rows lead the same
         // launch.  dot(x, y) is formed inside unless long rows exist (their sums arrive from other workgroups): then by k_rowdot.
@@ -1430,13 +1472,17 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         MIK_LAUNCH_CHECK(ctx);
     }
     const dim3 grid(nb + (merge ? nlb : 0)), block(MIK_BLOCK);
-#define MIK_SPMV_GO(FD, NT, WD, MG)                                                                              \
-    hipLaunchKernelGGL((k_spmv_rowblock<T, FD, NT, WD, MG>), grid, block, 0, ctx->stream, n, nb, map_mode, A->rowptr, \
-                       A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, nlb, lt)
+    // x served from an LDS window per row-block (csr_build_xwin; development knob 29 = 2: off at launch) -- wide loads and an aligned x only
+    const bool xwin = A->xwin_lo && wide && ctx->tuning[29] == 0 && mik_aligned16(x);
+    const size_t dyn = xwin ? sizeof(T) * (size_t)A->xwin_span : 0;
+#define MIK_SPMV_GO(FD, NT, WD, MG, XW)                                                                          \
+    hipLaunchKernelGGL((k_spmv_rowblock<T, FD, NT, WD, MG, XW>), grid, block, XW ? dyn : 0, ctx->stream, n, nb, map_mode, A->rowptr, \
+                       A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, nlb, lt, (const int *)A->xwin_lo, A->xwin_span)
 #define MIK_SPMV_GO2(FD, MG)                                                              \
     do {                                                                                  \
-        if (nt) { if (wide) MIK_SPMV_GO(FD, true, true, MG); else MIK_SPMV_GO(FD, true, false, MG); }   \
-        else    { if (wide) MIK_SPMV_GO(FD, false, true, MG); else MIK_SPMV_GO(FD, false, false, MG); } \
+        if (xwin) { if (nt) MIK_SPMV_GO(FD, true, true, MG, true); else MIK_SPMV_GO(FD, false, true, MG, true); }   \
+        else if (nt) { if (wide) MIK_SPMV_GO(FD, true, true, MG, false); else MIK_SPMV_GO(FD, true, false, MG, false); }   \
+        else    { if (wide) MIK_SPMV_GO(FD, false, true, MG, false); else MIK_SPMV_GO(FD, false, false, MG, false); } \
     } while (0)
     if (fuse_dot) MIK_SPMV_GO2(true, false);
     else if (merge) MIK_SPMV_GO2(false, true);

@@ -63,7 +63,8 @@ struct mik_csr {
     int force_layout = -1;           // mik_csr_set_layout: 0 = run on the CSR arrays, -1 = automatic
     int max_rowblock_nnz = 0;        // largest nnz of any 256-row block (short part)
     int n_long = 0;                  // rows longer than MIK_LONG_ROW, stored behind the short part
-    int n_long_big = 0;              // how many of them exceed 256 entries (one wave each; the rest go 4 per wave)
+    int *xwin_lo = nullptr;          // device, one per 256-row block: first column of the block's window of x (k_spmv_rowblock XWIN); NULL = no windows
+    int xwin_span = 0;               // elements of x per window (a multiple of 1 KiB)
     int *long_rows = nullptr;        // device: [n_long] targets, [n_long] start offsets, [n_long] lengths of the virtual rows, then the
                                      // segment tables: [n_seg] cut-row index, [n_cut] row, [n_cut] first segment, [n_cut] segments, [n_cut] tickets
     int n_seg = 0, n_cut = 0;        // rows longer than MIK_LONG_SEG are cut into n_seg segments (csrc/mik_spmv.h)

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_jds(int n, int rb0, const in
     int bid = blockIdx.x;
     if (MERGE_LONG) {
         if (bid < nlb) {       // long-row workgroups first: their chains are the longest
-            spmv_longrow_group<T>(bid * (MIK_BLOCK / 64) + (t >> 6), lt, col, val, x, y);
+            spmv_longrow_wave<T>(bid * (MIK_BLOCK / 64) + (t >> 6), lt, col, val, x, y);
             return;
         }
         bid -= nlb;

@@ -70,44 +70,47 @@ __device__ __forceinline__ int spmv_block_map(int b, int nb, int mode)
 }
 
 // ---------------------------------------------------------------------------------------------
-// long rows: one wave per row
+// long rows: one wave per segment
 // ---------------------------------------------------------------------------------------------
 // Rows with more than MIK_LONG_ROW entries are stored behind the short part (mik_csr_create) and summed
 // here -- a thread-per-row tile only pays while a 2048-entry tile covers many rows, and a single serial
 // chain over a 20,000-entry row costs > 100 us however it is fed (measured: ~13 cycles per entry).
 //
 // Row-sum shape for these rows (part of the documented reduction semantics, include/mik.h; the oracle's
-// TREE mode mirrors it): lane l of the wave sums the products of entries l, l+64, l+128, ... of the row
-// in ascending order starting from +0, then the wave-64 shuffle-down tree (offsets 32..1) -- the same
-// shape as one 64-thread segment of a dot product.  Rows up to MIK_LONG_ROW entries keep the reference's
-// strictly sequential order.
+// long-row mode mirrors it): a row is cut into SEGMENTS of MIK_LONG_SEG consecutive entries; inside a segment
+// lane l of a wave sums, starting from +0 and in ascending order, the products of the GROUPS l, l + 64, l + 128, ...
+// of MIK_LONG_G = 4 consecutive entries (entry e of the segment belongs to lane (e / 4) % 64) -- the shape of one
+// 64-thread segment of a dot product with 16-byte loads (include/mik.h, level 1) -- then the wave-64 shuffle-down
+// tree (offsets 32..1); the segment sums are added left to right.  Rows up to MIK_LONG_ROW entries keep the
+// reference's strictly sequential order.
 //
-// The wave streams the row in chunks of 64*U entries (coalesced val/col loads, gathered x) through a
-// three-stage software pipeline: while chunk c is accumulated, the x-gather of chunk c+1 and the
-// val/col stream of chunk c+2 are in flight.
-constexpr int MIK_LONG_U = 8;                          // entries per lane per chunk
-constexpr int MIK_LONG_CH = 64 * MIK_LONG_U;           // 512-entry chunks
+// Round 4: until round 3 a lane took single entries l, l + 64, ... with 4-byte loads through a
+// three-stage chunk pipeline, 4 unrelated rows per workgroup, longest first: 40.7 us for the 12.5 M long-row entries
+// of the banded configs[4] stand-in (2.4 TB/s; profiles/r04_c5_banded_*).  A vector-memory instruction is priced
+// per instruction on this GPU (scripts/micro/gather_width.hip), so the operator streams now come as ONE 16-byte
+// column load and one (fp64: two) 16-byte value load(s) per lane and group -- which is what fixes the group of 4
+// in the shape above -- every row starts 16-byte aligned in the long part, all loads of a pass are issued before
+// anything is waited for, the next pass's streams go out ahead of this pass's gathers, and the virtual rows are
+// listed in (row, segment) order so that the four waves of a workgroup walk neighbouring pieces of ONE row's
+// sorted column window (val / col streamed non-temporally, x gathered with the default policy).
+constexpr int MIK_LONG_G = 4;                          // entries per lane and group (one 16-byte column load)
 
-// Rows with more than MIK_LONG_SEG entries are cut into SEGMENTS of MIK_LONG_SEG consecutive entries: every segment is
-// summed by its own wave with the shape above (lane l: the segment's entries l, l + 64, ... in order; wave tree), and
-// the segment sums are added left to right -- by whichever wave finishes the row's last outstanding segment (an integer
-// ticket elects it; the sums themselves are stored individually and always added in segment order, so the result does
-// not depend on the order in which the waves finish).  A guard against pathological rows: one wave per row makes a dense
-// row of 10^6 entries a single serial chain of ~2000 chunks (milliseconds).  On the irregular configs[4] stand-in (rows up
-// to 20 k entries) cutting changes nothing -- 196 us uncut, 198 us cut: that SpMV is bound by its 34 M random gathers of x
-// (profiles/r02_c5_*), not by the length of any chain.
-// The oracle's long-row mode mirrors the segments (orc.set_long_row(threshold, segment)).
+// Rows with more than MIK_LONG_SEG entries are cut into segments: every segment is summed by its own wave with the
+// shape above and the segment sums are added left to right -- by whichever wave finishes the row's last outstanding
+// segment (an integer ticket elects it; the sums themselves are stored individually and always added in segment order,
+// so the result does not depend on the order in which the waves finish).
+// The oracle's long-row mode mirrors the segments and the groups (orc.set_long_row(threshold, segment, group)).
 constexpr int MIK_LONG_SEG = 2048;
 
 // Tables of the long-row part (device, built at upload).  `rows[w]` >= 0: virtual row w is a whole row, its sum goes to
 // y[rows[w]]; < 0: it is segment -(rows[w] + 1) of a cut row.
 struct LongTab {
-    const int *rows, *starts, *lens;   // per virtual row (whole rows and segments, longest first)
+    const int *rows, *starts, *lens;   // per virtual row (whole rows and segments, in (row, segment) order); starts are multiples of 4
     const int *seg_row;                // per segment: index h of its cut row
     const int *cut_row, *cut_first, *cut_nseg;   // per cut row: matrix row, first segment, number of segments
     unsigned *tickets;                 // per cut row, zero between launches
     void *seg_sum;                     // per segment, dtype of the operator
-    int nlong, nbig;
+    int nlong;
 };
 
 template <typename T> __device__ __forceinline__ void longrow_store(const LongTab &lt, int w, T acc, T *__restrict__ y)
@@ -133,113 +136,67 @@ template <typename T> __device__ __forceinline__ void longrow_store(const LongTa
     }
 }
 
-template <typename T>
-__device__ __forceinline__ void spmv_longrow_wave(int w, const LongTab &lt, const int *__restrict__ col,
-                                                  const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y)
-{
-    constexpr int U = MIK_LONG_U, CH = MIK_LONG_CH;
-    const int lane = threadIdx.x & 63;
-    const int k0 = lt.starts[w], len = lt.lens[w];
-    T acc = T(0);
-    if (len <= CH) {
-        // medium rows: one chunk, every load issued at once (no pipeline prologue / epilogue)
-        T v[U], xv[U];
-        int c[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = u * 64 + lane;
-            if (j < len) { v[u] = val[k0 + j]; c[u] = col[k0 + j]; }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (u * 64 + lane < len) xv[u] = x[c[u]];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (u * 64 + lane < len) { const T prod = v[u] * xv[u]; acc = acc + prod; }
-        acc = wave_tree(acc);
-        if (lane == 0) longrow_store<T>(lt, w, acc, y);
-        return;
+// the 4 values of a group: one 16-byte load (fp32) or two (fp64)
+template <typename T> struct LongVal;
+template <> struct LongVal<float> {
+    mik_f32x4 a;
+    __device__ __forceinline__ void load(const float *p) { a = __builtin_nontemporal_load(reinterpret_cast<const mik_f32x4 *>(p)); }
+    __device__ __forceinline__ float get(int e) const { return a[e]; }
+};
+template <> struct LongVal<double> {
+    mik_f64x2 a, b;
+    __device__ __forceinline__ void load(const double *p)
+    {
+        a = __builtin_nontemporal_load(reinterpret_cast<const mik_f64x2 *>(p));
+        b = __builtin_nontemporal_load(reinterpret_cast<const mik_f64x2 *>(p) + 1);
     }
-    T vA[U], xA[U], vB[U], vC[U];
-    int cB[U], cC[U];
-    auto stream = [&](int base, T(&vv)[U], int(&cc)[U]) {
+    __device__ __forceinline__ double get(int e) const { return e < 2 ? a[e] : b[e - 2]; }
+};
+
+// wave w of the long part: virtual row w (a whole row of at most one segment, or one segment of a cut row)
+template <typename T>
+__device__ __forceinline__ void spmv_longrow_wave(int w, const LongTab &lt, const int *__restrict__ col, const T *__restrict__ val,
+                                                  const T *__restrict__ x, T *__restrict__ y)
+{
+    if (w >= lt.nlong) return;                          // wave-uniform
+    constexpr int G = MIK_LONG_G, U = sizeof(T) == 8 ? 2 : 4;   // groups per lane and pass (fp64 carries twice the value registers)
+    const int lane = threadIdx.x & 63;
+    const int k0 = lt.starts[w], len = lt.lens[w];      // k0 is a multiple of 4: 16-byte aligned streams
+    const int ng = (len + G - 1) / G;                   // groups of this virtual row (the last one padded in storage)
+    const int npass = (ng + 64 * U - 1) / (64 * U);
+    mik_i32x4 cA[U], cB[U];
+    LongVal<T> vA[U], vB[U];
+    auto stream = [&](int p, mik_i32x4(&cc)[U], LongVal<T>(&vv)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int j = base + u * 64 + lane;
-            vv[u] = j < len ? val[k0 + j] : T(0);
-            cc[u] = j < len ? col[k0 + j] : 0;       // padding gathers x[0]; its product is never added
+            const int g = lane + 64 * (U * p + u);
+            const int gg = g < ng ? g : 0;              // a lane without a group re-reads the first one; its products are never added
+            cc[u] = __builtin_nontemporal_load(reinterpret_cast<const mik_i32x4 *>(col + k0 + G * gg));
+            vv[u].load(val + k0 + G * gg);
         }
     };
-    stream(0, vA, cB);                                  // chunk 0 (cB doubles as its column registers)
+    T acc = T(0);
+    stream(0, cA, vA);
+    for (int p = 0; p < npass; ++p) {
+        if (p + 1 < npass) stream(p + 1, cB, vB);       // the next pass's streams go out ahead of this pass's gathers
+        T xv[U][G];
 #pragma unroll
-    for (int u = 0; u < U; ++u) xA[u] = x[cB[u]];
-    stream(CH, vB, cB);                                 // chunk 1
-    for (int base = 0; base < len; base += CH) {
-        stream(base + 2 * CH, vC, cC);                  // chunk c+2: stream
-        T xB[U];
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int u = 0; u < U; ++u) xB[u] = x[cB[u]];   // chunk c+1: gather
+            for (int e = 0; e < G; ++e) xv[u][e] = x[cA[u][e]];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {                   // chunk c: this lane's entries, ascending
-            const T prod = vA[u] * xA[u];
-            if (base + u * 64 + lane < len) acc = acc + prod;
-        }
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int u = 0; u < U; ++u) { vA[u] = vB[u]; xA[u] = xB[u]; vB[u] = vC[u]; cB[u] = cC[u]; }
+            for (int e = 0; e < G; ++e) {               // this lane's entries of the pass, ascending
+                const T prod = vA[u].get(e) * xv[u][e];
+                const T s = acc + prod;
+                acc = G * (lane + 64 * (U * p + u)) + e < len ? s : acc;
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { cA[u] = cB[u]; vA[u] = vB[u]; }
     }
     acc = wave_tree(acc);
     if (lane == 0) longrow_store<T>(lt, w, acc, y);
-}
-
-// A wave takes MIK_LONG_R consecutive rows of the (longest-first) long-row list.  Medium rows (<= 256
-// entries) are latency-bound one at a time -- ~1 KB in flight per wave -- so their loads are issued for
-// all R rows before anything is waited for; longer rows go through the pipelined path one by one.  The
-// per-row arithmetic (lane l: entries l, l+64, ... in order; wave tree) is identical either way.
-constexpr int MIK_LONG_R = 4;
-
-template <typename T>
-__device__ __forceinline__ void spmv_longrow_group(int wv, const LongTab &lt, const int *__restrict__ col, const T *__restrict__ val,
-                                                   const T *__restrict__ x, T *__restrict__ y)
-{
-    constexpr int R = MIK_LONG_R, U = 4;
-    const int nlong = lt.nlong, nbig = lt.nbig;
-    const int *__restrict__ starts = lt.starts, *__restrict__ lens = lt.lens;
-    // waves [0, nbig): one virtual row each (more than 64*U entries, longest first: their pipelined sums are
-    // the critical path); waves from nbig on: R medium rows each (never segments: those are longer)
-    if (wv < nbig) { spmv_longrow_wave<T>(wv, lt, col, val, x, y); return; }
-    const int w0 = nbig + (wv - nbig) * R;
-    if (w0 >= nlong) return;
-    const int lane = threadIdx.x & 63;
-    int k0[R], len[R];
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-        const bool ok = w0 + q < nlong;
-        k0[q] = ok ? starts[w0 + q] : 0;
-        len[q] = ok ? lens[w0 + q] : 0;
-    }
-    T v[R][U], xv[R][U];
-    int c[R][U];
-#pragma unroll
-    for (int q = 0; q < R; ++q)
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = u * 64 + lane;
-            if (j < len[q]) { v[q][u] = val[k0[q] + j]; c[q][u] = col[k0[q] + j]; }
-        }
-#pragma unroll
-    for (int q = 0; q < R; ++q)
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (u * 64 + lane < len[q]) xv[q][u] = x[c[q][u]];
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-        T acc = T(0);
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (u * 64 + lane < len[q]) { const T prod = v[q][u] * xv[q][u]; acc = acc + prod; }
-        acc = wave_tree(acc);
-        if (lane == 0 && w0 + q < nlong) longrow_store<T>(lt, w0 + q, acc, y);     // a cut row's short last segment lands here too
-    }
 }
 
 template <typename T>
@@ -248,17 +205,28 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_longrows(LongTab lt, const i
 {
     if (done && *done) return;
     const int wv = blockIdx.x * (MIK_BLOCK / 64) + (threadIdx.x >> 6);     // whole waves work alone: no block-level barrier
-    spmv_longrow_group<T>(wv, lt, col, val, x, y);
+    spmv_longrow_wave<T>(wv, lt, col, val, x, y);
 }
 
-// MERGE_LONG: the first `nlong_blocks` workgroups of the launch are long-row workgroups (4 rows each,
-// scheduled first so the longest chains start earliest); the rest are row-block workgroups.
-template <typename T, bool FUSE_DOT, bool NT, bool WIDE, bool MERGE_LONG>
+// MERGE_LONG: the first `nlb` workgroups of the launch are long-row workgroups (4 virtual rows each,
+// scheduled first); the rest are row-block workgroups.
+//
+// XWIN (round 4): the gather of x from an LDS WINDOW.  On an irregular matrix with locality (an RCM-ordered FE
+// matrix, the banded configs[4] stand-in) the lanes that stream consecutive entries gather from all over the row-block's
+// column band: every lane its own cache line, and the texture path prices a gather per distinct line -- ~1 lane per clock and
+// CU, 66 us for 34 M entries whatever surrounds them (scripts/micro/gather_random.hip), more than the operator streams cost.
+// But the band of a 256-row block is small (256 + 2 x 2000 columns = 17 KB of fp32): the workgroup copies x[win_lo[rb] ..
+// + win_span) into LDS once with LDS-DMA (1 KiB per wave-instruction, no registers) and every gather becomes a ds_read.  The
+// window table is built at upload (csr_build_xwin: enabled when the row-blocks holding three quarters of the entries span at most
+// 32 KB of x each; a block that spans more -- rows that wrap around the matrix -- carries win_lo < 0 and gathers from memory);
+// same products, same order, same bits.
+template <typename T, bool FUSE_DOT, bool NT, bool WIDE, bool MERGE_LONG, bool XWIN = false>
 __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int map_mode, const int *__restrict__ rowptr,
                                                              const int *__restrict__ col, const T *__restrict__ val,
                                                              const T *__restrict__ x, T *__restrict__ y,
                                                              T *__restrict__ seg_out, const int *__restrict__ done,
-                                                             const unsigned char *__restrict__ is_long, int nlb, LongTab lt)
+                                                             const unsigned char *__restrict__ is_long, int nlb, LongTab lt,
+                                                             const int *__restrict__ win_lo = nullptr, int win_span = 0)
 {
     if (done && *done) return;
     constexpr int TILE = MIK_SPMV_TILE * (int)(8 / sizeof(T));   // 16 KB of LDS: 2048 fp64 / 4096 fp32 products
@@ -266,12 +234,13 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
     constexpr int PER = TILE / (MIK_BLOCK * VW);       // loads per lane per tile
     __shared__ __attribute__((aligned(16))) T prod[TILE];
     __shared__ T lds4[4];
+    extern __shared__ __attribute__((aligned(16))) unsigned char mik_dyn_lds[];   // XWIN: win_span elements of x
 
     const int t = threadIdx.x;
     int bid = blockIdx.x;
     if (MERGE_LONG) {
         if (bid < nlb) {
-            spmv_longrow_group<T>(bid * (MIK_BLOCK / 64) + (t >> 6), lt, col, val, x, y);
+            spmv_longrow_wave<T>(bid * (MIK_BLOCK / 64) + (t >> 6), lt, col, val, x, y);
             return;
         }
         bid -= nlb;
@@ -283,6 +252,18 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
     if (r < n) { ks = rowptr[r]; ke = rowptr[r + 1]; }
     const int kb = rowptr[r0] & ~(VW - 1);             // tile start aligned for the wide loads
     const int kend = rowptr[min(r0 + MIK_BLOCK, n)];
+    T *xw = reinterpret_cast<T *>(mik_dyn_lds);
+    int wlo = 0;
+    if (XWIN) {
+        // the row-block's window of x -> LDS: wave wv issues the 1-KiB pieces wv, wv + 4, ... (win_span is a multiple of a piece;
+        // win_lo[rb] is 16-byte aligned and the window lies inside x); waited for together with the first tile's streams
+        constexpr int XP = 1024 / (int)sizeof(T);
+        wlo = win_lo[rb];                               // < 0: this block's columns span more than a window -- it gathers from memory
+        if (kb < kend && wlo >= 0)
+            for (int piece = t >> 6; piece * XP < win_span; piece += MIK_BLOCK / 64)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x + wlo + piece * XP + (t & 63) * (16 / (int)sizeof(T))),
+                                                 (__attribute__((address_space(3))) void *)(xw + piece * XP), 16, 0, 0);
+    }
 
     T acc = T(0);
     for (int kc = kb; kc < kend; kc += TILE) {
@@ -301,15 +282,34 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
                     c[i] = ld_stream<NT>(reinterpret_cast<const IV *>(col + kc + j));
                 }
             }
+            if (XWIN && wlo >= 0) {                     // workgroup-uniform
+                if (kc == kb) {                         // the window has landed once every wave's DMA has
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
 #pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int j = VW * (t + MIK_BLOCK * i);
-                if (j < cnt) {
-                    T xv[VW];
+                for (int i = 0; i < PER; ++i) {
+                    const int j = VW * (t + MIK_BLOCK * i);
+                    if (j < cnt) {
 #pragma unroll
-                    for (int e = 0; e < VW; ++e) xv[e] = x[c[i][e]];   // padding cols are 0
+                        for (int e = 0; e < VW; ++e) {
+                            // the aligned tile start may cover up to VW - 1 entries of the row-block before: clamped, never added
+                            const unsigned o = min((unsigned)(c[i][e] - wlo), (unsigned)(win_span - 1));
+                            prod[j + e] = v[i][e] * xw[o];
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
-                    for (int e = 0; e < VW; ++e) prod[j + e] = v[i][e] * xv[e];
+                for (int i = 0; i < PER; ++i) {
+                    const int j = VW * (t + MIK_BLOCK * i);
+                    if (j < cnt) {
+                        T xv[VW];
+#pragma unroll
+                        for (int e = 0; e < VW; ++e) xv[e] = x[c[i][e]];   // padding cols are 0
+#pragma unroll
+                        for (int e = 0; e < VW; ++e) prod[j + e] = v[i][e] * xv[e];
+                    }
                 }
             }
         } else {

@@ -46,6 +46,8 @@ int orc_set_partition(int nparts, const int64_t *offsets)
 /* optional device row-sum shape for long rows (0 = off: every row strictly sequential) */
 static int64_t g_orc_long_row = 0;
 static int64_t g_orc_long_seg = 0;     /* rows longer than this are summed segment by segment (0 = never cut) */
+static int64_t g_orc_long_grp = 1;     /* entries per lane and group of the long-row shape (mik_spmv_long_group(); 1 = lane-strided single entries) */
+void orc_set_long_group(int64_t group) { g_orc_long_grp = group > 0 ? group : 1; }
 void orc_set_long_row(int64_t threshold) { g_orc_long_row = threshold > 0 ? threshold : 0; }
 void orc_set_long_segment(int64_t segment) { g_orc_long_seg = segment > 0 ? segment : 0; }
 

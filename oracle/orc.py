@@ -148,6 +148,8 @@ def _declare(L):
     L.orc_set_long_row.restype = None
     L.orc_set_long_segment.argtypes = [C.c_int64]
     L.orc_set_long_segment.restype = None
+    L.orc_set_long_group.argtypes = [C.c_int64]
+    L.orc_set_long_group.restype = None
     L.orc_set_partition.argtypes = [C.c_int, _i64p]
     L.orc_set_partition.restype = C.c_int
     L.orc_hashed_rhs.argtypes = [C.c_int64, _f64p]
@@ -163,11 +165,13 @@ def set_partition(offsets=None):
     assert lib().orc_set_partition(off.size - 1, _p(off, C.c_int64)) == 0
 
 
-def set_long_row(threshold=0, segment=0):
-    """Rows with more than `threshold` entries use the device's wave-shaped row sum in spmv (0 = off); rows with more than
-    `segment` entries are summed segment by segment (0 = never cut) -- mik_spmv_long_row() / mik_spmv_long_segment()."""
+def set_long_row(threshold=0, segment=0, group=4):
+    """Rows with more than `threshold` entries use the device's wave-shaped row sum in spmv (0 = off): lane l of 64 sums the
+    groups l, l + 64, ... of `group` consecutive entries; rows with more than `segment` entries are summed segment by segment
+    (0 = never cut) -- mik_spmv_long_row() / mik_spmv_long_segment() / mik_spmv_long_group()."""
     lib().orc_set_long_row(int(threshold or 0))
     lib().orc_set_long_segment(int(segment or 0))
+    lib().orc_set_long_group(int(group or 1))
 
 
 def _suf(dtype):

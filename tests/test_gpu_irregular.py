@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def long_row_shape(orc, ctx):
     """rows longer than mik_spmv_long_row() use the wave-shaped row sum; the oracle's spmv mirrors it"""
-    orc.set_long_row(ctx.spmv_long_row(), ctx.spmv_long_segment())
+    orc.set_long_row(ctx.spmv_long_row(), ctx.spmv_long_segment(), ctx.spmv_long_group())
     yield
     orc.set_long_row(0)
 
@@ -65,7 +65,7 @@ def test_cut_rows_segment_sums(pkg, orc, ctx, dtype, segment):
     try:
         seg = ctx.spmv_long_segment()
         assert seg == (segment or 2048)
-        orc.set_long_row(ctx.spmv_long_row(), seg)
+        orc.set_long_row(ctx.spmv_long_row(), seg, ctx.spmv_long_group())
         rng = np.random.default_rng(9)
         n = 12000
         lens = rng.integers(3, 40, size=n)
@@ -90,3 +90,66 @@ def test_cut_rows_segment_sums(pkg, orc, ctx, dtype, segment):
     finally:
         L.mik_set_tuning(15, 0)
         L.mik_set_tuning(14, 0)
+
+
+def banded_irregular(n, dtype, halfwidth, seed=3, long_every=0):
+    """rows of 3 ... 60 entries with columns inside [row - halfwidth, row + halfwidth] clipped to the matrix (no wrap-around:
+    the first and last row-blocks have one-sided bands), optionally a few rows beyond the long-row threshold"""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(3, 60, size=n)
+    if long_every:
+        lens[5::long_every] = rng.integers(300, 3000, size=lens[5::long_every].size)
+    cols = []
+    for r, l in enumerate(lens):
+        w = max(halfwidth, 2 * l)
+        lo, hi = max(0, r - w), min(n - 1, r + w)
+        l = min(l, hi - lo + 1)
+        lens[r] = l
+        cols.append(np.sort(rng.choice(np.arange(lo, hi + 1), size=l, replace=False)))
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    cols = np.concatenate(cols).astype(np.int64)
+    return rowptr, cols, rng.standard_normal(cols.size).astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("long_every", [0, 997])
+def test_x_window_in_lds_bit_exact(pkg, orc, ctx, dtype, long_every):
+    """irregular rows inside a band -- the product-tile kernel serves x from an LDS window per 256-row block
+    (k_spmv_rowblock XWIN, csr_build_xwin): same products, same order, same bits as the oracle, with the windows (default), with
+    the windows built but not used (development knob 29 = 2) and never built (29 = 1); plain SpMV (long rows merged into the launch)
+    and the fused-dot launches of a CG step; one-sided bands at both ends of the matrix (the last window slides down)."""
+    n = 9000
+    rowptr, cols, val = banded_irregular(n, dtype, 700, long_every=long_every)
+    Ao = as_oracle_csc(orc, n, rowptr, cols, val)
+    x = np.random.default_rng(8).standard_normal(n).astype(dtype)
+    want = orc.spmv(Ao, x)
+    b = orc.hashed_rhs(n).astype(dtype)
+    xo, ho = orc.cg(Ao, b, maxiter=3, mode="tree", shape=ctx.cg_shape(dtype))
+    L = pkg.lib()
+    for knob, kern in ((0, "k_spmv_rowblock+xwin"), (2, "k_spmv_rowblock"), (1, "k_spmv_rowblock")):
+        L.mik_set_tuning(29, knob)
+        try:
+            A = pkg.HipCSR(n, n, rowptr, cols, val, index_base=0, is_csc=False)
+            assert A.spmv_kernel() == kern, (A.spmv_kernel(), A.layout())
+            dx = pkg.HipVector.from_numpy(x)
+            for _ in range(2):
+                assert np.array_equal((A @ dx).to_numpy(), want), knob
+            xs, ch = pkg.cg(A, pkg.HipVector.from_numpy(b), log=True, maxiter=3)          # fused-dot launches (matrix not SPD: bits only)
+            assert np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(xs.to_numpy(), xo)
+        finally:
+            L.mik_set_tuning(29, 0)
+
+
+def test_x_window_blocks_that_wrap_around_gather_from_memory(pkg, orc, ctx):
+    """fixtures.irregular_matrix(bandwidth > 0) wraps its bands around the matrix: the first and last row-blocks span all of x,
+    carry no window (win_lo = -1) and gather from memory inside the same launch; every other block reads its LDS window"""
+    n, rowptr, colidx, val = pkg.fixtures.irregular_matrix(40000, np.float32, bandwidth=600)
+    A = pkg.HipCSR(n, n, rowptr, colidx, val, index_base=0, is_csc=False)
+    assert A.spmv_kernel() == "k_spmv_rowblock+xwin"
+    x = np.random.default_rng(2).standard_normal(n).astype(np.float32)
+    Ao = as_oracle_csc(orc, n, rowptr, colidx, val)
+    assert np.array_equal((A @ pkg.HipVector.from_numpy(x)).to_numpy(), orc.spmv(Ao, x))
+    b = pkg.fixtures.hashed_rhs(n, dtype=np.float32)
+    xg, ch = pkg.gmres(A, pkg.HipVector.from_numpy(b), restart=50, log=True, maxiter=60)
+    xo, ho = orc.gmres(Ao, b, restart=50, maxiter=60, mode="tree", shape=ctx.reduce_shape(np.float32))
+    assert ch.iters == ho["iters"] and np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(xg.to_numpy(), xo)

@@ -294,7 +294,7 @@ def test_jagged_slices_with_split_off_long_rows(pkg, orc, ctx, dtype):
     dA = pkg.HipCSR(n, n, S.indptr.astype(np.int64), S.indices.astype(np.int64), S.data, index_base=0, is_csc=False)
     assert dA.layout() == "jagged-slices" and dA.spmv_kernel() == "k_spmv_jds"
     A = orc.CSC.from_scipy(S.tocsc())
-    orc.set_long_row(ctx.spmv_long_row(), ctx.spmv_long_segment())
+    orc.set_long_row(ctx.spmv_long_row(), ctx.spmv_long_segment(), ctx.spmv_long_group())
     try:
         x = rng.standard_normal(n).astype(dtype)
         for _ in range(2):                                        # the segment tickets reset themselves

@@ -56,7 +56,7 @@ def test_spmv_irregular_rows_empty_rows_long_rows(pkg, orc, ctx):
     A = orc.CSC.from_scipy(M)
     x = rng.standard_normal(n)
     y = (upload(pkg, A) @ pkg.HipVector.from_numpy(x)).to_numpy()
-    orc.set_long_row(ctx.spmv_long_row(), ctx.spmv_long_segment())        # rows longer than this use the wave-shaped row sum (include/mik.h)
+    orc.set_long_row(ctx.spmv_long_row(), ctx.spmv_long_segment(), ctx.spmv_long_group())        # rows longer than this use the wave-shaped row sum (include/mik.h)
     try:
         assert np.array_equal(y, orc.spmv(A, x))
     finally:

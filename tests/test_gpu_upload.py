@@ -98,7 +98,7 @@ def test_device_upload_of_a_rank_block_with_halo_columns(pkg, orc, ctx, dist):
 
 def test_matrices_handed_back_to_the_host_path(pkg, orc, ctx):
     """long rows (the wave-shaped row sum) and duplicate (row, column) entries in CSC input keep the host path's semantics"""
-    orc.set_long_row(ctx.spmv_long_row(), ctx.spmv_long_segment())
+    orc.set_long_row(ctx.spmv_long_row(), ctx.spmv_long_segment(), ctx.spmv_long_group())
     try:
         n, rowptr, colidx, val = pkg.fixtures.irregular_matrix(6000, np.float64)
         dev, host = both_paths(pkg, lambda: pkg.HipCSR(n, n, rowptr, colidx, val, index_base=0, is_csc=False))
@@ -144,7 +144,7 @@ def test_device_resident_input_arrays(pkg, orc, ctx, dist):
     x = np.random.default_rng(8).standard_normal(A.n)
     same_operator(pkg, orc, dA, hA, A, x)
     # long rows: handed back to the host path, which stages the device arrays once
-    orc.set_long_row(ctx.spmv_long_row(), ctx.spmv_long_segment())
+    orc.set_long_row(ctx.spmv_long_row(), ctx.spmv_long_segment(), ctx.spmv_long_group())
     try:
         n, rowptr, colidx, val = pkg.fixtures.irregular_matrix(6000, np.float64)
         tp, ti, tv = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (rowptr.astype(np.int64), colidx.astype(np.int64), val))

@@ -178,3 +178,49 @@ def test_tree_reduction_shape_written_from_the_documentation(orc, n, W, L):
     rng = np.random.default_rng(n)
     x, y = rng.standard_normal(n), rng.standard_normal(n)
     assert py_tree_dot(list(map(float, x)), list(map(float, y)), W, L) == orc.dot(x, y, "tree", W, L)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("group", [1, 4])
+def test_long_row_shape_against_a_python_restatement(orc, dtype, group):
+    """The oracle's long-row mode (the device's documented row-sum shape for rows beyond mik_spmv_long_row(), include/mik.h):
+    segments of `seg` entries; in a segment entry q goes to virtual lane (q / group) % 64, lanes add their products in ascending
+    order from +0, wave-64 shuffle-down tree, segment sums left to right -- restated here in scalar Python, bit for bit."""
+    rng = np.random.default_rng(41)
+    n, thr, seg = 700, 40, 96
+    lens = rng.integers(1, 30, size=n)
+    for i, l in enumerate((41, 95, 96, 97, 192, 193, 500, 700)):
+        lens[11 + 80 * i] = l
+    rows = np.repeat(np.arange(n), lens)
+    cols = np.concatenate([np.sort(rng.choice(n, size=l, replace=False)) for l in lens])
+    vals = rng.standard_normal(cols.size).astype(dtype)
+    import scipy.sparse as sp
+    M = sp.csr_matrix((vals, cols, np.concatenate([[0], np.cumsum(lens)])), shape=(n, n)).tocsc()
+    M.sort_indices()
+    A = orc.CSC(n, M.indptr.astype(np.int64), M.indices.astype(np.int64), M.data.astype(dtype), 0)
+    x = rng.standard_normal(n).astype(dtype)
+    orc.set_long_row(thr, seg, group)
+    try:
+        y = orc.spmv(A, x)
+    finally:
+        orc.set_long_row(0)
+    yseq = orc.spmv(A, x)
+    T = dtype
+    start = np.concatenate([[0], np.cumsum(lens)])
+    for r in range(n):
+        if lens[r] <= thr:
+            assert y[r] == yseq[r]
+            continue
+        prods = [T(vals[k]) * T(x[cols[k]]) for k in range(start[r], start[r + 1])]
+        tot = None
+        for s0 in range(0, len(prods), seg):
+            lanes = [T(0)] * 64
+            for q, pq in enumerate(prods[s0:s0 + seg]):
+                lanes[(q // group) % 64] = T(lanes[(q // group) % 64] + pq)
+            off = 32
+            while off >= 1:
+                for l in range(off):
+                    lanes[l] = T(lanes[l] + lanes[l + off])
+                off //= 2
+            tot = lanes[0] if tot is None else T(tot + lanes[0])
+        assert y[r] == tot, (r, lens[r])
