@@ -430,8 +430,8 @@ int mik_cgd_halo_early(const mik_cgd *it, int *runs, int64_t *rows, int *merged)
 /* Transport 1 -- RCCL over xGMI, one process per GPU.  librccl is bound at run time (dlopen; a process that already
  * carries RCCL, e.g. PyTorch-ROCm, shares that copy); MIK_ERR_NOTIMPL if it cannot be loaded.  Rank 0 obtains the
  * 128-byte ncclUniqueId with mik_comm_unique_id and hands it to the other ranks by whatever channel the host has (MPI.jl
- * bcast, a file, torch.distributed); every rank then calls mik_comm_create (collective).  id128 = NULL with nranks = 1
- * gives a world of one that needs no library. */
+ * bcast, a file, torch.distributed); every rank then calls mik_comm_create (collective).  id128 = NULL gives a communicator
+ * without RCCL: a world of one needs nothing else, more ranks connect mailboxes and ghost regions (transport 3 below). */
 typedef struct mik_comm mik_comm;
 int mik_comm_unique_id(void *id128);
 int mik_comm_create(mik_ctx *ctx, const void *id128, int rank, int nranks, mik_comm **out);
@@ -461,6 +461,28 @@ int mik_cgd_iterate_many(mik_cgd *it, int64_t iteration, int64_t max_steps, doub
 int mik_cgd_group_init(mik_cgd **its, int P, double *residual, double *tol);
 int mik_cgd_group_iterate_many(mik_cgd **its, int P, int64_t iteration, int64_t max_steps, double *residuals, int64_t *steps_done);
 int mik_cgd_group_release(mik_cgd **its, int P);    /* frees the group's events / side streams (also done by mik_cgd_destroy) */
+
+/* Transport 3 -- peer-mapped mailbox over xGMI (SURVEY.md section 5 "backend B", section 8e): no collective launch in the step.
+ * Every communicator owns a mailbox in fine-grained device memory.  mik_comm_mailbox_export gives its 64-byte HIP IPC handle; the
+ * host gathers the handles of all ranks (rank order) over whatever channel it has and every rank calls mik_comm_mailbox_connect
+ * (ranks may even share one GPU: HIP IPC has no one-rank-per-device rule).  From then on the two scalars of a step travel as
+ * {value, sequence number} stores into every peer's mailbox, issued by the kernel that finalised the reduction; every rank adds the
+ * P values in rank order -- the bits of transports 1 and 2.  The halo: every rank exports the allocation that holds its u_ext
+ * (mik_mem_export) and the host tells every sender where its segments land (mik_cgd_connect_ghosts); a push kernel on the library's
+ * side stream then stores the packed buffer straight into the neighbours' ghost regions and posts the exchange number, a one-wave
+ * kernel in front of the boundary row-blocks waits for it.  A communicator created with id128 = NULL and nranks > 1 has no RCCL at
+ * all and needs both; one created with a ncclUniqueId may connect mailboxes only (scalars by mailbox, halo by ncclSend / ncclRecv).
+ * Waits are bounded (MIK_MAILBOX_TIMEOUT_MS, default 10000): MIK_ERR_HIP instead of a hung queue. */
+int mik_comm_mailbox_export(mik_comm *comm, void *handle64);
+int mik_comm_mailbox_connect(mik_comm *comm, const void *handles /* nranks x 64 bytes, rank order; this rank's entry is ignored */);
+int mik_comm_mailbox_info(const mik_comm *comm, int *connected, int *finegrained);
+/* HIP IPC handle (64 bytes) of the ALLOCATION that holds device pointer dptr, and the byte offset of dptr inside it (a tensor of a
+ * pooling allocator sits anywhere in its block). */
+int mik_mem_export(mik_ctx *ctx, const void *dptr, void *handle64, int64_t *offset);
+/* After mik_cgd_set_halo_plan and mik_cgd_set_comm.  handles / offsets: per rank, mik_mem_export of its u_ext (this rank's entry is
+ * ignored; a rank may be its own neighbour).  dst_elem: per SEND segment of the halo plan, the element of the receiver's u_ext at
+ * which the segment lands (the receiver's n_loc + the offset of its matching receive segment).  At most 8 segments per direction. */
+int mik_cgd_connect_ghosts(mik_cgd *it, const void *handles, const int64_t *offsets, const int64_t *dst_elem);
 
 /* ---- Hessenberg least squares (host) ------------------------------------------------------ */
 /* ldiv!(FastHessenberg(H), rhs) -- src/hessenberg.jl:15-46.  Host arrays of `dtype`; H is

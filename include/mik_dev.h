@@ -34,6 +34,9 @@ extern "C" {
  *  31: 1 = GMRES without the single-launch Gram-Schmidt kernels (read at mik_gmres_create)
  *  30: 1 = treat the next single-launch Gram-Schmidt column as timed out (exercises the fall-back to the multi-launch chains)
  *  28: jagged slices (layout 1): 1 = never, 2 = whenever the operator has no structured layout (read at mik_csr_create)
+ *   6: transports of the row-partitioned CG (bits): 1 = the side stream ordered by events instead of mailbox flags, 2 = the two scalars of a step over
+ *      RCCL although a mailbox is connected, 4 = ... through the mailbox even in a world of one, 8 = ... through the one-wave gather launches
+ *      (k_mail_gather) instead of inside the finalising kernels
  *  29: x windows in LDS for the product-tile CSR kernel (k_spmv_rowblock XWIN): 1 = never built (read at mik_csr_create), 2 = built but not used at launch
  *  27: direction of the streaming launches of a plain CG step (bit 0 / 1 / 2: the u sweep / the SpMV / the update walk from
  *      the end of the vectors; 8: every launch against the one before it) -- no effect at the default cache hints */

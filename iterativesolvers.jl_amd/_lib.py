@@ -149,6 +149,11 @@ SIGNATURES = {
     "mik_comm_allgather_sum": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "mik_comm_halo": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _ip, _i64p, _i64p, C.c_int, _ip, _i64p, _i64p]),
     "mik_cgd_set_comm": (C.c_int, [_vp, _vp]),
+    "mik_comm_mailbox_export": (C.c_int, [_vp, _vp]),
+    "mik_comm_mailbox_connect": (C.c_int, [_vp, _vp]),
+    "mik_comm_mailbox_info": (C.c_int, [_vp, _ip, _ip]),
+    "mik_mem_export": (C.c_int, [_vp, _vp, _vp, _i64p]),
+    "mik_cgd_connect_ghosts": (C.c_int, [_vp, _vp, _i64p, _i64p]),
     "mik_cgd_init": (C.c_int, [_vp, _f64p, _f64p]),
     "mik_cgd_iterate_many": (C.c_int, [_vp, _i64, _i64, _f64p, _i64p]),
     "mik_cgd_group_init": (C.c_int, [C.POINTER(_vp), C.c_int, _f64p, _f64p]),

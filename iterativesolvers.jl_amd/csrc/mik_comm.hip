@@ -72,6 +72,34 @@ Rccl *rccl()
 constexpr int NCCL_F32 = 7, NCCL_F64 = 8;   // ncclFloat32 / ncclFloat64 (rccl.h)
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// Transport 3: the peer-mapped mailbox (SURVEY.md section 5 "backend B", section 8e)
+// ---------------------------------------------------------------------------------------------
+// A CG step couples the ranks at three points: the halo of u and two sums of one scalar per rank.  Over RCCL each of them is a
+// collective launch (ncclSend/ncclRecv on a side stream ordered by two events; two dependent one-element ncclAllGather on the
+// compute stream).  Here every rank owns a MAILBOX in fine-grained device memory that its peers map (hipIpcOpenMemHandle between
+// processes) and write to over xGMI with ordinary stores:
+//   * a scalar: the kernel that finalises the producing reduction stores {value, sequence number} into slot [kind][rank] of EVERY
+//     peer's mailbox, then waits for the P slots of its own mailbox to carry this sequence number and adds the values in rank
+//     order -- every rank the same additions, bit-identical scalars, no collective launch, no host;
+//   * the halo: a push kernel on the side stream copies the packed send buffer straight into the neighbours' ghost regions
+//     (peer-mapped u_ext) and then publishes the exchange number in their mailboxes; a one-wave kernel on the compute stream
+//     waits for it in front of the boundary row-blocks.  The ghost data is read by the kernel AFTER the waiting one (its start is
+//     the acquire that makes peer writes visible to cached loads); slots and flags are read inside a kernel and therefore live in
+//     fine-grained memory and are accessed with system-scope atomics.
+// Sequence numbers only grow, every rank enqueues the same sequence of exchanges, and two exchanges of one kind are always
+// separated by one of another kind that needs every rank's contribution -- a slot is never overwritten before its reader took it
+// (two parities per kind are kept anyway).  Every wait is bounded (MIK_MAILBOX_TIMEOUT_MS, default 10 s): a peer that died turns
+// into MIK_ERR_HIP on the host instead of a hung queue.
+constexpr int MIK_MAIL_MAXP = 64;
+constexpr int MIK_MAIL_KINDS = 3;        // 0: dot(u, c)   1: |r|^2   2: every other gather (initial residual, the scaled-norm stages)
+struct MailSlot { unsigned long long bits, seq; };
+struct MailBox {
+    MailSlot slot[MIK_MAIL_KINDS][2][MIK_MAIL_MAXP];    // [kind][seq & 1][sender]
+    unsigned long long halo_seq[MIK_MAIL_MAXP];          // [sender]: its halo of exchange no. halo_seq[sender] has landed in this rank's ghost region
+    unsigned long long packed_seq;                       // this rank: the send buffer of exchange no. packed_seq is packed (the side stream waits for it)
+};
+
 struct mik_comm {
     mik_ctx *ctx = nullptr;
     int rank = 0, nranks = 1;
@@ -81,7 +109,179 @@ struct mik_comm {
     void *scratch = nullptr;             // device: nranks * MAX_COUNT scalars for mik_comm_allgather_sum
     void *scratch_host = nullptr;        // pinned mirror
     static constexpr int MAX_COUNT = 256;
+    // mailbox transport
+    MailBox *mail = nullptr;             // this rank's mailbox (fine-grained device memory)
+    MailBox **peers_dev = nullptr;       // device: peer q's mailbox as mapped into this process (q = rank: mail)
+    std::vector<MailBox *> peers;
+    std::vector<void *> ipc_open;        // mappings to close
+    void *ghost_base[MIK_MAIL_MAXP] = {};   // peer q's u_ext allocation as mapped here (mik_cgd_connect_ghosts)
+    bool mail_ready = false;
+    unsigned long long mseq[MIK_MAIL_KINDS] = {0, 0, 0};   // exchanges enqueued so far, per kind
+    unsigned long long halo_no = 0;
+    unsigned *mail_err = nullptr;        // pinned, device-mapped: a wait timed out
+    unsigned long long timeout_ticks = 0;   // of the 100 MHz wall clock
+    unsigned *push_ticket = nullptr;     // device: arrival counter of k_halo_push
 };
+
+namespace {
+template <typename T> __device__ __forceinline__ unsigned long long mail_bits(T v)
+{
+    if (sizeof(T) == 8) { double d = (double)v; return __builtin_bit_cast(unsigned long long, d); }
+    float f = (float)v;
+    return (unsigned long long)__builtin_bit_cast(unsigned, f);
+}
+template <typename T> __device__ __forceinline__ T mail_value(unsigned long long b)
+{
+    if (sizeof(T) == 8) return (T)__builtin_bit_cast(double, b);
+    return (T)__builtin_bit_cast(float, (unsigned)b);
+}
+
+// wait until *p >= want (system scope); false after `ticks` of the wall clock
+__device__ __forceinline__ bool mail_wait(const unsigned long long *p, unsigned long long want, unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    for (unsigned spins = 0;; ++spins) {
+        if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return true;
+        if ((spins & 255u) == 255u && wall_clock64() - t0 > ticks) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// value -> slot [kind][seq & 1][rank] of every peer; then the P slots of this rank's own mailbox -> all[0 .. P): lane q serves peer q
+template <typename T>
+__device__ __forceinline__ T mail_exchange(MailBox *const *__restrict__ peers, int P, int rank, int kind, unsigned long long seq, T mine,
+                                           T *__restrict__ all, unsigned long long ticks, unsigned *__restrict__ err)
+{
+    const int q = threadIdx.x & 63;
+    if (q >= P) return T(0);
+    MailSlot *dst = &peers[q]->slot[kind][seq & 1ull][rank];
+    __hip_atomic_store(&dst->bits, mail_bits<T>(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&dst->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const MailSlot *src = &peers[rank]->slot[kind][seq & 1ull][q];
+    if (!mail_wait(&src->seq, seq, ticks)) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const T v = mail_value<T>(__hip_atomic_load(&src->bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    all[q] = v;
+    return v;
+}
+
+// the P values of a wave (lane q: rank q's) added in rank order, in every lane
+template <typename T> __device__ __forceinline__ T mail_rank_sum(T v, int P)
+{
+    T s = __shfl(v, 0);
+    for (int p = 1; p < P; ++p) s = s + __shfl(v, p);
+    return s;
+}
+
+// all[rank] (this rank's partial, written by the kernel before on the stream) -> all[0 .. P) on every rank: what ncclAllGather of one
+// element per rank did, as one single-wave launch
+template <typename T>
+__global__ __launch_bounds__(64) void k_mail_gather(MailBox *const *__restrict__ peers, int P, int rank, int kind, unsigned long long seq,
+                                                    T *__restrict__ all, unsigned long long ticks, unsigned *__restrict__ err)
+{
+    const T mine = all[rank];
+    (void)mail_exchange<T>(peers, P, rank, kind, seq, mine, all, ticks, err);
+}
+
+// The two scalar exchanges of a step INSIDE the kernels that finalise the producing reductions (no gather launch at all):
+// level 2 of this rank's partials over MIK_FIN_WGS single-wave workgroups with a ticket, exactly as k_cgd_fin_slot; the wave that
+// arrives last posts the rank's sum to every peer, collects the P sums and adds them in rank order.
+//   k_cgd_fin_dot_mail: ... then dot(u, c) and alpha = residual^2 / dot(u, c) (src/cg.jl:55) -- what k_cgd_alpha / CoefAlphaRanks did;
+//   k_cgd_fin_rr_mail:  ... then residual, beta, history and the stopping test -- what k_cgd_fin_res did (cgd_close_step).
+template <typename T>
+__global__ __launch_bounds__(64) void k_cgd_fin_dot_mail(const T *__restrict__ S, int64_t m, FinScratch<T> *fs, CgDev<T> *d, T *__restrict__ dot_all,
+                                                          MailBox *const *__restrict__ peers, int P, int rank, unsigned long long seq,
+                                                          unsigned long long ticks, unsigned *__restrict__ err)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) d->x_pending = 0;      // the sweep over u of this step's head applied it (OpXpbyX)
+    if (d->done) return;                                             // identical on every rank: nobody posts, nobody waits
+    T tot = T(0);
+    int last = level2_sum_spread(S, m, fs, tot) ? 1 : 0;
+    last = __shfl(last, 0);
+    if (!last) return;
+    tot = __shfl(tot, 0);
+    const T v = mail_exchange<T>(peers, P, rank, 0, seq, tot, dot_all, ticks, err);
+    const T sum = mail_rank_sum(v, P);
+    if (threadIdx.x == 0) { d->dot_uc = sum; d->alpha = (d->res * d->res) / sum; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_cgd_fin_rr_mail(const T *__restrict__ S, int64_t m, FinScratch<T> *fs, CgDev<T> *d, T *__restrict__ rr_all,
+                                                         MailBox *const *__restrict__ peers, int P, int rank, unsigned long long seq,
+                                                         unsigned long long ticks, unsigned *__restrict__ err, T *__restrict__ hist, long long it_next,
+                                                         long long maxiter, CgMirror *mirror, unsigned long long step_seq, int hist_index, int fuse_x)
+{
+    if (d->done) {                                                   // a no-op step (the stopping test fired earlier in this batch): still publish
+        if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&mirror->seq, step_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    T tot = T(0);
+    int last = level2_sum_spread(S, m, fs, tot) ? 1 : 0;
+    last = __shfl(last, 0);
+    if (!last) return;
+    tot = __shfl(tot, 0);
+    const T v = mail_exchange<T>(peers, P, rank, 1, seq, tot, rr_all, ticks, err);
+    const T sum = mail_rank_sum(v, P);
+    if (threadIdx.x == 0) cgd_close_step<T>(d, sum, hist, it_next, maxiter, mirror, step_seq, hist_index, fuse_x);
+}
+
+__global__ void k_mail_mark(unsigned long long *flag, unsigned long long v)
+{
+    __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_mail_wait_flag(const unsigned long long *flag, unsigned long long want, unsigned long long ticks, unsigned *err)
+{
+    if (!mail_wait(flag, want, ticks)) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// the halo of this rank's neighbours: segment i of the packed send buffer -> dst[i] (a pointer into the peer's ghost region), 16 bytes
+// per lane where the alignment allows; the last workgroup to finish publishes the exchange number in the receivers' mailboxes
+struct PushSegs {
+    static constexpr int MAX = 8;
+    void *dst[MAX];
+    long long off[MAX], cnt[MAX];
+    int peer[MAX];
+    int n;
+};
+template <typename T>
+__global__ __launch_bounds__(MIK_BLOCK) void k_halo_push(const T *__restrict__ send_buf, PushSegs sg, MailBox *const *__restrict__ peers, int rank,
+                                                         unsigned long long halo_no, unsigned *__restrict__ ticket)
+{
+    constexpr int W = 16 / (int)sizeof(T);
+    for (int i = 0; i < sg.n; ++i) {
+        const T *src = send_buf + sg.off[i];
+        T *dst = (T *)sg.dst[i];
+        const long long cnt = sg.cnt[i];
+        const bool wide = ((((size_t)src) | ((size_t)dst)) & 15) == 0;
+        if (wide) {
+            const long long nv = cnt / W;
+            for (long long j = (long long)blockIdx.x * MIK_BLOCK + threadIdx.x; j < nv; j += (long long)gridDim.x * MIK_BLOCK)
+                reinterpret_cast<uint4 *>(dst)[j] = reinterpret_cast<const uint4 *>(src)[j];
+            for (long long j = nv * W + (long long)blockIdx.x * MIK_BLOCK + threadIdx.x; j < cnt; j += (long long)gridDim.x * MIK_BLOCK) dst[j] = src[j];
+        } else {
+            for (long long j = (long long)blockIdx.x * MIK_BLOCK + threadIdx.x; j < cnt; j += (long long)gridDim.x * MIK_BLOCK) dst[j] = src[j];
+        }
+    }
+    __threadfence_system();                              // this thread's stores have reached the peers
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (tk == gridDim.x - 1u) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < sg.n; ++i)
+                __hip_atomic_store(&peers[sg.peer[i]]->halo_seq[rank], halo_no, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+struct WaitPeers { int peer[PushSegs::MAX]; int n; };
+__global__ __launch_bounds__(64) void k_halo_wait(const MailBox *__restrict__ mine, WaitPeers wp, unsigned long long halo_no, unsigned long long ticks,
+                                                  unsigned *__restrict__ err)
+{
+    const int i = threadIdx.x;
+    if (i < wp.n && !mail_wait(&mine->halo_seq[wp.peer[i]], halo_no, ticks)) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
 
 #define MIK_NCCL(ctx, call)                                                                                        \
     do {                                                                                                           \
@@ -92,6 +292,8 @@ struct mik_comm {
                             (R_ && R_->GetErrorString) ? R_->GetErrorString(r_) : "rccl error", __FILE__, __LINE__); \
         }                                                                                                          \
     } while (0)
+
+static int mailbox_alloc(mik_comm *cm);
 
 extern "C" int mik_comm_unique_id(void *id128)
 {
@@ -109,7 +311,8 @@ extern "C" int mik_comm_create(mik_ctx *ctx, const void *id128, int rank, int nr
     if (!ctx || !out) return MIK_ERR_INVALID;
     *out = nullptr;
     if (nranks < 1 || rank < 0 || rank >= nranks) return mik_fail(ctx, MIK_ERR_INVALID, "mik_comm_create: bad rank %d of %d", rank, nranks);
-    if (nranks > 1 && !id128) return mik_fail(ctx, MIK_ERR_INVALID, "mik_comm_create: %d ranks need the ncclUniqueId of rank 0", nranks);
+    // id128 = NULL with nranks > 1: a communicator without RCCL -- its ranks connect mailboxes (mik_comm_mailbox_export / _connect)
+    // and ghost regions (mik_cgd_connect_ghosts) instead
     mik_comm *cm = new (std::nothrow) mik_comm();
     if (!cm) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_comm_create: host allocation failed");
     cm->ctx = ctx; cm->rank = rank; cm->nranks = nranks;
@@ -130,6 +333,7 @@ extern "C" int mik_comm_create(mik_ctx *ctx, const void *id128, int rank, int nr
         int r = R->CommInitRank(&cm->nccl, nranks, id, rank);
         if (r != 0) return bail(mik_fail(ctx, MIK_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, nranks, R->GetErrorString ? R->GetErrorString(r) : "?"));
     }
+    if (nranks <= MIK_MAIL_MAXP) { const int rc = mailbox_alloc(cm); if (rc) return bail(rc); }   // the local flags of the halo ordering at least
     *out = cm;
     return MIK_OK;
 }
@@ -145,6 +349,11 @@ extern "C" int mik_comm_destroy(mik_comm *cm)
     if (cm->ev_halo) (void)hipEventDestroy(cm->ev_halo);
     if (cm->scratch) (void)hipFree(cm->scratch);
     if (cm->scratch_host) (void)hipHostFree(cm->scratch_host);
+    for (void *p : cm->ipc_open) (void)hipIpcCloseMemHandle(p);
+    if (cm->mail) (void)hipFree(cm->mail);
+    if (cm->peers_dev) (void)hipFree(cm->peers_dev);
+    if (cm->push_ticket) (void)hipFree(cm->push_ticket);
+    if (cm->mail_err) (void)hipHostFree(cm->mail_err);
     delete cm;
     return MIK_OK;
 }
@@ -287,62 +496,276 @@ extern "C" int mik_cgd_set_comm(mik_cgd *it, mik_comm *cm)
     return MIK_OK;
 }
 
-// The halo of u (or of x during init) over RCCL: issued on the side stream after the pack kernel; *pending = true if
-// the compute stream still has to wait for ev_halo.
-// rccl_halo_begin = rccl_halo_mark ("the send buffer is packed": an event on the compute stream) + rccl_halo_issue (the side
-// stream waits for that event, then the RCCL group).  Split so that the compute-stream work that overlaps the exchange can be
-// enqueued BEFORE the host spends its tens of microseconds inside the RCCL calls.
-static int rccl_halo_mark(mik_cgd *it)
+// ---- mailbox: allocation, export, connection ----------------------------------------------------------------------------------
+static int mailbox_alloc(mik_comm *cm)
 {
-    mik_comm *cm = it->comm;
-    if (!cm || !cm->nccl || (it->recv.empty() && it->send.empty())) return MIK_OK;
-    MIK_HIP(it->base.ctx, hipEventRecord(cm->ev_packed, it->base.ctx->stream));
+    if (cm->mail) return MIK_OK;
+    mik_ctx *ctx = cm->ctx;
+    if (cm->nranks > MIK_MAIL_MAXP) return mik_fail(ctx, MIK_ERR_NOTIMPL, "mailbox transport: at most %d ranks", MIK_MAIL_MAXP);
+    (void)hipSetDevice(ctx->device);
+    hipError_t e = hipExtMallocWithFlags((void **)&cm->mail, sizeof(MailBox), hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { (void)hipGetLastError(); cm->mail = nullptr; e = hipMalloc((void **)&cm->mail, sizeof(MailBox)); }   // system-scope atomics still reach memory
+    if (e != hipSuccess) return mik_fail(ctx, MIK_ERR_NOMEM, "mailbox transport: %s", hipGetErrorString(e));
+    if ((e = hipMemset(cm->mail, 0, sizeof(MailBox))) != hipSuccess ||
+        (e = hipMalloc((void **)&cm->peers_dev, sizeof(MailBox *) * MIK_MAIL_MAXP)) != hipSuccess ||
+        (e = hipMalloc((void **)&cm->push_ticket, sizeof(unsigned))) != hipSuccess || (e = hipMemset(cm->push_ticket, 0, sizeof(unsigned))) != hipSuccess ||
+        (e = hipHostMalloc((void **)&cm->mail_err, sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
+        return mik_fail(ctx, MIK_ERR_HIP, "mailbox transport: %s", hipGetErrorString(e));
+    *cm->mail_err = 0;
+    cm->peers.assign((size_t)cm->nranks, nullptr);
+    cm->peers[(size_t)cm->rank] = cm->mail;
+    if ((e = hipMemcpy(cm->peers_dev, cm->peers.data(), sizeof(MailBox *) * cm->peers.size(), hipMemcpyHostToDevice)) != hipSuccess)
+        return mik_fail(ctx, MIK_ERR_HIP, "mailbox transport: %s", hipGetErrorString(e));
+    const char *ms = getenv("MIK_MAILBOX_TIMEOUT_MS");
+    const double msv = ms && atof(ms) > 0 ? atof(ms) : 10000.0;
+    cm->timeout_ticks = (unsigned long long)(msv * 1e5);               // wall_clock64 runs at 100 MHz
+    cm->mail_ready = cm->nranks == 1;                                  // a world of one has nobody to connect to
     return MIK_OK;
 }
 
-static int rccl_halo_issue(mik_cgd *it, bool *pending);
-
-static int rccl_halo_begin(mik_cgd *it, bool *pending)
+static int mailbox_check(mik_comm *cm, const char *who)
 {
-    MIK_TRY(rccl_halo_mark(it));
-    return rccl_halo_issue(it, pending);
+    if (cm && cm->mail_err && *cm->mail_err) {
+        *cm->mail_err = 0;
+        return mik_fail(cm->ctx, MIK_ERR_HIP, "%s: a mailbox wait timed out (a peer rank stopped, or the ranks enqueued different exchange sequences)", who);
+    }
+    return MIK_OK;
 }
 
-static int rccl_halo_issue(mik_cgd *it, bool *pending)
+extern "C" int mik_comm_mailbox_export(mik_comm *cm, void *handle64)
+{
+    if (!cm || !handle64) return MIK_ERR_INVALID;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    MIK_TRY(mailbox_alloc(cm));
+    hipIpcMemHandle_t h;
+    memset(&h, 0, sizeof(h));
+    if (cm->nranks > 1) MIK_HIP(cm->ctx, hipIpcGetMemHandle(&h, cm->mail));
+    memcpy(handle64, &h, 64);
+    return MIK_OK;
+}
+
+extern "C" int mik_comm_mailbox_connect(mik_comm *cm, const void *handles)
+{
+    if (!cm || (cm->nranks > 1 && !handles)) return MIK_ERR_INVALID;
+    MIK_TRY(mailbox_alloc(cm));
+    mik_ctx *ctx = cm->ctx;
+    (void)hipSetDevice(ctx->device);
+    for (int q = 0; q < cm->nranks; ++q) {
+        if (q == cm->rank || cm->peers[(size_t)q]) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const unsigned char *)handles + 64 * (size_t)q, 64);
+        void *p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return mik_fail(ctx, MIK_ERR_HIP, "mik_comm_mailbox_connect: hipIpcOpenMemHandle(rank %d): %s", q, hipGetErrorString(e));
+        cm->ipc_open.push_back(p);
+        cm->peers[(size_t)q] = (MailBox *)p;
+    }
+    MIK_HIP(ctx, hipMemcpy(cm->peers_dev, cm->peers.data(), sizeof(MailBox *) * cm->peers.size(), hipMemcpyHostToDevice));
+    cm->mail_ready = true;
+    return MIK_OK;
+}
+
+// IPC handle of the ALLOCATION that holds dptr + the byte offset of dptr inside it (a host's tensor may sit anywhere in a pool block)
+extern "C" int mik_mem_export(mik_ctx *ctx, const void *dptr, void *handle64, int64_t *offset)
+{
+    if (!ctx || !dptr || !handle64 || !offset) return MIK_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    MIK_HIP(ctx, hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)dptr));
+    hipIpcMemHandle_t h;
+    MIK_HIP(ctx, hipIpcGetMemHandle(&h, (void *)base));
+    memcpy(handle64, &h, 64);
+    *offset = (int64_t)((const unsigned char *)dptr - (const unsigned char *)base);
+    return MIK_OK;
+}
+
+// handles / offsets: per RANK, the allocation that holds its u_ext and the byte offset of u_ext[0] in it (mik_mem_export on that
+// rank; ignored for this rank itself); dst_elem: per SEND segment of the halo plan, the element of the receiver's u_ext at which the
+// segment lands (its n_loc + the offset of the matching receive segment there).
+extern "C" int mik_cgd_connect_ghosts(mik_cgd *it, const void *handles, const int64_t *offsets, const int64_t *dst_elem)
+{
+    if (!it || !it->comm) return MIK_ERR_INVALID;
+    mik_comm *cm = it->comm;
+    mik_ctx *ctx = it->base.ctx;
+    if (it->send.size() > (size_t)PushSegs::MAX || it->recv.size() > (size_t)PushSegs::MAX)
+        return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_cgd_connect_ghosts: more than %d halo segments per direction", PushSegs::MAX);
+    if (!it->send.empty() && !dst_elem) return MIK_ERR_INVALID;
+    MIK_TRY(mailbox_alloc(cm));
+    const size_t es = mik_dtype_size(it->base.dtype);
+    (void)hipSetDevice(ctx->device);
+    it->send_dst.clear();
+    for (size_t i = 0; i < it->send.size(); ++i) {
+        const int q = it->send[i].peer;
+        unsigned char *base = nullptr;
+        if (q == it->rank) base = (unsigned char *)it->u_ext;
+        else {
+            if (!handles || !offsets) return MIK_ERR_INVALID;
+            if (!cm->ghost_base[q]) {
+                hipIpcMemHandle_t h;
+                memcpy(&h, (const unsigned char *)handles + 64 * (size_t)q, 64);
+                void *p = nullptr;
+                hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+                if (e != hipSuccess) return mik_fail(ctx, MIK_ERR_HIP, "mik_cgd_connect_ghosts: hipIpcOpenMemHandle(rank %d): %s", q, hipGetErrorString(e));
+                cm->ipc_open.push_back(p);
+                cm->ghost_base[q] = p;
+            }
+            base = (unsigned char *)cm->ghost_base[q] + offsets[q];
+        }
+        it->send_dst.push_back(base + es * (size_t)dst_elem[i]);
+    }
+    it->ghosts = true;
+    return MIK_OK;
+}
+
+extern "C" int mik_comm_mailbox_info(const mik_comm *cm, int *ready, int *finegrained)
+{
+    if (!cm) return MIK_ERR_INVALID;
+    if (ready) *ready = cm->mail_ready ? 1 : 0;
+    if (finegrained) {
+        *finegrained = 0;
+        if (cm->mail) {
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, cm->mail) == hipSuccess) *finegrained = 1; else (void)hipGetLastError();
+        }
+    }
+    return MIK_OK;
+}
+
+// The halo of u (or of x during init).  Three steps, split so that the compute-stream work that overlaps the exchange can be
+// enqueued BEFORE the host spends its tens of microseconds inside RCCL:
+//   halo_mark  "the send buffer is packed" on the compute stream;
+//   halo_issue the transfer on the side stream, ordered behind the mark;
+//   halo_end   the compute stream waits for the ghost region.
+// With a mailbox the two orderings are FLAGS: a one-thread kernel stores the exchange number behind the pack kernel, a one-thread
+// kernel on the side stream waits for it; the side stream (or, for peer-mapped ghosts, the sender's push kernel) stores it in the
+// receiver's mailbox and a one-wave kernel on the compute stream waits there.  hipEventRecord / hipStreamWaitEvent each cost the
+// compute stream a ~6 us hole between two kernels (profiles/r03_dist_selfhalo_timeline.txt); a 1-thread launch costs ~2.
+// Development knob 6, bit 0: events.  Every waiting kernel is submitted after the kernel that satisfies it, so streams that share a
+// hardware queue cannot deadlock.
+static bool halo_flags(const mik_cgd *it) { return it->comm && it->comm->mail && (it->base.ctx->tuning[6] & 1) == 0; }
+static bool halo_p2p(const mik_cgd *it) { return it->comm && it->comm->mail_ready && it->ghosts; }
+static bool halo_any(const mik_cgd *it)
+{
+    return it->comm && (it->comm->nccl || halo_p2p(it)) && !(it->recv.empty() && it->send.empty());
+}
+
+static int halo_mark(mik_cgd *it)
+{
+    mik_comm *cm = it->comm;
+    if (!halo_any(it)) return MIK_OK;
+    mik_ctx *ctx = it->base.ctx;
+    cm->halo_no += 1;
+    if (halo_flags(it)) {
+        hipLaunchKernelGGL(k_mail_mark, dim3(1), dim3(1), 0, ctx->stream, &cm->mail->packed_seq, cm->halo_no);
+        MIK_LAUNCH_CHECK(ctx);
+    } else {
+        MIK_HIP(ctx, hipEventRecord(cm->ev_packed, ctx->stream));
+    }
+    return MIK_OK;
+}
+
+static int halo_issue(mik_cgd *it, bool *pending)
 {
     *pending = false;
     mik_comm *cm = it->comm;
     mik_ctx *ctx = it->base.ctx;
-    if (!cm || !cm->nccl || (it->recv.empty() && it->send.empty())) return MIK_OK;
-    Rccl *R = rccl();
+    if (!halo_any(it)) return MIK_OK;
+    const bool flags = halo_flags(it);
+    if (flags) {
+        hipLaunchKernelGGL(k_mail_wait_flag, dim3(1), dim3(1), 0, cm->side, (const unsigned long long *)&cm->mail->packed_seq, cm->halo_no, cm->timeout_ticks, cm->mail_err);
+        MIK_LAUNCH_CHECK(ctx);
+    } else {
+        MIK_HIP(ctx, hipStreamWaitEvent(cm->side, cm->ev_packed, 0));
+    }
     const size_t es = mik_dtype_size(it->base.dtype);
-    const int nt = it->base.dtype == MIK_F64 ? NCCL_F64 : NCCL_F32;
-    unsigned char *ghost = (unsigned char *)it->u_ext + es * (size_t)it->base.n;
-    MIK_HIP(ctx, hipStreamWaitEvent(cm->side, cm->ev_packed, 0));
-    MIK_NCCL(ctx, R->GroupStart());
-    for (const auto &sg : it->recv) MIK_NCCL(ctx, R->Recv(ghost + es * (size_t)sg.off, (size_t)sg.cnt, nt, sg.peer, cm->nccl, cm->side));
-    for (const auto &sg : it->send) MIK_NCCL(ctx, R->Send((const unsigned char *)it->send_buf + es * (size_t)sg.off, (size_t)sg.cnt, nt, sg.peer, cm->nccl, cm->side));
-    MIK_NCCL(ctx, R->GroupEnd());
-    MIK_HIP(ctx, hipEventRecord(cm->ev_halo, cm->side));
+    if (halo_p2p(it)) {
+        PushSegs sg{};
+        int64_t total = 0;
+        sg.n = (int)it->send.size();
+        for (int i = 0; i < sg.n; ++i) {
+            sg.dst[i] = it->send_dst[(size_t)i]; sg.off[i] = it->send[(size_t)i].off; sg.cnt[i] = it->send[(size_t)i].cnt; sg.peer[i] = it->send[(size_t)i].peer;
+            total += it->send[(size_t)i].cnt;
+        }
+        if (sg.n > 0) {
+            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(64, (total * (int64_t)es / 16 + MIK_BLOCK - 1) / MIK_BLOCK));
+            if (it->base.dtype == MIK_F64)
+                hipLaunchKernelGGL((k_halo_push<double>), dim3(grid), dim3(MIK_BLOCK), 0, cm->side, (const double *)it->send_buf, sg, (MailBox *const *)cm->peers_dev, cm->rank, cm->halo_no, cm->push_ticket);
+            else
+                hipLaunchKernelGGL((k_halo_push<float>), dim3(grid), dim3(MIK_BLOCK), 0, cm->side, (const float *)it->send_buf, sg, (MailBox *const *)cm->peers_dev, cm->rank, cm->halo_no, cm->push_ticket);
+            MIK_LAUNCH_CHECK(ctx);
+        }
+    } else {
+        Rccl *R = rccl();
+        const int nt = it->base.dtype == MIK_F64 ? NCCL_F64 : NCCL_F32;
+        unsigned char *ghost = (unsigned char *)it->u_ext + es * (size_t)it->base.n;
+        MIK_NCCL(ctx, R->GroupStart());
+        for (const auto &sg : it->recv) MIK_NCCL(ctx, R->Recv(ghost + es * (size_t)sg.off, (size_t)sg.cnt, nt, sg.peer, cm->nccl, cm->side));
+        for (const auto &sg : it->send) MIK_NCCL(ctx, R->Send((const unsigned char *)it->send_buf + es * (size_t)sg.off, (size_t)sg.cnt, nt, sg.peer, cm->nccl, cm->side));
+        MIK_NCCL(ctx, R->GroupEnd());
+        if (flags) {      // "every receive of exchange no. halo_no has landed", under this rank's own name
+            hipLaunchKernelGGL(k_mail_mark, dim3(1), dim3(1), 0, cm->side, &cm->mail->halo_seq[cm->rank], cm->halo_no);
+            MIK_LAUNCH_CHECK(ctx);
+        } else {
+            MIK_HIP(ctx, hipEventRecord(cm->ev_halo, cm->side));
+        }
+    }
     *pending = true;
     return MIK_OK;
 }
 
-static int rccl_halo_end(mik_cgd *it, bool pending)
+static int halo_begin(mik_cgd *it, bool *pending)
 {
-    if (pending) MIK_HIP(it->base.ctx, hipStreamWaitEvent(it->base.ctx->stream, it->comm->ev_halo, 0));
+    MIK_TRY(halo_mark(it));
+    return halo_issue(it, pending);
+}
+
+static int halo_end(mik_cgd *it, bool pending)
+{
+    if (!pending) return MIK_OK;
+    mik_comm *cm = it->comm;
+    mik_ctx *ctx = it->base.ctx;
+    if (halo_p2p(it)) {
+        WaitPeers wp{};
+        wp.n = (int)it->recv.size();
+        for (int i = 0; i < wp.n; ++i) wp.peer[i] = it->recv[(size_t)i].peer;
+        if (wp.n > 0) {
+            hipLaunchKernelGGL(k_halo_wait, dim3(1), dim3(64), 0, ctx->stream, (const MailBox *)cm->mail, wp, cm->halo_no, cm->timeout_ticks, cm->mail_err);
+            MIK_LAUNCH_CHECK(ctx);
+        }
+    } else if (halo_flags(it)) {
+        WaitPeers wp{};
+        wp.n = 1; wp.peer[0] = cm->rank;
+        hipLaunchKernelGGL(k_halo_wait, dim3(1), dim3(64), 0, ctx->stream, (const MailBox *)cm->mail, wp, cm->halo_no, cm->timeout_ticks, cm->mail_err);
+        MIK_LAUNCH_CHECK(ctx);
+    } else {
+        MIK_HIP(ctx, hipStreamWaitEvent(ctx->stream, cm->ev_halo, 0));
+    }
     return MIK_OK;
 }
 
-// slot [rank] of `all` -> every rank's `all` (one scalar per rank), on the compute stream
-static int rccl_gather_scalar(mik_cgd *it, void *all)
+// slot [rank] of `all` -> every rank's `all` (one scalar per rank), on the compute stream.  kind: the mailbox lane (0 dot, 1 |r|^2, 2 other)
+static int gather_scalar(mik_cgd *it, void *all, int kind)
 {
     mik_comm *cm = it->comm;
-    if (!cm || !cm->nccl) return MIK_OK;
+    if (!cm) return MIK_OK;
+    mik_ctx *ctx = it->base.ctx;
+    // development knob 6, bit 1: the scalars over RCCL although a mailbox is connected; bit 2: through the mailbox even in a world of one
+    if (cm->mail_ready && (ctx->tuning[6] & 2) == 0 && (it->nranks > 1 || (ctx->tuning[6] & 4) != 0)) {
+        const unsigned long long seq = ++cm->mseq[kind];
+        if (it->base.dtype == MIK_F64)
+            hipLaunchKernelGGL((k_mail_gather<double>), dim3(1), dim3(64), 0, ctx->stream, (MailBox *const *)cm->peers_dev, it->nranks, it->rank, kind, seq, (double *)all,
+                               cm->timeout_ticks, cm->mail_err);
+        else
+            hipLaunchKernelGGL((k_mail_gather<float>), dim3(1), dim3(64), 0, ctx->stream, (MailBox *const *)cm->peers_dev, it->nranks, it->rank, kind, seq, (float *)all,
+                               cm->timeout_ticks, cm->mail_err);
+        MIK_LAUNCH_CHECK(ctx);
+        return MIK_OK;
+    }
+    if (!cm->nccl) return MIK_OK;
     Rccl *R = rccl();
     const size_t es = mik_dtype_size(it->base.dtype);
-    MIK_NCCL(it->base.ctx, R->AllGather((const unsigned char *)all + es * (size_t)it->rank, all, 1, it->base.dtype == MIK_F64 ? NCCL_F64 : NCCL_F32,
-                                        cm->nccl, it->base.ctx->stream));
+    MIK_NCCL(ctx, R->AllGather((const unsigned char *)all + es * (size_t)it->rank, all, 1, it->base.dtype == MIK_F64 ? NCCL_F64 : NCCL_F32, cm->nccl, ctx->stream));
     return MIK_OK;
 }
 
@@ -392,19 +815,21 @@ static int cgd_norm_stage2_any(mik_cgd *it) { return it->base.dtype == MIK_F64 ?
 
 static int cgd_require_transport(mik_cgd *it, const char *who)
 {
-    if (it->nranks > 1 && (!it->comm || !it->comm->nccl))
-        return mik_fail(it->base.ctx, MIK_ERR_INVALID, "%s: %d ranks need a communicator (mik_cgd_set_comm) or the in-process group calls", who, it->nranks);
+    if (it->nranks > 1 && (!it->comm || !(it->comm->nccl || it->comm->mail_ready)))
+        return mik_fail(it->base.ctx, MIK_ERR_INVALID, "%s: %d ranks need a communicator (mik_cgd_set_comm) with RCCL or a connected mailbox, or the in-process group calls", who, it->nranks);
+    if (it->nranks > 1 && !it->comm->nccl && !(it->recv.empty() && it->send.empty()) && !it->ghosts)
+        return mik_fail(it->base.ctx, MIK_ERR_INVALID, "%s: a communicator without RCCL needs the peers' ghost regions (mik_cgd_connect_ghosts)", who);
     return MIK_OK;
 }
 
-static int rccl_scaled_norm(mik_cgd *it)
+static int comm_scaled_norm(mik_cgd *it)
 {
     bool direct = false;
     MIK_TRY(mik_cgd_phase(it, 20, 0));
-    MIK_TRY(rccl_gather_scalar(it, it->rr_all));
+    MIK_TRY(gather_scalar(it, it->rr_all, 2));
     MIK_TRY(cgd_norm_stage1_any(it, &direct));
     if (direct) return MIK_OK;
-    MIK_TRY(rccl_gather_scalar(it, it->rr_all));
+    MIK_TRY(gather_scalar(it, it->rr_all, 2));
     return cgd_norm_stage2_any(it);
 }
 
@@ -415,20 +840,21 @@ extern "C" int mik_cgd_init(mik_cgd *it, double *residual, double *tol)
     MIK_TRY(cgd_require_transport(it, "mik_cgd_init"));
     MIK_TRY(mik_cgd_phase(it, 10, 0));
     bool pending = false;
-    if (!it->initially_zero) MIK_TRY(rccl_halo_begin(it, &pending));
-    MIK_TRY(rccl_halo_end(it, pending));
+    if (!it->initially_zero) MIK_TRY(halo_begin(it, &pending));
+    MIK_TRY(halo_end(it, pending));
     MIK_TRY(mik_cgd_phase(it, 11, 0));
-    MIK_TRY(rccl_gather_scalar(it, it->rr_all));
+    MIK_TRY(gather_scalar(it, it->rr_all, 2));
     MIK_TRY(mik_cgd_phase(it, 12, 0));
     int done = 0;
     int64_t steps = 0;
     CgMirror m;
     MIK_TRY(cgd_wait_raw(it, &m));
     if (m.range) {                                                  // norm(r) outside the safe range on every rank alike: common scale
-        MIK_TRY(rccl_scaled_norm(it));
+        MIK_TRY(comm_scaled_norm(it));
         MIK_TRY(mik_cgd_phase(it, 24, 0));
         MIK_TRY(cgd_wait_raw(it, &m));
     }
+    MIK_TRY(mailbox_check(it->comm, "mik_cgd_init"));
     MIK_TRY(cgd_collect(it, m, residual, tol, &done, nullptr, 0, &steps));
     it->initialised = true;
     return MIK_OK;
@@ -438,41 +864,89 @@ extern "C" int mik_cgd_init(mik_cgd *it, double *residual, double *tol)
 // only u (with its halo), c and this rank's dot slot -- all of its inputs are final once the previous tail has run -- so the
 // head of the step after a call is enqueued before the host waits (as in the single-GPU path, cg_enqueue_head); every rank
 // takes the same decision (same iteration counts, identical stopping scalars), so the RCCL call sequences stay aligned.
+// the step's two scalar exchanges inside the finalising kernels: a connected mailbox, more than one rank (or development knob 6 bit 2),
+// not switched to the one-wave gather launches (bit 3) or to RCCL (bit 1)
+static bool mail_fused(const mik_cgd *it)
+{
+    const mik_comm *cm = it->comm;
+    const int k = it->base.ctx->tuning[6];
+    return cm && cm->mail_ready && (k & 2) == 0 && (k & 8) == 0 && (it->nranks > 1 || (k & 4) != 0);
+}
+
+template <typename T> static int mail_fin_dot(mik_cgd *it)
+{
+    mik_comm *cm = it->comm;
+    mik_cg &bs = it->base;
+    const unsigned long long seq = ++cm->mseq[0];
+    hipLaunchKernelGGL((k_cgd_fin_dot_mail<T>), dim3(MIK_FIN_WGS), dim3(64), 0, bs.ctx->stream, (const T *)bs.seg_spmv, (int64_t)mik_spmv_nwg(bs.n), (FinScratch<T> *)bs.fin,
+                       (CgDev<T> *)bs.dev, (T *)it->dot_all, (MailBox *const *)cm->peers_dev, it->nranks, it->rank, seq, cm->timeout_ticks, cm->mail_err);
+    MIK_LAUNCH_CHECK(bs.ctx);
+    return MIK_OK;
+}
+
+template <typename T> static int mail_fin_rr(mik_cgd *it, int64_t iteration)
+{
+    mik_comm *cm = it->comm;
+    mik_cg &bs = it->base;
+    if (it->hist_total >= bs.hist_cap) return mik_fail(bs.ctx, MIK_ERR_INVALID, "mik_cgd_iterate_many: more than %lld steps enqueued without a wait", (long long)bs.hist_cap);
+    it->hist_total += 1;
+    bs.seq += 1;
+    const unsigned long long seq = ++cm->mseq[1];
+    hipLaunchKernelGGL((k_cgd_fin_rr_mail<T>), dim3(MIK_FIN_WGS), dim3(64), 0, bs.ctx->stream, (const T *)bs.seg_vec, mik_nseg<T>(bs.n), (FinScratch<T> *)bs.fin,
+                       (CgDev<T> *)bs.dev, (T *)it->rr_all, (MailBox *const *)cm->peers_dev, it->nranks, it->rank, seq, cm->timeout_ticks, cm->mail_err, (T *)bs.hist,
+                       (long long)(iteration + 1), (long long)bs.maxiter, bs.mirror, bs.seq, (int)(it->hist_total - 1), bs.fuse_x ? 1 : 0);
+    MIK_LAUNCH_CHECK(bs.ctx);
+    return MIK_OK;
+}
+
+// the local dot(u, c) of the head and its sum over the ranks: phase `with_fin` (SpMV + finaliser into the rank's slot) and a gather, or
+// phase `without` and the finaliser that exchanges by itself
+static int head_spmv_dot(mik_cgd *it, int with_fin, int without, int64_t iteration)
+{
+    if (mail_fused(it)) {
+        MIK_TRY(mik_cgd_phase(it, without, iteration));
+        return it->base.dtype == MIK_F64 ? mail_fin_dot<double>(it) : mail_fin_dot<float>(it);
+    }
+    MIK_TRY(mik_cgd_phase(it, with_fin, iteration));
+    return gather_scalar(it, it->dot_all, 0);
+}
+
 static int cgd_enqueue_head(mik_cgd *it, int64_t iteration)
 {
-    const bool early = it->n_early > 0 && it->comm && it->comm->nccl && !(it->recv.empty() && it->send.empty());
+    const bool early = it->n_early > 0 && halo_any(it);
     bool pending = false;
     if (early) {
         MIK_TRY(mik_cgd_phase(it, it->early_merged ? 9 : 7, iteration));   // u on the rows the neighbours need; pack
-        MIK_TRY(rccl_halo_mark(it));
+        MIK_TRY(halo_mark(it));
         MIK_TRY(mik_cgd_phase(it, 8, iteration));                   // the bulk of the sweep over u ...
         if (it->int_end > it->int_begin) {
             MIK_TRY(mik_cgd_phase(it, 4, iteration));               // ... and the interior row-blocks are on the compute stream
-            MIK_TRY(rccl_halo_issue(it, &pending));                 // before the host enters RCCL: the halo travels underneath them
-            MIK_TRY(rccl_halo_end(it, pending));
-            MIK_TRY(mik_cgd_phase(it, 5, iteration));               // boundary row-blocks + local dot(u, c)
-            return rccl_gather_scalar(it, it->dot_all);
+            MIK_TRY(halo_issue(it, &pending));                 // before the host enters RCCL: the halo travels underneath them
+            MIK_TRY(halo_end(it, pending));
+            return head_spmv_dot(it, 5, 13, iteration);             // boundary row-blocks + local dot(u, c), summed over the ranks
         }
-        MIK_TRY(rccl_halo_issue(it, &pending));
+        MIK_TRY(halo_issue(it, &pending));
     } else {
         MIK_TRY(mik_cgd_phase(it, 0, iteration));                   // u = r + beta u; pack the halo
-        MIK_TRY(rccl_halo_begin(it, &pending));
+        MIK_TRY(halo_begin(it, &pending));
     }
     if (pending && it->int_end > it->int_begin) {
         MIK_TRY(mik_cgd_phase(it, 4, iteration));                   // interior row-blocks while the halo is in flight
-        MIK_TRY(rccl_halo_end(it, pending));
-        MIK_TRY(mik_cgd_phase(it, 5, iteration));                   // boundary row-blocks + local dot(u, c)
-    } else {
-        MIK_TRY(rccl_halo_end(it, pending));
-        MIK_TRY(mik_cgd_phase(it, 1, iteration));
+        MIK_TRY(halo_end(it, pending));
+        return head_spmv_dot(it, 5, 13, iteration);                 // boundary row-blocks + local dot(u, c), summed over the ranks
     }
-    return rccl_gather_scalar(it, it->dot_all);
+    MIK_TRY(halo_end(it, pending));
+    return head_spmv_dot(it, 1, 14, iteration);
 }
 
 static int cgd_enqueue_tail(mik_cgd *it, int64_t iteration)
 {
+    if (mail_fused(it)) {
+        MIK_TRY(mik_cgd_phase(it, 16, iteration));                  // x, r update with the alpha k_cgd_fin_dot_mail stored; local |r|^2 partials
+        return it->base.dtype == MIK_F64 ? mail_fin_rr<double>(it, iteration) : mail_fin_rr<float>(it, iteration);   // ... summed over the ranks; residual, stopping test
+    }
     MIK_TRY(mik_cgd_phase(it, 2, iteration));                       // alpha; x, r update; local |r|^2
-    MIK_TRY(rccl_gather_scalar(it, it->rr_all));
+    MIK_TRY(gather_scalar(it, it->rr_all, 1));
     return mik_cgd_phase(it, 3, iteration);                         // residual, beta, stopping test
 }
 
@@ -509,7 +983,7 @@ extern "C" int mik_cgd_iterate_many(mik_cgd *it, int64_t iteration, int64_t max_
         // none follows the head ahead when the frozen step was the last of the batch.  Left set, the fresh head of the next call
         // would add the same alpha u to x a second time: clear it behind everything that is enqueued.
         if (bs.fuse_x) MIK_TRY(mik_cgd_phase(it, 25, 0));
-        MIK_TRY(rccl_scaled_norm(it));
+        MIK_TRY(comm_scaled_norm(it));
         it->norm_fix_index = (int)m.nhist;
         it->norm_it_next = iteration + m.nhist + 1;
         MIK_TRY(mik_cgd_phase(it, 23, 0));
@@ -518,6 +992,7 @@ extern "C" int mik_cgd_iterate_many(mik_cgd *it, int64_t iteration, int64_t max_
         if (m.done || j0 >= max_steps) break;
     }
     int done = 0;
+    MIK_TRY(mailbox_check(it->comm, "mik_cgd_iterate_many"));
     return cgd_collect(it, m, nullptr, nullptr, &done, residuals, max_steps, steps_done);
 }
 

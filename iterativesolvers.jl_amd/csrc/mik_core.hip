@@ -912,6 +912,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
         if (rc == MIK_OK && !A->sdia_val && !A->sdia_pats && ctx->tuning[8] == 0 && ctx->tuning[20] != 2) {
             rc = mik_build_sdiaw_device(ctx, A);
             if (rc == MIK_OK) rc = mik_build_jds_device(ctx, A);
+            if (rc == MIK_OK) rc = mik_build_xwin_device(ctx, A);
         } else if (rc == MIK_OK && !A->sdia_val && !A->sdia_pats && ctx->tuning[8] == 0) {
             try {
                 rowptr.resize((size_t)n_rows + 1);
@@ -929,6 +930,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
             }
             rc = csr_build_sdiaw(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz);
             if (rc == MIK_OK) rc = csr_build_jds(ctx, A, rowptr, col, v, es, n_rows, nullptr);
+            if (rc == MIK_OK) rc = csr_build_xwin(ctx, A, rowptr, col, es, n_rows, n_cols, A->max_row_nnz);
         }
         if (rc == MIK_OK) rc = sdiaw_chunk_bits(ctx, A);
         if (rc == MIK_OK) { *out = A; return MIK_OK; }

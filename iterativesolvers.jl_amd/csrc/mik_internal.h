@@ -126,6 +126,7 @@ int mik_ensure_partials(mik_ctx *ctx, size_t bytes);
 // device builders of the wide slice-constant layout and of the jagged slices from A's device CSR arrays (mik_upload.hip)
 int mik_build_sdiaw_device(mik_ctx *ctx, mik_csr *A);
 int mik_build_jds_device(mik_ctx *ctx, mik_csr *A);
+int mik_build_xwin_device(mik_ctx *ctx, mik_csr *A);   // after the jagged slices: windows of x for the product-tile kernel (k_spmv_rowblock XWIN)
 
 #define MIK_HIP(ctx, call)                                                                    \
     do {                                                                                      \

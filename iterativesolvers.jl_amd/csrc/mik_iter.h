@@ -57,6 +57,91 @@ struct mik_cg {
     int64_t kern_launches[3] = {0, 0, 0};
 };
 
+#ifdef __HIPCC__
+// Level 2 of a reduction spread over MIK_FIN_WGS single-wave workgroups (the single 1024-thread workgroup of
+// level2_sum pulls its 64 k partials through ONE CU: ~10 us at 256^3).  Workgroup w plays virtual threads
+// 64 w .. 64 w + 63 of the same 1024-thread shape (serial stride-1024 sums, then the wave tree); the workgroup that
+// arrives last at the ticket adds the 16 wave sums left to right -- the order block_tree_1024 uses -- so the
+// total is bit-identical.  Returns true in lane 0 of that last workgroup only.
+constexpr int MIK_FIN_WGS = MIK_FIN_THREADS / 64;
+template <typename T> struct FinScratch { T ws[MIK_FIN_WGS]; unsigned ticket; };
+
+template <typename T> __device__ __forceinline__ bool level2_sum_spread(const T *__restrict__ S, int64_t m, FinScratch<T> *fs, T &tot)
+{
+    const int w = blockIdx.x, lane = threadIdx.x;              // blockDim.x == 64, gridDim.x == MIK_FIN_WGS
+    T acc = T(0);
+    int64_t j = 64 * (int64_t)w + lane;
+    // (batches of 64 / 16 / 8 loads in flight, added in index order: 65,536 SpMV partials are ONE round trip per lane, the 16,384 of
+    //  a vector sweep too -- a single wave per workgroup has the registers for it)
+    for (; j + 63 * (int64_t)MIK_FIN_THREADS < m; j += 64 * (int64_t)MIK_FIN_THREADS) {
+        T v[64];
+#pragma unroll
+        for (int q = 0; q < 64; ++q) v[q] = S[j + q * (int64_t)MIK_FIN_THREADS];
+#pragma unroll
+        for (int q = 0; q < 64; ++q) acc = acc + v[q];
+    }
+    for (; j + 15 * (int64_t)MIK_FIN_THREADS < m; j += 16 * (int64_t)MIK_FIN_THREADS) {
+        T v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = S[j + q * (int64_t)MIK_FIN_THREADS];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc = acc + v[q];
+    }
+    for (; j + 7 * (int64_t)MIK_FIN_THREADS < m; j += 8 * (int64_t)MIK_FIN_THREADS) {
+        T v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = S[j + q * (int64_t)MIK_FIN_THREADS];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = acc + v[q];
+    }
+    for (; j < m; j += MIK_FIN_THREADS) acc = acc + S[j];
+    acc = wave_tree(acc);
+    bool last = false;
+    if (lane == 0) {
+        // hand-off without cache-wide fences (as longrow_store, mik_spmv.h): one write-through store, drained, then a relaxed ticket;
+        // the last arrival reads the sums with loads that are served past its L1
+        __hip_atomic_store(&fs->ws[w], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tk = __hip_atomic_fetch_add(&fs->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tk == (unsigned)gridDim.x - 1u) {
+            T t = __hip_atomic_load(&fs->ws[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int q = 1; q < MIK_FIN_WGS; ++q) t = t + __hip_atomic_load(&fs->ws[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&fs->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tot = t;
+            last = true;
+        }
+    }
+    return last;
+}
+
+
+// residual = norm(r) of a row-partitioned step from the rank-ordered total of |r|^2 (src/cg.jl:61-62), history, beta and the stopping test
+// of :36 for the next iterate() call; one thread.  A total outside the range of a safe sqrt(sum of squares) freezes the batch on every
+// rank alike (identical totals): x and r of the step are final, the hosts finish it with the scaled norm over the partition.
+template <typename T>
+__device__ __forceinline__ void cgd_close_step(CgDev<T> *d, T tot, T *__restrict__ hist, long long it_next, long long maxiter, CgMirror *mirror,
+                                               unsigned long long seq, int hist_index, int fuse_x)
+{
+    if (fuse_x) d->x_pending = 1;              // r of this step is final; its x update rides on the next sweep over u
+    if (!mik_nrm_in_range(tot)) {
+        d->done = 1; mirror->done = 0; mirror->nhist = hist_index; mirror->range = 1;
+        __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    const T prev = d->res;
+    const T res = mik_sqrt(tot);
+    d->rr = tot; d->prev_res = prev; d->res = res;
+    d->beta = (res * res) / (prev * prev);
+    hist[hist_index] = res;                   // step `hist_index` since the last wait (steps behind a stop are no-ops)
+    const int nh = hist_index + 1;
+    const int dn = (it_next >= maxiter || res <= d->tol) ? 1 : 0;
+    if (dn) d->done = 1;
+    mirror->res = (double)res; mirror->prev_res = (double)prev; mirror->done = dn; mirror->nhist = nh;
+    __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif  // __HIPCC__
+
 // Wait until the device has published step `it->seq` in the host-mapped mirror (bounded spin).
 int cg_wait_mirror(mik_cg *it);
 
@@ -78,6 +163,8 @@ struct mik_cgd {
     struct HaloSeg { int peer; int64_t off, cnt; };
     std::vector<HaloSeg> recv, send;      // offsets into the ghost tail of u_ext / into send_buf, in elements
     mik_comm *comm = nullptr;
+    std::vector<void *> send_dst;         // per send segment: where it lands in the receiver's ghost region, as mapped here (mik_cgd_connect_ghosts)
+    bool ghosts = false;                  // the halo is pushed into peer-mapped ghost regions (mailbox transport) instead of ncclSend / ncclRecv
     bool initialised = false;             // mik_cgd_init ran
     // rows the neighbours need (send_idx) as at most two contiguous runs [a, b): when they are, u is updated there FIRST, packed and
     // put on the wire before the bulk of the u = r + beta u sweep runs (mik_cgd_set_halo_plan decides; n_early = 0: not applicable)

@@ -357,62 +357,7 @@ extern "C" int mik_orthogonalize_vectors(mik_ctx *ctx, int dtype, int64_t n, int
 // =============================================================================================
 // CGIterable / PCGIterable
 // =============================================================================================
-// Level 2 of a reduction spread over MIK_FIN_WGS single-wave workgroups (the single 1024-thread workgroup of
-// level2_sum pulls its 64 k partials through ONE CU: ~10 us at 256^3).  Workgroup w plays virtual threads
-// 64 w .. 64 w + 63 of the same 1024-thread shape (serial stride-1024 sums, then the wave tree); the workgroup that
-// arrives last at the ticket adds the 16 wave sums left to right -- the order block_tree_1024 uses -- so the
-// total is bit-identical.  Returns true in lane 0 of that last workgroup only.
-constexpr int MIK_FIN_WGS = MIK_FIN_THREADS / 64;
-template <typename T> struct FinScratch { T ws[MIK_FIN_WGS]; unsigned ticket; };
-
-template <typename T> __device__ __forceinline__ bool level2_sum_spread(const T *__restrict__ S, int64_t m, FinScratch<T> *fs, T &tot)
-{
-    const int w = blockIdx.x, lane = threadIdx.x;              // blockDim.x == 64, gridDim.x == MIK_FIN_WGS
-    T acc = T(0);
-    int64_t j = 64 * (int64_t)w + lane;
-    // (batches of 64 / 16 / 8 loads in flight, added in index order: 65,536 SpMV partials are ONE round trip per lane, the 16,384 of
-    //  a vector sweep too -- a single wave per workgroup has the registers for it)
-    for (; j + 63 * (int64_t)MIK_FIN_THREADS < m; j += 64 * (int64_t)MIK_FIN_THREADS) {
-        T v[64];
-#pragma unroll
-        for (int q = 0; q < 64; ++q) v[q] = S[j + q * (int64_t)MIK_FIN_THREADS];
-#pragma unroll
-        for (int q = 0; q < 64; ++q) acc = acc + v[q];
-    }
-    for (; j + 15 * (int64_t)MIK_FIN_THREADS < m; j += 16 * (int64_t)MIK_FIN_THREADS) {
-        T v[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = S[j + q * (int64_t)MIK_FIN_THREADS];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc = acc + v[q];
-    }
-    for (; j + 7 * (int64_t)MIK_FIN_THREADS < m; j += 8 * (int64_t)MIK_FIN_THREADS) {
-        T v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = S[j + q * (int64_t)MIK_FIN_THREADS];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc = acc + v[q];
-    }
-    for (; j < m; j += MIK_FIN_THREADS) acc = acc + S[j];
-    acc = wave_tree(acc);
-    bool last = false;
-    if (lane == 0) {
-        // hand-off without cache-wide fences (as longrow_store, mik_spmv.h): one write-through store, drained, then a relaxed ticket;
-        // the last arrival reads the sums with loads that are served past its L1
-        __hip_atomic_store(&fs->ws[w], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned tk = __hip_atomic_fetch_add(&fs->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tk == (unsigned)gridDim.x - 1u) {
-            T t = __hip_atomic_load(&fs->ws[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int q = 1; q < MIK_FIN_WGS; ++q) t = t + __hip_atomic_load(&fs->ws[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&fs->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tot = t;
-            last = true;
-        }
-    }
-    return last;
-}
+// (level2_sum_spread / FinScratch: csrc/mik_iter.h -- shared with the mailbox finalisers of csrc/mik_comm.hip)
 
 // the same for TWO reductions finalised by one launch (the fused PCG tail): one ticket, the last arrival adds both sets
 template <typename T> struct FinScratch2 { T ws[MIK_FIN_WGS]; T ws2[MIK_FIN_WGS]; unsigned ticket; };
@@ -1974,25 +1919,7 @@ __global__ void k_cgd_fin_res(const T *__restrict__ rr_all, int nranks, CgDev<T>
                               CgMirror *mirror, unsigned long long seq, int hist_index, int fuse_x)
 {
     if (d->done) { __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); return; }
-    if (fuse_x) d->x_pending = 1;              // r of this step is final; its x update rides on the next sweep over u
-    const T tot = rank_sum(rr_all, nranks);
-    if (!mik_nrm_in_range(tot)) {
-        // as k_cg_fin_res: x and r of this step are final, its norm is not -- freeze the batch on every rank (identical totals);
-        // the hosts finish the step with the scaled norm over the partition (phases 20-23) and go on
-        d->done = 1; mirror->done = 0; mirror->nhist = hist_index; mirror->range = 1;
-        __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-    }
-    const T prev = d->res;
-    const T res = mik_sqrt(tot);
-    d->rr = tot; d->prev_res = prev; d->res = res;
-    d->beta = (res * res) / (prev * prev);
-    hist[hist_index] = res;                   // step `hist_index` since the last wait (steps behind a stop are no-ops)
-    const int nh = hist_index + 1;
-    const int dn = (it_next >= maxiter || res <= d->tol) ? 1 : 0;
-    if (dn) d->done = 1;
-    mirror->res = (double)res; mirror->prev_res = (double)prev; mirror->done = dn; mirror->nhist = nh;
-    __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    cgd_close_step<T>(d, rank_sum(rr_all, nranks), hist, it_next, maxiter, mirror, seq, hist_index, fuse_x);
 }
 
 // finishes cg_iterator! with a residual norm obtained through the scaled pass over the partition
@@ -2246,6 +2173,18 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
                            (long long)bs.maxiter, bs.mirror, bs.seq, it->norm_fix_index);
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
+    case 13:    // step B2 without the finaliser (the mailbox transport finalises and exchanges in one kernel: csrc/mik_comm.hip)
+        return mik_spmv_launch_outside<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done, (int)it->int_begin, (int)it->int_end);
+    case 14:    // step B without the finaliser
+        return mik_spmv_launch<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done);
+    case 16: {  // step C without alpha formation and without the finaliser: alpha is the stored scalar (k_cgd_fin_dot_mail)
+        if (bs.fuse_x) {
+            OpCgUpdateR<T> up{r, c, coef_ptr<T>(&d->alpha), cg_stream_hints(ctx, true, bs.A) >> 3};
+            return launch_map<T>(ctx, n, up, vec, (T *)bs.seg_vec, done);
+        }
+        OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints(ctx) >> 3};
+        return launch_map<T>(ctx, n, up, vec, (T *)bs.seg_vec, done);
+    }
     case 25:    // the pending x update of a frozen step has been applied (by a no-op head, the head ahead or phase 6): drop the flag
         hipLaunchKernelGGL((k_cg_clear_pending<T>), dim3(1), dim3(1), 0, ctx->stream, d);
         MIK_LAUNCH_CHECK(ctx);

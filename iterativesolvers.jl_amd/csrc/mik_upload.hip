@@ -782,3 +782,66 @@ int mik_build_jds_device(mik_ctx *ctx, mik_csr *A)
         return MIK_OK;
     return A->dtype == MIK_F64 ? build_jds_device_t<double>(ctx, A) : build_jds_device_t<float>(ctx, A);
 }
+
+
+// ---- windows of x for the product-tile kernel (csr_build_xwin in mik_core.hip is the host form of the same rule) -------------
+namespace {
+__global__ __launch_bounds__(MIK_BLOCK) void k_up_xwin(const int *__restrict__ rowptr, const int *__restrict__ col, long long n_rows, int *__restrict__ mn_out,
+                                                       int *__restrict__ mx_out, int *__restrict__ cnt_out)
+{
+    __shared__ int smn[MIK_BLOCK], smx[MIK_BLOCK];
+    const long long r0 = (long long)blockIdx.x * MIK_BLOCK, r1 = r0 + MIK_BLOCK < n_rows ? r0 + MIK_BLOCK : n_rows;
+    const int ka = rowptr[r0], kb = rowptr[r1];
+    int mn = INT32_MAX, mx = -1;
+    for (int k = ka + (int)threadIdx.x; k < kb; k += MIK_BLOCK) { const int c = col[k]; mn = c < mn ? c : mn; mx = c > mx ? c : mx; }
+    smn[threadIdx.x] = mn; smx[threadIdx.x] = mx;
+    __syncthreads();
+    for (int off = MIK_BLOCK / 2; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            smn[threadIdx.x] = smn[threadIdx.x] < smn[threadIdx.x + off] ? smn[threadIdx.x] : smn[threadIdx.x + off];
+            smx[threadIdx.x] = smx[threadIdx.x] > smx[threadIdx.x + off] ? smx[threadIdx.x] : smx[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { mn_out[blockIdx.x] = smn[0]; mx_out[blockIdx.x] = smx[0]; cnt_out[blockIdx.x] = kb - ka; }
+}
+}  // namespace
+
+int mik_build_xwin_device(mik_ctx *ctx, mik_csr *A)
+{
+    if (!A->rowptr || A->n_long || A->sdia_val || A->sdia_pats || A->sdiaw_pats || A->jds_val || A->nnz <= 0 || A->n_rows <= 0 || ctx->tuning[8] != 0 ||
+        ctx->tuning[29] == 1 || A->max_row_nnz <= 32)
+        return MIK_OK;
+    const int64_t nb = (A->n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
+    int *d = nullptr;
+    MIK_HIP(ctx, hipMalloc((void **)&d, sizeof(int) * 3 * (size_t)nb));
+    hipLaunchKernelGGL(k_up_xwin, dim3((unsigned)nb), dim3(MIK_BLOCK), 0, ctx->stream, (const int *)A->rowptr, (const int *)A->col, (long long)A->n_rows, d, d + nb, d + 2 * nb);
+    std::vector<int> h((size_t)(3 * nb));
+    hipError_t e = hipMemcpyAsync(h.data(), d, sizeof(int) * h.size(), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create: window statistics: %s", hipGetErrorString(e));
+    const size_t es = mik_dtype_size(A->dtype);
+    const int W = (int)(16 / es), XP = (int)(1024 / es);
+    const int64_t cap = 32768 / (int64_t)es - W, n_cols = A->n_cols;
+    std::vector<int> lo((size_t)nb, 0);
+    int64_t need = 0, inside = 0;
+    for (int64_t b = 0; b < nb; ++b) {
+        if (h[(size_t)(2 * nb + b)] <= 0) continue;
+        lo[(size_t)b] = h[(size_t)b] & ~(W - 1);
+        const int64_t nd = (int64_t)h[(size_t)(nb + b)] + 1 - lo[(size_t)b];
+        if (nd > cap) { lo[(size_t)b] = -1; continue; }
+        need = std::max(need, nd);
+        inside += h[(size_t)(2 * nb + b)];
+    }
+    if (need <= 0 || 4 * inside < 3 * A->nnz) return MIK_OK;
+    const int64_t span = (need + W + XP - 1) / XP * XP;
+    if (span + W > n_cols) return MIK_OK;
+    for (int64_t b = 0; b < nb; ++b)
+        if (lo[(size_t)b] >= 0 && (int64_t)lo[(size_t)b] + span > n_cols) lo[(size_t)b] = (int)((n_cols - span) & ~(int64_t)(W - 1));
+    if ((e = hipMalloc((void **)&A->xwin_lo, sizeof(int) * (size_t)nb)) != hipSuccess ||
+        (e = hipMemcpy(A->xwin_lo, lo.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice)) != hipSuccess)
+        return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: window table: %s", hipGetErrorString(e));
+    A->xwin_span = (int)span;
+    return MIK_OK;
+}

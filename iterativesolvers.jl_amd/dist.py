@@ -488,16 +488,25 @@ def register_halo_plan(pkg, engine):
 
 
 class NativeComm:
-    """``mik_comm``: RCCL bound INSIDE libmik.so (include/mik.h "Transport 1").  ``bootstrap`` is any communicator of this
-    module (TorchComm over gloo or nccl, SelfComm): it only carries rank 0's 128-byte ncclUniqueId to the other ranks --
-    what MPI.jl's ``bcast`` would do for a Julia host.  ``force_rccl`` creates a real RCCL communicator even in a world
-    of one (exercises the library's RCCL call path on a single-GPU box)."""
+    """``mik_comm``: the transports INSIDE libmik.so (include/mik.h "Transport 1" and "Transport 3").  ``bootstrap`` is any
+    communicator of this module (TorchComm over gloo or nccl, SelfComm): it only carries small host objects between the ranks --
+    rank 0's 128-byte ncclUniqueId, the 64-byte HIP IPC handles of the mailboxes and ghost regions -- what MPI.jl's ``bcast`` /
+    ``Allgather`` would do for a Julia host.
 
-    def __init__(self, pkg, ctx, bootstrap, *, force_rccl=False):
+    ``transport``: "rccl" (halo by ncclSend / ncclRecv, scalars by ncclAllGather), "rccl+mailbox" (halo by RCCL, the two scalars of a
+    step through peer-mapped mailboxes), "mailbox" (no RCCL at all: scalars through the mailboxes, the halo pushed into peer-mapped
+    ghost regions -- the only transport that lets several ranks share one GPU).  ``force_rccl`` creates a real RCCL communicator even
+    in a world of one (exercises the library's RCCL call path on a single-GPU box)."""
+
+    def __init__(self, pkg, ctx, bootstrap, *, force_rccl=False, transport="rccl"):
         self.pkg, self.ctx, self.L = pkg, ctx, pkg.lib()
+        self.boot = bootstrap
         self.rank, self.size = bootstrap.rank, bootstrap.size
+        self.transport = transport
+        if transport not in ("rccl", "rccl+mailbox", "mailbox"):
+            raise ValueError(f"NativeComm: unknown transport {transport!r}")
         ident = None
-        if self.size > 1 or force_rccl:
+        if transport != "mailbox" and (self.size > 1 or force_rccl):
             buf = C.create_string_buffer(128)
             payload = bytes(buf.raw)
             if self.rank == 0:                        # a failure on rank 0 is told to everybody instead of leaving them in the gather
@@ -512,11 +521,46 @@ class NativeComm:
         h = _vp()
         pkg._lib.check(self.L.mik_comm_create(ctx.handle, ident, self.rank, self.size, C.byref(h)), "mik_comm_create", ctx.handle)
         self.handle = h
+        if transport != "rccl":
+            mine = C.create_string_buffer(64)
+            pkg._lib.check(self.L.mik_comm_mailbox_export(self.handle, mine), "mik_comm_mailbox_export", ctx.handle)
+            handles = b"".join(bootstrap.all_gather_objects(bytes(mine.raw)))
+            pkg._lib.check(self.L.mik_comm_mailbox_connect(self.handle, handles), "mik_comm_mailbox_connect", ctx.handle)
+            bootstrap.barrier()
 
     def uses_rccl(self) -> bool:
         out = C.c_int()
         self.L.mik_comm_info(self.handle, None, None, C.byref(out))
         return bool(out.value)
+
+    def mailbox(self):
+        """(connected, fine-grained) of the communicator's mailbox"""
+        a, b = C.c_int(), C.c_int()
+        self.L.mik_comm_mailbox_info(self.handle, C.byref(a), C.byref(b))
+        return bool(a.value), bool(b.value)
+
+    def connect_ghosts(self, engine):
+        """transport "mailbox": every rank exports the allocation that holds its u_ext, every sender learns where its segments land
+        (mik_cgd_connect_ghosts).  Collective; after mik_cgd_set_halo_plan + mik_cgd_set_comm."""
+        plan, L, ctx = engine.plan, self.L, engine.ctx
+        hbuf, off = C.create_string_buffer(64), C.c_int64()
+        self.pkg._lib.check(L.mik_mem_export(ctx.handle, _vp(engine.u_ext.data_ptr()), hbuf, C.byref(off)), "mik_mem_export", ctx.handle)
+        info = self.boot.all_gather_objects((bytes(hbuf.raw), int(off.value), int(plan.n_loc), [tuple(int(v) for v in sg) for sg in plan.recv]))
+        handles = b"".join(i[0] for i in info)
+        offsets = np.array([i[1] for i in info], np.int64)
+        dst = []
+        taken = {}
+        for peer, _off, cnt in plan.send:
+            cands = [sg for sg in info[peer][3] if sg[0] == self.rank]
+            k = taken.get(peer, 0)
+            taken[peer] = k + 1
+            if k >= len(cands) or cands[k][2] != cnt:
+                raise RuntimeError(f"halo plans disagree: rank {self.rank} sends {cnt} entries to rank {peer}, which expects {cands}")
+            dst.append(info[peer][2] + cands[k][1])
+        dst = np.array(dst if dst else [0], np.int64)
+        self.pkg._lib.check(L.mik_cgd_connect_ghosts(engine.handle, handles, offsets.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                     dst.ctypes.data_as(C.POINTER(C.c_int64))), "mik_cgd_connect_ghosts", ctx.handle)
+        self.boot.barrier()
 
     def close(self):
         if getattr(self, "handle", None):
@@ -540,6 +584,8 @@ class NativeDistCGIterable:
         self.mv_products = 0
         register_halo_plan(pkg, engine)
         pkg._lib.check(engine.L.mik_cgd_set_comm(engine.handle, native_comm.handle), "mik_cgd_set_comm", engine.ctx.handle)
+        if native_comm.transport == "mailbox":
+            native_comm.connect_ghosts(engine)
         res, tol = C.c_double(), C.c_double()
         with engine.stream_ctx():
             pkg._lib.check(engine.L.mik_cgd_init(engine.handle, C.byref(res), C.byref(tol)), "mik_cgd_init", engine.ctx.handle)

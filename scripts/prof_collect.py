@@ -1,4 +1,4 @@
-"""Condense the rocprofv3 output of scripts/prof_r03.sh into small files fit for profiles/:
+"""Condense the rocprofv3 output of scripts/prof_r0N.sh into small files fit for profiles/:
    <what>_kernel_stats.csv   (name, calls, total / average / min / max duration in us, percentage)
    <what>_pmc_summary.txt    (mean counter value per dispatch, per kernel) + derived figures
    <what>_traffic.json       (HBM-side bytes per launch: 2 * FETCH_SIZE + WRITE_SIZE, KiB counters; gfx950 note in
@@ -59,7 +59,7 @@ for d in sorted(glob.glob(os.path.join(root, "*"))):
         continue
     traffic = {}
     with open(os.path.join(summ, f"{what}_pmc_summary.txt"), "w") as o:
-        o.write("mean counter value per dispatch (separate rocprofv3 --pmc passes; scripts/prof_r03.sh)\n")
+        o.write("mean counter value per dispatch (separate rocprofv3 --pmc passes; scripts/prof_r0N.sh)\n")
         for k in sorted(means, key=lambda k: -means[k].get("SQ_WAVE_CYCLES", means[k].get("FETCH_SIZE", 0))):
             m = means[k]
             if not any(s in k for s in ("spmv", "k_map", "k_cg", "multidot", "gemv", "k_mgs", "k_cgs", "finalize", "k_rowdot")):

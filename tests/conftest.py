@@ -46,5 +46,15 @@ def dist(pkg):
     return import_module(pkg.__name__ + ".dist")
 
 
+@pytest.fixture(autouse=True)
+def _development_knobs_back_to_default(request):
+    """a test that fails between setting a development knob (include/mik_dev.h) and resetting it must not leak it into the next one"""
+    yield
+    if "pkg" in request.fixturenames:
+        L = request.getfixturevalue("pkg").lib()
+        for k in range(32):
+            L.mik_set_tuning(k, 0)
+
+
 def fromhex(lst):
     return np.array([float.fromhex(s) for s in lst], dtype=np.float64)
