@@ -667,6 +667,32 @@ static int csr_build_sdiaw(mik_ctx *ctx, mik_csr *A, const std::vector<int> &row
     return MIK_OK;
 }
 
+// Rows of a 256-row block over its threads by length (k_spmv_rowblock RPERM, csrc/mik_spmv.h): the row with rank p among the block's
+// rows (longest first, ties in row order) goes to thread ((p / 64 + block) % 4) * 64 + p % 64 -- the 64 longest rows share a wave, and
+// that wave is a different one (a different SIMD) from block to block.  Built for the operators the product tile runs (irregular row
+// lengths: split-off long rows or rows beyond 32 entries); development knob 29 = 1: never.
+int mik_build_rperm_host(mik_ctx *ctx, mik_csr *A, const int *rowptr)
+{
+    const int64_t n = A->n_rows;
+    if (A->sdia_val || A->sdia_pats || A->sdiaw_pats || A->jds_val || n <= 0 || ctx->tuning[29] == 1) return MIK_OK;
+    if (A->n_long == 0 && A->max_row_nnz <= 32) return MIK_OK;
+    const int64_t nb = (n + MIK_BLOCK - 1) / MIK_BLOCK;
+    std::vector<unsigned char> perm((size_t)(nb * MIK_BLOCK));
+    int ord[MIK_BLOCK], len[MIK_BLOCK];
+    for (int64_t b = 0; b < nb; ++b) {
+        const int64_t r0 = b * MIK_BLOCK;
+        for (int t = 0; t < MIK_BLOCK; ++t) { ord[t] = t; len[t] = r0 + t < n ? rowptr[r0 + t + 1] - rowptr[r0 + t] : -1; }
+        std::stable_sort(ord, ord + MIK_BLOCK, [&](int a, int c) { return len[a] > len[c]; });
+        for (int p = 0; p < MIK_BLOCK; ++p) perm[(size_t)(r0 + (((p >> 6) + (int)(b & 3)) & 3) * 64 + (p & 63))] = (unsigned char)ord[p];
+    }
+    hipError_t e;
+    (void)hipSetDevice(ctx->device);
+    if ((e = hipMalloc((void **)&A->rperm, perm.size())) != hipSuccess ||
+        (e = hipMemcpy(A->rperm, perm.data(), perm.size(), hipMemcpyHostToDevice)) != hipSuccess)
+        return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: row permutation: %s", hipGetErrorString(e));
+    return MIK_OK;
+}
+
 // Windows of x for the product-tile kernel (k_spmv_rowblock XWIN, csrc/mik_spmv.h): for every 256-row block the first column its
 // SHORT rows reference, aligned down to 16 bytes; one common span = the widest block's, rounded up to whole 1-KiB LDS-DMA pieces.
 // Built for irregular operators (split-off long rows or rows beyond 32 entries: the uniform short-row operators stay with the
@@ -931,6 +957,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
             rc = csr_build_sdiaw(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz);
             if (rc == MIK_OK) rc = csr_build_jds(ctx, A, rowptr, col, v, es, n_rows, nullptr);
             if (rc == MIK_OK) rc = csr_build_xwin(ctx, A, rowptr, col, es, n_rows, n_cols, A->max_row_nnz);
+            if (rc == MIK_OK) rc = mik_build_rperm_host(ctx, A, rowptr.data());
         }
         if (rc == MIK_OK) rc = sdiaw_chunk_bits(ctx, A);
         if (rc == MIK_OK) { *out = A; return MIK_OK; }
@@ -1105,6 +1132,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
     if (rc_layout == MIK_OK) rc_layout = csr_build_sdiaw(ctx, A, rowptr, col, v, es, n_rows, n_cols, nnz);
     if (rc_layout == MIK_OK) rc_layout = csr_build_jds(ctx, A, rowptr, col, v, es, n_rows, is_long.empty() ? nullptr : is_long.data());
     if (rc_layout == MIK_OK) rc_layout = csr_build_xwin(ctx, A, rowptr, col, es, n_rows, n_cols, max_row);
+    if (rc_layout == MIK_OK) rc_layout = mik_build_rperm_host(ctx, A, rowptr.data());
     if (rc_layout == MIK_OK) rc_layout = sdiaw_chunk_bits(ctx, A);
     if (rc_layout != MIK_OK) { cleanup(); return rc_layout; }
     *out = A;
@@ -1134,6 +1162,7 @@ extern "C" int mik_csr_destroy(mik_csr *A)
     if (A->sdiaw_mask) (void)hipFree(A->sdiaw_mask);
     if (A->sdiaw_uz) (void)hipFree(A->sdiaw_uz);
     if (A->xwin_lo) (void)hipFree(A->xwin_lo);
+    if (A->rperm) (void)hipFree(A->rperm);
     if (A->jds_ptr) (void)hipFree(A->jds_ptr);
     if (A->jds_len) (void)hipFree(A->jds_len);
     if (A->jds_col) (void)hipFree(A->jds_col);
@@ -1173,7 +1202,7 @@ extern "C" int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes)
     case 1: *bytes = A->jds_groups * (16 / es) * (es + 4) + A->n_rows * 2 + ((A->n_rows + 63) / 64 + 1) * 4 +
                      (A->n_long ? (A->nnz - A->jds_short_nnz) * (es + 4) + 12LL * A->n_long + 4LL * A->n_seg + 16LL * A->n_cut : 0); break;
     default: *bytes = A->nnz * (es + 4) + (A->n_rows + 1) * 4 + (A->n_long ? A->n_rows + 12LL * A->n_long + 4LL * A->n_seg + 16LL * A->n_cut : 0) +
-                      ((A->xwin_lo && !spmv_csr_rowgather(A)) ? nb * 4 : 0); break;
+                      ((A->xwin_lo && !spmv_csr_rowgather(A)) ? nb * 4 : 0) + ((A->rperm && !spmv_csr_rowgather(A)) ? A->n_rows : 0); break;
     }
     return MIK_OK;
 }
@@ -1228,7 +1257,7 @@ extern "C" int mik_csr_compact(mik_csr *A)
 static inline bool spmv_csr_rowgather(const mik_csr *A)
 {
     // operators with x windows (irregular rows inside a band, csr_build_xwin) run on the product tile, which gathers from them
-    return A->ctx->tuning[14] == 2 || (A->ctx->tuning[14] == 0 && A->n_long == 0 && !A->xwin_lo);
+    return A->ctx->tuning[14] == 2 || (A->ctx->tuning[14] == 0 && A->n_long == 0 && !A->xwin_lo && !A->rperm);
 }
 
 // k_spmv_sdiab2 (two rows per lane): the operator's class has the lane-neighbour shape, n is even, and no development
@@ -1477,19 +1506,23 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
     // x served from an LDS window per row-block (csr_build_xwin; development knob 29 = 2: off at launch) -- wide loads and an aligned x only
     const bool xwin = A->xwin_lo && wide && ctx->tuning[29] == 0 && mik_aligned16(x);
     const size_t dyn = xwin ? sizeof(T) * (size_t)A->xwin_span : 0;
-#define MIK_SPMV_GO(FD, NT, WD, MG, XW)                                                                          \
-    hipLaunchKernelGGL((k_spmv_rowblock<T, FD, NT, WD, MG, XW>), grid, block, XW ? dyn : 0, ctx->stream, n, nb, map_mode, A->rowptr, \
-                       A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, nlb, lt, (const int *)A->xwin_lo, A->xwin_span)
-#define MIK_SPMV_GO2(FD, MG)                                                              \
+    const bool rp = A->rperm && wide && ctx->tuning[29] == 0;         // rows of a block over its threads by length (mik_build_rperm_host)
+#define MIK_SPMV_GO(FD, NT, WD, MG, XW, RP)                                                                      \
+    hipLaunchKernelGGL((k_spmv_rowblock<T, FD, NT, WD, MG, XW, RP>), grid, block, XW ? dyn : 0, ctx->stream, n, nb, map_mode, A->rowptr, \
+                       A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, nlb, lt, (const int *)A->xwin_lo, A->xwin_span, (const unsigned char *)A->rperm)
+#define MIK_SPMV_GO3(FD, NT, MG)                                                          \
     do {                                                                                  \
-        if (xwin) { if (nt) MIK_SPMV_GO(FD, true, true, MG, true); else MIK_SPMV_GO(FD, false, true, MG, true); }   \
-        else if (nt) { if (wide) MIK_SPMV_GO(FD, true, true, MG, false); else MIK_SPMV_GO(FD, true, false, MG, false); }   \
-        else    { if (wide) MIK_SPMV_GO(FD, false, true, MG, false); else MIK_SPMV_GO(FD, false, false, MG, false); } \
+        if (xwin) { if (rp) MIK_SPMV_GO(FD, NT, true, MG, true, true); else MIK_SPMV_GO(FD, NT, true, MG, true, false); }   \
+        else if (rp) MIK_SPMV_GO(FD, NT, true, MG, false, true);                          \
+        else if (wide) MIK_SPMV_GO(FD, NT, true, MG, false, false);                       \
+        else MIK_SPMV_GO(FD, NT, false, MG, false, false);                                \
     } while (0)
+#define MIK_SPMV_GO2(FD, MG) do { if (nt) MIK_SPMV_GO3(FD, true, MG); else MIK_SPMV_GO3(FD, false, MG); } while (0)
     if (fuse_dot) MIK_SPMV_GO2(true, false);
     else if (merge) MIK_SPMV_GO2(false, true);
     else MIK_SPMV_GO2(false, false);
 #undef MIK_SPMV_GO2
+#undef MIK_SPMV_GO3
 #undef MIK_SPMV_GO
     MIK_LAUNCH_CHECK(ctx);
     return MIK_OK;

@@ -65,6 +65,7 @@ struct mik_csr {
     int n_long = 0;                  // rows longer than MIK_LONG_ROW, stored behind the short part
     int *xwin_lo = nullptr;          // device, one per 256-row block: first column of the block's window of x (k_spmv_rowblock XWIN); NULL = no windows
     int xwin_span = 0;               // elements of x per window (a multiple of 1 KiB)
+    unsigned char *rperm = nullptr;  // device, n_rows rounded up to whole 256-row blocks: thread t of a row-block sums row rperm[r0 + t] (k_spmv_rowblock RPERM); NULL = row t
     int *long_rows = nullptr;        // device: [n_long] targets, [n_long] start offsets, [n_long] lengths of the virtual rows, then the
                                      // segment tables: [n_seg] cut-row index, [n_cut] row, [n_cut] first segment, [n_cut] segments, [n_cut] tickets
     int n_seg = 0, n_cut = 0;        // rows longer than MIK_LONG_SEG are cut into n_seg segments (csrc/mik_spmv.h)
@@ -126,7 +127,8 @@ int mik_ensure_partials(mik_ctx *ctx, size_t bytes);
 // device builders of the wide slice-constant layout and of the jagged slices from A's device CSR arrays (mik_upload.hip)
 int mik_build_sdiaw_device(mik_ctx *ctx, mik_csr *A);
 int mik_build_jds_device(mik_ctx *ctx, mik_csr *A);
-int mik_build_xwin_device(mik_ctx *ctx, mik_csr *A);   // after the jagged slices: windows of x for the product-tile kernel (k_spmv_rowblock XWIN)
+int mik_build_xwin_device(mik_ctx *ctx, mik_csr *A);
+int mik_build_rperm_host(mik_ctx *ctx, mik_csr *A, const int *rowptr_host);   // rows of a block sorted by length over its threads (k_spmv_rowblock RPERM)   // after the jagged slices: windows of x for the product-tile kernel (k_spmv_rowblock XWIN)
 
 #define MIK_HIP(ctx, call)                                                                    \
     do {                                                                                      \

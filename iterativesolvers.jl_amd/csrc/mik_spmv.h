@@ -89,10 +89,10 @@ __device__ __forceinline__ int spmv_block_map(int b, int nb, int mode)
 // of the banded configs[4] stand-in (2.4 TB/s; profiles/r04_c5_banded_*).  A vector-memory instruction is priced
 // per instruction on this GPU (scripts/micro/gather_width.hip), so the operator streams now come as ONE 16-byte
 // column load and one (fp64: two) 16-byte value load(s) per lane and group -- which is what fixes the group of 4
-// in the shape above -- every row starts 16-byte aligned in the long part, all loads of a pass are issued before
-// anything is waited for, the next pass's streams go out ahead of this pass's gathers, and the virtual rows are
-// listed in (row, segment) order so that the four waves of a workgroup walk neighbouring pieces of ONE row's
-// sorted column window (val / col streamed non-temporally, x gathered with the default policy).
+// in the shape above -- every row starts 16-byte aligned in the long part, a segment is ONE pass whose loads are all
+// issued before anything is waited for (few registers: eight waves per SIMD), and the virtual rows are listed in
+// (row, segment) order so that the four waves of a workgroup walk neighbouring pieces of ONE row's sorted column
+// window (val / col streamed non-temporally, x gathered with the default policy).
 constexpr int MIK_LONG_G = 4;                          // entries per lane and group (one 16-byte column load)
 
 // Rows with more than MIK_LONG_SEG entries are cut into segments: every segment is summed by its own wave with the
@@ -100,7 +100,7 @@ constexpr int MIK_LONG_G = 4;                          // entries per lane and g
 // segment (an integer ticket elects it; the sums themselves are stored individually and always added in segment order,
 // so the result does not depend on the order in which the waves finish).
 // The oracle's long-row mode mirrors the segments and the groups (orc.set_long_row(threshold, segment, group)).
-constexpr int MIK_LONG_SEG = 2048;
+constexpr int MIK_LONG_SEG = 1024;
 
 // Tables of the long-row part (device, built at upload).  `rows[w]` >= 0: virtual row w is a whole row, its sum goes to
 // y[rows[w]]; < 0: it is segment -(rows[w] + 1) of a cut row.
@@ -164,9 +164,13 @@ __device__ __forceinline__ void spmv_longrow_wave(int w, const LongTab &lt, cons
     const int k0 = lt.starts[w], len = lt.lens[w];      // k0 is a multiple of 4: 16-byte aligned streams
     const int ng = (len + G - 1) / G;                   // groups of this virtual row (the last one padded in storage)
     const int npass = (ng + 64 * U - 1) / (64 * U);
-    mik_i32x4 cA[U], cB[U];
-    LongVal<T> vA[U], vB[U];
-    auto stream = [&](int p, mik_i32x4(&cc)[U], LongVal<T>(&vv)[U]) {
+    // One pass = 64 U groups = 1024 entries at fp32 (512 at fp64): a whole default segment.  All of a pass's streams are issued, then all
+    // of its gathers; nothing is carried from pass to pass but the accumulator -- 48 vector registers, eight waves per SIMD (the double-
+    // buffered two-pass form of a 2048-entry segment needed ~100 registers: four waves per SIMD, 1,775 workgroups in two rounds, 42 us).
+    T acc = T(0);
+    for (int p = 0; p < npass; ++p) {
+        mik_i32x4 cc[U];
+        LongVal<T> vv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int g = lane + 64 * (U * p + u);
@@ -174,26 +178,19 @@ __device__ __forceinline__ void spmv_longrow_wave(int w, const LongTab &lt, cons
             cc[u] = __builtin_nontemporal_load(reinterpret_cast<const mik_i32x4 *>(col + k0 + G * gg));
             vv[u].load(val + k0 + G * gg);
         }
-    };
-    T acc = T(0);
-    stream(0, cA, vA);
-    for (int p = 0; p < npass; ++p) {
-        if (p + 1 < npass) stream(p + 1, cB, vB);       // the next pass's streams go out ahead of this pass's gathers
         T xv[U][G];
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int e = 0; e < G; ++e) xv[u][e] = x[cA[u][e]];
+            for (int e = 0; e < G; ++e) xv[u][e] = x[cc[u][e]];
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int e = 0; e < G; ++e) {               // this lane's entries of the pass, ascending
-                const T prod = vA[u].get(e) * xv[u][e];
+                const T prod = vv[u].get(e) * xv[u][e];
                 const T s = acc + prod;
                 acc = G * (lane + 64 * (U * p + u)) + e < len ? s : acc;
             }
-#pragma unroll
-        for (int u = 0; u < U; ++u) { cA[u] = cB[u]; vA[u] = vB[u]; }
     }
     acc = wave_tree(acc);
     if (lane == 0) longrow_store<T>(lt, w, acc, y);
@@ -220,19 +217,28 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_longrows(LongTab lt, const i
 // window table is built at upload (csr_build_xwin: enabled when the row-blocks holding three quarters of the entries span at most
 // 32 KB of x each; a block that spans more -- rows that wrap around the matrix -- carries win_lo < 0 and gathers from memory);
 // same products, same order, same bits.
-template <typename T, bool FUSE_DOT, bool NT, bool WIDE, bool MERGE_LONG, bool XWIN = false>
+//
+// RPERM (round 4): rows of very different lengths share a wave -- 64 lanes run the serial sum of the LONGEST of their rows: with 10 %
+// of the rows at 50-200 entries among rows of 5-15, every wave of the banded configs[4] stand-in spent ~20 loop trips where its
+// median row needs 2, and the kernel was bound by vector-ALU issue (20 M wave-instructions per launch, 35 us of the 64 us of the short
+// part; profiles/r04_c5_banded_pmc_summary.txt).  rperm[r0 + t] (one byte per row, built at upload) gives thread t of a row-block the
+// row whose length has rank t among the block's 256 -- the 64 longest rows meet in one wave (wave rb & 3, so the heavy waves spread
+// over the four SIMDs), the other three finish after two trips.  Which thread sums a row never shows in the result; the fused dot
+// puts x[r] * y[r] back into row order (through LDS) before the block tree, whose shape is defined over rows.
+template <typename T, bool FUSE_DOT, bool NT, bool WIDE, bool MERGE_LONG, bool XWIN = false, bool RPERM = false>
 __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int map_mode, const int *__restrict__ rowptr,
                                                              const int *__restrict__ col, const T *__restrict__ val,
                                                              const T *__restrict__ x, T *__restrict__ y,
                                                              T *__restrict__ seg_out, const int *__restrict__ done,
                                                              const unsigned char *__restrict__ is_long, int nlb, LongTab lt,
-                                                             const int *__restrict__ win_lo = nullptr, int win_span = 0)
+                                                             const int *__restrict__ win_lo = nullptr, int win_span = 0,
+                                                             const unsigned char *__restrict__ rperm = nullptr)
 {
     if (done && *done) return;
     constexpr int TILE = MIK_SPMV_TILE * (int)(8 / sizeof(T));   // 16 KB of LDS: 2048 fp64 / 4096 fp32 products
     constexpr int VW = WIDE ? VT<T>::W : 1;            // elements per lane per load
     constexpr int PER = TILE / (MIK_BLOCK * VW);       // loads per lane per tile
-    __shared__ __attribute__((aligned(16))) T prod[TILE];
+    __shared__ __attribute__((aligned(16))) T prod[TILE + 8];    // + 8: the row sums read whole groups of 8 (the surplus is never added)
     __shared__ T lds4[4];
     extern __shared__ __attribute__((aligned(16))) unsigned char mik_dyn_lds[];   // XWIN: win_span elements of x
 
@@ -247,7 +253,8 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
     }
     const int rb = spmv_block_map(bid, nb, map_mode);
     const int r0 = rb * MIK_BLOCK;
-    const int r = r0 + t;
+    const int tr = RPERM ? (int)rperm[r0 + t] : t;     // the row of this thread inside the block (rperm is padded to whole blocks)
+    const int r = r0 + tr;
     int ks = 0, ke = 0;
     if (r < n) { ks = rowptr[r]; ke = rowptr[r + 1]; }
     const int kb = rowptr[r0] & ~(VW - 1);             // tile start aligned for the wide loads
@@ -327,18 +334,25 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
             }
         }
         __syncthreads();
-        // ---- per-row serial sum, ascending column order ----
+        // ---- per-row serial sum, ascending column order: whole groups of 8 without a test, then the rest ----
         int a = max(ks, kc) - kc;
         int len = min(ke, kc + cnt) - kc - a;
-        while (len > 0) {
+        for (; len >= 8; len -= 8, a += 8) {
             T q[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) q[i] = prod[min(a + i, TILE - 1)];
+            for (int i = 0; i < 8; ++i) q[i] = prod[a + i];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (i < len) acc = acc + q[i];
-            a += 8;
-            len -= 8;
+            for (int i = 0; i < 8; ++i) acc = acc + q[i];
+        }
+        if (len > 0) {
+            T q[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[i] = prod[a + i];          // may run past the row (and, by up to 7, past the tile): never added
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const T s2 = acc + q[i];
+                acc = i < len ? s2 : acc;
+            }
         }
         __syncthreads();
     }
@@ -347,6 +361,11 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
     if (FUSE_DOT) {
         T p = T(0);
         if (r < n) p = x[r] * acc;
+        if (RPERM) {                                   // back into row order: thread t of the block tree holds row r0 + t
+            prod[tr] = p;
+            __syncthreads();
+            p = prod[t];
+        }
         T tot = block_tree_256(p, lds4);
         if (t == 0) seg_out[rb] = tot;
     }

@@ -812,6 +812,11 @@ int mik_build_xwin_device(mik_ctx *ctx, mik_csr *A)
     if (!A->rowptr || A->n_long || A->sdia_val || A->sdia_pats || A->sdiaw_pats || A->jds_val || A->nnz <= 0 || A->n_rows <= 0 || ctx->tuning[8] != 0 ||
         ctx->tuning[29] == 1 || A->max_row_nnz <= 32)
         return MIK_OK;
+    {   // the row permutation of the product tile (irregular rows): from a host copy of the row pointer (4 B per row, once)
+        std::vector<int> rp((size_t)A->n_rows + 1);
+        MIK_HIP(ctx, hipMemcpy(rp.data(), A->rowptr, sizeof(int) * rp.size(), hipMemcpyDeviceToHost));
+        MIK_TRY(mik_build_rperm_host(ctx, A, rp.data()));
+    }
     const int64_t nb = (A->n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
     int *d = nullptr;
     MIK_HIP(ctx, hipMalloc((void **)&d, sizeof(int) * 3 * (size_t)nb));

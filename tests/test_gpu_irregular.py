@@ -116,7 +116,8 @@ def banded_irregular(n, dtype, halfwidth, seed=3, long_every=0):
 def test_x_window_in_lds_bit_exact(pkg, orc, ctx, dtype, long_every):
     """irregular rows inside a band -- the product-tile kernel serves x from an LDS window per 256-row block
     (k_spmv_rowblock XWIN, csr_build_xwin): same products, same order, same bits as the oracle, with the windows (default), with
-    the windows built but not used (development knob 29 = 2) and never built (29 = 1); plain SpMV (long rows merged into the launch)
+    the windows and the by-length row permutation of a block's threads (RPERM) built but not used (development knob 29 = 2) and
+    never built (29 = 1); plain SpMV (long rows merged into the launch)
     and the fused-dot launches of a CG step; one-sided bands at both ends of the matrix (the last window slides down)."""
     n = 9000
     rowptr, cols, val = banded_irregular(n, dtype, 700, long_every=long_every)
@@ -126,7 +127,8 @@ def test_x_window_in_lds_bit_exact(pkg, orc, ctx, dtype, long_every):
     b = orc.hashed_rhs(n).astype(dtype)
     xo, ho = orc.cg(Ao, b, maxiter=3, mode="tree", shape=ctx.cg_shape(dtype))
     L = pkg.lib()
-    for knob, kern in ((0, "k_spmv_rowblock+xwin"), (2, "k_spmv_rowblock"), (1, "k_spmv_rowblock")):
+    # knob 29 = 1: neither windows nor the row permutation are built -- without long rows the operator is then back on the LDS-DMA tile
+    for knob, kern in ((0, "k_spmv_rowblock+xwin"), (2, "k_spmv_rowblock"), (1, "k_spmv_rowblock" if long_every else "k_spmv_rowgather")):
         L.mik_set_tuning(29, knob)
         try:
             A = pkg.HipCSR(n, n, rowptr, cols, val, index_base=0, is_csc=False)
