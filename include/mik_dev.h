@@ -14,7 +14,8 @@
 extern "C" {
 #endif
 /* key / value table (all default to 0; results never depend on them):
- *   0: 1 = cached (temporal) val/col/y streams in SpMV            1: 1 = narrow loads in the CSR kernel
+ *   0: 1 = cached (temporal) val/col/y streams in SpMV, 2 = streamed also where the default is cached (the irregular product tile)
+ *              1: 1 = narrow loads in the CSR kernel
  *   2: workgroup map: 0 = operator's choice, < 0 identity, 1 = contiguous range per XCD, P >= 8 = strips of P
  *   3: 1 = hipStreamSynchronize instead of the event spin wait    4: long-row threshold (> 0), < 0 = no split
  *   5: 1 = unfused MGS chain, 2 = launch-lean MGS without graphs, 3 = one hipGraph per GMRES column

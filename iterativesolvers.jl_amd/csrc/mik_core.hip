@@ -1071,7 +1071,19 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
                     seg_row.push_back((int)cut_row.size() - 1);
                 }
             }
-            long_rows.swap(vr); long_start.swap(vs); long_len.swap(vl);
+            // List order = order of the waves (4 per workgroup): by the FIRST COLUMN of the virtual row.  The gathers of a long row are
+            // what its time goes into -- a 128-byte line of x fetched from L2 for the ~4 entries the row has in it, 400 MB of L2 -> L1
+            // traffic for the 100 MB of operator streams of the banded configs[4] stand-in, and that traffic (not the texture path,
+            // not HBM) is the bound: the long part ran at the same ~10 TB/s of L2 -> L1 bandwidth alone and merged into the row-block
+            // launch (profiles/r04_c5_banded_*).  Long rows that are neighbours in the matrix reference almost the same columns; with the
+            // list sorted by first column the four waves of a workgroup walk the SAME 32 KB of x side by side, and three of them hit
+            // in L1.  (Sorting is a pure scheduling matter: every virtual row keeps its shape, the segment sums their order.)
+            std::vector<int> ord(vr.size());
+            for (size_t q = 0; q < ord.size(); ++q) ord[q] = (int)q;
+            if (ctx->tuning[2] >= 0)    // development knob 2 < 0 (identity block map) also keeps the (row, segment) order
+                std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return col[(size_t)vs[(size_t)a]] < col[(size_t)vs[(size_t)b]]; });
+            long_rows.resize(vr.size()); long_start.resize(vr.size()); long_len.resize(vr.size());
+            for (size_t q = 0; q < ord.size(); ++q) { long_rows[q] = vr[(size_t)ord[q]]; long_start[q] = vs[(size_t)ord[q]]; long_len[q] = vl[(size_t)ord[q]]; }
         }
     }
     const int64_t nnz_store = (int64_t)col.size();                     // entries physically stored (>= nnz when re-laid out)
@@ -1133,6 +1145,34 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
     if (rc_layout == MIK_OK) rc_layout = csr_build_jds(ctx, A, rowptr, col, v, es, n_rows, is_long.empty() ? nullptr : is_long.data());
     if (rc_layout == MIK_OK) rc_layout = csr_build_xwin(ctx, A, rowptr, col, es, n_rows, n_cols, max_row);
     if (rc_layout == MIK_OK) rc_layout = mik_build_rperm_host(ctx, A, rowptr.data());
+    if (rc_layout == MIK_OK && A->n_long && ctx->tuning[29] != 1 && !A->jds_val) {
+        // windows of x for the long-row workgroups (csrc/mik_spmv.h, spmv_long_window): workgroup g sums virtual rows 4 g .. 4 g + 3 of the
+        // list (sorted by first column); its window starts at their smallest first column and is as long as the LDS of a row-block
+        // workgroup ([product tile][wave sums][x window of the short rows]); -1 where less than about half of the workgroup's columns fit
+        const int TILE = MIK_SPMV_TILE * (int)(8 / es), XP = (int)(1024 / es), W = (int)(16 / es);
+        const int64_t LW = (int64_t)((size_t)(TILE + 12 + A->xwin_span) * es / 1024) * XP;
+        if (LW > 0 && n_cols >= LW + W) {
+            const size_t nwg = (long_rows.size() + 3) / 4;
+            std::vector<int> lwin(nwg, -1);
+            for (size_t g2 = 0; g2 < nwg; ++g2) {
+                int64_t lo = INT64_MAX, hi = -1;
+                for (size_t q = 4 * g2; q < std::min(4 * g2 + 4, long_rows.size()); ++q) {
+                    lo = std::min<int64_t>(lo, col[(size_t)long_start[q]]);
+                    hi = std::max<int64_t>(hi, col[(size_t)long_start[q] + (size_t)long_len[q] - 1]);
+                }
+                lo &= ~(int64_t)(W - 1);
+                if (lo + LW > n_cols) lo = (n_cols - LW) & ~(int64_t)(W - 1);
+                if (hi - lo < 2 * LW) lwin[g2] = (int)lo;
+            }
+            hipError_t e2;
+            if ((e2 = hipMalloc((void **)&A->long_win, sizeof(int) * nwg)) != hipSuccess ||
+                (e2 = hipMemcpy(A->long_win, lwin.data(), sizeof(int) * nwg, hipMemcpyHostToDevice)) != hipSuccess) {
+                cleanup();
+                return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create: long-row windows: %s", hipGetErrorString(e2));
+            }
+            A->long_lw = (int)LW;
+        }
+    }
     if (rc_layout == MIK_OK) rc_layout = sdiaw_chunk_bits(ctx, A);
     if (rc_layout != MIK_OK) { cleanup(); return rc_layout; }
     *out = A;
@@ -1163,6 +1203,7 @@ extern "C" int mik_csr_destroy(mik_csr *A)
     if (A->sdiaw_uz) (void)hipFree(A->sdiaw_uz);
     if (A->xwin_lo) (void)hipFree(A->xwin_lo);
     if (A->rperm) (void)hipFree(A->rperm);
+    if (A->long_win) (void)hipFree(A->long_win);
     if (A->jds_ptr) (void)hipFree(A->jds_ptr);
     if (A->jds_len) (void)hipFree(A->jds_len);
     if (A->jds_col) (void)hipFree(A->jds_col);
@@ -1453,6 +1494,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         lt.seg_sum = A->seg_sum; lt.nlong = nlong;
     }
     const int nlb = (nlong + 3) / 4;                    // one wave per virtual row (a whole row or a segment of a cut row)
+    const int *lwin = (A->long_win && ctx->tuning[29] == 0 && mik_aligned16(x)) ? A->long_win : nullptr;   // the long-row workgroups' windows of x in LDS
     if (choice == 1) {
         // jagged slices (mik_jds.h): one row per lane, 16-byte operator streams; the workgroups of split-off long rows lead the same
         // launch.  dot(x, y) is formed inside unless long rows exist (their sums arrive from other workgroups): then by k_rowdot.
@@ -1484,7 +1526,8 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
     // 1 = always k_spmv_rowblock, 2 = always k_spmv_rowgather.  Same results bit for bit (tests/test_gpu_layouts.py).
     if (spmv_csr_rowgather(A)) {
         if (nlong) {   // long rows first (whole launches only, see mik_spmv_can_split); the row kernel then picks y[r] up
-            hipLaunchKernelGGL((k_spmv_longrows<T>), dim3(nlb), dim3(MIK_BLOCK), 0, ctx->stream, lt, A->col, (const T *)A->val, x, y, done);
+            hipLaunchKernelGGL((k_spmv_longrows<T>), dim3(nlb), dim3(MIK_BLOCK), lwin ? sizeof(T) * (size_t)A->long_lw : 0, ctx->stream, lt, A->col, (const T *)A->val, x, y, done,
+                               lwin, A->long_lw);
             MIK_LAUNCH_CHECK(ctx);
         }
 #define MIK_RG_GO(FD, NTV)                                                                                                      \
@@ -1496,20 +1539,28 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     }
-    const bool merge = nlong > 0 && !fuse_dot;           // one launch: long-row workgroups first, then row-blocks
+    const bool merge = nlong > 0 && !fuse_dot;           // one launch: long-row workgroups spread over the row-blocks
+    // The operator streams of the product tile are read with the DEFAULT cache policy when the operator is irregular (long rows, a row
+    // permutation, x windows): non-temporal streams, right for the stencil operators, cost this kernel 10-15 % (banded configs[4] stand-
+    // in: 85.8 us streamed, 74.6 us cached; random 195.5 / 190.2 -- profiles/r04_c5_*).  Development knob 0: 1 = cached, 2 = streamed.
+    const bool nt_rb = ctx->tuning[0] == 2 || (ctx->tuning[0] == 0 && !(nlong || A->rperm || A->xwin_lo));
     if (nlong && !merge) {
         // fused dot: long rows first in their own launch, the row-block kernel then picks y[r] up
-        hipLaunchKernelGGL((k_spmv_longrows<T>), dim3(nlb), dim3(MIK_BLOCK), 0, ctx->stream, lt, A->col, (const T *)A->val, x, y, done);
+        hipLaunchKernelGGL((k_spmv_longrows<T>), dim3(nlb), dim3(MIK_BLOCK), lwin ? sizeof(T) * (size_t)A->long_lw : 0, ctx->stream, lt, A->col, (const T *)A->val, x, y, done,
+                           lwin, A->long_lw);
         MIK_LAUNCH_CHECK(ctx);
     }
     const dim3 grid(nb + (merge ? nlb : 0)), block(MIK_BLOCK);
     // x served from an LDS window per row-block (csr_build_xwin; development knob 29 = 2: off at launch) -- wide loads and an aligned x only
     const bool xwin = A->xwin_lo && wide && ctx->tuning[29] == 0 && mik_aligned16(x);
-    const size_t dyn = xwin ? sizeof(T) * (size_t)A->xwin_span : 0;
+    constexpr int RB_TILE = MIK_SPMV_TILE * (int)(8 / sizeof(T));
+    const size_t dyn = sizeof(T) * ((size_t)RB_TILE + 12 + (xwin ? (size_t)A->xwin_span : 0));          // [product tile + 8][4 wave sums][x window]
+    const int lw_launch = (int)std::min<size_t>((size_t)A->long_lw, dyn / 1024 * (1024 / sizeof(T)));  // what a long-row workgroup of this launch can hold
     const bool rp = A->rperm && wide && ctx->tuning[29] == 0;         // rows of a block over its threads by length (mik_build_rperm_host)
 #define MIK_SPMV_GO(FD, NT, WD, MG, XW, RP)                                                                      \
-    hipLaunchKernelGGL((k_spmv_rowblock<T, FD, NT, WD, MG, XW, RP>), grid, block, XW ? dyn : 0, ctx->stream, n, nb, map_mode, A->rowptr, \
-                       A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, nlb, lt, (const int *)A->xwin_lo, A->xwin_span, (const unsigned char *)A->rperm)
+    hipLaunchKernelGGL((k_spmv_rowblock<T, FD, NT, WD, MG, XW, RP>), grid, block, dyn, ctx->stream, n, nb, map_mode, A->rowptr, \
+                       A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, nlb, lt, (const int *)A->xwin_lo, A->xwin_span, (const unsigned char *)A->rperm, \
+                       MG ? lwin : (const int *)nullptr, lw_launch)
 #define MIK_SPMV_GO3(FD, NT, MG)                                                          \
     do {                                                                                  \
         if (xwin) { if (rp) MIK_SPMV_GO(FD, NT, true, MG, true, true); else MIK_SPMV_GO(FD, NT, true, MG, true, false); }   \
@@ -1517,7 +1568,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         else if (wide) MIK_SPMV_GO(FD, NT, true, MG, false, false);                       \
         else MIK_SPMV_GO(FD, NT, false, MG, false, false);                                \
     } while (0)
-#define MIK_SPMV_GO2(FD, MG) do { if (nt) MIK_SPMV_GO3(FD, true, MG); else MIK_SPMV_GO3(FD, false, MG); } while (0)
+#define MIK_SPMV_GO2(FD, MG) do { if (nt_rb) MIK_SPMV_GO3(FD, true, MG); else MIK_SPMV_GO3(FD, false, MG); } while (0)
     if (fuse_dot) MIK_SPMV_GO2(true, false);
     else if (merge) MIK_SPMV_GO2(false, true);
     else MIK_SPMV_GO2(false, false);

@@ -113,24 +113,39 @@ struct LongTab {
     int nlong;
 };
 
+// the sum of virtual row w (in lane 0) to its place; called by the WHOLE wave
 template <typename T> __device__ __forceinline__ void longrow_store(const LongTab &lt, int w, T acc, T *__restrict__ y)
 {
-    const int tgt = lt.rows[w];
-    if (tgt >= 0) { y[tgt] = acc; return; }
+    const int lane = threadIdx.x & 63;
+    const int tgt = lt.rows[w];                         // wave-uniform
+    if (tgt >= 0) { if (lane == 0) y[tgt] = acc; return; }
     const int sg = -tgt - 1;
     T *ss = (T *)lt.seg_sum;
+    const int h = lt.seg_row[sg];
+    const int ns = lt.cut_nseg[h];
     // Hand-off without cache-wide fences (an acq_rel ticket costs a buffer_wbl2 + buffer_inv per segment: measured 402 us
     // instead of 196 us for the whole SpMV): the segment sum is ONE write-through (sc1) store, drained before the ticket
-    // is taken; the wave that takes the last ticket reads the sums back with sc1 loads, which are served past its L1.
-    __hip_atomic_store(&ss[sg], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int h = lt.seg_row[sg];
-    const unsigned tk = __hip_atomic_fetch_add(&lt.tickets[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int ns = lt.cut_nseg[h];
-    if (tk == (unsigned)ns - 1u) {
-        const int f = lt.cut_first[h];
-        T t = __hip_atomic_load(&ss[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int q = 1; q < ns; ++q) t = t + __hip_atomic_load(&ss[f + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // is taken; the wave that takes the last ticket reads the sums back with sc1 loads, which are served past its L1 --
+    // 64 of them at a time, one per lane (a 20,000-entry row has 20 segments: one round trip instead of 20 dependent ones),
+    // and adds them left to right.
+    int last = 0;
+    if (lane == 0) {
+        __hip_atomic_store(&ss[sg], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tk = __hip_atomic_fetch_add(&lt.tickets[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = tk == (unsigned)ns - 1u ? 1 : 0;
+    }
+    last = __shfl(last, 0);
+    if (!last) return;
+    const int f = lt.cut_first[h];
+    T t = T(0);
+    for (int q0 = 0; q0 < ns; q0 += 64) {
+        const int m = min(64, ns - q0);
+        T v = T(0);
+        if (lane < m) v = __hip_atomic_load(&ss[f + q0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < m; ++q) { const T vq = __shfl(v, q); t = (q0 + q == 0) ? vq : t + vq; }
+    }
+    if (lane == 0) {
         __hip_atomic_store(&lt.tickets[h], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         y[lt.cut_row[h]] = t;
     }
@@ -154,9 +169,14 @@ template <> struct LongVal<double> {
 };
 
 // wave w of the long part: virtual row w (a whole row of at most one segment, or one segment of a cut row)
+//
+// xw / wlo / wlen (round 4): the workgroup's WINDOW of x in LDS.  The list of virtual rows is sorted by first column (mik_csr_create),
+// so the four waves of a workgroup gather from nearly the same stretch of x: the workgroup copies x[wlo .. wlo + wlen) into LDS once
+// (LDS-DMA, spmv_long_window) and a gather inside it is a ds_read -- a line of x then crosses L2 -> L1 once per workgroup instead of
+// once per wave and 128 bytes at a time for 16 useful ones; a column outside the window is gathered from memory as before.
 template <typename T>
 __device__ __forceinline__ void spmv_longrow_wave(int w, const LongTab &lt, const int *__restrict__ col, const T *__restrict__ val,
-                                                  const T *__restrict__ x, T *__restrict__ y)
+                                                  const T *__restrict__ x, T *__restrict__ y, const T *xw = nullptr, int wlo = 0, int wlen = 0)
 {
     if (w >= lt.nlong) return;                          // wave-uniform
     constexpr int G = MIK_LONG_G, U = sizeof(T) == 8 ? 2 : 4;   // groups per lane and pass (fp64 carries twice the value registers)
@@ -182,7 +202,11 @@ __device__ __forceinline__ void spmv_longrow_wave(int w, const LongTab &lt, cons
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int e = 0; e < G; ++e) xv[u][e] = x[cc[u][e]];
+            for (int e = 0; e < G; ++e) {
+                const int c = cc[u][e];
+                const unsigned o = (unsigned)(c - wlo);
+                xv[u][e] = o < (unsigned)wlen ? xw[o] : x[c];       // wlen = 0: no window
+            }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -193,16 +217,48 @@ __device__ __forceinline__ void spmv_longrow_wave(int w, const LongTab &lt, cons
             }
     }
     acc = wave_tree(acc);
-    if (lane == 0) longrow_store<T>(lt, w, acc, y);
+    longrow_store<T>(lt, w, acc, y);
 }
 
+// MERGE_LONG launches: nlb long-row workgroups spread EVENLY over the nb row-block workgroups of the same launch.  The long rows are
+// bound by the texture path (their gathers), the row-blocks by the operator streams (and LDS): run side by side they overlap;
+// run one after the other -- all long-row workgroups in front, as until round 4 -- the launch costs the SUM of the two (banded
+// configs[4] stand-in: long part 42-55 us + short part 49 us = 91.5 us merged, profiles/r04_c5_banded_*).
+// Returns true and the long-row workgroup index in `which`, or false and the row-block workgroup index.
+__device__ __forceinline__ bool spmv_merge_slot(unsigned bid, unsigned total, unsigned nlb, unsigned &which)
+{
+    const unsigned before = (unsigned)(((unsigned long long)bid * nlb + total - 1) / total);            // long-row workgroups in front of this one
+    const unsigned upto = (unsigned)(((unsigned long long)(bid + 1) * nlb + total - 1) / total);
+    if (upto > before) { which = before; return true; }
+    which = bid - before;
+    return false;
+}
+
+// x[wlo .. wlo + wlen) -> LDS at `xw` by LDS-DMA, 1-KiB pieces dealt to the four waves; workgroup-uniform; ends with a barrier
+template <typename T> __device__ __forceinline__ void spmv_long_window(const T *__restrict__ x, T *xw, int wlo, int wlen)
+{
+    constexpr int XP = 1024 / (int)sizeof(T);
+    const int t = threadIdx.x;
+    for (int piece = t >> 6; piece * XP < wlen; piece += MIK_BLOCK / 64)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x + wlo + piece * XP + (t & 63) * (16 / (int)sizeof(T))),
+                                         (__attribute__((address_space(3))) void *)(xw + piece * XP), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// long_win[workgroup] = first element of the workgroup's window of x (16-byte aligned, inside x) or -1; lw = its length (whole 1-KiB pieces)
 template <typename T>
 __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_longrows(LongTab lt, const int *__restrict__ col, const T *__restrict__ val,
-                                                             const T *__restrict__ x, T *__restrict__ y, const int *__restrict__ done)
+                                                             const T *__restrict__ x, T *__restrict__ y, const int *__restrict__ done,
+                                                             const int *__restrict__ long_win, int lw)
 {
     if (done && *done) return;
-    const int wv = blockIdx.x * (MIK_BLOCK / 64) + (threadIdx.x >> 6);     // whole waves work alone: no block-level barrier
-    spmv_longrow_wave<T>(wv, lt, col, val, x, y);
+    extern __shared__ __attribute__((aligned(16))) unsigned char mik_dyn_lds[];
+    T *xw = reinterpret_cast<T *>(mik_dyn_lds);
+    const int wlo = long_win ? long_win[blockIdx.x] : -1;
+    if (wlo >= 0) spmv_long_window<T>(x, xw, wlo, lw);
+    const int wv = blockIdx.x * (MIK_BLOCK / 64) + (threadIdx.x >> 6);     // after the window, whole waves work alone
+    spmv_longrow_wave<T>(wv, lt, col, val, x, y, xw, wlo >= 0 ? wlo : 0, wlo >= 0 ? lw : 0);
 }
 
 // MERGE_LONG: the first `nlb` workgroups of the launch are long-row workgroups (4 virtual rows each,
@@ -232,24 +288,30 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
                                                              T *__restrict__ seg_out, const int *__restrict__ done,
                                                              const unsigned char *__restrict__ is_long, int nlb, LongTab lt,
                                                              const int *__restrict__ win_lo = nullptr, int win_span = 0,
-                                                             const unsigned char *__restrict__ rperm = nullptr)
+                                                             const unsigned char *__restrict__ rperm = nullptr,
+                                                             const int *__restrict__ long_win = nullptr, int lw = 0)
 {
     if (done && *done) return;
     constexpr int TILE = MIK_SPMV_TILE * (int)(8 / sizeof(T));   // 16 KB of LDS: 2048 fp64 / 4096 fp32 products
     constexpr int VW = WIDE ? VT<T>::W : 1;            // elements per lane per load
     constexpr int PER = TILE / (MIK_BLOCK * VW);       // loads per lane per tile
-    __shared__ __attribute__((aligned(16))) T prod[TILE + 8];    // + 8: the row sums read whole groups of 8 (the surplus is never added)
-    __shared__ T lds4[4];
-    extern __shared__ __attribute__((aligned(16))) unsigned char mik_dyn_lds[];   // XWIN: win_span elements of x
+    // all LDS of this kernel is dynamic (mik_spmv_rowblock_lds): [prod: TILE + 8][4 wave sums, padded to 16 B][XWIN: win_span elements of x];
+    // a long-row workgroup of a MERGE_LONG launch uses the whole of it as ITS window of x
+    extern __shared__ __attribute__((aligned(16))) unsigned char mik_dyn_lds[];
+    T *prod = reinterpret_cast<T *>(mik_dyn_lds);      // + 8: the row sums read whole groups of 8 (the surplus is never added)
+    T *lds4 = prod + TILE + 8;
 
     const int t = threadIdx.x;
     int bid = blockIdx.x;
     if (MERGE_LONG) {
-        if (bid < nlb) {
-            spmv_longrow_wave<T>(bid * (MIK_BLOCK / 64) + (t >> 6), lt, col, val, x, y);
+        unsigned which;
+        if (spmv_merge_slot((unsigned)bid, gridDim.x, (unsigned)nlb, which)) {
+            const int lwlo = long_win ? long_win[which] : -1;
+            if (lwlo >= 0) spmv_long_window<T>(x, prod, lwlo, lw);
+            spmv_longrow_wave<T>((int)which * (MIK_BLOCK / 64) + (t >> 6), lt, col, val, x, y, prod, lwlo >= 0 ? lwlo : 0, lwlo >= 0 ? lw : 0);
             return;
         }
-        bid -= nlb;
+        bid = (int)which;
     }
     const int rb = spmv_block_map(bid, nb, map_mode);
     const int r0 = rb * MIK_BLOCK;
@@ -259,7 +321,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
     if (r < n) { ks = rowptr[r]; ke = rowptr[r + 1]; }
     const int kb = rowptr[r0] & ~(VW - 1);             // tile start aligned for the wide loads
     const int kend = rowptr[min(r0 + MIK_BLOCK, n)];
-    T *xw = reinterpret_cast<T *>(mik_dyn_lds);
+    T *xw = lds4 + 16 / (int)sizeof(T) * ((4 * (int)sizeof(T) + 15) / 16);     // behind the wave sums, 16-byte aligned
     int wlo = 0;
     if (XWIN) {
         // the row-block's window of x -> LDS: wave wv issues the 1-KiB pieces wv, wv + 4, ... (win_span is a multiple of a piece;

@@ -64,7 +64,7 @@ def test_cut_rows_segment_sums(pkg, orc, ctx, dtype, segment):
     L.mik_set_tuning(15, segment)
     try:
         seg = ctx.spmv_long_segment()
-        assert seg == (segment or 2048)
+        assert seg == (segment or 1024)
         orc.set_long_row(ctx.spmv_long_row(), seg, ctx.spmv_long_group())
         rng = np.random.default_rng(9)
         n = 12000
