@@ -93,7 +93,10 @@ constexpr int NCCL_F32 = 7, NCCL_F64 = 8;   // ncclFloat32 / ncclFloat64 (rccl.h
 // into MIK_ERR_HIP on the host instead of a hung queue.
 constexpr int MIK_MAIL_MAXP = 64;
 constexpr int MIK_MAIL_KINDS = 3;        // 0: dot(u, c)   1: |r|^2   2: every other gather (initial residual, the scaled-norm stages)
-struct MailSlot { unsigned long long bits, seq; };
+// a scalar in flight: two 8-byte words, each {low 32 bits of the sequence number, half of the value's bits} -- every word is ONE atomic
+// store, so the two need no ordering between them (no release fence, i.e. no L2 write-back, in the finalising kernels): the reader
+// takes the value once BOTH words carry the sequence number it waits for
+struct MailSlot { unsigned long long w0, w1; };
 struct MailBox {
     MailSlot slot[MIK_MAIL_KINDS][2][MIK_MAIL_MAXP];    // [kind][seq & 1][sender]
     unsigned long long halo_seq[MIK_MAIL_MAXP];          // [sender]: its halo of exchange no. halo_seq[sender] has landed in this rank's ghost region
@@ -136,14 +139,15 @@ template <typename T> __device__ __forceinline__ T mail_value(unsigned long long
     return (T)__builtin_bit_cast(float, (unsigned)b);
 }
 
-// wait until *p >= want (system scope); false after `ticks` of the wall clock
+// wait until *p >= want; false after `ticks` of the wall clock.  Relaxed system-scope loads: what the flag guards is read by the NEXT
+// kernel on the stream, whose start is the acquire (an acquire per poll would invalidate this XCD's L2 again and again)
 __device__ __forceinline__ bool mail_wait(const unsigned long long *p, unsigned long long want, unsigned long long ticks)
 {
     const unsigned long long t0 = wall_clock64();
     for (unsigned spins = 0;; ++spins) {
-        if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return true;
+        if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return true;
         if ((spins & 255u) == 255u && wall_clock64() - t0 > ticks) return false;
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(1);
     }
 }
 
@@ -154,12 +158,21 @@ __device__ __forceinline__ T mail_exchange(MailBox *const *__restrict__ peers, i
 {
     const int q = threadIdx.x & 63;
     if (q >= P) return T(0);
+    const unsigned long long tag = (seq & 0xFFFFFFFFull) << 32, b = mail_bits<T>(mine);
     MailSlot *dst = &peers[q]->slot[kind][seq & 1ull][rank];
-    __hip_atomic_store(&dst->bits, mail_bits<T>(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&dst->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&dst->w0, tag | (b & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&dst->w1, tag | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const MailSlot *src = &peers[rank]->slot[kind][seq & 1ull][q];
-    if (!mail_wait(&src->seq, seq, ticks)) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const T v = mail_value<T>(__hip_atomic_load(&src->bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    unsigned long long a0 = 0, a1 = 0;
+    const unsigned long long t0 = wall_clock64();
+    for (unsigned spins = 0;; ++spins) {
+        a0 = __hip_atomic_load(&src->w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        a1 = __hip_atomic_load(&src->w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((a0 >> 32 << 32) == tag && (a1 >> 32 << 32) == tag) break;
+        if ((spins & 255u) == 255u && wall_clock64() - t0 > ticks) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    const T v = mail_value<T>((a0 & 0xFFFFFFFFull) | (a1 << 32));
     all[q] = v;
     return v;
 }
@@ -224,9 +237,11 @@ __global__ __launch_bounds__(64) void k_cgd_fin_rr_mail(const T *__restrict__ S,
     if (threadIdx.x == 0) cgd_close_step<T>(d, sum, hist, it_next, maxiter, mirror, step_seq, hist_index, fuse_x);
 }
 
+// behind a kernel on the same stream: the kernel boundary orders that kernel's writes before the flag (no release fence: it would write
+// this XCD's L2 back, ~4 us on the compute stream)
 __global__ void k_mail_mark(unsigned long long *flag, unsigned long long v)
 {
-    __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void k_mail_wait_flag(const unsigned long long *flag, unsigned long long want, unsigned long long ticks, unsigned *err)
@@ -254,10 +269,16 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_halo_push(const T *__restrict__ s
         const long long cnt = sg.cnt[i];
         const bool wide = ((((size_t)src) | ((size_t)dst)) & 15) == 0;
         if (wide) {
-            const long long nv = cnt / W;
-            for (long long j = (long long)blockIdx.x * MIK_BLOCK + threadIdx.x; j < nv; j += (long long)gridDim.x * MIK_BLOCK)
-                reinterpret_cast<uint4 *>(dst)[j] = reinterpret_cast<const uint4 *>(src)[j];
-            for (long long j = nv * W + (long long)blockIdx.x * MIK_BLOCK + threadIdx.x; j < cnt; j += (long long)gridDim.x * MIK_BLOCK) dst[j] = src[j];
+            const long long nv = cnt / W, stride = (long long)gridDim.x * MIK_BLOCK;
+            long long j = (long long)blockIdx.x * MIK_BLOCK + threadIdx.x;
+            for (; j + 3 * stride < nv; j += 4 * stride) {          // four independent 16-byte copies in flight per lane
+                const uint4 a = reinterpret_cast<const uint4 *>(src)[j], b2 = reinterpret_cast<const uint4 *>(src)[j + stride];
+                const uint4 c2 = reinterpret_cast<const uint4 *>(src)[j + 2 * stride], d2 = reinterpret_cast<const uint4 *>(src)[j + 3 * stride];
+                reinterpret_cast<uint4 *>(dst)[j] = a; reinterpret_cast<uint4 *>(dst)[j + stride] = b2;
+                reinterpret_cast<uint4 *>(dst)[j + 2 * stride] = c2; reinterpret_cast<uint4 *>(dst)[j + 3 * stride] = d2;
+            }
+            for (; j < nv; j += stride) reinterpret_cast<uint4 *>(dst)[j] = reinterpret_cast<const uint4 *>(src)[j];
+            for (long long k2 = nv * W + (long long)blockIdx.x * MIK_BLOCK + threadIdx.x; k2 < cnt; k2 += stride) dst[k2] = src[k2];
         } else {
             for (long long j = (long long)blockIdx.x * MIK_BLOCK + threadIdx.x; j < cnt; j += (long long)gridDim.x * MIK_BLOCK) dst[j] = src[j];
         }
@@ -269,7 +290,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_halo_push(const T *__restrict__ s
         if (tk == gridDim.x - 1u) {
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int i = 0; i < sg.n; ++i)
-                __hip_atomic_store(&peers[sg.peer[i]]->halo_seq[rank], halo_no, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&peers[sg.peer[i]]->halo_seq[rank], halo_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // behind every workgroup's fence
         }
     }
 }
@@ -688,7 +709,7 @@ static int halo_issue(mik_cgd *it, bool *pending)
             total += it->send[(size_t)i].cnt;
         }
         if (sg.n > 0) {
-            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(64, (total * (int64_t)es / 16 + MIK_BLOCK - 1) / MIK_BLOCK));
+            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(128, (total * (int64_t)es / 64 + MIK_BLOCK - 1) / MIK_BLOCK));
             if (it->base.dtype == MIK_F64)
                 hipLaunchKernelGGL((k_halo_push<double>), dim3(grid), dim3(MIK_BLOCK), 0, cm->side, (const double *)it->send_buf, sg, (MailBox *const *)cm->peers_dev, cm->rank, cm->halo_no, cm->push_ticket);
             else
