@@ -1817,7 +1817,8 @@ __global__ void k_gather(int64_t m, const int *__restrict__ idx, const T *__rest
 // `flag` != NULL: the workgroup that finishes LAST stores `flag_value` there ("the send buffer is packed", read by the library's side
 // stream) -- a two-level ticket (64 counters of which every one collects the workgroups b with b % 64 == c, then one on top: a single
 // counter would serialise thousands of atomics, scripts/micro/ticket_cost.hip) instead of a one-thread launch behind this kernel, which
-// costs the compute stream ~5 us like any launch.  Every workgroup's stores are visible device-wide before it takes its ticket.
+// costs the compute stream ~5 us like any launch.  Every workgroup's stores into the send buffer are written through and drained before
+// it takes its (relaxed) ticket.
 template <typename T>
 __global__ __launch_bounds__(MIK_BLOCK) void k_cgd_early(int64_t m, const int *__restrict__ idx, const T *__restrict__ r, T *__restrict__ u, T *__restrict__ x,
                                                          const T *__restrict__ beta, const T *__restrict__ alpha, const int *__restrict__ done,
@@ -1830,16 +1831,19 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_cgd_early(int64_t m, const int *_
         T uo = u[i];
         if (pd) { T t = *alpha * uo; x[i] = x[i] + t; }
         if (!dn) { T t = *beta * uo; uo = r[i] + t; u[i] = uo; }
-        out[j] = uo;
+        // with a flag the send buffer is read (by a kernel on another stream, possibly on another XCD) BEFORE this kernel ends: written
+        // through (sc1), drained below -- an agent-scope release fence per workgroup instead would write the whole L2 back 2,048 times
+        if (flag) __hip_atomic_store(&out[j], uo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else out[j] = uo;
     }
     if (flag) {
-        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned c = blockIdx.x & 63u, members = (gridDim.x - c + 63u) / 64u, groups = gridDim.x < 64u ? gridDim.x : 64u;
-            if (__hip_atomic_fetch_add(&tickets[c], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
+            if (__hip_atomic_fetch_add(&tickets[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
                 __hip_atomic_store(&tickets[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__hip_atomic_fetch_add(&tickets[64], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u) {
+                if (__hip_atomic_fetch_add(&tickets[64], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u) {
                     __hip_atomic_store(&tickets[64], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(flag, flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
