@@ -837,7 +837,15 @@ template <bool XL, typename U> __device__ __forceinline__ void mgs_slot_store(U 
 }
 template <bool XL, typename U> __device__ __forceinline__ U mgs_slot_load(const U *p)
 {
-    return XL ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (XL) {
+        // an sc0 load: past this CU's L1, served by the XCD's L2.  (A workgroup-scope atomic load compiles to a plain, L1-cached load
+        // outside threadgroup-split mode: the poll then spins on -- or, worse, accepts -- a stale line.)
+        U v;
+        if (sizeof(U) == 8) asm volatile("global_load_dwordx2 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        else asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        return v;
+    }
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 struct MgsMirror {             // host-mapped; h[] follows (restart + 2 scalars of the handle's dtype)
