@@ -832,19 +832,15 @@ template <typename T> __device__ __forceinline__ typename MgsBits<T>::U mgs_slot
 // ~1.5 us of the write-through store + L2-bypassing load that coherence across the eight L2s costs (agent scope).
 template <bool XL, typename U> __device__ __forceinline__ void mgs_slot_store(U *p, U bits)
 {
-    if (XL) __hip_atomic_store(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (XL) (void)__hip_atomic_exchange(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // an atomic executes IN the L2
     else __hip_atomic_store(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <bool XL, typename U> __device__ __forceinline__ U mgs_slot_load(const U *p)
 {
-    if (XL) {
-        // an sc0 load: past this CU's L1, served by the XCD's L2.  (A workgroup-scope atomic load compiles to a plain, L1-cached load
-        // outside threadgroup-split mode: the poll then spins on -- or, worse, accepts -- a stale line.)
-        U v;
-        if (sizeof(U) == 8) asm volatile("global_load_dwordx2 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-        else asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-        return v;
-    }
+    // XL: a read-modify-write that changes nothing (or 0) -- it is performed by the XCD's L2 and returns what the L2 holds.  (There is no
+    // load that misses the L1 and still hits the L2: a workgroup-scope load is an ordinary L1-cached load outside threadgroup-split
+    // mode -- the poll would spin on, or accept, a stale line -- and an agent-scope load goes past the L2 as well.)
+    if (XL) return __hip_atomic_fetch_or(const_cast<U *>(p), (U)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
