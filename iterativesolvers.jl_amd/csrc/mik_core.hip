@@ -1540,10 +1540,12 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         return MIK_OK;
     }
     const bool merge = nlong > 0 && !fuse_dot;           // one launch: long-row workgroups spread over the row-blocks
-    // The operator streams of the product tile are read with the DEFAULT cache policy when the operator is irregular (long rows, a row
-    // permutation, x windows): non-temporal streams, right for the stencil operators, cost this kernel 10-15 % (banded configs[4] stand-
-    // in: 85.8 us streamed, 74.6 us cached; random 195.5 / 190.2 -- profiles/r04_c5_*).  Development knob 0: 1 = cached, 2 = streamed.
-    const bool nt_rb = ctx->tuning[0] == 2 || (ctx->tuning[0] == 0 && !(nlong || A->rperm || A->xwin_lo));
+    // The operator streams of the product tile are read with the DEFAULT cache policy when x is served from LDS windows: non-temporal
+    // streams, right for the stencil operators, cost this kernel 10 % there (banded configs[4] stand-in: 72.8 us streamed, 65.7 us
+    // cached -- profiles/r04_c5_*).  Development knob 0: 1 = cached, 2 = streamed.
+    // (Only where x comes from LDS windows: without them -- the `random` stand-in -- cached streams gain 3 % back to back and lose 6 % inside
+    // gmres!, where they push the Krylov basis out of the caches: 260 -> 275 us per inner iteration.)
+    const bool nt_rb = ctx->tuning[0] == 2 || (ctx->tuning[0] == 0 && !A->xwin_lo);
     if (nlong && !merge) {
         // fused dot: long rows first in their own launch, the row-block kernel then picks y[r] up
         hipLaunchKernelGGL((k_spmv_longrows<T>), dim3(nlb), dim3(MIK_BLOCK), lwin ? sizeof(T) * (size_t)A->long_lw : 0, ctx->stream, lt, A->col, (const T *)A->val, x, y, done,
