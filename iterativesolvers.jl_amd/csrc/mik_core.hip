@@ -1539,7 +1539,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     }
-    const bool merge = nlong > 0 && !fuse_dot;           // one launch: long-row workgroups spread over the row-blocks
+    const bool merge = nlong > 0 && !fuse_dot;           // one launch: long-row workgroups first, then row-blocks
     // The operator streams of the product tile are read with the DEFAULT cache policy when x is served from LDS windows: non-temporal
     // streams, right for the stencil operators, cost this kernel 10 % there (banded configs[4] stand-in: 72.8 us streamed, 65.7 us
     // cached -- profiles/r04_c5_*).  Development knob 0: 1 = cached, 2 = streamed.

@@ -51,13 +51,12 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_jds(int n, int rb0, const in
     using VV = typename WideVec<T>::val;
     const int t = threadIdx.x;
     int bid = blockIdx.x;
-    if (MERGE_LONG) {          // long-row workgroups spread evenly over the slices' (spmv_merge_slot, mik_spmv.h)
-        unsigned which;
-        if (spmv_merge_slot((unsigned)bid, gridDim.x, (unsigned)nlb, which)) {
-            spmv_longrow_wave<T>((int)which * (MIK_BLOCK / 64) + (t >> 6), lt, col, val, x, y);
+    if (MERGE_LONG) {
+        if (bid < nlb) {       // long-row workgroups first
+            spmv_longrow_wave<T>(bid * (MIK_BLOCK / 64) + (t >> 6), lt, col, val, x, y);
             return;
         }
-        bid = (int)which;
+        bid -= nlb;
     }
     const int rb = rb0 + bid;
     const int pos = rb * MIK_BLOCK + t;                 // this lane's row; the wave = slice pos >> 6

@@ -220,20 +220,6 @@ __device__ __forceinline__ void spmv_longrow_wave(int w, const LongTab &lt, cons
     longrow_store<T>(lt, w, acc, y);
 }
 
-// MERGE_LONG launches: nlb long-row workgroups spread EVENLY over the nb row-block workgroups of the same launch.  The long rows are
-// bound by the texture path (their gathers), the row-blocks by the operator streams (and LDS): run side by side they overlap;
-// run one after the other -- all long-row workgroups in front, as until round 4 -- the launch costs the SUM of the two (banded
-// configs[4] stand-in: long part 42-55 us + short part 49 us = 91.5 us merged, profiles/r04_c5_banded_*).
-// Returns true and the long-row workgroup index in `which`, or false and the row-block workgroup index.
-__device__ __forceinline__ bool spmv_merge_slot(unsigned bid, unsigned total, unsigned nlb, unsigned &which)
-{
-    const unsigned before = (unsigned)(((unsigned long long)bid * nlb + total - 1) / total);            // long-row workgroups in front of this one
-    const unsigned upto = (unsigned)(((unsigned long long)(bid + 1) * nlb + total - 1) / total);
-    if (upto > before) { which = before; return true; }
-    which = bid - before;
-    return false;
-}
-
 // x[wlo .. wlo + wlen) -> LDS at `xw` by LDS-DMA, 1-KiB pieces dealt to the four waves; workgroup-uniform; ends with a barrier
 template <typename T> __device__ __forceinline__ void spmv_long_window(const T *__restrict__ x, T *xw, int wlo, int wlen)
 {
@@ -304,14 +290,15 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
     const int t = threadIdx.x;
     int bid = blockIdx.x;
     if (MERGE_LONG) {
-        unsigned which;
-        if (spmv_merge_slot((unsigned)bid, gridDim.x, (unsigned)nlb, which)) {
-            const int lwlo = long_win ? long_win[which] : -1;
+        // (long-row workgroups spread evenly over the launch instead of leading it: measured in round 4 -- no gain on the banded stand-in,
+        //  195 instead of 186 us on the random one, whose two parts then compete for the same L2 gather bandwidth all the way)
+        if (bid < nlb) {
+            const int lwlo = long_win ? long_win[bid] : -1;
             if (lwlo >= 0) spmv_long_window<T>(x, prod, lwlo, lw);
-            spmv_longrow_wave<T>((int)which * (MIK_BLOCK / 64) + (t >> 6), lt, col, val, x, y, prod, lwlo >= 0 ? lwlo : 0, lwlo >= 0 ? lw : 0);
+            spmv_longrow_wave<T>(bid * (MIK_BLOCK / 64) + (t >> 6), lt, col, val, x, y, prod, lwlo >= 0 ? lwlo : 0, lwlo >= 0 ? lw : 0);
             return;
         }
-        bid = (int)which;
+        bid -= nlb;
     }
     const int rb = spmv_block_map(bid, nb, map_mode);
     const int r0 = rb * MIK_BLOCK;
