@@ -1154,6 +1154,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
         if (LW > 0 && n_cols >= LW + W) {
             const size_t nwg = (long_rows.size() + 3) / 4;
             std::vector<int> lwin(nwg, -1);
+            size_t with_window = 0;
             for (size_t g2 = 0; g2 < nwg; ++g2) {
                 int64_t lo = INT64_MAX, hi = -1;
                 for (size_t q = 4 * g2; q < std::min(4 * g2 + 4, long_rows.size()); ++q) {
@@ -1162,8 +1163,9 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
                 }
                 lo &= ~(int64_t)(W - 1);
                 if (lo + LW > n_cols) lo = (n_cols - LW) & ~(int64_t)(W - 1);
-                if (hi - lo < 2 * LW) lwin[g2] = (int)lo;
+                if (hi - lo < 2 * LW) { lwin[g2] = (int)lo; ++with_window; }
             }
+            A->long_spread = 2 * with_window >= nwg;
             hipError_t e2;
             if ((e2 = hipMalloc((void **)&A->long_win, sizeof(int) * nwg)) != hipSuccess ||
                 (e2 = hipMemcpy(A->long_win, lwin.data(), sizeof(int) * nwg, hipMemcpyHostToDevice)) != hipSuccess) {
@@ -1562,7 +1564,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
 #define MIK_SPMV_GO(FD, NT, WD, MG, XW, RP)                                                                      \
     hipLaunchKernelGGL((k_spmv_rowblock<T, FD, NT, WD, MG, XW, RP>), grid, block, dyn, ctx->stream, n, nb, map_mode, A->rowptr, \
                        A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, nlb, lt, (const int *)A->xwin_lo, A->xwin_span, (const unsigned char *)A->rperm, \
-                       MG ? lwin : (const int *)nullptr, lw_launch)
+                       MG ? lwin : (const int *)nullptr, (MG && lwin && A->long_spread) ? -lw_launch : lw_launch)
 #define MIK_SPMV_GO3(FD, NT, MG)                                                          \
     do {                                                                                  \
         if (xwin) { if (rp) MIK_SPMV_GO(FD, NT, true, MG, true, true); else MIK_SPMV_GO(FD, NT, true, MG, true, false); }   \

@@ -67,6 +67,7 @@ struct mik_csr {
     int xwin_span = 0;               // elements of x per window (a multiple of 1 KiB)
     int *long_win = nullptr;         // device, one per long-row workgroup (4 virtual rows): first element of its window of x in LDS, or -1 (spmv_long_window)
     int long_lw = 0;                 // elements of x per such window (whole 1-KiB pieces)
+    bool long_spread = false;        // most long-row workgroups have a window: they are spread over the merged launch instead of leading it
     unsigned char *rperm = nullptr;  // device, n_rows rounded up to whole 256-row blocks: thread t of a row-block sums row rperm[r0 + t] (k_spmv_rowblock RPERM); NULL = row t
     int *long_rows = nullptr;        // device: [n_long] targets, [n_long] start offsets, [n_long] lengths of the virtual rows, then the
                                      // segment tables: [n_seg] cut-row index, [n_cut] row, [n_cut] first segment, [n_cut] segments, [n_cut] tickets

@@ -290,15 +290,28 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
     const int t = threadIdx.x;
     int bid = blockIdx.x;
     if (MERGE_LONG) {
-        // (long-row workgroups spread evenly over the launch instead of leading it: measured in round 4 -- no gain on the banded stand-in,
-        //  195 instead of 186 us on the random one, whose two parts then compete for the same L2 gather bandwidth all the way)
-        if (bid < nlb) {
-            const int lwlo = long_win ? long_win[bid] : -1;
+        // The long-row workgroups LEAD the launch, or -- lw < 0: the operator's long rows gather from LDS windows -- are spread evenly over
+        // it (workgroup b is a long-row one where ceil(b nlb / total) steps up).  Measured in round 4 on the configs[4] stand-ins: banded
+        // (windows) 70.3 us leading, 65.7 us spread; random (no windows: both parts compete for the same L2 gather bandwidth all the way)
+        // 192 us leading, 196 us spread.
+        const bool spread = lw < 0;
+        if (spread) lw = -lw;
+        unsigned which = (unsigned)bid;
+        bool is_long = bid < nlb;
+        if (spread) {
+            const unsigned total = gridDim.x;
+            const unsigned before = (unsigned)(((unsigned long long)bid * (unsigned)nlb + total - 1) / total);
+            const unsigned upto = (unsigned)(((unsigned long long)(bid + 1) * (unsigned)nlb + total - 1) / total);
+            is_long = upto > before;
+            which = is_long ? before : (unsigned)bid - before;
+        } else if (!is_long) which = (unsigned)(bid - nlb);
+        if (is_long) {
+            const int lwlo = long_win ? long_win[which] : -1;
             if (lwlo >= 0) spmv_long_window<T>(x, prod, lwlo, lw);
-            spmv_longrow_wave<T>(bid * (MIK_BLOCK / 64) + (t >> 6), lt, col, val, x, y, prod, lwlo >= 0 ? lwlo : 0, lwlo >= 0 ? lw : 0);
+            spmv_longrow_wave<T>((int)which * (MIK_BLOCK / 64) + (t >> 6), lt, col, val, x, y, prod, lwlo >= 0 ? lwlo : 0, lwlo >= 0 ? lw : 0);
             return;
         }
-        bid -= nlb;
+        bid = (int)which;
     }
     const int rb = spmv_block_map(bid, nb, map_mode);
     const int r0 = rb * MIK_BLOCK;
