@@ -674,6 +674,26 @@ function Comm(ctx::Context, id::Union{Nothing, Vector{UInt8}}, rank::Integer, nr
     c
 end
 
+# Transport 3 (include/mik.h): peer-mapped mailboxes -- no collective launch in the step.  `allgather` is whatever the host has for
+# small byte vectors (MPI.Allgather!): it carries the 64-byte HIP IPC handles once.
+"64-byte HIP IPC handle of this communicator's mailbox (mik_comm_mailbox_export)"
+function mailbox_handle(c::Comm)
+    h = zeros(UInt8, 64)
+    check(ccall((:mik_comm_mailbox_export, libmik), Cint, (Ptr{Cvoid}, Ptr{UInt8}), c.handle, h), "mik_comm_mailbox_export", c.ctx.handle)
+    h
+end
+"every rank's mailbox handle, rank order, 64 bytes each (mik_comm_mailbox_connect; collective)"
+function connect_mailboxes!(c::Comm, handles::Vector{UInt8})
+    GC.@preserve handles check(ccall((:mik_comm_mailbox_connect, libmik), Cint, (Ptr{Cvoid}, Ptr{UInt8}), c.handle, handles), "mik_comm_mailbox_connect", c.ctx.handle)
+    c
+end
+"(handle, byte offset) of the allocation that holds a device vector (mik_mem_export): what a peer maps to push its halo into it"
+function export_memory(v::HipVector)
+    h = zeros(UInt8, 64); off = Ref{Int64}(0)
+    check(ccall((:mik_mem_export, libmik), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{UInt8}, Ref{Int64}), v.ctx.handle, v.ptr, h, off), "mik_mem_export", v.ctx.handle)
+    (h, off[])
+end
+
 "Row-partitioned CGIterable: this rank's block, the halo plan and the communicator; `iterate_many!` is ONE ccall per batch."
 mutable struct HipDistCG{T}
     handle::Ptr{Cvoid}
@@ -685,10 +705,12 @@ mutable struct HipDistCG{T}
 end
 function dist_cg_iterator!(x::HipVector{T}, A_loc::HipCSR{T}, b::HipVector{T}, comm::Comm, rank::Integer, nranks::Integer;
         send_idx::Vector{Int32}, recv::Vector{NTuple{3, Int}}, send::Vector{NTuple{3, Int}},        # (peer, offset, count)
-        abstol::Real = 0.0, reltol::Real = sqrt(eps(T)), maxiter::Int, initially_zero::Bool = true) where {T}
+        abstol::Real = 0.0, reltol::Real = sqrt(eps(T)), maxiter::Int, initially_zero::Bool = true,
+        u_ext::Union{Nothing, HipVector{T}} = nothing, ghosts = nothing) where {T}
     ctx = x.ctx
     n_loc, n_ext = size(A_loc)
-    u_ext = fill!(HipVector{T}(undef, n_ext, ctx), 0); r = similar(x); c = similar(x)
+    u_ext = u_ext === nothing ? fill!(HipVector{T}(undef, n_ext, ctx), 0) : u_ext
+    r = similar(x); c = similar(x)
     sbuf = HipVector{T}(undef, max(length(send_idx), 1), ctx)
     dot_all = fill!(HipVector{T}(undef, nranks, ctx), 0); rr_all = fill!(HipVector{T}(undef, nranks, ctx), 0)
     sidx = HipVector{Float32}(undef, max(length(send_idx), 1), ctx)      # 4-byte slots: holds the Int32 indices
@@ -705,6 +727,14 @@ function dist_cg_iterator!(x::HipVector{T}, A_loc::HipCSR{T}, b::HipVector{T}, c
     check(ccall((:mik_cgd_set_halo_plan, libmik), Cint, (Ptr{Cvoid}, Cint, Ptr{Cint}, Ptr{Int64}, Ptr{Int64}, Cint, Ptr{Cint}, Ptr{Int64}, Ptr{Int64}),
                 h[], length(rp), rp, ro, rc, length(sp), sp, so, sc), "mik_cgd_set_halo_plan", ctx.handle)
     check(ccall((:mik_cgd_set_comm, libmik), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h[], comm.handle), "mik_cgd_set_comm", ctx.handle)
+    if ghosts !== nothing
+        # transport 3, halo pushed into peer-mapped ghost regions: ghosts = (handles of every rank's u_ext allocation (64 bytes each, rank
+        # order), their byte offsets, and per SEND segment the element of the receiver's u_ext at which it lands) -- the host gathers them
+        # from `export_memory(u_ext)` / the receivers' plans; `u_ext` must then be the vector whose handle this rank published (keyword)
+        gh, goff, gdst = ghosts
+        GC.@preserve gh goff gdst check(ccall((:mik_cgd_connect_ghosts, libmik), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Ptr{Int64}, Ptr{Int64}), h[], gh, goff, gdst),
+                                        "mik_cgd_connect_ghosts", ctx.handle)
+    end
     res = Ref{Cdouble}(); tol = Ref{Cdouble}()
     check(ccall((:mik_cgd_init, libmik), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ref{Cdouble}), h[], res, tol), "mik_cgd_init", ctx.handle)
     it = HipDistCG{T}(h[], ctx, Any[x, b, u_ext, r, c, sbuf, dot_all, rr_all, sidx, A_loc, comm], res[], tol[], maxiter)
