@@ -1128,6 +1128,33 @@ def bench_main(args):
     transports = {}
     chosen = None
     eng = it = ncomm = None
+    import threading
+    watchdog = {"timer": None}
+
+    def emergency_line():
+        """A transport measured AFTER a good one hangs (no device-to-device transfer of any kind could be tried before the driver's own
+        multi-GPU run): every rank leaves, rank 0 first prints the line of the best transport measured so far."""
+        if rank == 0 and chosen is not None:
+            ms = transports[chosen]["ms_per_step"]
+            print(json.dumps({
+                "metric": "cg_iters_per_sec", "value": world * 1e3 / ms, "unit": "iters/s", "n_gpus": world, "world_size_checked": world, "steps": K, "warmup": Wm,
+                "global_system_iters_per_sec": 1e3 / ms, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic",
+                "config": {"workload": f"cg! on the {N}x{N}x{nz * world} 3D 7-point Laplacian row-partitioned into {world} z-slab(s) of {N}x{N}x{nz} rows",
+                           "n": int(n), "n_per_gpu": plan.n_loc, "host_sync_per_step": 1, "transport_chosen": chosen, "transports_measured": transports,
+                           "watchdog": "a transport measured after this one did not return in time; the process left with the best line it had"},
+                "roofline": None}), flush=True)
+        os._exit(0 if chosen is not None else 3)
+
+    def arm_watchdog():
+        if watchdog["timer"] is not None:
+            watchdog["timer"].cancel()
+        watchdog["timer"] = None
+        if world > 1 and chosen is not None:
+            watchdog["timer"] = threading.Timer(float(os.environ.get("MIK_BENCH_WATCHDOG_S", "150")), emergency_line)
+            watchdog["timer"].daemon = True
+            watchdog["timer"].start()
+
     if transport == "native":
         default = "rccl,rccl+mailbox,mailbox" if (world > 1 or self_halo) else "rccl"
         names = [t for t in os.environ.get("MIK_NATIVE_TRANSPORTS", default).split(",") if t]
@@ -1136,6 +1163,7 @@ def bench_main(args):
             pkg.lib().mik_set_tuning(6, int(os.environ.get("MIK_KNOB6", "4")))     # a world of one still sends its scalars through the mailbox (development)
         reference = None
         for name in names:
+            arm_watchdog()                      # (only once a transport has been measured: then a hang of the next one is survivable)
             e2 = c2 = i2 = None
             failure = None
             t_up = time.perf_counter()
@@ -1185,6 +1213,8 @@ def bench_main(args):
             else:
                 e2.close()
                 c2.close()
+        if watchdog["timer"] is not None:
+            watchdog["timer"].cancel()
         if chosen is None:
             if rank == 0:
                 print(f"bench.py: no native transport came up ({transports}); falling back to the Python-driven transport", file=sys.stderr)

@@ -14,9 +14,10 @@ python - "$T" "$TR" > $OUT/dist_selfhalo_timeline_$TR.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-mid = len(rows) // 2
-while "OpCgUpdateR" not in rows[mid]["Kernel_Name"]:
-    mid += 1
+# the shortest step (update sweep to update sweep) of the last third of the trace: inside a batch of 25 steps with one host wait
+marks = [i for i, r in enumerate(rows) if "OpCgUpdateR" in r["Kernel_Name"]]
+cand = [(int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"]), a) for a, b in zip(marks, marks[1:]) if a > 2 * len(rows) // 3]
+mid = min(cand)[1]
 t0 = int(rows[mid]["Start_Timestamp"])
 print(f"one steady-state step of mik_cgd_iterate_many, one configs[3] slab (512 x 512 x 64 rows) on one MI355X, halo (2 x 512^2 doubles) exchanged with the rank itself; transport {sys.argv[2]}")
 print("(rocprofv3 --kernel-trace; start offset and duration in us; queue = HIP stream: the halo transfer runs on the library's side stream)\n")
