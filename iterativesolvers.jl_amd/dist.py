@@ -1124,7 +1124,8 @@ def bench_main(args):
     #   mailbox       no RCCL at all: scalars by mailbox, halo pushed into IPC-mapped ghost regions
     # Every candidate that comes up on ALL ranks runs the warm-up and the timed regions; their first residuals must agree bit for bit
     # (the arithmetic is the same by construction -- a transport that delivered stale data would show here); `value` is the fastest
-    # of those that agree with the first one that came up.  MIK_NATIVE_TRANSPORTS narrows / reorders the list.
+    # of the largest group of transports with identical bits (a tie goes to the group with plain RCCL in it).  MIK_NATIVE_TRANSPORTS
+    # narrows / reorders the list.
     transports = {}
     chosen = None
     eng = it = ncomm = None
@@ -1156,12 +1157,13 @@ def bench_main(args):
             watchdog["timer"].start()
 
     if transport == "native":
-        default = "rccl,rccl+mailbox,mailbox" if (world > 1 or self_halo) else "rccl"
+        # (order: the transport whose waits are all bounded first -- once it has been measured, a hang of a later one is survivable)
+        default = "mailbox,rccl+mailbox,rccl" if (world > 1 or self_halo) else "rccl"
         names = [t for t in os.environ.get("MIK_NATIVE_TRANSPORTS", default).split(",") if t]
         force = self_halo or os.environ.get("MIK_DIST_FORCE_COLLECTIVES", "0") == "1"
         if world == 1:
             pkg.lib().mik_set_tuning(6, int(os.environ.get("MIK_KNOB6", "4")))     # a world of one still sends its scalars through the mailbox (development)
-        reference = None
+        alive = {}
         for name in names:
             arm_watchdog()                      # (only once a transport has been measured: then a hang of the next one is survivable)
             e2 = c2 = i2 = None
@@ -1200,16 +1202,19 @@ def bench_main(args):
                 continue
             rec.update(ms_per_step=float(np.median(tms)) / K * 1e3, timed_regions=len(tms), first_residuals=[float(v).hex() for v in first[:8]],
                        uses_rccl=c2.uses_rccl())
-            if reference is None:
-                reference = first[:8]
-            rec["same_bits_as_first_transport"] = first[:8] == reference
             transports[name] = rec
-            if rec["same_bits_as_first_transport"] and (chosen is None or rec["ms_per_step"] < transports[chosen]["ms_per_step"]):
-                if eng is not None:
-                    eng.close()
-                    ncomm.close()
-                chosen, eng, ncomm, it = name, e2, c2, i2
-                chosen_times, chosen_k = tms, state["k"]
+            alive[name] = (e2, c2, i2, tms, state["k"])
+            # provisional choice (what the watchdog would print): the fastest of the LARGEST group of transports with identical bits
+            groups = {}
+            for nm in alive:
+                groups.setdefault(tuple(transports[nm]["first_residuals"]), []).append(nm)
+            best = max(groups.values(), key=lambda g2: (len(g2), "rccl" in g2))
+            for nm in alive:
+                transports[nm]["same_bits_as_the_majority"] = nm in best
+            chosen = min(best, key=lambda nm: transports[nm]["ms_per_step"])
+        for nm, (e2, c2, i2, tms, kk) in alive.items():
+            if nm == chosen:
+                eng, ncomm, it, chosen_times, chosen_k = e2, c2, i2, tms, kk
             else:
                 e2.close()
                 c2.close()
