@@ -123,7 +123,7 @@ struct mik_comm {
     unsigned long long halo_no = 0;
     unsigned *mail_err = nullptr;        // pinned, device-mapped: a wait timed out
     unsigned long long timeout_ticks = 0;   // of the 100 MHz wall clock
-    unsigned *push_ticket = nullptr;     // device: arrival counter of k_halo_push, then the 65 counters of k_cgd_early's two-level ticket
+    unsigned *push_ticket = nullptr;     // device: arrival counter of k_halo_push
 };
 
 namespace {
@@ -671,18 +671,6 @@ static bool halo_any(const mik_cgd *it)
     return it->comm && (it->comm->nccl || halo_p2p(it)) && !(it->recv.empty() && it->send.empty());
 }
 
-// before the pack phase of a step whose pack is ONE kernel (k_cgd_early, phase 9): that kernel publishes "packed" itself
-static bool halo_arm(mik_cgd *it)
-{
-    mik_comm *cm = it->comm;
-    if (!halo_any(it) || !halo_flags(it) || !it->early_merged) return false;
-    cm->halo_no += 1;
-    it->pack_tickets = cm->push_ticket + 8;
-    it->pack_flag = &cm->mail->packed_seq;
-    it->pack_flag_value = cm->halo_no;
-    return true;
-}
-
 static int halo_mark(mik_cgd *it)
 {
     mik_comm *cm = it->comm;
@@ -949,15 +937,16 @@ static int cgd_enqueue_head(mik_cgd *it, int64_t iteration)
     const bool early = it->n_early > 0 && halo_any(it);
     bool pending = false;
     if (early && halo_flags(it)) {
-        // Flags instead of events (a mailbox exists): the boundary rows are updated and packed first, the kernel itself publishes
-        // "packed" (or a one-thread launch behind the pack phase, when that is several kernels), the halo travels on the side stream
+        // Flags instead of events (a mailbox exists): the boundary rows are updated and packed first, a one-thread launch publishes
+        // "packed", the halo travels on the side stream
         // underneath the bulk of the sweep over u (95 us at 16.7 M rows against ~20-30 us for the two 2 MB planes), ONE one-wave
         // launch waits for it, and the SpMV is ONE launch over all row-blocks -- no interior / boundary split: every launch costs the
         // compute stream ~5 us whatever it does (profiles/r04_dist_selfhalo_timeline_*.txt), and the split bought overlap that the
         // sweep already provides.
-        const bool armed = it->early_merged && halo_arm(it);
         MIK_TRY(mik_cgd_phase(it, it->early_merged ? 9 : 7, iteration));   // u on the rows the neighbours need; pack
-        if (!armed) MIK_TRY(halo_mark(it));
+        MIK_TRY(halo_mark(it));                                     // "packed": a one-thread launch (the pack kernel publishing the flag itself --
+                                                                    // write-through stores, a two-level ticket of its 2,048 workgroups -- cost it 8 us
+                                                                    // more than this launch costs: 15.8 us against 8.1 + 5.7, round 4)
         MIK_TRY(mik_cgd_phase(it, 8, iteration));                   // the bulk of the sweep over u is on the compute stream ...
         MIK_TRY(halo_issue(it, &pending));                          // ... before the host enters RCCL
         MIK_TRY(halo_end(it, pending));

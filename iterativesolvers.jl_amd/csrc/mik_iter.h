@@ -164,8 +164,6 @@ struct mik_cgd {
     std::vector<HaloSeg> recv, send;      // offsets into the ghost tail of u_ext / into send_buf, in elements
     mik_comm *comm = nullptr;
     std::vector<void *> send_dst;         // per send segment: where it lands in the receiver's ghost region, as mapped here (mik_cgd_connect_ghosts)
-    unsigned *pack_tickets = nullptr;     // device, 65 counters of the two-level ticket of k_cgd_early (owned by the communicator)
-    unsigned long long *pack_flag = nullptr, pack_flag_value = 0;   // armed by the transport for the NEXT phase 9: "packed" published by the kernel itself
     bool ghosts = false;                  // the halo is pushed into peer-mapped ghost regions (mailbox transport) instead of ncclSend / ncclRecv
     bool initialised = false;             // mik_cgd_init ran
     // rows the neighbours need (send_idx) as at most two contiguous runs [a, b): when they are, u is updated there FIRST, packed and

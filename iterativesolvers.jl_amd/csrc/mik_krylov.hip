@@ -1814,16 +1814,10 @@ __global__ void k_gather(int64_t m, const int *__restrict__ idx, const T *__rest
 
 // The rows the neighbours need, updated and packed in ONE launch (every send index occurs once): u = r + beta u (and the
 // pending x update) exactly as OpXpbyX::apply does it, then the new u straight into the send buffer.
-// `flag` != NULL: the workgroup that finishes LAST stores `flag_value` there ("the send buffer is packed", read by the library's side
-// stream) -- a two-level ticket (64 counters of which every one collects the workgroups b with b % 64 == c, then one on top: a single
-// counter would serialise thousands of atomics, scripts/micro/ticket_cost.hip) instead of a one-thread launch behind this kernel, which
-// costs the compute stream ~5 us like any launch.  Every workgroup's stores into the send buffer are written through and drained before
-// it takes its (relaxed) ticket.
 template <typename T>
 __global__ __launch_bounds__(MIK_BLOCK) void k_cgd_early(int64_t m, const int *__restrict__ idx, const T *__restrict__ r, T *__restrict__ u, T *__restrict__ x,
                                                          const T *__restrict__ beta, const T *__restrict__ alpha, const int *__restrict__ done,
-                                                         const int *__restrict__ pending, int fuse_x, T *__restrict__ out,
-                                                         unsigned *__restrict__ tickets, unsigned long long *__restrict__ flag, unsigned long long flag_value)
+                                                         const int *__restrict__ pending, int fuse_x, T *__restrict__ out)
 {
     const int dn = *done, pd = fuse_x ? *pending : 0;
     for (int64_t j = (int64_t)blockIdx.x * MIK_BLOCK + threadIdx.x; j < m; j += (int64_t)gridDim.x * MIK_BLOCK) {
@@ -1831,24 +1825,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_cgd_early(int64_t m, const int *_
         T uo = u[i];
         if (pd) { T t = *alpha * uo; x[i] = x[i] + t; }
         if (!dn) { T t = *beta * uo; uo = r[i] + t; u[i] = uo; }
-        // with a flag the send buffer is read (by a kernel on another stream, possibly on another XCD) BEFORE this kernel ends: written
-        // through (sc1), drained below -- an agent-scope release fence per workgroup instead would write the whole L2 back 2,048 times
-        if (flag) __hip_atomic_store(&out[j], uo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else out[j] = uo;
-    }
-    if (flag) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned c = blockIdx.x & 63u, members = (gridDim.x - c + 63u) / 64u, groups = gridDim.x < 64u ? gridDim.x : 64u;
-            if (__hip_atomic_fetch_add(&tickets[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
-                __hip_atomic_store(&tickets[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__hip_atomic_fetch_add(&tickets[64], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u) {
-                    __hip_atomic_store(&tickets[64], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(flag, flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-            }
-        }
+        out[j] = uo;
     }
 }
 
@@ -2117,8 +2094,7 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
         if (it->n_early <= 0 || !it->early_merged) return mik_fail(ctx, MIK_ERR_INVALID, "mik_cgd_phase: no merged early part");
         const int grid = (int)std::min<int64_t>((it->n_send + MIK_BLOCK - 1) / MIK_BLOCK, MIK_MAX_GRID);
         hipLaunchKernelGGL((k_cgd_early<T>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, it->n_send, it->send_idx, (const T *)r, u, x, (const T *)&d->beta,
-                           (const T *)&d->alpha, done, (const int *)&d->x_pending, bs.fuse_x ? 1 : 0, (T *)it->send_buf, it->pack_tickets, it->pack_flag, it->pack_flag_value);
-        it->pack_flag = nullptr;                         // armed per launch by the transport (cgd_enqueue_head)
+                           (const T *)&d->alpha, done, (const int *)&d->x_pending, bs.fuse_x ? 1 : 0, (T *)it->send_buf);
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     }
