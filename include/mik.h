@@ -347,6 +347,10 @@ typedef struct mik_minres mik_minres;
 int mik_minres_create(mik_ctx *ctx, const mik_csr *A, void *x, void *v_prev, void *v_curr, void *v_next, void *w_prev, void *w_curr,
                       void *w_next, double resnorm0, int skew_hermitian, mik_minres **out);
 int mik_minres_step(mik_minres *it, int64_t iteration, void *resnorm);   /* resnorm: one scalar of A's element type */
+/* (W, L) of the reduction tree of proj = dot(v_curr, v_next) (src/minres.jl:107) inside mik_minres_step: where the operator's SpMV
+ * kernel takes the Lanczos step as its epilogue (y = A x - H[2] v_prev stored once, the dot formed in the same launch) it is the
+ * shape of the dot fused into the CG SpMV (mik_spmv_dot_shape), else the vector shape (mik_reduce_shape).  The oracle takes it. */
+int mik_minres_proj_shape(const mik_minres *it, int *W, int *L);
 int mik_minres_destroy(mik_minres *it);
 
 /* ---- row-partitioned GMRESIterable: one process per GPU ---------------------------------------- */

@@ -1380,6 +1380,15 @@ class MINRESIterable:
                   "mik_minres_create", x.ctx.handle)
             self._step = h
 
+    def proj_shape(self):
+        """(W, L) of the reduction tree of ``proj = dot(v_curr, v_next)`` (src/minres.jl:107): the SpMV-dot shape where the whole-iteration
+        call forms it in the SpMV launch (``mik_minres_proj_shape``), the vector shape otherwise -- what the oracle's ``proj_shape`` takes."""
+        if self._step is None:
+            return self.x.ctx.reduce_shape(self.x.dtype)
+        w, l = C.c_int(), C.c_int()
+        check(lib().mik_minres_proj_shape(self._step, C.byref(w), C.byref(l)), "mik_minres_proj_shape", self.x.ctx.handle)
+        return w.value, l.value
+
     def converged(self):
         return self.resnorm <= self.tol                                      # :89
 

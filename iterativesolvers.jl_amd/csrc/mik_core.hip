@@ -1328,6 +1328,12 @@ static bool sdiab2_applies(const mik_csr *A)
            A->ctx->tuning[19] == 0;
 }
 
+// k_spmv_sdiab2 (whole launches with the fused dot) takes the epilogue y = A x + c w, dot(x, y) -- the Lanczos step of MINRES
+bool mik_spmv_has_epilogue(const mik_csr *A)
+{
+    return A && spmv_kernel_choice(A) == 5 && A->sdia_buf_ok && A->ctx->tuning[17] == 0 && sdiab2_applies(A) && A->ctx->tuning[25] != 2;   // development knob 25 = 2: never
+}
+
 // the operator's SpMV moves little more than x and y (the slice-constant layout): the CG step then picks other cache hints
 bool mik_spmv_is_light(const mik_csr *A) { return A && (spmv_kernel_choice(A) == 5 || spmv_kernel_choice(A) == 6); }
 
@@ -1411,6 +1417,8 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
     if (!whole && map_mode >= 8 && (rb0 % map_mode != 0 || nb % map_mode != 0)) map_mode = 0;   // strips need whole planes
     if (skip_len > 0) map_mode = 0;
     const int choice = spmv_kernel_choice(A);
+    if ((ctx->spmv_ep_w || ctx->spmv_ep_c) && !(whole && fuse_dot && mik_spmv_has_epilogue(A)))
+        return mik_fail(ctx, MIK_ERR_NOTIMPL, "SpMV: the y = A x + c w epilogue is not available for this operator's kernel");
     if (choice == 5) {
         // slice patterns {offsets, values} + one mask byte per row (mik_sell.h); G slices per workgroup
         const int G = ctx->tuning[16] > 0 ? ctx->tuning[16] : MIK_SDIAC_G;   // development knob 16: 1 / 2 / 4 slices per workgroup
@@ -1437,7 +1445,8 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
                 const int ps = sshift >= 1 ? sshift - 1 : -1, pfull = sshift >= 1 ? nfull / 2 : 0;
 #define MIK_SDIAB2_GO4(FD, NTV, C)                                                                                                       \
     hipLaunchKernelGGL((k_spmv_sdiab2<T, FD, NTV, mik_sdiab_cls_ns(C), mik_sdiab_cls_cq(C)>), dim3(wg2), dim3(MIK_BLOCK), 0, ctx->stream, n, (int)A->n_cols, A->sdia_koff, \
-                       pb0, np, pfull, ps, nb_all, ctx->sweep_rev, (const SdiaSliceRec *)A->sdia_recs, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done)
+                       pb0, np, pfull, ps, nb_all, ctx->sweep_rev, (const SdiaSliceRec *)A->sdia_recs, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done, \
+                       (const T *)ctx->spmv_ep_w, (const T *)ctx->spmv_ep_c)
 #define MIK_SDIAB2_GO(FD, NTV) do { if (cls == 1) MIK_SDIAB2_GO4(FD, NTV, 1); else if (cls == 2) MIK_SDIAB2_GO4(FD, NTV, 2); else MIK_SDIAB2_GO4(FD, NTV, 3); } while (0)
                 if (fuse_dot) { if (nt) MIK_SDIAB2_GO(true, true); else MIK_SDIAB2_GO(true, false); }
                 else          { if (nt) MIK_SDIAB2_GO(false, true); else MIK_SDIAB2_GO(false, false); }

@@ -43,6 +43,7 @@ struct mik_ctx {
     unsigned long long pub_seq = 0;
     static constexpr size_t PUB_BYTES = 4096;
     int sweep_rev = 0;               // 1: the next SpMV launch walks its row-blocks from the end (set and cleared by the CG step)
+    const void *spmv_ep_w = nullptr, *spmv_ep_c = nullptr;   // the next fused-dot SpMV launch stores y = A x + (*c) w and sums x .* y (set and cleared by mik_minres_step)
     int tuning[32] = {0};            // development knobs of THIS context (include/mik_dev.h): a copy of the defaults at creation, mik_ctx_set_tuning
     static constexpr size_t COEF_BYTES = 8192;      // [0, 4096): coefficient blocks of the callers; the tail: scratch of mik_safe_norm_slow
     static constexpr size_t COEF_SAFE_SLOT = 4096;  // byte offset of that scratch
@@ -130,6 +131,7 @@ int mik_ensure_partials(mik_ctx *ctx, size_t bytes);
 // device builders of the wide slice-constant layout and of the jagged slices from A's device CSR arrays (mik_upload.hip)
 int mik_build_sdiaw_device(mik_ctx *ctx, mik_csr *A);
 int mik_build_jds_device(mik_ctx *ctx, mik_csr *A);
+bool mik_spmv_has_epilogue(const mik_csr *A);   // the active SpMV kernel of A takes the y = A x + c w epilogue (ctx->spmv_ep_*)
 int mik_build_xwin_device(mik_ctx *ctx, mik_csr *A);
 int mik_build_rperm_host(mik_ctx *ctx, mik_csr *A, const int *rowptr_host);   // rows of a block sorted by length over its threads (k_spmv_rowblock RPERM)   // after the jagged slices: windows of x for the product-tile kernel (k_spmv_rowblock XWIN)
 

@@ -477,7 +477,8 @@ template <typename T, bool FUSE_DOT, bool NT, int NS, int CQ>
 __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab2(int n, int ncols, int koff, int pb0, int np, int nfull, int sshift, int nslices, int rev,
                                                            const SdiaSliceRec *__restrict__ recs, const SdiaPattern<T> *__restrict__ pats,
                                                            const unsigned char *__restrict__ mask, const T *__restrict__ x, T *__restrict__ y,
-                                                           T *__restrict__ seg_out, const int *__restrict__ done)
+                                                           T *__restrict__ seg_out, const int *__restrict__ done,
+                                                           const T *__restrict__ ep_w = nullptr, const T *__restrict__ ep_c = nullptr)
 {
     static_assert(NS >= 3 && CQ >= 1 && CQ + 1 < NS, "the class must have slots around the centre");
     if (done && *done) return;
@@ -564,6 +565,15 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab2(int n, int ncols, int
             if (FUSE_DOT && r0 + e < n && (cq < 0 || ((mi >> cq) & 1))) c = x[r0 + e];
             if (e) { acc1 = a; xr1 = c; } else { acc0 = a; xr0 = c; }
         }
+    }
+    if (FUSE_DOT && ep_w) {
+        // the Lanczos step of MINRES as the epilogue (src/minres.jl:102-107): y = A x + c w (a rounded multiply, a rounded add, as
+        // axpy! after mul! gives them), and the dot below is dot(x, y) of THAT y -- one sweep over v_prev, v_next, v_curr less
+        const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc((void *)ep_w, (short)0, (int)((unsigned)n * ES), (int)0x00020000);
+        const Pair2<T> wv = buffer_gather2<T>(wsr, rowoff, 0);             // a pair past the end reads +0
+        const T c = *ep_c;
+        const T t0 = c * wv.a, t1 = c * wv.b;
+        acc0 = acc0 + t0; acc1 = acc1 + t1;
     }
     buffer_put2<T>(ys, rowoff, acc0, acc1, NT);
     if (FUSE_DOT) {

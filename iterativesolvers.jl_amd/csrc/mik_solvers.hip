@@ -529,6 +529,7 @@ struct mik_minres {
     void *dev = nullptr;            // MinresDev<T>
     MinresMirror *mirror = nullptr;
     unsigned long long seq = 0;
+    bool epilogue = false;          // the Lanczos step rides on the SpMV (mik_spmv_has_epilogue): proj has the SpMV-dot shape
 };
 
 extern "C" int mik_minres_destroy(mik_minres *it)
@@ -554,6 +555,7 @@ extern "C" int mik_minres_create(mik_ctx *ctx, const mik_csr *A, void *x, void *
     mik_minres *it = new (std::nothrow) mik_minres();
     if (!it) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_minres_create: host allocation failed");
     it->ctx = ctx; it->A = A; it->dtype = A->dtype; it->skew = skew_hermitian ? 1 : 0; it->n = n; it->x = x;
+    it->epilogue = mik_spmv_has_epilogue(A) && mik_aligned16(v_prev) && mik_aligned16(v_curr) && mik_aligned16(v_next);
     it->v[0] = v_prev; it->v[1] = v_curr; it->v[2] = v_next;
     it->w[0] = w_prev; it->w[1] = w_curr; it->w[2] = w_next;
     (void)hipSetDevice(ctx->device);
@@ -611,25 +613,37 @@ template <typename T> static int minres_step_impl(mik_minres *it, int64_t iterat
     MinresDev<T> *d = (MinresDev<T> *)it->dev;
     T *x = (T *)it->x, *v_prev = (T *)it->v[0], *v_curr = (T *)it->v[1], *v_next = (T *)it->v[2];
     T *w_prev = (T *)it->w[0], *w_curr = (T *)it->w[1], *w_next = (T *)it->w[2];
-    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * 2 * (size_t)std::max<int64_t>(nseg, 1)));
-    const bool lean = nseg <= 1024 && ctx->tuning[25] == 0;   // the orthogonalisation sweep finalises the projection itself (k_map_with)
-    T *part_a = (T *)ctx->partials, *part_b = lean ? part_a + nseg : part_a;
-    MIK_TRY(mik_spmv_launch<T>(ctx, it->A, v_curr, v_next, false, nullptr, nullptr));                        // :102
-    {   // v_next -= H[2] v_prev (iteration > 1) and proj = dot(v_curr, v_next)                               :104, :107; v_prev is dead afterwards
+    // The Lanczos step (:102-107) as the EPILOGUE of the SpMV where the operator's kernel takes one (mik_spmv_has_epilogue, round 4): v_next =
+    // A v_curr - H[2] v_prev is stored once and proj = dot(v_curr, v_next) leaves the launch as one partial per 256-row block (the shape
+    // of the dot fused into the CG SpMV: mik_minres_proj_shape) -- the sweep that re-read v_prev, v_next and v_curr is gone.
+    const bool ep = it->epilogue;
+    const int64_t na = ep ? mik_spmv_nwg(n) : nseg;           // partials of the projection
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(na + nseg, 1)));
+    const bool lean = na <= 1024 && nseg <= 1024 && ctx->tuning[25] == 0;   // the orthogonalisation sweep finalises the projection itself (k_map_with)
+    T *part_a = (T *)ctx->partials, *part_b = lean ? part_a + na : part_a;
+    if (ep) {
+        ctx->spmv_ep_w = iteration > 1 ? v_prev : nullptr;   // (no v_prev in the first iteration: the plain fused dot)
+        ctx->spmv_ep_c = &d->neg_h1_lanczos;
+        const int rc_ep = mik_spmv_launch<T>(ctx, it->A, v_curr, v_next, true, part_a, nullptr);               // :102, :104, :107
+        ctx->spmv_ep_w = nullptr; ctx->spmv_ep_c = nullptr;
+        MIK_TRY(rc_ep);
+    } else {
+        MIK_TRY(mik_spmv_launch<T>(ctx, it->A, v_curr, v_next, false, nullptr, nullptr));                    // :102
+        // v_next -= H[2] v_prev (iteration > 1) and proj = dot(v_curr, v_next)                               :104, :107; v_prev is dead afterwards
         const T *xp = iteration > 1 ? v_prev : nullptr;
         OpAxpyDot<T> op{xp, v_next, v_curr, coef_ptr<T>(&d->neg_h1_lanczos), 1};
         const bool vec = mik_aligned16(v_next) && (!xp || mik_aligned16(xp)) && mik_aligned16(v_curr);
         MIK_TRY((launch_map<T>(ctx, n, op, vec, part_a, nullptr)));
-        if (!lean) {
-            hipLaunchKernelGGL((k_minres_fin_proj<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)part_a, nseg, d);
-            MIK_LAUNCH_CHECK(ctx);
-        }
+    }
+    if (!lean) {
+        hipLaunchKernelGGL((k_minres_fin_proj<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)part_a, na, d);
+        MIK_LAUNCH_CHECK(ctx);
     }
     it->seq += 1;
     {   // v_next -= proj v_curr; H[4] = norm(v_next)                                                          :109, :112
         OpAxpyDot<T> op{v_curr, v_next, nullptr, coef_ptr<T>(&d->neg_proj), 0};
         const bool vec = mik_aligned16(v_next) && mik_aligned16(v_curr);
-        if (lean) MIK_TRY((launch_map_with<T>(ctx, n, op, ProMinresProj<T>{d}, vec, (const T *)part_a, (int)nseg, part_b)));
+        if (lean) MIK_TRY((launch_map_with<T>(ctx, n, op, ProMinresProj<T>{d}, vec, (const T *)part_a, (int)na, part_b)));
         else MIK_TRY((launch_map<T>(ctx, n, op, vec, part_b, nullptr)));
         hipLaunchKernelGGL((k_minres_fin_norm<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)part_b, nseg, d, (long long)iteration,
                            it->skew, it->mirror, it->seq);
@@ -658,6 +672,13 @@ template <typename T> static int minres_step_impl(mik_minres *it, int64_t iterat
     void *t = it->v[0]; it->v[0] = it->v[1]; it->v[1] = it->v[2]; it->v[2] = t;              // :145
     t = it->w[0]; it->w[0] = it->w[1]; it->w[1] = it->w[2]; it->w[2] = t;                    // :146
     return MIK_OK;
+}
+
+extern "C" int mik_minres_proj_shape(const mik_minres *it, int *W, int *L)
+{
+    if (!it) return MIK_ERR_INVALID;
+    if (it->epilogue) return mik_spmv_dot_shape(W, L);
+    return mik_reduce_shape(it->dtype, W, L);
 }
 
 extern "C" int mik_minres_step(mik_minres *it, int64_t iteration, void *resnorm)

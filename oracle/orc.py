@@ -461,11 +461,12 @@ def chebyshev(A: CSC, b, lmin, lmax, x0=None, *, abstol=0.0, reltol=None, maxite
     return _run_simple("orc_chebyshev", A, b, x0, maxiter, call)
 
 
-def minres(A: CSC, b, x0=None, *, skew_hermitian=False, abstol=0.0, reltol=None, maxiter=None, mode="seq", shape=(1, 1)):
-    """``minres!(x, A, b; log=true)`` / ``minres(A, b)`` when ``x0 is None`` -- src/minres.jl:197-230,236."""
+def minres(A: CSC, b, x0=None, *, skew_hermitian=False, abstol=0.0, reltol=None, maxiter=None, mode="seq", shape=(1, 1), proj_shape=None):
+    """``minres!(x, A, b; log=true)`` / ``minres(A, b)`` when ``x0 is None`` -- src/minres.jl:197-230,236.  ``proj_shape``: (W, L) of
+    ``proj = dot(v_curr, v_next)`` (src/minres.jl:107; mik_minres_proj_shape), default = ``shape``."""
     dtype = A.nzval.dtype
     reltol = _eps_sqrt(dtype) if reltol is None else reltol
-    shp = np.asarray(shape, np.int32)
+    shp = np.asarray(tuple(shape) + tuple(proj_shape if proj_shape is not None else shape), np.int32)
 
     def call(f, ct, b, x, maxiter, res, iters, mvps, conv, res0, tol):
         f(A.n, _p(A.colptr, C.c_int64), _p(A.rowval, C.c_int64), _p(A.nzval, ct), A.index_base, _p(b, ct), _p(x, ct),

@@ -103,12 +103,16 @@ def test_minres_device_bit_exact(pkg, orc, ctx, dtype):
     b = orc.hashed_rhs(A.n).astype(dtype)
     dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
     x0 = np.random.default_rng(0).standard_normal(A.n).astype(dtype)
+    # proj = dot(v_curr, v_next) is formed inside the SpMV launch where the operator's kernel takes the Lanczos step as its epilogue
+    # (round 4): the oracle is told which tree that dot has (mik_minres_proj_shape)
+    ps = pkg.minres_iterable_(pkg.HipVector.from_numpy(np.zeros(A.n, dtype)), dA, pkg.HipVector.from_numpy(b), initially_zero=True, maxiter=1).proj_shape()
+    assert ps == ctx.spmv_dot_shape()                    # this operator (even n, 7-point pattern) runs on k_spmv_sdiab2
     for start in (None, x0):
         if start is None:
             x, ch = pkg.minres(dA, pkg.HipVector.from_numpy(b), log=True)
         else:
             x, ch = pkg.minres_(pkg.HipVector.from_numpy(start), dA, pkg.HipVector.from_numpy(b), log=True)
-        xo, ho = orc.minres(A, b, start, mode="tree", shape=ctx.reduce_shape(dtype))
+        xo, ho = orc.minres(A, b, start, mode="tree", shape=ctx.reduce_shape(dtype), proj_shape=ps)
         assert ch.iters == ho["iters"] and ch.mvps == ho["mvps"] and ch.isconverged == ho["isconverged"]
         assert np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
     S = A.to_scipy()
@@ -123,8 +127,10 @@ def test_minres_skew_symmetric_device(pkg, orc, ctx):
     Ak = B - B.T
     bk = Ak @ np.ones(n)
     A = orc.CSC.from_dense(Ak)
-    x, ch = pkg.minres(pkg.HipCSR(n, n, A.colptr, A.rowval, A.nzval), pkg.HipVector.from_numpy(bk), skew_hermitian=True, maxiter=10 * n, log=True)
-    xo, ho = orc.minres(A, bk, skew_hermitian=True, maxiter=10 * n, mode="tree", shape=ctx.reduce_shape(np.float64))
+    dA = pkg.HipCSR(n, n, A.colptr, A.rowval, A.nzval)
+    ps = pkg.minres_iterable_(pkg.HipVector.from_numpy(np.zeros(n)), dA, pkg.HipVector.from_numpy(bk), initially_zero=True, maxiter=1).proj_shape()
+    x, ch = pkg.minres(dA, pkg.HipVector.from_numpy(bk), skew_hermitian=True, maxiter=10 * n, log=True)
+    xo, ho = orc.minres(A, bk, skew_hermitian=True, maxiter=10 * n, mode="tree", shape=ctx.reduce_shape(np.float64), proj_shape=ps)
     assert ch.isconverged and np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
     assert np.linalg.norm(bk - Ak @ x.to_numpy()) / np.linalg.norm(bk) <= 1e-7
 
@@ -137,12 +143,18 @@ def test_fused_sweeps_equal_the_statement_by_statement_path(pkg, orc, ctx, dtype
     A = orc.laplace(9, 3).astype(dtype)
     b = orc.hashed_rhs(A.n).astype(dtype)
     dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
-    runs = []
-    for fused in (True, False):
-        x = pkg.HipVector.from_numpy(np.zeros(A.n, dtype))
-        it = pkg.minres_iterable_(x, dA, pkg.HipVector.from_numpy(b), initially_zero=True, maxiter=40, reltol=0.0, fused=fused)
-        runs.append((np.array(list(it)), x.to_numpy()))
-    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and runs[0][0].size == 40
+    for Am in (A, orc.laplace(8, 3).astype(dtype)):     # 9^3 rows: odd, no Lanczos epilogue; 8^3: even, the SpMV forms proj
+        bm = orc.hashed_rhs(Am.n).astype(dtype)
+        dAm = pkg.HipCSR(Am.n, Am.n, Am.colptr, Am.rowval, Am.nzval)
+        shapes = []
+        for fused in (True, False):
+            x = pkg.HipVector.from_numpy(np.zeros(Am.n, dtype))
+            it = pkg.minres_iterable_(x, dAm, pkg.HipVector.from_numpy(bm), initially_zero=True, maxiter=40, reltol=0.0, fused=fused)
+            hist = np.array(list(it))
+            shapes.append(it.proj_shape())
+            xo, ho = orc.minres(Am, bm, maxiter=40, reltol=0.0, mode="tree", shape=ctx.reduce_shape(dtype), proj_shape=it.proj_shape())
+            assert hist.size == 40 and np.array_equal(hist, ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
+        assert shapes[1] == ctx.reduce_shape(dtype) and (shapes[0] == ctx.spmv_dot_shape()) == (Am.n % 2 == 0)
     As = orc.CSC.from_scipy((A.to_scipy() + 20 * sp.eye(A.n)).tocsc()).astype(dtype)
     dAs = pkg.HipCSR(As.n, As.n, As.colptr, As.rowval, As.nzval)
     d = pkg.HipVector.from_numpy((1 + 0.1 * np.arange(A.n) / A.n).astype(dtype))
@@ -220,16 +232,16 @@ def test_fused_entry_points_against_numpy(pkg, orc, ctx, dtype, n, shift):
 def test_minres_whole_iteration_call_rescales_the_lanczos_norm(pkg, orc, ctx):
     """fp32 operator with entries ~1e22: |v_next|^2 overflows a plain sum of squares, so norm(v_next) (src/minres.jl:112) takes
     the scaled path -- inside mik_minres_step the tail sweep is held back, the host rescales, the scalar kernel and the tail
-    follow.  Same history and x as the statement-by-statement path, and finite."""
+    follow.  The whole-iteration call and the statement-by-statement path both equal the oracle (each with the tree its projection has), and stay finite."""
     dtype = np.float32
     A = orc.laplace(6, 3)
     A = orc.CSC(A.n, A.colptr, A.rowval, (A.nzval * 1e22).astype(dtype), A.index_base)
     b = (orc.hashed_rhs(A.n) * 1e22).astype(dtype)
     dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
-    runs = []
     for fused in (True, False):
         x = pkg.HipVector.from_numpy(np.zeros(A.n, dtype))
         it = pkg.minres_iterable_(x, dA, pkg.HipVector.from_numpy(b), reltol=0.0, initially_zero=True, maxiter=12, fused=fused)
-        runs.append((np.array(list(it)), x.to_numpy()))
-    assert runs[0][0].size == 12 and np.all(np.isfinite(runs[0][0])) and np.all(np.isfinite(runs[0][1]))
-    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+        hist = np.array(list(it))
+        assert hist.size == 12 and np.all(np.isfinite(hist)) and np.all(np.isfinite(x.to_numpy()))
+        xo, ho = orc.minres(A, b, maxiter=12, reltol=0.0, mode="tree", shape=ctx.reduce_shape(dtype), proj_shape=it.proj_shape())
+        assert np.array_equal(hist, ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
