@@ -76,7 +76,7 @@ words = sum(2 + 3 * (j + 1) + 2 + 3 * (j + 1) + 3 for j in range(l)) + (l + 1) *
 timed("bicgstabl2", pkg.bicgstabl_iterator_(x, A, b, 2, reltol=0.0, max_mv_products=10 ** 9, initial_zero=True), 0, words, 2 * l, iters=max(args.iters // 3, 10),
       moved_words=sum(2 + 3 * (j + 1) + 2 + 3 * (j + 1) + 3 for j in range(l)) + (l + 1) + (3 * l + 4))   # + one-pass Gram + one-sweep MR update
 x = pkg.zerox(A, b)
-timed("minres", pkg.minres_iterable_(x, A, b, reltol=0.0, initially_zero=True, maxiter=10 ** 9), 1, 27, 1, moved_words=4 + 3 + 8)             # Lanczos step + projection: 4; orthogonalise + norm: 3; tail: 8
+timed("minres", pkg.minres_iterable_(x, A, b, reltol=0.0, initially_zero=True, maxiter=10 ** 9), 1, 27, 1, moved_words=1 + 3 + 8)             # Lanczos step + projection in the SpMV epilogue (round 4): + v_prev; orthogonalise + norm: 3; tail: 8
 x = pkg.zerox(A, b)
 timed("chebyshev", pkg.chebyshev_iterable_(x, A, b, 4.5e-4, 12.0, reltol=0.0, initially_zero=True, maxiter=10 ** 9), 0, 2 + 3 + 3 + 3 + 1, 1,
       moved_words=3 + 6)                                               # direction: 3; x, r update + norm: 6
