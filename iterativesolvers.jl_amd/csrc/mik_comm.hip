@@ -354,7 +354,17 @@ extern "C" int mik_comm_create(mik_ctx *ctx, const void *id128, int rank, int nr
         int r = R->CommInitRank(&cm->nccl, nranks, id, rank);
         if (r != 0) return bail(mik_fail(ctx, MIK_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, nranks, R->GetErrorString ? R->GetErrorString(r) : "?"));
     }
-    if (nranks <= MIK_MAIL_MAXP) { const int rc = mailbox_alloc(cm); if (rc) return bail(rc); }   // the local flags of the halo ordering at least
+    // the local mailbox (the flags that order the side stream, at least).  Not fatal for a communicator that has RCCL: without it the
+    // side stream is ordered by events, as until round 4
+    if (nranks <= MIK_MAIL_MAXP) {
+        const int rc = mailbox_alloc(cm);
+        if (rc && !cm->nccl) return bail(rc);
+        if (rc) {
+            (void)hipGetLastError();
+            if (cm->mail) { (void)hipFree(cm->mail); cm->mail = nullptr; }
+            cm->mail_ready = false;
+        }
+    }
     *out = cm;
     return MIK_OK;
 }
