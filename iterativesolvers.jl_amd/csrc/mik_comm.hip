@@ -358,7 +358,7 @@ extern "C" int mik_comm_create(mik_ctx *ctx, const void *id128, int rank, int nr
     // side stream is ordered by events, as until round 4
     if (nranks <= MIK_MAIL_MAXP) {
         const int rc = mailbox_alloc(cm);
-        if (rc && !cm->nccl) return bail(rc);
+        if (rc && !cm->nccl && nranks > 1) return bail(rc);      // (more ranks and neither RCCL nor a mailbox: nothing to talk through)
         if (rc) {
             (void)hipGetLastError();
             if (cm->mail) { (void)hipFree(cm->mail); cm->mail = nullptr; }
