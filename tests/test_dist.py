@@ -626,6 +626,12 @@ def test_native_transport_argument_checks(pkg):
     assert L.mik_cgd_group_init(None, 2, None, None) == 1
     assert L.mik_comm_create(None, None, 0, 1, None) == 1
     assert L.mik_comm_destroy(None) == 0 and L.mik_comm_allgather_sum(None, 0, 1, None) == 1
+    # transport 3 (round 4)
+    off = C.c_int64()
+    assert L.mik_comm_mailbox_export(None, None) == 1 and L.mik_comm_mailbox_connect(None, None) == 1 and L.mik_comm_mailbox_info(None, None, None) == 1
+    assert L.mik_mem_export(None, None, None, C.byref(off)) == 1 and L.mik_cgd_connect_ghosts(None, None, None, None) == 1
+    g = C.c_int()
+    assert L.mik_spmv_long_group(C.byref(g)) == 0 and g.value == 4 and L.mik_minres_proj_shape(None, None, None) == 1
 
 
 def test_torch_slab_generator_and_localisation_equal_the_numpy_ones(pkg):
