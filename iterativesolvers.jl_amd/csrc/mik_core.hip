@@ -1328,10 +1328,14 @@ static bool sdiab2_applies(const mik_csr *A)
            A->ctx->tuning[19] == 0;
 }
 
-// k_spmv_sdiab2 (whole launches with the fused dot) takes the epilogue y = A x + c w, dot(x, y) -- the Lanczos step of MINRES
+// k_spmv_sdiab2, the two CSR kernels and the jagged slices (whole launches with the fused dot, no split-off long rows) take the epilogue
+// y = A x + c w, dot(x, y) -- the Lanczos step of MINRES
 bool mik_spmv_has_epilogue(const mik_csr *A)
 {
-    return A && spmv_kernel_choice(A) == 5 && A->sdia_buf_ok && A->ctx->tuning[17] == 0 && sdiab2_applies(A) && A->ctx->tuning[25] != 2;   // development knob 25 = 2: never
+    if (!A || A->ctx->tuning[25] == 2) return false;                    // development knob 25 = 2: never
+    const int kc = spmv_kernel_choice(A);
+    if (kc == 5) return A->sdia_buf_ok && A->ctx->tuning[17] == 0 && sdiab2_applies(A);
+    return (kc == 0 || kc == 1) && A->n_long == 0;                       // the CSR kernels and the jagged slices: one row per thread, no split-off long rows
 }
 
 // the operator's SpMV moves little more than x and y (the slice-constant layout): the CG step then picks other cache hints
@@ -1531,7 +1535,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         const bool inside = fuse_dot && nlong == 0;
 #define MIK_JDS_GO(FD, NTV, MG)                                                                                                        \
     hipLaunchKernelGGL((k_spmv_jds<T, FD, NTV, MG>), dim3(nb + (MG ? nlb : 0)), dim3(MIK_BLOCK), 0, ctx->stream, n, rb0, A->jds_ptr, A->jds_len, \
-                       (const IV *)A->jds_col, (const VV *)A->jds_val, x, y, seg_out, done, nlb, lt, A->col, (const T *)A->val)
+                       (const IV *)A->jds_col, (const VV *)A->jds_val, x, y, seg_out, done, nlb, lt, A->col, (const T *)A->val, (const T *)ctx->spmv_ep_w, (const T *)ctx->spmv_ep_c)
 #define MIK_JDS_GO2(NTV)                                                                      \
     do {                                                                                      \
         if (inside) MIK_JDS_GO(true, NTV, false);                                             \
@@ -1560,7 +1564,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         }
 #define MIK_RG_GO(FD, NTV)                                                                                                      \
     hipLaunchKernelGGL((k_spmv_rowgather<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, rb0, nb, map_mode, A->rowptr, \
-                       A->col, (const T *)A->val, x, y, seg_out, done, A->is_long)
+                       A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, (const T *)ctx->spmv_ep_w, (const T *)ctx->spmv_ep_c)
         if (fuse_dot) { if (nt) MIK_RG_GO(true, true); else MIK_RG_GO(true, false); }
         else          { if (nt) MIK_RG_GO(false, true); else MIK_RG_GO(false, false); }
 #undef MIK_RG_GO
@@ -1590,7 +1594,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
 #define MIK_SPMV_GO(FD, NT, WD, MG, XW, RP)                                                                      \
     hipLaunchKernelGGL((k_spmv_rowblock<T, FD, NT, WD, MG, XW, RP>), grid, block, dyn, ctx->stream, n, nb, map_mode, A->rowptr, \
                        A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, nlb, lt, (const int *)A->xwin_lo, A->xwin_span, (const unsigned char *)A->rperm, \
-                       MG ? lwin : (const int *)nullptr, (MG && lwin && A->long_spread) ? -lw_launch : lw_launch)
+                       MG ? lwin : (const int *)nullptr, (MG && lwin && A->long_spread) ? -lw_launch : lw_launch, (const T *)ctx->spmv_ep_w, (const T *)ctx->spmv_ep_c)
 #define MIK_SPMV_GO3(FD, NT, MG)                                                          \
     do {                                                                                  \
         if (xwin) { if (rp) MIK_SPMV_GO(FD, NT, true, MG, true, true); else MIK_SPMV_GO(FD, NT, true, MG, true, false); }   \

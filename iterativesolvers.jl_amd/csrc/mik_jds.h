@@ -43,7 +43,8 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_jds(int n, int rb0, const in
                                                         const typename WideVec<T>::idx *__restrict__ jcol,
                                                         const typename WideVec<T>::val *__restrict__ jval, const T *__restrict__ x,
                                                         T *__restrict__ y, T *__restrict__ seg_out, const int *__restrict__ done, int nlb,
-                                                        LongTab lt, const int *__restrict__ col, const T *__restrict__ val)
+                                                        LongTab lt, const int *__restrict__ col, const T *__restrict__ val,
+                                                        const T *__restrict__ ep_w = nullptr, const T *__restrict__ ep_c = nullptr)
 {
     if (done && *done) return;
     constexpr int W = VT<T>::W, U = MIK_JDS_U;
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_jds(int n, int rb0, const in
                 acc = (g0 + u) * W + e < len ? s : acc;
             }
     }
+    if (FUSE_DOT && ep_w && pos < n) { const T te = *ep_c * ep_w[pos]; acc = acc + te; }   // y = A x + c w (the Lanczos step of MINRES; FUSE_DOT: no long rows)
     if (store) st_stream<NT>(y + pos, acc);
     if (FUSE_DOT) {            // no long rows: thread t holds the sum of row r0 + t -- the (1, 1) shape of include/mik.h
         __shared__ T lds4[4];

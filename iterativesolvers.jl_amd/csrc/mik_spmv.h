@@ -275,7 +275,8 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
                                                              const unsigned char *__restrict__ is_long, int nlb, LongTab lt,
                                                              const int *__restrict__ win_lo = nullptr, int win_span = 0,
                                                              const unsigned char *__restrict__ rperm = nullptr,
-                                                             const int *__restrict__ long_win = nullptr, int lw = 0)
+                                                             const int *__restrict__ long_win = nullptr, int lw = 0,
+                                                             const T *__restrict__ ep_w = nullptr, const T *__restrict__ ep_c = nullptr)
 {
     if (done && *done) return;
     constexpr int TILE = MIK_SPMV_TILE * (int)(8 / sizeof(T));   // 16 KB of LDS: 2048 fp64 / 4096 fp32 products
@@ -418,6 +419,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
         }
         __syncthreads();
     }
+    if (FUSE_DOT && ep_w && r < n) { const T te = *ep_c * ep_w[r]; acc = acc + te; }    // y = A x + c w (the Lanczos step of MINRES; operators without long rows)
     if (is_long && r < n && is_long[r]) acc = y[r];    // summed by k_spmv_longrows earlier on the stream
     else if (r < n) st_stream<NT>(y + r, acc);
     if (FUSE_DOT) {
@@ -455,7 +457,8 @@ template <typename T, bool FUSE_DOT, bool NT>
 __global__ __launch_bounds__(MIK_BLOCK, 6) void k_spmv_rowgather(int n, int rb0, int nb, int map_mode, const int *__restrict__ rowptr,
                                                               const int *__restrict__ col, const T *__restrict__ val,
                                                               const T *__restrict__ x, T *__restrict__ y, T *__restrict__ seg_out,
-                                                              const int *__restrict__ done, const unsigned char *__restrict__ is_long)
+                                                              const int *__restrict__ done, const unsigned char *__restrict__ is_long,
+                                                              const T *__restrict__ ep_w = nullptr, const T *__restrict__ ep_c = nullptr)
 {
     if (done && *done) return;
     constexpr int TILE = MIK_SPMV_TILE;                // entries per pass: 2048 (fp64: 16 KB values + 8 KB columns)
@@ -521,6 +524,7 @@ __global__ __launch_bounds__(MIK_BLOCK, 6) void k_spmv_rowgather(int n, int rb0,
         }
         if (kc + TILE < kend) __syncthreads();         // workgroup-uniform: another pass will overwrite the tile
     }
+    if (FUSE_DOT && ep_w && r < n) { const T te = *ep_c * ep_w[r]; acc = acc + te; }    // y = A x + c w (the Lanczos step of MINRES; operators without long rows)
     if (is_long && r < n && is_long[r]) acc = y[r];    // summed by k_spmv_longrows earlier on the stream
     else if (r < n) st_stream<NT>(y + r, acc);
     if (FUSE_DOT) {

@@ -120,6 +120,36 @@ def test_minres_device_bit_exact(pkg, orc, ctx, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("kind", ["csr", "fe"])
+def test_minres_lanczos_epilogue_in_the_csr_and_jagged_kernels(pkg, orc, ctx, dtype, kind):
+    """the Lanczos step as the SpMV's epilogue (y = A x - H[2] v_prev stored once, proj formed in the launch) also in k_spmv_rowgather
+    (the operator on its plain CSR arrays) and k_spmv_jds (a finite-element operator): bit-exact against the oracle with the
+    projection in the SpMV-dot tree"""
+    import scipy.sparse as sp
+    if kind == "csr":
+        A = orc.laplace(10, 3).astype(dtype)
+        dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
+        dA.set_layout("csr")
+        want_kernel = "k_spmv_rowgather"
+    else:
+        n, rowptr, colidx, val = pkg.fixtures.fe_matrix((12, 12), 3, dtype)
+        M = sp.csr_matrix((val, colidx, rowptr), shape=(n, n)).tocsc()
+        M.sort_indices()
+        A = orc.CSC(n, M.indptr.astype(np.int64), M.indices.astype(np.int64), M.data.astype(dtype), 0)
+        dA = pkg.HipCSR(n, n, rowptr, colidx, val, index_base=0, is_csc=False)
+        want_kernel = "k_spmv_jds"
+    assert dA.spmv_kernel() == want_kernel
+    b = orc.hashed_rhs(A.n).astype(dtype)
+    x = pkg.HipVector.from_numpy(np.zeros(A.n, dtype))
+    it = pkg.minres_iterable_(x, dA, pkg.HipVector.from_numpy(b), initially_zero=True, maxiter=30, reltol=0.0)
+    assert it.proj_shape() == ctx.spmv_dot_shape()
+    hist = np.array(list(it))
+    xo, ho = orc.minres(A, b, maxiter=30, reltol=0.0, mode="tree", shape=ctx.reduce_shape(dtype), proj_shape=it.proj_shape())
+    assert hist.size == 30 and np.array_equal(hist, ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
+
+
+@pytest.mark.gpu
 def test_minres_skew_symmetric_device(pkg, orc, ctx):
     rng = np.random.default_rng(123)
     n = 15
