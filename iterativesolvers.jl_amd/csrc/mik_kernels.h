@@ -414,6 +414,8 @@ template <typename T> struct OpAxpy {
 template <typename T> struct OpBicgU {
     static constexpr bool REDUCE = false;
     T *__restrict__ us; int64_t ldu; const T *__restrict__ rs; int64_t ldr; int ncols; Coef<T> neg_beta;
+    int nt = 0;    // 1: everything streamed except the store of the LAST column -- the input of the SpMV that follows, which the Infinity Cache
+                   // should keep (the SpMV of the CG loop takes 47 us on a cached input, 75 us behind a sweep that left its tails there)
     __device__ __forceinline__ void apply(int64_t i, T &) const
     {
         const T b = neg_beta.get();
@@ -424,16 +426,18 @@ template <typename T> struct OpBicgU {
         const T b = neg_beta.get();
         for (int q = 0; q < ncols; ++q) {
             T *u = us + q * ldu;
-            auto xv = vload(rs + q * ldr + i); auto yv = vload<T>(u + i);
+            auto xv = nt ? vload_nt(rs + q * ldr + i) : vload(rs + q * ldr + i);
+            auto yv = nt ? vload_nt<T>(u + i) : vload<T>(u + i);
 #pragma unroll
             for (int e = 0; e < VT<T>::W; ++e) { T t = b * el<T>(yv, e); el<T>(yv, e) = el<T>(xv, e) + t; }
-            vstore(u + i, yv);
+            if (nt && q + 1 < ncols) vstore_nt(u + i, yv); else vstore(u + i, yv);
         }
     }
 };
 template <typename T> struct OpBicgR {
     static constexpr bool REDUCE = false;
     const T *__restrict__ us; int64_t ldu; T *__restrict__ rs; int64_t ldr; int ncols; T *__restrict__ x; Coef<T> neg_alpha, alpha;
+    int nt = 0;    // 1: everything streamed except the store of the LAST residual column (the input of the SpMV that follows), as in OpBicgU
     __device__ __forceinline__ void apply(int64_t i, T &) const
     {
         const T na = neg_alpha.get(), a = alpha.get();
@@ -444,15 +448,17 @@ template <typename T> struct OpBicgR {
     {
         const T na = neg_alpha.get(), a = alpha.get();
         for (int q = 0; q < ncols; ++q) {
-            auto xv = vload(us + (q + 1) * ldu + i); auto yv = vload<T>(rs + q * ldr + i);
+            auto xv = nt ? vload_nt(us + (q + 1) * ldu + i) : vload(us + (q + 1) * ldu + i);
+            auto yv = nt ? vload_nt<T>(rs + q * ldr + i) : vload<T>(rs + q * ldr + i);
 #pragma unroll
             for (int e = 0; e < VT<T>::W; ++e) { T t = na * el<T>(xv, e); el<T>(yv, e) = el<T>(yv, e) + t; }
-            vstore(rs + q * ldr + i, yv);
+            if (nt && q + 1 < ncols) vstore_nt(rs + q * ldr + i, yv); else vstore(rs + q * ldr + i, yv);
         }
-        auto uv = vload(us + i); auto xx = vload<T>(x + i);
+        auto uv = nt ? vload_nt(us + i) : vload(us + i);
+        auto xx = nt ? vload_nt<T>(x + i) : vload<T>(x + i);
 #pragma unroll
         for (int e = 0; e < VT<T>::W; ++e) { T t = a * el<T>(uv, e); el<T>(xx, e) = el<T>(xx, e) + t; }
-        vstore(x + i, xx);
+        if (nt) vstore_nt(x + i, xx); else vstore(x + i, xx);
     }
 };
 
@@ -664,7 +670,9 @@ template <typename T> struct OpMinresUpdate {
     T *__restrict__ v_next; const T *__restrict__ v_curr; const T *__restrict__ w_curr; const T *__restrict__ w_prev;
     T *__restrict__ w_next; T *__restrict__ x;
     Coef<T> inv_h3, neg_h1, neg_h0, inv_h2, rhs0;     // host values, or left on the device by the iteration's own scalar kernel (mik_minres_step)
-    int nt = 0;                                       // bit 0: x streamed, bit 1: w_prev streamed (dead afterwards)
+    int nt = 0;                                       // bit 0: x streamed, bit 1: w_prev streamed (dead afterwards), bit 2: w_next stored streamed and
+                                                      // bit 3: w_curr loaded streamed (both idle until the next tail) -- the Infinity Cache then keeps v_next and
+                                                      // v_curr, which the next SpMV (its input and its epilogue vector) reads
     __device__ __forceinline__ void apply(int64_t i, T &) const
     {
         v_next[i] = v_next[i] * inv_h3.get();
@@ -680,7 +688,7 @@ template <typename T> struct OpMinresUpdate {
         auto vn = vload<T>(v_next + i); auto w = vload(v_curr + i);
         auto xv = (nt & 1) ? vload_nt<T>(x + i) : vload<T>(x + i);
         typename VT<T>::vec wc, wp;
-        if (w_curr) wc = vload(w_curr + i);
+        if (w_curr) wc = (nt & 8) ? vload_nt(w_curr + i) : vload(w_curr + i);
         if (w_prev) wp = (nt & 2) ? vload_nt(w_prev + i) : vload(w_prev + i);
         const T c3 = inv_h3.get(), c1 = w_curr ? neg_h1.get() : T(0), c0 = w_prev ? neg_h0.get() : T(0), c2 = inv_h2.get(), cr = rhs0.get();
 #pragma unroll
@@ -693,7 +701,8 @@ template <typename T> struct OpMinresUpdate {
             el<T>(w, e) = we;
             T t = cr * we; el<T>(xv, e) = el<T>(xv, e) + t;
         }
-        vstore(v_next + i, vn); vstore(w_next + i, w);
+        vstore(v_next + i, vn);
+        if (nt & 4) vstore_nt(w_next + i, w); else vstore(w_next + i, w);
         if (nt & 1) vstore_nt(x + i, xv); else vstore(x + i, xv);
     }
 };

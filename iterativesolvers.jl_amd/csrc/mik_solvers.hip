@@ -304,27 +304,28 @@ template <typename T> static int bicg_step_impl(mik_bicgstab *it, T *residual)
     auto ldiv = [&](T *v) { return it->pl_diag ? mik_divide(ctx, it->dtype, n, v, it->pl_diag, v) : MIK_OK; };
     const bool blockvec = mik_aligned16(us) && mik_aligned16(rs) && mik_aligned16(x) && (it->ldu % VT<T>::W == 0) && (it->ldr % VT<T>::W == 0);
     const bool lean = nseg <= 1024 && ctx->tuning[25] == 0;   // the sweeps finalise their producers' reductions themselves (k_map_with; development knob 25 = 1: separate finaliser launches)
+    const int bnt = ctx->tuning[7] < 0 ? 0 : 1;               // the block sweeps stream everything but the input of the SpMV behind them (development knob 7 < 0: all cached)
     for (int j = 0; j < l; ++j) {                                                            // BiCG part  :88
         MIK_TRY(dot_partials(sh, col(rs, it->ldr, j)));                                      // :89
         if (lean) {                                                                          // :90, :93 -- us = rs - beta * us, all j + 1 columns
-            OpBicgU<T> op{us, it->ldu, rs, it->ldr, j + 1, Coef<T>{nullptr, T(0)}};
+            OpBicgU<T> op{us, it->ldu, rs, it->ldr, j + 1, Coef<T>{nullptr, T(0)}, bnt};
             MIK_TRY((launch_map_with<T>(ctx, n, op, ProBicgRho<T>{d, j == 0 ? 1 : 0}, blockvec, (const T *)ctx->partials, (int)nseg, (T *)nullptr)));
         } else {
             hipLaunchKernelGGL((k_bicg_fin_rho<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, d, j == 0 ? 1 : 0);
             MIK_LAUNCH_CHECK(ctx);
-            OpBicgU<T> op{us, it->ldu, rs, it->ldr, j + 1, coef_ptr<T>(&d->neg_beta)};
+            OpBicgU<T> op{us, it->ldu, rs, it->ldr, j + 1, coef_ptr<T>(&d->neg_beta), bnt};
             MIK_TRY((launch_map<T>(ctx, n, op, blockvec, (T *)nullptr, nullptr)));
         }
         MIK_TRY(mik_spmv_launch<T>(ctx, it->A, col(us, it->ldu, j), col(us, it->ldu, j + 1), false, nullptr, nullptr));   // :97
         MIK_TRY(ldiv(col(us, it->ldu, j + 1)));                                              // :98
         MIK_TRY(dot_partials(sh, col(us, it->ldu, j + 1)));                                  // :100
         if (lean) {                                                                          // :101, :103, :111 (x does not depend on :107)
-            OpBicgR<T> op{us, it->ldu, rs, it->ldr, j + 1, x, Coef<T>{nullptr, T(0)}, Coef<T>{nullptr, T(0)}};
+            OpBicgR<T> op{us, it->ldu, rs, it->ldr, j + 1, x, Coef<T>{nullptr, T(0)}, Coef<T>{nullptr, T(0)}, bnt};
             MIK_TRY((launch_map_with<T>(ctx, n, op, ProBicgSigma<T>{d}, blockvec, (const T *)ctx->partials, (int)nseg, (T *)nullptr)));
         } else {
             hipLaunchKernelGGL((k_bicg_fin_sigma<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, d);
             MIK_LAUNCH_CHECK(ctx);
-            OpBicgR<T> op{us, it->ldu, rs, it->ldr, j + 1, x, coef_ptr<T>(&d->neg_alpha), coef_ptr<T>(&d->alpha)};
+            OpBicgR<T> op{us, it->ldu, rs, it->ldr, j + 1, x, coef_ptr<T>(&d->neg_alpha), coef_ptr<T>(&d->alpha), bnt};
             MIK_TRY((launch_map<T>(ctx, n, op, blockvec, (T *)nullptr, nullptr)));
         }
         MIK_TRY(mik_spmv_launch<T>(ctx, it->A, col(rs, it->ldr, j), col(rs, it->ldr, j + 1), false, nullptr, nullptr));   // :107
@@ -652,7 +653,7 @@ template <typename T> static int minres_step_impl(mik_minres *it, int64_t iterat
     auto tail = [&]() {   // v_next /= H[4]; w_next = (v_curr - H[2] w_curr - H[1] w_prev) / H[3]; x += rhs[1] w_next   :113, :136-142
         const T *wc = iteration > 1 ? w_curr : nullptr, *wp = iteration > 2 ? w_prev : nullptr;
         OpMinresUpdate<T> op{v_next, v_curr, wc, wp, w_next, x, coef_ptr<T>(&d->inv_h3), coef_ptr<T>(&d->neg_h1), coef_ptr<T>(&d->neg_h0),
-                             coef_ptr<T>(&d->inv_h2), coef_ptr<T>(&d->rhs0), 3};
+                             coef_ptr<T>(&d->inv_h2), coef_ptr<T>(&d->rhs0), ctx->tuning[7] > 0 ? ctx->tuning[7] : (ctx->tuning[7] < 0 ? 0 : 15)};   // development knob 7: hint mask
         const bool vec = mik_aligned16(v_next) && mik_aligned16(v_curr) && mik_aligned16(w_next) && mik_aligned16(x) && (!wc || mik_aligned16(wc)) &&
                          (!wp || mik_aligned16(wp));
         return launch_map<T>(ctx, n, op, vec, (T *)nullptr, (const int *)&d->range);     // held back while the norm is being rescaled
