@@ -11,6 +11,7 @@
 // ~20 launches of a few microseconds each, and the host round trips were most of its time.
 #include "mik_internal.h"
 #include "mik_kernels.h"
+#include "mik_iter.h"
 
 #include <cmath>
 #include <limits>
@@ -489,6 +490,15 @@ __global__ __launch_bounds__(MIK_FIN_THREADS) void k_minres_fin_proj(const T *__
     if (threadIdx.x == 0) { d->H[2] = tot; d->neg_proj = -tot; }
 }
 
+// the same over many partials (one per 256-row block when the SpMV forms proj): 16 single-wave workgroups and a ticket, as k_cg_fin_alpha --
+// a single 1024-thread workgroup pulls 65,536 partials through one CU (11 us at 256^3 instead of 5)
+template <typename T>
+__global__ __launch_bounds__(64) void k_minres_fin_proj_spread(const T *__restrict__ S, int64_t m, MinresDev<T> *d, FinScratch<T> *fs)
+{
+    T tot;
+    if (level2_sum_spread(S, m, fs, tot)) { d->H[2] = tot; d->neg_proj = -tot; }
+}
+
 // H[4] = norm(v_next) (:112), then the scalar part of the iteration
 template <typename T>
 __global__ __launch_bounds__(MIK_FIN_THREADS) void k_minres_fin_norm(const T *__restrict__ S, int64_t m, MinresDev<T> *d, long long iteration, int skew,
@@ -531,6 +541,7 @@ struct mik_minres {
     MinresMirror *mirror = nullptr;
     unsigned long long seq = 0;
     bool epilogue = false;          // the Lanczos step rides on the SpMV (mik_spmv_has_epilogue): proj has the SpMV-dot shape
+    void *fin = nullptr;            // FinScratch<T>: wave sums + ticket of the spread level-2 sum of proj
 };
 
 extern "C" int mik_minres_destroy(mik_minres *it)
@@ -540,6 +551,7 @@ extern "C" int mik_minres_destroy(mik_minres *it)
     (void)hipSetDevice(it->ctx->device);
     (void)hipStreamSynchronize(it->ctx->stream);
     if (it->dev) (void)hipFree(it->dev);
+    if (it->fin) (void)hipFree(it->fin);
     if (it->mirror) (void)hipHostFree(it->mirror);
     delete it;
     return MIK_OK;
@@ -562,7 +574,7 @@ extern "C" int mik_minres_create(mik_ctx *ctx, const mik_csr *A, void *x, void *
     (void)hipSetDevice(ctx->device);
     hipError_t e;
     const size_t db = A->dtype == MIK_F64 ? sizeof(MinresDev<double>) : sizeof(MinresDev<float>);
-    if ((e = hipMalloc(&it->dev, db)) != hipSuccess ||
+    if ((e = hipMalloc(&it->dev, db)) != hipSuccess || (e = hipMalloc(&it->fin, 512)) != hipSuccess || (e = hipMemset(it->fin, 0, 512)) != hipSuccess ||
         (e = hipHostMalloc((void **)&it->mirror, sizeof(MinresMirror), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) {
         const int rc = mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_minres_create: %s", hipGetErrorString(e));
         mik_minres_destroy(it);
@@ -637,7 +649,8 @@ template <typename T> static int minres_step_impl(mik_minres *it, int64_t iterat
         MIK_TRY((launch_map<T>(ctx, n, op, vec, part_a, nullptr)));
     }
     if (!lean) {
-        hipLaunchKernelGGL((k_minres_fin_proj<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)part_a, na, d);
+        if (na > 16384) hipLaunchKernelGGL((k_minres_fin_proj_spread<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)part_a, na, d, (FinScratch<T> *)it->fin);
+        else hipLaunchKernelGGL((k_minres_fin_proj<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)part_a, na, d);
         MIK_LAUNCH_CHECK(ctx);
     }
     it->seq += 1;
