@@ -38,6 +38,17 @@ def test_irregular_spmv_bit_exact(pkg, orc, ctx, dtype):
     short = lens <= ctx.spmv_long_row()
     assert np.array_equal(y[short], yseq[short]) and not np.array_equal(y[~short], yseq[~short])
     np.testing.assert_allclose(y, yseq, rtol=1e-4 if dtype == np.float32 else 1e-12, atol=1e-4 if dtype == np.float32 else 1e-12)
+    # ... and both orders sit inside the forward-error bound of the reference's own loop (len * eps * sum |a_ij x_j|, Higham 3.1)
+    # around the sum in extended precision; over the long rows the wave shape is the more accurate of the two
+    S = sp.csr_matrix((val.astype(np.longdouble).astype(np.float64), colidx, rowptr), shape=(n, n))
+    exact = np.array([np.sum(val[rowptr[i]:rowptr[i + 1]].astype(np.longdouble) * x[colidx[rowptr[i]:rowptr[i + 1]]].astype(np.longdouble))
+                      for i in np.flatnonzero(~short)])
+    mag = np.asarray(abs(S) @ np.abs(x.astype(np.float64)))[~short]
+    bound = lens[~short] * np.finfo(dtype).eps * mag
+    err_dev = np.abs(y[~short].astype(np.longdouble) - exact).astype(np.float64)
+    err_seq = np.abs(yseq[~short].astype(np.longdouble) - exact).astype(np.float64)
+    assert np.all(err_dev <= bound) and np.all(err_seq <= bound)
+    assert np.sqrt(np.mean((err_dev / mag) ** 2)) <= np.sqrt(np.mean((err_seq / mag) ** 2))
 
 
 def test_irregular_gmres_fp32_restart50(pkg, orc, ctx):

@@ -224,3 +224,38 @@ def test_long_row_shape_against_a_python_restatement(orc, dtype, group):
                 off //= 2
             tot = lanes[0] if tot is None else T(tot + lanes[0])
         assert y[r] == tot, (r, lens[r])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_long_row_shape_stays_inside_the_error_bound_of_the_sequential_loop(orc, dtype):
+    """What "rows beyond mik_spmv_long_row() differ from src's sequential mul! by rounding only" means in numbers: against the row
+    sum in extended precision, the wave shape AND the reference's left-to-right loop both sit inside the forward-error bound of that
+    loop (len * eps * sum |a_ij x_j|), and over the long rows the wave shape is the more accurate one."""
+    import scipy.sparse as sp
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("mik_fixtures", os.path.join(os.path.dirname(__file__), "..", "iterativesolvers.jl_amd", "fixtures.py"))
+    fx = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fx)
+    n, rowptr, colidx, val = fx.irregular_matrix(20000, dtype)
+    lens = np.diff(rowptr)
+    M = sp.csr_matrix((val, colidx, rowptr), shape=(n, n)).tocsc()
+    M.sort_indices()
+    A = orc.CSC(n, M.indptr.astype(np.int64), M.indices.astype(np.int64), M.data.copy(), 0)
+    x = np.random.default_rng(2).standard_normal(n).astype(dtype)
+    orc.set_long_row(256, 1024, 4)             # the library's defaults (mik_spmv_long_row / _segment / _group)
+    try:
+        y = orc.spmv(A, x)
+    finally:
+        orc.set_long_row(0)
+    yseq = orc.spmv(A, x)
+    long_rows = np.flatnonzero(lens > 256)
+    assert long_rows.size >= 10 and np.array_equal(np.delete(y, long_rows), np.delete(yseq, long_rows))
+    exact = np.array([np.sum(val[rowptr[i]:rowptr[i + 1]].astype(np.longdouble) * x[colidx[rowptr[i]:rowptr[i + 1]]].astype(np.longdouble)) for i in long_rows])
+    S = sp.csr_matrix((np.abs(val.astype(np.float64)), colidx, rowptr), shape=(n, n))
+    mag = np.asarray(S @ np.abs(x.astype(np.float64)))[long_rows]
+    bound = lens[long_rows] * np.finfo(dtype).eps * mag
+    err_wave = np.abs(y[long_rows].astype(np.longdouble) - exact).astype(np.float64)
+    err_seq = np.abs(yseq[long_rows].astype(np.longdouble) - exact).astype(np.float64)
+    assert np.all(err_wave <= bound) and np.all(err_seq <= bound)
+    assert np.sqrt(np.mean((err_wave / mag) ** 2)) <= np.sqrt(np.mean((err_seq / mag) ** 2))
