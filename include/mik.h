@@ -323,17 +323,24 @@ int mik_bicgstab_mr_update(mik_ctx *ctx, int dtype, int64_t n, int l, void *us, 
 /* One whole outer iteration of BiCGStab(l) -- iterate(::BiCGStabIterable), src/bicgstabl.jl:79-134 -- per call, with rho, beta,
  * sigma, alpha, the Gram matrix, gamma and omega kept on the device: the host waits once, for the residual norm it returns
  * (the statement-by-statement form through mik_dot / mik_xpby / mik_spmv / mik_axpy / mik_gram / mik_lu_solve /
- * mik_bicgstab_mr_update waits 2 l + 3 times; both produce the same bits).  The caller owns x, the residual block rs and the
+ * mik_bicgstab_mr_update waits 2 l + 3 times; the same bits wherever mik_bicgstab_dot_shape reports the vector shape).  The caller owns x, the residual block rs and the
  * search block us (n x (l + 1), column-major, leading dimensions ldr / ldu) as set up by bicgstabl_iterator!
  * (src/bicgstabl.jl:25-73: rs[:, 1] = Pl \ (b - A x), us = 0) and the shadow residual r_shadow (:38); pl_diag: the diagonal
  * of a Jacobi Pl (ldiv! = elementwise division, :98, :108) or NULL for Identity.  omega = sigma = 1 at creation (:59).
- * l = 1 ... 4.  MIK_ERR_SINGULAR when lu! meets an exactly singular pivot (the reference throws SingularException); the handle is
+ * l = 1 ... 4.  Between two steps of a handle the blocks are the handle's state (as the fields of the reference's iterable are): the MR sweep of a
+ * step leaves the segment sums of dot(r_shadow, rs[:, 1]) -- rho of the next step's first column (:89) -- with the handle.
+ * MIK_ERR_SINGULAR when lu! meets an exactly singular pivot (the reference throws SingularException); the handle is
  * then latched: every later mik_bicgstab_step reports MIK_ERR_SINGULAR again (its device scalars are not steppable).  Handles a host
  * never destroys are freed by mik_ctx_destroy of their context (a finalizer that finds the context closed must skip the destroy call). */
 typedef struct mik_bicgstab mik_bicgstab;
 int mik_bicgstab_create(mik_ctx *ctx, const mik_csr *A, int l, void *x, void *rs, int64_t ldr, void *us, int64_t ldu,
                         const void *r_shadow, const void *pl_diag, mik_bicgstab **out);
 int mik_bicgstab_step(mik_bicgstab *it, void *residual);          /* residual: one scalar of A's element type */
+/* (W, L) of the reduction tree of sigma = dot(r_shadow, A u) (src/bicgstabl.jl:100) and of rho = dot(r_shadow, rs[:, j]) for j >= 2 (:89)
+ * inside mik_bicgstab_step: where the operator's SpMV kernel takes a dot epilogue and Pl = Identity, both are formed in the SpMV launch
+ * that produces the vector, one partial per 256-row block (mik_spmv_dot_shape); else the vector shape (mik_reduce_shape), which rho of
+ * the first column and the Gram matrix always have.  The oracle takes it. */
+int mik_bicgstab_dot_shape(const mik_bicgstab *it, int *W, int *L);
 int mik_bicgstab_destroy(mik_bicgstab *it);
 
 /* One whole iteration of MINRES -- iterate(::MINRESIterable), src/minres.jl:95-159 -- per call: mul!, the Lanczos step with its

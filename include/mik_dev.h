@@ -30,7 +30,8 @@ extern "C" {
  *  20: 1 = mik_csr_create on the host path only, 2 = device transpose but the host builders of layouts 6 / 1                 21: DGKS rounds inside the single-launch kernel (1..3; read at mik_gmres_create)
  *  22: 1 = PCG with a diagonal Pl as three vector sweeps (c = Pl \\ r and rho apart) instead of two (read at mik_cg_create)
  *  23: 1 = CG updates x in the step's own sweep (read at mik_cg_create)      24: 1 = the halo of a row-partitioned CG step after the whole sweep over u
- *  25: 1 = mik_bicgstab_step / mik_minres_step with separate finaliser launches at every size (the form used beyond 1,024 reduction segments)
+ *  25: 1 = mik_bicgstab_step / mik_minres_step with separate finaliser launches at every size (the form used beyond 1,024 reduction segments);
+ *      2 = no SpMV epilogues (the Lanczos step of MINRES, sigma / rho of BiCGStab(l) as sweeps of their own in the vector shape; no rho kept from the MR sweep)
  *  26: 1 = row-partitioned CG step with the separate alpha launch (k_cgd_alpha) instead of alpha formed inside the update sweep
  *  31: 1 = GMRES without the single-launch Gram-Schmidt kernels (read at mik_gmres_create)
  *  30: 1 = treat the next single-launch Gram-Schmidt column as timed out (exercises the fall-back to the multi-launch chains)

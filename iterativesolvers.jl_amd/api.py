@@ -1099,6 +1099,16 @@ class BiCGStabIterable:
         if isinstance(self.Pl, JacobiPrec):
             self.Pl.ldiv_(v)
 
+    def dot_shape(self):
+        """(W, L) of the reduction tree of ``sigma = dot(r_shadow, A u)`` (src/bicgstabl.jl:100) and of ``rho`` from the second column on
+        (:89): the SpMV-dot shape where the whole-iteration call forms them in the SpMV launch (``mik_bicgstab_dot_shape``), the vector
+        shape otherwise -- what the oracle's ``dot_shape`` takes."""
+        if self._step is None:
+            return self.x.ctx.reduce_shape(self.x.dtype)
+        w, l = C.c_int(), C.c_int()
+        check(lib().mik_bicgstab_dot_shape(self._step, C.byref(w), C.byref(l)), "mik_bicgstab_dot_shape", self.x.ctx.handle)
+        return w.value, l.value
+
     def converged(self) -> bool:                                             # :75
         return self.residual <= self.tol
 

@@ -1329,7 +1329,7 @@ static bool sdiab2_applies(const mik_csr *A)
 }
 
 // k_spmv_sdiab2, the two CSR kernels and the jagged slices (whole launches with the fused dot, no split-off long rows) take the epilogue
-// y = A x + c w, dot(x, y) -- the Lanczos step of MINRES
+// y = A x + c w, dot(x, y) -- the Lanczos step of MINRES -- and dot(z, y) in place of dot(x, y) -- sigma and rho of BiCGStab(l)
 bool mik_spmv_has_epilogue(const mik_csr *A)
 {
     if (!A || A->ctx->tuning[25] == 2) return false;                    // development knob 25 = 2: never
@@ -1421,8 +1421,8 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
     if (!whole && map_mode >= 8 && (rb0 % map_mode != 0 || nb % map_mode != 0)) map_mode = 0;   // strips need whole planes
     if (skip_len > 0) map_mode = 0;
     const int choice = spmv_kernel_choice(A);
-    if ((ctx->spmv_ep_w || ctx->spmv_ep_c) && !(whole && fuse_dot && mik_spmv_has_epilogue(A)))
-        return mik_fail(ctx, MIK_ERR_NOTIMPL, "SpMV: the y = A x + c w epilogue is not available for this operator's kernel");
+    if ((ctx->spmv_ep_w || ctx->spmv_ep_c || ctx->spmv_ep_z) && !(whole && fuse_dot && mik_spmv_has_epilogue(A)))
+        return mik_fail(ctx, MIK_ERR_NOTIMPL, "SpMV: the y = A x + c w / dot(z, y) epilogue is not available for this operator's kernel");
     if (choice == 5) {
         // slice patterns {offsets, values} + one mask byte per row (mik_sell.h); G slices per workgroup
         const int G = ctx->tuning[16] > 0 ? ctx->tuning[16] : MIK_SDIAC_G;   // development knob 16: 1 / 2 / 4 slices per workgroup
@@ -1450,7 +1450,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
 #define MIK_SDIAB2_GO4(FD, NTV, C)                                                                                                       \
     hipLaunchKernelGGL((k_spmv_sdiab2<T, FD, NTV, mik_sdiab_cls_ns(C), mik_sdiab_cls_cq(C)>), dim3(wg2), dim3(MIK_BLOCK), 0, ctx->stream, n, (int)A->n_cols, A->sdia_koff, \
                        pb0, np, pfull, ps, nb_all, ctx->sweep_rev, (const SdiaSliceRec *)A->sdia_recs, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done, \
-                       (const T *)ctx->spmv_ep_w, (const T *)ctx->spmv_ep_c)
+                       (const T *)ctx->spmv_ep_w, (const T *)ctx->spmv_ep_c, (const T *)ctx->spmv_ep_z)
 #define MIK_SDIAB2_GO(FD, NTV) do { if (cls == 1) MIK_SDIAB2_GO4(FD, NTV, 1); else if (cls == 2) MIK_SDIAB2_GO4(FD, NTV, 2); else MIK_SDIAB2_GO4(FD, NTV, 3); } while (0)
                 if (fuse_dot) { if (nt) MIK_SDIAB2_GO(true, true); else MIK_SDIAB2_GO(true, false); }
                 else          { if (nt) MIK_SDIAB2_GO(false, true); else MIK_SDIAB2_GO(false, false); }
@@ -1535,7 +1535,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         const bool inside = fuse_dot && nlong == 0;
 #define MIK_JDS_GO(FD, NTV, MG)                                                                                                        \
     hipLaunchKernelGGL((k_spmv_jds<T, FD, NTV, MG>), dim3(nb + (MG ? nlb : 0)), dim3(MIK_BLOCK), 0, ctx->stream, n, rb0, A->jds_ptr, A->jds_len, \
-                       (const IV *)A->jds_col, (const VV *)A->jds_val, x, y, seg_out, done, nlb, lt, A->col, (const T *)A->val, (const T *)ctx->spmv_ep_w, (const T *)ctx->spmv_ep_c)
+                       (const IV *)A->jds_col, (const VV *)A->jds_val, x, y, seg_out, done, nlb, lt, A->col, (const T *)A->val, (const T *)ctx->spmv_ep_w, (const T *)ctx->spmv_ep_c, (const T *)ctx->spmv_ep_z)
 #define MIK_JDS_GO2(NTV)                                                                      \
     do {                                                                                      \
         if (inside) MIK_JDS_GO(true, NTV, false);                                             \
@@ -1564,7 +1564,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         }
 #define MIK_RG_GO(FD, NTV)                                                                                                      \
     hipLaunchKernelGGL((k_spmv_rowgather<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, rb0, nb, map_mode, A->rowptr, \
-                       A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, (const T *)ctx->spmv_ep_w, (const T *)ctx->spmv_ep_c)
+                       A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, (const T *)ctx->spmv_ep_w, (const T *)ctx->spmv_ep_c, (const T *)ctx->spmv_ep_z)
         if (fuse_dot) { if (nt) MIK_RG_GO(true, true); else MIK_RG_GO(true, false); }
         else          { if (nt) MIK_RG_GO(false, true); else MIK_RG_GO(false, false); }
 #undef MIK_RG_GO
@@ -1594,7 +1594,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
 #define MIK_SPMV_GO(FD, NT, WD, MG, XW, RP)                                                                      \
     hipLaunchKernelGGL((k_spmv_rowblock<T, FD, NT, WD, MG, XW, RP>), grid, block, dyn, ctx->stream, n, nb, map_mode, A->rowptr, \
                        A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, nlb, lt, (const int *)A->xwin_lo, A->xwin_span, (const unsigned char *)A->rperm, \
-                       MG ? lwin : (const int *)nullptr, (MG && lwin && A->long_spread) ? -lw_launch : lw_launch, (const T *)ctx->spmv_ep_w, (const T *)ctx->spmv_ep_c)
+                       MG ? lwin : (const int *)nullptr, (MG && lwin && A->long_spread) ? -lw_launch : lw_launch, (const T *)ctx->spmv_ep_w, (const T *)ctx->spmv_ep_c, (const T *)ctx->spmv_ep_z)
 #define MIK_SPMV_GO3(FD, NT, MG)                                                          \
     do {                                                                                  \
         if (xwin) { if (rp) MIK_SPMV_GO(FD, NT, true, MG, true, true); else MIK_SPMV_GO(FD, NT, true, MG, true, false); }   \

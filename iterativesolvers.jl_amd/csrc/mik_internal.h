@@ -44,6 +44,7 @@ struct mik_ctx {
     static constexpr size_t PUB_BYTES = 4096;
     int sweep_rev = 0;               // 1: the next SpMV launch walks its row-blocks from the end (set and cleared by the CG step)
     const void *spmv_ep_w = nullptr, *spmv_ep_c = nullptr;   // the next fused-dot SpMV launch stores y = A x + (*c) w and sums x .* y (set and cleared by mik_minres_step)
+    const void *spmv_ep_z = nullptr;                         // ... and sums z .* y instead of x .* y (dot(r_shadow, A u) of BiCGStab(l): set and cleared by mik_bicgstab_step)
     int tuning[32] = {0};            // development knobs of THIS context (include/mik_dev.h): a copy of the defaults at creation, mik_ctx_set_tuning
     static constexpr size_t COEF_BYTES = 8192;      // [0, 4096): coefficient blocks of the callers; the tail: scratch of mik_safe_norm_slow
     static constexpr size_t COEF_SAFE_SLOT = 4096;  // byte offset of that scratch

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_jds(int n, int rb0, const in
                                                         const typename WideVec<T>::val *__restrict__ jval, const T *__restrict__ x,
                                                         T *__restrict__ y, T *__restrict__ seg_out, const int *__restrict__ done, int nlb,
                                                         LongTab lt, const int *__restrict__ col, const T *__restrict__ val,
-                                                        const T *__restrict__ ep_w = nullptr, const T *__restrict__ ep_c = nullptr)
+                                                        const T *__restrict__ ep_w = nullptr, const T *__restrict__ ep_c = nullptr,
+                                                        const T *__restrict__ ep_z = nullptr)
 {
     if (done && *done) return;
     constexpr int W = VT<T>::W, U = MIK_JDS_U;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_jds(int n, int rb0, const in
     if (FUSE_DOT) {            // no long rows: thread t holds the sum of row r0 + t -- the (1, 1) shape of include/mik.h
         __shared__ T lds4[4];
         T p = T(0);
-        if (pos < n) p = x[pos] * acc;
+        if (pos < n) p = (ep_z ? ep_z[pos] : x[pos]) * acc;   // ep_z: dot(z, y) instead of dot(x, y) (BiCGStab(l): z = r_shadow)
         const T tot = block_tree_256(p, lds4);
         if (t == 0) seg_out[rb] = tot;
     }

@@ -1342,11 +1342,14 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_gram(int64_t n, int64_t nseg, con
 //   us_0 -= sum_{j=1..l} gamma_j us_j;  x += sum_{j=0..l-1} gamma_{j+1} rs_j;  rs_0 -= sum_{j=1..l} gamma_j rs_j;
 //   partial sums of rs_0.^2.  Same per-element operations and order as the three mul!(y, V, c, alpha, 1) calls
 //   (k_gemv_n: temp = alpha * c[j]; y = y + temp * V[:, j], j ascending); x uses rs_0 before its update.
+//   sh != nullptr: also the segment sums of sh .* rs_0 (the new residual) at seg_out2 -- rho of the NEXT outer iteration's first
+//   column (src/bicgstabl.jl:89), the products and the tree of OpDot, without the sweep over two vectors.
 template <typename T> struct BicgGamma { T g[8]; };
 template <typename T, bool VEC>
 __global__ __launch_bounds__(MIK_BLOCK) void k_bicg_mr(int64_t n, int64_t nseg, int l, T *__restrict__ us, int64_t ldu,
                                                        T *__restrict__ rs, int64_t ldr, T *__restrict__ x, BicgGamma<T> gm,
-                                                       T *__restrict__ seg_out, const T *__restrict__ gamma_dev)
+                                                       T *__restrict__ seg_out, const T *__restrict__ gamma_dev,
+                                                       const T *__restrict__ sh = nullptr, T *__restrict__ seg_out2 = nullptr)
 {
     constexpr int W = VT<T>::W;
     constexpr int L = MIK_RED_L;
@@ -1358,7 +1361,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_bicg_mr(int64_t n, int64_t nseg, 
     }
     for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
         const int64_t base = s * SEG + (int64_t)W * threadIdx.x;
-        T acc = T(0);
+        T acc = T(0), acc2 = T(0);
 #pragma unroll
         for (int lq = 0; lq < L; ++lq) {
             const int64_t i0 = base + (int64_t)lq * MIK_BLOCK * W;
@@ -1420,9 +1423,24 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_bicg_mr(int64_t n, int64_t nseg, 
 #pragma unroll
             for (int e = 0; e < W; ++e)
                 if (i0 + e < n) { T p = r0[e] * r0[e]; acc = acc + p; }
+            if (sh) {
+                if (full) {
+                    auto hv = vload(sh + i0);
+#pragma unroll
+                    for (int e = 0; e < W; ++e) { T p = el<T>(hv, e) * r0[e]; acc2 = acc2 + p; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < W; ++e)
+                        if (i0 + e < n) { T p = sh[i0 + e] * r0[e]; acc2 = acc2 + p; }
+                }
+            }
         }
         T tot = block_tree_256(acc, lds4);
         if (threadIdx.x == 0) seg_out[s] = tot;
+        if (sh) {
+            tot = block_tree_256(acc2, lds4);
+            if (threadIdx.x == 0) seg_out2[s] = tot;
+        }
     }
 }
 

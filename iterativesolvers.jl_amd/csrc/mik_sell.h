@@ -478,7 +478,8 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab2(int n, int ncols, int
                                                            const SdiaSliceRec *__restrict__ recs, const SdiaPattern<T> *__restrict__ pats,
                                                            const unsigned char *__restrict__ mask, const T *__restrict__ x, T *__restrict__ y,
                                                            T *__restrict__ seg_out, const int *__restrict__ done,
-                                                           const T *__restrict__ ep_w = nullptr, const T *__restrict__ ep_c = nullptr)
+                                                           const T *__restrict__ ep_w = nullptr, const T *__restrict__ ep_c = nullptr,
+                                                           const T *__restrict__ ep_z = nullptr)
 {
     static_assert(NS >= 3 && CQ >= 1 && CQ + 1 < NS, "the class must have slots around the centre");
     if (done && *done) return;
@@ -576,6 +577,12 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab2(int n, int ncols, int
         acc0 = acc0 + t0; acc1 = acc1 + t1;
     }
     buffer_put2<T>(ys, rowoff, acc0, acc1, NT);
+    if (FUSE_DOT && ep_z) {
+        // dot(z, y) instead of dot(x, y): sigma = dot(r_shadow, A u) and rho = dot(r_shadow, A r) of BiCGStab(l) (src/bicgstabl.jl:100, :89)
+        const __amdgpu_buffer_rsrc_t zsr = __builtin_amdgcn_make_buffer_rsrc((void *)ep_z, (short)0, (int)((unsigned)n * ES), (int)0x00020000);
+        const Pair2<T> zv = buffer_gather2<T>(zsr, rowoff, 0);             // a pair past the end reads +0
+        xr0 = zv.a; xr1 = zv.b;
+    }
     if (FUSE_DOT) {
         T s0 = xr0 * acc0, s1 = xr1 * acc1;                                // a pair past the end: 0 * +0
         s0 = s0 + lane_down<16>(s0); s1 = s1 + lane_down<16>(s1);

@@ -133,6 +133,31 @@ __global__ __launch_bounds__(MIK_FIN_THREADS) void k_bicg_fin_sigma(const T *__r
     }
 }
 
+// the same two over one partial per 256-row block (rho / sigma formed in the SpMV launch: 65,536 partials at 256^3): 16 single-wave
+// workgroups and a ticket, as k_cg_fin_alpha
+template <typename T>
+__global__ __launch_bounds__(64) void k_bicg_fin_rho_spread(const T *__restrict__ S, int64_t m, BicgDev<T> *d, int first, FinScratch<T> *fs)
+{
+    T tot;
+    if (level2_sum_spread(S, m, fs, tot)) {
+        if (first) { const T p = d->omega * d->sigma; d->sigma = -p; }
+        d->rho = tot;
+        const T beta = tot / d->sigma;
+        d->neg_beta = -beta;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(64) void k_bicg_fin_sigma_spread(const T *__restrict__ S, int64_t m, BicgDev<T> *d, FinScratch<T> *fs)
+{
+    T tot;
+    if (level2_sum_spread(S, m, fs, tot)) {
+        d->sigma = tot;
+        const T alpha = d->rho / tot;
+        d->alpha = alpha;
+        d->neg_alpha = -alpha;
+    }
+}
+
 // F = lu!(view(M, L, L)); ldiv!(gamma, F, view(M, L, 1)); omega = gamma[l]   (:123-125, :131) -- lu_solve of mik_krylov.hip, on
 // the packed upper triangle the Gram finaliser left (row r, columns r..k-1, r ascending)
 template <typename T> __device__ void bicg_gamma(const T *__restrict__ packed, int l, BicgDev<T> *d, BicgMirror *mirror)
@@ -227,7 +252,11 @@ struct mik_bicgstab {
     void *x = nullptr, *rs = nullptr, *us = nullptr;
     const void *r_shadow = nullptr, *pl_diag = nullptr;
     bool failed = false;                       // a singular MR system was reported: every later step reports it again
+    bool fuse = false;              // no Pl, aligned r_shadow: sigma (:100) and rho of j >= 2 (:89) may leave the SpMV launch in front of them (bicg_fuses)
     void *dev = nullptr;            // BicgDev<T>
+    void *fin = nullptr;            // FinScratch<T> of the spread finalisers
+    void *rho_part = nullptr;       // segment sums of dot(r_shadow, rs[:, 1]) left by the MR sweep of the step before (rho of the first column, :89)
+    bool rho_ready = false;
     BicgMirror *mirror = nullptr;
     unsigned long long seq = 0;
 };
@@ -245,6 +274,8 @@ extern "C" int mik_bicgstab_destroy(mik_bicgstab *it)
     (void)hipSetDevice(it->ctx->device);
     (void)hipStreamSynchronize(it->ctx->stream);
     if (it->dev) (void)hipFree(it->dev);
+    if (it->fin) (void)hipFree(it->fin);
+    if (it->rho_part) (void)hipFree(it->rho_part);
     if (it->mirror) (void)hipHostFree(it->mirror);
     delete it;
     return MIK_OK;
@@ -266,7 +297,10 @@ extern "C" int mik_bicgstab_create(mik_ctx *ctx, const mik_csr *A, int l, void *
     (void)hipSetDevice(ctx->device);
     hipError_t e;
     const size_t db = A->dtype == MIK_F64 ? sizeof(BicgDev<double>) : sizeof(BicgDev<float>);
-    if ((e = hipMalloc(&it->dev, db)) != hipSuccess ||
+    it->fuse = !pl_diag && mik_aligned16(r_shadow);
+    const size_t rb = (A->dtype == MIK_F64 ? sizeof(double) * (size_t)mik_nseg<double>(n) : sizeof(float) * (size_t)mik_nseg<float>(n)) + 16;
+    if ((e = hipMalloc(&it->dev, db)) != hipSuccess || (e = hipMalloc(&it->fin, 512)) != hipSuccess || (e = hipMemset(it->fin, 0, 512)) != hipSuccess ||
+        (e = hipMalloc(&it->rho_part, rb)) != hipSuccess ||
         (e = hipHostMalloc((void **)&it->mirror, sizeof(BicgMirror), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) {
         const int rc = mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_bicgstab_create: %s", hipGetErrorString(e));
         mik_bicgstab_destroy(it);
@@ -284,6 +318,16 @@ extern "C" int mik_bicgstab_create(mik_ctx *ctx, const mik_csr *A, int l, void *
     ctx->owned.push_back({it, [](void *h) { return mik_bicgstab_destroy((mik_bicgstab *)h); }});
     *out = it;
     return MIK_OK;
+}
+
+// Do the steps of this handle form sigma and rho in the SpMV launches?  (The sweeps that finalise their producer's reduction themselves
+// at launch-bound sizes take at most 1024 partials.)
+template <typename T> static bool bicg_fuses(const mik_bicgstab *it)
+{
+    if (!it->fuse || !mik_spmv_has_epilogue(it->A)) return false;     // (development knob 25 = 2: no epilogues)
+    const int64_t nseg = mik_nseg<T>(it->n), nb = mik_spmv_nwg(it->n);
+    const bool lean = nseg <= 1024 && it->ctx->tuning[25] == 0;
+    return !lean || nb <= 1024;
 }
 
 template <typename T> static int bicg_step_impl(mik_bicgstab *it, T *residual)
@@ -306,31 +350,55 @@ template <typename T> static int bicg_step_impl(mik_bicgstab *it, T *residual)
     const bool blockvec = mik_aligned16(us) && mik_aligned16(rs) && mik_aligned16(x) && (it->ldu % VT<T>::W == 0) && (it->ldr % VT<T>::W == 0);
     const bool lean = nseg <= 1024 && ctx->tuning[25] == 0;   // the sweeps finalise their producers' reductions themselves (k_map_with; development knob 25 = 1: separate finaliser launches)
     const int bnt = ctx->tuning[7] < 0 ? 0 : 1;               // the block sweeps stream everything but the input of the SpMV behind them (development knob 7 < 0: all cached)
+    // sigma = dot(r_shadow, A u) (:100) and, from the second column on, rho = dot(r_shadow, A r) (:89) leave the SpMV launch that forms the
+    // vector (epilogue dot(z, y), one partial per 256-row block: mik_bicgstab_dot_shape) -- a sweep over two vectors and a launch less each
+    const int64_t nb = mik_spmv_nwg(n);
+    const bool fuse = bicg_fuses<T>(it);
+    if (fuse) MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(nb, nseg * np)));
+    auto spmv_dot = [&](const T *in, T *out) {                                               // out = A in; partials of dot(r_shadow, out)
+        ctx->spmv_ep_z = sh;
+        const int rc = mik_spmv_launch<T>(ctx, it->A, in, out, true, (T *)ctx->partials, nullptr);
+        ctx->spmv_ep_z = nullptr;
+        return rc;
+    };
     for (int j = 0; j < l; ++j) {                                                            // BiCG part  :88
-        MIK_TRY(dot_partials(sh, col(rs, it->ldr, j)));                                      // :89
+        const bool rho_here = fuse && j > 0;                                                 // its partials came out of :107 of the column before
+        const bool rho_kept = j == 0 && it->rho_ready;                                       // ... out of the MR sweep of the step before (k_bicg_mr)
+        const int64_t mr = rho_here ? nb : nseg;
+        const T *rpart = rho_kept ? (const T *)it->rho_part : (const T *)ctx->partials;
+        if (!rho_here && !rho_kept) MIK_TRY(dot_partials(sh, col(rs, it->ldr, j)));          // :89
         if (lean) {                                                                          // :90, :93 -- us = rs - beta * us, all j + 1 columns
             OpBicgU<T> op{us, it->ldu, rs, it->ldr, j + 1, Coef<T>{nullptr, T(0)}, bnt};
-            MIK_TRY((launch_map_with<T>(ctx, n, op, ProBicgRho<T>{d, j == 0 ? 1 : 0}, blockvec, (const T *)ctx->partials, (int)nseg, (T *)nullptr)));
+            MIK_TRY((launch_map_with<T>(ctx, n, op, ProBicgRho<T>{d, j == 0 ? 1 : 0}, blockvec, rpart, (int)mr, (T *)nullptr)));
         } else {
-            hipLaunchKernelGGL((k_bicg_fin_rho<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, d, j == 0 ? 1 : 0);
+            if (mr > 16384) hipLaunchKernelGGL((k_bicg_fin_rho_spread<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, rpart, mr, d, j == 0 ? 1 : 0, (FinScratch<T> *)it->fin);
+            else hipLaunchKernelGGL((k_bicg_fin_rho<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, rpart, mr, d, j == 0 ? 1 : 0);
             MIK_LAUNCH_CHECK(ctx);
             OpBicgU<T> op{us, it->ldu, rs, it->ldr, j + 1, coef_ptr<T>(&d->neg_beta), bnt};
             MIK_TRY((launch_map<T>(ctx, n, op, blockvec, (T *)nullptr, nullptr)));
         }
-        MIK_TRY(mik_spmv_launch<T>(ctx, it->A, col(us, it->ldu, j), col(us, it->ldu, j + 1), false, nullptr, nullptr));   // :97
-        MIK_TRY(ldiv(col(us, it->ldu, j + 1)));                                              // :98
-        MIK_TRY(dot_partials(sh, col(us, it->ldu, j + 1)));                                  // :100
+        const int64_t ms = fuse ? nb : nseg;
+        if (fuse) MIK_TRY(spmv_dot(col(us, it->ldu, j), col(us, it->ldu, j + 1)));           // :97 + :100
+        else {
+            MIK_TRY(mik_spmv_launch<T>(ctx, it->A, col(us, it->ldu, j), col(us, it->ldu, j + 1), false, nullptr, nullptr));   // :97
+            MIK_TRY(ldiv(col(us, it->ldu, j + 1)));                                          // :98
+            MIK_TRY(dot_partials(sh, col(us, it->ldu, j + 1)));                              // :100
+        }
         if (lean) {                                                                          // :101, :103, :111 (x does not depend on :107)
             OpBicgR<T> op{us, it->ldu, rs, it->ldr, j + 1, x, Coef<T>{nullptr, T(0)}, Coef<T>{nullptr, T(0)}, bnt};
-            MIK_TRY((launch_map_with<T>(ctx, n, op, ProBicgSigma<T>{d}, blockvec, (const T *)ctx->partials, (int)nseg, (T *)nullptr)));
+            MIK_TRY((launch_map_with<T>(ctx, n, op, ProBicgSigma<T>{d}, blockvec, (const T *)ctx->partials, (int)ms, (T *)nullptr)));
         } else {
-            hipLaunchKernelGGL((k_bicg_fin_sigma<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, d);
+            if (ms > 16384) hipLaunchKernelGGL((k_bicg_fin_sigma_spread<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)ctx->partials, ms, d, (FinScratch<T> *)it->fin);
+            else hipLaunchKernelGGL((k_bicg_fin_sigma<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, ms, d);
             MIK_LAUNCH_CHECK(ctx);
             OpBicgR<T> op{us, it->ldu, rs, it->ldr, j + 1, x, coef_ptr<T>(&d->neg_alpha), coef_ptr<T>(&d->alpha), bnt};
             MIK_TRY((launch_map<T>(ctx, n, op, blockvec, (T *)nullptr, nullptr)));
         }
-        MIK_TRY(mik_spmv_launch<T>(ctx, it->A, col(rs, it->ldr, j), col(rs, it->ldr, j + 1), false, nullptr, nullptr));   // :107
-        MIK_TRY(ldiv(col(rs, it->ldr, j + 1)));                                              // :108
+        if (fuse && j + 1 < l) MIK_TRY(spmv_dot(col(rs, it->ldr, j), col(rs, it->ldr, j + 1)));   // :107 + :89 of the next column
+        else {
+            MIK_TRY(mik_spmv_launch<T>(ctx, it->A, col(rs, it->ldr, j), col(rs, it->ldr, j + 1), false, nullptr, nullptr));   // :107
+            MIK_TRY(ldiv(col(rs, it->ldr, j + 1)));                                          // :108
+        }
     }
     // MR part: M = rs' * rs (:120) in one pass, gamma (:123-125), the three updates and the norm (:127-132) in one sweep
     switch (l + 1) {
@@ -353,9 +421,14 @@ template <typename T> static int bicg_step_impl(mik_bicgstab *it, T *residual)
         const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
         const bool vec = mik_aligned16(us) && mik_aligned16(rs) && mik_aligned16(x) && (it->ldu % VT<T>::W == 0) && (it->ldr % VT<T>::W == 0);
         BicgGamma<T> gm{};
-        if (vec) hipLaunchKernelGGL((k_bicg_mr<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, l, us, it->ldu, rs, it->ldr, x, gm, (T *)ctx->partials, (const T *)d->gamma);
-        else hipLaunchKernelGGL((k_bicg_mr<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, l, us, it->ldu, rs, it->ldr, x, gm, (T *)ctx->partials, (const T *)d->gamma);
+        // (+ the segment sums of dot(r_shadow, new residual): rho of the next step's first column, while the residual is in registers)
+        const bool keep = ctx->tuning[25] != 2 && (!vec || mik_aligned16(sh));
+        if (vec) hipLaunchKernelGGL((k_bicg_mr<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, l, us, it->ldu, rs, it->ldr, x, gm, (T *)ctx->partials, (const T *)d->gamma,
+                                    keep ? sh : (const T *)nullptr, (T *)it->rho_part);
+        else hipLaunchKernelGGL((k_bicg_mr<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, l, us, it->ldu, rs, it->ldr, x, gm, (T *)ctx->partials, (const T *)d->gamma,
+                                keep ? sh : (const T *)nullptr, (T *)it->rho_part);
         MIK_LAUNCH_CHECK(ctx);
+        it->rho_ready = keep;
     }
     it->seq += 1;
     hipLaunchKernelGGL((k_bicg_fin_norm<T>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const T *)ctx->partials, nseg, it->mirror, it->seq);
@@ -384,6 +457,13 @@ template <typename T> static int bicg_step_impl(mik_bicgstab *it, T *residual)
     if (it->mirror->range) return mik_safe_norm_slow<T>(ctx, n, rs, residual);               // norm(rs[:, 1]) of a badly scaled residual
     *residual = (T)it->mirror->residual;
     return MIK_OK;
+}
+
+extern "C" int mik_bicgstab_dot_shape(const mik_bicgstab *it, int *W, int *L)
+{
+    if (!it) return MIK_ERR_INVALID;
+    if (it->dtype == MIK_F64 ? bicg_fuses<double>(it) : bicg_fuses<float>(it)) return mik_spmv_dot_shape(W, L);
+    return mik_reduce_shape(it->dtype, W, L);
 }
 
 extern "C" int mik_bicgstab_step(mik_bicgstab *it, void *residual)

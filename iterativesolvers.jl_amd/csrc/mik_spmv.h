@@ -276,7 +276,8 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
                                                              const int *__restrict__ win_lo = nullptr, int win_span = 0,
                                                              const unsigned char *__restrict__ rperm = nullptr,
                                                              const int *__restrict__ long_win = nullptr, int lw = 0,
-                                                             const T *__restrict__ ep_w = nullptr, const T *__restrict__ ep_c = nullptr)
+                                                             const T *__restrict__ ep_w = nullptr, const T *__restrict__ ep_c = nullptr,
+                                                             const T *__restrict__ ep_z = nullptr)
 {
     if (done && *done) return;
     constexpr int TILE = MIK_SPMV_TILE * (int)(8 / sizeof(T));   // 16 KB of LDS: 2048 fp64 / 4096 fp32 products
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
     else if (r < n) st_stream<NT>(y + r, acc);
     if (FUSE_DOT) {
         T p = T(0);
-        if (r < n) p = x[r] * acc;
+        if (r < n) p = (ep_z ? ep_z[r] : x[r]) * acc;       // ep_z: dot(z, y) instead of dot(x, y) (BiCGStab(l): z = r_shadow)
         if (RPERM) {                                   // back into row order: thread t of the block tree holds row r0 + t
             prod[tr] = p;
             __syncthreads();
@@ -458,7 +459,8 @@ __global__ __launch_bounds__(MIK_BLOCK, 6) void k_spmv_rowgather(int n, int rb0,
                                                               const int *__restrict__ col, const T *__restrict__ val,
                                                               const T *__restrict__ x, T *__restrict__ y, T *__restrict__ seg_out,
                                                               const int *__restrict__ done, const unsigned char *__restrict__ is_long,
-                                                              const T *__restrict__ ep_w = nullptr, const T *__restrict__ ep_c = nullptr)
+                                                              const T *__restrict__ ep_w = nullptr, const T *__restrict__ ep_c = nullptr,
+                                                             const T *__restrict__ ep_z = nullptr)
 {
     if (done && *done) return;
     constexpr int TILE = MIK_SPMV_TILE;                // entries per pass: 2048 (fp64: 16 KB values + 8 KB columns)
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(MIK_BLOCK, 6) void k_spmv_rowgather(int n, int rb0,
     else if (r < n) st_stream<NT>(y + r, acc);
     if (FUSE_DOT) {
         T p = T(0);
-        if (r < n) p = x[r] * acc;
+        if (r < n) p = (ep_z ? ep_z[r] : x[r]) * acc;       // ep_z: dot(z, y) instead of dot(x, y) (BiCGStab(l): z = r_shadow)
         T tot = block_tree_256(p, lds4);
         if (t == 0) seg_out[rb] = tot;
     }

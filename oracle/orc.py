@@ -400,10 +400,11 @@ def lu_solve(A, b):
 
 
 def bicgstabl(A: CSC, b, l=2, x0=None, *, r_shadow, abstol=0.0, reltol=None, max_mv_products=None, mode="seq",
-              shape=(1, 1), pl_diag=None):
+              shape=(1, 1), pl_diag=None, dot_shape=None):
     """``bicgstabl!(x, A, b, l; Pl, log=true)`` / ``bicgstabl(A, b, l)`` when ``x0 is None`` -- src/bicgstabl.jl:181-219,142.
     ``r_shadow`` replaces the reference's ``rand(T, n)`` (src/bicgstabl.jl:38); ``pl_diag`` = the diagonal of a Jacobi ``Pl``
-    (``ldiv!`` at src/bicgstabl.jl:55,98,108), None = ``Identity()``."""
+    (``ldiv!`` at src/bicgstabl.jl:55,98,108), None = ``Identity()``.  ``dot_shape``: (W, L) of ``sigma`` (:100) and of ``rho`` from
+    the second column on (:89) (mik_bicgstab_dot_shape), default = ``shape``."""
     dtype = A.nzval.dtype
     suf, ct = _suf(dtype)
     b = np.ascontiguousarray(b, dtype)
@@ -417,7 +418,7 @@ def bicgstabl(A: CSC, b, l=2, x0=None, *, r_shadow, abstol=0.0, reltol=None, max
     iters, mvps = C.c_int64(0), C.c_int64(0)
     conv = C.c_int(0)
     res0, tol = C.c_double(0), C.c_double(0)
-    shp = np.asarray(shape, np.int32)
+    shp = np.asarray(tuple(shape) + tuple(dot_shape if dot_shape is not None else shape), np.int32)
     rc = getattr(lib(), f"orc_bicgstabl_{suf}")(n, _p(A.colptr, C.c_int64), _p(A.rowval, C.c_int64), _p(A.nzval, ct),
                                                 A.index_base, _p(b, ct), _p(x, ct), _p(rsh, ct),
                                                 _p(None if pl_diag is None else np.ascontiguousarray(pl_diag, dtype), ct), int(l), float(abstol),

@@ -73,8 +73,11 @@ x = pkg.zerox(A, b)
 # BiCGStab(2): per outer iteration 4 SpMV; sweeps: 2 dots x2 (2 words each) ... counted from src/bicgstabl.jl:88-132
 l = 2
 words = sum(2 + 3 * (j + 1) + 2 + 3 * (j + 1) + 3 for j in range(l)) + (l + 1) * (l + 1) * 2 + (l + 2) + (l + 2) + (l + 2) + 1
-timed("bicgstabl2", pkg.bicgstabl_iterator_(x, A, b, 2, reltol=0.0, max_mv_products=10 ** 9, initial_zero=True), 0, words, 2 * l, iters=max(args.iters // 3, 10),
-      moved_words=sum(2 + 3 * (j + 1) + 2 + 3 * (j + 1) + 3 for j in range(l)) + (l + 1) + (3 * l + 4))   # + one-pass Gram + one-sweep MR update
+bit = pkg.bicgstabl_iterator_(x, A, b, 2, reltol=0.0, max_mv_products=10 ** 9, initial_zero=True)
+kept = "25=2" not in os.environ.get("MIK_KNOBS", "")   # rho of the first column: segment sums left by the MR sweep of the step before
+ep = bit.dot_shape() == x.ctx.spmv_dot_shape()      # sigma and rho (from the second column on) leave the SpMV launches: r_shadow read once each, no sweep
+timed("bicgstabl2", bit, 0, words, 2 * l, iters=max(args.iters // 3, 10),
+      moved_words=sum((1 if ep and j else (0 if kept and j == 0 else 2)) + 3 * (j + 1) + (1 if ep else 2) + 3 * (j + 1) + 3 for j in range(l)) + (l + 1) + (3 * l + 4) + (1 if kept else 0))   # + one-pass Gram + one-sweep MR update (+ r_shadow for the next rho)
 x = pkg.zerox(A, b)
 timed("minres", pkg.minres_iterable_(x, A, b, reltol=0.0, initially_zero=True, maxiter=10 ** 9), 1, 27, 1, moved_words=1 + 3 + 8)             # Lanczos step + projection in the SpMV epilogue (round 4): + v_prev; orthogonalise + norm: 3; tail: 8
 x = pkg.zerox(A, b)

@@ -82,23 +82,35 @@ def test_lu_solve_matches_numpy(pkg, orc):
 
 
 # ---- device ----------------------------------------------------------------------------------------
+def step_dot_shape(pkg, dA, b, l, **kw):
+    """(W, L) of sigma and of rho from the second column on in the whole-iteration call for this operator (mik_bicgstab_dot_shape)"""
+    x = pkg.HipVector.from_numpy(np.zeros(b.size, b.dtype))
+    return pkg.bicgstabl_iterator_(x, dA, pkg.HipVector.from_numpy(b), l, max_mv_products=2 * l, initial_zero=True, **kw).dot_shape()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("l", [2, 4])
-def test_device_matches_oracle_bit_exact(pkg, orc, ctx, l, dtype):
-    """the reference authors' own BiCGStab benchmark operator (benchmark/benchmark-linear-systems.jl:68-77), small"""
+@pytest.mark.parametrize("knob25", [0, 1, 2])
+def test_device_matches_oracle_bit_exact(pkg, orc, ctx, l, dtype, knob25):
+    """the reference authors' own BiCGStab benchmark operator (benchmark/benchmark-linear-systems.jl:68-77), small.  Development knob 25:
+    0 = the sweeps finalise the reductions in front of them, 1 = separate finaliser launches, 2 = no SpMV epilogues (sigma and rho as
+    sweeps of their own, in the vector shape)"""
     A, b = orc.advdiff(12, 300.0)
     A, b = A.astype(dtype), b.astype(dtype)
     sh = (orc.hashed_rhs(A.n) + 0.5).astype(dtype)
     dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
     x0 = np.random.default_rng(2).standard_normal(A.n).astype(dtype)
+    ctx.set_tuning(25, knob25)
+    ds = step_dot_shape(pkg, dA, b, l)
+    assert ds == (ctx.reduce_shape(dtype) if knob25 == 2 else ctx.spmv_dot_shape())
     for start in (None, x0):
         if start is None:
             x, ch = pkg.bicgstabl(dA, pkg.HipVector.from_numpy(b), l, log=True, max_mv_products=2000, r_shadow=pkg.HipVector.from_numpy(sh))
         else:
             x, ch = pkg.bicgstabl_(pkg.HipVector.from_numpy(start), dA, pkg.HipVector.from_numpy(b), l, log=True, max_mv_products=2000,
                                    r_shadow=pkg.HipVector.from_numpy(sh))
-        xo, ho = orc.bicgstabl(A, b, l, start, r_shadow=sh, max_mv_products=2000, mode="tree", shape=ctx.reduce_shape(dtype))
+        xo, ho = orc.bicgstabl(A, b, l, start, r_shadow=sh, max_mv_products=2000, mode="tree", shape=ctx.reduce_shape(dtype), dot_shape=ds)
         assert ch.iters == ho["iters"] and ch.mvps == ho["mvps"] and ch.isconverged == ho["isconverged"]
         assert np.array_equal(ch["resnorm"], ho["resnorm"], equal_nan=True) and np.array_equal(x.to_numpy(), xo, equal_nan=True)   # fp32, l = 4 breaks down (NaN) identically on both sides
     if dtype == np.float64:
@@ -140,18 +152,83 @@ def test_gram_equals_pairwise_dots(pkg, orc, ctx, dtype, n, k):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("l", [1, 2, 4])
 def test_fused_bicgstab_equals_statement_by_statement(pkg, orc, ctx, l, dtype):
-    A, b = orc.advdiff(11, 300.0)
+    """the whole-iteration call and the statement-by-statement path against the oracle, each with the tree of its own sigma / rho (the
+    call forms them in the SpMV launches: one partial per 256-row block); with the epilogues off (development knob 25 = 2) the two
+    paths give the same bits"""
+    A, b = orc.advdiff(14, 300.0)                            # (an even n: the operator's default kernel, two rows per lane, takes epilogues)
     A, b = A.astype(dtype), b.astype(dtype)
     sh = (orc.hashed_rhs(A.n) + 0.5).astype(dtype)
     dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
-    runs = []
-    for fused in (True, False):
+    runs = {}
+    for fused, knob in ((True, 0), (False, 0), (True, 2)):
+        ctx.set_tuning(25, knob)
         x = pkg.HipVector.from_numpy(np.zeros(A.n, dtype))
         it = pkg.bicgstabl_iterator_(x, dA, pkg.HipVector.from_numpy(b), l, max_mv_products=60 * l, reltol=0.0, initial_zero=True,
                                      r_shadow=pkg.HipVector.from_numpy(sh), fused=fused)
-        runs.append((np.array(list(it)), x.to_numpy()))
-    assert runs[0][0].size == 30
-    assert np.array_equal(runs[0][0], runs[1][0], equal_nan=True) and np.array_equal(runs[0][1], runs[1][1], equal_nan=True)
+        ds = it.dot_shape()
+        assert ds == (ctx.spmv_dot_shape() if (fused and knob == 0) else ctx.reduce_shape(dtype))
+        runs[fused, knob] = (np.array(list(it)), x.to_numpy())
+        xo, ho = orc.bicgstabl(A, b, l, None, r_shadow=sh, max_mv_products=60 * l, reltol=0.0, mode="tree", shape=ctx.reduce_shape(dtype), dot_shape=ds)
+        assert runs[fused, knob][0].size == 30
+        assert np.array_equal(runs[fused, knob][0], ho["resnorm"], equal_nan=True) and np.array_equal(runs[fused, knob][1], xo, equal_nan=True)
+    assert np.array_equal(runs[False, 0][0], runs[True, 2][0], equal_nan=True) and np.array_equal(runs[False, 0][1], runs[True, 2][1], equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("kind", ["csr", "fe", "irregular"])
+def test_sigma_and_rho_in_the_csr_and_jagged_spmv_kernels(pkg, orc, ctx, dtype, kind):
+    """dot(r_shadow, A u) as the SpMV's epilogue also in k_spmv_rowgather (the operator on its plain CSR arrays) and k_spmv_jds (a
+    finite-element operator): bit-exact against the oracle with those dots in the SpMV-dot tree; an operator with split-off long rows
+    has no epilogue and keeps the vector shape"""
+    import scipy.sparse as sp
+    if kind == "csr":
+        A, b = orc.advdiff(10, 200.0)
+        A, b = A.astype(dtype), b.astype(dtype)
+        dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
+        dA.set_layout("csr")
+        want_kernel, want_shape = "k_spmv_rowgather", ctx.spmv_dot_shape()
+    else:
+        if kind == "fe":
+            n, rowptr, colidx, val = pkg.fixtures.fe_matrix((12, 12), 3, dtype)
+            want_kernel, want_shape = "k_spmv_jds", ctx.spmv_dot_shape()
+        else:
+            n, rowptr, colidx, val = pkg.fixtures.irregular_matrix(20000, dtype)
+            want_kernel, want_shape = "k_spmv_rowblock", ctx.reduce_shape(dtype)
+        M = sp.csr_matrix((val, colidx, rowptr), shape=(n, n)).tocsc()
+        M.sort_indices()
+        A = orc.CSC(n, M.indptr.astype(np.int64), M.indices.astype(np.int64), M.data.astype(dtype), 0)
+        dA = pkg.HipCSR(n, n, rowptr, colidx, val, index_base=0, is_csc=False)
+        b = orc.hashed_rhs(n).astype(dtype)
+    assert dA.spmv_kernel().split("+")[0] == want_kernel
+    sh = (orc.hashed_rhs(A.n) + 0.5).astype(dtype)
+    x = pkg.HipVector.from_numpy(np.zeros(A.n, dtype))
+    it = pkg.bicgstabl_iterator_(x, dA, pkg.HipVector.from_numpy(b), 2, max_mv_products=40, reltol=0.0, initial_zero=True, r_shadow=pkg.HipVector.from_numpy(sh))
+    assert it.dot_shape() == want_shape
+    if kind == "irregular":
+        orc.set_long_row(ctx.spmv_long_row(), ctx.spmv_long_segment(), ctx.spmv_long_group())
+    try:
+        hist = np.array(list(it))
+        xo, ho = orc.bicgstabl(A, b, 2, None, r_shadow=sh, max_mv_products=40, reltol=0.0, mode="tree", shape=ctx.reduce_shape(dtype), dot_shape=it.dot_shape())
+    finally:
+        orc.set_long_row(0)
+    assert hist.size == 10 and np.array_equal(hist, ho["resnorm"], equal_nan=True) and np.array_equal(x.to_numpy(), xo, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_sigma_and_rho_through_the_spread_finalisers(pkg, orc, ctx):
+    """more than 16,384 row-blocks: the partials of sigma / rho out of the SpMV launches go through the 16-workgroup finalisers"""
+    N = 164                                                  # 164^3 = 4.4 M rows = 17,231 row-blocks
+    A = orc.laplace(N, 3)
+    b = orc.hashed_rhs(A.n)
+    sh = orc.hashed_rhs(A.n) + 0.5
+    dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
+    x = pkg.HipVector.from_numpy(np.zeros(A.n))
+    it = pkg.bicgstabl_iterator_(x, dA, pkg.HipVector.from_numpy(b), 2, max_mv_products=12, reltol=0.0, initial_zero=True, r_shadow=pkg.HipVector.from_numpy(sh))
+    assert it.dot_shape() == ctx.spmv_dot_shape() and (A.n + 255) // 256 > 16384
+    hist = np.array(list(it))
+    xo, ho = orc.bicgstabl(A, b, 2, None, r_shadow=sh, max_mv_products=12, reltol=0.0, mode="tree", shape=ctx.reduce_shape(np.float64), dot_shape=it.dot_shape())
+    assert hist.size == 3 and np.array_equal(hist, ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
 
 
 @pytest.mark.gpu
@@ -212,7 +289,7 @@ def test_jacobi_pl_matches_oracle_bit_exact(pkg, orc, ctx, dtype, l, with_x0):
     sh = (orc.hashed_rhs(A.n) + 0.5).astype(dtype)
     x0 = np.random.default_rng(7).standard_normal(A.n).astype(dtype) if with_x0 else None
     max_mv = 40 * l
-    xo, ho = orc.bicgstabl(A, b, l, x0, r_shadow=sh, max_mv_products=max_mv, reltol=0.0, mode="tree", shape=ctx.reduce_shape(dtype), pl_diag=diag)
+    xo, ho = orc.bicgstabl(A, b, l, x0, r_shadow=sh, max_mv_products=max_mv, reltol=0.0, mode="tree", shape=ctx.reduce_shape(dtype), pl_diag=diag)   # Pl: no SpMV epilogue, the vector shape throughout
     assert ho["iters"] == 20
     for fused in (True, False):
         x = pkg.HipVector.from_numpy(np.zeros(A.n, dtype) if x0 is None else x0.copy())
