@@ -345,7 +345,7 @@ template <typename T, typename C = Coef<T>> struct OpCgUpdateR {
 // iteration at 256^3; two correctly rounded fp64 divisions per element make both sweeps instruction-bound.)
 template <typename T> struct OpPcgUpdateR {
     static constexpr bool REDUCE = true;
-    T *__restrict__ r; T *__restrict__ c; const T *__restrict__ d; Coef<T> alpha; int nt = 0;   // nt & 8 / 16: r load / store streamed
+    T *__restrict__ r; T *__restrict__ c; const T *__restrict__ d; Coef<T> alpha; int nt = 0;   // nt & 8 / 16: r load / store streamed; 32 / 64: c store / load streamed
     __device__ __forceinline__ void apply(int64_t i, T &a1, T &a2) const
     {
         T s = alpha.get() * c[i]; T rn = r[i] - s; r[i] = rn;
@@ -357,7 +357,7 @@ template <typename T> struct OpPcgUpdateR {
     {
         const T a = alpha.get();
         auto rv = (nt & 8) ? vload_nt<T>(r + i) : vload<T>(r + i);
-        auto cv = vload<T>(c + i);
+        auto cv = (nt & 64) ? vload_nt<T>(c + i) : vload<T>(c + i);
         auto dv = vload_nt(d + i);
 #pragma unroll
         for (int e = 0; e < VT<T>::W; ++e) { T s = a * el<T>(cv, e); el<T>(rv, e) = el<T>(rv, e) - s; }
@@ -366,7 +366,7 @@ template <typename T> struct OpPcgUpdateR {
         for (int e = 0; e < VT<T>::W; ++e) { T p = el<T>(rv, e) * el<T>(rv, e); a1 = a1 + p; }
 #pragma unroll
         for (int e = 0; e < VT<T>::W; ++e) el<T>(cv, e) = el<T>(rv, e) / el<T>(dv, e);
-        vstore(c + i, cv);
+        if (nt & 32) vstore_nt(c + i, cv); else vstore(c + i, cv);
 #pragma unroll
         for (int e = 0; e < VT<T>::W; ++e) { T q = el<T>(cv, e) * el<T>(rv, e); a2 = a2 + q; }
     }

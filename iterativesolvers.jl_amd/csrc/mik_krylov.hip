@@ -729,8 +729,11 @@ template <typename T> static int cg_enqueue_tail(mik_cg *it, long long it_next, 
     if (it->pcg_fused) {
         {
             CgProfileScope ps(it, 2);
-            // r is not read again before the next tail (the head reads c = Pl \\ r, u, x): both directions streamed unless development knob 7 says otherwise
-            OpPcgUpdateR<T> up{r, c, (const T *)it->diag, coef_ptr<T>(&d->alpha), ctx->tuning[7] == 0 ? 24 : (ctx->tuning[7] < 0 ? 0 : ctx->tuning[7] & 24)};
+            // r is not read again before the next tail (the head reads c = Pl \\ r, u, x): both directions streamed unless development knob 7 says otherwise.
+            // c too (bits 5, 6; round 4): c = Pl \\ r stored with the default policy shares the 256 MB Infinity Cache with the u the head writes for the SpMV --
+            // streamed, the in-loop SpMV runs at its back-to-back time (73 -> 52 us) and this sweep pays most of it back (99 -> 116 us): 280.7 -> 275.6 us
+            // per step, ten words per row + the operator at the copy ceiling (profiles/r04_pcg_kernel_stats.txt).
+            OpPcgUpdateR<T> up{r, c, (const T *)it->diag, coef_ptr<T>(&d->alpha), ctx->tuning[7] == 0 ? 120 : (ctx->tuning[7] < 0 ? 0 : ctx->tuning[7] & 120)};
             MIK_TRY((launch_map2<T>(ctx, n, up, vec, (T *)it->seg_vec, (T *)it->seg_vec2, done)));
         }
         it->seq += 1;
