@@ -1349,8 +1349,8 @@ template <typename T, bool VEC>
 __global__ __launch_bounds__(MIK_BLOCK) void k_bicg_mr(int64_t n, int64_t nseg, int l, T *__restrict__ us, int64_t ldu,
                                                        T *__restrict__ rs, int64_t ldr, T *__restrict__ x, BicgGamma<T> gm,
                                                        T *__restrict__ seg_out, const T *__restrict__ gamma_dev,
-                                                       const T *__restrict__ sh = nullptr, T *__restrict__ seg_out2 = nullptr)
-{
+                                                       const T *__restrict__ sh = nullptr, T *__restrict__ seg_out2 = nullptr, int nt = 0)
+{   // nt (cache hints, results unchanged): 1 = the columns that are dead after this sweep (us_j, rs_j, j >= 1) and r_shadow streamed, 2 = x streamed both ways, 4 / 8 = the us_0 / rs_0 store streamed
     constexpr int W = VT<T>::W;
     constexpr int L = MIK_RED_L;
     constexpr int64_t SEG = (int64_t)MIK_BLOCK * W * L;
@@ -1368,7 +1368,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_bicg_mr(int64_t n, int64_t nseg, 
             const bool full = VEC && i0 + W <= n;
             T u0[W], xx[W], r0[W], rold[W];
             if (full) {
-                auto a = vload<T>(us + i0); auto b = vload<T>(x + i0); auto c = vload<T>(rs + i0);
+                auto a = vload<T>(us + i0); auto b = (nt & 2) ? vload_nt<T>(x + i0) : vload<T>(x + i0); auto c = vload<T>(rs + i0);
 #pragma unroll
                 for (int e = 0; e < W; ++e) { u0[e] = el<T>(a, e); xx[e] = el<T>(b, e); r0[e] = el<T>(c, e); }
             } else {
@@ -1388,7 +1388,8 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_bicg_mr(int64_t n, int64_t nseg, 
             for (int j = 1; j <= l; ++j) {
                 T uj[W], rj[W];
                 if (full) {
-                    auto a = vload(us + (int64_t)j * ldu + i0); auto c = vload(rs + (int64_t)j * ldr + i0);
+                    auto a = (nt & 1) ? vload_nt(us + (int64_t)j * ldu + i0) : vload(us + (int64_t)j * ldu + i0);
+                    auto c = (nt & 1) ? vload_nt(rs + (int64_t)j * ldr + i0) : vload(rs + (int64_t)j * ldr + i0);
 #pragma unroll
                     for (int e = 0; e < W; ++e) { uj[e] = el<T>(a, e); rj[e] = el<T>(c, e); }
                 } else {
@@ -1414,7 +1415,9 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_bicg_mr(int64_t n, int64_t nseg, 
                 typename VT<T>::vec a, b, c;
 #pragma unroll
                 for (int e = 0; e < W; ++e) { el<T>(a, e) = u0[e]; el<T>(b, e) = xx[e]; el<T>(c, e) = r0[e]; }
-                vstore(us + i0, a); vstore(x + i0, b); vstore(rs + i0, c);
+                if (nt & 4) vstore_nt(us + i0, a); else vstore(us + i0, a);
+                if (nt & 8) vstore_nt(rs + i0, c); else vstore(rs + i0, c);
+                if (nt & 2) vstore_nt(x + i0, b); else vstore(x + i0, b);
             } else {
 #pragma unroll
                 for (int e = 0; e < W; ++e)
@@ -1425,7 +1428,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_bicg_mr(int64_t n, int64_t nseg, 
                 if (i0 + e < n) { T p = r0[e] * r0[e]; acc = acc + p; }
             if (sh) {
                 if (full) {
-                    auto hv = vload(sh + i0);
+                    auto hv = (nt & 1) ? vload_nt(sh + i0) : vload(sh + i0);
 #pragma unroll
                     for (int e = 0; e < W; ++e) { T p = el<T>(hv, e) * r0[e]; acc2 = acc2 + p; }
                 } else {

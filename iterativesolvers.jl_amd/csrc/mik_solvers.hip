@@ -423,8 +423,9 @@ template <typename T> static int bicg_step_impl(mik_bicgstab *it, T *residual)
         BicgGamma<T> gm{};
         // (+ the segment sums of dot(r_shadow, new residual): rho of the next step's first column, while the residual is in registers)
         const bool keep = ctx->tuning[25] != 2 && (!vec || mik_aligned16(sh));
+        const int mrnt = ctx->tuning[7] > 0 ? (ctx->tuning[7] & 15) : (ctx->tuning[7] < 0 ? 0 : 3);      // development knob 7: hint mask of the MR sweep
         if (vec) hipLaunchKernelGGL((k_bicg_mr<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, l, us, it->ldu, rs, it->ldr, x, gm, (T *)ctx->partials, (const T *)d->gamma,
-                                    keep ? sh : (const T *)nullptr, (T *)it->rho_part);
+                                    keep ? sh : (const T *)nullptr, (T *)it->rho_part, mrnt);
         else hipLaunchKernelGGL((k_bicg_mr<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, l, us, it->ldu, rs, it->ldr, x, gm, (T *)ctx->partials, (const T *)d->gamma,
                                 keep ? sh : (const T *)nullptr, (T *)it->rho_part);
         MIK_LAUNCH_CHECK(ctx);
