@@ -18,7 +18,7 @@ extern "C" {
  *              1: 1 = narrow loads in the CSR kernel
  *   2: workgroup map: 0 = operator's choice, < 0 identity, 1 = contiguous range per XCD, P >= 8 = strips of P
  *   3: 1 = hipStreamSynchronize instead of the event spin wait    4: long-row threshold (> 0), < 0 = no split
- *   5: 1 = unfused MGS chain, 2 = launch-lean MGS without graphs, 3 = one hipGraph per GMRES column
+ *   5: 1 = unfused MGS chain, 2 = launch-lean MGS without graphs, 3 = one hipGraph per GMRES column, 4 = single-launch MGS on all XCDs (not the XCD-local form)
  *   7: cache hints of the CG vector kernels
  *   8: 1 = CSR row-block layout only (read at mik_csr_create and at launch)    9: 1 = nothing enqueued ahead of the host (GMRES: the next Arnoldi column; CG: the head of the next step)
  *  10: 1 = scalar results through hipMemcpyAsync + event spin instead of the publish kernel + mailbox spin

@@ -835,6 +835,42 @@ template <typename T> __device__ __forceinline__ typename MgsBits<T>::U mgs_slot
     return v != v ? MgsBits<T>::QNAN : bits;
 }
 
+// slot accesses of the hand-off.  XL ("XCD-local", round 4): every participating workgroup runs on ONE XCD (the launch has 8 x as many
+// workgroups and only those with blockIdx % 8 == 0 -- the ones the dispatcher deals to the first XCD -- take part), so the slots only
+// have to be coherent in that XCD's L2: a workgroup-scope (sc0) store, which is written through the L1 into the L2, and a NON-TEMPORAL
+// load, which the L1 does not keep -- every poll is served by the L2.  (An ordinary or sc0 load hits the L1 line the first poll left
+// there for good, with or without `buffer_inv sc0` in front of it; an agent-scope load is served past the L2 as well.)  One hop then
+// costs 1.1-1.2 us instead of the 2.4-2.8 us of the device-wide hand-off (scripts/micro/xl_hop.hip: the skeleton of this kernel).
+// Should a non-temporal load ever be served from a stale line, it can only show "not yet written" once more: the poll goes on.
+template <bool XL> __device__ __forceinline__ void mgs_slot_store(unsigned long long *p, unsigned long long bits)
+{
+    if (XL) asm volatile("global_store_dwordx2 %0, %1, off sc0" ::"v"(p), "v"(bits) : "memory");
+    else __hip_atomic_store(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool XL> __device__ __forceinline__ void mgs_slot_store(unsigned *p, unsigned bits)
+{
+    if (XL) asm volatile("global_store_dword %0, %1, off sc0" ::"v"(p), "v"(bits) : "memory");
+    else __hip_atomic_store(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool XL> __device__ __forceinline__ unsigned long long mgs_slot_load(const unsigned long long *p)
+{
+    if (XL) {
+        unsigned long long v;
+        asm volatile("global_load_dwordx2 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        return v;
+    }
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool XL> __device__ __forceinline__ unsigned mgs_slot_load(const unsigned *p)
+{
+    if (XL) {
+        unsigned v;
+        asm volatile("global_load_dword %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        return v;
+    }
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct MgsMirror {             // host-mapped; h[] follows (restart + 2 scalars of the handle's dtype)
     unsigned long long seq;
     int err, pad;
@@ -844,7 +880,7 @@ struct MgsMirror {             // host-mapped; h[] follows (restart + 2 scalars 
 // of level2_sum evaluated by a 256-thread workgroup -- real thread (wave w, lane l) plays the virtual threads (w + 4 j) * 64 + l,
 // j = 0..3; a virtual thread adds its slots vt, vt + 1024 in ascending order from +0; wave tree per 64; the 16 wave sums left to
 // right.  Every slot is polled until it no longer holds the "not yet written" pattern (bounded).
-template <typename T>
+template <typename T, bool XL = false>
 __device__ __forceinline__ T mgs_grid_sum(const T *__restrict__ slots, int ns, T *lds16, int *err)
 {
     using U = typename MgsBits<T>::U;
@@ -856,7 +892,7 @@ __device__ __forceinline__ T mgs_grid_sum(const T *__restrict__ slots, int ns, T
         for (int q = vt; q < ns; q += MIK_FIN_THREADS) {
             U bits = MgsBits<T>::EMPTY;
             for (int spin = 0; spin < (1 << 18); ++spin) {
-                bits = __hip_atomic_load(reinterpret_cast<const U *>(slots) + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bits = mgs_slot_load<XL>(reinterpret_cast<const U *>(slots) + q);
                 if (bits != MgsBits<T>::EMPTY) break;
                 if (MIK_MGS_SLEEP) __builtin_amdgcn_s_sleep(1);
             }
@@ -880,10 +916,13 @@ __device__ __forceinline__ T mgs_grid_sum(const T *__restrict__ slots, int ns, T
 // G consecutive reduction segments per workgroup (G = 1, 2, 4, 8: n up to 2048 segments = 4.2 M fp32 / 2.1 M fp64 elements with at
 // most 256 workgroups -- one per CU, all resident, which the slot hand-off needs): a thread keeps G x L x W elements of w in
 // registers; segment sums, slots and trees are those of G = 1, so the bits are those of the multi-launch chain.
-template <typename T, bool VEC, int G>
+// XL (only with G = 1, at most 128 segments and columns of at most ~1.5 MB -- one XCD's share of the fabric has to feed them): see
+// mgs_slot_store.  xl_chk[parity] receives the XCC id of the first participant; one that finds another id raises err = 2 and the host
+// switches the handle to the all-XCD form for good (the slots of workgroups on different XCDs would never become visible).
+template <typename T, bool VEC, int G, bool XL = false>
 __global__ __launch_bounds__(MIK_BLOCK, 1) void k_mgs_fused(int64_t n, int k, const T *__restrict__ V, int64_t ldv, T *__restrict__ w,
                                                             T *__restrict__ P /* [2][kmax + 1][stride] */, int kmax, int stride, int nseg, int parity,
-                                                            MgsMirror *mirror, unsigned long long seq)
+                                                            MgsMirror *mirror, unsigned long long seq, unsigned *__restrict__ xl_chk = nullptr)
 {
     using U = typename MgsBits<T>::U;
     constexpr int W = VT<T>::W, L = MIK_RED_L;
@@ -891,12 +930,21 @@ __global__ __launch_bounds__(MIK_BLOCK, 1) void k_mgs_fused(int64_t n, int k, co
     __shared__ T lds16[16];
     __shared__ T ldsg[G][4];
     __shared__ int s_err;
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, s = blockIdx.x;
-    if (t == 0) s_err = 0;
+    if (XL && (blockIdx.x & 7u)) return;                   // the workgroups of the other seven XCDs
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, s = XL ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (t == 0) {
+        s_err = 0;
+        if (XL) {
+            const unsigned me = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) + 1u;      // HW_REG_XCC_ID[3:0] + 1
+            unsigned seen = 0u;
+            if (!__hip_atomic_compare_exchange_strong(&xl_chk[parity], &seen, me, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && seen != me) s_err = 2;
+            if (s == 0) __hip_atomic_store(&xl_chk[parity ^ 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     T *cur = P + (size_t)parity * (size_t)(kmax + 1) * stride;
     T *oth = P + (size_t)(parity ^ 1) * (size_t)(kmax + 1) * stride;
     for (int q = t; q < (kmax + 1) * G; q += MIK_BLOCK)     // re-arm this workgroup's slots of the other buffer
-        __hip_atomic_store(reinterpret_cast<U *>(oth + (size_t)(q / G) * stride) + s * G + q % G, MgsBits<T>::EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mgs_slot_store<XL>(reinterpret_cast<U *>(oth + (size_t)(q / G) * stride) + s * G + q % G, MgsBits<T>::EMPTY);
     const int64_t base = (int64_t)s * G * SEG + (int64_t)W * t;
     // this thread's elements of w and of the column in flight: segment g, load l: base + g SEG + l 256 W .. + W - 1, valid where < n
     T wr[G][L][W], zr[G][L][W], vr[G][L][W];
@@ -926,7 +974,7 @@ __global__ __launch_bounds__(MIK_BLOCK, 1) void k_mgs_fused(int64_t n, int k, co
         if (t < G && s * G + t < nseg) {
             T tot = ldsg[t][0];
             tot = tot + ldsg[t][1]; tot = tot + ldsg[t][2]; tot = tot + ldsg[t][3];
-            __hip_atomic_store(reinterpret_cast<U *>(cur + (size_t)pass * stride) + s * G + t, mgs_slot_bits<T>(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mgs_slot_store<XL>(reinterpret_cast<U *>(cur + (size_t)pass * stride) + s * G + t, mgs_slot_bits<T>(tot));
         }
         __syncthreads();
     };
@@ -964,7 +1012,7 @@ __global__ __launch_bounds__(MIK_BLOCK, 1) void k_mgs_fused(int64_t n, int k, co
                 for (int e = 0; e < W; ++e) vr[g][l][e] = zr[g][l][e];        // v_i: subtracted in this pass
         const bool last = i + 1 == k;
         if (!last) load(V + (int64_t)(i + 1) * ldv, zr);                   // v_{i+1}: in flight during the hand-off
-        const T h = mgs_grid_sum<T>(cur + (size_t)i * stride, nseg, lds16, &s_err);
+        const T h = mgs_grid_sum<T, XL>(cur + (size_t)i * stride, nseg, lds16, &s_err);
         if (s == 0 && t == 0) hout[i] = h;
         // w .-= h[i] .* v_i; then dot(v_{i+1}, w) or norm(w)^2            :72, :71 / :75 -- per 16-byte group: all W
         // elements updated, then their products added in element order (the order of OpMgsPass::compute_vec)
@@ -984,7 +1032,7 @@ __global__ __launch_bounds__(MIK_BLOCK, 1) void k_mgs_fused(int64_t n, int k, co
         }
         publish(i + 1, acc);
     }
-    const T ss = mgs_grid_sum<T>(cur + (size_t)k * stride, nseg, lds16, &s_err);
+    const T ss = mgs_grid_sum<T, XL>(cur + (size_t)k * stride, nseg, lds16, &s_err);
     T nrm = mik_sqrt(ss);
     const bool ok = mik_nrm_in_range(ss);          // outside the safe range: leave w unscaled, the host rescales
     const T inv = ok ? T(1) / nrm : T(1);
@@ -1005,7 +1053,7 @@ __global__ __launch_bounds__(MIK_BLOCK, 1) void k_mgs_fused(int64_t n, int k, co
                     if (i0 + e < n) w[i0 + e] = wr[g][l][e] * inv;
             }
         }
-    if (t == 0 && s_err) __hip_atomic_store(&mirror->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t == 0 && s_err) __hip_atomic_store(&mirror->err, s_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (s == 0 && t == 0) {
         hout[k] = nrm;
         __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -1114,6 +1114,9 @@ struct mik_gmres {
     void *mgs_P = nullptr;
     int mgs_G = 1, mgs_stride = 256;  // segments per workgroup of the single-launch kernels; slots per row of mgs_P
     bool fused_off = false;          // latched when the single-launch kernel's bounded spin expired once: multi-launch chains from then on
+    unsigned *xl_chk = nullptr;      // device, 2 words: XCC id + 1 of the participants of the XCD-local form (k_mgs_fused XL), per parity
+    bool xl_off = false;             // the XCD-local form failed once (its workgroups were not on one XCD, or a wait expired): all-XCD form from then on
+    bool xl_last = false;            // the column last enqueued used the XCD-local form
     int mgs_rounds = 1;              // DGKS rounds the single-launch kernel runs before it hands back to the host loop
     MgsMirror *mgs_mirror = nullptr;          // two mirrors (bytes apart: mgs_mirror_stride), used alternately
     size_t mgs_mirror_stride = 0;
@@ -1414,6 +1417,7 @@ static int gmres_create_common(mik_ctx *ctx, const mik_csr *A, void *x, const vo
             g->mgs_rounds = orth_method == MIK_DGKS ? (ctx->tuning[21] > 0 ? std::min(ctx->tuning[21], 3) : 3) : 1;   // development knob 21: DGKS rounds in the kernel
             const size_t pbytes = es * 2 * (size_t)g->mgs_rounds * (size_t)(restart + 2) * (size_t)g->mgs_stride;
             if ((e = hipMalloc(&g->mgs_P, pbytes)) != hipSuccess || (e = hipMemsetAsync(g->mgs_P, 0xFF, pbytes, ctx->stream)) != hipSuccess ||
+                (e = hipMalloc((void **)&g->xl_chk, 2 * sizeof(unsigned))) != hipSuccess || (e = hipMemsetAsync(g->xl_chk, 0, 2 * sizeof(unsigned), ctx->stream)) != hipSuccess ||
                 (g->mgs_mirror_stride = (sizeof(MgsMirror) + es * (size_t)(restart + 2) + 255) / 256 * 256, false) ||
                 (e = hipHostMalloc((void **)&g->mgs_mirror, 2 * g->mgs_mirror_stride, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) {
                 mik_gmres_destroy(g);
@@ -1471,6 +1475,7 @@ extern "C" int mik_gmres_destroy(mik_gmres *g)
     if (g->ctx) (void)hipStreamSynchronize(g->ctx->stream);
     gm_drop_graphs(g);
     if (g->mgs_P) (void)hipFree(g->mgs_P);
+    if (g->xl_chk) (void)hipFree(g->xl_chk);
     if (g->mgs_mirror) (void)hipHostFree(g->mgs_mirror);
     if (g->V) (void)hipFree(g->V);
     if (g->Ax) (void)hipFree(g->Ax);
@@ -1579,6 +1584,16 @@ template <typename T> static int gm_fused_enqueue(mik_gmres *g, int k, int slot)
         else if (g->method == MIK_CGS) MIK_CGS_GO(VECV, false, GG);                                  \
         else MIK_MGS_GO(VECV, GG);                                                                   \
     } while (0)
+    // Modified Gram-Schmidt on small systems: the XCD-local form (k_mgs_fused XL) -- at most 128 workgroups, all on the first XCD, a column
+    // of at most 512 KB per pass: every column then comes through ONE XCD's share of the fabric (~1 MB per us).  fe_shell (363 KB columns):
+    // GMRES(50) 64.2 -> 50.9 us per inner iteration; configs[2] (1 MB columns) would lose (36.5 -> 47.8 us) and keeps the device-wide
+    // form.  Development knob 5 = 4: the device-wide form at every size.
+    const bool xl = g->method == MIK_MGS && G == 1 && vec && m <= 128 && ((size_t)n * sizeof(T) <= (1u << 19) || ctx->tuning[5] == 5) && !g->xl_off && ctx->tuning[5] != 4 && g->xl_chk;   // (knob 5 = 5: whatever the column size)
+    g->xl_last = xl;
+    if (xl) {
+        hipLaunchKernelGGL((k_mgs_fused<T, true, 1, true>), dim3(8 * m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart,
+                           stride, nseg, g->mgs_parity, gm_mirror(g, slot), g->mgs_seq, g->xl_chk);
+    } else
     // G > 1 (more than 256 segments) is instantiated for 16-byte aligned bases only: gmres_create allocates V that way
     if (G == 1) { if (vec) MIK_GS_GO(true, 1); else MIK_GS_GO(false, 1); }
     else if (G == 2) MIK_GS_GO(true, 2);
@@ -1660,7 +1675,7 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
     if (ctx->tuning[5] == 3 && !g->dist && !g->graph_off && g->method != MIK_DGKS && mik_nseg<T>(g->n) <= 1024 && !g->op_mul && !g->pl_fn && !g->pr_fn)
         MIK_TRY(gm_step_graph<T>(g, k, vk, vk1, &Hat(0, k - 1), &nrm, &ran));
     if (!ran) {
-        if (g->mgs_P && !g->dist && !g->fused_off && ctx->tuning[5] == 0) {    // tuning[5]: 1 / 2 = the multi-launch chains
+        if (g->mgs_P && !g->dist && !g->fused_off && (ctx->tuning[5] == 0 || ctx->tuning[5] >= 4)) {    // tuning[5]: 1 / 2 = the multi-launch chains, 4 = single launch on all XCDs
             // single-launch Gram-Schmidt, one column ahead of the host: column k is on the stream already if the previous
             // call put it there; column k + 1 goes on the stream BEFORE this call waits for column k (never across a restart,
             // never with host callbacks in expand!, whose call count the caller may observe)
@@ -1678,7 +1693,8 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
                 MIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 gm_mirror(g, 0)->err = 0;
                 gm_mirror(g, 1)->err = 0;
-                g->fused_off = true;
+                if (g->xl_last && !g->xl_off) g->xl_off = true;       // the XCD-local form: back to the all-XCD single launch, not to the chains
+                else g->fused_off = true;
                 g->pre_k = 0;
                 MIK_TRY(gm_expand<T>(g, vk, vk1));
                 MIK_TRY(orthogonalize_impl<T>(ctx, g->n, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));

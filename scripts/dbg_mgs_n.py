@@ -5,7 +5,10 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 import __graft_entry__ as g
 pkg = g.load_package()
-for N in (8, 16, 24, 32, 40, 50):
+for kv in os.environ.get("MIK_KNOBS", "").split(","):
+    if kv:
+        pkg.lib().mik_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
+for N in [int(v) for v in os.environ.get("NS", "8,16,24,32,40,50").split(",")]:
     n, cp, rv, nz, b = pkg.fixtures.advection_dominated(N)
     A = pkg.HipCSR(n, n, cp, rv, nz, index_base=1)
     db = pkg.HipVector.from_numpy(b)

@@ -320,11 +320,14 @@ def test_orthogonalize_bit_exact_and_invariants(pkg, orc, ctx, method, n, k, dty
         np.testing.assert_allclose(nrm * w + V @ h, w0, rtol=1e-12, atol=1e-13)
 
 
-@pytest.mark.parametrize("orth", ["mgs", "cgs", "dgks"])
-def test_gmres_history_bit_exact_vs_tree_oracle(pkg, orc, ctx, orth):
+@pytest.mark.parametrize("orth,knob5", [("mgs", 0), ("mgs", 4), ("cgs", 0), ("dgks", 0)])
+def test_gmres_history_bit_exact_vs_tree_oracle(pkg, orc, ctx, orth, knob5):
+    """(Modified Gram-Schmidt on a system this small runs the XCD-local form of the single-launch kernel -- all participants on one XCD,
+    slots coherent in its L2; development knob 5 = 4: the device-wide form.  Same bits.)"""
     A, b = orc.advdiff(12, 1000.0)
     W, L = shape_of(ctx, np.float64)
     M = {"mgs": pkg.ModifiedGramSchmidt(), "cgs": pkg.ClassicalGramSchmidt(), "dgks": pkg.DGKS()}[orth]
+    ctx.set_tuning(5, knob5)
     x, ch = pkg.gmres(upload(pkg, A), pkg.HipVector.from_numpy(b), restart=10, log=True, orth_meth=M)
     xo, ho = orc.gmres(A, b, restart=10, orth_meth=orth, mode="tree", shape=(W, L))
     assert ch.iters == ho["iters"] and ch.mvps == ho["mvps"] and ch.isconverged == ho["isconverged"]
