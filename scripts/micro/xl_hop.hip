@@ -8,6 +8,7 @@
 //   mode 2: one XCD, agent-scope accesses (what the placement alone changes)
 //   mode 3: one XCD, store sc0 + "buffer_inv sc0" + plain load;  mode 4: store sc0 + load sc0;  mode 5: store sc1 + "buffer_inv sc0" + plain load
 //   mode 6: one XCD, store sc0 + load nt;  mode 7: store sc1 + load nt
+//   mode 8: all XCDs, slots in FINE-GRAINED device memory, agent-scope accesses;  mode 9: the same slots, plain store + load nt
 // Build: hipcc --offload-arch=gfx950 -O3 xl_hop.hip -o xl_hop
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -19,13 +20,14 @@ static constexpr U EMPTY = ~0ull;
 template <int MODE> __device__ __forceinline__ void slot_store(U *p, U v)
 {
     if (MODE == 1) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");      // no scope bits
+    else if (MODE == 9) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
     else if (MODE == 3 || MODE == 4 || MODE == 6) asm volatile("global_store_dwordx2 %0, %1, off sc0" ::"v"(p), "v"(v) : "memory");   // workgroup scope
     else if (MODE == 5 || MODE == 7) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");   // agent scope (write-through)
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <int MODE> __device__ __forceinline__ U slot_load(const U *p)
 {
-    if (MODE == 6 || MODE == 7) {                             // a non-temporal load: is it served past the L1 every time?
+    if (MODE == 6 || MODE == 7 || MODE == 9) {                // a non-temporal load: is it served past the L1 every time?
         U v;
         asm volatile("global_load_dwordx2 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
         return v;
@@ -47,8 +49,9 @@ template <int MODE>
 __global__ __launch_bounds__(256, 1) void k_hops(U *slots /* [H][NW] */, int NW, int H, const double *col, size_t colwords, int ncols, double *sink, U *result,
                                                 int *err)
 {
-    if (MODE != 0 && (blockIdx.x & 7u)) return;
-    const int s = MODE != 0 ? blockIdx.x >> 3 : blockIdx.x, t = threadIdx.x;
+    constexpr bool ALL = MODE == 0 || MODE >= 8;          // workgroups over all XCDs
+    if (!ALL && (blockIdx.x & 7u)) return;
+    const int s = !ALL ? blockIdx.x >> 3 : blockIdx.x, t = threadIdx.x;
     __shared__ U sh;
     U carry = 0;
     double keep = 0.0;
@@ -96,13 +99,15 @@ int main(int argc, char **argv)
             double *col, *sink;
             int *err;
             hipMalloc(&slots, sizeof(U) * H * NW);
+            U *fslots;
+            hipExtMallocWithFlags((void **)&fslots, sizeof(U) * H * NW, hipDeviceMallocFinegrained);
             hipMalloc(&result, sizeof(U) * NW);
             hipMalloc(&col, colbytes * ncols + 64);
             hipMemset(col, 0, colbytes * ncols + 64);
             hipMalloc(&sink, 64);
             hipMalloc(&err, 4);
             hipMemset(err, 0, 4);
-            for (int mode = 0; mode < 8; ++mode) {
+            for (int mode = 0; mode < 10; ++mode) {
                 if (mode == 1 || mode == 3 || mode == 4 || mode == 5) continue;      // measured: all of them time out (stale L1 lines)
                 hipEvent_t e0, e1;
                 hipEventCreate(&e0); hipEventCreate(&e1);
@@ -111,6 +116,7 @@ int main(int argc, char **argv)
                 bool same = true;
                 for (int rep = 0; rep < reps; ++rep) {
                     hipMemset(slots, 0xFF, sizeof(U) * H * NW);
+                    hipMemset(fslots, 0xFF, sizeof(U) * H * NW);
                     hipDeviceSynchronize();
                     hipEventRecord(e0);
                     if (mode == 0) hipLaunchKernelGGL(k_hops<0>, dim3(NW), dim3(256), 0, 0, slots, NW, H, col, colwords, ncols, sink, result, err);
@@ -120,7 +126,9 @@ int main(int argc, char **argv)
                     else if (mode == 4) hipLaunchKernelGGL(k_hops<4>, dim3(8 * NW), dim3(256), 0, 0, slots, NW, H, col, colwords, ncols, sink, result, err);
                     else if (mode == 5) hipLaunchKernelGGL(k_hops<5>, dim3(8 * NW), dim3(256), 0, 0, slots, NW, H, col, colwords, ncols, sink, result, err);
                     else if (mode == 6) hipLaunchKernelGGL(k_hops<6>, dim3(8 * NW), dim3(256), 0, 0, slots, NW, H, col, colwords, ncols, sink, result, err);
-                    else hipLaunchKernelGGL(k_hops<7>, dim3(8 * NW), dim3(256), 0, 0, slots, NW, H, col, colwords, ncols, sink, result, err);
+                    else if (mode == 7) hipLaunchKernelGGL(k_hops<7>, dim3(8 * NW), dim3(256), 0, 0, slots, NW, H, col, colwords, ncols, sink, result, err);
+                    else if (mode == 8) hipLaunchKernelGGL(k_hops<8>, dim3(NW), dim3(256), 0, 0, fslots, NW, H, col, colwords, ncols, sink, result, err);
+                    else hipLaunchKernelGGL(k_hops<9>, dim3(NW), dim3(256), 0, 0, fslots, NW, H, col, colwords, ncols, sink, result, err);
                     hipEventRecord(e1);
                     hipEventSynchronize(e1);
                     float ms;
