@@ -8,6 +8,7 @@
 //   mode 2: one XCD, agent-scope accesses (what the placement alone changes)
 //   mode 3: one XCD, store sc0 + "buffer_inv sc0" + plain load;  mode 4: store sc0 + load sc0;  mode 5: store sc1 + "buffer_inv sc0" + plain load
 //   mode 6: one XCD, store sc0 + load nt;  mode 7: store sc1 + load nt
+//   mode 10: as mode 0 with four polls in flight per lane
 //   mode 8: all XCDs, slots in FINE-GRAINED device memory, agent-scope accesses;  mode 9: the same slots, plain store + load nt
 // Build: hipcc --offload-arch=gfx950 -O3 xl_hop.hip -o xl_hop
 #include <hip/hip_runtime.h>
@@ -65,6 +66,26 @@ __global__ __launch_bounds__(256, 1) void k_hops(U *slots /* [H][NW] */, int NW,
         U mine = 0;
         if (t < NW) {
             U b = EMPTY;
+            if (MODE == 10) {             // four polls in flight, issued a fraction of a round trip apart: a slot that fills is seen by the next ISSUED load
+                const U *q = slots + (size_t)h * NW + t;
+                U p0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_s_sleep(3);
+                U p1 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_s_sleep(3);
+                U p2 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_s_sleep(3);
+                U p3 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int spin = 0; spin < (1 << 11); ++spin) {
+                    if (p0 != EMPTY) { b = p0; break; }
+                    p0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (p1 != EMPTY) { b = p1; break; }
+                    p1 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (p2 != EMPTY) { b = p2; break; }
+                    p2 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (p3 != EMPTY) { b = p3; break; }
+                    p3 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else
             for (int spin = 0; spin < (1 << 13); ++spin) {
                 b = slot_load<MODE>(slots + (size_t)h * NW + t);
                 if (b != EMPTY) break;
@@ -107,8 +128,8 @@ int main(int argc, char **argv)
             hipMalloc(&sink, 64);
             hipMalloc(&err, 4);
             hipMemset(err, 0, 4);
-            for (int mode = 0; mode < 10; ++mode) {
-                if (mode == 1 || mode == 3 || mode == 4 || mode == 5) continue;      // measured: all of them time out (stale L1 lines)
+            for (int mode = 0; mode < 11; ++mode) {
+                if (mode == 1 || mode == 3 || mode == 4 || mode == 5 || mode == 7 || mode == 9) continue;      // measured: all of them time out (stale L1 lines)
                 hipEvent_t e0, e1;
                 hipEventCreate(&e0); hipEventCreate(&e1);
                 float best = 1e30f;
@@ -128,7 +149,8 @@ int main(int argc, char **argv)
                     else if (mode == 6) hipLaunchKernelGGL(k_hops<6>, dim3(8 * NW), dim3(256), 0, 0, slots, NW, H, col, colwords, ncols, sink, result, err);
                     else if (mode == 7) hipLaunchKernelGGL(k_hops<7>, dim3(8 * NW), dim3(256), 0, 0, slots, NW, H, col, colwords, ncols, sink, result, err);
                     else if (mode == 8) hipLaunchKernelGGL(k_hops<8>, dim3(NW), dim3(256), 0, 0, fslots, NW, H, col, colwords, ncols, sink, result, err);
-                    else hipLaunchKernelGGL(k_hops<9>, dim3(NW), dim3(256), 0, 0, fslots, NW, H, col, colwords, ncols, sink, result, err);
+                    else if (mode == 9) hipLaunchKernelGGL(k_hops<9>, dim3(NW), dim3(256), 0, 0, fslots, NW, H, col, colwords, ncols, sink, result, err);
+                    else hipLaunchKernelGGL(k_hops<10>, dim3(NW), dim3(256), 0, 0, slots, NW, H, col, colwords, ncols, sink, result, err);
                     hipEventRecord(e1);
                     hipEventSynchronize(e1);
                     float ms;
