@@ -414,8 +414,10 @@ template <typename T> struct OpAxpy {
 template <typename T> struct OpBicgU {
     static constexpr bool REDUCE = false;
     T *__restrict__ us; int64_t ldu; const T *__restrict__ rs; int64_t ldr; int ncols; Coef<T> neg_beta;
-    int nt = 0;    // 1: everything streamed except the store of the LAST column -- the input of the SpMV that follows, which the Infinity Cache
-                   // should keep (the SpMV of the CG loop takes 47 us on a cached input, 75 us behind a sweep that left its tails there)
+    int nt = 0;    // bits: 1 loads streamed, 2 stores of all but the last column streamed, 4 store of the last column streamed (mik_bicgstab_step: 7).  (3 =
+                   // everything streamed except the store of the LAST column -- the input of the SpMV that follows, which the Infinity Cache
+                   // should keep (the SpMV of the CG loop takes 47 us on a cached input, 75 us behind a sweep that left its tails there) -- was the first
+                   // guess; measured, 7 is 1 % faster.)
     __device__ __forceinline__ void apply(int64_t i, T &) const
     {
         const T b = neg_beta.get();
@@ -426,18 +428,18 @@ template <typename T> struct OpBicgU {
         const T b = neg_beta.get();
         for (int q = 0; q < ncols; ++q) {
             T *u = us + q * ldu;
-            auto xv = nt ? vload_nt(rs + q * ldr + i) : vload(rs + q * ldr + i);
-            auto yv = nt ? vload_nt<T>(u + i) : vload<T>(u + i);
+            auto xv = (nt & 1) ? vload_nt(rs + q * ldr + i) : vload(rs + q * ldr + i);
+            auto yv = (nt & 1) ? vload_nt<T>(u + i) : vload<T>(u + i);
 #pragma unroll
             for (int e = 0; e < VT<T>::W; ++e) { T t = b * el<T>(yv, e); el<T>(yv, e) = el<T>(xv, e) + t; }
-            if (nt && q + 1 < ncols) vstore_nt(u + i, yv); else vstore(u + i, yv);
+            if (q + 1 < ncols ? (nt & 2) : (nt & 4)) vstore_nt(u + i, yv); else vstore(u + i, yv);
         }
     }
 };
 template <typename T> struct OpBicgR {
     static constexpr bool REDUCE = false;
     const T *__restrict__ us; int64_t ldu; T *__restrict__ rs; int64_t ldr; int ncols; T *__restrict__ x; Coef<T> neg_alpha, alpha;
-    int nt = 0;    // 1: everything streamed except the store of the LAST residual column (the input of the SpMV that follows), as in OpBicgU
+    int nt = 0;    // the bits of OpBicgU (last column = the last residual column, the input of the SpMV that follows; x counts as another column)
     __device__ __forceinline__ void apply(int64_t i, T &) const
     {
         const T na = neg_alpha.get(), a = alpha.get();
@@ -448,17 +450,17 @@ template <typename T> struct OpBicgR {
     {
         const T na = neg_alpha.get(), a = alpha.get();
         for (int q = 0; q < ncols; ++q) {
-            auto xv = nt ? vload_nt(us + (q + 1) * ldu + i) : vload(us + (q + 1) * ldu + i);
-            auto yv = nt ? vload_nt<T>(rs + q * ldr + i) : vload<T>(rs + q * ldr + i);
+            auto xv = (nt & 1) ? vload_nt(us + (q + 1) * ldu + i) : vload(us + (q + 1) * ldu + i);
+            auto yv = (nt & 1) ? vload_nt<T>(rs + q * ldr + i) : vload<T>(rs + q * ldr + i);
 #pragma unroll
             for (int e = 0; e < VT<T>::W; ++e) { T t = na * el<T>(xv, e); el<T>(yv, e) = el<T>(yv, e) + t; }
-            if (nt && q + 1 < ncols) vstore_nt(rs + q * ldr + i, yv); else vstore(rs + q * ldr + i, yv);
+            if (q + 1 < ncols ? (nt & 2) : (nt & 4)) vstore_nt(rs + q * ldr + i, yv); else vstore(rs + q * ldr + i, yv);
         }
-        auto uv = nt ? vload_nt(us + i) : vload(us + i);
-        auto xx = nt ? vload_nt<T>(x + i) : vload<T>(x + i);
+        auto uv = (nt & 1) ? vload_nt(us + i) : vload(us + i);
+        auto xx = (nt & 1) ? vload_nt<T>(x + i) : vload<T>(x + i);
 #pragma unroll
         for (int e = 0; e < VT<T>::W; ++e) { T t = a * el<T>(uv, e); el<T>(xx, e) = el<T>(xx, e) + t; }
-        if (nt) vstore_nt(x + i, xx); else vstore(x + i, xx);
+        if (nt & 2) vstore_nt(x + i, xx); else vstore(x + i, xx);
     }
 };
 

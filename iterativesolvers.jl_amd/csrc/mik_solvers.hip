@@ -349,7 +349,7 @@ template <typename T> static int bicg_step_impl(mik_bicgstab *it, T *residual)
     auto ldiv = [&](T *v) { return it->pl_diag ? mik_divide(ctx, it->dtype, n, v, it->pl_diag, v) : MIK_OK; };
     const bool blockvec = mik_aligned16(us) && mik_aligned16(rs) && mik_aligned16(x) && (it->ldu % VT<T>::W == 0) && (it->ldr % VT<T>::W == 0);
     const bool lean = nseg <= 1024 && ctx->tuning[25] == 0;   // the sweeps finalise their producers' reductions themselves (k_map_with; development knob 25 = 1: separate finaliser launches)
-    const int bnt = ctx->tuning[7] < 0 ? 0 : 1;               // the block sweeps stream everything but the input of the SpMV behind them (development knob 7 < 0: all cached)
+    const int bnt = ctx->tuning[7] < 0 ? 0 : (ctx->tuning[7] >= 16 ? (ctx->tuning[7] >> 4) & 7 : 7);   // the block sweeps stream everything -- also the column the SpMV behind them reads: with 3 to 9 columns in flight the Infinity Cache keeps too little of it to matter (mask 3, that store cached: 1,174-1,177 us; 7: 1,160-1,169; loads only: 1,217; development knob 7 < 0: all cached; bits 4-6: explicit mask)
     // sigma = dot(r_shadow, A u) (:100) and, from the second column on, rho = dot(r_shadow, A r) (:89) leave the SpMV launch that forms the
     // vector (epilogue dot(z, y), one partial per 256-row block: mik_bicgstab_dot_shape) -- a sweep over two vectors and a launch less each
     const int64_t nb = mik_spmv_nwg(n);
