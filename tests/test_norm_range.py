@@ -99,3 +99,33 @@ def test_gmres_on_a_badly_scaled_system(pkg, orc, ctx, orth):
     x1, h1 = pkg.gmres(pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval), pkg.HipVector.from_numpy(b), restart=12, log=True, orth_meth=M)
     assert abs(h.iters - h1.iters) <= 2
     np.testing.assert_allclose(x.to_numpy(), x1.to_numpy(), rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [1.0, 1e-140])
+@pytest.mark.parametrize("knob9", [0, 1])
+@pytest.mark.parametrize("batch", [1, 4])
+def test_cg_stepping_at_128_cubed_through_freezes_and_maxiter(pkg, orc, ctx, scale, knob9, batch):
+    """The production-size step (2 M rows: spread finalisers, look-ahead, x riding on the next sweep over u) stepped one by one and in
+    batches, with look-ahead on and off (knob 9), on a right-hand side whose |r|^2 leaves the safe range in every step (each step frozen
+    and finished by the host: x must not be updated twice, whichever kernel applied it), into maxiter and beyond: bit for bit the
+    oracle's history and x."""
+    A = orc.laplace(128, 3)
+    b = orc.hashed_rhs(A.n) * scale
+    dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
+    steps = 8 if scale != 1.0 else 12
+    ctx.set_tuning(9, knob9)
+    db = pkg.HipVector.from_numpy(b)
+    x = pkg.zerox(dA, db)
+    it = pkg.cg_iterator_(x, dA, db, initially_zero=True, reltol=0.0, maxiter=steps + 3)
+    hist = []
+    k = 0
+    while k < steps:
+        got = it.iterate_many(k, min(batch, steps - k))
+        assert got.size == min(batch, steps - k)
+        hist.extend(got.tolist())
+        k += got.size
+    tail = it.iterate_many(k, 10)                            # runs into maxiter; asked again, nothing may move
+    assert tail.size == 3 and it.iterate_many(k + 3, 5).size == 0
+    xo, ho = orc.cg(A, b, maxiter=steps + 3, reltol=0.0, mode="tree", shape=ctx.cg_shape(np.float64))
+    assert np.array_equal(np.array(hist + tail.tolist()), np.asarray(ho["resnorm"])) and np.array_equal(x.to_numpy(), xo)
