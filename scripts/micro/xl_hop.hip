@@ -8,7 +8,7 @@
 //   mode 2: one XCD, agent-scope accesses (what the placement alone changes)
 //   mode 3: one XCD, store sc0 + "buffer_inv sc0" + plain load;  mode 4: store sc0 + load sc0;  mode 5: store sc1 + "buffer_inv sc0" + plain load
 //   mode 6: one XCD, store sc0 + load nt;  mode 7: store sc1 + load nt
-//   mode 10: as mode 0 with four polls in flight per lane
+//   mode 10: as mode 0 with four polls in flight per lane;  mode 11 / 12: as mode 0 with s_sleep 2 / 8 after a poll that found the slot empty
 //   mode 8: all XCDs, slots in FINE-GRAINED device memory, agent-scope accesses;  mode 9: the same slots, plain store + load nt
 // Build: hipcc --offload-arch=gfx950 -O3 xl_hop.hip -o xl_hop
 #include <hip/hip_runtime.h>
@@ -87,8 +87,10 @@ __global__ __launch_bounds__(256, 1) void k_hops(U *slots /* [H][NW] */, int NW,
                 }
             } else
             for (int spin = 0; spin < (1 << 13); ++spin) {
-                b = slot_load<MODE>(slots + (size_t)h * NW + t);
+                b = slot_load<MODE == 11 || MODE == 12 ? 0 : MODE>(slots + (size_t)h * NW + t);
                 if (b != EMPTY) break;
+                if (MODE == 11) __builtin_amdgcn_s_sleep(2);
+                if (MODE == 12) __builtin_amdgcn_s_sleep(8);
             }
             if (b == EMPTY) { *err = 1; b = 0; }
             mine = b;
@@ -112,8 +114,8 @@ int main(int argc, char **argv)
 {
     const int H = 64, reps = 5;
     const int ncols = 32;
-    for (size_t colbytes : {(size_t)0, (size_t)1 << 20}) {
-        for (int NW : {32, 64}) {
+    for (size_t colbytes : {(size_t)0, (size_t)4 << 20}) {
+        for (int NW : {32, 64, 128, 245}) {
             const size_t colwords = colbytes / 8;
             if (colwords / NW > 4096) continue;                          // 16 loads of 256 doubles per thread and hop at most
             U *slots, *result;
@@ -128,8 +130,8 @@ int main(int argc, char **argv)
             hipMalloc(&sink, 64);
             hipMalloc(&err, 4);
             hipMemset(err, 0, 4);
-            for (int mode = 0; mode < 11; ++mode) {
-                if (mode == 1 || mode == 3 || mode == 4 || mode == 5 || mode == 7 || mode == 9) continue;      // measured: all of them time out (stale L1 lines)
+            for (int mode = 0; mode < 13; ++mode) {
+                if (mode == 1 || mode == 3 || mode == 4 || mode == 5 || mode == 7 || mode == 9 || mode == 2 || mode == 8 || mode == 10) continue;      // measured: all of them time out (stale L1 lines)
                 hipEvent_t e0, e1;
                 hipEventCreate(&e0); hipEventCreate(&e1);
                 float best = 1e30f;
@@ -150,7 +152,9 @@ int main(int argc, char **argv)
                     else if (mode == 7) hipLaunchKernelGGL(k_hops<7>, dim3(8 * NW), dim3(256), 0, 0, slots, NW, H, col, colwords, ncols, sink, result, err);
                     else if (mode == 8) hipLaunchKernelGGL(k_hops<8>, dim3(NW), dim3(256), 0, 0, fslots, NW, H, col, colwords, ncols, sink, result, err);
                     else if (mode == 9) hipLaunchKernelGGL(k_hops<9>, dim3(NW), dim3(256), 0, 0, fslots, NW, H, col, colwords, ncols, sink, result, err);
-                    else hipLaunchKernelGGL(k_hops<10>, dim3(NW), dim3(256), 0, 0, slots, NW, H, col, colwords, ncols, sink, result, err);
+                    else if (mode == 10) hipLaunchKernelGGL(k_hops<10>, dim3(NW), dim3(256), 0, 0, slots, NW, H, col, colwords, ncols, sink, result, err);
+                    else if (mode == 11) hipLaunchKernelGGL(k_hops<11>, dim3(NW), dim3(256), 0, 0, slots, NW, H, col, colwords, ncols, sink, result, err);
+                    else hipLaunchKernelGGL(k_hops<12>, dim3(NW), dim3(256), 0, 0, slots, NW, H, col, colwords, ncols, sink, result, err);
                     hipEventRecord(e1);
                     hipEventSynchronize(e1);
                     float ms;
