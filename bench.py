@@ -147,10 +147,10 @@ def gmres_config3():
     import torch
     pkg = graft.load_package()
     N, restart = 50, 30
-    orc = graft.load_oracle()
-    Ao, b = orc.advdiff(N, 1000.0)                        # the rhs of the golden run (exp / sin of the C library; numpy's differ by an ulp)
-    n = Ao.n
-    A = pkg.HipCSR(n, n, Ao.colptr, Ao.rowval, Ao.nzval, index_base=Ao.index_base)
+    # inputs from the PRODUCT-side fixture (rhs through libm's exp / sin, bit-equal to the oracle's generator and to the golden run:
+    # tests/test_host_logic.py::test_advection_dominated_fixture_equals_the_oracle_generator); the oracle is only the CPU leg below
+    n, colptr, rowval, nzval, b = pkg.fixtures.advection_dominated(N, 1000.0)
+    A = pkg.HipCSR(n, n, colptr, rowval, nzval, index_base=1)
     db = pkg.HipVector.from_numpy(b)
     out = {"workload": f"gmres!(restart={restart}) on advection_dominated(N={N}, beta=1000), fp64, n = {n}, nnz = {A.nnz} (BASELINE.json configs[2])",
            "operator_layout": A.layout(), "spmv_kernel": A.spmv_kernel(), "us_per_inner_iteration": {}}
@@ -181,6 +181,8 @@ def gmres_config3():
                                      "iters": int(hist.size), "golden_iters": int(g["tree"]["iters"]),
                                      "first_cycle_max_rel_dev_vs_blas": float(np.max(np.abs(hist[:restart] - blas[:restart]) / blas[:restart])),
                                      "whole_history_max_rel_dev_vs_blas": float(np.max(np.abs(hist[:m] - blas[:m]) / blas[:m]))}
+    orc = graft.load_oracle()                             # CPU leg only
+    Ao = orc.CSC(n, colptr, rowval, nzval, 1)
     t0 = time.perf_counter()
     _, ho = orc.gmres(Ao, b, restart=restart)
     dt = time.perf_counter() - t0
@@ -419,7 +421,7 @@ def run_single(args):
     default_spmv = {"kernel": kern + "<double, fused dot>", "operator_layout": layout, "bytes_moved_per_launch": stored_bytes, "avg_launch_ms": spmv_ms,
                     "launches_timed": int(spmv_launches), "back_to_back_ms": b2b_ms, "achieved_moved": moved_gbs, "frac_moved": moved_gbs / HBM_PEAK_GBS,
                     "frac_of_copy_ceiling_6290": moved_gbs / COPY_CEILING_GBS, "traffic": d_traffic, "traffic_source": d_src,
-                    "note": "the SpMV of the loop behind `value`: this constant-coefficient operator keeps ONE mask byte per row instead of 57 B of values "
+                    "note": "the SpMV of the loop behind `default_layout_iters_per_sec`: this constant-coefficient operator keeps ONE mask byte per row instead of 57 B of values "
                             "and indices, so the launch moves 17 B per row instead of 73; achieved_moved / frac_moved = the bytes it actually streams "
                             "(`traffic`: committed PMC constant) over its HIP-event time inside the loop.  Not the north star's CSR figure: that is `roofline`."}
     if csr is not None:
@@ -438,29 +440,41 @@ def run_single(args):
                     "note": "SURVEY.md 8d: algorithmic bytes of the Int32 CSR SpMV (nnz*(s+4) + (n+1)*4 + 2*n*s = 1,740,111,876 B at 256^3 fp64) over the "
                             "average HIP-event duration of the SpMV launch INSIDE the cg! loop, on the plain CSR arrays of the operator "
                             "(mik_csr_set_layout(A, 0); k_spmv_rowgather moves exactly those bytes: `traffic`).  loop_* = that CSR loop itself (the contract "
-                            "rate: cg! iterations/s moving B_spmv + 9 n s per step).  `value` is the SAME iteration, bit-identical results, in the operator's "
-                            "default layout, which moves config.value_loop_bytes_per_step instead (`default_layout_spmv`)."}
+                            "rate: cg! iterations/s moving B_spmv + 9 n s per step) = `value`.  `default_layout_iters_per_sec` is the SAME iteration, "
+                            "bit-identical results, in the operator's default layout, which moves config.default_layout.bytes_per_step instead (`default_layout_spmv`)."}
     else:
         roofline = {"bound": "hbm", "kernel": kern + "<double, fused dot>", "loop": "the timed loop (contract CSR loop skipped: --no-csr)",
                     "achieved": moved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved_gbs / HBM_PEAK_GBS, "traffic": d_traffic, "traffic_source": d_src,
                     "bytes_moved_per_launch": stored_bytes, "avg_launch_ms": spmv_ms,
                     "loop_ms_per_step": dt / K * 1e3, "loop_iters_per_sec": K / dt,
                     "note": "bytes this layout actually moves per launch over the in-loop HIP-event time; NOT the CSR-algorithmic figure"}
+    # `value` = the CONTRACT loop (BASELINE.json configs[1]: "HIP CSR SpMV + fused dot/axpy"): cg! on the operator's plain Int32 CSR arrays, which
+    # moves SURVEY.md 8d's B_cg = B_spmv + 9 n s per step -- so value_bytes_per_step / ms_per_step <= 8 TB/s can be checked from the top level alone.
+    # The same iteration in the layout mik_csr_create picks by itself for this constant-coefficient operator (one mask byte per row,
+    # bit-identical results) is reported next to it as `default_layout_iters_per_sec`.
+    value_is_csr = csr is not None
+    v_ips, v_ms = (csr["iters_per_sec"], csr["ms_per_step"]) if value_is_csr else (K / dt, dt / K * 1e3)
+    v_regions = csr["timed_regions"] if value_is_csr else len(times)
     out = {
-        "metric": "cg_iters_per_sec", "value": K / dt, "unit": "iters/s", "n_gpus": 1, "steps": K, "warmup": Wm,
-        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": "cg_iters_per_sec", "value": v_ips, "unit": "iters/s", "n_gpus": 1, "steps": K, "warmup": Wm,
+        "ms_per_step": v_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
+        "value_is_contract": bool(value_is_csr),
+        "value_bytes_per_step": iter_alg if value_is_csr else iter_moved,
+        "value_gbs": (iter_alg if value_is_csr else iter_moved) / (v_ms * 1e-3) / 1e9,
+        "default_layout_iters_per_sec": K / dt, "default_layout_ms_per_step": dt / K * 1e3,
         "config": {"workload": f"cg! on {N}^3 3D 7-point Laplacian (test/laplace_matrix.jl), fp64, hashed rhs, x0 = 0 "
                                f"(BASELINE.json configs[1])", "n": n, "nnz": nnz, "reltol_in_timed_loop": 0.0, "host_sync_per_step": 1,
-                   "operator_layout_of_the_timed_loop": layout,
-                   "value_loop_bytes_per_step": iter_moved, "value_loop_gbs": iter_moved / (dt / K) / 1e9,
-                   "value_loop_frac_of_8000": iter_moved / (dt / K) / 1e9 / HBM_PEAK_GBS,
-                   "value_loop_spmv_avg_launch_ms": spmv_ms,
-                   "value_loop_note": ("`value` = this loop.  Its SpMV streams one mask byte per row instead of the CSR arrays (constant-coefficient operator, "
-                                       "bit-identical results), so a step moves value_loop_bytes_per_step, not SURVEY.md 8d's B_cg; the CSR contract loop "
-                                       "(B_cg per step) is roofline.loop_*") if layout != "csr-rowblock" else "`value` = the CSR loop",
-                   "timed_regions": len(times), "timed_seconds_total": float(sum(times)), "region_seconds_min_max": [float(min(times)), float(max(times))],
-                   "operator_upload_seconds": upload_seconds, "final_residual": residual},
+                   "operator_layout_of_the_timed_loop": "csr (mik_csr_set_layout(A, 0): Int32 rowptr / col / val, k_spmv_rowgather)" if value_is_csr else layout,
+                   "timed_regions": v_regions,
+                   "operator_upload_seconds": upload_seconds, "final_residual": csr["final_residual"] if value_is_csr else residual,
+                   "default_layout": {"operator_layout": layout, "iters_per_sec": K / dt, "ms_per_step": dt / K * 1e3,
+                                      "bytes_per_step": iter_moved, "gbs": iter_moved / (dt / K) / 1e9,
+                                      "frac_of_8000": iter_moved / (dt / K) / 1e9 / HBM_PEAK_GBS, "spmv_avg_launch_ms": spmv_ms,
+                                      "timed_regions": len(times), "timed_seconds_total": float(sum(times)),
+                                      "region_seconds_min_max": [float(min(times)), float(max(times))], "final_residual": residual,
+                                      "note": "what cg! does on this input when the layout is left to mik_csr_create: the SpMV streams one mask byte per row "
+                                              "instead of the CSR arrays (constant-coefficient operator), same residual history bit for bit; NOT the contract figure"}},
         "contract_csr_loop": csr,
         "roofline": roofline,
         "default_layout_spmv": default_spmv,

@@ -6,6 +6,8 @@ generators in oracle/mik_oracle.c; tests cross-check the two.
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 
 
@@ -61,9 +63,16 @@ def advection_dominated(N: int = 50, beta: float = 1000.0, index_base: int = 1):
     nzval[diff == 0] = lap_diag
     nzval[diff == -1] = lap_off + dx_sup                    # A[i, i+1]
     nzval[diff == 1] = lap_off + dx_sub                     # A[i, i-1]
+    # rhs (benchmark/advection_diffusion.jl:1,27): f(x, y, z) = exp(x y z) sin(pi x) sin(pi y) sin(pi z) on the interior grid, x fastest.
+    # exp / sin are the C library's (math.exp / math.sin call libm, as Julia's and the oracle's do to within the same correctly-rounded
+    # results on this platform); numpy's SIMD exp differs from libm by an ulp on some arguments, which would move every residual
+    # of the committed golden history.  The products are formed left to right like the reference's expression.
     xs = np.arange(1, N + 1, dtype=np.float64) / np.float64(N + 1)
+    sn = np.array([math.sin(math.pi * float(v)) for v in xs])
     X, Y, Z = xs[None, None, :], xs[None, :, None], xs[:, None, None]    # x fastest
-    b = np.exp(X * Y * Z) * np.sin(np.pi * X) * np.sin(np.pi * Y) * np.sin(np.pi * Z)
+    arg = np.ascontiguousarray(np.broadcast_to((X * Y) * Z, (N, N, N))).reshape(-1)
+    ex = np.fromiter(map(math.exp, arg.tolist()), np.float64, count=arg.size).reshape(N, N, N)
+    b = ((ex * sn[None, None, :]) * sn[None, :, None]) * sn[:, None, None]
     return n, colptr + index_base, rowval + index_base, nzval, np.ascontiguousarray(b.reshape(-1))
 
 

@@ -211,7 +211,7 @@ def test_gloo_world2_partitioned_gmres_links_match_oracle(pkg, orc, tmp_path, me
     port = 29300 + os.getpid() % 250 + (7 if method == "cgs" else 0)
     mp.spawn(_gloo_gmres_worker, args=(world, port, method, str(tmp_path)), nprocs=world, join=True)
     A, _ = orc.advdiff(7, 300.0)
-    b = pkg.fixtures.advection_dominated(7, 300.0)[4]     # the workers' rhs (numpy's exp/sin, not libm's)
+    b = pkg.fixtures.advection_dominated(7, 300.0)[4]     # the workers' rhs (the product-side fixture)
     orc.set_partition(np.array([0, 150, A.n]))
     try:
         xo, ho = orc.gmres(A, b, restart=6, maxiter=60, reltol=1.5e-8, orth_meth=method, mode="tree", shape=(2, 2))

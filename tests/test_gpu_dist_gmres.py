@@ -197,7 +197,7 @@ def test_process_ranks_match_partitioned_oracle(pkg, orc, ctx, tmp_path, world, 
     port = 29900 + os.getpid() % 90 + world
     mp.spawn(_proc_worker, args=(world, port, str(tmp_path), backend), nprocs=world, join=True)
     A, _ = orc.advdiff(10, 1000.0)
-    b = pkg.fixtures.advection_dominated(10, 1000.0)[4]   # the workers' rhs (numpy's exp/sin, not libm's)
+    b = pkg.fixtures.advection_dominated(10, 1000.0)[4]   # the workers' rhs (the product-side fixture)
     offsets = np.load(tmp_path / "off0.npy")
     orc.set_partition(offsets)
     try:
