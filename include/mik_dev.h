@@ -44,6 +44,12 @@ extern "C" {
  *      the end of the vectors; 8: every launch against the one before it) -- no effect at the default cache hints */
 int mik_set_tuning(int key, int value);
 int mik_ctx_set_tuning(mik_ctx *ctx, int key, int value);
+/* Host-only: the rule that places a 256-row block's window of x in LDS (k_spmv_rowblock XWIN) on caller-supplied per-block statistics
+ * (first / last referenced column, entry count).  win_lo[b] = first column of block b's window (16-byte aligned) or -1 (the block gathers from
+ * memory); *span = common window length in elements, 0 = no window table.  Guarantee the tests check: win_lo[b] >= 0 implies
+ * win_lo[b] <= first_col[b], last_col[b] < win_lo[b] + span <= n_cols. */
+int mik_dev_xwin_plan(int64_t n_blocks, const int *first_col, const int *last_col, const int *entries, int elem_size, int64_t n_cols,
+                      int64_t total_entries, int *win_lo, int *span);
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,7 @@ SIGNATURES = {
     "mik_spmv_dot_shape": (C.c_int, [_ip, _ip]),
     "mik_set_tuning": (C.c_int, [C.c_int, C.c_int]),
     "mik_ctx_set_tuning": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "mik_dev_xwin_plan": (C.c_int, [_i64, _ip, _ip, _ip, C.c_int, _i64, _i64, _ip, _ip]),
     "mik_spmv_long_row": (C.c_int, [_ip]),
     "mik_spmv_long_segment": (C.c_int, [_ip]),
     "mik_spmv_long_group": (C.c_int, [_ip]),

@@ -188,6 +188,20 @@ extern "C" int mik_set_tuning(int key, int value)
     return MIK_OK;
 }
 
+// Host-only (no device needed): the window rule of the product-tile kernel on caller-supplied block statistics, so that the rule
+// itself is testable on a box without a GPU (tests/test_host_logic.py replays ADVICE r4's n = 9001 case).
+extern "C" int mik_dev_xwin_plan(int64_t n_blocks, const int *first_col, const int *last_col, const int *entries, int elem_size, int64_t n_cols,
+                                 int64_t total_entries, int *win_lo, int *span)
+{
+    if (n_blocks < 0 || !first_col || !last_col || !entries || !win_lo || !span || (elem_size != 4 && elem_size != 8)) return MIK_ERR_INVALID;
+    std::vector<int> lo;
+    int sp = 0;
+    const bool built = mik_xwin_plan(n_blocks, first_col, last_col, entries, (size_t)elem_size, n_cols, total_entries, lo, &sp);
+    *span = built ? sp : 0;
+    for (int64_t b = 0; b < n_blocks; ++b) win_lo[b] = built ? lo[(size_t)b] : -1;
+    return MIK_OK;
+}
+
 extern "C" int mik_reduce_shape(int dtype, int *W, int *L)
 {
     if (dtype != MIK_F64 && dtype != MIK_F32) return MIK_ERR_INVALID;
@@ -704,32 +718,21 @@ static int csr_build_xwin(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
 {
     if (A->sdia_val || A->sdia_pats || A->sdiaw_pats || A->jds_val || n_rows <= 0 || ctx->tuning[29] == 1) return MIK_OK;
     if (A->n_long == 0 && max_row <= 32) return MIK_OK;
-    const int W = (int)(16 / es), XP = (int)(1024 / es);
-    const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK, cap = 32768 / (int64_t)es - W;
-    std::vector<int> lo((size_t)nb, 0);
-    int64_t need = 0, inside = 0;                               // widest qualifying block; entries of the qualifying blocks
+    const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
+    std::vector<int> mn((size_t)nb, INT32_MAX), mx((size_t)nb, -1), cnt((size_t)nb, 0), lo;
     for (int64_t b = 0; b < nb; ++b) {
         const int ka = rowptr[(size_t)(b * MIK_BLOCK)], kb = rowptr[(size_t)std::min<int64_t>((b + 1) * MIK_BLOCK, n_rows)];
-        if (kb <= ka) continue;
-        int mn = INT32_MAX, mx = -1;
-        for (int k = ka; k < kb; ++k) { mn = std::min(mn, col[(size_t)k]); mx = std::max(mx, col[(size_t)k]); }
-        lo[(size_t)b] = mn & ~(W - 1);
-        const int64_t nd = (int64_t)mx + 1 - lo[(size_t)b];
-        if (nd > cap) { lo[(size_t)b] = -1; continue; }         // this block gathers from memory
-        need = std::max(need, nd);
-        inside += kb - ka;
+        cnt[(size_t)b] = kb - ka;
+        for (int k = ka; k < kb; ++k) { mn[(size_t)b] = std::min(mn[(size_t)b], col[(size_t)k]); mx[(size_t)b] = std::max(mx[(size_t)b], col[(size_t)k]); }
     }
-    if (need <= 0 || 4 * inside < 3 * (int64_t)rowptr[(size_t)n_rows]) return MIK_OK;
-    const int64_t span = (need + W + XP - 1) / XP * XP;
-    if (span + W > n_cols) return MIK_OK;
-    for (int64_t b = 0; b < nb; ++b)
-        if (lo[(size_t)b] >= 0 && (int64_t)lo[(size_t)b] + span > n_cols) lo[(size_t)b] = (int)((n_cols - span) & ~(int64_t)(W - 1));
+    int span = 0;
+    if (!mik_xwin_plan(nb, mn.data(), mx.data(), cnt.data(), es, n_cols, (int64_t)rowptr[(size_t)n_rows], lo, &span)) return MIK_OK;
     hipError_t e;
     (void)hipSetDevice(ctx->device);
     if ((e = hipMalloc((void **)&A->xwin_lo, sizeof(int) * (size_t)nb)) != hipSuccess ||
         (e = hipMemcpy(A->xwin_lo, lo.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice)) != hipSuccess)
         return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: window table: %s", hipGetErrorString(e));
-    A->xwin_span = (int)span;
+    A->xwin_span = span;
     return MIK_OK;
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -133,6 +134,41 @@ int mik_ensure_partials(mik_ctx *ctx, size_t bytes);
 int mik_build_sdiaw_device(mik_ctx *ctx, mik_csr *A);
 int mik_build_jds_device(mik_ctx *ctx, mik_csr *A);
 bool mik_spmv_has_epilogue(const mik_csr *A);   // the active SpMV kernel of A takes the y = A x + c w epilogue (ctx->spmv_ep_*)
+// The window rule of the product-tile kernel (k_spmv_rowblock XWIN), shared by the host builder (csr_build_xwin, mik_core.hip) and the
+// device builder (mik_build_xwin_device, mik_upload.hip) so that they cannot disagree.  Input: per 256-row block the smallest / largest
+// column its short rows reference and their entry count (cnt <= 0: no entries).  A block's window starts at its first column aligned
+// DOWN to 16 bytes (the LDS-DMA source must be 16-byte aligned); all windows share one span = the widest qualifying block's, rounded up
+// to whole 1-KiB pieces; a block that spans more than 32 KB of x is marked -1 (it gathers from memory).  A window that would leave x at
+// the end of the vector slides down to the last aligned start that keeps it inside x -- when n_cols is not a multiple of 16 bytes that
+// start leaves the last n_cols % W columns OUTSIDE the window, and the kernel has no memory fall-back inside a windowed block
+// (an out-of-window column would be clamped to the window's last element): such a block is marked -1 too.
+// Returns false when no window table should be built.
+static inline bool mik_xwin_plan(int64_t nb, const int *mn, const int *mx, const int *cnt, size_t es, int64_t n_cols, int64_t total_entries,
+                                 std::vector<int> &lo, int *span_out)
+{
+    const int W = (int)(16 / es), XP = (int)(1024 / es);
+    const int64_t cap = 32768 / (int64_t)es - W;
+    lo.assign((size_t)nb, 0);
+    int64_t need = 0, inside = 0;                               // widest qualifying block; entries of the qualifying blocks
+    for (int64_t b = 0; b < nb; ++b) {
+        if (cnt[b] <= 0) continue;
+        lo[(size_t)b] = mn[b] & ~(W - 1);
+        const int64_t nd = (int64_t)mx[b] + 1 - lo[(size_t)b];
+        if (nd > cap) { lo[(size_t)b] = -1; continue; }         // this block gathers from memory
+        need = std::max(need, nd);
+        inside += cnt[b];
+    }
+    if (need <= 0 || 4 * inside < 3 * total_entries) return false;
+    const int64_t span = (need + W + XP - 1) / XP * XP;
+    if (span + W > n_cols) return false;
+    for (int64_t b = 0; b < nb; ++b) {
+        if (cnt[b] <= 0 || lo[(size_t)b] < 0 || (int64_t)lo[(size_t)b] + span <= n_cols) continue;
+        const int64_t slid = (n_cols - span) & ~(int64_t)(W - 1);
+        lo[(size_t)b] = slid + span > (int64_t)mx[b] ? (int)slid : -1;
+    }
+    *span_out = (int)span;
+    return true;
+}
 int mik_build_xwin_device(mik_ctx *ctx, mik_csr *A);
 int mik_build_rperm_host(mik_ctx *ctx, mik_csr *A, const int *rowptr_host);   // rows of a block sorted by length over its threads (k_spmv_rowblock RPERM)   // after the jagged slices: windows of x for the product-tile kernel (k_spmv_rowblock XWIN)
 

@@ -826,27 +826,12 @@ int mik_build_xwin_device(mik_ctx *ctx, mik_csr *A)
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return mik_fail(ctx, MIK_ERR_HIP, "mik_csr_create: window statistics: %s", hipGetErrorString(e));
-    const size_t es = mik_dtype_size(A->dtype);
-    const int W = (int)(16 / es), XP = (int)(1024 / es);
-    const int64_t cap = 32768 / (int64_t)es - W, n_cols = A->n_cols;
-    std::vector<int> lo((size_t)nb, 0);
-    int64_t need = 0, inside = 0;
-    for (int64_t b = 0; b < nb; ++b) {
-        if (h[(size_t)(2 * nb + b)] <= 0) continue;
-        lo[(size_t)b] = h[(size_t)b] & ~(W - 1);
-        const int64_t nd = (int64_t)h[(size_t)(nb + b)] + 1 - lo[(size_t)b];
-        if (nd > cap) { lo[(size_t)b] = -1; continue; }
-        need = std::max(need, nd);
-        inside += h[(size_t)(2 * nb + b)];
-    }
-    if (need <= 0 || 4 * inside < 3 * A->nnz) return MIK_OK;
-    const int64_t span = (need + W + XP - 1) / XP * XP;
-    if (span + W > n_cols) return MIK_OK;
-    for (int64_t b = 0; b < nb; ++b)
-        if (lo[(size_t)b] >= 0 && (int64_t)lo[(size_t)b] + span > n_cols) lo[(size_t)b] = (int)((n_cols - span) & ~(int64_t)(W - 1));
+    std::vector<int> lo;
+    int span = 0;
+    if (!mik_xwin_plan(nb, h.data(), h.data() + nb, h.data() + 2 * nb, mik_dtype_size(A->dtype), A->n_cols, A->nnz, lo, &span)) return MIK_OK;
     if ((e = hipMalloc((void **)&A->xwin_lo, sizeof(int) * (size_t)nb)) != hipSuccess ||
         (e = hipMemcpy(A->xwin_lo, lo.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice)) != hipSuccess)
         return mik_fail(ctx, e == hipErrorOutOfMemory ? MIK_ERR_NOMEM : MIK_ERR_HIP, "mik_csr_create: window table: %s", hipGetErrorString(e));
-    A->xwin_span = (int)span;
+    A->xwin_span = span;
     return MIK_OK;
 }

@@ -103,7 +103,7 @@ def test_cut_rows_segment_sums(pkg, orc, ctx, dtype, segment):
         L.mik_set_tuning(14, 0)
 
 
-def banded_irregular(n, dtype, halfwidth, seed=3, long_every=0):
+def banded_irregular(n, dtype, halfwidth, seed=3, long_every=0, touch_last_column=False):
     """rows of 3 ... 60 entries with columns inside [row - halfwidth, row + halfwidth] clipped to the matrix (no wrap-around:
     the first and last row-blocks have one-sided bands), optionally a few rows beyond the long-row threshold"""
     rng = np.random.default_rng(seed)
@@ -116,22 +116,27 @@ def banded_irregular(n, dtype, halfwidth, seed=3, long_every=0):
         lo, hi = max(0, r - w), min(n - 1, r + w)
         l = min(l, hi - lo + 1)
         lens[r] = l
-        cols.append(np.sort(rng.choice(np.arange(lo, hi + 1), size=l, replace=False)))
+        cr = np.sort(rng.choice(np.arange(lo, hi + 1), size=l, replace=False))
+        if touch_last_column and r >= n - 600 and cr[-1] != n - 1:      # the last row-blocks all reference x[n - 1]
+            cr[-1] = n - 1
+        cols.append(cr)
     rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     cols = np.concatenate(cols).astype(np.int64)
     return rowptr, cols, rng.standard_normal(cols.size).astype(dtype)
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("long_every", [0, 997])
-def test_x_window_in_lds_bit_exact(pkg, orc, ctx, dtype, long_every):
+@pytest.mark.parametrize("long_every,n", [(0, 9000), (997, 9000), (0, 9001), (997, 9003)])
+def test_x_window_in_lds_bit_exact(pkg, orc, ctx, dtype, long_every, n):
     """irregular rows inside a band -- the product-tile kernel serves x from an LDS window per 256-row block
     (k_spmv_rowblock XWIN, csr_build_xwin): same products, same order, same bits as the oracle, with the windows (default), with
     the windows and the by-length row permutation of a block's threads (RPERM) built but not used (development knob 29 = 2) and
     never built (29 = 1); plain SpMV (long rows merged into the launch)
-    and the fused-dot launches of a CG step; one-sided bands at both ends of the matrix (the last window slides down)."""
-    n = 9000
-    rowptr, cols, val = banded_irregular(n, dtype, 700, long_every=long_every)
+    and the fused-dot launches of a CG step; one-sided bands at both ends of the matrix (the last window slides down).
+    n = 9001 / 9003: x is not a whole number of 16-byte groups, so the slid-down window of the last row-blocks
+    cannot reach x[n - 1] from an aligned start -- those blocks must gather from memory (mik_xwin_plan), and every one of them
+    references the last column."""
+    rowptr, cols, val = banded_irregular(n, dtype, 700, long_every=long_every, touch_last_column=n != 9000)
     Ao = as_oracle_csc(orc, n, rowptr, cols, val)
     x = np.random.default_rng(8).standard_normal(n).astype(dtype)
     want = orc.spmv(Ao, x)

@@ -98,3 +98,37 @@ def test_golden_noise_floor_is_what_design_md_says():
     s, t = fromhex(g["seq"]["resnorm"]), fromhex(g["tree"]["resnorm"])
     assert s.size == t.size == 195
     assert np.max(np.abs(s - t) / s) < 5e-12
+
+
+@pytest.mark.parametrize("dtype,n", [(np.float64, 9000), (np.float64, 9001), (np.float32, 9001), (np.float32, 9002), (np.float32, 9003),
+                                     (np.float64, 40001), (np.float32, 8193)])
+def test_x_window_rule_never_leaves_a_referenced_column_outside(pkg, dtype, n):
+    """the window of x a 256-row block reads from LDS (k_spmv_rowblock XWIN) must contain every column the block
+    references -- the kernel clamps an out-of-window column to the window's last element.  When x is not a whole number of 16-byte
+    groups the slid-down window of the last blocks cannot reach x[n - 1] from an aligned start: those blocks must be marked -1
+    (gather from memory).  Replayed on the host rule itself (mik_dev_xwin_plan, shared by the host and the device builder): banded
+    rows, half-width 700, every block of the tail referencing the last column."""
+    import ctypes as C
+    es = np.dtype(dtype).itemsize
+    W = 16 // es
+    nb = (n + 255) // 256
+    r0 = np.arange(nb, dtype=np.int64) * 256
+    r1 = np.minimum(r0 + 256, n) - 1
+    first = np.maximum(r0 - 700, 0).astype(np.int32)
+    last = np.minimum(r1 + 700, n - 1).astype(np.int32)
+    cnt = np.full(nb, 256 * 30, np.int32)
+    lo, span = np.empty(nb, np.int32), C.c_int()
+    ip = C.POINTER(C.c_int)
+    assert pkg.lib().mik_dev_xwin_plan(nb, first.ctypes.data_as(ip), last.ctypes.data_as(ip), cnt.ctypes.data_as(ip), es, n, int(cnt.sum()),
+                                       lo.ctypes.data_as(ip), C.byref(span)) == 0
+    sp = span.value
+    assert sp > 0 and sp % (1024 // es) == 0
+    have = lo >= 0
+    assert have.sum() >= nb - 4                                           # only the tail may lose its window
+    assert np.all(lo[have] % W == 0) and np.all(lo[have] <= first[have])
+    assert np.all(lo[have].astype(np.int64) + sp <= n), "a window leaves x"
+    assert np.all(last[have] < lo[have].astype(np.int64) + sp), "a referenced column lies outside its block's window"
+    if n % W:
+        assert not have[-1]                                               # the advisor's case: the last block cannot have a window
+    else:
+        assert have.all()
