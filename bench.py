@@ -525,12 +525,30 @@ def run_single(args):
     print(json.dumps(out))
 
 
+def partition_oracle(N: int, NZ: int, offsets, shape):
+    """The checker of the N > 1 line's `parity_vs_oracle` (rank 0 only): the oracle's cg! in TREE mode with the run's row partition
+    (rank-ordered sums of the per-rank trees) on the N x N x NZ Laplacian with the hashed rhs, to the default tolerance."""
+    from importlib import import_module
+    orc = graft.load_oracle()
+    pkg = graft.load_package()
+    d = import_module(pkg.__name__ + ".dist")
+    n, ptr, idx, val = d._laplace_rows(pkg, N, NZ, 0, N * N * NZ, np.float64)
+    A = orc.CSC(n, ptr, idx, val, 0)                 # symmetric: the CSR arrays are a valid CSC
+    b = pkg.fixtures.hashed_rhs(n)
+    orc.set_partition(np.asarray(offsets, np.int64))
+    try:
+        x, h = orc.cg(A, b, mode="tree", shape=shape)
+    finally:
+        orc.set_partition(None)
+    return {"iters": int(h["iters"]), "isconverged": bool(h["isconverged"]), "resnorm": np.asarray(h["resnorm"]), "x": x}
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks under torch.distributed.run ourselves."""
     import socket
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and "MIK_FORCE_DEVICE" not in os.environ:      # (development: MIK_FORCE_DEVICE puts every rank on one GPU -- mailbox transport only)
         sys.exit(f"bench.py: {args.gpus} ranks requested, {have} device(s) visible -- one rank per GPU is required "
                  f"(RCCL refuses two ranks on one device); run with --gpus <= {max(have, 1)}")
     with socket.socket() as s:
@@ -570,6 +588,7 @@ def main():
         pkg = graft.load_package()
         args.pmc_traffic = pmc_traffic
         args.cpu_baseline_fn = cpu_baseline
+        args.partition_oracle_fn = partition_oracle
         return import_module(pkg.__name__ + ".dist").bench_main(args)
     if args.n is None:
         args.n = 256

@@ -518,6 +518,9 @@ int mik_cg_profile(mik_cg *it, int enable, double *spmv_ms_total, int64_t *spmv_
 /* enable = 2 in mik_cg_profile brackets all three streaming launches of the step; totals per kernel:
  * [0] the SpMV (src/cg.jl:54), [1] u .= r .+ beta .* u (:51), [2] x / r update + |r|^2 (:58-62).  ms_total / launches: 3 entries each. */
 int mik_cg_profile_kernels(const mik_cg *it, double *ms_total, int64_t *launches);
+/* The same bracket around every SpMV launch of the row-partitioned iterable's steps (mik_cgd_iterate_many, mik_cgd_phase): the in-loop
+ * SpMV time of a rank of BASELINE.json configs[3] (bench.py --gpus N: `roofline`).  Same protocol as mik_cg_profile (enable 1 / 0 / -1). */
+int mik_cgd_profile(mik_cgd *it, int enable, double *spmv_ms_total, int64_t *spmv_launches);
 
 #ifdef __cplusplus
 }

@@ -166,6 +166,7 @@ SIGNATURES = {
     "mik_givens": (C.c_int, [C.c_int, _vp, _vp, _vp]),
     "mik_time_spmv": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _f64p]),
     "mik_cg_profile": (C.c_int, [_vp, C.c_int, _f64p, _i64p]),
+    "mik_cgd_profile": (C.c_int, [_vp, C.c_int, _f64p, _i64p]),
     "mik_cg_profile_kernels": (C.c_int, [_vp, _f64p, _i64p]),
 }
 

@@ -117,7 +117,13 @@ struct mik_comm {
     MailBox **peers_dev = nullptr;       // device: peer q's mailbox as mapped into this process (q = rank: mail)
     std::vector<MailBox *> peers;
     std::vector<void *> ipc_open;        // mappings to close
-    void *ghost_base[MIK_MAIL_MAXP] = {};   // peer q's u_ext allocation as mapped here (mik_cgd_connect_ghosts)
+    // peer allocations that hold ghost regions, as mapped into this process (mik_cgd_connect_ghosts).  Keyed by the 64-byte IPC handle, not
+    // by the rank: a second iterable on the same communicator may keep its u_ext in ANOTHER allocation of the same peer (a second solve, a
+    // re-created engine, another block of the host's memory pool) -- reusing the first mapping would push its halo into unrelated peer memory
+    // (ADVICE r4); and a handle must not be opened twice in one process.
+    struct GhostMap { int rank; unsigned char handle[64]; void *base; };
+    std::vector<GhostMap> ghost_maps;
+    bool mail_finegrained = false;       // hipExtMallocWithFlags(hipDeviceMallocFinegrained) succeeded for the mailbox
     bool mail_ready = false;
     unsigned long long mseq[MIK_MAIL_KINDS] = {0, 0, 0};   // exchanges enqueued so far, per kind
     unsigned long long halo_no = 0;
@@ -359,11 +365,7 @@ extern "C" int mik_comm_create(mik_ctx *ctx, const void *id128, int rank, int nr
     if (nranks <= MIK_MAIL_MAXP) {
         const int rc = mailbox_alloc(cm);
         if (rc && !cm->nccl && nranks > 1) return bail(rc);      // (more ranks and neither RCCL nor a mailbox: nothing to talk through)
-        if (rc) {
-            (void)hipGetLastError();
-            if (cm->mail) { (void)hipFree(cm->mail); cm->mail = nullptr; }
-            cm->mail_ready = false;
-        }
+        if (rc) cm->mail_ready = false;                          // (mailbox_alloc has released whatever it had allocated)
     }
     *out = cm;
     return MIK_OK;
@@ -534,19 +536,30 @@ static int mailbox_alloc(mik_comm *cm)
     mik_ctx *ctx = cm->ctx;
     if (cm->nranks > MIK_MAIL_MAXP) return mik_fail(ctx, MIK_ERR_NOTIMPL, "mailbox transport: at most %d ranks", MIK_MAIL_MAXP);
     (void)hipSetDevice(ctx->device);
+    // a failed attempt leaves nothing behind (a later mik_comm_mailbox_export re-runs this and must not leak the first attempt's pieces)
+    auto undo = [&](int rc) {
+        (void)hipGetLastError();
+        if (cm->mail) { (void)hipFree(cm->mail); cm->mail = nullptr; }
+        if (cm->peers_dev) { (void)hipFree(cm->peers_dev); cm->peers_dev = nullptr; }
+        if (cm->push_ticket) { (void)hipFree(cm->push_ticket); cm->push_ticket = nullptr; }
+        if (cm->mail_err) { (void)hipHostFree(cm->mail_err); cm->mail_err = nullptr; }
+        cm->mail_finegrained = false;
+        return rc;
+    };
     hipError_t e = hipExtMallocWithFlags((void **)&cm->mail, sizeof(MailBox), hipDeviceMallocFinegrained);
+    cm->mail_finegrained = e == hipSuccess;
     if (e != hipSuccess) { (void)hipGetLastError(); cm->mail = nullptr; e = hipMalloc((void **)&cm->mail, sizeof(MailBox)); }   // system-scope atomics still reach memory
-    if (e != hipSuccess) return mik_fail(ctx, MIK_ERR_NOMEM, "mailbox transport: %s", hipGetErrorString(e));
+    if (e != hipSuccess) { cm->mail = nullptr; return undo(mik_fail(ctx, MIK_ERR_NOMEM, "mailbox transport: %s", hipGetErrorString(e))); }
     if ((e = hipMemset(cm->mail, 0, sizeof(MailBox))) != hipSuccess ||
         (e = hipMalloc((void **)&cm->peers_dev, sizeof(MailBox *) * MIK_MAIL_MAXP)) != hipSuccess ||
         (e = hipMalloc((void **)&cm->push_ticket, sizeof(unsigned) * 80)) != hipSuccess || (e = hipMemset(cm->push_ticket, 0, sizeof(unsigned) * 80)) != hipSuccess ||
         (e = hipHostMalloc((void **)&cm->mail_err, sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
-        return mik_fail(ctx, MIK_ERR_HIP, "mailbox transport: %s", hipGetErrorString(e));
+        return undo(mik_fail(ctx, MIK_ERR_HIP, "mailbox transport: %s", hipGetErrorString(e)));
     *cm->mail_err = 0;
     cm->peers.assign((size_t)cm->nranks, nullptr);
     cm->peers[(size_t)cm->rank] = cm->mail;
     if ((e = hipMemcpy(cm->peers_dev, cm->peers.data(), sizeof(MailBox *) * cm->peers.size(), hipMemcpyHostToDevice)) != hipSuccess)
-        return mik_fail(ctx, MIK_ERR_HIP, "mailbox transport: %s", hipGetErrorString(e));
+        return undo(mik_fail(ctx, MIK_ERR_HIP, "mailbox transport: %s", hipGetErrorString(e)));
     const char *ms = getenv("MIK_MAILBOX_TIMEOUT_MS");
     const double msv = ms && atof(ms) > 0 ? atof(ms) : 10000.0;
     cm->timeout_ticks = (unsigned long long)(msv * 1e5);               // wall_clock64 runs at 100 MHz
@@ -632,16 +645,21 @@ extern "C" int mik_cgd_connect_ghosts(mik_cgd *it, const void *handles, const in
         if (q == it->rank) base = (unsigned char *)it->u_ext;
         else {
             if (!handles || !offsets) return MIK_ERR_INVALID;
-            if (!cm->ghost_base[q]) {
+            const unsigned char *hq = (const unsigned char *)handles + 64 * (size_t)q;
+            void *mapped = nullptr;
+            for (const mik_comm::GhostMap &g : cm->ghost_maps)
+                if (g.rank == q && memcmp(g.handle, hq, 64) == 0) { mapped = g.base; break; }
+            if (!mapped) {
                 hipIpcMemHandle_t h;
-                memcpy(&h, (const unsigned char *)handles + 64 * (size_t)q, 64);
-                void *p = nullptr;
-                hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+                memcpy(&h, hq, 64);
+                hipError_t e = hipIpcOpenMemHandle(&mapped, h, hipIpcMemLazyEnablePeerAccess);
                 if (e != hipSuccess) return mik_fail(ctx, MIK_ERR_HIP, "mik_cgd_connect_ghosts: hipIpcOpenMemHandle(rank %d): %s", q, hipGetErrorString(e));
-                cm->ipc_open.push_back(p);
-                cm->ghost_base[q] = p;
+                cm->ipc_open.push_back(mapped);
+                mik_comm::GhostMap g;
+                g.rank = q; memcpy(g.handle, hq, 64); g.base = mapped;
+                cm->ghost_maps.push_back(g);
             }
-            base = (unsigned char *)cm->ghost_base[q] + offsets[q];
+            base = (unsigned char *)mapped + offsets[q];
         }
         it->send_dst.push_back(base + es * (size_t)dst_elem[i]);
     }
@@ -653,13 +671,7 @@ extern "C" int mik_comm_mailbox_info(const mik_comm *cm, int *ready, int *finegr
 {
     if (!cm) return MIK_ERR_INVALID;
     if (ready) *ready = cm->mail_ready ? 1 : 0;
-    if (finegrained) {
-        *finegrained = 0;
-        if (cm->mail) {
-            hipPointerAttribute_t at;
-            if (hipPointerGetAttributes(&at, cm->mail) == hipSuccess) *finegrained = 1; else (void)hipGetLastError();
-        }
-    }
+    if (finegrained) *finegrained = cm->mail && cm->mail_finegrained ? 1 : 0;   // recorded when it was allocated (the plain hipMalloc fall-back reports 0)
     return MIK_OK;
 }
 

@@ -1057,6 +1057,14 @@ extern "C" int mik_cg_profile(mik_cg *it, int enable, double *spmv_ms_total, int
     return MIK_OK;
 }
 
+// The same for the row-partitioned iterable: HIP events on the compute stream around every SpMV launch of its steps (one per step with
+// flag-ordered halos; the interior and the boundary launch when the halo is ordered by events and an interior range is set).
+extern "C" int mik_cgd_profile(mik_cgd *it, int enable, double *spmv_ms_total, int64_t *spmv_launches)
+{
+    if (!it) return MIK_ERR_INVALID;
+    return mik_cg_profile(&it->base, enable > 1 ? 1 : enable, spmv_ms_total, spmv_launches);
+}
+
 extern "C" int mik_cg_profile_kernels(const mik_cg *it, double *ms_total, int64_t *launches)
 {
     if (!it) return MIK_ERR_INVALID;
@@ -2125,15 +2133,15 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
         return MIK_OK;
     }
     case 1:    // step B
-        MIK_TRY(mik_spmv_launch<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done));
+        { CgProfileScope ps(&bs, 0); MIK_TRY(mik_spmv_launch<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done)); }
         hipLaunchKernelGGL((k_cgd_fin_slot<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)bs.seg_spmv, nb, dot_slot, done, (FinScratch<T> *)bs.fin);
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     case 4:    // step B1: the row-blocks that reference no halo column -- runs while the halo is in flight
         if (it->int_end <= it->int_begin) return mik_fail(ctx, MIK_ERR_INVALID, "mik_cgd_phase: no interior range set (mik_cgd_set_interior)");
-        return mik_spmv_launch_range<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done, (int)it->int_begin, (int)(it->int_end - it->int_begin));
+        { CgProfileScope ps(&bs, 0); return mik_spmv_launch_range<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done, (int)it->int_begin, (int)(it->int_end - it->int_begin)); }
     case 5:    // step B2: the row-blocks before and after the interior range, then the local dot(u, c) as in step B
-        MIK_TRY(mik_spmv_launch_outside<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done, (int)it->int_begin, (int)it->int_end));
+        { CgProfileScope ps(&bs, 0); MIK_TRY(mik_spmv_launch_outside<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done, (int)it->int_begin, (int)it->int_end)); }
         hipLaunchKernelGGL((k_cgd_fin_slot<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)bs.seg_spmv, nb, dot_slot, done, (FinScratch<T> *)bs.fin);
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
@@ -2192,10 +2200,14 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
                            (long long)bs.maxiter, bs.mirror, bs.seq, it->norm_fix_index);
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
-    case 13:    // step B2 without the finaliser (the mailbox transport finalises and exchanges in one kernel: csrc/mik_comm.hip)
+    case 13: {  // step B2 without the finaliser (the mailbox transport finalises and exchanges in one kernel: csrc/mik_comm.hip)
+        CgProfileScope ps(&bs, 0);
         return mik_spmv_launch_outside<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done, (int)it->int_begin, (int)it->int_end);
-    case 14:    // step B without the finaliser
+    }
+    case 14: {  // step B without the finaliser
+        CgProfileScope ps(&bs, 0);
         return mik_spmv_launch<T>(ctx, bs.A, u, c, true, (T *)bs.seg_spmv, done);
+    }
     case 16: {  // step C without alpha formation and without the finaliser: alpha is the stored scalar (k_cgd_fin_dot_mail)
         if (bs.fuse_x) {
             OpCgUpdateR<T> up{r, c, coef_ptr<T>(&d->alpha), cg_stream_hints(ctx, true, bs.A) >> 3};
@@ -2248,6 +2260,7 @@ int cgd_collect(mik_cgd *it, const CgMirror &m, double *residual, double *tol, i
         for (int64_t j = 0; j < take; ++j)
             history[j] = bs.dtype == MIK_F64 ? ((const double *)tmp.data())[j] : (double)((const float *)tmp.data())[j];
     }
+    if (bs.profile) (void)cg_profile_collect(&bs);           // the bracketed SpMV launches of the steps the host has now seen (mik_cgd_profile)
     // start a fresh history window for the next batch of steps (the device is idle: the host owns the mirror)
     bs.mirror->nhist = 0;
     it->hist_total = 0;

@@ -316,7 +316,7 @@ class HipEngine:
     """Owns the device state of one rank and enqueues ``mik_cgd`` phases on the current torch stream."""
 
     def __init__(self, pkg, ptr, local_idx, val, plan: HaloPlan, b_loc, x_loc=None, *, abstol, reltol, maxiter, device=0,
-                 stream=None):
+                 stream=None, layout=None):
         import torch
         self.pkg, self.torch, self.plan = pkg, torch, plan
         L = pkg.lib()
@@ -334,6 +334,8 @@ class HipEngine:
                                             index_base=0, is_csc=False, ctx=self.ctx)
         else:
             self.A = pkg.HipCSR(n_loc, n_ext, ptr, local_idx, val, index_base=0, is_csc=False, ctx=self.ctx)
+        if layout not in (None, "auto"):
+            self.A.set_layout(layout)                   # "csr": the iterable runs on the plain CSR arrays (bench.py's contract loop)
         with torch.cuda.stream(self.stream):
             self.u_ext = torch.zeros(max(n_ext, 1), dtype=tdt, device=dev)           # receives the halo in place
             self.send_buf = torch.zeros(max(plan.n_send, 1), dtype=tdt, device=dev)
@@ -1115,17 +1117,51 @@ def bench_main(args):
         times = [first] + max_over_ranks([region(count, batch) for _ in range(more)])
         return times
 
-    def new_engine():
-        return HipEngine(pkg, ptr, local_idx, val, plan, b_loc, abstol=0.0, reltol=0.0, maxiter=10 ** 9, device=local_rank)
+    HBM_PEAK = 8000.0
+    sqrt_eps = float(np.sqrt(np.finfo(np.float64).eps))
+    big = dict(ptr=ptr, local_idx=local_idx, val=val, plan=plan, b_loc=b_loc)
+
+    def bring_up(name, layout, prob, reltol, maxiter):
+        """One transport on an engine of its own over `prob` (operator layout "auto" = mik_csr_create's choice, "csr" = the plain Int32 CSR
+        arrays: the contract loop).  Collective: returns (engine, comm, iterable, None) or (None, None, None, first failure of any rank)."""
+        e2 = c2 = i2 = None
+        failure = None
+        try:
+            e2 = HipEngine(pkg, prob["ptr"], prob["local_idx"], prob["val"], prob["plan"], prob["b_loc"], abstol=0.0, reltol=reltol, maxiter=maxiter,
+                           device=local_rank, layout=layout)
+            c2 = NativeComm(pkg, e2.ctx, boot, force_rccl=force and name != "mailbox", transport=name)
+            i2 = NativeDistCGIterable(pkg, e2, c2, maxiter=maxiter)
+        except Exception as exc:       # noqa: BLE001
+            failure = f"{type(exc).__name__}: {exc}"
+        failures = [f for f in boot.all_gather_objects(failure) if f]
+        if failures:
+            for o in (e2, c2):
+                try:
+                    o and o.close()
+                except Exception:      # noqa: BLE001
+                    pass
+            return None, None, None, failures[0][:300]
+        return e2, c2, i2, None
+
+    def tear_down(e2, c2):
+        boot.barrier()
+        for o in (e2, c2):
+            try:
+                o and o.close()
+            except Exception:          # noqa: BLE001
+                pass
 
     # The transports inside libmik.so (include/mik.h "Transport 1" / "Transport 3"), each on an engine of its own over the same slab:
     #   rccl          halo by ncclSend / ncclRecv on the side stream, the two scalars of a step by ncclAllGather
     #   rccl+mailbox  halo by RCCL, scalars as stores into peer-mapped mailboxes (no collective launch on the compute stream)
     #   mailbox       no RCCL at all: scalars by mailbox, halo pushed into IPC-mapped ghost regions
-    # Every candidate that comes up on ALL ranks runs the warm-up and the timed regions; their first residuals must agree bit for bit
-    # (the arithmetic is the same by construction -- a transport that delivered stale data would show here); `value` is the fastest
-    # of the largest group of transports with identical bits (a tie goes to the group with plain RCCL in it).  MIK_NATIVE_TRANSPORTS
-    # narrows / reorders the list.
+    # (1) parity: every transport solves a SMALL global system (64 x 64 x 8 P) to the default tolerance in both operator layouts and rank 0
+    #     compares history and solution with the partition-aware oracle (bench.py hands the checker in; this module never imports oracle/).
+    # (2) every transport that came up runs the warm-up and the timed regions in the operator's default layout; their first residuals must
+    #     agree bit for bit; the fastest of the largest agreeing group is `transport_chosen`.
+    # (3) the CONTRACT loop: the chosen transport on the plain CSR arrays of the slab (mik_csr_set_layout(A_loc, 0), k_spmv_rowgather) --
+    #     `value`, `ms_per_step` and `roofline` describe this loop, exactly as at N = 1.
+    # MIK_NATIVE_TRANSPORTS narrows / reorders the list.
     transports = {}
     chosen = None
     eng = it = ncomm = None
@@ -1134,15 +1170,17 @@ def bench_main(args):
 
     def emergency_line():
         """A transport measured AFTER a good one hangs (no device-to-device transfer of any kind could be tried before the driver's own
-        multi-GPU run): every rank leaves, rank 0 first prints the line of the best transport measured so far."""
+        multi-GPU run): every rank leaves, rank 0 first prints the line of the best transport measured so far (default layout: the
+        contract loop had not been reached)."""
         if rank == 0 and chosen is not None:
             ms = transports[chosen]["ms_per_step"]
             print(json.dumps({
-                "metric": "cg_iters_per_sec", "value": world * 1e3 / ms, "unit": "iters/s", "n_gpus": world, "world_size_checked": world, "steps": K, "warmup": Wm,
-                "global_system_iters_per_sec": 1e3 / ms, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-                "data": "synthetic",
+                "metric": "cg_iters_per_sec", "value": 1e3 / ms, "unit": "iters/s", "n_gpus": world, "world_size_checked": world, "steps": K, "warmup": Wm,
+                "value_is_contract": False, "aggregate_slab_iters_per_sec": world * 1e3 / ms, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": f"cg! on the {N}x{N}x{nz * world} 3D 7-point Laplacian row-partitioned into {world} z-slab(s) of {N}x{N}x{nz} rows",
                            "n": int(n), "n_per_gpu": plan.n_loc, "host_sync_per_step": 1, "transport_chosen": chosen, "transports_measured": transports,
+                           "operator_layout_of_the_timed_loop": "default (slice-constant); the CSR contract loop was not reached",
                            "watchdog": "a transport measured after this one did not return in time; the process left with the best line it had"},
                 "roofline": None}), flush=True)
         os._exit(0 if chosen is not None else 3)
@@ -1156,6 +1194,8 @@ def bench_main(args):
             watchdog["timer"].daemon = True
             watchdog["timer"].start()
 
+    parity = None
+    contract = None
     if transport == "native":
         # (order: the transport whose waits are all bounded first -- once it has been measured, a hang of a later one is survivable)
         default = "mailbox,rccl+mailbox,rccl" if (world > 1 or self_halo) else "rccl"
@@ -1163,28 +1203,63 @@ def bench_main(args):
         force = self_halo or os.environ.get("MIK_DIST_FORCE_COLLECTIVES", "0") == "1"
         if world == 1:
             pkg.lib().mik_set_tuning(6, int(os.environ.get("MIK_KNOB6", "4")))     # a world of one still sends its scalars through the mailbox (development)
+
+        # ---- (1) parity against the partition-aware oracle on a small global system ------------------------------------------------
+        check = getattr(args, "partition_oracle_fn", None)
+        if check is not None and not self_halo and not getattr(args, "no_parity", False):
+            Ns, nzs = 64, 8
+            sp, sli, sv, splan, sb, sn, soff = build_rank_problem(pkg, boot, Ns, nz_per_rank=nzs, device=None if on_host else local_rank)
+            small = dict(ptr=sp, local_idx=sli, val=sv, plan=splan, b_loc=sb)
+            parity = {"workload": f"cg! to reltol = sqrt(eps) on the {Ns}x{Ns}x{nzs * world} Laplacian, {world} z-slab(s) of {nzs} planes, hashed rhs, x0 = 0",
+                      "oracle": "oracle/mik_oracle.c cg, TREE mode with the same row partition (rank-ordered sums of the per-rank trees)", "transports": {}}
+            for name in names:
+                for layout in ("auto", "csr"):
+                    key = f"{name}/{layout}"
+                    e2, c2, i2, failure = bring_up(name, layout, small, sqrt_eps, 10 ** 6)
+                    if failure:
+                        parity["transports"][key] = {"came_up": False, "failure": failure}
+                        continue
+                    hist, k2, failure = [], 0, None
+                    try:
+                        while True:
+                            h = i2.iterate_many(k2, 1 if k2 < 2 else 25)       # single steps, then batches: both host protocols
+                            if h.size == 0:
+                                break
+                            hist.extend(h.tolist())
+                            k2 += h.size
+                        xs = e2.solution()
+                    except Exception as exc:      # noqa: BLE001
+                        failure, xs = f"{type(exc).__name__}: {exc}", None
+                    shape = e2.ctx.cg_shape(np.float64)
+                    gathered = boot.all_gather_objects((failure, [float(v).hex() for v in hist], xs))
+                    tear_down(e2, c2)
+                    if any(g[0] for g in gathered):
+                        parity["transports"][key] = {"came_up": True, "failure": next(g[0] for g in gathered if g[0])[:300]}
+                        continue
+                    rec = {"came_up": True, "iters": len(hist), "ranks_agree": all(g[1] == gathered[0][1] for g in gathered)}
+                    if rank == 0:
+                        ref = check(Ns, nzs * world, soff, shape)
+                        rec.update(oracle_iters=int(ref["iters"]), same_iters_isconverged=bool(len(hist) == ref["iters"] and ref["isconverged"]),
+                                   history_bit_identical=bool(np.array_equal(np.asarray(hist), ref["resnorm"])),
+                                   solution_bit_identical=bool(np.array_equal(np.concatenate([g[2] for g in gathered]), ref["x"])))
+                        rec["bit_identical"] = bool(rec["ranks_agree"] and rec["history_bit_identical"] and rec["solution_bit_identical"] and rec["same_iters_isconverged"])
+                    parity["transports"][key] = rec
+            if rank == 0:
+                ok = [k2 for k2, v in parity["transports"].items() if v.get("bit_identical")]
+                parity["bit_identical"] = bool(ok) and all(v.get("bit_identical") for v in parity["transports"].values() if v.get("came_up"))
+                parity["transports_bit_identical"] = ok
+            del small, sp, sli, sv
+
+        # ---- (2) every transport in the operator's default layout -----------------------------------------------------------------
         alive = {}
         for name in names:
             arm_watchdog()                      # (only once a transport has been measured: then a hang of the next one is survivable)
-            e2 = c2 = i2 = None
-            failure = None
             t_up = time.perf_counter()
-            try:
-                e2 = new_engine()
-                c2 = NativeComm(pkg, e2.ctx, boot, force_rccl=force and name != "mailbox", transport=name)
-                i2 = NativeDistCGIterable(pkg, e2, c2, maxiter=10 ** 9)
-            except Exception as exc:       # noqa: BLE001
-                failure = f"{type(exc).__name__}: {exc}"
-            failures = [f for f in boot.all_gather_objects(failure) if f]
-            rec = {"came_up": not failures}
-            if failures:
-                rec["failure"] = failures[0][:300]
+            e2, c2, i2, failure = bring_up(name, "auto", big, 0.0, 10 ** 9)
+            rec = {"came_up": failure is None}
+            if failure:
+                rec["failure"] = failure
                 transports[name] = rec
-                for o in (e2, c2):
-                    try:
-                        o and o.close()
-                    except Exception:      # noqa: BLE001
-                        pass
                 continue
             rec["operator_build_and_upload_seconds"] = time.perf_counter() - t_up
             state.update(k=0, it=i2)
@@ -1200,8 +1275,8 @@ def bench_main(args):
                 rec.update(came_up=False, failure=failures[0][:300])
                 transports[name] = rec
                 continue
-            rec.update(ms_per_step=float(np.median(tms)) / K * 1e3, timed_regions=len(tms), first_residuals=[float(v).hex() for v in first[:8]],
-                       uses_rccl=c2.uses_rccl())
+            rec.update(operator_layout=e2.A.layout(), ms_per_step=float(np.median(tms)) / K * 1e3, iters_per_sec=K / float(np.median(tms)), timed_regions=len(tms),
+                       first_residuals=[float(v).hex() for v in first[:8]], uses_rccl=c2.uses_rccl())
             transports[name] = rec
             alive[name] = (e2, c2, i2, tms, state["k"])
             # provisional choice (what the watchdog would print): the fastest of the LARGEST group of transports with identical bits
@@ -1218,9 +1293,9 @@ def bench_main(args):
             else:
                 e2.close()
                 c2.close()
-        if watchdog["timer"] is not None:
-            watchdog["timer"].cancel()
         if chosen is None:
+            if watchdog["timer"] is not None:
+                watchdog["timer"].cancel()
             if rank == 0:
                 print(f"bench.py: no native transport came up ({transports}); falling back to the Python-driven transport", file=sys.stderr)
             transport = "torch (fallback)"
@@ -1232,7 +1307,7 @@ def bench_main(args):
         times = chosen_times
     else:
         t_up = time.perf_counter()
-        eng = new_engine()
+        eng = HipEngine(pkg, ptr, local_idx, val, plan, b_loc, abstol=0.0, reltol=0.0, maxiter=10 ** 9, device=local_rank)
         upload_seconds = time.perf_counter() - t_up
         it = DistCGIterable(eng, boot, maxiter=10 ** 9)
         uses_rccl = world > 1
@@ -1242,33 +1317,98 @@ def bench_main(args):
     kb = max(1, K // 25) * 25
     times_b = timed(25, kb)                  # one host wait per 25 steps
     dt = float(np.median(times))
-    # SpMV roofline on rank 0: back-to-back launches of the local block on the live u (HIP events, own stream)
-    alg_bytes = eng.A.spmv_algorithmic_bytes()
+    default_layout = eng.A.layout()
+    default_kernel = eng.A.spmv_kernel()
     stored_bytes = eng.A.spmv_stored_bytes()
+    alg_bytes = eng.A.spmv_algorithmic_bytes()          # SURVEY.md 8d on the rank's n_loc x n_ext block: nnz (s + 4) + (n_loc + 1) 4 + n_ext s + n_loc s
     u = pkg.HipVector.wrap(eng.u_ext.data_ptr(), plan.n_loc + plan.n_ghost, np.float64, eng.ctx, owner=eng.u_ext)
-    spmv_ms = eng.A.time_spmv(u, eng.c, reps=20, fused_dot=True)
-    moved = stored_bytes / (spmv_ms * 1e-3) / 1e9
+    d_b2b_ms = eng.A.time_spmv(u, eng.c, reps=20, fused_dot=True)
+    default_first = transports[chosen]["first_residuals"] if transport == "native" else None
+
+    # ---- (3) the contract loop: the chosen transport on the plain CSR arrays ---------------------------------------------------
+    if transport == "native" and default_layout != "csr-rowblock" and not getattr(args, "no_csr", False):
+        arm_watchdog()
+        e3, c3, i3, failure = bring_up(chosen, "csr", big, 0.0, 10 ** 9)
+        if failure:
+            contract = {"came_up": False, "failure": failure}
+        else:
+            state.update(k=0, it=i3)
+            first = []
+            run_steps(max(Wm, 8), 1, keep=first)
+            ms0, cnt0 = C.c_double(), C.c_int64()
+            pkg._lib.check(e3.L.mik_cgd_profile(e3.handle, 1, None, None), "mik_cgd_profile", e3.ctx.handle)     # HIP events around every SpMV launch of the loop
+            tms = timed(1, K)
+            steps_timed = state["k"] - max(Wm, 8)
+            pkg._lib.check(e3.L.mik_cgd_profile(e3.handle, 0, C.byref(ms0), C.byref(cnt0)), "mik_cgd_profile", e3.ctx.handle)
+            tb3 = timed(25, kb)
+            dt3 = float(np.median(tms))
+            spmv_ms = ms0.value / max(steps_timed, 1)                   # per STEP (a step whose halo is ordered by events launches its SpMV in two parts)
+            u3 = pkg.HipVector.wrap(e3.u_ext.data_ptr(), plan.n_loc + plan.n_ghost, np.float64, e3.ctx, owner=e3.u_ext)
+            b2b = e3.A.time_spmv(u3, e3.c, reps=20, fused_dot=True)
+            per_rank = boot.all_gather_objects((spmv_ms, int(cnt0.value), [float(v).hex() for v in first[:8]]))
+            contract = {"came_up": True, "kernel": e3.A.spmv_kernel(), "operator_layout": e3.A.layout(), "iters_per_sec": K / dt3, "ms_per_step": dt3 / K * 1e3,
+                        "spmv_in_loop_ms": spmv_ms, "spmv_launches_timed": int(cnt0.value), "steps_timed": int(steps_timed),
+                        "spmv_in_loop_ms_per_rank": [q[0] for q in per_rank], "spmv_back_to_back_ms": b2b,
+                        "batched_25_steps_per_sync_iters_per_sec": kb / float(np.median(tb3)), "timed_regions": len(tms), "final_residual": i3.residual,
+                        "first_residuals_equal_the_default_layout_bit_for_bit": bool(all(q[2] == default_first for q in per_rank))}
+            tear_down(e3, c3)
+        if watchdog["timer"] is not None:
+            watchdog["timer"].cancel()
+    elif watchdog["timer"] is not None:
+        watchdog["timer"].cancel()
+
     if rank == 0:
-        # weak scaling: every rank iterates its own 16.7 M-row slab of one global system, so the units all ranks processed
-        # are world * K slab-iterations (at world = 1 this is exactly bench.py's single-GPU metric)
         halo = int(plan.n_ghost)
+        s8 = 8
+        iter_alg = alg_bytes + 9 * plan.n_loc * s8               # B_cg = B_spmv + 9 n s, on this rank's slab
+        iter_moved = stored_bytes + 8 * plan.n_loc * s8          # the default layout's SpMV + the two fused sweeps (x update rides on the u sweep)
+        is_contract = bool(contract and contract.get("came_up"))
+        v_ms = contract["ms_per_step"] if is_contract else dt / K * 1e3
+        v_ips = 1e3 / v_ms
+        pmc = getattr(args, "pmc_traffic", None) or (lambda k, with_source=False: (None, None) if with_source else None)
+        if is_contract:
+            c_ms = contract["spmv_in_loop_ms"]
+            c_traffic, c_src = pmc(contract["kernel"], with_source=True)
+            roofline = {"bound": "hbm", "kernel": contract["kernel"] + "<double, fused dot>", "loop": "contract_csr_loop (rank 0's slab; every rank runs the same loop)",
+                        "achieved": alg_bytes / (c_ms * 1e-3) / 1e9, "peak": HBM_PEAK, "unit": "GB/s", "frac": alg_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK,
+                        "traffic": c_traffic, "traffic_source": c_src,
+                        "traffic_is": "committed constant from separate rocprofv3 --pmc passes of the single-GPU command (same kernel, same rows per GPU), not measured in this run",
+                        "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": c_ms, "launches_timed": contract["spmv_launches_timed"],
+                        "avg_launch_ms_per_rank": contract["spmv_in_loop_ms_per_rank"], "back_to_back_ms": contract["spmv_back_to_back_ms"],
+                        "loop_ms_per_step": contract["ms_per_step"], "loop_iters_per_sec": contract["iters_per_sec"],
+                        "loop_algorithmic_bytes_per_step_per_gpu": iter_alg, "loop_gbs_per_gpu": iter_alg / (contract["ms_per_step"] * 1e-3) / 1e9,
+                        "loop_frac_per_gpu": iter_alg / (contract["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK, "target": 0.60,
+                        "note": "SURVEY.md 8d on one rank's slab: algorithmic bytes of the Int32 CSR SpMV of its n_loc x n_ext block over the average HIP-event time of the "
+                                "SpMV launch INSIDE the partitioned cg! loop (mik_cgd_profile; mik_csr_set_layout(A_loc, 0), k_spmv_rowgather).  loop_* = that loop: "
+                                "every GPU moves loop_algorithmic_bytes_per_step_per_gpu per step of the ONE global system, so bytes / ms_per_step <= 8 TB/s per GPU."}
+        else:
+            moved = stored_bytes / (d_b2b_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": f"{default_kernel}<double, fused dot> (operator layout {default_layout}; rank 0, back-to-back on the live u)",
+                        "loop": "default layout (the CSR contract loop did not run)", "achieved": moved, "peak": HBM_PEAK, "unit": "GB/s", "frac": moved / HBM_PEAK,
+                        "traffic": pmc(default_kernel), "bytes_moved_per_launch": stored_bytes, "avg_launch_ms": d_b2b_ms,
+                        "note": "bytes this layout moves per launch over the HIP-event time; NOT the CSR-algorithmic figure"}
         out = {
-            "metric": "cg_iters_per_sec", "value": world * K / dt, "unit": "iters/s", "n_gpus": world, "world_size_checked": world, "steps": K, "warmup": Wm,
-            "global_system_iters_per_sec": K / dt,
-            "value_semantics": "weak scaling: `value` = slab-iterations of all ranks per second (world * K / dt, the whole-job aggregate the bench contract asks "
-                               "for; at world = 1 exactly the single-GPU metric); the ABSOLUTE rate of the one global system -- what the north star quotes at "
-                               "1 / 2 / 4 / 8 GPUs -- is `global_system_iters_per_sec` = K / dt = 1000 / ms_per_step",
-            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "metric": "cg_iters_per_sec", "value": v_ips, "unit": "iters/s", "n_gpus": world, "world_size_checked": world, "steps": K, "warmup": Wm,
+            "ms_per_step": v_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "value_is_contract": is_contract,
+            "value_semantics": "cg! iterations per second of the ONE global system (K / dt, max over ranks; the absolute number the north star quotes at 1 / 2 / 4 / 8 "
+                               "GPUs), on the plain CSR arrays of every rank's slab.  Weak scaling: 16.7 M rows per GPU at every N, so the ideal is value(N) = value(1); "
+                               "the whole-job aggregate in slab-iterations (N * K / dt) is `aggregate_slab_iters_per_sec`, in row updates `aggregate_row_updates_per_sec`",
+            "value_bytes_per_step_per_gpu": iter_alg if is_contract else iter_moved,
+            "value_gbs_per_gpu": (iter_alg if is_contract else iter_moved) / (v_ms * 1e-3) / 1e9,
+            "aggregate_slab_iters_per_sec": world * v_ips, "aggregate_row_updates_per_sec": v_ips * n,
+            "default_layout_iters_per_sec": K / dt, "default_layout_ms_per_step": dt / K * 1e3,
             "config": {"workload": f"cg! on the {N}x{N}x{nz * world} 3D 7-point Laplacian row-partitioned into {world} z-slab(s) of {N}x{N}x{nz} rows"
                                    + (" (BASELINE.json configs[3]: the 512^3 grid on 8 GPUs)" if (N, nz, world) == (512, 64, 8) else
                                       " (BASELINE.json configs[3] layout, weak-scaled: 16.7 M rows per GPU)" if world > 1 else
                                       " (BASELINE.json configs[1] through the row-partitioned code path)")
                                    + (" -- z-PERIODIC variant: the slab exchanges its 2 N^2 halo entries with itself over RCCL (MIK_DIST_SELF_HALO)" if self_halo else ""),
                        "n": int(n), "n_per_gpu": plan.n_loc, "nnz_per_gpu": nnz_loc, "halo_doubles_received_per_rank": halo,
-                       "host_sync_per_step": 1, "timed_regions": len(times), "timed_seconds_total": float(sum(times)),
-                       "transport": ({"rccl": "RCCL inside libmik.so (mik_cgd_iterate_many: ncclSend/ncclRecv halo on a side stream overlapped with the "
-                                              "interior rows + 2 ncclAllGather of one double per rank per step)",
+                       "host_sync_per_step": 1, "reltol_in_timed_loop": 0.0,
+                       "operator_layout_of_the_timed_loop": "csr (mik_csr_set_layout(A_loc, 0): Int32 rowptr / col / val, k_spmv_rowgather)" if is_contract else default_layout,
+                       "timed_regions": contract["timed_regions"] if is_contract else len(times),
+                       "transport": ({"rccl": "RCCL inside libmik.so (mik_cgd_iterate_many: ncclSend/ncclRecv halo on a side stream underneath the sweep over u "
+                                              "+ 2 ncclAllGather of one double per rank per step)",
                                       "rccl+mailbox": "halo by ncclSend/ncclRecv on a side stream; the two scalars of a step as stores into peer-mapped "
                                                       "mailboxes, summed inside the finalising kernels (no collective launch on the compute stream)",
                                       "mailbox": "peer-mapped mailbox (no RCCL): scalars as stores into IPC-mapped slots, halo pushed into IPC-mapped ghost regions"}[chosen]
@@ -1276,24 +1416,24 @@ def bench_main(args):
                                      "none (world of one)" if transport == "native" else "torch.distributed driven from Python (legacy)"),
                        "transport_chosen": chosen, "transports_measured": transports,
                        "halo_overlap": bool(getattr(eng, "overlap", False)),
-                       "operator_build_and_upload_seconds": upload_seconds, "final_residual": it.residual},
-            "batched_25_steps_per_sync_iters_per_sec": world * kb / float(np.median(times_b)),
-            "roofline": {"bound": "hbm", "kernel": f"{eng.A.spmv_kernel()}<double, fused dot> (operator layout {eng.A.layout()}; rank 0, back-to-back on the live u)",
-                         "achieved": moved, "peak": 8000.0, "unit": "GB/s", "frac": moved / 8000.0,
-                         "traffic": (getattr(args, "pmc_traffic", None) or (lambda k: None))(eng.A.spmv_kernel()),
-                         "note": "bytes this layout moves per launch over the HIP-event time; the slice-constant layout of this operator is not HBM-bound "
-                                 "(DESIGN.md section 5) -- the single-GPU line carries the three-layout comparison and the CSR fraction",
-                         "bytes_moved_per_launch": stored_bytes, "avg_launch_ms": spmv_ms,
-                         "achieved_algorithmic": alg_bytes / (spmv_ms * 1e-3) / 1e9, "algorithmic_bytes_per_launch": alg_bytes},
-            "aggregate_row_updates_per_sec": K / dt * n,
+                       "operator_build_and_upload_seconds": upload_seconds, "final_residual": contract["final_residual"] if is_contract else it.residual,
+                       "default_layout": {"operator_layout": default_layout, "kernel": default_kernel, "iters_per_sec": K / dt, "ms_per_step": dt / K * 1e3,
+                                          "bytes_per_step_per_gpu": iter_moved, "gbs_per_gpu": iter_moved / (dt / K) / 1e9, "spmv_back_to_back_ms": d_b2b_ms,
+                                          "batched_25_steps_per_sync_iters_per_sec": kb / float(np.median(times_b)), "timed_regions": len(times),
+                                          "timed_seconds_total": float(sum(times)), "final_residual": it.residual,
+                                          "note": "the same partitioned iteration with every slab in the layout mik_csr_create picks for this constant-coefficient operator "
+                                                  "(one mask byte per row instead of the CSR arrays); same residuals bit for bit; NOT the contract figure"}},
+            "contract_csr_loop": contract,
+            "parity_vs_oracle": parity,
+            "roofline": roofline,
         }
         fn = getattr(args, "cpu_baseline_fn", None)
         if fn is not None and not getattr(args, "no_cpu_baseline", False):
             # the reference-shaped CPU restatement on this box's host cores, in the same run (rank 0 only; the other ranks wait at the
             # teardown): one rank's share is a 16.7 M-row system, i.e. the 256^3 workload of the single-GPU line
-            cb = fn(256, min(int(getattr(args, "cpu_iters", 40)), 40))
+            cb = fn(256, int(getattr(args, "cpu_iters", 120)))
             cb.pop("_history", None)
-            cb["sample"] += f"; one rank's share of the {world}-rank system has the same 16.7 M rows"
+            cb["sample"] += f"; one rank's share of the {world}-rank system has the same 16.7 M rows (the CPU would need {world} x as long per iteration of the global system)"
             out["cpu_baseline"] = cb
         print(json.dumps(out))
     if dist.is_initialized():
