@@ -191,6 +191,71 @@ def gmres_config3():
     return out
 
 
+def gmres_hbm_bound(A, b, n: int, restart: int = 30, inner: int = 60, reps: int = 3, methods=("mgs", "cgs")):
+    """gmres!(restart = 30) at an HBM-BOUND size: the 256^3 Laplacian of configs[1] on its plain CSR arrays, fp64 -- the Krylov
+    basis V is 31 x 134 MB = 4.2 GB, nothing of it survives in a cache from one sweep to the next.  `inner` inner iterations
+    (src/gmres.jl:57-106: expand! + orthogonalize_and_normalize!, two restart cycles with their solve / update / init!), loop inside
+    the library (mik_gmres_iterate_many), ModifiedGramSchmidt (the multi-launch chain: pass i = w -= h_i v_i fused with the next
+    projection v_{i+1} . w, src/orthogonalize.jl:69-76) and ClassicalGramSchmidt (k_multidot + k_gemv_n, :43-45).
+    Bytes per inner iteration: SURVEY.md 8d -- B_spmv + (3k + 2) n s (MGS) / (2k + 3) n s (CGS) for Arnoldi column k, plus per
+    restart (k + 2) n s (update) and B_spmv + 3 n s (init!) -- summed over the call and divided by its inner iterations; `moved` = what the
+    launches of this implementation stream (MGS (4k + 3) n s: v_i is read by the pass that projects on it and again by the pass
+    that subtracts it; CGS (2k + 6) n s)."""
+    import torch
+    pkg = graft.load_package()
+    s8 = 8
+    spmv_bytes = A.spmv_algorithmic_bytes()
+    out = {"workload": f"gmres!(restart={restart}) on the 256^3 7-point Laplacian, fp64, hashed rhs, x0 = 0, {inner} inner iterations (reltol = 0), "
+                       f"operator on its plain CSR arrays; V = {(restart + 1) * n * s8 / 1e9:.2f} GB",
+           "operator_layout": A.layout(), "spmv_kernel": A.spmv_kernel(), "spmv_algorithmic_bytes": spmv_bytes}
+    for name, M in (("mgs", pkg.ModifiedGramSchmidt()), ("cgs", pkg.ClassicalGramSchmidt())):
+        if name not in methods:
+            continue
+        best, hist, it = None, None, None
+        for _rep in range(reps):
+            it = pkg.gmres_iterable_(pkg.zerox(A, b), A, b, restart=restart, orth_meth=M, initially_zero=True, reltol=0.0, maxiter=inner)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hist = it.iterate_many(0, inner)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        iters = int(hist.size)
+        ks = [(j % restart) + 1 for j in range(iters)]                     # Arnoldi column of every inner iteration
+        cycles = (iters + restart - 1) // restart
+        alg = sum(spmv_bytes + ((3 * k + 2) if name == "mgs" else (2 * k + 3)) * n * s8 for k in ks)
+        moved = sum(spmv_bytes + ((4 * k + 3) if name == "mgs" else (2 * k + 6)) * n * s8 for k in ks)
+        per_restart = [(min(restart, iters - c * restart) + 2) * n * s8 + spmv_bytes + 3 * n * s8 for c in range(cycles)]
+        alg += sum(per_restart)
+        moved += sum(per_restart)
+        us = best / max(iters, 1) * 1e6
+        rec = {"us_per_inner_iteration": us, "inner_iterations": iters, "calls_timed": reps, "mv_products": int(it.mv_products), "restart_cycles": cycles,
+               "algorithmic_bytes_per_inner_iteration": alg / max(iters, 1), "achieved": alg / best / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+               "frac": alg / best / 1e9 / HBM_PEAK_GBS, "frac_of_copy_ceiling_6290": alg / best / 1e9 / COPY_CEILING_GBS,
+               "bytes_moved_per_inner_iteration": moved / max(iters, 1), "moved_gbs": moved / best / 1e9, "moved_frac": moved / best / 1e9 / HBM_PEAK_GBS,
+               "final_residual": float(hist[-1]) if iters else None}
+        tr = gmres_large_traffic(name)
+        if tr is not None:
+            rec["traffic_per_inner_iteration"] = tr["bytes"]
+            rec["traffic_source"] = tr["source"]
+            rec["traffic_is"] = "committed constant: sum over the kernels of one profiled call of 2 x FETCH_SIZE + WRITE_SIZE (separate rocprofv3 --pmc passes), divided by its inner iterations"
+        out[name] = rec
+        del it
+    return out
+
+
+def gmres_large_traffic(name: str):
+    """HBM-side bytes per inner iteration of the HBM-bound GMRES leg from the committed PMC passes (profiles/*gmres_large_<name>_traffic.json)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*gmres_large_{name}_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+            return {"bytes": t["traffic_bytes_per_inner_iteration"], "source": os.path.relpath(f, ROOT)}
+        except Exception:
+            continue
+    return None
+
+
 def c5_traffic(kind: str):
     """PMC traffic per SpMV launch of a configs[4] stand-in from the committed rocprofv3 passes (profiles/*c5_<kind>_traffic.json,
     written by scripts/prof_r03.sh + prof_collect.py from separate --pmc runs of scripts/config5_bench.py on that one matrix)."""
@@ -489,6 +554,12 @@ def run_single(args):
         "batched_25_steps_per_sync_iters_per_sec": kb / float(np.median(tb)),
         "parity_full_history": parity,
     }
+    if not args.no_gmres_large and N >= 128:
+        A.set_layout("csr")
+        try:
+            out["gmres_hbm_bound"] = gmres_hbm_bound(A, b, n)
+        finally:
+            A.set_layout("auto")
     del A, b, scratch, u
     if not args.no_gmres:
         out["gmres_config3"] = gmres_config3()
@@ -571,6 +642,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the full solve compared with tests/golden/")
     ap.add_argument("--no-csr", action="store_true", help="skip the contract loop on the plain CSR arrays (roofline then describes the default layout)")
     ap.add_argument("--no-gmres", action="store_true", help="skip the configs[2] sub-benchmark (gmres_config3)")
+    ap.add_argument("--no-gmres-large", action="store_true", help="skip the HBM-bound GMRES leg (gmres_hbm_bound: gmres!(restart=30) on the 256^3 operator)")
     ap.add_argument("--no-config5", action="store_true", help="skip the configs[4] stand-ins (config5)")
     ap.add_argument("--config5-kinds", default="fe_shell,fe_hex,banded,random")
     ap.add_argument("--stencil27", type=int, default=0, help="grid of the 27-point box-stencil sub-benchmark (off by default: outside every BASELINE.json config; frozen, VERDICT r3 #8)")

@@ -57,6 +57,34 @@ for d in sorted(glob.glob(os.path.join(root, "*"))):
                 counts[k] = len(v)
     if not means:
         continue
+    if what.startswith("gmres_large_"):
+        # whole-call traffic of the HBM-bound GMRES leg: every dispatch of the solver's kernels (SpMV, vector sweeps, batched dots, gemv,
+        # finalisers) of ONE profiled call, 2 x FETCH_SIZE + WRITE_SIZE summed, divided by the call's inner iterations
+        tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+        per_kernel = collections.defaultdict(lambda: {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "dispatches": 0})
+        for f in sorted(glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
+            for row in csv.DictReader(open(f)):
+                c = row["Counter_Name"]
+                k = short(row["Kernel_Name"])
+                if c in tot and any(t in k for t in ("spmv", "k_map", "multidot", "gemv", "finalize", "k_mgs", "k_cgs")):
+                    tot[c] += float(row["Counter_Value"])
+                    per_kernel[tkey(k)][c] += float(row["Counter_Value"])
+                    per_kernel[tkey(k)]["dispatches"] += 1 if c == "FETCH_SIZE" else 0
+        inner = None
+        for lf in sorted(glob.glob(os.path.join(d, "pmc_fetch.log"))):
+            for line in open(lf):
+                if line.startswith("{"):
+                    j = json.loads(line)
+                    name = what[len("gmres_large_"):]
+                    if name in j:
+                        inner = j[name]["inner_iterations"] * j[name].get("calls_timed", 1)
+        if inner:
+            rd, wr = 2.0 * tot["FETCH_SIZE"] * 1024.0, tot["WRITE_SIZE"] * 1024.0
+            json.dump({"inner_iterations_profiled": inner, "fetch_bytes_x2": rd, "write_bytes": wr,
+                       "traffic_bytes_per_inner_iteration": (rd + wr) / inner,
+                       "per_kernel_bytes_per_inner_iteration": {k: {"traffic": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 / inner,
+                                                                     "dispatches_per_inner_iteration": v["dispatches"] / inner} for k, v in per_kernel.items()}},
+                      open(os.path.join(summ, f"{what}_traffic.json"), "w"), indent=1)
     traffic = {}
     with open(os.path.join(summ, f"{what}_pmc_summary.txt"), "w") as o:
         o.write("mean counter value per dispatch (separate rocprofv3 --pmc passes; scripts/prof_r0N.sh)\n")
@@ -118,5 +146,5 @@ for d in sorted(glob.glob(os.path.join(root, "*"))):
             for line in der:
                 o.write(f"    => {line}\n")
     if traffic:
-        json.dump(traffic, open(os.path.join(summ, f"{what}_traffic.json"), "w"), indent=1)
+        json.dump(traffic, open(os.path.join(summ, f"{what}_traffic.json" if not what.startswith("gmres_large_") else f"{what}_traffic_per_launch.json"), "w"), indent=1)
 print("summaries:", sorted(os.listdir(summ)))
