@@ -97,10 +97,12 @@ constexpr int MIK_MAIL_KINDS = 3;        // 0: dot(u, c)   1: |r|^2   2: every o
 // store, so the two need no ordering between them (no release fence, i.e. no L2 write-back, in the finalising kernels): the reader
 // takes the value once BOTH words carry the sequence number it waits for
 struct MailSlot { unsigned long long w0, w1; };
+constexpr int MIK_MAIL_VEC = 64;         // scalars of one vector exchange (the k projections of a CGS / DGKS column of the row-partitioned GMRES)
 struct MailBox {
     MailSlot slot[MIK_MAIL_KINDS][2][MIK_MAIL_MAXP];    // [kind][seq & 1][sender]
-    unsigned long long halo_seq[MIK_MAIL_MAXP];          // [sender]: its halo of exchange no. halo_seq[sender] has landed in this rank's ghost region
+    unsigned long long halo_seq[MIK_MAIL_MAXP];          // [sender]: its halo of exchange no. halo_seq[sender] has landed in this rank's landing buffer
     unsigned long long packed_seq;                       // this rank: the send buffer of exchange no. packed_seq is packed (the side stream waits for it)
+    MailSlot vec[2][MIK_MAIL_MAXP][MIK_MAIL_VEC];        // [seq & 1][sender][j]: element j of a vector in flight (lane j of the one-wave exchange serves it)
 };
 
 struct mik_comm {
@@ -126,6 +128,7 @@ struct mik_comm {
     bool mail_finegrained = false;       // hipExtMallocWithFlags(hipDeviceMallocFinegrained) succeeded for the mailbox
     bool mail_ready = false;
     unsigned long long mseq[MIK_MAIL_KINDS] = {0, 0, 0};   // exchanges enqueued so far, per kind
+    unsigned long long vseq = 0;         // vector exchanges enqueued so far
     unsigned long long halo_no = 0;
     unsigned *mail_err = nullptr;        // pinned, device-mapped: a wait timed out
     unsigned long long timeout_ticks = 0;   // of the 100 MHz wall clock
@@ -301,7 +304,110 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_halo_push(const T *__restrict__ s
     }
 }
 
+// lane j's value -> element j of slot vec[seq & 1][rank] of every peer; then, per lane, the P values of element j added in rank order
+template <typename T>
+__device__ __forceinline__ T mail_exchange_vec(MailBox *const *__restrict__ peers, int P, int rank, unsigned long long seq, T mine, int count,
+                                               unsigned long long ticks, unsigned *__restrict__ err)
+{
+    const int j = threadIdx.x & 63;
+    if (j >= count) return T(0);
+    const unsigned long long tag = (seq & 0xFFFFFFFFull) << 32, b = mail_bits<T>(mine);
+    for (int q = 0; q < P; ++q) {
+        MailSlot *dst = &peers[q]->vec[seq & 1ull][rank][j];
+        __hip_atomic_store(&dst->w0, tag | (b & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&dst->w1, tag | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    T sum = T(0);
+    const unsigned long long t0 = wall_clock64();
+    for (int q = 0; q < P; ++q) {
+        const MailSlot *src = &peers[rank]->vec[seq & 1ull][q][j];
+        unsigned long long a0 = 0, a1 = 0;
+        for (unsigned spins = 0;; ++spins) {
+            a0 = __hip_atomic_load(&src->w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            a1 = __hip_atomic_load(&src->w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((a0 >> 32 << 32) == tag && (a1 >> 32 << 32) == tag) break;
+            if ((spins & 255u) == 255u && wall_clock64() - t0 > ticks) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const T v = mail_value<T>((a0 & 0xFFFFFFFFull) | (a1 << 32));
+        sum = q == 0 ? v : sum + v;                       // rank order: ((v_0 + v_1) + v_2) + ...
+    }
+    return sum;
+}
+
+// vals[0 .. count) (this rank's partial sums, written by the kernel before on the stream) -> the sums over the ranks in rank order, in place
+template <typename T>
+__global__ __launch_bounds__(64) void k_mail_sum_vec(MailBox *const *__restrict__ peers, int P, int rank, unsigned long long seq0, T *__restrict__ vals, int count,
+                                                     unsigned long long ticks, unsigned *__restrict__ err)
+{
+    for (int base = 0, c = 0; base < count; base += MIK_MAIL_VEC, ++c) {
+        const int j = base + (int)threadIdx.x, cnt = min(MIK_MAIL_VEC, count - base);
+        const T mine = j < count ? vals[j] : T(0);
+        const T sum = mail_exchange_vec<T>(peers, P, rank, seq0 + (unsigned long long)c, mine, cnt, ticks, err);
+        if (j < count) vals[j] = sum;
+    }
+}
+
+// Level 2 of this rank's segment sums (the fixed 1024-thread shape of k_finalize_store), the exchange of the rank totals and their sum in rank
+// order in ONE launch: what finalize -> D2H -> host all-gather -> H2D did for every projection of the row-partitioned GMRES.
+// mode 0: out[0] = sum;  mode 1: out[0] = nrm = sqrt(sum), out[1] = 1 / nrm  (k_finalize_nrm_inv: NaN / 1 outside the safe range -- the host recomputes)
+template <typename T>
+__global__ __launch_bounds__(MIK_FIN_THREADS) void k_fin_sum_mail(const T *__restrict__ S, int64_t m, T *__restrict__ out, int mode, MailBox *const *__restrict__ peers,
+                                                                   int P, int rank, unsigned long long seq, T *__restrict__ all, unsigned long long ticks,
+                                                                   unsigned *__restrict__ err)
+{
+    __shared__ T lds16[16];
+    __shared__ T tot_s;
+    const T tot = level2_sum(S, m, lds16);
+    if (threadIdx.x == 0) tot_s = tot;
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const T v = mail_exchange<T>(peers, P, rank, 2, seq, tot_s, all, ticks, err);
+    const T sum = mail_rank_sum(v, P);
+    if (threadIdx.x == 0) {
+        if (mode == 0) out[0] = sum;
+        else {
+            T nrm = mik_sqrt(sum);
+            T inv = T(1) / nrm;
+            if (!mik_nrm_in_range(sum)) { nrm = __builtin_nan(""); inv = T(1); }
+            out[0] = nrm;
+            out[1] = inv;
+        }
+    }
+}
+
 struct WaitPeers { int peer[PushSegs::MAX]; int n; };
+// The halo has landed: wait for the senders' flags, then copy this exchange's half of the LANDING BUFFER into the ghost tail of the
+// extended vector.  The landing buffer is fine-grained device memory owned by the library and written by the peers over xGMI; it is
+// read here with system-scope loads (never served from a cache of this device), and the ghost tail is written by THIS device -- so
+// the SpMV that follows reads halo data through the ordinary kernel-to-kernel visibility of its own device, whatever a cache of this
+// device still holds of the previous exchange (peer-written coarse-grained memory became visible only if the next kernel's
+// start invalidated the right lines).  U = the element's bit type (uint64 for fp64, uint32 for fp32).
+template <typename U>
+__global__ __launch_bounds__(MIK_BLOCK) void k_halo_land(const MailBox *__restrict__ mine, WaitPeers wp, unsigned long long halo_no, unsigned long long ticks,
+                                                         unsigned *__restrict__ err, const U *__restrict__ land, U *__restrict__ ghost, long long count)
+{
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < wp.n && !mail_wait(&mine->halo_seq[wp.peer[threadIdx.x]], halo_no, ticks)) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        bad = 1;
+    }
+    __syncthreads();
+    if (bad) return;
+    const long long stride = (long long)gridDim.x * MIK_BLOCK;
+    long long j = (long long)blockIdx.x * MIK_BLOCK + threadIdx.x;
+    for (; j + 7 * stride < count; j += 8 * stride) {
+        U v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = __hip_atomic_load(land + j + q * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ghost[j + q * stride] = v[q];
+    }
+    for (; j < count; j += stride) ghost[j] = __hip_atomic_load(land + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(64) void k_halo_wait(const MailBox *__restrict__ mine, WaitPeers wp, unsigned long long halo_no, unsigned long long ticks,
                                                   unsigned *__restrict__ err)
 {

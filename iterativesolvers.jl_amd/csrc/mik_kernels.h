@@ -762,7 +762,9 @@ template <typename T> struct OpJacobiDot {
 template <typename T, bool SELF> struct OpMgsPass {
     static constexpr bool REDUCE = true;
     T *__restrict__ w; const T *__restrict__ v; const T *__restrict__ z; Coef<T> h;
-    int nt = 0;    // 1: v (subtracted here, not needed again in this orthogonalisation) is streamed non-temporally
+    // cache hints (bits; results never depend on them): 1 = v (subtracted here, not needed again in this orthogonalisation) streamed
+    // non-temporally, 2 = z streamed, 4 = w loaded non-temporally, 8 = w stored non-temporally
+    int nt = 0;
     __device__ __forceinline__ void set_coef(T c) { h.ptr = nullptr; h.val = c; }
     struct Regs { typename VT<T>::vec wv, vv, zv; };          // load / compute halves of apply_vec (k_map_pro)
     __device__ __forceinline__ void load_vec(int64_t i, Regs &r) const
@@ -790,12 +792,12 @@ template <typename T, bool SELF> struct OpMgsPass {
     __device__ __forceinline__ void apply_vec(int64_t i, T &acc) const
     {
         const T hh = h.get();
-        auto wv = vload<T>(w + i); auto vv = nt ? vload_nt(v + i) : vload(v + i);
+        auto wv = (nt & 4) ? vload_nt<T>(w + i) : vload<T>(w + i); auto vv = (nt & 1) ? vload_nt(v + i) : vload(v + i);
         typename VT<T>::vec zv;
-        if (!SELF) zv = vload(z + i);
+        if (!SELF) zv = (nt & 2) ? vload_nt(z + i) : vload(z + i);
 #pragma unroll
         for (int e = 0; e < VT<T>::W; ++e) { T t = hh * el<T>(vv, e); el<T>(wv, e) = el<T>(wv, e) - t; }
-        vstore(w + i, wv);
+        if (nt & 8) vstore_nt(w + i, wv); else vstore(w + i, wv);
 #pragma unroll
         for (int e = 0; e < VT<T>::W; ++e) {
             T p = (SELF ? el<T>(wv, e) : el<T>(zv, e)) * el<T>(wv, e);

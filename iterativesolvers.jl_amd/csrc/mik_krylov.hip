@@ -102,6 +102,14 @@ template <typename T> static inline int mik_basis_nt(const mik_ctx *ctx, int64_t
     if (ctx->tuning[13] & bit) return 0;
     return (double)n * (double)k * sizeof(T) > 192.0e6 ? 1 : 0;
 }
+// Cache hints of a pass of the multi-launch Modified Gram-Schmidt chain (OpMgsPass::nt).  MGS_HINTS (development, read once): an explicit
+// mask for A/B runs; default: the column that is subtracted in this pass and not needed again is streamed.
+static inline int mik_mgs_pass_hints(const mik_ctx *ctx)
+{
+    static const int env = [] { const char *e = getenv("MIK_MGS_HINTS"); return e ? atoi(e) : -1; }();
+    if (env >= 0) return env;
+    return (ctx->tuning[13] & 1) == 0 ? 1 : 0;
+}
 
 template <typename T>
 static int gemv_n_dev(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, const T *cf_dev, T alpha, T *y)
@@ -235,11 +243,11 @@ static int orthogonalize_enqueue(mik_ctx *ctx, int64_t n, int k, const T *V, int
             MIK_TRY((launch_map<T>(ctx, n, d0, vec, part, nullptr)));
             MIK_TRY(finalize_store<T>(ctx, nseg, 1, hd));
             for (int i = 0; i + 1 < k; ++i) {
-                OpMgsPass<T, false> op{w, col(i), col(i + 1), coef_ptr<T>(hd + i), (ctx->tuning[13] & 1) == 0};
+                OpMgsPass<T, false> op{w, col(i), col(i + 1), coef_ptr<T>(hd + i), mik_mgs_pass_hints(ctx)};
                 MIK_TRY((launch_map<T>(ctx, n, op, vec, part, nullptr)));
                 MIK_TRY(finalize_store<T>(ctx, nseg, 1, hd + i + 1));
             }
-            OpMgsPass<T, true> last{w, col(k - 1), nullptr, coef_ptr<T>(hd + k - 1), (ctx->tuning[13] & 1) == 0};
+            OpMgsPass<T, true> last{w, col(k - 1), nullptr, coef_ptr<T>(hd + k - 1), mik_mgs_pass_hints(ctx)};
             MIK_TRY((launch_map<T>(ctx, n, last, vec, part, nullptr)));
         } else {
             MIK_TRY((launch_map<T>(ctx, n, dn, vecw, part, nullptr)));
