@@ -62,9 +62,11 @@
 extern "C" {
 #endif
 
-#define MIK_ABI_VERSION 4   /* 4 (round 4): MIK_ERR_SINGULAR replaces MIK_ERR_INVALID for an exactly singular pivot (mik_lu_solve, mik_bicgstab_step);
-                             *   the scalar mailbox transport (mik_mailbox_*); additions only otherwise.  3 (round 3): mik_csr_pack and the knob setters
-                             *   left this header (include/mik_dev.h) */
+#define MIK_ABI_VERSION 5   /* 5 (round 5): mik_partition gained `link`; the pushed halo lands in library-owned buffers (mik_plink_*, mik_cgd_ghost_export;
+                             *   mik_cgd_connect_ghosts takes ghost counts instead of byte offsets; mik_mem_export is gone); mik_cgd_profile.
+                             *   4 (round 4): MIK_ERR_SINGULAR replaces MIK_ERR_INVALID for an exactly singular pivot (mik_lu_solve, mik_bicgstab_step);
+                             *   the scalar mailbox transport (mik_mailbox_*).  3 (round 3): mik_csr_pack and the knob setters left this header
+                             *   (include/mik_dev.h) */
 
 /* status codes */
 enum {
@@ -387,6 +389,11 @@ typedef struct mik_partition {
     mik_halo_fn halo;
     mik_reduce_fn reduce;
     void *user;
+    struct mik_plink *link;     /* NULL: the two callbacks above couple the ranks.  A connected link ("Transport 3" below; created on a communicator
+                                 * of THIS ctx): the library exchanges by itself, on the device -- halo pushed into the neighbours' landing buffers,
+                                 * every projection / norm summed over the ranks inside the kernel that finalises it (rank order, same bits) -- and
+                                 * never calls halo / reduce: no host round trip between the k + 1 reductions of an Arnoldi column
+                                 * (src/orthogonalize.jl:69-76), one wait per inner iteration as on a single GPU. */
 } mik_partition;
 int mik_gmres_create_partitioned(mik_ctx *ctx, const mik_csr *A_loc, void *x, const void *b, const void *pl_diag,
                                  const void *pr_diag, double abstol, double reltol, int restart, int64_t maxiter,
@@ -478,22 +485,38 @@ int mik_cgd_group_release(mik_cgd **its, int P);    /* frees the group's events 
  * host gathers the handles of all ranks (rank order) over whatever channel it has and every rank calls mik_comm_mailbox_connect
  * (ranks may even share one GPU: HIP IPC has no one-rank-per-device rule).  From then on the two scalars of a step travel as
  * {value, sequence number} stores into every peer's mailbox, issued by the kernel that finalised the reduction; every rank adds the
- * P values in rank order -- the bits of transports 1 and 2.  The halo: every rank exports the allocation that holds its u_ext
- * (mik_mem_export) and the host tells every sender where its segments land (mik_cgd_connect_ghosts); a push kernel on the library's
- * side stream then stores the packed buffer straight into the neighbours' ghost regions and posts the exchange number, a one-wave
- * kernel in front of the boundary row-blocks waits for it.  A communicator created with id128 = NULL and nranks > 1 has no RCCL at
- * all and needs both; one created with a ncclUniqueId may connect mailboxes only (scalars by mailbox, halo by ncclSend / ncclRecv).
+ * P values in rank order -- the bits of transports 1 and 2.
+ * The halo travels through LANDING BUFFERS: fine-grained device memory owned by the library (one per link, two halves used
+ * alternately).  A push kernel stores the packed send buffer straight into the neighbours' landing buffers over xGMI and posts the
+ * exchange number in their mailboxes; on the receiving side one kernel waits for the flags and copies the landed entries into the
+ * ghost tail of the extended vector with system-scope loads.  The SpMV that follows therefore reads halo data its OWN device wrote --
+ * no memory of the host (a tensor of a pooling allocator) is ever mapped into a peer, and nothing depends on which peer-written
+ * lines a cache of the receiving device still holds.
+ * A communicator created with id128 = NULL and nranks > 1 has no RCCL at all and needs both mailboxes and links; one created with a
+ * ncclUniqueId may connect mailboxes only (scalars by mailbox, halo by ncclSend / ncclRecv).
  * Waits are bounded (MIK_MAILBOX_TIMEOUT_MS, default 10000): MIK_ERR_HIP instead of a hung queue. */
 int mik_comm_mailbox_export(mik_comm *comm, void *handle64);
 int mik_comm_mailbox_connect(mik_comm *comm, const void *handles /* nranks x 64 bytes, rank order; this rank's entry is ignored */);
 int mik_comm_mailbox_info(const mik_comm *comm, int *connected, int *finegrained);
-/* HIP IPC handle (64 bytes) of the ALLOCATION that holds device pointer dptr, and the byte offset of dptr inside it (a tensor of a
- * pooling allocator sits anywhere in its block). */
-int mik_mem_export(mik_ctx *ctx, const void *dptr, void *handle64, int64_t *offset);
-/* After mik_cgd_set_halo_plan and mik_cgd_set_comm.  handles / offsets: per rank, mik_mem_export of its u_ext (this rank's entry is
- * ignored; a rank may be its own neighbour).  dst_elem: per SEND segment of the halo plan, the element of the receiver's u_ext at
- * which the segment lands (the receiver's n_loc + the offset of its matching receive segment).  At most 8 segments per direction. */
-int mik_cgd_connect_ghosts(mik_cgd *it, const void *handles, const int64_t *offsets, const int64_t *dst_elem);
+
+/* The links of ONE row partition on a communicator: its halo plan (segments as in mik_cgd_set_halo_plan: offsets into the ghost region
+ * of n_ghost entries / into the packed send buffer, at most 8 per direction), its landing buffer and the mappings of the neighbours'.
+ *   mik_plink_export   64-byte HIP IPC handle of this rank's landing buffer;
+ *   mik_plink_connect  collective, after the host gathered handle and n_ghost of every rank: handles / ghost_counts per RANK (this
+ *                      rank's entries are ignored; a rank may be its own neighbour), dst_elem per SEND segment = the element of the
+ *                      receiver's ghost region at which the segment lands (the offset of its matching receive segment).
+ * A row-partitioned GMRES iterable takes a connected link in mik_partition.link; the row-partitioned CG iterable builds its own from the
+ * plan it was given (mik_cgd_ghost_export = create + export, mik_cgd_connect_ghosts = connect). */
+typedef struct mik_plink mik_plink;
+int mik_plink_create(mik_comm *comm, int dtype, int64_t n_ghost, int n_recv, const int *recv_peer, const int64_t *recv_off, const int64_t *recv_cnt,
+                     int n_send, const int *send_peer, const int64_t *send_off, const int64_t *send_cnt, mik_plink **out);
+int mik_plink_export(mik_plink *link, void *handle64);
+int mik_plink_connect(mik_plink *link, const void *handles, const int64_t *ghost_counts, const int64_t *dst_elem);
+int mik_plink_info(const mik_plink *link, int *connected, int *finegrained, int64_t *n_ghost);
+int mik_plink_destroy(mik_plink *link);
+/* After mik_cgd_set_halo_plan and mik_cgd_set_comm (transport "mailbox"): */
+int mik_cgd_ghost_export(mik_cgd *it, void *handle64);
+int mik_cgd_connect_ghosts(mik_cgd *it, const void *handles, const int64_t *ghost_counts, const int64_t *dst_elem);
 
 /* ---- Hessenberg least squares (host) ------------------------------------------------------ */
 /* ldiv!(FastHessenberg(H), rhs) -- src/hessenberg.jl:15-46.  Host arrays of `dtype`; H is

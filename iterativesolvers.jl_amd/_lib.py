@@ -53,7 +53,7 @@ class MikPrecond(C.Structure):
 class MikPartition(C.Structure):
     _fields_ = [("rank", C.c_int), ("nranks", C.c_int), ("n_ext", C.c_int64), ("x_ext", C.c_void_p),
                 ("send_idx", C.c_void_p), ("n_send", C.c_int64), ("send_buf", C.c_void_p),
-                ("halo", HALO_FN), ("reduce", REDUCE_FN), ("user", C.c_void_p)]
+                ("halo", HALO_FN), ("reduce", REDUCE_FN), ("user", C.c_void_p), ("link", C.c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/mik.h one to one
@@ -155,8 +155,13 @@ SIGNATURES = {
     "mik_comm_mailbox_export": (C.c_int, [_vp, _vp]),
     "mik_comm_mailbox_connect": (C.c_int, [_vp, _vp]),
     "mik_comm_mailbox_info": (C.c_int, [_vp, _ip, _ip]),
-    "mik_mem_export": (C.c_int, [_vp, _vp, _vp, _i64p]),
+    "mik_cgd_ghost_export": (C.c_int, [_vp, _vp]),
     "mik_cgd_connect_ghosts": (C.c_int, [_vp, _vp, _i64p, _i64p]),
+    "mik_plink_create": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _ip, _i64p, _i64p, C.c_int, _ip, _i64p, _i64p, C.POINTER(_vp)]),
+    "mik_plink_export": (C.c_int, [_vp, _vp]),
+    "mik_plink_connect": (C.c_int, [_vp, _vp, _i64p, _i64p]),
+    "mik_plink_info": (C.c_int, [_vp, _ip, _ip, _i64p]),
+    "mik_plink_destroy": (C.c_int, [_vp]),
     "mik_cgd_init": (C.c_int, [_vp, _f64p, _f64p]),
     "mik_cgd_iterate_many": (C.c_int, [_vp, _i64, _i64, _f64p, _i64p]),
     "mik_cgd_group_init": (C.c_int, [C.POINTER(_vp), C.c_int, _f64p, _f64p]),

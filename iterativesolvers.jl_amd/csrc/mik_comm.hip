@@ -715,42 +715,110 @@ extern "C" int mik_comm_mailbox_connect(mik_comm *cm, const void *handles)
     return MIK_OK;
 }
 
-// IPC handle of the ALLOCATION that holds dptr + the byte offset of dptr inside it (a host's tensor may sit anywhere in a pool block)
-extern "C" int mik_mem_export(mik_ctx *ctx, const void *dptr, void *handle64, int64_t *offset)
+// ---------------------------------------------------------------------------------------------
+// mik_plink: the device-driven links of ONE row partition (halo plan + landing buffer + peer mappings) on a communicator's mailboxes.
+// The row-partitioned CG iterable builds one from its halo plan (mik_cgd_ghost_export / mik_cgd_connect_ghosts); the row-partitioned
+// GMRES iterable takes one in mik_partition.link and then needs no host callbacks (csrc/mik_krylov.hip).
+// ---------------------------------------------------------------------------------------------
+struct mik_plink {
+    mik_comm *cm = nullptr;
+    int dtype = MIK_F64;
+    size_t es = 8;
+    int64_t n_ghost = 0;
+    std::vector<mik_cgd::HaloSeg> recv, send;   // offsets into the ghost region / into the packed send buffer, in elements
+    void *land = nullptr;                // fine-grained device memory: 2 (exchange parity) x n_ghost elements; the PEERS write it, this rank copies it out
+    size_t land_stride = 0;              // bytes between the two parities
+    bool land_finegrained = false;
+    std::vector<unsigned char *> send_dst;      // per send segment: parity 0 of its place in the receiver's landing buffer, as mapped here
+    std::vector<size_t> send_stride;            // ... and the receiver's parity stride
+    bool connected = false;
+};
+
+static size_t plink_stride(int64_t n_ghost, size_t es) { return ((size_t)std::max<int64_t>(n_ghost, 1) * es + 255) / 256 * 256; }
+
+extern "C" int mik_plink_destroy(mik_plink *pl)
 {
-    if (!ctx || !dptr || !handle64 || !offset) return MIK_ERR_INVALID;
-    (void)hipSetDevice(ctx->device);
-    hipDeviceptr_t base = nullptr;
-    size_t size = 0;
-    MIK_HIP(ctx, hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)dptr));
-    hipIpcMemHandle_t h;
-    MIK_HIP(ctx, hipIpcGetMemHandle(&h, (void *)base));
-    memcpy(handle64, &h, 64);
-    *offset = (int64_t)((const unsigned char *)dptr - (const unsigned char *)base);
+    if (!pl) return MIK_OK;
+    if (pl->cm && pl->cm->ctx) { (void)hipSetDevice(pl->cm->ctx->device); (void)hipStreamSynchronize(pl->cm->ctx->stream); if (pl->cm->side) (void)hipStreamSynchronize(pl->cm->side); }
+    if (pl->land) (void)hipFree(pl->land);
+    delete pl;
     return MIK_OK;
 }
 
-// handles / offsets: per RANK, the allocation that holds its u_ext and the byte offset of u_ext[0] in it (mik_mem_export on that
-// rank; ignored for this rank itself); dst_elem: per SEND segment of the halo plan, the element of the receiver's u_ext at which the
-// segment lands (its n_loc + the offset of the matching receive segment there).
-extern "C" int mik_cgd_connect_ghosts(mik_cgd *it, const void *handles, const int64_t *offsets, const int64_t *dst_elem)
+extern "C" int mik_plink_create(mik_comm *cm, int dtype, int64_t n_ghost, int n_recv, const int *recv_peer, const int64_t *recv_off, const int64_t *recv_cnt,
+                                int n_send, const int *send_peer, const int64_t *send_off, const int64_t *send_cnt, mik_plink **out)
 {
-    if (!it || !it->comm) return MIK_ERR_INVALID;
-    mik_comm *cm = it->comm;
-    mik_ctx *ctx = it->base.ctx;
-    if (it->send.size() > (size_t)PushSegs::MAX || it->recv.size() > (size_t)PushSegs::MAX)
-        return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_cgd_connect_ghosts: more than %d halo segments per direction", PushSegs::MAX);
-    if (!it->send.empty() && !dst_elem) return MIK_ERR_INVALID;
+    if (!cm || !out || n_ghost < 0 || n_recv < 0 || n_send < 0 || (dtype != MIK_F64 && dtype != MIK_F32) ||
+        (n_recv && (!recv_peer || !recv_off || !recv_cnt)) || (n_send && (!send_peer || !send_off || !send_cnt)))
+        return MIK_ERR_INVALID;
+    *out = nullptr;
+    mik_ctx *ctx = cm->ctx;
+    if (n_recv > PushSegs::MAX || n_send > PushSegs::MAX) return mik_fail(ctx, MIK_ERR_NOTIMPL, "mik_plink_create: more than %d halo segments per direction", PushSegs::MAX);
     MIK_TRY(mailbox_alloc(cm));
-    const size_t es = mik_dtype_size(it->base.dtype);
+    mik_plink *pl = new (std::nothrow) mik_plink();
+    if (!pl) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_plink_create: host allocation failed");
+    pl->cm = cm; pl->dtype = dtype; pl->es = mik_dtype_size(dtype); pl->n_ghost = n_ghost;
+    for (int i = 0; i < n_recv; ++i) {
+        if (recv_peer[i] < 0 || recv_peer[i] >= cm->nranks || recv_off[i] < 0 || recv_cnt[i] < 0 || recv_off[i] + recv_cnt[i] > n_ghost) {
+            delete pl;
+            return mik_fail(ctx, MIK_ERR_INVALID, "mik_plink_create: receive segment %d out of range", i);
+        }
+        pl->recv.push_back({recv_peer[i], recv_off[i], recv_cnt[i]});
+    }
+    for (int i = 0; i < n_send; ++i) {
+        if (send_peer[i] < 0 || send_peer[i] >= cm->nranks || send_off[i] < 0 || send_cnt[i] < 0) {
+            delete pl;
+            return mik_fail(ctx, MIK_ERR_INVALID, "mik_plink_create: send segment %d out of range", i);
+        }
+        pl->send.push_back({send_peer[i], send_off[i], send_cnt[i]});
+    }
     (void)hipSetDevice(ctx->device);
-    it->send_dst.clear();
-    for (size_t i = 0; i < it->send.size(); ++i) {
-        const int q = it->send[i].peer;
+    pl->land_stride = plink_stride(n_ghost, pl->es);
+    hipError_t e = hipExtMallocWithFlags(&pl->land, 2 * pl->land_stride, hipDeviceMallocFinegrained);
+    pl->land_finegrained = e == hipSuccess;
+    if (e != hipSuccess) { (void)hipGetLastError(); pl->land = nullptr; e = hipMalloc(&pl->land, 2 * pl->land_stride); }   // (read with system-scope loads either way)
+    if (e != hipSuccess || (e = hipMemset(pl->land, 0, 2 * pl->land_stride)) != hipSuccess) {
+        (void)hipGetLastError();
+        mik_plink_destroy(pl);
+        return mik_fail(ctx, MIK_ERR_NOMEM, "mik_plink_create: landing buffer (%zu bytes): %s", 2 * pl->land_stride, hipGetErrorString(e));
+    }
+    pl->connected = pl->send.empty() && pl->recv.empty();
+    *out = pl;
+    return MIK_OK;
+}
+
+// 64-byte HIP IPC handle of this rank's landing buffer (what its neighbours map to push their halo segments)
+extern "C" int mik_plink_export(mik_plink *pl, void *handle64)
+{
+    if (!pl || !handle64) return MIK_ERR_INVALID;
+    hipIpcMemHandle_t h;
+    memset(&h, 0, sizeof(h));
+    (void)hipSetDevice(pl->cm->ctx->device);
+    if (pl->cm->nranks > 1) MIK_HIP(pl->cm->ctx, hipIpcGetMemHandle(&h, pl->land));
+    memcpy(handle64, &h, 64);
+    return MIK_OK;
+}
+
+// handles: per RANK the landing-buffer handle of its link (mik_plink_export there; ignored for this rank itself); ghost_counts: per rank the
+// n_ghost of its link (the parity stride of its landing buffer follows from it); dst_elem: per SEND segment, the element of the receiver's
+// GHOST REGION at which the segment lands (the offset of the matching receive segment there).
+extern "C" int mik_plink_connect(mik_plink *pl, const void *handles, const int64_t *ghost_counts, const int64_t *dst_elem)
+{
+    if (!pl) return MIK_ERR_INVALID;
+    mik_comm *cm = pl->cm;
+    mik_ctx *ctx = cm->ctx;
+    if (!pl->send.empty() && (!dst_elem || !ghost_counts)) return MIK_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    pl->send_dst.clear();
+    pl->send_stride.clear();
+    for (size_t i = 0; i < pl->send.size(); ++i) {
+        const int q = pl->send[i].peer;
+        if (dst_elem[i] < 0 || dst_elem[i] + pl->send[i].cnt > ghost_counts[q])
+            return mik_fail(ctx, MIK_ERR_INVALID, "mik_plink_connect: send segment %zu does not fit rank %d's ghost region", i, q);
         unsigned char *base = nullptr;
-        if (q == it->rank) base = (unsigned char *)it->u_ext;
+        if (q == cm->rank) base = (unsigned char *)pl->land;
         else {
-            if (!handles || !offsets) return MIK_ERR_INVALID;
+            if (!handles) return MIK_ERR_INVALID;
             const unsigned char *hq = (const unsigned char *)handles + 64 * (size_t)q;
             void *mapped = nullptr;
             for (const mik_comm::GhostMap &g : cm->ghost_maps)
@@ -759,16 +827,167 @@ extern "C" int mik_cgd_connect_ghosts(mik_cgd *it, const void *handles, const in
                 hipIpcMemHandle_t h;
                 memcpy(&h, hq, 64);
                 hipError_t e = hipIpcOpenMemHandle(&mapped, h, hipIpcMemLazyEnablePeerAccess);
-                if (e != hipSuccess) return mik_fail(ctx, MIK_ERR_HIP, "mik_cgd_connect_ghosts: hipIpcOpenMemHandle(rank %d): %s", q, hipGetErrorString(e));
+                if (e != hipSuccess) return mik_fail(ctx, MIK_ERR_HIP, "mik_plink_connect: hipIpcOpenMemHandle(rank %d): %s", q, hipGetErrorString(e));
                 cm->ipc_open.push_back(mapped);
                 mik_comm::GhostMap g;
                 g.rank = q; memcpy(g.handle, hq, 64); g.base = mapped;
                 cm->ghost_maps.push_back(g);
             }
-            base = (unsigned char *)mapped + offsets[q];
+            base = (unsigned char *)mapped;
         }
-        it->send_dst.push_back(base + es * (size_t)dst_elem[i]);
+        pl->send_dst.push_back(base + pl->es * (size_t)dst_elem[i]);
+        pl->send_stride.push_back(plink_stride(ghost_counts[q], pl->es));
     }
+    pl->connected = true;
+    return MIK_OK;
+}
+
+extern "C" int mik_plink_info(const mik_plink *pl, int *connected, int *finegrained, int64_t *n_ghost)
+{
+    if (!pl) return MIK_ERR_INVALID;
+    if (connected) *connected = pl->connected ? 1 : 0;
+    if (finegrained) *finegrained = pl->land_finegrained ? 1 : 0;
+    if (n_ghost) *n_ghost = pl->n_ghost;
+    return MIK_OK;
+}
+
+// exchange no. `no` of the link: the packed send buffer -> the neighbours' landing buffers (half no & 1) + their flags, on stream `s`
+static int plink_push(mik_plink *pl, const void *send_buf, unsigned long long no, hipStream_t s)
+{
+    mik_comm *cm = pl->cm;
+    mik_ctx *ctx = cm->ctx;
+    PushSegs sg{};
+    int64_t total = 0;
+    sg.n = (int)pl->send.size();
+    if (sg.n == 0) return MIK_OK;
+    for (int i = 0; i < sg.n; ++i) {
+        sg.dst[i] = pl->send_dst[(size_t)i] + (no & 1ull) * pl->send_stride[(size_t)i];
+        sg.off[i] = pl->send[(size_t)i].off; sg.cnt[i] = pl->send[(size_t)i].cnt; sg.peer[i] = pl->send[(size_t)i].peer;
+        total += pl->send[(size_t)i].cnt;
+    }
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(128, (total * (int64_t)pl->es / 64 + MIK_BLOCK - 1) / MIK_BLOCK));
+    if (pl->dtype == MIK_F64)
+        hipLaunchKernelGGL((k_halo_push<double>), dim3(grid), dim3(MIK_BLOCK), 0, s, (const double *)send_buf, sg, (MailBox *const *)cm->peers_dev, cm->rank, no, cm->push_ticket);
+    else
+        hipLaunchKernelGGL((k_halo_push<float>), dim3(grid), dim3(MIK_BLOCK), 0, s, (const float *)send_buf, sg, (MailBox *const *)cm->peers_dev, cm->rank, no, cm->push_ticket);
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+
+// ... and on the receiving side: wait for the senders' flags of exchange `no`, copy its half of the landing buffer into `ghost`
+static int plink_land(mik_plink *pl, void *ghost, unsigned long long no, hipStream_t s)
+{
+    mik_comm *cm = pl->cm;
+    mik_ctx *ctx = cm->ctx;
+    WaitPeers wp{};
+    wp.n = (int)pl->recv.size();
+    if (wp.n == 0) return MIK_OK;
+    for (int i = 0; i < wp.n; ++i) wp.peer[i] = pl->recv[(size_t)i].peer;
+    const unsigned char *src = (const unsigned char *)pl->land + (no & 1ull) * pl->land_stride;
+    const long long cnt = (long long)pl->n_ghost;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(64, (cnt + 8 * MIK_BLOCK - 1) / (8 * MIK_BLOCK)));
+    if (pl->dtype == MIK_F64)
+        hipLaunchKernelGGL((k_halo_land<unsigned long long>), dim3(grid), dim3(MIK_BLOCK), 0, s, (const MailBox *)cm->mail, wp, no, cm->timeout_ticks, cm->mail_err,
+                           (const unsigned long long *)src, (unsigned long long *)ghost, cnt);
+    else
+        hipLaunchKernelGGL((k_halo_land<unsigned>), dim3(grid), dim3(MIK_BLOCK), 0, s, (const MailBox *)cm->mail, wp, no, cm->timeout_ticks, cm->mail_err,
+                           (const unsigned *)src, (unsigned *)ghost, cnt);
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+
+// ---- what csrc/mik_krylov.hip calls for a row-partitioned GMRES with a link (declared in mik_iter.h) -------------------------------
+bool plink_ready(const mik_plink *pl) { return pl && pl->connected && pl->cm && pl->cm->mail_ready; }
+const mik_ctx *plink_ctx(const mik_plink *pl) { return pl->cm->ctx; }
+int plink_rank(const mik_plink *pl) { return pl->cm->rank; }
+int plink_nranks(const mik_plink *pl) { return pl->cm->nranks; }
+
+int plink_check(mik_plink *pl, const char *who) { return mailbox_check(pl->cm, who); }
+
+// the halo of one SpMV, entirely on the compute stream (behind the pack kernel): push, land
+int plink_halo(mik_plink *pl, const void *send_buf, void *ghost)
+{
+    mik_comm *cm = pl->cm;
+    if (pl->send.empty() && pl->recv.empty()) return MIK_OK;
+    const unsigned long long no = ++cm->halo_no;
+    MIK_TRY(plink_push(pl, send_buf, no, cm->ctx->stream));
+    return plink_land(pl, ghost, no, cm->ctx->stream);
+}
+
+// level 2 of this rank's `nseg` segment sums + the sum over the ranks in rank order, one launch; mode 0: out[0] = sum, 1: out[0] = sqrt(sum), out[1] = 1 / out[0]
+int plink_fin_sum(mik_plink *pl, const void *partials, int64_t nseg, void *out_dev, int mode)
+{
+    mik_comm *cm = pl->cm;
+    mik_ctx *ctx = cm->ctx;
+    const unsigned long long seq = ++cm->mseq[2];
+    if (pl->dtype == MIK_F64)
+        hipLaunchKernelGGL((k_fin_sum_mail<double>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const double *)partials, nseg, (double *)out_dev, mode,
+                           (MailBox *const *)cm->peers_dev, cm->nranks, cm->rank, seq, (double *)cm->scratch, cm->timeout_ticks, cm->mail_err);
+    else
+        hipLaunchKernelGGL((k_fin_sum_mail<float>), dim3(1), dim3(MIK_FIN_THREADS), 0, ctx->stream, (const float *)partials, nseg, (float *)out_dev, mode,
+                           (MailBox *const *)cm->peers_dev, cm->nranks, cm->rank, seq, (float *)cm->scratch, cm->timeout_ticks, cm->mail_err);
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+
+// vals_dev[0 .. count): this rank's partial sums -> the sums over the ranks in rank order, in place, one one-wave launch
+int plink_sum_vec(mik_plink *pl, void *vals_dev, int count)
+{
+    mik_comm *cm = pl->cm;
+    mik_ctx *ctx = cm->ctx;
+    if (count <= 0) return MIK_OK;
+    const unsigned long long seq0 = cm->vseq + 1;
+    cm->vseq += (unsigned long long)((count + MIK_MAIL_VEC - 1) / MIK_MAIL_VEC);
+    if (pl->dtype == MIK_F64)
+        hipLaunchKernelGGL((k_mail_sum_vec<double>), dim3(1), dim3(64), 0, ctx->stream, (MailBox *const *)cm->peers_dev, cm->nranks, cm->rank, seq0, (double *)vals_dev, count,
+                           cm->timeout_ticks, cm->mail_err);
+    else
+        hipLaunchKernelGGL((k_mail_sum_vec<float>), dim3(1), dim3(64), 0, ctx->stream, (MailBox *const *)cm->peers_dev, cm->nranks, cm->rank, seq0, (float *)vals_dev, count,
+                           cm->timeout_ticks, cm->mail_err);
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+
+// all_dev[rank] (written by the kernel before on the stream) -> all_dev[0 .. P) on every rank
+int plink_gather(mik_plink *pl, void *all_dev)
+{
+    mik_comm *cm = pl->cm;
+    mik_ctx *ctx = cm->ctx;
+    const unsigned long long seq = ++cm->mseq[2];
+    if (pl->dtype == MIK_F64)
+        hipLaunchKernelGGL((k_mail_gather<double>), dim3(1), dim3(64), 0, ctx->stream, (MailBox *const *)cm->peers_dev, cm->nranks, cm->rank, 2, seq, (double *)all_dev,
+                           cm->timeout_ticks, cm->mail_err);
+    else
+        hipLaunchKernelGGL((k_mail_gather<float>), dim3(1), dim3(64), 0, ctx->stream, (MailBox *const *)cm->peers_dev, cm->nranks, cm->rank, 2, seq, (float *)all_dev,
+                           cm->timeout_ticks, cm->mail_err);
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+
+// ---- the row-partitioned CG iterable on the same links ---------------------------------------------------------------------------
+// After mik_cgd_set_halo_plan + mik_cgd_set_comm: allocate this rank's landing buffer and hand out its IPC handle ...
+extern "C" int mik_cgd_ghost_export(mik_cgd *it, void *handle64)
+{
+    if (!it || !it->comm || !handle64) return MIK_ERR_INVALID;
+    mik_ctx *ctx = it->base.ctx;
+    if (!it->link) {
+        std::vector<int> rp, sp;
+        std::vector<int64_t> ro, rc, so, sc;
+        for (const auto &g : it->recv) { rp.push_back(g.peer); ro.push_back(g.off); rc.push_back(g.cnt); }
+        for (const auto &g : it->send) { sp.push_back(g.peer); so.push_back(g.off); sc.push_back(g.cnt); }
+        MIK_TRY(mik_plink_create(it->comm, it->base.dtype, it->n_ext - it->base.n, (int)rp.size(), rp.data(), ro.data(), rc.data(), (int)sp.size(), sp.data(), so.data(),
+                                 sc.data(), &it->link));
+    }
+    (void)ctx;
+    return mik_plink_export(it->link, handle64);
+}
+
+// ... and, once every rank has exported, connect (collective; arguments as mik_plink_connect)
+extern "C" int mik_cgd_connect_ghosts(mik_cgd *it, const void *handles, const int64_t *ghost_counts, const int64_t *dst_elem)
+{
+    if (!it || !it->comm) return MIK_ERR_INVALID;
+    if (!it->link) { unsigned char tmp[64]; MIK_TRY(mik_cgd_ghost_export(it, tmp)); }
+    MIK_TRY(mik_plink_connect(it->link, handles, ghost_counts, dst_elem));
     it->ghosts = true;
     return MIK_OK;
 }
@@ -793,7 +1012,7 @@ extern "C" int mik_comm_mailbox_info(const mik_comm *cm, int *ready, int *finegr
 // Development knob 6, bit 0: events.  Every waiting kernel is submitted after the kernel that satisfies it, so streams that share a
 // hardware queue cannot deadlock.
 static bool halo_flags(const mik_cgd *it) { return it->comm && it->comm->mail && (it->base.ctx->tuning[6] & 1) == 0; }
-static bool halo_p2p(const mik_cgd *it) { return it->comm && it->comm->mail_ready && it->ghosts; }
+static bool halo_p2p(const mik_cgd *it) { return it->comm && it->comm->mail_ready && it->ghosts && it->link; }
 static bool halo_any(const mik_cgd *it)
 {
     return it->comm && (it->comm->nccl || halo_p2p(it)) && !(it->recv.empty() && it->send.empty());
@@ -829,21 +1048,7 @@ static int halo_issue(mik_cgd *it, bool *pending)
     }
     const size_t es = mik_dtype_size(it->base.dtype);
     if (halo_p2p(it)) {
-        PushSegs sg{};
-        int64_t total = 0;
-        sg.n = (int)it->send.size();
-        for (int i = 0; i < sg.n; ++i) {
-            sg.dst[i] = it->send_dst[(size_t)i]; sg.off[i] = it->send[(size_t)i].off; sg.cnt[i] = it->send[(size_t)i].cnt; sg.peer[i] = it->send[(size_t)i].peer;
-            total += it->send[(size_t)i].cnt;
-        }
-        if (sg.n > 0) {
-            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(128, (total * (int64_t)es / 64 + MIK_BLOCK - 1) / MIK_BLOCK));
-            if (it->base.dtype == MIK_F64)
-                hipLaunchKernelGGL((k_halo_push<double>), dim3(grid), dim3(MIK_BLOCK), 0, cm->side, (const double *)it->send_buf, sg, (MailBox *const *)cm->peers_dev, cm->rank, cm->halo_no, cm->push_ticket);
-            else
-                hipLaunchKernelGGL((k_halo_push<float>), dim3(grid), dim3(MIK_BLOCK), 0, cm->side, (const float *)it->send_buf, sg, (MailBox *const *)cm->peers_dev, cm->rank, cm->halo_no, cm->push_ticket);
-            MIK_LAUNCH_CHECK(ctx);
-        }
+        MIK_TRY(plink_push(it->link, it->send_buf, cm->halo_no, cm->side));
     } else {
         Rccl *R = rccl();
         const int nt = it->base.dtype == MIK_F64 ? NCCL_F64 : NCCL_F32;
@@ -875,13 +1080,8 @@ static int halo_end(mik_cgd *it, bool pending)
     mik_comm *cm = it->comm;
     mik_ctx *ctx = it->base.ctx;
     if (halo_p2p(it)) {
-        WaitPeers wp{};
-        wp.n = (int)it->recv.size();
-        for (int i = 0; i < wp.n; ++i) wp.peer[i] = it->recv[(size_t)i].peer;
-        if (wp.n > 0) {
-            hipLaunchKernelGGL(k_halo_wait, dim3(1), dim3(64), 0, ctx->stream, (const MailBox *)cm->mail, wp, cm->halo_no, cm->timeout_ticks, cm->mail_err);
-            MIK_LAUNCH_CHECK(ctx);
-        }
+        // wait for the neighbours' flags and copy the landed halo into the ghost tail of u_ext (k_halo_land)
+        MIK_TRY(plink_land(it->link, (unsigned char *)it->u_ext + mik_dtype_size(it->base.dtype) * (size_t)it->base.n, cm->halo_no, ctx->stream));
     } else if (halo_flags(it)) {
         WaitPeers wp{};
         wp.n = 1; wp.peer[0] = cm->rank;

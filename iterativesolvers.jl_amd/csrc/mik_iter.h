@@ -146,6 +146,7 @@ __device__ __forceinline__ void cgd_close_step(CgDev<T> *d, T tot, T *__restrict
 int cg_wait_mirror(mik_cg *it);
 
 struct mik_comm;
+struct mik_plink;
 struct mik_cgd {
     mik_cg base;                 // reuses the single-GPU handle's buffers / mirror / scalars
     int rank = 0, nranks = 1;
@@ -163,8 +164,8 @@ struct mik_cgd {
     struct HaloSeg { int peer; int64_t off, cnt; };
     std::vector<HaloSeg> recv, send;      // offsets into the ghost tail of u_ext / into send_buf, in elements
     mik_comm *comm = nullptr;
-    std::vector<void *> send_dst;         // per send segment: where it lands in the receiver's ghost region, as mapped here (mik_cgd_connect_ghosts)
-    bool ghosts = false;                  // the halo is pushed into peer-mapped ghost regions (mailbox transport) instead of ncclSend / ncclRecv
+    struct mik_plink *link = nullptr;     // landing buffer + peer mappings of the pushed halo (mik_cgd_ghost_export / mik_cgd_connect_ghosts; csrc/mik_comm.hip)
+    bool ghosts = false;                  // the halo is pushed into the peers' landing buffers (mailbox transport) instead of ncclSend / ncclRecv
     bool initialised = false;             // mik_cgd_init ran
     // rows the neighbours need (send_idx) as at most two contiguous runs [a, b): when they are, u is updated there FIRST, packed and
     // put on the wire before the bulk of the u = r + beta u sweep runs (mik_cgd_set_halo_plan decides; n_early = 0: not applicable)
@@ -182,3 +183,14 @@ int cgd_wait_raw(mik_cgd *it, struct CgMirror *m);
 // what mik_cgd_wait does after a successful wait: history of the steps since the previous wait, handle scalars
 int cgd_collect(mik_cgd *it, const struct CgMirror &m, double *residual, double *tol, int *done, double *history, int64_t cap, int64_t *steps);
 
+
+// Device-driven links of a row partition (csrc/mik_comm.hip), as the row-partitioned GMRES uses them (csrc/mik_krylov.hip):
+bool plink_ready(const mik_plink *pl);                   // connected, on a communicator whose mailboxes are connected
+const mik_ctx *plink_ctx(const mik_plink *pl);
+int plink_rank(const mik_plink *pl);
+int plink_nranks(const mik_plink *pl);
+int plink_check(mik_plink *pl, const char *who);         // MIK_ERR_HIP if a bounded wait of an earlier exchange expired
+int plink_halo(mik_plink *pl, const void *send_buf, void *ghost);                                   // behind the pack kernel, on the ctx stream
+int plink_fin_sum(mik_plink *pl, const void *partials, int64_t nseg, void *out_dev, int mode);      // level 2 + sum over the ranks (+ sqrt, inverse)
+int plink_sum_vec(mik_plink *pl, void *vals_dev, int count);                                        // in place, rank order
+int plink_gather(mik_plink *pl, void *all_dev);                                                     // all[rank] -> all[0 .. P)

@@ -102,13 +102,18 @@ template <typename T> static inline int mik_basis_nt(const mik_ctx *ctx, int64_t
     if (ctx->tuning[13] & bit) return 0;
     return (double)n * (double)k * sizeof(T) > 192.0e6 ? 1 : 0;
 }
-// Cache hints of a pass of the multi-launch Modified Gram-Schmidt chain (OpMgsPass::nt).  MGS_HINTS (development, read once): an explicit
-// mask for A/B runs; default: the column that is subtracted in this pass and not needed again is streamed.
-static inline int mik_mgs_pass_hints(const mik_ctx *ctx)
+// Cache hints of a pass of the multi-launch Modified Gram-Schmidt chain (OpMgsPass::nt).  MIK_MGS_HINTS (development, read once): an explicit
+// mask for A/B runs.  Default: the column that is subtracted in this pass and not needed again is streamed; when three vectors cannot
+// share the 256 MB Infinity Cache anyway, w is streamed too (load and store), so that the column projected on in this pass -- the one
+// the NEXT pass subtracts -- is what the cache keeps.  Measured at 256^3 fp64 (gmres!(30), 60 inner iterations, one box,
+// scripts/gpu_call2.sh): mask 0: 1,879 us per inner iteration, 1 (v): 1,651, 3 (v, z): 1,684, 9: 1,648, 5: 1,660, 11: 1,686, 15 (all): 1,835,
+// 13 (v, w): 1,622.
+static inline int mik_mgs_pass_hints(const mik_ctx *ctx, int64_t n, size_t es)
 {
     static const int env = [] { const char *e = getenv("MIK_MGS_HINTS"); return e ? atoi(e) : -1; }();
     if (env >= 0) return env;
-    return (ctx->tuning[13] & 1) == 0 ? 1 : 0;
+    if (ctx->tuning[13] & 1) return 0;
+    return (double)n * (double)es > 96.0e6 ? 13 : 1;
 }
 
 template <typename T>
@@ -243,11 +248,11 @@ static int orthogonalize_enqueue(mik_ctx *ctx, int64_t n, int k, const T *V, int
             MIK_TRY((launch_map<T>(ctx, n, d0, vec, part, nullptr)));
             MIK_TRY(finalize_store<T>(ctx, nseg, 1, hd));
             for (int i = 0; i + 1 < k; ++i) {
-                OpMgsPass<T, false> op{w, col(i), col(i + 1), coef_ptr<T>(hd + i), mik_mgs_pass_hints(ctx)};
+                OpMgsPass<T, false> op{w, col(i), col(i + 1), coef_ptr<T>(hd + i), mik_mgs_pass_hints(ctx, n, sizeof(T))};
                 MIK_TRY((launch_map<T>(ctx, n, op, vec, part, nullptr)));
                 MIK_TRY(finalize_store<T>(ctx, nseg, 1, hd + i + 1));
             }
-            OpMgsPass<T, true> last{w, col(k - 1), nullptr, coef_ptr<T>(hd + k - 1), mik_mgs_pass_hints(ctx)};
+            OpMgsPass<T, true> last{w, col(k - 1), nullptr, coef_ptr<T>(hd + k - 1), mik_mgs_pass_hints(ctx, n, sizeof(T))};
             MIK_TRY((launch_map<T>(ctx, n, last, vec, part, nullptr)));
         } else {
             MIK_TRY((launch_map<T>(ctx, n, dn, vecw, part, nullptr)));
@@ -1157,7 +1162,8 @@ template <typename T> static int gm_spmv(mik_gmres *g, const T *src, T *dst)
     T *ext = (T *)g->part.x_ext;
     if (src != ext && g->n > 0) MIK_HIP(ctx, hipMemcpyAsync(ext, src, sizeof(T) * (size_t)g->n, hipMemcpyDeviceToDevice, ctx->stream));
     if (g->part.n_send > 0) MIK_TRY(gather_launch<T>(ctx, g->part.n_send, g->part.send_idx, ext, (T *)g->part.send_buf, nullptr));
-    if (g->part.halo && g->part.halo(g->part.user) != 0) return mik_fail(ctx, MIK_ERR_CALLBACK, "gmres: halo callback failed");
+    if (g->part.link) MIK_TRY(plink_halo(g->part.link, g->part.send_buf, ext + g->n));     // device-driven: push, land -- no host in between
+    else if (g->part.halo && g->part.halo(g->part.user) != 0) return mik_fail(ctx, MIK_ERR_CALLBACK, "gmres: halo callback failed");
     return mik_spmv_launch<T>(ctx, g->A, ext, dst, false, nullptr, nullptr);
 }
 
@@ -1289,6 +1295,150 @@ static int orthogonalize_part(mik_gmres *g, int k, const T *V, int64_t ldv, T *w
 }
 
 
+// ---- the same over a DEVICE-DRIVEN link (mik_partition.link; csrc/mik_comm.hip "mik_plink") -------------------------------------------
+// Every reduction is finalised AND summed over the ranks by one kernel (plink_fin_sum: level 2 of the local tree, the rank totals through the
+// peer-mapped mailboxes, added in rank order -- the additions of gm_reduce's callback, the same bits); the sweeps take their coefficients from
+// device memory, so the k + 1 dependent reductions of an Arnoldi column run back to back on the stream and the host waits ONCE per inner
+// iteration, for the column of H (src/orthogonalize.jl:69-76).
+
+// norm(x) over the partition when the plain sum of squares left the safe range (the kernels flagged it with NaN): gm_part_norm's scaled
+// recomputation with the exchanges on the device
+template <typename T> static int gm_link_norm_slow(mik_gmres *g, const T *x, T *nrm)
+{
+    mik_ctx *ctx = g->ctx;
+    mik_plink *pl = g->part.link;
+    const int64_t n = g->n, nseg = mik_nseg<T>(n);
+    const int P = plink_nranks(pl), rank = plink_rank(pl);
+    T *scr = (T *)((unsigned char *)ctx->coef + mik_ctx::COEF_SAFE_SLOT);          // P scalars (P <= 64: the mailbox's limit)
+    if ((size_t)(P + 2) * sizeof(T) > mik_ctx::COEF_SAFE_SLOT) return mik_fail(ctx, MIK_ERR_NOTIMPL, "gmres (row-partitioned): scaled norm with %d ranks", P);
+    const int grid = (int)std::min<int64_t>((std::max<int64_t>(n, 1) + MIK_BLOCK - 1) / MIK_BLOCK, 1024);
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(std::max<int64_t>(nseg, grid), 1)));
+    hipLaunchKernelGGL((k_amax<T>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, x, (T *)ctx->partials);
+    MIK_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL((k_amax<T>), dim3(1), dim3(MIK_BLOCK), 0, ctx->stream, (int64_t)grid, (const T *)ctx->partials, scr + rank);
+    MIK_LAUNCH_CHECK(ctx);
+    MIK_TRY(plink_gather(pl, scr));
+    std::vector<T> v((size_t)P, T(0));
+    MIK_HIP(ctx, hipMemcpyAsync(v.data(), scr, sizeof(T) * (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
+    MIK_HIP(ctx, mik_wait(ctx));
+    MIK_TRY(plink_check(pl, "gmres (row-partitioned)"));
+    T amax = T(0);
+    for (T a : v) amax = (a > amax || a != a) ? a : amax;
+    if (amax == T(0) || amax != amax || amax > std::numeric_limits<T>::max()) { *nrm = amax; return MIK_OK; }
+    int e;
+    (void)std::frexp((double)amax, &e);
+    e = std::max(-NrmRange<T>::EC, std::min(NrmRange<T>::EC, e));
+    const T sc = (T)std::ldexp(1.0, -e), sinv = (T)std::ldexp(1.0, e);
+    OpScaledSq<T> op{x, sc};
+    MIK_TRY((launch_map<T>(ctx, n, op, mik_aligned16(x), (T *)ctx->partials, nullptr)));
+    MIK_TRY(plink_fin_sum(pl, ctx->partials, nseg, scr, 0));
+    T t2;
+    MIK_HIP(ctx, hipMemcpyAsync(&t2, scr, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    MIK_HIP(ctx, mik_wait(ctx));
+    MIK_TRY(plink_check(pl, "gmres (row-partitioned)"));
+    *nrm = (T)std::sqrt(t2) * sinv;
+    return MIK_OK;
+}
+
+template <typename T>
+static int orthogonalize_link(mik_gmres *g, int k, const T *V, int64_t ldv, T *w, T *h, T *nrm_out, int method)
+{
+    mik_ctx *ctx = g->ctx;
+    mik_plink *pl = g->part.link;
+    const int64_t n = g->n;
+    if ((size_t)(2 * k + 4) * sizeof(T) > mik_ctx::COEF_SAFE_SLOT) return mik_fail(ctx, MIK_ERR_NOTIMPL, "orthogonalize: k = %d too large", k);
+    const int64_t nseg = mik_nseg<T>(n);
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(nseg, 1) * (size_t)std::max(k, 1)));
+    T *hd = (T *)ctx->coef;                    // [0, k) h, [k] nrm, [k + 1] 1 / nrm, [k + 2, 2k + 2) DGKS correction
+    T *part = (T *)ctx->partials;
+    const bool vecw = mik_aligned16(w);
+    const bool vec = vecw && mik_aligned16(V) && (ldv % VT<T>::W == 0);
+    OpDot<T> dn{w, w};
+    std::vector<T> out((size_t)k + 2);
+    auto download = [&](int slot, T *dst, int cnt) -> int {      // the one host wait of the column (DGKS: of the round)
+        MIK_TRY(coef_download<T>(ctx, slot, dst, cnt));
+        return plink_check(pl, "gmres (row-partitioned)");
+    };
+    T nrm;
+    if (method == MIK_MGS) {                                             // :69-76
+        if (k > 0) {
+            OpDot<T> d0{V, w};
+            MIK_TRY((launch_map<T>(ctx, n, d0, vec, part, nullptr)));
+            MIK_TRY(plink_fin_sum(pl, part, nseg, hd, 0));
+            for (int i = 0; i + 1 < k; ++i) {
+                OpMgsPass<T, false> op{w, V + (int64_t)i * ldv, V + (int64_t)(i + 1) * ldv, coef_ptr<T>(hd + i), mik_mgs_pass_hints(ctx, n, sizeof(T))};
+                MIK_TRY((launch_map<T>(ctx, n, op, vec, part, nullptr)));
+                MIK_TRY(plink_fin_sum(pl, part, nseg, hd + i + 1, 0));
+            }
+            OpMgsPass<T, true> last{w, V + (int64_t)(k - 1) * ldv, nullptr, coef_ptr<T>(hd + k - 1), mik_mgs_pass_hints(ctx, n, sizeof(T))};
+            MIK_TRY((launch_map<T>(ctx, n, last, vec, part, nullptr)));
+        } else {
+            MIK_TRY((launch_map<T>(ctx, n, dn, vecw, part, nullptr)));
+        }
+        MIK_TRY(plink_fin_sum(pl, part, nseg, hd + k, 1));               // nrm, 1 / nrm (NaN, 1 outside the safe range)
+        OpScal<T> sc{w, coef_ptr<T>(hd + k + 1)};                        // w .*= inv(nrm)  :76
+        MIK_TRY((launch_map<T>(ctx, n, sc, vecw, (T *)nullptr, nullptr)));
+        MIK_TRY(download(0, out.data(), k + 1));
+        for (int j = 0; j < k; ++j) h[j] = out[(size_t)j];
+        nrm = out[(size_t)k];
+        if (nrm != nrm) {                                                // w was left unscaled
+            MIK_TRY(gm_link_norm_slow<T>(g, w, &nrm));
+            OpScal<T> sc2{w, coef_val<T>(T(1) / nrm)};
+            MIK_TRY((launch_map<T>(ctx, n, sc2, vecw, (T *)nullptr, nullptr)));
+        }
+        *nrm_out = nrm;
+        return MIK_OK;
+    }
+    // :15-17 / :43-45: h = V' w (batched dot, summed over the ranks in one exchange), w -= V h, norm
+    auto project = [&](int slot) -> int {
+        if (k == 0) return MIK_OK;
+        MIK_TRY(multidot<T>(ctx, n, k, V, ldv, w, hd + slot));
+        MIK_TRY(plink_sum_vec(pl, hd + slot, k));
+        return gemv_n_dev<T>(ctx, n, k, V, ldv, hd + slot, T(-1), w);
+    };
+    auto norm_w = [&](T *dst) -> int {           // norm(w) over the partition into hd[k] (and the host), scaled pass if flagged
+        MIK_TRY((launch_map<T>(ctx, n, dn, vecw, part, nullptr)));
+        return plink_fin_sum(pl, part, nseg, hd + k, 1);
+    };
+    MIK_TRY(project(0));
+    MIK_TRY(norm_w(&nrm));
+    if (method == MIK_CGS) {
+        OpScal<T> sc{w, coef_ptr<T>(hd + k + 1)};                        // :48
+        MIK_TRY((launch_map<T>(ctx, n, sc, vecw, (T *)nullptr, nullptr)));
+        MIK_TRY(download(0, out.data(), k + 1));
+        for (int j = 0; j < k; ++j) h[j] = out[(size_t)j];
+        nrm = out[(size_t)k];
+        if (nrm != nrm) {
+            MIK_TRY(gm_link_norm_slow<T>(g, w, &nrm));
+            OpScal<T> sc2{w, coef_val<T>(T(1) / nrm)};
+            MIK_TRY((launch_map<T>(ctx, n, sc2, vecw, (T *)nullptr, nullptr)));
+        }
+        *nrm_out = nrm;
+        return MIK_OK;
+    }
+    // DGKS (:19-36): the loop condition lives on the host, one wait per round
+    MIK_TRY(download(0, out.data(), k + 1));
+    for (int j = 0; j < k; ++j) h[j] = out[(size_t)j];
+    nrm = out[(size_t)k];
+    if (nrm != nrm) MIK_TRY(gm_link_norm_slow<T>(g, w, &nrm));
+    std::vector<T> corr((size_t)std::max(k, 1));
+    const T eta = T(1) / std::sqrt(T(2));                                // :20
+    T projection_size = dgks_small_norm<T>(h, k);                        // :22
+    while (nrm < eta * projection_size) {                                // :26
+        MIK_TRY(project(k + 2));                                         // :27, :30
+        MIK_TRY(norm_w(&nrm));                                           // :32
+        MIK_TRY(download(k + 2, corr.data(), k));
+        MIK_TRY(download(k, &nrm, 1));
+        if (nrm != nrm) MIK_TRY(gm_link_norm_slow<T>(g, w, &nrm));
+        projection_size = dgks_small_norm<T>(corr.data(), k);            // :28
+        for (int j = 0; j < k; ++j) h[j] = h[j] + corr[(size_t)j];       // :31
+    }
+    OpScal<T> sc{w, coef_val<T>(T(1) / nrm)};                            // :36
+    MIK_TRY((launch_map<T>(ctx, n, sc, vecw, (T *)nullptr, nullptr)));
+    *nrm_out = nrm;
+    return MIK_OK;
+}
+
 template <typename T> static std::vector<T> &gm_H(mik_gmres *g);
 template <> std::vector<double> &gm_H<double>(mik_gmres *g) { return g->H64; }
 template <> std::vector<float> &gm_H<float>(mik_gmres *g) { return g->H32; }
@@ -1335,6 +1485,21 @@ template <typename T> static int gmres_init_residual(mik_gmres *g, int initially
         MIK_TRY((launch_map<T>(ctx, n, dn, mik_aligned16(V0), (T *)ctx->partials, nullptr)));
     }
     T *hd = (T *)ctx->coef;
+    if (g->dist && g->part.link) {                                        // device-driven: norm over the ranks and 1 / norm inside the finaliser
+        MIK_TRY(plink_fin_sum(g->part.link, ctx->partials, nseg, hd, 1)); // :252
+        OpScal<T> scd{V0, coef_ptr<T>(hd + 1)};                           // :253
+        MIK_TRY((launch_map<T>(ctx, n, scd, mik_aligned16(V0), (T *)nullptr, nullptr)));
+        T out[2];
+        MIK_TRY(coef_download<T>(ctx, 0, out, 2));
+        MIK_TRY(plink_check(g->part.link, "gmres (row-partitioned)"));
+        *beta_out = out[0];
+        if (out[0] != out[0]) {                                           // badly scaled residual: scaled norm across the ranks, then :253
+            MIK_TRY(gm_link_norm_slow<T>(g, V0, beta_out));
+            OpScal<T> sc2{V0, coef_val<T>(T(1) / *beta_out)};
+            MIK_TRY((launch_map<T>(ctx, n, sc2, mik_aligned16(V0), (T *)nullptr, nullptr)));
+        }
+        return MIK_OK;
+    }
     if (g->dist) {
         T ss;
         MIK_TRY(finalize_store<T>(ctx, nseg, 1, hd));
@@ -1398,7 +1563,13 @@ static int gmres_create_common(mik_ctx *ctx, const mik_csr *A, void *x, const vo
         if (part->n_ext != A->n_cols || part->n_ext < A->n_rows) return mik_fail(ctx, MIK_ERR_MISMATCH, "mik_gmres_create_partitioned: A_loc must be n_loc x n_ext");
         if ((part->n_ext && !part->x_ext) || part->n_send < 0 || (part->n_send && (!part->send_idx || !part->send_buf)))
             return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create_partitioned: NULL halo buffers");
-        if (part->nranks > 1 && (!part->reduce || !part->halo)) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create_partitioned: callbacks required for nranks > 1");
+        if (part->link) {
+            if (!plink_ready(part->link)) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create_partitioned: the link is not connected (mik_plink_connect, mik_comm_mailbox_connect)");
+            if (plink_ctx(part->link) != ctx) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create_partitioned: the link's communicator lives on another context (stream)");
+            if (plink_rank(part->link) != part->rank || plink_nranks(part->link) != part->nranks)
+                return mik_fail(ctx, MIK_ERR_MISMATCH, "mik_gmres_create_partitioned: the link belongs to rank %d of %d", plink_rank(part->link), plink_nranks(part->link));
+        } else if (part->nranks > 1 && (!part->reduce || !part->halo))
+            return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create_partitioned: nranks > 1 needs the callbacks or a connected link");
     }
     if (restart < 1) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create: restart must be >= 1");
     if (orth_method != MIK_MGS && orth_method != MIK_CGS && orth_method != MIK_DGKS) return mik_fail(ctx, MIK_ERR_INVALID, "mik_gmres_create: bad orth_method");
@@ -1720,7 +1891,8 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
             }
         } else {
             MIK_TRY(gm_expand<T>(g, vk, vk1));
-            if (g->dist) MIK_TRY(orthogonalize_part<T>(g, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));
+            if (g->dist && g->part.link) MIK_TRY(orthogonalize_link<T>(g, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));
+            else if (g->dist) MIK_TRY(orthogonalize_part<T>(g, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));
             else MIK_TRY(orthogonalize_impl<T>(ctx, g->n, k, V, g->ldv, vk1, &Hat(0, k - 1), &nrm, g->method));
         }
     }
@@ -2035,6 +2207,7 @@ extern "C" int mik_cgd_destroy(mik_cgd *it)
     mik_cgd_group_forget(it);
     mik_cg &bs = it->base;
     if (bs.ctx) (void)hipStreamSynchronize(bs.ctx->stream);
+    if (it->link) { (void)mik_plink_destroy(it->link); it->link = nullptr; }
     if (bs.dev) (void)hipFree(bs.dev);
     if (bs.hist) (void)hipFree(bs.hist);
     if (bs.fin) (void)hipFree(bs.fin);

@@ -541,28 +541,52 @@ class NativeComm:
         self.L.mik_comm_mailbox_info(self.handle, C.byref(a), C.byref(b))
         return bool(a.value), bool(b.value)
 
-    def connect_ghosts(self, engine):
-        """transport "mailbox": every rank exports the allocation that holds its u_ext, every sender learns where its segments land
-        (mik_cgd_connect_ghosts).  Collective; after mik_cgd_set_halo_plan + mik_cgd_set_comm."""
-        plan, L, ctx = engine.plan, self.L, engine.ctx
-        hbuf, off = C.create_string_buffer(64), C.c_int64()
-        self.pkg._lib.check(L.mik_mem_export(ctx.handle, _vp(engine.u_ext.data_ptr()), hbuf, C.byref(off)), "mik_mem_export", ctx.handle)
-        info = self.boot.all_gather_objects((bytes(hbuf.raw), int(off.value), int(plan.n_loc), [tuple(int(v) for v in sg) for sg in plan.recv]))
-        handles = b"".join(i[0] for i in info)
-        offsets = np.array([i[1] for i in info], np.int64)
-        dst = []
-        taken = {}
+    def _landing_targets(self, plan, info):
+        """per SEND segment of `plan`: where it lands in the receiver's ghost region (the offset of the matching receive segment there).
+        info[q] = (..., recv segments of rank q)"""
+        dst, taken = [], {}
         for peer, _off, cnt in plan.send:
-            cands = [sg for sg in info[peer][3] if sg[0] == self.rank]
+            cands = [sg for sg in info[peer][-1] if sg[0] == self.rank]
             k = taken.get(peer, 0)
             taken[peer] = k + 1
             if k >= len(cands) or cands[k][2] != cnt:
                 raise RuntimeError(f"halo plans disagree: rank {self.rank} sends {cnt} entries to rank {peer}, which expects {cands}")
-            dst.append(info[peer][2] + cands[k][1])
-        dst = np.array(dst if dst else [0], np.int64)
-        self.pkg._lib.check(L.mik_cgd_connect_ghosts(engine.handle, handles, offsets.ctypes.data_as(C.POINTER(C.c_int64)),
+            dst.append(cands[k][1])
+        return np.array(dst if dst else [0], np.int64)
+
+    def connect_ghosts(self, engine):
+        """transport "mailbox": every rank allocates the landing buffer of its halo and exports it (mik_cgd_ghost_export), every sender learns
+        where its segments land (mik_cgd_connect_ghosts).  Collective; after mik_cgd_set_halo_plan + mik_cgd_set_comm."""
+        plan, L, ctx = engine.plan, self.L, engine.ctx
+        hbuf = C.create_string_buffer(64)
+        self.pkg._lib.check(L.mik_cgd_ghost_export(engine.handle, hbuf), "mik_cgd_ghost_export", ctx.handle)
+        info = self.boot.all_gather_objects((bytes(hbuf.raw), int(plan.n_ghost), [tuple(int(v) for v in sg) for sg in plan.recv]))
+        handles = b"".join(i[0] for i in info)
+        counts = np.array([i[1] for i in info], np.int64)
+        dst = self._landing_targets(plan, info)
+        self.pkg._lib.check(L.mik_cgd_connect_ghosts(engine.handle, handles, counts.ctypes.data_as(C.POINTER(C.c_int64)),
                                                      dst.ctypes.data_as(C.POINTER(C.c_int64))), "mik_cgd_connect_ghosts", ctx.handle)
         self.boot.barrier()
+
+    def make_link(self, plan: HaloPlan, dtype):
+        """A connected ``mik_plink`` for `plan` on this communicator (collective): what ``mik_partition.link`` of a row-partitioned GMRES
+        iterable takes -- halo and rank-ordered sums then run on the device, without host callbacks."""
+        L, ctx = self.L, self.ctx
+        (rp, ro, rc), (sp, so, sc) = _plan_arrays(plan)
+        ip, lp = C.POINTER(C.c_int), C.POINTER(C.c_int64)
+        h = _vp()
+        self.pkg._lib.check(L.mik_plink_create(self.handle, self.pkg._lib.MIK_F64 if np.dtype(dtype) == np.float64 else self.pkg._lib.MIK_F32, int(plan.n_ghost),
+                                               rp.size, rp.ctypes.data_as(ip), ro.ctypes.data_as(lp), rc.ctypes.data_as(lp),
+                                               sp.size, sp.ctypes.data_as(ip), so.ctypes.data_as(lp), sc.ctypes.data_as(lp), C.byref(h)), "mik_plink_create", ctx.handle)
+        hbuf = C.create_string_buffer(64)
+        self.pkg._lib.check(L.mik_plink_export(h, hbuf), "mik_plink_export", ctx.handle)
+        info = self.boot.all_gather_objects((bytes(hbuf.raw), int(plan.n_ghost), [tuple(int(v) for v in sg) for sg in plan.recv]))
+        handles = b"".join(i[0] for i in info)
+        counts = np.array([i[1] for i in info], np.int64)
+        dst = self._landing_targets(plan, info)
+        self.pkg._lib.check(L.mik_plink_connect(h, handles, counts.ctypes.data_as(lp), dst.ctypes.data_as(lp)), "mik_plink_connect", ctx.handle)
+        self.boot.barrier()
+        return h
 
     def close(self):
         if getattr(self, "handle", None):
@@ -707,7 +731,11 @@ class DistGMRESIterable:
     callbacks and go through ``comm``.  ``iterate`` follows src/gmres.jl:57-106 on every rank identically."""
 
     def __init__(self, pkg, comm, ptr, local_idx, val, plan: HaloPlan, b_loc, x_loc=None, *, abstol=0.0, reltol=None, restart=20,
-                 maxiter=None, orth_meth=None, pl_diag=None, pr_diag=None, device=0, n_global=None):
+                 maxiter=None, orth_meth=None, pl_diag=None, pr_diag=None, device=0, n_global=None, native=None):
+        """``native``: None -- the exchanges are host callbacks over ``comm`` (any communicator of this module); "mailbox" -- a ``mik_comm``
+        without RCCL is created on this iterable's context, its mailboxes and a ``mik_plink`` for `plan` are connected over ``comm`` (which then
+        only bootstraps, as in NativeComm), and the library couples the ranks on the device: no callback, no host round trip inside an
+        Arnoldi column."""
         import torch
         self.pkg, self.comm, self.plan, self.torch = pkg, comm, plan, torch
         L = pkg.lib()
@@ -758,8 +786,12 @@ class DistGMRESIterable:
                 return 1
 
         self._halo_cb, self._reduce_cb = pkg._lib.HALO_FN(_halo), pkg._lib.REDUCE_FN(_reduce)   # keep alive
+        self.ncomm, self.link = None, None
+        if native is not None:
+            self.ncomm = NativeComm(pkg, self.ctx, comm, transport=native)
+            self.link = self.ncomm.make_link(plan, dtype)
         self.part = pkg._lib.MikPartition(plan.rank, plan.nranks, n_ext, self.x_ext.data_ptr(), self.send_idx.data_ptr(), plan.n_send,
-                                          self.send_buf.data_ptr(), self._halo_cb, self._reduce_cb, None)
+                                          self.send_buf.data_ptr(), self._halo_cb, self._reduce_cb, None, self.link)
         h = _vp()
         with torch.cuda.stream(self.stream):
             self._check(L.mik_gmres_create_partitioned(
@@ -810,10 +842,27 @@ class DistGMRESIterable:
     def solution(self) -> np.ndarray:
         return self.x.to_numpy()
 
+    def iterate_many(self, iteration: int, max_steps: int) -> np.ndarray:
+        """Up to max_steps iterate() calls inside the library (mik_gmres_iterate_many): the loop of gmres! without a trip through the host
+        language per inner iteration."""
+        hist = np.empty(max(int(max_steps), 1), np.float64)
+        steps = C.c_int64()
+        with self.torch.cuda.stream(self.stream):
+            self._check(self.L.mik_gmres_iterate_many(self.handle, int(iteration), int(max_steps), hist.ctypes.data_as(C.POINTER(C.c_double)), C.byref(steps)),
+                        "mik_gmres_iterate_many")
+        self._refresh()
+        return hist[:steps.value].copy()
+
     def close(self):
         if getattr(self, "handle", None):
             self.L.mik_gmres_destroy(self.handle)
             self.handle = None
+        if getattr(self, "link", None):
+            self.L.mik_plink_destroy(self.link)
+            self.link = None
+        if getattr(self, "ncomm", None):
+            self.ncomm.close()
+            self.ncomm = None
 
     def __del__(self):
         try:

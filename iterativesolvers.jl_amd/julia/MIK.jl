@@ -611,7 +611,8 @@ end
 # ------------------------------------------------------------------------------------------------
 # gmres! over a row partition (one process per GPU): include/mik.h `mik_partition`
 # ------------------------------------------------------------------------------------------------
-# The handle calls back for the two couplings between ranks; everything else is the iterable above.
+# The handle calls back for the two couplings between ranks -- or, with `link` set, exchanges by itself on the device (Transport 3: no
+# host round trip inside an Arnoldi column); everything else is the iterable above.
 #   halo(user)::Cint                      -- send_buf is packed (stream-ordered); fill x_ext[n_loc+1:n_ext]
 #   reduce(user, dtype, count, values)    -- partial sums in, ((p0 + p1) + p2) + ... in rank order out
 struct Partition                     # same field order and types as the C struct
@@ -625,6 +626,7 @@ struct Partition                     # same field order and types as the C struc
     halo::Ptr{Cvoid}                 # @cfunction(halo_cb, Cint, (Ptr{Cvoid},))
     reduce::Ptr{Cvoid}               # @cfunction(reduce_cb, Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}))
     user::Ptr{Cvoid}
+    link::Ptr{Cvoid}                 # C_NULL: the callbacks couple the ranks; a connected PartitionLink's handle: the library does, on the device
 end
 
 """
@@ -687,11 +689,43 @@ function connect_mailboxes!(c::Comm, handles::Vector{UInt8})
     GC.@preserve handles check(ccall((:mik_comm_mailbox_connect, libmik), Cint, (Ptr{Cvoid}, Ptr{UInt8}), c.handle, handles), "mik_comm_mailbox_connect", c.ctx.handle)
     c
 end
-"(handle, byte offset) of the allocation that holds a device vector (mik_mem_export): what a peer maps to push its halo into it"
-function export_memory(v::HipVector)
-    h = zeros(UInt8, 64); off = Ref{Int64}(0)
-    check(ccall((:mik_mem_export, libmik), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{UInt8}, Ref{Int64}), v.ctx.handle, v.ptr, h, off), "mik_mem_export", v.ctx.handle)
-    (h, off[])
+"""
+The device-driven links of one row partition on a communicator whose mailboxes are connected (include/mik.h `mik_plink`): halo plan,
+landing buffer, peer mappings.  `recv` / `send`: (peer, offset, count) segments of the ghost region / of the packed send buffer.
+`allgather(x)` is whatever the host has for small host objects (MPI.Allgather of the 64-byte handle, the ghost count and the receive
+segments of every rank); `PartitionLink(...)` is collective.  Its `handle` goes into `Partition.link`.
+"""
+mutable struct PartitionLink
+    handle::Ptr{Cvoid}
+    comm::Comm
+end
+function PartitionLink(comm::Comm, ::Type{T}, n_ghost::Integer, recv::Vector{NTuple{3, Int}}, send::Vector{NTuple{3, Int}}, rank::Integer, allgather) where {T<:MikFloat}
+    rp = Cint[p for (p, _, _) in recv]; ro = Int64[o for (_, o, _) in recv]; rc = Int64[k for (_, _, k) in recv]
+    sp = Cint[p for (p, _, _) in send]; so = Int64[o for (_, o, _) in send]; sc = Int64[k for (_, _, k) in send]
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:mik_plink_create, libmik), Cint, (Ptr{Cvoid}, Cint, Int64, Cint, Ptr{Cint}, Ptr{Int64}, Ptr{Int64}, Cint, Ptr{Cint}, Ptr{Int64}, Ptr{Int64}, Ref{Ptr{Cvoid}}),
+                comm.handle, dtype_code(T), n_ghost, length(rp), rp, ro, rc, length(sp), sp, so, sc, h), "mik_plink_create", comm.ctx.handle)
+    mine = zeros(UInt8, 64)
+    check(ccall((:mik_plink_export, libmik), Cint, (Ptr{Cvoid}, Ptr{UInt8}), h[], mine), "mik_plink_export", comm.ctx.handle)
+    info = allgather((mine, Int64(n_ghost), recv))                       # per rank: (handle, ghost count, receive segments)
+    handles = reduce(vcat, [i[1] for i in info]); counts = Int64[i[2] for i in info]
+    dst = landing_targets(send, info, rank)
+    GC.@preserve handles counts dst check(ccall((:mik_plink_connect, libmik), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Ptr{Int64}, Ptr{Int64}), h[], handles, counts, dst),
+                                          "mik_plink_connect", comm.ctx.handle)
+    l = PartitionLink(h[], comm)
+    finalizer(x -> alive(x.comm.ctx) && ccall((:mik_plink_destroy, libmik), Cint, (Ptr{Cvoid},), x.handle), l)
+    l
+end
+"per SEND segment: the offset of the matching receive segment in the receiver's ghost region (info[q][3] = rank q's receive segments)"
+function landing_targets(send, info, rank)
+    taken = Dict{Int, Int}(); dst = Int64[]
+    for (peer, _, cnt) in send
+        cands = [sg for sg in info[peer + 1][3] if sg[1] == rank]
+        k = get(taken, peer, 0) + 1; taken[peer] = k
+        (k <= length(cands) && cands[k][3] == cnt) || throw(MikError(Cint(3), "landing_targets", "halo plans of ranks $rank and $peer disagree"))
+        push!(dst, cands[k][2])
+    end
+    isempty(dst) ? Int64[0] : dst
 end
 
 "Row-partitioned CGIterable: this rank's block, the halo plan and the communicator; `iterate_many!` is ONE ccall per batch."
@@ -728,11 +762,13 @@ function dist_cg_iterator!(x::HipVector{T}, A_loc::HipCSR{T}, b::HipVector{T}, c
                 h[], length(rp), rp, ro, rc, length(sp), sp, so, sc), "mik_cgd_set_halo_plan", ctx.handle)
     check(ccall((:mik_cgd_set_comm, libmik), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h[], comm.handle), "mik_cgd_set_comm", ctx.handle)
     if ghosts !== nothing
-        # transport 3, halo pushed into peer-mapped ghost regions: ghosts = (handles of every rank's u_ext allocation (64 bytes each, rank
-        # order), their byte offsets, and per SEND segment the element of the receiver's u_ext at which it lands) -- the host gathers them
-        # from `export_memory(u_ext)` / the receivers' plans; `u_ext` must then be the vector whose handle this rank published (keyword)
-        gh, goff, gdst = ghosts
-        GC.@preserve gh goff gdst check(ccall((:mik_cgd_connect_ghosts, libmik), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Ptr{Int64}, Ptr{Int64}), h[], gh, goff, gdst),
+        # transport 3, halo pushed into the neighbours' landing buffers: ghosts = allgather (as for PartitionLink).  Every rank exports the
+        # landing buffer the library allocated for its plan, the host gathers (handle, ghost count, receive segments) of every rank
+        mine = zeros(UInt8, 64)
+        check(ccall((:mik_cgd_ghost_export, libmik), Cint, (Ptr{Cvoid}, Ptr{UInt8}), h[], mine), "mik_cgd_ghost_export", ctx.handle)
+        info = ghosts((mine, Int64(n_ext - n_loc), recv))
+        gh = reduce(vcat, [i[1] for i in info]); gcnt = Int64[i[2] for i in info]; gdst = landing_targets(send, info, rank)
+        GC.@preserve gh gcnt gdst check(ccall((:mik_cgd_connect_ghosts, libmik), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Ptr{Int64}, Ptr{Int64}), h[], gh, gcnt, gdst),
                                         "mik_cgd_connect_ghosts", ctx.handle)
     end
     res = Ref{Cdouble}(); tol = Ref{Cdouble}()

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(pkg):
 def test_ctypes_binding_covers_header(pkg):
     assert sorted(pkg._lib.SIGNATURES) == declared_symbols()
     L = pkg.lib()
-    assert L.mik_abi_version() == 4
+    assert L.mik_abi_version() == 5
 
 
 def test_reduce_shape_is_exported_constant(pkg):

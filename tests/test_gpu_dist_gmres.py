@@ -207,3 +207,86 @@ def test_process_ranks_match_partitioned_oracle(pkg, orc, ctx, tmp_path, world, 
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"hist{r}.npy"), ho["resnorm"])
     assert np.array_equal(np.concatenate([np.load(tmp_path / f"x{r}.npy") for r in range(world)]), xo)
+
+
+# ------------------------------------------------------------------------------------------------
+# device-driven coupling (mik_partition.link, include/mik.h "Transport 3"): no host callback, no host round trip inside an Arnoldi column
+# ------------------------------------------------------------------------------------------------
+def _link_worker(rank, world, port, out_dir, orth, scale, dtype_name, restart, batch):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), MIK_MAILBOX_TIMEOUT_MS="20000")
+    import torch
+    import torch.distributed as td
+    import scipy.sparse as sp
+    import __graft_entry__ as graft
+    from importlib import import_module
+    pkg = graft.load_package()
+    dist = import_module(pkg.__name__ + ".dist")
+    torch.cuda.set_device(0)
+    td.init_process_group("gloo", rank=rank, world_size=world)          # carries the IPC handles, nothing else
+    comm = dist.TorchComm()
+    dtype = np.dtype(dtype_name)
+    n, colptr, rowval, nzval, b = pkg.fixtures.advection_dominated(11, 700.0)
+    S = sp.csc_matrix(((nzval * scale).astype(dtype), rowval - 1, colptr - 1), shape=(n, n)).tocsr()
+    b = (b * scale).astype(dtype)
+    offsets = dist.partition_rows(n, world)
+    r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
+    ptr, idx, val = csr_block(S, r0, r1)
+    local_idx, plan = dist.localize_block(ptr, idx, offsets, rank)
+    dist.complete_plan(plan, offsets, comm.all_gather_objects(plan.ghost_gids))
+    M = {"mgs": pkg.ModifiedGramSchmidt(), "cgs": pkg.ClassicalGramSchmidt(), "dgks": pkg.DGKS()}[orth]
+    calls = {"halo": 0, "reduce": 0}
+    it = dist.DistGMRESIterable(pkg, comm, ptr, local_idx, val, plan, b[r0:r1], n_global=n, restart=restart, orth_meth=M, native="mailbox")
+    orig_halo, orig_reduce = it.links.halo, it.links.reduce
+    it.links.halo = lambda: (calls.__setitem__("halo", calls["halo"] + 1), orig_halo())[1]
+    it.links.reduce = lambda v: (calls.__setitem__("reduce", calls["reduce"] + 1), orig_reduce(v))[1]
+    if batch:
+        hist, k = [], 0
+        while True:
+            h = it.iterate_many(k, 1 if k < 2 else batch)
+            if h.size == 0:
+                break
+            hist.extend(h.tolist())
+            k += h.size
+        hist = np.asarray(hist)
+    else:
+        hist = it.solve()
+    assert calls == {"halo": 0, "reduce": 0}, calls                     # the library never came back to the host for an exchange
+    np.save(os.path.join(out_dir, f"hist{rank}.npy"), hist)
+    np.save(os.path.join(out_dir, f"x{rank}.npy"), it.solution())
+    np.save(os.path.join(out_dir, f"off{rank}.npy"), offsets)
+    np.save(os.path.join(out_dir, f"mv{rank}.npy"), np.array([it.mv_products, int(it.converged())]))
+    comm.barrier()
+    it.close()
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,orth,scale,dtype_name,restart,batch", [
+    (2, "mgs", 1.0, "float64", 10, 0), (3, "mgs", 1.0, "float64", 10, 7), (2, "cgs", 1.0, "float64", 10, 0), (3, "dgks", 1.0, "float64", 8, 0),
+    (2, "mgs", 1.0, "float32", 10, 5), (2, "cgs", 1.0, "float32", 12, 0), (2, "dgks", 1.0, "float32", 10, 0),
+    (2, "mgs", 1e-160, "float64", 10, 0), (3, "cgs", 1e-160, "float64", 10, 4), (2, "dgks", 1e-160, "float64", 10, 0), (2, "mgs", 1e-22, "float32", 10, 0),
+    (1, "mgs", 1.0, "float64", 10, 0)])
+def test_device_driven_partitioned_gmres_ranks_in_processes_on_one_gpu(pkg, orc, ctx, tmp_path, world, orth, scale, dtype_name, restart, batch):
+    """mik_gmres_create_partitioned with mik_partition.link -- halo pushed into the neighbours' landing buffers, every
+    projection and norm summed over the ranks INSIDE the kernel that finalises it (mailbox slots, rank order), coefficients read from device
+    memory by the next sweep: no host callback at all (counted), one host wait per inner iteration.  2 and 3 ranks as separate processes
+    on the box's one GPU over HIP IPC; history, solution, mv_products and isconverged bit-exact against the partition-aware oracle --
+    ModifiedGramSchmidt, ClassicalGramSchmidt, DGKS; fp64 and fp32; systems scaled by 1e-160 (fp32: 1e-22), which send every norm through the
+    scaled pass across the ranks; per-step calls and mik_gmres_iterate_many batches."""
+    import torch.multiprocessing as mp
+    port = 29100 + (os.getpid() * 3 + world * 17 + len(orth) * 5 + restart + batch + (40 if scale != 1.0 else 0) + (80 if dtype_name == "float32" else 0)) % 700
+    mp.spawn(_link_worker, args=(world, port, str(tmp_path), orth, scale, dtype_name, restart, batch), nprocs=world, join=True)
+    dtype = np.dtype(dtype_name)
+    A64, b64 = orc.advdiff(11, 700.0)
+    A = orc.CSC(A64.n, A64.colptr, A64.rowval, (A64.nzval * scale).astype(dtype), A64.index_base)
+    b = (pkg.fixtures.advection_dominated(11, 700.0)[4] * scale).astype(dtype)
+    offsets = np.load(tmp_path / "off0.npy")
+    orc.set_partition(offsets)
+    try:
+        xo, ho = orc.gmres(A, b, restart=restart, orth_meth=orth, mode="tree", shape=ctx.reduce_shape(dtype))
+    finally:
+        orc.set_partition(None)
+    assert ho["iters"] > restart                                           # at least one restart cycle (update_solution!, init!)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"hist{r}.npy"), ho["resnorm"]), r
+        assert tuple(np.load(tmp_path / f"mv{r}.npy")) == (ho["mvps"], int(ho["isconverged"]))
+    assert np.array_equal(np.concatenate([np.load(tmp_path / f"x{r}.npy") for r in range(world)]), xo)

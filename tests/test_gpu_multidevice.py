@@ -123,7 +123,7 @@ def test_cg_halos_larger_than_l2_across_devices(pkg, orc, ctx, tmp_path, transpo
 
 
 def _gmres_worker(rank, world, port, out_dir, orth, scale, backend):
-    pkg, d, td = _init(rank, world, port, backend)
+    pkg, d, td = _init(rank, world, port, "gloo" if backend == "link" else backend)
     import scipy.sparse as sp
     comm = d.TorchComm()
     n, colptr, rowval, nzval, b = pkg.fixtures.advection_dominated(12, 1000.0)
@@ -135,7 +135,8 @@ def _gmres_worker(rank, world, port, out_dir, orth, scale, backend):
     local_idx, plan = d.localize_block(ptr, idx, offsets, rank)
     d.complete_plan(plan, offsets, comm.all_gather_objects(plan.ghost_gids))
     M = {"mgs": pkg.ModifiedGramSchmidt(), "cgs": pkg.ClassicalGramSchmidt(), "dgks": pkg.DGKS()}[orth]
-    it = d.DistGMRESIterable(pkg, comm, ptr, local_idx, val, plan, (b * scale)[r0:r1], n_global=n, restart=10, orth_meth=M, device=rank)
+    it = d.DistGMRESIterable(pkg, comm, ptr, local_idx, val, plan, (b * scale)[r0:r1], n_global=n, restart=10, orth_meth=M, device=rank,
+                             native="mailbox" if backend == "link" else None)
     hist = it.solve()
     np.save(os.path.join(out_dir, f"hist{rank}.npy"), hist)
     np.save(os.path.join(out_dir, f"x{rank}.npy"), it.solution())
@@ -145,14 +146,16 @@ def _gmres_worker(rank, world, port, out_dir, orth, scale, backend):
     td.destroy_process_group()
 
 
-@pytest.mark.parametrize("backend", ["nccl", "gloo"])
-@pytest.mark.parametrize("orth,scale", [("mgs", 1.0), ("cgs", 1.0), ("dgks", 1.0), ("mgs", 1e-160)])
+@pytest.mark.parametrize("backend", ["link", "nccl", "gloo"])
+@pytest.mark.parametrize("orth,scale", [("mgs", 1.0), ("cgs", 1.0), ("dgks", 1.0), ("mgs", 1e-160), ("cgs", 1e-160)])
 def test_partitioned_gmres_across_devices_matches_partitioned_oracle(pkg, orc, ctx, tmp_path, orth, scale, backend):
-    """mik_gmres_create_partitioned, one rank per device, halo and rank-ordered sums through the host's callbacks (RCCL device
-    collectives, or gloo with host staging): history, solution, bit-exact against the oracle's gmres with the same partition; a
-    system scaled by 1e-160 sends every norm through the scaled pass across the ranks."""
+    """mik_gmres_create_partitioned, one rank per device: "link" = the device-driven coupling (mik_partition.link: halo pushed over xGMI
+    into the neighbours' landing buffers, every projection / norm summed over the ranks inside the finalising kernel through the
+    peer-mapped mailboxes); "nccl" / "gloo" = halo and rank-ordered sums through the host's callbacks (RCCL device collectives, or gloo
+    with host staging).  History and solution bit-exact against the oracle's gmres with the same partition; a system scaled by 1e-160
+    sends every norm through the scaled pass across the ranks."""
     import torch.multiprocessing as mp
-    mp.spawn(_gmres_worker, args=(WORLD, _port(len(orth) + (3 if backend == "nccl" else 0) + (5 if scale != 1.0 else 0)), str(tmp_path), orth, scale, backend),
+    mp.spawn(_gmres_worker, args=(WORLD, _port(len(orth) + {"nccl": 3, "gloo": 0, "link": 7}[backend] + (5 if scale != 1.0 else 0)), str(tmp_path), orth, scale, backend),
              nprocs=WORLD, join=True)
     A, _ = orc.advdiff(12, 1000.0)
     A = orc.CSC(A.n, A.colptr, A.rowval, A.nzval * scale, A.index_base)
