@@ -1,11 +1,17 @@
 /*
  * mik_dev.h -- DEVELOPMENT interface of libmik.so.  Not part of the drop-in boundary (include/mik.h): nothing a host of the
- * reference needs is declared here.  The knobs select kernel variants for A/B timing (scripts/) and for the tests that pin
- * every variant against the oracle (tests/test_gpu_layouts.py, test_gpu_lookahead.py); results never depend on them.
- * Every mik_ctx carries its OWN table (a copy of the defaults when it is created); launches and object creation read only the
- * table of their context.  mik_ctx_set_tuning changes one context; mik_set_tuning is the process-wide convenience of the test
- * suite: it writes the defaults and every live context, and must not race with calls on those contexts.  A host that wants an
- * operator on its plain CSR arrays uses mik_csr_set_layout (include/mik.h), not a knob.
+ * reference needs is declared here.  The knobs pin kernel variants and fall-back paths for the tests that check every one of them
+ * against the oracle (tests/test_gpu_layouts.py, test_gpu_lookahead.py, test_gpu_irregular.py, test_dist.py, ...); results never
+ * depend on them.  Every mik_ctx carries its OWN table (a copy of the defaults when it is created); launches and object creation
+ * read only the table of their context.  mik_ctx_set_tuning changes one context; mik_set_tuning is the process-wide convenience
+ * of the test suite: it writes the defaults and every live context, and must not race with calls on those contexts.  A host that
+ * wants an operator on its plain CSR arrays uses mik_csr_set_layout (include/mik.h), not a knob.
+ *
+ * Round 5: 12 knobs, every one referenced by a test.  Knobs whose two settings had been measured and decided are
+ * gone with the losing variant (operator-stream cache policy, narrow CSR loads, workgroup-map override, long-row threshold, the
+ * hint masks of the vector sweeps and of the Krylov basis, slices per workgroup, hipGraph replay of a GMRES column, DGKS rounds in
+ * the single-launch kernel, sweep direction, hipStreamSynchronize vs event spin as a knob of its own); what remains selects between
+ * code paths that all ship because each is the fall-back of another.
  */
 #include "mik.h"
 #ifndef MIK_DEV_H
@@ -13,35 +19,34 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* key / value table (all default to 0; results never depend on them):
- *   0: 1 = cached (temporal) val/col/y streams in SpMV, 2 = streamed also where the default is cached (the irregular product tile)
- *              1: 1 = narrow loads in the CSR kernel
- *   2: workgroup map: 0 = operator's choice, < 0 identity, 1 = contiguous range per XCD, P >= 8 = strips of P
- *   3: 1 = hipStreamSynchronize instead of the event spin wait    4: long-row threshold (> 0), < 0 = no split
- *   5: 1 = unfused MGS chain, 2 = launch-lean MGS without graphs, 3 = one hipGraph per GMRES column, 4 = single-launch MGS on all XCDs (not the XCD-local form)
- *   7: cache hints of the CG vector kernels
- *   8: 1 = CSR row-block layout only (read at mik_csr_create and at launch)    9: 1 = nothing enqueued ahead of the host (GMRES: the next Arnoldi column; CG: the head of the next step)
- *  10: 1 = scalar results through hipMemcpyAsync + event spin instead of the publish kernel + mailbox spin
- *  11: 1 = no slice-constant values        12: 1 = no per-slice-offset layout
- *  13: bit mask switching the Krylov-basis streaming hints off    14: CSR kernel: 0 = by operator, 1 = register-staged products, 2 = LDS-DMA tile + per-row gather
- *  15: long-row segment length (> 0; read at mik_csr_create)   16: slices per workgroup of the layout-5 kernels (1 / 2 / 4)
- *  17: 1 = layout 5 through flat loads (k_spmv_sdiac)              18: 1 = k_spmv_sdiab without the compiled-in slot class
- *  19: 1 = layout 5 with one row per lane (k_spmv_sdiab instead of k_spmv_sdiab2)
- *  20: 1 = mik_csr_create on the host path only, 2 = device transpose but the host builders of layouts 6 / 1                 21: DGKS rounds inside the single-launch kernel (1..3; read at mik_gmres_create)
- *  22: 1 = PCG with a diagonal Pl as three vector sweeps (c = Pl \\ r and rho apart) instead of two (read at mik_cg_create)
- *  23: 1 = CG updates x in the step's own sweep (read at mik_cg_create)      24: 1 = the halo of a row-partitioned CG step after the whole sweep over u
- *  25: 1 = mik_bicgstab_step / mik_minres_step with separate finaliser launches at every size (the form used beyond 1,024 reduction segments);
- *      2 = no SpMV epilogues (the Lanczos step of MINRES, sigma / rho of BiCGStab(l) as sweeps of their own in the vector shape; no rho kept from the MR sweep)
- *  26: 1 = row-partitioned CG step with the separate alpha launch (k_cgd_alpha) instead of alpha formed inside the update sweep
- *  31: 1 = GMRES without the single-launch Gram-Schmidt kernels (read at mik_gmres_create)
- *  30: 1 = treat the next single-launch Gram-Schmidt column as timed out (exercises the fall-back to the multi-launch chains)
- *  28: jagged slices (layout 1): 1 = never, 2 = whenever the operator has no structured layout (read at mik_csr_create)
- *   6: transports of the row-partitioned CG (bits): 1 = the side stream ordered by events instead of mailbox flags, 2 = the two scalars of a step over
- *      RCCL although a mailbox is connected, 4 = ... through the mailbox even in a world of one, 8 = ... through the one-wave gather launches
- *      (k_mail_gather) instead of inside the finalising kernels
- *  29: x windows in LDS for the product-tile CSR kernel (k_spmv_rowblock XWIN): 1 = never built (read at mik_csr_create), 2 = built but not used at launch
- *  27: direction of the streaming launches of a plain CG step (bit 0 / 1 / 2: the u sweep / the SpMV / the update walk from
- *      the end of the vectors; 8: every launch against the one before it) -- no effect at the default cache hints */
+enum {
+    /* which operator layouts mik_csr_create builds / mik_spmv uses (bits).  1: the CSR arrays only.  2: no slice-constant values (the per-slice-
+     * offset form keeps one value per row and slot: layout 4).  4: no per-slice-offset and no wide slice-constant layout.  8: no jagged slices.
+     * 16: jagged slices whenever the operator has no structured layout.  32: no x windows / row permutation for the product-tile kernel (read at
+     * mik_csr_create).  64: windows built but not used at launch. */
+    MIK_KNOB_LAYOUTS = 0,
+    MIK_KNOB_CSR_KERNEL = 1,     /* CSR kernel: 0 = by operator, 1 = register-staged product tile (k_spmv_rowblock), 2 = LDS-DMA tile + per-row gather (k_spmv_rowgather) */
+    MIK_KNOB_SDIA_KERNEL = 2,    /* slice-constant layouts: 0 = by operator, 1 = flat loads (k_spmv_sdiac: the path of non-finite coefficients / 64-bit offsets),
+                                  * 2 = k_spmv_sdiab slot by slot (operators outside the compiled-in slot classes), 3 = one row per lane (odd n; layout 6: k_spmv_sdiaw) */
+    MIK_KNOB_LONG_SEGMENT = 3,   /* long-row segment length (> 0; read at mik_csr_create): lets a small test matrix exercise cut rows */
+    MIK_KNOB_UPLOAD = 4,         /* 1 = mik_csr_create on the host path only (rows beyond 256 entries, duplicates), 2 = device transpose but the host builders of layouts 6 / 1 */
+    MIK_KNOB_GS = 5,             /* Gram-Schmidt of GMRES: 0 = by size, 1 = unfused multi-launch chain (what n > 2048 segments and row partitions run), 2 = launch-lean chain
+                                  * (every pass finalises the previous reduction itself), 3 = single launch, but DGKS hands back to the host loop after ONE round (read at
+                                  * mik_gmres_create; default 3 rounds), 4 = single launch on all XCDs (not the XCD-local form), 5 = XCD-local form also beyond 512 KB columns */
+    MIK_KNOB_TRANSPORT = 6,      /* row-partitioned CG (bits): 1 = the side stream ordered by events instead of mailbox flags (the path without a mailbox), 2 = the two scalars of a
+                                  * step over RCCL although a mailbox is connected, 4 = ... through the mailbox even in a world of one, 8 = ... through the one-wave gather launches
+                                  * (k_mail_gather) instead of inside the finalising kernels */
+    MIK_KNOB_NO_LOOKAHEAD = 7,   /* 1 = nothing enqueued ahead of the host (GMRES: the next Arnoldi column; CG: the head of the next step) -- what callback operators run */
+    MIK_KNOB_SOLVER_FORM = 8,    /* mik_bicgstab_step / mik_minres_step: 1 = separate finaliser launches at every size (the form beyond 1,024 reduction segments), 2 = no SpMV
+                                  * epilogues (operators whose kernel takes none: sigma / rho / the Lanczos projection as sweeps of their own, vector tree shape) */
+    MIK_KNOB_GS_TIMEOUT = 9,     /* 1 = treat the next single-launch Gram-Schmidt column as timed out (exercises the fall-back to the chains) */
+    MIK_KNOB_CG_STEP = 10,       /* CG step (bits; read at create / set_halo_plan): 1 = x updated in the step's own sweep (the classic step of callback operators), 2 = PCG with a
+                                  * diagonal Pl as three vector sweeps, 4 = the halo of a row-partitioned step after the whole sweep over u (send rows that are not two runs),
+                                  * 8 = row-partitioned step with the separate alpha launch (k_cgd_alpha: the classic step's form) */
+    MIK_KNOB_HOST_WAIT = 11,     /* host-visible scalars (bits): 1 = hipMemcpyAsync + wait instead of the publish kernel + mailbox spin (more scalars than the mailbox holds),
+                                  * 2 = hipStreamSynchronize instead of the event spin (a context without its event) */
+    MIK_KNOB_COUNT = 12
+};
 int mik_set_tuning(int key, int value);
 int mik_ctx_set_tuning(mik_ctx *ctx, int key, int value);
 /* Host-only: the rule that places a 256-row block's window of x in LDS (k_spmv_rowblock XWIN) on caller-supplied per-block statistics

@@ -586,7 +586,7 @@ extern "C" int mik_cgd_set_halo_plan(mik_cgd *it, int n_recv, const int *recv_pe
     // updates and packs them first and puts the halo on the wire before the bulk of the sweep over u (cgd_enqueue_head).
     it->n_early = 0;
     it->early_merged = false;
-    if (it->n_send > 0 && it->n_send <= (1 << 26) && it->base.ctx->tuning[24] == 0) {       // development knob 24: 1 = halo after the whole sweep
+    if (it->n_send > 0 && it->n_send <= (1 << 26) && (it->base.ctx->tuning[MIK_KNOB_CG_STEP] & 4) == 0) {       // development knob MIK_KNOB_CG_STEP bit 2: halo after the whole sweep
         std::vector<int> idx((size_t)it->n_send);
         if (hipMemcpy(idx.data(), it->send_idx, sizeof(int) * idx.size(), hipMemcpyDeviceToHost) == hipSuccess) {
             std::vector<int> srt(idx);
@@ -1011,7 +1011,7 @@ extern "C" int mik_comm_mailbox_info(const mik_comm *cm, int *ready, int *finegr
 // compute stream a ~6 us hole between two kernels (profiles/r03_dist_selfhalo_timeline.txt); a 1-thread launch costs ~2.
 // Development knob 6, bit 0: events.  Every waiting kernel is submitted after the kernel that satisfies it, so streams that share a
 // hardware queue cannot deadlock.
-static bool halo_flags(const mik_cgd *it) { return it->comm && it->comm->mail && (it->base.ctx->tuning[6] & 1) == 0; }
+static bool halo_flags(const mik_cgd *it) { return it->comm && it->comm->mail && (it->base.ctx->tuning[MIK_KNOB_TRANSPORT] & 1) == 0; }
 static bool halo_p2p(const mik_cgd *it) { return it->comm && it->comm->mail_ready && it->ghosts && it->link; }
 static bool halo_any(const mik_cgd *it)
 {
@@ -1100,7 +1100,7 @@ static int gather_scalar(mik_cgd *it, void *all, int kind)
     if (!cm) return MIK_OK;
     mik_ctx *ctx = it->base.ctx;
     // development knob 6, bit 1: the scalars over RCCL although a mailbox is connected; bit 2: through the mailbox even in a world of one
-    if (cm->mail_ready && (ctx->tuning[6] & 2) == 0 && (it->nranks > 1 || (ctx->tuning[6] & 4) != 0)) {
+    if (cm->mail_ready && (ctx->tuning[MIK_KNOB_TRANSPORT] & 2) == 0 && (it->nranks > 1 || (ctx->tuning[MIK_KNOB_TRANSPORT] & 4) != 0)) {
         const unsigned long long seq = ++cm->mseq[kind];
         if (it->base.dtype == MIK_F64)
             hipLaunchKernelGGL((k_mail_gather<double>), dim3(1), dim3(64), 0, ctx->stream, (MailBox *const *)cm->peers_dev, it->nranks, it->rank, kind, seq, (double *)all,
@@ -1218,7 +1218,7 @@ extern "C" int mik_cgd_init(mik_cgd *it, double *residual, double *tol)
 static bool mail_fused(const mik_cgd *it)
 {
     const mik_comm *cm = it->comm;
-    const int k = it->base.ctx->tuning[6];
+    const int k = it->base.ctx->tuning[MIK_KNOB_TRANSPORT];
     return cm && cm->mail_ready && (k & 2) == 0 && (k & 8) == 0 && (it->nranks > 1 || (k & 4) != 0);
 }
 
@@ -1326,8 +1326,8 @@ extern "C" int mik_cgd_iterate_many(mik_cgd *it, int64_t iteration, int64_t max_
     mik_cg &bs = it->base;
     if (max_steps <= 0 || iteration >= bs.maxiter || bs.residual <= bs.tol) return MIK_OK;      // done(it, iteration), src/cg.jl:36
     max_steps = std::min<int64_t>(std::min<int64_t>(max_steps, bs.maxiter - iteration), bs.hist_cap);
-    const bool ahead_ok = bs.ctx->tuning[9] == 0 && iteration + max_steps < bs.maxiter;      // development knob 9: 1 = nothing ahead of the host
-    bs.fuse_x = bs.ctx->tuning[23] == 0;                              // x .+= alpha .* u rides on the next sweep over u (as in mik_cg_*)
+    const bool ahead_ok = bs.ctx->tuning[MIK_KNOB_NO_LOOKAHEAD] == 0 && iteration + max_steps < bs.maxiter;      // development knob 9: 1 = nothing ahead of the host
+    bs.fuse_x = (bs.ctx->tuning[MIK_KNOB_CG_STEP] & 1) == 0;                              // x .+= alpha .* u rides on the next sweep over u (as in mik_cg_*)
     CgMirror m;
     for (int64_t j0 = 0;;) {
         for (int64_t j = j0; j < max_steps; ++j) {
@@ -1616,7 +1616,7 @@ extern "C" int mik_cgd_group_iterate_many(mik_cgd **its, int P, int64_t iteratio
     for (int p = 0; p < P; ++p) {
         split = split && its[p]->int_end > its[p]->int_begin;
         early = early && its[p]->n_early > 0;
-        its[p]->base.fuse_x = its[p]->base.ctx->tuning[23] == 0;                // as mik_cgd_iterate_many: x .+= alpha .* u rides on the next sweep over u
+        its[p]->base.fuse_x = (its[p]->base.ctx->tuning[MIK_KNOB_CG_STEP] & 1) == 0;                // as mik_cgd_iterate_many: x .+= alpha .* u rides on the next sweep over u
     }
     early = early && split;
     std::vector<char> pending;

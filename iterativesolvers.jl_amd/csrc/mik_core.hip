@@ -18,7 +18,7 @@
 #include <unordered_map>
 
 thread_local std::string g_mik_create_error;
-int g_mik_tuning[32] = {0};
+int g_mik_tuning[MIK_KNOB_COUNT] = {0};
 // every live context: mik_set_tuning (the process-wide development setter) writes the defaults AND all of them; launches only ever read
 // their own context's table
 static std::vector<mik_ctx *> g_mik_contexts;
@@ -154,13 +154,13 @@ extern "C" int mik_spmv_dot_shape(int *W, int *L)
 
 extern "C" int mik_spmv_long_row(int *threshold)
 {
-    if (threshold) *threshold = g_mik_tuning[4] > 0 ? g_mik_tuning[4] : (g_mik_tuning[4] < 0 ? INT32_MAX : MIK_LONG_ROW);
+    if (threshold) *threshold = MIK_LONG_ROW;
     return MIK_OK;
 }
 
 extern "C" int mik_spmv_long_segment(int *segment)
 {
-    if (segment) *segment = ((g_mik_tuning[15] > 0 ? g_mik_tuning[15] : MIK_LONG_SEG) + 3) & ~3;   // whole groups of MIK_LONG_G entries
+    if (segment) *segment = ((g_mik_tuning[MIK_KNOB_LONG_SEGMENT] > 0 ? g_mik_tuning[MIK_KNOB_LONG_SEGMENT] : MIK_LONG_SEG) + 3) & ~3;   // whole groups of MIK_LONG_G entries
     return MIK_OK;
 }
 
@@ -174,14 +174,14 @@ static inline bool spmv_csr_rowgather(const mik_csr *A);
 
 extern "C" int mik_ctx_set_tuning(mik_ctx *ctx, int key, int value)
 {
-    if (!ctx || key < 0 || key >= 32) return MIK_ERR_INVALID;
+    if (!ctx || key < 0 || key >= MIK_KNOB_COUNT) return MIK_ERR_INVALID;
     ctx->tuning[key] = value;
     return MIK_OK;
 }
 
 extern "C" int mik_set_tuning(int key, int value)
 {
-    if (key < 0 || key >= 32) return MIK_ERR_INVALID;
+    if (key < 0 || key >= MIK_KNOB_COUNT) return MIK_ERR_INVALID;
     std::lock_guard<std::mutex> lk(g_mik_contexts_mu);
     g_mik_tuning[key] = value;
     for (mik_ctx *c : g_mik_contexts) c->tuning[key] = value;
@@ -406,7 +406,7 @@ static int csr_build_sdia(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
 {
     (void)max_row;
     hipError_t e;
-    if (A->n_long == 0 && n_rows > 0 && nnz > 0 && n_cols > 0 && ctx->tuning[8] == 0 && ctx->tuning[12] == 0)
+    if (A->n_long == 0 && n_rows > 0 && nnz > 0 && n_cols > 0 && (ctx->tuning[MIK_KNOB_LAYOUTS] & 1) == 0 && (ctx->tuning[MIK_KNOB_LAYOUTS] & 4) == 0)
     {
         const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
         std::vector<int> dptr((size_t)nb + 1, 0), doff((size_t)nb * 8, 0), dtri((size_t)nb, -1);
@@ -469,7 +469,7 @@ static int csr_build_sdia(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
             }
             // slice-constant slots (k_spmv_sdiac): every row of a slice that has slot q carries the same value BITS there
             std::vector<unsigned char> cval;
-            bool constant = ok && ctx->tuning[11] == 0;
+            bool constant = ok && (ctx->tuning[MIK_KNOB_LAYOUTS] & 2) == 0;
             if (constant) {
                 cval.assign((size_t)nb * 8 * es, 0);
                 std::vector<unsigned char> seen((size_t)nb * 8, 0);
@@ -618,7 +618,7 @@ static int sdiaw_chunk_bits(mik_ctx *ctx, mik_csr *A)
 static int csr_build_sdiaw(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowptr, const std::vector<int> &col, const std::vector<unsigned char> &v,
                            size_t es, int64_t n_rows, int64_t n_cols, int64_t nnz)
 {
-    if (A->sdia_val || A->sdia_pats || A->n_long || n_rows <= 0 || nnz <= 0 || n_cols <= 0 || ctx->tuning[8] != 0 || ctx->tuning[12] != 0) return MIK_OK;
+    if (A->sdia_val || A->sdia_pats || A->n_long || n_rows <= 0 || nnz <= 0 || n_cols <= 0 || (ctx->tuning[MIK_KNOB_LAYOUTS] & 1) != 0 || (ctx->tuning[MIK_KNOB_LAYOUTS] & 4) != 0) return MIK_OK;
     if ((uint64_t)n_rows * es >= 0xFFFFFFF0ull) return MIK_OK;
     const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
     struct Slot { int d; uint64_t bits; };
@@ -688,7 +688,7 @@ static int csr_build_sdiaw(mik_ctx *ctx, mik_csr *A, const std::vector<int> &row
 int mik_build_rperm_host(mik_ctx *ctx, mik_csr *A, const int *rowptr)
 {
     const int64_t n = A->n_rows;
-    if (A->sdia_val || A->sdia_pats || A->sdiaw_pats || A->jds_val || n <= 0 || ctx->tuning[29] == 1) return MIK_OK;
+    if (A->sdia_val || A->sdia_pats || A->sdiaw_pats || A->jds_val || n <= 0 || (ctx->tuning[MIK_KNOB_LAYOUTS] & 32) != 0) return MIK_OK;
     if (A->n_long == 0 && A->max_row_nnz <= 32) return MIK_OK;
     const int64_t nb = (n + MIK_BLOCK - 1) / MIK_BLOCK;
     std::vector<unsigned char> perm((size_t)(nb * MIK_BLOCK));
@@ -716,7 +716,7 @@ int mik_build_rperm_host(mik_ctx *ctx, mik_csr *A, const int *rowptr)
 static int csr_build_xwin(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowptr, const std::vector<int> &col, size_t es, int64_t n_rows, int64_t n_cols,
                           int max_row)
 {
-    if (A->sdia_val || A->sdia_pats || A->sdiaw_pats || A->jds_val || n_rows <= 0 || ctx->tuning[29] == 1) return MIK_OK;
+    if (A->sdia_val || A->sdia_pats || A->sdiaw_pats || A->jds_val || n_rows <= 0 || (ctx->tuning[MIK_KNOB_LAYOUTS] & 32) != 0) return MIK_OK;
     if (A->n_long == 0 && max_row <= 32) return MIK_OK;
     const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
     std::vector<int> mn((size_t)nb, INT32_MAX), mx((size_t)nb, -1), cnt((size_t)nb, 0), lo;
@@ -744,7 +744,7 @@ static int csr_build_xwin(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowp
 static int csr_build_jds(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowptr, const std::vector<int> &col, const std::vector<unsigned char> &v,
                          size_t es, int64_t n_rows, const unsigned char *is_long)
 {
-    if (A->sdia_val || A->sdia_pats || A->sdiaw_pats || n_rows <= 0 || ctx->tuning[8] != 0 || ctx->tuning[28] == 1) return MIK_OK;   // development knob 28: 1 = never, 2 = whenever possible
+    if (A->sdia_val || A->sdia_pats || A->sdiaw_pats || n_rows <= 0 || (ctx->tuning[MIK_KNOB_LAYOUTS] & 1) != 0 || (ctx->tuning[MIK_KNOB_LAYOUTS] & 8) != 0) return MIK_OK;   // development knob 28: 1 = never, 2 = whenever possible
     const int W = (int)(16 / es);
     const int64_t short_nnz = rowptr[(size_t)n_rows];
     if (short_nnz <= 0) return MIK_OK;
@@ -763,7 +763,7 @@ static int csr_build_jds(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowpt
     }
     if (maxlen >= MIK_JDS_LONG || groups * W >= INT32_MAX) return MIK_OK;
     const int64_t jds_bytes = groups * W * (int64_t)(es + 4) + 2 * n_rows, csr_bytes = short_nnz * (int64_t)(es + 4) + 4 * n_rows;
-    if (ctx->tuning[28] != 2 && !(iters * 64 * 4 <= groups * 5 && (maxlen > 32 || jds_bytes * 10 <= csr_bytes * 11))) return MIK_OK;
+    if ((ctx->tuning[MIK_KNOB_LAYOUTS] & 16) == 0 && !(iters * 64 * 4 <= groups * 5 && (maxlen > 32 || jds_bytes * 10 <= csr_bytes * 11))) return MIK_OK;
     std::vector<int> jptr, jcol;
     std::vector<unsigned short> jlen;
     std::vector<unsigned char> jval;
@@ -930,7 +930,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
     // Default: everything past the raw host-to-device copy happens on the device (mik_upload.hip).  MIK_ERR_NOTIMPL from it
     // = a matrix the host path below handles (long rows, duplicate entries, no room for the raw copy); development knob 20:
     // 1 = host path only.
-    if (ctx->tuning[20] != 1 && nnz > 0 && n_rows > 0 && n_cols > 0 && n_rows < 0x7f000000) {       // (row ids below the "no row yet" pattern of the analysis)
+    if (ctx->tuning[MIK_KNOB_UPLOAD] != 1 && nnz > 0 && n_rows > 0 && n_cols > 0 && n_rows < 0x7f000000) {       // (row ids below the "no row yet" pattern of the analysis)
         mik_csr *A = new (std::nothrow) mik_csr();
         if (!A) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_csr_create: host allocation failed");
         A->ctx = ctx; A->dtype = dtype; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz;
@@ -938,11 +938,11 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
         int rc = mik_upload_device(ctx, A, dtype, n_rows, n_cols, nnz, ptr, idx, val, index_base, is_csc);
         // no <= 8-offset layout: the wide slice-constant form, then the jagged slices, both built on the device from A's CSR arrays
         // (development knob 20 = 2: through the host builders, from a copy of the device CSR)
-        if (rc == MIK_OK && !A->sdia_val && !A->sdia_pats && ctx->tuning[8] == 0 && ctx->tuning[20] != 2) {
+        if (rc == MIK_OK && !A->sdia_val && !A->sdia_pats && (ctx->tuning[MIK_KNOB_LAYOUTS] & 1) == 0 && ctx->tuning[MIK_KNOB_UPLOAD] != 2) {
             rc = mik_build_sdiaw_device(ctx, A);
             if (rc == MIK_OK) rc = mik_build_jds_device(ctx, A);
             if (rc == MIK_OK) rc = mik_build_xwin_device(ctx, A);
-        } else if (rc == MIK_OK && !A->sdia_val && !A->sdia_pats && ctx->tuning[8] == 0) {
+        } else if (rc == MIK_OK && !A->sdia_val && !A->sdia_pats && (ctx->tuning[MIK_KNOB_LAYOUTS] & 1) == 0) {
             try {
                 rowptr.resize((size_t)n_rows + 1);
                 col.resize((size_t)nnz);
@@ -1027,8 +1027,8 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
     std::vector<int> seg_row, cut_row, cut_first, cut_nseg;    // segment -> cut row; cut row -> matrix row, first segment, segments
     std::vector<unsigned char> is_long;
     // development knob [4]: > 0 overrides the threshold, < 0 disables the split
-    const int long_row = ctx->tuning[4] > 0 ? ctx->tuning[4] : MIK_LONG_ROW;
-    if (max_row > long_row && ctx->tuning[4] >= 0) {
+    const int long_row = MIK_LONG_ROW;
+    if (max_row > long_row) {
         is_long.assign((size_t)n_rows, 0);
         std::vector<int> rp2((size_t)n_rows + 1, 0), col2;
         std::vector<unsigned char> v2;
@@ -1061,7 +1061,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
         rowptr.swap(rp2); col.swap(col2); v.swap(v2);
         {   // rows longer than one segment are cut: every segment becomes a virtual row of its own (csrc/mik_spmv.h, LongTab); the
             // list stays in (row, segment) order -- the four waves of a workgroup then walk neighbouring pieces of one row
-            const int seg = ((ctx->tuning[15] > 0 ? ctx->tuning[15] : MIK_LONG_SEG) + 3) & ~3;    // development knob: segment length (whole groups of 4)
+            const int seg = ((ctx->tuning[MIK_KNOB_LONG_SEGMENT] > 0 ? ctx->tuning[MIK_KNOB_LONG_SEGMENT] : MIK_LONG_SEG) + 3) & ~3;    // development knob: segment length (whole groups of 4)
             std::vector<int> vr, vs, vl;
             for (size_t q = 0; q < long_rows.size(); ++q) {
                 if (long_len[q] <= seg) { vr.push_back(long_rows[q]); vs.push_back(long_start[q]); vl.push_back(long_len[q]); continue; }
@@ -1083,8 +1083,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
             // in L1.  (Sorting is a pure scheduling matter: every virtual row keeps its shape, the segment sums their order.)
             std::vector<int> ord(vr.size());
             for (size_t q = 0; q < ord.size(); ++q) ord[q] = (int)q;
-            if (ctx->tuning[2] >= 0)    // development knob 2 < 0 (identity block map) also keeps the (row, segment) order
-                std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return col[(size_t)vs[(size_t)a]] < col[(size_t)vs[(size_t)b]]; });
+                    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return col[(size_t)vs[(size_t)a]] < col[(size_t)vs[(size_t)b]]; });
             long_rows.resize(vr.size()); long_start.resize(vr.size()); long_len.resize(vr.size());
             for (size_t q = 0; q < ord.size(); ++q) { long_rows[q] = vr[(size_t)ord[q]]; long_start[q] = vs[(size_t)ord[q]]; long_len[q] = vl[(size_t)ord[q]]; }
         }
@@ -1148,7 +1147,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
     if (rc_layout == MIK_OK) rc_layout = csr_build_jds(ctx, A, rowptr, col, v, es, n_rows, is_long.empty() ? nullptr : is_long.data());
     if (rc_layout == MIK_OK) rc_layout = csr_build_xwin(ctx, A, rowptr, col, es, n_rows, n_cols, max_row);
     if (rc_layout == MIK_OK) rc_layout = mik_build_rperm_host(ctx, A, rowptr.data());
-    if (rc_layout == MIK_OK && A->n_long && ctx->tuning[29] != 1 && !A->jds_val) {
+    if (rc_layout == MIK_OK && A->n_long && (ctx->tuning[MIK_KNOB_LAYOUTS] & 32) == 0 && !A->jds_val) {
         // windows of x for the long-row workgroups (csrc/mik_spmv.h, spmv_long_window): workgroup g sums virtual rows 4 g .. 4 g + 3 of the
         // list (sorted by first column); its window starts at their smallest first column and is as long as the LDS of a row-block
         // workgroup ([product tile][wave sums][x window of the short rows]); -1 where less than about half of the workgroup's columns fit
@@ -1259,7 +1258,7 @@ extern "C" int mik_csr_stored_bytes(const mik_csr *A, int64_t *bytes)
     const int64_t es = (int64_t)mik_dtype_size(A->dtype);
     const int64_t nb = (A->n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
     switch (layout) {
-    case 5: *bytes = A->n_rows + nb * ((A->sdia_recs && A->ctx->tuning[17] == 0) ? 64 : 4) + (int64_t)A->sdia_npat * (80 + 8 * es); break;
+    case 5: *bytes = A->n_rows + nb * ((A->sdia_recs && A->ctx->tuning[MIK_KNOB_SDIA_KERNEL] != 1) ? 64 : 4) + (int64_t)A->sdia_npat * (80 + 8 * es); break;
     case 6: *bytes = A->n_rows * 4 + nb * 4 + (nb + 1) / 2 * 64 + (int64_t)A->sdiaw_npat * A->sdiaw_pat_bytes; break;
     case 4: *bytes = A->sdia_entries * es + A->n_rows + nb * 36; break;
     case 1: *bytes = A->jds_groups * (16 / es) * (es + 4) + A->n_rows * 2 + ((A->n_rows + 63) / 64 + 1) * 4 +
@@ -1294,11 +1293,11 @@ static int spmv_kernel_choice(const mik_csr *A)
 {
     const bool csr = A->col != nullptr;                     // false after mik_csr_compact: the development knobs cannot fall back to CSR
     if (A->force_layout == 0 && csr) return 0;              // mik_csr_set_layout
-    if (A->ctx->tuning[8] == 0 || !csr) {
-        if (A->sdia_pats && (A->ctx->tuning[12] == 0 || !csr)) return 5;
-        if (A->sdia_val && (A->ctx->tuning[12] == 0 || !csr)) return 4;
-        if (A->sdiaw_pats && (A->ctx->tuning[12] == 0 || !csr)) return 6;
-        if (A->jds_val && A->ctx->tuning[28] != 1) return 1;
+    if ((A->ctx->tuning[MIK_KNOB_LAYOUTS] & 1) == 0 || !csr) {
+        if (A->sdia_pats && ((A->ctx->tuning[MIK_KNOB_LAYOUTS] & 4) == 0 || !csr)) return 5;
+        if (A->sdia_val && ((A->ctx->tuning[MIK_KNOB_LAYOUTS] & 4) == 0 || !csr)) return 4;
+        if (A->sdiaw_pats && ((A->ctx->tuning[MIK_KNOB_LAYOUTS] & 4) == 0 || !csr)) return 6;
+        if (A->jds_val && (A->ctx->tuning[MIK_KNOB_LAYOUTS] & 8) == 0) return 1;
     }
     return 0;
 }
@@ -1320,24 +1319,23 @@ extern "C" int mik_csr_compact(mik_csr *A)
 static inline bool spmv_csr_rowgather(const mik_csr *A)
 {
     // operators with x windows (irregular rows inside a band, csr_build_xwin) run on the product tile, which gathers from them
-    return A->ctx->tuning[14] == 2 || (A->ctx->tuning[14] == 0 && A->n_long == 0 && !A->xwin_lo && !A->rperm);
+    return A->ctx->tuning[MIK_KNOB_CSR_KERNEL] == 2 || (A->ctx->tuning[MIK_KNOB_CSR_KERNEL] == 0 && A->n_long == 0 && !A->xwin_lo && !A->rperm);
 }
 
 // k_spmv_sdiab2 (two rows per lane): the operator's class has the lane-neighbour shape, n is even, and no development
 // knob asks for another form (16: slices per workgroup; 18: no compiled-in class; 19: 1 = one row per lane)
 static bool sdiab2_applies(const mik_csr *A)
 {
-    return A->sdia_buf_ok && A->sdia_cls >= 1 && (A->n_rows & 1) == 0 && A->ctx->tuning[16] == 0 && A->ctx->tuning[17] == 0 && A->ctx->tuning[18] == 0 &&
-           A->ctx->tuning[19] == 0;
+    return A->sdia_buf_ok && A->sdia_cls >= 1 && (A->n_rows & 1) == 0 && A->ctx->tuning[MIK_KNOB_SDIA_KERNEL] == 0;
 }
 
 // k_spmv_sdiab2, the two CSR kernels and the jagged slices (whole launches with the fused dot, no split-off long rows) take the epilogue
 // y = A x + c w, dot(x, y) -- the Lanczos step of MINRES -- and dot(z, y) in place of dot(x, y) -- sigma and rho of BiCGStab(l)
 bool mik_spmv_has_epilogue(const mik_csr *A)
 {
-    if (!A || A->ctx->tuning[25] == 2) return false;                    // development knob 25 = 2: never
+    if (!A || A->ctx->tuning[MIK_KNOB_SOLVER_FORM] == 2) return false;                    // development knob 25 = 2: never
     const int kc = spmv_kernel_choice(A);
-    if (kc == 5) return A->sdia_buf_ok && A->ctx->tuning[17] == 0 && sdiab2_applies(A);
+    if (kc == 5) return A->sdia_buf_ok && A->ctx->tuning[MIK_KNOB_SDIA_KERNEL] != 1 && sdiab2_applies(A);
     return (kc == 0 || kc == 1) && A->n_long == 0;                       // the CSR kernels and the jagged slices: one row per thread, no split-off long rows
 }
 
@@ -1349,18 +1347,18 @@ extern "C" int mik_spmv_kernel(const mik_csr *A, char *name, int len)
     if (!A || !name || len <= 0) return MIK_ERR_INVALID;
     const char *k = "k_spmv_rowblock";
     switch (spmv_kernel_choice(A)) {
-    case 5: k = A->sdia_buf_ok && A->ctx->tuning[17] == 0 ? (sdiab2_applies(A) ? "k_spmv_sdiab2" : "k_spmv_sdiab") : "k_spmv_sdiac"; break;
-    case 6: k = ((A->n_rows & 1) == 0 && A->ctx->tuning[19] == 0) ? "k_spmv_sdiaw2" : "k_spmv_sdiaw"; break;
+    case 5: k = A->sdia_buf_ok && A->ctx->tuning[MIK_KNOB_SDIA_KERNEL] != 1 ? (sdiab2_applies(A) ? "k_spmv_sdiab2" : "k_spmv_sdiab") : "k_spmv_sdiac"; break;
+    case 6: k = ((A->n_rows & 1) == 0 && A->ctx->tuning[MIK_KNOB_SDIA_KERNEL] != 3) ? "k_spmv_sdiaw2" : "k_spmv_sdiaw"; break;
     case 4: k = "k_spmv_sdia"; break;
     case 1: k = "k_spmv_jds"; break;
-    default: k = spmv_csr_rowgather(A) ? "k_spmv_rowgather" : ((A->xwin_lo && A->ctx->tuning[29] == 0 && A->ctx->tuning[1] == 0) ? "k_spmv_rowblock+xwin" : "k_spmv_rowblock"); break;
+    default: k = spmv_csr_rowgather(A) ? "k_spmv_rowgather" : ((A->xwin_lo && (A->ctx->tuning[MIK_KNOB_LAYOUTS] & 96) == 0) ? "k_spmv_rowblock+xwin" : "k_spmv_rowblock"); break;
     }
     snprintf(name, (size_t)len, "%s", k);
     return MIK_OK;
 }
 
 // Can mik_spmv_launch_range serve a sub-range of row-blocks for this operator?  The sliced-ELL kernels and the default
-// CSR kernel take a first row-block; the dictionary-coded kernel, k_spmv_rowblock (tuning[14] = 1) and operators with
+// CSR kernel take a first row-block; the dictionary-coded kernel, k_spmv_rowblock (MIK_KNOB_CSR_KERNEL = 1) and operators with
 // split-off long rows (their wave-per-row launch covers the whole matrix) do not.
 bool mik_spmv_can_split(const mik_csr *A)
 {
@@ -1394,7 +1392,7 @@ int mik_spmv_launch_outside(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
 {
     const int nb_all = (int)mik_spmv_nwg(A->n_rows);
     if (skip_begin < 0 || skip_end < skip_begin || skip_end > nb_all) return mik_fail(ctx, MIK_ERR_INVALID, "SpMV: bad interior range");
-    if (spmv_kernel_choice(A) == 5 && A->sdia_buf_ok && A->ctx->tuning[17] == 0 && skip_begin + (nb_all - skip_end) > 0)
+    if (spmv_kernel_choice(A) == 5 && A->sdia_buf_ok && A->ctx->tuning[MIK_KNOB_SDIA_KERNEL] != 1 && skip_begin + (nb_all - skip_end) > 0)
         return spmv_launch_impl<T>(ctx, A, x, y, fuse_dot, seg_out, done, 0, skip_begin + (nb_all - skip_end), skip_begin, skip_end - skip_begin);
     MIK_TRY(mik_spmv_launch_range<T>(ctx, A, x, y, fuse_dot, seg_out, done, 0, skip_begin));
     return mik_spmv_launch_range<T>(ctx, A, x, y, fuse_dot, seg_out, done, skip_end, nb_all - skip_end);
@@ -1418,9 +1416,8 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
     // [2] block map (0 = the operator's own choice: strips for banded operators, else identity; < 0 identity;
     //     1 contiguous range per XCD; P >= 8 strips of P row-blocks)
     const int nb = whole ? nb_all : rb_count;
-    const bool nt = ctx->tuning[0] == 0;
-    const bool wide = ctx->tuning[1] == 0;
-    int map_mode = ctx->tuning[2] == 0 ? A->strip : std::max(ctx->tuning[2], 0);
+    const bool wide = true;
+    int map_mode = A->strip;
     if (!whole && map_mode >= 8 && (rb0 % map_mode != 0 || nb % map_mode != 0)) map_mode = 0;   // strips need whole planes
     if (skip_len > 0) map_mode = 0;
     const int choice = spmv_kernel_choice(A);
@@ -1428,9 +1425,9 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         return mik_fail(ctx, MIK_ERR_NOTIMPL, "SpMV: the y = A x + c w / dot(z, y) epilogue is not available for this operator's kernel");
     if (choice == 5) {
         // slice patterns {offsets, values} + one mask byte per row (mik_sell.h); G slices per workgroup
-        const int G = ctx->tuning[16] > 0 ? ctx->tuning[16] : MIK_SDIAC_G;   // development knob 16: 1 / 2 / 4 slices per workgroup
+        const int G = MIK_SDIAC_G;
         const int wgs = ((nb + G - 1) / G + 7) / 8 * 8;                         // a multiple of 8: see k_spmv_sdiac
-        if (A->sdia_buf_ok && ctx->tuning[17] == 0) {                          // development knob 17: 1 = the flat-load kernel
+        if (A->sdia_buf_ok && ctx->tuning[MIK_KNOB_SDIA_KERNEL] != 1) {                          // development knob MIK_KNOB_SDIA_KERNEL = 1: the flat-load kernel
             // strips of a power-of-two number of row-blocks are mapped by shifts; any other map runs as identity here
             int sshift = -1, nfull = 0;
             if (map_mode >= 8) {
@@ -1445,25 +1442,25 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
          else MIK_SDIAB_GO4(FD, NTV, GG, 0); } while (0)
 #define MIK_SDIAB_GO(FD, NTV)                                                                      \
     do { if (G == 1) MIK_SDIAB_GO4(FD, NTV, 1, 0); else if (G == 4) MIK_SDIAB_GO4(FD, NTV, 4, 0); else MIK_SDIAB_GO3(FD, NTV, 2); } while (0)
-            const int cls = ctx->tuning[18] == 1 ? 0 : A->sdia_cls;            // development knob 18: 1 = slot-by-slot path only
+            const int cls = ctx->tuning[MIK_KNOB_SDIA_KERNEL] == 2 ? 0 : A->sdia_cls;            // development knob MIK_KNOB_SDIA_KERNEL = 2: slot-by-slot path only
             if (sdiab2_applies(A) && skip_len == 0 && (rb0 & 1) == 0 && ((nb & 1) == 0 || rb0 + nb == nb_all)) {
                 // two rows per lane, 16-byte gathers (k_spmv_sdiab2): workgroups over PAIRS of slices; strips halve with them
                 const int np = (nb + 1) / 2, pb0 = rb0 / 2, wg2 = (np + 7) / 8 * 8;
                 const int ps = sshift >= 1 ? sshift - 1 : -1, pfull = sshift >= 1 ? nfull / 2 : 0;
 #define MIK_SDIAB2_GO4(FD, NTV, C)                                                                                                       \
     hipLaunchKernelGGL((k_spmv_sdiab2<T, FD, NTV, mik_sdiab_cls_ns(C), mik_sdiab_cls_cq(C)>), dim3(wg2), dim3(MIK_BLOCK), 0, ctx->stream, n, (int)A->n_cols, A->sdia_koff, \
-                       pb0, np, pfull, ps, nb_all, ctx->sweep_rev, (const SdiaSliceRec *)A->sdia_recs, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done, \
+                       pb0, np, pfull, ps, nb_all, (const SdiaSliceRec *)A->sdia_recs, (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done, \
                        (const T *)ctx->spmv_ep_w, (const T *)ctx->spmv_ep_c, (const T *)ctx->spmv_ep_z)
 #define MIK_SDIAB2_GO(FD, NTV) do { if (cls == 1) MIK_SDIAB2_GO4(FD, NTV, 1); else if (cls == 2) MIK_SDIAB2_GO4(FD, NTV, 2); else MIK_SDIAB2_GO4(FD, NTV, 3); } while (0)
-                if (fuse_dot) { if (nt) MIK_SDIAB2_GO(true, true); else MIK_SDIAB2_GO(true, false); }
-                else          { if (nt) MIK_SDIAB2_GO(false, true); else MIK_SDIAB2_GO(false, false); }
+                if (fuse_dot) { MIK_SDIAB2_GO(true, true); }
+                else          { MIK_SDIAB2_GO(false, true); }
 #undef MIK_SDIAB2_GO4
 #undef MIK_SDIAB2_GO
                 MIK_LAUNCH_CHECK(ctx);
                 return MIK_OK;
             }
-            if (fuse_dot) { if (nt) MIK_SDIAB_GO(true, true); else MIK_SDIAB_GO(true, false); }
-            else          { if (nt) MIK_SDIAB_GO(false, true); else MIK_SDIAB_GO(false, false); }
+            if (fuse_dot) { MIK_SDIAB_GO(true, true); }
+            else          { MIK_SDIAB_GO(false, true); }
 #undef MIK_SDIAB_GO4
 #undef MIK_SDIAB_GO3
 #undef MIK_SDIAB_GO
@@ -1475,14 +1472,14 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
                        (const SdiaPattern<T> *)A->sdia_pats, A->sdia_mask, x, y, seg_out, done)
 #define MIK_SDIAC_GO(FD, NTV)                                                                      \
     do { if (G == 1) MIK_SDIAC_GO3(FD, NTV, 1); else if (G == 4) MIK_SDIAC_GO3(FD, NTV, 4); else MIK_SDIAC_GO3(FD, NTV, 2); } while (0)
-        if (fuse_dot) { if (nt) MIK_SDIAC_GO(true, true); else MIK_SDIAC_GO(true, false); }
-        else          { if (nt) MIK_SDIAC_GO(false, true); else MIK_SDIAC_GO(false, false); }
+        if (fuse_dot) { MIK_SDIAC_GO(true, true); }
+        else          { MIK_SDIAC_GO(false, true); }
 #undef MIK_SDIAC_GO3
 #undef MIK_SDIAC_GO
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     }
-    if (choice == 6 && (n & 1) == 0 && (uint64_t)A->n_cols * sizeof(T) < 0x7FFFFFF0ull && ctx->tuning[19] == 0 && (rb0 & 1) == 0 &&
+    if (choice == 6 && (n & 1) == 0 && (uint64_t)A->n_cols * sizeof(T) < 0x7FFFFFF0ull && ctx->tuning[MIK_KNOB_SDIA_KERNEL] != 3 && (rb0 & 1) == 0 &&
         ((nb & 1) == 0 || rb0 + nb == nb_all)) {
         // ... two rows per lane (k_spmv_sdiaw2): workgroups over PAIRS of slices (development knob 19: 1 = one row per lane)
         const int np = (nb + 1) / 2, pb0 = rb0 / 2;
@@ -1490,8 +1487,8 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
 #define MIK_SDIAW2_GO(FD, NTV)                                                                                                \
     hipLaunchKernelGGL((k_spmv_sdiaw2<T, FD, NTV>), dim3(np), dim3(MIK_BLOCK), 0, ctx->stream, n, (int)A->n_cols, A->sdiaw_koff, pb0, np, pmode, nb_all, \
                        A->sdiaw_pat_id, (const SdiawPattern<T> *)A->sdiaw_pats, A->sdiaw_mask, (const uint4 *)A->sdiaw_uz, x, y, seg_out, done)
-        if (fuse_dot) { if (nt) MIK_SDIAW2_GO(true, true); else MIK_SDIAW2_GO(true, false); }
-        else          { if (nt) MIK_SDIAW2_GO(false, true); else MIK_SDIAW2_GO(false, false); }
+        if (fuse_dot) { MIK_SDIAW2_GO(true, true); }
+        else          { MIK_SDIAW2_GO(false, true); }
 #undef MIK_SDIAW2_GO
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
@@ -1501,8 +1498,8 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
 #define MIK_SDIAW_GO(FD, NTV)                                                                                                 \
     hipLaunchKernelGGL((k_spmv_sdiaw<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, A->sdiaw_koff, rb0, nb, map_mode, A->sdiaw_pat_id, \
                        (const SdiawPattern<T> *)A->sdiaw_pats, A->sdiaw_mask, x, y, seg_out, done)
-        if (fuse_dot) { if (nt) MIK_SDIAW_GO(true, true); else MIK_SDIAW_GO(true, false); }
-        else          { if (nt) MIK_SDIAW_GO(false, true); else MIK_SDIAW_GO(false, false); }
+        if (fuse_dot) { MIK_SDIAW_GO(true, true); }
+        else          { MIK_SDIAW_GO(false, true); }
 #undef MIK_SDIAW_GO
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
@@ -1512,8 +1509,8 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
 #define MIK_SDIA_GO(FD, NTV)                                                                                                  \
     hipLaunchKernelGGL((k_spmv_sdia<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, (int)A->n_cols, rb0, nb, map_mode, A->sdia_ptr, \
                        A->sdia_off, A->sdia_tri, A->sdia_mask, (const T *)A->sdia_val, x, y, seg_out, done)
-        if (fuse_dot) { if (nt) MIK_SDIA_GO(true, true); else MIK_SDIA_GO(true, false); }
-        else          { if (nt) MIK_SDIA_GO(false, true); else MIK_SDIA_GO(false, false); }
+        if (fuse_dot) { MIK_SDIA_GO(true, true); }
+        else          { MIK_SDIA_GO(false, true); }
 #undef MIK_SDIA_GO
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
@@ -1529,7 +1526,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         lt.seg_sum = A->seg_sum; lt.nlong = nlong;
     }
     const int nlb = (nlong + 3) / 4;                    // one wave per virtual row (a whole row or a segment of a cut row)
-    const int *lwin = (A->long_win && ctx->tuning[29] == 0 && mik_aligned16(x)) ? A->long_win : nullptr;   // the long-row workgroups' windows of x in LDS
+    const int *lwin = (A->long_win && (ctx->tuning[MIK_KNOB_LAYOUTS] & 96) == 0 && mik_aligned16(x)) ? A->long_win : nullptr;   // the long-row workgroups' windows of x in LDS
     if (choice == 1) {
         // jagged slices (mik_jds.h): one row per lane, 16-byte operator streams; the workgroups of split-off long rows lead the same
         // launch.  dot(x, y) is formed inside unless long rows exist (their sums arrive from other workgroups): then by k_rowdot.
@@ -1545,7 +1542,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         else if (nlong) MIK_JDS_GO(false, NTV, true);                                         \
         else MIK_JDS_GO(false, NTV, false);                                                   \
     } while (0)
-        if (nt) MIK_JDS_GO2(true); else MIK_JDS_GO2(false);
+        MIK_JDS_GO2(true);
 #undef MIK_JDS_GO2
 #undef MIK_JDS_GO
         MIK_LAUNCH_CHECK(ctx);
@@ -1557,7 +1554,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
     }
     // CSR kernels.  k_spmv_rowgather (row-block tile filled by LDS-DMA, per-row gather) unless the operator has split-off
     // long rows: then k_spmv_rowblock, whose launch carries the long-row workgroups along (one launch instead of two:
-    // 180 vs 196 us on the random configs[4] stand-in, 107 vs 121 us on the banded one).  tuning[14]: 0 = that rule,
+    // 180 vs 196 us on the random configs[4] stand-in, 107 vs 121 us on the banded one).  MIK_KNOB_CSR_KERNEL: 0 = that rule,
     // 1 = always k_spmv_rowblock, 2 = always k_spmv_rowgather.  Same results bit for bit (tests/test_gpu_layouts.py).
     if (spmv_csr_rowgather(A)) {
         if (nlong) {   // long rows first (whole launches only, see mik_spmv_can_split); the row kernel then picks y[r] up
@@ -1568,8 +1565,8 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
 #define MIK_RG_GO(FD, NTV)                                                                                                      \
     hipLaunchKernelGGL((k_spmv_rowgather<T, FD, NTV>), dim3(nb), dim3(MIK_BLOCK), 0, ctx->stream, n, rb0, nb, map_mode, A->rowptr, \
                        A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, (const T *)ctx->spmv_ep_w, (const T *)ctx->spmv_ep_c, (const T *)ctx->spmv_ep_z)
-        if (fuse_dot) { if (nt) MIK_RG_GO(true, true); else MIK_RG_GO(true, false); }
-        else          { if (nt) MIK_RG_GO(false, true); else MIK_RG_GO(false, false); }
+        if (fuse_dot) { MIK_RG_GO(true, true); }
+        else          { MIK_RG_GO(false, true); }
 #undef MIK_RG_GO
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
@@ -1580,7 +1577,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
     // cached -- profiles/r04_c5_*).  Development knob 0: 1 = cached, 2 = streamed.
     // (Only where x comes from LDS windows: without them -- the `random` stand-in -- cached streams gain 3 % back to back and lose 6 % inside
     // gmres!, where they push the Krylov basis out of the caches: 260 -> 275 us per inner iteration.)
-    const bool nt_rb = ctx->tuning[0] == 2 || (ctx->tuning[0] == 0 && !A->xwin_lo);
+    const bool nt_rb = !A->xwin_lo;
     if (nlong && !merge) {
         // fused dot: long rows first in their own launch, the row-block kernel then picks y[r] up
         hipLaunchKernelGGL((k_spmv_longrows<T>), dim3(nlb), dim3(MIK_BLOCK), lwin ? sizeof(T) * (size_t)A->long_lw : 0, ctx->stream, lt, A->col, (const T *)A->val, x, y, done,
@@ -1589,11 +1586,11 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
     }
     const dim3 grid(nb + (merge ? nlb : 0)), block(MIK_BLOCK);
     // x served from an LDS window per row-block (csr_build_xwin; development knob 29 = 2: off at launch) -- wide loads and an aligned x only
-    const bool xwin = A->xwin_lo && wide && ctx->tuning[29] == 0 && mik_aligned16(x);
+    const bool xwin = A->xwin_lo && wide && (ctx->tuning[MIK_KNOB_LAYOUTS] & 96) == 0 && mik_aligned16(x);
     constexpr int RB_TILE = MIK_SPMV_TILE * (int)(8 / sizeof(T));
     const size_t dyn = sizeof(T) * ((size_t)RB_TILE + 12 + (xwin ? (size_t)A->xwin_span : 0));          // [product tile + 8][4 wave sums][x window]
     const int lw_launch = (int)std::min<size_t>((size_t)A->long_lw, dyn / 1024 * (1024 / sizeof(T)));  // what a long-row workgroup of this launch can hold
-    const bool rp = A->rperm && wide && ctx->tuning[29] == 0;         // rows of a block over its threads by length (mik_build_rperm_host)
+    const bool rp = A->rperm && wide && (ctx->tuning[MIK_KNOB_LAYOUTS] & 96) == 0;         // rows of a block over its threads by length (mik_build_rperm_host)
 #define MIK_SPMV_GO(FD, NT, WD, MG, XW, RP)                                                                      \
     hipLaunchKernelGGL((k_spmv_rowblock<T, FD, NT, WD, MG, XW, RP>), grid, block, dyn, ctx->stream, n, nb, map_mode, A->rowptr, \
                        A->col, (const T *)A->val, x, y, seg_out, done, A->is_long, nlb, lt, (const int *)A->xwin_lo, A->xwin_span, (const unsigned char *)A->rperm, \

@@ -43,10 +43,9 @@ struct mik_ctx {
     void *pub = nullptr;             // pinned, device-mapped, coherent: PUB_BYTES of scalar results + the ticket of the last publication (read_scalars)
     unsigned long long pub_seq = 0;
     static constexpr size_t PUB_BYTES = 4096;
-    int sweep_rev = 0;               // 1: the next SpMV launch walks its row-blocks from the end (set and cleared by the CG step)
     const void *spmv_ep_w = nullptr, *spmv_ep_c = nullptr;   // the next fused-dot SpMV launch stores y = A x + (*c) w and sums x .* y (set and cleared by mik_minres_step)
     const void *spmv_ep_z = nullptr;                         // ... and sums z .* y instead of x .* y (dot(r_shadow, A u) of BiCGStab(l): set and cleared by mik_bicgstab_step)
-    int tuning[32] = {0};            // development knobs of THIS context (include/mik_dev.h): a copy of the defaults at creation, mik_ctx_set_tuning
+    int tuning[MIK_KNOB_COUNT] = {0};   // development knobs of THIS context (include/mik_dev.h): a copy of the defaults at creation, mik_ctx_set_tuning
     static constexpr size_t COEF_BYTES = 8192;      // [0, 4096): coefficient blocks of the callers; the tail: scratch of mik_safe_norm_slow
     static constexpr size_t COEF_SAFE_SLOT = 4096;  // byte offset of that scratch
     // whole-iteration handles (mik_bicgstab / mik_minres) still alive: mik_ctx_destroy frees them, so that a host finalizer which
@@ -120,7 +119,7 @@ template <typename T> __host__ __device__ static inline bool mik_nrm_in_range(T 
 template <typename T> int mik_safe_norm_slow(mik_ctx *ctx, int64_t n, const T *x, T *out);
 
 extern thread_local std::string g_mik_create_error;
-extern int g_mik_tuning[32];  // DEFAULTS of the development knobs (what a new context starts with; mik_set_tuning also writes every live context)
+extern int g_mik_tuning[MIK_KNOB_COUNT];  // DEFAULTS of the development knobs (what a new context starts with; mik_set_tuning also writes every live context)
 
 int mik_fail(mik_ctx *ctx, int code, const char *fmt, ...);
 // operator upload (mik_core.hip / mik_upload.hip)
@@ -374,10 +373,10 @@ __device__ __forceinline__ int xcd_remap(int b, int nb)
 
 // Wait for everything enqueued on the ctx stream.  hipStreamSynchronize parks the host thread when the queue
 // is not about to drain and takes hundreds of microseconds to come back -- more than the kernels of one solver
-// iteration -- so the per-iteration scalar reads spin on an event instead (tuning[3] = 1: plain synchronize).
+// iteration -- so the per-iteration scalar reads spin on an event instead (development knob MIK_KNOB_HOST_WAIT bit 1: plain synchronize).
 static inline hipError_t mik_wait(mik_ctx *ctx)
 {
-    if (ctx->tuning[3] == 1 || !ctx->wait_event) return hipStreamSynchronize(ctx->stream);
+    if ((ctx->tuning[MIK_KNOB_HOST_WAIT] & 2) || !ctx->wait_event) return hipStreamSynchronize(ctx->stream);
     hipError_t e = hipEventRecord(ctx->wait_event, ctx->stream);
     if (e != hipSuccess) return e;
     while ((e = hipEventQuery(ctx->wait_event)) == hipErrorNotReady) {
@@ -410,7 +409,7 @@ __global__ __launch_bounds__(64) void k_publish(const T *__restrict__ src, int c
 
 template <typename T> static inline int mik_read_scalars(mik_ctx *ctx, const T *dev, int count, T *host_out)
 {
-    if (ctx->tuning[10] == 1 || !ctx->pub || sizeof(T) * (size_t)count > mik_ctx::PUB_BYTES) {
+    if ((ctx->tuning[MIK_KNOB_HOST_WAIT] & 1) || !ctx->pub || sizeof(T) * (size_t)count > mik_ctx::PUB_BYTES) {
         MIK_HIP(ctx, hipMemcpyAsync(ctx->coef_host, dev, sizeof(T) * count, hipMemcpyDeviceToHost, ctx->stream));
         MIK_HIP(ctx, mik_wait(ctx));
         memcpy(host_out, ctx->coef_host, sizeof(T) * count);

@@ -26,17 +26,14 @@
 
 template <typename T, bool VEC, typename Op>
 __global__ __launch_bounds__(MIK_BLOCK) void k_map(int64_t n, int64_t nseg, Op op, T *__restrict__ seg_out,
-                                                    const int *__restrict__ done, int rev)
+                                                    const int *__restrict__ done)
 {
     if (done && *done) return;
     constexpr int W = VT<T>::W;
     constexpr int L = MIK_RED_L;
     constexpr int64_t SEG = (int64_t)MIK_BLOCK * W * L;
     __shared__ T lds4[4];
-    for (int64_t s0 = blockIdx.x; s0 < nseg; s0 += gridDim.x) {
-        // rev: the sweep runs from the END of the vectors (workgroups are dispatched in index order), where the previous sweep
-        // has just been -- what it left in the Infinity Cache is met first.  Segment sums keep their slots: same bits.
-        const int64_t s = rev ? nseg - 1 - s0 : s0;
+    for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
         const int64_t base = s * SEG + (int64_t)W * threadIdx.x;
         T acc = T(0);
 #pragma unroll
@@ -153,15 +150,15 @@ static inline int launch_map_pro(mik_ctx *ctx, int64_t n, Op op, bool vec, T *se
 
 // host-side launcher of k_map: one workgroup per segment, capped grid with a grid-stride loop
 template <typename T, typename Op>
-static inline int launch_map(mik_ctx *ctx, int64_t n, Op op, bool vec, T *seg_out, const int *done, bool rev = false)
+static inline int launch_map(mik_ctx *ctx, int64_t n, Op op, bool vec, T *seg_out, const int *done)
 {
     const int64_t nseg = mik_nseg<T>(n);
     if (nseg == 0) return MIK_OK;
     const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
     if (vec)
-        hipLaunchKernelGGL((k_map<T, true, Op>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, seg_out, done, rev ? 1 : 0);
+        hipLaunchKernelGGL((k_map<T, true, Op>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, seg_out, done);
     else
-        hipLaunchKernelGGL((k_map<T, false, Op>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, seg_out, done, rev ? 1 : 0);
+        hipLaunchKernelGGL((k_map<T, false, Op>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, seg_out, done);
     MIK_LAUNCH_CHECK(ctx);
     return MIK_OK;
 }

@@ -96,23 +96,19 @@ extern "C" int mik_hessenberg_ldiv(int dtype, void *H, int64_t ldh, int width, v
 // gemv-N and orthogonalisation
 // =============================================================================================
 // Stream the Krylov basis past the caches when it cannot stay resident anyway (k columns exceed the 256 MB
-// Infinity Cache), so that the vector being orthogonalised does.  tuning[13] bits switch the hints off for A/B runs.
+// Infinity Cache), so that the vector being orthogonalised does.  
 template <typename T> static inline int mik_basis_nt(const mik_ctx *ctx, int64_t n, int k, int bit)
 {
-    if (ctx->tuning[13] & bit) return 0;
     return (double)n * (double)k * sizeof(T) > 192.0e6 ? 1 : 0;
 }
-// Cache hints of a pass of the multi-launch Modified Gram-Schmidt chain (OpMgsPass::nt).  MIK_MGS_HINTS (development, read once): an explicit
-// mask for A/B runs.  Default: the column that is subtracted in this pass and not needed again is streamed; when three vectors cannot
-// share the 256 MB Infinity Cache anyway, w is streamed too (load and store), so that the column projected on in this pass -- the one
-// the NEXT pass subtracts -- is what the cache keeps.  Measured at 256^3 fp64 (gmres!(30), 60 inner iterations, one box,
-// scripts/gpu_call2.sh): mask 0: 1,879 us per inner iteration, 1 (v): 1,651, 3 (v, z): 1,684, 9: 1,648, 5: 1,660, 11: 1,686, 15 (all): 1,835,
-// 13 (v, w): 1,622.
+// Cache hints of a pass of the multi-launch Modified Gram-Schmidt chain (OpMgsPass::nt: 1 = v, 2 = z, 4 = w load, 8 = w store non-temporal).
+// The column that is subtracted in this pass and not needed again is streamed; when three vectors cannot share the 256 MB Infinity Cache
+// anyway, w is streamed too (load and store), so that the column projected on in this pass -- the one the NEXT pass subtracts -- is what
+// the cache keeps.  Measured at 256^3 fp64 (gmres!(30), 60 inner iterations, one box, round 5): mask 0: 1,879 us per inner iteration,
+// 1 (v): 1,651, 3 (v, z): 1,684, 9: 1,648, 5: 1,660, 11: 1,686, 15 (all): 1,835, 13 (v, w): 1,622.
 static inline int mik_mgs_pass_hints(const mik_ctx *ctx, int64_t n, size_t es)
 {
-    static const int env = [] { const char *e = getenv("MIK_MGS_HINTS"); return e ? atoi(e) : -1; }();
-    if (env >= 0) return env;
-    if (ctx->tuning[13] & 1) return 0;
+    (void)ctx;
     return (double)n * (double)es > 96.0e6 ? 13 : 1;
 }
 
@@ -219,7 +215,7 @@ static int orthogonalize_enqueue(mik_ctx *ctx, int64_t n, int k, const T *V, int
     if (cols) for (int i = 0; i < k; ++i) vec = vec && mik_aligned16(cols[i]);
     OpDot<T> dn{w, w};
 
-    if (method == MIK_MGS && nseg <= 1024 && ctx->tuning[5] != 1) {
+    if (method == MIK_MGS && nseg <= 1024 && ctx->tuning[MIK_KNOB_GS] != 1) {
         // src/orthogonalize.jl:69-76, launch-lean form for n up to ~1M: every pass finalises the
         // previous pass's reduction itself (k_map_pro), so the chain is k + 2 launches instead of
         // 2k + 3.  Segment sums ping-pong between two buffers (a pass reads one while writing the other).
@@ -615,8 +611,7 @@ struct CgProfileScope {
 // u .= r .+ beta .* u: streaming them past L2 (non-temporal) leaves the cache to the operator's gather and
 // took the in-loop SpMV from 322 to 307 us and the step from 546 to 507 us at 256^3.
 // bits 0-2: xpby {r load, u load, u store}; bits 3-7: update {x, c load, u load, r load, r store}.
-// tuning[7]: 0 = default, < 0 = all temporal, > 0 = explicit mask.  Defaults (sweeps of single-bit flips inside the CG loop at
-// 256^3, scripts/hint_sweep.py): 57 for the classic step; 248 when x .+= alpha .* u rides on the next sweep over u (OpXpbyX /
+// Masks (found by sweeps of single-bit flips inside the CG loop at 256^3 in round 2): 57 for the classic step; 248 when x .+= alpha .* u rides on the next sweep over u (OpXpbyX /
 // OpCgUpdateR: bit 3 = x of that sweep): x, c and both directions of r in the update streamed, r read with the default policy by
 // the sweep that follows.  With k_spmv_sdiab2 the r STORE is the bit that matters: streamed, it leaves the Infinity Cache to
 // what the SpMV reads (in-loop SpMV 62 -> 48 us = its back-to-back time; 121 -> 249: 4,330 -> 4,520 it/s), and r then read
@@ -625,20 +620,8 @@ struct CgProfileScope {
 // loop 10 us per step.)
 static inline int cg_stream_hints(const mik_ctx *ctx, bool fused_x = false, const mik_csr *A = nullptr)
 {
-    const int k = ctx->tuning[7];
-    return k == 0 ? (fused_x ? (mik_spmv_is_light(A) ? 248 : 121) : 57) : (k < 0 ? 0 : k);
-}
-
-// Development knob 27: direction of the three streaming launches of a plain CG step.  Workgroups are dispatched in index
-// order; a launch that starts where the previous one ended meets what that one left in the 256 MB Infinity Cache.
-// bit 0 / 1 / 2: the u sweep / the SpMV / the update walk from the END of the vectors; 8: every launch the other way
-// round than the one before it.  Results never depend on it (partials keep their slots).
-static inline bool cg_sweep_rev(mik_cg *it, int which)
-{
-    const int k = it->ctx->tuning[27];
-    if (k == 0) return false;
-    if (k & 8) return (it->sweeps++ & 1u) != 0;
-    return ((k >> which) & 1) != 0;
+    (void)ctx;
+    return fused_x ? (mik_spmv_is_light(A) ? 248 : 121) : 57;
 }
 
 // One iterate() = HEAD (u = r + beta u [after c = Pl \ r, rho]; c = A u; alpha) + TAIL (x, r update; residual, stopping test).
@@ -688,7 +671,7 @@ template <typename T> static int cg_enqueue_head(mik_cg *it)
         CgProfileScope ps(it, 1);
         if (it->fuse_x) {   // ... and x .+= alpha .* u of the previous step, on the u this sweep reads anyway (OpXpbyX)
             OpXpbyX<T> op{r, u, x, coef_ptr<T>(&d->beta), coef_ptr<T>(&d->alpha), done, &d->x_pending, cg_stream_hints(ctx, true, it->A) & 15};
-            MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, (const int *)nullptr, cg_sweep_rev(it, 0))));
+            MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, (const int *)nullptr)));
         } else {
             OpXpby<T> op{r, u, coef_ptr<T>(&d->beta), cg_stream_hints(ctx) & 7};
             MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)nullptr, done)));
@@ -698,9 +681,7 @@ template <typename T> static int cg_enqueue_head(mik_cg *it)
     if (it->A) {
         {
             CgProfileScope ps(it, 0);
-            ctx->sweep_rev = (!pcg && it->fuse_x && cg_sweep_rev(it, 1)) ? 1 : 0;
             const int rc_spmv = mik_spmv_launch<T>(ctx, it->A, u, c, true, (T *)it->seg_spmv, done);
-            ctx->sweep_rev = 0;
             MIK_TRY(rc_spmv);
         }
         hipLaunchKernelGGL((k_cg_fin_alpha<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)it->seg_spmv, nb, d, pcg, (FinScratch<T> *)it->fin);
@@ -746,7 +727,7 @@ template <typename T> static int cg_enqueue_tail(mik_cg *it, long long it_next, 
             // c too (bits 5, 6; round 4): c = Pl \\ r stored with the default policy shares the 256 MB Infinity Cache with the u the head writes for the SpMV --
             // streamed, the in-loop SpMV runs at its back-to-back time (73 -> 52 us) and this sweep pays most of it back (99 -> 116 us): 280.7 -> 275.6 us
             // per step, ten words per row + the operator at the copy ceiling (profiles/r04_pcg_kernel_stats.txt).
-            OpPcgUpdateR<T> up{r, c, (const T *)it->diag, coef_ptr<T>(&d->alpha), ctx->tuning[7] == 0 ? 120 : (ctx->tuning[7] < 0 ? 0 : ctx->tuning[7] & 120)};
+            OpPcgUpdateR<T> up{r, c, (const T *)it->diag, coef_ptr<T>(&d->alpha), 120};
             MIK_TRY((launch_map2<T>(ctx, n, up, vec, (T *)it->seg_vec, (T *)it->seg_vec2, done)));
         }
         it->seq += 1;
@@ -759,7 +740,7 @@ template <typename T> static int cg_enqueue_tail(mik_cg *it, long long it_next, 
         CgProfileScope ps(it, 2);
         if (it->fuse_x) {
             OpCgUpdateR<T> up{r, c, coef_ptr<T>(&d->alpha), cg_stream_hints(ctx, true, it->A) >> 3};
-            MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done, !it->diag && !it->pl_fn && cg_sweep_rev(it, 2))));
+            MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done)));
         } else {
             OpCgUpdate<T> up{x, r, u, c, coef_ptr<T>(&d->alpha), cg_stream_hints(ctx) >> 3};
             MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)it->seg_vec, done)));
@@ -862,8 +843,8 @@ static int cg_create_common(mik_ctx *ctx, const mik_csr *A, int dtype, int64_t n
     it->op_mul = op_mul; it->op_user = op_user; it->pl_fn = pl_fn; it->pl_user = pl_user;
     it->x = x; it->b = b; it->u = u; it->r = r; it->c = c; it->diag = jacobi_diag;
     it->maxiter = maxiter;
-    it->fuse_x = A != nullptr && !pl_fn && ctx->tuning[23] == 0;       // development knob 23: 1 = x updated by the step's own sweep
-    it->pcg_fused = it->fuse_x && jacobi_diag != nullptr && ctx->tuning[22] == 0;   // development knob 22: 1 = the three-sweep PCG step
+    it->fuse_x = A != nullptr && !pl_fn && (ctx->tuning[MIK_KNOB_CG_STEP] & 1) == 0;       // development knob MIK_KNOB_CG_STEP bit 0: x updated by the step's own sweep
+    it->pcg_fused = it->fuse_x && jacobi_diag != nullptr && (ctx->tuning[MIK_KNOB_CG_STEP] & 2) == 0;   // bit 1: the three-sweep PCG step
     const size_t es = mik_dtype_size(dtype);
     const int64_t nseg = dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
     const int64_t nb = mik_spmv_nwg(n);
@@ -985,7 +966,7 @@ static int cg_iterate_many_impl(mik_cg *it, int64_t iteration, int64_t max_steps
     CgMirror m;
     // the head of the step AFTER this call goes on the stream before the host waits (never with host callbacks, whose call
     // count the caller may observe; development knob 9: 1 = off)
-    const bool ahead_ok = ctx->tuning[9] == 0 && !it->op_mul && !it->pl_fn && iteration + max_steps < it->maxiter;
+    const bool ahead_ok = ctx->tuning[MIK_KNOB_NO_LOOKAHEAD] == 0 && !it->op_mul && !it->pl_fn && iteration + max_steps < it->maxiter;
     for (int64_t j0 = 0;;) {
         for (int64_t j = j0; j < max_steps; ++j) {
             if (!it->head_ahead) MIK_TRY(cg_enqueue_head<T>(it));
@@ -1127,10 +1108,6 @@ struct mik_gmres {
     int64_t maxiter = 0, mv_products = 0;
     bool dist = false;        // row-partitioned: SpMV input goes through part.x_ext + halo(), sums through reduce()
     mik_partition part{};
-    // launch-bound sizes: expand! + the Gram-Schmidt chain + the D2H of (h, nrm) of column k as ONE hipGraph
-    std::vector<hipGraphExec_t> graphs;       // index k = 1..restart
-    const void *graph_partials = nullptr;     // ctx->partials the graphs were captured against
-    bool graph_off = false;                   // capture / instantiation failed once: plain stream launches from then on
     // single-launch Modified Gram-Schmidt (k_mgs_fused): slot buffers [2][restart + 1][256] and the host-mapped mirror of (h, nrm)
     void *mgs_P = nullptr;
     int mgs_G = 1, mgs_stride = 256;  // segments per workgroup of the single-launch kernels; slots per row of mgs_P
@@ -1147,7 +1124,6 @@ struct mik_gmres {
 };
 
 template <typename T> static int gather_launch(mik_ctx *ctx, int64_t m, const int *idx, const T *x, T *out, const int *done);
-static void gm_drop_graphs(mik_gmres *g);
 
 // mul!(dst, A, src) on this rank's rows; with a partition, src is staged in x_ext and the halo callback
 // fills its ghost tail before the local block is applied.                src/gmres.jl:245,287,293,301
@@ -1597,11 +1573,11 @@ static int gmres_create_common(mik_ctx *ctx, const mik_csr *A, void *x, const vo
         const int64_t nseg = dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
         // single-launch Gram-Schmidt: up to 2048 reduction segments, G = 1 / 2 / 4 / 8 of them per workgroup (<= 256 workgroups, one
         // per CU); more than 256 segments need the library's own 16-byte aligned V (always the case here)
-        if (!part && nseg >= 1 && nseg <= 2048 && restart <= 254 && ctx->tuning[31] == 0 && (nseg <= 256 || g->ldv % 4 == 0)) {   // development knob 31: 1 = chains only
+        if (!part && nseg >= 1 && nseg <= 2048 && restart <= 254 && (nseg <= 256 || g->ldv % 4 == 0)) {
             g->mgs_G = nseg <= 256 ? 1 : nseg <= 512 ? 2 : nseg <= 1024 ? 4 : 8;
             g->mgs_stride = std::max<int>(256, (int)((nseg + g->mgs_G - 1) / g->mgs_G) * g->mgs_G);
             // k_cgs_fused: one more row per round (the final h values); DGKS: up to 3 rounds in the kernel
-            g->mgs_rounds = orth_method == MIK_DGKS ? (ctx->tuning[21] > 0 ? std::min(ctx->tuning[21], 3) : 3) : 1;   // development knob 21: DGKS rounds in the kernel
+            g->mgs_rounds = orth_method == MIK_DGKS ? (ctx->tuning[MIK_KNOB_GS] == 3 ? 1 : 3) : 1;   // DGKS rounds the kernel runs before it hands back to the host loop (MIK_KNOB_GS = 3: one)
             const size_t pbytes = es * 2 * (size_t)g->mgs_rounds * (size_t)(restart + 2) * (size_t)g->mgs_stride;
             if ((e = hipMalloc(&g->mgs_P, pbytes)) != hipSuccess || (e = hipMemsetAsync(g->mgs_P, 0xFF, pbytes, ctx->stream)) != hipSuccess ||
                 (e = hipMalloc((void **)&g->xl_chk, 2 * sizeof(unsigned))) != hipSuccess || (e = hipMemsetAsync(g->xl_chk, 0, 2 * sizeof(unsigned), ctx->stream)) != hipSuccess ||
@@ -1660,7 +1636,6 @@ extern "C" int mik_gmres_destroy(mik_gmres *g)
 {
     if (!g) return MIK_OK;
     if (g->ctx) (void)hipStreamSynchronize(g->ctx->stream);
-    gm_drop_graphs(g);
     if (g->mgs_P) (void)hipFree(g->mgs_P);
     if (g->xl_chk) (void)hipFree(g->xl_chk);
     if (g->mgs_mirror) (void)hipHostFree(g->mgs_mirror);
@@ -1683,59 +1658,6 @@ template <typename T> static int gm_expand(mik_gmres *g, T *vk, T *vk1)
         MIK_TRY(gm_spmv<T>(g, vk, vk1));                                  // V[:, k+1] = A * V[:, k]   :287
     }
     if (gm_has_pl(g)) MIK_TRY(gm_ldiv<T>(g, 0, vk1, vk1));              // ldiv!(Pl, nextV)  :294 / :303
-    return MIK_OK;
-}
-
-static void gm_drop_graphs(mik_gmres *g)
-{
-    for (hipGraphExec_t e : g->graphs)
-        if (e) (void)hipGraphExecDestroy(e);
-    g->graphs.clear();
-}
-
-// Column k of the Arnoldi process as one graph launch (n up to ~1M: the k + 3 small kernels are bound by their
-// launch / dependency latency, not by bandwidth).  Captured once per k and handle; results are those of the same
-// kernels launched one by one.  MEASURED (configs[2], n = 125 k, ROCm 7.2): no gain -- MGS 101 vs 100-112 us per
-// inner iteration, CGS 67 vs 60 us: the dependent-kernel boundary on the GPU (~3.7 us per pass inside a graph,
-// 4.3 us from the stream) is the cost, not host launch overhead, and a graph launch itself costs more than the
-// 6 launches of the CGS chain.  Therefore OFF by default; mik_set_tuning(5, 3) enables it.  *ran = false if the graph path is unavailable (the caller falls back).
-template <typename T> static int gm_step_graph(mik_gmres *g, int k, T *vk, T *vk1, T *h_out, T *nrm_out, bool *ran)
-{
-    *ran = false;
-    mik_ctx *ctx = g->ctx;
-    T *V = (T *)g->V;
-    MIK_TRY(mik_ensure_partials(ctx, orthogonalize_workspace<T>(g->n, g->restart)));
-    if (g->graph_partials != ctx->partials) {        // the reduction workspace moved: captured pointers are stale
-        gm_drop_graphs(g);
-        g->graph_partials = ctx->partials;
-    }
-    if (g->graphs.empty()) g->graphs.assign((size_t)g->restart + 1, nullptr);
-    hipGraphExec_t &exec = g->graphs[(size_t)k];
-    if (!exec) {
-        hipGraph_t graph = nullptr;
-        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); g->graph_off = true; return MIK_OK; }
-        int rc = gm_expand<T>(g, vk, vk1);
-        if (!rc) rc = orthogonalize_enqueue<T>(ctx, g->n, k, V, g->ldv, vk1, g->method);
-        hipError_t e = hipSuccess;
-        if (!rc) e = hipMemcpyAsync(ctx->coef_host, ctx->coef, sizeof(T) * (size_t)(k + 1), hipMemcpyDeviceToHost, ctx->stream);
-        hipError_t e2 = hipStreamEndCapture(ctx->stream, &graph);
-        if (rc || e != hipSuccess || e2 != hipSuccess || !graph ||
-            hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            if (graph) (void)hipGraphDestroy(graph);
-            exec = nullptr;
-            g->graph_off = true;
-            return MIK_OK;
-        }
-        (void)hipGraphDestroy(graph);
-    }
-    MIK_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
-    MIK_HIP(ctx, mik_wait(ctx));
-    const T *out = (const T *)ctx->coef_host;
-    for (int j = 0; j < k; ++j) h_out[j] = out[j];
-    *nrm_out = out[k];
-    *ran = true;
-    if (out[k] != out[k]) MIK_TRY(orth_rescale<T>(ctx, g->n, vk1, nrm_out));
     return MIK_OK;
 }
 
@@ -1775,7 +1697,7 @@ template <typename T> static int gm_fused_enqueue(mik_gmres *g, int k, int slot)
     // of at most 512 KB per pass: every column then comes through ONE XCD's share of the fabric (~1 MB per us).  fe_shell (363 KB columns):
     // GMRES(50) 64.2 -> 50.9 us per inner iteration; configs[2] (1 MB columns) would lose (36.5 -> 47.8 us) and keeps the device-wide
     // form.  Development knob 5 = 4: the device-wide form at every size.
-    const bool xl = g->method == MIK_MGS && G == 1 && vec && m <= 128 && ((size_t)n * sizeof(T) <= (1u << 19) || ctx->tuning[5] == 5) && !g->xl_off && ctx->tuning[5] != 4 && g->xl_chk;   // (knob 5 = 5: whatever the column size)
+    const bool xl = g->method == MIK_MGS && G == 1 && vec && m <= 128 && ((size_t)n * sizeof(T) <= (1u << 19) || ctx->tuning[MIK_KNOB_GS] == 5) && !g->xl_off && ctx->tuning[MIK_KNOB_GS] != 4 && g->xl_chk;   // (knob 5 = 5: whatever the column size)
     g->xl_last = xl;
     if (xl) {
         hipLaunchKernelGGL((k_mgs_fused<T, true, 1, true>), dim3(8 * m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart,
@@ -1816,7 +1738,7 @@ template <typename T> static int gm_fused_wait(mik_gmres *g, int k, int slot, T 
         __builtin_ia32_pause();
 #endif
     }
-    if (mir->err || ctx->tuning[30] == 1) return MIK_GS_TIMEOUT;        // (development knob 30: pretend it happened)
+    if (mir->err || ctx->tuning[MIK_KNOB_GS_TIMEOUT] == 1) return MIK_GS_TIMEOUT;        // (development knob MIK_KNOB_GS_TIMEOUT: pretend it happened)
     // a workgroup gave up waiting for a slot (GPU shared with other work?): the caller redoes the column
     const T *out = reinterpret_cast<const T *>(mir + 1);
     for (int j = 0; j < k; ++j) h_out[j] = out[j];
@@ -1858,18 +1780,15 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
 
     // expand! (:64, :285-304), then H[k+1, k] = orthogonalize_and_normalize!(V[:, 1:k], V[:, k+1], H[1:k, k], orth_meth)  :68-73
     T nrm;
-    bool ran = false;
-    if (ctx->tuning[5] == 3 && !g->dist && !g->graph_off && g->method != MIK_DGKS && mik_nseg<T>(g->n) <= 1024 && !g->op_mul && !g->pl_fn && !g->pr_fn)
-        MIK_TRY(gm_step_graph<T>(g, k, vk, vk1, &Hat(0, k - 1), &nrm, &ran));
-    if (!ran) {
-        if (g->mgs_P && !g->dist && !g->fused_off && (ctx->tuning[5] == 0 || ctx->tuning[5] >= 4)) {    // tuning[5]: 1 / 2 = the multi-launch chains, 4 = single launch on all XCDs
+    {
+        if (g->mgs_P && !g->dist && !g->fused_off && (ctx->tuning[MIK_KNOB_GS] == 0 || ctx->tuning[MIK_KNOB_GS] >= 4)) {    // MIK_KNOB_GS: 1 / 2 = the multi-launch chains, 4 = single launch on all XCDs
             // single-launch Gram-Schmidt, one column ahead of the host: column k is on the stream already if the previous
             // call put it there; column k + 1 goes on the stream BEFORE this call waits for column k (never across a restart,
             // never with host callbacks in expand!, whose call count the caller may observe)
             const int slot = g->pre_k == k ? g->pre_slot : 0;
             if (g->pre_k != k) MIK_TRY(gm_fused_enqueue<T>(g, k, slot));
             g->pre_k = 0;
-            const bool ahead = k < m && iteration + 1 < g->maxiter && !g->op_mul && !g->pl_fn && !g->pr_fn && ctx->tuning[9] == 0;
+            const bool ahead = k < m && iteration + 1 < g->maxiter && !g->op_mul && !g->pl_fn && !g->pr_fn && ctx->tuning[MIK_KNOB_NO_LOOKAHEAD] == 0;
             if (ahead) MIK_TRY(gm_fused_enqueue<T>(g, k + 1, slot ^ 1));
             bool rescaled = false;
             const int rcw = gm_fused_wait<T>(g, k, slot, &Hat(0, k - 1), &nrm, &rescaled);
@@ -2327,7 +2246,7 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
         MIK_LAUNCH_CHECK(ctx);
         return MIK_OK;
     case 2: {  // step C
-        if (bs.fuse_x && ctx->tuning[26] == 0) {   // alpha inside the sweep, its bookkeeping inside the finaliser (knob 26 = 1: the separate k_cgd_alpha)
+        if (bs.fuse_x && (ctx->tuning[MIK_KNOB_CG_STEP] & 8) == 0) {   // alpha inside the sweep, its bookkeeping inside the finaliser (MIK_KNOB_CG_STEP bit 3: the separate k_cgd_alpha)
             OpCgUpdateR<T, CoefAlphaRanks<T>> up{r, c, CoefAlphaRanks<T>{(const T *)it->dot_all, it->nranks, &d->res}, cg_stream_hints(ctx, true, bs.A) >> 3};
             MIK_TRY((launch_map<T>(ctx, n, up, vec, (T *)bs.seg_vec, done)));
             hipLaunchKernelGGL((k_cgd_fin_slot_alpha<T>), dim3(MIK_FIN_WGS), dim3(64), 0, ctx->stream, (const T *)bs.seg_vec, nseg, rr_slot, done,

@@ -474,7 +474,7 @@ template <> __device__ __forceinline__ void buffer_put2<float>(__amdgpu_buffer_r
 }
 
 template <typename T, bool FUSE_DOT, bool NT, int NS, int CQ>
-__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab2(int n, int ncols, int koff, int pb0, int np, int nfull, int sshift, int nslices, int rev,
+__global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab2(int n, int ncols, int koff, int pb0, int np, int nfull, int sshift, int nslices,
                                                            const SdiaSliceRec *__restrict__ recs, const SdiaPattern<T> *__restrict__ pats,
                                                            const unsigned char *__restrict__ mask, const T *__restrict__ x, T *__restrict__ y,
                                                            T *__restrict__ seg_out, const int *__restrict__ done,
@@ -494,8 +494,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_sdiab2(int n, int ncols, int
     const __amdgpu_buffer_rsrc_t xw = __builtin_amdgcn_make_buffer_rsrc((void *)x, (short)0, (int)((unsigned)ncols * ES), (int)0x00020000);
     const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc((void *)mask, (short)0, n, (int)0x00020000);
     const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc((void *)y, (short)0, (int)((unsigned)n * ES), (int)0x00020000);
-    const int vb0 = min((int)blockIdx.x, np - 1);                         // past the end: the last pair once more (same bits)
-    const int vb = rev ? np - 1 - vb0 : vb0;                              // rev: from the end of the vectors (k_map)
+    const int vb = min((int)blockIdx.x, np - 1);                          // past the end: the last pair once more (same bits)
     const int pb = pb0 + spmv_block_map_shift(vb, nfull, sshift);         // slices 2 pb and 2 pb + 1
     const int sl = min(2 * pb + (w >> 1), nslices - 1);                   // this wave's slice (a pair may lack its second one)
     const int r0 = pb * (2 * MIK_BLOCK) + w * 128 + 2 * lane;             // rows r0, r0 + 1 (n is even: both in range or neither)

@@ -326,7 +326,7 @@ template <typename T> static bool bicg_fuses(const mik_bicgstab *it)
 {
     if (!it->fuse || !mik_spmv_has_epilogue(it->A)) return false;     // (development knob 25 = 2: no epilogues)
     const int64_t nseg = mik_nseg<T>(it->n), nb = mik_spmv_nwg(it->n);
-    const bool lean = nseg <= 1024 && it->ctx->tuning[25] == 0;
+    const bool lean = nseg <= 1024 && it->ctx->tuning[MIK_KNOB_SOLVER_FORM] == 0;
     return !lean || nb <= 1024;
 }
 
@@ -348,8 +348,8 @@ template <typename T> static int bicg_step_impl(mik_bicgstab *it, T *residual)
     };
     auto ldiv = [&](T *v) { return it->pl_diag ? mik_divide(ctx, it->dtype, n, v, it->pl_diag, v) : MIK_OK; };
     const bool blockvec = mik_aligned16(us) && mik_aligned16(rs) && mik_aligned16(x) && (it->ldu % VT<T>::W == 0) && (it->ldr % VT<T>::W == 0);
-    const bool lean = nseg <= 1024 && ctx->tuning[25] == 0;   // the sweeps finalise their producers' reductions themselves (k_map_with; development knob 25 = 1: separate finaliser launches)
-    const int bnt = ctx->tuning[7] < 0 ? 0 : (ctx->tuning[7] >= 16 ? (ctx->tuning[7] >> 4) & 7 : 7);   // the block sweeps stream everything -- also the column the SpMV behind them reads: with 3 to 9 columns in flight the Infinity Cache keeps too little of it to matter (mask 3, that store cached: 1,174-1,177 us; 7: 1,160-1,169; loads only: 1,217; development knob 7 < 0: all cached; bits 4-6: explicit mask)
+    const bool lean = nseg <= 1024 && ctx->tuning[MIK_KNOB_SOLVER_FORM] == 0;   // the sweeps finalise their producers' reductions themselves (k_map_with; development knob 25 = 1: separate finaliser launches)
+    const int bnt = 7;   // the block sweeps stream everything -- also the column the SpMV behind them reads: with 3 to 9 columns in flight the Infinity Cache keeps too little of it to matter (mask 3, that store cached: 1,174-1,177 us; 7: 1,160-1,169; loads only: 1,217; development knob 7 < 0: all cached; bits 4-6: explicit mask)
     // sigma = dot(r_shadow, A u) (:100) and, from the second column on, rho = dot(r_shadow, A r) (:89) leave the SpMV launch that forms the
     // vector (epilogue dot(z, y), one partial per 256-row block: mik_bicgstab_dot_shape) -- a sweep over two vectors and a launch less each
     const int64_t nb = mik_spmv_nwg(n);
@@ -422,8 +422,8 @@ template <typename T> static int bicg_step_impl(mik_bicgstab *it, T *residual)
         const bool vec = mik_aligned16(us) && mik_aligned16(rs) && mik_aligned16(x) && (it->ldu % VT<T>::W == 0) && (it->ldr % VT<T>::W == 0);
         BicgGamma<T> gm{};
         // (+ the segment sums of dot(r_shadow, new residual): rho of the next step's first column, while the residual is in registers)
-        const bool keep = ctx->tuning[25] != 2 && (!vec || mik_aligned16(sh));
-        const int mrnt = ctx->tuning[7] > 0 ? (ctx->tuning[7] & 15) : (ctx->tuning[7] < 0 ? 0 : 3);      // development knob 7: hint mask of the MR sweep
+        const bool keep = ctx->tuning[MIK_KNOB_SOLVER_FORM] != 2 && (!vec || mik_aligned16(sh));
+        const int mrnt = 3;      // hint mask of the MR sweep
         if (vec) hipLaunchKernelGGL((k_bicg_mr<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, l, us, it->ldu, rs, it->ldr, x, gm, (T *)ctx->partials, (const T *)d->gamma,
                                     keep ? sh : (const T *)nullptr, (T *)it->rho_part, mrnt);
         else hipLaunchKernelGGL((k_bicg_mr<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, l, us, it->ldu, rs, it->ldr, x, gm, (T *)ctx->partials, (const T *)d->gamma,
@@ -621,7 +621,7 @@ struct mik_minres {
     void *dev = nullptr;            // MinresDev<T>
     MinresMirror *mirror = nullptr;
     unsigned long long seq = 0;
-    bool epilogue = false;          // the Lanczos step rides on the SpMV (mik_spmv_has_epilogue): proj has the SpMV-dot shape
+    bool epilogue = false;          // the three Lanczos vectors are 16-byte aligned: the Lanczos step may ride on the SpMV (minres_epilogue)
     void *fin = nullptr;            // FinScratch<T>: wave sums + ticket of the spread level-2 sum of proj
 };
 
@@ -649,7 +649,7 @@ extern "C" int mik_minres_create(mik_ctx *ctx, const mik_csr *A, void *x, void *
     mik_minres *it = new (std::nothrow) mik_minres();
     if (!it) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_minres_create: host allocation failed");
     it->ctx = ctx; it->A = A; it->dtype = A->dtype; it->skew = skew_hermitian ? 1 : 0; it->n = n; it->x = x;
-    it->epilogue = mik_spmv_has_epilogue(A) && mik_aligned16(v_prev) && mik_aligned16(v_curr) && mik_aligned16(v_next);
+    it->epilogue = mik_aligned16(v_prev) && mik_aligned16(v_curr) && mik_aligned16(v_next);   // the vectors allow it; whether the operator's kernel takes an epilogue is asked per step (minres_epilogue)
     it->v[0] = v_prev; it->v[1] = v_curr; it->v[2] = v_next;
     it->w[0] = w_prev; it->w[1] = w_curr; it->w[2] = w_next;
     (void)hipSetDevice(ctx->device);
@@ -700,6 +700,11 @@ template <typename T> static int minres_wait(mik_minres *it)
     }
 }
 
+// Does this step's Lanczos update ride on the SpMV launch?  Asked per step, like bicg_fuses: the operator's layout and the development knobs
+// may change between steps (mik_csr_set_layout, mik_set_tuning) -- the step then falls back to the separate sweep instead of failing, and
+// mik_minres_proj_shape reports the shape of the NEXT step's projection.
+static bool minres_epilogue(const mik_minres *it) { return it->epilogue && mik_spmv_has_epilogue(it->A); }
+
 template <typename T> static int minres_step_impl(mik_minres *it, int64_t iteration, T *resnorm)
 {
     mik_ctx *ctx = it->ctx;
@@ -710,10 +715,10 @@ template <typename T> static int minres_step_impl(mik_minres *it, int64_t iterat
     // The Lanczos step (:102-107) as the EPILOGUE of the SpMV where the operator's kernel takes one (mik_spmv_has_epilogue, round 4): v_next =
     // A v_curr - H[2] v_prev is stored once and proj = dot(v_curr, v_next) leaves the launch as one partial per 256-row block (the shape
     // of the dot fused into the CG SpMV: mik_minres_proj_shape) -- the sweep that re-read v_prev, v_next and v_curr is gone.
-    const bool ep = it->epilogue;
+    const bool ep = minres_epilogue(it);
     const int64_t na = ep ? mik_spmv_nwg(n) : nseg;           // partials of the projection
     MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(na + nseg, 1)));
-    const bool lean = na <= 1024 && nseg <= 1024 && ctx->tuning[25] == 0;   // the orthogonalisation sweep finalises the projection itself (k_map_with)
+    const bool lean = na <= 1024 && nseg <= 1024 && ctx->tuning[MIK_KNOB_SOLVER_FORM] == 0;   // the orthogonalisation sweep finalises the projection itself (k_map_with)
     T *part_a = (T *)ctx->partials, *part_b = lean ? part_a + na : part_a;
     if (ep) {
         ctx->spmv_ep_w = iteration > 1 ? v_prev : nullptr;   // (no v_prev in the first iteration: the plain fused dot)
@@ -747,7 +752,7 @@ template <typename T> static int minres_step_impl(mik_minres *it, int64_t iterat
     auto tail = [&]() {   // v_next /= H[4]; w_next = (v_curr - H[2] w_curr - H[1] w_prev) / H[3]; x += rhs[1] w_next   :113, :136-142
         const T *wc = iteration > 1 ? w_curr : nullptr, *wp = iteration > 2 ? w_prev : nullptr;
         OpMinresUpdate<T> op{v_next, v_curr, wc, wp, w_next, x, coef_ptr<T>(&d->inv_h3), coef_ptr<T>(&d->neg_h1), coef_ptr<T>(&d->neg_h0),
-                             coef_ptr<T>(&d->inv_h2), coef_ptr<T>(&d->rhs0), ctx->tuning[7] > 0 ? ctx->tuning[7] : (ctx->tuning[7] < 0 ? 0 : 15)};   // development knob 7: hint mask
+                             coef_ptr<T>(&d->inv_h2), coef_ptr<T>(&d->rhs0), 15};
         const bool vec = mik_aligned16(v_next) && mik_aligned16(v_curr) && mik_aligned16(w_next) && mik_aligned16(x) && (!wc || mik_aligned16(wc)) &&
                          (!wp || mik_aligned16(wp));
         return launch_map<T>(ctx, n, op, vec, (T *)nullptr, (const int *)&d->range);     // held back while the norm is being rescaled
@@ -772,7 +777,7 @@ template <typename T> static int minres_step_impl(mik_minres *it, int64_t iterat
 extern "C" int mik_minres_proj_shape(const mik_minres *it, int *W, int *L)
 {
     if (!it) return MIK_ERR_INVALID;
-    if (it->epilogue) return mik_spmv_dot_shape(W, L);
+    if (minres_epilogue(it)) return mik_spmv_dot_shape(W, L);
     return mik_reduce_shape(it->dtype, W, L);
 }
 

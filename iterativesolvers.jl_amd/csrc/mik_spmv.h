@@ -449,7 +449,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_spmv_rowblock(int n, int nb, int 
 // wave-instruction, the LDS image is the memory image), so staging costs no vector registers, no ds_write and no
 // VALU work; the stream is waited for with one vmcnt(0) before the barrier.
 //
-// Measured at 256^3 fp64 inside the CG loop (scripts/spmv_inloop.py, interleaved rounds): k_spmv_rowblock 302 us,
+// Measured at 256^3 fp64 inside the CG loop (round 2, interleaved rounds in one process): k_spmv_rowblock 302 us,
 // this layout staged through registers 299 us, filled by LDS-DMA 291 us (278 us back to back = 6.25 TB/s).  Also
 // built and measured: wave-private tiles (every wave stages its own 64 rows, no workgroup barrier at all) -- 354-380 us
 // in all four variants (row / entry gather, padded or not): the barriers were not what the workgroup tile was

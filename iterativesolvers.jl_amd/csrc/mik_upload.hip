@@ -409,10 +409,10 @@ int upload_device_t(mik_ctx *ctx, mik_csr *A, int64_t n_rows, int64_t n_cols, in
     UP_TRY(hipMemcpyAsync(&hs, d_st, sizeof(hs), hipMemcpyDeviceToHost, st));
     UP_TRY(hipStreamSynchronize(st));
     S.release(d_ptr); S.release(d_idx); S.release(d_val); S.release(cursor);       // the raw copy (2 GB at 256^3) is consumed
-    long_row = ctx->tuning[4] > 0 ? ctx->tuning[4] : MIK_LONG_ROW;
+    long_row = MIK_LONG_ROW;
     // the host path's business: duplicates, rows to split off -- and ANY row beyond 256 entries, which k_up_sort_rows does not sort
     // (whatever development knob 4 says: an unsorted row would break the ascending-column order = Julia's scatter order)
-    if (hs.dup || (hs.max_row > long_row && ctx->tuning[4] >= 0) || hs.max_row > 256) { rc = MIK_ERR_NOTIMPL; goto give_up; }
+    if (hs.dup || hs.max_row > long_row || hs.max_row > 256) { rc = MIK_ERR_NOTIMPL; goto give_up; }
     A->max_row_nnz = hs.max_row;
     A->max_rowblock_nnz = hs.max_rb;
     {
@@ -420,7 +420,7 @@ int upload_device_t(mik_ctx *ctx, mik_csr *A, int64_t n_rows, int64_t n_cols, in
         A->strip = (P >= 8 && P <= nb / 4) ? (int)P : 0;
     }
     // ---- the per-slice-offset layouts -------------------------------------------------------------------------
-    if (ctx->tuning[8] == 0 && ctx->tuning[12] == 0 && n_cols > 0) {
+    if ((ctx->tuning[MIK_KNOB_LAYOUTS] & 1) == 0 && (ctx->tuning[MIK_KNOB_LAYOUTS] & 4) == 0 && n_cols > 0) {
         int *doff = nullptr, *dtri = nullptr, *dptr = nullptr, *first_row = nullptr;
         unsigned char *mask = nullptr;
         SdiaPattern<T> *desc = nullptr;
@@ -440,13 +440,13 @@ int upload_device_t(mik_ctx *ctx, mik_csr *A, int64_t n_rows, int64_t n_cols, in
         // (the scan is in 32 bits: more than 2^31 slots cannot qualify anyway, and nnz < 2^31 bounds slots by the test below only if it did not wrap)
         if (!hs.sdia_bad && slots_total >= 0 && (int64_t)slots_total <= nnz + nnz / 8 + 8 * MIK_BLOCK && (int64_t)nb * 8 * MIK_BLOCK < INT32_MAX) {
             hipLaunchKernelGGL(k_up_row_masks, dim3(blocks_for(n_rows)), dim3(MIK_BLOCK), 0, st, A->rowptr, A->col, (long long)n_rows, doff, dptr, mask, first_row, d_st);
-            if (ctx->tuning[11] == 0)
+            if ((ctx->tuning[MIK_KNOB_LAYOUTS] & 2) == 0)
                 hipLaunchKernelGGL((k_up_row_constancy<T>), dim3(blocks_for(n_rows)), dim3(MIK_BLOCK), 0, st, A->rowptr, A->col, (const T *)A->val, (long long)n_rows,
                                    doff, dptr, first_row, d_st);
             UP_TRY(hipMemcpyAsync(&hs, d_st, sizeof(hs), hipMemcpyDeviceToHost, st));
             UP_TRY(hipStreamSynchronize(st));
             if (!hs.sdia_bad) {
-                const bool constant = ctx->tuning[11] == 0 && !hs.not_constant;
+                const bool constant = (ctx->tuning[MIK_KNOB_LAYOUTS] & 2) == 0 && !hs.not_constant;
                 if (constant) {
                     std::vector<unsigned char> hdesc((size_t)nb * sizeof(SdiaPattern<T>));
                     UP_TRY(S.alloc(&desc, sizeof(SdiaPattern<T>) * (size_t)nb));
@@ -725,7 +725,7 @@ template <typename T> static int build_sdiaw_device_t(mik_ctx *ctx, mik_csr *A)
 
 int mik_build_sdiaw_device(mik_ctx *ctx, mik_csr *A)
 {
-    if (!A->rowptr || A->n_long || A->sdia_val || A->sdia_pats || A->nnz <= 0 || ctx->tuning[8] != 0 || ctx->tuning[12] != 0) return MIK_OK;
+    if (!A->rowptr || A->n_long || A->sdia_val || A->sdia_pats || A->nnz <= 0 || (ctx->tuning[MIK_KNOB_LAYOUTS] & 1) != 0 || (ctx->tuning[MIK_KNOB_LAYOUTS] & 4) != 0) return MIK_OK;
     return A->dtype == MIK_F64 ? build_sdiaw_device_t<double>(ctx, A) : build_sdiaw_device_t<float>(ctx, A);
 }
 
@@ -756,7 +756,7 @@ template <typename T> static int build_jds_device_t(mik_ctx *ctx, mik_csr *A)
     const int64_t groups = total, short_nnz = A->nnz;
     if (groups <= 0 || hs.maxlen >= MIK_JDS_LONG || groups * W >= INT32_MAX) return MIK_OK;
     const int64_t jds_bytes = groups * W * (int64_t)(sizeof(T) + 4) + 2 * n_rows, csr_bytes = short_nnz * (int64_t)(sizeof(T) + 4) + 4 * n_rows;
-    if (ctx->tuning[28] != 2 && !((int64_t)hs.iters * 64 * 4 <= groups * 5 && (hs.maxlen > 32 || jds_bytes * 10 <= csr_bytes * 11))) return MIK_OK;
+    if ((ctx->tuning[MIK_KNOB_LAYOUTS] & 16) == 0 && !((int64_t)hs.iters * 64 * 4 <= groups * 5 && (hs.maxlen > 32 || jds_bytes * 10 <= csr_bytes * 11))) return MIK_OK;
     const size_t pad = 64 * 4 * (size_t)W;                  // = 64 * MIK_JDS_U * W: lanes without a group read (and gather through) the tail
     JD_TRY(S.alloc(&jcol, sizeof(int) * ((size_t)groups * W + pad)));
     JD_TRY(S.alloc(&jval, sizeof(T) * ((size_t)groups * W + pad)));
@@ -778,7 +778,7 @@ template <typename T> static int build_jds_device_t(mik_ctx *ctx, mik_csr *A)
 
 int mik_build_jds_device(mik_ctx *ctx, mik_csr *A)
 {
-    if (!A->rowptr || A->n_long || A->sdia_val || A->sdia_pats || A->sdiaw_pats || A->nnz <= 0 || ctx->tuning[8] != 0 || ctx->tuning[28] == 1)
+    if (!A->rowptr || A->n_long || A->sdia_val || A->sdia_pats || A->sdiaw_pats || A->nnz <= 0 || (ctx->tuning[MIK_KNOB_LAYOUTS] & 1) != 0 || (ctx->tuning[MIK_KNOB_LAYOUTS] & 8) != 0)
         return MIK_OK;
     return A->dtype == MIK_F64 ? build_jds_device_t<double>(ctx, A) : build_jds_device_t<float>(ctx, A);
 }
@@ -809,8 +809,8 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_up_xwin(const int *__restrict__ r
 
 int mik_build_xwin_device(mik_ctx *ctx, mik_csr *A)
 {
-    if (!A->rowptr || A->n_long || A->sdia_val || A->sdia_pats || A->sdiaw_pats || A->jds_val || A->nnz <= 0 || A->n_rows <= 0 || ctx->tuning[8] != 0 ||
-        ctx->tuning[29] == 1 || A->max_row_nnz <= 32)
+    if (!A->rowptr || A->n_long || A->sdia_val || A->sdia_pats || A->sdiaw_pats || A->jds_val || A->nnz <= 0 || A->n_rows <= 0 || (ctx->tuning[MIK_KNOB_LAYOUTS] & 1) != 0 ||
+        (ctx->tuning[MIK_KNOB_LAYOUTS] & 32) != 0 || A->max_row_nnz <= 32)
         return MIK_OK;
     {   // the row permutation of the product tile (irregular rows): from a host copy of the row pointer (4 B per row, once)
         std::vector<int> rp((size_t)A->n_rows + 1);

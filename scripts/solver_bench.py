@@ -24,7 +24,7 @@ args = ap.parse_args()
 pkg = graft.load_package()
 import torch  # noqa: E402
 
-for kv in os.environ.get("MIK_KNOBS", "").split(","):            # development knobs for A/B runs, e.g. MIK_KNOBS=10=1
+for kv in os.environ.get("MIK_KNOBS", "").split(","):            # development knobs for A/B runs, e.g. MIK_KNOBS=8=2 (MIK_KNOB_SOLVER_FORM = 2: no SpMV epilogues)
     if kv:
         pkg.lib().mik_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
 
@@ -74,7 +74,7 @@ x = pkg.zerox(A, b)
 l = 2
 words = sum(2 + 3 * (j + 1) + 2 + 3 * (j + 1) + 3 for j in range(l)) + (l + 1) * (l + 1) * 2 + (l + 2) + (l + 2) + (l + 2) + 1
 bit = pkg.bicgstabl_iterator_(x, A, b, 2, reltol=0.0, max_mv_products=10 ** 9, initial_zero=True)
-kept = "25=2" not in os.environ.get("MIK_KNOBS", "")   # rho of the first column: segment sums left by the MR sweep of the step before
+kept = "8=2" not in os.environ.get("MIK_KNOBS", "")   # rho of the first column: segment sums left by the MR sweep of the step before
 ep = bit.dot_shape() == x.ctx.spmv_dot_shape()      # sigma and rho (from the second column on) leave the SpMV launches: r_shadow read once each, no sweep
 timed("bicgstabl2", bit, 0, words, 2 * l, iters=max(args.iters // 3, 10),
       moved_words=sum((1 if ep and j else (0 if kept and j == 0 else 2)) + 3 * (j + 1) + (1 if ep else 2) + 3 * (j + 1) + 3 for j in range(l)) + (l + 1) + (3 * l + 4) + (1 if kept else 0))   # + one-pass Gram + one-sweep MR update (+ r_shadow for the next rho)

@@ -1,7 +1,7 @@
 """CSR SpMV when x does not fit the 256 MB Infinity Cache: z-slabs of the 512 x 512 x NZ 7-point Laplacian, fp64, on the
 plain CSR arrays (k_spmv_rowgather), generated on the device.  NZ=64 is one rank's slab of configs[3] (x = 134 MB, the north-star
 size), NZ=256 has x = 537 MB and 5.9 GB of CSR arrays.  Back-to-back HIP-event time per launch, SURVEY.md 8d bytes, fraction of 8 TB/s;
-plain launch and the launch with the CG step's fused dot.   NZS="64 256"  GRID=512  LAYOUT=csr|auto  KNOB2=<workgroup map>"""
+plain launch and the launch with the CG step's fused dot.   NZS="64 256"  GRID=512  LAYOUT=csr|auto"""
 import importlib
 import json
 import os
@@ -15,8 +15,6 @@ import __graft_entry__ as g  # noqa: E402
 pkg = g.load_package()
 d = importlib.import_module(pkg.__name__ + ".dist")
 N = int(os.environ.get("GRID", 512))
-if "KNOB2" in os.environ:
-    pkg.lib().mik_set_tuning(2, int(os.environ["KNOB2"]))
 out = {}
 for NZ in [int(v) for v in os.environ.get("NZS", "64 256").split()]:
     n, ptr, idx, val = d._laplace_rows_torch(N, NZ, 0, N * N * NZ, np.float64, 0)

@@ -17,8 +17,9 @@ N = int(os.environ.get("N", 256))
 n, colptr, rowval, nzval = pkg.fixtures.laplace_matrix(N, 3)
 x = pkg.HipVector.from_numpy(np.random.default_rng(0).standard_normal(n))
 ref = None
-for label, knobs in (("device pipeline", {}), ("host path", {20: 1}), ("device pipeline, per-row values", {11: 1}), ("host path, per-row values", {20: 1, 11: 1}),
-                     ("device pipeline, CSR only", {8: 1}), ("host path, CSR only", {20: 1, 8: 1})):
+# development knobs (include/mik_dev.h): 4 = MIK_KNOB_UPLOAD (1: host path), 0 = MIK_KNOB_LAYOUTS (1: CSR only, 2: no slice-constant values)
+for label, knobs in (("device pipeline", {}), ("host path", {4: 1}), ("device pipeline, per-row values", {0: 2}), ("host path, per-row values", {4: 1, 0: 2}),
+                     ("device pipeline, CSR only", {0: 1}), ("host path, CSR only", {4: 1, 0: 1})):
     for k, v in knobs.items():
         L.mik_set_tuning(k, v)
     ts = []

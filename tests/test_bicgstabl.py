@@ -101,7 +101,7 @@ def test_device_matches_oracle_bit_exact(pkg, orc, ctx, l, dtype, knob25):
     sh = (orc.hashed_rhs(A.n) + 0.5).astype(dtype)
     dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
     x0 = np.random.default_rng(2).standard_normal(A.n).astype(dtype)
-    ctx.set_tuning(25, knob25)
+    ctx.set_tuning(8, knob25)
     ds = step_dot_shape(pkg, dA, b, l)
     assert ds == (ctx.reduce_shape(dtype) if knob25 == 2 else ctx.spmv_dot_shape())
     for start in (None, x0):
@@ -162,7 +162,7 @@ def test_fused_bicgstab_equals_statement_by_statement(pkg, orc, ctx, l, dtype, N
     dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
     runs = {}
     for fused, knob in ((True, 0), (False, 0), (True, 2)):
-        ctx.set_tuning(25, knob)
+        ctx.set_tuning(8, knob)
         x = pkg.HipVector.from_numpy(np.zeros(A.n, dtype))
         it = pkg.bicgstabl_iterator_(x, dA, pkg.HipVector.from_numpy(b), l, max_mv_products=60 * l, reltol=0.0, initial_zero=True,
                                      r_shadow=pkg.HipVector.from_numpy(sh), fused=fused)
@@ -344,7 +344,7 @@ def test_whole_iteration_calls_with_separate_finalisers(pkg, orc, ctx, dtype):
     bl = orc.hashed_rhs(L.n).astype(dtype)
     runs = []
     for knob in (0, 1):
-        ctx.set_tuning(25, knob)
+        ctx.set_tuning(8, knob)
         try:
             x = pkg.HipVector.from_numpy(np.zeros(A.n, dtype))
             it = pkg.bicgstabl_iterator_(x, dA, pkg.HipVector.from_numpy(b), 2, max_mv_products=80, reltol=0.0, initial_zero=True,
@@ -355,7 +355,7 @@ def test_whole_iteration_calls_with_separate_finalisers(pkg, orc, ctx, dtype):
             hm = np.array(list(im))
             runs.append((hb, x.to_numpy(), hm, y.to_numpy()))
         finally:
-            ctx.set_tuning(25, 0)
+            ctx.set_tuning(8, 0)
     assert runs[0][0].size == 20 and runs[0][2].size == 25
     for a, c in zip(runs[0], runs[1]):
         assert np.array_equal(a, c, equal_nan=True)

@@ -150,6 +150,35 @@ def test_minres_lanczos_epilogue_in_the_csr_and_jagged_kernels(pkg, orc, ctx, dt
 
 
 @pytest.mark.gpu
+def test_minres_survives_a_knob_change_between_steps(pkg, orc, ctx):
+    """the Lanczos epilogue is decided per STEP (like BiCGStab's): switching the epilogues off after the iterable was created
+    (development knob MIK_KNOB_SOLVER_FORM = 2; a layout change does the same) makes the next steps form the projection in a sweep of their own instead of
+    failing with MIK_ERR_NOTIMPL, mik_minres_proj_shape follows, and the solve goes on -- same iteration to rounding (the projection's
+    tree changed shape in mid-solve, so only the first steps are bit-equal to the oracle run with the epilogue shape)."""
+    A = orc.laplace(10, 3)
+    dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
+    b = orc.hashed_rhs(A.n)
+    x = pkg.HipVector.from_numpy(np.zeros(A.n))
+    it = pkg.minres_iterable_(x, dA, pkg.HipVector.from_numpy(b), initially_zero=True, maxiter=40, reltol=0.0)
+    assert it.proj_shape() == ctx.spmv_dot_shape()
+    _, ho = orc.minres(A, b, maxiter=40, reltol=0.0, mode="tree", shape=ctx.reduce_shape(np.float64), proj_shape=it.proj_shape())
+    hist, k = [], it.start()
+    L = pkg.lib()
+    try:
+        for j in range(40):
+            if j == 5:
+                L.mik_set_tuning(8, 2)                    # MIK_KNOB_SOLVER_FORM
+                assert it.proj_shape() == ctx.reduce_shape(np.float64)
+            res, k = it.iterate(k)
+            hist.append(res)
+    finally:
+        L.mik_set_tuning(8, 0)
+    hist = np.array(hist)
+    assert np.array_equal(hist[:5], ho["resnorm"][:5])
+    np.testing.assert_allclose(hist, ho["resnorm"], rtol=1e-9)
+
+
+@pytest.mark.gpu
 def test_minres_skew_symmetric_device(pkg, orc, ctx):
     rng = np.random.default_rng(123)
     n = 15

@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import KN, ROOT
 
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
@@ -491,19 +491,18 @@ def test_inprocess_group_badly_scaled_rhs_takes_the_scaled_norm_across_ranks(pkg
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("P", [2, 3, 4])
-@pytest.mark.parametrize("knobs", [(), (23,), (24,)])
+@pytest.mark.parametrize("knobs", [0, KN.X_IN_STEP, KN.HALO_AFTER_SWEEP])
 def test_inprocess_group_early_halo_step(pkg, orc, ctx, P, knobs):
     """Tall slabs (48 planes of 8 x 8): the boundary planes of EVERY rank, middle ranks with two runs included, are at most a
     quarter of its rows, so the group runs the step of cgd_enqueue_head -- boundary planes updated and packed first
     (phase 9), halo copies, bulk of the sweep (phase 8), interior row-blocks, then the boundary row-blocks in one launch
     around the interior range (mik_spmv_launch_outside) -- with x .+= alpha .* u riding on the next sweep and the flush at
-    the end of a batch.  Bit-exact against the partition-aware oracle; knob 23 (x updated in the step) and knob 24 (halo
+    the end of a batch.  Bit-exact against the partition-aware oracle; MIK_KNOB_CG_STEP bit 0 (x updated in the step) and bit 2 (halo
     after the whole sweep) give the same bits."""
     d = dist_mod(pkg)
     N, NZ = 8, 48
     L = pkg.lib()
-    for k in knobs:
-        L.mik_set_tuning(k, 1)
+    L.mik_set_tuning(KN.CG_STEP, knobs)
     try:
         shape = ctx.cg_shape(np.float64)
         x0 = np.random.default_rng(11).standard_normal(N * N * NZ)
@@ -511,7 +510,7 @@ def test_inprocess_group_early_halo_step(pkg, orc, ctx, P, knobs):
         engines, offsets, b = make_engines(pkg, orc, N, NZ, P, mk, x0)
         grp = d.GroupCG(pkg, engines, maxiter=10 ** 6)
         early = grp.halo_early()
-        if 24 in knobs:
+        if knobs == KN.HALO_AFTER_SWEEP:
             assert all(runs == 0 for runs, _, _ in early)
         else:
             want = [1 if p in (0, P - 1) else 2 for p in range(P)]
@@ -535,8 +534,7 @@ def test_inprocess_group_early_halo_step(pkg, orc, ctx, P, knobs):
         for e in engines:
             e.close()
     finally:
-        for k in knobs:
-            L.mik_set_tuning(k, 0)
+        L.mik_set_tuning(KN.CG_STEP, 0)
 
 
 @pytest.mark.gpu
@@ -573,7 +571,7 @@ def test_native_comm_world1_equals_single_gpu_path(pkg, orc, ctx, force_rccl):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("knobs", [(), (9,), (26,), (9, 26)])
+@pytest.mark.parametrize("knobs", [(0, 0), (1, 0), (0, KN.SEPARATE_ALPHA), (1, KN.SEPARATE_ALPHA)])
 @pytest.mark.parametrize("scale,with_x0", [(1e-140, False), (1e140, False), (1e-140, True)])
 @pytest.mark.parametrize("batch", [1, 9])
 def test_rccl_path_badly_scaled_rhs_freezes_on_the_last_step_of_a_batch(pkg, orc, ctx, knobs, scale, with_x0, batch):
@@ -581,13 +579,13 @@ def test_rccl_path_badly_scaled_rhs_freezes_on_the_last_step_of_a_batch(pkg, orc
     leaves the safe range in EVERY step.  With batch = 1 (DistCG.iterate()) every frozen step is the last of its batch: the head
     enqueued ahead applies the step's x .+= alpha .* u but no tail follows to clear the pending flag, and the next call's fresh head
     used to add the same alpha u again -- a silently wrong x under a correct-looking history.  x and the history bit for bit
-    against the oracle, with and without look-ahead (knob 9), both alpha forms (knob 26), freezes mid-batch and on the last step
+    against the oracle, with and without look-ahead (MIK_KNOB_NO_LOOKAHEAD), both alpha forms (MIK_KNOB_CG_STEP bit 3), freezes mid-batch and on the last step
     (batch = 9 with a 1-step prologue)."""
     d = dist_mod(pkg)
     N, NZ = 12, 12
     L = pkg.lib()
-    for k in knobs:
-        L.mik_set_tuning(k, 1)
+    L.mik_set_tuning(KN.NO_LOOKAHEAD, knobs[0])
+    L.mik_set_tuning(KN.CG_STEP, knobs[1])
     try:
         shape = ctx.cg_shape(np.float64)
         x0 = np.random.default_rng(5).standard_normal(N * N * NZ) * scale if with_x0 else None
@@ -610,8 +608,8 @@ def test_rccl_path_badly_scaled_rhs_freezes_on_the_last_step_of_a_batch(pkg, orc
         eng.close()
         nc.close()
     finally:
-        for k in knobs:
-            L.mik_set_tuning(k, 0)
+        L.mik_set_tuning(KN.NO_LOOKAHEAD, 0)
+        L.mik_set_tuning(KN.CG_STEP, 0)
 
 
 def test_native_transport_argument_checks(pkg):
@@ -627,9 +625,13 @@ def test_native_transport_argument_checks(pkg):
     assert L.mik_comm_create(None, None, 0, 1, None) == 1
     assert L.mik_comm_destroy(None) == 0 and L.mik_comm_allgather_sum(None, 0, 1, None) == 1
     # transport 3 (round 4)
-    off = C.c_int64()
     assert L.mik_comm_mailbox_export(None, None) == 1 and L.mik_comm_mailbox_connect(None, None) == 1 and L.mik_comm_mailbox_info(None, None, None) == 1
-    assert L.mik_mem_export(None, None, None, C.byref(off)) == 1 and L.mik_cgd_connect_ghosts(None, None, None, None) == 1
+    assert L.mik_cgd_ghost_export(None, None) == 1 and L.mik_cgd_connect_ghosts(None, None, None, None) == 1
+    # the device-driven links (round 5)
+    h = C.c_void_p()
+    assert L.mik_plink_create(None, 0, 0, 0, None, None, None, 0, None, None, None, C.byref(h)) == 1 and L.mik_plink_export(None, None) == 1
+    assert L.mik_plink_connect(None, None, None, None) == 1 and L.mik_plink_info(None, None, None, None) == 1 and L.mik_plink_destroy(None) == 0
+    assert L.mik_cgd_profile(None, 0, None, None) == 1
     g = C.c_int()
     assert L.mik_spmv_long_group(C.byref(g)) == 0 and g.value == 4 and L.mik_minres_proj_shape(None, None, None) == 1
 

@@ -2,6 +2,8 @@
 thousands) -- the load-imbalance / long-row case of the SpMV.  GPU box only."""
 import numpy as np
 import pytest
+
+from conftest import KN
 import scipy.sparse as sp
 
 pytestmark = pytest.mark.gpu
@@ -72,7 +74,7 @@ def test_cut_rows_segment_sums(pkg, orc, ctx, dtype, segment):
     segment order whatever the order the waves finish in: lengths around the segment boundaries (a last segment of 1 or 4
     entries, exactly one / two segments), both CSR kernels, repeated launches (the tickets reset themselves)"""
     L = pkg.lib()
-    L.mik_set_tuning(15, segment)
+    L.mik_set_tuning(KN.LONG_SEGMENT, segment)
     try:
         seg = ctx.spmv_long_segment()
         assert seg == (segment or 1024)
@@ -89,7 +91,7 @@ def test_cut_rows_segment_sums(pkg, orc, ctx, dtype, segment):
         x = rng.standard_normal(n).astype(dtype)
         want = orc.spmv(Ao, x)
         for variant in (2, 1):
-            L.mik_set_tuning(14, variant)
+            L.mik_set_tuning(KN.CSR_KERNEL, variant)
             A = pkg.HipCSR(n, n, rowptr, cols, val, index_base=0, is_csc=False)
             dx = pkg.HipVector.from_numpy(x)
             for _ in range(3):
@@ -99,8 +101,8 @@ def test_cut_rows_segment_sums(pkg, orc, ctx, dtype, segment):
             xo, ho = orc.cg(Ao, orc.hashed_rhs(n).astype(dtype), maxiter=3, mode="tree", shape=ctx.cg_shape(dtype))
             assert np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(xs.to_numpy(), xo)
     finally:
-        L.mik_set_tuning(15, 0)
-        L.mik_set_tuning(14, 0)
+        L.mik_set_tuning(KN.LONG_SEGMENT, 0)
+        L.mik_set_tuning(KN.CSR_KERNEL, 0)
 
 
 def banded_irregular(n, dtype, halfwidth, seed=3, long_every=0, touch_last_column=False):
@@ -130,8 +132,8 @@ def banded_irregular(n, dtype, halfwidth, seed=3, long_every=0, touch_last_colum
 def test_x_window_in_lds_bit_exact(pkg, orc, ctx, dtype, long_every, n):
     """irregular rows inside a band -- the product-tile kernel serves x from an LDS window per 256-row block
     (k_spmv_rowblock XWIN, csr_build_xwin): same products, same order, same bits as the oracle, with the windows (default), with
-    the windows and the by-length row permutation of a block's threads (RPERM) built but not used (development knob 29 = 2) and
-    never built (29 = 1); plain SpMV (long rows merged into the launch)
+    the windows and the by-length row permutation of a block's threads (RPERM) built but not used (development knob MIK_KNOB_LAYOUTS bit 64) and
+    never built (bit 32); plain SpMV (long rows merged into the launch)
     and the fused-dot launches of a CG step; one-sided bands at both ends of the matrix (the last window slides down).
     n = 9001 / 9003: x is not a whole number of 16-byte groups, so the slid-down window of the last row-blocks
     cannot reach x[n - 1] from an aligned start -- those blocks must gather from memory (mik_xwin_plan), and every one of them
@@ -143,9 +145,9 @@ def test_x_window_in_lds_bit_exact(pkg, orc, ctx, dtype, long_every, n):
     b = orc.hashed_rhs(n).astype(dtype)
     xo, ho = orc.cg(Ao, b, maxiter=3, mode="tree", shape=ctx.cg_shape(dtype))
     L = pkg.lib()
-    # knob 29 = 1: neither windows nor the row permutation are built -- without long rows the operator is then back on the LDS-DMA tile
-    for knob, kern in ((0, "k_spmv_rowblock+xwin"), (2, "k_spmv_rowblock"), (1, "k_spmv_rowblock" if long_every else "k_spmv_rowgather")):
-        L.mik_set_tuning(29, knob)
+    # MIK_KNOB_LAYOUTS bit 32: neither windows nor the row permutation are built -- without long rows the operator is then back on the LDS-DMA tile
+    for knob, kern in ((0, "k_spmv_rowblock+xwin"), (KN.XWIN_UNUSED, "k_spmv_rowblock"), (KN.NO_XWIN, "k_spmv_rowblock" if long_every else "k_spmv_rowgather")):
+        L.mik_set_tuning(KN.LAYOUTS, knob)
         try:
             A = pkg.HipCSR(n, n, rowptr, cols, val, index_base=0, is_csc=False)
             assert A.spmv_kernel() == kern, (A.spmv_kernel(), A.layout())
@@ -155,7 +157,7 @@ def test_x_window_in_lds_bit_exact(pkg, orc, ctx, dtype, long_every, n):
             xs, ch = pkg.cg(A, pkg.HipVector.from_numpy(b), log=True, maxiter=3)          # fused-dot launches (matrix not SPD: bits only)
             assert np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(xs.to_numpy(), xo)
         finally:
-            L.mik_set_tuning(29, 0)
+            L.mik_set_tuning(KN.LAYOUTS, 0)
 
 
 def test_x_window_blocks_that_wrap_around_gather_from_memory(pkg, orc, ctx):

@@ -6,12 +6,14 @@ import scipy.sparse as sp
 
 pytestmark = pytest.mark.gpu
 
-# knob 14 selects the CSR kernel: 0 = tile filled by LDS-DMA + per-row gather (k_spmv_rowgather, default), 1 = products
+from conftest import KN
+
+# KN.CSR_KERNEL selects the CSR kernel: 0 = tile filled by LDS-DMA + per-row gather (k_spmv_rowgather, default), 1 = products
 # staged through registers (k_spmv_rowblock)
-FORMS = {"csr-rowblock": {8: 1}, "csr-rowblock/products": {8: 1, 14: 1},
-         "jagged-slices": {12: 1, 28: 2}, "sliced-ell+slice-offsets+row-masks": {11: 1}, "best": {},
-         # the kernels of the slice-constant layout: flat loads, buffer loads slot by slot, 1 / 4 slices per workgroup
-         "best/flat-loads": {17: 1}, "best/slot-by-slot": {18: 1}, "best/1-slice": {16: 1}, "best/4-slices": {16: 4}, "best/flat-4": {17: 1, 16: 4}}
+FORMS = {"csr-rowblock": {KN.LAYOUTS: KN.CSR_ONLY}, "csr-rowblock/products": {KN.LAYOUTS: KN.CSR_ONLY, KN.CSR_KERNEL: 1},
+         "jagged-slices": {KN.LAYOUTS: KN.NO_SLICE_OFFSETS | KN.JAGGED_ALWAYS}, "sliced-ell+slice-offsets+row-masks": {KN.LAYOUTS: KN.NO_SLICE_CONSTANT}, "best": {},
+         # the kernels of the slice-constant layout: flat loads, buffer loads slot by slot, one row per lane
+         "best/flat-loads": {KN.SDIA_KERNEL: 1}, "best/slot-by-slot": {KN.SDIA_KERNEL: 2}, "best/one-row-per-lane": {KN.SDIA_KERNEL: 3}}
 
 
 def with_knobs(pkg, knobs, fn):
@@ -160,7 +162,7 @@ def test_csr_kernel_variants_on_ragged_rows(pkg, orc, ctx, dtype):
             # 3 CG steps exercise the fused-dot epilogue (the matrix is not SPD; only the bits matter)
             xs, ch = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True, maxiter=3)
             return y, ch["resnorm"], xs.to_numpy()
-        y, res, xs = with_knobs(pkg, {8: 1, 14: variant} if variant != "jagged-slices" else {28: 2}, run)
+        y, res, xs = with_knobs(pkg, {KN.LAYOUTS: KN.CSR_ONLY, KN.CSR_KERNEL: variant} if variant != "jagged-slices" else {KN.LAYOUTS: KN.JAGGED_ALWAYS}, run)
         assert np.array_equal(y, want), variant
         if ref is None:
             ref = (res, xs)
@@ -216,13 +218,13 @@ def test_slice_constant_kernels_absent_slots_and_missing_diagonals(pkg, orc, ctx
     xf = rng.standard_normal(n).astype(dtype)
     b = orc.hashed_rhs(n).astype(dtype)
     ref = None
-    for form, knobs in (("csr-rowblock", {8: 1}), ("best", {}), ("best/flat-loads", {17: 1}), ("best/slot-by-slot", {18: 1}), ("best/4-slices", {16: 4}),
-                        ("best/one-row-per-lane", {19: 1})):
+    for form, knobs in (("csr-rowblock", {KN.LAYOUTS: KN.CSR_ONLY}), ("best", {}), ("best/flat-loads", {KN.SDIA_KERNEL: 1}), ("best/slot-by-slot", {KN.SDIA_KERNEL: 2}),
+                        ("best/one-row-per-lane", {KN.SDIA_KERNEL: 3})):
         def run():
             dA = upload(pkg, A)
             if form.startswith("best"):
                 assert dA.layout() == "slice-offsets+slice-values+row-masks"
-                assert dA.spmv_kernel() == ("k_spmv_sdiac" if 17 in knobs else "k_spmv_sdiab2" if not knobs and n % 2 == 0 else "k_spmv_sdiab")
+                assert dA.spmv_kernel() == ("k_spmv_sdiac" if knobs.get(KN.SDIA_KERNEL) == 1 else "k_spmv_sdiab2" if not knobs and n % 2 == 0 else "k_spmv_sdiab")
             y = pkg.mul_(pkg.HipVector(n, dtype), dA, pkg.HipVector.from_numpy(x)).to_numpy()
             xs, ch = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True, maxiter=4)     # fused dot; only the bits matter
             return y, ch["resnorm"], xs.to_numpy(), pkg.mul_(pkg.HipVector(n, dtype), dA, pkg.HipVector.from_numpy(xf)).to_numpy()
@@ -263,7 +265,8 @@ def test_rectangular_blocks_with_lane_neighbour_slots(pkg, ctx, dtype, rows):
     C = S.tocsc()
     C.sort_indices()
     seen = set()
-    for form, knobs in (("csr-rowblock", {8: 1}), ("best", {}), ("best/one-row-per-lane", {19: 1}), ("best/flat-loads", {17: 1}), ("best/slot-by-slot", {18: 1})):
+    for form, knobs in (("csr-rowblock", {KN.LAYOUTS: KN.CSR_ONLY}), ("best", {}), ("best/one-row-per-lane", {KN.SDIA_KERNEL: 3}), ("best/flat-loads", {KN.SDIA_KERNEL: 1}),
+                        ("best/slot-by-slot", {KN.SDIA_KERNEL: 2})):
         def run():
             dA = pkg.HipCSR(rows, cols, C.indptr.astype(np.int64), C.indices.astype(np.int64), C.data, index_base=0)
             seen.add(dA.spmv_kernel())
@@ -313,7 +316,7 @@ def test_development_knobs_are_per_context(pkg, orc, ctx):
     A = orc.laplace(9, 3)
     other = pkg.HipContext(0)
     try:
-        other.set_tuning(8, 1)                                       # CSR only -- on `other`
+        other.set_tuning(KN.LAYOUTS, KN.CSR_ONLY)                    # CSR only -- on `other`
         dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval, index_base=A.index_base, ctx=ctx)
         dB = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval, index_base=A.index_base, ctx=other)
         assert dA.layout() == "slice-offsets+slice-values+row-masks" and dB.layout() == "csr-rowblock"
@@ -322,11 +325,11 @@ def test_development_knobs_are_per_context(pkg, orc, ctx):
         yb = pkg.mul_(pkg.HipVector(A.n, ctx=other), dB, pkg.HipVector.from_numpy(x, ctx=other)).to_numpy()
         assert np.array_equal(ya, yb) and np.array_equal(ya, orc.spmv(A, x))
         del dB
-        pkg.lib().mik_set_tuning(8, 1)                               # process-wide: reaches both
+        pkg.lib().mik_set_tuning(KN.LAYOUTS, KN.CSR_ONLY)            # process-wide: reaches both
         try:
             assert pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval, index_base=A.index_base, ctx=ctx).layout() == "csr-rowblock"
         finally:
-            pkg.lib().mik_set_tuning(8, 0)
+            pkg.lib().mik_set_tuning(KN.LAYOUTS, 0)
         assert pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval, index_base=A.index_base, ctx=other).layout() == "slice-offsets+slice-values+row-masks"
     finally:
         other.close() if hasattr(other, "close") else None
@@ -419,14 +422,14 @@ def test_wide_slice_constant_layout_for_box_stencils(pkg, orc, ctx, dtype, N, di
     xc, cc = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True)
     assert np.array_equal(cc["resnorm"], ch["resnorm"]) and np.array_equal(xc.to_numpy(), xs.to_numpy())
     dA.set_layout("auto")
-    ctx.set_tuning(19, 1)                                              # one row per lane
+    ctx.set_tuning(KN.SDIA_KERNEL, 3)                                  # one row per lane
     try:
         assert dA.spmv_kernel() == "k_spmv_sdiaw"
         assert np.array_equal(pkg.mul_(pkg.HipVector(n, dtype), dA, pkg.HipVector.from_numpy(x)).to_numpy(), want, equal_nan=True)
         x1, c1 = pkg.cg(dA, pkg.HipVector.from_numpy(b), log=True)
         assert np.array_equal(c1["resnorm"], ch["resnorm"]) and np.array_equal(x1.to_numpy(), xs.to_numpy())
     finally:
-        ctx.set_tuning(19, 0)
+        ctx.set_tuning(KN.SDIA_KERNEL, 0)
     assert dA.set_layout("auto").compact() and dA.layout() == "wide-slice-values+row-masks"
     for bad in (np.nextafter(vv[5], dtype(10)), np.inf):
         v2 = vv.copy()

@@ -1,10 +1,12 @@
 """CG with the head of the next step enqueued ahead of the host wait, and with x .+= alpha .* u carried by the next sweep over u
 (csrc/mik_krylov.hip, cg_enqueue_head; OpXpbyX): x, r and the
-residual history after any mix of iterate / iterate_many calls equal those of the plain protocol (development knob 9 = 1)
+residual history after any mix of iterate / iterate_many calls equal those of the plain protocol (development knob MIK_KNOB_NO_LOOKAHEAD)
 and the oracle, bit for bit -- including stops by tolerance, by maxiter, and a solve that is continued after a pause.
 GPU box only."""
 import numpy as np
 import pytest
+
+from conftest import KN
 
 pytestmark = pytest.mark.gpu
 
@@ -48,7 +50,8 @@ def test_lookahead_changes_nothing_the_caller_can_see(pkg, orc, ctx, dtype, pcg,
     kw = dict(reltol=0.0, maxiter=10 ** 6)
     h1, s1, _ = run(pkg, A, b, schedule, {}, Pl, **kw)
     # no look-ahead; x updated by the step's own sweep; neither; one row per lane
-    for knobs in ({9: 1}, {23: 1}, {9: 1, 23: 1}, {19: 1}, {22: 1}, {22: 1, 9: 1}):
+    for knobs in ({KN.NO_LOOKAHEAD: 1}, {KN.CG_STEP: KN.X_IN_STEP}, {KN.NO_LOOKAHEAD: 1, KN.CG_STEP: KN.X_IN_STEP}, {KN.SDIA_KERNEL: 3}, {KN.CG_STEP: KN.PCG_THREE_SWEEPS},
+                  {KN.CG_STEP: KN.PCG_THREE_SWEEPS, KN.NO_LOOKAHEAD: 1}, {KN.HOST_WAIT: 3}):
         h0, s0, _ = run(pkg, A, b, schedule, knobs, Pl, **kw)
         assert np.array_equal(h1, h0) and len(s1) == len(s0), knobs
         for (x1, r1), (x0, r0) in zip(s1, s0):
@@ -66,7 +69,7 @@ def test_lookahead_at_the_stopping_tests(pkg, orc, ctx, N):
         for schedule in ([1] * 200, [4] * 60, [1, 5, 1, 9] * 20):
             h1, s1, _ = run(pkg, A, b, schedule, {}, **kw)
             u1 = run.last_u
-            for knobs in ({9: 1}, {23: 1}, {9: 1, 23: 1}):
+            for knobs in ({KN.NO_LOOKAHEAD: 1}, {KN.CG_STEP: KN.X_IN_STEP}, {KN.NO_LOOKAHEAD: 1, KN.CG_STEP: KN.X_IN_STEP}):
                 h0, s0, _ = run(pkg, A, b, schedule, knobs, **kw)
                 assert np.array_equal(h1, h0) and len(s1) == len(s0) and len(h1) > 0, knobs
                 assert np.array_equal(s1[-1][0], s0[-1][0]) and np.array_equal(s1[-1][1], s0[-1][1]), knobs

@@ -486,31 +486,11 @@ def test_full_size_256_properties_and_full_history(pkg, ctx):
     assert abs(pkg.norm(r) - ch["resnorm"][-1]) <= 1e-3 * ch["resnorm"][-1]
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("orth", ["mgs", "cgs"])
-def test_gmres_graph_replay_equals_stream_launches(pkg, orc, ctx, orth):
-    """mik_set_tuning(5, 3): every Arnoldi column as one captured hipGraph (off by default) -- same bits"""
-    A, b = orc.advdiff(12, 1000.0)
-    M = {"mgs": pkg.ModifiedGramSchmidt(), "cgs": pkg.ClassicalGramSchmidt()}[orth]
-    x0, ch0 = pkg.gmres(upload(pkg, A), pkg.HipVector.from_numpy(b), restart=10, log=True, orth_meth=M)
-    pkg.lib().mik_set_tuning(5, 3)
-    try:
-        x1, ch1 = pkg.gmres(upload(pkg, A), pkg.HipVector.from_numpy(b), restart=10, log=True, orth_meth=M)
-        d = (np.abs(A.to_scipy().diagonal()) ** 0.5)
-        P = pkg.JacobiPrec(pkg.HipVector.from_numpy(d))
-        x2, ch2 = pkg.gmres(upload(pkg, A), pkg.HipVector.from_numpy(b), restart=10, log=True, orth_meth=M, Pl=P, Pr=P)
-    finally:
-        pkg.lib().mik_set_tuning(5, 0)
-    x3, ch3 = pkg.gmres(upload(pkg, A), pkg.HipVector.from_numpy(b), restart=10, log=True, orth_meth=M, Pl=P, Pr=P)
-    assert np.array_equal(ch0["resnorm"], ch1["resnorm"]) and np.array_equal(x0.to_numpy(), x1.to_numpy()) and ch0.mvps == ch1.mvps
-    assert np.array_equal(ch2["resnorm"], ch3["resnorm"]) and np.array_equal(x2.to_numpy(), x3.to_numpy())
-
-
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_gmres_dgks_reorthogonalisation_inside_the_single_launch_kernel(pkg, orc, ctx, dtype):
     """A = I + tiny perturbation: every new Krylov vector lies almost in the span of the basis, so the DGKS condition
     (src/orthogonalize.jl:26) holds and the loop runs -- inside k_cgs_fused (3 rounds), handed back to the host after one
-    round (knob 21 = 1), and as the multi-launch chain (knob 5 = 2): all three equal the oracle bit for bit, and differ from
+    round (MIK_KNOB_GS = 3), and as the multi-launch chain (MIK_KNOB_GS = 2): all three equal the oracle bit for bit, and differ from
     plain CGS (i.e. the loop really ran)."""
     import scipy.sparse as sp
     n = 3000
@@ -524,7 +504,7 @@ def test_gmres_dgks_reorthogonalisation_inside_the_single_launch_kernel(pkg, orc
     xc, hc = orc.gmres(A, b, restart=12, orth_meth="cgs", mode="tree", shape=(W, L), maxiter=20, reltol=0.0)
     assert not np.array_equal(ho["resnorm"], hc["resnorm"]) or not np.array_equal(xo, xc)
     lib = pkg.lib()
-    for knobs in ({}, {21: 1}, {5: 2}):
+    for knobs in ({}, {5: 3}, {5: 2}):
         for kk, v in knobs.items():
             lib.mik_set_tuning(kk, v)
         try:
@@ -553,18 +533,18 @@ def test_cg_bit_exact_at_128_cubed(pkg, orc, ctx, dtype):
 
 def test_gmres_single_launch_gram_schmidt_falls_back_and_survives_nan(pkg, orc, ctx):
     """(1) if the bounded spin of the single-launch Gram-Schmidt expires (GPU shared with other work) the handle
-    redoes the column with the multi-launch chain and stays there -- same bits, no error (development knob 30 simulates the
+    redoes the column with the multi-launch chain and stays there -- same bits, no error (development knob MIK_KNOB_GS_TIMEOUT simulates the
     expiry); (2) a right-hand side whose bytes are all 0xFF is a NaN with the payload the slots use for "not yet written":
     the solve must report NaN residuals like the reference would, not a time-out."""
     A, b = orc.advdiff(8, 50.0)
     dA = upload(pkg, A)
     for M in (pkg.ModifiedGramSchmidt(), pkg.ClassicalGramSchmidt(), pkg.DGKS()):
         x0, h0 = pkg.gmres(dA, pkg.HipVector.from_numpy(b), restart=12, orth_meth=M, log=True, maxiter=60)
-        pkg.lib().mik_set_tuning(30, 1)
+        pkg.lib().mik_set_tuning(9, 1)           # MIK_KNOB_GS_TIMEOUT
         try:
             x1, h1 = pkg.gmres(dA, pkg.HipVector.from_numpy(b), restart=12, orth_meth=M, log=True, maxiter=60)
         finally:
-            pkg.lib().mik_set_tuning(30, 0)
+            pkg.lib().mik_set_tuning(9, 0)
         assert np.array_equal(h0["resnorm"], h1["resnorm"]) and np.array_equal(x0.to_numpy(), x1.to_numpy()) and h0.mvps == h1.mvps
     bad = np.frombuffer(b"\xff" * (8 * A.n), dtype=np.float64).copy()
     bad[::3] = b[::3]
@@ -628,11 +608,11 @@ def test_gmres_single_launch_gram_schmidt_beyond_256_segments(pkg, orc, ctx, dty
     dA = upload(pkg, A)
     for name, M in (("mgs", pkg.ModifiedGramSchmidt()), ("cgs", pkg.ClassicalGramSchmidt()), ("dgks", pkg.DGKS())):
         x1, h1 = pkg.gmres(dA, db, restart=7, orth_meth=M, log=True, maxiter=17)
-        pkg.lib().mik_set_tuning(31, 1)
+        pkg.lib().mik_set_tuning(5, 2)           # MIK_KNOB_GS = 2: the multi-launch chains
         try:
             x0, h0 = pkg.gmres(dA, db, restart=7, orth_meth=M, log=True, maxiter=17)
         finally:
-            pkg.lib().mik_set_tuning(31, 0)
+            pkg.lib().mik_set_tuning(5, 0)
         assert np.array_equal(h1["resnorm"], h0["resnorm"]) and np.array_equal(x1.to_numpy(), x0.to_numpy()) and h1.mvps == h0.mvps, name
         if N == 67 and name != "dgks":
             xo, ho = orc.gmres(A, b, restart=7, orth_meth=name, maxiter=17, mode="tree", shape=(W, L))

@@ -12,11 +12,11 @@ pytestmark = pytest.mark.gpu
 def both_paths(pkg, make):
     L = pkg.lib()
     dev = make()
-    L.mik_set_tuning(20, 1)
+    L.mik_set_tuning(4, 1)          # MIK_KNOB_UPLOAD
     try:
         host = make()
     finally:
-        L.mik_set_tuning(20, 0)
+        L.mik_set_tuning(4, 0)
     return dev, host
 
 
@@ -179,12 +179,12 @@ def test_compact_releases_the_csr_arrays(pkg, orc, ctx):
     assert dA.layout() == "slice-offsets+slice-values+row-masks"
     assert np.array_equal(pkg.mul_(pkg.HipVector(A.n), dA, pkg.HipVector.from_numpy(x)).to_numpy(), want)
     L = pkg.lib()
-    L.mik_set_tuning(8, 1)                                            # "CSR only" has nothing to fall back to any more
+    L.mik_set_tuning(0, 1)                                            # "CSR only" has nothing to fall back to any more
     try:
         assert dA.layout() == "slice-offsets+slice-values+row-masks"
         assert np.array_equal(pkg.mul_(pkg.HipVector(A.n), dA, pkg.HipVector.from_numpy(x)).to_numpy(), want)
     finally:
-        L.mik_set_tuning(8, 0)
+        L.mik_set_tuning(0, 0)
     xs, ch = pkg.cg(dA, pkg.HipVector.from_numpy(orc.hashed_rhs(A.n)), log=True)
     assert ch.isconverged
     # an operator that runs on its CSR arrays keeps them

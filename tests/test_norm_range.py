@@ -114,7 +114,7 @@ def test_cg_stepping_at_128_cubed_through_freezes_and_maxiter(pkg, orc, ctx, sca
     b = orc.hashed_rhs(A.n) * scale
     dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
     steps = 8 if scale != 1.0 else 12
-    ctx.set_tuning(9, knob9)
+    ctx.set_tuning(7, knob9)        # MIK_KNOB_NO_LOOKAHEAD
     db = pkg.HipVector.from_numpy(b)
     x = pkg.zerox(dA, db)
     it = pkg.cg_iterator_(x, dA, db, initially_zero=True, reltol=0.0, maxiter=steps + 3)
