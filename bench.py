@@ -7,12 +7,20 @@ A "step" is one cg! iteration (iterate(::CGIterable), src/cg.jl:43-66) on synthe
 
 N = 1: BASELINE.json configs[1] -- cg! on the 256^3 Laplacian through the fused single-GPU iterable.
 N > 1: BASELINE.json configs[3] -- the same iteration row-partitioned into z-slabs, one process per GPU, halo exchange
-       and scalar gathers over RCCL/xGMI issued from INSIDE libmik.so (mik_cgd_iterate_many).  N = 8 is the 512^3
-       grid (64 planes and two 512^2-double halos per rank); N = 2, 4 are its weak-scaled pieces 512 x 512 x 64N
+       and scalar sums issued from INSIDE libmik.so (mik_cgd_iterate_many; RCCL or peer-mapped mailboxes over xGMI).  N = 8 is the
+       512^3 grid (64 planes and two 512^2-double halos per rank); N = 2, 4 are its weak-scaled pieces 512 x 512 x 64N
        (16.7 M rows per GPU throughout, like the single-GPU 256^3).  If the process was not started by
        torch.distributed.run (WORLD_SIZE unset) bench.py launches the N ranks itself.
-Rank 0 prints ONE JSON line.  The same host protocol is timed at every N: `value` = one host-visible residual per step
-(what the reference's loop does); `batched_*` = one host wait per 25 steps.
+Rank 0 prints ONE JSON line.  At every N:
+  `value` / `ms_per_step`  the CONTRACT loop: the operator (every rank's slab) on its plain Int32 CSR arrays (k_spmv_rowgather), one
+                           host-visible residual per step like the reference's loop; iterations/s of the one (global) system;
+                           `value_bytes_per_step[_per_gpu]` = SURVEY.md 8d's B_cg, so bytes / ms <= 8 TB/s is checkable from the top level
+  `roofline`               SURVEY.md 8d bytes of the CSR SpMV over the in-loop HIP-event time of that kernel, + the loop it was timed in
+  `default_layout_*`       the same iteration in the layout mik_csr_create picks by itself (one mask byte per row for this
+                           constant-coefficient operator; bit-identical results) -- reported, NOT the contract figure
+N = 1 adds: parity_full_history (the 613-step solve against the committed CPU histories), gmres_hbm_bound (gmres!(30) at 256^3),
+f_solvers, gmres_config3 (configs[2]), config5 (configs[4] stand-ins), cpu_baseline (+ OpenMP).
+N > 1 adds: parity_vs_oracle (every transport on a small global system against the partition-aware oracle), transports_measured.
 """
 from __future__ import annotations
 
@@ -241,6 +249,52 @@ def gmres_hbm_bound(A, b, n: int, restart: int = 30, inner: int = 60, reps: int 
             rec["traffic_is"] = "committed constant: sum over the kernels of one profiled call of 2 x FETCH_SIZE + WRITE_SIZE (separate rocprofv3 --pmc passes), divided by its inner iterations"
         out[name] = rec
         del it
+    return out
+
+
+def f_solvers(A, b, n: int, iters: int = 40):
+    """SURVEY.md 8f rows on the driver's line: per-iteration wall time of PCG with a Jacobi Pl (src/cg.jl:72-100), Chebyshev
+    (src/chebyshev.jl:29-57), MINRES (src/minres.jl:95-159) and BiCGStab(2) (src/bicgstabl.jl:79-134; per OUTER iteration = 4 SpMV) on the 256^3
+    operator, fp64, one host-visible residual per iteration, in the operator's default layout and on its plain CSR arrays.  `bytes_moved` = what the
+    launches of one iteration stream (the layout's SpMV bytes x SpMVs + the words per row of its fused sweeps); `frac` = that over 8 TB/s."""
+    import gc
+    import torch
+    pkg = graft.load_package()
+    vec = 8 * n
+    out = {}
+    for layout in ("auto", "csr"):
+        A.set_layout(layout)
+        spmv_moved = A.spmv_stored_bytes()
+        rec = {"operator_layout": A.layout(), "spmv_kernel": A.spmv_kernel()}
+
+        def timed(it, start, mv, words, count):
+            i = start
+            for _ in range(4):
+                _, i = it.iterate(i)
+            gc.collect()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(count):
+                _, i = it.iterate(i)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / count
+            moved = mv * spmv_moved + words * vec
+            return {"us_per_iteration": dt * 1e6, "spmv_per_iteration": mv, "vector_words_per_row_moved": words, "bytes_moved": moved,
+                    "gbs": moved / dt / 1e9, "frac": moved / dt / 1e9 / HBM_PEAK_GBS}
+        d = pkg.HipVector.from_numpy(np.full(n, 6.0))
+        rec["pcg_jacobi"] = timed(pkg.cg_iterator_(pkg.zerox(A, b), A, b, pkg.JacobiPrec(d), reltol=0.0, initially_zero=True, maxiter=10 ** 9), 0, 1, 10, iters)
+        rec["chebyshev"] = timed(pkg.chebyshev_iterable_(pkg.zerox(A, b), A, b, 4.5e-4, 12.0, reltol=0.0, initially_zero=True, maxiter=10 ** 9), 0, 1, 9, iters)
+        mit = pkg.minres_iterable_(pkg.zerox(A, b), A, b, reltol=0.0, initially_zero=True, maxiter=10 ** 9)
+        ep = mit.proj_shape() == pkg.default_context().spmv_dot_shape()        # the Lanczos step rides on the SpMV launch
+        rec["minres"] = timed(mit, 1, 1, 12 if ep else 15, iters)
+        bit = pkg.bicgstabl_iterator_(pkg.zerox(A, b), A, b, 2, reltol=0.0, max_mv_products=10 ** 9, initial_zero=True)
+        epb = bit.dot_shape() == pkg.default_context().spmv_dot_shape()        # sigma / rho leave the SpMV launches
+        ll = 2
+        words = sum((1 if epb and j else (0 if j == 0 else 2)) + 3 * (j + 1) + (1 if epb else 2) + 3 * (j + 1) + 3 for j in range(ll)) + (ll + 1) + (3 * ll + 4) + 1
+        rec["bicgstab2_per_outer_iteration"] = timed(bit, 0, 2 * ll, words, max(iters // 3, 10))
+        out["default_layout" if layout == "auto" else "csr_arrays"] = rec
+        del d, mit, bit
+    A.set_layout("auto")
     return out
 
 
@@ -560,6 +614,8 @@ def run_single(args):
             out["gmres_hbm_bound"] = gmres_hbm_bound(A, b, n)
         finally:
             A.set_layout("auto")
+    if not args.no_f_solvers and N >= 128:
+        out["f_solvers"] = f_solvers(A, b, n)
     del A, b, scratch, u
     if not args.no_gmres:
         out["gmres_config3"] = gmres_config3()
@@ -643,6 +699,7 @@ def main():
     ap.add_argument("--no-csr", action="store_true", help="skip the contract loop on the plain CSR arrays (roofline then describes the default layout)")
     ap.add_argument("--no-gmres", action="store_true", help="skip the configs[2] sub-benchmark (gmres_config3)")
     ap.add_argument("--no-gmres-large", action="store_true", help="skip the HBM-bound GMRES leg (gmres_hbm_bound: gmres!(restart=30) on the 256^3 operator)")
+    ap.add_argument("--no-f-solvers", action="store_true", help="skip the SURVEY 8f solvers leg (f_solvers: PCG / Chebyshev / MINRES / BiCGStab(2) per iteration at 256^3)")
     ap.add_argument("--no-config5", action="store_true", help="skip the configs[4] stand-ins (config5)")
     ap.add_argument("--config5-kinds", default="fe_shell,fe_hex,banded,random")
     ap.add_argument("--stencil27", type=int, default=0, help="grid of the 27-point box-stencil sub-benchmark (off by default: outside every BASELINE.json config; frozen, VERDICT r3 #8)")

@@ -126,6 +126,7 @@ struct mik_comm {
     struct GhostMap { int rank; unsigned char handle[64]; void *base; };
     std::vector<GhostMap> ghost_maps;
     bool mail_finegrained = false;       // hipExtMallocWithFlags(hipDeviceMallocFinegrained) succeeded for the mailbox
+    std::vector<struct mik_plink *> links;   // live links on this communicator: orphaned (cm = NULL) when it is destroyed first
     bool mail_ready = false;
     unsigned long long mseq[MIK_MAIL_KINDS] = {0, 0, 0};   // exchanges enqueued so far, per kind
     unsigned long long vseq = 0;         // vector exchanges enqueued so far
@@ -477,9 +478,13 @@ extern "C" int mik_comm_create(mik_ctx *ctx, const void *id128, int rank, int nr
     return MIK_OK;
 }
 
+static void plink_orphan(struct mik_plink *pl);     // (defined with the struct below)
+
 extern "C" int mik_comm_destroy(mik_comm *cm)
 {
     if (!cm) return MIK_OK;
+    for (struct mik_plink *pl : cm->links) plink_orphan(pl);    // a host may destroy the communicator before the iterables that hold links on it
+    cm->links.clear();
     if (cm->ctx) { (void)hipSetDevice(cm->ctx->device); (void)hipStreamSynchronize(cm->ctx->stream); }
     if (cm->side) (void)hipStreamSynchronize(cm->side);
     if (cm->nccl) { Rccl *R = rccl(); if (R) (void)R->CommDestroy(cm->nccl); }
@@ -734,12 +739,15 @@ struct mik_plink {
     bool connected = false;
 };
 
+static void plink_orphan(mik_plink *pl) { pl->cm = nullptr; pl->connected = false; }
+
 static size_t plink_stride(int64_t n_ghost, size_t es) { return ((size_t)std::max<int64_t>(n_ghost, 1) * es + 255) / 256 * 256; }
 
 extern "C" int mik_plink_destroy(mik_plink *pl)
 {
     if (!pl) return MIK_OK;
     if (pl->cm && pl->cm->ctx) { (void)hipSetDevice(pl->cm->ctx->device); (void)hipStreamSynchronize(pl->cm->ctx->stream); if (pl->cm->side) (void)hipStreamSynchronize(pl->cm->side); }
+    if (pl->cm) pl->cm->links.erase(std::remove(pl->cm->links.begin(), pl->cm->links.end(), pl), pl->cm->links.end());
     if (pl->land) (void)hipFree(pl->land);
     delete pl;
     return MIK_OK;
@@ -783,6 +791,7 @@ extern "C" int mik_plink_create(mik_comm *cm, int dtype, int64_t n_ghost, int n_
         return mik_fail(ctx, MIK_ERR_NOMEM, "mik_plink_create: landing buffer (%zu bytes): %s", 2 * pl->land_stride, hipGetErrorString(e));
     }
     pl->connected = pl->send.empty() && pl->recv.empty();
+    cm->links.push_back(pl);
     *out = pl;
     return MIK_OK;
 }
@@ -790,7 +799,7 @@ extern "C" int mik_plink_create(mik_comm *cm, int dtype, int64_t n_ghost, int n_
 // 64-byte HIP IPC handle of this rank's landing buffer (what its neighbours map to push their halo segments)
 extern "C" int mik_plink_export(mik_plink *pl, void *handle64)
 {
-    if (!pl || !handle64) return MIK_ERR_INVALID;
+    if (!pl || !pl->cm || !handle64) return MIK_ERR_INVALID;
     hipIpcMemHandle_t h;
     memset(&h, 0, sizeof(h));
     (void)hipSetDevice(pl->cm->ctx->device);
@@ -804,7 +813,7 @@ extern "C" int mik_plink_export(mik_plink *pl, void *handle64)
 // GHOST REGION at which the segment lands (the offset of the matching receive segment there).
 extern "C" int mik_plink_connect(mik_plink *pl, const void *handles, const int64_t *ghost_counts, const int64_t *dst_elem)
 {
-    if (!pl) return MIK_ERR_INVALID;
+    if (!pl || !pl->cm) return MIK_ERR_INVALID;
     mik_comm *cm = pl->cm;
     mik_ctx *ctx = cm->ctx;
     if (!pl->send.empty() && (!dst_elem || !ghost_counts)) return MIK_ERR_INVALID;
@@ -897,16 +906,17 @@ static int plink_land(mik_plink *pl, void *ghost, unsigned long long no, hipStre
 }
 
 // ---- what csrc/mik_krylov.hip calls for a row-partitioned GMRES with a link (declared in mik_iter.h) -------------------------------
-bool plink_ready(const mik_plink *pl) { return pl && pl->connected && pl->cm && pl->cm->mail_ready; }
-const mik_ctx *plink_ctx(const mik_plink *pl) { return pl->cm->ctx; }
-int plink_rank(const mik_plink *pl) { return pl->cm->rank; }
-int plink_nranks(const mik_plink *pl) { return pl->cm->nranks; }
+bool plink_ready(const mik_plink *pl) { return pl && pl->cm && pl->connected && pl->cm->mail_ready; }
+const mik_ctx *plink_ctx(const mik_plink *pl) { return pl->cm ? pl->cm->ctx : nullptr; }
+int plink_rank(const mik_plink *pl) { return pl->cm ? pl->cm->rank : -1; }
+int plink_nranks(const mik_plink *pl) { return pl->cm ? pl->cm->nranks : 0; }
 
-int plink_check(mik_plink *pl, const char *who) { return mailbox_check(pl->cm, who); }
+int plink_check(mik_plink *pl, const char *who) { return pl->cm ? mailbox_check(pl->cm, who) : MIK_ERR_INVALID; }
 
 // the halo of one SpMV, entirely on the compute stream (behind the pack kernel): push, land
 int plink_halo(mik_plink *pl, const void *send_buf, void *ghost)
 {
+    if (!pl->cm) return MIK_ERR_INVALID;          // the communicator was destroyed before the iterable that holds this link
     mik_comm *cm = pl->cm;
     if (pl->send.empty() && pl->recv.empty()) return MIK_OK;
     const unsigned long long no = ++cm->halo_no;
@@ -917,6 +927,7 @@ int plink_halo(mik_plink *pl, const void *send_buf, void *ghost)
 // level 2 of this rank's `nseg` segment sums + the sum over the ranks in rank order, one launch; mode 0: out[0] = sum, 1: out[0] = sqrt(sum), out[1] = 1 / out[0]
 int plink_fin_sum(mik_plink *pl, const void *partials, int64_t nseg, void *out_dev, int mode)
 {
+    if (!pl->cm) return MIK_ERR_INVALID;          // the communicator was destroyed before the iterable that holds this link
     mik_comm *cm = pl->cm;
     mik_ctx *ctx = cm->ctx;
     const unsigned long long seq = ++cm->mseq[2];
@@ -933,6 +944,7 @@ int plink_fin_sum(mik_plink *pl, const void *partials, int64_t nseg, void *out_d
 // vals_dev[0 .. count): this rank's partial sums -> the sums over the ranks in rank order, in place, one one-wave launch
 int plink_sum_vec(mik_plink *pl, void *vals_dev, int count)
 {
+    if (!pl->cm) return MIK_ERR_INVALID;          // the communicator was destroyed before the iterable that holds this link
     mik_comm *cm = pl->cm;
     mik_ctx *ctx = cm->ctx;
     if (count <= 0) return MIK_OK;
@@ -951,6 +963,7 @@ int plink_sum_vec(mik_plink *pl, void *vals_dev, int count)
 // all_dev[rank] (written by the kernel before on the stream) -> all_dev[0 .. P) on every rank
 int plink_gather(mik_plink *pl, void *all_dev)
 {
+    if (!pl->cm) return MIK_ERR_INVALID;          // the communicator was destroyed before the iterable that holds this link
     mik_comm *cm = pl->cm;
     mik_ctx *ctx = cm->ctx;
     const unsigned long long seq = ++cm->mseq[2];

@@ -33,8 +33,18 @@ for kind in kinds:
     elif kind == "fe_hex":      # 3 unknowns per node, 27-node neighbourhoods, larger than the Infinity Cache
         n, rowptr, colidx, val = pkg.fixtures.fe_matrix((64, 64, 64), 3, np.float32)
     else:
-        n, rowptr, colidx, val = pkg.fixtures.irregular_matrix(n_req, np.float32, long_rows=os.environ.get("LONG", "1") == "1",
-                                                               bandwidth=0 if kind == "random" else int(os.environ.get("BAND", 2000)))
+        # C5_CACHE=<dir>: keep the generated arrays on disk between the separate rocprofv3 passes of one profiling call (the hash-defined
+        # generator takes ~25 s of numpy per matrix)
+        cache = os.path.join(os.environ["C5_CACHE"], f"{kind}_{n_req}.npz") if os.environ.get("C5_CACHE") and os.environ.get("LONG", "1") == "1" and "BAND" not in os.environ else None
+        if cache and os.path.exists(cache):
+            z = np.load(cache)
+            n, rowptr, colidx, val = int(z["n"]), z["rowptr"], z["colidx"], z["val"]
+        else:
+            n, rowptr, colidx, val = pkg.fixtures.irregular_matrix(n_req, np.float32, long_rows=os.environ.get("LONG", "1") == "1",
+                                                                   bandwidth=0 if kind == "random" else int(os.environ.get("BAND", 2000)))
+            if cache:
+                os.makedirs(os.path.dirname(cache), exist_ok=True)
+                np.savez(cache, n=n, rowptr=rowptr, colidx=colidx, val=val)
     cases.append((kind, n, rowptr, colidx, val, time.time() - t0))
 for path in sorted(glob.glob(os.path.join(os.environ.get("MIK_MTX_DIR", "/nonexistent"), "*.mtx"))):
     t0 = time.time()

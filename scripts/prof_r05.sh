@@ -22,9 +22,9 @@ for w in $WHAT; do
  case $w in
  bench)
   D=$OUT/bench; mkdir -p $D
-  rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -o run -- python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-gmres --no-gmres-large --no-config5 > $D/trace.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -o run -- python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-gmres --no-gmres-large --no-f-solvers --no-config5 > $D/trace.log 2>&1
   grep "^{" $D/trace.log | tail -1 > $D/bench_under_rocprof.json
-  B="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-parity --no-gmres --no-gmres-large --no-config5"
+  B="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-parity --no-gmres --no-gmres-large --no-f-solvers --no-config5"
   [ "${PMC:-1}" = "0" ] && continue            # PMC=0: the kernel trace only
   pmc $D/pmc_fetch FETCH_SIZE -- $B
   pmc $D/pmc_write WRITE_SIZE -- $B
@@ -64,14 +64,17 @@ for w in $WHAT; do
   for k in ${C5_KINDS:-random}; do
    D=$OUT/c5_$k; mkdir -p $D
    C5="python $R/scripts/config5_bench.py"
-   export KINDS=$k CSR=0
-   GMRES=1 rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -o run -- $C5 > $D/trace.log 2>&1
-   grep "==\|SpMV\|gmres" $D/trace.log > $D/config5_under_rocprof.txt
+   export KINDS=$k CSR=0 C5_CACHE=/tmp/c5cache
+   if [ "${C5_TA_ONLY:-0}" != "1" ]; then
+    GMRES=1 rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -o run -- $C5 > $D/trace.log 2>&1
+    grep "==\|SpMV\|gmres" $D/trace.log > $D/config5_under_rocprof.txt
+    export GMRES=0
+    pmc $D/pmc_fetch FETCH_SIZE -- $C5
+    pmc $D/pmc_write WRITE_SIZE -- $C5
+    pmc $D/pmc_l2 TCC_HIT_sum TCC_MISS_sum -- $C5
+   fi
    export GMRES=0
-   pmc $D/pmc_fetch FETCH_SIZE -- $C5
-   pmc $D/pmc_write WRITE_SIZE -- $C5
-   pmc $D/pmc_l2 TCC_HIT_sum TCC_MISS_sum -- $C5
-   if [ "${C5_SQ:-0}" = "1" ]; then
+   if [ "${C5_SQ:-0}" = "1" ] || [ "${C5_TA_ONLY:-0}" = "1" ]; then      # texture addresser / L1: what closes the `random` item
     pmc $D/pmc_ta TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE -- $C5
     pmc $D/pmc_tcp TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum -- $C5
    fi
