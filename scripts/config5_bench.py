@@ -62,7 +62,7 @@ for kind, n, rowptr, colidx, val, tgen in cases:
     b = pkg.HipVector.from_numpy(pkg.fixtures.hashed_rhs(n, dtype=val.dtype))
     y = pkg.HipVector(n, val.dtype)
     extra = {int(a.split("=")[0]): int(a.split("=")[1]) for a in os.environ.get("MIK_KNOBS", "").split(",") if a}     # development knobs for A/B runs
-    for knobs, name in ((extra, "default layout" + (f" + knobs {extra}" if extra else "")), ({0: 8, 1: 1}, "CSR only: k_spmv_rowblock (products in LDS, long rows merged)")   # MIK_KNOB_LAYOUTS bit 8 = no jagged slices, MIK_KNOB_CSR_KERNEL = 1):
+    for knobs, name in ((extra, "default layout" + (f" + knobs {extra}" if extra else "")), ({0: 8, 1: 1}, "CSR only: k_spmv_rowblock (products in LDS, long rows merged)")):   # MIK_KNOB_LAYOUTS bit 8 = no jagged slices, MIK_KNOB_CSR_KERNEL = 1
         if knobs is not extra and os.environ.get("CSR", "1") != "1":
             continue
         for k, vv in knobs.items():

@@ -16,7 +16,8 @@ WHAT=${@:-bench gmres_large spmv_large}
 export MIK_BENCH_MIN_SECONDS=0            # profiled runs: one timed region is enough
 pmc() {   # pmc <dir> <counters...> -- <command...>
   local d=$1; shift; local C=(); while [ "$1" != "--" ]; do C+=("$1"); shift; done; shift
-  rocprofv3 --kernel-trace --pmc "${C[@]}" --output-format csv -d $d -o run -- "$@" > $d.log 2>&1 || echo "pmc pass $d (${C[*]}) failed"
+  # (a counter set the hardware cannot collect in one pass makes rocprofv3 abort and then hang: bounded)
+  timeout -k 5 ${PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc "${C[@]}" --output-format csv -d $d -o run -- "$@" > $d.log 2>&1 || echo "pmc pass $d (${C[*]}) failed"
 }
 for w in $WHAT; do
  case $w in
@@ -75,8 +76,10 @@ for w in $WHAT; do
    fi
    export GMRES=0
    if [ "${C5_SQ:-0}" = "1" ] || [ "${C5_TA_ONLY:-0}" = "1" ]; then      # texture addresser / L1: what closes the `random` item
-    pmc $D/pmc_ta TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE -- $C5
-    pmc $D/pmc_tcp TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum -- $C5
+    pmc $D/pmc_ta TA_BUSY_avr GRBM_GUI_ACTIVE -- $C5
+    pmc $D/pmc_ta2 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum -- $C5
+    pmc $D/pmc_tcp TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum -- $C5
+    pmc $D/pmc_tcp2 TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum -- $C5
    fi
    unset GMRES KINDS CSR
   done

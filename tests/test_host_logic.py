@@ -132,3 +132,15 @@ def test_x_window_rule_never_leaves_a_referenced_column_outside(pkg, dtype, n):
         assert not have[-1]                                               # the advisor's case: the last block cannot have a window
     else:
         assert have.all()
+
+
+def test_every_script_and_the_bench_parse():
+    """scripts/ are not imported by anything: a syntax error in one of them would only show on the GPU box, in the middle of a profiling call"""
+    import ast
+    import glob
+    import subprocess
+    from conftest import ROOT
+    for f in sorted(glob.glob(os.path.join(ROOT, "scripts", "*.py"))) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]:
+        ast.parse(open(f).read(), filename=f)
+    for f in sorted(glob.glob(os.path.join(ROOT, "scripts", "*.sh"))):
+        assert subprocess.run(["bash", "-n", f]).returncode == 0, f
