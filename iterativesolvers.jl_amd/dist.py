@@ -1204,12 +1204,13 @@ def bench_main(args):
     #   rccl          halo by ncclSend / ncclRecv on the side stream, the two scalars of a step by ncclAllGather
     #   rccl+mailbox  halo by RCCL, scalars as stores into peer-mapped mailboxes (no collective launch on the compute stream)
     #   mailbox       no RCCL at all: scalars by mailbox, halo pushed into IPC-mapped ghost regions
-    # (1) parity: every transport solves a SMALL global system (64 x 64 x 8 P) to the default tolerance in both operator layouts and rank 0
-    #     compares history and solution with the partition-aware oracle (bench.py hands the checker in; this module never imports oracle/).
     # (2) every transport that came up runs the warm-up and the timed regions in the operator's default layout; their first residuals must
     #     agree bit for bit; the fastest of the largest agreeing group is `transport_chosen`.
     # (3) the CONTRACT loop: the chosen transport on the plain CSR arrays of the slab (mik_csr_set_layout(A_loc, 0), k_spmv_rowgather) --
     #     `value`, `ms_per_step` and `roofline` describe this loop, exactly as at N = 1.
+    # (1) parity, last (a hang in it cannot cost the timed line): every transport solves a SMALL global system (64 x 64 x 8 P) to the default
+    #     tolerance in both operator layouts and rank 0 compares history and solution with the partition-aware oracle (bench.py hands the
+    #     checker in; this module never imports oracle/).
     # MIK_NATIVE_TRANSPORTS narrows / reorders the list.
     transports = {}
     chosen = None
@@ -1218,10 +1219,17 @@ def bench_main(args):
     watchdog = {"timer": None}
 
     def emergency_line():
-        """A transport measured AFTER a good one hangs (no device-to-device transfer of any kind could be tried before the driver's own
-        multi-GPU run): every rank leaves, rank 0 first prints the line of the best transport measured so far (default layout: the
-        contract loop had not been reached)."""
-        if rank == 0 and chosen is not None:
+        """Something measured AFTER a good transport hangs (no device-to-device transfer of any kind could be tried before the driver's own
+        multi-GPU run): every rank leaves, rank 0 first prints the line of what has been measured so far -- the complete line without
+        parity_vs_oracle if the hang is in the parity leg, the default-layout line of the best transport if it is in a later transport or in the
+        contract loop."""
+        note = "a leg that ran after this measurement did not return in time; the process left with the line it had"
+        if rank == 0 and state.get("line_ready"):
+            line = make_line(note)
+            if line.get("parity_vs_oracle") is None:
+                line["parity_vs_oracle"] = {"reached": False, "note": "the parity leg runs last and did not finish"}
+            print(json.dumps(line), flush=True)
+        elif rank == 0 and chosen is not None:
             ms = transports[chosen]["ms_per_step"]
             print(json.dumps({
                 "metric": "cg_iters_per_sec", "value": 1e3 / ms, "unit": "iters/s", "n_gpus": world, "world_size_checked": world, "steps": K, "warmup": Wm,
@@ -1229,8 +1237,7 @@ def bench_main(args):
                 "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": f"cg! on the {N}x{N}x{nz * world} 3D 7-point Laplacian row-partitioned into {world} z-slab(s) of {N}x{N}x{nz} rows",
                            "n": int(n), "n_per_gpu": plan.n_loc, "host_sync_per_step": 1, "transport_chosen": chosen, "transports_measured": transports,
-                           "operator_layout_of_the_timed_loop": "default (slice-constant); the CSR contract loop was not reached",
-                           "watchdog": "a transport measured after this one did not return in time; the process left with the best line it had"},
+                           "operator_layout_of_the_timed_loop": "default (slice-constant); the CSR contract loop was not reached", "watchdog": note},
                 "roofline": None}), flush=True)
         os._exit(0 if chosen is not None else 3)
 
@@ -1245,15 +1252,11 @@ def bench_main(args):
 
     parity = None
     contract = None
-    if transport == "native":
-        # (order: the transport whose waits are all bounded first -- once it has been measured, a hang of a later one is survivable)
-        default = "mailbox,rccl+mailbox,rccl" if (world > 1 or self_halo) else "rccl"
-        names = [t for t in os.environ.get("MIK_NATIVE_TRANSPORTS", default).split(",") if t]
-        force = self_halo or os.environ.get("MIK_DIST_FORCE_COLLECTIVES", "0") == "1"
-        if world == 1:
-            pkg.lib().mik_set_tuning(6, int(os.environ.get("MIK_KNOB6", "4")))     # a world of one still sends its scalars through the mailbox (development)
-
-        # ---- (1) parity against the partition-aware oracle on a small global system ------------------------------------------------
+    names, force = [], False
+    def run_parity():
+        """every transport solves a SMALL global system (64 x 64 x 8 P) to the default tolerance in both operator layouts; rank 0 compares history
+        and solution with the partition-aware oracle (bench.py hands the checker in; this module never imports oracle/)"""
+        nonlocal parity
         check = getattr(args, "partition_oracle_fn", None)
         if check is not None and not self_halo and not getattr(args, "no_parity", False):
             Ns, nzs = 64, 8
@@ -1297,7 +1300,15 @@ def bench_main(args):
                 ok = [k2 for k2, v in parity["transports"].items() if v.get("bit_identical")]
                 parity["bit_identical"] = bool(ok) and all(v.get("bit_identical") for v in parity["transports"].values() if v.get("came_up"))
                 parity["transports_bit_identical"] = ok
-            del small, sp, sli, sv
+
+
+    if transport == "native":
+        # (order: the transport whose waits are all bounded first -- once it has been measured, a hang of a later one is survivable)
+        default = "mailbox,rccl+mailbox,rccl" if (world > 1 or self_halo) else "rccl"
+        names = [t for t in os.environ.get("MIK_NATIVE_TRANSPORTS", default).split(",") if t]
+        force = self_halo or os.environ.get("MIK_DIST_FORCE_COLLECTIVES", "0") == "1"
+        if world == 1:
+            pkg.lib().mik_set_tuning(6, int(os.environ.get("MIK_KNOB6", "4")))     # a world of one still sends its scalars through the mailbox (development)
 
         # ---- (2) every transport in the operator's default layout -----------------------------------------------------------------
         alive = {}
@@ -1406,7 +1417,8 @@ def bench_main(args):
     elif watchdog["timer"] is not None:
         watchdog["timer"].cancel()
 
-    if rank == 0:
+    def make_line(note=None):
+        """the JSON line from whatever has been measured so far (the watchdog prints it too, with `note`)"""
         halo = int(plan.n_ghost)
         s8 = 8
         iter_alg = alg_bytes + 9 * plan.n_loc * s8               # SURVEY.md 8d: B_cg = B_spmv + 9 n s, on this rank's slab
@@ -1476,6 +1488,19 @@ def bench_main(args):
             "parity_vs_oracle": parity,
             "roofline": roofline,
         }
+        if note:
+            out["config"]["watchdog"] = note
+        return out
+
+    state["line_ready"] = True
+    if transport == "native":
+        # ---- (1) parity, LAST: whatever happens in it, the timed line exists (the watchdog prints it with parity_vs_oracle = "not reached") ----------
+        arm_watchdog()
+        run_parity()
+        if watchdog["timer"] is not None:
+            watchdog["timer"].cancel()
+    if rank == 0:
+        out = make_line()
         fn = getattr(args, "cpu_baseline_fn", None)
         if fn is not None and not getattr(args, "no_cpu_baseline", False):
             # the reference-shaped CPU restatement on this box's host cores, in the same run (rank 0 only; the other ranks wait at the
