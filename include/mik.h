@@ -132,7 +132,7 @@ int mik_fill(mik_ctx *ctx, int dtype, int64_t n, const void *value, void *x); /*
  * Int32 CSR (CSC -> CSR transpose, columns ascending within a row = the order Julia's column scatter reaches a row), the
  * operator statistics and the layout analysis run there as kernels (csrc/mik_upload.hip; 0.06 s for the 256^3 Laplacian).
  * Matrices with rows longer than mik_spmv_long_row() or with duplicate (row, column) entries take the host path
- * (single-threaded counting-sort transpose + builders), as does everything when development knob 20 is set. */
+ * (single-threaded counting-sort transpose + builders), as does everything when the development knob MIK_KNOB_UPLOAD is set. */
 int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_cols, int64_t nnz,
                    const int64_t *ptr, const int64_t *idx, const void *val, int index_base,
                    int is_csc, mik_csr **out);

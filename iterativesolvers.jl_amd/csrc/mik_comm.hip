@@ -1022,7 +1022,7 @@ extern "C" int mik_comm_mailbox_info(const mik_comm *cm, int *ready, int *finegr
 // kernel on the side stream waits for it; the side stream (or, for peer-mapped ghosts, the sender's push kernel) stores it in the
 // receiver's mailbox and a one-wave kernel on the compute stream waits there.  hipEventRecord / hipStreamWaitEvent each cost the
 // compute stream a ~6 us hole between two kernels (profiles/r03_dist_selfhalo_timeline.txt); a 1-thread launch costs ~2.
-// Development knob 6, bit 0: events.  Every waiting kernel is submitted after the kernel that satisfies it, so streams that share a
+// MIK_KNOB_TRANSPORT, bit 0: events.  Every waiting kernel is submitted after the kernel that satisfies it, so streams that share a
 // hardware queue cannot deadlock.
 static bool halo_flags(const mik_cgd *it) { return it->comm && it->comm->mail && (it->base.ctx->tuning[MIK_KNOB_TRANSPORT] & 1) == 0; }
 static bool halo_p2p(const mik_cgd *it) { return it->comm && it->comm->mail_ready && it->ghosts && it->link; }
@@ -1112,7 +1112,7 @@ static int gather_scalar(mik_cgd *it, void *all, int kind)
     mik_comm *cm = it->comm;
     if (!cm) return MIK_OK;
     mik_ctx *ctx = it->base.ctx;
-    // development knob 6, bit 1: the scalars over RCCL although a mailbox is connected; bit 2: through the mailbox even in a world of one
+    // MIK_KNOB_TRANSPORT, bit 1: the scalars over RCCL although a mailbox is connected; bit 2: through the mailbox even in a world of one
     if (cm->mail_ready && (ctx->tuning[MIK_KNOB_TRANSPORT] & 2) == 0 && (it->nranks > 1 || (ctx->tuning[MIK_KNOB_TRANSPORT] & 4) != 0)) {
         const unsigned long long seq = ++cm->mseq[kind];
         if (it->base.dtype == MIK_F64)
@@ -1226,7 +1226,7 @@ extern "C" int mik_cgd_init(mik_cgd *it, double *residual, double *tol)
 // only u (with its halo), c and this rank's dot slot -- all of its inputs are final once the previous tail has run -- so the
 // head of the step after a call is enqueued before the host waits (as in the single-GPU path, cg_enqueue_head); every rank
 // takes the same decision (same iteration counts, identical stopping scalars), so the RCCL call sequences stay aligned.
-// the step's two scalar exchanges inside the finalising kernels: a connected mailbox, more than one rank (or development knob 6 bit 2),
+// the step's two scalar exchanges inside the finalising kernels: a connected mailbox, more than one rank (or MIK_KNOB_TRANSPORT bit 2),
 // not switched to the one-wave gather launches (bit 3) or to RCCL (bit 1)
 static bool mail_fused(const mik_cgd *it)
 {
@@ -1339,7 +1339,7 @@ extern "C" int mik_cgd_iterate_many(mik_cgd *it, int64_t iteration, int64_t max_
     mik_cg &bs = it->base;
     if (max_steps <= 0 || iteration >= bs.maxiter || bs.residual <= bs.tol) return MIK_OK;      // done(it, iteration), src/cg.jl:36
     max_steps = std::min<int64_t>(std::min<int64_t>(max_steps, bs.maxiter - iteration), bs.hist_cap);
-    const bool ahead_ok = bs.ctx->tuning[MIK_KNOB_NO_LOOKAHEAD] == 0 && iteration + max_steps < bs.maxiter;      // development knob 9: 1 = nothing ahead of the host
+    const bool ahead_ok = bs.ctx->tuning[MIK_KNOB_NO_LOOKAHEAD] == 0 && iteration + max_steps < bs.maxiter;      // MIK_KNOB_NO_LOOKAHEAD: nothing ahead of the host
     bs.fuse_x = (bs.ctx->tuning[MIK_KNOB_CG_STEP] & 1) == 0;                              // x .+= alpha .* u rides on the next sweep over u (as in mik_cg_*)
     CgMirror m;
     for (int64_t j0 = 0;;) {

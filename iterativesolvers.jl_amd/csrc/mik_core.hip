@@ -684,7 +684,7 @@ static int csr_build_sdiaw(mik_ctx *ctx, mik_csr *A, const std::vector<int> &row
 // Rows of a 256-row block over its threads by length (k_spmv_rowblock RPERM, csrc/mik_spmv.h): the row with rank p among the block's
 // rows (longest first, ties in row order) goes to thread ((p / 64 + block) % 4) * 64 + p % 64 -- the 64 longest rows share a wave, and
 // that wave is a different one (a different SIMD) from block to block.  Built for the operators the product tile runs (irregular row
-// lengths: split-off long rows or rows beyond 32 entries); development knob 29 = 1: never.
+// lengths: split-off long rows or rows beyond 32 entries); MIK_KNOB_LAYOUTS bit 5: never.
 int mik_build_rperm_host(mik_ctx *ctx, mik_csr *A, const int *rowptr)
 {
     const int64_t n = A->n_rows;
@@ -712,7 +712,7 @@ int mik_build_rperm_host(mik_ctx *ctx, mik_csr *A, const int *rowptr)
 // Built for irregular operators (split-off long rows or rows beyond 32 entries: the uniform short-row operators stay with the
 // LDS-DMA tile of k_spmv_rowgather) when the blocks that span at most 32 KB of x hold three quarters of the entries and x is at least
 // one span long; a wider block (rows that wrap around the matrix) is marked -1 and gathers from memory; a window that would leave x at
-// the end of the vector slides down.  Development knob 29: 1 = never (read here), 2 = not used at launch.
+// the end of the vector slides down.  MIK_KNOB_LAYOUTS bit 5 = never (read here), bit 6 = not used at launch.
 static int csr_build_xwin(mik_ctx *ctx, mik_csr *A, const std::vector<int> &rowptr, const std::vector<int> &col, size_t es, int64_t n_rows, int64_t n_cols,
                           int max_row)
 {
@@ -852,7 +852,7 @@ extern "C" int mik_csr_create(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n
     if (!dev_in) return csr_create_impl(ctx, dtype, n_rows, n_cols, nnz, ptr, idx, val, index_base, is_csc, false, out);
     int rc = csr_create_impl(ctx, dtype, n_rows, n_cols, nnz, ptr, idx, val, index_base, is_csc, true, out);
     if (rc != MIK_ERR_NOTIMPL) return rc;
-    // the host path's matrices (long rows, duplicates, knob 20): stage the arrays on the host once
+    // the host path's matrices (long rows, duplicates, MIK_KNOB_UPLOAD): stage the arrays on the host once
     const int64_t n_major = is_csc ? n_cols : n_rows;
     const size_t es = mik_dtype_size(dtype);
     std::vector<int64_t> hp, hi;
@@ -928,7 +928,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
     std::vector<int> rowptr, col;
     std::vector<unsigned char> v;
     // Default: everything past the raw host-to-device copy happens on the device (mik_upload.hip).  MIK_ERR_NOTIMPL from it
-    // = a matrix the host path below handles (long rows, duplicate entries, no room for the raw copy); development knob 20:
+    // = a matrix the host path below handles (long rows, duplicate entries, no room for the raw copy); MIK_KNOB_UPLOAD:
     // 1 = host path only.
     if (ctx->tuning[MIK_KNOB_UPLOAD] != 1 && nnz > 0 && n_rows > 0 && n_cols > 0 && n_rows < 0x7f000000) {       // (row ids below the "no row yet" pattern of the analysis)
         mik_csr *A = new (std::nothrow) mik_csr();
@@ -937,7 +937,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
         (void)hipSetDevice(ctx->device);
         int rc = mik_upload_device(ctx, A, dtype, n_rows, n_cols, nnz, ptr, idx, val, index_base, is_csc);
         // no <= 8-offset layout: the wide slice-constant form, then the jagged slices, both built on the device from A's CSR arrays
-        // (development knob 20 = 2: through the host builders, from a copy of the device CSR)
+        // (MIK_KNOB_UPLOAD = 2: through the host builders, from a copy of the device CSR)
         if (rc == MIK_OK && !A->sdia_val && !A->sdia_pats && (ctx->tuning[MIK_KNOB_LAYOUTS] & 1) == 0 && ctx->tuning[MIK_KNOB_UPLOAD] != 2) {
             rc = mik_build_sdiaw_device(ctx, A);
             if (rc == MIK_OK) rc = mik_build_jds_device(ctx, A);
@@ -1333,7 +1333,7 @@ static bool sdiab2_applies(const mik_csr *A)
 // y = A x + c w, dot(x, y) -- the Lanczos step of MINRES -- and dot(z, y) in place of dot(x, y) -- sigma and rho of BiCGStab(l)
 bool mik_spmv_has_epilogue(const mik_csr *A)
 {
-    if (!A || A->ctx->tuning[MIK_KNOB_SOLVER_FORM] == 2) return false;                    // development knob 25 = 2: never
+    if (!A || A->ctx->tuning[MIK_KNOB_SOLVER_FORM] == 2) return false;                    // MIK_KNOB_SOLVER_FORM = 2: never
     const int kc = spmv_kernel_choice(A);
     if (kc == 5) return A->sdia_buf_ok && A->ctx->tuning[MIK_KNOB_SDIA_KERNEL] != 1 && sdiab2_applies(A);
     return (kc == 0 || kc == 1) && A->n_long == 0;                       // the CSR kernels and the jagged slices: one row per thread, no split-off long rows
@@ -1481,7 +1481,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
     }
     if (choice == 6 && (n & 1) == 0 && (uint64_t)A->n_cols * sizeof(T) < 0x7FFFFFF0ull && ctx->tuning[MIK_KNOB_SDIA_KERNEL] != 3 && (rb0 & 1) == 0 &&
         ((nb & 1) == 0 || rb0 + nb == nb_all)) {
-        // ... two rows per lane (k_spmv_sdiaw2): workgroups over PAIRS of slices (development knob 19: 1 = one row per lane)
+        // ... two rows per lane (k_spmv_sdiaw2): workgroups over PAIRS of slices (MIK_KNOB_SDIA_KERNEL = 3: one row per lane)
         const int np = (nb + 1) / 2, pb0 = rb0 / 2;
         const int pmode = map_mode >= 16 ? (map_mode / 2 + 7) / 8 * 8 : 0;       // strips of slice PAIRS
 #define MIK_SDIAW2_GO(FD, NTV)                                                                                                \
@@ -1574,7 +1574,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
     const bool merge = nlong > 0 && !fuse_dot;           // one launch: long-row workgroups first, then row-blocks
     // The operator streams of the product tile are read with the DEFAULT cache policy when x is served from LDS windows: non-temporal
     // streams, right for the stencil operators, cost this kernel 10 % there (banded configs[4] stand-in: 72.8 us streamed, 65.7 us
-    // cached -- profiles/r04_c5_*).  Development knob 0: 1 = cached, 2 = streamed.
+    // cached -- profiles/r04_c5_*).  (A/B in round 5: cached 186.1 us, streamed 191.0 us on `random` -- profiles/r05_c5_random_stream_policy_ab.txt.)
     // (Only where x comes from LDS windows: without them -- the `random` stand-in -- cached streams gain 3 % back to back and lose 6 % inside
     // gmres!, where they push the Krylov basis out of the caches: 260 -> 275 us per inner iteration.)
     const bool nt_rb = !A->xwin_lo;
@@ -1585,7 +1585,7 @@ static int spmv_launch_impl(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bo
         MIK_LAUNCH_CHECK(ctx);
     }
     const dim3 grid(nb + (merge ? nlb : 0)), block(MIK_BLOCK);
-    // x served from an LDS window per row-block (csr_build_xwin; development knob 29 = 2: off at launch) -- wide loads and an aligned x only
+    // x served from an LDS window per row-block (csr_build_xwin; MIK_KNOB_LAYOUTS bit 6: off at launch) -- wide loads and an aligned x only
     const bool xwin = A->xwin_lo && wide && (ctx->tuning[MIK_KNOB_LAYOUTS] & 96) == 0 && mik_aligned16(x);
     constexpr int RB_TILE = MIK_SPMV_TILE * (int)(8 / sizeof(T));
     const size_t dyn = sizeof(T) * ((size_t)RB_TILE + 12 + (xwin ? (size_t)A->xwin_span : 0));          // [product tile + 8][4 wave sums][x window]

@@ -396,7 +396,7 @@ static inline hipError_t mik_wait(mik_ctx *ctx)
 
 // `count` values of the device array `dev`, as soon as everything enqueued before has run.  A one-wave kernel copies them into the
 // context's pinned mailbox and then stores a ticket (system scope); the host spins on the ticket -- no copy engine, no event in
-// the path (hipMemcpyAsync + event spin, development knob 10 = 1, takes several microseconds longer per read, and the solvers that
+// the path (hipMemcpyAsync + event spin, MIK_KNOB_HOST_WAIT bit 0, takes several microseconds longer per read, and the solvers that
 // are driven from the host -- MINRES, BiCGStab(l), the generic GMRES path -- read 2 ... 5 scalars per iteration).
 template <typename T>
 __global__ __launch_bounds__(64) void k_publish(const T *__restrict__ src, int count, T *__restrict__ dst, unsigned long long *ticket, unsigned long long seq)

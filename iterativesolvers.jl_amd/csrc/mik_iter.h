@@ -47,7 +47,6 @@ struct mik_cg {
     bool dev_done = false;           // device stopping flag known to be set
     bool head_ahead = false;         // the head of the next step (u, c, alpha) is on the stream already
     bool fuse_x = false;             // x .+= alpha .* u rides on the next u = r + beta u sweep (plain / Jacobi CG on a CSR operator)
-    unsigned sweeps = 0;             // streaming launches enqueued so far (development knob 27: alternating sweep direction)
     // optional in-loop timing of the SpMV launch (HIP events on the ctx stream)
     int profile = 0;               // 0 off, 1 = the SpMV launch, 2 = SpMV + the two vector sweeps of the step
     std::vector<hipEvent_t> ev;    // pairs (start, stop), recycled

@@ -723,7 +723,7 @@ template <typename T> static int cg_enqueue_tail(mik_cg *it, long long it_next, 
     if (it->pcg_fused) {
         {
             CgProfileScope ps(it, 2);
-            // r is not read again before the next tail (the head reads c = Pl \\ r, u, x): both directions streamed unless development knob 7 says otherwise.
+            // r is not read again before the next tail (the head reads c = Pl \\ r, u, x): both directions streamedherwise.
             // c too (bits 5, 6; round 4): c = Pl \\ r stored with the default policy shares the 256 MB Infinity Cache with the u the head writes for the SpMV --
             // streamed, the in-loop SpMV runs at its back-to-back time (73 -> 52 us) and this sweep pays most of it back (99 -> 116 us): 280.7 -> 275.6 us
             // per step, ten words per row + the operator at the copy ceiling (profiles/r04_pcg_kernel_stats.txt).
@@ -965,7 +965,7 @@ static int cg_iterate_many_impl(mik_cg *it, int64_t iteration, int64_t max_steps
     if (it->dev_done) MIK_HIP(ctx, hipMemsetAsync(&d->done, 0, sizeof(int), ctx->stream));
     CgMirror m;
     // the head of the step AFTER this call goes on the stream before the host waits (never with host callbacks, whose call
-    // count the caller may observe; development knob 9: 1 = off)
+    // count the caller may observe; MIK_KNOB_NO_LOOKAHEAD: off)
     const bool ahead_ok = ctx->tuning[MIK_KNOB_NO_LOOKAHEAD] == 0 && !it->op_mul && !it->pl_fn && iteration + max_steps < it->maxiter;
     for (int64_t j0 = 0;;) {
         for (int64_t j = j0; j < max_steps; ++j) {
@@ -1696,7 +1696,7 @@ template <typename T> static int gm_fused_enqueue(mik_gmres *g, int k, int slot)
     // Modified Gram-Schmidt on small systems: the XCD-local form (k_mgs_fused XL) -- at most 128 workgroups, all on the first XCD, a column
     // of at most 512 KB per pass: every column then comes through ONE XCD's share of the fabric (~1 MB per us).  fe_shell (363 KB columns):
     // GMRES(50) 64.2 -> 50.9 us per inner iteration; configs[2] (1 MB columns) would lose (36.5 -> 47.8 us) and keeps the device-wide
-    // form.  Development knob 5 = 4: the device-wide form at every size.
+    // form.  MIK_KNOB_GS = 4: the device-wide form at every size.
     const bool xl = g->method == MIK_MGS && G == 1 && vec && m <= 128 && ((size_t)n * sizeof(T) <= (1u << 19) || ctx->tuning[MIK_KNOB_GS] == 5) && !g->xl_off && ctx->tuning[MIK_KNOB_GS] != 4 && g->xl_chk;   // (knob 5 = 5: whatever the column size)
     g->xl_last = xl;
     if (xl) {

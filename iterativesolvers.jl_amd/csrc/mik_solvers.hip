@@ -324,7 +324,7 @@ extern "C" int mik_bicgstab_create(mik_ctx *ctx, const mik_csr *A, int l, void *
 // at launch-bound sizes take at most 1024 partials.)
 template <typename T> static bool bicg_fuses(const mik_bicgstab *it)
 {
-    if (!it->fuse || !mik_spmv_has_epilogue(it->A)) return false;     // (development knob 25 = 2: no epilogues)
+    if (!it->fuse || !mik_spmv_has_epilogue(it->A)) return false;     // (MIK_KNOB_SOLVER_FORM = 2: no epilogues)
     const int64_t nseg = mik_nseg<T>(it->n), nb = mik_spmv_nwg(it->n);
     const bool lean = nseg <= 1024 && it->ctx->tuning[MIK_KNOB_SOLVER_FORM] == 0;
     return !lean || nb <= 1024;

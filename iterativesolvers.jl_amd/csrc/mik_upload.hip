@@ -411,7 +411,7 @@ int upload_device_t(mik_ctx *ctx, mik_csr *A, int64_t n_rows, int64_t n_cols, in
     S.release(d_ptr); S.release(d_idx); S.release(d_val); S.release(cursor);       // the raw copy (2 GB at 256^3) is consumed
     long_row = MIK_LONG_ROW;
     // the host path's business: duplicates, rows to split off -- and ANY row beyond 256 entries, which k_up_sort_rows does not sort
-    // (whatever development knob 4 says: an unsorted row would break the ascending-column order = Julia's scatter order)
+    // (an unsorted row would break the ascending-column order = Julia's scatter order)
     if (hs.dup || hs.max_row > long_row || hs.max_row > 256) { rc = MIK_ERR_NOTIMPL; goto give_up; }
     A->max_row_nnz = hs.max_row;
     A->max_rowblock_nnz = hs.max_rb;

@@ -1,4 +1,4 @@
-"""Operator upload time (mik_csr_create) at 256^3: device-side pipeline vs the host path (development knob 20 = 1).
+"""Operator upload time (mik_csr_create) at 256^3: device-side pipeline vs the host path (MIK_KNOB_UPLOAD = 1).
 
     python scripts/upload_bench.py            # N=256 by default
 """

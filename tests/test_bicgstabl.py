@@ -93,7 +93,7 @@ def step_dot_shape(pkg, dA, b, l, **kw):
 @pytest.mark.parametrize("l", [2, 4])
 @pytest.mark.parametrize("knob25", [0, 1, 2])
 def test_device_matches_oracle_bit_exact(pkg, orc, ctx, l, dtype, knob25):
-    """the reference authors' own BiCGStab benchmark operator (benchmark/benchmark-linear-systems.jl:68-77), small.  Development knob 25:
+    """the reference authors' own BiCGStab benchmark operator (benchmark/benchmark-linear-systems.jl:68-77), small.  Development knob MIK_KNOB_SOLVER_FORM:
     0 = the sweeps finalise the reductions in front of them, 1 = separate finaliser launches, 2 = no SpMV epilogues (sigma and rho as
     sweeps of their own, in the vector shape)"""
     A, b = orc.advdiff(12, 300.0)
@@ -154,7 +154,7 @@ def test_gram_equals_pairwise_dots(pkg, orc, ctx, dtype, n, k):
 @pytest.mark.parametrize("N", [14, 11])
 def test_fused_bicgstab_equals_statement_by_statement(pkg, orc, ctx, l, dtype, N):
     """the whole-iteration call and the statement-by-statement path against the oracle, each with the tree of its own sigma / rho (the
-    call forms them in the SpMV launches: one partial per 256-row block); with the epilogues off (development knob 25 = 2) the two
+    call forms them in the SpMV launches: one partial per 256-row block); with the epilogues off (MIK_KNOB_SOLVER_FORM = 2) the two
     paths give the same bits"""
     A, b = orc.advdiff(N, 300.0)                             # (an even n: the operator's default kernel, two rows per lane, takes epilogues; N = 11: it does not)
     A, b = A.astype(dtype), b.astype(dtype)
@@ -334,7 +334,7 @@ def test_whole_iteration_calls_validate_their_arguments(pkg, ctx):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_whole_iteration_calls_with_separate_finalisers(pkg, orc, ctx, dtype):
     """Beyond 1,024 reduction segments mik_bicgstab_step / mik_minres_step run their finalisers as separate launches; development
-    knob 25 selects that form at any size: same histories and x as the launch-lean form (and therefore as the oracle)."""
+    MIK_KNOB_SOLVER_FORM = 1 selects that form at any size: same histories and x as the launch-lean form (and therefore as the oracle)."""
     A, b = orc.advdiff(12, 300.0)
     A, b = A.astype(dtype), b.astype(dtype)
     dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)

@@ -406,7 +406,7 @@ def test_mailbox_transport_ranks_in_processes_on_one_gpu(pkg, orc, ctx, tmp_path
     kernel on the side stream, flags instead of events.  2 and 3 ranks as separate PROCESSES on the one GPU of the box (HIP IPC has
     no one-rank-per-device rule; RCCL is not loaded at all); bit-exact against the partition-aware oracle, also on a right-hand
     side that sends every step through the scaled norm across the ranks (three more gathers per step, lane 2 of the mailbox).
-    Development knob 6: 8 = the step's scalars through the one-wave gather launches instead of inside the finalisers; 1 = the pack ->
+    MIK_KNOB_TRANSPORT: 8 = the step's scalars through the one-wave gather launches instead of inside the finalisers; 1 = the pack ->
     push ordering by an event instead of a flag."""
     import torch.multiprocessing as mp
     N, nz = 16, 4
@@ -717,7 +717,7 @@ def test_full_rccl_step_on_one_device_through_a_periodic_self_halo(pkg, orc, ctx
     b = orc.hashed_rhs(n)
     eng = d.HipEngine(pkg, S.indptr.astype(np.int64), li, S.data.copy(), plan, b, abstol=0.0, reltol=1e-9, maxiter=10 ** 6)
     assert eng.overlap == overlap
-    # transports: RCCL with flags (default) or events (development knob 6 bit 0) ordering the side stream; the two scalars through the
+    # transports: RCCL with flags (default) or events (MIK_KNOB_TRANSPORT bit 0) ordering the side stream; the two scalars through the
     # mailbox although the world is one rank (bit 2); no RCCL at all -- the halo pushed into the rank's own ghost region
     pkg.lib().mik_set_tuning(6, knob6)
     nc = d.NativeComm(pkg, eng.ctx, d.SelfComm(), force_rccl=transport != "mailbox", transport=transport)

@@ -90,7 +90,7 @@ def _port(salt):
 def test_cg_every_transport_across_devices_matches_partitioned_oracle(pkg, orc, ctx, tmp_path, transport, scale, batch, knob6):
     """mik_cgd_iterate_many, one rank per device: history and solution bit-exact against the oracle's cg! with the same partition;
     right-hand sides scaled by 1e-140 / 1e+140 freeze every step on the same total on every rank and finish it with the scaled
-    norm across the ranks (tests/test_dist.py does this with all ranks on one GPU).  knob 6: 1 = the side stream ordered by
+    norm across the ranks (tests/test_dist.py does this with all ranks on one GPU).  MIK_KNOB_TRANSPORT: 1 = the side stream ordered by
     events instead of mailbox flags, 8 = the step's scalars through the one-wave gather launches."""
     import torch.multiprocessing as mp
     N, nz = 16, 4

@@ -323,7 +323,7 @@ def test_orthogonalize_bit_exact_and_invariants(pkg, orc, ctx, method, n, k, dty
 @pytest.mark.parametrize("orth,knob5", [("mgs", 0), ("mgs", 4), ("cgs", 0), ("dgks", 0)])
 def test_gmres_history_bit_exact_vs_tree_oracle(pkg, orc, ctx, orth, knob5):
     """(Modified Gram-Schmidt on a system this small runs the XCD-local form of the single-launch kernel -- all participants on one XCD,
-    slots coherent in its L2; development knob 5 = 4: the device-wide form.  Same bits.)"""
+    slots coherent in its L2; MIK_KNOB_GS = 4: the device-wide form.  Same bits.)"""
     A, b = orc.advdiff(12, 1000.0)
     W, L = shape_of(ctx, np.float64)
     M = {"mgs": pkg.ModifiedGramSchmidt(), "cgs": pkg.ClassicalGramSchmidt(), "dgks": pkg.DGKS()}[orth]
@@ -596,7 +596,7 @@ def test_orthogonalize_vector_of_vectors_equals_the_matrix_method(pkg, orc, ctx,
 @pytest.mark.parametrize("dtype,N", [(np.float64, 67), (np.float64, 85), (np.float64, 107), (np.float32, 85), (np.float32, 107), (np.float32, 135)])
 def test_gmres_single_launch_gram_schmidt_beyond_256_segments(pkg, orc, ctx, dtype, N):
     """k_mgs_fused / k_cgs_fused with G = 2, 4, 8 reduction segments per workgroup (n up to 2048 segments): the
-    residual history, x and the counters of the multi-launch chains (development knob 31), bit for bit, for MGS, CGS and DGKS;
+    residual history, x and the counters of the multi-launch chains (MIK_KNOB_GS = 2), bit for bit, for MGS, CGS and DGKS;
     the smallest size also against the oracle"""
     A, b = orc.advdiff(N, 300.0)
     A = A.astype(dtype)

@@ -1,5 +1,5 @@
 """mik_csr_create: the device-side upload pipeline (csrc/mik_upload.hip: raw CSC -> validated Int32 CSR + layout analysis on
-the device) against the host path (development knob 20 = 1) and the oracle: same layout choice, same stored bytes, same bits
+the device) against the host path (MIK_KNOB_UPLOAD = 1) and the oracle: same layout choice, same stored bytes, same bits
 out of mul_ -- for symmetric and nonsymmetric CSC input, CSR input, a rank's rectangular block, empty rows, both dtypes --
 and the matrices that are handed back to the host path (long rows, duplicate entries).  GPU box only."""
 import numpy as np

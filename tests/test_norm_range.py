@@ -107,7 +107,7 @@ def test_gmres_on_a_badly_scaled_system(pkg, orc, ctx, orth):
 @pytest.mark.parametrize("batch", [1, 4])
 def test_cg_stepping_at_128_cubed_through_freezes_and_maxiter(pkg, orc, ctx, scale, knob9, batch):
     """The production-size step (2 M rows: spread finalisers, look-ahead, x riding on the next sweep over u) stepped one by one and in
-    batches, with look-ahead on and off (knob 9), on a right-hand side whose |r|^2 leaves the safe range in every step (each step frozen
+    batches, with look-ahead on and off (MIK_KNOB_NO_LOOKAHEAD), on a right-hand side whose |r|^2 leaves the safe range in every step (each step frozen
     and finished by the host: x must not be updated twice, whichever kernel applied it), into maxiter and beyond: bit for bit the
     oracle's history and x."""
     A = orc.laplace(128, 3)
