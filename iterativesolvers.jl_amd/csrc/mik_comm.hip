@@ -19,7 +19,9 @@
 #include <algorithm>
 #include <new>
 
+#include "mik_kernels.h"
 #include "mik_iter.h"
+#include "mik_mail.h"
 
 // ---------------------------------------------------------------------------------------------
 // RCCL, bound at run time
@@ -82,29 +84,13 @@ constexpr int NCCL_F32 = 7, NCCL_F64 = 8;   // ncclFloat32 / ncclFloat64 (rccl.h
 //   * a scalar: the kernel that finalises the producing reduction stores {value, sequence number} into slot [kind][rank] of EVERY
 //     peer's mailbox, then waits for the P slots of its own mailbox to carry this sequence number and adds the values in rank
 //     order -- every rank the same additions, bit-identical scalars, no collective launch, no host;
-//   * the halo: a push kernel on the side stream copies the packed send buffer straight into the neighbours' ghost regions
-//     (peer-mapped u_ext) and then publishes the exchange number in their mailboxes; a one-wave kernel on the compute stream
-//     waits for it in front of the boundary row-blocks.  The ghost data is read by the kernel AFTER the waiting one (its start is
-//     the acquire that makes peer writes visible to cached loads); slots and flags are read inside a kernel and therefore live in
-//     fine-grained memory and are accessed with system-scope atomics.
+//   * the halo: a push kernel copies the packed send buffer into the neighbours' LANDING BUFFERS (fine-grained memory owned by the library,
+//     mik_plink below) and then publishes the exchange number in their mailboxes; on the receiving side k_halo_land waits for the flags and
+//     copies the landed entries into the ghost tail of the extended vector with system-scope loads -- the SpMV reads what its own device wrote.
 // Sequence numbers only grow, every rank enqueues the same sequence of exchanges, and two exchanges of one kind are always
 // separated by one of another kind that needs every rank's contribution -- a slot is never overwritten before its reader took it
 // (two parities per kind are kept anyway).  Every wait is bounded (MIK_MAILBOX_TIMEOUT_MS, default 10 s): a peer that died turns
 // into MIK_ERR_HIP on the host instead of a hung queue.
-constexpr int MIK_MAIL_MAXP = 64;
-constexpr int MIK_MAIL_KINDS = 3;        // 0: dot(u, c)   1: |r|^2   2: every other gather (initial residual, the scaled-norm stages)
-// a scalar in flight: two 8-byte words, each {low 32 bits of the sequence number, half of the value's bits} -- every word is ONE atomic
-// store, so the two need no ordering between them (no release fence, i.e. no L2 write-back, in the finalising kernels): the reader
-// takes the value once BOTH words carry the sequence number it waits for
-struct MailSlot { unsigned long long w0, w1; };
-constexpr int MIK_MAIL_VEC = 64;         // scalars of one vector exchange (the k projections of a CGS / DGKS column of the row-partitioned GMRES)
-struct MailBox {
-    MailSlot slot[MIK_MAIL_KINDS][2][MIK_MAIL_MAXP];    // [kind][seq & 1][sender]
-    unsigned long long halo_seq[MIK_MAIL_MAXP];          // [sender]: its halo of exchange no. halo_seq[sender] has landed in this rank's landing buffer
-    unsigned long long packed_seq;                       // this rank: the send buffer of exchange no. packed_seq is packed (the side stream waits for it)
-    MailSlot vec[2][MIK_MAIL_MAXP][MIK_MAIL_VEC];        // [seq & 1][sender][j]: element j of a vector in flight (lane j of the one-wave exchange serves it)
-};
-
 struct mik_comm {
     mik_ctx *ctx = nullptr;
     int rank = 0, nranks = 1;
@@ -137,64 +123,6 @@ struct mik_comm {
 };
 
 namespace {
-template <typename T> __device__ __forceinline__ unsigned long long mail_bits(T v)
-{
-    if (sizeof(T) == 8) { double d = (double)v; return __builtin_bit_cast(unsigned long long, d); }
-    float f = (float)v;
-    return (unsigned long long)__builtin_bit_cast(unsigned, f);
-}
-template <typename T> __device__ __forceinline__ T mail_value(unsigned long long b)
-{
-    if (sizeof(T) == 8) return (T)__builtin_bit_cast(double, b);
-    return (T)__builtin_bit_cast(float, (unsigned)b);
-}
-
-// wait until *p >= want; false after `ticks` of the wall clock.  Relaxed system-scope loads: what the flag guards is read by the NEXT
-// kernel on the stream, whose start is the acquire (an acquire per poll would invalidate this XCD's L2 again and again)
-__device__ __forceinline__ bool mail_wait(const unsigned long long *p, unsigned long long want, unsigned long long ticks)
-{
-    const unsigned long long t0 = wall_clock64();
-    for (unsigned spins = 0;; ++spins) {
-        if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return true;
-        if ((spins & 255u) == 255u && wall_clock64() - t0 > ticks) return false;
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-
-// value -> slot [kind][seq & 1][rank] of every peer; then the P slots of this rank's own mailbox -> all[0 .. P): lane q serves peer q
-template <typename T>
-__device__ __forceinline__ T mail_exchange(MailBox *const *__restrict__ peers, int P, int rank, int kind, unsigned long long seq, T mine,
-                                           T *__restrict__ all, unsigned long long ticks, unsigned *__restrict__ err)
-{
-    const int q = threadIdx.x & 63;
-    if (q >= P) return T(0);
-    const unsigned long long tag = (seq & 0xFFFFFFFFull) << 32, b = mail_bits<T>(mine);
-    MailSlot *dst = &peers[q]->slot[kind][seq & 1ull][rank];
-    __hip_atomic_store(&dst->w0, tag | (b & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&dst->w1, tag | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const MailSlot *src = &peers[rank]->slot[kind][seq & 1ull][q];
-    unsigned long long a0 = 0, a1 = 0;
-    const unsigned long long t0 = wall_clock64();
-    for (unsigned spins = 0;; ++spins) {
-        a0 = __hip_atomic_load(&src->w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        a1 = __hip_atomic_load(&src->w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((a0 >> 32 << 32) == tag && (a1 >> 32 << 32) == tag) break;
-        if ((spins & 255u) == 255u && wall_clock64() - t0 > ticks) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-        __builtin_amdgcn_s_sleep(1);
-    }
-    const T v = mail_value<T>((a0 & 0xFFFFFFFFull) | (a1 << 32));
-    all[q] = v;
-    return v;
-}
-
-// the P values of a wave (lane q: rank q's) added in rank order, in every lane
-template <typename T> __device__ __forceinline__ T mail_rank_sum(T v, int P)
-{
-    T s = __shfl(v, 0);
-    for (int p = 1; p < P; ++p) s = s + __shfl(v, p);
-    return s;
-}
-
 // all[rank] (this rank's partial, written by the kernel before on the stream) -> all[0 .. P) on every rank: what ncclAllGather of one
 // element per rank did, as one single-wave launch
 template <typename T>
@@ -303,37 +231,6 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_halo_push(const T *__restrict__ s
                 __hip_atomic_store(&peers[sg.peer[i]]->halo_seq[rank], halo_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // behind every workgroup's fence
         }
     }
-}
-
-// lane j's value -> element j of slot vec[seq & 1][rank] of every peer; then, per lane, the P values of element j added in rank order
-template <typename T>
-__device__ __forceinline__ T mail_exchange_vec(MailBox *const *__restrict__ peers, int P, int rank, unsigned long long seq, T mine, int count,
-                                               unsigned long long ticks, unsigned *__restrict__ err)
-{
-    const int j = threadIdx.x & 63;
-    if (j >= count) return T(0);
-    const unsigned long long tag = (seq & 0xFFFFFFFFull) << 32, b = mail_bits<T>(mine);
-    for (int q = 0; q < P; ++q) {
-        MailSlot *dst = &peers[q]->vec[seq & 1ull][rank][j];
-        __hip_atomic_store(&dst->w0, tag | (b & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&dst->w1, tag | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    T sum = T(0);
-    const unsigned long long t0 = wall_clock64();
-    for (int q = 0; q < P; ++q) {
-        const MailSlot *src = &peers[rank]->vec[seq & 1ull][q][j];
-        unsigned long long a0 = 0, a1 = 0;
-        for (unsigned spins = 0;; ++spins) {
-            a0 = __hip_atomic_load(&src->w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            a1 = __hip_atomic_load(&src->w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if ((a0 >> 32 << 32) == tag && (a1 >> 32 << 32) == tag) break;
-            if ((spins & 255u) == 255u && wall_clock64() - t0 > ticks) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        const T v = mail_value<T>((a0 & 0xFFFFFFFFull) | (a1 << 32));
-        sum = q == 0 ? v : sum + v;                       // rank order: ((v_0 + v_1) + v_2) + ...
-    }
-    return sum;
 }
 
 // vals[0 .. count) (this rank's partial sums, written by the kernel before on the stream) -> the sums over the ranks in rank order, in place
@@ -911,6 +808,13 @@ const mik_ctx *plink_ctx(const mik_plink *pl) { return pl->cm ? pl->cm->ctx : nu
 int plink_rank(const mik_plink *pl) { return pl->cm ? pl->cm->rank : -1; }
 int plink_nranks(const mik_plink *pl) { return pl->cm ? pl->cm->nranks : 0; }
 
+PlinkMail plink_mail(const mik_plink *pl)
+{
+    const mik_comm *cm = pl->cm;
+    return PlinkMail{(MailBox *const *)cm->peers_dev, cm->nranks, cm->rank, cm->timeout_ticks, cm->mail_err};
+}
+unsigned long long plink_next_vec_tag(mik_plink *pl) { return ++pl->cm->vseq; }
+
 int plink_check(mik_plink *pl, const char *who) { return pl->cm ? mailbox_check(pl->cm, who) : MIK_ERR_INVALID; }
 
 // the halo of one SpMV, entirely on the compute stream (behind the pack kernel): push, land
@@ -939,6 +843,42 @@ int plink_fin_sum(mik_plink *pl, const void *partials, int64_t nseg, void *out_d
                            (MailBox *const *)cm->peers_dev, cm->nranks, cm->rank, seq, (float *)cm->scratch, cm->timeout_ticks, cm->mail_err);
     MIK_LAUNCH_CHECK(ctx);
     return MIK_OK;
+}
+
+// Modified Gram-Schmidt over a link as the LAUNCH-LEAN chain (orthogonalize_enqueue's form for n <= 1024 segments, csrc/mik_krylov.hip): every
+// pass finalises the previous pass's reduction itself AND exchanges it (k_map_pro<..., MailSum>), k + 2 launches per Arnoldi column instead of
+// 2 k + 3.  Leaves h in hd[0, k), nrm in hd[k], 1 / nrm in hd[k + 1] (NaN / 1 outside the safe range: w unscaled, the caller recomputes).
+// Every workgroup of a pass spins on the mailbox, so ranks that SHARE a GPU must all fit on it: the caller keeps this form to <= 256 segments.
+template <typename T>
+static int plink_mgs_lean_t(mik_plink *pl, int64_t n, int k, const T *V, int64_t ldv, T *w, T *hd, T *part, bool vec, bool vecw, int hints)
+{
+    mik_comm *cm = pl->cm;
+    mik_ctx *ctx = cm->ctx;
+    const int m = (int)mik_nseg<T>(n);
+    T *P2[2] = {part, part + 1024};
+    auto xch = [&]() { return MailSum{(MailBox *const *)cm->peers_dev, cm->nranks, cm->rank, ++cm->mseq[2], cm->timeout_ticks, cm->mail_err}; };
+    if (k > 0) {
+        OpDot<T> d0{V, w};
+        MIK_TRY((launch_map<T>(ctx, n, d0, vec, P2[0], nullptr)));
+        for (int i = 0; i + 1 < k; ++i) {
+            OpMgsPass<T, false> op{w, V + (int64_t)i * ldv, V + (int64_t)(i + 1) * ldv, coef_val<T>(T(0)), hints};
+            MIK_TRY((launch_map_pro<T, 1>(ctx, n, op, vec, P2[(i + 1) & 1], (const T *)P2[i & 1], m, hd + i, xch())));
+        }
+        OpMgsPass<T, true> last{w, V + (int64_t)(k - 1) * ldv, nullptr, coef_val<T>(T(0)), hints};
+        MIK_TRY((launch_map_pro<T, 1>(ctx, n, last, vec, P2[k & 1], (const T *)P2[(k - 1) & 1], m, hd + k - 1, xch())));
+    } else {
+        OpDot<T> dn{w, w};
+        MIK_TRY((launch_map<T>(ctx, n, dn, vecw, P2[0], nullptr)));
+    }
+    OpScal<T> sc{w, coef_val<T>(T(0))};                                // w .*= inv(norm(w))  src/orthogonalize.jl:75-76
+    return launch_map_pro<T, 2>(ctx, n, sc, vecw, (T *)nullptr, (const T *)P2[k & 1], m, hd + k, xch());
+}
+
+int plink_mgs_lean(mik_plink *pl, int64_t n, int k, const void *V, int64_t ldv, void *w, void *hd, void *partials, bool vec, bool vecw, int hints)
+{
+    if (!pl->cm) return MIK_ERR_INVALID;
+    return pl->dtype == MIK_F64 ? plink_mgs_lean_t<double>(pl, n, k, (const double *)V, ldv, (double *)w, (double *)hd, (double *)partials, vec, vecw, hints)
+                                : plink_mgs_lean_t<float>(pl, n, k, (const float *)V, ldv, (float *)w, (float *)hd, (float *)partials, vec, vecw, hints);
 }
 
 // vals_dev[0 .. count): this rank's partial sums -> the sums over the ranks in rank order, in place, one one-wave launch

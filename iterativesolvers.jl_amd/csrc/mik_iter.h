@@ -193,3 +193,5 @@ int plink_halo(mik_plink *pl, const void *send_buf, void *ghost);               
 int plink_fin_sum(mik_plink *pl, const void *partials, int64_t nseg, void *out_dev, int mode);      // level 2 + sum over the ranks (+ sqrt, inverse)
 int plink_sum_vec(mik_plink *pl, void *vals_dev, int count);                                        // in place, rank order
 int plink_gather(mik_plink *pl, void *all_dev);                                                     // all[rank] -> all[0 .. P)
+// Modified Gram-Schmidt as the launch-lean chain over a link (n <= 1024 segments; k + 2 launches): h -> hd[0, k), nrm -> hd[k], 1 / nrm -> hd[k + 1]
+int plink_mgs_lean(mik_plink *pl, int64_t n, int k, const void *V, int64_t ldv, void *w, void *hd, void *partials, bool vec, bool vecw, int hints);

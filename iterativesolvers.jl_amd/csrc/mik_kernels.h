@@ -59,9 +59,16 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_map(int64_t n, int64_t nseg, Op o
 // single-workgroup launch.  PRO = 1: coef = sum (a projection h_i of Gram-Schmidt); PRO = 2:
 // coef = 1 / sqrt(sum) (the closing normalisation), with sqrt(sum) stored next to it.  Workgroup 0
 // publishes the value(s) at `coef_out` for the host.  Halves the launch count of the MGS chain.
-template <typename T, bool VEC, typename Op, int PRO>
+// X: what happens to the finalised sum before it is used -- nothing on one GPU (NoExchange); over a row partition every workgroup swaps it for
+// the sum over the ranks (MailSum, csrc/mik_comm.hip: workgroup 0 posts this rank's total to the peers' mailboxes, every workgroup collects the P
+// totals from its own rank's mailbox and adds them in rank order).
+struct NoExchange {
+    template <typename T> __device__ __forceinline__ T operator()(T cf) const { return cf; }
+    template <typename T> __device__ __forceinline__ T pass(T cf, int, bool) const { return cf; }      // (the single-launch Gram-Schmidt: per pass)
+};
+template <typename T, bool VEC, typename Op, int PRO, typename X = NoExchange>
 __global__ __launch_bounds__(MIK_BLOCK) void k_map_pro(int64_t n, int64_t nseg, Op op, T *__restrict__ seg_out,
-                                                        const T *__restrict__ prev_part, int prev_m, T *__restrict__ coef_out)
+                                                        const T *__restrict__ prev_part, int prev_m, T *__restrict__ coef_out, X xch)
 {
     constexpr int W = VT<T>::W;
     constexpr int L = MIK_RED_L;
@@ -83,6 +90,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_map_pro(int64_t n, int64_t nseg, 
         }
     }
     T cf = block_level2_256(prev_part, prev_m, lds16);
+    cf = xch(cf);
     if (PRO == 2) {
         T nrm = mik_sqrt(cf);
         const bool ok = mik_nrm_in_range(cf);       // outside the safe range: leave w alone (* 1), the host rescales
@@ -135,15 +143,15 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_map_pro(int64_t n, int64_t nseg, 
     }
 }
 
-template <typename T, int PRO, typename Op>
-static inline int launch_map_pro(mik_ctx *ctx, int64_t n, Op op, bool vec, T *seg_out, const T *prev_part, int prev_m, T *coef_out)
+template <typename T, int PRO, typename Op, typename X = NoExchange>
+static inline int launch_map_pro(mik_ctx *ctx, int64_t n, Op op, bool vec, T *seg_out, const T *prev_part, int prev_m, T *coef_out, X xch = X())
 {
     const int64_t nseg = mik_nseg<T>(n);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(nseg, MIK_MAX_GRID));   // >= 1: workgroup 0 publishes the coefficient
     if (vec)
-        hipLaunchKernelGGL((k_map_pro<T, true, Op, PRO>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, seg_out, prev_part, prev_m, coef_out);
+        hipLaunchKernelGGL((k_map_pro<T, true, Op, PRO, X>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, seg_out, prev_part, prev_m, coef_out, xch);
     else
-        hipLaunchKernelGGL((k_map_pro<T, false, Op, PRO>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, seg_out, prev_part, prev_m, coef_out);
+        hipLaunchKernelGGL((k_map_pro<T, false, Op, PRO, X>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, seg_out, prev_part, prev_m, coef_out, xch);
     MIK_LAUNCH_CHECK(ctx);
     return MIK_OK;
 }
@@ -920,10 +928,12 @@ __device__ __forceinline__ T mgs_grid_sum(const T *__restrict__ slots, int ns, T
 // XL (only with G = 1, at most 128 segments and columns of at most ~1.5 MB -- one XCD's share of the fabric has to feed them): see
 // mgs_slot_store.  xl_chk[parity] receives the XCC id of the first participant; one that finds another id raises err = 2 and the host
 // switches the handle to the all-XCD form for good (the slots of workgroups on different XCDs would never become visible).
-template <typename T, bool VEC, int G, bool XL = false>
+// X (row partitions, csrc/mik_mail.h MailSumPass): the grid-wide sum of a pass is this RANK's total; xch.pass() swaps it for the sum over the ranks
+// in rank order, inside the launch -- every workgroup obtains the same bits, and they are those of the partition-aware chains.
+template <typename T, bool VEC, int G, bool XL = false, typename X = NoExchange>
 __global__ __launch_bounds__(MIK_BLOCK, 1) void k_mgs_fused(int64_t n, int k, const T *__restrict__ V, int64_t ldv, T *__restrict__ w,
                                                             T *__restrict__ P /* [2][kmax + 1][stride] */, int kmax, int stride, int nseg, int parity,
-                                                            MgsMirror *mirror, unsigned long long seq, unsigned *__restrict__ xl_chk = nullptr)
+                                                            MgsMirror *mirror, unsigned long long seq, unsigned *__restrict__ xl_chk = nullptr, X xch = X())
 {
     using U = typename MgsBits<T>::U;
     constexpr int W = VT<T>::W, L = MIK_RED_L;
@@ -1013,7 +1023,7 @@ __global__ __launch_bounds__(MIK_BLOCK, 1) void k_mgs_fused(int64_t n, int k, co
                 for (int e = 0; e < W; ++e) vr[g][l][e] = zr[g][l][e];        // v_i: subtracted in this pass
         const bool last = i + 1 == k;
         if (!last) load(V + (int64_t)(i + 1) * ldv, zr);                   // v_{i+1}: in flight during the hand-off
-        const T h = mgs_grid_sum<T, XL>(cur + (size_t)i * stride, nseg, lds16, &s_err);
+        const T h = xch.pass(mgs_grid_sum<T, XL>(cur + (size_t)i * stride, nseg, lds16, &s_err), i, s == 0);
         if (s == 0 && t == 0) hout[i] = h;
         // w .-= h[i] .* v_i; then dot(v_{i+1}, w) or norm(w)^2            :72, :71 / :75 -- per 16-byte group: all W
         // elements updated, then their products added in element order (the order of OpMgsPass::compute_vec)
@@ -1033,7 +1043,7 @@ __global__ __launch_bounds__(MIK_BLOCK, 1) void k_mgs_fused(int64_t n, int k, co
         }
         publish(i + 1, acc);
     }
-    const T ss = mgs_grid_sum<T, XL>(cur + (size_t)k * stride, nseg, lds16, &s_err);
+    const T ss = xch.pass(mgs_grid_sum<T, XL>(cur + (size_t)k * stride, nseg, lds16, &s_err), k, s == 0);
     T nrm = mik_sqrt(ss);
     const bool ok = mik_nrm_in_range(ss);          // outside the safe range: leave w unscaled, the host rescales
     const T inv = ok ? T(1) / nrm : T(1);

@@ -13,6 +13,7 @@
 
 #include "mik_kernels.h"
 #include "mik_iter.h"
+#include "mik_mail.h"
 
 template <typename T>
 int mik_spmv_launch(mik_ctx *ctx, const mik_csr *A, const T *x, T *y, bool fuse_dot, T *seg_out, const int *done);
@@ -1336,6 +1337,22 @@ static int orthogonalize_link(mik_gmres *g, int k, const T *V, int64_t ldv, T *w
         return plink_check(pl, "gmres (row-partitioned)");
     };
     T nrm;
+    if (method == MIK_MGS && nseg <= 256 && ctx->tuning[MIK_KNOB_GS] != 1) {
+        // the launch-lean chain: every pass finalises AND exchanges the previous reduction itself (k + 2 launches; csrc/mik_comm.hip plink_mgs_lean).
+        // Up to 256 segments: every workgroup of a pass spins on the mailbox, and ranks that share a GPU must all be resident on it.
+        MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * 2048));
+        MIK_TRY(plink_mgs_lean(pl, n, k, V, ldv, w, hd, ctx->partials, vec, vecw, mik_mgs_pass_hints(ctx, n, sizeof(T))));
+        MIK_TRY(download(0, out.data(), k + 1));
+        for (int j = 0; j < k; ++j) h[j] = out[(size_t)j];
+        nrm = out[(size_t)k];
+        if (nrm != nrm) {                                                // w was left unscaled
+            MIK_TRY(gm_link_norm_slow<T>(g, w, &nrm));
+            OpScal<T> sc2{w, coef_val<T>(T(1) / nrm)};
+            MIK_TRY((launch_map<T>(ctx, n, sc2, vecw, (T *)nullptr, nullptr)));
+        }
+        *nrm_out = nrm;
+        return MIK_OK;
+    }
     if (method == MIK_MGS) {                                             // :69-76
         if (k > 0) {
             OpDot<T> d0{V, w};
@@ -1573,7 +1590,10 @@ static int gmres_create_common(mik_ctx *ctx, const mik_csr *A, void *x, const vo
         const int64_t nseg = dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
         // single-launch Gram-Schmidt: up to 2048 reduction segments, G = 1 / 2 / 4 / 8 of them per workgroup (<= 256 workgroups, one
         // per CU); more than 256 segments need the library's own 16-byte aligned V (always the case here)
-        if (!part && nseg >= 1 && nseg <= 2048 && restart <= 254 && (nseg <= 256 || g->ldv % 4 == 0)) {
+        // (a row partition: only with a device-driven link, Modified Gram-Schmidt and restart <= 62 -- the totals of a launch's passes travel
+        // between the ranks through one vector slot per pass, csrc/mik_mail.h MailSumPass)
+        const bool part_ok = !part || (part->link && orth_method == MIK_MGS && restart <= MIK_MAIL_VEC - 2);
+        if (part_ok && nseg >= 1 && nseg <= 2048 && restart <= 254 && (nseg <= 256 || g->ldv % 4 == 0)) {
             g->mgs_G = nseg <= 256 ? 1 : nseg <= 512 ? 2 : nseg <= 1024 ? 4 : 8;
             g->mgs_stride = std::max<int>(256, (int)((nseg + g->mgs_G - 1) / g->mgs_G) * g->mgs_G);
             // k_cgs_fused: one more row per round (the final h values); DGKS: up to 3 rounds in the kernel
@@ -1685,8 +1705,16 @@ template <typename T> static int gm_fused_enqueue(mik_gmres *g, int k, int slot)
     hipLaunchKernelGGL((k_cgs_fused<T, VECV, DG, GG>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart, \
                        stride, nseg, g->mgs_rounds, g->mgs_parity, gm_mirror(g, slot), g->mgs_seq)
 #define MIK_MGS_GO(VECV, GG)                                                                                                                   \
-    hipLaunchKernelGGL((k_mgs_fused<T, VECV, GG>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart, \
-                       stride, nseg, g->mgs_parity, gm_mirror(g, slot), g->mgs_seq)
+    do {                                                                                                                                        \
+        if (g->dist) {        /* a row partition with a link: the totals of every pass are summed over the ranks inside the launch */          \
+            const PlinkMail pm = plink_mail(g->part.link);                                                                                      \
+            const MailSumPass xch{pm.peers, pm.P, pm.rank, plink_next_vec_tag(g->part.link), pm.ticks, pm.err};                                 \
+            hipLaunchKernelGGL((k_mgs_fused<T, VECV, GG, false, MailSumPass>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, \
+                               g->restart, stride, nseg, g->mgs_parity, gm_mirror(g, slot), g->mgs_seq, (unsigned *)nullptr, xch);              \
+        } else                                                                                                                                  \
+            hipLaunchKernelGGL((k_mgs_fused<T, VECV, GG>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart, \
+                               stride, nseg, g->mgs_parity, gm_mirror(g, slot), g->mgs_seq, (unsigned *)nullptr, NoExchange{});                 \
+    } while (0)
 #define MIK_GS_GO(VECV, GG)                                                                          \
     do {                                                                                             \
         if (g->method == MIK_DGKS) MIK_CGS_GO(VECV, true, GG);                                       \
@@ -1697,11 +1725,11 @@ template <typename T> static int gm_fused_enqueue(mik_gmres *g, int k, int slot)
     // of at most 512 KB per pass: every column then comes through ONE XCD's share of the fabric (~1 MB per us).  fe_shell (363 KB columns):
     // GMRES(50) 64.2 -> 50.9 us per inner iteration; configs[2] (1 MB columns) would lose (36.5 -> 47.8 us) and keeps the device-wide
     // form.  MIK_KNOB_GS = 4: the device-wide form at every size.
-    const bool xl = g->method == MIK_MGS && G == 1 && vec && m <= 128 && ((size_t)n * sizeof(T) <= (1u << 19) || ctx->tuning[MIK_KNOB_GS] == 5) && !g->xl_off && ctx->tuning[MIK_KNOB_GS] != 4 && g->xl_chk;   // (knob 5 = 5: whatever the column size)
+    const bool xl = g->method == MIK_MGS && G == 1 && vec && m <= 128 && ((size_t)n * sizeof(T) <= (1u << 19) || ctx->tuning[MIK_KNOB_GS] == 5) && !g->xl_off && ctx->tuning[MIK_KNOB_GS] != 4 && g->xl_chk && !g->dist;   // (MIK_KNOB_GS = 5: whatever the column size)
     g->xl_last = xl;
     if (xl) {
         hipLaunchKernelGGL((k_mgs_fused<T, true, 1, true>), dim3(8 * m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart,
-                           stride, nseg, g->mgs_parity, gm_mirror(g, slot), g->mgs_seq, g->xl_chk);
+                           stride, nseg, g->mgs_parity, gm_mirror(g, slot), g->mgs_seq, g->xl_chk, NoExchange{});
     } else
     // G > 1 (more than 256 segments) is instantiated for 16-byte aligned bases only: gmres_create allocates V that way
     if (G == 1) { if (vec) MIK_GS_GO(true, 1); else MIK_GS_GO(false, 1); }
@@ -1755,7 +1783,11 @@ template <typename T> static int gm_fused_wait(mik_gmres *g, int k, int slot, T 
     }
     if (out[k] != out[k]) {                     // sum of squares outside the safe range: the kernel left w unscaled
         T *w = (T *)g->V + (int64_t)k * g->ldv;
-        MIK_TRY(orth_rescale<T>(ctx, g->n, w, nrm_out));
+        if (g->dist) {                          // ... on every rank alike (identical totals): the scaled norm across the ranks
+            MIK_TRY(gm_link_norm_slow<T>(g, w, nrm_out));
+            OpScal<T> sc{w, coef_val<T>(T(1) / *nrm_out)};
+            MIK_TRY((launch_map<T>(ctx, g->n, sc, mik_aligned16(w), (T *)nullptr, nullptr)));
+        } else MIK_TRY(orth_rescale<T>(ctx, g->n, w, nrm_out));
         *rescaled = true;
     }
     return MIK_OK;
@@ -1781,7 +1813,7 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
     // expand! (:64, :285-304), then H[k+1, k] = orthogonalize_and_normalize!(V[:, 1:k], V[:, k+1], H[1:k, k], orth_meth)  :68-73
     T nrm;
     {
-        if (g->mgs_P && !g->dist && !g->fused_off && (ctx->tuning[MIK_KNOB_GS] == 0 || ctx->tuning[MIK_KNOB_GS] >= 4)) {    // MIK_KNOB_GS: 1 / 2 = the multi-launch chains, 4 = single launch on all XCDs
+        if (g->mgs_P && (!g->dist || g->part.link) && !g->fused_off && ctx->tuning[MIK_KNOB_GS] != 1 && ctx->tuning[MIK_KNOB_GS] != 2) {    // MIK_KNOB_GS: 1 / 2 = the multi-launch chains, 4 = single launch on all XCDs
             // single-launch Gram-Schmidt, one column ahead of the host: column k is on the stream already if the previous
             // call put it there; column k + 1 goes on the stream BEFORE this call waits for column k (never across a restart,
             // never with host callbacks in expand!, whose call count the caller may observe)
@@ -1792,6 +1824,8 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
             if (ahead) MIK_TRY(gm_fused_enqueue<T>(g, k + 1, slot ^ 1));
             bool rescaled = false;
             const int rcw = gm_fused_wait<T>(g, k, slot, &Hat(0, k - 1), &nrm, &rescaled);
+            if (rcw == MIK_GS_TIMEOUT && g->dist)      // (no local fall-back over a partition: the ranks' exchange sequences would part ways)
+                return mik_fail(ctx, MIK_ERR_HIP, "gmres (row-partitioned): a hand-off of the single-launch Gram-Schmidt timed out (a peer rank stopped, or the GPU is shared with other work)");
             if (rcw == MIK_GS_TIMEOUT) {
                 // The hand-off needs every workgroup resident; a GPU shared with other streams or processes can break that.
                 // Not an error of the solve: drain the stream (a column enqueued ahead drains with it), switch this handle to the

@@ -212,7 +212,7 @@ def test_process_ranks_match_partitioned_oracle(pkg, orc, ctx, tmp_path, world, 
 # ------------------------------------------------------------------------------------------------
 # device-driven coupling (mik_partition.link, include/mik.h "Transport 3"): no host callback, no host round trip inside an Arnoldi column
 # ------------------------------------------------------------------------------------------------
-def _link_worker(rank, world, port, out_dir, orth, scale, dtype_name, restart, batch):
+def _link_worker(rank, world, port, out_dir, orth, scale, dtype_name, restart, batch, gs=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), MIK_MAILBOX_TIMEOUT_MS="20000")
     import torch
     import torch.distributed as td
@@ -224,6 +224,7 @@ def _link_worker(rank, world, port, out_dir, orth, scale, dtype_name, restart, b
     torch.cuda.set_device(0)
     td.init_process_group("gloo", rank=rank, world_size=world)          # carries the IPC handles, nothing else
     comm = dist.TorchComm()
+    pkg.lib().mik_set_tuning(5, gs)                                       # MIK_KNOB_GS: 0 = single launch, 2 = launch-lean chain, 1 = general chain
     dtype = np.dtype(dtype_name)
     n, colptr, rowval, nzval, b = pkg.fixtures.advection_dominated(11, 700.0)
     S = sp.csc_matrix(((nzval * scale).astype(dtype), rowval - 1, colptr - 1), shape=(n, n)).tocsr()
@@ -260,21 +261,27 @@ def _link_worker(rank, world, port, out_dir, orth, scale, dtype_name, restart, b
     td.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,orth,scale,dtype_name,restart,batch", [
-    (2, "mgs", 1.0, "float64", 10, 0), (3, "mgs", 1.0, "float64", 10, 7), (2, "cgs", 1.0, "float64", 10, 0), (3, "dgks", 1.0, "float64", 8, 0),
-    (2, "mgs", 1.0, "float32", 10, 5), (2, "cgs", 1.0, "float32", 12, 0), (2, "dgks", 1.0, "float32", 10, 0),
-    (2, "mgs", 1e-160, "float64", 10, 0), (3, "cgs", 1e-160, "float64", 10, 4), (2, "dgks", 1e-160, "float64", 10, 0), (2, "mgs", 1e-22, "float32", 10, 0),
-    (1, "mgs", 1.0, "float64", 10, 0)])
-def test_device_driven_partitioned_gmres_ranks_in_processes_on_one_gpu(pkg, orc, ctx, tmp_path, world, orth, scale, dtype_name, restart, batch):
+@pytest.mark.parametrize("world,orth,scale,dtype_name,restart,batch,gs", [
+    (2, "mgs", 1.0, "float64", 10, 0, 0), (3, "mgs", 1.0, "float64", 10, 7, 0), (2, "cgs", 1.0, "float64", 10, 0, 0), (3, "dgks", 1.0, "float64", 8, 0, 0),
+    (2, "mgs", 1.0, "float32", 10, 5, 0), (2, "cgs", 1.0, "float32", 12, 0, 0), (2, "dgks", 1.0, "float32", 10, 0, 0),
+    (2, "mgs", 1e-160, "float64", 10, 0, 0), (3, "cgs", 1e-160, "float64", 10, 4, 0), (2, "dgks", 1e-160, "float64", 10, 0, 0), (2, "mgs", 1e-22, "float32", 10, 0, 0),
+    (1, "mgs", 1.0, "float64", 10, 0, 0),
+    (2, "mgs", 1.0, "float64", 10, 0, 1), (3, "mgs", 1e-160, "float64", 10, 3, 1), (2, "mgs", 1.0, "float32", 10, 0, 1),
+    (2, "mgs", 1.0, "float64", 10, 0, 2), (3, "mgs", 1e-160, "float64", 10, 3, 2), (2, "mgs", 1.0, "float32", 10, 6, 2), (3, "mgs", 1.0, "float64", 10, 0, 2)])
+def test_device_driven_partitioned_gmres_ranks_in_processes_on_one_gpu(pkg, orc, ctx, tmp_path, world, orth, scale, dtype_name, restart, batch, gs):
     """mik_gmres_create_partitioned with mik_partition.link -- halo pushed into the neighbours' landing buffers, every
     projection and norm summed over the ranks INSIDE the kernel that finalises it (mailbox slots, rank order), coefficients read from device
     memory by the next sweep: no host callback at all (counted), one host wait per inner iteration.  2 and 3 ranks as separate processes
     on the box's one GPU over HIP IPC; history, solution, mv_products and isconverged bit-exact against the partition-aware oracle --
     ModifiedGramSchmidt, ClassicalGramSchmidt, DGKS; fp64 and fp32; systems scaled by 1e-160 (fp32: 1e-22), which send every norm through the
-    scaled pass across the ranks; per-step calls and mik_gmres_iterate_many batches."""
+    scaled pass across the ranks; per-step calls and mik_gmres_iterate_many batches.  Modified Gram-Schmidt (gs = MIK_KNOB_GS): 0 = the SINGLE-LAUNCH
+    kernel with the exchange inside (k_mgs_fused<..., MailSumPass>: the total of every pass posted to the peers by workgroup 0, collected from
+    the mailbox by every workgroup, one vector slot per pass; up to 2048 segments per rank, restart <= 62, one Arnoldi column enqueued ahead of
+    the host), 2 = the launch-lean chain (every pass finalises AND exchanges the previous reduction itself: k + 2 launches, up to 256 segments
+    per rank), 1 = the general chain with its finalise-and-exchange launches (what larger slabs run)."""
     import torch.multiprocessing as mp
-    port = 29100 + (os.getpid() * 3 + world * 17 + len(orth) * 5 + restart + batch + (40 if scale != 1.0 else 0) + (80 if dtype_name == "float32" else 0)) % 700
-    mp.spawn(_link_worker, args=(world, port, str(tmp_path), orth, scale, dtype_name, restart, batch), nprocs=world, join=True)
+    port = 29100 + (os.getpid() * 3 + world * 17 + len(orth) * 5 + restart + batch + (40 if scale != 1.0 else 0) + (80 if dtype_name == "float32" else 0) + 160 * gs) % 700
+    mp.spawn(_link_worker, args=(world, port, str(tmp_path), orth, scale, dtype_name, restart, batch, gs), nprocs=world, join=True)
     dtype = np.dtype(dtype_name)
     A64, b64 = orc.advdiff(11, 700.0)
     A = orc.CSC(A64.n, A64.colptr, A64.rowval, (A64.nzval * scale).astype(dtype), A64.index_base)
