@@ -1082,10 +1082,12 @@ __global__ __launch_bounds__(MIK_BLOCK, 1) void k_mgs_fused(int64_t n, int k, co
 // block of slot rows; all workgroups evaluate the condition on identical values.  After `rounds` rounds (or when the sum of
 // squares leaves the safe range) the kernel stops WITHOUT scaling w and reports {h, nrm, projection size, more = 1}: the host
 // continues the loop with the multi-launch chain (it "typically runs once", ibid.).
-template <typename T, bool VEC, bool DGKS, int G>
+// X (row partitions, MailSumPass): the reducer workgroup of column j swaps the rank's total for the sum over the ranks before it publishes the final
+// value (vector slot round (kmax + 1) + j); the norm is exchanged by every workgroup like a pass of k_mgs_fused (slot round (kmax + 1) + k).
+template <typename T, bool VEC, bool DGKS, int G, typename X = NoExchange>
 __global__ __launch_bounds__(MIK_BLOCK, 1) void k_cgs_fused(int64_t n, int k, const T *__restrict__ V, int64_t ldv, T *__restrict__ w,
                                                             T *__restrict__ P /* [2][rounds][kmax + 2][stride] */, int kmax, int stride, int nseg, int rounds,
-                                                            int parity, MgsMirror *mirror, unsigned long long seq)
+                                                            int parity, MgsMirror *mirror, unsigned long long seq, X xch = X())
 {
     using U = typename MgsBits<T>::U;
     constexpr int W = VT<T>::W, L = MIK_RED_L;
@@ -1160,7 +1162,7 @@ __global__ __launch_bounds__(MIK_BLOCK, 1) void k_cgs_fused(int64_t n, int k, co
         __syncthreads();
         // (2) level 2 of column j by workgroup j mod m; everybody picks the finals up          k_finalize_store
         for (int j = s; j < k; j += m) {
-            const T h = mgs_grid_sum<T>(rb + (size_t)j * stride, nseg, lds16, &s_err);
+            const T h = xch.pass(mgs_grid_sum<T>(rb + (size_t)j * stride, nseg, lds16, &s_err), round * (kmax + 1) + j, true);
             if (t == 0)
                 __hip_atomic_store(reinterpret_cast<U *>(fin) + j, mgs_slot_bits<T>(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1210,7 +1212,7 @@ __global__ __launch_bounds__(MIK_BLOCK, 1) void k_cgs_fused(int64_t n, int k, co
             __hip_atomic_store(reinterpret_cast<U *>(rb + (size_t)k * stride) + s * G + t, mgs_slot_bits<T>(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        const T ss = mgs_grid_sum<T>(rb + (size_t)k * stride, nseg, lds16, &s_err);
+        const T ss = xch.pass(mgs_grid_sum<T>(rb + (size_t)k * stride, nseg, lds16, &s_err), round * (kmax + 1) + k, s == 0);
         nrm = mik_sqrt(ss);
         ok = mik_nrm_in_range(ss);
         if (!DGKS) break;

@@ -1592,7 +1592,7 @@ static int gmres_create_common(mik_ctx *ctx, const mik_csr *A, void *x, const vo
         // per CU); more than 256 segments need the library's own 16-byte aligned V (always the case here)
         // (a row partition: only with a device-driven link, Modified Gram-Schmidt and restart <= 62 -- the totals of a launch's passes travel
         // between the ranks through one vector slot per pass, csrc/mik_mail.h MailSumPass)
-        const bool part_ok = !part || (part->link && orth_method == MIK_MGS && restart <= MIK_MAIL_VEC - 2);
+        const bool part_ok = !part || (part->link && (orth_method == MIK_MGS || orth_method == MIK_CGS) && restart <= MIK_MAIL_VEC - 2);   // (DGKS over a link: the chains)
         if (part_ok && nseg >= 1 && nseg <= 2048 && restart <= 254 && (nseg <= 256 || g->ldv % 4 == 0)) {
             g->mgs_G = nseg <= 256 ? 1 : nseg <= 512 ? 2 : nseg <= 1024 ? 4 : 8;
             g->mgs_stride = std::max<int>(256, (int)((nseg + g->mgs_G - 1) / g->mgs_G) * g->mgs_G);
@@ -1702,8 +1702,16 @@ template <typename T> static int gm_fused_enqueue(mik_gmres *g, int k, int slot)
     g->mgs_seq += 1;
     g->mgs_slot_seq[slot] = g->mgs_seq;
 #define MIK_CGS_GO(VECV, DG, GG)                                                                                                               \
-    hipLaunchKernelGGL((k_cgs_fused<T, VECV, DG, GG>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart, \
-                       stride, nseg, g->mgs_rounds, g->mgs_parity, gm_mirror(g, slot), g->mgs_seq)
+    do {                                                                                                                                        \
+        if (g->dist && !DG) { /* a row partition with a link: column totals and the norm are summed over the ranks inside the launch */        \
+            const PlinkMail pm = plink_mail(g->part.link);                                                                                      \
+            const MailSumPass xch{pm.peers, pm.P, pm.rank, plink_next_vec_tag(g->part.link), pm.ticks, pm.err};                                 \
+            hipLaunchKernelGGL((k_cgs_fused<T, VECV, false, GG, MailSumPass>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, \
+                               g->restart, stride, nseg, g->mgs_rounds, g->mgs_parity, gm_mirror(g, slot), g->mgs_seq, xch);                    \
+        } else                                                                                                                                  \
+            hipLaunchKernelGGL((k_cgs_fused<T, VECV, DG, GG>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart, \
+                               stride, nseg, g->mgs_rounds, g->mgs_parity, gm_mirror(g, slot), g->mgs_seq, NoExchange{});                       \
+    } while (0)
 #define MIK_MGS_GO(VECV, GG)                                                                                                                   \
     do {                                                                                                                                        \
         if (g->dist) {        /* a row partition with a link: the totals of every pass are summed over the ranks inside the launch */          \

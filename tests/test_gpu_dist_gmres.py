@@ -267,7 +267,8 @@ def _link_worker(rank, world, port, out_dir, orth, scale, dtype_name, restart, b
     (2, "mgs", 1e-160, "float64", 10, 0, 0), (3, "cgs", 1e-160, "float64", 10, 4, 0), (2, "dgks", 1e-160, "float64", 10, 0, 0), (2, "mgs", 1e-22, "float32", 10, 0, 0),
     (1, "mgs", 1.0, "float64", 10, 0, 0),
     (2, "mgs", 1.0, "float64", 10, 0, 1), (3, "mgs", 1e-160, "float64", 10, 3, 1), (2, "mgs", 1.0, "float32", 10, 0, 1),
-    (2, "mgs", 1.0, "float64", 10, 0, 2), (3, "mgs", 1e-160, "float64", 10, 3, 2), (2, "mgs", 1.0, "float32", 10, 6, 2), (3, "mgs", 1.0, "float64", 10, 0, 2)])
+    (2, "mgs", 1.0, "float64", 10, 0, 2), (3, "mgs", 1e-160, "float64", 10, 3, 2), (2, "mgs", 1.0, "float32", 10, 6, 2), (3, "mgs", 1.0, "float64", 10, 0, 2),
+    (2, "cgs", 1.0, "float64", 10, 0, 2), (3, "cgs", 1e-160, "float64", 10, 4, 1), (2, "cgs", 1.0, "float32", 12, 5, 2)])
 def test_device_driven_partitioned_gmres_ranks_in_processes_on_one_gpu(pkg, orc, ctx, tmp_path, world, orth, scale, dtype_name, restart, batch, gs):
     """mik_gmres_create_partitioned with mik_partition.link -- halo pushed into the neighbours' landing buffers, every
     projection and norm summed over the ranks INSIDE the kernel that finalises it (mailbox slots, rank order), coefficients read from device
@@ -278,7 +279,9 @@ def test_device_driven_partitioned_gmres_ranks_in_processes_on_one_gpu(pkg, orc,
     kernel with the exchange inside (k_mgs_fused<..., MailSumPass>: the total of every pass posted to the peers by workgroup 0, collected from
     the mailbox by every workgroup, one vector slot per pass; up to 2048 segments per rank, restart <= 62, one Arnoldi column enqueued ahead of
     the host), 2 = the launch-lean chain (every pass finalises AND exchanges the previous reduction itself: k + 2 launches, up to 256 segments
-    per rank), 1 = the general chain with its finalise-and-exchange launches (what larger slabs run)."""
+    per rank), 1 = the general chain with its finalise-and-exchange launches (what larger slabs run).  ClassicalGramSchmidt: 0 = k_cgs_fused with the
+    exchange inside (the reducer workgroup of every column swaps the rank's total for the sum over the ranks), 1 / 2 = batched dot + one vector
+    exchange (k_mail_sum_vec) + axpy sweep; DGKS always runs that chain with its loop on the host."""
     import torch.multiprocessing as mp
     port = 29100 + (os.getpid() * 3 + world * 17 + len(orth) * 5 + restart + batch + (40 if scale != 1.0 else 0) + (80 if dtype_name == "float32" else 0) + 160 * gs) % 700
     mp.spawn(_link_worker, args=(world, port, str(tmp_path), orth, scale, dtype_name, restart, batch, gs), nprocs=world, join=True)
