@@ -472,6 +472,7 @@ extern "C" int mik_cgd_set_halo_plan(mik_cgd *it, int n_recv, const int *recv_pe
         return MIK_ERR_INVALID;
     mik_ctx *ctx = it->base.ctx;
     const int64_t n_ghost = it->n_ext - it->base.n;
+    if (it->link) { (void)mik_plink_destroy(it->link); it->link = nullptr; it->ghosts = false; }     // a new plan: the landing buffer and the peers' targets follow it
     it->recv.clear();
     it->send.clear();
     for (int i = 0; i < n_recv; ++i) {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# final-binary validation: GPU suite, the driver's bench line, the 2-ranks-on-one-GPU line
+# what a round-end validation on the GPU box runs: the GPU suite, the driver bench line, the 2-ranks-on-one-GPU line (gpurun -- bash scripts/gpu_validate.sh)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r05
 mkdir -p $O
