@@ -300,3 +300,65 @@ def test_device_driven_partitioned_gmres_ranks_in_processes_on_one_gpu(pkg, orc,
         assert np.array_equal(np.load(tmp_path / f"hist{r}.npy"), ho["resnorm"]), r
         assert tuple(np.load(tmp_path / f"mv{r}.npy")) == (ho["mvps"], int(ho["isconverged"]))
     assert np.array_equal(np.concatenate([np.load(tmp_path / f"x{r}.npy") for r in range(world)]), xo)
+
+
+def _link_precond_worker(rank, world, port, out_dir, orth):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), MIK_MAILBOX_TIMEOUT_MS="20000")
+    import torch
+    import torch.distributed as td
+    import scipy.sparse as sp
+    import __graft_entry__ as graft
+    from importlib import import_module
+    pkg = graft.load_package()
+    dist = import_module(pkg.__name__ + ".dist")
+    torch.cuda.set_device(0)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    comm = dist.TorchComm()
+    n, colptr, rowval, nzval, b = pkg.fixtures.advection_dominated(10, 400.0)
+    S = sp.csc_matrix((nzval, rowval - 1, colptr - 1), shape=(n, n)).tocsr()
+    pl = np.abs(S.diagonal()) ** 0.5
+    pr = 1.0 + 0.5 * np.cos(np.arange(n))
+    x0 = np.random.default_rng(4).standard_normal(n)
+    offsets = np.array([0, 517, n]) if world == 2 else dist.partition_rows(n, world)      # an uneven cut
+    r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
+    ptr, idx, val = csr_block(S, r0, r1)
+    local_idx, plan = dist.localize_block(ptr, idx, offsets, rank)
+    dist.complete_plan(plan, offsets, comm.all_gather_objects(plan.ghost_gids))
+    M = {"mgs": pkg.ModifiedGramSchmidt(), "cgs": pkg.ClassicalGramSchmidt(), "dgks": pkg.DGKS()}[orth]
+    it = dist.DistGMRESIterable(pkg, comm, ptr, local_idx, val, plan, b[r0:r1], x0[r0:r1], n_global=n, restart=7, maxiter=40, orth_meth=M,
+                                pl_diag=pl[r0:r1], pr_diag=pr[r0:r1], native="mailbox")
+    hist = it.solve()
+    np.save(os.path.join(out_dir, f"hist{rank}.npy"), hist)
+    np.save(os.path.join(out_dir, f"x{rank}.npy"), it.solution())
+    np.save(os.path.join(out_dir, f"off{rank}.npy"), offsets)
+    np.save(os.path.join(out_dir, f"mv{rank}.npy"), np.array([it.mv_products, int(it.converged())]))
+    comm.barrier()
+    it.close()
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,orth", [(2, "mgs"), (3, "cgs"), (2, "dgks")])
+def test_device_driven_partitioned_gmres_with_pl_pr_and_a_starting_guess(pkg, orc, ctx, tmp_path, world, orth):
+    """SURVEY 8f rank 2 over the device-driven link: all three expand! methods' preconditioned form (ldiv!(Pr, .), mul!, ldiv!(Pl, .) on the local
+    rows, src/gmres.jl:297-304), update_solution! with Pr (:278-283), and x0 != 0 -- init! then needs a halo exchange and a reduction before
+    the first Arnoldi column (src/gmres.jl:241-253); maxiter ends the solve inside a cycle (the mv_products quirk of :101).  Uneven row cut."""
+    import torch.multiprocessing as mp
+    port = 29050 + (os.getpid() * 5 + world * 11 + len(orth)) % 40
+    mp.spawn(_link_precond_worker, args=(world, port, str(tmp_path), orth), nprocs=world, join=True)
+    A, _ = orc.advdiff(10, 400.0)
+    n = A.n
+    b = pkg.fixtures.advection_dominated(10, 400.0)[4]
+    S = A.to_scipy().tocsr()
+    pl = np.abs(S.diagonal()) ** 0.5
+    pr = 1.0 + 0.5 * np.cos(np.arange(n))
+    x0 = np.random.default_rng(4).standard_normal(n)
+    offsets = np.load(tmp_path / "off0.npy")
+    orc.set_partition(offsets)
+    try:
+        xo, ho = orc.gmres(A, b, x0, restart=7, maxiter=40, orth_meth=orth, mode="tree", shape=ctx.reduce_shape(np.float64), pl_diag=pl, pr_diag=pr)
+    finally:
+        orc.set_partition(None)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"hist{r}.npy"), ho["resnorm"]), r
+        assert tuple(np.load(tmp_path / f"mv{r}.npy")) == (ho["mvps"], int(ho["isconverged"]))
+    assert np.array_equal(np.concatenate([np.load(tmp_path / f"x{r}.npy") for r in range(world)]), xo)
