@@ -615,7 +615,10 @@ def run_single(args):
         finally:
             A.set_layout("auto")
     if not args.no_f_solvers and N >= 128:
-        out["f_solvers"] = f_solvers(A, b, n)
+        try:
+            out["f_solvers"] = f_solvers(A, b, n)
+        finally:
+            A.set_layout("auto")
     del A, b, scratch, u
     if not args.no_gmres:
         out["gmres_config3"] = gmres_config3()
