@@ -1,9 +1,9 @@
 #!/bin/bash
 # Steady-state kernel timeline of ONE step of the row-partitioned CG on a single GPU (z-periodic slab: the rank is its own neighbour;
-# MIK_DIST_SELF_HALO=1), one file per transport -> gpurun_out/r04/dist_selfhalo_timeline_<transport>.txt
+# MIK_DIST_SELF_HALO=1), one file per transport -> gpurun_out/r05/dist_selfhalo_timeline_<transport>.txt
 #   TRANSPORTS="rccl mailbox" bash scripts/dist_timeline.sh        (on the GPU box, through gpurun)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$R/gpurun_out/r04
+OUT=$R/gpurun_out/r05
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for TR in ${TRANSPORTS:-rccl rccl+mailbox mailbox}; do
