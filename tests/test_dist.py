@@ -640,7 +640,7 @@ def test_torch_slab_generator_and_localisation_equal_the_numpy_ones(pkg):
     """dist._laplace_rows_torch / localize_block_torch / interior_row_blocks on tensors (here on the CPU device; the bench runs
     them on the GPU) against the numpy reference functions: same CSR slab, same local column ids, same halo plan"""
     import torch
-    dist = pkg.dist
+    dist = dist_mod(pkg)
     N, NZ, P = 10, 12, 4
     offsets = np.arange(P + 1, dtype=np.int64) * (N * N * (NZ // P))
     for r in range(P):
@@ -739,3 +739,29 @@ def test_full_rccl_step_on_one_device_through_a_periodic_self_halo(pkg, orc, ctx
     assert ch.isconverged and np.array_equal(hist, ch["resnorm"]) and np.array_equal(eng.solution(), x.to_numpy())
     eng.close()
     nc.close()
+
+
+def test_landing_targets_follow_the_receivers_plans(pkg):
+    """no GPU needed: where a sender's segments land in the receivers' landing buffers (NativeComm._landing_targets) -- the offset of the MATCHING
+    receive segment in the receiver's ghost region, matched in order when a rank receives several segments from the same peer (a z-periodic slab
+    that is its own lower and upper neighbour), and a loud failure when the plans of two ranks disagree"""
+    d = dist_mod(pkg)
+    nc = d.NativeComm.__new__(d.NativeComm)
+    # three z-slabs of a 4 x 4 x 12 grid: rank 1 receives 16 entries from rank 0 (ghost offset 0) and 16 from rank 2 (ghost offset 16)
+    recv = {0: [(1, 0, 16)], 1: [(0, 0, 16), (2, 16, 16)], 2: [(1, 0, 16)]}
+    send = {0: [(1, 0, 16)], 1: [(0, 0, 16), (2, 16, 16)], 2: [(1, 0, 16)]}
+    info = [(b"", 16 if q != 1 else 32, recv[q]) for q in range(3)]
+    want = {0: [0], 1: [0, 0], 2: [16]}            # rank 0 -> rank 1's ghost offset 0; rank 1 -> offset 0 of ranks 0 and 2; rank 2 -> rank 1's offset 16
+    for q in range(3):
+        nc.rank = q
+        plan = d.HaloPlan(q, 3, 64, np.zeros(0, np.int64))
+        plan.send = send[q]
+        assert nc._landing_targets(plan, info).tolist() == want[q]
+    # one slab, periodic in z: two segments to itself, landing at ghost offsets 0 and 16 in order
+    nc.rank = 0
+    plan = d.HaloPlan(0, 1, 64, np.zeros(0, np.int64))
+    plan.send = [(0, 0, 16), (0, 16, 16)]
+    assert nc._landing_targets(plan, [(b"", 32, [(0, 0, 16), (0, 16, 16)])]).tolist() == [0, 16]
+    plan.send = [(0, 0, 16), (0, 16, 8)]
+    with pytest.raises(RuntimeError, match="halo plans disagree"):
+        nc._landing_targets(plan, [(b"", 32, [(0, 0, 16), (0, 16, 16)])])
