@@ -268,7 +268,8 @@ def _link_worker(rank, world, port, out_dir, orth, scale, dtype_name, restart, b
     (1, "mgs", 1.0, "float64", 10, 0, 0),
     (2, "mgs", 1.0, "float64", 10, 0, 1), (3, "mgs", 1e-160, "float64", 10, 3, 1), (2, "mgs", 1.0, "float32", 10, 0, 1),
     (2, "mgs", 1.0, "float64", 10, 0, 2), (3, "mgs", 1e-160, "float64", 10, 3, 2), (2, "mgs", 1.0, "float32", 10, 6, 2), (3, "mgs", 1.0, "float64", 10, 0, 2),
-    (2, "cgs", 1.0, "float64", 10, 0, 2), (3, "cgs", 1e-160, "float64", 10, 4, 1), (2, "cgs", 1.0, "float32", 12, 5, 2)])
+    (2, "cgs", 1.0, "float64", 10, 0, 2), (3, "cgs", 1e-160, "float64", 10, 4, 1), (2, "cgs", 1.0, "float32", 12, 5, 2),
+    (2, "mgs", 1.0, "float64", 70, 0, 0), (2, "cgs", 1.0, "float64", 70, 0, 0)])     # restart > 62: more passes than vector slots -- the chains
 def test_device_driven_partitioned_gmres_ranks_in_processes_on_one_gpu(pkg, orc, ctx, tmp_path, world, orth, scale, dtype_name, restart, batch, gs):
     """mik_gmres_create_partitioned with mik_partition.link -- halo pushed into the neighbours' landing buffers, every
     projection and norm summed over the ranks INSIDE the kernel that finalises it (mailbox slots, rank order), coefficients read from device
@@ -295,7 +296,7 @@ def test_device_driven_partitioned_gmres_ranks_in_processes_on_one_gpu(pkg, orc,
         xo, ho = orc.gmres(A, b, restart=restart, orth_meth=orth, mode="tree", shape=ctx.reduce_shape(dtype))
     finally:
         orc.set_partition(None)
-    assert ho["iters"] > restart                                           # at least one restart cycle (update_solution!, init!)
+    assert ho["iters"] > min(restart, 40)                                  # (restart = 10: at least one restart cycle -- update_solution!, init!)
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"hist{r}.npy"), ho["resnorm"]), r
         assert tuple(np.load(tmp_path / f"mv{r}.npy")) == (ho["mvps"], int(ho["isconverged"]))
