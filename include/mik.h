@@ -449,7 +449,7 @@ int mik_cgd_halo_early(const mik_cgd *it, int *runs, int64_t *rows, int *merged)
  * carries RCCL, e.g. PyTorch-ROCm, shares that copy); MIK_ERR_NOTIMPL if it cannot be loaded.  Rank 0 obtains the
  * 128-byte ncclUniqueId with mik_comm_unique_id and hands it to the other ranks by whatever channel the host has (MPI.jl
  * bcast, a file, torch.distributed); every rank then calls mik_comm_create (collective).  id128 = NULL gives a communicator
- * without RCCL: a world of one needs nothing else, more ranks connect mailboxes and ghost regions (transport 3 below). */
+ * without RCCL: a world of one needs nothing else, more ranks connect mailboxes and landing buffers (transport 3 below). */
 typedef struct mik_comm mik_comm;
 int mik_comm_unique_id(void *id128);
 int mik_comm_create(mik_ctx *ctx, const void *id128, int rank, int nranks, mik_comm **out);

@@ -105,10 +105,9 @@ struct mik_comm {
     MailBox **peers_dev = nullptr;       // device: peer q's mailbox as mapped into this process (q = rank: mail)
     std::vector<MailBox *> peers;
     std::vector<void *> ipc_open;        // mappings to close
-    // peer allocations that hold ghost regions, as mapped into this process (mik_cgd_connect_ghosts).  Keyed by the 64-byte IPC handle, not
-    // by the rank: a second iterable on the same communicator may keep its u_ext in ANOTHER allocation of the same peer (a second solve, a
-    // re-created engine, another block of the host's memory pool) -- reusing the first mapping would push its halo into unrelated peer memory
-    // (ADVICE r4); and a handle must not be opened twice in one process.
+    // the peers' landing buffers as mapped into this process (mik_plink_connect).  Keyed by the 64-byte IPC handle, not by the rank: every link
+    // on this communicator (a second iterable, a second solve) has a landing buffer of its own on every peer; and a handle must not be opened
+    // twice in one process.
     struct GhostMap { int rank; unsigned char handle[64]; void *base; };
     std::vector<GhostMap> ghost_maps;
     bool mail_finegrained = false;       // hipExtMallocWithFlags(hipDeviceMallocFinegrained) succeeded for the mailbox
@@ -187,7 +186,7 @@ __global__ void k_mail_wait_flag(const unsigned long long *flag, unsigned long l
     if (!mail_wait(flag, want, ticks)) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// the halo of this rank's neighbours: segment i of the packed send buffer -> dst[i] (a pointer into the peer's ghost region), 16 bytes
+// the halo of this rank's neighbours: segment i of the packed send buffer -> dst[i] (a pointer into the peer's landing buffer), 16 bytes
 // per lane where the alignment allows; the last workgroup to finish publishes the exchange number in the receivers' mailboxes
 struct PushSegs {
     static constexpr int MAX = 8;
@@ -343,7 +342,7 @@ extern "C" int mik_comm_create(mik_ctx *ctx, const void *id128, int rank, int nr
     *out = nullptr;
     if (nranks < 1 || rank < 0 || rank >= nranks) return mik_fail(ctx, MIK_ERR_INVALID, "mik_comm_create: bad rank %d of %d", rank, nranks);
     // id128 = NULL with nranks > 1: a communicator without RCCL -- its ranks connect mailboxes (mik_comm_mailbox_export / _connect)
-    // and ghost regions (mik_cgd_connect_ghosts) instead
+    // and landing buffers (mik_cgd_ghost_export / mik_cgd_connect_ghosts, mik_plink_*) instead
     mik_comm *cm = new (std::nothrow) mik_comm();
     if (!cm) return mik_fail(ctx, MIK_ERR_NOMEM, "mik_comm_create: host allocation failed");
     cm->ctx = ctx; cm->rank = rank; cm->nranks = nranks;
@@ -960,7 +959,7 @@ extern "C" int mik_comm_mailbox_info(const mik_comm *cm, int *ready, int *finegr
 //   halo_issue the transfer on the side stream, ordered behind the mark;
 //   halo_end   the compute stream waits for the ghost region.
 // With a mailbox the two orderings are FLAGS: a one-thread kernel stores the exchange number behind the pack kernel, a one-thread
-// kernel on the side stream waits for it; the side stream (or, for peer-mapped ghosts, the sender's push kernel) stores it in the
+// kernel on the side stream waits for it; the side stream (or, for pushed halos, the sender's push kernel) stores it in the
 // receiver's mailbox and a one-wave kernel on the compute stream waits there.  hipEventRecord / hipStreamWaitEvent each cost the
 // compute stream a ~6 us hole between two kernels (profiles/r03_dist_selfhalo_timeline.txt); a 1-thread launch costs ~2.
 // MIK_KNOB_TRANSPORT, bit 0: events.  Every waiting kernel is submitted after the kernel that satisfies it, so streams that share a

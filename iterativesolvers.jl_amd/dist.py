@@ -492,12 +492,12 @@ def register_halo_plan(pkg, engine):
 class NativeComm:
     """``mik_comm``: the transports INSIDE libmik.so (include/mik.h "Transport 1" and "Transport 3").  ``bootstrap`` is any
     communicator of this module (TorchComm over gloo or nccl, SelfComm): it only carries small host objects between the ranks --
-    rank 0's 128-byte ncclUniqueId, the 64-byte HIP IPC handles of the mailboxes and ghost regions -- what MPI.jl's ``bcast`` /
+    rank 0's 128-byte ncclUniqueId, the 64-byte HIP IPC handles of the mailboxes and landing buffers -- what MPI.jl's ``bcast`` /
     ``Allgather`` would do for a Julia host.
 
     ``transport``: "rccl" (halo by ncclSend / ncclRecv, scalars by ncclAllGather), "rccl+mailbox" (halo by RCCL, the two scalars of a
-    step through peer-mapped mailboxes), "mailbox" (no RCCL at all: scalars through the mailboxes, the halo pushed into peer-mapped
-    ghost regions -- the only transport that lets several ranks share one GPU).  ``force_rccl`` creates a real RCCL communicator even
+    step through peer-mapped mailboxes), "mailbox" (no RCCL at all: scalars through the mailboxes, the halo pushed into the
+    neighbours' landing buffers -- the only transport that lets several ranks share one GPU).  ``force_rccl`` creates a real RCCL communicator even
     in a world of one (exercises the library's RCCL call path on a single-GPU box)."""
 
     def __init__(self, pkg, ctx, bootstrap, *, force_rccl=False, transport="rccl"):
@@ -1203,7 +1203,7 @@ def bench_main(args):
     # The transports inside libmik.so (include/mik.h "Transport 1" / "Transport 3"), each on an engine of its own over the same slab:
     #   rccl          halo by ncclSend / ncclRecv on the side stream, the two scalars of a step by ncclAllGather
     #   rccl+mailbox  halo by RCCL, scalars as stores into peer-mapped mailboxes (no collective launch on the compute stream)
-    #   mailbox       no RCCL at all: scalars by mailbox, halo pushed into IPC-mapped ghost regions
+    #   mailbox       no RCCL at all: scalars by mailbox, halo pushed into the neighbours' IPC-mapped landing buffers
     # (2) every transport that came up runs the warm-up and the timed regions in the operator's default layout; their first residuals must
     #     agree bit for bit; the fastest of the largest agreeing group is `transport_chosen`.
     # (3) the CONTRACT loop: the chosen transport on the plain CSR arrays of the slab (mik_csr_set_layout(A_loc, 0), k_spmv_rowgather) --
@@ -1472,7 +1472,7 @@ def bench_main(args):
                                               "+ 2 ncclAllGather of one double per rank per step)",
                                       "rccl+mailbox": "halo by ncclSend/ncclRecv on a side stream; the two scalars of a step as stores into peer-mapped "
                                                       "mailboxes, summed inside the finalising kernels (no collective launch on the compute stream)",
-                                      "mailbox": "peer-mapped mailbox (no RCCL): scalars as stores into IPC-mapped slots, halo pushed into IPC-mapped ghost regions"}[chosen]
+                                      "mailbox": "peer-mapped mailbox (no RCCL): scalars as stores into IPC-mapped slots, halo pushed into the neighbours' IPC-mapped landing buffers and copied into the ghost tail by the receiver"}[chosen]
                                      if transport == "native" and (uses_rccl or world > 1 or self_halo) else
                                      "none (world of one)" if transport == "native" else "torch.distributed driven from Python (legacy)"),
                        "transport_chosen": chosen, "transports_measured": transports,
