@@ -24,8 +24,23 @@ def _device_count():
         return 0
 
 
-WORLD = min(_device_count(), 8)
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(WORLD < 2, reason="needs at least two visible devices (one process per device)")]
+# MIK_TEST_WORLD=P (development): run this file's workers as P processes on the devices there are (rank r on device r mod device_count) -- on a
+# one-GPU box that exercises every line of the workers with the transports that allow ranks to share a device (mailbox, links, gloo callbacks);
+# the RCCL cases are skipped there (RCCL refuses two ranks on one device).
+FORCED = int(os.environ.get("MIK_TEST_WORLD", "0"))
+NDEV = _device_count()
+WORLD = FORCED if FORCED >= 2 else min(NDEV, 8)
+SHARED = WORLD > NDEV                      # ranks share devices
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(WORLD < 2 or NDEV < 1, reason="needs at least two visible devices (one process per device)")]
+
+
+def _dev(rank):
+    return rank % max(NDEV, 1)
+
+
+def _needs_distinct_devices(what):
+    if SHARED:
+        pytest.skip(f"{what}: RCCL refuses two ranks on one device (MIK_TEST_WORLD on a box with fewer devices than ranks)")
 
 
 def _init(rank, world, port, backend="gloo"):
@@ -37,9 +52,9 @@ def _init(rank, world, port, backend="gloo"):
     import __graft_entry__ as graft
     pkg = graft.load_package()
     d = importlib.import_module(pkg.__name__ + ".dist")
-    torch.cuda.set_device(rank)
+    torch.cuda.set_device(_dev(rank))
     if backend == "nccl":                  # the Python-side exchanges themselves run over RCCL (device tensors)
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", _dev(rank)))
     else:                                  # bootstrap only: ncclUniqueId, IPC handles, barriers
         td.init_process_group("gloo", rank=rank, world_size=world)
     return pkg, d, td
@@ -49,8 +64,8 @@ def _cg_worker(rank, world, port, N, nz, out_dir, transport, scale, batch, maxit
     pkg, d, td = _init(rank, world, port)
     boot = d.TorchComm()
     pkg.lib().mik_set_tuning(6, knob6)
-    ptr, li, val, plan, b_loc, n, offsets = d.build_rank_problem(pkg, boot, N, nz_per_rank=nz, device=rank)
-    eng = d.HipEngine(pkg, ptr, li, val, plan, b_loc * scale, abstol=0.0, reltol=1.5e-8, maxiter=maxiter, device=rank)
+    ptr, li, val, plan, b_loc, n, offsets = d.build_rank_problem(pkg, boot, N, nz_per_rank=nz, device=_dev(rank))
+    eng = d.HipEngine(pkg, ptr, li, val, plan, b_loc * scale, abstol=0.0, reltol=1.5e-8, maxiter=maxiter, device=_dev(rank))
     nc = d.NativeComm(pkg, eng.ctx, boot, transport=transport)
     assert nc.uses_rccl() == (transport != "mailbox")
     it = d.NativeDistCGIterable(pkg, eng, nc, maxiter=maxiter)
@@ -93,6 +108,8 @@ def test_cg_every_transport_across_devices_matches_partitioned_oracle(pkg, orc, 
     norm across the ranks (tests/test_dist.py does this with all ranks on one GPU).  MIK_KNOB_TRANSPORT: 1 = the side stream ordered by
     events instead of mailbox flags, 8 = the step's scalars through the one-wave gather launches."""
     import torch.multiprocessing as mp
+    if transport != "mailbox":
+        _needs_distinct_devices(transport)
     N, nz = 16, 4
     mp.spawn(_cg_worker, args=(WORLD, _port(len(transport) + batch + knob6), N, nz, str(tmp_path), transport, scale, batch, 10 ** 6, knob6), nprocs=WORLD, join=True)
     hs = [np.load(tmp_path / f"hist{r}.npy") for r in range(WORLD)]
@@ -111,6 +128,8 @@ def test_cg_halos_larger_than_l2_across_devices(pkg, orc, ctx, tmp_path, transpo
     this rank's next SpMV launch -- 24 steps, batches of 5, bit-exact against the oracle (a halo line served stale from a cache
     would move the history at once)."""
     import torch.multiprocessing as mp
+    if transport != "mailbox":
+        _needs_distinct_devices(transport)
     N, nz, steps = 512, 2, 24
     mp.spawn(_cg_worker, args=(WORLD, _port(91 + len(transport)), N, nz, str(tmp_path), transport, 1.0, 5, steps, 0), nprocs=WORLD, join=True)
     hs = [np.load(tmp_path / f"hist{r}.npy") for r in range(WORLD)]
@@ -135,7 +154,7 @@ def _gmres_worker(rank, world, port, out_dir, orth, scale, backend):
     local_idx, plan = d.localize_block(ptr, idx, offsets, rank)
     d.complete_plan(plan, offsets, comm.all_gather_objects(plan.ghost_gids))
     M = {"mgs": pkg.ModifiedGramSchmidt(), "cgs": pkg.ClassicalGramSchmidt(), "dgks": pkg.DGKS()}[orth]
-    it = d.DistGMRESIterable(pkg, comm, ptr, local_idx, val, plan, (b * scale)[r0:r1], n_global=n, restart=10, orth_meth=M, device=rank,
+    it = d.DistGMRESIterable(pkg, comm, ptr, local_idx, val, plan, (b * scale)[r0:r1], n_global=n, restart=10, orth_meth=M, device=_dev(rank),
                              native="mailbox" if backend == "link" else None)
     hist = it.solve()
     np.save(os.path.join(out_dir, f"hist{rank}.npy"), hist)
@@ -155,6 +174,8 @@ def test_partitioned_gmres_across_devices_matches_partitioned_oracle(pkg, orc, c
     with host staging).  History and solution bit-exact against the oracle's gmres with the same partition; a system scaled by 1e-160
     sends every norm through the scaled pass across the ranks."""
     import torch.multiprocessing as mp
+    if backend == "nccl":
+        _needs_distinct_devices("nccl callbacks")
     mp.spawn(_gmres_worker, args=(WORLD, _port(len(orth) + {"nccl": 3, "gloo": 0, "link": 7}[backend] + (5 if scale != 1.0 else 0)), str(tmp_path), orth, scale, backend),
              nprocs=WORLD, join=True)
     A, _ = orc.advdiff(12, 1000.0)
@@ -178,6 +199,8 @@ def test_bench_line_of_the_partitioned_run_is_contract_complete(tmp_path):
     import json
     import subprocess
     env = dict(os.environ, MIK_BENCH_MIN_SECONDS="0.05", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if SHARED:                             # all ranks on device 0, the one transport that allows it
+        env.update(MIK_FORCE_DEVICE="0", MIK_NATIVE_TRANSPORTS="mailbox")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(WORLD), "--steps", "40", "--warmup", "5", "--cpu-iters", "3"],
                          capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
