@@ -1317,6 +1317,43 @@ template <typename T> static int gm_link_norm_slow(mik_gmres *g, const T *x, T *
     return MIK_OK;
 }
 
+// The DGKS loop (src/orthogonalize.jl:26-33) over a link, from a first projection on: w unscaled on entry, scaled on exit; every round = batched dot,
+// one exchange of the k sums, the update, the norm over the ranks, ONE host wait.  Entered by the chain below and by the single launch's hand-back.
+template <typename T>
+static int dgks_link_loop(mik_gmres *g, int k, const T *V, int64_t ldv, T *w, T *h, T *nrm_io, T projection_size)
+{
+    mik_ctx *ctx = g->ctx;
+    mik_plink *pl = g->part.link;
+    const int64_t n = g->n, nseg = mik_nseg<T>(n);
+    if ((size_t)(2 * k + 4) * sizeof(T) > mik_ctx::COEF_SAFE_SLOT) return mik_fail(ctx, MIK_ERR_NOTIMPL, "orthogonalize: k = %d too large", k);
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(nseg, 1) * (size_t)std::max(k, 1)));
+    T *hd = (T *)ctx->coef, *part = (T *)ctx->partials;          // [k] nrm, [k + 1] 1 / nrm, [k + 2, 2k + 2) the round's correction
+    const bool vecw = mik_aligned16(w);
+    OpDot<T> dn{w, w};
+    std::vector<T> corr((size_t)std::max(k, 1));
+    const T eta = T(1) / std::sqrt(T(2));                                // :20
+    T nrm = *nrm_io;
+    while (nrm < eta * projection_size) {                                // :26
+        if (k > 0) {                                                     // :27, :30
+            MIK_TRY(multidot<T>(ctx, n, k, V, ldv, w, hd + k + 2));
+            MIK_TRY(plink_sum_vec(pl, hd + k + 2, k));
+            MIK_TRY(gemv_n_dev<T>(ctx, n, k, V, ldv, hd + k + 2, T(-1), w));
+        }
+        MIK_TRY((launch_map<T>(ctx, n, dn, vecw, part, nullptr)));       // :32
+        MIK_TRY(plink_fin_sum(pl, part, nseg, hd + k, 1));
+        MIK_TRY(coef_download<T>(ctx, k + 2, corr.data(), k));
+        MIK_TRY(coef_download<T>(ctx, k, &nrm, 1));
+        MIK_TRY(plink_check(pl, "gmres (row-partitioned)"));
+        if (nrm != nrm) MIK_TRY(gm_link_norm_slow<T>(g, w, &nrm));
+        projection_size = dgks_small_norm<T>(corr.data(), k);            // :28
+        for (int j = 0; j < k; ++j) h[j] = h[j] + corr[(size_t)j];       // :31
+    }
+    OpScal<T> sc{w, coef_val<T>(T(1) / nrm)};                            // :36
+    MIK_TRY((launch_map<T>(ctx, n, sc, vecw, (T *)nullptr, nullptr)));
+    *nrm_io = nrm;
+    return MIK_OK;
+}
+
 template <typename T>
 static int orthogonalize_link(mik_gmres *g, int k, const T *V, int64_t ldv, T *w, T *h, T *nrm_out, int method)
 {
@@ -1414,20 +1451,7 @@ static int orthogonalize_link(mik_gmres *g, int k, const T *V, int64_t ldv, T *w
     for (int j = 0; j < k; ++j) h[j] = out[(size_t)j];
     nrm = out[(size_t)k];
     if (nrm != nrm) MIK_TRY(gm_link_norm_slow<T>(g, w, &nrm));
-    std::vector<T> corr((size_t)std::max(k, 1));
-    const T eta = T(1) / std::sqrt(T(2));                                // :20
-    T projection_size = dgks_small_norm<T>(h, k);                        // :22
-    while (nrm < eta * projection_size) {                                // :26
-        MIK_TRY(project(k + 2));                                         // :27, :30
-        MIK_TRY(norm_w(&nrm));                                           // :32
-        MIK_TRY(download(k + 2, corr.data(), k));
-        MIK_TRY(download(k, &nrm, 1));
-        if (nrm != nrm) MIK_TRY(gm_link_norm_slow<T>(g, w, &nrm));
-        projection_size = dgks_small_norm<T>(corr.data(), k);            // :28
-        for (int j = 0; j < k; ++j) h[j] = h[j] + corr[(size_t)j];       // :31
-    }
-    OpScal<T> sc{w, coef_val<T>(T(1) / nrm)};                            // :36
-    MIK_TRY((launch_map<T>(ctx, n, sc, vecw, (T *)nullptr, nullptr)));
+    MIK_TRY(dgks_link_loop<T>(g, k, V, ldv, w, h, &nrm, dgks_small_norm<T>(h, k)));   // :22
     *nrm_out = nrm;
     return MIK_OK;
 }
@@ -1592,12 +1616,13 @@ static int gmres_create_common(mik_ctx *ctx, const mik_csr *A, void *x, const vo
         // per CU); more than 256 segments need the library's own 16-byte aligned V (always the case here)
         // (a row partition: only with a device-driven link, Modified Gram-Schmidt and restart <= 62 -- the totals of a launch's passes travel
         // between the ranks through one vector slot per pass, csrc/mik_mail.h MailSumPass)
-        const bool part_ok = !part || (part->link && (orth_method == MIK_MGS || orth_method == MIK_CGS) && restart <= MIK_MAIL_VEC - 2);   // (DGKS over a link: the chains)
+        const bool part_ok = !part || (part->link && restart <= MIK_MAIL_VEC - 2);   // (one vector mail slot per column total and the norm; DGKS: per round)
         if (part_ok && nseg >= 1 && nseg <= 2048 && restart <= 254 && (nseg <= 256 || g->ldv % 4 == 0)) {
             g->mgs_G = nseg <= 256 ? 1 : nseg <= 512 ? 2 : nseg <= 1024 ? 4 : 8;
             g->mgs_stride = std::max<int>(256, (int)((nseg + g->mgs_G - 1) / g->mgs_G) * g->mgs_G);
             // k_cgs_fused: one more row per round (the final h values); DGKS: up to 3 rounds in the kernel
             g->mgs_rounds = orth_method == MIK_DGKS ? (ctx->tuning[MIK_KNOB_GS] == 3 ? 1 : 3) : 1;   // DGKS rounds the kernel runs before it hands back to the host loop (MIK_KNOB_GS = 3: one)
+            if (part && orth_method == MIK_DGKS) g->mgs_rounds = std::max(1, std::min(g->mgs_rounds, MIK_MAIL_VEC / (restart + 1)));     // (the rounds of a launch share the 64 vector slots)
             const size_t pbytes = es * 2 * (size_t)g->mgs_rounds * (size_t)(restart + 2) * (size_t)g->mgs_stride;
             if ((e = hipMalloc(&g->mgs_P, pbytes)) != hipSuccess || (e = hipMemsetAsync(g->mgs_P, 0xFF, pbytes, ctx->stream)) != hipSuccess ||
                 (e = hipMalloc((void **)&g->xl_chk, 2 * sizeof(unsigned))) != hipSuccess || (e = hipMemsetAsync(g->xl_chk, 0, 2 * sizeof(unsigned), ctx->stream)) != hipSuccess ||
@@ -1703,10 +1728,10 @@ template <typename T> static int gm_fused_enqueue(mik_gmres *g, int k, int slot)
     g->mgs_slot_seq[slot] = g->mgs_seq;
 #define MIK_CGS_GO(VECV, DG, GG)                                                                                                               \
     do {                                                                                                                                        \
-        if (g->dist && !DG) { /* a row partition with a link: column totals and the norm are summed over the ranks inside the launch */        \
+        if (g->dist) {        /* a row partition with a link: column totals and the norm are summed over the ranks inside the launch */        \
             const PlinkMail pm = plink_mail(g->part.link);                                                                                      \
             const MailSumPass xch{pm.peers, pm.P, pm.rank, plink_next_vec_tag(g->part.link), pm.ticks, pm.err};                                 \
-            hipLaunchKernelGGL((k_cgs_fused<T, VECV, false, GG, MailSumPass>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, \
+            hipLaunchKernelGGL((k_cgs_fused<T, VECV, DG, GG, MailSumPass>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, \
                                g->restart, stride, nseg, g->mgs_rounds, g->mgs_parity, gm_mirror(g, slot), g->mgs_seq, xch);                    \
         } else                                                                                                                                  \
             hipLaunchKernelGGL((k_cgs_fused<T, VECV, DG, GG>), dim3(m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart, \
@@ -1783,8 +1808,13 @@ template <typename T> static int gm_fused_wait(mik_gmres *g, int k, int slot, T 
     if (g->method == MIK_DGKS && mir->pad) {    // the kernel stopped before the DGKS loop ended (round limit / unsafe norm): w is unscaled
         T *w = (T *)g->V + (int64_t)k * g->ldv;
         T nrm = out[k];
-        if (nrm != nrm) MIK_TRY(mik_safe_norm_slow<T>(ctx, g->n, w, &nrm));
-        MIK_TRY(dgks_host_loop<T>(ctx, g->n, k, (const T *)g->V, g->ldv, w, h_out, &nrm, out[k + 1]));
+        if (g->dist) {                          // (every rank sees the same totals: all of them come here together)
+            if (nrm != nrm) MIK_TRY(gm_link_norm_slow<T>(g, w, &nrm));
+            MIK_TRY(dgks_link_loop<T>(g, k, (const T *)g->V, g->ldv, w, h_out, &nrm, out[k + 1]));
+        } else {
+            if (nrm != nrm) MIK_TRY(mik_safe_norm_slow<T>(ctx, g->n, w, &nrm));
+            MIK_TRY(dgks_host_loop<T>(ctx, g->n, k, (const T *)g->V, g->ldv, w, h_out, &nrm, out[k + 1]));
+        }
         *nrm_out = nrm;
         *rescaled = true;
         return MIK_OK;

@@ -42,7 +42,7 @@ def worker(rank, world, port, case, mode, out_path):
     n, colptr, rowval, nzval, b = problem(pkg, case)
     restart, iters = 30, 90
     res = {}
-    for mname, M in (("mgs", pkg.ModifiedGramSchmidt()), ("cgs", pkg.ClassicalGramSchmidt())):
+    for mname, M in (("mgs", pkg.ModifiedGramSchmidt()), ("cgs", pkg.ClassicalGramSchmidt()), ("dgks", pkg.DGKS())):
         if mode == "fused":
             dA = pkg.HipCSR(n, n, colptr, rowval, nzval, index_base=1)
             db = pkg.HipVector.from_numpy(b)
@@ -98,7 +98,7 @@ def main():
             except Exception as e:     # noqa: BLE001
                 out[case][f"world{world}_{mode}"] = {"error": str(e)[:300]}
         o = out[case]
-        for m in ("mgs", "cgs"):
+        for m in ("mgs", "cgs", "dgks"):
             try:
                 o[f"{m}_world2_link_over_world1_link"] = o["world2_link"][m]["us_per_inner_iteration"] / o["world1_link"][m]["us_per_inner_iteration"]
                 o[f"{m}_same_bits_link_vs_callbacks_world2"] = o["world2_link"][m]["last_residual"] == o["world2_callbacks"][m]["last_residual"]

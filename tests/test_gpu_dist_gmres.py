@@ -269,7 +269,8 @@ def _link_worker(rank, world, port, out_dir, orth, scale, dtype_name, restart, b
     (2, "mgs", 1.0, "float64", 10, 0, 1), (3, "mgs", 1e-160, "float64", 10, 3, 1), (2, "mgs", 1.0, "float32", 10, 0, 1),
     (2, "mgs", 1.0, "float64", 10, 0, 2), (3, "mgs", 1e-160, "float64", 10, 3, 2), (2, "mgs", 1.0, "float32", 10, 6, 2), (3, "mgs", 1.0, "float64", 10, 0, 2),
     (2, "cgs", 1.0, "float64", 10, 0, 2), (3, "cgs", 1e-160, "float64", 10, 4, 1), (2, "cgs", 1.0, "float32", 12, 5, 2),
-    (2, "mgs", 1.0, "float64", 70, 0, 0), (2, "cgs", 1.0, "float64", 70, 0, 0)])     # restart > 62: more passes than vector slots -- the chains
+    (2, "dgks", 1.0, "float64", 10, 0, 1), (3, "dgks", 1e-160, "float64", 10, 4, 1), (2, "dgks", 1.0, "float32", 10, 3, 3), (2, "dgks", 1.0, "float64", 30, 0, 0),
+    (2, "mgs", 1.0, "float64", 70, 0, 0), (2, "cgs", 1.0, "float64", 70, 0, 0), (2, "dgks", 1.0, "float64", 70, 0, 0)])     # restart > 62: more passes than vector slots -- the chains
 def test_device_driven_partitioned_gmres_ranks_in_processes_on_one_gpu(pkg, orc, ctx, tmp_path, world, orth, scale, dtype_name, restart, batch, gs):
     """mik_gmres_create_partitioned with mik_partition.link -- halo pushed into the neighbours' landing buffers, every
     projection and norm summed over the ranks INSIDE the kernel that finalises it (mailbox slots, rank order), coefficients read from device
@@ -282,7 +283,8 @@ def test_device_driven_partitioned_gmres_ranks_in_processes_on_one_gpu(pkg, orc,
     the host), 2 = the launch-lean chain (every pass finalises AND exchanges the previous reduction itself: k + 2 launches, up to 256 segments
     per rank), 1 = the general chain with its finalise-and-exchange launches (what larger slabs run).  ClassicalGramSchmidt: 0 = k_cgs_fused with the
     exchange inside (the reducer workgroup of every column swaps the rank's total for the sum over the ranks), 1 / 2 = batched dot + one vector
-    exchange (k_mail_sum_vec) + axpy sweep; DGKS always runs that chain with its loop on the host."""
+    exchange (k_mail_sum_vec) + axpy sweep.  DGKS: 0 = k_cgs_fused<DGKS> with the exchange inside (as many rounds per launch as the 64 vector slots
+    hold: 64 / (restart + 1), at most 3), 3 = one round per launch, then the link's host loop, 1 / 2 = the chain with its loop on the host."""
     import torch.multiprocessing as mp
     port = 29100 + (os.getpid() * 3 + world * 17 + len(orth) * 5 + restart + batch + (40 if scale != 1.0 else 0) + (80 if dtype_name == "float32" else 0) + 160 * gs) % 700
     mp.spawn(_link_worker, args=(world, port, str(tmp_path), orth, scale, dtype_name, restart, batch, gs), nprocs=world, join=True)
@@ -300,6 +302,68 @@ def test_device_driven_partitioned_gmres_ranks_in_processes_on_one_gpu(pkg, orc,
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"hist{r}.npy"), ho["resnorm"]), r
         assert tuple(np.load(tmp_path / f"mv{r}.npy")) == (ho["mvps"], int(ho["isconverged"]))
+    assert np.array_equal(np.concatenate([np.load(tmp_path / f"x{r}.npy") for r in range(world)]), xo)
+
+
+def _reorth_system(dtype):
+    import scipy.sparse as sp
+    n = 3000
+    S = (sp.identity(n) + 1e-4 * sp.random(n, n, density=0.002, random_state=3)).tocsc()
+    S.sort_indices()
+    return n, S.astype(dtype), np.random.default_rng(21).standard_normal(n).astype(dtype)
+
+
+def _link_reorth_worker(rank, world, port, out_dir, dtype_name, gs):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), MIK_MAILBOX_TIMEOUT_MS="20000")
+    import torch
+    import torch.distributed as td
+    import __graft_entry__ as graft
+    from importlib import import_module
+    pkg = graft.load_package()
+    dist = import_module(pkg.__name__ + ".dist")
+    torch.cuda.set_device(0)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    comm = dist.TorchComm()
+    pkg.lib().mik_set_tuning(5, gs)                                       # MIK_KNOB_GS: 0 = three rounds inside the launch, 3 = one (then handed back), 1 = the chain
+    n, S, b = _reorth_system(np.dtype(dtype_name))
+    S = S.tocsr()
+    offsets = dist.partition_rows(n, world)
+    r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
+    ptr, idx, val = csr_block(S, r0, r1)
+    local_idx, plan = dist.localize_block(ptr, idx, offsets, rank)
+    dist.complete_plan(plan, offsets, comm.all_gather_objects(plan.ghost_gids))
+    it = dist.DistGMRESIterable(pkg, comm, ptr, local_idx, val, plan, b[r0:r1], n_global=n, restart=12, maxiter=20, reltol=0.0, orth_meth=pkg.DGKS(), native="mailbox")
+    hist = it.solve()
+    np.save(os.path.join(out_dir, f"hist{rank}.npy"), hist)
+    np.save(os.path.join(out_dir, f"x{rank}.npy"), it.solution())
+    np.save(os.path.join(out_dir, f"off{rank}.npy"), offsets)
+    comm.barrier()
+    it.close()
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dtype_name,gs", [(2, "float64", 0), (3, "float64", 3), (2, "float64", 1), (2, "float32", 0), (2, "float32", 3), (3, "float32", 1)])
+def test_device_driven_partitioned_dgks_reorthogonalises_across_the_ranks(pkg, orc, ctx, tmp_path, world, dtype_name, gs):
+    """A = I + a tiny perturbation (the system of test_gmres_dgks_reorthogonalisation_inside_the_single_launch_kernel) cut into 2 / 3 row blocks, ranks
+    as processes on one GPU: the DGKS condition (src/orthogonalize.jl:26) holds, so the loop runs -- inside k_cgs_fused<DGKS, MailSumPass> with
+    every round's column totals and norm summed over the ranks in the launch (gs = 0), handed back after one round to the link's host loop
+    (gs = 3: every rank takes the hand-back together, the totals being identical), and as the chain (gs = 1).  Bit-exact against the
+    partition-aware oracle, which differs from its own CGS run (the loop really ran)."""
+    import torch.multiprocessing as mp
+    port = 29100 + (os.getpid() * 3 + world * 19 + 7 * gs + (50 if dtype_name == "float32" else 0) + 333) % 700
+    mp.spawn(_link_reorth_worker, args=(world, port, str(tmp_path), dtype_name, gs), nprocs=world, join=True)
+    dtype = np.dtype(dtype_name)
+    n, S, b = _reorth_system(dtype)
+    A = orc.CSC.from_scipy(S).astype(dtype)
+    orc.set_partition(np.load(tmp_path / "off0.npy"))
+    try:
+        xo, ho = orc.gmres(A, b, restart=12, orth_meth="dgks", mode="tree", shape=ctx.reduce_shape(dtype), maxiter=20, reltol=0.0)
+        xc, hc = orc.gmres(A, b, restart=12, orth_meth="cgs", mode="tree", shape=ctx.reduce_shape(dtype), maxiter=20, reltol=0.0)
+    finally:
+        orc.set_partition(None)
+    assert not np.array_equal(ho["resnorm"], hc["resnorm"]) or not np.array_equal(xo, xc)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"hist{r}.npy"), ho["resnorm"]), r
     assert np.array_equal(np.concatenate([np.load(tmp_path / f"x{r}.npy") for r in range(world)]), xo)
 
 
