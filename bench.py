@@ -252,6 +252,14 @@ def gmres_hbm_bound(A, b, n: int, restart: int = 30, inner: int = 60, reps: int 
     return out
 
 
+def fixtures_shadow(n: int, j: int):
+    """shadow vector j of the IDR(s) leg: the hashed right-hand side generator shifted into (0, 1), a different stream per column (the reference draws
+    rand!, src/idrs.jl:136)"""
+    pkg = graft.load_package()
+    v = pkg.fixtures.hashed_rhs(n) + 0.5
+    return np.roll(v, 7919 * (j + 1))
+
+
 def f_solvers(A, b, n: int, iters: int = 40):
     """SURVEY.md 8f rows on the driver's line: per-iteration wall time of PCG with a Jacobi Pl (src/cg.jl:72-100), Chebyshev
     (src/chebyshev.jl:29-57), MINRES (src/minres.jl:95-159) and BiCGStab(2) (src/bicgstabl.jl:79-134; per OUTER iteration = 4 SpMV) on the 256^3
@@ -292,8 +300,18 @@ def f_solvers(A, b, n: int, iters: int = 40):
         ll = 2
         words = sum((1 if epb and j else (0 if j == 0 else 2)) + 3 * (j + 1) + (1 if epb else 2) + 3 * (j + 1) + 3 for j in range(ll)) + (ll + 1) + (3 * ll + 4) + 1
         rec["bicgstab2_per_outer_iteration"] = timed(bit, 0, 2 * ll, words, max(iters // 3, 10))
+        # IDR(8) (src/idrs.jl:164-272; the widening step after section 8f): average over whole cycles of s + 1 = 9 steps, each one SpMV.  Words per row of a
+        # cycle: step k (0-based, cnt = s - k): direction sweep 2 cnt + 2, bi-orthogonalisation 2 + 7 k - 1 (k > 0), batched dot cnt + 1, update 6;
+        # the polynomial step: 2 + 5
+        ss = 8
+        cyc = sum(2 * (ss - k) + 2 + ((2 + 7 * k - 1) if k else 0) + (ss - k) + 1 + 6 for k in range(ss)) + 7
+        Pm = pkg.HipMatrix(n, ss, np.float64)
+        for j in range(ss):
+            Pm.col(j).copy_from_host(fixtures_shadow(n, j))
+        iit = pkg.idrs_iterable_(None, pkg.zerox(A, b), A, b, ss, None, 0.0, 0.0, 10 ** 9, P=Pm)
+        rec["idrs8_per_step"] = timed(iit, (1, 1), 1, cyc / (ss + 1), 4 * (ss + 1))
         out["default_layout" if layout == "auto" else "csr_arrays"] = rec
-        del d, mit, bit
+        del d, mit, bit, iit, Pm
     A.set_layout("auto")
     return out
 

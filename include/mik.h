@@ -362,6 +362,22 @@ int mik_minres_step(mik_minres *it, int64_t iteration, void *resnorm);   /* resn
 int mik_minres_proj_shape(const mik_minres *it, int *W, int *L);
 int mik_minres_destroy(mik_minres *it);
 
+/* One step of IDR(s) -- iterate(::IDRSIterable, (iter, step)), src/idrs.jl:164-272 -- per call.  step = 1..s: the small triangular solve (:187,
+ * host), V / Q / ldiv!(Pl, V) / U[k] in ONE sweep (:188-202), mul! (:203), the bi-orthogonalisation against P[1..k-1] as a chain of sweeps whose
+ * coefficients never leave the device (:207-211), M[k..s, k] as one batched dot (:215-217), and beta / R / X / norm(R) in one sweep (:221-225);
+ * step = s + 1: the polynomial step with omega(Q, R) (:242-256).  Residual smoothing (:226-235) when X_s / R_s are given.  The host waits once per
+ * step (twice in steps 1 and s + 1).  The caller owns the vectors as idrs_iterable! sets them up (:116-147): R = C - A X, U = G = 0 (n x s,
+ * column-major), X_s = copy(X) and R_s = copy(R) for smoothing (both NULL otherwise), and P: the s shadow vectors (the reference fills them
+ * with rand!, :136).  pl_diag: diagonal of a Jacobi Pl or NULL (Identity).  M (= I), f, c and omega (= 1) live in the handle.  s <= 32.
+ * normR0 = norm(R).  mik_idrs_step returns it.normR of the reference after the step (norm(R), or norm(R_s) with smoothing); the caller copies
+ * X_s into X on termination as :171-173 do. */
+typedef struct mik_idrs mik_idrs;
+int mik_idrs_create(mik_ctx *ctx, const mik_csr *A, int s, void *x, void *r, const void *P, int64_t ldp, void *U, int64_t ldu, void *G,
+                    int64_t ldg, const void *pl_diag, void *x_s, void *r_s, double normR0, mik_idrs **out);
+int mik_idrs_step(mik_idrs *it, int step, void *normR);            /* normR: one scalar of A's element type */
+int mik_idrs_state(const mik_idrs *it, void *omega, void *M, void *f);   /* host copies (any may be NULL): omega, M (s x s column-major), f (s) */
+int mik_idrs_destroy(mik_idrs *it);
+
 /* ---- row-partitioned GMRESIterable: one process per GPU ---------------------------------------- */
 /* The same iterable (src/gmres.jl:57-106) over a contiguous row block.  The Arnoldi basis, x, b and
  * the diagonal preconditioners are this rank's n_loc rows; A_loc is the block as an n_loc x n_ext

@@ -1521,3 +1521,179 @@ def minres_(x, A, b, *, skew_hermitian=False, verbose=False, log=False, abstol=0
 def minres(A, b, **kwargs):
     """``minres(A, b; ...)`` -- src/minres.jl:236."""
     return minres_(zerox(A, b), A, b, initially_zero=True, **kwargs)
+
+
+class IDRSIterable:
+    """``IDRSIterable`` -- src/idrs.jl:84-113, construction per ``idrs_iterable!`` (:116-147); real element types.  ``P`` replaces the
+    reference's ``rand!`` shadow vectors (:136) when reproducibility is wanted: a ``HipMatrix`` or an n x s array; default: uniform [0, 1)
+    numbers like ``rand!``.  The iteration state is the pair ``(iter, step)`` of the reference (:164)."""
+
+    def __init__(self, log, X, A, C_, s, Pl, abstol, reltol, maxiter, *, smoothing=False, verbose=False, P=None, fused=True):
+        T = X.dtype.type
+        self.log, self.X, self.A, self.s, self.smoothing, self.verbose = log, X, A, int(s), bool(smoothing), bool(verbose)
+        self.Pl = Identity() if Pl is None else Pl
+        self.abstol, self.reltol, self.maxiter = abstol, reltol, maxiter
+        n = X.n
+        self.R = X.similar()
+        mul_(self.R, A, X)                                                   # R = C - A*X  :119
+        self.R.xpby_(C_, T(-1))
+        self.normR = norm(self.R)                                            # :120
+        self.tol = max(T(reltol) * self.normR, T(abstol))                    # :121
+        if self.smoothing:                                                   # :123-126
+            self.X_s, self.R_s, self.T_s = X.similar().copyto_(X), X.similar().copyto_(self.R), X.zero()
+        else:
+            self.X_s = self.R_s = self.T_s = None
+        if P is None:
+            P = np.random.default_rng().random((n, self.s)).astype(X.dtype)  # :136
+        self.P = P if isinstance(P, HipMatrix) else HipMatrix.from_numpy(np.asarray(P, X.dtype).reshape(n, self.s), X.ctx)
+        self.U, self.G = HipMatrix(n, self.s, X.dtype, X.ctx), HipMatrix(n, self.s, X.dtype, X.ctx)   # :137-138
+        self.Q, self.V = X.zero(), X.zero()                                  # :139-140
+        self.M = np.eye(self.s, dtype=X.dtype, order="F")                    # :142
+        self.f = np.zeros(self.s, X.dtype)                                   # :143
+        self.c = np.zeros(self.s, X.dtype)
+        self.omega = T(1)                                                    # :146
+        # fused, a HipCSR operator, Identity / diagonal Pl, s <= 32: one C call per step (mik_idrs_step); M, f and omega then live in the handle
+        self._step = None
+        if fused and isinstance(A, HipCSR) and isinstance(self.Pl, (Identity, JacobiPrec)) and self.s <= 32:
+            h = _vp()
+            d = self.Pl.diagonal.ptr if isinstance(self.Pl, JacobiPrec) else None
+            check(lib().mik_idrs_create(X.ctx.handle, A.handle, self.s, _vp(X.ptr), _vp(self.R.ptr), _vp(self.P.col(0).ptr), self.P.ld,
+                                        _vp(self.U.col(0).ptr), self.U.ld, _vp(self.G.col(0).ptr), self.G.ld, _vp(d),
+                                        _vp(self.X_s.ptr if self.smoothing else None), _vp(self.R_s.ptr if self.smoothing else None),
+                                        float(self.normR), C.byref(h)), "mik_idrs_create", X.ctx.handle)
+            self._step = h
+
+    def _ldiv(self, v):
+        if not isinstance(self.Pl, Identity):
+            self.Pl.ldiv_(v)
+
+    def _smooth(self):                                                       # :226-235, :257-266
+        self.T_s.copyto_(self.R_s).sub_(self.R)
+        gamma = dot(self.R_s, self.T_s) / dot(self.T_s, self.T_s)
+        self.R_s.axpy_(-gamma, self.T_s)
+        self.T_s.copyto_(self.X_s).sub_(self.X)                              # X_s .- X (T_s is free again)
+        self.X_s.axpy_(-gamma, self.T_s)
+        self.normR = norm(self.R_s)
+
+    def state(self):
+        """(omega, M, f) as the iteration holds them (the handle's copies on the fused path)."""
+        if self._step is None:
+            return self.omega, self.M.copy(), self.f.copy()
+        om, M, f = np.zeros(1, self.X.dtype), np.zeros((self.s, self.s), self.X.dtype, order="F"), np.zeros(self.s, self.X.dtype)
+        check(lib().mik_idrs_state(self._step, om.ctypes.data_as(_vp), M.ctypes.data_as(_vp), f.ctypes.data_as(_vp)), "mik_idrs_state", self.X.ctx.handle)
+        return om[0], M, f
+
+    def iterate(self, state=None):
+        """``iterate(it, (iter, step))`` -- src/idrs.jl:164-272."""
+        it, step = (1, 1) if state is None else state
+        T = self.X.dtype.type
+        s, P, U, G, M, f = self.s, self.P, self.U, self.G, self.M, self.f
+        if self.normR < self.tol or it > self.maxiter:                       # :168
+            if self.log is not None:
+                self.log.setconv(bool(0 <= self.normR < self.tol))
+            if self.smoothing:
+                self.X.copyto_(self.X_s)                                     # :171-173
+            return None
+        if self._step is not None:
+            out = np.zeros(1, self.X.dtype)
+            check(lib().mik_idrs_step(self._step, int(step), out.ctypes.data_as(_vp)), "mik_idrs_step", self.X.ctx.handle)
+            self.normR = out[0]
+            nextstep = step + 1 if step <= s else 1
+        elif step <= s:
+            if step == 1:
+                for i in range(s):
+                    f[i] = dot(P.col(i), self.R)                             # :179-181
+            k = step - 1
+            c = f[k:].copy()                                                 # c = LowerTriangular(M[k:s,k:s]) \ f[k:s]  :187
+            for j in range(k, s):
+                c[j - k] = c[j - k] / M[j, j]
+                for i in range(j + 1, s):
+                    c[i - k] = c[i - k] - M[i, j] * c[j - k]
+            self.V.copyto_(G.col(k)).scal_(c[0])                             # :188
+            self.Q.copyto_(U.col(k)).scal_(c[0])                             # :189
+            for i in range(k + 1, s):                                        # :191-194
+                self.V.axpy_(c[i - k], G.col(i))
+                self.Q.axpy_(c[i - k], U.col(i))
+            self.V.xpby_(self.R, T(-1))                                      # V .= R .- V  :197
+            self._ldiv(self.V)                                               # :200
+            U.col(k).copyto_(self.Q).axpy_(self.omega, self.V)               # :202
+            mul_(G.col(k), self.A, U.col(k))                                 # :203
+            for i in range(k):                                               # :207-211
+                alpha = dot(P.col(i), G.col(k)) / M[i, i]
+                G.col(k).axpy_(-alpha, G.col(i))
+                U.col(k).axpy_(-alpha, U.col(i))
+            for i in range(k, s):
+                M[i, k] = dot(P.col(i), G.col(k))                            # :215-217
+            beta = f[k] / M[k, k]                                            # :221
+            self.R.axpy_(-beta, G.col(k))                                    # :222
+            self.X.axpy_(beta, U.col(k))                                     # :223
+            self.normR = norm(self.R)                                        # :225
+            if self.smoothing:
+                self._smooth()
+            for i in range(k + 1, s):
+                f[i] = f[i] - beta * M[i, k]                                 # :237-239
+            nextstep = step + 1
+        else:                                                                # step == s + 1  :242
+            self.V.copyto_(self.R)                                           # :246
+            self._ldiv(self.V)                                               # :249
+            mul_(self.Q, self.A, self.V)                                     # :251
+            ns, nt, ts = norm(self.R), norm(self.Q), dot(self.Q, self.R)     # omega(Q, R)  :70-82
+            rho = abs(ts / (nt * ns))
+            omega = ts / (nt * nt)
+            if float(rho) < math.sqrt(2.) / 2:
+                omega = omega * T(math.sqrt(2.) / 2) / rho
+            self.omega = T(omega)
+            self.R.axpy_(-self.omega, self.Q)                                # :253
+            self.X.axpy_(self.omega, self.V)                                 # :254
+            self.normR = norm(self.R)                                        # :256
+            if self.smoothing:
+                self._smooth()
+            nextstep = 1
+        if self.log is not None:
+            self.log.nextiter_(mvps=1)                                       # :268-269
+            self.log.push_("resnorm", self.normR)
+        if self.verbose:
+            print("%3d\t%3d\t%1.2e" % (it, step, self.normR))
+        return self.normR, (it + 1, nextstep)
+
+    def __iter__(self):
+        state = (1, 1)
+        while (nxt := self.iterate(state)) is not None:
+            normR, state = nxt
+            yield normR
+
+    def __del__(self):
+        try:
+            if getattr(self, "_step", None) is not None and self.X.ctx.handle:
+                lib().mik_idrs_destroy(self._step)
+                self._step = None
+        except Exception:
+            pass
+
+
+def idrs_iterable_(log, X, A, C_, s, Pl, abstol, reltol, maxiter, *, smoothing=False, verbose=False, P=None, fused=True):
+    """``idrs_iterable!(log, X, A, C, s, Pl, abstol, reltol, maxiter; smoothing, verbose)`` -- src/idrs.jl:116-147."""
+    return IDRSIterable(log, X, A, C_, s, Pl, abstol, reltol, maxiter, smoothing=smoothing, verbose=verbose, P=P, fused=fused)
+
+
+def idrs_(x, A, b, *, s=8, Pl=None, abstol=0.0, reltol=None, maxiter=None, log=False, **kwargs):
+    """``idrs!(x, A, b; s, Pl, abstol, reltol, maxiter, log, smoothing, verbose)`` -- src/idrs.jl:49-64 (and idrs_method!, :150-162)."""
+    reltol = _default_reltol(b) if reltol is None else reltol
+    maxiter = A.size(2) if maxiter is None else maxiter
+    history = ConvergenceHistory(partial=not log)
+    history["abstol"], history["reltol"] = abstol, reltol
+    if log:
+        history.reserve_("resnorm", maxiter)
+    if kwargs.get("verbose"):
+        print("=== idrs ===\n%4s\t%4s\t%7s" % ("iter", "step", "resnorm"))
+    it = idrs_iterable_(history, x, A, b, s, Pl, abstol, reltol, maxiter, **kwargs)
+    for _ in it:                                                             # reduce((_, r) -> r, iterable; init = iterable.normR)  :158
+        pass
+    if log:
+        history.shrink_()
+    return (it.X, history) if log else it.X
+
+
+def idrs(A, b, **kwargs):
+    """``idrs(A, b; s = 8, ...)`` -- src/idrs.jl:10."""
+    return idrs_(zerox(A, b), A, b, **kwargs)

@@ -214,6 +214,53 @@ static inline int launch_map2(mik_ctx *ctx, int64_t n, Op op, bool vec, T *seg1,
     return MIK_OK;
 }
 
+// k_map whose coefficient comes from the level-2 sum of the PRODUCER's segment sums, formed by every workgroup itself (m <= 1024
+// partials: block_level2_256 = the tree of k_finalize_store) and turned into the sweep's coefficient by `pro` -- the scalar
+// statement of the reference that sits between the reduction and the sweep; workgroup 0 publishes what later kernels need.
+// One launch instead of reduction finaliser + sweep: at the sizes where an iteration is launch-bound that is where its time goes.
+template <typename T, bool VEC, typename Op, typename Pro>
+__global__ __launch_bounds__(MIK_BLOCK) void k_map_with(int64_t n, int64_t nseg, Op op, Pro pro, const T *__restrict__ part, int m, T *__restrict__ seg_out)
+{
+    constexpr int W = VT<T>::W;
+    constexpr int L = MIK_RED_L;
+    constexpr int64_t SEG = (int64_t)MIK_BLOCK * W * L;
+    __shared__ T lds16[16];
+    __shared__ T lds4[4];
+    const T tot = block_level2_256(part, m, lds16);
+    pro(tot, op, blockIdx.x == 0 && threadIdx.x == 0);
+    for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+        const int64_t base = s * SEG + (int64_t)W * threadIdx.x;
+        T acc = T(0);
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int64_t i = base + (int64_t)l * MIK_BLOCK * W;
+            if (VEC && i + W <= n) {
+                op.apply_vec(i, acc);
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; ++e)
+                    if (i + e < n) op.apply(i + e, acc);
+            }
+        }
+        if (Op::REDUCE) {
+            const T t2 = block_tree_256(acc, lds4);
+            if (threadIdx.x == 0) seg_out[s] = t2;
+        }
+    }
+}
+
+template <typename T, typename Op, typename Pro>
+static inline int launch_map_with(mik_ctx *ctx, int64_t n, Op op, Pro pro, bool vec, const T *part, int m, T *seg_out)
+{
+    const int64_t nseg = mik_nseg<T>(n);
+    if (nseg == 0) return MIK_OK;
+    const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
+    if (vec) hipLaunchKernelGGL((k_map_with<T, true, Op, Pro>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, pro, part, m, seg_out);
+    else hipLaunchKernelGGL((k_map_with<T, false, Op, Pro>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, pro, part, m, seg_out);
+    MIK_LAUNCH_CHECK(ctx);
+    return MIK_OK;
+}
+
 template <typename T> __device__ __forceinline__ typename VT<T>::vec vload(const T *p)
 {
     return *reinterpret_cast<const typename VT<T>::vec *>(p);

@@ -17,6 +17,8 @@
 #   bicgstabl!(x, A, b, l)   src/bicgstabl.jl:181 calls bicgstabl_iterator!(x, A, b, l; ...) at :197 -> HipBiCGStabIterable
 #   minres!(x, A, b)         src/minres.jl:197 calls minres_iterable!(x, A, b; ...) at :208 -> HipMINRESIterable
 #       (one C call per iteration each: mik_bicgstab_step, mik_minres_step)
+#   idrs!(x, A, b)           src/idrs.jl:49 -> idrs_method! (:150) calls idrs_iterable!(log, X, A, C, s, Pl, ...) at :156 -> HipIDRSIterable
+#       (one C call per step: mik_idrs_step)
 #   Generic code paths (any other solver of the package) see HipVector/HipCSR through
 #   mul!, dot, norm, axpy!, rmul!, ldiv!, copyto!, fill!, similar, zero and the broadcast style below (the four
 #   vector-update shapes of src/cg.jl), so the unmodified iterate(::CGIterable) runs on device vectors as well.
@@ -604,6 +606,85 @@ function Base.iterate(m::HipMINRESIterable{T}, iteration::Int = IterativeSolvers
     m.resnorm = res[]                                                        # :154
     m.mv_products += 1
     m.resnorm, iteration + 1
+end
+
+# ---- IDRSIterable -------------------------------------------------------------------------------
+# idrs!(x, A, b; ...) (src/idrs.jl:49-64) calls idrs_method! (:150-162), which calls idrs_iterable!(log, X, A, C, s, Pl, abstol, reltol,
+# maxiter; smoothing, verbose) at :156, reduces over it and returns `iterable.X`.  The reference's IDRSIterable keeps P, U, G as Vectors of
+# host vectors and its broadcasts would run statement by statement; the device path returns its own iterable with the fields the driver
+# reads (`X`, `normR`) and ONE C call per step (include/mik.h, mik_idrs_step): M, f and omega live in the handle.  `P` (a device n x s
+# block, leading dimension cld(n, 64) * 64) replaces rand! (:136) when reproducibility is wanted.
+mutable struct HipIDRSIterable{T, Tx<:HipVector{T}}
+    handle::Ptr{Cvoid}
+    A::HipCSR{T}
+    s::Int
+    X::Tx
+    R::Tx
+    X_s::Union{Tx, Nothing}
+    R_s::Union{Tx, Nothing}
+    P::Tx                  # n x s, column-major, leading dimension ld
+    U::Tx
+    G::Tx
+    ld::Int
+    maxiter::Int
+    smoothing::Bool
+    verbose::Bool
+    tol::T
+    normR::T
+    log
+    Pl
+end
+
+function IterativeSolvers.idrs_iterable!(log, X::HipVector{T}, A::HipCSR{T}, C::HipVector{T}, s::Number, Pl, abstol::Real, reltol::Real,
+        maxiter::Number; smoothing::Bool = false, verbose::Bool = false, P::Union{HipVector{T}, Nothing} = nothing) where {T}
+    (Pl isa Identity || Pl isa HipJacobi) || throw(MikError(Cint(5), "idrs_iterable!", "Pl must be Identity() or HipJacobi on the device path"))
+    1 <= s <= 32 || throw(MikError(Cint(5), "idrs_iterable!", "s must be 1 ... 32 on the device path"))
+    n = X.n
+    ld = cld(n, 64) * 64
+    R = similar(X)
+    mul!(R, A, X)                                                            # R = C - A*X  :119
+    xpby!(C, -one(T), R)
+    normR = norm(R)                                                          # :120
+    tolerance = max(T(reltol) * normR, T(abstol))                            # :121
+    X_s = smoothing ? copyto!(similar(X), X) : nothing                       # :123-126
+    R_s = smoothing ? copyto!(similar(X), R) : nothing
+    if P === nothing                                                         # :136
+        Ph = zeros(T, ld * Int(s))
+        for k in 1:Int(s)
+            Ph[(k - 1) * ld + 1:(k - 1) * ld + n] = rand(T, n)
+        end
+        P = HipVector(Ph, X.ctx)
+    end
+    U = fill!(HipVector{T}(undef, ld * Int(s), X.ctx), zero(T))              # :137
+    G = fill!(HipVector{T}(undef, ld * Int(s), X.ctx), zero(T))              # :138
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    pl = Pl isa HipJacobi ? Pl.diagonal.ptr : C_NULL
+    check(ccall((:mik_idrs_create, libmik), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+         Cdouble, Ref{Ptr{Cvoid}}),
+        X.ctx.handle, A.handle, s, X.ptr, R.ptr, P.ptr, ld, U.ptr, ld, G.ptr, ld, pl, smoothing ? X_s.ptr : C_NULL, smoothing ? R_s.ptr : C_NULL,
+        Float64(normR), h), "mik_idrs_create", X.ctx.handle)
+    it = HipIDRSIterable{T, typeof(X)}(h[], A, Int(s), X, R, X_s, R_s, P, U, G, ld, Int(maxiter), smoothing, verbose, tolerance, normR, log, Pl)
+    finalizer(i -> alive(i.X.ctx) && ccall((:mik_idrs_destroy, libmik), Cint, (Ptr{Cvoid},), i.handle), it)
+    it
+end
+
+# iterate(it, (iter, step)) -- src/idrs.jl:164-272, one call per step
+function Base.iterate(it::HipIDRSIterable{T}, (iter, step) = (1, 1)) where {T}
+    if it.normR < it.tol || iter > it.maxiter                                # :168
+        it.log !== nothing && IterativeSolvers.setconv(it.log, 0 <= it.normR < it.tol)
+        it.smoothing && copyto!(it.X, it.X_s)                                # :171-173
+        return nothing
+    end
+    res = Ref{T}()
+    check(ccall((:mik_idrs_step, libmik), Cint, (Ptr{Cvoid}, Cint, Ref{T}), it.handle, step, res), "mik_idrs_step", it.X.ctx.handle)
+    it.normR = res[]
+    nextstep = step <= it.s ? step + 1 : 1                                   # :240, :267
+    if it.log !== nothing
+        IterativeSolvers.nextiter!(it.log, mvps = 1)                         # :268-269
+        push!(it.log, :resnorm, it.normR)
+    end
+    it.normR, (iter + 1, nextstep)
 end
 
 # zerox(A, b) (src/common.jl:18-23) already works: similar(b, T, size(A, 2)) + fill! are defined above.

@@ -138,6 +138,10 @@ def _declare(L):
         f = getattr(L, f"orc_hessenberg_ldiv_{suf}")
         f.argtypes = [fp, C.c_int64, C.c_int, fp]
         f.restype = None
+        f = getattr(L, f"orc_idrs_{suf}")
+        f.argtypes = [C.c_int64, _i64p, _i64p, fp, C.c_int, fp, fp, fp, fp, C.c_int, C.c_double, C.c_double, C.c_int64, C.c_int,
+                      C.c_int, _i32p, _f64p, _i64p, _i64p, _i32p, _f64p, _f64p]
+        f.restype = None
     L.orc_laplace_nnz.argtypes = [C.c_int64, C.c_int]
     L.orc_laplace_nnz.restype = C.c_int64
     L.orc_laplace_csc.argtypes = [C.c_int64, C.c_int, C.c_int, _i64p, _i64p, _f64p]
@@ -474,6 +478,22 @@ def minres(A: CSC, b, x0=None, *, skew_hermitian=False, abstol=0.0, reltol=None,
           int(skew_hermitian), float(abstol), float(reltol), maxiter, int(x0 is None), _mode(mode), _p(shp, C.c_int),
           _p(res, C.c_double), C.byref(iters), C.byref(mvps), C.byref(conv), C.byref(res0), C.byref(tol))
     return _run_simple("orc_minres", A, b, x0, maxiter, call)
+
+
+def idrs(A: CSC, b, x0=None, *, P, s=8, pl_diag=None, abstol=0.0, reltol=None, maxiter=None, smoothing=False, mode="seq", shape=(1, 1)):
+    """``idrs!(x, A, b; s, Pl, smoothing, log=true)`` / ``idrs(A, b)`` when ``x0 is None`` -- src/idrs.jl:49-64,10.  ``P`` (n x s, any layout)
+    replaces the reference's ``rand!`` shadow vectors (src/idrs.jl:136); ``pl_diag`` = the diagonal of a Jacobi ``Pl``."""
+    dtype = A.nzval.dtype
+    reltol = _eps_sqrt(dtype) if reltol is None else reltol
+    shp = np.asarray(shape, np.int32)
+    Pm = np.asfortranarray(np.asarray(P, dtype).reshape(A.n, int(s)))
+    pd = None if pl_diag is None else np.ascontiguousarray(pl_diag, dtype)
+
+    def call(f, ct, b, x, maxiter, res, iters, mvps, conv, res0, tol):
+        f(A.n, _p(A.colptr, C.c_int64), _p(A.rowval, C.c_int64), _p(A.nzval, ct), A.index_base, _p(b, ct), _p(x, ct), _p(Pm, ct), _p(pd, ct),
+          int(s), float(abstol), float(reltol), maxiter, int(bool(smoothing)), _mode(mode), _p(shp, C.c_int),
+          _p(res, C.c_double), C.byref(iters), C.byref(mvps), C.byref(conv), C.byref(res0), C.byref(tol))
+    return _run_simple("orc_idrs", A, b, x0, maxiter, call)
 
 
 _omp = None
