@@ -332,10 +332,22 @@ class HipCSR:
         return self
 
     @staticmethod
-    def from_scipy(m, ctx=None) -> "HipCSR":
+    def from_scipy(m, ctx=None, adjoint=False) -> "HipCSR":
         m = m.tocsc()
         m.sort_indices()
+        if adjoint:
+            return HipCSR.with_adjoint(m.shape[0], m.shape[1], m.indptr, m.indices, m.data, index_base=0, ctx=ctx)
         return HipCSR(m.shape[0], m.shape[1], m.indptr, m.indices, m.data, index_base=0, is_csc=True, ctx=ctx)
+
+    @staticmethod
+    def with_adjoint(n_rows, n_cols, colptr, rowval, nzval, *, index_base=1, ctx=None) -> "HipCSR":
+        """The operator of a ``SparseMatrixCSC`` together with its adjoint (``adjoint(A)`` below; real element types): the SAME three arrays read
+        as a CSR matrix are A' (n_cols x n_rows) -- row j of A' is column j of A, entries in storage order, which is the order
+        ``mul!(y, adjoint(A), x)`` of SparseArrays sums them in.  Two device operators; no transpose is ever formed for the adjoint."""
+        A = HipCSR(n_rows, n_cols, colptr, rowval, nzval, index_base=index_base, is_csc=True, ctx=ctx)
+        A.adj = HipCSR(n_cols, n_rows, colptr, rowval, nzval, index_base=index_base, is_csc=False, ctx=A.ctx)
+        A.adj.adj = A
+        return A
 
     def compact(self) -> bool:
         """Release the CSR arrays of an operator that runs on one of the sliced layouts (``mik_csr_compact``); False (nothing
@@ -1697,3 +1709,314 @@ def idrs_(x, A, b, *, s=8, Pl=None, abstol=0.0, reltol=None, maxiter=None, log=F
 def idrs(A, b, **kwargs):
     """``idrs(A, b; s = 8, ...)`` -- src/idrs.jl:10."""
     return idrs_(zerox(A, b), A, b, **kwargs)
+
+
+# ==============================================================================================
+# lsqr.jl / lsmr.jl: rectangular operators and adjoint products
+# ==============================================================================================
+def adjoint(A):
+    """``adjoint(A)`` (src/lsqr.jl:120, src/lsmr.jl:113): the operator ``HipCSR.with_adjoint`` uploaded next to A."""
+    adj = getattr(A, "adj", None)
+    if adj is None:
+        raise MikError(5, "adjoint", "this operator was uploaded without its adjoint: create it with HipCSR.with_adjoint(...) / from_scipy(m, adjoint=True)")
+    return adj
+
+
+def _eps(dtype):
+    return np.finfo(np.dtype(dtype)).eps
+
+
+def _hypot(T, a, b):
+    """hypot in the element type through the C library (numpy's ufunc calls hypot / hypotf; math.hypot is Python's own algorithm and differs in
+    the last bit now and then)"""
+    return np.hypot(T(a), T(b))
+
+
+def lsqr_(x, A, b, *, damp=0, atol=None, btol=None, conlim=None, maxiter=None, verbose=False, log=False):
+    """``lsqr!(x, A, b; damp, atol, btol, conlim, maxiter, verbose, log)`` -- src/lsqr.jl:69-81 and lsqr_method! (:87-224), statement by
+    statement as written in v0.9.4; every vector statement is one L1 call (mul_, xpby_, scal_, axpy_, norm).  damp and the tolerances are
+    taken in the element type (what the defaults are)."""
+    T = x.dtype.type
+    m, n = A.size(1), A.size(2)
+    maxiter = max(m, n) if maxiter is None else int(maxiter)                 # :70
+    history = ConvergenceHistory(partial=not log)
+    for key in ("resnorm", "anorm", "rnorm", "cnorm"):
+        history.reserve_(key, maxiter)                                       # :76
+    if x.n != n or b.n != m:
+        raise MikError(3, "lsqr_", "x should be of length %d, b of length %d" % (n, m))          # :95-96
+    sq = T(np.sqrt(_eps(x.dtype)))
+    atol = sq if atol is None else T(atol)                                   # :88
+    btol = sq if btol is None else T(btol)
+    conlim = T(1) / sq if conlim is None else T(conlim)                      # :89
+    damp = T(damp)
+    if verbose:
+        print("=== lsqr ===\n%4s\t%7s\t\t%7s\t\t%7s\t\t%7s" % ("iter", "resnorm", "anorm", "cnorm", "rnorm"))
+    itn = istop = 0
+    ctol = T(1) / conlim if conlim > 0 else T(0)                             # :105
+    Anorm = Acond = ddnorm = res2 = xnorm = xxnorm = z = sn2 = T(0)          # :106
+    cs2 = T(-1)
+    dampsq = damp * damp                                                     # :108
+    tmpm, tmpn = b.similar(), x.similar()                                    # :109-110
+    history["atol"], history["btol"], history["ctol"] = atol, btol, ctol
+    u = b.similar()
+    mul_(u, A, x)
+    u.xpby_(b, T(-1))                                                        # u = b - A*x  :116
+    v = x.similar().copyto_(x)                                               # :117
+    beta = norm(u)                                                           # :118
+    alpha = T(0)
+    At = adjoint(A)                                                          # :120
+    if beta > 0:
+        history.mtvps = 1
+        u.scal_(T(1) / beta)
+        mul_(v, At, u)
+        alpha = norm(v)
+    if alpha > 0:
+        v.scal_(T(1) / alpha)
+    w = x.similar().copyto_(v)                                               # :130
+    wrho = x.similar()
+    Arnorm = alpha * beta                                                    # :133
+    if Arnorm == 0:
+        return (x, history) if log else x                                    # :134-136
+    rhobar = alpha
+    phibar = bnorm = rnorm = beta                                            # :138-139
+    while itn < maxiter and not history.isconverged:                         # :141
+        history.nextiter_(mvps=1)
+        itn += 1
+        mul_(tmpm, A, v)                                                     # :150
+        u.xpby_(tmpm, -alpha)                                                # u .= -alpha .* u .+ tmpm
+        beta = norm(u)
+        if beta > 0:
+            history.mtvps += 1
+            u.scal_(T(1) / beta)
+            Anorm = np.sqrt(Anorm * Anorm + alpha * alpha + beta * beta + dampsq)       # :156
+            mul_(tmpn, At, u)
+            v.xpby_(tmpn, -beta)                                             # v .= -beta .* v .+ tmpn
+            alpha = norm(v)
+            if alpha > 0:
+                v.scal_(T(1) / alpha)
+        rhobar1 = np.sqrt(rhobar * rhobar + dampsq)                          # :168-172
+        cs1 = rhobar / rhobar1
+        sn1 = damp / rhobar1
+        psi = sn1 * phibar
+        phibar = cs1 * phibar
+        rho = np.sqrt(rhobar1 * rhobar1 + beta * beta)                       # :176-183
+        cs = rhobar1 / rho
+        sn = beta / rho
+        theta = sn * alpha
+        rhobar = -cs * alpha
+        phi = cs * phibar
+        phibar = sn * phibar
+        tau = sn * phi
+        t1 = phi / rho                                                       # :186-187
+        t2 = -theta / rho
+        x.axpy_(t1, w)                                                       # x .+= t1*w
+        w.xpby_(v, t2)                                                       # w = t2 .* w .+ v
+        wrho.copyto_(w).scal_(T(1) / rho)                                    # wrho .= w .* inv(rho)
+        ddnorm = ddnorm + norm(wrho)                                         # ddnorm += norm(wrho)  (as written)
+        delta = sn2 * rho                                                    # :196-205
+        gambar = -cs2 * rho
+        rhs = phi - delta * z
+        zbar = rhs / gambar
+        xnorm = np.sqrt(xxnorm + zbar * zbar)
+        gamma = np.sqrt(gambar * gambar + theta * theta)
+        cs2 = gambar / gamma
+        sn2 = theta / gamma
+        z = rhs / gamma
+        xxnorm = xxnorm + z * z
+        Acond = Anorm * np.sqrt(ddnorm)                                      # :211-216
+        res1 = phibar * phibar
+        res2 = res2 + psi * psi
+        rnorm = np.sqrt(res1 + res2)
+        Arnorm = alpha * abs(tau)
+        r1sq = rnorm * rnorm - dampsq * xxnorm                               # :224-227
+        r1norm = np.sqrt(abs(r1sq))
+        if r1sq < 0:
+            r1norm = -r1norm
+        history.push_("resnorm", r1norm)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            test1 = rnorm / bnorm                                            # :233-238
+            test2 = Arnorm / (Anorm * rnorm)
+            test3 = T(1) / Acond
+            t1 = test1 / (T(1) + Anorm * xnorm / bnorm)
+            rtol = btol + atol * Anorm * xnorm / bnorm
+        history.push_("cnorm", test3)
+        history.push_("anorm", test2)
+        history.push_("rnorm", test1)
+        if verbose:
+            print("%3d\t%1.2e\t%1.2e\t%1.2e\t%1.2e" % (itn, r1norm, test2, test3, test1))
+        if itn >= maxiter:                                                   # :248-259
+            istop = 7
+        if T(1) + test3 <= 1:
+            istop = 6
+        if T(1) + test2 <= 1:
+            istop = 5
+        if T(1) + t1 <= 1:
+            istop = 4
+        if test3 <= ctol:
+            istop = 3
+        if test2 <= atol:
+            istop = 2
+        if test1 <= rtol:
+            istop = 1
+        history.setconv(istop > 0)
+    if log:
+        history.shrink_()
+    return (x, history) if log else x
+
+
+def lsqr(A, b, **kwargs):
+    """``lsqr(A, b; ...)`` -- src/lsqr.jl:10 (x = zerox(A, b): length size(A, 2))."""
+    return lsqr_(HipVector(A.size(2), b.dtype, b.ctx).fill_(0), A, b, **kwargs)
+
+
+def lsmr_(x, A, b, *, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=None, lam=0, verbose=False, log=False):
+    """``lsmr!(x, A, b; atol, btol, conlim, maxiter, λ, verbose, log)`` -- src/lsmr.jl:67-82 and lsmr_method! (:86-287), statement by statement
+    as written in v0.9.4.  atol / btol are Float64 like the defaults, so that with Float32 data ``rtol`` and the comparisons against them
+    promote, as does everything downstream of ``minrbar = 1e100`` (condA, test3) -- like the reference."""
+    T = x.dtype.type
+    m, n = A.size(1), A.size(2)
+    maxiter = max(m, n) if maxiter is None else int(maxiter)                 # :68
+    history = ConvergenceHistory(partial=not log)
+    for key in ("anorm", "rnorm", "cnorm"):
+        history.reserve_(key, maxiter)                                       # :72
+    if x.n != n or b.n != m:
+        raise MikError(3, "lsmr_", "x has length %d but should have length %d (b: %d, %d)" % (x.n, n, b.n, m))
+    if verbose:
+        print("=== lsmr ===\n%4s\t%7s\t\t%7s\t\t%7s" % ("iter", "anorm", "cnorm", "rnorm"))
+    u = b.similar().copyto_(b)                                               # btmp  :76-77
+    v, h, hbar = x.similar(), x.similar(), x.similar()                       # :78
+    atol, btol = np.float64(atol), np.float64(btol)
+    ctol = T(1.0 / conlim) if conlim > 0 else T(0)                           # :105
+    lam = T(lam)
+    tmp_u, tmp_v = b.similar(), x.similar()
+    mul_(tmp_u, A, x)                                                        # :108
+    u.sub_(tmp_u)                                                            # b .-= tmp_u; u = b
+    with np.errstate(divide="ignore", invalid="ignore"):
+        beta = norm(u)
+        u.scal_(T(1) / beta)                                                 # :112
+        At = adjoint(A)
+        mul_(v, At, u)                                                       # :114
+        alpha = norm(v)
+        v.scal_(T(1) / alpha)                                                # :116
+    history["atol"], history["btol"], history["ctol"] = atol, btol, ctol
+    zetabar = alpha * beta                                                   # :123-128
+    alphabar = alpha
+    rho = rhobar = cbar = T(1)
+    sbar = T(0)
+    h.copyto_(v)                                                             # :130
+    hbar.fill_(0)
+    betadd = beta                                                            # :134-140
+    betad = T(0)
+    rhodold = T(1)
+    tautildeold = thetatilde = zeta = d = T(0)
+    normA2 = alpha * alpha                                                   # :144
+    maxrbar = T(0)
+    minrbar = np.float64(1e100)                                              # :146
+    normb = beta
+    istop = 0
+    normAr = alpha * beta
+    it = 0
+    history.mvps = 1                                                         # :154-155
+    history.mtvps = 1
+    if normAr != 0:
+        while it < maxiter:
+            history.nextiter_(mvps=1)
+            it += 1
+            mul_(tmp_u, A, v)                                                # :160
+            u.xpby_(tmp_u, -alpha)                                           # u .= tmp_u .+ u .* -α
+            beta = norm(u)
+            if beta > 0:
+                history.mtvps += 1
+                u.scal_(T(1) / beta)
+                mul_(tmp_v, At, u)                                           # :166
+                v.xpby_(tmp_v, -beta)                                        # v .= tmp_v .+ v .* -β
+                alpha = norm(v)
+                with np.errstate(divide="ignore"):
+                    v.scal_(T(1) / alpha)
+            alphahat = _hypot(T, alphabar, lam)     # :175-177
+            chat = alphabar / alphahat
+            shat = lam / alphahat
+            rhoold = rho                                                     # :180-185
+            rho = _hypot(T, alphahat, beta)
+            c = alphahat / rho
+            s_ = beta / rho
+            thetanew = s_ * alpha
+            alphabar = c * alpha
+            rhobarold = rhobar                                               # :188-196
+            zetaold = zeta
+            thetabar = sbar * rho
+            rhotemp = cbar * rho
+            rhobar = _hypot(T, cbar * rho, thetanew)
+            cbar = cbar * rho / rhobar
+            sbar = thetanew / rhobar
+            zeta = cbar * zetabar
+            zetabar = -sbar * zetabar
+            hbar.xpby_(h, -thetabar * rho / (rhoold * rhobarold))            # hbar .= hbar .* (...) .+ h  :199
+            x.axpy_(zeta / (rho * rhobar), hbar)                             # :200
+            h.xpby_(v, -thetanew / rho)                                      # h .= h .* (-θnew / ρ) .+ v  :201
+            betaacute = chat * betadd                                        # :206-211
+            betacheck = -shat * betadd
+            betahat = c * betaacute
+            betadd = -s_ * betaacute
+            thetatildeold = thetatilde                                       # :214-220
+            rhotildeold = _hypot(T, rhodold, thetabar)
+            ctildeold = rhodold / rhotildeold
+            stildeold = thetabar / rhotildeold
+            thetatilde = stildeold * rhobar
+            rhodold = ctildeold * rhobar
+            betad = -stildeold * betad + ctildeold * betahat
+            tautildeold = (zetaold - thetatildeold * tautildeold) / rhotildeold          # :222-225
+            taud = (zeta - thetatilde * tautildeold) / rhodold
+            d = d + betacheck * betacheck
+            e = betad - taud
+            normr = np.sqrt(d + e * e + betadd * betadd)
+            normA2 = normA2 + beta * beta                                    # :228-230
+            normA = np.sqrt(normA2)
+            normA2 = normA2 + alpha * alpha
+            maxrbar = max(maxrbar, rhobarold)                                # :233-237
+            if it > 1:
+                minrbar = min(minrbar, np.float64(rhobarold))
+            condA = np.float64(max(maxrbar, rhotemp)) / min(minrbar, np.float64(rhotemp))
+            normAr = abs(zetabar)                                            # :241-242
+            normx = norm(x)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                test1 = normr / normb                                        # :245-247
+                test2 = normAr / (normA * normr)
+                test3 = np.float64(1.0) / condA
+                t1 = test1 / (T(1) + normA * normx / normb)                  # :252
+                rtol = btol + atol * np.float64(normA) * np.float64(normx) / np.float64(normb)   # :253
+            history.push_("cnorm", test3)
+            history.push_("anorm", test2)
+            history.push_("rnorm", test1)
+            if verbose:
+                print("%3d\t%1.2e\t%1.2e\t%1.2e" % (it, test2, test3, test1))
+            if it >= maxiter:                                                # :254-260
+                istop = 7
+                break
+            if np.float64(1.0) + test3 <= 1:
+                istop = 6
+                break
+            if T(1) + test2 <= 1:
+                istop = 5
+                break
+            if T(1) + t1 <= 1:
+                istop = 4
+                break
+            if test3 <= np.float64(ctol):
+                istop = 3
+                break
+            if np.float64(test2) <= atol:
+                istop = 2
+                break
+            if np.float64(test1) <= rtol:
+                istop = 1
+                break
+    history.setconv(istop not in (3, 6, 7))                                  # :285
+    if log:
+        history.shrink_()
+    return (x, history) if log else x
+
+
+def lsmr(A, b, **kwargs):
+    """``lsmr(A, b; ...)`` -- src/lsmr.jl:7."""
+    return lsmr_(HipVector(A.size(2), b.dtype, b.ctx).fill_(0), A, b, **kwargs)

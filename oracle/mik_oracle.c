@@ -78,6 +78,7 @@ int orc_have_blas(void) { return g_blas_dot_f64 != 0; }
 #define T double
 #define F(x) x##_f64
 #define SQRT_f64 sqrt
+#define HYPOT_f64 hypot
 #define FABS_f64 fabs
 #define POW_f64 pow
 #define LOG_f64 log
@@ -95,6 +96,7 @@ int orc_have_blas(void) { return g_blas_dot_f64 != 0; }
 #define T float
 #define F(x) x##_f32
 #define SQRT_f32 sqrtf
+#define HYPOT_f32 hypotf
 #define FABS_f32 fabsf
 #define POW_f32 powf
 #define LOG_f32 logf

@@ -138,6 +138,14 @@ def _declare(L):
         f = getattr(L, f"orc_hessenberg_ldiv_{suf}")
         f.argtypes = [fp, C.c_int64, C.c_int, fp]
         f.restype = None
+        f = getattr(L, f"orc_lsqr_{suf}")
+        f.argtypes = [C.c_int64, C.c_int64, _i64p, _i64p, fp, _i64p, _i64p, fp, C.c_int, fp, fp, C.c_double, C.c_double, C.c_double, C.c_double,
+                      C.c_int64, C.c_int, _i32p, _f64p, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p, _i32p]
+        f.restype = None
+        f = getattr(L, f"orc_lsmr_{suf}")
+        f.argtypes = [C.c_int64, C.c_int64, _i64p, _i64p, fp, _i64p, _i64p, fp, C.c_int, fp, fp, C.c_double, C.c_double, C.c_double, C.c_double,
+                      C.c_int64, C.c_int, _i32p, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p, _i32p]
+        f.restype = None
         f = getattr(L, f"orc_idrs_{suf}")
         f.argtypes = [C.c_int64, _i64p, _i64p, fp, C.c_int, fp, fp, fp, fp, C.c_int, C.c_double, C.c_double, C.c_int64, C.c_int,
                       C.c_int, _i32p, _f64p, _i64p, _i64p, _i32p, _f64p, _f64p]
@@ -494,6 +502,66 @@ def idrs(A: CSC, b, x0=None, *, P, s=8, pl_diag=None, abstol=0.0, reltol=None, m
           int(s), float(abstol), float(reltol), maxiter, int(bool(smoothing)), _mode(mode), _p(shp, C.c_int),
           _p(res, C.c_double), C.byref(iters), C.byref(mvps), C.byref(conv), C.byref(res0), C.byref(tol))
     return _run_simple("orc_idrs", A, b, x0, maxiter, call)
+
+
+def _csc_pair(A):
+    """(m, n, colptr, rowval, nzval, tcolptr, trowval, tnzval), 0-based Int64: A (a CSC of this module or any scipy sparse matrix, m x n) and
+    A' as a SparseMatrixCSC of its own -- its column scatter is `mul!(y, adjoint(A), x)` of SparseArrays bit for bit (see orc_impl.inc)."""
+    S = (A.to_scipy() if isinstance(A, CSC) else A).tocsc()
+    S.sort_indices()
+    St = S.T.tocsc()
+    St.sort_indices()
+    i64 = lambda a: np.ascontiguousarray(a, np.int64)   # noqa: E731
+    return (S.shape[0], S.shape[1], i64(S.indptr), i64(S.indices), np.ascontiguousarray(S.data), i64(St.indptr), i64(St.indices),
+            np.ascontiguousarray(St.data))
+
+
+def lsqr(A, b, x0=None, *, damp=0.0, atol=None, btol=None, conlim=None, maxiter=None, mode="seq", shape=(1, 1)):
+    """``lsqr!(x, A, b; damp, atol, btol, conlim, maxiter, log=true)`` / ``lsqr(A, b)`` when ``x0 is None`` -- src/lsqr.jl:69-81,10.  A: a CSC of
+    this module or a scipy sparse matrix (m x n).  History keys as the reference's: resnorm, anorm, rnorm, cnorm."""
+    m, n, cp, rv, nz, tcp, trv, tnz = _csc_pair(A)
+    dtype = nz.dtype
+    suf, ct = _suf(dtype)
+    eps_s = _eps_sqrt(dtype)
+    atol = eps_s if atol is None else atol                                    # :88
+    btol = eps_s if btol is None else btol
+    conlim = float(dtype.type(1) / dtype.type(eps_s)) if conlim is None else conlim   # :89
+    maxiter = max(m, n) if maxiter is None else int(maxiter)                  # :70
+    b = np.ascontiguousarray(b, dtype)
+    x = np.zeros(n, dtype) if x0 is None else np.array(x0, dtype, copy=True)
+    res, an, rn, cn = (np.zeros(max(maxiter, 1)) for _ in range(4))
+    iters, mvps, mtvps = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    conv = C.c_int(0)
+    shp = np.asarray(shape, np.int32)
+    getattr(lib(), f"orc_lsqr_{suf}")(m, n, _p(cp, C.c_int64), _p(rv, C.c_int64), _p(nz, ct), _p(tcp, C.c_int64), _p(trv, C.c_int64), _p(tnz, ct), 0,
+                                      _p(b, ct), _p(x, ct), float(damp), float(atol), float(btol), float(conlim), maxiter, _mode(mode),
+                                      _p(shp, C.c_int), _p(res, C.c_double), _p(an, C.c_double), _p(rn, C.c_double), _p(cn, C.c_double),
+                                      C.byref(iters), C.byref(mvps), C.byref(mtvps), C.byref(conv))
+    k = iters.value
+    return x, dict(iters=k, mvps=mvps.value, mtvps=mtvps.value, isconverged=bool(conv.value), resnorm=res[:k].copy(), anorm=an[:k].copy(),
+                   rnorm=rn[:k].copy(), cnorm=cn[:k].copy())
+
+
+def lsmr(A, b, x0=None, *, lam=0.0, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=None, mode="seq", shape=(1, 1)):
+    """``lsmr!(x, A, b; atol, btol, conlim, maxiter, λ, log=true)`` / ``lsmr(A, b)`` when ``x0 is None`` -- src/lsmr.jl:67-82,7.  History keys as
+    the reference's: anorm, rnorm, cnorm."""
+    m, n, cp, rv, nz, tcp, trv, tnz = _csc_pair(A)
+    dtype = nz.dtype
+    suf, ct = _suf(dtype)
+    maxiter = max(m, n) if maxiter is None else int(maxiter)                  # :68
+    b = np.ascontiguousarray(b, dtype)
+    x = np.zeros(n, dtype) if x0 is None else np.array(x0, dtype, copy=True)
+    an, rn, cn = (np.zeros(max(maxiter, 1)) for _ in range(3))
+    iters, mvps, mtvps = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    conv = C.c_int(0)
+    shp = np.asarray(shape, np.int32)
+    getattr(lib(), f"orc_lsmr_{suf}")(m, n, _p(cp, C.c_int64), _p(rv, C.c_int64), _p(nz, ct), _p(tcp, C.c_int64), _p(trv, C.c_int64), _p(tnz, ct), 0,
+                                      _p(b, ct), _p(x, ct), float(lam), float(atol), float(btol), float(conlim), maxiter, _mode(mode),
+                                      _p(shp, C.c_int), _p(an, C.c_double), _p(rn, C.c_double), _p(cn, C.c_double),
+                                      C.byref(iters), C.byref(mvps), C.byref(mtvps), C.byref(conv))
+    k = iters.value
+    return x, dict(iters=k, mvps=mvps.value, mtvps=mtvps.value, isconverged=bool(conv.value), anorm=an[:k].copy(), rnorm=rn[:k].copy(),
+                   cnorm=cn[:k].copy())
 
 
 _omp = None

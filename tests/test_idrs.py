@@ -177,6 +177,33 @@ def test_python_idrs_equals_the_c_oracle_bit_for_bit(orc, s, smoothing, precond)
     assert np.array_equal(ho["resnorm"], np.array(hp)) and np.array_equal(xo, np.array(xp))
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("s,smoothing,precond,start", [(4, False, False, False), (3, True, False, True), (8, False, True, True), (1, True, True, False)])
+def test_python_mirror_equals_the_c_oracle_on_a_host_double(pkg, orc, monkeypatch, dtype, s, smoothing, precond, start):
+    """IDRSIterable (fused=False: the statement-by-statement form the device path also carries) with every vector statement evaluated by the
+    oracle's SEQ primitives (tests/host_double.py): history, counters and solution equal the C restatement bit for bit, fp64 and fp32."""
+    from importlib import import_module
+    from host_double import FakeOperator, FakeVector, patch
+    api = import_module(pkg.__name__ + ".api")
+    patch(monkeypatch, api, orc)
+    rng = np.random.default_rng(31 + s)
+    n = 30
+    S = sprand_plus(rng, n, 0.3, 5, dtype)
+    b, P = rng.random(n).astype(dtype), rng.random((n, s)).astype(dtype)
+    x0 = rng.random(n).astype(dtype) if start else np.zeros(n, dtype)
+    d = S.diagonal().astype(dtype) if precond else None
+
+    class Diag:
+        def ldiv_(self, v):
+            v.a[:] = v.a / d
+            return v
+    xo, ho = orc.idrs(orc.CSC.from_scipy(S), b, x0 if start else None, P=P, s=s, pl_diag=d, maxiter=60, smoothing=smoothing)
+    x, ch = api.idrs_(FakeVector(x0.copy()), FakeOperator(orc, S), FakeVector(b), s=s, Pl=Diag() if precond else None, maxiter=60, log=True,
+                      smoothing=smoothing, P=P, fused=False)
+    assert ch.iters == ho["iters"] >= min(s + 2, 8) and ch.mvps == ho["mvps"] and ch.isconverged == ho["isconverged"]
+    assert np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
+
+
 # ---- device ------------------------------------------------------------------------------------------
 def _system(pkg, orc, name, dtype):
     import scipy.sparse as sp
