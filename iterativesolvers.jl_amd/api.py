@@ -2020,3 +2020,147 @@ def lsmr_(x, A, b, *, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=None, lam=0, ver
 def lsmr(A, b, **kwargs):
     """``lsmr(A, b; ...)`` -- src/lsmr.jl:7."""
     return lsmr_(HipVector(A.size(2), b.dtype, b.ctx).fill_(0), A, b, **kwargs)
+
+
+# ==============================================================================================
+# qmr.jl
+# ==============================================================================================
+class LanczosDecomp:
+    """``LanczosDecomp`` -- src/qmr.jl:5-58: the two-sided Lanczos process on A and adjoint(A); real element types."""
+
+    def __init__(self, x, A, b, *, initially_zero=False):
+        T = x.dtype.type
+        self.A, self.At = A, adjoint(A)                                      # :51
+        self.v_prev, self.v_curr, self.v_next = x.zero(), x.similar().copyto_(b), x.similar()        # :27-29
+        if not initially_zero:
+            mul_(self.v_next, A, x)                                          # :33
+            self.v_curr.axpy_(T(-1), self.v_next)                            # :34
+        self.resnorm = norm(self.v_curr)                                     # :36
+        with np.errstate(divide="ignore"):
+            self.v_curr.scal_(T(1) / self.resnorm)                           # :37
+        self.w_prev, self.w_curr, self.w_next = x.zero(), x.similar().copyto_(self.v_curr), x.similar()   # :39-41
+        self.alpha = self.beta_prev = self.beta_curr = self.delta = T(0)     # :43-46
+
+    def iterate(self, iteration=1):
+        """``iterate(l::LanczosDecomp, iteration)`` -- src/qmr.jl:62-101; None on a breakdown (delta == 0), vectors unrotated."""
+        T = self.v_curr.dtype.type
+        mul_(self.v_next, self.A, self.v_curr)                               # :67
+        self.alpha = dot(self.v_next, self.w_curr)                           # :69
+        self.v_next.axpy_(-self.alpha, self.v_curr)                          # :70
+        if iteration > 1:
+            self.v_next.axpy_(-self.beta_curr, self.v_prev)                  # :72
+        mul_(self.w_next, self.At, self.w_curr)                              # :75
+        self.w_next.axpy_(-self.alpha, self.w_curr)                          # :76
+        if iteration > 1:
+            self.w_next.axpy_(-self.delta, self.w_prev)                      # :78
+        vw = dot(self.v_next, self.w_next)                                   # :81
+        self.delta = np.sqrt(abs(vw))                                        # :82
+        if self.delta == 0:
+            return None                                                      # :83-85
+        self.beta_prev = self.beta_curr                                      # :87-88
+        self.beta_curr = vw / self.delta
+        self.v_next.scal_(T(1) / self.delta)                                 # :90
+        self.w_next.scal_(T(1) / self.beta_curr)                             # :91
+        self.w_next, self.w_curr, self.w_prev = self.w_prev, self.w_next, self.w_curr     # :93
+        self.v_next, self.v_curr, self.v_prev = self.v_prev, self.v_next, self.v_curr     # :94
+        return None, iteration + 1
+
+
+class QMRIterable:
+    """``QMRIterable`` -- src/qmr.jl:103-121, construction per ``qmr_iterable!`` (:123-154)."""
+
+    def __init__(self, x, A, b, *, abstol, reltol, maxiter, initially_zero=False):
+        T = x.dtype.type
+        self.x = x
+        self.lanczos = LanczosDecomp(x, A, b, initially_zero=initially_zero)  # :131
+        self.resnorm = self.lanczos.resnorm
+        self.g = np.array([self.resnorm, 0], x.dtype)                        # :134
+        self.H = np.zeros(4, x.dtype)
+        self.c_prev, self.s_prev, self.c_curr, self.s_curr = T(1), T(0), T(1), T(0)       # :137-138
+        self.p_prev, self.p_curr = x.zero(), x.zero()                        # :140-141
+        self.tol = max(T(reltol) * self.lanczos.resnorm, T(abstol))          # :143
+        self.maxiter = int(maxiter)
+
+    def converged(self):
+        return self.resnorm <= self.tol                                      # :156
+
+    def start(self):
+        return 1
+
+    def done(self, iteration):
+        return iteration > self.maxiter or self.converged()                  # :158
+
+    def iterate(self, iteration=None):
+        """``iterate(q::QMRIterable, iteration)`` -- src/qmr.jl:160-207 (the Lanczos step's return value is ignored, :165, as written)."""
+        iteration = 1 if iteration is None else iteration
+        if self.done(iteration):
+            return None
+        T, H, g, lz = self.x.dtype.type, self.H, self.g, self.lanczos
+        lz.iterate(iteration)                                                # :165
+        H[1] = lz.beta_prev                                                  # :167-169
+        H[2] = lz.alpha
+        H[3] = lz.delta
+        if iteration > 2:                                                    # :171-174
+            H[0] = self.s_prev * H[1]
+            H[1] = self.c_prev * H[1]
+        if iteration > 1:                                                    # :176-180
+            tmp = -self.s_curr * H[1] + self.c_curr * H[2]
+            H[1] = self.c_curr * H[1] + self.s_curr * H[2]
+            H[2] = tmp
+        c, s, H[2] = givens_algorithm(H[2], H[3], self.x.dtype)              # :183
+        g[1] = -s * g[0]                                                     # :185-186
+        g[0] = c * g[0]
+        lz.v_next.copyto_(lz.v_prev)                                         # we need v_m, not v_m+1  :188
+        if iteration > 1:
+            lz.v_next.axpy_(-H[1], self.p_curr)                              # :189
+        if iteration > 2:
+            lz.v_next.axpy_(-H[0], self.p_prev)                              # :190
+        with np.errstate(divide="ignore"):
+            lz.v_next.scal_(T(1) / H[2])                                     # :191
+        self.x.axpy_(g[0], lz.v_next)                                        # :193
+        self.c_prev, self.s_prev, self.c_curr, self.s_curr = self.c_curr, self.s_curr, c, s           # :195
+        self.p_prev.copyto_(self.p_curr)                                     # :196-197
+        self.p_curr.copyto_(lz.v_next)
+        g[0] = g[1]                                                          # :198
+        self.resnorm = abs(g[1])                                             # :200
+        return self.resnorm, iteration + 1
+
+    def __iter__(self):
+        iteration = 1
+        while (nxt := self.iterate(iteration)) is not None:
+            resnorm, iteration = nxt
+            yield resnorm
+
+
+def qmr_iterable_(x, A, b, *, abstol=0.0, reltol=None, maxiter=None, initially_zero=False, lookahead=False):
+    """``qmr_iterable!`` -- src/qmr.jl:123-154."""
+    return QMRIterable(x, A, b, abstol=abstol, reltol=_default_reltol(b) if reltol is None else reltol,
+                       maxiter=A.size(2) if maxiter is None else maxiter, initially_zero=initially_zero)
+
+
+def qmr_(x, A, b, *, abstol=0.0, reltol=None, maxiter=None, lookahead=False, log=False, initially_zero=False, verbose=False):
+    """``qmr!(x, A, b; ...)`` -- src/qmr.jl:256-297."""
+    reltol = _default_reltol(b) if reltol is None else reltol
+    maxiter = A.size(2) if maxiter is None else maxiter
+    history = ConvergenceHistory(partial=not log)
+    history["abstol"], history["reltol"] = abstol, reltol
+    if log:
+        history.reserve_("resnorm", maxiter)
+    it = qmr_iterable_(x, A, b, abstol=abstol, reltol=reltol, maxiter=maxiter, initially_zero=initially_zero)
+    if verbose:
+        print("=== qmr ===\n%4s\t%7s" % ("iter", "resnorm"))
+    for iteration, residual in enumerate(it, start=1):
+        if log:
+            history.nextiter_()                                              # :283
+            history.push_("resnorm", residual)
+        if verbose:
+            print("%3d\t%1.2e" % (iteration, residual))
+    if log:
+        history.setconv(it.converged())
+        history.shrink_()
+    return (x, history) if log else x
+
+
+def qmr(A, b, **kwargs):
+    """``qmr(A, b; ...)`` -- src/qmr.jl:210."""
+    return qmr_(zerox(A, b), A, b, initially_zero=True, **kwargs)

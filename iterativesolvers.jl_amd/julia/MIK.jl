@@ -17,6 +17,8 @@
 #   bicgstabl!(x, A, b, l)   src/bicgstabl.jl:181 calls bicgstabl_iterator!(x, A, b, l; ...) at :197 -> HipBiCGStabIterable
 #   minres!(x, A, b)         src/minres.jl:197 calls minres_iterable!(x, A, b; ...) at :208 -> HipMINRESIterable
 #       (one C call per iteration each: mik_bicgstab_step, mik_minres_step)
+#   lsqr! / lsmr! / qmr!     run UNMODIFIED on HipVector / HipCSR: adjoint(A) is the operator uploaded by MIK.with_adjoint (the CSC arrays read
+#       as CSR), their vector statements lower through the broadcast style and axpy! / rmul! / dot / norm below (one L1 call per statement)
 #   idrs!(x, A, b)           src/idrs.jl:49 -> idrs_method! (:150) calls idrs_iterable!(log, X, A, C, s, Pl, ...) at :156 -> HipIDRSIterable
 #       (one C call per step: mik_idrs_step)
 #   Generic code paths (any other solver of the package) see HipVector/HipCSR through
@@ -157,6 +159,8 @@ end
 #     x .+= alpha .* u         (:58, :93)   -> mik_axpy(alpha)
 #     r .-= alpha .* c         (:59, :94)   -> mik_axpy(-alpha)        [same rounded product, then a rounded subtract]
 #     r .-= c                  (:138)       -> mik_sub
+# and the scaled-sum shapes of src/lsqr.jl / src/lsmr.jl (`dest .= a .* v .+ w`, `dest .= v .+ w .* a`, `dest .= v .* a`, scale on either side)
+#                                              -> mik_copy (when dest is not the scaled vector) + mik_xpby / mik_scal
 # plus  x .= value (fill!) and  y .= x (copyto!).  Anything else throws -- by design: a shape that is not listed here
 # would otherwise run as n scalar device-to-host copies.
 struct HipStyle <: Base.Broadcast.AbstractArrayStyle{1} end
@@ -166,17 +170,43 @@ Base.BroadcastStyle(::Type{<:HipVector}) = HipStyle()
 const Bc = Base.Broadcast.Broadcasted
 
 is_scaled(b) = b isa Bc && b.f === (*) && length(b.args) == 2 && b.args[1] isa Number && b.args[2] isa HipVector
+# (scale, vector) of a term `v`, `a .* v` or `v .* a` (scale === nothing: unscaled); nothing for anything else.  The second form is how
+# src/lsqr.jl:151,159 and src/lsmr.jl:161,167,199,201 write their updates; a rounded product is commutative, so both lower to the same call.
+term(t::HipVector) = (nothing, t)
+function term(t)
+    (t isa Bc && t.f === (*) && length(t.args) == 2) || return nothing
+    p, q = t.args
+    p isa Number && q isa HipVector && return (p, q)
+    q isa Number && p isa HipVector && return (q, p)
+    nothing
+end
 function Base.copyto!(dest::HipVector{T}, bc::Bc{HipStyle}) where {T}
     f, a = bc.f, bc.args
     if f === identity && length(a) == 1
         return a[1] isa Number ? fill!(dest, a[1]) : copyto!(dest, a[1]::HipVector{T})
-    elseif f === (+) && length(a) == 2 && is_scaled(a[2])
+    elseif f === (+) && length(a) == 2 && is_scaled(a[2]) && (a[1] === dest || (a[2].args[2] === dest && a[1] isa HipVector))
         s, v = a[2].args
         a[1] === dest && return LinearAlgebra.axpy!(s, v, dest)                    # x .+= alpha .* u
-        v === dest && a[1] isa HipVector && return xpby!(a[1], s, dest)              # u .= r .+ beta .* u
+        return xpby!(a[1], s, dest)                                                  # u .= r .+ beta .* u
     elseif f === (-) && length(a) == 2 && a[1] === dest
         is_scaled(a[2]) && return LinearAlgebra.axpy!(-a[2].args[1], a[2].args[2], dest)   # r .-= alpha .* c
         a[2] isa HipVector && return sub!(a[2], dest)                                # r .-= c
+    elseif f === (+) && length(a) == 2 && term(a[1]) !== nothing && term(a[2]) !== nothing
+        (s1, v1), (s2, v2) = term(a[1]), term(a[2])
+        if s1 !== nothing && s2 === nothing                                          # dest .= s1 .* v1 .+ v2
+            v2 === dest && v1 !== dest && return LinearAlgebra.axpy!(s1, v1, dest)
+            v1 === dest || copyto!(dest, v1)                                         #   (u .= -alpha .* u .+ tmpm; w = t2 .* w .+ v; hbar .= hbar .* c .+ h)
+            return xpby!(v2, s1, dest)
+        elseif s1 === nothing && s2 !== nothing                                      # dest .= v1 .+ s2 .* v2   (u .= tmp_u .+ u .* -α)
+            v2 === dest || (v1 === dest ? (return LinearAlgebra.axpy!(s2, v2, dest)) : copyto!(dest, v2))
+            return xpby!(v1, s2, dest)
+        elseif s1 === nothing && s2 === nothing && v1 === dest                       # x .+= (t1 * w)  with the product formed first (src/lsqr.jl:189)
+            return LinearAlgebra.axpy!(one(T), v2, dest)
+        end
+    elseif f === (*) && length(a) == 2 && term(bc) !== nothing                       # u .*= inv(beta); wrho .= w .* inv(rho)
+        s1, v1 = term(bc)
+        v1 === dest || copyto!(dest, v1)
+        return LinearAlgebra.rmul!(dest, s1)
     end
     error("broadcast shape not lowered for HipVector (MIK.jl lists the supported ones); expression: ", f, " over ", map(typeof, a))
 end
@@ -226,6 +256,29 @@ function HipCSR(::Type{T}, m::Integer, n::Integer, nz::Integer, colptr::Ptr{Int6
     finalizer(o -> alive(o.ctx) && ccall((:mik_csr_destroy, libmik), Cint, (Ptr{Cvoid},), o.handle), op)
     op
 end
+# adjoint(A) for lsqr! / lsmr! / qmr! (src/lsqr.jl:120, src/lsmr.jl:113, src/qmr.jl:51): the SAME colptr / rowval / nzval read as a CSR matrix
+# are A' (row j of A' = column j of A, entries in storage order = the order mul!(y, adjoint(A), x) of SparseArrays sums them in), so the
+# adjoint is a second upload with is_csc = 0 -- no transpose is formed for it.  `with_adjoint(A)` returns the operator; `adjoint(op)` / `op'`
+# its partner.  (Real element types.)
+const ADJOINTS = IdDict{Any, Any}()
+function with_adjoint(A::SparseMatrixCSC{T, Int64}, ctx::Context = context()) where {T<:MikFloat}
+    op = HipCSR(A, ctx)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve A check(ccall((:mik_csr_create, libmik), Cint,
+        (Ptr{Cvoid}, Cint, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}, Cint, Cint, Ref{Ptr{Cvoid}}),
+        ctx.handle, dtype_code(T), size(A, 2), size(A, 1), nnz(A), pointer(A.colptr), pointer(A.rowval), pointer(A.nzval), 1, 0, h),
+        "mik_csr_create", ctx.handle)
+    adj = HipCSR{T}(h[], size(A, 2), size(A, 1), ctx)
+    finalizer(o -> alive(o.ctx) && ccall((:mik_csr_destroy, libmik), Cint, (Ptr{Cvoid},), o.handle), adj)
+    ADJOINTS[op] = adj; ADJOINTS[adj] = op
+    op
+end
+function LinearAlgebra.adjoint(A::HipCSR)
+    haskey(ADJOINTS, A) || throw(MikError(Cint(5), "adjoint", "this operator was uploaded without its adjoint: use MIK.with_adjoint(A)"))
+    ADJOINTS[A]
+end
+Base.:*(a::Number, x::HipVector{T}) where {T} = LinearAlgebra.rmul!(copyto!(similar(x), x), T(a))       # t1*w (src/lsqr.jl:189)
+
 "Release the CSR arrays of an operator that runs on one of the sliced layouts (mik_csr_compact); false if it needs them."
 function compact!(A::HipCSR)
     rc = ccall((:mik_csr_compact, libmik), Cint, (Ptr{Cvoid},), A.handle)

@@ -146,6 +146,10 @@ def _declare(L):
         f.argtypes = [C.c_int64, C.c_int64, _i64p, _i64p, fp, _i64p, _i64p, fp, C.c_int, fp, fp, C.c_double, C.c_double, C.c_double, C.c_double,
                       C.c_int64, C.c_int, _i32p, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p, _i32p]
         f.restype = None
+        f = getattr(L, f"orc_qmr_{suf}")
+        f.argtypes = [C.c_int64, _i64p, _i64p, fp, _i64p, _i64p, fp, C.c_int, fp, fp, C.c_double, C.c_double, C.c_int64, C.c_int, C.c_int, _i32p,
+                      _f64p, _i64p, _i32p, _f64p, _f64p]
+        f.restype = None
         f = getattr(L, f"orc_idrs_{suf}")
         f.argtypes = [C.c_int64, _i64p, _i64p, fp, C.c_int, fp, fp, fp, fp, C.c_int, C.c_double, C.c_double, C.c_int64, C.c_int,
                       C.c_int, _i32p, _f64p, _i64p, _i64p, _i32p, _f64p, _f64p]
@@ -562,6 +566,27 @@ def lsmr(A, b, x0=None, *, lam=0.0, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=No
     k = iters.value
     return x, dict(iters=k, mvps=mvps.value, mtvps=mtvps.value, isconverged=bool(conv.value), anorm=an[:k].copy(), rnorm=rn[:k].copy(),
                    cnorm=cn[:k].copy())
+
+
+def qmr(A, b, x0=None, *, abstol=0.0, reltol=None, maxiter=None, mode="seq", shape=(1, 1)):
+    """``qmr!(x, A, b; abstol, reltol, maxiter, log=true)`` / ``qmr(A, b)`` (initially_zero) when ``x0 is None`` -- src/qmr.jl:256-297,210."""
+    m, n, cp, rv, nz, tcp, trv, tnz = _csc_pair(A)
+    dtype = nz.dtype
+    suf, ct = _suf(dtype)
+    reltol = _eps_sqrt(dtype) if reltol is None else reltol
+    maxiter = n if maxiter is None else int(maxiter)
+    b = np.ascontiguousarray(b, dtype)
+    x = np.zeros(n, dtype) if x0 is None else np.array(x0, dtype, copy=True)
+    res = np.zeros(max(maxiter, 1))
+    iters = C.c_int64(0)
+    conv = C.c_int(0)
+    res0, tol = C.c_double(0), C.c_double(0)
+    shp = np.asarray(shape, np.int32)
+    getattr(lib(), f"orc_qmr_{suf}")(n, _p(cp, C.c_int64), _p(rv, C.c_int64), _p(nz, ct), _p(tcp, C.c_int64), _p(trv, C.c_int64), _p(tnz, ct), 0,
+                                     _p(b, ct), _p(x, ct), float(abstol), float(reltol), maxiter, int(x0 is None), _mode(mode), _p(shp, C.c_int),
+                                     _p(res, C.c_double), C.byref(iters), C.byref(conv), C.byref(res0), C.byref(tol))
+    k = iters.value
+    return x, dict(iters=k, mvps=0, isconverged=bool(conv.value), resnorm=res[:k].copy(), res0=res0.value, tol=tol.value)
 
 
 _omp = None
