@@ -2164,3 +2164,84 @@ def qmr_(x, A, b, *, abstol=0.0, reltol=None, maxiter=None, lookahead=False, log
 def qmr(A, b, **kwargs):
     """``qmr(A, b; ...)`` -- src/qmr.jl:210."""
     return qmr_(zerox(A, b), A, b, initially_zero=True, **kwargs)
+
+
+# ==============================================================================================
+# simple.jl: power method
+# ==============================================================================================
+class PowerMethodIterable:
+    """``PowerMethodIterable`` -- src/simple.jl:5-14, construction per ``powm_iterable!`` (:36-39); real element types."""
+
+    def __init__(self, A, x, *, tol, maxiter):
+        T = x.dtype.type
+        self.A, self.x, self.tol, self.maxiter = A, x, T(tol), int(maxiter)
+        self.theta = T(0)
+        self.r, self.Ax = x.similar(), x.similar()
+        self.residual = np.finfo(x.dtype).max                                # floatmax  :38
+
+    def converged(self):
+        return self.residual <= self.tol                                     # :15
+
+    def start(self):
+        return 0
+
+    def done(self, iteration):
+        return iteration > self.maxiter or self.converged()                  # :17
+
+    def iterate(self, iteration=None):
+        """``iterate(p::PowerMethodIterable, iteration)`` -- src/simple.jl:19-32."""
+        iteration = 0 if iteration is None else iteration
+        if self.done(iteration):
+            return None
+        T = self.x.dtype.type
+        mul_(self.Ax, self.A, self.x)                                        # :22
+        self.theta = dot(self.x, self.Ax)                                    # :25
+        self.r.copyto_(self.Ax)                                              # :26
+        self.r.axpy_(-self.theta, self.x)                                    # :27
+        self.residual = norm(self.r)                                         # :28
+        self.x.copyto_(self.Ax)                                              # :31
+        with np.errstate(divide="ignore"):
+            self.x.scal_(T(1) / norm(self.x))                                # :32
+        return self.residual, iteration + 1
+
+    def __iter__(self):
+        iteration = 0
+        while (nxt := self.iterate(iteration)) is not None:
+            residual, iteration = nxt
+            yield residual
+
+
+def powm_iterable_(A, x, *, tol=None, maxiter=None):
+    """``powm_iterable!(A, x; tol, maxiter)`` -- src/simple.jl:36-39."""
+    tol = np.finfo(x.dtype).eps * A.size(2) ** 3 if tol is None else tol
+    return PowerMethodIterable(A, x, tol=tol, maxiter=A.size(1) if maxiter is None else maxiter)
+
+
+def powm_(B, x, *, tol=None, maxiter=None, shift=0, inverse=False, log=False, verbose=False):
+    """``powm!(B, x; tol, maxiter, shift, inverse, log, verbose)`` -- src/simple.jl:113-142: (λ, x[, history]).  With ``log`` the history also
+    carries the residual norm of every iterate (the reference reserves ``:resnorm`` but never pushes to it)."""
+    T = x.dtype.type
+    tol = np.finfo(x.dtype).eps * B.size(2) ** 3 if tol is None else tol     # :114
+    maxiter = B.size(1) if maxiter is None else maxiter
+    history = ConvergenceHistory(partial=not log)
+    history["tol"] = tol
+    history.reserve_("resnorm", maxiter + 1)
+    if verbose:
+        print("=== powm ===\n%4s\t%7s" % ("iter", "resnorm"))
+    it = powm_iterable_(B, x, tol=tol, maxiter=maxiter)
+    for iteration, residual in enumerate(it, start=1):
+        history.nextiter_(mvps=1)                                            # :128
+        history.push_("resnorm", residual)
+        if verbose:
+            print("%3d\t%1.2e" % (iteration, residual))
+    history.setconv(it.converged())
+    if log:
+        history.shrink_()
+    with np.errstate(divide="ignore"):
+        lam = T(shift) + (T(1) / it.theta if inverse else it.theta)          # transform_eigenvalue  :34
+    return (lam, it.x, history) if log else (lam, it.x)
+
+
+def invpowm_(B, x0, **kwargs):
+    """``invpowm!(B, x0; shift = σ, ...)`` -- src/simple.jl:185: B has the action of inv(A - σI) (any LinearOperator)."""
+    return powm_(B, x0, inverse=True, **kwargs)

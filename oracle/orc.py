@@ -150,6 +150,9 @@ def _declare(L):
         f.argtypes = [C.c_int64, _i64p, _i64p, fp, _i64p, _i64p, fp, C.c_int, fp, fp, C.c_double, C.c_double, C.c_int64, C.c_int, C.c_int, _i32p,
                       _f64p, _i64p, _i32p, _f64p, _f64p]
         f.restype = None
+        f = getattr(L, f"orc_powm_{suf}")
+        f.argtypes = [C.c_int64, _i64p, _i64p, fp, C.c_int, fp, C.c_double, C.c_int64, C.c_int, _i32p, _f64p, _i64p, _i32p, _f64p]
+        f.restype = None
         f = getattr(L, f"orc_idrs_{suf}")
         f.argtypes = [C.c_int64, _i64p, _i64p, fp, C.c_int, fp, fp, fp, fp, C.c_int, C.c_double, C.c_double, C.c_int64, C.c_int,
                       C.c_int, _i32p, _f64p, _i64p, _i64p, _i32p, _f64p, _f64p]
@@ -587,6 +590,28 @@ def qmr(A, b, x0=None, *, abstol=0.0, reltol=None, maxiter=None, mode="seq", sha
                                      _p(res, C.c_double), C.byref(iters), C.byref(conv), C.byref(res0), C.byref(tol))
     k = iters.value
     return x, dict(iters=k, mvps=0, isconverged=bool(conv.value), resnorm=res[:k].copy(), res0=res0.value, tol=tol.value)
+
+
+def powm(A: CSC, x0, *, tol=None, maxiter=None, shift=0.0, inverse=False, mode="seq", shape=(1, 1)):
+    """``powm!(B, x; tol, maxiter, shift, inverse, log=true)`` -- src/simple.jl:113-142.  Returns (λ, x, history); history["resnorm"] holds the
+    residual norm of every iterate (the reference reserves the key but never pushes to it, :120-130)."""
+    dtype = A.nzval.dtype
+    suf, ct = _suf(dtype)
+    n = A.n
+    tol = float(np.finfo(dtype).eps) * n ** 3 if tol is None else tol        # :114
+    maxiter = n if maxiter is None else int(maxiter)
+    x = np.array(x0, dtype, copy=True)
+    res = np.zeros(maxiter + 2)
+    iters = C.c_int64(0)
+    conv = C.c_int(0)
+    theta = C.c_double(0)
+    shp = np.asarray(shape, np.int32)
+    getattr(lib(), f"orc_powm_{suf}")(n, _p(A.colptr, C.c_int64), _p(A.rowval, C.c_int64), _p(A.nzval, ct), A.index_base, _p(x, ct), float(tol),
+                                      maxiter, _mode(mode), _p(shp, C.c_int), _p(res, C.c_double), C.byref(iters), C.byref(conv), C.byref(theta))
+    th = dtype.type(theta.value)
+    lam = dtype.type(shift) + (dtype.type(1) / th if inverse else th)         # transform_eigenvalue  :34
+    k = iters.value
+    return lam, x, dict(iters=k, mvps=k, isconverged=bool(conv.value), resnorm=res[:k].copy(), tol=tol)
 
 
 _omp = None

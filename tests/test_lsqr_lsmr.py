@@ -168,3 +168,26 @@ def test_python_mirrors_equal_the_c_oracle_on_a_host_double(pkg, orc, monkeypatc
     for key in ("anorm", "rnorm", "cnorm"):
         assert np.array_equal(ch[key], ho[key]), key
     assert np.array_equal(x.to_numpy(), xo)
+
+
+@pytest.mark.gpu
+def test_lsqr_lsmr_qmr_device_across_operator_layouts(pkg, orc, ctx):
+    """the three solvers with adjoint products on an operator whose default layout is NOT the CSR arrays (the 12^3 Laplacian: one mask byte per row,
+    for A and for adjoint(A) alike), then with both operators pinned to their plain CSR arrays: same bits, equal to the oracle"""
+    A = orc.laplace(12, 3)
+    b = orc.hashed_rhs(A.n)
+    S = A.to_scipy()
+    shape = ctx.reduce_shape(np.float64)
+    ref = {"lsqr": orc.lsqr(S, b, maxiter=40, mode="tree", shape=shape), "lsmr": orc.lsmr(S, b, maxiter=40, mode="tree", shape=shape),
+           "qmr": orc.qmr(S, b, maxiter=40, mode="tree", shape=shape)}
+    dA = pkg.HipCSR.with_adjoint(A.n, A.n, A.colptr, A.rowval, A.nzval)
+    assert dA.layout() != "csr-rowblock" and pkg.adjoint(dA).layout() == dA.layout()
+    for layout in ("auto", "csr"):
+        dA.set_layout(layout)
+        pkg.adjoint(dA).set_layout(layout)
+        for name, fn in (("lsqr", pkg.lsqr), ("lsmr", pkg.lsmr), ("qmr", pkg.qmr)):
+            x, ch = fn(dA, pkg.HipVector.from_numpy(b), maxiter=40, log=True)
+            xo, ho = ref[name]
+            assert ch.iters == ho["iters"] and np.array_equal(x.to_numpy(), xo), (name, layout)
+            key = "resnorm" if name != "lsmr" else "rnorm"
+            assert np.array_equal(ch[key], ho[key]), (name, layout)
