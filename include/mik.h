@@ -308,6 +308,15 @@ int mik_axpy2_nrm2(mik_ctx *ctx, int dtype, int64_t n, const void *alpha, const 
                    int hints /* 1: x, 2: c, 4: u */);
 /* c = Pl \ r (pl_diag NULL = Identity); u .= c when `first`, else u .= c .+ beta .* c   -- src/chebyshev.jl:35-45 */
 int mik_cheb_direction(mik_ctx *ctx, int dtype, int64_t n, const void *r, const void *pl_diag, const void *beta, int first, void *u);
+/* LSQR / LSMR (src/lsqr.jl, src/lsmr.jl), groups of consecutive statements as single sweeps with the same per-element operations:
+ *   mik_xpby_nrm2     y .= x .+ beta .* y; *out = norm(y)           u .= -alpha .* u .+ tmpm; beta = norm(u)  (src/lsqr.jl:151-152, :159-160;
+ *                                                                   src/lsmr.jl:161-162, :167-168)
+ *   mik_lsqr_update   x .+= t1*w; w = t2 .* w .+ v; wrho .= w .* inv_rho (never stored); *out = norm(wrho)              (src/lsqr.jl:189-192)
+ *   mik_lsmr_update   hbar .= hbar .* c1 .+ h; x .+= c2 * hbar; h .= h .* c3 .+ v; *out = norm(x)                        (src/lsmr.jl:199-201, :242)
+ * Scalars: HOST values of `dtype`. */
+int mik_xpby_nrm2(mik_ctx *ctx, int dtype, int64_t n, const void *x, const void *beta, void *y, void *out);
+int mik_lsqr_update(mik_ctx *ctx, int dtype, int64_t n, const void *t1, const void *t2, const void *inv_rho, void *x, void *w, const void *v, void *out);
+int mik_lsmr_update(mik_ctx *ctx, int dtype, int64_t n, const void *c1, const void *c2, const void *c3, void *hbar, void *h, void *x, const void *v, void *out);
 /* v_next .*= inv_h3; w_next .= v_curr .+ neg_h1 .* w_curr .+ neg_h0 .* w_prev (each term skipped when its vector
  * is NULL); w_next .*= inv_h2; x .+= rhs0 .* w_next   -- src/minres.jl:113, :136-142 */
 int mik_minres_update(mik_ctx *ctx, int dtype, int64_t n, const void *inv_h3, void *v_next, const void *v_curr, const void *neg_h1,

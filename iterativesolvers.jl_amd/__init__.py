@@ -18,4 +18,4 @@ from .api import (CGIterable, CGStateVariables, ClassicalGramSchmidt, Convergenc
                   dot, gemv_n_, gmres, gmres_, gmres_iterable_, hessenberg_ldiv_, mul_, niters, norm, nprods,
                   nrests, orthogonalize_and_normalize_, zerox, BiCGStabIterable, bicgstabl, bicgstabl_, bicgstabl_iterator_,
                   gemv_t_, lu_solve_, ChebyshevIterable, chebyshev, chebyshev_, chebyshev_iterable_, MINRESIterable, minres, minres_,
-                  minres_iterable_, IDRSIterable, idrs, idrs_, idrs_iterable_, adjoint, lsqr, lsqr_, lsmr, lsmr_, LanczosDecomp, QMRIterable, qmr, qmr_, qmr_iterable_, PowerMethodIterable, powm_, powm_iterable_, invpowm_, givens_algorithm, axpy_dot_, axpy2_nrm2_, gram_, LinearOperator)
+                  minres_iterable_, IDRSIterable, idrs, idrs_, idrs_iterable_, adjoint, lsqr, lsqr_, lsmr, lsmr_, xpby_nrm2_, LanczosDecomp, QMRIterable, qmr, qmr_, qmr_iterable_, PowerMethodIterable, powm_, powm_iterable_, invpowm_, givens_algorithm, axpy_dot_, axpy2_nrm2_, gram_, LinearOperator)

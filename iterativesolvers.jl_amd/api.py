@@ -1732,11 +1732,21 @@ def _hypot(T, a, b):
     return np.hypot(T(a), T(b))
 
 
-def lsqr_(x, A, b, *, damp=0, atol=None, btol=None, conlim=None, maxiter=None, verbose=False, log=False):
+def xpby_nrm2_(x, beta, y):
+    """``y .= x .+ beta .* y`` and ``norm(y)`` in one sweep (``mik_xpby_nrm2``): the bidiagonalisation updates of LSQR / LSMR."""
+    out = np.zeros(1, y.dtype)
+    _, pb = _scalar(y.dtype, beta)
+    check(lib().mik_xpby_nrm2(y.ctx.handle, y.code, y.n, _vp(x.ptr), pb, _vp(y.ptr), out.ctypes.data_as(_vp)), "mik_xpby_nrm2", y.ctx.handle)
+    return out[0]
+
+
+def lsqr_(x, A, b, *, damp=0, atol=None, btol=None, conlim=None, maxiter=None, verbose=False, log=False, fused=True):
     """``lsqr!(x, A, b; damp, atol, btol, conlim, maxiter, verbose, log)`` -- src/lsqr.jl:69-81 and lsqr_method! (:87-224), statement by
-    statement as written in v0.9.4; every vector statement is one L1 call (mul_, xpby_, scal_, axpy_, norm).  damp and the tolerances are
-    taken in the element type (what the defaults are)."""
+    statement as written in v0.9.4.  ``fused`` (device vectors): the two bidiagonalisation updates carry their norms (``mik_xpby_nrm2``) and the tail
+    :189-192 is one sweep (``mik_lsqr_update``: wrho is never stored) -- same per-element operations, same bits; otherwise every vector statement
+    is one L1 call (mul_, xpby_, scal_, axpy_, norm).  damp and the tolerances are taken in the element type (what the defaults are)."""
     T = x.dtype.type
+    fused = bool(fused) and isinstance(x, HipVector)
     m, n = A.size(1), A.size(2)
     maxiter = max(m, n) if maxiter is None else int(maxiter)                 # :70
     history = ConvergenceHistory(partial=not log)
@@ -1783,15 +1793,21 @@ def lsqr_(x, A, b, *, damp=0, atol=None, btol=None, conlim=None, maxiter=None, v
         history.nextiter_(mvps=1)
         itn += 1
         mul_(tmpm, A, v)                                                     # :150
-        u.xpby_(tmpm, -alpha)                                                # u .= -alpha .* u .+ tmpm
-        beta = norm(u)
+        if fused:
+            beta = xpby_nrm2_(tmpm, -alpha, u)                               # :151-152 in one sweep
+        else:
+            u.xpby_(tmpm, -alpha)                                            # u .= -alpha .* u .+ tmpm
+            beta = norm(u)
         if beta > 0:
             history.mtvps += 1
             u.scal_(T(1) / beta)
             Anorm = np.sqrt(Anorm * Anorm + alpha * alpha + beta * beta + dampsq)       # :156
             mul_(tmpn, At, u)
-            v.xpby_(tmpn, -beta)                                             # v .= -beta .* v .+ tmpn
-            alpha = norm(v)
+            if fused:
+                alpha = xpby_nrm2_(tmpn, -beta, v)                           # :159-160 in one sweep
+            else:
+                v.xpby_(tmpn, -beta)                                         # v .= -beta .* v .+ tmpn
+                alpha = norm(v)
             if alpha > 0:
                 v.scal_(T(1) / alpha)
         rhobar1 = np.sqrt(rhobar * rhobar + dampsq)                          # :168-172
@@ -1809,10 +1825,17 @@ def lsqr_(x, A, b, *, damp=0, atol=None, btol=None, conlim=None, maxiter=None, v
         tau = sn * phi
         t1 = phi / rho                                                       # :186-187
         t2 = -theta / rho
-        x.axpy_(t1, w)                                                       # x .+= t1*w
-        w.xpby_(v, t2)                                                       # w = t2 .* w .+ v
-        wrho.copyto_(w).scal_(T(1) / rho)                                    # wrho .= w .* inv(rho)
-        ddnorm = ddnorm + norm(wrho)                                         # ddnorm += norm(wrho)  (as written)
+        if fused:                                                            # :189-192 in one sweep, wrho never stored
+            outn = np.zeros(1, x.dtype)
+            sc = [_scalar(x.dtype, val) for val in (t1, t2, T(1) / rho)]
+            check(lib().mik_lsqr_update(x.ctx.handle, x.code, x.n, sc[0][1], sc[1][1], sc[2][1], _vp(x.ptr), _vp(w.ptr), _vp(v.ptr),
+                                        outn.ctypes.data_as(_vp)), "mik_lsqr_update", x.ctx.handle)
+            ddnorm = ddnorm + outn[0]
+        else:
+            x.axpy_(t1, w)                                                   # x .+= t1*w
+            w.xpby_(v, t2)                                                   # w = t2 .* w .+ v
+            wrho.copyto_(w).scal_(T(1) / rho)                                # wrho .= w .* inv(rho)
+            ddnorm = ddnorm + norm(wrho)                                     # ddnorm += norm(wrho)  (as written)
         delta = sn2 * rho                                                    # :196-205
         gambar = -cs2 * rho
         rhs = phi - delta * z
@@ -1869,11 +1892,13 @@ def lsqr(A, b, **kwargs):
     return lsqr_(HipVector(A.size(2), b.dtype, b.ctx).fill_(0), A, b, **kwargs)
 
 
-def lsmr_(x, A, b, *, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=None, lam=0, verbose=False, log=False):
+def lsmr_(x, A, b, *, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=None, lam=0, verbose=False, log=False, fused=True):
     """``lsmr!(x, A, b; atol, btol, conlim, maxiter, λ, verbose, log)`` -- src/lsmr.jl:67-82 and lsmr_method! (:86-287), statement by statement
     as written in v0.9.4.  atol / btol are Float64 like the defaults, so that with Float32 data ``rtol`` and the comparisons against them
-    promote, as does everything downstream of ``minrbar = 1e100`` (condA, test3) -- like the reference."""
+    promote, as does everything downstream of ``minrbar = 1e100`` (condA, test3) -- like the reference.  ``fused`` (device vectors): the
+    bidiagonalisation updates carry their norms (``mik_xpby_nrm2``) and :199-201 with ``norm(x)`` (:242) are one sweep (``mik_lsmr_update``)."""
     T = x.dtype.type
+    fused = bool(fused) and isinstance(x, HipVector)
     m, n = A.size(1), A.size(2)
     maxiter = max(m, n) if maxiter is None else int(maxiter)                 # :68
     history = ConvergenceHistory(partial=not log)
@@ -1923,14 +1948,20 @@ def lsmr_(x, A, b, *, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=None, lam=0, ver
             history.nextiter_(mvps=1)
             it += 1
             mul_(tmp_u, A, v)                                                # :160
-            u.xpby_(tmp_u, -alpha)                                           # u .= tmp_u .+ u .* -α
-            beta = norm(u)
+            if fused:
+                beta = xpby_nrm2_(tmp_u, -alpha, u)                          # :161-162 in one sweep
+            else:
+                u.xpby_(tmp_u, -alpha)                                       # u .= tmp_u .+ u .* -α
+                beta = norm(u)
             if beta > 0:
                 history.mtvps += 1
                 u.scal_(T(1) / beta)
                 mul_(tmp_v, At, u)                                           # :166
-                v.xpby_(tmp_v, -beta)                                        # v .= tmp_v .+ v .* -β
-                alpha = norm(v)
+                if fused:
+                    alpha = xpby_nrm2_(tmp_v, -beta, v)                      # :167-168 in one sweep
+                else:
+                    v.xpby_(tmp_v, -beta)                                    # v .= tmp_v .+ v .* -β
+                    alpha = norm(v)
                 with np.errstate(divide="ignore"):
                     v.scal_(T(1) / alpha)
             alphahat = _hypot(T, alphabar, lam)     # :175-177
@@ -1951,9 +1982,17 @@ def lsmr_(x, A, b, *, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=None, lam=0, ver
             sbar = thetanew / rhobar
             zeta = cbar * zetabar
             zetabar = -sbar * zetabar
-            hbar.xpby_(h, -thetabar * rho / (rhoold * rhobarold))            # hbar .= hbar .* (...) .+ h  :199
-            x.axpy_(zeta / (rho * rhobar), hbar)                             # :200
-            h.xpby_(v, -thetanew / rho)                                      # h .= h .* (-θnew / ρ) .+ v  :201
+            normx_fused = None
+            if fused:                                                        # :199-201 and norm(x) (:242) in one sweep
+                outn = np.zeros(1, x.dtype)
+                sc = [_scalar(x.dtype, val) for val in (-thetabar * rho / (rhoold * rhobarold), zeta / (rho * rhobar), -thetanew / rho)]
+                check(lib().mik_lsmr_update(x.ctx.handle, x.code, x.n, sc[0][1], sc[1][1], sc[2][1], _vp(hbar.ptr), _vp(h.ptr), _vp(x.ptr), _vp(v.ptr),
+                                            outn.ctypes.data_as(_vp)), "mik_lsmr_update", x.ctx.handle)
+                normx_fused = outn[0]
+            else:
+                hbar.xpby_(h, -thetabar * rho / (rhoold * rhobarold))        # hbar .= hbar .* (...) .+ h  :199
+                x.axpy_(zeta / (rho * rhobar), hbar)                         # :200
+                h.xpby_(v, -thetanew / rho)                                  # h .= h .* (-θnew / ρ) .+ v  :201
             betaacute = chat * betadd                                        # :206-211
             betacheck = -shat * betadd
             betahat = c * betaacute
@@ -1978,7 +2017,7 @@ def lsmr_(x, A, b, *, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=None, lam=0, ver
                 minrbar = min(minrbar, np.float64(rhobarold))
             condA = np.float64(max(maxrbar, rhotemp)) / min(minrbar, np.float64(rhotemp))
             normAr = abs(zetabar)                                            # :241-242
-            normx = norm(x)
+            normx = norm(x) if normx_fused is None else normx_fused
             with np.errstate(divide="ignore", invalid="ignore"):
                 test1 = normr / normb                                        # :245-247
                 test2 = normAr / (normA * normr)

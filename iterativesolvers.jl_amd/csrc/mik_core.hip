@@ -1813,6 +1813,71 @@ extern "C" int mik_axpy2_nrm2(mik_ctx *ctx, int dtype, int64_t n, const void *al
     return MIK_ERR_INVALID;
 }
 
+template <typename T> static int xpby_nrm2_impl(mik_ctx *ctx, int64_t n, const void *x, const void *beta, void *y, void *out)
+{
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(mik_nseg<T>(n), 1)));
+    OpXpbyNrm<T> op{(const T *)x, (T *)y, *(const T *)beta};
+    MIK_TRY((launch_map<T>(ctx, n, op, mik_aligned16(x) && mik_aligned16(y), (T *)ctx->partials, nullptr)));
+    T v;
+    MIK_TRY(reduce_to_host<T>(ctx, n, &v));
+    return norm_from_sumsq<T>(ctx, n, (const T *)y, v, (T *)out);           // norm(y)
+}
+
+extern "C" int mik_xpby_nrm2(mik_ctx *ctx, int dtype, int64_t n, const void *x, const void *beta, void *y, void *out)
+{
+    if (!ctx || n < 0 || !out || !beta || (n && (!x || !y))) return MIK_ERR_INVALID;
+    if (dtype == MIK_F64) return xpby_nrm2_impl<double>(ctx, n, x, beta, y, out);
+    if (dtype == MIK_F32) return xpby_nrm2_impl<float>(ctx, n, x, beta, y, out);
+    return MIK_ERR_INVALID;
+}
+
+template <typename T> static int lsqr_update_impl(mik_ctx *ctx, int64_t n, const void *t1, const void *t2, const void *inv_rho, void *x, void *w, const void *v, void *out)
+{
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(mik_nseg<T>(n), 1)));
+    OpLsqrUpdate<T> op{(T *)x, (T *)w, (const T *)v, *(const T *)t1, *(const T *)t2, *(const T *)inv_rho};
+    MIK_TRY((launch_map<T>(ctx, n, op, mik_aligned16(x) && mik_aligned16(w) && mik_aligned16(v), (T *)ctx->partials, nullptr)));
+    T s;
+    MIK_TRY(reduce_to_host<T>(ctx, n, &s));
+    if (mik_nrm_in_range(s) || n == 0) { *(T *)out = n ? (T)std::sqrt(s) : T(0); return MIK_OK; }
+    // |wrho|^2 outside the range of a plain sum of squares: wrho = w .* inv(rho) in a scratch vector, then the scaled norm (rare; allocation and all)
+    T *tmp = nullptr;
+    MIK_HIP(ctx, hipMalloc((void **)&tmp, sizeof(T) * (size_t)n));
+    int rc = MIK_OK;
+    hipError_t e = hipMemcpyAsync(tmp, w, sizeof(T) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) rc = mik_fail(ctx, MIK_ERR_HIP, "mik_lsqr_update: %s", hipGetErrorString(e));
+    if (!rc) { OpScal<T> sc{tmp, coef_val(*(const T *)inv_rho)}; rc = launch_map<T>(ctx, n, sc, mik_aligned16(tmp), (T *)nullptr, nullptr); }
+    if (!rc) rc = mik_safe_norm_slow<T>(ctx, n, tmp, (T *)out);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    return rc;
+}
+
+extern "C" int mik_lsqr_update(mik_ctx *ctx, int dtype, int64_t n, const void *t1, const void *t2, const void *inv_rho, void *x, void *w, const void *v, void *out)
+{
+    if (!ctx || n < 0 || !out || !t1 || !t2 || !inv_rho || (n && (!x || !w || !v))) return MIK_ERR_INVALID;
+    if (dtype == MIK_F64) return lsqr_update_impl<double>(ctx, n, t1, t2, inv_rho, x, w, v, out);
+    if (dtype == MIK_F32) return lsqr_update_impl<float>(ctx, n, t1, t2, inv_rho, x, w, v, out);
+    return MIK_ERR_INVALID;
+}
+
+template <typename T> static int lsmr_update_impl(mik_ctx *ctx, int64_t n, const void *c1, const void *c2, const void *c3, void *hbar, void *h, void *x, const void *v, void *out)
+{
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(mik_nseg<T>(n), 1)));
+    OpLsmrUpdate<T> op{(T *)hbar, (T *)h, (T *)x, (const T *)v, *(const T *)c1, *(const T *)c2, *(const T *)c3};
+    MIK_TRY((launch_map<T>(ctx, n, op, mik_aligned16(hbar) && mik_aligned16(h) && mik_aligned16(x) && mik_aligned16(v), (T *)ctx->partials, nullptr)));
+    T s;
+    MIK_TRY(reduce_to_host<T>(ctx, n, &s));
+    return norm_from_sumsq<T>(ctx, n, (const T *)x, s, (T *)out);           // norm(x)
+}
+
+extern "C" int mik_lsmr_update(mik_ctx *ctx, int dtype, int64_t n, const void *c1, const void *c2, const void *c3, void *hbar, void *h, void *x, const void *v, void *out)
+{
+    if (!ctx || n < 0 || !out || !c1 || !c2 || !c3 || (n && (!hbar || !h || !x || !v))) return MIK_ERR_INVALID;
+    if (dtype == MIK_F64) return lsmr_update_impl<double>(ctx, n, c1, c2, c3, hbar, h, x, v, out);
+    if (dtype == MIK_F32) return lsmr_update_impl<float>(ctx, n, c1, c2, c3, hbar, h, x, v, out);
+    return MIK_ERR_INVALID;
+}
+
 extern "C" int mik_cheb_direction(mik_ctx *ctx, int dtype, int64_t n, const void *r, const void *pl_diag, const void *beta, int first,
                                   void *u)
 {

@@ -315,6 +315,82 @@ template <typename T> struct OpXpby {
     }
 };
 
+// y .= x .+ beta .* y; partial sums of y.^2      -- the bidiagonalisation updates of LSQR / LSMR with their norms:
+//   u .= -alpha .* u .+ tmpm; norm(u) (src/lsqr.jl:151-152), v .= -beta .* v .+ tmpn; norm(v) (:159-160); src/lsmr.jl:161-162, :167-168
+template <typename T> struct OpXpbyNrm {
+    static constexpr bool REDUCE = true;
+    const T *__restrict__ x; T *__restrict__ y; T beta;
+    __device__ __forceinline__ void apply(int64_t i, T &acc) const { T t = beta * y[i]; const T v = x[i] + t; y[i] = v; T p = v * v; acc = acc + p; }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &acc) const
+    {
+        auto xv = vload_nt(x + i); auto yv = vload<T>(y + i);          // x (the product just formed) is dead afterwards
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) { T t = beta * el<T>(yv, e); el<T>(yv, e) = el<T>(xv, e) + t; }
+        vstore(y + i, yv);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) { T p = el<T>(yv, e) * el<T>(yv, e); acc = acc + p; }
+    }
+};
+
+// LSQR, the tail of an iteration in one sweep        -- src/lsqr.jl:189-192
+//   x .+= t1*w;  w = t2 .* w .+ v;  wrho .= w .* inv(rho) (not stored);  partial sums of wrho.^2
+template <typename T> struct OpLsqrUpdate {
+    static constexpr bool REDUCE = true;
+    T *__restrict__ x; T *__restrict__ w; const T *__restrict__ v; T t1, t2, inv_rho;
+    __device__ __forceinline__ void apply(int64_t i, T &acc) const
+    {
+        const T wo = w[i];
+        T a = t1 * wo; x[i] = x[i] + a;
+        T b = t2 * wo; const T wn = b + v[i]; w[i] = wn;
+        const T r = wn * inv_rho;
+        T p = r * r; acc = acc + p;
+    }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &acc) const
+    {
+        constexpr int W = VT<T>::W;
+        auto xv = vload_nt<T>(x + i); auto wv = vload<T>(w + i); auto vv = vload(v + i);
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            const T wo = el<T>(wv, e);
+            T a = t1 * wo; el<T>(xv, e) = el<T>(xv, e) + a;
+            T b = t2 * wo; el<T>(wv, e) = b + el<T>(vv, e);
+        }
+        vstore_nt(x + i, xv); vstore(w + i, wv);                         // x is touched once per iteration: streamed both ways
+#pragma unroll
+        for (int e = 0; e < W; ++e) { const T r = el<T>(wv, e) * inv_rho; T p = r * r; acc = acc + p; }
+    }
+};
+
+// LSMR, the three vector updates of an iteration in one sweep, with norm(x)        -- src/lsmr.jl:199-201, :242
+//   hbar .= hbar .* c1 .+ h;  x .+= c2 * hbar;  h .= h .* c3 .+ v;  partial sums of x.^2
+template <typename T> struct OpLsmrUpdate {
+    static constexpr bool REDUCE = true;
+    T *__restrict__ hbar; T *__restrict__ h; T *__restrict__ x; const T *__restrict__ v; T c1, c2, c3;
+    __device__ __forceinline__ void apply(int64_t i, T &acc) const
+    {
+        const T ho = h[i];
+        T a = hbar[i] * c1; const T hb = a + ho; hbar[i] = hb;
+        T b = c2 * hb; const T xn = x[i] + b; x[i] = xn;
+        T c = ho * c3; h[i] = c + v[i];
+        T p = xn * xn; acc = acc + p;
+    }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &acc) const
+    {
+        constexpr int W = VT<T>::W;
+        auto hbv = vload<T>(hbar + i); auto hv = vload<T>(h + i); auto xv = vload<T>(x + i); auto vv = vload(v + i);
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            const T ho = el<T>(hv, e);
+            T a = el<T>(hbv, e) * c1; el<T>(hbv, e) = a + ho;
+            T b = c2 * el<T>(hbv, e); el<T>(xv, e) = el<T>(xv, e) + b;
+            T c = ho * c3; el<T>(hv, e) = c + el<T>(vv, e);
+        }
+        vstore(hbar + i, hbv); vstore(h + i, hv); vstore(x + i, xv);
+#pragma unroll
+        for (int e = 0; e < W; ++e) { T p = el<T>(xv, e) * el<T>(xv, e); acc = acc + p; }
+    }
+};
+
 // The CG step with the update of x moved one sweep later (same operands, same rounding, so the same bits): the tail of
 // step k only does r .-= alpha .* c and |r|^2 (OpCgUpdateR), and x .+= alpha_k .* u_k is applied by the sweep that reads
 // u_k anyway -- u = r + beta u of step k + 1 -- saving one read of u (n s bytes, 19 us at 256^3) per iteration.  That sweep is

@@ -1,7 +1,8 @@
 """LSQR, LSMR and QMR (src/lsqr.jl, src/lsmr.jl, src/qmr.jl) per iteration on the 256^3 Laplacian, fp64, one MI355X: two SpMV per iteration (A and
-adjoint(A) -- the second operator is the SAME CSC arrays uploaded as CSR, HipCSR.with_adjoint) plus their vector statements, each ONE L1 call
-(statement by statement, several host-visible norms per iteration like the reference's loop).  `frac` = bytes the launches of an iteration move
-(both operators' stored bytes + the words per row of the unfused statements) / time / 8 TB/s.
+adjoint(A) -- the second operator is the SAME CSC arrays uploaded as CSR, HipCSR.with_adjoint) plus their vector statements: LSQR / LSMR with the
+fused sweeps (mik_xpby_nrm2, mik_lsqr_update / mik_lsmr_update) and statement by statement, QMR statement by statement (several host-visible
+norms per iteration like the reference's loop).  `frac` = bytes the launches of an iteration move (both operators' stored bytes + the words per
+row of its sweeps) / time / 8 TB/s.
     python scripts/adjoint_solver_bench.py [--grid 256] [--iters 30]"""
 import argparse
 import gc
@@ -44,12 +45,14 @@ def run(name, fn, words):
     torch.cuda.synchronize()
     dt = (t_all - (time.perf_counter() - t0)) / args.iters                   # per iteration, the set-up (initial products, allocations) cancelled
     moved = spmv + words * 8 * n
-    out[name] = {"us_per_iteration": dt * 1e6, "vector_words_per_row_unfused": words, "bytes_moved": moved, "frac_of_8000": moved / dt / 8e12,
+    out[name] = {"us_per_iteration": dt * 1e6, "vector_words_per_row": words, "bytes_moved": moved, "frac_of_8000": moved / dt / 8e12,
                  "iterations": int(h.iters)}
 
 
-# words per row of the statements of one iteration (reads + writes), unfused as the reference writes them
-run("lsqr", lambda k: pkg.lsqr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, log=True)[1], 3 + 1 + 2 + 3 + 1 + 2 + 3 + 3 + 2 + 2 + 1)
-run("lsmr", lambda k: pkg.lsmr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, log=True)[1], 3 + 1 + 2 + 3 + 1 + 2 + 3 + 3 + 3 + 1)
+# words per row of the sweeps of one iteration (reads + writes): fused / unfused as the reference writes them
+run("lsqr", lambda k: pkg.lsqr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, log=True)[1], 3 + 2 + 3 + 2 + 5)
+run("lsqr_statement_by_statement", lambda k: pkg.lsqr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, log=True, fused=False)[1], 3 + 1 + 2 + 3 + 1 + 2 + 3 + 3 + 2 + 2 + 1)
+run("lsmr", lambda k: pkg.lsmr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, log=True)[1], 3 + 2 + 3 + 2 + 7)
+run("lsmr_statement_by_statement", lambda k: pkg.lsmr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, log=True, fused=False)[1], 3 + 1 + 2 + 3 + 1 + 2 + 3 + 3 + 3 + 1)
 run("qmr", lambda k: pkg.qmr(A, b, maxiter=k, reltol=0.0, log=True)[1], 2 + 3 + 3 + 2 + 3 + 3 + 2 + 2 + 2 + 2 + 3 + 3 + 2 + 3 + 2 + 2)
 print(json.dumps(out))

@@ -91,14 +91,15 @@ def test_lsqr_device_bit_exact(pkg, orc, ctx, dtype, shape, damp, start):
     xo, ho = orc.lsqr(S, b, x0, damp=damp, maxiter=60, mode="tree", shape=ctx.reduce_shape(dtype))
     dA = pkg.HipCSR.from_scipy(S, adjoint=True)
     assert (dA.size(1), dA.size(2)) == (m, n) and (pkg.adjoint(dA).size(1), pkg.adjoint(dA).size(2)) == (n, m)
-    if start:
-        x, ch = pkg.lsqr_(pkg.HipVector.from_numpy(x0), dA, pkg.HipVector.from_numpy(b), damp=damp, maxiter=60, log=True)
-    else:
-        x, ch = pkg.lsqr(dA, pkg.HipVector.from_numpy(b), damp=damp, maxiter=60, log=True)
-    assert ch.iters == ho["iters"] > 5 and ch.mvps == ho["mvps"] and ch.mtvps == ho["mtvps"] and ch.isconverged == ho["isconverged"]
-    for key in ("resnorm", "anorm", "rnorm", "cnorm"):
-        assert np.array_equal(ch[key], ho[key]), key
-    assert np.array_equal(x.to_numpy(), xo)
+    for fused in (True, False):                  # the fused sweeps (mik_xpby_nrm2, mik_lsqr_update) and one L1 call per statement: same bits
+        if start:
+            x, ch = pkg.lsqr_(pkg.HipVector.from_numpy(x0), dA, pkg.HipVector.from_numpy(b), damp=damp, maxiter=60, log=True, fused=fused)
+        else:
+            x, ch = pkg.lsqr(dA, pkg.HipVector.from_numpy(b), damp=damp, maxiter=60, log=True, fused=fused)
+        assert ch.iters == ho["iters"] > 5 and ch.mvps == ho["mvps"] and ch.mtvps == ho["mtvps"] and ch.isconverged == ho["isconverged"], fused
+        for key in ("resnorm", "anorm", "rnorm", "cnorm"):
+            assert np.array_equal(ch[key], ho[key]), (key, fused)
+        assert np.array_equal(x.to_numpy(), xo), fused
 
 
 @pytest.mark.gpu
@@ -112,14 +113,15 @@ def test_lsmr_device_bit_exact(pkg, orc, ctx, dtype, shape, lam, start):
     x0 = rng.standard_normal(n).astype(dtype) if start else None
     xo, ho = orc.lsmr(S, b, x0, lam=lam, maxiter=60, mode="tree", shape=ctx.reduce_shape(dtype))
     dA = pkg.HipCSR.from_scipy(S, adjoint=True)
-    if start:
-        x, ch = pkg.lsmr_(pkg.HipVector.from_numpy(x0), dA, pkg.HipVector.from_numpy(b), lam=lam, maxiter=60, log=True)
-    else:
-        x, ch = pkg.lsmr(dA, pkg.HipVector.from_numpy(b), lam=lam, maxiter=60, log=True)
-    assert ch.iters == ho["iters"] > 5 and ch.mvps == ho["mvps"] and ch.mtvps == ho["mtvps"] and ch.isconverged == ho["isconverged"]
-    for key in ("anorm", "rnorm", "cnorm"):
-        assert np.array_equal(ch[key], ho[key]), key
-    assert np.array_equal(x.to_numpy(), xo)
+    for fused in (True, False):                  # mik_xpby_nrm2 + mik_lsmr_update, and one L1 call per statement: same bits
+        if start:
+            x, ch = pkg.lsmr_(pkg.HipVector.from_numpy(x0), dA, pkg.HipVector.from_numpy(b), lam=lam, maxiter=60, log=True, fused=fused)
+        else:
+            x, ch = pkg.lsmr(dA, pkg.HipVector.from_numpy(b), lam=lam, maxiter=60, log=True, fused=fused)
+        assert ch.iters == ho["iters"] > 5 and ch.mvps == ho["mvps"] and ch.mtvps == ho["mtvps"] and ch.isconverged == ho["isconverged"], fused
+        for key in ("anorm", "rnorm", "cnorm"):
+            assert np.array_equal(ch[key], ho[key]), (key, fused)
+        assert np.array_equal(x.to_numpy(), xo), fused
 
 
 @pytest.mark.gpu
@@ -191,3 +193,27 @@ def test_lsqr_lsmr_qmr_device_across_operator_layouts(pkg, orc, ctx):
             assert ch.iters == ho["iters"] and np.array_equal(x.to_numpy(), xo), (name, layout)
             key = "resnorm" if name != "lsmr" else "rnorm"
             assert np.array_equal(ch[key], ho[key]), (name, layout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [1e-140, 1e137])
+def test_lsqr_lsmr_device_on_a_badly_scaled_operator(pkg, orc, ctx, scale):
+    """A scaled by 1e-140 / 1e137 (x, of the size of 1 / scale, still has a representable square): rho, alpha and with them wrho = w / rho leave the range where a plain sum of squares is safe -- norm(wrho) of the
+    fused LSQR tail (wrho is never stored) goes through its scratch-vector fallback, norm(v) through the scaled recomputation; same bits as the
+    oracle and as the statement-by-statement path"""
+    rng = np.random.default_rng(29)
+    S = (_rect(rng, 200, 90, 0.06, np.float64) * scale).tocsc()
+    b = rng.standard_normal(200)
+    shape = ctx.reduce_shape(np.float64)
+    dA = pkg.HipCSR.from_scipy(S, adjoint=True)
+    xo, ho = orc.lsqr(S, b, maxiter=25, atol=0.0, btol=0.0, conlim=0.0, mode="tree", shape=shape)
+    assert np.all(np.isfinite(ho["resnorm"])) and ho["iters"] > (5 if scale < 1 else 0)     # (1e137: the reference's own 1 + test3 <= 1 stops it after one iteration)
+    for fused in (True, False):
+        x, ch = pkg.lsqr(dA, pkg.HipVector.from_numpy(b), maxiter=25, atol=0.0, btol=0.0, conlim=0.0, log=True, fused=fused)
+        assert ch.iters == ho["iters"] and np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(ch["cnorm"], ho["cnorm"]), fused
+        assert np.array_equal(x.to_numpy(), xo), fused
+    xo, ho = orc.lsmr(S, b, maxiter=25, atol=0.0, btol=0.0, conlim=0.0, mode="tree", shape=shape)
+    assert ho["iters"] >= 1                      # (LSMR's condA starts from rhobar = 1, src/lsmr.jl:126: it stops after one iteration on such operators)
+    for fused in (True, False):
+        x, ch = pkg.lsmr(dA, pkg.HipVector.from_numpy(b), maxiter=25, atol=0.0, btol=0.0, conlim=0.0, log=True, fused=fused)
+        assert ch.iters == ho["iters"] and np.array_equal(ch["rnorm"], ho["rnorm"]) and np.array_equal(x.to_numpy(), xo), fused
