@@ -317,6 +317,17 @@ int mik_cheb_direction(mik_ctx *ctx, int dtype, int64_t n, const void *r, const 
 int mik_xpby_nrm2(mik_ctx *ctx, int dtype, int64_t n, const void *x, const void *beta, void *y, void *out);
 int mik_lsqr_update(mik_ctx *ctx, int dtype, int64_t n, const void *t1, const void *t2, const void *inv_rho, void *x, void *w, const void *v, void *out);
 int mik_lsmr_update(mik_ctx *ctx, int dtype, int64_t n, const void *c1, const void *c2, const void *c3, void *hbar, void *h, void *x, const void *v, void *out);
+/* QMR (src/qmr.jl), groups of consecutive statements as single sweeps with the same per-element operations:
+ *   mik_axpy2_dot    y .+= a .* x1; y .+= b .* x2 (x2 may be NULL); *out = dot(y, z) (z may be NULL: no reduction, out untouched)
+ *                    -- the two axpy! of a Lanczos vector (:70-72 / :76-78) and, for the second vector, vw = dot(v_next, w_next) (:81)
+ *   mik_scal2        x .*= a; y .*= b                                                                             (:90-91)
+ *   mik_qmr_update   p = v - h1 p_curr - h0 p_prev (either may be NULL), p .*= inv, x .+= g .* p; p is stored at p_out, the next p_curr
+ *                    (p_out may be p_prev's storage: the caller rotates names instead of the two copies of :196-197)  (:188-197)
+ * Scalars: HOST values of `dtype` (neg_h1 = -H[2], neg_h0 = -H[1]). */
+int mik_axpy2_dot(mik_ctx *ctx, int dtype, int64_t n, const void *a, const void *x1, const void *b, const void *x2, void *y, const void *z, void *out);
+int mik_scal2(mik_ctx *ctx, int dtype, int64_t n, const void *a, void *x, const void *b, void *y);
+int mik_qmr_update(mik_ctx *ctx, int dtype, int64_t n, const void *v, const void *neg_h1, const void *p_curr, const void *neg_h0, const void *p_prev,
+                   const void *inv, const void *g, void *x, void *p_out);
 /* v_next .*= inv_h3; w_next .= v_curr .+ neg_h1 .* w_curr .+ neg_h0 .* w_prev (each term skipped when its vector
  * is NULL); w_next .*= inv_h2; x .+= rhs0 .* w_next   -- src/minres.jl:113, :136-142 */
 int mik_minres_update(mik_ctx *ctx, int dtype, int64_t n, const void *inv_h3, void *v_next, const void *v_curr, const void *neg_h1,

@@ -139,6 +139,9 @@ SIGNATURES = {
     "mik_xpby_nrm2": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp, _vp]),
     "mik_lsqr_update": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mik_lsmr_update": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mik_axpy2_dot": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mik_scal2": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp, _vp]),
+    "mik_qmr_update": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mik_idrs_create": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, C.c_double, C.POINTER(_vp)]),
     "mik_idrs_step": (C.c_int, [_vp, C.c_int, _vp]),
     "mik_idrs_state": (C.c_int, [_vp, _vp, _vp, _vp]),

@@ -2067,8 +2067,9 @@ def lsmr(A, b, **kwargs):
 class LanczosDecomp:
     """``LanczosDecomp`` -- src/qmr.jl:5-58: the two-sided Lanczos process on A and adjoint(A); real element types."""
 
-    def __init__(self, x, A, b, *, initially_zero=False):
+    def __init__(self, x, A, b, *, initially_zero=False, fused=True):
         T = x.dtype.type
+        self.fused = bool(fused) and isinstance(x, HipVector)   # two axpy! (+ the dot behind them) per sweep, both scalings in one (same bits)
         self.A, self.At = A, adjoint(A)                                      # :51
         self.v_prev, self.v_curr, self.v_next = x.zero(), x.similar().copyto_(b), x.similar()        # :27-29
         if not initially_zero:
@@ -2085,33 +2086,54 @@ class LanczosDecomp:
         T = self.v_curr.dtype.type
         mul_(self.v_next, self.A, self.v_curr)                               # :67
         self.alpha = dot(self.v_next, self.w_curr)                           # :69
-        self.v_next.axpy_(-self.alpha, self.v_curr)                          # :70
-        if iteration > 1:
-            self.v_next.axpy_(-self.beta_curr, self.v_prev)                  # :72
-        mul_(self.w_next, self.At, self.w_curr)                              # :75
-        self.w_next.axpy_(-self.alpha, self.w_curr)                          # :76
-        if iteration > 1:
-            self.w_next.axpy_(-self.delta, self.w_prev)                      # :78
-        vw = dot(self.v_next, self.w_next)                                   # :81
+        if self.fused:
+            _axpy2_dot(self.v_next, -self.alpha, self.v_curr, -self.beta_curr, self.v_prev if iteration > 1 else None, None)      # :70-72
+            mul_(self.w_next, self.At, self.w_curr)                          # :75
+            vw = _axpy2_dot(self.w_next, -self.alpha, self.w_curr, -self.delta, self.w_prev if iteration > 1 else None, self.v_next)   # :76-81
+        else:
+            self.v_next.axpy_(-self.alpha, self.v_curr)                      # :70
+            if iteration > 1:
+                self.v_next.axpy_(-self.beta_curr, self.v_prev)              # :72
+            mul_(self.w_next, self.At, self.w_curr)                          # :75
+            self.w_next.axpy_(-self.alpha, self.w_curr)                      # :76
+            if iteration > 1:
+                self.w_next.axpy_(-self.delta, self.w_prev)                  # :78
+            vw = dot(self.v_next, self.w_next)                               # :81
         self.delta = np.sqrt(abs(vw))                                        # :82
         if self.delta == 0:
             return None                                                      # :83-85
         self.beta_prev = self.beta_curr                                      # :87-88
         self.beta_curr = vw / self.delta
-        self.v_next.scal_(T(1) / self.delta)                                 # :90
-        self.w_next.scal_(T(1) / self.beta_curr)                             # :91
+        if self.fused:
+            sa, sb = _scalar(self.v_next.dtype, T(1) / self.delta), _scalar(self.v_next.dtype, T(1) / self.beta_curr)
+            check(lib().mik_scal2(self.v_next.ctx.handle, self.v_next.code, self.v_next.n, sa[1], _vp(self.v_next.ptr), sb[1], _vp(self.w_next.ptr)),
+                  "mik_scal2", self.v_next.ctx.handle)                       # :90-91
+        else:
+            self.v_next.scal_(T(1) / self.delta)                             # :90
+            self.w_next.scal_(T(1) / self.beta_curr)                         # :91
         self.w_next, self.w_curr, self.w_prev = self.w_prev, self.w_next, self.w_curr     # :93
         self.v_next, self.v_curr, self.v_prev = self.v_prev, self.v_next, self.v_curr     # :94
         return None, iteration + 1
 
 
-class QMRIterable:
-    """``QMRIterable`` -- src/qmr.jl:103-121, construction per ``qmr_iterable!`` (:123-154)."""
+def _axpy2_dot(y, a, x1, b, x2, z):
+    """``y .+= a .* x1; y .+= b .* x2`` (x2 may be None) and ``dot(y, z)`` (z may be None) in one sweep (``mik_axpy2_dot``)."""
+    out = np.zeros(1, y.dtype)
+    sa, sb = _scalar(y.dtype, a), _scalar(y.dtype, b)
+    check(lib().mik_axpy2_dot(y.ctx.handle, y.code, y.n, sa[1], _vp(x1.ptr), sb[1], _vp(x2.ptr if x2 is not None else None), _vp(y.ptr),
+                              _vp(z.ptr if z is not None else None), out.ctypes.data_as(_vp)), "mik_axpy2_dot", y.ctx.handle)
+    return out[0]
 
-    def __init__(self, x, A, b, *, abstol, reltol, maxiter, initially_zero=False):
+
+class QMRIterable:
+    """``QMRIterable`` -- src/qmr.jl:103-121, construction per ``qmr_iterable!`` (:123-154).  ``fused`` (device vectors): the Lanczos step's
+    axpy! pairs, its scalings and the tail :188-197 are single sweeps (``mik_axpy2_dot``, ``mik_scal2``, ``mik_qmr_update``); same bits."""
+
+    def __init__(self, x, A, b, *, abstol, reltol, maxiter, initially_zero=False, fused=True):
         T = x.dtype.type
         self.x = x
-        self.lanczos = LanczosDecomp(x, A, b, initially_zero=initially_zero)  # :131
+        self.fused = bool(fused) and isinstance(x, HipVector)
+        self.lanczos = LanczosDecomp(x, A, b, initially_zero=initially_zero, fused=fused)  # :131
         self.resnorm = self.lanczos.resnorm
         self.g = np.array([self.resnorm, 0], x.dtype)                        # :134
         self.H = np.zeros(4, x.dtype)
@@ -2149,17 +2171,25 @@ class QMRIterable:
         c, s, H[2] = givens_algorithm(H[2], H[3], self.x.dtype)              # :183
         g[1] = -s * g[0]                                                     # :185-186
         g[0] = c * g[0]
-        lz.v_next.copyto_(lz.v_prev)                                         # we need v_m, not v_m+1  :188
-        if iteration > 1:
-            lz.v_next.axpy_(-H[1], self.p_curr)                              # :189
-        if iteration > 2:
-            lz.v_next.axpy_(-H[0], self.p_prev)                              # :190
-        with np.errstate(divide="ignore"):
-            lz.v_next.scal_(T(1) / H[2])                                     # :191
-        self.x.axpy_(g[0], lz.v_next)                                        # :193
+        if self.fused:                                                       # :188-197 in one sweep; the names rotate instead of the two copies
+            with np.errstate(divide="ignore"):
+                sc = [_scalar(self.x.dtype, val) for val in (-H[1], -H[0], T(1) / H[2], g[0])]
+            check(lib().mik_qmr_update(self.x.ctx.handle, self.x.code, self.x.n, _vp(lz.v_prev.ptr), sc[0][1], _vp(self.p_curr.ptr if iteration > 1 else None),
+                                       sc[1][1], _vp(self.p_prev.ptr if iteration > 2 else None), sc[2][1], sc[3][1], _vp(self.x.ptr), _vp(self.p_prev.ptr)),
+                  "mik_qmr_update", self.x.ctx.handle)
+            self.p_prev, self.p_curr = self.p_curr, self.p_prev
+        else:
+            lz.v_next.copyto_(lz.v_prev)                                     # we need v_m, not v_m+1  :188
+            if iteration > 1:
+                lz.v_next.axpy_(-H[1], self.p_curr)                          # :189
+            if iteration > 2:
+                lz.v_next.axpy_(-H[0], self.p_prev)                          # :190
+            with np.errstate(divide="ignore"):
+                lz.v_next.scal_(T(1) / H[2])                                 # :191
+            self.x.axpy_(g[0], lz.v_next)                                    # :193
+            self.p_prev.copyto_(self.p_curr)                                 # :196-197
+            self.p_curr.copyto_(lz.v_next)
         self.c_prev, self.s_prev, self.c_curr, self.s_curr = self.c_curr, self.s_curr, c, s           # :195
-        self.p_prev.copyto_(self.p_curr)                                     # :196-197
-        self.p_curr.copyto_(lz.v_next)
         g[0] = g[1]                                                          # :198
         self.resnorm = abs(g[1])                                             # :200
         return self.resnorm, iteration + 1
@@ -2171,13 +2201,13 @@ class QMRIterable:
             yield resnorm
 
 
-def qmr_iterable_(x, A, b, *, abstol=0.0, reltol=None, maxiter=None, initially_zero=False, lookahead=False):
+def qmr_iterable_(x, A, b, *, abstol=0.0, reltol=None, maxiter=None, initially_zero=False, lookahead=False, fused=True):
     """``qmr_iterable!`` -- src/qmr.jl:123-154."""
     return QMRIterable(x, A, b, abstol=abstol, reltol=_default_reltol(b) if reltol is None else reltol,
-                       maxiter=A.size(2) if maxiter is None else maxiter, initially_zero=initially_zero)
+                       maxiter=A.size(2) if maxiter is None else maxiter, initially_zero=initially_zero, fused=fused)
 
 
-def qmr_(x, A, b, *, abstol=0.0, reltol=None, maxiter=None, lookahead=False, log=False, initially_zero=False, verbose=False):
+def qmr_(x, A, b, *, abstol=0.0, reltol=None, maxiter=None, lookahead=False, log=False, initially_zero=False, verbose=False, fused=True):
     """``qmr!(x, A, b; ...)`` -- src/qmr.jl:256-297."""
     reltol = _default_reltol(b) if reltol is None else reltol
     maxiter = A.size(2) if maxiter is None else maxiter
@@ -2185,7 +2215,7 @@ def qmr_(x, A, b, *, abstol=0.0, reltol=None, maxiter=None, lookahead=False, log
     history["abstol"], history["reltol"] = abstol, reltol
     if log:
         history.reserve_("resnorm", maxiter)
-    it = qmr_iterable_(x, A, b, abstol=abstol, reltol=reltol, maxiter=maxiter, initially_zero=initially_zero)
+    it = qmr_iterable_(x, A, b, abstol=abstol, reltol=reltol, maxiter=maxiter, initially_zero=initially_zero, fused=fused)
     if verbose:
         print("=== qmr ===\n%4s\t%7s" % ("iter", "resnorm"))
     for iteration, residual in enumerate(it, start=1):

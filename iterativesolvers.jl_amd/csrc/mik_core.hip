@@ -1878,6 +1878,52 @@ extern "C" int mik_lsmr_update(mik_ctx *ctx, int dtype, int64_t n, const void *c
     return MIK_ERR_INVALID;
 }
 
+template <typename T> static int axpy2_dot_impl(mik_ctx *ctx, int64_t n, const void *a, const void *x1, const void *b, const void *x2, void *y, const void *z, void *out)
+{
+    MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)std::max<int64_t>(mik_nseg<T>(n), 1)));
+    OpAxpy2Dot<T> op{(T *)y, (const T *)x1, (const T *)x2, (const T *)z, *(const T *)a, x2 ? *(const T *)b : T(0)};
+    const bool vec = mik_aligned16(y) && mik_aligned16(x1) && (!x2 || mik_aligned16(x2)) && (!z || mik_aligned16(z));
+    MIK_TRY((launch_map<T>(ctx, n, op, vec, (T *)ctx->partials, nullptr)));
+    if (!z) return MIK_OK;
+    return reduce_to_host<T>(ctx, n, (T *)out);
+}
+
+extern "C" int mik_axpy2_dot(mik_ctx *ctx, int dtype, int64_t n, const void *a, const void *x1, const void *b, const void *x2, void *y, const void *z, void *out)
+{
+    if (!ctx || n < 0 || !a || (x2 && !b) || (z && !out) || (n && (!x1 || !y))) return MIK_ERR_INVALID;
+    if (dtype == MIK_F64) return axpy2_dot_impl<double>(ctx, n, a, x1, b, x2, y, z, out);
+    if (dtype == MIK_F32) return axpy2_dot_impl<float>(ctx, n, a, x1, b, x2, y, z, out);
+    return MIK_ERR_INVALID;
+}
+
+extern "C" int mik_scal2(mik_ctx *ctx, int dtype, int64_t n, const void *a, void *x, const void *b, void *y)
+{
+    if (!ctx || n < 0 || !a || !b || (n && (!x || !y))) return MIK_ERR_INVALID;
+    const bool vec = mik_aligned16(x) && mik_aligned16(y);
+    if (dtype == MIK_F64) { OpScal2<double> op{(double *)x, (double *)y, *(const double *)a, *(const double *)b}; return launch_map<double>(ctx, n, op, vec, (double *)nullptr, nullptr); }
+    if (dtype == MIK_F32) { OpScal2<float> op{(float *)x, (float *)y, *(const float *)a, *(const float *)b}; return launch_map<float>(ctx, n, op, vec, (float *)nullptr, nullptr); }
+    return MIK_ERR_INVALID;
+}
+
+extern "C" int mik_qmr_update(mik_ctx *ctx, int dtype, int64_t n, const void *v, const void *neg_h1, const void *p_curr, const void *neg_h0, const void *p_prev,
+                              const void *inv, const void *g, void *x, void *p_out)
+{
+    if (!ctx || n < 0 || !inv || !g || (p_curr && !neg_h1) || (p_prev && !neg_h0) || (n && (!v || !x || !p_out))) return MIK_ERR_INVALID;
+    if (p_out == v || p_out == p_curr) return MIK_ERR_INVALID;      // p_out may only be p_prev's storage (element i is read before it is written) or a vector of its own
+    const bool vec = mik_aligned16(v) && mik_aligned16(x) && mik_aligned16(p_out) && (!p_curr || mik_aligned16(p_curr)) && (!p_prev || mik_aligned16(p_prev));
+    if (dtype == MIK_F64) {
+        OpQmrUpdate<double> op{(const double *)v, (const double *)p_curr, (const double *)p_prev, (double *)p_out, (double *)x,
+                               p_curr ? *(const double *)neg_h1 : 0.0, p_prev ? *(const double *)neg_h0 : 0.0, *(const double *)inv, *(const double *)g};
+        return launch_map<double>(ctx, n, op, vec, (double *)nullptr, nullptr);
+    }
+    if (dtype == MIK_F32) {
+        OpQmrUpdate<float> op{(const float *)v, (const float *)p_curr, (const float *)p_prev, (float *)p_out, (float *)x,
+                              p_curr ? *(const float *)neg_h1 : 0.0f, p_prev ? *(const float *)neg_h0 : 0.0f, *(const float *)inv, *(const float *)g};
+        return launch_map<float>(ctx, n, op, vec, (float *)nullptr, nullptr);
+    }
+    return MIK_ERR_INVALID;
+}
+
 extern "C" int mik_cheb_direction(mik_ctx *ctx, int dtype, int64_t n, const void *r, const void *pl_diag, const void *beta, int first,
                                   void *u)
 {

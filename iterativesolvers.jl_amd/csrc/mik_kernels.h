@@ -391,6 +391,87 @@ template <typename T> struct OpLsmrUpdate {
     }
 };
 
+// QMR's two-sided Lanczos step (src/qmr.jl:70-72, :76-78, :81): y .+= a .* x1; y .+= b .* x2 (skipped when x2 is null), then partial sums of
+// z .* y (skipped when z is null) -- two axpy! and the dot that follows them in one sweep
+template <typename T> struct OpAxpy2Dot {
+    static constexpr bool REDUCE = true;
+    T *__restrict__ y; const T *__restrict__ x1; const T *__restrict__ x2; const T *__restrict__ z; T a, b;
+    __device__ __forceinline__ void apply(int64_t i, T &acc) const
+    {
+        T t = a * x1[i]; T v = y[i] + t;
+        if (x2) { T u = b * x2[i]; v = v + u; }
+        y[i] = v;
+        if (z) { T p = v * z[i]; acc = acc + p; }
+    }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &acc) const
+    {
+        constexpr int W = VT<T>::W;
+        auto yv = vload<T>(y + i); auto xv = vload(x1 + i);
+#pragma unroll
+        for (int e = 0; e < W; ++e) { T t = a * el<T>(xv, e); el<T>(yv, e) = el<T>(yv, e) + t; }
+        if (x2) {
+            auto x2v = vload(x2 + i);
+#pragma unroll
+            for (int e = 0; e < W; ++e) { T u = b * el<T>(x2v, e); el<T>(yv, e) = el<T>(yv, e) + u; }
+        }
+        vstore(y + i, yv);
+        if (z) {
+            auto zv = vload(z + i);
+#pragma unroll
+            for (int e = 0; e < W; ++e) { T p = el<T>(yv, e) * el<T>(zv, e); acc = acc + p; }
+        }
+    }
+};
+
+// x .*= a; y .*= b      -- rmul!(v_next, inv(δ)); rmul!(w_next, inv(β)): src/qmr.jl:90-91
+template <typename T> struct OpScal2 {
+    static constexpr bool REDUCE = false;
+    T *__restrict__ x; T *__restrict__ y; T a, b;
+    __device__ __forceinline__ void apply(int64_t i, T &) const { x[i] = x[i] * a; y[i] = y[i] * b; }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &) const
+    {
+        auto xv = vload<T>(x + i); auto yv = vload<T>(y + i);
+#pragma unroll
+        for (int e = 0; e < VT<T>::W; ++e) { el<T>(xv, e) = el<T>(xv, e) * a; el<T>(yv, e) = el<T>(yv, e) * b; }
+        vstore(x + i, xv); vstore(y + i, yv);
+    }
+};
+
+// QMR, the tail of an iteration in one sweep        -- src/qmr.jl:188-197
+//   p = v; p .+= (-h1) .* p_curr (if p_curr); p .+= (-h0) .* p_prev (if p_prev); p .*= inv; x .+= g .* p; the result is the next p_curr
+//   (stored over p_out, which may be p_prev's storage: the caller rotates its names instead of the reference's two copies)
+template <typename T> struct OpQmrUpdate {
+    static constexpr bool REDUCE = false;
+    const T *__restrict__ v; const T *p_curr; const T *p_prev; T *p_out; T *__restrict__ x; T neg_h1, neg_h0, inv, g;
+    __device__ __forceinline__ void apply(int64_t i, T &) const
+    {
+        T p = v[i];
+        if (p_curr) { T t = neg_h1 * p_curr[i]; p = p + t; }
+        if (p_prev) { T t = neg_h0 * p_prev[i]; p = p + t; }
+        p = p * inv;
+        p_out[i] = p;
+        T t = g * p; x[i] = x[i] + t;
+    }
+    __device__ __forceinline__ void apply_vec(int64_t i, T &) const
+    {
+        constexpr int W = VT<T>::W;
+        auto pv = vload(v + i); auto xv = vload_nt<T>(x + i);
+        if (p_curr) {
+            auto cv = vload(p_curr + i);
+#pragma unroll
+            for (int e = 0; e < W; ++e) { T t = neg_h1 * el<T>(cv, e); el<T>(pv, e) = el<T>(pv, e) + t; }
+        }
+        if (p_prev) {
+            auto qv = vload(p_prev + i);
+#pragma unroll
+            for (int e = 0; e < W; ++e) { T t = neg_h0 * el<T>(qv, e); el<T>(pv, e) = el<T>(pv, e) + t; }
+        }
+#pragma unroll
+        for (int e = 0; e < W; ++e) { el<T>(pv, e) = el<T>(pv, e) * inv; T t = g * el<T>(pv, e); el<T>(xv, e) = el<T>(xv, e) + t; }
+        vstore(p_out + i, pv); vstore_nt(x + i, xv);
+    }
+};
+
 // The CG step with the update of x moved one sweep later (same operands, same rounding, so the same bits): the tail of
 // step k only does r .-= alpha .* c and |r|^2 (OpCgUpdateR), and x .+= alpha_k .* u_k is applied by the sweep that reads
 // u_k anyway -- u = r + beta u of step k + 1 -- saving one read of u (n s bytes, 19 us at 256^3) per iteration.  That sweep is

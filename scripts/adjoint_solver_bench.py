@@ -1,6 +1,6 @@
 """LSQR, LSMR and QMR (src/lsqr.jl, src/lsmr.jl, src/qmr.jl) per iteration on the 256^3 Laplacian, fp64, one MI355X: two SpMV per iteration (A and
 adjoint(A) -- the second operator is the SAME CSC arrays uploaded as CSR, HipCSR.with_adjoint) plus their vector statements: LSQR / LSMR with the
-fused sweeps (mik_xpby_nrm2, mik_lsqr_update / mik_lsmr_update) and statement by statement, QMR statement by statement (several host-visible
+fused sweeps (mik_xpby_nrm2, mik_lsqr_update / mik_lsmr_update; QMR: mik_axpy2_dot, mik_scal2, mik_qmr_update) and statement by statement (several host-visible
 norms per iteration like the reference's loop).  `frac` = bytes the launches of an iteration move (both operators' stored bytes + the words per
 row of its sweeps) / time / 8 TB/s.
     python scripts/adjoint_solver_bench.py [--grid 256] [--iters 30]"""
@@ -54,5 +54,6 @@ run("lsqr", lambda k: pkg.lsqr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, 
 run("lsqr_statement_by_statement", lambda k: pkg.lsqr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, log=True, fused=False)[1], 3 + 1 + 2 + 3 + 1 + 2 + 3 + 3 + 2 + 2 + 1)
 run("lsmr", lambda k: pkg.lsmr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, log=True)[1], 3 + 2 + 3 + 2 + 7)
 run("lsmr_statement_by_statement", lambda k: pkg.lsmr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, log=True, fused=False)[1], 3 + 1 + 2 + 3 + 1 + 2 + 3 + 3 + 3 + 1)
-run("qmr", lambda k: pkg.qmr(A, b, maxiter=k, reltol=0.0, log=True)[1], 2 + 3 + 3 + 2 + 3 + 3 + 2 + 2 + 2 + 2 + 3 + 3 + 2 + 3 + 2 + 2)
+run("qmr", lambda k: pkg.qmr(A, b, maxiter=k, reltol=0.0, log=True)[1], 2 + 4 + 5 + 4 + 6)
+run("qmr_statement_by_statement", lambda k: pkg.qmr(A, b, maxiter=k, reltol=0.0, log=True, fused=False)[1], 2 + 3 + 3 + 2 + 3 + 3 + 2 + 2 + 2 + 2 + 3 + 3 + 2 + 3 + 2 + 2)
 print(json.dumps(out))

@@ -77,11 +77,12 @@ def test_qmr_device_bit_exact(pkg, orc, ctx, dtype, name, start):
     x0 = rng.standard_normal(n).astype(dtype) if start else None
     xo, ho = orc.qmr(S, b, x0, maxiter=120, mode="tree", shape=ctx.reduce_shape(dtype))
     dA = pkg.HipCSR.from_scipy(S, adjoint=True)
-    if start:
-        x, ch = pkg.qmr_(pkg.HipVector.from_numpy(x0), dA, pkg.HipVector.from_numpy(b), maxiter=120, log=True)
-    else:
-        x, ch = pkg.qmr(dA, pkg.HipVector.from_numpy(b), maxiter=120, log=True)
-    assert ch.iters == ho["iters"] > 10 and ch.isconverged == ho["isconverged"]
-    assert np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
+    for fused in (True, False):                  # the fused sweeps (mik_axpy2_dot, mik_scal2, mik_qmr_update) and one L1 call per statement: same bits
+        if start:
+            x, ch = pkg.qmr_(pkg.HipVector.from_numpy(x0), dA, pkg.HipVector.from_numpy(b), maxiter=120, log=True, fused=fused)
+        else:
+            x, ch = pkg.qmr(dA, pkg.HipVector.from_numpy(b), maxiter=120, log=True, fused=fused)
+        assert ch.iters == ho["iters"] > 10 and ch.isconverged == ho["isconverged"], fused
+        assert np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo), fused
     if ho["isconverged"] and dtype == np.float64:                            # resnorm is the QUASI-residual: the true one is within sqrt(k + 1) of it at best
         assert np.linalg.norm(S @ xo - b) / np.linalg.norm(b) <= 1e-3
