@@ -19,7 +19,7 @@ Rank 0 prints ONE JSON line.  At every N:
   `default_layout_*`       the same iteration in the layout mik_csr_create picks by itself (one mask byte per row for this
                            constant-coefficient operator; bit-identical results) -- reported, NOT the contract figure
 N = 1 adds: parity_full_history (the 613-step solve against the committed CPU histories), gmres_hbm_bound (gmres!(30) at 256^3),
-f_solvers, gmres_config3 (configs[2]), config5 (configs[4] stand-ins), cpu_baseline (+ OpenMP).
+f_solvers (SURVEY 8f + IDR(s), LSQR / LSMR / QMR), gmres_config3 (configs[2]), config5 (configs[4] stand-ins), cpu_baseline (+ OpenMP).
 N > 1 adds: parity_vs_oracle (every transport on a small global system against the partition-aware oracle), transports_measured.
 """
 from __future__ import annotations
@@ -316,6 +316,41 @@ def f_solvers(A, b, n: int, iters: int = 40):
     return out
 
 
+def adjoint_solvers(A, csc, b, n: int, iters: int = 20):
+    """LSQR, LSMR, QMR (src/lsqr.jl, src/lsmr.jl, src/qmr.jl) per iteration on the 256^3 operator, default layout: two SpMV per iteration, with A and
+    with adjoint(A) -- a second upload of the SAME CSC arrays as CSR (no transpose formed) -- and their fused sweeps; several host-visible norms per
+    iteration like the reference's loops.  Time of (iters + 3) iterations minus that of 3 (set-up cancelled)."""
+    import gc
+    import torch
+    pkg = graft.load_package()
+    t0 = time.perf_counter()
+    A.adj = pkg.HipCSR(n, n, *csc, index_base=1, is_csc=False)
+    A.adj.adj = A
+    rec = {"adjoint_upload_seconds": time.perf_counter() - t0, "operator_layout": A.layout(), "adjoint_layout": A.adj.layout()}
+    spmv = A.spmv_stored_bytes() + A.adj.spmv_stored_bytes()
+
+    def run(name, fn, words):
+        fn(3)
+        gc.collect()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fn(iters + 3)
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        fn(3)
+        torch.cuda.synchronize()
+        dt = (t_all - (time.perf_counter() - t1)) / iters
+        moved = spmv + words * 8 * n
+        rec[name] = {"us_per_iteration": dt * 1e6, "vector_words_per_row_moved": words, "bytes_moved": moved, "frac": moved / dt / 1e9 / HBM_PEAK_GBS}
+    run("lsqr", lambda k: pkg.lsqr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0), 15)
+    run("lsmr", lambda k: pkg.lsmr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0), 17)
+    run("qmr", lambda k: pkg.qmr(A, b, maxiter=k, reltol=0.0), 21)
+    A.adj.adj = None
+    A.adj = None
+    return rec
+
+
 def gmres_large_traffic(name: str):
     """HBM-side bytes per inner iteration of the HBM-bound GMRES leg from the committed PMC passes (profiles/*gmres_large_<name>_traffic.json)."""
     import glob
@@ -451,6 +486,7 @@ def run_single(args):
     t_up = time.perf_counter()
     A = pkg.HipCSR(n, n, colptr, rowval, nzval, index_base=1)
     upload_seconds = time.perf_counter() - t_up
+    csc = (colptr, rowval, nzval) if (not args.no_f_solvers and N >= 128) else None     # kept for the adjoint operator of the LSQR / LSMR / QMR leg
     del colptr, rowval, nzval
     nnz = A.nnz
     b = pkg.HipVector.from_numpy(pkg.fixtures.hashed_rhs(n))
@@ -642,6 +678,11 @@ def run_single(args):
             out["f_solvers"] = f_solvers(A, b, n)
         finally:
             A.set_layout("auto")
+        try:
+            out["f_solvers"]["adjoint_solvers"] = adjoint_solvers(A, csc, b, n)
+        except Exception as e:     # noqa: BLE001 -- a widening leg must never cost the driver its line
+            out["f_solvers"]["adjoint_solvers"] = {"error": repr(e)[:300]}
+        csc = None
     del A, b, scratch, u
     if not args.no_gmres:
         out["gmres_config3"] = gmres_config3()
