@@ -75,6 +75,13 @@ def test_call_sequences_equal_the_python_mirror():
     assert jl("Base.iterate(it::HipBiCGStabIterable") == ["mik_bicgstab_step"] == py_calls("BiCGStabIterable", "iterate")[:1]
     assert jl("IterativeSolvers.minres_iterable!") == ["mik_minres_create"] == py_calls("MINRESIterable", "__init__")
     assert jl("Base.iterate(m::HipMINRESIterable") == ["mik_minres_step"] == py_calls("MINRESIterable", "iterate")[:1]
+    assert jl("IterativeSolvers.idrs_iterable!") == ["mik_idrs_create"] == py_calls("IDRSIterable", "__init__")
+    assert jl("Base.iterate(it::HipIDRSIterable") == ["mik_idrs_step"] == py_calls("IDRSIterable", "iterate")[:1]
+    # adjoint(A) for lsqr! / lsmr! / qmr!: a second upload of the same arrays with is_csc = 0 on both sides
+    wa = julia_function("with_adjoint")
+    assert "pointer(A.colptr), pointer(A.rowval), pointer(A.nzval), 1, 0, h)" in wa and "size(A, 2), size(A, 1), nnz(A)" in wa
+    i = api.index("def with_adjoint")
+    assert "is_csc=False" in api[i:api.index("return A", i)]
 
 
 def test_shim_has_no_silent_scalar_fallback_and_reference_defaults():
