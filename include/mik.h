@@ -62,7 +62,8 @@
 extern "C" {
 #endif
 
-#define MIK_ABI_VERSION 5   /* 5 (round 5): mik_partition gained `link`; the pushed halo lands in library-owned buffers (mik_plink_*, mik_cgd_ghost_export;
+#define MIK_ABI_VERSION 6   /* 6 (round 6): mik_ctx_info / mik_device_info (the machine is queried, not assumed); mik_comm_selftest.
+                             *   5 (round 5): mik_partition gained `link`; the pushed halo lands in library-owned buffers (mik_plink_*, mik_cgd_ghost_export;
                              *   mik_cgd_connect_ghosts takes ghost counts instead of byte offsets; mik_mem_export is gone); mik_cgd_profile.
                              *   4 (round 4): MIK_ERR_SINGULAR replaces MIK_ERR_INVALID for an exactly singular pivot (mik_lu_solve, mik_bicgstab_step);
                              *   the scalar mailbox transport (mik_mailbox_*).  3 (round 3): mik_csr_pack and the knob setters left this header
@@ -97,6 +98,27 @@ int mik_abi_version(void);
 int mik_device_count(int *count);
 int mik_ctx_create(int device, mik_ctx **out);
 int mik_ctx_destroy(mik_ctx *ctx);
+/* The machine behind a context, as hipDeviceGetAttribute reported it in mik_ctx_create, and what the library's selection paths derive
+ * from it: nothing assumes "256 compute units in 8 XCDs".  The workgroup -> XCD maps of the banded SpMV kernels and the XCD-local
+ * Gram-Schmidt are written for the 8-XCD round-robin dispatch of an unpartitioned MI355X; on any other shape (xcd_maps = 0) the
+ * identity map and the device-wide forms run -- same bits (src/orthogonalize.jl:67-79 has one result whatever the form). */
+typedef struct mik_device_info {
+    int device;                          /* HIP ordinal */
+    int compute_units;                   /* hipDeviceAttributeMultiprocessorCount */
+    int xcds;                            /* hipDeviceAttributeNumberOfXccs (1 if the runtime does not know the attribute) */
+    int wavefront_size;                  /* 64 (mik_ctx_create refuses anything else) */
+    int64_t lds_bytes_per_cu, l2_bytes, hbm_bytes;
+    char arch[64];                       /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
+    /* derived (what launch and selection code reads): */
+    int planned_compute_units, planned_xcds;   /* = the two above unless a development override is set (include/mik_dev.h MIK_KNOB_MACHINE) */
+    int xcd_maps;                        /* 1: XCD-aware workgroup maps in use (planned_xcds == 8) */
+    int resident_workgroup_cap;          /* workgroups of a launch whose workgroups wait for each other: one per compute unit */
+    int gs_single_launch_max_segments;   /* orthogonalize_and_normalize! as ONE launch up to this many reduction segments (8 per workgroup) */
+    int gs_xcd_local_max_workgroups;     /* ... in its XCD-local form up to this many workgroups (0: form not available on this shape) */
+    int sweep_grid_cap;                  /* grid cap of the grid-stride vector sweeps */
+    int reserved[8];
+} mik_device_info;
+int mik_ctx_info(const mik_ctx *ctx, mik_device_info *out);
 /* Adopt an external hipStream_t (e.g. torch's current stream); NULL restores the ctx's own. */
 int mik_ctx_set_stream(mik_ctx *ctx, void *hip_stream);
 int mik_ctx_synchronize(mik_ctx *ctx);

@@ -7,7 +7,7 @@
  * of the test suite: it writes the defaults and every live context, and must not race with calls on those contexts.  A host that
  * wants an operator on its plain CSR arrays uses mik_csr_set_layout (include/mik.h), not a knob.
  *
- * Round 5: 12 knobs, every one referenced by a test.  Knobs whose two settings had been measured and decided are
+ * Round 5: 12 knobs, every one referenced by a test (round 6: + MIK_KNOB_MACHINE, the machine-shape override of VERDICT r5 #4).  Knobs whose two settings had been measured and decided are
  * gone with the losing variant (operator-stream cache policy, narrow CSR loads, workgroup-map override, long-row threshold, the
  * hint masks of the vector sweeps and of the Krylov basis, slices per workgroup, hipGraph replay of a GMRES column, DGKS rounds in
  * the single-launch kernel, sweep direction, hipStreamSynchronize vs event spin as a knob of its own); what remains selects between
@@ -45,10 +45,16 @@ enum {
                                   * 8 = row-partitioned step with the separate alpha launch (k_cgd_alpha: the classic step's form) */
     MIK_KNOB_HOST_WAIT = 11,     /* host-visible scalars (bits): 1 = hipMemcpyAsync + wait instead of the publish kernel + mailbox spin (more scalars than the mailbox holds),
                                   * 2 = hipStreamSynchronize instead of the event spin (a context without its event) */
-    MIK_KNOB_COUNT = 12
+    MIK_KNOB_MACHINE = 12,       /* the machine shape the selection paths plan for instead of the queried one (mik_ctx_info): compute units | XCDs << 16; 0 = as queried.
+                                  * Read at mik_csr_create (workgroup map), mik_gmres_create (single-launch Gram-Schmidt) and at launch.  32 | 1 << 16 = a CPX partition */
+    MIK_KNOB_COUNT = 13
 };
 int mik_set_tuning(int key, int value);
 int mik_ctx_set_tuning(mik_ctx *ctx, int key, int value);
+/* Which form orthogonalize_and_normalize! (src/orthogonalize.jl:13-79) of this handle runs in: *single_launch = 1 the whole column as one
+ * kernel (0: the multi-launch chains), *segments_per_workgroup = its G (0: buffers never allocated -- too many segments for this machine),
+ * *xcd_local_last = the column last enqueued used the XCD-local form, *timeouts = columns that came back timed out so far.  Any pointer may be NULL. */
+int mik_dev_gmres_form(const mik_gmres *it, int *single_launch, int *segments_per_workgroup, int *xcd_local_last, int *timeouts);
 /* Host-only: the rule that places a 256-row block's window of x in LDS (k_spmv_rowblock XWIN) on caller-supplied per-block statistics
  * (first / last referenced column, entry count).  win_lo[b] = first column of block b's window (16-byte aligned) or -1 (the block gathers from
  * memory); *span = common window length in elements, 0 = no window table.  Guarantee the tests check: win_lo[b] >= 0 implies

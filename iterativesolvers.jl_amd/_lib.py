@@ -50,6 +50,15 @@ class MikPrecond(C.Structure):
     _fields_ = [("diag", C.c_void_p), ("ldiv", LDIV_FN), ("user", C.c_void_p)]
 
 
+class MikDeviceInfo(C.Structure):
+    """include/mik.h mik_device_info"""
+    _fields_ = [("device", C.c_int), ("compute_units", C.c_int), ("xcds", C.c_int), ("wavefront_size", C.c_int),
+                ("lds_bytes_per_cu", C.c_int64), ("l2_bytes", C.c_int64), ("hbm_bytes", C.c_int64), ("arch", C.c_char * 64),
+                ("planned_compute_units", C.c_int), ("planned_xcds", C.c_int), ("xcd_maps", C.c_int), ("resident_workgroup_cap", C.c_int),
+                ("gs_single_launch_max_segments", C.c_int), ("gs_xcd_local_max_workgroups", C.c_int), ("sweep_grid_cap", C.c_int),
+                ("reserved", C.c_int * 8)]
+
+
 class MikPartition(C.Structure):
     _fields_ = [("rank", C.c_int), ("nranks", C.c_int), ("n_ext", C.c_int64), ("x_ext", C.c_void_p),
                 ("send_idx", C.c_void_p), ("n_send", C.c_int64), ("send_buf", C.c_void_p),
@@ -62,6 +71,8 @@ SIGNATURES = {
     "mik_device_count": (C.c_int, [_ip]),
     "mik_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "mik_ctx_destroy": (C.c_int, [_vp]),
+    "mik_ctx_info": (C.c_int, [_vp, C.POINTER(MikDeviceInfo)]),
+    "mik_dev_gmres_form": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
     "mik_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "mik_ctx_synchronize": (C.c_int, [_vp]),
     "mik_last_error": (C.c_char_p, [_vp]),

@@ -90,6 +90,30 @@ extern "C" int mik_ctx_create(int device, mik_ctx **out)
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
     if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     ctx->stream = ctx->own_stream;
+    {   // the machine: compute units, XCDs, LDS, L2 -- every "one workgroup per CU" cap and XCD map is derived from this (mik_ctx_info)
+        int v = 0;
+        if ((e = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return bail(e, "hipDeviceGetAttribute(MultiprocessorCount)");
+        ctx->cu_count = v;
+        v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, device) != hipSuccess || v < 1) { (void)hipGetLastError(); v = 1; }   // (a runtime without the attribute: one XCD = identity maps, device-wide forms)
+        ctx->xcd_count = v;
+        v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeWarpSize, device) == hipSuccess) ctx->wave_size = v; else (void)hipGetLastError();
+        v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) == hipSuccess) ctx->lds_per_cu = v; else (void)hipGetLastError();
+        v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeL2CacheSize, device) == hipSuccess) ctx->l2_bytes = v; else (void)hipGetLastError();
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+            ctx->hbm_bytes = (int64_t)prop.totalGlobalMem;
+            snprintf(ctx->arch, sizeof(ctx->arch), "%s", prop.gcnArchName);
+        } else (void)hipGetLastError();
+        if (ctx->wave_size != 0 && ctx->wave_size != 64) {
+            int rc = mik_fail(nullptr, MIK_ERR_HIP, "mik_ctx_create: device %d runs %d-wide wavefronts; libmik's kernels are written for wave-64 (gfx950)", device, ctx->wave_size);
+            delete ctx;
+            return rc;
+        }
+    }
     if ((e = hipMalloc(&ctx->coef, mik_ctx::COEF_BYTES)) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipHostMalloc(&ctx->coef_host, mik_ctx::COEF_BYTES, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
     if ((e = hipEventCreateWithFlags(&ctx->wait_event, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -101,6 +125,29 @@ extern "C" int mik_ctx_create(int device, mik_ctx **out)
         g_mik_contexts.push_back(ctx);
     }
     *out = ctx;
+    return MIK_OK;
+}
+
+extern "C" int mik_ctx_info(const mik_ctx *ctx, mik_device_info *out)
+{
+    if (!ctx || !out) return MIK_ERR_INVALID;
+    memset(out, 0, sizeof(*out));
+    out->device = ctx->device;
+    out->compute_units = ctx->cu_count;
+    out->xcds = ctx->xcd_count;
+    out->wavefront_size = ctx->wave_size;
+    out->lds_bytes_per_cu = ctx->lds_per_cu;
+    out->l2_bytes = ctx->l2_bytes;
+    out->hbm_bytes = ctx->hbm_bytes;
+    snprintf(out->arch, sizeof(out->arch), "%s", ctx->arch);
+    // what the selection paths derive from it (development knob MIK_KNOB_MACHINE applied)
+    out->planned_compute_units = mik_cus(ctx);
+    out->planned_xcds = mik_xcds(ctx);
+    out->xcd_maps = mik_xcd_maps(ctx) ? 1 : 0;
+    out->resident_workgroup_cap = mik_resident_cap(ctx);
+    out->gs_single_launch_max_segments = 8 * mik_resident_cap(ctx);
+    out->gs_xcd_local_max_workgroups = mik_xcd_maps(ctx) ? 4 * (mik_cus(ctx) / mik_xcds(ctx)) : 0;
+    out->sweep_grid_cap = mik_max_grid(ctx);
     return MIK_OK;
 }
 
@@ -1015,9 +1062,7 @@ static int csr_create_impl(mik_ctx *ctx, int dtype, int64_t n_rows, int64_t n_co
         for (int64_t r = 0; r < n_rows; ++r)
             for (int k = rowptr[r]; k < rowptr[r + 1]; ++k)
                 if (col[k] < n_rows) bw = std::max<int64_t>(bw, std::llabs((long long)col[k] - (long long)r));
-        const int64_t nb = (n_rows + MIK_BLOCK - 1) / MIK_BLOCK;
-        const int64_t P = ((bw + MIK_BLOCK - 1) / MIK_BLOCK + 7) / 8 * 8;
-        if (P >= 8 && P <= nb / 4) strip = (int)P;
+        strip = mik_strip_for(ctx, bw, (n_rows + MIK_BLOCK - 1) / MIK_BLOCK);
     }
 
     // Long rows (> MIK_LONG_ROW entries) leave the row-block layout: their entries move behind all

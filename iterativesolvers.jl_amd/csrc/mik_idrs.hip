@@ -366,7 +366,7 @@ template <typename T> static int idrs_multidot(mik_ctx *ctx, int64_t n, int k, c
     const int64_t nseg = mik_nseg<T>(n);
     if (k <= 0) return MIK_OK;
     if (nseg == 0) { MIK_HIP(ctx, hipMemsetAsync(out_dev, 0, sizeof(T) * k, ctx->stream)); return MIK_OK; }
-    const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
+    const int grid = (int)std::min<int64_t>(nseg, mik_max_grid(ctx));
     const bool vec = mik_aligned16(V) && mik_aligned16(w) && (ldv % VT<T>::W == 0);
     if (vec) hipLaunchKernelGGL((k_multidot<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, w, (T *)ctx->partials, nt);
     else hipLaunchKernelGGL((k_multidot<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, w, (T *)ctx->partials, 0);

@@ -21,7 +21,9 @@ constexpr int MIK_FIN_THREADS = 1024;
 constexpr int MIK_SPMV_TILE = 2048;  // nnz staged in LDS per row-block pass
 constexpr int MIK_SPMV_G = 1;        // row-blocks per SpMV workgroup (= L of the fused-dot tree); >1 measured slower
 constexpr int MIK_LONG_ROW = 256;      // rows with more entries go to the wave-per-row kernel (wave-shaped row sum)
-constexpr int MIK_MAX_GRID = 256 * 8 * 4;
+constexpr int MIK_XCD_MAP = 8;       // the block -> XCD maps below (xcd_remap, spmv_block_map strips, the XCD-local Gram-Schmidt) are written for the
+                                     // round-robin dispatch over the 8 XCDs of an unpartitioned MI355X; a context whose device reports another
+                                     // count (CPX / partitioned modes) runs the identity map and the device-wide forms (mik_xcd_maps)
 
 template <typename T> struct VT;
 template <> struct VT<double> { static constexpr int W = 2; using vec = double2; };
@@ -32,6 +34,10 @@ template <> struct VT<float>  { static constexpr int W = 4; using vec = float4; 
 // ---------------------------------------------------------------------------------------------
 struct mik_ctx {
     int device = 0;
+    // the machine, queried in mik_ctx_create (hipDeviceGetAttribute); nothing on a selection path assumes 256 CUs / 8 XCDs (mik_cus / mik_xcds below)
+    int cu_count = 0, xcd_count = 0, wave_size = 0;
+    int64_t lds_per_cu = 0, l2_bytes = 0, hbm_bytes = 0;
+    char arch[64] = {0};
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
@@ -52,6 +58,23 @@ struct mik_ctx {
     // finds its context already closed (and must then skip mik_*_destroy) leaks nothing
     std::vector<std::pair<void *, int (*)(void *)>> owned;
 };
+
+// The machine shape the selection paths plan for: what the device reported, unless the development knob MIK_KNOB_MACHINE
+// (compute units | XCDs << 16) overrides it for a test.
+static inline int mik_cus(const mik_ctx *ctx) { const int v = ctx->tuning[MIK_KNOB_MACHINE] & 0xFFFF; return v > 0 ? v : std::max(1, ctx->cu_count); }
+static inline int mik_xcds(const mik_ctx *ctx) { const int v = (ctx->tuning[MIK_KNOB_MACHINE] >> 16) & 0xFF; return v > 0 ? v : std::max(1, ctx->xcd_count); }
+static inline bool mik_xcd_maps(const mik_ctx *ctx) { return mik_xcds(ctx) == MIK_XCD_MAP; }
+// grid cap of the grid-stride sweeps: 32 workgroups (8 resident x 4 rounds) per compute unit; results never depend on it (segments are fixed)
+static inline int mik_max_grid(const mik_ctx *ctx) { return mik_cus(ctx) * 32; }
+// workgroups of a launch whose workgroups wait for each other (single-launch Gram-Schmidt, mailbox spins): one per compute unit
+static inline int mik_resident_cap(const mik_ctx *ctx) { return mik_cus(ctx); }
+// "strips" workgroup map of a banded operator (spmv_block_map): bandwidth bw in rows, nb 256-row blocks; 0 = identity
+static inline int mik_strip_for(const mik_ctx *ctx, int64_t bw, int64_t nb)
+{
+    if (!mik_xcd_maps(ctx)) return 0;
+    const int64_t P = ((bw + MIK_BLOCK - 1) / MIK_BLOCK + MIK_XCD_MAP - 1) / MIK_XCD_MAP * MIK_XCD_MAP;
+    return (P >= MIK_XCD_MAP && P <= nb / 4) ? (int)P : 0;
+}
 
 struct mik_csr {
     mik_ctx *ctx = nullptr;

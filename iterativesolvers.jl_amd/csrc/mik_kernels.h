@@ -147,7 +147,7 @@ template <typename T, int PRO, typename Op, typename X = NoExchange>
 static inline int launch_map_pro(mik_ctx *ctx, int64_t n, Op op, bool vec, T *seg_out, const T *prev_part, int prev_m, T *coef_out, X xch = X())
 {
     const int64_t nseg = mik_nseg<T>(n);
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(nseg, MIK_MAX_GRID));   // >= 1: workgroup 0 publishes the coefficient
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(nseg, mik_max_grid(ctx)));   // >= 1: workgroup 0 publishes the coefficient
     if (vec)
         hipLaunchKernelGGL((k_map_pro<T, true, Op, PRO, X>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, seg_out, prev_part, prev_m, coef_out, xch);
     else
@@ -162,7 +162,7 @@ static inline int launch_map(mik_ctx *ctx, int64_t n, Op op, bool vec, T *seg_ou
 {
     const int64_t nseg = mik_nseg<T>(n);
     if (nseg == 0) return MIK_OK;
-    const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
+    const int grid = (int)std::min<int64_t>(nseg, mik_max_grid(ctx));
     if (vec)
         hipLaunchKernelGGL((k_map<T, true, Op>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, seg_out, done);
     else
@@ -207,7 +207,7 @@ static inline int launch_map2(mik_ctx *ctx, int64_t n, Op op, bool vec, T *seg1,
 {
     const int64_t nseg = mik_nseg<T>(n);
     if (nseg == 0) return MIK_OK;
-    const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
+    const int grid = (int)std::min<int64_t>(nseg, mik_max_grid(ctx));
     if (vec) hipLaunchKernelGGL((k_map2<T, true, Op>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, seg1, seg2, done);
     else hipLaunchKernelGGL((k_map2<T, false, Op>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, seg1, seg2, done);
     MIK_LAUNCH_CHECK(ctx);
@@ -254,7 +254,7 @@ static inline int launch_map_with(mik_ctx *ctx, int64_t n, Op op, Pro pro, bool 
 {
     const int64_t nseg = mik_nseg<T>(n);
     if (nseg == 0) return MIK_OK;
-    const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
+    const int grid = (int)std::min<int64_t>(nseg, mik_max_grid(ctx));
     if (vec) hipLaunchKernelGGL((k_map_with<T, true, Op, Pro>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, pro, part, m, seg_out);
     else hipLaunchKernelGGL((k_map_with<T, false, Op, Pro>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, op, pro, part, m, seg_out);
     MIK_LAUNCH_CHECK(ctx);

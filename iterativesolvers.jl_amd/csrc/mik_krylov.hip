@@ -118,7 +118,7 @@ static int gemv_n_dev(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, c
 {
     const int64_t nseg = mik_nseg<T>(n);
     if (nseg == 0 || k == 0) return MIK_OK;
-    const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
+    const int grid = (int)std::min<int64_t>(nseg, mik_max_grid(ctx));
     const bool vec = mik_aligned16(V) && mik_aligned16(y) && (ldv % VT<T>::W == 0);
     if (vec) hipLaunchKernelGGL((k_gemv_n<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, cf_dev, alpha, y, mik_basis_nt<T>(ctx, n, k, 2));
     else hipLaunchKernelGGL((k_gemv_n<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, cf_dev, alpha, y, 0);
@@ -182,7 +182,7 @@ static int multidot(mik_ctx *ctx, int64_t n, int k, const T *V, int64_t ldv, con
         MIK_HIP(ctx, hipMemsetAsync(out_dev, 0, sizeof(T) * k, ctx->stream));
         return MIK_OK;
     }
-    const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
+    const int grid = (int)std::min<int64_t>(nseg, mik_max_grid(ctx));
     const bool vec = mik_aligned16(V) && mik_aligned16(w) && (ldv % VT<T>::W == 0);
     if (vec) hipLaunchKernelGGL((k_multidot<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, w, (T *)ctx->partials, mik_basis_nt<T>(ctx, n, k, 4));
     else hipLaunchKernelGGL((k_multidot<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, k, V, ldv, w, (T *)ctx->partials, 0);
@@ -1112,6 +1112,7 @@ struct mik_gmres {
     // single-launch Modified Gram-Schmidt (k_mgs_fused): slot buffers [2][restart + 1][256] and the host-mapped mirror of (h, nrm)
     void *mgs_P = nullptr;
     int mgs_G = 1, mgs_stride = 256;  // segments per workgroup of the single-launch kernels; slots per row of mgs_P
+    int gs_timeouts = 0;             // how often a single-launch column came back timed out (mik_dev_gmres_form)
     bool fused_off = false;          // latched when the single-launch kernel's bounded spin expired once: multi-launch chains from then on
     unsigned *xl_chk = nullptr;      // device, 2 words: XCC id + 1 of the participants of the XCD-local form (k_mgs_fused XL), per parity
     bool xl_off = false;             // the XCD-local form failed once (its workgroups were not on one XCD, or a wait expired): all-XCD form from then on
@@ -1374,9 +1375,9 @@ static int orthogonalize_link(mik_gmres *g, int k, const T *V, int64_t ldv, T *w
         return plink_check(pl, "gmres (row-partitioned)");
     };
     T nrm;
-    if (method == MIK_MGS && nseg <= 256 && ctx->tuning[MIK_KNOB_GS] != 1) {
+    if (method == MIK_MGS && nseg <= mik_resident_cap(ctx) && ctx->tuning[MIK_KNOB_GS] != 1) {
         // the launch-lean chain: every pass finalises AND exchanges the previous reduction itself (k + 2 launches; csrc/mik_comm.hip plink_mgs_lean).
-        // Up to 256 segments: every workgroup of a pass spins on the mailbox, and ranks that share a GPU must all be resident on it.
+        // At most one segment per compute unit (256 on an unpartitioned MI355X): every workgroup of a pass spins on the mailbox, and ranks that share a GPU must all be resident on it.
         MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * 2048));
         MIK_TRY(plink_mgs_lean(pl, n, k, V, ldv, w, hd, ctx->partials, vec, vecw, mik_mgs_pass_hints(ctx, n, sizeof(T))));
         MIK_TRY(download(0, out.data(), k + 1));
@@ -1612,13 +1613,17 @@ static int gmres_create_common(mik_ctx *ctx, const mik_csr *A, void *x, const vo
     }
     {
         const int64_t nseg = dtype == MIK_F64 ? mik_nseg<double>(n) : mik_nseg<float>(n);
-        // single-launch Gram-Schmidt: up to 2048 reduction segments, G = 1 / 2 / 4 / 8 of them per workgroup (<= 256 workgroups, one
-        // per CU); more than 256 segments need the library's own 16-byte aligned V (always the case here)
+        // single-launch Gram-Schmidt: G = 1 / 2 / 4 / 8 reduction segments per workgroup, one workgroup per compute unit at most;
+        // G > 1 needs the library's own 16-byte aligned V (always the case here)
         // (a row partition: only with a device-driven link, Modified Gram-Schmidt and restart <= 62 -- the totals of a launch's passes travel
         // between the ranks through one vector slot per pass, csrc/mik_mail.h MailSumPass)
         const bool part_ok = !part || (part->link && restart <= MIK_MAIL_VEC - 2);   // (one vector mail slot per column total and the norm; DGKS: per round)
-        if (part_ok && nseg >= 1 && nseg <= 2048 && restart <= 254 && (nseg <= 256 || g->ldv % 4 == 0)) {
-            g->mgs_G = nseg <= 256 ? 1 : nseg <= 512 ? 2 : nseg <= 1024 ? 4 : 8;
+        // every workgroup of the launch waits for all the others: at most one per compute unit of THIS device (mik_resident_cap: 256 on an
+        // unpartitioned MI355X, so up to 2048 segments; a 32-CU partition: up to 256), G = the smallest of 1 / 2 / 4 / 8 segments per workgroup that fits
+        const int64_t cap = std::min(mik_resident_cap(ctx), 256);        // (the slot layout of k_mgs_fused / k_cgs_fused holds 256 workgroups)
+        const int G = nseg <= cap ? 1 : nseg <= 2 * cap ? 2 : nseg <= 4 * cap ? 4 : 8;
+        if (part_ok && nseg >= 1 && nseg <= 8 * cap && restart <= 254 && (G == 1 || g->ldv % 4 == 0)) {
+            g->mgs_G = G;
             g->mgs_stride = std::max<int>(256, (int)((nseg + g->mgs_G - 1) / g->mgs_G) * g->mgs_G);
             // k_cgs_fused: one more row per round (the final h values); DGKS: up to 3 rounds in the kernel
             g->mgs_rounds = orth_method == MIK_DGKS ? (ctx->tuning[MIK_KNOB_GS] == 3 ? 1 : 3) : 1;   // DGKS rounds the kernel runs before it hands back to the host loop (MIK_KNOB_GS = 3: one)
@@ -1758,7 +1763,8 @@ template <typename T> static int gm_fused_enqueue(mik_gmres *g, int k, int slot)
     // of at most 512 KB per pass: every column then comes through ONE XCD's share of the fabric (~1 MB per us).  fe_shell (363 KB columns):
     // GMRES(50) 64.2 -> 50.9 us per inner iteration; configs[2] (1 MB columns) would lose (36.5 -> 47.8 us) and keeps the device-wide
     // form.  MIK_KNOB_GS = 4: the device-wide form at every size.
-    const bool xl = g->method == MIK_MGS && G == 1 && vec && m <= 128 && ((size_t)n * sizeof(T) <= (1u << 19) || ctx->tuning[MIK_KNOB_GS] == 5) && !g->xl_off && ctx->tuning[MIK_KNOB_GS] != 4 && g->xl_chk && !g->dist;   // (MIK_KNOB_GS = 5: whatever the column size)
+    // (the form is compiled for the 8-XCD dispatch: blockIdx % 8 == 0 -> first XCD; up to 4 workgroups on each of that XCD's compute units)
+    const bool xl = g->method == MIK_MGS && G == 1 && vec && mik_xcd_maps(ctx) && m <= 4 * (mik_cus(ctx) / mik_xcds(ctx)) && ((size_t)n * sizeof(T) <= (1u << 19) || ctx->tuning[MIK_KNOB_GS] == 5) && !g->xl_off && ctx->tuning[MIK_KNOB_GS] != 4 && g->xl_chk && !g->dist;   // (MIK_KNOB_GS = 5: whatever the column size)
     g->xl_last = xl;
     if (xl) {
         hipLaunchKernelGGL((k_mgs_fused<T, true, 1, true>), dim3(8 * m), dim3(MIK_BLOCK), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart,
@@ -1865,6 +1871,7 @@ template <typename T> static int gmres_iterate_impl(mik_gmres *g, int64_t iterat
             if (rcw == MIK_GS_TIMEOUT && g->dist)      // (no local fall-back over a partition: the ranks' exchange sequences would part ways)
                 return mik_fail(ctx, MIK_ERR_HIP, "gmres (row-partitioned): a hand-off of the single-launch Gram-Schmidt timed out (a peer rank stopped, or the GPU is shared with other work)");
             if (rcw == MIK_GS_TIMEOUT) {
+                g->gs_timeouts += 1;
                 // The hand-off needs every workgroup resident; a GPU shared with other streams or processes can break that.
                 // Not an error of the solve: drain the stream (a column enqueued ahead drains with it), switch this handle to the
                 // multi-launch chains for good, and redo column k from V[:, k - 1], which the kernel never writes.
@@ -1968,6 +1975,19 @@ extern "C" int mik_gmres_iterate_many(mik_gmres *g, int64_t iteration, int64_t m
     return MIK_OK;
 }
 
+// development introspection (include/mik_dev.h): which form the next Arnoldi column's orthogonalize_and_normalize! runs in
+extern "C" int mik_dev_gmres_form(const mik_gmres *g, int *single_launch, int *segments_per_workgroup, int *xcd_local_last, int *timeouts)
+{
+    if (!g) return MIK_ERR_INVALID;
+    const mik_ctx *ctx = g->ctx;
+    const bool single = g->mgs_P && (!g->dist || g->part.link) && !g->fused_off && ctx->tuning[MIK_KNOB_GS] != 1 && ctx->tuning[MIK_KNOB_GS] != 2;
+    if (single_launch) *single_launch = single ? 1 : 0;
+    if (segments_per_workgroup) *segments_per_workgroup = g->mgs_P ? g->mgs_G : 0;
+    if (xcd_local_last) *xcd_local_last = g->xl_last ? 1 : 0;
+    if (timeouts) *timeouts = g->gs_timeouts;
+    return MIK_OK;
+}
+
 extern "C" int mik_gmres_state(const mik_gmres *g, double *residual, double *tol, double *beta, int *k, int64_t *mv_products,
                                int *converged)
 {
@@ -2030,7 +2050,7 @@ __global__ __launch_bounds__(MIK_BLOCK) void k_cgd_early(int64_t m, const int *_
 template <typename T> static int gather_launch(mik_ctx *ctx, int64_t m, const int *idx, const T *x, T *out, const int *done)
 {
     if (m <= 0) return MIK_OK;
-    const int grid = (int)std::min<int64_t>((m + MIK_BLOCK - 1) / MIK_BLOCK, MIK_MAX_GRID);
+    const int grid = (int)std::min<int64_t>((m + MIK_BLOCK - 1) / MIK_BLOCK, mik_max_grid(ctx));
     hipLaunchKernelGGL((k_gather<T>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, m, idx, x, out, done);
     MIK_LAUNCH_CHECK(ctx);
     return MIK_OK;
@@ -2291,7 +2311,7 @@ template <typename T> static int cgd_phase_impl(mik_cgd *it, int phase, int64_t 
     }
     case 9: {  // step A, early part as one launch (every send index occurs once: mik_cgd_set_halo_plan)
         if (it->n_early <= 0 || !it->early_merged) return mik_fail(ctx, MIK_ERR_INVALID, "mik_cgd_phase: no merged early part");
-        const int grid = (int)std::min<int64_t>((it->n_send + MIK_BLOCK - 1) / MIK_BLOCK, MIK_MAX_GRID);
+        const int grid = (int)std::min<int64_t>((it->n_send + MIK_BLOCK - 1) / MIK_BLOCK, mik_max_grid(ctx));
         hipLaunchKernelGGL((k_cgd_early<T>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, it->n_send, it->send_idx, (const T *)r, u, x, (const T *)&d->beta,
                            (const T *)&d->alpha, done, (const int *)&d->x_pending, bs.fuse_x ? 1 : 0, (T *)it->send_buf);
         MIK_LAUNCH_CHECK(ctx);
@@ -2496,7 +2516,7 @@ extern "C" int mik_gemv_t(mik_ctx *ctx, int dtype, int64_t n, int k, const void 
 template <typename T, int K> static int gram_launch(mik_ctx *ctx, int64_t n, const T *V, int64_t ldv)
 {
     const int64_t nseg = mik_nseg<T>(n);
-    const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
+    const int grid = (int)std::min<int64_t>(nseg, mik_max_grid(ctx));
     const bool vec = mik_aligned16(V) && (ldv % VT<T>::W == 0);
     if (vec) hipLaunchKernelGGL((k_gram<T, true, K>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, V, ldv, (T *)ctx->partials);
     else hipLaunchKernelGGL((k_gram<T, false, K>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, V, ldv, (T *)ctx->partials);
@@ -2548,7 +2568,7 @@ static int bicg_mr_impl(mik_ctx *ctx, int64_t n, int l, T *us, int64_t ldu, T *r
     MIK_TRY(mik_ensure_partials(ctx, sizeof(T) * (size_t)nseg));
     BicgGamma<T> gm{};
     for (int j = 0; j < l; ++j) gm.g[j] = gamma[j];
-    const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
+    const int grid = (int)std::min<int64_t>(nseg, mik_max_grid(ctx));
     const bool vec = mik_aligned16(us) && mik_aligned16(rs) && mik_aligned16(x) && (ldu % VT<T>::W == 0) && (ldr % VT<T>::W == 0);
     if (vec) hipLaunchKernelGGL((k_bicg_mr<T, true>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, l, us, ldu, rs, ldr, x, gm, (T *)ctx->partials, (const T *)nullptr);
     else hipLaunchKernelGGL((k_bicg_mr<T, false>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, l, us, ldu, rs, ldr, x, gm, (T *)ctx->partials, (const T *)nullptr);

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(MIK_FIN_THREADS) void k_bicg_fin_norm(const T *__re
 template <typename T, int K> int gram_partials(mik_ctx *ctx, int64_t n, const T *V, int64_t ldv)
 {
     const int64_t nseg = mik_nseg<T>(n);
-    const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
+    const int grid = (int)std::min<int64_t>(nseg, mik_max_grid(ctx));
     const bool vec = mik_aligned16(V) && (ldv % VT<T>::W == 0);
     if (vec) hipLaunchKernelGGL((k_gram<T, true, K>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, V, ldv, (T *)ctx->partials);
     else hipLaunchKernelGGL((k_gram<T, false, K>), dim3(grid), dim3(MIK_BLOCK), 0, ctx->stream, n, nseg, V, ldv, (T *)ctx->partials);
@@ -371,7 +371,7 @@ template <typename T> static int bicg_step_impl(mik_bicgstab *it, T *residual)
         MIK_LAUNCH_CHECK(ctx);
     }
     {
-        const int grid = (int)std::min<int64_t>(nseg, MIK_MAX_GRID);
+        const int grid = (int)std::min<int64_t>(nseg, mik_max_grid(ctx));
         const bool vec = mik_aligned16(us) && mik_aligned16(rs) && mik_aligned16(x) && (it->ldu % VT<T>::W == 0) && (it->ldr % VT<T>::W == 0);
         BicgGamma<T> gm{};
         // (+ the segment sums of dot(r_shadow, new residual): rho of the next step's first column, while the residual is in registers)

@@ -415,10 +415,7 @@ int upload_device_t(mik_ctx *ctx, mik_csr *A, int64_t n_rows, int64_t n_cols, in
     if (hs.dup || hs.max_row > long_row || hs.max_row > 256) { rc = MIK_ERR_NOTIMPL; goto give_up; }
     A->max_row_nnz = hs.max_row;
     A->max_rowblock_nnz = hs.max_rb;
-    {
-        const int64_t P = ((hs.bw + MIK_BLOCK - 1) / MIK_BLOCK + 7) / 8 * 8;
-        A->strip = (P >= 8 && P <= nb / 4) ? (int)P : 0;
-    }
+    A->strip = mik_strip_for(ctx, hs.bw, nb);
     // ---- the per-slice-offset layouts -------------------------------------------------------------------------
     if ((ctx->tuning[MIK_KNOB_LAYOUTS] & 1) == 0 && (ctx->tuning[MIK_KNOB_LAYOUTS] & 4) == 0 && n_cols > 0) {
         int *doff = nullptr, *dtri = nullptr, *dptr = nullptr, *first_row = nullptr;

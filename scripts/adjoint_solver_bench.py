@@ -25,11 +25,11 @@ import torch  # noqa: E402
 
 N = args.grid
 n, colptr, rowval, nzval = pkg.fixtures.laplace_matrix(N, 3)
-A = pkg.HipCSR.with_adjoint(n, n, colptr, rowval, nzval, index_base=1)
+A = pkg.extras.with_adjoint(n, n, colptr, rowval, nzval, index_base=1)
 del colptr, rowval, nzval
 b = pkg.HipVector.from_numpy(pkg.fixtures.hashed_rhs(n))
-out = {"grid": N, "n": n, "operator_layout": A.layout(), "adjoint_layout": pkg.adjoint(A).layout()}
-spmv = A.spmv_stored_bytes() + pkg.adjoint(A).spmv_stored_bytes()
+out = {"grid": N, "n": n, "operator_layout": A.layout(), "adjoint_layout": pkg.extras.adjoint(A).layout()}
+spmv = A.spmv_stored_bytes() + pkg.extras.adjoint(A).spmv_stored_bytes()
 
 
 def run(name, fn, words):
@@ -50,10 +50,10 @@ def run(name, fn, words):
 
 
 # words per row of the sweeps of one iteration (reads + writes): fused / unfused as the reference writes them
-run("lsqr", lambda k: pkg.lsqr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, log=True)[1], 3 + 2 + 3 + 2 + 5)
-run("lsqr_statement_by_statement", lambda k: pkg.lsqr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, log=True, fused=False)[1], 3 + 1 + 2 + 3 + 1 + 2 + 3 + 3 + 2 + 2 + 1)
-run("lsmr", lambda k: pkg.lsmr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, log=True)[1], 3 + 2 + 3 + 2 + 7)
-run("lsmr_statement_by_statement", lambda k: pkg.lsmr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, log=True, fused=False)[1], 3 + 1 + 2 + 3 + 1 + 2 + 3 + 3 + 3 + 1)
-run("qmr", lambda k: pkg.qmr(A, b, maxiter=k, reltol=0.0, log=True)[1], 2 + 4 + 5 + 4 + 6)
-run("qmr_statement_by_statement", lambda k: pkg.qmr(A, b, maxiter=k, reltol=0.0, log=True, fused=False)[1], 2 + 3 + 3 + 2 + 3 + 3 + 2 + 2 + 2 + 2 + 3 + 3 + 2 + 3 + 2 + 2)
+run("lsqr", lambda k: pkg.extras.lsqr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, log=True)[1], 3 + 2 + 3 + 2 + 5)
+run("lsqr_statement_by_statement", lambda k: pkg.extras.lsqr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, log=True, fused=False)[1], 3 + 1 + 2 + 3 + 1 + 2 + 3 + 3 + 2 + 2 + 1)
+run("lsmr", lambda k: pkg.extras.lsmr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, log=True)[1], 3 + 2 + 3 + 2 + 7)
+run("lsmr_statement_by_statement", lambda k: pkg.extras.lsmr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, log=True, fused=False)[1], 3 + 1 + 2 + 3 + 1 + 2 + 3 + 3 + 3 + 1)
+run("qmr", lambda k: pkg.extras.qmr(A, b, maxiter=k, reltol=0.0, log=True)[1], 2 + 4 + 5 + 4 + 6)
+run("qmr_statement_by_statement", lambda k: pkg.extras.qmr(A, b, maxiter=k, reltol=0.0, log=True, fused=False)[1], 2 + 3 + 3 + 2 + 3 + 3 + 2 + 2 + 2 + 2 + 3 + 3 + 2 + 3 + 2 + 2)
 print(json.dumps(out))

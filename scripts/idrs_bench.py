@@ -35,7 +35,7 @@ def shadow(n, dtype=np.float64):
 
 
 def timed(A, b, P, fused, cycles):
-    it = pkg.idrs_iterable_(None, pkg.zerox(A, b), A, b, S, None, 0.0, 0.0, 10 ** 9, P=P, fused=fused)
+    it = pkg.extras.idrs_iterable_(None, pkg.zerox(A, b), A, b, S, None, 0.0, 0.0, 10 ** 9, P=P, fused=fused)
     state = (1, 1)
     for _ in range(S + 1):
         _, state = it.iterate(state)

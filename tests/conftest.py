@@ -58,8 +58,8 @@ def _development_knobs_back_to_default(request):
 
 class KN:
     """the development knobs of include/mik_dev.h by name (tests/test_abi.py checks this table against the header's enum)"""
-    LAYOUTS, CSR_KERNEL, SDIA_KERNEL, LONG_SEGMENT, UPLOAD, GS, TRANSPORT, NO_LOOKAHEAD, SOLVER_FORM, GS_TIMEOUT, CG_STEP, HOST_WAIT = range(12)
-    COUNT = 12
+    LAYOUTS, CSR_KERNEL, SDIA_KERNEL, LONG_SEGMENT, UPLOAD, GS, TRANSPORT, NO_LOOKAHEAD, SOLVER_FORM, GS_TIMEOUT, CG_STEP, HOST_WAIT, MACHINE = range(13)
+    COUNT = 13
     # bits of LAYOUTS
     CSR_ONLY, NO_SLICE_CONSTANT, NO_SLICE_OFFSETS, NO_JAGGED, JAGGED_ALWAYS, NO_XWIN, XWIN_UNUSED = 1, 2, 4, 8, 16, 32, 64
     # bits of CG_STEP

@@ -25,11 +25,11 @@ def test_boundary_header_is_free_of_development_knobs():
 
 
 def test_development_knob_table_is_small_named_and_every_knob_is_referenced_by_a_test():
-    """VERDICT r4 #8: include/mik_dev.h holds at most 12 knobs; tests/conftest.py's KN mirrors the enum; every knob is used by a test."""
+    """include/mik_dev.h holds at most 12 knobs (+ the machine-shape override of VERDICT r5 #4); tests/conftest.py's KN mirrors the enum; every knob is used by a test."""
     from conftest import KN
     src = re.sub(r"/\*.*?\*/", "", open(DEV_HEADER).read(), flags=re.S)
     enum = {m.group(1): int(m.group(2)) for m in re.finditer(r"MIK_KNOB_([A-Z_]+)\s*=\s*(\d+)", src)}
-    assert enum.pop("COUNT") == len(enum) <= 12
+    assert enum.pop("COUNT") == len(enum) <= 13
     assert {k: getattr(KN, k) for k in enum} == enum and KN.COUNT == len(enum)
     tests = "".join(open(os.path.join(ROOT, "tests", f)).read() for f in sorted(os.listdir(os.path.join(ROOT, "tests"))) if f.startswith("test_") and f.endswith(".py"))
     for name, key in enum.items():
@@ -53,7 +53,7 @@ def test_library_exports_every_declared_symbol(pkg):
 def test_ctypes_binding_covers_header(pkg):
     assert sorted(pkg._lib.SIGNATURES) == declared_symbols()
     L = pkg.lib()
-    assert L.mik_abi_version() == 5
+    assert L.mik_abi_version() == 6
 
 
 def test_reduce_shape_is_exported_constant(pkg):

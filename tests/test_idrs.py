@@ -184,7 +184,7 @@ def test_python_mirror_equals_the_c_oracle_on_a_host_double(pkg, orc, monkeypatc
     oracle's SEQ primitives (tests/host_double.py): history, counters and solution equal the C restatement bit for bit, fp64 and fp32."""
     from importlib import import_module
     from host_double import FakeOperator, FakeVector, patch
-    api = import_module(pkg.__name__ + ".api")
+    api = import_module(pkg.__name__ + ".extras")
     patch(monkeypatch, api, orc)
     rng = np.random.default_rng(31 + s)
     n = 30
@@ -243,9 +243,9 @@ def test_idrs_device_bit_exact(pkg, orc, ctx, dtype, name, s, smoothing, precond
         if precond:
             kw["Pl"] = pkg.JacobiPrec(pkg.HipVector.from_numpy(d))
         if start:
-            x, ch = pkg.idrs_(pkg.HipVector.from_numpy(x0), dA, pkg.HipVector.from_numpy(b), **kw)
+            x, ch = pkg.extras.idrs_(pkg.HipVector.from_numpy(x0), dA, pkg.HipVector.from_numpy(b), **kw)
         else:
-            x, ch = pkg.idrs(dA, pkg.HipVector.from_numpy(b), **kw)
+            x, ch = pkg.extras.idrs(dA, pkg.HipVector.from_numpy(b), **kw)
         assert ch.iters == ho["iters"] and ch.mvps == ho["mvps"] and ch.isconverged == ho["isconverged"], fused
         assert np.array_equal(ch["resnorm"], ho["resnorm"]), fused
         assert np.array_equal(x.to_numpy(), xo), fused
@@ -267,7 +267,7 @@ def test_idrs_device_on_badly_scaled_systems(pkg, orc, ctx, dtype, scale):
     assert np.all(np.isfinite(ho["resnorm"])) and ho["iters"] == 40
     dA = pkg.HipCSR(n, n, A.colptr, A.rowval, A.nzval)
     for fused in (True, False):
-        x, ch = pkg.idrs(dA, pkg.HipVector.from_numpy(b), s=4, P=P, maxiter=40, log=True, fused=fused)
+        x, ch = pkg.extras.idrs(dA, pkg.HipVector.from_numpy(b), s=4, P=P, maxiter=40, log=True, fused=fused)
         assert ch.iters == ho["iters"] and np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo), fused
 
 
@@ -282,7 +282,7 @@ def test_idrs_device_beyond_1024_segments(pkg, orc, ctx):
     dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval)
     for layout in ("auto", "csr"):
         dA.set_layout(layout)
-        x, ch = pkg.idrs(dA, pkg.HipVector.from_numpy(b), s=4, P=P, maxiter=14, reltol=0.0, log=True)
+        x, ch = pkg.extras.idrs(dA, pkg.HipVector.from_numpy(b), s=4, P=P, maxiter=14, reltol=0.0, log=True)
         assert ch.iters == 14 and np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo), layout
 
 
@@ -292,7 +292,7 @@ def test_idrs_state_and_argument_checks(pkg, orc, ctx):
     n = A.n
     P = np.random.default_rng(9).random((n, 5))
     dA = pkg.HipCSR(n, n, A.colptr, A.rowval, A.nzval)
-    its = [pkg.idrs_iterable_(None, pkg.zerox(dA, pkg.HipVector.from_numpy(b)), dA, pkg.HipVector.from_numpy(b), 5, None, 0.0, 1e-8, 100, P=P, fused=f)
+    its = [pkg.extras.idrs_iterable_(None, pkg.zerox(dA, pkg.HipVector.from_numpy(b)), dA, pkg.HipVector.from_numpy(b), 5, None, 0.0, 1e-8, 100, P=P, fused=f)
            for f in (True, False)]
     for it in its:
         state = (1, 1)

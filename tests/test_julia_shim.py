@@ -56,7 +56,7 @@ def test_every_ccall_matches_the_c_abi(pkg):
 
 def test_call_sequences_equal_the_python_mirror():
     """the C calls behind cg_iterator! / iterate / gmres_iterable! in MIK.jl, in order, are the ones api.py makes"""
-    api = open(os.path.join(ROOT, "iterativesolvers.jl_amd", "api.py")).read()
+    api = open(os.path.join(ROOT, "iterativesolvers.jl_amd", "api.py")).read() + "\n" + open(os.path.join(ROOT, "iterativesolvers.jl_amd", "extras.py")).read()
 
     def py_calls(cls, method):
         i = api.index(f"class {cls}")

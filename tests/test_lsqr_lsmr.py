@@ -67,7 +67,7 @@ def test_adjoint_needs_an_operator_uploaded_with_it(pkg):
     class Plain:
         pass
     with pytest.raises(pkg.MikError):
-        pkg.adjoint(Plain())
+        pkg.extras.adjoint(Plain())
 
 
 # ---- device ------------------------------------------------------------------------------------------
@@ -89,13 +89,13 @@ def test_lsqr_device_bit_exact(pkg, orc, ctx, dtype, shape, damp, start):
     b = rng.standard_normal(m).astype(dtype)
     x0 = rng.standard_normal(n).astype(dtype) if start else None
     xo, ho = orc.lsqr(S, b, x0, damp=damp, maxiter=60, mode="tree", shape=ctx.reduce_shape(dtype))
-    dA = pkg.HipCSR.from_scipy(S, adjoint=True)
-    assert (dA.size(1), dA.size(2)) == (m, n) and (pkg.adjoint(dA).size(1), pkg.adjoint(dA).size(2)) == (n, m)
+    dA = pkg.extras.with_adjoint_from_scipy(S)
+    assert (dA.size(1), dA.size(2)) == (m, n) and (pkg.extras.adjoint(dA).size(1), pkg.extras.adjoint(dA).size(2)) == (n, m)
     for fused in (True, False):                  # the fused sweeps (mik_xpby_nrm2, mik_lsqr_update) and one L1 call per statement: same bits
         if start:
-            x, ch = pkg.lsqr_(pkg.HipVector.from_numpy(x0), dA, pkg.HipVector.from_numpy(b), damp=damp, maxiter=60, log=True, fused=fused)
+            x, ch = pkg.extras.lsqr_(pkg.HipVector.from_numpy(x0), dA, pkg.HipVector.from_numpy(b), damp=damp, maxiter=60, log=True, fused=fused)
         else:
-            x, ch = pkg.lsqr(dA, pkg.HipVector.from_numpy(b), damp=damp, maxiter=60, log=True, fused=fused)
+            x, ch = pkg.extras.lsqr(dA, pkg.HipVector.from_numpy(b), damp=damp, maxiter=60, log=True, fused=fused)
         assert ch.iters == ho["iters"] > 5 and ch.mvps == ho["mvps"] and ch.mtvps == ho["mtvps"] and ch.isconverged == ho["isconverged"], fused
         for key in ("resnorm", "anorm", "rnorm", "cnorm"):
             assert np.array_equal(ch[key], ho[key]), (key, fused)
@@ -112,12 +112,12 @@ def test_lsmr_device_bit_exact(pkg, orc, ctx, dtype, shape, lam, start):
     b = rng.standard_normal(m).astype(dtype)
     x0 = rng.standard_normal(n).astype(dtype) if start else None
     xo, ho = orc.lsmr(S, b, x0, lam=lam, maxiter=60, mode="tree", shape=ctx.reduce_shape(dtype))
-    dA = pkg.HipCSR.from_scipy(S, adjoint=True)
+    dA = pkg.extras.with_adjoint_from_scipy(S)
     for fused in (True, False):                  # mik_xpby_nrm2 + mik_lsmr_update, and one L1 call per statement: same bits
         if start:
-            x, ch = pkg.lsmr_(pkg.HipVector.from_numpy(x0), dA, pkg.HipVector.from_numpy(b), lam=lam, maxiter=60, log=True, fused=fused)
+            x, ch = pkg.extras.lsmr_(pkg.HipVector.from_numpy(x0), dA, pkg.HipVector.from_numpy(b), lam=lam, maxiter=60, log=True, fused=fused)
         else:
-            x, ch = pkg.lsmr(dA, pkg.HipVector.from_numpy(b), lam=lam, maxiter=60, log=True, fused=fused)
+            x, ch = pkg.extras.lsmr(dA, pkg.HipVector.from_numpy(b), lam=lam, maxiter=60, log=True, fused=fused)
         assert ch.iters == ho["iters"] > 5 and ch.mvps == ho["mvps"] and ch.mtvps == ho["mtvps"] and ch.isconverged == ho["isconverged"], fused
         for key in ("anorm", "rnorm", "cnorm"):
             assert np.array_equal(ch[key], ho[key]), (key, fused)
@@ -131,13 +131,13 @@ def test_lsqr_lsmr_device_sol_known_answer(pkg, orc, ctx):
         A = sol_matrix(m, n)
         xt = np.arange(n, 0, -1, dtype=np.float64)
         b = A @ xt
-        dA = pkg.HipCSR.from_scipy(A, adjoint=True)
-        x = pkg.lsqr(dA, pkg.HipVector.from_numpy(b), atol=1e-6, btol=1e-6, conlim=1e10, maxiter=10 * n)
+        dA = pkg.extras.with_adjoint_from_scipy(A)
+        x = pkg.extras.lsqr(dA, pkg.HipVector.from_numpy(b), atol=1e-6, btol=1e-6, conlim=1e10, maxiter=10 * n)
         assert np.linalg.norm(b - A @ x.to_numpy()) <= 1e-4
-        x = pkg.lsmr(dA, pkg.HipVector.from_numpy(b), atol=1e-7, btol=1e-7, conlim=1e10, maxiter=10 * n)
+        x = pkg.extras.lsmr(dA, pkg.HipVector.from_numpy(b), atol=1e-7, btol=1e-7, conlim=1e10, maxiter=10 * n)
         assert np.linalg.norm(b - A @ x.to_numpy()) <= 1e-4
         y = pkg.HipVector.from_numpy(np.zeros(n))
-        pkg.mul_(y, pkg.adjoint(dA), pkg.HipVector.from_numpy(b))
+        pkg.mul_(y, pkg.extras.adjoint(dA), pkg.HipVector.from_numpy(b))
         assert np.allclose(y.to_numpy(), A.T @ b, rtol=1e-14, atol=0)
 
 
@@ -150,7 +150,7 @@ def test_python_mirrors_equal_the_c_oracle_on_a_host_double(pkg, orc, monkeypatc
     (C, Python) from the same reference lines; on the GPU the same Python code is compared in TREE mode (tests below)."""
     from importlib import import_module
     from host_double import FakeOperator, FakeVector, patch
-    api = import_module(pkg.__name__ + ".api")
+    api = import_module(pkg.__name__ + ".extras")
     patch(monkeypatch, api, orc)
     rng = np.random.default_rng(23)
     m, n = shape
@@ -182,12 +182,12 @@ def test_lsqr_lsmr_qmr_device_across_operator_layouts(pkg, orc, ctx):
     shape = ctx.reduce_shape(np.float64)
     ref = {"lsqr": orc.lsqr(S, b, maxiter=40, mode="tree", shape=shape), "lsmr": orc.lsmr(S, b, maxiter=40, mode="tree", shape=shape),
            "qmr": orc.qmr(S, b, maxiter=40, mode="tree", shape=shape)}
-    dA = pkg.HipCSR.with_adjoint(A.n, A.n, A.colptr, A.rowval, A.nzval)
-    assert dA.layout() != "csr-rowblock" and pkg.adjoint(dA).layout() == dA.layout()
+    dA = pkg.extras.with_adjoint(A.n, A.n, A.colptr, A.rowval, A.nzval)
+    assert dA.layout() != "csr-rowblock" and pkg.extras.adjoint(dA).layout() == dA.layout()
     for layout in ("auto", "csr"):
         dA.set_layout(layout)
-        pkg.adjoint(dA).set_layout(layout)
-        for name, fn in (("lsqr", pkg.lsqr), ("lsmr", pkg.lsmr), ("qmr", pkg.qmr)):
+        pkg.extras.adjoint(dA).set_layout(layout)
+        for name, fn in (("lsqr", pkg.extras.lsqr), ("lsmr", pkg.extras.lsmr), ("qmr", pkg.extras.qmr)):
             x, ch = fn(dA, pkg.HipVector.from_numpy(b), maxiter=40, log=True)
             xo, ho = ref[name]
             assert ch.iters == ho["iters"] and np.array_equal(x.to_numpy(), xo), (name, layout)
@@ -205,15 +205,15 @@ def test_lsqr_lsmr_device_on_a_badly_scaled_operator(pkg, orc, ctx, scale):
     S = (_rect(rng, 200, 90, 0.06, np.float64) * scale).tocsc()
     b = rng.standard_normal(200)
     shape = ctx.reduce_shape(np.float64)
-    dA = pkg.HipCSR.from_scipy(S, adjoint=True)
+    dA = pkg.extras.with_adjoint_from_scipy(S)
     xo, ho = orc.lsqr(S, b, maxiter=25, atol=0.0, btol=0.0, conlim=0.0, mode="tree", shape=shape)
     assert np.all(np.isfinite(ho["resnorm"])) and ho["iters"] > (5 if scale < 1 else 0)     # (1e137: the reference's own 1 + test3 <= 1 stops it after one iteration)
     for fused in (True, False):
-        x, ch = pkg.lsqr(dA, pkg.HipVector.from_numpy(b), maxiter=25, atol=0.0, btol=0.0, conlim=0.0, log=True, fused=fused)
+        x, ch = pkg.extras.lsqr(dA, pkg.HipVector.from_numpy(b), maxiter=25, atol=0.0, btol=0.0, conlim=0.0, log=True, fused=fused)
         assert ch.iters == ho["iters"] and np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(ch["cnorm"], ho["cnorm"]), fused
         assert np.array_equal(x.to_numpy(), xo), fused
     xo, ho = orc.lsmr(S, b, maxiter=25, atol=0.0, btol=0.0, conlim=0.0, mode="tree", shape=shape)
     assert ho["iters"] >= 1                      # (LSMR's condA starts from rhobar = 1, src/lsmr.jl:126: it stops after one iteration on such operators)
     for fused in (True, False):
-        x, ch = pkg.lsmr(dA, pkg.HipVector.from_numpy(b), maxiter=25, atol=0.0, btol=0.0, conlim=0.0, log=True, fused=fused)
+        x, ch = pkg.extras.lsmr(dA, pkg.HipVector.from_numpy(b), maxiter=25, atol=0.0, btol=0.0, conlim=0.0, log=True, fused=fused)
         assert ch.iters == ho["iters"] and np.array_equal(ch["rnorm"], ho["rnorm"]) and np.array_equal(x.to_numpy(), xo), fused

@@ -29,7 +29,7 @@ def test_python_mirror_equals_the_c_oracle_on_a_host_double(pkg, orc, monkeypatc
     import scipy.sparse as sp
     from importlib import import_module
     from host_double import FakeOperator, FakeVector, patch
-    api = import_module(pkg.__name__ + ".api")
+    api = import_module(pkg.__name__ + ".extras")
     patch(monkeypatch, api, orc)
     rng = np.random.default_rng(5)
     n = 30
@@ -54,7 +54,7 @@ def test_powm_device_bit_exact_and_inverse_iteration(pkg, orc, ctx, dtype):
     x0 = (x0 / np.linalg.norm(x0)).astype(dtype)
     lo, xo, ho = orc.powm(A, x0, tol=1e-3, maxiter=80, mode="tree", shape=ctx.reduce_shape(dtype))
     dA = pkg.HipCSR(n, n, A.colptr, A.rowval, A.nzval)
-    lam, x, ch = pkg.powm_(dA, pkg.HipVector.from_numpy(x0), tol=1e-3, maxiter=80, log=True)
+    lam, x, ch = pkg.extras.powm_(dA, pkg.HipVector.from_numpy(x0), tol=1e-3, maxiter=80, log=True)
     assert ch.iters == ho["iters"] > 20 and ch.mvps == ho["mvps"] and ch.isconverged == ho["isconverged"]
     assert lam == lo and np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo)
     assert 11.0 < float(lam) < 12.0                                          # the largest eigenvalue of the 7-point Laplacian stays below 12
@@ -68,7 +68,7 @@ def test_powm_device_bit_exact_and_inverse_iteration(pkg, orc, ctx, dtype):
             y.fill_(0)
             pkg.cg_(y, dS, v, reltol=1e-12, maxiter=500)
         B = pkg.LinearOperator(n, np.float64, solve, dA.ctx)
-        lam, x = pkg.invpowm_(B, pkg.HipVector.from_numpy(x0.astype(np.float64)), shift=sigma, tol=1e-6, maxiter=60)
+        lam, x = pkg.extras.invpowm_(B, pkg.HipVector.from_numpy(x0.astype(np.float64)), shift=sigma, tol=1e-6, maxiter=60)
         smallest = 6 - 6 * np.cos(np.pi / 13)                                # eigenvalues of the 12^3 Dirichlet Laplacian: sum of 2 - 2 cos(k pi / 13)
         assert abs(float(lam) - smallest) <= 1e-6 * smallest
         xv = x.to_numpy()

@@ -43,7 +43,7 @@ def test_oracle_qmr_reference_properties(orc, dtype):
 def test_python_mirror_equals_the_c_oracle_on_a_host_double(pkg, orc, monkeypatch, dtype, start):
     from importlib import import_module
     from host_double import FakeOperator, FakeVector, patch
-    api = import_module(pkg.__name__ + ".api")
+    api = import_module(pkg.__name__ + ".extras")
     patch(monkeypatch, api, orc)
     monkeypatch.setattr(api, "givens_algorithm", lambda f, g, dt=np.float64: orc.givens(f, g, dt))
     monkeypatch.setattr(api, "zerox", lambda A, b: FakeVector(np.zeros(A.size(2), b.dtype)))
@@ -76,12 +76,12 @@ def test_qmr_device_bit_exact(pkg, orc, ctx, dtype, name, start):
     n = S.shape[0]
     x0 = rng.standard_normal(n).astype(dtype) if start else None
     xo, ho = orc.qmr(S, b, x0, maxiter=120, mode="tree", shape=ctx.reduce_shape(dtype))
-    dA = pkg.HipCSR.from_scipy(S, adjoint=True)
+    dA = pkg.extras.with_adjoint_from_scipy(S)
     for fused in (True, False):                  # the fused sweeps (mik_axpy2_dot, mik_scal2, mik_qmr_update) and one L1 call per statement: same bits
         if start:
-            x, ch = pkg.qmr_(pkg.HipVector.from_numpy(x0), dA, pkg.HipVector.from_numpy(b), maxiter=120, log=True, fused=fused)
+            x, ch = pkg.extras.qmr_(pkg.HipVector.from_numpy(x0), dA, pkg.HipVector.from_numpy(b), maxiter=120, log=True, fused=fused)
         else:
-            x, ch = pkg.qmr(dA, pkg.HipVector.from_numpy(b), maxiter=120, log=True, fused=fused)
+            x, ch = pkg.extras.qmr(dA, pkg.HipVector.from_numpy(b), maxiter=120, log=True, fused=fused)
         assert ch.iters == ho["iters"] > 10 and ch.isconverged == ho["isconverged"], fused
         assert np.array_equal(ch["resnorm"], ho["resnorm"]) and np.array_equal(x.to_numpy(), xo), fused
     if ho["isconverged"] and dtype == np.float64:                            # resnorm is the QUASI-residual: the true one is within sqrt(k + 1) of it at best
