@@ -62,7 +62,8 @@
 extern "C" {
 #endif
 
-#define MIK_ABI_VERSION 6   /* 6 (round 6): mik_ctx_info / mik_device_info (the machine is queried, not assumed); mik_comm_selftest.
+#define MIK_ABI_VERSION 6   /* 6 (round 6): mik_ctx_info / mik_device_info (the machine is queried, not assumed); mik_plink_exchange;
+                             *   mik_comm_allgather_sum also over a mailbox-only communicator.
                              *   5 (round 5): mik_partition gained `link`; the pushed halo lands in library-owned buffers (mik_plink_*, mik_cgd_ghost_export;
                              *   mik_cgd_connect_ghosts takes ghost counts instead of byte offsets; mik_mem_export is gone); mik_cgd_profile.
                              *   4 (round 4): MIK_ERR_SINGULAR replaces MIK_ERR_INVALID for an exactly singular pivot (mik_lu_solve, mik_bicgstab_step);
@@ -515,7 +516,8 @@ int mik_comm_destroy(mik_comm *comm);
 int mik_comm_info(const mik_comm *comm, int *rank, int *nranks, int *uses_rccl);
 /* values[0..count) (host scalars of dtype, count <= 256): this rank's partial sums in, ((p_0 + p_1) + p_2) + ... over the
  * ranks out, identical on every rank -- exactly the mik_reduce_fn contract, so a row-partitioned GMRES host passes a
- * two-line callback around it.  Blocks (ncclAllGather on the ctx stream + one read-back). */
+ * two-line callback around it.  Blocks (ncclAllGather on the ctx stream + one read-back; a communicator without RCCL sends the
+ * values through the vector slots of its connected mailboxes -- same bits, bounded wait). */
 int mik_comm_allgather_sum(mik_comm *comm, int dtype, int count, void *values);
 /* The mik_halo_fn of a row-partitioned GMRES over RCCL: ncclSend / ncclRecv of the packed buffer into the ghost region
  * on the ctx stream; segments as in mik_cgd_set_halo_plan. */
@@ -571,6 +573,11 @@ int mik_plink_create(mik_comm *comm, int dtype, int64_t n_ghost, int n_recv, con
 int mik_plink_export(mik_plink *link, void *handle64);
 int mik_plink_connect(mik_plink *link, const void *handles, const int64_t *ghost_counts, const int64_t *dst_elem);
 int mik_plink_info(const mik_plink *link, int *connected, int *finegrained, int64_t *n_ghost);
+/* One halo exchange through a connected link, blocking (collective: every rank of the plan calls it): send_buf (device, packed as the
+ * plan's send segments say) is stored into the neighbours' landing buffers, the entries that landed here are copied into ghost (device,
+ * n_ghost entries).  What a host that drives a row-partitioned operator itself passes as its mik_halo_fn, and what the transport
+ * self-test of bench.py --gpus N times.  A peer that never arrives: MIK_ERR_HIP after MIK_MAILBOX_TIMEOUT_MS. */
+int mik_plink_exchange(mik_plink *link, const void *send_buf, void *ghost);
 int mik_plink_destroy(mik_plink *link);
 /* After mik_cgd_set_halo_plan and mik_cgd_set_comm (transport "mailbox"): */
 int mik_cgd_ghost_export(mik_cgd *it, void *handle64);

@@ -182,6 +182,7 @@ SIGNATURES = {
     "mik_plink_export": (C.c_int, [_vp, _vp]),
     "mik_plink_connect": (C.c_int, [_vp, _vp, _i64p, _i64p]),
     "mik_plink_info": (C.c_int, [_vp, _ip, _ip, _i64p]),
+    "mik_plink_exchange": (C.c_int, [_vp, _vp, _vp]),
     "mik_plink_destroy": (C.c_int, [_vp]),
     "mik_cgd_init": (C.c_int, [_vp, _f64p, _f64p]),
     "mik_cgd_iterate_many": (C.c_int, [_vp, _i64, _i64, _f64p, _i64p]),

@@ -324,6 +324,7 @@ __global__ __launch_bounds__(64) void k_halo_wait(const MailBox *__restrict__ mi
     } while (0)
 
 static int mailbox_alloc(mik_comm *cm);
+static int mailbox_check(mik_comm *cm, const char *who);
 
 extern "C" int mik_comm_unique_id(void *id128)
 {
@@ -413,10 +414,26 @@ template <typename T> static int allgather_sum_impl(mik_comm *cm, int count, T *
 {
     mik_ctx *ctx = cm->ctx;
     if (cm->nranks == 1 && !cm->nccl) return MIK_OK;
-    Rccl *R = rccl();
     T *dev = (T *)cm->scratch, *host = (T *)cm->scratch_host;
     MIK_HIP(ctx, mik_wait(ctx));                                       // the pinned staging buffer must be idle
     memcpy(host, values, sizeof(T) * count);
+    if (!cm->nccl) {
+        // a communicator without RCCL ("Transport 3"): the partial sums travel through the vector slots of the connected mailboxes and are
+        // added in rank order by the one-wave exchange kernel -- the same bits; a bounded wait (MIK_ERR_HIP, never a hung queue)
+        if (!cm->mail_ready) return mik_fail(ctx, MIK_ERR_INVALID, "mik_comm_allgather_sum: this communicator has neither RCCL nor connected mailboxes");
+        MIK_HIP(ctx, hipMemcpyAsync(dev, host, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream));
+        const unsigned long long seq0 = cm->vseq + 1;
+        cm->vseq += (unsigned long long)((count + MIK_MAIL_VEC - 1) / MIK_MAIL_VEC);
+        hipLaunchKernelGGL((k_mail_sum_vec<T>), dim3(1), dim3(64), 0, ctx->stream, (MailBox *const *)cm->peers_dev, cm->nranks, cm->rank, seq0, dev, count,
+                           cm->timeout_ticks, cm->mail_err);
+        MIK_LAUNCH_CHECK(ctx);
+        MIK_HIP(ctx, hipMemcpyAsync(host, dev, sizeof(T) * count, hipMemcpyDeviceToHost, ctx->stream));
+        MIK_HIP(ctx, mik_wait(ctx));
+        MIK_TRY(mailbox_check(cm, "mik_comm_allgather_sum"));
+        memcpy(values, host, sizeof(T) * count);
+        return MIK_OK;
+    }
+    Rccl *R = rccl();
     MIK_HIP(ctx, hipMemcpyAsync(dev + (size_t)cm->rank * count, host, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream));
     MIK_NCCL(ctx, R->AllGather(dev + (size_t)cm->rank * count, dev, (size_t)count, sizeof(T) == 8 ? NCCL_F64 : NCCL_F32, cm->nccl, ctx->stream));
     MIK_HIP(ctx, hipMemcpyAsync(host, dev, sizeof(T) * count * cm->nranks, hipMemcpyDeviceToHost, ctx->stream));
@@ -826,6 +843,20 @@ int plink_halo(mik_plink *pl, const void *send_buf, void *ghost)
     const unsigned long long no = ++cm->halo_no;
     MIK_TRY(plink_push(pl, send_buf, no, cm->ctx->stream));
     return plink_land(pl, ghost, no, cm->ctx->stream);
+}
+
+// One halo exchange through the link, blocking: the mik_halo_fn of a host that drives a row-partitioned operator itself, and what a
+// transport self-test times (bench.py --gpus N).  Bounded like every mailbox wait.
+extern "C" int mik_plink_exchange(mik_plink *pl, const void *send_buf, void *ghost)
+{
+    if (!pl || !pl->cm) return MIK_ERR_INVALID;
+    mik_comm *cm = pl->cm;
+    if (!pl->connected || !cm->mail_ready) return mik_fail(cm->ctx, MIK_ERR_INVALID, "mik_plink_exchange: the link (or its communicator's mailbox) is not connected");
+    if ((!pl->send.empty() && !send_buf) || (!pl->recv.empty() && !ghost)) return MIK_ERR_INVALID;
+    (void)hipSetDevice(cm->ctx->device);
+    MIK_TRY(plink_halo(pl, send_buf, ghost));
+    MIK_HIP(cm->ctx, mik_wait(cm->ctx));
+    return mailbox_check(cm, "mik_plink_exchange");
 }
 
 // level 2 of this rank's `nseg` segment sums + the sum over the ranks in rank order, one launch; mode 0: out[0] = sum, 1: out[0] = sqrt(sum), out[1] = 1 / out[0]
