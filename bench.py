@@ -85,20 +85,51 @@ def cpu_baseline_omp(N: int, iters: int):
                       f"(not the reference's serial loop; summation order differs)", "seconds": dt}
 
 
+_LIB_SHA = {}
+
+
+def loaded_library_sha256():
+    """sha256 of the libmik.so this process has loaded (the file the ctypes binding opened)"""
+    import hashlib
+    pkg = graft.load_package()
+    path = pkg._lib.LIB_PATH
+    if path not in _LIB_SHA:
+        _LIB_SHA[path] = hashlib.sha256(open(path, "rb").read()).hexdigest()
+    return _LIB_SHA[path]
+
+
+def traffic_file_matches(t: dict):
+    """Does a committed *_traffic.json describe the binary that is running?  scripts/prof_collect.py records the sha256 of the libmik.so its
+    counters were collected on; files written before round 6 carry none (-> False: their figures are withheld)."""
+    sha = (t.get("_binary") or {}).get("libmik_sha256")
+    return bool(sha) and sha == loaded_library_sha256()
+
+
 def pmc_traffic(kernel_key: str, with_source: bool = False):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_traffic.json,
-    written by scripts/prof_r04.sh + prof_collect.py from separate --pmc runs of this same command: FETCH_SIZE x 2 per the gfx950 note
-    in MI355X_MICROARCH.md + WRITE_SIZE).  None if absent.  A COMMITTED CONSTANT, not a measurement of this run (counters need
-    rocprofv3 around the process): every consumer prints the file it came from next to it (`traffic_source`)."""
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/*bench*_traffic.json, written by
+    scripts/prof_r06.sh + prof_collect.py from separate --pmc runs of this same command: FETCH_SIZE x 2 per the gfx950 note in
+    MI355X_MICROARCH.md + WRITE_SIZE).  A COMMITTED CONSTANT, not a measurement of this run (counters need rocprofv3 around the
+    process) -- therefore tied to the binary: the newest file is used, and only if it was collected on the very libmik.so that is loaded
+    now (`traffic_binary_matches`); otherwise the figure is WITHHELD (None).  with_source: (bytes | None, file, matches)."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*bench*_traffic.json")), reverse=True):     # newest round first
         try:
-            v = json.load(open(f)).get(kernel_key, {}).get("traffic_bytes_per_launch")
+            t = json.load(open(f))
+            v = t.get(kernel_key, {}).get("traffic_bytes_per_launch")
         except Exception:
-            v = None
+            continue
         if v:
-            return (v, os.path.relpath(f, ROOT)) if with_source else v
-    return (None, None) if with_source else None
+            ok = traffic_file_matches(t)
+            return ((v if ok else None), os.path.relpath(f, ROOT), ok) if with_source else (v if ok else None)
+    return (None, None, None) if with_source else None
+
+
+def traffic_fields(kernel_key: str):
+    v, src, ok = pmc_traffic(kernel_key, with_source=True)
+    out = {"traffic": v, "traffic_source": src, "traffic_binary_matches": ok}
+    if src and not ok:
+        out["traffic_withheld"] = "the counters in traffic_source were collected on another build of libmik.so (sha256 differs): re-run scripts/prof_r06.sh"
+    return out
 
 
 def history_parity(N: int, gpu_hist: np.ndarray, gpu_iters: int, gpu_mvps: int, gpu_converged: bool):
@@ -124,6 +155,46 @@ def history_parity(N: int, gpu_hist: np.ndarray, gpu_iters: int, gpu_mvps: int, 
                                                                                  g[key]["isconverged"] == gpu_converged),
                     "gpu_vs_cpu_history_max_rel_dev": float(dev.max()), "at_iteration": int(dev.argmax()) + 1, "steps_compared": int(m),
                     "bit_identical": bool(m == r.size == gpu_hist.size and np.array_equal(gpu_hist, r))}
+
+    # the same solve with dot / norm by OTHER hosts' OpenBLAS kernels (tests/golden/cg_lap<N>_blas_<host>.json, make_golden.py --blas-only): the
+    # committed `blas` above was generated on the build container's Xeon (SkylakeX kernels); the GPU box's EPYC runs Zen kernels, a Julia
+    # installation whatever its OpenBLAS build picks.  Every host must be within the north star's 1e-12; `spread` = how far the hosts are apart.
+    import glob
+    hosts = {}
+    if "blas" in ref:
+        hosts[str((g.get("blas_library") or {}).get("core", "golden")).lower()] = {"blas": ref["blas"], "blas8": ref.get("blas8"), "file": os.path.relpath(path, ROOT),
+                                                                                  "cpu_model": "build container (Intel Xeon)", "core": (g.get("blas_library") or {}).get("core")}
+    for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", f"cg_lap{N}_blas_*.json"))):
+        try:
+            h = json.load(open(f))
+            hosts[h["host_tag"]] = {"blas": np.array([float.fromhex(s) for s in h["blas"]["resnorm"]]),
+                                    "blas8": np.array([float.fromhex(s) for s in h["blas8"]["resnorm"]]) if "blas8" in h else None,
+                                    "file": os.path.relpath(f, ROOT), "cpu_model": h.get("cpu_model"), "core": (h.get("blas_library") or {}).get("core"),
+                                    "forced_coretype": h.get("forced_coretype"), "iters": h["blas"]["iters"], "isconverged": h["blas"]["isconverged"]}
+        except Exception:      # noqa: BLE001
+            continue
+    if hosts:
+        bh = {}
+        for tag, h in hosts.items():
+            rec = {"file": h["file"], "cpu_model": h["cpu_model"], "openblas_core": h["core"], **({"forced_coretype": h["forced_coretype"]} if h.get("forced_coretype") else {})}
+            for key in ("blas", "blas8"):
+                r = h.get(key)
+                if r is None:
+                    continue
+                m = min(r.size, gpu_hist.size)
+                rec[f"gpu_vs_{key}_history_max_rel_dev"] = float(np.max(np.abs(gpu_hist[:m] - r[:m]) / r[:m]))
+                rec[f"{key}_same_iteration_count"] = bool(r.size == gpu_hist.size)
+            bh[tag] = rec
+        tags = list(hosts)
+        spread = 0.0
+        for i in range(len(tags)):
+            for j in range(i + 1, len(tags)):
+                a, b2 = hosts[tags[i]]["blas"], hosts[tags[j]]["blas"]
+                m = min(a.size, b2.size)
+                spread = max(spread, float(np.max(np.abs(a[:m] - b2[:m]) / b2[:m])))
+        out["blas_hosts"] = bh
+        out["blas_hosts_spread_single_thread"] = spread if len(tags) > 1 else None
+        out["blas_hosts_all_within_1e-12"] = bool(all(v.get("gpu_vs_blas_history_max_rel_dev", 1.0) <= 1e-12 for v in bh.values()))
 
     def floor(a, b):
         m = min(ref[a].size, ref[b].size)
@@ -246,6 +317,7 @@ def gmres_hbm_bound(A, b, n: int, restart: int = 30, inner: int = 60, reps: int 
         if tr is not None:
             rec["traffic_per_inner_iteration"] = tr["bytes"]
             rec["traffic_source"] = tr["source"]
+            rec["traffic_binary_matches"] = tr["matches"]
             rec["traffic_is"] = "committed constant: sum over the kernels of one profiled call of 2 x FETCH_SIZE + WRITE_SIZE (separate rocprofv3 --pmc passes), divided by its inner iterations"
         out[name] = rec
         del it
@@ -359,7 +431,8 @@ def gmres_large_traffic(name: str):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*gmres_large_{name}_traffic.json")), reverse=True):
         try:
             t = json.load(open(f))
-            return {"bytes": t["traffic_bytes_per_inner_iteration"], "source": os.path.relpath(f, ROOT)}
+            ok = traffic_file_matches(t)
+            return {"bytes": t["traffic_bytes_per_inner_iteration"] if ok else None, "source": os.path.relpath(f, ROOT), "matches": ok}
         except Exception:
             continue
     return None
@@ -376,8 +449,9 @@ def c5_traffic(kind: str):
             continue
         cand = [v for k2, v in t.items() if k2.startswith("k_spmv") and v.get("traffic_bytes_per_launch")]
         if cand:
-            return max(c["traffic_bytes_per_launch"] for c in cand)
-    return None
+            ok = traffic_file_matches(t)
+            return {"traffic": max(c["traffic_bytes_per_launch"] for c in cand) if ok else None, "traffic_source": os.path.relpath(f, ROOT), "traffic_binary_matches": ok}
+    return {"traffic": None, "traffic_source": None, "traffic_binary_matches": None}
 
 
 def config5(kinds):
@@ -413,7 +487,7 @@ def config5(kinds):
                "rows_longer_than_256": int((lens > 256).sum()), "operator_layout": A.layout(), "kernel": A.spmv_kernel() + "<float>",
                "spmv_us": ms * 1e3, "algorithmic_bytes_per_launch": ab, "bytes_stored_per_launch": sb,
                "achieved": ab / (ms * 1e-3) / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-               "traffic": c5_traffic(kind), "generate_seconds": tgen, "upload_seconds": tup}
+               **c5_traffic(kind), "generate_seconds": tgen, "upload_seconds": tup}
         if ab < 200e6:
             rec["note"] = "operator smaller than the 256 MB Infinity Cache: back-to-back launches are served on-die, `frac` is not an HBM fraction"
         gm = {}
@@ -561,7 +635,7 @@ def run_single(args):
     for kk in step_kernels:
         kk["gbs"] = kk["bytes_moved"] / (kk["avg_launch_ms"] * 1e-3) / 1e9
         kk["frac_of_8000"] = kk["gbs"] / HBM_PEAK_GBS
-        kk["traffic"], kk["traffic_source"] = pmc_traffic(kk["kernel"].split("<")[0] if kk["kernel"].startswith("k_spmv") else kk["kernel"], with_source=True)
+        kk.update(traffic_fields(kk["kernel"].split("<")[0] if kk["kernel"].startswith("k_spmv") else kk["kernel"]))
         if kk["gbs"] > COPY_CEILING_GBS:
             kk["note"] = "above the 6,290 GB/s HBM copy ceiling: part of this sweep is served by the Infinity Cache (the previous launch left it there); frac_of_8000 is then not an HBM fraction"
     del it
@@ -592,19 +666,20 @@ def run_single(args):
     moved_gbs = stored_bytes / (spmv_ms * 1e-3) / 1e9
     iter_moved = stored_bytes + (8 if fx else 9) * n * 8          # bytes ONE step of the loop behind `value` moves (its SpMV + the two sweeps)
     iter_alg = alg_bytes + 9 * n * 8                               # B_cg = B_spmv + 9 n s
-    d_traffic, d_src = pmc_traffic(kern, with_source=True)
+    d_tf = traffic_fields(kern)
     default_spmv = {"kernel": kern + "<double, fused dot>", "operator_layout": layout, "bytes_moved_per_launch": stored_bytes, "avg_launch_ms": spmv_ms,
                     "launches_timed": int(spmv_launches), "back_to_back_ms": b2b_ms, "achieved_moved": moved_gbs, "frac_moved": moved_gbs / HBM_PEAK_GBS,
-                    "frac_of_copy_ceiling_6290": moved_gbs / COPY_CEILING_GBS, "traffic": d_traffic, "traffic_source": d_src,
+                    "frac_of_copy_ceiling_6290": moved_gbs / COPY_CEILING_GBS, **d_tf,
                     "note": "the SpMV of the loop behind `default_layout_iters_per_sec`: this constant-coefficient operator keeps ONE mask byte per row instead of 57 B of values "
                             "and indices, so the launch moves 17 B per row instead of 73; achieved_moved / frac_moved = the bytes it actually streams "
                             "(`traffic`: committed PMC constant) over its HIP-event time inside the loop.  Not the north star's CSR figure: that is `roofline`."}
     if csr is not None:
         c_ms = csr["spmv_in_loop_ms"]
-        c_traffic, c_src = pmc_traffic(csr["kernel"], with_source=True)
+        c_tf = traffic_fields(csr["kernel"])
         roofline = {"bound": "hbm", "kernel": csr["kernel"] + "<double, fused dot>", "loop": "contract_csr_loop" if layout != "csr-rowblock" else "the timed loop",
                     "achieved": alg_bytes / (c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "traffic": c_traffic, "traffic_source": c_src, "traffic_is": "committed constant from separate rocprofv3 --pmc passes of this command, not measured in this run",
+                    **c_tf, "libmik_sha256": loaded_library_sha256(),
+                    "traffic_is": "committed constant from separate rocprofv3 --pmc passes of this command on the binary named by libmik_sha256 (traffic_binary_matches), not measured in this run",
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": c_ms, "launches_timed": csr["launches_timed"],
                     "back_to_back_ms": csr["spmv_back_to_back_ms"], "frac_of_copy_ceiling_6290": alg_bytes / (c_ms * 1e-3) / 1e9 / COPY_CEILING_GBS,
                     # the loop this kernel was timed in -- so that bytes/step / ms_per_step <= peak and avg_launch_ms <= ms_per_step can be checked from here alone
@@ -619,7 +694,7 @@ def run_single(args):
                             "bit-identical results, in the operator's default layout, which moves config.default_layout.bytes_per_step instead (`default_layout_spmv`)."}
     else:
         roofline = {"bound": "hbm", "kernel": kern + "<double, fused dot>", "loop": "the timed loop (contract CSR loop skipped: --no-csr)",
-                    "achieved": moved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved_gbs / HBM_PEAK_GBS, "traffic": d_traffic, "traffic_source": d_src,
+                    "achieved": moved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved_gbs / HBM_PEAK_GBS, **d_tf,
                     "bytes_moved_per_launch": stored_bytes, "avg_launch_ms": spmv_ms,
                     "loop_ms_per_step": dt / K * 1e3, "loop_iters_per_sec": K / dt,
                     "note": "bytes this layout actually moves per launch over the in-loop HIP-event time; NOT the CSR-algorithmic figure"}
@@ -655,6 +730,7 @@ def run_single(args):
         "default_layout_spmv": default_spmv,
         "longest_kernel_of_the_step": (lambda kk: {"kernel": kk["kernel"], "avg_launch_ms": kk["avg_launch_ms"], "bytes_moved": kk["bytes_moved"],
                                                    "frac_of_8000": kk["frac_of_8000"], "traffic": kk["traffic"], "traffic_source": kk["traffic_source"],
+                                                   "traffic_binary_matches": kk["traffic_binary_matches"],
                                                    **({"note": kk["note"]} if "note" in kk else {})})(max(step_kernels, key=lambda q: q["avg_launch_ms"])),
         "step_kernels": step_kernels,
         "cg_iteration_moved_bytes": iter_moved, "cg_iteration_moved_gbs": iter_moved / (dt / K) / 1e9,

@@ -576,7 +576,12 @@ int mik_plink_info(const mik_plink *link, int *connected, int *finegrained, int6
 /* One halo exchange through a connected link, blocking (collective: every rank of the plan calls it): send_buf (device, packed as the
  * plan's send segments say) is stored into the neighbours' landing buffers, the entries that landed here are copied into ghost (device,
  * n_ghost entries).  What a host that drives a row-partitioned operator itself passes as its mik_halo_fn, and what the transport
- * self-test of bench.py --gpus N times.  A peer that never arrives: MIK_ERR_HIP after MIK_MAILBOX_TIMEOUT_MS. */
+ * self-test of bench.py --gpus N times.  A peer that never arrives: MIK_ERR_HIP after MIK_MAILBOX_TIMEOUT_MS.
+ * Invariants of the landing buffers (two halves used alternately, no consumed-acknowledgement; one push ticket per communicator):
+ *   - ONE exchange in flight per communicator: links of one communicator are used from its context's stream, one after the other;
+ *   - a rank must not run two exchanges ahead of a neighbour.  A plan whose send peers equal its receive peers guarantees that by itself;
+ *     any other plan only when a sum over all ranks separates two exchanges -- true for cg! / gmres! (a dot or norm follows every
+ *     product), so the iterables accept such plans; mik_plink_exchange refuses them (MIK_ERR_NOTIMPL). */
 int mik_plink_exchange(mik_plink *link, const void *send_buf, void *ghost);
 int mik_plink_destroy(mik_plink *link);
 /* After mik_cgd_set_halo_plan and mik_cgd_set_comm (transport "mailbox"): */

@@ -651,6 +651,7 @@ struct mik_plink {
     std::vector<unsigned char *> send_dst;      // per send segment: parity 0 of its place in the receiver's landing buffer, as mapped here
     std::vector<size_t> send_stride;            // ... and the receiver's parity stride
     bool connected = false;
+    bool symmetric = true;           // send peers == receive peers (mik_plink_create)
 };
 
 static void plink_orphan(mik_plink *pl) { pl->cm = nullptr; pl->connected = false; }
@@ -705,6 +706,17 @@ extern "C" int mik_plink_create(mik_comm *cm, int dtype, int64_t n_ghost, int n_
         return mik_fail(ctx, MIK_ERR_NOMEM, "mik_plink_create: landing buffer (%zu bytes): %s", 2 * pl->land_stride, hipGetErrorString(e));
     }
     pl->connected = pl->send.empty() && pl->recv.empty();
+    {   // Does every peer this rank sends to also send to this rank?  Then a rank cannot run two exchanges ahead of a neighbour by itself (its
+        // own landing of exchange n + 1 waits for that neighbour's push, which follows the neighbour's landing of exchange n), and the two-parity
+        // landing buffer needs no consumed-acknowledgement.  An asymmetric plan (structurally unsymmetric operators) is safe only because
+        // cg! / gmres! put a sum over ALL ranks between two products; mik_plink_exchange, which has no such sum, refuses it.
+        std::vector<int> sp, rp;
+        for (auto &sg : pl->send) sp.push_back(sg.peer);
+        for (auto &sg : pl->recv) rp.push_back(sg.peer);
+        std::sort(sp.begin(), sp.end()); sp.erase(std::unique(sp.begin(), sp.end()), sp.end());
+        std::sort(rp.begin(), rp.end()); rp.erase(std::unique(rp.begin(), rp.end()), rp.end());
+        pl->symmetric = sp == rp;
+    }
     cm->links.push_back(pl);
     *out = pl;
     return MIK_OK;
@@ -853,6 +865,9 @@ extern "C" int mik_plink_exchange(mik_plink *pl, const void *send_buf, void *gho
     mik_comm *cm = pl->cm;
     if (!pl->connected || !cm->mail_ready) return mik_fail(cm->ctx, MIK_ERR_INVALID, "mik_plink_exchange: the link (or its communicator's mailbox) is not connected");
     if ((!pl->send.empty() && !send_buf) || (!pl->recv.empty() && !ghost)) return MIK_ERR_INVALID;
+    if (!pl->symmetric)
+        return mik_fail(cm->ctx, MIK_ERR_NOTIMPL, "mik_plink_exchange: this rank's send and receive peers differ; back-to-back exchanges of such a plan need a sum over all "
+                                                  "ranks between them (what cg! / gmres! have) -- the landing buffers carry no consumed-acknowledgement");
     (void)hipSetDevice(cm->ctx->device);
     MIK_TRY(plink_halo(pl, send_buf, ghost));
     MIK_HIP(cm->ctx, mik_wait(cm->ctx));
@@ -1364,6 +1379,7 @@ struct GroupState {
             for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
         for (hipStream_t s : ev.side) if (s) (void)hipStreamDestroy(s);
     }
+    bool peer_access = true;         // hipDeviceEnablePeerAccess succeeded between every pair of devices
 };
 
 // groups are keyed by their rank-0 handle and live until mik_cgd_group_release (or process exit)
@@ -1388,6 +1404,12 @@ static int group_check(mik_cgd **its, int P, const char *who)
     return MIK_OK;
 }
 
+// a copy between two ranks of the group: same device -> device-to-device, else an explicit peer copy (works with and without peer access)
+static inline hipError_t group_copy(void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, hipStream_t s)
+{
+    return dst_dev == src_dev ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) : hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, s);
+}
+
 static int group_get(mik_cgd **its, int P, GroupState **out)
 {
     GroupState *g = find_group(its, P);
@@ -1403,8 +1425,10 @@ static int group_get(mik_cgd **its, int P, GroupState **out)
             MIK_HIP(ctx, hipSetDevice(ctx->device));
             for (int q = 0; q < P; ++q)          // peer access for copies between different devices (xGMI P2P)
                 if (its[q]->base.ctx->device != ctx->device) {
+                    // (not fatal: the copies below are hipMemcpyPeerAsync, which the runtime stages through the host where two devices
+                    // cannot address each other -- the group is the transport of last resort and must come up on any topology)
                     hipError_t e = hipDeviceEnablePeerAccess(its[q]->base.ctx->device, 0);
-                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { delete g; return mik_fail(ctx, MIK_ERR_HIP, "hipDeviceEnablePeerAccess(%d): %s", its[q]->base.ctx->device, hipGetErrorString(e)); }
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) g->peer_access = false;
                     (void)hipGetLastError();
                 }
             for (auto *v : {&g->ev.packed, &g->ev.halo, &g->ev.dot, &g->ev.rr}) MIK_HIP(ctx, hipEventCreateWithFlags(&(*v)[p], hipEventDisableTiming));
@@ -1465,8 +1489,8 @@ static int group_halo_begin(GroupState *g, std::vector<char> &pending)
             if (!match || match->cnt != sg.cnt)
                 return mik_fail(ctx, MIK_ERR_MISMATCH, "halo plans disagree: rank %d expects %lld entries from rank %d", p, (long long)sg.cnt, sg.peer);
             MIK_HIP(ctx, hipStreamWaitEvent(g->ev.side[p], g->ev.packed[sg.peer], 0));
-            MIK_HIP(ctx, hipMemcpyAsync(ghost + es * (size_t)sg.off, (const unsigned char *)src->send_buf + es * (size_t)match->off, es * (size_t)sg.cnt,
-                                        hipMemcpyDeviceToDevice, g->ev.side[p]));
+            MIK_HIP(ctx, group_copy(ghost + es * (size_t)sg.off, ctx->device, (const unsigned char *)src->send_buf + es * (size_t)match->off, src->base.ctx->device,
+                                    es * (size_t)sg.cnt, g->ev.side[p]));
         }
         MIK_HIP(ctx, hipEventRecord(g->ev.halo[p], g->ev.side[p]));
         pending[(size_t)p] = 1;
@@ -1495,7 +1519,7 @@ static int group_gather_scalar(GroupState *g, int which)
             if (q == p) continue;
             const unsigned char *theirs = (const unsigned char *)(which == 0 ? g->its[q]->dot_all : g->its[q]->rr_all);
             MIK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ev[q], 0));
-            MIK_HIP(ctx, hipMemcpyAsync(mine + es * (size_t)q, theirs + es * (size_t)q, es, hipMemcpyDeviceToDevice, ctx->stream));
+            MIK_HIP(ctx, group_copy(mine + es * (size_t)q, ctx->device, theirs + es * (size_t)q, g->its[q]->base.ctx->device, es, ctx->stream));
         }
     }
     return MIK_OK;

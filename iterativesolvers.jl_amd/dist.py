@@ -1662,13 +1662,13 @@ def bench_main(args):
         is_contract = bool(contract and contract.get("came_up"))
         v_ms = contract["ms_per_step"] if is_contract else dt / K * 1e3
         v_ips = 1e3 / v_ms
-        pmc = getattr(args, "pmc_traffic", None) or (lambda k, with_source=False: (None, None) if with_source else None)
+        pmc = getattr(args, "pmc_traffic", None) or (lambda k, with_source=False: (None, None, None) if with_source else None)
         if is_contract:
             c_ms = contract["spmv_in_loop_ms"]
-            c_traffic, c_src = pmc(contract["kernel"], with_source=True)
+            c_traffic, c_src, c_ok = pmc(contract["kernel"], with_source=True)
             roofline = {"bound": "hbm", "kernel": contract["kernel"] + "<double, fused dot>", "loop": "contract_csr_loop (rank 0's slab; every rank runs the same loop)",
                         "achieved": alg_bytes / (c_ms * 1e-3) / 1e9, "peak": HBM_PEAK, "unit": "GB/s", "frac": alg_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK,
-                        "traffic": c_traffic, "traffic_source": c_src,
+                        "traffic": c_traffic, "traffic_source": c_src, "traffic_binary_matches": c_ok,
                         "traffic_is": "committed constant from separate rocprofv3 --pmc passes of the single-GPU command (same kernel, same rows per GPU), not measured in this run",
                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": c_ms, "launches_timed": contract["spmv_launches_timed"],
                         "avg_launch_ms_per_rank": contract["spmv_in_loop_ms_per_rank"], "back_to_back_ms": contract["spmv_back_to_back_ms"],
@@ -1728,9 +1728,11 @@ def bench_main(args):
             "roofline": roofline,
             "transport_selftest": selftest,
             "wall": {"seconds_so_far": time.perf_counter() - t_bench0,
-                     "expected_seconds_at_8_gpus": "about 150: ~12 s bootstrap and slab generation, ~15 s self-test children (2 transports), ~20 s per transport "
-                                                   "(engine + 0.25 s timed), ~25 s contract loop, ~45 s parity (3 transports x 2 layouts on the small system), "
-                                                   "~15 s CPU baseline on rank 0; measured with 2 / 3 / 4 ranks on ONE GPU: profiles/r06_ranks_on_one_gpu_wall.json",
+                     "expected_seconds_of_the_whole_command_at_8_gpus": "60 - 90: launcher + imports ~8 s, slab generation ~2 s, self-test children ~3 s per transport "
+                                                   "(RCCL bootstrap of 8 ranks: up to ~15 s), ~2 s per measured transport, contract loop ~2 s, parity (3 transports x 2 "
+                                                   "layouts, small system) ~6 s, CPU baseline on rank 0 ~14 s.  Measured with every rank on ONE GPU (one transport): "
+                                                   "2 / 3 / 4 ranks = 21 / 13 / 15 s incl. launcher (profiles/r06_first_contact_wall.json); hard limits: self-test child "
+                                                   "75 s, mailbox waits 10 s, watchdog 150 s per leg",
                      "limit_seconds": 600},
         }
         if boot_failure:

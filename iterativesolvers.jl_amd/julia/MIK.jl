@@ -68,6 +68,30 @@ mutable struct Context
     end
 end
 alive(c::Context) = c.handle != C_NULL
+struct DeviceInfo                    # same field order and types as the C struct mik_device_info
+    device::Cint
+    compute_units::Cint
+    xcds::Cint
+    wavefront_size::Cint
+    lds_bytes_per_cu::Int64
+    l2_bytes::Int64
+    hbm_bytes::Int64
+    arch::NTuple{64, UInt8}
+    planned_compute_units::Cint
+    planned_xcds::Cint
+    xcd_maps::Cint
+    resident_workgroup_cap::Cint
+    gs_single_launch_max_segments::Cint
+    gs_xcd_local_max_workgroups::Cint
+    sweep_grid_cap::Cint
+    reserved::NTuple{8, Cint}
+end
+"The machine behind a context as the library queried it, and the launch caps it derived (mik_ctx_info)."
+function device_info(ctx::Context = context())
+    r = Ref{DeviceInfo}()
+    check(ccall((:mik_ctx_info, libmik), Cint, (Ptr{Cvoid}, Ref{DeviceInfo}), ctx.handle, r), "mik_ctx_info", ctx.handle)
+    r[]
+end
 const default_ctx = Ref{Union{Nothing, Context}}(nothing)
 context() = (default_ctx[] === nothing && (default_ctx[] = Context(0)); default_ctx[]::Context)
 
@@ -218,6 +242,8 @@ mutable struct HipCSR{T<:MikFloat}
     m::Int
     n::Int
     ctx::Context
+    adj::Union{HipCSR{T}, Nothing}   # partner uploaded by with_adjoint: a reference cycle the GC collects as a whole (no global table keeps it alive)
+    HipCSR{T}(handle, m, n, ctx) where {T<:MikFloat} = new{T}(handle, m, n, ctx, nothing)
 end
 "Upload a SparseMatrixCSC{T,Int} (colptr/rowval/nzval, 1-based Int64: test/laplace_matrix.jl:12)."
 function HipCSR(A::SparseMatrixCSC{T, Int64}, ctx::Context = context()) where {T<:MikFloat}
@@ -260,7 +286,6 @@ end
 # are A' (row j of A' = column j of A, entries in storage order = the order mul!(y, adjoint(A), x) of SparseArrays sums them in), so the
 # adjoint is a second upload with is_csc = 0 -- no transpose is formed for it.  `with_adjoint(A)` returns the operator; `adjoint(op)` / `op'`
 # its partner.  (Real element types.)
-const ADJOINTS = IdDict{Any, Any}()
 function with_adjoint(A::SparseMatrixCSC{T, Int64}, ctx::Context = context()) where {T<:MikFloat}
     op = HipCSR(A, ctx)
     h = Ref{Ptr{Cvoid}}(C_NULL)
@@ -270,12 +295,12 @@ function with_adjoint(A::SparseMatrixCSC{T, Int64}, ctx::Context = context()) wh
         "mik_csr_create", ctx.handle)
     adj = HipCSR{T}(h[], size(A, 2), size(A, 1), ctx)
     finalizer(o -> alive(o.ctx) && ccall((:mik_csr_destroy, libmik), Cint, (Ptr{Cvoid},), o.handle), adj)
-    ADJOINTS[op] = adj; ADJOINTS[adj] = op
+    op.adj = adj; adj.adj = op
     op
 end
 function LinearAlgebra.adjoint(A::HipCSR)
-    haskey(ADJOINTS, A) || throw(MikError(Cint(5), "adjoint", "this operator was uploaded without its adjoint: use MIK.with_adjoint(A)"))
-    ADJOINTS[A]
+    A.adj === nothing && throw(MikError(Cint(5), "adjoint", "this operator was uploaded without its adjoint: use MIK.with_adjoint(A)"))
+    A.adj
 end
 Base.:*(a::Number, x::HipVector{T}) where {T} = LinearAlgebra.rmul!(copyto!(similar(x), x), T(a))       # t1*w (src/lsqr.jl:189)
 
@@ -708,6 +733,7 @@ function IterativeSolvers.idrs_iterable!(log, X::HipVector{T}, A::HipCSR{T}, C::
         end
         P = HipVector(Ph, X.ctx)
     end
+    (P.n >= ld * Int(s) && P.ctx === X.ctx) || throw(MikError(Cint(3), "idrs_iterable!", "P must hold ld * s = $(ld * Int(s)) entries (column-major, leading dimension $ld) on X's context"))
     U = fill!(HipVector{T}(undef, ld * Int(s), X.ctx), zero(T))              # :137
     G = fill!(HipVector{T}(undef, ld * Int(s), X.ctx), zero(T))              # :138
     h = Ref{Ptr{Cvoid}}(C_NULL)

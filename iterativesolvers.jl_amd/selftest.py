@@ -194,8 +194,28 @@ def run(args):
                     pr["pass"] = rec["pass"] = False
                     first = int(np.flatnonzero(got[off:off + cnt] != want)[0])
                     pr.setdefault("first_wrong", {"round": r, "index": first, "got": hex(int(got[off + first])), "expected": hex(int(want[first]))})
-        rec.update(rounds=len(lat), us_per_exchange_median=float(np.median(lat) * 1e6), us_first_exchange=float(lat[0] * 1e6),
-                   gbs_received=float(M * 8 * len(recv) / np.median(lat) / 1e9))
+        # latency: back-to-back exchanges of the last payload without the file barrier in between (a symmetric plan needs none: a rank cannot run
+        # two exchanges ahead of its neighbours), one blocking call each
+        meet.barrier("timing")
+        reps = 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            if args.transport == "mailbox":
+                check(L.mik_plink_exchange(link, C.c_void_p(sendv.ptr), C.c_void_p(ghost.ptr)), "mik_plink_exchange", ctx.handle)
+            else:
+                check(L.mik_comm_halo(comm, 0, C.c_void_p(sendv.ptr), C.c_void_p(ghost.ptr), rp.size, rp.ctypes.data_as(ip), ro.ctypes.data_as(lp),
+                                      rc.ctypes.data_as(lp), sp.size, sp.ctypes.data_as(ip), so.ctypes.data_as(lp), sc.ctypes.data_as(lp)), "mik_comm_halo", ctx.handle)
+                ctx.synchronize()
+        per = (time.perf_counter() - t0) / reps
+        got = ghost.to_numpy().view(np.uint64)          # ... and the last one still carries the right words
+        for (q, off, cnt) in recv:
+            if np.count_nonzero(got[off:off + cnt] != pattern(q, rank, args.payload_rounds - 1, M)):
+                rec["pass"] = rec["per_neighbour"][f"{q}->{rank}"]["pass"] = False
+                rec["per_neighbour"][f"{q}->{rank}"]["failure"] = "wrong words after the back-to-back exchanges"
+        rec.update(rounds=len(lat), us_first_exchange=float(lat[0] * 1e6), us_per_exchange_median=float(per * 1e6), back_to_back_exchanges_timed=reps,
+                   gbs_received=float(M * 8 * len(recv) / per / 1e9),
+                   what="blocking call: push kernel into the neighbours' landing buffers + flag + landing copy + host wait" if args.transport == "mailbox"
+                        else "ncclSend / ncclRecv group on the ctx stream + host wait")
     else:
         rec["note"] = "a world of one has no neighbour"
     out["checks"][name] = rec

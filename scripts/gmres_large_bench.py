@@ -1,4 +1,4 @@
-"""The HBM-bound GMRES leg of bench.py on its own (for rocprofv3: scripts/prof_r05.sh gmres_large): gmres!(restart = 30) on the 256^3
+"""The HBM-bound GMRES leg of bench.py on its own (for rocprofv3: scripts/prof_r06.sh gmres_large): gmres!(restart = 30) on the 256^3
 Laplacian, fp64, plain CSR arrays, 60 inner iterations.  ORTH=mgs|cgs|both  N=<grid>  LAYOUT=csr|auto  REPS=<calls>."""
 import json
 import os

@@ -17,6 +17,40 @@ root = sys.argv[1]
 summ = os.path.join(root, "summary")
 os.makedirs(summ, exist_ok=True)
 
+# Every *_traffic.json names the binary its counters were collected on: sha256 of the libmik.so of THIS checkout (the one the
+# profiled commands loaded) and the mangled names of the kernels it lists, so that bench.py can tell whether the constants still describe the
+# library it has loaded (`traffic_binary_matches`) and withholds them otherwise.
+import hashlib
+import re
+import subprocess
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(REPO, "iterativesolvers.jl_amd", "libmik.so")
+
+
+def binary_record(kernel_names=()):
+    rec = {"libmik_sha256": None, "libmik_bytes": None, "mangled": {}}
+    try:
+        blob = open(LIB, "rb").read()
+    except OSError:
+        return rec
+    rec["libmik_sha256"], rec["libmik_bytes"] = hashlib.sha256(blob).hexdigest(), len(blob)
+    # kernel symbols of the embedded gfx950 code object: strings of the form _Z...<name>...; demangled with c++filt and matched on the text
+    cands = sorted(set(m.decode() for m in re.findall(rb"_Z[A-Za-z0-9_]{6,400}", blob) if b"k_" in m))
+    import shutil
+    filt = shutil.which("c++filt") or shutil.which("llvm-cxxfilt")
+    try:
+        dem = subprocess.run([filt], input="\n".join(cands), capture_output=True, text=True, timeout=60).stdout.splitlines() if cands and filt else []
+    except Exception:
+        dem = []
+    table = {}
+    for m, d in zip(cands, dem):
+        d = d.replace("void ", "").replace("(anonymous namespace)::", "").strip().split("(")[0]
+        table.setdefault(d, m)
+    for k in kernel_names:
+        if k in table:
+            rec["mangled"][k] = table[k]
+    return rec
+
 
 def tkey(k):
     """key of a kernel in <what>_traffic.json: the name up to its template list; k_map / k_map_pro kernels by their Op"""
@@ -80,7 +114,7 @@ for d in sorted(glob.glob(os.path.join(root, "*"))):
                         inner = j[name]["inner_iterations"] * j[name].get("calls_timed", 1)
         if inner:
             rd, wr = 2.0 * tot["FETCH_SIZE"] * 1024.0, tot["WRITE_SIZE"] * 1024.0
-            json.dump({"inner_iterations_profiled": inner, "fetch_bytes_x2": rd, "write_bytes": wr,
+            json.dump({"_binary": binary_record(), "inner_iterations_profiled": inner, "fetch_bytes_x2": rd, "write_bytes": wr,
                        "traffic_bytes_per_inner_iteration": (rd + wr) / inner,
                        "per_kernel_bytes_per_inner_iteration": {k: {"traffic": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 / inner,
                                                                      "dispatches_per_inner_iteration": v["dispatches"] / inner} for k, v in per_kernel.items()}},
@@ -146,5 +180,6 @@ for d in sorted(glob.glob(os.path.join(root, "*"))):
             for line in der:
                 o.write(f"    => {line}\n")
     if traffic:
+        traffic["_binary"] = binary_record([v["kernel"] for v in traffic.values() if isinstance(v, dict) and "kernel" in v])
         json.dump(traffic, open(os.path.join(summ, f"{what}_traffic.json" if not what.startswith("gmres_large_") else f"{what}_traffic_per_launch.json"), "w"), indent=1)
 print("summaries:", sorted(os.listdir(summ)))

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-5 profiling recipe (run on the GPU box through gpurun):  scripts/prof_r05.sh [what...]
+# Round-6 profiling recipe (run on the GPU box through gpurun):  scripts/prof_r06.sh [what...]   (ROUND=r06: output directory and file prefix)
 #   what = bench | gmres_large | spmv_large | c5 | gmres
-#   rocprofv3 --kernel-trace --stats           -> gpurun_out/r05/<what>/trace
+#   rocprofv3 --kernel-trace --stats           -> gpurun_out/r06/<what>/trace
 #   separate --pmc passes (never combined with other trace domains; PMC=0 skips them)
 # scripts/prof_collect.py then condenses everything into the small CSV / txt / json files that are committed under profiles/.
 #   bench        the driver's command: the CSR contract loop (k_spmv_rowgather = `value` and `roofline`) and the default-layout loop
@@ -9,7 +9,7 @@
 #                directory divided by its inner iterations is that method's HBM traffic per inner iteration
 #   spmv_large   CSR SpMV with x = 134 MB and x = 537 MB
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$R/gpurun_out/r05
+OUT=$R/gpurun_out/${ROUND:-r06}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 WHAT=${@:-bench gmres_large spmv_large}

@@ -14,7 +14,8 @@ Summation orders per file: `seq` (one accumulator), `pair` (pairwise), `tree` (t
 `blas` / `blas8`: dot, norm and gemv evaluated by the host's OpenBLAS (the library SciPy bundles; recorded under
 "blas_library") with 1 resp. 8 BLAS threads -- the library family the reference executes for LinearAlgebra.dot /
 norm / mul!.  OpenBLAS picks its kernel by CPU (DYNAMIC_ARCH) and splits long vectors across threads, so the
-`blas*` histories are those of THIS machine ("core" in the file); they are not regenerated on the GPU box.
+`blas*` histories are those of THIS machine ("core" in the file).  `--blas-only TAG` regenerates only them on another host (or another
+forced core type) into cg_lap<N>_blas_<TAG>.json: committed for the GPU box's EPYC (Zen kernels) and for forced Haswell / Zen cores.
 """
 import json
 import os
@@ -82,7 +83,40 @@ def gmres_case(N, restart):
     return out
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def blas_only(tag, sizes):
+    """--blas-only TAG [N ...]: the `blas` / `blas8` histories of THIS host's OpenBLAS kernels (or of the core forced with OPENBLAS_CORETYPE, which
+    must be set before the library loads: one process per core type) -> cg_lap<N>_blas_<TAG>.json next to the full goldens.  bench.py compares the
+    device history with every such file (`parity_full_history.blas_hosts`) and reports the spread between the hosts: the band a Julia run
+    (its own OpenBLAS build, an unknown core) lands in (VERDICT r5 #5)."""
+    for N in sizes:
+        A = orc.laplace(N, 3)
+        b = orc.hashed_rhs(A.n)
+        out = dict(case=f"cg(laplace_matrix(Float64,{N},3), hashed_rhs) reltol=sqrt(eps) abstol=0, dot / norm by the host OpenBLAS", N=N, host_tag=tag,
+                   cpu_model=cpu_model(), forced_coretype=os.environ.get("OPENBLAS_CORETYPE"))
+        for key, mode, thr in blas_modes():
+            out["blas_library"] = {k: v for k, v in orc.bind_blas(thr).items() if k != "threads"}
+            out.setdefault("blas_threads", {})[key] = thr
+            x, h = orc.cg(A, b, mode=mode, shape=(1, 1, 1, 1))
+            print(f"  cg {N}^3 {key} [{tag}: {out['blas_library']['core']}]: {h['iters']} iterations", flush=True)
+            out[key] = dict(iters=h["iters"], mvps=h["mvps"], isconverged=h["isconverged"], res0=float(h["res0"]).hex(), tol=float(h["tol"]).hex(),
+                            resnorm=hexlist(h["resnorm"]), x_checksum=float(np.sum(x)).hex(), x_norm=float(np.linalg.norm(x)).hex())
+        dump(f"cg_lap{N}_blas_{tag}.json", out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--blas-only":
+        blas_only(sys.argv[2], [int(v) for v in sys.argv[3:]] or [64, 256])
+        sys.exit(0)
     dump("cg_lap32.json", cg_case(32))
     dump("cg_lap64.json", cg_case(64))
     dump("gmres_advdiff50_r30.json", gmres_case(50, 30))
