@@ -194,7 +194,12 @@ def history_parity(N: int, gpu_hist: np.ndarray, gpu_iters: int, gpu_mvps: int, 
                 spread = max(spread, float(np.max(np.abs(a[:m] - b2[:m]) / b2[:m])))
         out["blas_hosts"] = bh
         out["blas_hosts_spread_single_thread"] = spread if len(tags) > 1 else None
-        out["blas_hosts_all_within_1e-12"] = bool(all(v.get("gpu_vs_blas_history_max_rel_dev", 1.0) <= 1e-12 for v in bh.values()))
+        worst = max(v.get("gpu_vs_blas_history_max_rel_dev", 1.0) for v in bh.values())
+        out["blas_hosts_worst_single_thread"] = worst
+        out["blas_hosts_all_within_1e-12"] = bool(worst <= 1e-12)
+        # SURVEY.md 8d's parity statement: "<= max(1e-12, 3 x floor)", the floor being what two equally valid CPU summation orders differ by --
+        # here two OpenBLAS kernels (AVX-512 vs AVX2) running the reference's own dot / norm calls
+        out["blas_hosts_all_within_max_of_1e-12_and_3x_their_own_spread"] = bool(worst <= max(1e-12, 3.0 * spread)) if len(tags) > 1 else None
 
     def floor(a, b):
         m = min(ref[a].size, ref[b].size)

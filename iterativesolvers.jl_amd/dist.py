@@ -1193,6 +1193,11 @@ def bench_main(args):
     transport = os.environ.get("MIK_DIST_TRANSPORT", "native")   # "native": RCCL inside libmik.so; "torch": phases driven from Python
     t_bench0 = time.perf_counter()
     group_only, boot_failure = False, None
+
+    def note(msg):
+        """progress on stderr with the time since start (rank 0): where a first run on new hardware spends its time, or stops, is visible in the log"""
+        if rank == 0:
+            print(f"bench.py [{time.perf_counter() - t_bench0:7.1f} s] {msg}", file=sys.stderr, flush=True)
     if world > 1 or "RANK" in os.environ:
         # the process group only bootstraps (ncclUniqueId, barriers, max over ranks of the timings): gloo suffices for the
         # native transport; the legacy transport needs torch's own RCCL communicator
@@ -1245,6 +1250,7 @@ def bench_main(args):
     else:
         ptr, local_idx, val, plan, b_loc, n, offsets = build_rank_problem(pkg, boot, N, nz_per_rank=nz, device=None if on_host else local_rank)
     nnz_loc = int(val.numel() if hasattr(val, "numel") else val.size)
+    note(f"{world} rank(s) met, slabs of {N}x{N}x{nz} generated ({plan.n_loc} rows, {nnz_loc} entries, {plan.n_ghost} halo entries on rank 0)")
     ptr_keep = True
     state = {"k": 0, "it": None}
 
@@ -1393,6 +1399,7 @@ def bench_main(args):
             for name in names:
                 for layout in ("auto", "csr"):
                     key = f"{name}/{layout}"
+                    note(f"parity: {key} on the {Ns}x{Ns}x{nzs * world} system")
                     e2, c2, i2, failure = bring_up(name, layout, small, sqrt_eps, 10 ** 6)
                     if failure:
                         parity["transports"][key] = {"came_up": False, "failure": failure}
@@ -1456,6 +1463,7 @@ def bench_main(args):
         for name in names:
             arm_watchdog()                      # (only once a transport has been measured: then a hang of the next one is survivable)
             t_up = time.perf_counter()
+            note(f"transport {name}: bring-up (default layout)")
             e2, c2, i2, failure = bring_up(name, "auto", big, 0.0, 10 ** 9)
             rec = {"came_up": failure is None}
             if failure:
@@ -1476,6 +1484,7 @@ def bench_main(args):
                 rec.update(came_up=False, failure=failures[0][:300])
                 transports[name] = rec
                 continue
+            note(f"transport {name}: {float(np.median(tms)) / K * 1e3:.4f} ms per step over {len(tms)} timed region(s) of {K} steps")
             rec.update(operator_layout=e2.A.layout(), ms_per_step=float(np.median(tms)) / K * 1e3, iters_per_sec=K / float(np.median(tms)), timed_regions=len(tms),
                        first_residuals=[float(v).hex() for v in first[:8]], uses_rccl=c2.uses_rccl())
             transports[name] = rec
@@ -1511,6 +1520,7 @@ def bench_main(args):
                 dist.destroy_process_group()
             return
         state["solo"] = True
+        note(f"in-process group: {world} slabs on devices {group_devices}")
         if max(group_devices) >= torch.cuda.device_count():
             raise SystemExit(f"bench.py: the in-process group needs devices {group_devices}, {torch.cuda.device_count()} visible")
         del ptr, local_idx, val
@@ -1624,6 +1634,7 @@ def bench_main(args):
             parity["transports_bit_identical"] = ok
     if transport == "native" and default_layout != "csr-rowblock" and not getattr(args, "no_csr", False):
         arm_watchdog()
+        note(f"contract loop: transport {chosen} on the plain CSR arrays")
         e3, c3, i3, failure = bring_up(chosen, "csr", big, 0.0, 10 ** 9)
         if failure:
             contract = {"came_up": False, "failure": failure}
@@ -1748,6 +1759,7 @@ def bench_main(args):
         run_parity()
         if watchdog["timer"] is not None:
             watchdog["timer"].cancel()
+    note("all GPU legs done" + ("; CPU baseline on rank 0" if not getattr(args, "no_cpu_baseline", False) else ""))
     if rank == 0:
         out = make_line()
         fn = getattr(args, "cpu_baseline_fn", None)

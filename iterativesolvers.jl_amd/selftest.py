@@ -18,7 +18,7 @@ Per transport, every check bit-exact and timed:
 
 The ranks of one self-test meet through files in a directory the parent names (rank 0's ncclUniqueId, the 64-byte IPC handles): the
 test does not depend on the parent's own bootstrap channel.  Every wait is bounded; the result is ONE JSON line on stdout.
-No torch import (a child starts in about a second)."""
+The child loads PyTorch first when it is there (--no-torch: not), so that it runs on the HIP runtime and RCCL the parent uses."""
 from __future__ import annotations
 
 import argparse
@@ -87,6 +87,15 @@ def run(args):
     t_start = time.monotonic()
     deadline = t_start + args.timeout
     sys.path.insert(0, ROOT)
+    runtime = "system (libmik.so's RUNPATH)"
+    if not args.no_torch:
+        # the parent (bench.py) runs inside PyTorch-ROCm, whose bundled HIP runtime and RCCL libmik.so then shares; the child must prove the
+        # transports on the SAME libraries, so it loads them first (costs about two seconds)
+        try:
+            import torch  # noqa: F401
+            runtime = f"the one PyTorch {torch.__version__} bundles"
+        except Exception as exc:      # noqa: BLE001
+            runtime += f" (import torch failed: {type(exc).__name__})"
     import __graft_entry__ as graft
     pkg = graft.load_package()
     L = pkg.lib()
@@ -97,6 +106,7 @@ def run(args):
     os.environ.setdefault("MIK_MAILBOX_TIMEOUT_MS", str(int(min(20.0, args.timeout / 3) * 1000)))
     ctx = pkg.HipContext(args.device)
     out["machine"] = {k: v for k, v in ctx.info().items() if k in ("compute_units", "xcds", "arch")}
+    out["hip_runtime_and_rccl"] = runtime
     ident = None
     if args.transport == "rccl":
         if rank == 0:
@@ -239,6 +249,7 @@ def main():
     ap.add_argument("--payload-rounds", type=int, default=6)
     ap.add_argument("--bytes", type=int, default=4 << 20, help="payload per neighbour (default 4 MB: larger than one XCD's L2)")
     ap.add_argument("--timeout", type=float, default=60.0)
+    ap.add_argument("--no-torch", action="store_true", help="do not load PyTorch's HIP runtime / RCCL first (a host without PyTorch)")
     args = ap.parse_args()
     try:
         out = run(args)

@@ -15,7 +15,8 @@ Summation orders per file: `seq` (one accumulator), `pair` (pairwise), `tree` (t
 "blas_library") with 1 resp. 8 BLAS threads -- the library family the reference executes for LinearAlgebra.dot /
 norm / mul!.  OpenBLAS picks its kernel by CPU (DYNAMIC_ARCH) and splits long vectors across threads, so the
 `blas*` histories are those of THIS machine ("core" in the file).  `--blas-only TAG` regenerates only them on another host (or another
-forced core type) into cg_lap<N>_blas_<TAG>.json: committed for the GPU box's EPYC (Zen kernels) and for forced Haswell / Zen cores.
+forced core type) into cg_lap<N>_blas_<TAG>.json: committed for the GPU box's EPYC 9575F (OpenBLAS 0.3.28 picks its SkylakeX / AVX-512 kernels there: the history equals the build container's bit
+for bit) and for the forced Haswell core (AVX2 kernels; OPENBLAS_CORETYPE=Zen selects the same kernels in this build).
 """
 import json
 import os
