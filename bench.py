@@ -35,6 +35,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (before the HIP runtime initialises): what hipIpcGetMemHandle / RCCL need between processes on this driver
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
@@ -883,7 +884,7 @@ def main():
     ap.add_argument("--config5-kinds", default="fe_shell,fe_hex,banded,random")
     ap.add_argument("--stencil27", type=int, default=0, help="grid of the 27-point box-stencil sub-benchmark (off by default: outside every BASELINE.json config; frozen, VERDICT r3 #8)")
     ap.add_argument("--extras", action="store_true", help="also time the solvers OUTSIDE the scope contract (IDR(8) in f_solvers, LSQR / LSMR / QMR): unjudged, off by default")
-    ap.add_argument("--cpu-iters", type=int, default=120)
+    ap.add_argument("--cpu-iters", type=int, default=100, help="iterations of the CPU baseline's bounded sample (about 12 s of one EPYC core at 256^3)")
     ap.add_argument("--force-dist", action="store_true", help="run the row-partitioned code path even with one rank")
     args = ap.parse_args()
 

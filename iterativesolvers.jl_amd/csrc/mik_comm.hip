@@ -49,9 +49,13 @@ Rccl *rccl()
     static bool tried = false;
     if (tried) return R.h ? &R : nullptr;
     tried = true;
+    // MIK_RCCL_LIB names the library explicitly (a host whose RCCL lives elsewhere); otherwise the copy the process already carries
+    // (PyTorch-ROCm bundles one) or the system's
+    const char *forced = getenv("MIK_RCCL_LIB");
+    if (forced && *forced) R.h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        R.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (R.h) break;
+        R.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
     }
     if (!R.h) { const char *de = dlerror(); R.err = de ? de : "librccl.so not found"; return nullptr; }
     auto sym = [&](const char *s) { void *p = dlsym(R.h, s); if (!p) R.err = std::string("missing symbol ") + s; return p; };

@@ -1203,6 +1203,8 @@ def bench_main(args):
         # native transport; the legacy transport needs torch's own RCCL communicator
         try:
             import datetime
+            if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: no hostname lookup (a container's hostname may not resolve, or resolve slowly)
             if os.environ.get("MIK_BOOT_FAIL") == "1":
                 raise RuntimeError("bootstrap failure simulated by MIK_BOOT_FAIL=1 (development)")
             if transport == "torch" and os.environ.get("MIK_DIST_BACKEND", "nccl") == "nccl":
