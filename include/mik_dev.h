@@ -32,7 +32,8 @@ enum {
     MIK_KNOB_UPLOAD = 4,         /* 1 = mik_csr_create on the host path only (rows beyond 256 entries, duplicates), 2 = device transpose but the host builders of layouts 6 / 1 */
     MIK_KNOB_GS = 5,             /* Gram-Schmidt of GMRES: 0 = by size, 1 = unfused multi-launch chain (what n > 2048 segments and row partitions run), 2 = launch-lean chain
                                   * (every pass finalises the previous reduction itself), 3 = single launch, but DGKS hands back to the host loop after ONE round (read at
-                                  * mik_gmres_create; default 3 rounds), 4 = single launch on all XCDs (not the XCD-local form), 5 = XCD-local form also beyond 512 KB columns */
+                                  * mik_gmres_create; default 3 rounds), 4 = single launch on all XCDs (not the XCD-local form), 5 = XCD-local form also beyond 512 KB columns,
+                                  * 6 = no resident-w form beyond 8 segments per compute unit (read at mik_gmres_create): the multi-launch chain there, as until round 5 */
     MIK_KNOB_TRANSPORT = 6,      /* row-partitioned CG (bits): 1 = the side stream ordered by events instead of mailbox flags (the path without a mailbox), 2 = the two scalars of a
                                   * step over RCCL although a mailbox is connected, 4 = ... through the mailbox even in a world of one, 8 = ... through the one-wave gather launches
                                   * (k_mail_gather) instead of inside the finalising kernels */

@@ -12,6 +12,7 @@
 #include <tuple>
 
 #include "mik_kernels.h"
+#include "mik_mgs_res.h"
 #include "mik_iter.h"
 #include "mik_mail.h"
 
@@ -1112,6 +1113,7 @@ struct mik_gmres {
     // single-launch Modified Gram-Schmidt (k_mgs_fused): slot buffers [2][restart + 1][256] and the host-mapped mirror of (h, nrm)
     void *mgs_P = nullptr;
     int mgs_G = 1, mgs_stride = 256;  // segments per workgroup of the single-launch kernels; slots per row of mgs_P
+    int mgs_res_S = 0;               // > 0: Modified Gram-Schmidt runs in the resident-w form (k_mgs_resident) with this many segments per workgroup
     int gs_timeouts = 0;             // how often a single-launch column came back timed out (mik_dev_gmres_form)
     bool fused_off = false;          // latched when the single-launch kernel's bounded spin expired once: multi-launch chains from then on
     unsigned *xl_chk = nullptr;      // device, 2 words: XCC id + 1 of the participants of the XCD-local form (k_mgs_fused XL), per parity
@@ -1622,9 +1624,15 @@ static int gmres_create_common(mik_ctx *ctx, const mik_csr *A, void *x, const vo
         // unpartitioned MI355X, so up to 2048 segments; a 32-CU partition: up to 256), G = the smallest of 1 / 2 / 4 / 8 segments per workgroup that fits
         const int64_t cap = std::min(mik_resident_cap(ctx), 256);        // (the slot layout of k_mgs_fused / k_cgs_fused holds 256 workgroups)
         const int G = nseg <= cap ? 1 : nseg <= 2 * cap ? 2 : nseg <= 4 * cap ? 4 : 8;
-        if (part_ok && nseg >= 1 && nseg <= 8 * cap && restart <= 254 && (G == 1 || g->ldv % 4 == 0)) {
-            g->mgs_G = G;
-            g->mgs_stride = std::max<int>(256, (int)((nseg + g->mgs_G - 1) / g->mgs_G) * g->mgs_G);
+        // Beyond that: Modified Gram-Schmidt in its "resident w" form (csrc/mik_mgs_res.h) -- one workgroup per compute unit keeps its part of w in
+        // registers and LDS between the passes; S consecutive segments per workgroup, at most 128.  Single GPU only; MIK_KNOB_GS = 6 keeps the chains.
+        const int64_t res_S = (nseg + mik_resident_cap(ctx) - 1) / mik_resident_cap(ctx);
+        const bool resident = !part && orth_method == MIK_MGS && nseg > 8 * cap && res_S <= 128 && restart <= 254 && g->ldv % 4 == 0 && A != nullptr &&
+                              ctx->tuning[MIK_KNOB_GS] != 6 && ctx->lds_per_cu >= 160 * 1024;
+        if (resident) g->mgs_res_S = (int)res_S;
+        if (resident || (part_ok && nseg >= 1 && nseg <= 8 * cap && restart <= 254 && (G == 1 || g->ldv % 4 == 0))) {
+            g->mgs_G = resident ? 1 : G;
+            g->mgs_stride = resident ? (int)((nseg + 63) / 64 * 64) : std::max<int>(256, (int)((nseg + g->mgs_G - 1) / g->mgs_G) * g->mgs_G);
             // k_cgs_fused: one more row per round (the final h values); DGKS: up to 3 rounds in the kernel
             g->mgs_rounds = orth_method == MIK_DGKS ? (ctx->tuning[MIK_KNOB_GS] == 3 ? 1 : 3) : 1;   // DGKS rounds the kernel runs before it hands back to the host loop (MIK_KNOB_GS = 3: one)
             if (part && orth_method == MIK_DGKS) g->mgs_rounds = std::max(1, std::min(g->mgs_rounds, MIK_MAIL_VEC / (restart + 1)));     // (the rounds of a launch share the 64 vector slots)
@@ -1759,6 +1767,16 @@ template <typename T> static int gm_fused_enqueue(mik_gmres *g, int k, int slot)
         else if (g->method == MIK_CGS) MIK_CGS_GO(VECV, false, GG);                                  \
         else MIK_MGS_GO(VECV, GG);                                                                   \
     } while (0)
+    if (g->mgs_res_S > 0) {
+        // the resident-w form: ceil(nseg / S) workgroups of 512 threads, one per compute unit (128 KB of LDS each)
+        const int S = g->mgs_res_S, wgs = (nseg + S - 1) / S;
+        hipLaunchKernelGGL((k_mgs_resident<T, 512, MIK_MGS_RES_RR, MIK_MGS_RES_RL>), dim3(wgs), dim3(512), 0, ctx->stream, n, k, (const T *)V, g->ldv, w, (T *)g->mgs_P, g->restart,
+                           stride, nseg, S, g->mgs_parity, gm_mirror(g, slot), g->mgs_seq);
+        g->xl_last = false;
+        MIK_LAUNCH_CHECK(ctx);
+        g->mgs_parity ^= 1;
+        return MIK_OK;
+    }
     // Modified Gram-Schmidt on small systems: the XCD-local form (k_mgs_fused XL) -- at most 128 workgroups, all on the first XCD, a column
     // of at most 512 KB per pass: every column then comes through ONE XCD's share of the fabric (~1 MB per us).  fe_shell (363 KB columns):
     // GMRES(50) 64.2 -> 50.9 us per inner iteration; configs[2] (1 MB columns) would lose (36.5 -> 47.8 us) and keeps the device-wide
@@ -1982,7 +2000,7 @@ extern "C" int mik_dev_gmres_form(const mik_gmres *g, int *single_launch, int *s
     const mik_ctx *ctx = g->ctx;
     const bool single = g->mgs_P && (!g->dist || g->part.link) && !g->fused_off && ctx->tuning[MIK_KNOB_GS] != 1 && ctx->tuning[MIK_KNOB_GS] != 2;
     if (single_launch) *single_launch = single ? 1 : 0;
-    if (segments_per_workgroup) *segments_per_workgroup = g->mgs_P ? g->mgs_G : 0;
+    if (segments_per_workgroup) *segments_per_workgroup = g->mgs_P ? (g->mgs_res_S > 0 ? g->mgs_res_S : g->mgs_G) : 0;
     if (xcd_local_last) *xcd_local_last = g->xl_last ? 1 : 0;
     if (timeouts) *timeouts = g->gs_timeouts;
     return MIK_OK;
