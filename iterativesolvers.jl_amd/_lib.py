@@ -56,7 +56,7 @@ class MikDeviceInfo(C.Structure):
                 ("lds_bytes_per_cu", C.c_int64), ("l2_bytes", C.c_int64), ("hbm_bytes", C.c_int64), ("arch", C.c_char * 64),
                 ("planned_compute_units", C.c_int), ("planned_xcds", C.c_int), ("xcd_maps", C.c_int), ("resident_workgroup_cap", C.c_int),
                 ("gs_single_launch_max_segments", C.c_int), ("gs_xcd_local_max_workgroups", C.c_int), ("sweep_grid_cap", C.c_int),
-                ("reserved", C.c_int * 8)]
+                ("mgs_resident_max_segments", C.c_int), ("reserved", C.c_int * 7)]
 
 
 class MikPartition(C.Structure):

@@ -24,7 +24,7 @@
 #define MIK_MGS_RES_DEPTH 2      // rounds of the column streams in flight ahead of the arithmetic (register rounds)
 #endif
 #ifndef MIK_MGS_RES_RL
-#define MIK_MGS_RES_RL 8         // rounds in LDS: 8 x 2 segments x 8 KB = 128 KB
+#define MIK_MGS_RES_RL 9         // rounds in LDS: 9 x 2 segments x 8 KB = 144 KB of the 160 KB
 #endif
 
 // level 2 over `ns` slots by a workgroup of NT threads (NT / 64 waves): real thread (wave w, lane l) plays the virtual threads

@@ -84,7 +84,8 @@ struct DeviceInfo                    # same field order and types as the C struc
     gs_single_launch_max_segments::Cint
     gs_xcd_local_max_workgroups::Cint
     sweep_grid_cap::Cint
-    reserved::NTuple{8, Cint}
+    mgs_resident_max_segments::Cint
+    reserved::NTuple{7, Cint}
 end
 "The machine behind a context as the library queried it, and the launch caps it derived (mik_ctx_info)."
 function device_info(ctx::Context = context())

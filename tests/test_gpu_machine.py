@@ -33,6 +33,7 @@ def test_ctx_info_reports_the_queried_machine(pkg, ctx):
     assert d["resident_workgroup_cap"] == d["compute_units"] and d["gs_single_launch_max_segments"] == 8 * d["compute_units"]
     assert d["xcd_maps"] == (1 if d["xcds"] == 8 else 0)
     assert d["gs_xcd_local_max_workgroups"] == (4 * d["compute_units"] // d["xcds"] if d["xcds"] == 8 else 0)
+    assert d["mgs_resident_max_segments"] == 128 * d["compute_units"]
     assert d["sweep_grid_cap"] == 32 * d["compute_units"] and d["hbm_bytes"] > 2 ** 30 and d["lds_bytes_per_cu"] >= 65536
     ctx.set_tuning(KN.MACHINE, CPX)
     try:
@@ -48,7 +49,7 @@ def test_ctx_info_reports_the_queried_machine(pkg, ctx):
 @pytest.mark.parametrize("N,expect", [(12, "G1"), (40, "G2"), (60, "G8"), (70, "chains")])
 def test_gmres_forms_follow_the_machine_shape_bit_exact(pkg, orc, ctx, N, expect, orth):
     """advection_dominated(N) planned for 32 CUs / 1 XCD: up to 32 segments one per workgroup, up to 256 with G = 2 / 4 / 8, beyond that the
-    multi-launch chains -- chosen at mik_gmres_create, never through the time-out; history, x and counters equal the run planned for
+    multi-launch chains (Modified Gram-Schmidt: the resident-w form on 31 workgroups) -- chosen at mik_gmres_create, never through the time-out; history, x and counters equal the run planned for
     the real machine and (MGS / CGS) the oracle."""
     A, b = orc.advdiff(N, 200.0)
     W, L = ctx.reduce_shape(np.float64)
@@ -75,6 +76,8 @@ def test_gmres_forms_follow_the_machine_shape_bit_exact(pkg, orc, ctx, N, expect
     finally:
         ctx.set_tuning(KN.MACHINE, 0)
     want = {"G1": (1, 1), "G2": (1, 2), "G8": (1, 8), "chains": (0, 0)}[expect]
+    if expect == "chains" and orth == "mgs":
+        want = (1, -(-nseg // 32))             # Modified Gram-Schmidt beyond 8 segments per CU: the resident-w form, ceil(nseg / CUs) segments per workgroup
     assert nseg <= 32 if expect == "G1" else True
     assert (f_before["single"], f_before["G"]) == want == (f1["single"], f1["G"]), (nseg, f_before, f1)
     assert f1["timeouts"] == 0 and f1["xl"] == 0              # nothing timed out; the XCD-local form is not planned on one XCD

@@ -102,7 +102,7 @@ C_MIRRORS = {"MikOperator": ("mik_operator", ["dtype", "n", "csr", "mul", "user"
              "Partition": ("mik_partition", ["rank", "nranks", "n_ext", "x_ext", "send_idx", "n_send", "send_buf", "halo", "reduce", "user", "link"]),
              "DeviceInfo": ("mik_device_info", ["device", "compute_units", "xcds", "wavefront_size", "lds_bytes_per_cu", "l2_bytes", "hbm_bytes", "arch",
                                                 "planned_compute_units", "planned_xcds", "xcd_maps", "resident_workgroup_cap", "gs_single_launch_max_segments",
-                                                "gs_xcd_local_max_workgroups", "sweep_grid_cap", "reserved"])}
+                                                "gs_xcd_local_max_workgroups", "sweep_grid_cap", "mgs_resident_max_segments", "reserved"])}
 
 
 def julia_type_layout(t):
