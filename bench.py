@@ -280,12 +280,12 @@ def gmres_hbm_bound(A, b, n: int, restart: int = 30, inner: int = 60, reps: int 
     """gmres!(restart = 30) at an HBM-BOUND size: the 256^3 Laplacian of configs[1] on its plain CSR arrays, fp64 -- the Krylov
     basis V is 31 x 134 MB = 4.2 GB, nothing of it survives in a cache from one sweep to the next.  `inner` inner iterations
     (src/gmres.jl:57-106: expand! + orthogonalize_and_normalize!, two restart cycles with their solve / update / init!), loop inside
-    the library (mik_gmres_iterate_many), ModifiedGramSchmidt (the multi-launch chain: pass i = w -= h_i v_i fused with the next
+    the library (mik_gmres_iterate_many), ModifiedGramSchmidt (one launch per column with w kept on the chip between the passes: pass i = w -= h_i v_i fused with the next
     projection v_{i+1} . w, src/orthogonalize.jl:69-76) and ClassicalGramSchmidt (k_multidot + k_gemv_n, :43-45).
     Bytes per inner iteration: SURVEY.md 8d -- B_spmv + (3k + 2) n s (MGS) / (2k + 3) n s (CGS) for Arnoldi column k, plus per
     restart (k + 2) n s (update) and B_spmv + 3 n s (init!) -- summed over the call and divided by its inner iterations; `moved` = what the
-    launches of this implementation stream (MGS (4k + 3) n s: v_i is read by the pass that projects on it and again by the pass
-    that subtracts it; CGS (2k + 6) n s)."""
+    launches of this implementation stream (MGS, resident-w form: (2k + 2 + (2k + 1) g) n s with g the share of w that does not fit on the chip --
+    v_i is read by the pass that projects on it and again by the pass that subtracts it; the multi-launch chain (4k + 3) n s; CGS (2k + 6) n s)."""
     import torch
     pkg = graft.load_package()
     s8 = 8
@@ -309,7 +309,24 @@ def gmres_hbm_bound(A, b, n: int, restart: int = 30, inner: int = 60, reps: int 
         ks = [(j % restart) + 1 for j in range(iters)]                     # Arnoldi column of every inner iteration
         cycles = (iters + restart - 1) // restart
         alg = sum(spmv_bytes + ((3 * k + 2) if name == "mgs" else (2 * k + 3)) * n * s8 for k in ks)
-        moved = sum(spmv_bytes + ((4 * k + 3) if name == "mgs" else (2 * k + 6)) * n * s8 for k in ks)
+        # what the launches stream.  Modified Gram-Schmidt in the resident-w form (csrc/mik_mgs_res.h; n > 2048 segments): first sweep w + v_1 (2 n),
+        # k - 1 middle passes v_i + v_{i+1} + the non-resident share g of w read and written (2 + 2 g) n, last pass (1 + 2 g) n, final scale (1 + g) n
+        # -> (2 k + 2 + (2 k + 1) g) n per column, instead of the chain's (4 k + 3) n
+        form = None
+        if name == "mgs":
+            import ctypes as C
+            sl, sg, th, rr, rl = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            L = pkg.lib()
+            if L.mik_dev_gmres_form(it.handle, C.byref(sl), C.byref(sg), None, None) == 0 and L.mik_dev_mgs_resident_shape(C.byref(th), C.byref(rr), C.byref(rl)) == 0 \
+                    and sl.value == 1 and sg.value > 8:
+                spr = th.value // 256
+                rounds = -(-sg.value // spr)
+                g_share = max(0.0, 1.0 - (rr.value + rl.value) / rounds)
+                form = {"form": "one launch per Arnoldi column, w resident in registers / LDS (k_mgs_resident)", "segments_per_workgroup": sg.value,
+                        "rounds_per_workgroup": rounds, "rounds_in_registers": rr.value, "rounds_in_lds": rl.value, "resident_share_of_w": 1.0 - g_share}
+                moved = sum(spmv_bytes + (2 * k + 2 + (2 * k + 1) * g_share) * n * s8 for k in ks)
+        if form is None:
+            moved = sum(spmv_bytes + ((4 * k + 3) if name == "mgs" else (2 * k + 6)) * n * s8 for k in ks)
         per_restart = [(min(restart, iters - c * restart) + 2) * n * s8 + spmv_bytes + 3 * n * s8 for c in range(cycles)]
         alg += sum(per_restart)
         moved += sum(per_restart)
@@ -319,6 +336,8 @@ def gmres_hbm_bound(A, b, n: int, restart: int = 30, inner: int = 60, reps: int 
                "frac": alg / best / 1e9 / HBM_PEAK_GBS, "frac_of_copy_ceiling_6290": alg / best / 1e9 / COPY_CEILING_GBS,
                "bytes_moved_per_inner_iteration": moved / max(iters, 1), "moved_gbs": moved / best / 1e9, "moved_frac": moved / best / 1e9 / HBM_PEAK_GBS,
                "final_residual": float(hist[-1]) if iters else None}
+        if form is not None:
+            rec["orthogonalisation"] = form
         tr = gmres_large_traffic(name)
         if tr is not None:
             rec["traffic_per_inner_iteration"] = tr["bytes"]

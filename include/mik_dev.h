@@ -56,6 +56,9 @@ int mik_ctx_set_tuning(mik_ctx *ctx, int key, int value);
  * kernel (0: the multi-launch chains), *segments_per_workgroup = its G (0: buffers never allocated -- too many segments for this machine),
  * *xcd_local_last = the column last enqueued used the XCD-local form, *timeouts = columns that came back timed out so far.  Any pointer may be NULL. */
 int mik_dev_gmres_form(const mik_gmres *it, int *single_launch, int *segments_per_workgroup, int *xcd_local_last, int *timeouts);
+/* Shape of the resident-w Modified Gram-Schmidt kernel (csrc/mik_mgs_res.h): threads per workgroup (threads / 256 segments per round), rounds of a
+ * workgroup's segments kept in registers and in LDS; the rest of w is streamed in every pass.  For byte accounting (bench.py). */
+int mik_dev_mgs_resident_shape(int *threads, int *register_rounds, int *lds_rounds);
 /* Host-only: the rule that places a 256-row block's window of x in LDS (k_spmv_rowblock XWIN) on caller-supplied per-block statistics
  * (first / last referenced column, entry count).  win_lo[b] = first column of block b's window (16-byte aligned) or -1 (the block gathers from
  * memory); *span = common window length in elements, 0 = no window table.  Guarantee the tests check: win_lo[b] >= 0 implies

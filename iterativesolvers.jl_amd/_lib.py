@@ -73,6 +73,7 @@ SIGNATURES = {
     "mik_ctx_destroy": (C.c_int, [_vp]),
     "mik_ctx_info": (C.c_int, [_vp, C.POINTER(MikDeviceInfo)]),
     "mik_dev_gmres_form": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
+    "mik_dev_mgs_resident_shape": (C.c_int, [_ip, _ip, _ip]),
     "mik_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "mik_ctx_synchronize": (C.c_int, [_vp]),
     "mik_last_error": (C.c_char_p, [_vp]),

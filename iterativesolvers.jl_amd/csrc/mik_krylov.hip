@@ -2006,6 +2006,14 @@ extern "C" int mik_dev_gmres_form(const mik_gmres *g, int *single_launch, int *s
     return MIK_OK;
 }
 
+extern "C" int mik_dev_mgs_resident_shape(int *threads, int *register_rounds, int *lds_rounds)
+{
+    if (threads) *threads = 512;
+    if (register_rounds) *register_rounds = MIK_MGS_RES_RR;
+    if (lds_rounds) *lds_rounds = MIK_MGS_RES_RL;
+    return MIK_OK;
+}
+
 extern "C" int mik_gmres_state(const mik_gmres *g, double *residual, double *tol, double *beta, int *k, int64_t *mv_products,
                                int *converged)
 {
