@@ -18,7 +18,7 @@
 #include "mik_kernels.h"
 
 #ifndef MIK_MGS_RES_RR
-#define MIK_MGS_RES_RR 18        // rounds of w a thread keeps in registers (4 doubles / 8 floats each = 8 registers): 144 of the 256 registers of a thread of a 512-thread workgroup (19 and more spill)
+#define MIK_MGS_RES_RR 17        // rounds of w a thread keeps in registers (4 doubles / 8 floats each = 8 registers): 136 of the 256 registers of a thread of a 512-thread workgroup (18 and more spill)
 #endif
 #ifndef MIK_MGS_RES_DEPTH
 #define MIK_MGS_RES_DEPTH 2      // rounds of the column streams in flight ahead of the arithmetic (register rounds)
@@ -158,7 +158,9 @@ __device__ __forceinline__ void mgs_resident_body(int64_t n, int k, const T *__r
     // of the unrolled sweep to the top, which would spill): 2 D L 16-byte loads per thread in flight.
     constexpr int D = MIK_MGS_RES_DEPTH;
     const __amdgpu_buffer_rsrc_t wrs = rsrc(w);
-    auto sweep = [&](auto First, auto HasB, const T *__restrict__ pa, const T *__restrict__ pb, const T h) {
+    // geth() delivers the coefficient of this pass (the grid-wide sum of the previous one) AFTER the first column loads have been issued: they do
+    // not depend on it, and travel while the workgroups hand their segment sums to each other.
+    auto sweep = [&](auto First, auto HasB, const T *__restrict__ pa, const T *__restrict__ pb, auto geth) {
         constexpr bool first = decltype(First)::value, hasb = decltype(HasB)::value;       // (compile-time: no selects between the two sources in the sweep)
         const __amdgpu_buffer_rsrc_t ars = rsrc(pa), brs = rsrc(hasb ? pb : pa);
         T sa[D][L][W], sb[D][L][W];
@@ -172,6 +174,7 @@ __device__ __forceinline__ void mgs_resident_body(int64_t n, int k, const T *__r
             }
         };
         mgs_static_for<0, (D < RR ? D : RR)>(issue);
+        const T h = geth();
         mgs_static_for<0, RR>([&](auto Rc) {
             constexpr int r = decltype(Rc)::value, slot = r % D;
             T acc = T(0);
@@ -273,25 +276,29 @@ __device__ __forceinline__ void mgs_resident_body(int64_t n, int k, const T *__r
     // Straight-line control flow around the register-resident part of w (no branch whose two sides both rewrite it: the register allocator
     // would otherwise hold two copies at the merge): a column-free call; else first sweep, k - 1 middle passes in ONE loop body, the last pass.
     if (k == 0) {
-        sweep(Yes{}, No{}, w, (const T *)nullptr, T(0));        // norm(w)^2
+        sweep(Yes{}, No{}, w, (const T *)nullptr, [] { return T(0); });        // norm(w)^2
         publish(0);
         finish();
         return;
     }
-    sweep(Yes{}, Yes{}, w, V, T(0));                            // dot(v_1, w)                                    :71 (i = 1)
+    sweep(Yes{}, Yes{}, w, V, [] { return T(0); });             // dot(v_1, w)                                    :71 (i = 1)
     publish(0);
 #pragma unroll 1
     for (int c = 0; c + 1 < k; ++c) {
-        const T h = mgs_grid_sum_wide<T, NT>(cur + (size_t)c * stride, nseg, lds16, &s_err);
-        if (s == 0 && t == 0) hout[c] = h;
-        sweep(No{}, Yes{}, V + (int64_t)c * ldv, V + (int64_t)(c + 1) * ldv, h);       // w .-= h v_i; dot(v_{i+1}, w)      :72, :71
+        sweep(No{}, Yes{}, V + (int64_t)c * ldv, V + (int64_t)(c + 1) * ldv, [&] {     // w .-= h v_i; dot(v_{i+1}, w)      :72, :71
+            const T h = mgs_grid_sum_wide<T, NT>(cur + (size_t)c * stride, nseg, lds16, &s_err);
+            if (s == 0 && t == 0) hout[c] = h;
+            return h;
+        });
         publish(c + 1);
     }
     {
         const int c = k - 1;
-        const T h = mgs_grid_sum_wide<T, NT>(cur + (size_t)c * stride, nseg, lds16, &s_err);
-        if (s == 0 && t == 0) hout[c] = h;
-        sweep(No{}, No{}, V + (int64_t)c * ldv, (const T *)nullptr, h);                // w .-= h v_k; norm(w)^2            :72, :75
+        sweep(No{}, No{}, V + (int64_t)c * ldv, (const T *)nullptr, [&] {              // w .-= h v_k; norm(w)^2            :72, :75
+            const T h = mgs_grid_sum_wide<T, NT>(cur + (size_t)c * stride, nseg, lds16, &s_err);
+            if (s == 0 && t == 0) hout[c] = h;
+            return h;
+        });
         publish(k);
     }
     finish();
