@@ -949,7 +949,7 @@ class LoopbackCG:
         return np.concatenate([e.solution() for e in self.engines])
 
 
-def build_rank_problem(pkg, comm, N: int, nz_per_rank: Optional[int] = None, dtype=np.float64, device=None):
+def build_rank_problem(pkg, comm, N: int, nz_per_rank: Optional[int] = None, dtype=np.float64, device=None, note=None):
     """z-slab of the 3D Laplacian on an N x N x (nz_per_rank * P) grid -- or of the cubic N^3 grid when
     nz_per_rank is None -- plus the hashed rhs; returns (ptr, local_idx, val, plan, b_loc, n_global)."""
     P, rank = comm.size, comm.rank
@@ -967,10 +967,15 @@ def build_rank_problem(pkg, comm, N: int, nz_per_rank: Optional[int] = None, dty
         n = N * N * NZ
         offsets = np.arange(P + 1, dtype=np.int64) * (N * N * nz_per_rank)
         n_glob, ptr, idx, val = rows(pkg, N, NZ, offsets[rank], offsets[rank + 1], dtype)
+    note = note or (lambda msg: None)
+    note("slab rows generated")
     local_idx, plan = localize(ptr, idx, offsets, rank)
+    note("columns localised")
     needs = comm.all_gather_objects(plan.ghost_gids)
+    note("halo needs gathered")
     complete_plan(plan, offsets, needs)
     b_loc = pkg.fixtures.hashed_rhs(n, int(offsets[rank]), int(offsets[rank + 1]), dtype)
+    note("halo plan complete, right-hand side generated")
     return ptr, local_idx, val, plan, b_loc, n, offsets
 
 
@@ -1214,6 +1219,7 @@ def bench_main(args):
                                         timeout=datetime.timedelta(seconds=float(os.environ.get("MIK_BOOT_TIMEOUT_S", "180"))))
             boot = TorchComm()
             assert dist.get_world_size() == world
+            note("process group (gloo) up")
         except Exception as exc:       # noqa: BLE001
             # The ranks cannot even meet (rendezvous refused, store unreachable): rank 0 measures the partitioned system alone through the
             # in-process group (include/mik.h "Transport 2": one host thread, every rank's slab on its own device, peer copies) -- the
@@ -1238,19 +1244,24 @@ def bench_main(args):
     if "MIK_DIST_NZ" in os.environ:                      # development: planes per rank (e.g. --grid 512 with 64 planes = one rank's slab of configs[3])
         nz = int(os.environ["MIK_DIST_NZ"])
     t_up = time.perf_counter()
-    on_host = os.environ.get("MIK_DIST_HOST_BUILD", "0") == "1"           # development: the numpy generator + host arrays
+    # The slab is generated on the HOST (numpy, ~1.5 s for 16.7 M rows) and uploaded like any SparseMatrixCSC.  MIK_DIST_HOST_BUILD=0 generates it with
+    # PyTorch on the device instead -- measured in round 6 with 3 / 4 processes on one GPU: 1 s on a fresh box, then 30 ... 500 s on the same box in
+    # later runs (inside torch's indexing / scan ops; libmik's own allocations and kernels stayed at their usual times), so it is not the default.
+    on_host = os.environ.get("MIK_DIST_HOST_BUILD", "1") == "1"
     self_halo = world == 1 and os.environ.get("MIK_DIST_SELF_HALO", "0") == "1"      # z-periodic slab: the rank exchanges its halo with itself
+    torch.cuda.synchronize()
+    note("HIP runtime up on the rank's device")
     group_devices = [int(os.environ["MIK_FORCE_DEVICE"])] * world if "MIK_FORCE_DEVICE" in os.environ else list(range(world))
     group_probs = None
     if group_only:
         if max(group_devices) >= torch.cuda.device_count():
             raise SystemExit(f"bench.py: the in-process group needs devices {group_devices}, {torch.cuda.device_count()} visible")
-        group_probs = build_group_problem(pkg, N, nz, world, group_devices)
+        group_probs = build_group_problem(pkg, N, nz, world, [None] * world if on_host else group_devices)
         ptr, local_idx, val, plan, b_loc, n, offsets = group_probs[0]
     elif self_halo:
         ptr, local_idx, val, plan, b_loc, n, offsets = build_self_halo_problem(pkg, N, nz, local_rank)
     else:
-        ptr, local_idx, val, plan, b_loc, n, offsets = build_rank_problem(pkg, boot, N, nz_per_rank=nz, device=None if on_host else local_rank)
+        ptr, local_idx, val, plan, b_loc, n, offsets = build_rank_problem(pkg, boot, N, nz_per_rank=nz, device=None if on_host else local_rank, note=note)
     nnz_loc = int(val.numel() if hasattr(val, "numel") else val.size)
     note(f"{world} rank(s) met, slabs of {N}x{N}x{nz} generated ({plan.n_loc} rows, {nnz_loc} entries, {plan.n_ghost} halo entries on rank 0)")
     ptr_keep = True
@@ -1528,7 +1539,7 @@ def bench_main(args):
         del ptr, local_idx, val
         big = None
         if group_probs is None:
-            group_probs = build_group_problem(pkg, N, nz, world, group_devices)
+            group_probs = build_group_problem(pkg, N, nz, world, [None] * world if on_host else group_devices)
         plan = group_probs[0][3]
 
         def group_up(probs, layout, reltol, maxiter):
@@ -1611,7 +1622,7 @@ def bench_main(args):
         check = getattr(args, "partition_oracle_fn", None)
         if check is not None and not getattr(args, "no_parity", False):
             Ns, nzs = 64, 8
-            small = build_group_problem(pkg, Ns, nzs, world, group_devices)
+            small = build_group_problem(pkg, Ns, nzs, world, [None] * world if on_host else group_devices)
             parity = {"workload": f"cg! to reltol = sqrt(eps) on the {Ns}x{Ns}x{nzs * world} Laplacian, {world} z-slab(s) of {nzs} planes, hashed rhs, x0 = 0",
                       "oracle": "oracle/mik_oracle.c cg, TREE mode with the same row partition (rank-ordered sums of the per-rank trees)", "transports": {}}
             for layout in ("auto", "csr"):
