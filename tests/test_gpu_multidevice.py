@@ -64,7 +64,7 @@ def _cg_worker(rank, world, port, N, nz, out_dir, transport, scale, batch, maxit
     pkg, d, td = _init(rank, world, port)
     boot = d.TorchComm()
     pkg.lib().mik_set_tuning(6, knob6)
-    ptr, li, val, plan, b_loc, n, offsets = d.build_rank_problem(pkg, boot, N, nz_per_rank=nz, device=_dev(rank))
+    ptr, li, val, plan, b_loc, n, offsets = d.build_rank_problem(pkg, boot, N, nz_per_rank=nz, device=None)          # (host generation: PyTorch device generation stalls with several processes per GPU)
     eng = d.HipEngine(pkg, ptr, li, val, plan, b_loc * scale, abstol=0.0, reltol=1.5e-8, maxiter=maxiter, device=_dev(rank))
     nc = d.NativeComm(pkg, eng.ctx, boot, transport=transport)
     assert nc.uses_rccl() == (transport != "mailbox")
