@@ -848,7 +848,7 @@ def run_partitioned(args):
     args.pmc_traffic = pmc_traffic
     args.cpu_baseline_fn = cpu_baseline
     args.partition_oracle_fn = partition_oracle
-    return import_module(pkg.__name__ + ".dist").bench_main(args)
+    return import_module(pkg.__name__ + ".bench_dist").bench_main(args)
 
 
 def launch_ranks(args):

@@ -7,7 +7,9 @@ The directory name (``iterativesolvers.jl_amd``) is not a Python identifier; loa
   _lib.py    ctypes binding of that ABI (fails loudly when the library is missing)
   api.py     host-side mirror of the reference interface (cg, cg_, gmres, gmres_, iterables ...): SURVEY section 8 rows only
   extras.py  solvers outside the scope contract (IDR(s), LSQR, LSMR, QMR, power method); kept apart, unjudged
-  dist.py    row-partitioned multi-GPU CG (one process per GPU, torch.distributed / RCCL)
+  dist.py    row-partitioned multi-GPU CG / GMRES (one process per GPU; RCCL, peer-mapped mailboxes, in-process group)
+  bench_dist.py  measurement harness of bench.py --gpus N (self-test orchestration, group fall-back, the line) -- not product code
+  selftest.py    transport self-test child process
   fixtures.py  the reference's test/benchmark inputs as SparseMatrixCSC arrays
   julia/     the Julia-side shim (ccall bindings + dispatch methods), see INTEGRATION.md
 """

@@ -1,5 +1,5 @@
 """Transport self-test of the row-partitioned path -- one CHILD PROCESS per rank and transport, started by ``bench.py --gpus N``
-(``dist.transport_selftest``) BEFORE anything is timed, and usable by any host (``python selftest.py --help``).
+(``bench_dist.transport_selftest``) BEFORE anything is timed, and usable by any host (``python selftest.py --help``).
 
 Why a child: the first contact of RCCL / HIP IPC with a new machine can hang inside a library call (communicator bootstrap, a
 collective whose peer never arrives), and a thread stuck in a C call cannot be cancelled.  A child can be killed: a transport whose

@@ -1,4 +1,4 @@
-"""Host logic of the transport self-test (iterativesolvers.jl_amd/selftest.py, dist.transport_selftest): the ring plan and its landing
+"""Host logic of the transport self-test (iterativesolvers.jl_amd/selftest.py, bench_dist.transport_selftest): the ring plan and its landing
 offsets, the payload words, the file rendezvous, and the verdict logic of the parent -- a transport whose child fails, cannot start or is
 told to fail is dropped from the candidates, never entered.  No GPU: on this box the children fail loudly with "no HIP device"."""
 import importlib.util
@@ -58,20 +58,26 @@ def test_file_rendezvous_gathers_in_rank_order_and_times_out(st, tmp_path):
         lone.gather("h", b"x")
 
 
-def test_parent_verdicts_drop_failed_transports(dist):
+@pytest.fixture(scope="module")
+def bench_dist(pkg):
+    from importlib import import_module
+    return import_module(pkg.__name__ + ".bench_dist")
+
+
+def test_parent_verdicts_drop_failed_transports(dist, bench_dist):
     boot = dist.SelfComm()
     boot.rank, boot.size = 0, 1
-    rep = dist.transport_selftest(boot, 0, 1, 0, ["mailbox", "rccl"], timeout=60, simulate_failure=["mailbox"])
+    rep = bench_dist.transport_selftest(boot, 0, 1, 0, ["mailbox", "rccl"], timeout=60, simulate_failure=["mailbox"])
     assert rep["mailbox"]["pass"] is False and "simulated" in rep["mailbox"]["failure"]
     assert rep["rccl"]["pass"] is False and rep["rccl"]["skipped"] is True
     assert rep["usable"] == []
 
 
-def test_child_without_a_device_fails_loudly_and_the_parent_reports_it(dist):
+def test_child_without_a_device_fails_loudly_and_the_parent_reports_it(dist, bench_dist):
     import torch
     if torch.cuda.is_available():
         pytest.skip("a GPU is visible")
     boot = dist.SelfComm()
     boot.rank, boot.size = 0, 1
-    rep = dist.transport_selftest(boot, 0, 1, 0, ["mailbox"], timeout=120)
+    rep = bench_dist.transport_selftest(boot, 0, 1, 0, ["mailbox"], timeout=120)
     assert rep["mailbox"]["pass"] is False and "no HIP device" in rep["mailbox"]["failure"] and rep["usable"] == []
