@@ -194,19 +194,33 @@ __device__ __forceinline__ void mgs_resident_body(int64_t n, int k, const T *__r
             if constexpr (r + D < RR) issue(std::integral_constant<int, r + D>{});
             __builtin_amdgcn_sched_barrier(0);
         });
+        // the rounds that live in LDS or are streamed: the column data of round r + 1 is requested before round r is worked on
+        T na[L][W], nb[L][W];
+        auto fetch = [&](int r) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                ld(ars, r, l, na[l]);
+                if (hasb) ld(brs, r, l, nb[l]);
+            }
+        };
+        if (RR < rounds) fetch(RR);
 #pragma unroll 1
         for (int r = RR; r < rounds; ++r) {
             const bool in_lds = r < RR + RL;
+            T ca[L][W], cb[L][W];
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+#pragma unroll
+                for (int e = 0; e < W; ++e) { ca[l][e] = na[l][e]; if (hasb) cb[l][e] = nb[l][e]; }
+            if (r + 1 < rounds) fetch(r + 1);
             T acc = T(0);
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const int64_t i = idx(r, l);
-                T aa[W], bb[W], ww[W];
-                ld(ars, r, l, aa);
-                if (hasb) ld(brs, r, l, bb);
+                T ww[W];
                 if (first) {
 #pragma unroll
-                    for (int e = 0; e < W; ++e) ww[e] = aa[e];
+                    for (int e = 0; e < W; ++e) ww[e] = ca[l][e];
                 } else {
                     if (in_lds) {
                         vec v = lds_at(r, l);
@@ -215,11 +229,11 @@ __device__ __forceinline__ void mgs_resident_body(int64_t n, int k, const T *__r
                     } else ld(wrs, r, l, ww);
 #pragma unroll
                     for (int e = 0; e < W; ++e)
-                        if (i + e < n) { T tq = h * aa[e]; ww[e] = ww[e] - tq; }
+                        if (i + e < n) { T tq = h * ca[l][e]; ww[e] = ww[e] - tq; }
                 }
 #pragma unroll
                 for (int e = 0; e < W; ++e)
-                    if (i + e < n) { T p = (hasb ? bb[e] : ww[e]) * ww[e]; acc = acc + p; }
+                    if (i + e < n) { T p = (hasb ? cb[l][e] : ww[e]) * ww[e]; acc = acc + p; }
                 if (in_lds) {
                     vec v;
 #pragma unroll
