@@ -322,13 +322,35 @@ def bench_main(args):
                            "n": int(n), "n_per_gpu": plan.n_loc, "host_sync_per_step": 1, "transport_chosen": chosen, "transports_measured": transports,
                            "operator_layout_of_the_timed_loop": "default (slice-constant); the CSR contract loop was not reached", "watchdog": note},
                 "roofline": None}), flush=True)
-        os._exit(0 if chosen is not None else 3)
+        elif rank == 0 and state.get("solo"):
+            print("bench.py: the in-process group leg itself did not return in time; no line", file=sys.stderr, flush=True)
+            os._exit(3)
+        elif rank == 0:
+            # Nothing measured yet and the FIRST transport hangs inside this process (it passed its self-test in a child, so this should not happen;
+            # a thread stuck in a library call cannot be cancelled).  Last resort: a fresh process measures through the in-process group -- the other
+            # ranks leave now and free their devices -- and this one forwards its line.
+            import subprocess
+            print("bench.py: the first transport did not return in time inside the rank processes; a fresh process measures through the in-process group",
+                  file=sys.stderr, flush=True)
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                                     "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS")}
+            env["MIK_SPAWN_FAIL"] = "1"
+            time.sleep(3.0)                                     # (the other ranks are leaving)
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            argv = [a for a in sys.argv[1:]]
+            try:
+                rc = subprocess.call([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, timeout=float(os.environ.get("MIK_BENCH_GROUP_RESCUE_S", "300")))
+            except Exception as exc:       # noqa: BLE001
+                print(f"bench.py: the rescue process failed: {exc}", file=sys.stderr, flush=True)
+                rc = 3
+            os._exit(rc)
+        os._exit(0 if (chosen is not None or rank != 0) else 3)
 
     def arm_watchdog():
         if watchdog["timer"] is not None:
             watchdog["timer"].cancel()
         watchdog["timer"] = None
-        if world > 1 and chosen is not None:
+        if world > 1 and not group_only:      # (also before anything has been measured: a first transport that hangs in here must not hang the run)
             watchdog["timer"] = threading.Timer(float(os.environ.get("MIK_BENCH_WATCHDOG_S", "150")), emergency_line)
             watchdog["timer"].daemon = True
             watchdog["timer"].start()
@@ -415,6 +437,8 @@ def bench_main(args):
             arm_watchdog()                      # (only once a transport has been measured: then a hang of the next one is survivable)
             t_up = time.perf_counter()
             note(f"transport {name}: bring-up (default layout)")
+            if os.environ.get("MIK_BENCH_HANG_FIRST") == "1" and not alive:        # development: what the watchdog does when the first transport never returns
+                time.sleep(10 ** 6)
             e2, c2, i2, failure = bring_up(name, "auto", big, 0.0, 10 ** 9)
             rec = {"came_up": failure is None}
             if failure:

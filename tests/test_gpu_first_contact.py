@@ -98,3 +98,10 @@ def test_launcher_that_cannot_start_ranks_measures_through_the_group_itself():
     assert "produced no line" in err and line["config"]["transport_chosen"] == "group" and "bootstrap_failure" in line["config"]
     assert line["transport_selftest"]["reached"] is False
     _contract_complete(line)
+
+
+def test_first_transport_that_never_returns_is_rescued_by_a_fresh_group_process():
+    """the watchdog covers the first transport too: nothing measured yet -> the ranks leave, a fresh process measures through the in-process group"""
+    line, err = _bench(MIK_BENCH_HANG_FIRST="1", MIK_BENCH_WATCHDOG_S="8")
+    assert "did not return in time inside the rank processes" in err and line["config"]["transport_chosen"] == "group"
+    _contract_complete(line)
