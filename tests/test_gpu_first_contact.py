@@ -5,7 +5,8 @@ otherwise both on device 0 (HIP IPC has no one-rank-per-device rule; RCCL has, a
   * the line carries `transport_selftest`, only transports that passed are entered;
   * with every transport between processes told to fail the line still comes -- through the in-process group -- contract-complete and
     bit-identical to the partition-aware oracle;
-  * a launcher that cannot start ranks at all measures through the group itself."""
+  * a launcher that cannot start ranks at all measures through the group itself;
+  * a first transport that never returns inside the rank processes is rescued by the watchdog: a fresh process measures through the group."""
 import json
 import os
 import subprocess
