@@ -1,6 +1,10 @@
+"""Modified Gram-Schmidt in the resident-w form (csrc/mik_mgs_res.h) against the multi-launch chain (MIK_KNOB_GS = 6): same residual history and
+solution bit for bit, and microseconds per inner iteration, at five sizes (advection_dominated(N), fp64 / fp32) and on the 256^3 CSR operator.
+    gpurun -- python scripts/micro/mgs_resident_check.py"""
 import sys, time, json
 import numpy as np
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import __graft_entry__ as g
 pkg = g.load_package()
 import torch
