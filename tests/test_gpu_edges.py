@@ -114,3 +114,23 @@ def test_orthogonalize_large_basis_with_streaming_hints(pkg, orc, ctx, method):
     W, L = ctx.reduce_shape(np.float64)
     wo, ho, no = orc.orthogonalize(V, w0, method=method, mode="tree", W=W, L=L)
     assert nrm == no and np.array_equal(h, ho) and np.array_equal(dw.to_numpy(), wo)
+
+
+@pytest.mark.parametrize("off", [1, 3, 64])
+def test_cg_with_x_a_view(pkg, orc, ctx, off):
+    """test/cg.jl:89-96 "CG with a view": x = view(rand(10, 2), :, 1) -- the solution vector is a slice of a larger device buffer (here also at an
+    offset that is only 8-byte aligned: the sweeps over x take their scalar-load form); history and solution equal the oracle's bit for bit and the
+    neighbouring entries of the buffer stay untouched"""
+    A = orc.laplace(9, 3)
+    b = orc.hashed_rhs(A.n)
+    x0 = np.random.default_rng(7).standard_normal(A.n)
+    big = np.full(A.n + 130, 7.25)
+    big[off:off + A.n] = x0
+    dbig = pkg.HipVector.from_numpy(big)
+    xv = dbig.view(off, A.n)
+    dA = pkg.HipCSR(A.n, A.n, A.colptr, A.rowval, A.nzval, index_base=A.index_base)
+    x, ch = pkg.cg_(xv, dA, pkg.HipVector.from_numpy(b), log=True)
+    xo, ho = orc.cg(A, b, x0=x0, mode="tree", shape=ctx.cg_shape(np.float64))
+    assert ch.isconverged and ch.iters == ho["iters"] and np.array_equal(ch["resnorm"], np.asarray(ho["resnorm"]))
+    out = dbig.to_numpy()
+    assert np.array_equal(out[off:off + A.n], xo) and np.all(out[:off] == 7.25) and np.all(out[off + A.n:] == 7.25)
