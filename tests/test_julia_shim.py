@@ -254,3 +254,51 @@ def test_specialised_methods_are_strictly_more_specific_than_the_reference():
 def test_readme_says_the_julia_shim_was_never_executed():
     head = open(os.path.join(ROOT, "README.md")).read().split("\n## ")[0]
     assert "never been executed" in head and "MIK.jl" in head
+
+
+def _julia_code_only(s):
+    """MIK.jl without comments, strings and character literals (placeholders keep the token boundaries)"""
+    out, i, n = [], 0, len(s)
+    while i < n:
+        if s.startswith("#=", i):
+            i = s.index("=#", i) + 2
+        elif s.startswith('"""', i):
+            i = s.index('"""', i + 3) + 3
+            out.append('""')
+        elif s[i] == '"':
+            j = i + 1
+            while s[j] != '"':
+                j += 2 if s[j] == "\\" else 1
+            out.append('""')
+            i = j + 1
+        elif s[i] == "#":
+            j = s.find("\n", i)
+            i = n if j < 0 else j
+        elif s[i] == "'" and i + 2 < n and (s[i + 2] == "'" or (s[i + 1] == "\\" and s[i + 3] == "'")):
+            out.append("' '")
+            i += 3 if s[i + 2] == "'" else 4
+        else:
+            out.append(s[i])
+            i += 1
+    return "".join(out)
+
+
+def test_shim_blocks_and_brackets_balance():
+    """No Julia parser exists here: at least every block opener (function / if / for / while / let / do / struct / module / begin / try / quote / macro)
+    has its `end`, and (), [], {} nest -- an edit that drops or doubles one is caught on the CPU box"""
+    toks = re.findall(r"[A-Za-z_][A-Za-z_0-9!]*|[\[\]\(\)\{\}]|.", _julia_code_only(JL), flags=re.S)
+    stack, openers, ends = [], 0, 0
+    pairs = {")": "(", "]": "[", "}": "{"}
+    for k, tok in enumerate(toks):
+        prev = toks[k - 1] if k else ""
+        if tok in "([{":
+            stack.append(tok)
+        elif tok in pairs:
+            assert stack and stack.pop() == pairs[tok], f"unbalanced {tok!r} near token {k}"
+        elif tok in ("function", "if", "for", "while", "let", "do", "struct", "module", "begin", "try", "quote", "macro"):
+            if prev in (".", ":") or (any(b in "([" for b in stack) and tok in ("for", "if")):       # field / symbol; comprehension or generator
+                continue
+            openers += 1
+        elif tok == "end" and prev not in (".", ":") and not any(b in "([" for b in stack):          # (a[end] is an index, not a block end)
+            ends += 1
+    assert not stack and openers == ends and openers >= 80, (openers, ends, stack[:3])
