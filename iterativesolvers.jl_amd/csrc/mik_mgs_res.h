@@ -53,7 +53,10 @@ __device__ __forceinline__ T mgs_grid_sum_wide(const T *__restrict__ slots, int 
             for (int c = 0; c < 8; ++c) {
                 const int q = q0 + c * MIK_FIN_THREADS;
                 if (q < ns) {
-                    for (int spin = 0; bits[c] == MgsBits<T>::EMPTY && spin < (1 << 18); ++spin)
+                    // bounded, and at most ONE wait runs to its bound: once any thread of the workgroup has given up (a workgroup of the launch never got
+                    // its compute unit: GPU shared with other work) nobody spins any more -- the launch drains in well under a second with err set, and
+                    // the host redoes the column with the chain
+                    for (int spin = 0; bits[c] == MgsBits<T>::EMPTY && spin < (1 << 18) && !*(volatile int *)err; ++spin)
                         bits[c] = __hip_atomic_load(sp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (bits[c] == MgsBits<T>::EMPTY) *err = 1;      // timed out: never hang the device
                     T val;
