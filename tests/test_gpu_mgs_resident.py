@@ -82,3 +82,34 @@ def test_resident_form_timeout_falls_back_to_the_chain(pkg, ctx):
     finally:
         pkg.lib().mik_set_tuning(KN.GS_TIMEOUT, 0)
     assert f2["timeouts"] >= 1 and f2["single"] == 0 and np.array_equal(h1, h2) and np.array_equal(x1, x2)
+
+
+@pytest.mark.parametrize("precond", ["none", "pl", "pl+pr"])
+def test_resident_form_long_cycles_restarts_and_preconditioners(pkg, ctx, precond):
+    """restart = 30 (columns k = 1 ... 30: up to 31 hand-offs per launch), two restarts, a start vector, and the three expand! methods of
+    src/gmres.jl:285-304 (Identity / Pl / Pl and Pr as diagonal preconditioners) in front of the resident form -- against the chain, bit for bit"""
+    n, cp, rv, nz, b = pkg.fixtures.advection_dominated(140, 300.0)
+    A = pkg.HipCSR(n, n, cp, rv, nz, index_base=1)
+    db = pkg.HipVector.from_numpy(b)
+    rng = np.random.default_rng(11)
+    x0 = rng.standard_normal(n)
+    d1 = pkg.HipVector.from_numpy(1.0 + rng.random(n))
+    d2 = pkg.HipVector.from_numpy(0.5 + rng.random(n))
+    kw = dict(restart=30, orth_meth=pkg.ModifiedGramSchmidt(), reltol=0.0, maxiter=65)
+    if precond != "none":
+        kw["Pl"] = pkg.JacobiPrec(d1)
+    if precond == "pl+pr":
+        kw["Pr"] = pkg.JacobiPrec(d2)
+    out = []
+    for knob in (0, 6):
+        ctx.set_tuning(KN.GS, knob)
+        try:
+            it = pkg.gmres_iterable_(pkg.HipVector.from_numpy(x0), A, db, **kw)
+            f = form(pkg, it)
+            h = it.iterate_many(0, 65)
+            out.append((h, it.x.to_numpy(), it.mv_products, f, form(pkg, it)))
+        finally:
+            ctx.set_tuning(KN.GS, 0)
+    (h1, x1, mv1, f1, f1b), (h0, x0_, mv0, f0, _) = out
+    assert f1["single"] == 1 and f1b["timeouts"] == 0 and f0["single"] == 0 and h1.size == 65
+    assert np.array_equal(h1, h0) and np.array_equal(x1, x0_) and mv1 == mv0
