@@ -117,8 +117,8 @@ typedef struct mik_device_info {
     int gs_single_launch_max_segments;   /* orthogonalize_and_normalize! as ONE launch up to this many reduction segments (8 per workgroup) */
     int gs_xcd_local_max_workgroups;     /* ... in its XCD-local form up to this many workgroups (0: form not available on this shape) */
     int sweep_grid_cap;                  /* grid cap of the grid-stride vector sweeps */
-    int mgs_resident_max_segments;       /* ... and ModifiedGramSchmidt beyond that, with w resident in registers / LDS, up to this many (128 per workgroup; 0: the
-                                          * device reports less than 160 KB of LDS per compute unit) */
+    int mgs_resident_max_segments;       /* ... and ModifiedGramSchmidt beyond that, with w resident in registers / LDS, up to this many (86 per workgroup: while at
+                                          * least 0.6 of w fits on the chip; 0: the device reports less than 160 KB of LDS per compute unit) */
     int reserved[7];
 } mik_device_info;
 int mik_ctx_info(const mik_ctx *ctx, mik_device_info *out);

@@ -148,7 +148,7 @@ extern "C" int mik_ctx_info(const mik_ctx *ctx, mik_device_info *out)
     out->gs_single_launch_max_segments = 8 * mik_resident_cap(ctx);
     out->gs_xcd_local_max_workgroups = mik_xcd_maps(ctx) ? 4 * (mik_cus(ctx) / mik_xcds(ctx)) : 0;
     out->sweep_grid_cap = mik_max_grid(ctx);
-    out->mgs_resident_max_segments = ctx->lds_per_cu >= 160 * 1024 ? 128 * mik_resident_cap(ctx) : 0;
+    out->mgs_resident_max_segments = ctx->lds_per_cu >= 160 * 1024 ? mik_mgs_resident_max_s() * mik_resident_cap(ctx) : 0;
     return MIK_OK;
 }
 

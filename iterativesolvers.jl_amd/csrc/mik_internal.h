@@ -76,6 +76,8 @@ static inline int mik_strip_for(const mik_ctx *ctx, int64_t bw, int64_t nb)
     return (P >= MIK_XCD_MAP && P <= nb / 4) ? (int)P : 0;
 }
 
+int mik_mgs_resident_max_s();          // segments per workgroup up to which Modified Gram-Schmidt runs in the resident-w form (csrc/mik_mgs_res.h, mik_krylov.hip)
+
 struct mik_csr {
     mik_ctx *ctx = nullptr;
     int dtype = MIK_F64;

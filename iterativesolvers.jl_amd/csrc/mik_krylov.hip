@@ -1625,9 +1625,10 @@ static int gmres_create_common(mik_ctx *ctx, const mik_csr *A, void *x, const vo
         const int64_t cap = std::min(mik_resident_cap(ctx), 256);        // (the slot layout of k_mgs_fused / k_cgs_fused holds 256 workgroups)
         const int G = nseg <= cap ? 1 : nseg <= 2 * cap ? 2 : nseg <= 4 * cap ? 4 : 8;
         // Beyond that: Modified Gram-Schmidt in its "resident w" form (csrc/mik_mgs_res.h) -- one workgroup per compute unit keeps its part of w in
-        // registers and LDS between the passes; S consecutive segments per workgroup, at most 128.  Single GPU only; MIK_KNOB_GS = 6 keeps the chains.
+        // registers and LDS between the passes; S consecutive segments per workgroup, as long as at least 0.6 of w fits (86 segments per workgroup:
+        // 22.5 M fp64 / 45 M fp32 elements on 256 CUs).  Single GPU only; MIK_KNOB_GS = 6 keeps the chains.
         const int64_t res_S = (nseg + mik_resident_cap(ctx) - 1) / mik_resident_cap(ctx);
-        const bool resident = !part && orth_method == MIK_MGS && nseg > 8 * cap && res_S <= 128 && restart <= 254 && g->ldv % 4 == 0 && A != nullptr &&
+        const bool resident = !part && orth_method == MIK_MGS && nseg > 8 * cap && res_S <= MIK_MGS_RES_MAX_S(MIK_MGS_RES_RR, MIK_MGS_RES_RL) && restart <= 254 && g->ldv % 4 == 0 && A != nullptr &&
                               ctx->tuning[MIK_KNOB_GS] != 6 && ctx->lds_per_cu >= 160 * 1024;
         if (resident) g->mgs_res_S = (int)res_S;
         if (resident || (part_ok && nseg >= 1 && nseg <= 8 * cap && restart <= 254 && (G == 1 || g->ldv % 4 == 0))) {
@@ -2005,6 +2006,8 @@ extern "C" int mik_dev_gmres_form(const mik_gmres *g, int *single_launch, int *s
     if (timeouts) *timeouts = g->gs_timeouts;
     return MIK_OK;
 }
+
+int mik_mgs_resident_max_s() { return MIK_MGS_RES_MAX_S(MIK_MGS_RES_RR, MIK_MGS_RES_RL); }
 
 extern "C" int mik_dev_mgs_resident_shape(int *threads, int *register_rounds, int *lds_rounds)
 {

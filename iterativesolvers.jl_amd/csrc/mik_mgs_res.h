@@ -23,6 +23,10 @@
 #ifndef MIK_MGS_RES_DEPTH
 #define MIK_MGS_RES_DEPTH 2      // rounds of the column streams in flight ahead of the arithmetic (register rounds)
 #endif
+// The form pays while at least 0.6 of w stays on the chip: measured per inner iteration of gmres!(30), chain -> resident, at a resident share of
+// 0.81 (256^3) 1,620 -> 1,215 us, 0.67 (272^3) 1,717 -> 1,482, 0.57 (288^3) 2,055 -> 2,015, 0.50 (300^3) 2,282 -> 2,399, 0.41 (320^3) 2,855 -> 3,068
+// (scripts/micro/mgs_resident_big.py): the streamed rounds run at less memory-level parallelism than the chain's sweeps.  Beyond: the chain.
+#define MIK_MGS_RES_MAX_S(rr, rl) ((((rr) + (rl)) * 2 * 5) / 3)      /* segments per workgroup (2 per round) with (rr + rl) / rounds >= 0.6 */
 #ifndef MIK_MGS_RES_RL
 #define MIK_MGS_RES_RL 9         // rounds in LDS: 9 x 2 segments x 8 KB = 144 KB of the 160 KB
 #endif

@@ -33,7 +33,7 @@ def test_ctx_info_reports_the_queried_machine(pkg, ctx):
     assert d["resident_workgroup_cap"] == d["compute_units"] and d["gs_single_launch_max_segments"] == 8 * d["compute_units"]
     assert d["xcd_maps"] == (1 if d["xcds"] == 8 else 0)
     assert d["gs_xcd_local_max_workgroups"] == (4 * d["compute_units"] // d["xcds"] if d["xcds"] == 8 else 0)
-    assert d["mgs_resident_max_segments"] == 128 * d["compute_units"]
+    assert d["mgs_resident_max_segments"] == 86 * d["compute_units"]
     assert d["sweep_grid_cap"] == 32 * d["compute_units"] and d["hbm_bytes"] > 2 ** 30 and d["lds_bytes_per_cu"] >= 65536
     ctx.set_tuning(KN.MACHINE, CPX)
     try:

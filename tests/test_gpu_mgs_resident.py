@@ -113,3 +113,20 @@ def test_resident_form_long_cycles_restarts_and_preconditioners(pkg, ctx, precon
     (h1, x1, mv1, f1, f1b), (h0, x0_, mv0, f0, _) = out
     assert f1["single"] == 1 and f1b["timeouts"] == 0 and f0["single"] == 0 and h1.size == 65
     assert np.array_equal(h1, h0) and np.array_equal(x1, x0_) and mv1 == mv0
+
+
+def test_resident_form_only_while_most_of_w_fits(pkg, ctx):
+    """planned for 32 compute units: 2,680 segments -> 84 per workgroup (0.62 of w on the chip: resident form), 4,076 segments -> 128 per workgroup
+    (0.41: the chain is faster there, scripts/micro/mgs_resident_big.py) -- decided at mik_gmres_create; same bits either way"""
+    for N, resident in ((140, True), (161, False)):
+        n, cp, rv, nz, b = pkg.fixtures.advection_dominated(N, 300.0)
+        A = pkg.HipCSR(n, n, cp, rv, nz, index_base=1)
+        db = pkg.HipVector.from_numpy(b)
+        h_ref, x_ref, _, _, _ = run(pkg, ctx, A, db, 6, 6, 10)
+        ctx.set_tuning(KN.MACHINE, 32 | (1 << 16))
+        try:
+            h, x, _, f, fb = run(pkg, ctx, A, db, 0, 6, 10)
+        finally:
+            ctx.set_tuning(KN.MACHINE, 0)
+        assert (f["single"], f["G"]) == ((1, -(-(-(-n // 1024)) // 32)) if resident else (0, 0)), (N, f)
+        assert fb["timeouts"] == 0 and np.array_equal(h, h_ref) and np.array_equal(x, x_ref)
