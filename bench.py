@@ -743,6 +743,8 @@ def run_single(args):
                    "operator_layout_of_the_timed_loop": "csr (mik_csr_set_layout(A, 0): Int32 rowptr / col / val, k_spmv_rowgather)" if value_is_csr else layout,
                    "timed_regions": v_regions,
                    "operator_upload_seconds": upload_seconds, "final_residual": csr["final_residual"] if value_is_csr else residual,
+                   "machine": {k: v for k, v in ctx.info().items() if k in ("arch", "compute_units", "xcds", "lds_bytes_per_cu", "l2_bytes", "hbm_bytes", "xcd_maps",
+                                                                             "resident_workgroup_cap", "gs_single_launch_max_segments", "mgs_resident_max_segments")},
                    "default_layout": {"operator_layout": layout, "iters_per_sec": K / dt, "ms_per_step": dt / K * 1e3,
                                       "bytes_per_step": iter_moved, "gbs": iter_moved / (dt / K) / 1e9,
                                       "frac_of_8000": iter_moved / (dt / K) / 1e9 / HBM_PEAK_GBS, "spmv_avg_launch_ms": spmv_ms,

@@ -702,6 +702,7 @@ def bench_main(args):
                                      if transport == "group" else "torch.distributed driven from Python (legacy)"),
                        "transport_chosen": chosen, "transports_measured": transports,
                        "halo_overlap": bool(getattr(eng, "overlap", False)),
+                       "machine_of_rank_0": {k: v for k, v in eng.ctx.info().items() if k in ("arch", "compute_units", "xcds", "lds_bytes_per_cu", "hbm_bytes", "xcd_maps")},
                        "operator_build_and_upload_seconds": upload_seconds, "final_residual": contract["final_residual"] if is_contract else it.residual,
                        "default_layout": {"operator_layout": default_layout, "kernel": default_kernel, "iters_per_sec": K / dt, "ms_per_step": dt / K * 1e3,
                                           "bytes_per_step_per_gpu": iter_moved, "gbs_per_gpu": iter_moved / (dt / K) / 1e9, "spmv_back_to_back_ms": d_b2b_ms,
