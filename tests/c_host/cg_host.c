@@ -43,6 +43,12 @@ int main(int argc, char **argv)
     const int64_t n = N * N * N, nnz = 7 * n - 6 * N * N;
     mik_ctx *ctx = NULL;
     CHECK(mik_ctx_create(0, &ctx));
+    {   /* the machine the library found (mik_ctx_info): nothing in it is assumed */
+        mik_device_info di;
+        CHECK(mik_ctx_info(ctx, &di));
+        printf("machine %s cus %d xcds %d wave %d lds %lld xcd_maps %d gs_cap %d\n", di.arch, di.compute_units, di.xcds, di.wavefront_size,
+               (long long)di.lds_bytes_per_cu, di.xcd_maps, di.resident_workgroup_cap);
+    }
 
     /* laplace_matrix(Float64, N, 3): column j = x + N (y + N z); symmetric, so column j lists rows j -+ N^2, j -+ N, j -+ 1, j */
     int64_t *colptr = malloc(sizeof(int64_t) * (size_t)(n + 1)), *rowval = malloc(sizeof(int64_t) * (size_t)nnz);

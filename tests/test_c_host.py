@@ -38,6 +38,9 @@ def test_c_host_reproduces_the_oracle_history(pkg, orc, ctx, tmp_path, solver):
     lines = p.stdout.split("\n")
     hist = np.array([float.fromhex(s) for s in lines if s.startswith("0x")])
     tail = next(s for s in lines if s.startswith("iters")).split()
+    mach = next(s for s in lines if s.startswith("machine")).split()           # mik_ctx_info from plain C: the same answer as the ctypes binding
+    info = ctx.info()
+    assert mach[1] == info["arch"] and int(mach[3]) == info["compute_units"] and int(mach[5]) == info["xcds"] and int(mach[7]) == 64
     A = orc.laplace(N, 3)
     b = orc.hashed_rhs(A.n)
     if solver == "cg":
